@@ -1,0 +1,407 @@
+"""CPU oracle, module/model level (torch CPU ops) -- TEST INFRASTRUCTURE ONLY.
+
+``np_oracle.py`` restates the arithmetic of each primitive; this file restates
+how the reference *composes* them into ``nn.Module``s and rewrites a model
+(``prepare``), using the same ATen CPU ops in the same order so that on CPU it
+is bit-identical to the reference (checked live in the build container by
+``tests/test_oracle_vs_reference.py`` and against the committed fixtures by
+``tests/test_oracle_golden.py``).  It is also the ``cpu_baseline`` ("port")
+that ``bench.py`` times on the host cores.
+
+Never imported by ``micronet_amd/`` (the product).  Reference lines followed
+(relative to micronet/compression/quantization/):
+  dorefa:  wqaq/dorefa/quantize.py 11-73 (quantizers), 107-122/192-199 (modules), 202-323 (prepare)
+  wbwtab:  wbwtab/quantize.py 11-149, 181-195, 247-347
+  iao:     wqaq/iao/quantize.py 15-113 (observers), 144-321 (quantizers), 492-507, 837-994 (bn-fuse),
+           1150-1157 (linear), 1330-1438 (pools), 1484-1498 (add), 1501-1824 (prepare)
+One class per role instead of the reference's per-scheme copies; the scheme is data.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+
+class _RoundSTE(Function):
+    @staticmethod
+    def forward(ctx, v):
+        return torch.sign(v) * torch.floor(torch.abs(v) + 0.5)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone()
+
+
+class _RoundClipSTE(Function):
+    """iao Round: clip-STE against the observer range expressed in the q-domain."""
+
+    @staticmethod
+    def forward(ctx, v, lo, hi, symmetric):
+        if symmetric:
+            hi = torch.max(torch.abs(lo), torch.abs(hi))
+            lo = -hi
+        ctx.save_for_backward(v, lo, hi)
+        return torch.sign(v) * torch.floor(torch.abs(v) + 0.5)
+
+    @staticmethod
+    def backward(ctx, g):
+        v, lo, hi = ctx.saved_tensors
+        g = g.clone()
+        g[v.gt(hi)] = 0
+        g[v.lt(lo)] = 0
+        return g, None, None, None
+
+
+class _SignSatSTE(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        y = torch.sign(x)
+        y[y == 0] = 1
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.clone()
+        g[x.ge(1.0)] = 0
+        g[x.le(-1.0)] = 0
+        return g
+
+
+class _SignSTE(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.sign(x)
+        y[y == 0] = 1
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone()
+
+
+class _TernarySTE(Function):
+    @staticmethod
+    def forward(ctx, w):
+        thr = torch.mean(torch.abs(w), (3, 2, 1), keepdim=True) * 0.7
+        t = torch.sign(torch.add(torch.sign(torch.add(w, thr)), torch.sign(torch.add(w, -thr))))
+        return t, thr
+
+    @staticmethod
+    def backward(ctx, g, g_thr):
+        return g.clone()
+
+
+# ------------------------------------------------------------------ quantizers
+def dorefa_act(x, bits):
+    if bits == 32:
+        return x
+    assert bits != 1
+    y = torch.clamp(x * 0.1, 0, 1)
+    s = 1 / float(2 ** bits - 1)
+    return _RoundSTE.apply(y / s) * s
+
+
+def dorefa_weight(w, bits):
+    if bits == 32:
+        return w
+    assert bits != 1
+    t = torch.tanh(w)
+    t = t / 2 / torch.max(torch.abs(t)) + 0.5
+    s = 1 / float(2 ** bits - 1)
+    q = _RoundSTE.apply(t / s) * s
+    return 2 * q - 1
+
+
+def wbwtab_weight(w, W):
+    """w is the Parameter; W==2 mutates w.data in place like the reference."""
+    if W == 2:
+        w.data.sub_(w.data.mean(1, keepdim=True))
+        w.data.clamp_(-1.0, 1.0)
+        alpha = torch.mean(torch.abs(w), (3, 2, 1), keepdim=True)
+        return _SignSTE.apply(w) * alpha
+    if W == 3:
+        fp = w.clone()
+        t, thr = _TernarySTE.apply(w)
+        a = torch.abs(fp)
+        le, gt = a.le(thr), a.gt(thr)
+        a[le] = 0
+        a_th = a.clone()
+        alpha = torch.sum(a_th, (3, 2, 1), keepdim=True) / torch.sum(gt, (3, 2, 1), keepdim=True).float()
+        return t * alpha
+    return w
+
+
+class Observer(nn.Module):
+    def __init__(self, level, channels=None, ema=True, momentum=0.1):
+        super().__init__()
+        self.level, self.ema, self.momentum, self.first = level, ema, momentum, True
+        shape = {"L": (1,), "C": (channels, 1, 1, 1), "FC": (channels, 1)}[level]
+        self.register_buffer("min_val", torch.zeros(shape))
+        self.register_buffer("max_val", torch.zeros(shape))
+
+    @torch.no_grad()
+    def forward(self, x):
+        if self.level == "L":
+            lo, hi = torch.min(x), torch.max(x)
+        elif self.level == "C":
+            f = torch.flatten(x, start_dim=1)
+            lo, hi = torch.min(f, 1)[0].reshape(self.min_val.shape), torch.max(f, 1)[0].reshape(self.max_val.shape)
+        else:
+            lo, hi = torch.min(x, 1, keepdim=True)[0], torch.max(x, 1, keepdim=True)[0]
+        if self.first:
+            self.first = False
+        elif self.ema:
+            lo = (1 - self.momentum) * self.min_val + self.momentum * lo
+            hi = (1 - self.momentum) * self.max_val + self.momentum * hi
+        else:
+            lo, hi = torch.min(lo, self.min_val), torch.max(hi, self.max_val)
+        self.min_val.copy_(lo)
+        self.max_val.copy_(hi)
+
+
+class IaoQuantizer(nn.Module):
+    def __init__(self, bits, observer, is_act, q_type, union=False, qaft=False):
+        super().__init__()
+        self.bits, self.observer, self.is_act, self.q_type, self.union, self.qaft = bits, observer, is_act, q_type, union, qaft
+        self.register_buffer("scale", torch.ones_like(observer.min_val))
+        self.register_buffer("zero_point", torch.zeros_like(observer.min_val))
+        self.register_buffer("eps", torch.tensor(torch.finfo(torch.float32).eps))
+        if q_type == 0:
+            lo = -(1 << (bits - 1)) if is_act else -((1 << (bits - 1)) - 1)
+            hi = (1 << (bits - 1)) - 1
+        else:
+            lo, hi = 0, ((1 << bits) - 1 if is_act else (1 << bits) - 2)
+        self.register_buffer("qmin", torch.tensor(float(lo)))
+        self.register_buffer("qmax", torch.tensor(float(hi)))
+
+    def update_qparams(self):
+        o = self.observer
+        if self.q_type == 0:
+            qr = float(self.qmax - self.qmin) / 2
+            fr = torch.max(torch.abs(o.min_val), torch.abs(o.max_val))
+            scale = torch.max(fr / qr, self.eps)
+            zp = torch.zeros_like(scale)
+        else:
+            qr = float(self.qmax - self.qmin)
+            scale = torch.max((o.max_val - o.min_val) / qr, self.eps)
+            zp = torch.sign(o.min_val) * torch.floor(torch.abs(o.min_val / scale) + 0.5)
+        self.scale.copy_(scale)
+        self.zero_point.copy_(zp)
+
+    def forward(self, x):
+        if self.bits == 32:
+            return x
+        assert self.bits != 1
+        if not self.qaft and self.training:
+            if not self.union:
+                self.observer(x)
+            self.update_qparams()
+        o = self.observer
+        r = _RoundClipSTE.apply(x / self.scale.clone() - self.zero_point,
+                                o.min_val / self.scale - self.zero_point,
+                                o.max_val / self.scale - self.zero_point, self.q_type == 0)
+        return (torch.clamp(r, self.qmin, self.qmax) + self.zero_point) * self.scale.clone()
+
+
+def _iao_pair(a_bits, w_bits, q_type, q_level, weight_observer, out_ch, w_level_c):
+    aq = IaoQuantizer(a_bits, Observer("L"), True, q_type)
+    lvl = w_level_c if q_level == 0 else "L"
+    wq = IaoQuantizer(w_bits, Observer(lvl, out_ch if lvl != "L" else None, ema=(weight_observer != 0)), False, q_type)
+    return aq, wq
+
+
+# --------------------------------------------------------------------- modules
+class OConv2d(nn.Conv2d):
+    """scheme in {'dorefa','wbwtab','iao'}; cfg is the scheme's keyword dict."""
+
+    def __init__(self, src, scheme, **cfg):
+        super().__init__(src.in_channels, src.out_channels, src.kernel_size, src.stride, src.padding, src.dilation,
+                         src.groups, src.bias is not None, src.padding_mode)
+        self.scheme, self.cfg = scheme, cfg
+        self.weight = src.weight
+        if src.bias is not None:
+            self.bias = src.bias
+        if scheme == "iao":
+            self.aq, self.wq = _iao_pair(cfg["a_bits"], cfg["w_bits"], cfg.get("q_type", 0), cfg.get("q_level", 0),
+                                         cfg.get("weight_observer", 0), src.out_channels, "C")
+
+    def _conv(self, x, w, b):
+        return F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
+
+    def forward(self, x):
+        if self.scheme == "dorefa":
+            return self._conv(dorefa_act(x, self.cfg["a_bits"]), dorefa_weight(self.weight, self.cfg["w_bits"]), self.bias)
+        if self.scheme == "wbwtab":
+            return self._conv(x, wbwtab_weight(self.weight, self.cfg["W"]), self.bias)
+        return self._conv(self.aq(x), self.wq(self.weight), self.bias)
+
+
+class OBNFuseConv2d(OConv2d):
+    def __init__(self, src, bn, **cfg):
+        super().__init__(src, "iao", **cfg)
+        self.eps, self.momentum, self.first = bn.eps, bn.momentum, True
+        self.gamma, self.beta = bn.weight, bn.bias
+        self.register_buffer("running_mean", bn.running_mean.clone())
+        self.register_buffer("running_var", bn.running_var.clone())
+
+    def forward(self, x):
+        if self.training:
+            o = self._conv(x, self.weight, self.bias)
+            mean, var = torch.mean(o, dim=[0, 2, 3]), torch.var(o, dim=[0, 2, 3])
+            with torch.no_grad():
+                if self.first:
+                    self.first = False
+                    rm, rv = mean, var
+                else:
+                    rm = (1 - self.momentum) * self.running_mean + self.momentum * mean
+                    rv = (1 - self.momentum) * self.running_var + self.momentum * var
+                self.running_mean.copy_(rm)
+                self.running_var.copy_(rv)
+        else:
+            mean, var = self.running_mean, self.running_var
+        if self.bias is not None:
+            b_f = (self.beta + (self.bias - mean) * (self.gamma / torch.sqrt(var + self.eps))).reshape(-1)
+        else:
+            b_f = (self.beta - mean * (self.gamma / torch.sqrt(var + self.eps))).reshape(-1)
+        w_f = self.weight * (self.gamma / torch.sqrt(var + self.eps)).reshape(-1, 1, 1, 1)
+        return self._conv(self.aq(x), self.wq(w_f), b_f)
+
+
+class OLinear(nn.Linear):
+    def __init__(self, src, scheme, **cfg):
+        super().__init__(src.in_features, src.out_features, src.bias is not None)
+        self.scheme, self.cfg = scheme, cfg
+        self.weight = src.weight
+        if src.bias is not None:
+            self.bias = src.bias
+        if scheme == "iao":
+            self.aq, self.wq = _iao_pair(cfg["a_bits"], cfg["w_bits"], cfg.get("q_type", 0), cfg.get("q_level", 0),
+                                         cfg.get("weight_observer", 0), src.out_features, "FC")
+
+    def forward(self, x):
+        if self.scheme == "dorefa":
+            return F.linear(dorefa_act(x, self.cfg["a_bits"]), dorefa_weight(self.weight, self.cfg["w_bits"]), self.bias)
+        return F.linear(self.aq(x), self.wq(self.weight), self.bias)
+
+
+class OBinAct(nn.Module):
+    def forward(self, x):
+        return _SignSatSTE.apply(x)
+
+
+class OQuantWrap(nn.Module):
+    """iao Quant{MaxPool2d,AvgPool2d,AdaptiveAvgPool2d}: quantise the input, then the op."""
+
+    def __init__(self, op, a_bits, q_type):
+        super().__init__()
+        self.op = op
+        self.aq = IaoQuantizer(a_bits, Observer("L"), True, q_type)
+
+    def forward(self, x):
+        return self.op(self.aq(x))
+
+
+class OQuantAdd(nn.Module):
+    def __init__(self, a_bits, q_type):
+        super().__init__()
+        self.obs_res, self.obs_short = Observer("L"), Observer("L")
+        self.aq = IaoQuantizer(a_bits, Observer("L"), True, q_type, union=True)
+
+    def forward(self, res, shortcut):
+        self.obs_res(res)
+        self.obs_short(shortcut)
+        self.aq.observer.min_val = torch.min(self.obs_res.min_val, self.obs_short.min_val)
+        self.aq.observer.max_val = torch.max(self.obs_res.max_val, self.obs_short.max_val)
+        return self.aq(res) + self.aq(shortcut)
+
+
+# --------------------------------------------------------------------- prepare
+def _is_add(m):
+    return type(m).__name__ == "Add"
+
+
+def prepare(model, scheme, inplace=False, **cfg):
+    """Graph rewrite with the reference's per-scheme skip rules."""
+    if not inplace:
+        model = copy.deepcopy(model)
+    if scheme == "dorefa":
+        counter = [0]
+
+        def walk(mod):
+            for name, ch in mod.named_children():
+                if isinstance(ch, (nn.Conv2d, nn.Linear)):
+                    counter[0] += 1
+                    if counter[0] > 1:
+                        mod._modules[name] = (OConv2d if isinstance(ch, nn.Conv2d) else OLinear)(ch, "dorefa", **cfg)
+                else:
+                    walk(ch)
+        walk(model)
+    elif scheme == "wbwtab":
+        total = sum(isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) for m in model.modules())
+        counter = [0]
+
+        def walk(mod):
+            for name, ch in mod.named_children():
+                if isinstance(ch, nn.Conv2d):
+                    counter[0] += 1
+                    if 1 < counter[0] < total:
+                        mod._modules[name] = OConv2d(ch, "wbwtab", W=cfg.get("W", 2))
+                elif isinstance(ch, nn.ReLU):
+                    if 0 < counter[0] < total:
+                        mod._modules[name] = OBinAct() if cfg.get("A", 2) == 2 else nn.ReLU(inplace=True)
+                else:
+                    walk(ch)
+        walk(model)
+    elif scheme == "iao":
+        bn_fuse = cfg.get("bn_fuse", False)
+        a_bits, q_type = cfg["a_bits"], cfg.get("q_type", 0)
+
+        def walk(mod):
+            pending = None
+            for name, ch in mod.named_children():
+                if isinstance(ch, nn.Conv2d):
+                    if bn_fuse:
+                        pending = (name, ch)
+                    else:
+                        mod._modules[name] = OConv2d(ch, "iao", **cfg)
+                elif isinstance(ch, nn.BatchNorm2d):
+                    if bn_fuse:
+                        mod._modules[pending[0]] = OBNFuseConv2d(pending[1], ch, **cfg)
+                        mod._modules[name] = nn.Identity()
+                elif isinstance(ch, nn.Linear):
+                    mod._modules[name] = OLinear(ch, "iao", **cfg)
+                elif isinstance(ch, nn.MaxPool2d):   # the rewrite keeps only k/stride/padding (1727-1737)
+                    mod._modules[name] = OQuantWrap(nn.MaxPool2d(ch.kernel_size, ch.stride, ch.padding), a_bits, q_type)
+                elif isinstance(ch, nn.AvgPool2d):
+                    mod._modules[name] = OQuantWrap(nn.AvgPool2d(ch.kernel_size, ch.stride, ch.padding), a_bits, q_type)
+                elif isinstance(ch, nn.AdaptiveAvgPool2d):
+                    mod._modules[name] = OQuantWrap(nn.AdaptiveAvgPool2d(ch.output_size), a_bits, q_type)
+                elif _is_add(ch):
+                    mod._modules[name] = OQuantAdd(a_bits, q_type)
+                else:
+                    walk(ch)
+        walk(model)
+    else:
+        raise ValueError(scheme)
+    return model
+
+
+# ---------------------------------------------------------------- train step
+def make_optimizer(model, lr=0.01, wd=1e-5):
+    """dorefa/main.py:308-315 -- Adam, one param group per tensor."""
+    groups = [{"params": [p], "lr": lr, "weight_decay": wd} for _, p in model.named_parameters()]
+    return torch.optim.Adam(groups, lr=lr, weight_decay=wd)
+
+
+def train_step(model, opt, x, y):
+    """dorefa/main.py:77-82."""
+    out = model(x)
+    loss = F.cross_entropy(out, y)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss, out

@@ -1,0 +1,383 @@
+"""Generate golden vectors from the REAL reference (666DZY666/micronet) on CPU.
+
+Run in the build container only (the reference is mounted read-only at
+/root/reference and does not exist on the GPU box):
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's three ``quantize.py`` modules and model files
+unmodified, drives them on seeded + adversarial inputs, and stores inputs and
+outputs as small ``.npz`` fixtures next to this file.  The fixtures pin
+``oracle/`` (tests/test_oracle_golden.py) and, on the GPU box, the HIP path
+(tests/test_gpu_golden.py).  Nothing here is copied from the reference: it is
+only *executed*.
+"""
+import json
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REF = os.environ.get("MICRONET_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import micronet.compression.quantization.wqaq.dorefa.quantize as ref_dorefa
+import micronet.compression.quantization.wbwtab.quantize as ref_wbwtab
+import micronet.compression.quantization.wqaq.iao.quantize as ref_iao
+from micronet.models import nin_gc as ref_nin_gc, nin as ref_nin, resnet as ref_resnet
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def T(a):
+    return torch.from_numpy(np.array(a, dtype=np.float32, copy=True))  # always copy: the reference mutates W in place
+
+
+def N(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+# ---------------------------------------------------------------- quantizers
+def adversarial_act(bits):
+    """values that land on rounding ties / clamp edges of the DoReFa act chain."""
+    n = 2 ** bits - 1
+    s = np.float32(1.0 / n)
+    vals = [0.0, -0.0, 10.0, 10.000001, 9.999999, -1e-30, 1e-30, 1e-40, -5.0, 25.0, np.float32(0.49999997) * s * 10]
+    for k in range(n + 1):
+        for d in (-0.5, -0.25, 0.0, 0.25, 0.5):
+            v = np.float32((k + d)) * s * np.float32(10.0)
+            vals += [v, np.nextafter(np.float32(v), np.float32(100)), np.nextafter(np.float32(v), np.float32(-100))]
+    return np.array(vals, dtype=np.float32)
+
+
+def gen_dorefa(out):
+    for bits in (2, 3, 4, 8):
+        r = rng(100 + bits)
+        x = np.concatenate([(r.standard_normal(600) * 6).astype(np.float32), adversarial_act(bits)])
+        g = r.standard_normal(x.shape).astype(np.float32)
+        xt = T(x).requires_grad_(True)
+        q = ref_dorefa.ActivationQuantizer(a_bits=bits)
+        y = q(xt)
+        y.backward(T(g))
+        out[f"dorefa_act{bits}_x"] = x
+        out[f"dorefa_act{bits}_g"] = g
+        out[f"dorefa_act{bits}_y"] = N(y)
+        out[f"dorefa_act{bits}_dx"] = N(xt.grad)
+    for bits in (2, 4, 8):
+        r = rng(200 + bits)
+        w = (r.standard_normal((8, 4, 3, 3)) * 0.4).astype(np.float32)
+        if bits == 4:  # two-way tie for the global max |tanh|
+            w[0, 0, 0, 0] = 1.7
+            w[5, 2, 1, 1] = -1.7
+        g = r.standard_normal(w.shape).astype(np.float32)
+        wt = T(w).requires_grad_(True)
+        q = ref_dorefa.WeightQuantizer(w_bits=bits)
+        y = q(wt)
+        y.backward(T(g))
+        out[f"dorefa_w{bits}_w"] = w
+        out[f"dorefa_w{bits}_g"] = g
+        out[f"dorefa_w{bits}_tanh"] = N(torch.tanh(T(w)))
+        out[f"dorefa_w{bits}_y"] = N(y)
+        out[f"dorefa_w{bits}_dw"] = N(wt.grad)
+
+
+def gen_wbwtab(out):
+    r = rng(300)
+    x = np.concatenate([(r.standard_normal(500) * 1.2).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, np.nextafter(np.float32(1), np.float32(0)),
+                                  np.nextafter(np.float32(1), np.float32(2)), np.nextafter(np.float32(-1), np.float32(0)),
+                                  np.nextafter(np.float32(-1), np.float32(-2)), 1e-38, -1e-38, 1e-45, 3.0, -3.0],
+                                 dtype=np.float32)])
+    g = r.standard_normal(x.shape).astype(np.float32)
+    xt = T(x).requires_grad_(True)
+    y = ref_wbwtab.ActivationQuantizer(A=2)(xt)
+    y.backward(T(g))
+    out["binact_x"], out["binact_g"], out["binact_y"], out["binact_dx"] = x, g, N(y), N(xt.grad)
+
+    # ternary: random + a constant-magnitude channel + an all-zero channel (NaN alpha)
+    w = (r.standard_normal((6, 4, 3, 3)) * 0.1).astype(np.float32)
+    w[2] = np.where(r.standard_normal((4, 3, 3)) > 0, 0.25, -0.25).astype(np.float32)
+    w[4] = 0.0
+    g = r.standard_normal(w.shape).astype(np.float32)
+    wt = T(w).requires_grad_(True)
+    y = ref_wbwtab.WeightQuantizer(W=3)(wt)
+    y.backward(T(g))
+    out["ternary_w"], out["ternary_g"], out["ternary_y"], out["ternary_dw"] = w, g, N(y), N(wt.grad)
+
+    w = (r.standard_normal((6, 4, 3, 3)) * 0.8).astype(np.float32)
+    g = r.standard_normal(w.shape).astype(np.float32)
+    p = nn.Parameter(T(w))
+    y = ref_wbwtab.WeightQuantizer(W=2)(p)
+    y.backward(T(g))
+    out["binary_w"], out["binary_g"], out["binary_y"] = w, g, N(y)
+    out["binary_w_after"], out["binary_dw"] = N(p.data), N(p.grad)
+
+
+def gen_iao(out):
+    """Three successive training-mode calls of each quantizer flavour."""
+    cases = []
+    for q_type in (0, 1):
+        for bits in (4, 8):
+            cases.append(("act", "L", "ema", q_type, bits, (3, 5, 4, 4)))
+            cases.append(("w", "C", "minmax", q_type, bits, (6, 4, 3, 3)))
+            cases.append(("w", "C", "ema", q_type, bits, (6, 4, 3, 3)))
+            cases.append(("w", "L", "minmax", q_type, bits, (6, 4, 3, 3)))
+            cases.append(("w", "FC", "minmax", q_type, bits, (7, 20)))
+    meta = []
+    for ci, (kind, level, obs, q_type, bits, shape) in enumerate(cases):
+        r = rng(400 + ci)
+        oc = shape[0] if level in ("C", "FC") else None
+        observer = (ref_iao.MinMaxObserver if obs == "minmax" else ref_iao.MovingAverageMinMaxObserver)(
+            q_level=level, out_channels=oc)
+        cls = ref_iao.SymmetricQuantizer if q_type == 0 else ref_iao.AsymmetricQuantizer
+        q = cls(bits=bits, observer=observer, activation_weight_flag=1 if kind == "act" else 0)
+        q.train()
+        key = f"iao{ci}"
+        meta.append(dict(key=key, kind=kind, level=level, obs=obs, q_type=q_type, bits=bits, shape=list(shape)))
+        for step in range(3):
+            scale_in = [1.0, 2.5, 0.3][step]
+            x = (r.standard_normal(shape) * scale_in + (0.4 if q_type == 1 else 0.0)).astype(np.float32)
+            if step == 2 and kind == "w" and level == "C":
+                x[1] = 0.0  # zero channel -> eps scale
+            g = r.standard_normal(shape).astype(np.float32)
+            xt = T(x).requires_grad_(True)
+            y = q(xt)
+            y.backward(T(g))
+            out[f"{key}_s{step}_x"] = x
+            out[f"{key}_s{step}_g"] = g
+            out[f"{key}_s{step}_y"] = N(y)
+            out[f"{key}_s{step}_dx"] = N(xt.grad)
+            out[f"{key}_s{step}_min"] = N(q.observer.min_val)
+            out[f"{key}_s{step}_max"] = N(q.observer.max_val)
+            out[f"{key}_s{step}_scale"] = N(q.scale)
+            out[f"{key}_s{step}_zp"] = N(q.zero_point)
+        # eval-mode call (no observer update)
+        q.eval()
+        x = (r.standard_normal(shape) * 1.5).astype(np.float32)
+        out[f"{key}_eval_x"] = x
+        out[f"{key}_eval_y"] = N(q(T(x)))
+    return meta
+
+
+# ------------------------------------------------------------------- modules
+CONV_CASES = [
+    # name, cin, cout, k, stride, pad, dil, groups, bias, H, W, N
+    ("g2_3x3", 8, 12, 3, 1, 1, 1, 2, True, 6, 6, 2),
+    ("g4_1x1", 16, 16, 1, 1, 0, 1, 4, False, 4, 4, 3),
+    ("s2_3x3", 6, 10, 3, 2, 1, 1, 1, False, 8, 8, 2),
+    ("s2_1x1", 8, 16, 1, 2, 0, 1, 1, False, 8, 8, 2),
+    ("d2_3x3", 4, 6, 3, 1, 2, 2, 1, True, 7, 7, 2),
+    ("k5_first", 3, 16, 5, 1, 2, 1, 1, True, 8, 8, 2),
+]
+
+
+def run_module(mod, x, g, steps=1):
+    res = {}
+    for s in range(steps):
+        for p in mod.parameters():
+            p.grad = None
+        xt = T(x).requires_grad_(True)
+        y = mod(xt)
+        y.backward(T(g))
+        res[f"s{s}_y"] = N(y)
+        res[f"s{s}_dx"] = N(xt.grad)
+        for n_, p in mod.named_parameters():
+            res[f"s{s}_d_{n_}"] = N(p.grad)
+    for n_, b in mod.named_buffers():
+        res[f"buf_{n_}"] = N(b)
+    for n_, p in mod.named_parameters():
+        res[f"par_{n_}"] = N(p.data)
+    return res
+
+
+def gen_modules(out):
+    meta = []
+    for ci, (name, cin, cout, k, st, pd, dl, gr, bias, H, W, Nb) in enumerate(CONV_CASES):
+        r = rng(500 + ci)
+        w = (r.standard_normal((cout, cin // gr, k, k)) * 0.3).astype(np.float32)
+        b = (r.standard_normal(cout) * 0.1).astype(np.float32) if bias else None
+        Ho = (H + 2 * pd - dl * (k - 1) - 1) // st + 1
+        Wo = (W + 2 * pd - dl * (k - 1) - 1) // st + 1
+        x_real = (r.standard_normal((Nb, cin, H, W)) * 4).astype(np.float32)
+        x_bin = np.where(r.standard_normal((Nb, cin, H, W)) > 0, 1.0, -1.0).astype(np.float32)
+        g = r.standard_normal((Nb, cout, Ho, Wo)).astype(np.float32)
+        gamma = (r.random(cout) + 0.5).astype(np.float32)
+        beta = (r.standard_normal(cout) * 0.1).astype(np.float32)
+        base = f"conv_{name}"
+        out[f"{base}_w"], out[f"{base}_xreal"], out[f"{base}_xbin"], out[f"{base}_g"] = w, x_real, x_bin, g
+        out[f"{base}_gamma"], out[f"{base}_beta"] = gamma, beta
+        if b is not None:
+            out[f"{base}_b"] = b
+        kw = dict(stride=st, padding=pd, dilation=dl, groups=gr, bias=bias)
+        variants = {
+            "dorefa_w2a2": (lambda: ref_dorefa.QuantConv2d(cin, cout, k, a_bits=2, w_bits=2, **kw), x_real, 1),
+            "dorefa_w8a8": (lambda: ref_dorefa.QuantConv2d(cin, cout, k, a_bits=8, w_bits=8, **kw), x_real, 1),
+            "wbwtab_w3": (lambda: ref_wbwtab.QuantConv2d(cin, cout, k, W=3, **kw), x_bin, 1),
+            "wbwtab_w2": (lambda: ref_wbwtab.QuantConv2d(cin, cout, k, W=2, **kw), x_bin, 1),
+            "iao_w8a8_sym_c": (lambda: ref_iao.QuantConv2d(cin, cout, k, a_bits=8, w_bits=8, q_type=0, q_level=0, **kw), x_real, 2),
+            "iao_w4a4_sym_c": (lambda: ref_iao.QuantConv2d(cin, cout, k, a_bits=4, w_bits=4, q_type=0, q_level=0, **kw), x_real, 2),
+            "iao_w8a8_asym_l": (lambda: ref_iao.QuantConv2d(cin, cout, k, a_bits=8, w_bits=8, q_type=1, q_level=1, **kw), x_real, 2),
+            "iao_bnfuse_w8a8": (lambda: ref_iao.QuantBNFuseConv2d(cin, cout, k, a_bits=8, w_bits=8, q_type=0, q_level=0, **kw), x_real, 2),
+        }
+        for vname, (ctor, x, steps) in variants.items():
+            torch.manual_seed(0)
+            m = ctor()
+            m.weight.data = T(w)
+            if bias:
+                m.bias.data = T(b)
+            if "bnfuse" in vname:
+                m.gamma.data = T(gamma)
+                m.beta.data = T(beta)
+            m.train()
+            res = run_module(m, x, g, steps)
+            if "bnfuse" in vname:  # eval forward with the running stats
+                m.eval()
+                res["eval_y"] = N(m(T(x)))
+            for kk, vv in res.items():
+                out[f"{base}_{vname}_{kk}"] = vv
+            meta.append(dict(base=base, variant=vname, steps=steps, cin=cin, cout=cout, k=k, stride=st, padding=pd,
+                             dilation=dl, groups=gr, bias=bias))
+    # linear
+    r = rng(600)
+    w = (r.standard_normal((10, 32)) * 0.2).astype(np.float32)
+    b = (r.standard_normal(10) * 0.1).astype(np.float32)
+    x = (r.standard_normal((5, 32)) * 3).astype(np.float32)
+    g = r.standard_normal((5, 10)).astype(np.float32)
+    out["lin_w"], out["lin_b"], out["lin_x"], out["lin_g"] = w, b, x, g
+    for vname, ctor, steps in (
+        ("dorefa_w4a4", lambda: ref_dorefa.QuantLinear(32, 10, a_bits=4, w_bits=4), 1),
+        ("iao_w8a8_sym_fc", lambda: ref_iao.QuantLinear(32, 10, a_bits=8, w_bits=8, q_type=0, q_level=0), 2),
+    ):
+        m = ctor()
+        m.weight.data = T(w)
+        m.bias.data = T(b)
+        m.train()
+        for kk, vv in run_module(m, x, g, steps).items():
+            out[f"lin_{vname}_{kk}"] = vv
+    # QuantAdd: two training calls, then eval
+    for q_type, bits in ((0, 4), (1, 8)):
+        r = rng(700 + q_type)
+        qa = ref_iao.QuantAdd(a_bits=bits, q_type=q_type)
+        qa.train()
+        key = f"qadd_t{q_type}b{bits}"
+        for s in range(2):
+            a = (r.standard_normal((2, 4, 5, 5)) * (1 + s)).astype(np.float32)
+            c = (r.standard_normal((2, 4, 5, 5)) * 0.5 + 0.3).astype(np.float32)
+            g = r.standard_normal((2, 4, 5, 5)).astype(np.float32)
+            at, ct = T(a).requires_grad_(True), T(c).requires_grad_(True)
+            y = qa(at, ct)
+            y.backward(T(g))
+            out[f"{key}_s{s}_a"], out[f"{key}_s{s}_c"], out[f"{key}_s{s}_g"] = a, c, g
+            out[f"{key}_s{s}_y"], out[f"{key}_s{s}_da"], out[f"{key}_s{s}_dc"] = N(y), N(at.grad), N(ct.grad)
+            out[f"{key}_s{s}_scale"] = N(qa.activation_quantizer.scale)
+            out[f"{key}_s{s}_zp"] = N(qa.activation_quantizer.zero_point)
+    return meta
+
+
+# --------------------------------------------------------------------- models
+def init_like_main(model):
+    """mirror of dorefa/main.py:289-297."""
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, 0, 0.01)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+
+MODEL_CASES = {
+    # key: (model ctor, prepare fn, batch, weight_decay)
+    "c1_nin_gc_dorefa_w8a8": (lambda: ref_nin_gc.Net(), lambda m: ref_dorefa.prepare(m, inplace=True, a_bits=8, w_bits=8), 8, 1e-5),
+    "c2_nin_gc_wbwtab_w3a2": (lambda: ref_nin_gc.Net(), lambda m: ref_wbwtab.prepare(m, inplace=True, A=2, W=3), 8, 0.0),
+    "c2b_nin_gc_wbwtab_w2a2": (lambda: ref_nin_gc.Net(), lambda m: ref_wbwtab.prepare(m, inplace=True, A=2, W=2), 8, 0.0),
+    "c3_nin_gc_iao_w8a8_bnfuse": (lambda: ref_nin_gc.Net(), lambda m: ref_iao.prepare(
+        m, inplace=True, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=True), 8, 1e-5),
+    "c4_resnet18_dorefa_w2a2": (lambda: ref_resnet.resnet18(), lambda m: ref_dorefa.prepare(m, inplace=True, a_bits=2, w_bits=2), 4, 1e-5),
+    "c5_resnet18_iao_w4a4": (lambda: ref_resnet.resnet18(), lambda m: ref_iao.prepare(
+        m, inplace=True, a_bits=4, w_bits=4, q_type=0, q_level=0), 4, 1e-5),
+    "nin_dorefa_w4a4": (lambda: ref_nin.Net(), lambda m: ref_dorefa.prepare(m, inplace=True, a_bits=4, w_bits=4), 4, 1e-5),
+}
+
+
+def synth_batch(B):
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    return x, y
+
+
+def gen_models(out):
+    surface = {}
+    for key, (ctor, prep, B, wd) in MODEL_CASES.items():
+        torch.manual_seed(1)
+        model = ctor()
+        init_like_main(model)
+        prep(model)
+        surface[key] = dict(
+            modules=[(n_, type(m).__name__) for n_, m in model.named_modules()],
+            state=[(k, list(v.shape)) for k, v in model.state_dict().items()],
+        )
+        params = [{"params": [v], "lr": 0.01, "weight_decay": wd} for _, v in model.named_parameters()]
+        opt = torch.optim.Adam(params, lr=0.01, weight_decay=wd)
+        crit = nn.CrossEntropyLoss()
+        x, y = synth_batch(B)
+        model.train()
+        losses = []
+        for step in range(3):
+            o = model(x)
+            loss = crit(o, y)
+            opt.zero_grad()
+            loss.backward()
+            if step == 0:
+                out[f"{key}_logits0"] = N(o)
+                gn = {}
+                for n_, p in model.named_parameters():
+                    gn[n_] = float(p.grad.double().norm())
+                surface[key]["gradnorm0"] = gn
+                # one small gradient slice for a quantised mid layer
+                names = [n_ for n_, p in model.named_parameters() if p.dim() == 4]
+                mid = names[len(names) // 2]
+                out[f"{key}_grad0_mid"] = N(dict(model.named_parameters())[mid].grad)[:8]
+                surface[key]["mid"] = mid
+            opt.step()
+            losses.append(float(loss))
+        model.eval()
+        out[f"{key}_eval_logits"] = N(model(x))
+        surface[key]["losses"] = losses
+        print(key, losses)
+    return surface
+
+
+def main():
+    q = {}
+    gen_dorefa(q)
+    gen_wbwtab(q)
+    iao_meta = gen_iao(q)
+    np.savez_compressed(os.path.join(HERE, "quantizers.npz"), **q)
+    m = {}
+    mod_meta = gen_modules(m)
+    np.savez_compressed(os.path.join(HERE, "modules.npz"), **m)
+    mo = {}
+    surface = gen_models(mo)
+    np.savez_compressed(os.path.join(HERE, "models.npz"), **mo)
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump(dict(iao=iao_meta, modules=mod_meta, surface=surface,
+                       torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
+    for fn in ("quantizers.npz", "modules.npz", "models.npz", "meta.json"):
+        print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

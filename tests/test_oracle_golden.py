@@ -1,0 +1,193 @@
+"""Pin oracle/ against the golden vectors produced by the real reference (tests/golden/make_golden.py).
+
+Tolerances (stated once, used below):
+  * every elementwise quantizer value, code, observer statistic and STE gradient: BIT-EXACT;
+  * DoReFa weight path: bit-exact when fed torch-CPU's tanh (Sleef) -- numpy's libm tanh differs in the last ulp,
+    so with np.tanh at most a handful of codes may move at rounding boundaries;
+  * float conv accumulate (numpy fp64 einsum vs the reference's MKLDNN fp32): |diff| <= 1e-5 * max|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from oracle import torch_oracle as TO
+
+
+def eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 8])
+def test_dorefa_act(golden, bits):
+    q = golden.q
+    x, g = q[f"dorefa_act{bits}_x"], q[f"dorefa_act{bits}_g"]
+    y, codes = O.dorefa_act_fwd(x, bits)
+    assert eq(y, q[f"dorefa_act{bits}_y"])
+    assert codes.min() >= 0 and codes.max() <= 2 ** bits - 1 and eq(codes, np.round(codes))
+    assert eq(O.dorefa_act_bwd(g, x, bits), q[f"dorefa_act{bits}_dx"])
+
+
+@pytest.mark.parametrize("bits", [2, 4, 8])
+def test_dorefa_weight(golden, bits):
+    q = golden.q
+    w, g, th = q[f"dorefa_w{bits}_w"], q[f"dorefa_w{bits}_g"], q[f"dorefa_w{bits}_tanh"]
+    y, k, t, M = O.dorefa_w_fwd(w, bits, tanh_w=th)
+    assert eq(y, q[f"dorefa_w{bits}_y"])
+    dw = O.dorefa_w_bwd(g, w, bits, tanh_w=th)
+    ref = q[f"dorefa_w{bits}_dw"]
+    # two autograd branches are summed in autograd's order: <= 1e-6 rel
+    assert np.max(np.abs(dw - ref)) <= 1e-6 * np.max(np.abs(ref))
+    # libm tanh instead of Sleef: codes may differ only at rounding boundaries
+    y2, k2, _, _ = O.dorefa_w_fwd(w, bits)
+    assert (k2 != k).sum() <= 2
+
+
+def test_wbwtab(golden):
+    q = golden.q
+    assert eq(O.binact_fwd(q["binact_x"]), q["binact_y"])
+    assert eq(O.binact_bwd(q["binact_g"], q["binact_x"]), q["binact_dx"])
+    out, t, alpha, thr, cnt = O.ternary_w_fwd(q["ternary_w"])
+    ref = q["ternary_y"]
+    assert np.isnan(out[4]).all() and np.isnan(ref[4]).all()          # all-zero channel -> 0/0
+    ok = ~np.isnan(ref)
+    assert eq(np.sign(out[ok]), np.sign(ref[ok]))                      # ternary CODES: bit-exact
+    assert eq(t[ok], np.sign(ref[ok]))
+    # alpha is an fp32 SUM over the channel: summation order (numpy pairwise vs ATen vectorised) moves the last ulp
+    assert np.max(np.abs(out[ok] - ref[ok])) <= 5e-7 * np.max(np.abs(ref[ok]))
+    dw, ref = O.ternary_w_bwd(q["ternary_g"], q["ternary_w"]), q["ternary_dw"]
+    ok = ~np.isnan(ref)
+    assert eq(np.isnan(dw), np.isnan(ref))
+    assert np.max(np.abs(dw[ok] - ref[ok])) <= 1e-6 * np.max(np.abs(ref[ok]))
+    out, w_new, b, alpha = O.binary_w_fwd(q["binary_w"])
+    assert np.max(np.abs(w_new - q["binary_w_after"])) <= 2e-7      # mean over Cin is an fp32 sum (order-dependent ulp)
+    assert eq(np.sign(out), np.sign(q["binary_y"]))                  # binary CODES: bit-exact
+    assert np.max(np.abs(out - q["binary_y"])) <= 5e-7 * np.max(np.abs(out))
+    dw, ref = O.binary_w_bwd(q["binary_g"], w_new), q["binary_dw"]
+    assert np.max(np.abs(dw - ref)) <= 1e-6 * np.max(np.abs(ref))
+
+
+def test_iao_quantizers(golden):
+    q = golden.q
+    for c in golden.meta["iao"]:
+        key, bits, q_type, is_act = c["key"], c["bits"], c["q_type"], c["kind"] == "act"
+        mn = mx = None
+        for s in range(3):
+            x, g = q[f"{key}_s{s}_x"], q[f"{key}_s{s}_g"]
+            cmin, cmax = O.observe(x, c["level"])
+            mn, mx = O.observer_update(c["obs"], s == 0, mn, mx, cmin, cmax)
+            assert eq(mn, q[f"{key}_s{s}_min"]) and eq(mx, q[f"{key}_s{s}_max"]), key
+            scale, zp = O.iao_qparams(mn, mx, bits, q_type, is_act)
+            assert eq(scale, q[f"{key}_s{s}_scale"]) and eq(zp, q[f"{key}_s{s}_zp"]), key
+            y, codes = O.iao_fq_fwd(x, scale, zp, bits, q_type, is_act)
+            assert eq(y, q[f"{key}_s{s}_y"]), key
+            dx = O.iao_fq_bwd(g, x, scale, zp, mn, mx, bits, q_type, is_act)
+            assert eq(dx, q[f"{key}_s{s}_dx"]), key
+        y, _ = O.iao_fq_fwd(q[f"{key}_eval_x"], scale, zp, bits, q_type, is_act)
+        assert eq(y, q[f"{key}_eval_y"]), key
+
+
+def test_conv_accumulate(golden):
+    """numpy fp64 conv vs the reference's fp32 conv on the same quantised operands."""
+    m = golden.m
+    for c in golden.meta["modules"]:
+        if c["variant"] != "wbwtab_w3":
+            continue
+        base = c["base"]
+        x, w, g = m[f"{base}_xbin"], m[f"{base}_w"], m[f"{base}_g"]
+        b = m[f"{base}_b"] if c["bias"] else None
+        wq = O.ternary_w_fwd(w)[0]
+        kw = dict(stride=c["stride"], padding=c["padding"], dilation=c["dilation"], groups=c["groups"])
+        y = O.conv2d_fwd(x, wq, b, **kw)
+        ref = m[f"{base}_wbwtab_w3_s0_y"]
+        assert np.max(np.abs(y - ref)) <= 1e-5 * np.max(np.abs(ref)), base
+        dx, dwq, db = O.conv2d_bwd(g, x, wq, **kw)
+        ref = m[f"{base}_wbwtab_w3_s0_dx"]
+        assert np.max(np.abs(dx - ref)) <= 1e-5 * np.max(np.abs(ref)), base
+        dw = O.ternary_w_bwd(dwq.astype(np.float32), w)
+        ref = m[f"{base}_wbwtab_w3_s0_d_weight"]
+        assert np.max(np.abs(dw - ref)) <= 1e-5 * np.max(np.abs(ref)), base
+
+
+# ------------------------------------------------------------------ torch oracle, module level (bit-exact on CPU)
+def _mk(c, variant, m):
+    import torch.nn as nn
+    base = c["base"]
+    src = nn.Conv2d(c["cin"], c["cout"], c["k"], c["stride"], c["padding"], c["dilation"], c["groups"], c["bias"])
+    src.weight.data = torch.from_numpy(m[f"{base}_w"].copy())
+    if c["bias"]:
+        src.bias.data = torch.from_numpy(m[f"{base}_b"].copy())
+    if variant.startswith("dorefa"):
+        bits = int(variant[-1])
+        return TO.OConv2d(src, "dorefa", a_bits=bits, w_bits=bits)
+    if variant.startswith("wbwtab"):
+        return TO.OConv2d(src, "wbwtab", W=int(variant[-1]))
+    cfg = {"iao_w8a8_sym_c": dict(a_bits=8, w_bits=8, q_type=0, q_level=0),
+           "iao_w4a4_sym_c": dict(a_bits=4, w_bits=4, q_type=0, q_level=0),
+           "iao_w8a8_asym_l": dict(a_bits=8, w_bits=8, q_type=1, q_level=1),
+           "iao_bnfuse_w8a8": dict(a_bits=8, w_bits=8, q_type=0, q_level=0)}[variant]
+    if "bnfuse" in variant:
+        bn = nn.BatchNorm2d(c["cout"])
+        bn.weight.data = torch.from_numpy(m[f"{base}_gamma"].copy())
+        bn.bias.data = torch.from_numpy(m[f"{base}_beta"].copy())
+        return TO.OBNFuseConv2d(src, bn, **cfg)
+    return TO.OConv2d(src, "iao", **cfg)
+
+
+def test_torch_oracle_modules(golden):
+    m = golden.m
+    torch.set_num_threads(8)
+    for c in golden.meta["modules"]:
+        base, v = c["base"], c["variant"]
+        mod = _mk(c, v, m).train()
+        x = m[f"{base}_xbin"] if v.startswith("wbwtab") else m[f"{base}_xreal"]
+        for s in range(c["steps"]):
+            for p in mod.parameters():
+                p.grad = None
+            xt = torch.from_numpy(x.copy()).requires_grad_(True)
+            y = mod(xt)
+            y.backward(torch.from_numpy(m[f"{base}_g"].copy()))
+            pre = f"{base}_{v}_s{s}"
+            assert eq(y.detach().numpy(), m[f"{pre}_y"]), pre
+            assert eq(xt.grad.numpy(), m[f"{pre}_dx"]), pre
+            assert eq(mod.weight.grad.numpy(), m[f"{pre}_d_weight"]), pre
+            if "bnfuse" in v:
+                assert eq(mod.gamma.grad.numpy(), m[f"{pre}_d_gamma"]) and eq(mod.beta.grad.numpy(), m[f"{pre}_d_beta"])
+        if "bnfuse" in v:
+            mod.eval()
+            assert eq(mod(torch.from_numpy(x.copy())).detach().numpy(), m[f"{base}_{v}_eval_y"])
+            assert eq(mod.running_var.numpy(), m[f"{base}_{v}_buf_running_var"])
+
+
+MODEL_CFG = {
+    "c1_nin_gc_dorefa_w8a8": ("nin_gc", "dorefa", dict(a_bits=8, w_bits=8), 8, 1e-5),
+    "c2_nin_gc_wbwtab_w3a2": ("nin_gc", "wbwtab", dict(A=2, W=3), 8, 0.0),
+    "c2b_nin_gc_wbwtab_w2a2": ("nin_gc", "wbwtab", dict(A=2, W=2), 8, 0.0),
+    "c3_nin_gc_iao_w8a8_bnfuse": ("nin_gc", "iao", dict(a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=True), 8, 1e-5),
+    "c4_resnet18_dorefa_w2a2": ("resnet18", "dorefa", dict(a_bits=2, w_bits=2), 4, 1e-5),
+    "c5_resnet18_iao_w4a4": ("resnet18", "iao", dict(a_bits=4, w_bits=4, q_type=0, q_level=0), 4, 1e-5),
+    "nin_dorefa_w4a4": ("nin", "dorefa", dict(a_bits=4, w_bits=4), 4, 1e-5),
+}
+
+
+@pytest.mark.parametrize("key", list(MODEL_CFG))
+def test_torch_oracle_models(golden, key):
+    """3 Adam steps of the whole net: same losses / logits as the reference, bit for bit, on CPU."""
+    from micronet_amd.train import build_model, synth_batch
+    torch.set_num_threads(8)
+    arch, scheme, cfg, B, wd = MODEL_CFG[key]
+    model = build_model(arch)
+    TO.prepare(model, scheme, inplace=True, **cfg)
+    opt = TO.make_optimizer(model, 0.01, wd)
+    x, y = synth_batch(B)
+    model.train()
+    losses = []
+    for step in range(3):
+        loss, out = TO.train_step(model, opt, x, y)
+        if step == 0:
+            assert eq(out.detach().numpy(), golden.mo[f"{key}_logits0"])
+        losses.append(float(loss.detach()))
+    assert losses == golden.meta["surface"][key]["losses"]
+    model.eval()
+    assert eq(model(x).detach().numpy(), golden.mo[f"{key}_eval_logits"])
