@@ -1,0 +1,149 @@
+/*
+ * libmicronet_hip -- C ABI of the MI355X (gfx950) fake-quantized conv hot path.
+ *
+ * This is the drop-in boundary under micronet's Python `torch.nn.Module` surface
+ * (reference repo 666DZY666/micronet, paths relative to
+ * micronet/compression/quantization/).  The reference has no native layer: each
+ * entry point below replaces the chain of ATen ops that the cited reference lines
+ * launch.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the library
+ *     never allocates, frees or retains memory; scratch is passed in as `ws`;
+ *   - tensors are contiguous fp32, activations NCHW, weights OIHW;
+ *   - `stream` is a hipStream_t (passed as void*); all work is enqueued on it,
+ *     nothing synchronises with the host;
+ *   - return value: 0 on success, negative errno-style code otherwise
+ *     (MN_EINVAL bad argument, MN_ENOTSUP unsupported shape/algo, MN_EHIP launch
+ *     failure); `mn_last_error()` gives a thread-local message.
+ */
+#ifndef MICRONET_HIP_H
+#define MICRONET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MN_OK 0
+#define MN_EINVAL (-22)
+#define MN_ENOTSUP (-95)
+#define MN_EHIP (-5)
+#define MN_ENOSPC (-28) /* workspace too small */
+
+typedef void* mn_stream_t;
+
+int mn_version(void);
+const char* mn_last_error(void);
+/* 1 if the library was built as the CPU SIMT emulation used by the unit tests, 0 for the gfx950 build */
+int mn_is_emulation(void);
+
+/* ------------------------------------------------------------------ DoReFa
+ * wqaq/dorefa/quantize.py */
+/* Round.forward 13-16: out = sign(v) * floor(|v| + 0.5) in fp32 */
+int mn_round_half_away(const float* v, float* out, int64_t n, mn_stream_t stream);
+/* ActivationQuantizer.forward 36-46 (a_bits in 2..31): y = rha(clamp(0.1x,0,1)/s)*s */
+int mn_dorefa_act_fwd(const float* x, float* y, int64_t n, int a_bits, mn_stream_t stream);
+/* its autograd backward: dx = ((g*s)/s) * [0 <= 0.1x <= 1] * 0.1 */
+int mn_dorefa_act_bwd(const float* g, const float* x, float* dx, int64_t n, int a_bits, mn_stream_t stream);
+/* WeightQuantizer.forward 61-73 over the whole tensor (global max of |tanh w|).
+ * ws: >= mn_dorefa_w_ws_floats(n) floats; ws[0] receives M = max|tanh w|. */
+int64_t mn_dorefa_w_ws_floats(int64_t n);
+int mn_dorefa_w_fwd(const float* w, float* qw, int64_t n, int w_bits, float* ws, mn_stream_t stream);
+/* backward incl. the path through the global max (ties share equally) */
+int mn_dorefa_w_bwd(const float* g, const float* w, float* dw, int64_t n, int w_bits, float* ws, mn_stream_t stream);
+
+/* ------------------------------------------------------------------ WbWtAb
+ * wbwtab/quantize.py */
+/* BinaryActivation.forward 13-19 / backward 22-36 */
+int mn_binact_fwd(const float* x, float* y, int64_t n, mn_stream_t stream);
+int mn_binact_bwd(const float* g, const float* x, float* dx, int64_t n, mn_stream_t stream);
+/* WeightQuantizer W==3 branch 132-146 (+ Ternary 55-75). w: [O][K] rows (K = Cin/g*kh*kw).
+ * stats: [O][4] = {alpha, thr, cnt, sum|w|>thr} written by fwd, read by bwd. */
+int mn_ternary_w_fwd(const float* w, float* qw, float* stats, int64_t O, int64_t K, mn_stream_t stream);
+int mn_ternary_w_bwd(const float* g, const float* w, const float* stats, float* dw, int64_t O, int64_t K,
+                     mn_stream_t stream);
+/* WeightQuantizer W==2 branch 121-130 incl. meancenter_clamp_convparams 98-102, which
+ * MUTATES w in place (w -= mean over the Cin axis; clamp to [-1,1]).  w: [O][C][R] with R = kh*kw.
+ * alpha: [O] written by fwd, read by bwd. */
+int mn_binary_w_fwd(float* w_inplace, float* qw, float* alpha, int64_t O, int64_t C, int64_t R, mn_stream_t stream);
+int mn_binary_w_bwd(const float* g, const float* w, const float* alpha, float* dw, int64_t O, int64_t K,
+                    mn_stream_t stream);
+
+/* ------------------------------------------------------------------ IAO
+ * wqaq/iao/quantize.py */
+/* ObserverBase.forward 23-36 + update_range (MinMax 62-74, MovingAverage 101-113).
+ * x viewed as [rows][cols]: rows == 1 is level 'L' (whole tensor), rows == O is 'C'/'FC'.
+ * obs_kind: 0 = running min/max, 1 = EMA(momentum).  first != 0 copies (num_flag == 0).
+ * min_val/max_val: [rows] module buffers, updated in place.
+ * ws: >= mn_iao_observe_ws_floats(rows, cols) floats. */
+int64_t mn_iao_observe_ws_floats(int64_t rows, int64_t cols);
+int mn_iao_observe(const float* x, int64_t rows, int64_t cols, int obs_kind, int first, double momentum,
+                   float* min_val, float* max_val, float* ws, mn_stream_t stream);
+/* update_qparams (symmetric 293-305 / asymmetric 310-321) + a snapshot for the kernels.
+ * update != 0: recompute scale/zero_point from min_val/max_val and store them ([rows] each);
+ * update == 0: keep scale/zero_point (eval / qaft).  Always writes qp: [rows][4] =
+ * {scale, zero_point, lo, hi} with (lo,hi) the clip-STE bounds of Round.forward 148-157. */
+int mn_iao_qparams(const float* min_val, const float* max_val, int64_t rows, int bits, int q_type, int is_act,
+                   int update, float* scale, float* zero_point, float* qp, mn_stream_t stream);
+/* Quantizer.forward 227-239 with the snapshot: y = (clamp(rha(x/s - zp), qmin, qmax) + zp) * s */
+int mn_iao_fq_fwd(const float* x, float* y, int64_t rows, int64_t cols, const float* qp, int bits, int q_type,
+                  int is_act, mn_stream_t stream);
+/* backward: dx = ((g*s)/s) * [qmin <= r <= qmax] * [lo <= v <= hi] */
+int mn_iao_fq_bwd(const float* g, const float* x, float* dx, int64_t rows, int64_t cols, const float* qp, int bits,
+                  int q_type, int is_act, mn_stream_t stream);
+/* QuantAdd.forward 1487-1492: union of two observer ranges */
+int mn_iao_union_range(const float* min_a, const float* max_a, const float* min_b, const float* max_b,
+                       float* min_out, float* max_out, mn_stream_t stream);
+/* QuantBNFuseConv2d.forward 853-855: per-channel mean and UNBIASED variance of o[N][C][HW] over (N,HW).
+ * stats: [2][C] = mean, var.  ws: >= mn_bn_stats_ws_floats(N, C, HW) floats. */
+int64_t mn_bn_stats_ws_floats(int64_t N, int64_t C, int64_t HW);
+int mn_bn_stats_fwd(const float* o, int64_t N, int64_t C, int64_t HW, float* stats, float* ws, mn_stream_t stream);
+/* backward: do = dmean/n + dvar * 2 (o - mean)/(n - 1) */
+int mn_bn_stats_bwd(const float* o, const float* stats, const float* dmean, const float* dvar, float* d_o,
+                    int64_t N, int64_t C, int64_t HW, mn_stream_t stream);
+
+/* ------------------------------------------------------------------ convolution
+ * F.conv2d call sites: dorefa 113-121, wbwtab 186-194, iao 498-506 / 843-851 / 947-993;
+ * F.linear: dorefa 198, iao 1156 (use H = W = 1, 1x1 kernel). */
+typedef struct mn_conv_geom {
+    int32_t N, C, H, W;      /* input  [N][C][H][W] */
+    int32_t O, KH, KW;       /* weight [O][C/groups][KH][KW] */
+    int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups;
+} mn_conv_geom;
+
+/* activation quantizer fused into the conv prologue (fwd, bwd_weight) and into the
+ * clip-STE epilogue of bwd_data */
+#define MN_ACTQ_NONE 0
+#define MN_ACTQ_DOREFA 1
+#define MN_ACTQ_IAO 2
+typedef struct mn_actq {
+    int32_t mode;    /* MN_ACTQ_* */
+    int32_t bits;
+    int32_t q_type;  /* iao: 0 symmetric, 1 asymmetric */
+    int32_t reserved;
+    const float* qp; /* iao: device {scale, zero_point, lo, hi} (per-tensor) */
+} mn_actq;
+
+#define MN_ALGO_AUTO 0
+#define MN_ALGO_DIRECT 1 /* generic VALU kernels: any geometry */
+#define MN_ALGO_MFMA 2   /* implicit-GEMM on v_mfma_f32_16x16x4_f32; MN_ENOTSUP if the shape does not tile */
+
+/* which: 0 fwd, 1 bwd_data, 2 bwd_weight.  Bytes of `ws` the call needs for `algo`. */
+int64_t mn_conv2d_ws_bytes(const mn_conv_geom* g, int which, int algo);
+/* 1 if MN_ALGO_MFMA supports this geometry for `which` */
+int mn_conv2d_mfma_supported(const mn_conv_geom* g, int which);
+/* y[N][O][Ho][Wo] = conv2d(actq(x), w, bias); w are the (already fake-quantised) fp32 weights */
+int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const float* x, const float* w, const float* bias,
+                  float* y, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
+/* dx = conv2d_backward_data(gy, w) * d actq(x)/dx  (x may be NULL when aq->mode == NONE) */
+int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* w, const float* x,
+                       float* dx, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
+/* dw = conv2d_backward_weight(gy, actq(x)); dbias = sum gy (dbias may be NULL) */
+int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw,
+                         float* dbias, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICRONET_HIP_H */

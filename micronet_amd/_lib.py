@@ -1,0 +1,105 @@
+"""ctypes binding of ``libmicronet_hip.so`` (C ABI declared in ``include/micronet_hip.h``).
+
+The product path has NO fallback: if the gfx950 library is missing, or it is the CPU emulation build the unit
+tests use, ``get_lib()`` raises.  Every entry point returns 0 or a negative errno-style code; ``check`` turns a
+failure into a Python exception carrying ``mn_last_error()``.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmicronet_hip.so")
+
+MN_ACTQ_NONE, MN_ACTQ_DOREFA, MN_ACTQ_IAO = 0, 1, 2
+MN_ALGO_AUTO, MN_ALGO_DIRECT, MN_ALGO_MFMA = 0, 1, 2
+MN_ENOTSUP = -95
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "C", "H", "W", "O", "KH", "KW", "stride_h", "stride_w", "pad_h", "pad_w",
+                                         "dil_h", "dil_w", "groups")]
+
+
+class ActQ(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("bits", C.c_int32), ("q_type", C.c_int32), ("reserved", C.c_int32),
+                ("qp", C.c_void_p)]
+
+
+_P, _I, _L, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_G, _A = C.POINTER(ConvGeom), C.POINTER(ActQ)
+
+# name -> (restype, argtypes); must list every symbol declared in include/micronet_hip.h
+PROTOTYPES = {
+    "mn_version": (_I, []),
+    "mn_last_error": (C.c_char_p, []),
+    "mn_is_emulation": (_I, []),
+    "mn_round_half_away": (_I, [_P, _P, _L, _P]),
+    "mn_dorefa_act_fwd": (_I, [_P, _P, _L, _I, _P]),
+    "mn_dorefa_act_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
+    "mn_dorefa_w_ws_floats": (_L, [_L]),
+    "mn_dorefa_w_fwd": (_I, [_P, _P, _L, _I, _P, _P]),
+    "mn_dorefa_w_bwd": (_I, [_P, _P, _P, _L, _I, _P, _P]),
+    "mn_binact_fwd": (_I, [_P, _P, _L, _P]),
+    "mn_binact_bwd": (_I, [_P, _P, _P, _L, _P]),
+    "mn_ternary_w_fwd": (_I, [_P, _P, _P, _L, _L, _P]),
+    "mn_ternary_w_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P]),
+    "mn_binary_w_fwd": (_I, [_P, _P, _P, _L, _L, _L, _P]),
+    "mn_binary_w_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P]),
+    "mn_iao_observe_ws_floats": (_L, [_L, _L]),
+    "mn_iao_observe": (_I, [_P, _L, _L, _I, _I, _D, _P, _P, _P, _P]),
+    "mn_iao_qparams": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mn_iao_fq_fwd": (_I, [_P, _P, _L, _L, _P, _I, _I, _I, _P]),
+    "mn_iao_fq_bwd": (_I, [_P, _P, _P, _L, _L, _P, _I, _I, _I, _P]),
+    "mn_iao_union_range": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "mn_bn_stats_ws_floats": (_L, [_L, _L, _L]),
+    "mn_bn_stats_fwd": (_I, [_P, _L, _L, _L, _P, _P, _P]),
+    "mn_bn_stats_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _P]),
+    "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),
+    "mn_conv2d_mfma_supported": (_I, [_G, _I]),
+    "mn_conv2d_fwd": (_I, [_G, _A, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "mn_conv2d_bwd_data": (_I, [_G, _A, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "mn_conv2d_bwd_weight": (_I, [_G, _A, _P, _P, _P, _P, _P, _L, _I, _P]),
+}
+
+
+class MicronetHipError(RuntimeError):
+    pass
+
+
+class Lib:
+    def __init__(self, path):
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(self.cdll, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            msg = self.mn_last_error()
+            raise MicronetHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+        return rc
+
+
+_LIB = None
+
+
+def load(path):
+    return Lib(path)
+
+
+def get_lib():
+    """The gfx950 library, or an exception -- never a CPU fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MicronetHipError(
+                "libmicronet_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python -m micronet_amd.build`; there is no CPU fallback." % LIB_PATH)
+        lib = Lib(LIB_PATH)
+        if lib.mn_is_emulation():
+            raise MicronetHipError("%s is an emulation build; the product requires the gfx950 build" % LIB_PATH)
+        _LIB = lib
+    return _LIB

@@ -1,0 +1,48 @@
+"""Build ``micronet_amd/lib/libmicronet_hip.so`` for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m micronet_amd.build [--force]
+
+Flags: ``-ffp-contract=off`` (the integer quantize step must round exactly like the reference's separate ATen ops),
+IEEE-correct fp32 division is hipcc's default (never -ffast-math).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib", "libmicronet_hip.so")
+SOURCES = ["quant_kernels.hip", "conv_kernels.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc"]
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "micronet_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(HERE, "lib", src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

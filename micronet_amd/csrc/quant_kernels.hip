@@ -1,0 +1,656 @@
+// Quantizer kernels of the three micronet schemes (DoReFa, WbWtAb, IAO) for gfx950.
+//
+// Everything here is HBM-bound streaming work (activations) or tiny per-channel work (weights):
+//   * activation-sized tensors: one fused pass, 16 B per lane coalesced (float4), grid capped at
+//     256 CUs x 8 blocks and grid-strided -- replaces the 5..15 separate ATen pointwise kernels the
+//     reference launches per quantizer;
+//   * weight tensors: one workgroup per output channel, statistics accumulated in fp64 so the
+//     result does not depend on the reduction order (deterministic, within 1 ulp of any fp32 order);
+//   * the integer step (divide by scale, round half away, clamp) uses IEEE fp32 division and the
+//     exact expression order of the reference, so codes are bit-identical to the CPU path.
+// Compile with -ffp-contract=off: no fma contraction may change a rounding.
+#include "common.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local char g_err[512] = "";
+void mn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mn_last_error(void) { return g_err; }
+extern "C" int mn_version(void) { return 100; }
+extern "C" int mn_is_emulation(void) {
+#ifdef MN_EMULATION
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic streaming maps: out = f(in0[, in1]) ; float4 body + scalar tail
+static const int EW_BLOCK = 256;
+static const int EW_GRID_CAP = 256 * 8;
+
+template <typename F>
+__global__ __launch_bounds__(256) void k_map1(const float* __restrict__ a, float* __restrict__ y, int64_t n, int vec, F f) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        for (int64_t j = i; j < n4; j += stride) {
+            float4 v = a4[j], r;
+            r.x = f(v.x); r.y = f(v.y); r.z = f(v.z); r.w = f(v.w);
+            y4[j] = r;
+        }
+        for (int64_t j = (n4 << 2) + i; j < n; j += stride) y[j] = f(a[j]);
+    } else {
+        for (int64_t j = i; j < n; j += stride) y[j] = f(a[j]);
+    }
+}
+template <typename F>
+__global__ __launch_bounds__(256) void k_map2(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                              int64_t n, int vec, F f) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        const float4* b4 = reinterpret_cast<const float4*>(b);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        for (int64_t j = i; j < n4; j += stride) {
+            float4 v = a4[j], w = b4[j], r;
+            r.x = f(v.x, w.x); r.y = f(v.y, w.y); r.z = f(v.z, w.z); r.w = f(v.w, w.w);
+            y4[j] = r;
+        }
+        for (int64_t j = (n4 << 2) + i; j < n; j += stride) y[j] = f(a[j], b[j]);
+    } else {
+        for (int64_t j = i; j < n; j += stride) y[j] = f(a[j], b[j]);
+    }
+}
+template <typename F>
+static int launch_map1(const float* a, float* y, int64_t n, F f, hipStream_t s, const char* what) {
+    if (n < 0 || (n > 0 && (!a || !y))) MN_FAIL(MN_EINVAL, "%s: bad arguments", what);
+    if (n == 0) return MN_OK;
+    int vec = aligned16(a) && aligned16(y);
+    int grid = mn_grid_for(vec ? (n + 3) / 4 : n, EW_BLOCK, EW_GRID_CAP);
+    hipLaunchKernelGGL(k_map1<F>, dim3(grid), dim3(EW_BLOCK), 0, s, a, y, n, vec, f);
+    MN_CHECK_LAUNCH(what);
+    return MN_OK;
+}
+template <typename F>
+static int launch_map2(const float* a, const float* b, float* y, int64_t n, F f, hipStream_t s, const char* what) {
+    if (n < 0 || (n > 0 && (!a || !b || !y))) MN_FAIL(MN_EINVAL, "%s: bad arguments", what);
+    if (n == 0) return MN_OK;
+    int vec = aligned16(a) && aligned16(b) && aligned16(y);
+    int grid = mn_grid_for(vec ? (n + 3) / 4 : n, EW_BLOCK, EW_GRID_CAP);
+    hipLaunchKernelGGL(k_map2<F>, dim3(grid), dim3(EW_BLOCK), 0, s, a, b, y, n, vec, f);
+    MN_CHECK_LAUNCH(what);
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DoReFa activation (wqaq/dorefa/quantize.py:36-46) and Round (11-21)
+struct FRha { __device__ float operator()(float v) const { return mn_rha(v); } };
+struct FDorefaActFwd {
+    float s;
+    __device__ float operator()(float x) const { return dorefa_act_q(x, s); }
+};
+struct FDorefaActBwd {
+    float s;
+    __device__ float operator()(float g, float x) const { return dorefa_act_grad(g, x, s); }
+};
+
+extern "C" int mn_round_half_away(const float* v, float* out, int64_t n, mn_stream_t stream) {
+    return launch_map1(v, out, n, FRha(), (hipStream_t)stream, "mn_round_half_away");
+}
+extern "C" int mn_dorefa_act_fwd(const float* x, float* y, int64_t n, int a_bits, mn_stream_t stream) {
+    if (a_bits < 2 || a_bits > 31) MN_FAIL(MN_EINVAL, "mn_dorefa_act_fwd: a_bits=%d (1 unsupported, 32 is a pass-through handled by the caller)", a_bits);
+    FDorefaActFwd f{dorefa_scale(a_bits)};
+    return launch_map1(x, y, n, f, (hipStream_t)stream, "mn_dorefa_act_fwd");
+}
+extern "C" int mn_dorefa_act_bwd(const float* g, const float* x, float* dx, int64_t n, int a_bits, mn_stream_t stream) {
+    if (a_bits < 2 || a_bits > 31) MN_FAIL(MN_EINVAL, "mn_dorefa_act_bwd: a_bits=%d", a_bits);
+    FDorefaActBwd f{dorefa_scale(a_bits)};
+    return launch_map2(g, x, dx, n, f, (hipStream_t)stream, "mn_dorefa_act_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// DoReFa weight (61-73): global max of |tanh w| -> normalise -> round -> 2q-1.
+// ws layout (floats): [0] M, [1] dM (bwd), [2] tie count (bwd), [16 .. 16+3*NB) per-block partials.
+static const int DW_NB = 128;  // partial blocks
+extern "C" int64_t mn_dorefa_w_ws_floats(int64_t) { return 16 + 3 * DW_NB; }
+
+__global__ __launch_bounds__(256) void k_dorefa_w_absmax(const float* __restrict__ w, int64_t n, float* __restrict__ ws) {
+    __shared__ float sc[16];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = OpMaxF()(m, fabsf(tanhf(w[i])));
+    m = block_reduce(m, OpMaxF(), 0.f, sc);
+    if (threadIdx.x == 0) ws[16 + blockIdx.x] = m;
+}
+__device__ __forceinline__ float dorefa_w_global_max(const float* ws, int nb, float* sc) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) m = OpMaxF()(m, ws[16 + i]);
+    return block_reduce(m, OpMaxF(), 0.f, sc);
+}
+__global__ __launch_bounds__(256) void k_dorefa_w_fwd(const float* __restrict__ w, float* __restrict__ qw, int64_t n, float s,
+                                                      float* __restrict__ ws, int nb) {
+    __shared__ float sc[16];
+    const float M = dorefa_w_global_max(ws, nb, sc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws[0] = M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float t = tanhf(w[i]);
+        float u = (t / 2.f) / M + 0.5f;
+        float q = mn_rha(u / s) * s;
+        qw[i] = 2.f * q - 1.f;
+    }
+}
+// backward pass 1: per-block partial of dM = -sum(du * (t/2) / M^2) (fp64) and of the tie count
+__global__ __launch_bounds__(256) void k_dorefa_w_bwd_partial(const float* __restrict__ g, const float* __restrict__ w, int64_t n,
+                                                              float s, float* __restrict__ ws, int nb) {
+    __shared__ float sc[16];
+    __shared__ double scd[16];
+    const float M = dorefa_w_global_max(ws, nb, sc);
+    double acc = 0.0;
+    float ties = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float t = tanhf(w[i]);
+        float du = ((g[i] * 2.f) * s) / s;
+        float v = t / 2.f;
+        acc += (double)(-du * v / (M * M));
+        ties += (fabsf(t) == M) ? 1.f : 0.f;
+    }
+    acc = block_reduce(acc, OpAddD(), 0.0, scd);
+    ties = block_reduce(ties, OpAddF(), 0.f, sc);
+    if (threadIdx.x == 0) {
+        ws[16 + nb + blockIdx.x] = (float)acc;       // partial sums are small in count; final sum again in fp64
+        ws[16 + 2 * nb + blockIdx.x] = ties;
+    }
+}
+__global__ __launch_bounds__(256) void k_dorefa_w_bwd(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dw,
+                                                      int64_t n, float s, float* __restrict__ ws, int nb) {
+    __shared__ float sc[16];
+    __shared__ double scd[16];
+    const float M = dorefa_w_global_max(ws, nb, sc);
+    double a = 0.0;
+    float c = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        a += (double)ws[16 + nb + i];
+        c += ws[16 + 2 * nb + i];
+    }
+    const float dM = (float)block_reduce(a, OpAddD(), 0.0, scd);
+    const float cnt = block_reduce(c, OpAddF(), 0.f, sc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ws[1] = dM; ws[2] = cnt; }
+    const float share = dM / cnt;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float t = tanhf(w[i]);
+        float du = ((g[i] * 2.f) * s) / s;
+        float dt = (du / M) / 2.f;
+        if (fabsf(t) == M) dt += share * mn_sign(t);
+        dw[i] = dt * (1.f - t * t);
+    }
+}
+extern "C" int mn_dorefa_w_fwd(const float* w, float* qw, int64_t n, int w_bits, float* ws, mn_stream_t stream) {
+    if (w_bits < 2 || w_bits > 31 || n <= 0 || !w || !qw || !ws) MN_FAIL(MN_EINVAL, "mn_dorefa_w_fwd: bad arguments (w_bits=%d n=%lld)", w_bits, (long long)n);
+    hipStream_t s = (hipStream_t)stream;
+    int nb = mn_grid_for(n, 256, DW_NB);
+    hipLaunchKernelGGL(k_dorefa_w_absmax, dim3(nb), dim3(256), 0, s, w, n, ws);
+    hipLaunchKernelGGL(k_dorefa_w_fwd, dim3(mn_grid_for(n, 256, 1024)), dim3(256), 0, s, w, qw, n, dorefa_scale(w_bits), ws, nb);
+    MN_CHECK_LAUNCH("mn_dorefa_w_fwd");
+    return MN_OK;
+}
+extern "C" int mn_dorefa_w_bwd(const float* g, const float* w, float* dw, int64_t n, int w_bits, float* ws, mn_stream_t stream) {
+    if (w_bits < 2 || w_bits > 31 || n <= 0 || !g || !w || !dw || !ws) MN_FAIL(MN_EINVAL, "mn_dorefa_w_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int nb = mn_grid_for(n, 256, DW_NB);
+    float sc = dorefa_scale(w_bits);
+    hipLaunchKernelGGL(k_dorefa_w_absmax, dim3(nb), dim3(256), 0, s, w, n, ws);
+    hipLaunchKernelGGL(k_dorefa_w_bwd_partial, dim3(nb), dim3(256), 0, s, g, w, n, sc, ws, nb);
+    hipLaunchKernelGGL(k_dorefa_w_bwd, dim3(mn_grid_for(n, 256, 1024)), dim3(256), 0, s, g, w, dw, n, sc, ws, nb);
+    MN_CHECK_LAUNCH("mn_dorefa_w_bwd");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// WbWtAb binary activation (wbwtab/quantize.py:11-36)
+struct FBinActFwd { __device__ float operator()(float x) const { return (x < 0.f) ? -1.f : 1.f; } };  // 0, -0, NaN -> +1
+struct FBinActBwd { __device__ float operator()(float g, float x) const { return (x >= 1.f || x <= -1.f) ? 0.f : g; } };
+extern "C" int mn_binact_fwd(const float* x, float* y, int64_t n, mn_stream_t stream) {
+    return launch_map1(x, y, n, FBinActFwd(), (hipStream_t)stream, "mn_binact_fwd");
+}
+extern "C" int mn_binact_bwd(const float* g, const float* x, float* dx, int64_t n, mn_stream_t stream) {
+    return launch_map2(g, x, dx, n, FBinActBwd(), (hipStream_t)stream, "mn_binact_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ternary weights (55-75, 132-146): one workgroup per output channel.
+__global__ __launch_bounds__(256) void k_ternary_w_fwd(const float* __restrict__ w, float* __restrict__ qw, float* __restrict__ stats, int64_t K) {
+    __shared__ double scd[16];
+    const float* wr = w + (int64_t)blockIdx.x * K;
+    float* qr = qw + (int64_t)blockIdx.x * K;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) s += (double)fabsf(wr[i]);
+    s = block_reduce(s, OpAddD(), 0.0, scd);
+    const float E = (float)s / (float)K;          // torch.mean = fp32 sum / n
+    const float thr = E * 0.7f;
+    double sa = 0.0, sc = 0.0;
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+        float a = fabsf(wr[i]);
+        if (a > thr) { sa += (double)a; sc += 1.0; }
+    }
+    sa = block_reduce(sa, OpAddD(), 0.0, scd);
+    sc = block_reduce(sc, OpAddD(), 0.0, scd);
+    const float ssum = (float)sa, cnt = (float)sc;
+    const float alpha = ssum / cnt;               // 0/0 = NaN for an all-zero channel, as in the reference
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+        float v = wr[i];
+        float t = mn_sign(mn_sign(v + thr) + mn_sign(v - thr));
+        qr[i] = t * alpha;
+    }
+    if (threadIdx.x == 0) {
+        float* st = stats + (int64_t)blockIdx.x * 4;
+        st[0] = alpha; st[1] = thr; st[2] = cnt; st[3] = ssum;
+    }
+}
+__global__ __launch_bounds__(256) void k_ternary_w_bwd(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ stats,
+                                                       float* __restrict__ dw, int64_t K) {
+    __shared__ double scd[16];
+    const int64_t off = (int64_t)blockIdx.x * K;
+    const float alpha = stats[blockIdx.x * 4 + 0], thr = stats[blockIdx.x * 4 + 1], cnt = stats[blockIdx.x * 4 + 2];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+        float v = w[off + i];
+        float t = mn_sign(mn_sign(v + thr) + mn_sign(v - thr));
+        s += (double)(g[off + i] * t);
+    }
+    s = block_reduce(s, OpAddD(), 0.0, scd);
+    const float share = (float)s / cnt;           // d(alpha)/d|w_i| = [|w_i|>thr]/cnt, upstream = sum(g*t)
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+        float v = w[off + i];
+        float d = g[off + i] * alpha;
+        if (fabsf(v) > thr) d += mn_sign(v) * share;
+        dw[off + i] = d;
+    }
+}
+extern "C" int mn_ternary_w_fwd(const float* w, float* qw, float* stats, int64_t O, int64_t K, mn_stream_t stream) {
+    if (O <= 0 || K <= 0 || !w || !qw || !stats) MN_FAIL(MN_EINVAL, "mn_ternary_w_fwd: bad arguments");
+    hipLaunchKernelGGL(k_ternary_w_fwd, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, w, qw, stats, K);
+    MN_CHECK_LAUNCH("mn_ternary_w_fwd");
+    return MN_OK;
+}
+extern "C" int mn_ternary_w_bwd(const float* g, const float* w, const float* stats, float* dw, int64_t O, int64_t K, mn_stream_t stream) {
+    if (O <= 0 || K <= 0 || !g || !w || !stats || !dw) MN_FAIL(MN_EINVAL, "mn_ternary_w_bwd: bad arguments");
+    hipLaunchKernelGGL(k_ternary_w_bwd, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, g, w, stats, dw, K);
+    MN_CHECK_LAUNCH("mn_ternary_w_bwd");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Binary weights (98-102, 121-130): in-place mean-centre over Cin + clamp, then sign * mean|w|.
+// One workgroup per output channel; w row = [C][R].
+__global__ __launch_bounds__(256) void k_binary_w_fwd(float* __restrict__ w, float* __restrict__ qw, float* __restrict__ alpha_out,
+                                                      int C, int R) {
+    HIP_DYNAMIC_SHARED(double, colsum)   // [R] column sums, then [R] means as float reinterpretation is avoided: keep doubles
+    __shared__ double scd[16];
+    const int64_t K = (int64_t)C * R;
+    float* wr = w + (int64_t)blockIdx.x * K;
+    float* qr = qw + (int64_t)blockIdx.x * K;
+    // column (kh,kw) sums over the Cin axis: thread t owns column t % R, rows t / R, t / R + stride ...
+    for (int r = threadIdx.x; r < R; r += blockDim.x) colsum[r] = 0.0;
+    __syncthreads();
+    // deterministic two-level: partial per thread -> LDS slot -> ordered sum by one thread per column
+    double* part = colsum + R;           // [blockDim.x]
+    {
+        const int lanes_per_col = blockDim.x / R > 0 ? blockDim.x / R : 1;
+        const int col = threadIdx.x % R, sub = threadIdx.x / R;
+        double p = 0.0;
+        if (sub < lanes_per_col)
+            for (int c = sub; c < C; c += lanes_per_col) p += (double)wr[(int64_t)c * R + col];
+        part[threadIdx.x] = p;
+        __syncthreads();
+        if (threadIdx.x < R) {
+            double s = 0.0;
+            for (int j = 0; j < lanes_per_col; ++j) {
+                int t = j * R + threadIdx.x;
+                if (t < (int)blockDim.x) s += part[t];
+            }
+            colsum[threadIdx.x] = s;
+        }
+        __syncthreads();
+    }
+    double sabs = 0.0;
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+        const int col = (int)(i % R);
+        const float mean = (float)colsum[col] / (float)C;
+        float v = wr[i] - mean;
+        v = fminf(fmaxf(v, -1.f), 1.f);
+        wr[i] = v;                                  // the reference mutates weight.data here
+        sabs += (double)fabsf(v);
+    }
+    sabs = block_reduce(sabs, OpAddD(), 0.0, scd);
+    const float alpha = (float)sabs / (float)K;
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) qr[i] = ((wr[i] < 0.f) ? -1.f : 1.f) * alpha;
+    if (threadIdx.x == 0) alpha_out[blockIdx.x] = alpha;
+}
+__global__ __launch_bounds__(256) void k_binary_w_bwd(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ alpha_in,
+                                                      float* __restrict__ dw, int64_t K) {
+    __shared__ double scd[16];
+    const int64_t off = (int64_t)blockIdx.x * K;
+    const float alpha = alpha_in[blockIdx.x];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) s += (double)(g[off + i] * ((w[off + i] < 0.f) ? -1.f : 1.f));
+    s = block_reduce(s, OpAddD(), 0.0, scd);
+    const float share = (float)s / (float)K;      // d mean|w| / dw_i = sign(w_i)/K
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) dw[off + i] = g[off + i] * alpha + mn_sign(w[off + i]) * share;
+}
+extern "C" int mn_binary_w_fwd(float* w, float* qw, float* alpha, int64_t O, int64_t C, int64_t R, mn_stream_t stream) {
+    if (O <= 0 || C <= 0 || R <= 0 || R > 256 || !w || !qw || !alpha) MN_FAIL(MN_EINVAL, "mn_binary_w_fwd: bad arguments (R=%lld must be <= 256)", (long long)R);
+    size_t sh = (size_t)(R + 256) * sizeof(double);
+    hipLaunchKernelGGL(k_binary_w_fwd, dim3((unsigned)O), dim3(256), sh, (hipStream_t)stream, w, qw, alpha, (int)C, (int)R);
+    MN_CHECK_LAUNCH("mn_binary_w_fwd");
+    return MN_OK;
+}
+extern "C" int mn_binary_w_bwd(const float* g, const float* w, const float* alpha, float* dw, int64_t O, int64_t K, mn_stream_t stream) {
+    if (O <= 0 || K <= 0 || !g || !w || !alpha || !dw) MN_FAIL(MN_EINVAL, "mn_binary_w_bwd: bad arguments");
+    hipLaunchKernelGGL(k_binary_w_bwd, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, g, w, alpha, dw, K);
+    MN_CHECK_LAUNCH("mn_binary_w_bwd");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IAO observers (15-113).  rows == 1: two-stage grid reduction over the whole tensor (wave shuffles +
+// LDS, no atomics -> deterministic); rows > 1: one workgroup per row.
+static const int OBS_NB = 1024;
+extern "C" int64_t mn_iao_observe_ws_floats(int64_t rows, int64_t) { return rows == 1 ? 2 * OBS_NB : 0; }
+
+__device__ __forceinline__ void observer_update(int obs_kind, int first, double momentum, float cmin, float cmax,
+                                                float* min_val, float* max_val) {
+    float lo, hi;
+    if (first) { lo = cmin; hi = cmax; }
+    else if (obs_kind == 0) { lo = OpMinF()(cmin, *min_val); hi = OpMaxF()(cmax, *max_val); }
+    else {
+        const float a = (float)(1.0 - momentum), b = (float)momentum;   // python doubles (1 - m), m become fp32 scalars
+        lo = a * (*min_val) + b * cmin;
+        hi = a * (*max_val) + b * cmax;
+    }
+    *min_val = lo;
+    *max_val = hi;
+}
+__global__ __launch_bounds__(256) void k_minmax_partial(const float* __restrict__ x, int64_t n, int vec, float* __restrict__ ws) {
+    __shared__ float sc[16];
+    float lo = INFINITY, hi = -INFINITY;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (int64_t j = i0; j < n4; j += stride) {
+            float4 v = x4[j];
+            lo = OpMinF()(OpMinF()(lo, v.x), OpMinF()(OpMinF()(v.y, v.z), v.w));
+            hi = OpMaxF()(OpMaxF()(hi, v.x), OpMaxF()(OpMaxF()(v.y, v.z), v.w));
+        }
+        for (int64_t j = (n4 << 2) + i0; j < n; j += stride) { lo = OpMinF()(lo, x[j]); hi = OpMaxF()(hi, x[j]); }
+    } else {
+        for (int64_t j = i0; j < n; j += stride) { lo = OpMinF()(lo, x[j]); hi = OpMaxF()(hi, x[j]); }
+    }
+    lo = block_reduce(lo, OpMinF(), INFINITY, sc);
+    hi = block_reduce(hi, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) { ws[blockIdx.x] = lo; ws[OBS_NB + blockIdx.x] = hi; }
+}
+__global__ __launch_bounds__(256) void k_minmax_final(const float* __restrict__ ws, int nb, int obs_kind, int first, double momentum,
+                                                      float* __restrict__ min_val, float* __restrict__ max_val) {
+    __shared__ float sc[16];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) { lo = OpMinF()(lo, ws[i]); hi = OpMaxF()(hi, ws[OBS_NB + i]); }
+    lo = block_reduce(lo, OpMinF(), INFINITY, sc);
+    hi = block_reduce(hi, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) observer_update(obs_kind, first, momentum, lo, hi, min_val, max_val);
+}
+__global__ __launch_bounds__(256) void k_minmax_rows(const float* __restrict__ x, int64_t cols, int obs_kind, int first, double momentum,
+                                                     float* __restrict__ min_val, float* __restrict__ max_val) {
+    __shared__ float sc[16];
+    const float* xr = x + (int64_t)blockIdx.x * cols;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t j = threadIdx.x; j < cols; j += blockDim.x) { lo = OpMinF()(lo, xr[j]); hi = OpMaxF()(hi, xr[j]); }
+    lo = block_reduce(lo, OpMinF(), INFINITY, sc);
+    hi = block_reduce(hi, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) observer_update(obs_kind, first, momentum, lo, hi, min_val + blockIdx.x, max_val + blockIdx.x);
+}
+extern "C" int mn_iao_observe(const float* x, int64_t rows, int64_t cols, int obs_kind, int first, double momentum,
+                              float* min_val, float* max_val, float* ws, mn_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || !x || !min_val || !max_val || (obs_kind != 0 && obs_kind != 1)) MN_FAIL(MN_EINVAL, "mn_iao_observe: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows == 1) {
+        if (!ws) MN_FAIL(MN_EINVAL, "mn_iao_observe: workspace required for rows == 1");
+        int vec = aligned16(x);
+        int nb = mn_grid_for(vec ? (cols + 3) / 4 : cols, 256 * 4, OBS_NB);
+        hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(256), 0, s, x, cols, vec, ws);
+        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, s, ws, nb, obs_kind, first, momentum, min_val, max_val);
+    } else {
+        hipLaunchKernelGGL(k_minmax_rows, dim3((unsigned)rows), dim3(256), 0, s, x, cols, obs_kind, first, momentum, min_val, max_val);
+    }
+    MN_CHECK_LAUNCH("mn_iao_observe");
+    return MN_OK;
+}
+
+// qparams (293-321) + clip-STE bounds (148-157)
+__global__ __launch_bounds__(256) void k_iao_qparams(const float* __restrict__ min_val, const float* __restrict__ max_val, int64_t rows,
+                                                     int q_type, float quant_range, int update, float* __restrict__ scale,
+                                                     float* __restrict__ zero_point, float* __restrict__ qp) {
+    const float EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        const float mn = min_val[i], mx = max_val[i];
+        float sc, zp;
+        if (update) {
+            if (q_type == 0) {
+                float fr = OpMaxF()(fabsf(mn), fabsf(mx));
+                sc = OpMaxF()(fr / quant_range, EPS);
+                zp = 0.f;
+            } else {
+                sc = OpMaxF()((mx - mn) / quant_range, EPS);
+                zp = mn_sign(mn) * floorf(fabsf(mn / sc) + 0.5f);
+            }
+            scale[i] = sc;
+            zero_point[i] = zp;
+        } else {
+            sc = scale[i];
+            zp = zero_point[i];
+        }
+        float lo = mn / sc - zp, hi = mx / sc - zp;
+        if (q_type == 0) { hi = OpMaxF()(fabsf(lo), fabsf(hi)); lo = -hi; }
+        qp[i * 4 + 0] = sc; qp[i * 4 + 1] = zp; qp[i * 4 + 2] = lo; qp[i * 4 + 3] = hi;
+    }
+}
+extern "C" int mn_iao_qparams(const float* min_val, const float* max_val, int64_t rows, int bits, int q_type, int is_act,
+                              int update, float* scale, float* zero_point, float* qp, mn_stream_t stream) {
+    if (rows <= 0 || bits < 2 || bits > 24 || !min_val || !max_val || !scale || !zero_point || !qp || (q_type != 0 && q_type != 1))
+        MN_FAIL(MN_EINVAL, "mn_iao_qparams: bad arguments (bits=%d)", bits);
+    IaoRange r = iao_range(bits, q_type, is_act);
+    // python: float(qmax - qmin) / 2 for symmetric, float(qmax - qmin) for asymmetric; the fp32 tensor is divided by fp32(that)
+    float qr = (q_type == 0) ? (float)((double)(r.qmax - r.qmin) / 2.0) : (float)(r.qmax - r.qmin);
+    hipLaunchKernelGGL(k_iao_qparams, dim3(mn_grid_for(rows, 256, 64)), dim3(256), 0, (hipStream_t)stream, min_val, max_val, rows,
+                       q_type, qr, update, scale, zero_point, qp);
+    MN_CHECK_LAUNCH("mn_iao_qparams");
+    return MN_OK;
+}
+
+// fake-quant (227-239) and its clip-STE backward; x viewed as [rows][cols] with per-row qp
+__global__ __launch_bounds__(256) void k_iao_fq_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t cols,
+                                                    const float* __restrict__ qp, float qmin, float qmax, int vec) {
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float sc = qp[row * 4], zp = qp[row * 4 + 1];
+        const float* xr = x + row * cols;
+        float* yr = y + row * cols;
+        const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+        if (vec) {
+            const int64_t n4 = cols >> 2;
+            for (int64_t j = t0; j < n4; j += stride) {
+                float4 v = reinterpret_cast<const float4*>(xr)[j], o;
+                o.x = iao_fq(v.x, sc, zp, qmin, qmax); o.y = iao_fq(v.y, sc, zp, qmin, qmax);
+                o.z = iao_fq(v.z, sc, zp, qmin, qmax); o.w = iao_fq(v.w, sc, zp, qmin, qmax);
+                reinterpret_cast<float4*>(yr)[j] = o;
+            }
+            for (int64_t j = (n4 << 2) + t0; j < cols; j += stride) yr[j] = iao_fq(xr[j], sc, zp, qmin, qmax);
+        } else {
+            for (int64_t j = t0; j < cols; j += stride) yr[j] = iao_fq(xr[j], sc, zp, qmin, qmax);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_iao_fq_bwd(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dx,
+                                                    int64_t rows, int64_t cols, const float* __restrict__ qp, float qmin, float qmax, int vec) {
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float sc = qp[row * 4], zp = qp[row * 4 + 1], lo = qp[row * 4 + 2], hi = qp[row * 4 + 3];
+        const float* xr = x + row * cols;
+        const float* gr = g + row * cols;
+        float* dr = dx + row * cols;
+        const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+        if (vec) {
+            const int64_t n4 = cols >> 2;
+            for (int64_t j = t0; j < n4; j += stride) {
+                float4 v = reinterpret_cast<const float4*>(xr)[j], gg = reinterpret_cast<const float4*>(gr)[j], o;
+                o.x = iao_fq_grad(gg.x, v.x, sc, zp, lo, hi, qmin, qmax); o.y = iao_fq_grad(gg.y, v.y, sc, zp, lo, hi, qmin, qmax);
+                o.z = iao_fq_grad(gg.z, v.z, sc, zp, lo, hi, qmin, qmax); o.w = iao_fq_grad(gg.w, v.w, sc, zp, lo, hi, qmin, qmax);
+                reinterpret_cast<float4*>(dr)[j] = o;
+            }
+            for (int64_t j = (n4 << 2) + t0; j < cols; j += stride) dr[j] = iao_fq_grad(gr[j], xr[j], sc, zp, lo, hi, qmin, qmax);
+        } else {
+            for (int64_t j = t0; j < cols; j += stride) dr[j] = iao_fq_grad(gr[j], xr[j], sc, zp, lo, hi, qmin, qmax);
+        }
+    }
+}
+static void fq_grid(int64_t rows, int64_t cols, dim3* grid, int* vec, const void* a, const void* b, const void* c) {
+    *vec = aligned16(a) && aligned16(b) && (c ? aligned16(c) : 1) && (rows == 1 || cols % 4 == 0);
+    int per_row = mn_grid_for(*vec ? (cols + 3) / 4 : cols, 256, EW_GRID_CAP);
+    int64_t gy = EW_GRID_CAP / per_row;
+    if (gy < 1) gy = 1;
+    if (gy > rows) gy = rows;
+    *grid = dim3((unsigned)per_row, (unsigned)gy);
+}
+extern "C" int mn_iao_fq_fwd(const float* x, float* y, int64_t rows, int64_t cols, const float* qp, int bits, int q_type,
+                             int is_act, mn_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || !x || !y || !qp || bits < 2 || bits > 24) MN_FAIL(MN_EINVAL, "mn_iao_fq_fwd: bad arguments");
+    IaoRange r = iao_range(bits, q_type, is_act);
+    dim3 grid;
+    int vec;
+    fq_grid(rows, cols, &grid, &vec, x, y, nullptr);
+    hipLaunchKernelGGL(k_iao_fq_fwd, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, qp, r.qmin, r.qmax, vec);
+    MN_CHECK_LAUNCH("mn_iao_fq_fwd");
+    return MN_OK;
+}
+extern "C" int mn_iao_fq_bwd(const float* g, const float* x, float* dx, int64_t rows, int64_t cols, const float* qp, int bits,
+                             int q_type, int is_act, mn_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || !g || !x || !dx || !qp || bits < 2 || bits > 24) MN_FAIL(MN_EINVAL, "mn_iao_fq_bwd: bad arguments");
+    IaoRange r = iao_range(bits, q_type, is_act);
+    dim3 grid;
+    int vec;
+    fq_grid(rows, cols, &grid, &vec, g, x, dx);
+    hipLaunchKernelGGL(k_iao_fq_bwd, grid, dim3(256), 0, (hipStream_t)stream, g, x, dx, rows, cols, qp, r.qmin, r.qmax, vec);
+    MN_CHECK_LAUNCH("mn_iao_fq_bwd");
+    return MN_OK;
+}
+__global__ void k_iao_union(const float* a0, const float* a1, const float* b0, const float* b1, float* o0, float* o1) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { *o0 = OpMinF()(*a0, *b0); *o1 = OpMaxF()(*a1, *b1); }
+}
+extern "C" int mn_iao_union_range(const float* min_a, const float* max_a, const float* min_b, const float* max_b,
+                                  float* min_out, float* max_out, mn_stream_t stream) {
+    if (!min_a || !max_a || !min_b || !max_b || !min_out || !max_out) MN_FAIL(MN_EINVAL, "mn_iao_union_range: null pointer");
+    hipLaunchKernelGGL(k_iao_union, dim3(1), dim3(64), 0, (hipStream_t)stream, min_a, max_a, min_b, max_b, min_out, max_out);
+    MN_CHECK_LAUNCH("mn_iao_union_range");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN-fuse statistics (853-855): per-channel mean / unbiased variance over (N, HW) of o[N][C][HW].
+// Pass 1: grid (C, S) blocks, each sums a slice of images of one channel in fp64 (sum, sum of squares about a
+// pivot = first element of the channel, which keeps the one-pass variance well conditioned).
+// Pass 2: one block per channel combines the S partials.
+static const int BN_SPLIT = 32;
+extern "C" int64_t mn_bn_stats_ws_floats(int64_t, int64_t C, int64_t) { return C * BN_SPLIT * 4; }  // 2 doubles per partial
+
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ o, int N, int C, int HW, double* __restrict__ part) {
+    __shared__ double scd[16];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const float pivot = o[(int64_t)c * HW];
+    double s1 = 0.0, s2 = 0.0;
+    const int vec = (HW % 4 == 0) && aligned16(o);
+    for (int n = sp; n < N; n += S) {
+        const float* p = o + ((int64_t)n * C + c) * HW;
+        if (vec) {
+            for (int j = threadIdx.x; j < HW / 4; j += blockDim.x) {
+                float4 v = reinterpret_cast<const float4*>(p)[j];
+                double a = (double)v.x - pivot, b = (double)v.y - pivot, cc = (double)v.z - pivot, d = (double)v.w - pivot;
+                s1 += (a + b) + (cc + d);
+                s2 += (a * a + b * b) + (cc * cc + d * d);
+            }
+        } else {
+            for (int j = threadIdx.x; j < HW; j += blockDim.x) {
+                double a = (double)p[j] - pivot;
+                s1 += a;
+                s2 += a * a;
+            }
+        }
+    }
+    s1 = block_reduce(s1, OpAddD(), 0.0, scd);
+    s2 = block_reduce(s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { part[((int64_t)c * S + sp) * 2] = s1; part[((int64_t)c * S + sp) * 2 + 1] = s2; }
+}
+__global__ void k_bn_stats_final(const float* __restrict__ o, const double* __restrict__ part, int N, int C, int HW, int S,
+                                 float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < S; ++i) { s1 += part[((int64_t)c * S + i) * 2]; s2 += part[((int64_t)c * S + i) * 2 + 1]; }
+    const double n = (double)N * (double)HW;
+    const double pivot = (double)o[(int64_t)c * HW];
+    const double m = s1 / n;
+    stats[c] = (float)(pivot + m);
+    stats[C + c] = (float)((s2 - s1 * m) / (n - 1.0));    // unbiased; n == 1 -> NaN like torch.var
+}
+extern "C" int mn_bn_stats_fwd(const float* o, int64_t N, int64_t C, int64_t HW, float* stats, float* ws, mn_stream_t stream) {
+    if (N <= 0 || C <= 0 || HW <= 0 || !o || !stats || !ws || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bn_stats_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int S = (int)(N < BN_SPLIT ? N : BN_SPLIT);
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, o, (int)N, (int)C, (int)HW, (double*)ws);
+    hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, o, (const double*)ws, (int)N, (int)C, (int)HW, S, stats);
+    MN_CHECK_LAUNCH("mn_bn_stats_fwd");
+    return MN_OK;
+}
+__global__ __launch_bounds__(256) void k_bn_stats_bwd(const float* __restrict__ o, const float* __restrict__ stats, const float* __restrict__ dmean,
+                                                      const float* __restrict__ dvar, float* __restrict__ d_o, int N, int C, int HW) {
+    // grid: (C, N-slices). d_o = dmean/n + dvar * 2 (o - mean) / (n - 1)   (autograd of mean / var(unbiased))
+    const int c = blockIdx.x;
+    const float n = (float)N * (float)HW;
+    const float a = dmean[c] / n, mean = stats[c];
+    const float k = dvar[c] * 2.f / (n - 1.f);
+    const int vec = (HW % 4 == 0) && aligned16(o) && aligned16(d_o);
+    for (int img = blockIdx.y; img < N; img += gridDim.y) {
+        const int64_t off = ((int64_t)img * C + c) * HW;
+        if (vec) {
+            for (int j = threadIdx.x; j < HW / 4; j += blockDim.x) {
+                float4 v = reinterpret_cast<const float4*>(o + off)[j], r;
+                r.x = a + k * (v.x - mean); r.y = a + k * (v.y - mean); r.z = a + k * (v.z - mean); r.w = a + k * (v.w - mean);
+                reinterpret_cast<float4*>(d_o + off)[j] = r;
+            }
+        } else {
+            for (int j = threadIdx.x; j < HW; j += blockDim.x) d_o[off + j] = a + k * (o[off + j] - mean);
+        }
+    }
+}
+extern "C" int mn_bn_stats_bwd(const float* o, const float* stats, const float* dmean, const float* dvar, float* d_o,
+                               int64_t N, int64_t C, int64_t HW, mn_stream_t stream) {
+    if (N <= 0 || C <= 0 || HW <= 0 || !o || !stats || !dmean || !dvar || !d_o) MN_FAIL(MN_EINVAL, "mn_bn_stats_bwd: bad arguments");
+    int S = (int)(N < 64 ? N : 64);
+    hipLaunchKernelGGL(k_bn_stats_bwd, dim3((unsigned)C, (unsigned)S), dim3(256), 0, (hipStream_t)stream, o, stats, dmean, dvar, d_o, (int)N, (int)C, (int)HW);
+    MN_CHECK_LAUNCH("mn_bn_stats_bwd");
+    return MN_OK;
+}

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build the CPU SIMT-emulation of libmicronet (TEST TOOL; see tests/emu/include/hip/hip_runtime.h)
+set -e
+cd "$(dirname "$0")/../.."
+mkdir -p tests/emu/build
+CXX="g++ -O2 -std=c++17 -fPIC -ffp-contract=off -I tests/emu/include -x c++"
+$CXX -DMN_EMU_MAIN -c micronet_amd/csrc/quant_kernels.hip -o tests/emu/build/quant_kernels.o
+$CXX -c micronet_amd/csrc/conv_kernels.hip -o tests/emu/build/conv_kernels.o
+g++ -shared -o tests/emu/build/libmicronet_emu.so tests/emu/build/quant_kernels.o tests/emu/build/conv_kernels.o
+echo built tests/emu/build/libmicronet_emu.so

@@ -1,0 +1,238 @@
+// TEST TOOL ONLY -- a minimal single-threaded SIMT emulator so the *unmodified* HIP kernel
+// sources under micronet_amd/csrc/ can be compiled with g++ and executed on a CPU:
+//     g++ -I tests/emu/include -x c++ micronet_amd/csrc/*.hip -> tests/emu/libmicronet_emu.so
+// It exists because the build container has no GPU: the unit tests drive the same extern "C"
+// ABI against this build to check index math, tiling, fragment layouts and reductions before
+// any GPU time is spent.  It is never loaded by micronet_amd (the product refuses to run
+// without the gfx950 library).
+//
+// Model: one OS thread; every GPU thread of the running block is a ucontext fiber; a fiber runs
+// until it reaches a block barrier or a wave collective, where it yields.  Blocks run one after
+// another.  Wave size 64.  MFMA v_mfma_f32_16x16x4_f32 is emulated with the lane->element maps
+// of the CDNA4 ISA: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+// D[row=(lane>>4)*4+reg][col=lane&15], as an in-order fp32 fma chain over k.
+#pragma once
+#define MN_EMULATION 1
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__ __restrict
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct int4 { int x, y, z, w; };
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+#define hipMemcpyDeviceToDevice 3
+
+namespace emu {
+enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
+struct Fiber {
+    ucontext_t ctx;
+    State st;
+    uint3_emu tid;
+    int wave;
+    char* stack;
+};
+struct Ctx {
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    Fiber* cur = nullptr;
+    std::function<void()> body;
+    char* dyn_smem = nullptr;
+    // per-wave exchange buffers
+    double xd[64 * 8];  // up to 8 waves x 64 lanes (reallocated as needed)
+    std::vector<double> wbuf;
+    std::vector<float> wa, wb;
+};
+inline Ctx& C() { static Ctx c; return c; }
+}  // namespace emu
+
+extern thread_local uint3_emu threadIdx, blockIdx;
+extern thread_local dim3 blockDim, gridDim;
+#ifdef MN_EMU_MAIN
+thread_local uint3_emu threadIdx, blockIdx;
+thread_local dim3 blockDim, gridDim;
+#endif
+
+namespace emu {
+inline void yield(State s) {
+    Ctx& c = C();
+    Fiber* f = c.cur;
+    f->st = s;
+    swapcontext(&f->ctx, &c.sched);
+}
+inline void trampoline() {
+    Ctx& c = C();
+    c.body();
+    c.cur->st = DONE;
+    swapcontext(&c.cur->ctx, &c.sched);
+}
+inline void run_block(unsigned nthreads, dim3 bdim) {
+    Ctx& c = C();
+    const size_t STK = 512 * 1024;
+    if (c.fibers.size() < nthreads) {
+        size_t old = c.fibers.size();
+        c.fibers.resize(nthreads);
+        for (size_t i = old; i < nthreads; ++i) c.fibers[i].stack = (char*)malloc(STK);
+    }
+    unsigned nw = (nthreads + 63) / 64;
+    c.wbuf.assign(nw * 64, 0.0);
+    c.wa.assign(nw * 64, 0.f);
+    c.wb.assign(nw * 64, 0.f);
+    for (unsigned i = 0; i < nthreads; ++i) {
+        Fiber& f = c.fibers[i];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STK;
+        f.ctx.uc_link = &c.sched;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        f.st = RUNNABLE;
+        f.tid.x = i % bdim.x;
+        f.tid.y = (i / bdim.x) % bdim.y;
+        f.tid.z = i / (bdim.x * bdim.y);
+        f.wave = i / 64;
+    }
+    unsigned alive = nthreads;
+    while (alive) {
+        bool progressed = false;
+        for (unsigned i = 0; i < nthreads; ++i) {
+            Fiber& f = c.fibers[i];
+            if (f.st != RUNNABLE) continue;
+            c.cur = &f;
+            threadIdx = f.tid;
+            swapcontext(&c.sched, &f.ctx);
+            progressed = true;
+            if (f.st == DONE) --alive;
+        }
+        // release barriers
+        bool released = false;
+        unsigned nblock = 0, nlive = 0;
+        for (unsigned i = 0; i < nthreads; ++i) {
+            if (c.fibers[i].st != DONE) ++nlive;
+            if (c.fibers[i].st == WAIT_BLOCK) ++nblock;
+        }
+        if (nlive && nblock == nlive) {
+            for (unsigned i = 0; i < nthreads; ++i)
+                if (c.fibers[i].st == WAIT_BLOCK) c.fibers[i].st = RUNNABLE;
+            released = true;
+        }
+        for (unsigned w = 0; w < nw; ++w) {
+            unsigned lo = w * 64, hi = std::min(nthreads, lo + 64), nl = 0, nwv = 0;
+            for (unsigned i = lo; i < hi; ++i) {
+                if (c.fibers[i].st != DONE) ++nl;
+                if (c.fibers[i].st == WAIT_WAVE) ++nwv;
+            }
+            if (nl && nwv == nl) {
+                for (unsigned i = lo; i < hi; ++i)
+                    if (c.fibers[i].st == WAIT_WAVE) c.fibers[i].st = RUNNABLE;
+                released = true;
+            }
+        }
+        if (!progressed && !released && alive) {
+            fprintf(stderr, "emu: deadlock (divergent barrier?)\n");
+            abort();
+        }
+    }
+}
+inline int lane() { return (int)((threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) & 63); }
+inline int flat_tid() { return (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)); }
+template <typename T>
+inline T wave_exchange(T v, int src_lane) {
+    Ctx& c = C();
+    int base = (flat_tid() / 64) * 64;
+    double d;
+    static_assert(sizeof(T) <= 8, "");
+    d = 0;
+    memcpy(&d, &v, sizeof(T));
+    c.wbuf[base + lane()] = d;
+    yield(WAIT_WAVE);
+    T out = v;
+    if (src_lane >= 0 && src_lane < 64) memcpy(&out, &c.wbuf[base + src_lane], sizeof(T));
+    yield(WAIT_WAVE);
+    return out;
+}
+}  // namespace emu
+
+static inline void __syncthreads() { emu::yield(emu::WAIT_BLOCK); }
+template <typename T>
+static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int l = emu::lane();
+    int src = l + (int)d;
+    if ((src / width) != (l / width)) src = l;  // out of segment: own value
+    return emu::wave_exchange(v, src);
+}
+template <typename T>
+static inline T __shfl_xor(T v, int m, int width = 64) {
+    return emu::wave_exchange(v, emu::lane() ^ m);
+}
+template <typename T>
+static inline T __shfl(T v, int src, int width = 64) {
+    int l = emu::lane();
+    return emu::wave_exchange(v, (l / width) * width + (src % width));
+}
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
+
+typedef float __emu_f32x4 __attribute__((vector_size(16)));
+static inline __emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, __emu_f32x4 c, int, int, int) {
+    emu::Ctx& cx = emu::C();
+    int base = (emu::flat_tid() / 64) * 64, l = emu::lane();
+    cx.wa[base + l] = a;
+    cx.wb[base + l] = b;
+    emu::yield(emu::WAIT_WAVE);
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(cx.wa[base + k * 16 + row], cx.wb[base + k * 16 + col], acc);
+        c[r] = acc;
+    }
+    emu::yield(emu::WAIT_WAVE);
+    return c;
+}
+
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::C().dyn_smem;
+
+template <typename K, typename... Args>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+    emu::Ctx& c = emu::C();
+    std::vector<char> sm(shmem + 64);
+    c.dyn_smem = (char*)(((uintptr_t)sm.data() + 63) & ~(uintptr_t)63);
+    gridDim = grid;
+    blockDim = block;
+    unsigned nthreads = block.x * block.y * block.z;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx.x = bx;
+                blockIdx.y = by;
+                blockIdx.z = bz;
+                c.body = [&]() { kernel(args...); };
+                emu::run_block(nthreads, block);
+            }
+}

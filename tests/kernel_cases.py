@@ -1,0 +1,250 @@
+"""Kernel-level parity cases shared by the CPU-emulation run (not gpu) and the MI355X run (-m gpu).
+
+Each check drives the C ABI through ``abi_driver.Backend`` and compares with ``oracle/np_oracle.py`` and the golden
+fixtures.  Tolerances: integer/quantize steps bit-exact; fp32 sums over a channel (alpha, mean) <= 5e-7 rel;
+float conv accumulate <= 1e-5 * max|ref| (north_star), checked against an fp64 evaluation of the same products.
+"""
+import ctypes as C
+
+import numpy as np
+
+from oracle import np_oracle as O
+
+F = np.float32
+
+
+def eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def close(a, b, rel):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.max(np.abs(b[np.isfinite(b)])) if np.isfinite(b).any() else 0.0, 1e-30)
+    ok = np.isfinite(b)
+    return a.shape == b.shape and eq(np.isnan(a), np.isnan(b)) and (np.max(np.abs(a[ok] - b[ok])) if ok.any() else 0.0) <= rel * scale
+
+
+# ----------------------------------------------------------------------------- quantizers vs golden
+def check_dorefa_act(be, q, bits):
+    x, g = q[f"dorefa_act{bits}_x"], q[f"dorefa_act{bits}_g"]
+    n = x.size
+    dx_, dg = be.to_dev(x), be.to_dev(g)
+    y, dxo = be.empty(n), be.empty(n)
+    be.call("mn_dorefa_act_fwd", be.ptr(dx_), be.ptr(y), n, bits, be.stream)
+    be.call("mn_dorefa_act_bwd", be.ptr(dg), be.ptr(dx_), be.ptr(dxo), n, bits, be.stream)
+    assert eq(be.to_host(y), q[f"dorefa_act{bits}_y"])
+    assert eq(be.to_host(dxo), q[f"dorefa_act{bits}_dx"])
+    # unaligned / odd length path
+    y2 = be.empty(n)
+    xs = be.to_dev(np.concatenate([[0], x]))
+    if be.kind == "emu":
+        be.call("mn_dorefa_act_fwd", C.c_void_p(xs.ctypes.data + 4), be.ptr(y2), n, bits, be.stream)
+    else:
+        be.call("mn_dorefa_act_fwd", C.c_void_p(xs.data_ptr() + 4), be.ptr(y2), n, bits, be.stream)
+    assert eq(be.to_host(y2), q[f"dorefa_act{bits}_y"])
+    r = be.empty(n)
+    be.call("mn_round_half_away", be.ptr(dx_), be.ptr(r), n, be.stream)
+    assert eq(be.to_host(r), O.rha(x))
+
+
+def check_dorefa_w(be, q, bits):
+    w, g = q[f"dorefa_w{bits}_w"], q[f"dorefa_w{bits}_g"]
+    n = w.size
+    dw_, dg = be.to_dev(w), be.to_dev(g)
+    ws = be.empty(int(be.lib.mn_dorefa_w_ws_floats(n)))
+    qw, dwo = be.empty(n), be.empty(n)
+    be.call("mn_dorefa_w_fwd", be.ptr(dw_), be.ptr(qw), n, bits, be.ptr(ws), be.stream)
+    be.call("mn_dorefa_w_bwd", be.ptr(dg), be.ptr(dw_), be.ptr(dwo), n, bits, be.ptr(ws), be.stream)
+    ref = q[f"dorefa_w{bits}_y"].reshape(-1)
+    got = be.to_host(qw).reshape(-1)
+    s = 1.0 / (2 ** bits - 1)
+    # codes: identical except where device tanh and torch-CPU (Sleef) tanh differ in the last ulp at a rounding boundary
+    codes_got, codes_ref = np.round((got + 1) / 2 / s), np.round((ref + 1) / 2 / s)
+    assert (codes_got != codes_ref).sum() <= 2, (codes_got != codes_ref).sum()
+    same = codes_got == codes_ref
+    assert eq(got[same], ref[same])
+    dref = q[f"dorefa_w{bits}_dw"].reshape(-1)
+    assert np.max(np.abs(be.to_host(dwo).reshape(-1) - dref)) <= 2e-6 * np.max(np.abs(dref))
+
+
+def check_wbwtab(be, q):
+    x, g = q["binact_x"], q["binact_g"]
+    n = x.size
+    dx_, dg = be.to_dev(x), be.to_dev(g)
+    y, dxo = be.empty(n), be.empty(n)
+    be.call("mn_binact_fwd", be.ptr(dx_), be.ptr(y), n, be.stream)
+    be.call("mn_binact_bwd", be.ptr(dg), be.ptr(dx_), be.ptr(dxo), n, be.stream)
+    assert eq(be.to_host(y), q["binact_y"]) and eq(be.to_host(dxo), q["binact_dx"])
+    # ternary
+    w, g = q["ternary_w"], q["ternary_g"]
+    Oc, K = w.shape[0], w[0].size
+    dw_, dg = be.to_dev(w), be.to_dev(g)
+    qw, st, dwo = be.empty(w.shape), be.empty((Oc, 4)), be.empty(w.shape)
+    be.call("mn_ternary_w_fwd", be.ptr(dw_), be.ptr(qw), be.ptr(st), Oc, K, be.stream)
+    be.call("mn_ternary_w_bwd", be.ptr(dg), be.ptr(dw_), be.ptr(st), be.ptr(dwo), Oc, K, be.stream)
+    got, ref = be.to_host(qw), q["ternary_y"]
+    ok = ~np.isnan(ref)
+    assert eq(np.isnan(got), np.isnan(ref))
+    assert eq(np.sign(got[ok]), np.sign(ref[ok]))                       # ternary codes bit-exact
+    assert np.max(np.abs(got[ok] - ref[ok])) <= 5e-7 * np.max(np.abs(ref[ok]))
+    got, ref = be.to_host(dwo), q["ternary_dw"]
+    assert eq(np.isnan(got), np.isnan(ref))
+    assert np.max(np.abs(got[ok] - ref[ok])) <= 2e-6 * np.max(np.abs(ref[ok]))
+    # binary (in-place centre + clamp)
+    w, g = q["binary_w"], q["binary_g"]
+    Oc, Cc, R = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+    dw_, dg = be.to_dev(w), be.to_dev(g)
+    qw, al, dwo = be.empty(w.shape), be.empty(Oc), be.empty(w.shape)
+    be.call("mn_binary_w_fwd", be.ptr(dw_), be.ptr(qw), be.ptr(al), Oc, Cc, R, be.stream)
+    be.call("mn_binary_w_bwd", be.ptr(dg), be.ptr(dw_), be.ptr(al), be.ptr(dwo), Oc, Cc * R, be.stream)
+    assert np.max(np.abs(be.to_host(dw_) - q["binary_w_after"])) <= 2e-7
+    got, ref = be.to_host(qw), q["binary_y"]
+    assert eq(np.sign(got), np.sign(ref)) and np.max(np.abs(got - ref)) <= 5e-7 * np.max(np.abs(ref))
+    got, ref = be.to_host(dwo), q["binary_dw"]
+    assert np.max(np.abs(got - ref)) <= 2e-6 * np.max(np.abs(ref))
+
+
+def check_iao(be, q, meta):
+    for c in meta:
+        key, bits, q_type, is_act = c["key"], c["bits"], c["q_type"], int(c["kind"] == "act")
+        shape = c["shape"]
+        rows = 1 if c["level"] == "L" else shape[0]
+        cols = int(np.prod(shape)) // rows
+        mn, mx, sc, zp, qp = (be.to_dev(np.zeros(rows)), be.to_dev(np.zeros(rows)), be.to_dev(np.ones(rows)),
+                              be.to_dev(np.zeros(rows)), be.empty((rows, 4)))
+        ws = be.empty(max(4, int(be.lib.mn_iao_observe_ws_floats(rows, cols))))
+        obs_kind = 0 if c["obs"] == "minmax" else 1
+        for s in range(3):
+            x, g = q[f"{key}_s{s}_x"], q[f"{key}_s{s}_g"]
+            dx_, dg = be.to_dev(x), be.to_dev(g)
+            be.call("mn_iao_observe", be.ptr(dx_), rows, cols, obs_kind, int(s == 0), 0.1, be.ptr(mn), be.ptr(mx), be.ptr(ws), be.stream)
+            be.call("mn_iao_qparams", be.ptr(mn), be.ptr(mx), rows, bits, q_type, is_act, 1, be.ptr(sc), be.ptr(zp), be.ptr(qp), be.stream)
+            assert eq(be.to_host(mn).reshape(-1), q[f"{key}_s{s}_min"].reshape(-1)), key
+            assert eq(be.to_host(mx).reshape(-1), q[f"{key}_s{s}_max"].reshape(-1)), key
+            assert eq(be.to_host(sc).reshape(-1), q[f"{key}_s{s}_scale"].reshape(-1)), key
+            assert eq(be.to_host(zp).reshape(-1), q[f"{key}_s{s}_zp"].reshape(-1)), key
+            y, dxo = be.empty(x.shape), be.empty(x.shape)
+            be.call("mn_iao_fq_fwd", be.ptr(dx_), be.ptr(y), rows, cols, be.ptr(qp), bits, q_type, is_act, be.stream)
+            be.call("mn_iao_fq_bwd", be.ptr(dg), be.ptr(dx_), be.ptr(dxo), rows, cols, be.ptr(qp), bits, q_type, is_act, be.stream)
+            assert eq(be.to_host(y), q[f"{key}_s{s}_y"]), key
+            assert eq(be.to_host(dxo), q[f"{key}_s{s}_dx"]), key
+        # eval: snapshot only (update = 0)
+        x = q[f"{key}_eval_x"]
+        dx_, y = be.to_dev(x), be.empty(x.shape)
+        be.call("mn_iao_qparams", be.ptr(mn), be.ptr(mx), rows, bits, q_type, is_act, 0, be.ptr(sc), be.ptr(zp), be.ptr(qp), be.stream)
+        be.call("mn_iao_fq_fwd", be.ptr(dx_), be.ptr(y), rows, cols, be.ptr(qp), bits, q_type, is_act, be.stream)
+        assert eq(be.to_host(y), q[f"{key}_eval_y"]), key
+
+
+def check_bn_stats(be, shape=(5, 6, 4, 8), seed=0):
+    r = np.random.default_rng(seed)
+    o = (r.standard_normal(shape) * 2 + 3).astype(F)
+    N, Cc, HW = shape[0], shape[1], shape[2] * shape[3]
+    do_, st = be.to_dev(o), be.empty((2, Cc))
+    ws = be.empty(int(be.lib.mn_bn_stats_ws_floats(N, Cc, HW)) + 2)
+    be.call("mn_bn_stats_fwd", be.ptr(do_), N, Cc, HW, be.ptr(st), be.ptr(ws), be.stream)
+    mean, var = O.bn_batch_stats(o)
+    got = be.to_host(st)
+    assert np.max(np.abs(got[0] - mean)) <= 1e-6 * np.max(np.abs(mean)) and np.max(np.abs(got[1] - var)) <= 2e-6 * np.max(np.abs(var))
+    dm, dv = r.standard_normal(Cc).astype(F), r.standard_normal(Cc).astype(F)
+    d_o = be.empty(shape)
+    be.call("mn_bn_stats_bwd", be.ptr(do_), be.ptr(st), be.ptr(be.to_dev(dm)), be.ptr(be.to_dev(dv)), be.ptr(d_o), N, Cc, HW, be.stream)
+    n = N * HW
+    ref = dm.reshape(1, -1, 1, 1) / n + dv.reshape(1, -1, 1, 1) * 2 * (o.astype(np.float64) - mean.reshape(1, -1, 1, 1)) / (n - 1)
+    assert close(be.to_host(d_o), ref, 2e-6)
+
+
+# ----------------------------------------------------------------------------- convolution vs numpy fp64
+def _quant_x(x, mode, bits, qp, q_type):
+    if mode == 1:
+        return O.dorefa_act_fwd(x, bits)[0]
+    if mode == 2:
+        return O.iao_fq_fwd(x, F(qp[0]), F(qp[1]), bits, q_type, True)[0]
+    return x
+
+
+def _ste(gx, x, mode, bits, qp, q_type):
+    gx = gx.astype(F)
+    if mode == 1:
+        return O.dorefa_act_bwd(gx, x, bits)
+    if mode == 2:
+        qmin, qmax = O.iao_qrange(bits, q_type, True)
+        v = x / F(qp[0]) - F(qp[1])
+        r = O.rha(v)
+        d = gx * F(qp[0])
+        d = np.where((r >= qmin) & (r <= qmax), d, F(0))
+        d = np.where((v > F(qp[3])) | (v < F(qp[2])), F(0), d)
+        return (d / F(qp[0])).astype(F)
+    return gx
+
+
+def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, bias=True, mode=0, bits=8, q_type=0,
+               algos=(1, 2), seed=0, binary_x=False, expect_mfma=None, rel=1e-5):
+    """fwd / bwd_data / bwd_weight of one geometry on every requested algo vs numpy fp64 on the same fp32 operands."""
+    r = np.random.default_rng(seed)
+    x = (np.where(r.standard_normal(x_shape) > 0, 1.0, -1.0) if binary_x else r.standard_normal(x_shape) * 4).astype(F)
+    w = (r.standard_normal(w_shape) * 0.3).astype(F)
+    b = (r.standard_normal(w_shape[0]) * 0.2).astype(F) if bias else None
+    g = be.geom(x_shape, w_shape, stride, padding, dilation, groups)
+    qp = None
+    if mode == 2:
+        mn, mx = F(x.min()), F(x.max())
+        sc, zp = O.iao_qparams(mn.reshape(1), mx.reshape(1), bits, q_type, True)
+        lo, hi = mn / sc[0] - zp[0], mx / sc[0] - zp[0]
+        if q_type == 0:
+            hi = max(abs(lo), abs(hi)); lo = -hi
+        qp = np.array([sc[0], zp[0], lo, hi], dtype=F)
+    qx = _quant_x(x, mode, bits, qp, q_type)
+    kw = dict(stride=stride, padding=padding, dilation=dilation, groups=groups)
+    y_ref = O.conv2d_fwd(qx, w, b, **kw)
+    gy = r.standard_normal(y_ref.shape).astype(F)
+    dqx_ref, dw_ref, db_ref = O.conv2d_bwd(gy, qx, w, **kw)
+    dx_ref = _ste(dqx_ref, x, mode, bits, qp, q_type)
+    dX, dW, dB, dG = be.to_dev(x), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(gy)
+    dqp = be.to_dev(qp) if qp is not None else None
+    aq = be.actq(mode, bits, q_type, dqp)
+    sup = [bool(be.lib.mn_conv2d_mfma_supported(C.byref(g), k)) for k in range(3)]
+    if expect_mfma is not None:
+        assert sup == [expect_mfma] * 3 if isinstance(expect_mfma, bool) else sup == list(expect_mfma), (sup, expect_mfma)
+    out = {}
+    for algo in algos:
+        if algo != 2 or sup[0]:
+            y = be.to_host(be.conv_fwd(g, aq, dX, dW, dB, algo))
+            assert close(y, y_ref, rel), ("fwd", algo, np.max(np.abs(y - y_ref)), np.max(np.abs(y_ref)))
+        if algo != 2 or sup[1]:
+            dx = be.to_host(be.conv_bwd_data(g, aq, dG, dW, dX, algo))
+            # the STE mask multiplies a float; compare where the mask passes with the float tolerance
+            assert close(dx, dx_ref, rel), ("bwd_data", algo, np.max(np.abs(dx - dx_ref)), np.max(np.abs(dx_ref)))
+        if algo != 2 or sup[2]:
+            dw, db = be.conv_bwd_weight(g, aq, dG, dX, algo, bias=True)
+            dw, db = be.to_host(dw), be.to_host(db)
+            assert close(dw, dw_ref, rel), ("bwd_weight", algo, np.max(np.abs(dw - dw_ref)), np.max(np.abs(dw_ref)))
+            assert close(db, db_ref, rel), ("dbias", algo)
+        out[algo] = True
+    return sup
+
+
+# geometry list: (x_shape, w_shape, kwargs) -- covers every tiler branch with small tensors
+SMALL_CONV_CASES = [
+    # 1x1 grouped, image smaller than a tile (NI > 1), N not a multiple of NI
+    dict(x_shape=(3, 16, 4, 4), w_shape=(16, 4, 1, 1), groups=4, bias=False, expect_mfma=True),
+    # 3x3 pad 1 grouped (nin_gc L7-like: 8x8, Cg=16, Mg=32)
+    dict(x_shape=(3, 32, 8, 8), w_shape=(64, 16, 3, 3), padding=1, groups=2, expect_mfma=True),
+    # partial-image tiles (16x16 -> 2 tiles per image), dense 3x3, Mg=40 (padded m-tile), Cg=6 (padded channels)
+    dict(x_shape=(2, 6, 16, 16), w_shape=(40, 6, 3, 3), padding=1, expect_mfma=True),
+    # stride 2 3x3 (resnet downsample): fwd strided, bwd-data by zero insertion
+    dict(x_shape=(2, 8, 16, 16), w_shape=(24, 8, 3, 3), stride=2, padding=1, bias=False, expect_mfma=True),
+    # stride 2 1x1 shortcut
+    dict(x_shape=(2, 8, 16, 16), w_shape=(16, 8, 1, 1), stride=2, bias=False, expect_mfma=True),
+    # 5x5 pad 2, Cin=3 (first layer), several m-blocks
+    dict(x_shape=(2, 3, 8, 8), w_shape=(160, 3, 5, 5), padding=2, expect_mfma=True),
+    # dilation 2
+    dict(x_shape=(2, 4, 8, 8), w_shape=(8, 4, 3, 3), padding=2, dilation=2, expect_mfma=True),
+    # 32-wide rows (4 rows per tile), Cg=128 -> several channel chunks
+    dict(x_shape=(1, 128, 8, 32), w_shape=(16, 128, 1, 1), expect_mfma=True),
+    # shapes the tiler rejects -> direct kernels only
+    dict(x_shape=(2, 8, 6, 6), w_shape=(12, 4, 3, 3), padding=1, groups=2, expect_mfma=False),
+    dict(x_shape=(2, 4, 7, 7), w_shape=(6, 4, 3, 3), padding=2, dilation=2, expect_mfma=False),
+    # linear layer as 1x1 conv on 1x1 images
+    dict(x_shape=(5, 32, 1, 1), w_shape=(10, 32, 1, 1), expect_mfma=False),
+]

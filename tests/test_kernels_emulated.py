@@ -1,0 +1,50 @@
+"""The HIP kernel sources, compiled for the CPU SIMT emulator (tests/emu), driven through the real C ABI and checked
+against the oracle + golden fixtures.  This validates index math / tiling / MFMA fragment maps without a GPU; the same
+checks run on the MI355X in tests/test_gpu_kernels.py."""
+import pytest
+
+import abi_driver
+import kernel_cases as K
+
+
+@pytest.fixture(scope="module")
+def be():
+    return abi_driver.Backend("emu")
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 8])
+def test_dorefa_act(be, golden, bits):
+    K.check_dorefa_act(be, golden.q, bits)
+
+
+@pytest.mark.parametrize("bits", [2, 4, 8])
+def test_dorefa_w(be, golden, bits):
+    K.check_dorefa_w(be, golden.q, bits)
+
+
+def test_wbwtab(be, golden):
+    K.check_wbwtab(be, golden.q)
+
+
+def test_iao(be, golden):
+    K.check_iao(be, golden.q, golden.meta["iao"])
+
+
+def test_bn_stats(be):
+    K.check_bn_stats(be)
+    K.check_bn_stats(be, shape=(3, 5, 3, 3), seed=1)   # HW % 4 != 0 path
+
+
+@pytest.mark.parametrize("case", range(len(K.SMALL_CONV_CASES)))
+def test_conv_plain(be, case):
+    K.check_conv(be, seed=case, **K.SMALL_CONV_CASES[case])
+
+
+@pytest.mark.parametrize("case", [1, 2, 3, 5])
+def test_conv_dorefa_fused(be, case):
+    K.check_conv(be, seed=10 + case, mode=1, bits=3, **K.SMALL_CONV_CASES[case])
+
+
+@pytest.mark.parametrize("case,q_type", [(1, 0), (2, 1), (3, 0), (8, 1)])
+def test_conv_iao_fused(be, case, q_type):
+    K.check_conv(be, seed=20 + case, mode=2, bits=4, q_type=q_type, **K.SMALL_CONV_CASES[case])
