@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""QAT training-step throughput of the fake-quantized conv hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = forward + CrossEntropy + zero_grad + backward + Adam.step on one synthetic CIFAR-10-shaped batch
+(mirror of the reference's wqaq/dorefa/main.py:77-82), data already resident in HBM.  Workload at every N:
+BASELINE.json configs[1] -- nin_gc, wbwtab W-ternary / A-binary, batch 256 PER GPU (weak scaling), data-parallel with a
+RCCL all-reduce of the gradients.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 rate
+NIN_GC_GFLOP_PER_IMG = 0.9068   # fwd+bwd, all nine convs
+NIN_GC_MB_PER_IMG = 22.71       # fused-ideal fp32 activation traffic fwd+bwd
+
+WORKLOADS = {
+    # name: (arch, scheme module, prepare kwargs, weight decay)   (BASELINE.json configs)
+    "c2": ("nin_gc", "wbwtab", dict(A=2, W=3), 0.0),
+    "c1": ("nin_gc", "wqaq.dorefa", dict(a_bits=8, w_bits=8), 1e-5),
+    "c1_w2a2": ("nin_gc", "wqaq.dorefa", dict(a_bits=2, w_bits=2), 1e-5),
+    "c3": ("nin_gc", "wqaq.iao", dict(a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=True), 1e-5),
+    "c4": ("resnet18", "wqaq.dorefa", dict(a_bits=2, w_bits=2), 1e-5),
+    "c5": ("resnet18", "wqaq.iao", dict(a_bits=4, w_bits=4, q_type=0, q_level=0), 1e-5),
+}
+WORKLOAD_DESC = {
+    "c2": "nin_gc CIFAR-10 wbwtab W-ternary/A-binary QAT, batch=256 per GPU (BASELINE configs[1])",
+    "c1": "nin_gc CIFAR-10 DoReFa W8A8 QAT (BASELINE configs[0] scheme)",
+    "c1_w2a2": "nin_gc CIFAR-10 DoReFa W2A2 QAT",
+    "c3": "nin_gc CIFAR-10 IAO W8A8 per-channel + BN-fuse QAT (BASELINE configs[2])",
+    "c4": "resnet18 CIFAR-10 DoReFa W2A2 QAT (BASELINE configs[3])",
+    "c5": "resnet18 CIFAR-10 IAO W4A4 per-channel + quant_add QAT (BASELINE configs[4])",
+}
+
+
+class KernelProfiler:
+    """Brackets every conv launch with HIP events on the launch stream; durations are read after the timed region."""
+
+    def __init__(self):
+        self.spans = []
+        self.enabled = False
+
+    @contextlib.contextmanager
+    def span(self, g, which, nbytes):
+        if not self.enabled:
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream())
+        yield
+        b.record(torch.cuda.current_stream())
+        mg = (g.O // g.groups) if which == 0 else (g.C // g.groups)
+        mt = 1 if mg <= 16 else (2 if mg <= 32 else (4 if mg <= 64 else 8))
+        tag = "k_wgrad_mfma" if which == 2 else "k_conv_mfma<%d>" % mt
+        self.spans.append((tag, which, nbytes, a, b))
+
+    def summary(self):
+        agg = {}
+        for tag, which, nbytes, a, b in self.spans:
+            ms = a.elapsed_time(b)
+            d = agg.setdefault(tag, dict(ms=0.0, bytes=0, launches=0))
+            d["ms"] += ms
+            d["bytes"] += nbytes
+            d["launches"] += 1
+        return agg
+
+
+def build(workload, device):
+    import importlib
+    from micronet_amd.train import build_model, make_optimizer
+    arch, scheme, kw, wd = WORKLOADS[workload]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    model = quantize.prepare(build_model(arch), inplace=True, **kw).to(device)
+    model.train()
+    return model, make_optimizer(model, 0.01, wd)
+
+
+def cpu_baseline(workload, batch, steps):
+    """The reference's algorithm on the host cores: the torch-CPU oracle ("port", bit-identical to the reference on CPU)."""
+    from oracle import torch_oracle as TO
+    from micronet_amd.train import build_model, synth_batch
+    arch, scheme, kw, wd = WORKLOADS[workload]
+    scheme_name = scheme.split(".")[-1]
+    torch.set_num_threads(os.cpu_count())
+    model = TO.prepare(build_model(arch), scheme_name, inplace=True, **kw).train()
+    opt = TO.make_optimizer(model, 0.01, wd)
+    x, y = synth_batch(batch)
+    TO.train_step(model, opt, x, y)                     # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        TO.train_step(model, opt, x, y)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 2), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d timed steps (after 1 warm-up) of the same train step at batch %d, torch-CPU restatement of the "
+                       "reference modules (oracle/torch_oracle.py), %.1f s of CPU work" % (steps, batch, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from micronet_amd import dp, ops
+    from micronet_amd.train import synth_batch
+    model, opt = build(args.workload, device)
+    dp.broadcast_parameters(model)
+    sync = dp.GradSync(model)
+    x, y = synth_batch(args.batch, seed=1234 + rank, device=device)
+    prof = KernelProfiler()
+    ops.PROFILER = prof
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dp.train_step_dp(model, opt, sync, x, y)
+    prof.enabled = not args.no_kernel_timing
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = dp.train_step_dp(model, opt, sync, x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        out = {
+            "metric": "QAT images/sec (nin_gc CIFAR-10, W-ternary/A-binary)" if args.workload == "c2" else "QAT images/sec (%s)" % args.workload,
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD_DESC[args.workload], "global_batch": args.batch * world,
+                       "per_gpu_batch": args.batch, "parallelism": "dp%d" % world, "optimizer": "Adam lr=0.01",
+                       "final_loss": round(final_loss, 4)},
+        }
+        agg = prof.summary()
+        if agg:
+            dom = max(agg, key=lambda k: agg[k]["ms"])
+            d = agg[dom]
+            achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "avg_launch_us": round(1000.0 * d["ms"] / d["launches"], 2), "launches": d["launches"]}
+            out["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] / args.steps,
+                                  "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in sorted(agg.items())}
+            if args.workload in ("c1", "c2", "c3", "c1_w2a2"):
+                per_gpu = value / world
+                out["step_level"] = {"algorithmic_GBps": round(per_gpu * NIN_GC_MB_PER_IMG / 1e3, 1),
+                                     "hbm_frac": round(per_gpu * NIN_GC_MB_PER_IMG / 1e3 / HBM_PEAK_GBS, 4),
+                                     "algorithmic_TFLOPs": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3, 2),
+                                     "fp32_mfma_frac": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

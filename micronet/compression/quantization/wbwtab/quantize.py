@@ -1,0 +1,7 @@
+"""Alias of ``micronet_amd.quantization.wbwtab.quantize`` under the reference's module path
+(micronet/compression/quantization/wbwtab/quantize.py); ``import quantize`` from a reference ``main.py`` resolves
+here when this directory is the script's cwd."""
+import micronet_amd.quantization.wbwtab.quantize as _impl
+from micronet_amd.quantization.wbwtab.quantize import *  # noqa: F401,F403
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

@@ -1,0 +1,424 @@
+"""torch.autograd bindings of the libmicronet_hip C ABI -- the only compute path of the product.
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape; every forward/backward below is one or
+a few launches of hand-written gfx950 kernels (``micronet_amd/csrc``).  There is NO fallback: a CPU tensor or a
+missing library raises ``MicronetHipError``.
+
+Reference call sites each op replaces (micronet/compression/quantization/...):
+  round_half_away      wqaq/dorefa/quantize.py:11-21 (Round)
+  dorefa_act           wqaq/dorefa/quantize.py:36-46
+  dorefa_weight        wqaq/dorefa/quantize.py:61-73
+  binary_act           wbwtab/quantize.py:11-36
+  ternary_weight       wbwtab/quantize.py:55-75 + 132-146
+  binary_weight        wbwtab/quantize.py:40-51 + 98-102 + 121-130
+  iao_*                wqaq/iao/quantize.py:15-113 (observers), 214-240 (fake-quant), 293-321 (qparams)
+  qconv2d / qlinear    F.conv2d / F.linear call sites (dorefa 113-121/198, wbwtab 186-194, iao 498-506/843-851/947-993/1156)
+  bn_batch_stats       wqaq/iao/quantize.py:853-855
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import ActQ, ConvGeom, MicronetHipError
+
+ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO
+
+# algorithm used by the conv entry points; tests flip it to compare kernels (0 auto, 1 direct VALU, 2 MFMA only)
+CONV_ALGO = _lib.MN_ALGO_AUTO
+
+
+# optional per-launch timing (bench.py): an object with .span(tag, nbytes) returning a context manager that brackets the
+# launch with HIP events on the current stream
+PROFILER = None
+
+
+class _NoSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOSPAN = _NoSpan()
+
+
+def _span(g, which, nbytes):
+    if PROFILER is None:
+        return _NOSPAN
+    return PROFILER.span(g, which, nbytes)
+
+
+def _lib_():
+    return _lib.get_lib()
+
+
+def _chk(t, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MicronetHipError("%s is on %s: micronet_amd runs on MI355X only (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise MicronetHipError("%s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _call(name, *args):
+    lib = _lib_()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        lib.check(rc, name)
+
+
+# ------------------------------------------------------------------------------------------------ DoReFa
+class RoundHalfAway(Function):
+    @staticmethod
+    def forward(ctx, v):
+        v = _chk(v, "input")
+        out = torch.empty_like(v)
+        with torch.cuda.device_of(v):
+            _call("mn_round_half_away", _p(v), _p(out), v.numel(), _s())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone()
+
+
+class DorefaAct(Function):
+    @staticmethod
+    def forward(ctx, x, bits):
+        x = _chk(x, "input")
+        y = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_dorefa_act_fwd", _p(x), _p(y), x.numel(), bits, _s())
+        ctx.save_for_backward(x)
+        ctx.bits = bits
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _chk(g, "grad")
+        dx = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_dorefa_act_bwd", _p(g), _p(x), _p(dx), x.numel(), ctx.bits, _s())
+        return dx, None
+
+
+class DorefaWeight(Function):
+    @staticmethod
+    def forward(ctx, w, bits):
+        w = _chk(w, "weight")
+        lib = _lib_()
+        ws = torch.empty(int(lib.mn_dorefa_w_ws_floats(w.numel())), dtype=torch.float32, device=w.device)
+        qw = torch.empty_like(w)
+        with torch.cuda.device_of(w):
+            _call("mn_dorefa_w_fwd", _p(w), _p(qw), w.numel(), bits, _p(ws), _s())
+        ctx.save_for_backward(w)
+        ctx.bits = bits
+        return qw
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        g = _chk(g, "grad")
+        lib = _lib_()
+        ws = torch.empty(int(lib.mn_dorefa_w_ws_floats(w.numel())), dtype=torch.float32, device=w.device)
+        dw = torch.empty_like(w)
+        with torch.cuda.device_of(w):
+            _call("mn_dorefa_w_bwd", _p(g), _p(w), _p(dw), w.numel(), ctx.bits, _p(ws), _s())
+        return dw, None
+
+
+# ------------------------------------------------------------------------------------------------ WbWtAb
+class BinaryAct(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "input")
+        y = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_binact_fwd", _p(x), _p(y), x.numel(), _s())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _chk(g, "grad")
+        dx = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_binact_bwd", _p(g), _p(x), _p(dx), x.numel(), _s())
+        return dx
+
+
+class TernaryWeight(Function):
+    """out = ternary(w) * alpha, backward = STE + the autograd path through alpha."""
+
+    @staticmethod
+    def forward(ctx, w):
+        w = _chk(w, "weight")
+        O, K = w.shape[0], w[0].numel()
+        qw = torch.empty_like(w)
+        stats = torch.empty((O, 4), dtype=torch.float32, device=w.device)
+        with torch.cuda.device_of(w):
+            _call("mn_ternary_w_fwd", _p(w), _p(qw), _p(stats), O, K, _s())
+        ctx.save_for_backward(w, stats)
+        return qw
+
+    @staticmethod
+    def backward(ctx, g):
+        w, stats = ctx.saved_tensors
+        g = _chk(g, "grad")
+        dw = torch.empty_like(w)
+        with torch.cuda.device_of(w):
+            _call("mn_ternary_w_bwd", _p(g), _p(w), _p(stats), _p(dw), w.shape[0], w[0].numel(), _s())
+        return dw
+
+
+def ternary_stats(w):
+    """(qw, stats[O,4] = alpha, thr, cnt, sum) without autograd."""
+    w = _chk(w.detach(), "weight")
+    qw = torch.empty_like(w)
+    stats = torch.empty((w.shape[0], 4), dtype=torch.float32, device=w.device)
+    with torch.cuda.device_of(w):
+        _call("mn_ternary_w_fwd", _p(w), _p(qw), _p(stats), w.shape[0], w[0].numel(), _s())
+    return qw, stats
+
+
+class BinaryWeight(Function):
+    """Mean-centre + clamp ``w`` IN PLACE (as the reference mutates weight.data), then sign(w) * mean|w|."""
+
+    @staticmethod
+    def forward(ctx, w):
+        if not w.is_contiguous():
+            raise MicronetHipError("binary weight quantizer mutates the weight in place and needs it contiguous")
+        _chk(w, "weight")
+        if w.dim() != 4:
+            raise MicronetHipError("binary weight quantizer expects a 4-D conv weight")
+        O, Cc, R = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+        qw = torch.empty_like(w)
+        alpha = torch.empty(O, dtype=torch.float32, device=w.device)
+        with torch.cuda.device_of(w):
+            _call("mn_binary_w_fwd", _p(w), _p(qw), _p(alpha), O, Cc, R, _s())
+        ctx.save_for_backward(w, alpha)
+        return qw
+
+    @staticmethod
+    def backward(ctx, g):
+        w, alpha = ctx.saved_tensors
+        g = _chk(g, "grad")
+        dw = torch.empty_like(w)
+        with torch.cuda.device_of(w):
+            _call("mn_binary_w_bwd", _p(g), _p(w), _p(alpha), _p(dw), w.shape[0], w[0].numel(), _s())
+        return dw
+
+
+# ------------------------------------------------------------------------------------------------ IAO
+def iao_observe(x, rows, obs_kind, first, momentum, min_val, max_val):
+    x = _chk(x.detach(), "input")
+    cols = x.numel() // rows
+    lib = _lib_()
+    nws = int(lib.mn_iao_observe_ws_floats(rows, cols))
+    ws = torch.empty(max(nws, 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device_of(x):
+        _call("mn_iao_observe", _p(x), rows, cols, obs_kind, int(first), float(momentum), _p(min_val), _p(max_val), _p(ws), _s())
+
+
+def iao_qparams(min_val, max_val, bits, q_type, is_act, update, scale, zero_point):
+    """Returns the {scale, zp, lo, hi} snapshot ([rows, 4]) the kernels read; updates scale/zero_point if ``update``."""
+    rows = min_val.numel()
+    qp = torch.empty((rows, 4), dtype=torch.float32, device=min_val.device)
+    with torch.cuda.device_of(min_val):
+        _call("mn_iao_qparams", _p(min_val), _p(max_val), rows, bits, q_type, int(is_act), int(update), _p(scale),
+              _p(zero_point), _p(qp), _s())
+    return qp
+
+
+def iao_union_range(a_min, a_max, b_min, b_max, out_min, out_max):
+    with torch.cuda.device_of(a_min):
+        _call("mn_iao_union_range", _p(a_min), _p(a_max), _p(b_min), _p(b_max), _p(out_min), _p(out_max), _s())
+
+
+class IaoFakeQuant(Function):
+    @staticmethod
+    def forward(ctx, x, qp, bits, q_type, is_act):
+        x = _chk(x, "input")
+        rows = qp.shape[0]
+        cols = x.numel() // rows
+        y = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_iao_fq_fwd", _p(x), _p(y), rows, cols, _p(qp), bits, q_type, int(is_act), _s())
+        ctx.save_for_backward(x, qp)
+        ctx.cfg = (bits, q_type, int(is_act), rows, cols)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, qp = ctx.saved_tensors
+        bits, q_type, is_act, rows, cols = ctx.cfg
+        g = _chk(g, "grad")
+        dx = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_iao_fq_bwd", _p(g), _p(x), _p(dx), rows, cols, _p(qp), bits, q_type, is_act, _s())
+        return dx, None, None, None, None
+
+
+class BnBatchStats(Function):
+    """(mean, unbiased var) over (N, H, W) of a conv output; differentiable (the BN-fuse fold keeps them in the graph)."""
+
+    @staticmethod
+    def forward(ctx, o):
+        o = _chk(o, "conv output")
+        N, Cc, HW = o.shape[0], o.shape[1], o.shape[2] * o.shape[3]
+        lib = _lib_()
+        stats = torch.empty((2, Cc), dtype=torch.float32, device=o.device)
+        ws = torch.empty(int(lib.mn_bn_stats_ws_floats(N, Cc, HW)) + 2, dtype=torch.float32, device=o.device)
+        with torch.cuda.device_of(o):
+            _call("mn_bn_stats_fwd", _p(o), N, Cc, HW, _p(stats), _p(ws), _s())
+        ctx.save_for_backward(o, stats)
+        return stats[0], stats[1]
+
+    @staticmethod
+    def backward(ctx, dmean, dvar):
+        o, stats = ctx.saved_tensors
+        dmean, dvar = _chk(dmean, "dmean"), _chk(dvar, "dvar")
+        d_o = torch.empty_like(o)
+        with torch.cuda.device_of(o):
+            _call("mn_bn_stats_bwd", _p(o), _p(stats), _p(dmean), _p(dvar), _p(d_o), o.shape[0], o.shape[1],
+                  o.shape[2] * o.shape[3], _s())
+        return d_o
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def _geom(x_shape, w_shape, stride, padding, dilation, groups):
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    N, Cc, H, W = x_shape
+    O, _, KH, KW = w_shape
+    return ConvGeom(N, Cc, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw, groups)
+
+
+def _out_hw(g):
+    return ((g.H + 2 * g.pad_h - g.dil_h * (g.KH - 1) - 1) // g.stride_h + 1,
+            (g.W + 2 * g.pad_w - g.dil_w * (g.KW - 1) - 1) // g.stride_w + 1)
+
+
+def _ws(g, which, device):
+    nb = int(_lib_().mn_conv2d_ws_bytes(C.byref(g), which, CONV_ALGO))
+    if nb < 0:
+        raise MicronetHipError("invalid convolution geometry")
+    return torch.empty(max(nb // 4, 4), dtype=torch.float32, device=device), nb
+
+
+class QConv2d(Function):
+    """y = conv2d(actq(x), wq, bias): the activation quantizer runs inside the conv kernels' prologue, its clip-STE in the
+    backward-data epilogue; ``wq`` is the already fake-quantised weight (its own Function supplies d wq / d w)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp):
+        x, wq, bias = _chk(x, "input"), _chk(wq, "weight"), _chk(bias, "bias")
+        if x.dim() != 4 or wq.dim() != 4 or x.shape[1] != wq.shape[1] * groups:
+            raise MicronetHipError("conv2d shape mismatch: input %s weight %s groups %d" % (tuple(x.shape), tuple(wq.shape), groups))
+        g = _geom(x.shape, wq.shape, stride, padding, dilation, groups)
+        Ho, Wo = _out_hw(g)
+        y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
+        aq = ActQ(aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
+        with torch.cuda.device_of(x):
+            ws, nb = _ws(g, 0, x.device)
+            with _span(g, 0, 4 * (x.numel() + y.numel() + wq.numel())):
+                _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _p(x), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
+        ctx.save_for_backward(x, wq, qp)
+        ctx.cfg = (g, aq_mode, aq_bits, aq_qtype, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wq, qp = ctx.saved_tensors
+        g, aq_mode, aq_bits, aq_qtype, has_bias = ctx.cfg
+        gy = _chk(gy, "grad")
+        aq = ActQ(aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
+        dx = dw = db = None
+        with torch.cuda.device_of(x):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                ws, nb = _ws(g, 1, x.device)
+                with _span(g, 1, 4 * (gy.numel() + dx.numel() + wq.numel() + (x.numel() if aq_mode != ACTQ_NONE else 0))):
+                    _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), _p(gy), _p(wq), _p(x), _p(dx), _p(ws), nb, CONV_ALGO, _s())
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(wq)
+                db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
+                ws, nb = _ws(g, 2, x.device)
+                with _span(g, 2, 4 * (gy.numel() + x.numel() + dw.numel())):
+                    _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None):
+    return QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp)
+
+
+def qlinear(x, wq, bias, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None):
+    """F.linear as a 1x1 convolution over 1x1 'images' (same kernels, same fused quantizer)."""
+    lead = x.shape[:-1]
+    x4 = x.reshape(-1, x.shape[-1], 1, 1)
+    y = QConv2d.apply(x4, wq.reshape(wq.shape[0], wq.shape[1], 1, 1), bias, 1, 0, 1, 1, aq_mode, aq_bits, aq_qtype, qp)
+    return y.reshape(*lead, wq.shape[0])
+
+
+class ConvTranspose2d(Function):
+    """conv_transpose2d(x, w) = backward-data of the convolution whose weight is w (OIHW with O = in_channels)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, output_padding, groups, dilation):
+        x, w, bias = _chk(x, "input"), _chk(w, "weight"), _chk(bias, "bias")
+        (sh, sw), (ph, pw), (dh, dw_), (oph, opw) = _pair(stride), _pair(padding), _pair(dilation), _pair(output_padding)
+        N, Cin, H, W = x.shape
+        KH, KW = w.shape[2], w.shape[3]
+        Cout = w.shape[1] * groups
+        Hout = (H - 1) * sh - 2 * ph + dh * (KH - 1) + oph + 1
+        Wout = (W - 1) * sw - 2 * pw + dw_ * (KW - 1) + opw + 1
+        g = ConvGeom(N, Cout, Hout, Wout, Cin, KH, KW, sh, sw, ph, pw, dh, dw_, groups)   # the "forward conv": y -> x
+        y = torch.empty((N, Cout, Hout, Wout), dtype=torch.float32, device=x.device)
+        none = ActQ(ACTQ_NONE, 0, 0, 0, None)
+        with torch.cuda.device_of(x):
+            ws, nb = _ws(g, 1, x.device)
+            _call("mn_conv2d_bwd_data", C.byref(g), C.byref(none), _p(x), _p(w), None, _p(y), _p(ws), nb, CONV_ALGO, _s())
+        if bias is not None:
+            y += bias.view(1, -1, 1, 1)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (g, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        g, has_bias = ctx.cfg
+        gy = _chk(gy, "grad")
+        none = ActQ(ACTQ_NONE, 0, 0, 0, None)
+        dx = dw = db = None
+        with torch.cuda.device_of(x):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                ws, nb = _ws(g, 0, x.device)
+                _call("mn_conv2d_fwd", C.byref(g), C.byref(none), _p(gy), _p(w), None, _p(dx), _p(ws), nb, CONV_ALGO, _s())
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(w)
+                ws, nb = _ws(g, 2, x.device)
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(none), _p(x), _p(gy), _p(dw), None, _p(ws), nb, CONV_ALGO, _s())
+            if has_bias and ctx.needs_input_grad[2]:
+                db = gy.sum(dim=(0, 2, 3))
+        return dx, dw, db, None, None, None, None, None

@@ -1,0 +1,165 @@
+"""Binary / ternary weights and binary activations on MI355X -- same module surface as the reference's
+``micronet/compression/quantization/wbwtab/quantize.py``.
+
+  * ``WeightQuantizer`` (ref 105-149): W==3 ternary (TWN threshold 0.7*E|w|, per-channel alpha) and W==2 binary
+    (in-place mean-centre + clamp of ``weight.data``, per-channel alpha) are ONE gfx950 launch each, one workgroup
+    per output channel; their backward includes the autograd path through alpha.
+  * ``ActivationQuantizer`` (ref 79-94) replaces ``nn.ReLU``: sign with saturating STE, one fused pass.
+  * ``QuantConv2d`` (ref 152-195): the +-1 activations are contracted against the quantised weights by the MFMA
+    implicit-GEMM kernels.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from micronet_amd import ops
+
+__all__ = ["BinaryActivation", "BinaryWeight", "Ternary", "ActivationQuantizer", "meancenter_clamp_convparams",
+           "WeightQuantizer", "QuantConv2d", "QuantConvTranspose2d", "add_quant_op", "prepare"]
+
+
+class BinaryActivation(Function):
+    """sign(x) with 0 -> +1; backward zeroes the gradient where |x| >= 1 (ref 11-36)."""
+
+    @staticmethod
+    def forward(self, input):
+        return ops.BinaryAct.forward(self, input)
+
+    @staticmethod
+    def backward(self, grad_output):
+        return ops.BinaryAct.backward(self, grad_output)
+
+
+class BinaryWeight(Function):
+    """sign(w) with 0 -> +1, identity STE (ref 40-51)."""
+
+    @staticmethod
+    def forward(self, input):
+        return ops.BinaryAct.forward(self, input)
+
+    @staticmethod
+    def backward(self, grad_output):
+        return grad_output.clone()
+
+
+class Ternary(Function):
+    """(t, threshold) with t in {-1, 0, +1}, threshold = 0.7 * mean|w| per output channel; identity STE (ref 55-75)."""
+
+    @staticmethod
+    def forward(self, input):
+        _, stats = ops.ternary_stats(input)
+        thr = stats[:, 1].reshape(-1, 1, 1, 1)
+        w = input.detach()
+        t = torch.sign(torch.sign(w + thr) + torch.sign(w - thr))
+        return t, thr
+
+    @staticmethod
+    def backward(self, grad_output, grad_threshold):
+        return grad_output.clone()
+
+
+class ActivationQuantizer(nn.Module):
+    def __init__(self, A=2):
+        super().__init__()
+        self.A = A
+        self.relu = nn.ReLU(inplace=True)
+
+    def binary(self, input):
+        return BinaryActivation.apply(input)
+
+    def forward(self, input):
+        return self.binary(input) if self.A == 2 else self.relu(input)
+
+
+def meancenter_clamp_convparams(w):
+    """In place on ``w.data``: subtract the mean over the input-channel axis, clamp to [-1, 1] (ref 98-102)."""
+    ops.BinaryWeight.apply(w.data)
+    return w
+
+
+class WeightQuantizer(nn.Module):
+    def __init__(self, W=2):
+        super().__init__()
+        self.W = W
+
+    def binary(self, input):
+        return BinaryWeight.apply(input)
+
+    def ternary(self, input):
+        return Ternary.apply(input)
+
+    def forward(self, input):
+        if self.W == 2:
+            return ops.BinaryWeight.apply(input)     # mutates input.data like the reference (ref 123)
+        if self.W == 3:
+            return ops.TernaryWeight.apply(input)
+        return input
+
+
+class QuantConv2d(nn.Conv2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 padding_mode="zeros", W=2, quant_inference=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, padding_mode)
+        self.quant_inference = quant_inference
+        self.weight_quantizer = WeightQuantizer(W=W)
+
+    def forward(self, input):
+        tnn_bin_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
+        return ops.qconv2d(input, tnn_bin_weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class QuantConvTranspose2d(nn.ConvTranspose2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros", W=2, quant_inference=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, output_padding, groups, bias,
+                         dilation, padding_mode)
+        self.quant_inference = quant_inference
+        self.weight_quantizer = WeightQuantizer(W=W)
+
+    def forward(self, input):
+        tnn_bin_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
+        return ops.ConvTranspose2d.apply(input, tnn_bin_weight, self.bias, self.stride, self.padding,
+                                         self.output_padding, self.groups, self.dilation)
+
+
+def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=False):
+    """Quantise conv k iff 1 < k < layer_num; every ReLU met while 0 < k < layer_num becomes the binary activation
+    (ref 247-331)."""
+    for name, child in module.named_children():
+        if isinstance(child, nn.Conv2d):
+            layer_counter[0] += 1
+            if 1 < layer_counter[0] < layer_num:
+                new = QuantConv2d(child.in_channels, child.out_channels, child.kernel_size, stride=child.stride,
+                                  padding=child.padding, dilation=child.dilation, groups=child.groups,
+                                  bias=child.bias is not None, padding_mode=child.padding_mode, W=W,
+                                  quant_inference=quant_inference)
+                if child.bias is not None:
+                    new.bias.data = child.bias
+                new.weight.data = child.weight
+                module._modules[name] = new
+        elif isinstance(child, nn.ConvTranspose2d):
+            layer_counter[0] += 1
+            if 1 < layer_counter[0] < layer_num:
+                new = QuantConvTranspose2d(child.in_channels, child.out_channels, child.kernel_size, stride=child.stride,
+                                           padding=child.padding, output_padding=child.output_padding,
+                                           dilation=child.dilation, groups=child.groups, bias=child.bias is not None,
+                                           padding_mode=child.padding_mode, W=W, quant_inference=quant_inference)
+                if child.bias is not None:
+                    new.bias.data = child.bias
+                new.weight.data = child.weight
+                module._modules[name] = new
+        elif isinstance(child, nn.ReLU):
+            if 0 < layer_counter[0] < layer_num:
+                module._modules[name] = ActivationQuantizer(A=A)
+        else:
+            add_quant_op(child, layer_counter, layer_num, A=A, W=W, quant_inference=quant_inference)
+
+
+def prepare(model, inplace=False, A=2, W=2, quant_inference=False):
+    if not inplace:
+        model = copy.deepcopy(model)
+    layer_num = sum(isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) for m in model.modules())
+    add_quant_op(model, [0], layer_num, A=A, W=W, quant_inference=quant_inference)
+    return model

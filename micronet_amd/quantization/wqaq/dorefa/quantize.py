@@ -1,0 +1,168 @@
+"""DoReFa k-bit fake-quantised layers on MI355X -- same module surface as the reference's
+``micronet/compression/quantization/wqaq/dorefa/quantize.py`` (class names, constructor signatures, attributes,
+``state_dict`` keys, ``prepare`` rewrite rule), with the arithmetic done by hand-written gfx950 kernels:
+
+  * ``QuantConv2d`` / ``QuantLinear`` forward (ref 107-122 / 192-199): one weight-quantizer launch pair + ONE fused
+    kernel that clamps/rounds the activations in the implicit-GEMM prologue and contracts on the MFMA units;
+    backward: the clip-STE of the activation quantizer is the epilogue of the backward-data kernel.
+  * ``ActivationQuantizer`` / ``WeightQuantizer`` / ``Round`` (ref 11-73) remain callable on their own
+    (``m.weight_quantizer(m.weight)`` is used by the reference's quant_model_test scripts).
+"""
+import copy
+
+import torch.nn as nn
+from torch.autograd import Function
+
+from micronet_amd import ops
+
+__all__ = ["Round", "ActivationQuantizer", "WeightQuantizer", "QuantConv2d", "QuantConvTranspose2d", "QuantLinear",
+           "add_quant_op", "prepare"]
+
+
+class Round(Function):
+    """sign(v) * floor(|v| + 0.5) with a straight-through gradient (ref 11-21)."""
+
+    @staticmethod
+    def forward(self, input):
+        return ops.RoundHalfAway.forward(self, input)
+
+    @staticmethod
+    def backward(self, grad_output):
+        return grad_output.clone()
+
+
+def _check_bits(bits):
+    if bits == 1:
+        print("！Binary quantization is not supported ！")
+        assert bits != 1
+
+
+class ActivationQuantizer(nn.Module):
+    def __init__(self, a_bits):
+        super().__init__()
+        self.a_bits = a_bits
+
+    def round(self, input):
+        return Round.apply(input)
+
+    def forward(self, input):
+        if self.a_bits == 32:
+            return input
+        _check_bits(self.a_bits)
+        return ops.DorefaAct.apply(input, self.a_bits)
+
+
+class WeightQuantizer(nn.Module):
+    def __init__(self, w_bits):
+        super().__init__()
+        self.w_bits = w_bits
+
+    def round(self, input):
+        return Round.apply(input)
+
+    def forward(self, input):
+        if self.w_bits == 32:
+            return input
+        _check_bits(self.w_bits)
+        return ops.DorefaWeight.apply(input, self.w_bits)
+
+
+def _aq_args(quantizer):
+    """(mode, bits) of the activation quantizer fused into the conv kernels."""
+    if quantizer.a_bits == 32:
+        return ops.ACTQ_NONE, 0
+    _check_bits(quantizer.a_bits)
+    return ops.ACTQ_DOREFA, quantizer.a_bits
+
+
+class QuantConv2d(nn.Conv2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 padding_mode="zeros", a_bits=8, w_bits=8, quant_inference=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, padding_mode)
+        self.quant_inference = quant_inference
+        self.activation_quantizer = ActivationQuantizer(a_bits=a_bits)
+        self.weight_quantizer = WeightQuantizer(w_bits=w_bits)
+
+    def forward(self, input):
+        quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
+        mode, bits = _aq_args(self.activation_quantizer)
+        # like the reference, the forward always zero-pads whatever padding_mode says (ref 113-121)
+        return ops.qconv2d(input, quant_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
+                           aq_mode=mode, aq_bits=bits)
+
+
+class QuantConvTranspose2d(nn.ConvTranspose2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros", a_bits=8, w_bits=8, quant_inference=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, output_padding, groups, bias,
+                         dilation, padding_mode)
+        self.quant_inference = quant_inference
+        self.activation_quantizer = ActivationQuantizer(a_bits=a_bits)
+        self.weight_quantizer = WeightQuantizer(w_bits=w_bits)
+
+    def forward(self, input):
+        quant_input = self.activation_quantizer(input)
+        quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
+        return ops.ConvTranspose2d.apply(quant_input, quant_weight, self.bias, self.stride, self.padding,
+                                         self.output_padding, self.groups, self.dilation)
+
+
+class QuantLinear(nn.Linear):
+    def __init__(self, in_features, out_features, bias=True, a_bits=8, w_bits=8, quant_inference=False):
+        super().__init__(in_features, out_features, bias)
+        self.quant_inference = quant_inference
+        self.activation_quantizer = ActivationQuantizer(a_bits=a_bits)
+        self.weight_quantizer = WeightQuantizer(w_bits=w_bits)
+
+    def forward(self, input):
+        quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
+        mode, bits = _aq_args(self.activation_quantizer)
+        return ops.qlinear(input, quant_weight, self.bias, aq_mode=mode, aq_bits=bits)
+
+
+def _swap_conv(child, cls, **kw):
+    new = cls(child.in_channels, child.out_channels, child.kernel_size, stride=child.stride, padding=child.padding,
+              dilation=child.dilation, groups=child.groups, bias=child.bias is not None,
+              padding_mode=child.padding_mode, **kw)
+    if child.bias is not None:
+        new.bias.data = child.bias
+    new.weight.data = child.weight      # shares the original storage, as the reference does
+    return new
+
+
+def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=False):
+    """Swap every conv / conv-transpose / linear EXCEPT the first one met (ref 202-309: ``layer_counter[0] > 1``)."""
+    kw = dict(a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference)
+    for name, child in module.named_children():
+        if isinstance(child, nn.Conv2d):
+            layer_counter[0] += 1
+            if layer_counter[0] > 1:
+                module._modules[name] = _swap_conv(child, QuantConv2d, **kw)
+        elif isinstance(child, nn.ConvTranspose2d):
+            layer_counter[0] += 1
+            if layer_counter[0] > 1:
+                new = QuantConvTranspose2d(child.in_channels, child.out_channels, child.kernel_size, stride=child.stride,
+                                           padding=child.padding, output_padding=child.output_padding,
+                                           dilation=child.dilation, groups=child.groups, bias=child.bias is not None,
+                                           padding_mode=child.padding_mode, **kw)
+                if child.bias is not None:
+                    new.bias.data = child.bias
+                new.weight.data = child.weight
+                module._modules[name] = new
+        elif isinstance(child, nn.Linear):
+            layer_counter[0] += 1
+            if layer_counter[0] > 1:
+                new = QuantLinear(child.in_features, child.out_features, bias=child.bias is not None, **kw)
+                if child.bias is not None:
+                    new.bias.data = child.bias
+                new.weight.data = child.weight
+                module._modules[name] = new
+        else:
+            add_quant_op(child, layer_counter, **kw)
+
+
+def prepare(model, inplace=False, a_bits=8, w_bits=8, quant_inference=False):
+    if not inplace:
+        model = copy.deepcopy(model)
+    add_quant_op(model, [0], a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference)
+    return model

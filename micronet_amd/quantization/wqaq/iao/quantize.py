@@ -1,0 +1,531 @@
+"""IAO (integer-arithmetic-only, Jacob et al.) fake-quantised layers on MI355X -- same module surface as the
+reference's ``micronet/compression/quantization/wqaq/iao/quantize.py`` (class names, constructor signatures,
+buffer names/shapes hence ``state_dict`` keys, ``prepare`` rewrite rules), computed by gfx950 kernels:
+
+  * observers (ref 15-113): min/max by wavefront reductions, the running-extreme / EMA update and
+    ``update_qparams`` (ref 293-321) happen ON DEVICE -- no host synchronisation inside ``forward``;
+  * ``Quantizer.forward`` (ref 214-240): one fused fake-quant pass; for conv / linear inputs it is not even a pass:
+    the scale / round / clamp runs in the prologue of the implicit-GEMM kernel and its clip-STE (ref 163-168) in the
+    epilogue of the backward-data kernel;
+  * ``QuantBNFuseConv2d`` (ref 652-994): raw conv -> batch mean / unbiased var (kept in the autograd graph) -> fold
+    -> per-channel weight quantizer -> quantised conv, all on the same kernels.
+Python attributes that the reference keeps off the ``state_dict`` (``num_flag``) are kept the same way.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.nn import init
+from torch.nn.parameter import Parameter
+
+from micronet_amd import ops
+from micronet_amd.base_module.op import Add
+
+__all__ = ["ObserverBase", "MinMaxObserver", "MovingAverageMinMaxObserver", "HistogramObserver", "Round", "Quantizer",
+           "SignedQuantizer", "UnsignedQuantizer", "SymmetricQuantizer", "AsymmetricQuantizer", "QuantConv2d",
+           "QuantConvTranspose2d", "QuantBNFuseConv2d", "QuantLinear", "QuantReLU", "QuantLeakyReLU", "QuantSigmoid",
+           "QuantMaxPool2d", "QuantAvgPool2d", "QuantAdaptiveAvgPool2d", "QuantAdd", "add_quant_op", "prepare",
+           "reshape_to_activation", "reshape_to_weight", "reshape_to_bias"]
+
+
+# ------------------------------------------------------------------------------------------------ observers
+def _range_shape(q_level, out_channels):
+    return {"L": (1,), "C": (out_channels, 1, 1, 1), "FC": (out_channels, 1)}[q_level]
+
+
+class ObserverBase(nn.Module):
+    """min/max at level 'L' (whole tensor), 'C' (conv out-channel) or 'FC' (linear row) (ref 15-36)."""
+    _kind = None  # 0 running min/max, 1 EMA
+
+    def __init__(self, q_level):
+        super().__init__()
+        self.q_level = q_level
+
+    def update_range(self, min_val, max_val):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def forward(self, input):
+        rows = 1 if self.q_level == "L" else input.shape[0]
+        ops.iao_observe(input, rows, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
+                        self.min_val, self.max_val)
+        if self.num_flag == 0:
+            self.num_flag += 1
+
+
+class MinMaxObserver(ObserverBase):
+    _kind = 0
+
+    def __init__(self, q_level, out_channels):
+        super().__init__(q_level)
+        self.num_flag = 0
+        self.out_channels = out_channels
+        shape = _range_shape(q_level, out_channels)
+        self.register_buffer("min_val", torch.zeros(shape, dtype=torch.float32))
+        self.register_buffer("max_val", torch.zeros(shape, dtype=torch.float32))
+
+
+class MovingAverageMinMaxObserver(ObserverBase):
+    _kind = 1
+
+    def __init__(self, q_level, out_channels, momentum=0.1):
+        super().__init__(q_level)
+        self.momentum = momentum
+        self.num_flag = 0
+        self.out_channels = out_channels
+        shape = _range_shape(q_level, out_channels)
+        self.register_buffer("min_val", torch.zeros(shape, dtype=torch.float32))
+        self.register_buffer("max_val", torch.zeros(shape, dtype=torch.float32))
+
+
+class HistogramObserver(nn.Module):
+    """Percentile calibrator of the PTQ mode (ref 116-139).  PTQ is off the QAT hot path: the
+    k-th value selection is delegated to ``torch.kthvalue`` on the device; only ``max_val`` is maintained."""
+
+    def __init__(self, q_level, momentum=0.1, percentile=0.9999):
+        super().__init__()
+        self.q_level = q_level
+        self.momentum = momentum
+        self.percentile = percentile
+        self.num_flag = 0
+        self.register_buffer("min_val", torch.zeros((1), dtype=torch.float32))
+        self.register_buffer("max_val", torch.zeros((1), dtype=torch.float32))
+
+    @torch.no_grad()
+    def forward(self, input):
+        flat = input.abs().view(-1)
+        cur = torch.kthvalue(flat, int(self.percentile * flat.size(0)), dim=0)[0]
+        if self.num_flag == 0:
+            self.num_flag += 1
+            new = cur
+        else:
+            new = (1 - self.momentum) * self.max_val + self.momentum * cur
+        self.max_val.copy_(new)
+
+
+# ------------------------------------------------------------------------------------------------ quantizers
+class Round(Function):
+    """round-half-away with the clip-STE of ref 144-168 (kept for API parity; the modules use the fused kernels)."""
+
+    @staticmethod
+    def forward(self, input, observer_min_val, observer_max_val, q_type):
+        if q_type == 0:
+            max_val = torch.max(torch.abs(observer_min_val), torch.abs(observer_max_val))
+            min_val = -max_val
+        else:
+            max_val, min_val = observer_max_val, observer_min_val
+        self.save_for_backward(input, min_val, max_val)
+        return ops.RoundHalfAway.forward(self, input)
+
+    @staticmethod
+    def backward(self, grad_output):
+        input, min_val, max_val = self.saved_tensors
+        grad_input = grad_output.clone()
+        grad_input[input.gt(max_val)] = 0
+        grad_input[input.lt(min_val)] = 0
+        return grad_input, None, None, None
+
+
+class Quantizer(nn.Module):
+    def __init__(self, bits, observer, activation_weight_flag, qaft=False, union=False):
+        super().__init__()
+        self.bits = bits
+        self.observer = observer
+        self.activation_weight_flag = activation_weight_flag
+        self.qaft = qaft
+        self.union = union
+        self.q_type = 0
+        shape = _range_shape(observer.q_level, getattr(observer, "out_channels", None))
+        self.register_buffer("scale", torch.ones(shape, dtype=torch.float32))
+        self.register_buffer("zero_point", torch.zeros(shape, dtype=torch.float32))
+        self.register_buffer("eps", torch.tensor((torch.finfo(torch.float32).eps), dtype=torch.float32))
+
+    _q_type_static = 0
+
+    def update_qparams(self):
+        """scale / zero_point from the observer range, on device (ref 293-305 / 310-321)."""
+        self.q_type = self._q_type_static
+        return ops.iao_qparams(self.observer.min_val, self.observer.max_val, self.bits, self._q_type_static,
+                               self.activation_weight_flag == 1, True, self.scale, self.zero_point)
+
+    def round(self, input, observer_min_val, observer_max_val, q_type):
+        return Round.apply(input, observer_min_val, observer_max_val, q_type)
+
+    def qparams(self, input):
+        """Observer + qparams bookkeeping of ``forward`` (ref 221-226); returns the device snapshot
+        {scale, zero_point, lo, hi} that the fused kernels read, or None for 32 bit."""
+        if self.bits == 32:
+            return None
+        if self.bits == 1:
+            print("！Binary quantization is not supported ！")
+            assert self.bits != 1
+        if not self.qaft and self.training:
+            if not self.union:
+                self.observer(input)
+            return self.update_qparams()
+        # the reference sets q_type only inside update_qparams (default 0 until the first training step)
+        return ops.iao_qparams(self.observer.min_val, self.observer.max_val, self.bits, self.q_type,
+                               self.activation_weight_flag == 1, False, self.scale, self.zero_point)
+
+    def forward(self, input):
+        qp = self.qparams(input)
+        if qp is None:
+            return input
+        return ops.IaoFakeQuant.apply(input, qp, self.bits, self.q_type, self.activation_weight_flag == 1)
+
+
+def _register_range(q, lo, hi):
+    q.register_buffer("quant_min_val", torch.tensor(lo, dtype=torch.float32))
+    q.register_buffer("quant_max_val", torch.tensor(hi, dtype=torch.float32))
+
+
+class SignedQuantizer(Quantizer):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.activation_weight_flag == 0:
+            _register_range(self, -((1 << (self.bits - 1)) - 1), (1 << (self.bits - 1)) - 1)
+        elif self.activation_weight_flag == 1:
+            _register_range(self, -(1 << (self.bits - 1)), (1 << (self.bits - 1)) - 1)
+        else:
+            print("activation_weight_flag error")
+
+
+class UnsignedQuantizer(Quantizer):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.activation_weight_flag == 0:
+            _register_range(self, 0, (1 << self.bits) - 2)
+        elif self.activation_weight_flag == 1:
+            _register_range(self, 0, (1 << self.bits) - 1)
+        else:
+            print("activation_weight_flag error")
+
+
+class SymmetricQuantizer(SignedQuantizer):
+    _q_type_static = 0
+
+
+class AsymmetricQuantizer(UnsignedQuantizer):
+    _q_type_static = 1
+
+
+def _activation_quantizer(a_bits, q_type, qaft, ptq, percentile, union=False):
+    if ptq:
+        return SymmetricQuantizer(bits=a_bits, observer=HistogramObserver(q_level="L", percentile=percentile),
+                                  activation_weight_flag=1, qaft=qaft, union=union)
+    cls = SymmetricQuantizer if q_type == 0 else AsymmetricQuantizer
+    return cls(bits=a_bits, observer=MovingAverageMinMaxObserver(q_level="L", out_channels=None),
+               activation_weight_flag=1, qaft=qaft, union=union)
+
+
+def _weight_quantizer(w_bits, q_type, q_level, weight_observer, out_channels, channel_level, qaft, ptq):
+    """ref 369-490: per-channel ('C'/'FC') when q_level == 0 else per-layer; MinMax or EMA observer."""
+    cls = SymmetricQuantizer if (q_type == 0 or ptq) else AsymmetricQuantizer
+    level = channel_level if q_level == 0 else "L"
+    obs_cls = MinMaxObserver if weight_observer == 0 else MovingAverageMinMaxObserver
+    observer = obs_cls(q_level=level, out_channels=out_channels if level != "L" else None)
+    return cls(bits=w_bits, observer=observer, activation_weight_flag=0, qaft=qaft)
+
+
+def _fused_aq(quantizer, input):
+    """(mode, bits, q_type, qp) for the activation quantizer fused into the conv kernels."""
+    qp = quantizer.qparams(input)
+    if qp is None:
+        return ops.ACTQ_NONE, 0, 0, None
+    return ops.ACTQ_IAO, quantizer.bits, quantizer.q_type, qp
+
+
+# ------------------------------------------------------------------------------------------------ conv / linear
+class QuantConv2d(nn.Conv2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 padding_mode="zeros", a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0,
+                 quant_inference=False, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, padding_mode)
+        self.quant_inference = quant_inference
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+        self.weight_quantizer = _weight_quantizer(w_bits, q_type, q_level, weight_observer, out_channels, "C", qaft, ptq)
+
+    def _qconv(self, input, weight, bias):
+        mode, bits, q_type, qp = _fused_aq(self.activation_quantizer, input)
+        return ops.qconv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups,
+                           aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp)
+
+    def forward(self, input):
+        # (the reference quantises the input first; the two quantizers are independent, order is immaterial)
+        quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
+        return self._qconv(input, quant_weight, self.bias)
+
+
+class QuantConvTranspose2d(nn.ConvTranspose2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros", a_bits=8, w_bits=8, q_type=0, weight_observer=0,
+                 quant_inference=False, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, output_padding, groups, bias,
+                         dilation, padding_mode)
+        self.quant_inference = quant_inference
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+        # conv-transpose weights are quantised per layer only (ref 555-570)
+        self.weight_quantizer = _weight_quantizer(w_bits, q_type, 1, weight_observer, None, "C", qaft, ptq)
+
+    def forward(self, input):
+        quant_input = self.activation_quantizer(input)
+        quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
+        return ops.ConvTranspose2d.apply(quant_input, quant_weight, self.bias, self.stride, self.padding,
+                                         self.output_padding, self.groups, self.dilation)
+
+
+def reshape_to_activation(input):
+    return input.reshape(1, -1, 1, 1)
+
+
+def reshape_to_weight(input):
+    return input.reshape(-1, 1, 1, 1)
+
+
+def reshape_to_bias(input):
+    return input.reshape(-1)
+
+
+class QuantBNFuseConv2d(QuantConv2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=False,
+                 padding_mode="zeros", eps=1e-5, momentum=0.1, a_bits=8, w_bits=8, q_type=0, q_level=0,
+                 weight_observer=0, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999,
+                 bn_fuse_calib=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, padding_mode,
+                         a_bits=a_bits, w_bits=w_bits, q_type=q_type, q_level=q_level, weight_observer=weight_observer,
+                         qaft=qaft, ptq=ptq, percentile=percentile)
+        self.num_flag = 0
+        self.pretrained_model = pretrained_model
+        self.qaft = qaft
+        self.bn_fuse_calib = bn_fuse_calib
+        self.eps = eps
+        self.momentum = momentum
+        self.gamma = Parameter(torch.Tensor(out_channels))
+        self.beta = Parameter(torch.Tensor(out_channels))
+        self.register_buffer("running_mean", torch.zeros((out_channels), dtype=torch.float32))
+        self.register_buffer("running_var", torch.ones((out_channels), dtype=torch.float32))
+        init.uniform_(self.gamma)
+        init.zeros_(self.beta)
+
+    def _fold(self, mean, var_for_bias, var_for_weight):
+        k_b = self.gamma / torch.sqrt(var_for_bias + self.eps)
+        if self.bias is not None:
+            bias_fused = reshape_to_bias(self.beta + (self.bias - mean) * k_b)
+        else:
+            bias_fused = reshape_to_bias(self.beta - mean * k_b)
+        weight_fused = self.weight * reshape_to_weight(self.gamma / torch.sqrt(var_for_weight + self.eps))
+        return weight_fused, bias_fused
+
+    def forward(self, input):
+        training_stats = (not self.qaft) and self.training
+        if training_stats:
+            # raw conv for the batch statistics (ref 843-855); the statistics stay in the autograd graph
+            output = ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            batch_mean, batch_var = ops.BnBatchStats.apply(output)
+            with torch.no_grad():
+                if not self.pretrained_model and self.num_flag == 0:
+                    self.num_flag += 1
+                    running_mean, running_var = batch_mean, batch_var
+                else:
+                    running_mean = (1 - self.momentum) * self.running_mean + self.momentum * batch_mean
+                    running_var = (1 - self.momentum) * self.running_var + self.momentum * batch_var
+                self.running_mean.copy_(running_mean)
+                self.running_var.copy_(running_var)
+            weight_fused, bias_fused = self._fold(batch_mean, batch_var,
+                                                  self.running_var if self.bn_fuse_calib else batch_var)
+        else:
+            weight_fused, bias_fused = self._fold(self.running_mean, self.running_var, self.running_var)
+
+        quant_weight = self.weight_quantizer(weight_fused)
+        if training_stats and self.bn_fuse_calib:
+            # weights folded with the running sigma, output rescaled to the batch sigma (ref 957-972)
+            output = self._qconv(input, quant_weight, None)
+            output = output * reshape_to_activation(torch.sqrt(self.running_var + self.eps) / torch.sqrt(batch_var + self.eps))
+            return output + reshape_to_activation(bias_fused)
+        return self._qconv(input, quant_weight, bias_fused)
+
+
+class QuantLinear(nn.Linear):
+    def __init__(self, in_features, out_features, bias=True, a_bits=8, w_bits=8, q_type=0, q_level=0,
+                 weight_observer=0, quant_inference=False, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__(in_features, out_features, bias)
+        self.quant_inference = quant_inference
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+        self.weight_quantizer = _weight_quantizer(w_bits, q_type, q_level, weight_observer, out_features, "FC", qaft, ptq)
+
+    def forward(self, input):
+        quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
+        mode, bits, q_type, qp = _fused_aq(self.activation_quantizer, input)
+        return ops.qlinear(input, quant_weight, self.bias, aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp)
+
+
+# ------------------------------------------------------------------------------------------------ quantised non-conv ops
+class QuantReLU(nn.ReLU):
+    def __init__(self, inplace=False, a_bits=8, q_type=0, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__(inplace)
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+
+    def forward(self, input):
+        return F.relu(self.activation_quantizer(input), self.inplace)
+
+
+class QuantLeakyReLU(nn.LeakyReLU):
+    def __init__(self, negative_slope=0.01, inplace=False, a_bits=8, q_type=0, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__(negative_slope, inplace)
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+
+    def forward(self, input):
+        return F.leaky_relu(self.activation_quantizer(input), self.negative_slope, self.inplace)
+
+
+class QuantSigmoid(nn.Sigmoid):
+    def __init__(self, a_bits=8, q_type=0, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__()
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+
+    def forward(self, input):
+        return torch.sigmoid(self.activation_quantizer(input))
+
+
+class QuantMaxPool2d(nn.MaxPool2d):
+    def __init__(self, kernel_size, stride=None, padding=0, dilation=1, return_indices=False, ceil_mode=False, a_bits=8,
+                 q_type=0, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__(kernel_size, stride, padding, dilation, return_indices, ceil_mode)
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+
+    def forward(self, input):
+        return F.max_pool2d(self.activation_quantizer(input), self.kernel_size, self.stride, self.padding, self.dilation,
+                            self.ceil_mode, self.return_indices)
+
+
+class QuantAvgPool2d(nn.AvgPool2d):
+    def __init__(self, kernel_size, stride=None, padding=0, ceil_mode=False, count_include_pad=True,
+                 divisor_override=None, a_bits=8, q_type=0, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__(kernel_size, stride, padding, ceil_mode, count_include_pad, divisor_override)
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+
+    def forward(self, input):
+        return F.avg_pool2d(self.activation_quantizer(input), self.kernel_size, self.stride, self.padding, self.ceil_mode,
+                            self.count_include_pad, self.divisor_override)
+
+
+class QuantAdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
+    def __init__(self, output_size, a_bits=8, q_type=0, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__(output_size)
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
+
+    def forward(self, input):
+        return F.adaptive_avg_pool2d(self.activation_quantizer(input), self.output_size)
+
+
+class QuantAdd(nn.Module):
+    def __init__(self, a_bits=8, q_type=0, qaft=False, ptq=False, percentile=0.9999):
+        super().__init__()
+        if not ptq:
+            self.observer_res = MovingAverageMinMaxObserver(q_level="L", out_channels=None)
+            self.observer_shortcut = MovingAverageMinMaxObserver(q_level="L", out_channels=None)
+        else:
+            self.observer_res = HistogramObserver(q_level="L", percentile=percentile)
+            self.observer_shortcut = HistogramObserver(q_level="L", percentile=percentile)
+        self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile, union=True)
+
+    def forward(self, res, shortcut):
+        # both observers run unconditionally, also in eval (ref 1485-1486); the union range feeds ONE shared quantizer
+        self.observer_res(res)
+        self.observer_shortcut(shortcut)
+        obs = self.activation_quantizer.observer
+        ops.iao_union_range(self.observer_res.min_val, self.observer_res.max_val, self.observer_shortcut.min_val,
+                            self.observer_shortcut.max_val, obs.min_val, obs.max_val)
+        q = self.activation_quantizer
+        qp = q.qparams(res)
+        if qp is None:
+            return res + shortcut
+        is_act = q.activation_weight_flag == 1
+        return ops.IaoFakeQuant.apply(res, qp, q.bits, q.q_type, is_act) + ops.IaoFakeQuant.apply(shortcut, qp, q.bits, q.q_type, is_act)
+
+
+# ------------------------------------------------------------------------------------------------ graph rewrite
+def _copy_params(new, child):
+    if child.bias is not None:
+        new.bias.data = child.bias
+    new.weight.data = child.weight
+
+
+def add_quant_op(module, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=False, bn_fuse_calib=False,
+                 quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999):
+    """ref 1501-1788: every conv / linear is quantised (no first/last skip); with ``bn_fuse`` a conv is replaced when
+    the BatchNorm2d that follows it among the same parent's children is met, and that BN becomes ``nn.Identity``."""
+    common = dict(a_bits=a_bits, q_type=q_type, qaft=qaft, ptq=ptq, percentile=percentile)
+    kw_all = dict(a_bits=a_bits, w_bits=w_bits, q_type=q_type, q_level=q_level, weight_observer=weight_observer,
+                  bn_fuse=bn_fuse, bn_fuse_calib=bn_fuse_calib, quant_inference=quant_inference,
+                  pretrained_model=pretrained_model, qaft=qaft, ptq=ptq, percentile=percentile)
+    conv_name_temp = conv_child_temp = None
+    for name, child in module.named_children():
+        if isinstance(child, nn.Conv2d):
+            if bn_fuse:
+                conv_name_temp, conv_child_temp = name, child
+            else:
+                new = QuantConv2d(child.in_channels, child.out_channels, child.kernel_size, stride=child.stride,
+                                  padding=child.padding, dilation=child.dilation, groups=child.groups,
+                                  bias=child.bias is not None, padding_mode=child.padding_mode, w_bits=w_bits,
+                                  q_level=q_level, weight_observer=weight_observer, quant_inference=quant_inference,
+                                  **common)
+                _copy_params(new, child)
+                module._modules[name] = new
+        elif isinstance(child, nn.BatchNorm2d):
+            if bn_fuse:
+                c = conv_child_temp
+                new = QuantBNFuseConv2d(c.in_channels, c.out_channels, c.kernel_size, stride=c.stride, padding=c.padding,
+                                        dilation=c.dilation, groups=c.groups, bias=c.bias is not None,
+                                        padding_mode=c.padding_mode, eps=child.eps, momentum=child.momentum,
+                                        w_bits=w_bits, q_level=q_level, weight_observer=weight_observer,
+                                        pretrained_model=pretrained_model, bn_fuse_calib=bn_fuse_calib, **common)
+                _copy_params(new, c)
+                new.gamma.data = child.weight
+                new.beta.data = child.bias
+                new.running_mean.copy_(child.running_mean)
+                new.running_var.copy_(child.running_var)
+                module._modules[conv_name_temp] = new
+                module._modules[name] = nn.Identity()
+        elif isinstance(child, nn.ConvTranspose2d):
+            new = QuantConvTranspose2d(child.in_channels, child.out_channels, child.kernel_size, stride=child.stride,
+                                       padding=child.padding, output_padding=child.output_padding, groups=child.groups,
+                                       bias=child.bias is not None, dilation=child.dilation,
+                                       padding_mode=child.padding_mode, w_bits=w_bits, weight_observer=weight_observer,
+                                       quant_inference=quant_inference, **common)
+            _copy_params(new, child)
+            module._modules[name] = new
+        elif isinstance(child, nn.Linear):
+            new = QuantLinear(child.in_features, child.out_features, bias=child.bias is not None, w_bits=w_bits,
+                              q_level=q_level, weight_observer=weight_observer, quant_inference=quant_inference, **common)
+            _copy_params(new, child)
+            module._modules[name] = new
+        # nn.ReLU is deliberately left alone: it is fused at inference (ref 1705-1709)
+        elif isinstance(child, nn.LeakyReLU):
+            module._modules[name] = QuantLeakyReLU(negative_slope=child.negative_slope, inplace=child.inplace, **common)
+        elif isinstance(child, nn.Sigmoid):
+            module._modules[name] = QuantSigmoid(**common)
+        elif isinstance(child, nn.MaxPool2d):
+            module._modules[name] = QuantMaxPool2d(kernel_size=child.kernel_size, stride=child.stride,
+                                                   padding=child.padding, **common)
+        elif isinstance(child, nn.AvgPool2d):
+            module._modules[name] = QuantAvgPool2d(kernel_size=child.kernel_size, stride=child.stride,
+                                                   padding=child.padding, **common)
+        elif isinstance(child, nn.AdaptiveAvgPool2d):
+            module._modules[name] = QuantAdaptiveAvgPool2d(output_size=child.output_size, **common)
+        elif isinstance(child, Add):
+            module._modules[name] = QuantAdd(**common)
+        else:
+            add_quant_op(child, **kw_all)
+
+
+def prepare(model, inplace=False, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=False,
+            bn_fuse_calib=False, quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999):
+    if not inplace:
+        model = copy.deepcopy(model)
+    add_quant_op(model, a_bits=a_bits, w_bits=w_bits, q_type=q_type, q_level=q_level, weight_observer=weight_observer,
+                 bn_fuse=bn_fuse, bn_fuse_calib=bn_fuse_calib, quant_inference=quant_inference,
+                 pretrained_model=pretrained_model, qaft=qaft, ptq=ptq, percentile=percentile)
+    return model

@@ -1,0 +1,121 @@
+"""Parity tests proper: the gfx950 kernels through the C ABI on a real MI355X vs the oracle and the golden fixtures
+generated from the reference.  Same checks as tests/test_kernels_emulated.py plus hot-path shapes and full-size
+properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import abi_driver
+import kernel_cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    return abi_driver.Backend("gpu")
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 8])
+def test_dorefa_act(be, golden, bits):
+    K.check_dorefa_act(be, golden.q, bits)
+
+
+@pytest.mark.parametrize("bits", [2, 4, 8])
+def test_dorefa_w(be, golden, bits):
+    K.check_dorefa_w(be, golden.q, bits)
+
+
+def test_wbwtab(be, golden):
+    K.check_wbwtab(be, golden.q)
+
+
+def test_iao(be, golden):
+    K.check_iao(be, golden.q, golden.meta["iao"])
+
+
+def test_bn_stats(be):
+    K.check_bn_stats(be)
+    K.check_bn_stats(be, shape=(3, 5, 3, 3), seed=1)
+    K.check_bn_stats(be, shape=(64, 32, 16, 16), seed=2)
+
+
+@pytest.mark.parametrize("case", range(len(K.SMALL_CONV_CASES)))
+def test_conv_plain(be, case):
+    K.check_conv(be, seed=case, **K.SMALL_CONV_CASES[case])
+
+
+@pytest.mark.parametrize("case", [1, 2, 3, 5, 8])
+def test_conv_dorefa_fused(be, case):
+    K.check_conv(be, seed=10 + case, mode=1, bits=3, **K.SMALL_CONV_CASES[case])
+
+
+@pytest.mark.parametrize("case,q_type", [(1, 0), (2, 1), (3, 0), (8, 1), (5, 0)])
+def test_conv_iao_fused(be, case, q_type):
+    K.check_conv(be, seed=20 + case, mode=2, bits=4, q_type=q_type, **K.SMALL_CONV_CASES[case])
+
+
+# the real layer shapes of the benchmark nets at a batch the numpy oracle finishes in seconds
+HOT_SHAPES = [
+    ("nin_gc L1 5x5 (iao)", dict(x_shape=(4, 3, 32, 32), w_shape=(256, 3, 5, 5), padding=2)),
+    ("nin_gc L2 1x1 g2", dict(x_shape=(4, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2)),
+    ("nin_gc L4 3x3 g16", dict(x_shape=(4, 256, 16, 16), w_shape=(512, 16, 3, 3), padding=1, groups=16)),
+    ("nin_gc L5 1x1 g4", dict(x_shape=(4, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4)),
+    ("nin_gc L7 3x3 g32", dict(x_shape=(6, 512, 8, 8), w_shape=(1024, 16, 3, 3), padding=1, groups=32)),
+    ("nin_gc L8 1x1 g8", dict(x_shape=(6, 1024, 8, 8), w_shape=(1024, 128, 1, 1), groups=8)),
+    ("nin_gc L9 1x1 ->10", dict(x_shape=(6, 1024, 8, 8), w_shape=(10, 1024, 1, 1))),
+    ("resnet 3x3 64", dict(x_shape=(2, 64, 32, 32), w_shape=(64, 64, 3, 3), padding=1, bias=False)),
+    ("resnet 3x3 s2 64->128", dict(x_shape=(2, 64, 32, 32), w_shape=(128, 64, 3, 3), stride=2, padding=1, bias=False)),
+    ("resnet 1x1 s2 shortcut", dict(x_shape=(2, 64, 32, 32), w_shape=(128, 64, 1, 1), stride=2, bias=False)),
+    ("resnet 3x3 512 @4x4", dict(x_shape=(9, 512, 4, 4), w_shape=(512, 512, 3, 3), padding=1, bias=False)),
+]
+
+
+@pytest.mark.parametrize("name,kw", HOT_SHAPES, ids=[n for n, _ in HOT_SHAPES])
+def test_hot_shapes(be, name, kw):
+    K.check_conv(be, seed=77, expect_mfma=True, **kw)
+    K.check_conv(be, seed=78, mode=1, bits=2, algos=(2,), **kw)
+
+
+def test_full_size_properties(be):
+    """BASELINE config 2 layer L2 at batch 256 (268 MB activations): properties that need no CPU-sized oracle.
+    (1) MFMA kernel == direct kernel on a strided sample of outputs; (2) linearity in the weights;
+    (3) backward-weight of ones == per-channel input sums (a checksum of checksums)."""
+    torch = be.torch
+    N = 256
+    g = be.geom((N, 256, 32, 32), (256, 128, 1, 1), groups=2)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.rand((N, 256, 32, 32), device="cuda", generator=gen) > 0.5).float() * 2 - 1      # +-1 activations
+    w = torch.randn((256, 128, 1, 1), device="cuda", generator=gen) * 0.1
+    aq = be.actq(0)
+    y = be.conv_fwd(g, aq, x, w, None, 2)
+    y2 = be.conv_fwd(g, aq, x, 2 * w, None, 2)
+    assert torch.equal(y2, 2 * y)                                # scaling by 2 is exact in fp32
+    # sampled comparison with an fp64 einsum on 3 images
+    for n in (0, 100, 255):
+        ref = torch.einsum("gchw,goc->gohw", x[n].double().view(2, 128, 32, 32), w.double().view(2, 128, 128)).reshape(256, 32, 32)
+        assert (y[n].double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    gy = torch.ones_like(y)
+    dw, db = be.conv_bwd_weight(g, aq, gy, x, 2)
+    colsum = x.double().sum(dim=(0, 2, 3))                       # [256]
+    ref = colsum.view(2, 1, 128).expand(2, 128, 128).reshape(256, 128)
+    assert (dw.view(256, 128).double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp_min(1.0)
+    assert torch.equal(db, torch.full_like(db, float(N * 32 * 32)))
+    dx = be.conv_bwd_data(g, aq, gy, w, None, 2)
+    ref = w.double().view(2, 128, 128).sum(dim=1).reshape(256)    # sum over out-channels of each group
+    assert (dx[17, :, 5, 9].double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    assert torch.equal(dx[0, :, 0, 0], dx[255, :, 31, 31])
+
+
+def test_errors_are_reported(be):
+    g = be.geom((1, 4, 8, 8), (4, 3, 1, 1))      # C not divisible consistently -> invalid
+    g.groups = 3
+    rc = be.lib.mn_conv2d_fwd(C.byref(g), C.byref(be.actq(0)), None, None, None, None, None, 0, 0, be.stream)
+    assert rc == -22 and b"invalid" in be.lib.mn_last_error()
+    g2 = be.geom((2, 8, 6, 6), (12, 4, 3, 3), padding=1, groups=2)
+    x = be.to_dev(np.zeros((2, 8, 6, 6)))
+    w = be.to_dev(np.zeros((12, 4, 3, 3)))
+    y = be.empty((2, 12, 6, 6))
+    rc = be.lib.mn_conv2d_fwd(C.byref(g2), C.byref(be.actq(0)), be.ptr(x), be.ptr(w), None, be.ptr(y), None, 0, 2, be.stream)
+    assert rc == -95       # MFMA requested for a shape the tiler rejects

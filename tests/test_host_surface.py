@@ -1,0 +1,82 @@
+"""The Python boundary (module surface) without running any kernel: graph rewrite, class names, state_dict keys and
+shapes must equal the reference's (recorded in tests/golden/meta.json by make_golden.py)."""
+import importlib
+
+import pytest
+import torch
+import torch.nn as nn
+
+from micronet_amd.train import build_model
+
+CFG = {
+    "c1_nin_gc_dorefa_w8a8": ("nin_gc", "wqaq.dorefa", dict(a_bits=8, w_bits=8)),
+    "c2_nin_gc_wbwtab_w3a2": ("nin_gc", "wbwtab", dict(A=2, W=3)),
+    "c2b_nin_gc_wbwtab_w2a2": ("nin_gc", "wbwtab", dict(A=2, W=2)),
+    "c3_nin_gc_iao_w8a8_bnfuse": ("nin_gc", "wqaq.iao", dict(a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=True)),
+    "c4_resnet18_dorefa_w2a2": ("resnet18", "wqaq.dorefa", dict(a_bits=2, w_bits=2)),
+    "c5_resnet18_iao_w4a4": ("resnet18", "wqaq.iao", dict(a_bits=4, w_bits=4, q_type=0, q_level=0)),
+    "nin_dorefa_w4a4": ("nin", "wqaq.dorefa", dict(a_bits=4, w_bits=4)),
+}
+
+
+@pytest.mark.parametrize("key", list(CFG))
+def test_prepare_matches_reference_surface(golden, key):
+    arch, scheme, kw = CFG[key]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    model = build_model(arch)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    q = quantize.prepare(model, inplace=True, **kw)
+    surf = golden.meta["surface"][key]
+    assert [[n, type(m).__name__] for n, m in q.named_modules()] == surf["modules"]
+    assert [[k, list(v.shape)] for k, v in q.state_dict().items()] == surf["state"]
+    # parameters keep their values and the quantised modules share the original storage
+    for k, v in q.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k])
+
+
+def test_not_inplace_deepcopies():
+    from micronet.compression.quantization.wqaq.dorefa import quantize
+    m = build_model("nin")
+    q = quantize.prepare(m, inplace=False, a_bits=4, w_bits=4)
+    assert isinstance(m.model[1].conv, nn.Conv2d) and not isinstance(m.model[1].conv, quantize.QuantConv2d)
+    assert isinstance(q.model[1].conv, quantize.QuantConv2d)
+    assert isinstance(q.model[0].conv, nn.Conv2d) and not isinstance(q.model[0].conv, quantize.QuantConv2d)   # first conv skipped
+
+
+def test_smoke_constructors(capsys):
+    import micronet
+    out = micronet.quant_test_auto()
+    assert set(out) == {"wbwtab", "dorefa", "iao"}
+    micronet.quant_test_manual()
+    assert "quant_model is ready" in capsys.readouterr().out
+
+
+def test_binary_bits_rejected():
+    from micronet.compression.quantization.wqaq.dorefa.quantize import ActivationQuantizer
+    with pytest.raises(AssertionError):
+        ActivationQuantizer(a_bits=1)(torch.zeros(4))
+
+
+def test_no_cpu_fallback():
+    """The product refuses CPU tensors instead of silently computing somewhere else."""
+    from micronet_amd import ops
+    from micronet_amd._lib import MicronetHipError
+    with pytest.raises(MicronetHipError):
+        ops.DorefaAct.apply(torch.zeros(8), 4)
+    from micronet.compression.quantization.wbwtab.quantize import QuantConv2d
+    with pytest.raises(MicronetHipError):
+        QuantConv2d(4, 4, 1, W=3)(torch.zeros(1, 4, 4, 4))
+
+
+def test_abi_exports_every_declared_symbol():
+    """libmicronet_hip.so loads without a GPU and exports exactly what include/micronet_hip.h declares."""
+    import os, re
+    from micronet_amd import _lib, build
+    build.build(verbose=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "micronet_hip.h")).read()
+    declared = set(re.findall(r"\b(mn_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = _lib.Lib(_lib.LIB_PATH)           # AttributeError if a symbol is missing
+    assert lib.mn_version() >= 100 and lib.mn_is_emulation() == 0
