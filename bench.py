@@ -87,13 +87,13 @@ def build(workload, device):
     return model, make_optimizer(model, 0.01, wd)
 
 
-def cpu_baseline(workload, batch, steps):
+def cpu_baseline(workload, batch, steps, threads=0):
     """The reference's algorithm on the host cores: the torch-CPU oracle ("port", bit-identical to the reference on CPU)."""
     from oracle import torch_oracle as TO
     from micronet_amd.train import build_model, synth_batch
     arch, scheme, kw, wd = WORKLOADS[workload]
     scheme_name = scheme.split(".")[-1]
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(threads if threads > 0 else os.cpu_count())
     model = TO.prepare(build_model(arch), scheme_name, inplace=True, **kw).train()
     opt = TO.make_optimizer(model, 0.01, wd)
     x, y = synth_batch(batch)
@@ -117,9 +117,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = os.cpu_count()")
+    ap.add_argument("--cpu-only", action="store_true", help="only time the CPU baseline (no GPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
+    if args.cpu_only:
+        print(json.dumps(cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_threads)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -192,7 +197,7 @@ def main():
                                      "algorithmic_TFLOPs": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3, 2),
                                      "fp32_mfma_frac": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

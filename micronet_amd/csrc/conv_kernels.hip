@@ -627,22 +627,33 @@ static int plan_wgrad(const mn_conv_geom* g, WgradPlan* pl) {
         if (MTW == 1) return 0;
         MTW /= 2;
     }
-    int CTW = (Cg + 15) / 16;
-    if (CTW > JTmax / T) CTW = JTmax / T;
+    int CTWmax = (Cg + 15) / 16;
+    if (CTWmax > JTmax / T) CTWmax = JTmax / T;
     WgradParams& p = pl->p;
-    p.MTW = MTW; p.CTW = CTW; p.WM = WM; p.WJ = WJ; p.TMW = MTW * 16; p.TCW = CTW * 16;
-    p.nmb = (Mg + p.TMW - 1) / p.TMW; p.ncb = (Cg + p.TCW - 1) / p.TCW;
-    p.Mgw = p.nmb * p.TMW; p.Cgw = p.ncb * p.TCW;
+    p.MTW = MTW; p.WM = WM; p.WJ = WJ; p.TMW = MTW * 16;
+    p.nmb = (Mg + p.TMW - 1) / p.TMW;
+    p.Mgw = p.nmb * p.TMW;
+    // largest pixel tile whose gy tile + input patch fit in LDS; shrink the channel block before the pixel tile
     TileGeom t;
     int ok = 0;
     size_t lds = 0;
-    for (int TP = 128; TP >= 16; TP /= 2) {
-        if (!make_tile_geom(v, TP, 4, &t)) continue;
-        p.GS = TP + 4;
-        lds = ((size_t)p.TMW * p.GS + (size_t)p.TCW * t.CS + TP) * sizeof(float);
-        if (lds <= (size_t)LDS_CAP_WGRAD) { ok = 1; break; }
+    for (int pass = 0; pass < 2 && !ok; ++pass) {
+        for (int TP = 128; TP >= 16 && !ok; TP /= 2) {
+            if (!make_tile_geom(v, TP, 4, &t)) continue;
+            p.GS = TP + 4;
+            for (int ctw = CTWmax; ctw >= 1; --ctw) {
+                lds = ((size_t)p.TMW * p.GS + (size_t)ctw * 16 * t.CS + TP) * sizeof(float);
+                if (lds > (size_t)LDS_CAP_WGRAD) continue;
+                if (pass == 0 && ctw < (CTWmax < 4 ? CTWmax : 4)) break;   // first pass: insist on a decent channel block
+                p.CTW = ctw; ok = 1;
+                break;
+            }
+        }
     }
     if (!ok) return 0;
+    p.TCW = p.CTW * 16;
+    p.ncb = (Cg + p.TCW - 1) / p.TCW;
+    p.Cgw = p.ncb * p.TCW;
     p.v = v; p.t = t;
     const int base = v.G * p.nmb * p.ncb;
     int Z = 512 / base;

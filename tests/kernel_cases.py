@@ -148,7 +148,8 @@ def check_bn_stats(be, shape=(5, 6, 4, 8), seed=0):
     assert np.max(np.abs(got[0] - mean)) <= 1e-6 * np.max(np.abs(mean)) and np.max(np.abs(got[1] - var)) <= 2e-6 * np.max(np.abs(var))
     dm, dv = r.standard_normal(Cc).astype(F), r.standard_normal(Cc).astype(F)
     d_o = be.empty(shape)
-    be.call("mn_bn_stats_bwd", be.ptr(do_), be.ptr(st), be.ptr(be.to_dev(dm)), be.ptr(be.to_dev(dv)), be.ptr(d_o), N, Cc, HW, be.stream)
+    ddm, ddv = be.to_dev(dm), be.to_dev(dv)      # keep the device buffers alive across the call
+    be.call("mn_bn_stats_bwd", be.ptr(do_), be.ptr(st), be.ptr(ddm), be.ptr(ddv), be.ptr(d_o), N, Cc, HW, be.stream)
     n = N * HW
     ref = dm.reshape(1, -1, 1, 1) / n + dv.reshape(1, -1, 1, 1) * 2 * (o.astype(np.float64) - mean.reshape(1, -1, 1, 1)) / (n - 1)
     assert close(be.to_host(d_o), ref, 2e-6)
