@@ -117,28 +117,57 @@ typedef struct mn_conv_geom {
 #define MN_ACTQ_NONE 0
 #define MN_ACTQ_DOREFA 1
 #define MN_ACTQ_IAO 2
+#define MN_ACTQ_X_IS_CODE 1 /* flags: optional hint that with MN_ACTQ_NONE x holds small integers exact in bf16 (the +-1 of
+                              wbwtab's BinaryActivation, wbwtab/quantize.py:13-19).  Never required: real-valued x is split
+                              into exact bf16 terms on the fly and all-zero terms are skipped. */
 typedef struct mn_actq {
     int32_t mode;    /* MN_ACTQ_* */
     int32_t bits;
     int32_t q_type;  /* iao: 0 symmetric, 1 asymmetric */
-    int32_t reserved;
+    int32_t flags;   /* MN_ACTQ_X_IS_CODE */
     const float* qp; /* iao: device {scale, zero_point, lo, hi} (per-tensor) */
 } mn_actq;
+
+/* How the (already fake-quantised, fp32 OIHW) weight tensor factors into integer codes x per-channel scale.  The
+ * code-domain kernels (MN_ALGO_QGEMM) contract bf16-exact integer codes on v_mfma_f32_16x16x32_bf16 and apply the scale
+ * outside the sum; the descriptor tells the pack kernel how to recover the codes from w:
+ *   MN_WQ_TERNARY  w[o,:] = t * alpha[o], t in {-1,0,+1}   (wbwtab/quantize.py:121-146)   alpha[o] := max|w[o,:]|
+ *   MN_WQ_DOREFA   w = (2k - n)/n, n = 2^bits - 1           (wqaq/dorefa/quantize.py:68-72)
+ *   MN_WQ_IAO      w = code * scale[o]                       (wqaq/iao/quantize.py:227-239); scale = the quantizer's buffer
+ *   MN_WQ_REAL     arbitrary fp32 weights: the code-domain kernels do not apply (fp32-MFMA kernels are used) */
+#define MN_WQ_REAL 0
+#define MN_WQ_TERNARY 1
+#define MN_WQ_DOREFA 2
+#define MN_WQ_IAO 3
+typedef struct mn_wq {
+    int32_t mode;         /* MN_WQ_* */
+    int32_t bits;
+    int32_t q_type;       /* iao: 0 symmetric, 1 asymmetric */
+    int32_t per_channel;  /* iao: stride, in floats, between the scales of consecutive out-channels: 0 = one scale for the
+                             tensor, 1 = a dense [O] vector, 4 = the rows of an mn_iao_qparams snapshot */
+    const float* scale;   /* iao: device pointer */
+} mn_wq;
 
 #define MN_ALGO_AUTO 0
 #define MN_ALGO_DIRECT 1 /* generic VALU kernels: any geometry */
 #define MN_ALGO_MFMA 2   /* implicit-GEMM on v_mfma_f32_16x16x4_f32; MN_ENOTSUP if the shape does not tile */
+#define MN_ALGO_QGEMM 3  /* code-domain kernels on v_mfma_f32_16x16x32_bf16 (exact integer codes; real operands as exact
+                            3-term bf16 splits); MN_ENOTSUP if geometry / quantizer combination is not covered.
+                            MN_ALGO_AUTO tries QGEMM, then MFMA, then DIRECT. */
 
-/* which: 0 fwd, 1 bwd_data, 2 bwd_weight.  Bytes of `ws` the call needs for `algo`. */
+/* which: 0 fwd, 1 bwd_data, 2 bwd_weight.  Bytes of `ws` the call needs for `algo` (AUTO: enough for whichever is chosen). */
 int64_t mn_conv2d_ws_bytes(const mn_conv_geom* g, int which, int algo);
 /* 1 if MN_ALGO_MFMA supports this geometry for `which` */
 int mn_conv2d_mfma_supported(const mn_conv_geom* g, int which);
-/* y[N][O][Ho][Wo] = conv2d(actq(x), w, bias); w are the (already fake-quantised) fp32 weights */
-int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const float* x, const float* w, const float* bias,
-                  float* y, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
+/* 1 if MN_ALGO_QGEMM supports this geometry and quantizer combination for `which` (aq / wq may be NULL = none / real) */
+int mn_conv2d_qgemm_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
+/* y[N][O][Ho][Wo] = conv2d(actq(x), w, bias); w are the (already fake-quantised) fp32 weights, wq says how they factor
+ * (NULL = MN_WQ_REAL) */
+int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w,
+                  const float* bias, float* y, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
 /* dx = conv2d_backward_data(gy, w) * d actq(x)/dx  (x may be NULL when aq->mode == NONE) */
-int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* w, const float* x,
-                       float* dx, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
+int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w,
+                       const float* x, float* dx, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
 /* dw = conv2d_backward_weight(gy, actq(x)); dbias = sum gy (dbias may be NULL) */
 int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw,
                          float* dbias, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);

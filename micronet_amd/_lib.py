@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libmicronet_hip.so")
 
 MN_ACTQ_NONE, MN_ACTQ_DOREFA, MN_ACTQ_IAO = 0, 1, 2
-MN_ALGO_AUTO, MN_ALGO_DIRECT, MN_ALGO_MFMA = 0, 1, 2
+MN_ALGO_AUTO, MN_ALGO_DIRECT, MN_ALGO_MFMA, MN_ALGO_QGEMM = 0, 1, 2, 3
+MN_WQ_REAL, MN_WQ_TERNARY, MN_WQ_DOREFA, MN_WQ_IAO = 0, 1, 2, 3
+MN_ACTQ_X_IS_CODE = 1
 MN_ENOTSUP = -95
 
 
@@ -21,12 +23,18 @@ class ConvGeom(C.Structure):
 
 
 class ActQ(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("bits", C.c_int32), ("q_type", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("mode", C.c_int32), ("bits", C.c_int32), ("q_type", C.c_int32), ("flags", C.c_int32),
                 ("qp", C.c_void_p)]
 
 
+class WQ(C.Structure):
+    """mn_wq: how the fake-quantised fp32 weights factor into integer codes x per-channel scale."""
+    _fields_ = [("mode", C.c_int32), ("bits", C.c_int32), ("q_type", C.c_int32), ("per_channel", C.c_int32),
+                ("scale", C.c_void_p)]
+
+
 _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
-_G, _A = C.POINTER(ConvGeom), C.POINTER(ActQ)
+_G, _A, _W = C.POINTER(ConvGeom), C.POINTER(ActQ), C.POINTER(WQ)
 
 # name -> (restype, argtypes); must list every symbol declared in include/micronet_hip.h
 PROTOTYPES = {
@@ -56,8 +64,9 @@ PROTOTYPES = {
     "mn_bn_stats_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),
     "mn_conv2d_mfma_supported": (_I, [_G, _I]),
-    "mn_conv2d_fwd": (_I, [_G, _A, _P, _P, _P, _P, _P, _L, _I, _P]),
-    "mn_conv2d_bwd_data": (_I, [_G, _A, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "mn_conv2d_qgemm_supported": (_I, [_G, _A, _W, _I]),
+    "mn_conv2d_fwd": (_I, [_G, _A, _W, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "mn_conv2d_bwd_data": (_I, [_G, _A, _W, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mn_conv2d_bwd_weight": (_I, [_G, _A, _P, _P, _P, _P, _P, _L, _I, _P]),
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/micronet_hip.h"
 
@@ -20,6 +21,36 @@ void mn_set_error(const char* fmt, ...);
         hipError_t e_ = hipGetLastError();                                \
         if (e_ != hipSuccess) MN_FAIL(MN_EHIP, "%s: %s", what, hipGetErrorString(e_)); \
     } while (0)
+
+
+// ---------------------------------------------------------------- bf16 MFMA (v_mfma_f32_16x16x32_bf16) plumbing
+// A/B fragments are 8 bf16 per lane packed into 4 dwords (element e in dword e/2, low half first):
+//   A[i = lane&15][k = 8*(lane>>4) + e]     B[k = 8*(lane>>4) + e][j = lane&15]     D[row = 4*(lane>>4) + reg][col = lane&15]
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+#ifdef MN_EMULATION
+__device__ __forceinline__ f32x4 mn_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) { return emu_mfma_f32_16x16x32_bf16(a, b, c); }
+__device__ __forceinline__ int mn_wave_any(int pred) { return emu_wave_any(pred); }
+__device__ __forceinline__ unsigned mn_f2u(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+__device__ __forceinline__ float mn_u2f(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+#else
+typedef __bf16 mn_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mn_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mn_bf16x8, a), __builtin_bit_cast(mn_bf16x8, b),
+                                                    __builtin_bit_cast(v4f, c), 0, 0, 0);
+    return __builtin_bit_cast(f32x4, r);
+}
+__device__ __forceinline__ int mn_wave_any(int pred) { return __builtin_amdgcn_ballot_w64(pred != 0) != 0ull; }
+__device__ __forceinline__ unsigned mn_f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float mn_u2f(unsigned u) { return __uint_as_float(u); }
+#endif
+// bf16 "head" of an fp32 (truncation): exact for integers |v| <= 256; v - head is exact in fp32, so
+// v = t0 + t1 + t2 with t_i = head(remainder) reproduces all 24 significant bits (three-term split).
+__device__ __forceinline__ float mn_bf16_head(float v) { return mn_u2f(mn_f2u(v) & 0xffff0000u); }
+// pack the bf16 heads of two floats: low half = lo_elem, high half = hi_elem
+__device__ __forceinline__ unsigned mn_pack_bf16x2(float lo_elem, float hi_elem) {
+    return (mn_f2u(lo_elem) >> 16) | (mn_f2u(hi_elem) & 0xffff0000u);
+}
 
 // ---------------------------------------------------------------- arithmetic shared by all schemes
 // round-half-away-from-zero evaluated in fp32 exactly like the reference's
@@ -71,6 +102,39 @@ static inline IaoRange iao_range(int bits, int q_type, int is_act) {
     return r;
 }
 static inline float dorefa_scale(int bits) { return (float)(1.0 / (double)((1ll << bits) - 1)); }
+
+// activation-quantizer descriptor (device side) shared by the conv kernels
+struct Pro {           // prologue applied to loaded input elements
+    int mode;          // MN_ACTQ_*
+    float s;           // dorefa scale
+    float qmin, qmax;  // iao
+    const float* qp;   // iao {scale, zp, lo, hi}
+};
+__device__ __forceinline__ float pro_apply(const Pro& p, float v, float sc, float zp) {
+    if (p.mode == MN_ACTQ_DOREFA) return dorefa_act_q(v, p.s);
+    if (p.mode == MN_ACTQ_IAO) return iao_fq(v, sc, zp, p.qmin, p.qmax);
+    return v;
+}
+
+static int make_pro(const mn_actq* aq, Pro* p, int need_bounds, const char* what) {
+    p->mode = MN_ACTQ_NONE; p->s = 1.f; p->qmin = p->qmax = 0.f; p->qp = nullptr;
+    if (!aq || aq->mode == MN_ACTQ_NONE) return MN_OK;
+    if (aq->mode == MN_ACTQ_DOREFA) {
+        if (aq->bits < 2 || aq->bits > 31) MN_FAIL(MN_EINVAL, "%s: dorefa bits=%d", what, aq->bits);
+        p->mode = MN_ACTQ_DOREFA; p->s = dorefa_scale(aq->bits);
+        return MN_OK;
+    }
+    if (aq->mode == MN_ACTQ_IAO) {
+        if (aq->bits < 2 || aq->bits > 24 || !aq->qp) MN_FAIL(MN_EINVAL, "%s: iao bits=%d / null qp", what, aq->bits);
+        IaoRange r = iao_range(aq->bits, aq->q_type, 1);
+        p->mode = MN_ACTQ_IAO; p->qmin = r.qmin; p->qmax = r.qmax; p->qp = aq->qp;
+        return MN_OK;
+    }
+    (void)need_bounds;
+    MN_FAIL(MN_EINVAL, "%s: unknown activation quantizer mode %d", what, aq->mode);
+}
+
+
 __host__ __device__ static inline int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // exact unsigned division by a runtime-uniform divisor (host-precomputed); valid while n*d < 2^32

@@ -20,20 +20,10 @@
 // A block is 256 threads = 4 waves (one per SIMD); 128-pixel tiles give >=2048 workgroups per
 // layer at batch 256, i.e. >=8 per CU across the 8 XCDs.
 #include "common.h"
+#include "qgemm.h"
 
 // ------------------------------------------------------------------------------------------------
-// activation-quantizer descriptors (device side)
-struct Pro {           // prologue applied to loaded input elements
-    int mode;          // MN_ACTQ_*
-    float s;           // dorefa scale
-    float qmin, qmax;  // iao
-    const float* qp;   // iao {scale, zp, lo, hi}
-};
-__device__ __forceinline__ float pro_apply(const Pro& p, float v, float sc, float zp) {
-    if (p.mode == MN_ACTQ_DOREFA) return dorefa_act_q(v, p.s);
-    if (p.mode == MN_ACTQ_IAO) return iao_fq(v, sc, zp, p.qmin, p.qmax);
-    return v;
-}
+// activation-quantizer descriptors: Pro / pro_apply / make_pro live in common.h
 #define EPI_PLAIN 0
 #define EPI_BIAS 1
 #define EPI_STE 2   // multiply by d actq(x)/dx, x read from aux (same shape as the output)
@@ -538,24 +528,6 @@ static int check_geom(const mn_conv_geom* g, const char* what) {
         MN_FAIL(MN_EINVAL, "%s: empty output", what);
     return MN_OK;
 }
-static int make_pro(const mn_actq* aq, Pro* p, int need_bounds, const char* what) {
-    p->mode = MN_ACTQ_NONE; p->s = 1.f; p->qmin = p->qmax = 0.f; p->qp = nullptr;
-    if (!aq || aq->mode == MN_ACTQ_NONE) return MN_OK;
-    if (aq->mode == MN_ACTQ_DOREFA) {
-        if (aq->bits < 2 || aq->bits > 31) MN_FAIL(MN_EINVAL, "%s: dorefa bits=%d", what, aq->bits);
-        p->mode = MN_ACTQ_DOREFA; p->s = dorefa_scale(aq->bits);
-        return MN_OK;
-    }
-    if (aq->mode == MN_ACTQ_IAO) {
-        if (aq->bits < 2 || aq->bits > 24 || !aq->qp) MN_FAIL(MN_EINVAL, "%s: iao bits=%d / null qp", what, aq->bits);
-        IaoRange r = iao_range(aq->bits, aq->q_type, 1);
-        p->mode = MN_ACTQ_IAO; p->qmin = r.qmin; p->qmax = r.qmax; p->qp = aq->qp;
-        return MN_OK;
-    }
-    (void)need_bounds;
-    MN_FAIL(MN_EINVAL, "%s: unknown activation quantizer mode %d", what, aq->mode);
-}
-
 static const int LDS_CAP_FWD = 64 * 1024;
 static const int LDS_CAP_WGRAD = 64 * 1024;
 
@@ -676,9 +648,18 @@ extern "C" int mn_conv2d_mfma_supported(const mn_conv_geom* g, int which) {
 extern "C" int64_t mn_conv2d_ws_bytes(const mn_conv_geom* g, int which, int algo) {
     if (check_geom(g, "mn_conv2d_ws_bytes") != MN_OK) return -1;
     if (algo == MN_ALGO_DIRECT) return 0;
-    if (which == 0 || which == 1) { FwdPlan pl; return plan_fwd_view(g, which, &pl) ? pl.wp_floats * 4 : 0; }
-    if (which == 2) { WgradPlan pl; return plan_wgrad(g, &pl) ? pl.part_floats * 4 : 0; }
-    return -1;
+    if (which < 0 || which > 2) return -1;
+    int64_t q = (algo == MN_ALGO_AUTO || algo == MN_ALGO_QGEMM) ? qg_ws_bytes(g, which) : 0;
+    int64_t m = 0;
+    if (algo == MN_ALGO_AUTO || algo == MN_ALGO_MFMA) {
+        if (which == 0 || which == 1) { FwdPlan pl; m = plan_fwd_view(g, which, &pl) ? pl.wp_floats * 4 : 0; }
+        else { WgradPlan pl; m = plan_wgrad(g, &pl) ? pl.part_floats * 4 : 0; }
+    }
+    return q > m ? q : m;
+}
+extern "C" int mn_conv2d_qgemm_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
+    if (check_geom(g, "mn_conv2d_qgemm_supported") != MN_OK) return 0;
+    return qg_supported(g, aq, wq, which);
 }
 
 static DirectParams make_direct(const mn_conv_geom* g, const Pro& pro) {
@@ -705,14 +686,16 @@ static int run_fwd_plan(FwdPlan& pl, hipStream_t s, const char* what) {
     return MN_OK;
 }
 
-extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const float* x, const float* w, const float* bias,
-                             float* y, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream) {
+extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w,
+                             const float* bias, float* y, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream) {
     int rc = check_geom(g, "mn_conv2d_fwd");
     if (rc) return rc;
     if (!x || !w || !y) MN_FAIL(MN_EINVAL, "mn_conv2d_fwd: null tensor");
     Pro pro;
     if ((rc = make_pro(aq, &pro, 0, "mn_conv2d_fwd"))) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, wq, 0) && aligned16(x) && aligned16(y)))
+        return qg_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
     FwdPlan pl;
     const int can = (algo != MN_ALGO_DIRECT) && plan_fwd_view(g, 0, &pl) && aligned16(x) && aligned16(y);
     if (algo == MN_ALGO_MFMA && !can) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: geometry not supported by the MFMA tiler");
@@ -731,8 +714,8 @@ extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const flo
     return MN_OK;
 }
 
-extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* w, const float* x,
-                                  float* dx, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream) {
+extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w,
+                                  const float* x, float* dx, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream) {
     int rc = check_geom(g, "mn_conv2d_bwd_data");
     if (rc) return rc;
     if (!gy || !w || !dx) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data: null tensor");
@@ -740,6 +723,9 @@ extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, cons
     if ((rc = make_pro(aq, &ste, 1, "mn_conv2d_bwd_data"))) return rc;
     if (ste.mode != MN_ACTQ_NONE && !x) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data: x required for the clip-STE epilogue");
     hipStream_t s = (hipStream_t)stream;
+    if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, wq, 1) && aligned16(gy) && aligned16(dx) &&
+                                  (ste.mode == MN_ACTQ_NONE || aligned16(x))))
+        return qg_bwd_data(g, aq, wq, gy, w, x, dx, ws, ws_bytes, s);
     FwdPlan pl;
     const int can = (algo != MN_ALGO_DIRECT) && plan_fwd_view(g, 1, &pl) && aligned16(gy) && aligned16(dx) && (ste.mode == MN_ACTQ_NONE || aligned16(x));
     if (algo == MN_ALGO_MFMA && !can) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data: geometry not supported by the MFMA tiler");
@@ -769,6 +755,8 @@ extern "C" int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, co
     if ((rc = make_pro(aq, &pro, 0, "mn_conv2d_bwd_weight"))) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int Ho = out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+    if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, nullptr, 2) && aligned16(x) && aligned16(gy)))
+        return qg_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
     WgradPlan pl;
     const int can = (algo != MN_ALGO_DIRECT) && plan_wgrad(g, &pl) && aligned16(x) && aligned16(gy);
     if (algo == MN_ALGO_MFMA && !can) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight: geometry not supported by the MFMA tiler");

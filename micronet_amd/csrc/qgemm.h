@@ -1,0 +1,13 @@
+// Internal interface between the C-ABI entry points (conv_kernels.hip) and the code-domain kernels (qgemm_kernels.hip).
+#pragma once
+#include "common.h"
+
+// which: 0 fwd, 1 bwd_data, 2 bwd_weight.  All return MN_OK / negative code; *_supported return 0/1 and never set the error.
+int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
+int64_t qg_ws_bytes(const mn_conv_geom* g, int which);
+int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y,
+           void* ws, int64_t ws_bytes, hipStream_t s);
+int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
+                void* ws, int64_t ws_bytes, hipStream_t s);
+int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
+                  int64_t ws_bytes, hipStream_t s);

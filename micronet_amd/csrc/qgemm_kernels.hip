@@ -1,0 +1,735 @@
+// Code-domain convolution kernels for gfx950 (CDNA4): the contraction runs on v_mfma_f32_16x16x32_bf16.
+//
+// Why this is exact.  Every fake-quantised operand of the reference is `integer code x scale` with |code| <= 255 at
+// <= 8 bit: DoReFa act j*s, weight (2k-n)/n; ternary/binary t*alpha[o]; IAO (clamp(r)+zp)*s[o].
+// Integers up to 256 are exact in bf16, their products are exact in fp32 and the fp32 accumulation is exact while
+// K*max|a|*max|w| < 2^24 -- so the forward is ONE bf16 MFMA pass over codes and an epilogue `* s_a*s_w[o] + bias`.
+// The backward passes have one real-valued operand (gy): it is written as gy = t0 + t1 + t2 with t_i the bf16 head of the
+// running remainder (exact: 3 x 8 significant bits = the 24 of an fp32), so three MFMA passes form exactly the fp32
+// products the reference forms, at 3/16 of the fp32-MFMA cost.  Real-valued activations (wbwtab feeds the +-1 of
+// BinaryActivation as ordinary floats) go through the same split and the passes of an all-zero term are skipped
+// wave-uniformly, so +-1 inputs cost one pass and arbitrary floats stay exact.
+//
+// Pointwise (1x1, stride 1) convolutions -- 72 % of nin_gc's activation bytes -- need no LDS for the activations:
+//   lane (j = lane&15, kg = lane>>4) loads float4 = 4 consecutive pixels of each of 8 channels (16 lanes -> 256-B runs);
+//   pixel column q of those loads is the B fragment (k = channel, column = pixel 4j+q) of MFMA q, q = 0..3;
+//   the A fragments are weight codes read from LDS (row = out-channel); D[q] leaves lane (j, kg) with out-channels
+//   4kg..4kg+3 of pixel 4j+q, i.e. across q a float4 of 4 consecutive pixels per out-channel: stores are again 256-B runs.
+// The pixel <-> MFMA-column permutation costs nothing.  Backward-data is the same kernel on gy with transposed codes, the
+// per-channel weight scale applied to gy before the split, and the clip-STE of the activation quantizer in the epilogue.
+// Backward-weight contracts over pixels: both operands are pixel-contiguous in NCHW, so 64-pixel slabs of gy (3 terms)
+// and of the activation codes are staged in LDS as bf16 rows and read back as b128 fragments; the grid splits the pixel
+// range (Z) and a second kernel reduces the partial tiles in a fixed order with fp64 accumulation (deterministic).
+#include "qgemm.h"
+
+typedef unsigned int u32x2 __attribute__((vector_size(8)));
+
+#define QG_EPI_SCALE_BIAS 0
+#define QG_EPI_PLAIN 1
+#define QG_EPI_STE 2
+
+static inline int qg_roundup(int a, int b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------------
+// activation codes in the conv prologue
+template <int XMODE>
+__device__ __forceinline__ float act_code(float x, const Pro& p, float sc, float zp) {
+    if (XMODE == MN_ACTQ_DOREFA) return mn_rha(mn_clamp(x * 0.1f, 0.f, 1.f) / p.s);           // j in [0, 2^a - 1]
+    if (XMODE == MN_ACTQ_IAO) return mn_clamp(mn_rha(x / sc - zp), p.qmin, p.qmax) + zp;       // clamp(r) + zp
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight codes: one workgroup (one wave) per padded row; recovers code and scale from the fake-quantised fp32 weights
+struct PackParams {
+    const float* w;        // [G*Mg][Cg*T]
+    uint16_t* codes;
+    float* scale_out;      // per out-channel scale (fwd: rowscale [G][Mpad]; bwd: kscale [G][Mgp])
+    const float* scale_in; // IAO
+    int G, Mg, Cg, T, KW;
+    int mode, bits, per_channel;
+    int transpose;         // 0: codes[(g*Mpad + m)*T*Cgp + tap*Cgp + c]   1: codes[((g*Cpad + c)*T + tapflip)*Mgp + m]
+    int Mpad, Cgp, Cpad, Mgp;
+};
+__device__ __forceinline__ float wq_code(float w, int mode, float sc, float n) {
+    if (mode == MN_WQ_TERNARY) return (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : w);   // +-0 -> 0, NaN stays NaN
+    if (mode == MN_WQ_DOREFA) {
+        const float s = 1.0f / n;                 // fp32(1/n): the same scale the quantizer divides by
+        const float k = mn_rha(((w + 1.0f) * 0.5f) / s);
+        return 2.0f * k - n;
+    }
+    return mn_rha(w / sc);                        // IAO: (clamp(r) + zp)
+}
+__global__ __launch_bounds__(64) void k_qg_pack(const PackParams p) {
+    const int rows = p.transpose ? p.Mgp : p.Mpad;
+    const int g = blockIdx.x / rows, m = blockIdx.x % rows;
+    const int lane = threadIdx.x;
+    const bool mv = m < p.Mg;
+    const int K = p.Cg * p.T;
+    const float* wr = p.w + ((int64_t)g * p.Mg + (mv ? m : 0)) * K;
+    float sc = 0.f;
+    const float n = (float)((1ll << p.bits) - 1);
+    if (mv) {
+        if (p.mode == MN_WQ_TERNARY) {
+            float mx = 0.f;
+            for (int i = lane; i < K; i += 64) mx = OpMaxF()(mx, fabsf(wr[i]));
+            mx = wave_reduce(mx, OpMaxF());
+            sc = __shfl(mx, 0, 64);
+        } else if (p.mode == MN_WQ_DOREFA) {
+            sc = 1.0f / n;
+        } else {
+            sc = p.scale_in[(int64_t)(g * p.Mg + m) * p.per_channel];   // per_channel = stride in floats (0: one scale)
+        }
+    }
+    if (lane == 0) p.scale_out[g * rows + m] = sc;
+    if (!p.transpose) {
+        uint16_t* dst = p.codes + ((int64_t)g * p.Mpad + m) * p.T * p.Cgp;
+        for (int i = lane; i < p.T * p.Cgp; i += 64) {
+            const int tap = i / p.Cgp, c = i - tap * p.Cgp;
+            float code = 0.f;
+            if (mv && c < p.Cg) code = wq_code(wr[c * p.T + tap], p.mode, sc, n);
+            dst[i] = (uint16_t)(mn_f2u(code) >> 16);
+        }
+    } else {
+        for (int i = lane; i < p.T * p.Cpad; i += 64) {
+            const int c = i / p.T, tap = i - c * p.T;
+            float code = 0.f;
+            if (mv && c < p.Cg) code = wq_code(wr[c * p.T + tap], p.mode, sc, n);
+            const int tapflip = p.T - 1 - tap;
+            p.codes[(((int64_t)g * p.Cpad + c) * p.T + tapflip) * p.Mgp + m] = (uint16_t)(mn_f2u(code) >> 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pointwise forward / backward-data
+struct PwParams {
+    const float* x;          // streamed operand: x (fwd) or gy (bwd-data)   [N][G*Kc][HW]
+    float* y;                // y (fwd) or dx (bwd-data)                      [N][G*Mr][HW]
+    const uint16_t* wc;      // codes [G][Mpad][Kp]
+    const float* rowscale;   // [G][Mpad] scale of output row (fwd) or null
+    const float* kscale;     // [G][Kp]   scale of contraction channel (bwd-data) or null
+    const float* bias;       // fwd
+    const float* aux;        // bwd-data STE: x
+    Pro pro, ste;
+    int N, HW, Cin_total, Cout_total, Kc, Mr, G;
+    int Kp, KS, Mpad, num_mblk, nchunks, CB, epi;
+    uint32_t NP;
+    FastDiv fd_hw, fd_ks;
+    float ascale;
+};
+
+template <int NT, int XMODE>
+__global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int MB = 16 * NT;
+    const int LDW = p.Kp + 8;                      // u16 per weight row: +16 B spreads the 16 rows of a fragment over all banks
+    uint16_t* wsm = reinterpret_cast<uint16_t*>(smem);
+    float* rs = smem + (MB * LDW) / 2;
+    float* bs = rs + MB;
+    float* ks = bs + MB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+
+    // block -> (group, m-block, chunk-block); blocks that share a chunk set differ only in m-block and sit on one XCD (b % 8)
+    uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u; b >>= 3;
+    const int mblk = b % p.num_mblk; b /= p.num_mblk;
+    const uint32_t idx = b * 8u + xcd;
+    if (idx >= (uint32_t)(p.G * p.CB)) return;
+    const int cb = idx % p.CB, g = idx / p.CB;
+
+    {   // stage weight codes, scales, bias
+        const uint16_t* wg = p.wc + ((int64_t)g * p.Mpad + mblk * MB) * p.Kp;
+        const int k8 = p.Kp >> 3;
+        for (int q = tid; q < MB * k8; q += 256) {
+            const int row = q / k8, c8 = q - row * k8;
+            *reinterpret_cast<u32x4*>(wsm + row * LDW + c8 * 8) = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.Kp + c8 * 8);
+        }
+        float as = p.ascale;
+        if (XMODE == MN_ACTQ_IAO) as = p.pro.qp[0];
+        for (int i = tid; i < MB; i += 256) {
+            const int m = mblk * MB + i;
+            rs[i] = p.rowscale ? p.rowscale[g * p.Mpad + m] * as : 1.f;
+            bs[i] = (p.bias && m < p.Mr) ? p.bias[g * p.Mr + m] : 0.f;
+        }
+        for (int i = tid; i < p.Kp; i += 256) ks[i] = p.kscale ? p.kscale[g * p.Kp + i] : 1.f;
+    }
+    __syncthreads();
+
+    float sc = 1.f, zp = 0.f;
+    if (XMODE == MN_ACTQ_IAO) { sc = p.pro.qp[0]; zp = p.pro.qp[1]; }
+    float ste_sc = 1.f, ste_zp = 0.f, ste_lo = 0.f, ste_hi = 0.f;
+    if (p.epi == QG_EPI_STE && p.ste.mode == MN_ACTQ_IAO) { ste_sc = p.ste.qp[0]; ste_zp = p.ste.qp[1]; ste_lo = p.ste.qp[2]; ste_hi = p.ste.qp[3]; }
+
+    const int chunk0 = cb * 4 + wave, cstride = p.CB * 4;
+    const int my_chunks = chunk0 < p.nchunks ? (p.nchunks - chunk0 + cstride - 1) / cstride : 0;
+    const int total = my_chunks * p.KS;
+    const uint16_t* wl = wsm + j * LDW + kg * 8;
+    const int64_t HW = p.HW;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](float (&raw)[8][4], int it) {
+        const uint32_t ci = fd_div((uint32_t)it, p.fd_ks);
+        const int s = it - (int)ci * p.KS;
+        const uint32_t P = (uint32_t)(chunk0 + (int)ci * cstride) * 64u + 4u * j;
+        const bool pv = P < p.NP;
+        const uint32_t n = fd_div(P, p.fd_hw);
+        const int pp = (int)(P - n * (uint32_t)p.HW);
+        const float* base = p.x + ((int64_t)n * p.Cin_total + (int64_t)g * p.Kc) * HW + pp;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int c = s * 32 + kg * 8 + jj;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv && c < p.Kc) v = *reinterpret_cast<const float4*>(base + (int64_t)c * HW);
+            raw[jj][0] = v.x; raw[jj][1] = v.y; raw[jj][2] = v.z; raw[jj][3] = v.w;
+        }
+    };
+
+    // one K-step: build the B fragments from the landed loads, re-issue the loads of the next step into the same registers
+    // (they fly during this step's LDS reads + MFMAs), contract, store at the end of a chunk
+    auto compute = [&](float (&raw)[8][4], int it) {
+        const uint32_t ci = fd_div((uint32_t)it, p.fd_ks);
+        const int s = it - (int)ci * p.KS;
+        u32x4 b0[4], b1[4], b2[4];
+        int use1 = 0, use2 = 0;
+        if (XMODE == MN_ACTQ_NONE) {
+            unsigned any1 = 0u, any2 = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t0[8], t1[8], t2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = raw[e][q];
+                    if (p.kscale) v = v * ks[s * 32 + kg * 8 + e];
+                    t0[e] = mn_bf16_head(v);
+                    const float r1 = v - t0[e];
+                    t1[e] = mn_bf16_head(r1);
+                    const float r2 = r1 - t1[e];
+                    t2[e] = r2;                            // <= 8 significant bits: its bf16 head is r2 itself
+                    any1 |= mn_f2u(r1) << 1;               // ignore the sign of a zero
+                    any2 |= mn_f2u(r2) << 1;
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    b0[q][d] = mn_pack_bf16x2(t0[2 * d], t0[2 * d + 1]);
+                    b1[q][d] = mn_pack_bf16x2(t1[2 * d], t1[2 * d + 1]);
+                    b2[q][d] = mn_pack_bf16x2(t2[2 * d], t2[2 * d + 1]);
+                }
+            }
+            use1 = mn_wave_any(any1 != 0u);
+            use2 = mn_wave_any(any2 != 0u);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float c8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c8[e] = act_code<XMODE>(raw[e][q], p.pro, sc, zp);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) b0[q][d] = mn_pack_bf16x2(c8[2 * d], c8[2 * d + 1]);
+            }
+        }
+        if (it + 1 < total) issue(raw, it + 1);
+        const uint16_t* wk = wl + s * 32;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(wk + t * 16 * LDW);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b0[q], acc[q][t]);
+            if (XMODE == MN_ACTQ_NONE) {
+                if (use1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b1[q], acc[q][t]);
+                }
+                if (use2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b2[q], acc[q][t]);
+                }
+            }
+        }
+        if (s == p.KS - 1) {
+            const uint32_t P = (uint32_t)(chunk0 + (int)ci * cstride) * 64u + 4u * j;
+            const uint32_t n = fd_div(P, p.fd_hw);
+            const int pp = (int)(P - n * (uint32_t)p.HW);
+            if (P < p.NP) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = t * 16 + kg * 4 + r;
+                        const int m = mblk * MB + ml;
+                        if (m < p.Mr) {
+                            const int64_t off = ((int64_t)n * p.Cout_total + (int64_t)g * p.Mr + m) * HW + pp;
+                            float o0 = acc[0][t][r], o1 = acc[1][t][r], o2 = acc[2][t][r], o3 = acc[3][t][r];
+                            if (p.epi == QG_EPI_SCALE_BIAS) {
+                                const float a_ = rs[ml], b_ = bs[ml];
+                                o0 = o0 * a_ + b_; o1 = o1 * a_ + b_; o2 = o2 * a_ + b_; o3 = o3 * a_ + b_;
+                            } else if (p.epi == QG_EPI_STE) {
+                                const float4 xv = *reinterpret_cast<const float4*>(p.aux + off);
+                                if (p.ste.mode == MN_ACTQ_DOREFA) {
+                                    o0 = dorefa_act_grad(o0, xv.x, p.ste.s); o1 = dorefa_act_grad(o1, xv.y, p.ste.s);
+                                    o2 = dorefa_act_grad(o2, xv.z, p.ste.s); o3 = dorefa_act_grad(o3, xv.w, p.ste.s);
+                                } else if (p.ste.mode == MN_ACTQ_IAO) {
+                                    o0 = iao_fq_grad(o0, xv.x, ste_sc, ste_zp, ste_lo, ste_hi, p.ste.qmin, p.ste.qmax);
+                                    o1 = iao_fq_grad(o1, xv.y, ste_sc, ste_zp, ste_lo, ste_hi, p.ste.qmin, p.ste.qmax);
+                                    o2 = iao_fq_grad(o2, xv.z, ste_sc, ste_zp, ste_lo, ste_hi, p.ste.qmin, p.ste.qmax);
+                                    o3 = iao_fq_grad(o3, xv.w, ste_sc, ste_zp, ste_lo, ste_hi, p.ste.qmin, p.ste.qmax);
+                                }
+                            }
+                            *reinterpret_cast<float4*>(p.y + off) = make_float4(o0, o1, o2, o3);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    float ra[8][4];
+    if (total > 0) issue(ra, 0);
+    for (int it = 0; it < total; ++it) compute(ra, it);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pointwise backward-weight: dwq[g][m][c] = sum_{n,p} gy[n][g*Mg+m][p] * code_a[n][g*Cg+c][p]   (times the activation scale)
+struct PwWgParams {
+    const float* gy;
+    const float* x;
+    float* part;     // [Z][G][Mgw][Cgw]
+    float* dbpart;   // [Z][G][Mgw]
+    Pro pro;
+    int N, HW, Cin_total, Cout_total, Cg, Mg, G;
+    int nmb, ncb, Z, nchunks, Mgw, Cgw, want_db;
+    uint32_t NP;
+    FastDiv fd_hw;
+};
+#define WG_LDP 72   // u16 per LDS row: 64 pixels + 8 pad -> 144 B rows, the 16 rows of a b128 fragment read hit all 64 banks
+
+template <int MW, int CW, int WGC, int XMODE>
+__global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int WGM = 4 / WGC, TM = 16 * MW * WGM, TC = 16 * CW * WGC, RM = TM / 16, RC = TC / 16;
+    uint16_t* gt = reinterpret_cast<uint16_t*>(smem);        // [3][TM][WG_LDP]
+    uint16_t* xq = gt + 3 * TM * WG_LDP;                     // [TC][WG_LDP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const int r0 = tid >> 4, qd = tid & 15;
+    uint32_t b = blockIdx.x;
+    const int z = b % p.Z; b /= p.Z;
+    const int cb = b % p.ncb; b /= p.ncb;
+    const int mb = b % p.nmb;
+    const int g = b / p.nmb;
+    const int wm = wave / WGC, wc = wave % WGC;
+    const int64_t HW = p.HW;
+    float sc = 1.f, zp = 0.f;
+    if (XMODE == MN_ACTQ_IAO) { sc = p.pro.qp[0]; zp = p.pro.qp[1]; }
+
+    f32x4 acc[MW][CW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbacc[RM];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) dbacc[i] = 0.f;
+
+    float4 rg[RM], rx[RC];
+    auto fetch = [&](int chunk) {
+        const uint32_t P = (uint32_t)chunk * 64u + 4u * qd;
+        const bool pv = P < p.NP;
+        const uint32_t n = fd_div(P, p.fd_hw);
+        const int pp = (int)(P - n * (uint32_t)p.HW);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            const int m = mb * TM + r0 + 16 * i;
+            rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv && m < p.Mg) rg[i] = *reinterpret_cast<const float4*>(p.gy + ((int64_t)n * p.Cout_total + (int64_t)g * p.Mg + m) * HW + pp);
+        }
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const int c = cb * TC + r0 + 16 * i;
+            rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv && c < p.Cg) rx[i] = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.Cin_total + (int64_t)g * p.Cg + c) * HW + pp);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            const float v[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
+            float t0[4], t1[4], t2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t0[e] = mn_bf16_head(v[e]);
+                const float r1 = v[e] - t0[e];
+                t1[e] = mn_bf16_head(r1);
+                t2[e] = r1 - t1[e];
+            }
+            dbacc[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            uint16_t* d = gt + (r0 + 16 * i) * WG_LDP + qd * 4;
+            *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
+            *reinterpret_cast<u32x2*>(d + TM * WG_LDP) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
+            *reinterpret_cast<u32x2*>(d + 2 * TM * WG_LDP) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
+        }
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const float c0 = act_code<XMODE>(rx[i].x, p.pro, sc, zp), c1 = act_code<XMODE>(rx[i].y, p.pro, sc, zp);
+            const float c2 = act_code<XMODE>(rx[i].z, p.pro, sc, zp), c3 = act_code<XMODE>(rx[i].w, p.pro, sc, zp);
+            *reinterpret_cast<u32x2*>(xq + (r0 + 16 * i) * WG_LDP + qd * 4) = u32x2{mn_pack_bf16x2(c0, c1), mn_pack_bf16x2(c2, c3)};
+        }
+    };
+
+    // MFMA phase over the slab currently in LDS: 3 gy terms x the x plane
+    auto contract = [&]() {
+#pragma unroll
+        for (int ksx = 0; ksx < 2; ++ksx) {
+            const int ko = ksx * 32 + kg * 8;
+            u32x4 bf[CW];
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) bf[ci] = *reinterpret_cast<const u32x4*>(xq + ((wc * CW + ci) * 16 + j) * WG_LDP + ko);
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi) {
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(gt + (term * TM + (wm * MW + mi) * 16 + j) * WG_LDP + ko);
+#pragma unroll
+                    for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a, bf[ci], acc[mi][ci]);
+                }
+            }
+        }
+    };
+    // XMODE NONE only: x is an arbitrary float tensor.  The slab is contracted with the bf16 head of x (exact when x holds
+    // small integers such as the +-1 of BinaryActivation); if any element of the slab has a remainder, the x plane is
+    // re-staged with the second and third term of the split and contracted again -- exact for any fp32 input.
+    int* xflag = reinterpret_cast<int*>(xq + TC * WG_LDP);   // [2], alternating per slab
+    auto restage_x_term = [&](int chunk, int term) {
+        const uint32_t P = (uint32_t)chunk * 64u + 4u * qd;
+        const bool pv = P < p.NP;
+        const uint32_t n = fd_div(P, p.fd_hw);
+        const int pp = (int)(P - n * (uint32_t)p.HW);
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const int c = cb * TC + r0 + 16 * i;
+            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv && c < p.Cg) v4 = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.Cin_total + (int64_t)g * p.Cg + c) * HW + pp);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float r = v[e] - mn_bf16_head(v[e]);
+                if (term == 2) r = r - mn_bf16_head(r);
+                v[e] = r;
+            }
+            *reinterpret_cast<u32x2*>(xq + (r0 + 16 * i) * WG_LDP + qd * 4) = u32x2{mn_pack_bf16x2(v[0], v[1]), mn_pack_bf16x2(v[2], v[3])};
+        }
+    };
+
+    int chunk = z, par = 0;
+    if (XMODE == MN_ACTQ_NONE && tid < 2) xflag[tid] = 0;
+    if (chunk < p.nchunks) fetch(chunk);
+    for (; chunk < p.nchunks; chunk += p.Z, par ^= 1) {
+        __syncthreads();          // previous slab fully consumed
+        if (XMODE == MN_ACTQ_NONE) {
+            unsigned inx = 0u;
+#pragma unroll
+            for (int i = 0; i < RC; ++i)
+                inx |= (mn_f2u(rx[i].x - mn_bf16_head(rx[i].x)) | mn_f2u(rx[i].y - mn_bf16_head(rx[i].y)) |
+                        mn_f2u(rx[i].z - mn_bf16_head(rx[i].z)) | mn_f2u(rx[i].w - mn_bf16_head(rx[i].w))) << 1;
+            if (inx) xflag[par] = 1;
+        }
+        commit();
+        __syncthreads();
+        const int inexact = (XMODE == MN_ACTQ_NONE) ? xflag[par] : 0;
+        if (XMODE == MN_ACTQ_NONE && tid == 0) xflag[par ^ 1] = 0;
+        if (chunk + p.Z < p.nchunks) fetch(chunk + p.Z);     // in flight during the MFMA phase
+        contract();
+        if (inexact) {            // block-uniform
+            for (int term = 1; term <= 2; ++term) {
+                __syncthreads();
+                restage_x_term(chunk, term);
+                __syncthreads();
+                contract();
+            }
+        }
+    }
+    // partial tile: lane (j, kg) holds rows m = 4kg + r, column c = j
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) {
+            const int mrow = mb * TM + (wm * MW + mi) * 16 + kg * 4;
+            const int ccol = cb * TC + (wc * CW + ci) * 16 + j;
+            float* dst = p.part + (((int64_t)z * p.G + g) * p.Mgw + mrow) * p.Cgw + ccol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.Cgw] = acc[mi][ci][r];
+        }
+    if (p.want_db && cb == 0) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            float v = dbacc[i];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            if (qd == 0) p.dbpart[((int64_t)z * p.G + g) * p.Mgw + mb * TM + r0 + 16 * i] = v;
+        }
+    }
+}
+// fixed-order reduction of the Z partial tiles (fp64 accumulate, one rounding), times the activation scale
+__global__ __launch_bounds__(256) void k_pw_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
+                                                         float* __restrict__ db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
+                                                         float ascale, const float* __restrict__ qp) {
+    const float as = qp ? qp[0] : ascale;
+    const int64_t nw = (int64_t)G * Mg * Cg, total = nw + (db ? (int64_t)G * Mg : 0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nw) {
+            const int c = (int)(i % Cg);
+            const int64_t o = i / Cg;
+            const int g = (int)(o / Mg), m = (int)(o % Mg);
+            double s = 0.0;
+            for (int z = 0; z < Z; ++z) s += (double)part[(((int64_t)z * G + g) * Mgw + m) * Cgw + c];
+            dw[i] = (float)s * as;
+        } else {
+            const int64_t o = i - nw;
+            const int g = (int)(o / Mg), m = (int)(o % Mg);
+            double s = 0.0;
+            for (int z = 0; z < Z; ++z) s += (double)dbpart[((int64_t)z * G + g) * Mgw + m];
+            db[o] = (float)s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static const size_t QG_LDS_CAP = 64 * 1024;
+
+static int pw_geom_ok(const mn_conv_geom* g) {
+    if (g->KH != 1 || g->KW != 1 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 0 || g->pad_w != 0) return 0;
+    const int64_t HW = (int64_t)g->H * g->W, NP = (int64_t)g->N * HW;
+    if (HW % 4) return 0;
+    if (NP * HW >= ((int64_t)1 << 32) || NP + 256 >= ((int64_t)1 << 31)) return 0;   // FastDiv range
+    return 1;
+}
+static int aq_codeable(const mn_actq* aq, int need_exact_x) {
+    (void)need_exact_x;   // real-valued x is handled exactly by term splitting (zero terms are skipped)
+    if (!aq || aq->mode == MN_ACTQ_NONE) return 1;
+    if (aq->mode == MN_ACTQ_DOREFA) return aq->bits >= 2 && aq->bits <= 8;
+    if (aq->mode == MN_ACTQ_IAO) return aq->bits >= 2 && aq->bits <= 8 && aq->q_type == 0 && aq->qp;
+    return 0;
+}
+static int wq_codeable(const mn_wq* wq) {
+    if (!wq) return 0;
+    if (wq->mode == MN_WQ_TERNARY) return 1;
+    if (wq->mode == MN_WQ_DOREFA) return wq->bits >= 2 && wq->bits <= 8;
+    if (wq->mode == MN_WQ_IAO) return wq->bits >= 2 && wq->bits <= 8 && wq->q_type == 0 && wq->scale;
+    return 0;
+}
+
+struct PwPlan {
+    PwParams p;
+    PackParams pk;
+    int NT;
+    size_t lds;
+    int grid, pack_grid;
+    int64_t off_codes, off_scale, ws_bytes;
+};
+static int plan_pw(const mn_conv_geom* g, int which, int xmode, PwPlan* pl) {
+    if (!pw_geom_ok(g)) return 0;
+    const int Cg = g->C / g->groups, Mg = g->O / g->groups;
+    PwParams& p = pl->p;
+    p.N = g->N; p.HW = g->H * g->W; p.G = g->groups;
+    p.NP = (uint32_t)((int64_t)g->N * p.HW);
+    if (which == 0) { p.Cin_total = g->C; p.Cout_total = g->O; p.Kc = Cg; p.Mr = Mg; }
+    else { p.Cin_total = g->O; p.Cout_total = g->C; p.Kc = Mg; p.Mr = Cg; }
+    p.Kp = qg_roundup(p.Kc, 32);
+    p.KS = p.Kp / 32;
+    int NT = p.Mr > 64 ? 8 : (p.Mr > 32 ? 4 : (p.Mr > 16 ? 2 : 1));
+    (void)xmode;
+    if (NT > 4) NT = 4;   // 64 accumulator VGPRs: two waves per SIMD without spills (NT = 8 spills at 256 VGPRs); the second m-block
+                          // of a 128-channel group re-reads x through the XCD's L2 (same-XCD block placement, see k_pw)
+    size_t lds;
+    for (;;) {
+        lds = (size_t)16 * NT * (p.Kp + 8) * 2 + ((size_t)2 * 16 * NT + p.Kp) * 4;
+        if (lds <= QG_LDS_CAP) break;
+        if (NT == 1) return 0;
+        NT /= 2;
+    }
+    pl->NT = NT; pl->lds = lds;
+    p.num_mblk = (p.Mr + 16 * NT - 1) / (16 * NT);
+    p.Mpad = p.num_mblk * 16 * NT;
+    p.nchunks = (int)((p.NP + 63) / 64);
+    int CB = (p.nchunks + 3) / 4;
+    const int cap = 1024 / (p.G * p.num_mblk) > 0 ? 1024 / (p.G * p.num_mblk) : 1;
+    if (CB > cap) CB = cap;
+    p.CB = CB;
+    p.fd_hw = make_fastdiv((uint32_t)p.HW);
+    p.fd_ks = make_fastdiv((uint32_t)p.KS);
+    const int64_t nb = (int64_t)qg_roundup(p.G * CB, 8) * p.num_mblk;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    // workspace: codes [G][Mpad][Kp] u16, then per-channel scale floats
+    pl->off_codes = 0;
+    const int64_t code_bytes = (int64_t)p.G * p.Mpad * p.Kp * 2;
+    pl->off_scale = (code_bytes + 255) / 256 * 256;
+    const int64_t nscale = which == 0 ? (int64_t)p.G * p.Mpad : (int64_t)p.G * p.Kp;
+    pl->ws_bytes = pl->off_scale + nscale * 4;
+    PackParams& k = pl->pk;
+    k.G = g->groups; k.Mg = Mg; k.Cg = Cg; k.T = 1; k.KW = 1; k.transpose = which == 1;
+    k.Mpad = which == 0 ? p.Mpad : 0; k.Cgp = which == 0 ? p.Kp : 0;
+    k.Cpad = which == 1 ? p.Mpad : 0; k.Mgp = which == 1 ? p.Kp : 0;
+    pl->pack_grid = k.G * (which == 0 ? k.Mpad : k.Mgp);
+    return 1;
+}
+
+struct WgPlan {
+    PwWgParams p;
+    int cfg;          // 0: 128x128  1: 16x128  2: 128x16  3: 64x64
+    size_t lds;
+    int grid;
+    int64_t off_db, ws_bytes;
+};
+static int plan_pw_wgrad(const mn_conv_geom* g, WgPlan* pl) {
+    if (!pw_geom_ok(g)) return 0;
+    const int Cg = g->C / g->groups, Mg = g->O / g->groups;
+    PwWgParams& p = pl->p;
+    p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.Cin_total = g->C; p.Cout_total = g->O; p.Cg = Cg; p.Mg = Mg;
+    p.NP = (uint32_t)((int64_t)g->N * p.HW);
+    int TM, TC;
+    if (Mg <= 16) { pl->cfg = 1; TM = 16; TC = 128; }
+    else if (Cg <= 16) { pl->cfg = 2; TM = 128; TC = 16; }
+    else if (Mg <= 64 && Cg <= 64) { pl->cfg = 3; TM = 64; TC = 64; }
+    else { pl->cfg = 0; TM = 128; TC = 128; }
+    pl->lds = (size_t)(3 * TM + TC) * WG_LDP * 2 + 16;   // + the two exactness flags of the real-x path
+    p.nmb = (Mg + TM - 1) / TM; p.ncb = (Cg + TC - 1) / TC;
+    p.Mgw = p.nmb * TM; p.Cgw = p.ncb * TC;
+    p.nchunks = (int)((p.NP + 63) / 64);
+    const int base = p.G * p.nmb * p.ncb;
+    int Z = 512 / base;
+    if (Z > p.nchunks / 4) Z = p.nchunks / 4;
+    if (Z < 1) Z = 1;
+    p.Z = Z;
+    p.fd_hw = make_fastdiv((uint32_t)p.HW);
+    const int64_t nb = (int64_t)base * Z;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    const int64_t part_bytes = (int64_t)Z * p.G * p.Mgw * p.Cgw * 4;
+    pl->off_db = (part_bytes + 255) / 256 * 256;
+    pl->ws_bytes = pl->off_db + (int64_t)Z * p.G * p.Mgw * 4;
+    return 1;
+}
+
+int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
+    if (which == 0) { PwPlan pl; return wq_codeable(wq) && aq_codeable(aq, 0) && plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl); }
+    if (which == 1) { PwPlan pl; return wq_codeable(wq) && plan_pw(g, 1, MN_ACTQ_NONE, &pl); }
+    if (which == 2) { WgPlan pl; return aq_codeable(aq, 1) && plan_pw_wgrad(g, &pl); }
+    return 0;
+}
+int64_t qg_ws_bytes(const mn_conv_geom* g, int which) {
+    if (which == 0 || which == 1) { PwPlan pl; return plan_pw(g, which, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0; }   // NT <= 4: the larger Mpad
+    if (which == 2) { WgPlan pl; return plan_pw_wgrad(g, &pl) ? pl.ws_bytes : 0; }
+    return 0;
+}
+
+static void raise_lds_limit(const void* fn, size_t bytes) {
+#ifndef MN_EMULATION
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+#else
+    (void)fn; (void)bytes;
+#endif
+}
+template <int NT>
+static void launch_pw(const PwPlan& pl, int xmode, hipStream_t s) {
+    if (xmode == MN_ACTQ_DOREFA) hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_DOREFA>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    else if (xmode == MN_ACTQ_IAO) hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_IAO>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    else hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+}
+static int run_pw(PwPlan& pl, int xmode, hipStream_t s, const char* what) {
+    switch (pl.NT) {
+        case 1: launch_pw<1>(pl, xmode, s); break;
+        case 2: launch_pw<2>(pl, xmode, s); break;
+        case 4: launch_pw<4>(pl, xmode, s); break;
+        default: MN_FAIL(MN_EINVAL, "%s: bad NT", what);
+    }
+    MN_CHECK_LAUNCH(what);
+    return MN_OK;
+}
+static void fill_pack(PackParams& k, const mn_wq* wq, const float* w, void* ws, int64_t off_codes, int64_t off_scale) {
+    k.w = w; k.codes = (uint16_t*)((char*)ws + off_codes); k.scale_out = (float*)((char*)ws + off_scale);
+    k.mode = wq->mode; k.bits = wq->bits > 0 ? wq->bits : 8; k.per_channel = wq->per_channel; k.scale_in = wq->scale;
+}
+
+int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y,
+           void* ws, int64_t ws_bytes, hipStream_t s) {
+    PwPlan pl;
+    if (!wq_codeable(wq) || !aq_codeable(aq, 0) || !plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl) || !aligned16(x) || !aligned16(y))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(qgemm): geometry / quantizer combination not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(qgemm): workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)pl.ws_bytes);
+    Pro pro;
+    int rc = make_pro(aq, &pro, 0, "mn_conv2d_fwd(qgemm)");
+    if (rc) return rc;
+    fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
+    hipLaunchKernelGGL(k_qg_pack, dim3(pl.pack_grid), dim3(64), 0, s, pl.pk);
+    PwParams& p = pl.p;
+    p.x = x; p.y = y; p.wc = pl.pk.codes; p.rowscale = pl.pk.scale_out; p.kscale = nullptr; p.bias = bias; p.aux = nullptr;
+    p.pro = pro; p.ste = pro; p.epi = QG_EPI_SCALE_BIAS;
+    p.ascale = pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f;
+    return run_pw(pl, pro.mode, s, "mn_conv2d_fwd(qgemm)");
+}
+
+int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
+                void* ws, int64_t ws_bytes, hipStream_t s) {
+    PwPlan pl;
+    if (!wq_codeable(wq) || !plan_pw(g, 1, MN_ACTQ_NONE, &pl) || !aligned16(gy) || !aligned16(dx))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(qgemm): geometry / quantizer combination not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data(qgemm): workspace too small");
+    Pro ste;
+    int rc = make_pro(aq, &ste, 1, "mn_conv2d_bwd_data(qgemm)");
+    if (rc) return rc;
+    if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
+    fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
+    hipLaunchKernelGGL(k_qg_pack, dim3(pl.pack_grid), dim3(64), 0, s, pl.pk);
+    Pro none; none.mode = MN_ACTQ_NONE; none.s = 1.f; none.qmin = none.qmax = 0.f; none.qp = nullptr;
+    PwParams& p = pl.p;
+    p.x = gy; p.y = dx; p.wc = pl.pk.codes; p.rowscale = nullptr; p.kscale = pl.pk.scale_out; p.bias = nullptr; p.aux = x;
+    p.pro = none; p.ste = ste; p.epi = ste.mode == MN_ACTQ_NONE ? QG_EPI_PLAIN : QG_EPI_STE; p.ascale = 1.f;
+    return run_pw(pl, MN_ACTQ_NONE, s, "mn_conv2d_bwd_data(qgemm)");
+}
+
+template <int MW, int CW, int WGC>
+static void launch_wg(const WgPlan& pl, int xmode, hipStream_t s) {
+    if (xmode == MN_ACTQ_DOREFA) {
+        raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_DOREFA>, pl.lds);
+        hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_DOREFA>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else if (xmode == MN_ACTQ_IAO) {
+        raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_IAO>, pl.lds);
+        hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_IAO>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else {
+        raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_NONE>, pl.lds);
+        hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    }
+}
+int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
+                  int64_t ws_bytes, hipStream_t s) {
+    WgPlan pl;
+    if (!aq_codeable(aq, 1) || !plan_pw_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(qgemm): geometry / quantizer combination not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(qgemm): workspace too small");
+    Pro pro;
+    int rc = make_pro(aq, &pro, 0, "mn_conv2d_bwd_weight(qgemm)");
+    if (rc) return rc;
+    PwWgParams& p = pl.p;
+    p.gy = gy; p.x = x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.pro = pro; p.want_db = dbias != nullptr;
+    switch (pl.cfg) {
+        case 0: launch_wg<4, 4, 2>(pl, pro.mode, s); break;
+        case 1: launch_wg<1, 2, 4>(pl, pro.mode, s); break;
+        case 2: launch_wg<2, 1, 1>(pl, pro.mode, s); break;
+        default: launch_wg<2, 2, 2>(pl, pro.mode, s); break;
+    }
+    const int64_t total = (int64_t)g->O * (g->C / g->groups) + (dbias ? g->O : 0);
+    hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(mn_grid_for(total, 256, 2048)), dim3(256), 0, s, (const float*)p.part, (const float*)p.dbpart, dw,
+                       dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f,
+                       pro.mode == MN_ACTQ_IAO ? pro.qp : (const float*)nullptr);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(qgemm)");
+    return MN_OK;
+}

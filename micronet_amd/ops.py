@@ -21,11 +21,12 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from ._lib import ActQ, ConvGeom, MicronetHipError
+from ._lib import ActQ, ConvGeom, MicronetHipError, WQ
 
 ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO
+WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _lib.MN_WQ_DOREFA, _lib.MN_WQ_IAO
 
-# algorithm used by the conv entry points; tests flip it to compare kernels (0 auto, 1 direct VALU, 2 MFMA only)
+# algorithm used by the conv entry points; tests flip it to compare kernels (0 auto, 1 direct VALU, 2 fp32-MFMA only, 3 code-domain bf16-MFMA only)
 CONV_ALGO = _lib.MN_ALGO_AUTO
 
 
@@ -324,58 +325,76 @@ def _ws(g, which, device):
     return torch.empty(max(nb // 4, 4), dtype=torch.float32, device=device), nb
 
 
+def _wq_desc(wdesc):
+    """wdesc = None | (mode, bits, q_type, per_channel, scale_tensor) -> (ctypes struct or None, keep-alive)"""
+    if wdesc is None:
+        return None
+    mode, bits, q_type, per_channel, scale = wdesc
+    return WQ(mode, bits, q_type, per_channel, scale.data_ptr() if scale is not None else None)
+
+
+def _ref(d):
+    return None if d is None else C.byref(d)
+
+
 class QConv2d(Function):
     """y = conv2d(actq(x), wq, bias): the activation quantizer runs inside the conv kernels' prologue, its clip-STE in the
-    backward-data epilogue; ``wq`` is the already fake-quantised weight (its own Function supplies d wq / d w)."""
+    backward-data epilogue; ``wq`` is the already fake-quantised weight (its own Function supplies d wq / d w);
+    ``wdesc`` tells the code-domain kernels how wq factors into integer codes x scale (None: arbitrary fp32 weights)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp):
+    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc, aq_flags):
         x, wq, bias = _chk(x, "input"), _chk(wq, "weight"), _chk(bias, "bias")
         if x.dim() != 4 or wq.dim() != 4 or x.shape[1] != wq.shape[1] * groups:
             raise MicronetHipError("conv2d shape mismatch: input %s weight %s groups %d" % (tuple(x.shape), tuple(wq.shape), groups))
         g = _geom(x.shape, wq.shape, stride, padding, dilation, groups)
         Ho, Wo = _out_hw(g)
         y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
-        aq = ActQ(aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
+        aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
+        wd = _wq_desc(wdesc)
         with torch.cuda.device_of(x):
             ws, nb = _ws(g, 0, x.device)
             with _span(g, 0, 4 * (x.numel() + y.numel() + wq.numel())):
-                _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _p(x), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
-        ctx.save_for_backward(x, wq, qp)
-        ctx.cfg = (g, aq_mode, aq_bits, aq_qtype, bias is not None)
+                _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _ref(wd), _p(x), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
+        wscale = wdesc[4] if wdesc is not None else None
+        ctx.save_for_backward(x, wq, qp, wscale)
+        ctx.cfg = (g, aq_mode, aq_bits, aq_qtype, bias is not None, wdesc[:4] if wdesc is not None else None, aq_flags)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, wq, qp = ctx.saved_tensors
-        g, aq_mode, aq_bits, aq_qtype, has_bias = ctx.cfg
+        x, wq, qp, wscale = ctx.saved_tensors
+        g, aq_mode, aq_bits, aq_qtype, has_bias, wd4, aq_flags = ctx.cfg
         gy = _chk(gy, "grad")
-        aq = ActQ(aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
+        aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
+        wd = _wq_desc(wd4 + (wscale,)) if wd4 is not None else None
         dx = dw = db = None
         with torch.cuda.device_of(x):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 ws, nb = _ws(g, 1, x.device)
                 with _span(g, 1, 4 * (gy.numel() + dx.numel() + wq.numel() + (x.numel() if aq_mode != ACTQ_NONE else 0))):
-                    _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), _p(gy), _p(wq), _p(x), _p(dx), _p(ws), nb, CONV_ALGO, _s())
+                    _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), _ref(wd), _p(gy), _p(wq), _p(x), _p(dx), _p(ws), nb, CONV_ALGO, _s())
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(wq)
                 db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
                 ws, nb = _ws(g, 2, x.device)
                 with _span(g, 2, 4 * (gy.numel() + x.numel() + dw.numel())):
                     _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
-def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None):
-    return QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp)
+def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None,
+            wdesc=None, x_is_code=False):
+    return QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc,
+                         _lib.MN_ACTQ_X_IS_CODE if x_is_code else 0)
 
 
-def qlinear(x, wq, bias, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None):
+def qlinear(x, wq, bias, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None, wdesc=None):
     """F.linear as a 1x1 convolution over 1x1 'images' (same kernels, same fused quantizer)."""
     lead = x.shape[:-1]
     x4 = x.reshape(-1, x.shape[-1], 1, 1)
-    y = QConv2d.apply(x4, wq.reshape(wq.shape[0], wq.shape[1], 1, 1), bias, 1, 0, 1, 1, aq_mode, aq_bits, aq_qtype, qp)
+    y = QConv2d.apply(x4, wq.reshape(wq.shape[0], wq.shape[1], 1, 1), bias, 1, 0, 1, 1, aq_mode, aq_bits, aq_qtype, qp, wdesc, 0)
     return y.reshape(*lead, wq.shape[0])
 
 
@@ -396,7 +415,7 @@ class ConvTranspose2d(Function):
         none = ActQ(ACTQ_NONE, 0, 0, 0, None)
         with torch.cuda.device_of(x):
             ws, nb = _ws(g, 1, x.device)
-            _call("mn_conv2d_bwd_data", C.byref(g), C.byref(none), _p(x), _p(w), None, _p(y), _p(ws), nb, CONV_ALGO, _s())
+            _call("mn_conv2d_bwd_data", C.byref(g), C.byref(none), None, _p(x), _p(w), None, _p(y), _p(ws), nb, CONV_ALGO, _s())
         if bias is not None:
             y += bias.view(1, -1, 1, 1)
         ctx.save_for_backward(x, w)
@@ -414,7 +433,7 @@ class ConvTranspose2d(Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 ws, nb = _ws(g, 0, x.device)
-                _call("mn_conv2d_fwd", C.byref(g), C.byref(none), _p(gy), _p(w), None, _p(dx), _p(ws), nb, CONV_ALGO, _s())
+                _call("mn_conv2d_fwd", C.byref(g), C.byref(none), None, _p(gy), _p(w), None, _p(dx), _p(ws), nb, CONV_ALGO, _s())
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(w)
                 ws, nb = _ws(g, 2, x.device)

@@ -107,7 +107,10 @@ class QuantConv2d(nn.Conv2d):
 
     def forward(self, input):
         tnn_bin_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
-        return ops.qconv2d(input, tnn_bin_weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        # binary / ternary weights are t * alpha[o]: the conv contracts the integer codes t on the bf16 matrix cores
+        coded = (not self.quant_inference) and self.weight_quantizer.W in (2, 3)
+        return ops.qconv2d(input, tnn_bin_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
+                           wdesc=(ops.WQ_TERNARY, 0, 0, 0, None) if coded else None)
 
 
 class QuantConvTranspose2d(nn.ConvTranspose2d):

@@ -67,6 +67,12 @@ class WeightQuantizer(nn.Module):
         return ops.DorefaWeight.apply(input, self.w_bits)
 
 
+def _wdesc(module):
+    """weight-code descriptor for the code-domain conv kernels: w = (2k - n)/n, n = 2^w_bits - 1"""
+    b = module.weight_quantizer.w_bits
+    return (ops.WQ_DOREFA, b, 0, 0, None) if (not module.quant_inference and 2 <= b <= 8) else None
+
+
 def _aq_args(quantizer):
     """(mode, bits) of the activation quantizer fused into the conv kernels."""
     if quantizer.a_bits == 32:
@@ -88,7 +94,7 @@ class QuantConv2d(nn.Conv2d):
         mode, bits = _aq_args(self.activation_quantizer)
         # like the reference, the forward always zero-pads whatever padding_mode says (ref 113-121)
         return ops.qconv2d(input, quant_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
-                           aq_mode=mode, aq_bits=bits)
+                           aq_mode=mode, aq_bits=bits, wdesc=_wdesc(self))
 
 
 class QuantConvTranspose2d(nn.ConvTranspose2d):
@@ -117,7 +123,7 @@ class QuantLinear(nn.Linear):
     def forward(self, input):
         quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
         mode, bits = _aq_args(self.activation_quantizer)
-        return ops.qlinear(input, quant_weight, self.bias, aq_mode=mode, aq_bits=bits)
+        return ops.qlinear(input, quant_weight, self.bias, aq_mode=mode, aq_bits=bits, wdesc=_wdesc(self))
 
 
 def _swap_conv(child, cls, **kw):

@@ -171,6 +171,7 @@ class Quantizer(nn.Module):
 
     def forward(self, input):
         qp = self.qparams(input)
+        self._last_qp = qp        # snapshot {scale, zp, lo, hi} of THIS call (python attribute, not in the state_dict)
         if qp is None:
             return input
         return ops.IaoFakeQuant.apply(input, qp, self.bits, self.q_type, self.activation_weight_flag == 1)
@@ -229,6 +230,15 @@ def _weight_quantizer(w_bits, q_type, q_level, weight_observer, out_channels, ch
     return cls(bits=w_bits, observer=observer, activation_weight_flag=0, qaft=qaft)
 
 
+def _wdesc(weight_quantizer, quantized):
+    """weight-code descriptor for the code-domain conv kernels: w = code * scale[o], scale = column 0 of the qparams snapshot
+    the weight quantizer used in this forward (stride 4 floats per channel, 0 for per-layer)."""
+    qp = getattr(weight_quantizer, "_last_qp", None)
+    if not quantized or qp is None or not (2 <= weight_quantizer.bits <= 8) or weight_quantizer.q_type != 0:
+        return None
+    return (ops.WQ_IAO, weight_quantizer.bits, 0, 4 if qp.shape[0] > 1 else 0, qp)
+
+
 def _fused_aq(quantizer, input):
     """(mode, bits, q_type, qp) for the activation quantizer fused into the conv kernels."""
     qp = quantizer.qparams(input)
@@ -247,15 +257,15 @@ class QuantConv2d(nn.Conv2d):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
         self.weight_quantizer = _weight_quantizer(w_bits, q_type, q_level, weight_observer, out_channels, "C", qaft, ptq)
 
-    def _qconv(self, input, weight, bias):
+    def _qconv(self, input, weight, bias, quantized=True):
         mode, bits, q_type, qp = _fused_aq(self.activation_quantizer, input)
         return ops.qconv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups,
-                           aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp)
+                           aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp, wdesc=_wdesc(self.weight_quantizer, quantized))
 
     def forward(self, input):
         # (the reference quantises the input first; the two quantizers are independent, order is immaterial)
         quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
-        return self._qconv(input, quant_weight, self.bias)
+        return self._qconv(input, quant_weight, self.bias, quantized=not self.quant_inference)
 
 
 class QuantConvTranspose2d(nn.ConvTranspose2d):
@@ -358,7 +368,8 @@ class QuantLinear(nn.Linear):
     def forward(self, input):
         quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
         mode, bits, q_type, qp = _fused_aq(self.activation_quantizer, input)
-        return ops.qlinear(input, quant_weight, self.bias, aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp)
+        return ops.qlinear(input, quant_weight, self.bias, aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp,
+                           wdesc=_wdesc(self.weight_quantizer, not self.quant_inference))
 
 
 # ------------------------------------------------------------------------------------------------ quantised non-conv ops

@@ -75,24 +75,28 @@ class Backend:
         (sh, sw), (ph, pw), (dh, dw) = p2(stride), p2(padding), p2(dilation)
         return _lib.ConvGeom(N, Cc, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw, groups)
 
-    def actq(self, mode=0, bits=8, q_type=0, qp=None):
+    def actq(self, mode=0, bits=8, q_type=0, qp=None, flags=0):
         self._qp_keep = qp
-        return _lib.ActQ(mode, bits, q_type, 0, self.ptr(qp).value if qp is not None else None)
+        return _lib.ActQ(mode, bits, q_type, flags, self.ptr(qp).value if qp is not None else None)
 
-    def conv_fwd(self, g, aq, x, w, b, algo):
+    def wq(self, mode=0, bits=8, q_type=0, per_channel=0, scale=None):
+        self._ws_keep = scale
+        return _lib.WQ(mode, bits, q_type, per_channel, self.ptr(scale).value if scale is not None else None)
+
+    def conv_fwd(self, g, aq, x, w, b, algo, wq=None):
         Ho = (g.H + 2 * g.pad_h - g.dil_h * (g.KH - 1) - 1) // g.stride_h + 1
         Wo = (g.W + 2 * g.pad_w - g.dil_w * (g.KW - 1) - 1) // g.stride_w + 1
         y = self.empty((g.N, g.O, Ho, Wo))
         nb = self.lib.mn_conv2d_ws_bytes(C.byref(g), 0, algo)
         ws = self.empty(max(4, nb // 4 + 4))
-        self.call("mn_conv2d_fwd", C.byref(g), C.byref(aq), self.ptr(x), self.ptr(w), self.ptr(b), self.ptr(y), self.ptr(ws), nb, algo, self.stream)
+        self.call("mn_conv2d_fwd", C.byref(g), C.byref(aq), C.byref(wq) if wq is not None else None, self.ptr(x), self.ptr(w), self.ptr(b), self.ptr(y), self.ptr(ws), nb, algo, self.stream)
         return y
 
-    def conv_bwd_data(self, g, aq, gy, w, x, algo):
+    def conv_bwd_data(self, g, aq, gy, w, x, algo, wq=None):
         dx = self.empty((g.N, g.C, g.H, g.W))
         nb = self.lib.mn_conv2d_ws_bytes(C.byref(g), 1, algo)
         ws = self.empty(max(4, nb // 4 + 4))
-        self.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), self.ptr(gy), self.ptr(w), self.ptr(x), self.ptr(dx), self.ptr(ws), nb, algo, self.stream)
+        self.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq) if wq is not None else None, self.ptr(gy), self.ptr(w), self.ptr(x), self.ptr(dx), self.ptr(ws), nb, algo, self.stream)
         return dx
 
     def conv_bwd_weight(self, g, aq, gy, x, algo, bias=True):

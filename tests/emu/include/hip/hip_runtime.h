@@ -69,6 +69,8 @@ struct Ctx {
     double xd[64 * 8];  // up to 8 waves x 64 lanes (reallocated as needed)
     std::vector<double> wbuf;
     std::vector<float> wa, wb;
+    std::vector<float> wa8, wb8;   // bf16 MFMA operands, 8 per lane
+    std::vector<int> wflag;
 };
 inline Ctx& C() { static Ctx c; return c; }
 }  // namespace emu
@@ -105,6 +107,9 @@ inline void run_block(unsigned nthreads, dim3 bdim) {
     c.wbuf.assign(nw * 64, 0.0);
     c.wa.assign(nw * 64, 0.f);
     c.wb.assign(nw * 64, 0.f);
+    c.wa8.assign(nw * 64 * 8, 0.f);
+    c.wb8.assign(nw * 64 * 8, 0.f);
+    c.wflag.assign(nw * 64, 0);
     for (unsigned i = 0; i < nthreads; ++i) {
         Fiber& f = c.fibers[i];
         getcontext(&f.ctx);
@@ -214,6 +219,44 @@ static inline __emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b,
     }
     emu::yield(emu::WAIT_WAVE);
     return c;
+}
+
+
+// v_mfma_f32_16x16x32_bf16: A[i = lane&15][k = 8*(lane>>4) + e], B[k = 8*(lane>>4) + e][j = lane&15], e = 0..7 packed two per
+// dword (low half first); D[row = 4*(lane>>4) + reg][col = lane&15].  Products of two bf16 are exact in fp32; the sum is
+// emulated as an in-order fp32 chain over k (the hardware's internal order is unspecified; tests use tolerances).
+static inline float emu_bf16_to_f32(uint32_t h) { uint32_t u = h << 16; float f; memcpy(&f, &u, 4); return f; }
+typedef unsigned __emu_u32x4 __attribute__((vector_size(16)));
+static inline __emu_f32x4 emu_mfma_f32_16x16x32_bf16(__emu_u32x4 a, __emu_u32x4 b, __emu_f32x4 c) {
+    emu::Ctx& cx = emu::C();
+    int base = (emu::flat_tid() / 64) * 64, l = emu::lane();
+    for (int e = 0; e < 8; ++e) {
+        cx.wa8[(base + l) * 8 + e] = emu_bf16_to_f32((a[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        cx.wb8[(base + l) * 8 + e] = emu_bf16_to_f32((b[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    }
+    emu::yield(emu::WAIT_WAVE);
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg)
+            for (int e = 0; e < 8; ++e) acc = fmaf(cx.wa8[(base + kg * 16 + row) * 8 + e], cx.wb8[(base + kg * 16 + col) * 8 + e], acc);
+        c[r] = acc;
+    }
+    emu::yield(emu::WAIT_WAVE);
+    return c;
+}
+// wave-wide "any lane has pred != 0"
+static inline int emu_wave_any(int pred) {
+    emu::Ctx& cx = emu::C();
+    int base = (emu::flat_tid() / 64) * 64, l = emu::lane();
+    cx.wflag[base + l] = pred ? 1 : 0;
+    emu::yield(emu::WAIT_WAVE);
+    int any = 0;
+    unsigned nthreads = blockDim.x * blockDim.y * blockDim.z;
+    for (int i = 0; i < 64 && (unsigned)(base + i) < nthreads; ++i) any |= cx.wflag[base + i];
+    emu::yield(emu::WAIT_WAVE);
+    return any;
 }
 
 #define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::C().dyn_smem;

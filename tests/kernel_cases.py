@@ -179,12 +179,40 @@ def _ste(gx, x, mode, bits, qp, q_type):
     return gx
 
 
+def make_coded_weights(r, w_shape, wmode, wbits=8):
+    """Fake-quantised fp32 weights of the given scheme (what the weight quantizer kernels emit) + the wq descriptor fields."""
+    O = w_shape[0]
+    if wmode == 1:      # ternary / binary: t * alpha[o]
+        t = r.integers(-1, 2, size=w_shape).astype(F)
+        alpha = (np.abs(r.standard_normal(O)) * 0.2 + 0.05).astype(F).reshape(-1, 1, 1, 1)
+        t.reshape(O, -1)[:, 0] = 1          # every channel has a non-zero code, so max|w| recovers alpha
+        return (t * alpha).astype(F), dict(mode=1), None
+    if wmode == 2:      # dorefa: 2 * (k * s) - 1
+        n = 2 ** wbits - 1
+        s = F(1.0 / n)
+        k = r.integers(0, n + 1, size=w_shape).astype(F)
+        q = (k * s).astype(F)
+        return (F(2) * q - F(1)).astype(F), dict(mode=2, bits=wbits), None
+    if wmode == 3:      # iao symmetric per-channel: code * scale[o]
+        qmax = 2 ** (wbits - 1) - 1
+        code = r.integers(-qmax, qmax + 1, size=w_shape).astype(F)
+        scale = (np.abs(r.standard_normal(O)) * 0.01 + 0.002).astype(F)
+        return (code * scale.reshape(-1, 1, 1, 1)).astype(F), dict(mode=3, bits=wbits, q_type=0, per_channel=1), scale
+    raise ValueError(wmode)
+
+
 def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, bias=True, mode=0, bits=8, q_type=0,
-               algos=(1, 2), seed=0, binary_x=False, expect_mfma=None, rel=1e-5):
-    """fwd / bwd_data / bwd_weight of one geometry on every requested algo vs numpy fp64 on the same fp32 operands."""
+               algos=(1, 2), seed=0, binary_x=False, expect_mfma=None, rel=1e-5, wmode=0, wbits=8, expect_qgemm=None):
+    """fwd / bwd_data / bwd_weight of one geometry on every requested algo vs numpy fp64 on the same fp32 operands.
+    wmode != 0: the weights are fake-quantised (ternary / dorefa / iao) and algo 3 (code-domain bf16 MFMA) is exercised."""
     r = np.random.default_rng(seed)
     x = (np.where(r.standard_normal(x_shape) > 0, 1.0, -1.0) if binary_x else r.standard_normal(x_shape) * 4).astype(F)
-    w = (r.standard_normal(w_shape) * 0.3).astype(F)
+    wq = None
+    if wmode:
+        w, wkw, wscale = make_coded_weights(r, w_shape, wmode, wbits)
+        wq = be.wq(scale=be.to_dev(wscale) if wscale is not None else None, **wkw)
+    else:
+        w = (r.standard_normal(w_shape) * 0.3).astype(F)
     b = (r.standard_normal(w_shape[0]) * 0.2).astype(F) if bias else None
     g = be.geom(x_shape, w_shape, stride, padding, dilation, groups)
     qp = None
@@ -203,26 +231,30 @@ def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, 
     dx_ref = _ste(dqx_ref, x, mode, bits, qp, q_type)
     dX, dW, dB, dG = be.to_dev(x), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(gy)
     dqp = be.to_dev(qp) if qp is not None else None
-    aq = be.actq(mode, bits, q_type, dqp)
+    aq = be.actq(mode, bits, q_type, dqp, flags=1 if (binary_x and mode == 0) else 0)
     sup = [bool(be.lib.mn_conv2d_mfma_supported(C.byref(g), k)) for k in range(3)]
+    supq = [bool(be.lib.mn_conv2d_qgemm_supported(C.byref(g), C.byref(aq), C.byref(wq) if wq is not None else None, k)) for k in range(3)]
     if expect_mfma is not None:
         assert sup == [expect_mfma] * 3 if isinstance(expect_mfma, bool) else sup == list(expect_mfma), (sup, expect_mfma)
+    if expect_qgemm is not None:
+        assert supq == ([expect_qgemm] * 3 if isinstance(expect_qgemm, bool) else list(expect_qgemm)), (supq, expect_qgemm)
     out = {}
     for algo in algos:
-        if algo != 2 or sup[0]:
-            y = be.to_host(be.conv_fwd(g, aq, dX, dW, dB, algo))
+        ok = lambda k: (algo == 1 or algo == 0) or (algo == 2 and sup[k]) or (algo == 3 and supq[k])
+        if ok(0):
+            y = be.to_host(be.conv_fwd(g, aq, dX, dW, dB, algo, wq=wq))
             assert close(y, y_ref, rel), ("fwd", algo, np.max(np.abs(y - y_ref)), np.max(np.abs(y_ref)))
-        if algo != 2 or sup[1]:
-            dx = be.to_host(be.conv_bwd_data(g, aq, dG, dW, dX, algo))
+        if ok(1):
+            dx = be.to_host(be.conv_bwd_data(g, aq, dG, dW, dX, algo, wq=wq))
             # the STE mask multiplies a float; compare where the mask passes with the float tolerance
             assert close(dx, dx_ref, rel), ("bwd_data", algo, np.max(np.abs(dx - dx_ref)), np.max(np.abs(dx_ref)))
-        if algo != 2 or sup[2]:
+        if ok(2):
             dw, db = be.conv_bwd_weight(g, aq, dG, dX, algo, bias=True)
             dw, db = be.to_host(dw), be.to_host(db)
             assert close(dw, dw_ref, rel), ("bwd_weight", algo, np.max(np.abs(dw - dw_ref)), np.max(np.abs(dw_ref)))
             assert close(db, db_ref, rel), ("dbias", algo)
         out[algo] = True
-    return sup
+    return sup, supq
 
 
 # geometry list: (x_shape, w_shape, kwargs) -- covers every tiler branch with small tensors
@@ -248,4 +280,17 @@ SMALL_CONV_CASES = [
     dict(x_shape=(2, 4, 7, 7), w_shape=(6, 4, 3, 3), padding=2, dilation=2, expect_mfma=False),
     # linear layer as 1x1 conv on 1x1 images
     dict(x_shape=(5, 32, 1, 1), w_shape=(10, 32, 1, 1), expect_mfma=False),
+]
+
+
+# pointwise (1x1 stride 1) geometries for the code-domain kernels: (kwargs, what they cover)
+QGEMM_PW_CASES = [
+    # tiny: one chunk, partly masked pixels (3*16 = 48 < 64), Cg=4 padded to 32, Mg=4
+    dict(x_shape=(3, 16, 4, 4), w_shape=(16, 4, 1, 1), groups=4, bias=False),
+    # two K-steps (Cg=40 -> Kp=64), Mg=24 (NT=2, padded rows), several chunks, images smaller than a chunk
+    dict(x_shape=(5, 80, 4, 8), w_shape=(48, 40, 1, 1), groups=2),
+    # Mg=72 -> two m-blocks of 64, Cg=32, 8x8 images (1 chunk per image)
+    dict(x_shape=(3, 32, 8, 8), w_shape=(72, 32, 1, 1)),
+    # Mg=10 (single 16-row tile), Cg=96 (3 K-steps): the nin_gc L9 pattern
+    dict(x_shape=(2, 96, 8, 8), w_shape=(10, 96, 1, 1)),
 ]

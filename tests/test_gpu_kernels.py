@@ -78,6 +78,35 @@ def test_hot_shapes(be, name, kw):
     K.check_conv(be, seed=78, mode=1, bits=2, algos=(2,), **kw)
 
 
+# ---- code-domain (bf16 MFMA) kernels, algo 3: same cases as the emulated run + the hot pointwise shapes
+@pytest.mark.parametrize("case", range(len(K.QGEMM_PW_CASES)))
+@pytest.mark.parametrize("wmode", [1, 2, 3])
+def test_qgemm_pointwise_binary_x(be, case, wmode):
+    K.check_conv(be, seed=40 + case, wmode=wmode, wbits=4, binary_x=True, algos=(3,), expect_qgemm=True, **K.QGEMM_PW_CASES[case])
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_qgemm_pointwise_real_x(be, case):
+    K.check_conv(be, seed=50 + case, wmode=1, algos=(3,), expect_qgemm=True, **K.QGEMM_PW_CASES[case])
+
+
+@pytest.mark.parametrize("case,mode,q_type", [(1, 1, 0), (2, 1, 0), (1, 2, 0), (3, 2, 0)])
+def test_qgemm_pointwise_fused_actq(be, case, mode, q_type):
+    K.check_conv(be, seed=60 + case, mode=mode, bits=4, q_type=q_type, wmode=2 if mode == 1 else 3, wbits=4, algos=(3,),
+                 expect_qgemm=True, **K.QGEMM_PW_CASES[case])
+
+
+QGEMM_HOT = [(n, kw) for n, kw in HOT_SHAPES if kw["w_shape"][2] == 1 and kw.get("stride", 1) == 1]
+
+
+@pytest.mark.parametrize("name,kw", QGEMM_HOT, ids=[n for n, _ in QGEMM_HOT])
+def test_qgemm_hot_shapes(be, name, kw):
+    K.check_conv(be, seed=81, wmode=1, binary_x=True, algos=(3, 0), expect_qgemm=True, **kw)          # wbwtab W3/A2
+    K.check_conv(be, seed=82, wmode=2, wbits=8, mode=1, bits=8, algos=(3,), expect_qgemm=True, **kw)   # DoReFa W8A8
+    K.check_conv(be, seed=83, wmode=3, wbits=8, mode=2, bits=8, algos=(3,), expect_qgemm=True, **kw)   # IAO W8A8 sym per-channel
+    K.check_conv(be, seed=84, wmode=1, algos=(3,), expect_qgemm=True, **kw)                           # real x (W-only quantization)
+
+
 def test_full_size_properties(be):
     """BASELINE config 2 layer L2 at batch 256 (268 MB activations): properties that need no CPU-sized oracle.
     (1) MFMA kernel == direct kernel on a strided sample of outputs; (2) linearity in the weights;
@@ -89,20 +118,30 @@ def test_full_size_properties(be):
     x = (torch.rand((N, 256, 32, 32), device="cuda", generator=gen) > 0.5).float() * 2 - 1      # +-1 activations
     w = torch.randn((256, 128, 1, 1), device="cuda", generator=gen) * 0.1
     aq = be.actq(0)
-    y = be.conv_fwd(g, aq, x, w, None, 2)
-    y2 = be.conv_fwd(g, aq, x, 2 * w, None, 2)
+    _full_size_checks(be, g, aq, x, w, N, 2, None)
+    # the same through the code-domain kernels: ternary weights t * alpha[o]
+    t = torch.randint(-1, 2, (256, 128, 1, 1), device="cuda", generator=gen).float()
+    t[:, 0] = 1
+    alpha = torch.rand((256, 1, 1, 1), device="cuda", generator=gen) * 0.2 + 0.05
+    _full_size_checks(be, g, aq, x, t * alpha, N, 3, be.wq(mode=1))
+
+
+def _full_size_checks(be, g, aq, x, w, N, algo, wq):
+    torch = be.torch
+    y = be.conv_fwd(g, aq, x, w, None, algo, wq=wq)
+    y2 = be.conv_fwd(g, aq, x, 2 * w, None, algo, wq=wq)
     assert torch.equal(y2, 2 * y)                                # scaling by 2 is exact in fp32
     # sampled comparison with an fp64 einsum on 3 images
     for n in (0, 100, 255):
         ref = torch.einsum("gchw,goc->gohw", x[n].double().view(2, 128, 32, 32), w.double().view(2, 128, 128)).reshape(256, 32, 32)
         assert (y[n].double() - ref).abs().max() <= 1e-5 * ref.abs().max()
     gy = torch.ones_like(y)
-    dw, db = be.conv_bwd_weight(g, aq, gy, x, 2)
+    dw, db = be.conv_bwd_weight(g, aq, gy, x, algo)
     colsum = x.double().sum(dim=(0, 2, 3))                       # [256]
     ref = colsum.view(2, 1, 128).expand(2, 128, 128).reshape(256, 128)
     assert (dw.view(256, 128).double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp_min(1.0)
     assert torch.equal(db, torch.full_like(db, float(N * 32 * 32)))
-    dx = be.conv_bwd_data(g, aq, gy, w, None, 2)
+    dx = be.conv_bwd_data(g, aq, gy, w, None, algo, wq=wq)
     ref = w.double().view(2, 128, 128).sum(dim=1).reshape(256)    # sum over out-channels of each group
     assert (dx[17, :, 5, 9].double() - ref).abs().max() <= 1e-5 * ref.abs().max()
     assert torch.equal(dx[0, :, 0, 0], dx[255, :, 31, 31])
@@ -111,11 +150,11 @@ def test_full_size_properties(be):
 def test_errors_are_reported(be):
     g = be.geom((1, 4, 8, 8), (4, 3, 1, 1))      # C not divisible consistently -> invalid
     g.groups = 3
-    rc = be.lib.mn_conv2d_fwd(C.byref(g), C.byref(be.actq(0)), None, None, None, None, None, 0, 0, be.stream)
+    rc = be.lib.mn_conv2d_fwd(C.byref(g), C.byref(be.actq(0)), None, None, None, None, None, None, 0, 0, be.stream)
     assert rc == -22 and b"invalid" in be.lib.mn_last_error()
     g2 = be.geom((2, 8, 6, 6), (12, 4, 3, 3), padding=1, groups=2)
     x = be.to_dev(np.zeros((2, 8, 6, 6)))
     w = be.to_dev(np.zeros((12, 4, 3, 3)))
     y = be.empty((2, 12, 6, 6))
-    rc = be.lib.mn_conv2d_fwd(C.byref(g2), C.byref(be.actq(0)), be.ptr(x), be.ptr(w), None, be.ptr(y), None, 0, 2, be.stream)
+    rc = be.lib.mn_conv2d_fwd(C.byref(g2), C.byref(be.actq(0)), None, be.ptr(x), be.ptr(w), None, be.ptr(y), None, 0, 2, be.stream)
     assert rc == -95       # MFMA requested for a shape the tiler rejects

@@ -48,3 +48,24 @@ def test_conv_dorefa_fused(be, case):
 @pytest.mark.parametrize("case,q_type", [(1, 0), (2, 1), (3, 0), (8, 1)])
 def test_conv_iao_fused(be, case, q_type):
     K.check_conv(be, seed=20 + case, mode=2, bits=4, q_type=q_type, **K.SMALL_CONV_CASES[case])
+
+
+# ---- code-domain (bf16 MFMA) kernels: algo 3
+@pytest.mark.parametrize("case", range(len(K.QGEMM_PW_CASES)))
+@pytest.mark.parametrize("wmode", [1, 2, 3])
+def test_qgemm_pointwise_binary_x(be, case, wmode):
+    """wbwtab-style: +-1 activations (no fused quantizer), coded weights; fwd / bwd-data / bwd-weight on algo 3."""
+    K.check_conv(be, seed=40 + case, wmode=wmode, wbits=4, binary_x=True, algos=(3,), expect_qgemm=True, **K.QGEMM_PW_CASES[case])
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_qgemm_pointwise_real_x(be, case):
+    """real-valued activations: the three-term split (zero terms skipped) keeps all three passes exact."""
+    K.check_conv(be, seed=50 + case, wmode=1, algos=(3,), expect_qgemm=True, **K.QGEMM_PW_CASES[case])
+
+
+@pytest.mark.parametrize("case,mode,q_type", [(1, 1, 0), (2, 1, 0), (1, 2, 0), (3, 2, 0)])
+def test_qgemm_pointwise_fused_actq(be, case, mode, q_type):
+    """DoReFa / IAO activation quantizer fused: codes in the prologue, scale in the epilogue, clip-STE in bwd-data."""
+    K.check_conv(be, seed=60 + case, mode=mode, bits=4, q_type=q_type, wmode=2 if mode == 1 else 3, wbits=4, algos=(3,),
+                 expect_qgemm=True, **K.QGEMM_PW_CASES[case])
