@@ -1,0 +1,79 @@
+// Device/host helpers shared by the code-domain kernel files (qgemm_kernels.hip: pointwise; qgemm_kxk.hip: k x k).
+#pragma once
+#include "qgemm.h"
+
+typedef unsigned int u32x2 __attribute__((vector_size(8)));
+
+#define QG_EPI_SCALE_BIAS 0
+#define QG_EPI_PLAIN 1
+#define QG_EPI_STE 2
+
+static inline int qg_roundup(int a, int b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------------
+// activation codes in the conv prologue
+template <int XMODE>
+__device__ __forceinline__ float act_code(float x, const Pro& p, float sc, float zp) {
+    if (XMODE == MN_ACTQ_DOREFA) return mn_rha(mn_clamp(x * 0.1f, 0.f, 1.f) / p.s);           // j in [0, 2^a - 1]
+    if (XMODE == MN_ACTQ_IAO) return mn_clamp(mn_rha(x / sc - zp), p.qmin, p.qmax) + zp;       // clamp(r) + zp
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight codes: one workgroup (one wave) per padded row; recovers code and scale from the fake-quantised fp32 weights
+struct PackParams {
+    const float* w;        // [G*Mg][Cg*T]
+    uint16_t* codes;
+    float* scale_out;      // per out-channel scale (fwd: rowscale [G][Mpad]; bwd: kscale [G][Mgp])
+    const float* scale_in; // IAO
+    int G, Mg, Cg, T, KW;
+    int mode, bits, per_channel;
+    int transpose;         // 0: codes[(g*Mpad + m)*T*Cgp + tap*Cgp + c]   1: codes[((g*Cpad + c)*T + tapflip)*Mgp + m]
+    int Mpad, Cgp, Cpad, Mgp;
+};
+
+void qg_launch_pack(const PackParams& p, int grid, hipStream_t s);
+
+// fixed-order fp64 reduction of Z partial dw tiles [Z][G][Mgw][Cgw] (+ dbias [Z][G][Mgw]); dw = sum * ascale (or * qp[0])
+void qg_launch_wgrad_reduce(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
+                            float ascale, const float* qp, hipStream_t s);
+
+// k x k kernels (qgemm_kxk.hip)
+int kk_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
+int64_t kk_ws_bytes(const mn_conv_geom* g, int which);
+int kk_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y,
+           void* ws, int64_t ws_bytes, hipStream_t s);
+int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
+                void* ws, int64_t ws_bytes, hipStream_t s);
+int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
+                  int64_t ws_bytes, hipStream_t s);
+
+static inline int aq_codeable(const mn_actq* aq, int need_exact_x) {
+    (void)need_exact_x;   // real-valued x is handled exactly by term splitting (zero terms are skipped)
+    if (!aq || aq->mode == MN_ACTQ_NONE) return 1;
+    if (aq->mode == MN_ACTQ_DOREFA) return aq->bits >= 2 && aq->bits <= 8;
+    if (aq->mode == MN_ACTQ_IAO) return aq->bits >= 2 && aq->bits <= 8 && aq->q_type == 0 && aq->qp;
+    return 0;
+}
+static inline int wq_codeable(const mn_wq* wq) {
+    if (!wq) return 0;
+    if (wq->mode == MN_WQ_TERNARY) return 1;
+    if (wq->mode == MN_WQ_DOREFA) return wq->bits >= 2 && wq->bits <= 8;
+    if (wq->mode == MN_WQ_IAO) return wq->bits >= 2 && wq->bits <= 8 && wq->q_type == 0 && wq->scale;
+    return 0;
+}
+
+static inline void raise_lds_limit(const void* fn, size_t bytes) {
+#ifndef MN_EMULATION
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+#else
+    (void)fn; (void)bytes;
+#endif
+}
+static inline void fill_pack(PackParams& k, const mn_wq* wq, const float* w, void* ws, int64_t off_codes, int64_t off_scale) {
+    k.w = w; k.codes = (uint16_t*)((char*)ws + off_codes); k.scale_out = (float*)((char*)ws + off_scale);
+    k.mode = wq->mode; k.bits = wq->bits > 0 ? wq->bits : 8; k.per_channel = wq->per_channel; k.scale_in = wq->scale;
+}
+
+
+static const size_t QG_LDS_CAP = 64 * 1024;

@@ -22,35 +22,8 @@
 // range (Z) and a second kernel reduces the partial tiles in a fixed order with fp64 accumulation (deterministic).
 #include "qgemm.h"
 
-typedef unsigned int u32x2 __attribute__((vector_size(8)));
+#include "qgemm_dev.h"
 
-#define QG_EPI_SCALE_BIAS 0
-#define QG_EPI_PLAIN 1
-#define QG_EPI_STE 2
-
-static inline int qg_roundup(int a, int b) { return (a + b - 1) / b * b; }
-
-// ------------------------------------------------------------------------------------------------
-// activation codes in the conv prologue
-template <int XMODE>
-__device__ __forceinline__ float act_code(float x, const Pro& p, float sc, float zp) {
-    if (XMODE == MN_ACTQ_DOREFA) return mn_rha(mn_clamp(x * 0.1f, 0.f, 1.f) / p.s);           // j in [0, 2^a - 1]
-    if (XMODE == MN_ACTQ_IAO) return mn_clamp(mn_rha(x / sc - zp), p.qmin, p.qmax) + zp;       // clamp(r) + zp
-    return x;
-}
-
-// ------------------------------------------------------------------------------------------------
-// weight codes: one workgroup (one wave) per padded row; recovers code and scale from the fake-quantised fp32 weights
-struct PackParams {
-    const float* w;        // [G*Mg][Cg*T]
-    uint16_t* codes;
-    float* scale_out;      // per out-channel scale (fwd: rowscale [G][Mpad]; bwd: kscale [G][Mgp])
-    const float* scale_in; // IAO
-    int G, Mg, Cg, T, KW;
-    int mode, bits, per_channel;
-    int transpose;         // 0: codes[(g*Mpad + m)*T*Cgp + tap*Cgp + c]   1: codes[((g*Cpad + c)*T + tapflip)*Mgp + m]
-    int Mpad, Cgp, Cpad, Mgp;
-};
 __device__ __forceinline__ float wq_code(float w, int mode, float sc, float n) {
     if (mode == MN_WQ_TERNARY) return (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : w);   // +-0 -> 0, NaN stays NaN
     if (mode == MN_WQ_DOREFA) {
@@ -100,6 +73,8 @@ __global__ __launch_bounds__(64) void k_qg_pack(const PackParams p) {
         }
     }
 }
+
+void qg_launch_pack(const PackParams& p, int grid, hipStream_t s) { hipLaunchKernelGGL(k_qg_pack, dim3(grid), dim3(64), 0, s, p); }
 
 // ------------------------------------------------------------------------------------------------
 // pointwise forward / backward-data
@@ -500,9 +475,14 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_reduce(const float* __restrict
     }
 }
 
+void qg_launch_wgrad_reduce(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
+                            float ascale, const float* qp, hipStream_t s) {
+    const int64_t total = (int64_t)G * Mg * Cg + (db ? (int64_t)G * Mg : 0);
+    hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(mn_grid_for(total, 256, 2048)), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
-static const size_t QG_LDS_CAP = 64 * 1024;
 
 static int pw_geom_ok(const mn_conv_geom* g) {
     if (g->KH != 1 || g->KW != 1 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 0 || g->pad_w != 0) return 0;
@@ -511,21 +491,6 @@ static int pw_geom_ok(const mn_conv_geom* g) {
     if (NP * HW >= ((int64_t)1 << 32) || NP + 256 >= ((int64_t)1 << 31)) return 0;   // FastDiv range
     return 1;
 }
-static int aq_codeable(const mn_actq* aq, int need_exact_x) {
-    (void)need_exact_x;   // real-valued x is handled exactly by term splitting (zero terms are skipped)
-    if (!aq || aq->mode == MN_ACTQ_NONE) return 1;
-    if (aq->mode == MN_ACTQ_DOREFA) return aq->bits >= 2 && aq->bits <= 8;
-    if (aq->mode == MN_ACTQ_IAO) return aq->bits >= 2 && aq->bits <= 8 && aq->q_type == 0 && aq->qp;
-    return 0;
-}
-static int wq_codeable(const mn_wq* wq) {
-    if (!wq) return 0;
-    if (wq->mode == MN_WQ_TERNARY) return 1;
-    if (wq->mode == MN_WQ_DOREFA) return wq->bits >= 2 && wq->bits <= 8;
-    if (wq->mode == MN_WQ_IAO) return wq->bits >= 2 && wq->bits <= 8 && wq->q_type == 0 && wq->scale;
-    return 0;
-}
-
 struct PwPlan {
     PwParams p;
     PackParams pk;
@@ -620,24 +585,19 @@ static int plan_pw_wgrad(const mn_conv_geom* g, WgPlan* pl) {
 }
 
 int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
+    if (!pw_geom_ok(g)) return kk_supported(g, aq, wq, which);
     if (which == 0) { PwPlan pl; return wq_codeable(wq) && aq_codeable(aq, 0) && plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl); }
     if (which == 1) { PwPlan pl; return wq_codeable(wq) && plan_pw(g, 1, MN_ACTQ_NONE, &pl); }
     if (which == 2) { WgPlan pl; return aq_codeable(aq, 1) && plan_pw_wgrad(g, &pl); }
     return 0;
 }
 int64_t qg_ws_bytes(const mn_conv_geom* g, int which) {
+    if (!pw_geom_ok(g)) return kk_ws_bytes(g, which);
     if (which == 0 || which == 1) { PwPlan pl; return plan_pw(g, which, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0; }   // NT <= 4: the larger Mpad
     if (which == 2) { WgPlan pl; return plan_pw_wgrad(g, &pl) ? pl.ws_bytes : 0; }
     return 0;
 }
 
-static void raise_lds_limit(const void* fn, size_t bytes) {
-#ifndef MN_EMULATION
-    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-#else
-    (void)fn; (void)bytes;
-#endif
-}
 template <int NT>
 static void launch_pw(const PwPlan& pl, int xmode, hipStream_t s) {
     if (xmode == MN_ACTQ_DOREFA) hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_DOREFA>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
@@ -654,13 +614,9 @@ static int run_pw(PwPlan& pl, int xmode, hipStream_t s, const char* what) {
     MN_CHECK_LAUNCH(what);
     return MN_OK;
 }
-static void fill_pack(PackParams& k, const mn_wq* wq, const float* w, void* ws, int64_t off_codes, int64_t off_scale) {
-    k.w = w; k.codes = (uint16_t*)((char*)ws + off_codes); k.scale_out = (float*)((char*)ws + off_scale);
-    k.mode = wq->mode; k.bits = wq->bits > 0 ? wq->bits : 8; k.per_channel = wq->per_channel; k.scale_in = wq->scale;
-}
-
 int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y,
            void* ws, int64_t ws_bytes, hipStream_t s) {
+    if (!pw_geom_ok(g)) return kk_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
     PwPlan pl;
     if (!wq_codeable(wq) || !aq_codeable(aq, 0) || !plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl) || !aligned16(x) || !aligned16(y))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(qgemm): geometry / quantizer combination not covered");
@@ -669,7 +625,7 @@ int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const floa
     int rc = make_pro(aq, &pro, 0, "mn_conv2d_fwd(qgemm)");
     if (rc) return rc;
     fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
-    hipLaunchKernelGGL(k_qg_pack, dim3(pl.pack_grid), dim3(64), 0, s, pl.pk);
+    qg_launch_pack(pl.pk, pl.pack_grid, s);
     PwParams& p = pl.p;
     p.x = x; p.y = y; p.wc = pl.pk.codes; p.rowscale = pl.pk.scale_out; p.kscale = nullptr; p.bias = bias; p.aux = nullptr;
     p.pro = pro; p.ste = pro; p.epi = QG_EPI_SCALE_BIAS;
@@ -679,6 +635,7 @@ int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const floa
 
 int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
                 void* ws, int64_t ws_bytes, hipStream_t s) {
+    if (!pw_geom_ok(g)) return kk_bwd_data(g, aq, wq, gy, w, x, dx, ws, ws_bytes, s);
     PwPlan pl;
     if (!wq_codeable(wq) || !plan_pw(g, 1, MN_ACTQ_NONE, &pl) || !aligned16(gy) || !aligned16(dx))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(qgemm): geometry / quantizer combination not covered");
@@ -688,7 +645,7 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     if (rc) return rc;
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
     fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
-    hipLaunchKernelGGL(k_qg_pack, dim3(pl.pack_grid), dim3(64), 0, s, pl.pk);
+    qg_launch_pack(pl.pk, pl.pack_grid, s);
     Pro none; none.mode = MN_ACTQ_NONE; none.s = 1.f; none.qmin = none.qmax = 0.f; none.qp = nullptr;
     PwParams& p = pl.p;
     p.x = gy; p.y = dx; p.wc = pl.pk.codes; p.rowscale = nullptr; p.kscale = pl.pk.scale_out; p.bias = nullptr; p.aux = x;
@@ -711,6 +668,7 @@ static void launch_wg(const WgPlan& pl, int xmode, hipStream_t s) {
 }
 int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s) {
+    if (!pw_geom_ok(g)) return kk_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
     WgPlan pl;
     if (!aq_codeable(aq, 1) || !plan_pw_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(qgemm): geometry / quantizer combination not covered");
@@ -727,9 +685,9 @@ int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
         default: launch_wg<2, 2, 2>(pl, pro.mode, s); break;
     }
     const int64_t total = (int64_t)g->O * (g->C / g->groups) + (dbias ? g->O : 0);
-    hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(mn_grid_for(total, 256, 2048)), dim3(256), 0, s, (const float*)p.part, (const float*)p.dbpart, dw,
-                       dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f,
-                       pro.mode == MN_ACTQ_IAO ? pro.qp : (const float*)nullptr);
+    (void)total;
+    qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f,
+                           pro.mode == MN_ACTQ_IAO ? pro.qp : (const float*)nullptr, s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(qgemm)");
     return MN_OK;
 }

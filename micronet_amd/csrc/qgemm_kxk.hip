@@ -1,0 +1,715 @@
+// Code-domain k x k convolution (any kernel size / stride / dilation / groups) for gfx950: forward and backward-data.
+//
+// Same arithmetic as the pointwise kernels (qgemm_kernels.hip): integer codes, exact in bf16, contracted on
+// v_mfma_f32_16x16x32_bf16; a real-valued streamed operand is written as three exact bf16 terms and all-zero terms are
+// skipped.  What differs is the data path: the taps re-read every input pixel KH*KW times, so the input patch of a
+// 256-pixel output tile is staged ONCE in LDS -- transposed on the way in from NCHW rows (coalesced float4 loads of 8
+// channels x 4 pixels per thread) to channel-innermost records [position][term][CC channels] of bf16 codes, so that the B
+// fragment of (pixel, tap) is one aligned ds_read_b128 of 8 consecutive channels.  Records are padded by 16 B: the 16
+// pixels of a fragment read then fall on distinct bank quads.  K is ordered tap-major inside a channel chunk
+// (k = tap*CC + c), the weight codes are packed in the same order and staged per chunk as A fragments.
+// Pixel <-> MFMA column permutation as in the pointwise kernel: MFMA q takes pixel 4j+q from lane j, so the epilogue stores
+// float4 = 4 consecutive pixels per out-channel (256-B runs per 16 lanes).
+// Backward-data = the same kernel on gy with tap-flipped, transposed codes (stride 1 only; strided convolutions fall back
+// to the fp32-MFMA kernels), gy pre-scaled by the per-channel weight scale and split in three terms, clip-STE epilogue.
+#include "qgemm_dev.h"
+
+struct KkParams {
+    const float* in;          // x (fwd) / gy (bwd-data)   [N][G*Kc][Hin][Win]
+    float* out;               // y / dx                     [N][G*Mr][Ho][Wo]
+    const uint16_t* wc;       // codes [G][Mpad][T][Cgp]
+    const float* rowscale;    // [G][Mpad] or null
+    const float* kscale;      // [G][Cgp]  or null (bwd-data: weight scale of the contraction channel)
+    const float* bias;
+    const float* aux;         // bwd-data STE: x
+    Pro pro, ste;
+    int N, Cin_total, Hin, Win, Kc, G, Cout_total, Ho, Wo, Mr;
+    int KH, KW, T, Sh, Sw, Dh, Dw, ph, pw;
+    int Cgp, CC, cc_shift, nck, KS, LDW, PSB;      // PSB: bytes per patch position record
+    int NI, TR, tpi, PR, PWp, npos, num_ptiles, Mpad, num_mblk, epi, W4;
+    FastDiv fd_wo, fd_tr, fd_tpi, fd_pwp, fd_pr, fd_w4, fd_o8;
+    float ascale;
+};
+
+template <int NT, int XMODE>
+__global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int MB = 16 * NT;
+    constexpr int NTERM = (XMODE == MN_ACTQ_NONE) ? 3 : 1;
+    char* patch = reinterpret_cast<char*>(smem);                              // [npos][PSB]
+    uint16_t* wsm = reinterpret_cast<uint16_t*>(patch + (size_t)p.npos * p.PSB);   // [MB][LDW]
+    float* rs = reinterpret_cast<float*>(wsm + MB * p.LDW);
+    float* bs = rs + MB;
+    int* toff = reinterpret_cast<int*>(bs + MB);                             // [T] byte offset of a tap inside the patch
+    int* tflag = toff + p.T;                                                 // [nck][2] any non-zero second / third term in the chunk's patch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+
+    uint32_t b = blockIdx.x;
+    const int pt = b % p.num_ptiles; b /= p.num_ptiles;
+    const int mblk = b % p.num_mblk;
+    const int g = b / p.num_mblk;
+    const uint32_t timg = fd_div(pt, p.fd_tpi);
+    const int n0 = (int)timg * p.NI;
+    const int oh0 = (pt - (int)timg * p.tpi) * p.TR;
+    const int row0 = oh0 * p.Sh - p.ph;
+
+    float sc = 1.f, zp = 0.f;
+    if (XMODE == MN_ACTQ_IAO) { sc = p.pro.qp[0]; zp = p.pro.qp[1]; }
+    {
+        float as = p.ascale;
+        if (XMODE == MN_ACTQ_IAO) as = sc;
+        for (int i = tid; i < MB; i += 256) {
+            const int m = mblk * MB + i;
+            rs[i] = p.rowscale ? p.rowscale[g * p.Mpad + m] * as : 1.f;
+            bs[i] = (p.bias && m < p.Mr) ? p.bias[g * p.Mr + m] : 0.f;
+        }
+        for (int t = tid; t < p.T; t += 256) toff[t] = ((t / p.KW) * p.Dh * p.PWp + (t % p.KW) * p.Dw) * p.PSB;
+        if (NTERM == 3) for (int t = tid; t < 2 * p.nck; t += 256) tflag[t] = 0;
+    }
+
+    // patch byte offset of tap (0,0) of this lane's four pixels
+    int pos0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pix = wave * 64 + 4 * j + q;
+        const uint32_t fr = fd_div(pix, p.fd_wo);
+        const int ocol = pix - fr * p.Wo;
+        const uint32_t img = fd_div(fr, p.fd_tr);
+        const int orow = fr - img * p.TR;
+        pos0[q] = (((int)img * p.PR + orow * p.Sh) * p.PWp + ocol * p.Sw) * p.PSB;
+    }
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int o8n = p.CC >> 3;
+    const int64_t plane = (int64_t)p.Hin * p.Win;
+    for (int ck = 0; ck < p.nck; ++ck) {
+        __syncthreads();                             // the previous chunk's fragments are consumed (first pass: flags / tables visible)
+        // ---- weights of this chunk: wsm[row][k], k = tap*CC + cc
+        {
+            const int k8n = (p.KS * 32) >> 3;
+            const uint16_t* wg = p.wc + ((int64_t)g * p.Mpad + mblk * MB) * p.T * p.Cgp + ck * p.CC;
+            for (int q = tid; q < MB * k8n; q += 256) {
+                const int row = q / k8n, k8 = q - row * k8n;
+                const int k = k8 * 8, tap = k >> p.cc_shift, cc = k & (p.CC - 1);
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (tap < p.T) v = *reinterpret_cast<const u32x4*>(wg + ((int64_t)row * p.T + tap) * p.Cgp + cc);
+                *reinterpret_cast<u32x4*>(wsm + row * p.LDW + k) = v;
+            }
+        }
+        // ---- zero the halo records (zero padding is code 0 in every scheme)
+        {
+            const int nrec = p.npos * o8n * NTERM;
+            for (int q = tid; q < nrec; q += 256) {
+                const int sub = q % (o8n * NTERM);
+                const int pos = q / (o8n * NTERM);
+                const uint32_t t1 = fd_div(pos, p.fd_pwp);
+                const int pcol = pos - t1 * p.PWp;
+                const uint32_t slot = fd_div(t1, p.fd_pr);
+                const int prow = t1 - slot * p.PR;
+                const int ir = row0 + prow, ic = pcol - p.pw;
+                if (ir < 0 || ir >= p.Hin || ic < 0 || ic >= p.Win || n0 + (int)slot >= p.N)
+                    *reinterpret_cast<u32x4*>(patch + (size_t)pos * p.PSB + sub * 16) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        // ---- stage the interior: item = (slot, channel octet, patch row, input column quad)
+        {
+            const int nitem = p.NI * o8n * p.PR * p.W4;
+            unsigned any1 = 0u, any2 = 0u;
+            for (int it = tid; it < nitem; it += 256) {
+                const uint32_t t1 = fd_div(it, p.fd_w4);
+                const int iq = it - t1 * p.W4;
+                const uint32_t t2 = fd_div(t1, p.fd_pr);
+                const int prow = t1 - t2 * p.PR;
+                const uint32_t slot = fd_div(t2, p.fd_o8);
+                const int o8 = t2 - slot * o8n;
+                const int ir = row0 + prow, n = n0 + (int)slot;
+                if (ir < 0 || ir >= p.Hin || n >= p.N) continue;
+                const int c0 = ck * p.CC + o8 * 8;
+                const float* src = p.in + (((int64_t)n * p.Cin_total + (int64_t)g * p.Kc + c0) * p.Hin + ir) * p.Win + iq * 4;
+                float v[8][4];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c0 + jj < p.Kc) f = *reinterpret_cast<const float4*>(src + jj * plane);
+                    v[jj][0] = f.x; v[jj][1] = f.y; v[jj][2] = f.z; v[jj][3] = f.w;
+                }
+                if (XMODE == MN_ACTQ_NONE && p.kscale) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const float ksv = p.kscale[g * p.Cgp + c0 + jj];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[jj][e] *= ksv;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pcol = iq * 4 + e + p.pw;
+                    if (pcol >= p.PWp) continue;
+                    char* rec = patch + (size_t)(((int)slot * p.PR + prow) * p.PWp + pcol) * p.PSB + o8 * 16;
+                    if (NTERM == 1) {
+                        float c8[8];
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) c8[jj] = act_code<XMODE>(v[jj][e], p.pro, sc, zp);
+                        *reinterpret_cast<u32x4*>(rec) = u32x4{mn_pack_bf16x2(c8[0], c8[1]), mn_pack_bf16x2(c8[2], c8[3]),
+                                                              mn_pack_bf16x2(c8[4], c8[5]), mn_pack_bf16x2(c8[6], c8[7])};
+                    } else {
+                        float t0[8], t1_[8], t2_[8];
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const float x0 = v[jj][e];
+                            t0[jj] = mn_bf16_head(x0);
+                            const float r1 = x0 - t0[jj];
+                            t1_[jj] = mn_bf16_head(r1);
+                            t2_[jj] = r1 - t1_[jj];
+                            any1 |= mn_f2u(r1) << 1;
+                            any2 |= mn_f2u(t2_[jj]) << 1;
+                        }
+                        *reinterpret_cast<u32x4*>(rec) = u32x4{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3]),
+                                                              mn_pack_bf16x2(t0[4], t0[5]), mn_pack_bf16x2(t0[6], t0[7])};
+                        *reinterpret_cast<u32x4*>(rec + p.CC * 2) = u32x4{mn_pack_bf16x2(t1_[0], t1_[1]), mn_pack_bf16x2(t1_[2], t1_[3]),
+                                                                         mn_pack_bf16x2(t1_[4], t1_[5]), mn_pack_bf16x2(t1_[6], t1_[7])};
+                        *reinterpret_cast<u32x4*>(rec + p.CC * 4) = u32x4{mn_pack_bf16x2(t2_[0], t2_[1]), mn_pack_bf16x2(t2_[2], t2_[3]),
+                                                                         mn_pack_bf16x2(t2_[4], t2_[5]), mn_pack_bf16x2(t2_[6], t2_[7])};
+                    }
+                }
+            }
+            if (NTERM == 3) {
+                if (any1) tflag[2 * ck] = 1;
+                if (any2) tflag[2 * ck + 1] = 1;
+            }
+        }
+        __syncthreads();
+        const int use1 = NTERM == 3 ? tflag[2 * ck] : 0, use2 = NTERM == 3 ? tflag[2 * ck + 1] : 0;   // block-uniform
+        // ---- contraction over this chunk's K = T*CC
+        for (int ks = 0; ks < p.KS; ++ks) {
+            const int kl = ks * 32 + kg * 8;
+            const int tap = kl >> p.cc_shift, choff = (kl & (p.CC - 1)) * 2;
+            const bool tv = tap < p.T;
+            const int to = tv ? toff[tap] + choff : 0;
+            u32x4 b0[4], b1[4], b2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const char* rec = patch + pos0[q] + to;
+                b0[q] = tv ? *reinterpret_cast<const u32x4*>(rec) : u32x4{0u, 0u, 0u, 0u};
+                if (NTERM == 3) {
+                    b1[q] = (tv && use1) ? *reinterpret_cast<const u32x4*>(rec + p.CC * 2) : u32x4{0u, 0u, 0u, 0u};
+                    b2[q] = (tv && use2) ? *reinterpret_cast<const u32x4*>(rec + p.CC * 4) : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+            const uint16_t* wk = wsm + j * p.LDW + kl;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(wk + t * 16 * p.LDW);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b0[q], acc[q][t]);
+                if (NTERM == 3) {
+                    if (use1) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b1[q], acc[q][t]);
+                    }
+                    if (use2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b2[q], acc[q][t]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane (j, kg) holds out-channels 4kg..4kg+3 of pixels 4j..4j+3 of the wave's 64-pixel span
+    float ste_sc = 1.f, ste_zp = 0.f, ste_lo = 0.f, ste_hi = 0.f;
+    if (p.epi == QG_EPI_STE && p.ste.mode == MN_ACTQ_IAO) { ste_sc = p.ste.qp[0]; ste_zp = p.ste.qp[1]; ste_lo = p.ste.qp[2]; ste_hi = p.ste.qp[3]; }
+    const int pix = wave * 64 + 4 * j;
+    const uint32_t fr = fd_div(pix, p.fd_wo);
+    const int ocol = pix - fr * p.Wo;
+    const uint32_t img = fd_div(fr, p.fd_tr);
+    const int orow = fr - img * p.TR;
+    const int n = n0 + (int)img;
+    if (n >= p.N) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ml = t * 16 + kg * 4 + r;
+            const int m = mblk * MB + ml;
+            if (m >= p.Mr) continue;
+            const int64_t off = (((int64_t)n * p.Cout_total + (int64_t)g * p.Mr + m) * p.Ho + oh0 + orow) * p.Wo + ocol;
+            float o0 = acc[0][t][r], o1 = acc[1][t][r], o2 = acc[2][t][r], o3 = acc[3][t][r];
+            if (p.epi == QG_EPI_SCALE_BIAS) {
+                const float a_ = rs[ml], b_ = bs[ml];
+                o0 = o0 * a_ + b_; o1 = o1 * a_ + b_; o2 = o2 * a_ + b_; o3 = o3 * a_ + b_;
+            } else if (p.epi == QG_EPI_STE) {
+                const float4 xv = *reinterpret_cast<const float4*>(p.aux + off);
+                if (p.ste.mode == MN_ACTQ_DOREFA) {
+                    o0 = dorefa_act_grad(o0, xv.x, p.ste.s); o1 = dorefa_act_grad(o1, xv.y, p.ste.s);
+                    o2 = dorefa_act_grad(o2, xv.z, p.ste.s); o3 = dorefa_act_grad(o3, xv.w, p.ste.s);
+                } else if (p.ste.mode == MN_ACTQ_IAO) {
+                    o0 = iao_fq_grad(o0, xv.x, ste_sc, ste_zp, ste_lo, ste_hi, p.ste.qmin, p.ste.qmax);
+                    o1 = iao_fq_grad(o1, xv.y, ste_sc, ste_zp, ste_lo, ste_hi, p.ste.qmin, p.ste.qmax);
+                    o2 = iao_fq_grad(o2, xv.z, ste_sc, ste_zp, ste_lo, ste_hi, p.ste.qmin, p.ste.qmax);
+                    o3 = iao_fq_grad(o3, xv.w, ste_sc, ste_zp, ste_lo, ste_hi, p.ste.qmin, p.ste.qmax);
+                }
+            }
+            *reinterpret_cast<float4*>(p.out + off) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static const size_t KK_LDS_CAP = 128 * 1024;   // one block per CU in the worst case (large kernels on small images); typical layers use 25-60 KB
+static int kk_out_dim(int in, int k, int s, int pd, int d) { return (in + 2 * pd - d * (k - 1) - 1) / s + 1; }
+
+struct KkPlan {
+    KkParams p;
+    PackParams pk;
+    int NT, xmode;
+    size_t lds;
+    int grid, pack_grid;
+    int64_t off_codes, off_scale, ws_bytes;
+};
+// which: 0 forward, 1 backward-data (as a forward-style contraction over gy with flipped taps)
+static int plan_kk(const mn_conv_geom* g, int which, int xmode, KkPlan* pl) {
+    KkParams& p = pl->p;
+    const int Ho = kk_out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = kk_out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+    const int Cg = g->C / g->groups, Mg = g->O / g->groups;
+    p.N = g->N; p.G = g->groups; p.KH = g->KH; p.KW = g->KW; p.T = g->KH * g->KW; p.Dh = g->dil_h; p.Dw = g->dil_w;
+    if (which == 0) {
+        p.Cin_total = g->C; p.Hin = g->H; p.Win = g->W; p.Kc = Cg; p.Cout_total = g->O; p.Ho = Ho; p.Wo = Wo; p.Mr = Mg;
+        p.Sh = g->stride_h; p.Sw = g->stride_w; p.ph = g->pad_h; p.pw = g->pad_w;
+    } else {
+        if (g->stride_h != 1 || g->stride_w != 1) return 0;
+        p.Cin_total = g->O; p.Hin = Ho; p.Win = Wo; p.Kc = Mg; p.Cout_total = g->C; p.Ho = g->H; p.Wo = g->W; p.Mr = Cg;
+        p.Sh = 1; p.Sw = 1; p.ph = (g->KH - 1) * g->dil_h - g->pad_h; p.pw = (g->KW - 1) * g->dil_w - g->pad_w;
+        if (p.ph < 0 || p.pw < 0) return 0;
+        xmode = MN_ACTQ_NONE;
+    }
+    if (p.Win % 4 || p.Wo % 4 || p.T > 64) return 0;
+    // 256-pixel tiles made of whole output rows
+    const int TP = 256;
+    if (TP % p.Wo) return 0;
+    const int rpt = TP / p.Wo;
+    if (rpt >= p.Ho) {
+        if (rpt % p.Ho) return 0;
+        p.NI = rpt / p.Ho; p.TR = p.Ho; p.tpi = 1;
+        p.num_ptiles = (p.N + p.NI - 1) / p.NI;
+    } else {
+        if (p.Ho % rpt) return 0;
+        p.NI = 1; p.TR = rpt; p.tpi = p.Ho / rpt;
+        p.num_ptiles = p.N * p.tpi;
+    }
+    p.PR = (p.TR - 1) * p.Sh + (p.KH - 1) * p.Dh + 1;
+    p.PWp = (p.Wo - 1) * p.Sw + (p.KW - 1) * p.Dw + 1;
+    p.npos = p.NI * p.PR * p.PWp;
+    const int nterm = xmode == MN_ACTQ_NONE ? 3 : 1;
+    p.CC = (p.Kc <= 16 || nterm == 3) ? 16 : 32;
+    p.cc_shift = p.CC == 16 ? 4 : 5;
+    p.nck = (p.Kc + p.CC - 1) / p.CC;
+    p.Cgp = p.nck * p.CC;
+    p.KS = (p.T * p.CC + 31) / 32;
+    p.LDW = p.KS * 32 + 8;
+    p.PSB = nterm * p.CC * 2 + 16;
+    p.W4 = p.Win / 4;
+    int NT = p.Mr > 32 ? 4 : (p.Mr > 16 ? 2 : 1);
+    size_t lds;
+    for (;;) {
+        lds = (size_t)p.npos * p.PSB + (size_t)16 * NT * p.LDW * 2 + (size_t)2 * 16 * NT * 4 + (size_t)p.T * 4 + (size_t)p.nck * 8;
+        lds = (lds + 15) / 16 * 16;
+        if (lds <= KK_LDS_CAP) break;
+        if (NT == 1) return 0;
+        NT /= 2;
+    }
+    pl->NT = NT; pl->lds = lds; pl->xmode = xmode;
+    p.num_mblk = (p.Mr + 16 * NT - 1) / (16 * NT);
+    p.Mpad = p.num_mblk * 16 * NT;
+    p.fd_wo = make_fastdiv(p.Wo); p.fd_tr = make_fastdiv(p.TR); p.fd_tpi = make_fastdiv(p.tpi); p.fd_pwp = make_fastdiv(p.PWp);
+    p.fd_pr = make_fastdiv(p.PR); p.fd_w4 = make_fastdiv(p.W4); p.fd_o8 = make_fastdiv(p.CC / 8);
+    const int64_t nb = (int64_t)p.num_ptiles * p.num_mblk * p.G;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    pl->off_codes = 0;
+    const int64_t code_bytes = (int64_t)p.G * p.Mpad * p.T * p.Cgp * 2;
+    pl->off_scale = (code_bytes + 255) / 256 * 256;
+    const int64_t nscale = which == 0 ? (int64_t)p.G * p.Mpad : (int64_t)p.G * p.Cgp;
+    pl->ws_bytes = pl->off_scale + nscale * 4;
+    PackParams& k = pl->pk;
+    k.G = g->groups; k.Mg = Mg; k.Cg = Cg; k.T = p.T; k.KW = g->KW; k.transpose = which == 1;
+    k.Mpad = which == 0 ? p.Mpad : 0; k.Cgp = which == 0 ? p.Cgp : 0;
+    k.Cpad = which == 1 ? p.Mpad : 0; k.Mgp = which == 1 ? p.Cgp : 0;
+    pl->pack_grid = k.G * (which == 0 ? k.Mpad : k.Mgp);
+    return 1;
+}
+
+template <int NT>
+static void launch_kk(const KkPlan& pl, hipStream_t s) {
+    if (pl.xmode == MN_ACTQ_DOREFA) {
+        raise_lds_limit((const void*)k_kk<NT, MN_ACTQ_DOREFA>, pl.lds);
+        hipLaunchKernelGGL((k_kk<NT, MN_ACTQ_DOREFA>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else if (pl.xmode == MN_ACTQ_IAO) {
+        raise_lds_limit((const void*)k_kk<NT, MN_ACTQ_IAO>, pl.lds);
+        hipLaunchKernelGGL((k_kk<NT, MN_ACTQ_IAO>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else {
+        raise_lds_limit((const void*)k_kk<NT, MN_ACTQ_NONE>, pl.lds);
+        hipLaunchKernelGGL((k_kk<NT, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    }
+}
+static int run_kk(const KkPlan& pl, hipStream_t s, const char* what) {
+    switch (pl.NT) {
+        case 1: launch_kk<1>(pl, s); break;
+        case 2: launch_kk<2>(pl, s); break;
+        case 4: launch_kk<4>(pl, s); break;
+        default: MN_FAIL(MN_EINVAL, "%s: bad NT", what);
+    }
+    MN_CHECK_LAUNCH(what);
+    return MN_OK;
+}
+
+int kk_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y,
+           void* ws, int64_t ws_bytes, hipStream_t s) {
+    KkPlan pl;
+    if (!wq_codeable(wq) || !aq_codeable(aq, 0) || !plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl) || !aligned16(x) || !aligned16(y))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(qgemm): geometry / quantizer combination not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(qgemm kxk): workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)pl.ws_bytes);
+    Pro pro;
+    int rc = make_pro(aq, &pro, 0, "mn_conv2d_fwd(qgemm)");
+    if (rc) return rc;
+    fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
+    qg_launch_pack(pl.pk, pl.pack_grid, s);
+    KkParams& p = pl.p;
+    p.in = x; p.out = y; p.wc = pl.pk.codes; p.rowscale = pl.pk.scale_out; p.kscale = nullptr; p.bias = bias; p.aux = nullptr;
+    p.pro = pro; p.ste = pro; p.epi = QG_EPI_SCALE_BIAS; p.ascale = pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f;
+    return run_kk(pl, s, "mn_conv2d_fwd(qgemm kxk)");
+}
+int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
+                void* ws, int64_t ws_bytes, hipStream_t s) {
+    KkPlan pl;
+    if (!wq_codeable(wq) || !plan_kk(g, 1, MN_ACTQ_NONE, &pl) || !aligned16(gy) || !aligned16(dx))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(qgemm): geometry / quantizer combination not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data(qgemm kxk): workspace too small");
+    Pro ste;
+    int rc = make_pro(aq, &ste, 1, "mn_conv2d_bwd_data(qgemm)");
+    if (rc) return rc;
+    if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
+    fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
+    qg_launch_pack(pl.pk, pl.pack_grid, s);
+    Pro none; none.mode = MN_ACTQ_NONE; none.s = 1.f; none.qmin = none.qmax = 0.f; none.qp = nullptr;
+    KkParams& p = pl.p;
+    p.in = gy; p.out = dx; p.wc = pl.pk.codes; p.rowscale = nullptr; p.kscale = pl.pk.scale_out; p.bias = nullptr; p.aux = x;
+    p.pro = none; p.ste = ste; p.epi = ste.mode == MN_ACTQ_NONE ? QG_EPI_PLAIN : QG_EPI_STE; p.ascale = 1.f;
+    return run_kk(pl, s, "mn_conv2d_bwd_data(qgemm kxk)");
+}
+
+// ------------------------------------------------------------------------------------------------
+// k x k backward-weight:  dwq[g][m][c][tap] = sum over output pixels of gy[m][pixel] * code_x[c][pixel shifted by tap].
+// K = output pixels.  Both operands are pixel-contiguous in NCHW, so fragments are 8 consecutive pixels of one row:
+//   A: gy rows (three exact bf16 terms) staged as [term][m][tile pixel];
+//   B: the activation codes staged as KW column-shifted copies [s][c][patch row][ocol] = code_x[c][row][ocol + s*Dw - pw],
+//      so that the fragment of tap (r, s) starts on a 16-byte boundary for every s (a ds_read_b128 must be aligned);
+// every tap is one 16-column N tile (16 input channels per block).  The four waves split the tile's 32-pixel K-steps; at
+// the end of the block's tile range they sum their accumulators through LDS in wave order (deterministic) and write ONE
+// partial tile; a second kernel reduces the Z partials in fp64.  dbias is accumulated from the staged gy values.
+struct KwParams {
+    const float* gy;
+    const float* x;
+    float* part;      // [Z][G][Mgw][Cgw*T]
+    float* dbpart;    // [Z][G][Mgw]
+    Pro pro;
+    int N, C, H, W, O, Ho, Wo, Cg, Mg, G, KH, KW, T, Sh, Dh, Dw, ph, pw;
+    int NI, TR, tpi, PR, num_ptiles, GS, XCS, EQ, PWL, nmb, ncb, Z, Mgw, Cgw, want_db;
+    FastDiv fd_wo, fd_tr, fd_tpi, fd_pr, fd_eq, fd_ppi;
+};
+#define KW_TP 256     // output pixels per tile
+#define KW_CC 16      // input channels per block (one c-tile)
+
+template <int MT, int NTL, int XMODE>
+__global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int MTt = 16 * MT, NDB = MTt / 4;
+    uint16_t* gt = reinterpret_cast<uint16_t*>(smem);                 // [3][MTt][GS]; after the last tile: float red[MTt][16*T]
+    const size_t gt_bytes = (size_t)3 * MTt * p.GS * 2, red_bytes = (size_t)MTt * KW_CC * p.T * 4;
+    uint16_t* xc = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + (gt_bytes > red_bytes ? gt_bytes : red_bytes));   // [KW][16][XCS]
+    int* ntoff = reinterpret_cast<int*>(xc + (size_t)p.KW * KW_CC * p.XCS);      // [T] element offset of a tap inside xc
+    int* xflag = ntoff + p.T;                                        // [2], alternating per tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    uint32_t b = blockIdx.x;
+    const int z = b % p.Z; b /= p.Z;
+    const int cb = b % p.ncb; b /= p.ncb;
+    const int mb = b % p.nmb;
+    const int g = b / p.nmb;
+    float sc = 1.f, zp = 0.f;
+    if (XMODE == MN_ACTQ_IAO) { sc = p.pro.qp[0]; zp = p.pro.qp[1]; }
+
+    for (int tap = tid; tap < p.T; tap += 256) {
+        const int r = tap / p.KW, s_ = tap - r * p.KW;
+        ntoff[tap] = s_ * KW_CC * p.XCS + r * p.Dh * p.Wo;
+    }
+    if (tid < 2) xflag[tid] = 0;
+
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbacc[NDB];          // rows wave + 4i of the block's gy slab (the staging loop below always gives a thread the same rows)
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) dbacc[i] = 0.f;
+
+    const int HoWo = p.Ho * p.Wo, px_per_img = p.TR * p.Wo;
+    const int64_t xplane = (int64_t)p.H * p.W;
+
+    auto stage_gy = [&](int n0, int oh0) {
+        const int pix = (tid & 63) * 4;
+        const uint32_t img = fd_div(pix, p.fd_ppi);
+        const int rem = pix - img * px_per_img;
+        const int n = n0 + (int)img;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+            const int m = wave + 4 * i, mo = mb * MTt + m;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < p.N && mo < p.Mg) f = *reinterpret_cast<const float4*>(p.gy + ((int64_t)n * p.O + (int64_t)g * p.Mg + mo) * HoWo + oh0 * p.Wo + rem);
+            const float v[4] = {f.x, f.y, f.z, f.w};
+            float t0[4], t1[4], t2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t0[e] = mn_bf16_head(v[e]);
+                const float r1 = v[e] - t0[e];
+                t1[e] = mn_bf16_head(r1);
+                t2[e] = r1 - t1[e];
+            }
+            dbacc[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            uint16_t* d = gt + m * p.GS + pix;
+            *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
+            *reinterpret_cast<u32x2*>(d + MTt * p.GS) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
+            *reinterpret_cast<u32x2*>(d + 2 * MTt * p.GS) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
+        }
+    };
+    // term 0: codes (or the bf16 head of a real x); terms 1, 2: the remainders of a real x (slow path)
+    auto stage_x = [&](int n0, int row0, int term, int par) {
+        const int nitem = KW_CC * p.NI * p.PR * p.EQ;
+        unsigned inx = 0u;
+        for (int it = tid; it < nitem; it += 256) {
+            const uint32_t t1 = fd_div(it, p.fd_eq);
+            const int eq = it - t1 * p.EQ;
+            const uint32_t t2 = fd_div(t1, p.fd_pr);
+            const int prow = t1 - t2 * p.PR;
+            const int cl = (int)t2 / p.NI, slot = (int)t2 - cl * p.NI;
+            const int c = cb * KW_CC + cl, n = n0 + slot, ir = row0 + prow, ic0 = eq * 4 - p.PWL;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = c < p.Cg && n < p.N && ir >= 0 && ir < p.H && ic0 >= 0 && ic0 + 3 < p.W;
+            if (ok) f = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.C + (int64_t)g * p.Cg + c) * xplane + (int64_t)ir * p.W + ic0);
+            float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (XMODE == MN_ACTQ_NONE) {
+                    float r = v[e] - mn_bf16_head(v[e]);
+                    if (term == 0) { inx |= mn_f2u(r) << 1; }
+                    else { if (term == 2) r = r - mn_bf16_head(r); v[e] = r; }
+                } else {
+                    v[e] = ok ? act_code<XMODE>(v[e], p.pro, sc, zp) : 0.f;
+                }
+            }
+            uint16_t* rowp = xc + (size_t)cl * p.XCS + (slot * p.PR + prow) * p.Wo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint16_t hb = (uint16_t)(mn_f2u(v[e]) >> 16);
+                for (int s_ = 0; s_ < p.KW; ++s_) {
+                    const int ocol = ic0 + e - s_ * p.Dw + p.pw;
+                    if (ocol >= 0 && ocol < p.Wo) rowp[(size_t)s_ * KW_CC * p.XCS + ocol] = hb;
+                }
+            }
+        }
+        if (XMODE == MN_ACTQ_NONE && term == 0 && inx) xflag[par] = 1;
+    };
+    auto contract = [&]() {
+        for (int ks = wave; ks < KW_TP / 32; ks += 4) {
+            const int pi = ks * 32 + kg * 8;
+            const uint32_t fr = fd_div(pi, p.fd_wo);
+            const int ocol0 = pi - fr * p.Wo;
+            const uint32_t slot = fd_div(fr, p.fd_tr);
+            const int orow = fr - slot * p.TR;
+            const uint16_t* xb = xc + (size_t)j * p.XCS + ((int)slot * p.PR + orow * p.Sh) * p.Wo + ocol0;
+            u32x4 a[MT][3];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+                    a[mi][term] = *reinterpret_cast<const u32x4*>(gt + (term * MTt + mi * 16 + j) * p.GS + pi);
+#pragma unroll
+            for (int ni = 0; ni < NTL; ++ni) {
+                if (ni < p.T) {
+                    const u32x4 bf = *reinterpret_cast<const u32x4*>(xb + ntoff[ni]);
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int term = 0; term < 3; ++term) acc[mi][ni] = mn_mfma_bf16(a[mi][term], bf, acc[mi][ni]);
+                }
+            }
+        }
+    };
+
+    int par = 0;
+    for (int pt = z; pt < p.num_ptiles; pt += p.Z, par ^= 1) {
+        const uint32_t timg = fd_div(pt, p.fd_tpi);
+        const int n0 = (int)timg * p.NI;
+        const int oh0 = (pt - (int)timg * p.tpi) * p.TR;
+        const int row0 = oh0 * p.Sh - p.ph;
+        __syncthreads();                       // previous tile consumed; tables / flags visible
+        stage_gy(n0, oh0);
+        stage_x(n0, row0, 0, par);
+        __syncthreads();
+        const int inexact = (XMODE == MN_ACTQ_NONE) ? xflag[par] : 0;
+        if (XMODE == MN_ACTQ_NONE && tid == 0) xflag[par ^ 1] = 0;
+        contract();
+        if (inexact) {                         // block-uniform: a real-valued x, contract its second and third term as well
+            for (int term = 1; term <= 2; ++term) {
+                __syncthreads();
+                stage_x(n0, row0, term, par);
+                __syncthreads();
+                contract();
+            }
+        }
+    }
+    // ---- sum the four waves' accumulators in wave order through LDS, then one coalesced partial-tile write
+    float* red = reinterpret_cast<float*>(smem);
+    const int RW = KW_CC * p.T;                // columns of the block's dw tile: (c_local, tap)
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NTL; ++ni) {
+                    if (ni < p.T) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int idx = (mi * 16 + kg * 4 + r) * RW + j * p.T + ni;
+                            red[idx] = (w == 0) ? acc[mi][ni][r] : red[idx] + acc[mi][ni][r];
+                        }
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < MTt * RW; i += 256) {
+        const int m = i / RW, col = i - m * RW;
+        p.part[(((int64_t)z * p.G + g) * p.Mgw + mb * MTt + m) * ((int64_t)p.Cgw * p.T) + (int64_t)cb * RW + col] = red[i];
+    }
+    if (p.want_db && cb == 0) {
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+            float v = dbacc[i];
+            v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            if (lane == 0) p.dbpart[((int64_t)z * p.G + g) * p.Mgw + mb * MTt + wave + 4 * i] = v;
+        }
+    }
+}
+
+struct KwPlan {
+    KwParams p;
+    int MT, NTL;
+    size_t lds;
+    int grid;
+    int64_t off_db, ws_bytes;
+};
+static int plan_kk_wgrad(const mn_conv_geom* g, KwPlan* pl) {
+    KwParams& p = pl->p;
+    p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.G = g->groups; p.KH = g->KH; p.KW = g->KW; p.T = g->KH * g->KW;
+    p.Ho = kk_out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h); p.Wo = kk_out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+    p.Cg = g->C / g->groups; p.Mg = g->O / g->groups; p.Sh = g->stride_h; p.Dh = g->dil_h; p.Dw = g->dil_w; p.ph = g->pad_h; p.pw = g->pad_w;
+    if (g->stride_w != 1 || p.W % 4 || p.Wo % 8 || KW_TP % p.Wo) return 0;
+    if (p.T <= 9) pl->NTL = 9; else if (p.T <= 25) pl->NTL = 25; else return 0;
+    pl->MT = (pl->NTL == 9 && p.Mg > 16) ? 2 : 1;
+    const int MTt = 16 * pl->MT;
+    const int rpt = KW_TP / p.Wo;
+    if (rpt >= p.Ho) {
+        if (rpt % p.Ho) return 0;
+        p.NI = rpt / p.Ho; p.TR = p.Ho; p.tpi = 1; p.num_ptiles = (p.N + p.NI - 1) / p.NI;
+    } else {
+        if (p.Ho % rpt) return 0;
+        p.NI = 1; p.TR = rpt; p.tpi = p.Ho / rpt; p.num_ptiles = p.N * p.tpi;
+    }
+    p.PR = (p.TR - 1) * p.Sh + (p.KH - 1) * p.Dh + 1;
+    p.GS = KW_TP + 8;
+    p.XCS = p.NI * p.PR * p.Wo + 8;
+    p.PWL = qg_roundup(p.pw, 4);
+    const int max_ic = p.Wo - 1 + (p.KW - 1) * p.Dw - p.pw;          // last input column any tap touches
+    p.EQ = (max_ic + p.PWL) / 4 + 1;
+    const size_t gt_bytes = (size_t)3 * MTt * p.GS * 2, red_bytes = (size_t)MTt * KW_CC * p.T * 4;
+    size_t lds = (gt_bytes > red_bytes ? gt_bytes : red_bytes) + (size_t)p.KW * KW_CC * p.XCS * 2 + (size_t)p.T * 4 + 16;
+    lds = (lds + 15) / 16 * 16;
+    if (lds > KK_LDS_CAP) return 0;
+    pl->lds = lds;
+    p.nmb = (p.Mg + MTt - 1) / MTt; p.ncb = (p.Cg + KW_CC - 1) / KW_CC;
+    p.Mgw = p.nmb * MTt; p.Cgw = p.ncb * KW_CC;
+    const int base = p.G * p.nmb * p.ncb;
+    int Z = 512 / base;
+    if (Z > p.num_ptiles / 2) Z = p.num_ptiles / 2;
+    if (Z < 1) Z = 1;
+    p.Z = Z;
+    p.fd_wo = make_fastdiv(p.Wo); p.fd_tr = make_fastdiv(p.TR); p.fd_tpi = make_fastdiv(p.tpi); p.fd_pr = make_fastdiv(p.PR);
+    p.fd_eq = make_fastdiv(p.EQ); p.fd_ppi = make_fastdiv(p.TR * p.Wo);
+    const int64_t nb = (int64_t)base * Z;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    const int64_t part_bytes = (int64_t)Z * p.G * p.Mgw * p.Cgw * p.T * 4;
+    pl->off_db = (part_bytes + 255) / 256 * 256;
+    pl->ws_bytes = pl->off_db + (int64_t)Z * p.G * p.Mgw * 4;
+    return 1;
+}
+template <int MT, int NTL>
+static void launch_kw(const KwPlan& pl, int xmode, hipStream_t s) {
+    if (xmode == MN_ACTQ_DOREFA) {
+        raise_lds_limit((const void*)k_kk_wgrad<MT, NTL, MN_ACTQ_DOREFA>, pl.lds);
+        hipLaunchKernelGGL((k_kk_wgrad<MT, NTL, MN_ACTQ_DOREFA>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else if (xmode == MN_ACTQ_IAO) {
+        raise_lds_limit((const void*)k_kk_wgrad<MT, NTL, MN_ACTQ_IAO>, pl.lds);
+        hipLaunchKernelGGL((k_kk_wgrad<MT, NTL, MN_ACTQ_IAO>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else {
+        raise_lds_limit((const void*)k_kk_wgrad<MT, NTL, MN_ACTQ_NONE>, pl.lds);
+        hipLaunchKernelGGL((k_kk_wgrad<MT, NTL, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    }
+}
+
+int kk_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
+    KkPlan pl;
+    if (which == 0) return wq_codeable(wq) && aq_codeable(aq, 0) && plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl);
+    if (which == 1) return wq_codeable(wq) && plan_kk(g, 1, MN_ACTQ_NONE, &pl);
+    if (which == 2) { KwPlan kw; return aq_codeable(aq, 1) && plan_kk_wgrad(g, &kw); }
+    return 0;
+}
+int64_t kk_ws_bytes(const mn_conv_geom* g, int which) {
+    KkPlan pl;
+    if (which == 0) {   // the plan (hence Mpad / Cgp) depends on the activation mode: take the larger
+        int64_t a = plan_kk(g, 0, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0;
+        int64_t b = plan_kk(g, 0, MN_ACTQ_DOREFA, &pl) ? pl.ws_bytes : 0;
+        return a > b ? a : b;
+    }
+    if (which == 1) return plan_kk(g, 1, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0;
+    if (which == 2) { KwPlan kw; return plan_kk_wgrad(g, &kw) ? kw.ws_bytes : 0; }
+    return 0;
+}
+int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
+                  int64_t ws_bytes, hipStream_t s) {
+    KwPlan pl;
+    if (!aq_codeable(aq, 1) || !plan_kk_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(qgemm): geometry / quantizer combination not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(qgemm kxk): workspace too small");
+    Pro pro;
+    int rc = make_pro(aq, &pro, 0, "mn_conv2d_bwd_weight(qgemm)");
+    if (rc) return rc;
+    KwParams& p = pl.p;
+    p.gy = gy; p.x = x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.pro = pro; p.want_db = dbias != nullptr;
+    if (pl.NTL == 9 && pl.MT == 2) launch_kw<2, 9>(pl, pro.mode, s);
+    else if (pl.NTL == 9) launch_kw<1, 9>(pl, pro.mode, s);
+    else launch_kw<1, 25>(pl, pro.mode, s);
+    qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg * p.T, p.Mgw, p.Cgw * p.T,
+                           pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f, pro.mode == MN_ACTQ_IAO ? pro.qp : (const float*)nullptr, s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(qgemm kxk)");
+    return MN_OK;
+}

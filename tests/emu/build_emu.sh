@@ -7,6 +7,7 @@ CXX="g++ -O2 -std=c++17 -fPIC -ffp-contract=off -I tests/emu/include -x c++"
 $CXX -DMN_EMU_MAIN -c micronet_amd/csrc/quant_kernels.hip -o tests/emu/build/quant_kernels.o &
 $CXX -c micronet_amd/csrc/conv_kernels.hip -o tests/emu/build/conv_kernels.o &
 $CXX -c micronet_amd/csrc/qgemm_kernels.hip -o tests/emu/build/qgemm_kernels.o &
+$CXX -c micronet_amd/csrc/qgemm_kxk.hip -o tests/emu/build/qgemm_kxk.o &
 wait
-g++ -shared -o tests/emu/build/libmicronet_emu.so tests/emu/build/quant_kernels.o tests/emu/build/conv_kernels.o tests/emu/build/qgemm_kernels.o
+g++ -shared -o tests/emu/build/libmicronet_emu.so tests/emu/build/quant_kernels.o tests/emu/build/conv_kernels.o tests/emu/build/qgemm_kernels.o tests/emu/build/qgemm_kxk.o
 echo built tests/emu/build/libmicronet_emu.so

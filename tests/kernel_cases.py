@@ -294,3 +294,19 @@ QGEMM_PW_CASES = [
     # Mg=10 (single 16-row tile), Cg=96 (3 K-steps): the nin_gc L9 pattern
     dict(x_shape=(2, 96, 8, 8), w_shape=(10, 96, 1, 1)),
 ]
+
+# k x k geometries for the code-domain kernels (tile = 256 output pixels = whole rows)
+QGEMM_KXK_CASES = [
+    # 3x3 pad 1 grouped, 8x8 images (4 images per tile, N=3 -> masked slot), Cg=16, Mg=32: the nin_gc L7 pattern
+    dict(x_shape=(3, 32, 8, 8), w_shape=(64, 16, 3, 3), padding=1, groups=2),
+    # 16x16 image = one tile, Cg=6 (padded to 16), Mg=40 (NT=4 with masked rows)
+    dict(x_shape=(2, 6, 16, 16), w_shape=(40, 6, 3, 3), padding=1),
+    # 5x5 pad 2, Cin=3: the first-layer pattern (iao)
+    dict(x_shape=(2, 3, 8, 8), w_shape=(24, 3, 5, 5), padding=2),
+    # dilation 2
+    dict(x_shape=(2, 4, 8, 8), w_shape=(8, 4, 3, 3), padding=2, dilation=2),
+    # two channel chunks (Cg=40), 32-wide rows (8 rows per tile, 2 tiles per image)
+    dict(x_shape=(1, 40, 16, 32), w_shape=(16, 40, 3, 3), padding=1, bias=False),
+    # stride 2 (forward only in the code domain)
+    dict(x_shape=(2, 8, 16, 16), w_shape=(24, 8, 3, 3), stride=2, padding=1, bias=False),
+]

@@ -96,15 +96,37 @@ def test_qgemm_pointwise_fused_actq(be, case, mode, q_type):
                  expect_qgemm=True, **K.QGEMM_PW_CASES[case])
 
 
-QGEMM_HOT = [(n, kw) for n, kw in HOT_SHAPES if kw["w_shape"][2] == 1 and kw.get("stride", 1) == 1]
+KXK_SUP = [True] * 5 + [(True, False, False)]
+
+
+@pytest.mark.parametrize("case", range(len(K.QGEMM_KXK_CASES)))
+def test_qgemm_kxk_binary_x(be, case):
+    K.check_conv(be, seed=70 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=KXK_SUP[case] if case != 5 else False,
+                 **K.QGEMM_KXK_CASES[case])
+
+
+@pytest.mark.parametrize("case", [0, 4])
+def test_qgemm_kxk_real_x(be, case):
+    K.check_conv(be, seed=75 + case, wmode=3, wbits=8, algos=(3,), expect_qgemm=KXK_SUP[case], **K.QGEMM_KXK_CASES[case])
+
+
+@pytest.mark.parametrize("case,mode", [(0, 1), (1, 2), (2, 2), (4, 1), (5, 1)])
+def test_qgemm_kxk_fused_actq(be, case, mode):
+    K.check_conv(be, seed=80 + case, mode=mode, bits=4, wmode=2 if mode == 1 else 3, wbits=4, algos=(3,),
+                 expect_qgemm=KXK_SUP[case], **K.QGEMM_KXK_CASES[case])
+
+
+QGEMM_HOT = [(n, kw) for n, kw in HOT_SHAPES if kw.get("stride", 1) == 1]
 
 
 @pytest.mark.parametrize("name,kw", QGEMM_HOT, ids=[n for n, _ in QGEMM_HOT])
 def test_qgemm_hot_shapes(be, name, kw):
-    K.check_conv(be, seed=81, wmode=1, binary_x=True, algos=(3, 0), expect_qgemm=True, **kw)          # wbwtab W3/A2
-    K.check_conv(be, seed=82, wmode=2, wbits=8, mode=1, bits=8, algos=(3,), expect_qgemm=True, **kw)   # DoReFa W8A8
-    K.check_conv(be, seed=83, wmode=3, wbits=8, mode=2, bits=8, algos=(3,), expect_qgemm=True, **kw)   # IAO W8A8 sym per-channel
-    K.check_conv(be, seed=84, wmode=1, algos=(3,), expect_qgemm=True, **kw)                           # real x (W-only quantization)
+    # 4x4 images: rows are shorter than one 8-pixel fragment, backward-weight stays on the fp32-MFMA kernel
+    exp = (True, True, False) if kw["x_shape"][3] < 8 and kw["w_shape"][2] > 1 else True
+    K.check_conv(be, seed=81, wmode=1, binary_x=True, algos=(3, 0), expect_qgemm=exp, **kw)          # wbwtab W3/A2
+    K.check_conv(be, seed=82, wmode=2, wbits=8, mode=1, bits=8, algos=(3,), expect_qgemm=exp, **kw)   # DoReFa W8A8
+    K.check_conv(be, seed=83, wmode=3, wbits=8, mode=2, bits=8, algos=(3,), expect_qgemm=exp, **kw)   # IAO W8A8 sym per-channel
+    K.check_conv(be, seed=84, wmode=1, algos=(3,), expect_qgemm=exp, **kw)                           # real x (W-only quantization)
 
 
 def test_full_size_properties(be):

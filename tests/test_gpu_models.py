@@ -154,10 +154,32 @@ def test_layerwise_teacher_forced(key):
                 errs["dbias"] = float((pn[pname].grad.cpu().double() - op.grad.double()).abs().max() / scale)
                 continue
             errs["d" + pname] = _rel(pn[pname].grad, op.grad)
+        # wbwtab convs sit behind a BatchNorm: the incoming gradient sums to ~0 per channel, so d weight is a heavily
+        # cancelling sum and the REFERENCE's own fp32 summation order shows up at the 1e-5 level.  For these units both
+        # sides are measured against an fp64 evaluation of the same oracle module (the quantizer decisions -- ternary
+        # threshold, signs -- do not depend on the precision for generic weights): ours must be within the tolerance of
+        # the exact value, or at least as close to it as the reference's fp32 CPU result is.
+        ref_slack = {}
+        if scheme == "wbwtab" and isinstance(om, TO.OConv2d):
+            import copy
+            om64 = copy.deepcopy(om).double()
+            for p_ in om64.parameters():
+                p_.grad = None
+            ins64 = [i.double().requires_grad_(True) for i in r["in"]]
+            om64(*ins64).backward(r["gout"].double())
+            p64 = dict(om64.named_parameters(recurse=False))
+            if "weight" in pn and p64["weight"].grad is not None:
+                g64 = p64["weight"].grad
+                sc64 = g64.abs().max().clamp_min(1e-300)
+                e_ours = float((pn["weight"].grad.double().cpu() - g64).abs().max() / sc64)
+                e_ref = float((oparams[n]["weight"].grad.double() - g64).abs().max() / sc64)
+                errs["dweight"] = e_ours
+                ref_slack["dweight"] = 2.0 * e_ref
         report.append((n, type(pm).__name__, {k_: float("%.1e" % v) for k_, v in errs.items()}))
         for k_, v in errs.items():
             # DoReFa d weight: the element holding max|tanh w| receives -sum(du*t/2)/M^2, a cancelling fp32 sum whose
             # rounding in the REFERENCE depends on ATen's summation order (ours is accumulated in fp64)
             lim = 1e-4 if (k_ == "dweight" and "dorefa" in scheme) else tol
-            assert v <= lim, (key, n, type(pm).__name__, k_, v, report[-3:])
+            lim = max(lim, ref_slack.get(k_, 0.0))
+            assert v <= lim, (key, n, type(pm).__name__, k_, v, ref_slack, report[-3:])
     print(key, "worst per-layer rel err:", max(max(e.values()) for _, _, e in report))

@@ -69,3 +69,24 @@ def test_qgemm_pointwise_fused_actq(be, case, mode, q_type):
     """DoReFa / IAO activation quantizer fused: codes in the prologue, scale in the epilogue, clip-STE in bwd-data."""
     K.check_conv(be, seed=60 + case, mode=mode, bits=4, q_type=q_type, wmode=2 if mode == 1 else 3, wbits=4, algos=(3,),
                  expect_qgemm=True, **K.QGEMM_PW_CASES[case])
+
+
+KXK_SUP = [True] * 5 + [(True, False, False)]   # per case: (fwd, bwd_data, bwd_weight); stride 2: forward only
+
+
+@pytest.mark.parametrize("case", range(len(K.QGEMM_KXK_CASES)))
+def test_qgemm_kxk_binary_x(be, case):
+    # case 5 (stride 2 on 16x16): the three-term patch of 4 images exceeds the LDS budget -> not offered for real-valued x
+    K.check_conv(be, seed=70 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=KXK_SUP[case] if case != 5 else False,
+                 **K.QGEMM_KXK_CASES[case])
+
+
+@pytest.mark.parametrize("case", [0, 4])
+def test_qgemm_kxk_real_x(be, case):
+    K.check_conv(be, seed=75 + case, wmode=3, wbits=8, algos=(3,), expect_qgemm=KXK_SUP[case], **K.QGEMM_KXK_CASES[case])
+
+
+@pytest.mark.parametrize("case,mode", [(0, 1), (1, 2), (2, 2), (4, 1), (5, 1)])
+def test_qgemm_kxk_fused_actq(be, case, mode):
+    K.check_conv(be, seed=80 + case, mode=mode, bits=4, wmode=2 if mode == 1 else 3, wbits=4, algos=(3,),
+                 expect_qgemm=KXK_SUP[case], **K.QGEMM_KXK_CASES[case])
