@@ -172,6 +172,21 @@ int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq
 int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw,
                          float* dbias, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
 
+/* ------------------------------------------------------------------ optimizer step of the training loop
+ * <scheme>/main.py: optimizer.step() with torch.optim.Adam, one parameter group per tensor (wqaq/dorefa/main.py:308-315).
+ * One launch per MN_ADAM_MAX_TENSORS tensors; `tensors` is a HOST array (device pointers inside), copied into the kernel
+ * arguments.  Math = torch.optim.Adam (amsgrad off, L2 weight decay added to the gradient). `step` counts from 1. */
+#define MN_ADAM_MAX_TENSORS 32
+typedef struct mn_adam_tensor {
+    float* p;          /* parameter, updated in place */
+    const float* g;    /* gradient */
+    float* m;          /* exp_avg, updated in place */
+    float* v;          /* exp_avg_sq, updated in place */
+    int64_t n;         /* elements */
+    float lr, weight_decay;
+} mn_adam_tensor;
+int mn_adam_step(const mn_adam_tensor* tensors, int count, int step, float beta1, float beta2, float eps, mn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

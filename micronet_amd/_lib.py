@@ -33,6 +33,11 @@ class WQ(C.Structure):
                 ("scale", C.c_void_p)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
+                ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
 _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _G, _A, _W = C.POINTER(ConvGeom), C.POINTER(ActQ), C.POINTER(WQ)
 
@@ -62,6 +67,7 @@ PROTOTYPES = {
     "mn_bn_stats_ws_floats": (_L, [_L, _L, _L]),
     "mn_bn_stats_fwd": (_I, [_P, _L, _L, _L, _P, _P, _P]),
     "mn_bn_stats_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _P]),
+    "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),
     "mn_conv2d_mfma_supported": (_I, [_G, _I]),
     "mn_conv2d_qgemm_supported": (_I, [_G, _A, _W, _I]),

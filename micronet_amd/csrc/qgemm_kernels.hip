@@ -451,26 +451,32 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
         }
     }
 }
-// fixed-order reduction of the Z partial tiles (fp64 accumulate, one rounding), times the activation scale
+// fixed-order reduction of the Z partial tiles (fp64 accumulate, one rounding), times the activation scale.
+// Eight lanes share an output: lane s sums partials s, s+8, ... and the eight sums are combined by a butterfly -- the same
+// order on every run (deterministic), 8x the parallelism of one thread per output.
 __global__ __launch_bounds__(256) void k_pw_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
                                                          float* __restrict__ db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
                                                          float ascale, const float* __restrict__ qp) {
     const float as = qp ? qp[0] : ascale;
     const int64_t nw = (int64_t)G * Mg * Cg, total = nw + (db ? (int64_t)G * Mg : 0);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x & 7;
+    const int64_t nslots = ((total + 31) / 32) * 32;           // whole waves take part in the shuffles
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < nslots; i += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        double s = 0.0;
         if (i < nw) {
             const int c = (int)(i % Cg);
             const int64_t o = i / Cg;
             const int g = (int)(o / Mg), m = (int)(o % Mg);
-            double s = 0.0;
-            for (int z = 0; z < Z; ++z) s += (double)part[(((int64_t)z * G + g) * Mgw + m) * Cgw + c];
-            dw[i] = (float)s * as;
-        } else {
+            for (int z = sub; z < Z; z += 8) s += (double)part[(((int64_t)z * G + g) * Mgw + m) * Cgw + c];
+        } else if (i < total) {
             const int64_t o = i - nw;
             const int g = (int)(o / Mg), m = (int)(o % Mg);
-            double s = 0.0;
-            for (int z = 0; z < Z; ++z) s += (double)dbpart[((int64_t)z * G + g) * Mgw + m];
-            db[o] = (float)s;
+            for (int z = sub; z < Z; z += 8) s += (double)dbpart[((int64_t)z * G + g) * Mgw + m];
+        }
+        s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+        if (sub == 0) {
+            if (i < nw) dw[i] = (float)s * as;
+            else if (i < total) db[i - nw] = (float)s;
         }
     }
 }
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_reduce(const float* __restrict
 void qg_launch_wgrad_reduce(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
                             float ascale, const float* qp, hipStream_t s) {
     const int64_t total = (int64_t)G * Mg * Cg + (db ? (int64_t)G * Mg : 0);
-    hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(mn_grid_for(total, 256, 2048)), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp);
+    hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(mn_grid_for(total * 8, 256, 4096)), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -31,11 +31,15 @@ struct KkParams {
     float ascale;
 };
 
-template <int NT, int XMODE>
+// PL = number of term planes kept in LDS.  XMODE NONE (a real-valued stream): PL = 3 stores the three terms side by side
+// (backward-data: gy always needs them); PL = 1 stores one term at a time -- the forward of wbwtab, whose +-1 activations
+// are exact in the first term: a block re-stages and re-contracts terms 2 and 3 only if it met an inexact element.
+template <int NT, int XMODE, int PL>
 __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     constexpr int MB = 16 * NT;
-    constexpr int NTERM = (XMODE == MN_ACTQ_NONE) ? 3 : 1;
+    constexpr int NTERM = PL;
+    constexpr bool ADAPT = (XMODE == MN_ACTQ_NONE) && PL == 1;
     char* patch = reinterpret_cast<char*>(smem);                              // [npos][PSB]
     uint16_t* wsm = reinterpret_cast<uint16_t*>(patch + (size_t)p.npos * p.PSB);   // [MB][LDW]
     float* rs = reinterpret_cast<float*>(wsm + MB * p.LDW);
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
             bs[i] = (p.bias && m < p.Mr) ? p.bias[g * p.Mr + m] : 0.f;
         }
         for (int t = tid; t < p.T; t += 256) toff[t] = ((t / p.KW) * p.Dh * p.PWp + (t % p.KW) * p.Dw) * p.PSB;
-        if (NTERM == 3) for (int t = tid; t < 2 * p.nck; t += 256) tflag[t] = 0;
+        if (XMODE == MN_ACTQ_NONE) for (int t = tid; t < 2 * p.nck; t += 256) tflag[t] = 0;
     }
 
     // patch byte offset of tap (0,0) of this lane's four pixels
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
             }
         }
         // ---- stage the interior: item = (slot, channel octet, patch row, input column quad)
-        {
+        auto stage_interior = [&](int term) {
             const int nitem = p.NI * o8n * p.PR * p.W4;
             unsigned any1 = 0u, any2 = 0u;
             for (int it = tid; it < nitem; it += 256) {
@@ -154,7 +158,14 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
                     if (NTERM == 1) {
                         float c8[8];
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) c8[jj] = act_code<XMODE>(v[jj][e], p.pro, sc, zp);
+                        for (int jj = 0; jj < 8; ++jj) {
+                            c8[jj] = act_code<XMODE>(v[jj][e], p.pro, sc, zp);
+                            if (ADAPT) {          // term 0: the bf16 head (packing truncates); terms 1, 2: the remainders
+                                float r = c8[jj] - mn_bf16_head(c8[jj]);
+                                if (term == 0) any1 |= mn_f2u(r) << 1;
+                                else { if (term == 2) r = r - mn_bf16_head(r); c8[jj] = r; }
+                            }
+                        }
                         *reinterpret_cast<u32x4*>(rec) = u32x4{mn_pack_bf16x2(c8[0], c8[1]), mn_pack_bf16x2(c8[2], c8[3]),
                                                               mn_pack_bf16x2(c8[4], c8[5]), mn_pack_bf16x2(c8[6], c8[7])};
                     } else {
@@ -178,14 +189,16 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
                     }
                 }
             }
-            if (NTERM == 3) {
+            if (NTERM == 3 || (ADAPT && term == 0)) {
                 if (any1) tflag[2 * ck] = 1;
                 if (any2) tflag[2 * ck + 1] = 1;
             }
-        }
+        };
+        stage_interior(0);
         __syncthreads();
         const int use1 = NTERM == 3 ? tflag[2 * ck] : 0, use2 = NTERM == 3 ? tflag[2 * ck + 1] : 0;   // block-uniform
         // ---- contraction over this chunk's K = T*CC
+        auto contract = [&]() {
         for (int ks = 0; ks < p.KS; ++ks) {
             const int kl = ks * 32 + kg * 8;
             const int tap = kl >> p.cc_shift, choff = (kl & (p.CC - 1)) * 2;
@@ -217,6 +230,16 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
                         for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b2[q], acc[q][t]);
                     }
                 }
+            }
+        }
+        };
+        contract();
+        if (ADAPT && tflag[2 * ck]) {          // block-uniform: real-valued x, add the contributions of its second and third term
+            for (int term = 1; term <= 2; ++term) {
+                __syncthreads();
+                stage_interior(term);
+                __syncthreads();
+                contract();
             }
         }
     }
@@ -268,7 +291,7 @@ static int kk_out_dim(int in, int k, int s, int pd, int d) { return (in + 2 * pd
 struct KkPlan {
     KkParams p;
     PackParams pk;
-    int NT, xmode;
+    int NT, xmode, planes;
     size_t lds;
     int grid, pack_grid;
     int64_t off_codes, off_scale, ws_bytes;
@@ -306,7 +329,7 @@ static int plan_kk(const mn_conv_geom* g, int which, int xmode, KkPlan* pl) {
     p.PR = (p.TR - 1) * p.Sh + (p.KH - 1) * p.Dh + 1;
     p.PWp = (p.Wo - 1) * p.Sw + (p.KW - 1) * p.Dw + 1;
     p.npos = p.NI * p.PR * p.PWp;
-    const int nterm = xmode == MN_ACTQ_NONE ? 3 : 1;
+    const int nterm = which == 1 ? 3 : 1;      // backward-data keeps the three terms of gy side by side
     p.CC = (p.Kc <= 16 || nterm == 3) ? 16 : 32;
     p.cc_shift = p.CC == 16 ? 4 : 5;
     p.nck = (p.Kc + p.CC - 1) / p.CC;
@@ -324,7 +347,7 @@ static int plan_kk(const mn_conv_geom* g, int which, int xmode, KkPlan* pl) {
         if (NT == 1) return 0;
         NT /= 2;
     }
-    pl->NT = NT; pl->lds = lds; pl->xmode = xmode;
+    pl->NT = NT; pl->lds = lds; pl->xmode = xmode; pl->planes = nterm;
     p.num_mblk = (p.Mr + 16 * NT - 1) / (16 * NT);
     p.Mpad = p.num_mblk * 16 * NT;
     p.fd_wo = make_fastdiv(p.Wo); p.fd_tr = make_fastdiv(p.TR); p.fd_tpi = make_fastdiv(p.tpi); p.fd_pwp = make_fastdiv(p.PWp);
@@ -345,18 +368,17 @@ static int plan_kk(const mn_conv_geom* g, int which, int xmode, KkPlan* pl) {
     return 1;
 }
 
+template <int NT, int XMODE, int PL>
+static void launch_kk1(const KkPlan& pl, hipStream_t s) {
+    raise_lds_limit((const void*)k_kk<NT, XMODE, PL>, pl.lds);
+    hipLaunchKernelGGL((k_kk<NT, XMODE, PL>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+}
 template <int NT>
 static void launch_kk(const KkPlan& pl, hipStream_t s) {
-    if (pl.xmode == MN_ACTQ_DOREFA) {
-        raise_lds_limit((const void*)k_kk<NT, MN_ACTQ_DOREFA>, pl.lds);
-        hipLaunchKernelGGL((k_kk<NT, MN_ACTQ_DOREFA>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
-    } else if (pl.xmode == MN_ACTQ_IAO) {
-        raise_lds_limit((const void*)k_kk<NT, MN_ACTQ_IAO>, pl.lds);
-        hipLaunchKernelGGL((k_kk<NT, MN_ACTQ_IAO>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
-    } else {
-        raise_lds_limit((const void*)k_kk<NT, MN_ACTQ_NONE>, pl.lds);
-        hipLaunchKernelGGL((k_kk<NT, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
-    }
+    if (pl.planes == 3) launch_kk1<NT, MN_ACTQ_NONE, 3>(pl, s);
+    else if (pl.xmode == MN_ACTQ_DOREFA) launch_kk1<NT, MN_ACTQ_DOREFA, 1>(pl, s);
+    else if (pl.xmode == MN_ACTQ_IAO) launch_kk1<NT, MN_ACTQ_IAO, 1>(pl, s);
+    else launch_kk1<NT, MN_ACTQ_NONE, 1>(pl, s);
 }
 static int run_kk(const KkPlan& pl, hipStream_t s, const char* what) {
     switch (pl.NT) {
@@ -423,13 +445,14 @@ struct KwParams {
     int NI, TR, tpi, PR, num_ptiles, GS, XCS, EQ, PWL, nmb, ncb, Z, Mgw, Cgw, want_db;
     FastDiv fd_wo, fd_tr, fd_tpi, fd_pr, fd_eq, fd_ppi;
 };
-#define KW_TP 256     // output pixels per tile
+#define KW_TP 128     // output pixels per tile (4 K-steps of 32 pixels: one per wave)
 #define KW_CC 16      // input channels per block (one c-tile)
+#define KW_XPF 5      // x items (float4) a thread prefetches into registers per tile (nin_gc 3x3 layers: 4-5 per thread)
 
 template <int MT, int NTL, int XMODE>
 __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
-    constexpr int MTt = 16 * MT, NDB = MTt / 4;
+    constexpr int MTt = 16 * MT, NDB = MTt / 8, TPQ = KW_TP / 4;
     uint16_t* gt = reinterpret_cast<uint16_t*>(smem);                 // [3][MTt][GS]; after the last tile: float red[MTt][16*T]
     const size_t gt_bytes = (size_t)3 * MTt * p.GS * 2, red_bytes = (size_t)MTt * KW_CC * p.T * 4;
     uint16_t* xc = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + (gt_bytes > red_bytes ? gt_bytes : red_bytes));   // [KW][16][XCS]
@@ -455,24 +478,93 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NTL; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dbacc[NDB];          // rows wave + 4i of the block's gy slab (the staging loop below always gives a thread the same rows)
+    float dbacc[NDB];          // rows (tid >> 5) + 8i of the block's gy slab: the staging always gives a thread the same rows
 #pragma unroll
     for (int i = 0; i < NDB; ++i) dbacc[i] = 0.f;
 
     const int HoWo = p.Ho * p.Wo, px_per_img = p.TR * p.Wo;
     const int64_t xplane = (int64_t)p.H * p.W;
+    // channels beyond Cg are skipped altogether: they only feed dw columns that are never read
+    const int ccv = (p.Cg - cb * KW_CC) < KW_CC ? (p.Cg - cb * KW_CC) : KW_CC;
+    const int nitem = ccv * p.NI * p.PR * p.EQ;
 
-    auto stage_gy = [&](int n0, int oh0) {
-        const int pix = (tid & 63) * 4;
+    struct XItem { int dst, ic0; const float* src; };      // dst < 0: no item; src == nullptr: zero padding
+    auto x_item = [&](int it, int n0, int row0) {
+        XItem r; r.dst = -1; r.ic0 = 0; r.src = nullptr;
+        if (it < nitem) {
+            const uint32_t t1 = fd_div(it, p.fd_eq);
+            const int eq = it - t1 * p.EQ;
+            const uint32_t t2 = fd_div(t1, p.fd_pr);
+            const int prow = t1 - t2 * p.PR;
+            const int cl = (int)t2 / p.NI, slot = (int)t2 - cl * p.NI;
+            const int c = cb * KW_CC + cl, n = n0 + slot, ir = row0 + prow, ic0 = eq * 4 - p.PWL;
+            r.dst = cl * p.XCS + (slot * p.PR + prow) * p.Wo;
+            r.ic0 = ic0;
+            if (n < p.N && ir >= 0 && ir < p.H && ic0 >= 0 && ic0 + 3 < p.W)
+                r.src = p.x + ((int64_t)n * p.C + (int64_t)g * p.Cg + c) * xplane + (int64_t)ir * p.W + ic0;
+        }
+        return r;
+    };
+    unsigned inx = 0u;
+    auto x_scatter = [&](const XItem& xi, float4 f, int term) {
+        if (xi.dst < 0) return;
+        float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (XMODE == MN_ACTQ_NONE) {
+                float r = v[e] - mn_bf16_head(v[e]);
+                if (term == 0) { inx |= mn_f2u(r) << 1; }
+                else { if (term == 2) r = r - mn_bf16_head(r); v[e] = r; }
+            } else {
+                v[e] = act_code<XMODE>(v[e], p.pro, sc, zp);    // a zero-padded element quantises to code 0 in both schemes
+            }
+        }
+        uint16_t* rowp = xc + xi.dst;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint16_t hb = (uint16_t)(mn_f2u(v[e]) >> 16);
+            for (int s_ = 0; s_ < p.KW; ++s_) {
+                const int ocol = xi.ic0 + e - s_ * p.Dw + p.pw;
+                if (ocol >= 0 && ocol < p.Wo) rowp[(size_t)s_ * KW_CC * p.XCS + ocol] = hb;
+            }
+        }
+    };
+    auto tile_origin = [&](int pt, int& n0, int& oh0, int& row0) {
+        const uint32_t timg = fd_div(pt, p.fd_tpi);
+        n0 = (int)timg * p.NI;
+        oh0 = (pt - (int)timg * p.tpi) * p.TR;
+        row0 = oh0 * p.Sh - p.ph;
+    };
+
+    float4 rg[NDB], rx[KW_XPF];
+    auto fetch = [&](int pt) {            // global loads of one tile, left in flight
+        int n0, oh0, row0;
+        tile_origin(pt, n0, oh0, row0);
+        const int pix = (tid & (TPQ - 1)) * 4;
         const uint32_t img = fd_div(pix, p.fd_ppi);
         const int rem = pix - img * px_per_img;
         const int n = n0 + (int)img;
 #pragma unroll
         for (int i = 0; i < NDB; ++i) {
-            const int m = wave + 4 * i, mo = mb * MTt + m;
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.N && mo < p.Mg) f = *reinterpret_cast<const float4*>(p.gy + ((int64_t)n * p.O + (int64_t)g * p.Mg + mo) * HoWo + oh0 * p.Wo + rem);
-            const float v[4] = {f.x, f.y, f.z, f.w};
+            const int m = (tid >> 5) + 8 * i, mo = mb * MTt + m;
+            rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < p.N && mo < p.Mg) rg[i] = *reinterpret_cast<const float4*>(p.gy + ((int64_t)n * p.O + (int64_t)g * p.Mg + mo) * HoWo + oh0 * p.Wo + rem);
+        }
+#pragma unroll
+        for (int u = 0; u < KW_XPF; ++u) {
+            const XItem xi = x_item(tid + u * 256, n0, row0);
+            rx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xi.src) rx[u] = *reinterpret_cast<const float4*>(xi.src);
+        }
+    };
+    auto commit = [&](int pt, int par) {   // registers -> LDS
+        int n0, oh0, row0;
+        tile_origin(pt, n0, oh0, row0);
+        const int pix = (tid & (TPQ - 1)) * 4;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+            const int m = (tid >> 5) + 8 * i;
+            const float v[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
             float t0[4], t1[4], t2[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -487,88 +579,62 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
             *reinterpret_cast<u32x2*>(d + MTt * p.GS) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
             *reinterpret_cast<u32x2*>(d + 2 * MTt * p.GS) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
         }
-    };
-    // term 0: codes (or the bf16 head of a real x); terms 1, 2: the remainders of a real x (slow path)
-    auto stage_x = [&](int n0, int row0, int term, int par) {
-        const int nitem = KW_CC * p.NI * p.PR * p.EQ;
-        unsigned inx = 0u;
-        for (int it = tid; it < nitem; it += 256) {
-            const uint32_t t1 = fd_div(it, p.fd_eq);
-            const int eq = it - t1 * p.EQ;
-            const uint32_t t2 = fd_div(t1, p.fd_pr);
-            const int prow = t1 - t2 * p.PR;
-            const int cl = (int)t2 / p.NI, slot = (int)t2 - cl * p.NI;
-            const int c = cb * KW_CC + cl, n = n0 + slot, ir = row0 + prow, ic0 = eq * 4 - p.PWL;
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool ok = c < p.Cg && n < p.N && ir >= 0 && ir < p.H && ic0 >= 0 && ic0 + 3 < p.W;
-            if (ok) f = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.C + (int64_t)g * p.Cg + c) * xplane + (int64_t)ir * p.W + ic0);
-            float v[4] = {f.x, f.y, f.z, f.w};
+        inx = 0u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (XMODE == MN_ACTQ_NONE) {
-                    float r = v[e] - mn_bf16_head(v[e]);
-                    if (term == 0) { inx |= mn_f2u(r) << 1; }
-                    else { if (term == 2) r = r - mn_bf16_head(r); v[e] = r; }
-                } else {
-                    v[e] = ok ? act_code<XMODE>(v[e], p.pro, sc, zp) : 0.f;
-                }
-            }
-            uint16_t* rowp = xc + (size_t)cl * p.XCS + (slot * p.PR + prow) * p.Wo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint16_t hb = (uint16_t)(mn_f2u(v[e]) >> 16);
-                for (int s_ = 0; s_ < p.KW; ++s_) {
-                    const int ocol = ic0 + e - s_ * p.Dw + p.pw;
-                    if (ocol >= 0 && ocol < p.Wo) rowp[(size_t)s_ * KW_CC * p.XCS + ocol] = hb;
-                }
-            }
+        for (int u = 0; u < KW_XPF; ++u) x_scatter(x_item(tid + u * 256, n0, row0), rx[u], 0);
+        for (int it = tid + KW_XPF * 256; it < nitem; it += 256) {      // patches larger than the prefetch window
+            const XItem xi = x_item(it, n0, row0);
+            x_scatter(xi, xi.src ? *reinterpret_cast<const float4*>(xi.src) : make_float4(0.f, 0.f, 0.f, 0.f), 0);
         }
-        if (XMODE == MN_ACTQ_NONE && term == 0 && inx) xflag[par] = 1;
+        if (XMODE == MN_ACTQ_NONE && inx) xflag[par] = 1;
+    };
+    auto restage_x_term = [&](int pt, int term) {     // slow path of a real-valued x
+        int n0, oh0, row0;
+        tile_origin(pt, n0, oh0, row0);
+        for (int it = tid; it < nitem; it += 256) {
+            const XItem xi = x_item(it, n0, row0);
+            x_scatter(xi, xi.src ? *reinterpret_cast<const float4*>(xi.src) : make_float4(0.f, 0.f, 0.f, 0.f), term);
+        }
     };
     auto contract = [&]() {
-        for (int ks = wave; ks < KW_TP / 32; ks += 4) {
-            const int pi = ks * 32 + kg * 8;
-            const uint32_t fr = fd_div(pi, p.fd_wo);
-            const int ocol0 = pi - fr * p.Wo;
-            const uint32_t slot = fd_div(fr, p.fd_tr);
-            const int orow = fr - slot * p.TR;
-            const uint16_t* xb = xc + (size_t)j * p.XCS + ((int)slot * p.PR + orow * p.Sh) * p.Wo + ocol0;
-            u32x4 a[MT][3];
+        const int pi = wave * 32 + kg * 8;      // this wave's K-step of the tile
+        const uint32_t fr = fd_div(pi, p.fd_wo);
+        const int ocol0 = pi - fr * p.Wo;
+        const uint32_t slot = fd_div(fr, p.fd_tr);
+        const int orow = fr - slot * p.TR;
+        const uint16_t* xb = xc + (size_t)j * p.XCS + ((int)slot * p.PR + orow * p.Sh) * p.Wo + ocol0;
+        u32x4 a[MT][3];
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int term = 0; term < 3; ++term)
-                    a[mi][term] = *reinterpret_cast<const u32x4*>(gt + (term * MTt + mi * 16 + j) * p.GS + pi);
+            for (int term = 0; term < 3; ++term)
+                a[mi][term] = *reinterpret_cast<const u32x4*>(gt + (term * MTt + mi * 16 + j) * p.GS + pi);
 #pragma unroll
-            for (int ni = 0; ni < NTL; ++ni) {
-                if (ni < p.T) {
-                    const u32x4 bf = *reinterpret_cast<const u32x4*>(xb + ntoff[ni]);
+        for (int ni = 0; ni < NTL; ++ni) {
+            if (ni < p.T) {
+                const u32x4 bf = *reinterpret_cast<const u32x4*>(xb + ntoff[ni]);
 #pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                        for (int term = 0; term < 3; ++term) acc[mi][ni] = mn_mfma_bf16(a[mi][term], bf, acc[mi][ni]);
-                }
+                    for (int term = 0; term < 3; ++term) acc[mi][ni] = mn_mfma_bf16(a[mi][term], bf, acc[mi][ni]);
             }
         }
     };
 
     int par = 0;
+    if (z < p.num_ptiles) fetch(z);
     for (int pt = z; pt < p.num_ptiles; pt += p.Z, par ^= 1) {
-        const uint32_t timg = fd_div(pt, p.fd_tpi);
-        const int n0 = (int)timg * p.NI;
-        const int oh0 = (pt - (int)timg * p.tpi) * p.TR;
-        const int row0 = oh0 * p.Sh - p.ph;
         __syncthreads();                       // previous tile consumed; tables / flags visible
-        stage_gy(n0, oh0);
-        stage_x(n0, row0, 0, par);
+        commit(pt, par);
         __syncthreads();
         const int inexact = (XMODE == MN_ACTQ_NONE) ? xflag[par] : 0;
         if (XMODE == MN_ACTQ_NONE && tid == 0) xflag[par ^ 1] = 0;
+        if (pt + p.Z < p.num_ptiles) fetch(pt + p.Z);       // in flight during the MFMA phase
         contract();
         if (inexact) {                         // block-uniform: a real-valued x, contract its second and third term as well
             for (int term = 1; term <= 2; ++term) {
                 __syncthreads();
-                stage_x(n0, row0, term, par);
+                restage_x_term(pt, term);
                 __syncthreads();
                 contract();
             }
@@ -603,9 +669,8 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
 #pragma unroll
         for (int i = 0; i < NDB; ++i) {
             float v = dbacc[i];
-            v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64);
-            v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-            if (lane == 0) p.dbpart[((int64_t)z * p.G + g) * p.Mgw + mb * MTt + wave + 4 * i] = v;
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            if ((tid & 31) == 0) p.dbpart[((int64_t)z * p.G + g) * p.Mgw + mb * MTt + (tid >> 5) + 8 * i] = v;
         }
     }
 }

@@ -1,0 +1,53 @@
+"""``Adam``: drop-in for ``torch.optim.Adam`` as the reference training scripts construct it (``*/main.py:308-315``: one
+parameter group per tensor, ``lr``, ``weight_decay``), executed as ONE gfx950 launch over all tensors (``mn_adam_step``)
+instead of ~7 small kernels per group.  Same update as torch (amsgrad off, L2 weight decay folded into the gradient),
+same ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq``), so checkpoints interchange."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.get_lib()
+        # tensors that share (step, betas, eps) go into one launch table
+        batches = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
+                    raise _lib.MicronetHipError("micronet_amd.optim.Adam handles dense float32 CUDA parameters")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not p.is_contiguous():
+                    raise _lib.MicronetHipError("non-contiguous parameter")
+                key = (int(st["step"]), float(b1), float(b2), float(group["eps"]), p.device.index)
+                batches.setdefault(key, []).append((p, g, st, float(group["lr"]), float(group["weight_decay"])))
+        for (step, b1, b2, eps, dev), items in batches.items():
+            arr = (_lib.AdamTensor * len(items))()
+            for i, (p, g, st, lr, wd) in enumerate(items):
+                arr[i] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), lr, wd)
+            with torch.cuda.device(dev):
+                rc = lib.mn_adam_step(arr, len(items), step, b1, b2, eps, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                lib.check(rc, "mn_adam_step")
+        return loss

@@ -41,8 +41,16 @@ def synth_batch(batch, seed=1234, device=None):
     return x, y
 
 
-def make_optimizer(model, lr=0.01, weight_decay=1e-5, **kw):
+def make_optimizer(model, lr=0.01, weight_decay=1e-5, fused=None, **kw):
+    """Adam with one parameter group per tensor, as main.py:308-315 builds it.  On the GPU the step runs as ONE launch
+    over all tensors (micronet_amd.optim.Adam, same update and state layout as torch.optim.Adam); ``fused=False`` keeps
+    torch's implementation (used by tests to compare)."""
     groups = [{"params": [p], "lr": lr, "weight_decay": weight_decay} for _, p in model.named_parameters()]
+    if fused is None:
+        fused = all(p.is_cuda for g in groups for p in g["params"])
+    if fused:
+        from micronet_amd.optim import Adam
+        return Adam(groups, lr=lr, weight_decay=weight_decay, **kw)
     return torch.optim.Adam(groups, lr=lr, weight_decay=weight_decay, **kw)
 
 

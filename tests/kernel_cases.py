@@ -310,3 +310,30 @@ QGEMM_KXK_CASES = [
     # stride 2 (forward only in the code domain)
     dict(x_shape=(2, 8, 16, 16), w_shape=(24, 8, 3, 3), stride=2, padding=1, bias=False),
 ]
+
+
+def check_adam(be, sizes=(5, 4099, 2048, 1), steps=3, lr=0.01, wd=1e-5, seed=0):
+    """mn_adam_step vs torch.optim.Adam (CPU, fp32) on the same parameters / gradients for a few steps."""
+    import torch
+    from micronet_amd import _lib
+    r = np.random.default_rng(seed)
+    ps = [r.standard_normal(n).astype(F) for n in sizes]
+    tp = [torch.nn.Parameter(torch.from_numpy(p.copy())) for p in ps]
+    opt = torch.optim.Adam([{"params": [t], "lr": lr * (1 + i), "weight_decay": wd * i} for i, t in enumerate(tp)], lr=lr)
+    dp = [be.to_dev(p) for p in ps]
+    dm = [be.to_dev(np.zeros_like(p)) for p in ps]
+    dv = [be.to_dev(np.zeros_like(p)) for p in ps]
+    for step in range(1, steps + 1):
+        gs = [(r.standard_normal(n) * 0.1).astype(F) for n in sizes]
+        for t, g in zip(tp, gs):
+            t.grad = torch.from_numpy(g.copy())
+        opt.step()
+        dg = [be.to_dev(g) for g in gs]
+        arr = (_lib.AdamTensor * len(sizes))()
+        for i, n in enumerate(sizes):
+            arr[i] = _lib.AdamTensor(be.ptr(dp[i]).value, be.ptr(dg[i]).value, be.ptr(dm[i]).value, be.ptr(dv[i]).value, n,
+                                     lr * (1 + i), wd * i)
+        be.call("mn_adam_step", arr, len(sizes), step, 0.9, 0.999, 1e-8, be.stream)
+        for i, t in enumerate(tp):
+            got, ref = be.to_host(dp[i]), t.detach().numpy()
+            assert np.max(np.abs(got - ref)) <= 2e-6 * max(1.0, np.max(np.abs(ref))), (step, i, np.max(np.abs(got - ref)))

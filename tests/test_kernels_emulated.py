@@ -76,8 +76,7 @@ KXK_SUP = [True] * 5 + [(True, False, False)]   # per case: (fwd, bwd_data, bwd_
 
 @pytest.mark.parametrize("case", range(len(K.QGEMM_KXK_CASES)))
 def test_qgemm_kxk_binary_x(be, case):
-    # case 5 (stride 2 on 16x16): the three-term patch of 4 images exceeds the LDS budget -> not offered for real-valued x
-    K.check_conv(be, seed=70 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=KXK_SUP[case] if case != 5 else False,
+    K.check_conv(be, seed=70 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=KXK_SUP[case],
                  **K.QGEMM_KXK_CASES[case])
 
 
@@ -90,3 +89,8 @@ def test_qgemm_kxk_real_x(be, case):
 def test_qgemm_kxk_fused_actq(be, case, mode):
     K.check_conv(be, seed=80 + case, mode=mode, bits=4, wmode=2 if mode == 1 else 3, wbits=4, algos=(3,),
                  expect_qgemm=KXK_SUP[case], **K.QGEMM_KXK_CASES[case])
+
+
+def test_adam_step(be):
+    K.check_adam(be)
+    K.check_adam(be, sizes=tuple(range(1, 41)), steps=2, seed=1)      # more tensors than one launch table holds
