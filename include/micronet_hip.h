@@ -35,6 +35,11 @@ typedef void* mn_stream_t;
 
 int mn_version(void);
 const char* mn_last_error(void);
+/* name (as rocprofv3 prints it, without the argument list) of the main kernel the last mn_conv2d_* call on this thread launched */
+const char* mn_last_kernel(void);
+/* measurement hook: the next mn_conv2d_* call on this thread records `start_event` / `stop_event` (hipEvent_t, may be NULL)
+ * on its stream immediately around its main kernel launch (not around the small weight-pack / partial-reduce helpers). */
+void mn_profile_next(void* start_event, void* stop_event);
 /* 1 if the library was built as the CPU SIMT emulation used by the unit tests, 0 for the gfx950 build */
 int mn_is_emulation(void);
 
@@ -110,6 +115,11 @@ typedef struct mn_conv_geom {
     int32_t N, C, H, W;      /* input  [N][C][H][W] */
     int32_t O, KH, KW;       /* weight [O][C/groups][KH][KW] */
     int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups;
+    int32_t in_shuffle;      /* > 1: the conv reads its input through a ShuffleNet channel shuffle with this many groups
+                                (models/nin_gc.py:4-15 `channel_shuffle`, called in front of the conv at 53-56): logical input
+                                channel cl lives at physical channel (cl % s) * (C / s) + cl / s of x; dx is written through the
+                                same map.  Folding the permutation into the addressing removes a full copy of the activation
+                                tensor in forward and backward.  Code-domain kernels only (else MN_ENOTSUP). 0 / 1: none. */
 } mn_conv_geom;
 
 /* activation quantizer fused into the conv prologue (fwd, bwd_weight) and into the
@@ -171,6 +181,19 @@ int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq
 /* dw = conv2d_backward_weight(gy, actq(x)); dbias = sum gy (dbias may be NULL) */
 int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw,
                          float* dbias, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
+
+/* ------------------------------------------------------------------ BatchNorm2d + BinaryActivation, fused
+ * models/nin_gc.py:53-59 `relu(bn(conv(x)))` with the ReLU replaced by BinaryActivation (wbwtab/quantize.py:79-94, 319-322).
+ * y, a, da, dy: [N][C][HW] fp32 (HW % 4 == 0, 16-byte aligned).  save: [2][C] = mean, invstd (written by fwd, read by bwd).
+ * training != 0: batch statistics; running_mean / running_var (nullable) are updated in place with `momentum` and the
+ * unbiased variance, as nn.BatchNorm2d does.  training == 0: the running statistics normalise, nothing is updated.
+ * ws: >= mn_bnsign_ws_floats(C) floats, 8-byte aligned. */
+int64_t mn_bnsign_ws_floats(int64_t C);
+int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                  int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream);
+/* dy = d loss / d y given da = d loss / d a (clip-STE of the sign through the BatchNorm backward); dgamma / dbeta nullable */
+int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                  int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer step of the training loop
  * <scheme>/main.py: optimizer.step() with torch.optim.Adam, one parameter group per tensor (wqaq/dorefa/main.py:308-315).

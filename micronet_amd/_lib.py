@@ -19,7 +19,7 @@ MN_ENOTSUP = -95
 
 class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "C", "H", "W", "O", "KH", "KW", "stride_h", "stride_w", "pad_h", "pad_w",
-                                         "dil_h", "dil_w", "groups")]
+                                         "dil_h", "dil_w", "groups", "in_shuffle")]
 
 
 class ActQ(C.Structure):
@@ -45,6 +45,8 @@ _G, _A, _W = C.POINTER(ConvGeom), C.POINTER(ActQ), C.POINTER(WQ)
 PROTOTYPES = {
     "mn_version": (_I, []),
     "mn_last_error": (C.c_char_p, []),
+    "mn_last_kernel": (C.c_char_p, []),
+    "mn_profile_next": (None, [_P, _P]),
     "mn_is_emulation": (_I, []),
     "mn_round_half_away": (_I, [_P, _P, _L, _P]),
     "mn_dorefa_act_fwd": (_I, [_P, _P, _L, _I, _P]),
@@ -67,6 +69,9 @@ PROTOTYPES = {
     "mn_bn_stats_ws_floats": (_L, [_L, _L, _L]),
     "mn_bn_stats_fwd": (_I, [_P, _L, _L, _L, _P, _P, _P]),
     "mn_bn_stats_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _P]),
+    "mn_bnsign_ws_floats": (_L, [_L]),
+    "mn_bnsign_fwd": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P]),
+    "mn_bnsign_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),
     "mn_conv2d_mfma_supported": (_I, [_G, _I]),

@@ -11,6 +11,11 @@ typedef float f32x4 __attribute__((vector_size(16)));
 
 // ---------------------------------------------------------------- errors
 void mn_set_error(const char* fmt, ...);
+// name of the dominant kernel the last conv entry point launched on this thread (read back by mn_last_kernel())
+void mn_set_last_kernel(const char* fmt, ...);
+// optional HIP-event bracket around the MAIN kernel of the next conv entry point (armed by mn_profile_next)
+void mn_prof_begin(hipStream_t s);
+void mn_prof_end(hipStream_t s);
 #define MN_FAIL(code, ...)        \
     do {                          \
         mn_set_error(__VA_ARGS__); \
@@ -172,6 +177,19 @@ struct OpAddD { __device__ __forceinline__ double operator()(double a, double b)
 struct OpAddF { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
 struct OpMaxF { __device__ __forceinline__ float operator()(float a, float b) const { return (a != a || b != b) ? (a != a ? a : b) : fmaxf(a, b); } };
 struct OpMinF { __device__ __forceinline__ float operator()(float a, float b) const { return (a != a || b != b) ? (a != a ? a : b) : fminf(a, b); } };
+
+// logical -> physical channel through a channel shuffle with `sg` groups over C channels (identity when sg <= 1)
+struct ChanMap { int sg, cps; FastDiv fd_sg; };
+static inline ChanMap make_chanmap(int sg, int C) {
+    ChanMap m;
+    m.sg = sg > 1 ? sg : 1; m.cps = sg > 1 ? C / sg : 0; m.fd_sg = make_fastdiv((uint32_t)m.sg);
+    return m;
+}
+__device__ __forceinline__ int chan_phys(const ChanMap& m, int cl) {
+    if (m.sg <= 1) return cl;
+    const uint32_t jq = fd_div((uint32_t)cl, m.fd_sg);
+    return (cl - (int)jq * m.sg) * m.cps + (int)jq;
+}
 
 static inline int mn_grid_for(int64_t n_items, int per_block, int cap) {
     int64_t b = (n_items + per_block - 1) / per_block;

@@ -675,6 +675,8 @@ static void launch_fwd(const FwdPlan& pl, hipStream_t s) {
     hipLaunchKernelGGL(k_conv_mfma<MT>, dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
 }
 static int run_fwd_plan(FwdPlan& pl, hipStream_t s, const char* what) {
+    mn_set_last_kernel("k_conv_mfma<%d>", pl.MT);
+    mn_prof_begin(s);
     switch (pl.MT) {
         case 1: launch_fwd<1>(pl, s); break;
         case 2: launch_fwd<2>(pl, s); break;
@@ -682,6 +684,7 @@ static int run_fwd_plan(FwdPlan& pl, hipStream_t s, const char* what) {
         case 8: launch_fwd<8>(pl, s); break;
         default: MN_FAIL(MN_EINVAL, "%s: bad MT", what);
     }
+    mn_prof_end(s);
     MN_CHECK_LAUNCH(what);
     return MN_OK;
 }
@@ -696,6 +699,7 @@ extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_
     hipStream_t s = (hipStream_t)stream;
     if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, wq, 0) && aligned16(x) && aligned16(y)))
         return qg_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
+    if (g->in_shuffle > 1) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: in_shuffle is only available on the code-domain kernels");
     FwdPlan pl;
     const int can = (algo != MN_ALGO_DIRECT) && plan_fwd_view(g, 0, &pl) && aligned16(x) && aligned16(y);
     if (algo == MN_ALGO_MFMA && !can) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: geometry not supported by the MFMA tiler");
@@ -708,6 +712,7 @@ extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_
         return run_fwd_plan(pl, s, "mn_conv2d_fwd(mfma)");
     }
     DirectParams d = make_direct(g, pro);
+    mn_set_last_kernel("k_conv_direct_fwd");
     const int64_t total = (int64_t)d.N * d.O * d.Ho * d.Wo;
     hipLaunchKernelGGL(k_conv_direct_fwd, dim3(mn_grid_for(total, 256, 65535)), dim3(256), 0, s, d, x, w, bias, y);
     MN_CHECK_LAUNCH("mn_conv2d_fwd(direct)");
@@ -726,6 +731,7 @@ extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, cons
     if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, wq, 1) && aligned16(gy) && aligned16(dx) &&
                                   (ste.mode == MN_ACTQ_NONE || aligned16(x))))
         return qg_bwd_data(g, aq, wq, gy, w, x, dx, ws, ws_bytes, s);
+    if (g->in_shuffle > 1) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data: in_shuffle is only available on the code-domain kernels");
     FwdPlan pl;
     const int can = (algo != MN_ALGO_DIRECT) && plan_fwd_view(g, 1, &pl) && aligned16(gy) && aligned16(dx) && (ste.mode == MN_ACTQ_NONE || aligned16(x));
     if (algo == MN_ALGO_MFMA && !can) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data: geometry not supported by the MFMA tiler");
@@ -740,6 +746,7 @@ extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, cons
         return run_fwd_plan(pl, s, "mn_conv2d_bwd_data(mfma)");
     }
     DirectParams d = make_direct(g, ste);
+    mn_set_last_kernel("k_conv_direct_bwd_data");
     const int64_t total = (int64_t)d.N * d.C * d.H * d.W;
     hipLaunchKernelGGL(k_conv_direct_bwd_data, dim3(mn_grid_for(total, 256, 65535)), dim3(256), 0, s, d, gy, w, x, dx);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_data(direct)");
@@ -757,19 +764,24 @@ extern "C" int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, co
     const int Ho = out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
     if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, nullptr, 2) && aligned16(x) && aligned16(gy)))
         return qg_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
+    if (g->in_shuffle > 1) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight: in_shuffle is only available on the code-domain kernels");
     WgradPlan pl;
     const int can = (algo != MN_ALGO_DIRECT) && plan_wgrad(g, &pl) && aligned16(x) && aligned16(gy);
     if (algo == MN_ALGO_MFMA && !can) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight: geometry not supported by the MFMA tiler");
     if (can) {
         if (!ws || ws_bytes < pl.part_floats * 4 || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight: workspace too small");
         pl.p.v.in = x; pl.p.gy = gy; pl.p.part = (float*)ws; pl.p.pro = pro;
+        mn_set_last_kernel(pl.MPW == 2 ? "k_wgrad_mfma<2, 9>" : "k_wgrad_mfma<1, 13>");
+        mn_prof_begin(s);
         if (pl.MPW == 2) hipLaunchKernelGGL((k_wgrad_mfma<2, 9>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
         else hipLaunchKernelGGL((k_wgrad_mfma<1, 13>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+        mn_prof_end(s);
         const int64_t total = (int64_t)g->O * (g->C / g->groups) * g->KH * g->KW;
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(mn_grid_for(total, 256, 2048)), dim3(256), 0, s, (const float*)ws, dw, pl.p.Z, g->groups,
                            g->O / g->groups, g->C / g->groups, g->KH, g->KW, pl.p.Mgw, pl.p.Cgw);
     } else {
         DirectParams d = make_direct(g, pro);
+        mn_set_last_kernel("k_conv_direct_bwd_weight");
         const int64_t total = (int64_t)g->O * d.Cg * g->KH * g->KW;
         if (total > 0x7fffffff) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(direct): too many weights");
         hipLaunchKernelGGL(k_conv_direct_bwd_weight, dim3((unsigned)total), dim3(256), 0, s, d, gy, x, dw);

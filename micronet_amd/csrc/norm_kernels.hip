@@ -1,0 +1,195 @@
+// BatchNorm2d followed by the binary activation, fused, for gfx950.
+//
+// In the reference's W/A-binary nets every quantised conv is followed by `relu(bn(.))` with the ReLU replaced by
+// BinaryActivation (models/nin_gc.py:53-59, wbwtab/quantize.py:79-94, 319-322).  Run as separate modules that is
+// BN (3 tensor passes) + sign (2 passes) forward and sign-backward (3) + BN-backward (5) backward, all HBM-bound on
+// the largest tensors of the net.  Fused, the normalised value z never exists in memory:
+//   forward : pass 1 per-channel sum / sum of squares of y (fp64 partials, pivoted) -> mean, invstd, running stats
+//             pass 2 a = sign((y - mean) * invstd * gamma + beta), 0 -> +1                 (read y, write a)
+//   backward: pass 1 z recomputed from y; dz = da * [|z| < 1]; per-channel sum dz, sum dz*zhat  (read da, y)
+//             pass 2 dy = gamma * invstd * (dz - sum_dz/n - zhat * sum_dzzhat/n)                (read da, y, write dy)
+// i.e. 3 + 5 passes instead of 5 + 8.  All kernels address the tensor as C channels x (N planes of HW contiguous floats),
+// float4 per lane, every lane busy whatever HW is.
+#include "common.h"
+
+#define BNS_SPLIT 32
+
+struct BnsGeom {
+    int N, C, HW, HW4;      // HW4 = HW / 4
+    FastDiv fd_hw4;
+    int64_t n4;             // float4 per channel = N * HW4
+};
+static BnsGeom bns_geom(int64_t N, int64_t C, int64_t HW) {
+    BnsGeom g;
+    g.N = (int)N; g.C = (int)C; g.HW = (int)HW; g.HW4 = (int)(HW / 4); g.fd_hw4 = make_fastdiv((uint32_t)g.HW4); g.n4 = N * (HW / 4);
+    return g;
+}
+// float4 index i of channel c -> element offset
+__device__ __forceinline__ int64_t bns_off(const BnsGeom& g, int c, uint32_t i) {
+    const uint32_t n = fd_div(i, g.fd_hw4);
+    const uint32_t q = i - n * (uint32_t)g.HW4;
+    return ((int64_t)n * g.C + c) * g.HW + (int64_t)q * 4;
+}
+__device__ __forceinline__ float bns_sign(float z) { return (z < 0.f) ? -1.f : ((z != z) ? z : 1.f); }   // 0, -0 -> +1; NaN stays
+
+// MODE 0: s1 = sum(y - pivot), s2 = sum((y - pivot)^2).   MODE 1: s1 = sum dz, s2 = sum dz * zhat.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bns_partial(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ da,
+                                                     const float* __restrict__ save, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, double* __restrict__ part) {
+    __shared__ double scd[16];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    float pivot = 0.f, mean = 0.f, invstd = 0.f, ga = 0.f, be = 0.f;
+    if (MODE == 0) pivot = y[(int64_t)c * g.HW];
+    else { mean = save[c]; invstd = save[g.C + c]; ga = gamma[c]; be = beta[c]; }
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
+        const int64_t off = bns_off(g, c, (uint32_t)i);
+        const float4 v = *reinterpret_cast<const float4*>(y + off);
+        if (MODE == 0) {
+            const float a = v.x - pivot, b = v.y - pivot, cc = v.z - pivot, d = v.w - pivot;
+            s1 += (double)((a + b) + (cc + d));
+            s2 += (double)((a * a + b * b) + (cc * cc + d * d));
+        } else {
+            const float4 gg = *reinterpret_cast<const float4*>(da + off);
+            const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};
+            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = zh[e] * ga + be;
+                const float dz = (z > -1.f && z < 1.f) ? gv[e] : 0.f;       // BinaryActivation.backward: zero where |z| >= 1
+                t1 += dz;
+                t2 += dz * zh[e];
+            }
+            s1 += (double)t1;
+            s2 += (double)t2;
+        }
+    }
+    s1 = block_reduce(s1, OpAddD(), 0.0, scd);
+    s2 = block_reduce(s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { part[((int64_t)c * S + sp) * 2] = s1; part[((int64_t)c * S + sp) * 2 + 1] = s2; }
+}
+// forward: mean / invstd (+ running statistics, momentum update with the UNBIASED variance like nn.BatchNorm2d)
+__global__ void k_bns_final_fwd(const BnsGeom g, const float* __restrict__ y, const double* __restrict__ part, int S, float eps, float momentum,
+                                float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < S; ++i) { s1 += part[((int64_t)c * S + i) * 2]; s2 += part[((int64_t)c * S + i) * 2 + 1]; }
+    const double n = (double)g.N * (double)g.HW;
+    const double m = s1 / n;
+    const double mean = (double)y[(int64_t)c * g.HW] + m;
+    const double ss = s2 - s1 * m;                 // sum of squared deviations
+    const float var_b = (float)(ss / n);
+    save[c] = (float)mean;
+    save[g.C + c] = 1.0f / sqrtf(var_b + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(ss / (n - 1.0));
+}
+__global__ void k_bns_final_bwd(const BnsGeom g, const double* __restrict__ part, int S, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                float* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < S; ++i) { s1 += part[((int64_t)c * S + i) * 2]; s2 += part[((int64_t)c * S + i) * 2 + 1]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    sums[c] = (float)s1; sums[g.C + c] = (float)s2;
+}
+// eval mode: mean / invstd from the running statistics
+__global__ void k_bns_eval_stats(int C, float eps, const float* __restrict__ running_mean, const float* __restrict__ running_var, float* __restrict__ save) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    save[c] = running_mean[c];
+    save[C + c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+// MODE 0: a = sign(bn(y)).   MODE 1: dy (training: full BN backward; eval: statistics are constants)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ da,
+                                                   const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ sums, int training, float* __restrict__ out) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const float mean = save[c], invstd = save[g.C + c], ga = gamma[c], be = beta[c];
+    float k1 = 0.f, k2 = 0.f;
+    if (MODE == 1 && training) {
+        const float n = (float)g.N * (float)g.HW;
+        k1 = sums[c] / n; k2 = sums[g.C + c] / n;
+    }
+    const float gi = ga * invstd;
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
+        const int64_t off = bns_off(g, c, (uint32_t)i);
+        const float4 v = *reinterpret_cast<const float4*>(y + off);
+        const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};
+        float r[4];
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = bns_sign(zh[e] * ga + be);
+        } else {
+            const float4 gg = *reinterpret_cast<const float4*>(da + off);
+            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = zh[e] * ga + be;
+                const float dz = (z > -1.f && z < 1.f) ? gv[e] : 0.f;
+                r[e] = gi * (dz - k1 - zh[e] * k2);
+            }
+        }
+        *reinterpret_cast<float4*>(out + off) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+extern "C" int64_t mn_bnsign_ws_floats(int64_t C) { return C * BNS_SPLIT * 4 + 2 * C + 16; }   // fp64 partials + {sum dz, sum dz*zhat}
+
+static int bns_check(int64_t N, int64_t C, int64_t HW, const void* a, const void* b, const char* what) {
+    if (N <= 0 || C <= 0 || HW <= 0 || HW % 4 || N * (HW / 4) >= ((int64_t)1 << 31)) MN_FAIL(MN_EINVAL, "%s: bad shape (HW must be a multiple of 4)", what);
+    if (!aligned16(a) || !aligned16(b)) MN_FAIL(MN_EINVAL, "%s: tensors must be 16-byte aligned", what);
+    return MN_OK;
+}
+static int bns_split(const BnsGeom& g) {
+    // enough workgroups to fill 256 CUs several times, at least one 256-thread sweep per workgroup
+    int64_t S = (2048 + g.C - 1) / g.C;
+    const int64_t maxS = (g.n4 + 255) / 256;
+    if (S > maxS) S = maxS;
+    if (S > BNS_SPLIT) S = BNS_SPLIT;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+extern "C" int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                             int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, y, a, "mn_bnsign_fwd");
+    if (rc) return rc;
+    if (!y || !gamma || !beta || !save || !a || !ws || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: null / misaligned argument");
+    if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: eval mode needs the running statistics");
+    hipStream_t s = (hipStream_t)stream;
+    const BnsGeom g = bns_geom(N, C, HW);
+    const int S = bns_split(g);
+    if (training) {
+        hipLaunchKernelGGL(k_bns_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (double*)ws);
+        hipLaunchKernelGGL(k_bns_final_fwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, y, (const double*)ws, S, eps, momentum, running_mean, running_var, save);
+    } else {
+        hipLaunchKernelGGL(k_bns_eval_stats, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (int)C, eps, (const float*)running_mean, (const float*)running_var, save);
+    }
+    hipLaunchKernelGGL(k_bns_apply<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
+                       (const float*)nullptr, training, a);
+    MN_CHECK_LAUNCH("mn_bnsign_fwd");
+    return MN_OK;
+}
+
+extern "C" int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                             int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, y, dy, "mn_bnsign_bwd");
+    if (rc) return rc;
+    if (!da || !y || !save || !gamma || !beta || !dy || !ws || !aligned16(da) || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bnsign_bwd: null / misaligned argument");
+    hipStream_t s = (hipStream_t)stream;
+    const BnsGeom g = bns_geom(N, C, HW);
+    const int S = bns_split(g);
+    float* sums = ws + C * BNS_SPLIT * 4;
+    hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws);
+    hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(k_bns_apply<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy);
+    MN_CHECK_LAUNCH("mn_bnsign_bwd");
+    return MN_OK;
+}

@@ -92,6 +92,7 @@ struct PwParams {
     uint32_t NP;
     FastDiv fd_hw, fd_ks;
     float ascale;
+    ChanMap in_map, out_map;   // channel shuffle folded into the input (fwd) / output (bwd-data) addressing
 };
 
 template <int NT, int XMODE>
@@ -155,12 +156,12 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
         const bool pv = P < p.NP;
         const uint32_t n = fd_div(P, p.fd_hw);
         const int pp = (int)(P - n * (uint32_t)p.HW);
-        const float* base = p.x + ((int64_t)n * p.Cin_total + (int64_t)g * p.Kc) * HW + pp;
+        const float* base = p.x + (int64_t)n * p.Cin_total * HW + pp;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int c = s * 32 + kg * 8 + jj;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pv && c < p.Kc) v = *reinterpret_cast<const float4*>(base + (int64_t)c * HW);
+            if (pv && c < p.Kc) v = *reinterpret_cast<const float4*>(base + (int64_t)chan_phys(p.in_map, g * p.Kc + c) * HW);
             raw[jj][0] = v.x; raw[jj][1] = v.y; raw[jj][2] = v.z; raw[jj][3] = v.w;
         }
     };
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
                         const int ml = t * 16 + kg * 4 + r;
                         const int m = mblk * MB + ml;
                         if (m < p.Mr) {
-                            const int64_t off = ((int64_t)n * p.Cout_total + (int64_t)g * p.Mr + m) * HW + pp;
+                            const int64_t off = ((int64_t)n * p.Cout_total + chan_phys(p.out_map, g * p.Mr + m)) * HW + pp;
                             float o0 = acc[0][t][r], o1 = acc[1][t][r], o2 = acc[2][t][r], o3 = acc[3][t][r];
                             if (p.epi == QG_EPI_SCALE_BIAS) {
                                 const float a_ = rs[ml], b_ = bs[ml];
@@ -284,6 +285,7 @@ struct PwWgParams {
     int nmb, ncb, Z, nchunks, Mgw, Cgw, want_db;
     uint32_t NP;
     FastDiv fd_hw;
+    ChanMap in_map;
 };
 #define WG_LDP 72   // u16 per LDS row: 64 pixels + 8 pad -> 144 B rows, the 16 rows of a b128 fragment read hit all 64 banks
 
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
         for (int i = 0; i < RC; ++i) {
             const int c = cb * TC + r0 + 16 * i;
             rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pv && c < p.Cg) rx[i] = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.Cin_total + (int64_t)g * p.Cg + c) * HW + pp);
+            if (pv && c < p.Cg) rx[i] = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.Cin_total + chan_phys(p.in_map, g * p.Cg + c)) * HW + pp);
         }
     };
     auto commit = [&]() {
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
         for (int i = 0; i < RC; ++i) {
             const int c = cb * TC + r0 + 16 * i;
             float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pv && c < p.Cg) v4 = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.Cin_total + (int64_t)g * p.Cg + c) * HW + pp);
+            if (pv && c < p.Cg) v4 = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.Cin_total + chan_phys(p.in_map, g * p.Cg + c)) * HW + pp);
             float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -511,8 +513,9 @@ static int plan_pw(const mn_conv_geom* g, int which, int xmode, PwPlan* pl) {
     PwParams& p = pl->p;
     p.N = g->N; p.HW = g->H * g->W; p.G = g->groups;
     p.NP = (uint32_t)((int64_t)g->N * p.HW);
-    if (which == 0) { p.Cin_total = g->C; p.Cout_total = g->O; p.Kc = Cg; p.Mr = Mg; }
-    else { p.Cin_total = g->O; p.Cout_total = g->C; p.Kc = Mg; p.Mr = Cg; }
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    if (which == 0) { p.Cin_total = g->C; p.Cout_total = g->O; p.Kc = Cg; p.Mr = Mg; p.in_map = make_chanmap(g->in_shuffle, g->C); p.out_map = make_chanmap(0, 0); }
+    else { p.Cin_total = g->O; p.Cout_total = g->C; p.Kc = Mg; p.Mr = Cg; p.in_map = make_chanmap(0, 0); p.out_map = make_chanmap(g->in_shuffle, g->C); }
     p.Kp = qg_roundup(p.Kc, 32);
     p.KS = p.Kp / 32;
     int NT = p.Mr > 64 ? 8 : (p.Mr > 32 ? 4 : (p.Mr > 16 ? 2 : 1));
@@ -564,6 +567,8 @@ static int plan_pw_wgrad(const mn_conv_geom* g, WgPlan* pl) {
     if (!pw_geom_ok(g)) return 0;
     const int Cg = g->C / g->groups, Mg = g->O / g->groups;
     PwWgParams& p = pl->p;
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    p.in_map = make_chanmap(g->in_shuffle, g->C);
     p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.Cin_total = g->C; p.Cout_total = g->O; p.Cg = Cg; p.Mg = Mg;
     p.NP = (uint32_t)((int64_t)g->N * p.HW);
     int TM, TC;
@@ -611,12 +616,15 @@ static void launch_pw(const PwPlan& pl, int xmode, hipStream_t s) {
     else hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
 }
 static int run_pw(PwPlan& pl, int xmode, hipStream_t s, const char* what) {
+    mn_set_last_kernel("k_pw<%d, %d>", pl.NT, xmode);
+    mn_prof_begin(s);
     switch (pl.NT) {
         case 1: launch_pw<1>(pl, xmode, s); break;
         case 2: launch_pw<2>(pl, xmode, s); break;
         case 4: launch_pw<4>(pl, xmode, s); break;
         default: MN_FAIL(MN_EINVAL, "%s: bad NT", what);
     }
+    mn_prof_end(s);
     MN_CHECK_LAUNCH(what);
     return MN_OK;
 }
@@ -684,12 +692,16 @@ int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
     if (rc) return rc;
     PwWgParams& p = pl.p;
     p.gy = gy; p.x = x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.pro = pro; p.want_db = dbias != nullptr;
+    static const char* cfgname[4] = {"4, 4, 2", "1, 2, 4", "2, 1, 1", "2, 2, 2"};
+    mn_set_last_kernel("k_pw_wgrad<%s, %d>", cfgname[pl.cfg], pro.mode);
+    mn_prof_begin(s);
     switch (pl.cfg) {
         case 0: launch_wg<4, 4, 2>(pl, pro.mode, s); break;
         case 1: launch_wg<1, 2, 4>(pl, pro.mode, s); break;
         case 2: launch_wg<2, 1, 1>(pl, pro.mode, s); break;
         default: launch_wg<2, 2, 2>(pl, pro.mode, s); break;
     }
+    mn_prof_end(s);
     const int64_t total = (int64_t)g->O * (g->C / g->groups) + (dbias ? g->O : 0);
     (void)total;
     qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f,

@@ -29,6 +29,7 @@ struct KkParams {
     int NI, TR, tpi, PR, PWp, npos, num_ptiles, Mpad, num_mblk, epi, W4;
     FastDiv fd_wo, fd_tr, fd_tpi, fd_pwp, fd_pr, fd_w4, fd_o8;
     float ascale;
+    ChanMap in_map, out_map;   // channel shuffle folded into the input (fwd) / output (bwd-data) addressing
 };
 
 // PL = number of term planes kept in LDS.  XMODE NONE (a real-valued stream): PL = 3 stores the three terms side by side
@@ -134,12 +135,12 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
                 const int ir = row0 + prow, n = n0 + (int)slot;
                 if (ir < 0 || ir >= p.Hin || n >= p.N) continue;
                 const int c0 = ck * p.CC + o8 * 8;
-                const float* src = p.in + (((int64_t)n * p.Cin_total + (int64_t)g * p.Kc + c0) * p.Hin + ir) * p.Win + iq * 4;
+                const float* src = p.in + (int64_t)n * p.Cin_total * plane + (int64_t)ir * p.Win + iq * 4;
                 float v[8][4];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c0 + jj < p.Kc) f = *reinterpret_cast<const float4*>(src + jj * plane);
+                    if (c0 + jj < p.Kc) f = *reinterpret_cast<const float4*>(src + (int64_t)chan_phys(p.in_map, g * p.Kc + c0 + jj) * plane);
                     v[jj][0] = f.x; v[jj][1] = f.y; v[jj][2] = f.z; v[jj][3] = f.w;
                 }
                 if (XMODE == MN_ACTQ_NONE && p.kscale) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
             const int ml = t * 16 + kg * 4 + r;
             const int m = mblk * MB + ml;
             if (m >= p.Mr) continue;
-            const int64_t off = (((int64_t)n * p.Cout_total + (int64_t)g * p.Mr + m) * p.Ho + oh0 + orow) * p.Wo + ocol;
+            const int64_t off = (((int64_t)n * p.Cout_total + chan_phys(p.out_map, g * p.Mr + m)) * p.Ho + oh0 + orow) * p.Wo + ocol;
             float o0 = acc[0][t][r], o1 = acc[1][t][r], o2 = acc[2][t][r], o3 = acc[3][t][r];
             if (p.epi == QG_EPI_SCALE_BIAS) {
                 const float a_ = rs[ml], b_ = bs[ml];
@@ -302,6 +303,9 @@ static int plan_kk(const mn_conv_geom* g, int which, int xmode, KkPlan* pl) {
     const int Ho = kk_out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = kk_out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
     const int Cg = g->C / g->groups, Mg = g->O / g->groups;
     p.N = g->N; p.G = g->groups; p.KH = g->KH; p.KW = g->KW; p.T = g->KH * g->KW; p.Dh = g->dil_h; p.Dw = g->dil_w;
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    p.in_map = make_chanmap(which == 0 ? g->in_shuffle : 0, g->C);
+    p.out_map = make_chanmap(which == 1 ? g->in_shuffle : 0, g->C);
     if (which == 0) {
         p.Cin_total = g->C; p.Hin = g->H; p.Win = g->W; p.Kc = Cg; p.Cout_total = g->O; p.Ho = Ho; p.Wo = Wo; p.Mr = Mg;
         p.Sh = g->stride_h; p.Sw = g->stride_w; p.ph = g->pad_h; p.pw = g->pad_w;
@@ -381,12 +385,15 @@ static void launch_kk(const KkPlan& pl, hipStream_t s) {
     else launch_kk1<NT, MN_ACTQ_NONE, 1>(pl, s);
 }
 static int run_kk(const KkPlan& pl, hipStream_t s, const char* what) {
+    mn_set_last_kernel("k_kk<%d, %d, %d>", pl.NT, pl.planes == 3 ? 0 : pl.xmode, pl.planes);
+    mn_prof_begin(s);
     switch (pl.NT) {
         case 1: launch_kk<1>(pl, s); break;
         case 2: launch_kk<2>(pl, s); break;
         case 4: launch_kk<4>(pl, s); break;
         default: MN_FAIL(MN_EINVAL, "%s: bad NT", what);
     }
+    mn_prof_end(s);
     MN_CHECK_LAUNCH(what);
     return MN_OK;
 }
@@ -444,6 +451,7 @@ struct KwParams {
     int N, C, H, W, O, Ho, Wo, Cg, Mg, G, KH, KW, T, Sh, Dh, Dw, ph, pw;
     int NI, TR, tpi, PR, num_ptiles, GS, XCS, EQ, PWL, nmb, ncb, Z, Mgw, Cgw, want_db;
     FastDiv fd_wo, fd_tr, fd_tpi, fd_pr, fd_eq, fd_ppi;
+    ChanMap in_map;
 };
 #define KW_TP 128     // output pixels per tile (4 K-steps of 32 pixels: one per wave)
 #define KW_CC 16      // input channels per block (one c-tile)
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
             r.dst = cl * p.XCS + (slot * p.PR + prow) * p.Wo;
             r.ic0 = ic0;
             if (n < p.N && ir >= 0 && ir < p.H && ic0 >= 0 && ic0 + 3 < p.W)
-                r.src = p.x + ((int64_t)n * p.C + (int64_t)g * p.Cg + c) * xplane + (int64_t)ir * p.W + ic0;
+                r.src = p.x + ((int64_t)n * p.C + chan_phys(p.in_map, g * p.Cg + c)) * xplane + (int64_t)ir * p.W + ic0;
         }
         return r;
     };
@@ -688,6 +696,8 @@ static int plan_kk_wgrad(const mn_conv_geom* g, KwPlan* pl) {
     p.Ho = kk_out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h); p.Wo = kk_out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
     p.Cg = g->C / g->groups; p.Mg = g->O / g->groups; p.Sh = g->stride_h; p.Dh = g->dil_h; p.Dw = g->dil_w; p.ph = g->pad_h; p.pw = g->pad_w;
     if (g->stride_w != 1 || p.W % 4 || p.Wo % 8 || KW_TP % p.Wo) return 0;
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    p.in_map = make_chanmap(g->in_shuffle, g->C);
     if (p.T <= 9) pl->NTL = 9; else if (p.T <= 25) pl->NTL = 25; else return 0;
     pl->MT = (pl->NTL == 9 && p.Mg > 16) ? 2 : 1;
     const int MTt = 16 * pl->MT;
@@ -770,9 +780,12 @@ int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
     if (rc) return rc;
     KwParams& p = pl.p;
     p.gy = gy; p.x = x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.pro = pro; p.want_db = dbias != nullptr;
+    mn_set_last_kernel("k_kk_wgrad<%d, %d, %d>", pl.MT, pl.NTL, pro.mode);
+    mn_prof_begin(s);
     if (pl.NTL == 9 && pl.MT == 2) launch_kw<2, 9>(pl, pro.mode, s);
     else if (pl.NTL == 9) launch_kw<1, 9>(pl, pro.mode, s);
     else launch_kw<1, 25>(pl, pro.mode, s);
+    mn_prof_end(s);
     qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg * p.T, p.Mgw, p.Cgw * p.T,
                            pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f, pro.mode == MN_ACTQ_IAO ? pro.qp : (const float*)nullptr, s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(qgemm kxk)");

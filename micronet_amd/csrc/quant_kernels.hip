@@ -25,6 +25,31 @@ void mn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mn_last_error(void) { return g_err; }
+static thread_local char g_kernel[96] = "";
+void mn_set_last_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mn_last_kernel(void) { return g_kernel; }
+static thread_local void* g_prof_ev[2] = {nullptr, nullptr};
+extern "C" void mn_profile_next(void* start_event, void* stop_event) { g_prof_ev[0] = start_event; g_prof_ev[1] = stop_event; }
+void mn_prof_begin(hipStream_t s) {
+#ifndef MN_EMULATION
+    if (g_prof_ev[0]) (void)hipEventRecord((hipEvent_t)g_prof_ev[0], s);
+#else
+    (void)s;
+#endif
+}
+void mn_prof_end(hipStream_t s) {
+#ifndef MN_EMULATION
+    if (g_prof_ev[1]) (void)hipEventRecord((hipEvent_t)g_prof_ev[1], s);
+#else
+    (void)s;
+#endif
+    g_prof_ev[0] = g_prof_ev[1] = nullptr;
+}
 extern "C" int mn_version(void) { return 100; }
 extern "C" int mn_is_emulation(void) {
 #ifdef MN_EMULATION

@@ -30,26 +30,40 @@ WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _l
 CONV_ALGO = _lib.MN_ALGO_AUTO
 
 
-# optional per-launch timing (bench.py): an object with .span(tag, nbytes) returning a context manager that brackets the
-# launch with HIP events on the current stream
+# optional per-launch timing (bench.py): an object with .arm(which, nbytes) -> token (arms mn_profile_next with two raw HIP
+# events that the library records right around the main kernel) and .done(token, kernel_name)
 PROFILER = None
 
 
-class _NoSpan:
+class _Span:
+    __slots__ = ("tok",)
+
+    def __init__(self, tok):
+        self.tok = tok
+
     def __enter__(self):
         return self
 
     def __exit__(self, *a):
+        if self.tok is not None:
+            PROFILER.done(self.tok, last_kernel())
         return False
 
 
-_NOSPAN = _NoSpan()
+_NOSPAN = _Span(None)
 
 
 def _span(g, which, nbytes):
     if PROFILER is None:
         return _NOSPAN
-    return PROFILER.span(g, which, nbytes)
+    tok = PROFILER.arm(which, nbytes)
+    return _Span(tok) if tok is not None else _NOSPAN
+
+
+def last_kernel():
+    """Name of the main kernel the last conv call launched (for the profiler's per-kernel aggregation)."""
+    k = _lib_().mn_last_kernel()
+    return k.decode() if k else "?"
 
 
 def _lib_():
@@ -301,16 +315,48 @@ class BnBatchStats(Function):
         return d_o
 
 
+class BNSign(Function):
+    """a = sign(batch_norm(y)) in one fused op (training or eval statistics); backward = clip-STE of the sign through the
+    BatchNorm backward.  The normalised tensor is never materialised (it is recomputed from y in the backward)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training):
+        y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
+        N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
+        a = torch.empty_like(y)
+        save = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+        ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
+        with torch.cuda.device_of(y):
+            _call("mn_bnsign_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training),
+                  _p(running_mean), _p(running_var), _p(save), _p(a), _p(ws), _s())
+        ctx.save_for_backward(y, gamma, beta, save)
+        ctx.training = int(training)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        y, gamma, beta, save = ctx.saved_tensors
+        da = _chk(da, "grad")
+        N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
+        dy = torch.empty_like(y)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
+        with torch.cuda.device_of(y):
+            _call("mn_bnsign_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, ctx.training, _p(dy), _p(dgamma), _p(dbeta),
+                  _p(ws), _s())
+        return dy, dgamma, dbeta, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ convolution
 def _pair(v):
     return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
 
-def _geom(x_shape, w_shape, stride, padding, dilation, groups):
+def _geom(x_shape, w_shape, stride, padding, dilation, groups, in_shuffle=0):
     (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
     N, Cc, H, W = x_shape
     O, _, KH, KW = w_shape
-    return ConvGeom(N, Cc, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw, groups)
+    return ConvGeom(N, Cc, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw, groups, in_shuffle)
 
 
 def _out_hw(g):
@@ -343,11 +389,11 @@ class QConv2d(Function):
     ``wdesc`` tells the code-domain kernels how wq factors into integer codes x scale (None: arbitrary fp32 weights)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc, aq_flags):
+    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc, aq_flags, in_shuffle=0):
         x, wq, bias = _chk(x, "input"), _chk(wq, "weight"), _chk(bias, "bias")
         if x.dim() != 4 or wq.dim() != 4 or x.shape[1] != wq.shape[1] * groups:
             raise MicronetHipError("conv2d shape mismatch: input %s weight %s groups %d" % (tuple(x.shape), tuple(wq.shape), groups))
-        g = _geom(x.shape, wq.shape, stride, padding, dilation, groups)
+        g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle)
         Ho, Wo = _out_hw(g)
         y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
@@ -381,13 +427,30 @@ class QConv2d(Function):
                 ws, nb = _ws(g, 2, x.device)
                 with _span(g, 2, 4 * (gy.numel() + x.numel() + dw.numel())):
                     _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+
+
+def channel_shuffle(x, groups):
+    """(N, g*c, H, W) -> interleave the g groups (models/nin_gc.py:4-15), materialised with torch."""
+    n, ch, h, w = x.size()
+    return x.view(n, groups, ch // groups, h, w).transpose(1, 2).contiguous().view(n, ch, h, w)
 
 
 def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None,
-            wdesc=None, x_is_code=False):
+            wdesc=None, x_is_code=False, in_shuffle=0):
+    """``in_shuffle`` > 1: the convolution of ``channel_shuffle(x, in_shuffle)``; the permutation is folded into the kernels'
+    channel addressing when the code-domain kernels cover all three passes, else materialised."""
+    if in_shuffle and in_shuffle > 1:
+        g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle)
+        aq = ActQ(aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
+        wd = _wq_desc(wdesc)
+        lib = _lib_()
+        ok = CONV_ALGO in (_lib.MN_ALGO_AUTO, _lib.MN_ALGO_QGEMM) and all(
+            lib.mn_conv2d_qgemm_supported(C.byref(g), C.byref(aq), _ref(wd), k) for k in range(3))
+        if not ok:
+            x, in_shuffle = channel_shuffle(x, in_shuffle), 0
     return QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc,
-                         _lib.MN_ACTQ_X_IS_CODE if x_is_code else 0)
+                         _lib.MN_ACTQ_X_IS_CODE if x_is_code else 0, in_shuffle or 0)
 
 
 def qlinear(x, wq, bias, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None, wdesc=None):

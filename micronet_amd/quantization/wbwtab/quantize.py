@@ -17,7 +17,7 @@ from torch.autograd import Function
 from micronet_amd import ops
 
 __all__ = ["BinaryActivation", "BinaryWeight", "Ternary", "ActivationQuantizer", "meancenter_clamp_convparams",
-           "WeightQuantizer", "QuantConv2d", "QuantConvTranspose2d", "add_quant_op", "prepare"]
+           "WeightQuantizer", "QuantConv2d", "QuantConvTranspose2d", "BatchNorm2dBinAct", "add_quant_op", "prepare"]
 
 
 class BinaryActivation(Function):
@@ -70,7 +70,32 @@ class ActivationQuantizer(nn.Module):
         return BinaryActivation.apply(input)
 
     def forward(self, input):
+        if self.A == 2 and getattr(input, "_mn_binarized", False):
+            return input              # the BatchNorm2dBinAct in front already produced sign(bn(x)) in its fused kernel
         return self.binary(input) if self.A == 2 else self.relu(input)
+
+
+class BatchNorm2dBinAct(nn.BatchNorm2d):
+    """``nn.BatchNorm2d`` (same parameters, buffers and ``state_dict`` keys) that is immediately followed by a binary
+    ``ActivationQuantizer``: on the GPU it computes ``sign(bn(x))`` in ONE fused op -- the normalised tensor is never written,
+    the backward recomputes it -- and tags the result so that the ``ActivationQuantizer`` passes it through.  ``prepare()``
+    installs it only where the module order guarantees that hand-off (``nn.Sequential`` parents and the reference's
+    ``ConvBNReLU`` blocks, models/nin_gc.py:53-59); everywhere else the plain modules run."""
+
+    def forward(self, input):
+        hw = input.shape[2] * input.shape[3] if input.dim() == 4 else 0
+        if not (input.is_cuda and input.dim() == 4 and hw % 4 == 0 and self.affine and input.dtype == torch.float32):
+            return super().forward(input)
+        use_batch = self.training or self.running_mean is None
+        momentum = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:
+                momentum = 1.0 / float(self.num_batches_tracked)
+        out = ops.BNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                               self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
+        out._mn_binarized = True
+        return out
 
 
 def meancenter_clamp_convparams(w):
@@ -104,13 +129,14 @@ class QuantConv2d(nn.Conv2d):
         super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, padding_mode)
         self.quant_inference = quant_inference
         self.weight_quantizer = WeightQuantizer(W=W)
+        self.in_shuffle_groups = 0     # > 1: this conv reads channel_shuffle(input, groups) (set by prepare(), see add_quant_op)
 
     def forward(self, input):
         tnn_bin_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
         # binary / ternary weights are t * alpha[o]: the conv contracts the integer codes t on the bf16 matrix cores
         coded = (not self.quant_inference) and self.weight_quantizer.W in (2, 3)
         return ops.qconv2d(input, tnn_bin_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
-                           wdesc=(ops.WQ_TERNARY, 0, 0, 0, None) if coded else None)
+                           wdesc=(ops.WQ_TERNARY, 0, 0, 0, None) if coded else None, in_shuffle=self.in_shuffle_groups)
 
 
 class QuantConvTranspose2d(nn.ConvTranspose2d):
@@ -127,9 +153,16 @@ class QuantConvTranspose2d(nn.ConvTranspose2d):
                                          self.output_padding, self.groups, self.dilation)
 
 
-def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=False):
+def _ordered_parent(module):
+    """True when the parent calls its children in definition order, so bn -> relu adjacency means bn feeds relu."""
+    return isinstance(module, nn.Sequential) or type(module).__name__ == "ConvBNReLU"
+
+
+def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True):
     """Quantise conv k iff 1 < k < layer_num; every ReLU met while 0 < k < layer_num becomes the binary activation
-    (ref 247-331)."""
+    (ref 247-331).  With ``fuse_bn_act`` a plain BatchNorm2d directly in front of such a binary activation is switched to
+    ``BatchNorm2dBinAct`` (same object, same state: only its class changes)."""
+    prev = None
     for name, child in module.named_children():
         if isinstance(child, nn.Conv2d):
             layer_counter[0] += 1
@@ -142,6 +175,12 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                     new.bias.data = child.bias
                 new.weight.data = child.weight
                 module._modules[name] = new
+                # the reference's ConvBNReLU block shuffles its input in front of the conv (models/nin_gc.py:53-56):
+                # hand the permutation to the conv, which folds it into its channel addressing (no copy of the tensor)
+                if fold_shuffle and type(module).__name__ == "ConvBNReLU" and getattr(module, "channel_shuffle_flag", 0) \
+                        and getattr(module, "shuffle_groups", 1) > 1 and child.in_channels % module.shuffle_groups == 0:
+                    new.in_shuffle_groups = int(module.shuffle_groups)
+                    module.channel_shuffle_flag = 0
         elif isinstance(child, nn.ConvTranspose2d):
             layer_counter[0] += 1
             if 1 < layer_counter[0] < layer_num:
@@ -156,13 +195,20 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
         elif isinstance(child, nn.ReLU):
             if 0 < layer_counter[0] < layer_num:
                 module._modules[name] = ActivationQuantizer(A=A)
+                if fuse_bn_act and A == 2 and type(prev) is nn.BatchNorm2d and prev.affine and _ordered_parent(module):
+                    prev.__class__ = BatchNorm2dBinAct
         else:
-            add_quant_op(child, layer_counter, layer_num, A=A, W=W, quant_inference=quant_inference)
+            add_quant_op(child, layer_counter, layer_num, A=A, W=W, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act,
+                         fold_shuffle=fold_shuffle)
+        prev = child
 
 
-def prepare(model, inplace=False, A=2, W=2, quant_inference=False):
+def prepare(model, inplace=False, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True):
+    """Same rewrite as the reference (ref 334-347); ``fuse_bn_act`` (ours, default on) additionally fuses BatchNorm2d with
+    the binary activation that follows it (see ``BatchNorm2dBinAct``), and ``fold_shuffle`` (ours, default on) moves the
+    channel shuffle of a ``ConvBNReLU`` block into its quantised conv's addressing -- numerically the same function."""
     if not inplace:
         model = copy.deepcopy(model)
     layer_num = sum(isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) for m in model.modules())
-    add_quant_op(model, [0], layer_num, A=A, W=W, quant_inference=quant_inference)
+    add_quant_op(model, [0], layer_num, A=A, W=W, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act, fold_shuffle=fold_shuffle)
     return model

@@ -202,7 +202,7 @@ def make_coded_weights(r, w_shape, wmode, wbits=8):
 
 
 def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, bias=True, mode=0, bits=8, q_type=0,
-               algos=(1, 2), seed=0, binary_x=False, expect_mfma=None, rel=1e-5, wmode=0, wbits=8, expect_qgemm=None):
+               algos=(1, 2), seed=0, binary_x=False, expect_mfma=None, rel=1e-5, wmode=0, wbits=8, expect_qgemm=None, in_shuffle=0):
     """fwd / bwd_data / bwd_weight of one geometry on every requested algo vs numpy fp64 on the same fp32 operands.
     wmode != 0: the weights are fake-quantised (ternary / dorefa / iao) and algo 3 (code-domain bf16 MFMA) is exercised."""
     r = np.random.default_rng(seed)
@@ -215,6 +215,11 @@ def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, 
         w = (r.standard_normal(w_shape) * 0.3).astype(F)
     b = (r.standard_normal(w_shape[0]) * 0.2).astype(F) if bias else None
     g = be.geom(x_shape, w_shape, stride, padding, dilation, groups)
+    x_phys = x
+    if in_shuffle > 1:          # the kernels see the physical tensor; the reference convolves channel_shuffle(x_phys)
+        g.in_shuffle = in_shuffle
+        n_, c_, h_, w_ = x.shape
+        x = np.ascontiguousarray(x_phys.reshape(n_, in_shuffle, c_ // in_shuffle, h_, w_).transpose(0, 2, 1, 3, 4).reshape(x.shape))
     qp = None
     if mode == 2:
         mn, mx = F(x.min()), F(x.max())
@@ -229,7 +234,10 @@ def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, 
     gy = r.standard_normal(y_ref.shape).astype(F)
     dqx_ref, dw_ref, db_ref = O.conv2d_bwd(gy, qx, w, **kw)
     dx_ref = _ste(dqx_ref, x, mode, bits, qp, q_type)
-    dX, dW, dB, dG = be.to_dev(x), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(gy)
+    if in_shuffle > 1:          # gradient w.r.t. the physical tensor = inverse shuffle of the logical gradient
+        n_, c_, h_, w_ = x.shape
+        dx_ref = np.ascontiguousarray(dx_ref.reshape(n_, c_ // in_shuffle, in_shuffle, h_, w_).transpose(0, 2, 1, 3, 4).reshape(x.shape))
+    dX, dW, dB, dG = be.to_dev(x_phys), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(gy)
     dqp = be.to_dev(qp) if qp is not None else None
     aq = be.actq(mode, bits, q_type, dqp, flags=1 if (binary_x and mode == 0) else 0)
     sup = [bool(be.lib.mn_conv2d_mfma_supported(C.byref(g), k)) for k in range(3)]
@@ -337,3 +345,53 @@ def check_adam(be, sizes=(5, 4099, 2048, 1), steps=3, lr=0.01, wd=1e-5, seed=0):
         for i, t in enumerate(tp):
             got, ref = be.to_host(dp[i]), t.detach().numpy()
             assert np.max(np.abs(got - ref)) <= 2e-6 * max(1.0, np.max(np.abs(ref))), (step, i, np.max(np.abs(got - ref)))
+
+
+def check_bnsign(be, shape=(6, 5, 4, 8), seed=0, training=True):
+    """mn_bnsign_fwd/bwd vs an fp64 numpy evaluation of BatchNorm2d (batch or running statistics) + BinaryActivation."""
+    r = np.random.default_rng(seed)
+    N, Cc, H, W = shape
+    HW = H * W
+    y = (r.standard_normal(shape) * 1.5 + r.standard_normal((1, Cc, 1, 1))).astype(F)
+    gamma, beta = (r.standard_normal(Cc) * 0.5 + 1).astype(F), (r.standard_normal(Cc) * 0.3).astype(F)
+    rm, rv = (r.standard_normal(Cc) * 0.1).astype(F), (np.abs(r.standard_normal(Cc)) + 0.5).astype(F)
+    da = r.standard_normal(shape).astype(F)
+    eps, mom = 1e-5, 0.1
+    y64 = y.astype(np.float64)
+    n = N * HW
+    if training:
+        mean = y64.mean(axis=(0, 2, 3)); var_b = y64.var(axis=(0, 2, 3)); var_u = var_b * n / (n - 1)
+    else:
+        mean, var_b = rm.astype(np.float64), rv.astype(np.float64)
+    invstd = 1.0 / np.sqrt(var_b + eps)
+    zh = (y64 - mean.reshape(1, -1, 1, 1)) * invstd.reshape(1, -1, 1, 1)
+    z = zh * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
+    a_ref = np.where(z < 0, -1.0, 1.0)
+    dz = np.where((z > -1) & (z < 1), da.astype(np.float64), 0.0)
+    dbeta_ref, dgamma_ref = dz.sum(axis=(0, 2, 3)), (dz * zh).sum(axis=(0, 2, 3))
+    gi = (gamma * invstd).reshape(1, -1, 1, 1)
+    if training:
+        dy_ref = gi * (dz - dbeta_ref.reshape(1, -1, 1, 1) / n - zh * dgamma_ref.reshape(1, -1, 1, 1) / n)
+    else:
+        dy_ref = gi * dz
+    dY, dG, dB, dRM, dRV, dDA = be.to_dev(y), be.to_dev(gamma), be.to_dev(beta), be.to_dev(rm), be.to_dev(rv), be.to_dev(da)
+    save, a, dy, dgam, dbet = be.empty((2, Cc)), be.empty(shape), be.empty(shape), be.empty(Cc), be.empty(Cc)
+    ws = be.empty(int(be.lib.mn_bnsign_ws_floats(Cc)) + 2)
+    be.call("mn_bnsign_fwd", be.ptr(dY), N, Cc, HW, be.ptr(dG), be.ptr(dB), eps, mom, int(training), be.ptr(dRM), be.ptr(dRV),
+            be.ptr(save), be.ptr(a), be.ptr(ws), be.stream)
+    be.call("mn_bnsign_bwd", be.ptr(dDA), be.ptr(dY), be.ptr(save), be.ptr(dG), be.ptr(dB), N, Cc, HW, int(training), be.ptr(dy),
+            be.ptr(dgam), be.ptr(dbet), be.ptr(ws), be.stream)
+    a_got = be.to_host(a)
+    safe = np.abs(z) > 1e-5                      # away from the sign tie
+    assert np.array_equal(a_got[safe], a_ref[safe]) and np.all(np.abs(a_got) == 1.0)
+    sv = be.to_host(save)
+    assert np.max(np.abs(sv[0] - mean)) <= 1e-6 * max(1.0, np.max(np.abs(mean))) and np.max(np.abs(sv[1] - invstd) / invstd) <= 2e-6
+    if training:
+        assert np.max(np.abs(be.to_host(dRM) - ((1 - mom) * rm + mom * mean))) <= 1e-6
+        assert np.max(np.abs(be.to_host(dRV) - ((1 - mom) * rv + mom * var_u))) <= 2e-6 * np.max(var_u)
+    else:
+        assert eq(be.to_host(dRM), rm) and eq(be.to_host(dRV), rv)
+    edge = (np.abs(np.abs(z) - 1) < 1e-5).any()
+    tol = 1e-3 if edge else 1e-5
+    assert close(be.to_host(dbet), dbeta_ref, tol) and close(be.to_host(dgam), dgamma_ref, tol)
+    assert close(be.to_host(dy), dy_ref, tol)

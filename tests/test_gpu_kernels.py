@@ -209,3 +209,21 @@ def test_adam_optimizer_matches_torch():
         # conv biases in front of a BatchNorm see gradients ~1e-9: m/(sqrt(v)+eps) amplifies last-bit differences there
         assert (pa - pb).abs().max() <= 1e-5 * pb.abs().max().clamp_min(1.0)
     assert set(oa.state_dict()["state"][0].keys()) == set(ob.state_dict()["state"][0].keys())
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bnsign(be, training):
+    K.check_bnsign(be, training=training)
+    K.check_bnsign(be, shape=(3, 7, 2, 2), seed=3, training=training)
+    K.check_bnsign(be, shape=(32, 64, 16, 16), seed=4, training=training)
+
+
+@pytest.mark.parametrize("case,sg", [(1, 2), (1, 5), (2, 4)])
+def test_qgemm_pointwise_in_shuffle(be, case, sg):
+    K.check_conv(be, seed=90 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=True, in_shuffle=sg, **K.QGEMM_PW_CASES[case])
+    K.check_conv(be, seed=95 + case, mode=1, bits=4, wmode=2, wbits=4, algos=(3,), expect_qgemm=True, in_shuffle=sg, **K.QGEMM_PW_CASES[case])
+
+
+@pytest.mark.parametrize("case,sg", [(0, 2), (0, 8), (4, 5)])
+def test_qgemm_kxk_in_shuffle(be, case, sg):
+    K.check_conv(be, seed=97 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=True, in_shuffle=sg, **K.QGEMM_KXK_CASES[case])

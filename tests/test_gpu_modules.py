@@ -209,3 +209,63 @@ def test_small_net_vs_torch_oracle(scheme, cfg, okw):
         e = rel_err(gp[n_].grad.cpu(), p.grad)
         assert e <= (0.6 if chaotic else 0.25), (n_, e)       # free-running: a handful of activation-code flips perturb deep-layer gradients;
                                         # the tight per-layer statement is test_gpu_models.py::test_layerwise_teacher_forced
+
+
+def test_wbwtab_fused_bn_binact_matches_unfused():
+    """prepare(fuse_bn_act=True) (BatchNorm2dBinAct: one fused kernel) vs the plain BatchNorm2d + ActivationQuantizer modules:
+    same binary activations except at BatchNorm outputs within rounding of zero, same gradients, same running statistics and
+    state_dict keys."""
+    w = _q("wbwtab")
+
+    def net():
+        torch.manual_seed(3)
+        return nn.Sequential(nn.Conv2d(3, 32, 3, padding=1), nn.BatchNorm2d(32), nn.ReLU(inplace=True),
+                             nn.Conv2d(32, 64, 3, padding=1, groups=2), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+                             nn.Conv2d(64, 10, 1)).cuda().train()
+    fused = w.prepare(net(), inplace=True, A=2, W=3)
+    plain = w.prepare(net(), inplace=True, A=2, W=3, fuse_bn_act=False)
+    assert type(fused[1]).__name__ == "BatchNorm2dBinAct" and type(plain[1]) is nn.BatchNorm2d
+    assert list(fused.state_dict().keys()) == list(plain.state_dict().keys())
+    x = torch.randn(8, 3, 16, 16, device="cuda")
+    acts = {}
+    fused[2].register_forward_hook(lambda m, i, o: acts.__setitem__("f", o.detach().clone()))
+    plain[2].register_forward_hook(lambda m, i, o: acts.__setitem__("p", o.detach().clone()))
+    yf, yp = fused(x), plain(x)
+    flips = (acts["f"] != acts["p"]).float().mean().item()
+    assert flips <= 1e-4, flips
+    assert torch.all(acts["f"].abs() == 1)
+    (yf.square().mean()).backward()
+    (yp.square().mean()).backward()
+    assert rel_err(fused[0].weight.grad.cpu(), plain[0].weight.grad.cpu()) <= (2e-2 if flips else 2e-5)
+    assert rel_err(fused[1].weight.grad.cpu(), plain[1].weight.grad.cpu()) <= (2e-2 if flips else 2e-5)
+    assert rel_err(fused[1].running_var.cpu(), plain[1].running_var.cpu()) <= 1e-5
+    assert int(fused[1].num_batches_tracked) == 1
+    fused.eval(), plain.eval()
+    ef, ep = fused(x), plain(x)
+    assert rel_err(ef.detach().cpu(), ep.detach().cpu()) <= 0.2
+
+
+def test_wbwtab_folded_channel_shuffle_is_bit_identical():
+    """prepare(fold_shuffle=True) moves ConvBNReLU's channel shuffle into the conv kernels' addressing: outputs and every
+    gradient must be bit-identical to the materialised shuffle (same products, same summation order)."""
+    from micronet_amd.models.nin_gc import ConvBNReLU
+    w = _q("wbwtab")
+
+    def net():
+        torch.manual_seed(5)
+        return nn.Sequential(ConvBNReLU(3, 16, 3, padding=1), ConvBNReLU(16, 32, 1, groups=2, channel_shuffle=1, shuffle_groups=2),
+                             ConvBNReLU(32, 32, 3, padding=1, groups=2, channel_shuffle=1, shuffle_groups=4),
+                             ConvBNReLU(32, 10, 1)).cuda().train()
+    a = w.prepare(net(), inplace=True, A=2, W=3, fold_shuffle=True)
+    b = w.prepare(net(), inplace=True, A=2, W=3, fold_shuffle=False)
+    assert a[1].conv.in_shuffle_groups == 2 and a[1].channel_shuffle_flag == 0 and b[1].channel_shuffle_flag == 1
+    x = torch.randn(8, 3, 16, 16, device="cuda")
+    ya, yb = a(x), b(x)
+    assert torch.equal(ya, yb)
+    ya.square().mean().backward()
+    yb.square().mean().backward()
+    for (n_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if n_.startswith(("1.", "2.")):        # our kernels: deterministic, bit-identical
+            assert torch.equal(pa.grad, pb.grad), n_
+        else:                                  # plain nn.Conv2d layers run MIOpen's (atomic) backward-weight: equal to rounding
+            assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 1e-5, n_

@@ -94,3 +94,21 @@ def test_qgemm_kxk_fused_actq(be, case, mode):
 def test_adam_step(be):
     K.check_adam(be)
     K.check_adam(be, sizes=tuple(range(1, 41)), steps=2, seed=1)      # more tensors than one launch table holds
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bnsign(be, training):
+    K.check_bnsign(be, training=training)
+    K.check_bnsign(be, shape=(3, 7, 2, 2), seed=3, training=training)
+
+
+@pytest.mark.parametrize("case,sg", [(1, 2), (1, 5), (2, 4)])
+def test_qgemm_pointwise_in_shuffle(be, case, sg):
+    """channel shuffle folded into the conv's addressing: fwd reads, bwd-data writes and bwd-weight reads through the map."""
+    K.check_conv(be, seed=90 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=True, in_shuffle=sg, **K.QGEMM_PW_CASES[case])
+    K.check_conv(be, seed=95 + case, mode=1, bits=4, wmode=2, wbits=4, algos=(3,), expect_qgemm=True, in_shuffle=sg, **K.QGEMM_PW_CASES[case])
+
+
+@pytest.mark.parametrize("case,sg", [(0, 2), (0, 8), (4, 5)])
+def test_qgemm_kxk_in_shuffle(be, case, sg):
+    K.check_conv(be, seed=97 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=True, in_shuffle=sg, **K.QGEMM_KXK_CASES[case])
