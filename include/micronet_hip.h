@@ -127,6 +127,11 @@ typedef struct mn_conv_geom {
 #define MN_ACTQ_NONE 0
 #define MN_ACTQ_DOREFA 1
 #define MN_ACTQ_IAO 2
+#define MN_ACTQ_SIGN8 3 /* `x` is NOT fp32: it points to int8 codes in {-1, +1}, laid out NCHW like x -- the packed output of
+                          mn_bnsign_fwd_i8 / mn_maxpool2x2_sign8_fwd (the BinaryActivation of wbwtab/quantize.py:13-19 stored in
+                          one byte per element: a quarter of the HBM traffic of the fp32 +-1 tensor).  fwd and bwd_weight read the
+                          codes directly (4-byte aligned rows: H*W % 4 == 0); bwd_data ignores x (the clip-STE of the sign lives
+                          in mn_bnsign_bwd).  Code-domain kernels only (else MN_ENOTSUP). */
 #define MN_ACTQ_X_IS_CODE 1 /* flags: optional hint that with MN_ACTQ_NONE x holds small integers exact in bf16 (the +-1 of
                               wbwtab's BinaryActivation, wbwtab/quantize.py:13-19).  Never required: real-valued x is split
                               into exact bf16 terms on the fly and all-zero terms are skipped. */
@@ -191,6 +196,15 @@ int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* 
 int64_t mn_bnsign_ws_floats(int64_t C);
 int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                   int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream);
+/* same, but `a` is written as int8 sign codes {-1,+1} (one byte per element, NCHW like y): the packed activation the
+ * code-domain conv kernels read with MN_ACTQ_SIGN8.  NaN inputs map to +1 (no NaN in int8). */
+int mn_bnsign_fwd_i8(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                     int training, float* running_mean, float* running_var, float* save, int8_t* a, float* ws, mn_stream_t stream);
+/* nn.MaxPool2d(kernel_size=2, stride=2) between binary-activation blocks (models/nin_gc.py:88,119) on int8 sign codes:
+ * a [planes][H][W] -> out [planes][H/2][W/2] (even H, W % 8 == 0).  Backward routes each output gradient to the first
+ * maximum of its window in row-major order (what ATen's max_pool2d backward does): din [planes][H][W] fp32 (W % 4 == 0). */
+int mn_maxpool2x2_sign8_fwd(const int8_t* a, int64_t planes, int64_t H, int64_t W, int8_t* out, mn_stream_t stream);
+int mn_maxpool2x2_sign8_bwd(const float* dout, const int8_t* a, int64_t planes, int64_t H, int64_t W, float* din, mn_stream_t stream);
 /* dy = d loss / d y given da = d loss / d a (clip-STE of the sign through the BatchNorm backward); dgamma / dbeta nullable */
 int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                   int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libmicronet_hip.so")
 
-MN_ACTQ_NONE, MN_ACTQ_DOREFA, MN_ACTQ_IAO = 0, 1, 2
+MN_ACTQ_NONE, MN_ACTQ_DOREFA, MN_ACTQ_IAO, MN_ACTQ_SIGN8 = 0, 1, 2, 3
 MN_ALGO_AUTO, MN_ALGO_DIRECT, MN_ALGO_MFMA, MN_ALGO_QGEMM = 0, 1, 2, 3
 MN_WQ_REAL, MN_WQ_TERNARY, MN_WQ_DOREFA, MN_WQ_IAO = 0, 1, 2, 3
 MN_ACTQ_X_IS_CODE = 1
@@ -71,6 +71,9 @@ PROTOTYPES = {
     "mn_bn_stats_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _P]),
     "mn_bnsign_ws_floats": (_L, [_L]),
     "mn_bnsign_fwd": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P]),
+    "mn_bnsign_fwd_i8": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P]),
+    "mn_maxpool2x2_sign8_fwd": (_I, [_P, _L, _L, _L, _P, _P]),
+    "mn_maxpool2x2_sign8_bwd": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "mn_bnsign_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),

@@ -135,10 +135,26 @@ static int make_pro(const mn_actq* aq, Pro* p, int need_bounds, const char* what
         p->mode = MN_ACTQ_IAO; p->qmin = r.qmin; p->qmax = r.qmax; p->qp = aq->qp;
         return MN_OK;
     }
+    if (aq->mode == MN_ACTQ_SIGN8) { p->mode = MN_ACTQ_SIGN8; return MN_OK; }
     (void)need_bounds;
     MN_FAIL(MN_EINVAL, "%s: unknown activation quantizer mode %d", what, aq->mode);
 }
 
+
+// four consecutive elements of the streamed conv input at element offset `off` (a multiple of 4): fp32, or -- MN_ACTQ_SIGN8 --
+// int8 sign codes widened to +-1.0f (any negative byte is -1, anything else +1)
+template <int XMODE>
+__device__ __forceinline__ float4 mn_ld_x4(const float* base, int64_t off) {
+    if (XMODE == MN_ACTQ_SIGN8) {
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + off);
+        return make_float4((u & 0x80u) ? -1.f : 1.f, (u & 0x8000u) ? -1.f : 1.f, (u & 0x800000u) ? -1.f : 1.f, (u & 0x80000000u) ? -1.f : 1.f);
+    }
+    return *reinterpret_cast<const float4*>(base + off);
+}
+// bf16 pair {sign of byte q of u_lo, sign of byte q of u_hi} as +-1 (0x3F80 / 0xBF80): low half = u_lo's element
+__device__ __forceinline__ unsigned mn_sign8_pair(unsigned u_lo, unsigned u_hi, int q) {
+    return 0x3F803F80u | (((u_lo >> (8 * q)) & 0x80u) << 8) | (((u_hi >> (8 * q)) & 0x80u) << 24);
+}
 
 __host__ __device__ static inline int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

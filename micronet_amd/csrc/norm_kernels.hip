@@ -105,7 +105,8 @@ __global__ void k_bns_eval_stats(int C, float eps, const float* __restrict__ run
     save[C + c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 // MODE 0: a = sign(bn(y)).   MODE 1: dy (training: full BN backward; eval: statistics are constants)
-template <int MODE>
+// OUT8 (MODE 0 only): a is written as int8 sign codes (0x01 / 0xFF), 4 per lane and store
+template <int MODE, int OUT8 = 0>
 __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ da,
                                                    const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ sums, int training, float* __restrict__ out) {
@@ -135,8 +136,77 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
                 r[e] = gi * (dz - k1 - zh[e] * k2);
             }
         }
-        *reinterpret_cast<float4*>(out + off) = make_float4(r[0], r[1], r[2], r[3]);
+        if (OUT8) {
+            const uint32_t u = (r[0] < 0.f ? 0xFFu : 0x01u) | (r[1] < 0.f ? 0xFF00u : 0x0100u) | (r[2] < 0.f ? 0xFF0000u : 0x010000u) |
+                               (r[3] < 0.f ? 0xFF000000u : 0x01000000u);
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + off) = u;
+        } else {
+            *reinterpret_cast<float4*>(out + off) = make_float4(r[0], r[1], r[2], r[3]);
+        }
     }
+}
+
+// ---------------------------------------------------------------- 2x2 / stride-2 max-pool on int8 sign codes
+// max over +-1 = +1 unless all four are -1.  Thread = 4 output pixels of one output row (8 input bytes of two rows).
+__global__ __launch_bounds__(256) void k_pool2_sign8_fwd(const char* __restrict__ a, char* __restrict__ out, int64_t nq, int H, int W) {
+    const int Wo = W >> 1, Ho = H >> 1, q4 = Wo >> 2;      // q4 quads per output row
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / q4;                         // (plane, out row)
+        const int qc = (int)(i - row * q4);
+        const int64_t pl = row / Ho;
+        const int orow = (int)(row - pl * Ho);
+        const char* src = a + (pl * H + 2 * orow) * W + qc * 8;
+        const uint64_t r0 = *reinterpret_cast<const uint64_t*>(src), r1 = *reinterpret_cast<const uint64_t*>(src + W);
+        const uint64_t vv = r0 & r1 & 0x8080808080808080ull;                                // vertical AND of the sign bits
+        const uint32_t v0 = (uint32_t)vv, v1 = (uint32_t)(vv >> 32);
+        const uint32_t n0 = v0 & (v0 >> 8), n1 = v1 & (v1 >> 8);                            // horizontal: bytes (0,1) -> bit 7, (2,3) -> bit 23
+        const uint32_t o = ((n0 & 0x80u) ? 0xFFu : 0x01u) | ((n0 & 0x800000u) ? 0xFF00u : 0x0100u) |
+                           ((n1 & 0x80u) ? 0xFF0000u : 0x010000u) | ((n1 & 0x800000u) ? 0xFF000000u : 0x01000000u);
+        *reinterpret_cast<uint32_t*>(out + (pl * Ho + orow) * Wo + qc * 4) = o;
+    }
+}
+// backward: the gradient of an output pixel goes to the FIRST maximum of its window in row-major order (ATen's
+// max_pool2d picks `val > max`): the first +1, or the first element when all four are -1.  Thread = 2 output pixels.
+__global__ __launch_bounds__(256) void k_pool2_sign8_bwd(const float* __restrict__ dout, const char* __restrict__ a, float* __restrict__ din,
+                                                         int64_t np, int H, int W) {
+    const int Wo = W >> 1, Ho = H >> 1, p2 = Wo >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / p2;
+        const int pc = (int)(i - row * p2);
+        const int64_t pl = row / Ho;
+        const int orow = (int)(row - pl * Ho);
+        const float2 g = *reinterpret_cast<const float2*>(dout + (pl * Ho + orow) * Wo + pc * 2);
+        const int64_t ioff = (pl * H + 2 * orow) * W + pc * 4;
+        const uint32_t r0 = *reinterpret_cast<const uint32_t*>(a + ioff), r1 = *reinterpret_cast<const uint32_t*>(a + ioff + W);
+        float t[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool p00 = !((r0 >> (16 * e)) & 0x80u), p01 = !((r0 >> (16 * e + 8)) & 0x80u);
+            const bool p10 = !((r1 >> (16 * e)) & 0x80u), p11 = !((r1 >> (16 * e + 8)) & 0x80u);
+            const float gv = e ? g.y : g.x;
+            const int win = p00 ? 0 : (p01 ? 1 : (p10 ? 2 : (p11 ? 3 : 0)));
+            t[2 * e] = win == 0 ? gv : 0.f; t[2 * e + 1] = win == 1 ? gv : 0.f;
+            b[2 * e] = win == 2 ? gv : 0.f; b[2 * e + 1] = win == 3 ? gv : 0.f;
+        }
+        *reinterpret_cast<float4*>(din + ioff) = make_float4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<float4*>(din + ioff + W) = make_float4(b[0], b[1], b[2], b[3]);
+    }
+}
+extern "C" int mn_maxpool2x2_sign8_fwd(const int8_t* a, int64_t planes, int64_t H, int64_t W, int8_t* out, mn_stream_t stream) {
+    if (!a || !out || planes <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 7) || (((uintptr_t)a) & 7) || (((uintptr_t)out) & 3))
+        MN_FAIL(MN_EINVAL, "mn_maxpool2x2_sign8_fwd: needs even H, W %% 8 == 0, 8-byte aligned input");
+    const int64_t nq = planes * (H / 2) * (W / 8);
+    hipLaunchKernelGGL(k_pool2_sign8_fwd, dim3(mn_grid_for(nq, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const char*)a, (char*)out, nq, (int)H, (int)W);
+    MN_CHECK_LAUNCH("mn_maxpool2x2_sign8_fwd");
+    return MN_OK;
+}
+extern "C" int mn_maxpool2x2_sign8_bwd(const float* dout, const int8_t* a, int64_t planes, int64_t H, int64_t W, float* din, mn_stream_t stream) {
+    if (!dout || !a || !din || planes <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 3) || (((uintptr_t)a) & 3) || !aligned16(din) || (((uintptr_t)dout) & 7))
+        MN_FAIL(MN_EINVAL, "mn_maxpool2x2_sign8_bwd: needs even H, W %% 4 == 0, aligned tensors");
+    const int64_t np = planes * (H / 2) * (W / 4);
+    hipLaunchKernelGGL(k_pool2_sign8_bwd, dim3(mn_grid_for(np, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dout, (const char*)a, din, np, (int)H, (int)W);
+    MN_CHECK_LAUNCH("mn_maxpool2x2_sign8_bwd");
+    return MN_OK;
 }
 
 extern "C" int64_t mn_bnsign_ws_floats(int64_t C) { return C * BNS_SPLIT * 4 + 2 * C + 16; }   // fp64 partials + {sum dz, sum dz*zhat}
@@ -156,9 +226,10 @@ static int bns_split(const BnsGeom& g) {
     return (int)S;
 }
 
-extern "C" int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
-                             int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
-    int rc = bns_check(N, C, HW, y, a, "mn_bnsign_fwd");
+static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                           int training, float* running_mean, float* running_var, float* save, float* a, int out8, float* ws, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, y, out8 ? (const void*)y : (const void*)a, "mn_bnsign_fwd");
+    if (!rc && out8 && (((uintptr_t)a) & 3)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd_i8: output must be 4-byte aligned");
     if (rc) return rc;
     if (!y || !gamma || !beta || !save || !a || !ws || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: null / misaligned argument");
     if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: eval mode needs the running statistics");
@@ -172,10 +243,20 @@ extern "C" int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, c
     } else {
         hipLaunchKernelGGL(k_bns_eval_stats, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (int)C, eps, (const float*)running_mean, (const float*)running_var, save);
     }
-    hipLaunchKernelGGL(k_bns_apply<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
-                       (const float*)nullptr, training, a);
+    if (out8) hipLaunchKernelGGL((k_bns_apply<0, 1>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
+                                 (const float*)nullptr, training, a);
+    else hipLaunchKernelGGL((k_bns_apply<0, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
+                            (const float*)nullptr, training, a);
     MN_CHECK_LAUNCH("mn_bnsign_fwd");
     return MN_OK;
+}
+extern "C" int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                             int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
+    return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream);
+}
+extern "C" int mn_bnsign_fwd_i8(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                                int training, float* running_mean, float* running_var, float* save, int8_t* a, float* ws, mn_stream_t stream) {
+    return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, (float*)a, 1, ws, stream);
 }
 
 extern "C" int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
@@ -189,7 +270,7 @@ extern "C" int mn_bnsign_bwd(const float* da, const float* y, const float* save,
     float* sums = ws + C * BNS_SPLIT * 4;
     hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws);
     hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
-    hipLaunchKernelGGL(k_bns_apply<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy);
+    hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy);
     MN_CHECK_LAUNCH("mn_bnsign_bwd");
     return MN_OK;
 }

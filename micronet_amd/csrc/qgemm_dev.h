@@ -53,6 +53,7 @@ static inline int aq_codeable(const mn_actq* aq, int need_exact_x) {
     if (!aq || aq->mode == MN_ACTQ_NONE) return 1;
     if (aq->mode == MN_ACTQ_DOREFA) return aq->bits >= 2 && aq->bits <= 8;
     if (aq->mode == MN_ACTQ_IAO) return aq->bits >= 2 && aq->bits <= 8 && aq->q_type == 0 && aq->qp;
+    if (aq->mode == MN_ACTQ_SIGN8) return 1;
     return 0;
 }
 static inline int wq_codeable(const mn_wq* wq) {

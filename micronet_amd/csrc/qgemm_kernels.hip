@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // MN_ACTQ_SIGN8: the stream is int8 sign codes -- one dword (4 pixels) per channel lands in raw[jj][0] as raw bits
     auto issue = [&](float (&raw)[8][4], int it) {
         const uint32_t ci = fd_div((uint32_t)it, p.fd_ks);
         const int s = it - (int)ci * p.KS;
@@ -156,13 +157,19 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
         const bool pv = P < p.NP;
         const uint32_t n = fd_div(P, p.fd_hw);
         const int pp = (int)(P - n * (uint32_t)p.HW);
-        const float* base = p.x + (int64_t)n * p.Cin_total * HW + pp;
+        const int64_t boff = (int64_t)n * p.Cin_total * HW + pp;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int c = s * 32 + kg * 8 + jj;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pv && c < p.Kc) v = *reinterpret_cast<const float4*>(base + (int64_t)chan_phys(p.in_map, g * p.Kc + c) * HW);
-            raw[jj][0] = v.x; raw[jj][1] = v.y; raw[jj][2] = v.z; raw[jj][3] = v.w;
+            if (XMODE == MN_ACTQ_SIGN8) {
+                uint32_t u = 0u;
+                if (pv && c < p.Kc) u = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.x) + boff + (int64_t)chan_phys(p.in_map, g * p.Kc + c) * HW);
+                raw[jj][0] = mn_u2f(u);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pv && c < p.Kc) v = *reinterpret_cast<const float4*>(p.x + boff + (int64_t)chan_phys(p.in_map, g * p.Kc + c) * HW);
+                raw[jj][0] = v.x; raw[jj][1] = v.y; raw[jj][2] = v.z; raw[jj][3] = v.w;
+            }
         }
     };
 
@@ -199,6 +206,11 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
             }
             use1 = mn_wave_any(any1 != 0u);
             use2 = mn_wave_any(any2 != 0u);
+        } else if (XMODE == MN_ACTQ_SIGN8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) b0[q][d] = mn_sign8_pair(mn_f2u(raw[2 * d][0]), mn_f2u(raw[2 * d + 1][0]), q);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -332,7 +344,10 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
         for (int i = 0; i < RC; ++i) {
             const int c = cb * TC + r0 + 16 * i;
             rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pv && c < p.Cg) rx[i] = *reinterpret_cast<const float4*>(p.x + ((int64_t)n * p.Cin_total + chan_phys(p.in_map, g * p.Cg + c)) * HW + pp);
+            const int64_t xoff = ((int64_t)n * p.Cin_total + chan_phys(p.in_map, g * p.Cg + c)) * HW + pp;
+            if (XMODE == MN_ACTQ_SIGN8) {       // int8 sign codes: one dword = the 4 pixels, kept as raw bits in rx[i].x
+                if (pv && c < p.Cg) rx[i].x = mn_u2f(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.x) + xoff));
+            } else if (pv && c < p.Cg) rx[i] = *reinterpret_cast<const float4*>(p.x + xoff);
         }
     };
     auto commit = [&]() {
@@ -355,6 +370,12 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
         }
 #pragma unroll
         for (int i = 0; i < RC; ++i) {
+            if (XMODE == MN_ACTQ_SIGN8) {
+                const unsigned u = mn_f2u(rx[i].x);
+                *reinterpret_cast<u32x2*>(xq + (r0 + 16 * i) * WG_LDP + qd * 4) =
+                    u32x2{0x3F803F80u | ((u & 0x80u) << 8) | ((u & 0x8000u) << 16), 0x3F803F80u | ((u & 0x800000u) >> 8) | (u & 0x80000000u)};
+                continue;
+            }
             const float c0 = act_code<XMODE>(rx[i].x, p.pro, sc, zp), c1 = act_code<XMODE>(rx[i].y, p.pro, sc, zp);
             const float c2 = act_code<XMODE>(rx[i].z, p.pro, sc, zp), c3 = act_code<XMODE>(rx[i].w, p.pro, sc, zp);
             *reinterpret_cast<u32x2*>(xq + (r0 + 16 * i) * WG_LDP + qd * 4) = u32x2{mn_pack_bf16x2(c0, c1), mn_pack_bf16x2(c2, c3)};
@@ -613,6 +634,7 @@ template <int NT>
 static void launch_pw(const PwPlan& pl, int xmode, hipStream_t s) {
     if (xmode == MN_ACTQ_DOREFA) hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_DOREFA>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
     else if (xmode == MN_ACTQ_IAO) hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_IAO>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    else if (xmode == MN_ACTQ_SIGN8) hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_SIGN8>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
     else hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
 }
 static int run_pw(PwPlan& pl, int xmode, hipStream_t s, const char* what) {
@@ -657,6 +679,7 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     Pro ste;
     int rc = make_pro(aq, &ste, 1, "mn_conv2d_bwd_data(qgemm)");
     if (rc) return rc;
+    if (ste.mode == MN_ACTQ_SIGN8) ste.mode = MN_ACTQ_NONE;      // the clip-STE of the sign lives in mn_bnsign_bwd
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
     fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
     qg_launch_pack(pl.pk, pl.pack_grid, s);
@@ -675,6 +698,9 @@ static void launch_wg(const WgPlan& pl, int xmode, hipStream_t s) {
     } else if (xmode == MN_ACTQ_IAO) {
         raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_IAO>, pl.lds);
         hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_IAO>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else if (xmode == MN_ACTQ_SIGN8) {
+        raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_SIGN8>, pl.lds);
+        hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_SIGN8>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
     } else {
         raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_NONE>, pl.lds);
         hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);

@@ -135,12 +135,12 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
                 const int ir = row0 + prow, n = n0 + (int)slot;
                 if (ir < 0 || ir >= p.Hin || n >= p.N) continue;
                 const int c0 = ck * p.CC + o8 * 8;
-                const float* src = p.in + (int64_t)n * p.Cin_total * plane + (int64_t)ir * p.Win + iq * 4;
+                const int64_t soff = (int64_t)n * p.Cin_total * plane + (int64_t)ir * p.Win + iq * 4;
                 float v[8][4];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c0 + jj < p.Kc) f = *reinterpret_cast<const float4*>(src + (int64_t)chan_phys(p.in_map, g * p.Kc + c0 + jj) * plane);
+                    if (c0 + jj < p.Kc) f = mn_ld_x4<XMODE>(p.in, soff + (int64_t)chan_phys(p.in_map, g * p.Kc + c0 + jj) * plane);
                     v[jj][0] = f.x; v[jj][1] = f.y; v[jj][2] = f.z; v[jj][3] = f.w;
                 }
                 if (XMODE == MN_ACTQ_NONE && p.kscale) {
@@ -382,6 +382,7 @@ static void launch_kk(const KkPlan& pl, hipStream_t s) {
     if (pl.planes == 3) launch_kk1<NT, MN_ACTQ_NONE, 3>(pl, s);
     else if (pl.xmode == MN_ACTQ_DOREFA) launch_kk1<NT, MN_ACTQ_DOREFA, 1>(pl, s);
     else if (pl.xmode == MN_ACTQ_IAO) launch_kk1<NT, MN_ACTQ_IAO, 1>(pl, s);
+    else if (pl.xmode == MN_ACTQ_SIGN8) launch_kk1<NT, MN_ACTQ_SIGN8, 1>(pl, s);
     else launch_kk1<NT, MN_ACTQ_NONE, 1>(pl, s);
 }
 static int run_kk(const KkPlan& pl, hipStream_t s, const char* what) {
@@ -423,6 +424,7 @@ int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     Pro ste;
     int rc = make_pro(aq, &ste, 1, "mn_conv2d_bwd_data(qgemm)");
     if (rc) return rc;
+    if (ste.mode == MN_ACTQ_SIGN8) ste.mode = MN_ACTQ_NONE;      // the clip-STE of the sign lives in mn_bnsign_bwd
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
     fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
     qg_launch_pack(pl.pk, pl.pack_grid, s);
@@ -496,9 +498,9 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
     const int ccv = (p.Cg - cb * KW_CC) < KW_CC ? (p.Cg - cb * KW_CC) : KW_CC;
     const int nitem = ccv * p.NI * p.PR * p.EQ;
 
-    struct XItem { int dst, ic0; const float* src; };      // dst < 0: no item; src == nullptr: zero padding
+    struct XItem { int dst, ic0; int64_t src; };      // dst < 0: no item; src < 0: zero padding; else element offset into x
     auto x_item = [&](int it, int n0, int row0) {
-        XItem r; r.dst = -1; r.ic0 = 0; r.src = nullptr;
+        XItem r; r.dst = -1; r.ic0 = 0; r.src = -1;
         if (it < nitem) {
             const uint32_t t1 = fd_div(it, p.fd_eq);
             const int eq = it - t1 * p.EQ;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
             r.dst = cl * p.XCS + (slot * p.PR + prow) * p.Wo;
             r.ic0 = ic0;
             if (n < p.N && ir >= 0 && ir < p.H && ic0 >= 0 && ic0 + 3 < p.W)
-                r.src = p.x + ((int64_t)n * p.C + chan_phys(p.in_map, g * p.Cg + c)) * xplane + (int64_t)ir * p.W + ic0;
+                r.src = ((int64_t)n * p.C + chan_phys(p.in_map, g * p.Cg + c)) * xplane + (int64_t)ir * p.W + ic0;
         }
         return r;
     };
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
         for (int u = 0; u < KW_XPF; ++u) {
             const XItem xi = x_item(tid + u * 256, n0, row0);
             rx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xi.src) rx[u] = *reinterpret_cast<const float4*>(xi.src);
+            if (xi.src >= 0) rx[u] = mn_ld_x4<XMODE>(p.x, xi.src);
         }
     };
     auto commit = [&](int pt, int par) {   // registers -> LDS
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
         for (int u = 0; u < KW_XPF; ++u) x_scatter(x_item(tid + u * 256, n0, row0), rx[u], 0);
         for (int it = tid + KW_XPF * 256; it < nitem; it += 256) {      // patches larger than the prefetch window
             const XItem xi = x_item(it, n0, row0);
-            x_scatter(xi, xi.src ? *reinterpret_cast<const float4*>(xi.src) : make_float4(0.f, 0.f, 0.f, 0.f), 0);
+            x_scatter(xi, xi.src >= 0 ? mn_ld_x4<XMODE>(p.x, xi.src) : make_float4(0.f, 0.f, 0.f, 0.f), 0);
         }
         if (XMODE == MN_ACTQ_NONE && inx) xflag[par] = 1;
     };
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
         tile_origin(pt, n0, oh0, row0);
         for (int it = tid; it < nitem; it += 256) {
             const XItem xi = x_item(it, n0, row0);
-            x_scatter(xi, xi.src ? *reinterpret_cast<const float4*>(xi.src) : make_float4(0.f, 0.f, 0.f, 0.f), term);
+            x_scatter(xi, xi.src >= 0 ? mn_ld_x4<XMODE>(p.x, xi.src) : make_float4(0.f, 0.f, 0.f, 0.f), term);
         }
     };
     auto contract = [&]() {
@@ -745,6 +747,9 @@ static void launch_kw(const KwPlan& pl, int xmode, hipStream_t s) {
     } else if (xmode == MN_ACTQ_IAO) {
         raise_lds_limit((const void*)k_kk_wgrad<MT, NTL, MN_ACTQ_IAO>, pl.lds);
         hipLaunchKernelGGL((k_kk_wgrad<MT, NTL, MN_ACTQ_IAO>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else if (xmode == MN_ACTQ_SIGN8) {
+        raise_lds_limit((const void*)k_kk_wgrad<MT, NTL, MN_ACTQ_SIGN8>, pl.lds);
+        hipLaunchKernelGGL((k_kk_wgrad<MT, NTL, MN_ACTQ_SIGN8>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
     } else {
         raise_lds_limit((const void*)k_kk_wgrad<MT, NTL, MN_ACTQ_NONE>, pl.lds);
         hipLaunchKernelGGL((k_kk_wgrad<MT, NTL, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);

@@ -22,8 +22,9 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import ActQ, ConvGeom, MicronetHipError, WQ
+from .sign_tensor import SignTensor
 
-ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO
+ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO, ACTQ_SIGN8 = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO, _lib.MN_ACTQ_SIGN8
 WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _lib.MN_WQ_DOREFA, _lib.MN_WQ_IAO
 
 # algorithm used by the conv entry points; tests flip it to compare kernels (0 auto, 1 direct VALU, 2 fp32-MFMA only, 3 code-domain bf16-MFMA only)
@@ -320,18 +321,18 @@ class BNSign(Function):
     BatchNorm backward.  The normalised tensor is never materialised (it is recomputed from y in the backward)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, packed=False):
         y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
         N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
-        a = torch.empty_like(y)
+        a = torch.empty(y.shape, dtype=torch.int8 if packed else torch.float32, device=y.device)
         save = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
         with torch.cuda.device_of(y):
-            _call("mn_bnsign_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training),
-                  _p(running_mean), _p(running_var), _p(save), _p(a), _p(ws), _s())
+            _call("mn_bnsign_fwd_i8" if packed else "mn_bnsign_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum),
+                  int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(ws), _s())
         ctx.save_for_backward(y, gamma, beta, save)
         ctx.training = int(training)
-        return a
+        return SignTensor(a) if packed else a
 
     @staticmethod
     def backward(ctx, da):
@@ -344,7 +345,54 @@ class BNSign(Function):
         with torch.cuda.device_of(y):
             _call("mn_bnsign_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, ctx.training, _p(dy), _p(dgamma), _p(dbeta),
                   _p(ws), _s())
-        return dy, dgamma, dbeta, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None
+
+
+class SignToFloat(Function):
+    """SignTensor -> the float32 +-1 tensor, with an identity backward (for consumers our kernels do not cover)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        return a.codes.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def sign_to_float(a):
+    return SignToFloat.apply(a) if isinstance(a, SignTensor) else a
+
+
+def sign_pool_supported(a, kernel_size, stride, padding, dilation, ceil_mode):
+    two = lambda v: v in (2, (2, 2), [2, 2])
+    return (isinstance(a, SignTensor) and a.dim() == 4 and two(kernel_size) and two(stride) and padding in (0, (0, 0)) and
+            dilation in (1, (1, 1)) and not ceil_mode and a.shape[2] % 2 == 0 and a.shape[3] % 8 == 0)
+
+
+class SignMaxPool2x2(Function):
+    """nn.MaxPool2d(2, 2) on packed sign activations (models/nin_gc.py:88,119): int8 in, int8 out; the backward routes each
+    output gradient to the first maximum of its window, as ATen's max_pool2d does."""
+
+    @staticmethod
+    def forward(ctx, a):
+        codes = a.codes
+        N, Cc, H, W = codes.shape
+        out = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.int8, device=codes.device)
+        with torch.cuda.device_of(codes):
+            _call("mn_maxpool2x2_sign8_fwd", _p(codes), N * Cc, H, W, _p(out), _s())
+        ctx.save_for_backward(codes)
+        return SignTensor(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        (codes,) = ctx.saved_tensors
+        g = _chk(g, "grad")
+        N, Cc, H, W = codes.shape
+        din = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+        with torch.cuda.device_of(codes):
+            _call("mn_maxpool2x2_sign8_bwd", _p(g), _p(codes), N * Cc, H, W, _p(din), _s())
+        return din
 
 
 # ------------------------------------------------------------------------------------------------ convolution
@@ -390,7 +438,13 @@ class QConv2d(Function):
 
     @staticmethod
     def forward(ctx, x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc, aq_flags, in_shuffle=0):
-        x, wq, bias = _chk(x, "input"), _chk(wq, "weight"), _chk(bias, "bias")
+        if isinstance(x, SignTensor):       # packed +-1 activations: the kernels read the int8 codes (MN_ACTQ_SIGN8)
+            if aq_mode != ACTQ_NONE:
+                raise MicronetHipError("a SignTensor input cannot be combined with a fused activation quantizer")
+            x, aq_mode = x.codes, ACTQ_SIGN8
+        else:
+            x = _chk(x, "input")
+        wq, bias = _chk(wq, "weight"), _chk(bias, "bias")
         if x.dim() != 4 or wq.dim() != 4 or x.shape[1] != wq.shape[1] * groups:
             raise MicronetHipError("conv2d shape mismatch: input %s weight %s groups %d" % (tuple(x.shape), tuple(wq.shape), groups))
         g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle)
@@ -417,9 +471,9 @@ class QConv2d(Function):
         dx = dw = db = None
         with torch.cuda.device_of(x):
             if ctx.needs_input_grad[0]:
-                dx = torch.empty_like(x)
+                dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
                 ws, nb = _ws(g, 1, x.device)
-                with _span(g, 1, 4 * (gy.numel() + dx.numel() + wq.numel() + (x.numel() if aq_mode != ACTQ_NONE else 0))):
+                with _span(g, 1, 4 * (gy.numel() + dx.numel() + wq.numel() + (x.numel() if aq_mode not in (ACTQ_NONE, ACTQ_SIGN8) else 0))):
                     _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), _ref(wd), _p(gy), _p(wq), _p(x), _p(dx), _p(ws), nb, CONV_ALGO, _s())
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(wq)
@@ -440,15 +494,18 @@ def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ
             wdesc=None, x_is_code=False, in_shuffle=0):
     """``in_shuffle`` > 1: the convolution of ``channel_shuffle(x, in_shuffle)``; the permutation is folded into the kernels'
     channel addressing when the code-domain kernels cover all three passes, else materialised."""
-    if in_shuffle and in_shuffle > 1:
-        g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle)
-        aq = ActQ(aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
+    packed = isinstance(x, SignTensor)
+    if packed or (in_shuffle and in_shuffle > 1):
+        g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle or 0)
+        aq = ActQ(ACTQ_SIGN8 if packed else aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
         wd = _wq_desc(wdesc)
         lib = _lib_()
         ok = CONV_ALGO in (_lib.MN_ALGO_AUTO, _lib.MN_ALGO_QGEMM) and all(
             lib.mn_conv2d_qgemm_supported(C.byref(g), C.byref(aq), _ref(wd), k) for k in range(3))
-        if not ok:
-            x, in_shuffle = channel_shuffle(x, in_shuffle), 0
+        if not ok:                          # kernels that read neither int8 codes nor shuffled channels: hand them the plain tensor
+            x = sign_to_float(x)
+            if in_shuffle and in_shuffle > 1:
+                x, in_shuffle = channel_shuffle(x, in_shuffle), 0
     return QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc,
                          _lib.MN_ACTQ_X_IS_CODE if x_is_code else 0, in_shuffle or 0)
 

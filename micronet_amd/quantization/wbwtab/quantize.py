@@ -15,9 +15,11 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from micronet_amd import ops
+from micronet_amd.sign_tensor import SignTensor
 
 __all__ = ["BinaryActivation", "BinaryWeight", "Ternary", "ActivationQuantizer", "meancenter_clamp_convparams",
-           "WeightQuantizer", "QuantConv2d", "QuantConvTranspose2d", "BatchNorm2dBinAct", "add_quant_op", "prepare"]
+           "WeightQuantizer", "QuantConv2d", "QuantConvTranspose2d", "BatchNorm2dBinAct", "MaxPool2dSign", "SignTensor",
+           "add_quant_op", "prepare"]
 
 
 class BinaryActivation(Function):
@@ -70,7 +72,7 @@ class ActivationQuantizer(nn.Module):
         return BinaryActivation.apply(input)
 
     def forward(self, input):
-        if self.A == 2 and getattr(input, "_mn_binarized", False):
+        if self.A == 2 and (isinstance(input, SignTensor) or getattr(input, "_mn_binarized", False)):
             return input              # the BatchNorm2dBinAct in front already produced sign(bn(x)) in its fused kernel
         return self.binary(input) if self.A == 2 else self.relu(input)
 
@@ -80,7 +82,13 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
     ``ActivationQuantizer``: on the GPU it computes ``sign(bn(x))`` in ONE fused op -- the normalised tensor is never written,
     the backward recomputes it -- and tags the result so that the ``ActivationQuantizer`` passes it through.  ``prepare()``
     installs it only where the module order guarantees that hand-off (``nn.Sequential`` parents and the reference's
-    ``ConvBNReLU`` blocks, models/nin_gc.py:53-59); everywhere else the plain modules run."""
+    ``ConvBNReLU`` blocks, models/nin_gc.py:53-59); everywhere else the plain modules run.
+
+    ``packed`` (set by ``prepare(packed_activations=True)``, the default): the result is a ``SignTensor`` -- logically the
+    same float32 +-1 tensor, physically one byte per element, read directly by the next QuantConv2d / MaxPool2dSign; any
+    other consumer sees the float32 values (micronet_amd/sign_tensor.py)."""
+
+    packed = False
 
     def forward(self, input):
         hw = input.shape[2] * input.shape[3] if input.dim() == 4 else 0
@@ -93,9 +101,20 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
             if self.momentum is None:
                 momentum = 1.0 / float(self.num_batches_tracked)
         out = ops.BNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                               self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
-        out._mn_binarized = True
+                               self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, bool(self.packed))
+        if not self.packed:
+            out._mn_binarized = True
         return out
+
+
+class MaxPool2dSign(nn.MaxPool2d):
+    """``nn.MaxPool2d`` that pools packed sign activations in their int8 form (2x2 / stride 2); anything else takes the
+    stock path (a SignTensor is materialised as float32 on the way)."""
+
+    def forward(self, input):
+        if not self.return_indices and ops.sign_pool_supported(input, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode):
+            return ops.SignMaxPool2x2.apply(input)
+        return super().forward(input)
 
 
 def meancenter_clamp_convparams(w):
@@ -158,7 +177,8 @@ def _ordered_parent(module):
     return isinstance(module, nn.Sequential) or type(module).__name__ == "ConvBNReLU"
 
 
-def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True):
+def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True,
+                 packed_activations=True):
     """Quantise conv k iff 1 < k < layer_num; every ReLU met while 0 < k < layer_num becomes the binary activation
     (ref 247-331).  With ``fuse_bn_act`` a plain BatchNorm2d directly in front of such a binary activation is switched to
     ``BatchNorm2dBinAct`` (same object, same state: only its class changes)."""
@@ -197,18 +217,24 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                 module._modules[name] = ActivationQuantizer(A=A)
                 if fuse_bn_act and A == 2 and type(prev) is nn.BatchNorm2d and prev.affine and _ordered_parent(module):
                     prev.__class__ = BatchNorm2dBinAct
+                    prev.packed = bool(packed_activations)
+        elif type(child) is nn.MaxPool2d and packed_activations and A == 2:
+            child.__class__ = MaxPool2dSign       # same object and state; pools SignTensors without unpacking them
         else:
             add_quant_op(child, layer_counter, layer_num, A=A, W=W, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act,
-                         fold_shuffle=fold_shuffle)
+                         fold_shuffle=fold_shuffle, packed_activations=packed_activations)
         prev = child
 
 
-def prepare(model, inplace=False, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True):
+def prepare(model, inplace=False, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True, packed_activations=True):
     """Same rewrite as the reference (ref 334-347); ``fuse_bn_act`` (ours, default on) additionally fuses BatchNorm2d with
     the binary activation that follows it (see ``BatchNorm2dBinAct``), and ``fold_shuffle`` (ours, default on) moves the
-    channel shuffle of a ``ConvBNReLU`` block into its quantised conv's addressing -- numerically the same function."""
+    channel shuffle of a ``ConvBNReLU`` block into its quantised conv's addressing -- numerically the same function;
+    ``packed_activations`` (ours, default on) lets the fused BN+sign hand its +-1 output to the next conv / max-pool as one
+    byte per element (``SignTensor``), float32 for everybody else."""
     if not inplace:
         model = copy.deepcopy(model)
     layer_num = sum(isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) for m in model.modules())
-    add_quant_op(model, [0], layer_num, A=A, W=W, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act, fold_shuffle=fold_shuffle)
+    add_quant_op(model, [0], layer_num, A=A, W=W, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act, fold_shuffle=fold_shuffle,
+                 packed_activations=packed_activations)
     return model

@@ -1,0 +1,61 @@
+"""Packed binary activations.
+
+In the reference's W/A-binary nets (wbwtab) every tensor between ``BinaryActivation`` and the next convolution holds only
++-1 (wbwtab/quantize.py:13-19), yet travels as fp32: 4 bytes per element written by the activation and read again by the
+convolution's forward and by its backward-weight.  ``SignTensor`` is that tensor with a one-byte physical representation:
+
+  * logically a float32 NCHW tensor (shape / dtype / device / autograd behave as such),
+  * physically an int8 tensor of codes in {-1, +1} (``.codes``) produced by ``mn_bnsign_fwd_i8`` and consumed directly by
+    the code-domain conv kernels (``MN_ACTQ_SIGN8``) and by the sign max-pool -- a quarter of the HBM traffic.
+
+It is a wrapper subclass: operators of this package read ``.codes`` and never touch fp32; ANY other torch operator
+that receives a SignTensor (a hook, a plain ``nn.Conv2d`` such as the un-quantised last layer, ``.cpu()`` ...) goes through
+``__torch_dispatch__``, which materialises the float32 values first -- so foreign consumers see exactly the tensor the
+reference produces, gradients included.  Safe by construction; fast only between our own modules.
+"""
+import torch
+from torch.utils._pytree import tree_map
+
+_ALIAS_OPS = None
+
+
+def _alias_ops():
+    global _ALIAS_OPS
+    if _ALIAS_OPS is None:
+        a = torch.ops.aten
+        _ALIAS_OPS = {a.detach.default, a.alias.default}
+    return _ALIAS_OPS
+
+
+class SignTensor(torch.Tensor):
+    @staticmethod
+    def __new__(cls, codes):
+        if codes.dtype != torch.int8 or not codes.is_contiguous():
+            raise TypeError("SignTensor wraps a contiguous int8 tensor of +-1 codes")
+        r = torch.Tensor._make_wrapper_subclass(cls, codes.shape, dtype=torch.float32, device=codes.device, requires_grad=False)
+        r._mn_codes = codes
+        return r
+
+    def __init__(self, codes):
+        pass
+
+    @property
+    def codes(self):
+        return self._mn_codes
+
+    def to_float(self):
+        """The float32 tensor the reference holds at this point (no autograd link; use ops.sign_to_float for one)."""
+        return self._mn_codes.to(torch.float32)
+
+    def __repr__(self):
+        return "SignTensor(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], SignTensor):
+            return SignTensor(args[0]._mn_codes)
+        un = lambda t: t._mn_codes.to(torch.float32) if isinstance(t, SignTensor) else t
+        return func(*tree_map(un, args), **tree_map(un, kwargs))

@@ -44,6 +44,17 @@ class Backend:
             return a.copy()
         return self.torch.from_numpy(a.copy()).cuda()
 
+    def to_dev_i8(self, a):
+        a = np.ascontiguousarray(a, dtype=np.int8)
+        if self.kind == "emu":
+            return a.copy()
+        return self.torch.from_numpy(a.copy()).cuda()
+
+    def empty_i8(self, shape):
+        if self.kind == "emu":
+            return np.full(shape, 77, dtype=np.int8)   # poison
+        return self.torch.full(tuple(shape), 77, dtype=self.torch.int8, device="cuda")
+
     def empty(self, shape):
         if self.kind == "emu":
             return np.full(shape, np.float32(-1234.5), dtype=np.float32)   # poison

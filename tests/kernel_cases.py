@@ -202,10 +202,14 @@ def make_coded_weights(r, w_shape, wmode, wbits=8):
 
 
 def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, bias=True, mode=0, bits=8, q_type=0,
-               algos=(1, 2), seed=0, binary_x=False, expect_mfma=None, rel=1e-5, wmode=0, wbits=8, expect_qgemm=None, in_shuffle=0):
+               algos=(1, 2), seed=0, binary_x=False, expect_mfma=None, rel=1e-5, wmode=0, wbits=8, expect_qgemm=None, in_shuffle=0,
+               sign8=False):
     """fwd / bwd_data / bwd_weight of one geometry on every requested algo vs numpy fp64 on the same fp32 operands.
-    wmode != 0: the weights are fake-quantised (ternary / dorefa / iao) and algo 3 (code-domain bf16 MFMA) is exercised."""
+    wmode != 0: the weights are fake-quantised (ternary / dorefa / iao) and algo 3 (code-domain bf16 MFMA) is exercised.
+    sign8: the +-1 activations are handed over as int8 codes (MN_ACTQ_SIGN8, the packed output of mn_bnsign_fwd_i8)."""
     r = np.random.default_rng(seed)
+    if sign8:
+        binary_x, mode = True, 0
     x = (np.where(r.standard_normal(x_shape) > 0, 1.0, -1.0) if binary_x else r.standard_normal(x_shape) * 4).astype(F)
     wq = None
     if wmode:
@@ -237,9 +241,9 @@ def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, 
     if in_shuffle > 1:          # gradient w.r.t. the physical tensor = inverse shuffle of the logical gradient
         n_, c_, h_, w_ = x.shape
         dx_ref = np.ascontiguousarray(dx_ref.reshape(n_, c_ // in_shuffle, in_shuffle, h_, w_).transpose(0, 2, 1, 3, 4).reshape(x.shape))
-    dX, dW, dB, dG = be.to_dev(x_phys), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(gy)
+    dX, dW, dB, dG = (be.to_dev_i8(x_phys) if sign8 else be.to_dev(x_phys)), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(gy)
     dqp = be.to_dev(qp) if qp is not None else None
-    aq = be.actq(mode, bits, q_type, dqp, flags=1 if (binary_x and mode == 0) else 0)
+    aq = be.actq(3 if sign8 else mode, bits, q_type, dqp, flags=1 if (binary_x and mode == 0) else 0)
     sup = [bool(be.lib.mn_conv2d_mfma_supported(C.byref(g), k)) for k in range(3)]
     supq = [bool(be.lib.mn_conv2d_qgemm_supported(C.byref(g), C.byref(aq), C.byref(wq) if wq is not None else None, k)) for k in range(3)]
     if expect_mfma is not None:
@@ -381,7 +385,11 @@ def check_bnsign(be, shape=(6, 5, 4, 8), seed=0, training=True):
             be.ptr(save), be.ptr(a), be.ptr(ws), be.stream)
     be.call("mn_bnsign_bwd", be.ptr(dDA), be.ptr(dY), be.ptr(save), be.ptr(dG), be.ptr(dB), N, Cc, HW, int(training), be.ptr(dy),
             be.ptr(dgam), be.ptr(dbet), be.ptr(ws), be.stream)
+    a8 = be.empty_i8(shape)                      # the packed (int8) output must hold the same signs
+    be.call("mn_bnsign_fwd_i8", be.ptr(dY), N, Cc, HW, be.ptr(dG), be.ptr(dB), eps, 0.0, int(training), be.ptr(dRM), be.ptr(dRV),
+            be.ptr(be.empty((2, Cc))), be.ptr(a8), be.ptr(ws), be.stream)
     a_got = be.to_host(a)
+    assert np.array_equal(be.to_host(a8).astype(F), a_got)
     safe = np.abs(z) > 1e-5                      # away from the sign tie
     assert np.array_equal(a_got[safe], a_ref[safe]) and np.all(np.abs(a_got) == 1.0)
     sv = be.to_host(save)
@@ -395,3 +403,21 @@ def check_bnsign(be, shape=(6, 5, 4, 8), seed=0, training=True):
     tol = 1e-3 if edge else 1e-5
     assert close(be.to_host(dbet), dbeta_ref, tol) and close(be.to_host(dgam), dgamma_ref, tol)
     assert close(be.to_host(dy), dy_ref, tol)
+
+
+def check_pool_sign8(be, shape=(3, 5, 8, 16), seed=0):
+    """mn_maxpool2x2_sign8_fwd/bwd vs torch CPU max_pool2d (forward values and the gradient routing to the first maximum)."""
+    import torch
+    r = np.random.default_rng(seed)
+    a = np.where(r.standard_normal(shape) > 0.3, 1, -1).astype(np.int8)       # mostly -1: windows with 0, 1, several +1
+    N, Cc, H, W = shape
+    t = torch.from_numpy(a.astype(F)).requires_grad_(True)
+    out = torch.nn.functional.max_pool2d(t, 2, 2)
+    g = r.standard_normal(tuple(out.shape)).astype(F)
+    out.backward(torch.from_numpy(g))
+    dA, dG = be.to_dev_i8(a), be.to_dev(g)
+    o8, din = be.empty_i8((N, Cc, H // 2, W // 2)), be.empty(shape)
+    be.call("mn_maxpool2x2_sign8_fwd", be.ptr(dA), N * Cc, H, W, be.ptr(o8), be.stream)
+    be.call("mn_maxpool2x2_sign8_bwd", be.ptr(dG), be.ptr(dA), N * Cc, H, W, be.ptr(din), be.stream)
+    assert np.array_equal(be.to_host(o8).astype(F), out.detach().numpy())
+    assert np.array_equal(be.to_host(din), t.grad.numpy())

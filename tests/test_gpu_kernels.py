@@ -227,3 +227,32 @@ def test_qgemm_pointwise_in_shuffle(be, case, sg):
 @pytest.mark.parametrize("case,sg", [(0, 2), (0, 8), (4, 5)])
 def test_qgemm_kxk_in_shuffle(be, case, sg):
     K.check_conv(be, seed=97 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=True, in_shuffle=sg, **K.QGEMM_KXK_CASES[case])
+
+
+# ---- packed (int8) sign activations
+@pytest.mark.parametrize("case", range(len(K.QGEMM_PW_CASES)))
+def test_qgemm_pointwise_sign8(be, case):
+    K.check_conv(be, seed=140 + case, wmode=1, sign8=True, algos=(3, 0), expect_qgemm=True, **K.QGEMM_PW_CASES[case])
+
+
+@pytest.mark.parametrize("case", [0, 1, 3, 4])
+def test_qgemm_kxk_sign8(be, case):
+    K.check_conv(be, seed=150 + case, wmode=1, sign8=True, algos=(3,), expect_qgemm=True, **K.QGEMM_KXK_CASES[case])
+
+
+def test_qgemm_sign8_shuffle(be):
+    K.check_conv(be, seed=160, wmode=1, sign8=True, algos=(3,), in_shuffle=2, **K.QGEMM_PW_CASES[1])
+    K.check_conv(be, seed=161, wmode=1, sign8=True, algos=(3,), in_shuffle=2, **K.QGEMM_KXK_CASES[0])
+
+
+@pytest.mark.parametrize("name,kw", [(n, kw) for n, kw in QGEMM_HOT if "nin_gc" in n], ids=[n for n, _ in QGEMM_HOT if "nin_gc" in n])
+def test_qgemm_hot_shapes_sign8(be, name, kw):
+    if kw["w_shape"][1] * kw.get("groups", 1) == 3:
+        pytest.skip("first layer reads the image, not sign codes")
+    K.check_conv(be, seed=181, wmode=1, sign8=True, algos=(3,), expect_qgemm=True, **kw)
+
+
+def test_pool_sign8(be):
+    K.check_pool_sign8(be)
+    K.check_pool_sign8(be, shape=(2, 3, 2, 8), seed=1)
+    K.check_pool_sign8(be, shape=(16, 64, 32, 32), seed=2)

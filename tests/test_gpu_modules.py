@@ -269,3 +269,42 @@ def test_wbwtab_folded_channel_shuffle_is_bit_identical():
             assert torch.equal(pa.grad, pb.grad), n_
         else:                                  # plain nn.Conv2d layers run MIOpen's (atomic) backward-weight: equal to rounding
             assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 1e-5, n_
+
+
+def test_wbwtab_packed_activations_are_bit_identical():
+    """prepare(packed_activations=True): the fused BN+sign hands its +-1 output to the next conv / max-pool as int8
+    (SignTensor).  Same codes, same products, same summation order: logits, running statistics and every gradient must be
+    bit-identical to the float32 hand-off; a foreign consumer (forward hook, the plain last conv) sees the float32 values."""
+    from micronet_amd.models.nin_gc import ConvBNReLU
+    from micronet_amd.sign_tensor import SignTensor
+    w = _q("wbwtab")
+
+    def net():
+        torch.manual_seed(7)
+        return nn.Sequential(ConvBNReLU(3, 32, 5, padding=2), ConvBNReLU(32, 32, 1, groups=2),
+                             ConvBNReLU(32, 64, 1, groups=2, channel_shuffle=1, shuffle_groups=2), nn.MaxPool2d(2, 2),
+                             ConvBNReLU(64, 64, 3, padding=1, groups=4, channel_shuffle=1, shuffle_groups=2),
+                             ConvBNReLU(64, 64, 1, groups=2, channel_shuffle=1, shuffle_groups=4), nn.MaxPool2d(2, 2),
+                             ConvBNReLU(64, 10, 1), nn.AvgPool2d(4)).cuda().train()
+    a = w.prepare(net(), inplace=True, A=2, W=3, packed_activations=True)
+    b = w.prepare(net(), inplace=True, A=2, W=3, packed_activations=False)
+    assert type(a[3]).__name__ == "MaxPool2dSign" and type(b[3]) is nn.MaxPool2d
+    seen = {}
+    a[1].register_forward_hook(lambda m, i, o: seen.__setitem__("a", (type(i[0]), type(o), o.detach().float().clone())))
+    b[1].register_forward_hook(lambda m, i, o: seen.__setitem__("b", o.detach().clone()))
+    x = torch.randn(8, 3, 16, 16, device="cuda")
+    ya, yb = a(x), b(x)
+    assert seen["a"][0] is SignTensor and seen["a"][1] is SignTensor           # the packed hand-off really happened
+    assert torch.equal(seen["a"][2], seen["b"]) and torch.all(seen["b"].abs() == 1)
+    assert type(ya) is torch.Tensor and torch.equal(ya, yb)
+    ya.square().mean().backward()
+    yb.square().mean().backward()
+    for (n_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if n_.startswith(("0.conv", "5.conv")):    # plain nn.Conv2d layers run MIOpen's (atomic) backward-weight: equal to rounding
+            assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 1e-5, n_
+        else:
+            assert torch.equal(pa.grad, pb.grad), n_
+    for (n_, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(ba, bb), n_
+    a.eval(), b.eval()
+    assert torch.equal(a(x), b(x))

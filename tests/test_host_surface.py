@@ -85,3 +85,50 @@ def test_abi_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     lib = _lib.Lib(_lib.LIB_PATH)           # AttributeError if a symbol is missing
     assert lib.mn_version() >= 100 and lib.mn_is_emulation() == 0
+
+
+def test_sign_tensor_is_a_float_tensor_to_everyone_else():
+    """SignTensor: logically float32 +-1, physically int8.  Foreign operators see the float values and gradients flow through
+    them; our Functions get the codes without any dispatch (checked on CPU with toy Functions: no kernel involved)."""
+    from micronet_amd.sign_tensor import SignTensor
+
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, y):
+            ctx.save_for_backward(y)
+            return SignTensor(torch.where(y < 0, -1, 1).to(torch.int8))
+
+        @staticmethod
+        def backward(ctx, da):
+            (y,) = ctx.saved_tensors
+            assert type(da) is torch.Tensor and da.dtype == torch.float32
+            return da * (y.abs() < 1)
+
+    y = torch.randn(4, 6, 2, 8, requires_grad=True)
+    a = Producer.apply(y)
+    assert isinstance(a, SignTensor) and a.dtype == torch.float32 and a.shape == y.shape and a.requires_grad
+    assert a.codes.dtype == torch.int8 and a.detach().codes is a.codes
+    ref = torch.where(y.detach() < 0, -1.0, 1.0)
+    assert torch.equal(a.to_float(), ref)
+    # a foreign consumer (here a stock conv, like the un-quantised last layer of nin_gc) sees float32 and back-propagates
+    w = torch.randn(3, 6, 1, 1, requires_grad=True)
+    out = torch.nn.functional.conv2d(a, w)
+    assert type(out) is torch.Tensor and torch.allclose(out, torch.nn.functional.conv2d(ref, w))
+    out.sum().backward()
+    y2 = y.detach().clone().requires_grad_(True)
+    g_ref = torch.autograd.grad(torch.nn.functional.conv2d(ref.requires_grad_(True), w).sum(), ref)[0] * (y2.abs() < 1)
+    assert torch.allclose(y.grad, g_ref)
+    assert torch.equal(a.cpu().numpy() if False else (a + 0), ref)
+    with pytest.raises(TypeError):
+        SignTensor(torch.zeros(3))
+
+
+def test_wbwtab_prepare_packs_activations_by_default():
+    from micronet.compression.quantization.wbwtab import quantize
+    q = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=3)
+    bns = [m for m in q.modules() if isinstance(m, quantize.BatchNorm2dBinAct)]
+    assert len(bns) == 8 and all(m.packed for m in bns)
+    assert sum(isinstance(m, quantize.MaxPool2dSign) for m in q.modules()) == 2
+    q2 = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=3, packed_activations=False)
+    assert not any(m.packed for m in q2.modules() if isinstance(m, quantize.BatchNorm2dBinAct))
+    assert not any(isinstance(m, quantize.MaxPool2dSign) for m in q2.modules())

@@ -112,3 +112,24 @@ def test_qgemm_pointwise_in_shuffle(be, case, sg):
 @pytest.mark.parametrize("case,sg", [(0, 2), (0, 8), (4, 5)])
 def test_qgemm_kxk_in_shuffle(be, case, sg):
     K.check_conv(be, seed=97 + case, wmode=1, binary_x=True, algos=(3,), expect_qgemm=True, in_shuffle=sg, **K.QGEMM_KXK_CASES[case])
+
+
+# ---- packed (int8) sign activations: MN_ACTQ_SIGN8 input of the code-domain kernels, int8 BN-sign output, sign max-pool
+@pytest.mark.parametrize("case", range(len(K.QGEMM_PW_CASES)))
+def test_qgemm_pointwise_sign8(be, case):
+    K.check_conv(be, seed=140 + case, wmode=1, sign8=True, algos=(3,), expect_qgemm=True, **K.QGEMM_PW_CASES[case])
+
+
+@pytest.mark.parametrize("case", [0, 1, 4])
+def test_qgemm_kxk_sign8(be, case):
+    K.check_conv(be, seed=150 + case, wmode=1, sign8=True, algos=(3,), expect_qgemm=True, **K.QGEMM_KXK_CASES[case])
+
+
+def test_qgemm_sign8_shuffle(be):
+    K.check_conv(be, seed=160, wmode=1, sign8=True, algos=(3,), in_shuffle=2, **K.QGEMM_PW_CASES[1])
+    K.check_conv(be, seed=161, wmode=1, sign8=True, algos=(3,), in_shuffle=2, **K.QGEMM_KXK_CASES[0])
+
+
+def test_pool_sign8(be):
+    K.check_pool_sign8(be)
+    K.check_pool_sign8(be, shape=(2, 3, 2, 8), seed=1)
