@@ -46,50 +46,23 @@ WORKLOAD_DESC = {
 
 
 class KernelProfiler:
-    """Per-kernel timing inside the timed region: the library records two raw HIP events on the launch stream immediately
-    around each conv call's MAIN kernel (mn_profile_next); elapsed times are read after the final synchronize."""
+    """Per-kernel timing with HIP events recorded by the library itself around every main kernel it launches (conv, BN+sign,
+    pool), on the launch stream: mn_profile_enable / mn_profile_collect (include/micronet_hip.h)."""
 
     def __init__(self):
-        import ctypes as C
         from micronet_amd import _lib
-        self.C = C
-        self.hip = C.CDLL("libamdhip64.so")
+        self._lib = _lib
         self.lib = _lib.get_lib()
-        self.spans = []
-        self.enabled = False
 
-    def _event(self):
-        e = self.C.c_void_p()
-        rc = self.hip.hipEventCreate(self.C.byref(e))
-        if rc != 0:
-            raise RuntimeError("hipEventCreate rc=%d" % rc)
-        return e
+    def start(self):
+        self.lib.mn_profile_enable(1)
 
-    def arm(self, which, nbytes):
-        if not self.enabled:
-            return None
-        a, b = self._event(), self._event()
-        self.lib.mn_profile_next(a, b)
-        return (which, nbytes, a, b)
-
-    def done(self, tok, kernel):
-        which, nbytes, a, b = tok
-        self.spans.append((kernel, which, nbytes, a, b))
-
-    def summary(self):
-        agg = {}
-        ms = self.C.c_float()
-        for tag, which, nbytes, a, b in self.spans:
-            if self.hip.hipEventElapsedTime(self.C.byref(ms), a, b) != 0:
-                continue
-            d = agg.setdefault(tag, dict(ms=0.0, bytes=0, launches=0, which=which))
-            d["ms"] += ms.value
-            d["bytes"] += nbytes
-            d["launches"] += 1
-            self.hip.hipEventDestroy(a)
-            self.hip.hipEventDestroy(b)
-        self.spans = []
-        return agg
+    def stop(self):
+        """Call after torch.cuda.synchronize(): {kernel: dict(ms, bytes, launches)}."""
+        buf = (self._lib.ProfEntry * 128)()
+        n = self.lib.mn_profile_collect(buf, 128)
+        self.lib.mn_profile_enable(0)
+        return {buf[i].name.decode(): dict(ms=buf[i].total_ms, bytes=buf[i].bytes, launches=buf[i].launches) for i in range(n)}
 
 
 def build(workload, device):
@@ -131,7 +104,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=16, help="timed CPU steps at --cpu-batch (about 10-15 s of CPU work)")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying captured HIP graphs")
+    ap.add_argument("--kernel-steps", type=int, default=5, help="eager steps of the per-kernel HIP-event timing pass")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads for the CPU baseline; 0 = os.cpu_count(). 16 is the fastest setting measured on the MI355X host "
                          "(2x EPYC 9575F: 97 img/s at 16 threads, 72 at 32, 41 at 64, 24 at 128, 1.1 at 256)")
@@ -155,35 +130,67 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from micronet_amd import dp, ops
-    from micronet_amd.train import synth_batch
+    from micronet_amd import dp
+    from micronet_amd.train import GraphedTrainStep, synth_batch
     model, opt = build(args.workload, device)
     dp.broadcast_parameters(model)
-    sync = dp.GradSync(model)
     x, y = synth_batch(args.batch, seed=1234 + rank, device=device)
-    prof = KernelProfiler()
-    ops.PROFILER = prof
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The step is captured once in HIP graphs and replayed (micronet_amd.train.GraphedTrainStep): the eager step issues ~150
+    # launches through Python and is host-bound.  --no-graph (or a failed capture) runs it eagerly with the bucketed,
+    # backward-overlapped gradient all-reduce of micronet_amd.dp.GradSync.
+    graphed, graph_err, sync = None, None, None
+    if not args.no_graph:
+        try:
+            graphed = GraphedTrainStep(model, opt, x, y)
+        except Exception as e:                      # noqa: BLE001 -- report and measure the eager step instead
+            graph_err = "%s: %s" % (type(e).__name__, str(e)[:200])
+            graphed = None
+            model, opt = build(args.workload, device)
+            dp.broadcast_parameters(model)
+    if graphed is None:
+        sync = dp.GradSync(model)
+
+    def one_step():
+        if graphed is not None:
+            return graphed.step()[0]
+        return dp.train_step_dp(model, opt, sync, x, y)[0]
+
     for _ in range(args.warmup):
-        dp.train_step_dp(model, opt, sync, x, y)
-    prof.enabled = not args.no_kernel_timing
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = dp.train_step_dp(model, opt, sync, x, y)
+        loss = one_step()
     barrier()
     dt = time.perf_counter() - t0
-    prof.enabled = False
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss)
+
+    # per-kernel HIP-event timing: the same step, same process, run eagerly right after the timed region (events cannot be
+    # read back from inside a replayed graph); single-GPU runs only
+    agg = {}
+    if world == 1 and not args.no_kernel_timing:
+        if sync is None:
+            sync = dp.GradSync(model)
+        prof = KernelProfiler()
+        dp.train_step_dp(model, opt, sync, x, y)
+        torch.cuda.synchronize()
+        prof.start()
+        for _ in range(args.kernel_steps):
+            dp.train_step_dp(model, opt, sync, x, y)
+        torch.cuda.synchronize()
+        agg = prof.stop()
+    if graphed is not None:
+        graphed.finish()
 
     if rank == 0:
         imgs = args.batch * world * args.steps
@@ -195,10 +202,12 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_DESC[args.workload], "global_batch": args.batch * world,
                        "per_gpu_batch": args.batch, "parallelism": "dp%d" % world, "optimizer": "Adam lr=0.01",
-                       "final_loss": round(final_loss, 4)},
+                       "hip_graph": graphed is not None, "final_loss": round(final_loss, 4)},
         }
-        agg = prof.summary()
+        if graph_err:
+            out["config"]["hip_graph_error"] = graph_err
         if agg:
+            ks = args.kernel_steps
             dom = max(agg, key=lambda k: agg[k]["ms"])
             d = agg[dom]
             achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
@@ -210,17 +219,18 @@ def main():
                 traffic = json.load(open(tj)).get(dom, {}).get("bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
-                               "avg_launch_us": round(1000.0 * d["ms"] / d["launches"], 2), "launches": d["launches"]}
-            out["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] / args.steps,
+                               "bytes_per_launch": int(d["bytes"] / d["launches"]),
+                               "avg_launch_us": round(1000.0 * d["ms"] / d["launches"], 2), "launches": d["launches"],
+                               "timing": "HIP events on the launch stream around every launch, %d eager steps after the timed region" % ks}
+            out["kernels"] = {k: {"ms_per_step": round(v["ms"] / ks, 4), "launches_per_step": v["launches"] / ks,
                                   "avg_us": round(1000.0 * v["ms"] / v["launches"], 1),
-                                  "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in sorted(agg.items())}
-            if args.workload in ("c1", "c2", "c3", "c1_w2a2"):
-                per_gpu = value / world
-                out["step_level"] = {"algorithmic_GBps": round(per_gpu * NIN_GC_MB_PER_IMG / 1e3, 1),
-                                     "hbm_frac": round(per_gpu * NIN_GC_MB_PER_IMG / 1e3 / HBM_PEAK_GBS, 4),
-                                     "algorithmic_TFLOPs": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3, 2),
-                                     "fp32_mfma_frac": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                                  "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if args.workload in ("c1", "c2", "c3", "c1_w2a2"):
+            per_gpu = value / world
+            out["step_level"] = {"algorithmic_GBps": round(per_gpu * NIN_GC_MB_PER_IMG / 1e3, 1),
+                                 "hbm_frac": round(per_gpu * NIN_GC_MB_PER_IMG / 1e3 / HBM_PEAK_GBS, 4),
+                                 "algorithmic_TFLOPs": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3, 2),
+                                 "fp32_mfma_frac": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)

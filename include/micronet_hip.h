@@ -40,6 +40,18 @@ const char* mn_last_kernel(void);
 /* measurement hook: the next mn_conv2d_* call on this thread records `start_event` / `stop_event` (hipEvent_t, may be NULL)
  * on its stream immediately around its main kernel launch (not around the small weight-pack / partial-reduce helpers). */
 void mn_profile_next(void* start_event, void* stop_event);
+/* library-kept measurement: while enabled (per calling thread), EVERY main kernel launch of the library (conv, BN+sign, pool) is
+ * bracketed by two pooled HIP events on its stream.  mn_profile_collect -- call it once the stream is idle -- aggregates the
+ * recorded spans by kernel name into `out` (at most `cap` entries), clears them and returns the number of entries.
+ * `bytes` = the kernel's designed HBM bytes (each operand read or written once, int8 codes counted as 1 byte). */
+typedef struct mn_prof_entry {
+    char name[96];
+    int64_t launches;
+    double total_ms;
+    double bytes;
+} mn_prof_entry;
+void mn_profile_enable(int on);
+int mn_profile_collect(mn_prof_entry* out, int cap);
 /* 1 if the library was built as the CPU SIMT emulation used by the unit tests, 0 for the gfx950 build */
 int mn_is_emulation(void);
 
@@ -223,6 +235,9 @@ typedef struct mn_adam_tensor {
     float lr, weight_decay;
 } mn_adam_tensor;
 int mn_adam_step(const mn_adam_tensor* tensors, int count, int step, float beta1, float beta2, float eps, mn_stream_t stream);
+/* same update, but the step count (>= 1) is read from DEVICE memory by the kernel: the launch can then be captured in a HIP
+ * graph and replayed while a device-side counter advances (the caller increments *step_dev before the launch). */
+int mn_adam_step_dev(const mn_adam_tensor* tensors, int count, const int32_t* step_dev, float beta1, float beta2, float eps, mn_stream_t stream);
 
 #ifdef __cplusplus
 }

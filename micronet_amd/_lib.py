@@ -33,6 +33,10 @@ class WQ(C.Structure):
                 ("scale", C.c_void_p)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("bytes", C.c_double)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
                 ("lr", C.c_float), ("weight_decay", C.c_float)]
@@ -47,6 +51,8 @@ PROTOTYPES = {
     "mn_last_error": (C.c_char_p, []),
     "mn_last_kernel": (C.c_char_p, []),
     "mn_profile_next": (None, [_P, _P]),
+    "mn_profile_enable": (None, [_I]),
+    "mn_profile_collect": (_I, [C.POINTER(ProfEntry), _I]),
     "mn_is_emulation": (_I, []),
     "mn_round_half_away": (_I, [_P, _P, _L, _P]),
     "mn_dorefa_act_fwd": (_I, [_P, _P, _L, _I, _P]),
@@ -76,6 +82,7 @@ PROTOTYPES = {
     "mn_maxpool2x2_sign8_bwd": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "mn_bnsign_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
+    "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),
     "mn_conv2d_mfma_supported": (_I, [_G, _I]),
     "mn_conv2d_qgemm_supported": (_I, [_G, _A, _W, _I]),

@@ -14,6 +14,7 @@ void mn_set_error(const char* fmt, ...);
 // name of the dominant kernel the last conv entry point launched on this thread (read back by mn_last_kernel())
 void mn_set_last_kernel(const char* fmt, ...);
 // optional HIP-event bracket around the MAIN kernel of the next conv entry point (armed by mn_profile_next)
+void mn_prof_bytes(double nbytes);     // designed HBM bytes of the main kernel about to be launched (read + written once)
 void mn_prof_begin(hipStream_t s);
 void mn_prof_end(hipStream_t s);
 #define MN_FAIL(code, ...)        \

@@ -697,6 +697,11 @@ extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_
     Pro pro;
     if ((rc = make_pro(aq, &pro, 0, "mn_conv2d_fwd"))) return rc;
     hipStream_t s = (hipStream_t)stream;
+    {
+        const double nx = (double)g->N * g->C * g->H * g->W, nw = (double)g->O * (g->C / g->groups) * g->KH * g->KW;
+        const double ny = (double)g->N * g->O * out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h) * out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+        mn_prof_bytes((pro.mode == MN_ACTQ_SIGN8 ? 1.0 : 4.0) * nx + 4.0 * (ny + nw));
+    }
     if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, wq, 0) && aligned16(x) && aligned16(y)))
         return qg_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
     if (g->in_shuffle > 1) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: in_shuffle is only available on the code-domain kernels");
@@ -730,6 +735,11 @@ extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, cons
     if (ste.mode == MN_ACTQ_SIGN8) ste.mode = MN_ACTQ_NONE;      // +-1 codes carry no STE here (it lives in mn_bnsign_bwd); x is not read
     if (ste.mode != MN_ACTQ_NONE && !x) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data: x required for the clip-STE epilogue");
     hipStream_t s = (hipStream_t)stream;
+    {
+        const double nx = (double)g->N * g->C * g->H * g->W, nw = (double)g->O * (g->C / g->groups) * g->KH * g->KW;
+        const double ny = (double)g->N * g->O * out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h) * out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+        mn_prof_bytes(4.0 * (ny + nx + nw + (ste.mode != MN_ACTQ_NONE ? nx : 0.0)));
+    }
     if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, wq, 1) && aligned16(gy) && aligned16(dx) &&
                                   (ste.mode == MN_ACTQ_NONE || aligned16(x))))
         return qg_bwd_data(g, aq, wq, gy, w, x, dx, ws, ws_bytes, s);
@@ -763,6 +773,11 @@ extern "C" int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, co
     Pro pro;
     if ((rc = make_pro(aq, &pro, 0, "mn_conv2d_bwd_weight"))) return rc;
     hipStream_t s = (hipStream_t)stream;
+    {
+        const double nx = (double)g->N * g->C * g->H * g->W, nw = (double)g->O * (g->C / g->groups) * g->KH * g->KW;
+        const double ny = (double)g->N * g->O * out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h) * out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+        mn_prof_bytes((pro.mode == MN_ACTQ_SIGN8 ? 1.0 : 4.0) * nx + 4.0 * (ny + nw));
+    }
     const int Ho = out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
     if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, nullptr, 2) && aligned16(x) && aligned16(gy)))
         return qg_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);

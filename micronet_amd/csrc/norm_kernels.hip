@@ -196,7 +196,9 @@ extern "C" int mn_maxpool2x2_sign8_fwd(const int8_t* a, int64_t planes, int64_t 
     if (!a || !out || planes <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 7) || (((uintptr_t)a) & 7) || (((uintptr_t)out) & 3))
         MN_FAIL(MN_EINVAL, "mn_maxpool2x2_sign8_fwd: needs even H, W %% 8 == 0, 8-byte aligned input");
     const int64_t nq = planes * (H / 2) * (W / 8);
+    mn_set_last_kernel("k_pool2_sign8_fwd"); mn_prof_bytes(1.25 * (double)planes * H * W); mn_prof_begin((hipStream_t)stream);
     hipLaunchKernelGGL(k_pool2_sign8_fwd, dim3(mn_grid_for(nq, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const char*)a, (char*)out, nq, (int)H, (int)W);
+    mn_prof_end((hipStream_t)stream);
     MN_CHECK_LAUNCH("mn_maxpool2x2_sign8_fwd");
     return MN_OK;
 }
@@ -204,7 +206,9 @@ extern "C" int mn_maxpool2x2_sign8_bwd(const float* dout, const int8_t* a, int64
     if (!dout || !a || !din || planes <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 3) || (((uintptr_t)a) & 3) || !aligned16(din) || (((uintptr_t)dout) & 7))
         MN_FAIL(MN_EINVAL, "mn_maxpool2x2_sign8_bwd: needs even H, W %% 4 == 0, aligned tensors");
     const int64_t np = planes * (H / 2) * (W / 4);
+    mn_set_last_kernel("k_pool2_sign8_bwd"); mn_prof_bytes(6.0 * (double)planes * H * W); mn_prof_begin((hipStream_t)stream);
     hipLaunchKernelGGL(k_pool2_sign8_bwd, dim3(mn_grid_for(np, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dout, (const char*)a, din, np, (int)H, (int)W);
+    mn_prof_end((hipStream_t)stream);
     MN_CHECK_LAUNCH("mn_maxpool2x2_sign8_bwd");
     return MN_OK;
 }
@@ -236,17 +240,22 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
     hipStream_t s = (hipStream_t)stream;
     const BnsGeom g = bns_geom(N, C, HW);
     const int S = bns_split(g);
+    const double nel = (double)N * C * HW;
     if (training) {
+        mn_set_last_kernel("k_bns_partial<0>"); mn_prof_bytes(4.0 * nel); mn_prof_begin(s);
         hipLaunchKernelGGL(k_bns_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (double*)ws);
+        mn_prof_end(s);
         hipLaunchKernelGGL(k_bns_final_fwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, y, (const double*)ws, S, eps, momentum, running_mean, running_var, save);
     } else {
         hipLaunchKernelGGL(k_bns_eval_stats, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (int)C, eps, (const float*)running_mean, (const float*)running_var, save);
     }
+    mn_set_last_kernel(out8 ? "k_bns_apply<0, 1>" : "k_bns_apply<0, 0>"); mn_prof_bytes((out8 ? 5.0 : 8.0) * nel); mn_prof_begin(s);
     if (out8) hipLaunchKernelGGL((k_bns_apply<0, 1>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
                                  (const float*)nullptr, training, a);
     else hipLaunchKernelGGL((k_bns_apply<0, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
                             (const float*)nullptr, training, a);
+    mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bnsign_fwd");
     return MN_OK;
 }
@@ -268,9 +277,14 @@ extern "C" int mn_bnsign_bwd(const float* da, const float* y, const float* save,
     const BnsGeom g = bns_geom(N, C, HW);
     const int S = bns_split(g);
     float* sums = ws + C * BNS_SPLIT * 4;
+    const double nel = (double)N * C * HW;
+    mn_set_last_kernel("k_bns_partial<1>"); mn_prof_bytes(8.0 * nel); mn_prof_begin(s);
     hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws);
+    mn_prof_end(s);
     hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
+    mn_set_last_kernel("k_bns_apply<1, 0>"); mn_prof_bytes(12.0 * nel); mn_prof_begin(s);
     hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy);
+    mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bnsign_bwd");
     return MN_OK;
 }

@@ -19,6 +19,7 @@ struct AdamTable {
     int chunk0[MN_ADAM_MAX_TENSORS + 1];     // first chunk of each tensor
     int count;
     float beta1, beta2, eps, bc1, bc2_sqrt;
+    const int* step_dev;     // non-null: the step count lives in device memory (HIP-graph replay), bias corrections computed here
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_bc1, float wd, const AdamTable& t) {
@@ -29,7 +30,12 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - lr_bc1 * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void k_adam(const AdamTable t) {
+__global__ __launch_bounds__(256) void k_adam(AdamTable t) {
+    if (t.step_dev) {        // uniform: same expressions as the host path of mn_adam_step
+        const double st = (double)*t.step_dev;
+        t.bc1 = (float)(1.0 - pow((double)t.beta1, st));
+        t.bc2_sqrt = (float)sqrt(1.0 - pow((double)t.beta2, st));
+    }
     int ti = 0;
     const int b = blockIdx.x;
     while (ti + 1 < t.count && t.chunk0[ti + 1] <= b) ++ti;      // <= 32 steps, uniform
@@ -58,10 +64,10 @@ __global__ __launch_bounds__(256) void k_adam(const AdamTable t) {
     }
 }
 
-extern "C" int mn_adam_step(const mn_adam_tensor* tensors, int count, int step, float beta1, float beta2, float eps, mn_stream_t stream) {
-    if (count < 0 || (count > 0 && !tensors) || step < 1) MN_FAIL(MN_EINVAL, "mn_adam_step: bad arguments");
+static int adam_impl(const mn_adam_tensor* tensors, int count, int step, const int32_t* step_dev, float beta1, float beta2, float eps, mn_stream_t stream) {
+    if (count < 0 || (count > 0 && !tensors) || (!step_dev && step < 1)) MN_FAIL(MN_EINVAL, "mn_adam_step: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = step_dev ? 1.0 : 1.0 - pow((double)beta1, (double)step), bc2 = step_dev ? 1.0 : 1.0 - pow((double)beta2, (double)step);
     for (int base = 0; base < count; base += MN_ADAM_MAX_TENSORS) {
         AdamTable t;
         const int cnt = count - base < MN_ADAM_MAX_TENSORS ? count - base : MN_ADAM_MAX_TENSORS;
@@ -78,8 +84,16 @@ extern "C" int mn_adam_step(const mn_adam_tensor* tensors, int count, int step, 
         if (!used) continue;
         t.chunk0[used] = chunks;
         t.count = used; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.bc1 = (float)bc1; t.bc2_sqrt = (float)sqrt(bc2);
+        t.step_dev = (const int*)step_dev;
         hipLaunchKernelGGL(k_adam, dim3(chunks), dim3(256), 0, s, t);
     }
     MN_CHECK_LAUNCH("mn_adam_step");
     return MN_OK;
+}
+extern "C" int mn_adam_step(const mn_adam_tensor* tensors, int count, int step, float beta1, float beta2, float eps, mn_stream_t stream) {
+    return adam_impl(tensors, count, step, nullptr, beta1, beta2, eps, stream);
+}
+extern "C" int mn_adam_step_dev(const mn_adam_tensor* tensors, int count, const int32_t* step_dev, float beta1, float beta2, float eps, mn_stream_t stream) {
+    if (!step_dev) MN_FAIL(MN_EINVAL, "mn_adam_step_dev: null step counter");
+    return adam_impl(tensors, count, 0, step_dev, beta1, beta2, eps, stream);
 }

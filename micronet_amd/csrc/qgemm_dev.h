@@ -2,6 +2,9 @@
 #pragma once
 #include "qgemm.h"
 
+#include <map>
+#include <mutex>
+
 typedef unsigned int u32x2 __attribute__((vector_size(8)));
 
 #define QG_EPI_SCALE_BIAS 0
@@ -64,9 +67,18 @@ static inline int wq_codeable(const mn_wq* wq) {
     return 0;
 }
 
+// raise a kernel's dynamic-LDS limit once per (kernel, size high-water mark): not per launch, so that nothing but kernel
+// launches is issued while a HIP graph is being captured (the training step is captured after a few eager warm-up steps)
 static inline void raise_lds_limit(const void* fn, size_t bytes) {
 #ifndef MN_EMULATION
-    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (bytes <= 48 * 1024) return;
+    static std::mutex mu;
+    static std::map<const void*, size_t> done;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = done[fn];
+    if (have >= bytes) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    have = bytes;
 #else
     (void)fn; (void)bytes;
 #endif

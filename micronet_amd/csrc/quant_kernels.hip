@@ -15,6 +15,11 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 static thread_local char g_err[512] = "";
@@ -33,11 +38,74 @@ void mn_set_last_kernel(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mn_last_kernel(void) { return g_kernel; }
+// ---- measurement: HIP events around the main kernel of each entry point, on the stream it is launched on.
+// (a) mn_profile_next: caller-owned events for the next conv call;  (b) mn_profile_enable / mn_profile_collect: the library
+// keeps its own spans (name, designed bytes, two pooled events per launch) for EVERY main kernel and aggregates them by name.
 static thread_local void* g_prof_ev[2] = {nullptr, nullptr};
+static thread_local double g_prof_bytes = 0.0;
 extern "C" void mn_profile_next(void* start_event, void* stop_event) { g_prof_ev[0] = start_event; g_prof_ev[1] = stop_event; }
+void mn_prof_bytes(double nbytes) { g_prof_bytes = nbytes; }
+#ifndef MN_EMULATION
+struct ProfSpan { std::string name; double bytes; hipEvent_t a, b; };
+// process-wide (autograd runs the backward on its own thread); guarded by g_prof_mu
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfSpan>* g_spans = nullptr;
+static std::vector<hipEvent_t>* g_evpool = nullptr;
+static thread_local hipEvent_t g_open_stop = nullptr;     // stop event of the span this thread has open
+static hipEvent_t prof_event() {
+    if (g_evpool && !g_evpool->empty()) { hipEvent_t e = g_evpool->back(); g_evpool->pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+#endif
+extern "C" void mn_profile_enable(int on) {
+#ifndef MN_EMULATION
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_spans) { g_spans = new std::vector<ProfSpan>(); g_evpool = new std::vector<hipEvent_t>(); }
+    for (auto& sp : *g_spans) { g_evpool->push_back(sp.a); g_evpool->push_back(sp.b); }
+    g_spans->clear();
+    g_prof_on = on != 0;
+#else
+    (void)on;
+#endif
+}
+extern "C" int mn_profile_collect(mn_prof_entry* out, int cap) {
+#ifndef MN_EMULATION
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_spans) return 0;
+    std::map<std::string, mn_prof_entry> agg;
+    for (auto& sp : *g_spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            mn_prof_entry& e = agg[sp.name];
+            if (e.launches == 0) { memset(e.name, 0, sizeof(e.name)); strncpy(e.name, sp.name.c_str(), sizeof(e.name) - 1); }
+            e.launches += 1; e.total_ms += ms; e.bytes += sp.bytes;
+        }
+        g_evpool->push_back(sp.a); g_evpool->push_back(sp.b);
+    }
+    g_spans->clear();
+    int n = 0;
+    for (auto& kv : agg) { if (n < cap && out) out[n] = kv.second; ++n; }
+    return n < cap ? n : cap;
+#else
+    (void)out; (void)cap;
+    return 0;
+#endif
+}
 void mn_prof_begin(hipStream_t s) {
 #ifndef MN_EMULATION
     if (g_prof_ev[0]) (void)hipEventRecord((hipEvent_t)g_prof_ev[0], s);
+    if (g_prof_on) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_on && g_spans) {
+            ProfSpan sp; sp.name = g_kernel; sp.bytes = g_prof_bytes; sp.a = prof_event(); sp.b = prof_event();
+            (void)hipEventRecord(sp.a, s);
+            g_open_stop = sp.b;
+            g_spans->push_back(sp);
+        }
+    }
 #else
     (void)s;
 #endif
@@ -45,6 +113,7 @@ void mn_prof_begin(hipStream_t s) {
 void mn_prof_end(hipStream_t s) {
 #ifndef MN_EMULATION
     if (g_prof_ev[1]) (void)hipEventRecord((hipEvent_t)g_prof_ev[1], s);
+    if (g_open_stop) { (void)hipEventRecord(g_open_stop, s); g_open_stop = nullptr; }
 #else
     (void)s;
 #endif

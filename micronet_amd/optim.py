@@ -1,7 +1,10 @@
 """``Adam``: drop-in for ``torch.optim.Adam`` as the reference training scripts construct it (``*/main.py:308-315``: one
 parameter group per tensor, ``lr``, ``weight_decay``), executed as ONE gfx950 launch over all tensors (``mn_adam_step``)
 instead of ~7 small kernels per group.  Same update as torch (amsgrad off, L2 weight decay folded into the gradient),
-same ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq``), so checkpoints interchange."""
+same ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq``), so checkpoints interchange.
+
+``capturable = True`` keeps the step count in device memory (``mn_adam_step_dev``) so that ``step()`` can be captured in a HIP
+graph and replayed (micronet_amd.train.GraphedTrainStep); ``sync_steps()`` writes the device count back into ``state``."""
 import ctypes as C
 
 import torch
@@ -14,6 +17,22 @@ class Adam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = False
+        self._step_dev = None
+
+    def _host_step(self):
+        steps = {int(st["step"]) for st in self.state.values() if st}
+        if len(steps) > 1:
+            raise _lib.MicronetHipError("capturable Adam needs one common step count for all parameters")
+        return steps.pop() if steps else 0
+
+    def sync_steps(self):
+        """Copy the device-side step count (advanced by graph replays) into every ``state[p]['step']``."""
+        if self._step_dev is not None:
+            n = int(self._step_dev.item())
+            for st in self.state.values():
+                if st:
+                    st["step"].fill_(n)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -22,6 +41,8 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.get_lib()
+        if self.capturable:
+            return self._step_capturable(lib, loss)
         # tensors that share (step, betas, eps) go into one launch table
         batches = {}
         for group in self.param_groups:
@@ -50,4 +71,37 @@ class Adam(torch.optim.Optimizer):
                 rc = lib.mn_adam_step(arr, len(items), step, b1, b2, eps, C.c_void_p(torch.cuda.current_stream().cuda_stream))
             if rc != 0:
                 lib.check(rc, "mn_adam_step")
+        return loss
+
+    def _step_capturable(self, lib, loss):
+        items, dev = {}, None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    raise _lib.MicronetHipError("capturable Adam: every parameter needs a gradient on every step")
+                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise _lib.MicronetHipError("micronet_amd.optim.Adam handles dense contiguous float32 CUDA parameters")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                dev = p.device
+                items.setdefault((float(b1), float(b2), float(group["eps"])), []).append(
+                    (p, p.grad, st, float(group["lr"]), float(group["weight_decay"])))
+        if dev is None:
+            return loss
+        if self._step_dev is None:
+            self._step_dev = torch.full((1,), self._host_step(), dtype=torch.int32, device=dev)
+        self._step_dev.add_(1)
+        for (b1, b2, eps), its in items.items():
+            arr = (_lib.AdamTensor * len(its))()
+            for i, (p, g, st, lr, wd) in enumerate(its):
+                arr[i] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), lr, wd)
+            with torch.cuda.device(dev):
+                rc = lib.mn_adam_step_dev(arr, len(its), C.c_void_p(self._step_dev.data_ptr()), b1, b2, eps,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                lib.check(rc, "mn_adam_step_dev")
         return loss

@@ -55,6 +55,10 @@ def main():
             kk = torch.randint(0, 256, (Cout, Cin // G, k, k), device="cuda", generator=gen).float()
             w = 2 * (kk * (1.0 / n)) - 1
             aq, wq = be.actq(1, 8), be.wq(mode=2, bits=8)
+        elif args.scheme == "real":      # un-quantised layer (the first conv of wbwtab / dorefa nets): fp32 x, fp32 w
+            x = torch.randn((N, Cin, S, S), device="cuda", generator=gen)
+            w = torch.randn((Cout, Cin // G, k, k), device="cuda", generator=gen) * 0.1
+            aq, wq = be.actq(0), None
         else:
             x = torch.randn((N, Cin, S, S), device="cuda", generator=gen) * 4
             code = torch.randint(-127, 128, (Cout, Cin // G, k, k), device="cuda", generator=gen).float()
@@ -76,10 +80,10 @@ def main():
             ws = torch.empty(max(wsb) // 4 + 64, device="cuda")
 
             def f_fwd():
-                be.call("mn_conv2d_fwd", C.byref(g), C.byref(aq), C.byref(wq), P(x), P(w), None, P(y), P(ws), wsb[0], algo, be.stream)
+                be.call("mn_conv2d_fwd", C.byref(g), C.byref(aq), C.byref(wq) if wq is not None else None, P(x), P(w), None, P(y), P(ws), wsb[0], algo, be.stream)
 
             def f_dgrad():
-                be.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq), P(gy), P(w), P(x), P(dx), P(ws), wsb[1], algo, be.stream)
+                be.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq) if wq is not None else None, P(gy), P(w), P(x), P(dx), P(ws), wsb[1], algo, be.stream)
 
             def f_wgrad():
                 be.call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), P(gy), P(x), P(dw), P(db), P(ws), wsb[2], algo, be.stream)

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o t -- python $R/bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o t -- python $R/bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-graph > $R/gpurun_out/pmc_$c.log 2>&1
 done
 cd $R
 python - <<PY

@@ -188,3 +188,34 @@ def test_layerwise_teacher_forced(key):
             lim = max(lim, ref_slack.get(k_, 0.0))
             assert v <= lim, (key, n, type(pm).__name__, k_, v, ref_slack, report[-3:])
     print(key, "worst per-layer rel err:", max(max(e.values()) for _, _, e in report))
+
+
+@pytest.mark.parametrize("key", ["c1_nin_gc_dorefa_w8a8", "c2_nin_gc_wbwtab_w3a2"])
+def test_graphed_train_step_matches_eager(key):
+    """GraphedTrainStep (whole step captured in a HIP graph, Adam step count in device memory) trains like the eager loop."""
+    from micronet_amd.train import GraphedTrainStep, build_model, make_optimizer, synth_batch, train_step
+    arch, scheme, kw, B, wd = CFG[key]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    x, y = synth_batch(16, device="cuda")
+
+    def fresh():
+        m = quantize.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+        return m, make_optimizer(m, 0.01, wd)
+    m1, o1 = fresh()
+    eager = [float(train_step(m1, o1, x, y)[0].detach()) for _ in range(6)]
+    m2, o2 = fresh()
+    g = GraphedTrainStep(m2, o2, x, y, warmup=2)          # 2 eager steps, then replays
+    graphed = [float(g.step()[0]) for _ in range(4)]
+    g.finish()
+    print(key, "eager", eager, "graphed", graphed)
+    assert all(int(st["step"]) == 6 for st in o2.state.values())
+    chaotic = "wbwtab" in key
+    for a, b in zip(eager[2:], graphed):
+        assert abs(a - b) <= (0.25 if chaotic else 2e-2) * max(1.0, abs(a)), (eager, graphed)   # MIOpen's atomic wgrad of the first conv: not bit-reproducible
+    if not chaotic:
+        for (n_, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert float((p1 - p2).abs().max()) <= 5e-2 * max(1.0, float(p1.abs().max())), n_
+    # new data through the static input tensors
+    x2, y2 = synth_batch(16, seed=99, device="cuda")
+    g.data.copy_(x2); g.target.copy_(y2)
+    assert torch.isfinite(g.step()[0])
