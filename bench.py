@@ -70,6 +70,8 @@ def build(workload, device):
     from micronet_amd.train import build_model, make_optimizer
     arch, scheme, kw, wd = WORKLOADS[workload]
     quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    if scheme == "wbwtab" and os.environ.get("MN_BENCH_WBWTAB_KW"):      # A/B switches, e.g. "fuse_conv_bn=0,packed_activations=1"
+        kw = dict(kw, **{k: bool(int(v)) for k, v in (it.split("=") for it in os.environ["MN_BENCH_WBWTAB_KW"].split(","))})
     model = quantize.prepare(build_model(arch), inplace=True, **kw).to(device)
     model.train()
     return model, make_optimizer(model, 0.01, wd)

@@ -221,6 +221,26 @@ int mn_maxpool2x2_sign8_bwd(const float* dout, const int8_t* a, int64_t planes, 
 int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                   int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 
+/* ------------------------------------------------------------------ conv + BatchNorm2d + BinaryActivation, fused, on packed signs
+ * The whole W/A-binary block of the reference -- `relu(bn(conv(x)))` with the ReLU replaced by BinaryActivation
+ * (models/nin_gc.py:53-59; wbwtab/quantize.py:79-94, 181-195) -- for pointwise (1x1, stride 1) convolutions whose input is
+ * already packed sign codes (`x`: int8 {-1,+1}, NCHW, as MN_ACTQ_SIGN8) and whose weights factor as codes x scale (`wq`,
+ * `w` = the fake-quantised fp32 weights as for mn_conv2d_fwd).  The conv output y is NEVER written: it is recomputed on the
+ * matrix cores wherever it is needed.
+ *   fwd: batch statistics of y (training) or the running ones (eval) -> save [2][O] = mean, invstd; running_* updated like
+ *        nn.BatchNorm2d; a = sign(bn(y)) as int8 codes [N][O][H][W].
+ *   bwd: given da = d loss / d a (fp32): dy = d loss / d y (what mn_conv2d_bwd_data / _bwd_weight consume), dgamma, dbeta
+ *        (nullable) -- the clip-STE of the sign through the BatchNorm backward, y recomputed from x.
+ * ws: >= mn_qconv_bnsign_ws_bytes(g) bytes, 16-byte aligned.  MN_ENOTSUP if mn_qconv_bnsign_supported(g, wq) == 0. */
+int mn_qconv_bnsign_supported(const mn_conv_geom* g, const mn_wq* wq);
+int64_t mn_qconv_bnsign_ws_bytes(const mn_conv_geom* g);
+int mn_qconv_bnsign_fwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                        const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                        float* save, int8_t* a, void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                        const float* beta, const float* save, const float* da, int training, float* dy, float* dgamma, float* dbeta,
+                        void* ws, int64_t ws_bytes, mn_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer step of the training loop
  * <scheme>/main.py: optimizer.step() with torch.optim.Adam, one parameter group per tensor (wqaq/dorefa/main.py:308-315).
  * One launch per MN_ADAM_MAX_TENSORS tensors; `tensors` is a HOST array (device pointers inside), copied into the kernel

@@ -81,6 +81,10 @@ PROTOTYPES = {
     "mn_maxpool2x2_sign8_fwd": (_I, [_P, _L, _L, _L, _P, _P]),
     "mn_maxpool2x2_sign8_bwd": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "mn_bnsign_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P]),
+    "mn_qconv_bnsign_supported": (_I, [_G, _W]),
+    "mn_qconv_bnsign_ws_bytes": (_L, [_G]),
+    "mn_qconv_bnsign_fwd": (_I, [_G, _W, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _L, _P]),
+    "mn_qconv_bnsign_bwd": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),

@@ -50,6 +50,12 @@ __device__ __forceinline__ int mn_wave_any(int pred) { return __builtin_amdgcn_b
 __device__ __forceinline__ unsigned mn_f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float mn_u2f(unsigned u) { return __uint_as_float(u); }
 #endif
+// scheduling fence: no instruction may be moved across it (keeps software-pipelined loads from being hoisted en bloc)
+#ifdef MN_EMULATION
+#define MN_SCHED_FENCE() do { } while (0)
+#else
+#define MN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // bf16 "head" of an fp32 (truncation): exact for integers |v| <= 256; v - head is exact in fp32, so
 // v = t0 + t1 + t2 with t_i = head(remainder) reproduces all 24 significant bits (three-term split).
 __device__ __forceinline__ float mn_bf16_head(float v) { return mn_u2f(mn_f2u(v) & 0xffff0000u); }

@@ -625,7 +625,11 @@ int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int 
 }
 int64_t qg_ws_bytes(const mn_conv_geom* g, int which) {
     if (!pw_geom_ok(g)) return kk_ws_bytes(g, which);
-    if (which == 0 || which == 1) { PwPlan pl; return plan_pw(g, which, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0; }   // NT <= 4: the larger Mpad
+    if (which == 0 || which == 1) {   // NT <= 4: the larger Mpad; forward: also the fused sign kernels' workspace
+        PwPlan pl;
+        const int64_t a = plan_pw(g, which, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0, b = which == 0 ? pws_ws_bytes(g) : 0;
+        return a > b ? a : b;
+    }
     if (which == 2) { WgPlan pl; return plan_pw_wgrad(g, &pl) ? pl.ws_bytes : 0; }
     return 0;
 }
@@ -653,6 +657,8 @@ static int run_pw(PwPlan& pl, int xmode, hipStream_t s, const char* what) {
 int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y,
            void* ws, int64_t ws_bytes, hipStream_t s) {
     if (!pw_geom_ok(g)) return kk_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
+    if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_supported(g, wq) && ws_bytes >= pws_ws_bytes(g))     // sign codes: the prefetching kernel
+        return pws_fwd(g, wq, (const int8_t*)x, w, bias, y, ws, ws_bytes, s);
     PwPlan pl;
     if (!wq_codeable(wq) || !aq_codeable(aq, 0) || !plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl) || !aligned16(x) || !aligned16(y))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(qgemm): geometry / quantizer combination not covered");

@@ -1,0 +1,538 @@
+// Pointwise convolution on packed sign activations with fused BatchNorm + BinaryActivation epilogues, for gfx950.
+//
+// The reference's W/A-binary block is  a_out = sign(bn(conv(a_in, Wq)))  (models/nin_gc.py:53-59 with the ReLU replaced by
+// BinaryActivation, wbwtab/quantize.py:79-94,181-195).  Its input is +-1 and its weights are ternary/binary codes x alpha[o]
+// -- so the convolution output y = alpha[o] * acc + bias, with acc an EXACT small integer (|acc| <= Cin/groups), is cheap
+// to recompute from one byte per input element (int8 sign codes, MN_ACTQ_SIGN8) on the bf16 matrix cores, while writing y
+// (fp32) and reading it back are the HBM passes that dominate the step.  This kernel never needs y in memory: one main
+// loop (weight codes as A fragments in LDS, sign codes streamed straight into B fragments, v_mfma_f32_16x16x32_bf16 -- see
+// qgemm_kernels.hip for the fragment mapping) ends in one of
+//   PWS_Y          y = acc * alpha[o] + bias                                  -> fp32 store   (the plain convolution)
+//   PWS_STATS      per-channel sum acc, sum acc^2 (exact integers)            -> partials     (BatchNorm batch statistics)
+//   PWS_SIGN8      a = sign(bn(y)) = [acc*flip >= T[o]]                       -> int8 store   (the block's output)
+//   PWS_BWD_PART   dz = da * [L[o] <= acc*flip <= U[o]]; sum dz, sum dz*zhat  -> partials     (dgamma, dbeta, BN backward sums)
+//   PWS_BWD_APPLY  dy = gamma * invstd * (dz - sum_dz/n - zhat * sum_dzzhat/n) -> fp32 store  (what conv backward consumes)
+// Forward of a block = PWS_STATS + PWS_SIGN8: reads |a_in| bytes twice, writes |a_out| bytes once; y is never stored.
+// Backward of its BatchNorm+sign = PWS_BWD_PART + PWS_BWD_APPLY: reads da twice, writes dy once; y is recomputed.
+//
+// Integer-domain epilogues.  z(acc) = ((acc*alpha + bias) - mean) * invstd * gamma + beta, evaluated in fp32 exactly as the
+// unfused kernels do, is a monotone step function of the integer acc, so sign(z) and the clip mask |z| < 1 are integer
+// interval tests.  k_pws_chan_prep evaluates the fp32 expression for EVERY possible acc in [-K, K] (K <= 128) per channel
+// and stores the exact thresholds: the decisions are bit-identical to the unfused path at ~2 instructions per element
+// instead of ~9, and the batch statistics are exact integer sums (mean / variance formed in fp64 afterwards).
+//
+// Throughput: the kernel is bound by instruction issue, not by HBM or MFMA, so a wave contracts ALL output channels of its
+// group (NT tiles of 16, up to 128) per 64-pixel chunk -- the sign -> bf16 expansion of a B fragment is shared by NT MFMAs --
+// loads are unconditional (indices are clamped instead of masked), channel offsets come from an LDS table, and the codes of the
+// wave's next chunk are prefetched into the registers of each K-step as soon as that step's fragments are built.
+#include "qgemm_dev.h"
+
+#include <stdlib.h>
+
+#define PWS_Y 0
+#define PWS_STATS 1
+#define PWS_SIGN8 2
+#define PWS_BWD_PART 3
+#define PWS_BWD_APPLY 4
+
+#define PWS_NCH 8           // per-channel constants (k_pws_chan_prep): T, flip, L, U, A, B, gi, unused
+struct PwsParams {
+    const char* x;            // int8 sign codes [N][Cin_total][HW]
+    const uint16_t* wc;       // weight codes [G][Mpad][Kp] (bf16 bits)
+    const float* rowscale;    // [G][Mpad]
+    const float* bias;        // [G*Mr] or null
+    float* y;                 // PWS_Y: y     PWS_BWD_APPLY: dy        [N][Cout_total][HW]
+    char* a8;                 // PWS_SIGN8 output
+    float* part;              // PWS_STATS / PWS_BWD_PART: [CB][G*Mpad][2]
+    const float* chan;        // [PWS_NCH][Cout_total] per-channel constants
+    const float* da;          // gradient w.r.t. the sign output
+    const float* sums;        // [2][Cout_total] sum dz, sum dz*zhat (PWS_BWD_APPLY, training)
+    int training;
+    float n_f;                // (float)N * (float)HW, the divisor k_bns_apply uses
+    int N, HW, Cin_total, Cout_total, Kc, Mr, G, Kp, Mpad, num_mblk, nchunks, CB;
+    uint32_t NP;
+    FastDiv fd_hw;
+    ChanMap in_map;
+};
+
+template <int NT, int KS, int EPI>
+__global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int MB = 16 * NT;
+    constexpr bool RED = EPI == PWS_STATS || EPI == PWS_BWD_PART;
+    constexpr bool GRAD = EPI == PWS_BWD_PART || EPI == PWS_BWD_APPLY;
+    const int LDW = p.Kp + 8;
+    uint16_t* wsm = reinterpret_cast<uint16_t*>(smem);
+    float* c0 = smem + (MB * LDW) / 2;     // Y: alpha       SIGN8: T      BWD: L
+    float* c1 = c0 + MB;                   // Y: bias        SIGN8: flip   BWD: U
+    float* c2 = c1 + MB;                   //                              BWD: flip
+    float* c3 = c2 + MB;                   //                              BWD: A  (zhat = acc * A + B)
+    float* c4 = c3 + MB;                   //                              BWD: B
+    float* c5 = c4 + MB;                   //                              APPLY: gi = gamma * invstd
+    float* c6 = c5 + MB;                   //                              APPLY: k1 = sum_dz / n
+    float* c7 = c6 + MB;                   //                              APPLY: k2 = sum_dzzhat / n
+    uint32_t* coff = reinterpret_cast<uint32_t*>(c7 + MB);      // [Kp] element offset of the (clamped, shuffled) input channel
+    double* red = reinterpret_cast<double*>(coff + p.Kp);      // [4][MB][2] cross-wave reduction (RED); 8-byte aligned by layout
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const uint32_t HW = (uint32_t)p.HW;
+
+    uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u; b >>= 3;
+    const int mblk = b % p.num_mblk; b /= p.num_mblk;
+    const uint32_t idx = b * 8u + xcd;
+    if (idx >= (uint32_t)(p.G * p.CB)) return;
+    const int cb = idx % p.CB, g = idx / p.CB;
+
+    {   // stage weight codes, the per-channel constants of this m-block and the input-channel offset table
+        const uint16_t* wg = p.wc + ((int64_t)g * p.Mpad + mblk * MB) * p.Kp;
+        const int k8 = p.Kp >> 3;
+        for (int q = tid; q < MB * k8; q += 256) {
+            const int row = q / k8, c8 = q - row * k8;
+            *reinterpret_cast<u32x4*>(wsm + row * LDW + c8 * 8) = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.Kp + c8 * 8);
+        }
+        for (int i = tid; i < MB; i += 256) {
+            const int m = mblk * MB + i;
+            const bool mv = m < p.Mr;
+            const int co = g * p.Mr + (mv ? m : 0);
+            const int C = p.Cout_total;
+            if (EPI == PWS_Y) { c0[i] = p.rowscale[g * p.Mpad + m]; c1[i] = (p.bias && mv) ? p.bias[co] : 0.f; }
+            if (EPI == PWS_SIGN8) { c0[i] = p.chan[co]; c1[i] = p.chan[C + co]; }
+            if (GRAD) { c0[i] = p.chan[2 * C + co]; c1[i] = p.chan[3 * C + co]; c2[i] = p.chan[C + co]; c3[i] = p.chan[4 * C + co]; c4[i] = p.chan[5 * C + co]; }
+            if (EPI == PWS_BWD_APPLY) {
+                c5[i] = p.chan[6 * C + co];
+                c6[i] = p.training ? p.sums[co] / p.n_f : 0.f;
+                c7[i] = p.training ? p.sums[C + co] / p.n_f : 0.f;
+            }
+        }
+        for (int c = tid; c < p.Kp; c += 256) coff[c] = (uint32_t)chan_phys(p.in_map, g * p.Kc + (c < p.Kc ? c : p.Kc - 1)) * HW;
+    }
+    __syncthreads();
+
+    const int chunk0 = cb * 4 + wave, cstride = p.CB * 4;
+    const uint16_t* wl = wsm + j * LDW + kg * 8;
+    const uint32_t Pmax = p.NP - 4u;                         // NP is a multiple of 4: the last valid quad
+
+    // codes of K-step s of a chunk: dword (4 pixels) of channel s*32 + kg*8 + jj.  Unconditional: a pixel quad beyond the
+    // tensor is clamped to the last one (its results are never stored or summed), channels beyond Kc to channel Kc-1
+    // (their weight codes are zero).  All tensors are < 4 GiB (planner): 32-bit offsets from the uniform base pointer.
+    auto load_step = [&](uint32_t (&dst)[KS * 8], int s, uint32_t xo) {
+        const u32x4 o0 = *reinterpret_cast<const u32x4*>(coff + s * 32 + kg * 8), o1 = *reinterpret_cast<const u32x4*>(coff + s * 32 + kg * 8 + 4);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            dst[s * 8 + jj] = *reinterpret_cast<const uint32_t*>(p.x + (xo + o0[jj]));
+            dst[s * 8 + 4 + jj] = *reinterpret_cast<const uint32_t*>(p.x + (xo + o1[jj]));
+        }
+    };
+    auto chunk_xo = [&](int chunk) {
+        uint32_t P = (uint32_t)chunk * 64u + 4u * j;
+        P = P < Pmax ? P : Pmax;
+        const uint32_t n = fd_div(P, p.fd_hw);
+        return n * (uint32_t)p.Cin_total * HW + (P - n * HW);
+    };
+
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+
+    uint32_t cur[KS * 8];
+    if (chunk0 < p.nchunks) {
+        const uint32_t xo = chunk_xo(chunk0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) load_step(cur, s, xo);
+    }
+    for (int chunk = chunk0; chunk < p.nchunks; chunk += cstride) {
+        const uint32_t P = (uint32_t)chunk * 64u + 4u * j;
+        const bool pv = P < p.NP;
+        const uint32_t n = fd_div(P, p.fd_hw);
+        const uint32_t obase = n * (uint32_t)p.Cout_total * HW + (P - n * HW) + (uint32_t)(g * p.Mr + mblk * MB + kg * 4) * HW;   // + (t*16 + r) * HW
+        const bool more = chunk + cstride < p.nchunks;       // wave-uniform
+        const uint32_t xo_next = more ? chunk_xo(chunk + cstride) : 0u;
+
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bq[q][d] = mn_sign8_pair(cur[s * 8 + 2 * d], cur[s * 8 + 2 * d + 1], q);
+            if (more) load_step(cur, s, xo_next);            // this step's registers are free: prefetch the next chunk into them
+            // A fragments one tile ahead only: the scheduler would otherwise hoist all NT LDS reads (4 VGPRs each) above the MFMAs
+            u32x4 a = *reinterpret_cast<const u32x4*>(wl + s * 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                u32x4 an = a;
+                if (t + 1 < NT) an = *reinterpret_cast<const u32x4*>(wl + s * 32 + (t + 1) * 16 * LDW);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, bq[q], acc[q][t]);
+                a = an;
+                MN_SCHED_FENCE();
+            }
+        }
+
+        // epilogue: lane (j, kg) holds out-channels t*16 + 4kg + r of pixels P .. P+3; acc is an exact integer
+        float4 gq[2][4];                         // backward: the gradient rows of tile t (one tile ahead)
+        if (GRAD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gq[0][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pv && mblk * MB + kg * 4 + r < p.Mr) gq[0][r] = *reinterpret_cast<const float4*>(p.da + (obase + (uint32_t)r * HW));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (GRAD && t + 1 < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gq[(t + 1) & 1][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pv && mblk * MB + (t + 1) * 16 + kg * 4 + r < p.Mr)
+                        gq[(t + 1) & 1][r] = *reinterpret_cast<const float4*>(p.da + (obase + (uint32_t)((t + 1) * 16 + r) * HW));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ml = t * 16 + kg * 4 + r;
+                const bool ok = pv && mblk * MB + ml < p.Mr;
+                const float o[4] = {acc[0][t][r], acc[1][t][r], acc[2][t][r], acc[3][t][r]};
+                const uint32_t off = obase + (uint32_t)(t * 16 + r) * HW;
+                if (EPI == PWS_STATS) {
+                    if (ok) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1[t][r] += o[e]; s2[t][r] += o[e] * o[e]; }      // exact: integers below 2^24
+                    }
+                } else if (EPI == PWS_Y) {
+                    const float a_ = c0[ml], b_ = c1[ml];
+                    if (ok) *reinterpret_cast<float4*>(p.y + off) = make_float4(o[0] * a_ + b_, o[1] * a_ + b_, o[2] * a_ + b_, o[3] * a_ + b_);
+                } else if (EPI == PWS_SIGN8) {
+                    const float T = c0[ml], fl = c1[ml];
+                    if (ok) {
+                        const uint32_t u = (o[0] * fl >= T ? 0x01u : 0xFFu) | (o[1] * fl >= T ? 0x0100u : 0xFF00u) | (o[2] * fl >= T ? 0x010000u : 0xFF0000u) |
+                                           (o[3] * fl >= T ? 0x01000000u : 0xFF000000u);
+                        *reinterpret_cast<uint32_t*>(p.a8 + off) = u;
+                    }
+                } else {
+                    const float L = c0[ml], U = c1[ml], fl = c2[ml], A = c3[ml], B = c4[ml];
+                    const float4 g4 = gq[t & 1][r];
+                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+                    float dz[4], zh[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = o[e] * fl;
+                        dz[e] = (u >= L && u <= U) ? gv[e] : 0.f;          // BinaryActivation.backward: |z| < 1
+                        zh[e] = fmaf(o[e], A, B);                           // (y - mean) * invstd
+                    }
+                    if (EPI == PWS_BWD_PART) {
+                        if (ok) {
+                            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { t1 += dz[e]; t2 += dz[e] * zh[e]; }
+                            s1[t][r] += t1; s2[t][r] += t2;
+                        }
+                    } else {
+                        const float gi = c5[ml], k1 = c6[ml], k2 = c7[ml];
+                        if (ok) *reinterpret_cast<float4*>(p.y + off) = make_float4(gi * (dz[0] - k1 - zh[0] * k2), gi * (dz[1] - k1 - zh[1] * k2),
+                                                                                    gi * (dz[2] - k1 - zh[2] * k2), gi * (dz[3] - k1 - zh[3] * k2));
+                    }
+                }
+            }
+        }
+    }
+
+    if (RED) {   // block partial in fp64: 16 pixel lanes -> wave -> 4 waves (fixed order), one [MB][2] row per block
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v1 = (double)s1[t][r], v2 = (double)s2[t][r];
+                v1 += __shfl_xor(v1, 8, 64); v1 += __shfl_xor(v1, 4, 64); v1 += __shfl_xor(v1, 2, 64); v1 += __shfl_xor(v1, 1, 64);
+                v2 += __shfl_xor(v2, 8, 64); v2 += __shfl_xor(v2, 4, 64); v2 += __shfl_xor(v2, 2, 64); v2 += __shfl_xor(v2, 1, 64);
+                if (j == 0) {
+                    const int ml = t * 16 + kg * 4 + r;
+                    red[(wave * MB + ml) * 2] = v1; red[(wave * MB + ml) * 2 + 1] = v2;
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < MB; i += 256) {
+            const double v1 = ((red[i * 2] + red[(MB + i) * 2]) + red[(2 * MB + i) * 2]) + red[(3 * MB + i) * 2];
+            const double v2 = ((red[i * 2 + 1] + red[(MB + i) * 2 + 1]) + red[(2 * MB + i) * 2 + 1]) + red[(3 * MB + i) * 2 + 1];
+            double* dst = reinterpret_cast<double*>(p.part) + ((int64_t)cb * p.G * p.Mpad + g * p.Mpad + mblk * MB + i) * 2;
+            dst[0] = v1; dst[1] = v2;
+        }
+    }
+}
+
+// batch statistics from the PWS_STATS partials (exact integer sums S1 = sum acc, S2 = sum acc^2 over N*HW): y = alpha*acc + bias,
+// so mean = alpha * S1/n + bias and the biased variance = alpha^2 * (S2/n - (S1/n)^2), formed in fp64; same outputs as
+// k_bns_final_fwd (norm_kernels.hip): save = {mean, invstd}, running stats with the UNBIASED variance.  One wave per channel.
+__global__ __launch_bounds__(64) void k_pws_final_fwd(const double* __restrict__ part, int CB, int G, int Mpad, int Mr, const float* __restrict__ rowscale,
+                                                     const float* __restrict__ bias, double n, float eps, float momentum, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, float* __restrict__ save, int Cout) {
+    const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = lane; i < CB; i += 64) {
+        const double* src = part + ((int64_t)i * G * Mpad + g * Mpad + m) * 2;
+        a1 += src[0]; a2 += src[1];
+    }
+    a1 = wave_reduce(a1, OpAddD()); a2 = wave_reduce(a2, OpAddD());
+    if (lane == 0) {
+        const double al = (double)rowscale[g * Mpad + m];
+        const double ma = a1 / n;
+        const double mean = al * ma + (double)(bias ? bias[co] : 0.f);
+        double ss = al * al * (a2 - a1 * ma);                 // sum of squared deviations of y
+        if (ss < 0.0) ss = 0.0;
+        const float var_b = (float)(ss / n);
+        save[co] = (float)mean;
+        save[Cout + co] = 1.0f / sqrtf(var_b + eps);
+        if (running_mean) running_mean[co] = (1.f - momentum) * running_mean[co] + momentum * (float)mean;
+        if (running_var) running_var[co] = (1.f - momentum) * running_var[co] + momentum * (float)(ss / (n - 1.0));
+    }
+}
+__global__ __launch_bounds__(64) void k_pws_final_bwd(const double* __restrict__ part, int CB, int G, int Mpad, int Mr, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ sums, int Cout) {
+    const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = lane; i < CB; i += 64) {
+        const double* src = part + ((int64_t)i * G * Mpad + g * Mpad + m) * 2;
+        a1 += src[0]; a2 += src[1];
+    }
+    a1 = wave_reduce(a1, OpAddD()); a2 = wave_reduce(a2, OpAddD());
+    if (lane == 0) {
+        if (dbeta) dbeta[co] = (float)a1;
+        if (dgamma) dgamma[co] = (float)a2;
+        sums[co] = (float)a1; sums[Cout + co] = (float)a2;
+    }
+}
+__global__ void k_pws_eval_stats(int C, float eps, const float* __restrict__ running_mean, const float* __restrict__ running_var, float* __restrict__ save) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    save[c] = running_mean[c];
+    save[C + c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+// per-channel integer-domain constants.  z(acc) below is the fp32 expression chain of the unfused kernels (k_pw epilogue:
+// y = acc*alpha + bias; k_bns_apply: zh = (y - mean)*invstd, z = zh*gamma + beta; -ffp-contract=off keeps every rounding).
+// Each step is monotone in acc, so z is a monotone step function over the integers [-K, K]; with u = acc*flip it is
+// non-decreasing and  z < 0  <=>  u < T,   -1 < z < 1  <=>  L <= u <= U.  One wave evaluates all 2K+1 values.
+__device__ __forceinline__ float pws_z(float acc, float al, float b, float mean, float invstd, float ga, float be) {
+    const float y = acc * al + b;
+    const float zh = (y - mean) * invstd;
+    return zh * ga + be;
+}
+__global__ __launch_bounds__(64) void k_pws_chan_prep(int K, int G, int Mpad, int Mr, const float* __restrict__ rowscale, const float* __restrict__ bias,
+                                                     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ chan, int Cout) {
+    const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
+    const float al = rowscale[g * Mpad + m], b = bias ? bias[co] : 0.f, mean = save[co], invstd = save[Cout + co], ga = gamma[co], be = beta[co];
+    const float zlo = pws_z(-(float)K, al, b, mean, invstd, ga, be), zhi = pws_z((float)K, al, b, mean, invstd, ga, be);
+    const float flip = (zhi < zlo) ? -1.f : 1.f;              // NaN anywhere: flip = +1 and every test below is false -> constant outputs
+    // non-decreasing in u: T = min{u : !(z < 0)}, L = min{u : z > -1}, U = max{u : z < 1}
+    int T = K + 1, L = K + 1, U = -K - 1;
+    for (int u = -K + lane; u <= K; u += 64) {
+        const float z = pws_z((float)u * flip, al, b, mean, invstd, ga, be);
+        if (!(z < 0.f) && u < T) T = u;
+        if (z > -1.f && u < L) L = u;
+        if (z < 1.f && u > U) U = u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int t2 = __shfl_xor(T, o, 64), l2 = __shfl_xor(L, o, 64), u2 = __shfl_xor(U, o, 64);
+        T = t2 < T ? t2 : T; L = l2 < L ? l2 : L; U = u2 > U ? u2 : U;
+    }
+    if (lane == 0) {
+        chan[co] = (float)T; chan[Cout + co] = flip; chan[2 * Cout + co] = (float)L; chan[3 * Cout + co] = (float)U;
+        chan[4 * Cout + co] = al * invstd;                    // zhat = acc*A + B  (<= 2 ulp from the unfused chain; dy tolerance 1e-5)
+        chan[5 * Cout + co] = (b - mean) * invstd;
+        chan[6 * Cout + co] = ga * invstd;
+        chan[7 * Cout + co] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct PwsPlan {
+    PwsParams p;
+    PackParams pk;
+    int NT, KS;
+    size_t lds;
+    int grid, pack_grid;
+    int64_t off_scale, off_part, off_sums, off_chan, ws_bytes;
+};
+static int pws_geom_ok(const mn_conv_geom* g) {
+    if (g->KH != 1 || g->KW != 1 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 0 || g->pad_w != 0) return 0;
+    const int64_t HW = (int64_t)g->H * g->W, NP = (int64_t)g->N * HW;
+    if (HW % 4) return 0;
+    if (NP * HW >= ((int64_t)1 << 32) || NP + 256 >= ((int64_t)1 << 31)) return 0;   // FastDiv range
+    if (4 * NP * (g->C > g->O ? g->C : g->O) >= ((int64_t)1 << 32)) return 0;        // 32-bit byte offsets
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    return 1;
+}
+// nt_max: largest tile count per wave (8 = a whole 128-channel group; the backward epilogues also hold gradient rows)
+static int plan_pws(const mn_conv_geom* g, int nt_max, PwsPlan* pl) {
+    if (!pws_geom_ok(g)) return 0;
+    const int Cg = g->C / g->groups, Mg = g->O / g->groups;
+    PwsParams& p = pl->p;
+    p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.NP = (uint32_t)((int64_t)g->N * p.HW);
+    p.Cin_total = g->C; p.Cout_total = g->O; p.Kc = Cg; p.Mr = Mg;
+    p.in_map = make_chanmap(g->in_shuffle, g->C);
+    p.Kp = qg_roundup(Cg, 32);
+    const int KS = p.Kp / 32;
+    if (KS < 1 || KS > 4) return 0;                       // up to 128 input channels per group
+    pl->KS = KS;
+    int NT = nt_max;
+    if (const char* e = getenv("MN_PWS_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) NT = v < nt_max ? v : nt_max; }   // tuning knob
+    while (NT > 1 && 16 * (NT / 2) >= Mg) NT /= 2;
+    pl->NT = NT;
+    const int MB = 16 * NT;
+    pl->lds = (size_t)MB * (p.Kp + 8) * 2 + (size_t)8 * MB * 4 + (size_t)p.Kp * 4 + (size_t)4 * MB * 2 * 8;
+    p.num_mblk = (Mg + MB - 1) / MB;
+    p.Mpad = ((Mg + 127) / 128) * 128;                    // one packed-code layout for every tile height
+    p.nchunks = (int)((p.NP + 63) / 64);
+    int CB = (p.nchunks + 3) / 4;
+    int capb = 1024;
+    if (const char* e = getenv("MN_PWS_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 2048) capb = v; }   // tuning knob
+    const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
+    if (CB > cap) CB = cap;
+    p.CB = CB;
+    p.fd_hw = make_fastdiv((uint32_t)p.HW);
+    p.n_f = (float)g->N * (float)p.HW;
+    const int64_t nb = (int64_t)qg_roundup(p.G * CB, 8) * p.num_mblk;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    const int64_t code_bytes = (int64_t)p.G * p.Mpad * p.Kp * 2;
+    pl->off_scale = (code_bytes + 255) / 256 * 256;
+    pl->off_part = pl->off_scale + ((int64_t)p.G * p.Mpad * 4 + 255) / 256 * 256;
+    pl->off_sums = pl->off_part + ((int64_t)2048 * p.Mpad * 2 * 8 + 255) / 256 * 256;   // CB * G <= 2048 rows of [Mpad][2] doubles
+    pl->off_chan = pl->off_sums + ((int64_t)2 * g->O * 4 + 255) / 256 * 256;
+    pl->ws_bytes = pl->off_chan + (int64_t)PWS_NCH * g->O * 4 + 256;
+    PackParams& k = pl->pk;
+    k.G = g->groups; k.Mg = Mg; k.Cg = Cg; k.T = 1; k.KW = 1; k.transpose = 0;
+    k.Mpad = p.Mpad; k.Cgp = p.Kp; k.Cpad = 0; k.Mgp = 0;
+    pl->pack_grid = k.G * k.Mpad;
+    return 1;
+}
+
+template <int NT, int KS, int EPI>
+static void launch_pws3(const PwsPlan& pl, hipStream_t s) {
+    raise_lds_limit((const void*)k_pws<NT, KS, EPI>, pl.lds);
+    hipLaunchKernelGGL((k_pws<NT, KS, EPI>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+}
+template <int NT, int EPI>
+static void launch_pws2(const PwsPlan& pl, hipStream_t s) {
+    if (pl.KS == 4) launch_pws3<NT, 4, EPI>(pl, s);
+    else if (pl.KS == 3) launch_pws3<NT, 3, EPI>(pl, s);
+    else if (pl.KS == 2) launch_pws3<NT, 2, EPI>(pl, s);
+    else launch_pws3<NT, 1, EPI>(pl, s);
+}
+template <int EPI>
+static int launch_pws(const PwsPlan& pl, hipStream_t s, double nbytes, const char* what) {
+    static const char* en[5] = {"Y", "STATS", "SIGN8", "BWD_PART", "BWD_APPLY"};
+    mn_set_last_kernel("k_pws<%d, %d, %s>", pl.NT, pl.KS, en[EPI]);
+    mn_prof_bytes(nbytes);
+    mn_prof_begin(s);
+    switch (pl.NT) {
+        case 1: launch_pws2<1, EPI>(pl, s); break;
+        case 2: launch_pws2<2, EPI>(pl, s); break;
+        case 4: launch_pws2<4, EPI>(pl, s); break;
+        case 8: if (EPI == PWS_BWD_PART || EPI == PWS_BWD_APPLY) MN_FAIL(MN_EINVAL, "%s: bad NT", what); launch_pws2<(EPI == PWS_BWD_PART || EPI == PWS_BWD_APPLY) ? 4 : 8, EPI>(pl, s); break;
+        default: MN_FAIL(MN_EINVAL, "%s: bad NT", what);
+    }
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH(what);
+    return MN_OK;
+}
+#define PWS_NT_FWD 4      // NT = 8 (a whole 128-channel group per wave) spills: 2 x 64 accumulators + statistics do not fit 256 VGPRs
+#define PWS_NT_BWD 4
+
+static int pws_prepare(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, void* ws, int64_t ws_bytes, int nt_max, PwsPlan* pl,
+                       hipStream_t s, const char* what) {
+    if (!wq_codeable(wq) || !plan_pws(g, nt_max, pl)) MN_FAIL(MN_ENOTSUP, "%s: geometry / weight quantizer not covered by the fused sign kernels", what);
+    if (!x || !w || (((uintptr_t)x) & 3)) MN_FAIL(MN_EINVAL, "%s: null / misaligned tensor", what);
+    if (!ws || ws_bytes < pl->ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "%s: workspace too small (%lld < %lld)", what, (long long)ws_bytes, (long long)pl->ws_bytes);
+    fill_pack(pl->pk, wq, w, ws, 0, pl->off_scale);
+    qg_launch_pack(pl->pk, pl->pack_grid, s);
+    PwsParams& p = pl->p;
+    p.x = (const char*)x; p.wc = pl->pk.codes; p.rowscale = pl->pk.scale_out;
+    p.part = (float*)((char*)ws + pl->off_part);
+    p.chan = (const float*)((char*)ws + pl->off_chan);
+    p.y = nullptr; p.a8 = nullptr; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr;
+    return MN_OK;
+}
+
+int pws_supported(const mn_conv_geom* g, const mn_wq* wq) {
+    PwsPlan pl;
+    return wq_codeable(wq) && plan_pws(g, PWS_NT_FWD, &pl);
+}
+// plain forward on sign codes (used by mn_conv2d_fwd for MN_ACTQ_SIGN8 inputs)
+int pws_fwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes, hipStream_t s) {
+    PwsPlan pl;
+    int rc = pws_prepare(g, wq, x, w, ws, ws_bytes, PWS_NT_FWD, &pl, s, "mn_conv2d_fwd(sign)");
+    if (rc) return rc;
+    if (!y || !aligned16(y)) MN_FAIL(MN_EINVAL, "mn_conv2d_fwd(sign): bad output");
+    pl.p.y = y; pl.p.bias = bias;
+    const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
+    return launch_pws<PWS_Y>(pl, s, nx + 4.0 * ny, "mn_conv2d_fwd(sign)");
+}
+int64_t pws_ws_bytes(const mn_conv_geom* g) {
+    PwsPlan pl;
+    return plan_pws(g, PWS_NT_FWD, &pl) ? pl.ws_bytes : 0;
+}
+
+// the fused BatchNorm epilogues rely on |acc| <= Cin/groups: weight codes in {-1, 0, +1} (ternary / binary weights)
+static int pws_bn_ok(const mn_conv_geom* g, const mn_wq* wq) { return g && wq && wq->mode == MN_WQ_TERNARY && pws_supported(g, wq); }
+extern "C" int mn_qconv_bnsign_supported(const mn_conv_geom* g, const mn_wq* wq) { return pws_bn_ok(g, wq); }
+extern "C" int64_t mn_qconv_bnsign_ws_bytes(const mn_conv_geom* g) { return g ? pws_ws_bytes(g) : -1; }
+
+static void pws_chan_prep(const PwsPlan& pl, const mn_conv_geom* g, const float* bias, const float* save, const float* gamma, const float* beta, hipStream_t s) {
+    hipLaunchKernelGGL(k_pws_chan_prep, dim3((unsigned)g->O), dim3(64), 0, s, pl.p.Kc, pl.p.G, pl.p.Mpad, pl.p.Mr, pl.p.rowscale, bias, save, gamma, beta,
+                       (float*)pl.p.chan, (int)g->O);
+}
+
+extern "C" int mn_qconv_bnsign_fwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                   const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                   float* save, int8_t* a, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    if (!g || !gamma || !beta || !save || !a || (((uintptr_t)a) & 3)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd: null / misaligned argument");
+    if (!pws_bn_ok(g, wq)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd: needs a pointwise convolution with ternary / binary weights");
+    if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd: eval mode needs the running statistics");
+    hipStream_t s = (hipStream_t)stream;
+    PwsPlan pl;
+    int rc = pws_prepare(g, wq, x, w, ws, ws_bytes, PWS_NT_FWD, &pl, s, "mn_qconv_bnsign_fwd");
+    if (rc) return rc;
+    PwsParams& p = pl.p;
+    p.bias = bias;
+    const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
+    if (training) {
+        if ((rc = launch_pws<PWS_STATS>(pl, s, nx, "mn_qconv_bnsign_fwd(stats)"))) return rc;
+        hipLaunchKernelGGL(k_pws_final_fwd, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, bias,
+                           (double)g->N * p.HW, eps, momentum, running_mean, running_var, save, (int)g->O);
+    } else {
+        hipLaunchKernelGGL(k_pws_eval_stats, dim3((unsigned)((g->O + 63) / 64)), dim3(64), 0, s, (int)g->O, eps, (const float*)running_mean,
+                           (const float*)running_var, save);
+    }
+    pws_chan_prep(pl, g, bias, save, gamma, beta, s);
+    p.a8 = (char*)a;
+    return launch_pws<PWS_SIGN8>(pl, s, nx + ny, "mn_qconv_bnsign_fwd(sign)");
+}
+
+extern "C" int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                   const float* beta, const float* save, const float* da, int training, float* dy, float* dgamma, float* dbeta,
+                                   void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    if (!g || !gamma || !beta || !save || !da || !dy || !aligned16(da) || !aligned16(dy)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_bwd: null / misaligned argument");
+    if (!pws_bn_ok(g, wq)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_bwd: needs a pointwise convolution with ternary / binary weights");
+    hipStream_t s = (hipStream_t)stream;
+    PwsPlan pl;
+    int rc = pws_prepare(g, wq, x, w, ws, ws_bytes, PWS_NT_BWD, &pl, s, "mn_qconv_bnsign_bwd");
+    if (rc) return rc;
+    PwsParams& p = pl.p;
+    float* sums = (float*)((char*)ws + pl.off_sums);
+    p.bias = bias; p.da = da; p.training = training;
+    pws_chan_prep(pl, g, bias, save, gamma, beta, s);
+    const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
+    if ((rc = launch_pws<PWS_BWD_PART>(pl, s, nx + 4.0 * ny, "mn_qconv_bnsign_bwd(partial)"))) return rc;
+    hipLaunchKernelGGL(k_pws_final_bwd, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, dgamma, dbeta, sums, (int)g->O);
+    p.sums = sums; p.y = dy;
+    return launch_pws<PWS_BWD_APPLY>(pl, s, nx + 8.0 * ny, "mn_qconv_bnsign_bwd(apply)");
+}

@@ -22,7 +22,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import ActQ, ConvGeom, MicronetHipError, WQ
-from .sign_tensor import SignTensor
+from .sign_tensor import LazyConvOut, SignTensor
 
 ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO, ACTQ_SIGN8 = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO, _lib.MN_ACTQ_SIGN8
 WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _lib.MN_WQ_DOREFA, _lib.MN_WQ_IAO
@@ -484,6 +484,80 @@ class QConv2d(Function):
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
+class QConv2dLazy(Function):
+    """QConv2d on packed sign activations whose result is NOT computed: returns a ``LazyConvOut`` carrying the recipe (see
+    micronet_amd/sign_tensor.py).  Backward is QConv2d's (mn_conv2d_bwd_data / _bwd_weight on the int8 codes)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, wdesc, in_shuffle):
+        codes = x.codes
+        wq, bias = _chk(wq, "weight"), _chk(bias, "bias")
+        g = _geom(codes.shape, wq.shape, stride, padding, dilation, groups, in_shuffle)
+        Ho, Wo = _out_hw(g)
+        wscale = wdesc[4] if wdesc is not None else None
+        ctx.save_for_backward(codes, wq, None, wscale)
+        ctx.cfg = (g, ACTQ_SIGN8, 8, 0, bias is not None, wdesc[:4] if wdesc is not None else None, 0)
+
+        def compute():
+            y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=codes.device)
+            aq = ActQ(ACTQ_SIGN8, 8, 0, 0, None)
+            wd = _wq_desc(wdesc)
+            with torch.cuda.device_of(codes):
+                ws, nb = _ws(g, 0, codes.device)
+                _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _ref(wd), _p(codes), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
+            return y
+        recipe = dict(codes=codes, wq=wq, bias=bias, geom=g, wdesc=wdesc, compute=compute)
+        return LazyConvOut((g.N, g.O, Ho, Wo), codes.device, recipe)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return QConv2d.backward(ctx, gy)[:9]
+
+
+def qconv_bnsign_supported(x, wq, stride, padding, dilation, groups, wdesc, in_shuffle):
+    if not isinstance(x, SignTensor) or wdesc is None or CONV_ALGO != _lib.MN_ALGO_AUTO:
+        return False
+    g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle or 0)
+    return bool(_lib_().mn_qconv_bnsign_supported(C.byref(g), _ref(_wq_desc(wdesc))))
+
+
+class ConvBNSign(Function):
+    """a = sign(batch_norm(y)) for a LazyConvOut y: conv, batch statistics, normalisation and sign in the fused kernels of
+    qgemm_sign.hip -- y is never written.  Backward = clip-STE of the sign through the BatchNorm backward, y recomputed."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training):
+        r = y.recipe
+        codes, wq, bias, g, wdesc = r["codes"], r["wq"], r["bias"], r["geom"], r["wdesc"]
+        gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
+        a = torch.empty(y.shape, dtype=torch.int8, device=codes.device)
+        save = torch.empty((2, g.O), dtype=torch.float32, device=codes.device)
+        wd = _wq_desc(wdesc)
+        with torch.cuda.device_of(codes):
+            nb = int(_lib_().mn_qconv_bnsign_ws_bytes(C.byref(g)))
+            ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
+            _call("mn_qconv_bnsign_fwd", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), float(eps), float(momentum),
+                  int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(ws), nb, _s())
+        ctx.save_for_backward(codes, wq, bias, gamma, beta, save, wdesc[4])
+        ctx.cfg = (g, wdesc[:4], int(training))
+        return SignTensor(a)
+
+    @staticmethod
+    def backward(ctx, da):
+        codes, wq, bias, gamma, beta, save, wscale = ctx.saved_tensors
+        g, wd4, training = ctx.cfg
+        da = _chk(da, "grad")
+        dy = torch.empty(da.shape, dtype=torch.float32, device=da.device)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        wd = _wq_desc(wd4 + (wscale,))
+        with torch.cuda.device_of(codes):
+            nb = int(_lib_().mn_qconv_bnsign_ws_bytes(C.byref(g)))
+            ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
+            _call("mn_qconv_bnsign_bwd", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), _p(save), _p(da), training,
+                  _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _s())
+        return dy, dgamma, dbeta, None, None, None, None, None
+
+
 def channel_shuffle(x, groups):
     """(N, g*c, H, W) -> interleave the g groups (models/nin_gc.py:4-15), materialised with torch."""
     n, ch, h, w = x.size()
@@ -491,10 +565,12 @@ def channel_shuffle(x, groups):
 
 
 def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None,
-            wdesc=None, x_is_code=False, in_shuffle=0):
+            wdesc=None, x_is_code=False, in_shuffle=0, lazy_for_bn=False):
     """``in_shuffle`` > 1: the convolution of ``channel_shuffle(x, in_shuffle)``; the permutation is folded into the kernels'
     channel addressing when the code-domain kernels cover all three passes, else materialised."""
     packed = isinstance(x, SignTensor)
+    if lazy_for_bn and packed and aq_mode == ACTQ_NONE and qconv_bnsign_supported(x, wq, stride, padding, dilation, groups, wdesc, in_shuffle):
+        return QConv2dLazy.apply(x, wq, bias, stride, padding, dilation, groups, wdesc, in_shuffle or 0)
     if packed or (in_shuffle and in_shuffle > 1):
         g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle or 0)
         aq = ActQ(ACTQ_SIGN8 if packed else aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)

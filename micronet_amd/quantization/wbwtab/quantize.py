@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from micronet_amd import ops
-from micronet_amd.sign_tensor import SignTensor
+from micronet_amd.sign_tensor import LazyConvOut, SignTensor
 
 __all__ = ["BinaryActivation", "BinaryWeight", "Ternary", "ActivationQuantizer", "meancenter_clamp_convparams",
            "WeightQuantizer", "QuantConv2d", "QuantConvTranspose2d", "BatchNorm2dBinAct", "MaxPool2dSign", "SignTensor",
@@ -100,6 +100,10 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
             self.num_batches_tracked.add_(1)
             if self.momentum is None:
                 momentum = 1.0 / float(self.num_batches_tracked)
+        if isinstance(input, LazyConvOut) and (use_batch or self.track_running_stats):
+            # the conv in front did not compute its output: conv + statistics + normalisation + sign in the fused kernels
+            return ops.ConvBNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                        self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
         out = ops.BNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, bool(self.packed))
         if not self.packed:
@@ -149,13 +153,15 @@ class QuantConv2d(nn.Conv2d):
         self.quant_inference = quant_inference
         self.weight_quantizer = WeightQuantizer(W=W)
         self.in_shuffle_groups = 0     # > 1: this conv reads channel_shuffle(input, groups) (set by prepare(), see add_quant_op)
+        self.lazy_for_bn = False       # True (set by prepare()): a packed BatchNorm2dBinAct consumes the output -> it may stay uncomputed
 
     def forward(self, input):
         tnn_bin_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
         # binary / ternary weights are t * alpha[o]: the conv contracts the integer codes t on the bf16 matrix cores
         coded = (not self.quant_inference) and self.weight_quantizer.W in (2, 3)
         return ops.qconv2d(input, tnn_bin_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
-                           wdesc=(ops.WQ_TERNARY, 0, 0, 0, None) if coded else None, in_shuffle=self.in_shuffle_groups)
+                           wdesc=(ops.WQ_TERNARY, 0, 0, 0, None) if coded else None, in_shuffle=self.in_shuffle_groups,
+                           lazy_for_bn=self.lazy_for_bn and coded)
 
 
 class QuantConvTranspose2d(nn.ConvTranspose2d):
@@ -178,11 +184,11 @@ def _ordered_parent(module):
 
 
 def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True,
-                 packed_activations=True):
+                 packed_activations=True, fuse_conv_bn=True):
     """Quantise conv k iff 1 < k < layer_num; every ReLU met while 0 < k < layer_num becomes the binary activation
     (ref 247-331).  With ``fuse_bn_act`` a plain BatchNorm2d directly in front of such a binary activation is switched to
     ``BatchNorm2dBinAct`` (same object, same state: only its class changes)."""
-    prev = None
+    prev = prev2 = None
     for name, child in module.named_children():
         if isinstance(child, nn.Conv2d):
             layer_counter[0] += 1
@@ -218,23 +224,28 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                 if fuse_bn_act and A == 2 and type(prev) is nn.BatchNorm2d and prev.affine and _ordered_parent(module):
                     prev.__class__ = BatchNorm2dBinAct
                     prev.packed = bool(packed_activations)
+                    if packed_activations and fuse_conv_bn and isinstance(prev2, QuantConv2d):
+                        prev2.lazy_for_bn = True        # conv -> bn -> sign in definition order: the conv output need never be stored
         elif type(child) is nn.MaxPool2d and packed_activations and A == 2:
             child.__class__ = MaxPool2dSign       # same object and state; pools SignTensors without unpacking them
         else:
             add_quant_op(child, layer_counter, layer_num, A=A, W=W, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act,
-                         fold_shuffle=fold_shuffle, packed_activations=packed_activations)
-        prev = child
+                         fold_shuffle=fold_shuffle, packed_activations=packed_activations, fuse_conv_bn=fuse_conv_bn)
+        prev2, prev = prev, module._modules[name]
 
 
-def prepare(model, inplace=False, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True, packed_activations=True):
+def prepare(model, inplace=False, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True, packed_activations=True,
+            fuse_conv_bn=True):
     """Same rewrite as the reference (ref 334-347); ``fuse_bn_act`` (ours, default on) additionally fuses BatchNorm2d with
     the binary activation that follows it (see ``BatchNorm2dBinAct``), and ``fold_shuffle`` (ours, default on) moves the
     channel shuffle of a ``ConvBNReLU`` block into its quantised conv's addressing -- numerically the same function;
     ``packed_activations`` (ours, default on) lets the fused BN+sign hand its +-1 output to the next conv / max-pool as one
-    byte per element (``SignTensor``), float32 for everybody else."""
+    byte per element (``SignTensor``), float32 for everybody else; ``fuse_conv_bn`` (ours, default on) lets a quantised
+    conv whose packed input and BatchNorm2dBinAct consumer are both ours skip writing its output (``LazyConvOut``): the fused
+    kernels recompute it on the matrix cores."""
     if not inplace:
         model = copy.deepcopy(model)
     layer_num = sum(isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) for m in model.modules())
     add_quant_op(model, [0], layer_num, A=A, W=W, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act, fold_shuffle=fold_shuffle,
-                 packed_activations=packed_activations)
+                 packed_activations=packed_activations, fuse_conv_bn=fuse_conv_bn)
     return model

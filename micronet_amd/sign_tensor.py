@@ -59,3 +59,48 @@ class SignTensor(torch.Tensor):
             return SignTensor(args[0]._mn_codes)
         un = lambda t: t._mn_codes.to(torch.float32) if isinstance(t, SignTensor) else t
         return func(*tree_map(un, args), **tree_map(un, kwargs))
+
+
+class LazyConvOut(torch.Tensor):
+    """The output of a binary-weight convolution on a SignTensor that has NOT been computed.
+
+    Between ``QuantConv2d`` and the ``BatchNorm2dBinAct`` that follows it the convolution result y (fp32, the largest tensor
+    of the block) would be written once and read back three times.  Its input is one byte per element and its weights are
+    ternary codes, so y is cheaper to RECOMPUTE on the matrix cores than to move: the conv module returns this wrapper (shape /
+    dtype / device / autograd of y, plus the recipe: input codes, fake-quantised weights, bias, geometry) and the fused
+    BatchNorm+sign kernels (``mn_qconv_bnsign_*``) consume the recipe directly.  Any other consumer triggers
+    ``__torch_dispatch__``, which runs the convolution kernel first -- it then sees exactly the tensor the reference produces."""
+
+    @staticmethod
+    def __new__(cls, shape, device, recipe):
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=torch.float32, device=device, requires_grad=False)
+        r._mn_recipe = recipe
+        r._mn_value = None
+        return r
+
+    def __init__(self, shape, device, recipe):
+        pass
+
+    @property
+    def recipe(self):
+        return self._mn_recipe
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_recipe["compute"]()
+        return self._mn_value
+
+    def __repr__(self):
+        return "LazyConvOut(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], LazyConvOut):
+            r = LazyConvOut(args[0].shape, args[0].device, args[0]._mn_recipe)
+            r._mn_value = args[0]._mn_value
+            return r
+        un = lambda t: t.materialize() if isinstance(t, LazyConvOut) else (t._mn_codes.to(torch.float32) if isinstance(t, SignTensor) else t)
+        return func(*tree_map(un, args), **tree_map(un, kwargs))

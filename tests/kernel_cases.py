@@ -421,3 +421,69 @@ def check_pool_sign8(be, shape=(3, 5, 8, 16), seed=0):
     be.call("mn_maxpool2x2_sign8_bwd", be.ptr(dG), be.ptr(dA), N * Cc, H, W, be.ptr(din), be.stream)
     assert np.array_equal(be.to_host(o8).astype(F), out.detach().numpy())
     assert np.array_equal(be.to_host(din), t.grad.numpy())
+
+
+def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, **_):
+    """mn_qconv_bnsign_fwd/bwd (conv + BatchNorm + sign on packed codes; y never stored) vs an fp64 numpy evaluation of the
+    same block on the same +-1 input and ternary-coded weights."""
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    Oc = w_shape[0]
+    HW = H * W
+    a_in = np.where(r.standard_normal(x_shape) > 0, 1, -1).astype(np.int8)
+    w, wkw, _ = make_coded_weights(r, w_shape, 1)
+    b = (r.standard_normal(Oc) * 0.2).astype(F) if bias else None
+    gamma, beta = (r.standard_normal(Oc) * 0.5 + 1).astype(F), (r.standard_normal(Oc) * 0.3).astype(F)
+    rm, rv = (r.standard_normal(Oc) * 0.1).astype(F), (np.abs(r.standard_normal(Oc)) * 20 + 5).astype(F)
+    da = r.standard_normal((N, Oc, H, W)).astype(F)
+    eps, mom = 1e-5, 0.1
+    x_log = a_in.astype(F)
+    if in_shuffle > 1:
+        x_log = np.ascontiguousarray(x_log.reshape(N, in_shuffle, Cin // in_shuffle, H, W).transpose(0, 2, 1, 3, 4).reshape(x_shape))
+    y64 = O.conv2d_fwd(x_log, w, b, groups=groups).astype(np.float64)      # exact: integer sums times alpha (+ bias), rounded once to fp32
+    n = N * HW
+    if training:
+        mean = y64.mean(axis=(0, 2, 3)); var_b = y64.var(axis=(0, 2, 3)); var_u = var_b * n / (n - 1)
+    else:
+        mean, var_b = rm.astype(np.float64), rv.astype(np.float64)
+    invstd = 1.0 / np.sqrt(var_b + eps)
+    zh = (y64 - mean.reshape(1, -1, 1, 1)) * invstd.reshape(1, -1, 1, 1)
+    z = zh * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
+    a_ref = np.where(z < 0, -1, 1)
+    dz = np.where((z > -1) & (z < 1), da.astype(np.float64), 0.0)
+    dbeta_ref, dgamma_ref = dz.sum(axis=(0, 2, 3)), (dz * zh).sum(axis=(0, 2, 3))
+    gi = (gamma * invstd).reshape(1, -1, 1, 1)
+    dy_ref = gi * (dz - dbeta_ref.reshape(1, -1, 1, 1) / n - zh * dgamma_ref.reshape(1, -1, 1, 1) / n) if training else gi * dz
+
+    g = be.geom(x_shape, w_shape, groups=groups)
+    g.in_shuffle = in_shuffle
+    wq = be.wq(**wkw)
+    assert be.lib.mn_qconv_bnsign_supported(C.byref(g), C.byref(wq)) == 1
+    nb = int(be.lib.mn_qconv_bnsign_ws_bytes(C.byref(g)))
+    ws = be.empty(nb // 4 + 8)
+    dA, dW, dB = be.to_dev_i8(a_in), be.to_dev(w), (be.to_dev(b) if bias else None)
+    dG, dBe, dRM, dRV, dDA = be.to_dev(gamma), be.to_dev(beta), be.to_dev(rm), be.to_dev(rv), be.to_dev(da)
+    save, a8 = be.empty((2, Oc)), be.empty_i8((N, Oc, H, W))
+    be.call("mn_qconv_bnsign_fwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
+            be.ptr(dRM), be.ptr(dRV), be.ptr(save), be.ptr(a8), be.ptr(ws), nb, be.stream)
+    dy, dgam, dbet = be.empty((N, Oc, H, W)), be.empty(Oc), be.empty(Oc)
+    be.call("mn_qconv_bnsign_bwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save), be.ptr(dDA),
+            int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)
+    sv = be.to_host(save)
+    assert np.max(np.abs(sv[0] - mean)) <= 2e-6 * max(1.0, np.max(np.abs(mean))) and np.max(np.abs(sv[1] - invstd) / invstd) <= 4e-6
+    a_got = be.to_host(a8).astype(np.int64)
+    safe = np.abs(z) > 2e-5
+    assert np.all(np.abs(a_got) == 1) and np.array_equal(a_got[safe], a_ref[safe])
+    if training:
+        assert np.max(np.abs(be.to_host(dRM) - ((1 - mom) * rm + mom * mean))) <= 2e-6 * max(1.0, np.max(np.abs(mean)))
+        assert np.max(np.abs(be.to_host(dRV) - ((1 - mom) * rv + mom * var_u))) <= 4e-6 * np.max(np.maximum(var_u, rv))
+    else:
+        assert eq(be.to_host(dRM), rm) and eq(be.to_host(dRV), rv)
+    edge = (np.abs(np.abs(z) - 1) < 2e-5).any()
+    tol = 1e-3 if edge else 2e-5
+    assert close(be.to_host(dbet), dbeta_ref, tol) and close(be.to_host(dgam), dgamma_ref, tol)
+    assert close(be.to_host(dy), dy_ref, tol)
+    # the plain forward on sign codes (PWS_Y through mn_conv2d_fwd) against the same y
+    aq = be.actq(3)
+    y = be.to_host(be.conv_fwd(g, aq, dA, dW, dB, 3, wq=wq))
+    assert close(y, y64, 1e-6)

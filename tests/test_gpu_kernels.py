@@ -256,3 +256,16 @@ def test_pool_sign8(be):
     K.check_pool_sign8(be)
     K.check_pool_sign8(be, shape=(2, 3, 2, 8), seed=1)
     K.check_pool_sign8(be, shape=(16, 64, 32, 32), seed=2)
+
+
+@pytest.mark.parametrize("case", range(len(K.QGEMM_PW_CASES)))
+@pytest.mark.parametrize("training", [True, False])
+def test_qconv_bnsign_fused(be, case, training):
+    K.check_qconv_bnsign(be, seed=170 + case, training=training, **K.QGEMM_PW_CASES[case])
+
+
+def test_qconv_bnsign_fused_hot_shapes(be):
+    K.check_qconv_bnsign(be, seed=180, in_shuffle=2, **K.QGEMM_PW_CASES[1])
+    K.check_qconv_bnsign(be, seed=181, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)      # nin_gc L3
+    K.check_qconv_bnsign(be, seed=182, x_shape=(8, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=16)     # L5
+    K.check_qconv_bnsign(be, seed=183, x_shape=(16, 1024, 8, 8), w_shape=(1024, 128, 1, 1), groups=8, in_shuffle=32)    # L8

@@ -133,3 +133,14 @@ def test_qgemm_sign8_shuffle(be):
 def test_pool_sign8(be):
     K.check_pool_sign8(be)
     K.check_pool_sign8(be, shape=(2, 3, 2, 8), seed=1)
+
+
+@pytest.mark.parametrize("case", range(len(K.QGEMM_PW_CASES)))
+@pytest.mark.parametrize("training", [True, False])
+def test_qconv_bnsign_fused(be, case, training):
+    K.check_qconv_bnsign(be, seed=170 + case, training=training, **K.QGEMM_PW_CASES[case])
+
+
+def test_qconv_bnsign_fused_shuffle_and_wide(be):
+    K.check_qconv_bnsign(be, seed=180, in_shuffle=2, **K.QGEMM_PW_CASES[1])
+    K.check_qconv_bnsign(be, seed=181, x_shape=(2, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)   # KS = 4, two m-blocks: the nin_gc pattern
