@@ -186,6 +186,10 @@ typedef struct mn_wq {
 int64_t mn_conv2d_ws_bytes(const mn_conv_geom* g, int which, int algo);
 /* 1 if MN_ALGO_MFMA supports this geometry for `which` */
 int mn_conv2d_mfma_supported(const mn_conv_geom* g, int which);
+/* 1 if the first-layer kernels (real fp32 operands, groups 1, stride 1, "same" padding, Cin*KH*KW <= 76: the un-quantised first
+ * convolution of the DoReFa / WbWtAb nets, wqaq/dorefa/quantize.py:206, wbwtab/quantize.py:251) cover `which` (0 fwd, 2 bwd_weight);
+ * MN_ALGO_AUTO uses them when no activation quantizer is fused. */
+int mn_conv2d_first_supported(const mn_conv_geom* g, int which);
 /* 1 if MN_ALGO_QGEMM supports this geometry and quantizer combination for `which` (aq / wq may be NULL = none / real) */
 int mn_conv2d_qgemm_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
 /* y[N][O][Ho][Wo] = conv2d(actq(x), w, bias); w are the (already fake-quantised) fp32 weights, wq says how they factor

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),
     "mn_conv2d_mfma_supported": (_I, [_G, _I]),
+    "mn_conv2d_first_supported": (_I, [_G, _I]),
     "mn_conv2d_qgemm_supported": (_I, [_G, _A, _W, _I]),
     "mn_conv2d_fwd": (_I, [_G, _A, _W, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mn_conv2d_bwd_data": (_I, [_G, _A, _W, _P, _P, _P, _P, _P, _L, _I, _P]),

@@ -1,0 +1,322 @@
+// First-layer convolution (few input channels, real-valued fp32 operands) for gfx950: forward and backward-weight.
+//
+// The first convolution of the reference's nets reads the image (3 channels) with full-precision weights (it is skipped by
+// the DoReFa and WbWtAb rewrites: wqaq/dorefa/quantize.py:206, wbwtab/quantize.py:251).  K = Cin*KH*KW is tiny (75 for
+// nin_gc's 5x5, 27 for resnet's 3x3) while the output is the LARGEST tensor of the net, so the layer is bound by writing y
+// (forward) / reading gy (backward-weight) -- unless the contraction is done badly: generic implicit-GEMM tilings pad the
+// 3 channels of every tap to a K-step of 4 and stage operands they barely reuse (this library's fp32 kernel: 196 us forward,
+// 1078 us backward-weight on nin_gc L1 at batch 256; MIOpen: 341 / 393 us incl. its bias kernels and layout transposes).
+// Here the whole im2col row k = (c, r, s) is the contraction index: ceil(K/4) steps of v_mfma_f32_16x16x4_f32 (exact fp32
+// products, fp32 accumulate -- the arithmetic of the reference's F.conv2d), the image strip sits in LDS with its zero halo,
+// and the OTHER operand streams through registers exactly once:
+//   forward : weights are A fragments held in registers for the whole kernel (19 x MT floats per lane); the patch value
+//             B[k][pixel] is one LDS read shared by the MT out-channel tiles; D[channel][pixel] leaves each lane with
+//             float4 = 4 consecutive pixels per out-channel (256-B runs per 16 lanes) + bias.
+//   wgrad   : gy streams as A[channel][pixel] (float4 per lane = 4 K-steps), the patch as B[pixel][k] from LDS;
+//             D[channel][k] accumulates over the block's pixels; dbias falls out of the streamed gy; a second kernel reduces
+//             the per-block partial tiles in a fixed order (fp64), deterministic.
+// Geometry: groups 1, stride 1, dilation 1, "same" padding (Ho = H, Wo = W), W % 4 == 0, K <= 76 -- anything else stays on
+// the generic kernels.
+#include "qgemm_dev.h"
+
+#define C1_KS 19          // K-steps of 4: K <= 76
+#define MN_MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+
+struct C1Params {
+    const float* x;       // [N][C][H][W]
+    const float* wp;      // packed weights [KS*4][Opad]  (fwd)
+    const float* bias;
+    float* y;             // fwd out [N][O][H][W]
+    const float* gy;      // wgrad in
+    float* part;          // wgrad partials [Z][Opad][80]
+    float* dbpart;        // [Z][Opad]
+    int N, C, H, W, O, KH, KW, ph, pw, K, KS, Opad;
+    int R, strips, PR, PW, CS;      // strip of R output rows; LDS patch rows / row pitch / channel stride
+    int Z, want_db;
+    FastDiv fd_w;
+};
+
+// stage the image strip (with zero halo) of image n, rows [row0 - ph, row0 + R + KH - 1 - ph) into xs[c][prow][pcol]
+__device__ __forceinline__ void c1_stage(const C1Params& p, float* xs, int n, int row0) {
+    const int per_c = p.PR * p.PW, total = p.C * per_c;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int c = i / per_c, rem = i - c * per_c;
+        const int pr = rem / p.PW, pc = rem - pr * p.PW;
+        const int ir = row0 - p.ph + pr, ic = pc - p.pw;
+        float v = 0.f;
+        if (ir >= 0 && ir < p.H && ic >= 0 && ic < p.W) v = p.x[(((int64_t)n * p.C + c) * p.H + ir) * p.W + ic];
+        xs[c * p.CS + pr * p.PW + pc] = v;
+    }
+}
+// LDS offset of im2col row k = (c, r, s) relative to the top-left tap of a pixel
+__device__ __forceinline__ int c1_koff(const C1Params& p, int k) {
+    if (k >= p.K) return 0;          // padded rows: their weights / accumulators are never used
+    const int T = p.KH * p.KW;
+    const int c = k / T, t = k - c * T, r = t / p.KW, s = t - r * p.KW;
+    return c * p.CS + r * p.PW + s;
+}
+
+// forward: block = (image, strip of R rows, 64*MT out-channels per wave x 4 waves)
+template <int MT>
+__global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* xs = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    uint32_t b = blockIdx.x;
+    const int strip = b % p.strips; b /= p.strips;
+    const int n = b % p.N;
+    const int cblk = b / p.N;
+    const int row0 = strip * p.R;
+    const int m0 = (cblk * 4 + wave) * 16 * MT;              // first out-channel of this wave
+
+    c1_stage(p, xs, n, row0);
+    // A fragments: wa[s][t] = w[m0 + t*16 + j][k = 4s + kq]
+    float wa[C1_KS][MT];
+    int koff[C1_KS];
+#pragma unroll
+    for (int s = 0; s < C1_KS; ++s) {
+        koff[s] = c1_koff(p, 4 * s + kq);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) wa[s][t] = (s < p.KS) ? p.wp[(int64_t)(4 * s + kq) * p.Opad + m0 + t * 16 + j] : 0.f;
+    }
+    __syncthreads();
+
+    const int npix = p.R * p.W, nchunks = (npix + 63) >> 6;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int pix = chunk * 64 + 4 * j;
+        const bool pv = pix < npix;
+        const uint32_t prow = fd_div(pv ? pix : 0, p.fd_w);
+        const int pcol = (pv ? pix : 0) - prow * p.W;
+        const int pb = (int)prow * p.PW + pcol;               // top-left tap of pixel (4j + 0)
+        f32x4 acc[4][MT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < C1_KS; ++s) {
+            if (s < p.KS) {
+                const float* src = xs + pb + koff[s];
+                const float b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    acc[0][t] = MN_MFMA_F32(wa[s][t], b0, acc[0][t]);
+                    acc[1][t] = MN_MFMA_F32(wa[s][t], b1, acc[1][t]);
+                    acc[2][t] = MN_MFMA_F32(wa[s][t], b2, acc[2][t]);
+                    acc[3][t] = MN_MFMA_F32(wa[s][t], b3, acc[3][t]);
+                }
+            }
+        }
+        // D[row = channel 4kq + r][col = pixel j]: across q a float4 of 4 consecutive pixels per channel
+        if (pv) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + t * 16 + kq * 4 + r;
+                    if (m < p.O) {
+                        const float bb = p.bias ? p.bias[m] : 0.f;
+                        float* dst = p.y + (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol;
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][t][r] + bb, acc[1][t][r] + bb, acc[2][t][r] + bb, acc[3][t][r] + bb);
+                    }
+                }
+        }
+    }
+}
+
+// backward-weight: block z accumulates dw over its share of (image, strip) tiles for the 64*MT... out-channels of its channel block.
+// wave w owns out-channels [m0, m0 + 16*MT); the five 16-wide tiles of the k axis cover K <= 80.
+template <int MT>
+__global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* xs = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    uint32_t b = blockIdx.x;
+    const int z = b % p.Z;
+    const int cblk = b / p.Z;
+    const int m0 = (cblk * 4 + wave) * 16 * MT;
+    int koff[5];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) koff[nt] = c1_koff(p, nt * 16 + j);     // B[pixel][k = nt*16 + j]
+
+    f32x4 acc[MT][5];
+    float dbs[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        dbs[t] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int ntiles = p.N * p.strips, npix = p.R * p.W, nsteps = npix >> 4;     // 16 pixels per step (R*W % 16 == 0)
+    for (int tile = z; tile < ntiles; tile += p.Z) {
+        const int n = tile / p.strips, strip = tile - n * p.strips, row0 = strip * p.R;
+        __syncthreads();                      // previous tile's patch fully consumed
+        c1_stage(p, xs, n, row0);
+        __syncthreads();
+        // A[i = channel j][k = kq]: float4 = pixels st*16 + 4kq + e, e = MFMA step; loaded one step ahead
+        auto load_g = [&](float4 (&dst)[MT], int st) {
+            const int pix = st * 16 + 4 * kq;
+            const uint32_t prow = fd_div(pix, p.fd_w);
+            const int pcol = pix - prow * p.W;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int m = m0 + t * 16 + j;
+                dst[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < p.O) dst[t] = *reinterpret_cast<const float4*>(p.gy + (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol);
+            }
+        };
+        float4 gn[MT];
+        load_g(gn, 0);
+        for (int st = 0; st < nsteps; ++st) {
+            const int pix = st * 16 + 4 * kq;
+            const uint32_t prow = fd_div(pix, p.fd_w);
+            const int pcol = pix - prow * p.W;
+            float4 ga[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { ga[t] = gn[t]; dbs[t] += (ga[t].x + ga[t].y) + (ga[t].z + ga[t].w); }
+            if (st + 1 < nsteps) load_g(gn, st + 1);
+            const int pb = (int)prow * p.PW + pcol;
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                const float* src = xs + pb + koff[nt];
+                const float b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    acc[t][nt] = MN_MFMA_F32(ga[t].x, b0, acc[t][nt]);
+                    acc[t][nt] = MN_MFMA_F32(ga[t].y, b1, acc[t][nt]);
+                    acc[t][nt] = MN_MFMA_F32(ga[t].z, b2, acc[t][nt]);
+                    acc[t][nt] = MN_MFMA_F32(ga[t].w, b3, acc[t][nt]);
+                }
+            }
+        }
+    }
+    // D[row = channel 4kq + r][col = k = nt*16 + j]
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + t * 16 + kq * 4 + r;
+                p.part[((int64_t)z * p.Opad + m) * 80 + nt * 16 + j] = acc[t][nt][r];
+            }
+        if (p.want_db) {
+            float v = dbs[t];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);      // the four kq groups hold different pixels of channel j
+            if (kq == 0) p.dbpart[(int64_t)z * p.Opad + m0 + t * 16 + j] = v;
+        }
+    }
+}
+// wp[k][Opad] = w[m][k] (k = (c, r, s) in OIHW order), zero padded
+__global__ __launch_bounds__(256) void k_c1_pack(const float* __restrict__ w, float* __restrict__ wp, int O, int K, int Opad, int Kp) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Kp * Opad; i += gridDim.x * 256) {
+        const int k = i / Opad, m = i - k * Opad;
+        wp[i] = (k < K && m < O) ? w[(int64_t)m * K + k] : 0.f;
+    }
+}
+// fixed-order fp64 reduction of the Z partial tiles: dw[m][k], dbias[m]
+__global__ __launch_bounds__(256) void k_c1_reduce(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw, float* __restrict__ db,
+                                                   int Z, int O, int K, int Opad) {
+    const int64_t nw = (int64_t)O * K, total = nw + (db ? O : 0);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        double s = 0.0;
+        if (i < nw) {
+            const int m = (int)(i / K), k = (int)(i - (int64_t)m * K);
+            for (int z = 0; z < Z; ++z) s += (double)part[((int64_t)z * Opad + m) * 80 + k];
+            dw[i] = (float)s;
+        } else {
+            const int m = (int)(i - nw);
+            for (int z = 0; z < Z; ++z) s += (double)dbpart[(int64_t)z * Opad + m];
+            db[m] = (float)s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct C1Plan {
+    C1Params p;
+    int MT, grid_f, grid_w, cblks;
+    size_t lds;
+    int64_t wp_bytes, off_db, ws_bytes_f, ws_bytes_w;
+};
+static int plan_c1(const mn_conv_geom* g, C1Plan* pl) {
+    if (g->groups != 1 || g->stride_h != 1 || g->stride_w != 1 || g->dil_h != 1 || g->dil_w != 1 || g->in_shuffle > 1) return 0;
+    if (2 * g->pad_h != g->KH - 1 || 2 * g->pad_w != g->KW - 1) return 0;       // "same": Ho = H, Wo = W
+    const int K = g->C * g->KH * g->KW;
+    if (K > 76 || g->W % 4 || g->W < 4) return 0;
+    C1Params& p = pl->p;
+    p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.KH = g->KH; p.KW = g->KW; p.ph = g->pad_h; p.pw = g->pad_w;
+    p.K = K; p.KS = (K + 3) / 4;
+    pl->MT = g->O > 128 ? 4 : (g->O > 64 ? 2 : 1);
+    const int per_blk = 64 * pl->MT;                      // out-channels per block (4 waves)
+    pl->cblks = (g->O + per_blk - 1) / per_blk;
+    p.Opad = pl->cblks * per_blk;
+    int R = g->H;                                          // strip height: halve while that keeps 16-pixel steps and fills the chip
+    while (R % 2 == 0 && ((R / 2) * g->W) % 64 == 0 && (int64_t)g->N * (g->H / R) * pl->cblks < 1024) R /= 2;
+    if ((R * g->W) % 16) return 0;
+    p.R = R; p.strips = g->H / R;
+    p.PR = R + g->KH - 1; p.PW = g->W + g->KW - 1 + 3;     // + 3: the 4-wide reads of the last pixel quad stay inside the row
+    p.CS = p.PR * p.PW;
+    pl->lds = (size_t)g->C * p.CS * 4 + 64;
+    if (pl->lds > 64 * 1024) return 0;
+    p.fd_w = make_fastdiv((uint32_t)g->W);
+    const int64_t nbf = (int64_t)g->N * p.strips * pl->cblks;
+    if (nbf > 0x7fffffff) return 0;
+    pl->grid_f = (int)nbf;
+    const int ntiles = g->N * p.strips;
+    int Z = 512 / pl->cblks;
+    if (Z > ntiles) Z = ntiles;
+    if (Z < 1) Z = 1;
+    p.Z = Z;
+    pl->grid_w = Z * pl->cblks;
+    pl->wp_bytes = (int64_t)C1_KS * 4 * p.Opad * 4;
+    pl->ws_bytes_f = pl->wp_bytes;
+    const int64_t part_bytes = (int64_t)Z * p.Opad * 80 * 4;
+    pl->off_db = (part_bytes + 255) / 256 * 256;
+    pl->ws_bytes_w = pl->off_db + (int64_t)Z * p.Opad * 4;
+    return 1;
+}
+int c1_supported(const mn_conv_geom* g, int which) {
+    C1Plan pl;
+    return (which == 0 || which == 2) && plan_c1(g, &pl);
+}
+int64_t c1_ws_bytes(const mn_conv_geom* g, int which) {
+    C1Plan pl;
+    if (!plan_c1(g, &pl)) return 0;
+    return which == 0 ? pl.ws_bytes_f : (which == 2 ? pl.ws_bytes_w : 0);
+}
+int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes, hipStream_t s) {
+    C1Plan pl;
+    if (!plan_c1(g, &pl) || !aligned16(y)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(first-layer): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes_f || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(first-layer): workspace too small");
+    C1Params& p = pl.p;
+    float* wp = (float*)ws;
+    hipLaunchKernelGGL(k_c1_pack, dim3(mn_grid_for((int64_t)C1_KS * 4 * p.Opad, 256, 256)), dim3(256), 0, s, w, wp, p.O, p.K, p.Opad, C1_KS * 4);
+    p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0;
+    mn_set_last_kernel("k_c1_fwd<%d>", pl.MT);
+    mn_prof_begin(s);
+    if (pl.MT == 4) { raise_lds_limit((const void*)k_c1_fwd<4>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<4>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }
+    else if (pl.MT == 2) { raise_lds_limit((const void*)k_c1_fwd<2>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<2>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }
+    else { raise_lds_limit((const void*)k_c1_fwd<1>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<1>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_conv2d_fwd(first-layer)");
+    return MN_OK;
+}
+int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    C1Plan pl;
+    if (!plan_c1(g, &pl) || !aligned16(gy)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(first-layer): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes_w || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(first-layer): workspace too small");
+    C1Params& p = pl.p;
+    p.x = x; p.gy = gy; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
+    p.wp = nullptr; p.bias = nullptr; p.y = nullptr;
+    mn_set_last_kernel("k_c1_wgrad<%d>", pl.MT);
+    mn_prof_begin(s);
+    if (pl.MT == 4) { raise_lds_limit((const void*)k_c1_wgrad<4>, pl.lds); hipLaunchKernelGGL(k_c1_wgrad<4>, dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    else if (pl.MT == 2) { raise_lds_limit((const void*)k_c1_wgrad<2>, pl.lds); hipLaunchKernelGGL(k_c1_wgrad<2>, dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    else { raise_lds_limit((const void*)k_c1_wgrad<1>, pl.lds); hipLaunchKernelGGL(k_c1_wgrad<1>, dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    mn_prof_end(s);
+    const int64_t total = (int64_t)p.O * p.K + (dbias ? p.O : 0);
+    hipLaunchKernelGGL(k_c1_reduce, dim3(mn_grid_for(total, 256, 1024)), dim3(256), 0, s, (const float*)p.part, (const float*)p.dbpart, dw, dbias, p.Z, p.O, p.K, p.Opad);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(first-layer)");
+    return MN_OK;
+}

@@ -650,12 +650,17 @@ extern "C" int64_t mn_conv2d_ws_bytes(const mn_conv_geom* g, int which, int algo
     if (algo == MN_ALGO_DIRECT) return 0;
     if (which < 0 || which > 2) return -1;
     int64_t q = (algo == MN_ALGO_AUTO || algo == MN_ALGO_QGEMM) ? qg_ws_bytes(g, which) : 0;
+    if (algo == MN_ALGO_AUTO) { const int64_t c1 = c1_ws_bytes(g, which); q = q > c1 ? q : c1; }
     int64_t m = 0;
     if (algo == MN_ALGO_AUTO || algo == MN_ALGO_MFMA) {
         if (which == 0 || which == 1) { FwdPlan pl; m = plan_fwd_view(g, which, &pl) ? pl.wp_floats * 4 : 0; }
         else { WgradPlan pl; m = plan_wgrad(g, &pl) ? pl.part_floats * 4 : 0; }
     }
     return q > m ? q : m;
+}
+extern "C" int mn_conv2d_first_supported(const mn_conv_geom* g, int which) {
+    if (check_geom(g, "mn_conv2d_first_supported") != MN_OK) return 0;
+    return c1_supported(g, which);
 }
 extern "C" int mn_conv2d_qgemm_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
     if (check_geom(g, "mn_conv2d_qgemm_supported") != MN_OK) return 0;
@@ -704,6 +709,8 @@ extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_
     }
     if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, wq, 0) && aligned16(x) && aligned16(y)))
         return qg_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
+    if (algo == MN_ALGO_AUTO && pro.mode == MN_ACTQ_NONE && c1_supported(g, 0) && aligned16(y) && ws && ws_bytes >= c1_ws_bytes(g, 0))
+        return c1_fwd(g, x, w, bias, y, ws, ws_bytes, s);          // un-quantised first layer: real fp32 operands
     if (g->in_shuffle > 1) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: in_shuffle is only available on the code-domain kernels");
     if (pro.mode == MN_ACTQ_SIGN8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: int8 sign codes are only read by the code-domain kernels");
     FwdPlan pl;
@@ -779,6 +786,8 @@ extern "C" int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, co
         mn_prof_bytes((pro.mode == MN_ACTQ_SIGN8 ? 1.0 : 4.0) * nx + 4.0 * (ny + nw));
     }
     const int Ho = out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+    if (algo == MN_ALGO_AUTO && pro.mode == MN_ACTQ_NONE && c1_supported(g, 2) && aligned16(gy) && ws && ws_bytes >= c1_ws_bytes(g, 2))
+        return c1_bwd_weight(g, gy, x, dw, dbias, ws, ws_bytes, s);   // first layer: K = Cin*KH*KW <= 76, exact fp32 MFMA
     if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, nullptr, 2) && aligned16(x) && aligned16(gy)))
         return qg_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
     if (g->in_shuffle > 1) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight: in_shuffle is only available on the code-domain kernels");

@@ -9,6 +9,11 @@ int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const floa
            void* ws, int64_t ws_bytes, hipStream_t s);
 int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
                 void* ws, int64_t ws_bytes, hipStream_t s);
+// first-layer convolution, real fp32 operands, K = Cin*KH*KW <= 76 (conv_first.hip); which: 0 fwd, 2 bwd_weight
+int c1_supported(const mn_conv_geom* g, int which);
+int64_t c1_ws_bytes(const mn_conv_geom* g, int which);
+int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes, hipStream_t s);
+int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 // pointwise convolution on int8 sign codes, fused BatchNorm + sign epilogues (qgemm_sign.hip)
 int pws_supported(const mn_conv_geom* g, const mn_wq* wq);
 int64_t pws_ws_bytes(const mn_conv_geom* g);

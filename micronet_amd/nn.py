@@ -1,0 +1,21 @@
+"""Plain (un-quantised) layers of the reference nets that sit ON the QAT step and are worth a gfx950 kernel.
+
+``Conv2dFirst``: the first convolution of a net is skipped by the DoReFa and WbWtAb rewrites (wqaq/dorefa/quantize.py:206,
+wbwtab/quantize.py:251) and stays an ``nn.Conv2d`` -- but its output is the largest tensor of the step.  ``prepare()`` switches
+that module (same object, same parameters, same ``state_dict``) to this subclass, whose forward / backward-weight run on
+``conv_first.hip`` (exact fp32 products on v_mfma_f32_16x16x4_f32, bias and dbias fused) whenever the geometry is covered;
+anything else falls through to ``nn.Conv2d``."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .sign_tensor import LazyConvOut, SignTensor
+
+
+class Conv2dFirst(nn.Conv2d):
+    def forward(self, input):
+        if (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and self.padding_mode == "zeros" and
+                not isinstance(input, (SignTensor, LazyConvOut)) and not isinstance(self.padding, str) and
+                ops.first_conv_supported(input.shape, self.weight.shape, self.stride, self.padding, self.dilation, self.groups)):
+            return ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        return super().forward(input)

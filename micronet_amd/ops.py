@@ -637,3 +637,12 @@ class ConvTranspose2d(Function):
             if has_bias and ctx.needs_input_grad[2]:
                 db = gy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None, None
+
+
+def first_conv_supported(x_shape, w_shape, stride, padding, dilation, groups):
+    """True when the first-layer kernels (conv_first.hip: real fp32 operands, Cin*KH*KW <= 76) cover forward and backward-weight."""
+    if CONV_ALGO != _lib.MN_ALGO_AUTO:
+        return False
+    g = _geom(x_shape, w_shape, stride, padding, dilation, groups)
+    lib = _lib_()
+    return bool(lib.mn_conv2d_first_supported(C.byref(g), 0)) and bool(lib.mn_conv2d_first_supported(C.byref(g), 2))

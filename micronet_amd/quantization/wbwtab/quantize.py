@@ -15,6 +15,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from micronet_amd import ops
+from micronet_amd.nn import Conv2dFirst
 from micronet_amd.sign_tensor import LazyConvOut, SignTensor
 
 __all__ = ["BinaryActivation", "BinaryWeight", "Ternary", "ActivationQuantizer", "meancenter_clamp_convparams",
@@ -207,6 +208,8 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                         and getattr(module, "shuffle_groups", 1) > 1 and child.in_channels % module.shuffle_groups == 0:
                     new.in_shuffle_groups = int(module.shuffle_groups)
                     module.channel_shuffle_flag = 0
+            elif layer_counter[0] == 1 and type(child) is nn.Conv2d:
+                child.__class__ = Conv2dFirst       # the un-quantised first conv: same object and state, gfx950 kernels when covered
         elif isinstance(child, nn.ConvTranspose2d):
             layer_counter[0] += 1
             if 1 < layer_counter[0] < layer_num:

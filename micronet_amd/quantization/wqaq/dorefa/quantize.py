@@ -144,6 +144,9 @@ def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=Fals
             layer_counter[0] += 1
             if layer_counter[0] > 1:
                 module._modules[name] = _swap_conv(child, QuantConv2d, **kw)
+            elif type(child) is nn.Conv2d:
+                from micronet_amd.nn import Conv2dFirst
+                child.__class__ = Conv2dFirst      # the un-quantised first conv: same object and state, gfx950 kernels when covered
         elif isinstance(child, nn.ConvTranspose2d):
             layer_counter[0] += 1
             if layer_counter[0] > 1:

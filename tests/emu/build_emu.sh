@@ -9,8 +9,9 @@ $CXX -c micronet_amd/csrc/conv_kernels.hip -o tests/emu/build/conv_kernels.o &
 $CXX -c micronet_amd/csrc/qgemm_kernels.hip -o tests/emu/build/qgemm_kernels.o &
 $CXX -c micronet_amd/csrc/qgemm_kxk.hip -o tests/emu/build/qgemm_kxk.o &
 $CXX -c micronet_amd/csrc/qgemm_sign.hip -o tests/emu/build/qgemm_sign.o &
+$CXX -c micronet_amd/csrc/conv_first.hip -o tests/emu/build/conv_first.o &
 $CXX -c micronet_amd/csrc/optim_kernels.hip -o tests/emu/build/optim_kernels.o &
 $CXX -c micronet_amd/csrc/norm_kernels.hip -o tests/emu/build/norm_kernels.o &
 wait
-g++ -shared -o tests/emu/build/libmicronet_emu.so tests/emu/build/quant_kernels.o tests/emu/build/conv_kernels.o tests/emu/build/qgemm_kernels.o tests/emu/build/qgemm_kxk.o tests/emu/build/qgemm_sign.o tests/emu/build/optim_kernels.o tests/emu/build/norm_kernels.o
+g++ -shared -o tests/emu/build/libmicronet_emu.so tests/emu/build/quant_kernels.o tests/emu/build/conv_kernels.o tests/emu/build/qgemm_kernels.o tests/emu/build/qgemm_kxk.o tests/emu/build/qgemm_sign.o tests/emu/build/conv_first.o tests/emu/build/optim_kernels.o tests/emu/build/norm_kernels.o
 echo built tests/emu/build/libmicronet_emu.so

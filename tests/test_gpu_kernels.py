@@ -269,3 +269,20 @@ def test_qconv_bnsign_fused_hot_shapes(be):
     K.check_qconv_bnsign(be, seed=181, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)      # nin_gc L3
     K.check_qconv_bnsign(be, seed=182, x_shape=(8, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=16)     # L5
     K.check_qconv_bnsign(be, seed=183, x_shape=(16, 1024, 8, 8), w_shape=(1024, 128, 1, 1), groups=8, in_shuffle=32)    # L8
+
+
+FIRST_CASES = [
+    dict(x_shape=(3, 3, 8, 8), w_shape=(24, 3, 5, 5), padding=2),
+    dict(x_shape=(2, 3, 16, 16), w_shape=(160, 3, 3, 3), padding=1),
+    dict(x_shape=(2, 1, 8, 16), w_shape=(70, 1, 3, 3), padding=1, bias=False),
+    dict(x_shape=(8, 3, 32, 32), w_shape=(256, 3, 5, 5), padding=2),                 # nin_gc L1
+    dict(x_shape=(8, 3, 32, 32), w_shape=(64, 3, 3, 3), padding=1, bias=False),      # resnet conv1
+]
+
+
+@pytest.mark.parametrize("case", range(len(FIRST_CASES)))
+def test_conv_first_layer(be, case):
+    kw = FIRST_CASES[case]
+    g = be.geom(kw["x_shape"], kw["w_shape"], padding=kw["padding"])
+    assert be.lib.mn_conv2d_first_supported(C.byref(g), 0) == 1 and be.lib.mn_conv2d_first_supported(C.byref(g), 2) == 1
+    K.check_conv(be, seed=200 + case, algos=(0,), rel=2e-6 if case < 3 else 1e-5, **kw)     # fp32 accumulation over 8k pixels per partial

@@ -383,3 +383,30 @@ def test_wbwtab_fused_conv_bn_matches_unfused():
     a.eval(), b.eval()
     ea, eb = a(x), b(x)
     assert rel_err(ea.detach().cpu(), eb.detach().cpu()) <= 0.2
+
+
+def test_first_conv_runs_on_our_kernels_and_matches_torch():
+    """prepare() switches the un-quantised first conv to Conv2dFirst (conv_first.hip); output and gradients match nn.Conv2d."""
+    from micronet_amd.nn import Conv2dFirst
+    from micronet_amd import ops
+    for mod in ("wbwtab", "wqaq.dorefa"):
+        q = _q(mod)
+        net = nn.Sequential(nn.Conv2d(3, 96, 5, padding=2), nn.BatchNorm2d(96), nn.ReLU(), nn.Conv2d(96, 32, 1), nn.BatchNorm2d(32), nn.ReLU(),
+                            nn.Conv2d(32, 10, 1)).cuda()
+        p = q.prepare(net, inplace=False)
+        assert type(p[0]) is Conv2dFirst and isinstance(p[0], nn.Conv2d) and list(p.state_dict()) == list(net.state_dict())
+    torch.manual_seed(0)
+    ref = nn.Conv2d(3, 96, 5, padding=2).cuda()
+    ours = Conv2dFirst(3, 96, 5, padding=2).cuda()
+    ours.load_state_dict(ref.state_dict())
+    x = torch.randn(16, 3, 32, 32, device="cuda")
+    assert ops.first_conv_supported(x.shape, ours.weight.shape, ours.stride, ours.padding, ours.dilation, ours.groups)
+    yr, yo = ref(x), ours(x)
+    assert rel_err(yo.detach().cpu(), yr.detach().cpu()) <= 2e-6
+    g = torch.randn_like(yr)
+    yr.backward(g), yo.backward(g)
+    assert rel_err(ours.weight.grad.cpu(), ref.weight.grad.cpu()) <= 1e-5
+    assert rel_err(ours.bias.grad.cpu(), ref.bias.grad.cpu()) <= 1e-5
+    # a geometry the kernels do not cover (stride 2) silently takes the stock path
+    s2 = Conv2dFirst(3, 8, 3, stride=2, padding=1).cuda()
+    assert s2(x).shape == (16, 8, 16, 16)

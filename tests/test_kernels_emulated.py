@@ -144,3 +144,20 @@ def test_qconv_bnsign_fused(be, case, training):
 def test_qconv_bnsign_fused_shuffle_and_wide(be):
     K.check_qconv_bnsign(be, seed=180, in_shuffle=2, **K.QGEMM_PW_CASES[1])
     K.check_qconv_bnsign(be, seed=181, x_shape=(2, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)   # KS = 4, two m-blocks: the nin_gc pattern
+
+
+# ---- first-layer kernels (real fp32 operands, K = Cin*KH*KW <= 76): algo 0 (auto) must pick them and match fp64
+FIRST_CASES = [
+    dict(x_shape=(3, 3, 8, 8), w_shape=(24, 3, 5, 5), padding=2),                 # nin_gc L1 pattern, MT = 1, masked channels
+    dict(x_shape=(2, 3, 16, 16), w_shape=(160, 3, 3, 3), padding=1),              # resnet conv1 pattern, MT = 4, two strips
+    dict(x_shape=(2, 1, 8, 16), w_shape=(70, 1, 3, 3), padding=1, bias=False),    # one input channel, MT = 2
+]
+
+
+@pytest.mark.parametrize("case", range(len(FIRST_CASES)))
+def test_conv_first_layer(be, case):
+    import ctypes as C
+    kw = FIRST_CASES[case]
+    g = be.geom(kw["x_shape"], kw["w_shape"], padding=kw["padding"])
+    assert be.lib.mn_conv2d_first_supported(C.byref(g), 0) == 1 and be.lib.mn_conv2d_first_supported(C.byref(g), 2) == 1
+    K.check_conv(be, seed=200 + case, algos=(0,), rel=2e-6, **kw)
