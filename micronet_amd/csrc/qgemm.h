@@ -18,5 +18,8 @@ int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float*
 int pws_supported(const mn_conv_geom* g, const mn_wq* wq);
 int64_t pws_ws_bytes(const mn_conv_geom* g);
 int pws_fwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes, hipStream_t s);
+int pws_wgrad_supported(const mn_conv_geom* g);
+int64_t pws_wgrad_ws_bytes(const mn_conv_geom* g);
+int pws_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s);

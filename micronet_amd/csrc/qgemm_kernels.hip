@@ -24,6 +24,8 @@
 
 #include "qgemm_dev.h"
 
+#include <stdlib.h>
+
 __device__ __forceinline__ float wq_code(float w, int mode, float sc, float n) {
     if (mode == MN_WQ_TERNARY) return (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : w);   // +-0 -> 0, NaN stays NaN
     if (mode == MN_WQ_DOREFA) {
@@ -223,20 +225,26 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
         }
         if (it + 1 < total) issue(raw, it + 1);
         const uint16_t* wk = wl + s * 32;
+        // term-outer: 4*NT independent accumulators between two MFMAs on the same one (a dependent MFMA stalls the issue)
+        u32x4 av[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(wk + t * 16 * LDW);
+        for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const u32x4*>(wk + t * 16 * LDW);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b0[q], acc[q][t]);
-            if (XMODE == MN_ACTQ_NONE) {
-                if (use1) {
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b1[q], acc[q][t]);
-                }
-                if (use2) {
+            for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(av[t], b0[q], acc[q][t]);
+        if (XMODE == MN_ACTQ_NONE) {
+            if (use1) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b2[q], acc[q][t]);
-                }
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(av[t], b1[q], acc[q][t]);
+            }
+            if (use2) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(av[t], b2[q], acc[q][t]);
             }
         }
         if (s == p.KS - 1) {
@@ -391,9 +399,9 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
 #pragma unroll
             for (int ci = 0; ci < CW; ++ci) bf[ci] = *reinterpret_cast<const u32x4*>(xq + ((wc * CW + ci) * 16 + j) * WG_LDP + ko);
 #pragma unroll
-            for (int mi = 0; mi < MW; ++mi) {
+            for (int term = 0; term < 3; ++term) {          // term-outer: MW*CW independent accumulators between dependent MFMAs
 #pragma unroll
-                for (int term = 0; term < 3; ++term) {
+                for (int mi = 0; mi < MW; ++mi) {
                     const u32x4 a = *reinterpret_cast<const u32x4*>(gt + (term * TM + (wm * MW + mi) * 16 + j) * WG_LDP + ko);
 #pragma unroll
                     for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a, bf[ci], acc[mi][ci]);
@@ -630,7 +638,11 @@ int64_t qg_ws_bytes(const mn_conv_geom* g, int which) {
         const int64_t a = plan_pw(g, which, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0, b = which == 0 ? pws_ws_bytes(g) : 0;
         return a > b ? a : b;
     }
-    if (which == 2) { WgPlan pl; return plan_pw_wgrad(g, &pl) ? pl.ws_bytes : 0; }
+    if (which == 2) {
+        WgPlan pl;
+        const int64_t a = plan_pw_wgrad(g, &pl) ? pl.ws_bytes : 0, b = pws_wgrad_ws_bytes(g);
+        return a > b ? a : b;
+    }
     return 0;
 }
 
@@ -715,6 +727,8 @@ static void launch_wg(const WgPlan& pl, int xmode, hipStream_t s) {
 int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s) {
     if (!pw_geom_ok(g)) return kk_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
+    if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_wgrad_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g) && !getenv("MN_NO_WG2"))
+        return pws_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // sign codes: fragments straight from global memory
     WgPlan pl;
     if (!aq_codeable(aq, 1) || !plan_pw_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(qgemm): geometry / quantizer combination not covered");

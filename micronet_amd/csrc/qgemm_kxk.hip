@@ -216,20 +216,26 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
                 }
             }
             const uint16_t* wk = wsm + j * p.LDW + kl;
+            // term-outer: 4*NT independent accumulators between two MFMAs on the same one (a dependent MFMA stalls the issue)
+            u32x4 av[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const u32x4 a = *reinterpret_cast<const u32x4*>(wk + t * 16 * p.LDW);
+            for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const u32x4*>(wk + t * 16 * p.LDW);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b0[q], acc[q][t]);
-                if (NTERM == 3) {
-                    if (use1) {
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b1[q], acc[q][t]);
-                    }
-                    if (use2) {
+                for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(av[t], b0[q], acc[q][t]);
+            if (NTERM == 3) {
+                if (use1) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, b2[q], acc[q][t]);
-                    }
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(av[t], b1[q], acc[q][t]);
+                }
+                if (use2) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(av[t], b2[q], acc[q][t]);
                 }
             }
         }
@@ -619,15 +625,21 @@ __global__ __launch_bounds__(256, 2) void k_kk_wgrad(const KwParams p) {
 #pragma unroll
             for (int term = 0; term < 3; ++term)
                 a[mi][term] = *reinterpret_cast<const u32x4*>(gt + (term * MTt + mi * 16 + j) * p.GS + pi);
+        // three taps at a time, term-outer: 3*MT independent accumulators between two MFMAs on the same one
 #pragma unroll
-        for (int ni = 0; ni < NTL; ++ni) {
-            if (ni < p.T) {
-                const u32x4 bf = *reinterpret_cast<const u32x4*>(xb + ntoff[ni]);
+        for (int n0 = 0; n0 < NTL; n0 += 3) {
+            u32x4 bf[3];
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
+            for (int u = 0; u < 3; ++u) bf[u] = (n0 + u < NTL && n0 + u < p.T) ? *reinterpret_cast<const u32x4*>(xb + ntoff[n0 + u]) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-                    for (int term = 0; term < 3; ++term) acc[mi][ni] = mn_mfma_bf16(a[mi][term], bf, acc[mi][ni]);
-            }
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (n0 + u < NTL && n0 + u < p.T) {
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) acc[mi][n0 + u] = mn_mfma_bf16(a[mi][term], bf[u], acc[mi][n0 + u]);
+                    }
+                }
         }
     };
 

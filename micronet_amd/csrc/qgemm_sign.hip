@@ -352,6 +352,195 @@ __global__ __launch_bounds__(64) void k_pws_chan_prep(int K, int G, int Mpad, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pointwise backward-weight on sign codes, without LDS:  dwq[g][m][c] = sum_{n,p} gy[n][g*Mg+m][p] * a[n][g*Cg+c][p].
+// The contraction index is the pixel, and BOTH operands are pixel-contiguous in NCHW: lane (i, kg) loads the 8 pixels of its
+// K slots of channel row i straight from global memory -- gy as two float4 (split into three exact bf16 terms in registers),
+// the activation as two dwords of sign codes -- so fragments are built without staging, transposition or barriers.  K slot
+// (kg, e) of a 32-pixel step is pixel 4kg + e (e < 4) / 16 + 4kg + (e - 4): each load instruction covers 64 contiguous bytes of
+// a gy row.  A wave owns a (16 MW) x (16 CW) tile of dw over the block's pixel range, the four waves of a block a 2 x 2
+// arrangement of such tiles (their re-reads of gy / codes hit L1 / L2); the next step's loads fly during the MFMAs of the
+// current one.  Partial tiles and dbias partials have the layout of k_pw_wgrad and are reduced by k_pw_wgrad_reduce
+// (fixed order, fp64): deterministic.
+struct Wg2Params {
+    const float* gy;
+    const char* x;
+    float* part;     // [Z][G][Mgw][Cgw]
+    float* dbpart;   // [Z][G][Mgw]
+    int N, HW, Cin_total, Cout_total, Cg, Mg, G, nmb, ncb, Z, nsteps, Mgw, Cgw, want_db;
+    int st_per_z, st_stride;      // block z contracts steps z*st_per_z + i*st_stride, i < its count (contiguous ranges: st_stride = 1)
+    FastDiv fd_hw;
+    ChanMap in_map;
+};
+template <int MW, int CW>
+__global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const int wm = wave >> 1, wc = wave & 1;
+    uint32_t b = blockIdx.x;
+    const int z = b % p.Z; b /= p.Z;
+    const int cb = b % p.ncb; b /= p.ncb;
+    const int mb = b % p.nmb;
+    const int g = b / p.nmb;
+    const uint32_t HW = (uint32_t)p.HW;
+    constexpr int TM = 32 * MW, TC = 32 * CW;
+
+    uint32_t goff[MW], xoff[CW];          // channel offsets (rows beyond Mg / Cg are clamped: their dw entries are never read)
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        int m = mb * TM + (wm * MW + mi) * 16 + j;
+        m = m < p.Mg ? m : p.Mg - 1;
+        goff[mi] = (uint32_t)(g * p.Mg + m) * HW;
+    }
+#pragma unroll
+    for (int ci = 0; ci < CW; ++ci) {
+        int c = cb * TC + (wc * CW + ci) * 16 + j;
+        c = c < p.Cg ? c : p.Cg - 1;
+        xoff[ci] = (uint32_t)chan_phys(p.in_map, g * p.Cg + c) * HW;
+    }
+    f32x4 acc[MW][CW];
+    float dbacc[MW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        dbacc[mi] = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    float4 ga[MW], gb[MW];
+    uint32_t ua[CW], ub[CW];
+    auto fetch = [&](int st) {
+        const uint32_t Pa = (uint32_t)st * 32u + 4u * kg, Pb = Pa + 16u;
+        const uint32_t na = fd_div(Pa, p.fd_hw), nb = fd_div(Pb, p.fd_hw);
+        const uint32_t pa = Pa - na * HW, pb = Pb - nb * HW;
+        const uint32_t oa = na * (uint32_t)p.Cout_total * HW + pa, ob = nb * (uint32_t)p.Cout_total * HW + pb;
+        const uint32_t xa = na * (uint32_t)p.Cin_total * HW + pa, xb = nb * (uint32_t)p.Cin_total * HW + pb;
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            ga[mi] = *reinterpret_cast<const float4*>(p.gy + (oa + goff[mi]));
+            gb[mi] = *reinterpret_cast<const float4*>(p.gy + (ob + goff[mi]));
+        }
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) {
+            ua[ci] = *reinterpret_cast<const uint32_t*>(p.x + (xa + xoff[ci]));
+            ub[ci] = *reinterpret_cast<const uint32_t*>(p.x + (xb + xoff[ci]));
+        }
+    };
+    const int st0 = p.st_stride == 1 ? z * p.st_per_z : z;
+    const int st_end = p.st_stride == 1 ? ((st0 + p.st_per_z) < p.nsteps ? (st0 + p.st_per_z) : p.nsteps) : p.nsteps;
+    if (st0 < st_end) fetch(st0);
+    for (int st = st0; st < st_end; st += p.st_stride) {
+        // B fragments: sign codes -> bf16 +-1
+        u32x4 bf[CW];
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) {
+            const uint32_t u = ua[ci], v = ub[ci];
+            bf[ci] = u32x4{0x3F803F80u | ((u & 0x80u) << 8) | ((u & 0x8000u) << 16), 0x3F803F80u | ((u & 0x800000u) >> 8) | (u & 0x80000000u),
+                           0x3F803F80u | ((v & 0x80u) << 8) | ((v & 0x8000u) << 16), 0x3F803F80u | ((v & 0x800000u) >> 8) | (v & 0x80000000u)};
+        }
+        // A fragments: three exact bf16 terms of the 8 gy values
+        u32x4 a0[MW], a1[MW], a2[MW];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            const float v[8] = {ga[mi].x, ga[mi].y, ga[mi].z, ga[mi].w, gb[mi].x, gb[mi].y, gb[mi].z, gb[mi].w};
+            float t0[8], t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                t0[e] = mn_bf16_head(v[e]);
+                const float r1 = v[e] - t0[e];
+                t1[e] = mn_bf16_head(r1);
+                t2[e] = r1 - t1[e];
+            }
+            dbacc[mi] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                a0[mi][d] = mn_pack_bf16x2(t0[2 * d], t0[2 * d + 1]);
+                a1[mi][d] = mn_pack_bf16x2(t1[2 * d], t1[2 * d + 1]);
+                a2[mi][d] = mn_pack_bf16x2(t2[2 * d], t2[2 * d + 1]);
+            }
+        }
+        if (st + p.st_stride < st_end) fetch(st + p.st_stride);          // in flight during the MFMAs below
+        // term-outer: MW*CW independent accumulators between two MFMAs on the same one (a dependent MFMA waits ~2 issue slots)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a0[mi], bf[ci], acc[mi][ci]);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a1[mi], bf[ci], acc[mi][ci]);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a2[mi], bf[ci], acc[mi][ci]);
+    }
+    // partial tile: lane (j, kg) holds rows m = 4kg + r, column c = j
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) {
+            const int mrow = mb * TM + (wm * MW + mi) * 16 + kg * 4;
+            const int ccol = cb * TC + (wc * CW + ci) * 16 + j;
+            float* dst = p.part + (((int64_t)z * p.G + g) * p.Mgw + mrow) * p.Cgw + ccol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.Cgw] = acc[mi][ci][r];
+        }
+        if (p.want_db && cb == 0 && wc == 0) {
+            float v = dbacc[mi];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);        // the four kg groups hold different pixels of row j
+            if (kg == 0) p.dbpart[((int64_t)z * p.G + g) * p.Mgw + mb * TM + (wm * MW + mi) * 16 + j] = v;
+        }
+    }
+}
+static int pws_geom_ok(const mn_conv_geom* g);
+struct Wg2Plan { Wg2Params p; int MW; int grid; int64_t off_db, ws_bytes; };
+static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
+    if (!pws_geom_ok(g)) return 0;
+    const int Cg = g->C / g->groups, Mg = g->O / g->groups;
+    const int64_t NP = (int64_t)g->N * g->H * g->W;
+    if (NP % 32 || Mg < 33 || Cg < 33) return 0;           // small tiles stay on the LDS-staged kernel
+    Wg2Params& p = pl->p;
+    pl->MW = (Mg > 64 || Cg > 64) ? 4 : 2;
+    const int T = 32 * pl->MW;
+    p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.Cin_total = g->C; p.Cout_total = g->O; p.Cg = Cg; p.Mg = Mg;
+    p.in_map = make_chanmap(g->in_shuffle, g->C);
+    p.nmb = (Mg + T - 1) / T; p.ncb = (Cg + T - 1) / T;
+    p.Mgw = p.nmb * T; p.Cgw = p.ncb * T;
+    p.nsteps = (int)(NP / 32);
+    const int base = p.G * p.nmb * p.ncb;
+    int Z = 512 / base;
+    if (const char* e = getenv("MN_WG2_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }   // tuning knob
+    if (Z > p.nsteps / 2) Z = p.nsteps / 2;
+    if (Z < 1) Z = 1;
+    p.Z = Z;
+    p.st_per_z = (p.nsteps + Z - 1) / Z; p.st_stride = 1;     // contiguous pixel ranges: each block streams its gy rows sequentially
+    if (getenv("MN_WG2_STRIDED")) { p.st_stride = Z; }
+    p.fd_hw = make_fastdiv((uint32_t)p.HW);
+    const int64_t nb = (int64_t)base * Z;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    const int64_t part_bytes = (int64_t)Z * p.G * p.Mgw * p.Cgw * 4;
+    pl->off_db = (part_bytes + 255) / 256 * 256;
+    pl->ws_bytes = pl->off_db + (int64_t)Z * p.G * p.Mgw * 4;
+    return 1;
+}
+int pws_wgrad_supported(const mn_conv_geom* g) { Wg2Plan pl; return plan_pws_wgrad(g, &pl); }
+int64_t pws_wgrad_ws_bytes(const mn_conv_geom* g) { Wg2Plan pl; return plan_pws_wgrad(g, &pl) ? pl.ws_bytes : 0; }
+int pws_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    Wg2Plan pl;
+    if (!plan_pws_wgrad(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(sign): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(sign): workspace too small");
+    Wg2Params& p = pl.p;
+    p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
+    mn_set_last_kernel("k_pws_wgrad<%d, %d>", pl.MW, pl.MW);
+    mn_prof_begin(s);
+    if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4>), dim3(pl.grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_pws_wgrad<2, 2>), dim3(pl.grid), dim3(256), 0, s, p);
+    mn_prof_end(s);
+    qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, 1.f, nullptr, s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(sign)");
+    return MN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct PwsPlan {
     PwsParams p;

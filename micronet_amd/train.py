@@ -136,6 +136,9 @@ class GraphedTrainStep:
         self.graph_a.replay()
         if self.world > 1:
             import torch.distributed as dist
+            # the collective needs graph A's result anyway: wait for it on the host before enqueueing the all-reduce (a
+            # collective that waits on a stream with a freshly launched graph was seen to stall for seconds with gloo)
+            torch.cuda.current_stream().synchronize()
             dist.all_reduce(self.flat, group=self.group)
             self.graph_b.replay()
         return self.loss, self.output

@@ -55,6 +55,12 @@ def main():
             kk = torch.randint(0, 256, (Cout, Cin // G, k, k), device="cuda", generator=gen).float()
             w = 2 * (kk * (1.0 / n)) - 1
             aq, wq = be.actq(1, 8), be.wq(mode=2, bits=8)
+        elif args.scheme == "sign8":     # packed +-1 activations (int8 codes), ternary weights
+            x = (torch.randint(0, 2, (N, Cin, S, S), device="cuda", generator=gen, dtype=torch.int8) * 2 - 1)
+            t = torch.randint(-1, 2, (Cout, Cin // G, k, k), device="cuda", generator=gen).float()
+            t[:, 0] = 1
+            w = t * (torch.rand((Cout, 1, 1, 1), device="cuda", generator=gen) * 0.2 + 0.05)
+            aq, wq = be.actq(3), be.wq(mode=1)
         elif args.scheme == "real":      # un-quantised layer (the first conv of wbwtab / dorefa nets): fp32 x, fp32 w
             x = torch.randn((N, Cin, S, S), device="cuda", generator=gen)
             w = torch.randn((Cout, Cin // G, k, k), device="cuda", generator=gen) * 0.1
@@ -68,10 +74,10 @@ def main():
             aq, wq = be.actq(2, 8, 0, qp), be.wq(mode=3, bits=8, per_channel=1, scale=scale)
         y = be.conv_fwd(g, aq, x, w, None, 0, wq=wq)
         gy = torch.randn(y.shape, device="cuda", generator=gen)
-        nx, ny, nw = x.numel() * 4, y.numel() * 4, w.numel() * 4
+        nx, ny, nw = x.numel() * x.element_size(), y.numel() * 4, w.numel() * 4
         ste = args.scheme != "wbwtab"
         nbytes = {"fwd": nx + ny + nw, "dgrad": ny + nx + nw + (nx if ste else 0), "wgrad": ny + nx + nw}
-        dx = torch.empty_like(x)
+        dx = torch.empty(x.shape, device="cuda")
         dw = torch.empty_like(w)
         db = torch.empty(Cout, device="cuda")
         P = be.ptr

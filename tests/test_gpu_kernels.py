@@ -286,3 +286,17 @@ def test_conv_first_layer(be, case):
     g = be.geom(kw["x_shape"], kw["w_shape"], padding=kw["padding"])
     assert be.lib.mn_conv2d_first_supported(C.byref(g), 0) == 1 and be.lib.mn_conv2d_first_supported(C.byref(g), 2) == 1
     K.check_conv(be, seed=200 + case, algos=(0,), rel=2e-6 if case < 3 else 1e-5, **kw)     # fp32 accumulation over 8k pixels per partial
+
+
+WG2_CASES = [
+    dict(x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2),
+    dict(x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, bias=False),
+    dict(x_shape=(2, 80, 4, 4), w_shape=(100, 40, 1, 1), groups=2),
+    dict(x_shape=(8, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4),              # nin_gc L5 at batch 8
+]
+
+
+@pytest.mark.parametrize("case", range(len(WG2_CASES)))
+def test_qgemm_sign8_wgrad_direct(be, case):
+    K.check_conv(be, seed=210 + case, wmode=1, sign8=True, algos=(3,), **WG2_CASES[case])
+    K.check_conv(be, seed=215 + case, wmode=1, sign8=True, algos=(3,), in_shuffle=2, **WG2_CASES[case])

@@ -161,3 +161,17 @@ def test_conv_first_layer(be, case):
     g = be.geom(kw["x_shape"], kw["w_shape"], padding=kw["padding"])
     assert be.lib.mn_conv2d_first_supported(C.byref(g), 0) == 1 and be.lib.mn_conv2d_first_supported(C.byref(g), 2) == 1
     K.check_conv(be, seed=200 + case, algos=(0,), rel=2e-6, **kw)
+
+
+WG2_CASES = [
+    dict(x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2),                 # 64 x 64 tiles (MW = 2), two steps
+    dict(x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, bias=False),    # 128 x 128 tiles (MW = 4): the nin_gc pattern
+    dict(x_shape=(2, 80, 4, 4), w_shape=(100, 40, 1, 1), groups=2),                  # clamped rows / columns (Mg = 50, Cg = 40), 16-pixel images
+]
+
+
+@pytest.mark.parametrize("case", range(len(WG2_CASES)))
+def test_qgemm_sign8_wgrad_direct(be, case):
+    """k_pws_wgrad (LDS-free backward-weight on sign codes)."""
+    K.check_conv(be, seed=210 + case, wmode=1, sign8=True, algos=(3,), **WG2_CASES[case])
+    K.check_conv(be, seed=215 + case, wmode=1, sign8=True, algos=(3,), in_shuffle=2, **WG2_CASES[case])
