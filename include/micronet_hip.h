@@ -245,6 +245,13 @@ int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x,
                         const float* beta, const float* save, const float* da, int training, float* dy, float* dgamma, float* dbeta,
                         void* ws, int64_t ws_bytes, mn_stream_t stream);
 
+/* same backward when a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119) sits behind the block: `dpool` = d loss / d pool(a),
+ * [N][O][H/2][W/2] fp32, `a_own` = the block's own output codes (what mn_qconv_bnsign_fwd wrote); the pool's backward (gradient to
+ * the first maximum of each window) is applied while the gradient is read -- a quarter of the bytes, no full-size da tensor. */
+int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                               const float* beta, const float* save, const float* dpool, const int8_t* a_own, int training, float* dy,
+                               float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, mn_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer step of the training loop
  * <scheme>/main.py: optimizer.step() with torch.optim.Adam, one parameter group per tensor (wqaq/dorefa/main.py:308-315).
  * One launch per MN_ADAM_MAX_TENSORS tensors; `tensors` is a HOST array (device pointers inside), copied into the kernel

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "mn_qconv_bnsign_ws_bytes": (_L, [_G]),
     "mn_qconv_bnsign_fwd": (_I, [_G, _W, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _L, _P]),
     "mn_qconv_bnsign_bwd": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    "mn_qconv_bnsign_bwd_pooled": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),

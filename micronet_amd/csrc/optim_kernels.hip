@@ -22,19 +22,20 @@ struct AdamTable {
     const int* step_dev;     // non-null: the step count lives in device memory (HIP-graph replay), bias corrections computed here
 };
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_bc1, float wd, const AdamTable& t) {
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_bc1, float wd, const AdamTable& t, float bc2_sqrt) {
     if (wd != 0.f) g = g + wd * p;
     m = m + (g - m) * (1.f - t.beta1);
     v = v * t.beta2 + (1.f - t.beta2) * g * g;
-    const float denom = sqrtf(v) / t.bc2_sqrt + t.eps;
+    const float denom = sqrtf(v) / bc2_sqrt + t.eps;
     p = p - lr_bc1 * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void k_adam(AdamTable t) {
-    if (t.step_dev) {        // uniform: same expressions as the host path of mn_adam_step
-        const double st = (double)*t.step_dev;
-        t.bc1 = (float)(1.0 - pow((double)t.beta1, st));
-        t.bc2_sqrt = (float)sqrt(1.0 - pow((double)t.beta2, st));
+__global__ __launch_bounds__(256) void k_adam(const AdamTable t) {
+    float bc1 = t.bc1, bc2_sqrt = t.bc2_sqrt;
+    if (t.step_dev) {        // uniform: same expressions as the host path of mn_adam_step (the table itself stays read-only:
+        const double st = (double)*t.step_dev;          // writing to a by-value kernel argument would spill it to scratch)
+        bc1 = (float)(1.0 - pow((double)t.beta1, st));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)t.beta2, st));
     }
     int ti = 0;
     const int b = blockIdx.x;
@@ -45,19 +46,19 @@ __global__ __launch_bounds__(256) void k_adam(AdamTable t) {
     const float* __restrict__ G = t.g[ti];
     float* __restrict__ M = t.m[ti];
     float* __restrict__ V = t.v[ti];
-    const float lr_bc1 = t.lr[ti] / t.bc1, wd = t.wd[ti];
+    const float lr_bc1 = t.lr[ti] / bc1, wd = t.wd[ti];
     const bool vec = aligned16(P) && aligned16(G) && aligned16(M) && aligned16(V);
     for (int i = off + threadIdx.x * 4; i < off + ADAM_CHUNK && i < n; i += 256 * 4) {
         if (vec && i + 3 < n) {
             float4 p4 = *reinterpret_cast<float4*>(P + i), m4 = *reinterpret_cast<float4*>(M + i), v4 = *reinterpret_cast<float4*>(V + i);
             const float4 g4 = *reinterpret_cast<const float4*>(G + i);
-            adam_one(p4.x, g4.x, m4.x, v4.x, lr_bc1, wd, t); adam_one(p4.y, g4.y, m4.y, v4.y, lr_bc1, wd, t);
-            adam_one(p4.z, g4.z, m4.z, v4.z, lr_bc1, wd, t); adam_one(p4.w, g4.w, m4.w, v4.w, lr_bc1, wd, t);
+            adam_one(p4.x, g4.x, m4.x, v4.x, lr_bc1, wd, t, bc2_sqrt); adam_one(p4.y, g4.y, m4.y, v4.y, lr_bc1, wd, t, bc2_sqrt);
+            adam_one(p4.z, g4.z, m4.z, v4.z, lr_bc1, wd, t, bc2_sqrt); adam_one(p4.w, g4.w, m4.w, v4.w, lr_bc1, wd, t, bc2_sqrt);
             *reinterpret_cast<float4*>(P + i) = p4; *reinterpret_cast<float4*>(M + i) = m4; *reinterpret_cast<float4*>(V + i) = v4;
         } else {
             for (int k = i; k < i + 4 && k < n; ++k) {
                 float p = P[k], m = M[k], v = V[k];
-                adam_one(p, G[k], m, v, lr_bc1, wd, t);
+                adam_one(p, G[k], m, v, lr_bc1, wd, t, bc2_sqrt);
                 P[k] = p; M[k] = m; V[k] = v;
             }
         }

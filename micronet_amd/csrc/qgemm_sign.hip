@@ -34,6 +34,8 @@
 #define PWS_SIGN8 2
 #define PWS_BWD_PART 3
 #define PWS_BWD_APPLY 4
+#define PWS_BWD_PART_POOL 5      // as PWS_BWD_PART / PWS_BWD_APPLY, but the incoming gradient is that of the 2x2 / stride-2 max-pool
+#define PWS_BWD_APPLY_POOL 6     // behind this block: read pooled (a quarter of the bytes) and routed through the pool here
 
 #define PWS_NCH 8           // per-channel constants (k_pws_chan_prep): T, flip, L, U, A, B, gi, unused
 struct PwsParams {
@@ -45,7 +47,10 @@ struct PwsParams {
     char* a8;                 // PWS_SIGN8 output
     float* part;              // PWS_STATS / PWS_BWD_PART: [CB][G*Mpad][2]
     const float* chan;        // [PWS_NCH][Cout_total] per-channel constants
-    const float* da;          // gradient w.r.t. the sign output
+    const float* da;          // gradient w.r.t. the sign output ([N][Cout][H][W]), or -- *_POOL -- w.r.t. the pooled output ([N][Cout][H/2][W/2])
+    const char* own;          // *_POOL: this block's own output codes [N][Cout][H][W] (the pool routes a gradient to the first +1 of a window)
+    int W;                    // *_POOL: image width
+    FastDiv fd_w;
     const float* sums;        // [2][Cout_total] sum dz, sum dz*zhat (PWS_BWD_APPLY, training)
     int training;
     float n_f;                // (float)N * (float)HW, the divisor k_bns_apply uses
@@ -59,8 +64,11 @@ template <int NT, int KS, int EPI>
 __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     constexpr int MB = 16 * NT;
-    constexpr bool RED = EPI == PWS_STATS || EPI == PWS_BWD_PART;
-    constexpr bool GRAD = EPI == PWS_BWD_PART || EPI == PWS_BWD_APPLY;
+    constexpr bool POOL = EPI == PWS_BWD_PART_POOL || EPI == PWS_BWD_APPLY_POOL;
+    constexpr bool PART = EPI == PWS_BWD_PART || EPI == PWS_BWD_PART_POOL;
+    constexpr bool APPLY = EPI == PWS_BWD_APPLY || EPI == PWS_BWD_APPLY_POOL;
+    constexpr bool RED = EPI == PWS_STATS || PART;
+    constexpr bool GRAD = PART || APPLY;
     const int LDW = p.Kp + 8;
     uint16_t* wsm = reinterpret_cast<uint16_t*>(smem);
     float* c0 = smem + (MB * LDW) / 2;     // Y: alpha       SIGN8: T      BWD: L
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             if (EPI == PWS_Y) { c0[i] = p.rowscale[g * p.Mpad + m]; c1[i] = (p.bias && mv) ? p.bias[co] : 0.f; }
             if (EPI == PWS_SIGN8) { c0[i] = p.chan[co]; c1[i] = p.chan[C + co]; }
             if (GRAD) { c0[i] = p.chan[2 * C + co]; c1[i] = p.chan[3 * C + co]; c2[i] = p.chan[C + co]; c3[i] = p.chan[4 * C + co]; c4[i] = p.chan[5 * C + co]; }
-            if (EPI == PWS_BWD_APPLY) {
+            if (APPLY) {
                 c5[i] = p.chan[6 * C + co];
                 c6[i] = p.training ? p.sums[co] / p.n_f : 0.f;
                 c7[i] = p.training ? p.sums[C + co] / p.n_f : 0.f;
@@ -178,22 +186,41 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
 
         // epilogue: lane (j, kg) holds out-channels t*16 + 4kg + r of pixels P .. P+3; acc is an exact integer
         float4 gq[2][4];                         // backward: the gradient rows of tile t (one tile ahead)
+        // *_POOL: the lane's pixel quad (row h, columns w .. w+3) covers half of two pooling windows: gq = {g[win 0], g[win 1],
+        // own codes of row h & ~1, own codes of row h | 1} and the quad's gradient is g where the pixel is the window's first maximum
+        uint32_t gbase = 0u, cbase = 0u, hb = 0u;
+        if (POOL) {
+            const uint32_t pp = P - n * HW;
+            const uint32_t h = fd_div(pv ? pp : 0u, p.fd_w), w = (pv ? pp : 0u) - h * (uint32_t)p.W;
+            const uint32_t ch0 = (uint32_t)(g * p.Mr + mblk * MB + kg * 4);
+            hb = h & 1u;
+            gbase = (n * (uint32_t)p.Cout_total + ch0) * (HW >> 2) + (h >> 1) * ((uint32_t)p.W >> 1) + (w >> 1);
+            cbase = (n * (uint32_t)p.Cout_total + ch0) * HW + (h & ~1u) * (uint32_t)p.W + w;
+        }
+        auto load_grad = [&](int t, int r) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv && mblk * MB + t * 16 + kg * 4 + r < p.Mr) {
+                if (POOL) {
+                    const uint32_t ch = (uint32_t)(t * 16 + r);
+                    const float2 g2 = *reinterpret_cast<const float2*>(p.da + (gbase + ch * (HW >> 2)));
+                    const uint32_t r0 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + ch * HW));
+                    const uint32_t r1 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + ch * HW + (uint32_t)p.W));
+                    v = make_float4(g2.x, g2.y, mn_u2f(r0), mn_u2f(r1));
+                } else {
+                    v = *reinterpret_cast<const float4*>(p.da + (obase + (uint32_t)(t * 16 + r) * HW));
+                }
+            }
+            return v;
+        };
         if (GRAD) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                gq[0][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pv && mblk * MB + kg * 4 + r < p.Mr) gq[0][r] = *reinterpret_cast<const float4*>(p.da + (obase + (uint32_t)r * HW));
-            }
+            for (int r = 0; r < 4; ++r) gq[0][r] = load_grad(0, r);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (GRAD && t + 1 < NT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    gq[(t + 1) & 1][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (pv && mblk * MB + (t + 1) * 16 + kg * 4 + r < p.Mr)
-                        gq[(t + 1) & 1][r] = *reinterpret_cast<const float4*>(p.da + (obase + (uint32_t)((t + 1) * 16 + r) * HW));
-                }
+                for (int r = 0; r < 4; ++r) gq[(t + 1) & 1][r] = load_grad(t + 1, r);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -219,7 +246,19 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                 } else {
                     const float L = c0[ml], U = c1[ml], fl = c2[ml], A = c3[ml], B = c4[ml];
                     const float4 g4 = gq[t & 1][r];
-                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+                    float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+                    if (POOL) {      // first maximum of each window in row-major order (ATen's max_pool2d): the first +1, else element 0
+                        const uint32_t r0 = mn_f2u(g4.z), r1 = mn_f2u(g4.w);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const bool p00 = !((r0 >> (16 * e)) & 0x80u), p01 = !((r0 >> (16 * e + 8)) & 0x80u);
+                            const bool p10 = !((r1 >> (16 * e)) & 0x80u), p11 = !((r1 >> (16 * e + 8)) & 0x80u);
+                            const uint32_t win = p00 ? 0u : (p01 ? 1u : (p10 ? 2u : (p11 ? 3u : 0u)));
+                            const float ge = e ? g4.y : g4.x;
+                            gv[2 * e] = win == hb * 2u ? ge : 0.f;
+                            gv[2 * e + 1] = win == hb * 2u + 1u ? ge : 0.f;
+                        }
+                    }
                     float dz[4], zh[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -227,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                         dz[e] = (u >= L && u <= U) ? gv[e] : 0.f;          // BinaryActivation.backward: |z| < 1
                         zh[e] = fmaf(o[e], A, B);                           // (y - mean) * invstd
                     }
-                    if (EPI == PWS_BWD_PART) {
+                    if (PART) {
                         if (ok) {
                             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -618,7 +657,7 @@ static void launch_pws2(const PwsPlan& pl, hipStream_t s) {
 }
 template <int EPI>
 static int launch_pws(const PwsPlan& pl, hipStream_t s, double nbytes, const char* what) {
-    static const char* en[5] = {"Y", "STATS", "SIGN8", "BWD_PART", "BWD_APPLY"};
+    static const char* en[7] = {"Y", "STATS", "SIGN8", "BWD_PART", "BWD_APPLY", "BWD_PART_POOL", "BWD_APPLY_POOL"};
     mn_set_last_kernel("k_pws<%d, %d, %s>", pl.NT, pl.KS, en[EPI]);
     mn_prof_bytes(nbytes);
     mn_prof_begin(s);
@@ -626,7 +665,7 @@ static int launch_pws(const PwsPlan& pl, hipStream_t s, double nbytes, const cha
         case 1: launch_pws2<1, EPI>(pl, s); break;
         case 2: launch_pws2<2, EPI>(pl, s); break;
         case 4: launch_pws2<4, EPI>(pl, s); break;
-        case 8: if (EPI == PWS_BWD_PART || EPI == PWS_BWD_APPLY) MN_FAIL(MN_EINVAL, "%s: bad NT", what); launch_pws2<(EPI == PWS_BWD_PART || EPI == PWS_BWD_APPLY) ? 4 : 8, EPI>(pl, s); break;
+        case 8: if (EPI >= PWS_BWD_PART) MN_FAIL(MN_EINVAL, "%s: bad NT", what); launch_pws2<(EPI >= PWS_BWD_PART) ? 4 : 8, EPI>(pl, s); break;
         default: MN_FAIL(MN_EINVAL, "%s: bad NT", what);
     }
     mn_prof_end(s);
@@ -647,7 +686,8 @@ static int pws_prepare(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, 
     p.x = (const char*)x; p.wc = pl->pk.codes; p.rowscale = pl->pk.scale_out;
     p.part = (float*)((char*)ws + pl->off_part);
     p.chan = (const float*)((char*)ws + pl->off_chan);
-    p.y = nullptr; p.a8 = nullptr; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr;
+    p.y = nullptr; p.a8 = nullptr; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr; p.own = nullptr;
+    p.W = g->W; p.fd_w = make_fastdiv((uint32_t)g->W);
     return MN_OK;
 }
 
@@ -706,10 +746,11 @@ extern "C" int mn_qconv_bnsign_fwd(const mn_conv_geom* g, const mn_wq* wq, const
     return launch_pws<PWS_SIGN8>(pl, s, nx + ny, "mn_qconv_bnsign_fwd(sign)");
 }
 
-extern "C" int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
-                                   const float* beta, const float* save, const float* da, int training, float* dy, float* dgamma, float* dbeta,
-                                   void* ws, int64_t ws_bytes, mn_stream_t stream) {
+static int bnsign_bwd_impl(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                           const float* beta, const float* save, const float* da, const int8_t* own, int training, float* dy, float* dgamma, float* dbeta,
+                           void* ws, int64_t ws_bytes, mn_stream_t stream) {
     if (!g || !gamma || !beta || !save || !da || !dy || !aligned16(da) || !aligned16(dy)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_bwd: null / misaligned argument");
+    if (own && ((g->H & 1) || (g->W & 3) || (((uintptr_t)own) & 3))) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_bwd_pooled: needs even H, W %% 4 == 0");
     if (!pws_bn_ok(g, wq)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_bwd: needs a pointwise convolution with ternary / binary weights");
     hipStream_t s = (hipStream_t)stream;
     PwsPlan pl;
@@ -717,11 +758,25 @@ extern "C" int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const
     if (rc) return rc;
     PwsParams& p = pl.p;
     float* sums = (float*)((char*)ws + pl.off_sums);
-    p.bias = bias; p.da = da; p.training = training;
+    p.bias = bias; p.da = da; p.training = training; p.own = (const char*)own;
     pws_chan_prep(pl, g, bias, save, gamma, beta, s);
     const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
-    if ((rc = launch_pws<PWS_BWD_PART>(pl, s, nx + 4.0 * ny, "mn_qconv_bnsign_bwd(partial)"))) return rc;
+    if (own) rc = launch_pws<PWS_BWD_PART_POOL>(pl, s, nx + 2.0 * ny, "mn_qconv_bnsign_bwd(partial, pooled)");
+    else rc = launch_pws<PWS_BWD_PART>(pl, s, nx + 4.0 * ny, "mn_qconv_bnsign_bwd(partial)");
+    if (rc) return rc;
     hipLaunchKernelGGL(k_pws_final_bwd, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, dgamma, dbeta, sums, (int)g->O);
     p.sums = sums; p.y = dy;
+    if (own) return launch_pws<PWS_BWD_APPLY_POOL>(pl, s, nx + 6.0 * ny, "mn_qconv_bnsign_bwd(apply, pooled)");
     return launch_pws<PWS_BWD_APPLY>(pl, s, nx + 8.0 * ny, "mn_qconv_bnsign_bwd(apply)");
+}
+extern "C" int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                   const float* beta, const float* save, const float* da, int training, float* dy, float* dgamma, float* dbeta,
+                                   void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    return bnsign_bwd_impl(g, wq, x, w, bias, gamma, beta, save, da, nullptr, training, dy, dgamma, dbeta, ws, ws_bytes, stream);
+}
+extern "C" int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                          const float* beta, const float* save, const float* dpool, const int8_t* a_own, int training, float* dy,
+                                          float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    if (!a_own) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_bwd_pooled: null output codes");
+    return bnsign_bwd_impl(g, wq, x, w, bias, gamma, beta, save, dpool, a_own, training, dy, dgamma, dbeta, ws, ws_bytes, stream);
 }

@@ -22,7 +22,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import ActQ, ConvGeom, MicronetHipError, WQ
-from .sign_tensor import LazyConvOut, SignTensor
+from .sign_tensor import LazyConvOut, LazyPoolGrad, SignTensor
 
 ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO, ACTQ_SIGN8 = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO, _lib.MN_ACTQ_SIGN8
 WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _lib.MN_WQ_DOREFA, _lib.MN_WQ_IAO
@@ -74,6 +74,10 @@ def _lib_():
 def _chk(t, name="tensor"):
     if t is None:
         return None
+    if isinstance(t, (LazyPoolGrad, LazyConvOut)):      # a lazy tensor reaching a kernel that wants plain memory
+        t = t.materialize()
+    elif isinstance(t, SignTensor):
+        t = t.to_float()
     if not t.is_cuda:
         raise MicronetHipError("%s is on %s: micronet_amd runs on MI355X only (no CPU fallback)" % (name, t.device))
     if t.dtype != torch.float32:
@@ -370,6 +374,17 @@ def sign_pool_supported(a, kernel_size, stride, padding, dilation, ceil_mode):
             dilation in (1, (1, 1)) and not ceil_mode and a.shape[2] % 2 == 0 and a.shape[3] % 8 == 0)
 
 
+LAZY_POOL_GRAD = True
+
+
+def _expand_pool_grad(g, codes):
+    N, Cc, H, W = codes.shape
+    din = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+    with torch.cuda.device_of(codes):
+        _call("mn_maxpool2x2_sign8_bwd", _p(g), _p(codes), N * Cc, H, W, _p(din), _s())
+    return din
+
+
 class SignMaxPool2x2(Function):
     """nn.MaxPool2d(2, 2) on packed sign activations (models/nin_gc.py:88,119): int8 in, int8 out; the backward routes each
     output gradient to the first maximum of its window, as ATen's max_pool2d does."""
@@ -388,11 +403,10 @@ class SignMaxPool2x2(Function):
     def backward(ctx, g):
         (codes,) = ctx.saved_tensors
         g = _chk(g, "grad")
-        N, Cc, H, W = codes.shape
-        din = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
-        with torch.cuda.device_of(codes):
-            _call("mn_maxpool2x2_sign8_bwd", _p(g), _p(codes), N * Cc, H, W, _p(din), _s())
-        return din
+        if LAZY_POOL_GRAD and codes.shape[3] % 4 == 0:
+            # hand the POOLED gradient on: the fused block in front expands it inside its kernels (anything else materialises it)
+            return LazyPoolGrad(codes.shape, codes.device, g, codes, _expand_pool_grad)
+        return _expand_pool_grad(g, codes)
 
 
 # ------------------------------------------------------------------------------------------------ convolution
@@ -546,15 +560,23 @@ class ConvBNSign(Function):
     def backward(ctx, da):
         codes, wq, bias, gamma, beta, save, wscale = ctx.saved_tensors
         g, wd4, training = ctx.cfg
-        da = _chk(da, "grad")
+        pooled = isinstance(da, LazyPoolGrad) and da._mn_value is None
+        if pooled:
+            dpool, own = da._mn_pg, da._mn_codes          # the 2x2 max-pool behind this block: gradient still pooled
+        else:
+            da = _chk(da, "grad")
         dy = torch.empty(da.shape, dtype=torch.float32, device=da.device)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         wd = _wq_desc(wd4 + (wscale,))
         with torch.cuda.device_of(codes):
             nb = int(_lib_().mn_qconv_bnsign_ws_bytes(C.byref(g)))
             ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
-            _call("mn_qconv_bnsign_bwd", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), _p(save), _p(da), training,
-                  _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _s())
+            if pooled:
+                _call("mn_qconv_bnsign_bwd_pooled", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), _p(save), _p(dpool),
+                      _p(own), training, _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _s())
+            else:
+                _call("mn_qconv_bnsign_bwd", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), _p(save), _p(da), training,
+                      _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _s())
         return dy, dgamma, dbeta, None, None, None, None, None
 
 

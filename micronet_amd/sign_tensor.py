@@ -104,3 +104,40 @@ class LazyConvOut(torch.Tensor):
             return r
         un = lambda t: t.materialize() if isinstance(t, LazyConvOut) else (t._mn_codes.to(torch.float32) if isinstance(t, SignTensor) else t)
         return func(*tree_map(un, args), **tree_map(un, kwargs))
+
+
+class LazyPoolGrad(torch.Tensor):
+    """The gradient of a 2x2 max-pool's INPUT that has not been expanded: logically the full-size float32 tensor, physically the
+    pooled gradient plus the pool's input codes.  ``ConvBNSign.backward`` (the block in front of the pool) reads it in this
+    form -- a quarter of the bytes, no full-size write -- and routes it through the pool inside its kernels
+    (``mn_qconv_bnsign_bwd_pooled``); any other consumer materialises it with the sign max-pool backward kernel."""
+
+    @staticmethod
+    def __new__(cls, shape, device, pooled_grad, codes, expand):
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=torch.float32, device=device, requires_grad=False)
+        r._mn_pg, r._mn_codes, r._mn_expand, r._mn_value = pooled_grad, codes, expand, None
+        return r
+
+    def __init__(self, shape, device, pooled_grad, codes, expand):
+        pass
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_expand(self._mn_pg, self._mn_codes)
+        return self._mn_value
+
+    def __repr__(self):
+        return "LazyPoolGrad(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], LazyPoolGrad):
+            a = args[0]
+            r = LazyPoolGrad(a.shape, a.device, a._mn_pg, a._mn_codes, a._mn_expand)
+            r._mn_value = a._mn_value
+            return r
+        un = lambda t: t.materialize() if isinstance(t, (LazyPoolGrad, LazyConvOut)) else (t._mn_codes.to(torch.float32) if isinstance(t, SignTensor) else t)
+        return func(*tree_map(un, args), **tree_map(un, kwargs))

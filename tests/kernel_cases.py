@@ -423,7 +423,7 @@ def check_pool_sign8(be, shape=(3, 5, 8, 16), seed=0):
     assert np.array_equal(be.to_host(din), t.grad.numpy())
 
 
-def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, **_):
+def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, pooled=False, **_):
     """mn_qconv_bnsign_fwd/bwd (conv + BatchNorm + sign on packed codes; y never stored) vs an fp64 numpy evaluation of the
     same block on the same +-1 input and ternary-coded weights."""
     r = np.random.default_rng(seed)
@@ -467,8 +467,23 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
     be.call("mn_qconv_bnsign_fwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
             be.ptr(dRM), be.ptr(dRV), be.ptr(save), be.ptr(a8), be.ptr(ws), nb, be.stream)
     dy, dgam, dbet = be.empty((N, Oc, H, W)), be.empty(Oc), be.empty(Oc)
-    be.call("mn_qconv_bnsign_bwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save), be.ptr(dDA),
-            int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)
+    if pooled:
+        # a 2x2 max-pool behind the block: the kernel gets the POOLED gradient + the block's own output codes; the reference routes
+        # it through torch's max_pool2d backward on those same codes and then takes the ordinary path
+        import torch
+        gp = r.standard_normal((N, Oc, H // 2, W // 2)).astype(F)
+        t_ = torch.from_numpy(be.to_host(a8).astype(F)).requires_grad_(True)
+        torch.nn.functional.max_pool2d(t_, 2, 2).backward(torch.from_numpy(gp))
+        da = t_.grad.numpy().astype(F)
+        dz = np.where((z > -1) & (z < 1), da.astype(np.float64), 0.0)
+        dbeta_ref, dgamma_ref = dz.sum(axis=(0, 2, 3)), (dz * zh).sum(axis=(0, 2, 3))
+        dy_ref = gi * (dz - dbeta_ref.reshape(1, -1, 1, 1) / n - zh * dgamma_ref.reshape(1, -1, 1, 1) / n) if training else gi * dz
+        dGP = be.to_dev(gp)
+        be.call("mn_qconv_bnsign_bwd_pooled", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save),
+                be.ptr(dGP), be.ptr(a8), int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)
+    else:
+        be.call("mn_qconv_bnsign_bwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save), be.ptr(dDA),
+                int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)
     sv = be.to_host(save)
     assert np.max(np.abs(sv[0] - mean)) <= 2e-6 * max(1.0, np.max(np.abs(mean))) and np.max(np.abs(sv[1] - invstd) / invstd) <= 4e-6
     a_got = be.to_host(a8).astype(np.int64)

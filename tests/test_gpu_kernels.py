@@ -300,3 +300,10 @@ WG2_CASES = [
 def test_qgemm_sign8_wgrad_direct(be, case):
     K.check_conv(be, seed=210 + case, wmode=1, sign8=True, algos=(3,), **WG2_CASES[case])
     K.check_conv(be, seed=215 + case, wmode=1, sign8=True, algos=(3,), in_shuffle=2, **WG2_CASES[case])
+
+
+@pytest.mark.parametrize("case", [1, 2])
+def test_qconv_bnsign_fused_pooled_gradient(be, case):
+    K.check_qconv_bnsign(be, seed=190 + case, pooled=True, **K.QGEMM_PW_CASES[case])
+    K.check_qconv_bnsign(be, seed=195 + case, pooled=True, training=False, in_shuffle=2 if case == 1 else 0, **K.QGEMM_PW_CASES[case])
+    K.check_qconv_bnsign(be, seed=199, pooled=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)      # nin_gc L3

@@ -410,3 +410,49 @@ def test_first_conv_runs_on_our_kernels_and_matches_torch():
     # a geometry the kernels do not cover (stride 2) silently takes the stock path
     s2 = Conv2dFirst(3, 8, 3, stride=2, padding=1).cuda()
     assert s2(x).shape == (16, 8, 16, 16)
+
+
+def test_wbwtab_pool_gradient_stays_pooled_and_matches():
+    """The sign max-pool hands its input gradient on in pooled form (LazyPoolGrad); the fused block in front expands it inside
+    its backward kernels.  Teacher-forced on block + pool: identical input codes and output gradient with the fusion on / off."""
+    from micronet_amd import ops
+    from micronet_amd.models.nin_gc import ConvBNReLU
+    from micronet_amd.sign_tensor import SignTensor
+    w = _q("wbwtab")
+    torch.manual_seed(13)
+    net = nn.Sequential(ConvBNReLU(3, 64, 3, padding=1), ConvBNReLU(64, 128, 1, groups=2, channel_shuffle=1, shuffle_groups=2), nn.MaxPool2d(2, 2),
+                        ConvBNReLU(128, 10, 1), nn.AvgPool2d(8)).cuda().train()
+    q = w.prepare(net, inplace=True, A=2, W=3)
+    blk, pool = q[1], q[2]
+    codes = (torch.randint(0, 2, (8, 64, 16, 16), device="cuda", dtype=torch.int8) * 2 - 1)
+    gout = torch.randn(8, 128, 8, 8, device="cuda")
+    res = {}
+    for lazy in (True, False):
+        ops.LAZY_POOL_GRAD = lazy
+        try:
+            for p_ in blk.parameters():
+                p_.grad = None
+            blk.bn.running_mean.zero_(); blk.bn.running_var.fill_(1.0)
+            x = SignTensor(codes.clone()).requires_grad_(True)
+            out = pool(blk(x))
+            assert isinstance(out, SignTensor)
+            out.backward(gout)
+            res[lazy] = (x.grad.clone(), blk.conv.weight.grad.clone(), blk.bn.weight.grad.clone(), blk.bn.bias.grad.clone(), out.to_float())
+        finally:
+            ops.LAZY_POOL_GRAD = True
+    assert torch.equal(res[True][4], res[False][4])
+    for a_, b_, name in zip(res[True][:4], res[False][:4], ("dx", "dweight", "dgamma", "dbeta")):
+        assert rel_err(a_.cpu(), b_.cpu()) <= 2e-6, (name, rel_err(a_.cpu(), b_.cpu()))
+    # a foreign consumer of the lazy gradient (a tensor hook) sees the expanded gradient
+    x = SignTensor(codes.clone()).requires_grad_(True)
+    mid = blk(x)
+    seen = {}
+    mid.register_hook(lambda g_: seen.__setitem__("g", (type(g_).__name__, (g_ * 1.0).clone())))
+    pool(mid).backward(gout)
+    ref = torch.zeros(8, 128, 16, 16, device="cuda").requires_grad_(True)
+    assert seen["g"][1].shape == (8, 128, 16, 16) and float(seen["g"][1].abs().sum()) > 0
+    assert torch.allclose(seen["g"][1].sum(), gout.sum(), rtol=1e-4)
+    # and the whole net still trains
+    y = q(torch.randn(8, 3, 16, 16, device="cuda"))
+    y.square().mean().backward()
+    assert all(torch.isfinite(p_.grad).all() for p_ in q.parameters() if p_.grad is not None)
