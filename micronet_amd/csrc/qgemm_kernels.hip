@@ -294,6 +294,151 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// pointwise backward-data without a clip-STE epilogue (binary / ternary nets: the STE of the sign lives in the BatchNorm+sign
+// backward), tuned for instruction issue and memory-level parallelism -- the structure of k_pws (qgemm_sign.hip):
+//   * gy is streamed with UNCONDITIONAL float4 loads (indices clamped, never masked) from 32-bit offsets; the channel offsets
+//     of a K-step come from an LDS table; the registers of a K-step are re-loaded with the data of TWO steps ahead as soon as
+//     its fragments are built, so two steps (16 KB per wave) are always in flight;
+//   * the three exact bf16 terms are built per pixel column q and contracted term-outer: NT independent accumulators
+//     between two MFMAs on the same one;
+//   * dx leaves as float4 = 4 consecutive pixels per channel through the output channel map (folded shuffle).
+struct PwdParams {
+    const float* gy;          // [N][G*Kc][HW]     (Kc = out-channels of the group: the contraction index)
+    float* dx;                // [N][G*Mr][HW]     (Mr = in-channels of the group)
+    const uint16_t* wc;       // transposed codes [G][Mpad][Kp]
+    const float* kscale;      // [G][Kp] weight scale of contraction channel k
+    int N, HW, Cin_total, Cout_total, Kc, Mr, G, Kp, KS, Mpad, num_mblk, nchunks, CB;
+    uint32_t NP;
+    FastDiv fd_hw;
+    ChanMap out_map;
+};
+template <int NT, int KS>
+__global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int MB = 16 * NT;
+    const int LDW = p.Kp + 8;
+    uint16_t* wsm = reinterpret_cast<uint16_t*>(smem);
+    float* ks = smem + (MB * LDW) / 2;                            // [Kp]
+    uint32_t* koff = reinterpret_cast<uint32_t*>(ks + p.Kp);      // [Kp] element offset of gy channel k (clamped)
+    uint32_t* ooff = koff + p.Kp;                                  // [MB] element offset of the (shuffled) dx channel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const uint32_t HW = (uint32_t)p.HW;
+
+    uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u; b >>= 3;
+    const int mblk = b % p.num_mblk; b /= p.num_mblk;
+    const uint32_t idx = b * 8u + xcd;
+    if (idx >= (uint32_t)(p.G * p.CB)) return;
+    const int cb = idx % p.CB, g = idx / p.CB;
+    {
+        const uint16_t* wg = p.wc + ((int64_t)g * p.Mpad + mblk * MB) * p.Kp;
+        const int k8 = p.Kp >> 3;
+        for (int q = tid; q < MB * k8; q += 256) {
+            const int row = q / k8, c8 = q - row * k8;
+            *reinterpret_cast<u32x4*>(wsm + row * LDW + c8 * 8) = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.Kp + c8 * 8);
+        }
+        for (int k = tid; k < p.Kp; k += 256) {
+            ks[k] = p.kscale[g * p.Kp + k];
+            koff[k] = (uint32_t)(g * p.Kc + (k < p.Kc ? k : p.Kc - 1)) * HW;
+        }
+        for (int i = tid; i < MB; i += 256) {
+            const int m = mblk * MB + i;
+            ooff[i] = (uint32_t)chan_phys(p.out_map, g * p.Mr + (m < p.Mr ? m : p.Mr - 1)) * HW;
+        }
+    }
+    __syncthreads();
+
+    const int chunk0 = cb * 4 + wave, cstride = p.CB * 4;
+    const int my_chunks = chunk0 < p.nchunks ? (p.nchunks - chunk0 + cstride - 1) / cstride : 0;
+    const int total = my_chunks * KS;
+    const uint16_t* wl = wsm + j * LDW + kg * 8;
+    const uint32_t Pmax = p.NP - 4u;
+
+    // K-step `it` (chunk it / KS, step it % KS) of this wave: 8 channels x 4 pixels per lane
+    auto issue = [&](float4 (&raw)[8], int it) {
+        const int ci = it / KS, s = it - ci * KS;
+        uint32_t P = (uint32_t)(chunk0 + ci * cstride) * 64u + 4u * j;
+        P = P < Pmax ? P : Pmax;
+        const uint32_t n = fd_div(P, p.fd_hw);
+        const uint32_t go = n * (uint32_t)p.Cin_total * HW + (P - n * HW);
+        const u32x4 o0 = *reinterpret_cast<const u32x4*>(koff + s * 32 + kg * 8), o1 = *reinterpret_cast<const u32x4*>(koff + s * 32 + kg * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            raw[e] = *reinterpret_cast<const float4*>(p.gy + (go + o0[e]));
+            raw[4 + e] = *reinterpret_cast<const float4*>(p.gy + (go + o1[e]));
+        }
+    };
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[8], rb[8];
+    if (total > 0) issue(ra, 0);
+    if (total > 1) issue(rb, 1);
+    auto step = [&](float4 (&raw)[8], int it) {
+        const int ci = it / KS, s = it - ci * KS;
+        // weight scale of the 8 contraction channels of this lane
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(ks + s * 32 + kg * 8), s1 = *reinterpret_cast<const f32x4*>(ks + s * 32 + kg * 8 + 4);
+        float v[8][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e][0] = raw[e].x * s0[e]; v[e][1] = raw[e].y * s0[e]; v[e][2] = raw[e].z * s0[e]; v[e][3] = raw[e].w * s0[e];
+            v[4 + e][0] = raw[4 + e].x * s1[e]; v[4 + e][1] = raw[4 + e].y * s1[e]; v[4 + e][2] = raw[4 + e].z * s1[e]; v[4 + e][3] = raw[4 + e].w * s1[e];
+        }
+        if (it + 2 < total) issue(raw, it + 2);           // the registers are free: two steps ahead
+        u32x4 av[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const u32x4*>(wl + s * 32 + t * 16 * LDW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x4 b0, b1, b2;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float x0 = v[2 * d][q], x1 = v[2 * d + 1][q];
+                const float h0 = mn_bf16_head(x0), h1 = mn_bf16_head(x1);
+                const float r0 = x0 - h0, r1 = x1 - h1;
+                const float m0 = mn_bf16_head(r0), m1 = mn_bf16_head(r1);
+                b0[d] = mn_pack_bf16x2(h0, h1);
+                b1[d] = mn_pack_bf16x2(m0, m1);
+                b2[d] = mn_pack_bf16x2(r0 - m0, r1 - m1);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[q][t] = mn_mfma_bf16(av[t], b0, acc[q][t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[q][t] = mn_mfma_bf16(av[t], b1, acc[q][t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[q][t] = mn_mfma_bf16(av[t], b2, acc[q][t]);
+        }
+        if (s == KS - 1) {
+            const uint32_t P = (uint32_t)(chunk0 + ci * cstride) * 64u + 4u * j;
+            if (P < p.NP) {
+                const uint32_t n = fd_div(P, p.fd_hw);
+                const uint32_t ob = n * (uint32_t)p.Cout_total * HW + (P - n * HW);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = t * 16 + kg * 4 + r;
+                        if (mblk * MB + ml < p.Mr)
+                            *reinterpret_cast<float4*>(p.dx + (ob + ooff[ml])) = make_float4(acc[0][t][r], acc[1][t][r], acc[2][t][r], acc[3][t][r]);
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    for (int it = 0; it < total; it += 2) {
+        step(ra, it);
+        if (it + 1 < total) step(rb, it + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pointwise backward-weight: dwq[g][m][c] = sum_{n,p} gy[n][g*Mg+m][p] * code_a[n][g*Cg+c][p]   (times the activation scale)
 struct PwWgParams {
     const float* gy;
@@ -624,6 +769,51 @@ static int plan_pw_wgrad(const mn_conv_geom* g, WgPlan* pl) {
     return 1;
 }
 
+struct PwdPlan { PwdParams p; PackParams pk; int NT; size_t lds; int grid, pack_grid; int64_t off_scale, ws_bytes; };
+static int plan_pwd(const mn_conv_geom* g, PwdPlan* pl) {
+    if (!pw_geom_ok(g)) return 0;
+    const int Cg = g->C / g->groups, Mg = g->O / g->groups;
+    const int64_t NP = (int64_t)g->N * g->H * g->W;
+    if (4 * NP * (g->C > g->O ? g->C : g->O) >= ((int64_t)1 << 32)) return 0;        // 32-bit element offsets
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    PwdParams& p = pl->p;
+    p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.NP = (uint32_t)NP;
+    p.Cin_total = g->O; p.Cout_total = g->C; p.Kc = Mg; p.Mr = Cg;
+    p.out_map = make_chanmap(g->in_shuffle, g->C);
+    p.Kp = qg_roundup(Mg, 32); p.KS = p.Kp / 32;
+    if (p.KS < 1 || p.KS > 4) return 0;
+    int NT = Cg > 32 ? 4 : (Cg > 16 ? 2 : 1);
+    pl->NT = NT;
+    const int MB = 16 * NT;
+    p.num_mblk = (Cg + MB - 1) / MB; p.Mpad = p.num_mblk * MB;
+    pl->lds = (size_t)MB * (p.Kp + 8) * 2 + (size_t)2 * p.Kp * 4 + (size_t)MB * 4;
+    p.nchunks = (int)((NP + 63) / 64);
+    int CB = (p.nchunks + 3) / 4;
+    const int cap = 1024 / (p.G * p.num_mblk) > 0 ? 1024 / (p.G * p.num_mblk) : 1;
+    if (CB > cap) CB = cap;
+    p.CB = CB;
+    p.fd_hw = make_fastdiv((uint32_t)p.HW);
+    const int64_t nb = (int64_t)qg_roundup(p.G * CB, 8) * p.num_mblk;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    const int64_t code_bytes = (int64_t)p.G * p.Mpad * p.Kp * 2;
+    pl->off_scale = (code_bytes + 255) / 256 * 256;
+    pl->ws_bytes = pl->off_scale + (int64_t)p.G * p.Kp * 4;
+    PackParams& k = pl->pk;
+    k.G = g->groups; k.Mg = Mg; k.Cg = Cg; k.T = 1; k.KW = 1; k.transpose = 1;
+    k.Mpad = 0; k.Cgp = 0; k.Cpad = p.Mpad; k.Mgp = p.Kp;
+    pl->pack_grid = k.G * k.Mgp;
+    return 1;
+}
+template <int NT>
+static void launch_pwd(const PwdPlan& pl, hipStream_t s) {
+    switch (pl.p.KS) {
+        case 1: hipLaunchKernelGGL((k_pwd<NT, 1>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
+        case 2: hipLaunchKernelGGL((k_pwd<NT, 2>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
+        case 3: hipLaunchKernelGGL((k_pwd<NT, 3>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
+        default: hipLaunchKernelGGL((k_pwd<NT, 4>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
+    }
+}
 int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
     if (!pw_geom_ok(g)) return kk_supported(g, aq, wq, which);
     if (which == 0) { PwPlan pl; return wq_codeable(wq) && aq_codeable(aq, 0) && plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl); }
@@ -635,7 +825,9 @@ int64_t qg_ws_bytes(const mn_conv_geom* g, int which) {
     if (!pw_geom_ok(g)) return kk_ws_bytes(g, which);
     if (which == 0 || which == 1) {   // NT <= 4: the larger Mpad; forward: also the fused sign kernels' workspace
         PwPlan pl;
-        const int64_t a = plan_pw(g, which, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0, b = which == 0 ? pws_ws_bytes(g) : 0;
+        PwdPlan pd;
+        const int64_t a = plan_pw(g, which, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0;
+        const int64_t b = which == 0 ? pws_ws_bytes(g) : (plan_pwd(g, &pd) ? pd.ws_bytes : 0);
         return a > b ? a : b;
     }
     if (which == 2) {
@@ -699,6 +891,20 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     if (rc) return rc;
     if (ste.mode == MN_ACTQ_SIGN8) ste.mode = MN_ACTQ_NONE;      // the clip-STE of the sign lives in mn_bnsign_bwd
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
+    if (ste.mode == MN_ACTQ_NONE && !getenv("MN_NO_PWD")) {      // no clip-STE epilogue: the prefetching kernel
+        PwdPlan pd;
+        if (plan_pwd(g, &pd) && ws_bytes >= pd.ws_bytes) {
+            fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
+            qg_launch_pack(pd.pk, pd.pack_grid, s);
+            pd.p.gy = gy; pd.p.dx = dx; pd.p.wc = pd.pk.codes; pd.p.kscale = pd.pk.scale_out;
+            mn_set_last_kernel("k_pwd<%d, %d>", pd.NT, pd.p.KS);
+            mn_prof_begin(s);
+            if (pd.NT == 4) launch_pwd<4>(pd, s); else if (pd.NT == 2) launch_pwd<2>(pd, s); else launch_pwd<1>(pd, s);
+            mn_prof_end(s);
+            MN_CHECK_LAUNCH("mn_conv2d_bwd_data(qgemm)");
+            return MN_OK;
+        }
+    }
     fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
     qg_launch_pack(pl.pk, pl.pack_grid, s);
     Pro none; none.mode = MN_ACTQ_NONE; none.s = 1.f; none.qmin = none.qmax = 0.f; none.qp = nullptr;

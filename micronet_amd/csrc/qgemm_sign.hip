@@ -158,34 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
         const bool more = chunk + cstride < p.nchunks;       // wave-uniform
         const uint32_t xo_next = more ? chunk_xo(chunk + cstride) : 0u;
 
-        f32x4 acc[4][NT];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            u32x4 bq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) bq[q][d] = mn_sign8_pair(cur[s * 8 + 2 * d], cur[s * 8 + 2 * d + 1], q);
-            if (more) load_step(cur, s, xo_next);            // this step's registers are free: prefetch the next chunk into them
-            // A fragments one tile ahead only: the scheduler would otherwise hoist all NT LDS reads (4 VGPRs each) above the MFMAs
-            u32x4 a = *reinterpret_cast<const u32x4*>(wl + s * 32);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                u32x4 an = a;
-                if (t + 1 < NT) an = *reinterpret_cast<const u32x4*>(wl + s * 32 + (t + 1) * 16 * LDW);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, bq[q], acc[q][t]);
-                a = an;
-                MN_SCHED_FENCE();
-            }
-        }
-
-        // epilogue: lane (j, kg) holds out-channels t*16 + 4kg + r of pixels P .. P+3; acc is an exact integer
-        float4 gq[2][4];                         // backward: the gradient rows of tile t (one tile ahead)
+        float4 gq[NT][4];                        // backward: the gradient rows of every tile, in flight during the MFMAs below
         // *_POOL: the lane's pixel quad (row h, columns w .. w+3) covers half of two pooling windows: gq = {g[win 0], g[win 1],
         // own codes of row h & ~1, own codes of row h | 1} and the quad's gradient is g where the pixel is the window's first maximum
         uint32_t gbase = 0u, cbase = 0u, hb = 0u;
@@ -214,14 +187,39 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
         };
         if (GRAD) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gq[0][r] = load_grad(0, r);
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gq[t][r] = load_grad(t, r);
         }
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bq[q][d] = mn_sign8_pair(cur[s * 8 + 2 * d], cur[s * 8 + 2 * d + 1], q);
+            if (more) load_step(cur, s, xo_next);            // this step's registers are free: prefetch the next chunk into them
+            // A fragments one tile ahead only: the scheduler would otherwise hoist all NT LDS reads (4 VGPRs each) above the MFMAs
+            u32x4 a = *reinterpret_cast<const u32x4*>(wl + s * 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                u32x4 an = a;
+                if (t + 1 < NT) an = *reinterpret_cast<const u32x4*>(wl + s * 32 + (t + 1) * 16 * LDW);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q][t] = mn_mfma_bf16(a, bq[q], acc[q][t]);
+                a = an;
+                MN_SCHED_FENCE();
+            }
+        }
+
+        // epilogue: lane (j, kg) holds out-channels t*16 + 4kg + r of pixels P .. P+3; acc is an exact integer
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (GRAD && t + 1 < NT) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gq[(t + 1) & 1][r] = load_grad(t + 1, r);
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ml = t * 16 + kg * 4 + r;
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                     }
                 } else {
                     const float L = c0[ml], U = c1[ml], fl = c2[ml], A = c3[ml], B = c4[ml];
-                    const float4 g4 = gq[t & 1][r];
+                    const float4 g4 = gq[t][r];
                     float gv[4] = {g4.x, g4.y, g4.z, g4.w};
                     if (POOL) {      // first maximum of each window in row-major order (ATen's max_pool2d): the first +1, else element 0
                         const uint32_t r0 = mn_f2u(g4.z), r1 = mn_f2u(g4.w);
@@ -445,9 +443,10 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    float4 ga[MW], gb[MW];
-    uint32_t ua[CW], ub[CW];
-    auto fetch = [&](int st) {
+    // two register sets alternate: while one step is contracted, the loads of the next TWO steps are in flight
+    struct Raw { float4 ga[MW], gb[MW]; uint32_t ua[CW], ub[CW]; };
+    Raw r0, r1;
+    auto fetch = [&](Raw& R, int st) {
         const uint32_t Pa = (uint32_t)st * 32u + 4u * kg, Pb = Pa + 16u;
         const uint32_t na = fd_div(Pa, p.fd_hw), nb = fd_div(Pb, p.fd_hw);
         const uint32_t pa = Pa - na * HW, pb = Pb - nb * HW;
@@ -455,24 +454,23 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         const uint32_t xa = na * (uint32_t)p.Cin_total * HW + pa, xb = nb * (uint32_t)p.Cin_total * HW + pb;
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
-            ga[mi] = *reinterpret_cast<const float4*>(p.gy + (oa + goff[mi]));
-            gb[mi] = *reinterpret_cast<const float4*>(p.gy + (ob + goff[mi]));
+            R.ga[mi] = *reinterpret_cast<const float4*>(p.gy + (oa + goff[mi]));
+            R.gb[mi] = *reinterpret_cast<const float4*>(p.gy + (ob + goff[mi]));
         }
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
-            ua[ci] = *reinterpret_cast<const uint32_t*>(p.x + (xa + xoff[ci]));
-            ub[ci] = *reinterpret_cast<const uint32_t*>(p.x + (xb + xoff[ci]));
+            R.ua[ci] = *reinterpret_cast<const uint32_t*>(p.x + (xa + xoff[ci]));
+            R.ub[ci] = *reinterpret_cast<const uint32_t*>(p.x + (xb + xoff[ci]));
         }
     };
     const int st0 = p.st_stride == 1 ? z * p.st_per_z : z;
     const int st_end = p.st_stride == 1 ? ((st0 + p.st_per_z) < p.nsteps ? (st0 + p.st_per_z) : p.nsteps) : p.nsteps;
-    if (st0 < st_end) fetch(st0);
-    for (int st = st0; st < st_end; st += p.st_stride) {
+    auto contract = [&](Raw& R, int st) {
         // B fragments: sign codes -> bf16 +-1
         u32x4 bf[CW];
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
-            const uint32_t u = ua[ci], v = ub[ci];
+            const uint32_t u = R.ua[ci], v = R.ub[ci];
             bf[ci] = u32x4{0x3F803F80u | ((u & 0x80u) << 8) | ((u & 0x8000u) << 16), 0x3F803F80u | ((u & 0x800000u) >> 8) | (u & 0x80000000u),
                            0x3F803F80u | ((v & 0x80u) << 8) | ((v & 0x8000u) << 16), 0x3F803F80u | ((v & 0x800000u) >> 8) | (v & 0x80000000u)};
         }
@@ -480,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         u32x4 a0[MW], a1[MW], a2[MW];
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
-            const float v[8] = {ga[mi].x, ga[mi].y, ga[mi].z, ga[mi].w, gb[mi].x, gb[mi].y, gb[mi].z, gb[mi].w};
+            const float v[8] = {R.ga[mi].x, R.ga[mi].y, R.ga[mi].z, R.ga[mi].w, R.gb[mi].x, R.gb[mi].y, R.gb[mi].z, R.gb[mi].w};
             float t0[8], t1[8], t2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -497,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
                 a2[mi][d] = mn_pack_bf16x2(t2[2 * d], t2[2 * d + 1]);
             }
         }
-        if (st + p.st_stride < st_end) fetch(st + p.st_stride);          // in flight during the MFMAs below
+        if (st + 2 * p.st_stride < st_end) fetch(R, st + 2 * p.st_stride);     // the registers are free: two steps ahead
         // term-outer: MW*CW independent accumulators between two MFMAs on the same one (a dependent MFMA waits ~2 issue slots)
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
@@ -511,6 +509,12 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
             for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a2[mi], bf[ci], acc[mi][ci]);
+    };
+    if (st0 < st_end) fetch(r0, st0);
+    if (st0 + p.st_stride < st_end) fetch(r1, st0 + p.st_stride);
+    for (int st = st0; st < st_end; st += 2 * p.st_stride) {
+        contract(r0, st);
+        if (st + p.st_stride < st_end) contract(r1, st + p.st_stride);
     }
     // partial tile: lane (j, kg) holds rows m = 4kg + r, column c = j
 #pragma unroll

@@ -23,6 +23,8 @@ LAYERS = {   # name: (Cin, Cout, k, pad, groups, HW side)
     "L1": (3, 256, 5, 2, 1, 32), "L2": (256, 256, 1, 0, 2, 32), "L3": (256, 256, 1, 0, 2, 32),
     "L4": (256, 512, 3, 1, 16, 16), "L5": (512, 512, 1, 0, 4, 16), "L6": (512, 512, 1, 0, 4, 16),
     "L7": (512, 1024, 3, 1, 32, 8), "L8": (1024, 1024, 1, 0, 8, 8), "L9": (1024, 10, 1, 0, 1, 8),
+    # L2 / L5 with image sides that are not powers of two (probe for power-of-two row-stride effects in HBM channel mapping)
+    "X2": (256, 256, 1, 0, 2, 36), "X2b": (256, 256, 1, 0, 2, 28), "X5": (512, 512, 1, 0, 4, 20),
 }
 
 
