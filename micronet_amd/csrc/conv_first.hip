@@ -214,25 +214,32 @@ __global__ __launch_bounds__(256) void k_c1_pack(const float* __restrict__ w, fl
         wp[i] = (k < K && m < O) ? w[(int64_t)m * K + k] : 0.f;
     }
 }
-// fixed-order fp64 reduction of the Z partial tiles: dw[m][k], dbias[m].  One wave per output: lane l sums partials l, l+64, ...
-// and the 64 sums are combined by a butterfly -- the same order on every run (deterministic).
+// fixed-order fp64 reduction of the Z partial tiles: dw[m][k], dbias[m].  A block owns 64 consecutive outputs (coalesced 256-B
+// rows of every partial tile); its four waves sum z = w, w+4, ... and the four sums are combined in wave order through LDS --
+// the same order on every run (deterministic).  Outputs are indexed over the padded [Opad][80] tile, then dbias.
 __global__ __launch_bounds__(256) void k_c1_reduce(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw, float* __restrict__ db,
                                                    int Z, int O, int K, int Opad) {
-    const int64_t nw = (int64_t)O * K, total = nw + (db ? O : 0);
-    const int lane = threadIdx.x & 63;
-    const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; i < total; i += nwaves) {
+    __shared__ double red[4][64];
+    const int og = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const int64_t ntile = (int64_t)Opad * 80, total = ntile + (db ? Opad : 0);
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + og;
         double s = 0.0;
-        if (i < nw) {
-            const int m = (int)(i / K), k = (int)(i - (int64_t)m * K);
-            for (int z = lane; z < Z; z += 64) s += (double)part[((int64_t)z * Opad + m) * 80 + k];
-        } else {
-            const int m = (int)(i - nw);
-            for (int z = lane; z < Z; z += 64) s += (double)dbpart[(int64_t)z * Opad + m];
+        if (i < ntile) { for (int z = zg; z < Z; z += 4) s += (double)part[(int64_t)z * ntile + i]; }
+        else if (i < total) { for (int z = zg; z < Z; z += 4) s += (double)dbpart[(int64_t)z * Opad + (i - ntile)]; }
+        __syncthreads();
+        red[zg][og] = s;
+        __syncthreads();
+        if (zg == 0 && i < total) {
+            const double v = ((red[0][og] + red[1][og]) + red[2][og]) + red[3][og];
+            if (i < ntile) {
+                const int m = (int)(i / 80), k = (int)(i - (int64_t)m * 80);
+                if (m < O && k < K) dw[(int64_t)m * K + k] = (float)v;
+            } else {
+                const int m = (int)(i - ntile);
+                if (m < O) db[m] = (float)v;
+            }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) { if (i < nw) dw[i] = (float)s; else db[i - nw] = (float)s; }
     }
 }
 
@@ -320,7 +327,7 @@ int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float*
     else { raise_lds_limit((const void*)k_c1_wgrad<1>, pl.lds); hipLaunchKernelGGL(k_c1_wgrad<1>, dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
     mn_prof_end(s);
     const int64_t total = (int64_t)p.O * p.K + (dbias ? p.O : 0);
-    hipLaunchKernelGGL(k_c1_reduce, dim3(mn_grid_for(total * 64, 256, 4096)), dim3(256), 0, s, (const float*)p.part, (const float*)p.dbpart, dw, dbias, p.Z, p.O, p.K, p.Opad);
+    hipLaunchKernelGGL(k_c1_reduce, dim3(mn_grid_for((int64_t)p.Opad * 81, 64, 2048)), dim3(256), 0, s, (const float*)p.part, (const float*)p.dbpart, dw, dbias, p.Z, p.O, p.K, p.Opad);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(first-layer)");
     return MN_OK;
 }

@@ -661,8 +661,8 @@ static void launch_pws2(const PwsPlan& pl, hipStream_t s) {
 }
 template <int EPI>
 static int launch_pws(const PwsPlan& pl, hipStream_t s, double nbytes, const char* what) {
-    static const char* en[7] = {"Y", "STATS", "SIGN8", "BWD_PART", "BWD_APPLY", "BWD_PART_POOL", "BWD_APPLY_POOL"};
-    mn_set_last_kernel("k_pws<%d, %d, %s>", pl.NT, pl.KS, en[EPI]);
+    // the name rocprofv3 prints: EPI 0 Y, 1 STATS, 2 SIGN8, 3 BWD_PART, 4 BWD_APPLY, 5 BWD_PART_POOL, 6 BWD_APPLY_POOL
+    mn_set_last_kernel("k_pws<%d, %d, %d>", pl.NT, pl.KS, EPI);
     mn_prof_bytes(nbytes);
     mn_prof_begin(s);
     switch (pl.NT) {
