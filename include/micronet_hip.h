@@ -252,6 +252,16 @@ int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq, const int
                                const float* beta, const float* save, const float* dpool, const int8_t* a_own, int training, float* dy,
                                float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, mn_stream_t stream);
 
+/* ------------------------------------------------------------------ classifier conv of a binary net
+ * The LAST conv of the WbWtAb nets keeps fp32 weights (the rewrite skips it, wbwtab/quantize.py:251) but reads the +-1 output of the
+ * previous block (models/nin_gc.py: 1024 -> 10, 1x1).  With O <= 16 this is a per-pixel dot product over C sign codes:
+ *   fwd:      y[n][o][p] = bias[o] + sum_c w[o][c] * a[n][c][p]        (a: int8 codes [N][C][HW], w: [O][C], y: [N][O][HW] fp32)
+ *   bwd_data: dx[n][c][p] = sum_o w[o][c] * gy[n][o][p]
+ * (backward-weight is mn_conv2d_bwd_weight with MN_ACTQ_SIGN8).  Needs O <= 16, HW % 4 == 0. */
+int mn_signconv1x1_small_supported(int64_t C, int64_t HW, int64_t O);
+int mn_signconv1x1_small_fwd(const int8_t* a, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream);
+int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float* dx, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer step of the training loop
  * <scheme>/main.py: optimizer.step() with torch.optim.Adam, one parameter group per tensor (wqaq/dorefa/main.py:308-315).
  * One launch per MN_ADAM_MAX_TENSORS tensors; `tensors` is a HOST array (device pointers inside), copied into the kernel

@@ -86,6 +86,9 @@ PROTOTYPES = {
     "mn_qconv_bnsign_fwd": (_I, [_G, _W, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _L, _P]),
     "mn_qconv_bnsign_bwd": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_qconv_bnsign_bwd_pooled": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    "mn_signconv1x1_small_supported": (_I, [_L, _L, _L]),
+    "mn_signconv1x1_small_fwd": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P]),
+    "mn_conv1x1_small_bwd_data": (_I, [_P, _P, _P, _L, _L, _L, _L, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),

@@ -50,6 +50,12 @@ __device__ __forceinline__ int mn_wave_any(int pred) { return __builtin_amdgcn_b
 __device__ __forceinline__ unsigned mn_f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float mn_u2f(unsigned u) { return __uint_as_float(u); }
 #endif
+// a value that is the same in every lane of the wave, told to the compiler (scalar registers / scalar loads downstream)
+#ifdef MN_EMULATION
+__device__ __forceinline__ int mn_uniform(int v) { return v; }
+#else
+__device__ __forceinline__ int mn_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
 // scheduling fence: no instruction may be moved across it (keeps software-pipelined loads from being hoisted en bloc)
 #ifdef MN_EMULATION
 #define MN_SCHED_FENCE() do { } while (0)

@@ -288,3 +288,109 @@ extern "C" int mn_bnsign_bwd(const float* da, const float* y, const float* save,
     MN_CHECK_LAUNCH("mn_bnsign_bwd");
     return MN_OK;
 }
+
+// ---------------------------------------------------------------- last layer of a binary net: 1x1 conv, few outputs, sign-code input
+// The classifier conv of the WbWtAb nets (models/nin_gc.py: 1024 -> 10, 1x1) keeps full-precision weights (the rewrite skips the
+// last conv, wbwtab/quantize.py:251) but its INPUT is the +-1 output of the previous block.  O is tiny, so this is a per-pixel dot
+// product over C sign codes: y[n][o][p] = bias[o] + sum_c w[o][c] * a[n][c][p].  Block = (image, 64 pixels), 16 waves split the
+// channels (wave-uniform ranges: the weights come through the scalar cache), keep O <= 16 running sums per lane and combine them in
+// wave order through LDS.  The layer is bound by the latency of its byte loads: each lane keeps 16 in flight, 4 waves per SIMD.
+#define SC_MAXO 16
+#define SC_WAVES 16
+__global__ __launch_bounds__(1024) void k_sconv_fwd(const char* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
+                                                    float* __restrict__ y, int C, int HW, int O) {
+    HIP_DYNAMIC_SHARED(float, red)            // [SC_WAVES][O][64]
+    const int tid = threadIdx.x, px = tid & 63, wv = mn_uniform(tid >> 6);
+    const int chunks = (HW + 63) >> 6;
+    const int n = blockIdx.x / chunks, p = (blockIdx.x - n * chunks) * 64 + px;
+    float acc[SC_MAXO];
+#pragma unroll
+    for (int o = 0; o < SC_MAXO; ++o) acc[o] = 0.f;
+    const int per = (C + SC_WAVES - 1) / SC_WAVES;
+    const int c0 = wv * per, c1 = (c0 + per) < C ? (c0 + per) : C;
+    const char* src = a + (int64_t)n * C * HW + (p < HW ? p : 0);
+    int c = c0;
+    for (; c + 16 <= c1; c += 16) {
+        char v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(int64_t)(c + u) * HW];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float s = v[u] < 0 ? -1.f : 1.f;
+#pragma unroll
+            for (int o = 0; o < SC_MAXO; ++o)
+                if (o < O) acc[o] += w[o * C + c + u] * s;
+        }
+    }
+    for (; c < c1; ++c) {
+        const float s = src[(int64_t)c * HW] < 0 ? -1.f : 1.f;
+#pragma unroll
+        for (int o = 0; o < SC_MAXO; ++o)
+            if (o < O) acc[o] += w[o * C + c] * s;
+    }
+#pragma unroll
+    for (int o = 0; o < SC_MAXO; ++o)
+        if (o < O) red[(wv * O + o) * 64 + px] = acc[o];
+    __syncthreads();
+    for (int i = tid; i < O * 64; i += 1024) {
+        const int o = i >> 6, q = i & 63, pp = (blockIdx.x - n * chunks) * 64 + q;
+        if (pp < HW) {
+            float v = 0.f;
+            for (int k = 0; k < SC_WAVES; ++k) v += red[(k * O + o) * 64 + q];          // fixed order
+            y[((int64_t)n * O + o) * HW + pp] = v + (bias ? bias[o] : 0.f);
+        }
+    }
+}
+// its backward-data: dx[n][c][p] = sum_o w[o][c] * gy[n][o][p]  (O terms); thread = one float4 of 4 pixels of one channel
+__global__ __launch_bounds__(256) void k_sconv_dgrad(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ dx, int C, int HW, int O) {
+    __shared__ float gs[SC_MAXO * 64];
+    const int tid = threadIdx.x, q4 = tid & 15, cl = tid >> 4;
+    const int chunks = (HW + 63) >> 6, cblks = (C + 63) >> 6;
+    uint32_t b = blockIdx.x;
+    const int cb = b % cblks; b /= cblks;
+    const int ch = b % chunks;
+    const int n = b / chunks;
+    const int p0 = ch * 64;
+    for (int i = tid; i < O * 64; i += 256) {
+        const int o = i >> 6, q = i & 63;
+        gs[i] = (p0 + q < HW) ? gy[((int64_t)n * O + o) * HW + p0 + q] : 0.f;
+    }
+    __syncthreads();
+    if (p0 + q4 * 4 >= HW) return;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int c = cb * 64 + pass * 16 + cl;
+        if (c < C) {
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int o = 0; o < O; ++o) {
+                const float wv = w[(int64_t)o * C + c];
+                const float4 g4 = *reinterpret_cast<const float4*>(gs + o * 64 + q4 * 4);
+                r.x += wv * g4.x; r.y += wv * g4.y; r.z += wv * g4.z; r.w += wv * g4.w;
+            }
+            *reinterpret_cast<float4*>(dx + ((int64_t)n * C + c) * HW + p0 + q4 * 4) = r;
+        }
+    }
+}
+extern "C" int mn_signconv1x1_small_supported(int64_t C, int64_t HW, int64_t O) { return O >= 1 && O <= SC_MAXO && C >= 4 && HW % 4 == 0; }
+extern "C" int mn_signconv1x1_small_fwd(const int8_t* a, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream) {
+    if (!a || !w || !y || N <= 0 || !mn_signconv1x1_small_supported(C, HW, O)) MN_FAIL(MN_EINVAL, "mn_signconv1x1_small_fwd: needs O <= 16, HW %% 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nb = N * ((HW + 63) / 64);
+    if (nb > 0x7fffffff) MN_FAIL(MN_EINVAL, "mn_signconv1x1_small_fwd: too many blocks");
+    mn_set_last_kernel("k_sconv_fwd"); mn_prof_bytes((double)N * C * HW + 4.0 * N * O * HW); mn_prof_begin(s);
+    hipLaunchKernelGGL(k_sconv_fwd, dim3((unsigned)nb), dim3(1024), (size_t)SC_WAVES * O * 64 * 4, s, (const char*)a, w, bias, y, (int)C, (int)HW, (int)O);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_signconv1x1_small_fwd");
+    return MN_OK;
+}
+extern "C" int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float* dx, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream) {
+    if (!gy || !w || !dx || N <= 0 || !mn_signconv1x1_small_supported(C, HW, O) || !aligned16(dx)) MN_FAIL(MN_EINVAL, "mn_conv1x1_small_bwd_data: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nb = N * ((HW + 63) / 64) * ((C + 63) / 64);
+    if (nb > 0x7fffffff) MN_FAIL(MN_EINVAL, "mn_conv1x1_small_bwd_data: too many blocks");
+    mn_set_last_kernel("k_sconv_dgrad"); mn_prof_bytes(4.0 * N * C * HW + 4.0 * N * O * HW); mn_prof_begin(s);
+    hipLaunchKernelGGL(k_sconv_dgrad, dim3((unsigned)nb), dim3(256), 0, s, gy, w, dx, (int)C, (int)HW, (int)O);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_conv1x1_small_bwd_data");
+    return MN_OK;
+}

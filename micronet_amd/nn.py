@@ -19,3 +19,15 @@ class Conv2dFirst(nn.Conv2d):
                 ops.first_conv_supported(input.shape, self.weight.shape, self.stride, self.padding, self.dilation, self.groups)):
             return ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         return super().forward(input)
+
+
+class Conv2dSignIn(nn.Conv2d):
+    """The LAST conv of a WbWtAb net: full-precision weights (the rewrite skips it, wbwtab/quantize.py:251) but a +-1 input.  When
+    that input arrives packed (``SignTensor``) and the layer is a 1x1 classifier with few outputs it runs on the sign-code kernels
+    (``mn_signconv1x1_small_*``); otherwise it is an ordinary ``nn.Conv2d`` (a SignTensor is then unpacked on the way in)."""
+
+    def forward(self, input):
+        if self.padding_mode == "zeros" and not isinstance(self.padding, str) and \
+                ops.sign_classifier_supported(input, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            return ops.SignClassifierConv.apply(input, self.weight, self.bias)
+        return super().forward(input)

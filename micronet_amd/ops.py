@@ -668,3 +668,54 @@ def first_conv_supported(x_shape, w_shape, stride, padding, dilation, groups):
     g = _geom(x_shape, w_shape, stride, padding, dilation, groups)
     lib = _lib_()
     return bool(lib.mn_conv2d_first_supported(C.byref(g), 0)) and bool(lib.mn_conv2d_first_supported(C.byref(g), 2))
+
+
+def sign_classifier_supported(x, weight, stride, padding, dilation, groups):
+    if not isinstance(x, SignTensor) or x.dim() != 4 or weight.dim() != 4 or CONV_ALGO != _lib.MN_ALGO_AUTO:
+        return False
+    one = lambda v, k: v in (k, (k, k), [k, k])
+    if not (weight.shape[2] == 1 and weight.shape[3] == 1 and one(stride, 1) and one(padding, 0) and one(dilation, 1) and groups == 1):
+        return False
+    g = _geom(x.shape, weight.shape, 1, 0, 1, 1)
+    aq = ActQ(ACTQ_SIGN8, 8, 0, 0, None)
+    lib = _lib_()
+    return bool(lib.mn_signconv1x1_small_supported(x.shape[1], x.shape[2] * x.shape[3], weight.shape[0])) and \
+        bool(lib.mn_conv2d_qgemm_supported(C.byref(g), C.byref(aq), None, 2))
+
+
+class SignClassifierConv(Function):
+    """1x1 convolution with few outputs and full-precision weights on packed sign activations -- the last conv of a WbWtAb net
+    (models/nin_gc.py 1024 -> 10; wbwtab/quantize.py:251 leaves it un-quantised): the codes are read directly, nothing is unpacked."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        codes = x.codes
+        weight, bias = _chk(weight, "weight"), _chk(bias, "bias")
+        N, Cc, H, W = codes.shape
+        Oc = weight.shape[0]
+        y = torch.empty((N, Oc, H, W), dtype=torch.float32, device=codes.device)
+        with torch.cuda.device_of(codes):
+            _call("mn_signconv1x1_small_fwd", _p(codes), _p(weight), _p(bias), _p(y), N, Cc, H * W, Oc, _s())
+        ctx.save_for_backward(codes, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        codes, weight = ctx.saved_tensors
+        gy = _chk(gy, "grad")
+        N, Cc, H, W = codes.shape
+        Oc = weight.shape[0]
+        dx = dw = db = None
+        with torch.cuda.device_of(codes):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+                _call("mn_conv1x1_small_bwd_data", _p(gy), _p(weight), _p(dx), N, Cc, H * W, Oc, _s())
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                g = _geom(codes.shape, weight.shape, 1, 0, 1, 1)
+                aq = ActQ(ACTQ_SIGN8, 8, 0, 0, None)
+                dw = torch.empty_like(weight)
+                db = torch.empty(Oc, dtype=torch.float32, device=codes.device) if ctx.has_bias else None
+                ws, nb = _ws(g, 2, codes.device)
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
+        return dx, dw, db

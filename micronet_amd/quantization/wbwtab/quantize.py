@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from micronet_amd import ops
-from micronet_amd.nn import Conv2dFirst
+from micronet_amd.nn import Conv2dFirst, Conv2dSignIn
 from micronet_amd.sign_tensor import LazyConvOut, SignTensor
 
 __all__ = ["BinaryActivation", "BinaryWeight", "Ternary", "ActivationQuantizer", "meancenter_clamp_convparams",
@@ -210,6 +210,8 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                     module.channel_shuffle_flag = 0
             elif layer_counter[0] == 1 and type(child) is nn.Conv2d:
                 child.__class__ = Conv2dFirst       # the un-quantised first conv: same object and state, gfx950 kernels when covered
+            elif layer_counter[0] == layer_num and type(child) is nn.Conv2d and packed_activations:
+                child.__class__ = Conv2dSignIn      # the un-quantised last conv reads the packed +-1 output of the block in front
         elif isinstance(child, nn.ConvTranspose2d):
             layer_counter[0] += 1
             if 1 < layer_counter[0] < layer_num:

@@ -502,3 +502,23 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
     aq = be.actq(3)
     y = be.to_host(be.conv_fwd(g, aq, dA, dW, dB, 3, wq=wq))
     assert close(y, y64, 1e-6)
+
+
+def check_sign_classifier(be, N=3, Cc=96, H=4, W=8, Oc=10, bias=True, seed=0):
+    """mn_signconv1x1_small_fwd / mn_conv1x1_small_bwd_data (+ backward-weight through mn_conv2d_bwd_weight on the codes) vs fp64."""
+    r = np.random.default_rng(seed)
+    a = np.where(r.standard_normal((N, Cc, H, W)) > 0, 1, -1).astype(np.int8)
+    w = (r.standard_normal((Oc, Cc, 1, 1)) * 0.1).astype(F)
+    b = (r.standard_normal(Oc) * 0.2).astype(F) if bias else None
+    assert be.lib.mn_signconv1x1_small_supported(Cc, H * W, Oc) == 1
+    y_ref = O.conv2d_fwd(a.astype(F), w, b)
+    gy = r.standard_normal(y_ref.shape).astype(F)
+    dx_ref, dw_ref, db_ref = O.conv2d_bwd(gy, a.astype(F), w)
+    dA, dW, dB, dG = be.to_dev_i8(a), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(gy)
+    y, dx = be.empty((N, Oc, H, W)), be.empty((N, Cc, H, W))
+    be.call("mn_signconv1x1_small_fwd", be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(y), N, Cc, H * W, Oc, be.stream)
+    be.call("mn_conv1x1_small_bwd_data", be.ptr(dG), be.ptr(dW), be.ptr(dx), N, Cc, H * W, Oc, be.stream)
+    assert close(be.to_host(y), y_ref, 2e-6) and close(be.to_host(dx), dx_ref, 2e-6)
+    g = be.geom((N, Cc, H, W), (Oc, Cc, 1, 1))
+    dw, db = be.conv_bwd_weight(g, be.actq(3), dG, dA, 0, bias=True)
+    assert close(be.to_host(dw), dw_ref, 1e-5) and close(be.to_host(db), db_ref, 1e-5)

@@ -307,3 +307,9 @@ def test_qconv_bnsign_fused_pooled_gradient(be, case):
     K.check_qconv_bnsign(be, seed=190 + case, pooled=True, **K.QGEMM_PW_CASES[case])
     K.check_qconv_bnsign(be, seed=195 + case, pooled=True, training=False, in_shuffle=2 if case == 1 else 0, **K.QGEMM_PW_CASES[case])
     K.check_qconv_bnsign(be, seed=199, pooled=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)      # nin_gc L3
+
+
+def test_sign_classifier(be):
+    K.check_sign_classifier(be)
+    K.check_sign_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bias=False, seed=1)
+    K.check_sign_classifier(be, N=16, Cc=1024, H=8, W=8, Oc=10, seed=2)                 # nin_gc L9

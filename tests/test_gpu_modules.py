@@ -456,3 +456,27 @@ def test_wbwtab_pool_gradient_stays_pooled_and_matches():
     y = q(torch.randn(8, 3, 16, 16, device="cuda"))
     y.square().mean().backward()
     assert all(torch.isfinite(p_.grad).all() for p_ in q.parameters() if p_.grad is not None)
+
+
+def test_wbwtab_last_conv_reads_sign_codes():
+    """prepare() turns the un-quantised LAST conv into Conv2dSignIn: with a packed input it runs on the sign-code classifier kernels;
+    output and all gradients match the stock nn.Conv2d applied to the unpacked float32 tensor."""
+    from micronet_amd.nn import Conv2dSignIn
+    from micronet_amd.sign_tensor import SignTensor
+    w = _q("wbwtab")
+    q = w.prepare(nn.Sequential(nn.Conv2d(3, 32, 3, padding=1), nn.BatchNorm2d(32), nn.ReLU(), nn.Conv2d(32, 64, 1), nn.BatchNorm2d(64), nn.ReLU(),
+                                nn.Conv2d(64, 10, 1)).cuda(), inplace=True)
+    assert type(q[6]) is Conv2dSignIn
+    torch.manual_seed(3)
+    ours, ref = Conv2dSignIn(256, 10, 1).cuda(), nn.Conv2d(256, 10, 1).cuda()
+    ref.load_state_dict(ours.state_dict())
+    codes = (torch.randint(0, 2, (8, 256, 8, 8), device="cuda", dtype=torch.int8) * 2 - 1)
+    xs = SignTensor(codes.clone()).requires_grad_(True)
+    xf = codes.float().requires_grad_(True)
+    yo, yr = ours(xs), ref(xf)
+    assert type(yo) is torch.Tensor and rel_err(yo.detach().cpu(), yr.detach().cpu()) <= 2e-6
+    g = torch.randn_like(yr)
+    yo.backward(g), yr.backward(g)
+    assert rel_err(xs.grad.cpu(), xf.grad.cpu()) <= 2e-6
+    assert rel_err(ours.weight.grad.cpu(), ref.weight.grad.cpu()) <= 1e-5 and rel_err(ours.bias.grad.cpu(), ref.bias.grad.cpu()) <= 1e-5
+    assert rel_err(ours(xf.detach()).detach().cpu(), yr.detach().cpu()) <= 1e-5        # a float32 input takes the stock path

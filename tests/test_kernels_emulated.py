@@ -181,3 +181,8 @@ def test_qgemm_sign8_wgrad_direct(be, case):
 def test_qconv_bnsign_fused_pooled_gradient(be, case):
     K.check_qconv_bnsign(be, seed=190 + case, pooled=True, **K.QGEMM_PW_CASES[case])
     K.check_qconv_bnsign(be, seed=195 + case, pooled=True, training=False, in_shuffle=2 if case == 1 else 0, **K.QGEMM_PW_CASES[case])
+
+
+def test_sign_classifier(be):
+    K.check_sign_classifier(be)
+    K.check_sign_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bias=False, seed=1)      # partial pixel chunk, C not a multiple of 64
