@@ -225,6 +225,16 @@ int mn_maxpool2x2_sign8_bwd(const float* dout, const int8_t* a, int64_t planes, 
 int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                   int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 
+/* the two halves of mn_bnsign_bwd for a consumer that forms dy itself: mn_bnsign_bwd_sums = dgamma, dbeta and sums [2][C] =
+ * {sum dz, sum dz*zhat}; mn_conv2d_bwd_weight_first_bn = backward-weight (+ dbias) of the first-layer convolution
+ * (mn_conv2d_first_supported) whose output y went through BatchNorm2d + BinaryActivation: dy is formed from (da, y, save, gamma,
+ * beta, sums) while the operands stream in -- the first layer has no backward-data, so dy is needed nowhere else. */
+int mn_bnsign_bwd_sums(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                       int64_t HW, float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
+int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta,
+                                  const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes,
+                                  mn_stream_t stream);
+
 /* ------------------------------------------------------------------ conv + BatchNorm2d + BinaryActivation, fused, on packed signs
  * The whole W/A-binary block of the reference -- `relu(bn(conv(x)))` with the ReLU replaced by BinaryActivation
  * (models/nin_gc.py:53-59; wbwtab/quantize.py:79-94, 181-195) -- for pointwise (1x1, stride 1) convolutions whose input is

@@ -34,6 +34,15 @@ struct C1Params {
     int R, strips, PR, PW, CS;      // strip of R output rows; LDS patch rows / row pitch / channel stride
     int Z, want_db;
     FastDiv fd_w;
+    // BN variant of the backward-weight: gy is not given, it is the BatchNorm+sign backward of (da, yb) formed in registers
+    const float* da;      // d loss / d sign output      [N][O][H][W]
+    const float* yb;      // the conv output the BatchNorm saw
+    const float* save;    // [2][O] mean, invstd
+    const float* gamma;
+    const float* beta;
+    const float* sums;    // [2][O] sum dz, sum dz*zhat
+    int training;
+    float n_f;
 };
 
 // stage the image strip (with zero halo) of image n, rows [row0 - ph, row0 + R + KH - 1 - ph) into xs[c][prow][pcol]
@@ -93,11 +102,21 @@ __global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the patch values of step s + 1 are read from LDS before the MFMAs of step s are issued (padded steps read offset 0: their
+        // weights are zero), so the matrix pipe never waits for an LDS round trip
+        float bn[4];
+        {
+            const float* src = xs + pb + koff[0];
+            bn[0] = src[0]; bn[1] = src[1]; bn[2] = src[2]; bn[3] = src[3];
+        }
 #pragma unroll
         for (int s = 0; s < C1_KS; ++s) {
+            const float b0 = bn[0], b1 = bn[1], b2 = bn[2], b3 = bn[3];
+            if (s + 1 < C1_KS) {
+                const float* src = xs + pb + koff[s + 1];
+                bn[0] = src[0]; bn[1] = src[1]; bn[2] = src[2]; bn[3] = src[3];
+            }
             if (s < p.KS) {
-                const float* src = xs + pb + koff[s];
-                const float b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     acc[0][t] = MN_MFMA_F32(wa[s][t], b0, acc[0][t]);
@@ -106,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
                     acc[3][t] = MN_MFMA_F32(wa[s][t], b3, acc[3][t]);
                 }
             }
+            MN_SCHED_FENCE();
         }
         // D[row = channel 4kq + r][col = pixel j]: across q a float4 of 4 consecutive pixels per channel
         if (pv) {
@@ -126,7 +146,10 @@ __global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
 
 // backward-weight: block z accumulates dw over its share of (image, strip) tiles for the 64*MT... out-channels of its channel block.
 // wave w owns out-channels [m0, m0 + 16*MT); the five 16-wide tiles of the k axis cover K <= 80.
-template <int MT>
+// BN = 1: the layer is followed by BatchNorm2d + BinaryActivation and nothing else consumes d loss / d y (the first layer has no
+// backward-data): dy = gamma*invstd*(dz - sum_dz/n - zhat*sum_dzzhat/n) with dz = da*[|z| < 1] is formed from (da, y) while they
+// stream in -- expression for expression what k_bns_apply<1> computes -- so the full-size dy tensor is never written or re-read.
+template <int MT, int BN>
 __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
@@ -139,6 +162,18 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) koff[nt] = c1_koff(p, nt * 16 + j);     // B[pixel][k = nt*16 + j]
 
+    float cmean[MT], cinv[MT], cga[MT], cbe[MT], cgi[MT], ck1[MT], ck2[MT];      // BN: constants of this lane's channel of each tile
+    if (BN) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = m0 + t * 16 + j;
+            const int mc = m < p.O ? m : p.O - 1;
+            cmean[t] = p.save[mc]; cinv[t] = p.save[p.O + mc]; cga[t] = p.gamma[mc]; cbe[t] = p.beta[mc];
+            cgi[t] = cga[t] * cinv[t];
+            ck1[t] = p.training ? p.sums[mc] / p.n_f : 0.f;
+            ck2[t] = p.training ? p.sums[p.O + mc] / p.n_f : 0.f;
+        }
+    }
     f32x4 acc[MT][5];
     float dbs[MT];
 #pragma unroll
@@ -162,7 +197,24 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
             for (int t = 0; t < MT; ++t) {
                 const int m = m0 + t * 16 + j;
                 dst[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < p.O) dst[t] = *reinterpret_cast<const float4*>(p.gy + (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol);
+                if (m < p.O) {
+                    const int64_t off = (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol;
+                    if (BN) {
+                        const float4 d4 = *reinterpret_cast<const float4*>(p.da + off), y4 = *reinterpret_cast<const float4*>(p.yb + off);
+                        const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+                        float r[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float zh = (yv[e] - cmean[t]) * cinv[t];
+                            const float z = zh * cga[t] + cbe[t];
+                            const float dz = (z > -1.f && z < 1.f) ? dv[e] : 0.f;
+                            r[e] = cgi[t] * (dz - ck1[t] - zh * ck2[t]);
+                        }
+                        dst[t] = make_float4(r[0], r[1], r[2], r[3]);
+                    } else {
+                        dst[t] = *reinterpret_cast<const float4*>(p.gy + off);
+                    }
+                }
             }
         };
         float4 gn[MT];
@@ -303,7 +355,7 @@ int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* b
     C1Params& p = pl.p;
     float* wp = (float*)ws;
     hipLaunchKernelGGL(k_c1_pack, dim3(mn_grid_for((int64_t)C1_KS * 4 * p.Opad, 256, 256)), dim3(256), 0, s, w, wp, p.O, p.K, p.Opad, C1_KS * 4);
-    p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0;
+    p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0; p.da = nullptr;
     mn_set_last_kernel("k_c1_fwd<%d>", pl.MT);
     mn_prof_begin(s);
     if (pl.MT == 4) { raise_lds_limit((const void*)k_c1_fwd<4>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<4>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }
@@ -313,18 +365,37 @@ int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* b
     MN_CHECK_LAUNCH("mn_conv2d_fwd(first-layer)");
     return MN_OK;
 }
+template <int MT>
+static void c1_launch_wgrad_mt(const C1Plan& pl, const C1Params& p, hipStream_t s) {
+    if (p.da) { raise_lds_limit((const void*)k_c1_wgrad<MT, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    else { raise_lds_limit((const void*)k_c1_wgrad<MT, 0>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 0>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+}
+static void c1_launch_wgrad(const C1Plan& pl, const C1Params& p, hipStream_t s) {
+    if (pl.MT == 4) c1_launch_wgrad_mt<4>(pl, p, s);
+    else if (pl.MT == 2) c1_launch_wgrad_mt<2>(pl, p, s);
+    else c1_launch_wgrad_mt<1>(pl, p, s);
+}
+// gy == nullptr: the BatchNorm+sign variant (da, yb, save, gamma, beta, sums as for mn_bnsign_bwd)
+int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, const float* yb, const float* save, const float* gamma, const float* beta,
+                     const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    return c1_bwd_weight_bn(g, gy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, x, dw, dbias, ws, ws_bytes, s);
+}
+int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, const float* yb, const float* save, const float* gamma, const float* beta,
+                     const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
     C1Plan pl;
-    if (!plan_c1(g, &pl) || !aligned16(gy)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(first-layer): geometry not covered");
+    if (!plan_c1(g, &pl) || (gy && !aligned16(gy)) || (da && (!aligned16(da) || !aligned16(yb)))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(first-layer): geometry not covered");
+    if (!gy && (!da || !yb || !save || !gamma || !beta || !sums)) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight(first-layer, bn): null argument");
     if (!ws || ws_bytes < pl.ws_bytes_w || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(first-layer): workspace too small");
     C1Params& p = pl.p;
     p.x = x; p.gy = gy; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
     p.wp = nullptr; p.bias = nullptr; p.y = nullptr;
-    mn_set_last_kernel("k_c1_wgrad<%d>", pl.MT);
+    p.da = gy ? nullptr : da; p.yb = yb; p.save = save; p.gamma = gamma; p.beta = beta; p.sums = sums; p.training = training;
+    p.n_f = (float)g->N * (float)(g->H * g->W);
+    mn_set_last_kernel("k_c1_wgrad<%d, %d>", pl.MT, p.da ? 1 : 0);
+    { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((p.da ? 8.0 : 4.0) * ny + 4.0 * g->N * g->C * g->H * g->W); }
     mn_prof_begin(s);
-    if (pl.MT == 4) { raise_lds_limit((const void*)k_c1_wgrad<4>, pl.lds); hipLaunchKernelGGL(k_c1_wgrad<4>, dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
-    else if (pl.MT == 2) { raise_lds_limit((const void*)k_c1_wgrad<2>, pl.lds); hipLaunchKernelGGL(k_c1_wgrad<2>, dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
-    else { raise_lds_limit((const void*)k_c1_wgrad<1>, pl.lds); hipLaunchKernelGGL(k_c1_wgrad<1>, dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    c1_launch_wgrad(pl, p, s);
     mn_prof_end(s);
     const int64_t total = (int64_t)p.O * p.K + (dbias ? p.O : 0);
     hipLaunchKernelGGL(k_c1_reduce, dim3(mn_grid_for((int64_t)p.Opad * 81, 64, 2048)), dim3(256), 0, s, (const float*)p.part, (const float*)p.dbpart, dw, dbias, p.Z, p.O, p.K, p.Opad);

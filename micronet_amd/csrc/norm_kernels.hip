@@ -268,6 +268,23 @@ extern "C" int mn_bnsign_fwd_i8(const float* y, int64_t N, int64_t C, int64_t HW
     return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, (float*)a, 1, ws, stream);
 }
 
+// first half of mn_bnsign_bwd only: dgamma, dbeta and sums [2][C] = {sum dz, sum dz*zhat}; a consumer that forms dy itself
+// (mn_conv2d_bwd_weight_first_bn) takes it from there
+extern "C" int mn_bnsign_bwd_sums(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                                  int64_t HW, float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, y, da, "mn_bnsign_bwd_sums");
+    if (rc) return rc;
+    if (!da || !y || !save || !gamma || !beta || !sums || !ws || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bnsign_bwd_sums: null / misaligned argument");
+    hipStream_t s = (hipStream_t)stream;
+    const BnsGeom g = bns_geom(N, C, HW);
+    const int S = bns_split(g);
+    mn_set_last_kernel("k_bns_partial<1>"); mn_prof_bytes(8.0 * (double)N * C * HW); mn_prof_begin(s);
+    hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws);
+    mn_prof_end(s);
+    hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
+    MN_CHECK_LAUNCH("mn_bnsign_bwd_sums");
+    return MN_OK;
+}
 extern "C" int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                              int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
     int rc = bns_check(N, C, HW, y, dy, "mn_bnsign_bwd");

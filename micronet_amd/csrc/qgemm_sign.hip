@@ -543,6 +543,7 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (NP % 32 || Mg < 33 || Cg < 33) return 0;           // small tiles stay on the LDS-staged kernel
     Wg2Params& p = pl->p;
     pl->MW = (Mg > 64 || Cg > 64) ? 4 : 2;
+    if (const char* e = getenv("MN_WG2_MW")) { const int v = atoi(e); if (v == 2 || v == 4) pl->MW = v; }   // tuning knob
     const int T = 32 * pl->MW;
     p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.Cin_total = g->C; p.Cout_total = g->O; p.Cg = Cg; p.Mg = Mg;
     p.in_map = make_chanmap(g->in_shuffle, g->C);

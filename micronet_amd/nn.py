@@ -17,7 +17,10 @@ class Conv2dFirst(nn.Conv2d):
         if (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and self.padding_mode == "zeros" and
                 not isinstance(input, (SignTensor, LazyConvOut)) and not isinstance(self.padding, str) and
                 ops.first_conv_supported(input.shape, self.weight.shape, self.stride, self.padding, self.dilation, self.groups)):
-            return ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            out = ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            if not input.requires_grad:
+                out._mn_first_conv_out = True      # no backward-data: a BatchNorm2dBinAct behind it may hand its gradient over lazily
+            return out
         return super().forward(input)
 
 

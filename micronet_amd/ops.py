@@ -22,7 +22,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import ActQ, ConvGeom, MicronetHipError, WQ
-from .sign_tensor import LazyConvOut, LazyPoolGrad, SignTensor
+from .sign_tensor import LazyBNGrad, LazyConvOut, LazyPoolGrad, SignTensor
 
 ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO, ACTQ_SIGN8 = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO, _lib.MN_ACTQ_SIGN8
 WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _lib.MN_WQ_DOREFA, _lib.MN_WQ_IAO
@@ -74,7 +74,7 @@ def _lib_():
 def _chk(t, name="tensor"):
     if t is None:
         return None
-    if isinstance(t, (LazyPoolGrad, LazyConvOut)):      # a lazy tensor reaching a kernel that wants plain memory
+    if isinstance(t, (LazyBNGrad, LazyPoolGrad, LazyConvOut)):      # a lazy tensor reaching a kernel that wants plain memory
         t = t.materialize()
     elif isinstance(t, SignTensor):
         t = t.to_float()
@@ -320,12 +320,15 @@ class BnBatchStats(Function):
         return d_o
 
 
+LAZY_BN_GRAD = True
+
+
 class BNSign(Function):
     """a = sign(batch_norm(y)) in one fused op (training or eval statistics); backward = clip-STE of the sign through the
     BatchNorm backward.  The normalised tensor is never materialised (it is recomputed from y in the backward)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, packed=False):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, packed=False, lazy_grad=False):
         y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
         N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
         a = torch.empty(y.shape, dtype=torch.int8 if packed else torch.float32, device=y.device)
@@ -336,6 +339,7 @@ class BNSign(Function):
                   int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(ws), _s())
         ctx.save_for_backward(y, gamma, beta, save)
         ctx.training = int(training)
+        ctx.lazy_grad = bool(lazy_grad)
         return SignTensor(a) if packed else a
 
     @staticmethod
@@ -343,13 +347,29 @@ class BNSign(Function):
         y, gamma, beta, save = ctx.saved_tensors
         da = _chk(da, "grad")
         N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
-        dy = torch.empty_like(y)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
+        training = ctx.training
+        if ctx.lazy_grad and LAZY_BN_GRAD:
+            # y comes from the first conv (no backward-data): only the sums are computed here; the conv's backward-weight forms dy itself
+            sums = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+            with torch.cuda.device_of(y):
+                _call("mn_bnsign_bwd_sums", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+
+            def expand(r):
+                dy_ = torch.empty_like(r["y"])
+                ws_ = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=dy_.device)
+                with torch.cuda.device_of(dy_):
+                    _call("mn_bnsign_bwd", _p(r["da"]), _p(r["y"]), _p(r["save"]), _p(r["gamma"]), _p(r["beta"]), N, Cc, HW, r["training"], _p(dy_),
+                          None, None, _p(ws_), _s())
+                return dy_
+            recipe = dict(da=da, y=y, save=save, gamma=gamma, beta=beta, sums=sums, training=training)
+            return LazyBNGrad(y.shape, y.device, recipe, expand), dgamma, dbeta, None, None, None, None, None, None, None
+        dy = torch.empty_like(y)
         with torch.cuda.device_of(y):
-            _call("mn_bnsign_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, ctx.training, _p(dy), _p(dgamma), _p(dbeta),
+            _call("mn_bnsign_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, training, _p(dy), _p(dgamma), _p(dbeta),
                   _p(ws), _s())
-        return dy, dgamma, dbeta, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class SignToFloat(Function):
@@ -479,6 +499,16 @@ class QConv2d(Function):
     def backward(ctx, gy):
         x, wq, qp, wscale = ctx.saved_tensors
         g, aq_mode, aq_bits, aq_qtype, has_bias, wd4, aq_flags = ctx.cfg
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
+                CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
+            r = gy._mn_recipe              # the BatchNorm+sign behind the first conv: dy is formed inside the backward-weight kernel
+            dw = torch.empty_like(wq)
+            db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
+            with torch.cuda.device_of(x):
+                ws, nb = _ws(g, 2, x.device)
+                _call("mn_conv2d_bwd_weight_first_bn", C.byref(g), _p(r["da"]), _p(r["y"]), _p(r["save"]), _p(r["gamma"]), _p(r["beta"]), _p(r["sums"]),
+                      r["training"], _p(x), _p(dw), _p(db), _p(ws), nb, _s())
+            return None, dw, db, None, None, None, None, None, None, None, None, None, None, None
         gy = _chk(gy, "grad")
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         wd = _wq_desc(wd4 + (wscale,)) if wd4 is not None else None

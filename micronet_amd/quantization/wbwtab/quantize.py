@@ -106,7 +106,8 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
             return ops.ConvBNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                         self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
         out = ops.BNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                               self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, bool(self.packed))
+                               self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, bool(self.packed),
+                               bool(getattr(input, "_mn_first_conv_out", False)))
         if not self.packed:
             out._mn_binarized = True
         return out

@@ -141,3 +141,40 @@ class LazyPoolGrad(torch.Tensor):
             return r
         un = lambda t: t.materialize() if isinstance(t, (LazyPoolGrad, LazyConvOut)) else (t._mn_codes.to(torch.float32) if isinstance(t, SignTensor) else t)
         return func(*tree_map(un, args), **tree_map(un, kwargs))
+
+
+class LazyBNGrad(torch.Tensor):
+    """d loss / d y of a BatchNorm2d + BinaryActivation whose input y is the output of the FIRST convolution: logically the full-size
+    float32 gradient, physically (da, y, statistics, sums).  The first layer has no backward-data, so its backward-weight is the only
+    consumer: it forms dy in registers while da and y stream in (``mn_conv2d_bwd_weight_first_bn``); any other consumer
+    materialises it with the BatchNorm+sign backward kernel."""
+
+    @staticmethod
+    def __new__(cls, shape, device, recipe, expand):
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=torch.float32, device=device, requires_grad=False)
+        r._mn_recipe, r._mn_expand, r._mn_value = recipe, expand, None
+        return r
+
+    def __init__(self, shape, device, recipe, expand):
+        pass
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_expand(self._mn_recipe)
+        return self._mn_value
+
+    def __repr__(self):
+        return "LazyBNGrad(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], LazyBNGrad):
+            a = args[0]
+            r = LazyBNGrad(a.shape, a.device, a._mn_recipe, a._mn_expand)
+            r._mn_value = a._mn_value
+            return r
+        un = lambda t: t.materialize() if isinstance(t, (LazyBNGrad, LazyPoolGrad, LazyConvOut)) else (t._mn_codes.to(torch.float32) if isinstance(t, SignTensor) else t)
+        return func(*tree_map(un, args), **tree_map(un, kwargs))

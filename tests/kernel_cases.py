@@ -522,3 +522,35 @@ def check_sign_classifier(be, N=3, Cc=96, H=4, W=8, Oc=10, bias=True, seed=0):
     g = be.geom((N, Cc, H, W), (Oc, Cc, 1, 1))
     dw, db = be.conv_bwd_weight(g, be.actq(3), dG, dA, 0, bias=True)
     assert close(be.to_host(dw), dw_ref, 1e-5) and close(be.to_host(db), db_ref, 1e-5)
+
+
+def check_first_conv_bn_wgrad(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, training=True, seed=0):
+    """mn_bnsign_bwd_sums + mn_conv2d_bwd_weight_first_bn (dy formed inside the first-layer backward-weight) vs the two-step path
+    mn_bnsign_bwd -> mn_conv2d_bwd_weight on the same tensors: same expressions, so the results agree to the last bit."""
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    x = r.standard_normal(x_shape).astype(F)
+    yb = (r.standard_normal((N, Oc, H, W)) * 1.5).astype(F)
+    da = r.standard_normal((N, Oc, H, W)).astype(F)
+    gamma, beta = (r.standard_normal(Oc) * 0.5 + 1).astype(F), (r.standard_normal(Oc) * 0.3).astype(F)
+    mean, var = yb.mean(axis=(0, 2, 3)), yb.var(axis=(0, 2, 3))
+    save = np.stack([mean, 1.0 / np.sqrt(var + 1e-5)]).astype(F)
+    g = be.geom(x_shape, (Oc, Cin, k, k), padding=k // 2)
+    assert be.lib.mn_conv2d_first_supported(C.byref(g), 2) == 1
+    dX, dY, dDA, dS, dG, dB = be.to_dev(x), be.to_dev(yb), be.to_dev(da), be.to_dev(save), be.to_dev(gamma), be.to_dev(beta)
+    HW = H * W
+    ws = be.empty(int(be.lib.mn_bnsign_ws_floats(Oc)) + 2)
+    dy, dgam, dbet = be.empty((N, Oc, H, W)), be.empty(Oc), be.empty(Oc)
+    be.call("mn_bnsign_bwd", be.ptr(dDA), be.ptr(dY), be.ptr(dS), be.ptr(dG), be.ptr(dB), N, Oc, HW, int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet),
+            be.ptr(ws), be.stream)
+    dw_ref, db_ref = be.conv_bwd_weight(g, be.actq(0), dy, dX, 0, bias=True)
+    sums, dgam2, dbet2 = be.empty((2, Oc)), be.empty(Oc), be.empty(Oc)
+    be.call("mn_bnsign_bwd_sums", be.ptr(dDA), be.ptr(dY), be.ptr(dS), be.ptr(dG), be.ptr(dB), N, Oc, HW, be.ptr(dgam2), be.ptr(dbet2), be.ptr(sums),
+            be.ptr(ws), be.stream)
+    assert eq(be.to_host(dgam2), be.to_host(dgam)) and eq(be.to_host(dbet2), be.to_host(dbet))
+    nb = be.lib.mn_conv2d_ws_bytes(C.byref(g), 2, 0)
+    ws2 = be.empty(max(4, nb // 4 + 4))
+    dw, db = be.empty((Oc, Cin, k, k)), be.empty(Oc)
+    be.call("mn_conv2d_bwd_weight_first_bn", C.byref(g), be.ptr(dDA), be.ptr(dY), be.ptr(dS), be.ptr(dG), be.ptr(dB), be.ptr(sums), int(training),
+            be.ptr(dX), be.ptr(dw), be.ptr(db), be.ptr(ws2), nb, be.stream)
+    assert eq(be.to_host(dw), be.to_host(dw_ref)) and eq(be.to_host(db), be.to_host(db_ref))

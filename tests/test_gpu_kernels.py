@@ -313,3 +313,10 @@ def test_sign_classifier(be):
     K.check_sign_classifier(be)
     K.check_sign_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bias=False, seed=1)
     K.check_sign_classifier(be, N=16, Cc=1024, H=8, W=8, Oc=10, seed=2)                 # nin_gc L9
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_first_conv_bn_wgrad(be, training):
+    K.check_first_conv_bn_wgrad(be, training=training)
+    K.check_first_conv_bn_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, seed=1)
+    K.check_first_conv_bn_wgrad(be, x_shape=(8, 3, 32, 32), Oc=256, k=5, training=training, seed=2)

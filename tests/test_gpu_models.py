@@ -220,3 +220,39 @@ def test_graphed_train_step_matches_eager(key):
     x2, y2 = synth_batch(16, seed=99, device="cuda")
     g.data.copy_(x2); g.target.copy_(y2)
     assert torch.isfinite(g.step()[0])
+
+
+def test_wbwtab_fused_pipeline_usage_scenarios(golden):
+    """The packed / fused wbwtab pipeline under the ways a training script uses a model: odd batch sizes (kernels fall back or
+    clamp), eval + no_grad inference, deepcopy, state_dict interchange with the un-fused module graph and with the reference's
+    key layout, batch 1."""
+    import copy
+    from micronet_amd.train import build_model
+    from micronet.compression.quantization.wbwtab import quantize
+    fused = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=3).cuda().train()
+    plain = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=3, fuse_bn_act=False, fold_shuffle=False,
+                             packed_activations=False, fuse_conv_bn=False).cuda().train()
+    assert list(fused.state_dict().keys()) == list(plain.state_dict().keys())
+    assert [[k, list(v.shape)] for k, v in fused.state_dict().items()] == golden.meta["surface"]["c2_nin_gc_wbwtab_w3a2"]["state"]
+    for B in (1, 3, 5, 8):
+        x = torch.randn(B, 3, 32, 32, device="cuda")
+        out = fused(x)
+        assert out.shape == (B, 10) and torch.isfinite(out).all()
+        out.square().mean().backward()
+        assert all(torch.isfinite(p.grad).all() for p in fused.parameters())
+        fused.zero_grad()
+    # same weights -> same function (up to BatchNorm-output ties) in eval mode, where the running statistics normalise
+    plain.load_state_dict(fused.state_dict())
+    fused.eval(), plain.eval()
+    x = torch.randn(16, 3, 32, 32, device="cuda")
+    with torch.no_grad():
+        of, op = fused(x), plain(x)
+    assert of.shape == op.shape and float((of.argmax(1) == op.argmax(1)).float().mean()) >= 0.8
+    clone = copy.deepcopy(fused)
+    with torch.no_grad():
+        assert torch.equal(clone(x), of)
+    # non-square images, H*W not a multiple of 64
+    fused.train()
+    y = fused.model[0:3](torch.randn(2, 3, 24, 40, device="cuda"))
+    assert y.shape[2:] == (24, 40)
+    y.float().sum().backward() if y.requires_grad else None

@@ -480,3 +480,36 @@ def test_wbwtab_last_conv_reads_sign_codes():
     assert rel_err(xs.grad.cpu(), xf.grad.cpu()) <= 2e-6
     assert rel_err(ours.weight.grad.cpu(), ref.weight.grad.cpu()) <= 1e-5 and rel_err(ours.bias.grad.cpu(), ref.bias.grad.cpu()) <= 1e-5
     assert rel_err(ours(xf.detach()).detach().cpu(), yr.detach().cpu()) <= 1e-5        # a float32 input takes the stock path
+
+
+def test_first_block_bn_gradient_stays_lazy_and_matches():
+    """Behind the first conv (no backward-data) the fused BatchNorm+sign backward only computes its sums and hands d loss / d y on as a
+    LazyBNGrad; the first-layer backward-weight forms dy in registers.  Same expressions: gradients are bit-identical to the two-step path."""
+    from micronet_amd import ops
+    from micronet_amd.models.nin_gc import ConvBNReLU
+    w = _q("wbwtab")
+    torch.manual_seed(17)
+    net = nn.Sequential(ConvBNReLU(3, 64, 5, padding=2), ConvBNReLU(64, 64, 1, groups=2), ConvBNReLU(64, 10, 1), nn.AvgPool2d(16)).cuda().train()
+    q = w.prepare(net, inplace=True, A=2, W=3)
+    x = torch.randn(8, 3, 16, 16, device="cuda")
+    res = {}
+    for lazy in (True, False):
+        ops.LAZY_BN_GRAD = lazy
+        try:
+            q.zero_grad()
+            torch.manual_seed(1)
+            q(x).square().mean().backward()
+            res[lazy] = [p_.grad.clone() for p_ in q.parameters()]
+        finally:
+            ops.LAZY_BN_GRAD = True
+    for (n_, _), a_, b_ in zip(q.named_parameters(), res[True], res[False]):
+        assert torch.equal(a_, b_), n_
+    # a hook on the conv output's gradient is a foreign consumer: it sees the expanded dy
+    seen = {}
+    h = q[0].conv.register_full_backward_hook(lambda m, gi, go: seen.__setitem__("go", (go[0] * 1.0).abs().sum().item()))
+    q.zero_grad()
+    q(x).square().mean().backward()
+    h.remove()
+    assert seen["go"] > 0
+    for a_, p_ in zip(res[True], q.parameters()):
+        assert torch.allclose(a_, p_.grad, rtol=1e-4, atol=1e-7)

@@ -186,3 +186,9 @@ def test_qconv_bnsign_fused_pooled_gradient(be, case):
 def test_sign_classifier(be):
     K.check_sign_classifier(be)
     K.check_sign_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bias=False, seed=1)      # partial pixel chunk, C not a multiple of 64
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_first_conv_bn_wgrad(be, training):
+    K.check_first_conv_bn_wgrad(be, training=training)
+    K.check_first_conv_bn_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, seed=1)
