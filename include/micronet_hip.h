@@ -255,6 +255,18 @@ int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x,
                         const float* beta, const float* save, const float* da, int training, float* dy, float* dgamma, float* dbeta,
                         void* ws, int64_t ws_bytes, mn_stream_t stream);
 
+/* forward that additionally STASHES the convolution result in one byte per element: h = (acc + nnz[o]) / 2 (uint8 [N][O][H][W]; y =
+ * alpha[o]*acc + bias, acc an integer with the parity of nnz[o] = number of non-zero weight codes of channel o) and keeps the per-channel
+ * constants `chan` [8][O] (thresholds of sign(z) and |z| < 1 in the integer domain, zhat = acc*A + B, gamma*invstd, nnz).  With them the
+ * BatchNorm+sign backward needs neither y nor the convolution: mn_bnh_bwd_sums (dgamma, dbeta, sums [2][O]) and mn_bnh_bwd_apply (dy)
+ * stream (da, h) once each; `own` != NULL: da is the gradient of the 2x2 max-pool behind the block, own = the block's output codes. */
+int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                              const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                              float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* own, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W,
+                    float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
+int mn_bnh_bwd_apply(const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int64_t N, int64_t C, int64_t H,
+                     int64_t W, int training, float* dy, mn_stream_t stream);
 /* same backward when a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119) sits behind the block: `dpool` = d loss / d pool(a),
  * [N][O][H/2][W/2] fp32, `a_own` = the block's own output codes (what mn_qconv_bnsign_fwd wrote); the pool's backward (gradient to
  * the first maximum of each window) is applied while the gradient is read -- a quarter of the bytes, no full-size da tensor. */

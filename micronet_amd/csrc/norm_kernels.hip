@@ -411,3 +411,141 @@ extern "C" int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float*
     MN_CHECK_LAUNCH("mn_conv1x1_small_bwd_data");
     return MN_OK;
 }
+
+// ---------------------------------------------------------------- BatchNorm + sign backward on the one-byte conv stash
+// For a binary block the conv output is y = alpha[o] * acc + bias with acc an exact integer of known parity (qgemm_sign.hip); the fused
+// forward stashes h = (acc + nnz[o]) / 2 as ONE BYTE per element.  The backward of the BatchNorm + sign then is a pure streaming pass
+// over (da, h) -- no convolution recompute, a quarter of the bytes of reading y as fp32.  chan = the [8][C] per-channel constants of
+// k_pws_chan_prep: T, flip, L, U (integer thresholds in the acc*flip domain), A, B (zhat = acc*A + B), gi = gamma*invstd, nnz.
+// POOL: da is the gradient of the 2x2 / stride-2 max-pool behind the block ([N][C][H/2][W/2]) and `own` the block's output codes.
+struct BnhGeom { int N, C, H, W, HW, HW4; FastDiv fd_hw4, fd_w4; int64_t n4; };
+template <int POOL>
+__device__ __forceinline__ void bnh_load(const BnhGeom& g, int c, uint32_t i, const float* __restrict__ da, const unsigned char* __restrict__ h,
+                                         const char* __restrict__ own, float (&gv)[4], float (&acc)[4], float nnz, int64_t& off) {
+    const uint32_t n = fd_div(i, g.fd_hw4);
+    const uint32_t q = i - n * (uint32_t)g.HW4;              // quad index inside the plane
+    off = ((int64_t)n * g.C + c) * g.HW + (int64_t)q * 4;
+    const uint32_t hb = *reinterpret_cast<const uint32_t*>(h + off);
+    acc[0] = 2.f * (float)(hb & 0xffu) - nnz; acc[1] = 2.f * (float)((hb >> 8) & 0xffu) - nnz;
+    acc[2] = 2.f * (float)((hb >> 16) & 0xffu) - nnz; acc[3] = 2.f * (float)(hb >> 24) - nnz;
+    if (!POOL) {
+        const float4 g4 = *reinterpret_cast<const float4*>(da + off);
+        gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+    } else {
+        const int W4 = g.W >> 2;
+        const uint32_t row = fd_div(q, g.fd_w4), w = (q - row * (uint32_t)W4) * 4u;
+        const uint32_t hbit = row & 1u;
+        const int64_t pb = ((int64_t)n * g.C + c) * (g.HW >> 2) + (int64_t)(row >> 1) * (g.W >> 1) + (w >> 1);
+        const float2 g2 = *reinterpret_cast<const float2*>(da + pb);
+        const int64_t cb = ((int64_t)n * g.C + c) * g.HW + (int64_t)(row & ~1u) * g.W + w;
+        const uint32_t r0 = *reinterpret_cast<const uint32_t*>(own + cb), r1 = *reinterpret_cast<const uint32_t*>(own + cb + g.W);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {      // first maximum of the window in row-major order (ATen): the first +1, else element 0
+            const bool p00 = !((r0 >> (16 * e)) & 0x80u), p01 = !((r0 >> (16 * e + 8)) & 0x80u);
+            const bool p10 = !((r1 >> (16 * e)) & 0x80u), p11 = !((r1 >> (16 * e + 8)) & 0x80u);
+            const uint32_t win = p00 ? 0u : (p01 ? 1u : (p10 ? 2u : (p11 ? 3u : 0u)));
+            const float ge = e ? g2.y : g2.x;
+            gv[2 * e] = win == hbit * 2u ? ge : 0.f;
+            gv[2 * e + 1] = win == hbit * 2u + 1u ? ge : 0.f;
+        }
+    }
+}
+template <int POOL>
+__global__ __launch_bounds__(256) void k_bnh_partial(const BnhGeom g, const float* __restrict__ da, const unsigned char* __restrict__ h,
+                                                     const char* __restrict__ own, const float* __restrict__ chan, double* __restrict__ part) {
+    __shared__ double scd[16];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
+    const float fl = chan[C + c], L = chan[2 * C + c], U = chan[3 * C + c], A = chan[4 * C + c], B = chan[5 * C + c], nnz = chan[7 * C + c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
+        float gv[4], acc[4];
+        int64_t off;
+        bnh_load<POOL>(g, c, (uint32_t)i, da, h, own, gv, acc, nnz, off);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = acc[e] * fl;
+            const float dz = (u >= L && u <= U) ? gv[e] : 0.f;
+            t1 += dz;
+            t2 += dz * fmaf(acc[e], A, B);
+        }
+        s1 += (double)t1; s2 += (double)t2;
+    }
+    s1 = block_reduce(s1, OpAddD(), 0.0, scd);
+    s2 = block_reduce(s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { part[((int64_t)c * S + sp) * 2] = s1; part[((int64_t)c * S + sp) * 2 + 1] = s2; }
+}
+template <int POOL>
+__global__ __launch_bounds__(256) void k_bnh_apply(const BnhGeom g, const float* __restrict__ da, const unsigned char* __restrict__ h,
+                                                   const char* __restrict__ own, const float* __restrict__ chan, const float* __restrict__ sums,
+                                                   int training, float* __restrict__ dy) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
+    const float fl = chan[C + c], L = chan[2 * C + c], U = chan[3 * C + c], A = chan[4 * C + c], B = chan[5 * C + c], gi = chan[6 * C + c], nnz = chan[7 * C + c];
+    float k1 = 0.f, k2 = 0.f;
+    if (training) { const float n = (float)g.N * (float)g.HW; k1 = sums[c] / n; k2 = sums[C + c] / n; }
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
+        float gv[4], acc[4], r[4];
+        int64_t off;
+        bnh_load<POOL>(g, c, (uint32_t)i, da, h, own, gv, acc, nnz, off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = acc[e] * fl;
+            const float dz = (u >= L && u <= U) ? gv[e] : 0.f;
+            r[e] = gi * (dz - k1 - fmaf(acc[e], A, B) * k2);
+        }
+        *reinterpret_cast<float4*>(dy + off) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+static int bnh_common(int64_t N, int64_t C, int64_t H, int64_t W, int pooled, const void* da, const void* h, const void* own, BnhGeom* g, const char* what) {
+    const int64_t HW = H * W;
+    if (N <= 0 || C <= 0 || HW <= 0 || W % 4 || N * (HW / 4) >= ((int64_t)1 << 31)) MN_FAIL(MN_EINVAL, "%s: bad shape (W must be a multiple of 4)", what);
+    if (pooled && ((H & 1) || !own || (((uintptr_t)own) & 3))) MN_FAIL(MN_EINVAL, "%s: pooled gradient needs even H and the block's output codes", what);
+    if (!da || !h || (((uintptr_t)h) & 3) || (((uintptr_t)da) & (pooled ? 7 : 15))) MN_FAIL(MN_EINVAL, "%s: null / misaligned tensor", what);
+    g->N = (int)N; g->C = (int)C; g->H = (int)H; g->W = (int)W; g->HW = (int)HW; g->HW4 = (int)(HW / 4);
+    g->fd_hw4 = make_fastdiv((uint32_t)g->HW4); g->fd_w4 = make_fastdiv((uint32_t)(W / 4)); g->n4 = N * (HW / 4);
+    return MN_OK;
+}
+static int bnh_split(const BnhGeom& g) {
+    int64_t S = (2048 + g.C - 1) / g.C;
+    const int64_t maxS = (g.n4 + 255) / 256;
+    if (S > maxS) S = maxS;
+    if (S > BNS_SPLIT) S = BNS_SPLIT;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+// sums [2][C] = {sum dz, sum dz*zhat}, dgamma, dbeta (nullable).  own == NULL: da is full size; else da is the pooled gradient.
+extern "C" int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* own, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W,
+                               float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream) {
+    BnhGeom g;
+    int rc = bnh_common(N, C, H, W, own != nullptr, da, h, own, &g, "mn_bnh_bwd_sums");
+    if (rc) return rc;
+    if (!chan || !sums || !ws || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bnh_bwd_sums: null / misaligned argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = bnh_split(g);
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel(own ? "k_bnh_partial<1>" : "k_bnh_partial<0>"); mn_prof_bytes((own ? 3.0 : 5.0) * nel); mn_prof_begin(s);
+    if (own) hipLaunchKernelGGL(k_bnh_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, (double*)ws);
+    else hipLaunchKernelGGL(k_bnh_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)nullptr, chan, (double*)ws);
+    mn_prof_end(s);
+    const BnsGeom bg = bns_geom(N, C, H * W);
+    hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, bg, (const double*)ws, S, dgamma, dbeta, sums);
+    MN_CHECK_LAUNCH("mn_bnh_bwd_sums");
+    return MN_OK;
+}
+// dy = d loss / d y from (da, h) and the sums
+extern "C" int mn_bnh_bwd_apply(const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int64_t N, int64_t C, int64_t H,
+                                int64_t W, int training, float* dy, mn_stream_t stream) {
+    BnhGeom g;
+    int rc = bnh_common(N, C, H, W, own != nullptr, da, h, own, &g, "mn_bnh_bwd_apply");
+    if (rc) return rc;
+    if (!chan || !sums || !dy || !aligned16(dy)) MN_FAIL(MN_EINVAL, "mn_bnh_bwd_apply: null / misaligned argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = bnh_split(g);
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel(own ? "k_bnh_apply<1>" : "k_bnh_apply<0>"); mn_prof_bytes((own ? 7.0 : 9.0) * nel); mn_prof_begin(s);
+    if (own) hipLaunchKernelGGL(k_bnh_apply<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, sums, training, dy);
+    else hipLaunchKernelGGL(k_bnh_apply<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)nullptr, chan, sums, training, dy);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_bnh_bwd_apply");
+    return MN_OK;
+}

@@ -45,6 +45,8 @@ struct PwsParams {
     const float* bias;        // [G*Mr] or null
     float* y;                 // PWS_Y: y     PWS_BWD_APPLY: dy        [N][Cout_total][HW]
     char* a8;                 // PWS_SIGN8 output
+    unsigned char* h8;        // PWS_SIGN8, optional: h = (acc + nnz[o]) / 2 in [0, 128] -- the conv result in one byte (acc has the parity
+                              // of nnz[o], the number of non-zero weight codes of the channel); the streaming BN backward reads it
     float* part;              // PWS_STATS / PWS_BWD_PART: [CB][G*Mpad][2]
     const float* chan;        // [PWS_NCH][Cout_total] per-channel constants
     const float* da;          // gradient w.r.t. the sign output ([N][Cout][H][W]), or -- *_POOL -- w.r.t. the pooled output ([N][Cout][H/2][W/2])
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             const int co = g * p.Mr + (mv ? m : 0);
             const int C = p.Cout_total;
             if (EPI == PWS_Y) { c0[i] = p.rowscale[g * p.Mpad + m]; c1[i] = (p.bias && mv) ? p.bias[co] : 0.f; }
-            if (EPI == PWS_SIGN8) { c0[i] = p.chan[co]; c1[i] = p.chan[C + co]; }
+            if (EPI == PWS_SIGN8) { c0[i] = p.chan[co]; c1[i] = p.chan[C + co]; c2[i] = p.chan[7 * C + co]; }
             if (GRAD) { c0[i] = p.chan[2 * C + co]; c1[i] = p.chan[3 * C + co]; c2[i] = p.chan[C + co]; c3[i] = p.chan[4 * C + co]; c4[i] = p.chan[5 * C + co]; }
             if (APPLY) {
                 c5[i] = p.chan[6 * C + co];
@@ -240,6 +242,12 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                         const uint32_t u = (o[0] * fl >= T ? 0x01u : 0xFFu) | (o[1] * fl >= T ? 0x0100u : 0xFF00u) | (o[2] * fl >= T ? 0x010000u : 0xFF0000u) |
                                            (o[3] * fl >= T ? 0x01000000u : 0xFF000000u);
                         *reinterpret_cast<uint32_t*>(p.a8 + off) = u;
+                        if (p.h8) {
+                            const float nz = c2[ml];
+                            const uint32_t hh = (uint32_t)((o[0] + nz) * 0.5f) | ((uint32_t)((o[1] + nz) * 0.5f) << 8) | ((uint32_t)((o[2] + nz) * 0.5f) << 16) |
+                                                ((uint32_t)((o[3] + nz) * 0.5f) << 24);
+                            *reinterpret_cast<uint32_t*>(p.h8 + off) = hh;
+                        }
                     }
                 } else {
                     const float L = c0[ml], U = c1[ml], fl = c2[ml], A = c3[ml], B = c4[ml];
@@ -360,7 +368,7 @@ __device__ __forceinline__ float pws_z(float acc, float al, float b, float mean,
     const float zh = (y - mean) * invstd;
     return zh * ga + be;
 }
-__global__ __launch_bounds__(64) void k_pws_chan_prep(int K, int G, int Mpad, int Mr, const float* __restrict__ rowscale, const float* __restrict__ bias,
+__global__ __launch_bounds__(64) void k_pws_chan_prep(int K, int Kp, const uint16_t* __restrict__ wc, int G, int Mpad, int Mr, const float* __restrict__ rowscale, const float* __restrict__ bias,
                                                      const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ chan, int Cout) {
     const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
@@ -380,12 +388,16 @@ __global__ __launch_bounds__(64) void k_pws_chan_prep(int K, int G, int Mpad, in
         const int t2 = __shfl_xor(T, o, 64), l2 = __shfl_xor(L, o, 64), u2 = __shfl_xor(U, o, 64);
         T = t2 < T ? t2 : T; L = l2 < L ? l2 : L; U = u2 > U ? u2 : U;
     }
+    int nnz = 0;                                               // non-zero weight codes of the row: acc has its parity
+    for (int k = lane; k < Kp; k += 64) nnz += (wc[((int64_t)g * Mpad + m) * Kp + k] & 0x7fffu) != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
     if (lane == 0) {
         chan[co] = (float)T; chan[Cout + co] = flip; chan[2 * Cout + co] = (float)L; chan[3 * Cout + co] = (float)U;
         chan[4 * Cout + co] = al * invstd;                    // zhat = acc*A + B  (<= 2 ulp from the unfused chain; dy tolerance 1e-5)
         chan[5 * Cout + co] = (b - mean) * invstd;
         chan[6 * Cout + co] = ga * invstd;
-        chan[7 * Cout + co] = 0.f;
+        chan[7 * Cout + co] = (float)nnz;
     }
 }
 
@@ -691,7 +703,7 @@ static int pws_prepare(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, 
     p.x = (const char*)x; p.wc = pl->pk.codes; p.rowscale = pl->pk.scale_out;
     p.part = (float*)((char*)ws + pl->off_part);
     p.chan = (const float*)((char*)ws + pl->off_chan);
-    p.y = nullptr; p.a8 = nullptr; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr; p.own = nullptr;
+    p.y = nullptr; p.a8 = nullptr; p.h8 = nullptr; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr; p.own = nullptr;
     p.W = g->W; p.fd_w = make_fastdiv((uint32_t)g->W);
     return MN_OK;
 }
@@ -720,14 +732,14 @@ static int pws_bn_ok(const mn_conv_geom* g, const mn_wq* wq) { return g && wq &&
 extern "C" int mn_qconv_bnsign_supported(const mn_conv_geom* g, const mn_wq* wq) { return pws_bn_ok(g, wq); }
 extern "C" int64_t mn_qconv_bnsign_ws_bytes(const mn_conv_geom* g) { return g ? pws_ws_bytes(g) : -1; }
 
-static void pws_chan_prep(const PwsPlan& pl, const mn_conv_geom* g, const float* bias, const float* save, const float* gamma, const float* beta, hipStream_t s) {
-    hipLaunchKernelGGL(k_pws_chan_prep, dim3((unsigned)g->O), dim3(64), 0, s, pl.p.Kc, pl.p.G, pl.p.Mpad, pl.p.Mr, pl.p.rowscale, bias, save, gamma, beta,
+static void pws_chan_prep(PwsPlan& pl, const mn_conv_geom* g, const float* bias, const float* save, const float* gamma, const float* beta, hipStream_t s) {
+    hipLaunchKernelGGL(k_pws_chan_prep, dim3((unsigned)g->O), dim3(64), 0, s, pl.p.Kc, pl.p.Kp, pl.p.wc, pl.p.G, pl.p.Mpad, pl.p.Mr, pl.p.rowscale, bias, save, gamma, beta,
                        (float*)pl.p.chan, (int)g->O);
 }
 
-extern "C" int mn_qconv_bnsign_fwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
-                                   const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
-                                   float* save, int8_t* a, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                 const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                 float* save, int8_t* a, uint8_t* h, float* chan_out, void* ws, int64_t ws_bytes, mn_stream_t stream) {
     if (!g || !gamma || !beta || !save || !a || (((uintptr_t)a) & 3)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd: null / misaligned argument");
     if (!pws_bn_ok(g, wq)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd: needs a pointwise convolution with ternary / binary weights");
     if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd: eval mode needs the running statistics");
@@ -746,9 +758,21 @@ extern "C" int mn_qconv_bnsign_fwd(const mn_conv_geom* g, const mn_wq* wq, const
         hipLaunchKernelGGL(k_pws_eval_stats, dim3((unsigned)((g->O + 63) / 64)), dim3(64), 0, s, (int)g->O, eps, (const float*)running_mean,
                            (const float*)running_var, save);
     }
+    if (chan_out) p.chan = chan_out;                     // caller-owned [8][O]: kept for the streaming backward (mn_bnh_bwd)
     pws_chan_prep(pl, g, bias, save, gamma, beta, s);
-    p.a8 = (char*)a;
-    return launch_pws<PWS_SIGN8>(pl, s, nx + ny, "mn_qconv_bnsign_fwd(sign)");
+    p.a8 = (char*)a; p.h8 = h;
+    return launch_pws<PWS_SIGN8>(pl, s, nx + (h ? 2.0 : 1.0) * ny, "mn_qconv_bnsign_fwd(sign)");
+}
+extern "C" int mn_qconv_bnsign_fwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                   const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                   float* save, int8_t* a, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, nullptr, nullptr, ws, ws_bytes, stream);
+}
+extern "C" int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                         const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                         float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    if (!h || !chan || (((uintptr_t)h) & 3)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd_stash: null / misaligned stash");
+    return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, h, chan, ws, ws_bytes, stream);
 }
 
 static int bnsign_bwd_impl(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,

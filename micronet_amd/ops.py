@@ -567,7 +567,9 @@ def qconv_bnsign_supported(x, wq, stride, padding, dilation, groups, wdesc, in_s
 
 class ConvBNSign(Function):
     """a = sign(batch_norm(y)) for a LazyConvOut y: conv, batch statistics, normalisation and sign in the fused kernels of
-    qgemm_sign.hip -- y is never written.  Backward = clip-STE of the sign through the BatchNorm backward, y recomputed."""
+    qgemm_sign.hip -- y is never written; the forward stashes the integer conv result in ONE byte per element (h) and the
+    per-channel integer thresholds (chan), so the backward -- clip-STE of the sign through the BatchNorm backward -- is two
+    streaming passes over (da, h) with no convolution recompute (mn_bnh_bwd_sums / mn_bnh_bwd_apply)."""
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training):
@@ -575,38 +577,36 @@ class ConvBNSign(Function):
         codes, wq, bias, g, wdesc = r["codes"], r["wq"], r["bias"], r["geom"], r["wdesc"]
         gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
         a = torch.empty(y.shape, dtype=torch.int8, device=codes.device)
+        h = torch.empty(y.shape, dtype=torch.uint8, device=codes.device)
         save = torch.empty((2, g.O), dtype=torch.float32, device=codes.device)
+        chan = torch.empty((8, g.O), dtype=torch.float32, device=codes.device)
         wd = _wq_desc(wdesc)
         with torch.cuda.device_of(codes):
             nb = int(_lib_().mn_qconv_bnsign_ws_bytes(C.byref(g)))
             ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
-            _call("mn_qconv_bnsign_fwd", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), float(eps), float(momentum),
-                  int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(ws), nb, _s())
-        ctx.save_for_backward(codes, wq, bias, gamma, beta, save, wdesc[4])
-        ctx.cfg = (g, wdesc[:4], int(training))
+            _call("mn_qconv_bnsign_fwd_stash", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), float(eps), float(momentum),
+                  int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(h), _p(chan), _p(ws), nb, _s())
+        ctx.save_for_backward(h, chan, gamma, beta)
+        ctx.training = int(training)
         return SignTensor(a)
 
     @staticmethod
     def backward(ctx, da):
-        codes, wq, bias, gamma, beta, save, wscale = ctx.saved_tensors
-        g, wd4, training = ctx.cfg
+        h, chan, gamma, beta = ctx.saved_tensors
+        training = ctx.training
         pooled = isinstance(da, LazyPoolGrad) and da._mn_value is None
         if pooled:
-            dpool, own = da._mn_pg, da._mn_codes          # the 2x2 max-pool behind this block: gradient still pooled
+            grad, own = da._mn_pg, da._mn_codes           # the 2x2 max-pool behind this block: gradient still pooled
         else:
-            da = _chk(da, "grad")
-        dy = torch.empty(da.shape, dtype=torch.float32, device=da.device)
+            grad, own = _chk(da, "grad"), None
+        N, Cc, H, W = h.shape
+        dy = torch.empty(h.shape, dtype=torch.float32, device=h.device)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
-        wd = _wq_desc(wd4 + (wscale,))
-        with torch.cuda.device_of(codes):
-            nb = int(_lib_().mn_qconv_bnsign_ws_bytes(C.byref(g)))
-            ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
-            if pooled:
-                _call("mn_qconv_bnsign_bwd_pooled", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), _p(save), _p(dpool),
-                      _p(own), training, _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _s())
-            else:
-                _call("mn_qconv_bnsign_bwd", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), _p(save), _p(da), training,
-                      _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _s())
+        sums = torch.empty((2, Cc), dtype=torch.float32, device=h.device)
+        ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=h.device)
+        with torch.cuda.device_of(h):
+            _call("mn_bnh_bwd_sums", _p(grad), _p(h), _p(own), _p(chan), N, Cc, H, W, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+            _call("mn_bnh_bwd_apply", _p(grad), _p(h), _p(own), _p(chan), _p(sums), N, Cc, H, W, training, _p(dy), _s())
         return dy, dgamma, dbeta, None, None, None, None, None
 
 

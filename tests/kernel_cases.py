@@ -423,7 +423,7 @@ def check_pool_sign8(be, shape=(3, 5, 8, 16), seed=0):
     assert np.array_equal(be.to_host(din), t.grad.numpy())
 
 
-def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, pooled=False, **_):
+def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, pooled=False, stash=False, **_):
     """mn_qconv_bnsign_fwd/bwd (conv + BatchNorm + sign on packed codes; y never stored) vs an fp64 numpy evaluation of the
     same block on the same +-1 input and ternary-coded weights."""
     r = np.random.default_rng(seed)
@@ -464,8 +464,16 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
     dA, dW, dB = be.to_dev_i8(a_in), be.to_dev(w), (be.to_dev(b) if bias else None)
     dG, dBe, dRM, dRV, dDA = be.to_dev(gamma), be.to_dev(beta), be.to_dev(rm), be.to_dev(rv), be.to_dev(da)
     save, a8 = be.empty((2, Oc)), be.empty_i8((N, Oc, H, W))
-    be.call("mn_qconv_bnsign_fwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
-            be.ptr(dRM), be.ptr(dRV), be.ptr(save), be.ptr(a8), be.ptr(ws), nb, be.stream)
+    if stash:      # forward that also stashes the integer conv result in one byte per element + the per-channel constants
+        h8, chan = be.empty_i8((N, Oc, H, W)), be.empty((8, Oc))
+        be.call("mn_qconv_bnsign_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
+                be.ptr(dRM), be.ptr(dRV), be.ptr(save), be.ptr(a8), be.ptr(h8), be.ptr(chan), be.ptr(ws), nb, be.stream)
+        acc_ref = O.conv2d_fwd(x_log, np.sign(w).astype(F), None, groups=groups)
+        nnz = (w != 0).reshape(Oc, -1).sum(axis=1).reshape(1, -1, 1, 1)
+        assert np.array_equal(be.to_host(h8).view(np.uint8).astype(np.int64), ((acc_ref + nnz) / 2).astype(np.int64))
+    else:
+        be.call("mn_qconv_bnsign_fwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
+                be.ptr(dRM), be.ptr(dRV), be.ptr(save), be.ptr(a8), be.ptr(ws), nb, be.stream)
     dy, dgam, dbet = be.empty((N, Oc, H, W)), be.empty(Oc), be.empty(Oc)
     if pooled:
         # a 2x2 max-pool behind the block: the kernel gets the POOLED gradient + the block's own output codes; the reference routes
@@ -479,8 +487,17 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
         dbeta_ref, dgamma_ref = dz.sum(axis=(0, 2, 3)), (dz * zh).sum(axis=(0, 2, 3))
         dy_ref = gi * (dz - dbeta_ref.reshape(1, -1, 1, 1) / n - zh * dgamma_ref.reshape(1, -1, 1, 1) / n) if training else gi * dz
         dGP = be.to_dev(gp)
-        be.call("mn_qconv_bnsign_bwd_pooled", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save),
+        if stash:
+            sums = be.empty((2, Oc))
+            be.call("mn_bnh_bwd_sums", be.ptr(dGP), be.ptr(h8), be.ptr(a8), be.ptr(chan), N, Oc, H, W, be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(ws), be.stream)
+            be.call("mn_bnh_bwd_apply", be.ptr(dGP), be.ptr(h8), be.ptr(a8), be.ptr(chan), be.ptr(sums), N, Oc, H, W, int(training), be.ptr(dy), be.stream)
+        else:
+          be.call("mn_qconv_bnsign_bwd_pooled", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save),
                 be.ptr(dGP), be.ptr(a8), int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)
+    elif stash:
+        sums = be.empty((2, Oc))
+        be.call("mn_bnh_bwd_sums", be.ptr(dDA), be.ptr(h8), None, be.ptr(chan), N, Oc, H, W, be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(ws), be.stream)
+        be.call("mn_bnh_bwd_apply", be.ptr(dDA), be.ptr(h8), None, be.ptr(chan), be.ptr(sums), N, Oc, H, W, int(training), be.ptr(dy), be.stream)
     else:
         be.call("mn_qconv_bnsign_bwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save), be.ptr(dDA),
                 int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)

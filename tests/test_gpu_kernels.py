@@ -320,3 +320,14 @@ def test_first_conv_bn_wgrad(be, training):
     K.check_first_conv_bn_wgrad(be, training=training)
     K.check_first_conv_bn_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, seed=1)
     K.check_first_conv_bn_wgrad(be, x_shape=(8, 3, 32, 32), Oc=256, k=5, training=training, seed=2)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_qconv_bnsign_byte_stash(be, case):
+    K.check_qconv_bnsign(be, seed=220 + case, stash=True, **K.QGEMM_PW_CASES[case])
+    K.check_qconv_bnsign(be, seed=225 + case, stash=True, training=False, **K.QGEMM_PW_CASES[case])
+    if case in (1, 2):
+        K.check_qconv_bnsign(be, seed=230 + case, stash=True, pooled=True, **K.QGEMM_PW_CASES[case])
+    if case == 0:
+        K.check_qconv_bnsign(be, seed=240, stash=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)
+        K.check_qconv_bnsign(be, seed=241, stash=True, pooled=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)

@@ -289,6 +289,10 @@ def test_wbwtab_packed_activations_are_bit_identical():
     a = w.prepare(net(), inplace=True, A=2, W=3, packed_activations=True, fuse_conv_bn=False)
     b = w.prepare(net(), inplace=True, A=2, W=3, packed_activations=False)
     assert type(a[3]).__name__ == "MaxPool2dSign" and type(b[3]) is nn.MaxPool2d
+    # the classifier conv on sign codes (Conv2dSignIn) sums in another order than MIOpen: keep the stock layer on both sides so that
+    # this test isolates the hand-off (Conv2dSignIn has its own test)
+    assert type(a[7].conv).__name__ == "Conv2dSignIn"
+    a[7].conv.__class__ = nn.Conv2d
     seen = {}
     a[1].register_forward_hook(lambda m, i, o: seen.__setitem__("a", (type(i[0]), type(o), o.detach().float().clone())))
     b[1].register_forward_hook(lambda m, i, o: seen.__setitem__("b", o.detach().clone()))
@@ -300,7 +304,7 @@ def test_wbwtab_packed_activations_are_bit_identical():
     ya.square().mean().backward()
     yb.square().mean().backward()
     for (n_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        if n_.startswith(("0.conv", "5.conv")):    # plain nn.Conv2d layers run MIOpen's (atomic) backward-weight: equal to rounding
+        if n_.startswith(("0.conv", "7.conv")):    # plain nn.Conv2d layers run MIOpen's (atomic) backward-weight: equal to rounding
             assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 1e-5, n_
         else:
             assert torch.equal(pa.grad, pb.grad), n_

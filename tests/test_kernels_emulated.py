@@ -192,3 +192,12 @@ def test_sign_classifier(be):
 def test_first_conv_bn_wgrad(be, training):
     K.check_first_conv_bn_wgrad(be, training=training)
     K.check_first_conv_bn_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, seed=1)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_qconv_bnsign_byte_stash(be, case):
+    """forward stash h = (acc + nnz) / 2 + the streaming BatchNorm+sign backward on (da, h)."""
+    K.check_qconv_bnsign(be, seed=220 + case, stash=True, **K.QGEMM_PW_CASES[case])
+    K.check_qconv_bnsign(be, seed=225 + case, stash=True, training=False, **K.QGEMM_PW_CASES[case])
+    if case in (1, 2):
+        K.check_qconv_bnsign(be, seed=230 + case, stash=True, pooled=True, **K.QGEMM_PW_CASES[case])
