@@ -267,6 +267,14 @@ int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* own, const 
                     float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
 int mn_bnh_bwd_apply(const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int64_t N, int64_t C, int64_t H,
                      int64_t W, int training, float* dy, mn_stream_t stream);
+/* ... and the consumers of that dy can form it themselves: backward-data / backward-weight of the block's pointwise convolution whose incoming
+ * gradient is the BatchNorm+sign backward of (da, h) -- evaluated in registers while da and h stream in, so dy is never written or re-read
+ * (x = the block's input codes; chan, sums as above; needs mn_conv2d_bnh_supported). */
+int mn_conv2d_bnh_supported(const mn_conv_geom* g, const mn_wq* wq);
+int mn_conv2d_bwd_data_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums,
+                           int training, const float* w, float* dx, void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_conv2d_bwd_weight_bnh(const mn_conv_geom* g, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
+                             const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
 /* same backward when a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119) sits behind the block: `dpool` = d loss / d pool(a),
  * [N][O][H/2][W/2] fp32, `a_own` = the block's own output codes (what mn_qconv_bnsign_fwd wrote); the pool's backward (gradient to
  * the first maximum of each window) is applied while the gradient is read -- a quarter of the bytes, no full-size da tensor. */

@@ -89,6 +89,9 @@ PROTOTYPES = {
     "mn_qconv_bnsign_fwd_stash": (_I, [_G, _W, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "mn_bnh_bwd_sums": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P]),
     "mn_bnh_bwd_apply": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P]),
+    "mn_conv2d_bnh_supported": (_I, [_G, _W]),
+    "mn_conv2d_bwd_data_bnh": (_I, [_G, _W, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
+    "mn_conv2d_bwd_weight_bnh": (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_qconv_bnsign_bwd": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_qconv_bnsign_bwd_pooled": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_signconv1x1_small_supported": (_I, [_L, _L, _L]),

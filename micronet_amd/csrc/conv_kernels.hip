@@ -772,6 +772,24 @@ extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, cons
     return MN_OK;
 }
 
+extern "C" int mn_conv2d_bnh_supported(const mn_conv_geom* g, const mn_wq* wq) {
+    if (check_geom(g, "mn_conv2d_bnh_supported") != MN_OK) return 0;
+    return pwd_supported(g, wq) && pws_wgrad_supported(g);
+}
+extern "C" int mn_conv2d_bwd_data_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums,
+                                      int training, const float* w, float* dx, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_data_bnh");
+    if (rc) return rc;
+    if (!da || !h || !chan || !sums || !w || !dx) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data_bnh: null tensor");
+    return pwd_bwd_data_bnh(g, wq, da, h, chan, sums, training, w, dx, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int mn_conv2d_bwd_weight_bnh(const mn_conv_geom* g, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
+                                        const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_weight_bnh");
+    if (rc) return rc;
+    if (!da || !h || !chan || !sums || !x || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null tensor");
+    return pws_bwd_weight_bnh(g, da, h, chan, sums, training, x, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta,
                                              const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                                              mn_stream_t stream) {

@@ -23,5 +23,12 @@ int pws_fwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float
 int pws_wgrad_supported(const mn_conv_geom* g);
 int64_t pws_wgrad_ws_bytes(const mn_conv_geom* g);
 int pws_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+// BatchNorm+sign backward folded into the consumers of dy (pointwise, sign-code activations): see k_pwd / k_pws_wgrad
+int pwd_supported(const mn_conv_geom* g, const mn_wq* wq);
+int64_t pwd_ws_bytes(const mn_conv_geom* g);
+int pwd_bwd_data_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
+                     const float* w, float* dx, void* ws, int64_t ws_bytes, hipStream_t s);
+int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* da, const uint8_t* h, const float* chan, const float* sums, int training, const int8_t* x,
+                       float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s);

@@ -22,6 +22,20 @@ __device__ __forceinline__ float act_code(float x, const Pro& p, float sc, float
     return x;
 }
 
+// per-channel fold of the BatchNorm+sign backward for the BNH variants (same algebra as k_bnh_apply, reassociated; `scale` = the weight
+// scale the consumer multiplies the operand with)
+__device__ __forceinline__ void bnh_fold(const float* __restrict__ chan, const float* __restrict__ sums, int C, int co, int training, float n_f, float scale,
+                                         float& hlo, float& hhi, float& G, float& E1, float& E0) {
+    const float fl = chan[C + co], L = chan[2 * C + co], U = chan[3 * C + co], A = chan[4 * C + co], B = chan[5 * C + co], gi = chan[6 * C + co], nnz = chan[7 * C + co];
+    const float k1 = training ? sums[co] / n_f : 0.f, k2 = training ? sums[C + co] / n_f : 0.f;
+    // L <= (2h - nnz)*flip <= U   (L, U, nnz integers; 2h - nnz has the parity of every admissible value)
+    if (fl > 0.f) { hlo = ceilf((L + nnz) * 0.5f); hhi = floorf((U + nnz) * 0.5f); }
+    else { hlo = ceilf((nnz - U) * 0.5f); hhi = floorf((nnz - L) * 0.5f); }
+    G = gi * scale;
+    E1 = -gi * k2 * 2.f * A * scale;
+    E0 = -gi * (k1 + k2 * (B - nnz * A)) * scale;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight codes: one workgroup (one wave) per padded row; recovers code and scale from the fake-quantised fp32 weights
 struct PackParams {

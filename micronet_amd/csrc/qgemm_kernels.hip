@@ -311,8 +311,15 @@ struct PwdParams {
     uint32_t NP;
     FastDiv fd_hw;
     ChanMap out_map;
+    // BNH variant: the streamed operand is not given, it is the BatchNorm+sign backward of (da, h) -- see k_bnh_apply (norm_kernels.hip):
+    // gy := gi*dz - gi*k1 - gi*k2*zhat with dz = da*[hlo <= h <= hhi], zhat = (2h - nnz)*A + B, folded per channel into G*dz + E1*h + E0
+    const unsigned char* h;   // [N][G*Kc][HW] one-byte conv stash
+    const float* chan;        // [8][G*Kc]
+    const float* sums;        // [2][G*Kc]
+    int training;
+    float n_f;
 };
-template <int NT, int KS>
+template <int NT, int KS, int BNH>
 __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     constexpr int MB = 16 * NT;
@@ -321,6 +328,11 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
     float* ks = smem + (MB * LDW) / 2;                            // [Kp]
     uint32_t* koff = reinterpret_cast<uint32_t*>(ks + p.Kp);      // [Kp] element offset of gy channel k (clamped)
     uint32_t* ooff = koff + p.Kp;                                  // [MB] element offset of the (shuffled) dx channel
+    float* fhlo = reinterpret_cast<float*>(ooff + MB);            // BNH: [Kp] each
+    float* fhhi = fhlo + p.Kp;
+    float* fG = fhhi + p.Kp;
+    float* fE1 = fG + p.Kp;
+    float* fE0 = fE1 + p.Kp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const uint32_t HW = (uint32_t)p.HW;
 
@@ -340,6 +352,11 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
         for (int k = tid; k < p.Kp; k += 256) {
             ks[k] = p.kscale[g * p.Kp + k];
             koff[k] = (uint32_t)(g * p.Kc + (k < p.Kc ? k : p.Kc - 1)) * HW;
+            if (BNH) {
+                float hlo = 1.f, hhi = 0.f, G = 0.f, E1 = 0.f, E0 = 0.f;      // padded channels: contribute exactly 0 (their weight codes are 0 too)
+                if (k < p.Kc) bnh_fold(p.chan, p.sums, p.Cin_total, g * p.Kc + k, p.training, p.n_f, ks[k], hlo, hhi, G, E1, E0);
+                fhlo[k] = hlo; fhhi[k] = hhi; fG[k] = G; fE1[k] = E1; fE0[k] = E0;
+            }
         }
         for (int i = tid; i < MB; i += 256) {
             const int m = mblk * MB + i;
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
     const uint32_t Pmax = p.NP - 4u;
 
     // K-step `it` (chunk it / KS, step it % KS) of this wave: 8 channels x 4 pixels per lane
-    auto issue = [&](float4 (&raw)[8], int it) {
+    auto issue = [&](float4 (&raw)[8], uint32_t (&hb)[8], int it) {
         const int ci = it / KS, s = it - ci * KS;
         uint32_t P = (uint32_t)(chunk0 + ci * cstride) * 64u + 4u * j;
         P = P < Pmax ? P : Pmax;
@@ -366,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
         for (int e = 0; e < 4; ++e) {
             raw[e] = *reinterpret_cast<const float4*>(p.gy + (go + o0[e]));
             raw[4 + e] = *reinterpret_cast<const float4*>(p.gy + (go + o1[e]));
+            if (BNH) {
+                hb[e] = *reinterpret_cast<const uint32_t*>(p.h + (go + o0[e]));
+                hb[4 + e] = *reinterpret_cast<const uint32_t*>(p.h + (go + o1[e]));
+            }
         }
     };
 
@@ -376,19 +397,42 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
         for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float4 ra[8], rb[8];
-    if (total > 0) issue(ra, 0);
-    if (total > 1) issue(rb, 1);
-    auto step = [&](float4 (&raw)[8], int it) {
+    uint32_t ha[8], hbb[8];
+    if (total > 0) issue(ra, ha, 0);
+    if (total > 1) issue(rb, hbb, 1);
+    auto step = [&](float4 (&raw)[8], uint32_t (&hb)[8], int it) {
         const int ci = it / KS, s = it - ci * KS;
-        // weight scale of the 8 contraction channels of this lane
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(ks + s * 32 + kg * 8), s1 = *reinterpret_cast<const f32x4*>(ks + s * 32 + kg * 8 + 4);
         float v[8][4];
+        if (BNH) {
+            // operand = BatchNorm+sign backward of (da, h), already times the weight scale: G*dz + E1*h + E0
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e][0] = raw[e].x * s0[e]; v[e][1] = raw[e].y * s0[e]; v[e][2] = raw[e].z * s0[e]; v[e][3] = raw[e].w * s0[e];
-            v[4 + e][0] = raw[4 + e].x * s1[e]; v[4 + e][1] = raw[4 + e].y * s1[e]; v[4 + e][2] = raw[4 + e].z * s1[e]; v[4 + e][3] = raw[4 + e].w * s1[e];
+            for (int half = 0; half < 2; ++half) {
+                const int kb = s * 32 + kg * 8 + half * 4;
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(fhlo + kb), hi4 = *reinterpret_cast<const f32x4*>(fhhi + kb);
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(fG + kb), e14 = *reinterpret_cast<const f32x4*>(fE1 + kb), e04 = *reinterpret_cast<const f32x4*>(fE0 + kb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 d4 = raw[half * 4 + e];
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const uint32_t hw = hb[half * 4 + e];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float hf = (float)((hw >> (8 * q)) & 0xffu);
+                        const float dz = (hf >= lo4[e] && hf <= hi4[e]) ? dv[q] : 0.f;
+                        v[half * 4 + e][q] = fmaf(g4[e], dz, fmaf(e14[e], hf, e04[e]));
+                    }
+                }
+            }
+        } else {
+            // weight scale of the 8 contraction channels of this lane
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(ks + s * 32 + kg * 8), s1 = *reinterpret_cast<const f32x4*>(ks + s * 32 + kg * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e][0] = raw[e].x * s0[e]; v[e][1] = raw[e].y * s0[e]; v[e][2] = raw[e].z * s0[e]; v[e][3] = raw[e].w * s0[e];
+                v[4 + e][0] = raw[4 + e].x * s1[e]; v[4 + e][1] = raw[4 + e].y * s1[e]; v[4 + e][2] = raw[4 + e].z * s1[e]; v[4 + e][3] = raw[4 + e].w * s1[e];
+            }
         }
-        if (it + 2 < total) issue(raw, it + 2);           // the registers are free: two steps ahead
+        if (it + 2 < total) issue(raw, hb, it + 2);           // the registers are free: two steps ahead
         u32x4 av[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const u32x4*>(wl + s * 32 + t * 16 * LDW);
@@ -433,8 +477,8 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
         }
     };
     for (int it = 0; it < total; it += 2) {
-        step(ra, it);
-        if (it + 1 < total) step(rb, it + 1);
+        step(ra, ha, it);
+        if (it + 1 < total) step(rb, hbb, it + 1);
     }
 }
 
@@ -786,7 +830,7 @@ static int plan_pwd(const mn_conv_geom* g, PwdPlan* pl) {
     pl->NT = NT;
     const int MB = 16 * NT;
     p.num_mblk = (Cg + MB - 1) / MB; p.Mpad = p.num_mblk * MB;
-    pl->lds = (size_t)MB * (p.Kp + 8) * 2 + (size_t)2 * p.Kp * 4 + (size_t)MB * 4;
+    pl->lds = (size_t)MB * (p.Kp + 8) * 2 + (size_t)2 * p.Kp * 4 + (size_t)MB * 4 + (size_t)5 * p.Kp * 4;
     p.nchunks = (int)((NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
     const int cap = 1024 / (p.G * p.num_mblk) > 0 ? 1024 / (p.G * p.num_mblk) : 1;
@@ -805,14 +849,39 @@ static int plan_pwd(const mn_conv_geom* g, PwdPlan* pl) {
     pl->pack_grid = k.G * k.Mgp;
     return 1;
 }
+template <int NT, int BNH>
+static void launch_pwd2(const PwdPlan& pl, hipStream_t s) {
+    switch (pl.p.KS) {
+        case 1: hipLaunchKernelGGL((k_pwd<NT, 1, BNH>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
+        case 2: hipLaunchKernelGGL((k_pwd<NT, 2, BNH>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
+        case 3: hipLaunchKernelGGL((k_pwd<NT, 3, BNH>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
+        default: hipLaunchKernelGGL((k_pwd<NT, 4, BNH>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
+    }
+}
 template <int NT>
 static void launch_pwd(const PwdPlan& pl, hipStream_t s) {
-    switch (pl.p.KS) {
-        case 1: hipLaunchKernelGGL((k_pwd<NT, 1>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
-        case 2: hipLaunchKernelGGL((k_pwd<NT, 2>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
-        case 3: hipLaunchKernelGGL((k_pwd<NT, 3>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
-        default: hipLaunchKernelGGL((k_pwd<NT, 4>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p); break;
-    }
+    if (pl.p.h) launch_pwd2<NT, 1>(pl, s); else launch_pwd2<NT, 0>(pl, s);
+}
+int pwd_supported(const mn_conv_geom* g, const mn_wq* wq) { PwdPlan pd; return wq_codeable(wq) && plan_pwd(g, &pd); }
+int64_t pwd_ws_bytes(const mn_conv_geom* g) { PwdPlan pd; return plan_pwd(g, &pd) ? pd.ws_bytes : 0; }
+// backward-data whose incoming gradient is the BatchNorm+sign backward of (da, h): formed inside the kernel
+int pwd_bwd_data_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
+                     const float* w, float* dx, void* ws, int64_t ws_bytes, hipStream_t s) {
+    PwdPlan pd;
+    if (!wq_codeable(wq) || !plan_pwd(g, &pd) || !aligned16(da) || !aligned16(dx) || (((uintptr_t)h) & 3))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data_bnh: geometry / quantizer combination not covered");
+    if (!ws || ws_bytes < pd.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data_bnh: workspace too small");
+    fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
+    qg_launch_pack(pd.pk, pd.pack_grid, s);
+    pd.p.gy = da; pd.p.dx = dx; pd.p.wc = pd.pk.codes; pd.p.kscale = pd.pk.scale_out;
+    pd.p.h = h; pd.p.chan = chan; pd.p.sums = sums; pd.p.training = training; pd.p.n_f = (float)g->N * (float)(g->H * g->W);
+    mn_set_last_kernel("k_pwd<%d, %d, 1>", pd.NT, pd.p.KS);
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(5.0 * ny + 4.0 * nx); }
+    mn_prof_begin(s);
+    if (pd.NT == 4) launch_pwd<4>(pd, s); else if (pd.NT == 2) launch_pwd<2>(pd, s); else launch_pwd<1>(pd, s);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_data_bnh");
+    return MN_OK;
 }
 int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
     if (!pw_geom_ok(g)) return kk_supported(g, aq, wq, which);
@@ -897,7 +966,8 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
             fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
             qg_launch_pack(pd.pk, pd.pack_grid, s);
             pd.p.gy = gy; pd.p.dx = dx; pd.p.wc = pd.pk.codes; pd.p.kscale = pd.pk.scale_out;
-            mn_set_last_kernel("k_pwd<%d, %d>", pd.NT, pd.p.KS);
+            pd.p.h = nullptr; pd.p.chan = nullptr; pd.p.sums = nullptr; pd.p.training = 0; pd.p.n_f = 1.f;
+            mn_set_last_kernel("k_pwd<%d, %d, 0>", pd.NT, pd.p.KS);
             mn_prof_begin(s);
             if (pd.NT == 4) launch_pwd<4>(pd, s); else if (pd.NT == 2) launch_pwd<2>(pd, s); else launch_pwd<1>(pd, s);
             mn_prof_end(s);

@@ -420,8 +420,14 @@ struct Wg2Params {
     int st_per_z, st_stride;      // block z contracts steps z*st_per_z + i*st_stride, i < its count (contiguous ranges: st_stride = 1)
     FastDiv fd_hw;
     ChanMap in_map;
+    // BNH variant: gy is the BatchNorm+sign backward of (da = gy pointer, h), formed in registers (bnh_fold, qgemm_dev.h)
+    const unsigned char* h;
+    const float* chan;
+    const float* sums;
+    int training;
+    float n_f;
 };
-template <int MW, int CW>
+template <int MW, int CW, int BNH>
 __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const int wm = wave >> 1, wc = wave & 1;
@@ -446,6 +452,17 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         c = c < p.Cg ? c : p.Cg - 1;
         xoff[ci] = (uint32_t)chan_phys(p.in_map, g * p.Cg + c) * HW;
     }
+    __shared__ float ftab[5 * 32 * MW];          // BNH: the per-channel fold of the block's TM channel rows (kept out of the register file)
+    if (BNH) {
+        for (int i = tid; i < TM; i += 256) {
+            int m = mb * TM + i;
+            m = m < p.Mg ? m : p.Mg - 1;
+            float hlo, hhi, G, E1, E0;
+            bnh_fold(p.chan, p.sums, p.Cout_total, g * p.Mg + m, p.training, p.n_f, 1.f, hlo, hhi, G, E1, E0);
+            ftab[i] = hlo; ftab[TM + i] = hhi; ftab[2 * TM + i] = G; ftab[3 * TM + i] = E1; ftab[4 * TM + i] = E0;
+        }
+        __syncthreads();
+    }
     f32x4 acc[MW][CW];
     float dbacc[MW];
 #pragma unroll
@@ -456,7 +473,8 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
     }
 
     // two register sets alternate: while one step is contracted, the loads of the next TWO steps are in flight
-    struct Raw { float4 ga[MW], gb[MW]; uint32_t ua[CW], ub[CW]; };
+    constexpr int NSETS = (BNH && MW == 4) ? 1 : 2;          // the BN fold needs 5*MW + 2*MW more registers: one register set then
+    struct Raw { float4 ga[MW], gb[MW]; uint32_t ua[CW], ub[CW]; uint32_t ha[MW], hb[MW]; };
     Raw r0, r1;
     auto fetch = [&](Raw& R, int st) {
         const uint32_t Pa = (uint32_t)st * 32u + 4u * kg, Pb = Pa + 16u;
@@ -468,6 +486,10 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         for (int mi = 0; mi < MW; ++mi) {
             R.ga[mi] = *reinterpret_cast<const float4*>(p.gy + (oa + goff[mi]));
             R.gb[mi] = *reinterpret_cast<const float4*>(p.gy + (ob + goff[mi]));
+            if (BNH) {
+                R.ha[mi] = *reinterpret_cast<const uint32_t*>(p.h + (oa + goff[mi]));
+                R.hb[mi] = *reinterpret_cast<const uint32_t*>(p.h + (ob + goff[mi]));
+            }
         }
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
@@ -490,7 +512,17 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         u32x4 a0[MW], a1[MW], a2[MW];
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
-            const float v[8] = {R.ga[mi].x, R.ga[mi].y, R.ga[mi].z, R.ga[mi].w, R.gb[mi].x, R.gb[mi].y, R.gb[mi].z, R.gb[mi].w};
+            float v[8] = {R.ga[mi].x, R.ga[mi].y, R.ga[mi].z, R.ga[mi].w, R.gb[mi].x, R.gb[mi].y, R.gb[mi].z, R.gb[mi].w};
+            if (BNH) {
+                const int row = (wm * MW + mi) * 16 + j;
+                const float hlo = ftab[row], hhi = ftab[TM + row], G = ftab[2 * TM + row], E1 = ftab[3 * TM + row], E0 = ftab[4 * TM + row];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float hf = (float)(((e < 4 ? R.ha[mi] : R.hb[mi]) >> (8 * (e & 3))) & 0xffu);
+                    const float dz = (hf >= hlo && hf <= hhi) ? v[e] : 0.f;
+                    v[e] = fmaf(G, dz, fmaf(E1, hf, E0));
+                }
+            }
             float t0[8], t1[8], t2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -507,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
                 a2[mi][d] = mn_pack_bf16x2(t2[2 * d], t2[2 * d + 1]);
             }
         }
-        if (st + 2 * p.st_stride < st_end) fetch(R, st + 2 * p.st_stride);     // the registers are free: two steps ahead
+        if (st + NSETS * p.st_stride < st_end) fetch(R, st + NSETS * p.st_stride);     // the registers are free: NSETS steps ahead
         // term-outer: MW*CW independent accumulators between two MFMAs on the same one (a dependent MFMA waits ~2 issue slots)
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
@@ -523,10 +555,14 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
             for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a2[mi], bf[ci], acc[mi][ci]);
     };
     if (st0 < st_end) fetch(r0, st0);
-    if (st0 + p.st_stride < st_end) fetch(r1, st0 + p.st_stride);
-    for (int st = st0; st < st_end; st += 2 * p.st_stride) {
-        contract(r0, st);
-        if (st + p.st_stride < st_end) contract(r1, st + p.st_stride);
+    if (NSETS == 2) {
+        if (st0 + p.st_stride < st_end) fetch(r1, st0 + p.st_stride);
+        for (int st = st0; st < st_end; st += 2 * p.st_stride) {
+            contract(r0, st);
+            if (st + p.st_stride < st_end) contract(r1, st + p.st_stride);
+        }
+    } else {
+        for (int st = st0; st < st_end; st += p.st_stride) contract(r0, st);
     }
     // partial tile: lane (j, kg) holds rows m = 4kg + r, column c = j
 #pragma unroll
@@ -582,15 +618,27 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
 int pws_wgrad_supported(const mn_conv_geom* g) { Wg2Plan pl; return plan_pws_wgrad(g, &pl); }
 int64_t pws_wgrad_ws_bytes(const mn_conv_geom* g) { Wg2Plan pl; return plan_pws_wgrad(g, &pl) ? pl.ws_bytes : 0; }
 int pws_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    return pws_bwd_weight_bnh(g, gy, nullptr, nullptr, nullptr, 0, x, dw, dbias, ws, ws_bytes, s);
+}
+int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h, const float* chan, const float* sums, int training, const int8_t* x,
+                       float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
     Wg2Plan pl;
     if (!plan_pws_wgrad(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(sign): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(sign): workspace too small");
     Wg2Params& p = pl.p;
     p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
-    mn_set_last_kernel("k_pws_wgrad<%d, %d>", pl.MW, pl.MW);
+    p.h = h; p.chan = chan; p.sums = sums; p.training = training; p.n_f = (float)g->N * (float)(g->H * g->W);
+    if (h && (!chan || !sums || (((uintptr_t)h) & 3))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null / misaligned argument");
+    mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.MW, pl.MW, h ? 1 : 0);
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((h ? 5.0 : 4.0) * ny + nx); }
     mn_prof_begin(s);
-    if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4>), dim3(pl.grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_pws_wgrad<2, 2>), dim3(pl.grid), dim3(256), 0, s, p);
+    if (p.h) {
+        if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_pws_wgrad<2, 2, 1>), dim3(pl.grid), dim3(256), 0, s, p);
+    } else {
+        if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 0>), dim3(pl.grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_pws_wgrad<2, 2, 0>), dim3(pl.grid), dim3(256), 0, s, p);
+    }
     mn_prof_end(s);
     qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, 1.f, nullptr, s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(sign)");

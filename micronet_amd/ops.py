@@ -499,7 +499,25 @@ class QConv2d(Function):
     def backward(ctx, gy):
         x, wq, qp, wscale = ctx.saved_tensors
         g, aq_mode, aq_bits, aq_qtype, has_bias, wd4, aq_flags = ctx.cfg
-        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") == "bnh" and aq_mode == ACTQ_SIGN8 and wd4 is not None and \
+                CONV_ALGO == _lib.MN_ALGO_AUTO:
+            r = gy._mn_recipe              # the fused BatchNorm+sign behind this conv: dy is formed inside backward-data / backward-weight
+            wd = _wq_desc(wd4 + (wscale,))
+            dx = dw = db = None
+            with torch.cuda.device_of(x):
+                if ctx.needs_input_grad[0]:
+                    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                    ws, nb = _ws(g, 1, x.device)
+                    _call("mn_conv2d_bwd_data_bnh", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(wq),
+                          _p(dx), _p(ws), nb, _s())
+                if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                    dw = torch.empty_like(wq)
+                    db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
+                    ws, nb = _ws(g, 2, x.device)
+                    _call("mn_conv2d_bwd_weight_bnh", C.byref(g), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(x), _p(dw),
+                          _p(db), _p(ws), nb, _s())
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") != "bnh" and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
             r = gy._mn_recipe              # the BatchNorm+sign behind the first conv: dy is formed inside the backward-weight kernel
             dw = torch.empty_like(wq)
@@ -565,6 +583,10 @@ def qconv_bnsign_supported(x, wq, stride, padding, dilation, groups, wdesc, in_s
     return bool(_lib_().mn_qconv_bnsign_supported(C.byref(g), _ref(_wq_desc(wdesc))))
 
 
+import os as _os
+FOLD_BN_INTO_CONV_BWD = _os.environ.get("MN_NO_BNH_FOLD", "") == ""      # A/B switch
+
+
 class ConvBNSign(Function):
     """a = sign(batch_norm(y)) for a LazyConvOut y: conv, batch statistics, normalisation and sign in the fused kernels of
     qgemm_sign.hip -- y is never written; the forward stashes the integer conv result in ONE byte per element (h) and the
@@ -588,6 +610,7 @@ class ConvBNSign(Function):
                   int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(h), _p(chan), _p(ws), nb, _s())
         ctx.save_for_backward(h, chan, gamma, beta)
         ctx.training = int(training)
+        ctx.fold_ok = FOLD_BN_INTO_CONV_BWD and bool(_lib_().mn_conv2d_bnh_supported(C.byref(g), _ref(wd)))     # the conv's own backward can form dy from (da, h)
         return SignTensor(a)
 
     @staticmethod
@@ -600,12 +623,21 @@ class ConvBNSign(Function):
         else:
             grad, own = _chk(da, "grad"), None
         N, Cc, H, W = h.shape
-        dy = torch.empty(h.shape, dtype=torch.float32, device=h.device)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         sums = torch.empty((2, Cc), dtype=torch.float32, device=h.device)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=h.device)
         with torch.cuda.device_of(h):
             _call("mn_bnh_bwd_sums", _p(grad), _p(h), _p(own), _p(chan), N, Cc, H, W, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+            if not pooled and ctx.fold_ok and LAZY_BN_GRAD:
+                # d loss / d y is not written: the convolution's backward-data / backward-weight form it from (da, h) while they stream in
+                def expand(r):
+                    dy_ = torch.empty(r["h"].shape, dtype=torch.float32, device=r["h"].device)
+                    with torch.cuda.device_of(dy_):
+                        _call("mn_bnh_bwd_apply", _p(r["da"]), _p(r["h"]), None, _p(r["chan"]), _p(r["sums"]), N, Cc, H, W, r["training"], _p(dy_), _s())
+                    return dy_
+                recipe = dict(kind="bnh", da=grad, h=h, chan=chan, sums=sums, training=training)
+                return LazyBNGrad(h.shape, h.device, recipe, expand), dgamma, dbeta, None, None, None, None, None
+            dy = torch.empty(h.shape, dtype=torch.float32, device=h.device)
             _call("mn_bnh_bwd_apply", _p(grad), _p(h), _p(own), _p(chan), _p(sums), N, Cc, H, W, training, _p(dy), _s())
         return dy, dgamma, dbeta, None, None, None, None, None
 

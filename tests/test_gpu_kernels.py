@@ -331,3 +331,10 @@ def test_qconv_bnsign_byte_stash(be, case):
     if case == 0:
         K.check_qconv_bnsign(be, seed=240, stash=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)
         K.check_qconv_bnsign(be, seed=241, stash=True, pooled=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)
+
+
+def test_conv_backward_with_bn_folded_in(be):
+    K.check_qconv_bnsign(be, seed=250, stash=True, x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2)
+    K.check_qconv_bnsign(be, seed=251, stash=True, x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2, bias=False)
+    K.check_qconv_bnsign(be, seed=252, stash=True, training=False, x_shape=(2, 80, 4, 4), w_shape=(100, 40, 1, 1), groups=2)
+    K.check_qconv_bnsign(be, seed=253, stash=True, x_shape=(8, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=16)

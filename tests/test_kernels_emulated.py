@@ -201,3 +201,10 @@ def test_qconv_bnsign_byte_stash(be, case):
     K.check_qconv_bnsign(be, seed=225 + case, stash=True, training=False, **K.QGEMM_PW_CASES[case])
     if case in (1, 2):
         K.check_qconv_bnsign(be, seed=230 + case, stash=True, pooled=True, **K.QGEMM_PW_CASES[case])
+
+
+def test_conv_backward_with_bn_folded_in(be):
+    """mn_conv2d_bwd_data_bnh / mn_conv2d_bwd_weight_bnh (dy formed in registers from (da, h)) on shapes the direct kernels cover."""
+    K.check_qconv_bnsign(be, seed=250, stash=True, x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2)
+    K.check_qconv_bnsign(be, seed=251, stash=True, x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2, bias=False)
+    K.check_qconv_bnsign(be, seed=252, stash=True, training=False, x_shape=(2, 80, 4, 4), w_shape=(100, 40, 1, 1), groups=2)
