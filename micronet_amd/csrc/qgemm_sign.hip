@@ -430,14 +430,17 @@ struct Wg2Params {
 template <int MW, int CW, int BNH>
 __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
-    const int wm = wave >> 1, wc = wave & 1;
+    // CW == 8: the four waves are four row slices of 16*MW channels each reading ALL 128 columns (gy is loaded once per block, only the
+    // one-byte codes are shared by the waves); otherwise a 2 x 2 arrangement
+    constexpr int WCN = CW == 8 ? 1 : 2;
+    const int wm = WCN == 1 ? wave : (wave >> 1), wc = WCN == 1 ? 0 : (wave & 1);
     uint32_t b = blockIdx.x;
     const int z = b % p.Z; b /= p.Z;
     const int cb = b % p.ncb; b /= p.ncb;
     const int mb = b % p.nmb;
     const int g = b / p.nmb;
     const uint32_t HW = (uint32_t)p.HW;
-    constexpr int TM = 32 * MW, TC = 32 * CW;
+    constexpr int TM = 16 * MW * (4 / WCN), TC = 16 * CW * WCN;
 
     uint32_t goff[MW], xoff[CW];          // channel offsets (rows beyond Mg / Cg are clamped: their dw entries are never read)
 #pragma unroll
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         c = c < p.Cg ? c : p.Cg - 1;
         xoff[ci] = (uint32_t)chan_phys(p.in_map, g * p.Cg + c) * HW;
     }
-    __shared__ float ftab[5 * 32 * MW];          // BNH: the per-channel fold of the block's TM channel rows (kept out of the register file)
+    __shared__ float ftab[5 * 16 * MW * (CW == 8 ? 4 : 2)];          // BNH: the per-channel fold of the block's TM channel rows (kept out of the register file)
     if (BNH) {
         for (int i = tid; i < TM; i += 256) {
             int m = mb * TM + i;
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
     }
 }
 static int pws_geom_ok(const mn_conv_geom* g);
-struct Wg2Plan { Wg2Params p; int MW; int grid; int64_t off_db, ws_bytes; };
+struct Wg2Plan { Wg2Params p; int MW, CW8; int grid; int64_t off_db, ws_bytes; };
 static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (!pws_geom_ok(g)) return 0;
     const int Cg = g->C / g->groups, Mg = g->O / g->groups;
@@ -591,7 +594,8 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (NP % 32 || Mg < 33 || Cg < 33) return 0;           // small tiles stay on the LDS-staged kernel
     Wg2Params& p = pl->p;
     pl->MW = (Mg > 64 || Cg > 64) ? 4 : 2;
-    if (const char* e = getenv("MN_WG2_MW")) { const int v = atoi(e); if (v == 2 || v == 4) pl->MW = v; }   // tuning knob
+    pl->CW8 = 0;
+    if (const char* e = getenv("MN_WG2_CW8")) pl->CW8 = atoi(e) != 0 && pl->MW == 4;   // tuning knob: 4 x 1 waves of 32 x 128
     const int T = 32 * pl->MW;
     p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.Cin_total = g->C; p.Cout_total = g->O; p.Cg = Cg; p.Mg = Mg;
     p.in_map = make_chanmap(g->in_shuffle, g->C);
@@ -629,14 +633,16 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
     p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
     p.h = h; p.chan = chan; p.sums = sums; p.training = training; p.n_f = (float)g->N * (float)(g->H * g->W);
     if (h && (!chan || !sums || (((uintptr_t)h) & 3))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null / misaligned argument");
-    mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.MW, pl.MW, h ? 1 : 0);
+    mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.CW8 ? 2 : pl.MW, pl.CW8 ? 8 : pl.MW, h ? 1 : 0);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((h ? 5.0 : 4.0) * ny + nx); }
     mn_prof_begin(s);
     if (p.h) {
-        if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
+        if (pl.CW8) hipLaunchKernelGGL((k_pws_wgrad<2, 8, 1>), dim3(pl.grid), dim3(256), 0, s, p);
+        else if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_pws_wgrad<2, 2, 1>), dim3(pl.grid), dim3(256), 0, s, p);
     } else {
-        if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 0>), dim3(pl.grid), dim3(256), 0, s, p);
+        if (pl.CW8) hipLaunchKernelGGL((k_pws_wgrad<2, 8, 0>), dim3(pl.grid), dim3(256), 0, s, p);
+        else if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 0>), dim3(pl.grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_pws_wgrad<2, 2, 0>), dim3(pl.grid), dim3(256), 0, s, p);
     }
     mn_prof_end(s);
