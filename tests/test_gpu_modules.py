@@ -517,3 +517,33 @@ def test_first_block_bn_gradient_stays_lazy_and_matches():
     assert seen["go"] > 0
     for a_, p_ in zip(res[True], q.parameters()):
         assert torch.allclose(a_, p_.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_bn_backward_folded_into_conv_backward_matches():
+    """ops.FOLD_BN_INTO_CONV_BWD: the fused block's BatchNorm+sign backward is not applied by a streaming pass but inside the conv's
+    backward-data / backward-weight (dy formed from (da, h) in registers).  Teacher-forced on one block: same gradients to rounding."""
+    from micronet_amd import ops
+    from micronet_amd.models.nin_gc import ConvBNReLU
+    from micronet_amd.sign_tensor import SignTensor
+    w = _q("wbwtab")
+    torch.manual_seed(19)
+    net = nn.Sequential(ConvBNReLU(3, 128, 3, padding=1), ConvBNReLU(128, 256, 1, groups=2, channel_shuffle=1, shuffle_groups=2),
+                        ConvBNReLU(256, 10, 1), nn.AvgPool2d(8)).cuda().train()
+    q = w.prepare(net, inplace=True, A=2, W=3)
+    blk = q[1]
+    codes = (torch.randint(0, 2, (8, 128, 8, 8), device="cuda", dtype=torch.int8) * 2 - 1)
+    gout = torch.randn(8, 256, 8, 8, device="cuda")
+    res = {}
+    old = ops.FOLD_BN_INTO_CONV_BWD
+    for fold in (True, False):
+        ops.FOLD_BN_INTO_CONV_BWD = fold
+        try:
+            for p_ in blk.parameters():
+                p_.grad = None
+            x = SignTensor(codes.clone()).requires_grad_(True)
+            blk(x).backward(gout)
+            res[fold] = [x.grad.clone()] + [p_.grad.clone() for n_, p_ in blk.named_parameters() if n_ != "conv.bias"]
+        finally:
+            ops.FOLD_BN_INTO_CONV_BWD = old
+    for a_, b_ in zip(res[True], res[False]):
+        assert rel_err(a_.cpu(), b_.cpu()) <= 1e-5
