@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmicronet_hip.so")
+LIB_PATH = os.environ.get("MN_LIB_PATH") or os.path.join(HERE, "lib", "libmicronet_hip.so")   # MN_LIB_PATH: ablation builds of the same library
 
 MN_ACTQ_NONE, MN_ACTQ_DOREFA, MN_ACTQ_IAO, MN_ACTQ_SIGN8 = 0, 1, 2, 3
 MN_ALGO_AUTO, MN_ALGO_DIRECT, MN_ALGO_MFMA, MN_ALGO_QGEMM = 0, 1, 2, 3

@@ -427,6 +427,9 @@ struct Wg2Params {
     int training;
     float n_f;
 };
+#ifndef MN_WG2_DBGC
+#define MN_WG2_DBGC 0      // ablation build only (scripts/ablate_wgrad.sh): 1 no MFMAs, 2 no term split, 4 no streaming (one step re-read)
+#endif
 template <int MW, int CW, int BNH>
 __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
@@ -479,7 +482,9 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
     constexpr int NSETS = (BNH && MW == 4) ? 1 : 2;          // the BN fold needs 5*MW + 2*MW more registers: one register set then
     struct Raw { float4 ga[MW], gb[MW]; uint32_t ua[CW], ub[CW]; uint32_t ha[MW], hb[MW]; };
     Raw r0, r1;
+    const int st0 = p.st_stride == 1 ? z * p.st_per_z : z;
     auto fetch = [&](Raw& R, int st) {
+        if (MN_WG2_DBGC & 4) st = st0;
         const uint32_t Pa = (uint32_t)st * 32u + 4u * kg, Pb = Pa + 16u;
         const uint32_t na = fd_div(Pa, p.fd_hw), nb = fd_div(Pb, p.fd_hw);
         const uint32_t pa = Pa - na * HW, pb = Pb - nb * HW;
@@ -500,7 +505,6 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
             R.ub[ci] = *reinterpret_cast<const uint32_t*>(p.x + (xb + xoff[ci]));
         }
     };
-    const int st0 = p.st_stride == 1 ? z * p.st_per_z : z;
     const int st_end = p.st_stride == 1 ? ((st0 + p.st_per_z) < p.nsteps ? (st0 + p.st_per_z) : p.nsteps) : p.nsteps;
     auto contract = [&](Raw& R, int st) {
         // B fragments: sign codes -> bf16 +-1
@@ -527,12 +531,17 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
                 }
             }
             float t0[8], t1[8], t2[8];
+            if (MN_WG2_DBGC & 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { t0[e] = v[e]; t1[e] = v[e]; t2[e] = v[e]; }
+            } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 t0[e] = mn_bf16_head(v[e]);
                 const float r1 = v[e] - t0[e];
                 t1[e] = mn_bf16_head(r1);
                 t2[e] = r1 - t1[e];
+            }
             }
             dbacc[mi] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 #pragma unroll
@@ -543,6 +552,16 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
             }
         }
         if (st + NSETS * p.st_stride < st_end) fetch(R, st + NSETS * p.st_stride);     // the registers are free: NSETS steps ahead
+        if (MN_WG2_DBGC & 1) {
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                for (int ci = 0; ci < CW; ++ci) {
+                    acc[mi][ci][0] += mn_u2f((a0[mi][0] ^ a1[mi][1] ^ a2[mi][2] ^ a0[mi][3] ^ a1[mi][0] ^ a2[mi][1] ^ a0[mi][2] ^ a1[mi][3] ^ a2[mi][0] ^ a0[mi][1] ^ a1[mi][2] ^ a2[mi][3]) & 0x3fffffffu);
+                    acc[mi][ci][1] += mn_u2f((bf[ci][0] ^ bf[ci][1] ^ bf[ci][2] ^ bf[ci][3]) & 0x3fffffffu);
+                }
+            return;
+        }
         // term-outer: MW*CW independent accumulators between two MFMAs on the same one (a dependent MFMA waits ~2 issue slots)
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
@@ -585,8 +604,182 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same contraction with the operands STAGED THROUGH LDS.  In k_pws_wgrad a load instruction's 16 consecutive lanes are the 16
+// channel rows of an MFMA fragment: every 16-lane group touches 16 different cache lines (64 tag look-ups per instruction instead
+// of 8), and the kernel is bound by the texture-address / L1 tag rate, not by HBM, MFMA or the term split (ablation: neither
+// removing the MFMAs, nor the split, nor the HBM stream -- one step re-read from L1 -- moved its time by more than 15 %).  Here
+// the 256 threads of a block load the block's 32-pixel step row by row (8 lanes = one 128-byte line of a gy row; 2 lanes = the
+// 32 codes of an activation row), two steps ahead into two register sets, and hand it over in a double-buffered LDS image
+// (gy rows padded to 160 B, code rows to 48 B and chunk-interleaved: the b128 / b64 fragment reads of a wave are conflict-free);
+// the fragments are then built exactly as in k_pws_wgrad.  One barrier per step.  The BatchNorm fold (BNH) and the bias gradient
+// move to the staging threads (once per block instead of once per wave).  Same partial-tile layout, same reduction kernel.
+#define WG3_RSA 160
+#define WG3_RSB 48
+template <int MW, int BNH>
+__global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
+    constexpr int CW = MW, TM = 32 * MW, TC = 32 * MW, RPT = TM / 32, BUF = TM * WG3_RSA + TC * WG3_RSB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const int wm = wave >> 1, wc = wave & 1;
+    uint32_t b = blockIdx.x;
+    const int z = b % p.Z; b /= p.Z;
+    const int cb = b % p.ncb; b /= p.ncb;
+    const int mb = b % p.nmb;
+    const int g = b / p.nmb;
+    const uint32_t HW = (uint32_t)p.HW;
+
+    // staging roles: gy row sr + 32 i, pixels 4 sq .. 4 sq + 3 of the step; code row cr, pixels 16 chf .. 16 chf + 15
+    const int sr = tid >> 3, sq = tid & 7, cr = tid >> 1, chf = tid & 1;
+    const bool cdo = TC >= 128 || cr < TC;
+    uint32_t goff[RPT], xoff;
+    float f_hlo[RPT], f_hhi[RPT], f_G[RPT], f_E1[RPT], f_E0[RPT], dbacc[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        int m = mb * TM + sr + 32 * i;
+        m = m < p.Mg ? m : p.Mg - 1;
+        goff[i] = (uint32_t)(g * p.Mg + m) * HW;
+        dbacc[i] = 0.f;
+        if (BNH) bnh_fold(p.chan, p.sums, p.Cout_total, g * p.Mg + m, p.training, p.n_f, 1.f, f_hlo[i], f_hhi[i], f_G[i], f_E1[i], f_E0[i]);
+    }
+    {
+        int c = cb * TC + (cdo ? cr : 0);
+        c = c < p.Cg ? c : p.Cg - 1;
+        xoff = (uint32_t)chan_phys(p.in_map, g * p.Cg + c) * HW;
+    }
+    f32x4 acc[MW][CW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Stage { float4 gv[RPT]; uint32_t hv[RPT]; u32x4 cv; };
+    Stage s0, s1;
+    const int st0 = z * p.st_per_z;
+    const int n = ((st0 + p.st_per_z) < p.nsteps ? (st0 + p.st_per_z) : p.nsteps) - st0;
+    // loads are unconditional (a conditional load makes the register set a phi: copies, and a vmcnt(0) right behind the issue):
+    // steps past the block's range re-read the last step of the tensor and are never contracted
+    auto fetch = [&](Stage& S, int k) {
+        int st = st0 + k;
+        st = st < p.nsteps ? st : p.nsteps - 1;
+        const uint32_t P = (uint32_t)st * 32u + 4u * sq;
+        const uint32_t ni = fd_div(P, p.fd_hw);
+        const uint32_t o = ni * (uint32_t)p.Cout_total * HW + (P - ni * HW);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            S.gv[i] = *reinterpret_cast<const float4*>(p.gy + (o + goff[i]));
+            if (BNH) S.hv[i] = *reinterpret_cast<const uint32_t*>(p.h + (o + goff[i]));
+        }
+        if (cdo) {
+            const uint32_t Pc = (uint32_t)st * 32u + 16u * chf;
+            const uint32_t nc = fd_div(Pc, p.fd_hw);
+            S.cv = *reinterpret_cast<const u32x4*>(p.x + (nc * (uint32_t)p.Cin_total * HW + (Pc - nc * HW) + xoff));
+        }
+    };
+    auto commit = [&](Stage& S, int buf, bool valid) {
+        unsigned char* A = lds + buf * BUF;
+        unsigned char* B = A + TM * WG3_RSA;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            float v[4] = {S.gv[i].x, S.gv[i].y, S.gv[i].z, S.gv[i].w};
+            if (BNH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float hf = (float)((S.hv[i] >> (8 * e)) & 0xffu);
+                    const float dz = (hf >= f_hlo[i] && hf <= f_hhi[i]) ? v[e] : 0.f;
+                    v[e] = fmaf(f_G[i], dz, fmaf(f_E1[i], hf, f_E0[i]));
+                }
+            }
+            dbacc[i] += valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+            *reinterpret_cast<float4*>(A + (sr + 32 * i) * WG3_RSA + 16 * sq) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (cdo) {          // chunk q of this half goes next to chunk q of the other half: lane (j, kg) reads its 8 codes as one b64
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint32_t*>(B + cr * WG3_RSB + 8 * q + 4 * chf) = S.cv[q];
+        }
+    };
+    auto contract = [&](int buf) {
+        const unsigned char* A = lds + buf * BUF;
+        const unsigned char* B = A + TM * WG3_RSA;
+        u32x4 bf[CW];
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) {
+            const u32x2 uv = *reinterpret_cast<const u32x2*>(B + ((wc * CW + ci) * 16 + j) * WG3_RSB + 8 * kg);
+            const uint32_t u = uv[0], v = uv[1];
+            bf[ci] = u32x4{0x3F803F80u | ((u & 0x80u) << 8) | ((u & 0x8000u) << 16), 0x3F803F80u | ((u & 0x800000u) >> 8) | (u & 0x80000000u),
+                           0x3F803F80u | ((v & 0x80u) << 8) | ((v & 0x8000u) << 16), 0x3F803F80u | ((v & 0x800000u) >> 8) | (v & 0x80000000u)};
+        }
+        u32x4 a0[MW], a1[MW], a2[MW];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            const unsigned char* row = A + ((wm * MW + mi) * 16 + j) * WG3_RSA + 16 * kg;
+            const float4 ga = *reinterpret_cast<const float4*>(row), gb = *reinterpret_cast<const float4*>(row + 64);
+            const float v[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+            float t0[8], t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                t0[e] = mn_bf16_head(v[e]);
+                const float r1 = v[e] - t0[e];
+                t1[e] = mn_bf16_head(r1);
+                t2[e] = r1 - t1[e];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                a0[mi][d] = mn_pack_bf16x2(t0[2 * d], t0[2 * d + 1]);
+                a1[mi][d] = mn_pack_bf16x2(t1[2 * d], t1[2 * d + 1]);
+                a2[mi][d] = mn_pack_bf16x2(t2[2 * d], t2[2 * d + 1]);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a0[mi], bf[ci], acc[mi][ci]);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a1[mi], bf[ci], acc[mi][ci]);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a2[mi], bf[ci], acc[mi][ci]);
+    };
+    fetch(s0, 0);
+    fetch(s1, 1);
+    commit(s0, 0, n > 0);
+    fetch(s0, 2);
+    __syncthreads();
+    for (int t = 0; t < n; t += 2) {
+        commit(s1, 1, t + 1 < n);
+        fetch(s1, t + 3);
+        contract(0);
+        __syncthreads();
+        commit(s0, 0, t + 2 < n);
+        fetch(s0, t + 4);
+        if (t + 1 < n) contract(1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) {
+            const int mrow = mb * TM + (wm * MW + mi) * 16 + kg * 4;
+            const int ccol = cb * TC + (wc * CW + ci) * 16 + j;
+            float* dst = p.part + (((int64_t)z * p.G + g) * p.Mgw + mrow) * p.Cgw + ccol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.Cgw] = acc[mi][ci][r];
+        }
+    if (p.want_db && cb == 0) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            float v = dbacc[i];
+            v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);     // the 8 pixel chunks of the row
+            if (sq == 0) p.dbpart[((int64_t)z * p.G + g) * p.Mgw + mb * TM + sr + 32 * i] = v;
+        }
+    }
+}
 static int pws_geom_ok(const mn_conv_geom* g);
-struct Wg2Plan { Wg2Params p; int MW, CW8; int grid; int64_t off_db, ws_bytes; };
+struct Wg2Plan { Wg2Params p; int MW, CW8, staged; int grid; int64_t off_db, ws_bytes; };
 static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (!pws_geom_ok(g)) return 0;
     const int Cg = g->C / g->groups, Mg = g->O / g->groups;
@@ -604,12 +797,17 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     p.nsteps = (int)(NP / 32);
     const int base = p.G * p.nmb * p.ncb;
     int Z = 512 / base;
+    // every block pays a fixed price (pipeline fill, a 64 KB partial tile written and reduced again): keep >= 32 steps per block as long
+    // as there is still one block per CU (measured: L5 67 -> 58 us, L8 40 -> 36 us)
+    while (Z > 1 && p.nsteps / Z < 32 && base * Z > 256) Z /= 2;
     if (const char* e = getenv("MN_WG2_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }   // tuning knob
     if (Z > p.nsteps / 2) Z = p.nsteps / 2;
     if (Z < 1) Z = 1;
     p.Z = Z;
     p.st_per_z = (p.nsteps + Z - 1) / Z; p.st_stride = 1;     // contiguous pixel ranges: each block streams its gy rows sequentially
     if (getenv("MN_WG2_STRIDED")) { p.st_stride = Z; }
+    // LDS-staged kernel: 16-byte code loads need HW % 16 == 0; MN_WG2_DIRECT=1 keeps the direct-load kernel (A/B knob)
+    pl->staged = p.HW % 16 == 0 && !pl->CW8 && p.st_stride == 1 && !getenv("MN_WG2_DIRECT");
     p.fd_hw = make_fastdiv((uint32_t)p.HW);
     const int64_t nb = (int64_t)base * Z;
     if (nb > 0x7fffffff) return 0;
@@ -633,10 +831,20 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
     p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
     p.h = h; p.chan = chan; p.sums = sums; p.training = training; p.n_f = (float)g->N * (float)(g->H * g->W);
     if (h && (!chan || !sums || (((uintptr_t)h) & 3))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null / misaligned argument");
-    mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.CW8 ? 2 : pl.MW, pl.CW8 ? 8 : pl.MW, h ? 1 : 0);
+    if (pl.staged && ((((uintptr_t)x) & 15) || (h && (((uintptr_t)h) & 3)))) pl.staged = 0;
+    if (pl.staged) mn_set_last_kernel("k_pws_wgrad_s<%d, %d>", pl.MW, h ? 1 : 0);
+    else mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.CW8 ? 2 : pl.MW, pl.CW8 ? 8 : pl.MW, h ? 1 : 0);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((h ? 5.0 : 4.0) * ny + nx); }
     mn_prof_begin(s);
-    if (p.h) {
+    if (pl.staged) {
+        if (p.h) {
+            if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad_s<4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_pws_wgrad_s<2, 1>), dim3(pl.grid), dim3(256), 0, s, p);
+        } else {
+            if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad_s<4, 0>), dim3(pl.grid), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_pws_wgrad_s<2, 0>), dim3(pl.grid), dim3(256), 0, s, p);
+        }
+    } else if (p.h) {
         if (pl.CW8) hipLaunchKernelGGL((k_pws_wgrad<2, 8, 1>), dim3(pl.grid), dim3(256), 0, s, p);
         else if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_pws_wgrad<2, 2, 1>), dim3(pl.grid), dim3(256), 0, s, p);

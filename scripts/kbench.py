@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--scheme", default="wbwtab")
     ap.add_argument("--layers", default="L2,L4,L5,L7,L8,L9")
     ap.add_argument("--json", default="")
+    ap.add_argument("--which", default="fwd,dgrad,wgrad")
     args = ap.parse_args()
     be = abi_driver.Backend("gpu")
     algos = [int(a) for a in args.algos.split(",")]
@@ -97,6 +98,8 @@ def main():
                 be.call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), P(gy), P(x), P(dw), P(db), P(ws), wsb[2], algo, be.stream)
 
             for which, fn in (("fwd", f_fwd), ("dgrad", f_dgrad), ("wgrad", f_wgrad)):
+                if which not in args.which.split(","):
+                    continue
                 try:
                     fn()
                 except RuntimeError as e:

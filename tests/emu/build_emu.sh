@@ -4,14 +4,14 @@ set -e
 cd "$(dirname "$0")/../.."
 mkdir -p tests/emu/build
 CXX="g++ -O2 -std=c++17 -fPIC -ffp-contract=off -I tests/emu/include -x c++"
-$CXX -DMN_EMU_MAIN -c micronet_amd/csrc/quant_kernels.hip -o tests/emu/build/quant_kernels.o &
-$CXX -c micronet_amd/csrc/conv_kernels.hip -o tests/emu/build/conv_kernels.o &
-$CXX -c micronet_amd/csrc/qgemm_kernels.hip -o tests/emu/build/qgemm_kernels.o &
-$CXX -c micronet_amd/csrc/qgemm_kxk.hip -o tests/emu/build/qgemm_kxk.o &
-$CXX -c micronet_amd/csrc/qgemm_sign.hip -o tests/emu/build/qgemm_sign.o &
-$CXX -c micronet_amd/csrc/conv_first.hip -o tests/emu/build/conv_first.o &
-$CXX -c micronet_amd/csrc/optim_kernels.hip -o tests/emu/build/optim_kernels.o &
-$CXX -c micronet_amd/csrc/norm_kernels.hip -o tests/emu/build/norm_kernels.o &
-wait
-g++ -shared -o tests/emu/build/libmicronet_emu.so tests/emu/build/quant_kernels.o tests/emu/build/conv_kernels.o tests/emu/build/qgemm_kernels.o tests/emu/build/qgemm_kxk.o tests/emu/build/qgemm_sign.o tests/emu/build/conv_first.o tests/emu/build/optim_kernels.o tests/emu/build/norm_kernels.o
+SRCS="quant_kernels conv_kernels qgemm_kernels qgemm_kxk qgemm_sign conv_first optim_kernels norm_kernels"
+pids=""
+for f in $SRCS; do
+  extra=""; [ $f = quant_kernels ] && extra="-DMN_EMU_MAIN"
+  $CXX $extra -c micronet_amd/csrc/$f.hip -o tests/emu/build/$f.o &
+  pids="$pids $!"
+done
+for p in $pids; do wait $p; done          # a failed compile fails the build (set -e), never links a stale object
+objs=""; for f in $SRCS; do objs="$objs tests/emu/build/$f.o"; done
+g++ -shared -o tests/emu/build/libmicronet_emu.so $objs
 echo built tests/emu/build/libmicronet_emu.so

@@ -245,6 +245,21 @@ def test_qgemm_sign8_shuffle(be):
     K.check_conv(be, seed=161, wmode=1, sign8=True, algos=(3,), in_shuffle=2, **K.QGEMM_KXK_CASES[0])
 
 
+# backward-weight on sign codes with Mg, Cg > 32: the LDS-staged kernel (k_pws_wgrad_s) when H*W % 16 == 0 -- odd step count, clamped
+# rows, shuffled input, bias gradient -- and the direct-load kernel (k_pws_wgrad) otherwise
+SIGN8_WGRAD_CASES = [
+    dict(x_shape=(3, 96, 4, 8), w_shape=(80, 48, 1, 1), groups=2),                    # MW = 2 (40 x 48 per group), 3 steps in one block
+    dict(x_shape=(5, 256, 4, 8), w_shape=(200, 128, 1, 1), groups=2, in_shuffle=2),   # MW = 4 (100 x 128), 5 steps over 2 blocks
+    dict(x_shape=(2, 70, 4, 4), w_shape=(66, 70, 1, 1), bias=False),                  # one step, rows 66..127 clamped
+    dict(x_shape=(8, 80, 2, 2), w_shape=(96, 40, 1, 1), groups=2),                    # H*W = 4: direct-load kernel
+]
+
+
+@pytest.mark.parametrize("case", range(len(SIGN8_WGRAD_CASES)))
+def test_sign8_wgrad_large_tiles(be, case):
+    K.check_conv(be, seed=165 + case, wmode=1, sign8=True, algos=(3,), expect_qgemm=True, **SIGN8_WGRAD_CASES[case])
+
+
 @pytest.mark.parametrize("name,kw", [(n, kw) for n, kw in QGEMM_HOT if "nin_gc" in n], ids=[n for n, _ in QGEMM_HOT if "nin_gc" in n])
 def test_qgemm_hot_shapes_sign8(be, name, kw):
     if kw["w_shape"][1] * kw.get("groups", 1) == 3:
