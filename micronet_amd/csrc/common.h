@@ -62,6 +62,25 @@ __device__ __forceinline__ int mn_uniform(int v) { return __builtin_amdgcn_readf
 #else
 #define MN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// wave-level hand-over of LDS data between the lanes of ONE wave (no block barrier): the hardware executes a wave's DS operations in
+// order, so only the compiler (and the emulator's lane scheduler) has to be told
+#ifdef MN_EMULATION
+#define MN_WAVE_SYNC() emu::yield(emu::WAIT_WAVE)
+__device__ __forceinline__ uint32_t mn_alignbyte(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * sh)); }
+__device__ __forceinline__ uint32_t mn_perm(uint32_t a, uint32_t b, uint32_t sel) {      // v_perm_b32: bytes 0-3 = b, 4-7 = a, 0x0c = 0x00
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s_ = (sel >> (8 * i)) & 0xffu;
+        const uint32_t byte = s_ < 4 ? (b >> (8 * s_)) & 0xffu : s_ < 8 ? (a >> (8 * (s_ - 4))) & 0xffu : 0u;
+        r |= byte << (8 * i);
+    }
+    return r;
+}
+#else
+#define MN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+__device__ __forceinline__ uint32_t mn_alignbyte(uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ uint32_t mn_perm(uint32_t a, uint32_t b, uint32_t sel) { return __builtin_amdgcn_perm(a, b, sel); }
+#endif
 // bf16 "head" of an fp32 (truncation): exact for integers |v| <= 256; v - head is exact in fp32, so
 // v = t0 + t1 + t2 with t_i = head(remainder) reproduces all 24 significant bits (three-term split).
 __device__ __forceinline__ float mn_bf16_head(float v) { return mn_u2f(mn_f2u(v) & 0xffff0000u); }

@@ -65,6 +65,11 @@ int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
 int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s);
 
+// 3 x 3 backward-weight on sign codes (qgemm_k3s.hip)
+int k3s_wgrad_supported(const mn_conv_geom* g);
+int64_t k3s_wgrad_ws_bytes(const mn_conv_geom* g);
+int k3s_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+
 static inline int aq_codeable(const mn_actq* aq, int need_exact_x) {
     (void)need_exact_x;   // real-valued x is handled exactly by term splitting (zero terms are skipped)
     if (!aq || aq->mode == MN_ACTQ_NONE) return 1;

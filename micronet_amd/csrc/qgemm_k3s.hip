@@ -1,0 +1,284 @@
+// 3 x 3 (stride 1, padding 1) backward-weight on packed sign activations, for gfx950.
+//
+//   dwq[g][m][c][r][s] = sum over (n, oh, ow) of gy[n][g*Mg + m][oh][ow] * a[n][g*Cg + c][oh + r - 1][ow + s - 1]
+//
+// (the weight gradient of the grouped 3x3 QuantConv2d layers of nin_gc, wbwtab/quantize.py:181-195 through autograd's
+// conv2d backward; a = the int8 sign codes of BinaryActivation).  The contraction index is the output pixel, and both operands
+// are pixel-contiguous in NCHW.  MFMA shape per group tile: M = 32 output channels (2 row tiles), N = 16 input channels, one
+// N tile PER TAP (9 accumulator tiles per row tile), K = 32 output pixels per step = 32 / W whole image rows.
+//
+// Every WAVE is an independent worker: it streams its own K-steps (the four waves of a block interleave over the block's step
+// range, so neighbouring rows of the same planes are read together), with NO block barrier in the loop:
+//   * global -> registers, coalesced, two steps ahead: 8 lanes read one 128-byte line of a gy row; the input patch of a step
+//     ((R + 2) image rows x W codes per channel) is one contiguous byte range per channel, read dword by dword;
+//   * registers -> the wave's private LDS image: gy rows padded to 160 B (conflict-free b128 fragment reads); the codes re-encoded
+//     as the HIGH byte of a bf16 (+-0.5 = 0x3F00 / 0xBF00, 0 = the zero padding) in rows of W + 4 bytes, the 4 bytes between two
+//     rows staying zero: left / right padding of every row, and rows outside the image are written as zeros (top / bottom);
+//   * fragments: gy as three exact bf16 terms (as k_pws_wgrad_s); for tap (r, s) a lane takes the three dwords around its 4-pixel
+//     chunk in patch row (local row + r), shifts by s - 1 bytes (v_alignbyte) and spreads the four bytes into two bf16 pairs
+//     (v_perm): 6 VALU instructions per B fragment, no shifted copies in LDS.
+// The +-0.5 encoding makes the products half of the true ones -- an exact power of two, undone by the reduction kernel's scale.
+// At the end the four waves add their tiles through LDS in wave order (deterministic) and write one partial tile per block in the
+// layout of k_kk_wgrad; k_pw_wgrad_reduce sums the Z partials in fp64.
+#include "qgemm_dev.h"
+
+#include <stdlib.h>
+
+#define K3_RSA 160            // LDS bytes per gy row (32 pixels fp32 + pad)
+#define K3_NXL 6              // code dwords a lane stages per step (W = 32: 16 channels x 3 rows x 8 dwords = 384 = 6 x 64)
+
+struct K3wParams {
+    const float* gy;
+    const char* x;
+    float* part;      // [Z][G][Mgw][Cgw*9]
+    float* dbpart;    // [Z][G][Mgw]
+    int N, C, H, W, O, Cg, Mg, G, nmb, ncb, Z, Mgw, Cgw, want_db;
+    int R, spi, nsteps, st_per_z, DPC, W4, CS, XB;    // rows per step, steps per image, dwords per channel patch, W/4, LDS bytes per channel / per wave
+    FastDiv fd_spi, fd_dpc, fd_w4;
+    ChanMap in_map;
+};
+
+__global__ __launch_bounds__(256, 2) void k_k3s_wgrad(const K3wParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    unsigned char* gsm = reinterpret_cast<unsigned char*>(smem) + wave * (32 * K3_RSA + p.XB);     // this wave's image: gy rows, then the code patch
+    unsigned char* xsm = gsm + 32 * K3_RSA;
+    uint32_t b = blockIdx.x;
+    const int z = b % p.Z; b /= p.Z;
+    const int cb = b % p.ncb; b /= p.ncb;
+    const int mb = b % p.nmb;
+    const int g = b / p.nmb;
+    const uint32_t HW = (uint32_t)(p.H * p.W);
+
+    // the zero dwords around the patch rows (never overwritten)
+    for (int i = lane; i < 16 * (p.R + 3); i += 64) {
+        const int c = i / (p.R + 3), k = i - c * (p.R + 3);
+        *reinterpret_cast<uint32_t*>(xsm + c * p.CS + k * (p.W + 4)) = 0u;
+    }
+    // staging roles.  gy: row (lane >> 3) + 8 i, pixels 4 (lane & 7) ...;  codes: dword (lane + 64 u) of the [16][DPC] patch
+    const int sr = lane >> 3, sq = lane & 7;
+    uint32_t goff[4];
+    float dbacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = mb * 32 + sr + 8 * i;
+        m = m < p.Mg ? m : p.Mg - 1;
+        goff[i] = (uint32_t)(g * p.Mg + m) * HW + 4u * sq;
+        dbacc[i] = 0.f;
+    }
+    const int ccv = (p.Cg - cb * 16) < 16 ? (p.Cg - cb * 16) : 16;      // channels beyond Cg: zero codes
+    uint32_t xoff[K3_NXL];      // byte offset of the dword inside image n, without its row
+    int xlds[K3_NXL], xpr[K3_NXL];      // LDS byte offset (-1: no item); patch row
+#pragma unroll
+    for (int u = 0; u < K3_NXL; ++u) {
+        const int idx = lane + 64 * u;
+        const uint32_t c = fd_div(idx, p.fd_dpc);
+        const int d = idx - (int)c * p.DPC;
+        const uint32_t pr = fd_div(d, p.fd_w4);
+        const int col4 = d - (int)pr * p.W4;
+        const int cc = (int)c < ccv ? (int)c : ccv - 1;
+        xoff[u] = (uint32_t)chan_phys(p.in_map, g * p.Cg + cb * 16 + cc) * HW + 4u * col4;
+        xlds[u] = (idx < 16 * p.DPC) ? (int)c * p.CS + 4 + (int)pr * (p.W + 4) + 4 * col4 : -1;
+        xpr[u] = ((int)c < ccv) ? (int)pr : -1000;      // a channel beyond Cg never has a valid row
+    }
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[mi][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Stage { float4 gv[4]; uint32_t xv[K3_NXL]; int oh0; };
+    Stage s0, s1;
+    const int st0 = z * p.st_per_z;
+    const int nblk = ((st0 + p.st_per_z) < p.nsteps ? (st0 + p.st_per_z) : p.nsteps) - st0;     // steps of this block
+    const int nw = nblk > wave ? (nblk - wave + 3) / 4 : 0;                                         // ... of this wave: st0 + wave + 4 t
+    // loads are unconditional (clamped step, clamped rows): steps past the range are never contracted
+    auto fetch = [&](Stage& S, int t) {
+        int st = st0 + wave + 4 * t;
+        st = st < p.nsteps ? st : p.nsteps - 1;
+        const uint32_t n = fd_div(st, p.fd_spi);
+        const int oh0 = (st - (int)n * p.spi) * p.R;
+        S.oh0 = oh0;
+        const uint32_t go = n * (uint32_t)p.O * HW + (uint32_t)(oh0 * p.W);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.gv[i] = *reinterpret_cast<const float4*>(p.gy + (go + goff[i]));
+        const uint32_t xo = n * (uint32_t)p.C * HW;
+#pragma unroll
+        for (int u = 0; u < K3_NXL; ++u) {
+            int ir = oh0 - 1 + (xpr[u] < 0 ? 0 : xpr[u]);
+            ir = ir < 0 ? 0 : (ir < p.H ? ir : p.H - 1);          // rows outside the image: any valid address (written as zeros)
+            S.xv[u] = *reinterpret_cast<const uint32_t*>(p.x + (xo + xoff[u] + (uint32_t)(ir * p.W)));
+        }
+    };
+    auto commit = [&](Stage& S, bool valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dbacc[i] += valid ? (S.gv[i].x + S.gv[i].y) + (S.gv[i].z + S.gv[i].w) : 0.f;
+            *reinterpret_cast<float4*>(gsm + (sr + 8 * i) * K3_RSA + 16 * sq) = S.gv[i];
+        }
+#pragma unroll
+        for (int u = 0; u < K3_NXL; ++u) {
+            const int ir = S.oh0 - 1 + xpr[u];
+            const uint32_t enc = (ir >= 0 && ir < p.H) ? ((S.xv[u] & 0x80808080u) | 0x3F3F3F3Fu) : 0u;
+            if (xlds[u] >= 0) *reinterpret_cast<uint32_t*>(xsm + xlds[u]) = enc;
+        }
+    };
+    // fragment geometry of this lane: chunk a = pixels 4 kg .. + 3, chunk b = pixels 16 + 4 kg .. + 3 of the step
+    int xa, xb;
+    {
+        const int pa = 4 * kg, pb = 16 + 4 * kg;
+        const int ra = pa / p.W, rb = pb / p.W;
+        xa = j * p.CS + 4 + ra * (p.W + 4) + (pa - ra * p.W);
+        xb = j * p.CS + 4 + rb * (p.W + 4) + (pb - rb * p.W);
+    }
+    const int xrs = p.W + 4;
+    auto contract = [&]() {
+        u32x4 a0[2], a1[2], a2[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const unsigned char* row = gsm + (mi * 16 + j) * K3_RSA + 16 * kg;
+            const float4 ga = *reinterpret_cast<const float4*>(row), gb = *reinterpret_cast<const float4*>(row + 64);
+            const float v[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+            float t0[8], t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                t0[e] = mn_bf16_head(v[e]);
+                const float r1 = v[e] - t0[e];
+                t1[e] = mn_bf16_head(r1);
+                t2[e] = r1 - t1[e];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                a0[mi][d] = mn_pack_bf16x2(t0[2 * d], t0[2 * d + 1]);
+                a1[mi][d] = mn_pack_bf16x2(t1[2 * d], t1[2 * d + 1]);
+                a2[mi][d] = mn_pack_bf16x2(t2[2 * d], t2[2 * d + 1]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const unsigned char* qa = xsm + xa + r * xrs;
+            const unsigned char* qb = xsm + xb + r * xrs;
+            const uint32_t ap = *reinterpret_cast<const uint32_t*>(qa - 4), ac = *reinterpret_cast<const uint32_t*>(qa), an = *reinterpret_cast<const uint32_t*>(qa + 4);
+            const uint32_t bp = *reinterpret_cast<const uint32_t*>(qb - 4), bc = *reinterpret_cast<const uint32_t*>(qb), bn = *reinterpret_cast<const uint32_t*>(qb + 4);
+            u32x4 bf[3];
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const uint32_t ua = s_ == 0 ? mn_alignbyte(ac, ap, 3) : (s_ == 1 ? ac : mn_alignbyte(an, ac, 1));
+                const uint32_t ub = s_ == 0 ? mn_alignbyte(bc, bp, 3) : (s_ == 1 ? bc : mn_alignbyte(bn, bc, 1));
+                bf[s_] = u32x4{mn_perm(0u, ua, 0x010c000cu), mn_perm(0u, ua, 0x030c020cu), mn_perm(0u, ub, 0x010c000cu), mn_perm(0u, ub, 0x030c020cu)};
+            }
+            // term-outer over the three taps of this kernel row: 6 independent accumulators between two MFMAs on the same one
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi][r * 3 + s_] = mn_mfma_bf16(a0[mi], bf[s_], acc[mi][r * 3 + s_]);
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi][r * 3 + s_] = mn_mfma_bf16(a1[mi], bf[s_], acc[mi][r * 3 + s_]);
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi][r * 3 + s_] = mn_mfma_bf16(a2[mi], bf[s_], acc[mi][r * 3 + s_]);
+        }
+    };
+    fetch(s0, 0);
+    fetch(s1, 1);
+    MN_WAVE_SYNC();                       // the zero dwords are in place
+    for (int t = 0; t < nw; t += 2) {
+        commit(s0, true);
+        fetch(s0, t + 2);
+        MN_WAVE_SYNC();
+        contract();
+        MN_WAVE_SYNC();
+        commit(s1, t + 1 < nw);
+        fetch(s1, t + 3);
+        MN_WAVE_SYNC();
+        if (t + 1 < nw) contract();
+        MN_WAVE_SYNC();
+    }
+    // ---- the four waves add their tiles through LDS in wave order, then one coalesced partial-tile write
+    float* red = smem;                    // [32][144]
+    float* dbs = smem + 32 * 144;         // [32]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = (mi * 16 + kg * 4 + r) * 144 + j * 9 + t;
+                        red[idx] = (w == 0) ? acc[mi][t][r] : red[idx] + acc[mi][t][r];
+                    }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = dbacc[i];
+                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+                if (sq == 0) dbs[sr + 8 * i] = (w == 0) ? v : dbs[sr + 8 * i] + v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * 144; i += 256) {
+        const int m = i / 144, col = i - m * 144;
+        p.part[(((int64_t)z * p.G + g) * p.Mgw + mb * 32 + m) * ((int64_t)p.Cgw * 9) + (int64_t)cb * 144 + col] = red[i];
+    }
+    if (p.want_db && cb == 0 && tid < 32) p.dbpart[((int64_t)z * p.G + g) * p.Mgw + mb * 32 + tid] = dbs[tid];
+}
+
+struct K3wPlan { K3wParams p; int grid; size_t lds; int64_t off_db, ws_bytes; };
+static int plan_k3s(const mn_conv_geom* g, K3wPlan* pl) {
+    if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1 || g->dil_h != 1 || g->dil_w != 1) return 0;
+    if (g->W != 8 && g->W != 16 && g->W != 32) return 0;
+    const int R = 32 / g->W;
+    if (g->H % R) return 0;
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    const int64_t HW = (int64_t)g->H * g->W;
+    if ((int64_t)g->N * g->O * HW >= ((int64_t)1 << 31) || (int64_t)g->N * g->C * HW >= ((int64_t)1 << 31)) return 0;     // 32-bit element offsets
+    if (getenv("MN_NO_K3S")) return 0;          // A/B knob: the generic k x k kernel
+    K3wParams& p = pl->p;
+    p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.G = g->groups; p.Cg = g->C / g->groups; p.Mg = g->O / g->groups;
+    p.in_map = make_chanmap(g->in_shuffle, g->C);
+    p.R = R; p.spi = g->H / R; p.nsteps = g->N * p.spi;
+    p.W4 = g->W / 4; p.DPC = (R + 2) * p.W4; p.CS = (R + 2) * (g->W + 4) + 4; p.XB = (16 * p.CS + 15) / 16 * 16;
+    p.nmb = (p.Mg + 31) / 32; p.ncb = (p.Cg + 15) / 16; p.Mgw = p.nmb * 32; p.Cgw = p.ncb * 16;
+    const int base = p.G * p.nmb * p.ncb;
+    int Z = 512 / base;
+    while (Z > 1 && p.nsteps / Z < 32 && base * Z > 256) Z /= 2;
+    if (const char* e = getenv("MN_K3S_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }     // tuning knob
+    if (Z > p.nsteps / 4) Z = p.nsteps / 4;
+    if (Z < 1) Z = 1;
+    p.Z = Z;
+    p.st_per_z = (p.nsteps + Z - 1) / Z;
+    p.fd_spi = make_fastdiv((uint32_t)p.spi); p.fd_dpc = make_fastdiv((uint32_t)p.DPC); p.fd_w4 = make_fastdiv((uint32_t)p.W4);
+    const int64_t nb = (int64_t)base * Z;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    size_t lds = (size_t)4 * (32 * K3_RSA + p.XB), red = (size_t)(32 * 144 + 32) * 4;
+    pl->lds = lds > red ? lds : red;
+    const int64_t part_bytes = (int64_t)Z * p.G * p.Mgw * p.Cgw * 9 * 4;
+    pl->off_db = (part_bytes + 255) / 256 * 256;
+    pl->ws_bytes = pl->off_db + (int64_t)Z * p.G * p.Mgw * 4;
+    return 1;
+}
+int k3s_wgrad_supported(const mn_conv_geom* g) { K3wPlan pl; return plan_k3s(g, &pl); }
+int64_t k3s_wgrad_ws_bytes(const mn_conv_geom* g) { K3wPlan pl; return plan_k3s(g, &pl) ? pl.ws_bytes : 0; }
+int k3s_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    K3wPlan pl;
+    if (!plan_k3s(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(sign 3x3): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(sign 3x3): workspace too small");
+    K3wParams& p = pl.p;
+    p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
+    mn_set_last_kernel("k_k3s_wgrad");
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + nx); }
+    mn_prof_begin(s);
+    raise_lds_limit((const void*)k_k3s_wgrad, pl.lds);
+    hipLaunchKernelGGL(k_k3s_wgrad, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    mn_prof_end(s);
+    // the codes were contracted as +-0.5: the reduction doubles (exact)
+    qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg * 9, p.Mgw, p.Cgw * 9, 2.f, nullptr, s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(sign 3x3)");
+    return MN_OK;
+}

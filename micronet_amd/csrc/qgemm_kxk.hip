@@ -772,7 +772,7 @@ int kk_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int 
     KkPlan pl;
     if (which == 0) return wq_codeable(wq) && aq_codeable(aq, 0) && plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl);
     if (which == 1) return wq_codeable(wq) && plan_kk(g, 1, MN_ACTQ_NONE, &pl);
-    if (which == 2) { KwPlan kw; return aq_codeable(aq, 1) && plan_kk_wgrad(g, &kw); }
+    if (which == 2) { KwPlan kw; return aq_codeable(aq, 1) && (plan_kk_wgrad(g, &kw) || (aq && aq->mode == MN_ACTQ_SIGN8 && k3s_wgrad_supported(g))); }
     return 0;
 }
 int64_t kk_ws_bytes(const mn_conv_geom* g, int which) {
@@ -783,11 +783,13 @@ int64_t kk_ws_bytes(const mn_conv_geom* g, int which) {
         return a > b ? a : b;
     }
     if (which == 1) return plan_kk(g, 1, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0;
-    if (which == 2) { KwPlan kw; return plan_kk_wgrad(g, &kw) ? kw.ws_bytes : 0; }
+    if (which == 2) { KwPlan kw; const int64_t a = plan_kk_wgrad(g, &kw) ? kw.ws_bytes : 0, b = k3s_wgrad_ws_bytes(g); return a > b ? a : b; }
     return 0;
 }
 int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s) {
+    if (aq && aq->mode == MN_ACTQ_SIGN8 && k3s_wgrad_supported(g) && ws_bytes >= k3s_wgrad_ws_bytes(g))
+        return k3s_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // 3x3 on sign codes: wave-private streaming kernel
     KwPlan pl;
     if (!aq_codeable(aq, 1) || !plan_kk_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(qgemm): geometry / quantizer combination not covered");

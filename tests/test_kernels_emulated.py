@@ -145,6 +145,20 @@ def test_sign8_wgrad_large_tiles(be, case):
     K.check_conv(be, seed=165 + case, wmode=1, sign8=True, algos=(3,), expect_qgemm=True, **SIGN8_WGRAD_CASES[case])
 
 
+# 3 x 3 backward-weight on sign codes (k_k3s_wgrad): several blocks per group with uneven step ranges, W = 8 / 16 / 32
+K3S_CASES = [
+    dict(x_shape=(9, 32, 4, 16), w_shape=(64, 16, 3, 3), padding=1, groups=2),                 # 18 steps over 4 blocks (5, 5, 5, 3)
+    dict(x_shape=(5, 48, 8, 8), w_shape=(96, 24, 3, 3), padding=1, groups=2, bias=False),      # Cg = 24: two c-tiles, the second half empty
+    # W = 32, H = 3: every step touches top or bottom padding (the generic k x k forward / backward-data tilers reject H = 3)
+    dict(x_shape=(3, 8, 3, 32), w_shape=(40, 8, 3, 3), padding=1, in_shuffle=2, expect_qgemm=(False, False, True)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(K3S_CASES)))
+def test_sign8_wgrad_3x3(be, case):
+    K.check_conv(be, seed=175 + case, wmode=1, sign8=True, algos=(3,), **{"expect_qgemm": True, **K3S_CASES[case]})
+
+
 def test_pool_sign8(be):
     K.check_pool_sign8(be)
     K.check_pool_sign8(be, shape=(2, 3, 2, 8), seed=1)
