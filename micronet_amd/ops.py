@@ -584,10 +584,10 @@ def qconv_bnsign_supported(x, wq, stride, padding, dilation, groups, wdesc, in_s
 
 
 import os as _os
-# Fold the BatchNorm+sign backward into the block's own conv backward (k_pwd / k_pws_wgrad form dy from (da, h) in registers, dy is
-# never written).  Measured on one MI355X box: +1 % step throughput (the streaming apply pass disappears, the two conv kernels get
-# ~25 % slower) -- within noise, so it is OFF by default; MN_BNH_FOLD=1 (or setting this flag) enables it.
-FOLD_BN_INTO_CONV_BWD = _os.environ.get("MN_BNH_FOLD", "") == "1"
+# Fold the BatchNorm+sign backward into the block's own conv backward (k_pwd / k_pws_wgrad_s form dy from (da, h) in registers / in
+# the LDS staging pass, dy is never written).  With the LDS-staged backward-weight kernel (the fold costs one pass per BLOCK there)
+# this is +3.5 % step throughput on c2 (3.25 -> 3.14 ms): ON by default, MN_BNH_FOLD=0 switches it off.
+FOLD_BN_INTO_CONV_BWD = _os.environ.get("MN_BNH_FOLD", "1") != "0"
 
 
 class ConvBNSign(Function):
