@@ -263,6 +263,15 @@ int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x,
 int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
                               const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
                               float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream);
+/* The stash forward also covers k x k convolutions with ternary / binary weights on sign codes (nin_gc's grouped 3x3 layers,
+ * models/nin_gc.py:88-119): the code-domain k x k kernel writes h instead of y, the batch statistics and the sign are streamed from h
+ * (one byte per element each).  These two queries answer for both kinds of block; the stash forward needs the workspace they name. */
+int mn_qconv_bnsign_stash_supported(const mn_conv_geom* g, const mn_wq* wq);
+int64_t mn_qconv_bnsign_stash_ws_bytes(const mn_conv_geom* g);
+/* rows of `chan` the stash forward fills (and mn_bnh_bwd_* read): 8 for a pointwise block; 17 for a 3x3 / padding 1 block, where the taps
+ * outside the image meet zeros, so acc has the parity of a PER-PIXEL-CLASS count (top / middle / bottom row x left / middle / right
+ * column): row 7 is -1 and rows 8..16 hold nnz[3 rc + cc][o]; h = (acc + nnz[class][o]) / 2 */
+int mn_qconv_bnsign_stash_chan_rows(const mn_conv_geom* g);
 int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* own, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W,
                     float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
 int mn_bnh_bwd_apply(const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int64_t N, int64_t C, int64_t H,

@@ -226,6 +226,28 @@ struct OpAddF { __device__ __forceinline__ float operator()(float a, float b) co
 struct OpMaxF { __device__ __forceinline__ float operator()(float a, float b) const { return (a != a || b != b) ? (a != a ? a : b) : fmaxf(a, b); } };
 struct OpMinF { __device__ __forceinline__ float operator()(float a, float b) const { return (a != a || b != b) ? (a != a ? a : b) : fminf(a, b); } };
 
+// Byte stash h = (acc + nnz) / 2 of a ternary-weight convolution on +-1 codes: acc has the parity of the number of non-zero weight codes
+// that meet a non-zero input.  For a pointwise block that is nnz[o] everywhere (chan row 7).  For a 3x3 / padding 1 block the taps
+// outside the image meet zeros, so the count depends on the pixel CLASS (top / middle / bottom row x left / middle / right column):
+// chan row 7 is then -1 and rows 8..16 hold nnz[class = 3 rc + cc][o].
+struct StashNnz { float v0, v1, v2, v3, v4, v5, v6, v7, v8; };
+__device__ __forceinline__ StashNnz stash_nnz_load(const float* __restrict__ chan, int C, int c) {
+    StashNnz z;
+    const float n7 = chan[7 * C + c];
+    const bool t = n7 < 0.f;
+    z.v0 = t ? chan[8 * C + c] : n7;  z.v1 = t ? chan[9 * C + c] : n7;  z.v2 = t ? chan[10 * C + c] : n7;
+    z.v3 = t ? chan[11 * C + c] : n7; z.v4 = t ? chan[12 * C + c] : n7; z.v5 = t ? chan[13 * C + c] : n7;
+    z.v6 = t ? chan[14 * C + c] : n7; z.v7 = t ? chan[15 * C + c] : n7; z.v8 = t ? chan[16 * C + c] : n7;
+    return z;
+}
+// nnz of the four pixels of quad col4 in row `row` of an H x (4 W4) plane
+__device__ __forceinline__ void stash_nnz_quad(const StashNnz& z, int row, int col4, int H, int W4, float (&nz)[4]) {
+    const float m0 = row == 0 ? z.v0 : (row == H - 1 ? z.v6 : z.v3);
+    const float m1 = row == 0 ? z.v1 : (row == H - 1 ? z.v7 : z.v4);
+    const float m2 = row == 0 ? z.v2 : (row == H - 1 ? z.v8 : z.v5);
+    nz[0] = col4 == 0 ? m0 : m1; nz[1] = m1; nz[2] = m1; nz[3] = col4 == W4 - 1 ? m2 : m1;
+}
+
 // logical -> physical channel through a channel shuffle with `sg` groups over C channels (identity when sg <= 1)
 struct ChanMap { int sg, cps; FastDiv fd_sg; };
 static inline ChanMap make_chanmap(int sg, int C) {

@@ -421,19 +421,22 @@ extern "C" int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float*
 struct BnhGeom { int N, C, H, W, HW, HW4; FastDiv fd_hw4, fd_w4; int64_t n4; };
 template <int POOL>
 __device__ __forceinline__ void bnh_load(const BnhGeom& g, int c, uint32_t i, const float* __restrict__ da, const unsigned char* __restrict__ h,
-                                         const char* __restrict__ own, float (&gv)[4], float (&acc)[4], float nnz, int64_t& off) {
+                                         const char* __restrict__ own, float (&gv)[4], float (&acc)[4], const StashNnz& nz9, int64_t& off) {
     const uint32_t n = fd_div(i, g.fd_hw4);
     const uint32_t q = i - n * (uint32_t)g.HW4;              // quad index inside the plane
     off = ((int64_t)n * g.C + c) * g.HW + (int64_t)q * 4;
     const uint32_t hb = *reinterpret_cast<const uint32_t*>(h + off);
-    acc[0] = 2.f * (float)(hb & 0xffu) - nnz; acc[1] = 2.f * (float)((hb >> 8) & 0xffu) - nnz;
-    acc[2] = 2.f * (float)((hb >> 16) & 0xffu) - nnz; acc[3] = 2.f * (float)(hb >> 24) - nnz;
+    const int W4 = g.W >> 2;
+    const uint32_t row = fd_div(q, g.fd_w4);
+    float nz[4];
+    stash_nnz_quad(nz9, (int)row, (int)(q - row * (uint32_t)W4), g.H, W4, nz);
+    acc[0] = 2.f * (float)(hb & 0xffu) - nz[0]; acc[1] = 2.f * (float)((hb >> 8) & 0xffu) - nz[1];
+    acc[2] = 2.f * (float)((hb >> 16) & 0xffu) - nz[2]; acc[3] = 2.f * (float)(hb >> 24) - nz[3];
     if (!POOL) {
         const float4 g4 = *reinterpret_cast<const float4*>(da + off);
         gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
     } else {
-        const int W4 = g.W >> 2;
-        const uint32_t row = fd_div(q, g.fd_w4), w = (q - row * (uint32_t)W4) * 4u;
+        const uint32_t w = (q - row * (uint32_t)W4) * 4u;
         const uint32_t hbit = row & 1u;
         const int64_t pb = ((int64_t)n * g.C + c) * (g.HW >> 2) + (int64_t)(row >> 1) * (g.W >> 1) + (w >> 1);
         const float2 g2 = *reinterpret_cast<const float2*>(da + pb);
@@ -455,7 +458,8 @@ __global__ __launch_bounds__(256) void k_bnh_partial(const BnhGeom g, const floa
                                                      const char* __restrict__ own, const float* __restrict__ chan, double* __restrict__ part) {
     __shared__ double scd[16];
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
-    const float fl = chan[C + c], L = chan[2 * C + c], U = chan[3 * C + c], A = chan[4 * C + c], B = chan[5 * C + c], nnz = chan[7 * C + c];
+    const float fl = chan[C + c], L = chan[2 * C + c], U = chan[3 * C + c], A = chan[4 * C + c], B = chan[5 * C + c];
+    const StashNnz nnz = stash_nnz_load(chan, C, c);
     double s1 = 0.0, s2 = 0.0;
     for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
         float gv[4], acc[4];
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(256) void k_bnh_apply(const BnhGeom g, const float*
                                                    const char* __restrict__ own, const float* __restrict__ chan, const float* __restrict__ sums,
                                                    int training, float* __restrict__ dy) {
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
-    const float fl = chan[C + c], L = chan[2 * C + c], U = chan[3 * C + c], A = chan[4 * C + c], B = chan[5 * C + c], gi = chan[6 * C + c], nnz = chan[7 * C + c];
+    const float fl = chan[C + c], L = chan[2 * C + c], U = chan[3 * C + c], A = chan[4 * C + c], B = chan[5 * C + c], gi = chan[6 * C + c];
+    const StashNnz nnz = stash_nnz_load(chan, C, c);
     float k1 = 0.f, k2 = 0.f;
     if (training) { const float n = (float)g.N * (float)g.HW; k1 = sums[c] / n; k2 = sums[C + c] / n; }
     for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {

@@ -10,6 +10,7 @@ typedef unsigned int u32x2 __attribute__((vector_size(8)));
 #define QG_EPI_SCALE_BIAS 0
 #define QG_EPI_PLAIN 1
 #define QG_EPI_STE 2
+#define QG_EPI_H8 3          // forward of a ternary-weight conv on sign codes: out8 = (acc + bias[o]) / 2 as one byte (bias = nnz[o]: the byte stash h)
 
 static inline int qg_roundup(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -64,6 +65,14 @@ int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
                 void* ws, int64_t ws_bytes, hipStream_t s);
 int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s);
+
+// k x k forward on sign codes that writes the byte stash h instead of y (qgemm_kxk.hip); info: what k_pws_final_fwd / k_pws_chan_prep need
+struct KkH8Info { const uint16_t* codes; const float* rowscale; int Mpad, Kp, K; };
+int kk_h8_supported(const mn_conv_geom* g, const mn_wq* wq);
+int64_t kk_h8_ws_bytes(const mn_conv_geom* g);
+int kk_h8_mpad(const mn_conv_geom* g);
+int kk_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* nnzf, uint8_t* h, void* ws, int64_t ws_bytes,
+              hipStream_t s, KkH8Info* info);
 
 // 3 x 3 backward-weight on sign codes (qgemm_k3s.hip)
 int k3s_wgrad_supported(const mn_conv_geom* g);

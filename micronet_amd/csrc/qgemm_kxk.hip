@@ -17,6 +17,7 @@
 struct KkParams {
     const float* in;          // x (fwd) / gy (bwd-data)   [N][G*Kc][Hin][Win]
     float* out;               // y / dx                     [N][G*Mr][Ho][Wo]
+    uint8_t* out8;            // QG_EPI_H8: the byte stash, same shape
     const uint16_t* wc;       // codes [G][Mpad][T][Cgp]
     const float* rowscale;    // [G][Mpad] or null
     const float* kscale;      // [G][Cgp]  or null (bwd-data: weight scale of the contraction channel)
@@ -270,6 +271,17 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
             if (m >= p.Mr) continue;
             const int64_t off = (((int64_t)n * p.Cout_total + chan_phys(p.out_map, g * p.Mr + m)) * p.Ho + oh0 + orow) * p.Wo + ocol;
             float o0 = acc[0][t][r], o1 = acc[1][t][r], o2 = acc[2][t][r], o3 = acc[3][t][r];
+            if (p.epi == QG_EPI_H8) {
+                // acc has the parity of the non-zero weights that meet a non-zero input: per pixel class at the image border (3x3, padding 1;
+                // p.bias = nnz9 [9][O], stash_nnz_quad in common.h): (acc + nnz) / 2 is an exact integer in [0, K]
+                const int ch = g * p.Mr + m, rowa = oh0 + orow;
+                const float* nb = p.bias + (rowa == 0 ? 0 : (rowa == p.Ho - 1 ? 6 : 3)) * (int64_t)p.Cout_total + ch;
+                const float m1 = nb[p.Cout_total];
+                const float b0 = ocol == 0 ? nb[0] : m1, b3 = ocol + 4 == p.Wo ? nb[2 * (int64_t)p.Cout_total] : m1;
+                *reinterpret_cast<uint32_t*>(p.out8 + off) = (uint32_t)((o0 + b0) * 0.5f) | ((uint32_t)((o1 + m1) * 0.5f) << 8) |
+                                                             ((uint32_t)((o2 + m1) * 0.5f) << 16) | ((uint32_t)((o3 + b3) * 0.5f) << 24);
+                continue;
+            }
             if (p.epi == QG_EPI_SCALE_BIAS) {
                 const float a_ = rs[ml], b_ = bs[ml];
                 o0 = o0 * a_ + b_; o1 = o1 * a_ + b_; o2 = o2 * a_ + b_; o3 = o3 * a_ + b_;
@@ -417,9 +429,36 @@ int kk_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const floa
     fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
     qg_launch_pack(pl.pk, pl.pack_grid, s);
     KkParams& p = pl.p;
-    p.in = x; p.out = y; p.wc = pl.pk.codes; p.rowscale = pl.pk.scale_out; p.kscale = nullptr; p.bias = bias; p.aux = nullptr;
+    p.in = x; p.out = y; p.out8 = nullptr; p.wc = pl.pk.codes; p.rowscale = pl.pk.scale_out; p.kscale = nullptr; p.bias = bias; p.aux = nullptr;
     p.pro = pro; p.ste = pro; p.epi = QG_EPI_SCALE_BIAS; p.ascale = pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f;
     return run_kk(pl, s, "mn_conv2d_fwd(qgemm kxk)");
+}
+int kk_h8_supported(const mn_conv_geom* g, const mn_wq* wq) {
+    KkPlan pl;
+    if (!g || !wq || wq->mode != MN_WQ_TERNARY || !plan_kk(g, 0, MN_ACTQ_SIGN8, &pl)) return 0;
+    if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1 || g->dil_h != 1 || g->dil_w != 1) return 0;
+    return (g->C / g->groups) * 9 <= 254 && g->H >= 2 && g->W % 4 == 0;
+}
+int64_t kk_h8_ws_bytes(const mn_conv_geom* g) { KkPlan pl; return plan_kk(g, 0, MN_ACTQ_SIGN8, &pl) ? pl.ws_bytes : 0; }
+int kk_h8_mpad(const mn_conv_geom* g) { KkPlan pl; return plan_kk(g, 0, MN_ACTQ_SIGN8, &pl) ? pl.pk.Mpad : 0; }
+int kk_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* nnzf, uint8_t* h, void* ws, int64_t ws_bytes,
+              hipStream_t s, KkH8Info* info) {
+    KkPlan pl;
+    if (!kk_h8_supported(g, wq) || !plan_kk(g, 0, MN_ACTQ_SIGN8, &pl) || (((uintptr_t)x) & 3) || (((uintptr_t)h) & 3))
+        MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd_stash(k x k): geometry / quantizer combination not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_qconv_bnsign_fwd_stash(k x k): workspace too small");
+    mn_actq aq; aq.mode = MN_ACTQ_SIGN8; aq.bits = 8; aq.q_type = 0; aq.flags = 0; aq.qp = nullptr;
+    Pro pro;
+    int rc = make_pro(&aq, &pro, 0, "mn_qconv_bnsign_fwd_stash(k x k)");
+    if (rc) return rc;
+    fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
+    qg_launch_pack(pl.pk, pl.pack_grid, s);
+    KkParams& p = pl.p;
+    p.in = reinterpret_cast<const float*>(x); p.out = nullptr; p.out8 = h; p.wc = pl.pk.codes; p.rowscale = pl.pk.scale_out; p.kscale = nullptr;
+    p.bias = nnzf; p.aux = nullptr; p.pro = pro; p.ste = pro; p.epi = QG_EPI_H8; p.ascale = 1.f;
+    info->codes = pl.pk.codes; info->rowscale = pl.pk.scale_out; info->Mpad = pl.pk.Mpad; info->Kp = p.T * p.Cgp; info->K = p.T * p.Kc;
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.Ho * p.Wo; mn_prof_bytes(nx + ny); }
+    return run_kk(pl, s, "mn_qconv_bnsign_fwd_stash(k x k)");
 }
 int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
                 void* ws, int64_t ws_bytes, hipStream_t s) {
@@ -436,7 +475,7 @@ int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     qg_launch_pack(pl.pk, pl.pack_grid, s);
     Pro none; none.mode = MN_ACTQ_NONE; none.s = 1.f; none.qmin = none.qmax = 0.f; none.qp = nullptr;
     KkParams& p = pl.p;
-    p.in = gy; p.out = dx; p.wc = pl.pk.codes; p.rowscale = nullptr; p.kscale = pl.pk.scale_out; p.bias = nullptr; p.aux = x;
+    p.in = gy; p.out = dx; p.out8 = nullptr; p.wc = pl.pk.codes; p.rowscale = nullptr; p.kscale = pl.pk.scale_out; p.bias = nullptr; p.aux = x;
     p.pro = none; p.ste = ste; p.epi = ste.mode == MN_ACTQ_NONE ? QG_EPI_PLAIN : QG_EPI_STE; p.ascale = 1.f;
     return run_kk(pl, s, "mn_conv2d_bwd_data(qgemm kxk)");
 }

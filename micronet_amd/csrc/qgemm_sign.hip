@@ -1030,11 +1030,196 @@ extern "C" int mn_qconv_bnsign_fwd(const mn_conv_geom* g, const mn_wq* wq, const
                                    float* save, int8_t* a, void* ws, int64_t ws_bytes, mn_stream_t stream) {
     return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, nullptr, nullptr, ws, ws_bytes, stream);
 }
+static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                      const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                      float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, hipStream_t s);
 extern "C" int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
                                          const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
                                          float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream) {
     if (!h || !chan || (((uintptr_t)h) & 3)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd_stash: null / misaligned stash");
+    if (g && wq && !pws_bn_ok(g, wq) && kk_h8_supported(g, wq))          // a k x k convolution: stash written by the conv kernel, statistics / sign streamed from it
+        return qconv_kxk_bnsign_fwd_stash(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, h, chan, ws, ws_bytes,
+                                          (hipStream_t)stream);
     return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, h, chan, ws, ws_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The stashed block around a k x k convolution (nin_gc's grouped 3x3 layers): the code-domain k x k kernel writes the byte stash
+// h = (acc + nnz[o]) / 2 instead of y (QG_EPI_H8, qgemm_kxk.hip); batch statistics and the sign are then two streaming passes over
+// ONE byte per element -- k_h_stats (exact integer sums of acc and acc^2, partials in the layout k_pws_final_fwd reads) and k_h_sign
+// (the integer threshold test of k_pws_chan_prep) -- and the backward is the same mn_bnh_bwd_sums / mn_bnh_bwd_apply as for the
+// pointwise blocks.  fp32 y is never written or read: 1 + 1 + 2 bytes per element instead of 4 + 4 + 5.
+// nnz9[3 rc + cc][o]: non-zero weights of row o among the taps that lie inside the image for a pixel of row class rc (0 top: r >= 1,
+// 1 middle, 2 bottom: r <= 1) and column class cc (same with s) -- 3 x 3, padding 1.  One wave per output channel.
+__global__ __launch_bounds__(64) void k_row_nnz9(const float* __restrict__ w, int Cg, int O, float* __restrict__ nnz9) {
+    const int o = blockIdx.x, lane = threadIdx.x;
+    int cnt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cnt[k] = 0;
+    for (int k = lane; k < Cg * 9; k += 64) {
+        const int tap = k % 9, r = tap / 3, s_ = tap - 3 * r;
+        const int nzv = w[(int64_t)o * Cg * 9 + k] != 0.f;
+#pragma unroll
+        for (int rc = 0; rc < 3; ++rc)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const bool in = (rc != 0 || r >= 1) && (rc != 2 || r <= 1) && (cc != 0 || s_ >= 1) && (cc != 2 || s_ <= 1);
+                cnt[rc * 3 + cc] += (in && nzv) ? 1 : 0;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        int c = cnt[k];
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) c += __shfl_xor(c, sft, 64);
+        if (lane == 0) nnz9[(int64_t)k * O + o] = (float)c;
+    }
+}
+// chan row 7 = -1: "the nnz of this block is per pixel class, rows 8..16" (stash_nnz_load, common.h)
+__global__ void k_chan_mark_classes(float* __restrict__ chan, const float* __restrict__ nnz9, int O) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= O) return;
+    chan[7 * O + o] = -1.f;
+    for (int k = 0; k < 9; ++k) chan[(8 + k) * O + o] = nnz9[k * O + o];
+}
+struct HGeom { int C, H, W4, HW, HW4, Mr, Mpad, G; FastDiv fd_hw4, fd_w4, fd_hwv; int64_t n4; };     // fd_hwv: HW4 / VEC of the launch
+// VEC quads (4 VEC bytes) per thread and iteration: one b32 / b128 load
+template <int VEC>
+__global__ __launch_bounds__(256) void k_h_stats(const HGeom g, const unsigned char* __restrict__ h, const float* __restrict__ nnz9, double* __restrict__ part) {
+    __shared__ double scd[16];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    StashNnz z;
+    z.v0 = nnz9[c]; z.v1 = nnz9[g.C + c]; z.v2 = nnz9[2 * g.C + c]; z.v3 = nnz9[3 * g.C + c]; z.v4 = nnz9[4 * g.C + c];
+    z.v5 = nnz9[5 * g.C + c]; z.v6 = nnz9[6 * g.C + c]; z.v7 = nnz9[7 * g.C + c]; z.v8 = nnz9[8 * g.C + c];
+    long long s1 = 0, s2 = 0;
+    const int64_t nv = g.n4 / VEC;
+    const uint32_t hwv = (uint32_t)(g.HW4 / VEC);
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < nv; i += (int64_t)S * 256) {
+        const uint32_t n = fd_div((uint32_t)i, g.fd_hwv);
+        const uint32_t q0 = ((uint32_t)i - n * hwv) * VEC;
+        const unsigned char* src = h + ((int64_t)n * g.C + c) * g.HW + (int64_t)q0 * 4;
+        uint32_t hb[VEC];
+        if (VEC == 4) { const u32x4 v = *reinterpret_cast<const u32x4*>(src); hb[0] = v[0]; hb[VEC > 1 ? 1 : 0] = v[1]; hb[VEC > 2 ? 2 : 0] = v[2]; hb[VEC > 3 ? 3 : 0] = v[3]; }
+        else hb[0] = *reinterpret_cast<const uint32_t*>(src);
+        int t1 = 0, t2 = 0;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const uint32_t q = q0 + k, row = fd_div(q, g.fd_w4);
+            float nz[4];
+            stash_nnz_quad(z, (int)row, (int)(q - row * (uint32_t)g.W4), g.H, g.W4, nz);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = 2 * (int)((hb[k] >> (8 * e)) & 0xffu) - (int)nz[e];
+                t1 += a; t2 += a * a;
+            }
+        }
+        s1 += t1; s2 += t2;
+    }
+    const double d1 = block_reduce((double)s1, OpAddD(), 0.0, scd);
+    const double d2 = block_reduce((double)s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) {
+        const int gi = c / g.Mr, m = c - gi * g.Mr;
+        double* dst = part + ((int64_t)sp * g.G * g.Mpad + gi * g.Mpad + m) * 2;
+        dst[0] = d1; dst[1] = d2;
+    }
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void k_h_sign(const HGeom g, const unsigned char* __restrict__ h, const float* __restrict__ chan, char* __restrict__ a) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
+    const float T = chan[c], fl = chan[C + c];
+    const StashNnz z = stash_nnz_load(chan, C, c);
+    const int64_t nv = g.n4 / VEC;
+    const uint32_t hwv = (uint32_t)(g.HW4 / VEC);
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < nv; i += (int64_t)S * 256) {
+        const uint32_t n = fd_div((uint32_t)i, g.fd_hwv);
+        const uint32_t q0 = ((uint32_t)i - n * hwv) * VEC;
+        const int64_t off = ((int64_t)n * g.C + c) * g.HW + (int64_t)q0 * 4;
+        uint32_t hb[VEC], out[VEC];
+        if (VEC == 4) { const u32x4 v = *reinterpret_cast<const u32x4*>(h + off); hb[0] = v[0]; hb[VEC > 1 ? 1 : 0] = v[1]; hb[VEC > 2 ? 2 : 0] = v[2]; hb[VEC > 3 ? 3 : 0] = v[3]; }
+        else hb[0] = *reinterpret_cast<const uint32_t*>(h + off);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const uint32_t q = q0 + k, row = fd_div(q, g.fd_w4);
+            float nz[4];
+            stash_nnz_quad(z, (int)row, (int)(q - row * (uint32_t)g.W4), g.H, g.W4, nz);
+            uint32_t o = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = (2.f * (float)((hb[k] >> (8 * e)) & 0xffu) - nz[e]) * fl;
+                o |= (u >= T ? 0x01u : 0xffu) << (8 * e);
+            }
+            out[k] = o;
+        }
+        if (VEC == 4) *reinterpret_cast<u32x4*>(a + off) = u32x4{out[0], out[VEC > 1 ? 1 : 0], out[VEC > 2 ? 2 : 0], out[VEC > 3 ? 3 : 0]};
+        else *reinterpret_cast<uint32_t*>(a + off) = out[0];
+    }
+}
+static int h_splits(int C) { int S = 2048 / (C > 0 ? C : 1); return S < 1 ? 1 : (S > 64 ? 64 : S); }
+static int kxk_out(int in, int k, int s_, int pd, int d) { return (in + 2 * pd - d * (k - 1) - 1) / s_ + 1; }
+static int64_t kxk_stash_ws(const mn_conv_geom* g, int64_t* off_nnz, int64_t* off_part) {
+    const int64_t a = (kk_h8_ws_bytes(g) + 255) / 256 * 256;
+    const int64_t b = ((int64_t)g->O * 9 * 4 + 255) / 256 * 256;
+    if (off_nnz) *off_nnz = a;
+    if (off_part) *off_part = a + b;
+    return a + b + (int64_t)h_splits(g->O) * g->groups * kk_h8_mpad(g) * 2 * 8;
+}
+static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                      const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                      float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, hipStream_t s) {
+    if (!gamma || !beta || !save || !a || (((uintptr_t)a) & 3) || !x || !w) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd_stash(k x k): null / misaligned argument");
+    if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd_stash(k x k): eval mode needs the running statistics");
+    int64_t off_nnz, off_part;
+    const int64_t need = kxk_stash_ws(g, &off_nnz, &off_part);
+    if (!ws || ws_bytes < need || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_qconv_bnsign_fwd_stash(k x k): workspace too small");
+    float* nnzf = (float*)((char*)ws + off_nnz);
+    double* part = (double*)((char*)ws + off_part);
+    const int Cg = g->C / g->groups, Mg = g->O / g->groups, S = h_splits(g->O);
+    const int Ho = kxk_out(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = kxk_out(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+    hipLaunchKernelGGL(k_row_nnz9, dim3((unsigned)g->O), dim3(64), 0, s, w, Cg, (int)g->O, nnzf);
+    KkH8Info info;
+    int rc = kk_fwd_h8(g, wq, x, w, nnzf, h, ws, off_nnz, s, &info);
+    if (rc) return rc;
+    HGeom hg;
+    hg.C = g->O; hg.H = Ho; hg.W4 = Wo / 4; hg.HW = Ho * Wo; hg.HW4 = hg.HW / 4; hg.Mr = Mg; hg.Mpad = info.Mpad; hg.G = g->groups;
+    hg.fd_hw4 = make_fastdiv((uint32_t)hg.HW4); hg.fd_w4 = make_fastdiv((uint32_t)hg.W4); hg.n4 = (int64_t)g->N * hg.HW4;
+    const double ny = (double)g->N * g->O * hg.HW;
+    const bool vec4 = hg.HW % 16 == 0 && !(((uintptr_t)h) & 15) && !(((uintptr_t)a) & 15);      // 16 codes per load
+    hg.fd_hwv = make_fastdiv((uint32_t)(vec4 ? hg.HW4 / 4 : hg.HW4));
+    if (training) {
+        mn_set_last_kernel("k_h_stats");
+        mn_prof_bytes(ny);
+        mn_prof_begin(s);
+        if (vec4) hipLaunchKernelGGL(k_h_stats<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, (const float*)nnzf, part);
+        else hipLaunchKernelGGL(k_h_stats<1>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, (const float*)nnzf, part);
+        mn_prof_end(s);
+        hipLaunchKernelGGL(k_pws_final_fwd, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)part, S, (int)g->groups, info.Mpad, Mg, info.rowscale, bias,
+                           (double)g->N * hg.HW, eps, momentum, running_mean, running_var, save, (int)g->O);
+    } else {
+        hipLaunchKernelGGL(k_pws_eval_stats, dim3((unsigned)((g->O + 63) / 64)), dim3(64), 0, s, (int)g->O, eps, (const float*)running_mean,
+                           (const float*)running_var, save);
+    }
+    hipLaunchKernelGGL(k_pws_chan_prep, dim3((unsigned)g->O), dim3(64), 0, s, info.K, info.Kp, info.codes, (int)g->groups, info.Mpad, Mg, info.rowscale, bias,
+                       (const float*)save, gamma, beta, chan, (int)g->O);
+    hipLaunchKernelGGL(k_chan_mark_classes, dim3((unsigned)((g->O + 63) / 64)), dim3(64), 0, s, chan, (const float*)nnzf, (int)g->O);
+    mn_set_last_kernel("k_h_sign");
+    mn_prof_bytes(2.0 * ny);
+    mn_prof_begin(s);
+    if (vec4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, (const float*)chan, (char*)a);
+    else hipLaunchKernelGGL(k_h_sign<1>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, (const float*)chan, (char*)a);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qconv_bnsign_fwd_stash(k x k)");
+    return MN_OK;
+}
+extern "C" int mn_qconv_bnsign_stash_supported(const mn_conv_geom* g, const mn_wq* wq) {
+    if (!g || !wq) return 0;
+    return pws_bn_ok(g, wq) || (!getenv("MN_NO_KXK_STASH") && kk_h8_supported(g, wq));
+}
+/* rows of the caller-owned per-channel table `chan` the stash forward fills: 8, or 17 for a 3x3 block (per-pixel-class nnz) */
+extern "C" int mn_qconv_bnsign_stash_chan_rows(const mn_conv_geom* g) { return (g && g->KH == 1 && g->KW == 1) ? 8 : 17; }
+extern "C" int64_t mn_qconv_bnsign_stash_ws_bytes(const mn_conv_geom* g) {
+    if (!g) return -1;
+    const int64_t a = pws_ws_bytes(g);
+    return a > 0 ? a : kxk_stash_ws(g, nullptr, nullptr);
 }
 
 static int bnsign_bwd_impl(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,

@@ -580,7 +580,7 @@ def qconv_bnsign_supported(x, wq, stride, padding, dilation, groups, wdesc, in_s
     if not isinstance(x, SignTensor) or wdesc is None or CONV_ALGO != _lib.MN_ALGO_AUTO:
         return False
     g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle or 0)
-    return bool(_lib_().mn_qconv_bnsign_supported(C.byref(g), _ref(_wq_desc(wdesc))))
+    return bool(_lib_().mn_qconv_bnsign_stash_supported(C.byref(g), _ref(_wq_desc(wdesc))))
 
 
 import os as _os
@@ -604,10 +604,10 @@ class ConvBNSign(Function):
         a = torch.empty(y.shape, dtype=torch.int8, device=codes.device)
         h = torch.empty(y.shape, dtype=torch.uint8, device=codes.device)
         save = torch.empty((2, g.O), dtype=torch.float32, device=codes.device)
-        chan = torch.empty((8, g.O), dtype=torch.float32, device=codes.device)
+        chan = torch.empty((int(_lib_().mn_qconv_bnsign_stash_chan_rows(C.byref(g))), g.O), dtype=torch.float32, device=codes.device)
         wd = _wq_desc(wdesc)
         with torch.cuda.device_of(codes):
-            nb = int(_lib_().mn_qconv_bnsign_ws_bytes(C.byref(g)))
+            nb = int(_lib_().mn_qconv_bnsign_stash_ws_bytes(C.byref(g)))
             ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
             _call("mn_qconv_bnsign_fwd_stash", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), float(eps), float(momentum),
                   int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(h), _p(chan), _p(ws), nb, _s())

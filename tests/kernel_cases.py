@@ -423,7 +423,7 @@ def check_pool_sign8(be, shape=(3, 5, 8, 16), seed=0):
     assert np.array_equal(be.to_host(din), t.grad.numpy())
 
 
-def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, pooled=False, stash=False, **_):
+def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, pooled=False, stash=False, padding=0, **_):
     """mn_qconv_bnsign_fwd/bwd (conv + BatchNorm + sign on packed codes; y never stored) vs an fp64 numpy evaluation of the
     same block on the same +-1 input and ternary-coded weights."""
     r = np.random.default_rng(seed)
@@ -440,7 +440,7 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
     x_log = a_in.astype(F)
     if in_shuffle > 1:
         x_log = np.ascontiguousarray(x_log.reshape(N, in_shuffle, Cin // in_shuffle, H, W).transpose(0, 2, 1, 3, 4).reshape(x_shape))
-    y64 = O.conv2d_fwd(x_log, w, b, groups=groups).astype(np.float64)      # exact: integer sums times alpha (+ bias), rounded once to fp32
+    y64 = O.conv2d_fwd(x_log, w, b, padding=padding, groups=groups).astype(np.float64)      # exact: integer sums times alpha (+ bias), rounded once to fp32
     n = N * HW
     if training:
         mean = y64.mean(axis=(0, 2, 3)); var_b = y64.var(axis=(0, 2, 3)); var_u = var_b * n / (n - 1)
@@ -455,21 +455,27 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
     gi = (gamma * invstd).reshape(1, -1, 1, 1)
     dy_ref = gi * (dz - dbeta_ref.reshape(1, -1, 1, 1) / n - zh * dgamma_ref.reshape(1, -1, 1, 1) / n) if training else gi * dz
 
-    g = be.geom(x_shape, w_shape, groups=groups)
+    g = be.geom(x_shape, w_shape, padding=padding, groups=groups)
     g.in_shuffle = in_shuffle
     wq = be.wq(**wkw)
-    assert be.lib.mn_qconv_bnsign_supported(C.byref(g), C.byref(wq)) == 1
-    nb = int(be.lib.mn_qconv_bnsign_ws_bytes(C.byref(g)))
+    if stash:       # the stash forward also covers k x k convolutions (same-size output: stride 1, padding = (k - 1) / 2)
+        assert be.lib.mn_qconv_bnsign_stash_supported(C.byref(g), C.byref(wq)) == 1
+        nb = max(int(be.lib.mn_qconv_bnsign_stash_ws_bytes(C.byref(g))), 4 * int(be.lib.mn_bnsign_ws_floats(Oc)))
+    else:
+        assert be.lib.mn_qconv_bnsign_supported(C.byref(g), C.byref(wq)) == 1
+        nb = int(be.lib.mn_qconv_bnsign_ws_bytes(C.byref(g)))
     ws = be.empty(nb // 4 + 8)
     dA, dW, dB = be.to_dev_i8(a_in), be.to_dev(w), (be.to_dev(b) if bias else None)
     dG, dBe, dRM, dRV, dDA = be.to_dev(gamma), be.to_dev(beta), be.to_dev(rm), be.to_dev(rv), be.to_dev(da)
     save, a8 = be.empty((2, Oc)), be.empty_i8((N, Oc, H, W))
     if stash:      # forward that also stashes the integer conv result in one byte per element + the per-channel constants
-        h8, chan = be.empty_i8((N, Oc, H, W)), be.empty((8, Oc))
+        h8, chan = be.empty_i8((N, Oc, H, W)), be.empty((int(be.lib.mn_qconv_bnsign_stash_chan_rows(C.byref(g))), Oc))
         be.call("mn_qconv_bnsign_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
                 be.ptr(dRM), be.ptr(dRV), be.ptr(save), be.ptr(a8), be.ptr(h8), be.ptr(chan), be.ptr(ws), nb, be.stream)
-        acc_ref = O.conv2d_fwd(x_log, np.sign(w).astype(F), None, groups=groups)
-        nnz = (w != 0).reshape(Oc, -1).sum(axis=1).reshape(1, -1, 1, 1)
+        acc_ref = O.conv2d_fwd(x_log, np.sign(w).astype(F), None, padding=padding, groups=groups)
+        # nnz per pixel: the non-zero weights that meet a non-zero input (= all of them, except at the zero-padded border of a 3x3 block)
+        nnz = O.conv2d_fwd(np.ones_like(x_log), (w != 0).astype(F), None, padding=padding, groups=groups)
+        assert np.array_equal((acc_ref + nnz) % 2, np.zeros_like(acc_ref))
         assert np.array_equal(be.to_host(h8).view(np.uint8).astype(np.int64), ((acc_ref + nnz) / 2).astype(np.int64))
     else:
         be.call("mn_qconv_bnsign_fwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),

@@ -265,7 +265,14 @@ def test_wbwtab_folded_channel_shuffle_is_bit_identical():
     ya.square().mean().backward()
     yb.square().mean().backward()
     for (n_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        if n_.startswith(("1.", "2.")):        # our kernels: deterministic, bit-identical
+        if n_.startswith("2.conv"):
+            # the folded net hands the 3x3 conv packed codes (k_k3s_wgrad), the other one the float tensor torch's shuffle made
+            # (k_kk_wgrad): same exact products, different summation order
+            if n_.endswith("bias"):            # d bias in front of a BatchNorm is a sum that cancels to ~0: absolute tolerance
+                assert (pa.grad - pb.grad).abs().max().item() <= 1e-4 * a[2].conv.weight.grad.abs().max().item(), n_
+            else:
+                assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 1e-5, n_
+        elif n_.startswith(("1.", "2.")):      # our kernels: deterministic, bit-identical
             assert torch.equal(pa.grad, pb.grad), n_
         else:                                  # plain nn.Conv2d layers run MIOpen's (atomic) backward-weight: equal to rounding
             assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 1e-5, n_
@@ -306,6 +313,10 @@ def test_wbwtab_packed_activations_are_bit_identical():
     for (n_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         if n_.startswith(("0.conv", "7.conv")):    # plain nn.Conv2d layers run MIOpen's (atomic) backward-weight: equal to rounding
             assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 1e-5, n_
+        elif n_ == "4.conv.weight":                # 3x3 on packed codes: k_k3s_wgrad; on the float hand-off: k_kk_wgrad -- same products, other order
+            assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 1e-5, n_
+        elif n_ == "4.conv.bias":                  # a sum that cancels to ~0 in front of a BatchNorm: absolute tolerance
+            assert (pa.grad - pb.grad).abs().max().item() <= 1e-4 * a[4].conv.weight.grad.abs().max().item(), n_
         else:
             assert torch.equal(pa.grad, pb.grad), n_
     for (n_, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):

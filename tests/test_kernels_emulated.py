@@ -237,3 +237,17 @@ def test_conv_backward_with_bn_folded_in(be):
     K.check_qconv_bnsign(be, seed=250, stash=True, x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2)
     K.check_qconv_bnsign(be, seed=251, stash=True, x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2, bias=False)
     K.check_qconv_bnsign(be, seed=252, stash=True, training=False, x_shape=(2, 80, 4, 4), w_shape=(100, 40, 1, 1), groups=2)
+
+
+# stashed block around a 3 x 3 convolution: h written by the k x k kernel, statistics / sign streamed from h (k_h_stats, k_h_sign)
+KXK_STASH_CASES = [
+    dict(x_shape=(3, 32, 8, 8), w_shape=(64, 16, 3, 3), padding=1, groups=2),                    # the nin_gc L7 pattern
+    dict(x_shape=(2, 32, 16, 16), w_shape=(64, 16, 3, 3), padding=1, groups=2, in_shuffle=2, bias=False),
+    dict(x_shape=(2, 6, 16, 16), w_shape=(40, 6, 3, 3), padding=1),
+]
+
+
+@pytest.mark.parametrize("case", range(len(KXK_STASH_CASES)))
+@pytest.mark.parametrize("training", [True, False])
+def test_qconv_kxk_bnsign_stash(be, case, training):
+    K.check_qconv_bnsign(be, seed=260 + case, stash=True, training=training, **KXK_STASH_CASES[case])
