@@ -200,7 +200,7 @@ static inline FastDiv make_fastdiv(uint32_t d) {
     f.m = (d <= 1) ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d);
     return f;
 }
-__device__ __forceinline__ uint32_t fd_div(uint32_t n, FastDiv f) { return f.d <= 1 ? n : __umulhi(n, f.m); }
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, FastDiv f) { const uint32_t q = __umulhi(n, f.m); return f.d <= 1 ? n : q; }     // select, not a branch
 
 // ---------------------------------------------------------------- wave / block reductions (wave = 64 lanes)
 template <typename T, typename Op>

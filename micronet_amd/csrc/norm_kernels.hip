@@ -12,6 +12,17 @@
 // float4 per lane, every lane busy whatever HW is.
 #include "common.h"
 
+// streaming loops: iterations are independent; MN_STREAM_2 handles two quads per trip -- both sets of loads are issued before the
+// first is consumed (twice the bytes in flight per thread; same per-thread accumulation order)
+#define MN_STREAM_2(i_, start_, stride_, n_, LOAD, FIN)                                  \
+    {                                                                                    \
+        int64_t i_ = (start_);                                                           \
+        for (; i_ + (stride_) < (n_); i_ += 2 * (stride_)) {                             \
+            LOAD(0, i_) LOAD(1, i_ + (stride_)) FIN(0) FIN(1)                            \
+        }                                                                                \
+        if (i_ < (n_)) { LOAD(0, i_) FIN(0) }                                            \
+    }
+
 #define BNS_SPLIT 32
 
 struct BnsGeom {
@@ -43,29 +54,31 @@ __global__ __launch_bounds__(256) void k_bns_partial(const BnsGeom g, const floa
     if (MODE == 0) pivot = y[(int64_t)c * g.HW];
     else { mean = save[c]; invstd = save[g.C + c]; ga = gamma[c]; be = beta[c]; }
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
-        const int64_t off = bns_off(g, c, (uint32_t)i);
-        const float4 v = *reinterpret_cast<const float4*>(y + off);
-        if (MODE == 0) {
-            const float a = v.x - pivot, b = v.y - pivot, cc = v.z - pivot, d = v.w - pivot;
-            s1 += (double)((a + b) + (cc + d));
-            s2 += (double)((a * a + b * b) + (cc * cc + d * d));
-        } else {
-            const float4 gg = *reinterpret_cast<const float4*>(da + off);
-            const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};
-            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float z = zh[e] * ga + be;
-                const float dz = (z > -1.f && z < 1.f) ? gv[e] : 0.f;       // BinaryActivation.backward: zero where |z| >= 1
-                t1 += dz;
-                t2 += dz * zh[e];
-            }
-            s1 += (double)t1;
-            s2 += (double)t2;
-        }
-    }
+    float4 v_[2], gg_[2];
+#define BNSP_LOAD(k, idx) { const int64_t off = bns_off(g, c, (uint32_t)(idx)); v_[k] = *reinterpret_cast<const float4*>(y + off); \
+                            if (MODE == 1) gg_[k] = *reinterpret_cast<const float4*>(da + off); }
+#define BNSP_FIN(k) { const float4 v = v_[k];                                                                                         \
+        if (MODE == 0) {                                                                                                              \
+            const float a = v.x - pivot, b = v.y - pivot, cc = v.z - pivot, d = v.w - pivot;                                          \
+            s1 += (double)((a + b) + (cc + d));                                                                                       \
+            s2 += (double)((a * a + b * b) + (cc * cc + d * d));                                                                      \
+        } else {                                                                                                                      \
+            const float4 gg = gg_[k];                                                                                                 \
+            const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};         \
+            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};                                                                             \
+            float t1 = 0.f, t2 = 0.f;                                                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                           \
+                const float z = zh[e] * ga + be;                                                                                      \
+                const float dz = (z > -1.f && z < 1.f) ? gv[e] : 0.f;       /* BinaryActivation.backward: zero where |z| >= 1 */      \
+                t1 += dz;                                                                                                             \
+                t2 += dz * zh[e];                                                                                                     \
+            }                                                                                                                         \
+            s1 += (double)t1;                                                                                                         \
+            s2 += (double)t2;                                                                                                         \
+        } }
+    MN_STREAM_2(i, (int64_t)sp * 256 + threadIdx.x, (int64_t)S * 256, g.n4, BNSP_LOAD, BNSP_FIN)
+#undef BNSP_LOAD
+#undef BNSP_FIN
     s1 = block_reduce(s1, OpAddD(), 0.0, scd);
     s2 = block_reduce(s2, OpAddD(), 0.0, scd);
     if (threadIdx.x == 0) { part[((int64_t)c * S + sp) * 2] = s1; part[((int64_t)c * S + sp) * 2 + 1] = s2; }
@@ -118,32 +131,34 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
         k1 = sums[c] / n; k2 = sums[g.C + c] / n;
     }
     const float gi = ga * invstd;
-    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
-        const int64_t off = bns_off(g, c, (uint32_t)i);
-        const float4 v = *reinterpret_cast<const float4*>(y + off);
-        const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};
-        float r[4];
-        if (MODE == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = bns_sign(zh[e] * ga + be);
-        } else {
-            const float4 gg = *reinterpret_cast<const float4*>(da + off);
-            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float z = zh[e] * ga + be;
-                const float dz = (z > -1.f && z < 1.f) ? gv[e] : 0.f;
-                r[e] = gi * (dz - k1 - zh[e] * k2);
-            }
-        }
-        if (OUT8) {
-            const uint32_t u = (r[0] < 0.f ? 0xFFu : 0x01u) | (r[1] < 0.f ? 0xFF00u : 0x0100u) | (r[2] < 0.f ? 0xFF0000u : 0x010000u) |
-                               (r[3] < 0.f ? 0xFF000000u : 0x01000000u);
-            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + off) = u;
-        } else {
-            *reinterpret_cast<float4*>(out + off) = make_float4(r[0], r[1], r[2], r[3]);
-        }
-    }
+    float4 v_[2], gg_[2];
+    int64_t off_[2];
+#define BNSA_LOAD(k, idx) { off_[k] = bns_off(g, c, (uint32_t)(idx)); v_[k] = *reinterpret_cast<const float4*>(y + off_[k]); \
+                            if (MODE == 1) gg_[k] = *reinterpret_cast<const float4*>(da + off_[k]); }
+#define BNSA_FIN(k) { const float4 v = v_[k]; const int64_t off = off_[k];                                                            \
+        const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};             \
+        float r[4];                                                                                                                   \
+        if (MODE == 0) {                                                                                                              \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) r[e] = bns_sign(zh[e] * ga + be);                                           \
+        } else {                                                                                                                      \
+            const float4 gg = gg_[k];                                                                                                 \
+            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                           \
+                const float z = zh[e] * ga + be;                                                                                      \
+                const float dz = (z > -1.f && z < 1.f) ? gv[e] : 0.f;                                                                 \
+                r[e] = gi * (dz - k1 - zh[e] * k2);                                                                                   \
+            }                                                                                                                         \
+        }                                                                                                                             \
+        if (OUT8) {                                                                                                                   \
+            const uint32_t u = (r[0] < 0.f ? 0xFFu : 0x01u) | (r[1] < 0.f ? 0xFF00u : 0x0100u) | (r[2] < 0.f ? 0xFF0000u : 0x010000u) | \
+                               (r[3] < 0.f ? 0xFF000000u : 0x01000000u);                                                              \
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + off) = u;                                                     \
+        } else {                                                                                                                      \
+            *reinterpret_cast<float4*>(out + off) = make_float4(r[0], r[1], r[2], r[3]);                                              \
+        } }
+    MN_STREAM_2(i, (int64_t)sp * 256 + threadIdx.x, (int64_t)S * 256, g.n4, BNSA_LOAD, BNSA_FIN)
+#undef BNSA_LOAD
+#undef BNSA_FIN
 }
 
 // ---------------------------------------------------------------- 2x2 / stride-2 max-pool on int8 sign codes
@@ -461,20 +476,20 @@ __global__ __launch_bounds__(256) void k_bnh_partial(const BnhGeom g, const floa
     const float fl = chan[C + c], L = chan[2 * C + c], U = chan[3 * C + c], A = chan[4 * C + c], B = chan[5 * C + c];
     const StashNnz nnz = stash_nnz_load(chan, C, c);
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
-        float gv[4], acc[4];
-        int64_t off;
-        bnh_load<POOL>(g, c, (uint32_t)i, da, h, own, gv, acc, nnz, off);
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float u = acc[e] * fl;
-            const float dz = (u >= L && u <= U) ? gv[e] : 0.f;
-            t1 += dz;
-            t2 += dz * fmaf(acc[e], A, B);
-        }
-        s1 += (double)t1; s2 += (double)t2;
-    }
+    float gv_[2][4], acc_[2][4];
+    int64_t off_[2];
+#define BNHP_LOAD(k, idx) bnh_load<POOL>(g, c, (uint32_t)(idx), da, h, own, gv_[k], acc_[k], nnz, off_[k]);
+#define BNHP_FIN(k) { float t1 = 0.f, t2 = 0.f;                                              \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
+            const float u = acc_[k][e] * fl;                                                 \
+            const float dz = (u >= L && u <= U) ? gv_[k][e] : 0.f;                           \
+            t1 += dz;                                                                        \
+            t2 += dz * fmaf(acc_[k][e], A, B);                                               \
+        }                                                                                    \
+        s1 += (double)t1; s2 += (double)t2; }
+    MN_STREAM_2(i, (int64_t)sp * 256 + threadIdx.x, (int64_t)S * 256, g.n4, BNHP_LOAD, BNHP_FIN)
+#undef BNHP_LOAD
+#undef BNHP_FIN
     s1 = block_reduce(s1, OpAddD(), 0.0, scd);
     s2 = block_reduce(s2, OpAddD(), 0.0, scd);
     if (threadIdx.x == 0) { part[((int64_t)c * S + sp) * 2] = s1; part[((int64_t)c * S + sp) * 2 + 1] = s2; }
@@ -488,18 +503,19 @@ __global__ __launch_bounds__(256) void k_bnh_apply(const BnhGeom g, const float*
     const StashNnz nnz = stash_nnz_load(chan, C, c);
     float k1 = 0.f, k2 = 0.f;
     if (training) { const float n = (float)g.N * (float)g.HW; k1 = sums[c] / n; k2 = sums[C + c] / n; }
-    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n4; i += (int64_t)S * 256) {
-        float gv[4], acc[4], r[4];
-        int64_t off;
-        bnh_load<POOL>(g, c, (uint32_t)i, da, h, own, gv, acc, nnz, off);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float u = acc[e] * fl;
-            const float dz = (u >= L && u <= U) ? gv[e] : 0.f;
-            r[e] = gi * (dz - k1 - fmaf(acc[e], A, B) * k2);
-        }
-        *reinterpret_cast<float4*>(dy + off) = make_float4(r[0], r[1], r[2], r[3]);
-    }
+    float gv_[2][4], acc_[2][4];
+    int64_t off_[2];
+#define BNHA_LOAD(k, idx) bnh_load<POOL>(g, c, (uint32_t)(idx), da, h, own, gv_[k], acc_[k], nnz, off_[k]);
+#define BNHA_FIN(k) { float r[4];                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
+            const float u = acc_[k][e] * fl;                                                 \
+            const float dz = (u >= L && u <= U) ? gv_[k][e] : 0.f;                           \
+            r[e] = gi * (dz - k1 - fmaf(acc_[k][e], A, B) * k2);                             \
+        }                                                                                    \
+        *reinterpret_cast<float4*>(dy + off_[k]) = make_float4(r[0], r[1], r[2], r[3]); }
+    MN_STREAM_2(i, (int64_t)sp * 256 + threadIdx.x, (int64_t)S * 256, g.n4, BNHA_LOAD, BNHA_FIN)
+#undef BNHA_LOAD
+#undef BNHA_FIN
 }
 static int bnh_common(int64_t N, int64_t C, int64_t H, int64_t W, int pooled, const void* da, const void* h, const void* own, BnhGeom* g, const char* what) {
     const int64_t HW = H * W;

@@ -98,7 +98,12 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
         const int k8 = p.Kp >> 3;
         for (int q = tid; q < MB * k8; q += 256) {
             const int row = q / k8, c8 = q - row * k8;
-            *reinterpret_cast<u32x4*>(wsm + row * LDW + c8 * 8) = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.Kp + c8 * 8);
+            // the sign codes are contracted as +-0.5 (one v_perm per B-fragment dword, see the main loop): the weight codes are doubled here --
+            // a bf16 integer code times two is its exponent field plus one (0x0080), zero stays zero -- so every product is the exact +-code
+            u32x4 wv = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.Kp + c8 * 8);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) wv[d] += ((wv[d] & 0x00007fffu) ? 0x00000080u : 0u) | ((wv[d] & 0x7fff0000u) ? 0x00800000u : 0u);
+            *reinterpret_cast<u32x4*>(wsm + row * LDW + c8 * 8) = wv;
         }
         for (int i = tid; i < MB; i += 256) {
             const int m = mblk * MB + i;
@@ -200,11 +205,19 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            // B fragments: byte q of the 8 channel dwords -> bf16 +-0.5 (0x3F00 / 0xBF00: the sign bit over 0x3F as the HIGH byte, low byte 0):
+            // one v_and_or per input dword, one v_perm per fragment dword
+            uint32_t en[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) en[d] = (cur[s * 8 + d] & 0x80808080u) | 0x3F3F3F3Fu;
             u32x4 bq[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) bq[q][d] = mn_sign8_pair(cur[s * 8 + 2 * d], cur[s * 8 + 2 * d + 1], q);
+            for (int d = 0; d < 4; ++d) {
+                bq[0][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x040c000cu);
+                bq[1][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x050c010cu);
+                bq[2][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x060c020cu);
+                bq[3][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x070c030cu);
+            }
             if (more) load_step(cur, s, xo_next);            // this step's registers are free: prefetch the next chunk into them
             // A fragments one tile ahead only: the scheduler would otherwise hoist all NT LDS reads (4 VGPRs each) above the MFMAs
             u32x4 a = *reinterpret_cast<const u32x4*>(wl + s * 32);

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build a variant of libmicronet_hip.so with one source recompiled under extra -D flags (A/B inside one gpurun call via MN_LIB_PATH).
+# Usage: scripts/variant_lib.sh <tag> <source.hip> <flags...>   -> micronet_amd/lib/libmicronet_hip_<tag>.so
+set -e
+cd "$(dirname "$0")/.."
+L=micronet_amd/lib
+tag=$1; src=$2; shift 2
+base=${src%.hip}
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc "$@" -c micronet_amd/csrc/$src -o $L/${base}_$tag.o
+objs=""
+for f in quant_kernels conv_kernels qgemm_kernels qgemm_kxk qgemm_sign qgemm_k3s conv_first optim_kernels norm_kernels; do
+  if [ $f = $base ]; then objs="$objs $L/${base}_$tag.o"; else objs="$objs $L/$f.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libmicronet_hip_$tag.so $objs
+echo $L/libmicronet_hip_$tag.so
