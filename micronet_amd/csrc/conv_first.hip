@@ -19,6 +19,8 @@
 // the generic kernels.
 #include "qgemm_dev.h"
 
+#include <stdlib.h>
+
 #define C1_KS 19          // K-steps of 4: K <= 76
 #define MN_MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 
@@ -32,7 +34,7 @@ struct C1Params {
     float* dbpart;        // [Z][Opad]
     int N, C, H, W, O, KH, KW, ph, pw, K, KS, Opad;
     int R, strips, PR, PW, CS;      // strip of R output rows; LDS patch rows / row pitch / channel stride
-    int Z, want_db;
+    int Z, want_db, xs_bytes;       // xs_bytes: LDS bytes of the image patch (the backward-weight's row images follow)
     FastDiv fd_w;
     // BN variant of the backward-weight: gy is not given, it is the BatchNorm+sign backward of (da, yb) formed in registers
     const float* da;      // d loss / d sign output      [N][O][H][W]
@@ -149,11 +151,18 @@ __global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
 // BN = 1: the layer is followed by BatchNorm2d + BinaryActivation and nothing else consumes d loss / d y (the first layer has no
 // backward-data): dy = gamma*invstd*(dz - sum_dz/n - zhat*sum_dzzhat/n) with dz = da*[|z| < 1] is formed from (da, y) while they
 // stream in -- expression for expression what k_bns_apply<1> computes -- so the full-size dy tensor is never written or re-read.
+// The gy rows reach the MFMA through a wave-private LDS image: lane (row j, k-group kq) of an A fragment wants 4 pixels of channel
+// row j, i.e. a fragment-direct load touches 16 different cache lines per 16 lanes and every line twice (measured: 2x the designed
+// HBM traffic, L1 tag rate bound).  Instead 8 lanes read one 128-byte line (32 pixels) of a row, the BatchNorm fold is applied on
+// those registers, the step is written to the wave's [16 MT rows][32 pixels] image (rows padded to 160 B: conflict-free b128
+// fragment reads) and read back as fragments -- no block barrier inside a tile, the next step's loads fly during the MFMAs.
+#define C1_RSA 160
 template <int MT, int BN>
 __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    unsigned char* gsm = reinterpret_cast<unsigned char*>(smem) + p.xs_bytes + wave * (16 * MT * C1_RSA);
     uint32_t b = blockIdx.x;
     const int z = b % p.Z;
     const int cblk = b / p.Z;
@@ -162,89 +171,94 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) koff[nt] = c1_koff(p, nt * 16 + j);     // B[pixel][k = nt*16 + j]
 
-    float cmean[MT], cinv[MT], cga[MT], cbe[MT], cgi[MT], ck1[MT], ck2[MT];      // BN: constants of this lane's channel of each tile
-    if (BN) {
+    // staging roles: row sr + 8 i of the wave's 16 MT rows, pixels 4 sq .. 4 sq + 3 of the 32-pixel step
+    constexpr int NR = 2 * MT;
+    const int sr = lane >> 3, sq = lane & 7;
+    uint32_t roff[NR];          // element offset of the lane's quad inside image 0 / strip 0 (planner: the tensor has < 2^31 elements)
+    float cmean[NR], cinv[NR], cga[NR], cbe[NR], ck1[NR], ck2[NR], dbs[NR];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const int m = m0 + t * 16 + j;
-            const int mc = m < p.O ? m : p.O - 1;
-            cmean[t] = p.save[mc]; cinv[t] = p.save[p.O + mc]; cga[t] = p.gamma[mc]; cbe[t] = p.beta[mc];
-            cgi[t] = cga[t] * cinv[t];
-            ck1[t] = p.training ? p.sums[mc] / p.n_f : 0.f;
-            ck2[t] = p.training ? p.sums[p.O + mc] / p.n_f : 0.f;
+    for (int i = 0; i < NR; ++i) {
+        const int m = m0 + sr + 8 * i;
+        const int mc = m < p.O ? m : p.O - 1;              // rows beyond O: clamped, their dw rows are never read
+        roff[i] = (uint32_t)mc * (uint32_t)(p.H * p.W) + 4u * sq;
+        dbs[i] = 0.f;
+        if (BN) {
+            cmean[i] = p.save[mc]; cinv[i] = p.save[p.O + mc]; cga[i] = p.gamma[mc]; cbe[i] = p.beta[mc];
+            ck1[i] = p.training ? p.sums[mc] / p.n_f : 0.f;
+            ck2[i] = p.training ? p.sums[p.O + mc] / p.n_f : 0.f;
         }
     }
     f32x4 acc[MT][5];
-    float dbs[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        dbs[t] = 0.f;
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int ntiles = p.N * p.strips, npix = p.R * p.W, nsteps = npix >> 4;     // 16 pixels per step (R*W % 16 == 0)
+    const int ntiles = p.N * p.strips, npix = p.R * p.W, nsteps = npix >> 5;     // 32 pixels per step (R*W % 32 == 0)
     for (int tile = z; tile < ntiles; tile += p.Z) {
         const int n = tile / p.strips, strip = tile - n * p.strips, row0 = strip * p.R;
         __syncthreads();                      // previous tile's patch fully consumed
         c1_stage(p, xs, n, row0);
         __syncthreads();
-        // A[i = channel j][k = kq]: float4 = pixels st*16 + 4kq + e, e = MFMA step; loaded one step ahead
-        auto load_g = [&](float4 (&dst)[MT], int st) {
-            const int pix = st * 16 + 4 * kq;
-            const uint32_t prow = fd_div(pix, p.fd_w);
-            const int pcol = pix - prow * p.W;
+        const uint32_t tbase = (uint32_t)n * (uint32_t)(p.O * p.H * p.W) + (uint32_t)(row0 * p.W);      // uniform; the strip's pixels are contiguous in a plane
+        float4 ra[NR], rb[NR];
+        auto fetch = [&](int st) {            // unconditional: the caller clamps st
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int m = m0 + t * 16 + j;
-                dst[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < p.O) {
-                    const int64_t off = (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol;
-                    if (BN) {
-                        const float4 d4 = *reinterpret_cast<const float4*>(p.da + off), y4 = *reinterpret_cast<const float4*>(p.yb + off);
-                        const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
-                        float r[4];
+            for (int i = 0; i < NR; ++i) {
+                const uint32_t off = tbase + roff[i] + (uint32_t)st * 32u;
+                if (BN) { ra[i] = *reinterpret_cast<const float4*>(p.da + off); rb[i] = *reinterpret_cast<const float4*>(p.yb + off); }
+                else ra[i] = *reinterpret_cast<const float4*>(p.gy + off);
+            }
+        };
+        fetch(0);
+        for (int st = 0; st < nsteps; ++st) {
+            // registers -> LDS image (BatchNorm + sign backward applied on the way: expression for expression k_bns_apply<1>)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float zh = (yv[e] - cmean[t]) * cinv[t];
-                            const float z = zh * cga[t] + cbe[t];
-                            const float dz = (z > -1.f && z < 1.f) ? dv[e] : 0.f;
-                            r[e] = cgi[t] * (dz - ck1[t] - zh * ck2[t]);
-                        }
-                        dst[t] = make_float4(r[0], r[1], r[2], r[3]);
-                    } else {
-                        dst[t] = *reinterpret_cast<const float4*>(p.gy + off);
+            for (int i = 0; i < NR; ++i) {
+                float r[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                if (BN) {
+                    const float yv[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+                    const float cgi_ = cga[i] * cinv[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float zh = (yv[e] - cmean[i]) * cinv[i];
+                        const float zz = zh * cga[i] + cbe[i];
+                        const float dz = (zz > -1.f && zz < 1.f) ? r[e] : 0.f;
+                        r[e] = cgi_ * (dz - ck1[i] - zh * ck2[i]);
+                    }
+                }
+                dbs[i] += (r[0] + r[1]) + (r[2] + r[3]);
+                *reinterpret_cast<float4*>(gsm + (sr + 8 * i) * C1_RSA + 16 * sq) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+            fetch(st + 1 < nsteps ? st + 1 : st);
+            MN_WAVE_SYNC();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // A[i = channel j][k = kq]: float4 = pixels st*32 + half*16 + 4kq + e, e = MFMA step
+                float4 ga[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) ga[t] = *reinterpret_cast<const float4*>(gsm + (t * 16 + j) * C1_RSA + half * 64 + 16 * kq);
+                const int pix = st * 32 + half * 16 + 4 * kq;
+                const uint32_t prow = fd_div(pix, p.fd_w);
+                const int pb = (int)prow * p.PW + (pix - (int)prow * p.W);
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    const float* src = xs + pb + koff[nt];
+                    const float b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        acc[t][nt] = MN_MFMA_F32(ga[t].x, b0, acc[t][nt]);
+                        acc[t][nt] = MN_MFMA_F32(ga[t].y, b1, acc[t][nt]);
+                        acc[t][nt] = MN_MFMA_F32(ga[t].z, b2, acc[t][nt]);
+                        acc[t][nt] = MN_MFMA_F32(ga[t].w, b3, acc[t][nt]);
                     }
                 }
             }
-        };
-        float4 gn[MT];
-        load_g(gn, 0);
-        for (int st = 0; st < nsteps; ++st) {
-            const int pix = st * 16 + 4 * kq;
-            const uint32_t prow = fd_div(pix, p.fd_w);
-            const int pcol = pix - prow * p.W;
-            float4 ga[MT];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) { ga[t] = gn[t]; dbs[t] += (ga[t].x + ga[t].y) + (ga[t].z + ga[t].w); }
-            if (st + 1 < nsteps) load_g(gn, st + 1);
-            const int pb = (int)prow * p.PW + pcol;
-#pragma unroll
-            for (int nt = 0; nt < 5; ++nt) {
-                const float* src = xs + pb + koff[nt];
-                const float b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    acc[t][nt] = MN_MFMA_F32(ga[t].x, b0, acc[t][nt]);
-                    acc[t][nt] = MN_MFMA_F32(ga[t].y, b1, acc[t][nt]);
-                    acc[t][nt] = MN_MFMA_F32(ga[t].z, b2, acc[t][nt]);
-                    acc[t][nt] = MN_MFMA_F32(ga[t].w, b3, acc[t][nt]);
-                }
-            }
+            MN_WAVE_SYNC();                   // the image is rewritten by the next step
         }
     }
     // D[row = channel 4kq + r][col = k = nt*16 + j]
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt)
 #pragma unroll
@@ -252,10 +266,12 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
                 const int m = m0 + t * 16 + kq * 4 + r;
                 p.part[((int64_t)z * p.Opad + m) * 80 + nt * 16 + j] = acc[t][nt][r];
             }
-        if (p.want_db) {
-            float v = dbs[t];
-            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);      // the four kq groups hold different pixels of channel j
-            if (kq == 0) p.dbpart[(int64_t)z * p.Opad + m0 + t * 16 + j] = v;
+    if (p.want_db) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            float v = dbs[i];
+            v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);      // the eight pixel chunks of the row
+            if (sq == 0) p.dbpart[(int64_t)z * p.Opad + m0 + sr + 8 * i] = v;
         }
     }
 }
@@ -302,25 +318,32 @@ struct C1Plan {
     size_t lds;
     int64_t wp_bytes, off_db, ws_bytes_f, ws_bytes_w;
 };
-static int plan_c1(const mn_conv_geom* g, C1Plan* pl) {
+// which: 0 forward, 2 backward-weight (different strip heights; everything else is common)
+static int plan_c1(const mn_conv_geom* g, C1Plan* pl, int which = 0) {
     if (g->groups != 1 || g->stride_h != 1 || g->stride_w != 1 || g->dil_h != 1 || g->dil_w != 1 || g->in_shuffle > 1) return 0;
     if (2 * g->pad_h != g->KH - 1 || 2 * g->pad_w != g->KW - 1) return 0;       // "same": Ho = H, Wo = W
     const int K = g->C * g->KH * g->KW;
     if (K > 76 || g->W % 4 || g->W < 4) return 0;
+    if ((int64_t)g->N * g->O * g->H * g->W >= ((int64_t)1 << 31)) return 0;       // 32-bit element offsets in the backward-weight
     C1Params& p = pl->p;
     p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.KH = g->KH; p.KW = g->KW; p.ph = g->pad_h; p.pw = g->pad_w;
     p.K = K; p.KS = (K + 3) / 4;
-    pl->MT = g->O > 128 ? 4 : (g->O > 64 ? 2 : 1);
+    pl->MT = g->O > 192 ? 4 : (g->O > 128 ? 3 : (g->O > 64 ? 2 : 1));        // 16 MT out-channels per wave, four waves
     const int per_blk = 64 * pl->MT;                      // out-channels per block (4 waves)
     pl->cblks = (g->O + per_blk - 1) / per_blk;
     p.Opad = pl->cblks * per_blk;
     int R = g->H;                                          // strip height: halve while that keeps 16-pixel steps and fills the chip
-    while (R % 2 == 0 && ((R / 2) * g->W) % 64 == 0 && (int64_t)g->N * (g->H / R) * pl->cblks < 1024) R /= 2;
-    if ((R * g->W) % 16) return 0;
+    // strips: the forward likes one block slot per (image, strip) -- 512 = 2 per CU; the backward-weight one tile per block (measured on L1:
+    // forward 131 -> 123 us, backward-weight 141 -> 128 us against 1024 blocks)
+    int64_t want_blocks = which == 2 ? 256 : 512;
+    if (const char* e = getenv("MN_C1_BLOCKS")) { const int v = atoi(e); if (v >= 1) want_blocks = v; }     // tuning knob
+    while (R % 2 == 0 && ((R / 2) * g->W) % 64 == 0 && (int64_t)g->N * (g->H / R) * pl->cblks < want_blocks) R /= 2;
+    if ((R * g->W) % 32) return 0;
     p.R = R; p.strips = g->H / R;
     p.PR = R + g->KH - 1; p.PW = g->W + g->KW - 1 + 3;     // + 3: the 4-wide reads of the last pixel quad stay inside the row
     p.CS = p.PR * p.PW;
-    pl->lds = (size_t)g->C * p.CS * 4 + 64;
+    p.xs_bytes = (int)(((size_t)g->C * p.CS * 4 + 64 + 15) / 16 * 16);
+    pl->lds = (size_t)p.xs_bytes + (size_t)4 * 16 * pl->MT * C1_RSA;          // forward uses the patch only
     if (pl->lds > 64 * 1024) return 0;
     p.fd_w = make_fastdiv((uint32_t)g->W);
     const int64_t nbf = (int64_t)g->N * p.strips * pl->cblks;
@@ -341,11 +364,11 @@ static int plan_c1(const mn_conv_geom* g, C1Plan* pl) {
 }
 int c1_supported(const mn_conv_geom* g, int which) {
     C1Plan pl;
-    return (which == 0 || which == 2) && plan_c1(g, &pl);
+    return (which == 0 || which == 2) && plan_c1(g, &pl, which);
 }
 int64_t c1_ws_bytes(const mn_conv_geom* g, int which) {
     C1Plan pl;
-    if (!plan_c1(g, &pl)) return 0;
+    if (!plan_c1(g, &pl, which)) return 0;
     return which == 0 ? pl.ws_bytes_f : (which == 2 ? pl.ws_bytes_w : 0);
 }
 int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes, hipStream_t s) {
@@ -359,6 +382,7 @@ int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* b
     mn_set_last_kernel("k_c1_fwd<%d>", pl.MT);
     mn_prof_begin(s);
     if (pl.MT == 4) { raise_lds_limit((const void*)k_c1_fwd<4>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<4>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }
+    else if (pl.MT == 3) { raise_lds_limit((const void*)k_c1_fwd<3>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<3>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }
     else if (pl.MT == 2) { raise_lds_limit((const void*)k_c1_fwd<2>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<2>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }
     else { raise_lds_limit((const void*)k_c1_fwd<1>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<1>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }
     mn_prof_end(s);
@@ -372,6 +396,7 @@ static void c1_launch_wgrad_mt(const C1Plan& pl, const C1Params& p, hipStream_t 
 }
 static void c1_launch_wgrad(const C1Plan& pl, const C1Params& p, hipStream_t s) {
     if (pl.MT == 4) c1_launch_wgrad_mt<4>(pl, p, s);
+    else if (pl.MT == 3) c1_launch_wgrad_mt<3>(pl, p, s);
     else if (pl.MT == 2) c1_launch_wgrad_mt<2>(pl, p, s);
     else c1_launch_wgrad_mt<1>(pl, p, s);
 }
@@ -384,7 +409,7 @@ int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float*
 int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, const float* yb, const float* save, const float* gamma, const float* beta,
                      const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
     C1Plan pl;
-    if (!plan_c1(g, &pl) || (gy && !aligned16(gy)) || (da && (!aligned16(da) || !aligned16(yb)))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(first-layer): geometry not covered");
+    if (!plan_c1(g, &pl, 2) || (gy && !aligned16(gy)) || (da && (!aligned16(da) || !aligned16(yb)))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(first-layer): geometry not covered");
     if (!gy && (!da || !yb || !save || !gamma || !beta || !sums)) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight(first-layer, bn): null argument");
     if (!ws || ws_bytes < pl.ws_bytes_w || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(first-layer): workspace too small");
     C1Params& p = pl.p;
