@@ -260,9 +260,12 @@ int mn_qconv_bnsign_bwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x,
  * constants `chan` [8][O] (thresholds of sign(z) and |z| < 1 in the integer domain, zhat = acc*A + B, gamma*invstd, nnz).  With them the
  * BatchNorm+sign backward needs neither y nor the convolution: mn_bnh_bwd_sums (dgamma, dbeta, sums [2][O]) and mn_bnh_bwd_apply (dy)
  * stream (da, h) once each; `own` != NULL: da is the gradient of the 2x2 max-pool behind the block, own = the block's output codes. */
+/* num_batches_tracked (nullable, int64 on the device): nn.BatchNorm2d's forward counter (torch/nn/modules/batchnorm.py: += 1 per training
+ * forward), incremented by the same launch that forms the statistics -- one tiny kernel per block less than a separate add. */
 int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
                               const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
-                              float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream);
+                              int64_t* num_batches_tracked, float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes,
+                              mn_stream_t stream);
 /* The stash forward also covers k x k convolutions with ternary / binary weights on sign codes (nin_gc's grouped 3x3 layers,
  * models/nin_gc.py:88-119): the code-domain k x k kernel writes h instead of y, the batch statistics and the sign are streamed from h
  * (one byte per element each).  These two queries answer for both kinds of block; the stash forward needs the workspace they name. */

@@ -381,11 +381,8 @@ __device__ __forceinline__ float pws_z(float acc, float al, float b, float mean,
     const float zh = (y - mean) * invstd;
     return zh * ga + be;
 }
-__global__ __launch_bounds__(64) void k_pws_chan_prep(int K, int Kp, const uint16_t* __restrict__ wc, int G, int Mpad, int Mr, const float* __restrict__ rowscale, const float* __restrict__ bias,
-                                                     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ chan, int Cout) {
-    const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
-    const float al = rowscale[g * Mpad + m], b = bias ? bias[co] : 0.f, mean = save[co], invstd = save[Cout + co], ga = gamma[co], be = beta[co];
+__device__ __forceinline__ void pws_prep_core(int K, int Kp, const uint16_t* __restrict__ wc, int g, int m, int Mpad, int co, int lane, float al, float b, float mean,
+                                              float invstd, float ga, float be, float* __restrict__ chan, int Cout, const float* __restrict__ nnz9) {
     const float zlo = pws_z(-(float)K, al, b, mean, invstd, ga, be), zhi = pws_z((float)K, al, b, mean, invstd, ga, be);
     const float flip = (zhi < zlo) ? -1.f : 1.f;              // NaN anywhere: flip = +1 and every test below is false -> constant outputs
     // non-decreasing in u: T = min{u : !(z < 0)}, L = min{u : z > -1}, U = max{u : z < 1}
@@ -410,8 +407,55 @@ __global__ __launch_bounds__(64) void k_pws_chan_prep(int K, int Kp, const uint1
         chan[4 * Cout + co] = al * invstd;                    // zhat = acc*A + B  (<= 2 ulp from the unfused chain; dy tolerance 1e-5)
         chan[5 * Cout + co] = (b - mean) * invstd;
         chan[6 * Cout + co] = ga * invstd;
-        chan[7 * Cout + co] = (float)nnz;
+        chan[7 * Cout + co] = nnz9 ? -1.f : (float)nnz;      // -1: per-pixel-class nnz in rows 8..16 (3x3 blocks; stash_nnz_load, common.h)
     }
+    if (nnz9 && lane < 9) chan[(8 + lane) * Cout + co] = nnz9[lane * Cout + co];
+}
+__global__ __launch_bounds__(64) void k_pws_chan_prep(int K, int Kp, const uint16_t* __restrict__ wc, int G, int Mpad, int Mr, const float* __restrict__ rowscale, const float* __restrict__ bias,
+                                                     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ chan, int Cout) {
+    const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
+    pws_prep_core(K, Kp, wc, g, m, Mpad, co, lane, rowscale[g * Mpad + m], bias ? bias[co] : 0.f, save[co], save[Cout + co], gamma[co], beta[co], chan, Cout, nullptr);
+}
+// forward of a stashed block, one launch per block instead of three: batch statistics from the partials (training; as k_pws_final_fwd) or
+// from the running statistics (eval), the per-channel constants (as k_pws_chan_prep), the per-pixel-class nnz rows of a 3x3 block and
+// BatchNorm's num_batches_tracked counter (nullable).  One wave per channel.
+__global__ __launch_bounds__(64) void k_pws_stats_prep(const double* __restrict__ part, int CB, int G, int Mpad, int Mr, const float* __restrict__ rowscale,
+                                                      const float* __restrict__ bias, double n, float eps, float momentum, int training,
+                                                      float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save, int Cout,
+                                                      int K, int Kp, const uint16_t* __restrict__ wc, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ chan, const float* __restrict__ nnz9, long long* __restrict__ nbt) {
+    const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
+    float mean_f = 0.f, inv_f = 0.f;
+    if (training) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int i = lane; i < CB; i += 64) {
+            const double* src = part + ((int64_t)i * G * Mpad + g * Mpad + m) * 2;
+            a1 += src[0]; a2 += src[1];
+        }
+        a1 = wave_reduce(a1, OpAddD()); a2 = wave_reduce(a2, OpAddD());
+        if (lane == 0) {
+            const double al = (double)rowscale[g * Mpad + m];
+            const double ma = a1 / n;
+            const double mean = al * ma + (double)(bias ? bias[co] : 0.f);
+            double ss = al * al * (a2 - a1 * ma);                 // sum of squared deviations of y
+            if (ss < 0.0) ss = 0.0;
+            const float var_b = (float)(ss / n);
+            mean_f = (float)mean;
+            inv_f = 1.0f / sqrtf(var_b + eps);
+            if (running_mean) running_mean[co] = (1.f - momentum) * running_mean[co] + momentum * (float)mean;
+            if (running_var) running_var[co] = (1.f - momentum) * running_var[co] + momentum * (float)(ss / (n - 1.0));
+        }
+    } else if (lane == 0) {
+        mean_f = running_mean[co];
+        inv_f = 1.0f / sqrtf(running_var[co] + eps);
+    }
+    if (lane == 0) {
+        save[co] = mean_f; save[Cout + co] = inv_f;
+        if (nbt && co == 0 && training) *nbt += 1;
+    }
+    mean_f = __shfl(mean_f, 0, 64); inv_f = __shfl(inv_f, 0, 64);
+    pws_prep_core(K, Kp, wc, g, m, Mpad, co, lane, rowscale[g * Mpad + m], bias ? bias[co] : 0.f, mean_f, inv_f, gamma[co], beta[co], chan, Cout, nnz9);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1013,7 +1057,7 @@ static void pws_chan_prep(PwsPlan& pl, const mn_conv_geom* g, const float* bias,
 }
 
 static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
-                                 const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                 const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var, int64_t* nbt,
                                  float* save, int8_t* a, uint8_t* h, float* chan_out, void* ws, int64_t ws_bytes, mn_stream_t stream) {
     if (!g || !gamma || !beta || !save || !a || (((uintptr_t)a) & 3)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd: null / misaligned argument");
     if (!pws_bn_ok(g, wq)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd: needs a pointwise convolution with ternary / binary weights");
@@ -1025,35 +1069,32 @@ static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const i
     PwsParams& p = pl.p;
     p.bias = bias;
     const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
-    if (training) {
-        if ((rc = launch_pws<PWS_STATS>(pl, s, nx, "mn_qconv_bnsign_fwd(stats)"))) return rc;
-        hipLaunchKernelGGL(k_pws_final_fwd, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, bias,
-                           (double)g->N * p.HW, eps, momentum, running_mean, running_var, save, (int)g->O);
-    } else {
-        hipLaunchKernelGGL(k_pws_eval_stats, dim3((unsigned)((g->O + 63) / 64)), dim3(64), 0, s, (int)g->O, eps, (const float*)running_mean,
-                           (const float*)running_var, save);
-    }
+    if (training && (rc = launch_pws<PWS_STATS>(pl, s, nx, "mn_qconv_bnsign_fwd(stats)"))) return rc;
     if (chan_out) p.chan = chan_out;                     // caller-owned [8][O]: kept for the streaming backward (mn_bnh_bwd)
-    pws_chan_prep(pl, g, bias, save, gamma, beta, s);
+    hipLaunchKernelGGL(k_pws_stats_prep, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, bias,
+                       (double)g->N * p.HW, eps, momentum, training, running_mean, running_var, save, (int)g->O, p.Kc, p.Kp, p.wc, gamma, beta,
+                       (float*)p.chan, (const float*)nullptr, (long long*)nbt);
     p.a8 = (char*)a; p.h8 = h;
     return launch_pws<PWS_SIGN8>(pl, s, nx + (h ? 2.0 : 1.0) * ny, "mn_qconv_bnsign_fwd(sign)");
 }
 extern "C" int mn_qconv_bnsign_fwd(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
                                    const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
                                    float* save, int8_t* a, void* ws, int64_t ws_bytes, mn_stream_t stream) {
-    return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, nullptr, nullptr, ws, ws_bytes, stream);
+    return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, nullptr, save, a, nullptr, nullptr, ws, ws_bytes, stream);
 }
 static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
-                                      const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                      const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var, int64_t* nbt,
                                       float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, hipStream_t s);
 extern "C" int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
                                          const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
-                                         float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+                                         int64_t* num_batches_tracked, float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes,
+                                         mn_stream_t stream) {
     if (!h || !chan || (((uintptr_t)h) & 3)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd_stash: null / misaligned stash");
     if (g && wq && !pws_bn_ok(g, wq) && kk_h8_supported(g, wq))          // a k x k convolution: stash written by the conv kernel, statistics / sign streamed from it
-        return qconv_kxk_bnsign_fwd_stash(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, h, chan, ws, ws_bytes,
-                                          (hipStream_t)stream);
-    return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, h, chan, ws, ws_bytes, stream);
+        return qconv_kxk_bnsign_fwd_stash(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, num_batches_tracked, save, a, h,
+                                          chan, ws, ws_bytes, (hipStream_t)stream);
+    return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, num_batches_tracked, save, a, h, chan, ws,
+                                 ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1177,7 +1218,7 @@ static int64_t kxk_stash_ws(const mn_conv_geom* g, int64_t* off_nnz, int64_t* of
     return a + b + (int64_t)h_splits(g->O) * g->groups * kk_h8_mpad(g) * 2 * 8;
 }
 static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
-                                      const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                      const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var, int64_t* nbt,
                                       float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, hipStream_t s) {
     if (!gamma || !beta || !save || !a || (((uintptr_t)a) & 3) || !x || !w) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd_stash(k x k): null / misaligned argument");
     if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd_stash(k x k): eval mode needs the running statistics");
@@ -1205,15 +1246,10 @@ static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
         if (vec4) hipLaunchKernelGGL(k_h_stats<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, (const float*)nnzf, part);
         else hipLaunchKernelGGL(k_h_stats<1>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, (const float*)nnzf, part);
         mn_prof_end(s);
-        hipLaunchKernelGGL(k_pws_final_fwd, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)part, S, (int)g->groups, info.Mpad, Mg, info.rowscale, bias,
-                           (double)g->N * hg.HW, eps, momentum, running_mean, running_var, save, (int)g->O);
-    } else {
-        hipLaunchKernelGGL(k_pws_eval_stats, dim3((unsigned)((g->O + 63) / 64)), dim3(64), 0, s, (int)g->O, eps, (const float*)running_mean,
-                           (const float*)running_var, save);
     }
-    hipLaunchKernelGGL(k_pws_chan_prep, dim3((unsigned)g->O), dim3(64), 0, s, info.K, info.Kp, info.codes, (int)g->groups, info.Mpad, Mg, info.rowscale, bias,
-                       (const float*)save, gamma, beta, chan, (int)g->O);
-    hipLaunchKernelGGL(k_chan_mark_classes, dim3((unsigned)((g->O + 63) / 64)), dim3(64), 0, s, chan, (const float*)nnzf, (int)g->O);
+    hipLaunchKernelGGL(k_pws_stats_prep, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)part, S, (int)g->groups, info.Mpad, Mg, info.rowscale, bias,
+                       (double)g->N * hg.HW, eps, momentum, training, running_mean, running_var, save, (int)g->O, info.K, info.Kp, info.codes, gamma, beta,
+                       chan, (const float*)nnzf, (long long*)nbt);
     mn_set_last_kernel("k_h_sign");
     mn_prof_bytes(2.0 * ny);
     mn_prof_begin(s);

@@ -597,7 +597,7 @@ class ConvBNSign(Function):
     streaming passes over (da, h) with no convolution recompute (mn_bnh_bwd_sums / mn_bnh_bwd_apply)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt=None):
         r = y.recipe
         codes, wq, bias, g, wdesc = r["codes"], r["wq"], r["bias"], r["geom"], r["wdesc"]
         gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
@@ -610,7 +610,7 @@ class ConvBNSign(Function):
             nb = int(_lib_().mn_qconv_bnsign_stash_ws_bytes(C.byref(g)))
             ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
             _call("mn_qconv_bnsign_fwd_stash", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), float(eps), float(momentum),
-                  int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(h), _p(chan), _p(ws), nb, _s())
+                  int(training), _p(running_mean), _p(running_var), _p(nbt), _p(save), _p(a), _p(h), _p(chan), _p(ws), nb, _s())
         ctx.save_for_backward(h, chan, gamma, beta)
         ctx.training = int(training)
         ctx.fold_ok = FOLD_BN_INTO_CONV_BWD and bool(_lib_().mn_conv2d_bnh_supported(C.byref(g), _ref(wd)))     # the conv's own backward can form dy from (da, h)
@@ -639,10 +639,10 @@ class ConvBNSign(Function):
                         _call("mn_bnh_bwd_apply", _p(r["da"]), _p(r["h"]), None, _p(r["chan"]), _p(r["sums"]), N, Cc, H, W, r["training"], _p(dy_), _s())
                     return dy_
                 recipe = dict(kind="bnh", da=grad, h=h, chan=chan, sums=sums, training=training)
-                return LazyBNGrad(h.shape, h.device, recipe, expand), dgamma, dbeta, None, None, None, None, None
+                return LazyBNGrad(h.shape, h.device, recipe, expand), dgamma, dbeta, None, None, None, None, None, None
             dy = torch.empty(h.shape, dtype=torch.float32, device=h.device)
             _call("mn_bnh_bwd_apply", _p(grad), _p(h), _p(own), _p(chan), _p(sums), N, Cc, H, W, training, _p(dy), _s())
-        return dy, dgamma, dbeta, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
 def channel_shuffle(x, groups):

@@ -97,14 +97,19 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
             return super().forward(input)
         use_batch = self.training or self.running_mean is None
         momentum = 0.0 if self.momentum is None else self.momentum
+        fused = isinstance(input, LazyConvOut) and (use_batch or self.track_running_stats)
+        nbt = None
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
-            if self.momentum is None:
-                momentum = 1.0 / float(self.num_batches_tracked)
-        if isinstance(input, LazyConvOut) and (use_batch or self.track_running_stats):
+            if fused and self.momentum is not None and self.num_batches_tracked.dtype == torch.int64 and self.num_batches_tracked.is_cuda:
+                nbt = self.num_batches_tracked           # incremented by the launch that forms the statistics (one tiny kernel less)
+            else:
+                self.num_batches_tracked.add_(1)
+                if self.momentum is None:
+                    momentum = 1.0 / float(self.num_batches_tracked)
+        if fused:
             # the conv in front did not compute its output: conv + statistics + normalisation + sign in the fused kernels
             return ops.ConvBNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                                        self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
+                                        self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, nbt)
         out = ops.BNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, bool(self.packed),
                                bool(getattr(input, "_mn_first_conv_out", False)))

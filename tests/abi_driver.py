@@ -50,6 +50,12 @@ class Backend:
             return a.copy()
         return self.torch.from_numpy(a.copy()).cuda()
 
+    def to_dev_i64(self, a):
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        if self.kind == "emu":
+            return a.copy()
+        return self.torch.from_numpy(a.copy()).cuda()
+
     def empty_i8(self, shape):
         if self.kind == "emu":
             return np.full(shape, 77, dtype=np.int8)   # poison

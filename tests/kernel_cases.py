@@ -470,8 +470,10 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
     save, a8 = be.empty((2, Oc)), be.empty_i8((N, Oc, H, W))
     if stash:      # forward that also stashes the integer conv result in one byte per element + the per-channel constants
         h8, chan = be.empty_i8((N, Oc, H, W)), be.empty((int(be.lib.mn_qconv_bnsign_stash_chan_rows(C.byref(g))), Oc))
+        nbt = be.to_dev_i64([41])
         be.call("mn_qconv_bnsign_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
-                be.ptr(dRM), be.ptr(dRV), be.ptr(save), be.ptr(a8), be.ptr(h8), be.ptr(chan), be.ptr(ws), nb, be.stream)
+                be.ptr(dRM), be.ptr(dRV), be.ptr(nbt), be.ptr(save), be.ptr(a8), be.ptr(h8), be.ptr(chan), be.ptr(ws), nb, be.stream)
+        assert int(be.to_host(nbt)[0]) == (42 if training else 41)         # BatchNorm's forward counter: incremented by the statistics launch
         acc_ref = O.conv2d_fwd(x_log, np.sign(w).astype(F), None, padding=padding, groups=groups)
         # nnz per pixel: the non-zero weights that meet a non-zero input (= all of them, except at the zero-padded border of a 3x3 block)
         nnz = O.conv2d_fwd(np.ones_like(x_log), (w != 0).astype(F), None, padding=padding, groups=groups)
