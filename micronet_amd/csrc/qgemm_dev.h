@@ -77,6 +77,9 @@ int kk_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const flo
 // 3 x 3 backward-weight on sign codes (qgemm_k3s.hip)
 int k3s_wgrad_supported(const mn_conv_geom* g);
 int64_t k3s_wgrad_ws_bytes(const mn_conv_geom* g);
+// 3 x 3 backward-data of a ternary / binary-weight layer (qgemm_k3s.hip); no clip-STE epilogue
+int k3s_dgrad_supported(const mn_conv_geom* g, const mn_wq* wq);
+int k3s_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, float* dx, hipStream_t s);
 int k3s_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 
 static inline int aq_codeable(const mn_actq* aq, int need_exact_x) {

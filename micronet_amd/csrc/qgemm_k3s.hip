@@ -282,3 +282,241 @@ int k3s_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, floa
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(sign 3x3)");
     return MN_OK;
 }
+
+// ================================================================================================
+// 3 x 3 (stride 1, padding 1) backward-data of a ternary / binary-weight layer:
+//
+//   dx[n][g*Cg + c][ih][iw] = sum over (m, r, s) of  t[m][c][r][s] * (alpha[m] * gy[n][g*Mg + m][ih + 1 - r][iw + 1 - s])
+//
+// (w = alpha[m] * t with t in {-1, 0, +1}: wbwtab/quantize.py:96-150; autograd's conv2d backward-data.)  The contraction runs over the
+// gy channels m, but memory is pixel-contiguous: a B fragment (8 channels of ONE pixel per lane) needs gy transposed.  k_kk does that
+// with 2-byte LDS stores (12 per float4).  Here a block stages a whole stage (NI images of one group) once:
+//   * 256 threads read the 32 gy rows coalesced (a wave = 1 KB of one row per load), scale by alpha[m], split into three exact bf16
+//     terms and write them TRANSPOSED as [pixel slot][32 k] with 8-byte stores: the contraction order k is a permutation of m
+//     (k = 4 (m % 8) + m / 8) chosen so that the four rows a thread holds are adjacent in k;
+//   * the image sits in LDS with a one-pixel zero frame ((H + 2) x (W + 2) slots, rows padded to 80 B): the nine taps of an output
+//     pixel are nine constant slot offsets, border handling costs nothing;
+//   * each wave owns 32-pixel tiles of the stage: per tile 2 (16-pixel halves) x 3 (terms) independent accumulators, 9 MFMAs each;
+//     the weight codes of the nine taps are A fragments held in registers for the whole kernel (same k permutation);
+//   * the next stage's gy rows are loaded into registers while the current one is contracted.
+// D[row = channel 4 kg + r][col = pixel j]: 16 lanes store 64 contiguous bytes of one dx row.
+#define K3D_RS 80             // LDS bytes per pixel slot and term (32 bf16 + pad: b128 reads of 16 consecutive slots at most 2-way)
+#define K3D_MAXF4 8           // float4 a thread stages per stage: 32 rows x SP pixels / 256 threads / 4, SP <= 256
+
+struct K3dParams {
+    const float* gy;
+    const float* w;           // fake-quantised weights [O][Cg][3][3]
+    float* dx;
+    int N, C, H, W, O, Cg, Mg, G, ncb, Zb;
+    int NI, SP, HW, IS, TS, nstages, WP;      // images per stage, pixels per stage, slots per image, bytes per term plane, W + 2
+    FastDiv fd_hw4, fd_w4, fd_w;
+    ChanMap out_map;
+};
+
+__global__ __launch_bounds__(256, 2) void k_k3s_dgrad(const K3dParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+    float* alpha = reinterpret_cast<float*>(lds + 3 * p.TS);          // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
+    uint32_t b = blockIdx.x;
+    const int z = b % p.Zb; b /= p.Zb;
+    const int cb = b % p.ncb;
+    const int g = b / p.ncb;
+    const int wrow = p.Cg * 9;                                         // floats per weight row
+
+    // zero frame (and everything else) once; alpha[m] = max |w[m][..]| (every non-zero weight of a ternary / binary row has that magnitude)
+    for (int i = tid; i < (3 * p.TS) / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    {
+        const int m = tid >> 3, part = tid & 7;
+        float a = 0.f;
+        if (m < p.Mg) for (int k = part; k < wrow; k += 8) a = fmaxf(a, fabsf(p.w[(int64_t)(g * p.Mg + m) * wrow + k]));
+        a = fmaxf(a, __shfl_xor(a, 4, 64)); a = fmaxf(a, __shfl_xor(a, 2, 64)); a = fmaxf(a, __shfl_xor(a, 1, 64));
+        if (part == 0) alpha[m] = a;
+    }
+    // A fragments: code t[m(k)][c = cb*16 + j][tap] for k = 8 kg + e  ->  m = 2 kg + e / 4 + 8 (e % 4)
+    u32x4 wa[9];
+    {
+        const int c = cb * 16 + j;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            uint32_t h16[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = 2 * kg + (e >> 2) + 8 * (e & 3);
+                float v = 0.f;
+                if (m < p.Mg && c < p.Cg) v = p.w[(int64_t)(g * p.Mg + m) * wrow + c * 9 + t];
+                h16[e] = v > 0.f ? 0x3F80u : (v < 0.f ? 0xBF80u : 0u);
+            }
+            wa[t] = u32x4{h16[0] | (h16[1] << 16), h16[2] | (h16[3] << 16), h16[4] | (h16[5] << 16), h16[6] | (h16[7] << 16)};
+        }
+    }
+    // staging roles: pair u of this thread = (chunk, sr): rows m = sr + 8 i, pixels 4 chunk .. of the stage
+    const int cps = p.SP >> 2;                                         // chunks per stage
+    const int npair = (p.SP * 2) >> 8;                                 // pairs per thread (1 or 2)
+    int s_slot[2];                                                     // LDS byte offset of the pair's first pixel slot (+ 8 sr)
+    uint32_t s_goff[2][4];                                             // element offset inside the stage's first image plane set
+    float s_al[2][4];
+    __syncthreads();                                                   // alpha visible
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int pi = tid + 256 * u;
+        const int chunk = pi % cps, sr = pi / cps;                     // sr < 8 when u < npair
+        const uint32_t img = fd_div(chunk, p.fd_hw4);
+        const int q = chunk - (int)img * (p.HW >> 2);
+        const uint32_t row = fd_div(q, p.fd_w4);
+        const int col = (q - (int)row * (p.W >> 2)) * 4;
+        s_slot[u] = ((int)img * p.IS + ((int)row + 1) * p.WP + col + 1) * K3D_RS + 8 * (sr & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = (sr & 7) + 8 * i;
+            s_al[u][i] = m < p.Mg ? alpha[m] : 0.f;
+            m = m < p.Mg ? m : p.Mg - 1;
+            s_goff[u][i] = (img * (uint32_t)p.O + (uint32_t)(g * p.Mg + m)) * (uint32_t)p.HW + 4u * q;
+        }
+    }
+    float4 rg[2][4];
+    auto fetch = [&](int st) {                                         // unconditional; images past N are clamped (never stored)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u < npair) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int64_t base = (int64_t)st * p.NI * p.O * p.HW;
+                    const int64_t lim = ((int64_t)p.N * p.O - 1) * p.HW + p.HW - 4;          // last valid quad
+                    int64_t off = base + s_goff[u][i];
+                    off = off < lim ? off : lim;
+                    rg[u][i] = *reinterpret_cast<const float4*>(p.gy + off);
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u < npair) {
+                float t0[4][4], t1[4][4], t2[4][4];                    // [i][e]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v[4] = {rg[u][i].x * s_al[u][i], rg[u][i].y * s_al[u][i], rg[u][i].z * s_al[u][i], rg[u][i].w * s_al[u][i]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t0[i][e] = mn_bf16_head(v[e]);
+                        const float r1 = v[e] - t0[i][e];
+                        t1[i][e] = mn_bf16_head(r1);
+                        t2[i][e] = r1 - t1[i][e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                          // pixel e of the chunk: k = 4 sr + i, i = 0..3 -> one 8-byte store per term
+                    unsigned char* d = lds + s_slot[u] + e * K3D_RS;
+                    *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0][e], t0[1][e]), mn_pack_bf16x2(t0[2][e], t0[3][e])};
+                    *reinterpret_cast<u32x2*>(d + p.TS) = u32x2{mn_pack_bf16x2(t1[0][e], t1[1][e]), mn_pack_bf16x2(t1[2][e], t1[3][e])};
+                    *reinterpret_cast<u32x2*>(d + 2 * p.TS) = u32x2{mn_pack_bf16x2(t2[0][e], t2[1][e]), mn_pack_bf16x2(t2[2][e], t2[3][e])};
+                }
+            }
+        }
+    };
+    const int ntile = p.SP >> 5;                                       // 32-pixel tiles per stage
+    int st = z;
+    if (st < p.nstages) fetch(st);
+    for (; st < p.nstages; st += p.Zb) {
+        __syncthreads();                                               // previous stage fully contracted
+        commit();
+        __syncthreads();
+        fetch(st + p.Zb < p.nstages ? st + p.Zb : st);                 // in flight during the MFMAs
+        for (int tile = wave; tile < ntile; tile += 4) {
+            f32x4 acc[2][3];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[hh][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int sb[2];                                                 // byte offset of pixel (hh, j)'s own slot + this lane's k chunk
+            int opix[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int sp = tile * 32 + hh * 16 + j;                // pixel of the stage
+                const uint32_t img = fd_div(sp >> 2, p.fd_hw4);
+                const int pp = sp - (int)img * p.HW;
+                const uint32_t row = fd_div(pp, p.fd_w);
+                const int col = pp - (int)row * p.W;
+                sb[hh] = ((int)img * p.IS + ((int)row + 1) * p.WP + col + 1) * K3D_RS + 16 * kg;
+                opix[hh] = sp;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    const int toff = ((1 - r) * p.WP + (1 - s_)) * K3D_RS;        // input pixel (ih + 1 - r, iw + 1 - s)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const u32x4 bf = *reinterpret_cast<const u32x4*>(lds + t * p.TS + sb[hh] + toff);
+                            acc[hh][t] = mn_mfma_bf16(wa[r * 3 + s_], bf, acc[hh][t]);
+                        }
+                }
+            // D[row = channel 4 kg + rr][col = pixel j]
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const uint32_t img = fd_div(opix[hh] >> 2, p.fd_hw4);
+                const int pp = opix[hh] - (int)img * p.HW;
+                const int n = st * p.NI + (int)img;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int c = cb * 16 + 4 * kg + rr;
+                    if (n < p.N && c < p.Cg)
+                        p.dx[((int64_t)n * p.C + chan_phys(p.out_map, g * p.Cg + c)) * p.HW + pp] = (acc[hh][0][rr] + acc[hh][1][rr]) + acc[hh][2][rr];
+                }
+            }
+        }
+    }
+}
+
+struct K3dPlan { K3dParams p; int grid; size_t lds; };
+static int plan_k3d(const mn_conv_geom* g, const mn_wq* wq, K3dPlan* pl) {
+    if (!wq || wq->mode != MN_WQ_TERNARY) return 0;
+    if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1 || g->dil_h != 1 || g->dil_w != 1) return 0;
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    const int HW = g->H * g->W, Mg = g->O / g->groups, Cg = g->C / g->groups;
+    if (g->W % 4 || HW % 32 || Mg > 32 || Mg < 1) return 0;
+    if ((int64_t)g->N * g->O * HW >= ((int64_t)1 << 31)) return 0;
+    if (getenv("MN_NO_K3D")) return 0;          // A/B knob: the generic k x k kernel
+    K3dParams& p = pl->p;
+    int NI = 1;
+    while (NI * HW < 128) NI *= 2;
+    const int SP = NI * HW;
+    if (SP > 256 || SP % 128) return 0;          // a thread stages at most K3D_MAXF4 float4
+    p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.Cg = Cg; p.Mg = Mg; p.G = g->groups;
+    p.NI = NI; p.SP = SP; p.HW = HW; p.WP = g->W + 2; p.IS = (g->H + 2) * (g->W + 2);
+    p.TS = (NI * p.IS * K3D_RS + 255) / 256 * 256;
+    pl->lds = (size_t)3 * p.TS + 128;
+    if (pl->lds > 80 * 1024) return 0;
+    p.nstages = (g->N + NI - 1) / NI;
+    p.ncb = (Cg + 15) / 16;
+    const int base = p.G * p.ncb;
+    int Zb = 512 / base;
+    if (Zb > p.nstages) Zb = p.nstages;
+    if (Zb < 1) Zb = 1;
+    p.Zb = Zb;
+    const int64_t nb = (int64_t)base * Zb;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    p.fd_hw4 = make_fastdiv((uint32_t)(HW / 4)); p.fd_w4 = make_fastdiv((uint32_t)(g->W / 4)); p.fd_w = make_fastdiv((uint32_t)g->W);
+    p.out_map = make_chanmap(g->in_shuffle, g->C);
+    return 1;
+}
+int k3s_dgrad_supported(const mn_conv_geom* g, const mn_wq* wq) { K3dPlan pl; return plan_k3d(g, wq, &pl); }
+int k3s_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, float* dx, hipStream_t s) {
+    K3dPlan pl;
+    if (!plan_k3d(g, wq, &pl) || !aligned16(gy) || !w || !dx) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(3x3 ternary): geometry not covered");
+    K3dParams& p = pl.p;
+    p.gy = gy; p.w = w; p.dx = dx;
+    mn_set_last_kernel("k_k3s_dgrad");
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + 4.0 * nx); }
+    mn_prof_begin(s);
+    raise_lds_limit((const void*)k_k3s_dgrad, pl.lds);
+    hipLaunchKernelGGL(k_k3s_dgrad, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_data(3x3 ternary)");
+    return MN_OK;
+}

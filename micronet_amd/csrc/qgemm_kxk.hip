@@ -471,6 +471,7 @@ int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     if (rc) return rc;
     if (ste.mode == MN_ACTQ_SIGN8) ste.mode = MN_ACTQ_NONE;      // the clip-STE of the sign lives in mn_bnsign_bwd
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
+    if (ste.mode == MN_ACTQ_NONE && k3s_dgrad_supported(g, wq)) return k3s_bwd_data(g, wq, gy, w, dx, s);      // 3x3, ternary / binary weights: staged-image kernel
     fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
     qg_launch_pack(pl.pk, pl.pack_grid, s);
     Pro none; none.mode = MN_ACTQ_NONE; none.s = 1.f; none.qmin = none.qmax = 0.f; none.qp = nullptr;

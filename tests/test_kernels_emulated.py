@@ -159,6 +159,19 @@ def test_sign8_wgrad_3x3(be, case):
     K.check_conv(be, seed=175 + case, wmode=1, sign8=True, algos=(3,), **{"expect_qgemm": True, **K3S_CASES[case]})
 
 
+# 3 x 3 backward-data of a ternary-weight layer (k_k3s_dgrad): staged image with zero frame, k-permuted transposition
+K3D_CASES = [
+    dict(x_shape=(3, 32, 16, 16), w_shape=(64, 16, 3, 3), padding=1, groups=2),                  # the nin_gc L4 pattern: one image per stage
+    dict(x_shape=(5, 48, 8, 8), w_shape=(48, 24, 3, 3), padding=1, groups=2, bias=False),        # Mg = 24 (padded k), Cg = 24 (two c-tiles), odd N with two images per stage
+    dict(x_shape=(2, 16, 4, 8), w_shape=(32, 16, 3, 3), padding=1, in_shuffle=2),                # 32-pixel images: four per stage; shuffled dx channels
+]
+
+
+@pytest.mark.parametrize("case", range(len(K3D_CASES)))
+def test_sign8_dgrad_3x3(be, case):
+    K.check_conv(be, seed=185 + case, wmode=1, sign8=True, algos=(3,), **{"expect_qgemm": True, **K3D_CASES[case]})
+
+
 def test_pool_sign8(be):
     K.check_pool_sign8(be)
     K.check_pool_sign8(be, shape=(2, 3, 2, 8), seed=1)
