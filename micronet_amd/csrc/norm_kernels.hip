@@ -10,7 +10,7 @@
 //             pass 2 dy = gamma * invstd * (dz - sum_dz/n - zhat * sum_dzzhat/n)                (read da, y, write dy)
 // i.e. 3 + 5 passes instead of 5 + 8.  All kernels address the tensor as C channels x (N planes of HW contiguous floats),
 // float4 per lane, every lane busy whatever HW is.
-#include "common.h"
+#include "qgemm_dev.h"
 
 // streaming loops: iterations are independent; MN_STREAM_2 handles two quads per trip -- both sets of loads are issued before the
 // first is consumed (twice the bytes in flight per thread; same per-thread accumulation order)
@@ -329,47 +329,95 @@ extern "C" int mn_bnsign_bwd(const float* da, const float* y, const float* save,
 // wave order through LDS.  The layer is bound by the latency of its byte loads: each lane keeps 16 in flight, 4 waves per SIMD.
 #define SC_MAXO 16
 #define SC_WAVES 16
+// Block = 64 consecutive pixels of the [N][HW] pixel axis (HW % 4 == 0: a lane's 4 pixels are one dword of one image plane); 16 waves
+// split the channels, and inside a wave the four 16-lane groups take every fourth channel: lane (pq, cs) accumulates 4 pixels x OP outputs
+// over channels c0 + cs + 4u.  The weights come from an LDS image [C][OP] (OP = O rounded up to 4; broadcast b128 reads, no per-output
+// branches, no scalar-load latency chain), the 16 code dwords of a lane are all in flight at once (the layer is latency-, not byte-bound).
+// The four channel groups of a wave are combined by two shuffles, the 16 waves through LDS in a fixed order: deterministic.
+template <int OP>
 __global__ __launch_bounds__(1024) void k_sconv_fwd(const char* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
-                                                    float* __restrict__ y, int C, int HW, int O) {
-    HIP_DYNAMIC_SHARED(float, red)            // [SC_WAVES][O][64]
-    const int tid = threadIdx.x, px = tid & 63, wv = mn_uniform(tid >> 6);
-    const int chunks = (HW + 63) >> 6;
-    const int n = blockIdx.x / chunks, p = (blockIdx.x - n * chunks) * 64 + px;
-    float acc[SC_MAXO];
+                                                    float* __restrict__ y, int C, int HW, int O, int64_t NP) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* wl = smem;                          // [C][OP]
+    float* red = smem + (size_t)C * OP;        // [8][OP][64]
+    const int tid = threadIdx.x, lane = tid & 63, wv = mn_uniform(tid >> 6), pq = lane & 15, cs = lane >> 4;
+    for (int i = tid; i < C * OP; i += 1024) wl[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < C * O; i += 1024) {       // coalesced read of w[o][c], transposed LDS write
+        const int o = i / C, c = i - o * C;
+        wl[c * OP + o] = w[i];
+    }
+    const int64_t P = (int64_t)blockIdx.x * 64 + 4 * pq;
+    const int64_t Pc = P < NP ? P : 0;
+    const int64_t n = Pc / HW;
+    const int p = (int)(Pc - n * HW);
+    float acc[4][OP];
 #pragma unroll
-    for (int o = 0; o < SC_MAXO; ++o) acc[o] = 0.f;
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int o = 0; o < OP; ++o) acc[e][o] = 0.f;
     const int per = (C + SC_WAVES - 1) / SC_WAVES;
     const int c0 = wv * per, c1 = (c0 + per) < C ? (c0 + per) : C;
-    const char* src = a + (int64_t)n * C * HW + (p < HW ? p : 0);
-    int c = c0;
-    for (; c + 16 <= c1; c += 16) {
-        char v[16];
+    const char* src = a + n * C * HW + p;
+    __syncthreads();
+    auto add = [&](uint32_t v, int c) {
+        const float s0 = (v & 0x80u) ? -1.f : 1.f, s1 = (v & 0x8000u) ? -1.f : 1.f, s2 = (v & 0x800000u) ? -1.f : 1.f, s3 = (v & 0x80000000u) ? -1.f : 1.f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = src[(int64_t)(c + u) * HW];
+        for (int o4 = 0; o4 < OP; o4 += 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wl + c * OP + o4);
+            const float wv_[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[0][o4 + k] += wv_[k] * s0; acc[1][o4 + k] += wv_[k] * s1; acc[2][o4 + k] += wv_[k] * s2; acc[3][o4 + k] += wv_[k] * s3;
+            }
+        }
+    };
+    for (int cb = c0 + cs; cb < c1; cb += 64) {               // 16 channels of this lane per trip (c = cb + 4u)
+        uint32_t v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const float s = v[u] < 0 ? -1.f : 1.f;
+            const int c = cb + 4 * u;
+            v[u] = *reinterpret_cast<const uint32_t*>(src + (int64_t)(c < c1 ? c : c1 - 1) * HW);
+        }
 #pragma unroll
-            for (int o = 0; o < SC_MAXO; ++o)
-                if (o < O) acc[o] += w[o * C + c + u] * s;
+        for (int u = 0; u < 16; ++u)
+            if (cb + 4 * u < c1) add(v[u], cb + 4 * u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int o = 0; o < OP; ++o) {
+            float t = acc[e][o];
+            t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            acc[e][o] = t;
+        }
+    if (wv >= 8 && cs == 0) {
+#pragma unroll
+        for (int o = 0; o < OP; ++o)
+            *reinterpret_cast<float4*>(red + ((wv - 8) * OP + o) * 64 + 4 * pq) = make_float4(acc[0][o], acc[1][o], acc[2][o], acc[3][o]);
+    }
+    __syncthreads();
+    if (wv < 8 && cs == 0) {
+#pragma unroll
+        for (int o = 0; o < OP; ++o) {
+            float4* r = reinterpret_cast<float4*>(red + (wv * OP + o) * 64 + 4 * pq);
+            const float4 t = *r;
+            *r = make_float4(acc[0][o] + t.x, acc[1][o] + t.y, acc[2][o] + t.z, acc[3][o] + t.w);
         }
     }
-    for (; c < c1; ++c) {
-        const float s = src[(int64_t)c * HW] < 0 ? -1.f : 1.f;
-#pragma unroll
-        for (int o = 0; o < SC_MAXO; ++o)
-            if (o < O) acc[o] += w[o * C + c] * s;
-    }
-#pragma unroll
-    for (int o = 0; o < SC_MAXO; ++o)
-        if (o < O) red[(wv * O + o) * 64 + px] = acc[o];
     __syncthreads();
-    for (int i = tid; i < O * 64; i += 1024) {
-        const int o = i >> 6, q = i & 63, pp = (blockIdx.x - n * chunks) * 64 + q;
-        if (pp < HW) {
-            float v = 0.f;
-            for (int k = 0; k < SC_WAVES; ++k) v += red[(k * O + o) * 64 + q];          // fixed order
-            y[((int64_t)n * O + o) * HW + pp] = v + (bias ? bias[o] : 0.f);
+    for (int i = tid; i < O * 16; i += 1024) {
+        const int o = i >> 4, q = i & 15;                       // quad q of the block
+        const int64_t Pq = (int64_t)blockIdx.x * 64 + 4 * q;
+        if (Pq < NP) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 8; ++k) {                        // fixed order
+                const float4 t = *reinterpret_cast<const float4*>(red + (k * OP + o) * 64 + 4 * q);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const float bb = bias ? bias[o] : 0.f;
+            const int64_t nq = Pq / HW;
+            *reinterpret_cast<float4*>(y + (nq * O + o) * HW + (Pq - nq * HW)) = make_float4(v.x + bb, v.y + bb, v.z + bb, v.w + bb);
         }
     }
 }
@@ -403,14 +451,24 @@ __global__ __launch_bounds__(256) void k_sconv_dgrad(const float* __restrict__ g
         }
     }
 }
-extern "C" int mn_signconv1x1_small_supported(int64_t C, int64_t HW, int64_t O) { return O >= 1 && O <= SC_MAXO && C >= 4 && HW % 4 == 0; }
+extern "C" int mn_signconv1x1_small_supported(int64_t C, int64_t HW, int64_t O) {
+    if (!(O >= 1 && O <= SC_MAXO && C >= 4 && HW % 4 == 0)) return 0;
+    const int64_t OP = (O + 3) / 4 * 4;
+    return (C * OP + 8 * OP * 64) * 4 <= 128 * 1024;          // the weight image and the partial sums live in LDS
+}
 extern "C" int mn_signconv1x1_small_fwd(const int8_t* a, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream) {
     if (!a || !w || !y || N <= 0 || !mn_signconv1x1_small_supported(C, HW, O)) MN_FAIL(MN_EINVAL, "mn_signconv1x1_small_fwd: needs O <= 16, HW %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t nb = N * ((HW + 63) / 64);
-    if (nb > 0x7fffffff) MN_FAIL(MN_EINVAL, "mn_signconv1x1_small_fwd: too many blocks");
+    const int64_t NP = N * HW, nb = (NP + 63) / 64;
+    if (nb > 0x7fffffff || (((uintptr_t)a) & 3) || !aligned16(y)) MN_FAIL(MN_EINVAL, "mn_signconv1x1_small_fwd: too many blocks / misaligned tensor");
     mn_set_last_kernel("k_sconv_fwd"); mn_prof_bytes((double)N * C * HW + 4.0 * N * O * HW); mn_prof_begin(s);
-    hipLaunchKernelGGL(k_sconv_fwd, dim3((unsigned)nb), dim3(1024), (size_t)SC_WAVES * O * 64 * 4, s, (const char*)a, w, bias, y, (int)C, (int)HW, (int)O);
+    const int OP = (int)((O + 3) / 4 * 4);
+    const size_t lds = ((size_t)C * OP + (size_t)8 * OP * 64) * 4;
+    if (lds > 128 * 1024) MN_FAIL(MN_ENOTSUP, "mn_signconv1x1_small_fwd: too many input channels for the LDS weight image");
+#define SC_LAUNCH(OPV) { raise_lds_limit((const void*)k_sconv_fwd<OPV>, lds); \
+        hipLaunchKernelGGL(k_sconv_fwd<OPV>, dim3((unsigned)nb), dim3(1024), lds, s, (const char*)a, w, bias, y, (int)C, (int)HW, (int)O, NP); }
+    if (OP == 4) SC_LAUNCH(4) else if (OP == 8) SC_LAUNCH(8) else if (OP == 12) SC_LAUNCH(12) else SC_LAUNCH(16)
+#undef SC_LAUNCH
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_signconv1x1_small_fwd");
     return MN_OK;

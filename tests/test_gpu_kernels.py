@@ -355,6 +355,7 @@ def test_sign_classifier(be):
     K.check_sign_classifier(be)
     K.check_sign_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bias=False, seed=1)
     K.check_sign_classifier(be, N=16, Cc=1024, H=8, W=8, Oc=10, seed=2)                 # nin_gc L9
+    K.check_sign_classifier(be, N=5, Cc=330, H=8, W=8, Oc=10, seed=3)
 
 
 @pytest.mark.parametrize("training", [True, False])

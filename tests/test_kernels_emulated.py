@@ -228,6 +228,7 @@ def test_qconv_bnsign_fused_pooled_gradient(be, case):
 def test_sign_classifier(be):
     K.check_sign_classifier(be)
     K.check_sign_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bias=False, seed=1)      # partial pixel chunk, C not a multiple of 64
+    K.check_sign_classifier(be, N=5, Cc=330, H=8, W=8, Oc=10, seed=3)                  # two blocks (320 pixels), 21 channels per wave: unrolled loads + tail
 
 
 @pytest.mark.parametrize("training", [True, False])
