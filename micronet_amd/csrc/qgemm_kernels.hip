@@ -833,7 +833,9 @@ static int plan_pwd(const mn_conv_geom* g, PwdPlan* pl) {
     pl->lds = (size_t)MB * (p.Kp + 8) * 2 + (size_t)2 * p.Kp * 4 + (size_t)MB * 4 + (size_t)5 * p.Kp * 4;
     p.nchunks = (int)((NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
-    const int cap = 1024 / (p.G * p.num_mblk) > 0 ? 1024 / (p.G * p.num_mblk) : 1;
+    int capb = 512;           // one round of 2 blocks per CU (against 1024: -2 ... -5 %)
+    if (const char* e = getenv("MN_PWD_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) capb = v; }   // tuning knob
+    const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
     p.CB = CB;
     p.fd_hw = make_fastdiv((uint32_t)p.HW);

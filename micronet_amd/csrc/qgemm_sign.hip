@@ -151,19 +151,28 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
 
-    uint32_t cur[KS * 8];
-    if (chunk0 < p.nchunks) {
+    // Two register sets of codes alternate between consecutive chunks of the wave (forward epilogues; the backward ones keep their
+    // gradient rows in registers instead): a set is refilled K-step by K-step while its chunk is contracted, i.e. TWO chunks ahead --
+    // one chunk of MFMAs (~1.5k cycles) does not cover the HBM latency under load with two waves per SIMD.  Loads are unconditional
+    // (chunk_xo clamps past the end).
+    constexpr int PF = GRAD ? 1 : 2;
+    uint32_t curA[KS * 8], curB[GRAD ? 1 : KS * 8];
+    {
         const uint32_t xo = chunk_xo(chunk0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) load_step(cur, s, xo);
+        for (int s = 0; s < KS; ++s) load_step(curA, s, xo);
+        if (!GRAD) {
+            const uint32_t xo1 = chunk_xo(chunk0 + cstride);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) load_step(reinterpret_cast<uint32_t (&)[KS * 8]>(curB), s, xo1);
+        }
     }
-    for (int chunk = chunk0; chunk < p.nchunks; chunk += cstride) {
+    auto body = [&](uint32_t (&cur)[KS * 8], int chunk) {
         const uint32_t P = (uint32_t)chunk * 64u + 4u * j;
         const bool pv = P < p.NP;
         const uint32_t n = fd_div(P, p.fd_hw);
         const uint32_t obase = n * (uint32_t)p.Cout_total * HW + (P - n * HW) + (uint32_t)(g * p.Mr + mblk * MB + kg * 4) * HW;   // + (t*16 + r) * HW
-        const bool more = chunk + cstride < p.nchunks;       // wave-uniform
-        const uint32_t xo_next = more ? chunk_xo(chunk + cstride) : 0u;
+        const uint32_t xo_next = chunk_xo(chunk + PF * cstride);
 
         float4 gq[NT][4];                        // backward: the gradient rows of every tile, in flight during the MFMAs below
         // *_POOL: the lane's pixel quad (row h, columns w .. w+3) covers half of two pooling windows: gq = {g[win 0], g[win 1],
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                 bq[2][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x060c020cu);
                 bq[3][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x070c030cu);
             }
-            if (more) load_step(cur, s, xo_next);            // this step's registers are free: prefetch the next chunk into them
+            load_step(cur, s, xo_next);                      // this step's registers are free: prefetch chunk + PF into them
             // A fragments one tile ahead only: the scheduler would otherwise hoist all NT LDS reads (4 VGPRs each) above the MFMAs
             u32x4 a = *reinterpret_cast<const u32x4*>(wl + s * 32);
 #pragma unroll
@@ -299,6 +308,14 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                     }
                 }
             }
+        }
+    };
+    if (GRAD) {
+        for (int chunk = chunk0; chunk < p.nchunks; chunk += cstride) body(curA, chunk);
+    } else {
+        for (int chunk = chunk0; chunk < p.nchunks; chunk += 2 * cstride) {
+            body(curA, chunk);
+            if (chunk + cstride < p.nchunks) body(reinterpret_cast<uint32_t (&)[KS * 8]>(curB), chunk + cstride);
         }
     }
 
@@ -956,7 +973,8 @@ static int plan_pws(const mn_conv_geom* g, int nt_max, PwsPlan* pl) {
     p.Mpad = ((Mg + 127) / 128) * 128;                    // one packed-code layout for every tile height
     p.nchunks = (int)((p.NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
-    int capb = 1024;
+    int capb = 512;           // one round of 2 blocks per CU: every block stages its weights and ends in a block reduction -- fewer, longer blocks
+                              // (measured against 1024: STATS 41 -> 33 us on L2, 32 -> 23 on L5, 26 -> 18 on L8; SIGN8 44 -> 38, 32 -> 24, 19 -> 16)
     if (const char* e = getenv("MN_PWS_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 2048) capb = v; }   // tuning knob
     const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
