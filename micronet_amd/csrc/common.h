@@ -240,12 +240,15 @@ __device__ __forceinline__ StashNnz stash_nnz_load(const float* __restrict__ cha
     z.v6 = t ? chan[14 * C + c] : n7; z.v7 = t ? chan[15 * C + c] : n7; z.v8 = t ? chan[16 * C + c] : n7;
     return z;
 }
-// nnz of the four pixels of quad col4 in row `row` of an H x (4 W4) plane
+// nnz of the four pixels of quad col4 in row `row` of an H x (4 W4) plane.  Blended arithmetically (the values are small integers: exact)
+// -- a chain of selects between the struct's fields is turned into an indexed load from a scratch copy of the struct by the compiler.
 __device__ __forceinline__ void stash_nnz_quad(const StashNnz& z, int row, int col4, int H, int W4, float (&nz)[4]) {
-    const float m0 = row == 0 ? z.v0 : (row == H - 1 ? z.v6 : z.v3);
-    const float m1 = row == 0 ? z.v1 : (row == H - 1 ? z.v7 : z.v4);
-    const float m2 = row == 0 ? z.v2 : (row == H - 1 ? z.v8 : z.v5);
-    nz[0] = col4 == 0 ? m0 : m1; nz[1] = m1; nz[2] = m1; nz[3] = col4 == W4 - 1 ? m2 : m1;
+    const float top = row == 0 ? 1.f : 0.f, bot = row == H - 1 ? 1.f : 0.f;
+    const float m0 = z.v3 + top * (z.v0 - z.v3) + bot * (z.v6 - z.v3);
+    const float m1 = z.v4 + top * (z.v1 - z.v4) + bot * (z.v7 - z.v4);
+    const float m2 = z.v5 + top * (z.v2 - z.v5) + bot * (z.v8 - z.v5);
+    const float lf = col4 == 0 ? 1.f : 0.f, rt = col4 == W4 - 1 ? 1.f : 0.f;
+    nz[0] = m1 + lf * (m0 - m1); nz[1] = m1; nz[2] = m1; nz[3] = m1 + rt * (m2 - m1);
 }
 
 // logical -> physical channel through a channel shuffle with `sg` groups over C channels (identity when sg <= 1)

@@ -77,6 +77,10 @@ int kk_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const flo
 // 3 x 3 backward-weight on sign codes (qgemm_k3s.hip)
 int k3s_wgrad_supported(const mn_conv_geom* g);
 int64_t k3s_wgrad_ws_bytes(const mn_conv_geom* g);
+// 3 x 3 forward of a ternary / binary-weight layer on sign codes writing the byte stash + statistics partials [parts][O][2] (qgemm_k3s.hip)
+int k3s_fwd_supported(const mn_conv_geom* g, const mn_wq* wq);
+int k3s_fwd_parts(const mn_conv_geom* g, const mn_wq* wq);
+int k3s_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* nnz9, uint8_t* h, double* part, hipStream_t s);
 // 3 x 3 backward-data of a ternary / binary-weight layer (qgemm_k3s.hip); no clip-STE epilogue
 int k3s_dgrad_supported(const mn_conv_geom* g, const mn_wq* wq);
 int k3s_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, float* dx, hipStream_t s);

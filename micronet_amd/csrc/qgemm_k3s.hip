@@ -324,14 +324,19 @@ __global__ __launch_bounds__(256, 2) void k_k3s_dgrad(const K3dParams p) {
     const int g = b / p.ncb;
     const int wrow = p.Cg * 9;                                         // floats per weight row
 
-    // zero frame (and everything else) once; alpha[m] = max |w[m][..]| (every non-zero weight of a ternary / binary row has that magnitude)
-    for (int i = tid; i < (3 * p.TS) / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    // the group's weights go through LDS first (coalesced; the fragment build below reads them 72 times per lane), then the image region is
+    // zeroed: the zero frame stays for the whole kernel.  alpha[m] = max |w[m][..]| (every non-zero weight of a ternary / binary row)
+    float* wl = reinterpret_cast<float*>(lds);
+    const int nwl = p.Mg * wrow;
+    for (int i = tid; i < nwl; i += 256) wl[i] = p.w[(int64_t)g * p.Mg * wrow + i];
+    __syncthreads();
+    float my_alpha = 0.f;
     {
         const int m = tid >> 3, part = tid & 7;
         float a = 0.f;
-        if (m < p.Mg) for (int k = part; k < wrow; k += 8) a = fmaxf(a, fabsf(p.w[(int64_t)(g * p.Mg + m) * wrow + k]));
+        if (m < p.Mg) for (int k = part; k < wrow; k += 8) a = fmaxf(a, fabsf(wl[m * wrow + k]));
         a = fmaxf(a, __shfl_xor(a, 4, 64)); a = fmaxf(a, __shfl_xor(a, 2, 64)); a = fmaxf(a, __shfl_xor(a, 1, 64));
-        if (part == 0) alpha[m] = a;
+        my_alpha = a;
     }
     // A fragments: code t[m(k)][c = cb*16 + j][tap] for k = 8 kg + e  ->  m = 2 kg + e / 4 + 8 (e % 4)
     u32x4 wa[9];
@@ -344,12 +349,15 @@ __global__ __launch_bounds__(256, 2) void k_k3s_dgrad(const K3dParams p) {
             for (int e = 0; e < 8; ++e) {
                 const int m = 2 * kg + (e >> 2) + 8 * (e & 3);
                 float v = 0.f;
-                if (m < p.Mg && c < p.Cg) v = p.w[(int64_t)(g * p.Mg + m) * wrow + c * 9 + t];
+                if (m < p.Mg && c < p.Cg) v = wl[m * wrow + c * 9 + t];
                 h16[e] = v > 0.f ? 0x3F80u : (v < 0.f ? 0xBF80u : 0u);
             }
             wa[t] = u32x4{h16[0] | (h16[1] << 16), h16[2] | (h16[3] << 16), h16[4] | (h16[5] << 16), h16[6] | (h16[7] << 16)};
         }
     }
+    __syncthreads();                                                   // everybody is done with the weight image
+    for (int i = tid; i < (3 * p.TS) / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    if ((tid & 7) == 0) alpha[tid >> 3] = my_alpha;
     // staging roles: pair u of this thread = (chunk, sr): rows m = sr + 8 i, pixels 4 chunk .. of the stage
     const int cps = p.SP >> 2;                                         // chunks per stage
     const int npair = (p.SP * 2) >> 8;                                 // pairs per thread (1 or 2)
@@ -490,6 +498,7 @@ static int plan_k3d(const mn_conv_geom* g, const mn_wq* wq, K3dPlan* pl) {
     p.NI = NI; p.SP = SP; p.HW = HW; p.WP = g->W + 2; p.IS = (g->H + 2) * (g->W + 2);
     p.TS = (NI * p.IS * K3D_RS + 255) / 256 * 256;
     pl->lds = (size_t)3 * p.TS + 128;
+    if (pl->lds < (size_t)Mg * Cg * 9 * 4) pl->lds = (size_t)Mg * Cg * 9 * 4;          // the prologue's weight image
     if (pl->lds > 80 * 1024) return 0;
     p.nstages = (g->N + NI - 1) / NI;
     p.ncb = (Cg + 15) / 16;
@@ -518,5 +527,255 @@ int k3s_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const 
     hipLaunchKernelGGL(k_k3s_dgrad, dim3(pl.grid), dim3(256), pl.lds, s, p);
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_data(3x3 ternary)");
+    return MN_OK;
+}
+
+// ================================================================================================
+// 3 x 3 (stride 1, padding 1) FORWARD of a ternary / binary-weight layer on sign codes, writing the byte stash:
+//
+//   acc[n][g*Mg + m][oh][ow] = sum over (c, r, s) of t[m][c][r][s] * a[n][g*Cg + c][oh + r - 1][ow + s - 1]      (exact integer)
+//   h = (acc + nnz[class(oh, ow)][m]) / 2 as one byte;   per-channel partial sums of acc and acc^2 (the BatchNorm batch statistics)
+//
+// (wbwtab/quantize.py:181-195 with binary activations; the block's BatchNorm + sign then only need h: mn_qconv_bnsign_fwd_stash.)
+// Same organisation as k_k3s_dgrad: a block stages NI images of one group in LDS with a zero frame -- here the codes themselves,
+// transposed to [pixel slot][16 c] as bf16 +-0.5 (sign byte over 0x3F as the high byte; one v_perm per dword; the weight codes are
+// +-2) under the channel permutation k = 4 (c % 4) + c / 4 that makes a thread's four channels adjacent (8-byte stores); a K-step is two
+// taps x 16 channels, 5 K-steps cover the 9 taps; the weights are B fragments in registers for the whole kernel.  M = pixels:
+// D[row = pixel 4 kg + r][col = channel j] leaves every lane with 4 consecutive pixels of one channel = one dword of h.  The statistics
+// are accumulated in integer registers over the block's stages and leave as one fp64 partial per (block, channel) in the layout
+// k_pws_stats_prep reads.
+#define K3F_RS 48             // LDS bytes per pixel slot (16 bf16 + pad)
+
+struct K3fParams {
+    const char* x;
+    const float* w;           // fake-quantised weights [O][Cg][3][3]
+    const float* nnz9;        // [9][O]
+    unsigned char* h;
+    double* part;             // [Zb][G*Mg][2]
+    int N, C, H, W, O, Cg, Mg, G, Zb;
+    int NI, SP, HW, IS, TS, nstages, WP;
+    FastDiv fd_hw4, fd_w4, fd_w;
+    ChanMap in_map;
+};
+
+__global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
+    uint32_t b = blockIdx.x;
+    const int z = b % p.Zb;
+    const int g = b / p.Zb;
+    const int wrow = p.Cg * 9;
+
+    // the group's weights through LDS (coalesced), fragments from there; then the image region is zeroed (the zero frame stays)
+    float* wl = reinterpret_cast<float*>(lds);
+    for (int i = tid; i < p.Mg * wrow; i += 256) wl[i] = p.w[(int64_t)g * p.Mg * wrow + i];
+    __syncthreads();
+    // B fragments: 2 * t[m = mt*16 + j][c(k)][tap(ks, kg)] for k = 8 kg + e: tap = 2 ks + (kg >> 1), position 8 (kg & 1) + e -> c = (pos >> 2) + 4 (pos & 3)
+    u32x4 wb[5][2];
+    StashNnz zn[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = mt * 16 + j;
+        const int co = g * p.Mg + (m < p.Mg ? m : p.Mg - 1);
+        zn[mt].v0 = p.nnz9[co]; zn[mt].v1 = p.nnz9[p.O + co]; zn[mt].v2 = p.nnz9[2 * p.O + co]; zn[mt].v3 = p.nnz9[3 * p.O + co];
+        zn[mt].v4 = p.nnz9[4 * p.O + co]; zn[mt].v5 = p.nnz9[5 * p.O + co]; zn[mt].v6 = p.nnz9[6 * p.O + co]; zn[mt].v7 = p.nnz9[7 * p.O + co];
+        zn[mt].v8 = p.nnz9[8 * p.O + co];
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const int tap = 2 * ks + (kg >> 1);
+            uint32_t h16[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int pos = 8 * (kg & 1) + e, c = (pos >> 2) + 4 * (pos & 3);
+                float v = 0.f;
+                if (m < p.Mg && c < p.Cg && tap < 9) v = wl[m * wrow + c * 9 + tap];
+                h16[e] = v > 0.f ? 0x4000u : (v < 0.f ? 0xC000u : 0u);
+            }
+            wb[ks][mt] = u32x4{h16[0] | (h16[1] << 16), h16[2] | (h16[3] << 16), h16[4] | (h16[5] << 16), h16[6] | (h16[7] << 16)};
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < p.TS / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    // tap offset (bytes) of this lane's half of every K-step; tap 9 (the padding half of the last step) reads tap 8's slot against zero weights
+    int toff[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        int tap = 2 * ks + (kg >> 1);
+        tap = tap < 9 ? tap : 8;
+        const int r = tap / 3, s_ = tap - 3 * r;
+        toff[ks] = ((r - 1) * p.WP + (s_ - 1)) * K3F_RS + 16 * (kg & 1);
+    }
+    // staging role: chunk (4 pixels) x channel quartet sr: channels sr + 4 i
+    const int cps = p.SP >> 2;
+    const bool sact = tid < cps * 4;
+    const int chunk = tid % cps, sr = (tid / cps) & 3;
+    int s_slot;
+    uint32_t s_goff[4];
+    bool s_cv[4];
+    {
+        const uint32_t img = fd_div(chunk, p.fd_hw4);
+        const int q = chunk - (int)img * (p.HW >> 2);
+        const uint32_t row = fd_div(q, p.fd_w4);
+        const int col = (q - (int)row * (p.W >> 2)) * 4;
+        s_slot = ((int)img * p.IS + ((int)row + 1) * p.WP + col + 1) * K3F_RS + 8 * sr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = sr + 4 * i;
+            s_cv[i] = c < p.Cg;
+            s_goff[i] = (img * (uint32_t)p.C + (uint32_t)chan_phys(p.in_map, g * p.Cg + (s_cv[i] ? c : p.Cg - 1))) * (uint32_t)p.HW + 4u * q;
+        }
+    }
+    uint32_t rg[4];
+    auto fetch = [&](int st) {
+        const int64_t lim = ((int64_t)p.N * p.C - 1) * p.HW + p.HW - 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t off = (int64_t)st * p.NI * p.C * p.HW + s_goff[i];
+            off = off < lim ? off : lim;
+            rg[i] = *reinterpret_cast<const uint32_t*>(p.x + off);
+        }
+    };
+    auto commit = [&]() {
+        if (!sact) return;
+        uint32_t en[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) en[i] = s_cv[i] ? ((rg[i] & 0x80808080u) | 0x3F3F3F3Fu) : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t se = 0x000c000cu | ((uint32_t)e << 8) | ((uint32_t)(4 + e) << 24);      // [0, b.byte e, 0, a.byte e]
+            *reinterpret_cast<u32x2*>(lds + s_slot + e * K3F_RS) = u32x2{mn_perm(en[1], en[0], se), mn_perm(en[3], en[2], se)};
+        }
+    };
+    int s1[2] = {0, 0}, s2[2] = {0, 0};
+    const int ntile = p.SP >> 5;
+    int st = z;
+    __syncthreads();
+    if (st < p.nstages) fetch(st);
+    for (; st < p.nstages; st += p.Zb) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        fetch(st + p.Zb < p.nstages ? st + p.Zb : st);
+        for (int tile = wave; tile < ntile; tile += 4) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[pt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int sb[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int sp = tile * 32 + pt * 16 + j;
+                const uint32_t img = fd_div(sp >> 2, p.fd_hw4);
+                const int pp = sp - (int)img * p.HW;
+                const uint32_t row = fd_div(pp, p.fd_w);
+                sb[pt] = ((int)img * p.IS + ((int)row + 1) * p.WP + (pp - (int)row * p.W) + 1) * K3F_RS;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const u32x4 af = *reinterpret_cast<const u32x4*>(lds + sb[pt] + toff[ks]);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[pt][mt] = mn_mfma_bf16(af, wb[ks][mt], acc[pt][mt]);
+                }
+            // D[row = pixel 4 kg + rr][col = channel j]: this lane's quad = stage pixels tile*32 + pt*16 + 4 kg .. + 3
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int sp0 = tile * 32 + pt * 16 + 4 * kg;
+                const uint32_t img = fd_div(sp0 >> 2, p.fd_hw4);
+                const int pp = sp0 - (int)img * p.HW;
+                const uint32_t row = fd_div(pp, p.fd_w);
+                const int col4 = (pp - (int)row * p.W) >> 2;
+                const int n = st * p.NI + (int)img;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int m = mt * 16 + j;
+                    if (n < p.N && m < p.Mg) {
+                        float nz[4];
+                        stash_nnz_quad(zn[mt], (int)row, col4, p.H, p.W >> 2, nz);
+                        uint32_t hb = 0u;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const float a = acc[pt][mt][rr];
+                            hb |= (uint32_t)((a + nz[rr]) * 0.5f) << (8 * rr);
+                            const int ai = (int)a;
+                            s1[mt] += ai; s2[mt] += ai * ai;
+                        }
+                        *reinterpret_cast<uint32_t*>(p.h + ((int64_t)n * p.O + g * p.Mg + m) * p.HW + pp) = hb;
+                    }
+                }
+            }
+        }
+    }
+    // statistics: the four pixel groups of a wave by shuffles, the four waves through LDS in wave order
+    __syncthreads();
+    int* red = reinterpret_cast<int*>(lds);          // [4 waves][2 mt][16][2]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int a1 = s1[mt], a2 = s2[mt];
+        a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+        a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+        if (kg == 0) { red[((wave * 2 + mt) * 16 + j) * 2] = a1; red[((wave * 2 + mt) * 16 + j) * 2 + 1] = a2; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int mt = tid >> 4, jj = tid & 15, m = mt * 16 + jj;
+        if (m < p.Mg) {
+            long long t1 = 0, t2 = 0;
+            for (int w_ = 0; w_ < 4; ++w_) { t1 += red[((w_ * 2 + mt) * 16 + jj) * 2]; t2 += red[((w_ * 2 + mt) * 16 + jj) * 2 + 1]; }
+            double* dst = p.part + ((int64_t)z * p.G * p.Mg + g * p.Mg + m) * 2;
+            dst[0] = (double)t1; dst[1] = (double)t2;
+        }
+    }
+}
+
+struct K3fPlan { K3fParams p; int grid; size_t lds; };
+static int plan_k3f(const mn_conv_geom* g, const mn_wq* wq, K3fPlan* pl) {
+    if (!wq || wq->mode != MN_WQ_TERNARY) return 0;
+    if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1 || g->dil_h != 1 || g->dil_w != 1) return 0;
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    const int HW = g->H * g->W, Mg = g->O / g->groups, Cg = g->C / g->groups;
+    if (g->W % 4 || HW % 32 || g->H < 2 || Mg > 32 || Cg > 16) return 0;
+    if ((int64_t)g->N * g->O * HW >= ((int64_t)1 << 31) || (int64_t)g->N * g->C * HW >= ((int64_t)1 << 31)) return 0;
+    if (getenv("MN_NO_K3F")) return 0;          // A/B knob: the generic k x k kernel + k_h_stats
+    K3fParams& p = pl->p;
+    int NI = 1;
+    while (NI * HW < 128) NI *= 2;
+    const int SP = NI * HW;
+    if (SP > 256 || SP % 128) return 0;
+    p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.Cg = Cg; p.Mg = Mg; p.G = g->groups;
+    p.NI = NI; p.SP = SP; p.HW = HW; p.WP = g->W + 2; p.IS = (g->H + 2) * (g->W + 2);
+    p.TS = (NI * p.IS * K3F_RS + 255) / 256 * 256;
+    pl->lds = (size_t)p.TS > 1024 ? (size_t)p.TS : 1024;
+    if (pl->lds < (size_t)Mg * Cg * 9 * 4) pl->lds = (size_t)Mg * Cg * 9 * 4;          // the prologue's weight image
+    if (pl->lds > 64 * 1024) return 0;
+    p.nstages = (g->N + NI - 1) / NI;
+    int Zb = 512 / p.G;
+    if (Zb > p.nstages) Zb = p.nstages;
+    if (Zb < 1) Zb = 1;
+    p.Zb = Zb;
+    const int64_t nb = (int64_t)p.G * Zb;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
+    p.fd_hw4 = make_fastdiv((uint32_t)(HW / 4)); p.fd_w4 = make_fastdiv((uint32_t)(g->W / 4)); p.fd_w = make_fastdiv((uint32_t)g->W);
+    p.in_map = make_chanmap(g->in_shuffle, g->C);
+    return 1;
+}
+int k3s_fwd_supported(const mn_conv_geom* g, const mn_wq* wq) { K3fPlan pl; return plan_k3f(g, wq, &pl); }
+int k3s_fwd_parts(const mn_conv_geom* g, const mn_wq* wq) { K3fPlan pl; return plan_k3f(g, wq, &pl) ? pl.p.Zb : 0; }     // partial rows per channel
+int k3s_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* nnz9, uint8_t* h, double* part, hipStream_t s) {
+    K3fPlan pl;
+    if (!plan_k3f(g, wq, &pl) || (((uintptr_t)x) & 3) || (((uintptr_t)h) & 3) || !w || !nnz9 || !part) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd_stash(3x3): geometry not covered");
+    K3fParams& p = pl.p;
+    p.x = (const char*)x; p.w = w; p.nnz9 = nnz9; p.h = h; p.part = part;
+    mn_set_last_kernel("k_k3s_fwd");
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(nx + ny); }
+    mn_prof_begin(s);
+    raise_lds_limit((const void*)k_k3s_fwd, pl.lds);
+    hipLaunchKernelGGL(k_k3s_fwd, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qconv_bnsign_fwd_stash(3x3)");
     return MN_OK;
 }

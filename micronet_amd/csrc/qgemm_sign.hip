@@ -1123,14 +1123,17 @@ extern "C" int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq,
 // pointwise blocks.  fp32 y is never written or read: 1 + 1 + 2 bytes per element instead of 4 + 4 + 5.
 // nnz9[3 rc + cc][o]: non-zero weights of row o among the taps that lie inside the image for a pixel of row class rc (0 top: r >= 1,
 // 1 middle, 2 bottom: r <= 1) and column class cc (same with s) -- 3 x 3, padding 1.  One wave per output channel.
-__global__ __launch_bounds__(64) void k_row_nnz9(const float* __restrict__ w, int Cg, int O, float* __restrict__ nnz9) {
+__global__ __launch_bounds__(64) void k_row_nnz9(const float* __restrict__ w, int Cg, int O, float* __restrict__ nnz9, float* __restrict__ alpha) {
     const int o = blockIdx.x, lane = threadIdx.x;
     int cnt[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) cnt[k] = 0;
+    float amax = 0.f;                          // alpha[o]: the magnitude of the row's non-zero weights (ternary / binary rows)
     for (int k = lane; k < Cg * 9; k += 64) {
         const int tap = k % 9, r = tap / 3, s_ = tap - 3 * r;
-        const int nzv = w[(int64_t)o * Cg * 9 + k] != 0.f;
+        const float wv = w[(int64_t)o * Cg * 9 + k];
+        amax = fmaxf(amax, fabsf(wv));
+        const int nzv = wv != 0.f;
 #pragma unroll
         for (int rc = 0; rc < 3; ++rc)
 #pragma unroll
@@ -1145,6 +1148,11 @@ __global__ __launch_bounds__(64) void k_row_nnz9(const float* __restrict__ w, in
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) c += __shfl_xor(c, sft, 64);
         if (lane == 0) nnz9[(int64_t)k * O + o] = (float)c;
+    }
+    if (alpha) {
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) amax = fmaxf(amax, __shfl_xor(amax, sft, 64));
+        if (lane == 0) alpha[o] = amax;
     }
 }
 // chan row 7 = -1: "the nnz of this block is per pixel class, rows 8..16" (stash_nnz_load, common.h)
@@ -1230,10 +1238,13 @@ static int h_splits(int C) { int S = 2048 / (C > 0 ? C : 1); return S < 1 ? 1 : 
 static int kxk_out(int in, int k, int s_, int pd, int d) { return (in + 2 * pd - d * (k - 1) - 1) / s_ + 1; }
 static int64_t kxk_stash_ws(const mn_conv_geom* g, int64_t* off_nnz, int64_t* off_part) {
     const int64_t a = (kk_h8_ws_bytes(g) + 255) / 256 * 256;
-    const int64_t b = ((int64_t)g->O * 9 * 4 + 255) / 256 * 256;
+    const int64_t b = ((int64_t)g->O * 10 * 4 + 255) / 256 * 256;          // nnz9 [9][O] + alpha [O]
     if (off_nnz) *off_nnz = a;
     if (off_part) *off_part = a + b;
-    return a + b + (int64_t)h_splits(g->O) * g->groups * kk_h8_mpad(g) * 2 * 8;
+    int64_t rows = (int64_t)h_splits(g->O) * g->groups * kk_h8_mpad(g);
+    const int64_t rows3 = (int64_t)512 * (g->O / g->groups + 1);                // k_k3s_fwd: at most 512 blocks x Mg partial rows
+    if (rows3 > rows) rows = rows3;
+    return a + b + rows * 2 * 8;
 }
 static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
                                       const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var, int64_t* nbt,
@@ -1247,7 +1258,31 @@ static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
     double* part = (double*)((char*)ws + off_part);
     const int Cg = g->C / g->groups, Mg = g->O / g->groups, S = h_splits(g->O);
     const int Ho = kxk_out(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = kxk_out(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
-    hipLaunchKernelGGL(k_row_nnz9, dim3((unsigned)g->O), dim3(64), 0, s, w, Cg, (int)g->O, nnzf);
+    float* alphaf = nnzf + 9 * (int64_t)g->O;
+    hipLaunchKernelGGL(k_row_nnz9, dim3((unsigned)g->O), dim3(64), 0, s, w, Cg, (int)g->O, nnzf, alphaf);
+    const int Hs = kxk_out(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Ws = kxk_out(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
+    if (k3s_fwd_supported(g, wq)) {
+        // staged-image kernel: conv -> h and the statistics partials in one launch, no weight pack; then constants + sign
+        int rc3 = 0;
+        rc3 = k3s_fwd_h8(g, wq, x, w, nnzf, h, part, s);
+        if (rc3) return rc3;
+        hipLaunchKernelGGL(k_pws_stats_prep, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)part, k3s_fwd_parts(g, wq), (int)g->groups, Mg, Mg,
+                           (const float*)alphaf, bias, (double)g->N * Hs * Ws, eps, momentum, training, running_mean, running_var, save, (int)g->O,
+                           Cg * 9, 0, (const uint16_t*)nullptr, gamma, beta, chan, (const float*)nnzf, (long long*)nbt);
+        HGeom hg3;
+        hg3.C = g->O; hg3.H = Hs; hg3.W4 = Ws / 4; hg3.HW = Hs * Ws; hg3.HW4 = hg3.HW / 4; hg3.Mr = Mg; hg3.Mpad = Mg; hg3.G = g->groups;
+        hg3.fd_hw4 = make_fastdiv((uint32_t)hg3.HW4); hg3.fd_w4 = make_fastdiv((uint32_t)hg3.W4); hg3.n4 = (int64_t)g->N * hg3.HW4;
+        const bool v4 = hg3.HW % 16 == 0 && !(((uintptr_t)h) & 15) && !(((uintptr_t)a) & 15);
+        hg3.fd_hwv = make_fastdiv((uint32_t)(v4 ? hg3.HW4 / 4 : hg3.HW4));
+        mn_set_last_kernel("k_h_sign");
+        mn_prof_bytes(2.0 * (double)g->N * g->O * hg3.HW);
+        mn_prof_begin(s);
+        if (v4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, (const float*)chan, (char*)a);
+        else hipLaunchKernelGGL(k_h_sign<1>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, (const float*)chan, (char*)a);
+        mn_prof_end(s);
+        MN_CHECK_LAUNCH("mn_qconv_bnsign_fwd_stash(3x3)");
+        return MN_OK;
+    }
     KkH8Info info;
     int rc = kk_fwd_h8(g, wq, x, w, nnzf, h, ws, off_nnz, s, &info);
     if (rc) return rc;
