@@ -251,6 +251,16 @@ __device__ __forceinline__ void stash_nnz_quad(const StashNnz& z, int row, int c
     nz[0] = m1 + lf * (m0 - m1); nz[1] = m1; nz[2] = m1; nz[3] = m1 + rt * (m2 - m1);
 }
 
+// nnz of one pixel (row, col) of an H x W plane
+__device__ __forceinline__ float stash_nnz_px(const StashNnz& z, int row, int col, int H, int W) {
+    const float top = row == 0 ? 1.f : 0.f, bot = row == H - 1 ? 1.f : 0.f;
+    const float m0 = z.v3 + top * (z.v0 - z.v3) + bot * (z.v6 - z.v3);
+    const float m1 = z.v4 + top * (z.v1 - z.v4) + bot * (z.v7 - z.v4);
+    const float m2 = z.v5 + top * (z.v2 - z.v5) + bot * (z.v8 - z.v5);
+    const float lf = col == 0 ? 1.f : 0.f, rt = col == W - 1 ? 1.f : 0.f;
+    return m1 + lf * (m0 - m1) + rt * (m2 - m1);
+}
+
 // logical -> physical channel through a channel shuffle with `sg` groups over C channels (identity when sg <= 1)
 struct ChanMap { int sg, cps; FastDiv fd_sg; };
 static inline ChanMap make_chanmap(int sg, int C) {

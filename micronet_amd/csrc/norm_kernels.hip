@@ -552,6 +552,50 @@ __global__ __launch_bounds__(256) void k_bnh_partial(const BnhGeom g, const floa
     s2 = block_reduce(s2, OpAddD(), 0.0, scd);
     if (threadIdx.x == 0) { part[((int64_t)c * S + sp) * 2] = s1; part[((int64_t)c * S + sp) * 2 + 1] = s2; }
 }
+// The pooled partial sums visit every 2x2 WINDOW once instead of every element: only the window's first maximum receives gradient, so
+// a thread takes four windows of one pooled row (a float4 of the pooled gradient, 8 codes and 8 stash bytes of each of the two image rows:
+// five loads for 16 elements instead of sixteen) and evaluates the clip mask / zhat for the four receiving pixels only.  W % 8 == 0.
+__global__ __launch_bounds__(256) void k_bnh_partial_pool(const BnhGeom g, const float* __restrict__ da, const unsigned char* __restrict__ h,
+                                                          const char* __restrict__ own, const float* __restrict__ chan, double* __restrict__ part) {
+    __shared__ double scd[16];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
+    const float fl = chan[C + c], L = chan[2 * C + c], U = chan[3 * C + c], A = chan[4 * C + c], B = chan[5 * C + c];
+    const StashNnz zn = stash_nnz_load(chan, C, c);
+    const int W8 = g.W >> 3, Hh = g.H >> 1;
+    const int64_t npq = (int64_t)g.N * Hh * W8;                 // pooled quads of this channel
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < npq; i += (int64_t)S * 256) {
+        const int64_t t = i / W8;
+        const int q = (int)(i - t * W8);
+        const int64_t n = t / Hh;
+        const int pr = (int)(t - n * Hh);
+        const int64_t plane = n * C + c;
+        const float4 g4 = *reinterpret_cast<const float4*>(da + plane * (g.HW >> 2) + (int64_t)pr * (g.W >> 1) + 4 * q);
+        const int64_t e0 = plane * g.HW + (int64_t)(2 * pr) * g.W + 8 * q;
+        const uint64_t o0 = *reinterpret_cast<const uint64_t*>(own + e0), o1 = *reinterpret_cast<const uint64_t*>(own + e0 + g.W);
+        const uint64_t h0 = *reinterpret_cast<const uint64_t*>(h + e0), h1 = *reinterpret_cast<const uint64_t*>(h + e0 + g.W);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {       // first maximum of the window in row-major order (ATen): the first +1, else element 0
+            const bool p00 = !((o0 >> (16 * w)) & 0x80u), p01 = !((o0 >> (16 * w + 8)) & 0x80u);
+            const bool p10 = !((o1 >> (16 * w)) & 0x80u), p11 = !((o1 >> (16 * w + 8)) & 0x80u);
+            const bool lower = !p00 && !p01 && (p10 || p11);
+            const bool right = p00 ? false : (p01 ? true : (p10 ? false : p11));
+            const uint64_t hr = lower ? h1 : h0;
+            const float hv = (float)((uint32_t)(hr >> (16 * w + (right ? 8 : 0))) & 0xffu);
+            const float acc = 2.f * hv - stash_nnz_px(zn, 2 * pr + (lower ? 1 : 0), 8 * q + 2 * w + (right ? 1 : 0), g.H, g.W);
+            const float u = acc * fl;
+            const float dz = (u >= L && u <= U) ? gv[w] : 0.f;
+            t1 += dz;
+            t2 += dz * fmaf(acc, A, B);
+        }
+        s1 += (double)t1; s2 += (double)t2;
+    }
+    s1 = block_reduce(s1, OpAddD(), 0.0, scd);
+    s2 = block_reduce(s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { part[((int64_t)c * S + sp) * 2] = s1; part[((int64_t)c * S + sp) * 2 + 1] = s2; }
+}
 template <int POOL>
 __global__ __launch_bounds__(256) void k_bnh_apply(const BnhGeom g, const float* __restrict__ da, const unsigned char* __restrict__ h,
                                                    const char* __restrict__ own, const float* __restrict__ chan, const float* __restrict__ sums,
@@ -603,7 +647,10 @@ extern "C" int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* 
     const int S = bnh_split(g);
     const double nel = (double)N * C * H * W;
     mn_set_last_kernel(own ? "k_bnh_partial<1>" : "k_bnh_partial<0>"); mn_prof_bytes((own ? 3.0 : 5.0) * nel); mn_prof_begin(s);
-    if (own) hipLaunchKernelGGL(k_bnh_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, (double*)ws);
+    // pooled fast path: W % 8 == 0, 8-byte aligned rows
+    const bool pool_fast = own && W % 8 == 0 && !(((uintptr_t)h) & 7) && !(((uintptr_t)own) & 7) && !(((uintptr_t)da) & 15) && !getenv("MN_NO_BNH_POOLFAST");
+    if (pool_fast) hipLaunchKernelGGL(k_bnh_partial_pool, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, (double*)ws);
+    else if (own) hipLaunchKernelGGL(k_bnh_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, (double*)ws);
     else hipLaunchKernelGGL(k_bnh_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)nullptr, chan, (double*)ws);
     mn_prof_end(s);
     const BnsGeom bg = bns_geom(N, C, H * W);

@@ -503,7 +503,9 @@ static int plan_k3d(const mn_conv_geom* g, const mn_wq* wq, K3dPlan* pl) {
     p.nstages = (g->N + NI - 1) / NI;
     p.ncb = (Cg + 15) / 16;
     const int base = p.G * p.ncb;
-    int Zb = 512 / base;
+    int tgt = 512;
+    if (const char* e = getenv("MN_K3D_BLOCKS")) { const int v = atoi(e); if (v >= 32 && v <= 8192) tgt = v; }     // tuning knob
+    int Zb = tgt / base;
     if (Zb > p.nstages) Zb = p.nstages;
     if (Zb < 1) Zb = 1;
     p.Zb = Zb;
@@ -752,7 +754,9 @@ static int plan_k3f(const mn_conv_geom* g, const mn_wq* wq, K3fPlan* pl) {
     if (pl->lds < (size_t)Mg * Cg * 9 * 4) pl->lds = (size_t)Mg * Cg * 9 * 4;          // the prologue's weight image
     if (pl->lds > 64 * 1024) return 0;
     p.nstages = (g->N + NI - 1) / NI;
-    int Zb = 512 / p.G;
+    int tgt = 512;
+    if (const char* e = getenv("MN_K3F_BLOCKS")) { const int v = atoi(e); if (v >= 32 && v <= 512) tgt = v; }      // tuning knob (the workspace is sized for 512)
+    int Zb = tgt / p.G;
     if (Zb > p.nstages) Zb = p.nstages;
     if (Zb < 1) Zb = 1;
     p.Zb = Zb;
