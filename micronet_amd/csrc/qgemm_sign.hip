@@ -730,12 +730,15 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
 
     struct Stage { float4 gv[RPT]; uint32_t hv[RPT]; u32x4 cv; };
     Stage s0, s1;
-    const int st0 = z * p.st_per_z;
-    const int n = ((st0 + p.st_per_z) < p.nsteps ? (st0 + p.st_per_z) : p.nsteps) - st0;
+    // contiguous ranges (st_stride == 1) or interleaved: block z takes steps z, z + Z, ... -- neighbouring blocks then read neighbouring
+    // 128-byte pieces of the same rows at about the same time (DRAM page locality)
+    const int st0 = p.st_stride == 1 ? z * p.st_per_z : z;
+    const int n = p.st_stride == 1 ? (((st0 + p.st_per_z) < p.nsteps ? (st0 + p.st_per_z) : p.nsteps) - st0)
+                                   : (st0 < p.nsteps ? (p.nsteps - st0 + p.st_stride - 1) / p.st_stride : 0);
     // loads are unconditional (a conditional load makes the register set a phi: copies, and a vmcnt(0) right behind the issue):
     // steps past the block's range re-read the last step of the tensor and are never contracted
     auto fetch = [&](Stage& S, int k) {
-        int st = st0 + k;
+        int st = st0 + k * p.st_stride;
         st = st < p.nsteps ? st : p.nsteps - 1;
         const uint32_t P = (uint32_t)st * 32u + 4u * sq;
         const uint32_t ni = fd_div(P, p.fd_hw);
@@ -881,7 +884,7 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     p.st_per_z = (p.nsteps + Z - 1) / Z; p.st_stride = 1;     // contiguous pixel ranges: each block streams its gy rows sequentially
     if (getenv("MN_WG2_STRIDED")) { p.st_stride = Z; }
     // LDS-staged kernel: 16-byte code loads need HW % 16 == 0; MN_WG2_DIRECT=1 keeps the direct-load kernel (A/B knob)
-    pl->staged = p.HW % 16 == 0 && !pl->CW8 && p.st_stride == 1 && !getenv("MN_WG2_DIRECT");
+    pl->staged = p.HW % 16 == 0 && !pl->CW8 && !getenv("MN_WG2_DIRECT");
     p.fd_hw = make_fastdiv((uint32_t)p.HW);
     const int64_t nb = (int64_t)base * Z;
     if (nb > 0x7fffffff) return 0;
