@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
-    unsigned char* gsm = reinterpret_cast<unsigned char*>(smem) + p.xs_bytes + wave * (16 * MT * C1_RSA);
+    unsigned char* gsm = reinterpret_cast<unsigned char*>(smem) + p.xs_bytes + wave * (16 * MT * (C1_RSA + 32));
+    float* ctab = reinterpret_cast<float*>(gsm + 16 * MT * C1_RSA);       // BN: [16 MT rows][8] = mean, invstd, gamma, beta, k1, k2 (kept out of the register file)
     uint32_t b = blockIdx.x;
     const int z = b % p.Z;
     const int cblk = b / p.Z;
@@ -175,18 +176,24 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
     constexpr int NR = 2 * MT;
     const int sr = lane >> 3, sq = lane & 7;
     uint32_t roff[NR];          // element offset of the lane's quad inside image 0 / strip 0 (planner: the tensor has < 2^31 elements)
-    float cmean[NR], cinv[NR], cga[NR], cbe[NR], ck1[NR], ck2[NR], dbs[NR];
+    float dbs[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int m = m0 + sr + 8 * i;
         const int mc = m < p.O ? m : p.O - 1;              // rows beyond O: clamped, their dw rows are never read
         roff[i] = (uint32_t)mc * (uint32_t)(p.H * p.W) + 4u * sq;
         dbs[i] = 0.f;
-        if (BN) {
-            cmean[i] = p.save[mc]; cinv[i] = p.save[p.O + mc]; cga[i] = p.gamma[mc]; cbe[i] = p.beta[mc];
-            ck1[i] = p.training ? p.sums[mc] / p.n_f : 0.f;
-            ck2[i] = p.training ? p.sums[p.O + mc] / p.n_f : 0.f;
+    }
+    if (BN) {
+        for (int r = lane; r < 16 * MT; r += 64) {
+            const int m = m0 + r;
+            const int mc = m < p.O ? m : p.O - 1;
+            ctab[r * 8 + 0] = p.save[mc]; ctab[r * 8 + 1] = p.save[p.O + mc]; ctab[r * 8 + 2] = p.gamma[mc]; ctab[r * 8 + 3] = p.beta[mc];
+            ctab[r * 8 + 4] = p.training ? p.sums[mc] / p.n_f : 0.f;
+            ctab[r * 8 + 5] = p.training ? p.sums[p.O + mc] / p.n_f : 0.f;
+            ctab[r * 8 + 6] = 0.f; ctab[r * 8 + 7] = 0.f;
         }
+        MN_WAVE_SYNC();
     }
     f32x4 acc[MT][5];
 #pragma unroll
@@ -217,13 +224,15 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
                 float r[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
                 if (BN) {
                     const float yv[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
-                    const float cgi_ = cga[i] * cinv[i];
+                    const float4 c0 = *reinterpret_cast<const float4*>(ctab + (sr + 8 * i) * 8);        // mean, invstd, gamma, beta
+                    const float2 c1 = *reinterpret_cast<const float2*>(ctab + (sr + 8 * i) * 8 + 4);    // k1, k2
+                    const float cgi_ = c0.z * c0.y;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float zh = (yv[e] - cmean[i]) * cinv[i];
-                        const float zz = zh * cga[i] + cbe[i];
+                        const float zh = (yv[e] - c0.x) * c0.y;
+                        const float zz = zh * c0.z + c0.w;
                         const float dz = (zz > -1.f && zz < 1.f) ? r[e] : 0.f;
-                        r[e] = cgi_ * (dz - ck1[i] - zh * ck2[i]);
+                        r[e] = cgi_ * (dz - c1.x - zh * c1.y);
                     }
                 }
                 dbs[i] += (r[0] + r[1]) + (r[2] + r[3]);
@@ -343,8 +352,8 @@ static int plan_c1(const mn_conv_geom* g, C1Plan* pl, int which = 0) {
     p.PR = R + g->KH - 1; p.PW = g->W + g->KW - 1 + 3;     // + 3: the 4-wide reads of the last pixel quad stay inside the row
     p.CS = p.PR * p.PW;
     p.xs_bytes = (int)(((size_t)g->C * p.CS * 4 + 64 + 15) / 16 * 16);
-    pl->lds = (size_t)p.xs_bytes + (size_t)4 * 16 * pl->MT * C1_RSA;          // forward uses the patch only
-    if (pl->lds > 64 * 1024) return 0;
+    pl->lds = (size_t)p.xs_bytes + (size_t)4 * 16 * pl->MT * (C1_RSA + 32);   // forward uses the patch only
+    if (pl->lds > 80 * 1024) return 0;          // two blocks per CU
     p.fd_w = make_fastdiv((uint32_t)g->W);
     const int64_t nbf = (int64_t)g->N * p.strips * pl->cblks;
     if (nbf > 0x7fffffff) return 0;

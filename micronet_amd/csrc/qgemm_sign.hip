@@ -708,14 +708,24 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     const int sr = tid >> 3, sq = tid & 7, cr = tid >> 1, chf = tid & 1;
     const bool cdo = TC >= 128 || cr < TC;
     uint32_t goff[RPT], xoff;
-    float f_hlo[RPT], f_hhi[RPT], f_G[RPT], f_E1[RPT], f_E0[RPT], dbacc[RPT];
+    float dbacc[RPT];
+    __shared__ __attribute__((aligned(16))) float ftab[BNH ? TM * 8 : 8];      // BNH: the per-row fold (hlo, hhi, G, E1, E0), kept out of the register file
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         int m = mb * TM + sr + 32 * i;
         m = m < p.Mg ? m : p.Mg - 1;
         goff[i] = (uint32_t)(g * p.Mg + m) * HW;
         dbacc[i] = 0.f;
-        if (BNH) bnh_fold(p.chan, p.sums, p.Cout_total, g * p.Mg + m, p.training, p.n_f, 1.f, f_hlo[i], f_hhi[i], f_G[i], f_E1[i], f_E0[i]);
+    }
+    if (BNH) {
+        for (int r = tid; r < TM; r += 256) {
+            int m = mb * TM + r;
+            m = m < p.Mg ? m : p.Mg - 1;
+            float hlo, hhi, G_, E1, E0;
+            bnh_fold(p.chan, p.sums, p.Cout_total, g * p.Mg + m, p.training, p.n_f, 1.f, hlo, hhi, G_, E1, E0);
+            ftab[r * 8 + 0] = hlo; ftab[r * 8 + 1] = hhi; ftab[r * 8 + 2] = G_; ftab[r * 8 + 3] = E1; ftab[r * 8 + 4] = E0;
+        }
+        // visible after the first __syncthreads below (before any commit)
     }
     {
         int c = cb * TC + (cdo ? cr : 0);
@@ -761,11 +771,13 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
         for (int i = 0; i < RPT; ++i) {
             float v[4] = {S.gv[i].x, S.gv[i].y, S.gv[i].z, S.gv[i].w};
             if (BNH) {
+                const float4 f0 = *reinterpret_cast<const float4*>(ftab + (sr + 32 * i) * 8);        // hlo, hhi, G, E1
+                const float fE0 = ftab[(sr + 32 * i) * 8 + 4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float hf = (float)((S.hv[i] >> (8 * e)) & 0xffu);
-                    const float dz = (hf >= f_hlo[i] && hf <= f_hhi[i]) ? v[e] : 0.f;
-                    v[e] = fmaf(f_G[i], dz, fmaf(f_E1[i], hf, f_E0[i]));
+                    const float dz = (hf >= f0.x && hf <= f0.y) ? v[e] : 0.f;
+                    v[e] = fmaf(f0.z, dz, fmaf(f0.w, hf, fE0));
                 }
             }
             dbacc[i] += valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
@@ -823,6 +835,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     };
     fetch(s0, 0);
     fetch(s1, 1);
+    if (BNH) __syncthreads();                 // the fold table
     commit(s0, 0, n > 0);
     fetch(s0, 2);
     __syncthreads();
