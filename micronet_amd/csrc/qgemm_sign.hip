@@ -27,6 +27,7 @@
 // wave's next chunk are prefetched into the registers of each K-step as soon as that step's fragments are built.
 #include "qgemm_dev.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #define PWS_Y 0
@@ -877,6 +878,7 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (NP % 32 || Mg < 33 || Cg < 33) return 0;           // small tiles stay on the LDS-staged kernel
     Wg2Params& p = pl->p;
     pl->MW = (Mg > 64 || Cg > 64) ? 4 : 2;
+    if (const char* e = getenv("MN_WG2_MW")) { const int v = atoi(e); if (v == 2 || v == 4) pl->MW = v; }   // tuning knob
     pl->CW8 = 0;
     if (const char* e = getenv("MN_WG2_CW8")) pl->CW8 = atoi(e) != 0 && pl->MW == 4;   // tuning knob: 4 x 1 waves of 32 x 128
     const int T = 32 * pl->MW;
@@ -894,6 +896,7 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (Z > p.nsteps / 2) Z = p.nsteps / 2;
     if (Z < 1) Z = 1;
     p.Z = Z;
+    if (getenv("MN_DEBUG_PLAN")) fprintf(stderr, "plan_pws_wgrad: nsteps %d base %d Z %d MW %d\n", p.nsteps, base, Z, pl->MW);
     p.st_per_z = (p.nsteps + Z - 1) / Z; p.st_stride = 1;     // contiguous pixel ranges: each block streams its gy rows sequentially
     if (getenv("MN_WG2_STRIDED")) { p.st_stride = Z; }
     // LDS-staged kernel: 16-byte code loads need HW % 16 == 0; MN_WG2_DIRECT=1 keeps the direct-load kernel (A/B knob)
