@@ -123,6 +123,14 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
         for (int c = tid; c < p.Kp; c += 256) coff[c] = (uint32_t)chan_phys(p.in_map, g * p.Kc + (c < p.Kc ? c : p.Kc - 1)) * HW;
     }
     __syncthreads();
+    if (EPI == PWS_STATS && p.h8) {          // the statistics pass also writes the byte stash: nnz[row] from the staged codes (4 threads per row)
+        const int row = tid >> 2, part = tid & 3;
+        int cnt = 0;
+        if (row < MB) for (int k = part; k < p.Kp; k += 4) cnt += (wsm[row * LDW + k] & 0x7fffu) != 0;
+        cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 1, 64);
+        if (row < MB && part == 0) c2[row] = (float)cnt;
+        __syncthreads();
+    }
 
     const int chunk0 = cb * 4 + wave, cstride = p.CB * 4;
     const uint16_t* wl = wsm + j * LDW + kg * 8;
@@ -255,6 +263,11 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                     if (ok) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { s1[t][r] += o[e]; s2[t][r] += o[e] * o[e]; }      // exact: integers below 2^24
+                        if (p.h8) {          // byte stash written by the statistics pass: the sign then is a streaming pass over h (k_h_sign)
+                            const float nz = c2[ml];
+                            *reinterpret_cast<uint32_t*>(p.h8 + off) = (uint32_t)((o[0] + nz) * 0.5f) | ((uint32_t)((o[1] + nz) * 0.5f) << 8) |
+                                                                       ((uint32_t)((o[2] + nz) * 0.5f) << 16) | ((uint32_t)((o[3] + nz) * 0.5f) << 24);
+                        }
                     }
                 } else if (EPI == PWS_Y) {
                     const float a_ = c0[ml], b_ = c1[ml];
@@ -1088,6 +1101,7 @@ static int pws_bn_ok(const mn_conv_geom* g, const mn_wq* wq) { return g && wq &&
 extern "C" int mn_qconv_bnsign_supported(const mn_conv_geom* g, const mn_wq* wq) { return pws_bn_ok(g, wq); }
 extern "C" int64_t mn_qconv_bnsign_ws_bytes(const mn_conv_geom* g) { return g ? pws_ws_bytes(g) : -1; }
 
+static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s);
 static void pws_chan_prep(PwsPlan& pl, const mn_conv_geom* g, const float* bias, const float* save, const float* gamma, const float* beta, hipStream_t s) {
     hipLaunchKernelGGL(k_pws_chan_prep, dim3((unsigned)g->O), dim3(64), 0, s, pl.p.Kc, pl.p.Kp, pl.p.wc, pl.p.G, pl.p.Mpad, pl.p.Mr, pl.p.rowscale, bias, save, gamma, beta,
                        (float*)pl.p.chan, (int)g->O);
@@ -1106,11 +1120,14 @@ static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const i
     PwsParams& p = pl.p;
     p.bias = bias;
     const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
-    if (training && (rc = launch_pws<PWS_STATS>(pl, s, nx, "mn_qconv_bnsign_fwd(stats)"))) return rc;
+    const bool stash_in_stats = training && h && !getenv("MN_NO_STATS_H");      // one MFMA pass instead of two: h from the statistics pass, sign streamed from h
+    p.h8 = stash_in_stats ? h : nullptr;
+    if (training && (rc = launch_pws<PWS_STATS>(pl, s, nx + (stash_in_stats ? ny : 0.0), "mn_qconv_bnsign_fwd(stats)"))) return rc;
     if (chan_out) p.chan = chan_out;                     // caller-owned [8][O]: kept for the streaming backward (mn_bnh_bwd)
     hipLaunchKernelGGL(k_pws_stats_prep, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, bias,
                        (double)g->N * p.HW, eps, momentum, training, running_mean, running_var, save, (int)g->O, p.Kc, p.Kp, p.wc, gamma, beta,
                        (float*)p.chan, (const float*)nullptr, (long long*)nbt);
+    if (stash_in_stats) return h_sign_launch(g->N, g->O, g->H, g->W, h, (const float*)p.chan, a, s);
     p.a8 = (char*)a; p.h8 = h;
     return launch_pws<PWS_SIGN8>(pl, s, nx + (h ? 2.0 : 1.0) * ny, "mn_qconv_bnsign_fwd(sign)");
 }
@@ -1254,6 +1271,22 @@ __global__ __launch_bounds__(256) void k_h_sign(const HGeom g, const unsigned ch
     }
 }
 static int h_splits(int C) { int S = 2048 / (C > 0 ? C : 1); return S < 1 ? 1 : (S > 64 ? 64 : S); }
+static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s) {
+    HGeom hg;
+    hg.C = (int)O; hg.H = (int)H; hg.W4 = (int)(W / 4); hg.HW = (int)(H * W); hg.HW4 = hg.HW / 4; hg.Mr = 1; hg.Mpad = 1; hg.G = 1;
+    hg.fd_hw4 = make_fastdiv((uint32_t)hg.HW4); hg.fd_w4 = make_fastdiv((uint32_t)hg.W4); hg.n4 = N * hg.HW4;
+    const bool v4 = hg.HW % 16 == 0 && !(((uintptr_t)h) & 15) && !(((uintptr_t)a) & 15);
+    hg.fd_hwv = make_fastdiv((uint32_t)(v4 ? hg.HW4 / 4 : hg.HW4));
+    const int S = h_splits((int)O);
+    mn_set_last_kernel("k_h_sign");
+    mn_prof_bytes(2.0 * (double)N * O * hg.HW);
+    mn_prof_begin(s);
+    if (v4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, chan, (char*)a);
+    else hipLaunchKernelGGL(k_h_sign<1>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, chan, (char*)a);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qconv_bnsign_fwd_stash(sign from h)");
+    return MN_OK;
+}
 static int kxk_out(int in, int k, int s_, int pd, int d) { return (in + 2 * pd - d * (k - 1) - 1) / s_ + 1; }
 static int64_t kxk_stash_ws(const mn_conv_geom* g, int64_t* off_nnz, int64_t* off_part) {
     const int64_t a = (kk_h8_ws_bytes(g) + 255) / 256 * 256;
