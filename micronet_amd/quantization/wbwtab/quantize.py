@@ -146,6 +146,13 @@ class WeightQuantizer(nn.Module):
         return Ternary.apply(input)
 
     def forward(self, input):
+        pre = self.__dict__.pop("_mn_pre", None)
+        if pre is not None and pre[0] is input:
+            # computed ahead on a side stream (micronet_amd.train.prefetch_weight_path): wait for it here, keep its memory alive for this stream
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pre[2])
+            pre[1].record_stream(cur)
+            return pre[1]
         if self.W == 2:
             return ops.BinaryWeight.apply(input)     # mutates input.data like the reference (ref 123)
         if self.W == 3:
