@@ -80,6 +80,12 @@ int mn_binact_bwd(const float* g, const float* x, float* dx, int64_t n, mn_strea
 int mn_ternary_w_fwd(const float* w, float* qw, float* stats, int64_t O, int64_t K, mn_stream_t stream);
 int mn_ternary_w_bwd(const float* g, const float* w, const float* stats, float* dw, int64_t O, int64_t K,
                      mn_stream_t stream);
+/* The same quantizer over n <= 32 weight tensors in ONE launch (host arrays of device pointers / row counts / row lengths; nothing is
+ * allocated, graph-capturable): a training step quantizes every conv's weights, each call above is a ~5 us launch. */
+int mn_ternary_w_fwd_multi(const float* const* w, float* const* qw, float* const* stats, const int64_t* O, const int64_t* K, int32_t n,
+                           mn_stream_t stream);
+int mn_ternary_w_bwd_multi(const float* const* g, const float* const* w, float* const* stats, float* const* dw, const int64_t* O, const int64_t* K,
+                           int32_t n, mn_stream_t stream);
 /* WeightQuantizer W==2 branch 121-130 incl. meancenter_clamp_convparams 98-102, which
  * MUTATES w in place (w -= mean over the Cin axis; clamp to [-1,1]).  w: [O][C][R] with R = kh*kw.
  * alpha: [O] written by fwd, read by bwd. */

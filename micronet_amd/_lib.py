@@ -64,6 +64,8 @@ PROTOTYPES = {
     "mn_binact_bwd": (_I, [_P, _P, _P, _L, _P]),
     "mn_ternary_w_fwd": (_I, [_P, _P, _P, _L, _L, _P]),
     "mn_ternary_w_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P]),
+    "mn_ternary_w_fwd_multi": (_I, [_P, _P, _P, _P, _P, C.c_int32, _P]),
+    "mn_ternary_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "mn_binary_w_fwd": (_I, [_P, _P, _P, _L, _L, _L, _P]),
     "mn_binary_w_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P]),
     "mn_iao_observe_ws_floats": (_L, [_L, _L]),

@@ -376,6 +376,93 @@ __global__ __launch_bounds__(256) void k_ternary_w_bwd(const float* __restrict__
         dw[off + i] = d;
     }
 }
+// The same two kernels over SEVERAL weight tensors in one launch (a step of nin_gc quantizes 7 of them: 7 + 7 launches of ~5 us otherwise).
+// The tensor table travels by value in the kernel arguments: nothing is allocated, the launch is graph-capturable.
+#define MN_TERN_MAXT 32
+struct TernTable {
+    const float* w[MN_TERN_MAXT];
+    const float* g[MN_TERN_MAXT];      // backward: upstream gradient
+    float* out[MN_TERN_MAXT];          // forward: qw; backward: dw
+    float* stats[MN_TERN_MAXT];
+    int K[MN_TERN_MAXT];
+    int row_end[MN_TERN_MAXT];         // cumulative row count
+    int n;
+};
+template <int BWD>
+__global__ __launch_bounds__(256) void k_ternary_w_multi(const TernTable t) {
+    __shared__ double scd[16];
+    int ti = 0;
+    while (ti + 1 < t.n && (int)blockIdx.x >= t.row_end[ti]) ++ti;
+    const int row = (int)blockIdx.x - (ti ? t.row_end[ti - 1] : 0);
+    const int64_t K = t.K[ti];
+    const float* wr = t.w[ti] + (int64_t)row * K;
+    float* orow = t.out[ti] + (int64_t)row * K;
+    float* st = t.stats[ti] + (int64_t)row * 4;
+    if (!BWD) {
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < K; i += blockDim.x) s += (double)fabsf(wr[i]);
+        s = block_reduce(s, OpAddD(), 0.0, scd);
+        const float E = (float)s / (float)K;
+        const float thr = E * 0.7f;
+        double sa = 0.0, sc = 0.0;
+        for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+            float a = fabsf(wr[i]);
+            if (a > thr) { sa += (double)a; sc += 1.0; }
+        }
+        sa = block_reduce(sa, OpAddD(), 0.0, scd);
+        sc = block_reduce(sc, OpAddD(), 0.0, scd);
+        const float ssum = (float)sa, cnt = (float)sc;
+        const float alpha = ssum / cnt;
+        for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+            float v = wr[i];
+            float tt = mn_sign(mn_sign(v + thr) + mn_sign(v - thr));
+            orow[i] = tt * alpha;
+        }
+        if (threadIdx.x == 0) { st[0] = alpha; st[1] = thr; st[2] = cnt; st[3] = ssum; }
+    } else {
+        const float* gr = t.g[ti] + (int64_t)row * K;
+        const float alpha = st[0], thr = st[1], cnt = st[2];
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+            float v = wr[i];
+            float tt = mn_sign(mn_sign(v + thr) + mn_sign(v - thr));
+            s += (double)(gr[i] * tt);
+        }
+        s = block_reduce(s, OpAddD(), 0.0, scd);
+        const float share = (float)s / cnt;
+        for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+            float v = wr[i];
+            float d = gr[i] * alpha;
+            if (fabsf(v) > thr) d += mn_sign(v) * share;
+            orow[i] = d;
+        }
+    }
+}
+static int ternary_multi(int bwd, const float* const* w, const float* const* g, float* const* out, float* const* stats, const int64_t* O, const int64_t* K,
+                         int n, mn_stream_t stream, const char* what) {
+    if (n <= 0 || n > MN_TERN_MAXT || !w || !out || !stats || !O || !K || (bwd && !g)) MN_FAIL(MN_EINVAL, "%s: bad arguments (1 .. %d tensors)", what, MN_TERN_MAXT);
+    TernTable t;
+    int64_t rows = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || !out[i] || !stats[i] || (bwd && !g[i]) || O[i] <= 0 || K[i] <= 0 || K[i] > 0x7fffffff) MN_FAIL(MN_EINVAL, "%s: bad tensor %d", what, i);
+        rows += O[i];
+        if (rows > 0x7fffffff) MN_FAIL(MN_EINVAL, "%s: too many rows", what);
+        t.w[i] = w[i]; t.g[i] = bwd ? g[i] : nullptr; t.out[i] = out[i]; t.stats[i] = stats[i]; t.K[i] = (int)K[i]; t.row_end[i] = (int)rows;
+    }
+    t.n = n;
+    if (bwd) hipLaunchKernelGGL(k_ternary_w_multi<1>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t);
+    else hipLaunchKernelGGL(k_ternary_w_multi<0>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t);
+    MN_CHECK_LAUNCH(what);
+    return MN_OK;
+}
+extern "C" int mn_ternary_w_fwd_multi(const float* const* w, float* const* qw, float* const* stats, const int64_t* O, const int64_t* K, int32_t n,
+                                      mn_stream_t stream) {
+    return ternary_multi(0, w, nullptr, qw, stats, O, K, n, stream, "mn_ternary_w_fwd_multi");
+}
+extern "C" int mn_ternary_w_bwd_multi(const float* const* g, const float* const* w, float* const* stats, float* const* dw, const int64_t* O, const int64_t* K,
+                                      int32_t n, mn_stream_t stream) {
+    return ternary_multi(1, w, g, dw, stats, O, K, n, stream, "mn_ternary_w_bwd_multi");
+}
 extern "C" int mn_ternary_w_fwd(const float* w, float* qw, float* stats, int64_t O, int64_t K, mn_stream_t stream) {
     if (O <= 0 || K <= 0 || !w || !qw || !stats) MN_FAIL(MN_EINVAL, "mn_ternary_w_fwd: bad arguments");
     hipLaunchKernelGGL(k_ternary_w_fwd, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, w, qw, stats, K);

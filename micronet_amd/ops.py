@@ -206,6 +206,44 @@ class TernaryWeight(Function):
         return dw
 
 
+class MultiTernaryWeight(Function):
+    """TernaryWeight over several weight tensors in ONE launch each way (mn_ternary_w_fwd_multi / _bwd_multi): a training step quantizes
+    the weights of every conv; as separate autograd nodes those are 2 x (#layers) launches of ~5 us.  Same arithmetic per tensor."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ws = [_chk(w, "weight") for w in ws]
+        n = len(ws)
+        qws = [torch.empty_like(w) for w in ws]
+        stats = [torch.empty((w.shape[0], 4), dtype=torch.float32, device=w.device) for w in ws]
+        PA, LA = C.c_void_p * n, C.c_int64 * n
+        Os, Ks = LA(*[w.shape[0] for w in ws]), LA(*[w[0].numel() for w in ws])
+        with torch.cuda.device_of(ws[0]):
+            _call("mn_ternary_w_fwd_multi", PA(*[w.data_ptr() for w in ws]), PA(*[q.data_ptr() for q in qws]), PA(*[t.data_ptr() for t in stats]),
+                  Os, Ks, n, _s())
+        ctx.save_for_backward(*ws, *stats)
+        ctx.n = n
+        return tuple(qws)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        ws, stats = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        idx = [i for i in range(n) if gs[i] is not None]
+        dws = [None] * n
+        if idx:
+            g = [_chk(gs[i], "grad") for i in idx]
+            out = [torch.empty_like(ws[i]) for i in idx]
+            m = len(idx)
+            PA, LA = C.c_void_p * m, C.c_int64 * m
+            with torch.cuda.device_of(ws[0]):
+                _call("mn_ternary_w_bwd_multi", PA(*[t.data_ptr() for t in g]), PA(*[ws[i].data_ptr() for i in idx]), PA(*[stats[i].data_ptr() for i in idx]),
+                      PA(*[t.data_ptr() for t in out]), LA(*[ws[i].shape[0] for i in idx]), LA(*[ws[i][0].numel() for i in idx]), m, _s())
+            for k, i in enumerate(idx):
+                dws[i] = out[k]
+        return tuple(dws)
+
+
 def ternary_stats(w):
     """(qw, stats[O,4] = alpha, thr, cnt, sum) without autograd."""
     w = _chk(w.detach(), "weight")

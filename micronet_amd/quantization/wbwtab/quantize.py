@@ -148,10 +148,12 @@ class WeightQuantizer(nn.Module):
     def forward(self, input):
         pre = self.__dict__.pop("_mn_pre", None)
         if pre is not None and pre[0] is input:
-            # computed ahead on a side stream (micronet_amd.train.prefetch_weight_path): wait for it here, keep its memory alive for this stream
-            cur = torch.cuda.current_stream()
-            cur.wait_event(pre[2])
-            pre[1].record_stream(cur)
+            # computed ahead (micronet_amd.train.prefetch_weight_path: all layers in one launch, or on a side stream -- then wait for it here
+            # and keep its memory alive for this stream)
+            if pre[2] is not None:
+                cur = torch.cuda.current_stream()
+                cur.wait_event(pre[2])
+                pre[1].record_stream(cur)
             return pre[1]
         if self.W == 2:
             return ops.BinaryWeight.apply(input)     # mutates input.data like the reference (ref 123)

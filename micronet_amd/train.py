@@ -63,23 +63,36 @@ def train_step(model, optimizer, data, target):
     return loss, output
 
 
-def prefetch_weight_path(model, side):
-    """Run every W-binary / W-ternary weight quantizer of ``model`` on the stream ``side`` now; the owning conv picks the result up in its
-    forward (after waiting for it).  The quantizers depend on the parameters only, so their ~5 us launches overlap the first layers
-    instead of sitting between the big kernels; autograd runs their backward on ``side`` as well.  Join with
-    ``torch.cuda.current_stream().wait_stream(side)`` after ``backward()``."""
+def prefetch_weight_path(model, side=None):
+    """Quantize the weights of every W-ternary conv of ``model`` NOW, in one launch (ops.MultiTernaryWeight: one autograd node, so the
+    backward is one launch too); the owning conv picks its tensor up in its forward.  A step of nin_gc saves 12 launches of ~5 us.
+    ``side``: a second stream instead (one launch per layer there, overlapping the first layers; measured slower under graph replay --
+    the fork / join edges cost more than the launches they hide); join with ``torch.cuda.current_stream().wait_stream(side)`` after
+    ``backward()``."""
+    from micronet_amd import ops
     from micronet_amd.quantization.wbwtab import quantize as wb
+    mods = [m for m in model.modules() if isinstance(m, wb.QuantConv2d) and not m.quant_inference and m.weight_quantizer.W in (2, 3)]
+    for m in mods:
+        m.weight_quantizer.__dict__.pop("_mn_pre", None)
+    if side is None:
+        tern = [m for m in mods if m.weight_quantizer.W == 3 and m.weight.is_cuda and m.weight.is_contiguous()]
+        for i in range(0, len(tern), 32):
+            grp = tern[i:i + 32]
+            if len(grp) < 2:
+                continue
+            qws = ops.MultiTernaryWeight.apply(*[m.weight for m in grp])
+            for m, wq in zip(grp, qws):
+                m.weight_quantizer._mn_pre = (m.weight, wq, None)
+        return
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        for m in model.modules():
-            if isinstance(m, wb.QuantConv2d) and not m.quant_inference and m.weight_quantizer.W in (2, 3):
-                q = m.weight_quantizer
-                q.__dict__.pop("_mn_pre", None)
-                wq = q(m.weight)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                q._mn_pre = (m.weight, wq, ev)
+        for m in mods:
+            q = m.weight_quantizer
+            wq = q(m.weight)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            q._mn_pre = (m.weight, wq, ev)
 
 
 class GraphedTrainStep:
@@ -138,6 +151,8 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         import os
         side = None
+        if os.environ.get("MN_MULTI_WQ", "1") != "0" and os.environ.get("MN_WEIGHT_STREAM", "") != "1":
+            prefetch_weight_path(self.model)                     # all ternary weight quantizers of the step in one launch (and one in backward)
         if os.environ.get("MN_WEIGHT_STREAM", "") == "1":       # the weight path on a second stream: opt-in -- measured on c2: 2.68 -> 2.73 ms,
                                                                 # the fork / join edges of the captured graph cost more than the 14 tiny launches they hide
             if not hasattr(self, "_wstream"):

@@ -596,3 +596,25 @@ def check_first_conv_bn_wgrad(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, training=Tru
     be.call("mn_conv2d_bwd_weight_first_bn", C.byref(g), be.ptr(dDA), be.ptr(dY), be.ptr(dS), be.ptr(dG), be.ptr(dB), be.ptr(sums), int(training),
             be.ptr(dX), be.ptr(dw), be.ptr(db), be.ptr(ws2), nb, be.stream)
     assert eq(be.to_host(dw), be.to_host(dw_ref)) and eq(be.to_host(db), be.to_host(db_ref))
+
+
+def check_ternary_multi(be, seed=0):
+    """mn_ternary_w_fwd_multi / mn_ternary_w_bwd_multi (one launch over several weight tensors) bit-identical to the per-tensor entry points."""
+    r = np.random.default_rng(seed)
+    shapes = [(24, 3 * 25), (40, 16), (7, 144), (64, 9)]
+    ws = [(r.standard_normal(sh) * 0.3).astype(F) for sh in shapes]
+    gs = [r.standard_normal(sh).astype(F) for sh in shapes]
+    n = len(ws)
+    dW, dG = [be.to_dev(w) for w in ws], [be.to_dev(g) for g in gs]
+    q1, s1, d1 = [be.empty(sh) for sh in shapes], [be.empty((sh[0], 4)) for sh in shapes], [be.empty(sh) for sh in shapes]
+    for i, sh in enumerate(shapes):
+        be.call("mn_ternary_w_fwd", be.ptr(dW[i]), be.ptr(q1[i]), be.ptr(s1[i]), sh[0], sh[1], be.stream)
+        be.call("mn_ternary_w_bwd", be.ptr(dG[i]), be.ptr(dW[i]), be.ptr(s1[i]), be.ptr(d1[i]), sh[0], sh[1], be.stream)
+    q2, s2, d2 = [be.empty(sh) for sh in shapes], [be.empty((sh[0], 4)) for sh in shapes], [be.empty(sh) for sh in shapes]
+    PA, LA = C.c_void_p * n, C.c_int64 * n
+    arr = lambda ts: PA(*[be.ptr(t).value for t in ts])
+    Os, Ks = LA(*[sh[0] for sh in shapes]), LA(*[sh[1] for sh in shapes])
+    be.call("mn_ternary_w_fwd_multi", arr(dW), arr(q2), arr(s2), Os, Ks, n, be.stream)
+    be.call("mn_ternary_w_bwd_multi", arr(dG), arr(dW), arr(s2), arr(d2), Os, Ks, n, be.stream)
+    for i in range(n):
+        assert eq(be.to_host(q1[i]), be.to_host(q2[i])) and eq(be.to_host(s1[i]), be.to_host(s2[i])) and eq(be.to_host(d1[i]), be.to_host(d2[i])), i

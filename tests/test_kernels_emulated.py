@@ -265,3 +265,7 @@ KXK_STASH_CASES = [
 @pytest.mark.parametrize("training", [True, False])
 def test_qconv_kxk_bnsign_stash(be, case, training):
     K.check_qconv_bnsign(be, seed=260 + case, stash=True, training=training, **KXK_STASH_CASES[case])
+
+
+def test_ternary_weight_quantizer_multi(be):
+    K.check_ternary_multi(be)
