@@ -705,10 +705,18 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
 // move to the staging threads (once per block instead of once per wave).  Same partial-tile layout, same reduction kernel.
 #define WG3_RSA 160
 #define WG3_RSB 48
+#ifndef WG3_PRESPLIT
+#define WG3_PRESPLIT 1
+#endif
 template <int MW, int BNH>
 __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
-    constexpr int CW = MW, TM = 32 * MW, TC = 32 * MW, RPT = TM / 32, BUF = TM * WG3_RSA + TC * WG3_RSB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    // WG3_PRESPLIT: the staging threads split gy into its three bf16 terms ONCE per block and store three bf16 planes (rows of 80 B); the
+    // waves then read ready fragments (no VALU between LDS and MFMA; the split is no longer done twice, by both waves of a row half)
+    constexpr int CW = MW, TM = 32 * MW, TC = 32 * MW, RPT = TM / 32;
+    constexpr int RS2 = 80, PLANE = TM * RS2;
+    constexpr int BUF = WG3_PRESPLIT ? 3 * PLANE + TC * WG3_RSB : TM * WG3_RSA + TC * WG3_RSB;
+    HIP_DYNAMIC_SHARED(float, smemw)
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const int wm = wave >> 1, wc = wave & 1;
     uint32_t b = blockIdx.x;
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     const bool cdo = TC >= 128 || cr < TC;
     uint32_t goff[RPT], xoff;
     float dbacc[RPT];
-    __shared__ __attribute__((aligned(16))) float ftab[BNH ? TM * 8 : 8];      // BNH: the per-row fold (hlo, hhi, G, E1, E0), kept out of the register file
+    float* ftab = reinterpret_cast<float*>(lds + 2 * BUF);                // BNH: [TM][8] the per-row fold (hlo, hhi, G, E1, E0), kept out of the register file
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         int m = mb * TM + sr + 32 * i;
@@ -780,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     };
     auto commit = [&](Stage& S, int buf, bool valid) {
         unsigned char* A = lds + buf * BUF;
-        unsigned char* B = A + TM * WG3_RSA;
+        unsigned char* B = A + (WG3_PRESPLIT ? 3 * PLANE : TM * WG3_RSA);
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             float v[4] = {S.gv[i].x, S.gv[i].y, S.gv[i].z, S.gv[i].w};
@@ -795,16 +803,35 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
                 }
             }
             dbacc[i] += valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
-            *reinterpret_cast<float4*>(A + (sr + 32 * i) * WG3_RSA + 16 * sq) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-        if (cdo) {          // chunk q of this half goes next to chunk q of the other half: lane (j, kg) reads its 8 codes as one b64
+            if (WG3_PRESPLIT) {
+                float t0[4], t1[4], t2[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint32_t*>(B + cr * WG3_RSB + 8 * q + 4 * chf) = S.cv[q];
+                for (int e = 0; e < 4; ++e) {
+                    t0[e] = mn_bf16_head(v[e]);
+                    const float r1 = v[e] - t0[e];
+                    t1[e] = mn_bf16_head(r1);
+                    t2[e] = r1 - t1[e];
+                }
+                unsigned char* d = A + (sr + 32 * i) * RS2 + 8 * sq;
+                *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
+                *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
+                *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
+            } else {
+                *reinterpret_cast<float4*>(A + (sr + 32 * i) * WG3_RSA + 16 * sq) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if (cdo) {
+            if (WG3_PRESPLIT) {          // K slot (kg, e) = pixel 8 kg + e: plain row order
+                *reinterpret_cast<u32x4*>(B + cr * WG3_RSB + 16 * chf) = S.cv;
+            } else {                     // chunk q of this half goes next to chunk q of the other half: lane (j, kg) reads its 8 codes as one b64
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint32_t*>(B + cr * WG3_RSB + 8 * q + 4 * chf) = S.cv[q];
+            }
         }
     };
     auto contract = [&](int buf) {
         const unsigned char* A = lds + buf * BUF;
-        const unsigned char* B = A + TM * WG3_RSA;
+        const unsigned char* B = A + (WG3_PRESPLIT ? 3 * PLANE : TM * WG3_RSA);
         u32x4 bf[CW];
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
@@ -816,6 +843,13 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
         u32x4 a0[MW], a1[MW], a2[MW];
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
+            if (WG3_PRESPLIT) {
+                const unsigned char* rowp = A + ((wm * MW + mi) * 16 + j) * RS2 + 16 * kg;
+                a0[mi] = *reinterpret_cast<const u32x4*>(rowp);
+                a1[mi] = *reinterpret_cast<const u32x4*>(rowp + PLANE);
+                a2[mi] = *reinterpret_cast<const u32x4*>(rowp + 2 * PLANE);
+                continue;
+            }
             const unsigned char* row = A + ((wm * MW + mi) * 16 + j) * WG3_RSA + 16 * kg;
             const float4 ga = *reinterpret_cast<const float4*>(row), gb = *reinterpret_cast<const float4*>(row + 64);
             const float v[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
@@ -943,13 +977,13 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((h ? 5.0 : 4.0) * ny + nx); }
     mn_prof_begin(s);
     if (pl.staged) {
-        if (p.h) {
-            if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad_s<4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((k_pws_wgrad_s<2, 1>), dim3(pl.grid), dim3(256), 0, s, p);
-        } else {
-            if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad_s<4, 0>), dim3(pl.grid), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((k_pws_wgrad_s<2, 0>), dim3(pl.grid), dim3(256), 0, s, p);
-        }
+        const int TMs = 32 * pl.MW;
+        const size_t buf = WG3_PRESPLIT ? (size_t)3 * TMs * 80 + (size_t)TMs * WG3_RSB : (size_t)TMs * WG3_RSA + (size_t)TMs * WG3_RSB;
+        const size_t ldsb = 2 * buf + (p.h ? (size_t)TMs * 32 : 0);
+#define WG3_LAUNCH(MWV, BV) { raise_lds_limit((const void*)k_pws_wgrad_s<MWV, BV>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<MWV, BV>), dim3(pl.grid), dim3(256), ldsb, s, p); }
+        if (p.h) { if (pl.MW == 4) WG3_LAUNCH(4, 1) else WG3_LAUNCH(2, 1) }
+        else { if (pl.MW == 4) WG3_LAUNCH(4, 0) else WG3_LAUNCH(2, 0) }
+#undef WG3_LAUNCH
     } else if (p.h) {
         if (pl.CW8) hipLaunchKernelGGL((k_pws_wgrad<2, 8, 1>), dim3(pl.grid), dim3(256), 0, s, p);
         else if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
