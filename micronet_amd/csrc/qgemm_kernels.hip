@@ -752,7 +752,9 @@ static int plan_pw(const mn_conv_geom* g, int which, int xmode, PwPlan* pl) {
     p.Mpad = p.num_mblk * 16 * NT;
     p.nchunks = (int)((p.NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
-    const int cap = 1024 / (p.G * p.num_mblk) > 0 ? 1024 / (p.G * p.num_mblk) : 1;
+    int capb = 512;           // one round of 2 blocks per CU (against 1024: -2 ... -3 % on the DoReFa layers)
+    if (const char* e = getenv("MN_PW_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) capb = v; }   // tuning knob
+    const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
     p.CB = CB;
     p.fd_hw = make_fastdiv((uint32_t)p.HW);
