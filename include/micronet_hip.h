@@ -231,6 +231,12 @@ int mn_maxpool2x2_sign8_bwd(const float* dout, const int8_t* a, int64_t planes, 
 int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                   int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 
+/* BatchNorm2d + ReLU fused the same way (relu(batch_norm(y)) of the ConvBNReLU blocks in the DoReFa / IAO nets, models/nin_gc.py:53-59;
+ * backward mask z > 0): same arguments as mn_bnsign_fwd / mn_bnsign_bwd, fp32 output. */
+int mn_bnrelu_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                  int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream);
+int mn_bnrelu_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                  int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 /* the two halves of mn_bnsign_bwd for a consumer that forms dy itself: mn_bnsign_bwd_sums = dgamma, dbeta and sums [2][C] =
  * {sum dz, sum dz*zhat}; mn_conv2d_bwd_weight_first_bn = backward-weight (+ dbias) of the first-layer convolution
  * (mn_conv2d_first_supported) whose output y went through BatchNorm2d + BinaryActivation: dy is formed from (da, y, save, gamma,

@@ -29,10 +29,11 @@ struct BnsGeom {
     int N, C, HW, HW4;      // HW4 = HW / 4
     FastDiv fd_hw4;
     int64_t n4;             // float4 per channel = N * HW4
+    int act;                // 0: BinaryActivation (sign; backward mask |z| < 1)   1: ReLU (max(z, 0); backward mask z > 0)
 };
 static BnsGeom bns_geom(int64_t N, int64_t C, int64_t HW) {
     BnsGeom g;
-    g.N = (int)N; g.C = (int)C; g.HW = (int)HW; g.HW4 = (int)(HW / 4); g.fd_hw4 = make_fastdiv((uint32_t)g.HW4); g.n4 = N * (HW / 4);
+    g.N = (int)N; g.C = (int)C; g.HW = (int)HW; g.HW4 = (int)(HW / 4); g.fd_hw4 = make_fastdiv((uint32_t)g.HW4); g.n4 = N * (HW / 4); g.act = 0;
     return g;
 }
 // float4 index i of channel c -> element offset
@@ -42,6 +43,7 @@ __device__ __forceinline__ int64_t bns_off(const BnsGeom& g, int c, uint32_t i) 
     return ((int64_t)n * g.C + c) * g.HW + (int64_t)q * 4;
 }
 __device__ __forceinline__ float bns_sign(float z) { return (z < 0.f) ? -1.f : ((z != z) ? z : 1.f); }   // 0, -0 -> +1; NaN stays
+__device__ __forceinline__ float bns_relu(float z) { return (z > 0.f) ? z : ((z != z) ? z : 0.f); }       // torch.relu: NaN stays
 
 // MODE 0: s1 = sum(y - pivot), s2 = sum((y - pivot)^2).   MODE 1: s1 = sum dz, s2 = sum dz * zhat.
 template <int MODE>
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void k_bns_partial(const BnsGeom g, const floa
             float t1 = 0.f, t2 = 0.f;                                                                                                 \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                           \
                 const float z = zh[e] * ga + be;                                                                                      \
-                const float dz = (z > -1.f && z < 1.f) ? gv[e] : 0.f;       /* BinaryActivation.backward: zero where |z| >= 1 */      \
+                const float dz = (g.act ? (z > 0.f) : (z > -1.f && z < 1.f)) ? gv[e] : 0.f;   /* clip-STE of the sign / ReLU mask */   \
                 t1 += dz;                                                                                                             \
                 t2 += dz * zh[e];                                                                                                     \
             }                                                                                                                         \
@@ -139,13 +141,13 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
         const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};             \
         float r[4];                                                                                                                   \
         if (MODE == 0) {                                                                                                              \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) r[e] = bns_sign(zh[e] * ga + be);                                           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float z = zh[e] * ga + be; r[e] = g.act ? bns_relu(z) : bns_sign(z); } \
         } else {                                                                                                                      \
             const float4 gg = gg_[k];                                                                                                 \
             const float gv[4] = {gg.x, gg.y, gg.z, gg.w};                                                                             \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                           \
                 const float z = zh[e] * ga + be;                                                                                      \
-                const float dz = (z > -1.f && z < 1.f) ? gv[e] : 0.f;                                                                 \
+                const float dz = (g.act ? (z > 0.f) : (z > -1.f && z < 1.f)) ? gv[e] : 0.f;                                           \
                 r[e] = gi * (dz - k1 - zh[e] * k2);                                                                                   \
             }                                                                                                                         \
         }                                                                                                                             \
@@ -246,14 +248,16 @@ static int bns_split(const BnsGeom& g) {
 }
 
 static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
-                           int training, float* running_mean, float* running_var, float* save, float* a, int out8, float* ws, mn_stream_t stream) {
+                           int training, float* running_mean, float* running_var, float* save, float* a, int out8, float* ws, mn_stream_t stream,
+                           int act = 0) {
     int rc = bns_check(N, C, HW, y, out8 ? (const void*)y : (const void*)a, "mn_bnsign_fwd");
     if (!rc && out8 && (((uintptr_t)a) & 3)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd_i8: output must be 4-byte aligned");
     if (rc) return rc;
     if (!y || !gamma || !beta || !save || !a || !ws || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: null / misaligned argument");
     if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: eval mode needs the running statistics");
     hipStream_t s = (hipStream_t)stream;
-    const BnsGeom g = bns_geom(N, C, HW);
+    BnsGeom g = bns_geom(N, C, HW);
+    g.act = act;
     const int S = bns_split(g);
     const double nel = (double)N * C * HW;
     if (training) {
@@ -300,13 +304,30 @@ extern "C" int mn_bnsign_bwd_sums(const float* da, const float* y, const float* 
     MN_CHECK_LAUNCH("mn_bnsign_bwd_sums");
     return MN_OK;
 }
+static int bnsign_bwd_impl(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                           int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream, int act);
 extern "C" int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                              int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
+    return bnsign_bwd_impl(da, y, save, gamma, beta, N, C, HW, training, dy, dgamma, dbeta, ws, stream, 0);
+}
+// BatchNorm2d + ReLU (the ConvBNReLU blocks of the DoReFa / IAO nets, models/nin_gc.py:53-59): the same three / five streaming passes with
+// max(z, 0) instead of the sign and the ReLU mask z > 0 instead of the clip-STE mask -- torch's relu(batch_norm(y)) and its backward
+extern "C" int mn_bnrelu_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                             int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
+    return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream, 1);
+}
+extern "C" int mn_bnrelu_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                             int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
+    return bnsign_bwd_impl(da, y, save, gamma, beta, N, C, HW, training, dy, dgamma, dbeta, ws, stream, 1);
+}
+static int bnsign_bwd_impl(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                           int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream, int act) {
     int rc = bns_check(N, C, HW, y, dy, "mn_bnsign_bwd");
     if (rc) return rc;
     if (!da || !y || !save || !gamma || !beta || !dy || !ws || !aligned16(da) || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bnsign_bwd: null / misaligned argument");
     hipStream_t s = (hipStream_t)stream;
-    const BnsGeom g = bns_geom(N, C, HW);
+    BnsGeom g = bns_geom(N, C, HW);
+    g.act = act;
     const int S = bns_split(g);
     float* sums = ws + C * BNS_SPLIT * 4;
     const double nel = (double)N * C * HW;

@@ -136,10 +136,52 @@ def _swap_conv(child, cls, **kw):
     return new
 
 
-def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=False):
+class BatchNorm2dReLU(nn.BatchNorm2d):
+    """``nn.BatchNorm2d`` whose forward also applies the ReLU behind it (same parameters, buffers and ``state_dict`` keys): one fused
+    gfx950 op (ops.BNReLU: three streaming passes forward, five backward, z never stored) instead of MIOpen's BatchNorm kernels plus
+    separate ReLU forward / backward kernels.  Installed by ``prepare(fuse_bn_act=True)`` in front of a ReLU that the parent calls right
+    after it; that ReLU becomes a ``ReLUAfterFusedBN`` (a no-op ``nn.ReLU``)."""
+
+    def forward(self, input):
+        from micronet_amd import ops
+        import torch.nn.functional as F
+        if not (self.affine and ops.bnrelu_supported(input)):
+            return F.relu(super().forward(input))
+        use_batch = self.training or self.running_mean is None
+        momentum = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:
+                momentum = 1.0 / float(self.num_batches_tracked)
+        return ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
+
+
+class ReLUAfterFusedBN(nn.ReLU):
+    """The ``nn.ReLU`` behind a ``BatchNorm2dReLU``: the rectification already happened in the fused op (relu is idempotent, so this is the
+    same function), the module stays in place (``isinstance(m, nn.ReLU)``, module names) and costs no kernel."""
+
+    def forward(self, input):
+        return input
+
+
+def _ordered_parent(module):
+    """True when the parent calls its children in definition order, so bn -> relu adjacency means bn feeds relu."""
+    return isinstance(module, nn.Sequential) or type(module).__name__ == "ConvBNReLU"
+
+
+def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=False, fuse_bn_act=True):
     """Swap every conv / conv-transpose / linear EXCEPT the first one met (ref 202-309: ``layer_counter[0] > 1``)."""
     kw = dict(a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference)
+    prev = None
     for name, child in module.named_children():
+        if (fuse_bn_act and type(child) is nn.ReLU and type(prev) is nn.BatchNorm2d and prev.affine and prev.track_running_stats
+                and _ordered_parent(module)):
+            prev.__class__ = BatchNorm2dReLU          # same object and state: only its class changes
+            child.__class__ = ReLUAfterFusedBN
+            prev = module._modules[name]
+            continue
+        prev = child
         if isinstance(child, nn.Conv2d):
             layer_counter[0] += 1
             if layer_counter[0] > 1:
@@ -167,11 +209,14 @@ def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=Fals
                 new.weight.data = child.weight
                 module._modules[name] = new
         else:
-            add_quant_op(child, layer_counter, **kw)
+            add_quant_op(child, layer_counter, fuse_bn_act=fuse_bn_act, **kw)
 
 
-def prepare(model, inplace=False, a_bits=8, w_bits=8, quant_inference=False):
+def prepare(model, inplace=False, a_bits=8, w_bits=8, quant_inference=False, fuse_bn_act=True):
+    """Same rewrite as the reference (ref 312-320).  ``fuse_bn_act`` (ours, default on): a ``BatchNorm2d`` directly in front of a ``ReLU`` in a
+    block that calls them in that order becomes ``BatchNorm2dReLU`` (one fused op) and the ReLU a no-op subclass; with it off the module
+    graph is exactly the reference's."""
     if not inplace:
         model = copy.deepcopy(model)
-    add_quant_op(model, [0], a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference)
+    add_quant_op(model, [0], a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act)
     return model

@@ -399,3 +399,10 @@ def test_qconv_kxk_bnsign_stash(be, case, training):
 
 def test_ternary_weight_quantizer_multi(be):
     K.check_ternary_multi(be)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bnrelu(be, training):
+    K.check_bnrelu(be, training=training)
+    K.check_bnrelu(be, shape=(3, 7, 2, 2), seed=3, training=training)
+    K.check_bnrelu(be, shape=(32, 64, 16, 16), seed=4, training=training)

@@ -558,3 +558,36 @@ def test_bn_backward_folded_into_conv_backward_matches():
             ops.FOLD_BN_INTO_CONV_BWD = old
     for a_, b_ in zip(res[True], res[False]):
         assert rel_err(a_.cpu(), b_.cpu()) <= 1e-5
+
+
+def test_dorefa_fused_bn_relu_matches_unfused():
+    """prepare(fuse_bn_act=True) of the DoReFa scheme: BatchNorm2d + ReLU of a ConvBNReLU block as one fused op (BatchNorm2dReLU, the ReLU a
+    no-op subclass) against the reference's module graph (MIOpen BatchNorm + ATen ReLU): logits, running statistics and every gradient."""
+    from micronet_amd.models.nin_gc import ConvBNReLU
+    w = _q("wqaq.dorefa")
+
+    def net():
+        torch.manual_seed(11)
+        return nn.Sequential(ConvBNReLU(3, 32, 5, padding=2), ConvBNReLU(32, 32, 1, groups=2), nn.MaxPool2d(2, 2),
+                             ConvBNReLU(32, 64, 3, padding=1, groups=2), ConvBNReLU(64, 10, 1), nn.AvgPool2d(8)).cuda().train()
+    a = w.prepare(net(), inplace=True, a_bits=8, w_bits=8)
+    b = w.prepare(net(), inplace=True, a_bits=8, w_bits=8, fuse_bn_act=False)
+    assert type(a[0].bn).__name__ == "BatchNorm2dReLU" and isinstance(a[0].bn, nn.BatchNorm2d) and isinstance(a[0].relu, nn.ReLU)
+    assert type(b[0].bn) is nn.BatchNorm2d and type(b[0].relu) is nn.ReLU
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    x = torch.randn(8, 3, 16, 16, device="cuda")
+    ya, yb = a(x), b(x)
+    assert rel_err(ya.detach().cpu(), yb.detach().cpu()) <= 2e-5
+    ya.square().mean().backward()
+    yb.square().mean().backward()
+    scale = max(p_.grad.abs().max().item() for n_, p_ in b.named_parameters() if n_.endswith("conv.weight"))
+    for (n_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if n_.endswith("conv.bias"):           # a sum that cancels to ~0 in front of a BatchNorm: absolute tolerance
+            assert (pa.grad - pb.grad).abs().max().item() <= 1e-4 * scale, n_
+        else:
+            assert rel_err(pa.grad.cpu(), pb.grad.cpu()) <= 2e-4, n_      # 8-bit activation codes may flip at a rounding boundary
+    for (n_, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert rel_err(ba.float().cpu(), bb.float().cpu()) <= 1e-5, n_
+    a.eval(), b.eval()
+    with torch.no_grad():
+        assert rel_err(a(x).cpu(), b(x).cpu()) <= 2e-5
