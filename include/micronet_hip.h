@@ -231,6 +231,11 @@ int mn_maxpool2x2_sign8_bwd(const float* dout, const int8_t* a, int64_t planes, 
 int mn_bnsign_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                   int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 
+/* nn.MaxPool2d(2, 2) on fp32 activations (models/nin_gc.py:88,119 in the DoReFa / IAO nets): forward also writes the argmax of every window
+ * as one byte (0..3, ATen's tie / NaN rule), the backward scatters from it.  x / dx: [planes][H][W], y / gy / idx: [planes][H/2][W/2]. */
+int mn_maxpool2x2_f32_supported(int64_t H, int64_t W);
+int mn_maxpool2x2_f32_fwd(const float* x, int64_t planes, int64_t H, int64_t W, float* y, uint8_t* idx, mn_stream_t stream);
+int mn_maxpool2x2_f32_bwd(const float* gy, const uint8_t* idx, int64_t planes, int64_t H, int64_t W, float* dx, mn_stream_t stream);
 /* BatchNorm2d + ReLU fused the same way (relu(batch_norm(y)) of the ConvBNReLU blocks in the DoReFa / IAO nets, models/nin_gc.py:53-59;
  * backward mask z > 0): same arguments as mn_bnsign_fwd / mn_bnsign_bwd, fp32 output. */
 int mn_bnrelu_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,

@@ -230,6 +230,85 @@ extern "C" int mn_maxpool2x2_sign8_bwd(const float* dout, const int8_t* a, int64
     return MN_OK;
 }
 
+// ---------------------------------------------------------------- 2x2 / stride-2 max-pool on fp32 activations (DoReFa / IAO nets)
+// Forward keeps the argmax of every window as one byte (0..3, row-major in the window) -- ATen's rule: a later element replaces the
+// maximum if it is greater OR NaN -- so the backward is a pure scatter of 4 B + 1 B per window into 16 B (ATen's backward kernel reads
+// int64 indices and is several times slower).  Thread = 4 consecutive windows of one output row.
+__global__ __launch_bounds__(256) void k_pool2_f32_fwd(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int64_t nq, int H, int W) {
+    const int Wo = W >> 1, Ho = H >> 1, q4 = Wo >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / q4;
+        const int qc = (int)(i - row * q4);
+        const int64_t pl = row / Ho;
+        const int orow = (int)(row - pl * Ho);
+        const float* src = x + (pl * H + 2 * orow) * W + qc * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(src + W), b1 = *reinterpret_cast<const float4*>(src + W + 4);
+        const float r0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, r1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[4];
+        uint32_t ib = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float v[4] = {r0[2 * w], r0[2 * w + 1], r1[2 * w], r1[2 * w + 1]};
+            float m = -INFINITY;
+            uint32_t k = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] > m || v[e] != v[e]) { m = v[e]; k = (uint32_t)e; }
+            o[w] = m; ib |= k << (8 * w);
+        }
+        const int64_t oo = (pl * Ho + orow) * Wo + qc * 4;
+        *reinterpret_cast<float4*>(y + oo) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint32_t*>(idx + oo) = ib;
+    }
+}
+__global__ __launch_bounds__(256) void k_pool2_f32_bwd(const float* __restrict__ gy, const unsigned char* __restrict__ idx, float* __restrict__ dx, int64_t nq, int H, int W) {
+    const int Wo = W >> 1, Ho = H >> 1, q4 = Wo >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / q4;
+        const int qc = (int)(i - row * q4);
+        const int64_t pl = row / Ho;
+        const int orow = (int)(row - pl * Ho);
+        const int64_t oo = (pl * Ho + orow) * Wo + qc * 4;
+        const float4 g4 = *reinterpret_cast<const float4*>(gy + oo);
+        const uint32_t ib = *reinterpret_cast<const uint32_t*>(idx + oo);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float r0[8], r1[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t k = (ib >> (8 * w)) & 3u;
+            r0[2 * w] = k == 0u ? g[w] : 0.f; r0[2 * w + 1] = k == 1u ? g[w] : 0.f;
+            r1[2 * w] = k == 2u ? g[w] : 0.f; r1[2 * w + 1] = k == 3u ? g[w] : 0.f;
+        }
+        float* dst = dx + (pl * H + 2 * orow) * W + qc * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(r0[4], r0[5], r0[6], r0[7]);
+        *reinterpret_cast<float4*>(dst + W) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+        *reinterpret_cast<float4*>(dst + W + 4) = make_float4(r1[4], r1[5], r1[6], r1[7]);
+    }
+}
+extern "C" int mn_maxpool2x2_f32_supported(int64_t H, int64_t W) { return H >= 2 && H % 2 == 0 && W >= 8 && W % 8 == 0; }
+extern "C" int mn_maxpool2x2_f32_fwd(const float* x, int64_t planes, int64_t H, int64_t W, float* y, uint8_t* idx, mn_stream_t stream) {
+    if (!x || !y || !idx || planes <= 0 || !mn_maxpool2x2_f32_supported(H, W) || !aligned16(x) || !aligned16(y) || (((uintptr_t)idx) & 3))
+        MN_FAIL(MN_EINVAL, "mn_maxpool2x2_f32_fwd: needs even H, W %% 8 == 0, aligned tensors");
+    const int64_t nq = planes * (H / 2) * (W / 8);
+    mn_set_last_kernel("k_pool2_f32_fwd"); mn_prof_bytes(5.25 * (double)planes * H * W); mn_prof_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(k_pool2_f32_fwd, dim3(mn_grid_for(nq, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, (unsigned char*)idx, nq, (int)H, (int)W);
+    mn_prof_end((hipStream_t)stream);
+    MN_CHECK_LAUNCH("mn_maxpool2x2_f32_fwd");
+    return MN_OK;
+}
+extern "C" int mn_maxpool2x2_f32_bwd(const float* gy, const uint8_t* idx, int64_t planes, int64_t H, int64_t W, float* dx, mn_stream_t stream) {
+    if (!gy || !dx || !idx || planes <= 0 || !mn_maxpool2x2_f32_supported(H, W) || !aligned16(gy) || !aligned16(dx) || (((uintptr_t)idx) & 3))
+        MN_FAIL(MN_EINVAL, "mn_maxpool2x2_f32_bwd: needs even H, W %% 8 == 0, aligned tensors");
+    const int64_t nq = planes * (H / 2) * (W / 8);
+    mn_set_last_kernel("k_pool2_f32_bwd"); mn_prof_bytes(5.25 * (double)planes * H * W); mn_prof_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(k_pool2_f32_bwd, dim3(mn_grid_for(nq, 256, 8192)), dim3(256), 0, (hipStream_t)stream, gy, (const unsigned char*)idx, dx, nq, (int)H, (int)W);
+    mn_prof_end((hipStream_t)stream);
+    MN_CHECK_LAUNCH("mn_maxpool2x2_f32_bwd");
+    return MN_OK;
+}
+
 extern "C" int64_t mn_bnsign_ws_floats(int64_t C) { return C * BNS_SPLIT * 4 + 2 * C + 16; }   // fp64 partials + {sum dz, sum dz*zhat}
 
 static int bns_check(int64_t N, int64_t C, int64_t HW, const void* a, const void* b, const char* what) {

@@ -445,6 +445,39 @@ def bnrelu_supported(x):
     return torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and (x.shape[2] * x.shape[3]) % 4 == 0
 
 
+class MaxPool2x2F32(Function):
+    """nn.MaxPool2d(2, 2) on fp32 activations: the forward keeps the argmax of every window in one byte, the backward is a scatter
+    (ATen keeps int64 indices and its backward kernel is several times slower)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "input")
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device_of(x):
+            _call("mn_maxpool2x2_f32_fwd", _p(x), N * Cc, H, W, _p(y), _p(idx), _s())
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _chk(g, "grad")
+        N, Cc, H, W = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device_of(g):
+            _call("mn_maxpool2x2_f32_bwd", _p(g), _p(idx), N * Cc, H, W, _p(dx), _s())
+        return dx
+
+
+def f32_pool_supported(x, kernel_size, stride, padding, dilation, ceil_mode):
+    two = lambda v: v in (2, (2, 2), [2, 2])
+    return (torch.is_tensor(x) and type(x) is torch.Tensor and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and two(kernel_size) and two(stride)
+            and padding in (0, (0, 0)) and dilation in (1, (1, 1)) and not ceil_mode and bool(_lib_().mn_maxpool2x2_f32_supported(x.shape[2], x.shape[3])))
+
+
 class SignToFloat(Function):
     """SignTensor -> the float32 +-1 tensor, with an identity backward (for consumers our kernels do not cover)."""
 

@@ -157,6 +157,16 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
                                 self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
 
 
+class MaxPool2dF32(nn.MaxPool2d):
+    """``nn.MaxPool2d`` whose 2x2 / stride-2 case runs on the gfx950 kernels (byte argmax, scatter backward); anything else is the stock module."""
+
+    def forward(self, input):
+        from micronet_amd import ops
+        if not self.return_indices and ops.f32_pool_supported(input, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode):
+            return ops.MaxPool2x2F32.apply(input)
+        return super().forward(input)
+
+
 class ReLUAfterFusedBN(nn.ReLU):
     """The ``nn.ReLU`` behind a ``BatchNorm2dReLU``: the rectification already happened in the fused op (relu is idempotent, so this is the
     same function), the module stays in place (``isinstance(m, nn.ReLU)``, module names) and costs no kernel."""
@@ -182,6 +192,9 @@ def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=Fals
             prev = module._modules[name]
             continue
         prev = child
+        if fuse_bn_act and type(child) is nn.MaxPool2d:
+            child.__class__ = MaxPool2dF32            # same object and state
+            continue
         if isinstance(child, nn.Conv2d):
             layer_counter[0] += 1
             if layer_counter[0] > 1:

@@ -661,3 +661,26 @@ def check_ternary_multi(be, seed=0):
     be.call("mn_ternary_w_bwd_multi", arr(dG), arr(dW), arr(s2), arr(d2), Os, Ks, n, be.stream)
     for i in range(n):
         assert eq(be.to_host(q1[i]), be.to_host(q2[i])) and eq(be.to_host(s1[i]), be.to_host(s2[i])) and eq(be.to_host(d1[i]), be.to_host(d2[i])), i
+
+
+def check_pool_f32(be, shape=(3, 5, 8, 16), seed=0):
+    """mn_maxpool2x2_f32_fwd/bwd vs torch CPU max_pool2d: values, the gradient routing (ties -> first maximum, NaN wins) bit-exact."""
+    import torch
+    r = np.random.default_rng(seed)
+    x = np.round(r.standard_normal(shape) * 2).astype(F) * 0.5          # coarse grid: many ties inside windows
+    x[0, 0, 0, 1] = np.nan; x[0, 0, 1, 0] = np.nan                      # two NaN in one window: the later one is the argmax
+    if shape[0] > 1 and shape[2] > 2:
+        x[1, 1, 2, 4] = np.nan
+    N, Cc, H, W = shape
+    t = torch.from_numpy(x.copy()).requires_grad_(True)
+    y_ref = torch.nn.functional.max_pool2d(t, 2, 2)
+    gy = r.standard_normal(tuple(y_ref.shape)).astype(F)
+    y_ref.backward(torch.from_numpy(gy))
+    dX, dG = be.to_dev(x), be.to_dev(gy)
+    y, dx = be.empty(tuple(y_ref.shape)), be.empty(shape)
+    idx = be.empty_i8(tuple(y_ref.shape))
+    assert be.lib.mn_maxpool2x2_f32_supported(H, W) == 1
+    be.call("mn_maxpool2x2_f32_fwd", be.ptr(dX), N * Cc, H, W, be.ptr(y), be.ptr(idx), be.stream)
+    be.call("mn_maxpool2x2_f32_bwd", be.ptr(dG), be.ptr(idx), N * Cc, H, W, be.ptr(dx), be.stream)
+    assert np.array_equal(be.to_host(y), y_ref.detach().numpy(), equal_nan=True)
+    assert np.array_equal(be.to_host(dx), t.grad.numpy())

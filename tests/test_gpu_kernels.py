@@ -406,3 +406,8 @@ def test_bnrelu(be, training):
     K.check_bnrelu(be, training=training)
     K.check_bnrelu(be, shape=(3, 7, 2, 2), seed=3, training=training)
     K.check_bnrelu(be, shape=(32, 64, 16, 16), seed=4, training=training)
+
+
+def test_pool_f32(be):
+    K.check_pool_f32(be)
+    K.check_pool_f32(be, shape=(2, 3, 2, 8), seed=1)

@@ -573,6 +573,7 @@ def test_dorefa_fused_bn_relu_matches_unfused():
     a = w.prepare(net(), inplace=True, a_bits=8, w_bits=8)
     b = w.prepare(net(), inplace=True, a_bits=8, w_bits=8, fuse_bn_act=False)
     assert type(a[0].bn).__name__ == "BatchNorm2dReLU" and isinstance(a[0].bn, nn.BatchNorm2d) and isinstance(a[0].relu, nn.ReLU)
+    assert type(a[2]).__name__ == "MaxPool2dF32" and isinstance(a[2], nn.MaxPool2d) and type(b[2]) is nn.MaxPool2d
     assert type(b[0].bn) is nn.BatchNorm2d and type(b[0].relu) is nn.ReLU
     assert list(a.state_dict().keys()) == list(b.state_dict().keys())
     x = torch.randn(8, 3, 16, 16, device="cuda")

@@ -275,3 +275,8 @@ def test_ternary_weight_quantizer_multi(be):
 def test_bnrelu(be, training):
     K.check_bnrelu(be, training=training)
     K.check_bnrelu(be, shape=(3, 7, 2, 2), seed=3, training=training)
+
+
+def test_pool_f32(be):
+    K.check_pool_f32(be)
+    K.check_pool_f32(be, shape=(2, 3, 2, 8), seed=1)
