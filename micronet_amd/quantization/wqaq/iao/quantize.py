@@ -407,8 +407,11 @@ class QuantMaxPool2d(nn.MaxPool2d):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
 
     def forward(self, input):
-        return F.max_pool2d(self.activation_quantizer(input), self.kernel_size, self.stride, self.padding, self.dilation,
-                            self.ceil_mode, self.return_indices)
+        q = self.activation_quantizer(input)
+        from micronet_amd import ops
+        if not self.return_indices and ops.f32_pool_supported(q, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode):
+            return ops.MaxPool2x2F32.apply(q)        # 2x2 / stride 2: byte argmax, scatter backward (same values and gradient routing as ATen)
+        return F.max_pool2d(q, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode, self.return_indices)
 
 
 class QuantAvgPool2d(nn.AvgPool2d):
