@@ -336,8 +336,12 @@ typedef struct mn_adam_tensor {
 } mn_adam_tensor;
 int mn_adam_step(const mn_adam_tensor* tensors, int count, int step, float beta1, float beta2, float eps, mn_stream_t stream);
 /* same update, but the step count (>= 1) is read from DEVICE memory by the kernel: the launch can then be captured in a HIP
- * graph and replayed while a device-side counter advances (the caller increments *step_dev before the launch). */
-int mn_adam_step_dev(const mn_adam_tensor* tensors, int count, const int32_t* step_dev, float beta1, float beta2, float eps, mn_stream_t stream);
+ * graph and replayed while a device-side counter advances (the caller increments *step_dev before the launch).
+ * hyper_dev (nullable): device array [count][2] = {lr, weight_decay} per tensor, read by the kernel INSTEAD of tensors[i].lr /
+ * .weight_decay -- a replayed graph then follows the training loop's learning-rate schedule (the reference edits
+ * param_group['lr'] every epoch: wbwtab/main.py:62-66 adjust_learning_rate) by refreshing that small array between replays. */
+int mn_adam_step_dev(const mn_adam_tensor* tensors, int count, const int32_t* step_dev, const float* hyper_dev, float beta1, float beta2, float eps,
+                     mn_stream_t stream);
 
 #ifdef __cplusplus
 }

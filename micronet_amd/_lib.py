@@ -108,7 +108,7 @@ PROTOTYPES = {
     "mn_signconv1x1_small_fwd": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P]),
     "mn_conv1x1_small_bwd_data": (_I, [_P, _P, _P, _L, _L, _L, _L, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
-    "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, C.c_float, C.c_float, C.c_float, _P]),
+    "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),
     "mn_conv2d_mfma_supported": (_I, [_G, _I]),
     "mn_conv2d_first_supported": (_I, [_G, _I]),

@@ -20,6 +20,9 @@ struct AdamTable {
     int count;
     float beta1, beta2, eps, bc1, bc2_sqrt;
     const int* step_dev;     // non-null: the step count lives in device memory (HIP-graph replay), bias corrections computed here
+    const float* hyper_dev;  // non-null: {lr, weight_decay} of tensor i at hyper_dev[2 * (hyper_base + slot_src[i])] -- a replayed graph then
+    int hyper_base;          // follows the host's param_group['lr'] edits (the reference's adjust_learning_rate, wbwtab/main.py:62-66)
+    int slot_src[MN_ADAM_MAX_TENSORS];
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_bc1, float wd, const AdamTable& t, float bc2_sqrt) {
@@ -46,7 +49,12 @@ __global__ __launch_bounds__(256) void k_adam(const AdamTable t) {
     const float* __restrict__ G = t.g[ti];
     float* __restrict__ M = t.m[ti];
     float* __restrict__ V = t.v[ti];
-    const float lr_bc1 = t.lr[ti] / bc1, wd = t.wd[ti];
+    float lr = t.lr[ti], wd = t.wd[ti];
+    if (t.hyper_dev) {
+        const float* hp = t.hyper_dev + 2 * (t.hyper_base + t.slot_src[ti]);
+        lr = hp[0]; wd = hp[1];
+    }
+    const float lr_bc1 = lr / bc1;
     const bool vec = aligned16(P) && aligned16(G) && aligned16(M) && aligned16(V);
     for (int i = off + threadIdx.x * 4; i < off + ADAM_CHUNK && i < n; i += 256 * 4) {
         if (vec && i + 3 < n) {
@@ -65,7 +73,8 @@ __global__ __launch_bounds__(256) void k_adam(const AdamTable t) {
     }
 }
 
-static int adam_impl(const mn_adam_tensor* tensors, int count, int step, const int32_t* step_dev, float beta1, float beta2, float eps, mn_stream_t stream) {
+static int adam_impl(const mn_adam_tensor* tensors, int count, int step, const int32_t* step_dev, const float* hyper_dev, float beta1, float beta2, float eps,
+                     mn_stream_t stream) {
     if (count < 0 || (count > 0 && !tensors) || (!step_dev && step < 1)) MN_FAIL(MN_EINVAL, "mn_adam_step: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const double bc1 = step_dev ? 1.0 : 1.0 - pow((double)beta1, (double)step), bc2 = step_dev ? 1.0 : 1.0 - pow((double)beta2, (double)step);
@@ -79,6 +88,7 @@ static int adam_impl(const mn_adam_tensor* tensors, int count, int step, const i
             if (!a.p || !a.g || !a.m || !a.v || a.n < 0 || a.n > 0x7fffffff - ADAM_CHUNK) MN_FAIL(MN_EINVAL, "mn_adam_step: tensor %d invalid", base + i);
             t.p[used] = a.p; t.g[used] = a.g; t.m[used] = a.m; t.v[used] = a.v; t.n[used] = (int)a.n; t.lr[used] = a.lr; t.wd[used] = a.weight_decay;
             t.chunk0[used] = chunks;
+            t.slot_src[used] = i;
             chunks += (int)((a.n + ADAM_CHUNK - 1) / ADAM_CHUNK);
             ++used;
         }
@@ -86,15 +96,17 @@ static int adam_impl(const mn_adam_tensor* tensors, int count, int step, const i
         t.chunk0[used] = chunks;
         t.count = used; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.bc1 = (float)bc1; t.bc2_sqrt = (float)sqrt(bc2);
         t.step_dev = (const int*)step_dev;
+        t.hyper_dev = hyper_dev; t.hyper_base = base;
         hipLaunchKernelGGL(k_adam, dim3(chunks), dim3(256), 0, s, t);
     }
     MN_CHECK_LAUNCH("mn_adam_step");
     return MN_OK;
 }
 extern "C" int mn_adam_step(const mn_adam_tensor* tensors, int count, int step, float beta1, float beta2, float eps, mn_stream_t stream) {
-    return adam_impl(tensors, count, step, nullptr, beta1, beta2, eps, stream);
+    return adam_impl(tensors, count, step, nullptr, nullptr, beta1, beta2, eps, stream);
 }
-extern "C" int mn_adam_step_dev(const mn_adam_tensor* tensors, int count, const int32_t* step_dev, float beta1, float beta2, float eps, mn_stream_t stream) {
+extern "C" int mn_adam_step_dev(const mn_adam_tensor* tensors, int count, const int32_t* step_dev, const float* hyper_dev, float beta1, float beta2, float eps,
+                                mn_stream_t stream) {
     if (!step_dev) MN_FAIL(MN_EINVAL, "mn_adam_step_dev: null step counter");
-    return adam_impl(tensors, count, 0, step_dev, beta1, beta2, eps, stream);
+    return adam_impl(tensors, count, 0, step_dev, hyper_dev, beta1, beta2, eps, stream);
 }

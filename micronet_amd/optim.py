@@ -3,8 +3,11 @@ parameter group per tensor, ``lr``, ``weight_decay``), executed as ONE gfx950 la
 instead of ~7 small kernels per group.  Same update as torch (amsgrad off, L2 weight decay folded into the gradient),
 same ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq``), so checkpoints interchange.
 
-``capturable = True`` keeps the step count in device memory (``mn_adam_step_dev``) so that ``step()`` can be captured in a HIP
-graph and replayed (micronet_amd.train.GraphedTrainStep); ``sync_steps()`` writes the device count back into ``state``."""
+``capturable = True`` keeps the step count AND every group's ``lr`` / ``weight_decay`` in device memory (``mn_adam_step_dev``) so that
+``step()`` can be captured in a HIP graph and replayed (micronet_amd.train.GraphedTrainStep): ``refresh_hyper()`` -- called before every
+replay -- copies the groups' current ``lr`` / ``weight_decay`` into that device table when the training loop edited them (the reference's
+``adjust_learning_rate``, wbwtab/main.py:62-66), ``sync_steps()`` writes the device step count back into ``state``.  betas / eps are
+frozen at capture time; changing them afterwards raises."""
 import ctypes as C
 
 import torch
@@ -19,6 +22,8 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.capturable = False
         self._step_dev = None
+        self._hyper_dev = {}          # (betas, eps) batch key -> device [n][2] = lr, weight_decay
+        self._hyper_host = {}
 
     def _host_step(self):
         steps = {int(st["step"]) for st in self.state.values() if st}
@@ -33,6 +38,33 @@ class Adam(torch.optim.Optimizer):
             for st in self.state.values():
                 if st:
                     st["step"].fill_(n)
+
+    def state_dict(self):
+        self.sync_steps()             # a checkpoint taken between graph replays carries the replayed step count
+        return super().state_dict()
+
+    def _hyper_items(self):
+        items = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                items.setdefault((float(b1), float(b2), float(group["eps"])), []).append((float(group["lr"]), float(group["weight_decay"])))
+        return items
+
+    def refresh_hyper(self):
+        """Bring the device-side {lr, weight_decay} table up to date with ``param_groups`` (no-op when nothing changed; one small
+        host-to-device copy per batch key when the schedule moved).  Raises if betas / eps differ from the captured values."""
+        if not self._hyper_dev:
+            return
+        items = self._hyper_items()
+        if set(items) != set(self._hyper_dev):
+            raise _lib.MicronetHipError("capturable Adam: betas / eps changed after the step was captured; re-capture the step")
+        for key, vals in items.items():
+            if vals != self._hyper_host[key]:
+                if len(vals) != len(self._hyper_host[key]):
+                    raise _lib.MicronetHipError("capturable Adam: parameter groups changed after capture")
+                self._hyper_dev[key].copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=False)
+                self._hyper_host[key] = vals
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -95,12 +127,20 @@ class Adam(torch.optim.Optimizer):
         if self._step_dev is None:
             self._step_dev = torch.full((1,), self._host_step(), dtype=torch.int32, device=dev)
         self._step_dev.add_(1)
-        for (b1, b2, eps), its in items.items():
+        for key, its in items.items():
+            b1, b2, eps = key
+            vals = [(lr, wd) for (_, _, _, lr, wd) in its]
+            if key not in self._hyper_dev:          # first capturable step (eager warm-up, outside any capture): allocate the table
+                self._hyper_dev[key] = torch.tensor(vals, dtype=torch.float32, device=dev)
+                self._hyper_host[key] = vals
+            elif vals != self._hyper_host[key] and not torch.cuda.is_current_stream_capturing():
+                self._hyper_dev[key].copy_(torch.tensor(vals, dtype=torch.float32))
+                self._hyper_host[key] = vals
             arr = (_lib.AdamTensor * len(its))()
             for i, (p, g, st, lr, wd) in enumerate(its):
                 arr[i] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), lr, wd)
             with torch.cuda.device(dev):
-                rc = lib.mn_adam_step_dev(arr, len(its), C.c_void_p(self._step_dev.data_ptr()), b1, b2, eps,
+                rc = lib.mn_adam_step_dev(arr, len(its), C.c_void_p(self._step_dev.data_ptr()), C.c_void_p(self._hyper_dev[key].data_ptr()), b1, b2, eps,
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
             if rc != 0:
                 lib.check(rc, "mn_adam_step_dev")

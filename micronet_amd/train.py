@@ -106,14 +106,22 @@ class GraphedTrainStep:
     the reduced bucket.  (nin_gc: one 2.4 MB collective per step.)
 
     Data is fed through the static tensors ``self.data`` / ``self.target`` (``copy_`` new batches into them); ``self.loss`` /
-    ``self.output`` hold the results of the last replay.  The optimizer must be ``micronet_amd.optim.Adam`` (its step count
-    moves to device memory)."""
+    ``self.output`` hold the results of the last replay.  The optimizer must be ``micronet_amd.optim.Adam``: its step count and every
+    group's ``lr`` / ``weight_decay`` live in device memory, and ``step()`` refreshes them from ``param_groups`` before each replay, so
+    the reference's per-epoch ``adjust_learning_rate`` (wbwtab/main.py:62-66, 343) keeps working on a replayed step.
+
+    What capture freezes (evaluated once, at construction): the module graph and every Python-side branch in it -- train/eval mode,
+    IAO observers' first-call flag (the capture happens after ``warmup`` real steps, so observers are past their first call),
+    ``BatchNorm.momentum is None``, Adam's betas / eps (changing them raises).  Construction itself CONSUMES ``warmup`` (default 3)
+    real training steps on ``data`` / ``target`` -- parameters, Adam moments, BN running statistics and IAO observer state advance
+    exactly as in three eager steps; count them in the schedule.  ``optimizer.state_dict()`` syncs the step count automatically."""
 
     def __init__(self, model, optimizer, data, target, warmup=3, group=None):
         import torch.distributed as dist
         self.model, self.optimizer = model, optimizer
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
+        self._host_sync = self.world > 1 and dist.get_backend(group) != "nccl"
         self.data, self.target = data.clone(), target.clone()
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not hasattr(optimizer, "capturable"):
@@ -177,12 +185,15 @@ class GraphedTrainStep:
                 off += p.numel()
 
     def step(self):
+        self.optimizer.refresh_hyper()        # lr / weight_decay edits of the training loop reach the captured Adam launch
         self.graph_a.replay()
         if self.world > 1:
             import torch.distributed as dist
-            # the collective needs graph A's result anyway: wait for it on the host before enqueueing the all-reduce (a
-            # collective that waits on a stream with a freshly launched graph was seen to stall for seconds with gloo)
-            torch.cuda.current_stream().synchronize()
+            if self._host_sync:
+                # gloo only (the CPU-side functional check of this path): its collective on a device tensor does not order itself behind
+                # a freshly launched graph.  RCCL enqueues the all-reduce behind graph A on the device (event wait on the current
+                # stream) and graph B behind the all-reduce: no host round-trip in the step.
+                torch.cuda.current_stream().synchronize()
             dist.all_reduce(self.flat, group=self.group)
             self.graph_b.replay()
         return self.loss, self.output

@@ -3,8 +3,8 @@
 ``np_oracle.py`` restates the arithmetic of each primitive; this file restates
 how the reference *composes* them into ``nn.Module``s and rewrites a model
 (``prepare``), using the same ATen CPU ops in the same order so that on CPU it
-is bit-identical to the reference (checked live in the build container by
-``tests/test_oracle_vs_reference.py`` and against the committed fixtures by
+is bit-identical to the reference (checked against the fixtures that
+``tests/golden/make_golden.py`` generated from the imported reference:
 ``tests/test_oracle_golden.py``).  It is also the ``cpu_baseline`` ("port")
 that ``bench.py`` times on the host cores.
 

@@ -9,7 +9,7 @@ It imports the reference's three ``quantize.py`` modules and model files
 unmodified, drives them on seeded + adversarial inputs, and stores inputs and
 outputs as small ``.npz`` fixtures next to this file.  The fixtures pin
 ``oracle/`` (tests/test_oracle_golden.py) and, on the GPU box, the HIP path
-(tests/test_gpu_golden.py).  Nothing here is copied from the reference: it is
+(tests/test_gpu_kernels.py, tests/test_gpu_modules.py, tests/test_gpu_models.py).  Nothing here is copied from the reference: it is
 only *executed*.
 """
 import json
