@@ -4,15 +4,28 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 One "step" = forward + CrossEntropy + zero_grad + backward + Adam.step on one synthetic CIFAR-10-shaped batch
-(mirror of the reference's wqaq/dorefa/main.py:77-82), data already resident in HBM.  Workload at every N:
-BASELINE.json configs[1] -- nin_gc, wbwtab W-ternary / A-binary, batch 256 PER GPU (weak scaling), data-parallel with a
-RCCL all-reduce of the gradients.  Prints ONE JSON line on rank 0.
+(mirror of the reference's wqaq/dorefa/main.py:77-82), data already resident in HBM.  BASELINE.json's metric names nin_gc
+under BOTH low-bit schemes, so one run measures both, batch 256 PER GPU (weak scaling), data-parallel with a RCCL all-reduce
+of the gradients:
+  * primary (`value`, `roofline`, `cpu_baseline`): configs[1] -- wbwtab W-ternary / A-binary;
+  * `also.c1_w2a2`: DoReFa W2A2 (value, ms_per_step, roofline of its own dominant kernel).
+`--only W` measures a single workload (profiling runs).  Prints ONE JSON line on rank 0.
+
+roofline.achieved = the dominant kernel's designed HBM bytes / its HIP-event duration (events recorded by the library on the
+launch stream around every launch).  roofline.traffic / roofline.mfma_busy come from rocprofv3 PMC passes that THIS run
+spawns on itself at N = 1 (separate passes: FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; no tracing
+domain combined with --pmc; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) -- `--no-pmc` skips them (traffic null).
 """
 import argparse
-import contextlib
+import collections
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,8 +36,10 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 rate
-NIN_GC_GFLOP_PER_IMG = 0.9068   # fwd+bwd, all nine convs
-NIN_GC_MB_PER_IMG = 22.71       # fused-ideal fp32 activation traffic fwd+bwd
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense
+N_SIMD = 1024                   # 256 CUs x 4
+GFLOP_PER_IMG = {"nin_gc": 0.9068, "resnet18": 3.3290}   # fwd+bwd, all convs
+MB_PER_IMG = {"nin_gc": 22.71, "resnet18": 12.91}        # fused-ideal fp32 activation traffic fwd+bwd
 
 WORKLOADS = {
     # name: (arch, scheme module, prepare kwargs, weight decay)   (BASELINE.json configs)
@@ -38,11 +53,12 @@ WORKLOADS = {
 WORKLOAD_DESC = {
     "c2": "nin_gc CIFAR-10 wbwtab W-ternary/A-binary QAT, batch=256 per GPU (BASELINE configs[1])",
     "c1": "nin_gc CIFAR-10 DoReFa W8A8 QAT (BASELINE configs[0] scheme)",
-    "c1_w2a2": "nin_gc CIFAR-10 DoReFa W2A2 QAT",
+    "c1_w2a2": "nin_gc CIFAR-10 DoReFa W2A2 QAT, batch=256 per GPU",
     "c3": "nin_gc CIFAR-10 IAO W8A8 per-channel + BN-fuse QAT (BASELINE configs[2])",
     "c4": "resnet18 CIFAR-10 DoReFa W2A2 QAT (BASELINE configs[3])",
     "c5": "resnet18 CIFAR-10 IAO W4A4 per-channel + quant_add QAT (BASELINE configs[4])",
 }
+METRIC = {"c2": "QAT images/sec (nin_gc CIFAR-10, W-ternary/A-binary)", "c1_w2a2": "QAT images/sec (nin_gc CIFAR-10, DoReFa W2A2)"}
 
 
 class KernelProfiler:
@@ -59,8 +75,8 @@ class KernelProfiler:
 
     def stop(self):
         """Call after torch.cuda.synchronize(): {kernel: dict(ms, bytes, launches)}."""
-        buf = (self._lib.ProfEntry * 128)()
-        n = self.lib.mn_profile_collect(buf, 128)
+        buf = (self._lib.ProfEntry * 192)()
+        n = self.lib.mn_profile_collect(buf, 192)
         self.lib.mn_profile_enable(0)
         return {buf[i].name.decode(): dict(ms=buf[i].total_ms, bytes=buf[i].bytes, launches=buf[i].launches) for i in range(n)}
 
@@ -70,8 +86,9 @@ def build(workload, device):
     from micronet_amd.train import build_model, make_optimizer
     arch, scheme, kw, wd = WORKLOADS[workload]
     quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
-    if scheme == "wbwtab" and os.environ.get("MN_BENCH_WBWTAB_KW"):      # A/B switches, e.g. "fuse_conv_bn=0,packed_activations=1"
-        kw = dict(kw, **{k: bool(int(v)) for k, v in (it.split("=") for it in os.environ["MN_BENCH_WBWTAB_KW"].split(","))})
+    envkw = os.environ.get("MN_BENCH_PREPARE_KW") or (os.environ.get("MN_BENCH_WBWTAB_KW") if scheme == "wbwtab" else None)
+    if envkw:      # A/B switches, e.g. "fuse_conv_bn=0,packed_activations=1"
+        kw = dict(kw, **{k: bool(int(v)) for k, v in (it.split("=") for it in envkw.split(","))})
     model = quantize.prepare(build_model(arch), inplace=True, **kw).to(device)
     model.train()
     return model, make_optimizer(model, 0.01, wd)
@@ -92,54 +109,16 @@ def cpu_baseline(workload, batch, steps, threads=0):
     for _ in range(steps):
         TO.train_step(model, opt, x, y)
     dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 2), unit="images/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=round(batch * steps / dt, 2), unit="images/s", cores=torch.get_num_threads(), kind="port", workload=workload,
                 sample="%d timed steps (after 1 warm-up) of the same train step at batch %d, torch-CPU restatement of the "
                        "reference modules (oracle/torch_oracle.py), %.1f s of CPU work" % (steps, batch, dt))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
-    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=16, help="timed CPU steps at --cpu-batch (about 10-15 s of CPU work)")
-    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying captured HIP graphs")
-    ap.add_argument("--kernel-steps", type=int, default=5, help="eager steps of the per-kernel HIP-event timing pass")
-    ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="threads for the CPU baseline; 0 = os.cpu_count(). 16 is the fastest setting measured on the MI355X host "
-                         "(2x EPYC 9575F: 97 img/s at 16 threads, 72 at 32, 41 at 64, 24 at 128, 1.1 at 256)")
-    ap.add_argument("--cpu-only", action="store_true", help="only time the CPU baseline (no GPU work)")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    args = ap.parse_args()
-
-    if args.cpu_only:
-        print(json.dumps(cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_threads)), flush=True)
-        return
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MN_DIST_BACKEND", "nccl")      # "gloo": functional check of the multi-rank path on one GPU
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
+def measure(workload, args, world, rank, device):
+    """Warm up, time exactly args.steps steps between barriers, then (N = 1) the per-kernel HIP-event pass."""
     from micronet_amd import dp
     from micronet_amd.train import GraphedTrainStep, synth_batch
-    model, opt = build(args.workload, device)
+    model, opt = build(workload, device)
     dp.broadcast_parameters(model)
     x, y = synth_batch(args.batch, seed=1234 + rank, device=device)
 
@@ -158,7 +137,7 @@ def main():
         except Exception as e:                      # noqa: BLE001 -- report and measure the eager step instead
             graph_err = "%s: %s" % (type(e).__name__, str(e)[:200])
             graphed = None
-            model, opt = build(args.workload, device)
+            model, opt = build(workload, device)
             dp.broadcast_parameters(model)
     if graphed is None:
         sync = dp.GradSync(model)
@@ -198,48 +177,235 @@ def main():
         agg = prof.stop()
     if graphed is not None:
         graphed.finish()
+    del graphed, model, opt, sync
+    torch.cuda.empty_cache()
+    return dict(dt=dt, final_loss=final_loss, hip_graph=graph_err is None and not args.no_graph, graph_err=graph_err, agg=agg)
+
+
+def section(workload, m, args, world, pmc):
+    """value / ms_per_step / roofline / kernels / step_level of one measured workload."""
+    arch = WORKLOADS[workload][0]
+    value = args.batch * world * args.steps / m["dt"]
+    out = {"workload": WORKLOAD_DESC[workload], "value": round(value, 1), "unit": "images/s", "ms_per_step": round(1000.0 * m["dt"] / args.steps, 3),
+           "hip_graph": m["hip_graph"], "final_loss": round(m["final_loss"], 4)}
+    if m["graph_err"]:
+        out["hip_graph_error"] = m["graph_err"]
+    agg = m["agg"]
+    if agg:
+        ks = args.kernel_steps
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        p = (pmc or {}).get(workload, {}).get(dom, {})
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": p.get("bytes_per_launch"),
+                           "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes spawned by this run" if p.get("bytes_per_launch")
+                                              else None),
+                           "mfma_busy": p.get("mfma_busy"),
+                           "bytes_per_launch": int(d["bytes"] / d["launches"]),
+                           "avg_launch_us": round(1000.0 * d["ms"] / d["launches"], 2), "launches": d["launches"],
+                           "timing": "HIP events on the launch stream around every launch, %d eager steps after the timed region" % ks}
+        out["kernels"] = {k: {"ms_per_step": round(v["ms"] / ks, 4), "launches_per_step": v["launches"] / ks,
+                              "avg_us": round(1000.0 * v["ms"] / v["launches"], 1),
+                              "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                              **({"pmc_bytes_per_launch": (pmc or {}).get(workload, {}).get(k, {}).get("bytes_per_launch"),
+                                  "mfma_busy": (pmc or {}).get(workload, {}).get(k, {}).get("mfma_busy")} if (pmc or {}).get(workload, {}).get(k) else {})}
+                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    per_gpu = value / world
+    out["step_level"] = {"algorithmic_GBps": round(per_gpu * MB_PER_IMG[arch] / 1e3, 1),
+                         "hbm_frac": round(per_gpu * MB_PER_IMG[arch] / 1e3 / HBM_PEAK_GBS, 4),
+                         "algorithmic_TFLOPs": round(per_gpu * GFLOP_PER_IMG[arch] / 1e3, 2),
+                         "bf16_mfma_frac": round(per_gpu * GFLOP_PER_IMG[arch] / 1e3 / BF16_MFMA_PEAK_TFLOPS, 5),
+                         "fp32_mfma_frac": round(per_gpu * GFLOP_PER_IMG[arch] / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    if (pmc or {}).get(workload, {}).get("_step"):
+        out["step_level"].update(pmc[workload]["_step"])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ PMC passes (rocprofv3, spawned on this script)
+PMC_PASSES = [("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")]
+
+
+def _kname(full):
+    k = full.replace("void ", "").split("(")[0]
+    return k
+
+
+def pmc_collect(workloads, batch, timeout_s=240):
+    """rocprofv3 --pmc passes of `bench.py --pmc-child` (2 eager steps per workload): per workload and kernel the HBM bytes per
+    launch (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes) and the MFMA-busy fraction (sum SQ_VALU_MFMA_BUSY_CYCLES / (max GRBM_GUI_ACTIVE x 1024
+    SIMDs), the MfmaUtil definition of rocprofiler-sdk's counter_defs.yaml).  Returns ({workload: {kernel: {...}, "_step": {...}}}, error)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="mn_pmc_", dir="/tmp")
+    acc = {w: collections.defaultdict(lambda: collections.defaultdict(float)) for w in workloads}
+    cnt = {w: collections.defaultdict(lambda: collections.defaultdict(int)) for w in workloads}
+    err = None
+    env = dict(os.environ, TMPDIR="/tmp", PYTHONDONTWRITEBYTECODE="1")
+    for counters in PMC_PASSES:
+        for w in workloads:
+            d = os.path.join(tmp, counters[0] + "_" + w)
+            cmd = [rocprof, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--pmc-child", "--only", w, "--batch", str(batch)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+                if r.returncode != 0:
+                    err = "rocprofv3 %s rc=%d: %s" % (counters[0], r.returncode, r.stdout.decode(errors="replace")[-300:])
+                    continue
+            except subprocess.TimeoutExpired:
+                err = "rocprofv3 %s timed out" % counters[0]
+                continue
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                err = "no counter_collection.csv for %s" % counters[0]
+                continue
+            for row in csv.DictReader(open(files[0])):
+                k = _kname(row["Kernel_Name"])
+                c = row["Counter_Name"]
+                acc[w][k][c] += float(row["Counter_Value"])
+                cnt[w][k][c] += 1
+    shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for w in workloads:
+        res[w] = {}
+        tot_bytes = tot_mfma = tot_gui = 0.0
+        for k, v in acc[w].items():
+            e = {}
+            n_f, n_w = cnt[w][k].get("FETCH_SIZE", 0), cnt[w][k].get("WRITE_SIZE", 0)
+            if n_f and n_w:
+                fetch = 2.0 * v["FETCH_SIZE"] / n_f * 1024.0
+                write = v["WRITE_SIZE"] / n_w * 1024.0
+                e.update(bytes_per_launch=int(fetch + write), fetch_bytes_x2=int(fetch), write_bytes=int(write))
+                tot_bytes += 2.0 * v["FETCH_SIZE"] * 1024.0 + v["WRITE_SIZE"] * 1024.0
+            n_m = cnt[w][k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+            if n_m and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+                e["mfma_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * N_SIMD), 4)
+                tot_mfma += v["SQ_VALU_MFMA_BUSY_CYCLES"]
+                tot_gui += v["GRBM_GUI_ACTIVE"]
+            if e and (k.startswith("k_") or "k_" in k[:8]):
+                res[w][k] = e
+        step = {}
+        if tot_bytes:
+            step["pmc_hbm_bytes_per_step_all_kernels"] = int(tot_bytes / PMC_CHILD_STEPS)
+        if tot_gui:
+            step["pmc_mfma_busy_all_kernels"] = round(tot_mfma / (tot_gui * N_SIMD), 4)
+        res[w]["_step"] = step
+    return res, err
+
+
+PMC_CHILD_STEPS = 2
+
+
+def pmc_child(args, device):
+    """What the PMC passes profile: PMC_CHILD_STEPS eager steps of one workload (every dispatch is serialised by the counter collection)."""
+    from micronet_amd import dp
+    from micronet_amd.train import synth_batch
+    model, opt = build(args.only, device)
+    x, y = synth_batch(args.batch, device=device)
+    sync = dp.GradSync(model)
+    lib_steps = PMC_CHILD_STEPS
+    for _ in range(lib_steps):
+        dp.train_step_dp(model, opt, sync, x, y)
+    torch.cuda.synchronize()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS), help="primary workload (value / roofline / cpu_baseline)")
+    ap.add_argument("--also", default="c1_w2a2", help="comma-separated secondary workloads reported under `also` ('' = none)")
+    ap.add_argument("--only", default=None, choices=list(WORKLOADS), help="measure this single workload (no `also`)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=16, help="timed CPU steps at --cpu-batch (about 10-15 s of CPU work)")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying captured HIP graphs")
+    ap.add_argument("--kernel-steps", type=int, default=5, help="eager steps of the per-kernel HIP-event timing pass")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads for the CPU baseline; 0 = os.cpu_count(). 16 is the fastest setting measured on the MI355X host "
+                         "(2x EPYC 9575F: 97 img/s at 16 threads, 72 at 32, 41 at 64, 24 at 128, 1.1 at 256)")
+    ap.add_argument("--cpu-only", action="store_true", help="only time the CPU baseline (no GPU work)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic / mfma_busy stay null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    primary = args.only or args.workload
+    also = [] if args.only else [w for w in args.also.split(",") if w and w != primary]
+    for w in also:
+        if w not in WORKLOADS:
+            raise SystemExit("unknown workload in --also: %s" % w)
+    if args.cpu_only:
+        print(json.dumps(cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads)), flush=True)
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if args.pmc_child:
+        pmc_child(args, device)
+        return
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("MN_DIST_BACKEND", "nccl")      # "gloo": functional check of the multi-rank path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    m_primary = measure(primary, args, world, rank, device)
+    m_also, also_err = {}, {}
+    for w in also:
+        try:
+            m_also[w] = measure(w, args, world, rank, device)
+        except Exception as e:          # noqa: BLE001 -- the primary line must survive a failing secondary workload
+            if world > 1:
+                raise                   # ranks must stay in lock-step
+            also_err[w] = "%s: %s" % (type(e).__name__, str(e)[:300])
+
+    pmc, pmc_err = None, None
+    if world == 1 and rank == 0 and not args.no_pmc and not args.no_kernel_timing:
+        torch.cuda.synchronize()
+        pmc, pmc_err = pmc_collect([primary] + list(m_also), args.batch)
 
     if rank == 0:
-        imgs = args.batch * world * args.steps
-        value = imgs / dt
+        sec = section(primary, m_primary, args, world, pmc)
         out = {
-            "metric": "QAT images/sec (nin_gc CIFAR-10, W-ternary/A-binary)" if args.workload == "c2" else "QAT images/sec (%s)" % args.workload,
-            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC.get(primary, "QAT images/sec (%s)" % primary),
+            "value": sec["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD_DESC[args.workload], "global_batch": args.batch * world,
+            "config": {"workload": WORKLOAD_DESC[primary], "global_batch": args.batch * world,
                        "per_gpu_batch": args.batch, "parallelism": "dp%d" % world, "optimizer": "Adam lr=0.01",
-                       "hip_graph": graphed is not None, "final_loss": round(final_loss, 4)},
+                       "hip_graph": sec["hip_graph"], "final_loss": sec["final_loss"]},
         }
-        if graph_err:
-            out["config"]["hip_graph_error"] = graph_err
-        if agg:
-            ks = args.kernel_steps
-            dom = max(agg, key=lambda k: agg[k]["ms"])
-            d = agg[dom]
-            achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note in
-            # MI355X_MICROARCH.md, + WRITE_SIZE), collected separately (scripts/pmc_traffic.sh) and committed under profiles/
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-            if os.path.exists(tj):
-                traffic = json.load(open(tj)).get(dom, {}).get("bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "bytes_per_launch": int(d["bytes"] / d["launches"]),
-                               "avg_launch_us": round(1000.0 * d["ms"] / d["launches"], 2), "launches": d["launches"],
-                               "timing": "HIP events on the launch stream around every launch, %d eager steps after the timed region" % ks}
-            out["kernels"] = {k: {"ms_per_step": round(v["ms"] / ks, 4), "launches_per_step": v["launches"] / ks,
-                                  "avg_us": round(1000.0 * v["ms"] / v["launches"], 1),
-                                  "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-        if args.workload in ("c1", "c2", "c3", "c1_w2a2"):
-            per_gpu = value / world
-            out["step_level"] = {"algorithmic_GBps": round(per_gpu * NIN_GC_MB_PER_IMG / 1e3, 1),
-                                 "hbm_frac": round(per_gpu * NIN_GC_MB_PER_IMG / 1e3 / HBM_PEAK_GBS, 4),
-                                 "algorithmic_TFLOPs": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3, 2),
-                                 "fp32_mfma_frac": round(per_gpu * NIN_GC_GFLOP_PER_IMG / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        if "hip_graph_error" in sec:
+            out["config"]["hip_graph_error"] = sec["hip_graph_error"]
+        for k in ("roofline", "kernels", "step_level"):
+            if k in sec:
+                out[k] = sec[k]
+        if pmc_err:
+            out.setdefault("roofline", {})["pmc_error"] = pmc_err
+        if m_also or also_err:
+            out["also"] = {}
+            for w, m in m_also.items():
+                s = section(w, m, args, world, pmc)
+                s["metric"] = METRIC.get(w, "QAT images/sec (%s)" % w)
+                s["steps"], s["warmup"], s["n_gpus"] = args.steps, args.warmup, world
+                out["also"][w] = s
+            for w, e in also_err.items():
+                out["also"][w] = {"error": e}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,7 +1,9 @@
 #!/bin/bash
-# local helper: rebuild the gfx950 library (hipcc cross-compiles here), then run a script on the MI355X box
+# local helper: rebuild the gfx950 library (hipcc cross-compiles here), then run scripts/gpu_check.sh <args> on the MI355X box
+#   scripts/grun.sh "tests bench" [gpurun timeout s] [tail lines]
 set -e
 cd /root/repo
 python -m micronet_amd.build | tail -1
 bash tests/emu/build_emu.sh > /dev/null 2>&1 || true
-timeout ${2:-1500} /usr/local/graft/bin/gpurun --timeout ${3:-1200} -- "bash $1" 2>&1 | tail -${4:-80}
+T=${2:-1500}
+timeout $((T + 900)) /usr/local/graft/bin/gpurun --timeout $T -- "bash scripts/gpu_check.sh $1" 2>&1 | tail -${3:-80}
