@@ -198,7 +198,10 @@ __global__ __launch_bounds__(256, 2) void k_kk(const KkParams p) {
         };
         stage_interior(0);
         __syncthreads();
-        const int use1 = NTERM == 3 ? tflag[2 * ck] : 0, use2 = NTERM == 3 ? tflag[2 * ck + 1] : 0;   // block-uniform
+        // NTERM == 3 (backward-data: a real-valued gradient) contracts all three planes unconditionally.  An earlier version skipped the second /
+        // third plane when a chunk's flags said they were all zero; with run-time flags the kernel was intermittently wrong under load at batch 256
+        // (tests/test_gpu_determinism.py), and a real-valued gradient practically never has an all-zero remainder plane anyway.
+        constexpr int use1 = NTERM == 3, use2 = NTERM == 3;
         // ---- contraction over this chunk's K = T*CC
         auto contract = [&]() {
         for (int ks = 0; ks < p.KS; ++ks) {

@@ -35,7 +35,8 @@ FULL = {
     "c3_nin_gc_iao_w8a8_bnfuse": ("nin_gc", "wqaq.iao", dict(a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=True)),
 }
 # nin_gc: model.model = [L1, L2, L3, pool, L4, L5, L6, pool, L7, L8, L9, avgpool]; a pool is teacher-forced together with the block in front
-SEGMENTS = [[0], [1], [2, 3], [4], [5], [6, 7], [8], [9], [10], [11]]
+SEGMENTS_FUSED_POOL = [[0], [1], [2, 3], [4], [5], [6, 7], [8], [9], [10], [11]]
+SEGMENTS_SINGLE = [[i] for i in range(12)]
 
 
 def _record(path, key, value):
@@ -124,7 +125,14 @@ def test_full_batch_teacher_forced(key):
     pstages, ostages, prist = list(prod.model.children()), list(orc.model.children()), list(pristine.model.children())
     binary = scheme == "wbwtab"
     report, worst, failures = {}, 0.0, []
-    for seg in SEGMENTS:
+    # Which stages are teacher-forced together.  wbwtab: a block and the max-pool behind it (the pool hands its gradient to the block
+    # un-expanded; +-1 activations have no near-ties: the pool's first-maximum rule is decided identically on both sides).  DoReFa / IAO:
+    # every stage alone.  A low-bit conv output takes few distinct values, so a 2x2 window holds many mathematically EQUAL maxima; the
+    # reference breaks such ties by the rounding noise of its fp32 convolution (its dequantised levels are not exact multiples of one
+    # step), which no other summation order reproduces -- so the argmax, and with it every gradient behind the pool, is only defined up
+    # to that tie-break.  Teacher-forcing the pool on its own (oracle input in, bit-exact first-maximum rule) keeps the statement exact.
+    segments = SEGMENTS_FUSED_POOL if binary else SEGMENTS_SINGLE
+    for seg in segments:
         first, last = str(seg[0]), str(seg[-1])
         r_in, r_out = rec[first], rec[last]
         # ---- input in the pipeline's physical form
@@ -179,6 +187,7 @@ def test_full_batch_teacher_forced(key):
                 e = _rel(g, g_ref)
                 errs["d" + name] = e
                 if e > 1e-5:
+                    errs["d" + name + "_vs_reference_fp32"] = e
                     need64[(i, name)] = (g, g_ref)
         slack = {}
         if need64:
@@ -195,7 +204,7 @@ def test_full_batch_teacher_forced(key):
                 slack["d" + name] = 2.0 * e_ref
         report["+".join(type(pstages[i]).__name__ + str(i) for i in seg)] = {k: float("%.2e" % v) for k, v in errs.items()}
         for k_, v in errs.items():
-            if k_ == "sign_mismatch" or k_.endswith("_vs_fp64"):
+            if k_ == "sign_mismatch" or k_.endswith("_vs_fp64") or k_.endswith("_vs_reference_fp32"):
                 continue
             lim = max(1e-5, slack.get(k_, 0.0))
             worst = max(worst, v)
