@@ -115,6 +115,24 @@ int mn_iao_fq_fwd(const float* x, float* y, int64_t rows, int64_t cols, const fl
 /* backward: dx = ((g*s)/s) * [qmin <= r <= qmax] * [lo <= v <= hi] */
 int mn_iao_fq_bwd(const float* g, const float* x, float* dx, int64_t rows, int64_t cols, const float* qp, int bits,
                   int q_type, int is_act, mn_stream_t stream);
+/* Fake-quant fused with the activation behind it: QuantReLU / QuantLeakyReLU / QuantSigmoid.forward (1196-1199, 1240-1243, 1279-1282):
+ * y = act(Q(x)), per-tensor quantizer snapshot qp = {scale, zero_point, lo, hi}; act: 1 relu, 2 leaky_relu(slope), 3 sigmoid.
+ * backward: dx = Q'(x) * act'(Q(x)) * g (threshold / leaky / sigmoid backward of ATen, then the clip-STE of Round.backward 163-168). */
+int mn_iao_fq_act_fwd(const float* x, float* y, int64_t n, const float* qp, int bits, int q_type, int act, float slope, mn_stream_t stream);
+int mn_iao_fq_act_bwd(const float* g, const float* x, float* dx, int64_t n, const float* qp, int bits, int q_type, int act, float slope,
+                      mn_stream_t stream);
+/* Fake-quant fused with average pooling: QuantAvgPool2d.forward (1401-1411) for kernel k x k, stride k, no padding (H % k == W % k == 0), and
+ * QuantAdaptiveAvgPool2d((1, 1)) as k == H == W (1433-1436).  x: [planes][H][W], y: [planes][H/k][W/k]. */
+int mn_iao_fq_avgpool_supported(int64_t H, int64_t W, int64_t k);
+int mn_iao_fq_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t H, int64_t W, int64_t k, const float* qp, int bits, int q_type,
+                          mn_stream_t stream);
+int mn_iao_fq_avgpool_bwd(const float* g, const float* x, float* dx, int64_t planes, int64_t H, int64_t W, int64_t k, const float* qp, int bits,
+                          int q_type, mn_stream_t stream);
+/* HistogramObserver.forward (116-139), the PTQ percentile calibrator: cur = k-th smallest |x| (k 1-based = int(percentile * n), exact --
+ * a radix select on the bit patterns, bit-identical to torch.kthvalue); max_val = cur when first != 0 else (1 - momentum) * max_val +
+ * momentum * cur, on the device.  out (nullable) receives cur.  ws: mn_kth_abs_ws_bytes() bytes, 4-byte aligned. */
+int64_t mn_kth_abs_ws_bytes(void);
+int mn_hist_observe(const float* x, int64_t n, int64_t k, int first, double momentum, float* max_val, float* out, void* ws, mn_stream_t stream);
 /* QuantAdd.forward 1487-1492: union of two observer ranges */
 int mn_iao_union_range(const float* min_a, const float* max_a, const float* min_b, const float* max_b,
                        float* min_out, float* max_out, mn_stream_t stream);

@@ -107,6 +107,13 @@ PROTOTYPES = {
     "mn_signconv1x1_small_supported": (_I, [_L, _L, _L]),
     "mn_signconv1x1_small_fwd": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P]),
     "mn_conv1x1_small_bwd_data": (_I, [_P, _P, _P, _L, _L, _L, _L, _P]),
+    "mn_iao_fq_act_fwd": (_I, [_P, _P, _L, _P, _I, _I, _I, C.c_float, _P]),
+    "mn_iao_fq_act_bwd": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, C.c_float, _P]),
+    "mn_iao_fq_avgpool_supported": (_I, [_L, _L, _L]),
+    "mn_iao_fq_avgpool_fwd": (_I, [_P, _P, _L, _L, _L, _L, _P, _I, _I, _P]),
+    "mn_iao_fq_avgpool_bwd": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _I, _I, _P]),
+    "mn_kth_abs_ws_bytes": (_L, []),
+    "mn_hist_observe": (_I, [_P, _L, _L, _I, C.c_double, _P, _P, _P, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),

@@ -1,0 +1,236 @@
+// The rest of the IAO module surface on gfx950 (reference: wqaq/iao/quantize.py):
+//   * fake-quant fused with the activation behind it -- QuantReLU / QuantLeakyReLU / QuantSigmoid (ref 1160-1330): y = act(Q(x)) in ONE streaming
+//     pass (the reference runs ~12 ATen kernels for Q plus one for the activation), backward dx = Q'(x) * act'(Q(x)) * g in one pass;
+//   * fake-quant fused with average pooling -- QuantAvgPool2d (k x k, stride k, no padding) and QuantAdaptiveAvgPool2d((1, 1)) (ref 1375-1438):
+//     the quantised tensor is never written;
+//   * the PTQ percentile calibrator -- HistogramObserver (ref 116-139): the k-th smallest |x| by an exact 3-pass radix select on the fp32 bit
+//     patterns (11 + 11 + 10 bits; integer atomics only, so the result is deterministic and bit-identical to torch.kthvalue), with the
+//     first-call / moving-average update of max_val in the last launch: no host synchronisation.
+// All HBM-bound streaming work: float4 per lane, grid-stride loops.
+#include "common.h"
+
+#include <math.h>
+
+#define ACT_RELU 1
+#define ACT_LEAKY 2
+#define ACT_SIGMOID 3
+
+struct FqC { float sc, zp, lo, hi, qmin, qmax, slope; int act; };
+
+__device__ __forceinline__ float act_apply(float q, const FqC& c) {
+    if (c.act == ACT_RELU) return q > 0.f ? q : 0.f;                       // at::relu = clamp_min(0): NaN propagates below
+    if (c.act == ACT_LEAKY) return q > 0.f ? q : q * c.slope;
+    return 1.f / (1.f + expf(-q));
+}
+__device__ __forceinline__ float fq_act_fwd1(float x, const FqC& c) {
+    const float q = iao_fq(x, c.sc, c.zp, c.qmin, c.qmax);
+    if (q != q) return q;
+    return act_apply(q, c);
+}
+__device__ __forceinline__ float fq_act_bwd1(float g, float x, const FqC& c) {
+    const float q = iao_fq(x, c.sc, c.zp, c.qmin, c.qmax);
+    float d;
+    if (c.act == ACT_RELU) d = q > 0.f ? g : 0.f;                           // threshold_backward: grad where result > 0
+    else if (c.act == ACT_LEAKY) d = q > 0.f ? g : g * c.slope;
+    else { const float y = 1.f / (1.f + expf(-q)); d = g * (1.f - y) * y; }  // sigmoid_backward: grad * (1 - y) * y
+    return iao_fq_grad(d, x, c.sc, c.zp, c.lo, c.hi, c.qmin, c.qmax);
+}
+
+__global__ __launch_bounds__(256) void k_fq_act_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, const float* __restrict__ qp, FqC c, int vec) {
+    c.sc = qp[0]; c.zp = qp[1]; c.lo = qp[2]; c.hi = qp[3];
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t j = t0; j < n4; j += stride) {
+            const float4 v = reinterpret_cast<const float4*>(x)[j];
+            reinterpret_cast<float4*>(y)[j] = make_float4(fq_act_fwd1(v.x, c), fq_act_fwd1(v.y, c), fq_act_fwd1(v.z, c), fq_act_fwd1(v.w, c));
+        }
+        for (int64_t j = (n4 << 2) + t0; j < n; j += stride) y[j] = fq_act_fwd1(x[j], c);
+    } else {
+        for (int64_t j = t0; j < n; j += stride) y[j] = fq_act_fwd1(x[j], c);
+    }
+}
+__global__ __launch_bounds__(256) void k_fq_act_bwd(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dx, int64_t n,
+                                                    const float* __restrict__ qp, FqC c, int vec) {
+    c.sc = qp[0]; c.zp = qp[1]; c.lo = qp[2]; c.hi = qp[3];
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t j = t0; j < n4; j += stride) {
+            const float4 v = reinterpret_cast<const float4*>(x)[j], gg = reinterpret_cast<const float4*>(g)[j];
+            reinterpret_cast<float4*>(dx)[j] = make_float4(fq_act_bwd1(gg.x, v.x, c), fq_act_bwd1(gg.y, v.y, c), fq_act_bwd1(gg.z, v.z, c), fq_act_bwd1(gg.w, v.w, c));
+        }
+        for (int64_t j = (n4 << 2) + t0; j < n; j += stride) dx[j] = fq_act_bwd1(g[j], x[j], c);
+    } else {
+        for (int64_t j = t0; j < n; j += stride) dx[j] = fq_act_bwd1(g[j], x[j], c);
+    }
+}
+static int fq_c(FqC* c, int bits, int q_type, int act, float slope, const char* what) {
+    if (bits < 2 || bits > 24 || act < ACT_RELU || act > ACT_SIGMOID) MN_FAIL(MN_EINVAL, "%s: bits=%d act=%d", what, bits, act);
+    const IaoRange r = iao_range(bits, q_type, 1);
+    c->qmin = r.qmin; c->qmax = r.qmax; c->slope = slope; c->act = act; c->sc = 1.f; c->zp = c->lo = c->hi = 0.f;
+    return MN_OK;
+}
+extern "C" int mn_iao_fq_act_fwd(const float* x, float* y, int64_t n, const float* qp, int bits, int q_type, int act, float slope, mn_stream_t stream) {
+    FqC c;
+    if (n <= 0 || !x || !y || !qp) MN_FAIL(MN_EINVAL, "mn_iao_fq_act_fwd: bad arguments");
+    int rc = fq_c(&c, bits, q_type, act, slope, "mn_iao_fq_act_fwd");
+    if (rc) return rc;
+    const int vec = aligned16(x) && aligned16(y);
+    hipLaunchKernelGGL(k_fq_act_fwd, dim3(mn_grid_for(vec ? (n + 3) / 4 : n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x, y, n, qp, c, vec);
+    MN_CHECK_LAUNCH("mn_iao_fq_act_fwd");
+    return MN_OK;
+}
+extern "C" int mn_iao_fq_act_bwd(const float* g, const float* x, float* dx, int64_t n, const float* qp, int bits, int q_type, int act, float slope,
+                                 mn_stream_t stream) {
+    FqC c;
+    if (n <= 0 || !g || !x || !dx || !qp) MN_FAIL(MN_EINVAL, "mn_iao_fq_act_bwd: bad arguments");
+    int rc = fq_c(&c, bits, q_type, act, slope, "mn_iao_fq_act_bwd");
+    if (rc) return rc;
+    const int vec = aligned16(x) && aligned16(g) && aligned16(dx);
+    hipLaunchKernelGGL(k_fq_act_bwd, dim3(mn_grid_for(vec ? (n + 3) / 4 : n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, g, x, dx, n, qp, c, vec);
+    MN_CHECK_LAUNCH("mn_iao_fq_act_bwd");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fake-quant + average pooling
+// y[p][oh][ow] = (sum over the k x k window, rows then columns, fp32 -- the order of ATen's avg_pool2d) / (k*k); one thread per output.
+__global__ __launch_bounds__(256) void k_fq_avgpool_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t planes, int H, int W, int k,
+                                                        const float* __restrict__ qp, FqC c) {
+    c.sc = qp[0]; c.zp = qp[1];
+    const int Ho = H / k, Wo = W / k;
+    const int64_t total = planes * Ho * Wo;
+    const float div = (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % Wo);
+        const int64_t t = i / Wo;
+        const int oh = (int)(t % Ho);
+        const int64_t p = t / Ho;
+        const float* src = x + (p * H + (int64_t)oh * k) * W + (int64_t)ow * k;
+        float s = 0.f;
+        for (int r = 0; r < k; ++r)
+            for (int q = 0; q < k; ++q) s += iao_fq(src[(int64_t)r * W + q], c.sc, c.zp, c.qmin, c.qmax);
+        y[i] = s / div;
+    }
+}
+// dx = Q'(x) * g[window] / (k*k); one thread per input element, float4 when W % 4 == 0 and k % 4 == 0 or k divides 4 ... kept scalar-simple: coalesced anyway
+__global__ __launch_bounds__(256) void k_fq_avgpool_bwd(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dx, int64_t planes, int H, int W,
+                                                        int k, const float* __restrict__ qp, FqC c) {
+    c.sc = qp[0]; c.zp = qp[1]; c.lo = qp[2]; c.hi = qp[3];
+    const int Ho = H / k, Wo = W / k;
+    const int64_t total = planes * H * W;
+    const float div = (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const int64_t t = i / W;
+        const int h = (int)(t % H);
+        const int64_t p = t / H;
+        const float gv = g[(p * Ho + h / k) * Wo + w / k] / div;
+        dx[i] = iao_fq_grad(gv, x[i], c.sc, c.zp, c.lo, c.hi, c.qmin, c.qmax);
+    }
+}
+// global average (AdaptiveAvgPool2d((1, 1))): one wave per plane, fp64 accumulation (order-independent to the last fp32 bit)
+__global__ __launch_bounds__(64) void k_fq_gap_fwd(const float* __restrict__ x, float* __restrict__ y, int HW, const float* __restrict__ qp, FqC c) {
+    c.sc = qp[0]; c.zp = qp[1];
+    const float* src = x + (int64_t)blockIdx.x * HW;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < HW; i += 64) s += (double)iao_fq(src[i], c.sc, c.zp, c.qmin, c.qmax);
+    s = wave_reduce(s, OpAddD());
+    if (threadIdx.x == 0) y[blockIdx.x] = (float)(s / (double)HW);
+}
+extern "C" int mn_iao_fq_avgpool_supported(int64_t H, int64_t W, int64_t k) { return k >= 1 && k <= 64 && H >= k && W >= k && H % k == 0 && W % k == 0; }
+extern "C" int mn_iao_fq_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t H, int64_t W, int64_t k, const float* qp, int bits, int q_type,
+                                     mn_stream_t stream) {
+    FqC c;
+    if (planes <= 0 || !x || !y || !qp || !mn_iao_fq_avgpool_supported(H, W, k)) MN_FAIL(MN_EINVAL, "mn_iao_fq_avgpool_fwd: bad arguments");
+    int rc = fq_c(&c, bits, q_type, ACT_RELU, 0.f, "mn_iao_fq_avgpool_fwd");
+    if (rc) return rc;
+    if (k == H && k == W) {
+        hipLaunchKernelGGL(k_fq_gap_fwd, dim3((unsigned)planes), dim3(64), 0, (hipStream_t)stream, x, y, (int)(H * W), qp, c);
+    } else {
+        const int64_t total = planes * (H / k) * (W / k);
+        hipLaunchKernelGGL(k_fq_avgpool_fwd, dim3(mn_grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, planes, (int)H, (int)W, (int)k, qp, c);
+    }
+    MN_CHECK_LAUNCH("mn_iao_fq_avgpool_fwd");
+    return MN_OK;
+}
+extern "C" int mn_iao_fq_avgpool_bwd(const float* g, const float* x, float* dx, int64_t planes, int64_t H, int64_t W, int64_t k, const float* qp, int bits,
+                                     int q_type, mn_stream_t stream) {
+    FqC c;
+    if (planes <= 0 || !g || !x || !dx || !qp || !mn_iao_fq_avgpool_supported(H, W, k)) MN_FAIL(MN_EINVAL, "mn_iao_fq_avgpool_bwd: bad arguments");
+    int rc = fq_c(&c, bits, q_type, ACT_RELU, 0.f, "mn_iao_fq_avgpool_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fq_avgpool_bwd, dim3(mn_grid_for(planes * H * W, 256, 4096)), dim3(256), 0, (hipStream_t)stream, g, x, dx, planes, (int)H, (int)W, (int)k, qp, c);
+    MN_CHECK_LAUNCH("mn_iao_fq_avgpool_bwd");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ HistogramObserver: exact k-th smallest |x|
+// ws (uint32): [0 .. 2048) histogram of the current digit, [2048] prefix (the bits decided so far), [2049] remaining rank (1-based) inside the prefix
+// bucket.  Pass d (0, 1, 2) histograms digit d of the elements whose higher digits equal the prefix; k_kth_pick then finds the digit that holds the
+// wanted rank.  |x| of a finite or infinite float orders like its bit pattern; NaN patterns sort above +inf, where torch.kthvalue also puts them.
+#define KTH_BINS 2048
+__device__ __forceinline__ uint32_t kth_digit(uint32_t u, int pass) { return pass == 0 ? (u >> 21) : (pass == 1 ? ((u >> 10) & 2047u) : (u & 1023u)); }
+__device__ __forceinline__ uint32_t kth_hi(uint32_t u, int pass) { return pass == 0 ? 0u : (pass == 1 ? (u >> 21) : (u >> 10)); }
+
+__global__ __launch_bounds__(256) void k_kth_hist(const float* __restrict__ x, int64_t n, int pass, uint32_t* __restrict__ ws) {
+    __shared__ uint32_t h[KTH_BINS];
+    for (int i = threadIdx.x; i < KTH_BINS; i += 256) h[i] = 0u;
+    __syncthreads();
+    const uint32_t prefix = pass == 0 ? 0u : ws[KTH_BINS];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = mn_f2u(x[i]) & 0x7fffffffu;
+        if (kth_hi(u, pass) == prefix) atomicAdd(&h[kth_digit(u, pass)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KTH_BINS; i += 256)
+        if (h[i]) atomicAdd(&ws[i], h[i]);
+}
+// one block: scan the histogram for the bucket that holds the rank; last pass: write the value and update max_val (first call copies, else EMA)
+__global__ __launch_bounds__(256) void k_kth_pick(uint32_t* __restrict__ ws, int pass, uint32_t k_rank, int first, float keep, float momentum, float* __restrict__ max_val,
+                                                  float* __restrict__ out) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t sel[2];
+    const int nb = pass == 2 ? 1024 : 2048, per = nb / 256;
+    uint32_t local = 0u;
+    for (int i = 0; i < per; ++i) local += ws[threadIdx.x * per + i];
+    cnt[threadIdx.x] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t rank = pass == 0 ? k_rank : ws[KTH_BINS + 1];
+        int t = 0;
+        while (t < 255 && rank > cnt[t]) { rank -= cnt[t]; ++t; }
+        int b = t * per;
+        while (b < t * per + per - 1 && rank > ws[b]) { rank -= ws[b]; ++b; }
+        sel[0] = (uint32_t)b; sel[1] = rank;
+    }
+    __syncthreads();
+    const uint32_t b = sel[0], rank = sel[1];
+    __syncthreads();
+    for (int i = threadIdx.x; i < KTH_BINS; i += 256) ws[i] = 0u;          // ready for the next pass
+    if (threadIdx.x == 0) {
+        const uint32_t prefix = pass == 0 ? b : (pass == 1 ? ((ws[KTH_BINS] << 11) | b) : ((ws[KTH_BINS] << 10) | b));
+        ws[KTH_BINS] = prefix; ws[KTH_BINS + 1] = rank;
+        if (pass == 2) {
+            const float cur = mn_u2f(prefix);
+            if (out) *out = cur;
+            if (max_val) *max_val = first ? cur : keep * (*max_val) + momentum * cur;
+        }
+    }
+}
+extern "C" int64_t mn_kth_abs_ws_bytes(void) { return (KTH_BINS + 16) * 4; }
+/* HistogramObserver.forward (ref 126-139): cur = k-th smallest |x| (k 1-based, = int(percentile * n)); max_val = cur on the first call, else
+ * (1 - momentum) * max_val + momentum * cur.  `out` (nullable) receives cur.  ws: mn_kth_abs_ws_bytes() bytes, 16-byte aligned. */
+extern "C" int mn_hist_observe(const float* x, int64_t n, int64_t k, int first, double momentum, float* max_val, float* out, void* ws, mn_stream_t stream) {
+    if (!x || n <= 0 || k < 1 || k > n || n > 0xffffffffll || !ws || (((uintptr_t)ws) & 3)) MN_FAIL(MN_EINVAL, "mn_hist_observe: bad arguments (n=%lld k=%lld)", (long long)n, (long long)k);
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* w = (uint32_t*)ws;
+    if (hipMemsetAsync(w, 0, (KTH_BINS + 16) * 4, s) != hipSuccess) MN_FAIL(MN_EHIP, "mn_hist_observe: memset failed");
+    const int grid = mn_grid_for(n, 256 * 8, 1024);
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL(k_kth_hist, dim3(grid), dim3(256), 0, s, x, n, pass, w);
+        hipLaunchKernelGGL(k_kth_pick, dim3(1), dim3(256), 0, s, w, pass, (uint32_t)k, first, (float)(1.0 - momentum), (float)momentum, max_val, out);
+    }
+    MN_CHECK_LAUNCH("mn_hist_observe");
+    return MN_OK;
+}

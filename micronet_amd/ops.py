@@ -332,6 +332,73 @@ class IaoFakeQuant(Function):
         return dx, None, None, None, None
 
 
+ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 1, 2, 3
+
+
+class IaoFakeQuantAct(Function):
+    """act(Q(x)) in one pass (QuantReLU / QuantLeakyReLU / QuantSigmoid, wqaq/iao/quantize.py:1196-1199, 1240-1243, 1279-1282); per-tensor quantizer."""
+
+    @staticmethod
+    def forward(ctx, x, qp, bits, q_type, act, slope):
+        x = _chk(x, "input")
+        y = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_iao_fq_act_fwd", _p(x), _p(y), x.numel(), _p(qp), bits, q_type, act, float(slope), _s())
+        ctx.save_for_backward(x, qp)
+        ctx.cfg = (bits, q_type, act, float(slope))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, qp = ctx.saved_tensors
+        bits, q_type, act, slope = ctx.cfg
+        g = _chk(g, "grad")
+        dx = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_iao_fq_act_bwd", _p(g), _p(x), _p(dx), x.numel(), _p(qp), bits, q_type, act, slope, _s())
+        return dx, None, None, None, None, None
+
+
+def iao_avgpool_supported(x, k):
+    return torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.numel() > 0 and \
+        bool(_lib_().mn_iao_fq_avgpool_supported(x.shape[2], x.shape[3], k))
+
+
+class IaoFakeQuantAvgPool(Function):
+    """avg_pool2d(Q(x), k, k) (QuantAvgPool2d / QuantAdaptiveAvgPool2d((1, 1)), wqaq/iao/quantize.py:1401-1436) without materialising Q(x)."""
+
+    @staticmethod
+    def forward(ctx, x, qp, bits, q_type, k):
+        x = _chk(x, "input")
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, H // k, W // k), dtype=torch.float32, device=x.device)
+        with torch.cuda.device_of(x):
+            _call("mn_iao_fq_avgpool_fwd", _p(x), _p(y), N * Cc, H, W, k, _p(qp), bits, q_type, _s())
+        ctx.save_for_backward(x, qp)
+        ctx.cfg = (bits, q_type, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, qp = ctx.saved_tensors
+        bits, q_type, k = ctx.cfg
+        g = _chk(g, "grad")
+        N, Cc, H, W = x.shape
+        dx = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_iao_fq_avgpool_bwd", _p(g), _p(x), _p(dx), N * Cc, H, W, k, _p(qp), bits, q_type, _s())
+        return dx, None, None, None, None
+
+
+def hist_observe(x, percentile, first, momentum, max_val):
+    """HistogramObserver.forward (ref 126-139) on the device: exact k-th smallest |x| + first-call / EMA update of ``max_val``."""
+    x = _chk(x.detach(), "input")
+    n = x.numel()
+    ws = torch.empty(int(_lib_().mn_kth_abs_ws_bytes()) // 4, dtype=torch.int32, device=x.device)
+    with torch.cuda.device_of(x):
+        _call("mn_hist_observe", _p(x), n, int(percentile * n), int(first), float(momentum), _p(max_val), None, _p(ws), _s())
+
+
 class BnBatchStats(Function):
     """(mean, unbiased var) over (N, H, W) of a conv output; differentiable (the BN-fuse fold keeps them in the graph)."""
 

@@ -81,8 +81,9 @@ class MovingAverageMinMaxObserver(ObserverBase):
 
 
 class HistogramObserver(nn.Module):
-    """Percentile calibrator of the PTQ mode (ref 116-139).  PTQ is off the QAT hot path: the
-    k-th value selection is delegated to ``torch.kthvalue`` on the device; only ``max_val`` is maintained."""
+    """Percentile calibrator of the PTQ mode (ref 116-139): max_val = moving average of the k-th smallest |x|, k = int(percentile * n).
+    On the GPU the selection is an exact three-pass radix select over the fp32 bit patterns (``mn_hist_observe``: bit-identical to
+    ``torch.kthvalue``, no sort, no host synchronisation -- the first-call / EMA update happens in the last launch)."""
 
     def __init__(self, q_level, momentum=0.1, percentile=0.9999):
         super().__init__()
@@ -95,14 +96,9 @@ class HistogramObserver(nn.Module):
 
     @torch.no_grad()
     def forward(self, input):
-        flat = input.abs().view(-1)
-        cur = torch.kthvalue(flat, int(self.percentile * flat.size(0)), dim=0)[0]
+        ops.hist_observe(input, self.percentile, self.num_flag == 0, self.momentum, self.max_val)
         if self.num_flag == 0:
             self.num_flag += 1
-            new = cur
-        else:
-            new = (1 - self.momentum) * self.max_val + self.momentum * cur
-        self.max_val.copy_(new)
 
 
 # ------------------------------------------------------------------------------------------------ quantizers
@@ -373,13 +369,27 @@ class QuantLinear(nn.Linear):
 
 
 # ------------------------------------------------------------------------------------------------ quantised non-conv ops
+def _fused_act(quantizer, input, act, slope, fallback):
+    """act(Q(input)): one fused gfx950 pass (ops.IaoFakeQuantAct) for a per-tensor quantizer on a CUDA fp32 tensor; ``fallback`` (the
+    reference's two-step form on our fake-quant kernel) otherwise."""
+    if torch.is_tensor(input) and input.is_cuda and input.dtype == torch.float32 and input.numel() > 0:
+        qp = quantizer.qparams(input)
+        quantizer._last_qp = qp
+        if qp is None:
+            return fallback(input)
+        if qp.shape[0] == 1:
+            return ops.IaoFakeQuantAct.apply(input, qp, quantizer.bits, quantizer.q_type, act, slope)
+        return fallback(ops.IaoFakeQuant.apply(input, qp, quantizer.bits, quantizer.q_type, quantizer.activation_weight_flag == 1))
+    return fallback(quantizer(input))
+
+
 class QuantReLU(nn.ReLU):
     def __init__(self, inplace=False, a_bits=8, q_type=0, qaft=False, ptq=False, percentile=0.9999):
         super().__init__(inplace)
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
 
     def forward(self, input):
-        return F.relu(self.activation_quantizer(input), self.inplace)
+        return _fused_act(self.activation_quantizer, input, ops.ACT_RELU, 0.0, lambda q: F.relu(q, self.inplace))
 
 
 class QuantLeakyReLU(nn.LeakyReLU):
@@ -388,7 +398,8 @@ class QuantLeakyReLU(nn.LeakyReLU):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
 
     def forward(self, input):
-        return F.leaky_relu(self.activation_quantizer(input), self.negative_slope, self.inplace)
+        return _fused_act(self.activation_quantizer, input, ops.ACT_LEAKY, self.negative_slope,
+                          lambda q: F.leaky_relu(q, self.negative_slope, self.inplace))
 
 
 class QuantSigmoid(nn.Sigmoid):
@@ -397,7 +408,7 @@ class QuantSigmoid(nn.Sigmoid):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
 
     def forward(self, input):
-        return torch.sigmoid(self.activation_quantizer(input))
+        return _fused_act(self.activation_quantizer, input, ops.ACT_SIGMOID, 0.0, torch.sigmoid)
 
 
 class QuantMaxPool2d(nn.MaxPool2d):
@@ -421,6 +432,15 @@ class QuantAvgPool2d(nn.AvgPool2d):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
 
     def forward(self, input):
+        k = self.kernel_size if isinstance(self.kernel_size, int) else (self.kernel_size[0] if self.kernel_size[0] == self.kernel_size[1] else 0)
+        st = self.stride if self.stride is not None else self.kernel_size
+        if k and st in (k, (k, k)) and self.padding in (0, (0, 0)) and not self.ceil_mode and self.divisor_override is None and ops.iao_avgpool_supported(input, k):
+            q = self.activation_quantizer
+            qp = q.qparams(input)
+            if qp is not None and qp.shape[0] == 1:
+                return ops.IaoFakeQuantAvgPool.apply(input, qp, q.bits, q.q_type, k)     # the quantised tensor is never written
+            return F.avg_pool2d(input if qp is None else ops.IaoFakeQuant.apply(input, qp, q.bits, q.q_type, True), self.kernel_size, self.stride,
+                                self.padding, self.ceil_mode, self.count_include_pad, self.divisor_override)
         return F.avg_pool2d(self.activation_quantizer(input), self.kernel_size, self.stride, self.padding, self.ceil_mode,
                             self.count_include_pad, self.divisor_override)
 
@@ -431,6 +451,12 @@ class QuantAdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
 
     def forward(self, input):
+        if self.output_size in (1, (1, 1)) and input.dim() == 4 and input.shape[2] == input.shape[3] and ops.iao_avgpool_supported(input, input.shape[2]):
+            q = self.activation_quantizer
+            qp = q.qparams(input)
+            if qp is not None and qp.shape[0] == 1:
+                return ops.IaoFakeQuantAvgPool.apply(input, qp, q.bits, q.q_type, int(input.shape[2]))
+            return F.adaptive_avg_pool2d(input if qp is None else ops.IaoFakeQuant.apply(input, qp, q.bits, q.q_type, True), self.output_size)
         return F.adaptive_avg_pool2d(self.activation_quantizer(input), self.output_size)
 
 

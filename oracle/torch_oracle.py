@@ -163,6 +163,26 @@ class Observer(nn.Module):
         self.max_val.copy_(hi)
 
 
+class HistObserver(nn.Module):
+    """wqaq/iao/quantize.py:116-139 (PTQ percentile calibrator): max_val = EMA of the k-th smallest |x|, k = int(percentile * n);
+    min_val stays 0."""
+
+    def __init__(self, percentile=0.9999, momentum=0.1):
+        super().__init__()
+        self.level, self.percentile, self.momentum, self.first = "L", percentile, momentum, True
+        self.register_buffer("min_val", torch.zeros(1))
+        self.register_buffer("max_val", torch.zeros(1))
+
+    @torch.no_grad()
+    def forward(self, x):
+        cur = torch.kthvalue(x.abs().view(-1), int(self.percentile * x.view(-1).size(0)), dim=0)[0]
+        if self.first:
+            self.first = False
+        else:
+            cur = (1 - self.momentum) * self.max_val + self.momentum * cur
+        self.max_val.copy_(cur)
+
+
 class IaoQuantizer(nn.Module):
     def __init__(self, bits, observer, is_act, q_type, union=False, qaft=False):
         super().__init__()
@@ -207,10 +227,17 @@ class IaoQuantizer(nn.Module):
         return (torch.clamp(r, self.qmin, self.qmax) + self.zero_point) * self.scale.clone()
 
 
-def _iao_pair(a_bits, w_bits, q_type, q_level, weight_observer, out_ch, w_level_c):
-    aq = IaoQuantizer(a_bits, Observer("L"), True, q_type)
+def _iao_act_quantizer(a_bits, q_type, qaft=False, ptq=False, percentile=0.9999, union=False):
+    """ref 361-368 and the `ptq` branches of every Quant* constructor: PTQ is always symmetric with the percentile observer."""
+    if ptq:
+        return IaoQuantizer(a_bits, HistObserver(percentile), True, 0, union=union, qaft=qaft)
+    return IaoQuantizer(a_bits, Observer("L"), True, q_type, union=union, qaft=qaft)
+
+
+def _iao_pair(a_bits, w_bits, q_type, q_level, weight_observer, out_ch, w_level_c, qaft=False, ptq=False, percentile=0.9999):
+    aq = _iao_act_quantizer(a_bits, q_type, qaft, ptq, percentile)
     lvl = w_level_c if q_level == 0 else "L"
-    wq = IaoQuantizer(w_bits, Observer(lvl, out_ch if lvl != "L" else None, ema=(weight_observer != 0)), False, q_type)
+    wq = IaoQuantizer(w_bits, Observer(lvl, out_ch if lvl != "L" else None, ema=(weight_observer != 0)), False, 0 if ptq else q_type, qaft=qaft)
     return aq, wq
 
 
@@ -227,7 +254,8 @@ class OConv2d(nn.Conv2d):
             self.bias = src.bias
         if scheme == "iao":
             self.aq, self.wq = _iao_pair(cfg["a_bits"], cfg["w_bits"], cfg.get("q_type", 0), cfg.get("q_level", 0),
-                                         cfg.get("weight_observer", 0), src.out_channels, "C")
+                                         cfg.get("weight_observer", 0), src.out_channels, "C", cfg.get("qaft", False),
+                                         cfg.get("ptq", False), cfg.get("percentile", 0.9999))
 
     def _conv(self, x, w, b):
         return F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
@@ -241,19 +269,23 @@ class OConv2d(nn.Conv2d):
 
 
 class OBNFuseConv2d(OConv2d):
+    """wqaq/iao/quantize.py:837-994 incl. the bn_fuse_calib (889-899, 957-972), qaft (918-935, 983-993) and pretrained_model (856-879) branches."""
+
     def __init__(self, src, bn, **cfg):
         super().__init__(src, "iao", **cfg)
         self.eps, self.momentum, self.first = bn.eps, bn.momentum, True
+        self.calib, self.qaft, self.pretrained = cfg.get("bn_fuse_calib", False), cfg.get("qaft", False), cfg.get("pretrained_model", False)
         self.gamma, self.beta = bn.weight, bn.bias
         self.register_buffer("running_mean", bn.running_mean.clone())
         self.register_buffer("running_var", bn.running_var.clone())
 
     def forward(self, x):
-        if self.training:
+        batch = self.training and not self.qaft
+        if batch:
             o = self._conv(x, self.weight, self.bias)
             mean, var = torch.mean(o, dim=[0, 2, 3]), torch.var(o, dim=[0, 2, 3])
             with torch.no_grad():
-                if self.first:
+                if self.first and not self.pretrained:
                     self.first = False
                     rm, rv = mean, var
                 else:
@@ -267,8 +299,15 @@ class OBNFuseConv2d(OConv2d):
             b_f = (self.beta + (self.bias - mean) * (self.gamma / torch.sqrt(var + self.eps))).reshape(-1)
         else:
             b_f = (self.beta - mean * (self.gamma / torch.sqrt(var + self.eps))).reshape(-1)
-        w_f = self.weight * (self.gamma / torch.sqrt(var + self.eps)).reshape(-1, 1, 1, 1)
-        return self._conv(self.aq(x), self.wq(w_f), b_f)
+        calib = batch and self.calib
+        var_w = self.running_var if calib else var          # calib: the weights are folded with the (already updated) running sigma
+        w_f = self.weight * (self.gamma / torch.sqrt(var_w + self.eps)).reshape(-1, 1, 1, 1)
+        qx, qw = self.aq(x), self.wq(w_f)
+        if not calib:
+            return self._conv(qx, qw, b_f)
+        out = self._conv(qx, qw, None)
+        out = out * (torch.sqrt(self.running_var + self.eps) / torch.sqrt(var + self.eps)).reshape(1, -1, 1, 1)
+        return out + b_f.reshape(1, -1, 1, 1)
 
 
 class OLinear(nn.Linear):
@@ -294,12 +333,12 @@ class OBinAct(nn.Module):
 
 
 class OQuantWrap(nn.Module):
-    """iao Quant{MaxPool2d,AvgPool2d,AdaptiveAvgPool2d}: quantise the input, then the op."""
+    """iao Quant{ReLU,LeakyReLU,Sigmoid,MaxPool2d,AvgPool2d,AdaptiveAvgPool2d} (ref 1160-1438): quantise the input, then the op."""
 
-    def __init__(self, op, a_bits, q_type):
+    def __init__(self, op, a_bits, q_type, qaft=False, ptq=False, percentile=0.9999):
         super().__init__()
         self.op = op
-        self.aq = IaoQuantizer(a_bits, Observer("L"), True, q_type)
+        self.aq = _iao_act_quantizer(a_bits, q_type, qaft, ptq, percentile)
 
     def forward(self, x):
         return self.op(self.aq(x))

@@ -201,6 +201,9 @@ static inline T __shfl(T v, int src, int width = 64) {
     int l = emu::lane();
     return emu::wave_exchange(v, (l / width) * width + (src % width));
 }
+// one OS thread, fibers switch only at barriers / wave collectives: a plain read-modify-write is atomic here
+template <typename T>
+static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 
 typedef float __emu_f32x4 __attribute__((vector_size(16)));

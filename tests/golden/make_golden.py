@@ -360,7 +360,122 @@ def gen_models(out):
     return surface
 
 
+# ---------------------------------------------------------------- IAO: the rest of the module surface
+def gen_iao_ops(out):
+    """QuantReLU / LeakyReLU / Sigmoid / MaxPool2d / AvgPool2d / AdaptiveAvgPool2d (ref 1160-1438) in QAT (sym / asym), PTQ (HistogramObserver,
+    ref 116-139) and QAFT mode; QuantBNFuseConv2d with bn_fuse_calib (ref 957-972), in QAFT mode and with pretrained_model; QuantConv2d in
+    PTQ mode.  Two training steps (observer first-call + EMA), then an eval forward."""
+    meta = []
+    r = rng(900)
+    x = (r.standard_normal((3, 8, 12, 12)) * 2.5).astype(np.float32)
+    x2 = (r.standard_normal((3, 8, 12, 12)) * 4.0 + 0.5).astype(np.float32)
+    out["ops_x0"], out["ops_x1"] = x, x2
+    ops = {
+        "relu": (lambda **kw: ref_iao.QuantReLU(inplace=False, **kw), (3, 8, 12, 12)),
+        "leakyrelu": (lambda **kw: ref_iao.QuantLeakyReLU(negative_slope=0.1, inplace=False, **kw), (3, 8, 12, 12)),
+        "sigmoid": (lambda **kw: ref_iao.QuantSigmoid(**kw), (3, 8, 12, 12)),
+        "maxpool": (lambda **kw: ref_iao.QuantMaxPool2d(kernel_size=2, stride=2, padding=0, **kw), (3, 8, 6, 6)),
+        "maxpool3": (lambda **kw: ref_iao.QuantMaxPool2d(kernel_size=3, stride=2, padding=1, **kw), (3, 8, 6, 6)),
+        "avgpool": (lambda **kw: ref_iao.QuantAvgPool2d(kernel_size=2, stride=2, padding=0, **kw), (3, 8, 6, 6)),
+        "avgpool4": (lambda **kw: ref_iao.QuantAvgPool2d(kernel_size=4, stride=4, padding=0, **kw), (3, 8, 3, 3)),
+        "adaptiveavgpool": (lambda **kw: ref_iao.QuantAdaptiveAvgPool2d(output_size=(1, 1), **kw), (3, 8, 1, 1)),
+    }
+    modes = {"sym8": dict(a_bits=8, q_type=0), "asym8": dict(a_bits=8, q_type=1), "sym4": dict(a_bits=4, q_type=0),
+             "ptq8": dict(a_bits=8, q_type=0, ptq=True, percentile=0.999), "qaft8": dict(a_bits=8, q_type=0, qaft=True)}
+    for oname, (ctor, oshape) in ops.items():
+        g = [r.standard_normal(oshape).astype(np.float32) for _ in range(2)]
+        out[f"ops_{oname}_g0"], out[f"ops_{oname}_g1"] = g
+        for mname, kw in modes.items():
+            m = ctor(**kw)
+            m.train()
+            key = f"ops_{oname}_{mname}"
+            for s_, (xi, gi) in enumerate(((x, g[0]), (x2, g[1]))):
+                xt = T(xi).requires_grad_(True)
+                y = m(xt)
+                y.backward(T(gi))
+                out[f"{key}_s{s_}_y"], out[f"{key}_s{s_}_dx"] = N(y), N(xt.grad)
+                for n_, b in m.named_buffers():
+                    out[f"{key}_s{s_}_buf_{n_}"] = N(b)
+            m.eval()
+            out[f"{key}_eval_y"] = N(m(T(x)))
+            meta.append(dict(op=oname, mode=mname, kw=kw))
+    # ---- BN-fuse conv variants + PTQ conv
+    cin, cout, k = 8, 12, 3
+    w = (r.standard_normal((cout, cin // 2, k, k)) * 0.3).astype(np.float32)
+    gamma = (r.random(cout) + 0.5).astype(np.float32)
+    beta = (r.standard_normal(cout) * 0.1).astype(np.float32)
+    rm = (r.standard_normal(cout) * 0.2).astype(np.float32)
+    rv = (r.random(cout) + 0.5).astype(np.float32)
+    gy = [r.standard_normal((3, cout, 12, 12)).astype(np.float32) for _ in range(2)]
+    out["bnf_w"], out["bnf_gamma"], out["bnf_beta"], out["bnf_rm"], out["bnf_rv"], out["bnf_g0"], out["bnf_g1"] = w, gamma, beta, rm, rv, gy[0], gy[1]
+    variants = {
+        "calib": dict(bn_fuse_calib=True),
+        "qaft": dict(qaft=True),
+        "pretrained": dict(pretrained_model=True),
+        "calib_pretrained": dict(bn_fuse_calib=True, pretrained_model=True),
+        "ptq": dict(ptq=True, percentile=0.999),
+    }
+    for vname, kw in variants.items():
+        torch.manual_seed(0)
+        m = ref_iao.QuantBNFuseConv2d(cin, cout, k, padding=1, groups=2, bias=False, a_bits=8, w_bits=8, q_type=0, q_level=0, **kw)
+        m.weight.data, m.gamma.data, m.beta.data = T(w), T(gamma), T(beta)
+        m.running_mean.copy_(T(rm)); m.running_var.copy_(T(rv))
+        m.train()
+        key = f"bnf_{vname}"
+        for s_, (xi, gi) in enumerate(((x, gy[0]), (x2, gy[1]))):
+            for p in m.parameters():
+                p.grad = None
+            xt = T(xi).requires_grad_(True)
+            y = m(xt)
+            y.backward(T(gi))
+            out[f"{key}_s{s_}_y"], out[f"{key}_s{s_}_dx"] = N(y), N(xt.grad)
+            for n_, p in m.named_parameters():
+                if p.grad is not None:
+                    out[f"{key}_s{s_}_d_{n_}"] = N(p.grad)
+            for n_, b in m.named_buffers():
+                out[f"{key}_s{s_}_buf_{n_}"] = N(b)
+        m.eval()
+        out[f"{key}_eval_y"] = N(m(T(x)))
+        meta.append(dict(op="bnfuse", mode=vname, kw=kw))
+    torch.manual_seed(0)
+    m = ref_iao.QuantConv2d(cin, cout, k, padding=1, groups=2, bias=True, a_bits=8, w_bits=8, q_type=0, q_level=0, ptq=True, percentile=0.999)
+    m.weight.data = T(w)
+    b = (r.standard_normal(cout) * 0.1).astype(np.float32)
+    out["ptqconv_b"] = b
+    m.bias.data = T(b)
+    m.train()
+    for s_, (xi, gi) in enumerate(((x, gy[0]), (x2, gy[1]))):
+        for p in m.parameters():
+            p.grad = None
+        xt = T(xi).requires_grad_(True)
+        y = m(xt)
+        y.backward(T(gi))
+        out[f"ptqconv_s{s_}_y"], out[f"ptqconv_s{s_}_dx"], out[f"ptqconv_s{s_}_d_weight"] = N(y), N(xt.grad), N(m.weight.grad)
+        for n_, bb in m.named_buffers():
+            out[f"ptqconv_s{s_}_buf_{n_}"] = N(bb)
+    # ---- HistogramObserver on its own: sizes around the k-th value index arithmetic, ties, first call + EMA
+    for i, (n, pct) in enumerate(((1000, 0.9999), (4096, 0.999), (100000, 0.9999), (37, 0.9), (65536, 0.99999))):
+        ho = ref_iao.HistogramObserver(q_level="L", percentile=pct)
+        for s_ in range(2):
+            v = (r.standard_normal(n) * (1 + s_)).astype(np.float32)
+            if i == 1:
+                v = np.round(v * 4) / 4          # many exact ties
+            out[f"hist_{i}_s{s_}_x"] = v
+            ho(T(v))
+            out[f"hist_{i}_s{s_}_max"] = N(ho.max_val)
+        meta.append(dict(op="hist", n=n, percentile=pct))
+    return meta
+
+
 def main():
+    if "--ops-only" in sys.argv:      # regenerate only iao_ops.npz (the three older fixture files stay byte-identical)
+        o = {}
+        ops_meta = gen_iao_ops(o)
+        np.savez_compressed(os.path.join(HERE, "iao_ops.npz"), **o)
+        with open(os.path.join(HERE, "iao_ops_meta.json"), "w") as f:
+            json.dump(dict(ops=ops_meta, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
+        print("iao_ops.npz", os.path.getsize(os.path.join(HERE, "iao_ops.npz")) // 1024, "KiB")
+        return
     q = {}
     gen_dorefa(q)
     gen_wbwtab(q)
@@ -377,6 +492,12 @@ def main():
                        torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
     for fn in ("quantizers.npz", "modules.npz", "models.npz", "meta.json"):
         print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
+    o = {}
+    ops_meta = gen_iao_ops(o)
+    np.savez_compressed(os.path.join(HERE, "iao_ops.npz"), **o)
+    with open(os.path.join(HERE, "iao_ops_meta.json"), "w") as f:
+        json.dump(dict(ops=ops_meta, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
+    print("iao_ops.npz", os.path.getsize(os.path.join(HERE, "iao_ops.npz")) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -141,7 +141,7 @@ def test_layerwise_teacher_forced(key):
             p.grad = None
         out = pm(*ins)
         bnfuse = type(pm).__name__ == "QuantBNFuseConv2d"
-        tol = 2e-4 if bnfuse else 1e-5
+        tol = 1e-5
         e_out = _rel(out, r["out"])
         out.backward(r["gout"].cuda())
         errs = {"y": e_out}

@@ -191,3 +191,65 @@ def test_torch_oracle_models(golden, key):
     assert losses == golden.meta["surface"][key]["losses"]
     model.eval()
     assert eq(model(x).detach().numpy(), golden.mo[f"{key}_eval_logits"])
+
+
+# ------------------------------------------------------------------------------------------------ IAO: the rest of the surface (f2)
+def _oracle_op(op, kw):
+    import torch.nn as nn
+    ctor = {"relu": lambda: nn.ReLU(), "leakyrelu": lambda: nn.LeakyReLU(0.1), "sigmoid": lambda: nn.Sigmoid(),
+            "maxpool": lambda: nn.MaxPool2d(2, 2, 0), "maxpool3": lambda: nn.MaxPool2d(3, 2, 1), "avgpool": lambda: nn.AvgPool2d(2, 2, 0),
+            "avgpool4": lambda: nn.AvgPool2d(4, 4, 0), "adaptiveavgpool": lambda: nn.AdaptiveAvgPool2d((1, 1))}[op]
+    return TO.OQuantWrap(ctor(), kw["a_bits"], kw.get("q_type", 0), kw.get("qaft", False), kw.get("ptq", False), kw.get("percentile", 0.9999))
+
+
+def test_iao_ops_oracle_vs_reference_golden():
+    """Quant{ReLU,LeakyReLU,Sigmoid,MaxPool2d,AvgPool2d,AdaptiveAvgPool2d} in QAT / PTQ / QAFT mode: the oracle is bit-exact."""
+    import iao_ops_cases as IC
+    g, meta = IC.load()
+    n = 0
+    for c in meta["ops"]:
+        if c["op"] in ("bnfuse", "hist"):
+            continue
+        IC.run_op(_oracle_op(c["op"], c["kw"]), g, c["op"], c["mode"], "cpu", exact=True)
+        n += 1
+    assert n == 40
+
+
+def test_histogram_observer_oracle_vs_reference_golden():
+    import iao_ops_cases as IC
+    g, meta = IC.load()
+    hs = [c for c in meta["ops"] if c["op"] == "hist"]
+    for i, c in enumerate(hs):
+        ho = TO.HistObserver(c["percentile"])
+        for s_ in range(2):
+            ho(torch.from_numpy(g[f"hist_{i}_s{s_}_x"].copy()))
+            assert eq(ho.max_val.numpy(), g[f"hist_{i}_s{s_}_max"]), (i, s_)
+
+
+@pytest.mark.parametrize("variant", ["calib", "qaft", "pretrained", "calib_pretrained", "ptq"])
+def test_bnfuse_variants_oracle_vs_reference_golden(variant):
+    """QuantBNFuseConv2d with bn_fuse_calib / qaft / pretrained_model / ptq (ref 837-994): same ATen ops in the same order -> bit-exact
+    buffers, outputs and gradients to fp32 round-off of autograd's accumulation order."""
+    import torch.nn as nn
+    import iao_ops_cases as IC
+    g, meta = IC.load()
+    kw = [c for c in meta["ops"] if c["op"] == "bnfuse" and c["mode"] == variant][0]["kw"]
+    conv = nn.Conv2d(8, 12, 3, padding=1, groups=2, bias=False)
+    bn = nn.BatchNorm2d(12)
+    conv.weight.data = torch.from_numpy(g["bnf_w"].copy())
+    bn.weight.data, bn.bias.data = torch.from_numpy(g["bnf_gamma"].copy()), torch.from_numpy(g["bnf_beta"].copy())
+    bn.running_mean.copy_(torch.from_numpy(g["bnf_rm"])); bn.running_var.copy_(torch.from_numpy(g["bnf_rv"]))
+    m = TO.OBNFuseConv2d(conv, bn, a_bits=8, w_bits=8, q_type=0, q_level=0, **kw).train()
+    for s_ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        x = torch.from_numpy(g[f"ops_x{s_}"].copy()).requires_grad_(True)
+        y = m(x)
+        y.backward(torch.from_numpy(g[f"bnf_g{s_}"].copy()))
+        key = f"bnf_{variant}_s{s_}"
+        assert eq(y.detach().numpy(), g[f"{key}_y"]), (variant, s_)
+        assert eq(m.running_mean.numpy(), g[f"{key}_buf_running_mean"]) and eq(m.running_var.numpy(), g[f"{key}_buf_running_var"])
+        for got, ref in ((x.grad, g[f"{key}_dx"]), (m.weight.grad, g[f"{key}_d_weight"]), (m.gamma.grad, g[f"{key}_d_gamma"]), (m.beta.grad, g[f"{key}_d_beta"])):
+            assert np.max(np.abs(got.numpy() - ref)) <= 2e-6 * max(np.max(np.abs(ref)), 1e-30), (variant, s_)
+    m.eval()
+    assert eq(m(torch.from_numpy(g["ops_x0"].copy())).detach().numpy(), g[f"bnf_{variant}_eval_y"])
