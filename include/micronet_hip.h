@@ -168,6 +168,11 @@ typedef struct mn_conv_geom {
                           one byte per element: a quarter of the HBM traffic of the fp32 +-1 tensor).  fwd and bwd_weight read the
                           codes directly (4-byte aligned rows: H*W % 4 == 0); bwd_data ignores x (the clip-STE of the sign lives
                           in mn_bnsign_bwd).  Code-domain kernels only (else MN_ENOTSUP). */
+#define MN_ACTQ_CODE8 4 /* `x` is NOT fp32: it points to the k-bit activation CODES j of the quantizer (uint8 in [0, 2^bits - 1], bits <= 7, NCHW like x;
+                          value = j * s, s = 1 / (2^bits - 1): DoReFa ActivationQuantizer, wqaq/dorefa/quantize.py:43-45) as written by mn_qa_fwd -- one byte
+                          per element instead of four, and the quantizer is not re-evaluated.  Supported by bwd_weight (dw = s * sum gy * j) and bwd_data
+                          (x ignored: the clip-STE lives in mn_qa_bwd_*) where mn_qconv_bnq_supported says so; the forward on codes is
+                          mn_qconv_bnq_fwd_stash. */
 #define MN_ACTQ_X_IS_CODE 1 /* flags: optional hint that with MN_ACTQ_NONE x holds small integers exact in bf16 (the +-1 of
                               wbwtab's BinaryActivation, wbwtab/quantize.py:13-19).  Never required: real-valued x is split
                               into exact bf16 terms on the fly and all-zero terms are skipped. */
@@ -328,6 +333,41 @@ int mn_conv2d_bwd_weight_bnh(const mn_conv_geom* g, const float* da, const uint8
 int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
                                const float* beta, const float* save, const float* dpool, const int8_t* a_own, int training, float* dy,
                                float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, mn_stream_t stream);
+
+/* ------------------------------------------------------------------ conv + BatchNorm2d + ReLU + the next layer's k-bit activation quantizer, fused
+ * The block of the reference's DoReFa nets: `relu(bn(conv(x)))` (models/nin_gc.py:53-59) whose output only feeds the ActivationQuantizer of the next
+ * QuantConv2d (wqaq/dorefa/quantize.py:36-46, 107-122), possibly through a 2x2 max-pool (models/nin_gc.py:88,119).  Input: activation codes j (uint8,
+ * MN_ACTQ_CODE8); weights: DoReFa codes (wq->mode == MN_WQ_DOREFA, `w` = the fake-quantised fp32 weights).  The conv result y = alpha * acc + bias with
+ * acc an EXACT integer is never written as fp32:
+ *   mn_qconv_bnq_fwd_stash   conv on codes -> acc as a 16-bit stash [N][O][H][W] + exact batch statistics -> save [2][O] (mean, invstd), running
+ *                            statistics / num_batches_tracked like nn.BatchNorm2d, chan [MN_QA_NCH][O] (the per-channel constants the streaming
+ *                            kernels below read).  ws: mn_qconv_bnq_ws_bytes(g).
+ *   mn_qa_fwd                stash (in_f32 == 0) or fp32 y (in_f32 == 1: the block behind the un-quantised first conv) -> a = relu(bn(y)) -> [2x2 max-pool]
+ *                            -> codes of the a_bits quantizer (codes != NULL) and / or the fp32 activation itself (act_f32 != NULL: foreign consumers)
+ *   mn_qa_bwd_sums / _apply  dq = d loss / d (pooled) activation -> dgamma, dbeta, sums [2][C]; dy [N][C][H][W] (what conv backward consumes).
+ *                            quant != 0: dq is the gradient w.r.t. the QUANTISED activation and the quantizer's clip-STE is applied here;
+ *                            quant == 0: dq is the gradient w.r.t. the activation (consumer applied its own STE, or is not quantised).
+ * Backward of the conv itself: mn_conv2d_bwd_data (no STE epilogue) and mn_conv2d_bwd_weight with aq->mode == MN_ACTQ_CODE8. */
+#define MN_QA_NCH 9
+int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in);
+int64_t mn_qconv_bnq_ws_bytes(const mn_conv_geom* g);
+int mn_qconv_bnq_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x_codes, int a_bits_in, const float* w, const float* bias, const float* gamma,
+                           const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float* save, int16_t* stash, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream);
+/* statistics half of mn_bnrelu_fwd: save [2][C] = {mean, invstd} of fp32 y (training: batch statistics + running update like nn.BatchNorm2d; eval: the
+ * running statistics); ws: mn_bnsign_ws_floats(C) */
+int mn_bn_save_stats(const float* y, int64_t N, int64_t C, int64_t HW, float eps, float momentum, int training, float* running_mean, float* running_var,
+                     float* save, float* ws, mn_stream_t stream);
+int mn_qa_supported(int64_t H, int64_t W, int pool);
+int64_t mn_qa_ws_floats(int64_t C);
+/* chan from the (mean, invstd) a BatchNorm over fp32 y saved (mn_bnrelu_fwd's `save`): the first block of a net */
+int mn_qa_chan_from_save(const float* save, const float* gamma, const float* beta, int64_t C, float* chan, mn_stream_t stream);
+int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, uint8_t* codes, float* act_f32,
+              mn_stream_t stream);
+int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, int quant,
+                   float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
+int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, const float* sums, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits,
+                    int pool, int quant, int training, float* dy, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ classifier conv of a binary net
  * The LAST conv of the WbWtAb nets keeps fp32 weights (the rewrite skips it, wbwtab/quantize.py:251) but reads the +-1 output of the

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MN_LIB_PATH") or os.path.join(HERE, "lib", "libmicronet_hip.so")   # MN_LIB_PATH: ablation builds of the same library
 
-MN_ACTQ_NONE, MN_ACTQ_DOREFA, MN_ACTQ_IAO, MN_ACTQ_SIGN8 = 0, 1, 2, 3
+MN_ACTQ_NONE, MN_ACTQ_DOREFA, MN_ACTQ_IAO, MN_ACTQ_SIGN8, MN_ACTQ_CODE8 = 0, 1, 2, 3, 4
 MN_ALGO_AUTO, MN_ALGO_DIRECT, MN_ALGO_MFMA, MN_ALGO_QGEMM = 0, 1, 2, 3
 MN_WQ_REAL, MN_WQ_TERNARY, MN_WQ_DOREFA, MN_WQ_IAO = 0, 1, 2, 3
 MN_ACTQ_X_IS_CODE = 1
@@ -114,6 +114,16 @@ PROTOTYPES = {
     "mn_iao_fq_avgpool_bwd": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _I, _I, _P]),
     "mn_kth_abs_ws_bytes": (_L, []),
     "mn_hist_observe": (_I, [_P, _L, _L, _I, C.c_double, _P, _P, _P, _P]),
+    "mn_qconv_bnq_supported": (_I, [_G, _W, _I]),
+    "mn_qconv_bnq_ws_bytes": (_L, [_G]),
+    "mn_qconv_bnq_fwd_stash": (_I, [_G, _W, _P, _I, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "mn_bn_save_stats": (_I, [_P, _L, _L, _L, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P]),
+    "mn_qa_supported": (_I, [_L, _L, _I]),
+    "mn_qa_ws_floats": (_L, [_L]),
+    "mn_qa_chan_from_save": (_I, [_P, _P, _P, _L, _P, _P]),
+    "mn_qa_fwd": (_I, [_I, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _P]),
+    "mn_qa_bwd_sums": (_I, [_I, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "mn_qa_bwd_apply": (_I, [_I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),

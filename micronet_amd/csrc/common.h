@@ -168,6 +168,11 @@ static int make_pro(const mn_actq* aq, Pro* p, int need_bounds, const char* what
         return MN_OK;
     }
     if (aq->mode == MN_ACTQ_SIGN8) { p->mode = MN_ACTQ_SIGN8; return MN_OK; }
+    if (aq->mode == MN_ACTQ_CODE8) {
+        if (aq->bits < 2 || aq->bits > 7) MN_FAIL(MN_EINVAL, "%s: code8 bits=%d", what, aq->bits);
+        p->mode = MN_ACTQ_CODE8; p->s = dorefa_scale(aq->bits);
+        return MN_OK;
+    }
     (void)need_bounds;
     MN_FAIL(MN_EINVAL, "%s: unknown activation quantizer mode %d", what, aq->mode);
 }

@@ -712,7 +712,7 @@ extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_
     if (algo == MN_ALGO_AUTO && pro.mode == MN_ACTQ_NONE && c1_supported(g, 0) && aligned16(y) && ws && ws_bytes >= c1_ws_bytes(g, 0))
         return c1_fwd(g, x, w, bias, y, ws, ws_bytes, s);          // un-quantised first layer: real fp32 operands
     if (g->in_shuffle > 1) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: in_shuffle is only available on the code-domain kernels");
-    if (pro.mode == MN_ACTQ_SIGN8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: int8 sign codes are only read by the code-domain kernels");
+    if (pro.mode == MN_ACTQ_SIGN8 || pro.mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: int8 sign / activation codes are only read by the code-domain kernels");
     FwdPlan pl;
     const int can = (algo != MN_ALGO_DIRECT) && plan_fwd_view(g, 0, &pl) && aligned16(x) && aligned16(y);
     if (algo == MN_ALGO_MFMA && !can) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: geometry not supported by the MFMA tiler");
@@ -739,7 +739,7 @@ extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, cons
     if (!gy || !w || !dx) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data: null tensor");
     Pro ste;
     if ((rc = make_pro(aq, &ste, 1, "mn_conv2d_bwd_data"))) return rc;
-    if (ste.mode == MN_ACTQ_SIGN8) ste.mode = MN_ACTQ_NONE;      // +-1 codes carry no STE here (it lives in mn_bnsign_bwd); x is not read
+    if (ste.mode == MN_ACTQ_SIGN8 || ste.mode == MN_ACTQ_CODE8) ste.mode = MN_ACTQ_NONE;      // codes carry no STE here (it lives in mn_bnsign_bwd / mn_qa_bwd_*); x is not read
     if (ste.mode != MN_ACTQ_NONE && !x) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data: x required for the clip-STE epilogue");
     hipStream_t s = (hipStream_t)stream;
     {
@@ -815,10 +815,10 @@ extern "C" int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, co
     const int Ho = out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h), Wo = out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);
     if (algo == MN_ALGO_AUTO && pro.mode == MN_ACTQ_NONE && c1_supported(g, 2) && aligned16(gy) && ws && ws_bytes >= c1_ws_bytes(g, 2))
         return c1_bwd_weight(g, gy, x, dw, dbias, ws, ws_bytes, s);   // first layer: K = Cin*KH*KW <= 76, exact fp32 MFMA
-    if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, nullptr, 2) && aligned16(x) && aligned16(gy)))
+    if (algo == MN_ALGO_QGEMM || (algo == MN_ALGO_AUTO && qg_supported(g, aq, nullptr, 2) && (aligned16(x) || pro.mode == MN_ACTQ_CODE8) && aligned16(gy)))
         return qg_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
     if (g->in_shuffle > 1) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight: in_shuffle is only available on the code-domain kernels");
-    if (pro.mode == MN_ACTQ_SIGN8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight: int8 sign codes are only read by the code-domain kernels");
+    if (pro.mode == MN_ACTQ_SIGN8 || pro.mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight: int8 sign / activation codes are only read by the code-domain kernels");
     WgradPlan pl;
     const int can = (algo != MN_ALGO_DIRECT) && plan_wgrad(g, &pl) && aligned16(x) && aligned16(gy);
     if (algo == MN_ALGO_MFMA && !can) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight: geometry not supported by the MFMA tiler");

@@ -357,6 +357,29 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
     MN_CHECK_LAUNCH("mn_bnsign_fwd");
     return MN_OK;
 }
+// statistics only: save = {mean, invstd} of a BatchNorm over fp32 y (training: batch statistics + running update; eval: the running ones) -- the
+// first half of mn_bnrelu_fwd for a consumer that normalises itself (mn_qa_fwd with in_f32 = 1)
+extern "C" int mn_bn_save_stats(const float* y, int64_t N, int64_t C, int64_t HW, float eps, float momentum, int training, float* running_mean,
+                                float* running_var, float* save, float* ws, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, y, y, "mn_bn_save_stats");
+    if (rc) return rc;
+    if (!y || !save || !ws || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bn_save_stats: null / misaligned argument");
+    if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_bn_save_stats: eval mode needs the running statistics");
+    hipStream_t s = (hipStream_t)stream;
+    BnsGeom g = bns_geom(N, C, HW);
+    const int S = bns_split(g);
+    if (training) {
+        mn_set_last_kernel("k_bns_partial<0>"); mn_prof_bytes(4.0 * (double)N * C * HW); mn_prof_begin(s);
+        hipLaunchKernelGGL(k_bns_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (double*)ws);
+        mn_prof_end(s);
+        hipLaunchKernelGGL(k_bns_final_fwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, y, (const double*)ws, S, eps, momentum, running_mean, running_var, save);
+    } else {
+        hipLaunchKernelGGL(k_bns_eval_stats, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (int)C, eps, (const float*)running_mean, (const float*)running_var, save);
+    }
+    MN_CHECK_LAUNCH("mn_bn_save_stats");
+    return MN_OK;
+}
 extern "C" int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                              int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
     return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream);

@@ -1,0 +1,397 @@
+// BatchNorm2d + ReLU + the NEXT layer's k-bit activation quantizer, fused, for gfx950 -- the block structure of the reference's DoReFa
+// nets:  conv -> bn -> relu -> [max-pool 2x2] -> QuantConv2d's ActivationQuantizer  (models/nin_gc.py:53-59,88,119 under
+// wqaq/dorefa/quantize.py:36-46,107-122).
+//
+// A k-bit block's conv output is y = alpha[o] * acc + bias[o] with acc an EXACT integer (input codes j in [0, 2^a - 1] times weight codes
+// 2k - n; SURVEY Appendix A "exact-integer GEMM").  So, exactly as for the binary blocks (qgemm_sign.hip), fp32 y is never stored: the conv
+// kernels leave acc as a 16-bit STASH (|acc| <= K * amax * wmax <= 32767, checked by the planner) plus exact integer batch-statistics
+// partials, and everything behind the conv streams that stash:
+//   forward   k_qa_fwd      stash (2 B/elt) -> z = bn(y) -> a = relu(z) -> [2x2 max] -> code j = rha(clamp(0.1 a, 0, 1) / s)   -> 1 B/elt
+//             (the next conv reads ONE byte per element instead of 4, and the quantizer is not re-evaluated by its three passes)
+//   backward  k_qa_partial  (dq [pooled], stash) -> dz = STE(dq) * [z > 0] (through the pool's first-maximum routing)  -> sum dz, sum dz zhat
+//             k_qa_apply    (dq, stash)          -> dy = gamma invstd (dz - sum_dz / n - zhat sum_dzzhat / n)           -> 4 B/elt
+// dq = d loss / d (quantised activation) is what the next conv's backward-data produces BEFORE its clip-STE epilogue; the STE
+// (wqaq/dorefa/quantize.py:36-46 backward: ((g s) / s) * [0 <= 0.1 a <= 1] * 0.1) is evaluated here from the recomputed a.
+// Every value is recomputed with the fp32 expression chain of the unfused kernels (k_pw epilogue: y = acc * alpha + bias; k_bns_apply:
+// zh = (y - mean) * invstd, z = zh * gamma + beta, relu; dorefa_act_q), so codes and masks are bit-identical to the unfused path whenever
+// the batch statistics are (they differ by fp32 round-off of the mean / variance: exact integer sums here).
+// IN = 1: the input is fp32 y (the block behind the un-quantised FIRST conv, whose output is not an integer): same kernels, 4 B/elt in.
+#include "qgemm_dev.h"
+
+#define QA_NCH 9          // chan rows: alpha, bias, mean, invstd, gamma, beta, A = alpha*invstd, B = (bias - mean)*invstd, gi = gamma*invstd
+struct QaGeom {
+    int N, C, H, W, HW, HW8, W8;
+    FastDiv fd_hw8, fd_w8;
+    int64_t n8;             // 8-element groups per channel (no pool) / 4-window groups per channel (pool)
+    float s;                // quantizer scale 1 / (2^a - 1)
+};
+struct QaCh { float alpha, bias, mean, invstd, ga, be, A, B, gi; };
+__device__ __forceinline__ QaCh qa_load_ch(const float* __restrict__ chan, int C, int c) {
+    QaCh k;
+    k.alpha = chan[c]; k.bias = chan[C + c]; k.mean = chan[2 * C + c]; k.invstd = chan[3 * C + c]; k.ga = chan[4 * C + c]; k.be = chan[5 * C + c];
+    k.A = chan[6 * C + c]; k.B = chan[7 * C + c]; k.gi = chan[8 * C + c];
+    return k;
+}
+template <int IN>
+__device__ __forceinline__ void qa_eval(float v, const QaCh& k, float& zh, float& z) {
+    const float y = IN ? v : v * k.alpha + k.bias;
+    zh = (y - k.mean) * k.invstd;
+    z = zh * k.ga + k.be;
+}
+__device__ __forceinline__ float qa_relu(float z) { return (z > 0.f) ? z : ((z != z) ? z : 0.f); }
+__device__ __forceinline__ uint32_t qa_code(float a, float s) {
+    const float j = mn_rha(mn_clamp(a * 0.1f, 0.f, 1.f) / s);
+    return (j > 0.f) ? (uint32_t)j : 0u;                 // NaN -> 0 (a byte cannot hold it)
+}
+// 8 consecutive elements (one row segment) of channel c at group index i: element offset
+__device__ __forceinline__ int64_t qa_off8(const QaGeom& g, int c, uint32_t i) {
+    const uint32_t n = fd_div(i, g.fd_hw8);
+    return ((int64_t)n * g.C + c) * g.HW + (int64_t)(i - n * (uint32_t)g.HW8) * 8;
+}
+template <int IN>
+__device__ __forceinline__ void qa_load8(const void* __restrict__ in, int64_t off, float (&v)[8]) {
+    if (IN) {
+        const float4 a = *reinterpret_cast<const float4*>((const float*)in + off), b = *reinterpret_cast<const float4*>((const float*)in + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const u32x4 u = *reinterpret_cast<const u32x4*>((const int16_t*)in + off);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { v[2 * d] = (float)(int16_t)(u[d] & 0xffffu); v[2 * d + 1] = (float)(int16_t)(u[d] >> 16); }
+    }
+}
+// pooled group i of channel c: 4 windows of one pooled row = 8 columns x 2 rows; e0 = element offset of the upper row's first column,
+// po = element offset of the first pooled output
+__device__ __forceinline__ void qa_pool_off(const QaGeom& g, int c, int64_t i, int64_t& e0, int64_t& po) {
+    const int Hh = g.H >> 1;
+    const int64_t t = i / g.W8;
+    const int q = (int)(i - t * g.W8);
+    const int64_t n = t / Hh;
+    const int pr = (int)(t - n * Hh);
+    const int64_t plane = n * g.C + c;
+    e0 = plane * g.HW + (int64_t)(2 * pr) * g.W + 8 * q;
+    po = plane * (g.HW >> 2) + (int64_t)pr * (g.W >> 1) + 4 * q;
+}
+// first maximum of a window in row-major order, ATen's rule (a later element wins if it is greater OR NaN): index 0..3
+__device__ __forceinline__ int qa_argmax4(const float (&a)[4]) {
+    float m = -INFINITY;
+    int k = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (a[e] > m || a[e] != a[e]) { m = a[e]; k = e; }
+    return k;
+}
+
+// ---------------------------------------------------------------- forward: stash / y  ->  codes (OUT 0) or the fp32 activation (OUT 1)
+template <int IN, int POOL, int OUT>
+__global__ __launch_bounds__(256) void k_qa_fwd(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, unsigned char* __restrict__ codes,
+                                                float* __restrict__ af) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const QaCh k = qa_load_ch(chan, g.C, c);
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
+        if (!POOL) {
+            const int64_t off = qa_off8(g, c, (uint32_t)i);
+            float v[8], a[8];
+            qa_load8<IN>(in, off, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float zh, z; qa_eval<IN>(v[e], k, zh, z); a[e] = qa_relu(z); }
+            if (OUT) {
+                *reinterpret_cast<float4*>(af + off) = make_float4(a[0], a[1], a[2], a[3]);
+                *reinterpret_cast<float4*>(af + off + 4) = make_float4(a[4], a[5], a[6], a[7]);
+            } else {
+                uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo |= qa_code(a[e], g.s) << (8 * e); hi |= qa_code(a[4 + e], g.s) << (8 * e); }
+                *reinterpret_cast<u32x2*>(codes + off) = u32x2{lo, hi};
+            }
+        } else {
+            int64_t e0, po;
+            qa_pool_off(g, c, i, e0, po);
+            float r0[8], r1[8];
+            qa_load8<IN>(in, e0, r0);
+            qa_load8<IN>(in, e0 + g.W, r1);
+            float m[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float a[4];
+                const float vv[4] = {r0[2 * w], r0[2 * w + 1], r1[2 * w], r1[2 * w + 1]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float zh, z; qa_eval<IN>(vv[e], k, zh, z); a[e] = qa_relu(z); }
+                m[w] = a[qa_argmax4(a)];
+            }
+            if (OUT) *reinterpret_cast<float4*>(af + po) = make_float4(m[0], m[1], m[2], m[3]);
+            else *reinterpret_cast<uint32_t*>(codes + po) = qa_code(m[0], g.s) | (qa_code(m[1], g.s) << 8) | (qa_code(m[2], g.s) << 16) | (qa_code(m[3], g.s) << 24);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward
+// dz of the 8 elements (no pool) / of the 16 elements of 4 windows (pool: only the window's first maximum receives gradient).
+// QUANT 1: dq is the gradient w.r.t. the QUANTISED activation (the clip-STE of the quantizer is applied here); 0: w.r.t. the activation itself
+// (the block's consumer is not a quantised conv: e.g. the last block of the net).
+__device__ __forceinline__ float qa_dz(float gq, float a, float z, float s, int quant) {
+    const float d = quant ? dorefa_act_grad(gq, a, s) : gq;
+    return (z > 0.f) ? d : 0.f;
+}
+template <int IN, int POOL>
+__global__ __launch_bounds__(256) void k_qa_partial(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, const float* __restrict__ dq,
+                                                    int quant, double* __restrict__ part) {
+    __shared__ double scd[16];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const QaCh k = qa_load_ch(chan, g.C, c);
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
+        float t1 = 0.f, t2 = 0.f;
+        if (!POOL) {
+            const int64_t off = qa_off8(g, c, (uint32_t)i);
+            float v[8];
+            qa_load8<IN>(in, off, v);
+            const float4 ga = *reinterpret_cast<const float4*>(dq + off), gb = *reinterpret_cast<const float4*>(dq + off + 4);
+            const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float zh, z;
+                qa_eval<IN>(v[e], k, zh, z);
+                const float dz = qa_dz(gv[e], qa_relu(z), z, g.s, quant);
+                t1 += dz; t2 += dz * zh;
+            }
+        } else {
+            int64_t e0, po;
+            qa_pool_off(g, c, i, e0, po);
+            float r0[8], r1[8];
+            qa_load8<IN>(in, e0, r0);
+            qa_load8<IN>(in, e0 + g.W, r1);
+            const float4 g4 = *reinterpret_cast<const float4*>(dq + po);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float a[4], zz[4], zhh[4];
+                const float vv[4] = {r0[2 * w], r0[2 * w + 1], r1[2 * w], r1[2 * w + 1]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qa_eval<IN>(vv[e], k, zhh[e], zz[e]); a[e] = qa_relu(zz[e]); }
+                const int kx = qa_argmax4(a);
+                float am = a[0], zm = zz[0], zhm = zhh[0];
+#pragma unroll
+                for (int e = 1; e < 4; ++e) if (kx == e) { am = a[e]; zm = zz[e]; zhm = zhh[e]; }
+                const float dz = qa_dz(gv[w], am, zm, g.s, quant);
+                t1 += dz; t2 += dz * zhm;
+            }
+        }
+        s1 += (double)t1; s2 += (double)t2;
+    }
+    s1 = block_reduce(s1, OpAddD(), 0.0, scd);
+    s2 = block_reduce(s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { part[((int64_t)c * S + sp) * 2] = s1; part[((int64_t)c * S + sp) * 2 + 1] = s2; }
+}
+__global__ void k_qa_final_bwd(int C, const double* __restrict__ part, int S, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < S; ++i) { s1 += part[((int64_t)c * S + i) * 2]; s2 += part[((int64_t)c * S + i) * 2 + 1]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    sums[c] = (float)s1; sums[C + c] = (float)s2;
+}
+template <int IN, int POOL>
+__global__ __launch_bounds__(256) void k_qa_apply(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, const float* __restrict__ dq,
+                                                  const float* __restrict__ sums, int training, int quant, float* __restrict__ dy) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const QaCh k = qa_load_ch(chan, g.C, c);
+    float k1 = 0.f, k2 = 0.f;
+    if (training) { const float n = (float)g.N * (float)g.HW; k1 = sums[c] / n; k2 = sums[g.C + c] / n; }
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
+        if (!POOL) {
+            const int64_t off = qa_off8(g, c, (uint32_t)i);
+            float v[8], r[8];
+            qa_load8<IN>(in, off, v);
+            const float4 ga = *reinterpret_cast<const float4*>(dq + off), gb = *reinterpret_cast<const float4*>(dq + off + 4);
+            const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float zh, z;
+                qa_eval<IN>(v[e], k, zh, z);
+                const float dz = qa_dz(gv[e], qa_relu(z), z, g.s, quant);
+                r[e] = k.gi * (dz - k1 - zh * k2);
+            }
+            *reinterpret_cast<float4*>(dy + off) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(dy + off + 4) = make_float4(r[4], r[5], r[6], r[7]);
+        } else {
+            int64_t e0, po;
+            qa_pool_off(g, c, i, e0, po);
+            float r0[8], r1[8], o0[8], o1[8];
+            qa_load8<IN>(in, e0, r0);
+            qa_load8<IN>(in, e0 + g.W, r1);
+            const float4 g4 = *reinterpret_cast<const float4*>(dq + po);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float a[4], zz[4], zhh[4];
+                const float vv[4] = {r0[2 * w], r0[2 * w + 1], r1[2 * w], r1[2 * w + 1]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qa_eval<IN>(vv[e], k, zhh[e], zz[e]); a[e] = qa_relu(zz[e]); }
+                const int kx = qa_argmax4(a);
+                float rr[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dz = (kx == e) ? qa_dz(gv[w], a[e], zz[e], g.s, quant) : 0.f;
+                    rr[e] = k.gi * (dz - k1 - zhh[e] * k2);
+                }
+                o0[2 * w] = rr[0]; o0[2 * w + 1] = rr[1]; o1[2 * w] = rr[2]; o1[2 * w + 1] = rr[3];
+            }
+            *reinterpret_cast<float4*>(dy + e0) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+            *reinterpret_cast<float4*>(dy + e0 + 4) = make_float4(o0[4], o0[5], o0[6], o0[7]);
+            *reinterpret_cast<float4*>(dy + e0 + g.W) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+            *reinterpret_cast<float4*>(dy + e0 + g.W + 4) = make_float4(o1[4], o1[5], o1[6], o1[7]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- per-channel constants
+// from (mean, invstd) of a BatchNorm over fp32 y (the first block: save = what mn_bnrelu_fwd / k_bns_final_fwd wrote); alpha = 1, bias = 0
+__global__ void k_qa_chan_f32(int C, const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ chan) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = save[c], invstd = save[C + c];
+    chan[c] = 1.f; chan[C + c] = 0.f; chan[2 * C + c] = mean; chan[3 * C + c] = invstd; chan[4 * C + c] = gamma[c]; chan[5 * C + c] = beta[c];
+    chan[6 * C + c] = invstd; chan[7 * C + c] = (0.f - mean) * invstd; chan[8 * C + c] = gamma[c] * invstd;
+}
+// from the exact integer statistics partials of a stashing conv (layout of k_pws / k_k3s_fwd: part[(i * G * Mpad + g * Mpad + m) * 2]):
+// mean / biased variance of y = alpha * acc + bias in fp64, running statistics (unbiased variance) and num_batches_tracked like nn.BatchNorm2d;
+// eval: the running statistics.  One wave per channel.
+__global__ __launch_bounds__(64) void k_qa_stats_prep(const double* __restrict__ part, int CB, int G, int Mpad, int Mr, const float* __restrict__ rowscale, float ascale,
+                                                     const float* __restrict__ bias, double n, float eps, float momentum, int training,
+                                                     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save, int Cout,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ chan,
+                                                     long long* __restrict__ nbt) {
+    const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
+    const float alpha = rowscale[g * Mpad + m] * ascale;          // what the unfused k_pw / k_kk epilogue multiplies acc with
+    const float b = bias ? bias[co] : 0.f;
+    float mean_f = 0.f, inv_f = 0.f;
+    if (training) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int i = lane; i < CB; i += 64) {
+            const double* src = part + ((int64_t)i * G * Mpad + g * Mpad + m) * 2;
+            a1 += src[0]; a2 += src[1];
+        }
+        a1 = wave_reduce(a1, OpAddD()); a2 = wave_reduce(a2, OpAddD());
+        if (lane == 0) {
+            const double al = (double)alpha;
+            const double ma = a1 / n;
+            const double mean = al * ma + (double)b;
+            double ss = al * al * (a2 - a1 * ma);
+            if (ss < 0.0) ss = 0.0;
+            mean_f = (float)mean;
+            inv_f = 1.0f / sqrtf((float)(ss / n) + eps);
+            if (running_mean) running_mean[co] = (1.f - momentum) * running_mean[co] + momentum * (float)mean;
+            if (running_var) running_var[co] = (1.f - momentum) * running_var[co] + momentum * (float)(ss / (n - 1.0));
+        }
+    } else if (lane == 0) {
+        mean_f = running_mean[co];
+        inv_f = 1.0f / sqrtf(running_var[co] + eps);
+    }
+    if (lane == 0) {
+        save[co] = mean_f; save[Cout + co] = inv_f;
+        if (nbt && co == 0 && training) *nbt += 1;
+        const float ga = gamma[co], be = beta[co];
+        chan[co] = alpha; chan[Cout + co] = b; chan[2 * Cout + co] = mean_f; chan[3 * Cout + co] = inv_f; chan[4 * Cout + co] = ga; chan[5 * Cout + co] = be;
+        chan[6 * Cout + co] = alpha * inv_f; chan[7 * Cout + co] = (b - mean_f) * inv_f; chan[8 * Cout + co] = ga * inv_f;
+    }
+}
+void qa_launch_stats_prep(const double* part, int CB, int G, int Mpad, int Mr, const float* rowscale, float ascale, const float* bias, double n, float eps,
+                          float momentum, int training, float* running_mean, float* running_var, float* save, int Cout, const float* gamma, const float* beta,
+                          float* chan, long long* nbt, hipStream_t s) {
+    hipLaunchKernelGGL(k_qa_stats_prep, dim3((unsigned)Cout), dim3(64), 0, s, part, CB, G, Mpad, Mr, rowscale, ascale, bias, n, eps, momentum, training, running_mean,
+                       running_var, save, Cout, gamma, beta, chan, nbt);
+}
+
+// ---------------------------------------------------------------- host side
+static int qa_geom(QaGeom* g, int64_t N, int64_t C, int64_t H, int64_t W, int bits, int pool, const char* what) {
+    const int64_t HW = H * W;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || HW % 8 || bits < 2 || bits > 8) MN_FAIL(MN_EINVAL, "%s: bad shape / bits (H*W must be a multiple of 8, 2 <= bits <= 8)", what);
+    if (pool && ((H & 1) || W % 8)) MN_FAIL(MN_EINVAL, "%s: pooled variant needs even H and W %% 8 == 0", what);
+    if (N * (HW / 8) >= ((int64_t)1 << 31)) MN_FAIL(MN_EINVAL, "%s: tensor too large", what);
+    g->N = (int)N; g->C = (int)C; g->H = (int)H; g->W = (int)W; g->HW = (int)HW; g->HW8 = (int)(HW / 8); g->W8 = (int)(W / 8);
+    g->fd_hw8 = make_fastdiv((uint32_t)g->HW8); g->fd_w8 = make_fastdiv((uint32_t)(g->W8 > 0 ? g->W8 : 1));
+    g->n8 = pool ? N * (H / 2) * (W / 8) : N * (HW / 8);
+    g->s = dorefa_scale(bits);
+    return MN_OK;
+}
+static int qa_split(const QaGeom& g) {
+    int64_t S = (2048 + g.C - 1) / g.C;
+    const int64_t maxS = (g.n8 + 255) / 256;
+    if (S > maxS) S = maxS;
+    if (S > 32) S = 32;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+extern "C" int mn_qa_supported(int64_t H, int64_t W, int pool) { return (H * W) % 8 == 0 && (!pool || ((H & 1) == 0 && W % 8 == 0)); }
+extern "C" int64_t mn_qa_ws_floats(int64_t C) { return C * 32 * 4 + 2 * C + 16; }
+extern "C" int mn_qa_chan_from_save(const float* save, const float* gamma, const float* beta, int64_t C, float* chan, mn_stream_t stream) {
+    if (!save || !gamma || !beta || !chan || C <= 0) MN_FAIL(MN_EINVAL, "mn_qa_chan_from_save: bad arguments");
+    hipLaunchKernelGGL(k_qa_chan_f32, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)C, save, gamma, beta, chan);
+    MN_CHECK_LAUNCH("mn_qa_chan_from_save");
+    return MN_OK;
+}
+#define QA_DISPATCH(KERNEL, ...)                                                                                         \
+    if (in_f32) { if (pool) hipLaunchKernelGGL((KERNEL<1, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<1, 0>), __VA_ARGS__); } \
+    else { if (pool) hipLaunchKernelGGL((KERNEL<0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<0, 0>), __VA_ARGS__); }
+extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, uint8_t* codes, float* act_f32,
+                         mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, a_bits, pool, "mn_qa_fwd");
+    if (rc) return rc;
+    if (!in || !chan || (!codes && !act_f32) || (((uintptr_t)in) & 15) || (codes && (((uintptr_t)codes) & 7)) || (act_f32 && !aligned16(act_f32)))
+        MN_FAIL(MN_EINVAL, "mn_qa_fwd: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)C, (unsigned)qa_split(g));
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qa_fwd<%d, %d>", in_f32 ? 1 : 0, pool ? 1 : 0);
+    mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + (codes ? 1.0 : 0.0) * nel / (pool ? 4.0 : 1.0) + (act_f32 ? 4.0 : 0.0) * nel / (pool ? 4.0 : 1.0));
+    mn_prof_begin(s);
+    if (codes) {
+        if (in_f32) { if (pool) hipLaunchKernelGGL((k_qa_fwd<1, 1, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); else hipLaunchKernelGGL((k_qa_fwd<1, 0, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); }
+        else { if (pool) hipLaunchKernelGGL((k_qa_fwd<0, 1, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); else hipLaunchKernelGGL((k_qa_fwd<0, 0, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); }
+    }
+    if (act_f32) {
+        if (in_f32) { if (pool) hipLaunchKernelGGL((k_qa_fwd<1, 1, 1>), grid, dim3(256), 0, s, g, in, chan, (unsigned char*)nullptr, act_f32); else hipLaunchKernelGGL((k_qa_fwd<1, 0, 1>), grid, dim3(256), 0, s, g, in, chan, (unsigned char*)nullptr, act_f32); }
+        else { if (pool) hipLaunchKernelGGL((k_qa_fwd<0, 1, 1>), grid, dim3(256), 0, s, g, in, chan, (unsigned char*)nullptr, act_f32); else hipLaunchKernelGGL((k_qa_fwd<0, 0, 1>), grid, dim3(256), 0, s, g, in, chan, (unsigned char*)nullptr, act_f32); }
+    }
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qa_fwd");
+    return MN_OK;
+}
+extern "C" int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, int quant,
+                              float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, a_bits, pool, "mn_qa_bwd_sums");
+    if (rc) return rc;
+    if (!in || !chan || !dq || !sums || !ws || (((uintptr_t)in) & 15) || !aligned16(dq) || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_qa_bwd_sums: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = qa_split(g);
+    const dim3 grid((unsigned)C, (unsigned)S);
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qa_partial<%d, %d>", in_f32 ? 1 : 0, pool ? 1 : 0);
+    mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + 4.0 * nel / (pool ? 4.0 : 1.0));
+    mn_prof_begin(s);
+    QA_DISPATCH(k_qa_partial, grid, dim3(256), 0, s, g, in, chan, dq, quant, (double*)ws)
+    mn_prof_end(s);
+    hipLaunchKernelGGL(k_qa_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (int)C, (const double*)ws, S, dgamma, dbeta, sums);
+    MN_CHECK_LAUNCH("mn_qa_bwd_sums");
+    return MN_OK;
+}
+extern "C" int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, const float* sums, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits,
+                               int pool, int quant, int training, float* dy, mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, a_bits, pool, "mn_qa_bwd_apply");
+    if (rc) return rc;
+    if (!in || !chan || !dq || !sums || !dy || (((uintptr_t)in) & 15) || !aligned16(dq) || !aligned16(dy)) MN_FAIL(MN_EINVAL, "mn_qa_bwd_apply: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)C, (unsigned)qa_split(g));
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qa_apply<%d, %d>", in_f32 ? 1 : 0, pool ? 1 : 0);
+    mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + 4.0 * nel / (pool ? 4.0 : 1.0) + 4.0 * nel);
+    mn_prof_begin(s);
+    QA_DISPATCH(k_qa_apply, grid, dim3(256), 0, s, g, in, chan, dq, sums, training, quant, dy)
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qa_bwd_apply");
+    return MN_OK;
+}

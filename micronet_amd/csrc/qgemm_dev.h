@@ -85,6 +85,17 @@ int k3s_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const fl
 int k3s_dgrad_supported(const mn_conv_geom* g, const mn_wq* wq);
 int k3s_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, float* dx, hipStream_t s);
 int k3s_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+// the k-bit activation-code (MN_ACTQ_CODE8) variants of the staged-image kernels (qgemm_k3s.hip, qgemm_sign.hip) and the stats / constants launch of qact_kernels.hip
+int k3s_wgrad_code8_supported(const mn_conv_geom* g, int a_bits);
+int k3s_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+int k3s_fwd16_supported(const mn_conv_geom* g, const mn_wq* wq);
+int k3s_fwd16_parts(const mn_conv_geom* g, const mn_wq* wq);
+int k3s_fwd_h16(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, const float* w, int16_t* h16, double* part, hipStream_t s);
+int pws_wgrad_code8_supported(const mn_conv_geom* g);
+int pws_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+void qa_launch_stats_prep(const double* part, int CB, int G, int Mpad, int Mr, const float* rowscale, float ascale, const float* bias, double n, float eps,
+                          float momentum, int training, float* running_mean, float* running_var, float* save, int Cout, const float* gamma, const float* beta,
+                          float* chan, long long* nbt, hipStream_t s);
 
 static inline int aq_codeable(const mn_actq* aq, int need_exact_x) {
     (void)need_exact_x;   // real-valued x is handled exactly by term splitting (zero terms are skipped)
@@ -92,6 +103,7 @@ static inline int aq_codeable(const mn_actq* aq, int need_exact_x) {
     if (aq->mode == MN_ACTQ_DOREFA) return aq->bits >= 2 && aq->bits <= 8;
     if (aq->mode == MN_ACTQ_IAO) return aq->bits >= 2 && aq->bits <= 8 && aq->q_type == 0 && aq->qp;
     if (aq->mode == MN_ACTQ_SIGN8) return 1;
+    // MN_ACTQ_CODE8 is NOT codeable for the generic kernels (they would read the bytes as fp32): the entry points that read codes test for it
     return 0;
 }
 static inline int wq_codeable(const mn_wq* wq) {

@@ -38,6 +38,10 @@ struct K3wParams {
     ChanMap in_map;
 };
 
+// XENC 1: x holds k-bit activation codes j <= 7 (a_bits <= 3): the patch keeps the raw bytes (0 = the zero padding = code 0) and the B fragment is
+// built by byte look-up -- v_perm with the CODES as the selector into an 8-entry table of bf16 bit patterns (high / low byte), then two
+// v_perm to interleave: exact bf16 j, 8 VALU per fragment dword pair instead of 2.  The reduction multiplies by the quantizer's scale.
+template <int XENC>
 __global__ __launch_bounds__(256, 2) void k_k3s_wgrad(const K3wParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_k3s_wgrad(const K3wParams p) {
 #pragma unroll
         for (int u = 0; u < K3_NXL; ++u) {
             const int ir = S.oh0 - 1 + xpr[u];
-            const uint32_t enc = (ir >= 0 && ir < p.H) ? ((S.xv[u] & 0x80808080u) | 0x3F3F3F3Fu) : 0u;
+            const uint32_t enc = (ir >= 0 && ir < p.H) ? (XENC ? S.xv[u] : ((S.xv[u] & 0x80808080u) | 0x3F3F3F3Fu)) : 0u;
             if (xlds[u] >= 0) *reinterpret_cast<uint32_t*>(xsm + xlds[u]) = enc;
         }
     };
@@ -165,7 +169,13 @@ __global__ __launch_bounds__(256, 2) void k_k3s_wgrad(const K3wParams p) {
             for (int s_ = 0; s_ < 3; ++s_) {
                 const uint32_t ua = s_ == 0 ? mn_alignbyte(ac, ap, 3) : (s_ == 1 ? ac : mn_alignbyte(an, ac, 1));
                 const uint32_t ub = s_ == 0 ? mn_alignbyte(bc, bp, 3) : (s_ == 1 ? bc : mn_alignbyte(bn, bc, 1));
-                bf[s_] = u32x4{mn_perm(0u, ua, 0x010c000cu), mn_perm(0u, ua, 0x030c020cu), mn_perm(0u, ub, 0x010c000cu), mn_perm(0u, ub, 0x030c020cu)};
+                if (XENC == 0) {
+                    bf[s_] = u32x4{mn_perm(0u, ua, 0x010c000cu), mn_perm(0u, ua, 0x030c020cu), mn_perm(0u, ub, 0x010c000cu), mn_perm(0u, ub, 0x030c020cu)};
+                } else {          // bf16(j), j = 0..7: 0000 3F80 4000 4040 4080 40A0 40C0 40E0
+                    const uint32_t ha = mn_perm(0x40404040u, 0x40403F00u, ua), la = mn_perm(0xE0C0A080u, 0x40008000u, ua);
+                    const uint32_t hb = mn_perm(0x40404040u, 0x40403F00u, ub), lb = mn_perm(0xE0C0A080u, 0x40008000u, ub);
+                    bf[s_] = u32x4{mn_perm(ha, la, 0x05010400u), mn_perm(ha, la, 0x07030602u), mn_perm(hb, lb, 0x05010400u), mn_perm(hb, lb, 0x07030602u)};
+                }
             }
             // term-outer over the three taps of this kernel row: 6 independent accumulators between two MFMAs on the same one
 #pragma unroll
@@ -274,12 +284,30 @@ int k3s_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, floa
     mn_set_last_kernel("k_k3s_wgrad");
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + nx); }
     mn_prof_begin(s);
-    raise_lds_limit((const void*)k_k3s_wgrad, pl.lds);
-    hipLaunchKernelGGL(k_k3s_wgrad, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    raise_lds_limit((const void*)k_k3s_wgrad<0>, pl.lds);
+    hipLaunchKernelGGL(k_k3s_wgrad<0>, dim3(pl.grid), dim3(256), pl.lds, s, p);
     mn_prof_end(s);
     // the codes were contracted as +-0.5: the reduction doubles (exact)
     qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg * 9, p.Mgw, p.Cgw * 9, 2.f, nullptr, s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(sign 3x3)");
+    return MN_OK;
+}
+// 3 x 3 backward-weight on k-bit activation codes (bytes, a_bits <= 3): dw = s * sum gy * j
+int k3s_wgrad_code8_supported(const mn_conv_geom* g, int a_bits) { K3wPlan pl; return a_bits >= 2 && a_bits <= 3 && plan_k3s(g, &pl); }
+int k3s_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    K3wPlan pl;
+    if (!plan_k3s(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8 3x3): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(code8 3x3): workspace too small");
+    K3wParams& p = pl.p;
+    p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
+    mn_set_last_kernel("k_k3s_wgrad<1>");
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + nx); }
+    mn_prof_begin(s);
+    raise_lds_limit((const void*)k_k3s_wgrad<1>, pl.lds);
+    hipLaunchKernelGGL(k_k3s_wgrad<1>, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    mn_prof_end(s);
+    qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg * 9, p.Mgw, p.Cgw * 9, ascale, nullptr, s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(code8 3x3)");
     return MN_OK;
 }
 
@@ -307,6 +335,8 @@ struct K3dParams {
     const float* gy;
     const float* w;           // fake-quantised weights [O][Cg][3][3]
     float* dx;
+    float wn;                 // 0: ternary / binary weights (code = sign, scale = max |w| of the row);  n = 2^w_bits - 1: DoReFa weights (2k - n) / n
+                              // (wqaq/dorefa/quantize.py:68-72): code = rint(w * n), scale = 1 / n
     int N, C, H, W, O, Cg, Mg, G, ncb, Zb;
     int NI, SP, HW, IS, TS, nstages, WP;      // images per stage, pixels per stage, slots per image, bytes per term plane, W + 2
     FastDiv fd_hw4, fd_w4, fd_w;
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_k3s_dgrad(const K3dParams p) {
         float a = 0.f;
         if (m < p.Mg) for (int k = part; k < wrow; k += 8) a = fmaxf(a, fabsf(wl[m * wrow + k]));
         a = fmaxf(a, __shfl_xor(a, 4, 64)); a = fmaxf(a, __shfl_xor(a, 2, 64)); a = fmaxf(a, __shfl_xor(a, 1, 64));
-        my_alpha = a;
+        my_alpha = p.wn > 0.f ? 1.0f / p.wn : a;
     }
     // A fragments: code t[m(k)][c = cb*16 + j][tap] for k = 8 kg + e  ->  m = 2 kg + e / 4 + 8 (e % 4)
     u32x4 wa[9];
@@ -350,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_k3s_dgrad(const K3dParams p) {
                 const int m = 2 * kg + (e >> 2) + 8 * (e & 3);
                 float v = 0.f;
                 if (m < p.Mg && c < p.Cg) v = wl[m * wrow + c * 9 + t];
-                h16[e] = v > 0.f ? 0x3F80u : (v < 0.f ? 0xBF80u : 0u);
+                h16[e] = p.wn > 0.f ? (mn_f2u(rintf(v * p.wn)) >> 16) : (v > 0.f ? 0x3F80u : (v < 0.f ? 0xBF80u : 0u));
             }
             wa[t] = u32x4{h16[0] | (h16[1] << 16), h16[2] | (h16[3] << 16), h16[4] | (h16[5] << 16), h16[6] | (h16[7] << 16)};
         }
@@ -482,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void k_k3s_dgrad(const K3dParams p) {
 
 struct K3dPlan { K3dParams p; int grid; size_t lds; };
 static int plan_k3d(const mn_conv_geom* g, const mn_wq* wq, K3dPlan* pl) {
-    if (!wq || wq->mode != MN_WQ_TERNARY) return 0;
+    if (!wq || !(wq->mode == MN_WQ_TERNARY || (wq->mode == MN_WQ_DOREFA && wq->bits >= 2 && wq->bits <= 8))) return 0;
     if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1 || g->dil_h != 1 || g->dil_w != 1) return 0;
     if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
     const int HW = g->H * g->W, Mg = g->O / g->groups, Cg = g->C / g->groups;
@@ -521,7 +551,7 @@ int k3s_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const 
     K3dPlan pl;
     if (!plan_k3d(g, wq, &pl) || !aligned16(gy) || !w || !dx) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(3x3 ternary): geometry not covered");
     K3dParams& p = pl.p;
-    p.gy = gy; p.w = w; p.dx = dx;
+    p.gy = gy; p.w = w; p.dx = dx; p.wn = wq->mode == MN_WQ_DOREFA ? (float)((1ll << wq->bits) - 1) : 0.f;
     mn_set_last_kernel("k_k3s_dgrad");
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + 4.0 * nx); }
     mn_prof_begin(s);
@@ -553,6 +583,8 @@ struct K3fParams {
     const float* w;           // fake-quantised weights [O][Cg][3][3]
     const float* nnz9;        // [9][O]
     unsigned char* h;
+    int16_t* h16;             // XENC 1: the 16-bit stash of acc
+    float wn;                 // XENC 1: DoReFa weights (2k - n) / n: the integer code is rint(w * wn), wn = 2^w_bits - 1
     double* part;             // [Zb][G*Mg][2]
     int N, C, H, W, O, Cg, Mg, G, Zb;
     int NI, SP, HW, IS, TS, nstages, WP;
@@ -560,6 +592,10 @@ struct K3fParams {
     ChanMap in_map;
 };
 
+// XENC 0: sign codes x ternary weights -> byte stash h (above).  XENC 1: k-bit activation codes j in [0, 127] x DoReFa weight codes: the LDS image
+// holds bf16 128 + j (the frame and the padding slots hold 128 = code 0), acc' - 128 * sum of the row's weight codes is the exact integer acc,
+// stored as int16; statistics in 64-bit integers.
+template <int XENC>
 __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
@@ -576,13 +612,20 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
     // B fragments: 2 * t[m = mt*16 + j][c(k)][tap(ks, kg)] for k = 8 kg + e: tap = 2 ks + (kg >> 1), position 8 (kg & 1) + e -> c = (pos >> 2) + 4 (pos & 3)
     u32x4 wb[5][2];
     StashNnz zn[2];
+    float wsum[2] = {0.f, 0.f};          // XENC 1: 128 * sum of the channel's weight codes
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = mt * 16 + j;
         const int co = g * p.Mg + (m < p.Mg ? m : p.Mg - 1);
-        zn[mt].v0 = p.nnz9[co]; zn[mt].v1 = p.nnz9[p.O + co]; zn[mt].v2 = p.nnz9[2 * p.O + co]; zn[mt].v3 = p.nnz9[3 * p.O + co];
-        zn[mt].v4 = p.nnz9[4 * p.O + co]; zn[mt].v5 = p.nnz9[5 * p.O + co]; zn[mt].v6 = p.nnz9[6 * p.O + co]; zn[mt].v7 = p.nnz9[7 * p.O + co];
-        zn[mt].v8 = p.nnz9[8 * p.O + co];
+        if (XENC == 0) {
+            zn[mt].v0 = p.nnz9[co]; zn[mt].v1 = p.nnz9[p.O + co]; zn[mt].v2 = p.nnz9[2 * p.O + co]; zn[mt].v3 = p.nnz9[3 * p.O + co];
+            zn[mt].v4 = p.nnz9[4 * p.O + co]; zn[mt].v5 = p.nnz9[5 * p.O + co]; zn[mt].v6 = p.nnz9[6 * p.O + co]; zn[mt].v7 = p.nnz9[7 * p.O + co];
+            zn[mt].v8 = p.nnz9[8 * p.O + co];
+        } else if (m < p.Mg) {
+            float sm = 0.f;
+            for (int i = 0; i < wrow; ++i) sm += rintf(wl[m * wrow + i] * p.wn);
+            wsum[mt] = 128.f * sm;
+        }
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) {
             const int tap = 2 * ks + (kg >> 1);
@@ -592,13 +635,17 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
                 const int pos = 8 * (kg & 1) + e, c = (pos >> 2) + 4 * (pos & 3);
                 float v = 0.f;
                 if (m < p.Mg && c < p.Cg && tap < 9) v = wl[m * wrow + c * 9 + tap];
-                h16[e] = v > 0.f ? 0x4000u : (v < 0.f ? 0xC000u : 0u);
+                if (XENC == 0) h16[e] = v > 0.f ? 0x4000u : (v < 0.f ? 0xC000u : 0u);
+                else h16[e] = mn_f2u(rintf(v * p.wn)) >> 16;               // an integer |code| <= 255: exact in bf16
             }
             wb[ks][mt] = u32x4{h16[0] | (h16[1] << 16), h16[2] | (h16[3] << 16), h16[4] | (h16[5] << 16), h16[6] | (h16[7] << 16)};
         }
     }
     __syncthreads();
-    for (int i = tid; i < p.TS / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    {
+        const uint32_t fill = XENC ? 0x43004300u : 0u;          // code 0 (the zero padding) is bf16 128 under XENC 1
+        for (int i = tid; i < p.TS / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{fill, fill, fill, fill};
+    }
     // tap offset (bytes) of this lane's half of every K-step; tap 9 (the padding half of the last step) reads tap 8's slot against zero weights
     int toff[5];
 #pragma unroll
@@ -641,15 +688,25 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
     auto commit = [&]() {
         if (!sact) return;
         uint32_t en[4];
+        if (XENC == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) en[i] = s_cv[i] ? ((rg[i] & 0x80808080u) | 0x3F3F3F3Fu) : 0u;
+            for (int i = 0; i < 4; ++i) en[i] = s_cv[i] ? ((rg[i] & 0x80808080u) | 0x3F3F3F3Fu) : 0u;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t se = 0x000c000cu | ((uint32_t)e << 8) | ((uint32_t)(4 + e) << 24);      // [0, b.byte e, 0, a.byte e]
-            *reinterpret_cast<u32x2*>(lds + s_slot + e * K3F_RS) = u32x2{mn_perm(en[1], en[0], se), mn_perm(en[3], en[2], se)};
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t se = 0x000c000cu | ((uint32_t)e << 8) | ((uint32_t)(4 + e) << 24);      // [0, b.byte e, 0, a.byte e]
+                *reinterpret_cast<u32x2*>(lds + s_slot + e * K3F_RS) = u32x2{mn_perm(en[1], en[0], se), mn_perm(en[3], en[2], se)};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) en[i] = s_cv[i] ? rg[i] : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t se = 0x0c000c00u | (uint32_t)e | ((uint32_t)(4 + e) << 16);            // [b.byte e, 0, a.byte e, 0], then the 0x43 high bytes
+                *reinterpret_cast<u32x2*>(lds + s_slot + e * K3F_RS) = u32x2{mn_perm(en[1], en[0], se) | 0x43004300u, mn_perm(en[3], en[2], se) | 0x43004300u};
+            }
         }
     };
-    int s1[2] = {0, 0}, s2[2] = {0, 0};
+    long long s1[2] = {0, 0}, s2[2] = {0, 0};
     const int ntile = p.SP >> 5;
     int st = z;
     __syncthreads();
@@ -695,17 +752,28 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
                 for (int mt = 0; mt < 2; ++mt) {
                     const int m = mt * 16 + j;
                     if (n < p.N && m < p.Mg) {
-                        float nz[4];
-                        stash_nnz_quad(zn[mt], (int)row, col4, p.H, p.W >> 2, nz);
-                        uint32_t hb = 0u;
+                        if (XENC == 0) {
+                            float nz[4];
+                            stash_nnz_quad(zn[mt], (int)row, col4, p.H, p.W >> 2, nz);
+                            uint32_t hb = 0u;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const float a = acc[pt][mt][rr];
-                            hb |= (uint32_t)((a + nz[rr]) * 0.5f) << (8 * rr);
-                            const int ai = (int)a;
-                            s1[mt] += ai; s2[mt] += ai * ai;
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const float a = acc[pt][mt][rr];
+                                hb |= (uint32_t)((a + nz[rr]) * 0.5f) << (8 * rr);
+                                const int ai = (int)a;
+                                s1[mt] += ai; s2[mt] += ai * ai;
+                            }
+                            *reinterpret_cast<uint32_t*>(p.h + ((int64_t)n * p.O + g * p.Mg + m) * p.HW + pp) = hb;
+                        } else {
+                            int ai[4];
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                ai[rr] = (int)(acc[pt][mt][rr] - wsum[mt]);
+                                s1[mt] += ai[rr]; s2[mt] += (long long)ai[rr] * ai[rr];
+                            }
+                            *reinterpret_cast<u32x2*>(p.h16 + ((int64_t)n * p.O + g * p.Mg + m) * p.HW + pp) =
+                                u32x2{((uint32_t)ai[0] & 0xffffu) | ((uint32_t)ai[1] << 16), ((uint32_t)ai[2] & 0xffffu) | ((uint32_t)ai[3] << 16)};
                         }
-                        *reinterpret_cast<uint32_t*>(p.h + ((int64_t)n * p.O + g * p.Mg + m) * p.HW + pp) = hb;
                     }
                 }
             }
@@ -713,10 +781,10 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
     }
     // statistics: the four pixel groups of a wave by shuffles, the four waves through LDS in wave order
     __syncthreads();
-    int* red = reinterpret_cast<int*>(lds);          // [4 waves][2 mt][16][2]
+    long long* red = reinterpret_cast<long long*>(lds);          // [4 waves][2 mt][16][2]
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        int a1 = s1[mt], a2 = s2[mt];
+        long long a1 = s1[mt], a2 = s2[mt];
         a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
         a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
         if (kg == 0) { red[((wave * 2 + mt) * 16 + j) * 2] = a1; red[((wave * 2 + mt) * 16 + j) * 2 + 1] = a2; }
@@ -734,8 +802,8 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
 }
 
 struct K3fPlan { K3fParams p; int grid; size_t lds; };
-static int plan_k3f(const mn_conv_geom* g, const mn_wq* wq, K3fPlan* pl) {
-    if (!wq || wq->mode != MN_WQ_TERNARY) return 0;
+static int plan_k3f(const mn_conv_geom* g, const mn_wq* wq, K3fPlan* pl, int xenc = 0) {
+    if (!wq || (xenc ? wq->mode != MN_WQ_DOREFA : wq->mode != MN_WQ_TERNARY)) return 0;
     if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1 || g->dil_h != 1 || g->dil_w != 1) return 0;
     if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
     const int HW = g->H * g->W, Mg = g->O / g->groups, Cg = g->C / g->groups;
@@ -773,13 +841,30 @@ int k3s_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const fl
     K3fPlan pl;
     if (!plan_k3f(g, wq, &pl) || (((uintptr_t)x) & 3) || (((uintptr_t)h) & 3) || !w || !nnz9 || !part) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd_stash(3x3): geometry not covered");
     K3fParams& p = pl.p;
-    p.x = (const char*)x; p.w = w; p.nnz9 = nnz9; p.h = h; p.part = part;
+    p.x = (const char*)x; p.w = w; p.nnz9 = nnz9; p.h = h; p.h16 = nullptr; p.wn = 1.f; p.part = part;
     mn_set_last_kernel("k_k3s_fwd");
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(nx + ny); }
     mn_prof_begin(s);
-    raise_lds_limit((const void*)k_k3s_fwd, pl.lds);
-    hipLaunchKernelGGL(k_k3s_fwd, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    raise_lds_limit((const void*)k_k3s_fwd<0>, pl.lds);
+    hipLaunchKernelGGL(k_k3s_fwd<0>, dim3(pl.grid), dim3(256), pl.lds, s, p);
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_qconv_bnsign_fwd_stash(3x3)");
+    return MN_OK;
+}
+// the same 3 x 3 forward on k-bit activation codes x DoReFa weights, writing the 16-bit stash of acc + the statistics partials
+int k3s_fwd16_supported(const mn_conv_geom* g, const mn_wq* wq) { K3fPlan pl; return plan_k3f(g, wq, &pl, 1) && pl.lds >= 4 * 2 * 16 * 2 * 8; }
+int k3s_fwd16_parts(const mn_conv_geom* g, const mn_wq* wq) { K3fPlan pl; return plan_k3f(g, wq, &pl, 1) ? pl.p.Zb : 0; }
+int k3s_fwd_h16(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, const float* w, int16_t* h16, double* part, hipStream_t s) {
+    K3fPlan pl;
+    if (!plan_k3f(g, wq, &pl, 1) || (((uintptr_t)x) & 3) || (((uintptr_t)h16) & 7) || !w || !part) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnq_fwd_stash(3x3): geometry not covered");
+    K3fParams& p = pl.p;
+    p.x = (const char*)x; p.w = w; p.nnz9 = nullptr; p.h = nullptr; p.h16 = h16; p.part = part; p.wn = (float)((1ll << wq->bits) - 1);
+    mn_set_last_kernel("k_k3s_fwd<1>");
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(nx + 2.0 * ny); }
+    mn_prof_begin(s);
+    raise_lds_limit((const void*)k_k3s_fwd<1>, pl.lds);
+    hipLaunchKernelGGL(k_k3s_fwd<1>, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash(3x3)");
     return MN_OK;
 }

@@ -891,6 +891,7 @@ int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int 
     if (!pw_geom_ok(g)) return kk_supported(g, aq, wq, which);
     if (which == 0) { PwPlan pl; return wq_codeable(wq) && aq_codeable(aq, 0) && plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl); }
     if (which == 1) { PwPlan pl; return wq_codeable(wq) && plan_pw(g, 1, MN_ACTQ_NONE, &pl); }
+    if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) return aq->bits >= 2 && aq->bits <= 7 && pws_wgrad_code8_supported(g);
     if (which == 2) { WgPlan pl; return aq_codeable(aq, 1) && plan_pw_wgrad(g, &pl); }
     return 0;
 }
@@ -933,6 +934,7 @@ static int run_pw(PwPlan& pl, int xmode, hipStream_t s, const char* what) {
 }
 int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y,
            void* ws, int64_t ws_bytes, hipStream_t s) {
+    if (aq && aq->mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: activation codes are read by mn_qconv_bnq_fwd_stash only");
     if (!pw_geom_ok(g)) return kk_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
     if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_supported(g, wq) && ws_bytes >= pws_ws_bytes(g))     // sign codes: the prefetching kernel
         return pws_fwd(g, wq, (const int8_t*)x, w, bias, y, ws, ws_bytes, s);
@@ -962,7 +964,7 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     Pro ste;
     int rc = make_pro(aq, &ste, 1, "mn_conv2d_bwd_data(qgemm)");
     if (rc) return rc;
-    if (ste.mode == MN_ACTQ_SIGN8) ste.mode = MN_ACTQ_NONE;      // the clip-STE of the sign lives in mn_bnsign_bwd
+    if (ste.mode == MN_ACTQ_SIGN8 || ste.mode == MN_ACTQ_CODE8) ste.mode = MN_ACTQ_NONE;      // the clip-STE lives in mn_bnsign_bwd / mn_qa_bwd_*
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
     if (ste.mode == MN_ACTQ_NONE && !getenv("MN_NO_PWD")) {      // no clip-STE epilogue: the prefetching kernel
         PwdPlan pd;
@@ -1009,6 +1011,10 @@ int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
     if (!pw_geom_ok(g)) return kk_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
     if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_wgrad_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g) && !getenv("MN_NO_WG2"))
         return pws_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // sign codes: fragments straight from global memory
+    if (aq && aq->mode == MN_ACTQ_CODE8) {        // k-bit activation codes: only the LDS-staged kernel reads them
+        if (aq->bits < 2 || aq->bits > 7 || !pws_wgrad_code8_supported(g)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): geometry not covered");
+        return pws_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);
+    }
     WgPlan pl;
     if (!aq_codeable(aq, 1) || !plan_pw_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(qgemm): geometry / quantizer combination not covered");

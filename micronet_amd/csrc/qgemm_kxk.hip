@@ -423,6 +423,7 @@ static int run_kk(const KkPlan& pl, hipStream_t s, const char* what) {
 int kk_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y,
            void* ws, int64_t ws_bytes, hipStream_t s) {
     KkPlan pl;
+    if (aq && aq->mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: activation codes are read by mn_qconv_bnq_fwd_stash only");
     if (!wq_codeable(wq) || !aq_codeable(aq, 0) || !plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl) || !aligned16(x) || !aligned16(y))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(qgemm): geometry / quantizer combination not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(qgemm kxk): workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)pl.ws_bytes);
@@ -472,7 +473,7 @@ int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     Pro ste;
     int rc = make_pro(aq, &ste, 1, "mn_conv2d_bwd_data(qgemm)");
     if (rc) return rc;
-    if (ste.mode == MN_ACTQ_SIGN8) ste.mode = MN_ACTQ_NONE;      // the clip-STE of the sign lives in mn_bnsign_bwd
+    if (ste.mode == MN_ACTQ_SIGN8 || ste.mode == MN_ACTQ_CODE8) ste.mode = MN_ACTQ_NONE;      // the clip-STE lives in mn_bnsign_bwd / mn_qa_bwd_*
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
     if (ste.mode == MN_ACTQ_NONE && k3s_dgrad_supported(g, wq)) return k3s_bwd_data(g, wq, gy, w, dx, s);      // 3x3, ternary / binary weights: staged-image kernel
     fill_pack(pl.pk, wq, w, ws, pl.off_codes, pl.off_scale);
@@ -815,6 +816,7 @@ int kk_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int 
     KkPlan pl;
     if (which == 0) return wq_codeable(wq) && aq_codeable(aq, 0) && plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl);
     if (which == 1) return wq_codeable(wq) && plan_kk(g, 1, MN_ACTQ_NONE, &pl);
+    if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) return k3s_wgrad_code8_supported(g, aq->bits);
     if (which == 2) { KwPlan kw; return aq_codeable(aq, 1) && (plan_kk_wgrad(g, &kw) || (aq && aq->mode == MN_ACTQ_SIGN8 && k3s_wgrad_supported(g))); }
     return 0;
 }
@@ -833,6 +835,10 @@ int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
                   int64_t ws_bytes, hipStream_t s) {
     if (aq && aq->mode == MN_ACTQ_SIGN8 && k3s_wgrad_supported(g) && ws_bytes >= k3s_wgrad_ws_bytes(g))
         return k3s_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // 3x3 on sign codes: wave-private streaming kernel
+    if (aq && aq->mode == MN_ACTQ_CODE8) {        // k-bit activation codes: only the wave-private 3x3 kernel reads them
+        if (!k3s_wgrad_code8_supported(g, aq->bits) || ws_bytes < k3s_wgrad_ws_bytes(g)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): geometry / bits not covered");
+        return k3s_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);
+    }
     KwPlan pl;
     if (!aq_codeable(aq, 1) || !plan_kk_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(qgemm): geometry / quantizer combination not covered");

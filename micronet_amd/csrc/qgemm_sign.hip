@@ -46,6 +46,7 @@ struct PwsParams {
     const float* bias;        // [G*Mr] or null
     float* y;                 // PWS_Y: y     PWS_BWD_APPLY: dy        [N][Cout_total][HW]
     char* a8;                 // PWS_SIGN8 output
+    int16_t* h16;             // XENC 1 (k-bit activation codes), PWS_STATS: the conv result acc as a 16-bit stash (qact_kernels.hip)
     unsigned char* h8;        // PWS_SIGN8, optional: h = (acc + nnz[o]) / 2 in [0, 128] -- the conv result in one byte (acc has the parity
                               // of nnz[o], the number of non-zero weight codes of the channel); the streaming BN backward reads it
     float* part;              // PWS_STATS / PWS_BWD_PART: [CB][G*Mpad][2]
@@ -57,13 +58,17 @@ struct PwsParams {
     const float* sums;        // [2][Cout_total] sum dz, sum dz*zhat (PWS_BWD_APPLY, training)
     int training;
     float n_f;                // (float)N * (float)HW, the divisor k_bns_apply uses
+    float ascale;             // PWS_Y: scale of the activation codes (XENC 1: the quantizer's s; 1 for sign codes)
     int N, HW, Cin_total, Cout_total, Kc, Mr, G, Kp, Mpad, num_mblk, nchunks, CB;
     uint32_t NP;
     FastDiv fd_hw;
     ChanMap in_map;
 };
 
-template <int NT, int KS, int EPI>
+// XENC 0: x holds int8 sign codes (+-1).  XENC 1: x holds k-bit activation codes j in [0, 127] as bytes (the DoReFa / IAO activation quantizer's
+// integer, wqaq/dorefa/quantize.py:43-45): the B fragments are built as bf16 128 + j (high byte 0x43, low byte j: one v_perm + one v_or per
+// fragment dword), every product and sum stays an exact integer, and the epilogue subtracts 128 * sum_k code_w[o][k] (c2 = that row constant).
+template <int NT, int KS, int EPI, int XENC = 0>
 __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     constexpr int MB = 16 * NT;
@@ -102,8 +107,10 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             // the sign codes are contracted as +-0.5 (one v_perm per B-fragment dword, see the main loop): the weight codes are doubled here --
             // a bf16 integer code times two is its exponent field plus one (0x0080), zero stays zero -- so every product is the exact +-code
             u32x4 wv = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.Kp + c8 * 8);
+            if (XENC == 0) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) wv[d] += ((wv[d] & 0x00007fffu) ? 0x00000080u : 0u) | ((wv[d] & 0x7fff0000u) ? 0x00800000u : 0u);
+                for (int d = 0; d < 4; ++d) wv[d] += ((wv[d] & 0x00007fffu) ? 0x00000080u : 0u) | ((wv[d] & 0x7fff0000u) ? 0x00800000u : 0u);
+            }
             *reinterpret_cast<u32x4*>(wsm + row * LDW + c8 * 8) = wv;
         }
         for (int i = tid; i < MB; i += 256) {
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             const bool mv = m < p.Mr;
             const int co = g * p.Mr + (mv ? m : 0);
             const int C = p.Cout_total;
-            if (EPI == PWS_Y) { c0[i] = p.rowscale[g * p.Mpad + m]; c1[i] = (p.bias && mv) ? p.bias[co] : 0.f; }
+            if (EPI == PWS_Y) { c0[i] = p.rowscale[g * p.Mpad + m] * p.ascale; c1[i] = (p.bias && mv) ? p.bias[co] : 0.f; }
             if (EPI == PWS_SIGN8) { c0[i] = p.chan[co]; c1[i] = p.chan[C + co]; c2[i] = p.chan[7 * C + co]; }
             if (GRAD) { c0[i] = p.chan[2 * C + co]; c1[i] = p.chan[3 * C + co]; c2[i] = p.chan[C + co]; c3[i] = p.chan[4 * C + co]; c4[i] = p.chan[5 * C + co]; }
             if (APPLY) {
@@ -123,7 +130,16 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
         for (int c = tid; c < p.Kp; c += 256) coff[c] = (uint32_t)chan_phys(p.in_map, g * p.Kc + (c < p.Kc ? c : p.Kc - 1)) * HW;
     }
     __syncthreads();
-    if (EPI == PWS_STATS && p.h8) {          // the statistics pass also writes the byte stash: nnz[row] from the staged codes (4 threads per row)
+    if (XENC == 1) {                          // c2[row] = 128 * sum of the row's weight codes (exact small integers in bf16)
+        for (int rb = 0; rb < MB; rb += 64) {
+            const int row = rb + (tid >> 2), part = tid & 3;
+            float sm = 0.f;
+            if (row < MB) for (int k = part; k < p.Kp; k += 4) sm += mn_u2f((uint32_t)wsm[row * LDW + k] << 16);
+            sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 1, 64);
+            if (row < MB && part == 0) c2[row] = 128.f * sm;
+        }
+        __syncthreads();
+    } else if (EPI == PWS_STATS && p.h8) {          // the statistics pass also writes the byte stash: nnz[row] from the staged codes (4 threads per row)
         const int row = tid >> 2, part = tid & 3;
         int cnt = 0;
         if (row < MB) for (int k = part; k < p.Kp; k += 4) cnt += (wsm[row * LDW + k] & 0x7fffu) != 0;
@@ -225,16 +241,26 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
         for (int s = 0; s < KS; ++s) {
             // B fragments: byte q of the 8 channel dwords -> bf16 +-0.5 (0x3F00 / 0xBF00: the sign bit over 0x3F as the HIGH byte, low byte 0):
             // one v_and_or per input dword, one v_perm per fragment dword
-            uint32_t en[8];
-#pragma unroll
-            for (int d = 0; d < 8; ++d) en[d] = (cur[s * 8 + d] & 0x80808080u) | 0x3F3F3F3Fu;
             u32x4 bq[4];
+            if (XENC == 0) {
+                uint32_t en[8];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                bq[0][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x040c000cu);
-                bq[1][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x050c010cu);
-                bq[2][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x060c020cu);
-                bq[3][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x070c030cu);
+                for (int d = 0; d < 8; ++d) en[d] = (cur[s * 8 + d] & 0x80808080u) | 0x3F3F3F3Fu;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bq[0][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x040c000cu);
+                    bq[1][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x050c010cu);
+                    bq[2][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x060c020cu);
+                    bq[3][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x070c030cu);
+                }
+            } else {          // bf16 (128 + j): low byte = the code, high byte 0x43
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bq[0][d] = mn_perm(cur[s * 8 + 2 * d + 1], cur[s * 8 + 2 * d], 0x0c040c00u) | 0x43004300u;
+                    bq[1][d] = mn_perm(cur[s * 8 + 2 * d + 1], cur[s * 8 + 2 * d], 0x0c050c01u) | 0x43004300u;
+                    bq[2][d] = mn_perm(cur[s * 8 + 2 * d + 1], cur[s * 8 + 2 * d], 0x0c060c02u) | 0x43004300u;
+                    bq[3][d] = mn_perm(cur[s * 8 + 2 * d + 1], cur[s * 8 + 2 * d], 0x0c070c03u) | 0x43004300u;
+                }
             }
             load_step(cur, s, xo_next);                      // this step's registers are free: prefetch chunk + PF into them
             // A fragments one tile ahead only: the scheduler would otherwise hoist all NT LDS reads (4 VGPRs each) above the MFMAs
@@ -257,13 +283,17 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int ml = t * 16 + kg * 4 + r;
                 const bool ok = pv && mblk * MB + ml < p.Mr;
-                const float o[4] = {acc[0][t][r], acc[1][t][r], acc[2][t][r], acc[3][t][r]};
+                const float xc = XENC == 1 ? c2[ml] : 0.f;
+                const float o[4] = {acc[0][t][r] - xc, acc[1][t][r] - xc, acc[2][t][r] - xc, acc[3][t][r] - xc};
                 const uint32_t off = obase + (uint32_t)(t * 16 + r) * HW;
                 if (EPI == PWS_STATS) {
                     if (ok) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { s1[t][r] += o[e]; s2[t][r] += o[e] * o[e]; }      // exact: integers below 2^24
-                        if (p.h8) {          // byte stash written by the statistics pass: the sign then is a streaming pass over h (k_h_sign)
+                        if (XENC == 1) {
+                            if (p.h16) *reinterpret_cast<u32x2*>(p.h16 + off) = u32x2{((uint32_t)(int)o[0] & 0xffffu) | ((uint32_t)(int)o[1] << 16),
+                                                                                     ((uint32_t)(int)o[2] & 0xffffu) | ((uint32_t)(int)o[3] << 16)};
+                        } else if (p.h8) {          // byte stash written by the statistics pass: the sign then is a streaming pass over h (k_h_sign)
                             const float nz = c2[ml];
                             *reinterpret_cast<uint32_t*>(p.h8 + off) = (uint32_t)((o[0] + nz) * 0.5f) | ((uint32_t)((o[1] + nz) * 0.5f) << 8) |
                                                                        ((uint32_t)((o[2] + nz) * 0.5f) << 16) | ((uint32_t)((o[3] + nz) * 0.5f) << 24);
@@ -708,13 +738,19 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
 #ifndef WG3_PRESPLIT
 #define WG3_PRESPLIT 1
 #endif
-template <int MW, int BNH>
+// XENC 1: x holds k-bit activation codes j (bytes): the staging threads expand them ONCE per block to bf16 j (exact; rows of 64 B = 4 chunks of 8
+// pixels, chunk c of row r stored at position c ^ ((r >> 2) & 3): the b128 fragment reads of 16 consecutive rows fall on distinct banks) and
+// the waves read ready B fragments; the reduction kernel multiplies by the quantizer's scale s.  (No 128-offset trick here: the gradient is
+// real-valued, an offset 40x larger than the signal would cost its low bits.)
+#define WG3_RSBX 64
+template <int MW, int BNH, int XENC = 0>
 __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     // WG3_PRESPLIT: the staging threads split gy into its three bf16 terms ONCE per block and store three bf16 planes (rows of 80 B); the
     // waves then read ready fragments (no VALU between LDS and MFMA; the split is no longer done twice, by both waves of a row half)
     constexpr int CW = MW, TM = 32 * MW, TC = 32 * MW, RPT = TM / 32;
     constexpr int RS2 = 80, PLANE = TM * RS2;
-    constexpr int BUF = WG3_PRESPLIT ? 3 * PLANE + TC * WG3_RSB : TM * WG3_RSA + TC * WG3_RSB;
+    constexpr int RSB = XENC ? WG3_RSBX : WG3_RSB;
+    constexpr int BUF = WG3_PRESPLIT ? 3 * PLANE + TC * RSB : TM * WG3_RSA + TC * RSB;
     HIP_DYNAMIC_SHARED(float, smemw)
     unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
@@ -820,7 +856,18 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
                 *reinterpret_cast<float4*>(A + (sr + 32 * i) * WG3_RSA + 16 * sq) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
-        if (cdo) {
+        if (cdo && XENC) {               // 16 code bytes -> 16 bf16 (exact small integers), K slot (kg, e) = pixel 8 kg + e
+            u32x4 lo, hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t u = S.cv[q];
+                const uint32_t p0 = mn_pack_bf16x2((float)(u & 0xffu), (float)((u >> 8) & 0xffu)), p1 = mn_pack_bf16x2((float)((u >> 16) & 0xffu), (float)(u >> 24));
+                if (q < 2) { lo[2 * q] = p0; lo[2 * q + 1] = p1; } else { hi[2 * (q - 2)] = p0; hi[2 * (q - 2) + 1] = p1; }
+            }
+            const int sw = (cr >> 2) & 3;
+            *reinterpret_cast<u32x4*>(B + cr * RSB + 16 * ((2 * chf) ^ sw)) = lo;
+            *reinterpret_cast<u32x4*>(B + cr * RSB + 16 * ((2 * chf + 1) ^ sw)) = hi;
+        } else if (cdo) {
             if (WG3_PRESPLIT) {          // K slot (kg, e) = pixel 8 kg + e: plain row order
                 *reinterpret_cast<u32x4*>(B + cr * WG3_RSB + 16 * chf) = S.cv;
             } else {                     // chunk q of this half goes next to chunk q of the other half: lane (j, kg) reads its 8 codes as one b64
@@ -835,6 +882,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
         u32x4 bf[CW];
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
+            if (XENC) { bf[ci] = *reinterpret_cast<const u32x4*>(B + ((wc * CW + ci) * 16 + j) * RSB + 16 * (kg ^ ((j >> 2) & 3))); continue; }
             const u32x2 uv = *reinterpret_cast<const u32x2*>(B + ((wc * CW + ci) * 16 + j) * WG3_RSB + 8 * kg);
             const uint32_t u = uv[0], v = uv[1];
             bf[ci] = u32x4{0x3F803F80u | ((u & 0x80u) << 8) | ((u & 0x8000u) << 16), 0x3F803F80u | ((u & 0x800000u) >> 8) | (u & 0x80000000u),
@@ -999,6 +1047,28 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
     return MN_OK;
 }
 
+// pointwise backward-weight on k-bit activation codes (bytes; dw = s * sum gy * j): the LDS-staged kernel only
+int pws_wgrad_code8_supported(const mn_conv_geom* g) { Wg2Plan pl; return plan_pws_wgrad(g, &pl) && pl.staged; }
+int pws_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    Wg2Plan pl;
+    if (!plan_pws_wgrad(g, &pl) || !pl.staged || !aligned16(gy) || (((uintptr_t)x) & 15)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(code8): workspace too small");
+    Wg2Params& p = pl.p;
+    p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
+    p.h = nullptr; p.chan = nullptr; p.sums = nullptr; p.training = 0; p.n_f = 1.f;
+    mn_set_last_kernel("k_pws_wgrad_s<%d, 0, 1>", pl.MW);
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + nx); }
+    mn_prof_begin(s);
+    const int TMs = 32 * pl.MW;
+    const size_t ldsb = 2 * ((size_t)3 * TMs * 80 + (size_t)TMs * WG3_RSBX);
+    if (pl.MW == 4) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
+    else { raise_lds_limit((const void*)k_pws_wgrad_s<2, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<2, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
+    mn_prof_end(s);
+    qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, ascale, nullptr, s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(code8)");
+    return MN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct PwsPlan {
     PwsParams p;
@@ -1063,29 +1133,30 @@ static int plan_pws(const mn_conv_geom* g, int nt_max, PwsPlan* pl) {
     return 1;
 }
 
-template <int NT, int KS, int EPI>
+template <int NT, int KS, int EPI, int XENC>
 static void launch_pws3(const PwsPlan& pl, hipStream_t s) {
-    raise_lds_limit((const void*)k_pws<NT, KS, EPI>, pl.lds);
-    hipLaunchKernelGGL((k_pws<NT, KS, EPI>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    raise_lds_limit((const void*)k_pws<NT, KS, EPI, XENC>, pl.lds);
+    hipLaunchKernelGGL((k_pws<NT, KS, EPI, XENC>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
 }
-template <int NT, int EPI>
+template <int NT, int EPI, int XENC>
 static void launch_pws2(const PwsPlan& pl, hipStream_t s) {
-    if (pl.KS == 4) launch_pws3<NT, 4, EPI>(pl, s);
-    else if (pl.KS == 3) launch_pws3<NT, 3, EPI>(pl, s);
-    else if (pl.KS == 2) launch_pws3<NT, 2, EPI>(pl, s);
-    else launch_pws3<NT, 1, EPI>(pl, s);
+    if (pl.KS == 4) launch_pws3<NT, 4, EPI, XENC>(pl, s);
+    else if (pl.KS == 3) launch_pws3<NT, 3, EPI, XENC>(pl, s);
+    else if (pl.KS == 2) launch_pws3<NT, 2, EPI, XENC>(pl, s);
+    else launch_pws3<NT, 1, EPI, XENC>(pl, s);
 }
-template <int EPI>
+template <int EPI, int XENC = 0>
 static int launch_pws(const PwsPlan& pl, hipStream_t s, double nbytes, const char* what) {
-    // the name rocprofv3 prints: EPI 0 Y, 1 STATS, 2 SIGN8, 3 BWD_PART, 4 BWD_APPLY, 5 BWD_PART_POOL, 6 BWD_APPLY_POOL
-    mn_set_last_kernel("k_pws<%d, %d, %d>", pl.NT, pl.KS, EPI);
+    // the name rocprofv3 prints: EPI 0 Y, 1 STATS, 2 SIGN8, 3 BWD_PART, 4 BWD_APPLY, 5 BWD_PART_POOL, 6 BWD_APPLY_POOL; XENC 1 = k-bit activation codes
+    if (XENC) mn_set_last_kernel("k_pws<%d, %d, %d, %d>", pl.NT, pl.KS, EPI, XENC);
+    else mn_set_last_kernel("k_pws<%d, %d, %d>", pl.NT, pl.KS, EPI);
     mn_prof_bytes(nbytes);
     mn_prof_begin(s);
     switch (pl.NT) {
-        case 1: launch_pws2<1, EPI>(pl, s); break;
-        case 2: launch_pws2<2, EPI>(pl, s); break;
-        case 4: launch_pws2<4, EPI>(pl, s); break;
-        case 8: if (EPI >= PWS_BWD_PART) MN_FAIL(MN_EINVAL, "%s: bad NT", what); launch_pws2<(EPI >= PWS_BWD_PART) ? 4 : 8, EPI>(pl, s); break;
+        case 1: launch_pws2<1, EPI, XENC>(pl, s); break;
+        case 2: launch_pws2<2, EPI, XENC>(pl, s); break;
+        case 4: launch_pws2<4, EPI, XENC>(pl, s); break;
+        case 8: if (EPI >= PWS_BWD_PART) MN_FAIL(MN_EINVAL, "%s: bad NT", what); launch_pws2<(EPI >= PWS_BWD_PART) ? 4 : 8, EPI, XENC>(pl, s); break;
         default: MN_FAIL(MN_EINVAL, "%s: bad NT", what);
     }
     mn_prof_end(s);
@@ -1106,7 +1177,7 @@ static int pws_prepare(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, 
     p.x = (const char*)x; p.wc = pl->pk.codes; p.rowscale = pl->pk.scale_out;
     p.part = (float*)((char*)ws + pl->off_part);
     p.chan = (const float*)((char*)ws + pl->off_chan);
-    p.y = nullptr; p.a8 = nullptr; p.h8 = nullptr; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr; p.own = nullptr;
+    p.y = nullptr; p.a8 = nullptr; p.h8 = nullptr; p.h16 = nullptr; p.ascale = 1.f; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr; p.own = nullptr;
     p.W = g->W; p.fd_w = make_fastdiv((uint32_t)g->W);
     return MN_OK;
 }
@@ -1443,4 +1514,66 @@ extern "C" int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq
                                           float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, mn_stream_t stream) {
     if (!a_own) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_bwd_pooled: null output codes");
     return bnsign_bwd_impl(g, wq, x, w, bias, gamma, beta, save, dpool, a_own, training, dy, dgamma, dbeta, ws, ws_bytes, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// conv + BatchNorm2d + ReLU + next-layer k-bit quantizer (DoReFa blocks): the forward on activation codes that leaves the 16-bit stash of acc,
+// the exact batch statistics and the per-channel constants of qact_kernels.hip.  Pointwise: k_pws<.., PWS_STATS, XENC 1>; 3 x 3: k_k3s_fwd<1>.
+static int bnq_amax(int a_bits) { return (1 << a_bits) - 1; }
+static int bnq_int16_ok(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
+    const int64_t K = (int64_t)(g->C / g->groups) * g->KH * g->KW, wmax = (1ll << wq->bits) - 1;
+    return K * bnq_amax(a_bits) * wmax <= 32767;
+}
+extern "C" int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in) {
+    if (!g || !wq || wq->mode != MN_WQ_DOREFA || wq->bits < 2 || wq->bits > 8 || a_bits_in < 2 || a_bits_in > 7 || g->groups < 1 || g->C % g->groups || g->O % g->groups) return 0;
+    if (!bnq_int16_ok(g, wq, a_bits_in)) return 0;
+    if (((int64_t)g->H * g->W) % 8) return 0;
+    if (g->KH == 1 && g->KW == 1) {
+        PwsPlan pl;
+        return plan_pws(g, PWS_NT_FWD, &pl) && pws_wgrad_code8_supported(g) && pwd_supported(g, wq);
+    }
+    return k3s_fwd16_supported(g, wq) && k3s_wgrad_code8_supported(g, a_bits_in) && k3s_dgrad_supported(g, wq);
+}
+extern "C" int64_t mn_qconv_bnq_ws_bytes(const mn_conv_geom* g) {
+    if (!g) return -1;
+    if (g->KH == 1 && g->KW == 1) return pws_ws_bytes(g);
+    return ((int64_t)512 * g->O * 2 * 8 + 255) / 256 * 256 + (int64_t)g->O * 4 + 256;      // statistics partials [<= 512][O][2] doubles + the per-channel scale
+}
+__global__ void k_fill_f32(float* __restrict__ p, int n, float v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+extern "C" int mn_qconv_bnq_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x_codes, int a_bits_in, const float* w, const float* bias, const float* gamma,
+                                      const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                      int64_t* num_batches_tracked, float* save, int16_t* stash, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    if (!mn_qconv_bnq_supported(g, wq, a_bits_in)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnq_fwd_stash: geometry / quantizer combination not covered");
+    if (!x_codes || !w || !gamma || !beta || !save || !stash || !chan || (((uintptr_t)x_codes) & 3) || (((uintptr_t)stash) & 15)) MN_FAIL(MN_EINVAL, "mn_qconv_bnq_fwd_stash: null / misaligned argument");
+    if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_qconv_bnq_fwd_stash: eval mode needs the running statistics");
+    hipStream_t s = (hipStream_t)stream;
+    const float ascale = dorefa_scale(a_bits_in);
+    const double npix = (double)g->N * g->H * g->W;
+    if (g->KH == 1 && g->KW == 1) {
+        PwsPlan pl;
+        int rc = pws_prepare(g, wq, (const int8_t*)x_codes, w, ws, ws_bytes, PWS_NT_FWD, &pl, s, "mn_qconv_bnq_fwd_stash");
+        if (rc) return rc;
+        PwsParams& p = pl.p;
+        p.h16 = stash;
+        const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
+        // the stash is needed in eval mode too (the streaming forward reads it): the statistics pass always runs, its sums are ignored in eval
+        if ((rc = launch_pws<PWS_STATS, 1>(pl, s, nx + 2.0 * ny, "mn_qconv_bnq_fwd_stash(stats)"))) return rc;
+        qa_launch_stats_prep((const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, ascale, bias, npix, eps, momentum, training, running_mean, running_var, save,
+                             (int)g->O, gamma, beta, chan, (long long*)num_batches_tracked, s);
+        MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash");
+        return MN_OK;
+    }
+    if (!ws || ws_bytes < mn_qconv_bnq_ws_bytes(g) || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_qconv_bnq_fwd_stash(3x3): workspace too small");
+    double* part = (double*)ws;
+    float* rowscale = (float*)((char*)ws + ((int64_t)512 * g->O * 2 * 8 + 255) / 256 * 256);
+    const int Mg = g->O / g->groups;
+    const float wsc = 1.0f / (float)((1ll << wq->bits) - 1);                 // the per-channel weight scale the pack kernel would produce (1 / n)
+    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((g->O + 255) / 256)), dim3(256), 0, s, rowscale, (int)g->O, wsc);
+    int rc = k3s_fwd_h16(g, wq, x_codes, w, stash, part, s);
+    if (rc) return rc;
+    qa_launch_stats_prep(part, k3s_fwd16_parts(g, wq), g->groups, Mg, Mg, rowscale, ascale, bias, npix, eps, momentum, training, running_mean, running_var, save,
+                         (int)g->O, gamma, beta, chan, (long long*)num_batches_tracked, s);
+    MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash(3x3)");
+    return MN_OK;
 }

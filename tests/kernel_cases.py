@@ -684,3 +684,150 @@ def check_pool_f32(be, shape=(3, 5, 8, 16), seed=0):
     be.call("mn_maxpool2x2_f32_bwd", be.ptr(dG), be.ptr(idx), N * Cc, H, W, be.ptr(dx), be.stream)
     assert np.array_equal(be.to_host(y), y_ref.detach().numpy(), equal_nan=True)
     assert np.array_equal(be.to_host(dx), t.grad.numpy())
+
+
+def check_qconv_bnq(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, pooled=False, padding=0, a_bits=2, w_bits=2,
+                    out_bits=None, quant=1, **_):
+    """The k-bit (DoReFa) fused block -- mn_qconv_bnq_fwd_stash + mn_qa_fwd + mn_qa_bwd_sums/_apply + mn_conv2d_bwd_weight/_bwd_data on activation codes --
+    vs a numpy evaluation of the unfused chain (wqaq/dorefa/quantize.py:36-46 act quantizer, 107-122 conv; BatchNorm2d; ReLU; 2x2 max-pool):
+      stash == the exact integer conv result; batch statistics / activation to fp32 round-off; codes equal away from rounding ties;
+      masks and pool routing recomputed from the same values; all gradients <= 1e-5 rel of an fp64 evaluation."""
+    import torch
+    r = np.random.default_rng(seed)
+    out_bits = out_bits or a_bits
+    N, Cin, H, W = x_shape
+    Oc = w_shape[0]
+    HW = H * W
+    na, nw = 2 ** a_bits - 1, 2 ** w_bits - 1
+    s_a, s_o = F(1.0 / na), F(1.0 / (2 ** out_bits - 1))
+    codes_in = r.integers(0, na + 1, size=x_shape).astype(np.uint8)
+    kw_ = r.integers(0, nw + 1, size=w_shape)
+    wcode = (2 * kw_ - nw).astype(np.float64)
+    w = (F(2.0) * (kw_.astype(F) * F(1.0 / nw)) - F(1.0)).astype(F)          # the fake-quantised fp32 weights the reference holds (2 k s - 1)
+    b = (r.standard_normal(Oc) * 0.2).astype(F) if bias else None
+    gamma, beta = (r.standard_normal(Oc) * 0.5 + 1).astype(F), (r.standard_normal(Oc) * 0.3).astype(F)
+    rm, rv = (r.standard_normal(Oc) * 0.1).astype(F), (np.abs(r.standard_normal(Oc)) * 2 + 0.5).astype(F)
+    eps, mom = 1e-5, 0.1
+    x_log = codes_in.astype(np.float64)
+    if in_shuffle > 1:
+        x_log = np.ascontiguousarray(x_log.reshape(N, in_shuffle, Cin // in_shuffle, H, W).transpose(0, 2, 1, 3, 4).reshape(x_shape))
+    tconv = lambda xx, ww: torch.nn.functional.conv2d(torch.from_numpy(xx), torch.from_numpy(ww), None, 1, padding, 1, groups).numpy()
+    acc = tconv(x_log, wcode)                                                # exact integers (float64)
+    assert np.abs(acc).max() <= 32767
+    alpha = F(F(1.0 / nw) * s_a)
+    y = (acc.astype(F) * alpha + (b.reshape(1, -1, 1, 1) if bias else F(0))).astype(F)      # the fp32 chain of the kernels' epilogue
+    y64 = y.astype(np.float64)
+    n = N * HW
+    if training:
+        # exact statistics of y = alpha * acc + bias (what the integer sums give), not of its fp32 rounding
+        ye = acc * float(alpha) + (b.astype(np.float64).reshape(1, -1, 1, 1) if bias else 0.0)
+        mean = ye.mean(axis=(0, 2, 3)); var_b = ye.var(axis=(0, 2, 3)); var_u = var_b * n / (n - 1)
+    else:
+        mean, var_b = rm.astype(np.float64), rv.astype(np.float64)
+    mean32 = mean.astype(F)
+    inv32 = (F(1.0) / np.sqrt(var_b.astype(F) + F(eps))).astype(F)
+    zh = ((y - mean32.reshape(1, -1, 1, 1)) * inv32.reshape(1, -1, 1, 1)).astype(F)
+    z = (zh * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)).astype(F)
+    a = np.maximum(z, F(0)).astype(F)
+
+    g = be.geom(x_shape, w_shape, padding=padding, groups=groups)
+    g.in_shuffle = in_shuffle
+    wq = be.wq(mode=2, bits=w_bits)
+    assert be.lib.mn_qconv_bnq_supported(C.byref(g), C.byref(wq), a_bits) == 1, "bnq not supported for this case"
+    nb = max(int(be.lib.mn_qconv_bnq_ws_bytes(C.byref(g))), 4 * int(be.lib.mn_qa_ws_floats(Oc)))
+    ws = be.empty(nb // 4 + 8)
+    dX = be.to_dev_i8(codes_in.view(np.int8))
+    dW, dB = be.to_dev(w), (be.to_dev(b) if bias else None)
+    dG, dBe, dRM, dRV = be.to_dev(gamma), be.to_dev(beta), be.to_dev(rm), be.to_dev(rv)
+    save, chan = be.empty((2, Oc)), be.empty((9, Oc))
+    stash = be.empty_i8((N, Oc, H, 2 * W))                                   # int16 [N][Oc][H][W]
+    nbt = be.to_dev_i64([7])
+    be.call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dX), a_bits, be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
+            be.ptr(dRM), be.ptr(dRV), be.ptr(nbt), be.ptr(save), be.ptr(stash), be.ptr(chan), be.ptr(ws), nb, be.stream)
+    assert int(be.to_host(nbt)[0]) == (8 if training else 7)
+    st = be.to_host(stash).view(np.int16).reshape(N, Oc, H, W)
+    assert np.array_equal(st.astype(np.float64), acc), ("stash != exact integer conv result", float(np.abs(st - acc).max()))
+    sv = be.to_host(save)
+    assert np.max(np.abs(sv[0] - mean32)) <= 2e-6 * max(np.max(np.abs(mean32)), 1e-3) + 1e-7, "mean"
+    assert np.max(np.abs(sv[1] - inv32) / inv32) <= 5e-6, "invstd"
+    if training:
+        assert close(be.to_host(dRM), ((1 - mom) * rm + mom * mean).astype(F), 1e-6) and close(be.to_host(dRV), ((1 - mom) * rv + mom * var_u).astype(F), 1e-5)
+    # ---- streaming forward: the fp32 activation and the codes of the NEXT quantizer (through the 2x2 max-pool if pooled)
+    Ho, Wo = (H // 2, W // 2) if pooled else (H, W)
+    codes_out = be.empty_i8((N, Oc, Ho, Wo))
+    act = be.empty((N, Oc, Ho, Wo))
+    be.call("mn_qa_fwd", 0, be.ptr(stash), be.ptr(chan), N, Oc, H, W, out_bits, int(pooled), be.ptr(codes_out), be.ptr(act), be.stream)
+    # the kernels use THEIR (mean, invstd): recompute the reference chain with them so that every downstream comparison is exact up to ties
+    m_k, i_k = sv[0].astype(F), sv[1].astype(F)
+    zh = ((y - m_k.reshape(1, -1, 1, 1)) * i_k.reshape(1, -1, 1, 1)).astype(F)
+    z = (zh * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)).astype(F)
+    a = np.maximum(z, F(0)).astype(F)
+    if pooled:
+        ta = torch.from_numpy(a.copy()).requires_grad_(True)
+        ap_t = torch.nn.functional.max_pool2d(ta, 2, 2)
+        a_out = ap_t.detach().numpy()
+    else:
+        a_out = a
+    got_act = be.to_host(act)
+    assert np.array_equal(got_act, a_out), ("activation", float(np.abs(got_act - a_out).max()))
+    c_ref = np.sign(a_out * F(0.1)) * np.floor(np.abs(np.clip(a_out * F(0.1), 0, 1).astype(F) / s_o) + F(0.5))
+    assert np.array_equal(be.to_host(codes_out).view(np.uint8).astype(np.float64), c_ref.astype(np.float64)), "codes of the next quantizer"
+    # ---- backward of BatchNorm + ReLU (+ pool) (+ the quantizer's clip-STE when quant)
+    dq = r.standard_normal((N, Oc, Ho, Wo)).astype(F)
+    if quant:
+        t_ = a_out * F(0.1)
+        d_ = ((dq * s_o) / s_o).astype(F)
+        d_ = np.where((t_ >= 0) & (t_ <= 1), d_, F(0)) * F(0.1)
+    else:
+        d_ = dq
+    if pooled:
+        ap_t.backward(torch.from_numpy(d_.astype(F)))
+        da = ta.grad.numpy()
+    else:
+        da = d_
+    dz = np.where(z > 0, da, F(0)).astype(np.float64)
+    dbeta_ref, dgamma_ref = dz.sum(axis=(0, 2, 3)), (dz * zh.astype(np.float64)).sum(axis=(0, 2, 3))
+    gi = (gamma.astype(np.float64) * i_k.astype(np.float64)).reshape(1, -1, 1, 1)
+    dy_ref = gi * (dz - dbeta_ref.reshape(1, -1, 1, 1) / n - zh.astype(np.float64) * dgamma_ref.reshape(1, -1, 1, 1) / n) if training else gi * dz
+    dDQ = be.to_dev(dq)
+    dy, dgam, dbet, sums = be.empty((N, Oc, H, W)), be.empty(Oc), be.empty(Oc), be.empty((2, Oc))
+    be.call("mn_qa_bwd_sums", 0, be.ptr(stash), be.ptr(chan), be.ptr(dDQ), N, Oc, H, W, out_bits, int(pooled), int(quant), be.ptr(dgam), be.ptr(dbet), be.ptr(sums),
+            be.ptr(ws), be.stream)
+    be.call("mn_qa_bwd_apply", 0, be.ptr(stash), be.ptr(chan), be.ptr(sums), be.ptr(dDQ), N, Oc, H, W, out_bits, int(pooled), int(quant), int(training), be.ptr(dy),
+            be.stream)
+    sc = max(np.max(np.abs(dz)) * np.sqrt(n), 1e-30)
+    assert np.max(np.abs(be.to_host(dbet) - dbeta_ref)) <= 2e-6 * sc and np.max(np.abs(be.to_host(dgam) - dgamma_ref)) <= 2e-6 * sc * max(1.0, np.abs(zh).max()), "dgamma / dbeta"
+    assert close(be.to_host(dy), dy_ref, 1e-5), ("dy", float(np.max(np.abs(be.to_host(dy) - dy_ref)) / np.max(np.abs(dy_ref))))
+    # ---- backward of the conv on codes: dx (no STE here) and dw = s_a * sum dy * j
+    gy = dy_ref.astype(F)
+    dGY = be.to_dev(gy)
+    aq = be.actq(4, a_bits)
+    tx = torch.from_numpy(x_log * float(s_a)).requires_grad_(True)
+    tw = torch.from_numpy(w.astype(np.float64)).requires_grad_(True)
+    torch.nn.functional.conv2d(tx, tw, None, 1, padding, 1, groups).backward(torch.from_numpy(gy.astype(np.float64)))
+    dx_ref, dw_ref = tx.grad.numpy(), tw.grad.numpy()
+    if in_shuffle > 1:      # dx is delivered in the PHYSICAL channel order
+        dx_ref = np.ascontiguousarray(dx_ref.reshape(N, Cin // in_shuffle, in_shuffle, H, W).transpose(0, 2, 1, 3, 4).reshape(x_shape))
+    dx = be.empty(x_shape)
+    nb1 = int(be.lib.mn_conv2d_ws_bytes(C.byref(g), 1, 0))
+    ws1 = be.empty(nb1 // 4 + 8)
+    be.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq), be.ptr(dGY), be.ptr(dW), None, be.ptr(dx), be.ptr(ws1), nb1, 0, be.stream)
+    assert close(be.to_host(dx), dx_ref, 1e-5), ("dx", float(np.max(np.abs(be.to_host(dx) - dx_ref)) / np.max(np.abs(dx_ref))))
+    dw, db = be.empty(w_shape), (be.empty(Oc) if bias else None)
+    nb2 = int(be.lib.mn_conv2d_ws_bytes(C.byref(g), 2, 0))
+    ws2 = be.empty(nb2 // 4 + 8)
+    be.call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), be.ptr(dGY), be.ptr(dX), be.ptr(dw), be.ptr(db), be.ptr(ws2), nb2, 0, be.stream)
+    assert close(be.to_host(dw), dw_ref, 1e-5), ("dw", float(np.max(np.abs(be.to_host(dw) - dw_ref)) / np.max(np.abs(dw_ref))))
+    if bias:
+        db_ref = gy.astype(np.float64).sum(axis=(0, 2, 3))
+        assert np.max(np.abs(be.to_host(db) - db_ref)) <= 1e-5 * max(np.abs(gy).sum(axis=(0, 2, 3)).max(), 1e-30), "dbias"
+
+
+BNQ_CASES = [
+    dict(x_shape=(2, 96, 8, 8), w_shape=(96, 48, 1, 1), groups=2),
+    dict(x_shape=(3, 80, 8, 16), w_shape=(96, 40, 1, 1), groups=2, in_shuffle=2, pooled=True),
+    dict(x_shape=(2, 128, 4, 8), w_shape=(48, 128, 1, 1), bias=False, training=False),
+    dict(x_shape=(2, 32, 8, 8), w_shape=(64, 16, 3, 3), groups=2, padding=1),
+    dict(x_shape=(2, 32, 16, 16), w_shape=(48, 8, 3, 3), groups=4, padding=1, in_shuffle=2, pooled=True, a_bits=3, w_bits=3, out_bits=2),
+    dict(x_shape=(4, 48, 8, 8), w_shape=(48, 48, 1, 1), quant=0, a_bits=4, w_bits=4),
+]

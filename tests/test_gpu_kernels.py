@@ -411,3 +411,26 @@ def test_bnrelu(be, training):
 def test_pool_f32(be):
     K.check_pool_f32(be)
     K.check_pool_f32(be, shape=(2, 3, 2, 8), seed=1)
+
+
+# ---- k-bit (DoReFa) fused block on activation codes (16-bit stash): the small cases of the emulated run + nin_gc's layers L2..L8
+@pytest.mark.parametrize("case", range(len(K.BNQ_CASES)))
+def test_qconv_bnq_block(be, case):
+    K.check_qconv_bnq(be, seed=300 + case, **K.BNQ_CASES[case])
+
+
+BNQ_HOT = [
+    ("nin_gc L2", dict(x_shape=(3, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2)),
+    ("nin_gc L3 + pool", dict(x_shape=(3, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2, pooled=True)),
+    ("nin_gc L4 3x3", dict(x_shape=(4, 256, 16, 16), w_shape=(512, 16, 3, 3), groups=16, padding=1, in_shuffle=2)),
+    ("nin_gc L5", dict(x_shape=(4, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=16)),
+    ("nin_gc L6 + pool", dict(x_shape=(4, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=4, pooled=True)),
+    ("nin_gc L7 3x3", dict(x_shape=(6, 512, 8, 8), w_shape=(1024, 16, 3, 3), groups=32, padding=1, in_shuffle=4)),
+    ("nin_gc L8 (fp32 consumer)", dict(x_shape=(6, 1024, 8, 8), w_shape=(1024, 128, 1, 1), groups=8, in_shuffle=32, quant=0)),
+]
+
+
+@pytest.mark.parametrize("name,kw", BNQ_HOT, ids=[n for n, _ in BNQ_HOT])
+@pytest.mark.parametrize("training", [True, False])
+def test_qconv_bnq_hot_shapes(be, name, kw, training):
+    K.check_qconv_bnq(be, seed=77, training=training, **kw)

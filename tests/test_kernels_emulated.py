@@ -280,3 +280,9 @@ def test_bnrelu(be, training):
 def test_pool_f32(be):
     K.check_pool_f32(be)
     K.check_pool_f32(be, shape=(2, 3, 2, 8), seed=1)
+
+
+@pytest.mark.parametrize("case", range(len(K.BNQ_CASES)))
+def test_qconv_bnq_block(be, case):
+    """k-bit (DoReFa) conv + BatchNorm + ReLU + next-layer quantizer on activation codes: 16-bit stash, streaming forward / backward, conv backward."""
+    K.check_qconv_bnq(be, seed=300 + case, **K.BNQ_CASES[case])
