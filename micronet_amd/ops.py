@@ -22,9 +22,9 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import ActQ, ConvGeom, MicronetHipError, WQ
-from .sign_tensor import LazyBNGrad, LazyConvOut, LazyPoolGrad, SignTensor
+from .sign_tensor import LazyBNGrad, LazyConvOut, LazyPoolGrad, LazyQConvOut, QActTensor, QGrad, SignTensor
 
-ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO, ACTQ_SIGN8 = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO, _lib.MN_ACTQ_SIGN8
+ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO, ACTQ_SIGN8, ACTQ_CODE8 = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO, _lib.MN_ACTQ_SIGN8, _lib.MN_ACTQ_CODE8
 WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _lib.MN_WQ_DOREFA, _lib.MN_WQ_IAO
 
 # algorithm used by the conv entry points; tests flip it to compare kernels (0 auto, 1 direct VALU, 2 fp32-MFMA only, 3 code-domain bf16-MFMA only)
@@ -74,7 +74,7 @@ def _lib_():
 def _chk(t, name="tensor"):
     if t is None:
         return None
-    if isinstance(t, (LazyBNGrad, LazyPoolGrad, LazyConvOut)):      # a lazy tensor reaching a kernel that wants plain memory
+    if isinstance(t, (LazyBNGrad, LazyPoolGrad, LazyConvOut, LazyQConvOut, QActTensor, QGrad)):      # a lazy tensor reaching a kernel that wants plain memory
         t = t.materialize()
     elif isinstance(t, SignTensor):
         t = t.to_float()
@@ -116,6 +116,15 @@ class RoundHalfAway(Function):
 
 
 class DorefaAct(Function):
+    @staticmethod
+    def backward_raw(g, x, bits):
+        """the clip-STE of the quantizer without autograd bookkeeping: dx = ((g*s)/s) * [0 <= 0.1x <= 1] * 0.1"""
+        g, x = _chk(g, "grad"), _chk(x, "input")
+        dx = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            _call("mn_dorefa_act_bwd", _p(g), _p(x), _p(dx), x.numel(), bits, _s())
+        return dx
+
     @staticmethod
     def forward(ctx, x, bits):
         x = _chk(x, "input")
@@ -816,6 +825,169 @@ class ConvBNSign(Function):
             dy = torch.empty(h.shape, dtype=torch.float32, device=h.device)
             _call("mn_bnh_bwd_apply", _p(grad), _p(h), _p(own), _p(chan), _p(sums), N, Cc, H, W, training, _p(dy), _s())
         return dy, dgamma, dbeta, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ k-bit (DoReFa) fused block
+def qconv_bnq_supported(x, wq, stride, padding, dilation, groups, w_bits, in_shuffle):
+    """True when conv(x) for a ``QActTensor`` x and DoReFa weights can stay un-computed: the fused kernels (16-bit stash forward, code-reading
+    backward-weight, STE-free backward-data) cover this geometry."""
+    if not isinstance(x, QActTensor) or CONV_ALGO != _lib.MN_ALGO_AUTO or x.dim() != 4 or not (2 <= w_bits <= 8):
+        return False
+    one = lambda v: v in (1, (1, 1), [1, 1])
+    if not (one(stride) and one(dilation)):
+        return False
+    g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle or 0)
+    if _out_hw(g) != (g.H, g.W):
+        return False
+    wd = WQ(WQ_DOREFA, w_bits, 0, 0, None)
+    return bool(_lib_().mn_qconv_bnq_supported(C.byref(g), C.byref(wd), x.bits))
+
+
+class QConvCodeLazy(Function):
+    """DoReFa QuantConv2d (wqaq/dorefa/quantize.py:107-122) on a ``QActTensor``: the activation codes ARE the quantizer's output, so nothing is
+    quantised here, and the result is NOT computed -- a ``LazyQConvOut`` goes to the fused BatchNorm+ReLU+quantizer (``BNReLUQ``).  Backward:
+    mn_conv2d_bwd_weight on the codes (dw = s * sum gy * j), mn_conv2d_bwd_data without the clip-STE (returned as a ``QGrad``: the producing block
+    applies the STE where it recomputes the activation)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, w_bits, in_shuffle):
+        codes, a_bits = x.codes, x.bits
+        wq, bias = _chk(wq, "weight"), _chk(bias, "bias")
+        g = _geom(codes.shape, wq.shape, stride, padding, dilation, groups, in_shuffle)
+        ctx.save_for_backward(codes, wq)
+        ctx.cfg = (g, a_bits, w_bits, bias is not None)
+        ctx.x_ref = x
+
+        def compute():          # a foreign consumer: the ordinary conv kernels on the materialised activation, quantizer in their prologue
+            xa = x.materialize()
+            if in_shuffle and in_shuffle > 1:
+                xa = channel_shuffle(xa, in_shuffle)
+            return QConv2d.apply(xa, wq, bias, stride, padding, dilation, groups, ACTQ_DOREFA, a_bits, 0, None, (WQ_DOREFA, w_bits, 0, 0, None), 0, 0)
+        recipe = dict(codes=codes, a_bits=a_bits, wq=wq, bias=bias, geom=g, w_bits=w_bits, compute=compute)
+        return LazyQConvOut((g.N, g.O, g.H, g.W), codes.device, recipe)
+
+    @staticmethod
+    def backward(ctx, gy):
+        codes, wq = ctx.saved_tensors
+        g, a_bits, w_bits, has_bias = ctx.cfg
+        x = ctx.x_ref
+        gy = _chk(gy, "grad")
+        aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
+        wd = WQ(WQ_DOREFA, w_bits, 0, 0, None)
+        dx = dw = db = None
+        with torch.cuda.device_of(codes):
+            if ctx.needs_input_grad[0]:
+                dq = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+                ws, nb = _ws(g, 1, codes.device)
+                _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wd), _p(gy), _p(wq), None, _p(dq), _p(ws), nb, CONV_ALGO, _s())
+
+                def expand(dq_):
+                    return DorefaAct.backward_raw(dq_, x.materialize(), a_bits)
+                dx = QGrad(dq, expand)
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(wq)
+                db = torch.empty(g.O, dtype=torch.float32, device=codes.device) if has_bias else None
+                ws, nb = _ws(g, 2, codes.device)
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
+        ctx.x_ref = None
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def materialize(t):
+    """The plain float32 tensor behind any lazy / packed wrapper of this package (identity for ordinary tensors); NO autograd link."""
+    return t.materialize() if hasattr(t, "materialize") else (t.to_float() if isinstance(t, SignTensor) else t)
+
+
+class QActToFloat(Function):
+    """QActTensor -> the float32 activation it stands for, WITH an autograd link (identity backward: the consumer's gradient is w.r.t. the
+    activation itself, so the producing block applies no quantizer STE)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        return a.materialize()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def qa_supported(shape, pool):
+    return len(shape) == 4 and bool(_lib_().mn_qa_supported(shape[2], shape[3], int(bool(pool))))
+
+
+class BNReLUQ(Function):
+    """relu(batch_norm(y)) [-> 2x2 max-pool] -> the k-bit activation quantizer of the NEXT QuantConv2d, fused (qact_kernels.hip).
+    y is a ``LazyQConvOut`` (the conv runs here, on codes: 16-bit stash + exact integer statistics; fp32 y never exists) or a plain fp32 tensor (the
+    block behind the un-quantised first conv).  Output: a ``QActTensor`` (codes of the ``out_bits`` quantizer; ``out_bits`` > 0) or the fp32 activation
+    (``out_bits`` == 0: the consumer is not a quantised conv of ours).  Backward: two streaming passes over (gradient, stash)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt, out_bits, pool):
+        gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
+        lib = _lib_()
+        lazy = isinstance(y, LazyQConvOut) and y._mn_value is None
+        if lazy:
+            r = y.recipe
+            g, codes_in, wq = r["geom"], r["codes"], r["wq"]
+            N, Cc, H, W = g.N, g.O, g.H, g.W
+            dev = codes_in.device
+            src = torch.empty((N, Cc, H, W), dtype=torch.int16, device=dev)
+            save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+            chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
+            wd = WQ(WQ_DOREFA, r["w_bits"], 0, 0, None)
+            with torch.cuda.device(dev):
+                nb = int(lib.mn_qconv_bnq_ws_bytes(C.byref(g)))
+                ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
+                _call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wd), _p(codes_in), r["a_bits"], _p(wq), _p(r["bias"]), _p(gamma), _p(beta), float(eps),
+                      float(momentum), int(training), _p(running_mean), _p(running_var), _p(nbt), _p(save), _p(src), _p(chan), _p(ws), nb, _s())
+            in_f32 = 0
+        else:
+            src = _chk(y, "input")
+            N, Cc, H, W = src.shape
+            dev = src.device
+            save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+            chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                ws = torch.empty(int(lib.mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=dev)
+                _call("mn_bn_save_stats", _p(src), N, Cc, H * W, float(eps), float(momentum), int(training), _p(running_mean), _p(running_var), _p(save), _p(ws), _s())
+                _call("mn_qa_chan_from_save", _p(save), _p(gamma), _p(beta), Cc, _p(chan), _s())
+            in_f32 = 1
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        qbits = out_bits if out_bits else 2          # the kernels want a valid width even when no code is produced
+        ctx.save_for_backward(src, chan, gamma, beta)
+        ctx.cfg = (in_f32, N, Cc, H, W, qbits, int(bool(pool)), int(training), bool(out_bits))
+
+        def materialize():
+            act = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _call("mn_qa_fwd", in_f32, _p(src), _p(chan), N, Cc, H, W, qbits, int(bool(pool)), None, _p(act), _s())
+            return act
+        if not out_bits:
+            return materialize()
+        codes = torch.empty((N, Cc, Ho, Wo), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _call("mn_qa_fwd", in_f32, _p(src), _p(chan), N, Cc, H, W, qbits, int(bool(pool)), _p(codes), None, _s())
+        out = QActTensor(codes, out_bits, materialize)
+        out._mn_pooled = bool(pool)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        src, chan, gamma, beta = ctx.saved_tensors
+        in_f32, N, Cc, H, W, qbits, pool, training, coded = ctx.cfg
+        if isinstance(g, QGrad) and g._mn_value is None and coded:
+            dq, quant = g._mn_dq, 1            # gradient w.r.t. the quantised activation: the clip-STE is applied by the kernels below
+        else:
+            dq, quant = _chk(g, "grad"), 0
+        dev = src.device
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = torch.empty(int(_lib_().mn_qa_ws_floats(Cc)), dtype=torch.float32, device=dev)
+            _call("mn_qa_bwd_sums", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+            _call("mn_qa_bwd_apply", in_f32, _p(src), _p(chan), _p(sums), _p(dq), N, Cc, H, W, qbits, pool, quant, training, _p(dy), _s())
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def channel_shuffle(x, groups):

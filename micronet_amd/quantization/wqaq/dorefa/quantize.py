@@ -10,6 +10,7 @@
 """
 import copy
 
+import torch
 import torch.nn as nn
 from torch.autograd import Function
 
@@ -88,13 +89,24 @@ class QuantConv2d(nn.Conv2d):
         self.quant_inference = quant_inference
         self.activation_quantizer = ActivationQuantizer(a_bits=a_bits)
         self.weight_quantizer = WeightQuantizer(w_bits=w_bits)
+        self.in_shuffle_groups = 0     # > 1: this conv reads channel_shuffle(input, groups) (set by prepare(fold_shuffle=True))
+        self.lazy_for_bn = False       # True (set by prepare(fuse_blocks=True)): a BatchNorm2dReLU of ours consumes the output -> it may stay un-computed
 
     def forward(self, input):
+        from micronet_amd.sign_tensor import QActTensor
         quant_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
         mode, bits = _aq_args(self.activation_quantizer)
+        if isinstance(input, QActTensor):
+            # the block in front already evaluated THIS conv's activation quantizer (codes, one byte per element)
+            w_bits = self.weight_quantizer.w_bits
+            if (self.lazy_for_bn and not self.quant_inference and input.bits == bits and mode == ops.ACTQ_DOREFA and
+                    ops.qconv_bnq_supported(input, quant_weight, self.stride, self.padding, self.dilation, self.groups, w_bits, self.in_shuffle_groups)):
+                return ops.QConvCodeLazy.apply(input, quant_weight, self.bias, self.stride, self.padding, self.dilation, self.groups, w_bits,
+                                               self.in_shuffle_groups or 0)
+            input = ops.QActToFloat.apply(input)       # anything else: the fp32 activation the reference holds here (one streaming kernel)
         # like the reference, the forward always zero-pads whatever padding_mode says (ref 113-121)
         return ops.qconv2d(input, quant_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
-                           aq_mode=mode, aq_bits=bits, wdesc=_wdesc(self))
+                           aq_mode=mode, aq_bits=bits, wdesc=_wdesc(self), in_shuffle=self.in_shuffle_groups)
 
 
 class QuantConvTranspose2d(nn.ConvTranspose2d):
@@ -142,12 +154,30 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
     separate ReLU forward / backward kernels.  Installed by ``prepare(fuse_bn_act=True)`` in front of a ReLU that the parent calls right
     after it; that ReLU becomes a ``ReLUAfterFusedBN`` (a no-op ``nn.ReLU``)."""
 
+    q_out_bits = 0          # > 0 (set by prepare(fuse_blocks=True)): the only consumer is the a-bit activation quantizer of the next QuantConv2d ->
+    q_pool = False          # emit its codes (QActTensor), through the 2x2 max-pool behind the block when q_pool
+
     def forward(self, input):
         from micronet_amd import ops
+        from micronet_amd.sign_tensor import LazyQConvOut
         import torch.nn.functional as F
-        if not (self.affine and ops.bnrelu_supported(input)):
-            return F.relu(super().forward(input))
+        lazy = isinstance(input, LazyQConvOut)
+        plain_ok = self.affine and ops.bnrelu_supported(input)
         use_batch = self.training or self.running_mean is None
+        stats_ok = self.momentum is not None and (use_batch or self.track_running_stats)
+        pool = bool(self.q_pool and self.q_out_bits)
+        if (lazy or (plain_ok and self.q_out_bits)) and self.affine and stats_ok and ops.qa_supported(input.shape, pool):
+            nbt = None
+            if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+                if lazy and self.num_batches_tracked.is_cuda and self.num_batches_tracked.dtype == torch.int64:
+                    nbt = self.num_batches_tracked           # incremented by the launch that forms the statistics
+                else:
+                    self.num_batches_tracked.add_(1)
+            return ops.BNReLUQ.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                     self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, nbt,
+                                     int(self.q_out_bits), pool)
+        if not plain_ok:
+            return F.relu(super().forward(input))
         momentum = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
@@ -162,6 +192,9 @@ class MaxPool2dF32(nn.MaxPool2d):
 
     def forward(self, input):
         from micronet_amd import ops
+        from micronet_amd.sign_tensor import QActTensor
+        if isinstance(input, QActTensor) and getattr(input, "_mn_pooled", False) and getattr(self, "_mn_fused_pool", False):
+            return input          # the fused block in front already pooled (max of the activation = max of its codes: the quantizer is monotone)
         if not self.return_indices and ops.f32_pool_supported(input, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode):
             return ops.MaxPool2x2F32.apply(input)
         return super().forward(input)
@@ -178,6 +211,43 @@ class ReLUAfterFusedBN(nn.ReLU):
 def _ordered_parent(module):
     """True when the parent calls its children in definition order, so bn -> relu adjacency means bn feeds relu."""
     return isinstance(module, nn.Sequential) or type(module).__name__ == "ConvBNReLU"
+
+
+def _fuse_blocks(model, fold_shuffle=True):
+    """Second pass of ``prepare(fuse_blocks=True)``: wherever a ``ConvBNReLU`` block's output feeds ONLY the activation quantizer of the next block's
+    QuantConv2d (directly, or through a 2x2 / stride-2 max-pool) inside an ``nn.Sequential``, the producing BatchNorm2dReLU emits that quantizer's
+    codes (``q_out_bits`` / ``q_pool``), and every QuantConv2d followed by a BatchNorm2dReLU in its block may leave its output un-computed
+    (``lazy_for_bn``); the block's channel shuffle moves into the conv's addressing (``in_shuffle_groups``)."""
+    def is_block(m):
+        return type(m).__name__ == "ConvBNReLU" and isinstance(getattr(m, "bn", None), BatchNorm2dReLU) and isinstance(getattr(m, "conv", None), nn.Conv2d)
+
+    def two(v):
+        return v in (2, (2, 2), [2, 2])
+    for parent in model.modules():
+        if not isinstance(parent, nn.Sequential):
+            continue
+        kids = list(parent.children())
+        for i, blk in enumerate(kids):
+            if not is_block(blk):
+                continue
+            if isinstance(blk.conv, QuantConv2d):
+                blk.conv.lazy_for_bn = True
+                if fold_shuffle and getattr(blk, "channel_shuffle_flag", 0) and getattr(blk, "shuffle_groups", 1) > 1 and \
+                        blk.conv.in_channels % blk.shuffle_groups == 0:
+                    blk.conv.in_shuffle_groups = int(blk.shuffle_groups)
+                    blk.channel_shuffle_flag = 0
+            nxt = kids[i + 1] if i + 1 < len(kids) else None
+            pool = None
+            if isinstance(nxt, MaxPool2dF32) and two(nxt.kernel_size) and two(nxt.stride) and nxt.padding in (0, (0, 0)) and nxt.dilation in (1, (1, 1)) \
+                    and not nxt.ceil_mode and not nxt.return_indices:
+                pool, nxt = nxt, (kids[i + 2] if i + 2 < len(kids) else None)
+            if nxt is not None and is_block(nxt) and isinstance(nxt.conv, QuantConv2d) and not nxt.conv.quant_inference:
+                bits = nxt.conv.activation_quantizer.a_bits
+                if 2 <= bits <= 7 and 2 <= nxt.conv.weight_quantizer.w_bits <= 8:
+                    blk.bn.q_out_bits = int(bits)
+                    blk.bn.q_pool = pool is not None
+                    if pool is not None:
+                        pool._mn_fused_pool = True
 
 
 def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=False, fuse_bn_act=True):
@@ -225,11 +295,15 @@ def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=Fals
             add_quant_op(child, layer_counter, fuse_bn_act=fuse_bn_act, **kw)
 
 
-def prepare(model, inplace=False, a_bits=8, w_bits=8, quant_inference=False, fuse_bn_act=True):
+def prepare(model, inplace=False, a_bits=8, w_bits=8, quant_inference=False, fuse_bn_act=True, fuse_blocks=True, fold_shuffle=True):
     """Same rewrite as the reference (ref 312-320).  ``fuse_bn_act`` (ours, default on): a ``BatchNorm2d`` directly in front of a ``ReLU`` in a
     block that calls them in that order becomes ``BatchNorm2dReLU`` (one fused op) and the ReLU a no-op subclass; with it off the module
-    graph is exactly the reference's."""
+    graph is exactly the reference's.  ``fuse_blocks`` (ours, default on, needs ``fuse_bn_act``): conv + BatchNorm + ReLU (+ 2x2 max-pool) + the next
+    layer's activation quantizer run as the fused k-bit block of ``_fuse_blocks`` -- activations travel as one-byte codes, the conv output as a
+    16-bit integer stash; numerically the same function (tests compare with it off).  ``fold_shuffle``: see ``_fuse_blocks``."""
     if not inplace:
         model = copy.deepcopy(model)
     add_quant_op(model, [0], a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act)
+    if fuse_bn_act and fuse_blocks and not quant_inference:
+        _fuse_blocks(model, fold_shuffle=fold_shuffle)
     return model

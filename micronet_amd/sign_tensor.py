@@ -178,3 +178,134 @@ class LazyBNGrad(torch.Tensor):
             return r
         un = lambda t: t.materialize() if isinstance(t, (LazyBNGrad, LazyPoolGrad, LazyConvOut)) else (t._mn_codes.to(torch.float32) if isinstance(t, SignTensor) else t)
         return func(*tree_map(un, args), **tree_map(un, kwargs))
+
+
+class QActTensor(torch.Tensor):
+    """The output of a k-bit (DoReFa) block -- relu(bn(conv(x))), possibly max-pooled -- whose only consumer is the activation quantizer of the
+    next QuantConv2d: logically the float32 activation a (shape / dtype / device / autograd behave as such), physically the CODES j of that
+    quantizer (uint8, one byte per element: what the next conv's kernels read) plus a recipe that re-creates a exactly from the producer's 16-bit
+    stash when anybody else asks (``materialize``: one streaming kernel).  Any torch operator outside this package goes through
+    ``__torch_dispatch__`` and sees the float32 activation the reference holds at this point."""
+
+    @staticmethod
+    def __new__(cls, codes, bits, materialize):
+        if codes.dtype != torch.uint8 or not codes.is_contiguous():
+            raise TypeError("QActTensor wraps a contiguous uint8 tensor of activation codes")
+        r = torch.Tensor._make_wrapper_subclass(cls, codes.shape, dtype=torch.float32, device=codes.device, requires_grad=False)
+        r._mn_codes, r._mn_bits, r._mn_mat, r._mn_value = codes, int(bits), materialize, None
+        return r
+
+    def __init__(self, codes, bits, materialize):
+        pass
+
+    @property
+    def codes(self):
+        return self._mn_codes
+
+    @property
+    def bits(self):
+        return self._mn_bits
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_mat()
+        return self._mn_value
+
+    def __repr__(self):
+        return "QActTensor(shape=%s, bits=%d, device=%s)" % (tuple(self.shape), self._mn_bits, self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], QActTensor):
+            a = args[0]
+            r = QActTensor(a._mn_codes, a._mn_bits, a._mn_mat)
+            r._mn_value = a._mn_value
+            return r
+        return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
+
+
+class QGrad(torch.Tensor):
+    """d loss / d (QUANTISED activation) handed back by a conv that read a ``QActTensor``'s codes: logically the gradient w.r.t. the activation itself
+    (i.e. after the quantizer's clip-STE, wqaq/dorefa/quantize.py:36-46), physically the raw gradient dq -- the producing block applies the STE inside
+    its streaming backward kernels, where it recomputes the activation anyway.  Any other consumer (e.g. autograd adding a second gradient)
+    materialises STE(dq) first."""
+
+    @staticmethod
+    def __new__(cls, dq, expand):
+        r = torch.Tensor._make_wrapper_subclass(cls, dq.shape, dtype=torch.float32, device=dq.device, requires_grad=False)
+        r._mn_dq, r._mn_expand, r._mn_value = dq, expand, None
+        return r
+
+    def __init__(self, dq, expand):
+        pass
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_expand(self._mn_dq)
+        return self._mn_value
+
+    def __repr__(self):
+        return "QGrad(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], QGrad):
+            a = args[0]
+            r = QGrad(a._mn_dq, a._mn_expand)
+            r._mn_value = a._mn_value
+            return r
+        return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
+
+
+class LazyQConvOut(torch.Tensor):
+    """The output of a DoReFa QuantConv2d on a ``QActTensor`` that has NOT been computed (the k-bit analogue of ``LazyConvOut``): the fused
+    BatchNorm+ReLU+quantizer behind it consumes the recipe (input codes, fake-quantised weights, bias, geometry) and never needs fp32 y.  Any other
+    consumer gets the convolution computed by the ordinary kernels on the materialised activation."""
+
+    @staticmethod
+    def __new__(cls, shape, device, recipe):
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=torch.float32, device=device, requires_grad=False)
+        r._mn_recipe, r._mn_value = recipe, None
+        return r
+
+    def __init__(self, shape, device, recipe):
+        pass
+
+    @property
+    def recipe(self):
+        return self._mn_recipe
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_recipe["compute"]()
+        return self._mn_value
+
+    def __repr__(self):
+        return "LazyQConvOut(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], LazyQConvOut):
+            a = args[0]
+            r = LazyQConvOut(a.shape, a.device, a._mn_recipe)
+            r._mn_value = a._mn_value
+            return r
+        return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
+
+
+def _unwrap_any(t):
+    """The plain tensor a foreign operator should see for any wrapper of this module."""
+    if isinstance(t, (QActTensor, QGrad, LazyQConvOut, LazyBNGrad, LazyPoolGrad, LazyConvOut)):
+        return t.materialize()
+    if isinstance(t, SignTensor):
+        return t._mn_codes.to(torch.float32)
+    return t
