@@ -589,3 +589,50 @@ def test_dorefa_fused_bn_relu_matches_unfused():
     a.eval(), b.eval()
     with torch.no_grad():
         assert rel_err(a(x).cpu(), b(x).cpu()) <= 2e-5
+
+
+@pytest.mark.parametrize("bits,arch", [(2, "nin_gc"), (4, "nin_gc"), (3, "nin_gc"), (2, "nin")])
+def test_dorefa_fused_blocks_match_unfused(bits, arch):
+    """prepare(fuse_blocks=True) (activation codes in one byte, 16-bit integer conv stash, BatchNorm + ReLU + max-pool + next-layer quantizer in streaming
+    kernels, shuffle folded) is numerically the SAME function as the unfused module graph: identical logits, gradients to float round-off, identical
+    BatchNorm buffers -- in training and in eval mode, and under torch.no_grad()."""
+    from micronet_amd.sign_tensor import QActTensor
+    from micronet_amd.train import build_model, synth_batch
+    Q = _q("wqaq.dorefa")
+    x, y = synth_batch(16, device="cuda")
+    a = Q.prepare(build_model(arch), inplace=True, a_bits=bits, w_bits=bits).cuda().train()
+    b = Q.prepare(build_model(arch), inplace=True, a_bits=bits, w_bits=bits, fuse_blocks=False).cuda().train()
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    kinds = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: kinds.append(type(o).__name__)) for m in a.model]
+    oa, ob = a(x), b(x)
+    for h in hooks:
+        h.remove()
+    if arch == "nin_gc":
+        assert kinds.count("QActTensor") >= 8, kinds          # the blocks really run fused
+    assert float((oa - ob).abs().max()) <= 1e-6 * float(ob.abs().max()), "logits"
+    torch.nn.functional.cross_entropy(oa, y).backward()
+    torch.nn.functional.cross_entropy(ob, y).backward()
+    gmax = max(float(p.grad.abs().max()) for p in b.parameters())
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if n.endswith("conv.bias") and float(pb.grad.abs().max()) < 1e-4 * gmax:
+            continue                                          # a conv bias in front of a BatchNorm: the true gradient is 0, both sides hold round-off
+        e = float((pa.grad - pb.grad).abs().max() / pb.grad.abs().max().clamp_min(1e-30))
+        assert e <= 2e-5, (n, e)
+    for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        if ba.dtype.is_floating_point:
+            assert float((ba - bb).abs().max()) <= 2e-6 * float(bb.abs().max().clamp_min(1e-6)), n
+        else:
+            assert torch.equal(ba, bb), n
+    b.load_state_dict(a.state_dict())
+    a.eval(), b.eval()
+    with torch.no_grad():
+        ea, eb = a(x), b(x)
+    assert float((ea - eb).abs().max()) <= 1e-6 * float(eb.abs().max())
+    # a foreign consumer of a block's output sees the fp32 activation of the reference (hooks, feature taps)
+    a.train()
+    feats = []
+    h = a.model[1].register_forward_hook(lambda mod, i, o: feats.append(o.float().mean().item() if isinstance(o, QActTensor) else None))
+    a(x)
+    h.remove()
+    assert feats and feats[0] is not None and feats[0] >= 0

@@ -70,6 +70,25 @@ class _FloatToSign(torch.autograd.Function):
         return ops._chk(g, "grad")          # materialises a lazy gradient
 
 
+class _FloatToQAct(torch.autograd.Function):
+    """fp32 activation leaf -> QActTensor (the codes of the consuming conv's DoReFa quantizer, what the previous fused block hands over);
+    backward: the gradient w.r.t. the activation (a QGrad is materialised: the quantizer's clip-STE applied to it)."""
+
+    @staticmethod
+    def forward(ctx, x, bits):
+        from micronet_amd.sign_tensor import QActTensor
+        s = torch.tensor(1.0 / (2 ** bits - 1), dtype=torch.float32, device=x.device)
+        v = torch.clamp(x * 0.1, 0, 1) / s                         # wqaq/dorefa/quantize.py:43-45, every op IEEE-exact
+        j = torch.sign(v) * torch.floor(torch.abs(v) + 0.5)
+        xd = x.detach()
+        return QActTensor(j.to(torch.uint8).contiguous(), bits, lambda: xd)
+
+    @staticmethod
+    def backward(ctx, g):
+        from micronet_amd import ops
+        return ops._chk(g, "grad"), None
+
+
 def _oracle_pass(arch, scheme, kw):
     """One full-batch forward + backward of the CPU oracle; per top-level stage: in, out, gout, gin, param grads, BN outputs."""
     from oracle import torch_oracle as TO
@@ -108,20 +127,42 @@ def _oracle_pass(arch, scheme, kw):
 TIE_EPS = 4e-6
 
 
-def _untie(pristine_stage, r, gout):
-    """Single ReLU-type block: zero the teacher-forced incoming gradient where the oracle's own pre-activation is within TIE_EPS of the
-    kink (z = 0; for a binary activation also |z| = 1), and re-run the oracle stage with it.  At such an element the mask [z > 0] is
-    decided by the last bit of the conv / BatchNorm sums -- on either side -- and one flipped mask moves dx by a whole term; with a zero
-    incoming gradient there the decision cannot matter, everywhere else it is unambiguous.  Returns (gout', gin', pgrad')."""
-    z = r["z"]
-    tie = (z.abs() <= TIE_EPS) | ((z.abs() - 1.0).abs() <= TIE_EPS)
-    if tie.shape != gout.shape or not bool(tie.any()):
-        return gout, r.get("gin"), r["pgrad"], 0
-    g2 = gout * (~tie)
-    st = copy.deepcopy(pristine_stage).train()
-    xi = r["in"].clone().requires_grad_(r.get("gin") is not None)
+def _untie(stages, r_in, rec_first, gout):
+    """Zero the teacher-forced incoming gradient where the oracle's own decisions are ties, and re-run the oracle stages with it.
+      * activation kink: the block's pre-activation z within TIE_EPS of 0 (for a binary activation also |z| within TIE_EPS of 1): the mask
+        [z > 0] is decided by the last bit of the conv / BatchNorm sums -- on either side -- and one flipped mask moves dx by a whole term;
+      * max-pool behind the block (two-stage segment): a window whose two largest inputs differ by <= TIE_EPS (relative).  A low-bit conv output
+        takes few distinct values, so mathematically EQUAL maxima are common; the reference breaks such ties by the rounding noise of its fp32
+        convolution (its dequantised levels are not exact multiples of one step), which no other summation order reproduces.
+    With a zero incoming gradient at those positions the decision cannot matter; everywhere else it is unambiguous.
+    Returns (gout', gin', {stage index in segment: pgrad'}, number of masked output positions)."""
+    z = rec_first.get("z")
+    keep = torch.ones_like(gout, dtype=torch.bool)
+    if len(stages) == 1:
+        if z is not None and z.shape == gout.shape:
+            keep &= ~((z.abs() <= TIE_EPS) | ((z.abs() - 1.0).abs() <= TIE_EPS))
+    else:
+        a = rec_first["out"]                                   # the pool's input
+        if a.dim() == 4 and a.shape[2] == 2 * gout.shape[2]:
+            N_, C_, H_, W_ = a.shape
+            win = a.reshape(N_, C_, H_ // 2, 2, W_ // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N_, C_, H_ // 2, W_ // 2, 4)
+            top2 = win.topk(2, dim=-1).values
+            tie_w = (top2[..., 0] - top2[..., 1]) <= TIE_EPS * top2[..., 0].abs().clamp_min(1.0)
+            keep &= ~tie_w
+            if z is not None and z.shape == a.shape:
+                kink = (z.abs() <= TIE_EPS).float()
+                keep &= ~(torch.nn.functional.max_pool2d(kink, 2, 2) > 0)
+    nmask = int((~keep).sum())
+    if nmask == 0:
+        return gout, r_in.get("gin"), None, 0
+    g2 = gout * keep
+    st = torch.nn.Sequential(*[copy.deepcopy(m) for m in stages]).train()
+    xi = r_in["in"].clone().requires_grad_(r_in.get("gin") is not None)
     st(xi).backward(g2)
-    return g2, (xi.grad if xi.grad is not None else None), {pn: p.grad.detach().clone() for pn, p in st.named_parameters() if p.grad is not None}, int(tie.sum())
+    pg = {}
+    for j, m in enumerate(st):
+        pg[j] = {pn: p.grad.detach().clone() for pn, p in m.named_parameters() if p.grad is not None}
+    return g2, (xi.grad if xi.grad is not None else None), pg, nmask
 
 
 def _fp64_stage_grads(pristine_stage, x_in, gout):
@@ -144,13 +185,11 @@ def test_full_batch_teacher_forced(key):
     pstages, ostages, prist = list(prod.model.children()), list(orc.model.children()), list(pristine.model.children())
     binary = scheme == "wbwtab"
     report, worst, failures = {}, 0.0, []
-    # Which stages are teacher-forced together.  wbwtab: a block and the max-pool behind it (the pool hands its gradient to the block
-    # un-expanded; +-1 activations have no near-ties: the pool's first-maximum rule is decided identically on both sides).  DoReFa / IAO:
-    # every stage alone.  A low-bit conv output takes few distinct values, so a 2x2 window holds many mathematically EQUAL maxima; the
-    # reference breaks such ties by the rounding noise of its fp32 convolution (its dequantised levels are not exact multiples of one
-    # step), which no other summation order reproduces -- so the argmax, and with it every gradient behind the pool, is only defined up
-    # to that tie-break.  Teacher-forcing the pool on its own (oracle input in, bit-exact first-maximum rule) keeps the statement exact.
-    segments = SEGMENTS_FUSED_POOL if binary else SEGMENTS_SINGLE
+    # Which stages are teacher-forced together: a block and the max-pool behind it wherever the product executes them as one fused unit (wbwtab:
+    # the pool hands its gradient to the block un-expanded; DoReFa fused blocks: the block emits pooled activation codes); every stage alone
+    # otherwise.  Decisions that are ties in the ORACLE (activation kinks, equal maxima in a pooling window) are taken out by _untie.
+    fused_pool = binary or any(getattr(getattr(m, "bn", None), "q_pool", False) for m in pstages)      # the product pools inside the block in front
+    segments = SEGMENTS_FUSED_POOL if fused_pool else SEGMENTS_SINGLE
     for seg in segments:
         first, last = str(seg[0]), str(seg[-1])
         r_in, r_out = rec[first], rec[last]
@@ -162,7 +201,20 @@ def test_full_batch_teacher_forced(key):
         else:
             leaf = xin.clone().requires_grad_(True)
             is_pm1 = binary and bool(((xin == 1) | (xin == -1)).all())
-            inp = _FloatToSign.apply(leaf) if is_pm1 else leaf
+            conv0 = getattr(pstages[seg[0]], "conv", None)
+            prod_bn = None                                  # the BatchNorm2dReLU of the product stage that produces this segment's input
+            for k_ in range(seg[0] - 1, -1, -1):
+                if getattr(pstages[k_], "bn", None) is not None:
+                    prod_bn = pstages[k_].bn
+                    break
+            coded = (conv0 is not None and getattr(conv0, "lazy_for_bn", False) and prod_bn is not None and getattr(prod_bn, "q_out_bits", 0) > 0
+                     and hasattr(conv0, "activation_quantizer"))
+            if is_pm1:
+                inp = _FloatToSign.apply(leaf)
+            elif coded:
+                inp = _FloatToQAct.apply(leaf, int(prod_bn.q_out_bits))
+            else:
+                inp = leaf
         for i in seg:
             for p in pstages[i].parameters():
                 p.grad = None
@@ -187,18 +239,29 @@ def test_full_batch_teacher_forced(key):
                 if not bool(tie[bad].all()):
                     failures.append((seg, "sign flips away from BatchNorm ties", nbad))
         else:
-            errs["y"] = _rel(out, ref_out)
+            errs["y"] = _rel(out, ref_out)             # a QActTensor materialises as the fp32 activation it stands for
+            if hasattr(out, "codes") and hasattr(out, "bits"):
+                # the codes of the next layer's quantizer vs the oracle's own quantizer on its own activation (wqaq/dorefa/quantize.py:43-45)
+                from oracle import np_oracle as NO
+                _, cref = NO.dorefa_act_fwd(ref_out.numpy(), out.bits)
+                nflip = int((out.codes.cpu().numpy().astype("float32") != cref).sum())
+                errs["codes_flipped_frac"] = nflip / max(1, cref.size)
+                if errs["codes_flipped_frac"] > 1e-5:
+                    failures.append((seg, "activation codes differ from the oracle's quantizer beyond rounding ties", errs["codes_flipped_frac"]))
         # ---- backward with the oracle's incoming gradient (zeroed at the oracle's activation ties: _untie)
         gout_cpu, gin_ref, pgrad_ref = r_out["gout"], r_in.get("gin"), {str(i): rec[str(i)]["pgrad"] for i in seg}
-        if len(seg) == 1 and "z" in r_in:
-            gout_cpu, gin_ref, pg, nt = _untie(prist[seg[0]], r_in, gout_cpu)
-            pgrad_ref[first] = pg
-            errs["activation_ties_masked"] = nt
+        if not (binary and len(seg) == 2):        # (+-1 activations have no near-ties in a pooling window: the wbwtab pooled segments stay as they are)
+            gout_cpu, gin_ref, pg, nt = _untie([prist[i] for i in seg], r_in, rec[first], gout_cpu)
+            if pg is not None:
+                for j, i in enumerate(seg):
+                    pgrad_ref[str(i)] = pg[j]
+            errs["ties_masked"] = nt
+            errs["ties_masked_frac"] = nt / max(1, gout_cpu.numel())
         gout = gout_cpu.cuda()
         torch.autograd.backward([out], [gout])
         if leaf is not None and gin_ref is not None:
             errs["dx"] = _rel(leaf.grad, gin_ref)
-        need64 = {}
+        need64, argmax64 = {}, {}
         for i in seg:
             pn = dict(pstages[i].named_parameters())
             for name, g_ref in pgrad_ref[str(i)].items():
@@ -209,12 +272,27 @@ def test_full_batch_teacher_forced(key):
                     # d bias of a conv in front of a BatchNorm is mathematically 0: compare on the scale of sum |gout|
                     continue
                 e = _rel(g, g_ref)
+                if "dorefa" in scheme and name.endswith("conv.weight") and hasattr(pstages[i].conv, "weight_quantizer"):
+                    # DoReFa's weight quantizer normalises by M = max |tanh w| over the whole tensor (wqaq/dorefa/quantize.py:68-72): the ONE element
+                    # that holds the maximum receives -sum(du * t / 2) / M^2 on top of its own term -- a sum over every weight that cancels to a
+                    # small remainder (condition number ~1e2-1e3), so fp32 round-off of d(quantised weight) at the 1e-7 level shows up there at
+                    # 1e-5..1e-3 in the REFERENCE's fp32 result and at up to 1.3e-4 in ours (the sum itself is accumulated in fp64 here, but its terms
+                    # inherit the 1e-7 round-off of dy).  That single element is judged against the fp64 evaluation of the oracle (within 2e-4, or as
+                    # close to it as the reference is) and all three distances are recorded; every other element against the reference at 1e-5.
+                    wabs = pn[name].detach().abs().flatten()
+                    k_arg = int(wabs.argmax())
+                    dflat = (g.detach().double().cpu().flatten() - g_ref.double().flatten()).abs() / g_ref.double().abs().max().clamp_min(1e-30)
+                    errs["d" + name + "_argmax_element_vs_reference_fp32"] = float(dflat[k_arg])
+                    if float(dflat[k_arg]) > 1e-5:
+                        argmax64[(i, name)] = (g, g_ref, k_arg)
+                    dflat[k_arg] = 0.0
+                    e = float(dflat.max())
                 errs["d" + name] = e
                 if e > 1e-5:
                     errs["d" + name + "_vs_reference_fp32"] = e
                     need64[(i, name)] = (g, g_ref)
         slack = {}
-        if need64:
+        if need64 or argmax64:
             # cancelling sums: measure both sides against the fp64 evaluation of the same oracle stages
             st64 = torch.nn.Sequential(*[prist[i] for i in seg])
             _, p64 = _fp64_stage_grads(st64, r_in["in"], gout_cpu)
@@ -226,9 +304,20 @@ def test_full_batch_teacher_forced(key):
                 errs["d" + name] = e_ours
                 errs["d" + name + "_reference_fp32_vs_fp64"] = e_ref
                 slack["d" + name] = 2.0 * e_ref
+            for (i, name), (g, g_ref, k_arg) in argmax64.items():
+                g64 = p64["%d.%s" % (seg.index(i), name)]
+                sc = g64.abs().max().clamp_min(1e-300)
+                e_ours = float((g.double().cpu().flatten()[k_arg] - g64.flatten()[k_arg]).abs() / sc)
+                e_ref = float((g_ref.double().flatten()[k_arg] - g64.flatten()[k_arg]).abs() / sc)
+                errs["d" + name + "_argmax_element"] = e_ours
+                errs["d" + name + "_argmax_element_reference_fp32_vs_fp64"] = e_ref
+                # measured over the four configurations: 4e-5 .. 1.3e-4 for ours and 9e-7 .. 1.05e-3 for the reference, both against fp64 (which one
+                # is closer varies from layer to layer: the element is ill-conditioned for everybody)
+                if e_ours > max(2e-4, 2.0 * e_ref):
+                    failures.append((seg, "d" + name + " at the arg-max element vs fp64", e_ours, e_ref))
         report["+".join(type(pstages[i]).__name__ + str(i) for i in seg)] = {k: float("%.2e" % v) for k, v in errs.items()}
         for k_, v in errs.items():
-            if k_ in ("sign_mismatch", "activation_ties_masked") or k_.endswith("_vs_fp64") or k_.endswith("_vs_reference_fp32"):
+            if k_ in ("sign_mismatch", "ties_masked", "ties_masked_frac", "codes_flipped_frac") or "_argmax_element" in k_ or k_.endswith("_vs_fp64") or k_.endswith("_vs_reference_fp32"):
                 continue
             lim = max(1e-5, slack.get(k_, 0.0))
             worst = max(worst, v)
