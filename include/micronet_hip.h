@@ -379,6 +379,14 @@ int mn_signconv1x1_small_supported(int64_t C, int64_t HW, int64_t O);
 int mn_signconv1x1_small_fwd(const int8_t* a, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream);
 int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float* dx, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream);
 
+/* ------------------------------------------------------------------ input pipeline of the training loop
+ * <scheme>/main.py:203-210: transforms.Compose([RandomCrop(32, padding=4), RandomHorizontalFlip(), ToTensor(), Normalize(mean, std)]) applied to a batch
+ * gathered from the uint8 dataset resident in device memory.  images: uint8 [n_images][H][W][C] (HWC, torchvision's CIFAR10.data); index [B]: the
+ * sample of each output image; ox / oy [B]: crop offsets in [0, 2 * pad]; flip [B]: 0 / 1; mean / std: HOST arrays of C floats;
+ * out: fp32 [B][C][H][W] = ((pixel / 255) - mean[c]) / std[c] with pixel = 0 in the padding -- bit-identical to the CPU transforms for the same draws. */
+int mn_cifar_augment(const uint8_t* images, int64_t n_images, const int32_t* index, const int32_t* ox, const int32_t* oy, const uint8_t* flip, int64_t B,
+                     int64_t H, int64_t W, int64_t C, int pad, const float* mean, const float* std, float* out, mn_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer step of the training loop
  * <scheme>/main.py: optimizer.step() with torch.optim.Adam, one parameter group per tensor (wqaq/dorefa/main.py:308-315).
  * One launch per MN_ADAM_MAX_TENSORS tensors; `tensors` is a HOST array (device pointers inside), copied into the kernel

@@ -394,3 +394,24 @@ def bn_batch_stats(o):
     mean = o64.mean(axis=(0, 2, 3))
     var = o64.var(axis=(0, 2, 3), ddof=1) if n > 1 else np.full_like(mean, np.nan)
     return mean, var
+
+
+# ---------------------------------------------------------------------------- input pipeline
+def cifar_augment(images_u8, index, ox, oy, flip, pad=4, mean=(0.4914, 0.4822, 0.4465), std=(0.2023, 0.1994, 0.2010)):
+    """wqaq/dorefa/main.py:203-210 restated for given random draws: RandomCrop(H, padding=pad) = zero-pad the uint8 HWC image by `pad`, take the H x W
+    window at (oy, ox); RandomHorizontalFlip = reverse the columns when flip; ToTensor = CHW, float32(pixel).div(255); Normalize = sub(mean).div(std)
+    (float32 tensors).  torchvision is not installed in the build container, so this follows its documented semantics (functional.pad fill=0,
+    functional.crop, functional.hflip, to_tensor, normalize)."""
+    images_u8 = np.asarray(images_u8, dtype=np.uint8)
+    n, H, W, C_ = images_u8.shape
+    out = np.empty((len(index), C_, H, W), dtype=F32)
+    m, s = np.asarray(mean, dtype=F32).reshape(-1, 1, 1), np.asarray(std, dtype=F32).reshape(-1, 1, 1)
+    for b, i in enumerate(index):
+        padded = np.zeros((H + 2 * pad, W + 2 * pad, C_), dtype=np.uint8)
+        padded[pad:pad + H, pad:pad + W] = images_u8[i]
+        crop = padded[oy[b]:oy[b] + H, ox[b]:ox[b] + W]
+        if flip[b]:
+            crop = crop[:, ::-1]
+        t = (crop.transpose(2, 0, 1).astype(F32) / F32(255)).astype(F32)
+        out[b] = ((t - m) / s).astype(F32)
+    return out

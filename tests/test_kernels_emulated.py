@@ -1,6 +1,7 @@
 """The HIP kernel sources, compiled for the CPU SIMT emulator (tests/emu), driven through the real C ABI and checked
 against the oracle + golden fixtures.  This validates index math / tiling / MFMA fragment maps without a GPU; the same
 checks run on the MI355X in tests/test_gpu_kernels.py."""
+import numpy as np
 import pytest
 
 import abi_driver
@@ -286,3 +287,20 @@ def test_pool_f32(be):
 def test_qconv_bnq_block(be, case):
     """k-bit (DoReFa) conv + BatchNorm + ReLU + next-layer quantizer on activation codes: 16-bit stash, streaming forward / backward, conv backward."""
     K.check_qconv_bnq(be, seed=300 + case, **K.BNQ_CASES[case])
+
+
+def test_cifar_augment_kernel_vs_oracle(be):
+    """mn_cifar_augment (RandomCrop(32, 4) + HFlip + ToTensor + Normalize for given draws) == the numpy restatement of wqaq/dorefa/main.py:203-210, bit for bit."""
+    import ctypes as C
+    from oracle import np_oracle as O
+    r = np.random.default_rng(0)
+    imgs = r.integers(0, 256, size=(10, 32, 32, 3), dtype=np.uint8)
+    B = 9
+    idx, ox, oy = r.integers(0, 10, size=B).astype(np.int32), r.integers(0, 9, size=B).astype(np.int32), r.integers(0, 9, size=B).astype(np.int32)
+    ox[:4], oy[:4] = [0, 8, 0, 8], [0, 0, 8, 8]
+    flip = (r.random(B) < 0.5).astype(np.uint8)
+    out = np.zeros((B, 3, 32, 32), dtype=np.float32)
+    FA = C.c_float * 3
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    be.call("mn_cifar_augment", p(imgs), 10, p(idx), p(ox), p(oy), p(flip), B, 32, 32, 3, 4, FA(0.4914, 0.4822, 0.4465), FA(0.2023, 0.1994, 0.2010), p(out), None)
+    assert np.array_equal(out, O.cifar_augment(imgs, idx, ox, oy, flip))
