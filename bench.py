@@ -120,6 +120,8 @@ def measure(workload, args, world, rank, device):
     from micronet_amd.train import GraphedTrainStep, synth_batch
     model, opt = build(workload, device)
     dp.broadcast_parameters(model)
+    if world > 1:
+        dp.sync_observers(model)          # IAO activation / QuantAdd ranges over the global batch (SURVEY 8e ii); no-op for DoReFa / wbwtab
     x, y = synth_batch(args.batch, seed=1234 + rank, device=device)
 
     def barrier():
@@ -139,6 +141,8 @@ def measure(workload, args, world, rank, device):
             graphed = None
             model, opt = build(workload, device)
             dp.broadcast_parameters(model)
+            if world > 1:
+                dp.sync_observers(model)
     if graphed is None:
         sync = dp.GradSync(model)
 

@@ -9,8 +9,15 @@ last gradient is accumulated, overlapping the rest of backward; ``wait()`` befor
 ``p.grad`` at its slice of the reduced bucket (no copy back).  nin_gc (2.37 MB of gradients) is one latency-bound
 collective; resnet18 (44.7 MB) splits into two.
 
-Batch statistics (BatchNorm, the BN-fuse conv, IAO activation observers) stay per-rank, which is what ``nn.BatchNorm2d``
-does under DP/DDP as well; weight quantizers are rank-invariant because the weights are.
+Cross-rank statistics: the parity target of data-parallel QAT is the single-process reference on the concatenated global batch.
+  * gradients: mean all-reduce == full-batch gradient (mean-reduced loss, equal shards);
+  * IAO activation / ``QuantAdd`` observers (level 'L'): ``sync_observers(model)`` makes every such observer all-reduce the CURRENT batch's
+    (min, max) over the ranks (one 2-float MAX collective on [-min, max]) BEFORE its running-extreme / moving-average update and the
+    ``update_qparams`` behind it (wqaq/iao/quantize.py:214-240, 1484-1498), so every rank quantises with the global-batch range -- exactly what the
+    single process sees, since min / max over a batch decompose over shards.  One tiny collective per activation quantizer per forward: each range
+    is needed before the next layer can run, so they cannot be packed;
+  * BatchNorm / BN-fuse batch mean and variance: per-rank (what ``nn.BatchNorm2d`` does under DP / DDP);
+  * weight observers and the DoReFa / wbwtab weight quantizers: rank-invariant (same weights everywhere).
 """
 import torch
 import torch.distributed as dist
@@ -94,3 +101,27 @@ def train_step_dp(model, optimizer, sync, data, target):
     sync.wait()
     optimizer.step()
     return loss, output
+
+
+def allreduce_minmax(min_t, max_t, group=None):
+    """In place: min_t <- min over ranks, max_t <- max over ranks (tensors of equal shape, any device the backend supports) with ONE collective:
+    MAX over the stacked [-min, max]."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    buf = torch.stack([-min_t.reshape(-1), max_t.reshape(-1)])
+    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+    min_t.copy_((-buf[0]).view_as(min_t))
+    max_t.copy_(buf[1].view_as(max_t))
+
+
+def sync_observers(model, group=None, enable=True):
+    """Switch the cross-rank range reduction of every level-'L' min/max observer of ``model`` on (IAO activation quantizers, QuantAdd); returns
+    how many observers were switched.  No-op for models without such observers (DoReFa, wbwtab)."""
+    n = 0
+    for m in model.modules():
+        if hasattr(m, "update_range") or type(m).__name__ in ("MinMaxObserver", "MovingAverageMinMaxObserver"):
+            if getattr(m, "q_level", None) == "L" and hasattr(m, "min_val") and hasattr(m, "max_val") and type(m).__name__ != "HistogramObserver":
+                m._mn_sync_group = group if enable else None
+                m._mn_sync = bool(enable)
+                n += 1
+    return n

@@ -46,11 +46,23 @@ class ObserverBase(nn.Module):
     def update_range(self, min_val, max_val):
         raise NotImplementedError
 
+    _mn_sync = False          # micronet_amd.dp.sync_observers(): reduce the current batch's range over the data-parallel ranks first
+    _mn_sync_group = None
+
     @torch.no_grad()
     def forward(self, input):
         rows = 1 if self.q_level == "L" else input.shape[0]
-        ops.iao_observe(input, rows, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
-                        self.min_val, self.max_val)
+        if self._mn_sync and rows == 1 and torch.distributed.is_initialized() and torch.distributed.get_world_size(self._mn_sync_group) > 1:
+            # local (min, max) of this rank's shard -> global over the ranks -> the ordinary update on the two global extremes
+            from micronet_amd import dp
+            cur_min, cur_max = torch.empty_like(self.min_val), torch.empty_like(self.max_val)
+            ops.iao_observe(input, 1, 0, True, 0.0, cur_min, cur_max)
+            dp.allreduce_minmax(cur_min, cur_max, self._mn_sync_group)
+            ops.iao_observe(torch.cat([cur_min.reshape(-1), cur_max.reshape(-1)]), 1, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
+                            self.min_val, self.max_val)
+        else:
+            ops.iao_observe(input, rows, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
+                            self.min_val, self.max_val)
         if self.num_flag == 0:
             self.num_flag += 1
 

@@ -126,6 +126,10 @@ class GraphedTrainStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not hasattr(optimizer, "capturable"):
             raise TypeError("GraphedTrainStep needs micronet_amd.optim.Adam")
+        if self.world > 1 and any(getattr(m, "_mn_sync", False) for m in model.modules()):
+            # the range collectives of synced IAO observers sit INSIDE forward: capturing RCCL calls into the graph is untested on this stack,
+            # so such models run the eager data-parallel step (dp.GradSync: bucketed all-reduce overlapped with backward)
+            raise RuntimeError("GraphedTrainStep: the model has cross-rank observer collectives inside forward; use the eager DP step")
         optimizer.capturable = True
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -72,3 +72,79 @@ def test_single_process_is_a_noop():
     s = dp.GradSync(m)
     s.wait()
     assert s.world == 1 and len(s.buckets) == 1
+
+
+# ------------------------------------------------------------------------------------------------ observer ranges over the global batch
+def _obs_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from micronet_amd import dp
+    from oracle import torch_oracle as TO
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    xs = [torch.randn(8, 4, 6, 6) * (1 + s) + 0.3 * s for s in range(3)]          # 3 steps of a global batch of 8
+    obs = TO.Observer("L", ema=True)
+    for x in xs:
+        shard = x[rank * 4:(rank + 1) * 4]
+        lo, hi = shard.min().reshape(1), shard.max().reshape(1)
+        dp.allreduce_minmax(lo, hi)                 # what the product's observer does between its two kernel launches
+        obs(torch.cat([lo, hi]))                    # the ordinary (first-call / EMA) update on the two global extremes
+    if rank == 0:
+        q.put((obs.min_val.numpy().copy(), obs.max_val.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_observer_ranges_reduce_to_the_global_batch():
+    """2 ranks x half batch: all-reduced (min, max) followed by the EMA update == the single-process observer on the full batch, bit for bit."""
+    sys.path.insert(0, ROOT)
+    from oracle import torch_oracle as TO
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_obs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    lo, hi = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    torch.manual_seed(5)
+    xs = [torch.randn(8, 4, 6, 6) * (1 + s) + 0.3 * s for s in range(3)]
+    ref = TO.Observer("L", ema=True)
+    for x in xs:
+        ref(x)
+    assert (lo == ref.min_val.numpy()).all() and (hi == ref.max_val.numpy()).all()
+
+
+def test_gradient_bucket_layout_resnet18():
+    """resnet18's 44.7 MB of fp32 gradients split into two buckets at the 32 MB cap, filled in reverse parameter order (the order backward
+    produces them), every parameter exactly once; nin_gc (2.37 MB) is a single bucket."""
+    sys.path.insert(0, ROOT)
+    from micronet_amd import dp
+    from micronet_amd.train import build_model
+    m = build_model("resnet18")
+    s = dp.GradSync(m)
+    total = sum(p.numel() for p in m.parameters())
+    assert total == 11173962 and len(s.buckets) == 2
+    assert sum(b.flat.numel() for b in s.buckets) == total
+    assert s.buckets[0].flat.numel() * 4 >= 32 << 20 and s.buckets[0].params[0] is list(m.parameters())[-1]
+    seen = [id(p) for b in s.buckets for p in b.params]
+    assert len(seen) == len(set(seen)) == len(list(m.parameters()))
+    n = build_model("nin_gc")
+    assert len(dp.GradSync(n).buckets) == 1 and sum(p.numel() for p in n.parameters()) == 591390
+
+
+def test_sync_observers_marks_only_level_L_minmax_observers():
+    sys.path.insert(0, ROOT)
+    from micronet_amd import dp
+    from micronet_amd.train import build_model
+    from micronet.compression.quantization.wqaq.iao import quantize as Q
+    from micronet.compression.quantization.wqaq.dorefa import quantize as D
+    m = Q.prepare(build_model("resnet18"), inplace=True, a_bits=4, w_bits=4, q_type=0, q_level=0)
+    n = dp.sync_observers(m)
+    acts = sum(1 for mod in m.modules() if isinstance(mod, (Q.QuantConv2d, Q.QuantLinear)))
+    adds = sum(1 for mod in m.modules() if isinstance(mod, Q.QuantAdd))
+    assert adds == 8 and n >= acts + 3 * adds            # one per activation quantizer + (res, shortcut, union) per QuantAdd; weight observers are per-channel
+    assert not any(getattr(o, "_mn_sync", False) for mod in m.modules() if isinstance(mod, (Q.QuantConv2d,)) for o in [mod.weight_quantizer.observer])
+    assert dp.sync_observers(D.prepare(build_model("nin_gc"), inplace=True, a_bits=2, w_bits=2)) == 0
