@@ -1,0 +1,101 @@
+"""Inference-graph tooling (micronet_amd/inference.py): the deployed graph computes the same function as the trained QAT graph in eval
+mode -- the check the reference's ``quant_model_test.py`` / ``bn_fused_model_test.py`` scripts make by comparing test accuracy, made here on the
+tensors themselves."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trained(scheme, arch, kw, steps=2, wd=1e-5):
+    from micronet_amd.train import build_model, make_optimizer, synth_batch, train_step
+    Q = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    m = Q.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+    opt = make_optimizer(m, 0.01, wd)
+    x, y = synth_batch(32, device="cuda")
+    for _ in range(steps):
+        train_step(m, opt, x, y)
+    return Q, m, x
+
+
+@pytest.mark.parametrize("bits", [2, 8])
+def test_dorefa_prequantized_inference_graph(bits):
+    """quant_model_test.py:189-191: weights stored fake-quantised, quant_inference=True skips the weight quantizer: same eval output."""
+    from micronet_amd import inference
+    from micronet_amd.train import build_model
+    Q, T, x = _trained("wqaq.dorefa", "nin_gc", dict(a_bits=bits, w_bits=bits))
+    I = Q.prepare(build_model("nin_gc"), inplace=True, a_bits=bits, w_bits=bits, quant_inference=True).cuda()
+    I.load_state_dict(T.state_dict())
+    assert inference.prequantize_weights(I) == 8                       # every QuantConv2d (the first conv stays fp32, ref 206)
+    T.eval(), I.eval()
+    with torch.no_grad():
+        a, b = T(x), I(x)
+        # stage by stage on the SAME input: the inference graph contracts the stored fp32 weights (fp32-exact kernels), the training graph the integer
+        # codes: equal to float round-off
+        ta = x
+        for mt, mi in (zip(T.model, I.model) if bits == 8 else ()):          # (the 2-bit training graph pools inside its fused blocks: stages do not align)
+            ya, yb = mt(ta), mi(ta.float() if hasattr(ta, "float") else ta)
+            assert float((ya.float() - yb.float()).abs().max()) <= 2e-6 * float(ya.float().abs().max().clamp_min(1e-30))
+            ta = ya
+    # free-running: at 8 bit a 5e-7 difference flips activation codes at rounding boundaries in the following layers (a code step is 1/255)
+    assert float((a - b).abs().max()) <= (1e-6 if bits == 2 else 2e-2) * float(a.abs().max()), float((a - b).abs().max())
+    n = 2 ** bits - 1
+    for m in I.modules():
+        if isinstance(m, Q.QuantConv2d):                               # stored weights are on the quantizer's grid (2k - n) / n
+            k = (m.weight * n + n) / 2
+            assert float((k - k.round()).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("W", [3, 2])
+def test_wbwtab_bn_fused_inference_graph(W):
+    """wbwtab/bn_fuse/bn_fuse.py:20-107: BatchNorm folded into the conv; in front of a binary activation the fold keeps the weights ternary / binary.
+    Binary nets amplify rounding at sign ties (a BatchNorm output within 1e-7 of zero), so the two graphs are compared on the logits with a small
+    tolerance and on the predicted classes."""
+    from micronet_amd import inference
+    from micronet_amd.train import build_model
+    Q, T, x = _trained("wbwtab", "nin_gc", dict(A=2, W=W), wd=0.0)
+    I = Q.prepare(build_model("nin_gc"), inplace=True, A=2, W=W, quant_inference=True).cuda()
+    I.load_state_dict(T.state_dict())
+    inference.prequantize_weights(I)
+    F = inference.wbwtab_model_bn_fuse(I, W=W)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in F.modules())
+    # the folded convs in front of binary activations still hold ternary / binary codes x alpha: at most 3 distinct |values| per output channel
+    qc = [m for m in F.modules() if isinstance(m, Q.QuantConv2d)]
+    assert len(qc) == 7
+    for m in qc:
+        w = m.weight.detach().flatten(1)
+        assert all(len(torch.unique(w[o].abs())) <= 2 for o in range(0, w.shape[0], 37))
+    T.eval(), I.eval(), F.eval()
+    with torch.no_grad():
+        t, i, f = T(x), I(x), F(x)
+    assert float((t - i).abs().max()) <= 1e-6 * float(t.abs().max())                                      # pre-quantisation alone is exact
+    agree = float((t.argmax(1) == f.argmax(1)).float().mean())
+    rel = float((t - f).abs().max() / t.abs().max())
+    print("W", W, "bn-fused vs train graph: max rel logit diff", rel, "class agreement", agree)
+    assert agree >= 0.9 and rel <= 0.2
+
+
+def test_iao_bn_fused_inference_graph():
+    """wqaq/iao/bn_fuse/bn_fuse.py:20-80 + pre-quantisation: QuantBNFuseConv2d -> QuantConv2d(quant_inference=True) with folded, quantised weights."""
+    from micronet_amd import inference
+    Q, T, x = _trained("wqaq.iao", "nin_gc", dict(a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=True))
+    T.eval()
+    with torch.no_grad():
+        t = T(x)
+    I = inference.iao_model_bn_fuse(T)
+    assert not any(isinstance(m, Q.QuantBNFuseConv2d) for m in I.modules())
+    assert inference.prequantize_weights(I) == 9
+    I.eval()
+    with torch.no_grad():
+        i = I(x)
+        ta = x
+        for mt, mi in zip(T.model, I.model):          # stage by stage on the same input: float round-off only
+            ya, yb = mt(ta), mi(ta)
+            assert float((ya - yb).abs().max()) <= 1e-5 * float(ya.abs().max().clamp_min(1e-30))
+            ta = ya
+    # free-running: 8-bit activation codes flip at rounding boundaries under a 5e-7 perturbation (a code step is 1/255 of the range)
+    assert float((t - i).abs().max()) <= 2e-2 * float(t.abs().max()), float((t - i).abs().max() / t.abs().max())
+    sd_keys = [k for k in I.state_dict() if "running" in k or "gamma" in k]
+    assert not sd_keys
