@@ -195,8 +195,16 @@ class QuantConvTranspose2d(nn.ConvTranspose2d):
 
 
 def _ordered_parent(module):
-    """True when the parent calls its children in definition order, so bn -> relu adjacency means bn feeds relu."""
-    return isinstance(module, nn.Sequential) or type(module).__name__ == "ConvBNReLU"
+    """True when the parent is KNOWN to call its children in definition order, so bn -> relu adjacency means bn feeds relu: ``nn.Sequential``, the
+    ``ConvBNReLU`` block of the reference's own model files (models/nin.py, models/nin_gc.py -- identified by class AND defining module, not by
+    name alone), or a user block that opts in with ``_mn_ordered_forward = True``."""
+    return isinstance(module, nn.Sequential) or _is_ref_block(module)
+
+
+def _is_ref_block(module):
+    """The reference's ``ConvBNReLU`` (shuffle -> conv -> bn -> relu, models/nin_gc.py:18-59) or a block that declares the same call order."""
+    t = type(module)
+    return bool(getattr(module, "_mn_ordered_forward", False)) or (t.__name__ == "ConvBNReLU" and t.__module__.split(".")[-1] in ("nin", "nin_gc"))
 
 
 def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=False, fuse_bn_act=True, fold_shuffle=True,
@@ -219,7 +227,7 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                 module._modules[name] = new
                 # the reference's ConvBNReLU block shuffles its input in front of the conv (models/nin_gc.py:53-56):
                 # hand the permutation to the conv, which folds it into its channel addressing (no copy of the tensor)
-                if fold_shuffle and type(module).__name__ == "ConvBNReLU" and getattr(module, "channel_shuffle_flag", 0) \
+                if fold_shuffle and _is_ref_block(module) and getattr(module, "channel_shuffle_flag", 0) \
                         and getattr(module, "shuffle_groups", 1) > 1 and child.in_channels % module.shuffle_groups == 0:
                     new.in_shuffle_groups = int(module.shuffle_groups)
                     module.channel_shuffle_flag = 0

@@ -209,8 +209,16 @@ class ReLUAfterFusedBN(nn.ReLU):
 
 
 def _ordered_parent(module):
-    """True when the parent calls its children in definition order, so bn -> relu adjacency means bn feeds relu."""
-    return isinstance(module, nn.Sequential) or type(module).__name__ == "ConvBNReLU"
+    """True when the parent is KNOWN to call its children in definition order, so bn -> relu adjacency means bn feeds relu: ``nn.Sequential``, the
+    ``ConvBNReLU`` block of the reference's own model files (models/nin.py, models/nin_gc.py -- identified by class AND defining module, not by
+    name alone), or a user block that opts in with ``_mn_ordered_forward = True``."""
+    return isinstance(module, nn.Sequential) or _is_ref_block(module)
+
+
+def _is_ref_block(module):
+    """The reference's ``ConvBNReLU`` (shuffle -> conv -> bn -> relu, models/nin_gc.py:18-59) or a block that declares the same call order."""
+    t = type(module)
+    return bool(getattr(module, "_mn_ordered_forward", False)) or (t.__name__ == "ConvBNReLU" and t.__module__.split(".")[-1] in ("nin", "nin_gc"))
 
 
 def _fuse_blocks(model, fold_shuffle=True):
@@ -219,7 +227,7 @@ def _fuse_blocks(model, fold_shuffle=True):
     codes (``q_out_bits`` / ``q_pool``), and every QuantConv2d followed by a BatchNorm2dReLU in its block may leave its output un-computed
     (``lazy_for_bn``); the block's channel shuffle moves into the conv's addressing (``in_shuffle_groups``)."""
     def is_block(m):
-        return type(m).__name__ == "ConvBNReLU" and isinstance(getattr(m, "bn", None), BatchNorm2dReLU) and isinstance(getattr(m, "conv", None), nn.Conv2d)
+        return _is_ref_block(m) and isinstance(getattr(m, "bn", None), BatchNorm2dReLU) and isinstance(getattr(m, "conv", None), nn.Conv2d)
 
     def two(v):
         return v in (2, (2, 2), [2, 2])
