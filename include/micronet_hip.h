@@ -70,6 +70,13 @@ int mn_dorefa_w_fwd(const float* w, float* qw, int64_t n, int w_bits, float* ws,
 /* backward incl. the path through the global max (ties share equally) */
 int mn_dorefa_w_bwd(const float* g, const float* w, float* dw, int64_t n, int w_bits, float* ws, mn_stream_t stream);
 
+/* The same quantizer over count <= 32 weight tensors in ONE launch per phase (host arrays of device pointers / element counts; nothing is allocated,
+ * graph-capturable): a training step quantizes every conv's weights, the calls above are 2 + 3 launches of ~5 us per layer.  Bit-identical to them.
+ * ws[i]: >= mn_dorefa_w_ws_floats(n[i]) floats each. */
+int mn_dorefa_w_fwd_multi(const float* const* w, float* const* qw, float* const* ws, const int64_t* n, int32_t count, int w_bits, mn_stream_t stream);
+int mn_dorefa_w_bwd_multi(const float* const* g, const float* const* w, float* const* dw, float* const* ws, const int64_t* n, int32_t count, int w_bits,
+                          mn_stream_t stream);
+
 /* ------------------------------------------------------------------ WbWtAb
  * wbwtab/quantize.py */
 /* BinaryActivation.forward 13-19 / backward 22-36 */

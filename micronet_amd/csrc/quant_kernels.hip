@@ -315,6 +315,130 @@ extern "C" int mn_dorefa_w_bwd(const float* g, const float* w, float* dw, int64_
     return MN_OK;
 }
 
+// The same quantizer over up to MN_DW_MAX_TENSORS weight tensors in ONE launch per phase (a training step quantizes the weights of every conv: as separate
+// calls that is 2 launches forward and 3 backward per layer, each ~5 us): a by-value table maps a block to (tensor, block-in-tensor).  Same
+// arithmetic per tensor (same partial-block count, same reduction order) as the single-tensor entry points: bit-identical results.
+#define MN_DW_MAX_TENSORS 32
+struct DwTable {
+    const float* w[MN_DW_MAX_TENSORS];
+    const float* g[MN_DW_MAX_TENSORS];
+    float* out[MN_DW_MAX_TENSORS];       // qw (forward) / dw (backward)
+    float* ws[MN_DW_MAX_TENSORS];
+    long long n[MN_DW_MAX_TENSORS];
+    int b0[MN_DW_MAX_TENSORS + 1];       // first block of each tensor
+    int nb[MN_DW_MAX_TENSORS];           // partial blocks of each tensor (<= DW_NB)
+    int count;
+    float s;
+};
+__device__ __forceinline__ int dw_find(const DwTable& t, int b) {
+    int ti = 0;
+    while (ti + 1 < t.count && t.b0[ti + 1] <= b) ++ti;
+    return ti;
+}
+__global__ __launch_bounds__(256) void k_dorefa_w_absmax_multi(const DwTable t) {
+    __shared__ float sc[16];
+    const int ti = dw_find(t, blockIdx.x), lb = blockIdx.x - t.b0[ti], nb = t.nb[ti];
+    const float* __restrict__ w = t.w[ti];
+    const long long n = t.n[ti];
+    float m = 0.f;
+    for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nb * 256) m = OpMaxF()(m, fabsf(tanhf(w[i])));
+    m = block_reduce(m, OpMaxF(), 0.f, sc);
+    if (threadIdx.x == 0) t.ws[ti][16 + lb] = m;
+}
+// phase: 0 forward (qw), 1 backward partial sums, 2 backward (dw).  Blocks of a tensor: the table's partition for phase 1 (one partial per block), b1 for 0 / 2.
+__global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int phase) {
+    __shared__ float sc[16];
+    __shared__ double scd[16];
+    const int ti = dw_find(t, blockIdx.x), lb = blockIdx.x - t.b0[ti], nbk = t.b0[ti + 1] - t.b0[ti], nb = t.nb[ti];
+    const float* __restrict__ w = t.w[ti];
+    const float* __restrict__ g = t.g[ti];
+    float* __restrict__ ws = t.ws[ti];
+    const long long n = t.n[ti];
+    const float s = t.s;
+    const float M = dorefa_w_global_max(ws, nb, sc);
+    if (phase == 0) {
+        if (lb == 0 && threadIdx.x == 0) ws[0] = M;
+        float* __restrict__ qw = t.out[ti];
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
+            const float tt = tanhf(w[i]);
+            const float u = (tt / 2.f) / M + 0.5f;
+            const float q = mn_rha(u / s) * s;
+            qw[i] = 2.f * q - 1.f;
+        }
+    } else if (phase == 1) {
+        double acc = 0.0;
+        float ties = 0.f;
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
+            const float tt = tanhf(w[i]);
+            const float du = ((g[i] * 2.f) * s) / s;
+            acc += (double)(-du * (tt / 2.f) / (M * M));
+            ties += (fabsf(tt) == M) ? 1.f : 0.f;
+        }
+        acc = block_reduce(acc, OpAddD(), 0.0, scd);
+        ties = block_reduce(ties, OpAddF(), 0.f, sc);
+        if (threadIdx.x == 0) { ws[16 + nb + lb] = (float)acc; ws[16 + 2 * nb + lb] = ties; }
+    } else {
+        double a = 0.0;
+        float c = 0.f;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) { a += (double)ws[16 + nb + i]; c += ws[16 + 2 * nb + i]; }
+        const float dM = (float)block_reduce(a, OpAddD(), 0.0, scd);
+        const float cnt = block_reduce(c, OpAddF(), 0.f, sc);
+        if (lb == 0 && threadIdx.x == 0) { ws[1] = dM; ws[2] = cnt; }
+        const float share = dM / cnt;
+        float* __restrict__ dw = t.out[ti];
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
+            const float tt = tanhf(w[i]);
+            const float du = ((g[i] * 2.f) * s) / s;
+            float dt = (du / M) / 2.f;
+            if (fabsf(tt) == M) dt += share * mn_sign(tt);
+            dw[i] = dt * (1.f - tt * tt);
+        }
+    }
+}
+// table for the phases: `wide` != 0 gives every tensor up to 1024 blocks (elementwise phases 0 / 2), else exactly its partial-block count
+static int dw_table(DwTable* t, const float* const* w, const float* const* g, float* const* out, float* const* ws, const int64_t* n, int count, int w_bits,
+                    int wide, int* grid, const char* what) {
+    if (count < 1 || count > MN_DW_MAX_TENSORS || w_bits < 2 || w_bits > 31 || !w || !out || !ws || !n) MN_FAIL(MN_EINVAL, "%s: bad arguments (count=%d w_bits=%d)", what, count, w_bits);
+    int b = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!w[i] || !out[i] || !ws[i] || n[i] <= 0 || (g && !g[i])) MN_FAIL(MN_EINVAL, "%s: tensor %d invalid", what, i);
+        t->w[i] = w[i]; t->g[i] = g ? g[i] : nullptr; t->out[i] = out[i]; t->ws[i] = ws[i]; t->n[i] = n[i];
+        t->nb[i] = mn_grid_for(n[i], 256, DW_NB);
+        t->b0[i] = b;
+        b += wide ? mn_grid_for(n[i], 256, 1024) : t->nb[i];
+    }
+    t->b0[count] = b; t->count = count; t->s = dorefa_scale(w_bits);
+    *grid = b;
+    return MN_OK;
+}
+extern "C" int mn_dorefa_w_fwd_multi(const float* const* w, float* const* qw, float* const* ws, const int64_t* n, int32_t count, int w_bits, mn_stream_t stream) {
+    DwTable t;
+    int grid;
+    int rc = dw_table(&t, w, nullptr, qw, ws, n, count, w_bits, 0, &grid, "mn_dorefa_w_fwd_multi");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_dorefa_w_absmax_multi, dim3(grid), dim3(256), 0, s, t);
+    if ((rc = dw_table(&t, w, nullptr, qw, ws, n, count, w_bits, 1, &grid, "mn_dorefa_w_fwd_multi"))) return rc;
+    hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 0);
+    MN_CHECK_LAUNCH("mn_dorefa_w_fwd_multi");
+    return MN_OK;
+}
+extern "C" int mn_dorefa_w_bwd_multi(const float* const* g, const float* const* w, float* const* dw, float* const* ws, const int64_t* n, int32_t count, int w_bits,
+                                     mn_stream_t stream) {
+    DwTable t;
+    int grid;
+    if (!g) MN_FAIL(MN_EINVAL, "mn_dorefa_w_bwd_multi: null gradient table");
+    int rc = dw_table(&t, w, g, dw, ws, n, count, w_bits, 0, &grid, "mn_dorefa_w_bwd_multi");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_dorefa_w_absmax_multi, dim3(grid), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 1);
+    if ((rc = dw_table(&t, w, g, dw, ws, n, count, w_bits, 1, &grid, "mn_dorefa_w_bwd_multi"))) return rc;
+    hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 2);
+    MN_CHECK_LAUNCH("mn_dorefa_w_bwd_multi");
+    return MN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // WbWtAb binary activation (wbwtab/quantize.py:11-36)
 struct FBinActFwd { __device__ float operator()(float x) const { return (x < 0.f) ? -1.f : 1.f; } };  // 0, -0, NaN -> +1

@@ -65,6 +65,9 @@ class WeightQuantizer(nn.Module):
         if self.w_bits == 32:
             return input
         _check_bits(self.w_bits)
+        pre = self.__dict__.pop("_mn_pre", None)
+        if pre is not None and pre[0] is input:
+            return pre[1]            # computed ahead for all layers in one launch (micronet_amd.train.prefetch_weight_path)
         return ops.DorefaWeight.apply(input, self.w_bits)
 
 

@@ -71,6 +71,23 @@ def prefetch_weight_path(model, side=None):
     ``backward()``."""
     from micronet_amd import ops
     from micronet_amd.quantization.wbwtab import quantize as wb
+    from micronet_amd.quantization.wqaq.dorefa import quantize as dr
+    if side is None:
+        # DoReFa nets: every conv / linear weight quantizer of one bit-width in one MultiDorefaWeight node (2 launches forward, 3 backward per step)
+        by_bits = {}
+        for m in model.modules():
+            if isinstance(m, (dr.QuantConv2d, dr.QuantLinear)) and not m.quant_inference and 2 <= m.weight_quantizer.w_bits <= 31 and m.weight.is_cuda \
+                    and m.weight.is_contiguous():
+                m.weight_quantizer.__dict__.pop("_mn_pre", None)
+                by_bits.setdefault(m.weight_quantizer.w_bits, []).append(m)
+        for bits, ms in by_bits.items():
+            for i in range(0, len(ms), 32):
+                grp = ms[i:i + 32]
+                if len(grp) < 2:
+                    continue
+                qws = ops.MultiDorefaWeight.apply(bits, *[m.weight for m in grp])
+                for m, wq in zip(grp, qws):
+                    m.weight_quantizer._mn_pre = (m.weight, wq, None)
     mods = [m for m in model.modules() if isinstance(m, wb.QuantConv2d) and not m.quant_inference and m.weight_quantizer.W in (2, 3)]
     for m in mods:
         m.weight_quantizer.__dict__.pop("_mn_pre", None)

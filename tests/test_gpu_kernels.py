@@ -434,3 +434,33 @@ BNQ_HOT = [
 @pytest.mark.parametrize("training", [True, False])
 def test_qconv_bnq_hot_shapes(be, name, kw, training):
     K.check_qconv_bnq(be, seed=77, training=training, **kw)
+
+
+def test_dorefa_weight_quantizer_multi_bit_identical(be):
+    """mn_dorefa_w_fwd_multi / _bwd_multi over several tensors == the per-tensor entry points, bit for bit (same partial blocks, same reduction order)."""
+    import ctypes as C
+    torch = be.torch
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    shapes = [(256, 128, 1, 1), (512, 16, 3, 3), (10, 1024, 1, 1), (7,), (1024, 128, 1, 1)]
+    ws = [torch.randn(s, device="cuda", generator=gen) * 0.7 for s in shapes]
+    ws[3][2] = ws[3][5] = ws[3].abs().max() + 1.0                      # a tie at the maximum
+    gs = [torch.randn(s, device="cuda", generator=gen) for s in shapes]
+    lib = be.lib
+    for bits in (2, 8):
+        single_q, single_d = [], []
+        for w, g in zip(ws, gs):
+            sc = torch.empty(int(lib.mn_dorefa_w_ws_floats(w.numel())), device="cuda")
+            q, d = torch.empty_like(w), torch.empty_like(w)
+            be.call("mn_dorefa_w_fwd", be.ptr(w), be.ptr(q), w.numel(), bits, be.ptr(sc), be.stream)
+            be.call("mn_dorefa_w_bwd", be.ptr(g), be.ptr(w), be.ptr(d), w.numel(), bits, be.ptr(sc), be.stream)
+            single_q.append(q); single_d.append(d)
+        n = len(ws)
+        PA, LA = C.c_void_p * n, C.c_int64 * n
+        qs, ds = [torch.empty_like(w) for w in ws], [torch.empty_like(w) for w in ws]
+        scs = [torch.empty(int(lib.mn_dorefa_w_ws_floats(w.numel())), device="cuda") for w in ws]
+        be.call("mn_dorefa_w_fwd_multi", PA(*[w.data_ptr() for w in ws]), PA(*[q.data_ptr() for q in qs]), PA(*[t.data_ptr() for t in scs]), LA(*[w.numel() for w in ws]), n, bits, be.stream)
+        be.call("mn_dorefa_w_bwd_multi", PA(*[g.data_ptr() for g in gs]), PA(*[w.data_ptr() for w in ws]), PA(*[d.data_ptr() for d in ds]), PA(*[t.data_ptr() for t in scs]),
+                LA(*[w.numel() for w in ws]), n, bits, be.stream)
+        torch.cuda.synchronize()
+        for a, b in zip(single_q + single_d, qs + ds):
+            assert torch.equal(a, b)
