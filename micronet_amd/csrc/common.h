@@ -89,6 +89,9 @@ __device__ __forceinline__ unsigned mn_pack_bf16x2(float lo_elem, float hi_elem)
     return (mn_f2u(lo_elem) >> 16) | (mn_f2u(hi_elem) & 0xffff0000u);
 }
 
+// the same from the high halves as they are (no masking of the low halves needed): one v_perm
+__device__ __forceinline__ unsigned mn_pack_hi16(float lo_elem, float hi_elem) { return mn_perm(mn_f2u(hi_elem), mn_f2u(lo_elem), 0x07060302u); }
+
 // ---------------------------------------------------------------- arithmetic shared by all schemes
 // round-half-away-from-zero evaluated in fp32 exactly like the reference's
 // sign(v) * floor(|v| + 0.5)  (dorefa/quantize.py:13-16, iao/quantize.py:158-160).

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_k3s_wgrad(const K3wParams p) {
     const int nw = nblk > wave ? (nblk - wave + 3) / 4 : 0;                                         // ... of this wave: st0 + wave + 4 t
     // loads are unconditional (clamped step, clamped rows): steps past the range are never contracted
     auto fetch = [&](Stage& S, int t) {
-        int st = st0 + wave + 4 * t;
+        int st = st0 + wave + 4 * (t < nw ? t : (nw > 0 ? nw - 1 : 0));      // past the range: this wave's own last step again (an L2 hit, not the neighbour's data)
         st = st < p.nsteps ? st : p.nsteps - 1;
         const uint32_t n = fd_div(st, p.fd_spi);
         const int oh0 = (st - (int)n * p.spi) * p.R;

@@ -701,8 +701,63 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_reduce(const float* __restrict
     }
 }
 
+// The same for many partial tiles (Z >= 16): a block owns 64 consecutive floats of the padded [G][Mgw][Cgw] tile; its 16 groups of 16 lanes each sum a
+// z subset (z = q, q + 16, ...) with 16-byte loads -- 256 contiguous bytes per group and z, against 32-byte pieces in the kernel above (10-12 us for
+// 17 MB of partials) -- and the 16 sums are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void k_pw_wgrad_reduce_v(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
+                                                           float* __restrict__ db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
+                                                           float ascale, const float* __restrict__ qp, int nblk_w) {
+    __shared__ double sm[16][16][4];
+    const float as = qp ? qp[0] : ascale;
+    const int q = threadIdx.x >> 4, l = threadIdx.x & 15;
+    if ((int)blockIdx.x < nblk_w) {
+        const int64_t tile = (int64_t)G * Mgw * Cgw;
+        const int64_t e0 = (int64_t)blockIdx.x * 64 + 4 * l;                  // first of this lane's four floats in the padded tile
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+        for (int z = q; z < Z; z += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)z * tile + e0);
+            s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+        }
+        sm[q][l][0] = s0; sm[q][l][1] = s1; sm[q][l][2] = s2; sm[q][l][3] = s3;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int ll = threadIdx.x >> 2, e = threadIdx.x & 3;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += sm[k][ll][e];
+            const int64_t ei = (int64_t)blockIdx.x * 64 + 4 * ll + e;
+            const int c = (int)(ei % Cgw);
+            const int64_t o = ei / Cgw;
+            const int m = (int)(o % Mgw), g = (int)(o / Mgw);
+            if (m < Mg && c < Cg) dw[((int64_t)g * Mg + m) * Cg + c] = (float)t * as;
+        }
+    } else if (db) {
+        // bias gradient: the 8-lane scheme of the kernel above
+        const int sub = threadIdx.x & 7;
+        const int64_t total = (int64_t)G * Mg, nslots = ((total + 31) / 32) * 32;
+        const int64_t nthr = (int64_t)(gridDim.x - nblk_w) * blockDim.x;
+        for (int64_t i = ((int64_t)(blockIdx.x - nblk_w) * blockDim.x + threadIdx.x) >> 3; i < nslots; i += nthr >> 3) {
+            double sd = 0.0;
+            if (i < total) {
+                const int g = (int)(i / Mg), m = (int)(i % Mg);
+                for (int z = sub; z < Z; z += 8) sd += (double)dbpart[((int64_t)z * G + g) * Mgw + m];
+            }
+            sd += __shfl_xor(sd, 4, 64); sd += __shfl_xor(sd, 2, 64); sd += __shfl_xor(sd, 1, 64);
+            if (sub == 0 && i < total) db[i] = (float)sd;
+        }
+    }
+}
+
 void qg_launch_wgrad_reduce(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
                             float ascale, const float* qp, hipStream_t s) {
+    const int64_t tile = (int64_t)G * Mgw * Cgw;
+    if (Z >= 16 && tile % 64 == 0 && tile / 64 < (1 << 22) && !(((uintptr_t)part) & 15) && !getenv("MN_REDUCE_OLD")) {
+        const int nblk_w = (int)(tile / 64);
+        const int nblk_b = db ? mn_grid_for((int64_t)G * Mg * 8, 256, 64) : 0;
+        hipLaunchKernelGGL(k_pw_wgrad_reduce_v, dim3(nblk_w + nblk_b), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp, nblk_w);
+        return;
+    }
     const int64_t total = (int64_t)G * Mg * Cg + (db ? (int64_t)G * Mg : 0);
     hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(mn_grid_for(total * 8, 256, 4096)), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp);
 }

@@ -743,8 +743,25 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
 // the waves read ready B fragments; the reduction kernel multiplies by the quantizer's scale s.  (No 128-offset trick here: the gradient is
 // real-valued, an offset 40x larger than the signal would cost its low bits.)
 #define WG3_RSBX 64
-template <int MW, int BNH, int XENC = 0>
-__global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
+#ifndef WG3_NS
+#define WG3_NS 4
+#endif
+#ifndef WG3_PRIO
+#define WG3_PRIO 0
+#endif
+#if WG3_TRACE      // debugging aid (variant builds only): cycle stamps of one producer and one consumer wave of block 0 around every barrier
+__device__ long long g_wg3_trace[2][3][1024];
+extern "C" int mn_debug_wg3_trace(long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg3_trace), sizeof(g_wg3_trace)) == hipSuccess ? 0 : 1; }
+#define WG3_STAMP(role, slot, idx) if (blockIdx.x == 7 && lane == 0 && (wave == 0) && (idx) >= 0 && (idx) < 1024) g_wg3_trace[role][slot][idx] = clock64();
+#else
+#define WG3_STAMP(role, slot, idx)
+#endif
+// SPEC 1: wave-specialised, 512 threads.  Waves 0-3 are PRODUCERS (global loads, BatchNorm fold, the three-term split, LDS writes: VALU only),
+// waves 4-7 CONSUMERS (fragment reads + MFMA only, the 2 x 2 wave grid of the tile).  Every SIMD hosts one of each, so the VALU pipe and the matrix
+// pipe run concurrently instead of one after the other in the same wave (PMC of the unspecialised kernel at one wave per SIMD: 46 % of the wave
+// cycles issuing VALU, 27 % stalled behind its own MFMAs, 27 % parked; two blocks per CU did not overlap the phases either).  Same barrier sequence.
+template <int MW, int BNH, int XENC = 0, int SPEC = 0>
+__global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void k_pws_wgrad_s(const Wg2Params p) {
     // WG3_PRESPLIT: the staging threads split gy into its three bf16 terms ONCE per block and store three bf16 planes (rows of 80 B); the
     // waves then read ready fragments (no VALU between LDS and MFMA; the split is no longer done twice, by both waves of a row half)
     constexpr int CW = MW, TM = 32 * MW, TC = 32 * MW, RPT = TM / 32;
@@ -753,7 +770,8 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     constexpr int BUF = WG3_PRESPLIT ? 3 * PLANE + TC * RSB : TM * WG3_RSA + TC * RSB;
     HIP_DYNAMIC_SHARED(float, smemw)
     unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const bool prod = !SPEC || threadIdx.x < 256, cons = !SPEC || threadIdx.x >= 256;
     const int wm = wave >> 1, wc = wave & 1;
     uint32_t b = blockIdx.x;
     const int z = b % p.Z; b /= p.Z;
@@ -767,6 +785,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     const bool cdo = TC >= 128 || cr < TC;
     uint32_t goff[RPT], xoff;
     float dbacc[RPT];
+    const bool want_db = p.want_db != 0;
     float* ftab = reinterpret_cast<float*>(lds + 2 * BUF);                // BNH: [TM][8] the per-row fold (hlo, hhi, G, E1, E0), kept out of the register file
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -775,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
         goff[i] = (uint32_t)(g * p.Mg + m) * HW;
         dbacc[i] = 0.f;
     }
-    if (BNH) {
+    if (BNH && prod) {
         for (int r = tid; r < TM; r += 256) {
             int m = mb * TM + r;
             m = m < p.Mg ? m : p.Mg - 1;
@@ -803,10 +822,12 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     const int st0 = p.st_stride == 1 ? z * p.st_per_z : z;
     const int n = p.st_stride == 1 ? (((st0 + p.st_per_z) < p.nsteps ? (st0 + p.st_per_z) : p.nsteps) - st0)
                                    : (st0 < p.nsteps ? (p.nsteps - st0 + p.st_stride - 1) / p.st_stride : 0);
-    // loads are unconditional (a conditional load makes the register set a phi: copies, and a vmcnt(0) right behind the issue):
-    // steps past the block's range re-read the last step of the tensor and are never contracted
+    // loads are unconditional (a conditional load makes the register set a phi: copies, and a vmcnt(0) right behind the issue)
     auto fetch = [&](Stage& S, int k) {
-        int st = st0 + k * p.st_stride;
+        // past the block's range: re-read the block's OWN last step (an L2 hit), not the neighbour's first steps (those were real HBM traffic:
+        // prefetch depth x 20 KB per block = 20 MB per launch)
+        const int kk = k < n ? k : (n > 0 ? n - 1 : 0);
+        int st = st0 + kk * p.st_stride;
         st = st < p.nsteps ? st : p.nsteps - 1;
         const uint32_t P = (uint32_t)st * 32u + 4u * sq;
         const uint32_t ni = fd_div(P, p.fd_hw);
@@ -838,20 +859,19 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
                     v[e] = fmaf(f0.z, dz, fmaf(f0.w, hf, fE0));
                 }
             }
-            dbacc[i] += valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+            if (want_db) dbacc[i] += valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;      // wave-uniform: layers without bias skip the 22 instructions
             if (WG3_PRESPLIT) {
-                float t0[4], t1[4], t2[4];
+                // head = the high half of the word (one v_perm packs two of them); the remainders need the masked value: 4 VALU per element + 3 per pair
+                float r1[4], r2[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    t0[e] = mn_bf16_head(v[e]);
-                    const float r1 = v[e] - t0[e];
-                    t1[e] = mn_bf16_head(r1);
-                    t2[e] = r1 - t1[e];
+                    r1[e] = v[e] - mn_bf16_head(v[e]);
+                    r2[e] = r1[e] - mn_bf16_head(r1[e]);
                 }
                 unsigned char* d = A + (sr + 32 * i) * RS2 + 8 * sq;
-                *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
-                *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
-                *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
+                *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_hi16(v[0], v[1]), mn_pack_hi16(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{mn_pack_hi16(r1[0], r1[1]), mn_pack_hi16(r1[2], r1[3])};
+                *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{mn_pack_hi16(r2[0], r2[1]), mn_pack_hi16(r2[2], r2[3])};
             } else {
                 *reinterpret_cast<float4*>(A + (sr + 32 * i) * WG3_RSA + 16 * sq) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -884,9 +904,9 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
         for (int ci = 0; ci < CW; ++ci) {
             if (XENC) { bf[ci] = *reinterpret_cast<const u32x4*>(B + ((wc * CW + ci) * 16 + j) * RSB + 16 * (kg ^ ((j >> 2) & 3))); continue; }
             const u32x2 uv = *reinterpret_cast<const u32x2*>(B + ((wc * CW + ci) * 16 + j) * WG3_RSB + 8 * kg);
-            const uint32_t u = uv[0], v = uv[1];
-            bf[ci] = u32x4{0x3F803F80u | ((u & 0x80u) << 8) | ((u & 0x8000u) << 16), 0x3F803F80u | ((u & 0x800000u) >> 8) | (u & 0x80000000u),
-                           0x3F803F80u | ((v & 0x80u) << 8) | ((v & 0x8000u) << 16), 0x3F803F80u | ((v & 0x800000u) >> 8) | (v & 0x80000000u)};
+            // sign byte c -> bf16 +-1.0 = bytes {0x80, (c & 0x80) | 0x3F}: one and-or per 4 codes, one v_perm per 2 (the 0x80 comes from the constant operand)
+            const uint32_t u = (uv[0] & 0x80808080u) | 0x3F3F3F3Fu, v = (uv[1] & 0x80808080u) | 0x3F3F3F3Fu;
+            bf[ci] = u32x4{mn_perm(u, 0x80u, 0x05000400u), mn_perm(u, 0x80u, 0x07000600u), mn_perm(v, 0x80u, 0x05000400u), mn_perm(v, 0x80u, 0x07000600u)};
         }
         u32x4 a0[MW], a1[MW], a2[MW];
 #pragma unroll
@@ -916,6 +936,9 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
                 a2[mi][d] = mn_pack_bf16x2(t2[2 * d], t2[2 * d + 1]);
             }
         }
+        // consumer waves have the registers for all 16 fragments of a step: issue every LDS read before the first MFMA (read just in time, each
+        // group of 8 MFMAs waited for its own LDS round trip: 1800 cycles per step against 770 of matrix work)
+        if (SPEC) MN_SCHED_FENCE();
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
@@ -929,6 +952,90 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
 #pragma unroll
             for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(a2[mi], bf[ci], acc[mi][ci]);
     };
+    if (SPEC) {
+        // NS steps of operands in flight per block (registers of the producer waves): one block per CU and a loaded HBM latency of ~3 us need
+        // >= 80 KB in flight per CU to stream at the HBM rate (2 steps = 40 KB gave 3.8 TB/s)
+        constexpr int NS = WG3_NS;
+        // Barrier k (after the producers committed step k into buffer k & 1) releases the consumers' contraction of step k; the producers overwrite
+        // that buffer with step k + 2 only behind barrier k + 1, which the consumers reach after contracting step k.  The loads are issued in the same
+        // stage order before the loop and inside it: the compiler's wait-count bookkeeping at the loop header then sees the same pending set on
+        // both incoming edges (an asymmetric prologue made every iteration wait for the newest loads).
+        if (prod) {
+            Stage st[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { fetch(st[k], k); MN_SCHED_FENCE(); }
+            if (BNH) __syncthreads();
+            for (int t = 0; t < n; t += NS) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    WG3_STAMP(0, 0, t + u)
+                    commit(st[u], u & 1, t + u < n);
+#if !WG3_NOLOAD
+                    fetch(st[u], t + u + NS);
+#endif
+                    WG3_STAMP(0, 1, t + u)
+                    __syncthreads();
+                    WG3_STAMP(0, 2, t + u)
+                }
+            }
+        } else {
+            // Consumers run one step behind: behind barrier k they ISSUE the fragment reads of step k (into register set k & 1) and then contract
+            // step k - 1 from the other set while those reads are in flight.  Reading and contracting the same step in one phase made all four waves
+            // of the block hit the LDS together right behind the barrier with the matrix pipe idle (1700 cycles per step for 820 of MFMA).
+            struct Frag { u32x4 a[3][MW]; u32x4 b[CW]; };
+            Frag fr[2];
+            auto ldfrag = [&](Frag& F, int buf) {
+                const unsigned char* A = lds + buf * BUF;
+                const unsigned char* B = A + 3 * PLANE;
+#pragma unroll
+                for (int ci = 0; ci < CW; ++ci) {
+                    if (XENC) F.b[ci] = *reinterpret_cast<const u32x4*>(B + ((wc * CW + ci) * 16 + j) * RSB + 16 * (kg ^ ((j >> 2) & 3)));
+                    else {          // raw sign bytes; expanded to bf16 +-1 right before the contraction
+                        const u32x2 uv = *reinterpret_cast<const u32x2*>(B + ((wc * CW + ci) * 16 + j) * WG3_RSB + 8 * kg);
+                        F.b[ci] = u32x4{uv[0], uv[1], 0u, 0u};
+                    }
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int mi = 0; mi < MW; ++mi) F.a[pl][mi] = *reinterpret_cast<const u32x4*>(A + pl * PLANE + ((wm * MW + mi) * 16 + j) * RS2 + 16 * kg);
+            };
+            auto mma = [&](Frag& F) {
+                u32x4 bf[CW];
+#pragma unroll
+                for (int ci = 0; ci < CW; ++ci) {
+                    if (XENC) { bf[ci] = F.b[ci]; continue; }
+                    const uint32_t u = (F.b[ci][0] & 0x80808080u) | 0x3F3F3F3Fu, v = (F.b[ci][1] & 0x80808080u) | 0x3F3F3F3Fu;
+                    bf[ci] = u32x4{mn_perm(u, 0x80u, 0x05000400u), mn_perm(u, 0x80u, 0x07000600u), mn_perm(v, 0x80u, 0x05000400u), mn_perm(v, 0x80u, 0x07000600u)};
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                        for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(F.a[pl][mi], bf[ci], acc[mi][ci]);
+            };
+#if !defined(MN_EMULATION) && WG3_PRIO
+            __builtin_amdgcn_s_setprio(WG3_PRIO);
+#endif
+            if (BNH) __syncthreads();
+            int kdone = -1;                  // last step whose fragments sit in registers, not yet contracted
+            for (int t = 0; t < n; t += NS) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    WG3_STAMP(1, 0, t + u)
+                    __syncthreads();
+                    WG3_STAMP(1, 1, t + u)
+                    if (t + u < n) ldfrag(fr[u & 1], u & 1);
+                    MN_SCHED_FENCE();
+                    if (t + u >= 1 && t + u - 1 < n) mma(fr[(u & 1) ^ 1]);
+                    WG3_STAMP(1, 2, t + u)
+                }
+                kdone = t + NS - 1;
+            }
+            if (kdone >= 0 && kdone < n) mma(fr[1]);          // n a multiple of NS: the last step (odd index) is still pending
+        }
+    } else {
     fetch(s0, 0);
     fetch(s1, 1);
     if (BNH) __syncthreads();                 // the fold table
@@ -945,6 +1052,29 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
         if (t + 1 < n) contract(1);
         __syncthreads();
     }
+    }
+    if (SPEC && MW == 4) {
+        // partial tile through LDS: a store instruction then covers four whole 256-byte rows.  (Straight from the accumulator layout a lane holds
+        // four ROWS of one column: 64-byte pieces, and every half-written 128-byte line cost a fetch -- 17 MB per launch, 8 ... 24 % of the reads.)
+        __syncthreads();                                   // the staging buffers are free
+        if (cons) {
+            constexpr int ERS = 16 * CW + 4;               // floats per staged row
+            float* T = reinterpret_cast<float*>(lds) + wave * (16 * MW) * ERS;
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                for (int ci = 0; ci < CW; ++ci)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[(mi * 16 + kg * 4 + r) * ERS + ci * 16 + j] = acc[mi][ci][r];
+            MN_WAVE_SYNC();
+            float* dst = p.part + (((int64_t)z * p.G + g) * p.Mgw + mb * TM + wm * (16 * MW)) * p.Cgw + cb * TC + wc * (16 * CW);
+#pragma unroll
+            for (int it = 0; it < (16 * MW) / 4; ++it) {
+                const int row = it * 4 + (lane >> 4), col = 4 * (lane & 15);
+                *reinterpret_cast<float4*>(dst + (int64_t)row * p.Cgw + col) = *reinterpret_cast<const float4*>(T + row * ERS + col);
+            }
+        }
+    } else if (cons)
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
@@ -955,7 +1085,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.Cgw] = acc[mi][ci][r];
         }
-    if (p.want_db && cb == 0) {
+    if (p.want_db && cb == 0 && prod) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             float v = dbacc[i];
@@ -965,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad_s(const Wg2Params p) {
     }
 }
 static int pws_geom_ok(const mn_conv_geom* g);
-struct Wg2Plan { Wg2Params p; int MW, CW8, staged; int grid; int64_t off_db, ws_bytes; };
+struct Wg2Plan { Wg2Params p; int MW, CW8, staged, spec; int grid; int64_t off_db, ws_bytes; };
 static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (!pws_geom_ok(g)) return 0;
     const int Cg = g->C / g->groups, Mg = g->O / g->groups;
@@ -983,7 +1113,10 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     p.Mgw = p.nmb * T; p.Cgw = p.ncb * T;
     p.nsteps = (int)(NP / 32);
     const int base = p.G * p.nmb * p.ncb;
-    int Z = 512 / base;
+    // LDS-staged kernel: 16-byte code loads need HW % 16 == 0; MN_WG2_DIRECT=1 keeps the direct-load kernel (A/B knob)
+    pl->staged = p.HW % 16 == 0 && !pl->CW8 && !getenv("MN_WG2_DIRECT");
+    pl->spec = pl->staged && pl->MW == 4 && !getenv("MN_WG2_NOSPEC");            // wave-specialised variant: 512 threads, one block per CU
+    int Z = (pl->spec ? 256 : 512) / base;
     // every block pays a fixed price (pipeline fill, a 64 KB partial tile written and reduced again): keep >= 32 steps per block as long
     // as there is still one block per CU (measured: L5 67 -> 58 us, L8 40 -> 36 us)
     while (Z > 1 && p.nsteps / Z < 32 && base * Z > 256) Z /= 2;
@@ -994,8 +1127,6 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (getenv("MN_DEBUG_PLAN")) fprintf(stderr, "plan_pws_wgrad: nsteps %d base %d Z %d MW %d\n", p.nsteps, base, Z, pl->MW);
     p.st_per_z = (p.nsteps + Z - 1) / Z; p.st_stride = 1;     // contiguous pixel ranges: each block streams its gy rows sequentially
     if (getenv("MN_WG2_STRIDED")) { p.st_stride = Z; }
-    // LDS-staged kernel: 16-byte code loads need HW % 16 == 0; MN_WG2_DIRECT=1 keeps the direct-load kernel (A/B knob)
-    pl->staged = p.HW % 16 == 0 && !pl->CW8 && !getenv("MN_WG2_DIRECT");
     p.fd_hw = make_fastdiv((uint32_t)p.HW);
     const int64_t nb = (int64_t)base * Z;
     if (nb > 0x7fffffff) return 0;
@@ -1020,7 +1151,7 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
     p.h = h; p.chan = chan; p.sums = sums; p.training = training; p.n_f = (float)g->N * (float)(g->H * g->W);
     if (h && (!chan || !sums || (((uintptr_t)h) & 3))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null / misaligned argument");
     if (pl.staged && ((((uintptr_t)x) & 15) || (h && (((uintptr_t)h) & 3)))) pl.staged = 0;
-    if (pl.staged) mn_set_last_kernel("k_pws_wgrad_s<%d, %d>", pl.MW, h ? 1 : 0);
+    if (pl.staged) mn_set_last_kernel(pl.spec ? "k_pws_wgrad_s<%d, %d, 0, 1>" : "k_pws_wgrad_s<%d, %d>", pl.MW, h ? 1 : 0);
     else mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.CW8 ? 2 : pl.MW, pl.CW8 ? 8 : pl.MW, h ? 1 : 0);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((h ? 5.0 : 4.0) * ny + nx); }
     mn_prof_begin(s);
@@ -1029,9 +1160,12 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
         const size_t buf = WG3_PRESPLIT ? (size_t)3 * TMs * 80 + (size_t)TMs * WG3_RSB : (size_t)TMs * WG3_RSA + (size_t)TMs * WG3_RSB;
         const size_t ldsb = 2 * buf + (p.h ? (size_t)TMs * 32 : 0);
 #define WG3_LAUNCH(MWV, BV) { raise_lds_limit((const void*)k_pws_wgrad_s<MWV, BV>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<MWV, BV>), dim3(pl.grid), dim3(256), ldsb, s, p); }
-        if (p.h) { if (pl.MW == 4) WG3_LAUNCH(4, 1) else WG3_LAUNCH(2, 1) }
+#define WG3_LAUNCH_SPEC(BV) { raise_lds_limit((const void*)k_pws_wgrad_s<4, BV, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, BV, 0, 1>), dim3(pl.grid), dim3(512), ldsb, s, p); }
+        if (pl.spec) { if (p.h) WG3_LAUNCH_SPEC(1) else WG3_LAUNCH_SPEC(0) }
+        else if (p.h) { if (pl.MW == 4) WG3_LAUNCH(4, 1) else WG3_LAUNCH(2, 1) }
         else { if (pl.MW == 4) WG3_LAUNCH(4, 0) else WG3_LAUNCH(2, 0) }
 #undef WG3_LAUNCH
+#undef WG3_LAUNCH_SPEC
     } else if (p.h) {
         if (pl.CW8) hipLaunchKernelGGL((k_pws_wgrad<2, 8, 1>), dim3(pl.grid), dim3(256), 0, s, p);
         else if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
@@ -1056,12 +1190,13 @@ int pws_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* 
     Wg2Params& p = pl.p;
     p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
     p.h = nullptr; p.chan = nullptr; p.sums = nullptr; p.training = 0; p.n_f = 1.f;
-    mn_set_last_kernel("k_pws_wgrad_s<%d, 0, 1>", pl.MW);
+    mn_set_last_kernel(pl.spec ? "k_pws_wgrad_s<%d, 0, 1, 1>" : "k_pws_wgrad_s<%d, 0, 1>", pl.MW);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + nx); }
     mn_prof_begin(s);
     const int TMs = 32 * pl.MW;
     const size_t ldsb = 2 * ((size_t)3 * TMs * 80 + (size_t)TMs * WG3_RSBX);
-    if (pl.MW == 4) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
+    if (pl.spec) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1, 1>), dim3(pl.grid), dim3(512), ldsb, s, p); }
+    else if (pl.MW == 4) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
     else { raise_lds_limit((const void*)k_pws_wgrad_s<2, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<2, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
     mn_prof_end(s);
     qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, ascale, nullptr, s);
