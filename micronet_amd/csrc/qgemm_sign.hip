@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
 #if WG3_TRACE      // debugging aid (variant builds only): cycle stamps of one producer and one consumer wave of block 0 around every barrier
 __device__ long long g_wg3_trace[2][3][1024];
 extern "C" int mn_debug_wg3_trace(long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg3_trace), sizeof(g_wg3_trace)) == hipSuccess ? 0 : 1; }
-#define WG3_STAMP(role, slot, idx) if (blockIdx.x == 7 && lane == 0 && (wave == 0) && (idx) >= 0 && (idx) < 1024) g_wg3_trace[role][slot][idx] = clock64();
+#define WG3_STAMP(role, slot, idx) if (blockIdx.x == 7 && lane == 0 && ((threadIdx.x >> 6) == (role ? 4 : 0)) && (idx) >= 0 && (idx) < 1024) g_wg3_trace[role][slot][idx] = clock64();
 #else
 #define WG3_STAMP(role, slot, idx)
 #endif
@@ -760,8 +760,10 @@ extern "C" int mn_debug_wg3_trace(long long* host) { return hipMemcpyFromSymbol(
 // waves 4-7 CONSUMERS (fragment reads + MFMA only, the 2 x 2 wave grid of the tile).  Every SIMD hosts one of each, so the VALU pipe and the matrix
 // pipe run concurrently instead of one after the other in the same wave (PMC of the unspecialised kernel at one wave per SIMD: 46 % of the wave
 // cycles issuing VALU, 27 % stalled behind its own MFMAs, 27 % parked; two blocks per CU did not overlap the phases either).  Same barrier sequence.
+// SPEC 2: EIGHT consumer waves (768 threads; 4 x 2 wave grid, 32 x 64 per wave).  One wave issues a v_mfma_f32_16x16x32_bf16 only every ~27 cycles
+// (measured: 16 independent accumulators, one wave per SIMD); two MFMA-issuing waves per SIMD bring the pipe to ~14-17 cycles per instruction.
 template <int MW, int BNH, int XENC = 0, int SPEC = 0>
-__global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void k_pws_wgrad_s(const Wg2Params p) {
+__global__ __launch_bounds__(SPEC == 2 ? 768 : (SPEC ? 512 : 256), SPEC ? 1 : 2) void k_pws_wgrad_s(const Wg2Params p) {
     // WG3_PRESPLIT: the staging threads split gy into its three bf16 terms ONCE per block and store three bf16 planes (rows of 80 B); the
     // waves then read ready fragments (no VALU between LDS and MFMA; the split is no longer done twice, by both waves of a row half)
     constexpr int CW = MW, TM = 32 * MW, TC = 32 * MW, RPT = TM / 32;
@@ -772,7 +774,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void k_pws_wgrad_s(
     unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const bool prod = !SPEC || threadIdx.x < 256, cons = !SPEC || threadIdx.x >= 256;
-    const int wm = wave >> 1, wc = wave & 1;
+    constexpr int MWc = SPEC == 2 ? MW / 2 : MW;                   // row tiles of a consumer wave
+    const int cwv = SPEC ? ((int)threadIdx.x - 256) >> 6 : wave;   // consumer wave index
+    const int wm = cwv >> 1, wc = cwv & 1;
     uint32_t b = blockIdx.x;
     const int z = b % p.Z; b /= p.Z;
     const int cb = b % p.ncb; b /= p.ncb;
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void k_pws_wgrad_s(
             // Consumers run one step behind: behind barrier k they ISSUE the fragment reads of step k (into register set k & 1) and then contract
             // step k - 1 from the other set while those reads are in flight.  Reading and contracting the same step in one phase made all four waves
             // of the block hit the LDS together right behind the barrier with the matrix pipe idle (1700 cycles per step for 820 of MFMA).
-            struct Frag { u32x4 a[3][MW]; u32x4 b[CW]; };
+            struct Frag { u32x4 a[3][MWc]; u32x4 b[CW]; };
             Frag fr[2];
             auto ldfrag = [&](Frag& F, int buf) {
                 const unsigned char* A = lds + buf * BUF;
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void k_pws_wgrad_s(
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                    for (int mi = 0; mi < MW; ++mi) F.a[pl][mi] = *reinterpret_cast<const u32x4*>(A + pl * PLANE + ((wm * MW + mi) * 16 + j) * RS2 + 16 * kg);
+                    for (int mi = 0; mi < MWc; ++mi) F.a[pl][mi] = *reinterpret_cast<const u32x4*>(A + pl * PLANE + ((wm * MWc + mi) * 16 + j) * RS2 + 16 * kg);
             };
             auto mma = [&](Frag& F) {
                 u32x4 bf[CW];
@@ -1011,7 +1015,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void k_pws_wgrad_s(
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                    for (int mi = 0; mi < MW; ++mi)
+                    for (int mi = 0; mi < MWc; ++mi)
 #pragma unroll
                         for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(F.a[pl][mi], bf[ci], acc[mi][ci]);
             };
@@ -1059,17 +1063,17 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void k_pws_wgrad_s(
         __syncthreads();                                   // the staging buffers are free
         if (cons) {
             constexpr int ERS = 16 * CW + 4;               // floats per staged row
-            float* T = reinterpret_cast<float*>(lds) + wave * (16 * MW) * ERS;
+            float* T = reinterpret_cast<float*>(lds) + cwv * (16 * MWc) * ERS;
 #pragma unroll
-            for (int mi = 0; mi < MW; ++mi)
+            for (int mi = 0; mi < MWc; ++mi)
 #pragma unroll
                 for (int ci = 0; ci < CW; ++ci)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) T[(mi * 16 + kg * 4 + r) * ERS + ci * 16 + j] = acc[mi][ci][r];
             MN_WAVE_SYNC();
-            float* dst = p.part + (((int64_t)z * p.G + g) * p.Mgw + mb * TM + wm * (16 * MW)) * p.Cgw + cb * TC + wc * (16 * CW);
+            float* dst = p.part + (((int64_t)z * p.G + g) * p.Mgw + mb * TM + wm * (16 * MWc)) * p.Cgw + cb * TC + wc * (16 * CW);
 #pragma unroll
-            for (int it = 0; it < (16 * MW) / 4; ++it) {
+            for (int it = 0; it < (16 * MWc) / 4; ++it) {
                 const int row = it * 4 + (lane >> 4), col = 4 * (lane & 15);
                 *reinterpret_cast<float4*>(dst + (int64_t)row * p.Cgw + col) = *reinterpret_cast<const float4*>(T + row * ERS + col);
             }
@@ -1115,7 +1119,8 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     const int base = p.G * p.nmb * p.ncb;
     // LDS-staged kernel: 16-byte code loads need HW % 16 == 0; MN_WG2_DIRECT=1 keeps the direct-load kernel (A/B knob)
     pl->staged = p.HW % 16 == 0 && !pl->CW8 && !getenv("MN_WG2_DIRECT");
-    pl->spec = pl->staged && pl->MW == 4 && !getenv("MN_WG2_NOSPEC");            // wave-specialised variant: 512 threads, one block per CU
+    pl->spec = pl->staged && pl->MW == 4 && !getenv("MN_WG2_NOSPEC") ? 2 : 0;    // wave-specialised variant: 768 threads, one block per CU
+    if (pl->spec) if (const char* e = getenv("MN_WG2_SPEC")) { const int v = atoi(e); if (v == 1 || v == 2) pl->spec = v; }   // A/B knob: 4 or 8 consumer waves
     int Z = (pl->spec ? 256 : 512) / base;
     // every block pays a fixed price (pipeline fill, a 64 KB partial tile written and reduced again): keep >= 32 steps per block as long
     // as there is still one block per CU (measured: L5 67 -> 58 us, L8 40 -> 36 us)
@@ -1151,7 +1156,7 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
     p.h = h; p.chan = chan; p.sums = sums; p.training = training; p.n_f = (float)g->N * (float)(g->H * g->W);
     if (h && (!chan || !sums || (((uintptr_t)h) & 3))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null / misaligned argument");
     if (pl.staged && ((((uintptr_t)x) & 15) || (h && (((uintptr_t)h) & 3)))) pl.staged = 0;
-    if (pl.staged) mn_set_last_kernel(pl.spec ? "k_pws_wgrad_s<%d, %d, 0, 1>" : "k_pws_wgrad_s<%d, %d>", pl.MW, h ? 1 : 0);
+    if (pl.staged) mn_set_last_kernel(pl.spec == 2 ? "k_pws_wgrad_s<%d, %d, 0, 2>" : pl.spec ? "k_pws_wgrad_s<%d, %d, 0, 1>" : "k_pws_wgrad_s<%d, %d>", pl.MW, h ? 1 : 0);
     else mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.CW8 ? 2 : pl.MW, pl.CW8 ? 8 : pl.MW, h ? 1 : 0);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((h ? 5.0 : 4.0) * ny + nx); }
     mn_prof_begin(s);
@@ -1160,8 +1165,9 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
         const size_t buf = WG3_PRESPLIT ? (size_t)3 * TMs * 80 + (size_t)TMs * WG3_RSB : (size_t)TMs * WG3_RSA + (size_t)TMs * WG3_RSB;
         const size_t ldsb = 2 * buf + (p.h ? (size_t)TMs * 32 : 0);
 #define WG3_LAUNCH(MWV, BV) { raise_lds_limit((const void*)k_pws_wgrad_s<MWV, BV>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<MWV, BV>), dim3(pl.grid), dim3(256), ldsb, s, p); }
-#define WG3_LAUNCH_SPEC(BV) { raise_lds_limit((const void*)k_pws_wgrad_s<4, BV, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, BV, 0, 1>), dim3(pl.grid), dim3(512), ldsb, s, p); }
-        if (pl.spec) { if (p.h) WG3_LAUNCH_SPEC(1) else WG3_LAUNCH_SPEC(0) }
+#define WG3_LAUNCH_SPEC(BV, SV) { raise_lds_limit((const void*)k_pws_wgrad_s<4, BV, 0, SV>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, BV, 0, SV>), dim3(pl.grid), dim3(256 + 256 * SV), ldsb, s, p); }
+        if (pl.spec == 2) { if (p.h) WG3_LAUNCH_SPEC(1, 2) else WG3_LAUNCH_SPEC(0, 2) }
+        else if (pl.spec) { if (p.h) WG3_LAUNCH_SPEC(1, 1) else WG3_LAUNCH_SPEC(0, 1) }
         else if (p.h) { if (pl.MW == 4) WG3_LAUNCH(4, 1) else WG3_LAUNCH(2, 1) }
         else { if (pl.MW == 4) WG3_LAUNCH(4, 0) else WG3_LAUNCH(2, 0) }
 #undef WG3_LAUNCH
@@ -1190,12 +1196,13 @@ int pws_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* 
     Wg2Params& p = pl.p;
     p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
     p.h = nullptr; p.chan = nullptr; p.sums = nullptr; p.training = 0; p.n_f = 1.f;
-    mn_set_last_kernel(pl.spec ? "k_pws_wgrad_s<%d, 0, 1, 1>" : "k_pws_wgrad_s<%d, 0, 1>", pl.MW);
+    mn_set_last_kernel(pl.spec == 2 ? "k_pws_wgrad_s<%d, 0, 1, 2>" : pl.spec ? "k_pws_wgrad_s<%d, 0, 1, 1>" : "k_pws_wgrad_s<%d, 0, 1>", pl.MW);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + nx); }
     mn_prof_begin(s);
     const int TMs = 32 * pl.MW;
     const size_t ldsb = 2 * ((size_t)3 * TMs * 80 + (size_t)TMs * WG3_RSBX);
-    if (pl.spec) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1, 1>), dim3(pl.grid), dim3(512), ldsb, s, p); }
+    if (pl.spec == 2) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1, 2>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1, 2>), dim3(pl.grid), dim3(768), ldsb, s, p); }
+    else if (pl.spec) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1, 1>), dim3(pl.grid), dim3(512), ldsb, s, p); }
     else if (pl.MW == 4) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
     else { raise_lds_limit((const void*)k_pws_wgrad_s<2, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<2, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
     mn_prof_end(s);
