@@ -385,6 +385,12 @@ int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, const float* 
 int mn_signconv1x1_small_supported(int64_t C, int64_t HW, int64_t O);
 int mn_signconv1x1_small_fwd(const int8_t* a, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream);
 int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float* dx, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream);
+/* The same layer in a DoReFa net (wqaq/dorefa/quantize.py:107-122; every conv but the first is quantised, so the classifier reads the k-bit
+ * activation codes of the block in front): codes uint8 j in [0, 2^a_bits - 1], w the fake-quantised weights:
+ *   y[n][o][p] = bias[o] + s * sum_c w[o][c] * j[n][c][p],   s = 1 / (2^a_bits - 1)
+ * backward-data is mn_conv1x1_small_bwd_data (gradient w.r.t. the QUANTISED activation), backward-weight mn_conv2d_bwd_weight with MN_ACTQ_CODE8. */
+int mn_codeconv1x1_small_fwd(const uint8_t* codes, int a_bits, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O,
+                             mn_stream_t stream);
 
 /* ------------------------------------------------------------------ input pipeline of the training loop
  * <scheme>/main.py:203-210: transforms.Compose([RandomCrop(32, padding=4), RandomHorizontalFlip(), ToTensor(), Normalize(mean, std)]) applied to a batch

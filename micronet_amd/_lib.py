@@ -106,6 +106,7 @@ PROTOTYPES = {
     "mn_qconv_bnsign_bwd_pooled": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_signconv1x1_small_supported": (_I, [_L, _L, _L]),
     "mn_signconv1x1_small_fwd": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P]),
+    "mn_codeconv1x1_small_fwd": (_I, [_P, _I, _P, _P, _P, _L, _L, _L, _L, _P]),
     "mn_conv1x1_small_bwd_data": (_I, [_P, _P, _P, _L, _L, _L, _L, _P]),
     "mn_iao_fq_act_fwd": (_I, [_P, _P, _L, _P, _I, _I, _I, C.c_float, _P]),
     "mn_iao_fq_act_bwd": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, C.c_float, _P]),

@@ -457,9 +457,10 @@ static int bnsign_bwd_impl(const float* da, const float* y, const float* save, c
 // over channels c0 + cs + 4u.  The weights come from an LDS image [C][OP] (OP = O rounded up to 4; broadcast b128 reads, no per-output
 // branches, no scalar-load latency chain), the 16 code dwords of a lane are all in flight at once (the layer is latency-, not byte-bound).
 // The four channel groups of a wave are combined by two shuffles, the 16 waves through LDS in a fixed order: deterministic.
-template <int OP>
+// ENC 1: the bytes are k-bit activation codes j (DoReFa quantizer output, q = j * ascale): y = bias + ascale * sum_c w[o][c] * j.
+template <int OP, int ENC = 0>
 __global__ __launch_bounds__(1024) void k_sconv_fwd(const char* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
-                                                    float* __restrict__ y, int C, int HW, int O, int64_t NP) {
+                                                    float* __restrict__ y, int C, int HW, int O, int64_t NP, float ascale) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* wl = smem;                          // [C][OP]
     float* red = smem + (size_t)C * OP;        // [8][OP][64]
@@ -484,7 +485,9 @@ __global__ __launch_bounds__(1024) void k_sconv_fwd(const char* __restrict__ a, 
     const char* src = a + n * C * HW + p;
     __syncthreads();
     auto add = [&](uint32_t v, int c) {
-        const float s0 = (v & 0x80u) ? -1.f : 1.f, s1 = (v & 0x8000u) ? -1.f : 1.f, s2 = (v & 0x800000u) ? -1.f : 1.f, s3 = (v & 0x80000000u) ? -1.f : 1.f;
+        float s0, s1, s2, s3;
+        if (ENC) { s0 = (float)(v & 0xffu); s1 = (float)((v >> 8) & 0xffu); s2 = (float)((v >> 16) & 0xffu); s3 = (float)(v >> 24); }
+        else { s0 = (v & 0x80u) ? -1.f : 1.f; s1 = (v & 0x8000u) ? -1.f : 1.f; s2 = (v & 0x800000u) ? -1.f : 1.f; s3 = (v & 0x80000000u) ? -1.f : 1.f; }
 #pragma unroll
         for (int o4 = 0; o4 < OP; o4 += 4) {
             const float4 w4 = *reinterpret_cast<const float4*>(wl + c * OP + o4);
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(1024) void k_sconv_fwd(const char* __restrict__ a, 
             }
             const float bb = bias ? bias[o] : 0.f;
             const int64_t nq = Pq / HW;
+            if (ENC) { v.x *= ascale; v.y *= ascale; v.z *= ascale; v.w *= ascale; }
             *reinterpret_cast<float4*>(y + (nq * O + o) * HW + (Pq - nq * HW)) = make_float4(v.x + bb, v.y + bb, v.z + bb, v.w + bb);
         }
     }
@@ -579,22 +583,32 @@ extern "C" int mn_signconv1x1_small_supported(int64_t C, int64_t HW, int64_t O) 
     const int64_t OP = (O + 3) / 4 * 4;
     return (C * OP + 8 * OP * 64) * 4 <= 128 * 1024;          // the weight image and the partial sums live in LDS
 }
-extern "C" int mn_signconv1x1_small_fwd(const int8_t* a, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream) {
-    if (!a || !w || !y || N <= 0 || !mn_signconv1x1_small_supported(C, HW, O)) MN_FAIL(MN_EINVAL, "mn_signconv1x1_small_fwd: needs O <= 16, HW %% 4 == 0");
+static int sconv_fwd(const void* a, int enc, float ascale, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O,
+                     mn_stream_t stream, const char* what) {
+    if (!a || !w || !y || N <= 0 || !mn_signconv1x1_small_supported(C, HW, O)) MN_FAIL(MN_EINVAL, "%s: needs O <= 16, HW %% 4 == 0", what);
     hipStream_t s = (hipStream_t)stream;
     const int64_t NP = N * HW, nb = (NP + 63) / 64;
-    if (nb > 0x7fffffff || (((uintptr_t)a) & 3) || !aligned16(y)) MN_FAIL(MN_EINVAL, "mn_signconv1x1_small_fwd: too many blocks / misaligned tensor");
-    mn_set_last_kernel("k_sconv_fwd"); mn_prof_bytes((double)N * C * HW + 4.0 * N * O * HW); mn_prof_begin(s);
+    if (nb > 0x7fffffff || (((uintptr_t)a) & 3) || !aligned16(y)) MN_FAIL(MN_EINVAL, "%s: too many blocks / misaligned tensor", what);
+    mn_set_last_kernel(enc ? "k_sconv_fwd<code8>" : "k_sconv_fwd"); mn_prof_bytes((double)N * C * HW + 4.0 * N * O * HW); mn_prof_begin(s);
     const int OP = (int)((O + 3) / 4 * 4);
     const size_t lds = ((size_t)C * OP + (size_t)8 * OP * 64) * 4;
-    if (lds > 128 * 1024) MN_FAIL(MN_ENOTSUP, "mn_signconv1x1_small_fwd: too many input channels for the LDS weight image");
-#define SC_LAUNCH(OPV) { raise_lds_limit((const void*)k_sconv_fwd<OPV>, lds); \
-        hipLaunchKernelGGL(k_sconv_fwd<OPV>, dim3((unsigned)nb), dim3(1024), lds, s, (const char*)a, w, bias, y, (int)C, (int)HW, (int)O, NP); }
-    if (OP == 4) SC_LAUNCH(4) else if (OP == 8) SC_LAUNCH(8) else if (OP == 12) SC_LAUNCH(12) else SC_LAUNCH(16)
+    if (lds > 128 * 1024) MN_FAIL(MN_ENOTSUP, "%s: too many input channels for the LDS weight image", what);
+#define SC_LAUNCH(OPV, EV) { raise_lds_limit((const void*)k_sconv_fwd<OPV, EV>, lds); \
+        hipLaunchKernelGGL((k_sconv_fwd<OPV, EV>), dim3((unsigned)nb), dim3(1024), lds, s, (const char*)a, w, bias, y, (int)C, (int)HW, (int)O, NP, ascale); }
+    if (enc) { if (OP == 4) SC_LAUNCH(4, 1) else if (OP == 8) SC_LAUNCH(8, 1) else if (OP == 12) SC_LAUNCH(12, 1) else SC_LAUNCH(16, 1) }
+    else { if (OP == 4) SC_LAUNCH(4, 0) else if (OP == 8) SC_LAUNCH(8, 0) else if (OP == 12) SC_LAUNCH(12, 0) else SC_LAUNCH(16, 0) }
 #undef SC_LAUNCH
     mn_prof_end(s);
-    MN_CHECK_LAUNCH("mn_signconv1x1_small_fwd");
+    MN_CHECK_LAUNCH(what);
     return MN_OK;
+}
+extern "C" int mn_signconv1x1_small_fwd(const int8_t* a, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream) {
+    return sconv_fwd(a, 0, 1.f, w, bias, y, N, C, HW, O, stream, "mn_signconv1x1_small_fwd");
+}
+extern "C" int mn_codeconv1x1_small_fwd(const uint8_t* codes, int a_bits, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O,
+                                        mn_stream_t stream) {
+    if (a_bits < 2 || a_bits > 7) MN_FAIL(MN_EINVAL, "mn_codeconv1x1_small_fwd: 2 ... 7 bit codes");
+    return sconv_fwd(codes, 1, dorefa_scale(a_bits), w, bias, y, N, C, HW, O, stream, "mn_codeconv1x1_small_fwd");
 }
 extern "C" int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float* dx, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream) {
     if (!gy || !w || !dx || N <= 0 || !mn_signconv1x1_small_supported(C, HW, O) || !aligned16(dx)) MN_FAIL(MN_EINVAL, "mn_conv1x1_small_bwd_data: bad arguments");

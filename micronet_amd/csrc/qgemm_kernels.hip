@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
             const int c = cb * TC + r0 + 16 * i;
             rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int64_t xoff = ((int64_t)n * p.Cin_total + chan_phys(p.in_map, g * p.Cg + c)) * HW + pp;
-            if (XMODE == MN_ACTQ_SIGN8) {       // int8 sign codes: one dword = the 4 pixels, kept as raw bits in rx[i].x
+            if (XMODE == MN_ACTQ_SIGN8 || XMODE == MN_ACTQ_CODE8) {       // byte codes: one dword = the 4 pixels, kept as raw bits in rx[i].x
                 if (pv && c < p.Cg) rx[i].x = mn_u2f(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.x) + xoff));
             } else if (pv && c < p.Cg) rx[i] = *reinterpret_cast<const float4*>(p.x + xoff);
         }
@@ -571,6 +571,12 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
                 const unsigned u = mn_f2u(rx[i].x);
                 *reinterpret_cast<u32x2*>(xq + (r0 + 16 * i) * WG_LDP + qd * 4) =
                     u32x2{0x3F803F80u | ((u & 0x80u) << 8) | ((u & 0x8000u) << 16), 0x3F803F80u | ((u & 0x800000u) >> 8) | (u & 0x80000000u)};
+                continue;
+            }
+            if (XMODE == MN_ACTQ_CODE8) {       // k-bit activation codes j (bytes): bf16 j, exact (rows beyond Cg / pixels beyond the tensor hold 0)
+                const unsigned u = mn_f2u(rx[i].x);
+                *reinterpret_cast<u32x2*>(xq + (r0 + 16 * i) * WG_LDP + qd * 4) =
+                    u32x2{mn_pack_bf16x2((float)(u & 0xffu), (float)((u >> 8) & 0xffu)), mn_pack_bf16x2((float)((u >> 16) & 0xffu), (float)(u >> 24))};
                 continue;
             }
             const float c0 = act_code<XMODE>(rx[i].x, p.pro, sc, zp), c1 = act_code<XMODE>(rx[i].y, p.pro, sc, zp);
@@ -946,7 +952,7 @@ int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int 
     if (!pw_geom_ok(g)) return kk_supported(g, aq, wq, which);
     if (which == 0) { PwPlan pl; return wq_codeable(wq) && aq_codeable(aq, 0) && plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl); }
     if (which == 1) { PwPlan pl; return wq_codeable(wq) && plan_pw(g, 1, MN_ACTQ_NONE, &pl); }
-    if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) return aq->bits >= 2 && aq->bits <= 7 && pws_wgrad_code8_supported(g);
+    if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) { WgPlan pl; return aq->bits >= 2 && aq->bits <= 7 && (pws_wgrad_code8_supported(g) || plan_pw_wgrad(g, &pl)); }
     if (which == 2) { WgPlan pl; return aq_codeable(aq, 1) && plan_pw_wgrad(g, &pl); }
     return 0;
 }
@@ -1056,6 +1062,9 @@ static void launch_wg(const WgPlan& pl, int xmode, hipStream_t s) {
     } else if (xmode == MN_ACTQ_SIGN8) {
         raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_SIGN8>, pl.lds);
         hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_SIGN8>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+    } else if (xmode == MN_ACTQ_CODE8) {
+        raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_CODE8>, pl.lds);
+        hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_CODE8>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
     } else {
         raise_lds_limit((const void*)k_pw_wgrad<MW, CW, WGC, MN_ACTQ_NONE>, pl.lds);
         hipLaunchKernelGGL((k_pw_wgrad<MW, CW, WGC, MN_ACTQ_NONE>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
@@ -1066,12 +1075,14 @@ int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
     if (!pw_geom_ok(g)) return kk_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
     if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_wgrad_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g) && !getenv("MN_NO_WG2"))
         return pws_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // sign codes: fragments straight from global memory
-    if (aq && aq->mode == MN_ACTQ_CODE8) {        // k-bit activation codes: only the LDS-staged kernel reads them
-        if (aq->bits < 2 || aq->bits > 7 || !pws_wgrad_code8_supported(g)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): geometry not covered");
-        return pws_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);
+    const int code8 = aq && aq->mode == MN_ACTQ_CODE8;
+    if (code8) {        // k-bit activation codes: the LDS-staged kernel, or (small tiles: the classifier conv) the generic kernel reading bytes
+        if (aq->bits < 2 || aq->bits > 7) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): 2 ... 7 bit codes");
+        if (pws_wgrad_code8_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g))
+            return pws_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);
     }
     WgPlan pl;
-    if (!aq_codeable(aq, 1) || !plan_pw_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))
+    if ((!code8 && !aq_codeable(aq, 1)) || !plan_pw_wgrad(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & (code8 ? 3 : 15)))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(qgemm): geometry / quantizer combination not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(qgemm): workspace too small");
     Pro pro;
@@ -1091,7 +1102,8 @@ int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
     mn_prof_end(s);
     const int64_t total = (int64_t)g->O * (g->C / g->groups) + (dbias ? g->O : 0);
     (void)total;
-    qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw, pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f,
+    qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg, p.Mgw, p.Cgw,
+                           (pro.mode == MN_ACTQ_DOREFA || pro.mode == MN_ACTQ_CODE8) ? pro.s : 1.f,
                            pro.mode == MN_ACTQ_IAO ? pro.qp : (const float*)nullptr, s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(qgemm)");
     return MN_OK;

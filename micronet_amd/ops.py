@@ -1169,3 +1169,64 @@ class SignClassifierConv(Function):
                 ws, nb = _ws(g, 2, codes.device)
                 _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
         return dx, dw, db
+
+
+def code_classifier_supported(x, weight, stride, padding, dilation, groups):
+    """True when a DoReFa QuantConv2d on a ``QActTensor`` is the small 1x1 classifier the dedicated kernels cover (O <= 16)."""
+    if not isinstance(x, QActTensor) or x.dim() != 4 or weight.dim() != 4 or CONV_ALGO != _lib.MN_ALGO_AUTO or not (2 <= x.bits <= 7):
+        return False
+    one = lambda v, k: v in (k, (k, k), [k, k])
+    if not (weight.shape[2] == 1 and weight.shape[3] == 1 and one(stride, 1) and one(padding, 0) and one(dilation, 1) and groups == 1):
+        return False
+    g = _geom(x.shape, weight.shape, 1, 0, 1, 1)
+    aq = ActQ(ACTQ_CODE8, x.bits, 0, 0, None)
+    lib = _lib_()
+    return bool(lib.mn_signconv1x1_small_supported(x.shape[1], x.shape[2] * x.shape[3], weight.shape[0])) and \
+        bool(lib.mn_conv2d_qgemm_supported(C.byref(g), C.byref(aq), None, 2))
+
+
+class CodeClassifierConv(Function):
+    """The classifier conv of a DoReFa net (models/nin_gc.py 1024 -> 10, 1x1; wqaq/dorefa/quantize.py:107-122) on a ``QActTensor``: the byte codes
+    are read directly (mn_codeconv1x1_small_fwd); backward-data returns the gradient w.r.t. the QUANTISED activation as a ``QGrad`` (the producing
+    block applies the clip-STE), backward-weight contracts gy with the codes (mn_conv2d_bwd_weight, MN_ACTQ_CODE8)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bias):
+        codes, a_bits = x.codes, x.bits
+        wq, bias = _chk(wq, "weight"), _chk(bias, "bias")
+        N, Cc, H, W = codes.shape
+        Oc = wq.shape[0]
+        y = torch.empty((N, Oc, H, W), dtype=torch.float32, device=codes.device)
+        with torch.cuda.device_of(codes):
+            _call("mn_codeconv1x1_small_fwd", _p(codes), a_bits, _p(wq), _p(bias), _p(y), N, Cc, H * W, Oc, _s())
+        ctx.save_for_backward(codes, wq)
+        ctx.cfg = (a_bits, bias is not None)
+        ctx.x_ref = x
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        codes, wq = ctx.saved_tensors
+        a_bits, has_bias = ctx.cfg
+        x = ctx.x_ref
+        gy = _chk(gy, "grad")
+        N, Cc, H, W = codes.shape
+        Oc = wq.shape[0]
+        dx = dw = db = None
+        with torch.cuda.device_of(codes):
+            if ctx.needs_input_grad[0]:
+                dq = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+                _call("mn_conv1x1_small_bwd_data", _p(gy), _p(wq), _p(dq), N, Cc, H * W, Oc, _s())
+
+                def expand(dq_):
+                    return DorefaAct.backward_raw(dq_, x.materialize(), a_bits)
+                dx = QGrad(dq, expand)
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                g = _geom(codes.shape, wq.shape, 1, 0, 1, 1)
+                aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
+                dw = torch.empty_like(wq)
+                db = torch.empty(Oc, dtype=torch.float32, device=codes.device) if has_bias else None
+                ws, nb = _ws(g, 2, codes.device)
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
+        ctx.x_ref = None
+        return dx, dw, db

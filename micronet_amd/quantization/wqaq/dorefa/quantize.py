@@ -106,6 +106,9 @@ class QuantConv2d(nn.Conv2d):
                     ops.qconv_bnq_supported(input, quant_weight, self.stride, self.padding, self.dilation, self.groups, w_bits, self.in_shuffle_groups)):
                 return ops.QConvCodeLazy.apply(input, quant_weight, self.bias, self.stride, self.padding, self.dilation, self.groups, w_bits,
                                                self.in_shuffle_groups or 0)
+            if (not self.quant_inference and input.bits == bits and mode == ops.ACTQ_DOREFA and not self.in_shuffle_groups and
+                    ops.code_classifier_supported(input, quant_weight, self.stride, self.padding, self.dilation, self.groups)):
+                return ops.CodeClassifierConv.apply(input, quant_weight, self.bias)       # the 1024 -> 10 classifier: reads the codes directly
             input = ops.QActToFloat.apply(input)       # anything else: the fp32 activation the reference holds here (one streaming kernel)
         # like the reference, the forward always zero-pads whatever padding_mode says (ref 113-121)
         return ops.qconv2d(input, quant_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,

@@ -609,6 +609,27 @@ def check_sign_classifier(be, N=3, Cc=96, H=4, W=8, Oc=10, bias=True, seed=0):
     assert close(be.to_host(dw), dw_ref, 1e-5) and close(be.to_host(db), db_ref, 1e-5)
 
 
+def check_code_classifier(be, N=3, Cc=96, H=4, W=8, Oc=10, bits=2, bias=True, seed=0):
+    """mn_codeconv1x1_small_fwd (k-bit activation codes) + mn_conv2d_bwd_weight with MN_ACTQ_CODE8 on a small tile (the generic pointwise kernel reading
+    bytes) vs the float conv of the de-quantised activation."""
+    r = np.random.default_rng(seed)
+    nlev = (1 << bits) - 1
+    j = r.integers(0, nlev + 1, size=(N, Cc, H, W)).astype(np.uint8)
+    q = (j.astype(np.float64) / nlev).astype(F)
+    w = (r.standard_normal((Oc, Cc, 1, 1)) * 0.1).astype(F)
+    b = (r.standard_normal(Oc) * 0.2).astype(F) if bias else None
+    y_ref = O.conv2d_fwd(q, w, b)
+    gy = r.standard_normal(y_ref.shape).astype(F)
+    _, dw_ref, db_ref = O.conv2d_bwd(gy, q, w)
+    dJ, dW, dB, dG = be.to_dev_u8(j), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(gy)
+    y = be.empty((N, Oc, H, W))
+    be.call("mn_codeconv1x1_small_fwd", be.ptr(dJ), bits, be.ptr(dW), be.ptr(dB), be.ptr(y), N, Cc, H * W, Oc, be.stream)
+    assert close(be.to_host(y), y_ref, 2e-6)
+    g = be.geom((N, Cc, H, W), (Oc, Cc, 1, 1))
+    dw, db = be.conv_bwd_weight(g, be.actq(4, bits), dG, dJ, 0, bias=True)
+    assert close(be.to_host(dw), dw_ref, 1e-5) and close(be.to_host(db), db_ref, 1e-5)
+
+
 def check_first_conv_bn_wgrad(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, training=True, seed=0):
     """mn_bnsign_bwd_sums + mn_conv2d_bwd_weight_first_bn (dy formed inside the first-layer backward-weight) vs the two-step path
     mn_bnsign_bwd -> mn_conv2d_bwd_weight on the same tensors: same expressions, so the results agree to the last bit."""

@@ -358,6 +358,13 @@ def test_sign_classifier(be):
     K.check_sign_classifier(be, N=5, Cc=330, H=8, W=8, Oc=10, seed=3)
 
 
+def test_code_classifier(be):
+    K.check_code_classifier(be)
+    K.check_code_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bits=3, bias=False, seed=1)
+    K.check_code_classifier(be, N=16, Cc=1024, H=8, W=8, Oc=10, bits=2, seed=2)         # nin_gc L9 under DoReFa W2A2
+    K.check_code_classifier(be, N=5, Cc=330, H=8, W=8, Oc=10, bits=4, seed=3)
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_first_conv_bn_wgrad(be, training):
     K.check_first_conv_bn_wgrad(be, training=training)

@@ -617,7 +617,16 @@ def test_dorefa_fused_blocks_match_unfused(bits, arch):
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         if n.endswith("conv.bias") and float(pb.grad.abs().max()) < 1e-4 * gmax:
             continue                                          # a conv bias in front of a BatchNorm: the true gradient is 0, both sides hold round-off
-        e = float((pa.grad - pb.grad).abs().max() / pb.grad.abs().max().clamp_min(1e-30))
+        d = (pa.grad - pb.grad).abs()
+        scale = pb.grad.abs().max().clamp_min(1e-30)
+        if n.endswith("conv.weight") and pa.dim() == 4:
+            # the DoReFa weight quantizer routes the gradient of its global max |tanh w| to ONE element: a sum of ~all other terms of both signs
+            # (ill-conditioned; the full-batch parity test judges it against fp64).  Everything else to 2e-5, that element to 2e-4.
+            k = int(pb.detach().abs().argmax())
+            assert float(d.flatten()[k] / scale) <= 2e-4, (n, "arg-max element", float(d.flatten()[k] / scale))
+            d = d.flatten().clone()
+            d[k] = 0
+        e = float(d.max() / scale)
         assert e <= 2e-5, (n, e)
     for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         if ba.dtype.is_floating_point:
