@@ -281,6 +281,11 @@ int mn_bnsign_bwd_sums(const float* da, const float* y, const float* save, const
 int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta,
                                   const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                                   mn_stream_t stream);
+/* the same for the first block of a DoReFa net (BatchNorm2d + ReLU + the next conv's k-bit activation quantizer, mn_qa_*): dq = the gradient handed to
+ * mn_qa_bwd_apply, y = the first conv's output, chan = the [9][O] constants of mn_qa_chan_from_save, sums = mn_qa_bwd_sums' output; dy (what
+ * mn_qa_bwd_apply(in_f32 = 1, pool = 0) would write) is formed in registers, expression for expression. */
+int mn_conv2d_bwd_weight_first_qa(const mn_conv_geom* g, const float* dq, const float* y, const float* chan, const float* sums, int a_bits, int quant,
+                                  int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ conv + BatchNorm2d + BinaryActivation, fused, on packed signs
  * The whole W/A-binary block of the reference -- `relu(bn(conv(x)))` with the ReLU replaced by BinaryActivation

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "mn_maxpool2x2_sign8_bwd": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "mn_bnsign_bwd_sums": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P]),
     "mn_conv2d_bwd_weight_first_bn": (_I, [_G, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    "mn_conv2d_bwd_weight_first_qa": (_I, [_G, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
     "mn_bnsign_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P]),
     "mn_maxpool2x2_f32_supported": (_I, [_L, _L]),
     "mn_maxpool2x2_f32_fwd": (_I, [_P, _L, _L, _L, _P, _P, _P]),

@@ -116,6 +116,13 @@ __device__ __forceinline__ float dorefa_act_grad(float g, float x, float s) {
     d = (t >= 0.f && t <= 1.f) ? d : 0.f;   // clamp backward: inclusive at both ends
     return d * 0.1f;
 }
+// the DoReFa block BatchNorm + ReLU + next-layer quantizer (qact_kernels.hip): ReLU with ATen's NaN rule, and dz from the incoming gradient.
+// quant 1: gq is the gradient w.r.t. the QUANTISED activation (the quantizer's clip-STE is applied here); 0: w.r.t. the activation itself
+__device__ __forceinline__ float qa_relu(float z) { return (z > 0.f) ? z : ((z != z) ? z : 0.f); }
+__device__ __forceinline__ float qa_dz(float gq, float a, float z, float s, int quant) {
+    const float d = quant ? dorefa_act_grad(gq, a, s) : gq;
+    return (z > 0.f) ? d : 0.f;
+}
 // IAO fake-quant, wqaq/iao/quantize.py:227-239 and Round.backward 163-168
 __device__ __forceinline__ float iao_fq(float x, float sc, float zp, float qmin, float qmax) {
     float r = mn_rha(x / sc - zp);

@@ -45,6 +45,10 @@ struct C1Params {
     const float* sums;    // [2][O] sum dz, sum dz*zhat
     int training;
     float n_f;
+    // BN = 2: the DoReFa block (BatchNorm2d + ReLU + the next conv's activation quantizer, qact_kernels.hip): da = dq, chan = its [9][O] constants
+    const float* chan;
+    int quant;            // dq is the gradient w.r.t. the QUANTISED activation (the clip-STE is applied here)
+    float qs;             // quantizer scale 1 / (2^a - 1)
 };
 
 // stage the image strip (with zero halo) of image n, rows [row0 - ph, row0 + R + KH - 1 - ph) into xs[c][prow][pcol]
@@ -188,10 +192,14 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
         for (int r = lane; r < 16 * MT; r += 64) {
             const int m = m0 + r;
             const int mc = m < p.O ? m : p.O - 1;
-            ctab[r * 8 + 0] = p.save[mc]; ctab[r * 8 + 1] = p.save[p.O + mc]; ctab[r * 8 + 2] = p.gamma[mc]; ctab[r * 8 + 3] = p.beta[mc];
+            if (BN == 2) {        // QaCh rows 2 .. 5: mean, invstd, gamma, beta; row 8: gi (slot 6)
+                ctab[r * 8 + 0] = p.chan[2 * p.O + mc]; ctab[r * 8 + 1] = p.chan[3 * p.O + mc]; ctab[r * 8 + 2] = p.chan[4 * p.O + mc]; ctab[r * 8 + 3] = p.chan[5 * p.O + mc];
+            } else {
+                ctab[r * 8 + 0] = p.save[mc]; ctab[r * 8 + 1] = p.save[p.O + mc]; ctab[r * 8 + 2] = p.gamma[mc]; ctab[r * 8 + 3] = p.beta[mc];
+            }
             ctab[r * 8 + 4] = p.training ? p.sums[mc] / p.n_f : 0.f;
             ctab[r * 8 + 5] = p.training ? p.sums[p.O + mc] / p.n_f : 0.f;
-            ctab[r * 8 + 6] = 0.f; ctab[r * 8 + 7] = 0.f;
+            ctab[r * 8 + 6] = BN == 2 ? p.chan[8 * p.O + mc] : 0.f; ctab[r * 8 + 7] = 0.f;
         }
         MN_WAVE_SYNC();
     }
@@ -226,12 +234,14 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
                     const float yv[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
                     const float4 c0 = *reinterpret_cast<const float4*>(ctab + (sr + 8 * i) * 8);        // mean, invstd, gamma, beta
                     const float2 c1 = *reinterpret_cast<const float2*>(ctab + (sr + 8 * i) * 8 + 4);    // k1, k2
-                    const float cgi_ = c0.z * c0.y;
+                    const float cgi_ = BN == 2 ? ctab[(sr + 8 * i) * 8 + 6] : c0.z * c0.y;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float zh = (yv[e] - c0.x) * c0.y;
                         const float zz = zh * c0.z + c0.w;
-                        const float dz = (zz > -1.f && zz < 1.f) ? r[e] : 0.f;
+                        float dz;
+                        if (BN == 2) dz = qa_dz(r[e], qa_relu(zz), zz, p.qs, p.quant);     // expression for expression k_qa_apply<1, 0>
+                        else dz = (zz > -1.f && zz < 1.f) ? r[e] : 0.f;
                         r[e] = cgi_ * (dz - c1.x - zh * c1.y);
                     }
                 }
@@ -400,7 +410,8 @@ int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* b
 }
 template <int MT>
 static void c1_launch_wgrad_mt(const C1Plan& pl, const C1Params& p, hipStream_t s) {
-    if (p.da) { raise_lds_limit((const void*)k_c1_wgrad<MT, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    if (p.da && p.chan) { raise_lds_limit((const void*)k_c1_wgrad<MT, 2>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 2>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    else if (p.da) { raise_lds_limit((const void*)k_c1_wgrad<MT, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
     else { raise_lds_limit((const void*)k_c1_wgrad<MT, 0>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 0>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
 }
 static void c1_launch_wgrad(const C1Plan& pl, const C1Params& p, hipStream_t s) {
@@ -415,18 +426,33 @@ int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, co
 int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
     return c1_bwd_weight_bn(g, gy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, x, dw, dbias, ws, ws_bytes, s);
 }
+static int c1_bwd_weight_any(const mn_conv_geom* g, const float* gy, const float* da, const float* yb, const float* save, const float* gamma, const float* beta,
+                             const float* chan, int quant, float qs, const float* sums, int training, const float* x, float* dw, float* dbias, void* ws,
+                             int64_t ws_bytes, hipStream_t s);
 int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, const float* yb, const float* save, const float* gamma, const float* beta,
                      const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    return c1_bwd_weight_any(g, gy, da, yb, save, gamma, beta, nullptr, 0, 1.f, sums, training, x, dw, dbias, ws, ws_bytes, s);
+}
+// the DoReFa block: dq, y, chan [9][O] (mn_qa_chan_from_save), sums of mn_qa_bwd_sums
+int c1_bwd_weight_qa(const mn_conv_geom* g, const float* dq, const float* yb, const float* chan, int quant, int a_bits, const float* sums, int training,
+                     const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    if (!chan || a_bits < 2 || a_bits > 8) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_first_qa: bad arguments");
+    return c1_bwd_weight_any(g, nullptr, dq, yb, nullptr, nullptr, nullptr, chan, quant, dorefa_scale(a_bits), sums, training, x, dw, dbias, ws, ws_bytes, s);
+}
+static int c1_bwd_weight_any(const mn_conv_geom* g, const float* gy, const float* da, const float* yb, const float* save, const float* gamma, const float* beta,
+                             const float* chan, int quant, float qs, const float* sums, int training, const float* x, float* dw, float* dbias, void* ws,
+                             int64_t ws_bytes, hipStream_t s) {
     C1Plan pl;
     if (!plan_c1(g, &pl, 2) || (gy && !aligned16(gy)) || (da && (!aligned16(da) || !aligned16(yb)))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(first-layer): geometry not covered");
-    if (!gy && (!da || !yb || !save || !gamma || !beta || !sums)) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight(first-layer, bn): null argument");
+    if (!gy && (!da || !yb || !sums || (!chan && (!save || !gamma || !beta)))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight(first-layer, bn): null argument");
     if (!ws || ws_bytes < pl.ws_bytes_w || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(first-layer): workspace too small");
     C1Params& p = pl.p;
     p.x = x; p.gy = gy; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
     p.wp = nullptr; p.bias = nullptr; p.y = nullptr;
     p.da = gy ? nullptr : da; p.yb = yb; p.save = save; p.gamma = gamma; p.beta = beta; p.sums = sums; p.training = training;
     p.n_f = (float)g->N * (float)(g->H * g->W);
-    mn_set_last_kernel("k_c1_wgrad<%d, %d>", pl.MT, p.da ? 1 : 0);
+    p.chan = gy ? nullptr : chan; p.quant = quant; p.qs = qs;
+    mn_set_last_kernel("k_c1_wgrad<%d, %d>", pl.MT, p.da ? (p.chan ? 2 : 1) : 0);
     { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((p.da ? 8.0 : 4.0) * ny + 4.0 * g->N * g->C * g->H * g->W); }
     mn_prof_begin(s);
     c1_launch_wgrad(pl, p, s);

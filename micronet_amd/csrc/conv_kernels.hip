@@ -799,6 +799,14 @@ extern "C" int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float*
     if (!c1_supported(g, 2)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight_first_bn: geometry not covered by the first-layer kernels");
     return c1_bwd_weight_bn(g, nullptr, da, y, save, gamma, beta, sums, training, x, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
 }
+extern "C" int mn_conv2d_bwd_weight_first_qa(const mn_conv_geom* g, const float* dq, const float* y, const float* chan, const float* sums, int a_bits,
+                                             int quant, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_weight_first_qa");
+    if (rc) return rc;
+    if (!x || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_first_qa: null tensor");
+    if (!c1_supported(g, 2)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight_first_qa: geometry not covered by the first-layer kernels");
+    return c1_bwd_weight_qa(g, dq, y, chan, quant, a_bits, sums, training, x, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw,
                                     float* dbias, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream) {
     int rc = check_geom(g, "mn_conv2d_bwd_weight");

@@ -38,7 +38,6 @@ __device__ __forceinline__ void qa_eval(float v, const QaCh& k, float& zh, float
     zh = (y - k.mean) * k.invstd;
     z = zh * k.ga + k.be;
 }
-__device__ __forceinline__ float qa_relu(float z) { return (z > 0.f) ? z : ((z != z) ? z : 0.f); }
 __device__ __forceinline__ uint32_t qa_code(float a, float s) {
     const float j = mn_rha(mn_clamp(a * 0.1f, 0.f, 1.f) / s);
     return (j > 0.f) ? (uint32_t)j : 0u;                 // NaN -> 0 (a byte cannot hold it)
@@ -128,10 +127,7 @@ __global__ __launch_bounds__(256) void k_qa_fwd(const QaGeom g, const void* __re
 // dz of the 8 elements (no pool) / of the 16 elements of 4 windows (pool: only the window's first maximum receives gradient).
 // QUANT 1: dq is the gradient w.r.t. the QUANTISED activation (the clip-STE of the quantizer is applied here); 0: w.r.t. the activation itself
 // (the block's consumer is not a quantised conv: e.g. the last block of the net).
-__device__ __forceinline__ float qa_dz(float gq, float a, float z, float s, int quant) {
-    const float d = quant ? dorefa_act_grad(gq, a, s) : gq;
-    return (z > 0.f) ? d : 0.f;
-}
+// (qa_relu, qa_dz: common.h -- shared with the first-layer backward-weight kernel that folds this block, conv_first.hip)
 template <int IN, int POOL>
 __global__ __launch_bounds__(256) void k_qa_partial(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, const float* __restrict__ dq,
                                                     int quant, double* __restrict__ part) {

@@ -16,6 +16,8 @@ int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* b
 int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, const float* yb, const float* save, const float* gamma, const float* beta,
                      const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+int c1_bwd_weight_qa(const mn_conv_geom* g, const float* dq, const float* yb, const float* chan, int quant, int a_bits, const float* sums, int training,
+                     const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 // pointwise convolution on int8 sign codes, fused BatchNorm + sign epilogues (qgemm_sign.hip)
 int pws_supported(const mn_conv_geom* g, const mn_wq* wq);
 int64_t pws_ws_bytes(const mn_conv_geom* g);

@@ -739,7 +739,17 @@ class QConv2d(Function):
                     _call("mn_conv2d_bwd_weight_bnh", C.byref(g), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(x), _p(dw),
                           _p(db), _p(ws), nb, _s())
             return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
-        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") != "bnh" and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") == "qa" and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
+                CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
+            r = gy._mn_recipe              # the DoReFa block (BatchNorm + ReLU + next quantizer) behind the first conv: dy is formed inside the backward-weight kernel
+            dw = torch.empty_like(wq)
+            db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
+            with torch.cuda.device_of(x):
+                ws, nb = _ws(g, 2, x.device)
+                _call("mn_conv2d_bwd_weight_first_qa", C.byref(g), _p(r["dq"]), _p(r["y"]), _p(r["chan"]), _p(r["sums"]), r["bits"], r["quant"], r["training"],
+                      _p(x), _p(dw), _p(db), _p(ws), nb, _s())
+            return None, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") not in ("bnh", "qa") and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
             r = gy._mn_recipe              # the BatchNorm+sign behind the first conv: dy is formed inside the backward-weight kernel
             dw = torch.empty_like(wq)
@@ -1022,10 +1032,20 @@ class BNReLUQ(Function):
         dev = src.device
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)
-        dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws = torch.empty(int(_lib_().mn_qa_ws_floats(Cc)), dtype=torch.float32, device=dev)
             _call("mn_qa_bwd_sums", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+            if in_f32 and not pool and LAZY_BN_GRAD and FOLD_BN_INTO_CONV_BWD:
+                # the block behind the un-quantised first conv: d loss / d y has ONE consumer, that conv's backward-weight, which forms it from
+                # (dq, y) while they stream in (mn_conv2d_bwd_weight_first_qa) -- dy is neither written nor re-read
+                def expand(r):
+                    dy_ = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+                    with torch.cuda.device(dev):
+                        _call("mn_qa_bwd_apply", 1, _p(r["y"]), _p(r["chan"]), _p(r["sums"]), _p(r["dq"]), N, Cc, H, W, r["bits"], 0, r["quant"], r["training"], _p(dy_), _s())
+                    return dy_
+                recipe = dict(kind="qa", dq=dq, y=src, chan=chan, sums=sums, bits=qbits, quant=quant, training=training)
+                return LazyBNGrad((N, Cc, H, W), dev, recipe, expand), dgamma, dbeta, None, None, None, None, None, None, None, None
+            dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
             _call("mn_qa_bwd_apply", in_f32, _p(src), _p(chan), _p(sums), _p(dq), N, Cc, H, W, qbits, pool, quant, training, _p(dy), _s())
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
 

@@ -662,6 +662,36 @@ def check_first_conv_bn_wgrad(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, training=Tru
     assert eq(be.to_host(dw), be.to_host(dw_ref)) and eq(be.to_host(db), be.to_host(db_ref))
 
 
+def check_first_conv_qa_wgrad(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, training=True, quant=1, bits=2, seed=0):
+    """mn_qa_bwd_sums + mn_conv2d_bwd_weight_first_qa (dy of the DoReFa block BatchNorm + ReLU + next-layer quantizer formed inside the first-layer
+    backward-weight) vs the two-step path mn_qa_bwd_apply -> mn_conv2d_bwd_weight: same expressions, so the results agree to the last bit."""
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    x = r.standard_normal(x_shape).astype(F)
+    yb = (r.standard_normal((N, Oc, H, W)) * 1.5).astype(F)
+    dq = r.standard_normal((N, Oc, H, W)).astype(F)
+    gamma, beta = (r.standard_normal(Oc) * 2.0 + 3.0).astype(F), (r.standard_normal(Oc) * 2.0 + 3.0).astype(F)      # activations on both sides of the clamp's upper edge (a = 10)
+    mean, var = yb.mean(axis=(0, 2, 3)), yb.var(axis=(0, 2, 3))
+    save = np.stack([mean, 1.0 / np.sqrt(var + 1e-5)]).astype(F)
+    g = be.geom(x_shape, (Oc, Cin, k, k), padding=k // 2)
+    assert be.lib.mn_conv2d_first_supported(C.byref(g), 2) == 1
+    dX, dY, dDQ, dS, dG, dB = be.to_dev(x), be.to_dev(yb), be.to_dev(dq), be.to_dev(save), be.to_dev(gamma), be.to_dev(beta)
+    chan = be.empty((9, Oc))
+    be.call("mn_qa_chan_from_save", be.ptr(dS), be.ptr(dG), be.ptr(dB), Oc, be.ptr(chan), be.stream)
+    ws = be.empty(int(be.lib.mn_qa_ws_floats(Oc)) + 2)
+    sums, dgam, dbet, dy = be.empty((2, Oc)), be.empty(Oc), be.empty(Oc), be.empty((N, Oc, H, W))
+    be.call("mn_qa_bwd_sums", 1, be.ptr(dY), be.ptr(chan), be.ptr(dDQ), N, Oc, H, W, bits, 0, quant, be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(ws), be.stream)
+    be.call("mn_qa_bwd_apply", 1, be.ptr(dY), be.ptr(chan), be.ptr(sums), be.ptr(dDQ), N, Oc, H, W, bits, 0, quant, int(training), be.ptr(dy), be.stream)
+    dw_ref, db_ref = be.conv_bwd_weight(g, be.actq(0), dy, dX, 0, bias=True)
+    nb = be.lib.mn_conv2d_ws_bytes(C.byref(g), 2, 0)
+    ws2 = be.empty(max(4, nb // 4 + 4))
+    dw, db = be.empty((Oc, Cin, k, k)), be.empty(Oc)
+    be.call("mn_conv2d_bwd_weight_first_qa", C.byref(g), be.ptr(dDQ), be.ptr(dY), be.ptr(chan), be.ptr(sums), bits, quant, int(training),
+            be.ptr(dX), be.ptr(dw), be.ptr(db), be.ptr(ws2), nb, be.stream)
+    assert np.abs(be.to_host(dw_ref)).max() > 0
+    assert eq(be.to_host(dw), be.to_host(dw_ref)) and eq(be.to_host(db), be.to_host(db_ref))
+
+
 def check_ternary_multi(be, seed=0):
     """mn_ternary_w_fwd_multi / mn_ternary_w_bwd_multi (one launch over several weight tensors) bit-identical to the per-tensor entry points."""
     r = np.random.default_rng(seed)

@@ -366,6 +366,13 @@ def test_code_classifier(be):
 
 
 @pytest.mark.parametrize("training", [True, False])
+def test_first_conv_qa_wgrad(be, training):
+    K.check_first_conv_qa_wgrad(be, training=training)
+    K.check_first_conv_qa_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, quant=0, bits=4, seed=1)
+    K.check_first_conv_qa_wgrad(be, x_shape=(8, 3, 32, 32), Oc=256, k=5, training=training, quant=1, seed=2)
+
+
+@pytest.mark.parametrize("training", [True, False])
 def test_first_conv_bn_wgrad(be, training):
     K.check_first_conv_bn_wgrad(be, training=training)
     K.check_first_conv_bn_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, seed=1)

@@ -239,6 +239,12 @@ def test_code_classifier(be):
 
 
 @pytest.mark.parametrize("training", [True, False])
+def test_first_conv_qa_wgrad(be, training):
+    K.check_first_conv_qa_wgrad(be, training=training)
+    K.check_first_conv_qa_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, quant=0, bits=4, seed=1)
+
+
+@pytest.mark.parametrize("training", [True, False])
 def test_first_conv_bn_wgrad(be, training):
     K.check_first_conv_bn_wgrad(be, training=training)
     K.check_first_conv_bn_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, seed=1)
