@@ -65,6 +65,22 @@ struct PwsParams {
     ChanMap in_map;
 };
 
+#ifndef WG3_TRACE
+#define WG3_TRACE 0
+#endif
+
+#if WG3_TRACE      // debugging aid (variant builds only): cycle stamps of one producer and one consumer wave of block 0 around every barrier
+__device__ long long g_wg3_trace[2][3][1024];
+extern "C" int mn_debug_wg3_trace(long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg3_trace), sizeof(g_wg3_trace)) == hipSuccess ? 0 : 1; }
+#define WG3_STAMP(role, slot, idx) if (blockIdx.x == 7 && lane == 0 && ((threadIdx.x >> 6) == (role ? 4 : 0)) && (idx) >= 0 && (idx) < 1024) g_wg3_trace[role][slot][idx] = clock64();
+#else
+#define WG3_STAMP(role, slot, idx)
+#endif
+#if WG3_TRACE
+#define PWS_STAMP(slot, idx) if (blockIdx.x == 9 && lane == 0 && wave == 0 && (idx) >= 0 && (idx) < 1024) g_wg3_trace[0][slot][idx] = clock64();
+#else
+#define PWS_STAMP(slot, idx)
+#endif
 // XENC 0: x holds int8 sign codes (+-1).  XENC 1: x holds k-bit activation codes j in [0, 127] as bytes (the DoReFa / IAO activation quantizer's
 // integer, wqaq/dorefa/quantize.py:43-45): the B fragments are built as bf16 128 + j (high byte 0x43, low byte j: one v_perm + one v_or per
 // fragment dword), every product and sum stays an exact integer, and the epilogue subtracts 128 * sum_k code_w[o][k] (c2 = that row constant).
@@ -91,6 +107,9 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
     double* red = reinterpret_cast<double*>(coff + p.Kp);      // [4][MB][2] cross-wave reduction (RED); 8-byte aligned by layout
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const uint32_t HW = (uint32_t)p.HW;
+#if WG3_TRACE
+    if (blockIdx.x == 9 && tid == 0) g_wg3_trace[1][0][0] = clock64();
+#endif
 
     uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7u; b >>= 3;
@@ -99,55 +118,13 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
     if (idx >= (uint32_t)(p.G * p.CB)) return;
     const int cb = idx % p.CB, g = idx / p.CB;
 
-    {   // stage weight codes, the per-channel constants of this m-block and the input-channel offset table
-        const uint16_t* wg = p.wc + ((int64_t)g * p.Mpad + mblk * MB) * p.Kp;
-        const int k8 = p.Kp >> 3;
-        for (int q = tid; q < MB * k8; q += 256) {
-            const int row = q / k8, c8 = q - row * k8;
-            // the sign codes are contracted as +-0.5 (one v_perm per B-fragment dword, see the main loop): the weight codes are doubled here --
-            // a bf16 integer code times two is its exponent field plus one (0x0080), zero stays zero -- so every product is the exact +-code
-            u32x4 wv = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.Kp + c8 * 8);
-            if (XENC == 0) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) wv[d] += ((wv[d] & 0x00007fffu) ? 0x00000080u : 0u) | ((wv[d] & 0x7fff0000u) ? 0x00800000u : 0u);
-            }
-            *reinterpret_cast<u32x4*>(wsm + row * LDW + c8 * 8) = wv;
-        }
-        for (int i = tid; i < MB; i += 256) {
-            const int m = mblk * MB + i;
-            const bool mv = m < p.Mr;
-            const int co = g * p.Mr + (mv ? m : 0);
-            const int C = p.Cout_total;
-            if (EPI == PWS_Y) { c0[i] = p.rowscale[g * p.Mpad + m] * p.ascale; c1[i] = (p.bias && mv) ? p.bias[co] : 0.f; }
-            if (EPI == PWS_SIGN8) { c0[i] = p.chan[co]; c1[i] = p.chan[C + co]; c2[i] = p.chan[7 * C + co]; }
-            if (GRAD) { c0[i] = p.chan[2 * C + co]; c1[i] = p.chan[3 * C + co]; c2[i] = p.chan[C + co]; c3[i] = p.chan[4 * C + co]; c4[i] = p.chan[5 * C + co]; }
-            if (APPLY) {
-                c5[i] = p.chan[6 * C + co];
-                c6[i] = p.training ? p.sums[co] / p.n_f : 0.f;
-                c7[i] = p.training ? p.sums[C + co] / p.n_f : 0.f;
-            }
-        }
-        for (int c = tid; c < p.Kp; c += 256) coff[c] = (uint32_t)chan_phys(p.in_map, g * p.Kc + (c < p.Kc ? c : p.Kc - 1)) * HW;
-    }
+    // the input-channel offset table first: the code loads of the wave's first two chunks are issued BEFORE the weights are staged, so the two
+    // latencies (HBM for the codes, L2 for the weights) overlap instead of adding up at the head of every block (7000 + 3300 of ~60000 cycles)
+    for (int c = tid; c < p.Kp; c += 256) coff[c] = (uint32_t)chan_phys(p.in_map, g * p.Kc + (c < p.Kc ? c : p.Kc - 1)) * HW;
     __syncthreads();
-    if (XENC == 1) {                          // c2[row] = 128 * sum of the row's weight codes (exact small integers in bf16)
-        for (int rb = 0; rb < MB; rb += 64) {
-            const int row = rb + (tid >> 2), part = tid & 3;
-            float sm = 0.f;
-            if (row < MB) for (int k = part; k < p.Kp; k += 4) sm += mn_u2f((uint32_t)wsm[row * LDW + k] << 16);
-            sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 1, 64);
-            if (row < MB && part == 0) c2[row] = 128.f * sm;
-        }
-        __syncthreads();
-    } else if (EPI == PWS_STATS && p.h8) {          // the statistics pass also writes the byte stash: nnz[row] from the staged codes (4 threads per row)
-        const int row = tid >> 2, part = tid & 3;
-        int cnt = 0;
-        if (row < MB) for (int k = part; k < p.Kp; k += 4) cnt += (wsm[row * LDW + k] & 0x7fffu) != 0;
-        cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 1, 64);
-        if (row < MB && part == 0) c2[row] = (float)cnt;
-        __syncthreads();
-    }
-
+#if WG3_TRACE
+    if (blockIdx.x == 9 && tid == 0) g_wg3_trace[1][1][0] = clock64();
+#endif
     const int chunk0 = cb * 4 + wave, cstride = p.CB * 4;
     const uint16_t* wl = wsm + j * LDW + kg * 8;
     const uint32_t Pmax = p.NP - 4u;                         // NP is a multiple of 4: the last valid quad
@@ -192,7 +169,72 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             for (int s = 0; s < KS; ++s) load_step(reinterpret_cast<uint32_t (&)[KS * 8]>(curB), s, xo1);
         }
     }
+    {   // stage weight codes and the per-channel constants of this m-block (the first two chunks of codes are already in flight)
+        const uint16_t* wg = p.wc + ((int64_t)g * p.Mpad + mblk * MB) * p.Kp;
+        const int k8 = p.Kp >> 3;
+        // row constant c2 (XENC 1: 128 * sum of the row's codes; statistics pass with byte stash: the row's non-zero count) in the same pass when the k8
+        // threads of a row are an aligned lane group (k8 = 4, 8, 16, 32, 64): 8 codes per thread, a log2(k8)-step butterfly.  Else: the loops below.
+        const bool rowc_here = (XENC == 1 || (EPI == PWS_STATS && p.h8)) && k8 >= 4 && k8 <= 64 && (k8 & (k8 - 1)) == 0 && (MB * k8) % 256 == 0;
+        for (int q = tid; q < MB * k8; q += 256) {
+            const int row = q / k8, c8 = q - row * k8;
+            // the sign codes are contracted as +-0.5 (one v_perm per B-fragment dword, see the main loop): the weight codes are doubled here --
+            // a bf16 integer code times two is its exponent field plus one (0x0080), zero stays zero -- so every product is the exact +-code
+            u32x4 wv = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.Kp + c8 * 8);
+            if (rowc_here) {
+                float v = 0.f;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (XENC == 1) v += mn_u2f(wv[d] << 16) + mn_u2f(wv[d] & 0xffff0000u);
+                    else v += ((wv[d] & 0x00007fffu) ? 1.f : 0.f) + ((wv[d] & 0x7fff0000u) ? 1.f : 0.f);
+                }
+                for (int o = k8 >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);         // exact: small integers
+                if (c8 == 0) c2[row] = XENC == 1 ? 128.f * v : v;
+            }
+            if (XENC == 0) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) wv[d] += ((wv[d] & 0x00007fffu) ? 0x00000080u : 0u) | ((wv[d] & 0x7fff0000u) ? 0x00800000u : 0u);
+            }
+            *reinterpret_cast<u32x4*>(wsm + row * LDW + c8 * 8) = wv;
+        }
+        for (int i = tid; i < MB; i += 256) {
+            const int m = mblk * MB + i;
+            const bool mv = m < p.Mr;
+            const int co = g * p.Mr + (mv ? m : 0);
+            const int C = p.Cout_total;
+            if (EPI == PWS_Y) { c0[i] = p.rowscale[g * p.Mpad + m] * p.ascale; c1[i] = (p.bias && mv) ? p.bias[co] : 0.f; }
+            if (EPI == PWS_SIGN8) { c0[i] = p.chan[co]; c1[i] = p.chan[C + co]; c2[i] = p.chan[7 * C + co]; }
+            if (GRAD) { c0[i] = p.chan[2 * C + co]; c1[i] = p.chan[3 * C + co]; c2[i] = p.chan[C + co]; c3[i] = p.chan[4 * C + co]; c4[i] = p.chan[5 * C + co]; }
+            if (APPLY) {
+                c5[i] = p.chan[6 * C + co];
+                c6[i] = p.training ? p.sums[co] / p.n_f : 0.f;
+                c7[i] = p.training ? p.sums[C + co] / p.n_f : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int k8_ = p.Kp >> 3;
+    const bool rowc_done = (XENC == 1 || (EPI == PWS_STATS && p.h8)) && k8_ >= 4 && k8_ <= 64 && (k8_ & (k8_ - 1)) == 0 && (MB * k8_) % 256 == 0;
+    if (rowc_done) {
+    } else if (XENC == 1) {                   // c2[row] = 128 * sum of the row's weight codes (exact small integers in bf16)
+        for (int rb = 0; rb < MB; rb += 64) {
+            const int row = rb + (tid >> 2), part = tid & 3;
+            float sm = 0.f;
+            if (row < MB) for (int k = part; k < p.Kp; k += 4) sm += mn_u2f((uint32_t)wsm[row * LDW + k] << 16);
+            sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 1, 64);
+            if (row < MB && part == 0) c2[row] = 128.f * sm;
+        }
+        __syncthreads();
+    } else if (EPI == PWS_STATS && p.h8) {          // the statistics pass also writes the byte stash: nnz[row] from the staged codes (4 threads per row)
+        const int row = tid >> 2, part = tid & 3;
+        int cnt = 0;
+        if (row < MB) for (int k = part; k < p.Kp; k += 4) cnt += (wsm[row * LDW + k] & 0x7fffu) != 0;
+        cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 1, 64);
+        if (row < MB && part == 0) c2[row] = (float)cnt;
+        __syncthreads();
+    }
+
     auto body = [&](uint32_t (&cur)[KS * 8], int chunk) {
+        PWS_STAMP(0, (chunk - chunk0) / cstride)
         const uint32_t P = (uint32_t)chunk * 64u + 4u * j;
         const bool pv = P < p.NP;
         const uint32_t n = fd_div(P, p.fd_hw);
@@ -276,7 +318,40 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             }
         }
 
+        PWS_STAMP(1, (chunk - chunk0) / cstride)
         // epilogue: lane (j, kg) holds out-channels t*16 + 4kg + r of pixels P .. P+3; acc is an exact integer
+        // Statistics pass, whole chunk and whole m-block valid (wave-uniform; every nin_gc chunk): straight-line code.  The guarded form below is one
+        // basic block per (tile, row), each with its own LDS read of the row constant and a full wait for it: 16 exposed LDS round trips per chunk,
+        // more cycles than the 64 MFMAs in front of them.
+        const bool whole = EPI == PWS_STATS && (uint32_t)chunk * 64u + 64u <= p.NP && mblk * MB + MB <= p.Mr;
+        if (whole) {
+            float4 rc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) rc[t] = *reinterpret_cast<const float4*>(c2 + t * 16 + kg * 4);      // XENC 1: 128 * sum w;  XENC 0: nnz
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float rcv[4] = {rc[t].x, rc[t].y, rc[t].z, rc[t].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xc = XENC == 1 ? rcv[r] : 0.f;
+                    const float o[4] = {acc[0][t][r] - xc, acc[1][t][r] - xc, acc[2][t][r] - xc, acc[3][t][r] - xc};
+                    const uint32_t off = obase + (uint32_t)(t * 16 + r) * HW;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1[t][r] += o[e]; s2[t][r] = fmaf(o[e], o[e], s2[t][r]); }
+                    if (XENC == 1) {
+                        if (p.h16) {
+                            const uint32_t f0 = mn_f2u(o[0] + 12582912.f), f1 = mn_f2u(o[1] + 12582912.f), f2 = mn_f2u(o[2] + 12582912.f), f3 = mn_f2u(o[3] + 12582912.f);
+                            *reinterpret_cast<u32x2*>(p.h16 + off) = u32x2{mn_perm(f1, f0, 0x05040100u), mn_perm(f3, f2, 0x05040100u)};
+                        }
+                    } else if (p.h8) {
+                        const float nz = rcv[r];
+                        const uint32_t f0 = mn_f2u(fmaf(o[0] + nz, 0.5f, 12582912.f)), f1 = mn_f2u(fmaf(o[1] + nz, 0.5f, 12582912.f));
+                        const uint32_t f2 = mn_f2u(fmaf(o[2] + nz, 0.5f, 12582912.f)), f3 = mn_f2u(fmaf(o[3] + nz, 0.5f, 12582912.f));
+                        *reinterpret_cast<uint32_t*>(p.h8 + off) = mn_perm(f1, f0, 0x0c0c0400u) | mn_perm(f3, f2, 0x04000c0cu);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -287,16 +362,22 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                 const float o[4] = {acc[0][t][r] - xc, acc[1][t][r] - xc, acc[2][t][r] - xc, acc[3][t][r] - xc};
                 const uint32_t off = obase + (uint32_t)(t * 16 + r) * HW;
                 if (EPI == PWS_STATS) {
+                    // This epilogue was 60 % of the kernel's cycles (stamps: 2300 per chunk in the K loop, 4100 here): ~40 VALU per (tile, row) in
+                    // float -> integer conversions, shifts and unfused multiply-adds.  Integers reach the stash through the float's own mantissa
+                    // instead (v + 1.5 * 2^23 holds v in two's complement in its low bits: exact for |v| < 2^22) and one v_perm packs the bytes.
                     if (ok) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1[t][r] += o[e]; s2[t][r] += o[e] * o[e]; }      // exact: integers below 2^24
+                        for (int e = 0; e < 4; ++e) { s1[t][r] += o[e]; s2[t][r] = fmaf(o[e], o[e], s2[t][r]); }      // exact: integers below 2^24 (fused or not)
                         if (XENC == 1) {
-                            if (p.h16) *reinterpret_cast<u32x2*>(p.h16 + off) = u32x2{((uint32_t)(int)o[0] & 0xffffu) | ((uint32_t)(int)o[1] << 16),
-                                                                                     ((uint32_t)(int)o[2] & 0xffffu) | ((uint32_t)(int)o[3] << 16)};
+                            if (p.h16) {
+                                const uint32_t f0 = mn_f2u(o[0] + 12582912.f), f1 = mn_f2u(o[1] + 12582912.f), f2 = mn_f2u(o[2] + 12582912.f), f3 = mn_f2u(o[3] + 12582912.f);
+                                *reinterpret_cast<u32x2*>(p.h16 + off) = u32x2{mn_perm(f1, f0, 0x05040100u), mn_perm(f3, f2, 0x05040100u)};
+                            }
                         } else if (p.h8) {          // byte stash written by the statistics pass: the sign then is a streaming pass over h (k_h_sign)
-                            const float nz = c2[ml];
-                            *reinterpret_cast<uint32_t*>(p.h8 + off) = (uint32_t)((o[0] + nz) * 0.5f) | ((uint32_t)((o[1] + nz) * 0.5f) << 8) |
-                                                                       ((uint32_t)((o[2] + nz) * 0.5f) << 16) | ((uint32_t)((o[3] + nz) * 0.5f) << 24);
+                            const float nz = c2[ml];           // o + nz is even: half of it plus the magic constant is exact
+                            const uint32_t f0 = mn_f2u(fmaf(o[0] + nz, 0.5f, 12582912.f)), f1 = mn_f2u(fmaf(o[1] + nz, 0.5f, 12582912.f));
+                            const uint32_t f2 = mn_f2u(fmaf(o[2] + nz, 0.5f, 12582912.f)), f3 = mn_f2u(fmaf(o[3] + nz, 0.5f, 12582912.f));
+                            *reinterpret_cast<uint32_t*>(p.h8 + off) = mn_perm(f1, f0, 0x0c0c0400u) | mn_perm(f3, f2, 0x04000c0cu);
                         }
                     }
                 } else if (EPI == PWS_Y) {
@@ -353,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                 }
             }
         }
+        PWS_STAMP(2, (chunk - chunk0) / cstride)
     };
     if (GRAD) {
         for (int chunk = chunk0; chunk < p.nchunks; chunk += cstride) body(curA, chunk);
@@ -363,27 +445,37 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
         }
     }
 
-    if (RED) {   // block partial in fp64: 16 pixel lanes -> wave -> 4 waves (fixed order), one [MB][2] row per block
+#if WG3_TRACE
+    if (blockIdx.x == 9 && tid == 0) g_wg3_trace[1][2][0] = clock64();
+#endif
+    if (RED) {
+        // block partial in fp64, fixed order: every lane's 2 * 4 NT floats go to LDS ([value][wave][lane]: conflict-free rows), then thread (row, which)
+        // adds its 4 waves x 16 pixel lanes.  (The butterfly of 64-bit shuffles this replaces cost ~9000 cycles per block: 256 ds_bpermute.)
+        __syncthreads();                                    // every wave is done with the staged weights: the LDS is free
+        float* rf = smem;                                   // [NT * 8][4][64]
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double v1 = (double)s1[t][r], v2 = (double)s2[t][r];
-                v1 += __shfl_xor(v1, 8, 64); v1 += __shfl_xor(v1, 4, 64); v1 += __shfl_xor(v1, 2, 64); v1 += __shfl_xor(v1, 1, 64);
-                v2 += __shfl_xor(v2, 8, 64); v2 += __shfl_xor(v2, 4, 64); v2 += __shfl_xor(v2, 2, 64); v2 += __shfl_xor(v2, 1, 64);
-                if (j == 0) {
-                    const int ml = t * 16 + kg * 4 + r;
-                    red[(wave * MB + ml) * 2] = v1; red[(wave * MB + ml) * 2 + 1] = v2;
-                }
+                rf[(((t * 4 + r) * 2 + 0) * 4 + wave) * 64 + lane] = s1[t][r];
+                rf[(((t * 4 + r) * 2 + 1) * 4 + wave) * 64 + lane] = s2[t][r];
             }
         __syncthreads();
-        for (int i = tid; i < MB; i += 256) {
-            const double v1 = ((red[i * 2] + red[(MB + i) * 2]) + red[(2 * MB + i) * 2]) + red[(3 * MB + i) * 2];
-            const double v2 = ((red[i * 2 + 1] + red[(MB + i) * 2 + 1]) + red[(2 * MB + i) * 2 + 1]) + red[(3 * MB + i) * 2 + 1];
-            double* dst = reinterpret_cast<double*>(p.part) + ((int64_t)cb * p.G * p.Mpad + g * p.Mpad + mblk * MB + i) * 2;
-            dst[0] = v1; dst[1] = v2;
+        for (int i = tid; i < 2 * MB; i += 256) {
+            const int ml = i >> 1, which = i & 1;
+            const int t = ml >> 4, kq = (ml >> 2) & 3, r = ml & 3;
+            const float* src = rf + ((t * 4 + r) * 2 + which) * 4 * 64 + kq * 16;
+            double v = 0.0;
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v += (double)src[w * 64 + q];
+            double* dst = reinterpret_cast<double*>(p.part) + ((int64_t)cb * p.G * p.Mpad + g * p.Mpad + mblk * MB + ml) * 2;
+            dst[which] = v;
         }
     }
+#if WG3_TRACE
+    if (blockIdx.x == 9 && tid == 0) g_wg3_trace[1][2][1] = clock64();
+#endif
 }
 
 // batch statistics from the PWS_STATS partials (exact integer sums S1 = sum acc, S2 = sum acc^2 over N*HW): y = alpha*acc + bias,
@@ -748,13 +840,6 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
 #endif
 #ifndef WG3_PRIO
 #define WG3_PRIO 0
-#endif
-#if WG3_TRACE      // debugging aid (variant builds only): cycle stamps of one producer and one consumer wave of block 0 around every barrier
-__device__ long long g_wg3_trace[2][3][1024];
-extern "C" int mn_debug_wg3_trace(long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg3_trace), sizeof(g_wg3_trace)) == hipSuccess ? 0 : 1; }
-#define WG3_STAMP(role, slot, idx) if (blockIdx.x == 7 && lane == 0 && ((threadIdx.x >> 6) == (role ? 4 : 0)) && (idx) >= 0 && (idx) < 1024) g_wg3_trace[role][slot][idx] = clock64();
-#else
-#define WG3_STAMP(role, slot, idx)
 #endif
 // SPEC 1: wave-specialised, 512 threads.  Waves 0-3 are PRODUCERS (global loads, BatchNorm fold, the three-term split, LDS writes: VALU only),
 // waves 4-7 CONSUMERS (fragment reads + MFMA only, the 2 x 2 wave grid of the tile).  Every SIMD hosts one of each, so the VALU pipe and the matrix
@@ -1247,6 +1332,7 @@ static int plan_pws(const mn_conv_geom* g, int nt_max, PwsPlan* pl) {
     pl->NT = NT;
     const int MB = 16 * NT;
     pl->lds = (size_t)MB * (p.Kp + 8) * 2 + (size_t)8 * MB * 4 + (size_t)p.Kp * 4 + (size_t)4 * MB * 2 * 8;
+    if (pl->lds < (size_t)NT * 8 * 4 * 64 * 4) pl->lds = (size_t)NT * 8 * 4 * 64 * 4;      // the block reduction's [value][wave][lane] image reuses the region
     p.num_mblk = (Mg + MB - 1) / MB;
     p.Mpad = ((Mg + 127) / 128) * 128;                    // one packed-code layout for every tile height
     p.nchunks = (int)((p.NP + 63) / 64);
