@@ -70,6 +70,11 @@ int mn_dorefa_w_fwd(const float* w, float* qw, int64_t n, int w_bits, float* ws,
 /* backward incl. the path through the global max (ties share equally) */
 int mn_dorefa_w_bwd(const float* g, const float* w, float* dw, int64_t n, int w_bits, float* ws, mn_stream_t stream);
 
+/* y = tanh(x) exactly as the weight-quantizer kernels evaluate it (device tanhf).  torch-CPU's tanh (Sleef), which the reference runs, differs from it in
+ * the last ulp for ~5 % of inputs (never more than 1 ulp); where such a difference straddles a rounding boundary a weight code differs by one step
+ * (<= 2 in 10^5).  tests/golden/tanh_device_vs_cpu.json pins both functions on inputs where they differ. */
+int mn_tanh_f32(const float* x, float* y, int64_t n, mn_stream_t stream);
+
 /* The same quantizer over count <= 32 weight tensors in ONE launch per phase (host arrays of device pointers / element counts; nothing is allocated,
  * graph-capturable): a training step quantizes every conv's weights, the calls above are 2 + 3 launches of ~5 us per layer.  Bit-identical to them.
  * ws[i]: >= mn_dorefa_w_ws_floats(n[i]) floats each. */

@@ -315,6 +315,17 @@ extern "C" int mn_dorefa_w_bwd(const float* g, const float* w, float* dw, int64_
     return MN_OK;
 }
 
+// the tanh the kernels above evaluate, element-wise: lets the tests pin it against torch-CPU's (tests/golden/tanh_device_vs_cpu.json)
+__global__ void k_tanh_f32(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = tanhf(x[i]);
+}
+extern "C" int mn_tanh_f32(const float* x, float* y, int64_t n, mn_stream_t stream) {
+    if (!x || !y || n <= 0) MN_FAIL(MN_EINVAL, "mn_tanh_f32: bad arguments");
+    hipLaunchKernelGGL(k_tanh_f32, dim3(mn_grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    MN_CHECK_LAUNCH("mn_tanh_f32");
+    return MN_OK;
+}
+
 // The same quantizer over up to MN_DW_MAX_TENSORS weight tensors in ONE launch per phase (a training step quantizes the weights of every conv: as separate
 // calls that is 2 launches forward and 3 backward per layer, each ~5 us): a by-value table maps a block to (tensor, block-in-tensor).  Same
 // arithmetic per tensor (same partial-block count, same reduction order) as the single-tensor entry points: bit-identical results.
