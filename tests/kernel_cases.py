@@ -882,3 +882,17 @@ BNQ_CASES = [
     dict(x_shape=(2, 32, 16, 16), w_shape=(48, 8, 3, 3), groups=4, padding=1, in_shuffle=2, pooled=True, a_bits=3, w_bits=3, out_bits=2),
     dict(x_shape=(4, 48, 8, 8), w_shape=(48, 48, 1, 1), quant=0, a_bits=4, w_bits=4),
 ]
+
+
+# pointwise backward-weight, wave-specialised kernel (tiles of 128: Mg or Cg above 64) on tiles that are NOT full and on short / odd step ranges
+WGRAD_SPEC_CASES = [
+    dict(x_shape=(4, 160, 8, 8), w_shape=(192, 80, 1, 1), groups=2),                  # Mg = 96, Cg = 80: clamped rows; 8 steps over 4 blocks per tile
+    dict(x_shape=(3, 96, 4, 8), w_shape=(80, 96, 1, 1)),                              # 3 steps in ONE block: fewer steps than the prefetch depth, odd count
+    dict(x_shape=(5, 144, 4, 8), w_shape=(144, 72, 1, 1), groups=2, in_shuffle=2),    # 5 steps, shuffled input channels
+]
+
+
+def check_wgrad_spec(be):
+    for i, case in enumerate(WGRAD_SPEC_CASES):
+        check_qconv_bnsign(be, seed=300 + i, stash=True, **case)
+        check_qconv_bnq(be, seed=310 + i, **case)

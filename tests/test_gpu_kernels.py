@@ -517,3 +517,7 @@ def test_dorefa_tanh_pinned(be):
         flips = np.nonzero(k_dev != k_ref)[0]
         assert flips.size <= 2 * (w.size // 100000 + 1), (bits, flips.size)
         assert np.all(np.abs(k_dev[flips] - k_ref[flips]) == 1)
+
+
+def test_pointwise_wgrad_specialised_edge_tiles(be):
+    K.check_wgrad_spec(be)

@@ -316,3 +316,7 @@ def test_cifar_augment_kernel_vs_oracle(be):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     be.call("mn_cifar_augment", p(imgs), 10, p(idx), p(ox), p(oy), p(flip), B, 32, 32, 3, 4, FA(0.4914, 0.4822, 0.4465), FA(0.2023, 0.1994, 0.2010), p(out), None)
     assert np.array_equal(out, O.cifar_augment(imgs, idx, ox, oy, flip))
+
+
+def test_pointwise_wgrad_specialised_edge_tiles(be):
+    K.check_wgrad_spec(be)
