@@ -402,6 +402,16 @@ int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float* dx, int64_
 int mn_codeconv1x1_small_fwd(const uint8_t* codes, int a_bits, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O,
                              mn_stream_t stream);
 
+/* BatchNorm folding of QuantBNFuseConv2d (wqaq/iao/quantize.py:900-956) in one launch (forward) / one launch (backward):
+ *   w_f[o][:] = w[o][:] * (gamma[o] / sqrt(var_w[o] + eps));   bias_f[o] = beta[o] + (bias[o] - mean[o]) * (gamma[o] / sqrt(var_b[o] + eps))
+ * (bias NULL: beta - mean * k_b).  w: [O][K] (K = Cin/g * KH * KW).  Backward: any output pointer may be NULL; dvar_b / dvar_w are returned separately
+ * (the caller adds them when both are the batch variance). */
+int mn_iao_bnfold_fwd(const float* w, const float* bias, const float* gamma, const float* beta, const float* mean, const float* var_b, const float* var_w,
+                      float eps, int64_t O, int64_t K, float* wf, float* bf, mn_stream_t stream);
+int mn_iao_bnfold_bwd(const float* dwf, const float* dbf, const float* w, const float* bias, const float* gamma, const float* mean, const float* var_b,
+                      const float* var_w, float eps, int64_t O, int64_t K, float* dw, float* dbias, float* dgamma, float* dbeta, float* dmean,
+                      float* dvar_b, float* dvar_w, mn_stream_t stream);
+
 /* ------------------------------------------------------------------ input pipeline of the training loop
  * <scheme>/main.py:203-210: transforms.Compose([RandomCrop(32, padding=4), RandomHorizontalFlip(), ToTensor(), Normalize(mean, std)]) applied to a batch
  * gathered from the uint8 dataset resident in device memory.  images: uint8 [n_images][H][W][C] (HWC, torchvision's CIFAR10.data); index [B]: the

@@ -127,6 +127,8 @@ PROTOTYPES = {
     "mn_qa_bwd_sums": (_I, [_I, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mn_qa_bwd_apply": (_I, [_I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
     "mn_cifar_augment": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _L, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
+    "mn_iao_bnfold_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _L, _L, _P, _P, _P]),
+    "mn_iao_bnfold_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mn_tanh_f32": (_I, [_P, _P, _L, _P]),
     "mn_dorefa_w_fwd_multi": (_I, [_P, _P, _P, _P, C.c_int32, _I, _P]),
     "mn_dorefa_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, C.c_int32, _I, _P]),

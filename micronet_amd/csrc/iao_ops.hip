@@ -234,3 +234,70 @@ extern "C" int mn_hist_observe(const float* x, int64_t n, int64_t k, int first, 
     MN_CHECK_LAUNCH("mn_hist_observe");
     return MN_OK;
 }
+
+
+// ---------------------------------------------------------------- BatchNorm folding of QuantBNFuseConv2d (wqaq/iao/quantize.py:900-956)
+//   k_b = gamma / sqrt(var_b + eps);  bias_f = beta + (bias - mean) * k_b   (beta - mean * k_b without a conv bias)
+//   w_f[o][:] = w[o][:] * (gamma / sqrt(var_w + eps))
+// as ONE launch (one block per out-channel) instead of ~8 element-wise launches forward and ~25 backward per layer; every step rounds as the
+// reference's separate fp32 ops do (IEEE divide / sqrt, no contraction).  Backward: the analytic gradients of the same expressions, row sums in fp64.
+__global__ __launch_bounds__(256) void k_iao_bnfold_fwd(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var_b,
+                                                        const float* __restrict__ var_w, float eps, int K, float* __restrict__ wf, float* __restrict__ bf) {
+    const int o = blockIdx.x;
+    const float kw = gamma[o] / sqrtf(var_w[o] + eps);
+    const float* __restrict__ wr = w + (int64_t)o * K;
+    float* __restrict__ dst = wf + (int64_t)o * K;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) dst[i] = wr[i] * kw;
+    if (threadIdx.x == 0) {
+        const float kb = gamma[o] / sqrtf(var_b[o] + eps);
+        bf[o] = bias ? beta[o] + (bias[o] - mean[o]) * kb : beta[o] - mean[o] * kb;
+    }
+}
+__global__ __launch_bounds__(256) void k_iao_bnfold_bwd(const float* __restrict__ dwf, const float* __restrict__ dbf, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ var_b, const float* __restrict__ var_w, float eps, int K,
+                                                        float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, float* __restrict__ dmean, float* __restrict__ dvar_b,
+                                                        float* __restrict__ dvar_w) {
+    __shared__ double scd[16];
+    const int o = blockIdx.x;
+    const float rw = 1.0f / sqrtf(var_w[o] + eps), kw = gamma[o] / sqrtf(var_w[o] + eps);
+    const float* __restrict__ wr = w + (int64_t)o * K;
+    const float* __restrict__ gr = dwf + (int64_t)o * K;
+    double S = 0.0;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const float g = gr[i];
+        if (dw) dw[(int64_t)o * K + i] = g * kw;
+        S += (double)g * (double)wr[i];
+    }
+    S = block_reduce(S, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) {
+        const float rb = 1.0f / sqrtf(var_b[o] + eps), kb = gamma[o] / sqrtf(var_b[o] + eps);
+        const float g = dbf[o];
+        const double D = (double)g * (bias ? (double)bias[o] - (double)mean[o] : -(double)mean[o]);
+        if (dgamma) dgamma[o] = (float)(S * (double)rw + D * (double)rb);
+        if (dbeta) dbeta[o] = g;
+        if (dbias) dbias[o] = g * kb;
+        if (dmean) dmean[o] = -(g * kb);
+        const double vw = (double)var_w[o] + (double)eps, vb = (double)var_b[o] + (double)eps;
+        if (dvar_w) dvar_w[o] = (float)(S * (double)gamma[o] * -0.5 / (vw * sqrt(vw)));
+        if (dvar_b) dvar_b[o] = (float)(D * (double)gamma[o] * -0.5 / (vb * sqrt(vb)));
+    }
+}
+extern "C" int mn_iao_bnfold_fwd(const float* w, const float* bias, const float* gamma, const float* beta, const float* mean, const float* var_b, const float* var_w,
+                                 float eps, int64_t O, int64_t K, float* wf, float* bf, mn_stream_t stream) {
+    if (!w || !gamma || !beta || !mean || !var_b || !var_w || !wf || !bf || O <= 0 || K <= 0 || K > 0x7fffffff) MN_FAIL(MN_EINVAL, "mn_iao_bnfold_fwd: bad arguments");
+    hipLaunchKernelGGL(k_iao_bnfold_fwd, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, w, bias, gamma, beta, mean, var_b, var_w, eps, (int)K, wf, bf);
+    MN_CHECK_LAUNCH("mn_iao_bnfold_fwd");
+    return MN_OK;
+}
+extern "C" int mn_iao_bnfold_bwd(const float* dwf, const float* dbf, const float* w, const float* bias, const float* gamma, const float* mean, const float* var_b,
+                                 const float* var_w, float eps, int64_t O, int64_t K, float* dw, float* dbias, float* dgamma, float* dbeta, float* dmean,
+                                 float* dvar_b, float* dvar_w, mn_stream_t stream) {
+    if (!dwf || !dbf || !w || !gamma || !mean || !var_b || !var_w || O <= 0 || K <= 0 || K > 0x7fffffff) MN_FAIL(MN_EINVAL, "mn_iao_bnfold_bwd: bad arguments");
+    hipLaunchKernelGGL(k_iao_bnfold_bwd, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, dwf, dbf, w, bias, gamma, mean, var_b, var_w, eps, (int)K, dw, dbias,
+                       dgamma, dbeta, dmean, dvar_b, dvar_w);
+    MN_CHECK_LAUNCH("mn_iao_bnfold_bwd");
+    return MN_OK;
+}

@@ -439,6 +439,43 @@ class IaoFakeQuantAvgPool(Function):
         return dx, None, None, None, None
 
 
+class IaoBNFold(Function):
+    """(weight_fused, bias_fused) of QuantBNFuseConv2d (wqaq/iao/quantize.py:900-956): w * (gamma / sqrt(var_w + eps)) and beta + (bias - mean) * (gamma /
+    sqrt(var_b + eps)) in one launch, the analytic backward in one launch (the reference's ~8 + ~25 element-wise kernels per layer)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, gamma, beta, mean, var_b, var_w, eps):
+        weight, gamma, beta, mean, var_b, var_w = (_chk(t, "tensor") for t in (weight, gamma, beta, mean, var_b, var_w))
+        bias = _chk(bias, "bias")
+        O = weight.shape[0]
+        K = weight.numel() // O
+        wf, bf = torch.empty_like(weight), torch.empty(O, dtype=torch.float32, device=weight.device)
+        with torch.cuda.device_of(weight):
+            _call("mn_iao_bnfold_fwd", _p(weight), _p(bias), _p(gamma), _p(beta), _p(mean), _p(var_b), _p(var_w), float(eps), O, K, _p(wf), _p(bf), _s())
+        ctx.save_for_backward(weight, bias, gamma, mean, var_b, var_w)
+        ctx.eps = float(eps)
+        return wf, bf
+
+    @staticmethod
+    def backward(ctx, dwf, dbf):
+        weight, bias, gamma, mean, var_b, var_w = ctx.saved_tensors
+        O = weight.shape[0]
+        K = weight.numel() // O
+        dev = weight.device
+        dwf = _chk(dwf, "grad") if dwf is not None else torch.zeros_like(weight)
+        dbf = _chk(dbf.reshape(-1), "grad") if dbf is not None else torch.zeros(O, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        new = lambda: torch.empty(O, dtype=torch.float32, device=dev)
+        dw = torch.empty_like(weight) if need[0] else None
+        dbias = new() if (bias is not None and need[1]) else None
+        dgamma, dbeta = (new() if need[2] else None), (new() if need[3] else None)
+        dmean, dvb, dvw = (new() if need[4] else None), (new() if need[5] else None), (new() if need[6] else None)
+        with torch.cuda.device_of(weight):
+            _call("mn_iao_bnfold_bwd", _p(dwf), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(mean), _p(var_b), _p(var_w), ctx.eps, O, K, _p(dw), _p(dbias),
+                  _p(dgamma), _p(dbeta), _p(dmean), _p(dvb), _p(dvw), _s())
+        return dw, dbias, dgamma, dbeta, dmean, dvb, dvw, None
+
+
 def hist_observe(x, percentile, first, momentum, max_val):
     """HistogramObserver.forward (ref 126-139) on the device: exact k-th smallest |x| + first-call / EMA update of ``max_val``."""
     x = _chk(x.detach(), "input")

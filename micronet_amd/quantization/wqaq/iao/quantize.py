@@ -328,6 +328,9 @@ class QuantBNFuseConv2d(QuantConv2d):
         init.zeros_(self.beta)
 
     def _fold(self, mean, var_for_bias, var_for_weight):
+        if self.weight.is_cuda and self.weight.dtype == torch.float32 and self.weight.is_contiguous():
+            wf, bf = ops.IaoBNFold.apply(self.weight, self.bias, self.gamma, self.beta, mean, var_for_bias, var_for_weight, self.eps)
+            return wf, reshape_to_bias(bf)
         k_b = self.gamma / torch.sqrt(var_for_bias + self.eps)
         if self.bias is not None:
             bias_fused = reshape_to_bias(self.beta + (self.bias - mean) * k_b)

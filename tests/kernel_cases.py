@@ -896,3 +896,38 @@ def check_wgrad_spec(be):
     for i, case in enumerate(WGRAD_SPEC_CASES):
         check_qconv_bnsign(be, seed=300 + i, stash=True, **case)
         check_qconv_bnq(be, seed=310 + i, **case)
+
+
+def check_iao_bnfold(be, O_=24, K_=37, bias=True, shared_var=True, seed=0):
+    """mn_iao_bnfold_fwd / _bwd vs an fp64 evaluation of wqaq/iao/quantize.py:900-956's fold expressions and their analytic gradients."""
+    r = np.random.default_rng(seed)
+    w = (r.standard_normal((O_, K_)) * 0.2).astype(F)
+    b = (r.standard_normal(O_) * 0.1).astype(F) if bias else None
+    gamma, beta = (r.random(O_) + 0.5).astype(F), (r.standard_normal(O_) * 0.2).astype(F)
+    mean, vb = (r.standard_normal(O_) * 0.3).astype(F), (r.random(O_) * 2 + 0.1).astype(F)
+    vw = vb if shared_var else (r.random(O_) * 2 + 0.1).astype(F)
+    eps = 1e-5
+    dwf, dbf = r.standard_normal((O_, K_)).astype(F), r.standard_normal(O_).astype(F)
+    D = np.float64
+    kw, kb = gamma.astype(D) / np.sqrt(vw.astype(D) + eps), gamma.astype(D) / np.sqrt(vb.astype(D) + eps)
+    wf_ref = w.astype(D) * kw[:, None]
+    bm = (b.astype(D) if bias else 0.0) - mean.astype(D)
+    bf_ref = beta.astype(D) + bm * kb
+    S = (dwf.astype(D) * w.astype(D)).sum(axis=1)
+    Dd = dbf.astype(D) * bm
+    ref = dict(dw=dwf.astype(D) * kw[:, None], dbias=dbf.astype(D) * kb, dgamma=S / np.sqrt(vw.astype(D) + eps) + Dd / np.sqrt(vb.astype(D) + eps), dbeta=dbf.astype(D),
+               dmean=-dbf.astype(D) * kb, dvb=Dd * gamma.astype(D) * -0.5 * (vb.astype(D) + eps) ** -1.5, dvw=S * gamma.astype(D) * -0.5 * (vw.astype(D) + eps) ** -1.5)
+    dW, dB = be.to_dev(w), (be.to_dev(b) if bias else None)
+    dG, dBe, dM, dVb, dVw = be.to_dev(gamma), be.to_dev(beta), be.to_dev(mean), be.to_dev(vb), be.to_dev(vw)
+    wf, bf = be.empty((O_, K_)), be.empty(O_)
+    be.call("mn_iao_bnfold_fwd", be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(dM), be.ptr(dVb), be.ptr(dVw), eps, O_, K_, be.ptr(wf), be.ptr(bf), be.stream)
+    assert close(be.to_host(wf), wf_ref, 2e-7) and close(be.to_host(bf), bf_ref, 5e-7)
+    out = {k: be.empty((O_, K_) if k == "dw" else O_) for k in ("dw", "dbias", "dgamma", "dbeta", "dmean", "dvb", "dvw")}
+    dDwf, dDbf = be.to_dev(dwf), be.to_dev(dbf)
+    be.call("mn_iao_bnfold_bwd", be.ptr(dDwf), be.ptr(dDbf), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dM), be.ptr(dVb), be.ptr(dVw), eps, O_, K_,
+            be.ptr(out["dw"]), be.ptr(out["dbias"]) if bias else None, be.ptr(out["dgamma"]), be.ptr(out["dbeta"]), be.ptr(out["dmean"]), be.ptr(out["dvb"]),
+            be.ptr(out["dvw"]), be.stream)
+    for k, v in ref.items():
+        if k == "dbias" and not bias:
+            continue
+        assert close(be.to_host(out[k]), v, 1e-6), k

@@ -320,3 +320,9 @@ def test_cifar_augment_kernel_vs_oracle(be):
 
 def test_pointwise_wgrad_specialised_edge_tiles(be):
     K.check_wgrad_spec(be)
+
+
+def test_iao_bnfold(be):
+    K.check_iao_bnfold(be)
+    K.check_iao_bnfold(be, O_=70, K_=288, bias=False, shared_var=False, seed=1)
+    K.check_iao_bnfold(be, O_=5, K_=1300, seed=2)
