@@ -15,6 +15,8 @@ void mn_set_error(const char* fmt, ...);
 void mn_set_last_kernel(const char* fmt, ...);
 // optional HIP-event bracket around the MAIN kernel of the next conv entry point (armed by mn_profile_next)
 void mn_prof_bytes(double nbytes);     // designed HBM bytes of the main kernel about to be launched (read + written once)
+// tuning / A-B knobs from the environment, read ONCE per process and call site (the planners run on every launch)
+#define MN_ENV(name) ([]() -> const char* { static const char* v_ = getenv(name); return v_; }())
 void mn_prof_begin(hipStream_t s);
 void mn_prof_end(hipStream_t s);
 #define MN_FAIL(code, ...)        \

@@ -355,7 +355,7 @@ static int plan_c1(const mn_conv_geom* g, C1Plan* pl, int which = 0) {
     // strips: the forward likes one block slot per (image, strip) -- 512 = 2 per CU; the backward-weight one tile per block (measured on L1:
     // forward 131 -> 123 us, backward-weight 141 -> 128 us against 1024 blocks)
     int64_t want_blocks = which == 2 ? 256 : 512;
-    if (const char* e = getenv("MN_C1_BLOCKS")) { const int v = atoi(e); if (v >= 1) want_blocks = v; }     // tuning knob
+    if (const char* e = MN_ENV("MN_C1_BLOCKS")) { const int v = atoi(e); if (v >= 1) want_blocks = v; }     // tuning knob
     while (R % 2 == 0 && ((R / 2) * g->W) % 64 == 0 && (int64_t)g->N * (g->H / R) * pl->cblks < want_blocks) R /= 2;
     if ((R * g->W) % 32) return 0;
     p.R = R; p.strips = g->H / R;

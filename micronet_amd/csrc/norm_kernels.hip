@@ -784,7 +784,7 @@ extern "C" int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* 
     const int S = bnh_split(g);
     const double nel = (double)N * C * H * W;
     // pooled fast path: W % 8 == 0, 8-byte aligned rows
-    const bool pool_fast = own && W % 8 == 0 && !(((uintptr_t)h) & 7) && !(((uintptr_t)own) & 7) && !(((uintptr_t)da) & 15) && !getenv("MN_NO_BNH_POOLFAST");
+    const bool pool_fast = own && W % 8 == 0 && !(((uintptr_t)h) & 7) && !(((uintptr_t)own) & 7) && !(((uintptr_t)da) & 15) && !MN_ENV("MN_NO_BNH_POOLFAST");
     mn_set_last_kernel(pool_fast ? "k_bnh_partial_pool" : (own ? "k_bnh_partial<1>" : "k_bnh_partial<0>")); mn_prof_bytes((own ? 3.0 : 5.0) * nel); mn_prof_begin(s);
     if (pool_fast) hipLaunchKernelGGL(k_bnh_partial_pool, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, (double*)ws);
     else if (own) hipLaunchKernelGGL(k_bnh_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, (double*)ws);

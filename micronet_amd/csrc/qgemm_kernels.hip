@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_reduce_v(const float* __restri
 void qg_launch_wgrad_reduce(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
                             float ascale, const float* qp, hipStream_t s) {
     const int64_t tile = (int64_t)G * Mgw * Cgw;
-    if (Z >= 16 && tile % 64 == 0 && tile / 64 < (1 << 22) && !(((uintptr_t)part) & 15) && !getenv("MN_REDUCE_OLD")) {
+    if (Z >= 16 && tile % 64 == 0 && tile / 64 < (1 << 22) && !(((uintptr_t)part) & 15) && !MN_ENV("MN_REDUCE_OLD")) {
         const int nblk_w = (int)(tile / 64);
         const int nblk_b = db ? mn_grid_for((int64_t)G * Mg * 8, 256, 64) : 0;
         hipLaunchKernelGGL(k_pw_wgrad_reduce_v, dim3(nblk_w + nblk_b), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp, nblk_w);
@@ -814,7 +814,7 @@ static int plan_pw(const mn_conv_geom* g, int which, int xmode, PwPlan* pl) {
     p.nchunks = (int)((p.NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
     int capb = 512;           // one round of 2 blocks per CU (against 1024: -2 ... -3 % on the DoReFa layers)
-    if (const char* e = getenv("MN_PW_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) capb = v; }   // tuning knob
+    if (const char* e = MN_ENV("MN_PW_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) capb = v; }   // tuning knob
     const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
     p.CB = CB;
@@ -897,7 +897,7 @@ static int plan_pwd(const mn_conv_geom* g, PwdPlan* pl) {
     p.nchunks = (int)((NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
     int capb = 512;           // one round of 2 blocks per CU (against 1024: -2 ... -5 %)
-    if (const char* e = getenv("MN_PWD_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) capb = v; }   // tuning knob
+    if (const char* e = MN_ENV("MN_PWD_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) capb = v; }   // tuning knob
     const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
     p.CB = CB;
@@ -1027,7 +1027,7 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     if (rc) return rc;
     if (ste.mode == MN_ACTQ_SIGN8 || ste.mode == MN_ACTQ_CODE8) ste.mode = MN_ACTQ_NONE;      // the clip-STE lives in mn_bnsign_bwd / mn_qa_bwd_*
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
-    if (ste.mode == MN_ACTQ_NONE && !getenv("MN_NO_PWD")) {      // no clip-STE epilogue: the prefetching kernel
+    if (ste.mode == MN_ACTQ_NONE && !MN_ENV("MN_NO_PWD")) {      // no clip-STE epilogue: the prefetching kernel
         PwdPlan pd;
         if (plan_pwd(g, &pd) && ws_bytes >= pd.ws_bytes) {
             fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
@@ -1073,7 +1073,7 @@ static void launch_wg(const WgPlan& pl, int xmode, hipStream_t s) {
 int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s) {
     if (!pw_geom_ok(g)) return kk_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
-    if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_wgrad_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g) && !getenv("MN_NO_WG2"))
+    if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_wgrad_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g) && !MN_ENV("MN_NO_WG2"))
         return pws_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // sign codes: fragments straight from global memory
     const int code8 = aq && aq->mode == MN_ACTQ_CODE8;
     if (code8) {        // k-bit activation codes: the LDS-staged kernel, or (small tiles: the classifier conv) the generic kernel reading bytes

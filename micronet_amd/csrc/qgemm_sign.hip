@@ -1192,9 +1192,9 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (NP % 32 || Mg < 33 || Cg < 33) return 0;           // small tiles stay on the LDS-staged kernel
     Wg2Params& p = pl->p;
     pl->MW = (Mg > 64 || Cg > 64) ? 4 : 2;
-    if (const char* e = getenv("MN_WG2_MW")) { const int v = atoi(e); if (v == 2 || v == 4) pl->MW = v; }   // tuning knob
+    if (const char* e = MN_ENV("MN_WG2_MW")) { const int v = atoi(e); if (v == 2 || v == 4) pl->MW = v; }   // tuning knob
     pl->CW8 = 0;
-    if (const char* e = getenv("MN_WG2_CW8")) pl->CW8 = atoi(e) != 0 && pl->MW == 4;   // tuning knob: 4 x 1 waves of 32 x 128
+    if (const char* e = MN_ENV("MN_WG2_CW8")) pl->CW8 = atoi(e) != 0 && pl->MW == 4;   // tuning knob: 4 x 1 waves of 32 x 128
     const int T = 32 * pl->MW;
     p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.Cin_total = g->C; p.Cout_total = g->O; p.Cg = Cg; p.Mg = Mg;
     p.in_map = make_chanmap(g->in_shuffle, g->C);
@@ -1203,20 +1203,20 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     p.nsteps = (int)(NP / 32);
     const int base = p.G * p.nmb * p.ncb;
     // LDS-staged kernel: 16-byte code loads need HW % 16 == 0; MN_WG2_DIRECT=1 keeps the direct-load kernel (A/B knob)
-    pl->staged = p.HW % 16 == 0 && !pl->CW8 && !getenv("MN_WG2_DIRECT");
-    pl->spec = pl->staged && pl->MW == 4 && !getenv("MN_WG2_NOSPEC") ? 2 : 0;    // wave-specialised variant: 768 threads, one block per CU
-    if (pl->spec) if (const char* e = getenv("MN_WG2_SPEC")) { const int v = atoi(e); if (v == 1 || v == 2) pl->spec = v; }   // A/B knob: 4 or 8 consumer waves
+    pl->staged = p.HW % 16 == 0 && !pl->CW8 && !MN_ENV("MN_WG2_DIRECT");
+    pl->spec = pl->staged && pl->MW == 4 && !MN_ENV("MN_WG2_NOSPEC") ? 2 : 0;    // wave-specialised variant: 768 threads, one block per CU
+    if (pl->spec) if (const char* e = MN_ENV("MN_WG2_SPEC")) { const int v = atoi(e); if (v == 1 || v == 2) pl->spec = v; }   // A/B knob: 4 or 8 consumer waves
     int Z = (pl->spec ? 256 : 512) / base;
     // every block pays a fixed price (pipeline fill, a 64 KB partial tile written and reduced again): keep >= 32 steps per block as long
     // as there is still one block per CU (measured: L5 67 -> 58 us, L8 40 -> 36 us)
     while (Z > 1 && p.nsteps / Z < 32 && base * Z > 256) Z /= 2;
-    if (const char* e = getenv("MN_WG2_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }   // tuning knob
+    if (const char* e = MN_ENV("MN_WG2_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }   // tuning knob
     if (Z > p.nsteps / 2) Z = p.nsteps / 2;
     if (Z < 1) Z = 1;
     p.Z = Z;
-    if (getenv("MN_DEBUG_PLAN")) fprintf(stderr, "plan_pws_wgrad: nsteps %d base %d Z %d MW %d\n", p.nsteps, base, Z, pl->MW);
+    if (MN_ENV("MN_DEBUG_PLAN")) fprintf(stderr, "plan_pws_wgrad: nsteps %d base %d Z %d MW %d\n", p.nsteps, base, Z, pl->MW);
     p.st_per_z = (p.nsteps + Z - 1) / Z; p.st_stride = 1;     // contiguous pixel ranges: each block streams its gy rows sequentially
-    if (getenv("MN_WG2_STRIDED")) { p.st_stride = Z; }
+    if (MN_ENV("MN_WG2_STRIDED")) { p.st_stride = Z; }
     p.fd_hw = make_fastdiv((uint32_t)p.HW);
     const int64_t nb = (int64_t)base * Z;
     if (nb > 0x7fffffff) return 0;
@@ -1327,7 +1327,7 @@ static int plan_pws(const mn_conv_geom* g, int nt_max, PwsPlan* pl) {
     if (KS < 1 || KS > 4) return 0;                       // up to 128 input channels per group
     pl->KS = KS;
     int NT = nt_max;
-    if (const char* e = getenv("MN_PWS_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) NT = v < nt_max ? v : nt_max; }   // tuning knob
+    if (const char* e = MN_ENV("MN_PWS_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) NT = v < nt_max ? v : nt_max; }   // tuning knob
     while (NT > 1 && 16 * (NT / 2) >= Mg) NT /= 2;
     pl->NT = NT;
     const int MB = 16 * NT;
@@ -1339,7 +1339,7 @@ static int plan_pws(const mn_conv_geom* g, int nt_max, PwsPlan* pl) {
     int CB = (p.nchunks + 3) / 4;
     int capb = 512;           // one round of 2 blocks per CU: every block stages its weights and ends in a block reduction -- fewer, longer blocks
                               // (measured against 1024: STATS 41 -> 33 us on L2, 32 -> 23 on L5, 26 -> 18 on L8; SIGN8 44 -> 38, 32 -> 24, 19 -> 16)
-    if (const char* e = getenv("MN_PWS_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 2048) capb = v; }   // tuning knob
+    if (const char* e = MN_ENV("MN_PWS_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 2048) capb = v; }   // tuning knob
     const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
     p.CB = CB;
@@ -1453,7 +1453,7 @@ static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const i
     PwsParams& p = pl.p;
     p.bias = bias;
     const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
-    const bool stash_in_stats = training && h && !getenv("MN_NO_STATS_H");      // one MFMA pass instead of two: h from the statistics pass, sign streamed from h
+    const bool stash_in_stats = training && h && !MN_ENV("MN_NO_STATS_H");      // one MFMA pass instead of two: h from the statistics pass, sign streamed from h
     p.h8 = stash_in_stats ? h : nullptr;
     if (training && (rc = launch_pws<PWS_STATS>(pl, s, nx + (stash_in_stats ? ny : 0.0), "mn_qconv_bnsign_fwd(stats)"))) return rc;
     if (chan_out) p.chan = chan_out;                     // caller-owned [8][O]: kept for the streaming backward (mn_bnh_bwd)
@@ -1699,7 +1699,7 @@ static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
 }
 extern "C" int mn_qconv_bnsign_stash_supported(const mn_conv_geom* g, const mn_wq* wq) {
     if (!g || !wq) return 0;
-    return pws_bn_ok(g, wq) || (!getenv("MN_NO_KXK_STASH") && kk_h8_supported(g, wq));
+    return pws_bn_ok(g, wq) || (!MN_ENV("MN_NO_KXK_STASH") && kk_h8_supported(g, wq));
 }
 /* rows of the caller-owned per-channel table `chan` the stash forward fills: 8, or 17 for a 3x3 block (per-pixel-class nnz) */
 extern "C" int mn_qconv_bnsign_stash_chan_rows(const mn_conv_geom* g) { return (g && g->KH == 1 && g->KW == 1) ? 8 : 17; }
