@@ -38,8 +38,16 @@ __device__ __forceinline__ void qa_eval(float v, const QaCh& k, float& zh, float
     zh = (y - k.mean) * k.invstd;
     z = zh * k.ga + k.be;
 }
+// j = rha(c / s), c = clamp(0.1 a, 0, 1) >= 0, i.e. floor(fl(c / s) + 0.5).  The IEEE division is ~10 instructions per element and made k_qa_fwd
+// VALU-bound (2.9 TB/s of 3 B/elt).  q = c * n differs from fl(c / s) by a few ulp only (s = fl(1/n)), so floor(q + 0.5) is the same integer unless
+// q + 0.5 lies within 2e-4 of one (q <= 255: 3 ulp < 5e-5); only then the division is evaluated -- bit-identical codes, the branch is rarely taken.
 __device__ __forceinline__ uint32_t qa_code(float a, float s) {
-    const float j = mn_rha(mn_clamp(a * 0.1f, 0.f, 1.f) / s);
+    const float c = mn_clamp(a * 0.1f, 0.f, 1.f);
+    const float nf = (float)(int)(1.0f / s + 0.5f);      // 2^bits - 1
+    const float t = c * nf + 0.5f;
+    float j = floorf(t);
+    const float r = t - j;
+    if (r < 2e-4f || r > 1.f - 2e-4f) j = floorf(c / s + 0.5f);
     return (j > 0.f) ? (uint32_t)j : 0u;                 // NaN -> 0 (a byte cannot hold it)
 }
 // 8 consecutive elements (one row segment) of channel c at group index i: element offset

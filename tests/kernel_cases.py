@@ -931,3 +931,47 @@ def check_iao_bnfold(be, O_=24, K_=37, bias=True, shared_var=True, seed=0):
         if k == "dbias" and not bias:
             continue
         assert close(be.to_host(out[k]), v, 1e-6), k
+
+
+def check_qa_code_exact(be, bits=2, seed=0):
+    """The k-bit activation code of mn_qa_fwd, j = rha(clamp(0.1 a, 0, 1) / s) (wqaq/dorefa/quantize.py:43-45), bit-exact on inputs AT the rounding
+    boundaries (k + 0.5) s / 0.1 and a few ulps around them, at the clamp edges, and on random values: the kernel takes a multiply-based shortcut and
+    evaluates the division only next to a boundary."""
+    r = np.random.default_rng(seed)
+    n = (1 << bits) - 1
+    s32 = F(1.0) / F(n)
+    vals = [F(0), F(-1), F(10), F(10.000001), F(9.999999), F(1e-8), F(1e9)]
+    for k in range(n):
+        a0 = F((k + 0.5) * float(s32) / 0.1)
+        u = a0.view(np.int32) if hasattr(a0, "view") else np.float32(a0).view(np.int32)
+        for d in range(-6, 7):
+            vals.append(np.int32(int(u) + d).view(np.float32))
+    vals = np.array(vals, dtype=F)
+    rnd = (r.random(8192 - vals.size % 8192) * 11 - 0.5).astype(F)
+    a = np.concatenate([vals, rnd]).astype(F)
+    a = a[: (a.size // 64) * 64]
+    N, Cc, H, W = 1, 1, a.size // 8, 8
+    y = a.reshape(N, Cc, H, W)
+    save = np.array([[0.0], [1.0]], dtype=F)
+    chan = be.empty((9, Cc))
+    be.call("mn_qa_chan_from_save", be.ptr(be_keep(be, save)), be.ptr(be_keep(be, np.ones(Cc, dtype=F))), be.ptr(be_keep(be, np.zeros(Cc, dtype=F))), Cc, be.ptr(chan), be.stream)
+    codes = be.empty_u8((N, Cc, H, W)) if hasattr(be, "empty_u8") else None
+    dY = be.to_dev(y)
+    if codes is None:
+        codes = be.to_dev_u8(np.zeros((N, Cc, H, W), dtype=np.uint8))
+    be.call("mn_qa_fwd", 1, be.ptr(dY), be.ptr(chan), N, Cc, H, W, bits, 0, be.ptr(codes), None, be.stream)
+    got = be.to_host(codes).reshape(-1).astype(np.int64)
+    z = ((y.reshape(-1) - F(0)) * F(1)) * F(1) + F(0)
+    act = np.where(z > 0, z, F(0)).astype(F)
+    c = np.minimum(np.maximum((act * F(0.1)).astype(F), F(0)), F(1)).astype(F)
+    ref = np.floor(((c / s32).astype(F) + F(0.5)).astype(F)).astype(np.int64)
+    assert np.array_equal(got, ref), (bits, np.nonzero(got != ref)[0][:8])
+
+
+_KEEP = []
+
+
+def be_keep(be, arr):
+    t = be.to_dev(arr)
+    _KEEP.append(t)
+    return t

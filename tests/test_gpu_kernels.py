@@ -527,3 +527,8 @@ def test_iao_bnfold(be):
     K.check_iao_bnfold(be)
     K.check_iao_bnfold(be, O_=70, K_=288, bias=False, shared_var=False, seed=1)
     K.check_iao_bnfold(be, O_=5, K_=1300, seed=2)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 7])
+def test_qa_activation_code_bit_exact_at_boundaries(be, bits):
+    K.check_qa_code_exact(be, bits=bits)
