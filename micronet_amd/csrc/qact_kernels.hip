@@ -24,6 +24,7 @@ struct QaGeom {
     FastDiv fd_hw8, fd_w8;
     int64_t n8;             // 8-element groups per channel (no pool) / 4-window groups per channel (pool)
     float s;                // quantizer scale 1 / (2^a - 1)
+    int nthr;               // > 0 (mn_qa_fwd on the integer stash, <= 3 bit codes): levels 2^a - 1 of the integer-threshold forward
 };
 struct QaCh { float alpha, bias, mean, invstd, ga, be, A, B, gi; };
 __device__ __forceinline__ QaCh qa_load_ch(const float* __restrict__ chan, int C, int c) {
@@ -89,11 +90,69 @@ __device__ __forceinline__ int qa_argmax4(const float (&a)[4]) {
 }
 
 // ---------------------------------------------------------------- forward: stash / y  ->  codes (OUT 0) or the fp32 activation (OUT 1)
+// Integer-threshold forward (stash input, codes of <= 3 bits): the code is a monotone step function of the integer accumulator -- every step of the
+// chain acc -> y -> zhat -> z -> relu -> clamp(0.1 a) -> rha(./s) is monotone in fp32 as well -- so per channel there are n = 2^a - 1 integers T_k with
+// code = #{k : u >= T_k}, u = flip * acc (flip = -1 when the chain decreases).  T_k = the smallest u whose EXACT chain value reaches k, found by a
+// binary search over the int16 range with that chain: the codes are bit-identical to the element-wise evaluation, at ~8 instead of ~20 VALU per
+// element (the pass was VALU-bound at 3.5 TB/s of 3 B/elt).  A channel with a non-finite constant keeps the element-wise path.
+#define QA_MAXTHR 7
+template <int IN>
+__device__ __forceinline__ uint32_t qa_code_of(float v, const QaCh& k, float s) { float zh, z; qa_eval<IN>(v, k, zh, z); return qa_code(qa_relu(z), s); }
+__device__ __forceinline__ bool qa_finite(float v) { return fabsf(v) <= 3.0e38f; }
 template <int IN, int POOL, int OUT>
 __global__ __launch_bounds__(256) void k_qa_fwd(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, unsigned char* __restrict__ codes,
                                                 float* __restrict__ af) {
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
     const QaCh k = qa_load_ch(chan, g.C, c);
+    if (!IN && !OUT && g.nthr > 0 && qa_finite(k.alpha) && qa_finite(k.bias) && qa_finite(k.mean) && qa_finite(k.invstd) && qa_finite(k.ga) && qa_finite(k.be)) {
+        __shared__ float thr[QA_MAXTHR + 1];
+        const float flip = (qa_code_of<0>(32767.f, k, g.s) < qa_code_of<0>(-32768.f, k, g.s)) ? -1.f : 1.f;
+        if ((int)threadIdx.x < g.nthr) {
+            // smallest u in [-32768, 32768] with code(flip * u) >= level, 32769 if none (u = 32768 only occurs as -(-32768))
+            const uint32_t level = threadIdx.x + 1u;
+            int lo = -32768, hi = 32769;                       // invariant: code(lo - 1) < level (virtually), code(hi) >= level (virtually at 32769)
+            while (lo < hi) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (qa_code_of<0>(flip * (float)mid, k, g.s) >= level) hi = mid; else lo = mid + 1;
+            }
+            thr[threadIdx.x] = (float)lo;
+        }
+        __syncthreads();
+        float T[QA_MAXTHR];
+#pragma unroll
+        for (int q = 0; q < QA_MAXTHR; ++q) T[q] = q < g.nthr ? thr[q] : 40000.f;
+        auto code_u = [&](float u) {
+            uint32_t j = 0u;
+#pragma unroll
+            for (int q = 0; q < QA_MAXTHR; ++q) if (q < 3 || g.nthr > 3) j += (u >= T[q]) ? 1u : 0u;
+            return j;
+        };
+        for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
+            if (!POOL) {
+                const int64_t off = qa_off8(g, c, (uint32_t)i);
+                float v[8];
+                qa_load8<0>(in, off, v);
+                uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo |= code_u(v[e] * flip) << (8 * e); hi |= code_u(v[4 + e] * flip) << (8 * e); }
+                *reinterpret_cast<u32x2*>(codes + off) = u32x2{lo, hi};
+            } else {
+                int64_t e0, po;
+                qa_pool_off(g, c, i, e0, po);
+                float r0[8], r1[8];
+                qa_load8<0>(in, e0, r0);
+                qa_load8<0>(in, e0 + g.W, r1);
+                uint32_t w4 = 0u;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {        // the window's largest activation is the one with the largest u
+                    const float m = fmaxf(fmaxf(r0[2 * w] * flip, r0[2 * w + 1] * flip), fmaxf(r1[2 * w] * flip, r1[2 * w + 1] * flip));
+                    w4 |= code_u(m) << (8 * w);
+                }
+                *reinterpret_cast<uint32_t*>(codes + po) = w4;
+            }
+        }
+        return;
+    }
     for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
         if (!POOL) {
             const int64_t off = qa_off8(g, c, (uint32_t)i);
@@ -317,6 +376,7 @@ static int qa_geom(QaGeom* g, int64_t N, int64_t C, int64_t H, int64_t W, int bi
     g->fd_hw8 = make_fastdiv((uint32_t)g->HW8); g->fd_w8 = make_fastdiv((uint32_t)(g->W8 > 0 ? g->W8 : 1));
     g->n8 = pool ? N * (H / 2) * (W / 8) : N * (HW / 8);
     g->s = dorefa_scale(bits);
+    g->nthr = 0;
     return MN_OK;
 }
 static int qa_split(const QaGeom& g) {
@@ -346,6 +406,7 @@ extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t 
     if (!in || !chan || (!codes && !act_f32) || (((uintptr_t)in) & 15) || (codes && (((uintptr_t)codes) & 7)) || (act_f32 && !aligned16(act_f32)))
         MN_FAIL(MN_EINVAL, "mn_qa_fwd: null / misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
+    if (!in_f32 && codes && a_bits <= 3 && !MN_ENV("MN_QA_NO_THRESHOLDS")) g.nthr = (1 << a_bits) - 1;       // integer-threshold forward (A/B knob)
     const dim3 grid((unsigned)C, (unsigned)qa_split(g));
     const double nel = (double)N * C * H * W;
     mn_set_last_kernel("k_qa_fwd<%d, %d>", in_f32 ? 1 : 0, pool ? 1 : 0);

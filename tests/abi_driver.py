@@ -56,6 +56,12 @@ class Backend:
             return a.copy()
         return self.torch.from_numpy(a.copy()).cuda()
 
+    def to_dev_i16(self, a):
+        a = np.ascontiguousarray(a, dtype=np.int16)
+        if self.kind == "emu":
+            return a.copy()
+        return self.torch.from_numpy(a.copy()).cuda()
+
     def to_dev_i64(self, a):
         a = np.ascontiguousarray(a, dtype=np.int64)
         if self.kind == "emu":

@@ -975,3 +975,41 @@ def be_keep(be, arr):
     t = be.to_dev(arr)
     _KEEP.append(t)
     return t
+
+
+def check_qa_thresholds(be, bits=2, pool=False, seed=0):
+    """mn_qa_fwd on the int16 stash (integer-threshold path for <= 3-bit codes) vs the element-wise fp32 chain in numpy: random stash values over the whole
+    int16 range and around every code boundary, channels with positive, negative, tiny and huge slopes, saturated and all-zero channels."""
+    r = np.random.default_rng(seed)
+    n = (1 << bits) - 1
+    s32 = F(1.0) / F(n)
+    Cc, N, H, W = 12, 2, 8, 16
+    alpha = (r.random(Cc) * 0.02 + 0.001).astype(F)
+    bias = (r.standard_normal(Cc) * 0.1).astype(F)
+    mean = (r.standard_normal(Cc) * 0.5).astype(F)
+    invstd = (r.random(Cc) * 3 + 0.2).astype(F)
+    ga = (r.standard_normal(Cc) * 1.5).astype(F)              # both signs: decreasing chains too
+    beb = (r.standard_normal(Cc) * 2 + 3).astype(F)
+    ga[0], beb[0] = F(0), F(5)                                 # constant channel (code fixed)
+    ga[1], beb[1] = F(1e-6), F(-1)                             # never positive
+    alpha[2], invstd[2], ga[2] = F(1.0), F(10.0), F(-3.0)      # steep, decreasing
+    chan = np.stack([alpha, bias, mean, invstd, ga, beb, alpha * invstd, (bias - mean) * invstd, ga * invstd]).astype(F)
+    st = r.integers(-32768, 32768, size=(N, Cc, H, W)).astype(np.int16)
+    st[:, :, :, : W // 2] = r.integers(-600, 600, size=(N, Cc, H, W // 2)).astype(np.int16)      # where the boundaries of typical channels are
+    st[0, :, 0, 0], st[0, :, 0, 1] = -32768, 32767
+    v = st.astype(F)
+    sh = (1, Cc, 1, 1)
+    y = (v * alpha.reshape(sh)).astype(F) + bias.reshape(sh)
+    zh = ((y - mean.reshape(sh)).astype(F) * invstd.reshape(sh)).astype(F)
+    z = ((zh * ga.reshape(sh)).astype(F) + beb.reshape(sh)).astype(F)
+    a = np.where(z > 0, z, F(0)).astype(F)
+    if pool:
+        a = a.reshape(N, Cc, H // 2, 2, W // 2, 2).max(axis=(3, 5))
+    c = np.minimum(np.maximum((a * F(0.1)).astype(F), F(0)), F(1)).astype(F)
+    ref = np.floor(((c / s32).astype(F) + F(0.5)).astype(F)).astype(np.int64)
+    dS = be.to_dev_i16(st) if hasattr(be, "to_dev_i16") else None
+    dC = be.to_dev(chan)
+    out = be.to_dev_u8(np.zeros(ref.shape, dtype=np.uint8))
+    be.call("mn_qa_fwd", 0, be.ptr(dS), be.ptr(dC), N, Cc, H, W, bits, int(pool), be.ptr(out), None, be.stream)
+    got = be.to_host(out).astype(np.int64)
+    assert np.array_equal(got, ref), (bits, pool, np.argwhere(got != ref)[:5])

@@ -331,3 +331,8 @@ def test_iao_bnfold(be):
 @pytest.mark.parametrize("bits", [2, 3, 4, 7])
 def test_qa_activation_code_bit_exact_at_boundaries(be, bits):
     K.check_qa_code_exact(be, bits=bits)
+
+
+@pytest.mark.parametrize("bits,pool", [(2, False), (2, True), (3, False), (3, True), (4, False)])
+def test_qa_forward_integer_thresholds(be, bits, pool):
+    K.check_qa_thresholds(be, bits=bits, pool=pool, seed=bits)
