@@ -94,11 +94,13 @@ __device__ __forceinline__ int qa_argmax4(const float (&a)[4]) {
 // chain acc -> y -> zhat -> z -> relu -> clamp(0.1 a) -> rha(./s) is monotone in fp32 as well -- so per channel there are n = 2^a - 1 integers T_k with
 // code = #{k : u >= T_k}, u = flip * acc (flip = -1 when the chain decreases).  T_k = the smallest u whose EXACT chain value reaches k, found by a
 // binary search over the int16 range with that chain: the codes are bit-identical to the element-wise evaluation, at ~8 instead of ~20 VALU per
-// element (the pass was VALU-bound at 3.5 TB/s of 3 B/elt).  A channel with a non-finite constant keeps the element-wise path.
+// element (the pass was VALU-bound at 3.5 TB/s of 3 B/elt).  A channel with a non-finite or absurdly large constant keeps the element-wise path.
 #define QA_MAXTHR 7
 template <int IN>
 __device__ __forceinline__ uint32_t qa_code_of(float v, const QaCh& k, float s) { float zh, z; qa_eval<IN>(v, k, zh, z); return qa_code(qa_relu(z), s); }
-__device__ __forceinline__ bool qa_finite(float v) { return fabsf(v) <= 3.0e38f; }
+// |constant| <= 1e9 for all six: no intermediate of the chain can overflow on an int16 input (|y| <= 3.3e13, |zhat| <= 3.3e22, |z| <= 3.3e31), so no
+// inf * 0 = NaN can break the monotonicity the thresholds rely on; anything wilder (or NaN) takes the element-wise path
+__device__ __forceinline__ bool qa_finite(float v) { return fabsf(v) <= 1.0e9f; }
 template <int IN, int POOL, int OUT>
 __global__ __launch_bounds__(256) void k_qa_fwd(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, unsigned char* __restrict__ codes,
                                                 float* __restrict__ af) {
