@@ -367,6 +367,10 @@ int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq, const int
  * Backward of the conv itself: mn_conv2d_bwd_data (no STE epilogue) and mn_conv2d_bwd_weight with aq->mode == MN_ACTQ_CODE8. */
 #define MN_QA_NCH 9
 int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in);
+/* width of the stash mn_qconv_bnq_fwd_stash writes for this layer: 16, or 32 for a DENSE layer (groups == 1, C and O multiples of 64: the 3 x 3 stride 1 / 2 and
+ * 1 x 1 stride 2 convolutions of the reference's ResNets, models/resnet.py:7-65) whose K * (2^a - 1) * (2^w - 1) exceeds 32767; 0 when unsupported.  A 32-bit stash is
+ * passed through the same `stash` pointer and read by mn_qa_* / mn_qr_* with in_kind == 2.  Dense layers write [N][O][Ho][Wo] (stride 2: half the input size). */
+int mn_qconv_bnq_stash_bits(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in);
 int64_t mn_qconv_bnq_ws_bytes(const mn_conv_geom* g);
 int mn_qconv_bnq_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x_codes, int a_bits_in, const float* w, const float* bias, const float* gamma,
                            const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,

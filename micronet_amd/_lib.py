@@ -117,6 +117,7 @@ PROTOTYPES = {
     "mn_kth_abs_ws_bytes": (_L, []),
     "mn_hist_observe": (_I, [_P, _L, _L, _I, C.c_double, _P, _P, _P, _P]),
     "mn_qconv_bnq_supported": (_I, [_G, _W, _I]),
+    "mn_qconv_bnq_stash_bits": (_I, [_G, _W, _I]),
     "mn_qconv_bnq_ws_bytes": (_L, [_G]),
     "mn_qconv_bnq_fwd_stash": (_I, [_G, _W, _P, _I, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "mn_bn_save_stats": (_I, [_P, _L, _L, _L, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P]),

@@ -1,0 +1,948 @@
+// Dense (groups = 1) code-domain convolutions for gfx950: the 3 x 3 / padding 1 (stride 1 and 2) and 1 x 1 / stride 2 layers of the
+// reference's CIFAR ResNets (models/resnet.py:7-65, 122-182) under the k-bit DoReFa scheme (wqaq/dorefa/quantize.py:107-122):
+//
+//   forward          acc[n][o][oh][ow] = sum over (c, r, s) of wcode[o][c][r][s] * j[n][c][oh*S + r - P][ow*S + s - P]      (exact integers)
+//   backward-data    dq[n][c][ih][iw]  = sum over (o, r, s) of wcode[o][c][r][s] * (gy[n][o][oh][ow] / n_w),  ih = oh*S + r - P ...
+//   backward-weight  dw[o][c][r][s]    = s_a * sum over (n, oh, ow) of gy[n][o][oh][ow] * j[n][c][oh*S + r - P][ow*S + s - P]
+//
+// with Cin, Cout multiples of 64 (64 ... 512) and small images (W = 4 ... 32): K = 9 Cin = 576 ... 4608 -- unlike the grouped layers of nin_gc
+// (qgemm_k3s.hip, K = 144) these are bound by the matrix cores, not by HBM.  All three are implicit GEMMs on v_mfma_f32_16x16x32_bf16 with
+// everything global in the reference's NCHW layout (so the streaming kernels of qact_kernels.hip consume / produce the same tensors):
+//
+//   * k_qd_fwd: a block (4 waves) owns 64 MF output pixels x 64 output channels and walks the input channels in chunks of 64.  The chunk's
+//     input patch ((TH - 1) S + 3 rows x (Wo - 1) S + 3 columns per image, one-pixel zero frame) is staged ONCE per chunk as bf16 codes,
+//     transposed to [pixel slot][64 c] (144-byte slots: conflict-free b128 reads): the nine taps are nine constant slot offsets, so one
+//     staged element feeds 9 x 64 MACs.  The weights arrive pre-packed in fragment order (k_qd_pack), 8 KB per (tap, chunk) step, through a
+//     two-slot LDS ring filled one step ahead; the next chunk's patch is fetched into registers while the current one is contracted.  A wave
+//     computes 16 MF pixels x 64 channels: per K-step of 32, MF A + 4 B fragment reads feed 4 MF MFMAs.  M = pixels: a lane ends with 4
+//     consecutive pixels of one channel = one 8-byte (int16) or 16-byte (int32) store of the NCHW stash.
+//   * the statistics of the stash (k_qd_stats) are exact integer sums per channel, in the partial layout k_qa_stats_prep reads.
+#include "qgemm_dev.h"
+
+#include <stdlib.h>
+
+#define QD_RS 144              // forward patch: LDS bytes per pixel slot (64 bf16 + pad)
+#define QD_WSTEP 8192          // bytes of packed weights per forward step (one tap x 64 input channels x 64 output channels)
+#define QDF_UPT 6              // staging units (4 channels x 4 pixels) per thread and chunk
+
+// ------------------------------------------------------------------------------------------------ weight codes in fragment order
+// orient 0 (forward):        [cot][chunk = c / 64][tap][ks = 0, 1][nf = 0..3][lane][e]: o = 64 cot + 16 nf + (lane & 15), c = 64 chunk + 32 ks + 8 (lane >> 4) + e
+// orient 1 (backward-data):  [cit][chunk = o / 32][tap][nf][lane][e]:                   c = 64 cit + 16 nf + (lane & 15), o = 32 chunk + 8 (lane >> 4) + e
+// code = rint(w * (2^bits - 1)): the integer 2k - n of a DoReFa weight (2k - n) / n (wqaq/dorefa/quantize.py:68-72); exact in bf16
+struct QdPackParams { const float* w; uint16_t* out; int O, C, T; float wn; int orient; int64_t ngroups; };
+__global__ __launch_bounds__(256) void k_qd_pack(const QdPackParams p) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= p.ngroups) return;
+    const int lane = (int)(gi & 63);
+    int64_t t = gi >> 6;
+    const int nf = (int)(t & 3); t >>= 2;
+    int o0, c0, tap, ostep, cstep;
+    if (p.orient == 0) {
+        const int ks = (int)(t & 1); t >>= 1;
+        tap = (int)(t % p.T); t /= p.T;
+        const int nch = p.C / 64;
+        const int chunk = (int)(t % nch), cot = (int)(t / nch);
+        o0 = cot * 64 + nf * 16 + (lane & 15); c0 = chunk * 64 + ks * 32 + (lane >> 4) * 8; ostep = 0; cstep = 1;
+    } else {
+        tap = (int)(t % p.T); t /= p.T;
+        const int nch = p.O / 32;
+        const int chunk = (int)(t % nch), cit = (int)(t / nch);
+        c0 = cit * 64 + nf * 16 + (lane & 15); o0 = chunk * 32 + (lane >> 4) * 8; ostep = 1; cstep = 0;
+    }
+    uint32_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = o0 + e * ostep, c = c0 + e * cstep;
+        const float v = p.w[((int64_t)o * p.C + c) * p.T + tap];
+        h[e] = mn_f2u(rintf(v * p.wn)) >> 16;
+    }
+    *reinterpret_cast<u32x4*>(p.out + gi * 8) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct QdfParams {
+    const unsigned char* x;       // [N][C][H][W] activation codes
+    const uint16_t* wpk;          // k_qd_pack orient 0
+    void* stash;                  // [N][O][Ho][Wo] int16 / int32
+    int N, C, H, W, O, Ho, Wo, HW, HoWo;
+    int S, PAD, TAPS;             // stride, padding, taps (9: 3 x 3, 1: 1 x 1)
+    int TH, NI, PH, PW, W4;       // output rows per tile and image, images per tile, patch rows / columns per image
+    int tpi, ncot, nchunks, nitems, nunits, out32, wo_shift;
+    FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_ncot, fd_tpi;
+};
+
+template <int MF>
+__global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* wbuf = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* patch = wbuf + 2 * QD_WSTEP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
+    if ((int)blockIdx.x >= p.nitems) return;
+    {   // the frame columns (and anything staging never writes) stay zero for the whole kernel
+        const int n16 = p.NI * p.PH * p.PW * (QD_RS / 16);
+        for (int i = tid; i < n16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    }
+    // staging roles: unit u = ((q * NI + img) * PH + pr) * W4 + d  ->  channels 4q .. 4q + 3, patch row pr of image img, input pixels 4d .. 4d + 3
+    int u_lds[QDF_UPT], u_goff[QDF_UPT], u_pi[QDF_UPT];
+#pragma unroll
+    for (int i = 0; i < QDF_UPT; ++i) {
+        const int u = tid + 256 * i;
+        const uint32_t t0 = fd_div((uint32_t)u, p.fd_w4);
+        const int d = u - (int)t0 * p.W4;
+        const uint32_t t1 = fd_div(t0, p.fd_ph);
+        const int pr = (int)t0 - (int)t1 * p.PH;
+        const uint32_t q = fd_div(t1, p.fd_ni);
+        const int img = (int)t1 - (int)q * p.NI;
+        const bool v = u < p.nunits;
+        u_lds[i] = v ? ((img * p.PH + pr) * p.PW + 4 * d + p.PAD) * QD_RS + 8 * (int)q : -1;
+        u_goff[i] = v ? 4 * (int)q * p.HW + 4 * d : 0;
+        u_pi[i] = pr | (img << 8);
+    }
+    uint32_t preg[QDF_UPT][4];
+    uint32_t pok = 0u;
+    auto tile_origin = [&](int item, int& n0, int& oh0, int& cot) {
+        const uint32_t tile = fd_div((uint32_t)item, p.fd_ncot);
+        cot = item - (int)tile * p.ncot;
+        if (p.NI == 1) { const uint32_t n = fd_div(tile, p.fd_tpi); n0 = (int)n; oh0 = ((int)tile - (int)n * p.tpi) * p.TH; }
+        else { n0 = (int)tile * p.NI; oh0 = 0; }
+    };
+    auto fetch_patch = [&](int item, int chunk) {
+        int n0, oh0, cot;
+        tile_origin(item, n0, oh0, cot);
+        const int ih0 = oh0 * p.S - p.PAD;
+        pok = 0u;
+#pragma unroll
+        for (int i = 0; i < QDF_UPT; ++i) {
+            int n = n0 + (u_pi[i] >> 8), ih = ih0 + (u_pi[i] & 255);
+            const bool ok = u_lds[i] >= 0 && n < p.N && ih >= 0 && ih < p.H;
+            n = n < p.N ? n : p.N - 1;
+            ih = ih < 0 ? 0 : (ih < p.H ? ih : p.H - 1);          // rows outside the image: any valid address (written as zeros)
+            const uint32_t base = (uint32_t)((n * p.C + chunk * 64) * p.H + ih) * (uint32_t)p.W + (uint32_t)u_goff[i];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) preg[i][cc] = *reinterpret_cast<const uint32_t*>(p.x + base + (uint32_t)(cc * p.HW));
+            pok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto commit_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < QDF_UPT; ++i) {
+            if (u_lds[i] < 0) continue;
+            const bool ok = (pok >> i) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float f0 = (float)((preg[i][0] >> (8 * e)) & 0xffu), f1 = (float)((preg[i][1] >> (8 * e)) & 0xffu);
+                const float f2 = (float)((preg[i][2] >> (8 * e)) & 0xffu), f3 = (float)((preg[i][3] >> (8 * e)) & 0xffu);
+                const u32x2 v = ok ? u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)} : u32x2{0u, 0u};       // integers <= 255: exact in bf16
+                *reinterpret_cast<u32x2*>(patch + u_lds[i] + e * QD_RS) = v;
+            }
+        }
+    };
+    u32x4 wreg[2];
+    struct Pos { int item, chunk, tap; };
+    auto fetch_w = [&](const Pos& q) {
+        const uint32_t tile = fd_div((uint32_t)q.item, p.fd_ncot);
+        const int cot = q.item - (int)tile * p.ncot;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.wpk) + (int64_t)((cot * p.nchunks + q.chunk) * p.TAPS + q.tap) * QD_WSTEP;
+        wreg[0] = *reinterpret_cast<const u32x4*>(src + tid * 16);
+        wreg[1] = *reinterpret_cast<const u32x4*>(src + 4096 + tid * 16);
+    };
+    auto commit_w = [&](int buf) {
+        *reinterpret_cast<u32x4*>(wbuf + buf * QD_WSTEP + tid * 16) = wreg[0];
+        *reinterpret_cast<u32x4*>(wbuf + buf * QD_WSTEP + 4096 + tid * 16) = wreg[1];
+    };
+    const int stride_items = (int)gridDim.x;
+    auto advance = [&](Pos& q) {
+        if (++q.tap == p.TAPS) { q.tap = 0; if (++q.chunk == p.nchunks) { q.chunk = 0; q.item += stride_items; } }
+    };
+    // A fragment bases: pixel tp = 16 MF wave + 16 mf + j of the tile -> the slot of its first tap
+    int abase[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int tp = wave * 16 * MF + mf * 16 + j;
+        const int ow = tp & (p.Wo - 1), t = tp >> p.wo_shift;
+        const uint32_t img = fd_div((uint32_t)t, p.fd_th);
+        const int ohl = t - (int)img * p.TH;
+        abase[mf] = (((int)img * p.PH + ohl * p.S) * p.PW + ow * p.S) * QD_RS + kg * 16;
+    }
+    Pos nxt{(int)blockIdx.x, 0, 0};
+    fetch_patch(nxt.item, 0);
+    fetch_w(nxt);
+    __syncthreads();                          // the zero fill is complete
+    commit_patch();
+    commit_w(0);
+    advance(nxt);
+    if (nxt.item < p.nitems) fetch_w(nxt);    // wreg: the weights of step 1
+    Pos la = nxt;
+    advance(la);
+    __syncthreads();
+    int buf = 0;
+    for (int item = (int)blockIdx.x; item < p.nitems; item += stride_items) {
+        f32x4 acc[MF][4];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+            int nitem = item, nchunk = chunk + 1;
+            if (nchunk == p.nchunks) { nchunk = 0; nitem += stride_items; }
+            const bool have_next = nitem < p.nitems;
+            if (have_next) fetch_patch(nitem, nchunk);             // in flight during the chunk's nine steps
+            for (int tap = 0; tap < p.TAPS; ++tap) {
+                // invariant: wbuf[buf] holds this step's weights, wreg the next step's
+                if (nxt.item < p.nitems) commit_w(buf ^ 1);
+                if (la.item < p.nitems) fetch_w(la);
+                advance(nxt);
+                advance(la);
+                const int r = p.TAPS == 9 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0;
+                const int toff = (r * p.PW + (tap - 3 * r)) * QD_RS;
+                const unsigned char* wb = wbuf + buf * QD_WSTEP + lane * 16;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 b[4], a[MF];
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) b[nf] = *reinterpret_cast<const u32x4*>(wb + (ks * 4 + nf) * 1024);
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const u32x4*>(patch + abase[mf] + toff + ks * 64);
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = mn_mfma_bf16(a[mf], b[nf], acc[mf][nf]);
+                }
+                __syncthreads();
+                buf ^= 1;
+            }
+            if (have_next) { commit_patch(); __syncthreads(); }
+        }
+        // D[row = pixel 4 kg + r][col = channel j]: 4 consecutive pixels of one channel per lane
+        int n0, oh0, cot;
+        tile_origin(item, n0, oh0, cot);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int tp = wave * 16 * MF + mf * 16 + 4 * kg;
+            const int ow = tp & (p.Wo - 1), t = tp >> p.wo_shift;
+            const uint32_t img = fd_div((uint32_t)t, p.fd_th);
+            const int ohl = t - (int)img * p.TH;
+            const int n = n0 + (int)img;
+            if (n >= p.N) continue;
+            const uint32_t base = (uint32_t)((n * p.O + cot * 64 + j) * p.Ho + oh0 + ohl) * (uint32_t)p.Wo + (uint32_t)ow;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const uint32_t off = base + (uint32_t)(nf * 16 * p.HoWo);
+                const int v0 = (int)acc[mf][nf][0], v1 = (int)acc[mf][nf][1], v2 = (int)acc[mf][nf][2], v3 = (int)acc[mf][nf][3];
+                if (p.out32) *reinterpret_cast<u32x4*>(reinterpret_cast<int32_t*>(p.stash) + off) = u32x4{(uint32_t)v0, (uint32_t)v1, (uint32_t)v2, (uint32_t)v3};
+                else *reinterpret_cast<u32x2*>(reinterpret_cast<int16_t*>(p.stash) + off) =
+                         u32x2{((uint32_t)v0 & 0xffffu) | ((uint32_t)v1 << 16), ((uint32_t)v2 & 0xffffu) | ((uint32_t)v3 << 16)};
+            }
+        }
+    }
+}
+
+// exact integer sums of the stash per channel: part[(sp * O + c) * 2 + {0, 1}] = sum acc, sum acc^2 of split sp
+template <int IN32>
+__global__ __launch_bounds__(256) void k_qd_stats(const void* __restrict__ stash, int N, int O, int HW, double* __restrict__ part) {
+    __shared__ double scd[16];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const int HW8 = HW >> 3;
+    const int64_t n8 = (int64_t)N * HW8;
+    long long s1 = 0, s2 = 0;
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < n8; i += (int64_t)S * 256) {
+        const int64_t n = i / HW8;
+        const int64_t off = (n * O + c) * HW + (i - n * HW8) * 8;
+        int v[8];
+        if (IN32) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(reinterpret_cast<const int32_t*>(stash) + off), b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const int32_t*>(stash) + off + 4);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { v[d] = (int)a[d]; v[4 + d] = (int)b[d]; }
+        } else {
+            const u32x4 u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const int16_t*>(stash) + off);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { v[2 * d] = (int)(int16_t)(u[d] & 0xffffu); v[2 * d + 1] = (int)(int16_t)(u[d] >> 16); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 += (long long)v[e] * v[e]; }
+    }
+    const double r1 = block_reduce((double)s1, OpAddD(), 0.0, scd);          // partial sums are integers below 2^53: exact
+    const double r2 = block_reduce((double)s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { part[((int64_t)sp * O + c) * 2] = r1; part[((int64_t)sp * O + c) * 2 + 1] = r2; }
+}
+
+// ------------------------------------------------------------------------------------------------ host side: forward
+struct QdfPlan { QdfParams p; int MF, grid; size_t lds; int64_t off_part, off_scale, ws_bytes; int S_stats; };
+static int qd_log2(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
+static int qd_geom_ok(const mn_conv_geom* g) {
+    if (!g || g->groups != 1 || g->in_shuffle > 1 || g->dil_h != 1 || g->dil_w != 1 || g->C % 64 || g->O % 64 || g->N < 1) return 0;
+    if (g->KH == 3 && g->KW == 3 && g->pad_h == 1 && g->pad_w == 1 && g->stride_h == g->stride_w && (g->stride_h == 1 || g->stride_h == 2)) { }
+    else if (g->KH == 1 && g->KW == 1 && g->pad_h == 0 && g->pad_w == 0 && g->stride_h == 2 && g->stride_w == 2) { }
+    else return 0;
+    if (g->W % 4 || g->H % g->stride_h || g->W % g->stride_w) return 0;
+    if (MN_ENV("MN_NO_QD")) return 0;          // A/B knob: the generic kernels
+    return 1;
+}
+static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
+    if (!qd_geom_ok(g)) return 0;
+    QdfParams& p = pl->p;
+    p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.S = g->stride_h; p.PAD = g->pad_h; p.TAPS = g->KH * g->KW;
+    p.Ho = (g->H + 2 * g->pad_h - g->KH) / p.S + 1; p.Wo = (g->W + 2 * g->pad_w - g->KW) / p.S + 1;
+    p.HW = g->H * g->W; p.HoWo = p.Ho * p.Wo;
+    p.wo_shift = qd_log2(p.Wo);
+    if (p.wo_shift < 2 || p.Wo > 32 || p.HoWo % 8) return 0;
+    if ((int64_t)g->N * g->C * p.HW >= ((int64_t)1 << 31) || (int64_t)g->N * g->O * p.HoWo >= ((int64_t)1 << 31)) return 0;          // 32-bit element offsets
+    int MF = 0;
+    for (int mf = 4; mf >= 1; mf >>= 1) {
+        const int BM = 64 * mf;
+        int TH, NI;
+        if (p.HoWo >= BM) { if (BM % p.Wo) continue; TH = BM / p.Wo; if (p.Ho % TH) continue; NI = 1; }
+        else { if (BM % p.HoWo) continue; NI = BM / p.HoWo; TH = p.Ho; }
+        const int PH = (TH - 1) * p.S + g->KH, PW = g->W + 2 * g->pad_w;          // staging writes whole input rows
+        if (PH > 255 || NI > 255) continue;
+        const int64_t patch = (int64_t)NI * PH * PW * QD_RS;
+        const int nunits = NI * PH * (g->W / 4) * 16;
+        if (patch > 60 * 1024 || nunits > 256 * QDF_UPT) continue;
+        MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.nunits = nunits;
+        break;
+    }
+    if (!MF) return 0;
+    if (const char* e = MN_ENV("MN_QD_MF")) { (void)e; }
+    pl->MF = MF;
+    p.W4 = g->W / 4;
+    p.tpi = p.NI == 1 ? p.Ho / p.TH : 1;
+    const int ntiles = p.NI == 1 ? g->N * p.tpi : (g->N + p.NI - 1) / p.NI;
+    p.ncot = g->O / 64; p.nchunks = g->C / 64; p.nitems = ntiles * p.ncot; p.out32 = out32;
+    p.fd_w4 = make_fastdiv((uint32_t)p.W4); p.fd_ph = make_fastdiv((uint32_t)p.PH); p.fd_ni = make_fastdiv((uint32_t)p.NI);
+    p.fd_th = make_fastdiv((uint32_t)p.TH); p.fd_ncot = make_fastdiv((uint32_t)p.ncot); p.fd_tpi = make_fastdiv((uint32_t)p.tpi);
+    int tgt = 512;
+    if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }     // tuning knob
+    pl->grid = p.nitems < tgt ? p.nitems : tgt;
+    pl->lds = (size_t)2 * QD_WSTEP + (size_t)p.NI * p.PH * p.PW * QD_RS;
+    // workspace: packed weights | statistics partials [S][O][2] doubles | per-channel weight scale [O]
+    const int64_t pack_bytes = ((int64_t)g->O * g->C * p.TAPS * 2 + 255) / 256 * 256;
+    int S = (2048 + g->O - 1) / g->O;
+    const int64_t maxS = ((int64_t)g->N * (p.HoWo / 8) + 255) / 256;
+    if (S > maxS) S = (int)maxS;
+    if (S > 32) S = 32;
+    if (S < 1) S = 1;
+    pl->S_stats = S;
+    pl->off_part = pack_bytes;
+    pl->off_scale = pl->off_part + ((int64_t)S * g->O * 2 * 8 + 255) / 256 * 256;
+    pl->ws_bytes = pl->off_scale + ((int64_t)g->O * 4 + 255) / 256 * 256;
+    return 1;
+}
+static void qd_launch_pack(const float* w, uint16_t* out, int O, int C, int T, int w_bits, int orient, hipStream_t s) {
+    QdPackParams k;
+    k.w = w; k.out = out; k.O = O; k.C = C; k.T = T; k.wn = (float)((1ll << w_bits) - 1); k.orient = orient; k.ngroups = (int64_t)O * C * T / 8;
+    hipLaunchKernelGGL(k_qd_pack, dim3((unsigned)((k.ngroups + 255) / 256)), dim3(256), 0, s, k);
+}
+// the stash of a dense layer is 32 bits wide when K * amax * wmax does not fit 16
+int qd_stash32(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
+    const int64_t K = (int64_t)g->C * g->KH * g->KW, wmax = (1ll << wq->bits) - 1, amax = (1ll << a_bits) - 1;
+    return K * amax * wmax > 32767;
+}
+int qd_fwd_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
+    if (!wq || wq->mode != MN_WQ_DOREFA || wq->bits < 2 || wq->bits > 8 || a_bits < 2 || a_bits > 7 || !g) return 0;
+    const int64_t K = (int64_t)g->C * g->KH * g->KW, wmax = (1ll << wq->bits) - 1, amax = (1ll << a_bits) - 1;
+    if (K * amax * wmax >= (1ll << 24)) return 0;          // the fp32 accumulation of integer products must stay exact
+    QdfPlan pl;
+    return plan_qdf(g, 0, &pl);
+}
+int64_t qd_fwd_ws_bytes(const mn_conv_geom* g) { QdfPlan pl; return plan_qdf(g, 0, &pl) ? pl.ws_bytes : 0; }
+// conv on activation codes -> stash (int16 / int32 by qd_stash32) + statistics partials; *parts / *nparts / *rowscale: what qa_launch_stats_prep reads
+int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a_bits, const float* w, void* stash, void* ws, int64_t ws_bytes, hipStream_t s,
+                 const double** parts, int* nparts, float** rowscale) {
+    QdfPlan pl;
+    const int out32 = qd_stash32(g, wq, a_bits);
+    if (!qd_fwd_supported(g, wq, a_bits) || !plan_qdf(g, out32, &pl) || (((uintptr_t)x) & 3) || !aligned16(stash) || !w) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnq_fwd_stash(dense): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_qconv_bnq_fwd_stash(dense): workspace too small");
+    QdfParams& p = pl.p;
+    uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
+    qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 0, s);
+    p.x = x; p.wpk = wpk; p.stash = stash;
+    mn_set_last_kernel("k_qd_fwd<%d>", pl.MF);
+    { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); }
+    mn_prof_begin(s);
+    if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4>, pl.lds); hipLaunchKernelGGL(k_qd_fwd<4>, dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2>, pl.lds); hipLaunchKernelGGL(k_qd_fwd<2>, dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    else { raise_lds_limit((const void*)k_qd_fwd<1>, pl.lds); hipLaunchKernelGGL(k_qd_fwd<1>, dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    mn_prof_end(s);
+    double* part = reinterpret_cast<double*>((char*)ws + pl.off_part);
+    const dim3 sgrid((unsigned)g->O, (unsigned)pl.S_stats);
+    if (out32) hipLaunchKernelGGL(k_qd_stats<1>, sgrid, dim3(256), 0, s, (const void*)stash, (int)g->N, (int)g->O, p.HoWo, part);
+    else hipLaunchKernelGGL(k_qd_stats<0>, sgrid, dim3(256), 0, s, (const void*)stash, (int)g->N, (int)g->O, p.HoWo, part);
+    *parts = part; *nparts = pl.S_stats; *rowscale = reinterpret_cast<float*>((char*)ws + pl.off_scale);
+    MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash(dense)");
+    return MN_OK;
+}
+
+// ================================================================================================ backward-data
+//   dq[n][c][ih][iw] = (1 / n_w) * sum over (o, r, s) of wcode[o][c][r][s] * gy[n][o][oh][ow],   ih = oh S + r - P, iw = ow S + s - P
+// The same organisation with the roles of the channel axes swapped: the staged patch is gy (fp32, three exact bf16 terms: three LDS planes of
+// [pixel slot][32 o] with 80-byte slots, one-pixel zero frame), the contraction walks the OUTPUT channels in chunks of 32 (one MFMA K), a step is
+// one kernel row (3 taps, 12 KB of weight fragments), a wave owns 16 MF gy-domain pixels x 64 input channels.
+//   S = 1: dq pixel (ih, iw) meets gy pixel (ih + 1 - r, iw + 1 - s): tap (r, s) is the patch offset (2 - r, 2 - s) from the window's corner.
+//   S = 2: a gy-domain CELL (oh', ow') owns the four dq pixels (2 oh' + ph, 2 ow' + pw); tap row r belongs to ph = (r != 1) and meets gy row
+//          oh' + (r == 0), columns alike: four accumulator sets [ph][pw], 1 + 2 + 2 + 4 = 9 taps per cell -- no multiplication by the zeros of a
+//          dilated gy; the two column parities of a row are interleaved in registers: 8 consecutive dq pixels per lane and channel.
+//          1 x 1 / stride 2 (the shortcut): only (ph, pw) = (0, 0) receives anything; the other three quarters are written as zeros.
+// No clip-STE epilogue: the consumer of dq (mn_qa_bwd_* / mn_qr_bwd_*) applies the quantizer's STE where it recomputes the activation.
+#define QDD_RS 80
+#define QDD_UPT 2
+struct QddParams {
+    const float* gy;              // [N][O][Hg][Wg]
+    const uint16_t* wpk;          // k_qd_pack orient 1
+    float* dx;                    // [N][C][S Hg][S Wg]
+    float wscale;
+    int N, C, Hg, Wg, O, HWg;
+    int TAPS, TPS, NSTEP, WSB;    // taps, taps per step, steps per chunk, bytes of weights per step
+    int TH, NI, PH, PW, W4, TS;   // TS: bytes per term plane
+    int tpi, ncit, nchunks, nitems, nunits, w_shift;
+    FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_ncit, fd_tpi;
+};
+
+template <int MF, int S, int TAPS>
+__global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* wbuf = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* patch = wbuf + 2 * p.WSB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
+    constexpr int TPS = TAPS == 9 ? 3 : 1, NSTEP = TAPS == 9 ? 3 : 1;
+    if ((int)blockIdx.x >= p.nitems) return;
+    for (int i = tid; i < (3 * p.TS) / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    // staging roles: unit u = ((q * NI + img) * PH + pr) * W4 + d  ->  output channels 4q .. 4q + 3 of the chunk, patch row pr, pixels 4d .. 4d + 3
+    int u_lds[QDD_UPT], u_goff[QDD_UPT], u_pi[QDD_UPT];
+#pragma unroll
+    for (int i = 0; i < QDD_UPT; ++i) {
+        const int u = tid + 256 * i;
+        const uint32_t t0 = fd_div((uint32_t)u, p.fd_w4);
+        const int d = u - (int)t0 * p.W4;
+        const uint32_t t1 = fd_div(t0, p.fd_ph);
+        const int pr = (int)t0 - (int)t1 * p.PH;
+        const uint32_t q = fd_div(t1, p.fd_ni);
+        const int img = (int)t1 - (int)q * p.NI;
+        const bool v = u < p.nunits;
+        u_lds[i] = v ? ((img * p.PH + pr) * p.PW + 4 * d + 1) * QDD_RS + 8 * (int)q : -1;
+        u_goff[i] = v ? 4 * (int)q * p.HWg + 4 * d : 0;
+        u_pi[i] = pr | (img << 8);
+    }
+    float4 preg[QDD_UPT][4];
+    uint32_t pok = 0u;
+    auto tile_origin = [&](int item, int& n0, int& oh0, int& cit) {
+        const uint32_t tile = fd_div((uint32_t)item, p.fd_ncit);
+        cit = item - (int)tile * p.ncit;
+        if (p.NI == 1) { const uint32_t n = fd_div(tile, p.fd_tpi); n0 = (int)n; oh0 = ((int)tile - (int)n * p.tpi) * p.TH; }
+        else { n0 = (int)tile * p.NI; oh0 = 0; }
+    };
+    auto fetch_patch = [&](int item, int chunk) {
+        int n0, oh0, cit;
+        tile_origin(item, n0, oh0, cit);
+        pok = 0u;
+#pragma unroll
+        for (int i = 0; i < QDD_UPT; ++i) {
+            int n = n0 + (u_pi[i] >> 8), oh = oh0 - 1 + (u_pi[i] & 255);
+            const bool ok = u_lds[i] >= 0 && n < p.N && oh >= 0 && oh < p.Hg;
+            n = n < p.N ? n : p.N - 1;
+            oh = oh < 0 ? 0 : (oh < p.Hg ? oh : p.Hg - 1);
+            const uint32_t base = (uint32_t)((n * p.O + chunk * 32) * p.Hg + oh) * (uint32_t)p.Wg + (uint32_t)u_goff[i];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) preg[i][cc] = *reinterpret_cast<const float4*>(p.gy + base + (uint32_t)(cc * p.HWg));
+            pok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto commit_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < QDD_UPT; ++i) {
+            if (u_lds[i] < 0) continue;
+            const bool ok = (pok >> i) & 1u;
+            float t0[4][4], t1[4][4], t2[4][4];                    // [channel][pixel]
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float v[4] = {preg[i][cc].x, preg[i][cc].y, preg[i][cc].z, preg[i][cc].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float vv = ok ? v[e] : 0.f;
+                    t0[cc][e] = mn_bf16_head(vv);
+                    const float r1 = vv - t0[cc][e];
+                    t1[cc][e] = mn_bf16_head(r1);
+                    t2[cc][e] = r1 - t1[cc][e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned char* d = patch + u_lds[i] + e * QDD_RS;
+                *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0][e], t0[1][e]), mn_pack_bf16x2(t0[2][e], t0[3][e])};
+                *reinterpret_cast<u32x2*>(d + p.TS) = u32x2{mn_pack_bf16x2(t1[0][e], t1[1][e]), mn_pack_bf16x2(t1[2][e], t1[3][e])};
+                *reinterpret_cast<u32x2*>(d + 2 * p.TS) = u32x2{mn_pack_bf16x2(t2[0][e], t2[1][e]), mn_pack_bf16x2(t2[2][e], t2[3][e])};
+            }
+        }
+    };
+    u32x4 wreg[TPS];
+    struct Pos { int item, chunk, step; };
+    auto fetch_w = [&](const Pos& q) {
+        const uint32_t tile = fd_div((uint32_t)q.item, p.fd_ncit);
+        const int cit = q.item - (int)tile * p.ncit;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.wpk) + (int64_t)((cit * p.nchunks + q.chunk) * NSTEP + q.step) * p.WSB;
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) wreg[t] = *reinterpret_cast<const u32x4*>(src + t * 4096 + tid * 16);
+    };
+    auto commit_w = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) *reinterpret_cast<u32x4*>(wbuf + buf * p.WSB + t * 4096 + tid * 16) = wreg[t];
+    };
+    const int stride_items = (int)gridDim.x;
+    auto advance = [&](Pos& q) {
+        if (++q.step == NSTEP) { q.step = 0; if (++q.chunk == p.nchunks) { q.chunk = 0; q.item += stride_items; } }
+    };
+    // S = 1: the corner of the pixel's 3 x 3 window;  S = 2: the cell's own slot
+    int abase[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int tp = wave * 16 * MF + mf * 16 + j;
+        const int ow = tp & (p.Wg - 1), t = tp >> p.w_shift;
+        const uint32_t img = fd_div((uint32_t)t, p.fd_th);
+        const int ohl = t - (int)img * p.TH;
+        abase[mf] = (((int)img * p.PH + ohl + (S == 2 ? 1 : 0)) * p.PW + ow + (S == 2 ? 1 : 0)) * QDD_RS + kg * 16;
+    }
+    constexpr int NACC = S == 2 ? 4 : 1;
+    Pos nxt{(int)blockIdx.x, 0, 0};
+    fetch_patch(nxt.item, 0);
+    fetch_w(nxt);
+    __syncthreads();
+    commit_patch();
+    commit_w(0);
+    advance(nxt);
+    if (nxt.item < p.nitems) fetch_w(nxt);
+    Pos la = nxt;
+    advance(la);
+    __syncthreads();
+    int buf = 0;
+    for (int item = (int)blockIdx.x; item < p.nitems; item += stride_items) {
+        f32x4 acc[NACC][MF][4];
+#pragma unroll
+        for (int a_ = 0; a_ < NACC; ++a_)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) acc[a_][mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+            int nitem = item, nchunk = chunk + 1;
+            if (nchunk == p.nchunks) { nchunk = 0; nitem += stride_items; }
+            const bool have_next = nitem < p.nitems;
+            if (have_next) fetch_patch(nitem, nchunk);
+#pragma unroll
+            for (int step = 0; step < NSTEP; ++step) {             // kernel row r = step (1 x 1: the single tap)
+                if (nxt.item < p.nitems) commit_w(buf ^ 1);
+                if (la.item < p.nitems) fetch_w(la);
+                advance(nxt);
+                advance(la);
+                const unsigned char* wb = wbuf + buf * p.WSB + lane * 16;
+#pragma unroll
+                for (int tis = 0; tis < TPS; ++tis) {               // kernel column s = tis
+                    const int toff = S == 1 ? ((2 - step) * p.PW + (2 - tis)) * QDD_RS : (TAPS == 9 ? ((step == 0 ? 1 : 0) * p.PW + (tis == 0 ? 1 : 0)) * QDD_RS : 0);
+                    const int ai = (S == 2 && TAPS == 9) ? (step != 1 ? 2 : 0) + (tis != 1 ? 1 : 0) : 0;
+                    u32x4 b[4];
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) b[nf] = *reinterpret_cast<const u32x4*>(wb + (tis * 4 + nf) * 1024);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        u32x4 a[MF];
+#pragma unroll
+                        for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const u32x4*>(patch + t * p.TS + abase[mf] + toff);
+#pragma unroll
+                        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < 4; ++nf) {
+                                if (NACC == 1) acc[0][mf][nf] = mn_mfma_bf16(a[mf], b[nf], acc[0][mf][nf]);
+                                else {
+#pragma unroll
+                                    for (int a_ = 0; a_ < NACC; ++a_) if (a_ == ai) acc[a_][mf][nf] = mn_mfma_bf16(a[mf], b[nf], acc[a_][mf][nf]);
+                                }
+                            }
+                    }
+                }
+                __syncthreads();
+                buf ^= 1;
+            }
+            if (have_next) { commit_patch(); __syncthreads(); }
+        }
+        int n0, oh0, cit;
+        tile_origin(item, n0, oh0, cit);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int tp = wave * 16 * MF + mf * 16 + 4 * kg;
+            const int ow = tp & (p.Wg - 1), t = tp >> p.w_shift;
+            const uint32_t img = fd_div((uint32_t)t, p.fd_th);
+            const int ohl = t - (int)img * p.TH;
+            const int n = n0 + (int)img;
+            if (n >= p.N) continue;
+            if (S == 1) {
+                const uint32_t base = (uint32_t)((n * p.C + cit * 64 + j) * p.Hg + oh0 + ohl) * (uint32_t)p.Wg + (uint32_t)ow;
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                    *reinterpret_cast<float4*>(p.dx + base + (uint32_t)(nf * 16 * p.HWg)) =
+                        make_float4(acc[0][mf][nf][0] * p.wscale, acc[0][mf][nf][1] * p.wscale, acc[0][mf][nf][2] * p.wscale, acc[0][mf][nf][3] * p.wscale);
+            } else {
+                const int WX = 2 * p.Wg;
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const uint32_t base = (uint32_t)((n * p.C + cit * 64 + j) * 2 * p.Hg + 2 * (oh0 + ohl) + ph) * (uint32_t)WX + (uint32_t)(2 * ow);
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) {
+                        const f32x4 e = acc[(NACC == 4 ? 2 * ph : 0)][mf][nf], o = acc[(NACC == 4 ? 2 * ph + 1 : 0)][mf][nf];
+                        float* dst = p.dx + base + (uint32_t)(nf * 16 * 4 * p.HWg);
+                        *reinterpret_cast<float4*>(dst) = make_float4(e[0] * p.wscale, o[0] * p.wscale, e[1] * p.wscale, o[1] * p.wscale);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(e[2] * p.wscale, o[2] * p.wscale, e[3] * p.wscale, o[3] * p.wscale);
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct QddPlan { QddParams p; int MF, S, grid; size_t lds; int64_t ws_bytes; };
+static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
+    if (!qd_geom_ok(g)) return 0;
+    QddParams& p = pl->p;
+    const int S = g->stride_h;
+    pl->S = S;
+    p.N = g->N; p.C = g->C; p.O = g->O; p.Hg = g->H / S; p.Wg = g->W / S; p.HWg = p.Hg * p.Wg;
+    p.TAPS = g->KH * g->KW; p.TPS = p.TAPS == 9 ? 3 : 1; p.NSTEP = p.TAPS == 9 ? 3 : 1; p.WSB = p.TPS * 4096;
+    p.w_shift = qd_log2(p.Wg);
+    if (p.w_shift < 2 || p.Wg > 32 || p.HWg % 8) return 0;
+    if ((int64_t)g->N * g->C * g->H * g->W >= ((int64_t)1 << 31) || (int64_t)g->N * g->O * p.HWg >= ((int64_t)1 << 31)) return 0;
+    int MF = 0;
+    for (int mf = (S == 2 ? 1 : 2); mf >= 1; mf >>= 1) {
+        const int BM = 64 * mf;
+        int TH, NI;
+        if (p.HWg >= BM) { if (BM % p.Wg) continue; TH = BM / p.Wg; if (p.Hg % TH) continue; NI = 1; }
+        else { if (BM % p.HWg) continue; NI = BM / p.HWg; TH = p.Hg; }
+        const int PH = TH + 2, PW = p.Wg + 2;
+        if (PH > 255 || NI > 255) continue;
+        const int64_t plane = ((int64_t)NI * PH * PW * QDD_RS + 255) / 256 * 256;
+        const int nunits = NI * PH * (p.Wg / 4) * 8;
+        if (3 * plane > 54 * 1024 || nunits > 256 * QDD_UPT) continue;
+        MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.TS = (int)plane; p.nunits = nunits;
+        break;
+    }
+    if (!MF) return 0;
+    pl->MF = MF;
+    p.W4 = p.Wg / 4;
+    p.tpi = p.NI == 1 ? p.Hg / p.TH : 1;
+    const int ntiles = p.NI == 1 ? g->N * p.tpi : (g->N + p.NI - 1) / p.NI;
+    p.ncit = g->C / 64; p.nchunks = g->O / 32; p.nitems = ntiles * p.ncit;
+    p.fd_w4 = make_fastdiv((uint32_t)p.W4); p.fd_ph = make_fastdiv((uint32_t)p.PH); p.fd_ni = make_fastdiv((uint32_t)p.NI);
+    p.fd_th = make_fastdiv((uint32_t)p.TH); p.fd_ncit = make_fastdiv((uint32_t)p.ncit); p.fd_tpi = make_fastdiv((uint32_t)p.tpi);
+    int tgt = 512;
+    if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }
+    pl->grid = p.nitems < tgt ? p.nitems : tgt;
+    pl->lds = (size_t)2 * p.WSB + (size_t)3 * p.TS;
+    pl->ws_bytes = ((int64_t)g->O * g->C * p.TAPS * 2 + 255) / 256 * 256;
+    return 1;
+}
+int qd_dgrad_supported(const mn_conv_geom* g, const mn_wq* wq) {
+    QddPlan pl;
+    return wq && wq->mode == MN_WQ_DOREFA && wq->bits >= 2 && wq->bits <= 8 && plan_qdd(g, &pl);
+}
+int qd_dgrad_native(const mn_conv_geom* g, const mn_wq* wq) { return qd_dgrad_supported(g, wq); }
+int64_t qd_dgrad_ws_bytes(const mn_conv_geom* g) { QddPlan pl; return plan_qdd(g, &pl) ? pl.ws_bytes : 0; }
+int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, float* dx, void* ws, int64_t ws_bytes, hipStream_t s) {
+    QddPlan pl;
+    if (!qd_dgrad_supported(g, wq) || !plan_qdd(g, &pl) || !aligned16(gy) || !aligned16(dx) || !w) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data(dense): workspace too small");
+    QddParams& p = pl.p;
+    uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
+    qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 1, s);
+    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1);
+    mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); }
+    mn_prof_begin(s);
+    if (pl.S == 2 && p.TAPS == 9) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    else if (pl.S == 2) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_dgrad<2, 1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<2, 1, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    else { raise_lds_limit((const void*)k_qd_dgrad<1, 1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 1, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_data(dense)");
+    return MN_OK;
+}
+
+// ================================================================================================ backward-weight
+//   dw[o][c][r][s] = s_a * sum over (n, oh, ow) of gy[n][o][oh][ow] * j[n][c][oh S + r - P][ow S + s - P]
+// M = 64 output channels, N = taps x 64 input channels, K = gy-domain pixels (contiguous in NCHW for both operands: no transposition anywhere).
+// A block (8 waves, one per CU) owns one (64 o, 64 c) pair and a range of pixel tiles (split-K); per tile it stages the input patch of its 64
+// channels ONCE as bf16 (rows 8-byte aligned, zero frame), per K-step of 32 pixels the gy rows as three exact bf16 term planes [o][32 px]
+// (80-byte rows, double buffered).  Wave w contracts input-channel fragment (w & 3) against output-channel fragments 2 (w >> 2), + 1 for all
+// taps: 18 accumulator tiles.  The B fragment of a tap = 2 x 4 consecutive gy-domain pixels shifted by the tap:
+//   S = 1: patch [c][image][row][4 + W + 4]; per kernel row one aligned 8-byte read + its two neighbour dwords per half fragment, the three
+//          column shifts by v_alignbyte (no shifted copies in LDS, no im2col);
+//   S = 2: the patch rows are split by column parity, [c][image][row][even | odd][4 + W/2 + 4]: tap column 1 reads the even plane, column 2 the
+//          odd plane, column 0 the odd plane one pixel to the left; 1 x 1 / stride 2: the even plane of the even rows only.
+// Partial tiles [z][pair][tap][o][c] are summed in fp64 in fixed order by k_qd_wgrad_reduce (deterministic).
+#define QDW_UPT 10             // patch dwords a thread stages per tile
+#define QDW_DYP 5120           // bytes per gy term plane (64 rows x 80)
+struct QdwParams {
+    const float* gy;              // [N][O][Hg][Wg]
+    const unsigned char* x;       // [N][C][S Hg][S Wg] codes
+    float* part;
+    int N, C, Hg, Wg, O, HWg, HX, WX, PAD;
+    int TH, NI, PH, PWp, RB, CS, W4, BMt, nks;    // tile rows / images, patch rows, padded plane row (bf16 elements), bytes per patch row, bytes per channel, K-steps per tile
+    int tpi, ntiles, tpz, Z, ncit, npairs, nunits, w_shift;
+    FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_tpi, fd_np;
+};
+
+template <int S, int TAPS>
+__global__ __launch_bounds__(512, 2) void k_qd_wgrad(const QdwParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* dyb = reinterpret_cast<unsigned char*>(smem);          // [2][3][64][80]
+    unsigned char* xp = dyb + 2 * 3 * QDW_DYP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
+    const int cf = wave & 3, coh = wave >> 2;
+    constexpr int KR = TAPS == 9 ? 3 : 1;
+    const uint32_t z = fd_div(blockIdx.x, p.fd_np);
+    const int pair = (int)blockIdx.x - (int)z * p.npairs;
+    const int cot = pair / p.ncit, cit = pair - cot * p.ncit;
+    const int t_begin = (int)z * p.tpz, t_end = (t_begin + p.tpz) < p.ntiles ? (t_begin + p.tpz) : p.ntiles;
+    for (int i = tid; i < (64 * p.CS) / 8; i += 512) *reinterpret_cast<u32x2*>(xp + 8 * i) = u32x2{0u, 0u};
+    // patch staging roles: unit u = ((c * NI + img) * PH + pr) * W4 + d: input pixels 4d .. 4d + 3 of patch row pr
+    int u_lds[QDW_UPT], u_goff[QDW_UPT], u_pi[QDW_UPT];
+#pragma unroll
+    for (int i = 0; i < QDW_UPT; ++i) {
+        const int u = tid + 512 * i;
+        const uint32_t t0 = fd_div((uint32_t)u, p.fd_w4);
+        const int d = u - (int)t0 * p.W4;
+        const uint32_t t1 = fd_div(t0, p.fd_ph);
+        const int pr = (int)t0 - (int)t1 * p.PH;
+        const uint32_t c = fd_div(t1, p.fd_ni);
+        const int img = (int)t1 - (int)c * p.NI;
+        const bool v = u < p.nunits;
+        // S = 1: pixels 4d.. at elements 4 + 4d ..;  S = 2: the even pixels (4d, 4d + 2) at even-plane elements 4 + 2d, the odd ones at the odd plane's
+        u_lds[i] = v ? (int)c * p.CS + (img * p.PH + pr) * p.RB + (4 + (S == 2 ? 2 : 4) * d) * 2 : -1;
+        u_goff[i] = v ? (int)c * p.HX * p.WX + 4 * d : 0;
+        u_pi[i] = pr | (img << 8);
+    }
+    uint32_t preg[QDW_UPT];
+    uint32_t pok = 0u;
+    auto tile_origin = [&](int tile, int& n0, int& oh0) {
+        if (p.NI == 1) { const uint32_t n = fd_div((uint32_t)tile, p.fd_tpi); n0 = (int)n; oh0 = (tile - (int)n * p.tpi) * p.TH; }
+        else { n0 = tile * p.NI; oh0 = 0; }
+    };
+    auto fetch_patch = [&](int tile) {
+        int n0, oh0;
+        tile_origin(tile, n0, oh0);
+        pok = 0u;
+#pragma unroll
+        for (int i = 0; i < QDW_UPT; ++i) {
+            int n = n0 + (u_pi[i] >> 8), ih = oh0 * S - p.PAD + (u_pi[i] & 255);
+            const bool ok = u_lds[i] >= 0 && n < p.N && ih >= 0 && ih < p.HX;
+            n = n < p.N ? n : p.N - 1;
+            ih = ih < 0 ? 0 : (ih < p.HX ? ih : p.HX - 1);
+            preg[i] = *reinterpret_cast<const uint32_t*>(p.x + (uint32_t)((n * p.C + cit * 64) * p.HX + ih) * (uint32_t)p.WX + (uint32_t)u_goff[i]);
+            pok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto commit_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < QDW_UPT; ++i) {
+            if (u_lds[i] < 0) continue;
+            const uint32_t v = ((pok >> i) & 1u) ? preg[i] : 0u;
+            const float f0 = (float)(v & 0xffu), f1 = (float)((v >> 8) & 0xffu), f2 = (float)((v >> 16) & 0xffu), f3 = (float)(v >> 24);
+            if (S == 1) *reinterpret_cast<u32x2*>(xp + u_lds[i]) = u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)};
+            else {
+                *reinterpret_cast<uint32_t*>(xp + u_lds[i]) = mn_pack_hi16(f0, f2);
+                *reinterpret_cast<uint32_t*>(xp + u_lds[i] + p.PWp * 2) = mn_pack_hi16(f1, f3);
+            }
+        }
+    };
+    // gy staging role: row co = tid >> 3, float4 f = tid & 7 of the K-step
+    const int s_co = tid >> 3, s_f = tid & 7;
+    float4 greg;
+    auto fetch_gy = [&](int tile, int ks) {
+        int n0, oh0;
+        tile_origin(tile, n0, oh0);
+        const int kp = ks * 32 + 4 * s_f;
+        const int col = kp & (p.Wg - 1), t = kp >> p.w_shift;
+        const uint32_t img = fd_div((uint32_t)t, p.fd_th);
+        const int ohl = t - (int)img * p.TH;
+        int n = n0 + (int)img;
+        const bool ok = n < p.N;
+        n = ok ? n : p.N - 1;
+        const float4 v = *reinterpret_cast<const float4*>(p.gy + (uint32_t)((n * p.O + cot * 64 + s_co) * p.Hg + oh0 + ohl) * (uint32_t)p.Wg + (uint32_t)col);
+        greg = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto commit_gy = [&](int buf) {
+        const float v[4] = {greg.x, greg.y, greg.z, greg.w};
+        float t0[4], t1[4], t2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t0[e] = mn_bf16_head(v[e]);
+            const float r1 = v[e] - t0[e];
+            t1[e] = mn_bf16_head(r1);
+            t2[e] = r1 - t1[e];
+        }
+        unsigned char* d = dyb + buf * 3 * QDW_DYP + s_co * 80 + s_f * 8;
+        *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
+        *reinterpret_cast<u32x2*>(d + QDW_DYP) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
+        *reinterpret_cast<u32x2*>(d + 2 * QDW_DYP) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
+    };
+    f32x4 acc[2][TAPS];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[c2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t_begin < t_end) {
+        fetch_patch(t_begin);
+        fetch_gy(t_begin, 0);
+    }
+    __syncthreads();                          // zero fill complete
+    int gbuf = 0;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        commit_patch();
+        commit_gy(gbuf);                      // buffer gbuf: every wave left it at the previous tile's last barrier
+        __syncthreads();
+        if (tile + 1 < t_end) fetch_patch(tile + 1);               // in flight during the tile's K-steps
+        for (int ks = 0; ks < p.nks; ++ks) {
+            // gy of the next K-step (of this tile, or the first of the next tile): fetched now, committed after this step's MFMAs
+            const bool more = ks + 1 < p.nks || tile + 1 < t_end;
+            if (more) fetch_gy(ks + 1 < p.nks ? tile : tile + 1, ks + 1 < p.nks ? ks + 1 : 0);
+            const unsigned char* gb = dyb + gbuf * 3 * QDW_DYP + ((2 * coh) * 16 + j) * 80 + kg * 16;
+            u32x4 a[2][3];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a[c2][t] = *reinterpret_cast<const u32x4*>(gb + t * QDW_DYP + c2 * 16 * 80);
+            // this lane's two half fragments: gy-domain pixels kp .. kp + 3 of the tile
+            int hoff[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kp = ks * 32 + 8 * kg + 4 * h;
+                const int col = kp & (p.Wg - 1), t = kp >> p.w_shift;
+                const uint32_t img = fd_div((uint32_t)t, p.fd_th);
+                const int ohl = t - (int)img * p.TH;
+                hoff[h] = (cf * 16 + j) * p.CS + ((int)img * p.PH + ohl * S) * p.RB + (4 + col) * 2;
+            }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                uint32_t lo[3][2], hi[3][2];                           // [s][half]
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned char* q = xp + hoff[h] + r * p.RB;
+                    if (S == 1) {
+                        const uint32_t pv = *reinterpret_cast<const uint32_t*>(q - 4), nx = *reinterpret_cast<const uint32_t*>(q + 8);
+                        const u32x2 c = *reinterpret_cast<const u32x2*>(q);
+                        lo[0][h] = mn_alignbyte(c[0], pv, 2); hi[0][h] = mn_alignbyte(c[1], c[0], 2);
+                        lo[1][h] = c[0]; hi[1][h] = c[1];
+                        lo[2][h] = mn_alignbyte(c[1], c[0], 2); hi[2][h] = mn_alignbyte(nx, c[1], 2);
+                    } else {
+                        const u32x2 e = *reinterpret_cast<const u32x2*>(q);
+                        lo[1][h] = e[0]; hi[1][h] = e[1];
+                        if (TAPS == 9) {
+                            const unsigned char* qo = q + p.PWp * 2;
+                            const uint32_t pv = *reinterpret_cast<const uint32_t*>(qo - 4);
+                            const u32x2 o = *reinterpret_cast<const u32x2*>(qo);
+                            lo[0][h] = mn_alignbyte(o[0], pv, 2); hi[0][h] = mn_alignbyte(o[1], o[0], 2);
+                            lo[2][h] = o[0]; hi[2][h] = o[1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    if (TAPS == 1 && s_ != 1) continue;
+                    const u32x4 b = u32x4{lo[s_][0], hi[s_][0], lo[s_][1], hi[s_][1]};
+                    const int ti = TAPS == 9 ? r * 3 + s_ : 0;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) acc[c2][ti] = mn_mfma_bf16(a[c2][t], b, acc[c2][ti]);
+                }
+            }
+            if (more && ks + 1 < p.nks) commit_gy(gbuf ^ 1);
+            __syncthreads();
+            if (ks + 1 < p.nks) gbuf ^= 1;
+        }
+    }
+    // D[row = o: 4 kg + r][col = c: j]
+    float* dst = p.part + ((int64_t)((int)z * p.npairs + pair) * TAPS) * 4096;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[t * 4096 + ((2 * coh + c2) * 16 + 4 * kg + r) * 64 + cf * 16 + j] = acc[c2][t][r];
+}
+// dw[o][c][tap] = scale * sum over z (fixed order, fp64) of part[z][pair][tap][o % 64][c % 64]
+__global__ __launch_bounds__(256) void k_qd_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int O, int C, int T, int Z, float scale) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                // (pair, tap, o, c) with c fastest
+    const int npairs = (O / 64) * (C / 64);
+    if (idx >= npairs * T * 4096) return;
+    const int c = idx & 63, o = (idx >> 6) & 63, t = (idx >> 12) % T, pair = (idx >> 12) / T;
+    double s = 0.0;
+    for (int zz = 0; zz < Z; ++zz) s += (double)part[(int64_t)zz * npairs * T * 4096 + idx];
+    const int cot = pair / (C / 64), cit = pair - cot * (C / 64);
+    dw[((int64_t)(cot * 64 + o) * C + cit * 64 + c) * T + t] = (float)(s * (double)scale);
+}
+
+struct QdwPlan { QdwParams p; int S, T, grid; size_t lds; int64_t ws_bytes; };
+static int plan_qdw(const mn_conv_geom* g, QdwPlan* pl) {
+    if (!qd_geom_ok(g)) return 0;
+    QdwParams& p = pl->p;
+    const int S = g->stride_h, T = g->KH * g->KW;
+    pl->S = S; pl->T = T;
+    p.N = g->N; p.C = g->C; p.O = g->O; p.HX = g->H; p.WX = g->W; p.Hg = g->H / S; p.Wg = g->W / S; p.HWg = p.Hg * p.Wg; p.PAD = g->pad_h;
+    p.w_shift = qd_log2(p.Wg);
+    if (p.w_shift < 2 || p.Wg > 32 || p.HWg % 8) return 0;
+    if ((int64_t)g->N * g->C * g->H * g->W >= ((int64_t)1 << 31) || (int64_t)g->N * g->O * p.HWg >= ((int64_t)1 << 31)) return 0;
+    int ok = 0;
+    for (int BMt = 256; BMt >= 32; BMt >>= 1) {
+        int TH, NI;
+        if (p.HWg >= BMt) { if (BMt % p.Wg) continue; TH = BMt / p.Wg; if (p.Hg % TH) continue; NI = 1; }
+        else { if (BMt % p.HWg) continue; NI = BMt / p.HWg; TH = p.Hg; }
+        const int PH = (TH - 1) * S + g->KH, PWp = p.Wg + 8, RB = PWp * 2 * S;
+        if (PH > 255 || NI > 255) continue;
+        int CS = NI * PH * RB;
+        if (((CS / 8) & 1) == 0) CS += 8;                     // odd multiple of 8 bytes: the 16 channels of a fragment fall on distinct 8-byte bank groups
+        const int nunits = 64 * NI * PH * (g->W / 4);
+        if ((int64_t)64 * CS > 120 * 1024 || nunits > 512 * QDW_UPT) continue;
+        p.BMt = BMt; p.TH = TH; p.NI = NI; p.PH = PH; p.PWp = PWp; p.RB = RB; p.CS = CS; p.nunits = nunits; p.nks = BMt / 32;
+        ok = 1;
+        break;
+    }
+    if (!ok) return 0;
+    p.W4 = g->W / 4;
+    p.tpi = p.NI == 1 ? p.Hg / p.TH : 1;
+    p.ntiles = p.NI == 1 ? g->N * p.tpi : (g->N + p.NI - 1) / p.NI;
+    p.ncit = g->C / 64; p.npairs = (g->O / 64) * p.ncit;
+    int tgt = 256;
+    if (const char* e = MN_ENV("MN_QDW_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }     // tuning knob
+    int Z = tgt / p.npairs;
+    if (Z > p.ntiles) Z = p.ntiles;
+    if (Z < 1) Z = 1;
+    p.tpz = (p.ntiles + Z - 1) / Z;
+    Z = (p.ntiles + p.tpz - 1) / p.tpz;
+    p.Z = Z;
+    p.fd_w4 = make_fastdiv((uint32_t)p.W4); p.fd_ph = make_fastdiv((uint32_t)p.PH); p.fd_ni = make_fastdiv((uint32_t)p.NI);
+    p.fd_th = make_fastdiv((uint32_t)p.TH); p.fd_tpi = make_fastdiv((uint32_t)p.tpi); p.fd_np = make_fastdiv((uint32_t)p.npairs);
+    pl->grid = p.npairs * Z;
+    pl->lds = (size_t)2 * 3 * QDW_DYP + (size_t)64 * p.CS;
+    pl->ws_bytes = (int64_t)Z * p.npairs * T * 4096 * 4;
+    return 1;
+}
+int qd_wgrad_supported(const mn_conv_geom* g, int a_bits) {
+    if (a_bits < 2 || a_bits > 7) return 0;
+    QdwPlan pl;
+    return plan_qdw(g, &pl);
+}
+int64_t qd_wgrad_ws_bytes(const mn_conv_geom* g) { QdwPlan pl; return plan_qdw(g, &pl) ? pl.ws_bytes : 0; }
+int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, void* ws, int64_t ws_bytes, hipStream_t s) {
+    QdwPlan pl;
+    if (!plan_qdw(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3) || !dw) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(dense): geometry not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense): workspace too small");
+    QdwParams& p = pl.p;
+    p.gy = gy; p.x = x; p.part = reinterpret_cast<float*>(ws);
+    mn_set_last_kernel("k_qd_wgrad<%d, %d>", pl.S, pl.T);
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + nx * (g->O / 64) + (double)pl.ws_bytes); }
+    mn_prof_begin(s);
+    if (pl.S == 1) { raise_lds_limit((const void*)k_qd_wgrad<1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<1, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
+    else if (pl.T == 9) { raise_lds_limit((const void*)k_qd_wgrad<2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
+    else { raise_lds_limit((const void*)k_qd_wgrad<2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 1>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
+    mn_prof_end(s);
+    const int total = p.npairs * pl.T * 4096;
+    hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)p.part, dw, (int)g->O, (int)g->C, pl.T, p.Z, ascale);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(dense)");
+    return MN_OK;
+}

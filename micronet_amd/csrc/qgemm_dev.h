@@ -97,6 +97,20 @@ void qa_launch_stats_prep(const double* part, int CB, int G, int Mpad, int Mr, c
                           float momentum, int training, float* running_mean, float* running_var, float* save, int Cout, const float* gamma, const float* beta,
                           float* chan, long long* nbt, hipStream_t s);
 
+// dense (groups = 1, C and O multiples of 64) layers on k-bit activation codes (qgemm_dense.hip): the ResNet family
+int qd_fwd_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits);
+int qd_stash32(const mn_conv_geom* g, const mn_wq* wq, int a_bits);
+int64_t qd_fwd_ws_bytes(const mn_conv_geom* g);
+int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a_bits, const float* w, void* stash, void* ws, int64_t ws_bytes, hipStream_t s,
+                 const double** parts, int* nparts, float** rowscale);
+int qd_dgrad_supported(const mn_conv_geom* g, const mn_wq* wq);      // covered by qd_bwd_data OR by the generic backward-data
+int qd_dgrad_native(const mn_conv_geom* g, const mn_wq* wq);         // covered by qd_bwd_data itself
+int64_t qd_dgrad_ws_bytes(const mn_conv_geom* g);
+int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, float* dx, void* ws, int64_t ws_bytes, hipStream_t s);
+int qd_wgrad_supported(const mn_conv_geom* g, int a_bits);
+int64_t qd_wgrad_ws_bytes(const mn_conv_geom* g);
+int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, void* ws, int64_t ws_bytes, hipStream_t s);
+
 static inline int aq_codeable(const mn_actq* aq, int need_exact_x) {
     (void)need_exact_x;   // real-valued x is handled exactly by term splitting (zero terms are skipped)
     if (!aq || aq->mode == MN_ACTQ_NONE) return 1;

@@ -466,6 +466,10 @@ int kk_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const flo
 }
 int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
                 void* ws, int64_t ws_bytes, hipStream_t s) {
+    // dense layers without a clip-STE epilogue (activation codes: the STE lives in mn_qa_bwd_* / mn_qr_bwd_*): the staged-patch kernel of qgemm_dense.hip
+    if ((!aq || aq->mode == MN_ACTQ_NONE || aq->mode == MN_ACTQ_CODE8 || aq->mode == MN_ACTQ_SIGN8) && qd_dgrad_native(g, wq) && ws_bytes >= qd_dgrad_ws_bytes(g) &&
+        aligned16(gy) && aligned16(dx))
+        return qd_bwd_data(g, wq, gy, w, dx, ws, ws_bytes, s);
     KkPlan pl;
     if (!wq_codeable(wq) || !plan_kk(g, 1, MN_ACTQ_NONE, &pl) || !aligned16(gy) || !aligned16(dx))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(qgemm): geometry / quantizer combination not covered");
@@ -815,8 +819,8 @@ static void launch_kw(const KwPlan& pl, int xmode, hipStream_t s) {
 int kk_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
     KkPlan pl;
     if (which == 0) return wq_codeable(wq) && aq_codeable(aq, 0) && plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl);
-    if (which == 1) return wq_codeable(wq) && plan_kk(g, 1, MN_ACTQ_NONE, &pl);
-    if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) return k3s_wgrad_code8_supported(g, aq->bits);
+    if (which == 1) return wq_codeable(wq) && (plan_kk(g, 1, MN_ACTQ_NONE, &pl) || qd_dgrad_native(g, wq));
+    if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) return k3s_wgrad_code8_supported(g, aq->bits) || qd_wgrad_supported(g, aq->bits);
     if (which == 2) { KwPlan kw; return aq_codeable(aq, 1) && (plan_kk_wgrad(g, &kw) || (aq && aq->mode == MN_ACTQ_SIGN8 && k3s_wgrad_supported(g))); }
     return 0;
 }
@@ -827,14 +831,21 @@ int64_t kk_ws_bytes(const mn_conv_geom* g, int which) {
         int64_t b = plan_kk(g, 0, MN_ACTQ_DOREFA, &pl) ? pl.ws_bytes : 0;
         return a > b ? a : b;
     }
-    if (which == 1) return plan_kk(g, 1, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0;
-    if (which == 2) { KwPlan kw; const int64_t a = plan_kk_wgrad(g, &kw) ? kw.ws_bytes : 0, b = k3s_wgrad_ws_bytes(g); return a > b ? a : b; }
+    if (which == 1) { const int64_t a = plan_kk(g, 1, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0, b = qd_dgrad_ws_bytes(g); return a > b ? a : b; }
+    if (which == 2) {
+        KwPlan kw;
+        const int64_t a = plan_kk_wgrad(g, &kw) ? kw.ws_bytes : 0, b = k3s_wgrad_ws_bytes(g), c = qd_wgrad_ws_bytes(g);
+        const int64_t m = a > b ? a : b;
+        return m > c ? m : c;
+    }
     return 0;
 }
 int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s) {
     if (aq && aq->mode == MN_ACTQ_SIGN8 && k3s_wgrad_supported(g) && ws_bytes >= k3s_wgrad_ws_bytes(g))
         return k3s_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // 3x3 on sign codes: wave-private streaming kernel
+    if (aq && aq->mode == MN_ACTQ_CODE8 && !dbias && qd_wgrad_supported(g, aq->bits) && ws_bytes >= qd_wgrad_ws_bytes(g))      // dense layers: qgemm_dense.hip
+        return qd_bwd_weight(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, ws, ws_bytes, s);
     if (aq && aq->mode == MN_ACTQ_CODE8) {        // k-bit activation codes: only the wave-private 3x3 kernel reads them
         if (!k3s_wgrad_code8_supported(g, aq->bits) || ws_bytes < k3s_wgrad_ws_bytes(g)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): geometry / bits not covered");
         return k3s_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);

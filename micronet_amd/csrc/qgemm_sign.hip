@@ -1755,7 +1755,9 @@ static int bnq_int16_ok(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
 }
 extern "C" int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in) {
     if (!g || !wq || wq->mode != MN_WQ_DOREFA || wq->bits < 2 || wq->bits > 8 || a_bits_in < 2 || a_bits_in > 7 || g->groups < 1 || g->C % g->groups || g->O % g->groups) return 0;
+    if (qd_fwd_supported(g, wq, a_bits_in) && qd_dgrad_supported(g, wq) && qd_wgrad_supported(g, a_bits_in)) return 1;      // dense layers (ResNets): qgemm_dense.hip
     if (!bnq_int16_ok(g, wq, a_bits_in)) return 0;
+    if (g->stride_h != 1 || g->stride_w != 1) return 0;
     if (((int64_t)g->H * g->W) % 8) return 0;
     if (g->KH == 1 && g->KW == 1) {
         PwsPlan pl;
@@ -1763,8 +1765,13 @@ extern "C" int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, in
     }
     return k3s_fwd16_supported(g, wq) && k3s_wgrad_code8_supported(g, a_bits_in) && k3s_dgrad_supported(g, wq);
 }
+extern "C" int mn_qconv_bnq_stash_bits(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in) {
+    if (!mn_qconv_bnq_supported(g, wq, a_bits_in)) return 0;
+    return (qd_fwd_supported(g, wq, a_bits_in) && qd_stash32(g, wq, a_bits_in)) ? 32 : 16;
+}
 extern "C" int64_t mn_qconv_bnq_ws_bytes(const mn_conv_geom* g) {
     if (!g) return -1;
+    if (qd_fwd_ws_bytes(g) > 0) return qd_fwd_ws_bytes(g);
     if (g->KH == 1 && g->KW == 1) return pws_ws_bytes(g);
     return ((int64_t)512 * g->O * 2 * 8 + 255) / 256 * 256 + (int64_t)g->O * 4 + 256;      // statistics partials [<= 512][O][2] doubles + the per-channel scale
 }
@@ -1777,6 +1784,17 @@ extern "C" int mn_qconv_bnq_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
     if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_qconv_bnq_fwd_stash: eval mode needs the running statistics");
     hipStream_t s = (hipStream_t)stream;
     const float ascale = dorefa_scale(a_bits_in);
+    if (qd_fwd_supported(g, wq, a_bits_in) && qd_dgrad_supported(g, wq) && qd_wgrad_supported(g, a_bits_in)) {      // dense layer: stash 16 / 32 bits wide (mn_qconv_bnq_stash_bits)
+        const double* part; int nparts; float* rowscale;
+        int rc = qd_fwd_stash(g, wq, x_codes, a_bits_in, w, (void*)stash, ws, ws_bytes, s, &part, &nparts, &rowscale);
+        if (rc) return rc;
+        const int Ho = (int)((g->H + 2 * g->pad_h - g->KH) / g->stride_h + 1), Wo = (int)((g->W + 2 * g->pad_w - g->KW) / g->stride_w + 1);
+        hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((g->O + 255) / 256)), dim3(256), 0, s, rowscale, (int)g->O, 1.0f / (float)((1ll << wq->bits) - 1));
+        qa_launch_stats_prep(part, nparts, 1, (int)g->O, (int)g->O, rowscale, ascale, bias, (double)g->N * Ho * Wo, eps, momentum, training, running_mean, running_var, save,
+                             (int)g->O, gamma, beta, chan, (long long*)num_batches_tracked, s);
+        MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash(dense)");
+        return MN_OK;
+    }
     const double npix = (double)g->N * g->H * g->W;
     if (g->KH == 1 && g->KW == 1) {
         PwsPlan pl;
