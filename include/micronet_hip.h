@@ -383,12 +383,34 @@ int mn_qa_supported(int64_t H, int64_t W, int pool);
 int64_t mn_qa_ws_floats(int64_t C);
 /* chan from the (mean, invstd) a BatchNorm over fp32 y saved (mn_bnrelu_fwd's `save`): the first block of a net */
 int mn_qa_chan_from_save(const float* save, const float* gamma, const float* beta, int64_t C, float* chan, mn_stream_t stream);
+/* in_f32: 0 = the int16 stash, 1 = fp32 y, 2 = the int32 stash of a dense layer (mn_qconv_bnq_stash_bits; no pooled variant) */
 int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, uint8_t* codes, float* act_f32,
               mn_stream_t stream);
 int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, int quant,
                    float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
 int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, const float* sums, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits,
                     int pool, int quant, int training, float* dy, mn_stream_t stream);
+
+/* ------------------------------------------------------------------ the END of a residual block (k-bit DoReFa ResNets)
+ * models/resnet.py:60-65 -- relu(add(residual_function(x), shortcut(x))) -- whose residual branch ends in a dense QuantConv2d + BatchNorm2d
+ * (wqaq/dorefa/quantize.py:107-122) and whose consumers are the next block's QuantConv2d(s) and / or its identity shortcut:
+ *     u = bn(y) + res,   a = relu(u)   ->   codes of the a_bits quantizer (codes != NULL) and / or the fp32 activation (act_f32 != NULL), ONE pass
+ *   in_kind   0: y is the int16 stash of mn_qconv_bnq_fwd_stash, 2: its int32 stash (mn_qconv_bnq_stash_bits), 1: fp32 y; chan as for mn_qa_*
+ *   res_kind  0: no residual (a block that must emit codes AND fp32 at once: the stem), 1: `res` = fp32 [N][C][H][W] (identity shortcut),
+ *             2 / 3: `res` = the int16 / int32 stash of the shortcut conv, res_chan = its chan table: res = bn_s(y_s) is evaluated on the fly
+ *   mn_qr_bwd_sums   du = (STE(dq) [+ STE(dq2)] [+ g_f32]) * [u > 0] -> du [N][C][H][W] (this IS the gradient of an identity shortcut), dgamma / dbeta /
+ *                    sums [2][C] of the main BatchNorm and (res_kind >= 2) dgamma_s / dbeta_s / sums_s of the shortcut's.  dq, dq2: gradients w.r.t. the
+ *                    QUANTISED activation from the convs that read the codes (clip-STE of wqaq/dorefa/quantize.py:36-46 applied here, per consumer, as
+ *                    autograd does); g_f32: gradient w.r.t. the activation itself.  ws: mn_qr_ws_floats(C) floats.
+ *   mn_qr_bwd_apply  dy = gamma invstd (du - sum_du / n - zhat sum_du_zhat / n) for the residual branch's conv and (res_kind >= 2) dy_s for the shortcut conv. */
+int64_t mn_qr_ws_floats(int64_t C);
+int mn_qr_fwd(int in_kind, const void* in, const float* chan, int res_kind, const void* res, const float* res_chan, int64_t N, int64_t C, int64_t H, int64_t W,
+              int a_bits, uint8_t* codes, float* act_f32, mn_stream_t stream);
+int mn_qr_bwd_sums(int in_kind, const void* in, const float* chan, int res_kind, const void* res, const float* res_chan, const float* dq, const float* dq2,
+                   const float* g_f32, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, float* du, float* dgamma, float* dbeta, float* sums,
+                   float* dgamma_s, float* dbeta_s, float* sums_s, float* ws, mn_stream_t stream);
+int mn_qr_bwd_apply(int in_kind, const void* in, const float* chan, const float* sums, int res_kind, const void* res, const float* res_chan, const float* sums_s,
+                    const float* du, int64_t N, int64_t C, int64_t H, int64_t W, int training, float* dy, float* dy_s, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ classifier conv of a binary net
  * The LAST conv of the WbWtAb nets keeps fp32 weights (the rewrite skips it, wbwtab/quantize.py:251) but reads the +-1 output of the

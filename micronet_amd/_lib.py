@@ -127,6 +127,10 @@ PROTOTYPES = {
     "mn_qa_fwd": (_I, [_I, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _P]),
     "mn_qa_bwd_sums": (_I, [_I, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mn_qa_bwd_apply": (_I, [_I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
+    "mn_qr_ws_floats": (_L, [_L]),
+    "mn_qr_fwd": (_I, [_I, _P, _P, _I, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
+    "mn_qr_bwd_sums": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mn_qr_bwd_apply": (_I, [_I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
     "mn_cifar_augment": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _L, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "mn_iao_bnfold_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _L, _L, _P, _P, _P]),
     "mn_iao_bnfold_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P]),

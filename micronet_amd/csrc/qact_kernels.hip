@@ -35,7 +35,7 @@ __device__ __forceinline__ QaCh qa_load_ch(const float* __restrict__ chan, int C
 }
 template <int IN>
 __device__ __forceinline__ void qa_eval(float v, const QaCh& k, float& zh, float& z) {
-    const float y = IN ? v : v * k.alpha + k.bias;
+    const float y = IN == 1 ? v : v * k.alpha + k.bias;
     zh = (y - k.mean) * k.invstd;
     z = zh * k.ga + k.be;
 }
@@ -58,9 +58,13 @@ __device__ __forceinline__ int64_t qa_off8(const QaGeom& g, int c, uint32_t i) {
 }
 template <int IN>
 __device__ __forceinline__ void qa_load8(const void* __restrict__ in, int64_t off, float (&v)[8]) {
-    if (IN) {
+    if (IN == 1) {
         const float4 a = *reinterpret_cast<const float4*>((const float*)in + off), b = *reinterpret_cast<const float4*>((const float*)in + off + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else if (IN == 2) {          // 32-bit stash of a dense layer (|acc| < 2^24: exact in fp32)
+        const u32x4 a = *reinterpret_cast<const u32x4*>((const int32_t*)in + off), b = *reinterpret_cast<const u32x4*>((const int32_t*)in + off + 4);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { v[d] = (float)(int)a[d]; v[4 + d] = (float)(int)b[d]; }
     } else {
         const u32x4 u = *reinterpret_cast<const u32x4*>((const int16_t*)in + off);
 #pragma unroll
@@ -398,7 +402,8 @@ extern "C" int mn_qa_chan_from_save(const float* save, const float* gamma, const
     return MN_OK;
 }
 #define QA_DISPATCH(KERNEL, ...)                                                                                         \
-    if (in_f32) { if (pool) hipLaunchKernelGGL((KERNEL<1, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<1, 0>), __VA_ARGS__); } \
+    if (in_f32 == 2) { hipLaunchKernelGGL((KERNEL<2, 0>), __VA_ARGS__); }                                                \
+    else if (in_f32) { if (pool) hipLaunchKernelGGL((KERNEL<1, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<1, 0>), __VA_ARGS__); } \
     else { if (pool) hipLaunchKernelGGL((KERNEL<0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<0, 0>), __VA_ARGS__); }
 extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, uint8_t* codes, float* act_f32,
                          mn_stream_t stream) {
@@ -408,12 +413,20 @@ extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t 
     if (!in || !chan || (!codes && !act_f32) || (((uintptr_t)in) & 15) || (codes && (((uintptr_t)codes) & 7)) || (act_f32 && !aligned16(act_f32)))
         MN_FAIL(MN_EINVAL, "mn_qa_fwd: null / misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
+    if (in_f32 == 2 && pool) MN_FAIL(MN_ENOTSUP, "mn_qa_fwd: the 32-bit stash (dense layers) has no pooled variant");
     if (!in_f32 && codes && a_bits <= 3 && !MN_ENV("MN_QA_NO_THRESHOLDS")) g.nthr = (1 << a_bits) - 1;       // integer-threshold forward (A/B knob)
     const dim3 grid((unsigned)C, (unsigned)qa_split(g));
     const double nel = (double)N * C * H * W;
-    mn_set_last_kernel("k_qa_fwd<%d, %d>", in_f32 ? 1 : 0, pool ? 1 : 0);
+    mn_set_last_kernel("k_qa_fwd<%d, %d>", in_f32, pool ? 1 : 0);
     mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + (codes ? 1.0 : 0.0) * nel / (pool ? 4.0 : 1.0) + (act_f32 ? 4.0 : 0.0) * nel / (pool ? 4.0 : 1.0));
     mn_prof_begin(s);
+    if (in_f32 == 2) {
+        if (codes) hipLaunchKernelGGL((k_qa_fwd<2, 0, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr);
+        if (act_f32) hipLaunchKernelGGL((k_qa_fwd<2, 0, 1>), grid, dim3(256), 0, s, g, in, chan, (unsigned char*)nullptr, act_f32);
+        mn_prof_end(s);
+        MN_CHECK_LAUNCH("mn_qa_fwd");
+        return MN_OK;
+    }
     if (codes) {
         if (in_f32) { if (pool) hipLaunchKernelGGL((k_qa_fwd<1, 1, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); else hipLaunchKernelGGL((k_qa_fwd<1, 0, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); }
         else { if (pool) hipLaunchKernelGGL((k_qa_fwd<0, 1, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); else hipLaunchKernelGGL((k_qa_fwd<0, 0, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); }
@@ -431,12 +444,13 @@ extern "C" int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, con
     QaGeom g;
     int rc = qa_geom(&g, N, C, H, W, a_bits, pool, "mn_qa_bwd_sums");
     if (rc) return rc;
+    if (in_f32 == 2 && pool) MN_FAIL(MN_ENOTSUP, "mn_qa_bwd_sums: the 32-bit stash (dense layers) has no pooled variant");
     if (!in || !chan || !dq || !sums || !ws || (((uintptr_t)in) & 15) || !aligned16(dq) || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_qa_bwd_sums: null / misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
     const int S = qa_split(g);
     const dim3 grid((unsigned)C, (unsigned)S);
     const double nel = (double)N * C * H * W;
-    mn_set_last_kernel("k_qa_partial<%d, %d>", in_f32 ? 1 : 0, pool ? 1 : 0);
+    mn_set_last_kernel("k_qa_partial<%d, %d>", in_f32, pool ? 1 : 0);
     mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + 4.0 * nel / (pool ? 4.0 : 1.0));
     mn_prof_begin(s);
     QA_DISPATCH(k_qa_partial, grid, dim3(256), 0, s, g, in, chan, dq, quant, (double*)ws)
@@ -450,15 +464,253 @@ extern "C" int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, co
     QaGeom g;
     int rc = qa_geom(&g, N, C, H, W, a_bits, pool, "mn_qa_bwd_apply");
     if (rc) return rc;
+    if (in_f32 == 2 && pool) MN_FAIL(MN_ENOTSUP, "mn_qa_bwd_apply: the 32-bit stash (dense layers) has no pooled variant");
     if (!in || !chan || !dq || !sums || !dy || (((uintptr_t)in) & 15) || !aligned16(dq) || !aligned16(dy)) MN_FAIL(MN_EINVAL, "mn_qa_bwd_apply: null / misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)C, (unsigned)qa_split(g));
     const double nel = (double)N * C * H * W;
-    mn_set_last_kernel("k_qa_apply<%d, %d>", in_f32 ? 1 : 0, pool ? 1 : 0);
+    mn_set_last_kernel("k_qa_apply<%d, %d>", in_f32, pool ? 1 : 0);
     mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + 4.0 * nel / (pool ? 4.0 : 1.0) + 4.0 * nel);
     mn_prof_begin(s);
     QA_DISPATCH(k_qa_apply, grid, dim3(256), 0, s, g, in, chan, dq, sums, training, quant, dy)
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_qa_bwd_apply");
+    return MN_OK;
+}
+
+// ================================================================================================
+// The END of a residual block of the reference's ResNets (models/resnet.py:60-65: relu(add(residual_function(x), shortcut(x)))) under the k-bit DoReFa
+// scheme, fused like the blocks above:
+//     u = bn(y) + res,   a = relu(u)   ->   codes of the NEXT convs' activation quantizer (1 B/elt) and / or fp32 a (the next block's identity shortcut)
+// y is the second conv's stash (IN 0 / 2) or fp32 (IN 1); res is nothing (RES 0: the stem block, when it has to emit codes AND fp32 in one pass), the
+// fp32 input of the block (RES 1: identity shortcut) or bn_s(y_s) evaluated from the stash of the 1 x 1 / stride 2 shortcut conv (RES 2: int16, 3: int32).
+// Backward in two streaming passes with du = d loss / d u stored once (it IS the gradient of an identity shortcut):
+//     k_qr_partial   du = (STE(dq) [+ STE(dq2)] [+ g]) * [u > 0];  sum du, sum du zhat (main BatchNorm) [, sum du zhat_s (shortcut BatchNorm)]
+//     k_qr_apply     dy = gamma invstd (du - sum_du / n - zhat sum_du_zhat / n)  [and dy_s likewise]
+// dq / dq2: gradients w.r.t. the QUANTISED activation from the (up to two) convs that read the codes -- the clip-STE of wqaq/dorefa/quantize.py:36-46 is
+// applied here, per consumer as autograd would; g: gradient w.r.t. the activation itself (the next block's identity shortcut, or a foreign consumer).
+template <int RES>
+__device__ __forceinline__ void qr_load_res8(const void* __restrict__ res, int64_t off, const QaCh& ks, float (&r)[8], float (&zhs)[8]) {
+    if (RES == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r[e] = 0.f; zhs[e] = 0.f; }
+    } else if (RES == 1) {
+        qa_load8<1>(res, off, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zhs[e] = 0.f;
+    } else {
+        float v[8];
+        qa_load8<(RES == 2 ? 0 : 2)>(res, off, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qa_eval<0>(v[e], ks, zhs[e], r[e]);
+    }
+}
+template <int IN, int RES>
+__global__ __launch_bounds__(256) void k_qr_fwd(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, const void* __restrict__ res,
+                                                const float* __restrict__ res_chan, unsigned char* __restrict__ codes, float* __restrict__ af) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const QaCh k = qa_load_ch(chan, g.C, c);
+    QaCh ks = k;
+    if (RES >= 2) ks = qa_load_ch(res_chan, g.C, c);
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
+        const int64_t off = qa_off8(g, c, (uint32_t)i);
+        float v[8], r[8], zhs[8], a[8];
+        qa_load8<IN>(in, off, v);
+        qr_load_res8<RES>(res, off, ks, r, zhs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float zh, z;
+            qa_eval<IN>(v[e], k, zh, z);
+            a[e] = qa_relu(RES ? z + r[e] : z);
+        }
+        if (af) {
+            *reinterpret_cast<float4*>(af + off) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4*>(af + off + 4) = make_float4(a[4], a[5], a[6], a[7]);
+        }
+        if (codes) {
+            uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo |= qa_code(a[e], g.s) << (8 * e); hi |= qa_code(a[4 + e], g.s) << (8 * e); }
+            *reinterpret_cast<u32x2*>(codes + off) = u32x2{lo, hi};
+        }
+    }
+}
+template <int IN, int RES>
+__global__ __launch_bounds__(256) void k_qr_partial(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, const void* __restrict__ res,
+                                                    const float* __restrict__ res_chan, const float* __restrict__ dq, const float* __restrict__ dq2,
+                                                    const float* __restrict__ gf, float* __restrict__ du, double* __restrict__ part) {
+    __shared__ double scd[16];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const QaCh k = qa_load_ch(chan, g.C, c);
+    QaCh ks = k;
+    if (RES >= 2) ks = qa_load_ch(res_chan, g.C, c);
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
+        const int64_t off = qa_off8(g, c, (uint32_t)i);
+        float v[8], r[8], zhs[8], d1[8], d2[8], d3[8], o[8];
+        qa_load8<IN>(in, off, v);
+        qr_load_res8<RES>(res, off, ks, r, zhs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { d1[e] = 0.f; d2[e] = 0.f; d3[e] = 0.f; }
+        if (dq) qa_load8<1>(dq, off, d1);
+        if (dq2) qa_load8<1>(dq2, off, d2);
+        if (gf) qa_load8<1>(gf, off, d3);
+        float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float zh, z;
+            qa_eval<IN>(v[e], k, zh, z);
+            const float u = RES ? z + r[e] : z;
+            const float a = qa_relu(u);
+            float da = 0.f;
+            if (dq) da = dorefa_act_grad(d1[e], a, g.s);
+            if (dq2) da = da + dorefa_act_grad(d2[e], a, g.s);
+            if (gf) da = (dq || dq2) ? da + d3[e] : d3[e];
+            const float dd = (u > 0.f) ? da : 0.f;
+            o[e] = dd;
+            t1 += dd; t2 += dd * zh; t3 += dd * zhs[e];
+        }
+        *reinterpret_cast<float4*>(du + off) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(du + off + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        s1 += (double)t1; s2 += (double)t2; s3 += (double)t3;
+    }
+    s1 = block_reduce(s1, OpAddD(), 0.0, scd);
+    s2 = block_reduce(s2, OpAddD(), 0.0, scd);
+    if (RES >= 2) s3 = block_reduce(s3, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { double* d = part + ((int64_t)c * S + sp) * 3; d[0] = s1; d[1] = s2; d[2] = s3; }
+}
+__global__ void k_qr_final_bwd(int C, const double* __restrict__ part, int S, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums,
+                               float* __restrict__ dgamma_s, float* __restrict__ dbeta_s, float* __restrict__ sums_s) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = 0; i < S; ++i) { const double* d = part + ((int64_t)c * S + i) * 3; s1 += d[0]; s2 += d[1]; s3 += d[2]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    sums[c] = (float)s1; sums[C + c] = (float)s2;
+    if (sums_s) { sums_s[c] = (float)s1; sums_s[C + c] = (float)s3; }
+    if (dbeta_s) dbeta_s[c] = (float)s1;
+    if (dgamma_s) dgamma_s[c] = (float)s3;
+}
+template <int IN, int RES>
+__global__ __launch_bounds__(256) void k_qr_apply(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, const float* __restrict__ sums,
+                                                  const void* __restrict__ res, const float* __restrict__ res_chan, const float* __restrict__ sums_s,
+                                                  const float* __restrict__ du, int training, float* __restrict__ dy, float* __restrict__ dy_s) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const QaCh k = qa_load_ch(chan, g.C, c);
+    QaCh ks = k;
+    if (RES >= 2) ks = qa_load_ch(res_chan, g.C, c);
+    float k1 = 0.f, k2 = 0.f, k1s = 0.f, k2s = 0.f;
+    if (training) {
+        const float n = (float)g.N * (float)g.HW;
+        k1 = sums[c] / n; k2 = sums[g.C + c] / n;
+        if (RES >= 2) { k1s = sums_s[c] / n; k2s = sums_s[g.C + c] / n; }
+    }
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
+        const int64_t off = qa_off8(g, c, (uint32_t)i);
+        float v[8], d[8], o[8];
+        qa_load8<IN>(in, off, v);
+        qa_load8<1>(du, off, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float zh, z;
+            qa_eval<IN>(v[e], k, zh, z);
+            o[e] = k.gi * (d[e] - k1 - zh * k2);
+        }
+        *reinterpret_cast<float4*>(dy + off) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dy + off + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        if (RES >= 2) {
+            float vs[8];
+            qa_load8<(RES == 2 ? 0 : 2)>(res, off, vs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float zh, z;
+                qa_eval<0>(vs[e], ks, zh, z);
+                o[e] = ks.gi * (d[e] - k1s - zh * k2s);
+            }
+            *reinterpret_cast<float4*>(dy_s + off) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dy_s + off + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+#define QR_DISPATCH_RES(KERNEL, INV, ...)                                              \
+    switch (res_kind) {                                                                \
+        case 0: hipLaunchKernelGGL((KERNEL<INV, 0>), __VA_ARGS__); break;              \
+        case 1: hipLaunchKernelGGL((KERNEL<INV, 1>), __VA_ARGS__); break;              \
+        case 2: hipLaunchKernelGGL((KERNEL<INV, 2>), __VA_ARGS__); break;              \
+        default: hipLaunchKernelGGL((KERNEL<INV, 3>), __VA_ARGS__); break;             \
+    }
+#define QR_DISPATCH(KERNEL, ...)                                                       \
+    if (in_kind == 0) { QR_DISPATCH_RES(KERNEL, 0, __VA_ARGS__) }                      \
+    else if (in_kind == 1) { QR_DISPATCH_RES(KERNEL, 1, __VA_ARGS__) }                 \
+    else { QR_DISPATCH_RES(KERNEL, 2, __VA_ARGS__) }
+static int qr_check(int in_kind, int res_kind, const void* res, const float* res_chan, const char* what) {
+    if (in_kind < 0 || in_kind > 2 || res_kind < 0 || res_kind > 3) MN_FAIL(MN_EINVAL, "%s: bad in_kind / res_kind", what);
+    if (res_kind && (!res || (((uintptr_t)res) & 15))) MN_FAIL(MN_EINVAL, "%s: null / misaligned residual", what);
+    if (res_kind >= 2 && !res_chan) MN_FAIL(MN_EINVAL, "%s: the shortcut's chan table is required", what);
+    return MN_OK;
+}
+extern "C" int64_t mn_qr_ws_floats(int64_t C) { return C * 32 * 6 + 16; }
+extern "C" int mn_qr_fwd(int in_kind, const void* in, const float* chan, int res_kind, const void* res, const float* res_chan, int64_t N, int64_t C, int64_t H, int64_t W,
+                         int a_bits, uint8_t* codes, float* act_f32, mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, a_bits, 0, "mn_qr_fwd");
+    if (rc) return rc;
+    if ((rc = qr_check(in_kind, res_kind, res, res_chan, "mn_qr_fwd"))) return rc;
+    if (!in || !chan || (!codes && !act_f32) || (((uintptr_t)in) & 15) || (codes && (((uintptr_t)codes) & 7)) || (act_f32 && !aligned16(act_f32)))
+        MN_FAIL(MN_EINVAL, "mn_qr_fwd: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)C, (unsigned)qa_split(g));
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qr_fwd<%d, %d>", in_kind, res_kind);
+    mn_prof_bytes(nel * ((in_kind == 0 ? 2.0 : 4.0) + (res_kind == 0 ? 0.0 : (res_kind == 2 ? 2.0 : 4.0)) + (codes ? 1.0 : 0.0) + (act_f32 ? 4.0 : 0.0)));
+    mn_prof_begin(s);
+    QR_DISPATCH(k_qr_fwd, grid, dim3(256), 0, s, g, in, chan, res, res_chan, (unsigned char*)codes, act_f32)
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qr_fwd");
+    return MN_OK;
+}
+extern "C" int mn_qr_bwd_sums(int in_kind, const void* in, const float* chan, int res_kind, const void* res, const float* res_chan, const float* dq, const float* dq2,
+                              const float* g_f32, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, float* du, float* dgamma, float* dbeta, float* sums,
+                              float* dgamma_s, float* dbeta_s, float* sums_s, float* ws, mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, a_bits, 0, "mn_qr_bwd_sums");
+    if (rc) return rc;
+    if ((rc = qr_check(in_kind, res_kind, res, res_chan, "mn_qr_bwd_sums"))) return rc;
+    if (!in || !chan || (!dq && !g_f32) || (dq2 && !dq) || !du || !sums || !ws || (((uintptr_t)in) & 15) || (dq && !aligned16(dq)) || (dq2 && !aligned16(dq2)) ||
+        (g_f32 && !aligned16(g_f32)) || !aligned16(du) || (((uintptr_t)ws) & 7) || (res_kind >= 2 && !sums_s))
+        MN_FAIL(MN_EINVAL, "mn_qr_bwd_sums: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = qa_split(g);
+    const dim3 grid((unsigned)C, (unsigned)S);
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qr_partial<%d, %d>", in_kind, res_kind);
+    mn_prof_bytes(nel * ((in_kind == 0 ? 2.0 : 4.0) + (res_kind == 0 ? 0.0 : (res_kind == 2 ? 2.0 : 4.0)) + (dq ? 4.0 : 0.0) + (dq2 ? 4.0 : 0.0) + (g_f32 ? 4.0 : 0.0) + 4.0));
+    mn_prof_begin(s);
+    QR_DISPATCH(k_qr_partial, grid, dim3(256), 0, s, g, in, chan, res, res_chan, dq, dq2, g_f32, du, (double*)ws)
+    mn_prof_end(s);
+    hipLaunchKernelGGL(k_qr_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (int)C, (const double*)ws, S, dgamma, dbeta, sums, res_kind >= 2 ? dgamma_s : (float*)nullptr,
+                       res_kind >= 2 ? dbeta_s : (float*)nullptr, res_kind >= 2 ? sums_s : (float*)nullptr);
+    MN_CHECK_LAUNCH("mn_qr_bwd_sums");
+    return MN_OK;
+}
+extern "C" int mn_qr_bwd_apply(int in_kind, const void* in, const float* chan, const float* sums, int res_kind, const void* res, const float* res_chan, const float* sums_s,
+                               const float* du, int64_t N, int64_t C, int64_t H, int64_t W, int training, float* dy, float* dy_s, mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, 2, 0, "mn_qr_bwd_apply");
+    if (rc) return rc;
+    if (res_kind == 1) res_kind = 0;          // an identity shortcut's gradient IS du: nothing to form here
+    if ((rc = qr_check(in_kind, res_kind, res, res_chan, "mn_qr_bwd_apply"))) return rc;
+    if (!in || !chan || !sums || !du || !dy || (((uintptr_t)in) & 15) || !aligned16(du) || !aligned16(dy) || (res_kind >= 2 && (!dy_s || !sums_s || !aligned16(dy_s))))
+        MN_FAIL(MN_EINVAL, "mn_qr_bwd_apply: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)C, (unsigned)qa_split(g));
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qr_apply<%d, %d>", in_kind, res_kind);
+    mn_prof_bytes(nel * ((in_kind == 0 ? 2.0 : 4.0) + 8.0 + (res_kind >= 2 ? (res_kind == 2 ? 2.0 : 4.0) + 4.0 : 0.0)));
+    mn_prof_begin(s);
+    QR_DISPATCH(k_qr_apply, grid, dim3(256), 0, s, g, in, chan, sums, res, res_chan, sums_s, du, training, dy, dy_s)
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qr_bwd_apply");
     return MN_OK;
 }

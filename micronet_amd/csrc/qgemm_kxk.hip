@@ -819,7 +819,8 @@ static void launch_kw(const KwPlan& pl, int xmode, hipStream_t s) {
 int kk_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
     KkPlan pl;
     if (which == 0) return wq_codeable(wq) && aq_codeable(aq, 0) && plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl);
-    if (which == 1) return wq_codeable(wq) && (plan_kk(g, 1, MN_ACTQ_NONE, &pl) || qd_dgrad_native(g, wq));
+    if (which == 1) return wq_codeable(wq) && (plan_kk(g, 1, MN_ACTQ_NONE, &pl) ||
+                                               ((!aq || aq->mode == MN_ACTQ_NONE || aq->mode == MN_ACTQ_CODE8 || aq->mode == MN_ACTQ_SIGN8) && qd_dgrad_native(g, wq)));
     if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) return k3s_wgrad_code8_supported(g, aq->bits) || qd_wgrad_supported(g, aq->bits);
     if (which == 2) { KwPlan kw; return aq_codeable(aq, 1) && (plan_kk_wgrad(g, &kw) || (aq && aq->mode == MN_ACTQ_SIGN8 && k3s_wgrad_supported(g))); }
     return 0;

@@ -916,18 +916,36 @@ class ConvBNSign(Function):
 
 # ------------------------------------------------------------------------------------------------ k-bit (DoReFa) fused block
 def qconv_bnq_supported(x, wq, stride, padding, dilation, groups, w_bits, in_shuffle):
-    """True when conv(x) for a ``QActTensor`` x and DoReFa weights can stay un-computed: the fused kernels (16-bit stash forward, code-reading
-    backward-weight, STE-free backward-data) cover this geometry."""
+    """True when conv(x) for a ``QActTensor`` x and DoReFa weights can stay un-computed: the fused kernels (16 / 32-bit stash forward, code-reading
+    backward-weight, STE-free backward-data) cover this geometry (grouped 1x1 / 3x3 stride 1: qgemm_sign / qgemm_k3s; dense layers with C, O multiples of
+    64, 3x3 stride 1 / 2 and 1x1 stride 2: qgemm_dense)."""
     if not isinstance(x, QActTensor) or CONV_ALGO != _lib.MN_ALGO_AUTO or x.dim() != 4 or not (2 <= w_bits <= 8):
         return False
     one = lambda v: v in (1, (1, 1), [1, 1])
-    if not (one(stride) and one(dilation)):
+    if not one(dilation):
         return False
     g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle or 0)
-    if _out_hw(g) != (g.H, g.W):
-        return False
     wd = WQ(WQ_DOREFA, w_bits, 0, 0, None)
     return bool(_lib_().mn_qconv_bnq_supported(C.byref(g), C.byref(wd), x.bits))
+
+
+def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw):
+    """(dq, dw) of a conv on activation codes: mn_conv2d_bwd_data without clip-STE, mn_conv2d_bwd_weight on the codes."""
+    gy = _chk(gy, "grad")
+    aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
+    wd = WQ(WQ_DOREFA, w_bits, 0, 0, None)
+    dq = dw = None
+    if need_dx:
+        dq = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+        ws, nb = _ws(g, 1, codes.device)
+        with _span(g, 1, 4 * (gy.numel() + dq.numel())):
+            _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wd), _p(gy), _p(wq), None, _p(dq), _p(ws), nb, CONV_ALGO, _s())
+    if need_dw:
+        dw = torch.empty_like(wq)
+        ws, nb = _ws(g, 2, codes.device)
+        with _span(g, 2, 4 * gy.numel() + codes.numel() + 4 * dw.numel()):
+            _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), None, _p(ws), nb, CONV_ALGO, _s())
+    return dq, dw
 
 
 class QConvCodeLazy(Function):
@@ -950,8 +968,10 @@ class QConvCodeLazy(Function):
             if in_shuffle and in_shuffle > 1:
                 xa = channel_shuffle(xa, in_shuffle)
             return QConv2d.apply(xa, wq, bias, stride, padding, dilation, groups, ACTQ_DOREFA, a_bits, 0, None, (WQ_DOREFA, w_bits, 0, 0, None), 0, 0)
-        recipe = dict(codes=codes, a_bits=a_bits, wq=wq, bias=bias, geom=g, w_bits=w_bits, compute=compute)
-        return LazyQConvOut((g.N, g.O, g.H, g.W), codes.device, recipe)
+        Ho, Wo = _out_hw(g)
+        recipe = dict(codes=codes, a_bits=a_bits, wq=wq, bias=bias, geom=g, w_bits=w_bits, compute=compute, out_hw=(Ho, Wo),
+                      stash_bits=int(_lib_().mn_qconv_bnq_stash_bits(C.byref(g), C.byref(WQ(WQ_DOREFA, w_bits, 0, 0, None)), a_bits)))
+        return LazyQConvOut((g.N, g.O, Ho, Wo), codes.device, recipe)
 
     @staticmethod
     def backward(ctx, gy):
@@ -980,6 +1000,50 @@ class QConvCodeLazy(Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+class QConvCodeLazy2(Function):
+    """Two DoReFa QuantConv2d reading the SAME ``QActTensor`` (the first conv of a down-sampling residual block and its 1x1 shortcut conv,
+    models/resnet.py:24-44): two ``LazyQConvOut``; the backward returns ONE ``QGrad`` carrying both raw gradients -- the producing block applies the
+    quantizer's clip-STE to each and adds them, exactly what autograd would do with two separate consumers."""
+
+    @staticmethod
+    def forward(ctx, x, wq1, wq2, cfg1, cfg2, w_bits):
+        codes, a_bits = x.codes, x.bits
+        wq1, wq2 = _chk(wq1, "weight"), _chk(wq2, "weight")
+        outs, geoms = [], []
+        for wq, (stride, padding, dilation, groups) in ((wq1, cfg1), (wq2, cfg2)):
+            g = _geom(codes.shape, wq.shape, stride, padding, dilation, groups, 0)
+            Ho, Wo = _out_hw(g)
+
+            def compute(wq=wq, stride=stride, padding=padding, dilation=dilation, groups=groups):
+                return QConv2d.apply(x.materialize(), wq, None, stride, padding, dilation, groups, ACTQ_DOREFA, a_bits, 0, None, (WQ_DOREFA, w_bits, 0, 0, None), 0, 0)
+            recipe = dict(codes=codes, a_bits=a_bits, wq=wq, bias=None, geom=g, w_bits=w_bits, compute=compute, out_hw=(Ho, Wo),
+                          stash_bits=int(_lib_().mn_qconv_bnq_stash_bits(C.byref(g), C.byref(WQ(WQ_DOREFA, w_bits, 0, 0, None)), a_bits)))
+            outs.append(LazyQConvOut((g.N, g.O, Ho, Wo), codes.device, recipe))
+            geoms.append(g)
+        ctx.save_for_backward(codes, wq1, wq2)
+        ctx.cfg = (geoms, a_bits, w_bits)
+        ctx.x_ref = x
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, gy1, gy2):
+        codes, wq1, wq2 = ctx.saved_tensors
+        geoms, a_bits, w_bits = ctx.cfg
+        x = ctx.x_ref
+        with torch.cuda.device_of(codes):
+            dq1, dw1 = _code_conv_backward(geoms[0], a_bits, w_bits, codes, wq1, gy1, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            dq2, dw2 = _code_conv_backward(geoms[1], a_bits, w_bits, codes, wq2, gy2, ctx.needs_input_grad[0], ctx.needs_input_grad[2])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            def expand(dq_, dq2_=dq2):
+                xa = x.materialize()
+                return DorefaAct.backward_raw(dq_, xa, a_bits) + DorefaAct.backward_raw(dq2_, xa, a_bits)
+            dx = QGrad(dq1, expand)
+            dx._mn_dq2 = dq2
+        ctx.x_ref = None
+        return dx, dw1, dw2, None, None, None
+
+
 def materialize(t):
     """The plain float32 tensor behind any lazy / packed wrapper of this package (identity for ordinary tensors); NO autograd link."""
     return t.materialize() if hasattr(t, "materialize") else (t.to_float() if isinstance(t, SignTensor) else t)
@@ -1002,6 +1066,41 @@ def qa_supported(shape, pool):
     return len(shape) == 4 and bool(_lib_().mn_qa_supported(shape[2], shape[3], int(bool(pool))))
 
 
+def _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt):
+    """The statistics half of a fused k-bit block.  ``y`` = a ``LazyQConvOut``: the conv runs HERE on activation codes (mn_qconv_bnq_fwd_stash: 16 / 32-bit stash
+    + exact integer statistics; fp32 y never exists); a plain fp32 tensor (the block behind the un-quantised first conv): mn_bn_save_stats.  Returns
+    (src, chan [9][C], in_kind 0 int16 / 1 fp32 / 2 int32, (N, C, H, W), device)."""
+    lib = _lib_()
+    if isinstance(y, LazyQConvOut) and y._mn_value is None:
+        r = y.recipe
+        g, codes_in, wq = r["geom"], r["codes"], r["wq"]
+        H, W = r.get("out_hw", (g.H, g.W))
+        N, Cc = g.N, g.O
+        dev = codes_in.device
+        wide = r.get("stash_bits", 16) == 32
+        src = torch.empty((N, Cc, H, W), dtype=torch.int32 if wide else torch.int16, device=dev)
+        save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
+        wd = WQ(WQ_DOREFA, r["w_bits"], 0, 0, None)
+        with torch.cuda.device(dev):
+            nb = int(lib.mn_qconv_bnq_ws_bytes(C.byref(g)))
+            ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
+            with _span(g, 0, codes_in.numel() + (4 if wide else 2) * src.numel()):
+                _call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wd), _p(codes_in), r["a_bits"], _p(wq), _p(r["bias"]), _p(gamma), _p(beta), float(eps),
+                      float(momentum), int(training), _p(running_mean), _p(running_var), _p(nbt), _p(save), _p(src), _p(chan), _p(ws), nb, _s())
+        return src, chan, (2 if wide else 0), (N, Cc, H, W), dev
+    src = _chk(y, "input")
+    N, Cc, H, W = src.shape
+    dev = src.device
+    save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+    chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = torch.empty(int(lib.mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=dev)
+        _call("mn_bn_save_stats", _p(src), N, Cc, H * W, float(eps), float(momentum), int(training), _p(running_mean), _p(running_var), _p(save), _p(ws), _s())
+        _call("mn_qa_chan_from_save", _p(save), _p(gamma), _p(beta), Cc, _p(chan), _s())
+    return src, chan, 1, (N, Cc, H, W), dev
+
+
 class BNReLUQ(Function):
     """relu(batch_norm(y)) [-> 2x2 max-pool] -> the k-bit activation quantizer of the NEXT QuantConv2d, fused (qact_kernels.hip).
     y is a ``LazyQConvOut`` (the conv runs here, on codes: 16-bit stash + exact integer statistics; fp32 y never exists) or a plain fp32 tensor (the
@@ -1011,34 +1110,8 @@ class BNReLUQ(Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt, out_bits, pool):
         gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
-        lib = _lib_()
         lazy = isinstance(y, LazyQConvOut) and y._mn_value is None
-        if lazy:
-            r = y.recipe
-            g, codes_in, wq = r["geom"], r["codes"], r["wq"]
-            N, Cc, H, W = g.N, g.O, g.H, g.W
-            dev = codes_in.device
-            src = torch.empty((N, Cc, H, W), dtype=torch.int16, device=dev)
-            save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
-            chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
-            wd = WQ(WQ_DOREFA, r["w_bits"], 0, 0, None)
-            with torch.cuda.device(dev):
-                nb = int(lib.mn_qconv_bnq_ws_bytes(C.byref(g)))
-                ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
-                _call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wd), _p(codes_in), r["a_bits"], _p(wq), _p(r["bias"]), _p(gamma), _p(beta), float(eps),
-                      float(momentum), int(training), _p(running_mean), _p(running_var), _p(nbt), _p(save), _p(src), _p(chan), _p(ws), nb, _s())
-            in_f32 = 0
-        else:
-            src = _chk(y, "input")
-            N, Cc, H, W = src.shape
-            dev = src.device
-            save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
-            chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                ws = torch.empty(int(lib.mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=dev)
-                _call("mn_bn_save_stats", _p(src), N, Cc, H * W, float(eps), float(momentum), int(training), _p(running_mean), _p(running_var), _p(save), _p(ws), _s())
-                _call("mn_qa_chan_from_save", _p(save), _p(gamma), _p(beta), Cc, _p(chan), _s())
-            in_f32 = 1
+        src, chan, in_f32, (N, Cc, H, W), dev = _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt)
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         qbits = out_bits if out_bits else 2          # the kernels want a valid width even when no code is produced
         ctx.save_for_backward(src, chan, gamma, beta)
@@ -1054,15 +1127,13 @@ class BNReLUQ(Function):
         codes = torch.empty((N, Cc, Ho, Wo), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             _call("mn_qa_fwd", in_f32, _p(src), _p(chan), N, Cc, H, W, qbits, int(bool(pool)), _p(codes), None, _s())
-        out = QActTensor(codes, out_bits, materialize)
-        out._mn_pooled = bool(pool)
-        return out
+        return QActTensor(codes, out_bits, materialize, pooled=bool(pool))
 
     @staticmethod
     def backward(ctx, g):
         src, chan, gamma, beta = ctx.saved_tensors
         in_f32, N, Cc, H, W, qbits, pool, training, coded = ctx.cfg
-        if isinstance(g, QGrad) and g._mn_value is None and coded:
+        if isinstance(g, QGrad) and g._mn_value is None and g._mn_dq2 is None and coded:
             dq, quant = g._mn_dq, 1            # gradient w.r.t. the quantised activation: the clip-STE is applied by the kernels below
         else:
             dq, quant = _chk(g, "grad"), 0
@@ -1071,8 +1142,9 @@ class BNReLUQ(Function):
         sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws = torch.empty(int(_lib_().mn_qa_ws_floats(Cc)), dtype=torch.float32, device=dev)
-            _call("mn_qa_bwd_sums", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
-            if in_f32 and not pool and LAZY_BN_GRAD and FOLD_BN_INTO_CONV_BWD:
+            with _span(None, 3, (2 if in_f32 == 0 else 4) * src.numel() + 4 * dq.numel()):
+                _call("mn_qa_bwd_sums", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+            if in_f32 == 1 and not pool and LAZY_BN_GRAD and FOLD_BN_INTO_CONV_BWD:
                 # the block behind the un-quantised first conv: d loss / d y has ONE consumer, that conv's backward-weight, which forms it from
                 # (dq, y) while they stream in (mn_conv2d_bwd_weight_first_qa) -- dy is neither written nor re-read
                 def expand(r):
@@ -1083,8 +1155,91 @@ class BNReLUQ(Function):
                 recipe = dict(kind="qa", dq=dq, y=src, chan=chan, sums=sums, bits=qbits, quant=quant, training=training)
                 return LazyBNGrad((N, Cc, H, W), dev, recipe, expand), dgamma, dbeta, None, None, None, None, None, None, None, None
             dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
-            _call("mn_qa_bwd_apply", in_f32, _p(src), _p(chan), _p(sums), _p(dq), N, Cc, H, W, qbits, pool, quant, training, _p(dy), _s())
+            with _span(None, 3, (2 if in_f32 == 0 else 4) * src.numel() + 4 * dq.numel() + 4 * dy.numel()):
+                _call("mn_qa_bwd_apply", in_f32, _p(src), _p(chan), _p(sums), _p(dq), N, Cc, H, W, qbits, pool, quant, training, _p(dy), _s())
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class BNAddReLUQ(Function):
+    """The END of a residual block (models/resnet.py:60-65 under the k-bit DoReFa scheme), fused (mn_qr_*, qact_kernels.hip):
+        u = batch_norm(y) + res,  a = relu(u)  ->  (codes of the next convs' ``out_bits`` quantizer as a ``QActTensor``, fp32 a)
+    ``y``: the ``LazyQConvOut`` of the branch's last QuantConv2d (the conv runs here: 16 / 32-bit stash) or a plain fp32 tensor; ``res``: None (no residual:
+    a plain block that has to emit codes AND fp32 -- the stem), the block's fp32 input (identity shortcut) or the ``LazyQConvOut`` of the 1x1 shortcut conv,
+    whose BatchNorm (``bn_s`` = its gamma, beta, running statistics ...) is evaluated in the same kernels.  Two autograd outputs, so the gradients of the code
+    readers (``QGrad``: raw, the clip-STE is applied here) and of the fp32 reader (the next block's identity shortcut) arrive separately and are added in
+    the streaming backward pass.  Either output may be switched off (``out_bits`` = 0 / ``want_f32`` = False: an empty tensor is returned in its place)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt, res, gamma_s, beta_s, rm_s, rv_s, eps_s, momentum_s, nbt_s,
+                out_bits, want_f32):
+        gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
+        src, chan, in_kind, (N, Cc, H, W), dev = _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt)
+        res_kind, rsrc, rchan = 0, None, None
+        if isinstance(res, LazyQConvOut) and res._mn_value is None:
+            gamma_s, beta_s = _chk(gamma_s, "weight"), _chk(beta_s, "bias")
+            rsrc, rchan, rk, rshape, _ = _bn_front(res, gamma_s, beta_s, rm_s, rv_s, eps_s, momentum_s, training, nbt_s)
+            if rshape != (N, Cc, H, W):
+                raise MicronetHipError("residual block: the shortcut's shape %s differs from the branch's %s" % (rshape, (N, Cc, H, W)))
+            res_kind = 3 if rk == 2 else 2
+        elif res is not None:
+            if gamma_s is not None:
+                raise MicronetHipError("residual block: a shortcut BatchNorm needs the shortcut conv's lazy output")
+            rsrc = _chk(res, "residual")
+            if tuple(rsrc.shape) != (N, Cc, H, W):
+                raise MicronetHipError("residual block: the shortcut's shape %s differs from the branch's %s" % (tuple(rsrc.shape), (N, Cc, H, W)))
+            res_kind = 1
+        qbits = out_bits if out_bits else 2
+        codes = torch.empty((N, Cc, H, W), dtype=torch.uint8, device=dev) if out_bits else None
+        act = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev) if (want_f32 or not out_bits) else None
+        with torch.cuda.device(dev):
+            with _span(None, 3, src.numel() * src.element_size() + (rsrc.numel() * rsrc.element_size() if rsrc is not None else 0) + (N * Cc * H * W) * ((1 if out_bits else 0) + (4 if act is not None else 0))):
+                _call("mn_qr_fwd", in_kind, _p(src), _p(chan), res_kind, _p(rsrc), _p(rchan), N, Cc, H, W, qbits, _p(codes), _p(act), _s())
+        ctx.save_for_backward(src, chan, rsrc, rchan, gamma, beta, gamma_s if res_kind >= 2 else None, beta_s if res_kind >= 2 else None)
+        ctx.cfg = (in_kind, res_kind, N, Cc, H, W, qbits, int(training))
+
+        def materialize():
+            a_ = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _call("mn_qr_fwd", in_kind, _p(src), _p(chan), res_kind, _p(rsrc), _p(rchan), N, Cc, H, W, qbits, None, _p(a_), _s())
+            return a_
+        q = QActTensor(codes, out_bits, (lambda: act) if act is not None else materialize) if out_bits else torch.empty(0, device=dev)
+        a = act if act is not None else torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(*([q] if not out_bits else []), *([a] if act is None else []))
+        return q, a
+
+    @staticmethod
+    def backward(ctx, gq, ga):
+        src, chan, rsrc, rchan, gamma, beta, gamma_s, beta_s = ctx.saved_tensors
+        in_kind, res_kind, N, Cc, H, W, qbits, training = ctx.cfg
+        dev = src.device
+        dq = dq2 = gf = None
+        if isinstance(gq, QGrad) and gq._mn_value is None:
+            dq, dq2 = gq._mn_dq, gq._mn_dq2       # raw gradients w.r.t. the QUANTISED activation: STE applied per consumer by the kernel
+        elif gq is not None and gq.numel():
+            gf = _chk(gq, "grad")                 # a foreign reader of the codes tensor saw the fp32 activation: its gradient is w.r.t. the activation
+        if ga is not None and ga.numel():
+            ga = _chk(ga, "grad")
+            gf = ga if gf is None else gf + ga
+        if dq is None and gf is None:
+            gf = torch.zeros((N, Cc, H, W), dtype=torch.float32, device=dev)
+        new = lambda: torch.empty(Cc, dtype=torch.float32, device=dev)
+        dgamma, dbeta, sums = new(), new(), torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        dgamma_s = dbeta_s = sums_s = dy_s = None
+        if res_kind >= 2:
+            dgamma_s, dbeta_s, sums_s = new(), new(), torch.empty((2, Cc), dtype=torch.float32, device=dev)
+            dy_s = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+        du = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+        dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+        nel = N * Cc * H * W
+        with torch.cuda.device(dev):
+            ws = torch.empty(int(_lib_().mn_qr_ws_floats(Cc)), dtype=torch.float32, device=dev)
+            with _span(None, 3, src.numel() * src.element_size() + (rsrc.numel() * rsrc.element_size() if rsrc is not None else 0) + 4 * nel * (1 + sum(t is not None for t in (dq, dq2, gf)))):
+                _call("mn_qr_bwd_sums", in_kind, _p(src), _p(chan), res_kind, _p(rsrc), _p(rchan), _p(dq), _p(dq2), _p(gf), N, Cc, H, W, qbits, _p(du), _p(dgamma), _p(dbeta),
+                      _p(sums), _p(dgamma_s), _p(dbeta_s), _p(sums_s), _p(ws), _s())
+            with _span(None, 3, src.numel() * src.element_size() + 8 * nel + ((rsrc.numel() * rsrc.element_size() + 4 * nel) if res_kind >= 2 else 0)):
+                _call("mn_qr_bwd_apply", in_kind, _p(src), _p(chan), _p(sums), res_kind, _p(rsrc), _p(rchan), _p(sums_s), _p(du), N, Cc, H, W, training, _p(dy), _p(dy_s), _s())
+        dres = du if res_kind == 1 else dy_s
+        return (dy, dgamma, dbeta, None, None, None, None, None, None, dres, dgamma_s, dbeta_s, None, None, None, None, None, None, None)
 
 
 def channel_shuffle(x, groups):

@@ -162,6 +162,7 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
 
     q_out_bits = 0          # > 0 (set by prepare(fuse_blocks=True)): the only consumer is the a-bit activation quantizer of the next QuantConv2d ->
     q_pool = False          # emit its codes (QActTensor), through the 2x2 max-pool behind the block when q_pool
+    q_also_f32 = False      # the consumer is a fused residual block with an identity shortcut: emit the codes AND the fp32 activation (one pass, two autograd outputs)
 
     def forward(self, input):
         from micronet_amd import ops
@@ -179,6 +180,12 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
                     nbt = self.num_batches_tracked           # incremented by the launch that forms the statistics
                 else:
                     self.num_batches_tracked.add_(1)
+            if self.q_also_f32 and self.q_out_bits and not pool:
+                q, a = ops.BNAddReLUQ.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                            self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, nbt,
+                                            None, None, None, None, None, 0.0, 0.0, None, int(self.q_out_bits), True)
+                q._mn_f32 = a
+                return q
             return ops.BNReLUQ.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                      self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, nbt,
                                      int(self.q_out_bits), pool)
@@ -264,6 +271,143 @@ def _fuse_blocks(model, fold_shuffle=True):
                         pool._mn_fused_pool = True
 
 
+def _bn_call_args(bn, lazy):
+    """(running_mean, running_var, eps, momentum, use_batch, nbt) of a BatchNorm2d for the fused ops, with nn.BatchNorm2d's bookkeeping; None when the
+    module's configuration is one the fused kernels do not cover (no affine parameters, cumulative moving average)."""
+    if not bn.affine or bn.momentum is None:
+        return None
+    use_batch = bn.training or bn.running_mean is None
+    if not (use_batch or bn.track_running_stats):
+        return None
+    nbt = None
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        if lazy and bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64:
+            nbt = bn.num_batches_tracked                 # incremented by the launch that forms the statistics
+        else:
+            bn.num_batches_tracked.add_(1)
+    return (bn.running_mean if bn.track_running_stats else None, bn.running_var if bn.track_running_stats else None, bn.eps, bn.momentum, use_batch, nbt)
+
+
+class _FusedBasicBlockMixin:
+    """forward of the reference's ``BasicBlock`` (models/resnet.py:7-65: relu(add(residual_function(x), shortcut(x)))) on the fused k-bit kernels, installed by
+    ``prepare(fuse_blocks=True)`` as a subclass of the block's own class (same children, parameters, ``state_dict``).  The block's input arrives as a ``QActTensor``
+    (codes of the first conv's quantizer + the fp32 activation for an identity shortcut); conv -> bn -> relu -> quantizer of the second conv is the fused
+    block of ``BatchNorm2dReLU``; the block's end -- bn + shortcut (identity, or 1x1 conv + bn) + relu + the NEXT block's quantizer -- is ``ops.BNAddReLUQ``.
+    Any other input (or a configuration the kernels do not cover) runs the reference's forward."""
+
+    _mn_out_bits = 0         # codes of the next block's activation quantizer (0: the consumer is not a fused block)
+    _mn_out_f32 = True       # the fp32 activation as well (the next block's identity shortcut / a foreign consumer)
+    _mn_mid_hook = None      # optional callable applied to the activation between the two convs (a QActTensor): the parity tests teacher-force it
+
+    def forward(self, x):
+        from micronet_amd import ops
+        from micronet_amd.sign_tensor import LazyQConvOut, QActTensor
+        rf = self.residual_function
+        conv_a, bn_a, conv_b, bn_b = rf[0], rf[1], rf[3], rf[4]
+        has_sc = len(self.shortcut) > 0
+        ok = isinstance(x, QActTensor) and x.bits == conv_a.activation_quantizer.a_bits and not conv_a.quant_inference and not conv_b.quant_inference
+        if ok and not has_sc and x._mn_f32 is None:
+            ok = False
+        w_bits = conv_a.weight_quantizer.w_bits
+        if ok and has_sc:
+            conv_s = self.shortcut[0]
+            ok = (not conv_s.quant_inference and conv_s.weight_quantizer.w_bits == w_bits and conv_s.activation_quantizer.a_bits == x.bits and
+                  conv_a.bias is None and conv_s.bias is None and
+                  ops.qconv_bnq_supported(x, conv_a.weight, conv_a.stride, conv_a.padding, conv_a.dilation, conv_a.groups, w_bits, 0) and
+                  ops.qconv_bnq_supported(x, conv_s.weight, conv_s.stride, conv_s.padding, conv_s.dilation, conv_s.groups, w_bits, 0))
+        if not ok:
+            return super().forward(ops.QActToFloat.apply(x) if isinstance(x, QActTensor) else x)
+        if has_sc:
+            ya, ys = ops.QConvCodeLazy2.apply(x, conv_a.weight_quantizer(conv_a.weight), conv_s.weight_quantizer(conv_s.weight),
+                                              (conv_a.stride, conv_a.padding, conv_a.dilation, conv_a.groups),
+                                              (conv_s.stride, conv_s.padding, conv_s.dilation, conv_s.groups), w_bits)
+        else:
+            ya, ys = conv_a(x), None
+        h = rf[2](bn_a(ya))                       # BatchNorm2dReLU -> codes of conv_b's quantizer; rf[2] is the no-op ReLUAfterFusedBN
+        if self._mn_mid_hook is not None:
+            h = self._mn_mid_hook(h)
+        yb = conv_b(h)
+        args_b = _bn_call_args(bn_b, isinstance(yb, LazyQConvOut)) if isinstance(yb, LazyQConvOut) else None
+        args_s = _bn_call_args(self.shortcut[1], True) if (has_sc and args_b is not None) else None
+        if args_b is None or (has_sc and args_s is None):
+            # a configuration outside the fused kernels: the reference's tail on materialised tensors
+            sc = self.shortcut[1](ys) if has_sc else ops.QActToFloat.apply(x) if x._mn_f32 is None else x._mn_f32
+            return nn.ReLU(inplace=True)(self.add(bn_b(yb), sc))
+        bn_s = self.shortcut[1] if has_sc else None
+        q, a = ops.BNAddReLUQ.apply(yb, bn_b.weight, bn_b.bias, args_b[0], args_b[1], args_b[2], args_b[3], args_b[4], args_b[5],
+                                    ys if has_sc else x._mn_f32,
+                                    bn_s.weight if has_sc else None, bn_s.bias if has_sc else None, args_s[0] if has_sc else None, args_s[1] if has_sc else None,
+                                    args_s[2] if has_sc else 0.0, args_s[3] if has_sc else 0.0, args_s[5] if has_sc else None,
+                                    int(self._mn_out_bits), bool(self._mn_out_f32 or not self._mn_out_bits))
+        if not self._mn_out_bits:
+            return a
+        q._mn_f32 = a if a.numel() else None
+        return q
+
+
+_FUSED_BLOCK_CLASSES = {}
+
+
+def _is_ref_basic_block(m):
+    t = type(m)
+    return (t.__name__ == "BasicBlock" and t.__module__.split(".")[-1] == "resnet") or bool(getattr(m, "_mn_basic_block", False))
+
+
+def _fuse_residual_blocks(model):
+    """Third pass of ``prepare(fuse_blocks=True)``: every ``BasicBlock`` of the reference's ResNets (models/resnet.py:7-65) whose convs became QuantConv2d
+    with 2..7-bit activations becomes a ``_FusedBasicBlockMixin`` subclass of its class.  Where the call order is known -- the reference's ``ResNet``
+    (stem ``conv1``, stages ``conv2_x .. conv5_x`` of blocks in ``nn.Sequential``) -- each block is told which outputs its consumer wants: the next block's
+    quantizer codes, and the fp32 activation only when that block's shortcut is the identity; the stem's BatchNorm2dReLU emits both."""
+    from micronet_amd.base_module.op import Add
+
+    def fusable(b):
+        rf, sc = getattr(b, "residual_function", None), getattr(b, "shortcut", None)
+        if not (isinstance(rf, nn.Sequential) and isinstance(sc, nn.Sequential) and len(rf) == 5 and len(sc) in (0, 2) and type(getattr(b, "add", None)) is Add):
+            return False
+        if not (isinstance(rf[0], QuantConv2d) and isinstance(rf[1], BatchNorm2dReLU) and isinstance(rf[2], ReLUAfterFusedBN) and isinstance(rf[3], QuantConv2d)
+                and type(rf[4]) is nn.BatchNorm2d):
+            return False
+        if len(sc) and not (isinstance(sc[0], QuantConv2d) and type(sc[1]) is nn.BatchNorm2d):
+            return False
+        convs = [rf[0], rf[3]] + ([sc[0]] if len(sc) else [])
+        return all(2 <= c.activation_quantizer.a_bits <= 7 and 2 <= c.weight_quantizer.w_bits <= 8 and c.bias is None and not c.quant_inference for c in convs)
+
+    blocks = []
+    for m in model.modules():
+        if _is_ref_basic_block(m) and fusable(m):
+            cls = type(m)
+            if cls not in _FUSED_BLOCK_CLASSES:
+                _FUSED_BLOCK_CLASSES[cls] = type("Fused" + cls.__name__, (_FusedBasicBlockMixin, cls), {"__module__": cls.__module__})
+            m.__class__ = _FUSED_BLOCK_CLASSES[cls]
+            rf = m.residual_function
+            rf[0].lazy_for_bn = True
+            rf[3].lazy_for_bn = True
+            rf[1].q_out_bits = int(rf[3].activation_quantizer.a_bits)
+            rf[1].q_pool = False
+            blocks.append(m)
+    if not blocks:
+        return
+    # call order: only for the reference's ResNet layout
+    t = type(model)
+    stages = [getattr(model, "conv%d_x" % i, None) for i in range(2, 6)]
+    if not (t.__name__ == "ResNet" and t.__module__.split(".")[-1] == "resnet" and all(isinstance(s, nn.Sequential) for s in stages)):
+        return          # unknown call order: every fused block emits fp32 only (``_mn_out_bits`` 0) and re-quantises its input itself -- still correct
+    chain = [b for s in stages for b in s.children()]
+    for i, b in enumerate(chain):
+        nxt = chain[i + 1] if i + 1 < len(chain) else None
+        if isinstance(b, _FusedBasicBlockMixin) and isinstance(nxt, _FusedBasicBlockMixin):
+            b._mn_out_bits = int(nxt.residual_function[0].activation_quantizer.a_bits)
+            b._mn_out_f32 = len(nxt.shortcut) == 0
+        elif isinstance(b, _FusedBasicBlockMixin):
+            b._mn_out_bits, b._mn_out_f32 = 0, True
+    stem = getattr(model, "conv1", None)
+    if isinstance(stem, nn.Sequential) and len(stem) == 3 and isinstance(stem[1], BatchNorm2dReLU) and isinstance(stem[2], ReLUAfterFusedBN) and chain and \
+            isinstance(chain[0], _FusedBasicBlockMixin):
+        stem[1].q_out_bits = int(chain[0].residual_function[0].activation_quantizer.a_bits)
+        stem[1].q_pool = False
+        stem[1].q_also_f32 = len(chain[0].shortcut) == 0
+
+
 def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=False, fuse_bn_act=True):
     """Swap every conv / conv-transpose / linear EXCEPT the first one met (ref 202-309: ``layer_counter[0] > 1``)."""
     kw = dict(a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference)
@@ -320,4 +464,5 @@ def prepare(model, inplace=False, a_bits=8, w_bits=8, quant_inference=False, fus
     add_quant_op(model, [0], a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act)
     if fuse_bn_act and fuse_blocks and not quant_inference:
         _fuse_blocks(model, fold_shuffle=fold_shuffle)
+        _fuse_residual_blocks(model)
     return model

@@ -188,14 +188,16 @@ class QActTensor(torch.Tensor):
     ``__torch_dispatch__`` and sees the float32 activation the reference holds at this point."""
 
     @staticmethod
-    def __new__(cls, codes, bits, materialize):
+    def __new__(cls, codes, bits, materialize, pooled=False, f32=None):
         if codes.dtype != torch.uint8 or not codes.is_contiguous():
             raise TypeError("QActTensor wraps a contiguous uint8 tensor of activation codes")
         r = torch.Tensor._make_wrapper_subclass(cls, codes.shape, dtype=torch.float32, device=codes.device, requires_grad=False)
         r._mn_codes, r._mn_bits, r._mn_mat, r._mn_value = codes, int(bits), materialize, None
+        r._mn_pooled = bool(pooled)       # the producing block already applied the 2x2 max-pool behind it (the pool module then passes the codes through)
+        r._mn_f32 = f32                   # the fp32 activation as a SECOND autograd output of the producer (the next residual block's identity shortcut)
         return r
 
-    def __init__(self, codes, bits, materialize):
+    def __init__(self, codes, bits, materialize, pooled=False, f32=None):
         pass
 
     @property
@@ -221,7 +223,7 @@ class QActTensor(torch.Tensor):
         kwargs = kwargs or {}
         if func in _alias_ops() and isinstance(args[0], QActTensor):
             a = args[0]
-            r = QActTensor(a._mn_codes, a._mn_bits, a._mn_mat)
+            r = QActTensor(a._mn_codes, a._mn_bits, a._mn_mat, a._mn_pooled, a._mn_f32)
             r._mn_value = a._mn_value
             return r
         return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
@@ -237,6 +239,7 @@ class QGrad(torch.Tensor):
     def __new__(cls, dq, expand):
         r = torch.Tensor._make_wrapper_subclass(cls, dq.shape, dtype=torch.float32, device=dq.device, requires_grad=False)
         r._mn_dq, r._mn_expand, r._mn_value = dq, expand, None
+        r._mn_dq2 = None                  # a second raw gradient from another conv that read the same codes (QConvCodeLazy2); ``expand`` accounts for it
         return r
 
     def __init__(self, dq, expand):
@@ -258,7 +261,7 @@ class QGrad(torch.Tensor):
         if func in _alias_ops() and isinstance(args[0], QGrad):
             a = args[0]
             r = QGrad(a._mn_dq, a._mn_expand)
-            r._mn_value = a._mn_value
+            r._mn_value, r._mn_dq2 = a._mn_value, a._mn_dq2
             return r
         return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
 

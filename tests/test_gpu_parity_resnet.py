@@ -1,0 +1,291 @@
+"""Parity AT THE BENCHED CONFIGURATION for the ResNet workloads (BASELINE configs[3]: resnet18 DoReFa W2A2, 256 images per GPU): the module graph ``prepare()``
+really builds -- fused residual blocks on activation codes (qgemm_dense.hip, mn_qa_* / mn_qr_*) -- against the torch-CPU oracle of the reference.
+
+The oracle runs ONE full forward + backward at batch 256 and records, per stage (the stem ``conv1``, each ``BasicBlock``, the classifier tail), input, output,
+incoming gradient, input gradient and parameter gradients, plus the two pre-activations of a block (the BatchNorm output in front of the inner ReLU, the sum in
+front of the final ReLU).  Each product stage is then TEACHER-FORCED: it gets the oracle's input in the pipeline's physical form (a ``QActTensor``: codes of the
+first conv's quantizer + the fp32 activation for an identity shortcut) and the oracle's incoming gradient.  Inside a block the activation between the two convs is
+teacher-forced as well (``_mn_mid_hook``): the product's own value is compared with the oracle's and then replaced by it, so that one code flip at a rounding tie
+does not hide everything behind it.
+
+Ties: where the ORACLE's own pre-activation lies within TIE_EPS of a ReLU kink (or the quantizer's clamp edge), a 1-ulp difference legitimately flips a mask and a
+whole gradient term with it.  The incoming gradient is zeroed at those positions ON BOTH SIDES (the oracle block is re-run with the same masks), so both
+back-propagate through identical decisions; the fraction of masked positions is recorded (it is ~1e-5).
+Tolerance: 1e-5 relative (max-norm) on every float result; integer codes: flips only at rounding ties (fraction <= 1e-5).  d weight of a DoReFa conv: the single
+arg-max |w| element carries a cancelling sum over the whole tensor (see tests/test_gpu_parity_full.py) and is judged against an fp64 evaluation.
+Results: ``gpurun_out/parity_r03.json`` (copied to ``profiles/``)."""
+import copy
+import importlib
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BATCH = 256
+TIE_EPS = 4e-6
+RES = {
+    "c4_resnet18_dorefa_w2a2": ("resnet18", "wqaq.dorefa", dict(a_bits=2, w_bits=2)),
+}
+
+
+def _record(path, key, value):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        try:
+            data = json.load(open(path))
+        except Exception:       # noqa: BLE001
+            data = {}
+    data[key] = value
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _codes_of(x, bits):
+    s = torch.tensor(1.0 / (2 ** bits - 1), dtype=torch.float32, device=x.device)
+    v = torch.clamp(x * 0.1, 0, 1) / s                             # wqaq/dorefa/quantize.py:43-45, every op IEEE-exact
+    return (torch.sign(v) * torch.floor(torch.abs(v) + 0.5)).to(torch.uint8).contiguous()
+
+
+class _FloatToQActF32(torch.autograd.Function):
+    """fp32 activation leaf -> what a fused block hands to the next one: (QActTensor of the consuming convs' quantizer codes, the fp32 activation).  Backward:
+    the clip-STE of the quantizer applied to the code readers' gradient (a QGrad materialises as exactly that) + the fp32 reader's gradient."""
+
+    @staticmethod
+    def forward(ctx, x, bits):
+        from micronet_amd.sign_tensor import QActTensor
+        xd = x.detach()
+        return QActTensor(_codes_of(xd, bits), bits, lambda: xd), xd.clone()
+
+    @staticmethod
+    def backward(ctx, gq, ga):
+        from micronet_amd import ops
+        g = None
+        if gq is not None:
+            g = ops._chk(gq, "grad")
+        if ga is not None:
+            g = ga if g is None else g + ga
+        return g, None
+
+
+class _ForceMid(torch.autograd.Function):
+    """Teacher-forces the activation between the two convs of a fused block: records the product's own codes / values, hands on the ORACLE's; the gradient coming
+    back (a raw QGrad) is zeroed where the oracle's pre-activation is a tie."""
+
+    @staticmethod
+    def forward(ctx, h, a_ref, keep, rec):
+        from micronet_amd.sign_tensor import QActTensor
+        rec["h_codes"], rec["h_f32"], rec["bits"] = h.codes.clone(), h.materialize().clone(), h.bits
+        ctx.keep = keep
+        return QActTensor(_codes_of(a_ref, h.bits), h.bits, lambda: a_ref)
+
+    @staticmethod
+    def backward(ctx, g):
+        from micronet_amd.sign_tensor import QGrad
+        assert isinstance(g, QGrad) and g._mn_value is None and g._mn_dq2 is None
+        return QGrad(g._mn_dq * ctx.keep, g._mn_expand), None, None, None
+
+
+def _oracle_pass(arch, scheme, kw):
+    from oracle import torch_oracle as TO
+    from micronet_amd.train import build_model, synth_batch
+    torch.set_num_threads(min(32, os.cpu_count()))
+    orc = TO.prepare(build_model(arch), scheme.split(".")[-1], inplace=True, **kw).train()
+    pristine = copy.deepcopy(orc)
+    rec = {}
+    blocks = [("conv%d_x.%d" % (i, j), b) for i in range(2, 6) for j, b in enumerate(getattr(orc, "conv%d_x" % i))]
+    stages = [("conv1", orc.conv1)] + blocks + [("fc", orc.fc)]
+
+    def hook(name):
+        def fn(mod, inputs, output):
+            r = rec.setdefault(name, {})
+            r["in"] = inputs[0].detach().clone()
+            r["out"] = output.detach().clone()
+            if inputs[0].requires_grad:
+                inputs[0].register_hook(lambda g, r=r: r.__setitem__("gin", g.detach().clone()))
+            output.register_hook(lambda g, r=r: r.__setitem__("gout", g.detach().clone()))
+        return fn
+    for n, m in stages:
+        m.register_forward_hook(hook(n))
+    orc.conv1[2].register_forward_pre_hook(lambda mod, i: rec.setdefault("conv1", {}).__setitem__("z", i[0].detach().clone()))
+    for n, b in blocks:
+        b.residual_function[2].register_forward_pre_hook(lambda mod, i, n=n: rec.setdefault(n, {}).__setitem__("z_mid", i[0].detach().clone()))
+        b.residual_function[2].register_forward_hook(lambda mod, i, o, n=n: rec.setdefault(n, {}).__setitem__("a_mid", o.detach().clone()))
+        b.add.register_forward_hook(lambda mod, i, o, n=n: rec.setdefault(n, {}).__setitem__("u", o.detach().clone()))
+    x, y = synth_batch(BATCH)
+    out = orc(x)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    return orc, pristine, rec, x, float(loss), [n for n, _ in stages]
+
+
+def _get(model, name):
+    m = model
+    for part in name.split("."):
+        m = m[int(part)] if part.isdigit() else getattr(m, part)
+    return m
+
+
+def _oracle_rerun(stage, x_in, gout, keep_out, keep_mid, double=False):
+    """The oracle stage again (fp32, or fp64 for the cancelling sums) with the tie masks applied to the incoming gradient and to the gradient of the mid activation."""
+    st = copy.deepcopy(stage).train()
+    if double:
+        st = st.double()
+    if keep_mid is not None:
+        km = keep_mid.double() if double else keep_mid.float()
+        def mid_hook(mod, i, o):
+            o.register_hook(lambda g: g * km)
+        st.residual_function[2].register_forward_hook(mid_hook)
+    xi = (x_in.double() if double else x_in.clone()).requires_grad_(True)
+    out = st(xi)
+    g = gout * keep_out if keep_out is not None else gout
+    out.backward(g.double() if double else g)
+    return xi.grad, {pn: p.grad.detach().clone() for pn, p in st.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("key", list(RES))
+def test_full_batch_teacher_forced_resnet(key):
+    from micronet_amd import ops
+    from micronet_amd.sign_tensor import QActTensor
+    from micronet_amd.train import build_model
+    from oracle import np_oracle as NO
+    arch, scheme, kw = RES[key]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    orc, pristine, rec, x, loss0, names = _oracle_pass(arch, scheme, kw)
+    prod = quantize.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+    bits = kw["a_bits"]
+    report, failures, worst = {}, [], 0.0
+
+    def check(tag, errs, k_, v, lim=1e-5):
+        nonlocal worst
+        errs[k_] = v
+        worst = max(worst, v)
+        if not v <= lim:
+            failures.append((tag, k_, v, lim))
+
+    def check_pgrads(tag, errs, pmod, pg_ref, stage_pristine, x_in, gout, keep_out, keep_mid):
+        pn = dict(pmod.named_parameters())
+        p64 = None
+        for name, g_ref in pg_ref.items():
+            if name not in pn or pn[name].grad is None:
+                failures.append((tag, "missing gradient", name))
+                continue
+            g = pn[name].grad
+            if name.endswith("weight") and g.dim() == 4 and g.shape[1] > 3:
+                # DoReFa weight quantizer: the arg-max |w| element carries the cancelling sum (tests/test_gpu_parity_full.py): fp64 judge for that element
+                k_arg = int(pn[name].detach().abs().flatten().argmax())
+                d = (g.detach().double().cpu().flatten() - g_ref.double().flatten()).abs() / g_ref.double().abs().max().clamp_min(1e-30)
+                e_arg = float(d[k_arg])
+                d[k_arg] = 0.0
+                check(tag, errs, "d" + name, float(d.max()))
+                errs["d" + name + "_argmax_element_vs_reference_fp32"] = e_arg
+                if e_arg > 1e-5:
+                    if p64 is None:
+                        _, p64 = _oracle_rerun(stage_pristine, x_in, gout, keep_out, keep_mid, double=True)
+                    g64 = p64[name]
+                    sc = g64.abs().max().clamp_min(1e-300)
+                    e_ours = float((g.double().cpu().flatten()[k_arg] - g64.flatten()[k_arg]).abs() / sc)
+                    e_ref = float((g_ref.double().flatten()[k_arg] - g64.flatten()[k_arg]).abs() / sc)
+                    errs["d" + name + "_argmax_element"], errs["d" + name + "_argmax_element_reference_fp32_vs_fp64"] = e_ours, e_ref
+                    if e_ours > max(2e-4, 2.0 * e_ref):
+                        failures.append((tag, "d" + name + " at the arg-max element vs fp64", e_ours, e_ref))
+            else:
+                e = _rel(g, g_ref)
+                if e > 1e-5:          # a cancelling per-channel sum (d gamma / d beta): ours must be as close to fp64 as the reference's own fp32 result
+                    if p64 is None:
+                        _, p64 = _oracle_rerun(stage_pristine, x_in, gout, keep_out, keep_mid, double=True)
+                    g64 = p64[name]
+                    sc = g64.abs().max().clamp_min(1e-300)
+                    e_ours, e_ref = float((g.double().cpu() - g64).abs().max() / sc), float((g_ref.double() - g64).abs().max() / sc)
+                    errs["d" + name + "_reference_fp32_vs_fp64"] = e_ref
+                    check(tag, errs, "d" + name, e_ours, max(1e-5, 2.0 * e_ref))
+                else:
+                    check(tag, errs, "d" + name, e)
+
+    for name in names:
+        r = rec[name]
+        pst, ost = _get(prod, name), _get(pristine, name)
+        for p in pst.parameters():
+            p.grad = None
+        errs = {}
+        if name == "conv1":
+            # ---- the stem: image -> conv (fp32) -> BatchNorm + ReLU -> codes of the first block's quantizer + fp32 (one pass, two autograd outputs)
+            out = pst(r["in"].cuda())
+            assert isinstance(out, QActTensor) and out._mn_f32 is not None, "the stem does not emit codes + fp32"
+            check(name, errs, "y", _rel(out._mn_f32, r["out"]))
+            _, cref = NO.dorefa_act_fwd(r["out"].numpy(), out.bits)
+            errs["codes_flipped_frac"] = float((out.codes.cpu().numpy().astype("float32") != cref).sum()) / cref.size
+            if errs["codes_flipped_frac"] > 1e-5:
+                failures.append((name, "codes differ beyond rounding ties", errs["codes_flipped_frac"]))
+            keep = ~(r["z"].abs() <= TIE_EPS)
+            errs["ties_masked_frac"] = float((~keep).sum()) / keep.numel()
+            st = copy.deepcopy(ost).train()
+            st(r["in"]).backward(r["gout"] * keep)
+            pg_ref = {pn: p.grad.detach().clone() for pn, p in st.named_parameters() if p.grad is not None}
+            torch.autograd.backward([out._mn_f32], [(r["gout"] * keep).cuda()])
+            for pn_, g_ref in pg_ref.items():
+                check(name, errs, "d" + pn_, _rel(dict(pst.named_parameters())[pn_].grad, g_ref))
+        elif name == "fc":
+            # ---- classifier tail: QuantLinear on the pooled fp32 activation (quantizer in the kernel prologue)
+            leaf = r["in"].cuda().requires_grad_(True)
+            out = pst(leaf)
+            check(name, errs, "y", _rel(out, r["out"]))
+            out.backward(r["gout"].cuda())
+            st = copy.deepcopy(ost).train()
+            xi = r["in"].clone().requires_grad_(True)
+            st(xi).backward(r["gout"])
+            check(name, errs, "dx", _rel(leaf.grad, xi.grad))
+            for pn_, p in st.named_parameters():
+                check(name, errs, "d" + pn_, _rel(dict(pst.named_parameters())[pn_].grad, p.grad), 2e-5 if pn_ == "weight" else 1e-5)
+        else:
+            # ---- a residual block
+            assert type(pst).__name__.startswith("Fused"), "prepare() did not fuse %s" % name
+            leaf = r["in"].cuda().requires_grad_(True)
+            q, a = _FloatToQActF32.apply(leaf, bits)
+            q._mn_f32 = a if len(pst.shortcut) == 0 else None
+            z_mid, u = r["z_mid"], r["u"]
+            keep_mid = ~((z_mid.abs() <= TIE_EPS) | ((0.1 * z_mid - 1.0).abs() <= TIE_EPS))
+            keep_out = ~(u.abs() <= TIE_EPS)
+            mid = {}
+            pst._mn_mid_hook = lambda h, r=r, keep_mid=keep_mid, mid=mid: _ForceMid.apply(h, r["a_mid"].cuda(), keep_mid.cuda(), mid)
+            try:
+                out = pst(q)
+            finally:
+                pst._mn_mid_hook = None
+            # the product's own mid activation (before it was replaced) and the block output
+            check(name, errs, "a_mid", _rel(mid["h_f32"], r["a_mid"]))
+            _, cref = NO.dorefa_act_fwd(r["a_mid"].numpy(), mid["bits"])
+            errs["mid_codes_flipped_frac"] = float((mid["h_codes"].cpu().numpy().astype("float32") != cref).sum()) / cref.size
+            if errs["mid_codes_flipped_frac"] > 1e-5:
+                failures.append((name, "mid codes differ beyond rounding ties", errs["mid_codes_flipped_frac"]))
+            out_f32 = out._mn_f32 if isinstance(out, QActTensor) and out._mn_f32 is not None else (out.materialize() if isinstance(out, QActTensor) else out)
+            check(name, errs, "y", _rel(out_f32, r["out"]))
+            if isinstance(out, QActTensor):
+                _, cref = NO.dorefa_act_fwd(r["out"].numpy(), out.bits)
+                errs["codes_flipped_frac"] = float((out.codes.cpu().numpy().astype("float32") != cref).sum()) / cref.size
+                if errs["codes_flipped_frac"] > 1e-5:
+                    failures.append((name, "codes differ beyond rounding ties", errs["codes_flipped_frac"]))
+            errs["ties_masked_frac"] = (float((~keep_mid).sum()) + float((~keep_out).sum())) / (keep_mid.numel() + keep_out.numel())
+            gin_ref, pg_ref = _oracle_rerun(ost, r["in"], r["gout"], keep_out, keep_mid)
+            gout = (r["gout"] * keep_out).cuda()
+            if isinstance(out, QActTensor):
+                # the oracle's incoming gradient is w.r.t. the block's fp32 output: feed it to the fp32 output when there is one, else through the code
+                # tensor as a plain (already STE-treated) gradient
+                torch.autograd.backward([out._mn_f32 if out._mn_f32 is not None else out], [gout])
+            else:
+                torch.autograd.backward([out], [gout])
+            check(name, errs, "dx", _rel(leaf.grad, gin_ref))
+            check_pgrads(name, errs, pst, pg_ref, ost, r["in"], r["gout"], keep_out, keep_mid)
+        report[name] = {k: float("%.2e" % v) for k, v in errs.items()}
+    report["_oracle_loss0"], report["_batch"], report["_failures"] = loss0, BATCH, [list(map(str, f)) for f in failures]
+    _record(os.path.join(ROOT, "gpurun_out", "parity_r03.json"), key, report)
+    print(key, "worst rel err over all stages:", worst)
+    assert not failures, (key, failures, report)
