@@ -8,8 +8,12 @@ One "step" = forward + CrossEntropy + zero_grad + backward + Adam.step on one sy
 under BOTH low-bit schemes, so one run measures both, batch 256 PER GPU (weak scaling), data-parallel with a RCCL all-reduce
 of the gradients:
   * primary (`value`, `roofline`, `cpu_baseline`): configs[1] -- wbwtab W-ternary / A-binary;
-  * `also.c1_w2a2`: DoReFa W2A2 (value, ms_per_step, roofline of its own dominant kernel).
+  * `also.{c1_w2a2, c1, c3, c4, c5}`: the same measurement (value, ms_per_step, roofline of its own dominant kernel) for DoReFa W2A2 on nin_gc (the
+    second half of the headline metric) and for every other BASELINE config at 256 images per GPU; `values` repeats all images/s figures at top level.
 `--only W` measures a single workload (profiling runs).  Prints ONE JSON line on rank 0.
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself (torch.distributed.run, 127.0.0.1) and relays rank 0's line.
+The timed region is repeated `--repeats` times (each EXACTLY `--steps` steps between barriers); `value` / `ms_per_step` are the MEDIAN window,
+`ms_per_step_min` the best one.
 
 roofline.achieved = the dominant kernel's designed HBM bytes / its HIP-event duration (events recorded by the library on the
 launch stream around every launch).  roofline.traffic / roofline.mfma_busy come from rocprofv3 PMC passes that THIS run
@@ -38,6 +42,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB
 FP32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense
 N_SIMD = 1024                   # 256 CUs x 4
+N_XCD = 8
 GFLOP_PER_IMG = {"nin_gc": 0.9068, "resnet18": 3.3290}   # fwd+bwd, all convs
 MB_PER_IMG = {"nin_gc": 22.71, "resnet18": 12.91}        # fused-ideal fp32 activation traffic fwd+bwd
 
@@ -78,7 +83,7 @@ class KernelProfiler:
         buf = (self._lib.ProfEntry * 192)()
         n = self.lib.mn_profile_collect(buf, 192)
         self.lib.mn_profile_enable(0)
-        return {buf[i].name.decode(): dict(ms=buf[i].total_ms, bytes=buf[i].bytes, launches=buf[i].launches) for i in range(n)}
+        return {buf[i].name.decode(): dict(ms=buf[i].total_ms, bytes=buf[i].bytes, flops=buf[i].flops, launches=buf[i].launches) for i in range(n)}
 
 
 def build(workload, device):
@@ -153,17 +158,21 @@ def measure(workload, args, world, rank, device):
 
     for _ in range(args.warmup):
         one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss)
+    windows = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        windows.append(dt)
+    dt = sorted(windows)[len(windows) // 2]                 # the median window (an odd count by default)
+    final_loss = float(loss.detach())
 
     # per-kernel HIP-event timing: the same step, same process, run eagerly right after the timed region (events cannot be
     # read back from inside a replayed graph); single-GPU runs only
@@ -183,7 +192,7 @@ def measure(workload, args, world, rank, device):
         graphed.finish()
     del graphed, model, opt, sync
     torch.cuda.empty_cache()
-    return dict(dt=dt, final_loss=final_loss, hip_graph=graph_err is None and not args.no_graph, graph_err=graph_err, agg=agg)
+    return dict(dt=dt, dt_min=min(windows), windows=windows, final_loss=final_loss, hip_graph=graph_err is None and not args.no_graph, graph_err=graph_err, agg=agg)
 
 
 def section(workload, m, args, world, pmc):
@@ -191,6 +200,8 @@ def section(workload, m, args, world, pmc):
     arch = WORKLOADS[workload][0]
     value = args.batch * world * args.steps / m["dt"]
     out = {"workload": WORKLOAD_DESC[workload], "value": round(value, 1), "unit": "images/s", "ms_per_step": round(1000.0 * m["dt"] / args.steps, 3),
+           "ms_per_step_min": round(1000.0 * m["dt_min"] / args.steps, 3), "value_best_window": round(args.batch * world * args.steps / m["dt_min"], 1),
+           "repeats": len(m["windows"]), "window_ms": [round(1000.0 * w, 2) for w in m["windows"]],
            "hip_graph": m["hip_graph"], "final_loss": round(m["final_loss"], 4)}
     if m["graph_err"]:
         out["hip_graph_error"] = m["graph_err"]
@@ -201,8 +212,19 @@ def section(workload, m, args, world, pmc):
         d = agg[dom]
         achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
         p = (pmc or {}).get(workload, {}).get(dom, {})
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": p.get("bytes_per_launch"),
+        # a dense-conv kernel (qgemm_dense.hip) whose matrix-core time bound exceeds its HBM time bound is priced against the bf16 MFMA peak:
+        # achieved = ALGORITHMIC flops (2 x MACs; the backward kernels issue 3 bf16 term passes per algorithmic flop) / HIP-event duration
+        terms = 3.0 if ("dgrad" in dom or "wgrad" in dom) else 1.0         # bf16 term passes the matrix cores execute per algorithmic flop (fp32 gy = 3 exact bf16 terms)
+        mfma_bound = d.get("flops", 0.0) > 0 and terms * d["flops"] / (BF16_MFMA_PEAK_TFLOPS * 1e12) > d["bytes"] / (HBM_PEAK_GBS * 1e9)
+        if mfma_bound:
+            ach_tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom, "achieved": round(ach_tf, 1) if mfma_bound else round(achieved, 1),
+                           "peak": BF16_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+                           "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                           "frac": round(ach_tf / BF16_MFMA_PEAK_TFLOPS, 4) if mfma_bound else round(achieved / HBM_PEAK_GBS, 4),
+                           **({"hbm_GBps": round(achieved, 1), "flops_per_launch": int(d["flops"] / d["launches"]), "bf16_term_passes": terms,
+                               "mfma_issued_frac": round(terms * ach_tf / BF16_MFMA_PEAK_TFLOPS, 4)} if mfma_bound else {}),
+                           "traffic": p.get("bytes_per_launch"),
                            "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes spawned by this run" if p.get("bytes_per_launch")
                                               else None),
                            "mfma_busy": p.get("mfma_busy"),
@@ -212,6 +234,7 @@ def section(workload, m, args, world, pmc):
         out["kernels"] = {k: {"ms_per_step": round(v["ms"] / ks, 4), "launches_per_step": v["launches"] / ks,
                               "avg_us": round(1000.0 * v["ms"] / v["launches"], 1),
                               "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                              **({"TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} if v.get("flops", 0.0) > 0 else {}),
                               **({"pmc_bytes_per_launch": (pmc or {}).get(workload, {}).get(k, {}).get("bytes_per_launch"),
                                   "mfma_busy": (pmc or {}).get(workload, {}).get(k, {}).get("mfma_busy")} if (pmc or {}).get(workload, {}).get(k) else {})}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
@@ -247,8 +270,12 @@ def pmc_collect(workloads, batch, timeout_s=240):
     cnt = {w: collections.defaultdict(lambda: collections.defaultdict(int)) for w in workloads}
     err = None
     env = dict(os.environ, TMPDIR="/tmp", PYTHONDONTWRITEBYTECODE="1")
+    t_start = time.perf_counter()
     for counters in PMC_PASSES:
         for w in workloads:
+            if time.perf_counter() - t_start > PMC_BUDGET_S:
+                err = "PMC time budget (%d s) exhausted: remaining passes skipped" % PMC_BUDGET_S
+                continue
             d = os.path.join(tmp, counters[0] + "_" + w)
             cmd = [rocprof, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--pmc-child", "--only", w, "--batch", str(batch)]
@@ -284,7 +311,7 @@ def pmc_collect(workloads, batch, timeout_s=240):
                 tot_bytes += 2.0 * v["FETCH_SIZE"] * 1024.0 + v["WRITE_SIZE"] * 1024.0
             n_m = cnt[w][k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
             if n_m and v.get("GRBM_GUI_ACTIVE", 0) > 0:
-                e["mfma_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * N_SIMD), 4)
+                e["mfma_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / N_XCD * N_SIMD), 4)      # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs
                 tot_mfma += v["SQ_VALU_MFMA_BUSY_CYCLES"]
                 tot_gui += v["GRBM_GUI_ACTIVE"]
             if e and (k.startswith("k_") or "k_" in k[:8]):
@@ -293,12 +320,13 @@ def pmc_collect(workloads, batch, timeout_s=240):
         if tot_bytes:
             step["pmc_hbm_bytes_per_step_all_kernels"] = int(tot_bytes / PMC_CHILD_STEPS)
         if tot_gui:
-            step["pmc_mfma_busy_all_kernels"] = round(tot_mfma / (tot_gui * N_SIMD), 4)
+            step["pmc_mfma_busy_all_kernels"] = round(tot_mfma / (tot_gui / N_XCD * N_SIMD), 4)
         res[w]["_step"] = step
     return res, err
 
 
 PMC_CHILD_STEPS = 2
+PMC_BUDGET_S = 240
 
 
 def pmc_child(args, device):
@@ -321,11 +349,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS), help="primary workload (value / roofline / cpu_baseline)")
-    ap.add_argument("--also", default="c1_w2a2", help="comma-separated secondary workloads reported under `also` ('' = none)")
+    ap.add_argument("--also", default="c1_w2a2,c1,c3,c4,c5", help="comma-separated secondary workloads reported under `also` ('' = none)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps each; value = the median window")
+    ap.add_argument("--master-port", type=int, default=29531, help="rendezvous port when --gpus N > 1 starts its own ranks")
     ap.add_argument("--only", default=None, choices=list(WORKLOADS), help="measure this single workload (no `also`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=16, help="timed CPU steps at --cpu-batch (about 10-15 s of CPU work)")
+    ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU baseline: the benched per-GPU batch")
+    ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU steps at --cpu-batch (about 20 s of CPU work at batch 256)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying captured HIP graphs")
     ap.add_argument("--kernel-steps", type=int, default=5, help="eager steps of the per-kernel HIP-event timing pass")
     ap.add_argument("--cpu-threads", type=int, default=16,
@@ -345,11 +375,17 @@ def main():
     if args.cpu_only:
         print(json.dumps(cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        # no launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI) and relay rank 0's JSON line
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report a line whose n_gpus differs from --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     local = local % max(1, torch.cuda.device_count())
@@ -392,6 +428,10 @@ def main():
                        "per_gpu_batch": args.batch, "parallelism": "dp%d" % world, "optimizer": "Adam lr=0.01",
                        "hip_graph": sec["hip_graph"], "final_loss": sec["final_loss"]},
         }
+        out["ms_per_step_min"], out["value_best_window"], out["repeats"], out["window_ms"] = sec["ms_per_step_min"], sec["value_best_window"], sec["repeats"], sec["window_ms"]
+        if world > 1:
+            out["config"]["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None}
         if "hip_graph_error" in sec:
             out["config"]["hip_graph_error"] = sec["hip_graph_error"]
         for k in ("roofline", "kernels", "step_level"):
@@ -408,6 +448,8 @@ def main():
                 out["also"][w] = s
             for w, e in also_err.items():
                 out["also"][w] = {"error": e}
+        # every images/s figure of the line at top level: the metric string names nin_gc under BOTH low-bit schemes (c2 = `value`, c1_w2a2)
+        out["values"] = {primary: sec["value"], **{w: v["value"] for w, v in out.get("also", {}).items() if "value" in v}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)

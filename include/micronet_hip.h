@@ -43,12 +43,14 @@ void mn_profile_next(void* start_event, void* stop_event);
 /* library-kept measurement: while enabled (per calling thread), EVERY main kernel launch of the library (conv, BN+sign, pool) is
  * bracketed by two pooled HIP events on its stream.  mn_profile_collect -- call it once the stream is idle -- aggregates the
  * recorded spans by kernel name into `out` (at most `cap` entries), clears them and returns the number of entries.
- * `bytes` = the kernel's designed HBM bytes (each operand read or written once, int8 codes counted as 1 byte). */
+ * `bytes` = the kernel's designed HBM bytes (each operand read or written once, int8 codes counted as 1 byte); `flops` = its algorithmic FLOPs
+ * (2 x MACs; 0 for the streaming kernels: only the matrix-bound dense convolutions report it). */
 typedef struct mn_prof_entry {
     char name[96];
     int64_t launches;
     double total_ms;
     double bytes;
+    double flops;
 } mn_prof_entry;
 void mn_profile_enable(int on);
 int mn_profile_collect(mn_prof_entry* out, int cap);
@@ -411,6 +413,15 @@ int mn_qr_bwd_sums(int in_kind, const void* in, const float* chan, int res_kind,
                    float* dgamma_s, float* dbeta_s, float* sums_s, float* ws, mn_stream_t stream);
 int mn_qr_bwd_apply(int in_kind, const void* in, const float* chan, const float* sums, int res_kind, const void* res, const float* res_chan, const float* sums_s,
                     const float* du, int64_t N, int64_t C, int64_t H, int64_t W, int training, float* dy, float* dy_s, mn_stream_t stream);
+
+/* ------------------------------------------------------------------ QuantLinear with few outputs (O <= 64: the classifier of the ResNets, 512 -> 10)
+ * y[n][o] = bias[o] + sum_c Q_a(x[n][c]) * w[o][c]  (wqaq/dorefa/quantize.py:192-199, wqaq/iao/quantize.py:1150-1157; F.linear call sites dorefa 198, iao 1156):
+ * x [N][C] fp32, `w` = the already fake-quantised weight [O][C], aq = the activation quantizer evaluated in registers (MN_ACTQ_NONE / _DOREFA / _IAO);
+ * bwd_data applies its clip-STE (x required unless MN_ACTQ_NONE); bwd_weight sums over n in a fixed order (deterministic), dbias may be NULL. */
+int mn_qlinear_supported(int64_t N, int64_t C, int64_t O);
+int mn_qlinear_fwd(const mn_actq* aq, const float* x, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t O, mn_stream_t stream);
+int mn_qlinear_bwd_data(const mn_actq* aq, const float* gy, const float* w, const float* x, float* dx, int64_t N, int64_t C, int64_t O, mn_stream_t stream);
+int mn_qlinear_bwd_weight(const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, int64_t N, int64_t C, int64_t O, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ classifier conv of a binary net
  * The LAST conv of the WbWtAb nets keeps fp32 weights (the rewrite skips it, wbwtab/quantize.py:251) but reads the +-1 output of the

@@ -34,7 +34,7 @@ class WQ(C.Structure):
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("bytes", C.c_double), ("flops", C.c_double)]
 
 
 class AdamTensor(C.Structure):
@@ -131,6 +131,10 @@ PROTOTYPES = {
     "mn_qr_fwd": (_I, [_I, _P, _P, _I, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
     "mn_qr_bwd_sums": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mn_qr_bwd_apply": (_I, [_I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
+    "mn_qlinear_supported": (_I, [_L, _L, _L]),
+    "mn_qlinear_fwd": (_I, [_A, _P, _P, _P, _P, _L, _L, _L, _P]),
+    "mn_qlinear_bwd_data": (_I, [_A, _P, _P, _P, _P, _L, _L, _L, _P]),
+    "mn_qlinear_bwd_weight": (_I, [_A, _P, _P, _P, _P, _L, _L, _L, _P]),
     "mn_cifar_augment": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _L, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "mn_iao_bnfold_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _L, _L, _P, _P, _P]),
     "mn_iao_bnfold_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -14,7 +14,8 @@ void mn_set_error(const char* fmt, ...);
 // name of the dominant kernel the last conv entry point launched on this thread (read back by mn_last_kernel())
 void mn_set_last_kernel(const char* fmt, ...);
 // optional HIP-event bracket around the MAIN kernel of the next conv entry point (armed by mn_profile_next)
-void mn_prof_bytes(double nbytes);     // designed HBM bytes of the main kernel about to be launched (read + written once)
+void mn_prof_bytes(double nbytes);     // designed HBM bytes of the main kernel about to be launched (read + written once); resets the flop count
+void mn_prof_flops(double nflops);     // algorithmic FLOPs (2 x MACs) of that kernel -- the matrix-bound kernels (qgemm_dense.hip); call AFTER mn_prof_bytes
 // tuning / A-B knobs from the environment, read ONCE per process and call site (the planners run on every launch)
 #define MN_ENV(name) ([]() -> const char* { static const char* v_ = getenv(name); return v_; }())
 void mn_prof_begin(hipStream_t s);

@@ -1,0 +1,113 @@
+// QuantLinear with few outputs (the classifier of the reference's ResNets: 512 -> 10, models/resnet.py:141,176 under wqaq/dorefa/quantize.py:192-199 /
+// wqaq/iao/quantize.py:1150-1157) for gfx950:
+//     y[n][o] = bias[o] + sum over c of Q_a(x[n][c]) * wq[o][c]
+// with the activation quantizer Q_a (DoReFa k-bit, IAO per-tensor, or none) evaluated in registers and its clip-STE applied to dx in the same launch.
+// N x C x O is tiny (256 x 512 x 10): three latency-bound launches of a few microseconds -- the generic kernels treat a linear layer as a 1 x 1 conv over
+// 1 x 1 images and ran this one on the direct VALU path (210 us forward).  One wave per sample row (forward, backward-data); one thread per input channel
+// with the output loop in registers (backward-weight, fixed summation order over n: deterministic).
+#include "common.h"
+
+#define QL_OMAX 16            // outputs per pass (larger O: several passes)
+
+__global__ __launch_bounds__(64) void k_qlin_fwd(const Pro pro, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                                 int N, int C, int O) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float sc = 1.f, zp = 0.f;
+    if (pro.mode == MN_ACTQ_IAO) { sc = pro.qp[0]; zp = pro.qp[1]; }
+    for (int o0 = 0; o0 < O; o0 += QL_OMAX) {
+        float acc[QL_OMAX];
+#pragma unroll
+        for (int k = 0; k < QL_OMAX; ++k) acc[k] = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float q = pro_apply(pro, x[(int64_t)n * C + c], sc, zp);
+#pragma unroll
+            for (int k = 0; k < QL_OMAX; ++k)
+                if (o0 + k < O) acc[k] = fmaf(q, w[(int64_t)(o0 + k) * C + c], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < QL_OMAX; ++k) {
+            if (o0 + k >= O) break;
+            const float v = wave_reduce(acc[k], OpAddF());
+            if (lane == 0) y[(int64_t)n * O + o0 + k] = v + (bias ? bias[o0 + k] : 0.f);
+        }
+    }
+}
+// dx[n][c] = STE(sum over o of gy[n][o] * wq[o][c])
+__global__ __launch_bounds__(256) void k_qlin_bwd_data(const Pro ste, const float* __restrict__ gy, const float* __restrict__ w, const float* __restrict__ x,
+                                                       float* __restrict__ dx, int N, int C, int O) {
+    const int64_t total = (int64_t)N * C;
+    float sc = 1.f, zp = 0.f, lo = 0.f, hi = 0.f;
+    if (ste.mode == MN_ACTQ_IAO) { sc = ste.qp[0]; zp = ste.qp[1]; lo = ste.qp[2]; hi = ste.qp[3]; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i / C), c = (int)(i - (int64_t)n * C);
+        float acc = 0.f;
+        for (int o = 0; o < O; ++o) acc = fmaf(gy[(int64_t)n * O + o], w[(int64_t)o * C + c], acc);
+        if (ste.mode == MN_ACTQ_DOREFA) acc = dorefa_act_grad(acc, x[i], ste.s);
+        else if (ste.mode == MN_ACTQ_IAO) acc = iao_fq_grad(acc, x[i], sc, zp, lo, hi, ste.qmin, ste.qmax);
+        dx[i] = acc;
+    }
+}
+// dw[o][c] = sum over n of gy[n][o] * Q_a(x[n][c]);  db[o] = sum over n of gy[n][o]
+__global__ __launch_bounds__(256) void k_qlin_bwd_weight(const Pro pro, const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
+                                                         int N, int C, int O) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float sc = 1.f, zp = 0.f;
+    if (pro.mode == MN_ACTQ_IAO) { sc = pro.qp[0]; zp = pro.qp[1]; }
+    for (int o0 = 0; o0 < O; o0 += QL_OMAX) {
+        float acc[QL_OMAX], bacc[QL_OMAX];
+#pragma unroll
+        for (int k = 0; k < QL_OMAX; ++k) { acc[k] = 0.f; bacc[k] = 0.f; }
+        for (int n = 0; n < N; ++n) {
+            const float q = c < C ? pro_apply(pro, x[(int64_t)n * C + c], sc, zp) : 0.f;
+#pragma unroll
+            for (int k = 0; k < QL_OMAX; ++k)
+                if (o0 + k < O) {
+                    const float g = gy[(int64_t)n * O + o0 + k];
+                    acc[k] = fmaf(g, q, acc[k]);
+                    bacc[k] += g;
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < QL_OMAX; ++k) {
+            if (o0 + k >= O) break;
+            if (c < C) dw[(int64_t)(o0 + k) * C + c] = acc[k];
+            if (db && c == 0) db[o0 + k] = bacc[k];
+        }
+    }
+}
+
+extern "C" int mn_qlinear_supported(int64_t N, int64_t C, int64_t O) { return N >= 1 && C >= 1 && O >= 1 && O <= 64 && N * C < ((int64_t)1 << 31); }
+extern "C" int mn_qlinear_fwd(const mn_actq* aq, const float* x, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t O, mn_stream_t stream) {
+    if (!mn_qlinear_supported(N, C, O) || !x || !w || !y) MN_FAIL(MN_EINVAL, "mn_qlinear_fwd: bad arguments");
+    Pro pro;
+    int rc = make_pro(aq, &pro, 0, "mn_qlinear_fwd");
+    if (rc) return rc;
+    if (pro.mode == MN_ACTQ_SIGN8 || pro.mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_qlinear_fwd: fp32 activations only");
+    mn_set_last_kernel("k_qlin_fwd");
+    hipLaunchKernelGGL(k_qlin_fwd, dim3((unsigned)N), dim3(64), 0, (hipStream_t)stream, pro, x, w, bias, y, (int)N, (int)C, (int)O);
+    MN_CHECK_LAUNCH("mn_qlinear_fwd");
+    return MN_OK;
+}
+extern "C" int mn_qlinear_bwd_data(const mn_actq* aq, const float* gy, const float* w, const float* x, float* dx, int64_t N, int64_t C, int64_t O, mn_stream_t stream) {
+    if (!mn_qlinear_supported(N, C, O) || !gy || !w || !dx) MN_FAIL(MN_EINVAL, "mn_qlinear_bwd_data: bad arguments");
+    Pro ste;
+    int rc = make_pro(aq, &ste, 1, "mn_qlinear_bwd_data");
+    if (rc) return rc;
+    if (ste.mode == MN_ACTQ_SIGN8 || ste.mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_qlinear_bwd_data: fp32 activations only");
+    if (ste.mode != MN_ACTQ_NONE && !x) MN_FAIL(MN_EINVAL, "mn_qlinear_bwd_data: x is required for the clip-STE");
+    mn_set_last_kernel("k_qlin_bwd_data");
+    hipLaunchKernelGGL(k_qlin_bwd_data, dim3((unsigned)mn_grid_for(N * C, 256, 2048)), dim3(256), 0, (hipStream_t)stream, ste, gy, w, x, dx, (int)N, (int)C, (int)O);
+    MN_CHECK_LAUNCH("mn_qlinear_bwd_data");
+    return MN_OK;
+}
+extern "C" int mn_qlinear_bwd_weight(const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, int64_t N, int64_t C, int64_t O, mn_stream_t stream) {
+    if (!mn_qlinear_supported(N, C, O) || !gy || !x || !dw) MN_FAIL(MN_EINVAL, "mn_qlinear_bwd_weight: bad arguments");
+    Pro pro;
+    int rc = make_pro(aq, &pro, 0, "mn_qlinear_bwd_weight");
+    if (rc) return rc;
+    if (pro.mode == MN_ACTQ_SIGN8 || pro.mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_qlinear_bwd_weight: fp32 activations only");
+    mn_set_last_kernel("k_qlin_bwd_weight");
+    hipLaunchKernelGGL(k_qlin_bwd_weight, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pro, gy, x, dw, dbias, (int)N, (int)C, (int)O);
+    MN_CHECK_LAUNCH("mn_qlinear_bwd_weight");
+    return MN_OK;
+}

@@ -326,13 +326,13 @@ __global__ void k_qa_chan_f32(int C, const float* __restrict__ save, const float
 // from the exact integer statistics partials of a stashing conv (layout of k_pws / k_k3s_fwd: part[(i * G * Mpad + g * Mpad + m) * 2]):
 // mean / biased variance of y = alpha * acc + bias in fp64, running statistics (unbiased variance) and num_batches_tracked like nn.BatchNorm2d;
 // eval: the running statistics.  One wave per channel.
-__global__ __launch_bounds__(64) void k_qa_stats_prep(const double* __restrict__ part, int CB, int G, int Mpad, int Mr, const float* __restrict__ rowscale, float ascale,
+__global__ __launch_bounds__(64) void k_qa_stats_prep(const double* __restrict__ part, int CB, int G, int Mpad, int Mr, const float* __restrict__ rowscale, float rowscale_const, float ascale,
                                                      const float* __restrict__ bias, double n, float eps, float momentum, int training,
                                                      float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save, int Cout,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ chan,
                                                      long long* __restrict__ nbt) {
     const int co = blockIdx.x, g = co / Mr, m = co - g * Mr, lane = threadIdx.x;
-    const float alpha = rowscale[g * Mpad + m] * ascale;          // what the unfused k_pw / k_kk epilogue multiplies acc with
+    const float alpha = (rowscale ? rowscale[g * Mpad + m] : rowscale_const) * ascale;          // what the unfused k_pw / k_kk epilogue multiplies acc with
     const float b = bias ? bias[co] : 0.f;
     float mean_f = 0.f, inv_f = 0.f;
     if (training) {
@@ -368,8 +368,14 @@ __global__ __launch_bounds__(64) void k_qa_stats_prep(const double* __restrict__
 void qa_launch_stats_prep(const double* part, int CB, int G, int Mpad, int Mr, const float* rowscale, float ascale, const float* bias, double n, float eps,
                           float momentum, int training, float* running_mean, float* running_var, float* save, int Cout, const float* gamma, const float* beta,
                           float* chan, long long* nbt, hipStream_t s) {
-    hipLaunchKernelGGL(k_qa_stats_prep, dim3((unsigned)Cout), dim3(64), 0, s, part, CB, G, Mpad, Mr, rowscale, ascale, bias, n, eps, momentum, training, running_mean,
+    hipLaunchKernelGGL(k_qa_stats_prep, dim3((unsigned)Cout), dim3(64), 0, s, part, CB, G, Mpad, Mr, rowscale, 0.f, ascale, bias, n, eps, momentum, training, running_mean,
                        running_var, save, Cout, gamma, beta, chan, nbt);
+}
+// the same with ONE weight scale for every channel (DoReFa: 1 / (2^w - 1)): no per-channel table to fill first
+void qa_launch_stats_prep_const(const double* part, int CB, int Cout, float wscale, float ascale, const float* bias, double n, float eps, float momentum, int training,
+                                float* running_mean, float* running_var, float* save, const float* gamma, const float* beta, float* chan, long long* nbt, hipStream_t s) {
+    hipLaunchKernelGGL(k_qa_stats_prep, dim3((unsigned)Cout), dim3(64), 0, s, part, CB, 1, Cout, Cout, (const float*)nullptr, wscale, ascale, bias, n, eps, momentum, training,
+                       running_mean, running_var, save, Cout, gamma, beta, chan, nbt);
 }
 
 // ---------------------------------------------------------------- host side

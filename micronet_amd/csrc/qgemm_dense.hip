@@ -68,7 +68,7 @@ struct QdfParams {
     int S, PAD, TAPS;             // stride, padding, taps (9: 3 x 3, 1: 1 x 1)
     int TH, NI, PH, PW, W4;       // output rows per tile and image, images per tile, patch rows / columns per image
     int tpi, ncot, nchunks, nitems, nunits, out32, wo_shift;
-    FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_ncot, fd_tpi;
+    FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_ncot, fd_tpi, fd_ipt;
 };
 
 template <int MF>
@@ -137,22 +137,28 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
             }
         }
     };
+    // weights: the steps of an item read consecutive 8 KB blocks of the packed image; the block loads the weights of step + 2 while step is contracted
     u32x4 wreg[2];
-    struct Pos { int item, chunk, tap; };
-    auto fetch_w = [&](const Pos& q) {
-        const uint32_t tile = fd_div((uint32_t)q.item, p.fd_ncot);
-        const int cot = q.item - (int)tile * p.ncot;
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.wpk) + (int64_t)((cot * p.nchunks + q.chunk) * p.TAPS + q.tap) * QD_WSTEP;
-        wreg[0] = *reinterpret_cast<const u32x4*>(src + tid * 16);
-        wreg[1] = *reinterpret_cast<const u32x4*>(src + 4096 + tid * 16);
+    const int stride_items = (int)gridDim.x;
+    const int steps_item = p.nchunks * p.TAPS;
+    const int my_items = (p.nitems - (int)blockIdx.x + stride_items - 1) / stride_items;
+    const int total_steps = my_items * steps_item;
+    auto item_wbase = [&](int item) {
+        const uint32_t tile = fd_div((uint32_t)item, p.fd_ncot);
+        const int cot = item - (int)tile * p.ncot;
+        return reinterpret_cast<const unsigned char*>(p.wpk) + (int64_t)cot * steps_item * QD_WSTEP + tid * 16;
+    };
+    const unsigned char* wsrc = item_wbase((int)blockIdx.x);      // source of the NEXT weight load
+    int w_item = (int)blockIdx.x, w_left = steps_item;            // its item, steps left in that item
+    auto fetch_w = [&]() {
+        wreg[0] = *reinterpret_cast<const u32x4*>(wsrc);
+        wreg[1] = *reinterpret_cast<const u32x4*>(wsrc + 4096);
+        wsrc += QD_WSTEP;
+        if (--w_left == 0) { w_item += stride_items; w_left = steps_item; if (w_item < p.nitems) wsrc = item_wbase(w_item); }
     };
     auto commit_w = [&](int buf) {
         *reinterpret_cast<u32x4*>(wbuf + buf * QD_WSTEP + tid * 16) = wreg[0];
         *reinterpret_cast<u32x4*>(wbuf + buf * QD_WSTEP + 4096 + tid * 16) = wreg[1];
-    };
-    const int stride_items = (int)gridDim.x;
-    auto advance = [&](Pos& q) {
-        if (++q.tap == p.TAPS) { q.tap = 0; if (++q.chunk == p.nchunks) { q.chunk = 0; q.item += stride_items; } }
     };
     // A fragment bases: pixel tp = 16 MF wave + 16 mf + j of the tile -> the slot of its first tap
     int abase[MF];
@@ -164,18 +170,14 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
         const int ohl = t - (int)img * p.TH;
         abase[mf] = (((int)img * p.PH + ohl * p.S) * p.PW + ow * p.S) * QD_RS + kg * 16;
     }
-    Pos nxt{(int)blockIdx.x, 0, 0};
-    fetch_patch(nxt.item, 0);
-    fetch_w(nxt);
+    fetch_patch((int)blockIdx.x, 0);
+    fetch_w();
     __syncthreads();                          // the zero fill is complete
     commit_patch();
     commit_w(0);
-    advance(nxt);
-    if (nxt.item < p.nitems) fetch_w(nxt);    // wreg: the weights of step 1
-    Pos la = nxt;
-    advance(la);
+    if (total_steps > 1) fetch_w();           // wreg: the weights of step 1
     __syncthreads();
-    int buf = 0;
+    int buf = 0, gs = 0;                      // gs: steps done by this block
     for (int item = (int)blockIdx.x; item < p.nitems; item += stride_items) {
         f32x4 acc[MF][4];
 #pragma unroll
@@ -189,10 +191,9 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
             if (have_next) fetch_patch(nitem, nchunk);             // in flight during the chunk's nine steps
             for (int tap = 0; tap < p.TAPS; ++tap) {
                 // invariant: wbuf[buf] holds this step's weights, wreg the next step's
-                if (nxt.item < p.nitems) commit_w(buf ^ 1);
-                if (la.item < p.nitems) fetch_w(la);
-                advance(nxt);
-                advance(la);
+                if (gs + 1 < total_steps) commit_w(buf ^ 1);
+                if (gs + 2 < total_steps) fetch_w();
+                ++gs;
                 const int r = p.TAPS == 9 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0;
                 const int toff = (r * p.PW + (tap - 3 * r)) * QD_RS;
                 const unsigned char* wb = wbuf + buf * QD_WSTEP + lane * 16;
@@ -211,28 +212,77 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
                 __syncthreads();
                 buf ^= 1;
             }
-            if (have_next) { commit_patch(); __syncthreads(); }
+            if (chunk + 1 < p.nchunks) { commit_patch(); __syncthreads(); }       // (the last chunk: after the epilogue, which borrows the patch memory)
         }
-        // D[row = pixel 4 kg + r][col = channel j]: 4 consecutive pixels of one channel per lane
+        // ---- epilogue.  D[row = pixel 4 kg + r][col = channel j].  The wave transposes its 16 MF pixels x 64 channels through its own piece of the (now idle)
+        // patch memory -- rows [channel][16 MF pixels] padded by 8 bytes (conflict-free 8-byte writes) -- and stores 16 bytes per lane: a store instruction
+        // writes whole contiguous rows of several channels (int16: 32 MF bytes per row; int32: two passes of 32 channels, 64 MF bytes per row).
         int n0, oh0, cot;
         tile_origin(item, n0, oh0, cot);
+        {
+            unsigned char* scr = patch + wave * (MF * 2048 + 64 * 8);
+            const int tp0 = wave * 16 * MF;                               // first tile pixel of this wave; its pixels are consecutive in ONE image when
+            const int ipt = p.TH * p.Wo;                                  // 16 MF <= pixels per image and tile, else whole images
+            if (!p.out32) {
+                constexpr int ROW = 32 * MF + 8;
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-            const int tp = wave * 16 * MF + mf * 16 + 4 * kg;
-            const int ow = tp & (p.Wo - 1), t = tp >> p.wo_shift;
-            const uint32_t img = fd_div((uint32_t)t, p.fd_th);
-            const int ohl = t - (int)img * p.TH;
-            const int n = n0 + (int)img;
-            if (n >= p.N) continue;
-            const uint32_t base = (uint32_t)((n * p.O + cot * 64 + j) * p.Ho + oh0 + ohl) * (uint32_t)p.Wo + (uint32_t)ow;
+                for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const uint32_t off = base + (uint32_t)(nf * 16 * p.HoWo);
-                const int v0 = (int)acc[mf][nf][0], v1 = (int)acc[mf][nf][1], v2 = (int)acc[mf][nf][2], v3 = (int)acc[mf][nf][3];
-                if (p.out32) *reinterpret_cast<u32x4*>(reinterpret_cast<int32_t*>(p.stash) + off) = u32x4{(uint32_t)v0, (uint32_t)v1, (uint32_t)v2, (uint32_t)v3};
-                else *reinterpret_cast<u32x2*>(reinterpret_cast<int16_t*>(p.stash) + off) =
-                         u32x2{((uint32_t)v0 & 0xffffu) | ((uint32_t)v1 << 16), ((uint32_t)v2 & 0xffffu) | ((uint32_t)v3 << 16)};
+                    for (int nf = 0; nf < 4; ++nf) {
+                        const int v0 = (int)acc[mf][nf][0], v1 = (int)acc[mf][nf][1], v2 = (int)acc[mf][nf][2], v3 = (int)acc[mf][nf][3];
+                        *reinterpret_cast<u32x2*>(scr + (nf * 16 + j) * ROW + (mf * 16 + 4 * kg) * 2) =
+                            u32x2{((uint32_t)v0 & 0xffffu) | ((uint32_t)v1 << 16), ((uint32_t)v2 & 0xffffu) | ((uint32_t)v3 << 16)};
+                    }
+                MN_WAVE_SYNC();
+                constexpr int CPR = 2 * MF, RPI = 64 / CPR;                // 16-byte chunks per row, rows per store instruction
+#pragma unroll
+                for (int it = 0; it < 64 / RPI; ++it) {
+                    const int co = it * RPI + lane / CPR, ch = lane % CPR;
+                    const unsigned char* q = scr + co * ROW + ch * 16;
+                    const u32x2 a = *reinterpret_cast<const u32x2*>(q), b = *reinterpret_cast<const u32x2*>(q + 8);
+                    const int tp = tp0 + ch * 8;
+                    const int im = (int)fd_div((uint32_t)tp, p.fd_ipt), lp = tp - im * ipt;
+                    const int n = n0 + im;
+                    if (n < p.N)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<int16_t*>(p.stash) + (uint32_t)((n * p.O + cot * 64 + co) * p.HoWo + oh0 * p.Wo + lp)) = u32x4{a[0], a[1], b[0], b[1]};
+                }
+            } else {
+                constexpr int ROW = 64 * MF + 8;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2) {
+                            const int nf = half * 2 + n2;
+                            unsigned char* d = scr + (n2 * 16 + j) * ROW + (mf * 16 + 4 * kg) * 4;
+                            *reinterpret_cast<u32x2*>(d) = u32x2{(uint32_t)(int)acc[mf][nf][0], (uint32_t)(int)acc[mf][nf][1]};
+                            *reinterpret_cast<u32x2*>(d + 8) = u32x2{(uint32_t)(int)acc[mf][nf][2], (uint32_t)(int)acc[mf][nf][3]};
+                        }
+                    MN_WAVE_SYNC();
+                    constexpr int CPR = 4 * MF, RPI = 64 / CPR;
+#pragma unroll
+                    for (int it = 0; it < 32 / RPI; ++it) {
+                        const int cl = it * RPI + lane / CPR, ch = lane % CPR;
+                        const unsigned char* q = scr + cl * ROW + ch * 16;
+                        const u32x2 a = *reinterpret_cast<const u32x2*>(q), b = *reinterpret_cast<const u32x2*>(q + 8);
+                        const int tp = tp0 + ch * 4;
+                        const int im = (int)fd_div((uint32_t)tp, p.fd_ipt), lp = tp - im * ipt;
+                        const int n = n0 + im;
+                        if (n < p.N)
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<int32_t*>(p.stash) + (uint32_t)((n * p.O + cot * 64 + half * 32 + cl) * p.HoWo + oh0 * p.Wo + lp)) =
+                                u32x4{a[0], a[1], b[0], b[1]};
+                    }
+                    MN_WAVE_SYNC();
+                }
             }
+        }
+        if (item + stride_items < p.nitems) {
+            __syncthreads();                  // every wave is done with its transposition scratch
+            for (int i = tid; i < (4 * (MF * 2048 + 512)) / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};      // the zero frame again
+            __syncthreads();
+            commit_patch();                   // the next item's first chunk (fetched during this item's last chunk)
+            __syncthreads();
         }
     }
 }
@@ -297,7 +347,7 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
         if (PH > 255 || NI > 255) continue;
         const int64_t patch = (int64_t)NI * PH * PW * QD_RS;
         const int nunits = NI * PH * (g->W / 4) * 16;
-        if (patch > 60 * 1024 || nunits > 256 * QDF_UPT) continue;
+        if (patch > 60 * 1024 || nunits > 256 * QDF_UPT || patch < 4 * (mf * 2048 + 512)) continue;      // (the epilogue borrows the patch memory)
         MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.nunits = nunits;
         break;
     }
@@ -310,6 +360,7 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
     p.ncot = g->O / 64; p.nchunks = g->C / 64; p.nitems = ntiles * p.ncot; p.out32 = out32;
     p.fd_w4 = make_fastdiv((uint32_t)p.W4); p.fd_ph = make_fastdiv((uint32_t)p.PH); p.fd_ni = make_fastdiv((uint32_t)p.NI);
     p.fd_th = make_fastdiv((uint32_t)p.TH); p.fd_ncot = make_fastdiv((uint32_t)p.ncot); p.fd_tpi = make_fastdiv((uint32_t)p.tpi);
+    p.fd_ipt = make_fastdiv((uint32_t)(p.TH * p.Wo));
     int tgt = 512;
     if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }     // tuning knob
     pl->grid = p.nitems < tgt ? p.nitems : tgt;
@@ -357,7 +408,7 @@ int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a
     qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 0, s);
     p.x = x; p.wpk = wpk; p.stash = stash;
     mn_set_last_kernel("k_qd_fwd<%d>", pl.MF);
-    { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); }
+    { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4>, pl.lds); hipLaunchKernelGGL(k_qd_fwd<4>, dim3(pl.grid), dim3(256), pl.lds, s, p); }
     else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2>, pl.lds); hipLaunchKernelGGL(k_qd_fwd<2>, dim3(pl.grid), dim3(256), pl.lds, s, p); }
@@ -651,7 +702,7 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
     qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 1, s);
     p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1);
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); }
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     if (pl.S == 2 && p.TAPS == 9) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
     else if (pl.S == 2) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
@@ -865,16 +916,31 @@ __global__ __launch_bounds__(512, 2) void k_qd_wgrad(const QdwParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[t * 4096 + ((2 * coh + c2) * 16 + 4 * kg + r) * 64 + cf * 16 + j] = acc[c2][t][r];
 }
-// dw[o][c][tap] = scale * sum over z (fixed order, fp64) of part[z][pair][tap][o % 64][c % 64]
+// dw[o][c][tap] = scale * sum over z (fixed order, fp64) of part[z][pair][tap][o % 64][c % 64].  A block owns 64 consecutive (pair, tap, o, c) indices (one
+// 256-byte row of every partial tile): thread (tx = 16 float4 columns, ty = 16 z residues) sums its z subset, the 16 subsets are added in order through LDS.
 __global__ __launch_bounds__(256) void k_qd_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int O, int C, int T, int Z, float scale) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;                // (pair, tap, o, c) with c fastest
+    __shared__ double red[16][64];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int npairs = (O / 64) * (C / 64);
-    if (idx >= npairs * T * 4096) return;
-    const int c = idx & 63, o = (idx >> 6) & 63, t = (idx >> 12) % T, pair = (idx >> 12) / T;
-    double s = 0.0;
-    for (int zz = 0; zz < Z; ++zz) s += (double)part[(int64_t)zz * npairs * T * 4096 + idx];
-    const int cot = pair / (C / 64), cit = pair - cot * (C / 64);
-    dw[((int64_t)(cot * 64 + o) * C + cit * 64 + c) * T + t] = (float)(s * (double)scale);
+    const int64_t tile = (int64_t)npairs * T * 4096;
+    const int64_t idx0 = (int64_t)blockIdx.x * 64 + 4 * tx;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int zz = ty; zz < Z; zz += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)zz * tile + idx0);
+        s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[ty][4 * tx + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][threadIdx.x];
+        const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        const int c = (int)(idx & 63), o = (int)((idx >> 6) & 63), t = (int)((idx >> 12) % T), pair = (int)((idx >> 12) / T);
+        const int cot = pair / (C / 64), cit = pair - cot * (C / 64);
+        dw[((int64_t)(cot * 64 + o) * C + cit * 64 + c) * T + t] = (float)(a * (double)scale);
+    }
 }
 
 struct QdwPlan { QdwParams p; int S, T, grid; size_t lds; int64_t ws_bytes; };
@@ -935,14 +1001,14 @@ int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, floa
     QdwParams& p = pl.p;
     p.gy = gy; p.x = x; p.part = reinterpret_cast<float*>(ws);
     mn_set_last_kernel("k_qd_wgrad<%d, %d>", pl.S, pl.T);
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + nx * (g->O / 64) + (double)pl.ws_bytes); }
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + nx * (g->O / 64) + (double)pl.ws_bytes); mn_prof_flops(2.0 * ny * g->C * pl.T); }
     mn_prof_begin(s);
     if (pl.S == 1) { raise_lds_limit((const void*)k_qd_wgrad<1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<1, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
     else if (pl.T == 9) { raise_lds_limit((const void*)k_qd_wgrad<2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
     else { raise_lds_limit((const void*)k_qd_wgrad<2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 1>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
     mn_prof_end(s);
     const int total = p.npairs * pl.T * 4096;
-    hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)p.part, dw, (int)g->O, (int)g->C, pl.T, p.Z, ascale);
+    hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(256), 0, s, (const float*)p.part, dw, (int)g->O, (int)g->C, pl.T, p.Z, ascale);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(dense)");
     return MN_OK;
 }

@@ -111,6 +111,9 @@ int qd_wgrad_supported(const mn_conv_geom* g, int a_bits);
 int64_t qd_wgrad_ws_bytes(const mn_conv_geom* g);
 int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, void* ws, int64_t ws_bytes, hipStream_t s);
 
+void qa_launch_stats_prep_const(const double* part, int CB, int Cout, float wscale, float ascale, const float* bias, double n, float eps, float momentum, int training,
+                                float* running_mean, float* running_var, float* save, const float* gamma, const float* beta, float* chan, long long* nbt, hipStream_t s);
+
 static inline int aq_codeable(const mn_actq* aq, int need_exact_x) {
     (void)need_exact_x;   // real-valued x is handled exactly by term splitting (zero terms are skipped)
     if (!aq || aq->mode == MN_ACTQ_NONE) return 1;

@@ -1789,9 +1789,9 @@ extern "C" int mn_qconv_bnq_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
         int rc = qd_fwd_stash(g, wq, x_codes, a_bits_in, w, (void*)stash, ws, ws_bytes, s, &part, &nparts, &rowscale);
         if (rc) return rc;
         const int Ho = (int)((g->H + 2 * g->pad_h - g->KH) / g->stride_h + 1), Wo = (int)((g->W + 2 * g->pad_w - g->KW) / g->stride_w + 1);
-        hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((g->O + 255) / 256)), dim3(256), 0, s, rowscale, (int)g->O, 1.0f / (float)((1ll << wq->bits) - 1));
-        qa_launch_stats_prep(part, nparts, 1, (int)g->O, (int)g->O, rowscale, ascale, bias, (double)g->N * Ho * Wo, eps, momentum, training, running_mean, running_var, save,
-                             (int)g->O, gamma, beta, chan, (long long*)num_batches_tracked, s);
+        (void)rowscale;
+        qa_launch_stats_prep_const(part, nparts, (int)g->O, 1.0f / (float)((1ll << wq->bits) - 1), ascale, bias, (double)g->N * Ho * Wo, eps, momentum, training, running_mean,
+                                   running_var, save, gamma, beta, chan, (long long*)num_batches_tracked, s);
         MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash(dense)");
         return MN_OK;
     }

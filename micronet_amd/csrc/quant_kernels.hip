@@ -43,10 +43,12 @@ extern "C" const char* mn_last_kernel(void) { return g_kernel; }
 // keeps its own spans (name, designed bytes, two pooled events per launch) for EVERY main kernel and aggregates them by name.
 static thread_local void* g_prof_ev[2] = {nullptr, nullptr};
 static thread_local double g_prof_bytes = 0.0;
+static thread_local double g_prof_flops = 0.0;
 extern "C" void mn_profile_next(void* start_event, void* stop_event) { g_prof_ev[0] = start_event; g_prof_ev[1] = stop_event; }
-void mn_prof_bytes(double nbytes) { g_prof_bytes = nbytes; }
+void mn_prof_bytes(double nbytes) { g_prof_bytes = nbytes; g_prof_flops = 0.0; }
+void mn_prof_flops(double nflops) { g_prof_flops = nflops; }
 #ifndef MN_EMULATION
-struct ProfSpan { std::string name; double bytes; hipEvent_t a, b; };
+struct ProfSpan { std::string name; double bytes, flops; hipEvent_t a, b; };
 // process-wide (autograd runs the backward on its own thread); guarded by g_prof_mu
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -81,7 +83,7 @@ extern "C" int mn_profile_collect(mn_prof_entry* out, int cap) {
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
             mn_prof_entry& e = agg[sp.name];
             if (e.launches == 0) { memset(e.name, 0, sizeof(e.name)); strncpy(e.name, sp.name.c_str(), sizeof(e.name) - 1); }
-            e.launches += 1; e.total_ms += ms; e.bytes += sp.bytes;
+            e.launches += 1; e.total_ms += ms; e.bytes += sp.bytes; e.flops += sp.flops;
         }
         g_evpool->push_back(sp.a); g_evpool->push_back(sp.b);
     }
@@ -100,7 +102,7 @@ void mn_prof_begin(hipStream_t s) {
     if (g_prof_on) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof_on && g_spans) {
-            ProfSpan sp; sp.name = g_kernel; sp.bytes = g_prof_bytes; sp.a = prof_event(); sp.b = prof_event();
+            ProfSpan sp; sp.name = g_kernel; sp.bytes = g_prof_bytes; sp.flops = g_prof_flops; sp.a = prof_event(); sp.b = prof_event();
             (void)hipEventRecord(sp.a, s);
             g_open_stop = sp.b;
             g_spans->push_back(sp);

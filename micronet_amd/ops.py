@@ -1270,8 +1270,48 @@ def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ
                          _lib.MN_ACTQ_X_IS_CODE if x_is_code else 0, in_shuffle or 0)
 
 
+class QLinearSmall(Function):
+    """F.linear(Q_a(x), wq, bias) for a layer with few outputs (the 512 -> 10 classifier of the ResNets): mn_qlinear_* -- the activation quantizer in registers,
+    its clip-STE in the backward-data launch; three launches of a few microseconds instead of the 1x1-conv route's direct VALU kernels."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bias, aq_mode, aq_bits, aq_qtype, qp):
+        x, wq, bias = _chk(x, "input"), _chk(wq, "weight"), _chk(bias, "bias")
+        N, Cc = x.shape
+        O = wq.shape[0]
+        y = torch.empty((N, O), dtype=torch.float32, device=x.device)
+        aq = ActQ(aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
+        with torch.cuda.device_of(x):
+            _call("mn_qlinear_fwd", C.byref(aq), _p(x), _p(wq), _p(bias), _p(y), N, Cc, O, _s())
+        ctx.save_for_backward(x, wq, qp)
+        ctx.cfg = (aq_mode, aq_bits, aq_qtype, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wq, qp = ctx.saved_tensors
+        aq_mode, aq_bits, aq_qtype, has_bias = ctx.cfg
+        gy = _chk(gy, "grad")
+        N, Cc = x.shape
+        O = wq.shape[0]
+        aq = ActQ(aq_mode, aq_bits, aq_qtype, 0, qp.data_ptr() if qp is not None else None)
+        dx = dw = db = None
+        with torch.cuda.device_of(x):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _call("mn_qlinear_bwd_data", C.byref(aq), _p(gy), _p(wq), _p(x), _p(dx), N, Cc, O, _s())
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(wq)
+                db = torch.empty(O, dtype=torch.float32, device=x.device) if has_bias else None
+                _call("mn_qlinear_bwd_weight", C.byref(aq), _p(gy), _p(x), _p(dw), _p(db), N, Cc, O, _s())
+        return dx, dw, db, None, None, None, None
+
+
 def qlinear(x, wq, bias, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None, wdesc=None):
-    """F.linear as a 1x1 convolution over 1x1 'images' (same kernels, same fused quantizer)."""
+    """F.linear as a 1x1 convolution over 1x1 'images' (same kernels, same fused quantizer); few outputs: the dedicated small-linear kernels."""
+    if (CONV_ALGO == _lib.MN_ALGO_AUTO and x.dim() == 2 and type(x) is torch.Tensor and x.is_cuda and x.dtype == torch.float32 and
+            aq_mode in (ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO) and _lib_().mn_qlinear_supported(x.shape[0], x.shape[1], wq.shape[0])):
+        return QLinearSmall.apply(x, wq, bias, aq_mode, aq_bits, aq_qtype, qp)
     lead = x.shape[:-1]
     x4 = x.reshape(-1, x.shape[-1], 1, 1)
     y = QConv2d.apply(x4, wq.reshape(wq.shape[0], wq.shape[1], 1, 1), bias, 1, 0, 1, 1, aq_mode, aq_bits, aq_qtype, qp, wdesc, 0)
