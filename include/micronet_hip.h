@@ -72,9 +72,10 @@ int mn_dorefa_w_fwd(const float* w, float* qw, int64_t n, int w_bits, float* ws,
 /* backward incl. the path through the global max (ties share equally) */
 int mn_dorefa_w_bwd(const float* g, const float* w, float* dw, int64_t n, int w_bits, float* ws, mn_stream_t stream);
 
-/* y = tanh(x) exactly as the weight-quantizer kernels evaluate it (device tanhf).  torch-CPU's tanh (Sleef), which the reference runs, differs from it in
- * the last ulp for ~5 % of inputs (never more than 1 ulp); where such a difference straddles a rounding boundary a weight code differs by one step
- * (<= 2 in 10^5).  tests/golden/tanh_device_vs_cpu.json pins both functions on inputs where they differ. */
+/* y = tanh(x) exactly as the weight-quantizer kernels evaluate it: the CORRECTLY ROUNDED fp32 value (fp64 evaluation, one rounding).  The reference runs
+ * torch.tanh on the CPU = Intel MKL VML vsTanh (HA) in a MKL build of torch: closed source, host-CPU dependent in the last bit (0.05 % ... 1.5 % of inputs differ
+ * from the correctly rounded value by one ulp depending on the host) -- it cannot be restated; where such a difference straddles a rounding boundary a weight
+ * code differs by one step (<= 2 in 10^5).  tests/golden/tanh_device_vs_cpu.json pins the kernels' function on inputs where the two differed. */
 int mn_tanh_f32(const float* x, float* y, int64_t n, mn_stream_t stream);
 
 /* The same quantizer over count <= 32 weight tensors in ONE launch per phase (host arrays of device pointers / element counts; nothing is allocated,

@@ -9,7 +9,7 @@
 // bit-identical to the CPU pipeline for the same random draws.  One thread = 4 consecutive output pixels of one channel row (float4 store).
 #include "common.h"
 
-struct AugParams { int B, H, W, C, pad; float mean[4], std[4]; };
+struct AugParams { int B, H, W, C, pad; int64_t n_images; float mean[4], std[4]; };
 
 __global__ __launch_bounds__(256) void k_cifar_augment(const unsigned char* __restrict__ images, const int* __restrict__ index, const int* __restrict__ ox,
                                                        const int* __restrict__ oy, const unsigned char* __restrict__ flip, float* __restrict__ out, AugParams p) {
@@ -21,8 +21,14 @@ __global__ __launch_bounds__(256) void k_cifar_augment(const unsigned char* __re
         const int h = (int)(t % p.H); t /= p.H;
         const int c = (int)(t % p.C);
         const int b = (int)(t / p.C);
-        const unsigned char* img = images + (int64_t)index[b] * p.H * p.W * p.C;
-        const int sy = h + oy[b] - p.pad, dx0 = ox[b] - p.pad;
+        // caller-supplied draws are clamped: an out-of-range image index or offset must not become an out-of-bounds read
+        int64_t idx = index[b];
+        idx = idx < 0 ? 0 : (idx < p.n_images ? idx : p.n_images - 1);
+        int oxb = ox[b], oyb = oy[b];
+        oxb = oxb < 0 ? 0 : (oxb > 2 * p.pad ? 2 * p.pad : oxb);
+        oyb = oyb < 0 ? 0 : (oyb > 2 * p.pad ? 2 * p.pad : oyb);
+        const unsigned char* img = images + idx * p.H * p.W * p.C;
+        const int sy = h + oyb - p.pad, dx0 = oxb - p.pad;
         const bool fl = flip[b] != 0;
         float r[4];
 #pragma unroll
@@ -43,7 +49,7 @@ extern "C" int mn_cifar_augment(const uint8_t* images, int64_t n_images, const i
     if (!images || !index || !ox || !oy || !flip || !out || !mean || !stdv || B <= 0 || n_images <= 0 || H <= 0 || W <= 0 || W % 4 || Cc < 1 || Cc > 4 || pad < 0 || !aligned16(out))
         MN_FAIL(MN_EINVAL, "mn_cifar_augment: bad arguments (W must be a multiple of 4, 1 <= C <= 4, out 16-byte aligned)");
     AugParams p;
-    p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)Cc; p.pad = pad;
+    p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)Cc; p.pad = pad; p.n_images = n_images;
     for (int c = 0; c < 4; ++c) { p.mean[c] = c < Cc ? mean[c] : 0.f; p.std[c] = c < Cc ? stdv[c] : 1.f; }
     const int64_t total = B * Cc * H * (W / 4);
     hipLaunchKernelGGL(k_cifar_augment, dim3(mn_grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, images, index, ox, oy, flip, out, p);

@@ -221,6 +221,12 @@ extern "C" int mn_dorefa_act_bwd(const float* g, const float* x, float* dx, int6
 }
 
 // ------------------------------------------------------------------------------------------------
+// tanh as the DoReFa weight quantizer needs it.  The reference evaluates torch.tanh on the CPU, which in the reference's environment (torch 2.10, MKL build) is
+// Intel MKL VML vsTanh in HA mode -- verified bit for bit; it is NOT Sleef's tanhf_u10 (1.5 % of inputs differ) nor libm -- a closed-source kernel with no published
+// algorithm, so it cannot be restated.  What can be done is to take the rounding error out of OUR side: the value is evaluated in fp64 and rounded once, i.e. the
+// correctly rounded fp32 tanh (MKL HA differs from it in the last ulp for 1.5 % of inputs; ocml's tanhf, used until round 2, for 5.4 %).  The tensors are small
+// (<= 11 M weights per net): the fp64 evaluation costs microseconds.  Pinned by tests/golden/tanh_device_vs_cpu.json.
+__device__ __forceinline__ float mn_tanh_cr(float x) { return (float)tanh((double)x); }
 // DoReFa weight (61-73): global max of |tanh w| -> normalise -> round -> 2q-1.
 // ws layout (floats): [0] M, [1] dM (bwd), [2] tie count (bwd), [16 .. 16+3*NB) per-block partials.
 static const int DW_NB = 128;  // partial blocks
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_absmax(const float* __restrict
     __shared__ float sc[16];
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        m = OpMaxF()(m, fabsf(tanhf(w[i])));
+        m = OpMaxF()(m, fabsf(mn_tanh_cr(w[i])));
     m = block_reduce(m, OpMaxF(), 0.f, sc);
     if (threadIdx.x == 0) ws[16 + blockIdx.x] = m;
 }
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_fwd(const float* __restrict__ 
     const float M = dorefa_w_global_max(ws, nb, sc);
     if (blockIdx.x == 0 && threadIdx.x == 0) ws[0] = M;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float t = tanhf(w[i]);
+        float t = mn_tanh_cr(w[i]);
         float u = (t / 2.f) / M + 0.5f;
         float q = mn_rha(u / s) * s;
         qw[i] = 2.f * q - 1.f;
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_bwd_partial(const float* __res
     double acc = 0.0;
     float ties = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float t = tanhf(w[i]);
+        float t = mn_tanh_cr(w[i]);
         float du = ((g[i] * 2.f) * s) / s;
         float v = t / 2.f;
         acc += (double)(-du * v / (M * M));
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_bwd(const float* __restrict__ 
     if (blockIdx.x == 0 && threadIdx.x == 0) { ws[1] = dM; ws[2] = cnt; }
     const float share = dM / cnt;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float t = tanhf(w[i]);
+        float t = mn_tanh_cr(w[i]);
         float du = ((g[i] * 2.f) * s) / s;
         float dt = (du / M) / 2.f;
         if (fabsf(t) == M) dt += share * mn_sign(t);
@@ -319,7 +325,7 @@ extern "C" int mn_dorefa_w_bwd(const float* g, const float* w, float* dw, int64_
 
 // the tanh the kernels above evaluate, element-wise: lets the tests pin it against torch-CPU's (tests/golden/tanh_device_vs_cpu.json)
 __global__ void k_tanh_f32(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = tanhf(x[i]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = mn_tanh_cr(x[i]);
 }
 extern "C" int mn_tanh_f32(const float* x, float* y, int64_t n, mn_stream_t stream) {
     if (!x || !y || n <= 0) MN_FAIL(MN_EINVAL, "mn_tanh_f32: bad arguments");
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_absmax_multi(const DwTable t) 
     const float* __restrict__ w = t.w[ti];
     const long long n = t.n[ti];
     float m = 0.f;
-    for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nb * 256) m = OpMaxF()(m, fabsf(tanhf(w[i])));
+    for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nb * 256) m = OpMaxF()(m, fabsf(mn_tanh_cr(w[i])));
     m = block_reduce(m, OpMaxF(), 0.f, sc);
     if (threadIdx.x == 0) t.ws[ti][16 + lb] = m;
 }
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int pha
         if (lb == 0 && threadIdx.x == 0) ws[0] = M;
         float* __restrict__ qw = t.out[ti];
         for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
-            const float tt = tanhf(w[i]);
+            const float tt = mn_tanh_cr(w[i]);
             const float u = (tt / 2.f) / M + 0.5f;
             const float q = mn_rha(u / s) * s;
             qw[i] = 2.f * q - 1.f;
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int pha
         double acc = 0.0;
         float ties = 0.f;
         for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
-            const float tt = tanhf(w[i]);
+            const float tt = mn_tanh_cr(w[i]);
             const float du = ((g[i] * 2.f) * s) / s;
             acc += (double)(-du * (tt / 2.f) / (M * M));
             ties += (fabsf(tt) == M) ? 1.f : 0.f;
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int pha
         const float share = dM / cnt;
         float* __restrict__ dw = t.out[ti];
         for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
-            const float tt = tanhf(w[i]);
+            const float tt = mn_tanh_cr(w[i]);
             const float du = ((g[i] * 2.f) * s) / s;
             float dt = (du / M) / 2.f;
             if (fabsf(tt) == M) dt += share * mn_sign(tt);

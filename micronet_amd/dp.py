@@ -115,13 +115,25 @@ def allreduce_minmax(min_t, max_t, group=None):
 
 
 def sync_observers(model, group=None, enable=True):
-    """Switch the cross-rank range reduction of every level-'L' min/max observer of ``model`` on (IAO activation quantizers, QuantAdd); returns
-    how many observers were switched.  No-op for models without such observers (DoReFa, wbwtab)."""
-    n = 0
+    """Switch the cross-rank range reduction of the ACTIVATION observers of ``model`` on: the observer of every IAO quantizer with ``activation_weight_flag == 1``
+    and the two input observers of every ``QuantAdd`` (each sees only its rank's shard of the batch).  Weight observers are left alone -- the weights are the
+    same on every rank, their ranges are rank-invariant and need no collective.  Returns how many observers were switched; a no-op for models without such
+    observers (DoReFa, wbwtab)."""
+    seen, n = set(), 0
+
+    def switch(obs):
+        nonlocal n
+        if obs is None or id(obs) in seen or type(obs).__name__ == "HistogramObserver":
+            return
+        if getattr(obs, "q_level", None) == "L" and hasattr(obs, "min_val") and hasattr(obs, "max_val"):
+            seen.add(id(obs))
+            obs._mn_sync_group = group if enable else None
+            obs._mn_sync = bool(enable)
+            n += 1
     for m in model.modules():
-        if hasattr(m, "update_range") or type(m).__name__ in ("MinMaxObserver", "MovingAverageMinMaxObserver"):
-            if getattr(m, "q_level", None) == "L" and hasattr(m, "min_val") and hasattr(m, "max_val") and type(m).__name__ != "HistogramObserver":
-                m._mn_sync_group = group if enable else None
-                m._mn_sync = bool(enable)
-                n += 1
+        if getattr(m, "activation_weight_flag", None) == 1 and hasattr(m, "observer"):
+            switch(m.observer)
+        if hasattr(m, "observer_res") and hasattr(m, "observer_shortcut"):
+            switch(m.observer_res)
+            switch(m.observer_shortcut)
     return n

@@ -97,7 +97,7 @@ def iao_model_bn_fuse(model, inplace=False):
         mean, std = m.running_mean, torch.sqrt(m.running_var + m.eps)
         b = m.bias if m.bias is not None else mean.new_zeros(mean.shape)
         aq, wq = m.activation_quantizer, m.weight_quantizer
-        q_level = 0 if wq.scale.numel() > 1 else 1
+        q_level = 0 if getattr(wq.observer, "q_level", "L") != "L" else 1          # per-channel iff the weight observer is (an out_channels == 1 conv has ONE scale either way)
         new = _conv_like(m, quantize.QuantConv2d, a_bits=aq.bits, w_bits=wq.bits, q_type=wq._q_type_static, q_level=q_level, quant_inference=True).to(m.weight.device)
         new.weight.data = m.weight * (m.gamma / std).reshape([m.out_channels, 1, 1, 1])
         new.bias.data = m.beta + (b - mean) * (m.gamma / std)

@@ -89,7 +89,7 @@ def dorefa_act_bwd(g, x, a_bits):
 def dorefa_w_fwd(w, w_bits, tanh_w=None):
     """WeightQuantizer.forward (61-73). Returns (out, codes, t, M).
 
-    ``tanh_w`` lets the caller inject tanh(w) computed by torch-CPU (Sleef), which
+    ``tanh_w`` lets the caller inject tanh(w) computed by torch-CPU (MKL VML vsTanh in the reference environment), which
     is not bit-identical to numpy's libm tanh.
     """
     w = _f(w)

@@ -58,7 +58,7 @@ def check_dorefa_w(be, q, bits):
     ref = q[f"dorefa_w{bits}_y"].reshape(-1)
     got = be.to_host(qw).reshape(-1)
     s = 1.0 / (2 ** bits - 1)
-    # codes: identical except where device tanh and torch-CPU (Sleef) tanh differ in the last ulp at a rounding boundary
+    # codes: identical except where the kernels' (correctly rounded) tanh and torch-CPU (MKL VML) tanh differ in the last ulp at a rounding boundary
     codes_got, codes_ref = np.round((got + 1) / 2 / s), np.round((ref + 1) / 2 / s)
     assert (codes_got != codes_ref).sum() <= 2, (codes_got != codes_ref).sum()
     same = codes_got == codes_ref

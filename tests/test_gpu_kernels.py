@@ -481,11 +481,15 @@ def test_dorefa_weight_quantizer_multi_bit_identical(be):
 
 
 def test_dorefa_tanh_pinned(be):
-    """The one documented deviation of the DoReFa weight quantizer: device tanhf vs torch-CPU (Sleef) tanh, which the reference evaluates.  Pinned three ways:
-    (1) on the committed inputs where the two differ (tests/golden/tanh_device_vs_cpu.json, harvested by scripts/make_tanh_fixture.py) both functions
-    still return the recorded bits -- a change of either library shows up here; (2) on 2^20 seeded inputs they never differ by more than one ulp;
-    (3) weight codes differ from the torch-CPU evaluation of the reference formula (wqaq/dorefa/quantize.py:61-73) only at elements whose tanh differs or
-    which sit next to one on the rounding grid through the shared maximum, at most 2 per 10^5, by one step."""
+    """The one documented deviation of the DoReFa weight quantizer: tanh.  The reference evaluates torch.tanh on the CPU, which in a MKL build of torch is Intel
+    MKL VML vsTanh (HA mode) -- a closed-source kernel whose last bit even depends on the host CPU (MKL dispatches per micro-architecture): it cannot be restated.
+    The kernels therefore evaluate the CORRECTLY ROUNDED fp32 tanh (fp64 evaluation, one rounding).  Pinned three ways:
+    (1) mn_tanh_f32 == float32(tanh(float64(x))) bit for bit on 2^20 seeded inputs and on the committed inputs of tests/golden/tanh_device_vs_cpu.json (inputs where
+        the reference host's torch.tanh and the kernels differed when the fixture was harvested by scripts/make_tanh_fixture.py), whose recorded kernel bits must
+        still come out -- machine independent;
+    (2) torch-CPU tanh of THIS host never differs from it by more than one ulp, and in less than 2 % of the inputs;
+    (3) weight codes differ from the torch-CPU evaluation of the reference formula (wqaq/dorefa/quantize.py:61-73) only where the two tanh differ across a rounding
+        boundary (or next to one through the shared maximum): at most 2 per 10^5, by one step."""
     import json
     import os
     torch = be.torch
@@ -494,15 +498,17 @@ def test_dorefa_tanh_pinned(be):
     y = torch.empty(x.size, device="cuda")
     be.call("mn_tanh_f32", be.ptr(torch.from_numpy(x).cuda()), be.ptr(y), x.size, be.stream)
     assert np.array_equal(y.cpu().numpy().view(np.int32), np.array(fx["dev_bits"], dtype=np.int32))
-    assert np.array_equal(torch.tanh(torch.from_numpy(x)).numpy().view(np.int32), np.array(fx["cpu_bits"], dtype=np.int32))
+    assert np.array_equal(np.tanh(x.astype(np.float64)).astype(np.float32).view(np.int32), np.array(fx["dev_bits"], dtype=np.int32))
     assert np.all(np.abs(np.array(fx["dev_bits"], dtype=np.int64) - np.array(fx["cpu_bits"], dtype=np.int64)) == 1)
     rng = np.random.default_rng(7)
     w = (rng.standard_normal(1 << 20) * 0.4).astype(np.float32)
     wt = torch.from_numpy(w)
     yd = torch.empty(w.size, device="cuda")
     be.call("mn_tanh_f32", be.ptr(wt.cuda()), be.ptr(yd), w.size, be.stream)
-    d = yd.cpu().numpy().view(np.int32).astype(np.int64) - torch.tanh(wt).numpy().view(np.int32).astype(np.int64)
-    assert np.abs(d).max() <= 1
+    dev = yd.cpu().numpy().view(np.int32)
+    assert np.array_equal(dev, np.tanh(w.astype(np.float64)).astype(np.float32).view(np.int32)), "the kernels' tanh is not the correctly rounded value"
+    d = dev.astype(np.int64) - torch.tanh(wt).numpy().view(np.int32).astype(np.int64)
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 0.02 * w.size, (int(np.abs(d).max()), int(np.count_nonzero(d)))
     for bits in (2, 4, 8):
         n = float(2 ** bits - 1)
         t = torch.tanh(wt)

@@ -2,7 +2,7 @@
 
 Tolerances (stated once, used below):
   * every elementwise quantizer value, code, observer statistic and STE gradient: BIT-EXACT;
-  * DoReFa weight path: bit-exact when fed torch-CPU's tanh (Sleef) -- numpy's libm tanh differs in the last ulp,
+  * DoReFa weight path: bit-exact when fed torch-CPU's tanh (MKL VML in the reference environment) -- numpy's libm tanh differs in the last ulp,
     so with np.tanh at most a handful of codes may move at rounding boundaries;
   * float conv accumulate (numpy fp64 einsum vs the reference's MKLDNN fp32): |diff| <= 1e-5 * max|ref|.
 """
@@ -39,7 +39,7 @@ def test_dorefa_weight(golden, bits):
     ref = q[f"dorefa_w{bits}_dw"]
     # two autograd branches are summed in autograd's order: <= 1e-6 rel
     assert np.max(np.abs(dw - ref)) <= 1e-6 * np.max(np.abs(ref))
-    # libm tanh instead of Sleef: codes may differ only at rounding boundaries
+    # libm tanh instead of the reference host's: codes may differ only at rounding boundaries
     y2, k2, _, _ = O.dorefa_w_fwd(w, bits)
     assert (k2 != k).sum() <= 2
 
