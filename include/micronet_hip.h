@@ -84,6 +84,12 @@ int mn_tanh_f32(const float* x, float* y, int64_t n, mn_stream_t stream);
 int mn_dorefa_w_fwd_multi(const float* const* w, float* const* qw, float* const* ws, const int64_t* n, int32_t count, int w_bits, mn_stream_t stream);
 int mn_dorefa_w_bwd_multi(const float* const* g, const float* const* w, float* const* dw, float* const* ws, const int64_t* n, int32_t count, int w_bits,
                           mn_stream_t stream);
+/* the same with tanh(w) cached for the step (th[i]: n[i] floats per tensor, written by the forward): the backward takes the FORWARD's ws and th of the same
+ * weights and skips the absmax pass; bit-identical results */
+int mn_dorefa_w_fwd_multi_cached(const float* const* w, float* const* qw, float* const* ws, float* const* th, const int64_t* n, int32_t count, int w_bits,
+                                 mn_stream_t stream);
+int mn_dorefa_w_bwd_multi_cached(const float* const* g, const float* const* w, float* const* dw, float* const* ws, float* const* th, const int64_t* n,
+                                 int32_t count, int w_bits, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ WbWtAb
  * wbwtab/quantize.py */

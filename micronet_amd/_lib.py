@@ -141,6 +141,8 @@ PROTOTYPES = {
     "mn_tanh_f32": (_I, [_P, _P, _L, _P]),
     "mn_dorefa_w_fwd_multi": (_I, [_P, _P, _P, _P, C.c_int32, _I, _P]),
     "mn_dorefa_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, C.c_int32, _I, _P]),
+    "mn_dorefa_w_fwd_multi_cached": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "mn_dorefa_w_bwd_multi_cached": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "mn_adam_step": (_I, [C.POINTER(AdamTensor), _I, _I, C.c_float, C.c_float, C.c_float, _P]),
     "mn_adam_step_dev": (_I, [C.POINTER(AdamTensor), _I, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
     "mn_conv2d_ws_bytes": (_L, [_G, _I, _I]),

@@ -3,8 +3,7 @@
 //     y[n][o] = bias[o] + sum over c of Q_a(x[n][c]) * wq[o][c]
 // with the activation quantizer Q_a (DoReFa k-bit, IAO per-tensor, or none) evaluated in registers and its clip-STE applied to dx in the same launch.
 // N x C x O is tiny (256 x 512 x 10): three latency-bound launches of a few microseconds -- the generic kernels treat a linear layer as a 1 x 1 conv over
-// 1 x 1 images and ran this one on the direct VALU path (210 us forward).  One wave per sample row (forward, backward-data); one thread per input channel
-// with the output loop in registers (backward-weight, fixed summation order over n: deterministic).
+// 1 x 1 images and ran this one on the direct VALU path (210 us forward).  One wave per sample row (forward, backward-data); backward-weight: see k_qlin_bwd_weight.
 #include "common.h"
 
 #define QL_OMAX 16            // outputs per pass (larger O: several passes)
@@ -47,17 +46,20 @@ __global__ __launch_bounds__(256) void k_qlin_bwd_data(const Pro ste, const floa
         dx[i] = acc;
     }
 }
-// dw[o][c] = sum over n of gy[n][o] * Q_a(x[n][c]);  db[o] = sum over n of gy[n][o]
-__global__ __launch_bounds__(256) void k_qlin_bwd_weight(const Pro pro, const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
+// dw[o][c] = sum over n of gy[n][o] * Q_a(x[n][c]);  db[o] = sum over n of gy[n][o].  A block owns 64 input channels; its 512 threads are 8 groups that each sum
+// the samples n = group (mod 8) for their channel, the eight partial sums are then added in group order through LDS (fixed order: deterministic).
+#define QL_NG 8
+__global__ __launch_bounds__(512) void k_qlin_bwd_weight(const Pro pro, const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
                                                          int N, int C, int O) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[QL_NG][QL_OMAX + 1][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float sc = 1.f, zp = 0.f;
     if (pro.mode == MN_ACTQ_IAO) { sc = pro.qp[0]; zp = pro.qp[1]; }
     for (int o0 = 0; o0 < O; o0 += QL_OMAX) {
         float acc[QL_OMAX], bacc[QL_OMAX];
 #pragma unroll
         for (int k = 0; k < QL_OMAX; ++k) { acc[k] = 0.f; bacc[k] = 0.f; }
-        for (int n = 0; n < N; ++n) {
+        for (int n = grp; n < N; n += QL_NG) {
             const float q = c < C ? pro_apply(pro, x[(int64_t)n * C + c], sc, zp) : 0.f;
 #pragma unroll
             for (int k = 0; k < QL_OMAX; ++k)
@@ -67,11 +69,29 @@ __global__ __launch_bounds__(256) void k_qlin_bwd_weight(const Pro pro, const fl
                     bacc[k] += g;
                 }
         }
+        __syncthreads();                      // (the previous pass's reads of `red` are done)
 #pragma unroll
-        for (int k = 0; k < QL_OMAX; ++k) {
-            if (o0 + k >= O) break;
-            if (c < C) dw[(int64_t)(o0 + k) * C + c] = acc[k];
-            if (db && c == 0) db[o0 + k] = bacc[k];
+        for (int k = 0; k < QL_OMAX; ++k) red[grp][k][cl] = acc[k];
+        if (cl == 0) {
+#pragma unroll
+            for (int k = 0; k < QL_OMAX; ++k) red[grp][QL_OMAX][k] = bacc[k];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int k = 0; k < QL_OMAX; ++k) {
+                if (o0 + k >= O) break;
+                float a = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < QL_NG; ++g2) a += red[g2][k][cl];
+                if (c < C) dw[(int64_t)(o0 + k) * C + c] = a;
+            }
+            if (db && blockIdx.x == 0 && cl < QL_OMAX && o0 + cl < O) {
+                float a = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < QL_NG; ++g2) a += red[g2][QL_OMAX][cl];
+                db[o0 + cl] = a;
+            }
         }
     }
 }
@@ -107,7 +127,7 @@ extern "C" int mn_qlinear_bwd_weight(const mn_actq* aq, const float* gy, const f
     if (rc) return rc;
     if (pro.mode == MN_ACTQ_SIGN8 || pro.mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_qlinear_bwd_weight: fp32 activations only");
     mn_set_last_kernel("k_qlin_bwd_weight");
-    hipLaunchKernelGGL(k_qlin_bwd_weight, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pro, gy, x, dw, dbias, (int)N, (int)C, (int)O);
+    hipLaunchKernelGGL(k_qlin_bwd_weight, dim3((unsigned)((C + 63) / 64)), dim3(512), 0, (hipStream_t)stream, pro, gy, x, dw, dbias, (int)N, (int)C, (int)O);
     MN_CHECK_LAUNCH("mn_qlinear_bwd_weight");
     return MN_OK;
 }

@@ -25,6 +25,36 @@
 #define QD_WSTEP 8192          // bytes of packed weights per forward step (one tap x 64 input channels x 64 output channels)
 #define QDF_UPT 6              // staging units (4 channels x 4 pixels) per thread and chunk
 
+// Order of the staging units (channel quad q, image, patch row pr, row dword d) over the threads.  A unit writes 8 bytes (4 channels of one pixel) per pixel into
+// slot-major LDS images whose slot stride is 144 or 80 bytes: the bank pair of a write is (4 or 20) * slot + 2 q mod 32 = 16 (d & 1) + 8 (pr & 1) + 2 q + const.
+// The low four bits of the unit index are therefore (q & 3, d & 1, pr & 1) -- rows of one dword, W = 4: (q & 3, pr & 3) -- so that the 16 lanes of an LDS write
+// group fall on 16 distinct bank pairs (the plain row-major order put all of them on two: 8-way conflicts, 2-3 k cycles per chunk); the global loads still read
+// 64 contiguous bytes per channel plane and instruction.
+struct QdUnits { int mode, A, B, NI, PH, NQ, nunits; FastDiv fd_a, fd_b, fd_ni; };
+static QdUnits qd_make_units(int W4, int PH, int NI, int NQ) {
+    QdUnits u;
+    u.mode = W4 >= 2 ? 0 : 1; u.A = W4 >= 2 ? W4 / 2 : 1; u.B = W4 >= 2 ? (PH + 1) / 2 : (PH + 3) / 4; u.NI = NI; u.PH = PH; u.NQ = NQ;
+    u.nunits = 16 * u.A * u.B * NI * (NQ / 4);
+    u.fd_a = make_fastdiv((uint32_t)u.A); u.fd_b = make_fastdiv((uint32_t)u.B); u.fd_ni = make_fastdiv((uint32_t)NI);
+    return u;
+}
+__device__ __forceinline__ bool qd_unit(const QdUnits& m, int u, int& q, int& img, int& pr, int& d) {
+    const int ql = u & 3;
+    uint32_t r = (uint32_t)u >> 4;
+    int dl = 0, prl;
+    if (m.mode == 0) { dl = (u >> 2) & 1; prl = (u >> 3) & 1; } else prl = (u >> 2) & 3;
+    const uint32_t r1 = fd_div(r, m.fd_a);
+    const int dh = (int)r - (int)r1 * m.A;
+    const uint32_t r2 = fd_div(r1, m.fd_b);
+    const int prh = (int)r1 - (int)r2 * m.B;
+    const uint32_t qh = fd_div(r2, m.fd_ni);
+    img = (int)r2 - (int)qh * m.NI;
+    q = 4 * (int)qh + ql;
+    d = m.mode == 0 ? 2 * dh + dl : 0;
+    pr = m.mode == 0 ? 2 * prh + prl : 4 * prh + prl;
+    return u < m.nunits && pr < m.PH && q < m.NQ;
+}
+
 // ------------------------------------------------------------------------------------------------ weight codes in fragment order
 // orient 0 (forward):        [cot][chunk = c / 64][tap][ks = 0, 1][nf = 0..3][lane][e]: o = 64 cot + 16 nf + (lane & 15), c = 64 chunk + 32 ks + 8 (lane >> 4) + e
 // orient 1 (backward-data):  [cit][chunk = o / 32][tap][nf][lane][e]:                   c = 64 cit + 16 nf + (lane & 15), o = 32 chunk + 8 (lane >> 4) + e
@@ -69,33 +99,28 @@ struct QdfParams {
     int TH, NI, PH, PW, W4;       // output rows per tile and image, images per tile, patch rows / columns per image
     int tpi, ncot, nchunks, nitems, nunits, out32, wo_shift;
     FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_ncot, fd_tpi, fd_ipt;
+    QdUnits units;
 };
 
-template <int MF>
+template <int MF, int TPS>
 __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* wbuf = reinterpret_cast<unsigned char*>(smem);
-    unsigned char* patch = wbuf + 2 * QD_WSTEP;
+    unsigned char* patch = wbuf + TPS * QD_WSTEP;          // ONE weight buffer of TPS taps (a step = TPS taps x 64 input channels)
     const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
     if ((int)blockIdx.x >= p.nitems) return;
     {   // the frame columns (and anything staging never writes) stay zero for the whole kernel
         const int n16 = p.NI * p.PH * p.PW * (QD_RS / 16);
         for (int i = tid; i < n16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
     }
-    // staging roles: unit u = ((q * NI + img) * PH + pr) * W4 + d  ->  channels 4q .. 4q + 3, patch row pr of image img, input pixels 4d .. 4d + 3
+    // staging roles: a unit = channels 4q .. 4q + 3, patch row pr of image img, input pixels 4d .. 4d + 3 (order over the threads: QdUnits)
     int u_lds[QDF_UPT], u_goff[QDF_UPT], u_pi[QDF_UPT];
 #pragma unroll
     for (int i = 0; i < QDF_UPT; ++i) {
-        const int u = tid + 256 * i;
-        const uint32_t t0 = fd_div((uint32_t)u, p.fd_w4);
-        const int d = u - (int)t0 * p.W4;
-        const uint32_t t1 = fd_div(t0, p.fd_ph);
-        const int pr = (int)t0 - (int)t1 * p.PH;
-        const uint32_t q = fd_div(t1, p.fd_ni);
-        const int img = (int)t1 - (int)q * p.NI;
-        const bool v = u < p.nunits;
-        u_lds[i] = v ? ((img * p.PH + pr) * p.PW + 4 * d + p.PAD) * QD_RS + 8 * (int)q : -1;
-        u_goff[i] = v ? 4 * (int)q * p.HW + 4 * d : 0;
+        int q, img, pr, d;
+        const bool v = qd_unit(p.units, tid + 256 * i, q, img, pr, d);
+        u_lds[i] = v ? ((img * p.PH + pr) * p.PW + 4 * d + p.PAD) * QD_RS + 8 * q : -1;
+        u_goff[i] = v ? 4 * q * p.HW + 4 * d : 0;
         u_pi[i] = pr | (img << 8);
     }
     uint32_t preg[QDF_UPT][4];
@@ -137,28 +162,31 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
             }
         }
     };
-    // weights: the steps of an item read consecutive 8 KB blocks of the packed image; the block loads the weights of step + 2 while step is contracted
-    u32x4 wreg[2];
+    // weights: the steps of an item read consecutive TPS x 8 KB blocks of the packed image.  A step is long (TPS x 32 MFMAs per wave), so ONE LDS buffer is enough:
+    // barrier -> write this step's weights (loaded into registers during the previous step; at a chunk start also the chunk's patch) -> barrier -> issue the next
+    // step's loads -> contract.  Two barriers per step, no write / read overlap to manage, 24 KB instead of 2 x 8.
+    u32x4 wreg[2 * TPS];
     const int stride_items = (int)gridDim.x;
-    const int steps_item = p.nchunks * p.TAPS;
+    const int nsteps_chunk = p.TAPS / TPS;
+    const int steps_item = p.nchunks * nsteps_chunk;
     const int my_items = (p.nitems - (int)blockIdx.x + stride_items - 1) / stride_items;
     const int total_steps = my_items * steps_item;
     auto item_wbase = [&](int item) {
         const uint32_t tile = fd_div((uint32_t)item, p.fd_ncot);
         const int cot = item - (int)tile * p.ncot;
-        return reinterpret_cast<const unsigned char*>(p.wpk) + (int64_t)cot * steps_item * QD_WSTEP + tid * 16;
+        return reinterpret_cast<const unsigned char*>(p.wpk) + (int64_t)cot * p.nchunks * p.TAPS * QD_WSTEP + tid * 16;
     };
     const unsigned char* wsrc = item_wbase((int)blockIdx.x);      // source of the NEXT weight load
     int w_item = (int)blockIdx.x, w_left = steps_item;            // its item, steps left in that item
     auto fetch_w = [&]() {
-        wreg[0] = *reinterpret_cast<const u32x4*>(wsrc);
-        wreg[1] = *reinterpret_cast<const u32x4*>(wsrc + 4096);
-        wsrc += QD_WSTEP;
+#pragma unroll
+        for (int t = 0; t < 2 * TPS; ++t) wreg[t] = *reinterpret_cast<const u32x4*>(wsrc + t * 4096);
+        wsrc += TPS * QD_WSTEP;
         if (--w_left == 0) { w_item += stride_items; w_left = steps_item; if (w_item < p.nitems) wsrc = item_wbase(w_item); }
     };
-    auto commit_w = [&](int buf) {
-        *reinterpret_cast<u32x4*>(wbuf + buf * QD_WSTEP + tid * 16) = wreg[0];
-        *reinterpret_cast<u32x4*>(wbuf + buf * QD_WSTEP + 4096 + tid * 16) = wreg[1];
+    auto commit_w = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2 * TPS; ++t) *reinterpret_cast<u32x4*>(wbuf + t * 4096 + tid * 16) = wreg[t];
     };
     // A fragment bases: pixel tp = 16 MF wave + 16 mf + j of the tile -> the slot of its first tap
     int abase[MF];
@@ -172,12 +200,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
     }
     fetch_patch((int)blockIdx.x, 0);
     fetch_w();
-    __syncthreads();                          // the zero fill is complete
-    commit_patch();
-    commit_w(0);
-    if (total_steps > 1) fetch_w();           // wreg: the weights of step 1
-    __syncthreads();
-    int buf = 0, gs = 0;                      // gs: steps done by this block
+    int gs = 0;                               // steps done by this block
     for (int item = (int)blockIdx.x; item < p.nitems; item += stride_items) {
         f32x4 acc[MF][4];
 #pragma unroll
@@ -188,32 +211,36 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
             int nitem = item, nchunk = chunk + 1;
             if (nchunk == p.nchunks) { nchunk = 0; nitem += stride_items; }
             const bool have_next = nitem < p.nitems;
-            if (have_next) fetch_patch(nitem, nchunk);             // in flight during the chunk's nine steps
-            for (int tap = 0; tap < p.TAPS; ++tap) {
-                // invariant: wbuf[buf] holds this step's weights, wreg the next step's
-                if (gs + 1 < total_steps) commit_w(buf ^ 1);
-                if (gs + 2 < total_steps) fetch_w();
-                ++gs;
-                const int r = p.TAPS == 9 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0;
-                const int toff = (r * p.PW + (tap - 3 * r)) * QD_RS;
-                const unsigned char* wb = wbuf + buf * QD_WSTEP + lane * 16;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    u32x4 b[4], a[MF];
-#pragma unroll
-                    for (int nf = 0; nf < 4; ++nf) b[nf] = *reinterpret_cast<const u32x4*>(wb + (ks * 4 + nf) * 1024);
-#pragma unroll
-                    for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const u32x4*>(patch + abase[mf] + toff + ks * 64);
-#pragma unroll
-                    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = mn_mfma_bf16(a[mf], b[nf], acc[mf][nf]);
-                }
+            for (int st = 0; st < nsteps_chunk; ++st) {
+                __syncthreads();                                   // every wave is done with the previous step (and, at a chunk start, with the previous patch / the zero fill)
+                if (st == 0) commit_patch();
+                commit_w();
                 __syncthreads();
-                buf ^= 1;
+                if (gs + 1 < total_steps) fetch_w();               // the next step's weights: in flight during this step's MFMAs
+                if (st == 0 && have_next) fetch_patch(nitem, nchunk);
+                ++gs;
+#pragma unroll
+                for (int tis = 0; tis < TPS; ++tis) {
+                    const int tap = st * TPS + tis;
+                    const int r = TPS == 3 ? st : 0;
+                    const int toff = (r * p.PW + (tap - 3 * r)) * QD_RS;
+                    const unsigned char* wb = wbuf + tis * QD_WSTEP + lane * 16;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        u32x4 b[4], a[MF];
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf) b[nf] = *reinterpret_cast<const u32x4*>(wb + (ks * 4 + nf) * 1024);
+#pragma unroll
+                        for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const u32x4*>(patch + abase[mf] + toff + ks * 64);
+#pragma unroll
+                        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = mn_mfma_bf16(a[mf], b[nf], acc[mf][nf]);
+                    }
+                }
             }
-            if (chunk + 1 < p.nchunks) { commit_patch(); __syncthreads(); }       // (the last chunk: after the epilogue, which borrows the patch memory)
         }
+        __syncthreads();                      // the patch memory is idle: the epilogue borrows it
         // ---- epilogue.  D[row = pixel 4 kg + r][col = channel j].  The wave transposes its 16 MF pixels x 64 channels through its own piece of the (now idle)
         // patch memory -- rows [channel][16 MF pixels] padded by 8 bytes (conflict-free 8-byte writes) -- and stores 16 bytes per lane: a store instruction
         // writes whole contiguous rows of several channels (int16: 32 MF bytes per row; int32: two passes of 32 channels, 64 MF bytes per row).
@@ -280,9 +307,6 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
         if (item + stride_items < p.nitems) {
             __syncthreads();                  // every wave is done with its transposition scratch
             for (int i = tid; i < (4 * (MF * 2048 + 512)) / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};      // the zero frame again
-            __syncthreads();
-            commit_patch();                   // the next item's first chunk (fetched during this item's last chunk)
-            __syncthreads();
         }
     }
 }
@@ -346,9 +370,9 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
         const int PH = (TH - 1) * p.S + g->KH, PW = g->W + 2 * g->pad_w;          // staging writes whole input rows
         if (PH > 255 || NI > 255) continue;
         const int64_t patch = (int64_t)NI * PH * PW * QD_RS;
-        const int nunits = NI * PH * (g->W / 4) * 16;
-        if (patch > 60 * 1024 || nunits > 256 * QDF_UPT || patch < 4 * (mf * 2048 + 512)) continue;      // (the epilogue borrows the patch memory)
-        MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.nunits = nunits;
+        const QdUnits units = qd_make_units(g->W / 4, PH, NI, 16);
+        if (patch > 56 * 1024 || units.nunits > 256 * QDF_UPT || patch < 4 * (mf * 2048 + 512)) continue;      // (the epilogue borrows the patch memory)
+        MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.nunits = units.nunits; p.units = units;
         break;
     }
     if (!MF) return 0;
@@ -364,7 +388,7 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
     int tgt = 512;
     if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }     // tuning knob
     pl->grid = p.nitems < tgt ? p.nitems : tgt;
-    pl->lds = (size_t)2 * QD_WSTEP + (size_t)p.NI * p.PH * p.PW * QD_RS;
+    pl->lds = (size_t)(p.TAPS == 9 ? 3 : 1) * QD_WSTEP + (size_t)p.NI * p.PH * p.PW * QD_RS;
     // workspace: packed weights | statistics partials [S][O][2] doubles | per-channel weight scale [O]
     const int64_t pack_bytes = ((int64_t)g->O * g->C * p.TAPS * 2 + 255) / 256 * 256;
     int S = (2048 + g->O - 1) / g->O;
@@ -407,12 +431,18 @@ int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a
     uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
     qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 0, s);
     p.x = x; p.wpk = wpk; p.stash = stash;
-    mn_set_last_kernel("k_qd_fwd<%d>", pl.MF);
+    mn_set_last_kernel("k_qd_fwd<%d, %d>", pl.MF, p.TAPS == 9 ? 3 : 1);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
-    if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4>, pl.lds); hipLaunchKernelGGL(k_qd_fwd<4>, dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2>, pl.lds); hipLaunchKernelGGL(k_qd_fwd<2>, dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    else { raise_lds_limit((const void*)k_qd_fwd<1>, pl.lds); hipLaunchKernelGGL(k_qd_fwd<1>, dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    if (p.TAPS == 9) {
+        if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<4, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+        else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<2, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+        else { raise_lds_limit((const void*)k_qd_fwd<1, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<1, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    } else {
+        if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<4, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+        else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<2, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+        else { raise_lds_limit((const void*)k_qd_fwd<1, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<1, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    }
     mn_prof_end(s);
     double* part = reinterpret_cast<double*>((char*)ws + pl.off_part);
     const dim3 sgrid((unsigned)g->O, (unsigned)pl.S_stats);
@@ -446,6 +476,7 @@ struct QddParams {
     int TH, NI, PH, PW, W4, TS;   // TS: bytes per term plane
     int tpi, ncit, nchunks, nitems, nunits, w_shift;
     FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_ncit, fd_tpi;
+    QdUnits units;
 };
 
 template <int MF, int S, int TAPS>
@@ -457,20 +488,14 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
     constexpr int TPS = TAPS == 9 ? 3 : 1, NSTEP = TAPS == 9 ? 3 : 1;
     if ((int)blockIdx.x >= p.nitems) return;
     for (int i = tid; i < (3 * p.TS) / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
-    // staging roles: unit u = ((q * NI + img) * PH + pr) * W4 + d  ->  output channels 4q .. 4q + 3 of the chunk, patch row pr, pixels 4d .. 4d + 3
+    // staging roles: a unit = output channels 4q .. 4q + 3 of the chunk, patch row pr of image img, pixels 4d .. 4d + 3 (order over the threads: QdUnits)
     int u_lds[QDD_UPT], u_goff[QDD_UPT], u_pi[QDD_UPT];
 #pragma unroll
     for (int i = 0; i < QDD_UPT; ++i) {
-        const int u = tid + 256 * i;
-        const uint32_t t0 = fd_div((uint32_t)u, p.fd_w4);
-        const int d = u - (int)t0 * p.W4;
-        const uint32_t t1 = fd_div(t0, p.fd_ph);
-        const int pr = (int)t0 - (int)t1 * p.PH;
-        const uint32_t q = fd_div(t1, p.fd_ni);
-        const int img = (int)t1 - (int)q * p.NI;
-        const bool v = u < p.nunits;
-        u_lds[i] = v ? ((img * p.PH + pr) * p.PW + 4 * d + 1) * QDD_RS + 8 * (int)q : -1;
-        u_goff[i] = v ? 4 * (int)q * p.HWg + 4 * d : 0;
+        int q, img, pr, d;
+        const bool v = qd_unit(p.units, tid + 256 * i, q, img, pr, d);
+        u_lds[i] = v ? ((img * p.PH + pr) * p.PW + 4 * d + 1) * QDD_RS + 8 * q : -1;
+        u_goff[i] = v ? 4 * q * p.HWg + 4 * d : 0;
         u_pi[i] = pr | (img << 8);
     }
     float4 preg[QDD_UPT][4];
@@ -667,9 +692,9 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
         const int PH = TH + 2, PW = p.Wg + 2;
         if (PH > 255 || NI > 255) continue;
         const int64_t plane = ((int64_t)NI * PH * PW * QDD_RS + 255) / 256 * 256;
-        const int nunits = NI * PH * (p.Wg / 4) * 8;
-        if (3 * plane > 54 * 1024 || nunits > 256 * QDD_UPT) continue;
-        MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.TS = (int)plane; p.nunits = nunits;
+        const QdUnits units = qd_make_units(p.Wg / 4, PH, NI, 8);
+        if (3 * plane > 54 * 1024 || units.nunits > 256 * QDD_UPT) continue;
+        MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.TS = (int)plane; p.nunits = units.nunits; p.units = units;
         break;
     }
     if (!MF) return 0;

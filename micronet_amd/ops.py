@@ -171,8 +171,9 @@ class DorefaWeight(Function):
 
 
 class MultiDorefaWeight(Function):
-    """DorefaWeight over several weight tensors in ONE launch per phase (mn_dorefa_w_fwd_multi / _bwd_multi: 2 launches forward, 3 backward for the
-    whole net instead of per layer).  Same arithmetic per tensor: bit-identical to the per-layer calls."""
+    """DorefaWeight over several weight tensors in ONE launch per phase (mn_dorefa_w_fwd/bwd_multi_cached: 2 launches forward, 2 backward for the whole net
+    instead of 5 per layer), with tanh(w) -- an fp64 evaluation, see quant_kernels.hip -- computed once per step and cached.  Same arithmetic per tensor:
+    bit-identical to the per-layer calls."""
 
     @staticmethod
     def forward(ctx, bits, *ws):
@@ -181,30 +182,29 @@ class MultiDorefaWeight(Function):
         lib = _lib_()
         qws = [torch.empty_like(w) for w in ws]
         scratch = [torch.empty(int(lib.mn_dorefa_w_ws_floats(w.numel())), dtype=torch.float32, device=w.device) for w in ws]
+        th = [torch.empty(w.numel(), dtype=torch.float32, device=w.device) for w in ws]
         PA, LA = C.c_void_p * n, C.c_int64 * n
         with torch.cuda.device_of(ws[0]):
-            _call("mn_dorefa_w_fwd_multi", PA(*[w.data_ptr() for w in ws]), PA(*[q.data_ptr() for q in qws]), PA(*[t.data_ptr() for t in scratch]),
-                  LA(*[w.numel() for w in ws]), n, bits, _s())
-        ctx.save_for_backward(*ws)
+            _call("mn_dorefa_w_fwd_multi_cached", PA(*[w.data_ptr() for w in ws]), PA(*[q.data_ptr() for q in qws]), PA(*[t.data_ptr() for t in scratch]),
+                  PA(*[t.data_ptr() for t in th]), LA(*[w.numel() for w in ws]), n, bits, _s())
+        ctx.save_for_backward(*ws, *scratch, *th)
         ctx.bits, ctx.n = bits, n
         return tuple(qws)
 
     @staticmethod
     def backward(ctx, *gs):
         n, bits = ctx.n, ctx.bits
-        ws = ctx.saved_tensors
+        ws, scratch, th = ctx.saved_tensors[:n], ctx.saved_tensors[n:2 * n], ctx.saved_tensors[2 * n:]
         idx = [i for i in range(n) if gs[i] is not None]
         dws = [None] * n
         if idx:
-            lib = _lib_()
             g = [_chk(gs[i], "grad") for i in idx]
             out = [torch.empty_like(ws[i]) for i in idx]
-            scratch = [torch.empty(int(lib.mn_dorefa_w_ws_floats(ws[i].numel())), dtype=torch.float32, device=ws[i].device) for i in idx]
             m = len(idx)
             PA, LA = C.c_void_p * m, C.c_int64 * m
             with torch.cuda.device_of(ws[0]):
-                _call("mn_dorefa_w_bwd_multi", PA(*[t.data_ptr() for t in g]), PA(*[ws[i].data_ptr() for i in idx]), PA(*[t.data_ptr() for t in out]),
-                      PA(*[t.data_ptr() for t in scratch]), LA(*[ws[i].numel() for i in idx]), m, bits, _s())
+                _call("mn_dorefa_w_bwd_multi_cached", PA(*[t.data_ptr() for t in g]), PA(*[ws[i].data_ptr() for i in idx]), PA(*[t.data_ptr() for t in out]),
+                      PA(*[scratch[i].data_ptr() for i in idx]), PA(*[th[i].data_ptr() for i in idx]), LA(*[ws[i].numel() for i in idx]), m, bits, _s())
             for k, i in enumerate(idx):
                 dws[i] = out[k]
         return (None,) + tuple(dws)

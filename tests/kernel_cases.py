@@ -1013,3 +1013,190 @@ def check_qa_thresholds(be, bits=2, pool=False, seed=0):
     be.call("mn_qa_fwd", 0, be.ptr(dS), be.ptr(dC), N, Cc, H, W, bits, int(pool), be.ptr(out), None, be.stream)
     got = be.to_host(out).astype(np.int64)
     assert np.array_equal(got, ref), (bits, pool, np.argwhere(got != ref)[:5])
+
+
+# ----------------------------------------------------------------------------- dense layers on activation codes (qgemm_dense.hip): the ResNet family
+def check_qdense(be, x_shape, Oc, k=3, stride=1, a_bits=2, w_bits=2, seed=0):
+    """mn_qconv_bnq_fwd_stash / mn_conv2d_bwd_data / mn_conv2d_bwd_weight on activation codes for a DENSE layer (groups = 1, C and O multiples of 64; 3x3 stride 1 / 2,
+    1x1 stride 2: models/resnet.py:7-65 under wqaq/dorefa/quantize.py:107-122): the stash (16 or 32 bits by mn_qconv_bnq_stash_bits) equals the exact integer conv,
+    the batch statistics follow, and both gradients agree with an fp64 evaluation of torch's conv backward to the float-accumulate tolerance."""
+    import torch
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    pad = 1 if k == 3 else 0
+    w_shape = (Oc, Cin, k, k)
+    na, nw = 2 ** a_bits - 1, 2 ** w_bits - 1
+    codes = r.integers(0, na + 1, size=x_shape).astype(np.uint8)
+    kw_ = r.integers(0, nw + 1, size=w_shape)
+    wcode = (2 * kw_ - nw).astype(np.float64)
+    w = (F(2.0) * (kw_.astype(F) * F(1.0 / nw)) - F(1.0)).astype(F)
+    g = be.geom(x_shape, w_shape, stride=stride, padding=pad)
+    wq = be.wq(mode=2, bits=w_bits)
+    assert be.lib.mn_qconv_bnq_supported(C.byref(g), C.byref(wq), a_bits) == 1, "dense layer not supported"
+    sb = int(be.lib.mn_qconv_bnq_stash_bits(C.byref(g), C.byref(wq), a_bits))
+    assert sb == (32 if Cin * k * k * na * nw > 32767 else 16)
+    acc = torch.nn.functional.conv2d(torch.from_numpy(codes.astype(np.float64)), torch.from_numpy(wcode), None, stride, pad).numpy()
+    Ho, Wo = acc.shape[2:]
+    nb = int(be.lib.mn_qconv_bnq_ws_bytes(C.byref(g)))
+    ws = be.empty(nb // 4 + 8)
+    dX, dW = be.to_dev_u8(codes), be.to_dev(w)
+    gamma, beta = (r.standard_normal(Oc) * 0.5 + 1).astype(F), (r.standard_normal(Oc) * 0.3).astype(F)
+    rm, rv = be.to_dev(np.zeros(Oc)), be.to_dev(np.ones(Oc))
+    save, chan = be.empty((2, Oc)), be.empty((9, Oc))
+    stash = be.empty_i8((N, Oc, Ho, Wo * (sb // 8)))
+    nbt = be.to_dev_i64([0])
+    be.call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dX), a_bits, be.ptr(dW), None, be.ptr(be.to_dev(gamma)), be.ptr(be.to_dev(beta)), 1e-5, 0.1, 1,
+            be.ptr(rm), be.ptr(rv), be.ptr(nbt), be.ptr(save), be.ptr(stash), be.ptr(chan), be.ptr(ws), nb, be.stream)
+    st = be.to_host(stash).view(np.int16 if sb == 16 else np.int32).reshape(N, Oc, Ho, Wo)
+    assert np.array_equal(st.astype(np.float64), acc), "stash != exact integer conv result"
+    alpha = float(F(F(1.0 / nw) * F(1.0 / na)))
+    ye = acc * alpha
+    sv = be.to_host(save)
+    assert np.max(np.abs(sv[0] - ye.mean(axis=(0, 2, 3)))) <= 2e-6 * max(np.abs(ye.mean(axis=(0, 2, 3))).max(), 1e-3) + 1e-7, "mean"
+    assert np.max(np.abs(sv[1] * np.sqrt(ye.var(axis=(0, 2, 3)) + 1e-5) - 1)) <= 5e-6, "invstd"
+    assert int(be.to_host(nbt)[0]) == 1
+    gy = r.standard_normal((N, Oc, Ho, Wo)).astype(F)
+    dGY = be.to_dev(gy)
+    aq = be.actq(4, a_bits)
+    tx = torch.from_numpy(codes.astype(np.float64) / na).requires_grad_(True)
+    tw = torch.from_numpy(w.astype(np.float64)).requires_grad_(True)
+    torch.nn.functional.conv2d(tx, tw, None, stride, pad).backward(torch.from_numpy(gy.astype(np.float64)))
+    dx = be.empty(x_shape)
+    nb1 = int(be.lib.mn_conv2d_ws_bytes(C.byref(g), 1, 0))
+    ws1 = be.empty(nb1 // 4 + 8)
+    be.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq), be.ptr(dGY), be.ptr(dW), None, be.ptr(dx), be.ptr(ws1), nb1, 0, be.stream)
+    assert be.lib.mn_last_kernel().decode().startswith("k_qd_dgrad"), be.lib.mn_last_kernel()
+    assert close(be.to_host(dx), tx.grad.numpy(), 1e-5), "dx"
+    dw = be.empty(w_shape)
+    nb2 = int(be.lib.mn_conv2d_ws_bytes(C.byref(g), 2, 0))
+    ws2 = be.empty(nb2 // 4 + 8)
+    be.call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), be.ptr(dGY), be.ptr(dX), be.ptr(dw), None, be.ptr(ws2), nb2, 0, be.stream)
+    assert be.lib.mn_last_kernel().decode().startswith("k_qd_wgrad"), be.lib.mn_last_kernel()
+    assert close(be.to_host(dw), tw.grad.numpy(), 1e-5), "dw"
+
+
+# (x shape, O, k, stride): small enough for the CPU emulator; every tile shape of the planners (W = 4 .. 32, images per tile > 1 with N not a multiple, several chunks,
+# several output / input channel tiles, stride 2, the 1x1 shortcut, the 32-bit stash)
+QDENSE_CASES = [
+    ((2, 64, 8, 8), 64, 3, 1), ((3, 128, 4, 4), 64, 3, 1), ((1, 64, 16, 16), 128, 3, 1), ((1, 64, 8, 32), 64, 3, 1), ((5, 128, 8, 8), 128, 3, 2),
+    ((1, 64, 32, 32), 64, 3, 2), ((2, 64, 16, 16), 128, 1, 2), ((2, 128, 8, 8), 64, 1, 2), ((1, 512, 4, 4), 64, 3, 1),
+]
+
+
+def check_qr(be, shape=(3, 6, 4, 8), in_kind=0, res_kind=1, bits=2, training=True, with_dq2=False, with_gf=True, seed=0):
+    """mn_qr_fwd / mn_qr_bwd_sums / mn_qr_bwd_apply -- the end of a residual block: u = bn(y) + res, a = relu(u) -> codes + fp32; backward through the ReLU, the
+    clip-STE of the code readers and both BatchNorms -- vs a numpy evaluation of the same fp32 chain (models/resnet.py:60-65, wqaq/dorefa/quantize.py:36-46)."""
+    r = np.random.default_rng(seed)
+    N, Cc, H, W = shape
+    n = N * H * W
+    s_o = F(1.0 / (2 ** bits - 1))
+
+    def make_branch(kind):          # kind 0 / 2: integer stash (int16 / int32) with chan constants; 1: fp32
+        if kind == 1:
+            y = (r.standard_normal(shape) * 2).astype(F)
+            alpha, bias = np.ones(Cc, F), np.zeros(Cc, F)
+            raw = y
+        else:
+            raw = r.integers(-300, 300, size=shape).astype(np.int32)
+            alpha, bias = (np.abs(r.standard_normal(Cc)) * 0.01 + 0.005).astype(F), (r.standard_normal(Cc) * 0.1).astype(F)
+            y = (raw.astype(F) * alpha.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)).astype(F)
+        mean, inv = y.mean(axis=(0, 2, 3)).astype(F), (F(1.0) / np.sqrt(y.var(axis=(0, 2, 3)).astype(F) + F(1e-5))).astype(F)
+        ga, be_ = (r.standard_normal(Cc) * 0.5 + 1).astype(F), (r.standard_normal(Cc) * 0.3).astype(F)
+        chan = np.stack([alpha, bias, mean, inv, ga, be_, (alpha * inv).astype(F), ((bias - mean) * inv).astype(F), (ga * inv).astype(F)]).astype(F)
+        zh = ((y - mean.reshape(1, -1, 1, 1)) * inv.reshape(1, -1, 1, 1)).astype(F)
+        z = (zh * ga.reshape(1, -1, 1, 1) + be_.reshape(1, -1, 1, 1)).astype(F)
+        dev = be.to_dev(raw) if kind == 1 else (be.to_dev_i16(raw.astype(np.int16)) if kind == 0 else _to_dev_i32(be, raw))
+        return dev, be.to_dev(chan), zh, z, (ga * inv).astype(np.float64)
+
+    src, chan, zh, z, gi = make_branch(in_kind)
+    res_dev = res_chan = None
+    zhs = gis = None
+    if res_kind == 1:
+        res = np.maximum(r.standard_normal(shape), 0).astype(F)
+        res_dev = be.to_dev(res)
+        u = (z + res).astype(F)
+    elif res_kind >= 2:
+        res_dev, res_chan, zhs, zs, gis = make_branch(0 if res_kind == 2 else 2)
+        u = (z + zs).astype(F)
+    else:
+        u = z
+    a = np.maximum(u, F(0)).astype(F)
+    codes, act = be.empty_i8(shape), be.empty(shape)
+    be.call("mn_qr_fwd", in_kind, be.ptr(src), be.ptr(chan), res_kind, be.ptr(res_dev), be.ptr(res_chan), N, Cc, H, W, bits, be.ptr(codes), be.ptr(act), be.stream)
+    assert np.array_equal(be.to_host(act), a), "activation"
+    c_ref = np.floor(np.abs(np.clip(a * F(0.1), 0, 1).astype(F) / s_o) + F(0.5))
+    assert np.array_equal(be.to_host(codes).view(np.uint8).astype(np.float64), c_ref.astype(np.float64)), "codes"
+    # backward
+    dq = r.standard_normal(shape).astype(F)
+    dq2 = r.standard_normal(shape).astype(F) if with_dq2 else None
+    gf = r.standard_normal(shape).astype(F) if with_gf else None
+
+    def ste(gq):
+        t_ = a * F(0.1)
+        d_ = ((gq * s_o) / s_o).astype(F)
+        return (np.where((t_ >= 0) & (t_ <= 1), d_, F(0)) * F(0.1)).astype(F)
+    da = ste(dq)
+    if dq2 is not None:
+        da = (da + ste(dq2)).astype(F)
+    if gf is not None:
+        da = (da + gf).astype(F)
+    du_ref = np.where(u > 0, da, F(0)).astype(F)
+    d64 = du_ref.astype(np.float64)
+    s1, s2 = d64.sum(axis=(0, 2, 3)), (d64 * zh.astype(np.float64)).sum(axis=(0, 2, 3))
+    du, dy, dys = be.empty(shape), be.empty(shape), (be.empty(shape) if res_kind >= 2 else None)
+    dgam, dbet, sums = be.empty(Cc), be.empty(Cc), be.empty((2, Cc))
+    dgam_s, dbet_s, sums_s = (be.empty(Cc), be.empty(Cc), be.empty((2, Cc))) if res_kind >= 2 else (None, None, None)
+    ws = be.empty(int(be.lib.mn_qr_ws_floats(Cc)))
+    be.call("mn_qr_bwd_sums", in_kind, be.ptr(src), be.ptr(chan), res_kind, be.ptr(res_dev), be.ptr(res_chan), be.ptr(be.to_dev(dq)), be.ptr(be.to_dev(dq2) if dq2 is not None else None),
+            be.ptr(be.to_dev(gf) if gf is not None else None), N, Cc, H, W, bits, be.ptr(du), be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(dgam_s), be.ptr(dbet_s),
+            be.ptr(sums_s), be.ptr(ws), be.stream)
+    assert np.array_equal(be.to_host(du), du_ref), "du"
+    sc = max(np.max(np.abs(d64)) * np.sqrt(n), 1e-30)
+    assert np.max(np.abs(be.to_host(dbet) - s1)) <= 2e-6 * sc and np.max(np.abs(be.to_host(dgam) - s2)) <= 2e-6 * sc * max(1.0, np.abs(zh).max()), "dgamma / dbeta"
+    be.call("mn_qr_bwd_apply", in_kind, be.ptr(src), be.ptr(chan), be.ptr(sums), res_kind, be.ptr(res_dev), be.ptr(res_chan), be.ptr(sums_s), be.ptr(du), N, Cc, H, W,
+            int(training), be.ptr(dy), be.ptr(dys), be.stream)
+    k1, k2 = (s1 / n, s2 / n) if training else (np.zeros(Cc), np.zeros(Cc))
+    dy_ref = gi.reshape(1, -1, 1, 1) * (d64 - k1.reshape(1, -1, 1, 1) - zh.astype(np.float64) * k2.reshape(1, -1, 1, 1))
+    assert close(be.to_host(dy), dy_ref, 1e-5), "dy"
+    if res_kind >= 2:
+        s3 = (d64 * zhs.astype(np.float64)).sum(axis=(0, 2, 3))
+        assert np.max(np.abs(be.to_host(dgam_s) - s3)) <= 2e-6 * sc * max(1.0, np.abs(zhs).max()) and np.max(np.abs(be.to_host(dbet_s) - s1)) <= 2e-6 * sc, "shortcut dgamma / dbeta"
+        k2s = s3 / n if training else np.zeros(Cc)
+        dys_ref = gis.reshape(1, -1, 1, 1) * (d64 - k1.reshape(1, -1, 1, 1) - zhs.astype(np.float64) * k2s.reshape(1, -1, 1, 1))
+        assert close(be.to_host(dys), dys_ref, 1e-5), "dy of the shortcut conv"
+
+
+def _to_dev_i32(be, a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if be.kind == "emu":
+        return a.copy()
+    return be.torch.from_numpy(a.copy()).cuda()
+
+
+def check_qlinear(be, N=5, Cc=70, Oc=10, mode=1, bits=2, bias=True, seed=0):
+    """mn_qlinear_fwd / _bwd_data / _bwd_weight (the ResNet classifier, wqaq/dorefa/quantize.py:192-199 / wqaq/iao/quantize.py:1150-1157) vs numpy; mode 0 none, 1 DoReFa, 2 IAO."""
+    r = np.random.default_rng(seed)
+    x = (r.standard_normal((N, Cc)) * 4).astype(F)
+    w = (r.standard_normal((Oc, Cc)) * 0.3).astype(F)
+    b = (r.standard_normal(Oc) * 0.2).astype(F) if bias else None
+    gy = r.standard_normal((N, Oc)).astype(F)
+    qp = None
+    if mode == 2:
+        qp_np = np.array([0.11, 0.0, -8.0, 7.0], dtype=F)
+        qp = be.to_dev(qp_np)
+    aq = be.actq(mode, bits, 0, qp)
+    xq = _quant_x(x, mode, bits, qp_np if mode == 2 else None, 0)
+    y = be.empty((N, Oc))
+    dX, dW, dG = be.to_dev(x), be.to_dev(w), be.to_dev(gy)
+    be.call("mn_qlinear_fwd", C.byref(aq), be.ptr(dX), be.ptr(dW), be.ptr(be.to_dev(b) if bias else None), be.ptr(y), N, Cc, Oc, be.stream)
+    y_ref = xq.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    assert close(be.to_host(y), y_ref, 1e-5), "y"
+    dx = be.empty((N, Cc))
+    be.call("mn_qlinear_bwd_data", C.byref(aq), be.ptr(dG), be.ptr(dW), be.ptr(dX), be.ptr(dx), N, Cc, Oc, be.stream)
+    dx_ref = _ste((gy.astype(np.float64) @ w.astype(np.float64)).astype(F), x, mode, bits, qp_np if mode == 2 else None, 0)
+    assert close(be.to_host(dx), dx_ref, 1e-5), "dx"
+    dw, db = be.empty((Oc, Cc)), (be.empty(Oc) if bias else None)
+    be.call("mn_qlinear_bwd_weight", C.byref(aq), be.ptr(dG), be.ptr(dX), be.ptr(dw), be.ptr(db), N, Cc, Oc, be.stream)
+    assert close(be.to_host(dw), gy.astype(np.float64).T @ xq.astype(np.float64), 1e-5), "dw"
+    if bias:
+        assert close(be.to_host(db), gy.astype(np.float64).sum(axis=0), 1e-5), "db"

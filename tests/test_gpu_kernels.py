@@ -478,6 +478,17 @@ def test_dorefa_weight_quantizer_multi_bit_identical(be):
         torch.cuda.synchronize()
         for a, b in zip(single_q + single_d, qs + ds):
             assert torch.equal(a, b)
+        # the variant the modules use: the forward keeps tanh(w) and its scratch, the backward reuses them (two launches instead of four)
+        qc, dc = [torch.empty_like(w) for w in ws], [torch.empty_like(w) for w in ws]
+        ths = [torch.empty_like(w) for w in ws]
+        sc2 = [torch.empty(int(lib.mn_dorefa_w_ws_floats(w.numel())), device="cuda") for w in ws]
+        be.call("mn_dorefa_w_fwd_multi_cached", PA(*[w.data_ptr() for w in ws]), PA(*[q.data_ptr() for q in qc]), PA(*[t.data_ptr() for t in sc2]),
+                PA(*[t.data_ptr() for t in ths]), LA(*[w.numel() for w in ws]), n, bits, be.stream)
+        be.call("mn_dorefa_w_bwd_multi_cached", PA(*[g.data_ptr() for g in gs]), PA(*[w.data_ptr() for w in ws]), PA(*[d.data_ptr() for d in dc]),
+                PA(*[t.data_ptr() for t in sc2]), PA(*[t.data_ptr() for t in ths]), LA(*[w.numel() for w in ws]), n, bits, be.stream)
+        torch.cuda.synchronize()
+        for a, b in zip(single_q + single_d, qc + dc):
+            assert torch.equal(a, b)
 
 
 def test_dorefa_tanh_pinned(be):
@@ -543,3 +554,37 @@ def test_qa_activation_code_bit_exact_at_boundaries(be, bits):
 @pytest.mark.parametrize("bits,pool", [(2, False), (2, True), (3, False), (3, True), (4, False)])
 def test_qa_forward_integer_thresholds(be, bits, pool):
     K.check_qa_thresholds(be, bits=bits, pool=pool, seed=bits)
+
+
+# ---- dense layers on activation codes (the ResNet family): qgemm_dense.hip
+@pytest.mark.parametrize("case", range(len(K.QDENSE_CASES)))
+def test_qdense_layer(be, case):
+    xs, Oc, k, s = K.QDENSE_CASES[case]
+    K.check_qdense(be, xs, Oc, k, s, seed=300 + case)
+
+
+def test_qdense_layer_wide_codes(be):
+    K.check_qdense(be, (2, 64, 8, 8), 64, 3, 1, a_bits=4, w_bits=4, seed=320)
+    K.check_qdense(be, (3, 128, 16, 16), 128, 3, 2, a_bits=4, w_bits=4, seed=321)     # 32-bit stash at stride 2
+
+
+# every layer shape of the reference's resnet18 on CIFAR (models/resnet.py:69-112) at a batch that leaves partial tiles
+@pytest.mark.parametrize("xs,Oc,k,s", [
+    ((37, 64, 32, 32), 64, 3, 1), ((37, 64, 32, 32), 128, 3, 2), ((37, 64, 32, 32), 128, 1, 2), ((37, 128, 16, 16), 128, 3, 1), ((37, 128, 16, 16), 256, 3, 2),
+    ((37, 128, 16, 16), 256, 1, 2), ((37, 256, 8, 8), 256, 3, 1), ((37, 256, 8, 8), 512, 3, 2), ((37, 256, 8, 8), 512, 1, 2), ((37, 512, 4, 4), 512, 3, 1)])
+def test_qdense_resnet18_shapes(be, xs, Oc, k, s):
+    K.check_qdense(be, xs, Oc, k, s, seed=hash((xs, Oc, k, s)) % 1000)
+
+
+@pytest.mark.parametrize("in_kind,res_kind", [(0, 1), (0, 2), (2, 3), (1, 1), (0, 0), (2, 1), (0, 3), (2, 2)])
+@pytest.mark.parametrize("training", [True, False])
+def test_residual_block_end(be, in_kind, res_kind, training):
+    K.check_qr(be, in_kind=in_kind, res_kind=res_kind, training=training, with_dq2=(res_kind != 1), with_gf=(res_kind != 0), seed=330 + in_kind * 4 + res_kind)
+    K.check_qr(be, shape=(33, 64, 16, 16), in_kind=in_kind, res_kind=res_kind, bits=4, training=training, with_dq2=True, with_gf=False, seed=350)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_qlinear(be, mode):
+    K.check_qlinear(be, mode=mode, seed=360 + mode)
+    K.check_qlinear(be, N=256, Cc=512, Oc=10, mode=mode, bits=4, bias=False, seed=365 + mode)
+    K.check_qlinear(be, N=3, Cc=64, Oc=64, mode=mode, seed=370 + mode)

@@ -133,3 +133,23 @@ def test_wbwtab_prepare_packs_activations_by_default():
     q2 = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=3, packed_activations=False)
     assert not any(m.packed for m in q2.modules() if isinstance(m, quantize.BatchNorm2dBinAct))
     assert not any(isinstance(m, quantize.MaxPool2dSign) for m in q2.modules())
+
+
+def test_dorefa_prepare_fuses_resnet_basic_blocks():
+    """prepare() on the reference's resnet18 (models/resnet.py:7-65, 69-112): every BasicBlock becomes a fused subclass of ITS class (isinstance and state_dict
+    unchanged), told what its consumer reads -- codes of the next block's quantizer, fp32 only for an identity shortcut -- and fuse_blocks=False leaves them alone."""
+    from micronet.compression.quantization.wqaq.dorefa import quantize
+    from micronet_amd.models.resnet import BasicBlock
+    q = quantize.prepare(build_model("resnet18"), inplace=True, a_bits=2, w_bits=2)
+    blocks = [m for m in q.modules() if isinstance(m, BasicBlock)]
+    assert len(blocks) == 8 and all(type(b).__name__ == "FusedBasicBlock" and isinstance(b, quantize._FusedBasicBlockMixin) for b in blocks)
+    assert [b._mn_out_bits for b in blocks] == [2] * 7 + [0]
+    # fp32 copy wanted exactly when the NEXT block adds its input back (identity shortcut); the last block feeds the pool / classifier in fp32
+    assert [b._mn_out_f32 for b in blocks] == [True, False, True, False, True, False, True, True]
+    assert q.conv1[1].q_out_bits == 2 and q.conv1[1].q_also_f32 is True
+    plain = quantize.prepare(build_model("resnet18"), inplace=True, a_bits=2, w_bits=2, fuse_blocks=False)
+    assert not any(isinstance(m, quantize._FusedBasicBlockMixin) for m in plain.modules())
+    assert list(plain.state_dict()) == list(q.state_dict())
+    # 8-bit activations do not fit the code path's exact-integer range for these layer widths: blocks stay unfused
+    q8 = quantize.prepare(build_model("resnet18"), inplace=True, a_bits=8, w_bits=8)
+    assert not any(isinstance(m, quantize._FusedBasicBlockMixin) for m in q8.modules())

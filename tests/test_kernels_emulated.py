@@ -336,3 +336,56 @@ def test_qa_activation_code_bit_exact_at_boundaries(be, bits):
 @pytest.mark.parametrize("bits,pool", [(2, False), (2, True), (3, False), (3, True), (4, False)])
 def test_qa_forward_integer_thresholds(be, bits, pool):
     K.check_qa_thresholds(be, bits=bits, pool=pool, seed=bits)
+
+
+# ---- dense layers on activation codes (the ResNet family): qgemm_dense.hip
+@pytest.mark.parametrize("case", range(len(K.QDENSE_CASES)))
+def test_qdense_layer(be, case):
+    xs, Oc, k, s = K.QDENSE_CASES[case]
+    K.check_qdense(be, xs, Oc, k, s, seed=300 + case)
+
+
+def test_qdense_layer_wide_codes(be):
+    """4-bit activations x 4-bit weights: the accumulator leaves int16 -> 32-bit stash."""
+    K.check_qdense(be, (2, 64, 8, 8), 64, 3, 1, a_bits=4, w_bits=4, seed=320)
+
+
+@pytest.mark.parametrize("in_kind,res_kind", [(0, 1), (0, 2), (2, 3), (1, 1), (0, 0), (2, 1)])
+@pytest.mark.parametrize("training", [True, False])
+def test_residual_block_end(be, in_kind, res_kind, training):
+    K.check_qr(be, in_kind=in_kind, res_kind=res_kind, training=training, with_dq2=(res_kind != 1), with_gf=(res_kind != 0), seed=330 + in_kind * 4 + res_kind)
+    K.check_qr(be, shape=(2, 3, 2, 4), in_kind=in_kind, res_kind=res_kind, bits=4, training=training, with_dq2=True, with_gf=False, seed=350)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_qlinear(be, mode):
+    K.check_qlinear(be, mode=mode, seed=360 + mode)
+    K.check_qlinear(be, N=19, Cc=512, Oc=10, mode=mode, bits=4, bias=False, seed=365 + mode)
+    K.check_qlinear(be, N=3, Cc=64, Oc=64, mode=mode, seed=370 + mode)
+
+
+def test_dorefa_weight_quantizer_multi_cached(be):
+    """mn_dorefa_w_fwd_multi_cached / _bwd_multi_cached (tanh(w) kept between forward and backward) == the per-tensor entry points, bit for bit."""
+    import ctypes as C
+    r = np.random.default_rng(11)
+    shapes = [(24, 16, 1, 1), (8, 4, 3, 3), (7,), (3000,)]
+    ws = [be.to_dev(r.standard_normal(s) * 0.7) for s in shapes]
+    gs = [be.to_dev(r.standard_normal(s)) for s in shapes]
+    lib, n = be.lib, len(shapes)
+    PA, LA = C.c_void_p * n, C.c_int64 * n
+    pa = lambda arrs: PA(*[be.ptr(a).value for a in arrs])
+    for bits in (2, 8):
+        ref = []
+        for w, g in zip(ws, gs):
+            sc = be.empty(int(lib.mn_dorefa_w_ws_floats(w.size)))
+            q, d = be.empty(w.shape), be.empty(w.shape)
+            be.call("mn_dorefa_w_fwd", be.ptr(w), be.ptr(q), w.size, bits, be.ptr(sc), be.stream)
+            be.call("mn_dorefa_w_bwd", be.ptr(g), be.ptr(w), be.ptr(d), w.size, bits, be.ptr(sc), be.stream)
+            ref.append((q, d))
+        qs, ds, ths = [be.empty(w.shape) for w in ws], [be.empty(w.shape) for w in ws], [be.empty(w.shape) for w in ws]
+        scs = [be.empty(int(lib.mn_dorefa_w_ws_floats(w.size))) for w in ws]
+        sizes = LA(*[w.size for w in ws])
+        be.call("mn_dorefa_w_fwd_multi_cached", pa(ws), pa(qs), pa(scs), pa(ths), sizes, n, bits, be.stream)
+        be.call("mn_dorefa_w_bwd_multi_cached", pa(gs), pa(ws), pa(ds), pa(scs), pa(ths), sizes, n, bits, be.stream)
+        for (q, d), q2, d2 in zip(ref, qs, ds):
+            assert np.array_equal(q, q2) and np.array_equal(d, d2)
