@@ -59,7 +59,8 @@ __device__ __forceinline__ bool qd_unit(const QdUnits& m, int u, int& q, int& im
 // orient 0 (forward):        [cot][chunk = c / 64][tap][ks = 0, 1][nf = 0..3][lane][e]: o = 64 cot + 16 nf + (lane & 15), c = 64 chunk + 32 ks + 8 (lane >> 4) + e
 // orient 1 (backward-data):  [cit][chunk = o / 32][tap][nf][lane][e]:                   c = 64 cit + 16 nf + (lane & 15), o = 32 chunk + 8 (lane >> 4) + e
 // code = rint(w * (2^bits - 1)): the integer 2k - n of a DoReFa weight (2k - n) / n (wqaq/dorefa/quantize.py:68-72); exact in bf16
-struct QdPackParams { const float* w; uint16_t* out; int O, C, T; float wn; int orient; int64_t ngroups; };
+// IAO weights (wqaq/iao/quantize.py:227-239, symmetric): w = code * scale[o] -> code = rint(w / scale[o]) (wsc != nullptr; stride: floats between channels, 0 per layer)
+struct QdPackParams { const float* w; uint16_t* out; int O, C, T; float wn; int orient; int64_t ngroups; const float* wsc; int wsc_stride; };
 __global__ __launch_bounds__(256) void k_qd_pack(const QdPackParams p) {
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gi >= p.ngroups) return;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void k_qd_pack(const QdPackParams p) {
     for (int e = 0; e < 8; ++e) {
         const int o = o0 + e * ostep, c = c0 + e * cstep;
         const float v = p.w[((int64_t)o * p.C + c) * p.T + tap];
-        h[e] = mn_f2u(rintf(v * p.wn)) >> 16;
+        h[e] = mn_f2u(p.wsc ? rintf(v / p.wsc[(int64_t)o * p.wsc_stride]) : rintf(v * p.wn)) >> 16;
     }
     *reinterpret_cast<u32x4*>(p.out + gi * 8) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
 }
@@ -100,6 +101,9 @@ struct QdfParams {
     int tpi, ncot, nchunks, nitems, nunits, out32, wo_shift;
     FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_ncot, fd_tpi, fd_ipt;
     QdUnits units;
+    // out32 == 2: the IAO layers -- x holds SIGNED codes (xsgn), the output is fp32 y = acc * (sa[0] * sw[o * sw_stride]) + bias[o] (wqaq/iao/quantize.py:492-507)
+    int xsgn, sw_stride;
+    const float *sa, *sw, *bias;
 };
 
 template <int MF, int TPS>
@@ -153,10 +157,13 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
         for (int i = 0; i < QDF_UPT; ++i) {
             if (u_lds[i] < 0) continue;
             const bool ok = (pok >> i) & 1u;
+            const uint32_t flip = p.xsgn ? 0x80808080u : 0u;          // signed codes: byte ^ 0x80 = code + 128 as an unsigned byte
+            const float off = p.xsgn ? 128.f : 0.f;
+            const uint32_t r0 = preg[i][0] ^ flip, r1 = preg[i][1] ^ flip, r2 = preg[i][2] ^ flip, r3 = preg[i][3] ^ flip;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float f0 = (float)((preg[i][0] >> (8 * e)) & 0xffu), f1 = (float)((preg[i][1] >> (8 * e)) & 0xffu);
-                const float f2 = (float)((preg[i][2] >> (8 * e)) & 0xffu), f3 = (float)((preg[i][3] >> (8 * e)) & 0xffu);
+                const float f0 = (float)((r0 >> (8 * e)) & 0xffu) - off, f1 = (float)((r1 >> (8 * e)) & 0xffu) - off;
+                const float f2 = (float)((r2 >> (8 * e)) & 0xffu) - off, f3 = (float)((r3 >> (8 * e)) & 0xffu) - off;
                 const u32x2 v = ok ? u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)} : u32x2{0u, 0u};       // integers <= 255: exact in bf16
                 *reinterpret_cast<u32x2*>(patch + u_lds[i] + e * QD_RS) = v;
             }
@@ -275,6 +282,16 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
                 }
             } else {
                 constexpr int ROW = 64 * MF + 8;
+                float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.out32 == 2) {
+                    const float sa = p.sa[0];
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) {
+                        const int o = cot * 64 + nf * 16 + j;
+                        al[nf] = sa * p.sw[(int64_t)o * p.sw_stride];
+                        bi[nf] = p.bias ? p.bias[o] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -283,8 +300,11 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
                         for (int n2 = 0; n2 < 2; ++n2) {
                             const int nf = half * 2 + n2;
                             unsigned char* d = scr + (n2 * 16 + j) * ROW + (mf * 16 + 4 * kg) * 4;
-                            *reinterpret_cast<u32x2*>(d) = u32x2{(uint32_t)(int)acc[mf][nf][0], (uint32_t)(int)acc[mf][nf][1]};
-                            *reinterpret_cast<u32x2*>(d + 8) = u32x2{(uint32_t)(int)acc[mf][nf][2], (uint32_t)(int)acc[mf][nf][3]};
+                            uint32_t w4[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) w4[r] = p.out32 == 2 ? mn_f2u(acc[mf][nf][r] * al[nf] + bi[nf]) : (uint32_t)(int)acc[mf][nf][r];
+                            *reinterpret_cast<u32x2*>(d) = u32x2{w4[0], w4[1]};
+                            *reinterpret_cast<u32x2*>(d + 8) = u32x2{w4[2], w4[3]};
                         }
                     MN_WAVE_SYNC();
                     constexpr int CPR = 4 * MF, RPI = 64 / CPR;
@@ -402,10 +422,23 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
     pl->ws_bytes = pl->off_scale + ((int64_t)g->O * 4 + 255) / 256 * 256;
     return 1;
 }
-static void qd_launch_pack(const float* w, uint16_t* out, int O, int C, int T, int w_bits, int orient, hipStream_t s) {
+static void qd_launch_pack(const float* w, uint16_t* out, int O, int C, int T, int w_bits, int orient, hipStream_t s, const float* wsc = nullptr, int wsc_stride = 0) {
     QdPackParams k;
     k.w = w; k.out = out; k.O = O; k.C = C; k.T = T; k.wn = (float)((1ll << w_bits) - 1); k.orient = orient; k.ngroups = (int64_t)O * C * T / 8;
+    k.wsc = wsc; k.wsc_stride = wsc_stride;
     hipLaunchKernelGGL(k_qd_pack, dim3((unsigned)((k.ngroups + 255) / 256)), dim3(256), 0, s, k);
+}
+static void qd_launch_fwd(const QdfPlan& pl, hipStream_t s) {
+    const QdfParams& p = pl.p;
+    if (p.TAPS == 9) {
+        if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<4, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+        else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<2, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+        else { raise_lds_limit((const void*)k_qd_fwd<1, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<1, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    } else {
+        if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<4, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+        else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<2, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+        else { raise_lds_limit((const void*)k_qd_fwd<1, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<1, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    }
 }
 // the stash of a dense layer is 32 bits wide when K * amax * wmax does not fit 16
 int qd_stash32(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
@@ -430,19 +463,11 @@ int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a
     QdfParams& p = pl.p;
     uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
     qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 0, s);
-    p.x = x; p.wpk = wpk; p.stash = stash;
+    p.x = x; p.wpk = wpk; p.stash = stash; p.xsgn = 0; p.sa = p.sw = p.bias = nullptr; p.sw_stride = 0;
     mn_set_last_kernel("k_qd_fwd<%d, %d>", pl.MF, p.TAPS == 9 ? 3 : 1);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
-    if (p.TAPS == 9) {
-        if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<4, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-        else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<2, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-        else { raise_lds_limit((const void*)k_qd_fwd<1, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<1, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    } else {
-        if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<4, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-        else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<2, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-        else { raise_lds_limit((const void*)k_qd_fwd<1, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<1, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    }
+    qd_launch_fwd(pl, s);
     mn_prof_end(s);
     double* part = reinterpret_cast<double*>((char*)ws + pl.off_part);
     const dim3 sgrid((unsigned)g->O, (unsigned)pl.S_stats);
@@ -471,6 +496,8 @@ struct QddParams {
     const uint16_t* wpk;          // k_qd_pack orient 1
     float* dx;                    // [N][C][S Hg][S Wg]
     float wscale;
+    const float* wsc;             // IAO: per-output-channel weight scale (stride wsc_stride floats, 0: per layer), folded into gy before the split; nullptr: none
+    int wsc_stride;
     int N, C, Hg, Wg, O, HWg;
     int TAPS, TPS, NSTEP, WSB;    // taps, taps per step, steps per chunk, bytes of weights per step
     int TH, NI, PH, PW, W4, TS;   // TS: bytes per term plane
@@ -499,6 +526,16 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
         u_pi[i] = pr | (img << 8);
     }
     float4 preg[QDD_UPT][4];
+    float psc[QDD_UPT][4];
+    int u_q[QDD_UPT];
+#pragma unroll
+    for (int i = 0; i < QDD_UPT; ++i) {
+        int q, img, pr, d;
+        qd_unit(p.units, tid + 256 * i, q, img, pr, d);
+        u_q[i] = q;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) psc[i][cc] = 1.f;
+    }
     uint32_t pok = 0u;
     auto tile_origin = [&](int item, int& n0, int& oh0, int& cit) {
         const uint32_t tile = fd_div((uint32_t)item, p.fd_ncit);
@@ -519,6 +556,10 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
             const uint32_t base = (uint32_t)((n * p.O + chunk * 32) * p.Hg + oh) * (uint32_t)p.Wg + (uint32_t)u_goff[i];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) preg[i][cc] = *reinterpret_cast<const float4*>(p.gy + base + (uint32_t)(cc * p.HWg));
+            if (p.wsc && u_lds[i] >= 0) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) psc[i][cc] = p.wsc[(int64_t)(chunk * 32 + 4 * u_q[i] + cc) * p.wsc_stride];
+            }
             pok |= (ok ? 1u : 0u) << i;
         }
     };
@@ -533,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
                 const float v[4] = {preg[i][cc].x, preg[i][cc].y, preg[i][cc].z, preg[i][cc].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float vv = ok ? v[e] : 0.f;
+                    const float vv = ok ? (p.wsc ? v[e] * psc[i][cc] : v[e]) : 0.f;
                     t0[cc][e] = mn_bf16_head(vv);
                     const float r1 = vv - t0[cc][e];
                     t1[cc][e] = mn_bf16_head(r1);
@@ -712,6 +753,13 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
     pl->ws_bytes = ((int64_t)g->O * g->C * p.TAPS * 2 + 255) / 256 * 256;
     return 1;
 }
+static void qd_launch_dgrad(const QddPlan& pl, hipStream_t s) {
+    const QddParams& p = pl.p;
+    if (pl.S == 2 && p.TAPS == 9) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    else if (pl.S == 2) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_dgrad<2, 1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<2, 1, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    else { raise_lds_limit((const void*)k_qd_dgrad<1, 1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 1, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+}
 int qd_dgrad_supported(const mn_conv_geom* g, const mn_wq* wq) {
     QddPlan pl;
     return wq && wq->mode == MN_WQ_DOREFA && wq->bits >= 2 && wq->bits <= 8 && plan_qdd(g, &pl);
@@ -725,14 +773,11 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
     QddParams& p = pl.p;
     uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
     qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 1, s);
-    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1);
+    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
-    if (pl.S == 2 && p.TAPS == 9) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    else if (pl.S == 2) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_dgrad<2, 1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<2, 1, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    else { raise_lds_limit((const void*)k_qd_dgrad<1, 1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 1, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    qd_launch_dgrad(pl, s);
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_data(dense)");
     return MN_OK;
@@ -760,6 +805,7 @@ struct QdwParams {
     int TH, NI, PH, PWp, RB, CS, W4, BMt, nks;    // tile rows / images, patch rows, padded plane row (bf16 elements), bytes per patch row, bytes per channel, K-steps per tile
     int tpi, ntiles, tpz, Z, ncit, npairs, nunits, w_shift;
     FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_tpi, fd_np;
+    int xsgn;                     // x holds signed codes (IAO)
 };
 
 template <int S, int TAPS>
@@ -816,8 +862,10 @@ __global__ __launch_bounds__(512, 2) void k_qd_wgrad(const QdwParams p) {
 #pragma unroll
         for (int i = 0; i < QDW_UPT; ++i) {
             if (u_lds[i] < 0) continue;
-            const uint32_t v = ((pok >> i) & 1u) ? preg[i] : 0u;
-            const float f0 = (float)(v & 0xffu), f1 = (float)((v >> 8) & 0xffu), f2 = (float)((v >> 16) & 0xffu), f3 = (float)(v >> 24);
+            const bool okv = (pok >> i) & 1u;
+            const uint32_t v = okv ? (p.xsgn ? preg[i] ^ 0x80808080u : preg[i]) : 0u;
+            const float off = (p.xsgn && okv) ? 128.f : 0.f;
+            const float f0 = (float)(v & 0xffu) - off, f1 = (float)((v >> 8) & 0xffu) - off, f2 = (float)((v >> 16) & 0xffu) - off, f3 = (float)(v >> 24) - off;
             if (S == 1) *reinterpret_cast<u32x2*>(xp + u_lds[i]) = u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)};
             else {
                 *reinterpret_cast<uint32_t*>(xp + u_lds[i]) = mn_pack_hi16(f0, f2);
@@ -943,7 +991,9 @@ __global__ __launch_bounds__(512, 2) void k_qd_wgrad(const QdwParams p) {
 }
 // dw[o][c][tap] = scale * sum over z (fixed order, fp64) of part[z][pair][tap][o % 64][c % 64].  A block owns 64 consecutive (pair, tap, o, c) indices (one
 // 256-byte row of every partial tile): thread (tx = 16 float4 columns, ty = 16 z residues) sums its z subset, the 16 subsets are added in order through LDS.
-__global__ __launch_bounds__(256) void k_qd_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int O, int C, int T, int Z, float scale) {
+__global__ __launch_bounds__(256) void k_qd_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int O, int C, int T, int Z, float scale_c,
+                                                         const float* __restrict__ scale_p) {
+    const float scale = scale_p ? scale_p[0] : scale_c;          // IAO: the activation scale lives on the device
     __shared__ double red[16][64];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int npairs = (O / 64) * (C / 64);
@@ -1020,11 +1070,16 @@ int qd_wgrad_supported(const mn_conv_geom* g, int a_bits) {
 }
 int64_t qd_wgrad_ws_bytes(const mn_conv_geom* g) { QdwPlan pl; return plan_qdw(g, &pl) ? pl.ws_bytes : 0; }
 int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, void* ws, int64_t ws_bytes, hipStream_t s) {
+    return qd_bwd_weight_ex(g, gy, x, 0, ascale, nullptr, dw, ws, ws_bytes, s);
+}
+// xsgn: x holds signed codes; ascale_dev != nullptr: the activation scale is read from the device (IAO qparams snapshot)
+int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, int xsgn, float ascale, const float* ascale_dev, float* dw, void* ws, int64_t ws_bytes,
+                     hipStream_t s) {
     QdwPlan pl;
     if (!plan_qdw(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3) || !dw) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(dense): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense): workspace too small");
     QdwParams& p = pl.p;
-    p.gy = gy; p.x = x; p.part = reinterpret_cast<float*>(ws);
+    p.gy = gy; p.x = x; p.part = reinterpret_cast<float*>(ws); p.xsgn = xsgn;
     mn_set_last_kernel("k_qd_wgrad<%d, %d>", pl.S, pl.T);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + nx * (g->O / 64) + (double)pl.ws_bytes); mn_prof_flops(2.0 * ny * g->C * pl.T); }
     mn_prof_begin(s);
@@ -1033,7 +1088,121 @@ int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, floa
     else { raise_lds_limit((const void*)k_qd_wgrad<2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 1>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
     mn_prof_end(s);
     const int total = p.npairs * pl.T * 4096;
-    hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(256), 0, s, (const float*)p.part, dw, (int)g->O, (int)g->C, pl.T, p.Z, ascale);
+    hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(256), 0, s, (const float*)p.part, dw, (int)g->O, (int)g->C, pl.T, p.Z, ascale, ascale_dev);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(dense)");
     return MN_OK;
+}
+
+
+// ================================================================================================ IAO layers (wqaq/iao/quantize.py:492-507 QuantConv2d)
+// Symmetric per-tensor activation quantizer (codes in [-2^(b-1), 2^(b-1) - 1], value = code * sa) and symmetric per-channel / per-layer weight quantizer
+// (w = wcode * sw[o]): y = sa sw[o] * sum wcode * code + bias.  The activation arrives as fp32 (the quantizer belongs to this conv in the reference), so each
+// direction first writes the codes once -- k_qd_iao_codes, 4 B in / 1 B out per element -- into its workspace and then runs the dense kernels above on them:
+// forward with the fp32 epilogue, backward-data with the per-channel scale folded into gy followed by the quantizer's clip-STE (k_qd_iao_ste, in place),
+// backward-weight on the signed codes with the activation scale taken from the device snapshot.
+__global__ __launch_bounds__(256) void k_qd_iao_codes(const float* __restrict__ x, signed char* __restrict__ codes, int64_t n8, const float* __restrict__ qp, float qmin, float qmax) {
+    const float sc = qp[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = *reinterpret_cast<const float4*>(x + 8 * i), b = *reinterpret_cast<const float4*>(x + 8 * i + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // clamp(rha(x / sc), qmin, qmax): the integer of iao_fq (zero_point == 0); NaN -> 0 (a byte cannot hold it)
+            const float c0 = mn_clamp(mn_rha(v[e] / sc), qmin, qmax), c1 = mn_clamp(mn_rha(v[4 + e] / sc), qmin, qmax);
+            lo |= ((uint32_t)(int)(c0 == c0 ? c0 : 0.f) & 0xffu) << (8 * e);
+            hi |= ((uint32_t)(int)(c1 == c1 ? c1 : 0.f) & 0xffu) << (8 * e);
+        }
+        *reinterpret_cast<u32x2*>(codes + 8 * i) = u32x2{lo, hi};
+    }
+}
+__global__ __launch_bounds__(256) void k_qd_iao_ste(float* __restrict__ dx, const float* __restrict__ x, int64_t n4, const float* __restrict__ qp, float qmin, float qmax) {
+    const float sc = qp[0], zp = qp[1], lo = qp[2], hi = qp[3];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 g = *reinterpret_cast<const float4*>(dx + 4 * i), v = *reinterpret_cast<const float4*>(x + 4 * i);
+        *reinterpret_cast<float4*>(dx + 4 * i) = make_float4(iao_fq_grad(g.x, v.x, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(g.y, v.y, sc, zp, lo, hi, qmin, qmax),
+                                                             iao_fq_grad(g.z, v.z, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(g.w, v.w, sc, zp, lo, hi, qmin, qmax));
+    }
+}
+static int qd_iao_quant_ok(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int need_w) {
+    if (!g || !aq || aq->mode != MN_ACTQ_IAO || aq->q_type != 0 || aq->bits < 2 || aq->bits > 8 || !aq->qp) return 0;
+    int64_t wmax = 127;
+    if (need_w) {
+        if (!wq || wq->mode != MN_WQ_IAO || wq->q_type != 0 || wq->bits < 2 || wq->bits > 8 || !wq->scale) return 0;
+        wmax = (1ll << (wq->bits - 1)) - 1;
+    }
+    const int64_t K = (int64_t)g->C * g->KH * g->KW, amax = 1ll << (aq->bits - 1);
+    if (K * amax * wmax >= (1ll << 24)) return 0;          // the fp32 accumulation of integer products must stay exact
+    if (((int64_t)g->N * g->C * g->H * g->W) % 8) return 0;
+    return 1;
+}
+static int64_t qd_iao_codes_bytes(const mn_conv_geom* g) { return ((int64_t)g->N * g->C * g->H * g->W + 255) / 256 * 256; }
+int qd_iao_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
+    if (which == 0) { QdfPlan pl; return qd_iao_quant_ok(g, aq, wq, 1) && plan_qdf(g, 2, &pl); }
+    if (which == 1) { QddPlan pl; return qd_iao_quant_ok(g, aq, wq, 1) && plan_qdd(g, &pl); }
+    if (which == 2) { QdwPlan pl; return qd_iao_quant_ok(g, aq, nullptr, 0) && plan_qdw(g, &pl); }
+    return 0;
+}
+int64_t qd_iao_ws_bytes(const mn_conv_geom* g, int which) {
+    if (which == 0) { QdfPlan pl; return plan_qdf(g, 2, &pl) ? qd_iao_codes_bytes(g) + pl.ws_bytes : 0; }
+    if (which == 1) { QddPlan pl; return plan_qdd(g, &pl) ? pl.ws_bytes : 0; }
+    if (which == 2) { QdwPlan pl; return plan_qdw(g, &pl) ? qd_iao_codes_bytes(g) + pl.ws_bytes : 0; }
+    return 0;
+}
+static void qd_iao_launch_codes(const mn_conv_geom* g, const mn_actq* aq, const float* x, void* codes, hipStream_t s) {
+    const int64_t n8 = (int64_t)g->N * g->C * g->H * g->W / 8;
+    const IaoRange r = iao_range(aq->bits, 0, 1);
+    int64_t nb = (n8 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_qd_iao_codes, dim3((unsigned)nb), dim3(256), 0, s, x, (signed char*)codes, n8, aq->qp, r.qmin, r.qmax);
+}
+int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes,
+               hipStream_t s) {
+    QdfPlan pl;
+    if (!qd_iao_quant_ok(g, aq, wq, 1) || !plan_qdf(g, 2, &pl) || !aligned16(x) || !aligned16(y) || !w) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(dense iao): geometry / quantizer not covered");
+    const int64_t cb = qd_iao_codes_bytes(g);
+    if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(dense iao): workspace too small");
+    QdfParams& p = pl.p;
+    qd_iao_launch_codes(g, aq, x, ws, s);
+    uint16_t* wpk = reinterpret_cast<uint16_t*>((char*)ws + cb);
+    qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 0, s, wq->scale, wq->per_channel);
+    p.x = (const unsigned char*)ws; p.wpk = wpk; p.stash = y; p.xsgn = 1; p.sa = aq->qp; p.sw = wq->scale; p.sw_stride = wq->per_channel; p.bias = bias;
+    mn_set_last_kernel("k_qd_fwd<%d, %d>", pl.MF, p.TAPS == 9 ? 3 : 1);
+    { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + 4.0 * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
+    mn_prof_begin(s);
+    qd_launch_fwd(pl, s);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_conv2d_fwd(dense iao)");
+    return MN_OK;
+}
+int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx, void* ws, int64_t ws_bytes,
+                    hipStream_t s) {
+    QddPlan pl;
+    if (!qd_iao_quant_ok(g, aq, wq, 1) || !plan_qdd(g, &pl) || !aligned16(gy) || !aligned16(dx) || !aligned16(x) || !w)
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense iao): geometry / quantizer not covered");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data(dense iao): workspace too small");
+    QddParams& p = pl.p;
+    uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
+    qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 1, s, wq->scale, wq->per_channel);
+    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f; p.wsc = wq->scale; p.wsc_stride = wq->per_channel;
+    mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
+    mn_prof_begin(s);
+    qd_launch_dgrad(pl, s);
+    mn_prof_end(s);
+    const int64_t n4 = (int64_t)g->N * g->C * g->H * g->W / 4;
+    const IaoRange r = iao_range(aq->bits, 0, 1);
+    int64_t nb = (n4 + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_qd_iao_ste, dim3((unsigned)nb), dim3(256), 0, s, dx, x, n4, aq->qp, r.qmin, r.qmax);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_data(dense iao)");
+    return MN_OK;
+}
+int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, void* ws, int64_t ws_bytes, hipStream_t s) {
+    QdwPlan pl;
+    if (!qd_iao_quant_ok(g, aq, nullptr, 0) || !plan_qdw(g, &pl) || !aligned16(x)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(dense iao): geometry / quantizer not covered");
+    const int64_t cb = qd_iao_codes_bytes(g);
+    if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense iao): workspace too small");
+    qd_iao_launch_codes(g, aq, x, ws, s);
+    return qd_bwd_weight_ex(g, gy, (const uint8_t*)ws, 1, 1.f, aq->qp, dw, (char*)ws + cb, ws_bytes - cb, s);
 }

@@ -110,6 +110,16 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
 int qd_wgrad_supported(const mn_conv_geom* g, int a_bits);
 int64_t qd_wgrad_ws_bytes(const mn_conv_geom* g);
 int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, void* ws, int64_t ws_bytes, hipStream_t s);
+int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, int xsgn, float ascale, const float* ascale_dev, float* dw, void* ws, int64_t ws_bytes,
+                     hipStream_t s);
+// IAO layers (symmetric 2..8-bit activation / weight quantizers) on the dense kernels: which = 0 forward, 1 backward-data, 2 backward-weight (wq unused)
+int qd_iao_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
+int64_t qd_iao_ws_bytes(const mn_conv_geom* g, int which);
+int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes,
+               hipStream_t s);
+int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx, void* ws, int64_t ws_bytes,
+                    hipStream_t s);
+int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, void* ws, int64_t ws_bytes, hipStream_t s);
 
 void qa_launch_stats_prep_const(const double* part, int CB, int Cout, float wscale, float ascale, const float* bias, double n, float eps, float momentum, int training,
                                 float* running_mean, float* running_var, float* save, const float* gamma, const float* beta, float* chan, long long* nbt, hipStream_t s);

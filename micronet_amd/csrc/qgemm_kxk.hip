@@ -424,6 +424,8 @@ int kk_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const floa
            void* ws, int64_t ws_bytes, hipStream_t s) {
     KkPlan pl;
     if (aq && aq->mode == MN_ACTQ_CODE8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd: activation codes are read by mn_qconv_bnq_fwd_stash only");
+    if (qd_iao_supported(g, aq, wq, 0) && ws_bytes >= qd_iao_ws_bytes(g, 0) && aligned16(x) && aligned16(y))          // dense IAO layers (the ResNets): qgemm_dense.hip
+        return qd_iao_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
     if (!wq_codeable(wq) || !aq_codeable(aq, 0) || !plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl) || !aligned16(x) || !aligned16(y))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(qgemm): geometry / quantizer combination not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(qgemm kxk): workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)pl.ws_bytes);
@@ -470,6 +472,8 @@ int kk_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     if ((!aq || aq->mode == MN_ACTQ_NONE || aq->mode == MN_ACTQ_CODE8 || aq->mode == MN_ACTQ_SIGN8) && qd_dgrad_native(g, wq) && ws_bytes >= qd_dgrad_ws_bytes(g) &&
         aligned16(gy) && aligned16(dx))
         return qd_bwd_data(g, wq, gy, w, dx, ws, ws_bytes, s);
+    if (qd_iao_supported(g, aq, wq, 1) && ws_bytes >= qd_iao_ws_bytes(g, 1) && aligned16(gy) && aligned16(dx) && aligned16(x))
+        return qd_iao_bwd_data(g, aq, wq, gy, w, x, dx, ws, ws_bytes, s);
     KkPlan pl;
     if (!wq_codeable(wq) || !plan_kk(g, 1, MN_ACTQ_NONE, &pl) || !aligned16(gy) || !aligned16(dx))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(qgemm): geometry / quantizer combination not covered");
@@ -818,6 +822,7 @@ static void launch_kw(const KwPlan& pl, int xmode, hipStream_t s) {
 
 int kk_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
     KkPlan pl;
+    if (which >= 0 && which <= 2 && qd_iao_supported(g, aq, wq, which)) return 1;
     if (which == 0) return wq_codeable(wq) && aq_codeable(aq, 0) && plan_kk(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl);
     if (which == 1) return wq_codeable(wq) && (plan_kk(g, 1, MN_ACTQ_NONE, &pl) ||
                                                ((!aq || aq->mode == MN_ACTQ_NONE || aq->mode == MN_ACTQ_CODE8 || aq->mode == MN_ACTQ_SIGN8) && qd_dgrad_native(g, wq)));
@@ -830,14 +835,17 @@ int64_t kk_ws_bytes(const mn_conv_geom* g, int which) {
     if (which == 0) {   // the plan (hence Mpad / Cgp) depends on the activation mode: take the larger
         int64_t a = plan_kk(g, 0, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0;
         int64_t b = plan_kk(g, 0, MN_ACTQ_DOREFA, &pl) ? pl.ws_bytes : 0;
+        const int64_t c = qd_iao_ws_bytes(g, 0);
+        if (c > a) a = c;
         return a > b ? a : b;
     }
     if (which == 1) { const int64_t a = plan_kk(g, 1, MN_ACTQ_NONE, &pl) ? pl.ws_bytes : 0, b = qd_dgrad_ws_bytes(g); return a > b ? a : b; }
     if (which == 2) {
         KwPlan kw;
-        const int64_t a = plan_kk_wgrad(g, &kw) ? kw.ws_bytes : 0, b = k3s_wgrad_ws_bytes(g), c = qd_wgrad_ws_bytes(g);
-        const int64_t m = a > b ? a : b;
-        return m > c ? m : c;
+        const int64_t a = plan_kk_wgrad(g, &kw) ? kw.ws_bytes : 0, b = k3s_wgrad_ws_bytes(g), c = qd_wgrad_ws_bytes(g), d = qd_iao_ws_bytes(g, 2);
+        int64_t m = a > b ? a : b;
+        if (c > m) m = c;
+        return m > d ? m : d;
     }
     return 0;
 }
@@ -847,6 +855,8 @@ int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
         return k3s_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // 3x3 on sign codes: wave-private streaming kernel
     if (aq && aq->mode == MN_ACTQ_CODE8 && !dbias && qd_wgrad_supported(g, aq->bits) && ws_bytes >= qd_wgrad_ws_bytes(g))      // dense layers: qgemm_dense.hip
         return qd_bwd_weight(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, ws, ws_bytes, s);
+    if (!dbias && qd_iao_supported(g, aq, nullptr, 2) && ws_bytes >= qd_iao_ws_bytes(g, 2) && aligned16(gy) && aligned16(x))          // dense IAO layers
+        return qd_iao_bwd_weight(g, aq, gy, x, dw, ws, ws_bytes, s);
     if (aq && aq->mode == MN_ACTQ_CODE8) {        // k-bit activation codes: only the wave-private 3x3 kernel reads them
         if (!k3s_wgrad_code8_supported(g, aq->bits) || ws_bytes < k3s_wgrad_ws_bytes(g)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): geometry / bits not covered");
         return k3s_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);

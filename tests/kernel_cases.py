@@ -203,7 +203,7 @@ def make_coded_weights(r, w_shape, wmode, wbits=8):
 
 def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, bias=True, mode=0, bits=8, q_type=0,
                algos=(1, 2), seed=0, binary_x=False, expect_mfma=None, rel=1e-5, wmode=0, wbits=8, expect_qgemm=None, in_shuffle=0,
-               sign8=False):
+               sign8=False, want_dbias=True, expect_kernels=None):
     """fwd / bwd_data / bwd_weight of one geometry on every requested algo vs numpy fp64 on the same fp32 operands.
     wmode != 0: the weights are fake-quantised (ternary / dorefa / iao) and algo 3 (code-domain bf16 MFMA) is exercised.
     sign8: the +-1 activations are handed over as int8 codes (MN_ACTQ_SIGN8, the packed output of mn_bnsign_fwd_i8)."""
@@ -253,18 +253,23 @@ def check_conv(be, x_shape, w_shape, stride=1, padding=0, dilation=1, groups=1, 
     out = {}
     for algo in algos:
         ok = lambda k: (algo == 1 or algo == 0) or (algo == 2 and sup[k]) or (algo == 3 and supq[k])
+        lk = lambda: be.lib.mn_last_kernel().decode()
         if ok(0):
             y = be.to_host(be.conv_fwd(g, aq, dX, dW, dB, algo, wq=wq))
             assert close(y, y_ref, rel), ("fwd", algo, np.max(np.abs(y - y_ref)), np.max(np.abs(y_ref)))
+            assert expect_kernels is None or lk().startswith(expect_kernels[0]), lk()
         if ok(1):
             dx = be.to_host(be.conv_bwd_data(g, aq, dG, dW, dX, algo, wq=wq))
             # the STE mask multiplies a float; compare where the mask passes with the float tolerance
             assert close(dx, dx_ref, rel), ("bwd_data", algo, np.max(np.abs(dx - dx_ref)), np.max(np.abs(dx_ref)))
+            assert expect_kernels is None or lk().startswith(expect_kernels[1]), lk()
         if ok(2):
-            dw, db = be.conv_bwd_weight(g, aq, dG, dX, algo, bias=True)
-            dw, db = be.to_host(dw), be.to_host(db)
+            dw, db = be.conv_bwd_weight(g, aq, dG, dX, algo, bias=want_dbias)
+            dw = be.to_host(dw)
             assert close(dw, dw_ref, rel), ("bwd_weight", algo, np.max(np.abs(dw - dw_ref)), np.max(np.abs(dw_ref)))
-            assert close(db, db_ref, rel), ("dbias", algo)
+            assert expect_kernels is None or lk().startswith(expect_kernels[2]), lk()
+            if want_dbias:
+                assert close(be.to_host(db), db_ref, rel), ("dbias", algo)
         out[algo] = True
     return sup, supq
 
@@ -1045,7 +1050,8 @@ def check_qdense(be, x_shape, Oc, k=3, stride=1, a_bits=2, w_bits=2, seed=0):
     save, chan = be.empty((2, Oc)), be.empty((9, Oc))
     stash = be.empty_i8((N, Oc, Ho, Wo * (sb // 8)))
     nbt = be.to_dev_i64([0])
-    be.call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dX), a_bits, be.ptr(dW), None, be.ptr(be.to_dev(gamma)), be.ptr(be.to_dev(beta)), 1e-5, 0.1, 1,
+    dGa, dBe = be.to_dev(gamma), be.to_dev(beta)
+    be.call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dX), a_bits, be.ptr(dW), None, be.ptr(dGa), be.ptr(dBe), 1e-5, 0.1, 1,
             be.ptr(rm), be.ptr(rv), be.ptr(nbt), be.ptr(save), be.ptr(stash), be.ptr(chan), be.ptr(ws), nb, be.stream)
     st = be.to_host(stash).view(np.int16 if sb == 16 else np.int32).reshape(N, Oc, Ho, Wo)
     assert np.array_equal(st.astype(np.float64), acc), "stash != exact integer conv result"
@@ -1147,9 +1153,9 @@ def check_qr(be, shape=(3, 6, 4, 8), in_kind=0, res_kind=1, bits=2, training=Tru
     dgam, dbet, sums = be.empty(Cc), be.empty(Cc), be.empty((2, Cc))
     dgam_s, dbet_s, sums_s = (be.empty(Cc), be.empty(Cc), be.empty((2, Cc))) if res_kind >= 2 else (None, None, None)
     ws = be.empty(int(be.lib.mn_qr_ws_floats(Cc)))
-    be.call("mn_qr_bwd_sums", in_kind, be.ptr(src), be.ptr(chan), res_kind, be.ptr(res_dev), be.ptr(res_chan), be.ptr(be.to_dev(dq)), be.ptr(be.to_dev(dq2) if dq2 is not None else None),
-            be.ptr(be.to_dev(gf) if gf is not None else None), N, Cc, H, W, bits, be.ptr(du), be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(dgam_s), be.ptr(dbet_s),
-            be.ptr(sums_s), be.ptr(ws), be.stream)
+    dDQ, dDQ2, dGF = be.to_dev(dq), (be.to_dev(dq2) if dq2 is not None else None), (be.to_dev(gf) if gf is not None else None)      # (kept alive across the call)
+    be.call("mn_qr_bwd_sums", in_kind, be.ptr(src), be.ptr(chan), res_kind, be.ptr(res_dev), be.ptr(res_chan), be.ptr(dDQ), be.ptr(dDQ2), be.ptr(dGF), N, Cc, H, W, bits,
+            be.ptr(du), be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(dgam_s), be.ptr(dbet_s), be.ptr(sums_s), be.ptr(ws), be.stream)
     assert np.array_equal(be.to_host(du), du_ref), "du"
     sc = max(np.max(np.abs(d64)) * np.sqrt(n), 1e-30)
     assert np.max(np.abs(be.to_host(dbet) - s1)) <= 2e-6 * sc and np.max(np.abs(be.to_host(dgam) - s2)) <= 2e-6 * sc * max(1.0, np.abs(zh).max()), "dgamma / dbeta"
@@ -1188,7 +1194,8 @@ def check_qlinear(be, N=5, Cc=70, Oc=10, mode=1, bits=2, bias=True, seed=0):
     xq = _quant_x(x, mode, bits, qp_np if mode == 2 else None, 0)
     y = be.empty((N, Oc))
     dX, dW, dG = be.to_dev(x), be.to_dev(w), be.to_dev(gy)
-    be.call("mn_qlinear_fwd", C.byref(aq), be.ptr(dX), be.ptr(dW), be.ptr(be.to_dev(b) if bias else None), be.ptr(y), N, Cc, Oc, be.stream)
+    dB = be.to_dev(b) if bias else None
+    be.call("mn_qlinear_fwd", C.byref(aq), be.ptr(dX), be.ptr(dW), be.ptr(dB), be.ptr(y), N, Cc, Oc, be.stream)
     y_ref = xq.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
     assert close(be.to_host(y), y_ref, 1e-5), "y"
     dx = be.empty((N, Cc))
@@ -1200,3 +1207,11 @@ def check_qlinear(be, N=5, Cc=70, Oc=10, mode=1, bits=2, bias=True, seed=0):
     assert close(be.to_host(dw), gy.astype(np.float64).T @ xq.astype(np.float64), 1e-5), "dw"
     if bias:
         assert close(be.to_host(db), gy.astype(np.float64).sum(axis=0), 1e-5), "db"
+
+
+def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=False, seed=0):
+    """The IAO QuantConv2d of the ResNets (wqaq/iao/quantize.py:492-507; symmetric activation quantizer in the conv, symmetric per-channel weights) on the dense
+    kernels: mn_conv2d_fwd / _bwd_data / _bwd_weight with MN_ACTQ_IAO + MN_WQ_IAO route to k_qd_* and agree with the fp64 evaluation of the fake-quantised conv."""
+    pad = 1 if k == 3 else 0
+    check_conv(be, x_shape, (Oc, x_shape[1], k, k), stride=stride, padding=pad, bias=bias, mode=2, bits=a_bits, q_type=0, wmode=3, wbits=w_bits, algos=(3,), seed=seed,
+               expect_qgemm=True, want_dbias=False, expect_kernels=("k_qd_fwd", "k_qd_dgrad", "k_qd_wgrad"))

@@ -588,3 +588,15 @@ def test_qlinear(be, mode):
     K.check_qlinear(be, mode=mode, seed=360 + mode)
     K.check_qlinear(be, N=256, Cc=512, Oc=10, mode=mode, bits=4, bias=False, seed=365 + mode)
     K.check_qlinear(be, N=3, Cc=64, Oc=64, mode=mode, seed=370 + mode)
+
+
+@pytest.mark.parametrize("case", range(len(K.QDENSE_CASES)))
+def test_qdense_layer_iao(be, case):
+    xs, Oc, k, s = K.QDENSE_CASES[case]
+    K.check_qdense_iao(be, xs, Oc, k, s, seed=400 + case)
+
+
+def test_qdense_layer_iao_w8a8_bias(be):
+    K.check_qdense_iao(be, (2, 64, 8, 8), 64, 3, 1, a_bits=8, w_bits=8, bias=True, seed=410)
+    K.check_qdense_iao(be, (37, 256, 8, 8), 512, 3, 2, seed=411)
+    K.check_qdense_iao(be, (37, 128, 16, 16), 256, 1, 2, seed=412)

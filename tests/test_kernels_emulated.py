@@ -389,3 +389,13 @@ def test_dorefa_weight_quantizer_multi_cached(be):
         be.call("mn_dorefa_w_bwd_multi_cached", pa(gs), pa(ws), pa(ds), pa(scs), pa(ths), sizes, n, bits, be.stream)
         for (q, d), q2, d2 in zip(ref, qs, ds):
             assert np.array_equal(q, q2) and np.array_equal(d, d2)
+
+
+@pytest.mark.parametrize("case", [0, 1, 4, 6])
+def test_qdense_layer_iao(be, case):
+    xs, Oc, k, s = K.QDENSE_CASES[case]
+    K.check_qdense_iao(be, xs, Oc, k, s, seed=400 + case)
+
+
+def test_qdense_layer_iao_w8a8_bias(be):
+    K.check_qdense_iao(be, (2, 64, 8, 8), 64, 3, 1, a_bits=8, w_bits=8, bias=True, seed=410)
