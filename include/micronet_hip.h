@@ -223,6 +223,8 @@ typedef struct mn_wq {
     int32_t per_channel;  /* iao: stride, in floats, between the scales of consecutive out-channels: 0 = one scale for the
                              tensor, 1 = a dense [O] vector, 4 = the rows of an mn_iao_qparams snapshot */
     const float* scale;   /* iao: device pointer */
+    const void* packed_fwd; /* optional (NULL: the kernels pack the codes themselves, once per call): the weight codes in the fragment order of the dense */
+    const void* packed_bwd; /* family's forward / backward-data kernels, written by mn_qd_pack_multi for THIS `w` (same step, same quantizer state)   */
 } mn_wq;
 
 #define MN_ALGO_AUTO 0
@@ -376,6 +378,13 @@ int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq, const int
  * Backward of the conv itself: mn_conv2d_bwd_data (no STE epilogue) and mn_conv2d_bwd_weight with aq->mode == MN_ACTQ_CODE8. */
 #define MN_QA_NCH 9
 int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in);
+/* Dense layers (groups == 1, C and O multiples of 64, 3 x 3 stride 1 / 2 or 1 x 1 stride 2: the ResNets): the weight codes of every such layer of a net, in
+ * both fragment orders, in ONE launch -- once per training step, right after the weight quantizer, instead of one launch per conv call and direction.
+ * w[i]: the fake-quantised fp32 weights [O][C][taps]; out_fwd[i] / out_bwd[i]: mn_qd_packed_bytes(g) bytes each (either may be NULL), handed to the conv
+ * entry points through mn_wq.packed_fwd / packed_bwd.  wscale == NULL: DoReFa codes rint(w (2^bits - 1)); else IAO codes rint(w / wscale[i][o * stride]). */
+int64_t mn_qd_packed_bytes(const mn_conv_geom* g);
+int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, void* const* out_bwd, const int64_t* O, const int64_t* Cin, const int64_t* taps,
+                     const float* const* wscale, const int32_t* wscale_stride, int32_t count, int w_bits, mn_stream_t stream);
 /* width of the stash mn_qconv_bnq_fwd_stash writes for this layer: 16, or 32 for a DENSE layer (groups == 1, C and O multiples of 64: the 3 x 3 stride 1 / 2 and
  * 1 x 1 stride 2 convolutions of the reference's ResNets, models/resnet.py:7-65) whose K * (2^a - 1) * (2^w - 1) exceeds 32767; 0 when unsupported.  A 32-bit stash is
  * passed through the same `stash` pointer and read by mn_qa_* / mn_qr_* with in_kind == 2.  Dense layers write [N][O][Ho][Wo] (stride 2: half the input size). */

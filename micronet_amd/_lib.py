@@ -30,7 +30,7 @@ class ActQ(C.Structure):
 class WQ(C.Structure):
     """mn_wq: how the fake-quantised fp32 weights factor into integer codes x per-channel scale."""
     _fields_ = [("mode", C.c_int32), ("bits", C.c_int32), ("q_type", C.c_int32), ("per_channel", C.c_int32),
-                ("scale", C.c_void_p)]
+                ("scale", C.c_void_p), ("packed_fwd", C.c_void_p), ("packed_bwd", C.c_void_p)]
 
 
 class ProfEntry(C.Structure):
@@ -127,6 +127,8 @@ PROTOTYPES = {
     "mn_qa_fwd": (_I, [_I, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _P]),
     "mn_qa_bwd_sums": (_I, [_I, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mn_qa_bwd_apply": (_I, [_I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
+    "mn_qd_packed_bytes": (_L, [_G]),
+    "mn_qd_pack_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "mn_qr_ws_floats": (_L, [_L]),
     "mn_qr_fwd": (_I, [_I, _P, _P, _I, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
     "mn_qr_bwd_sums": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -38,6 +38,8 @@ void mn_prof_end(hipStream_t s);
 typedef unsigned int u32x4 __attribute__((vector_size(16)));
 #ifdef MN_EMULATION
 __device__ __forceinline__ f32x4 mn_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) { return emu_mfma_f32_16x16x32_bf16(a, b, c); }
+typedef int i32x4 __attribute__((vector_size(16)));
+__device__ __forceinline__ i32x4 mn_mfma_i8(u32x4 a, u32x4 b, i32x4 c) { return emu_mfma_i32_16x16x64_i8(a, b, c); }
 __device__ __forceinline__ int mn_wave_any(int pred) { return emu_wave_any(pred); }
 __device__ __forceinline__ unsigned mn_f2u(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 __device__ __forceinline__ float mn_u2f(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
@@ -48,6 +50,13 @@ __device__ __forceinline__ f32x4 mn_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     v4f r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mn_bf16x8, a), __builtin_bit_cast(mn_bf16x8, b),
                                                     __builtin_bit_cast(v4f, c), 0, 0, 0);
     return __builtin_bit_cast(f32x4, r);
+}
+// v_mfma_i32_16x16x64_i8: signed bytes, A[i = lane&15][k = 16*(lane>>4) + e], B[k = 16*(lane>>4) + e][j = lane&15], D like the bf16 form; exact i32 accumulation
+typedef int i32x4 __attribute__((vector_size(16)));
+__device__ __forceinline__ i32x4 mn_mfma_i8(u32x4 a, u32x4 b, i32x4 c) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i r = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(v4i, a), __builtin_bit_cast(v4i, b), __builtin_bit_cast(v4i, c), 0, 0, 0);
+    return __builtin_bit_cast(i32x4, r);
 }
 __device__ __forceinline__ int mn_wave_any(int pred) { return __builtin_amdgcn_ballot_w64(pred != 0) != 0ull; }
 __device__ __forceinline__ unsigned mn_f2u(float f) { return __float_as_uint(f); }

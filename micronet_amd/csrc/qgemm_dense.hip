@@ -61,9 +61,7 @@ __device__ __forceinline__ bool qd_unit(const QdUnits& m, int u, int& q, int& im
 // code = rint(w * (2^bits - 1)): the integer 2k - n of a DoReFa weight (2k - n) / n (wqaq/dorefa/quantize.py:68-72); exact in bf16
 // IAO weights (wqaq/iao/quantize.py:227-239, symmetric): w = code * scale[o] -> code = rint(w / scale[o]) (wsc != nullptr; stride: floats between channels, 0 per layer)
 struct QdPackParams { const float* w; uint16_t* out; int O, C, T; float wn; int orient; int64_t ngroups; const float* wsc; int wsc_stride; };
-__global__ __launch_bounds__(256) void k_qd_pack(const QdPackParams p) {
-    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gi >= p.ngroups) return;
+__device__ __forceinline__ void qd_pack_group(const QdPackParams& p, int64_t gi) {
     const int lane = (int)(gi & 63);
     int64_t t = gi >> 6;
     const int nf = (int)(t & 3); t >>= 2;
@@ -88,6 +86,54 @@ __global__ __launch_bounds__(256) void k_qd_pack(const QdPackParams p) {
         h[e] = mn_f2u(p.wsc ? rintf(v / p.wsc[(int64_t)o * p.wsc_stride]) : rintf(v * p.wn)) >> 16;
     }
     *reinterpret_cast<u32x4*>(p.out + gi * 8) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+}
+// orient 2 (forward on v_mfma_i32_16x16x64_i8): [cot][chunk = c / 64][tap][nf = 0..3][lane][e = 0..15] signed bytes: o = 64 cot + 16 nf + (lane & 15),
+// c = 64 chunk + 16 (lane >> 4) + e; a group = 16 codes = 16 bytes
+__device__ __forceinline__ void qd_pack_group8(const QdPackParams& p, int64_t gi) {
+    const int lane = (int)(gi & 63);
+    int64_t t = gi >> 6;
+    const int nf = (int)(t & 3); t >>= 2;
+    const int tap = (int)(t % p.T); t /= p.T;
+    const int nch = p.C / 64;
+    const int chunk = (int)(t % nch), cot = (int)(t / nch);
+    const int o = cot * 64 + nf * 16 + (lane & 15), c0 = chunk * 64 + (lane >> 4) * 16;
+    const float isc = p.wsc ? p.wsc[(int64_t)o * p.wsc_stride] : 1.f;
+    uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float v = p.w[((int64_t)o * p.C + c0 + e) * p.T + tap];
+        const int code = (int)(p.wsc ? rintf(v / isc) : rintf(v * p.wn));
+        d[e >> 2] |= ((uint32_t)code & 0xffu) << (8 * (e & 3));
+    }
+    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(p.out) + gi * 16) = u32x4{d[0], d[1], d[2], d[3]};
+}
+__global__ __launch_bounds__(256) void k_qd_pack(const QdPackParams p) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= p.ngroups) return;
+    if (p.orient == 2) qd_pack_group8(p, gi); else qd_pack_group(p, gi);
+}
+// both orientations of up to QD_PACK_MAX weight tensors in ONE launch (mn_qd_pack_multi: once per training step, right after the weight quantizer)
+#define QD_PACK_MAX 32
+struct QdPackTable {
+    const float* w[QD_PACK_MAX]; uint16_t* outf[QD_PACK_MAX]; uint16_t* outd[QD_PACK_MAX]; const float* wsc[QD_PACK_MAX];
+    int O[QD_PACK_MAX], C[QD_PACK_MAX], T[QD_PACK_MAX], wsc_stride[QD_PACK_MAX], blk0[QD_PACK_MAX + 1];
+    int n; float wn; int fwd8;          // fwd8: the forward image in the int8 order (orient 2)
+};
+__global__ __launch_bounds__(256) void k_qd_pack_multi(const QdPackTable t) {
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.blk0[e + 1]) ++e;
+    QdPackParams p;
+    p.w = t.w[e]; p.O = t.O[e]; p.C = t.C[e]; p.T = t.T[e]; p.wn = t.wn; p.wsc = t.wsc[e]; p.wsc_stride = t.wsc_stride[e];
+    p.ngroups = (int64_t)p.O * p.C * p.T / 8;
+    const int nb = (int)((p.ngroups + 255) / 256);          // (the int8 image needs half of its blocks: the rest return)
+    int b = (int)blockIdx.x - t.blk0[e];
+    p.orient = b >= nb ? 1 : (t.fwd8 ? 2 : 0);
+    if (b >= nb) b -= nb;
+    p.out = p.orient == 1 ? t.outd[e] : t.outf[e];
+    if (p.orient == 2) p.ngroups /= 2;
+    const int64_t gi = (int64_t)b * 256 + threadIdx.x;
+    if (gi >= p.ngroups || !p.out) return;
+    if (p.orient == 2) qd_pack_group8(p, gi); else qd_pack_group(p, gi);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -331,6 +377,227 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd(const QdfParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward on the int8 matrix cores
+// The same organisation on v_mfma_i32_16x16x64_i8 (twice the bf16 rate, exact i32 accumulation for any K): the codes stay BYTES from HBM to the MFMA -- the
+// patch is [pixel slot][64 c] signed bytes (80-byte slots: a lane's A fragment = 16 consecutive channels of its pixel, one conflict-free b128 read), the weights
+// arrive as k_qd_pack orient 2 (4 KB per tap and chunk), one MFMA K-step = a whole 64-channel chunk of one tap.  Half the LDS bytes per MAC of the bf16 form.
+// Requires codes in [-128, 127]: DoReFa activations of <= 7 bits (0 .. 127), IAO activations (signed), weight codes of <= 7 (DoReFa) / <= 8 (IAO) bits.
+#define QD8_RS 80
+#define QD8_WSTEP 4096
+template <int MF, int TPS>
+__global__ __launch_bounds__(256, 2) void k_qd_fwd8(const QdfParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* wbuf = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* patch = wbuf + TPS * QD8_WSTEP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
+    if ((int)blockIdx.x >= p.nitems) return;
+    {
+        const int n16 = p.NI * p.PH * p.PW * (QD8_RS / 16);
+        for (int i = tid; i < n16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    }
+    int u_lds[QDF_UPT], u_goff[QDF_UPT], u_pi[QDF_UPT];
+#pragma unroll
+    for (int i = 0; i < QDF_UPT; ++i) {
+        int q, img, pr, d;
+        const bool v = qd_unit(p.units, tid + 256 * i, q, img, pr, d);
+        u_lds[i] = v ? ((img * p.PH + pr) * p.PW + 4 * d + p.PAD) * QD8_RS + 4 * q : -1;
+        u_goff[i] = v ? 4 * q * p.HW + 4 * d : 0;
+        u_pi[i] = pr | (img << 8);
+    }
+    uint32_t preg[QDF_UPT][4];
+    uint32_t pok = 0u;
+    auto tile_origin = [&](int item, int& n0, int& oh0, int& cot) {
+        const uint32_t tile = fd_div((uint32_t)item, p.fd_ncot);
+        cot = item - (int)tile * p.ncot;
+        if (p.NI == 1) { const uint32_t n = fd_div(tile, p.fd_tpi); n0 = (int)n; oh0 = ((int)tile - (int)n * p.tpi) * p.TH; }
+        else { n0 = (int)tile * p.NI; oh0 = 0; }
+    };
+    auto fetch_patch = [&](int item, int chunk) {
+        int n0, oh0, cot;
+        tile_origin(item, n0, oh0, cot);
+        const int ih0 = oh0 * p.S - p.PAD;
+        pok = 0u;
+#pragma unroll
+        for (int i = 0; i < QDF_UPT; ++i) {
+            int n = n0 + (u_pi[i] >> 8), ih = ih0 + (u_pi[i] & 255);
+            const bool ok = u_lds[i] >= 0 && n < p.N && ih >= 0 && ih < p.H;
+            n = n < p.N ? n : p.N - 1;
+            ih = ih < 0 ? 0 : (ih < p.H ? ih : p.H - 1);
+            const uint32_t base = (uint32_t)((n * p.C + chunk * 64) * p.H + ih) * (uint32_t)p.W + (uint32_t)u_goff[i];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) preg[i][cc] = *reinterpret_cast<const uint32_t*>(p.x + base + (uint32_t)(cc * p.HW));
+            pok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto commit_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < QDF_UPT; ++i) {
+            if (u_lds[i] < 0) continue;
+            const bool ok = (pok >> i) & 1u;
+            // 4 channels x 4 pixels of bytes, transposed: one dword (4 channels) per pixel
+            const uint32_t lo01 = mn_perm(preg[i][1], preg[i][0], 0x05010400u), hi01 = mn_perm(preg[i][1], preg[i][0], 0x07030602u);
+            const uint32_t lo23 = mn_perm(preg[i][3], preg[i][2], 0x05010400u), hi23 = mn_perm(preg[i][3], preg[i][2], 0x07030602u);
+            const uint32_t o0 = mn_perm(lo23, lo01, 0x05040100u), o1 = mn_perm(lo23, lo01, 0x07060302u);
+            const uint32_t o2 = mn_perm(hi23, hi01, 0x05040100u), o3 = mn_perm(hi23, hi01, 0x07060302u);
+            unsigned char* d = patch + u_lds[i];
+            *reinterpret_cast<uint32_t*>(d) = ok ? o0 : 0u;
+            *reinterpret_cast<uint32_t*>(d + QD8_RS) = ok ? o1 : 0u;
+            *reinterpret_cast<uint32_t*>(d + 2 * QD8_RS) = ok ? o2 : 0u;
+            *reinterpret_cast<uint32_t*>(d + 3 * QD8_RS) = ok ? o3 : 0u;
+        }
+    };
+    u32x4 wreg[TPS];
+    const int stride_items = (int)gridDim.x;
+    const int nsteps_chunk = p.TAPS / TPS;
+    const int steps_item = p.nchunks * nsteps_chunk;
+    const int my_items = (p.nitems - (int)blockIdx.x + stride_items - 1) / stride_items;
+    const int total_steps = my_items * steps_item;
+    auto item_wbase = [&](int item) {
+        const uint32_t tile = fd_div((uint32_t)item, p.fd_ncot);
+        const int cot = item - (int)tile * p.ncot;
+        return reinterpret_cast<const unsigned char*>(p.wpk) + (int64_t)cot * p.nchunks * p.TAPS * QD8_WSTEP + tid * 16;
+    };
+    const unsigned char* wsrc = item_wbase((int)blockIdx.x);
+    int w_item = (int)blockIdx.x, w_left = steps_item;
+    auto fetch_w = [&]() {
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) wreg[t] = *reinterpret_cast<const u32x4*>(wsrc + t * QD8_WSTEP);
+        wsrc += TPS * QD8_WSTEP;
+        if (--w_left == 0) { w_item += stride_items; w_left = steps_item; if (w_item < p.nitems) wsrc = item_wbase(w_item); }
+    };
+    auto commit_w = [&]() {
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) *reinterpret_cast<u32x4*>(wbuf + t * QD8_WSTEP + tid * 16) = wreg[t];
+    };
+    int abase[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int tp = wave * 16 * MF + mf * 16 + j;
+        const int ow = tp & (p.Wo - 1), t = tp >> p.wo_shift;
+        const uint32_t img = fd_div((uint32_t)t, p.fd_th);
+        const int ohl = t - (int)img * p.TH;
+        abase[mf] = (((int)img * p.PH + ohl * p.S) * p.PW + ow * p.S) * QD8_RS + kg * 16;
+    }
+    fetch_patch((int)blockIdx.x, 0);
+    fetch_w();
+    int gs = 0;
+    for (int item = (int)blockIdx.x; item < p.nitems; item += stride_items) {
+        i32x4 acc[MF][4];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = i32x4{0, 0, 0, 0};
+        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+            int nitem = item, nchunk = chunk + 1;
+            if (nchunk == p.nchunks) { nchunk = 0; nitem += stride_items; }
+            const bool have_next = nitem < p.nitems;
+            for (int st = 0; st < nsteps_chunk; ++st) {
+                __syncthreads();
+                if (st == 0) commit_patch();
+                commit_w();
+                __syncthreads();
+                if (gs + 1 < total_steps) fetch_w();
+                if (st == 0 && have_next) fetch_patch(nitem, nchunk);
+                ++gs;
+#pragma unroll
+                for (int tis = 0; tis < TPS; ++tis) {
+                    const int tap = st * TPS + tis;
+                    const int r = TPS == 9 ? tis / 3 : (TPS == 3 ? st : 0);
+                    const int toff = (r * p.PW + (tap - 3 * r)) * QD8_RS;
+                    const unsigned char* wb = wbuf + tis * QD8_WSTEP + lane * 16;
+                    u32x4 b[4], a[MF];
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) b[nf] = *reinterpret_cast<const u32x4*>(wb + nf * 1024);
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const u32x4*>(patch + abase[mf] + toff);
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = mn_mfma_i8(a[mf], b[nf], acc[mf][nf]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- epilogue: as k_qd_fwd (transposition through the wave's piece of the idle patch memory, 16-byte stores), on exact i32 values
+        int n0, oh0, cot;
+        tile_origin(item, n0, oh0, cot);
+        {
+            unsigned char* scr = wbuf + wave * (MF * 2048 + 64 * 8);          // weights and patch are both idle here: the scratch starts at the weight buffer
+            const int tp0 = wave * 16 * MF;
+            const int ipt = p.TH * p.Wo;
+            if (!p.out32) {
+                constexpr int ROW = 32 * MF + 8;
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+                        *reinterpret_cast<u32x2*>(scr + (nf * 16 + j) * ROW + (mf * 16 + 4 * kg) * 2) =
+                            u32x2{((uint32_t)acc[mf][nf][0] & 0xffffu) | ((uint32_t)acc[mf][nf][1] << 16), ((uint32_t)acc[mf][nf][2] & 0xffffu) | ((uint32_t)acc[mf][nf][3] << 16)};
+                MN_WAVE_SYNC();
+                constexpr int CPR = 2 * MF, RPI = 64 / CPR;
+#pragma unroll
+                for (int it = 0; it < 64 / RPI; ++it) {
+                    const int co = it * RPI + lane / CPR, ch = lane % CPR;
+                    const unsigned char* q = scr + co * ROW + ch * 16;
+                    const u32x2 a = *reinterpret_cast<const u32x2*>(q), b = *reinterpret_cast<const u32x2*>(q + 8);
+                    const int tp = tp0 + ch * 8;
+                    const int im = (int)fd_div((uint32_t)tp, p.fd_ipt), lp = tp - im * ipt;
+                    const int n = n0 + im;
+                    if (n < p.N)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<int16_t*>(p.stash) + (uint32_t)((n * p.O + cot * 64 + co) * p.HoWo + oh0 * p.Wo + lp)) = u32x4{a[0], a[1], b[0], b[1]};
+                }
+            } else {
+                constexpr int ROW = 64 * MF + 8;
+                float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.out32 == 2) {
+                    const float sa = p.sa[0];
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) {
+                        const int o = cot * 64 + nf * 16 + j;
+                        al[nf] = sa * p.sw[(int64_t)o * p.sw_stride];
+                        bi[nf] = p.bias ? p.bias[o] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2) {
+                            const int nf = half * 2 + n2;
+                            unsigned char* d = scr + (n2 * 16 + j) * ROW + (mf * 16 + 4 * kg) * 4;
+                            uint32_t w4[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) w4[r] = p.out32 == 2 ? mn_f2u((float)acc[mf][nf][r] * al[nf] + bi[nf]) : (uint32_t)acc[mf][nf][r];
+                            *reinterpret_cast<u32x2*>(d) = u32x2{w4[0], w4[1]};
+                            *reinterpret_cast<u32x2*>(d + 8) = u32x2{w4[2], w4[3]};
+                        }
+                    MN_WAVE_SYNC();
+                    constexpr int CPR = 4 * MF, RPI = 64 / CPR;
+#pragma unroll
+                    for (int it = 0; it < 32 / RPI; ++it) {
+                        const int cl = it * RPI + lane / CPR, ch = lane % CPR;
+                        const unsigned char* q = scr + cl * ROW + ch * 16;
+                        const u32x2 a = *reinterpret_cast<const u32x2*>(q), b = *reinterpret_cast<const u32x2*>(q + 8);
+                        const int tp = tp0 + ch * 4;
+                        const int im = (int)fd_div((uint32_t)tp, p.fd_ipt), lp = tp - im * ipt;
+                        const int n = n0 + im;
+                        if (n < p.N)
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<int32_t*>(p.stash) + (uint32_t)((n * p.O + cot * 64 + half * 32 + cl) * p.HoWo + oh0 * p.Wo + lp)) =
+                                u32x4{a[0], a[1], b[0], b[1]};
+                    }
+                    MN_WAVE_SYNC();
+                }
+            }
+        }
+        if (item + stride_items < p.nitems) {
+            __syncthreads();
+            constexpr int over = 4 * (MF * 2048 + 512) - TPS * QD8_WSTEP;          // bytes of the patch the scratch covered: the zero frame again
+            for (int i = tid; i < over / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+
 // exact integer sums of the stash per channel: part[(sp * O + c) * 2 + {0, 1}] = sum acc, sum acc^2 of split sp
 template <int IN32>
 __global__ __launch_bounds__(256) void k_qd_stats(const void* __restrict__ stash, int N, int O, int HW, double* __restrict__ part) {
@@ -361,7 +628,7 @@ __global__ __launch_bounds__(256) void k_qd_stats(const void* __restrict__ stash
 }
 
 // ------------------------------------------------------------------------------------------------ host side: forward
-struct QdfPlan { QdfParams p; int MF, grid; size_t lds; int64_t off_part, off_scale, ws_bytes; int S_stats; };
+struct QdfPlan { QdfParams p; int MF, grid, i8, TPS; size_t lds; int64_t off_part, off_scale, ws_bytes; int S_stats; };
 static int qd_log2(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
 static int qd_geom_ok(const mn_conv_geom* g) {
     if (!g || g->groups != 1 || g->in_shuffle > 1 || g->dil_h != 1 || g->dil_w != 1 || g->C % 64 || g->O % 64 || g->N < 1) return 0;
@@ -372,9 +639,11 @@ static int qd_geom_ok(const mn_conv_geom* g) {
     if (MN_ENV("MN_NO_QD")) return 0;          // A/B knob: the generic kernels
     return 1;
 }
-static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
+static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl, int i8 = 0) {
     if (!qd_geom_ok(g)) return 0;
     QdfParams& p = pl->p;
+    const int RS = i8 ? QD8_RS : QD_RS;
+    pl->i8 = i8;
     p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.S = g->stride_h; p.PAD = g->pad_h; p.TAPS = g->KH * g->KW;
     p.Ho = (g->H + 2 * g->pad_h - g->KH) / p.S + 1; p.Wo = (g->W + 2 * g->pad_w - g->KW) / p.S + 1;
     p.HW = g->H * g->W; p.HoWo = p.Ho * p.Wo;
@@ -389,9 +658,9 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
         else { if (BM % p.HoWo) continue; NI = BM / p.HoWo; TH = p.Ho; }
         const int PH = (TH - 1) * p.S + g->KH, PW = g->W + 2 * g->pad_w;          // staging writes whole input rows
         if (PH > 255 || NI > 255) continue;
-        const int64_t patch = (int64_t)NI * PH * PW * QD_RS;
+        const int64_t patch = (int64_t)NI * PH * PW * RS;
         const QdUnits units = qd_make_units(g->W / 4, PH, NI, 16);
-        if (patch > 56 * 1024 || units.nunits > 256 * QDF_UPT || patch < 4 * (mf * 2048 + 512)) continue;      // (the epilogue borrows the patch memory)
+        if (patch > 56 * 1024 || units.nunits > 256 * QDF_UPT || (!i8 && patch < 4 * (mf * 2048 + 512))) continue;      // (the epilogue borrows the patch memory)
         MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.nunits = units.nunits; p.units = units;
         break;
     }
@@ -408,7 +677,10 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
     int tgt = 512;
     if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }     // tuning knob
     pl->grid = p.nitems < tgt ? p.nitems : tgt;
-    pl->lds = (size_t)(p.TAPS == 9 ? 3 : 1) * QD_WSTEP + (size_t)p.NI * p.PH * p.PW * QD_RS;
+    pl->TPS = p.TAPS == 9 ? 3 : 1;
+    if (i8 && p.TAPS == 9) { if (const char* e = MN_ENV("MN_QD8_TPS")) { if (atoi(e) == 9) pl->TPS = 9; } }          // A/B knob
+    pl->lds = (size_t)pl->TPS * (i8 ? QD8_WSTEP : QD_WSTEP) + (size_t)p.NI * p.PH * p.PW * RS;
+    if (i8 && pl->lds < (size_t)4 * (MF * 2048 + 512)) pl->lds = (size_t)4 * (MF * 2048 + 512);          // its epilogue scratch starts at the weight buffer
     // workspace: packed weights | statistics partials [S][O][2] doubles | per-channel weight scale [O]
     const int64_t pack_bytes = ((int64_t)g->O * g->C * p.TAPS * 2 + 255) / 256 * 256;
     int S = (2048 + g->O - 1) / g->O;
@@ -424,12 +696,23 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl) {
 }
 static void qd_launch_pack(const float* w, uint16_t* out, int O, int C, int T, int w_bits, int orient, hipStream_t s, const float* wsc = nullptr, int wsc_stride = 0) {
     QdPackParams k;
-    k.w = w; k.out = out; k.O = O; k.C = C; k.T = T; k.wn = (float)((1ll << w_bits) - 1); k.orient = orient; k.ngroups = (int64_t)O * C * T / 8;
+    k.w = w; k.out = out; k.O = O; k.C = C; k.T = T; k.wn = (float)((1ll << w_bits) - 1); k.orient = orient; k.ngroups = (int64_t)O * C * T / (orient == 2 ? 16 : 8);
     k.wsc = wsc; k.wsc_stride = wsc_stride;
     hipLaunchKernelGGL(k_qd_pack, dim3((unsigned)((k.ngroups + 255) / 256)), dim3(256), 0, s, k);
 }
+template <int MF, int TPS>
+static void qd_launch_fwd8_t(const QdfPlan& pl, hipStream_t s) {
+    raise_lds_limit((const void*)k_qd_fwd8<MF, TPS>, pl.lds);
+    hipLaunchKernelGGL((k_qd_fwd8<MF, TPS>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
+}
 static void qd_launch_fwd(const QdfPlan& pl, hipStream_t s) {
     const QdfParams& p = pl.p;
+    if (pl.i8) {
+        if (pl.TPS == 9) { if (pl.MF == 4) qd_launch_fwd8_t<4, 9>(pl, s); else if (pl.MF == 2) qd_launch_fwd8_t<2, 9>(pl, s); else qd_launch_fwd8_t<1, 9>(pl, s); }
+        else if (pl.TPS == 3) { if (pl.MF == 4) qd_launch_fwd8_t<4, 3>(pl, s); else if (pl.MF == 2) qd_launch_fwd8_t<2, 3>(pl, s); else qd_launch_fwd8_t<1, 3>(pl, s); }
+        else { if (pl.MF == 4) qd_launch_fwd8_t<4, 1>(pl, s); else if (pl.MF == 2) qd_launch_fwd8_t<2, 1>(pl, s); else qd_launch_fwd8_t<1, 1>(pl, s); }
+        return;
+    }
     if (p.TAPS == 9) {
         if (pl.MF == 4) { raise_lds_limit((const void*)k_qd_fwd<4, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<4, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
         else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_fwd<2, 3>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<2, 3>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
@@ -440,6 +723,11 @@ static void qd_launch_fwd(const QdfPlan& pl, hipStream_t s) {
         else { raise_lds_limit((const void*)k_qd_fwd<1, 1>, pl.lds); hipLaunchKernelGGL((k_qd_fwd<1, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
     }
 }
+// the forward runs on the int8 matrix cores whenever the weight codes fit signed bytes (activation codes always do: DoReFa <= 7 bits unsigned, IAO signed)
+static int qd_fwd_i8(const mn_wq* wq) {
+    if (MN_ENV("MN_NO_QD8")) return 0;          // A/B knob: the bf16 forward
+    return wq && ((wq->mode == MN_WQ_DOREFA && wq->bits <= 7) || (wq->mode == MN_WQ_IAO && wq->bits <= 8));
+}
 // the stash of a dense layer is 32 bits wide when K * amax * wmax does not fit 16
 int qd_stash32(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
     const int64_t K = (int64_t)g->C * g->KH * g->KW, wmax = (1ll << wq->bits) - 1, amax = (1ll << a_bits) - 1;
@@ -448,23 +736,25 @@ int qd_stash32(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
 int qd_fwd_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
     if (!wq || wq->mode != MN_WQ_DOREFA || wq->bits < 2 || wq->bits > 8 || a_bits < 2 || a_bits > 7 || !g) return 0;
     const int64_t K = (int64_t)g->C * g->KH * g->KW, wmax = (1ll << wq->bits) - 1, amax = (1ll << a_bits) - 1;
-    if (K * amax * wmax >= (1ll << 24)) return 0;          // the fp32 accumulation of integer products must stay exact
+    const int i8 = qd_fwd_i8(wq);
+    if (!i8 && K * amax * wmax >= (1ll << 24)) return 0;          // bf16 forward: the fp32 accumulation of integer products must stay exact (i32 always is)
+    if (K * amax * wmax >= (1ll << 31)) return 0;
     QdfPlan pl;
-    return plan_qdf(g, 0, &pl);
+    return plan_qdf(g, 0, &pl, i8);
 }
-int64_t qd_fwd_ws_bytes(const mn_conv_geom* g) { QdfPlan pl; return plan_qdf(g, 0, &pl) ? pl.ws_bytes : 0; }
+int64_t qd_fwd_ws_bytes(const mn_conv_geom* g) { QdfPlan pl; return (plan_qdf(g, 0, &pl, 0) || plan_qdf(g, 0, &pl, 1)) ? pl.ws_bytes : 0; }          // (the layout does not depend on the variant)
 // conv on activation codes -> stash (int16 / int32 by qd_stash32) + statistics partials; *parts / *nparts / *rowscale: what qa_launch_stats_prep reads
 int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a_bits, const float* w, void* stash, void* ws, int64_t ws_bytes, hipStream_t s,
                  const double** parts, int* nparts, float** rowscale) {
     QdfPlan pl;
-    const int out32 = qd_stash32(g, wq, a_bits);
-    if (!qd_fwd_supported(g, wq, a_bits) || !plan_qdf(g, out32, &pl) || (((uintptr_t)x) & 3) || !aligned16(stash) || !w) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnq_fwd_stash(dense): geometry not covered");
+    const int out32 = qd_stash32(g, wq, a_bits), i8 = qd_fwd_i8(wq);
+    if (!qd_fwd_supported(g, wq, a_bits) || !plan_qdf(g, out32, &pl, i8) || (((uintptr_t)x) & 3) || !aligned16(stash) || !w) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnq_fwd_stash(dense): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_qconv_bnq_fwd_stash(dense): workspace too small");
     QdfParams& p = pl.p;
-    uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
-    qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 0, s);
+    const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_fwd);
+    if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.x = x; p.wpk = wpk; p.stash = stash; p.xsgn = 0; p.sa = p.sw = p.bias = nullptr; p.sw_stride = 0;
-    mn_set_last_kernel("k_qd_fwd<%d, %d>", pl.MF, p.TAPS == 9 ? 3 : 1);
+    mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     qd_launch_fwd(pl, s);
@@ -771,8 +1061,8 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
     if (!qd_dgrad_supported(g, wq) || !plan_qdd(g, &pl) || !aligned16(gy) || !aligned16(dx) || !w) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data(dense): workspace too small");
     QddParams& p = pl.p;
-    uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
-    qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 1, s);
+    const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_bwd);
+    if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
@@ -1132,19 +1422,19 @@ static int qd_iao_quant_ok(const mn_conv_geom* g, const mn_actq* aq, const mn_wq
         wmax = (1ll << (wq->bits - 1)) - 1;
     }
     const int64_t K = (int64_t)g->C * g->KH * g->KW, amax = 1ll << (aq->bits - 1);
-    if (K * amax * wmax >= (1ll << 24)) return 0;          // the fp32 accumulation of integer products must stay exact
+    if (need_w == 1 && !qd_fwd_i8(wq) && K * amax * wmax >= (1ll << 24)) return 0;          // bf16 forward only: the fp32 accumulation of integer products must stay exact
     if (((int64_t)g->N * g->C * g->H * g->W) % 8) return 0;
     return 1;
 }
 static int64_t qd_iao_codes_bytes(const mn_conv_geom* g) { return ((int64_t)g->N * g->C * g->H * g->W + 255) / 256 * 256; }
 int qd_iao_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
-    if (which == 0) { QdfPlan pl; return qd_iao_quant_ok(g, aq, wq, 1) && plan_qdf(g, 2, &pl); }
-    if (which == 1) { QddPlan pl; return qd_iao_quant_ok(g, aq, wq, 1) && plan_qdd(g, &pl); }
+    if (which == 0) { QdfPlan pl; return qd_iao_quant_ok(g, aq, wq, 1) && plan_qdf(g, 2, &pl, qd_fwd_i8(wq)); }
+    if (which == 1) { QddPlan pl; return qd_iao_quant_ok(g, aq, wq, 2) && plan_qdd(g, &pl); }
     if (which == 2) { QdwPlan pl; return qd_iao_quant_ok(g, aq, nullptr, 0) && plan_qdw(g, &pl); }
     return 0;
 }
 int64_t qd_iao_ws_bytes(const mn_conv_geom* g, int which) {
-    if (which == 0) { QdfPlan pl; return plan_qdf(g, 2, &pl) ? qd_iao_codes_bytes(g) + pl.ws_bytes : 0; }
+    if (which == 0) { QdfPlan pl; return (plan_qdf(g, 2, &pl, 0) || plan_qdf(g, 2, &pl, 1)) ? qd_iao_codes_bytes(g) + pl.ws_bytes : 0; }
     if (which == 1) { QddPlan pl; return plan_qdd(g, &pl) ? pl.ws_bytes : 0; }
     if (which == 2) { QdwPlan pl; return plan_qdw(g, &pl) ? qd_iao_codes_bytes(g) + pl.ws_bytes : 0; }
     return 0;
@@ -1159,15 +1449,19 @@ static void qd_iao_launch_codes(const mn_conv_geom* g, const mn_actq* aq, const 
 int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes,
                hipStream_t s) {
     QdfPlan pl;
-    if (!qd_iao_quant_ok(g, aq, wq, 1) || !plan_qdf(g, 2, &pl) || !aligned16(x) || !aligned16(y) || !w) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(dense iao): geometry / quantizer not covered");
+    const int i8 = qd_fwd_i8(wq);
+    if (!qd_iao_quant_ok(g, aq, wq, 1) || !plan_qdf(g, 2, &pl, i8) || !aligned16(x) || !aligned16(y) || !w) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(dense iao): geometry / quantizer not covered");
     const int64_t cb = qd_iao_codes_bytes(g);
     if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(dense iao): workspace too small");
     QdfParams& p = pl.p;
     qd_iao_launch_codes(g, aq, x, ws, s);
-    uint16_t* wpk = reinterpret_cast<uint16_t*>((char*)ws + cb);
-    qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 0, s, wq->scale, wq->per_channel);
+    const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_fwd);
+    if (!wpk) {
+        qd_launch_pack(w, reinterpret_cast<uint16_t*>((char*)ws + cb), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s, wq->scale, wq->per_channel);
+        wpk = reinterpret_cast<const uint16_t*>((char*)ws + cb);
+    }
     p.x = (const unsigned char*)ws; p.wpk = wpk; p.stash = y; p.xsgn = 1; p.sa = aq->qp; p.sw = wq->scale; p.sw_stride = wq->per_channel; p.bias = bias;
-    mn_set_last_kernel("k_qd_fwd<%d, %d>", pl.MF, p.TAPS == 9 ? 3 : 1);
+    mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + 4.0 * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     qd_launch_fwd(pl, s);
@@ -1178,12 +1472,12 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
 int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx, void* ws, int64_t ws_bytes,
                     hipStream_t s) {
     QddPlan pl;
-    if (!qd_iao_quant_ok(g, aq, wq, 1) || !plan_qdd(g, &pl) || !aligned16(gy) || !aligned16(dx) || !aligned16(x) || !w)
+    if (!qd_iao_quant_ok(g, aq, wq, 2) || !plan_qdd(g, &pl) || !aligned16(gy) || !aligned16(dx) || !aligned16(x) || !w)
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense iao): geometry / quantizer not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data(dense iao): workspace too small");
     QddParams& p = pl.p;
-    uint16_t* wpk = reinterpret_cast<uint16_t*>(ws);
-    qd_launch_pack(w, wpk, g->O, g->C, p.TAPS, wq->bits, 1, s, wq->scale, wq->per_channel);
+    const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_bwd);
+    if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s, wq->scale, wq->per_channel); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f; p.wsc = wq->scale; p.wsc_stride = wq->per_channel;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
@@ -1205,4 +1499,39 @@ int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy,
     if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense iao): workspace too small");
     qd_iao_launch_codes(g, aq, x, ws, s);
     return qd_bwd_weight_ex(g, gy, (const uint8_t*)ws, 1, 1.f, aq->qp, dw, (char*)ws + cb, ws_bytes - cb, s);
+}
+
+
+// ================================================================================================ weight codes of a whole net in one launch
+extern "C" int64_t mn_qd_packed_bytes(const mn_conv_geom* g) {
+    if (!g || !qd_geom_ok(g)) return 0;
+    return ((int64_t)g->O * g->C * g->KH * g->KW * 2 + 255) / 256 * 256;
+}
+extern "C" int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, void* const* out_bwd, const int64_t* O, const int64_t* Cin, const int64_t* taps,
+                                const float* const* wscale, const int32_t* wscale_stride, int32_t count, int w_bits, mn_stream_t stream) {
+    if (count <= 0) return MN_OK;
+    if (!w || !out_fwd || !out_bwd || !O || !Cin || !taps || w_bits < 2 || w_bits > 8) MN_FAIL(MN_EINVAL, "mn_qd_pack_multi: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < count; base += QD_PACK_MAX) {
+        QdPackTable t;
+        t.n = count - base < QD_PACK_MAX ? count - base : QD_PACK_MAX;
+        t.wn = (float)((1ll << w_bits) - 1);
+        { mn_wq q; q.mode = wscale ? MN_WQ_IAO : MN_WQ_DOREFA; q.bits = w_bits; t.fwd8 = qd_fwd_i8(&q); }
+        int blk = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const int k = base + i;
+            if (!w[k] || O[k] % 64 || Cin[k] % 64 || (taps[k] != 9 && taps[k] != 1) || (out_fwd[k] && !aligned16(out_fwd[k])) || (out_bwd[k] && !aligned16(out_bwd[k])))
+                MN_FAIL(MN_EINVAL, "mn_qd_pack_multi: tensor %d is not a dense-family weight (O, C multiples of 64; 9 or 1 taps) or its output is misaligned", k);
+            t.w[i] = w[k]; t.outf[i] = (uint16_t*)out_fwd[k]; t.outd[i] = (uint16_t*)out_bwd[k]; t.wsc[i] = wscale ? wscale[k] : nullptr;
+            t.wsc_stride[i] = (wscale && wscale_stride) ? wscale_stride[k] : 0;
+            t.O[i] = (int)O[k]; t.C[i] = (int)Cin[k]; t.T[i] = (int)taps[k];
+            t.blk0[i] = blk;
+            blk += 2 * (int)((O[k] * Cin[k] * taps[k] / 8 + 255) / 256);
+        }
+        t.blk0[t.n] = blk;
+        mn_set_last_kernel("k_qd_pack_multi");
+        hipLaunchKernelGGL(k_qd_pack_multi, dim3((unsigned)blk), dim3(256), 0, s, t);
+    }
+    MN_CHECK_LAUNCH("mn_qd_pack_multi");
+    return MN_OK;
 }

@@ -229,7 +229,7 @@ extern "C" int mn_dorefa_act_bwd(const float* g, const float* x, float* dx, int6
 __device__ __forceinline__ float mn_tanh_cr(float x) { return (float)tanh((double)x); }
 // DoReFa weight (61-73): global max of |tanh w| -> normalise -> round -> 2q-1.
 // ws layout (floats): [0] M, [1] dM (bwd), [2] tie count (bwd), [16 .. 16+3*NB) per-block partials.
-static const int DW_NB = 128;  // partial blocks
+static const int DW_NB = 1024;  // partial blocks per tensor (a 2.4 M-element resnet layer: 9 elements per thread; 128 blocks left the absmax pass latency-bound at 97 us)
 extern "C" int64_t mn_dorefa_w_ws_floats(int64_t) { return 16 + 3 * DW_NB; }
 
 __global__ __launch_bounds__(256) void k_dorefa_w_absmax(const float* __restrict__ w, int64_t n, float* __restrict__ ws) {

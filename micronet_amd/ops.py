@@ -929,11 +929,54 @@ def qconv_bnq_supported(x, wq, stride, padding, dilation, groups, w_bits, in_shu
     return bool(_lib_().mn_qconv_bnq_supported(C.byref(g), C.byref(wd), x.bits))
 
 
-def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw):
+def _wq_dorefa(w_bits, packed=None, which=0):
+    """mn_wq of DoReFa weights; ``packed`` = the (forward, backward-data) code images mn_qd_pack_multi wrote for this step's weights (or None)."""
+    wd = WQ(WQ_DOREFA, w_bits, 0, 0, None)
+    if packed is not None:
+        if which == 0 and packed[0] is not None:
+            wd.packed_fwd = packed[0].data_ptr()
+        if which == 1 and packed[1] is not None:
+            wd.packed_bwd = packed[1].data_ptr()
+    return wd
+
+
+def pack_dense_weights(mods_wq, w_bits):
+    """One launch writing the weight codes of every dense-family conv (both fragment orders) for this step: ``mods_wq`` = [(conv module, quantised weight)].
+    The images ride on the quantised weight tensor (``_mn_packed``) to the convs' forward and backward."""
+    lib = _lib_()
+    items = []
+    for m, wq in mods_wq:
+        if wq.dim() != 4 or not wq.is_cuda or getattr(m, "groups", 1) != 1 or wq.shape[0] % 64 or wq.shape[1] % 64:
+            continue
+        g = _geom((1, wq.shape[1], 8, 8), wq.shape, m.stride, m.padding, m.dilation, 1, 0)
+        nb = int(lib.mn_qd_packed_bytes(C.byref(g)))
+        if nb <= 0:
+            continue
+        items.append((wq, nb))
+    if not items:
+        return
+    n = len(items)
+    dev = items[0][0].device
+    total = sum(2 * nb for _, nb in items)
+    buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    outs, off = [], 0
+    for wq, nb in items:
+        outs.append((buf[off:off + nb], buf[off + nb:off + 2 * nb]))
+        off += 2 * nb
+    PA, LA = C.c_void_p * n, C.c_int64 * n
+    with torch.cuda.device_of(buf):
+        _call("mn_qd_pack_multi", PA(*[wq.data_ptr() for wq, _ in items]), PA(*[o[0].data_ptr() for o in outs]), PA(*[o[1].data_ptr() for o in outs]),
+              LA(*[wq.shape[0] for wq, _ in items]), LA(*[wq.shape[1] for wq, _ in items]), LA(*[wq.shape[2] * wq.shape[3] for wq, _ in items]),
+              None, None, n, w_bits, _s())
+    for (wq, _), o in zip(items, outs):
+        wq._mn_packed = o
+
+
+def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw, packed=None):
     """(dq, dw) of a conv on activation codes: mn_conv2d_bwd_data without clip-STE, mn_conv2d_bwd_weight on the codes."""
     gy = _chk(gy, "grad")
     aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
-    wd = WQ(WQ_DOREFA, w_bits, 0, 0, None)
+    wd = _wq_dorefa(w_bits, packed, 1)
     dq = dw = None
     if need_dx:
         dq = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
@@ -962,6 +1005,7 @@ class QConvCodeLazy(Function):
         ctx.save_for_backward(codes, wq)
         ctx.cfg = (g, a_bits, w_bits, bias is not None)
         ctx.x_ref = x
+        ctx.packed = packed = getattr(wq, "_mn_packed", None)
 
         def compute():          # a foreign consumer: the ordinary conv kernels on the materialised activation, quantizer in their prologue
             xa = x.materialize()
@@ -969,7 +1013,7 @@ class QConvCodeLazy(Function):
                 xa = channel_shuffle(xa, in_shuffle)
             return QConv2d.apply(xa, wq, bias, stride, padding, dilation, groups, ACTQ_DOREFA, a_bits, 0, None, (WQ_DOREFA, w_bits, 0, 0, None), 0, 0)
         Ho, Wo = _out_hw(g)
-        recipe = dict(codes=codes, a_bits=a_bits, wq=wq, bias=bias, geom=g, w_bits=w_bits, compute=compute, out_hw=(Ho, Wo),
+        recipe = dict(codes=codes, a_bits=a_bits, wq=wq, bias=bias, geom=g, w_bits=w_bits, compute=compute, out_hw=(Ho, Wo), packed=packed,
                       stash_bits=int(_lib_().mn_qconv_bnq_stash_bits(C.byref(g), C.byref(WQ(WQ_DOREFA, w_bits, 0, 0, None)), a_bits)))
         return LazyQConvOut((g.N, g.O, Ho, Wo), codes.device, recipe)
 
@@ -980,7 +1024,7 @@ class QConvCodeLazy(Function):
         x = ctx.x_ref
         gy = _chk(gy, "grad")
         aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
-        wd = WQ(WQ_DOREFA, w_bits, 0, 0, None)
+        wd = _wq_dorefa(w_bits, ctx.packed, 1)
         dx = dw = db = None
         with torch.cuda.device_of(codes):
             if ctx.needs_input_grad[0]:
@@ -1010,13 +1054,14 @@ class QConvCodeLazy2(Function):
         codes, a_bits = x.codes, x.bits
         wq1, wq2 = _chk(wq1, "weight"), _chk(wq2, "weight")
         outs, geoms = [], []
+        ctx.packed = (getattr(wq1, "_mn_packed", None), getattr(wq2, "_mn_packed", None))
         for wq, (stride, padding, dilation, groups) in ((wq1, cfg1), (wq2, cfg2)):
             g = _geom(codes.shape, wq.shape, stride, padding, dilation, groups, 0)
             Ho, Wo = _out_hw(g)
 
             def compute(wq=wq, stride=stride, padding=padding, dilation=dilation, groups=groups):
                 return QConv2d.apply(x.materialize(), wq, None, stride, padding, dilation, groups, ACTQ_DOREFA, a_bits, 0, None, (WQ_DOREFA, w_bits, 0, 0, None), 0, 0)
-            recipe = dict(codes=codes, a_bits=a_bits, wq=wq, bias=None, geom=g, w_bits=w_bits, compute=compute, out_hw=(Ho, Wo),
+            recipe = dict(codes=codes, a_bits=a_bits, wq=wq, bias=None, geom=g, w_bits=w_bits, compute=compute, out_hw=(Ho, Wo), packed=getattr(wq, "_mn_packed", None),
                           stash_bits=int(_lib_().mn_qconv_bnq_stash_bits(C.byref(g), C.byref(WQ(WQ_DOREFA, w_bits, 0, 0, None)), a_bits)))
             outs.append(LazyQConvOut((g.N, g.O, Ho, Wo), codes.device, recipe))
             geoms.append(g)
@@ -1031,8 +1076,8 @@ class QConvCodeLazy2(Function):
         geoms, a_bits, w_bits = ctx.cfg
         x = ctx.x_ref
         with torch.cuda.device_of(codes):
-            dq1, dw1 = _code_conv_backward(geoms[0], a_bits, w_bits, codes, wq1, gy1, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-            dq2, dw2 = _code_conv_backward(geoms[1], a_bits, w_bits, codes, wq2, gy2, ctx.needs_input_grad[0], ctx.needs_input_grad[2])
+            dq1, dw1 = _code_conv_backward(geoms[0], a_bits, w_bits, codes, wq1, gy1, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.packed[0])
+            dq2, dw2 = _code_conv_backward(geoms[1], a_bits, w_bits, codes, wq2, gy2, ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.packed[1])
         dx = None
         if ctx.needs_input_grad[0]:
             def expand(dq_, dq2_=dq2):
@@ -1081,7 +1126,7 @@ def _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training
         src = torch.empty((N, Cc, H, W), dtype=torch.int32 if wide else torch.int16, device=dev)
         save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
         chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
-        wd = WQ(WQ_DOREFA, r["w_bits"], 0, 0, None)
+        wd = _wq_dorefa(r["w_bits"], r.get("packed"), 0)
         with torch.cuda.device(dev):
             nb = int(lib.mn_qconv_bnq_ws_bytes(C.byref(g)))
             ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)

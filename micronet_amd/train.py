@@ -88,6 +88,8 @@ def prefetch_weight_path(model, side=None):
                 qws = ops.MultiDorefaWeight.apply(bits, *[m.weight for m in grp])
                 for m, wq in zip(grp, qws):
                     m.weight_quantizer._mn_pre = (m.weight, wq, None)
+                if 2 <= bits <= 8:          # the dense layers (ResNets): their weight codes in both fragment orders, one launch for the net
+                    ops.pack_dense_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], bits)
     mods = [m for m in model.modules() if isinstance(m, wb.QuantConv2d) and not m.quant_inference and m.weight_quantizer.W in (2, 3)]
     for m in mods:
         m.weight_quantizer.__dict__.pop("_mn_pre", None)

@@ -70,6 +70,7 @@ struct Ctx {
     std::vector<double> wbuf;
     std::vector<float> wa, wb;
     std::vector<float> wa8, wb8;   // bf16 MFMA operands, 8 per lane
+    std::vector<int> wi16a, wi16b; // int8 MFMA operands, 16 per lane
     std::vector<int> wflag;
 };
 inline Ctx& C() { static Ctx c; return c; }
@@ -109,6 +110,8 @@ inline void run_block(unsigned nthreads, dim3 bdim) {
     c.wb.assign(nw * 64, 0.f);
     c.wa8.assign(nw * 64 * 8, 0.f);
     c.wb8.assign(nw * 64 * 8, 0.f);
+    c.wi16a.assign(nw * 64 * 16, 0);
+    c.wi16b.assign(nw * 64 * 16, 0);
     c.wflag.assign(nw * 64, 0);
     for (unsigned i = 0; i < nthreads; ++i) {
         Fiber& f = c.fibers[i];
@@ -244,6 +247,27 @@ static inline __emu_f32x4 emu_mfma_f32_16x16x32_bf16(__emu_u32x4 a, __emu_u32x4 
         float acc = c[r];
         for (int kg = 0; kg < 4; ++kg)
             for (int e = 0; e < 8; ++e) acc = fmaf(cx.wa8[(base + kg * 16 + row) * 8 + e], cx.wb8[(base + kg * 16 + col) * 8 + e], acc);
+        c[r] = acc;
+    }
+    emu::yield(emu::WAIT_WAVE);
+    return c;
+}
+// v_mfma_i32_16x16x64_i8: A[i = lane&15][k = 16*(lane>>4) + e], B[k = 16*(lane>>4) + e][j = lane&15] (signed bytes, little endian in the four dwords), D as above
+typedef int __emu_i32x4 __attribute__((vector_size(16)));
+static inline __emu_i32x4 emu_mfma_i32_16x16x64_i8(__emu_u32x4 a, __emu_u32x4 b, __emu_i32x4 c) {
+    emu::Ctx& cx = emu::C();
+    int base = (emu::flat_tid() / 64) * 64, l = emu::lane();
+    for (int e = 0; e < 16; ++e) {
+        cx.wi16a[(base + l) * 16 + e] = (int)(signed char)((a[e >> 2] >> ((e & 3) * 8)) & 0xffu);
+        cx.wi16b[(base + l) * 16 + e] = (int)(signed char)((b[e >> 2] >> ((e & 3) * 8)) & 0xffu);
+    }
+    emu::yield(emu::WAIT_WAVE);
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        int acc = c[r];
+        for (int kg = 0; kg < 4; ++kg)
+            for (int e = 0; e < 16; ++e) acc += cx.wi16a[(base + kg * 16 + row) * 16 + e] * cx.wi16b[(base + kg * 16 + col) * 16 + e];
         c[r] = acc;
     }
     emu::yield(emu::WAIT_WAVE);

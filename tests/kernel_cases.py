@@ -1021,7 +1021,7 @@ def check_qa_thresholds(be, bits=2, pool=False, seed=0):
 
 
 # ----------------------------------------------------------------------------- dense layers on activation codes (qgemm_dense.hip): the ResNet family
-def check_qdense(be, x_shape, Oc, k=3, stride=1, a_bits=2, w_bits=2, seed=0):
+def check_qdense(be, x_shape, Oc, k=3, stride=1, a_bits=2, w_bits=2, seed=0, prepack=False):
     """mn_qconv_bnq_fwd_stash / mn_conv2d_bwd_data / mn_conv2d_bwd_weight on activation codes for a DENSE layer (groups = 1, C and O multiples of 64; 3x3 stride 1 / 2,
     1x1 stride 2: models/resnet.py:7-65 under wqaq/dorefa/quantize.py:107-122): the stash (16 or 32 bits by mn_qconv_bnq_stash_bits) equals the exact integer conv,
     the batch statistics follow, and both gradients agree with an fp64 evaluation of torch's conv backward to the float-accumulate tolerance."""
@@ -1045,14 +1045,26 @@ def check_qdense(be, x_shape, Oc, k=3, stride=1, a_bits=2, w_bits=2, seed=0):
     nb = int(be.lib.mn_qconv_bnq_ws_bytes(C.byref(g)))
     ws = be.empty(nb // 4 + 8)
     dX, dW = be.to_dev_u8(codes), be.to_dev(w)
+    if prepack:         # the weight codes written once by mn_qd_pack_multi (both fragment orders) instead of by every call
+        pb = int(be.lib.mn_qd_packed_bytes(C.byref(g)))
+        assert pb == (Oc * Cin * k * k * 2 + 255) // 256 * 256
+        pk_f, pk_b = be.empty_i8((pb,)), be.empty_i8((pb,))
+        PA, LA = C.c_void_p * 1, C.c_int64 * 1
+        be.call("mn_qd_pack_multi", PA(be.ptr(dW).value), PA(be.ptr(pk_f).value), PA(be.ptr(pk_b).value), LA(Oc), LA(Cin), LA(k * k), None, None, 1, w_bits, be.stream)
+        wq.packed_fwd, wq.packed_bwd = be.ptr(pk_f).value, be.ptr(pk_b).value
+        dW_call = be.to_dev(np.full(w_shape, np.nan, dtype=F))       # the fp32 weights must not be read again
+    else:
+        dW_call = dW
     gamma, beta = (r.standard_normal(Oc) * 0.5 + 1).astype(F), (r.standard_normal(Oc) * 0.3).astype(F)
     rm, rv = be.to_dev(np.zeros(Oc)), be.to_dev(np.ones(Oc))
     save, chan = be.empty((2, Oc)), be.empty((9, Oc))
     stash = be.empty_i8((N, Oc, Ho, Wo * (sb // 8)))
     nbt = be.to_dev_i64([0])
     dGa, dBe = be.to_dev(gamma), be.to_dev(beta)
-    be.call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dX), a_bits, be.ptr(dW), None, be.ptr(dGa), be.ptr(dBe), 1e-5, 0.1, 1,
+    be.call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dX), a_bits, be.ptr(dW_call), None, be.ptr(dGa), be.ptr(dBe), 1e-5, 0.1, 1,
             be.ptr(rm), be.ptr(rv), be.ptr(nbt), be.ptr(save), be.ptr(stash), be.ptr(chan), be.ptr(ws), nb, be.stream)
+    # weight codes of <= 7 bits fit signed bytes: the forward runs on the int8 matrix cores (k_qd_fwd8), else on bf16 (k_qd_fwd)
+    assert be.lib.mn_last_kernel().decode().startswith("k_qd_fwd8<" if w_bits <= 7 else "k_qd_fwd<"), be.lib.mn_last_kernel()
     st = be.to_host(stash).view(np.int16 if sb == 16 else np.int32).reshape(N, Oc, Ho, Wo)
     assert np.array_equal(st.astype(np.float64), acc), "stash != exact integer conv result"
     alpha = float(F(F(1.0 / nw) * F(1.0 / na)))
@@ -1070,7 +1082,7 @@ def check_qdense(be, x_shape, Oc, k=3, stride=1, a_bits=2, w_bits=2, seed=0):
     dx = be.empty(x_shape)
     nb1 = int(be.lib.mn_conv2d_ws_bytes(C.byref(g), 1, 0))
     ws1 = be.empty(nb1 // 4 + 8)
-    be.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq), be.ptr(dGY), be.ptr(dW), None, be.ptr(dx), be.ptr(ws1), nb1, 0, be.stream)
+    be.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq), be.ptr(dGY), be.ptr(dW_call), None, be.ptr(dx), be.ptr(ws1), nb1, 0, be.stream)
     assert be.lib.mn_last_kernel().decode().startswith("k_qd_dgrad"), be.lib.mn_last_kernel()
     assert close(be.to_host(dx), tx.grad.numpy(), 1e-5), "dx"
     dw = be.empty(w_shape)

@@ -345,6 +345,18 @@ def test_qdense_layer(be, case):
     K.check_qdense(be, xs, Oc, k, s, seed=300 + case)
 
 
+@pytest.mark.parametrize("case", [1, 4, 6])
+def test_qdense_layer_prepacked_weights(be, case):
+    xs, Oc, k, s = K.QDENSE_CASES[case]
+    K.check_qdense(be, xs, Oc, k, s, seed=380 + case, prepack=True)
+
+
+def test_qdense_layer_bf16_forward(be):
+    """8-bit DoReFa weight codes (+-255) do not fit signed bytes: the bf16 forward."""
+    K.check_qdense(be, (2, 64, 8, 8), 64, 3, 1, a_bits=2, w_bits=8, seed=390)
+    K.check_qdense(be, (3, 128, 8, 8), 64, 3, 2, a_bits=3, w_bits=8, seed=391, prepack=True)
+
+
 def test_qdense_layer_wide_codes(be):
     """4-bit activations x 4-bit weights: the accumulator leaves int16 -> 32-bit stash."""
     K.check_qdense(be, (2, 64, 8, 8), 64, 3, 1, a_bits=4, w_bits=4, seed=320)
