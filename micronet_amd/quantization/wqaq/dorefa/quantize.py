@@ -71,10 +71,35 @@ class WeightQuantizer(nn.Module):
         return ops.DorefaWeight.apply(input, self.w_bits)
 
 
+def _weight_is_coded(module):
+    """May the code-domain kernels read ``module``'s effective weights as integer codes (2k - n) / n?  Always for the training graph (the weight quantizer
+    produced them).  ``quant_inference=True`` uses the STORED weights as they are (ref 107-122): only when they lie on the quantizer's grid -- true after
+    ``inference.prequantize_weights`` / quant_model_test.py:189-191 -- which is checked once per weight version (one host sync); anything else keeps the
+    fp32-weight kernels, as the reference would convolve raw weights."""
+    b = module.weight_quantizer.w_bits
+    if not (2 <= b <= 8):
+        return False
+    if not module.quant_inference:
+        return True
+    w = module.weight
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    c = module.__dict__.get("_mn_grid")
+    if c is None or c[0] != key:
+        ok = False
+        if w.numel() and w.is_cuda and w.dtype == torch.float32:
+            n = float(2 ** b - 1)
+            with torch.no_grad():
+                k = (w.detach() * n + n) * 0.5
+                ok = bool(((k - k.round()).abs().max() <= 1e-4) & (k.min() >= -1e-4) & (k.max() <= n + 1e-4))
+        c = (key, ok)
+        module.__dict__["_mn_grid"] = c
+    return c[1]
+
+
 def _wdesc(module):
     """weight-code descriptor for the code-domain conv kernels: w = (2k - n)/n, n = 2^w_bits - 1"""
     b = module.weight_quantizer.w_bits
-    return (ops.WQ_DOREFA, b, 0, 0, None) if (not module.quant_inference and 2 <= b <= 8) else None
+    return (ops.WQ_DOREFA, b, 0, 0, None) if (2 <= b <= 8 and _weight_is_coded(module)) else None
 
 
 def _aq_args(quantizer):
@@ -102,11 +127,11 @@ class QuantConv2d(nn.Conv2d):
         if isinstance(input, QActTensor):
             # the block in front already evaluated THIS conv's activation quantizer (codes, one byte per element)
             w_bits = self.weight_quantizer.w_bits
-            if (self.lazy_for_bn and not self.quant_inference and input.bits == bits and mode == ops.ACTQ_DOREFA and
+            if (self.lazy_for_bn and _weight_is_coded(self) and input.bits == bits and mode == ops.ACTQ_DOREFA and
                     ops.qconv_bnq_supported(input, quant_weight, self.stride, self.padding, self.dilation, self.groups, w_bits, self.in_shuffle_groups)):
                 return ops.QConvCodeLazy.apply(input, quant_weight, self.bias, self.stride, self.padding, self.dilation, self.groups, w_bits,
                                                self.in_shuffle_groups or 0)
-            if (not self.quant_inference and input.bits == bits and mode == ops.ACTQ_DOREFA and not self.in_shuffle_groups and
+            if (_weight_is_coded(self) and input.bits == bits and mode == ops.ACTQ_DOREFA and not self.in_shuffle_groups and
                     ops.code_classifier_supported(input, quant_weight, self.stride, self.padding, self.dilation, self.groups)):
                 return ops.CodeClassifierConv.apply(input, quant_weight, self.bias)       # the 1024 -> 10 classifier: reads the codes directly
             input = ops.QActToFloat.apply(input)       # anything else: the fp32 activation the reference holds here (one streaming kernel)
@@ -262,7 +287,7 @@ def _fuse_blocks(model, fold_shuffle=True):
             if isinstance(nxt, MaxPool2dF32) and two(nxt.kernel_size) and two(nxt.stride) and nxt.padding in (0, (0, 0)) and nxt.dilation in (1, (1, 1)) \
                     and not nxt.ceil_mode and not nxt.return_indices:
                 pool, nxt = nxt, (kids[i + 2] if i + 2 < len(kids) else None)
-            if nxt is not None and is_block(nxt) and isinstance(nxt.conv, QuantConv2d) and not nxt.conv.quant_inference:
+            if nxt is not None and is_block(nxt) and isinstance(nxt.conv, QuantConv2d):
                 bits = nxt.conv.activation_quantizer.a_bits
                 if 2 <= bits <= 7 and 2 <= nxt.conv.weight_quantizer.w_bits <= 8:
                     blk.bn.q_out_bits = int(bits)
@@ -305,20 +330,21 @@ class _FusedBasicBlockMixin:
         rf = self.residual_function
         conv_a, bn_a, conv_b, bn_b = rf[0], rf[1], rf[3], rf[4]
         has_sc = len(self.shortcut) > 0
-        ok = isinstance(x, QActTensor) and x.bits == conv_a.activation_quantizer.a_bits and not conv_a.quant_inference and not conv_b.quant_inference
+        ok = isinstance(x, QActTensor) and x.bits == conv_a.activation_quantizer.a_bits and _weight_is_coded(conv_a) and _weight_is_coded(conv_b)
         if ok and not has_sc and x._mn_f32 is None:
             ok = False
         w_bits = conv_a.weight_quantizer.w_bits
         if ok and has_sc:
             conv_s = self.shortcut[0]
-            ok = (not conv_s.quant_inference and conv_s.weight_quantizer.w_bits == w_bits and conv_s.activation_quantizer.a_bits == x.bits and
+            ok = (_weight_is_coded(conv_s) and conv_s.weight_quantizer.w_bits == w_bits and conv_s.activation_quantizer.a_bits == x.bits and
                   conv_a.bias is None and conv_s.bias is None and
                   ops.qconv_bnq_supported(x, conv_a.weight, conv_a.stride, conv_a.padding, conv_a.dilation, conv_a.groups, w_bits, 0) and
                   ops.qconv_bnq_supported(x, conv_s.weight, conv_s.stride, conv_s.padding, conv_s.dilation, conv_s.groups, w_bits, 0))
         if not ok:
             return super().forward(ops.QActToFloat.apply(x) if isinstance(x, QActTensor) else x)
         if has_sc:
-            ya, ys = ops.QConvCodeLazy2.apply(x, conv_a.weight_quantizer(conv_a.weight), conv_s.weight_quantizer(conv_s.weight),
+            wq = lambda c: c.weight if c.quant_inference else c.weight_quantizer(c.weight)
+            ya, ys = ops.QConvCodeLazy2.apply(x, wq(conv_a), wq(conv_s),
                                               (conv_a.stride, conv_a.padding, conv_a.dilation, conv_a.groups),
                                               (conv_s.stride, conv_s.padding, conv_s.dilation, conv_s.groups), w_bits)
         else:
@@ -370,7 +396,7 @@ def _fuse_residual_blocks(model):
         if len(sc) and not (isinstance(sc[0], QuantConv2d) and type(sc[1]) is nn.BatchNorm2d):
             return False
         convs = [rf[0], rf[3]] + ([sc[0]] if len(sc) else [])
-        return all(2 <= c.activation_quantizer.a_bits <= 7 and 2 <= c.weight_quantizer.w_bits <= 8 and c.bias is None and not c.quant_inference for c in convs)
+        return all(2 <= c.activation_quantizer.a_bits <= 7 and 2 <= c.weight_quantizer.w_bits <= 8 and c.bias is None for c in convs)
 
     blocks = []
     for m in model.modules():
@@ -462,7 +488,7 @@ def prepare(model, inplace=False, a_bits=8, w_bits=8, quant_inference=False, fus
     if not inplace:
         model = copy.deepcopy(model)
     add_quant_op(model, [0], a_bits=a_bits, w_bits=w_bits, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act)
-    if fuse_bn_act and fuse_blocks and not quant_inference:
+    if fuse_bn_act and fuse_blocks:          # (quant_inference graphs too: their convs take the code kernels once the stored weights are on the grid)
         _fuse_blocks(model, fold_shuffle=fold_shuffle)
         _fuse_residual_blocks(model)
     return model

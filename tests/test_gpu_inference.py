@@ -99,3 +99,42 @@ def test_iao_bn_fused_inference_graph():
     assert float((t - i).abs().max()) <= 2e-2 * float(t.abs().max()), float((t - i).abs().max() / t.abs().max())
     sd_keys = [k for k in I.state_dict() if "running" in k or "gamma" in k]
     assert not sd_keys
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_dorefa_resnet_inference_graph_on_int8_matrix_cores(bits):
+    """SURVEY 8 (f3), second half: the deployed DoReFa ResNet (weights stored fake-quantised, quant_model_test.py:189-191) runs its convolutions on
+    v_mfma_i32_16x16x64_i8 -- activation codes and weight codes as bytes, exact i32 accumulators (k_qd_fwd8) -- and computes the same function as the
+    training graph in eval mode (bit for bit: same codes, same integer sums) and as the un-fused inference graph on the fp32-weight kernels."""
+    import ctypes as C
+    from micronet_amd import _lib, inference
+    from micronet_amd.train import build_model
+    Q, T, x = _trained("wqaq.dorefa", "resnet18", dict(a_bits=bits, w_bits=bits))
+    I = Q.prepare(build_model("resnet18"), inplace=True, a_bits=bits, w_bits=bits, quant_inference=True).cuda()
+    U = Q.prepare(build_model("resnet18"), inplace=True, a_bits=bits, w_bits=bits, quant_inference=True, fuse_blocks=False).cuda()
+    I.load_state_dict(T.state_dict()), U.load_state_dict(T.state_dict())
+    assert inference.prequantize_weights(I) == 20 and inference.prequantize_weights(U) == 20          # 16 block convs + 3 shortcuts + the classifier
+    T.eval(), I.eval(), U.eval()
+    lib = _lib.get_lib()
+    with torch.no_grad():
+        a = T(x)
+        lib.mn_profile_enable(1)
+        b = I(x)
+        torch.cuda.synchronize()
+        buf = (_lib.ProfEntry * 192)()
+        n = lib.mn_profile_collect(buf, 192)
+        lib.mn_profile_enable(0)
+        u = U(x)
+    names = [buf[i].name.decode() for i in range(n)]
+    convs = [k for k in names if k.startswith("k_qd_") or k.startswith("k_kk") or k.startswith("k_conv")]
+    assert convs and all(k.startswith("k_qd_fwd8<") for k in convs), names            # every quantised conv of the deployed graph: the int8 kernel
+    assert torch.equal(a, b), float((a - b).abs().max())
+    assert float((u - b).abs().max()) <= 1e-5 * float(u.abs().max()), float((u - b).abs().max())
+    # weights NOT on the quantizer's grid (quant_inference without pre-quantisation): the reference convolves them as they are -- so do we (no code kernels)
+    R = Q.prepare(build_model("resnet18"), inplace=True, a_bits=bits, w_bits=bits, quant_inference=True).cuda().eval()
+    R.load_state_dict(T.state_dict())
+    R2 = Q.prepare(build_model("resnet18"), inplace=True, a_bits=bits, w_bits=bits, quant_inference=True, fuse_blocks=False).cuda().eval()
+    R2.load_state_dict(T.state_dict())
+    with torch.no_grad():
+        r, r2 = R(x), R2(x)
+    assert float((r - r2).abs().max()) <= 1e-4 * float(r2.abs().max()), float((r - r2).abs().max())
