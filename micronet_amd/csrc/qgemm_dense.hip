@@ -1492,12 +1492,22 @@ int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, c
     MN_CHECK_LAUNCH("mn_conv2d_bwd_data(dense iao)");
     return MN_OK;
 }
-int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, void* ws, int64_t ws_bytes, hipStream_t s) {
+// dbias[o] = sum over (n, pixels) of gy: one block per channel, fp64 (the IAO convs of the ResNets carry no bias; QuantConv2d(bias=True) elsewhere does)
+__global__ __launch_bounds__(256) void k_qd_bias_grad(const float* __restrict__ gy, float* __restrict__ db, int N, int O, int HW) {
+    __shared__ double scd[16];
+    const int o = blockIdx.x;
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < (int64_t)N * HW; i += 256) { const int64_t n = i / HW; a += (double)gy[(n * O + o) * HW + (i - n * HW)]; }
+    a = block_reduce(a, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) db[o] = (float)a;
+}
+int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
     QdwPlan pl;
     if (!qd_iao_quant_ok(g, aq, nullptr, 0) || !plan_qdw(g, &pl) || !aligned16(x)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(dense iao): geometry / quantizer not covered");
     const int64_t cb = qd_iao_codes_bytes(g);
     if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense iao): workspace too small");
     qd_iao_launch_codes(g, aq, x, ws, s);
+    if (dbias) hipLaunchKernelGGL(k_qd_bias_grad, dim3((unsigned)g->O), dim3(256), 0, s, gy, dbias, (int)g->N, (int)g->O, pl.p.HWg);
     return qd_bwd_weight_ex(g, gy, (const uint8_t*)ws, 1, 1.f, aq->qp, dw, (char*)ws + cb, ws_bytes - cb, s);
 }
 

@@ -119,7 +119,7 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
                hipStream_t s);
 int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx, void* ws, int64_t ws_bytes,
                     hipStream_t s);
-int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, void* ws, int64_t ws_bytes, hipStream_t s);
+int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 
 void qa_launch_stats_prep_const(const double* part, int CB, int Cout, float wscale, float ascale, const float* bias, double n, float eps, float momentum, int training,
                                 float* running_mean, float* running_var, float* save, const float* gamma, const float* beta, float* chan, long long* nbt, hipStream_t s);

@@ -855,8 +855,8 @@ int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
         return k3s_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // 3x3 on sign codes: wave-private streaming kernel
     if (aq && aq->mode == MN_ACTQ_CODE8 && !dbias && qd_wgrad_supported(g, aq->bits) && ws_bytes >= qd_wgrad_ws_bytes(g))      // dense layers: qgemm_dense.hip
         return qd_bwd_weight(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, ws, ws_bytes, s);
-    if (!dbias && qd_iao_supported(g, aq, nullptr, 2) && ws_bytes >= qd_iao_ws_bytes(g, 2) && aligned16(gy) && aligned16(x))          // dense IAO layers
-        return qd_iao_bwd_weight(g, aq, gy, x, dw, ws, ws_bytes, s);
+    if (qd_iao_supported(g, aq, nullptr, 2) && ws_bytes >= qd_iao_ws_bytes(g, 2) && aligned16(gy) && aligned16(x))          // dense IAO layers
+        return qd_iao_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
     if (aq && aq->mode == MN_ACTQ_CODE8) {        // k-bit activation codes: only the wave-private 3x3 kernel reads them
         if (!k3s_wgrad_code8_supported(g, aq->bits) || ws_bytes < k3s_wgrad_ws_bytes(g)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): geometry / bits not covered");
         return k3s_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);

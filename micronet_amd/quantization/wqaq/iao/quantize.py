@@ -509,15 +509,27 @@ def _copy_params(new, child):
 
 
 def add_quant_op(module, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=False, bn_fuse_calib=False,
-                 quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999):
+                 quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999, fuse_bn_act=True):
     """ref 1501-1788: every conv / linear is quantised (no first/last skip); with ``bn_fuse`` a conv is replaced when
     the BatchNorm2d that follows it among the same parent's children is met, and that BN becomes ``nn.Identity``."""
     common = dict(a_bits=a_bits, q_type=q_type, qaft=qaft, ptq=ptq, percentile=percentile)
     kw_all = dict(a_bits=a_bits, w_bits=w_bits, q_type=q_type, q_level=q_level, weight_observer=weight_observer,
                   bn_fuse=bn_fuse, bn_fuse_calib=bn_fuse_calib, quant_inference=quant_inference,
-                  pretrained_model=pretrained_model, qaft=qaft, ptq=ptq, percentile=percentile)
+                  pretrained_model=pretrained_model, qaft=qaft, ptq=ptq, percentile=percentile, fuse_bn_act=fuse_bn_act)
     conv_name_temp = conv_child_temp = None
+    prev = None
     for name, child in module.named_children():
+        if (fuse_bn_act and not bn_fuse and type(child) is nn.ReLU and type(prev) is nn.BatchNorm2d and prev.affine and prev.track_running_stats
+                and isinstance(module, nn.Sequential)):
+            # ours (numerically the same function): BatchNorm2d directly in front of a ReLU the Sequential calls right after it -> one fused gfx950 op
+            # (ops.BNReLU) instead of MIOpen's BatchNorm kernels + ReLU forward / backward; the ReLU stays in place as a no-op subclass.  Same objects,
+            # same parameters / buffers / state_dict keys, isinstance contracts intact (the reference leaves nn.ReLU alone: ref 1705-1709).
+            from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dReLU, ReLUAfterFusedBN
+            prev.__class__ = BatchNorm2dReLU
+            child.__class__ = ReLUAfterFusedBN
+            prev = child
+            continue
+        prev = child
         if isinstance(child, nn.Conv2d):
             if bn_fuse:
                 conv_name_temp, conv_child_temp = name, child
@@ -577,10 +589,11 @@ def add_quant_op(module, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observe
 
 
 def prepare(model, inplace=False, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=False,
-            bn_fuse_calib=False, quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999):
+            bn_fuse_calib=False, quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999, fuse_bn_act=True):
+    """Same rewrite as the reference (ref 1791-1830).  ``fuse_bn_act`` (ours, default on): see add_quant_op; off = exactly the reference's module classes."""
     if not inplace:
         model = copy.deepcopy(model)
     add_quant_op(model, a_bits=a_bits, w_bits=w_bits, q_type=q_type, q_level=q_level, weight_observer=weight_observer,
                  bn_fuse=bn_fuse, bn_fuse_calib=bn_fuse_calib, quant_inference=quant_inference,
-                 pretrained_model=pretrained_model, qaft=qaft, ptq=ptq, percentile=percentile)
+                 pretrained_model=pretrained_model, qaft=qaft, ptq=ptq, percentile=percentile, fuse_bn_act=fuse_bn_act)
     return model

@@ -1226,4 +1226,4 @@ def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=Fa
     kernels: mn_conv2d_fwd / _bwd_data / _bwd_weight with MN_ACTQ_IAO + MN_WQ_IAO route to k_qd_* and agree with the fp64 evaluation of the fake-quantised conv."""
     pad = 1 if k == 3 else 0
     check_conv(be, x_shape, (Oc, x_shape[1], k, k), stride=stride, padding=pad, bias=bias, mode=2, bits=a_bits, q_type=0, wmode=3, wbits=w_bits, algos=(3,), seed=seed,
-               expect_qgemm=True, want_dbias=False, expect_kernels=("k_qd_fwd", "k_qd_dgrad", "k_qd_wgrad"))
+               expect_qgemm=True, want_dbias=bias, expect_kernels=("k_qd_fwd", "k_qd_dgrad", "k_qd_wgrad"))
