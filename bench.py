@@ -369,6 +369,10 @@ def main():
 
     primary = args.only or args.workload
     also = [] if args.only else [w for w in args.also.split(",") if w and w != primary]
+    if args.gpus > 1 and args.also == ap.get_default("also"):
+        # multi-GPU runs measure the scaling of the headline step: by default only the two nin_gc schemes the metric names (same graphed data-parallel step);
+        # the other BASELINE configs are single-GPU lines (`also` of the --gpus 1 run) unless --also asks for them explicitly
+        also = [w for w in also if w == "c1_w2a2"]
     for w in also:
         if w not in WORKLOADS:
             raise SystemExit("unknown workload in --also: %s" % w)
