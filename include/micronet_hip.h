@@ -157,6 +157,18 @@ int mn_hist_observe(const float* x, int64_t n, int64_t k, int first, double mome
 /* QuantAdd.forward 1487-1492: union of two observer ranges */
 int mn_iao_union_range(const float* min_a, const float* max_a, const float* min_b, const float* max_b,
                        float* min_out, float* max_out, mn_stream_t stream);
+/* QuantAdd (wqaq/iao/quantize.py:1484-1498: out = Q(res) + Q(shortcut) with ONE quantizer whose range is the union of the two inputs' observed ranges) in three
+ * launches: mn_iao_qadd_observe = observer_res(res), observer_shortcut(shortcut) (per-tensor, obs_kind 0 running min / max, 1 moving average; first_*: the
+ * observer's first call), union -> (min_out, max_out) = the shared quantizer's observer, and its qparams (update != 0: scale / zero_point recomputed, as in
+ * training; 0: taken as they are) -> qp {scale, zero_point, lo, hi}; ws: mn_iao_qadd_ws_floats() floats.  mn_iao_qadd_fwd: out = fq(res) + fq(shortcut);
+ * mn_iao_qadd_bwd: both clip-STE gradients from one read of g.  n % 4 == 0, 16-byte aligned tensors.  Bit-identical to the separate entry points. */
+int64_t mn_iao_qadd_ws_floats(void);
+int mn_iao_qadd_observe(const float* res, const float* shortcut, int64_t n, int obs_kind, int first_res, int first_shortcut, double momentum, float* min_res,
+                        float* max_res, float* min_shortcut, float* max_shortcut, float* min_out, float* max_out, int bits, int q_type, int update, float* scale,
+                        float* zero_point, float* qp, float* ws, mn_stream_t stream);
+int mn_iao_qadd_fwd(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, mn_stream_t stream);
+int mn_iao_qadd_bwd(const float* g, const float* res, const float* shortcut, float* dres, float* dshortcut, int64_t n, const float* qp, int bits, int q_type,
+                    mn_stream_t stream);
 /* QuantBNFuseConv2d.forward 853-855: per-channel mean and UNBIASED variance of o[N][C][HW] over (N,HW).
  * stats: [2][C] = mean, var.  ws: >= mn_bn_stats_ws_floats(N, C, HW) floats. */
 int64_t mn_bn_stats_ws_floats(int64_t N, int64_t C, int64_t HW);
@@ -203,6 +215,9 @@ typedef struct mn_actq {
     int32_t q_type;  /* iao: 0 symmetric, 1 asymmetric */
     int32_t flags;   /* MN_ACTQ_X_IS_CODE */
     const float* qp; /* iao: device {scale, zero_point, lo, hi} (per-tensor) */
+    void* codes;     /* optional, MN_ACTQ_IAO on a dense layer (mn_conv2d_iao_codes_bytes(g, aq, wq) > 0): that many bytes owned by the caller.  mn_conv2d_fwd
+                        writes the activation's signed codes there instead of into its workspace, and a later mn_conv2d_bwd_weight handed the SAME buffer (same x,
+                        same qp) reads them instead of quantising x again.  NULL: every call quantises for itself. */
 } mn_actq;
 
 /* How the (already fake-quantised, fp32 OIHW) weight tensor factors into integer codes x per-channel scale.  The
@@ -244,6 +259,7 @@ int mn_conv2d_mfma_supported(const mn_conv_geom* g, int which);
 int mn_conv2d_first_supported(const mn_conv_geom* g, int which);
 /* 1 if MN_ALGO_QGEMM supports this geometry and quantizer combination for `which` (aq / wq may be NULL = none / real) */
 int mn_conv2d_qgemm_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
+int64_t mn_conv2d_iao_codes_bytes(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);   /* size of mn_actq.codes for this layer; 0: not used */
 /* y[N][O][Ho][Wo] = conv2d(actq(x), w, bias); w are the (already fake-quantised) fp32 weights, wq says how they factor
  * (NULL = MN_WQ_REAL) */
 int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w,

@@ -1426,7 +1426,12 @@ static int qd_iao_quant_ok(const mn_conv_geom* g, const mn_actq* aq, const mn_wq
     if (((int64_t)g->N * g->C * g->H * g->W) % 8) return 0;
     return 1;
 }
+int qd_iao_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
 static int64_t qd_iao_codes_bytes(const mn_conv_geom* g) { return ((int64_t)g->N * g->C * g->H * g->W + 255) / 256 * 256; }
+extern "C" int64_t mn_conv2d_iao_codes_bytes(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
+    if (!g || !aq || !wq || !qd_iao_supported(g, aq, wq, 0) || !qd_iao_supported(g, aq, nullptr, 2)) return 0;
+    return qd_iao_codes_bytes(g);
+}
 int qd_iao_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which) {
     if (which == 0) { QdfPlan pl; return qd_iao_quant_ok(g, aq, wq, 1) && plan_qdf(g, 2, &pl, qd_fwd_i8(wq)); }
     if (which == 1) { QddPlan pl; return qd_iao_quant_ok(g, aq, wq, 2) && plan_qdd(g, &pl); }
@@ -1454,13 +1459,15 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
     const int64_t cb = qd_iao_codes_bytes(g);
     if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(dense iao): workspace too small");
     QdfParams& p = pl.p;
-    qd_iao_launch_codes(g, aq, x, ws, s);
+    void* cbuf = aq->codes ? aq->codes : ws;          // a caller-owned buffer keeps the codes for backward-weight
+    if (!aligned16(cbuf)) MN_FAIL(MN_EINVAL, "mn_conv2d_fwd(dense iao): mn_actq.codes is not 16-byte aligned");
+    qd_iao_launch_codes(g, aq, x, cbuf, s);
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_fwd);
     if (!wpk) {
         qd_launch_pack(w, reinterpret_cast<uint16_t*>((char*)ws + cb), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s, wq->scale, wq->per_channel);
         wpk = reinterpret_cast<const uint16_t*>((char*)ws + cb);
     }
-    p.x = (const unsigned char*)ws; p.wpk = wpk; p.stash = y; p.xsgn = 1; p.sa = aq->qp; p.sw = wq->scale; p.sw_stride = wq->per_channel; p.bias = bias;
+    p.x = (const unsigned char*)cbuf; p.wpk = wpk; p.stash = y; p.xsgn = 1; p.sa = aq->qp; p.sw = wq->scale; p.sw_stride = wq->per_channel; p.bias = bias;
     mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + 4.0 * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
@@ -1506,9 +1513,10 @@ int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy,
     if (!qd_iao_quant_ok(g, aq, nullptr, 0) || !plan_qdw(g, &pl) || !aligned16(x)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(dense iao): geometry / quantizer not covered");
     const int64_t cb = qd_iao_codes_bytes(g);
     if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense iao): workspace too small");
-    qd_iao_launch_codes(g, aq, x, ws, s);
+    const void* cbuf = aq->codes ? aq->codes : ws;
+    if (!aq->codes) qd_iao_launch_codes(g, aq, x, ws, s);          // else: the forward of this step left them there
     if (dbias) hipLaunchKernelGGL(k_qd_bias_grad, dim3((unsigned)g->O), dim3(256), 0, s, gy, dbias, (int)g->N, (int)g->O, pl.p.HWg);
-    return qd_bwd_weight_ex(g, gy, (const uint8_t*)ws, 1, 1.f, aq->qp, dw, (char*)ws + cb, ws_bytes - cb, s);
+    return qd_bwd_weight_ex(g, gy, (const uint8_t*)cbuf, 1, 1.f, aq->qp, dw, (char*)ws + cb, ws_bytes - cb, s);
 }
 
 

@@ -806,32 +806,33 @@ extern "C" int mn_iao_observe(const float* x, int64_t rows, int64_t cols, int ob
 }
 
 // qparams (293-321) + clip-STE bounds (148-157)
+__device__ __forceinline__ void iao_qparams_row(float mn, float mx, int q_type, float quant_range, int update, float* scale, float* zero_point, float* qp) {
+    const float EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps
+    float sc, zp;
+    if (update) {
+        if (q_type == 0) {
+            float fr = OpMaxF()(fabsf(mn), fabsf(mx));
+            sc = OpMaxF()(fr / quant_range, EPS);
+            zp = 0.f;
+        } else {
+            sc = OpMaxF()((mx - mn) / quant_range, EPS);
+            zp = mn_sign(mn) * floorf(fabsf(mn / sc) + 0.5f);
+        }
+        *scale = sc;
+        *zero_point = zp;
+    } else {
+        sc = *scale;
+        zp = *zero_point;
+    }
+    float lo = mn / sc - zp, hi = mx / sc - zp;
+    if (q_type == 0) { hi = OpMaxF()(fabsf(lo), fabsf(hi)); lo = -hi; }
+    qp[0] = sc; qp[1] = zp; qp[2] = lo; qp[3] = hi;
+}
 __global__ __launch_bounds__(256) void k_iao_qparams(const float* __restrict__ min_val, const float* __restrict__ max_val, int64_t rows,
                                                      int q_type, float quant_range, int update, float* __restrict__ scale,
                                                      float* __restrict__ zero_point, float* __restrict__ qp) {
-    const float EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
-        const float mn = min_val[i], mx = max_val[i];
-        float sc, zp;
-        if (update) {
-            if (q_type == 0) {
-                float fr = OpMaxF()(fabsf(mn), fabsf(mx));
-                sc = OpMaxF()(fr / quant_range, EPS);
-                zp = 0.f;
-            } else {
-                sc = OpMaxF()((mx - mn) / quant_range, EPS);
-                zp = mn_sign(mn) * floorf(fabsf(mn / sc) + 0.5f);
-            }
-            scale[i] = sc;
-            zero_point[i] = zp;
-        } else {
-            sc = scale[i];
-            zp = zero_point[i];
-        }
-        float lo = mn / sc - zp, hi = mx / sc - zp;
-        if (q_type == 0) { hi = OpMaxF()(fabsf(lo), fabsf(hi)); lo = -hi; }
-        qp[i * 4 + 0] = sc; qp[i * 4 + 1] = zp; qp[i * 4 + 2] = lo; qp[i * 4 + 3] = hi;
-    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x)
+        iao_qparams_row(min_val[i], max_val[i], q_type, quant_range, update, scale + i, zero_point + i, qp + i * 4);
 }
 extern "C" int mn_iao_qparams(const float* min_val, const float* max_val, int64_t rows, int bits, int q_type, int is_act,
                               int update, float* scale, float* zero_point, float* qp, mn_stream_t stream) {
@@ -928,6 +929,109 @@ extern "C" int mn_iao_union_range(const float* min_a, const float* max_a, const 
     if (!min_a || !max_a || !min_b || !max_b || !min_out || !max_out) MN_FAIL(MN_EINVAL, "mn_iao_union_range: null pointer");
     hipLaunchKernelGGL(k_iao_union, dim3(1), dim3(64), 0, (hipStream_t)stream, min_a, max_a, min_b, max_b, min_out, max_out);
     MN_CHECK_LAUNCH("mn_iao_union_range");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// QuantAdd (wqaq/iao/quantize.py:1484-1498) in three launches instead of nine: both input observers (per-tensor min / max, running or moving-average update),
+// their union range, the shared quantizer's qparams -- k_qadd_partial + k_qadd_final -- and out = fq(res) + fq(shortcut) in one pass (k_qadd_fwd); backward: both
+// clip-STE gradients from one read of g (k_qadd_bwd).  Same arithmetic as mn_iao_observe x 2 + mn_iao_union_range + mn_iao_qparams + mn_iao_fq_fwd x 2 + add.
+__global__ __launch_bounds__(256) void k_qadd_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n4, float* __restrict__ ws) {
+    __shared__ float sc[16];
+    float la = INFINITY, ha = -INFINITY, lb = INFINITY, hb = -INFINITY;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(a)[j], w = reinterpret_cast<const float4*>(b)[j];
+        la = OpMinF()(OpMinF()(la, v.x), OpMinF()(OpMinF()(v.y, v.z), v.w)); ha = OpMaxF()(OpMaxF()(ha, v.x), OpMaxF()(OpMaxF()(v.y, v.z), v.w));
+        lb = OpMinF()(OpMinF()(lb, w.x), OpMinF()(OpMinF()(w.y, w.z), w.w)); hb = OpMaxF()(OpMaxF()(hb, w.x), OpMaxF()(OpMaxF()(w.y, w.z), w.w));
+    }
+    la = block_reduce(la, OpMinF(), INFINITY, sc); ha = block_reduce(ha, OpMaxF(), -INFINITY, sc);
+    lb = block_reduce(lb, OpMinF(), INFINITY, sc); hb = block_reduce(hb, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) { ws[blockIdx.x] = la; ws[OBS_NB + blockIdx.x] = ha; ws[2 * OBS_NB + blockIdx.x] = lb; ws[3 * OBS_NB + blockIdx.x] = hb; }
+}
+struct QaddFinal {
+    int nb, obs_kind, first_a, first_b, q_type, update; double momentum; float quant_range;
+    float *min_a, *max_a, *min_b, *max_b, *min_o, *max_o, *scale, *zero_point, *qp;
+};
+__global__ __launch_bounds__(256) void k_qadd_final(const float* __restrict__ ws, const QaddFinal f) {
+    __shared__ float sc[16];
+    float la = INFINITY, ha = -INFINITY, lb = INFINITY, hb = -INFINITY;
+    for (int i = threadIdx.x; i < f.nb; i += 256) {
+        la = OpMinF()(la, ws[i]); ha = OpMaxF()(ha, ws[OBS_NB + i]); lb = OpMinF()(lb, ws[2 * OBS_NB + i]); hb = OpMaxF()(hb, ws[3 * OBS_NB + i]);
+    }
+    la = block_reduce(la, OpMinF(), INFINITY, sc); ha = block_reduce(ha, OpMaxF(), -INFINITY, sc);
+    lb = block_reduce(lb, OpMinF(), INFINITY, sc); hb = block_reduce(hb, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) {
+        observer_update(f.obs_kind, f.first_a, f.momentum, la, ha, f.min_a, f.max_a);
+        observer_update(f.obs_kind, f.first_b, f.momentum, lb, hb, f.min_b, f.max_b);
+        const float mn = OpMinF()(*f.min_a, *f.min_b), mx = OpMaxF()(*f.max_a, *f.max_b);
+        *f.min_o = mn; *f.max_o = mx;
+        iao_qparams_row(mn, mx, f.q_type, f.quant_range, f.update, f.scale, f.zero_point, f.qp);
+    }
+}
+__global__ __launch_bounds__(256) void k_qadd_fwd(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n4,
+                                                  const float* __restrict__ qp, float qmin, float qmax) {
+    const float sc = qp[0], zp = qp[1];
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(a)[j], w = reinterpret_cast<const float4*>(b)[j];
+        reinterpret_cast<float4*>(y)[j] = make_float4(iao_fq(v.x, sc, zp, qmin, qmax) + iao_fq(w.x, sc, zp, qmin, qmax), iao_fq(v.y, sc, zp, qmin, qmax) + iao_fq(w.y, sc, zp, qmin, qmax),
+                                                      iao_fq(v.z, sc, zp, qmin, qmax) + iao_fq(w.z, sc, zp, qmin, qmax), iao_fq(v.w, sc, zp, qmin, qmax) + iao_fq(w.w, sc, zp, qmin, qmax));
+    }
+}
+__global__ __launch_bounds__(256) void k_qadd_bwd(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ da,
+                                                  float* __restrict__ db, int64_t n4, const float* __restrict__ qp, float qmin, float qmax) {
+    const float sc = qp[0], zp = qp[1], lo = qp[2], hi = qp[3];
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+        const float4 gv = reinterpret_cast<const float4*>(g)[j], v = reinterpret_cast<const float4*>(a)[j], w = reinterpret_cast<const float4*>(b)[j];
+        reinterpret_cast<float4*>(da)[j] = make_float4(iao_fq_grad(gv.x, v.x, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(gv.y, v.y, sc, zp, lo, hi, qmin, qmax),
+                                                       iao_fq_grad(gv.z, v.z, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(gv.w, v.w, sc, zp, lo, hi, qmin, qmax));
+        reinterpret_cast<float4*>(db)[j] = make_float4(iao_fq_grad(gv.x, w.x, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(gv.y, w.y, sc, zp, lo, hi, qmin, qmax),
+                                                       iao_fq_grad(gv.z, w.z, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(gv.w, w.w, sc, zp, lo, hi, qmin, qmax));
+    }
+}
+extern "C" int64_t mn_iao_qadd_ws_floats(void) { return 4 * OBS_NB; }
+extern "C" int mn_iao_qadd_observe(const float* res, const float* shortcut, int64_t n, int obs_kind, int first_res, int first_shortcut, double momentum,
+                                   float* min_res, float* max_res, float* min_shortcut, float* max_shortcut, float* min_out, float* max_out, int bits, int q_type,
+                                   int update, float* scale, float* zero_point, float* qp, float* ws, mn_stream_t stream) {
+    if (n <= 0 || n % 4 || !res || !shortcut || !aligned16(res) || !aligned16(shortcut) || !min_res || !max_res || !min_shortcut || !max_shortcut || !min_out || !max_out ||
+        !scale || !zero_point || !qp || !ws || bits < 2 || bits > 24 || (obs_kind != 0 && obs_kind != 1) || (q_type != 0 && q_type != 1))
+        MN_FAIL(MN_EINVAL, "mn_iao_qadd_observe: bad arguments (n must be a multiple of 4, tensors 16-byte aligned)");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = mn_grid_for(n / 4, 256 * 4, OBS_NB);
+    hipLaunchKernelGGL(k_qadd_partial, dim3(nb), dim3(256), 0, s, res, shortcut, n / 4, ws);
+    const IaoRange r = iao_range(bits, q_type, 1);
+    QaddFinal f;
+    f.nb = nb; f.obs_kind = obs_kind; f.first_a = first_res; f.first_b = first_shortcut; f.q_type = q_type; f.update = update; f.momentum = momentum;
+    f.quant_range = (q_type == 0) ? (float)((double)(r.qmax - r.qmin) / 2.0) : (float)(r.qmax - r.qmin);
+    f.min_a = min_res; f.max_a = max_res; f.min_b = min_shortcut; f.max_b = max_shortcut; f.min_o = min_out; f.max_o = max_out;
+    f.scale = scale; f.zero_point = zero_point; f.qp = qp;
+    hipLaunchKernelGGL(k_qadd_final, dim3(1), dim3(256), 0, s, (const float*)ws, f);
+    MN_CHECK_LAUNCH("mn_iao_qadd_observe");
+    return MN_OK;
+}
+extern "C" int mn_iao_qadd_fwd(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, mn_stream_t stream) {
+    if (n <= 0 || n % 4 || !res || !shortcut || !out || !qp || !aligned16(res) || !aligned16(shortcut) || !aligned16(out) || bits < 2 || bits > 24)
+        MN_FAIL(MN_EINVAL, "mn_iao_qadd_fwd: bad arguments");
+    const IaoRange r = iao_range(bits, q_type, 1);
+    mn_prof_bytes(12.0 * (double)n);
+    mn_set_last_kernel("k_qadd_fwd");
+    mn_prof_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(k_qadd_fwd, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, res, shortcut, out, n / 4, qp, r.qmin, r.qmax);
+    mn_prof_end((hipStream_t)stream);
+    MN_CHECK_LAUNCH("mn_iao_qadd_fwd");
+    return MN_OK;
+}
+extern "C" int mn_iao_qadd_bwd(const float* g, const float* res, const float* shortcut, float* dres, float* dshortcut, int64_t n, const float* qp, int bits, int q_type,
+                               mn_stream_t stream) {
+    if (n <= 0 || n % 4 || !g || !res || !shortcut || !dres || !dshortcut || !qp || !aligned16(g) || !aligned16(res) || !aligned16(shortcut) || !aligned16(dres) ||
+        !aligned16(dshortcut) || bits < 2 || bits > 24)
+        MN_FAIL(MN_EINVAL, "mn_iao_qadd_bwd: bad arguments");
+    const IaoRange r = iao_range(bits, q_type, 1);
+    mn_prof_bytes(20.0 * (double)n);
+    mn_set_last_kernel("k_qadd_bwd");
+    mn_prof_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(k_qadd_bwd, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, g, res, shortcut, dres, dshortcut, n / 4, qp, r.qmin, r.qmax);
+    mn_prof_end((hipStream_t)stream);
+    MN_CHECK_LAUNCH("mn_iao_qadd_bwd");
     return MN_OK;
 }
 

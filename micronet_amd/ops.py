@@ -357,6 +357,45 @@ def iao_union_range(a_min, a_max, b_min, b_max, out_min, out_max):
         _call("mn_iao_union_range", _p(a_min), _p(a_max), _p(b_min), _p(b_max), _p(out_min), _p(out_max), _s())
 
 
+def iao_qadd_observe(res, shortcut, obs_res, obs_sc, quantizer, update):
+    """QuantAdd's bookkeeping in two launches (mn_iao_qadd_observe): both input observers, the union range into the shared quantizer's observer, its qparams.
+    Returns the {scale, zero_point, lo, hi} snapshot."""
+    lib = _lib_()
+    res, shortcut = _chk(res.detach(), "res"), _chk(shortcut.detach(), "shortcut")
+    obs = quantizer.observer
+    ws = torch.empty(int(lib.mn_iao_qadd_ws_floats()), dtype=torch.float32, device=res.device)
+    qp = torch.empty((1, 4), dtype=torch.float32, device=res.device)
+    with torch.cuda.device_of(res):
+        _call("mn_iao_qadd_observe", _p(res), _p(shortcut), res.numel(), obs_res._kind, int(obs_res.num_flag == 0), int(obs_sc.num_flag == 0),
+              float(getattr(obs_res, "momentum", 0.1)), _p(obs_res.min_val), _p(obs_res.max_val), _p(obs_sc.min_val), _p(obs_sc.max_val), _p(obs.min_val), _p(obs.max_val),
+              quantizer.bits, quantizer._q_type_static if update else quantizer.q_type, int(update), _p(quantizer.scale), _p(quantizer.zero_point), _p(qp), _p(ws), _s())
+    return qp
+
+
+class IaoQuantAdd(Function):
+    """out = Q(res) + Q(shortcut) with one shared per-tensor quantizer (QuantAdd, wqaq/iao/quantize.py:1484-1498): one pass forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, res, shortcut, qp, bits, q_type):
+        res, shortcut = _chk(res, "res"), _chk(shortcut, "shortcut")
+        out = torch.empty_like(res)
+        with torch.cuda.device_of(res):
+            _call("mn_iao_qadd_fwd", _p(res), _p(shortcut), _p(out), res.numel(), _p(qp), bits, q_type, _s())
+        ctx.save_for_backward(res, shortcut, qp)
+        ctx.cfg = (bits, q_type)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        res, shortcut, qp = ctx.saved_tensors
+        bits, q_type = ctx.cfg
+        g = _chk(g, "grad")
+        da, db = torch.empty_like(res), torch.empty_like(shortcut)
+        with torch.cuda.device_of(res):
+            _call("mn_iao_qadd_bwd", _p(g), _p(res), _p(shortcut), _p(da), _p(db), res.numel(), _p(qp), bits, q_type, _s())
+        return da, db, None, None, None
+
+
 class IaoFakeQuant(Function):
     @staticmethod
     def forward(ctx, x, qp, bits, q_type, is_act):
@@ -745,11 +784,18 @@ class QConv2d(Function):
         y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         wd = _wq_desc(wdesc)
+        codes = None
+        if aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[1]:
+            nc = int(_lib_().mn_conv2d_iao_codes_bytes(C.byref(g), C.byref(aq), C.byref(wd)))
+            if nc > 0:          # dense IAO layer: the forward's signed activation codes are kept for backward-weight (1 byte per element)
+                codes = torch.empty(nc, dtype=torch.int8, device=x.device)
+                aq.codes = codes.data_ptr()
         with torch.cuda.device_of(x):
             ws, nb = _ws(g, 0, x.device)
             with _span(g, 0, 4 * (x.numel() + y.numel() + wq.numel())):
                 _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _ref(wd), _p(x), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
         wscale = wdesc[4] if wdesc is not None else None
+        ctx.iao_codes = codes
         ctx.save_for_backward(x, wq, qp, wscale)
         ctx.cfg = (g, aq_mode, aq_bits, aq_qtype, bias is not None, wdesc[:4] if wdesc is not None else None, aq_flags)
         return y
@@ -798,6 +844,8 @@ class QConv2d(Function):
             return None, dw, db, None, None, None, None, None, None, None, None, None, None, None
         gy = _chk(gy, "grad")
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
+        if getattr(ctx, "iao_codes", None) is not None:
+            aq.codes = ctx.iao_codes.data_ptr()
         wd = _wq_desc(wd4 + (wscale,)) if wd4 is not None else None
         dx = dw = db = None
         with torch.cuda.device_of(x):

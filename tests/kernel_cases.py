@@ -1227,3 +1227,73 @@ def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=Fa
     pad = 1 if k == 3 else 0
     check_conv(be, x_shape, (Oc, x_shape[1], k, k), stride=stride, padding=pad, bias=bias, mode=2, bits=a_bits, q_type=0, wmode=3, wbits=w_bits, algos=(3,), seed=seed,
                expect_qgemm=True, want_dbias=bias, expect_kernels=("k_qd_fwd", "k_qd_dgrad", "k_qd_wgrad"))
+    # the activation codes of the forward kept in a caller-owned buffer (mn_actq.codes) and reused by backward-weight: same dw without reading x again
+    r = np.random.default_rng(seed + 1000)
+    w_shape = (Oc, x_shape[1], k, k)
+    x = (r.standard_normal(x_shape) * 4).astype(F)
+    w, wkw, wscale = make_coded_weights(r, w_shape, 3, w_bits)
+    dWs = be.to_dev(wscale)
+    wq = be.wq(scale=dWs, **wkw)
+    g = be.geom(x_shape, w_shape, stride, pad)
+    mn, mx = F(x.min()), F(x.max())
+    sc, zp = O.iao_qparams(mn.reshape(1), mx.reshape(1), a_bits, 0, True)
+    hi = max(abs(mn / sc[0]), abs(mx / sc[0]))
+    dqp = be.to_dev(np.array([sc[0], zp[0], -hi, hi], dtype=F))
+    aq = be.actq(2, a_bits, 0, dqp)
+    nc = int(be.lib.mn_conv2d_iao_codes_bytes(C.byref(g), C.byref(aq), C.byref(wq)))
+    assert nc == (int(np.prod(x_shape)) + 255) // 256 * 256
+    codes = be.empty_i8((nc,))
+    dX, dW = be.to_dev(x), be.to_dev(w)
+    y1 = be.to_host(be.conv_fwd(g, aq, dX, dW, None, 3, wq=wq))
+    aq.codes = be.ptr(codes).value
+    y2 = be.to_host(be.conv_fwd(g, aq, dX, dW, None, 3, wq=wq))
+    assert np.array_equal(y1, y2)
+    gy = r.standard_normal(y1.shape).astype(F)
+    dG = be.to_dev(gy)
+    aq0 = be.actq(2, a_bits, 0, dqp)
+    dw_a, _ = be.conv_bwd_weight(g, aq0, dG, dX, 3, bias=False)
+    dw_b, _ = be.conv_bwd_weight(g, aq, dG, be.to_dev(np.full(x_shape, np.nan, dtype=F)), 3, bias=False)
+    assert np.array_equal(be.to_host(dw_a), be.to_host(dw_b))
+
+
+def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, False), update=True, seed=0):
+    """mn_iao_qadd_observe / _fwd / _bwd (QuantAdd, wqaq/iao/quantize.py:1484-1498, in three launches) == the separate entry points it replaces
+    (mn_iao_observe x 2, mn_iao_union_range, mn_iao_qparams, mn_iao_fq_fwd x 2 + add, mn_iao_fq_bwd x 2), bit for bit: outputs, gradients, every buffer."""
+    r = np.random.default_rng(seed)
+    a, b = (r.standard_normal(n) * 3).astype(F), (r.standard_normal(n) * 2 + 0.5).astype(F)
+    g = r.standard_normal(n).astype(F)
+    st0 = dict(min_a=F(-1.5), max_a=F(2.5), min_b=F(-0.7), max_b=F(3.1), min_o=F(-9), max_o=F(9), scale=F(0.031), zp=F(3.0 if q_type else 0.0))
+    mom = 0.1
+
+    def fresh():
+        return {k: be.to_dev(np.array([v], dtype=F)) for k, v in st0.items()}
+    dA, dB, dG = be.to_dev(a), be.to_dev(b), be.to_dev(g)
+    # ---- reference sequence
+    s1 = fresh()
+    ws1 = be.empty(int(be.lib.mn_iao_observe_ws_floats(1, n)))
+    be.call("mn_iao_observe", be.ptr(dA), 1, n, obs_kind, int(first[0]), mom, be.ptr(s1["min_a"]), be.ptr(s1["max_a"]), be.ptr(ws1), be.stream)
+    be.call("mn_iao_observe", be.ptr(dB), 1, n, obs_kind, int(first[1]), mom, be.ptr(s1["min_b"]), be.ptr(s1["max_b"]), be.ptr(ws1), be.stream)
+    be.call("mn_iao_union_range", be.ptr(s1["min_a"]), be.ptr(s1["max_a"]), be.ptr(s1["min_b"]), be.ptr(s1["max_b"]), be.ptr(s1["min_o"]), be.ptr(s1["max_o"]), be.stream)
+    qp1 = be.empty((1, 4))
+    be.call("mn_iao_qparams", be.ptr(s1["min_o"]), be.ptr(s1["max_o"]), 1, bits, q_type, 1, int(update), be.ptr(s1["scale"]), be.ptr(s1["zp"]), be.ptr(qp1), be.stream)
+    ya, yb = be.empty(n), be.empty(n)
+    be.call("mn_iao_fq_fwd", be.ptr(dA), be.ptr(ya), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
+    be.call("mn_iao_fq_fwd", be.ptr(dB), be.ptr(yb), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
+    y_ref = (be.to_host(ya) + be.to_host(yb)).astype(F)
+    da1, db1 = be.empty(n), be.empty(n)
+    be.call("mn_iao_fq_bwd", be.ptr(dG), be.ptr(dA), be.ptr(da1), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
+    be.call("mn_iao_fq_bwd", be.ptr(dG), be.ptr(dB), be.ptr(db1), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
+    # ---- fused
+    s2 = fresh()
+    ws2 = be.empty(int(be.lib.mn_iao_qadd_ws_floats()))
+    qp2 = be.empty((1, 4))
+    be.call("mn_iao_qadd_observe", be.ptr(dA), be.ptr(dB), n, obs_kind, int(first[0]), int(first[1]), mom, be.ptr(s2["min_a"]), be.ptr(s2["max_a"]), be.ptr(s2["min_b"]),
+            be.ptr(s2["max_b"]), be.ptr(s2["min_o"]), be.ptr(s2["max_o"]), bits, q_type, int(update), be.ptr(s2["scale"]), be.ptr(s2["zp"]), be.ptr(qp2), be.ptr(ws2), be.stream)
+    y2, da2, db2 = be.empty(n), be.empty(n), be.empty(n)
+    be.call("mn_iao_qadd_fwd", be.ptr(dA), be.ptr(dB), be.ptr(y2), n, be.ptr(qp2), bits, q_type, be.stream)
+    be.call("mn_iao_qadd_bwd", be.ptr(dG), be.ptr(dA), be.ptr(dB), be.ptr(da2), be.ptr(db2), n, be.ptr(qp2), bits, q_type, be.stream)
+    for k in st0:
+        assert np.array_equal(be.to_host(s1[k]), be.to_host(s2[k])), k
+    assert np.array_equal(be.to_host(qp1), be.to_host(qp2)), "qp"
+    assert np.array_equal(be.to_host(y2), y_ref), "out"
+    assert np.array_equal(be.to_host(da1), be.to_host(da2)) and np.array_equal(be.to_host(db1), be.to_host(db2)), "gradients"

@@ -613,3 +613,10 @@ def test_qdense_layer_iao_w8a8_bias(be):
     K.check_qdense_iao(be, (2, 64, 8, 8), 64, 3, 1, a_bits=8, w_bits=8, bias=True, seed=410)
     K.check_qdense_iao(be, (37, 256, 8, 8), 512, 3, 2, seed=411)
     K.check_qdense_iao(be, (37, 128, 16, 16), 256, 1, 2, seed=412)
+
+
+@pytest.mark.parametrize("bits,q_type,obs_kind,first,update", [(8, 0, 1, (True, True), True), (4, 0, 1, (False, False), True), (8, 1, 1, (False, True), True),
+                                                              (8, 0, 0, (False, False), True), (4, 0, 1, (False, False), False)])
+def test_iao_quant_add_fused(be, bits, q_type, obs_kind, first, update):
+    K.check_iao_qadd(be, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=bits + q_type)
+    K.check_iao_qadd(be, n=256 * 64 * 32 * 32, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=1)
