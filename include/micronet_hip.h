@@ -162,6 +162,15 @@ int mn_iao_union_range(const float* min_a, const float* max_a, const float* min_
  * observer's first call), union -> (min_out, max_out) = the shared quantizer's observer, and its qparams (update != 0: scale / zero_point recomputed, as in
  * training; 0: taken as they are) -> qp {scale, zero_point, lo, hi}; ws: mn_iao_qadd_ws_floats() floats.  mn_iao_qadd_fwd: out = fq(res) + fq(shortcut);
  * mn_iao_qadd_bwd: both clip-STE gradients from one read of g.  n % 4 == 0, 16-byte aligned tensors.  Bit-identical to the separate entry points. */
+/* The IAO weight quantizers of a whole net (per-channel observers: one row per output channel) in ONE launch per direction: for every row of every tensor the
+ * observer update (obs_kind 0 running min / max, 1 moving average; first[i]: tensor i's observer is at its first call), scale / zero_point, the
+ * {scale, zero_point, lo, hi} snapshot qp[i][rows][4] and the fake-quantised row (wqaq/iao/quantize.py:15-36, 293-321, 227-239, weights: activation_weight_flag 0).
+ * Backward: the clip-STE of every row from the forward's qp.  count <= 32.  Bit-identical to mn_iao_observe + mn_iao_qparams + mn_iao_fq_fwd / _bwd per tensor. */
+int mn_iao_w_fwd_multi(const float* const* w, float* const* qw, float* const* min_val, float* const* max_val, float* const* scale, float* const* zero_point,
+                       float* const* qp, const int64_t* rows, const int64_t* cols, const int32_t* first, int32_t count, int obs_kind, double momentum, int bits,
+                       int q_type, mn_stream_t stream);
+int mn_iao_w_bwd_multi(const float* const* g, const float* const* w, float* const* dw, float* const* qp, const int64_t* rows, const int64_t* cols, int32_t count,
+                       int bits, int q_type, mn_stream_t stream);
 int64_t mn_iao_qadd_ws_floats(void);
 int mn_iao_qadd_observe(const float* res, const float* shortcut, int64_t n, int obs_kind, int first_res, int first_shortcut, double momentum, float* min_res,
                         float* max_res, float* min_shortcut, float* max_shortcut, float* min_out, float* max_out, int bits, int q_type, int update, float* scale,

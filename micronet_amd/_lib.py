@@ -128,6 +128,8 @@ PROTOTYPES = {
     "mn_qa_bwd_sums": (_I, [_I, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mn_qa_bwd_apply": (_I, [_I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
     "mn_conv2d_iao_codes_bytes": (_L, [_G, _A, _W]),
+    "mn_iao_w_fwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _I, _I, _P]),
+    "mn_iao_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mn_iao_qadd_ws_floats": (_L, []),
     "mn_iao_qadd_observe": (_I, [_P, _P, _L, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mn_iao_qadd_fwd": (_I, [_P, _P, _P, _L, _P, _I, _I, _P]),

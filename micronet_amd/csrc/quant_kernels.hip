@@ -933,6 +933,96 @@ extern "C" int mn_iao_union_range(const float* min_a, const float* max_a, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The IAO weight path of a whole net in one launch per direction (per-channel weight quantizers: wqaq/iao/quantize.py:15-36 observer, 293-321 qparams, 227-239
+// fake-quant): a block owns one output channel (row) of one tensor -- min / max of the row, the observer update (running min / max, or moving average), scale /
+// zero_point / the {scale, zp, lo, hi} snapshot, and the fake-quantised row -- instead of mn_iao_observe + mn_iao_qparams + mn_iao_fq_fwd per layer.  Same
+// arithmetic per row: bit-identical to those entry points.
+#define MN_IW_MAX 32
+struct IwTable {
+    const float* w[MN_IW_MAX]; const float* g[MN_IW_MAX]; float* out[MN_IW_MAX];
+    float *min_val[MN_IW_MAX], *max_val[MN_IW_MAX], *scale[MN_IW_MAX], *zero_point[MN_IW_MAX], *qp[MN_IW_MAX];
+    int rows[MN_IW_MAX], first[MN_IW_MAX], row0[MN_IW_MAX + 1];
+    long long cols[MN_IW_MAX];
+    int count, obs_kind, q_type; float quant_range, qmin, qmax; double momentum;
+};
+__device__ __forceinline__ int iw_find(const IwTable& t, int b) { int i = 0; while (i + 1 < t.count && t.row0[i + 1] <= b) ++i; return i; }
+__global__ __launch_bounds__(256) void k_iao_w_fwd_multi(const IwTable t) {
+    __shared__ float sc[16];
+    __shared__ float sq[2];
+    const int ti = iw_find(t, blockIdx.x), row = blockIdx.x - t.row0[ti];
+    const long long cols = t.cols[ti];
+    const float* xr = t.w[ti] + (long long)row * cols;
+    float lo = INFINITY, hi = -INFINITY;
+    for (long long j = threadIdx.x; j < cols; j += 256) { lo = OpMinF()(lo, xr[j]); hi = OpMaxF()(hi, xr[j]); }
+    lo = block_reduce(lo, OpMinF(), INFINITY, sc);
+    hi = block_reduce(hi, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) {
+        observer_update(t.obs_kind, t.first[ti], t.momentum, lo, hi, t.min_val[ti] + row, t.max_val[ti] + row);
+        float* qp = t.qp[ti] + 4 * row;
+        iao_qparams_row(t.min_val[ti][row], t.max_val[ti][row], t.q_type, t.quant_range, 1, t.scale[ti] + row, t.zero_point[ti] + row, qp);
+        sq[0] = qp[0]; sq[1] = qp[1];
+    }
+    __syncthreads();
+    const float s_ = sq[0], zp = sq[1];
+    float* yr = t.out[ti] + (long long)row * cols;
+    for (long long j = threadIdx.x; j < cols; j += 256) yr[j] = iao_fq(xr[j], s_, zp, t.qmin, t.qmax);
+}
+__global__ __launch_bounds__(256) void k_iao_w_bwd_multi(const IwTable t) {
+    const int ti = iw_find(t, blockIdx.x), row = blockIdx.x - t.row0[ti];
+    const long long cols = t.cols[ti];
+    const float* qp = t.qp[ti] + 4 * row;
+    const float s_ = qp[0], zp = qp[1], lo = qp[2], hi = qp[3];
+    const float* xr = t.w[ti] + (long long)row * cols;
+    const float* gr = t.g[ti] + (long long)row * cols;
+    float* dr = t.out[ti] + (long long)row * cols;
+    for (long long j = threadIdx.x; j < cols; j += 256) dr[j] = iao_fq_grad(gr[j], xr[j], s_, zp, lo, hi, t.qmin, t.qmax);
+}
+static int iw_table(IwTable* t, const float* const* w, const float* const* g, float* const* out, float* const* min_val, float* const* max_val, float* const* scale,
+                    float* const* zero_point, float* const* qp, const int64_t* rows, const int64_t* cols, const int32_t* first, int count, int obs_kind, double momentum,
+                    int bits, int q_type, const char* what) {
+    if (count < 1 || count > MN_IW_MAX || !w || !out || !qp || !rows || !cols || bits < 2 || bits > 24 || (q_type != 0 && q_type != 1) || (obs_kind != 0 && obs_kind != 1))
+        MN_FAIL(MN_EINVAL, "%s: bad arguments (count=%d bits=%d)", what, count, bits);
+    int b = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!w[i] || !out[i] || !qp[i] || rows[i] <= 0 || cols[i] <= 0 || (g && !g[i]) || (min_val && (!min_val[i] || !max_val[i] || !scale[i] || !zero_point[i])))
+            MN_FAIL(MN_EINVAL, "%s: tensor %d invalid", what, i);
+        t->w[i] = w[i]; t->g[i] = g ? g[i] : nullptr; t->out[i] = out[i]; t->qp[i] = qp[i];
+        t->min_val[i] = min_val ? min_val[i] : nullptr; t->max_val[i] = max_val ? max_val[i] : nullptr;
+        t->scale[i] = scale ? scale[i] : nullptr; t->zero_point[i] = zero_point ? zero_point[i] : nullptr;
+        t->rows[i] = (int)rows[i]; t->cols[i] = cols[i]; t->first[i] = first ? first[i] : 0; t->row0[i] = b;
+        b += (int)rows[i];
+    }
+    t->row0[count] = b; t->count = count; t->obs_kind = obs_kind; t->q_type = q_type; t->momentum = momentum;
+    const IaoRange r = iao_range(bits, q_type, 0);
+    t->qmin = r.qmin; t->qmax = r.qmax;
+    t->quant_range = (q_type == 0) ? (float)((double)(r.qmax - r.qmin) / 2.0) : (float)(r.qmax - r.qmin);
+    return MN_OK;
+}
+extern "C" int mn_iao_w_fwd_multi(const float* const* w, float* const* qw, float* const* min_val, float* const* max_val, float* const* scale, float* const* zero_point,
+                                  float* const* qp, const int64_t* rows, const int64_t* cols, const int32_t* first, int32_t count, int obs_kind, double momentum,
+                                  int bits, int q_type, mn_stream_t stream) {
+    IwTable t;
+    if (!min_val || !max_val || !scale || !zero_point) MN_FAIL(MN_EINVAL, "mn_iao_w_fwd_multi: null buffer table");
+    int rc = iw_table(&t, w, nullptr, qw, min_val, max_val, scale, zero_point, qp, rows, cols, first, count, obs_kind, momentum, bits, q_type, "mn_iao_w_fwd_multi");
+    if (rc) return rc;
+    mn_set_last_kernel("k_iao_w_fwd_multi");
+    hipLaunchKernelGGL(k_iao_w_fwd_multi, dim3((unsigned)t.row0[count]), dim3(256), 0, (hipStream_t)stream, t);
+    MN_CHECK_LAUNCH("mn_iao_w_fwd_multi");
+    return MN_OK;
+}
+extern "C" int mn_iao_w_bwd_multi(const float* const* g, const float* const* w, float* const* dw, float* const* qp, const int64_t* rows, const int64_t* cols,
+                                  int32_t count, int bits, int q_type, mn_stream_t stream) {
+    IwTable t;
+    if (!g) MN_FAIL(MN_EINVAL, "mn_iao_w_bwd_multi: null gradient table");
+    int rc = iw_table(&t, w, g, dw, nullptr, nullptr, nullptr, nullptr, qp, rows, cols, nullptr, count, 0, 0.0, bits, q_type, "mn_iao_w_bwd_multi");
+    if (rc) return rc;
+    mn_set_last_kernel("k_iao_w_bwd_multi");
+    hipLaunchKernelGGL(k_iao_w_bwd_multi, dim3((unsigned)t.row0[count]), dim3(256), 0, (hipStream_t)stream, t);
+    MN_CHECK_LAUNCH("mn_iao_w_bwd_multi");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // QuantAdd (wqaq/iao/quantize.py:1484-1498) in three launches instead of nine: both input observers (per-tensor min / max, running or moving-average update),
 // their union range, the shared quantizer's qparams -- k_qadd_partial + k_qadd_final -- and out = fq(res) + fq(shortcut) in one pass (k_qadd_fwd); backward: both
 // clip-STE gradients from one read of g (k_qadd_bwd).  Same arithmetic as mn_iao_observe x 2 + mn_iao_union_range + mn_iao_qparams + mn_iao_fq_fwd x 2 + add.

@@ -357,6 +357,48 @@ def iao_union_range(a_min, a_max, b_min, b_max, out_min, out_max):
         _call("mn_iao_union_range", _p(a_min), _p(a_max), _p(b_min), _p(b_max), _p(out_min), _p(out_max), _s())
 
 
+class MultiIaoWeight(Function):
+    """The per-channel IAO weight quantizers of several layers in ONE launch (mn_iao_w_fwd_multi: observer update, qparams and fake-quant of every output
+    channel) and one in backward, instead of four launches per layer.  ``state`` = per tensor (min_val, max_val, scale, zero_point, qp [rows, 4], first-call flag):
+    the quantizers' own buffers, updated in place exactly as ``Quantizer.forward`` would.  Bit-identical to the per-layer path."""
+
+    @staticmethod
+    def forward(ctx, cfg, state, *ws):
+        bits, q_type, obs_kind, momentum = cfg
+        ws = [_chk(w, "weight") for w in ws]
+        n = len(ws)
+        qws = [torch.empty_like(w) for w in ws]
+        rows = [w.shape[0] for w in ws]
+        cols = [w.numel() // w.shape[0] for w in ws]
+        PA, LA, IA = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+        with torch.cuda.device_of(ws[0]):
+            _call("mn_iao_w_fwd_multi", PA(*[w.data_ptr() for w in ws]), PA(*[q.data_ptr() for q in qws]), PA(*[st[0].data_ptr() for st in state]),
+                  PA(*[st[1].data_ptr() for st in state]), PA(*[st[2].data_ptr() for st in state]), PA(*[st[3].data_ptr() for st in state]),
+                  PA(*[st[4].data_ptr() for st in state]), LA(*rows), LA(*cols), IA(*[int(st[5]) for st in state]), n, obs_kind, float(momentum), bits, q_type, _s())
+        ctx.save_for_backward(*ws)
+        ctx.qps = [st[4] for st in state]
+        ctx.cfg = (bits, q_type, rows, cols)
+        return tuple(qws)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ws = ctx.saved_tensors
+        bits, q_type, rows, cols = ctx.cfg
+        idx = [i for i in range(len(ws)) if gs[i] is not None]
+        dws = [None] * len(ws)
+        if idx:
+            g = [_chk(gs[i], "grad") for i in idx]
+            out = [torch.empty_like(ws[i]) for i in idx]
+            m = len(idx)
+            PA, LA = C.c_void_p * m, C.c_int64 * m
+            with torch.cuda.device_of(ws[0]):
+                _call("mn_iao_w_bwd_multi", PA(*[t.data_ptr() for t in g]), PA(*[ws[i].data_ptr() for i in idx]), PA(*[t.data_ptr() for t in out]),
+                      PA(*[ctx.qps[i].data_ptr() for i in idx]), LA(*[rows[i] for i in idx]), LA(*[cols[i] for i in idx]), m, bits, q_type, _s())
+            for k, i in enumerate(idx):
+                dws[i] = out[k]
+        return (None, None) + tuple(dws)
+
+
 def iao_qadd_observe(res, shortcut, obs_res, obs_sc, quantizer, update):
     """QuantAdd's bookkeeping in two launches (mn_iao_qadd_observe): both input observers, the union range into the shared quantizer's observer, its qparams.
     Returns the {scale, zero_point, lo, hi} snapshot."""
@@ -784,6 +826,9 @@ class QConv2d(Function):
         y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         wd = _wq_desc(wdesc)
+        ctx.packed = packed = getattr(wq, "_mn_packed", None) if wd is not None else None
+        if packed is not None and packed[0] is not None:
+            wd.packed_fwd = packed[0].data_ptr()
         codes = None
         if aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[1]:
             nc = int(_lib_().mn_conv2d_iao_codes_bytes(C.byref(g), C.byref(aq), C.byref(wd)))
@@ -847,6 +892,8 @@ class QConv2d(Function):
         if getattr(ctx, "iao_codes", None) is not None:
             aq.codes = ctx.iao_codes.data_ptr()
         wd = _wq_desc(wd4 + (wscale,)) if wd4 is not None else None
+        if wd is not None and getattr(ctx, "packed", None) is not None and ctx.packed[1] is not None:
+            wd.packed_bwd = ctx.packed[1].data_ptr()
         dx = dw = db = None
         with torch.cuda.device_of(x):
             if ctx.needs_input_grad[0]:
@@ -988,12 +1035,13 @@ def _wq_dorefa(w_bits, packed=None, which=0):
     return wd
 
 
-def pack_dense_weights(mods_wq, w_bits):
+def pack_dense_weights(mods_wq, w_bits, qps=None):
     """One launch writing the weight codes of every dense-family conv (both fragment orders) for this step: ``mods_wq`` = [(conv module, quantised weight)].
-    The images ride on the quantised weight tensor (``_mn_packed``) to the convs' forward and backward."""
+    The images ride on the quantised weight tensor (``_mn_packed``) to the convs' forward and backward.  ``qps`` (IAO): the per-channel {scale, ...} snapshots
+    [O, 4] of the same tensors -- codes = rint(w / scale[o]); None (DoReFa): codes = rint(w (2^bits - 1))."""
     lib = _lib_()
-    items = []
-    for m, wq in mods_wq:
+    items, scales = [], []
+    for k, (m, wq) in enumerate(mods_wq):
         if wq.dim() != 4 or not wq.is_cuda or getattr(m, "groups", 1) != 1 or wq.shape[0] % 64 or wq.shape[1] % 64:
             continue
         g = _geom((1, wq.shape[1], 8, 8), wq.shape, m.stride, m.padding, m.dilation, 1, 0)
@@ -1001,6 +1049,8 @@ def pack_dense_weights(mods_wq, w_bits):
         if nb <= 0:
             continue
         items.append((wq, nb))
+        if qps is not None:
+            scales.append(qps[k])
     if not items:
         return
     n = len(items)
@@ -1011,11 +1061,11 @@ def pack_dense_weights(mods_wq, w_bits):
     for wq, nb in items:
         outs.append((buf[off:off + nb], buf[off + nb:off + 2 * nb]))
         off += 2 * nb
-    PA, LA = C.c_void_p * n, C.c_int64 * n
+    PA, LA, IA = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
     with torch.cuda.device_of(buf):
         _call("mn_qd_pack_multi", PA(*[wq.data_ptr() for wq, _ in items]), PA(*[o[0].data_ptr() for o in outs]), PA(*[o[1].data_ptr() for o in outs]),
               LA(*[wq.shape[0] for wq, _ in items]), LA(*[wq.shape[1] for wq, _ in items]), LA(*[wq.shape[2] * wq.shape[3] for wq, _ in items]),
-              None, None, n, w_bits, _s())
+              PA(*[q.data_ptr() for q in scales]) if qps is not None else None, IA(*[4] * n) if qps is not None else None, n, w_bits, _s())
     for (wq, _), o in zip(items, outs):
         wq._mn_packed = o
 

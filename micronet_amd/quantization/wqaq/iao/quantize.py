@@ -178,6 +178,13 @@ class Quantizer(nn.Module):
                                self.activation_weight_flag == 1, False, self.scale, self.zero_point)
 
     def forward(self, input):
+        pre = self.__dict__.pop("_mn_pre", None)
+        if pre is not None and pre[0] is input:
+            # computed ahead for all layers in one launch (micronet_amd.train.prefetch_weight_path -> ops.MultiIaoWeight): observer, qparams and the
+            # fake-quantised weights of THIS step; only the python-side bookkeeping of the ordinary path is left
+            self.q_type = self._q_type_static
+            self._last_qp = pre[2]
+            return pre[1]
         qp = self.qparams(input)
         self._last_qp = qp        # snapshot {scale, zp, lo, hi} of THIS call (python attribute, not in the state_dict)
         if qp is None:

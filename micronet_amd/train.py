@@ -90,6 +90,39 @@ def prefetch_weight_path(model, side=None):
                     m.weight_quantizer._mn_pre = (m.weight, wq, None)
                 if 2 <= bits <= 8:          # the dense layers (ResNets): their weight codes in both fragment orders, one launch for the net
                     ops.pack_dense_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], bits)
+    if side is None:
+        # IAO nets: every per-channel weight quantizer (observer update + qparams + fake-quant of each output channel) of one flavour in one MultiIaoWeight
+        # node, then the dense layers' weight codes in one launch.  QuantBNFuseConv2d is excluded: it quantises weights folded with THIS step's batch statistics.
+        from micronet_amd.quantization.wqaq.iao import quantize as ia
+        groups = {}
+        for m in model.modules():
+            if type(m) in (ia.QuantConv2d, ia.QuantLinear) and not m.quant_inference and m.training and m.weight.is_cuda and m.weight.is_contiguous() \
+                    and m.weight.dtype == torch.float32:
+                q = m.weight_quantizer
+                obs = q.observer
+                q.__dict__.pop("_mn_pre", None)
+                if 2 <= q.bits <= 24 and not q.qaft and getattr(obs, "q_level", None) in ("C", "FC") and getattr(obs, "_kind", None) in (0, 1) \
+                        and not getattr(obs, "_mn_sync", False) and obs.min_val.numel() == m.weight.shape[0]:
+                    groups.setdefault((q.bits, q._q_type_static, obs._kind, float(getattr(obs, "momentum", 0.1))), []).append(m)
+        for cfg, ms in groups.items():
+            for i in range(0, len(ms), 32):
+                grp = ms[i:i + 32]
+                if len(grp) < 2:
+                    continue
+                state = []
+                for m in grp:
+                    q, obs = m.weight_quantizer, m.weight_quantizer.observer
+                    qp = torch.empty((m.weight.shape[0], 4), dtype=torch.float32, device=m.weight.device)
+                    state.append((obs.min_val, obs.max_val, q.scale, q.zero_point, qp, obs.num_flag == 0))
+                qws = ops.MultiIaoWeight.apply(cfg, state, *[m.weight for m in grp])
+                for m, wq, st in zip(grp, qws, state):
+                    obs = m.weight_quantizer.observer
+                    if obs.num_flag == 0:
+                        obs.num_flag += 1
+                    m.weight_quantizer._mn_pre = (m.weight, wq, st[4])
+                if cfg[1] == 0 and 2 <= cfg[0] <= 8:
+                    convs = [(m, wq, st[4]) for m, wq, st in zip(grp, qws, state) if type(m) is ia.QuantConv2d]
+                    ops.pack_dense_weights([(m, wq) for m, wq, _ in convs], cfg[0], qps=[qp for _, _, qp in convs])
     mods = [m for m in model.modules() if isinstance(m, wb.QuantConv2d) and not m.quant_inference and m.weight_quantizer.W in (2, 3)]
     for m in mods:
         m.weight_quantizer.__dict__.pop("_mn_pre", None)

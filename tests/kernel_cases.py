@@ -1297,3 +1297,44 @@ def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, Fa
     assert np.array_equal(be.to_host(qp1), be.to_host(qp2)), "qp"
     assert np.array_equal(be.to_host(y2), y_ref), "out"
     assert np.array_equal(be.to_host(da1), be.to_host(da2)) and np.array_equal(be.to_host(db1), be.to_host(db2)), "gradients"
+
+
+def check_iao_w_multi(be, bits=4, q_type=0, obs_kind=0, seed=0):
+    """mn_iao_w_fwd_multi / _bwd_multi (per-channel IAO weight quantizers of several layers in one launch) == mn_iao_observe + mn_iao_qparams + mn_iao_fq_fwd /
+    _bwd per tensor, bit for bit: quantised weights, gradients, observer / scale / zero_point buffers, the qp snapshots."""
+    r = np.random.default_rng(seed)
+    shapes = [(24, 16, 3, 3), (8, 4, 1, 1), (10, 33), (5, 700)]
+    first = [True, False, False, True]
+    ws = [(r.standard_normal(s_) * 0.3).astype(F) for s_ in shapes]
+    gs = [r.standard_normal(s_).astype(F) for s_ in shapes]
+    n = len(shapes)
+
+    def fresh():
+        out = []
+        for s_ in shapes:
+            O_ = s_[0]
+            out.append(dict(mn=be.to_dev((r2.standard_normal(O_) * 0.1 - 0.5).astype(F)), mx=be.to_dev((r2.standard_normal(O_) * 0.1 + 0.5).astype(F)),
+                            sc=be.to_dev(np.full(O_, 0.01, dtype=F)), zp=be.to_dev(np.zeros(O_, dtype=F)), qp=be.empty((O_, 4))))
+        return out
+    r2 = np.random.default_rng(seed + 1); st1 = fresh()
+    r2 = np.random.default_rng(seed + 1); st2 = fresh()
+    dW, dG = [be.to_dev(w) for w in ws], [be.to_dev(g) for g in gs]
+    q1, d1 = [be.empty(s_) for s_ in shapes], [be.empty(s_) for s_ in shapes]
+    for i, s_ in enumerate(shapes):
+        rows, cols = s_[0], int(np.prod(s_[1:]))
+        be.call("mn_iao_observe", be.ptr(dW[i]), rows, cols, obs_kind, int(first[i]), 0.1, be.ptr(st1[i]["mn"]), be.ptr(st1[i]["mx"]), None, be.stream)
+        be.call("mn_iao_qparams", be.ptr(st1[i]["mn"]), be.ptr(st1[i]["mx"]), rows, bits, q_type, 0, 1, be.ptr(st1[i]["sc"]), be.ptr(st1[i]["zp"]), be.ptr(st1[i]["qp"]), be.stream)
+        be.call("mn_iao_fq_fwd", be.ptr(dW[i]), be.ptr(q1[i]), rows, cols, be.ptr(st1[i]["qp"]), bits, q_type, 0, be.stream)
+        be.call("mn_iao_fq_bwd", be.ptr(dG[i]), be.ptr(dW[i]), be.ptr(d1[i]), rows, cols, be.ptr(st1[i]["qp"]), bits, q_type, 0, be.stream)
+    q2, d2 = [be.empty(s_) for s_ in shapes], [be.empty(s_) for s_ in shapes]
+    PA, LA, IA = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+    pa = lambda arrs: PA(*[be.ptr(a).value for a in arrs])
+    rows_a, cols_a = LA(*[s_[0] for s_ in shapes]), LA(*[int(np.prod(s_[1:])) for s_ in shapes])
+    be.call("mn_iao_w_fwd_multi", pa(dW), pa(q2), pa([t["mn"] for t in st2]), pa([t["mx"] for t in st2]), pa([t["sc"] for t in st2]), pa([t["zp"] for t in st2]),
+            pa([t["qp"] for t in st2]), rows_a, cols_a, IA(*[int(f) for f in first]), n, obs_kind, 0.1, bits, q_type, be.stream)
+    be.call("mn_iao_w_bwd_multi", pa(dG), pa(dW), pa(d2), pa([t["qp"] for t in st2]), rows_a, cols_a, n, bits, q_type, be.stream)
+    for i in range(n):
+        for k in ("mn", "mx", "sc", "zp", "qp"):
+            assert np.array_equal(be.to_host(st1[i][k]), be.to_host(st2[i][k])), (i, k)
+        assert np.array_equal(be.to_host(q1[i]), be.to_host(q2[i])), ("qw", i)
+        assert np.array_equal(be.to_host(d1[i]), be.to_host(d2[i])), ("dw", i)

@@ -418,3 +418,8 @@ def test_qdense_layer_iao_w8a8_bias(be):
 def test_iao_quant_add_fused(be, bits, q_type, obs_kind, first, update):
     K.check_iao_qadd(be, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=bits + q_type)
     K.check_iao_qadd(be, n=12, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=1)
+
+
+@pytest.mark.parametrize("bits,q_type,obs_kind", [(4, 0, 0), (8, 0, 1), (8, 1, 0)])
+def test_iao_weight_quantizers_multi(be, bits, q_type, obs_kind):
+    K.check_iao_w_multi(be, bits=bits, q_type=q_type, obs_kind=obs_kind, seed=bits)
