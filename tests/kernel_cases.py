@@ -1254,6 +1254,18 @@ def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=Fa
     dw_a, _ = be.conv_bwd_weight(g, aq0, dG, dX, 3, bias=False)
     dw_b, _ = be.conv_bwd_weight(g, aq, dG, be.to_dev(np.full(x_shape, np.nan, dtype=F)), 3, bias=False)
     assert np.array_equal(be.to_host(dw_a), be.to_host(dw_b))
+    # the IAO weight codes written once by mn_qd_pack_multi (codes = rint(w / scale[o])): same forward and backward-data without reading w again
+    dx1 = be.to_host(be.conv_bwd_data(g, aq0, dG, dW, dX, 3, wq=wq))
+    pb = int(be.lib.mn_qd_packed_bytes(C.byref(g)))
+    pk_f, pk_b = be.empty_i8((pb,)), be.empty_i8((pb,))
+    PA, LA, IA = C.c_void_p * 1, C.c_int64 * 1, C.c_int32 * 1
+    be.call("mn_qd_pack_multi", PA(be.ptr(dW).value), PA(be.ptr(pk_f).value), PA(be.ptr(pk_b).value), LA(Oc), LA(x_shape[1]), LA(k * k), PA(be.ptr(dWs).value), IA(1), 1,
+            w_bits, be.stream)
+    wq.packed_fwd, wq.packed_bwd = be.ptr(pk_f).value, be.ptr(pk_b).value
+    dWn = be.to_dev(np.full(w_shape, np.nan, dtype=F))
+    y3 = be.to_host(be.conv_fwd(g, aq0, dX, dWn, None, 3, wq=wq))
+    dx3 = be.to_host(be.conv_bwd_data(g, aq0, dG, dWn, dX, 3, wq=wq))
+    assert np.array_equal(y1, y3) and np.array_equal(dx1, dx3)
 
 
 def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, False), update=True, seed=0):
