@@ -161,7 +161,8 @@ int mn_iao_union_range(const float* min_a, const float* max_a, const float* min_
  * launches: mn_iao_qadd_observe = observer_res(res), observer_shortcut(shortcut) (per-tensor, obs_kind 0 running min / max, 1 moving average; first_*: the
  * observer's first call), union -> (min_out, max_out) = the shared quantizer's observer, and its qparams (update != 0: scale / zero_point recomputed, as in
  * training; 0: taken as they are) -> qp {scale, zero_point, lo, hi}; ws: mn_iao_qadd_ws_floats() floats.  mn_iao_qadd_fwd: out = fq(res) + fq(shortcut);
- * mn_iao_qadd_bwd: both clip-STE gradients from one read of g.  n % 4 == 0, 16-byte aligned tensors.  Bit-identical to the separate entry points. */
+ * mn_iao_qadd_bwd: both clip-STE gradients from one read of g.  relu != 0: the ReLU a ResNet block applies to the sum (models/resnet.py:63) in the same
+ * pass (backward: the gradient passes where the recomputed sum is > 0).  n % 4 == 0, 16-byte aligned tensors.  Bit-identical to the separate entry points. */
 /* The IAO weight quantizers of a whole net (per-channel observers: one row per output channel) in ONE launch per direction: for every row of every tensor the
  * observer update (obs_kind 0 running min / max, 1 moving average; first[i]: tensor i's observer is at its first call), scale / zero_point, the
  * {scale, zero_point, lo, hi} snapshot qp[i][rows][4] and the fake-quantised row (wqaq/iao/quantize.py:15-36, 293-321, 227-239, weights: activation_weight_flag 0).
@@ -175,9 +176,9 @@ int64_t mn_iao_qadd_ws_floats(void);
 int mn_iao_qadd_observe(const float* res, const float* shortcut, int64_t n, int obs_kind, int first_res, int first_shortcut, double momentum, float* min_res,
                         float* max_res, float* min_shortcut, float* max_shortcut, float* min_out, float* max_out, int bits, int q_type, int update, float* scale,
                         float* zero_point, float* qp, float* ws, mn_stream_t stream);
-int mn_iao_qadd_fwd(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, mn_stream_t stream);
+int mn_iao_qadd_fwd(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, mn_stream_t stream);
 int mn_iao_qadd_bwd(const float* g, const float* res, const float* shortcut, float* dres, float* dshortcut, int64_t n, const float* qp, int bits, int q_type,
-                    mn_stream_t stream);
+                    int relu, mn_stream_t stream);
 /* QuantBNFuseConv2d.forward 853-855: per-channel mean and UNBIASED variance of o[N][C][HW] over (N,HW).
  * stats: [2][C] = mean, var.  ws: >= mn_bn_stats_ws_floats(N, C, HW) floats. */
 int64_t mn_bn_stats_ws_floats(int64_t N, int64_t C, int64_t HW);

@@ -132,8 +132,8 @@ PROTOTYPES = {
     "mn_iao_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mn_iao_qadd_ws_floats": (_L, []),
     "mn_iao_qadd_observe": (_I, [_P, _P, _L, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "mn_iao_qadd_fwd": (_I, [_P, _P, _P, _L, _P, _I, _I, _P]),
-    "mn_iao_qadd_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _P]),
+    "mn_iao_qadd_fwd": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, _P]),
+    "mn_iao_qadd_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _P]),
     "mn_qd_packed_bytes": (_L, [_G]),
     "mn_qd_pack_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "mn_qr_ws_floats": (_L, [_L]),

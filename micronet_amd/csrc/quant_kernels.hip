@@ -1058,20 +1058,30 @@ __global__ __launch_bounds__(256) void k_qadd_final(const float* __restrict__ ws
         iao_qparams_row(mn, mx, f.q_type, f.quant_range, f.update, f.scale, f.zero_point, f.qp);
     }
 }
+// RELU: the ReLU the ResNet block applies to the sum (models/resnet.py:63) in the same pass -- relu(s) with ATen's NaN rule; backward mask s > 0 from the recomputed sum
+__device__ __forceinline__ float qadd_sum(float a, float b, float sc, float zp, float qmin, float qmax) { return iao_fq(a, sc, zp, qmin, qmax) + iao_fq(b, sc, zp, qmin, qmax); }
+template <int RELU>
 __global__ __launch_bounds__(256) void k_qadd_fwd(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n4,
                                                   const float* __restrict__ qp, float qmin, float qmax) {
     const float sc = qp[0], zp = qp[1];
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(a)[j], w = reinterpret_cast<const float4*>(b)[j];
-        reinterpret_cast<float4*>(y)[j] = make_float4(iao_fq(v.x, sc, zp, qmin, qmax) + iao_fq(w.x, sc, zp, qmin, qmax), iao_fq(v.y, sc, zp, qmin, qmax) + iao_fq(w.y, sc, zp, qmin, qmax),
-                                                      iao_fq(v.z, sc, zp, qmin, qmax) + iao_fq(w.z, sc, zp, qmin, qmax), iao_fq(v.w, sc, zp, qmin, qmax) + iao_fq(w.w, sc, zp, qmin, qmax));
+        float4 o = make_float4(qadd_sum(v.x, w.x, sc, zp, qmin, qmax), qadd_sum(v.y, w.y, sc, zp, qmin, qmax), qadd_sum(v.z, w.z, sc, zp, qmin, qmax), qadd_sum(v.w, w.w, sc, zp, qmin, qmax));
+        if (RELU) o = make_float4(qa_relu(o.x), qa_relu(o.y), qa_relu(o.z), qa_relu(o.w));
+        reinterpret_cast<float4*>(y)[j] = o;
     }
 }
+template <int RELU>
 __global__ __launch_bounds__(256) void k_qadd_bwd(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ da,
                                                   float* __restrict__ db, int64_t n4, const float* __restrict__ qp, float qmin, float qmax) {
     const float sc = qp[0], zp = qp[1], lo = qp[2], hi = qp[3];
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
-        const float4 gv = reinterpret_cast<const float4*>(g)[j], v = reinterpret_cast<const float4*>(a)[j], w = reinterpret_cast<const float4*>(b)[j];
+        float4 gv = reinterpret_cast<const float4*>(g)[j];
+        const float4 v = reinterpret_cast<const float4*>(a)[j], w = reinterpret_cast<const float4*>(b)[j];
+        if (RELU) {          // threshold_backward: the gradient passes where the (recomputed) sum is > 0
+            gv.x = qadd_sum(v.x, w.x, sc, zp, qmin, qmax) > 0.f ? gv.x : 0.f; gv.y = qadd_sum(v.y, w.y, sc, zp, qmin, qmax) > 0.f ? gv.y : 0.f;
+            gv.z = qadd_sum(v.z, w.z, sc, zp, qmin, qmax) > 0.f ? gv.z : 0.f; gv.w = qadd_sum(v.w, w.w, sc, zp, qmin, qmax) > 0.f ? gv.w : 0.f;
+        }
         reinterpret_cast<float4*>(da)[j] = make_float4(iao_fq_grad(gv.x, v.x, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(gv.y, v.y, sc, zp, lo, hi, qmin, qmax),
                                                        iao_fq_grad(gv.z, v.z, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(gv.w, v.w, sc, zp, lo, hi, qmin, qmax));
         reinterpret_cast<float4*>(db)[j] = make_float4(iao_fq_grad(gv.x, w.x, sc, zp, lo, hi, qmin, qmax), iao_fq_grad(gv.y, w.y, sc, zp, lo, hi, qmin, qmax),
@@ -1098,28 +1108,30 @@ extern "C" int mn_iao_qadd_observe(const float* res, const float* shortcut, int6
     MN_CHECK_LAUNCH("mn_iao_qadd_observe");
     return MN_OK;
 }
-extern "C" int mn_iao_qadd_fwd(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, mn_stream_t stream) {
+extern "C" int mn_iao_qadd_fwd(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, mn_stream_t stream) {
     if (n <= 0 || n % 4 || !res || !shortcut || !out || !qp || !aligned16(res) || !aligned16(shortcut) || !aligned16(out) || bits < 2 || bits > 24)
         MN_FAIL(MN_EINVAL, "mn_iao_qadd_fwd: bad arguments");
     const IaoRange r = iao_range(bits, q_type, 1);
     mn_prof_bytes(12.0 * (double)n);
-    mn_set_last_kernel("k_qadd_fwd");
+    mn_set_last_kernel("k_qadd_fwd<%d>", relu ? 1 : 0);
     mn_prof_begin((hipStream_t)stream);
-    hipLaunchKernelGGL(k_qadd_fwd, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, res, shortcut, out, n / 4, qp, r.qmin, r.qmax);
+    if (relu) hipLaunchKernelGGL(k_qadd_fwd<1>, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, res, shortcut, out, n / 4, qp, r.qmin, r.qmax);
+    else hipLaunchKernelGGL(k_qadd_fwd<0>, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, res, shortcut, out, n / 4, qp, r.qmin, r.qmax);
     mn_prof_end((hipStream_t)stream);
     MN_CHECK_LAUNCH("mn_iao_qadd_fwd");
     return MN_OK;
 }
 extern "C" int mn_iao_qadd_bwd(const float* g, const float* res, const float* shortcut, float* dres, float* dshortcut, int64_t n, const float* qp, int bits, int q_type,
-                               mn_stream_t stream) {
+                               int relu, mn_stream_t stream) {
     if (n <= 0 || n % 4 || !g || !res || !shortcut || !dres || !dshortcut || !qp || !aligned16(g) || !aligned16(res) || !aligned16(shortcut) || !aligned16(dres) ||
         !aligned16(dshortcut) || bits < 2 || bits > 24)
         MN_FAIL(MN_EINVAL, "mn_iao_qadd_bwd: bad arguments");
     const IaoRange r = iao_range(bits, q_type, 1);
     mn_prof_bytes(20.0 * (double)n);
-    mn_set_last_kernel("k_qadd_bwd");
+    mn_set_last_kernel("k_qadd_bwd<%d>", relu ? 1 : 0);
     mn_prof_begin((hipStream_t)stream);
-    hipLaunchKernelGGL(k_qadd_bwd, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, g, res, shortcut, dres, dshortcut, n / 4, qp, r.qmin, r.qmax);
+    if (relu) hipLaunchKernelGGL(k_qadd_bwd<1>, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, g, res, shortcut, dres, dshortcut, n / 4, qp, r.qmin, r.qmax);
+    else hipLaunchKernelGGL(k_qadd_bwd<0>, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, g, res, shortcut, dres, dshortcut, n / 4, qp, r.qmin, r.qmax);
     mn_prof_end((hipStream_t)stream);
     MN_CHECK_LAUNCH("mn_iao_qadd_bwd");
     return MN_OK;

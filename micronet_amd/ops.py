@@ -418,24 +418,24 @@ class IaoQuantAdd(Function):
     """out = Q(res) + Q(shortcut) with one shared per-tensor quantizer (QuantAdd, wqaq/iao/quantize.py:1484-1498): one pass forward, one backward."""
 
     @staticmethod
-    def forward(ctx, res, shortcut, qp, bits, q_type):
+    def forward(ctx, res, shortcut, qp, bits, q_type, relu=False):
         res, shortcut = _chk(res, "res"), _chk(shortcut, "shortcut")
         out = torch.empty_like(res)
         with torch.cuda.device_of(res):
-            _call("mn_iao_qadd_fwd", _p(res), _p(shortcut), _p(out), res.numel(), _p(qp), bits, q_type, _s())
+            _call("mn_iao_qadd_fwd", _p(res), _p(shortcut), _p(out), res.numel(), _p(qp), bits, q_type, int(relu), _s())
         ctx.save_for_backward(res, shortcut, qp)
-        ctx.cfg = (bits, q_type)
+        ctx.cfg = (bits, q_type, int(relu))
         return out
 
     @staticmethod
     def backward(ctx, g):
         res, shortcut, qp = ctx.saved_tensors
-        bits, q_type = ctx.cfg
+        bits, q_type, relu = ctx.cfg
         g = _chk(g, "grad")
         da, db = torch.empty_like(res), torch.empty_like(shortcut)
         with torch.cuda.device_of(res):
-            _call("mn_iao_qadd_bwd", _p(g), _p(res), _p(shortcut), _p(da), _p(db), res.numel(), _p(qp), bits, q_type, _s())
-        return da, db, None, None, None
+            _call("mn_iao_qadd_bwd", _p(g), _p(res), _p(shortcut), _p(da), _p(db), res.numel(), _p(qp), bits, q_type, relu, _s())
+        return da, db, None, None, None, None
 
 
 class IaoFakeQuant(Function):

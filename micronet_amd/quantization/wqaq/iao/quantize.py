@@ -493,7 +493,14 @@ class QuantAdd(nn.Module):
             self.observer_shortcut = HistogramObserver(q_level="L", percentile=percentile)
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile, union=True)
 
-    def forward(self, res, shortcut):
+    def forward(self, res, shortcut, relu=False):
+        """``relu`` (ours): also apply the ReLU the ResNet block puts on the sum (models/resnet.py:63) -- in the same pass on the fused path."""
+        if relu:
+            out = self._forward(res, shortcut, True)
+            return out if getattr(out, "_mn_relu_done", False) else F.relu(out)
+        return self._forward(res, shortcut, False)
+
+    def _forward(self, res, shortcut, relu):
         q = self.activation_quantizer
         obs_r, obs_s = self.observer_res, self.observer_shortcut
         if (torch.is_tensor(res) and torch.is_tensor(shortcut) and res.is_cuda and shortcut.is_cuda and res.dtype == torch.float32 and shortcut.dtype == torch.float32
@@ -510,7 +517,10 @@ class QuantAdd(nn.Module):
                 if o.num_flag == 0:
                     o.num_flag += 1
             q._last_qp = qp
-            return ops.IaoQuantAdd.apply(res, shortcut, qp, q.bits, q.q_type)
+            out = ops.IaoQuantAdd.apply(res, shortcut, qp, q.bits, q.q_type, bool(relu))
+            if relu:
+                out._mn_relu_done = True
+            return out
         # both observers run unconditionally, also in eval (ref 1485-1486); the union range feeds ONE shared quantizer
         self.observer_res(res)
         self.observer_shortcut(shortcut)
@@ -612,6 +622,27 @@ def add_quant_op(module, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observe
             add_quant_op(child, **kw_all)
 
 
+class _ResidualAddReLUMixin:
+    """forward of the reference's residual blocks (models/resnet.py:60-65: ``relu(add(residual_function(x), shortcut(x)))``) with the trailing ReLU folded into
+    the QuantAdd pass; installed by ``prepare(fuse_bn_act=True)`` as a subclass of the block's own class (same children, parameters, ``state_dict``)."""
+
+    def forward(self, x):
+        return self.add(self.residual_function(x), self.shortcut(x), relu=True)
+
+
+_RES_BLOCK_CLASSES = {}
+
+
+def _fuse_residual_tails(model):
+    for m in model.modules():
+        t = type(m)
+        if t.__name__ in ("BasicBlock", "BottleNeck") and t.__module__.split(".")[-1] == "resnet" and isinstance(getattr(m, "add", None), QuantAdd) \
+                and isinstance(getattr(m, "residual_function", None), nn.Sequential) and isinstance(getattr(m, "shortcut", None), nn.Sequential):
+            if t not in _RES_BLOCK_CLASSES:
+                _RES_BLOCK_CLASSES[t] = type("AddReLU" + t.__name__, (_ResidualAddReLUMixin, t), {"__module__": t.__module__})
+            m.__class__ = _RES_BLOCK_CLASSES[t]
+
+
 def prepare(model, inplace=False, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=False,
             bn_fuse_calib=False, quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999, fuse_bn_act=True):
     """Same rewrite as the reference (ref 1791-1830).  ``fuse_bn_act`` (ours, default on): see add_quant_op; off = exactly the reference's module classes."""
@@ -620,4 +651,6 @@ def prepare(model, inplace=False, a_bits=8, w_bits=8, q_type=0, q_level=0, weigh
     add_quant_op(model, a_bits=a_bits, w_bits=w_bits, q_type=q_type, q_level=q_level, weight_observer=weight_observer,
                  bn_fuse=bn_fuse, bn_fuse_calib=bn_fuse_calib, quant_inference=quant_inference,
                  pretrained_model=pretrained_model, qaft=qaft, ptq=ptq, percentile=percentile, fuse_bn_act=fuse_bn_act)
+    if fuse_bn_act:
+        _fuse_residual_tails(model)
     return model

@@ -1268,7 +1268,7 @@ def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=Fa
     assert np.array_equal(y1, y3) and np.array_equal(dx1, dx3)
 
 
-def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, False), update=True, seed=0):
+def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, False), update=True, seed=0, relu=False):
     """mn_iao_qadd_observe / _fwd / _bwd (QuantAdd, wqaq/iao/quantize.py:1484-1498, in three launches) == the separate entry points it replaces
     (mn_iao_observe x 2, mn_iao_union_range, mn_iao_qparams, mn_iao_fq_fwd x 2 + add, mn_iao_fq_bwd x 2), bit for bit: outputs, gradients, every buffer."""
     r = np.random.default_rng(seed)
@@ -1292,9 +1292,13 @@ def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, Fa
     be.call("mn_iao_fq_fwd", be.ptr(dA), be.ptr(ya), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
     be.call("mn_iao_fq_fwd", be.ptr(dB), be.ptr(yb), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
     y_ref = (be.to_host(ya) + be.to_host(yb)).astype(F)
+    dG_eff = dG
+    if relu:            # the block's ReLU on the sum: forward max(s, 0), backward g * [s > 0]
+        dG_eff = be.to_dev(np.where(y_ref > 0, g, F(0)).astype(F))
+        y_ref = np.maximum(y_ref, F(0))
     da1, db1 = be.empty(n), be.empty(n)
-    be.call("mn_iao_fq_bwd", be.ptr(dG), be.ptr(dA), be.ptr(da1), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
-    be.call("mn_iao_fq_bwd", be.ptr(dG), be.ptr(dB), be.ptr(db1), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
+    be.call("mn_iao_fq_bwd", be.ptr(dG_eff), be.ptr(dA), be.ptr(da1), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
+    be.call("mn_iao_fq_bwd", be.ptr(dG_eff), be.ptr(dB), be.ptr(db1), 1, n, be.ptr(qp1), bits, q_type, 1, be.stream)
     # ---- fused
     s2 = fresh()
     ws2 = be.empty(int(be.lib.mn_iao_qadd_ws_floats()))
@@ -1302,8 +1306,8 @@ def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, Fa
     be.call("mn_iao_qadd_observe", be.ptr(dA), be.ptr(dB), n, obs_kind, int(first[0]), int(first[1]), mom, be.ptr(s2["min_a"]), be.ptr(s2["max_a"]), be.ptr(s2["min_b"]),
             be.ptr(s2["max_b"]), be.ptr(s2["min_o"]), be.ptr(s2["max_o"]), bits, q_type, int(update), be.ptr(s2["scale"]), be.ptr(s2["zp"]), be.ptr(qp2), be.ptr(ws2), be.stream)
     y2, da2, db2 = be.empty(n), be.empty(n), be.empty(n)
-    be.call("mn_iao_qadd_fwd", be.ptr(dA), be.ptr(dB), be.ptr(y2), n, be.ptr(qp2), bits, q_type, be.stream)
-    be.call("mn_iao_qadd_bwd", be.ptr(dG), be.ptr(dA), be.ptr(dB), be.ptr(da2), be.ptr(db2), n, be.ptr(qp2), bits, q_type, be.stream)
+    be.call("mn_iao_qadd_fwd", be.ptr(dA), be.ptr(dB), be.ptr(y2), n, be.ptr(qp2), bits, q_type, int(relu), be.stream)
+    be.call("mn_iao_qadd_bwd", be.ptr(dG), be.ptr(dA), be.ptr(dB), be.ptr(da2), be.ptr(db2), n, be.ptr(qp2), bits, q_type, int(relu), be.stream)
     for k in st0:
         assert np.array_equal(be.to_host(s1[k]), be.to_host(s2[k])), k
     assert np.array_equal(be.to_host(qp1), be.to_host(qp2)), "qp"

@@ -619,6 +619,7 @@ def test_qdense_layer_iao_w8a8_bias(be):
                                                               (8, 0, 0, (False, False), True), (4, 0, 1, (False, False), False)])
 def test_iao_quant_add_fused(be, bits, q_type, obs_kind, first, update):
     K.check_iao_qadd(be, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=bits + q_type)
+    K.check_iao_qadd(be, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=bits + q_type + 7, relu=True)
     K.check_iao_qadd(be, n=256 * 64 * 32 * 32, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=1)
 
 

@@ -449,7 +449,13 @@ def test_full_batch_teacher_forced_resnet_iao(key):
         errs = {}
         tail_o = [ob.add] + ([ob.relu] if hasattr(ob, "relu") else [])
         tail_p = [pb.add] + ([pb.relu] if hasattr(pb, "relu") else [])
-        comb = lambda mods, u, v: (mods[1](mods[0](u, v)) if len(mods) > 1 else torch.nn.functional.relu(mods[0](u, v)))
+        def comb(mods, u, v):          # the product's QuantAdd takes the block's ReLU into its own pass (relu=True); the oracle's is the reference's
+            import inspect
+            if len(mods) > 1:
+                return mods[1](mods[0](u, v))
+            if "relu" in inspect.signature(mods[0].forward).parameters:
+                return mods[0](u, v, relu=True)
+            return torch.nn.functional.relu(mods[0](u, v))
         errs["ties_masked_frac"] = float((~keep_t).sum()) / keep_t.numel()
         run_piece(n + ":t", errs, tail_o, tail_p, [zb.detach(), zs.detach()], gout * keep_t, True, combine=comb)
         report[n + ":qadd-relu"] = {k: float("%.2e" % v) for k, v in errs.items()}
