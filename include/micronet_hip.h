@@ -314,6 +314,12 @@ int mn_bnrelu_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float*
                   int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream);
 int mn_bnrelu_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                   int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
+/* plain nn.BatchNorm2d (no activation behind it: the BatchNorms in front of a residual add, models/resnet.py:21-29) on the same streaming kernels: same
+ * arguments as mn_bnrelu_fwd / _bwd. */
+int mn_bn2d_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream);
+int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 /* the two halves of mn_bnsign_bwd for a consumer that forms dy itself: mn_bnsign_bwd_sums = dgamma, dbeta and sums [2][C] =
  * {sum dz, sum dz*zhat}; mn_conv2d_bwd_weight_first_bn = backward-weight (+ dbias) of the first-layer convolution
  * (mn_conv2d_first_supported) whose output y went through BatchNorm2d + BinaryActivation: dy is formed from (da, y, save, gamma,

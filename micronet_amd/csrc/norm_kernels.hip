@@ -29,7 +29,7 @@ struct BnsGeom {
     int N, C, HW, HW4;      // HW4 = HW / 4
     FastDiv fd_hw4;
     int64_t n4;             // float4 per channel = N * HW4
-    int act;                // 0: BinaryActivation (sign; backward mask |z| < 1)   1: ReLU (max(z, 0); backward mask z > 0)
+    int act;                // 0: BinaryActivation (sign; backward mask |z| < 1)   1: ReLU (max(z, 0); backward mask z > 0)   2: none (plain BatchNorm2d)
 };
 static BnsGeom bns_geom(int64_t N, int64_t C, int64_t HW) {
     BnsGeom g;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_bns_partial(const BnsGeom g, const floa
             float t1 = 0.f, t2 = 0.f;                                                                                                 \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                           \
                 const float z = zh[e] * ga + be;                                                                                      \
-                const float dz = (g.act ? (z > 0.f) : (z > -1.f && z < 1.f)) ? gv[e] : 0.f;   /* clip-STE of the sign / ReLU mask */   \
+                const float dz = (g.act == 2 || (g.act ? (z > 0.f) : (z > -1.f && z < 1.f))) ? gv[e] : 0.f;   /* clip-STE of the sign / ReLU mask */   \
                 t1 += dz;                                                                                                             \
                 t2 += dz * zh[e];                                                                                                     \
             }                                                                                                                         \
@@ -141,13 +141,13 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
         const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};             \
         float r[4];                                                                                                                   \
         if (MODE == 0) {                                                                                                              \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float z = zh[e] * ga + be; r[e] = g.act ? bns_relu(z) : bns_sign(z); } \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float z = zh[e] * ga + be; r[e] = g.act == 2 ? z : (g.act ? bns_relu(z) : bns_sign(z)); } \
         } else {                                                                                                                      \
             const float4 gg = gg_[k];                                                                                                 \
             const float gv[4] = {gg.x, gg.y, gg.z, gg.w};                                                                             \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                           \
                 const float z = zh[e] * ga + be;                                                                                      \
-                const float dz = (g.act ? (z > 0.f) : (z > -1.f && z < 1.f)) ? gv[e] : 0.f;                                           \
+                const float dz = (g.act == 2 || (g.act ? (z > 0.f) : (z > -1.f && z < 1.f))) ? gv[e] : 0.f;                                           \
                 r[e] = gi * (dz - k1 - zh[e] * k2);                                                                                   \
             }                                                                                                                         \
         }                                                                                                                             \
@@ -421,6 +421,15 @@ extern "C" int mn_bnrelu_fwd(const float* y, int64_t N, int64_t C, int64_t HW, c
 extern "C" int mn_bnrelu_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                              int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
     return bnsign_bwd_impl(da, y, save, gamma, beta, N, C, HW, training, dy, dgamma, dbeta, ws, stream, 1);
+}
+// plain nn.BatchNorm2d on the same streaming kernels (no activation: the BatchNorms in front of a residual add, models/resnet.py:21-29)
+extern "C" int mn_bn2d_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                           int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
+    return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream, 2);
+}
+extern "C" int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
+                           int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
+    return bnsign_bwd_impl(da, y, save, gamma, beta, N, C, HW, training, dy, dgamma, dbeta, ws, stream, 2);
 }
 static int bnsign_bwd_impl(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                            int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream, int act) {

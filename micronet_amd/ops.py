@@ -647,20 +647,22 @@ class BNSign(Function):
 class BNReLU(Function):
     """relu(batch_norm(y)) in one fused op (training or eval statistics): the three / five streaming passes of BNSign with max(z, 0) and
     the ReLU mask -- the ConvBNReLU blocks of the DoReFa / IAO nets (models/nin_gc.py:53-59) otherwise run MIOpen's BatchNorm kernels
-    plus separate ReLU forward / backward kernels.  z is recomputed from y in the backward, never stored."""
+    plus separate ReLU forward / backward kernels.  z is recomputed from y in the backward, never stored.  ``_fn``: "mn_bn2d" = the same passes without
+    the activation (plain nn.BatchNorm2d: ``BatchNorm2dPlain``)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, fn="mn_bnrelu"):
         y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
         N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
         a = torch.empty_like(y)
         save = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
         with torch.cuda.device_of(y):
-            _call("mn_bnrelu_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training), _p(running_mean),
+            _call(fn + "_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training), _p(running_mean),
                   _p(running_var), _p(save), _p(a), _p(ws), _s())
         ctx.save_for_backward(y, gamma, beta, save)
         ctx.training = int(training)
+        ctx.fn = fn
         return a
 
     @staticmethod
@@ -671,8 +673,8 @@ class BNReLU(Function):
         dgamma, dbeta, dy = torch.empty_like(gamma), torch.empty_like(beta), torch.empty_like(y)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
         with torch.cuda.device_of(y):
-            _call("mn_bnrelu_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, ctx.training, _p(dy), _p(dgamma), _p(dbeta), _p(ws), _s())
-        return dy, dgamma, dbeta, None, None, None, None, None
+            _call(ctx.fn + "_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, ctx.training, _p(dy), _p(dgamma), _p(dbeta), _p(ws), _s())
+        return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
 def bnrelu_supported(x):

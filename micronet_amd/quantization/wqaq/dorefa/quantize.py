@@ -225,6 +225,21 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
                                 self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
 
 
+class BatchNorm2dPlain(nn.BatchNorm2d):
+    """``nn.BatchNorm2d`` (no activation behind it -- the BatchNorms in front of a residual add, models/resnet.py:21-29) on the streaming kernels of
+    ``BatchNorm2dReLU`` instead of MIOpen's: same parameters, buffers and ``state_dict`` keys; anything the kernels do not cover runs the stock forward."""
+
+    def forward(self, input):
+        from micronet_amd import ops
+        use_batch = self.training or self.running_mean is None
+        if not (self.affine and ops.bnrelu_supported(input) and self.momentum is not None and (use_batch or self.track_running_stats)):
+            return super().forward(input)
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d")
+
+
 class MaxPool2dF32(nn.MaxPool2d):
     """``nn.MaxPool2d`` whose 2x2 / stride-2 case runs on the gfx950 kernels (byte argmax, scatter backward); anything else is the stock module."""
 

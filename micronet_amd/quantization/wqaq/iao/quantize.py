@@ -634,6 +634,13 @@ _RES_BLOCK_CLASSES = {}
 
 
 def _fuse_residual_tails(model):
+    from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dPlain
+    for m in model.modules():
+        # the BatchNorms that are NOT followed by a ReLU inside a Sequential (the last one of a residual function, the shortcut's): our streaming kernels
+        if isinstance(m, nn.Sequential):
+            for child in m.children():
+                if type(child) is nn.BatchNorm2d and child.affine and child.track_running_stats:
+                    child.__class__ = BatchNorm2dPlain
     for m in model.modules():
         t = type(m)
         if t.__name__ in ("BasicBlock", "BottleNeck") and t.__module__.split(".")[-1] == "resnet" and isinstance(getattr(m, "add", None), QuantAdd) \

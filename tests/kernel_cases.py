@@ -410,8 +410,9 @@ def check_bnsign(be, shape=(6, 5, 4, 8), seed=0, training=True):
     assert close(be.to_host(dy), dy_ref, tol)
 
 
-def check_bnrelu(be, shape=(6, 5, 4, 8), seed=0, training=True):
-    """mn_bnrelu_fwd/bwd vs an fp64 numpy evaluation of relu(BatchNorm2d(y)) (batch or running statistics) and its backward."""
+def check_bnrelu(be, shape=(6, 5, 4, 8), seed=0, training=True, plain=False):
+    """mn_bnrelu_fwd/bwd vs an fp64 numpy evaluation of relu(BatchNorm2d(y)) (batch or running statistics) and its backward; plain: mn_bn2d_fwd/bwd, the
+    same passes without the activation (nn.BatchNorm2d)."""
     r = np.random.default_rng(seed)
     N, Cc, H, W = shape
     HW = H * W
@@ -429,25 +430,26 @@ def check_bnrelu(be, shape=(6, 5, 4, 8), seed=0, training=True):
     invstd = 1.0 / np.sqrt(var_b + eps)
     zh = (y64 - mean.reshape(1, -1, 1, 1)) * invstd.reshape(1, -1, 1, 1)
     z = zh * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
-    a_ref = np.maximum(z, 0.0)
-    dz = np.where(z > 0, da.astype(np.float64), 0.0)
+    a_ref = z if plain else np.maximum(z, 0.0)
+    dz = da.astype(np.float64) if plain else np.where(z > 0, da.astype(np.float64), 0.0)
     dbeta_ref, dgamma_ref = dz.sum(axis=(0, 2, 3)), (dz * zh).sum(axis=(0, 2, 3))
     gi = (gamma * invstd).reshape(1, -1, 1, 1)
     dy_ref = gi * (dz - dbeta_ref.reshape(1, -1, 1, 1) / n - zh * dgamma_ref.reshape(1, -1, 1, 1) / n) if training else gi * dz
     dY, dG, dB, dRM, dRV, dDA = be.to_dev(y), be.to_dev(gamma), be.to_dev(beta), be.to_dev(rm), be.to_dev(rv), be.to_dev(da)
     save, a, dy, dgam, dbet = be.empty((2, Cc)), be.empty(shape), be.empty(shape), be.empty(Cc), be.empty(Cc)
     ws = be.empty(int(be.lib.mn_bnsign_ws_floats(Cc)) + 2)
-    be.call("mn_bnrelu_fwd", be.ptr(dY), N, Cc, HW, be.ptr(dG), be.ptr(dB), eps, mom, int(training), be.ptr(dRM), be.ptr(dRV),
+    fn = "mn_bn2d" if plain else "mn_bnrelu"
+    be.call(fn + "_fwd", be.ptr(dY), N, Cc, HW, be.ptr(dG), be.ptr(dB), eps, mom, int(training), be.ptr(dRM), be.ptr(dRV),
             be.ptr(save), be.ptr(a), be.ptr(ws), be.stream)
-    be.call("mn_bnrelu_bwd", be.ptr(dDA), be.ptr(dY), be.ptr(save), be.ptr(dG), be.ptr(dB), N, Cc, HW, int(training), be.ptr(dy),
+    be.call(fn + "_bwd", be.ptr(dDA), be.ptr(dY), be.ptr(save), be.ptr(dG), be.ptr(dB), N, Cc, HW, int(training), be.ptr(dy),
             be.ptr(dgam), be.ptr(dbet), be.ptr(ws), be.stream)
-    assert close(be.to_host(a), a_ref, 2e-6) and np.all(be.to_host(a) >= 0)
+    assert close(be.to_host(a), a_ref, 2e-6) and (plain or np.all(be.to_host(a) >= 0))
     sv = be.to_host(save)
     assert np.max(np.abs(sv[0] - mean)) <= 1e-6 * max(1.0, np.max(np.abs(mean))) and np.max(np.abs(sv[1] - invstd) / invstd) <= 2e-6
     if training:
         assert np.max(np.abs(be.to_host(dRM) - ((1 - mom) * rm + mom * mean))) <= 1e-6
         assert np.max(np.abs(be.to_host(dRV) - ((1 - mom) * rv + mom * var_u))) <= 2e-6 * np.max(var_u)
-    edge = (np.abs(z) < 1e-5).any()              # an element within rounding of the ReLU kink
+    edge = (not plain) and (np.abs(z) < 1e-5).any()              # an element within rounding of the ReLU kink
     tol = 1e-3 if edge else 1e-5
     assert close(be.to_host(dbet), dbeta_ref, tol) and close(be.to_host(dgam), dgamma_ref, tol)
     assert close(be.to_host(dy), dy_ref, tol)

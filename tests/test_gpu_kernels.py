@@ -626,3 +626,9 @@ def test_iao_quant_add_fused(be, bits, q_type, obs_kind, first, update):
 @pytest.mark.parametrize("bits,q_type,obs_kind", [(4, 0, 0), (8, 0, 1), (8, 1, 0)])
 def test_iao_weight_quantizers_multi(be, bits, q_type, obs_kind):
     K.check_iao_w_multi(be, bits=bits, q_type=q_type, obs_kind=obs_kind, seed=bits)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bn2d_plain(be, training):
+    K.check_bnrelu(be, training=training, plain=True)
+    K.check_bnrelu(be, shape=(33, 64, 16, 16), seed=3, training=training, plain=True)
