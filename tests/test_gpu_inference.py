@@ -71,6 +71,48 @@ def test_wbwtab_bn_fused_inference_graph(W):
     with torch.no_grad():
         t, i, f = T(x), I(x), F(x)
     assert float((t - i).abs().max()) <= 1e-6 * float(t.abs().max())                                      # pre-quantisation alone is exact
+    # ---- block by block on the SAME (teacher-forced) input: every stage of the folded graph gets the training graph's input of that stage; a binary block's
+    # output must carry the same signs except where the folded pre-activation is a tie (|c| within 1e-5 of the channel's scale: there the fold's
+    # y - mean + beta std / gamma and the BatchNorm's gamma (y - mean) / std + beta legitimately round to different sides); the last (real-valued) block
+    # to 1e-5.  A sign error on a gamma < 0 channel or a lost channel shuffle of a replaced conv moves half of a block's outputs.
+    from micronet_amd.sign_tensor import SignTensor
+    tof = lambda v: v.to_float() if isinstance(v, SignTensor) else v.float()
+    rec_in, rec_out, pre = {}, {}, {}
+    hooks = []
+    def recorder(k):
+        def fn(mod, inp, out):          # (returns None: a hook's return value would replace the output)
+            rec_in[k], rec_out[k] = inp[0], out
+        return fn
+    for k, m in enumerate(T.model):
+        hooks.append(m.register_forward_hook(recorder(k)))
+    with torch.no_grad():
+        T(x)
+    for h in hooks:
+        h.remove()
+    n_bin = 0
+    for k, (mt, mf) in enumerate(zip(T.model, F.model)):
+        act = getattr(mf, "relu", None)
+        def pre_rec(mod, inp, k=k):
+            pre[k] = tof(inp[0])
+        hk = act.register_forward_pre_hook(pre_rec) if isinstance(act, torch.nn.Module) else None
+        with torch.no_grad():
+            of = tof(mf(rec_in[k]))
+        if hk is not None:
+            hk.remove()
+        ot = tof(rec_out[k])
+        binary = bool(((ot == 1) | (ot == -1)).all()) and k in pre
+        if binary:
+            n_bin += 1
+            c = pre[k]
+            tie = c.abs() <= 1e-5 * c.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
+            if of.shape != c.shape:          # (a pooled block: compare through the pool on the tie mask too)
+                tie = torch.nn.functional.max_pool2d(tie.float(), 2, 2) > 0 if c.shape[2] == 2 * of.shape[2] else tie
+            bad = (of != ot)
+            assert float(bad.float().mean()) <= 1e-3 and bool(tie[bad].all()) if tie.shape == bad.shape else float(bad.float().mean()) <= 1e-4, \
+                ("stage %d: folded block disagrees with BatchNorm + sign away from ties" % k, int(bad.sum()), float(bad.float().mean()))
+        else:
+            assert float((of - ot).abs().max()) <= 1e-5 * float(ot.abs().max().clamp_min(1e-30)), ("stage %d" % k, float((of - ot).abs().max()))
+    assert n_bin >= 7
     agree = float((t.argmax(1) == f.argmax(1)).float().mean())
     rel = float((t - f).abs().max() / t.abs().max())
     print("W", W, "bn-fused vs train graph: max rel logit diff", rel, "class agreement", agree)
