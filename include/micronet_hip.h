@@ -308,6 +308,9 @@ int mn_bnsign_bwd(const float* da, const float* y, const float* save, const floa
 int mn_maxpool2x2_f32_supported(int64_t H, int64_t W);
 int mn_maxpool2x2_f32_fwd(const float* x, int64_t planes, int64_t H, int64_t W, float* y, uint8_t* idx, mn_stream_t stream);
 int mn_maxpool2x2_f32_bwd(const float* gy, const uint8_t* idx, int64_t planes, int64_t H, int64_t W, float* dx, mn_stream_t stream);
+/* nn.AvgPool2d whose window covers the whole image (the tail of nin / nin_gc, models/nin_gc.py:139): x [planes][HW] -> y [planes] = sum / HW; backward gy / HW. */
+int mn_avgpool_global_fwd(const float* x, int64_t planes, int64_t HW, float* y, mn_stream_t stream);
+int mn_avgpool_global_bwd(const float* gy, int64_t planes, int64_t HW, float* dx, mn_stream_t stream);
 /* BatchNorm2d + ReLU fused the same way (relu(batch_norm(y)) of the ConvBNReLU blocks in the DoReFa / IAO nets, models/nin_gc.py:53-59;
  * backward mask z > 0): same arguments as mn_bnsign_fwd / mn_bnsign_bwd, fp32 output. */
 int mn_bnrelu_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,

@@ -91,6 +91,8 @@ PROTOTYPES = {
     "mn_maxpool2x2_f32_bwd": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "mn_bnrelu_fwd": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P]),
     "mn_bnrelu_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P]),
+    "mn_avgpool_global_fwd": (_I, [_P, _L, _L, _P, _P]),
+    "mn_avgpool_global_bwd": (_I, [_P, _L, _L, _P, _P]),
     "mn_bn2d_fwd": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P]),
     "mn_bn2d_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P]),
     "mn_qconv_bnsign_supported": (_I, [_G, _W]),

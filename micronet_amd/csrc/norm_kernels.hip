@@ -309,6 +309,35 @@ extern "C" int mn_maxpool2x2_f32_bwd(const float* gy, const uint8_t* idx, int64_
     return MN_OK;
 }
 
+// nn.AvgPool2d whose window is the whole image (the tail of the reference's nin / nin_gc: AvgPool2d(8) on 8 x 8 maps, models/nin_gc.py:139): one wave per
+// plane, lanes stride over the pixels, fixed-order wave reduction -- ATen's generic avg_pool2d kernel takes 32 us for this 160 KB tensor.
+__global__ __launch_bounds__(256) void k_gap_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t planes, int HW, float inv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float s = 0.f;
+    if (pl < planes) for (int i = lane; i < HW; i += 64) s += x[pl * HW + i];
+    s = wave_reduce(s, OpAddF());
+    if (pl < planes && lane == 0) y[pl] = s / inv;          // (inv holds the window size: ATen divides)
+}
+__global__ __launch_bounds__(256) void k_gap_bwd(const float* __restrict__ gy, float* __restrict__ dx, int64_t n, int HW, float inv) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] = gy[i / HW] / inv;
+}
+extern "C" int mn_avgpool_global_fwd(const float* x, int64_t planes, int64_t HW, float* y, mn_stream_t stream) {
+    if (!x || !y || planes <= 0 || HW <= 0 || HW > (1 << 20)) MN_FAIL(MN_EINVAL, "mn_avgpool_global_fwd: bad arguments");
+    mn_set_last_kernel("k_gap_fwd");
+    hipLaunchKernelGGL(k_gap_fwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, planes, (int)HW, (float)HW);
+    MN_CHECK_LAUNCH("mn_avgpool_global_fwd");
+    return MN_OK;
+}
+extern "C" int mn_avgpool_global_bwd(const float* gy, int64_t planes, int64_t HW, float* dx, mn_stream_t stream) {
+    if (!gy || !dx || planes <= 0 || HW <= 0 || HW > (1 << 20)) MN_FAIL(MN_EINVAL, "mn_avgpool_global_bwd: bad arguments");
+    const int64_t n = planes * HW;
+    mn_set_last_kernel("k_gap_bwd");
+    hipLaunchKernelGGL(k_gap_bwd, dim3(mn_grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, gy, dx, n, (int)HW, (float)HW);
+    MN_CHECK_LAUNCH("mn_avgpool_global_bwd");
+    return MN_OK;
+}
+
 extern "C" int64_t mn_bnsign_ws_floats(int64_t C) { return C * BNS_SPLIT * 4 + 2 * C + 16; }   // fp64 partials + {sum dz, sum dz*zhat}
 
 static int bns_check(int64_t N, int64_t C, int64_t HW, const void* a, const void* b, const char* what) {

@@ -34,3 +34,15 @@ class Conv2dSignIn(nn.Conv2d):
                 ops.sign_classifier_supported(input, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return ops.SignClassifierConv.apply(input, self.weight, self.bias)
         return super().forward(input)
+
+
+class AvgPool2dGlobal(nn.AvgPool2d):
+    """``nn.AvgPool2d`` whose window is the whole image (the tail of the reference's nin / nin_gc, models/nin_gc.py:139: AvgPool2d(8) on 8 x 8 maps): one small
+    gfx950 kernel instead of ATen's generic pooling kernel (32 us for a 160 KB tensor).  Any other geometry is the stock module."""
+
+    def forward(self, input):
+        pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+        if (torch.is_tensor(input) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and type(input) is torch.Tensor and input.is_contiguous()
+                and pair(self.kernel_size) == tuple(input.shape[2:]) and pair(self.padding) == (0, 0) and not self.ceil_mode and self.divisor_override is None):
+            return ops.GlobalAvgPool.apply(input)
+        return super().forward(input)

@@ -677,6 +677,29 @@ class BNReLU(Function):
         return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
+class GlobalAvgPool(Function):
+    """nn.AvgPool2d over the whole image (the tail of nin / nin_gc): [N, C, H, W] -> [N, C, 1, 1]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "input")
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, 1, 1), dtype=torch.float32, device=x.device)
+        with torch.cuda.device_of(x):
+            _call("mn_avgpool_global_fwd", _p(x), N * Cc, H * W, _p(y), _s())
+        ctx.shape = (N, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _chk(gy, "grad")
+        N, Cc, H, W = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=gy.device)
+        with torch.cuda.device_of(gy):
+            _call("mn_avgpool_global_bwd", _p(gy), N * Cc, H * W, _p(dx), _s())
+        return dx
+
+
 def bnrelu_supported(x):
     return torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and (x.shape[2] * x.shape[3]) % 4 == 0
 

@@ -256,6 +256,9 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                         prev2.lazy_for_bn = True        # conv -> bn -> sign in definition order: the conv output need never be stored
         elif type(child) is nn.MaxPool2d and packed_activations and A == 2:
             child.__class__ = MaxPool2dSign       # same object and state; pools SignTensors without unpacking them
+        elif type(child) is nn.AvgPool2d and fuse_bn_act:
+            from micronet_amd.nn import AvgPool2dGlobal
+            child.__class__ = AvgPool2dGlobal     # same object and state; its own kernel only when the window is the whole image
         else:
             add_quant_op(child, layer_counter, layer_num, A=A, W=W, quant_inference=quant_inference, fuse_bn_act=fuse_bn_act,
                          fold_shuffle=fold_shuffle, packed_activations=packed_activations, fuse_conv_bn=fuse_conv_bn)

@@ -464,6 +464,10 @@ def add_quant_op(module, layer_counter, a_bits=8, w_bits=8, quant_inference=Fals
         if fuse_bn_act and type(child) is nn.MaxPool2d:
             child.__class__ = MaxPool2dF32            # same object and state
             continue
+        if fuse_bn_act and type(child) is nn.AvgPool2d:
+            from micronet_amd.nn import AvgPool2dGlobal
+            child.__class__ = AvgPool2dGlobal         # same object and state; its own kernel only when the window is the whole image
+            continue
         if isinstance(child, nn.Conv2d):
             layer_counter[0] += 1
             if layer_counter[0] > 1:

@@ -1356,3 +1356,16 @@ def check_iao_w_multi(be, bits=4, q_type=0, obs_kind=0, seed=0):
             assert np.array_equal(be.to_host(st1[i][k]), be.to_host(st2[i][k])), (i, k)
         assert np.array_equal(be.to_host(q1[i]), be.to_host(q2[i])), ("qw", i)
         assert np.array_equal(be.to_host(d1[i]), be.to_host(d2[i])), ("dw", i)
+
+
+def check_gap(be, planes=37, HW=64, seed=0):
+    """mn_avgpool_global_fwd / _bwd (nn.AvgPool2d over the whole image) vs numpy."""
+    r = np.random.default_rng(seed)
+    x = r.standard_normal((planes, HW)).astype(F)
+    gy = r.standard_normal(planes).astype(F)
+    y, dx = be.empty(planes), be.empty((planes, HW))
+    dX, dG = be.to_dev(x), be.to_dev(gy)
+    be.call("mn_avgpool_global_fwd", be.ptr(dX), planes, HW, be.ptr(y), be.stream)
+    be.call("mn_avgpool_global_bwd", be.ptr(dG), planes, HW, be.ptr(dx), be.stream)
+    assert close(be.to_host(y), x.astype(np.float64).mean(axis=1), 1e-6)
+    assert np.array_equal(be.to_host(dx), np.repeat((gy / F(HW)).astype(F)[:, None], HW, axis=1))

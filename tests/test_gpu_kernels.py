@@ -632,3 +632,8 @@ def test_iao_weight_quantizers_multi(be, bits, q_type, obs_kind):
 def test_bn2d_plain(be, training):
     K.check_bnrelu(be, training=training, plain=True)
     K.check_bnrelu(be, shape=(33, 64, 16, 16), seed=3, training=training, plain=True)
+
+
+def test_global_avgpool(be):
+    K.check_gap(be)
+    K.check_gap(be, planes=2560, HW=64, seed=1)

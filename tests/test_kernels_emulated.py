@@ -430,3 +430,8 @@ def test_iao_weight_quantizers_multi(be, bits, q_type, obs_kind):
 def test_bn2d_plain(be, training):
     K.check_bnrelu(be, training=training, plain=True)
     K.check_bnrelu(be, shape=(3, 7, 2, 6), seed=3, training=training, plain=True)
+
+
+def test_global_avgpool(be):
+    K.check_gap(be)
+    K.check_gap(be, planes=5, HW=9, seed=1)
