@@ -194,6 +194,9 @@ struct QdfParams {
     // out32 == 2: the IAO layers -- x holds SIGNED codes (xsgn), the output is fp32 y = acc * (sa[0] * sw[o * sw_stride]) + bias[o] (wqaq/iao/quantize.py:492-507)
     int xsgn, sw_stride;
     const float *sa, *sw, *bias;
+    // k_qd_fwd8 with a stash output: exact per-channel sums of acc and acc^2 over the block's items (every item of a block has the same channel tile: the grid
+    // is a multiple of ncot) -> stats[((blockIdx / ncot) * O + channel) * 2 + {0, 1}]: the partial layout k_qa_stats_prep reads; nullptr: none (k_qd_stats instead)
+    double* stats;
 };
 
 template <int MF, int TPS>
@@ -525,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd8(const QdfParams p) {
     fetch_patch((int)blockIdx.x, 0);
     fetch_w();
     int gs = 0;
+    double st1[4] = {0.0, 0.0, 0.0, 0.0}, st2[4] = {0.0, 0.0, 0.0, 0.0};          // this lane's share of sum acc, sum acc^2 of channels 16 nf + j (exact: < 2^53)
     for (int item = (int)blockIdx.x; item < p.nitems; item += stride_items) {
         i32x4 acc[MF][4];
 #pragma unroll
@@ -565,6 +569,18 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd8(const QdfParams p) {
         // ---- epilogue: as k_qd_fwd (transposition through the wave's piece of the idle patch memory, 16-byte stores), on exact i32 values
         int n0, oh0, cot;
         tile_origin(item, n0, oh0, cot);
+        if (p.stats) {          // (pixels of images beyond N were staged as zeros: they add nothing)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                int s1 = 0;
+                double s2 = 0.0;
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int v = acc[mf][nf][r]; s1 += v; const double dv = (double)v; s2 = fma(dv, dv, s2); }
+                st1[nf] += (double)s1; st2[nf] += s2;
+            }
+        }
         {
             unsigned char* scr = wbuf + wave * (MF * 2048 + 64 * 8);          // weights and patch are both idle here: the scratch starts at the weight buffer
             const int tp0 = wave * 16 * MF;
@@ -638,6 +654,24 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd8(const QdfParams p) {
             __syncthreads();
             constexpr int over = 4 * (MF * 2048 + 512) - TPS * QD8_WSTEP;          // bytes of the patch the scratch covered: the zero frame again
             for (int i = tid; i < over / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);          // [wave][kg][64 channels][2]: 16 KB of the (idle) dynamic LDS
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            double* d = red + (((wave * 4 + kg) * 64) + nf * 16 + j) * 2;
+            d[0] = st1[nf]; d[1] = st2[nf];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { a1 += red[(q * 64 + tid) * 2]; a2 += red[(q * 64 + tid) * 2 + 1]; }
+            const int sp = (int)blockIdx.x / p.ncot, cot = (int)blockIdx.x - sp * p.ncot;
+            double* dst = p.stats + ((int64_t)sp * p.O + cot * 64 + tid) * 2;
+            dst[0] = a1; dst[1] = a2;
         }
     }
 }
@@ -721,10 +755,14 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl, int i8 = 0) {
     int tgt = 512;
     if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }     // tuning knob
     pl->grid = p.nitems < tgt ? p.nitems : tgt;
+    if (pl->grid > 512) pl->grid = 512;
+    pl->grid -= pl->grid % p.ncot;          // every item of a block then has the block's channel tile (item % ncot == blockIdx % ncot): the epilogue statistics rely on it
+    if (pl->grid < p.ncot) pl->grid = p.ncot;
     pl->TPS = p.TAPS == 9 ? 3 : 1;
     if (i8 && p.TAPS == 9) { if (const char* e = MN_ENV("MN_QD8_TPS")) { if (atoi(e) == 9) pl->TPS = 9; } }          // A/B knob
     pl->lds = (size_t)pl->TPS * (i8 ? QD8_WSTEP : QD_WSTEP) + (size_t)p.NI * p.PH * p.PW * RS;
     if (i8 && pl->lds < (size_t)4 * (MF * 2048 + 512)) pl->lds = (size_t)4 * (MF * 2048 + 512);          // its epilogue scratch starts at the weight buffer
+    if (i8 && pl->lds < 16384) pl->lds = 16384;                                                           // (and the 16 KB of the statistics hand-over)
     // workspace: packed weights | statistics partials [S][O][2] doubles | per-channel weight scale [O]
     const int64_t pack_bytes = ((int64_t)g->O * g->C * p.TAPS * 2 + 255) / 256 * 256;
     int S = (2048 + g->O - 1) / g->O;
@@ -734,7 +772,8 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl, int i8 = 0) {
     if (S < 1) S = 1;
     pl->S_stats = S;
     pl->off_part = pack_bytes;
-    pl->off_scale = pl->off_part + ((int64_t)S * g->O * 2 * 8 + 255) / 256 * 256;
+    const int64_t nslots = S > 512 ? S : 512;          // (the int8 forward writes one partial per block of its channel tile: up to 512)
+    pl->off_scale = pl->off_part + (nslots * g->O * 2 * 8 + 255) / 256 * 256;
     pl->ws_bytes = pl->off_scale + ((int64_t)g->O * 4 + 255) / 256 * 256;
     return 1;
 }
@@ -798,16 +837,20 @@ int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_fwd);
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.x = x; p.wpk = wpk; p.stash = stash; p.xsgn = 0; p.sa = p.sw = p.bias = nullptr; p.sw_stride = 0;
+    double* part = reinterpret_cast<double*>((char*)ws + pl.off_part);
+    const int epi_stats = i8 && !MN_ENV("MN_QD_NO_EPI_STATS");          // A/B knob: the separate statistics pass
+    p.stats = epi_stats ? part : nullptr;
     mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     qd_launch_fwd(pl, s);
     mn_prof_end(s);
-    double* part = reinterpret_cast<double*>((char*)ws + pl.off_part);
-    const dim3 sgrid((unsigned)g->O, (unsigned)pl.S_stats);
-    if (out32) hipLaunchKernelGGL(k_qd_stats<1>, sgrid, dim3(256), 0, s, (const void*)stash, (int)g->N, (int)g->O, p.HoWo, part);
-    else hipLaunchKernelGGL(k_qd_stats<0>, sgrid, dim3(256), 0, s, (const void*)stash, (int)g->N, (int)g->O, p.HoWo, part);
-    *parts = part; *nparts = pl.S_stats; *rowscale = reinterpret_cast<float*>((char*)ws + pl.off_scale);
+    if (!epi_stats) {
+        const dim3 sgrid((unsigned)g->O, (unsigned)pl.S_stats);
+        if (out32) hipLaunchKernelGGL(k_qd_stats<1>, sgrid, dim3(256), 0, s, (const void*)stash, (int)g->N, (int)g->O, p.HoWo, part);
+        else hipLaunchKernelGGL(k_qd_stats<0>, sgrid, dim3(256), 0, s, (const void*)stash, (int)g->N, (int)g->O, p.HoWo, part);
+    }
+    *parts = part; *nparts = epi_stats ? pl.grid / p.ncot : pl.S_stats; *rowscale = reinterpret_cast<float*>((char*)ws + pl.off_scale);
     MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash(dense)");
     return MN_OK;
 }
@@ -1334,6 +1377,7 @@ __global__ __launch_bounds__(256) void k_qd_wgrad_reduce(const float* __restrict
     const int64_t tile = (int64_t)npairs * T * 4096;
     const int64_t idx0 = (int64_t)blockIdx.x * 64 + 4 * tx;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4                                  // (independent loads: keep several in flight, the kernel is pure latency otherwise)
     for (int zz = ty; zz < Z; zz += 16) {
         const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)zz * tile + idx0);
         s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
@@ -1511,6 +1555,7 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
         qd_launch_pack(w, reinterpret_cast<uint16_t*>((char*)ws + cb), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s, wq->scale, wq->per_channel);
         wpk = reinterpret_cast<const uint16_t*>((char*)ws + cb);
     }
+    p.stats = nullptr;
     p.x = (const unsigned char*)cbuf; p.wpk = wpk; p.stash = y; p.xsgn = 1; p.sa = aq->qp; p.sw = wq->scale; p.sw_stride = wq->per_channel; p.bias = bias;
     mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + 4.0 * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
