@@ -173,6 +173,10 @@ int mn_iao_w_fwd_multi(const float* const* w, float* const* qw, float* const* mi
 int mn_iao_w_bwd_multi(const float* const* g, const float* const* w, float* const* dw, float* const* qp, const int64_t* rows, const int64_t* cols, int32_t count,
                        int bits, int q_type, mn_stream_t stream);
 int64_t mn_iao_qadd_ws_floats(void);
+int64_t mn_iao_qadd_mm_count(int64_t n);
+int mn_iao_qadd_fwd_mm(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, float* mm, mn_stream_t stream);
+/* observer update (as mn_iao_observe with rows == 1) from the (min, max) partials a producing kernel left: mm[0 .. count) minima, mm[count .. 2 count) maxima */
+int mn_iao_observe_partials(const float* mm, int64_t count, int obs_kind, int first, double momentum, float* min_val, float* max_val, mn_stream_t stream);
 int mn_iao_qadd_observe(const float* res, const float* shortcut, int64_t n, int obs_kind, int first_res, int first_shortcut, double momentum, float* min_res,
                         float* max_res, float* min_shortcut, float* max_shortcut, float* min_out, float* max_out, int bits, int q_type, int update, float* scale,
                         float* zero_point, float* qp, float* ws, mn_stream_t stream);
@@ -317,6 +321,11 @@ int mn_bnrelu_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float*
                   int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream);
 int mn_bnrelu_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                   int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
+/* mn_bnrelu_fwd that also leaves per-block (min, max) of its output in mm (2 * mn_bnrelu_mm_count(N, C, HW) floats): the IAO observer of the layer that reads
+ * the activation (wqaq/iao/quantize.py:23-36) is then updated by mn_iao_observe_partials without a pass of its own over the tensor. */
+int64_t mn_bnrelu_mm_count(int64_t N, int64_t C, int64_t HW);
+int mn_bnrelu_fwd_mm(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                     int training, float* running_mean, float* running_var, float* save, float* a, float* ws, float* mm, mn_stream_t stream);
 /* plain nn.BatchNorm2d (no activation behind it: the BatchNorms in front of a residual add, models/resnet.py:21-29) on the same streaming kernels: same
  * arguments as mn_bnrelu_fwd / _bwd. */
 int mn_bn2d_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,

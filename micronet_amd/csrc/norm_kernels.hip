@@ -124,9 +124,12 @@ __global__ void k_bns_eval_stats(int C, float eps, const float* __restrict__ run
 template <int MODE, int OUT8 = 0>
 __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ da,
                                                    const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   const float* __restrict__ sums, int training, float* __restrict__ out) {
+                                                   const float* __restrict__ sums, int training, float* __restrict__ out, float* __restrict__ mm) {
+    // mm (forward, fp32 output only; may be null): per-block min / max of the values written -> mm[block], mm[nblocks + block]: the NEXT layer's IAO observer
+    // (wqaq/iao/quantize.py:23-36) reduces these instead of reading the activation again (mn_iao_observe_partials)
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
     const float mean = save[c], invstd = save[g.C + c], ga = gamma[c], be = beta[c];
+    float mlo = INFINITY, mhi = -INFINITY;
     float k1 = 0.f, k2 = 0.f;
     if (MODE == 1 && training) {
         const float n = (float)g.N * (float)g.HW;
@@ -157,10 +160,20 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
             *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + off) = u;                                                     \
         } else {                                                                                                                      \
             *reinterpret_cast<float4*>(out + off) = make_float4(r[0], r[1], r[2], r[3]);                                              \
+            if (MODE == 0 && mm) {                                                                                                    \
+                mlo = OpMinF()(OpMinF()(mlo, r[0]), OpMinF()(OpMinF()(r[1], r[2]), r[3]));                                            \
+                mhi = OpMaxF()(OpMaxF()(mhi, r[0]), OpMaxF()(OpMaxF()(r[1], r[2]), r[3]));                                            \
+            }                                                                                                                         \
         } }
     MN_STREAM_2(i, (int64_t)sp * 256 + threadIdx.x, (int64_t)S * 256, g.n4, BNSA_LOAD, BNSA_FIN)
 #undef BNSA_LOAD
 #undef BNSA_FIN
+    if (MODE == 0 && !OUT8 && mm) {
+        __shared__ float scm[16];
+        mlo = block_reduce(mlo, OpMinF(), INFINITY, scm);
+        mhi = block_reduce(mhi, OpMaxF(), -INFINITY, scm);
+        if (threadIdx.x == 0) { const int b = sp * (int)gridDim.x + c, nb = (int)(gridDim.x * gridDim.y); mm[b] = mlo; mm[nb + b] = mhi; }
+    }
 }
 
 // ---------------------------------------------------------------- 2x2 / stride-2 max-pool on int8 sign codes
@@ -357,7 +370,7 @@ static int bns_split(const BnsGeom& g) {
 
 static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                            int training, float* running_mean, float* running_var, float* save, float* a, int out8, float* ws, mn_stream_t stream,
-                           int act = 0) {
+                           int act = 0, float* mm = nullptr) {
     int rc = bns_check(N, C, HW, y, out8 ? (const void*)y : (const void*)a, "mn_bnsign_fwd");
     if (!rc && out8 && (((uintptr_t)a) & 3)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd_i8: output must be 4-byte aligned");
     if (rc) return rc;
@@ -379,9 +392,9 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
     }
     mn_set_last_kernel(out8 ? "k_bns_apply<0, 1>" : "k_bns_apply<0, 0>"); mn_prof_bytes((out8 ? 5.0 : 8.0) * nel); mn_prof_begin(s);
     if (out8) hipLaunchKernelGGL((k_bns_apply<0, 1>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
-                                 (const float*)nullptr, training, a);
+                                 (const float*)nullptr, training, a, (float*)nullptr);
     else hipLaunchKernelGGL((k_bns_apply<0, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
-                            (const float*)nullptr, training, a);
+                            (const float*)nullptr, training, a, mm);
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bnsign_fwd");
     return MN_OK;
@@ -451,6 +464,16 @@ extern "C" int mn_bnrelu_bwd(const float* da, const float* y, const float* save,
                              int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
     return bnsign_bwd_impl(da, y, save, gamma, beta, N, C, HW, training, dy, dgamma, dbeta, ws, stream, 1);
 }
+// the same + per-block min / max of the output for the next layer's IAO observer: mm holds 2 * mn_bnrelu_mm_count(N, C, HW) floats
+extern "C" int64_t mn_bnrelu_mm_count(int64_t N, int64_t C, int64_t HW) {
+    if (N <= 0 || C <= 0 || HW <= 0 || HW % 4) return 0;
+    BnsGeom g = bns_geom(N, C, HW);
+    return C * bns_split(g);
+}
+extern "C" int mn_bnrelu_fwd_mm(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                                int training, float* running_mean, float* running_var, float* save, float* a, float* ws, float* mm, mn_stream_t stream) {
+    return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream, 1, mm);
+}
 // plain nn.BatchNorm2d on the same streaming kernels (no activation: the BatchNorms in front of a residual add, models/resnet.py:21-29)
 extern "C" int mn_bn2d_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                            int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
@@ -476,7 +499,7 @@ static int bnsign_bwd_impl(const float* da, const float* y, const float* save, c
     mn_prof_end(s);
     hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
     mn_set_last_kernel("k_bns_apply<1, 0>"); mn_prof_bytes(12.0 * nel); mn_prof_begin(s);
-    hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy);
+    hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy, (float*)nullptr);
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bnsign_bwd");
     return MN_OK;

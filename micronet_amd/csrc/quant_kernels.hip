@@ -805,6 +805,24 @@ extern "C" int mn_iao_observe(const float* x, int64_t rows, int64_t cols, int ob
     return MN_OK;
 }
 
+// the observer update from per-block (min, max) partials written by the kernel that PRODUCED the tensor (mn_bnrelu_fwd_mm, mn_iao_qadd_fwd_mm): mm[0 .. count)
+// minima, mm[count .. 2 count) maxima.  min / max are exact and order-free, so this equals mn_iao_observe on the tensor itself bit for bit -- without reading it.
+__global__ __launch_bounds__(256) void k_minmax_from_partials(const float* __restrict__ mm, int count, int obs_kind, int first, double momentum,
+                                                              float* __restrict__ min_val, float* __restrict__ max_val) {
+    __shared__ float sc[16];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < count; i += 256) { lo = OpMinF()(lo, mm[i]); hi = OpMaxF()(hi, mm[count + i]); }
+    lo = block_reduce(lo, OpMinF(), INFINITY, sc);
+    hi = block_reduce(hi, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) observer_update(obs_kind, first, momentum, lo, hi, min_val, max_val);
+}
+extern "C" int mn_iao_observe_partials(const float* mm, int64_t count, int obs_kind, int first, double momentum, float* min_val, float* max_val, mn_stream_t stream) {
+    if (!mm || count <= 0 || count > (1 << 24) || !min_val || !max_val || (obs_kind != 0 && obs_kind != 1)) MN_FAIL(MN_EINVAL, "mn_iao_observe_partials: bad arguments");
+    hipLaunchKernelGGL(k_minmax_from_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, mm, (int)count, obs_kind, first, momentum, min_val, max_val);
+    MN_CHECK_LAUNCH("mn_iao_observe_partials");
+    return MN_OK;
+}
+
 // qparams (293-321) + clip-STE bounds (148-157)
 __device__ __forceinline__ void iao_qparams_row(float mn, float mx, int q_type, float quant_range, int update, float* scale, float* zero_point, float* qp) {
     const float EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps
@@ -1062,13 +1080,25 @@ __global__ __launch_bounds__(256) void k_qadd_final(const float* __restrict__ ws
 __device__ __forceinline__ float qadd_sum(float a, float b, float sc, float zp, float qmin, float qmax) { return iao_fq(a, sc, zp, qmin, qmax) + iao_fq(b, sc, zp, qmin, qmax); }
 template <int RELU>
 __global__ __launch_bounds__(256) void k_qadd_fwd(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n4,
-                                                  const float* __restrict__ qp, float qmin, float qmax) {
+                                                  const float* __restrict__ qp, float qmin, float qmax, float* __restrict__ mm) {
+    // mm (may be null): per-block min / max of the output -> mm[block], mm[nblocks + block] for the next layers' observers (mn_iao_observe_partials)
+    __shared__ float scm[16];
+    float mlo = INFINITY, mhi = -INFINITY;
     const float sc = qp[0], zp = qp[1];
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(a)[j], w = reinterpret_cast<const float4*>(b)[j];
         float4 o = make_float4(qadd_sum(v.x, w.x, sc, zp, qmin, qmax), qadd_sum(v.y, w.y, sc, zp, qmin, qmax), qadd_sum(v.z, w.z, sc, zp, qmin, qmax), qadd_sum(v.w, w.w, sc, zp, qmin, qmax));
         if (RELU) o = make_float4(qa_relu(o.x), qa_relu(o.y), qa_relu(o.z), qa_relu(o.w));
         reinterpret_cast<float4*>(y)[j] = o;
+        if (mm) {
+            mlo = OpMinF()(OpMinF()(mlo, o.x), OpMinF()(OpMinF()(o.y, o.z), o.w));
+            mhi = OpMaxF()(OpMaxF()(mhi, o.x), OpMaxF()(OpMaxF()(o.y, o.z), o.w));
+        }
+    }
+    if (mm) {
+        mlo = block_reduce(mlo, OpMinF(), INFINITY, scm);
+        mhi = block_reduce(mhi, OpMaxF(), -INFINITY, scm);
+        if (threadIdx.x == 0) { mm[blockIdx.x] = mlo; mm[gridDim.x + blockIdx.x] = mhi; }
     }
 }
 template <int RELU>
@@ -1108,15 +1138,22 @@ extern "C" int mn_iao_qadd_observe(const float* res, const float* shortcut, int6
     MN_CHECK_LAUNCH("mn_iao_qadd_observe");
     return MN_OK;
 }
+static int qadd_fwd_grid(int64_t n) { return mn_grid_for(n / 4, 256, 4096); }
+extern "C" int64_t mn_iao_qadd_mm_count(int64_t n) { return (n > 0 && n % 4 == 0) ? qadd_fwd_grid(n) : 0; }
+extern "C" int mn_iao_qadd_fwd_mm(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, float* mm, mn_stream_t stream);
 extern "C" int mn_iao_qadd_fwd(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, mn_stream_t stream) {
+    return mn_iao_qadd_fwd_mm(res, shortcut, out, n, qp, bits, q_type, relu, nullptr, stream);
+}
+// the same + per-block min / max of `out` (mm: 2 * mn_iao_qadd_mm_count(n) floats) for the observers of the layers that read it
+extern "C" int mn_iao_qadd_fwd_mm(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, float* mm, mn_stream_t stream) {
     if (n <= 0 || n % 4 || !res || !shortcut || !out || !qp || !aligned16(res) || !aligned16(shortcut) || !aligned16(out) || bits < 2 || bits > 24)
         MN_FAIL(MN_EINVAL, "mn_iao_qadd_fwd: bad arguments");
     const IaoRange r = iao_range(bits, q_type, 1);
     mn_prof_bytes(12.0 * (double)n);
     mn_set_last_kernel("k_qadd_fwd<%d>", relu ? 1 : 0);
     mn_prof_begin((hipStream_t)stream);
-    if (relu) hipLaunchKernelGGL(k_qadd_fwd<1>, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, res, shortcut, out, n / 4, qp, r.qmin, r.qmax);
-    else hipLaunchKernelGGL(k_qadd_fwd<0>, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, res, shortcut, out, n / 4, qp, r.qmin, r.qmax);
+    if (relu) hipLaunchKernelGGL(k_qadd_fwd<1>, dim3(qadd_fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, res, shortcut, out, n / 4, qp, r.qmin, r.qmax, mm);
+    else hipLaunchKernelGGL(k_qadd_fwd<0>, dim3(qadd_fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, res, shortcut, out, n / 4, qp, r.qmin, r.qmax, mm);
     mn_prof_end((hipStream_t)stream);
     MN_CHECK_LAUNCH("mn_iao_qadd_fwd");
     return MN_OK;

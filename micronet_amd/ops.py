@@ -418,11 +418,17 @@ class IaoQuantAdd(Function):
     """out = Q(res) + Q(shortcut) with one shared per-tensor quantizer (QuantAdd, wqaq/iao/quantize.py:1484-1498): one pass forward, one backward."""
 
     @staticmethod
-    def forward(ctx, res, shortcut, qp, bits, q_type, relu=False):
+    def forward(ctx, res, shortcut, qp, bits, q_type, relu=False, want_minmax=False):
         res, shortcut = _chk(res, "res"), _chk(shortcut, "shortcut")
         out = torch.empty_like(res)
         with torch.cuda.device_of(res):
-            _call("mn_iao_qadd_fwd", _p(res), _p(shortcut), _p(out), res.numel(), _p(qp), bits, q_type, int(relu), _s())
+            if want_minmax:
+                count = int(_lib_().mn_iao_qadd_mm_count(res.numel()))
+                mm = torch.empty(2 * count, dtype=torch.float32, device=res.device)
+                _call("mn_iao_qadd_fwd_mm", _p(res), _p(shortcut), _p(out), res.numel(), _p(qp), bits, q_type, int(relu), _p(mm), _s())
+                _PENDING_MINMAX[0] = (mm, count)
+            else:
+                _call("mn_iao_qadd_fwd", _p(res), _p(shortcut), _p(out), res.numel(), _p(qp), bits, q_type, int(relu), _s())
         ctx.save_for_backward(res, shortcut, qp)
         ctx.cfg = (bits, q_type, int(relu))
         return out
@@ -435,7 +441,7 @@ class IaoQuantAdd(Function):
         da, db = torch.empty_like(res), torch.empty_like(shortcut)
         with torch.cuda.device_of(res):
             _call("mn_iao_qadd_bwd", _p(g), _p(res), _p(shortcut), _p(da), _p(db), res.numel(), _p(qp), bits, q_type, relu, _s())
-        return da, db, None, None, None, None
+        return da, db, None, None, None, None, None
 
 
 class IaoFakeQuant(Function):
@@ -644,6 +650,23 @@ class BNSign(Function):
         return dy, dgamma, dbeta, None, None, None, None, None, None, None
 
 
+_PENDING_MINMAX = [None]
+
+
+def take_minmax():
+    """(mm, count) left by the last forward that was asked for per-block (min, max) partials of its output, or None; cleared by the call."""
+    v = _PENDING_MINMAX[0]
+    _PENDING_MINMAX[0] = None
+    return v
+
+
+def iao_observe_partials(mm, obs_kind, first, momentum, min_val, max_val):
+    """Observer update from the producer's partials (``tensor._mn_minmax``): no pass over the tensor."""
+    buf, count = mm
+    with torch.cuda.device_of(buf):
+        _call("mn_iao_observe_partials", _p(buf), count, obs_kind, int(first), float(momentum), _p(min_val), _p(max_val), _s())
+
+
 class BNReLU(Function):
     """relu(batch_norm(y)) in one fused op (training or eval statistics): the three / five streaming passes of BNSign with max(z, 0) and
     the ReLU mask -- the ConvBNReLU blocks of the DoReFa / IAO nets (models/nin_gc.py:53-59) otherwise run MIOpen's BatchNorm kernels
@@ -651,15 +674,22 @@ class BNReLU(Function):
     the activation (plain nn.BatchNorm2d: ``BatchNorm2dPlain``)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, fn="mn_bnrelu"):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, fn="mn_bnrelu", want_minmax=False):
         y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
         N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
         a = torch.empty_like(y)
         save = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
         with torch.cuda.device_of(y):
-            _call(fn + "_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training), _p(running_mean),
-                  _p(running_var), _p(save), _p(a), _p(ws), _s())
+            if want_minmax and fn == "mn_bnrelu":
+                count = int(_lib_().mn_bnrelu_mm_count(N, Cc, HW))
+                mm = torch.empty(2 * count, dtype=torch.float32, device=y.device)
+                _call("mn_bnrelu_fwd_mm", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training), _p(running_mean),
+                      _p(running_var), _p(save), _p(a), _p(ws), _p(mm), _s())
+                _PENDING_MINMAX[0] = (mm, count)
+            else:
+                _call(fn + "_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training), _p(running_mean),
+                      _p(running_var), _p(save), _p(a), _p(ws), _s())
         ctx.save_for_backward(y, gamma, beta, save)
         ctx.training = int(training)
         ctx.fn = fn
@@ -674,7 +704,7 @@ class BNReLU(Function):
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
         with torch.cuda.device_of(y):
             _call(ctx.fn + "_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, ctx.training, _p(dy), _p(dgamma), _p(dbeta), _p(ws), _s())
-        return dy, dgamma, dbeta, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class GlobalAvgPool(Function):

@@ -188,6 +188,7 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
     q_out_bits = 0          # > 0 (set by prepare(fuse_blocks=True)): the only consumer is the a-bit activation quantizer of the next QuantConv2d ->
     q_pool = False          # emit its codes (QActTensor), through the 2x2 max-pool behind the block when q_pool
     q_also_f32 = False      # the consumer is a fused residual block with an identity shortcut: emit the codes AND the fp32 activation (one pass, two autograd outputs)
+    emit_minmax = False     # (set by the IAO prepare) leave per-block (min, max) of the output for the observer of the IAO layer that reads it
 
     def forward(self, input):
         from micronet_amd import ops
@@ -221,6 +222,13 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
             self.num_batches_tracked.add_(1)
             if self.momentum is None:
                 momentum = 1.0 / float(self.num_batches_tracked)
+        if self.emit_minmax and self.training:
+            out = ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                   self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, "mn_bnrelu", True)
+            mm = ops.take_minmax()
+            if mm is not None:
+                out._mn_minmax = mm
+            return out
         return ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                 self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
 

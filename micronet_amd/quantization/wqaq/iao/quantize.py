@@ -20,8 +20,12 @@ from torch.autograd import Function
 from torch.nn import init
 from torch.nn.parameter import Parameter
 
+import os
+
 from micronet_amd import ops
 from micronet_amd.base_module.op import Add
+
+_PRODUCER_MINMAX = os.environ.get("MN_NO_PRODUCER_MINMAX") is None          # A/B knob: observers read the tensor themselves
 
 __all__ = ["ObserverBase", "MinMaxObserver", "MovingAverageMinMaxObserver", "HistogramObserver", "Round", "Quantizer",
            "SignedQuantizer", "UnsignedQuantizer", "SymmetricQuantizer", "AsymmetricQuantizer", "QuantConv2d",
@@ -60,6 +64,9 @@ class ObserverBase(nn.Module):
             dp.allreduce_minmax(cur_min, cur_max, self._mn_sync_group)
             ops.iao_observe(torch.cat([cur_min.reshape(-1), cur_max.reshape(-1)]), 1, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
                             self.min_val, self.max_val)
+        elif rows == 1 and getattr(input, "_mn_minmax", None) is not None and self._kind in (0, 1):
+            # the kernel that produced this activation left per-block (min, max): the same update without a pass over the tensor
+            ops.iao_observe_partials(input._mn_minmax, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1), self.min_val, self.max_val)
         else:
             ops.iao_observe(input, rows, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
                             self.min_val, self.max_val)
@@ -517,9 +524,14 @@ class QuantAdd(nn.Module):
                 if o.num_flag == 0:
                     o.num_flag += 1
             q._last_qp = qp
-            out = ops.IaoQuantAdd.apply(res, shortcut, qp, q.bits, q.q_type, bool(relu))
+            want_mm = bool(relu) and self.training and _PRODUCER_MINMAX          # (a ResNet block's output: the next block's convs observe it)
+            out = ops.IaoQuantAdd.apply(res, shortcut, qp, q.bits, q.q_type, bool(relu), want_mm)
             if relu:
                 out._mn_relu_done = True
+            if want_mm:
+                mm = ops.take_minmax()
+                if mm is not None:
+                    out._mn_minmax = mm
             return out
         # both observers run unconditionally, also in eval (ref 1485-1486); the union range feeds ONE shared quantizer
         self.observer_res(res)
@@ -560,6 +572,7 @@ def add_quant_op(module, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observe
             # same parameters / buffers / state_dict keys, isinstance contracts intact (the reference leaves nn.ReLU alone: ref 1705-1709).
             from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dReLU, ReLUAfterFusedBN
             prev.__class__ = BatchNorm2dReLU
+            prev.emit_minmax = _PRODUCER_MINMAX          # the IAO conv behind it observes this activation: the fused op hands over per-block (min, max)
             child.__class__ = ReLUAfterFusedBN
             prev = child
             continue

@@ -444,6 +444,20 @@ def check_bnrelu(be, shape=(6, 5, 4, 8), seed=0, training=True, plain=False):
     be.call(fn + "_bwd", be.ptr(dDA), be.ptr(dY), be.ptr(save), be.ptr(dG), be.ptr(dB), N, Cc, HW, int(training), be.ptr(dy),
             be.ptr(dgam), be.ptr(dbet), be.ptr(ws), be.stream)
     assert close(be.to_host(a), a_ref, 2e-6) and (plain or np.all(be.to_host(a) >= 0))
+    if not plain:       # the variant that leaves per-block (min, max) of its output for the next layer's IAO observer: same output, and the observer update from
+        # the partials equals mn_iao_observe on the tensor itself, bit for bit
+        cnt = int(be.lib.mn_bnrelu_mm_count(N, Cc, HW))
+        a2, mm = be.empty(shape), be.empty(2 * cnt)
+        dRM2, dRV2, save2 = be.to_dev(rm), be.to_dev(rv), be.empty((2, Cc))
+        be.call("mn_bnrelu_fwd_mm", be.ptr(dY), N, Cc, HW, be.ptr(dG), be.ptr(dB), eps, mom, int(training), be.ptr(dRM2), be.ptr(dRV2), be.ptr(save2), be.ptr(a2), be.ptr(ws),
+                be.ptr(mm), be.stream)
+        assert np.array_equal(be.to_host(a2), be.to_host(a))
+        for kind, first in ((1, 1), (1, 0), (0, 0)):
+            m1, M1, m2, M2 = be.to_dev(np.array([-0.25], dtype=F)), be.to_dev(np.array([0.75], dtype=F)), be.to_dev(np.array([-0.25], dtype=F)), be.to_dev(np.array([0.75], dtype=F))
+            wso = be.empty(int(be.lib.mn_iao_observe_ws_floats(1, N * Cc * HW)))
+            be.call("mn_iao_observe", be.ptr(a2), 1, N * Cc * HW, kind, first, 0.1, be.ptr(m1), be.ptr(M1), be.ptr(wso), be.stream)
+            be.call("mn_iao_observe_partials", be.ptr(mm), cnt, kind, first, 0.1, be.ptr(m2), be.ptr(M2), be.stream)
+            assert np.array_equal(be.to_host(m1), be.to_host(m2)) and np.array_equal(be.to_host(M1), be.to_host(M2)), (kind, first)
     sv = be.to_host(save)
     assert np.max(np.abs(sv[0] - mean)) <= 1e-6 * max(1.0, np.max(np.abs(mean))) and np.max(np.abs(sv[1] - invstd) / invstd) <= 2e-6
     if training:
@@ -1310,6 +1324,16 @@ def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, Fa
     y2, da2, db2 = be.empty(n), be.empty(n), be.empty(n)
     be.call("mn_iao_qadd_fwd", be.ptr(dA), be.ptr(dB), be.ptr(y2), n, be.ptr(qp2), bits, q_type, int(relu), be.stream)
     be.call("mn_iao_qadd_bwd", be.ptr(dG), be.ptr(dA), be.ptr(dB), be.ptr(da2), be.ptr(db2), n, be.ptr(qp2), bits, q_type, int(relu), be.stream)
+    # + per-block (min, max) of the output for the observers of the layers that read it
+    cnt = int(be.lib.mn_iao_qadd_mm_count(n))
+    y3, mm = be.empty(n), be.empty(2 * cnt)
+    be.call("mn_iao_qadd_fwd_mm", be.ptr(dA), be.ptr(dB), be.ptr(y3), n, be.ptr(qp2), bits, q_type, int(relu), be.ptr(mm), be.stream)
+    assert np.array_equal(be.to_host(y3), be.to_host(y2))
+    m1, M1, m2, M2 = be.to_dev(np.array([-0.25], dtype=F)), be.to_dev(np.array([0.75], dtype=F)), be.to_dev(np.array([-0.25], dtype=F)), be.to_dev(np.array([0.75], dtype=F))
+    wso = be.empty(int(be.lib.mn_iao_observe_ws_floats(1, n)))
+    be.call("mn_iao_observe", be.ptr(y3), 1, n, 1, 0, 0.1, be.ptr(m1), be.ptr(M1), be.ptr(wso), be.stream)
+    be.call("mn_iao_observe_partials", be.ptr(mm), cnt, 1, 0, 0.1, be.ptr(m2), be.ptr(M2), be.stream)
+    assert np.array_equal(be.to_host(m1), be.to_host(m2)) and np.array_equal(be.to_host(M1), be.to_host(M2))
     for k in st0:
         assert np.array_equal(be.to_host(s1[k]), be.to_host(s2[k])), k
     assert np.array_equal(be.to_host(qp1), be.to_host(qp2)), "qp"
