@@ -177,6 +177,9 @@ int64_t mn_iao_qadd_mm_count(int64_t n);
 int mn_iao_qadd_fwd_mm(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, float* mm, mn_stream_t stream);
 /* observer update (as mn_iao_observe with rows == 1) from the (min, max) partials a producing kernel left: mm[0 .. count) minima, mm[count .. 2 count) maxima */
 int mn_iao_observe_partials(const float* mm, int64_t count, int obs_kind, int first, double momentum, float* min_val, float* max_val, mn_stream_t stream);
+/* the same followed by the per-tensor quantizer's update_qparams (wqaq/iao/quantize.py:293-321) in the same launch: scale / zero_point recomputed, qp [4] written */
+int mn_iao_observe_partials_qparams(const float* mm, int64_t count, int obs_kind, int first, double momentum, float* min_val, float* max_val, int bits, int q_type,
+                                    int is_act, float* scale, float* zero_point, float* qp, mn_stream_t stream);
 int mn_iao_qadd_observe(const float* res, const float* shortcut, int64_t n, int obs_kind, int first_res, int first_shortcut, double momentum, float* min_res,
                         float* max_res, float* min_shortcut, float* max_shortcut, float* min_out, float* max_out, int bits, int q_type, int update, float* scale,
                         float* zero_point, float* qp, float* ws, mn_stream_t stream);

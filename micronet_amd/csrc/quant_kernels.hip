@@ -807,19 +807,38 @@ extern "C" int mn_iao_observe(const float* x, int64_t rows, int64_t cols, int ob
 
 // the observer update from per-block (min, max) partials written by the kernel that PRODUCED the tensor (mn_bnrelu_fwd_mm, mn_iao_qadd_fwd_mm): mm[0 .. count)
 // minima, mm[count .. 2 count) maxima.  min / max are exact and order-free, so this equals mn_iao_observe on the tensor itself bit for bit -- without reading it.
+__device__ __forceinline__ void iao_qparams_row(float mn, float mx, int q_type, float quant_range, int update, float* scale, float* zero_point, float* qp);
 __global__ __launch_bounds__(256) void k_minmax_from_partials(const float* __restrict__ mm, int count, int obs_kind, int first, double momentum,
-                                                              float* __restrict__ min_val, float* __restrict__ max_val) {
+                                                              float* __restrict__ min_val, float* __restrict__ max_val, int q_type, float quant_range,
+                                                              float* __restrict__ scale, float* __restrict__ zero_point, float* __restrict__ qp) {
     __shared__ float sc[16];
     float lo = INFINITY, hi = -INFINITY;
     for (int i = threadIdx.x; i < count; i += 256) { lo = OpMinF()(lo, mm[i]); hi = OpMaxF()(hi, mm[count + i]); }
     lo = block_reduce(lo, OpMinF(), INFINITY, sc);
     hi = block_reduce(hi, OpMaxF(), -INFINITY, sc);
-    if (threadIdx.x == 0) observer_update(obs_kind, first, momentum, lo, hi, min_val, max_val);
+    if (threadIdx.x == 0) {
+        observer_update(obs_kind, first, momentum, lo, hi, min_val, max_val);
+        if (qp) iao_qparams_row(*min_val, *max_val, q_type, quant_range, 1, scale, zero_point, qp);          // + the quantizer's update_qparams in the same launch
+    }
 }
 extern "C" int mn_iao_observe_partials(const float* mm, int64_t count, int obs_kind, int first, double momentum, float* min_val, float* max_val, mn_stream_t stream) {
     if (!mm || count <= 0 || count > (1 << 24) || !min_val || !max_val || (obs_kind != 0 && obs_kind != 1)) MN_FAIL(MN_EINVAL, "mn_iao_observe_partials: bad arguments");
-    hipLaunchKernelGGL(k_minmax_from_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, mm, (int)count, obs_kind, first, momentum, min_val, max_val);
+    hipLaunchKernelGGL(k_minmax_from_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, mm, (int)count, obs_kind, first, momentum, min_val, max_val, 0, 1.f,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr);
     MN_CHECK_LAUNCH("mn_iao_observe_partials");
+    return MN_OK;
+}
+// the same + the per-tensor quantizer's update_qparams (scale / zero_point recomputed from the updated range; qp = {scale, zero_point, lo, hi}) in ONE launch
+extern "C" int mn_iao_observe_partials_qparams(const float* mm, int64_t count, int obs_kind, int first, double momentum, float* min_val, float* max_val, int bits,
+                                               int q_type, int is_act, float* scale, float* zero_point, float* qp, mn_stream_t stream) {
+    if (!mm || count <= 0 || count > (1 << 24) || !min_val || !max_val || !scale || !zero_point || !qp || bits < 2 || bits > 24 || (obs_kind != 0 && obs_kind != 1) ||
+        (q_type != 0 && q_type != 1))
+        MN_FAIL(MN_EINVAL, "mn_iao_observe_partials_qparams: bad arguments");
+    const IaoRange r = iao_range(bits, q_type, is_act);
+    const float qr = (q_type == 0) ? (float)((double)(r.qmax - r.qmin) / 2.0) : (float)(r.qmax - r.qmin);
+    hipLaunchKernelGGL(k_minmax_from_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, mm, (int)count, obs_kind, first, momentum, min_val, max_val, q_type, qr, scale,
+                       zero_point, qp);
+    MN_CHECK_LAUNCH("mn_iao_observe_partials_qparams");
     return MN_OK;
 }
 

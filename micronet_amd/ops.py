@@ -667,6 +667,16 @@ def iao_observe_partials(mm, obs_kind, first, momentum, min_val, max_val):
         _call("mn_iao_observe_partials", _p(buf), count, obs_kind, int(first), float(momentum), _p(min_val), _p(max_val), _s())
 
 
+def iao_observe_partials_qparams(mm, obs_kind, first, momentum, min_val, max_val, bits, q_type, is_act, scale, zero_point):
+    """Observer update from the producer's partials + the quantizer's update_qparams, one launch; returns the {scale, zero_point, lo, hi} snapshot."""
+    buf, count = mm
+    qp = torch.empty((1, 4), dtype=torch.float32, device=buf.device)
+    with torch.cuda.device_of(buf):
+        _call("mn_iao_observe_partials_qparams", _p(buf), count, obs_kind, int(first), float(momentum), _p(min_val), _p(max_val), bits, q_type, int(is_act),
+              _p(scale), _p(zero_point), _p(qp), _s())
+    return qp
+
+
 class BNReLU(Function):
     """relu(batch_norm(y)) in one fused op (training or eval statistics): the three / five streaming passes of BNSign with max(z, 0) and
     the ReLU mask -- the ConvBNReLU blocks of the DoReFa / IAO nets (models/nin_gc.py:53-59) otherwise run MIOpen's BatchNorm kernels

@@ -177,6 +177,17 @@ class Quantizer(nn.Module):
             print("！Binary quantization is not supported ！")
             assert self.bits != 1
         if not self.qaft and self.training:
+            obs = self.observer
+            mm = getattr(input, "_mn_minmax", None)
+            if (not self.union and mm is not None and isinstance(obs, ObserverBase) and obs.q_level == "L" and obs._kind in (0, 1) and not obs._mn_sync
+                    and 2 <= self.bits <= 24):
+                # the producing kernel left per-block (min, max): observer update + update_qparams in one launch, no pass over the activation
+                self.q_type = self._q_type_static
+                qp = ops.iao_observe_partials_qparams(mm, obs._kind, obs.num_flag == 0, getattr(obs, "momentum", 0.1), obs.min_val, obs.max_val, self.bits,
+                                                      self._q_type_static, self.activation_weight_flag == 1, self.scale, self.zero_point)
+                if obs.num_flag == 0:
+                    obs.num_flag += 1
+                return qp
             if not self.union:
                 self.observer(input)
             return self.update_qparams()

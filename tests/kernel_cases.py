@@ -458,6 +458,13 @@ def check_bnrelu(be, shape=(6, 5, 4, 8), seed=0, training=True, plain=False):
             be.call("mn_iao_observe", be.ptr(a2), 1, N * Cc * HW, kind, first, 0.1, be.ptr(m1), be.ptr(M1), be.ptr(wso), be.stream)
             be.call("mn_iao_observe_partials", be.ptr(mm), cnt, kind, first, 0.1, be.ptr(m2), be.ptr(M2), be.stream)
             assert np.array_equal(be.to_host(m1), be.to_host(m2)) and np.array_equal(be.to_host(M1), be.to_host(M2)), (kind, first)
+            # + the quantizer's update_qparams in the same launch == mn_iao_observe_partials then mn_iao_qparams
+            m3, M3 = be.to_dev(np.array([-0.25], dtype=F)), be.to_dev(np.array([0.75], dtype=F))
+            sc1, zp1, qp1, sc3, zp3, qp3 = be.empty(1), be.empty(1), be.empty((1, 4)), be.empty(1), be.empty(1), be.empty((1, 4))
+            be.call("mn_iao_qparams", be.ptr(m2), be.ptr(M2), 1, 4, 0, 1, 1, be.ptr(sc1), be.ptr(zp1), be.ptr(qp1), be.stream)
+            be.call("mn_iao_observe_partials_qparams", be.ptr(mm), cnt, kind, first, 0.1, be.ptr(m3), be.ptr(M3), 4, 0, 1, be.ptr(sc3), be.ptr(zp3), be.ptr(qp3), be.stream)
+            for u, v in ((m2, m3), (M2, M3), (sc1, sc3), (zp1, zp3), (qp1, qp3)):
+                assert np.array_equal(be.to_host(u), be.to_host(v))
     sv = be.to_host(save)
     assert np.max(np.abs(sv[0] - mean)) <= 1e-6 * max(1.0, np.max(np.abs(mean))) and np.max(np.abs(sv[1] - invstd) / invstd) <= 2e-6
     if training:
