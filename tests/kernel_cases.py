@@ -1400,3 +1400,39 @@ def check_gap(be, planes=37, HW=64, seed=0):
     be.call("mn_avgpool_global_bwd", be.ptr(dG), planes, HW, be.ptr(dx), be.stream)
     assert close(be.to_host(y), x.astype(np.float64).mean(axis=1), 1e-6)
     assert np.array_equal(be.to_host(dx), np.repeat((gy / F(HW)).astype(F)[:, None], HW, axis=1))
+
+
+def check_qd_pack_multi(be, w_bits=2, iao=False, seed=0):
+    """mn_qd_pack_multi over several tensors (mixed shapes, 3 x 3 and 1 x 1) == the same call per tensor: the table / tile bookkeeping of the one-launch pack."""
+    r = np.random.default_rng(seed)
+    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (64, 128, 3, 3), (128, 128, 3, 3)]
+    n = len(shapes)
+    nw = 2 ** w_bits - 1
+    ws, scs = [], []
+    for s_ in shapes:
+        if iao:
+            qmax = 2 ** (w_bits - 1) - 1
+            sc = (np.abs(r.standard_normal(s_[0])) * 0.01 + 0.002).astype(F)
+            ws.append((r.integers(-qmax, qmax + 1, size=s_).astype(F) * sc.reshape(-1, 1, 1, 1)).astype(F)); scs.append(sc)
+        else:
+            k = r.integers(0, nw + 1, size=s_).astype(F)
+            ws.append((F(2) * (k * F(1.0 / nw)) - F(1)).astype(F))
+    dW = [be.to_dev(w) for w in ws]
+    dS = [be.to_dev(sc) for sc in scs]
+    nbytes = [s_[0] * s_[1] * s_[2] * s_[3] * 2 for s_ in shapes]
+    PA1, LA1, IA1 = C.c_void_p * 1, C.c_int64 * 1, C.c_int32 * 1
+    ref = []
+    for i, s_ in enumerate(shapes):
+        f, b = be.empty_i8((nbytes[i],)), be.empty_i8((nbytes[i],))
+        be.call("mn_qd_pack_multi", PA1(be.ptr(dW[i]).value), PA1(be.ptr(f).value), PA1(be.ptr(b).value), LA1(s_[0]), LA1(s_[1]), LA1(s_[2] * s_[3]),
+                PA1(be.ptr(dS[i]).value) if iao else None, IA1(1) if iao else None, 1, w_bits, be.stream)
+        ref.append((be.to_host(f), be.to_host(b)))
+    PA, LA, IA = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+    fs, bs = [be.empty_i8((nb,)) for nb in nbytes], [be.empty_i8((nb,)) for nb in nbytes]
+    be.call("mn_qd_pack_multi", PA(*[be.ptr(t).value for t in dW]), PA(*[be.ptr(t).value for t in fs]), PA(*[be.ptr(t).value for t in bs]),
+            LA(*[s_[0] for s_ in shapes]), LA(*[s_[1] for s_ in shapes]), LA(*[s_[2] * s_[3] for s_ in shapes]),
+            PA(*[be.ptr(t).value for t in dS]) if iao else None, IA(*[1] * n) if iao else None, n, w_bits, be.stream)
+    fwd_bytes = lambda i: nbytes[i] // 2 if (w_bits <= 7 or iao) else nbytes[i]          # the int8 forward image is half the size
+    for i in range(n):
+        assert np.array_equal(be.to_host(fs[i])[:fwd_bytes(i)], ref[i][0][:fwd_bytes(i)]), ("forward image", i)
+        assert np.array_equal(be.to_host(bs[i]), ref[i][1]), ("backward-data image", i)

@@ -435,3 +435,8 @@ def test_bn2d_plain(be, training):
 def test_global_avgpool(be):
     K.check_gap(be)
     K.check_gap(be, planes=5, HW=9, seed=1)
+
+
+@pytest.mark.parametrize("w_bits,iao", [(2, False), (8, False), (4, True)])
+def test_qd_pack_multi_tables(be, w_bits, iao):
+    K.check_qd_pack_multi(be, w_bits=w_bits, iao=iao, seed=w_bits)
