@@ -65,22 +65,7 @@ struct PwsParams {
     ChanMap in_map;
 };
 
-#ifndef WG3_TRACE
-#define WG3_TRACE 0
-#endif
 
-#if WG3_TRACE      // debugging aid (variant builds only): cycle stamps of one producer and one consumer wave of block 0 around every barrier
-__device__ long long g_wg3_trace[2][3][1024];
-extern "C" int mn_debug_wg3_trace(long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg3_trace), sizeof(g_wg3_trace)) == hipSuccess ? 0 : 1; }
-#define WG3_STAMP(role, slot, idx) if (blockIdx.x == 7 && lane == 0 && ((threadIdx.x >> 6) == (role ? 4 : 0)) && (idx) >= 0 && (idx) < 1024) g_wg3_trace[role][slot][idx] = clock64();
-#else
-#define WG3_STAMP(role, slot, idx)
-#endif
-#if WG3_TRACE
-#define PWS_STAMP(slot, idx) if (blockIdx.x == 9 && lane == 0 && wave == 0 && (idx) >= 0 && (idx) < 1024) g_wg3_trace[0][slot][idx] = clock64();
-#else
-#define PWS_STAMP(slot, idx)
-#endif
 // XENC 0: x holds int8 sign codes (+-1).  XENC 1: x holds k-bit activation codes j in [0, 127] as bytes (the DoReFa / IAO activation quantizer's
 // integer, wqaq/dorefa/quantize.py:43-45): the B fragments are built as bf16 128 + j (high byte 0x43, low byte j: one v_perm + one v_or per
 // fragment dword), every product and sum stays an exact integer, and the epilogue subtracts 128 * sum_k code_w[o][k] (c2 = that row constant).
@@ -107,9 +92,6 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
     double* red = reinterpret_cast<double*>(coff + p.Kp);      // [4][MB][2] cross-wave reduction (RED); 8-byte aligned by layout
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const uint32_t HW = (uint32_t)p.HW;
-#if WG3_TRACE
-    if (blockIdx.x == 9 && tid == 0) g_wg3_trace[1][0][0] = clock64();
-#endif
 
     uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7u; b >>= 3;
@@ -122,9 +104,6 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
     // latencies (HBM for the codes, L2 for the weights) overlap instead of adding up at the head of every block (7000 + 3300 of ~60000 cycles)
     for (int c = tid; c < p.Kp; c += 256) coff[c] = (uint32_t)chan_phys(p.in_map, g * p.Kc + (c < p.Kc ? c : p.Kc - 1)) * HW;
     __syncthreads();
-#if WG3_TRACE
-    if (blockIdx.x == 9 && tid == 0) g_wg3_trace[1][1][0] = clock64();
-#endif
     const int chunk0 = cb * 4 + wave, cstride = p.CB * 4;
     const uint16_t* wl = wsm + j * LDW + kg * 8;
     const uint32_t Pmax = p.NP - 4u;                         // NP is a multiple of 4: the last valid quad
@@ -234,7 +213,6 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
     }
 
     auto body = [&](uint32_t (&cur)[KS * 8], int chunk) {
-        PWS_STAMP(0, (chunk - chunk0) / cstride)
         const uint32_t P = (uint32_t)chunk * 64u + 4u * j;
         const bool pv = P < p.NP;
         const uint32_t n = fd_div(P, p.fd_hw);
@@ -318,7 +296,6 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             }
         }
 
-        PWS_STAMP(1, (chunk - chunk0) / cstride)
         // epilogue: lane (j, kg) holds out-channels t*16 + 4kg + r of pixels P .. P+3; acc is an exact integer
         // Statistics pass, whole chunk and whole m-block valid (wave-uniform; every nin_gc chunk): straight-line code.  The guarded form below is one
         // basic block per (tile, row), each with its own LDS read of the row constant and a full wait for it: 16 exposed LDS round trips per chunk,
@@ -434,7 +411,6 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                 }
             }
         }
-        PWS_STAMP(2, (chunk - chunk0) / cstride)
     };
     if (GRAD) {
         for (int chunk = chunk0; chunk < p.nchunks; chunk += cstride) body(curA, chunk);
@@ -445,9 +421,6 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
         }
     }
 
-#if WG3_TRACE
-    if (blockIdx.x == 9 && tid == 0) g_wg3_trace[1][2][0] = clock64();
-#endif
     if (RED) {
         // block partial in fp64, fixed order: every lane's 2 * 4 NT floats go to LDS ([value][wave][lane]: conflict-free rows), then thread (row, which)
         // adds its 4 waves x 16 pixel lanes.  (The butterfly of 64-bit shuffles this replaces cost ~9000 cycles per block: 256 ds_bpermute.)
@@ -473,9 +446,6 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
             dst[which] = v;
         }
     }
-#if WG3_TRACE
-    if (blockIdx.x == 9 && tid == 0) g_wg3_trace[1][2][1] = clock64();
-#endif
 }
 
 // batch statistics from the PWS_STATS partials (exact integer sums S1 = sum acc, S2 = sum acc^2 over N*HW): y = alpha*acc + bias,
@@ -637,9 +607,6 @@ struct Wg2Params {
     int training;
     float n_f;
 };
-#ifndef MN_WG2_DBGC
-#define MN_WG2_DBGC 0      // ablation build only (scripts/ablate_wgrad.sh): 1 no MFMAs, 2 no term split, 4 no streaming (one step re-read)
-#endif
 template <int MW, int CW, int BNH>
 __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
@@ -694,7 +661,6 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
     Raw r0, r1;
     const int st0 = p.st_stride == 1 ? z * p.st_per_z : z;
     auto fetch = [&](Raw& R, int st) {
-        if (MN_WG2_DBGC & 4) st = st0;
         const uint32_t Pa = (uint32_t)st * 32u + 4u * kg, Pb = Pa + 16u;
         const uint32_t na = fd_div(Pa, p.fd_hw), nb = fd_div(Pb, p.fd_hw);
         const uint32_t pa = Pa - na * HW, pb = Pb - nb * HW;
@@ -741,17 +707,12 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
                 }
             }
             float t0[8], t1[8], t2[8];
-            if (MN_WG2_DBGC & 2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { t0[e] = v[e]; t1[e] = v[e]; t2[e] = v[e]; }
-            } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 t0[e] = mn_bf16_head(v[e]);
                 const float r1 = v[e] - t0[e];
                 t1[e] = mn_bf16_head(r1);
                 t2[e] = r1 - t1[e];
-            }
             }
             dbacc[mi] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 #pragma unroll
@@ -762,16 +723,6 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
             }
         }
         if (st + NSETS * p.st_stride < st_end) fetch(R, st + NSETS * p.st_stride);     // the registers are free: NSETS steps ahead
-        if (MN_WG2_DBGC & 1) {
-#pragma unroll
-            for (int mi = 0; mi < MW; ++mi)
-#pragma unroll
-                for (int ci = 0; ci < CW; ++ci) {
-                    acc[mi][ci][0] += mn_u2f((a0[mi][0] ^ a1[mi][1] ^ a2[mi][2] ^ a0[mi][3] ^ a1[mi][0] ^ a2[mi][1] ^ a0[mi][2] ^ a1[mi][3] ^ a2[mi][0] ^ a0[mi][1] ^ a1[mi][2] ^ a2[mi][3]) & 0x3fffffffu);
-                    acc[mi][ci][1] += mn_u2f((bf[ci][0] ^ bf[ci][1] ^ bf[ci][2] ^ bf[ci][3]) & 0x3fffffffu);
-                }
-            return;
-        }
         // term-outer: MW*CW independent accumulators between two MFMAs on the same one (a dependent MFMA waits ~2 issue slots)
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
@@ -837,9 +788,6 @@ __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
 #define WG3_RSBX 64
 #ifndef WG3_NS
 #define WG3_NS 4
-#endif
-#ifndef WG3_PRIO
-#define WG3_PRIO 0
 #endif
 // SPEC 1: wave-specialised, 512 threads.  Waves 0-3 are PRODUCERS (global loads, BatchNorm fold, the three-term split, LDS writes: VALU only),
 // waves 4-7 CONSUMERS (fragment reads + MFMA only, the 2 x 2 wave grid of the tile).  Every SIMD hosts one of each, so the VALU pipe and the matrix
@@ -1057,14 +1005,9 @@ __global__ __launch_bounds__(SPEC == 2 ? 768 : (SPEC ? 512 : 256), SPEC ? 1 : 2)
             for (int t = 0; t < n; t += NS) {
 #pragma unroll
                 for (int u = 0; u < NS; ++u) {
-                    WG3_STAMP(0, 0, t + u)
                     commit(st[u], u & 1, t + u < n);
-#if !WG3_NOLOAD
                     fetch(st[u], t + u + NS);
-#endif
-                    WG3_STAMP(0, 1, t + u)
                     __syncthreads();
-                    WG3_STAMP(0, 2, t + u)
                 }
             }
         } else {
@@ -1104,21 +1047,15 @@ __global__ __launch_bounds__(SPEC == 2 ? 768 : (SPEC ? 512 : 256), SPEC ? 1 : 2)
 #pragma unroll
                         for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = mn_mfma_bf16(F.a[pl][mi], bf[ci], acc[mi][ci]);
             };
-#if !defined(MN_EMULATION) && WG3_PRIO
-            __builtin_amdgcn_s_setprio(WG3_PRIO);
-#endif
             if (BNH) __syncthreads();
             int kdone = -1;                  // last step whose fragments sit in registers, not yet contracted
             for (int t = 0; t < n; t += NS) {
 #pragma unroll
                 for (int u = 0; u < NS; ++u) {
-                    WG3_STAMP(1, 0, t + u)
                     __syncthreads();
-                    WG3_STAMP(1, 1, t + u)
                     if (t + u < n) ldfrag(fr[u & 1], u & 1);
                     MN_SCHED_FENCE();
                     if (t + u >= 1 && t + u - 1 < n) mma(fr[(u & 1) ^ 1]);
-                    WG3_STAMP(1, 2, t + u)
                 }
                 kdone = t + NS - 1;
             }
