@@ -743,7 +743,6 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl, int i8 = 0) {
         break;
     }
     if (!MF) return 0;
-    if (const char* e = MN_ENV("MN_QD_MF")) { (void)e; }
     pl->MF = MF;
     p.W4 = g->W / 4;
     p.tpi = p.NI == 1 ? p.Ho / p.TH : 1;
