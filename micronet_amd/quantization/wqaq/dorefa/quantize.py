@@ -227,7 +227,7 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
                                    self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, "mn_bnrelu", True)
             mm = ops.take_minmax()
             if mm is not None:
-                out._mn_minmax = mm
+                out._mn_minmax = mm + (out._version,)          # (valid only while nothing writes into the tensor in place)
             return out
         return ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                 self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)

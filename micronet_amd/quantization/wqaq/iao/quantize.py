@@ -35,6 +35,14 @@ __all__ = ["ObserverBase", "MinMaxObserver", "MovingAverageMinMaxObserver", "His
 
 
 # ------------------------------------------------------------------------------------------------ observers
+def _producer_minmax(t):
+    """(partials, count) the producing kernel left on ``t`` (``_mn_minmax``), or None -- also None once the tensor has been written in place since."""
+    mm = getattr(t, "_mn_minmax", None)
+    if mm is None or not torch.is_tensor(t) or t._version != mm[2]:
+        return None
+    return mm[0], mm[1]
+
+
 def _range_shape(q_level, out_channels):
     return {"L": (1,), "C": (out_channels, 1, 1, 1), "FC": (out_channels, 1)}[q_level]
 
@@ -64,9 +72,9 @@ class ObserverBase(nn.Module):
             dp.allreduce_minmax(cur_min, cur_max, self._mn_sync_group)
             ops.iao_observe(torch.cat([cur_min.reshape(-1), cur_max.reshape(-1)]), 1, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
                             self.min_val, self.max_val)
-        elif rows == 1 and getattr(input, "_mn_minmax", None) is not None and self._kind in (0, 1):
+        elif rows == 1 and _producer_minmax(input) is not None and self._kind in (0, 1):
             # the kernel that produced this activation left per-block (min, max): the same update without a pass over the tensor
-            ops.iao_observe_partials(input._mn_minmax, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1), self.min_val, self.max_val)
+            ops.iao_observe_partials(_producer_minmax(input), self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1), self.min_val, self.max_val)
         else:
             ops.iao_observe(input, rows, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
                             self.min_val, self.max_val)
@@ -178,7 +186,7 @@ class Quantizer(nn.Module):
             assert self.bits != 1
         if not self.qaft and self.training:
             obs = self.observer
-            mm = getattr(input, "_mn_minmax", None)
+            mm = _producer_minmax(input)
             if (not self.union and mm is not None and isinstance(obs, ObserverBase) and obs.q_level == "L" and obs._kind in (0, 1) and not obs._mn_sync
                     and 2 <= self.bits <= 24):
                 # the producing kernel left per-block (min, max): observer update + update_qparams in one launch, no pass over the activation
@@ -542,7 +550,7 @@ class QuantAdd(nn.Module):
             if want_mm:
                 mm = ops.take_minmax()
                 if mm is not None:
-                    out._mn_minmax = mm
+                    out._mn_minmax = mm + (out._version,)          # (valid only while nothing writes into the tensor in place)
             return out
         # both observers run unconditionally, also in eval (ref 1485-1486); the union range feeds ONE shared quantizer
         self.observer_res(res)

@@ -119,3 +119,28 @@ def test_ptq_conv_vs_reference_golden():
         assert rel(m.weight.grad.cpu().numpy(), g[f"ptqconv_s{s_}_d_weight"]) <= 1e-5
         for n_, b in m.named_buffers():
             assert np.array_equal(b.detach().cpu().numpy().reshape(-1), g[f"ptqconv_s{s_}_buf_{n_}"].reshape(-1)), (s_, n_)
+
+
+def test_observer_from_producer_partials_equals_observer_on_tensor():
+    """The fused BN+ReLU forward of an IAO ResNet leaves per-block (min, max) of its output (``_mn_minmax``); the observer + update_qparams of the conv that reads
+    it then run from those partials (one launch, no pass over the activation).  Same ranges, scales and qparams as the ordinary observer, bit for bit; an in-place
+    write into the tensor invalidates the hand-over (the observer reads the tensor again)."""
+    from micronet.compression.quantization.wqaq.iao import quantize as Q
+    from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dReLU
+    torch.manual_seed(3)
+    bn = BatchNorm2dReLU(32).cuda().train()
+    bn.emit_minmax = True
+    y = torch.randn(9, 32, 8, 8, device="cuda") * 2
+    qa = Q.SymmetricQuantizer(bits=4, observer=Q.MovingAverageMinMaxObserver(q_level="L", out_channels=None), activation_weight_flag=1).cuda().train()
+    qb = Q.SymmetricQuantizer(bits=4, observer=Q.MovingAverageMinMaxObserver(q_level="L", out_channels=None), activation_weight_flag=1).cuda().train()
+    for step in range(3):          # first call, then two moving-average updates
+        a = bn(y + step)
+        assert getattr(a, "_mn_minmax", None) is not None
+        qp1 = qa.qparams(a)                                   # from the producer's partials
+        qp2 = qb.qparams(a.detach().clone())                  # the ordinary observer on the tensor
+        for u, v in ((qp1, qp2), (qa.observer.min_val, qb.observer.min_val), (qa.observer.max_val, qb.observer.max_val), (qa.scale, qb.scale)):
+            assert torch.equal(u, v), step
+    a = bn(y)
+    a.add_(1.0)                                               # written in place: the partials are stale and must not be used
+    qp1, qp2 = qa.qparams(a), qb.qparams(a.detach().clone())
+    assert torch.equal(qp1, qp2) and torch.equal(qa.observer.max_val, qb.observer.max_val)
