@@ -153,3 +153,20 @@ def test_dorefa_prepare_fuses_resnet_basic_blocks():
     # 8-bit activations do not fit the code path's exact-integer range for these layer widths: blocks stay unfused
     q8 = quantize.prepare(build_model("resnet18"), inplace=True, a_bits=8, w_bits=8)
     assert not any(isinstance(m, quantize._FusedBasicBlockMixin) for m in q8.modules())
+
+
+def test_bench_cli_contract_without_gpu():
+    """bench.py (the driver's contract): refuses a line whose n_gpus would differ from --gpus, fails loudly without an MI355X (no CPU fallback), and its
+    self-launch for --gpus N > 1 goes through torch.distributed.run on 127.0.0.1 (checked on the command it would run, not by running it)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to report a line whose n_gpus differs" in (r.stderr + r.stdout)
+    env.pop("WORLD_SIZE")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "torch.distributed.run" in src and '"--master-addr", "127.0.0.1"' in src and "--nproc-per-node" in src
