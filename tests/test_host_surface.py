@@ -170,3 +170,33 @@ def test_bench_cli_contract_without_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
     src = open(os.path.join(root, "bench.py")).read()
     assert "torch.distributed.run" in src and '"--master-addr", "127.0.0.1"' in src and "--nproc-per-node" in src
+
+
+def test_bench_final_line_stays_parsable():
+    """Round 3's line was 34 KB (six workloads x per-kernel tables) and the driver could not parse it.  Feed the sections of that very run
+    (profiles/r03_c_bench.json) through bench.compose_line: the final line must stay under bench.MAX_LINE_BYTES, carry the contract's keys with the
+    headline roofline and cpu_baseline, and push every per-kernel table to the detail record instead."""
+    import argparse
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("mn_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r3 = json.load(open(os.path.join(root, "profiles", "r03_c_bench.json")))
+    sec = {k: r3[k] for k in ("value", "ms_per_step", "ms_per_step_min", "value_best_window", "repeats", "window_ms", "roofline", "kernels", "step_level")}
+    sec.update(hip_graph=True, final_loss=1.6, unit="images/s", workload="x")
+    args = argparse.Namespace(steps=20, warmup=5, batch=256)
+    also_err = {"cX": "RuntimeError: " + "x" * 1000}
+    out, detail = bench.compose_line("c2", sec, dict(r3["also"]), also_err, "PMC time budget exhausted " * 20, r3["cpu_baseline"], args, 1)
+    line = json.dumps(out)
+    assert len(line) + 64 <= bench.MAX_LINE_BYTES, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "values"):
+        assert k in out, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in out["roofline"], k
+    assert "kernels" not in out and set(out["values"]) == {"c2", "c1_w2a2", "c1", "c3", "c4", "c5"}
+    assert "workload" in out["config"] and "model" not in out["config"]
+    assert set(detail["sections"]) >= {"c2", "c1", "c3", "c4", "c5"} and "kernels" in detail["sections"]["c4"]
