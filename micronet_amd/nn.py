@@ -46,3 +46,32 @@ class AvgPool2dGlobal(nn.AvgPool2d):
                 and pair(self.kernel_size) == tuple(input.shape[2:]) and pair(self.padding) == (0, 0) and not self.ceil_mode and self.divisor_override is None):
             return ops.GlobalAvgPool.apply(input)
         return super().forward(input)
+
+
+# ------------------------------------------------------------------------------------------------ class swaps that survive pickling
+_DERIVED = {}
+
+
+def _mixin_by_name(mixin_module, mixin_name):
+    import importlib
+    return getattr(importlib.import_module(mixin_module), mixin_name)
+
+
+def _rebuild_derived(prefix, mixin_module, mixin_name, base):
+    """Unpickling hook: an EMPTY instance of the derived class (pickle restores its ``__dict__`` through ``nn.Module.__setstate__``)."""
+    cls = derive_class(prefix, _mixin_by_name(mixin_module, mixin_name), base)
+    return cls.__new__(cls)
+
+
+def derive_class(prefix, mixin, base):
+    """``type(prefix + base.__name__, (mixin, base))`` -- the subclass ``prepare()`` swaps a reference block's class for -- created once per (mixin, base) and
+    picklable: ``torch.save(model)`` of a prepared net (the reference saves whole models: wqaq/dorefa/quant_model_test/quant_model_para.py:67,84) stores
+    (prefix, mixin, base class) and rebuilds the class on load, so neither side needs the generated class to be importable by name."""
+    key = (prefix, mixin, base)
+    cls = _DERIVED.get(key)
+    if cls is None:
+        def __reduce_ex__(self, protocol, _a=(prefix, mixin.__module__, mixin.__name__, base)):
+            return _rebuild_derived, _a, self.__dict__
+        cls = type(prefix + base.__name__, (mixin, base), {"__module__": base.__module__, "__reduce_ex__": __reduce_ex__})
+        _DERIVED[key] = cls
+    return cls

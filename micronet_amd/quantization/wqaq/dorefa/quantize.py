@@ -394,9 +394,6 @@ class _FusedBasicBlockMixin:
         return q
 
 
-_FUSED_BLOCK_CLASSES = {}
-
-
 def _is_ref_basic_block(m):
     t = type(m)
     return (t.__name__ == "BasicBlock" and t.__module__.split(".")[-1] == "resnet") or bool(getattr(m, "_mn_basic_block", False))
@@ -425,9 +422,8 @@ def _fuse_residual_blocks(model):
     for m in model.modules():
         if _is_ref_basic_block(m) and fusable(m):
             cls = type(m)
-            if cls not in _FUSED_BLOCK_CLASSES:
-                _FUSED_BLOCK_CLASSES[cls] = type("Fused" + cls.__name__, (_FusedBasicBlockMixin, cls), {"__module__": cls.__module__})
-            m.__class__ = _FUSED_BLOCK_CLASSES[cls]
+            from micronet_amd.nn import derive_class
+            m.__class__ = derive_class("Fused", _FusedBasicBlockMixin, cls)
             rf = m.residual_function
             rf[0].lazy_for_bn = True
             rf[3].lazy_for_bn = True

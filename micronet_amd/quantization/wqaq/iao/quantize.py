@@ -662,9 +662,6 @@ class _ResidualAddReLUMixin:
         return self.add(self.residual_function(x), self.shortcut(x), relu=True)
 
 
-_RES_BLOCK_CLASSES = {}
-
-
 def _fuse_residual_tails(model):
     from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dPlain
     for m in model.modules():
@@ -677,9 +674,8 @@ def _fuse_residual_tails(model):
         t = type(m)
         if t.__name__ in ("BasicBlock", "BottleNeck") and t.__module__.split(".")[-1] == "resnet" and isinstance(getattr(m, "add", None), QuantAdd) \
                 and isinstance(getattr(m, "residual_function", None), nn.Sequential) and isinstance(getattr(m, "shortcut", None), nn.Sequential):
-            if t not in _RES_BLOCK_CLASSES:
-                _RES_BLOCK_CLASSES[t] = type("AddReLU" + t.__name__, (_ResidualAddReLUMixin, t), {"__module__": t.__module__})
-            m.__class__ = _RES_BLOCK_CLASSES[t]
+            from micronet_amd.nn import derive_class
+            m.__class__ = derive_class("AddReLU", _ResidualAddReLUMixin, t)
 
 
 def prepare(model, inplace=False, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=False,

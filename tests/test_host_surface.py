@@ -200,3 +200,23 @@ def test_bench_final_line_stays_parsable():
     assert "kernels" not in out and set(out["values"]) == {"c2", "c1_w2a2", "c1", "c3", "c4", "c5"}
     assert "workload" in out["config"] and "model" not in out["config"]
     assert set(detail["sections"]) >= {"c2", "c1", "c3", "c4", "c5"} and "kernels" in detail["sections"]["c4"]
+
+
+@pytest.mark.parametrize("scheme,kw", [("wqaq.dorefa", dict(a_bits=2, w_bits=2)), ("wqaq.iao", dict(a_bits=4, w_bits=4, q_type=0, q_level=0))])
+def test_prepared_resnet_pickles(scheme, kw):
+    """The reference saves whole prepared models (wqaq/dorefa/quant_model_test/quant_model_para.py:67,84): torch.save / torch.load of a prepared resnet18 must
+    round-trip although prepare() swapped its BasicBlocks for generated subclasses (micronet_amd.nn.derive_class)."""
+    import importlib
+    import io
+    import torch
+    from micronet_amd.train import build_model
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    m = quantize.prepare(build_model("resnet18"), inplace=True, **kw)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    assert [type(a).__name__ for a in m.modules()] == [type(a).__name__ for a in m2.modules()]
+    assert [type(a).__mro__[1:] for a in m.modules()] == [type(a).__mro__[1:] for a in m2.modules()]
+    sd, sd2 = m.state_dict(), m2.state_dict()
+    assert list(sd) == list(sd2) and all(torch.equal(sd[k], sd2[k]) for k in sd)
