@@ -281,6 +281,13 @@ int64_t mn_conv2d_iao_codes_bytes(const mn_conv_geom* g, const mn_actq* aq, cons
  * (NULL = MN_WQ_REAL) */
 int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w,
                   const float* bias, float* y, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
+/* y = relu?(conv2d(actq(x), w, bias)) for pointwise (1 x 1, stride 1) code-domain layers, with -- mm != NULL -- the per-wave (min, max) of everything stored left in
+ * mm[0 .. count) / mm[count .. 2 count), count = mn_conv2d_fwd_act_mm_count(g, aq, wq) (0: layer not covered): the block `relu(bn(conv(x)))` of the reference's nets
+ * after the IAO rewrite folded the BatchNorm into the conv (models/nin_gc.py:53-59 with bn = nn.Identity, wqaq/iao/quantize.py:1567-1624); the NEXT layer's
+ * observer (wqaq/iao/quantize.py:23-36) is then updated by mn_iao_observe_partials without a pass of its own over the activation. */
+int64_t mn_conv2d_fwd_act_mm_count(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);
+int mn_conv2d_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, int relu, float* mm,
+                      void* ws, int64_t ws_bytes, mn_stream_t stream);
 /* dx = conv2d_backward_data(gy, w) * d actq(x)/dx  (x may be NULL when aq->mode == NONE) */
 int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w,
                        const float* x, float* dx, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream);
@@ -511,6 +518,37 @@ int mn_iao_bnfold_fwd(const float* w, const float* bias, const float* gamma, con
 int mn_iao_bnfold_bwd(const float* dwf, const float* dbf, const float* w, const float* bias, const float* gamma, const float* mean, const float* var_b,
                       const float* var_w, float eps, int64_t O, int64_t K, float* dw, float* dbias, float* dgamma, float* dbeta, float* dmean,
                       float* dvar_b, float* dvar_w, mn_stream_t stream);
+
+/* ------------------------------------------------------------------ QuantBNFuseConv2d in training mode without the statistics convolution
+ * wqaq/iao/quantize.py:837-994 for POINTWISE grouped layers (1 x 1, stride 1, <= 128 channels per group; g->in_shuffle honoured).  The raw convolution of
+ * 843-851 is linear, and the block needs only the per-channel mean / unbiased variance of its output (853-855) and their gradient; both follow from the
+ * per-channel sums sx[c] = sum_p x[c,p] and the Gram matrix gram[g][c][c'] = sum_p x[c,p] x[c',p] of each group's input channels (logical, i.e. post-shuffle,
+ * channel order), accumulated on the matrix cores in fp32 over <= 2048 pixels per partial and combined in fp64:
+ *   mn_iaobf_gram      x -> gram [G][Cg][Cg], sx [G * Cg] (fp64).
+ *   mn_iaobf_prep_fwd  ONE launch for: batch statistics (from gram / sx, or given as stats_in [2][O] for other geometries), running statistics (856-879; first_bn:
+ *                      the copy of the first forward of a non-pretrained net), the fold w_f = w * gamma / sqrt(var + eps), bias_f = beta + (bias - mean) * ...
+ *                      (881-901), the per-channel weight observer + update_qparams + fake-quant (945 with 15-36 / 62-74 / 101-113, 293-321, 227-239).
+ *                      Outputs: stats [2][O] = mean, var; kfold [O]; bias_f [O]; qw [O][K] = the fake-quantised folded weights; qp [O][4].
+ *   mn_iaobf_prep_bwd  ONE launch for: the weight quantizer's clip-STE on dwq (gradient w.r.t. qw), the fold's backward (dgamma, dbeta, dbias), dmean / dvar and
+ *                      coef [3][O] = {dmean / n, 2 dvar / (n - 1), dmean}; with gram != NULL also the raw convolution's weight gradient, so that dw is complete;
+ *                      with gram == NULL dw holds the quantised path only and the caller adds the raw conv's backward-weight of d y_raw = coef0 + coef1 (y - mean).
+ *   mn_iaobf_bwd_data  dx = STE_x(W_q^T gy) + W^T d y_raw, the second term evaluated as M (x - x_bar) + v with M = W^T diag(coef1) W inside the same kernel
+ *                      (no raw convolution output exists); relu_mask != 0: x is the output of a ReLU whose backward mask [x > 0] is applied to dx here.
+ *                      gy must already carry the block's own ReLU mask.  aq: the activation quantizer snapshot (MN_ACTQ_IAO); wqp = qp of prep_fwd. */
+int mn_iaobf_gram_supported(const mn_conv_geom* g);
+int64_t mn_iaobf_gram_ws_bytes(const mn_conv_geom* g);
+int mn_iaobf_gram(const mn_conv_geom* g, const float* x, double* gram, double* sx, void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_iaobf_prep_fwd(const float* w, const float* bias, const float* gamma, const float* beta, int64_t O, int64_t K, int64_t groups, const double* gram,
+                      const double* sx, const float* stats_in, double n, float eps, float momentum, int first_bn, float* running_mean, float* running_var,
+                      int w_bits, int w_qtype, int w_obs_kind, int first_w, double momentum_w, float* wmin, float* wmax, float* wscale, float* wzp,
+                      float* stats, float* kfold, float* bias_f, float* qw, float* qp, mn_stream_t stream);
+int mn_iaobf_prep_bwd(const float* dwq, const float* dbf, const float* w, const float* bias, const float* gamma, const float* stats, const float* qp,
+                      int64_t O, int64_t K, int64_t groups, const double* gram, const double* sx, double n, float eps, int w_bits, int w_qtype, float* dw,
+                      float* dbias, float* dgamma, float* dbeta, float* coef, mn_stream_t stream);
+int mn_iaobf_bwd_data_supported(const mn_conv_geom* g);
+int64_t mn_iaobf_bwd_data_ws_bytes(const mn_conv_geom* g);
+int mn_iaobf_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, const float* w, const float* qw, const float* wqp,
+                      const float* coef, const double* sx, int relu_mask, float* dx, void* ws, int64_t ws_bytes, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ input pipeline of the training loop
  * <scheme>/main.py:203-210: transforms.Compose([RandomCrop(32, padding=4), RandomHorizontalFlip(), ToTensor(), Normalize(mean, std)]) applied to a batch

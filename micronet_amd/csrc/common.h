@@ -148,6 +148,45 @@ __device__ __forceinline__ float iao_fq_grad(float g, float x, float sc, float z
     d = (v > hi || v < lo) ? 0.f : d;          // Round.backward 166-167
     return d / sc;
 }
+// observer update (MinMax 62-74: running extremes; MovingAverage 101-113) and update_qparams -- shared by quant_kernels.hip and iao_bnfuse.hip
+struct OpMaxF_ { __device__ __forceinline__ float operator()(float a, float b) const { return (a != a || b != b) ? (a != a ? a : b) : fmaxf(a, b); } };
+struct OpMinF_ { __device__ __forceinline__ float operator()(float a, float b) const { return (a != a || b != b) ? (a != a ? a : b) : fminf(a, b); } };
+__device__ __forceinline__ void observer_update(int obs_kind, int first, double momentum, float cmin, float cmax,
+                                                float* min_val, float* max_val) {
+    float lo, hi;
+    if (first) { lo = cmin; hi = cmax; }
+    else if (obs_kind == 0) { lo = OpMinF_()(cmin, *min_val); hi = OpMaxF_()(cmax, *max_val); }
+    else {
+        const float a = (float)(1.0 - momentum), b = (float)momentum;   // python doubles (1 - m), m become fp32 scalars
+        lo = a * (*min_val) + b * cmin;
+        hi = a * (*max_val) + b * cmax;
+    }
+    *min_val = lo;
+    *max_val = hi;
+}
+// qparams (293-321) + clip-STE bounds (148-157)
+__device__ __forceinline__ void iao_qparams_row(float mn, float mx, int q_type, float quant_range, int update, float* scale, float* zero_point, float* qp) {
+    const float EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps
+    float sc, zp;
+    if (update) {
+        if (q_type == 0) {
+            float fr = OpMaxF_()(fabsf(mn), fabsf(mx));
+            sc = OpMaxF_()(fr / quant_range, EPS);
+            zp = 0.f;
+        } else {
+            sc = OpMaxF_()((mx - mn) / quant_range, EPS);
+            zp = mn_sign(mn) * floorf(fabsf(mn / sc) + 0.5f);
+        }
+        *scale = sc;
+        *zero_point = zp;
+    } else {
+        sc = *scale;
+        zp = *zero_point;
+    }
+    float lo = mn / sc - zp, hi = mx / sc - zp;
+    if (q_type == 0) { hi = OpMaxF_()(fabsf(lo), fabsf(hi)); lo = -hi; }
+    qp[0] = sc; qp[1] = zp; qp[2] = lo; qp[3] = hi;
+}
 struct IaoRange { float qmin, qmax; };
 static inline IaoRange iao_range(int bits, int q_type, int is_act) {
     IaoRange r;

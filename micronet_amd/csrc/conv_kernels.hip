@@ -732,6 +732,24 @@ extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_
     return MN_OK;
 }
 
+extern "C" int64_t mn_conv2d_fwd_act_mm_count(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
+    if (!g || check_geom(g, "mn_conv2d_fwd_act_mm_count") || !qg_supported(g, aq, wq, 0)) return 0;
+    return qg_fwd_act_mm_count(g);
+}
+extern "C" int mn_conv2d_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, int relu,
+                                 float* mm, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_fwd_act");
+    if (rc) return rc;
+    if (!x || !w || !y) MN_FAIL(MN_EINVAL, "mn_conv2d_fwd_act: null tensor");
+    if (!qg_fwd_act_mm_count(g) || !qg_supported(g, aq, wq, 0) || !aligned16(x) || !aligned16(y))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd_act: pointwise code-domain layers only");
+    {
+        const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
+        mn_prof_bytes(4.0 * (nx + ny));
+    }
+    return qg_fwd_act(g, aq, wq, x, w, bias, y, relu, mm, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w,
                                   const float* x, float* dx, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream) {
     int rc = check_geom(g, "mn_conv2d_bwd_data");

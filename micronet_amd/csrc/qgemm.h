@@ -9,6 +9,10 @@ int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const floa
            void* ws, int64_t ws_bytes, hipStream_t s);
 int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
                 void* ws, int64_t ws_bytes, hipStream_t s);
+// pointwise forward with the ReLU behind the conv and per-wave (min, max) partials of the result in the epilogue (mm: 2 * qg_fwd_act_mm_count(g) floats, nullable)
+int qg_fwd_act_mm_count(const mn_conv_geom* g);
+int qg_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, int relu, float* mm,
+               void* ws, int64_t ws_bytes, hipStream_t s);
 // first-layer convolution, real fp32 operands, K = Cin*KH*KW <= 76 (conv_first.hip); which: 0 fwd, 2 bwd_weight
 int c1_supported(const mn_conv_geom* g, int which);
 int64_t c1_ws_bytes(const mn_conv_geom* g, int which);

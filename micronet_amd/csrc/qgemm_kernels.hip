@@ -95,6 +95,8 @@ struct PwParams {
     FastDiv fd_hw, fd_ks;
     float ascale;
     ChanMap in_map, out_map;   // channel shuffle folded into the input (fwd) / output (bwd-data) addressing
+    int relu;                  // QG_EPI_SCALE_BIAS only: y = relu(y) (the nn.ReLU behind a BN-fused IAO conv, models/nin_gc.py:53-59 with bn = Identity)
+    float* mm;                 // nullable: per-wave (min, max) of what this launch stores -> mm[4 b + wave], mm[4 gridDim + 4 b + wave]: the NEXT layer's observer
 };
 
 template <int NT, int XMODE>
@@ -113,8 +115,12 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
     const uint32_t xcd = b & 7u; b >>= 3;
     const int mblk = b % p.num_mblk; b /= p.num_mblk;
     const uint32_t idx = b * 8u + xcd;
-    if (idx >= (uint32_t)(p.G * p.CB)) return;
+    if (idx >= (uint32_t)(p.G * p.CB)) {
+        if (p.mm && lane == 0) { p.mm[4 * blockIdx.x + wave] = INFINITY; p.mm[4 * gridDim.x + 4 * blockIdx.x + wave] = -INFINITY; }
+        return;
+    }
     const int cb = idx % p.CB, g = idx / p.CB;
+    float mlo = INFINITY, mhi = -INFINITY;
 
     {   // stage weight codes, scales, bias
         const uint16_t* wg = p.wc + ((int64_t)g * p.Mpad + mblk * MB) * p.Kp;
@@ -264,6 +270,11 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
                             if (p.epi == QG_EPI_SCALE_BIAS) {
                                 const float a_ = rs[ml], b_ = bs[ml];
                                 o0 = o0 * a_ + b_; o1 = o1 * a_ + b_; o2 = o2 * a_ + b_; o3 = o3 * a_ + b_;
+                                if (p.relu) { o0 = qa_relu(o0); o1 = qa_relu(o1); o2 = qa_relu(o2); o3 = qa_relu(o3); }
+                                if (p.mm) {
+                                    mlo = OpMinF()(OpMinF()(mlo, o0), OpMinF()(OpMinF()(o1, o2), o3));
+                                    mhi = OpMaxF()(OpMaxF()(mhi, o0), OpMaxF()(OpMaxF()(o1, o2), o3));
+                                }
                             } else if (p.epi == QG_EPI_STE) {
                                 const float4 xv = *reinterpret_cast<const float4*>(p.aux + off);
                                 if (p.ste.mode == MN_ACTQ_DOREFA) {
@@ -291,6 +302,11 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
     float ra[8][4];
     if (total > 0) issue(ra, 0);
     for (int it = 0; it < total; ++it) compute(ra, it);
+    if (p.mm) {
+        mlo = wave_reduce(mlo, OpMinF());
+        mhi = wave_reduce(mhi, OpMaxF());
+        if (lane == 0) { p.mm[4 * blockIdx.x + wave] = mlo; p.mm[4 * gridDim.x + 4 * blockIdx.x + wave] = mhi; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -973,6 +989,8 @@ int64_t qg_ws_bytes(const mn_conv_geom* g, int which) {
     return 0;
 }
 
+static thread_local int g_pw_relu = 0;          // set by qg_fwd_act around its call of qg_fwd
+static thread_local float* g_pw_mm = nullptr;
 template <int NT>
 static void launch_pw(const PwPlan& pl, int xmode, hipStream_t s) {
     if (xmode == MN_ACTQ_DOREFA) hipLaunchKernelGGL((k_pw<NT, MN_ACTQ_DOREFA>), dim3(pl.grid), dim3(256), pl.lds, s, pl.p);
@@ -1012,7 +1030,23 @@ int qg_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const floa
     p.x = x; p.y = y; p.wc = pl.pk.codes; p.rowscale = pl.pk.scale_out; p.kscale = nullptr; p.bias = bias; p.aux = nullptr;
     p.pro = pro; p.ste = pro; p.epi = QG_EPI_SCALE_BIAS;
     p.ascale = pro.mode == MN_ACTQ_DOREFA ? pro.s : 1.f;
+    p.relu = g_pw_relu; p.mm = g_pw_mm;
     return run_pw(pl, pro.mode, s, "mn_conv2d_fwd(qgemm)");
+}
+// forward with the ReLU behind the conv and the per-wave (min, max) of the result in the epilogue (pointwise code-domain layers only)
+int qg_fwd_act_mm_count(const mn_conv_geom* g) {
+    PwPlan pl;
+    if (!pw_geom_ok(g) || !plan_pw(g, 0, MN_ACTQ_NONE, &pl)) return 0;
+    return 4 * pl.grid;
+}
+int qg_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, int relu, float* mm,
+               void* ws, int64_t ws_bytes, hipStream_t s) {
+    if (!pw_geom_ok(g) || (aq && (aq->mode == MN_ACTQ_SIGN8 || aq->mode == MN_ACTQ_CODE8)))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd_act: pointwise code-domain layers with fp32 input only");
+    g_pw_relu = relu; g_pw_mm = mm;
+    const int rc = qg_fwd(g, aq, wq, x, w, bias, y, ws, ws_bytes, s);
+    g_pw_relu = 0; g_pw_mm = nullptr;
+    return rc;
 }
 
 int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx,
@@ -1048,6 +1082,7 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     PwParams& p = pl.p;
     p.x = gy; p.y = dx; p.wc = pl.pk.codes; p.rowscale = nullptr; p.kscale = pl.pk.scale_out; p.bias = nullptr; p.aux = x;
     p.pro = none; p.ste = ste; p.epi = ste.mode == MN_ACTQ_NONE ? QG_EPI_PLAIN : QG_EPI_STE; p.ascale = 1.f;
+    p.relu = 0; p.mm = nullptr;
     return run_pw(pl, MN_ACTQ_NONE, s, "mn_conv2d_bwd_data(qgemm)");
 }
 

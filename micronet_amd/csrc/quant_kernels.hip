@@ -735,19 +735,6 @@ extern "C" int mn_binary_w_bwd(const float* g, const float* w, const float* alph
 static const int OBS_NB = 1024;
 extern "C" int64_t mn_iao_observe_ws_floats(int64_t rows, int64_t) { return rows == 1 ? 2 * OBS_NB : 0; }
 
-__device__ __forceinline__ void observer_update(int obs_kind, int first, double momentum, float cmin, float cmax,
-                                                float* min_val, float* max_val) {
-    float lo, hi;
-    if (first) { lo = cmin; hi = cmax; }
-    else if (obs_kind == 0) { lo = OpMinF()(cmin, *min_val); hi = OpMaxF()(cmax, *max_val); }
-    else {
-        const float a = (float)(1.0 - momentum), b = (float)momentum;   // python doubles (1 - m), m become fp32 scalars
-        lo = a * (*min_val) + b * cmin;
-        hi = a * (*max_val) + b * cmax;
-    }
-    *min_val = lo;
-    *max_val = hi;
-}
 __global__ __launch_bounds__(256) void k_minmax_partial(const float* __restrict__ x, int64_t n, int vec, float* __restrict__ ws) {
     __shared__ float sc[16];
     float lo = INFINITY, hi = -INFINITY;
@@ -807,7 +794,6 @@ extern "C" int mn_iao_observe(const float* x, int64_t rows, int64_t cols, int ob
 
 // the observer update from per-block (min, max) partials written by the kernel that PRODUCED the tensor (mn_bnrelu_fwd_mm, mn_iao_qadd_fwd_mm): mm[0 .. count)
 // minima, mm[count .. 2 count) maxima.  min / max are exact and order-free, so this equals mn_iao_observe on the tensor itself bit for bit -- without reading it.
-__device__ __forceinline__ void iao_qparams_row(float mn, float mx, int q_type, float quant_range, int update, float* scale, float* zero_point, float* qp);
 __global__ __launch_bounds__(256) void k_minmax_from_partials(const float* __restrict__ mm, int count, int obs_kind, int first, double momentum,
                                                               float* __restrict__ min_val, float* __restrict__ max_val, int q_type, float quant_range,
                                                               float* __restrict__ scale, float* __restrict__ zero_point, float* __restrict__ qp) {
@@ -842,29 +828,6 @@ extern "C" int mn_iao_observe_partials_qparams(const float* mm, int64_t count, i
     return MN_OK;
 }
 
-// qparams (293-321) + clip-STE bounds (148-157)
-__device__ __forceinline__ void iao_qparams_row(float mn, float mx, int q_type, float quant_range, int update, float* scale, float* zero_point, float* qp) {
-    const float EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps
-    float sc, zp;
-    if (update) {
-        if (q_type == 0) {
-            float fr = OpMaxF()(fabsf(mn), fabsf(mx));
-            sc = OpMaxF()(fr / quant_range, EPS);
-            zp = 0.f;
-        } else {
-            sc = OpMaxF()((mx - mn) / quant_range, EPS);
-            zp = mn_sign(mn) * floorf(fabsf(mn / sc) + 0.5f);
-        }
-        *scale = sc;
-        *zero_point = zp;
-    } else {
-        sc = *scale;
-        zp = *zero_point;
-    }
-    float lo = mn / sc - zp, hi = mx / sc - zp;
-    if (q_type == 0) { hi = OpMaxF()(fabsf(lo), fabsf(hi)); lo = -hi; }
-    qp[0] = sc; qp[1] = zp; qp[2] = lo; qp[3] = hi;
-}
 __global__ __launch_bounds__(256) void k_iao_qparams(const float* __restrict__ min_val, const float* __restrict__ max_val, int64_t rows,
                                                      int q_type, float quant_range, int update, float* __restrict__ scale,
                                                      float* __restrict__ zero_point, float* __restrict__ qp) {

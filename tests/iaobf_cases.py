@@ -1,0 +1,164 @@
+"""Checks of the BN-fused IAO block kernels (micronet_amd/csrc/iao_bnfuse.hip) through the C ABI, written once for the CPU emulation build and the gfx950
+build: the pipeline gram -> prep_fwd -> conv(+ReLU, min/max) -> bwd_weight -> prep_bwd -> bwd_data against the torch-CPU oracle of the reference's
+QuantBNFuseConv2d (oracle/torch_oracle.py:OBNFuseConv2d = wqaq/iao/quantize.py:837-994) followed by the block's ReLU, evaluated in fp32 (the reference) and
+in fp64 (the conditioning reference for sums that cancel)."""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from micronet_amd import _lib
+from oracle import torch_oracle as TO
+
+CASES = [
+    # N, C, O, H, W, groups, shuffle, bias
+    dict(N=3, C=32, O=32, H=4, W=8, groups=2, shuffle=0, bias=True),
+    dict(N=2, C=64, O=32, H=8, W=8, groups=2, shuffle=2, bias=True),
+    dict(N=2, C=256, O=256, H=4, W=4, groups=2, shuffle=2, bias=False),      # Cg = Mg = 128: the nin_gc tile
+    dict(N=5, C=48, O=96, H=2, W=6, groups=1, shuffle=0, bias=True),         # Cg = 48 (padded to 64), Mg = 96 (three K-steps)
+]
+
+
+def _shuffle(x, g):
+    n, c, h, w = x.shape
+    return x.view(n, g, c // g, h, w).transpose(1, 2).contiguous().view(n, c, h, w)
+
+
+def _oracle(case, seed, dtype, steps):
+    """steps: list of (x_phys, g); returns per step dict of outputs / gradients, and the module after the last step."""
+    torch.manual_seed(seed)
+    conv = nn.Conv2d(case["C"], case["O"], 1, groups=case["groups"], bias=case["bias"])
+    bn = nn.BatchNorm2d(case["O"])
+    with torch.no_grad():
+        bn.weight.uniform_(0.3, 1.2)
+        bn.bias.normal_(0, 0.2)
+    m = TO.OBNFuseConv2d(conv, bn, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0).train()
+    if dtype == torch.float64:
+        m = m.double()
+    recs = []
+    for x_phys, g in steps:
+        xp = x_phys.to(dtype).clone().requires_grad_(True)
+        xin = _shuffle(xp, case["shuffle"]) if case["shuffle"] > 1 else xp
+        for p in m.parameters():
+            p.grad = None
+        out = torch.relu(m(xin))
+        out.backward(g.to(dtype))
+        recs.append(dict(out=out.detach(), dx=xp.grad.detach(), dw=m.weight.grad.detach().clone(), db=None if m.bias is None else m.bias.grad.detach().clone(),
+                         dgamma=m.gamma.grad.detach().clone(), dbeta=m.beta.grad.detach().clone(), rm=m.running_mean.clone(), rv=m.running_var.clone(),
+                         wmin=m.wq.observer.min_val.clone(), wmax=m.wq.observer.max_val.clone(), wscale=m.wq.scale.clone(),
+                         amin=m.aq.observer.min_val.clone(), amax=m.aq.observer.max_val.clone()))
+    return recs, m
+
+
+def _close(name, got, ref32, ref64, tol=1e-5):
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    r32 = ref32.detach().double().numpy().reshape(-1)
+    r64 = ref64.detach().double().numpy().reshape(-1)
+    scale = max(np.abs(r64).max(), 1e-30)
+    e_ref = np.abs(got - r32).max() / scale
+    e64 = np.abs(got - r64).max() / scale
+    own = np.abs(r32 - r64).max() / scale                    # the reference's own fp32 error
+    assert e_ref <= tol or e64 <= max(tol, 2.0 * own), "%s: vs fp32 reference %.3g, vs fp64 %.3g (reference's own error %.3g)" % (name, e_ref, e64, own)
+    return e_ref, e64
+
+
+def check_iaobf_pointwise(be, case, seed=0, nsteps=2, relu_mask=True):
+    N, Cc, O, H, W, G, sg = case["N"], case["C"], case["O"], case["H"], case["W"], case["groups"], case["shuffle"]
+    rng = torch.Generator().manual_seed(1000 + seed)
+    steps = []
+    for _ in range(nsteps):
+        x = torch.relu(torch.randn(N, Cc, H, W, generator=rng) * 1.5 + 0.4)          # what a ReLU block hands over
+        g = torch.randn(N, O, H, W, generator=rng)
+        steps.append((x, g))
+    r32, m32 = _oracle(case, seed, torch.float32, steps)
+    r64, _ = _oracle(case, seed, torch.float64, steps)
+    torch.manual_seed(seed)
+    conv = nn.Conv2d(Cc, O, 1, groups=G, bias=case["bias"])        # the same initial parameters as the oracle's
+    bn = nn.BatchNorm2d(O)
+    with torch.no_grad():
+        bn.weight.uniform_(0.3, 1.2)
+        bn.bias.normal_(0, 0.2)
+    lib = be.lib
+    geom = _lib.ConvGeom(N, Cc, H, W, O, 1, 1, 1, 1, 0, 0, 1, 1, G, sg)
+    Cg = Cc // G
+    n = float(N * H * W)
+    w = be.to_dev(conv.weight.detach().numpy().reshape(O, Cg))
+    bias = be.to_dev(conv.bias.detach().numpy()) if case["bias"] else None
+    gamma, beta = be.to_dev(bn.weight.detach().numpy()), be.to_dev(bn.bias.detach().numpy())
+    rm, rv = be.to_dev(np.zeros(O)), be.to_dev(np.ones(O))
+    wmin, wmax, wscale, wzp = be.to_dev(np.zeros(O)), be.to_dev(np.zeros(O)), be.to_dev(np.ones(O)), be.to_dev(np.zeros(O))
+    amin, amax, ascale, azp = be.to_dev(np.zeros(1)), be.to_dev(np.zeros(1)), be.to_dev(np.ones(1)), be.to_dev(np.zeros(1))
+    assert lib.mn_iaobf_gram_supported(C.byref(geom)) == 1 and lib.mn_iaobf_bwd_data_supported(C.byref(geom)) == 1
+    worst = {}
+    for it, (x_t, g_t) in enumerate(steps):
+        first = int(it == 0)
+        x = be.to_dev(x_t.numpy())
+        # activation observer + qparams of the input (per tensor, moving average): the existing entry points
+        ows = be.empty(int(lib.mn_iao_observe_ws_floats(1, x_t.numel())) + 4)
+        be.call("mn_iao_observe", be.ptr(x), 1, x_t.numel(), 1, first, 0.1, be.ptr(amin), be.ptr(amax), be.ptr(ows), be.stream)
+        aqp = be.empty(4)
+        be.call("mn_iao_qparams", be.ptr(amin), be.ptr(amax), 1, 8, 0, 1, 1, be.ptr(ascale), be.ptr(azp), be.ptr(aqp), be.stream)
+        # Gram data
+        nb = int(lib.mn_iaobf_gram_ws_bytes(C.byref(geom)))
+        ws = be.empty(nb // 4 + 4)
+        gram = be.empty(2 * G * Cg * Cg)          # doubles
+        sx = be.empty(2 * Cc)
+        be.call("mn_iaobf_gram", C.byref(geom), be.ptr(x), be.ptr(gram), be.ptr(sx), be.ptr(ws), nb, be.stream)
+        xl = (_shuffle(x_t, sg) if sg > 1 else x_t).double()
+        xg = xl.permute(1, 0, 2, 3).reshape(G, Cg, -1)
+        gram_ref = torch.einsum("gcp,gdp->gcd", xg, xg).numpy()
+        gram_got = np.frombuffer(be.to_host(gram).tobytes(), dtype=np.float64).reshape(G, Cg, Cg)
+        sx_got = np.frombuffer(be.to_host(sx).tobytes(), dtype=np.float64)
+        assert np.abs(gram_got - gram_ref).max() <= 2e-6 * np.abs(gram_ref).max(), ("gram", np.abs(gram_got - gram_ref).max() / np.abs(gram_ref).max())
+        assert np.abs(sx_got - xg.sum(-1).reshape(-1).numpy()).max() <= 2e-6 * np.abs(xg.sum(-1)).max().item()
+        # forward preparation
+        stats, kfold, bias_f, qw, wqp = be.empty(2 * O), be.empty(O), be.empty(O), be.empty((O, Cg)), be.empty((O, 4))
+        be.call("mn_iaobf_prep_fwd", be.ptr(w), be.ptr(bias), be.ptr(gamma), be.ptr(beta), O, Cg, G, be.ptr(gram), be.ptr(sx), None, n, 1e-5, 0.1, first,
+                be.ptr(rm), be.ptr(rv), 8, 0, 0, first, 0.1, be.ptr(wmin), be.ptr(wmax), be.ptr(wscale), be.ptr(wzp), be.ptr(stats), be.ptr(kfold), be.ptr(bias_f),
+                be.ptr(qw), be.ptr(wqp), be.stream)
+        worst["rm%d" % it] = _close("running_mean", be.to_host(rm), r32[it]["rm"], r64[it]["rm"])
+        worst["rv%d" % it] = _close("running_var", be.to_host(rv), r32[it]["rv"], r64[it]["rv"])
+        worst["wmin%d" % it] = _close("weight observer min", be.to_host(wmin), r32[it]["wmin"], r64[it]["wmin"])
+        worst["wmax%d" % it] = _close("weight observer max", be.to_host(wmax), r32[it]["wmax"], r64[it]["wmax"])
+        worst["wscale%d" % it] = _close("weight scale", be.to_host(wscale), r32[it]["wscale"], r64[it]["wscale"])
+        assert np.array_equal(be.to_host(amin), r32[it]["amin"].numpy()) and np.array_equal(be.to_host(amax), r32[it]["amax"].numpy())
+        # quantised conv + ReLU + (min, max) partials
+        aq = be.actq(2, 8, 0, aqp)
+        wq = be.wq(3, 8, 0, 4, wqp)
+        cnt = int(lib.mn_conv2d_fwd_act_mm_count(C.byref(geom), C.byref(aq), C.byref(wq)))
+        assert cnt > 0
+        mm = be.empty(2 * cnt)
+        a = be.empty((N, O, H, W))
+        nbf = int(lib.mn_conv2d_ws_bytes(C.byref(geom), 0, 0))
+        wsf = be.empty(nbf // 4 + 4)
+        be.call("mn_conv2d_fwd_act", C.byref(geom), C.byref(aq), C.byref(wq), be.ptr(x), be.ptr(qw), be.ptr(bias_f), be.ptr(a), 1, be.ptr(mm), be.ptr(wsf), nbf, be.stream)
+        a_h = be.to_host(a)
+        worst["out%d" % it] = _close("relu(out)", a_h, r32[it]["out"], r64[it]["out"])
+        mm_h = be.to_host(mm)
+        assert mm_h[:cnt].min() == a_h.min() and mm_h[cnt:].max() == a_h.max()
+        # backward: the block's own ReLU mask, quantised backward-weight, preparation, fused backward-data
+        gy_h = (g_t.numpy() * (a_h > 0)).astype(np.float32)
+        gy = be.to_dev(gy_h)
+        dwq, dbf = be.empty((O, Cg)), be.empty(O)
+        nbw = int(lib.mn_conv2d_ws_bytes(C.byref(geom), 2, 0))
+        wsw = be.empty(nbw // 4 + 4)
+        be.call("mn_conv2d_bwd_weight", C.byref(geom), C.byref(aq), be.ptr(gy), be.ptr(x), be.ptr(dwq), be.ptr(dbf), be.ptr(wsw), nbw, 0, be.stream)
+        dw, dbias, dgamma, dbeta, coef = be.empty((O, Cg)), (be.empty(O) if case["bias"] else None), be.empty(O), be.empty(O), be.empty(3 * O)
+        be.call("mn_iaobf_prep_bwd", be.ptr(dwq), be.ptr(dbf), be.ptr(w), be.ptr(bias), be.ptr(gamma), be.ptr(stats), be.ptr(wqp), O, Cg, G, be.ptr(gram), be.ptr(sx), n,
+                1e-5, 8, 0, be.ptr(dw), be.ptr(dbias), be.ptr(dgamma), be.ptr(dbeta), be.ptr(coef), be.stream)
+        worst["dw%d" % it] = _close("dw", be.to_host(dw), r32[it]["dw"], r64[it]["dw"])
+        worst["dgamma%d" % it] = _close("dgamma", be.to_host(dgamma), r32[it]["dgamma"], r64[it]["dgamma"])
+        worst["dbeta%d" % it] = _close("dbeta", be.to_host(dbeta), r32[it]["dbeta"], r64[it]["dbeta"])
+        if case["bias"]:
+            # the gradient of a conv bias in front of a BatchNorm is zero in exact arithmetic; the reference's value is rounding noise relative to dbeta
+            assert np.abs(be.to_host(dbias)).max() <= 1e-5 * max(np.abs(r64[it]["dbeta"].numpy()).max(), 1e-30)
+        nbd = int(lib.mn_iaobf_bwd_data_ws_bytes(C.byref(geom)))
+        wsd = be.empty(nbd // 4 + 4)
+        dx = be.empty((N, Cc, H, W))
+        be.call("mn_iaobf_bwd_data", C.byref(geom), C.byref(aq), be.ptr(gy), be.ptr(x), be.ptr(w), be.ptr(qw), be.ptr(wqp), be.ptr(coef), be.ptr(sx), int(relu_mask),
+                be.ptr(dx), be.ptr(wsd), nbd, be.stream)
+        mask = (x_t > 0).to(torch.float32) if relu_mask else torch.ones_like(x_t)
+        worst["dx%d" % it] = _close("dx", be.to_host(dx), r32[it]["dx"] * mask, r64[it]["dx"] * mask.double())
+        # next step: updated parameters would come from the optimizer; the test keeps them (the oracle does too)
+    return worst

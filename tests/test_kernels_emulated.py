@@ -440,3 +440,12 @@ def test_global_avgpool(be):
 @pytest.mark.parametrize("w_bits,iao", [(2, False), (8, False), (4, True)])
 def test_qd_pack_multi_tables(be, w_bits, iao):
     K.check_qd_pack_multi(be, w_bits=w_bits, iao=iao, seed=w_bits)
+
+
+# ---- the BN-fused IAO block without the statistics convolution (iao_bnfuse.hip)
+@pytest.mark.parametrize("case", range(4))
+def test_iaobf_pointwise(be, case):
+    """Gram data -> batch statistics / fold / weight quantizer in one launch -> conv + ReLU + (min, max) -> backward-weight -> one-launch backward preparation ->
+    backward-data with the raw path folded in, two training steps, against the oracle's QuantBNFuseConv2d + ReLU in fp32 and fp64."""
+    import iaobf_cases as B
+    B.check_iaobf_pointwise(be, B.CASES[case], seed=case)
