@@ -16,6 +16,7 @@ Reference call sites each op replaces (micronet/compression/quantization/...):
   bn_batch_stats       wqaq/iao/quantize.py:853-855
 """
 import ctypes as C
+import threading
 
 import torch
 from torch.autograd import Function
@@ -563,6 +564,137 @@ class IaoBNFold(Function):
         return dw, dbias, dgamma, dbeta, dmean, dvb, dvw, None
 
 
+class ReluToken:
+    """Hand-shake between a block that ends in a ReLU and the ONE consumer of its output: the consumer's backward-data kernel reads that activation anyway (the
+    clip-STE of its activation quantizer), so it applies the ReLU's backward mask [a > 0] to the gradient it returns and leaves the tensor here; the producer
+    recognises its incoming gradient as exactly that tensor (same storage, same version -- autograd passes a single contribution through untouched, and adds
+    two contributions OUT of place while this reference keeps the first one alive) and skips its own masking pass.  Masking is idempotent, so any other path
+    (a second consumer, a hook, a foreign op) simply masks again: always correct, one streaming pass slower."""
+    __slots__ = ("dx",)
+
+    def __init__(self):
+        self.dx = None
+
+    def premasked(self, g):
+        d = self.dx
+        self.dx = None
+        return d is not None and torch.is_tensor(g) and type(g) is torch.Tensor and g.data_ptr() == d.data_ptr() and g.shape == d.shape and g._version == d._version
+
+
+def relu_premask_ok(x):
+    """May the consumer of ``x`` (the output of a fused conv + ReLU) return its input gradient already masked by [x > 0]?  Only when nobody else can observe the
+    un-masked gradient of ``x``: no tensor hooks, no retain_grad."""
+    return getattr(x, "_mn_relu_token", None) is not None and not getattr(x, "_backward_hooks", None) and not x.retains_grad
+
+
+def iao_bnfuse_pw_supported(x, weight, stride, padding, dilation, groups, in_shuffle):
+    if not (torch.is_tensor(x) and type(x) is torch.Tensor and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() > 0
+            and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()):
+        return False
+    if x.shape[1] != weight.shape[1] * groups:
+        return False
+    g = _geom(x.shape, weight.shape, stride, padding, dilation, groups, in_shuffle)
+    lib = _lib_()
+    return bool(lib.mn_iaobf_gram_supported(C.byref(g))) and bool(lib.mn_iaobf_bwd_data_supported(C.byref(g)))
+
+
+class IaoBNFusePW(Function):
+    """The whole training-mode ``QuantBNFuseConv2d.forward`` (wqaq/iao/quantize.py:837-994, not qaft, not bn_fuse_calib) of a POINTWISE grouped layer, optionally
+    with the ReLU the block applies to its output, WITHOUT the statistics convolution (csrc/iao_bnfuse.hip): Gram data of the input -> one preparation launch
+    (batch / running statistics, fold, per-channel weight observer + qparams + fake-quant) -> the quantised convolution with ReLU and the (min, max) partials of its
+    output in the epilogue.  Backward: quantised backward-weight -> one preparation launch (weight clip-STE, fold backward, dmean / dvar, the raw convolution's
+    weight gradient from the Gram data) -> ONE backward-data kernel for the quantised and the raw path.  ``st``: the module (buffers are updated in place exactly as
+    the reference does)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, st, aqp, relu, want_mm):
+        lib = _lib_()
+        x, weight, gamma, beta = _chk(x, "input"), _chk(weight, "weight"), _chk(gamma, "gamma"), _chk(beta, "beta")
+        bias = _chk(bias, "bias")
+        wq_, aq_ = st.weight_quantizer, st.activation_quantizer
+        wobs = wq_.observer
+        g = _geom(x.shape, weight.shape, st.stride, st.padding, st.dilation, st.groups, int(getattr(st, "in_shuffle_groups", 0) or 0))
+        N, O, H, W = g.N, g.O, g.H, g.W
+        Cg = weight.shape[1]
+        dev = x.device
+        n = float(N * H * W)
+        with torch.cuda.device_of(x):
+            nb = int(lib.mn_iaobf_gram_ws_bytes(C.byref(g)))
+            ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
+            gram = torch.empty((g.groups, Cg, Cg), dtype=torch.float64, device=dev)
+            sx = torch.empty(g.C, dtype=torch.float64, device=dev)
+            _call("mn_iaobf_gram", C.byref(g), _p(x), _p(gram), _p(sx), _p(ws), nb, _s())
+            first_bn = (not st.pretrained_model) and st.num_flag == 0
+            if first_bn:
+                st.num_flag += 1
+            first_w = wobs.num_flag == 0
+            stats = torch.empty((2, O), dtype=torch.float32, device=dev)
+            kfold, bias_f = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
+            qw, wqp = torch.empty_like(weight), torch.empty((O, 4), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_prep_fwd", _p(weight), _p(bias), _p(gamma), _p(beta), O, Cg, g.groups, _p(gram), _p(sx), None, n, float(st.eps), float(st.momentum),
+                  int(first_bn), _p(st.running_mean), _p(st.running_var), wq_.bits, wq_._q_type_static, wobs._kind, int(first_w), float(getattr(wobs, "momentum", 0.1)),
+                  _p(wobs.min_val), _p(wobs.max_val), _p(wq_.scale), _p(wq_.zero_point), _p(stats), _p(kfold), _p(bias_f), _p(qw), _p(wqp), _s())
+            if first_w:
+                wobs.num_flag += 1
+            wq_.q_type = wq_._q_type_static
+            wq_._last_qp = wqp
+            aq = ActQ(ACTQ_IAO, aq_.bits, aq_.q_type, 0, aqp.data_ptr())
+            wd = WQ(WQ_IAO, wq_.bits, 0, 4, wqp.data_ptr())
+            a = torch.empty((N, O, H, W), dtype=torch.float32, device=dev)
+            mm, count = None, 0
+            if want_mm:
+                count = int(lib.mn_conv2d_fwd_act_mm_count(C.byref(g), C.byref(aq), C.byref(wd)))
+                mm = torch.empty(2 * count, dtype=torch.float32, device=dev)
+            wsf, nbf = _ws(g, 0, dev)
+            _call("mn_conv2d_fwd_act", C.byref(g), C.byref(aq), C.byref(wd), _p(x), _p(qw), _p(bias_f), _p(a), int(relu), _p(mm), _p(wsf), nbf, _s())
+        ctx.save_for_backward(x, weight, bias, gamma, a if relu else None, stats, qw, wqp, aqp, gram, sx)
+        ctx.cfg = (g, aq_.bits, aq_.q_type, wq_.bits, wq_._q_type_static, float(st.eps), n, bool(relu))
+        ctx.tok_in = getattr(x, "_mn_relu_token", None)          # the ReLU in FRONT of this block (its producer's token)
+        ctx.x_obj = x
+        ctx.tok_out = ReluToken() if relu else None
+        st.__dict__["_mn_fwd_out"] = ((mm, count) if want_mm else None, ctx.tok_out)      # picked up (and cleared) by the module right after apply()
+        return a
+
+    @staticmethod
+    def backward(ctx, gin):
+        x, weight, bias, gamma, a, stats, qw, wqp, aqp, gram, sx = ctx.saved_tensors
+        g, a_bits, a_qtype, w_bits, w_qtype, eps, n, relu = ctx.cfg
+        lib = _lib_()
+        dev = x.device
+        premasked = relu and ctx.tok_out.premasked(gin)
+        gy = _chk(gin, "grad")
+        if relu and not premasked:
+            gy = relu_mask(gy, a)
+        O, Cg = weight.shape[0], weight.shape[1]
+        aq = ActQ(ACTQ_IAO, a_bits, a_qtype, 0, aqp.data_ptr())
+        dx = None
+        with torch.cuda.device_of(x):
+            dwq, dbf = torch.empty_like(weight), torch.empty(O, dtype=torch.float32, device=dev)
+            ws, nb = _ws(g, 2, dev)
+            _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dwq), _p(dbf), _p(ws), nb, CONV_ALGO, _s())
+            dw = torch.empty_like(weight)
+            dbias = torch.empty(O, dtype=torch.float32, device=dev) if bias is not None else None
+            dgamma, dbeta = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
+            coef = torch.empty((3, O), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_prep_bwd", _p(dwq), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(stats), _p(wqp), O, Cg, g.groups, _p(gram), _p(sx), n, eps, w_bits, w_qtype,
+                  _p(dw), _p(dbias), _p(dgamma), _p(dbeta), _p(coef), _s())
+            if ctx.needs_input_grad[0]:
+                pre = ctx.tok_in is not None and relu_premask_ok(ctx.x_obj)
+                nbd = int(lib.mn_iaobf_bwd_data_ws_bytes(C.byref(g)))
+                wsd = torch.empty(nbd // 4 + 4, dtype=torch.float32, device=dev)
+                dx = torch.empty_like(x)
+                _call("mn_iaobf_bwd_data", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(weight), _p(qw), _p(wqp), _p(coef), _p(sx), int(pre), _p(dx), _p(wsd), nbd, _s())
+                if pre:
+                    ctx.tok_in.dx = dx
+        ctx.x_obj = None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None
+
+
+def relu_mask(g, a):
+    """g * [a > 0]: the backward of a ReLU whose output is ``a`` (only on paths where no consumer pre-masked the gradient)."""
+    return torch.where(a > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))
+
+
 def hist_observe(x, percentile, first, momentum, max_val):
     """HistogramObserver.forward (ref 126-139) on the device: exact k-th smallest |x| + first-call / EMA update of ``max_val``."""
     x = _chk(x.detach(), "input")
@@ -650,11 +782,24 @@ class BNSign(Function):
         return dy, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-_PENDING_MINMAX = [None]
+class _PendingMinMax(threading.local):
+    """One slot per THREAD (nn.DataParallel-style replicas run their forwards on separate threads; the GIL is released inside the ctypes / HIP calls)."""
+
+    def __init__(self):
+        self.v = None
+
+    def __setitem__(self, i, v):
+        self.v = v
+
+    def __getitem__(self, i):
+        return self.v
+
+
+_PENDING_MINMAX = _PendingMinMax()
 
 
 def take_minmax():
-    """(mm, count) left by the last forward that was asked for per-block (min, max) partials of its output, or None; cleared by the call."""
+    """(mm, count) left by the last forward OF THIS THREAD that was asked for per-block (min, max) partials of its output, or None; cleared by the call."""
     v = _PENDING_MINMAX[0]
     _PENDING_MINMAX[0] = None
     return v

@@ -26,6 +26,7 @@ from micronet_amd import ops
 from micronet_amd.base_module.op import Add
 
 _PRODUCER_MINMAX = os.environ.get("MN_NO_PRODUCER_MINMAX") is None          # A/B knob: observers read the tensor themselves
+_FUSE_BNFUSE = os.environ.get("MN_NO_BNFUSE_BLOCK") is None                 # A/B knob: QuantBNFuseConv2d on the generic kernels (raw conv + statistics passes)
 
 __all__ = ["ObserverBase", "MinMaxObserver", "MovingAverageMinMaxObserver", "HistogramObserver", "Round", "Quantizer",
            "SignedQuantizer", "UnsignedQuantizer", "SymmetricQuantizer", "AsymmetricQuantizer", "QuantConv2d",
@@ -372,8 +373,38 @@ class QuantBNFuseConv2d(QuantConv2d):
         weight_fused = self.weight * reshape_to_weight(self.gamma / torch.sqrt(var_for_weight + self.eps))
         return weight_fused, bias_fused
 
+    relu_fused = False          # set by prepare(fuse_blocks=True): the block applies nn.ReLU to this conv's output (ConvBNReLU with bn = Identity) -> fused
+    in_shuffle_groups = 0       # > 1: this conv reads channel_shuffle(input, groups) (the block's shuffle folded into the kernels' addressing)
+
+    def _fused_pw_ok(self, input):
+        """Training-mode forward on the kernels of csrc/iao_bnfuse.hip: pointwise grouped layer, symmetric <= 8-bit quantizers, per-channel weight observer."""
+        wq, aq = self.weight_quantizer, self.activation_quantizer
+        wobs, aobs = wq.observer, aq.observer
+        return (_FUSE_BNFUSE and not self.bn_fuse_calib and self.padding_mode == "zeros" and not isinstance(self.padding, str)
+                and isinstance(wobs, ObserverBase) and wobs.q_level == "C" and wobs._kind in (0, 1) and not wobs._mn_sync and wq._q_type_static == 0 and 2 <= wq.bits <= 8
+                and not wq.qaft and isinstance(aobs, ObserverBase) and aobs.q_level == "L" and aq._q_type_static == 0 and 2 <= aq.bits <= 8 and not aq.qaft and not aq.union
+                and ops.iao_bnfuse_pw_supported(input, self.weight, self.stride, self.padding, self.dilation, self.groups, self.in_shuffle_groups))
+
+    def _forward_fused_pw(self, input):
+        aq = self.activation_quantizer
+        qp = aq.qparams(input)          # observer (from the producer's partials when it left them) + update_qparams: the snapshot {scale, zp, lo, hi}
+        aq._last_qp = qp
+        relu = bool(self.relu_fused)
+        out = ops.IaoBNFusePW.apply(input, self.weight, self.bias, self.gamma, self.beta, self, qp, relu, relu and _PRODUCER_MINMAX)
+        mm, tok = self.__dict__.pop("_mn_fwd_out", (None, None))
+        if relu:
+            out._mn_relu_done = True
+            out._mn_relu_token = tok
+        if mm is not None:
+            out._mn_minmax = mm + (out._version,)
+        return out
+
     def forward(self, input):
         training_stats = (not self.qaft) and self.training
+        if training_stats and self._fused_pw_ok(input):
+            return self._forward_fused_pw(input)
+        if self.in_shuffle_groups > 1:
+            input = ops.channel_shuffle(input, self.in_shuffle_groups)
         if training_stats:
             # raw conv for the batch statistics (ref 843-855); the statistics stay in the autograd graph
             output = ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
@@ -678,9 +709,39 @@ def _fuse_residual_tails(model):
             m.__class__ = derive_class("AddReLU", _ResidualAddReLUMixin, t)
 
 
+class ReLUAfterFusedConv(nn.ReLU):
+    """The ``nn.ReLU`` of a ``ConvBNReLU`` block whose conv is a BN-fused ``QuantBNFuseConv2d``: when the conv's kernel already rectified its output (the tensor
+    says so) this is the identity -- relu is idempotent, same function -- else the ordinary ReLU.  Same module object, name and ``isinstance`` as before."""
+
+    def forward(self, input):
+        if getattr(input, "_mn_relu_done", False):
+            return input
+        return super().forward(input)
+
+
+def _fuse_bnfuse_blocks(model):
+    """``prepare(bn_fuse=True, fuse_blocks=True)``: in every block KNOWN to run shuffle -> conv -> bn -> relu (the reference's ``ConvBNReLU``, models/nin_gc.py:18-59,
+    or a block that declares ``_mn_ordered_forward``) whose conv became a ``QuantBNFuseConv2d`` and whose bn became ``nn.Identity``: the block's ReLU moves into the
+    conv's epilogue (``relu_fused``), the channel shuffle into the conv's addressing (``in_shuffle_groups``).  Same objects, parameters, buffers, ``state_dict``."""
+    from micronet_amd.quantization.wqaq.dorefa.quantize import _is_ref_block
+    for blk in model.modules():
+        if not _is_ref_block(blk):
+            continue
+        conv, bn, relu = getattr(blk, "conv", None), getattr(blk, "bn", None), getattr(blk, "relu", None)
+        if not (type(conv) is QuantBNFuseConv2d and type(bn) is nn.Identity):
+            continue
+        if type(relu) is nn.ReLU:
+            relu.__class__ = ReLUAfterFusedConv
+            conv.relu_fused = True
+        if getattr(blk, "channel_shuffle_flag", 0) and getattr(blk, "shuffle_groups", 1) > 1 and conv.in_channels % blk.shuffle_groups == 0:
+            conv.in_shuffle_groups = int(blk.shuffle_groups)
+            blk.channel_shuffle_flag = 0
+
+
 def prepare(model, inplace=False, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=False,
-            bn_fuse_calib=False, quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999, fuse_bn_act=True):
-    """Same rewrite as the reference (ref 1791-1830).  ``fuse_bn_act`` (ours, default on): see add_quant_op; off = exactly the reference's module classes."""
+            bn_fuse_calib=False, quant_inference=False, pretrained_model=False, qaft=False, ptq=False, percentile=0.9999, fuse_bn_act=True, fuse_blocks=True):
+    """Same rewrite as the reference (ref 1791-1830).  ``fuse_bn_act`` (ours, default on): see add_quant_op; off = exactly the reference's module classes.
+    ``fuse_blocks`` (ours, default on, only with ``bn_fuse``): see ``_fuse_bnfuse_blocks``."""
     if not inplace:
         model = copy.deepcopy(model)
     add_quant_op(model, a_bits=a_bits, w_bits=w_bits, q_type=q_type, q_level=q_level, weight_observer=weight_observer,
@@ -688,4 +749,6 @@ def prepare(model, inplace=False, a_bits=8, w_bits=8, q_type=0, q_level=0, weigh
                  pretrained_model=pretrained_model, qaft=qaft, ptq=ptq, percentile=percentile, fuse_bn_act=fuse_bn_act)
     if fuse_bn_act:
         _fuse_residual_tails(model)
+    if bn_fuse and fuse_blocks:
+        _fuse_bnfuse_blocks(model)
     return model

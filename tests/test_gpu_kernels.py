@@ -642,3 +642,17 @@ def test_global_avgpool(be):
 @pytest.mark.parametrize("w_bits,iao", [(2, False), (8, False), (4, True)])
 def test_qd_pack_multi_tables(be, w_bits, iao):
     K.check_qd_pack_multi(be, w_bits=w_bits, iao=iao, seed=w_bits)
+
+
+# ---- the BN-fused IAO block without the statistics convolution (iao_bnfuse.hip)
+@pytest.mark.parametrize("case", range(4))
+def test_iaobf_pointwise(be, case):
+    import iaobf_cases as B
+    B.check_iaobf_pointwise(be, B.CASES[case], seed=case)
+
+
+def test_iaobf_pointwise_nin_gc_layer(be):
+    """the 256 -> 256, groups 2, shuffle 2 layer of nin_gc (models/nin_gc.py:78-87) at 16 images of 32 x 32: full-size tiles, several slabs per block, all four
+    waves of the backward-data kernel busy"""
+    import iaobf_cases as B
+    B.check_iaobf_pointwise(be, dict(N=16, C=256, O=256, H=32, W=32, groups=2, shuffle=2, bias=True), seed=11, nsteps=1)
