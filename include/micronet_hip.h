@@ -149,6 +149,16 @@ int mn_iao_fq_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t H, i
                           mn_stream_t stream);
 int mn_iao_fq_avgpool_bwd(const float* g, const float* x, float* dx, int64_t planes, int64_t H, int64_t W, int64_t k, const float* qp, int bits,
                           int q_type, mn_stream_t stream);
+/* Fake-quant fused with the 2 x 2 / stride-2 max-pool behind it: QuantMaxPool2d.forward (1347-1359) = max_pool2d(Q(x), 2, 2).  x / dx: [planes][H][W] (even H,
+ * W % 8 == 0), y / gy / idx: [planes][H/2][W/2]; idx = the argmax of every window (0..3, ATen's tie / NaN rule); mm (nullable): 2 * mn_iao_fq_maxpool2x2_mm_count
+ * floats = per-block (min, max) of y for mn_iao_observe_partials (the observer of the layer that reads y).  Backward: pool scatter, then the quantizer's clip-STE
+ * (Round.backward 163-168), then -- relu_mask != 0, x being the output of a ReLU -- that ReLU's mask [x > 0]. */
+int mn_iao_fq_maxpool2x2_supported(int64_t H, int64_t W);
+int64_t mn_iao_fq_maxpool2x2_mm_count(int64_t planes, int64_t H, int64_t W);
+int mn_iao_fq_maxpool2x2_fwd(const float* x, int64_t planes, int64_t H, int64_t W, const float* qp, int bits, int q_type, float* y, uint8_t* idx, float* mm,
+                             mn_stream_t stream);
+int mn_iao_fq_maxpool2x2_bwd(const float* gy, const uint8_t* idx, const float* x, int64_t planes, int64_t H, int64_t W, const float* qp, int bits, int q_type,
+                             int relu_mask, float* dx, mn_stream_t stream);
 /* HistogramObserver.forward (116-139), the PTQ percentile calibrator: cur = k-th smallest |x| (k 1-based = int(percentile * n), exact --
  * a radix select on the bit patterns, bit-identical to torch.kthvalue); max_val = cur when first != 0 else (1 - momentum) * max_val +
  * momentum * cur, on the device.  out (nullable) receives cur.  ws: mn_kth_abs_ws_bytes() bytes, 4-byte aligned. */

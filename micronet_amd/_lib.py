@@ -173,6 +173,10 @@ PROTOTYPES = {
     "mn_conv2d_bwd_weight": (_I, [_G, _A, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mn_conv2d_fwd_act_mm_count": (_L, [_G, _A, _W]),
     "mn_conv2d_fwd_act": (_I, [_G, _A, _W, _P, _P, _P, _P, _I, _P, _P, _L, _P]),
+    "mn_iao_fq_maxpool2x2_supported": (_I, [_L, _L]),
+    "mn_iao_fq_maxpool2x2_mm_count": (_L, [_L, _L, _L]),
+    "mn_iao_fq_maxpool2x2_fwd": (_I, [_P, _L, _L, _L, _P, _I, _I, _P, _P, _P, _P]),
+    "mn_iao_fq_maxpool2x2_bwd": (_I, [_P, _P, _P, _L, _L, _L, _P, _I, _I, _I, _P, _P]),
     "mn_iaobf_gram_supported": (_I, [_G]),
     "mn_iaobf_gram_ws_bytes": (_L, [_G]),
     "mn_iaobf_gram": (_I, [_G, _P, _P, _P, _P, _L, _P]),

@@ -301,3 +301,120 @@ extern "C" int mn_iao_bnfold_bwd(const float* dwf, const float* dbf, const float
     MN_CHECK_LAUNCH("mn_iao_bnfold_bwd");
     return MN_OK;
 }
+
+// ---------------------------------------------------------------- QuantMaxPool2d(2, 2) in one pass per direction (wqaq/iao/quantize.py:1347-1359: max_pool2d(Q(x)))
+// forward: y = the 2 x 2 / stride-2 maximum of the fake-quantised input with ATen's window rule (row-major, a later element replaces the maximum if it is greater
+// or NaN), the argmax of every window as one byte, and -- mm != NULL -- per-block (min, max) of y for the observer of the layer that reads it.  Q(x) is never
+// written.  backward: the pooled gradient goes to the window's argmax, through the quantizer's clip-STE (Round.backward 163-168 + the clamp of 232), and
+// -- relu_mask != 0: x is the output of a ReLU -- through that ReLU's mask [x > 0]: one read of (gy, idx, x), one write of dx.
+// Thread = 4 consecutive windows of one output row.
+__global__ __launch_bounds__(256) void k_iao_fq_pool2_fwd(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int64_t nq, int H, int W,
+                                                          const float* __restrict__ qp, float qmin, float qmax, float* __restrict__ mm) {
+    __shared__ float scf[16];
+    const float sc = qp[0], zp = qp[1];
+    const int Wo = W >> 1, Ho = H >> 1, q4 = Wo >> 2;
+    float mlo = INFINITY, mhi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / q4;
+        const int qc = (int)(i - row * q4);
+        const int64_t pl = row / Ho;
+        const int orow = (int)(row - pl * Ho);
+        const float* src = x + (pl * H + 2 * orow) * W + qc * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(src + W), b1 = *reinterpret_cast<const float4*>(src + W + 4);
+        const float r0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, r1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[4];
+        uint32_t ib = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float v[4] = {iao_fq(r0[2 * w], sc, zp, qmin, qmax), iao_fq(r0[2 * w + 1], sc, zp, qmin, qmax), iao_fq(r1[2 * w], sc, zp, qmin, qmax),
+                                iao_fq(r1[2 * w + 1], sc, zp, qmin, qmax)};
+            float m = -INFINITY;
+            uint32_t k = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] > m || v[e] != v[e]) { m = v[e]; k = (uint32_t)e; }
+            o[w] = m; ib |= k << (8 * w);
+            mlo = OpMinF()(mlo, m); mhi = OpMaxF()(mhi, m);
+        }
+        const int64_t oo = (pl * Ho + orow) * Wo + qc * 4;
+        *reinterpret_cast<float4*>(y + oo) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint32_t*>(idx + oo) = ib;
+    }
+    if (mm) {
+        mlo = block_reduce(mlo, OpMinF(), INFINITY, scf);
+        mhi = block_reduce(mhi, OpMaxF(), -INFINITY, scf);
+        if (threadIdx.x == 0) { mm[blockIdx.x] = mlo; mm[gridDim.x + blockIdx.x] = mhi; }
+    }
+}
+__global__ __launch_bounds__(256) void k_iao_fq_pool2_bwd(const float* __restrict__ gy, const unsigned char* __restrict__ idx, const float* __restrict__ x,
+                                                          float* __restrict__ dx, int64_t nq, int H, int W, const float* __restrict__ qp, float qmin, float qmax,
+                                                          int relu_mask) {
+    const float sc = qp[0], zp = qp[1], lo = qp[2], hi = qp[3];
+    const int Wo = W >> 1, Ho = H >> 1, q4 = Wo >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / q4;
+        const int qc = (int)(i - row * q4);
+        const int64_t pl = row / Ho;
+        const int orow = (int)(row - pl * Ho);
+        const int64_t oo = (pl * Ho + orow) * Wo + qc * 4;
+        const float4 g4 = *reinterpret_cast<const float4*>(gy + oo);
+        const uint32_t ib = *reinterpret_cast<const uint32_t*>(idx + oo);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int64_t so = (pl * H + 2 * orow) * W + qc * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(x + so), a1 = *reinterpret_cast<const float4*>(x + so + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(x + so + W), b1 = *reinterpret_cast<const float4*>(x + so + W + 4);
+        const float x0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, x1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float r0[8], r1[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t k = (ib >> (8 * w)) & 3u;
+            r0[2 * w] = k == 0u ? g[w] : 0.f; r0[2 * w + 1] = k == 1u ? g[w] : 0.f;
+            r1[2 * w] = k == 2u ? g[w] : 0.f; r1[2 * w + 1] = k == 3u ? g[w] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            r0[e] = iao_fq_grad(r0[e], x0[e], sc, zp, lo, hi, qmin, qmax);
+            r1[e] = iao_fq_grad(r1[e], x1[e], sc, zp, lo, hi, qmin, qmax);
+            if (relu_mask) { r0[e] = x0[e] > 0.f ? r0[e] : 0.f; r1[e] = x1[e] > 0.f ? r1[e] : 0.f; }
+        }
+        float* dst = dx + so;
+        *reinterpret_cast<float4*>(dst) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(r0[4], r0[5], r0[6], r0[7]);
+        *reinterpret_cast<float4*>(dst + W) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+        *reinterpret_cast<float4*>(dst + W + 4) = make_float4(r1[4], r1[5], r1[6], r1[7]);
+    }
+}
+static int fq_pool_grid(int64_t planes, int64_t H, int64_t W) { return mn_grid_for(planes * (H / 2) * (W / 8), 256, 4096); }
+extern "C" int mn_iao_fq_maxpool2x2_supported(int64_t H, int64_t W) { return H >= 2 && H % 2 == 0 && W >= 8 && W % 8 == 0; }
+extern "C" int64_t mn_iao_fq_maxpool2x2_mm_count(int64_t planes, int64_t H, int64_t W) {
+    return (planes > 0 && mn_iao_fq_maxpool2x2_supported(H, W)) ? fq_pool_grid(planes, H, W) : 0;
+}
+extern "C" int mn_iao_fq_maxpool2x2_fwd(const float* x, int64_t planes, int64_t H, int64_t W, const float* qp, int bits, int q_type, float* y, uint8_t* idx, float* mm,
+                                        mn_stream_t stream) {
+    if (!x || !y || !idx || !qp || planes <= 0 || bits < 2 || bits > 24 || (q_type != 0 && q_type != 1) || !mn_iao_fq_maxpool2x2_supported(H, W) || !aligned16(x) ||
+        !aligned16(y) || (((uintptr_t)idx) & 3))
+        MN_FAIL(MN_EINVAL, "mn_iao_fq_maxpool2x2_fwd: needs even H, W %% 8 == 0, aligned tensors, 2..24 bits");
+    const IaoRange r = iao_range(bits, q_type, 1);
+    const int64_t nq = planes * (H / 2) * (W / 8);
+    mn_set_last_kernel("k_iao_fq_pool2_fwd"); mn_prof_bytes(5.25 * (double)planes * H * W); mn_prof_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(k_iao_fq_pool2_fwd, dim3(fq_pool_grid(planes, H, W)), dim3(256), 0, (hipStream_t)stream, x, y, (unsigned char*)idx, nq, (int)H, (int)W, qp, r.qmin,
+                       r.qmax, mm);
+    mn_prof_end((hipStream_t)stream);
+    MN_CHECK_LAUNCH("mn_iao_fq_maxpool2x2_fwd");
+    return MN_OK;
+}
+extern "C" int mn_iao_fq_maxpool2x2_bwd(const float* gy, const uint8_t* idx, const float* x, int64_t planes, int64_t H, int64_t W, const float* qp, int bits, int q_type,
+                                        int relu_mask, float* dx, mn_stream_t stream) {
+    if (!gy || !dx || !idx || !x || !qp || planes <= 0 || bits < 2 || bits > 24 || (q_type != 0 && q_type != 1) || !mn_iao_fq_maxpool2x2_supported(H, W) ||
+        !aligned16(gy) || !aligned16(dx) || !aligned16(x) || (((uintptr_t)idx) & 3))
+        MN_FAIL(MN_EINVAL, "mn_iao_fq_maxpool2x2_bwd: needs even H, W %% 8 == 0, aligned tensors, 2..24 bits");
+    const IaoRange r = iao_range(bits, q_type, 1);
+    const int64_t nq = planes * (H / 2) * (W / 8);
+    mn_set_last_kernel("k_iao_fq_pool2_bwd"); mn_prof_bytes(9.25 * (double)planes * H * W); mn_prof_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(k_iao_fq_pool2_bwd, dim3(fq_pool_grid(planes, H, W)), dim3(256), 0, (hipStream_t)stream, gy, (const unsigned char*)idx, x, dx, nq, (int)H, (int)W, qp,
+                       r.qmin, r.qmax, relu_mask);
+    mn_prof_end((hipStream_t)stream);
+    MN_CHECK_LAUNCH("mn_iao_fq_maxpool2x2_bwd");
+    return MN_OK;
+}

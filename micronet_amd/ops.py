@@ -695,6 +695,53 @@ def relu_mask(g, a):
     return torch.where(a > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))
 
 
+def iao_fq_maxpool_supported(x, kernel_size, stride, padding, dilation, ceil_mode):
+    two = lambda v: v in (2, (2, 2), [2, 2])
+    return (torch.is_tensor(x) and type(x) is torch.Tensor and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() > 0
+            and two(kernel_size) and two(stride if stride is not None else kernel_size) and padding in (0, (0, 0)) and dilation in (1, (1, 1)) and not ceil_mode
+            and bool(_lib_().mn_iao_fq_maxpool2x2_supported(x.shape[2], x.shape[3])))
+
+
+class IaoFakeQuantMaxPool2x2(Function):
+    """max_pool2d(Q(x), 2, 2) (QuantMaxPool2d, wqaq/iao/quantize.py:1347-1359) in one pass per direction: Q(x) is never written, the backward applies pool scatter,
+    the quantizer's clip-STE and -- when x is the output of a fused conv + ReLU block -- that ReLU's mask in the same pass (``ReluToken``).  ``st``: the module
+    (receives the (min, max) partials of the output for the next layer's observer)."""
+
+    @staticmethod
+    def forward(ctx, x, qp, bits, q_type, want_mm, st):
+        x = _chk(x, "input")
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.uint8, device=x.device)
+        mm, count = None, 0
+        with torch.cuda.device_of(x):
+            if want_mm:
+                count = int(_lib_().mn_iao_fq_maxpool2x2_mm_count(N * Cc, H, W))
+                mm = torch.empty(2 * count, dtype=torch.float32, device=x.device)
+            _call("mn_iao_fq_maxpool2x2_fwd", _p(x), N * Cc, H, W, _p(qp), bits, q_type, _p(y), _p(idx), _p(mm), _s())
+        ctx.save_for_backward(x, qp, idx)
+        ctx.cfg = (bits, q_type)
+        ctx.tok_in = getattr(x, "_mn_relu_token", None)
+        ctx.x_obj = x
+        st.__dict__["_mn_fwd_out"] = (mm, count) if want_mm else None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, qp, idx = ctx.saved_tensors
+        bits, q_type = ctx.cfg
+        g = _chk(g, "grad")
+        N, Cc, H, W = x.shape
+        dx = torch.empty_like(x)
+        pre = ctx.tok_in is not None and relu_premask_ok(ctx.x_obj)
+        with torch.cuda.device_of(x):
+            _call("mn_iao_fq_maxpool2x2_bwd", _p(g), _p(idx), _p(x), N * Cc, H, W, _p(qp), bits, q_type, int(pre), _p(dx), _s())
+        if pre:
+            ctx.tok_in.dx = dx
+        ctx.x_obj = None
+        return dx, None, None, None, None, None
+
+
 def hist_observe(x, percentile, first, momentum, max_val):
     """HistogramObserver.forward (ref 126-139) on the device: exact k-th smallest |x| + first-call / EMA update of ``max_val``."""
     x = _chk(x.detach(), "input")

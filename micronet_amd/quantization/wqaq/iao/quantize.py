@@ -497,8 +497,22 @@ class QuantMaxPool2d(nn.MaxPool2d):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
 
     def forward(self, input):
-        q = self.activation_quantizer(input)
-        from micronet_amd import ops
+        aq = self.activation_quantizer
+        if (_FUSE_BNFUSE and not self.return_indices and aq.bits != 32 and 2 <= aq.bits <= 24 and isinstance(aq.observer, (ObserverBase, HistogramObserver))
+                and getattr(aq.observer, "q_level", "L") == "L" and ops.iao_fq_maxpool_supported(input, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode)):
+            # quantizer + 2 x 2 max-pool in one pass (and one in backward); leaves (min, max) partials of its output for the next layer's observer
+            qp = aq.qparams(input)
+            aq._last_qp = qp
+            if qp is not None and qp.shape[0] == 1:
+                want_mm = self.training and _PRODUCER_MINMAX
+                out = ops.IaoFakeQuantMaxPool2x2.apply(input, qp, aq.bits, aq.q_type, want_mm, self)
+                mm = self.__dict__.pop("_mn_fwd_out", None)
+                if mm is not None:
+                    out._mn_minmax = mm + (out._version,)
+                return out
+            q = input if qp is None else ops.IaoFakeQuant.apply(input, qp, aq.bits, aq.q_type, True)
+        else:
+            q = aq(input)
         if not self.return_indices and ops.f32_pool_supported(q, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode):
             return ops.MaxPool2x2F32.apply(q)        # 2x2 / stride 2: byte argmax, scatter backward (same values and gradient routing as ATen)
         return F.max_pool2d(q, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode, self.return_indices)

@@ -162,3 +162,39 @@ def check_iaobf_pointwise(be, case, seed=0, nsteps=2, relu_mask=True):
         worst["dx%d" % it] = _close("dx", be.to_host(dx), r32[it]["dx"] * mask, r64[it]["dx"] * mask.double())
         # next step: updated parameters would come from the optimizer; the test keeps them (the oracle does too)
     return worst
+
+
+def check_fq_maxpool(be, shape=(2, 6, 8, 16), bits=8, q_type=0, seed=0, relu_mask=False):
+    """mn_iao_fq_maxpool2x2_fwd / _bwd against the oracle's QuantMaxPool2d (OQuantWrap(nn.MaxPool2d(2, 2)) = wqaq/iao/quantize.py:1347-1359), first training step
+    (the observer takes its range from this tensor): values, gradient routing (ATen's first maximum) and the clip-STE bit for bit; ties are frequent (a coarse grid)."""
+    lib = be.lib
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=gen) * 2.0
+    if relu_mask:
+        x = torch.relu(x)
+    x[0, 0, 0, :4] = torch.tensor([0.5, 0.5, 0.5, 0.5])            # an exact tie inside a window
+    N, Cc, H, W = shape
+    g = torch.randn(N, Cc, H // 2, W // 2, generator=gen)
+    m = TO.OQuantWrap(nn.MaxPool2d(2, 2, 0), bits, q_type).train()
+    xr = x.clone().requires_grad_(True)
+    y_ref = m(xr)
+    y_ref.backward(g)
+    dx_ref = xr.grad * ((x > 0).float() if relu_mask else 1.0)
+    xd = be.to_dev(x.numpy())
+    amin, amax, ascale, azp = be.to_dev(np.zeros(1)), be.to_dev(np.zeros(1)), be.to_dev(np.ones(1)), be.to_dev(np.zeros(1))
+    ows = be.empty(int(lib.mn_iao_observe_ws_floats(1, x.numel())) + 4)
+    be.call("mn_iao_observe", be.ptr(xd), 1, x.numel(), 1, 1, 0.1, be.ptr(amin), be.ptr(amax), be.ptr(ows), be.stream)
+    qp = be.empty(4)
+    be.call("mn_iao_qparams", be.ptr(amin), be.ptr(amax), 1, bits, q_type, 1, 1, be.ptr(ascale), be.ptr(azp), be.ptr(qp), be.stream)
+    assert lib.mn_iao_fq_maxpool2x2_supported(H, W) == 1
+    cnt = int(lib.mn_iao_fq_maxpool2x2_mm_count(N * Cc, H, W))
+    y, idx, mm = be.empty((N, Cc, H // 2, W // 2)), be.to_dev_u8(np.zeros((N, Cc, H // 2, W // 2))), be.empty(2 * cnt)
+    be.call("mn_iao_fq_maxpool2x2_fwd", be.ptr(xd), N * Cc, H, W, be.ptr(qp), bits, q_type, be.ptr(y), be.ptr(idx), be.ptr(mm), be.stream)
+    y_h = be.to_host(y)
+    assert np.array_equal(y_h, y_ref.detach().numpy())
+    mm_h = be.to_host(mm)
+    assert mm_h[:cnt].min() == y_h.min() and mm_h[cnt:].max() == y_h.max()
+    dx = be.empty(shape)
+    gd = be.to_dev(g.numpy())
+    be.call("mn_iao_fq_maxpool2x2_bwd", be.ptr(gd), be.ptr(idx), be.ptr(xd), N * Cc, H, W, be.ptr(qp), bits, q_type, int(relu_mask), be.ptr(dx), be.stream)
+    assert np.array_equal(be.to_host(dx), dx_ref.numpy())

@@ -656,3 +656,10 @@ def test_iaobf_pointwise_nin_gc_layer(be):
     waves of the backward-data kernel busy"""
     import iaobf_cases as B
     B.check_iaobf_pointwise(be, dict(N=16, C=256, O=256, H=32, W=32, groups=2, shuffle=2, bias=True), seed=11, nsteps=1)
+
+
+@pytest.mark.parametrize("bits,q_type,relu_mask", [(8, 0, False), (4, 1, False), (8, 0, True)])
+def test_iao_fq_maxpool(be, bits, q_type, relu_mask):
+    import iaobf_cases as B
+    B.check_fq_maxpool(be, bits=bits, q_type=q_type, relu_mask=relu_mask, seed=bits + q_type)
+    B.check_fq_maxpool(be, shape=(8, 64, 32, 32), bits=bits, q_type=q_type, relu_mask=relu_mask, seed=100 + bits)

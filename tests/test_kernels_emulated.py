@@ -449,3 +449,9 @@ def test_iaobf_pointwise(be, case):
     backward-data with the raw path folded in, two training steps, against the oracle's QuantBNFuseConv2d + ReLU in fp32 and fp64."""
     import iaobf_cases as B
     B.check_iaobf_pointwise(be, B.CASES[case], seed=case)
+
+
+@pytest.mark.parametrize("bits,q_type,relu_mask", [(8, 0, False), (4, 1, False), (8, 0, True)])
+def test_iao_fq_maxpool(be, bits, q_type, relu_mask):
+    import iaobf_cases as B
+    B.check_fq_maxpool(be, bits=bits, q_type=q_type, relu_mask=relu_mask, seed=bits + q_type)
