@@ -159,6 +159,12 @@ int mn_iao_fq_maxpool2x2_fwd(const float* x, int64_t planes, int64_t H, int64_t 
                              mn_stream_t stream);
 int mn_iao_fq_maxpool2x2_bwd(const float* gy, const uint8_t* idx, const float* x, int64_t planes, int64_t H, int64_t W, const float* qp, int bits, int q_type,
                              int relu_mask, float* dx, mn_stream_t stream);
+/* Streaming helpers of the BN-fused blocks (n % 4 == 0, 16-byte aligned): mn_add_relu_mask: out = (a [+ b]) * [x > 0] (b, x nullable) -- the sum of
+ * QuantBNFuseConv2d's two input gradients (quantised path 947-955, statistics path 843-855) with the ReLU mask of the block in front, or a ReLU backward alone;
+ * mn_relu_mm: y = relu(x) (in place allowed) + per-block (min, max) of y in mm (nullable, 2 * mn_relu_mm_count(n) floats) for mn_iao_observe_partials. */
+int mn_add_relu_mask(const float* a, const float* b, const float* x, float* out, int64_t n, mn_stream_t stream);
+int64_t mn_relu_mm_count(int64_t n);
+int mn_relu_mm(const float* x, float* y, int64_t n, float* mm, mn_stream_t stream);
 /* HistogramObserver.forward (116-139), the PTQ percentile calibrator: cur = k-th smallest |x| (k 1-based = int(percentile * n), exact --
  * a radix select on the bit patterns, bit-identical to torch.kthvalue); max_val = cur when first != 0 else (1 - momentum) * max_val +
  * momentum * cur, on the device.  out (nullable) receives cur.  ws: mn_kth_abs_ws_bytes() bytes, 4-byte aligned. */
@@ -540,7 +546,7 @@ int mn_iao_bnfold_bwd(const float* dwf, const float* dbf, const float* w, const 
  *                      (881-901), the per-channel weight observer + update_qparams + fake-quant (945 with 15-36 / 62-74 / 101-113, 293-321, 227-239).
  *                      Outputs: stats [2][O] = mean, var; kfold [O]; bias_f [O]; qw [O][K] = the fake-quantised folded weights; qp [O][4].
  *   mn_iaobf_prep_bwd  ONE launch for: the weight quantizer's clip-STE on dwq (gradient w.r.t. qw), the fold's backward (dgamma, dbeta, dbias), dmean / dvar and
- *                      coef [3][O] = {dmean / n, 2 dvar / (n - 1), dmean}; with gram != NULL also the raw convolution's weight gradient, so that dw is complete;
+ *                      coef [4][O] = {dmean / n, 2 dvar / (n - 1), dmean, dvar}; with gram != NULL also the raw convolution's weight gradient, so that dw is complete;
  *                      with gram == NULL dw holds the quantised path only and the caller adds the raw conv's backward-weight of d y_raw = coef0 + coef1 (y - mean).
  *   mn_iaobf_bwd_data  dx = STE_x(W_q^T gy) + W^T d y_raw, the second term evaluated as M (x - x_bar) + v with M = W^T diag(coef1) W inside the same kernel
  *                      (no raw convolution output exists); relu_mask != 0: x is the output of a ReLU whose backward mask [x > 0] is applied to dx here.

@@ -177,6 +177,9 @@ PROTOTYPES = {
     "mn_iao_fq_maxpool2x2_mm_count": (_L, [_L, _L, _L]),
     "mn_iao_fq_maxpool2x2_fwd": (_I, [_P, _L, _L, _L, _P, _I, _I, _P, _P, _P, _P]),
     "mn_iao_fq_maxpool2x2_bwd": (_I, [_P, _P, _P, _L, _L, _L, _P, _I, _I, _I, _P, _P]),
+    "mn_add_relu_mask": (_I, [_P, _P, _P, _P, _L, _P]),
+    "mn_relu_mm_count": (_L, [_L]),
+    "mn_relu_mm": (_I, [_P, _P, _L, _P, _P]),
     "mn_iaobf_gram_supported": (_I, [_G]),
     "mn_iaobf_gram_ws_bytes": (_L, [_G]),
     "mn_iaobf_gram": (_I, [_G, _P, _P, _P, _P, _L, _P]),

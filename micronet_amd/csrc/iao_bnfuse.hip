@@ -332,7 +332,7 @@ extern "C" int mn_iaobf_prep_fwd(const float* w, const float* bias, const float*
 struct PrepBwd {
     const float* dwq; const float* dbf; const float* w; const float* bias; const float* gamma; const float* stats; const float* qp;
     const double* gram; const double* sx;
-    float* dw; float* dbias; float* dgamma; float* dbeta; float* coef;       // coef [3][O] = {dmean / n, B = 2 dvar / (n - 1), dmean}
+    float* dw; float* dbias; float* dgamma; float* dbeta; float* coef;       // coef [4][O] = {dmean / n, B = 2 dvar / (n - 1), dmean, dvar}
     int O, K, Mg, Cg;
     float eps, qmin, qmax;
     double n;
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void k_bf_prep_bwd(const PrepBwd p) {
         p.coef[o] = dmean / nf;
         p.coef[p.O + o] = dvar * 2.f / (nf - 1.f);
         p.coef[2 * p.O + o] = dmean;
+        p.coef[3 * p.O + o] = dvar;
         shd[0] = (double)dmean; shd[1] = (double)(dvar * 2.f / (nf - 1.f));
     }
     if (!p.gram) return;

@@ -418,3 +418,53 @@ extern "C" int mn_iao_fq_maxpool2x2_bwd(const float* gy, const uint8_t* idx, con
     MN_CHECK_LAUNCH("mn_iao_fq_maxpool2x2_bwd");
     return MN_OK;
 }
+
+// ---------------------------------------------------------------- small streaming helpers of the BN-fused blocks
+// out = (a [+ b]) * [x > 0] (x == NULL: no mask): the sum of the two input gradients of QuantBNFuseConv2d (quantised path + raw statistics path) with the ReLU mask of
+// the block in front, or the ReLU backward alone -- one pass instead of ATen's add / gt / where kernels.  n % 4 == 0, 16-byte aligned.
+__global__ __launch_bounds__(256) void k_add_mask(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ x, float* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(a)[i];
+        if (b) { const float4 w = reinterpret_cast<const float4*>(b)[i]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        if (x) {
+            const float4 m = reinterpret_cast<const float4*>(x)[i];
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+extern "C" int mn_add_relu_mask(const float* a, const float* b, const float* x, float* out, int64_t n, mn_stream_t stream) {
+    if (!a || !out || n <= 0 || n % 4 || !aligned16(a) || !aligned16(out) || (b && !aligned16(b)) || (x && !aligned16(x)))
+        MN_FAIL(MN_EINVAL, "mn_add_relu_mask: needs n %% 4 == 0 and 16-byte aligned tensors");
+    mn_set_last_kernel("k_add_mask");
+    hipLaunchKernelGGL(k_add_mask, dim3(mn_grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, x, out, n / 4);
+    MN_CHECK_LAUNCH("mn_add_relu_mask");
+    return MN_OK;
+}
+// y = relu(x) in place or out of place with per-block (min, max) of the result (mm nullable: 2 * mn_relu_mm_count(n) floats): the ReLU behind a BN-fused conv whose
+// kernel has no ReLU epilogue, feeding the next layer's observer
+static int relu_mm_grid(int64_t n) { return mn_grid_for(n / 4, 256, 2048); }
+__global__ __launch_bounds__(256) void k_relu_mm(const float* __restrict__ x, float* __restrict__ y, int64_t n4, float* __restrict__ mm) {
+    __shared__ float scf[16];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = qa_relu(v.x); v.y = qa_relu(v.y); v.z = qa_relu(v.z); v.w = qa_relu(v.w);
+        lo = OpMinF()(OpMinF()(lo, v.x), OpMinF()(OpMinF()(v.y, v.z), v.w));
+        hi = OpMaxF()(OpMaxF()(hi, v.x), OpMaxF()(OpMaxF()(v.y, v.z), v.w));
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    if (mm) {
+        lo = block_reduce(lo, OpMinF(), INFINITY, scf);
+        hi = block_reduce(hi, OpMaxF(), -INFINITY, scf);
+        if (threadIdx.x == 0) { mm[blockIdx.x] = lo; mm[gridDim.x + blockIdx.x] = hi; }
+    }
+}
+extern "C" int64_t mn_relu_mm_count(int64_t n) { return (n > 0 && n % 4 == 0) ? relu_mm_grid(n) : 0; }
+extern "C" int mn_relu_mm(const float* x, float* y, int64_t n, float* mm, mn_stream_t stream) {
+    if (!x || !y || n <= 0 || n % 4 || !aligned16(x) || !aligned16(y)) MN_FAIL(MN_EINVAL, "mn_relu_mm: needs n %% 4 == 0 and 16-byte aligned tensors");
+    mn_set_last_kernel("k_relu_mm");
+    hipLaunchKernelGGL(k_relu_mm, dim3(relu_mm_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4, mm);
+    MN_CHECK_LAUNCH("mn_relu_mm");
+    return MN_OK;
+}

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
     }
     const int cb = idx % p.CB, g = idx / p.CB;
     float mlo = INFINITY, mhi = -INFINITY;
+    int mnan = 0;
 
     {   // stage weight codes, scales, bias
         const uint16_t* wg = p.wc + ((int64_t)g * p.Mpad + mblk * MB) * p.Kp;
@@ -271,9 +272,10 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
                                 const float a_ = rs[ml], b_ = bs[ml];
                                 o0 = o0 * a_ + b_; o1 = o1 * a_ + b_; o2 = o2 * a_ + b_; o3 = o3 * a_ + b_;
                                 if (p.relu) { o0 = qa_relu(o0); o1 = qa_relu(o1); o2 = qa_relu(o2); o3 = qa_relu(o3); }
-                                if (p.mm) {
-                                    mlo = OpMinF()(OpMinF()(mlo, o0), OpMinF()(OpMinF()(o1, o2), o3));
-                                    mhi = OpMaxF()(OpMaxF()(mhi, o0), OpMaxF()(OpMaxF()(o1, o2), o3));
+                                if (p.mm) {          // plain min / max (NaN-ignoring, 8 instructions) + a NaN flag: torch.min / max propagate a NaN
+                                    mlo = fminf(mlo, fminf(fminf(o0, o1), fminf(o2, o3)));
+                                    mhi = fmaxf(mhi, fmaxf(fmaxf(o0, o1), fmaxf(o2, o3)));
+                                    mnan |= (int)((o0 != o0) | (o1 != o1) | (o2 != o2) | (o3 != o3));
                                 }
                             } else if (p.epi == QG_EPI_STE) {
                                 const float4 xv = *reinterpret_cast<const float4*>(p.aux + off);
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
     if (total > 0) issue(ra, 0);
     for (int it = 0; it < total; ++it) compute(ra, it);
     if (p.mm) {
+        if (mnan) mlo = mhi = NAN;
         mlo = wave_reduce(mlo, OpMinF());
         mhi = wave_reduce(mhi, OpMaxF());
         if (lane == 0) { p.mm[4 * blockIdx.x + wave] = mlo; p.mm[4 * gridDim.x + 4 * blockIdx.x + wave] = mhi; }

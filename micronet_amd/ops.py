@@ -23,7 +23,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import ActQ, ConvGeom, MicronetHipError, WQ
-from .sign_tensor import LazyBNGrad, LazyConvOut, LazyPoolGrad, LazyQConvOut, QActTensor, QGrad, SignTensor
+from .sign_tensor import LazyBNGrad, LazyConvOut, LazyPoolGrad, LazyQConvOut, LazyReluConvOut, LazyReluGrad, QActTensor, QGrad, SignTensor
 
 ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO, ACTQ_SIGN8, ACTQ_CODE8 = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO, _lib.MN_ACTQ_SIGN8, _lib.MN_ACTQ_CODE8
 WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _lib.MN_WQ_DOREFA, _lib.MN_WQ_IAO
@@ -75,7 +75,7 @@ def _lib_():
 def _chk(t, name="tensor"):
     if t is None:
         return None
-    if isinstance(t, (LazyBNGrad, LazyPoolGrad, LazyConvOut, LazyQConvOut, QActTensor, QGrad)):      # a lazy tensor reaching a kernel that wants plain memory
+    if isinstance(t, (LazyBNGrad, LazyPoolGrad, LazyConvOut, LazyQConvOut, LazyReluConvOut, LazyReluGrad, QActTensor, QGrad)):      # a lazy tensor reaching a kernel that wants plain memory
         t = t.materialize()
     elif isinstance(t, SignTensor):
         t = t.to_float()
@@ -638,6 +638,7 @@ class IaoBNFusePW(Function):
                 wobs.num_flag += 1
             wq_.q_type = wq_._q_type_static
             wq_._last_qp = wqp
+            st.__dict__["_mn_last_qw"] = qw          # (tests: the quantised folded weights of this forward)
             aq = ActQ(ACTQ_IAO, aq_.bits, aq_.q_type, 0, aqp.data_ptr())
             wd = WQ(WQ_IAO, wq_.bits, 0, 4, wqp.data_ptr())
             a = torch.empty((N, O, H, W), dtype=torch.float32, device=dev)
@@ -651,9 +652,18 @@ class IaoBNFusePW(Function):
         ctx.cfg = (g, aq_.bits, aq_.q_type, wq_.bits, wq_._q_type_static, float(st.eps), n, bool(relu))
         ctx.tok_in = getattr(x, "_mn_relu_token", None)          # the ReLU in FRONT of this block (its producer's token)
         ctx.x_obj = x
-        ctx.tok_out = ReluToken() if relu else None
-        st.__dict__["_mn_fwd_out"] = ((mm, count) if want_mm else None, ctx.tok_out)      # picked up (and cleared) by the module right after apply()
-        return a
+        if not relu:
+            return a
+
+        def compute():          # the un-rectified convolution output for a consumer other than the block's ReLU: the same kernel without the epilogue
+            out = torch.empty_like(a)
+            aq2 = ActQ(ACTQ_IAO, aq.bits, aq.q_type, 0, aqp.data_ptr())
+            wd2 = WQ(WQ_IAO, wd.bits, 0, 4, wqp.data_ptr())
+            with torch.cuda.device_of(x):
+                ws2, nb2 = _ws(g, 0, dev)
+                _call("mn_conv2d_fwd_act", C.byref(g), C.byref(aq2), C.byref(wd2), _p(x), _p(qw), _p(bias_f), _p(out), 0, None, _p(ws2), nb2, _s())
+            return out
+        return LazyReluConvOut(a, dict(compute=compute, mm=(mm, count) if want_mm else None))
 
     @staticmethod
     def backward(ctx, gin):
@@ -661,10 +671,10 @@ class IaoBNFusePW(Function):
         g, a_bits, a_qtype, w_bits, w_qtype, eps, n, relu = ctx.cfg
         lib = _lib_()
         dev = x.device
-        premasked = relu and ctx.tok_out.premasked(gin)
-        gy = _chk(gin, "grad")
-        if relu and not premasked:
-            gy = relu_mask(gy, a)
+        if relu and isinstance(gin, LazyReluGrad) and gin._mn_value is None:
+            gy = _chk(gin._mn_g, "grad") if gin._mn_premasked else relu_mask(_chk(gin._mn_g, "grad"), a)          # from the block's fused ReLU
+        else:
+            gy = _chk(gin, "grad")          # a gradient w.r.t. the un-rectified output (a foreign consumer of the conv module): nothing to mask
         O, Cg = weight.shape[0], weight.shape[1]
         aq = ActQ(ACTQ_IAO, a_bits, a_qtype, 0, aqp.data_ptr())
         dx = None
@@ -675,7 +685,7 @@ class IaoBNFusePW(Function):
             dw = torch.empty_like(weight)
             dbias = torch.empty(O, dtype=torch.float32, device=dev) if bias is not None else None
             dgamma, dbeta = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
-            coef = torch.empty((3, O), dtype=torch.float32, device=dev)
+            coef = torch.empty((4, O), dtype=torch.float32, device=dev)
             _call("mn_iaobf_prep_bwd", _p(dwq), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(stats), _p(wqp), O, Cg, g.groups, _p(gram), _p(sx), n, eps, w_bits, w_qtype,
                   _p(dw), _p(dbias), _p(dgamma), _p(dbeta), _p(coef), _s())
             if ctx.needs_input_grad[0]:
@@ -690,9 +700,200 @@ class IaoBNFusePW(Function):
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
+class ReluOfFusedConv(Function):
+    """The block's ``nn.ReLU`` behind a ``LazyReluConvOut``: forward takes the rectified tensor out of the wrapper (no kernel); backward hands the gradient back as a
+    ``LazyReluGrad`` -- already masked when the ONE consumer of the activation did it inside its backward-data kernel (``ReluToken``), else masked by the conv."""
+
+    @staticmethod
+    def forward(ctx, lazy):
+        a = lazy._mn_a
+        ctx.a = a
+        ctx.tok = ReluToken()
+        return a
+
+    @staticmethod
+    def backward(ctx, g):
+        a, tok = ctx.a, ctx.tok
+        ctx.a = None
+        return LazyReluGrad(g if type(g) is torch.Tensor else _chk(g, "grad"), a, tok.premasked(g))
+
+
+def relu_of_fused(lazy):
+    """``relu`` of a ``LazyReluConvOut``: the plain rectified tensor, tagged with the ReLU's token and the (min, max) partials the conv's epilogue left."""
+    if torch.is_grad_enabled() and lazy.requires_grad:
+        out = ReluOfFusedConv.apply(lazy)
+        out._mn_relu_token = out.grad_fn.tok if out.grad_fn is not None else None
+    else:
+        out = lazy._mn_a
+    mm = lazy._mn_recipe.get("mm")
+    if mm is not None:
+        out._mn_minmax = mm + (out._version,)
+    return out
+
+
 def relu_mask(g, a):
     """g * [a > 0]: the backward of a ReLU whose output is ``a`` (only on paths where no consumer pre-masked the gradient)."""
-    return torch.where(a > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))
+    return add_relu_mask(g, None, a)
+
+
+def add_relu_mask(a, b, x):
+    """(a [+ b]) * [x > 0] in one pass (``mn_add_relu_mask``); b / x may be None."""
+    if a.numel() % 4 == 0 and a.is_contiguous() and (b is None or b.is_contiguous()) and (x is None or x.is_contiguous()):
+        out = torch.empty_like(a)
+        with torch.cuda.device_of(a):
+            _call("mn_add_relu_mask", _p(a), _p(b), _p(x), _p(out), a.numel(), _s())
+        return out
+    out = a if b is None else a + b
+    return out if x is None else torch.where(x > 0, out, torch.zeros((), dtype=out.dtype, device=out.device))
+
+
+def iao_bnfuse_generic_supported(x, weight):
+    return (torch.is_tensor(x) and type(x) is torch.Tensor and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() > 0
+            and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous())
+
+
+class IaoBNFuseGeneric(Function):
+    """Training-mode ``QuantBNFuseConv2d.forward`` (wqaq/iao/quantize.py:837-994, not qaft, not bn_fuse_calib) for geometries the pointwise kernels do not cover
+    (k x k, > 128 channels per group): the reference's own dataflow -- raw convolution (843-851) -> batch statistics (853-855) -> fold + weight quantizer ->
+    quantised convolution (947-955) [-> the block's ReLU] -- as ONE autograd node: the bookkeeping between the convolutions is one launch per direction
+    (``mn_iaobf_prep_fwd`` / ``_bwd`` with the statistics given), the two input gradients are summed (and masked for the ReLU in front) in one pass, and the first
+    layer (an image with <= 76 taps per output: ``mn_conv2d_first_supported``) runs its quantised convolution and backward-weight on the exact-fp32 first-layer
+    kernels over the fake-quantised image.  The raw output y_raw is kept for the backward (d y_raw = dmean / n + 2 dvar (y_raw - mean) / (n - 1))."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, st, aqp, relu, want_mm):
+        lib = _lib_()
+        x, weight, gamma, beta = _chk(x, "input"), _chk(weight, "weight"), _chk(gamma, "gamma"), _chk(beta, "beta")
+        bias = _chk(bias, "bias")
+        wq_, aq_ = st.weight_quantizer, st.activation_quantizer
+        wobs = wq_.observer
+        g = _geom(x.shape, weight.shape, st.stride, st.padding, st.dilation, st.groups, 0)
+        O = g.O
+        K = weight[0].numel()
+        Ho, Wo = _out_hw(g)
+        dev = x.device
+        n = float(g.N * Ho * Wo)
+        none = ActQ(ACTQ_NONE, 0, 0, 0, None)
+        with torch.cuda.device_of(x):
+            y_raw = torch.empty((g.N, O, Ho, Wo), dtype=torch.float32, device=dev)
+            ws, nb = _ws(g, 0, dev)
+            _call("mn_conv2d_fwd", C.byref(g), C.byref(none), None, _p(x), _p(weight), _p(bias), _p(y_raw), _p(ws), nb, CONV_ALGO, _s())
+            stats_raw = torch.empty((2, O), dtype=torch.float32, device=dev)
+            wss = torch.empty(int(lib.mn_bn_stats_ws_floats(g.N, O, Ho * Wo)) + 2, dtype=torch.float32, device=dev)
+            _call("mn_bn_stats_fwd", _p(y_raw), g.N, O, Ho * Wo, _p(stats_raw), _p(wss), _s())
+            first_bn = (not st.pretrained_model) and st.num_flag == 0
+            if first_bn:
+                st.num_flag += 1
+            first_w = wobs.num_flag == 0
+            stats = torch.empty((2, O), dtype=torch.float32, device=dev)
+            kfold, bias_f = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
+            qw, wqp = torch.empty_like(weight), torch.empty((O, 4), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_prep_fwd", _p(weight), _p(bias), _p(gamma), _p(beta), O, K, g.groups, None, None, _p(stats_raw), n, float(st.eps), float(st.momentum),
+                  int(first_bn), _p(st.running_mean), _p(st.running_var), wq_.bits, wq_._q_type_static, wobs._kind, int(first_w), float(getattr(wobs, "momentum", 0.1)),
+                  _p(wobs.min_val), _p(wobs.max_val), _p(wq_.scale), _p(wq_.zero_point), _p(stats), _p(kfold), _p(bias_f), _p(qw), _p(wqp), _s())
+            if first_w:
+                wobs.num_flag += 1
+            wq_.q_type = wq_._q_type_static
+            wq_._last_qp = wqp
+            st.__dict__["_mn_last_qw"] = qw
+            aq = ActQ(ACTQ_IAO, aq_.bits, aq_.q_type, 0, aqp.data_ptr())
+            wd = WQ(WQ_IAO, wq_.bits, 0, 4, wqp.data_ptr())
+            first_layer = (not x.requires_grad) and CONV_ALGO == _lib.MN_ALGO_AUTO and bool(lib.mn_conv2d_first_supported(C.byref(g), 0)) and \
+                bool(lib.mn_conv2d_first_supported(C.byref(g), 2))
+            out = torch.empty((g.N, O, Ho, Wo), dtype=torch.float32, device=dev)
+            xq, mm, count, relu_done = None, None, 0, False
+            if first_layer:
+                xq = torch.empty_like(x)          # the fake-quantised image (tiny): exact fp32 products on the first-layer kernels
+                _call("mn_iao_fq_fwd", _p(x), _p(xq), 1, x.numel(), _p(aqp), aq_.bits, aq_.q_type, 1, _s())
+                _call("mn_conv2d_fwd", C.byref(g), C.byref(none), None, _p(xq), _p(qw), _p(bias_f), _p(out), _p(ws), nb, CONV_ALGO, _s())
+            else:
+                cnt = int(lib.mn_conv2d_fwd_act_mm_count(C.byref(g), C.byref(aq), C.byref(wd))) if relu else 0
+                if cnt > 0:
+                    if want_mm:
+                        mm, count = torch.empty(2 * cnt, dtype=torch.float32, device=dev), cnt
+                    _call("mn_conv2d_fwd_act", C.byref(g), C.byref(aq), C.byref(wd), _p(x), _p(qw), _p(bias_f), _p(out), 1, _p(mm), _p(ws), nb, _s())
+                    relu_done = True
+                else:
+                    _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), C.byref(wd), _p(x), _p(qw), _p(bias_f), _p(out), _p(ws), nb, CONV_ALGO, _s())
+            pre = None
+            if relu and not relu_done:
+                # the conv kernel has no ReLU epilogue: one streaming pass (in place would lose the un-rectified output a foreign consumer may ask for -- it is
+                # recomputed in that case, so in place it is) + the (min, max) partials for the next layer's observer
+                if want_mm:
+                    count = int(lib.mn_relu_mm_count(out.numel()))
+                    mm = torch.empty(2 * count, dtype=torch.float32, device=dev) if count > 0 else None
+                if out.numel() % 4 == 0:
+                    _call("mn_relu_mm", _p(out), _p(out), out.numel(), _p(mm), _s())
+                else:
+                    out.clamp_(min=0)
+                    mm, count = None, 0
+        ctx.save_for_backward(x, weight, bias, gamma, out if relu else None, stats, qw, wqp, aqp, y_raw, xq)
+        ctx.cfg = (g, aq_.bits, aq_.q_type, wq_.bits, wq_._q_type_static, float(st.eps), n, bool(relu), bool(first_layer))
+        ctx.tok_in = getattr(x, "_mn_relu_token", None)
+        ctx.x_obj = x
+        if not relu:
+            return out
+
+        def compute():          # the un-rectified output for a consumer other than the block's ReLU
+            o2 = torch.empty_like(out)
+            with torch.cuda.device_of(x):
+                ws2, nb2 = _ws(g, 0, dev)
+                if first_layer:
+                    _call("mn_conv2d_fwd", C.byref(g), C.byref(ActQ(ACTQ_NONE, 0, 0, 0, None)), None, _p(xq), _p(qw), _p(bias_f), _p(o2), _p(ws2), nb2, CONV_ALGO, _s())
+                else:
+                    aq2 = ActQ(ACTQ_IAO, aq.bits, aq.q_type, 0, aqp.data_ptr())
+                    wd2 = WQ(WQ_IAO, wd.bits, 0, 4, wqp.data_ptr())
+                    _call("mn_conv2d_fwd", C.byref(g), C.byref(aq2), C.byref(wd2), _p(x), _p(qw), _p(bias_f), _p(o2), _p(ws2), nb2, CONV_ALGO, _s())
+            return o2
+        return LazyReluConvOut(out, dict(compute=compute, mm=(mm, count) if (want_mm and mm is not None) else None))
+
+    @staticmethod
+    def backward(ctx, gin):
+        x, weight, bias, gamma, a, stats, qw, wqp, aqp, y_raw, xq = ctx.saved_tensors
+        g, a_bits, a_qtype, w_bits, w_qtype, eps, n, relu, first_layer = ctx.cfg
+        dev = x.device
+        if relu and isinstance(gin, LazyReluGrad) and gin._mn_value is None:
+            gy = _chk(gin._mn_g, "grad") if gin._mn_premasked else relu_mask(_chk(gin._mn_g, "grad"), a)
+        else:
+            gy = _chk(gin, "grad")
+        O = weight.shape[0]
+        K = weight[0].numel()
+        aq = ActQ(ACTQ_IAO, a_bits, a_qtype, 0, aqp.data_ptr())
+        none = ActQ(ACTQ_NONE, 0, 0, 0, None)
+        wd = WQ(WQ_IAO, w_bits, 0, 4, wqp.data_ptr())
+        dx = None
+        with torch.cuda.device_of(x):
+            dwq, dbf = torch.empty_like(weight), torch.empty(O, dtype=torch.float32, device=dev)
+            ws, nb = _ws(g, 2, dev)
+            if first_layer:
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(none), _p(gy), _p(xq), _p(dwq), _p(dbf), _p(ws), nb, CONV_ALGO, _s())
+            else:
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dwq), _p(dbf), _p(ws), nb, CONV_ALGO, _s())
+            dw = torch.empty_like(weight)
+            dbias = torch.empty(O, dtype=torch.float32, device=dev) if bias is not None else None
+            dgamma, dbeta = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
+            coef = torch.empty((4, O), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_prep_bwd", _p(dwq), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(stats), _p(wqp), O, K, g.groups, None, None, n, eps, w_bits, w_qtype,
+                  _p(dw), _p(dbias), _p(dgamma), _p(dbeta), _p(coef), _s())
+            # the statistics path: d y_raw from (dmean, dvar), the raw convolution's backward-weight (and backward-data)
+            d_o = torch.empty_like(y_raw)
+            _call("mn_bn_stats_bwd", _p(y_raw), _p(stats), _p(coef[2]), _p(coef[3]), _p(d_o), y_raw.shape[0], O, y_raw.shape[2] * y_raw.shape[3], _s())
+            dw_raw = torch.empty_like(weight)
+            _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(none), _p(d_o), _p(x), _p(dw_raw), None, _p(ws), nb, CONV_ALGO, _s())
+            dw.add_(dw_raw)
+            if ctx.needs_input_grad[0]:
+                dxq, dxr = torch.empty_like(x), torch.empty_like(x)
+                ws1, nb1 = _ws(g, 1, dev)
+                _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wd), _p(gy), _p(qw), _p(x), _p(dxq), _p(ws1), nb1, CONV_ALGO, _s())
+                _call("mn_conv2d_bwd_data", C.byref(g), C.byref(none), None, _p(d_o), _p(weight), None, _p(dxr), _p(ws1), nb1, CONV_ALGO, _s())
+                pre = ctx.tok_in is not None and relu_premask_ok(ctx.x_obj)
+                dx = add_relu_mask(dxq, dxr, x if pre else None)
+                if pre:
+                    ctx.tok_in.dx = dx
+        ctx.x_obj = None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None
+
+
 
 
 def iao_fq_maxpool_supported(x, kernel_size, stride, padding, dilation, ceil_mode):

@@ -378,26 +378,30 @@ class QuantBNFuseConv2d(QuantConv2d):
 
     def _fused_pw_ok(self, input):
         """Training-mode forward on the kernels of csrc/iao_bnfuse.hip: pointwise grouped layer, symmetric <= 8-bit quantizers, per-channel weight observer."""
-        wq, aq = self.weight_quantizer, self.activation_quantizer
-        wobs, aobs = wq.observer, aq.observer
-        return (_FUSE_BNFUSE and not self.bn_fuse_calib and self.padding_mode == "zeros" and not isinstance(self.padding, str)
-                and isinstance(wobs, ObserverBase) and wobs.q_level == "C" and wobs._kind in (0, 1) and not wobs._mn_sync and wq._q_type_static == 0 and 2 <= wq.bits <= 8
-                and not wq.qaft and isinstance(aobs, ObserverBase) and aobs.q_level == "L" and aq._q_type_static == 0 and 2 <= aq.bits <= 8 and not aq.qaft and not aq.union
-                and ops.iao_bnfuse_pw_supported(input, self.weight, self.stride, self.padding, self.dilation, self.groups, self.in_shuffle_groups))
+        return self._fused_quantizers_ok() and ops.iao_bnfuse_pw_supported(input, self.weight, self.stride, self.padding, self.dilation, self.groups, self.in_shuffle_groups)
 
     def _forward_fused_pw(self, input):
         aq = self.activation_quantizer
         qp = aq.qparams(input)          # observer (from the producer's partials when it left them) + update_qparams: the snapshot {scale, zp, lo, hi}
         aq._last_qp = qp
         relu = bool(self.relu_fused)
-        out = ops.IaoBNFusePW.apply(input, self.weight, self.bias, self.gamma, self.beta, self, qp, relu, relu and _PRODUCER_MINMAX)
-        mm, tok = self.__dict__.pop("_mn_fwd_out", (None, None))
-        if relu:
-            out._mn_relu_done = True
-            out._mn_relu_token = tok
-        if mm is not None:
-            out._mn_minmax = mm + (out._version,)
-        return out
+        # relu: the result is a LazyReluConvOut -- logically the conv's output (the reference module's contract), physically the rectified tensor the block's
+        # ReLUAfterFusedConv takes out of it
+        return ops.IaoBNFusePW.apply(input, self.weight, self.bias, self.gamma, self.beta, self, qp, relu, relu and _PRODUCER_MINMAX)
+
+    def _fused_quantizers_ok(self):
+        wq, aq = self.weight_quantizer, self.activation_quantizer
+        wobs, aobs = wq.observer, aq.observer
+        return (_FUSE_BNFUSE and not self.bn_fuse_calib and self.padding_mode == "zeros" and not isinstance(self.padding, str)
+                and isinstance(wobs, ObserverBase) and wobs.q_level == "C" and wobs._kind in (0, 1) and not wobs._mn_sync and wq._q_type_static == 0 and 2 <= wq.bits <= 8
+                and not wq.qaft and isinstance(aobs, ObserverBase) and aobs.q_level == "L" and aq._q_type_static == 0 and 2 <= aq.bits <= 8 and not aq.qaft and not aq.union)
+
+    def _forward_fused_generic(self, input):
+        aq = self.activation_quantizer
+        qp = aq.qparams(input)
+        aq._last_qp = qp
+        relu = bool(self.relu_fused)
+        return ops.IaoBNFuseGeneric.apply(input, self.weight, self.bias, self.gamma, self.beta, self, qp, relu, relu and _PRODUCER_MINMAX)
 
     def forward(self, input):
         training_stats = (not self.qaft) and self.training
@@ -405,6 +409,8 @@ class QuantBNFuseConv2d(QuantConv2d):
             return self._forward_fused_pw(input)
         if self.in_shuffle_groups > 1:
             input = ops.channel_shuffle(input, self.in_shuffle_groups)
+        if training_stats and self._fused_quantizers_ok() and ops.iao_bnfuse_generic_supported(input, self.weight) and ops.CONV_ALGO == 0:
+            return self._forward_fused_generic(input)
         if training_stats:
             # raw conv for the batch statistics (ref 843-855); the statistics stay in the autograd graph
             output = ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
@@ -424,6 +430,7 @@ class QuantBNFuseConv2d(QuantConv2d):
             weight_fused, bias_fused = self._fold(self.running_mean, self.running_var, self.running_var)
 
         quant_weight = self.weight_quantizer(weight_fused)
+        self.__dict__["_mn_last_qw"] = quant_weight.detach()          # (tests: the quantised folded weights of this forward)
         if training_stats and self.bn_fuse_calib:
             # weights folded with the running sigma, output rescaled to the batch sigma (ref 957-972)
             output = self._qconv(input, quant_weight, None)
@@ -724,12 +731,13 @@ def _fuse_residual_tails(model):
 
 
 class ReLUAfterFusedConv(nn.ReLU):
-    """The ``nn.ReLU`` of a ``ConvBNReLU`` block whose conv is a BN-fused ``QuantBNFuseConv2d``: when the conv's kernel already rectified its output (the tensor
-    says so) this is the identity -- relu is idempotent, same function -- else the ordinary ReLU.  Same module object, name and ``isinstance`` as before."""
+    """The ``nn.ReLU`` of a ``ConvBNReLU`` block whose conv is a BN-fused ``QuantBNFuseConv2d``: when the conv handed over a ``LazyReluConvOut`` (its kernel already
+    wrote relu(out)) this takes the rectified tensor out of the wrapper -- no kernel -- else the ordinary ReLU.  Same module object, name and ``isinstance``."""
 
     def forward(self, input):
-        if getattr(input, "_mn_relu_done", False):
-            return input
+        from micronet_amd.sign_tensor import LazyReluConvOut
+        if isinstance(input, LazyReluConvOut) and input._mn_value is None:
+            return ops.relu_of_fused(input)
         return super().forward(input)
 
 

@@ -305,9 +305,79 @@ class LazyQConvOut(torch.Tensor):
         return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
 
 
+class LazyReluConvOut(torch.Tensor):
+    """The output of a BN-fused IAO convolution whose block applies a ReLU right behind it (``ConvBNReLU`` with ``bn = nn.Identity``, models/nin_gc.py:53-59 after
+    the rewrite of wqaq/iao/quantize.py:1567-1624): LOGICALLY the convolution's output (what the reference's ``QuantBNFuseConv2d.forward`` returns), PHYSICALLY the
+    already rectified tensor ``a = relu(out)`` the kernel's epilogue wrote.  The block's ReLU module (``ReLUAfterFusedConv``) takes ``a`` out of the wrapper; any other
+    consumer -- a hook, a direct call of the conv module -- gets the un-rectified output, recomputed by the same kernel without the epilogue (``recipe['compute']``)."""
+
+    @staticmethod
+    def __new__(cls, a, recipe):
+        r = torch.Tensor._make_wrapper_subclass(cls, a.shape, dtype=torch.float32, device=a.device, requires_grad=False)
+        r._mn_a, r._mn_recipe, r._mn_value = a, recipe, None
+        return r
+
+    def __init__(self, a, recipe):
+        pass
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_recipe["compute"]()
+        return self._mn_value
+
+    def __repr__(self):
+        return "LazyReluConvOut(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], LazyReluConvOut):
+            a = args[0]
+            r = LazyReluConvOut(a._mn_a, a._mn_recipe)
+            r._mn_value = a._mn_value
+            return r
+        return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
+
+
+class LazyReluGrad(torch.Tensor):
+    """The gradient a fused ReLU hands back to the convolution in front of it: logically ``g * [a > 0]``, physically ``g`` (+ whether the consumer of ``a`` already
+    applied that mask in its own backward-data kernel).  The convolution's backward unpacks it; any other consumer materialises the masked gradient."""
+
+    @staticmethod
+    def __new__(cls, g, a, premasked):
+        r = torch.Tensor._make_wrapper_subclass(cls, g.shape, dtype=torch.float32, device=g.device, requires_grad=False)
+        r._mn_g, r._mn_a, r._mn_premasked, r._mn_value = g, a, bool(premasked), None
+        return r
+
+    def __init__(self, g, a, premasked):
+        pass
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_g if self._mn_premasked else torch.where(self._mn_a > 0, self._mn_g, torch.zeros((), dtype=self._mn_g.dtype, device=self._mn_g.device))
+        return self._mn_value
+
+    def __repr__(self):
+        return "LazyReluGrad(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], LazyReluGrad):
+            a = args[0]
+            r = LazyReluGrad(a._mn_g, a._mn_a, a._mn_premasked)
+            r._mn_value = a._mn_value
+            return r
+        return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
+
+
 def _unwrap_any(t):
     """The plain tensor a foreign operator should see for any wrapper of this module."""
-    if isinstance(t, (QActTensor, QGrad, LazyQConvOut, LazyBNGrad, LazyPoolGrad, LazyConvOut)):
+    if isinstance(t, (QActTensor, QGrad, LazyQConvOut, LazyBNGrad, LazyPoolGrad, LazyConvOut, LazyReluConvOut, LazyReluGrad)):
         return t.materialize()
     if isinstance(t, SignTensor):
         return t._mn_codes.to(torch.float32)

@@ -144,7 +144,7 @@ def check_iaobf_pointwise(be, case, seed=0, nsteps=2, relu_mask=True):
         nbw = int(lib.mn_conv2d_ws_bytes(C.byref(geom), 2, 0))
         wsw = be.empty(nbw // 4 + 4)
         be.call("mn_conv2d_bwd_weight", C.byref(geom), C.byref(aq), be.ptr(gy), be.ptr(x), be.ptr(dwq), be.ptr(dbf), be.ptr(wsw), nbw, 0, be.stream)
-        dw, dbias, dgamma, dbeta, coef = be.empty((O, Cg)), (be.empty(O) if case["bias"] else None), be.empty(O), be.empty(O), be.empty(3 * O)
+        dw, dbias, dgamma, dbeta, coef = be.empty((O, Cg)), (be.empty(O) if case["bias"] else None), be.empty(O), be.empty(O), be.empty(4 * O)
         be.call("mn_iaobf_prep_bwd", be.ptr(dwq), be.ptr(dbf), be.ptr(w), be.ptr(bias), be.ptr(gamma), be.ptr(stats), be.ptr(wqp), O, Cg, G, be.ptr(gram), be.ptr(sx), n,
                 1e-5, 8, 0, be.ptr(dw), be.ptr(dbias), be.ptr(dgamma), be.ptr(dbeta), be.ptr(coef), be.stream)
         worst["dw%d" % it] = _close("dw", be.to_host(dw), r32[it]["dw"], r64[it]["dw"])
@@ -198,3 +198,24 @@ def check_fq_maxpool(be, shape=(2, 6, 8, 16), bits=8, q_type=0, seed=0, relu_mas
     gd = be.to_dev(g.numpy())
     be.call("mn_iao_fq_maxpool2x2_bwd", be.ptr(gd), be.ptr(idx), be.ptr(xd), N * Cc, H, W, be.ptr(qp), bits, q_type, int(relu_mask), be.ptr(dx), be.stream)
     assert np.array_equal(be.to_host(dx), dx_ref.numpy())
+
+
+def check_stream_helpers(be, n=4 * 1000 + 8, seed=0):
+    """mn_add_relu_mask / mn_relu_mm against numpy, bit for bit."""
+    rng = np.random.RandomState(seed)
+    a, b, x = (rng.randn(n).astype(np.float32) for _ in range(3))
+    x[::7] = 0.0
+    ad, bd, xd = be.to_dev(a), be.to_dev(b), be.to_dev(x)
+    for bb, xx in ((bd, xd), (None, xd), (bd, None)):
+        out = be.empty(n)
+        be.call("mn_add_relu_mask", be.ptr(ad), be.ptr(bb), be.ptr(xx), be.ptr(out), n, be.stream)
+        ref = a + (b if bb is not None else 0)
+        ref = np.where(x > 0, ref, 0).astype(np.float32) if xx is not None else ref.astype(np.float32)
+        assert np.array_equal(be.to_host(out), ref)
+    cnt = int(be.lib.mn_relu_mm_count(n))
+    y, mm = be.empty(n), be.empty(2 * cnt)
+    be.call("mn_relu_mm", be.ptr(ad), be.ptr(y), n, be.ptr(mm), be.stream)
+    ref = np.maximum(a, 0)
+    assert np.array_equal(be.to_host(y), ref)
+    mmh = be.to_host(mm)
+    assert mmh[:cnt].min() == ref.min() and mmh[cnt:].max() == ref.max()

@@ -115,3 +115,68 @@ def test_fused_equals_generic_path_and_hooks_see_true_gradients():
     dxf, dxp = run_hooked(fused), run_hooked(plain)
     assert _rel(seen[id(fused)], seen[id(plain)]) <= 2e-5
     assert _rel(dxf, dxp) <= 2e-5
+
+
+def _mixed_chain(seed=2):
+    torch.manual_seed(seed)
+    net = nn.Sequential(ConvBNReLU(3, 32, kernel_size=5, padding=2),                                  # the first layer: image input, first-layer kernels
+                        ConvBNReLU(32, 32, kernel_size=1, groups=2),                                    # pointwise fused
+                        nn.MaxPool2d(2, 2),                                                             # -> QuantMaxPool2d (fused quantizer + pool)
+                        ConvBNReLU(32, 64, kernel_size=3, padding=1, groups=2, channel_shuffle=1, shuffle_groups=2),      # generic fused (k x k)
+                        ConvBNReLU(64, 16, kernel_size=1, groups=1, channel_shuffle=1, shuffle_groups=2))
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.4, 1.3)
+            nn.init.normal_(m.bias, 0, 0.2)
+    return net
+
+
+def test_mixed_chain_vs_oracle():
+    """first layer (5 x 5 on the image) -> pointwise -> QuantMaxPool2d -> grouped 3 x 3 with a folded shuffle -> pointwise: every hand-over of the nin_gc pipeline
+    (ReLU masks pre-applied by the pool / the next block, (min, max) partials from epilogues and from the pool) against the oracle, two steps"""
+    Q = _q()
+    base = _mixed_chain()
+    x = torch.randn(4, 3, 16, 16)
+    g = torch.randn(4, 16, 8, 8)
+    orc = TO.prepare(copy.deepcopy(base), "iao", inplace=True, **KW).train()
+    o64 = TO.prepare(copy.deepcopy(base), "iao", inplace=True, **KW).double().train()
+    ours = Q.prepare(copy.deepcopy(base), inplace=True, **KW).cuda().train()
+    steps = 2
+
+    def run(model, xx_, g_):
+        recs = []
+        for _ in range(steps):
+            for p in model.parameters():
+                p.grad = None
+            out = model(xx_)
+            out.backward(g_)
+            recs.append(dict(out=out.detach().clone(), **{"d_" + n: p.grad.clone() for n, p in model.named_parameters()}))
+        return recs
+    r_ours, r_ref, r_64 = run(ours, x.cuda(), g.cuda()), run(orc, x, g), run(o64, x.double(), g.double())
+    for s in range(steps):
+        for k in r_ref[s]:
+            if k.endswith(".conv.bias"):
+                continue
+            e32, e64, own = _rel(r_ours[s][k], r_ref[s][k]), _rel(r_ours[s][k], r_64[s][k]), _rel(r_ref[s][k], r_64[s][k])
+            assert e32 <= 1e-5 or e64 <= max(1e-5, 2 * own), (s, k, e32, e64, own)
+
+
+def test_conv_module_called_directly_keeps_the_reference_contract():
+    """the conv of a fused block called on its own returns the UN-rectified output (what the reference's QuantBNFuseConv2d.forward returns) and accepts a gradient
+    with respect to it -- the wrapper recomputes it for a foreign consumer"""
+    Q = _q()
+    base = _chain(3)
+    x = (torch.randn(4, 32, 8, 8) * 1.3 + 0.2)
+    g = torch.randn(4, 64, 8, 8)
+    ours = Q.prepare(copy.deepcopy(base), inplace=True, **KW).cuda().train()
+    orc = TO.prepare(copy.deepcopy(base), "iao", inplace=True, **KW).train()
+    xo = x.clone().requires_grad_(True)
+    yo = orc[0].conv(xo)
+    yo.backward(g)
+    xp = x.cuda().requires_grad_(True)
+    yp = ours[0].conv(xp)
+    assert type(yp).__name__ == "LazyReluConvOut"
+    assert _rel(yp, yo) <= 1e-5 and float(yp.detach().min().cpu()) < 0          # not rectified
+    torch.autograd.backward([yp], [g.cuda()])
+    assert _rel(xp.grad, xo.grad) <= 1e-5
+    assert _rel(ours[0].conv.weight.grad, orc[0].conv.weight.grad) <= 1e-5

@@ -663,3 +663,9 @@ def test_iao_fq_maxpool(be, bits, q_type, relu_mask):
     import iaobf_cases as B
     B.check_fq_maxpool(be, bits=bits, q_type=q_type, relu_mask=relu_mask, seed=bits + q_type)
     B.check_fq_maxpool(be, shape=(8, 64, 32, 32), bits=bits, q_type=q_type, relu_mask=relu_mask, seed=100 + bits)
+
+
+def test_bnfuse_stream_helpers(be):
+    import iaobf_cases as B
+    B.check_stream_helpers(be)
+    B.check_stream_helpers(be, n=4 * 3000017, seed=3)

@@ -455,3 +455,8 @@ def test_iaobf_pointwise(be, case):
 def test_iao_fq_maxpool(be, bits, q_type, relu_mask):
     import iaobf_cases as B
     B.check_fq_maxpool(be, bits=bits, q_type=q_type, relu_mask=relu_mask, seed=bits + q_type)
+
+
+def test_bnfuse_stream_helpers(be):
+    import iaobf_cases as B
+    B.check_stream_helpers(be)
