@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
                     bq[q][2][d] = mn_pack_bf16x2(r0 - m0, r1 - m1);
                 }
         }
-        if (it + 1 < total) issue_next(raw);              // the registers are free: the next step's loads fly during this step's LDS reads + MFMAs
+        if (it + 2 < total) issue_next(raw);              // the registers are free: two steps (16 KB per wave) are always in flight
         if (phaseA) {
             u32x4 av[NT];
 #pragma unroll
@@ -614,12 +614,17 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
             }
         }
     };
-    float4 ra[8];
+    float4 ra[8], rb[8];
     if (total > 0) issue_next(ra);
+    if (total > 1) issue_next(rb);
     int ci_c = 0, s_c = 0;
-    for (int it = 0; it < total; ++it) {
+    for (int it = 0; it < total; it += 2) {
         step(ra, it, ci_c, s_c);
         if (++s_c == KST) { s_c = 0; ++ci_c; }
+        if (it + 1 < total) {
+            step(rb, it + 1, ci_c, s_c);
+            if (++s_c == KST) { s_c = 0; ++ci_c; }
+        }
     }
 }
 

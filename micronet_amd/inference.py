@@ -115,6 +115,8 @@ def iao_model_bn_fuse(model, inplace=False):
         for name, child in module.named_children():
             if isinstance(child, quantize.QuantBNFuseConv2d):
                 module._modules[name] = fuse(child)
+                if getattr(child, "in_shuffle_groups", 0) > 1 and getattr(module, "shuffle_groups", 0) == child.in_shuffle_groups and hasattr(module, "channel_shuffle_flag"):
+                    module.channel_shuffle_flag = 1          # prepare(fuse_blocks=True) had folded the block's shuffle into the BN-fused conv: hand it back to the block
             else:
                 walk(child)
     walk(model)

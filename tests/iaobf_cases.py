@@ -219,3 +219,47 @@ def check_stream_helpers(be, n=4 * 1000 + 8, seed=0):
     assert np.array_equal(be.to_host(y), ref)
     mmh = be.to_host(mm)
     assert mmh[:cnt].min() == ref.min() and mmh[cnt:].max() == ref.max()
+
+
+def check_iao_codes_at_boundaries(be, seed=0):
+    """The division-free activation-code path of the pointwise code-domain kernels (iao_code_fast, qgemm_dev.h) on inputs that sit ON and within a few ulp of every
+    rounding boundary (k + 0.5) * scale: forward and backward-weight must use exactly the codes of the reference expression clamp(rha(x / s)) -- one wrong code moves
+    an output by a whole weight step (>= 1e-3 relative), the test allows 1e-6."""
+    lib = be.lib
+    rng = np.random.RandomState(seed)
+    N, Cc, H, W, O = 2, 32, 8, 8, 32
+    amax = np.float32(100.0)
+    sc = np.float32(np.float32(amax) / np.float32(127.5))          # update_qparams (293-305): float_range / ((qmax - qmin) / 2), activations: qmin = -128
+    ks = rng.randint(-127, 127, size=(N, Cc, H, W)).astype(np.float32)
+    x = ((ks + np.float32(0.5)) * sc).astype(np.float32)
+    ulps = rng.randint(-6, 7, size=x.shape)
+    for u in range(1, 7):
+        x = np.where(ulps >= u, np.nextafter(x, np.float32(np.inf)), x)
+        x = np.where(ulps <= -u, np.nextafter(x, np.float32(-np.inf)), x)
+    x = x.astype(np.float32)
+    x.reshape(-1)[0], x.reshape(-1)[1] = amax, -amax
+    x = np.clip(x, -amax, amax)
+    wcode = rng.randint(-127, 128, size=(O, Cc)).astype(np.float32)
+    wsc = (rng.rand(O).astype(np.float32) * 0.01 + 0.001).astype(np.float32)
+    qw = (wcode * wsc[:, None]).astype(np.float32)
+    code_ref = np.clip(np.sign(x / sc) * np.floor(np.abs(x / sc) + np.float32(0.5)), -128, 127).astype(np.float64)
+    y_ref = np.einsum("oc,nchw->nohw", wcode.astype(np.float64), code_ref) * (wsc.astype(np.float64)[None, :, None, None] * np.float64(sc))
+    xd = be.to_dev(x)
+    amin_d, amax_d, asc_d, azp_d = be.to_dev(np.zeros(1)), be.to_dev(np.zeros(1)), be.to_dev(np.ones(1)), be.to_dev(np.zeros(1))
+    ows = be.empty(int(lib.mn_iao_observe_ws_floats(1, x.size)) + 4)
+    be.call("mn_iao_observe", be.ptr(xd), 1, x.size, 1, 1, 0.1, be.ptr(amin_d), be.ptr(amax_d), be.ptr(ows), be.stream)
+    qp = be.empty(4)
+    be.call("mn_iao_qparams", be.ptr(amin_d), be.ptr(amax_d), 1, 8, 0, 1, 1, be.ptr(asc_d), be.ptr(azp_d), be.ptr(qp), be.stream)
+    assert be.to_host(asc_d)[0] == sc
+    geom = _lib.ConvGeom(N, Cc, H, W, O, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0)
+    aq = be.actq(2, 8, 0, qp)
+    wsd = be.to_dev(wsc)
+    wq = be.wq(3, 8, 0, 1, wsd)
+    y = be.conv_fwd(geom, aq, xd, be.to_dev(qw), None, 3, wq=wq)
+    err = np.abs(be.to_host(y).astype(np.float64) - y_ref).max() / np.abs(y_ref).max()
+    assert err <= 1e-6, ("forward codes", err)
+    g = rng.randn(N, O, H, W).astype(np.float32)
+    dw, _ = be.conv_bwd_weight(geom, aq, be.to_dev(g), xd, 3, bias=False)
+    dw_ref = np.einsum("nohw,nchw->oc", g.astype(np.float64), code_ref) * np.float64(sc)
+    errw = np.abs(be.to_host(dw).reshape(O, Cc).astype(np.float64) - dw_ref).max() / np.abs(dw_ref).max()
+    assert errw <= 2e-6, ("backward-weight codes", errw)

@@ -669,3 +669,9 @@ def test_bnfuse_stream_helpers(be):
     import iaobf_cases as B
     B.check_stream_helpers(be)
     B.check_stream_helpers(be, n=4 * 3000017, seed=3)
+
+
+def test_iao_codes_at_rounding_boundaries(be):
+    import iaobf_cases as B
+    B.check_iao_codes_at_boundaries(be)
+    B.check_iao_codes_at_boundaries(be, seed=5)

@@ -460,3 +460,8 @@ def test_iao_fq_maxpool(be, bits, q_type, relu_mask):
 def test_bnfuse_stream_helpers(be):
     import iaobf_cases as B
     B.check_stream_helpers(be)
+
+
+def test_iao_codes_at_rounding_boundaries(be):
+    import iaobf_cases as B
+    B.check_iao_codes_at_boundaries(be)
