@@ -23,18 +23,6 @@ __device__ __forceinline__ float act_code(float x, const Pro& p, float sc, float
     return x;
 }
 
-// The IAO activation code without the IEEE division per element: t = x * (1 / sc) differs from fl(x / sc) by at most ~1.5 ulp, and |t| + 0.5 adds one rounding on
-// either route, so floor(|.| + 0.5) -- the code -- is the same whenever |t| + 0.5 keeps a distance of more than 2e-6 relative (+ 1e-6) from the nearest integer
-// (6x the worst-case route difference).  Otherwise `slow` is raised and the caller recomputes the wave's elements with the exact expression (wave-uniform branch,
-// taken for ~10 % of the K-steps at 8 bits).  Symmetric quantizers only (zp = 0 in every code-domain kernel).  Bit-identical to act_code<MN_ACTQ_IAO> by construction.
-__device__ __forceinline__ float iao_code_fast(float x, float inv, float qmin, float qmax, int& slow) {
-    const float t = x * inv;
-    const float w = fabsf(t) + 0.5f, fl = floorf(w);
-    const float d = fminf(w - fl, (fl + 1.0f) - w);
-    slow |= !(d > 2e-6f * w + 1e-6f);                         // (NaN / inf land here too)
-    return mn_clamp(mn_sign(t) * fl, qmin, qmax);
-}
-
 // per-channel fold of the BatchNorm+sign backward for the BNH variants (same algebra as k_bnh_apply, reassociated; `scale` = the weight
 // scale the consumer multiplies the operand with)
 __device__ __forceinline__ void bnh_fold(const float* __restrict__ chan, const float* __restrict__ sums, int C, int co, int training, float n_f, float scale,

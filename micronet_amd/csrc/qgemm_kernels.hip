@@ -143,7 +143,6 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
 
     float sc = 1.f, zp = 0.f;
     if (XMODE == MN_ACTQ_IAO) { sc = p.pro.qp[0]; zp = p.pro.qp[1]; }
-    const float inv_sc = 1.0f / sc;
     float ste_sc = 1.f, ste_zp = 0.f, ste_lo = 0.f, ste_hi = 0.f;
     if (p.epi == QG_EPI_STE && p.ste.mode == MN_ACTQ_IAO) { ste_sc = p.ste.qp[0]; ste_zp = p.ste.qp[1]; ste_lo = p.ste.qp[2]; ste_hi = p.ste.qp[3]; }
 
@@ -222,27 +221,13 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) b0[q][d] = mn_sign8_pair(mn_f2u(raw[2 * d][0]), mn_f2u(raw[2 * d + 1][0]), q);
         } else {
-            int slow = XMODE == MN_ACTQ_IAO ? 0 : 1;
-            if (XMODE == MN_ACTQ_IAO) {          // codes by multiplication with 1 / scale, exact division only for the K-steps that hold a near-boundary element
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float c8[8];
+            for (int q = 0; q < 4; ++q) {
+                float c8[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) c8[e] = iao_code_fast(raw[e][q], inv_sc, p.pro.qmin, p.pro.qmax, slow);
+                for (int e = 0; e < 8; ++e) c8[e] = act_code<XMODE>(raw[e][q], p.pro, sc, zp);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) b0[q][d] = mn_pack_bf16x2(c8[2 * d], c8[2 * d + 1]);
-                }
-                slow = mn_wave_any(slow);
-            }
-            if (slow) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float c8[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) c8[e] = act_code<XMODE>(raw[e][q], p.pro, sc, zp);
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) b0[q][d] = mn_pack_bf16x2(c8[2 * d], c8[2 * d + 1]);
-                }
+                for (int d = 0; d < 4; ++d) b0[q][d] = mn_pack_bf16x2(c8[2 * d], c8[2 * d + 1]);
             }
         }
         if (it + 1 < total) issue(raw, it + 1);
@@ -549,7 +534,6 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
     const int64_t HW = p.HW;
     float sc = 1.f, zp = 0.f;
     if (XMODE == MN_ACTQ_IAO) { sc = p.pro.qp[0]; zp = p.pro.qp[1]; }
-    const float inv_sc = 1.0f / sc;
 
     f32x4 acc[MW][CW];
 #pragma unroll
@@ -614,16 +598,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
                     u32x2{mn_pack_bf16x2((float)(u & 0xffu), (float)((u >> 8) & 0xffu)), mn_pack_bf16x2((float)((u >> 16) & 0xffu), (float)(u >> 24))};
                 continue;
             }
-            float c0, c1, c2, c3;
-            int slow = XMODE == MN_ACTQ_IAO ? 0 : 1;
-            if (XMODE == MN_ACTQ_IAO) {
-                c0 = iao_code_fast(rx[i].x, inv_sc, p.pro.qmin, p.pro.qmax, slow); c1 = iao_code_fast(rx[i].y, inv_sc, p.pro.qmin, p.pro.qmax, slow);
-                c2 = iao_code_fast(rx[i].z, inv_sc, p.pro.qmin, p.pro.qmax, slow); c3 = iao_code_fast(rx[i].w, inv_sc, p.pro.qmin, p.pro.qmax, slow);
-            }
-            if (slow) {          // (per lane here: four elements, no wave collective inside the staging loop)
-                c0 = act_code<XMODE>(rx[i].x, p.pro, sc, zp); c1 = act_code<XMODE>(rx[i].y, p.pro, sc, zp);
-                c2 = act_code<XMODE>(rx[i].z, p.pro, sc, zp); c3 = act_code<XMODE>(rx[i].w, p.pro, sc, zp);
-            }
+            const float c0 = act_code<XMODE>(rx[i].x, p.pro, sc, zp), c1 = act_code<XMODE>(rx[i].y, p.pro, sc, zp);
+            const float c2 = act_code<XMODE>(rx[i].z, p.pro, sc, zp), c3 = act_code<XMODE>(rx[i].w, p.pro, sc, zp);
             *reinterpret_cast<u32x2*>(xq + (r0 + 16 * i) * WG_LDP + qd * 4) = u32x2{mn_pack_bf16x2(c0, c1), mn_pack_bf16x2(c2, c3)};
         }
     };

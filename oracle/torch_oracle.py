@@ -269,12 +269,15 @@ class OConv2d(nn.Conv2d):
     def _conv(self, x, w, b):
         return F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
 
+    quant_inference = False          # True: the stored weights are convolved as they are (every scheme's `if not self.quant_inference` branch: dorefa 107-112,
+                                      # wbwtab 181-185, iao 492-497)
+
     def forward(self, x):
         if self.scheme == "dorefa":
-            return self._conv(dorefa_act(x, self.cfg["a_bits"]), dorefa_weight(self.weight, self.cfg["w_bits"]), self.bias)
+            return self._conv(dorefa_act(x, self.cfg["a_bits"]), self.weight if self.quant_inference else dorefa_weight(self.weight, self.cfg["w_bits"]), self.bias)
         if self.scheme == "wbwtab":
-            return self._conv(x, wbwtab_weight(self.weight, self.cfg["W"]), self.bias)
-        return self._conv(self.aq(x), self.wq(self.weight), self.bias)
+            return self._conv(x, self.weight if self.quant_inference else wbwtab_weight(self.weight, self.cfg["W"]), self.bias)
+        return self._conv(self.aq(x), self.weight if self.quant_inference else self.wq(self.weight), self.bias)
 
 
 class OBNFuseConv2d(OConv2d):
@@ -435,6 +438,94 @@ def prepare(model, scheme, inplace=False, **cfg):
         walk(model)
     else:
         raise ValueError(scheme)
+    return model
+
+
+# ---------------------------------------------------------------- inference graphs
+def _plain_conv_like(conv):
+    return nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, stride=conv.stride, padding=conv.padding, dilation=conv.dilation, groups=conv.groups,
+                     bias=True, padding_mode=conv.padding_mode)
+
+
+@torch.no_grad()
+def bn_fuse_wbwtab(model, W, inplace=False):
+    """wbwtab/bn_fuse/bn_fuse.py:20-107 on an oracle-prepared net (``prepare(model, "wbwtab", ...)``): every Conv2d -> BatchNorm2d pair (in child order, 86-95) becomes
+    one conv with a bias and the BatchNorm an Identity.  The first ``bin_bn_fuse_num`` BatchNorms (= the number of binary activations, ref __main__ 172-177) sit in
+    front of a sign: sign(gamma (y - mean) / std + beta) = sign(+-(y - mean + beta std / gamma)), so only the bias -- and the weights' sign where gamma < 0 -- changes
+    (36-55); the others get the ordinary w gamma / std fold (56-59).  BatchNorm 2 .. bin_bn_fuse_num yield a quantised conv that convolves its stored weights
+    (quant_inference=True, 60-73), the first and the ones past the binary part a plain nn.Conv2d (74-85)."""
+    if not inplace:
+        model = copy.deepcopy(model)
+    bin_bn_fuse_num = sum(isinstance(m, OBinAct) for m in model.modules())
+    counter = [0]
+
+    def fuse(conv, bn):
+        counter[0] += 1
+        k = counter[0]
+        mean, std, gamma, beta = bn.running_mean, torch.sqrt(bn.running_var + bn.eps), bn.weight, bn.bias
+        w = conv.weight
+        b = conv.bias if conv.bias is not None else mean.new_zeros(mean.shape)
+        w_f, b_f = w.clone(), b.clone()
+        if 1 <= k <= bin_bn_fuse_num:
+            pos, neg = gamma.data.gt(0), gamma.data.lt(0)
+            w_f[pos] = w[pos]
+            b_f[pos] = b[pos] - mean[pos] + beta[pos] * (std[pos] / gamma[pos])
+            w_f[neg] = w[neg] * -1
+            b_f[neg] = mean[neg] - b[neg] - beta[neg] * (std[neg] / gamma[neg])
+        else:
+            w_f = w * (gamma / std).reshape([conv.out_channels, 1, 1, 1])
+            b_f = beta + (b - mean) * (gamma / std)
+        if 2 <= k <= bin_bn_fuse_num:
+            new = OConv2d(_plain_conv_like(conv), "wbwtab", W=W)
+            new.quant_inference = True
+        else:
+            new = _plain_conv_like(conv)
+        new.weight = nn.Parameter(w_f.detach().clone())
+        new.bias = nn.Parameter(b_f.detach().clone())
+        return new
+
+    def walk(mod):
+        last = None
+        for name, ch in mod.named_children():
+            if isinstance(ch, nn.Conv2d):
+                last = (name, ch)
+            elif isinstance(ch, nn.BatchNorm2d):
+                mod._modules[last[0]] = fuse(last[1], ch)
+                mod._modules[name] = nn.Identity()
+            else:
+                walk(ch)
+    walk(model)
+    return model
+
+
+@torch.no_grad()
+def bn_fuse_iao(model, inplace=False):
+    """wqaq/iao/bn_fuse/bn_fuse.py:20-80 on an oracle-prepared net: every BN-fused conv (``OBNFuseConv2d``) becomes a quantised conv that convolves its stored
+    weights (quant_inference=True) -- w gamma / std and beta + (b - mean) gamma / std from the running statistics (34-35) -- with the trained scale / zero point of
+    both quantizers copied over (55-62; the observers' ranges are NOT copied, exactly as in the reference)."""
+    if not inplace:
+        model = copy.deepcopy(model)
+
+    def fuse(m):
+        mean, std = m.running_mean, torch.sqrt(m.running_var + m.eps)
+        b = m.bias if m.bias is not None else mean.new_zeros(mean.shape)
+        new = OConv2d(_plain_conv_like(m), "iao", **m.cfg)
+        new.quant_inference = True
+        new.weight = nn.Parameter((m.weight * (m.gamma / std).reshape([m.out_channels, 1, 1, 1])).detach().clone())
+        new.bias = nn.Parameter((m.beta + (b - mean) * (m.gamma / std)).detach().clone())
+        for src, dst in ((m.aq, new.aq), (m.wq, new.wq)):
+            dst.scale.copy_(src.scale)
+            dst.zero_point.copy_(src.zero_point)
+            dst.eps = src.eps
+        return new
+
+    def walk(mod):
+        for name, ch in mod.named_children():
+            if isinstance(ch, OBNFuseConv2d):
+                mod._modules[name] = fuse(ch)
+            else:
+                walk(ch)
+    walk(model)
     return model
 
 

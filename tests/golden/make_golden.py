@@ -467,7 +467,147 @@ def gen_iao_ops(out):
     return meta
 
 
+# ---------------------------------------------------------------- inference graphs: the reference's own bn_fuse functions
+SMALL_CFG = [32, 32, 32, 64, 64, 64, 128, 128]          # nin_gc at an eighth of the width (every group count of the net still divides): small fixtures
+
+
+def _load_ref_script(rel_dir, name):
+    """Load <REF>/micronet/compression/quantization/<rel_dir>/bn_fuse/bn_fuse.py the way it runs as a script: its `import quantize` / `from models import ...`
+    resolve through the sys.path entries it appends (its parent directory, the package root)."""
+    import importlib.util
+    qdir = os.path.join(REF, "micronet", "compression", "quantization", *rel_dir.split("/"))
+    saved_path, saved_mods = list(sys.path), {k: sys.modules.get(k) for k in ("quantize", "models")}
+    sys.path[:0] = [qdir, os.path.join(REF, "micronet")]
+    for k in ("quantize", "models"):
+        sys.modules.pop(k, None)
+    try:
+        spec = importlib.util.spec_from_file_location("ref_%s_%s" % (rel_dir.replace("/", "_"), name), os.path.join(qdir, "bn_fuse", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path[:] = saved_path
+        for k, v in saved_mods.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+    return mod
+
+
+def _train3(model, x, y, wd):
+    params = [{"params": [v], "lr": 0.01, "weight_decay": wd} for _, v in model.named_parameters()]
+    opt = torch.optim.Adam(params, lr=0.01, weight_decay=wd)
+    crit = nn.CrossEntropyLoss()
+    model.train()
+    for _ in range(3):
+        loss = crit(model(x), y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+
+def _stage_outputs(model, x):
+    outs, t = [], x
+    for st in model.model:
+        t = st(t)
+        outs.append(t)
+    return outs
+
+
+def gen_inference(out):
+    """Folded inference graphs produced by the REFERENCE's functions -- wbwtab/bn_fuse/bn_fuse.py:20-107 (bn_fuse / bn_fuse_module / model_bn_fuse, with the two
+    globals its __main__ sets: bin_bn_fuse_num = number of ActivationQuantizer modules, args.W) and wqaq/iao/bn_fuse/bn_fuse.py:20-80 -- from models trained
+    for three steps with the reference.  Stored: the initial state_dict to start from, the trained state_dict, every folded conv's weight / bias, the eval-mode
+    logits of the training graph and of the folded graph, and two intermediate stage outputs of the folded graph.
+    The IAO script passes a `device=` keyword that this version of the reference's QuantConv2d does not accept (the script is stale); the generator strips that one
+    keyword and runs the function otherwise unmodified."""
+    import argparse
+    import copy
+    meta = {}
+    x, y = synth_batch(4)
+    for W in (3, 2):
+        bnf = _load_ref_script("wbwtab", "bn_fuse")
+        Q = bnf.quantize
+        key = "inf_wbwtab_w%d" % W
+        torch.manual_seed(1)
+        base = ref_nin_gc.Net(cfg=SMALL_CFG)
+        init_like_main(base)
+        train = copy.deepcopy(base)
+        Q.prepare(train, inplace=True, A=2, W=W)
+        for k_, v in train.state_dict().items():
+            out[f"{key}_init_{k_}"] = N(v)
+        _train3(train, x, y, 0.0)
+        inf = copy.deepcopy(base)
+        Q.prepare(inf, inplace=True, A=2, W=W, quant_inference=True)
+        inf.load_state_dict(train.state_dict())
+        for k_, v in train.state_dict().items():
+            out[f"{key}_trained_{k_}"] = N(v)
+        bnf.args = argparse.Namespace(W=W, A=2)
+        bnf.bn_counter = 0
+        bnf.bin_bn_fuse_num = sum(isinstance(m, Q.ActivationQuantizer) for m in inf.modules())
+        fused = bnf.model_bn_fuse(inf, inplace=False)
+        train.eval(), fused.eval()
+        with torch.no_grad():
+            out[f"{key}_train_eval_logits"] = N(train(x))
+            outs = _stage_outputs(fused, x)
+            out[f"{key}_fused_logits"] = N(fused(x))
+            out[f"{key}_fused_stage1"] = N(outs[1])
+            out[f"{key}_fused_stage8"] = N(outs[8])
+        convs = [(n_, m) for n_, m in fused.named_modules() if isinstance(m, nn.Conv2d)]
+        for n_, m in convs:
+            out[f"{key}_fused_{n_}_weight"], out[f"{key}_fused_{n_}_bias"] = N(m.weight), N(m.bias)
+        meta[key] = dict(W=W, bin_bn_fuse_num=int(bnf.bin_bn_fuse_num), convs=[(n_, type(m).__name__) for n_, m in convs],
+                         modules=[(n_, type(m).__name__) for n_, m in fused.named_modules()])
+        print(key, "bin_bn_fuse_num", bnf.bin_bn_fuse_num, [t for _, t in meta[key]["convs"]])
+    # IAO
+    bnf = _load_ref_script("wqaq/iao", "bn_fuse")
+    Q = bnf.quantize
+    key = "inf_iao_w8a8"
+    kw = dict(a_bits=8, w_bits=8, q_type=0, q_level=0)
+    torch.manual_seed(1)
+    base = ref_nin_gc.Net(cfg=SMALL_CFG)
+    init_like_main(base)
+    train = copy.deepcopy(base)
+    Q.prepare(train, inplace=True, bn_fuse=1, **kw)
+    for k_, v in train.state_dict().items():
+        out[f"{key}_init_{k_}"] = N(v)
+    _train3(train, x, y, 1e-5)
+    for k_, v in train.state_dict().items():
+        out[f"{key}_trained_{k_}"] = N(v)
+    bnf.args = argparse.Namespace(**kw)
+    bnf.device = "cpu"
+    import types
+
+    def ctor_without_device(*a, **k):
+        k.pop("device", None)
+        return Q.QuantConv2d(*a, **k)
+    bnf.quantize = types.SimpleNamespace(QuantConv2d=ctor_without_device, QuantBNFuseConv2d=Q.QuantBNFuseConv2d)      # what bn_fuse.py reads from its `quantize`
+    inf = copy.deepcopy(train)          # (the script loads the same state into a graph prepared with quant_inference=True; QuantBNFuseConv2d ignores that flag)
+    fused = bnf.model_bn_fuse(inf, inplace=False)
+    train.eval(), fused.eval()
+    with torch.no_grad():
+        out[f"{key}_train_eval_logits"] = N(train(x))
+        outs = _stage_outputs(fused, x)
+        out[f"{key}_fused_logits"] = N(fused(x))
+        out[f"{key}_fused_stage1"] = N(outs[1])
+        out[f"{key}_fused_stage8"] = N(outs[8])
+    convs = [(n_, m) for n_, m in fused.named_modules() if isinstance(m, nn.Conv2d)]
+    for n_, m in convs:
+        out[f"{key}_fused_{n_}_weight"], out[f"{key}_fused_{n_}_bias"] = N(m.weight), N(m.bias)
+        out[f"{key}_fused_{n_}_ascale"], out[f"{key}_fused_{n_}_wscale"] = N(m.activation_quantizer.scale), N(m.weight_quantizer.scale)
+    meta[key] = dict(convs=[(n_, type(m).__name__) for n_, m in convs], modules=[(n_, type(m).__name__) for n_, m in fused.named_modules()], **kw)
+    print(key, [t for _, t in meta[key]["convs"]])
+    return meta
+
+
 def main():
+    if "--inference-only" in sys.argv:      # regenerate only inference.npz (the older fixture files stay byte-identical)
+        o = {}
+        inf_meta = gen_inference(o)
+        np.savez_compressed(os.path.join(HERE, "inference.npz"), **o)
+        with open(os.path.join(HERE, "inference_meta.json"), "w") as f:
+            json.dump(dict(cases=inf_meta, cfg=SMALL_CFG, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
+        print("inference.npz", os.path.getsize(os.path.join(HERE, "inference.npz")) // 1024, "KiB")
+        return
     if "--ops-only" in sys.argv:      # regenerate only iao_ops.npz (the three older fixture files stay byte-identical)
         o = {}
         ops_meta = gen_iao_ops(o)
@@ -498,6 +638,12 @@ def main():
     with open(os.path.join(HERE, "iao_ops_meta.json"), "w") as f:
         json.dump(dict(ops=ops_meta, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
     print("iao_ops.npz", os.path.getsize(os.path.join(HERE, "iao_ops.npz")) // 1024, "KiB")
+    o = {}
+    inf_meta = gen_inference(o)
+    np.savez_compressed(os.path.join(HERE, "inference.npz"), **o)
+    with open(os.path.join(HERE, "inference_meta.json"), "w") as f:
+        json.dump(dict(cases=inf_meta, cfg=SMALL_CFG, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
+    print("inference.npz", os.path.getsize(os.path.join(HERE, "inference.npz")) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -180,3 +180,107 @@ def test_dorefa_resnet_inference_graph_on_int8_matrix_cores(bits):
     with torch.no_grad():
         r, r2 = R(x), R2(x)
     assert float((r - r2).abs().max()) <= 1e-4 * float(r2.abs().max()), float((r - r2).abs().max())
+
+
+# ---- the folded graphs against the REFERENCE's own (tests/golden/inference.npz: make_golden.py:gen_inference runs wbwtab/bn_fuse/bn_fuse.py:20-107 and
+# wqaq/iao/bn_fuse/bn_fuse.py:20-80 on models the reference trained; tests/test_oracle_golden.py pins oracle/torch_oracle.py:bn_fuse_* to the same vectors)
+def _inference_golden():
+    import json
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return np.load(os.path.join(here, "inference.npz")), json.load(open(os.path.join(here, "inference_meta.json")))
+
+
+def _small_net(meta):
+    from micronet_amd.models import nin_gc
+    from micronet_amd.train import init_like_main
+    torch.manual_seed(1)
+    return init_like_main(nin_gc.Net(cfg=meta["cfg"]))
+
+
+def _rel(a, ref):
+    import numpy as np
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.mark.parametrize("W", [3, 2])
+def test_wbwtab_bn_fused_graph_vs_reference_golden(W):
+    """micronet_amd.inference.wbwtab_model_bn_fuse on the state the reference trained: the same module kinds per conv, every folded weight / bias equal to the
+    reference's fold (<= 1e-6: the same few fp32 ops), and the folded graph run on the gfx950 kernels stage by stage ON THE REFERENCE'S OWN stage inputs --
+    +-1 outputs equal except at sign ties of the reference's pre-activation, logits within float round-off of the last (fp32) conv."""
+    import numpy as np
+    from micronet_amd import inference
+    from oracle import torch_oracle as TO
+    from micronet_amd.train import synth_batch
+    Q = importlib.import_module("micronet.compression.quantization.wbwtab.quantize")
+    g, meta = _inference_golden()
+    key = "inf_wbwtab_w%d" % W
+    I = Q.prepare(_small_net(meta), inplace=True, A=2, W=W, quant_inference=True)
+    I.load_state_dict({k[len(key) + 9:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(key + "_trained_")})
+    F = inference.wbwtab_model_bn_fuse(I.cuda(), W=W).eval()
+    convs = [(n_, m) for n_, m in F.named_modules() if isinstance(m, torch.nn.Conv2d)]
+    assert [n_ for n_, _ in convs] == [n_ for n_, _ in meta["cases"][key]["convs"]]
+    assert ["QuantConv2d" if isinstance(m, Q.QuantConv2d) else "Conv2d" for _, m in convs] == [t for _, t in meta["cases"][key]["convs"]]
+    for n_, m in convs:
+        assert _rel(m.weight, g[f"{key}_fused_{n_}_weight"]) <= 1e-6 and _rel(m.bias, g[f"{key}_fused_{n_}_bias"]) <= 1e-6, n_
+    # the oracle's folded graph (pinned bit for bit to the reference's in tests/test_oracle_golden.py) supplies every stage's input / output on the CPU
+    orc = TO.prepare(_small_net(meta), "wbwtab", inplace=True, A=2, W=W)
+    orc.load_state_dict({k[len(key) + 9:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(key + "_trained_")})
+    OF = TO.bn_fuse_wbwtab(orc, W).eval()
+    x, _ = synth_batch(4)
+    with torch.no_grad():
+        t = x
+        for i, (so, sp) in enumerate(zip(OF.model, F.model)):
+            ref = so(t)
+            got = sp(t.cuda())
+            got = got.to_float() if hasattr(got, "to_float") else got
+            if bool(((ref == 1) | (ref == -1)).all()):
+                bad = (got.cpu() != ref)
+                assert float(bad.float().mean()) <= 2e-4, (i, float(bad.float().mean()))         # sign ties of a pre-activation within round-off of 0
+            else:
+                assert _rel(got, ref.double().numpy()) <= 1e-5, (i, _rel(got, ref.double().numpy()))
+            t = ref
+        assert np.array_equal(OF(x).numpy(), g[f"{key}_fused_logits"])
+        lg = F(x.cuda())
+        assert bool((lg.argmax(1).cpu() == torch.from_numpy(g[f"{key}_fused_logits"]).argmax(1)).float().mean() >= 0.75)
+
+
+def test_iao_bn_fused_graph_vs_reference_golden():
+    """micronet_amd.inference.iao_model_bn_fuse on the state the reference trained: folded weights / biases and the copied quantizer scales equal the reference's,
+    every stage of the folded graph on the reference's own stage input within 1e-5 (8-bit activation codes flip only at rounding ties: <= 1e-4 of the elements may
+    differ by one step)."""
+    import numpy as np
+    from micronet_amd import inference
+    from oracle import torch_oracle as TO
+    from micronet_amd.train import synth_batch
+    Q = importlib.import_module("micronet.compression.quantization.wqaq.iao.quantize")
+    g, meta = _inference_golden()
+    key = "inf_iao_w8a8"
+    kw = dict(a_bits=8, w_bits=8, q_type=0, q_level=0)
+    T = Q.prepare(_small_net(meta), inplace=True, bn_fuse=True, **kw)
+    T.load_state_dict({k[len(key) + 9:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(key + "_trained_")})
+    F = inference.iao_model_bn_fuse(T.cuda()).eval()
+    convs = [(n_, m) for n_, m in F.named_modules() if isinstance(m, torch.nn.Conv2d)]
+    assert [n_ for n_, _ in convs] == [n_ for n_, _ in meta["cases"][key]["convs"]] and all(type(m) is Q.QuantConv2d and m.quant_inference for _, m in convs)
+    for n_, m in convs:
+        assert _rel(m.weight, g[f"{key}_fused_{n_}_weight"]) <= 1e-6 and _rel(m.bias, g[f"{key}_fused_{n_}_bias"]) <= 1e-6, n_
+        assert np.array_equal(m.activation_quantizer.scale.cpu().numpy().reshape(-1), g[f"{key}_fused_{n_}_ascale"].reshape(-1))
+        assert np.array_equal(m.weight_quantizer.scale.cpu().numpy().reshape(-1), g[f"{key}_fused_{n_}_wscale"].reshape(-1))
+    orc = TO.prepare(_small_net(meta), "iao", inplace=True, bn_fuse=True, **kw)
+    sd = {k[len(key) + 9:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(key + "_trained_")}
+    ren = lambda k: k.replace("activation_quantizer.", "aq.").replace("weight_quantizer.", "wq.").replace("quant_min_val", "qmin").replace("quant_max_val", "qmax")
+    missing = orc.load_state_dict({ren(k): v for k, v in sd.items()}, strict=False)
+    assert not [k for k in missing.missing_keys if not k.endswith(("qmin", "qmax"))], missing
+    OF = TO.bn_fuse_iao(orc).eval()
+    x, _ = synth_batch(4)
+    with torch.no_grad():
+        assert np.array_equal(OF(x).numpy(), g[f"{key}_fused_logits"])
+        t = x
+        for i, (so, sp) in enumerate(zip(OF.model, F.model)):
+            ref = so(t)
+            got = sp(t.cuda()).cpu()
+            d = (got - ref).abs() / ref.abs().max().clamp_min(1e-30)
+            assert float((d > 1e-5).float().mean()) <= 1e-4 and float(d.max()) <= 2e-2, (i, float(d.max()), float((d > 1e-5).float().mean()))
+            t = ref
