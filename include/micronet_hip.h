@@ -541,25 +541,30 @@ int mn_iao_bnfold_bwd(const float* dwf, const float* dbf, const float* w, const 
  * per-channel sums sx[c] = sum_p x[c,p] and the Gram matrix gram[g][c][c'] = sum_p x[c,p] x[c',p] of each group's input channels (logical, i.e. post-shuffle,
  * channel order), accumulated on the matrix cores in fp32 over <= 2048 pixels per partial and combined in fp64:
  *   mn_iaobf_gram      x -> gram [G][Cg][Cg], sx [G * Cg] (fp64).
- *   mn_iaobf_prep_fwd  ONE launch for: batch statistics (from gram / sx, or given as stats_in [2][O] for other geometries), running statistics (856-879; first_bn:
- *                      the copy of the first forward of a non-pretrained net), the fold w_f = w * gamma / sqrt(var + eps), bias_f = beta + (bias - mean) * ...
- *                      (881-901), the per-channel weight observer + update_qparams + fake-quant (945 with 15-36 / 62-74 / 101-113, 293-321, 227-239).
- *                      Outputs: stats [2][O] = mean, var; kfold [O]; bias_f [O]; qw [O][K] = the fake-quantised folded weights; qp [O][4].
+ *   mn_iaobf_gram_stats  statistics of the raw convolution's output from the Gram data, no pass over any activation: stats [2][O] = mean[o] = W[o,:] . x_bar + b[o]
+ *                      and the unbiased var[o] = W[o,:] S W[o,:]^T / (n - 1) (S = gram - n x_bar x_bar^T), plus vc [O][Cg] = W S for the backward.
+ *   mn_iaobf_prep_fwd  ONE launch for: running statistics from stats_in [2][O] (856-879; first_bn: the copy of the first forward of a non-pretrained net; stats_in =
+ *                      mn_iaobf_gram_stats' output, or mn_bn_stats_fwd of a materialised raw output for other geometries), the fold w_f = w * gamma / sqrt(var + eps),
+ *                      bias_f = beta + (bias - mean) * ... (881-901), the per-channel weight observer + update_qparams + fake-quant (945 with 15-36 / 62-74 / 101-113,
+ *                      293-321, 227-239).  Outputs: stats [2][O] = mean, var; kfold [O]; bias_f [O]; qw [O][K] = the fake-quantised folded weights; qp [O][4].
  *   mn_iaobf_prep_bwd  ONE launch for: the weight quantizer's clip-STE on dwq (gradient w.r.t. qw), the fold's backward (dgamma, dbeta, dbias), dmean / dvar and
- *                      coef [4][O] = {dmean / n, 2 dvar / (n - 1), dmean, dvar}; with gram != NULL also the raw convolution's weight gradient, so that dw is complete;
- *                      with gram == NULL dw holds the quantised path only and the caller adds the raw conv's backward-weight of d y_raw = coef0 + coef1 (y - mean).
+ *                      coef [4][O] = {dmean / n, 2 dvar / (n - 1), dmean, dvar}; with vc != NULL (pointwise: mn_iaobf_gram_stats' vc, and sx) also the raw
+ *                      convolution's weight gradient dmean x_bar + coef1 vc, so that dw is complete; with vc == NULL dw holds the quantised path only and the caller
+ *                      adds the raw conv's backward-weight of d y_raw = coef0 + coef1 (y - mean).
  *   mn_iaobf_bwd_data  dx = STE_x(W_q^T gy) + W^T d y_raw, the second term evaluated as M (x - x_bar) + v with M = W^T diag(coef1) W inside the same kernel
  *                      (no raw convolution output exists); relu_mask != 0: x is the output of a ReLU whose backward mask [x > 0] is applied to dx here.
  *                      gy must already carry the block's own ReLU mask.  aq: the activation quantizer snapshot (MN_ACTQ_IAO); wqp = qp of prep_fwd. */
 int mn_iaobf_gram_supported(const mn_conv_geom* g);
 int64_t mn_iaobf_gram_ws_bytes(const mn_conv_geom* g);
 int mn_iaobf_gram(const mn_conv_geom* g, const float* x, double* gram, double* sx, void* ws, int64_t ws_bytes, mn_stream_t stream);
-int mn_iaobf_prep_fwd(const float* w, const float* bias, const float* gamma, const float* beta, int64_t O, int64_t K, int64_t groups, const double* gram,
-                      const double* sx, const float* stats_in, double n, float eps, float momentum, int first_bn, float* running_mean, float* running_var,
+int mn_iaobf_gram_stats(const float* w, const float* bias, const double* gram, const double* sx, int64_t O, int64_t Cg, int64_t groups, double n, float* stats, float* vc,
+                        mn_stream_t stream);
+int mn_iaobf_prep_fwd(const float* w, const float* bias, const float* gamma, const float* beta, int64_t O, int64_t K, const float* stats_in, float eps, float momentum,
+                      int first_bn, float* running_mean, float* running_var,
                       int w_bits, int w_qtype, int w_obs_kind, int first_w, double momentum_w, float* wmin, float* wmax, float* wscale, float* wzp,
                       float* stats, float* kfold, float* bias_f, float* qw, float* qp, mn_stream_t stream);
 int mn_iaobf_prep_bwd(const float* dwq, const float* dbf, const float* w, const float* bias, const float* gamma, const float* stats, const float* qp,
-                      int64_t O, int64_t K, int64_t groups, const double* gram, const double* sx, double n, float eps, int w_bits, int w_qtype, float* dw,
+                      int64_t O, int64_t K, int64_t groups, const float* vc, const double* sx, double n, float eps, int w_bits, int w_qtype, float* dw,
                       float* dbias, float* dgamma, float* dbeta, float* coef, mn_stream_t stream);
 int mn_iaobf_bwd_data_supported(const mn_conv_geom* g);
 int64_t mn_iaobf_bwd_data_ws_bytes(const mn_conv_geom* g);

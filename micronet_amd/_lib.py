@@ -183,7 +183,8 @@ PROTOTYPES = {
     "mn_iaobf_gram_supported": (_I, [_G]),
     "mn_iaobf_gram_ws_bytes": (_L, [_G]),
     "mn_iaobf_gram": (_I, [_G, _P, _P, _P, _P, _L, _P]),
-    "mn_iaobf_prep_fwd": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _D, C.c_float, C.c_float, _I, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mn_iaobf_gram_stats": (_I, [_P, _P, _P, _P, _L, _L, _L, _D, _P, _P, _P]),
+    "mn_iaobf_prep_fwd": (_I, [_P, _P, _P, _P, _L, _L, _P, C.c_float, C.c_float, _I, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mn_iaobf_prep_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P, _P, _D, C.c_float, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mn_iaobf_bwd_data_supported": (_I, [_G]),
     "mn_iaobf_bwd_data_ws_bytes": (_L, [_G]),

@@ -235,43 +235,97 @@ extern "C" int mn_iaobf_gram(const mn_conv_geom* g, const float* x, double* gram
     return MN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ statistics of the raw convolution's output from the Gram data
+// A block owns BF_GS_CH output channels of one group: mean[o] = W[o,:] . x_bar + b[o],  Vc[o,:] = W[o,:] S (S = G - n x_bar x_bar^T, the centred second moment),
+// var[o] = Vc[o,:] . W[o,:] / (n - 1), everything in fp64; Vc (rounded to fp32: it is the centred quantity, no cancellation left) is kept for the backward, where
+// the raw convolution's weight gradient is dmean x_bar + B Vc.  G is read once per BF_GS_CH channels (a block per channel re-read all of it: 128 KB x O).
+#define BF_GS_CH 8
+__global__ __launch_bounds__(128) void k_bf_gram_stats(const float* __restrict__ w, const float* __restrict__ bias, const double* __restrict__ gram,
+                                                       const double* __restrict__ sx, int O, int Mg, int Cg, double n, float* __restrict__ stats,
+                                                       float* __restrict__ vc) {
+    __shared__ float ws[BF_GS_CH][128];
+    __shared__ double red[BF_GS_CH][2][2];
+    const int nb = (Mg + BF_GS_CH - 1) / BF_GS_CH;
+    const int g = blockIdx.x / nb, o0 = g * Mg + (blockIdx.x % nb) * BF_GS_CH;
+    const int tid = threadIdx.x;
+    const double* __restrict__ G = gram + (int64_t)g * Cg * Cg;
+    const double* __restrict__ sxg = sx + (int64_t)g * Cg;
+    int nch = Mg - (blockIdx.x % nb) * BF_GS_CH;
+    nch = nch < BF_GS_CH ? nch : BF_GS_CH;
+    for (int k = 0; k < BF_GS_CH; ++k) ws[k][tid] = (k < nch && tid < Cg) ? w[(int64_t)(o0 + k) * Cg + tid] : 0.f;
+    __syncthreads();
+    double acc[BF_GS_CH], m1p[BF_GS_CH];
+#pragma unroll
+    for (int k = 0; k < BF_GS_CH; ++k) { acc[k] = 0.0; m1p[k] = 0.0; }
+    const double xbi = tid < Cg ? sxg[tid] / n : 0.0;
+    if (tid < Cg) {
+        for (int c = 0; c < Cg; ++c) {
+            const double gv = G[(int64_t)c * Cg + tid];
+#pragma unroll
+            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (double)ws[k][c] * gv;
+        }
+#pragma unroll
+        for (int k = 0; k < BF_GS_CH; ++k) m1p[k] = (double)ws[k][tid] * xbi;
+    }
+    // m1[k] = sum_i w[k][i] x_bar[i] (wave shuffles, two waves through LDS)
+#pragma unroll
+    for (int k = 0; k < BF_GS_CH; ++k) {
+        double v = m1p[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) red[k][tid >> 6][0] = v;
+    }
+    __syncthreads();
+    double qp_[BF_GS_CH];
+#pragma unroll
+    for (int k = 0; k < BF_GS_CH; ++k) {
+        const double m1 = red[k][0][0] + red[k][1][0];
+        const double vcv = acc[k] - n * m1 * xbi;          // centred: (W S)[o, i]
+        if (k < nch && tid < Cg) vc[(int64_t)(o0 + k) * Cg + tid] = (float)vcv;
+        qp_[k] = tid < Cg ? vcv * (double)ws[k][tid] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < BF_GS_CH; ++k) {
+        double v = qp_[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) red[k][tid >> 6][1] = v;
+    }
+    __syncthreads();
+    if (tid < nch) {
+        const int k = tid;
+        const double m1 = red[k][0][0] + red[k][1][0], q = red[k][0][1] + red[k][1][1];
+        stats[o0 + k] = (float)(m1 + (bias ? (double)bias[o0 + k] : 0.0));
+        stats[O + o0 + k] = (float)(q / (n - 1.0));
+    }
+}
+extern "C" int mn_iaobf_gram_stats(const float* w, const float* bias, const double* gram, const double* sx, int64_t O, int64_t Cg, int64_t groups, double n, float* stats,
+                                   float* vc, mn_stream_t stream) {
+    if (!w || !gram || !sx || !stats || !vc || O <= 0 || Cg <= 0 || Cg > 128 || groups < 1 || O % groups || !(n > 1.0)) MN_FAIL(MN_EINVAL, "mn_iaobf_gram_stats: bad arguments");
+    const int Mg = (int)(O / groups), nb = (Mg + BF_GS_CH - 1) / BF_GS_CH;
+    mn_set_last_kernel("k_bf_gram_stats");
+    hipLaunchKernelGGL(k_bf_gram_stats, dim3((unsigned)(groups * nb)), dim3(128), 0, (hipStream_t)stream, w, bias, gram, sx, (int)O, Mg, (int)Cg, n, stats, vc);
+    MN_CHECK_LAUNCH("mn_iaobf_gram_stats");
+    return MN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ forward preparation of a layer: one launch, one block per out-channel
 struct PrepFwd {
     const float* w; const float* bias; const float* gamma; const float* beta;
-    const double* gram; const double* sx;     // statistics source A: Gram data of the layer's input ([G][Cg][Cg], [G * Cg]); pointwise only
-    const float* stats_in;                    // statistics source B: [2][O] = mean, unbiased var of the raw conv output (any geometry)
+    const float* stats_in;                    // [2][O] = mean, unbiased var of the raw conv output: mn_bn_stats_fwd on y_raw, or mn_iaobf_gram_stats (pointwise, no y_raw)
     float* running_mean; float* running_var;
     float* wmin; float* wmax; float* wscale; float* wzp;       // the per-channel ('C') or per-layer weight quantizer's buffers
     float* stats; float* kfold; float* bias_f; float* qw; float* qp;
-    int O, K, Mg, Cg, per_channel, first_bn, first_w, obs_kind, q_type;
+    int O, K, per_channel, first_bn, first_w, obs_kind, q_type;
     float eps, momentum, quant_range, qmin, qmax;
-    double momentum_w, n;
+    double momentum_w;
 };
 __global__ __launch_bounds__(256) void k_bf_prep_fwd(const PrepFwd p) {
-    __shared__ double scd[16];
     __shared__ float scf[16];
     __shared__ float sh[4];
     const int o = blockIdx.x, tid = threadIdx.x;
     const float* __restrict__ wr = p.w + (int64_t)o * p.K;
-    float mean, var;
-    if (p.gram) {
-        const int g = o / p.Mg;
-        const double* __restrict__ G = p.gram + (int64_t)g * p.Cg * p.Cg;
-        const double* __restrict__ sxg = p.sx + (int64_t)g * p.Cg;
-        double m1 = 0.0, q = 0.0;
-        for (int c = tid; c < p.Cg; c += 256) m1 += (double)wr[c] * (sxg[c] / p.n);
-        for (int i = tid; i < p.Cg * p.Cg; i += 256) {
-            const int c = i / p.Cg, c2 = i - c * p.Cg;
-            q += (double)wr[c] * G[i] * (double)wr[c2];
-        }
-        m1 = block_reduce(m1, OpAddD(), 0.0, scd);
-        q = block_reduce(q, OpAddD(), 0.0, scd);
-        mean = (float)(m1 + (p.bias ? (double)p.bias[o] : 0.0));
-        var = (float)((q - p.n * m1 * m1) / (p.n - 1.0));
-    } else {
-        mean = p.stats_in[o];
-        var = p.stats_in[p.O + o];
-    }
+    const float mean = p.stats_in[o], var = p.stats_in[p.O + o];
     // running statistics (ref 856-879): the first training forward of a net that is not pretrained copies the batch statistics
     if (tid == 0) {
         p.stats[o] = mean; p.stats[p.O + o] = var;
@@ -306,19 +360,18 @@ __global__ __launch_bounds__(256) void k_bf_prep_fwd(const PrepFwd p) {
         p.bias_f[o] = p.bias ? p.beta[o] + (p.bias[o] - mean) * kf : p.beta[o] - mean * kf;
     }
 }
-extern "C" int mn_iaobf_prep_fwd(const float* w, const float* bias, const float* gamma, const float* beta, int64_t O, int64_t K, int64_t groups, const double* gram,
-                                 const double* sx, const float* stats_in, double n, float eps, float momentum, int first_bn, float* running_mean, float* running_var,
+extern "C" int mn_iaobf_prep_fwd(const float* w, const float* bias, const float* gamma, const float* beta, int64_t O, int64_t K, const float* stats_in, float eps,
+                                 float momentum, int first_bn, float* running_mean, float* running_var,
                                  int w_bits, int w_qtype, int w_obs_kind, int first_w, double momentum_w, float* wmin, float* wmax, float* wscale, float* wzp,
                                  float* stats, float* kfold, float* bias_f, float* qw, float* qp, mn_stream_t stream) {
-    if (!w || !gamma || !beta || !running_mean || !running_var || !wmin || !wmax || !wscale || !wzp || !stats || !kfold || !bias_f || !qw || !qp || O <= 0 || K <= 0 ||
-        K > (1 << 20) || groups < 1 || O % groups || w_bits < 2 || w_bits > 24 || (w_qtype != 0 && w_qtype != 1) || (w_obs_kind != 0 && w_obs_kind != 1) || !(n > 1.0))
+    if (!w || !gamma || !beta || !stats_in || !running_mean || !running_var || !wmin || !wmax || !wscale || !wzp || !stats || !kfold || !bias_f || !qw || !qp || O <= 0 ||
+        K <= 0 || K > (1 << 20) || w_bits < 2 || w_bits > 24 || (w_qtype != 0 && w_qtype != 1) || (w_obs_kind != 0 && w_obs_kind != 1))
         MN_FAIL(MN_EINVAL, "mn_iaobf_prep_fwd: bad arguments");
-    if ((gram == nullptr) == (stats_in == nullptr) || (gram && !sx)) MN_FAIL(MN_EINVAL, "mn_iaobf_prep_fwd: exactly one statistics source (gram + sx, or stats_in)");
     PrepFwd p;
-    p.w = w; p.bias = bias; p.gamma = gamma; p.beta = beta; p.gram = gram; p.sx = sx; p.stats_in = stats_in; p.running_mean = running_mean; p.running_var = running_var;
+    p.w = w; p.bias = bias; p.gamma = gamma; p.beta = beta; p.stats_in = stats_in; p.running_mean = running_mean; p.running_var = running_var;
     p.wmin = wmin; p.wmax = wmax; p.wscale = wscale; p.wzp = wzp; p.stats = stats; p.kfold = kfold; p.bias_f = bias_f; p.qw = qw; p.qp = qp;
-    p.O = (int)O; p.K = (int)K; p.Mg = (int)(O / groups); p.Cg = (int)K; p.per_channel = 1; p.first_bn = first_bn; p.first_w = first_w; p.obs_kind = w_obs_kind;
-    p.q_type = w_qtype; p.eps = eps; p.momentum = momentum; p.momentum_w = momentum_w; p.n = n;
+    p.O = (int)O; p.K = (int)K; p.per_channel = 1; p.first_bn = first_bn; p.first_w = first_w; p.obs_kind = w_obs_kind;
+    p.q_type = w_qtype; p.eps = eps; p.momentum = momentum; p.momentum_w = momentum_w;
     const IaoRange r = iao_range(w_bits, w_qtype, 0);
     p.qmin = r.qmin; p.qmax = r.qmax;
     p.quant_range = (w_qtype == 0) ? (float)((double)(r.qmax - r.qmin) / 2.0) : (float)(r.qmax - r.qmin);
@@ -331,7 +384,7 @@ extern "C" int mn_iaobf_prep_fwd(const float* w, const float* bias, const float*
 // ------------------------------------------------------------------------------------------------ backward preparation: one launch, one block per out-channel
 struct PrepBwd {
     const float* dwq; const float* dbf; const float* w; const float* bias; const float* gamma; const float* stats; const float* qp;
-    const double* gram; const double* sx;
+    const float* vc; const double* sx;     // gram path: Vc = W S of mn_iaobf_gram_stats [O][Cg], channel sums
     float* dw; float* dbias; float* dgamma; float* dbeta; float* coef;       // coef [4][O] = {dmean / n, B = 2 dvar / (n - 1), dmean, dvar}
     int O, K, Mg, Cg;
     float eps, qmin, qmax;
@@ -350,7 +403,7 @@ __global__ __launch_bounds__(256) void k_bf_prep_bwd(const PrepBwd p) {
     double S = 0.0;
     for (int i = tid; i < p.K; i += 256) {
         const float gq = iao_fq_grad(gr[i], wr[i] * kf, s_, zp, lo, hi, p.qmin, p.qmax);
-        if (!p.gram) p.dw[(int64_t)o * p.K + i] = gq * kf;
+        if (!p.vc) p.dw[(int64_t)o * p.K + i] = gq * kf;
         S += (double)gq * (double)wr[i];
     }
     S = block_reduce(S, OpAddD(), 0.0, scd);
@@ -370,32 +423,26 @@ __global__ __launch_bounds__(256) void k_bf_prep_bwd(const PrepBwd p) {
         p.coef[3 * p.O + o] = dvar;
         shd[0] = (double)dmean; shd[1] = (double)(dvar * 2.f / (nf - 1.f));
     }
-    if (!p.gram) return;
+    if (!p.vc) return;
     __syncthreads();
-    // raw-path weight gradient from the Gram data: dmean x_bar + B (W[o,:] G - n (W[o,:] . x_bar) x_bar)
+    // raw-path weight gradient from the Gram data: dmean x_bar + B (W[o,:] S), the second factor kept from the forward (mn_iaobf_gram_stats)
     const int g = o / p.Mg;
-    const double* __restrict__ G = p.gram + (int64_t)g * p.Cg * p.Cg;
     const double* __restrict__ sxg = p.sx + (int64_t)g * p.Cg;
-    double m1 = 0.0;
-    for (int c = tid; c < p.Cg; c += 256) m1 += (double)wr[c] * (sxg[c] / p.n);
-    m1 = block_reduce(m1, OpAddD(), 0.0, scd);
     const double dmean = shd[0], B = shd[1];
     for (int i = tid; i < p.Cg; i += 256) {
-        double t = 0.0;
-        for (int c = 0; c < p.Cg; ++c) t += (double)wr[c] * G[(int64_t)c * p.Cg + i];
         const double xb = sxg[i] / p.n;
         const float gq = iao_fq_grad(gr[i], wr[i] * kf, s_, zp, lo, hi, p.qmin, p.qmax);
-        p.dw[(int64_t)o * p.K + i] = (float)((double)(gq * kf) + dmean * xb + B * (t - p.n * m1 * xb));
+        p.dw[(int64_t)o * p.K + i] = (float)((double)(gq * kf) + dmean * xb + B * (double)p.vc[(int64_t)o * p.Cg + i]);
     }
 }
 extern "C" int mn_iaobf_prep_bwd(const float* dwq, const float* dbf, const float* w, const float* bias, const float* gamma, const float* stats, const float* qp,
-                                 int64_t O, int64_t K, int64_t groups, const double* gram, const double* sx, double n, float eps, int w_bits, int w_qtype, float* dw,
+                                 int64_t O, int64_t K, int64_t groups, const float* vc, const double* sx, double n, float eps, int w_bits, int w_qtype, float* dw,
                                  float* dbias, float* dgamma, float* dbeta, float* coef, mn_stream_t stream) {
     if (!dwq || !dbf || !w || !gamma || !stats || !qp || !dw || !coef || O <= 0 || K <= 0 || K > (1 << 20) || groups < 1 || O % groups || w_bits < 2 || w_bits > 24 ||
-        (w_qtype != 0 && w_qtype != 1) || !(n > 1.0) || (gram && !sx))
+        (w_qtype != 0 && w_qtype != 1) || !(n > 1.0) || (vc && !sx))
         MN_FAIL(MN_EINVAL, "mn_iaobf_prep_bwd: bad arguments");
     PrepBwd p;
-    p.dwq = dwq; p.dbf = dbf; p.w = w; p.bias = bias; p.gamma = gamma; p.stats = stats; p.qp = qp; p.gram = gram; p.sx = sx;
+    p.dwq = dwq; p.dbf = dbf; p.w = w; p.bias = bias; p.gamma = gamma; p.stats = stats; p.qp = qp; p.vc = vc; p.sx = sx;
     p.dw = dw; p.dbias = dbias; p.dgamma = dgamma; p.dbeta = dbeta; p.coef = coef;
     p.O = (int)O; p.K = (int)K; p.Mg = (int)(O / groups); p.Cg = (int)K; p.eps = eps; p.n = n;
     const IaoRange r = iao_range(w_bits, w_qtype, 0);
@@ -636,39 +683,66 @@ struct BfMParams {
     int O, Cg, Mg, G, Mpad, KpA, KpB, wscale_stride;
     double n;
 };
+#define BF_M_ROWS 8
 __global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
-    const int g = blockIdx.x / p.Mpad, c = blockIdx.x % p.Mpad, tid = threadIdx.x;
-    const bool cv = c < p.Cg;
+    __shared__ float wcol[BF_M_ROWS][128];          // B[o] * W[o][c0 + r] for the block's rows
+    const int nrb = p.Mpad / BF_M_ROWS;
+    const int g = blockIdx.x / nrb, c0 = (blockIdx.x % nrb) * BF_M_ROWS, tid = threadIdx.x;
     const float* __restrict__ wg = p.w + (int64_t)g * p.Mg * p.Cg;
     const float* __restrict__ B = p.coef + p.O + g * p.Mg;
+    const float* __restrict__ A = p.coef + g * p.Mg;
+    // M[c][c2] = sum_o B[o] W[o][c] W[o][c2] (fp64), BF_M_ROWS rows c per block: W is read once per BF_M_ROWS rows
+    double m[BF_M_ROWS];
+#pragma unroll
+    for (int r = 0; r < BF_M_ROWS; ++r) m[r] = 0.0;
+    double vsum = 0.0;          // thread r < BF_M_ROWS: v[c0 + r] = sum_o (dmean[o] / n) W[o][c0 + r]
+    for (int ob = 0; ob < p.Mg; ob += 128) {
+        __syncthreads();
+        for (int r = 0; r < BF_M_ROWS; ++r) {
+            const int o = ob + tid;
+            wcol[r][tid] = (o < p.Mg && c0 + r < p.Cg) ? wg[(int64_t)o * p.Cg + c0 + r] : 0.f;
+        }
+        __syncthreads();
+        const int no = p.Mg - ob < 128 ? p.Mg - ob : 128;
+        if (tid < p.KpB && tid < p.Cg) {
+            for (int oo = 0; oo < no; ++oo) {
+                const double wv = (double)B[ob + oo] * (double)wg[(int64_t)(ob + oo) * p.Cg + tid];
+#pragma unroll
+                for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (double)wcol[r][oo];
+            }
+        }
+        if (tid < BF_M_ROWS)
+            for (int oo = 0; oo < no; ++oo) vsum += (double)A[ob + oo] * (double)wcol[tid][oo];
+    }
+    const int64_t plane = (int64_t)p.G * p.Mpad * p.KpB;
     for (int c2 = tid; c2 < p.KpB; c2 += 128) {
-        double m = 0.0;
-        if (cv && c2 < p.Cg)
-            for (int o = 0; o < p.Mg; ++o) m += (double)B[o] * (double)wg[(int64_t)o * p.Cg + c] * (double)wg[(int64_t)o * p.Cg + c2];
-        const float v = (float)m;
-        const float t0 = mn_bf16_head(v), r1 = v - t0, t1 = mn_bf16_head(r1), t2 = r1 - t1;
-        const int64_t at = ((int64_t)g * p.Mpad + c) * p.KpB + c2, plane = (int64_t)p.G * p.Mpad * p.KpB;
-        p.mt[at] = (uint16_t)(mn_f2u(t0) >> 16);
-        p.mt[plane + at] = (uint16_t)(mn_f2u(t1) >> 16);
-        p.mt[2 * plane + at] = (uint16_t)(mn_f2u(t2) >> 16);
+#pragma unroll
+        for (int r = 0; r < BF_M_ROWS; ++r) {
+            const float v = (c2 == tid && c2 < p.Cg && c0 + r < p.Cg) ? (float)m[r] : 0.f;
+            const float t0 = mn_bf16_head(v), r1 = v - t0, t1 = mn_bf16_head(r1), t2 = r1 - t1;
+            const int64_t at = ((int64_t)g * p.Mpad + c0 + r) * p.KpB + c2;
+            p.mt[at] = (uint16_t)(mn_f2u(t0) >> 16);
+            p.mt[plane + at] = (uint16_t)(mn_f2u(t1) >> 16);
+            p.mt[2 * plane + at] = (uint16_t)(mn_f2u(t2) >> 16);
+        }
     }
     // transposed codes of the quantised weights: code = rha(qw / scale[o]) (exact small integers)
-    for (int o = tid; o < p.KpA; o += 128) {
-        float code = 0.f;
-        if (cv && o < p.Mg) {
-            const int oo = g * p.Mg + o;
-            code = mn_rha(p.qw[(int64_t)oo * p.Cg + c] / p.wscale[(int64_t)oo * p.wscale_stride]);
+    for (int r = 0; r < BF_M_ROWS; ++r) {
+        const int c = c0 + r;
+        for (int o = tid; o < p.KpA; o += 128) {
+            float code = 0.f;
+            if (c < p.Cg && o < p.Mg) {
+                const int oo = g * p.Mg + o;
+                code = mn_rha(p.qw[(int64_t)oo * p.Cg + c] / p.wscale[(int64_t)oo * p.wscale_stride]);
+            }
+            p.wc[((int64_t)g * p.Mpad + c) * p.KpA + o] = (uint16_t)(mn_f2u(code) >> 16);
         }
-        p.wc[((int64_t)g * p.Mpad + c) * p.KpA + o] = (uint16_t)(mn_f2u(code) >> 16);
     }
-    if (c == 0)
+    if (c0 == 0)
         for (int o = tid; o < p.KpA; o += 128) p.kscale[g * p.KpA + o] = o < p.Mg ? p.wscale[(int64_t)(g * p.Mg + o) * p.wscale_stride] : 0.f;
-    if (cv && tid == 0) {
-        double v = 0.0;
-        const float* A = p.coef + g * p.Mg;
-        for (int o = 0; o < p.Mg; ++o) v += (double)A[o] * (double)wg[(int64_t)o * p.Cg + c];
-        p.vadd[g * p.Cg + c] = (float)v;
-        p.xbar[g * p.Cg + c] = (float)(p.sx[g * p.Cg + c] / p.n);
+    if (tid < BF_M_ROWS && c0 + tid < p.Cg) {
+        p.vadd[g * p.Cg + c0 + tid] = (float)vsum;
+        p.xbar[g * p.Cg + c0 + tid] = (float)(p.sx[g * p.Cg + c0 + tid] / p.n);
     }
 }
 
@@ -725,7 +799,7 @@ extern "C" int mn_iaobf_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const
     m.mt = (uint16_t*)ws; m.wc = (uint16_t*)((char*)ws + pl.off_wc); m.kscale = (float*)((char*)ws + pl.off_ks);
     m.xbar = (float*)((char*)ws + pl.off_xbar); m.vadd = (float*)((char*)ws + pl.off_v);
     m.O = g->O; m.Cg = p.Cg; m.Mg = p.Mg; m.G = p.G; m.Mpad = p.Mpad; m.KpA = p.KpA; m.KpB = p.KpB; m.n = (double)g->N * g->H * g->W;
-    hipLaunchKernelGGL(k_bf_M, dim3((unsigned)(p.G * p.Mpad)), dim3(128), 0, s, m);
+    hipLaunchKernelGGL(k_bf_M, dim3((unsigned)(p.G * p.Mpad / BF_M_ROWS)), dim3(128), 0, s, m);
     const IaoRange r = iao_range(aq->bits, aq->q_type, 1);
     p.gy = gy; p.x = x; p.dx = dx; p.wc = m.wc; p.kscale = m.kscale; p.mt = m.mt; p.xbar = m.xbar; p.vadd = m.vadd; p.qp = aq->qp; p.qmin = r.qmin; p.qmax = r.qmax;
     p.relu_mask = relu_mask;

@@ -631,7 +631,10 @@ class IaoBNFusePW(Function):
             stats = torch.empty((2, O), dtype=torch.float32, device=dev)
             kfold, bias_f = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
             qw, wqp = torch.empty_like(weight), torch.empty((O, 4), dtype=torch.float32, device=dev)
-            _call("mn_iaobf_prep_fwd", _p(weight), _p(bias), _p(gamma), _p(beta), O, Cg, g.groups, _p(gram), _p(sx), None, n, float(st.eps), float(st.momentum),
+            stats_raw = torch.empty((2, O), dtype=torch.float32, device=dev)
+            vc = torch.empty((O, Cg), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_gram_stats", _p(weight), _p(bias), _p(gram), _p(sx), O, Cg, g.groups, n, _p(stats_raw), _p(vc), _s())
+            _call("mn_iaobf_prep_fwd", _p(weight), _p(bias), _p(gamma), _p(beta), O, Cg, _p(stats_raw), float(st.eps), float(st.momentum),
                   int(first_bn), _p(st.running_mean), _p(st.running_var), wq_.bits, wq_._q_type_static, wobs._kind, int(first_w), float(getattr(wobs, "momentum", 0.1)),
                   _p(wobs.min_val), _p(wobs.max_val), _p(wq_.scale), _p(wq_.zero_point), _p(stats), _p(kfold), _p(bias_f), _p(qw), _p(wqp), _s())
             if first_w:
@@ -648,7 +651,7 @@ class IaoBNFusePW(Function):
                 mm = torch.empty(2 * count, dtype=torch.float32, device=dev)
             wsf, nbf = _ws(g, 0, dev)
             _call("mn_conv2d_fwd_act", C.byref(g), C.byref(aq), C.byref(wd), _p(x), _p(qw), _p(bias_f), _p(a), int(relu), _p(mm), _p(wsf), nbf, _s())
-        ctx.save_for_backward(x, weight, bias, gamma, a if relu else None, stats, qw, wqp, aqp, gram, sx)
+        ctx.save_for_backward(x, weight, bias, gamma, a if relu else None, stats, qw, wqp, aqp, vc, sx)
         ctx.cfg = (g, aq_.bits, aq_.q_type, wq_.bits, wq_._q_type_static, float(st.eps), n, bool(relu))
         ctx.tok_in = getattr(x, "_mn_relu_token", None)          # the ReLU in FRONT of this block (its producer's token)
         ctx.x_obj = x
@@ -667,7 +670,7 @@ class IaoBNFusePW(Function):
 
     @staticmethod
     def backward(ctx, gin):
-        x, weight, bias, gamma, a, stats, qw, wqp, aqp, gram, sx = ctx.saved_tensors
+        x, weight, bias, gamma, a, stats, qw, wqp, aqp, vc, sx = ctx.saved_tensors
         g, a_bits, a_qtype, w_bits, w_qtype, eps, n, relu = ctx.cfg
         lib = _lib_()
         dev = x.device
@@ -686,7 +689,7 @@ class IaoBNFusePW(Function):
             dbias = torch.empty(O, dtype=torch.float32, device=dev) if bias is not None else None
             dgamma, dbeta = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
             coef = torch.empty((4, O), dtype=torch.float32, device=dev)
-            _call("mn_iaobf_prep_bwd", _p(dwq), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(stats), _p(wqp), O, Cg, g.groups, _p(gram), _p(sx), n, eps, w_bits, w_qtype,
+            _call("mn_iaobf_prep_bwd", _p(dwq), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(stats), _p(wqp), O, Cg, g.groups, _p(vc), _p(sx), n, eps, w_bits, w_qtype,
                   _p(dw), _p(dbias), _p(dgamma), _p(dbeta), _p(coef), _s())
             if ctx.needs_input_grad[0]:
                 pre = ctx.tok_in is not None and relu_premask_ok(ctx.x_obj)
@@ -788,7 +791,7 @@ class IaoBNFuseGeneric(Function):
             stats = torch.empty((2, O), dtype=torch.float32, device=dev)
             kfold, bias_f = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
             qw, wqp = torch.empty_like(weight), torch.empty((O, 4), dtype=torch.float32, device=dev)
-            _call("mn_iaobf_prep_fwd", _p(weight), _p(bias), _p(gamma), _p(beta), O, K, g.groups, None, None, _p(stats_raw), n, float(st.eps), float(st.momentum),
+            _call("mn_iaobf_prep_fwd", _p(weight), _p(bias), _p(gamma), _p(beta), O, K, _p(stats_raw), float(st.eps), float(st.momentum),
                   int(first_bn), _p(st.running_mean), _p(st.running_var), wq_.bits, wq_._q_type_static, wobs._kind, int(first_w), float(getattr(wobs, "momentum", 0.1)),
                   _p(wobs.min_val), _p(wobs.max_val), _p(wq_.scale), _p(wq_.zero_point), _p(stats), _p(kfold), _p(bias_f), _p(qw), _p(wqp), _s())
             if first_w:

@@ -114,7 +114,9 @@ def check_iaobf_pointwise(be, case, seed=0, nsteps=2, relu_mask=True):
         assert np.abs(sx_got - xg.sum(-1).reshape(-1).numpy()).max() <= 2e-6 * np.abs(xg.sum(-1)).max().item()
         # forward preparation
         stats, kfold, bias_f, qw, wqp = be.empty(2 * O), be.empty(O), be.empty(O), be.empty((O, Cg)), be.empty((O, 4))
-        be.call("mn_iaobf_prep_fwd", be.ptr(w), be.ptr(bias), be.ptr(gamma), be.ptr(beta), O, Cg, G, be.ptr(gram), be.ptr(sx), None, n, 1e-5, 0.1, first,
+        stats_raw, vc = be.empty(2 * O), be.empty((O, Cg))
+        be.call("mn_iaobf_gram_stats", be.ptr(w), be.ptr(bias), be.ptr(gram), be.ptr(sx), O, Cg, G, n, be.ptr(stats_raw), be.ptr(vc), be.stream)
+        be.call("mn_iaobf_prep_fwd", be.ptr(w), be.ptr(bias), be.ptr(gamma), be.ptr(beta), O, Cg, be.ptr(stats_raw), 1e-5, 0.1, first,
                 be.ptr(rm), be.ptr(rv), 8, 0, 0, first, 0.1, be.ptr(wmin), be.ptr(wmax), be.ptr(wscale), be.ptr(wzp), be.ptr(stats), be.ptr(kfold), be.ptr(bias_f),
                 be.ptr(qw), be.ptr(wqp), be.stream)
         worst["rm%d" % it] = _close("running_mean", be.to_host(rm), r32[it]["rm"], r64[it]["rm"])
@@ -145,7 +147,7 @@ def check_iaobf_pointwise(be, case, seed=0, nsteps=2, relu_mask=True):
         wsw = be.empty(nbw // 4 + 4)
         be.call("mn_conv2d_bwd_weight", C.byref(geom), C.byref(aq), be.ptr(gy), be.ptr(x), be.ptr(dwq), be.ptr(dbf), be.ptr(wsw), nbw, 0, be.stream)
         dw, dbias, dgamma, dbeta, coef = be.empty((O, Cg)), (be.empty(O) if case["bias"] else None), be.empty(O), be.empty(O), be.empty(4 * O)
-        be.call("mn_iaobf_prep_bwd", be.ptr(dwq), be.ptr(dbf), be.ptr(w), be.ptr(bias), be.ptr(gamma), be.ptr(stats), be.ptr(wqp), O, Cg, G, be.ptr(gram), be.ptr(sx), n,
+        be.call("mn_iaobf_prep_bwd", be.ptr(dwq), be.ptr(dbf), be.ptr(w), be.ptr(bias), be.ptr(gamma), be.ptr(stats), be.ptr(wqp), O, Cg, G, be.ptr(vc), be.ptr(sx), n,
                 1e-5, 8, 0, be.ptr(dw), be.ptr(dbias), be.ptr(dgamma), be.ptr(dbeta), be.ptr(coef), be.stream)
         worst["dw%d" % it] = _close("dw", be.to_host(dw), r32[it]["dw"], r64[it]["dw"])
         worst["dgamma%d" % it] = _close("dgamma", be.to_host(dgamma), r32[it]["dgamma"], r64[it]["dgamma"])
