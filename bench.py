@@ -174,6 +174,20 @@ def measure(workload, args, world, rank, device):
         windows.append(dt)
     dt = sorted(windows)[len(windows) // 2]                 # the median window (an odd count by default)
     final_loss = float(loss.detach())
+    # data-parallel IAO models: the eager step (one blocking 2-float collective per activation quantizer, ~360 launches issued from Python) next to the graphed one,
+    # so that the cost of falling back to it is a number
+    eager_dp = None
+    if world > 1 and graphed is not None and getattr(graphed, "collectives_in_graph", False):
+        sync2 = dp.GradSync(model)
+        for _ in range(2):
+            dp.train_step_dp(model, opt, sync2, x, y)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dp.train_step_dp(model, opt, sync2, x, y)
+        barrier()
+        eager_dp = time.perf_counter() - t0
+        sync2.remove()
 
     # per-kernel HIP-event timing: the same step, same process, run eagerly right after the timed region (events cannot be
     # read back from inside a replayed graph); single-GPU runs only
@@ -193,7 +207,8 @@ def measure(workload, args, world, rank, device):
         graphed.finish()
     del graphed, model, opt, sync
     torch.cuda.empty_cache()
-    return dict(dt=dt, dt_min=min(windows), windows=windows, final_loss=final_loss, hip_graph=graph_err is None and not args.no_graph, graph_err=graph_err, agg=agg)
+    return dict(dt=dt, dt_min=min(windows), windows=windows, final_loss=final_loss, hip_graph=graph_err is None and not args.no_graph, graph_err=graph_err, agg=agg,
+                eager_dp=eager_dp)
 
 
 def section(workload, m, args, world, pmc):
@@ -206,6 +221,8 @@ def section(workload, m, args, world, pmc):
            "hip_graph": m["hip_graph"], "final_loss": round(m["final_loss"], 4)}
     if m["graph_err"]:
         out["hip_graph_error"] = m["graph_err"]
+    if m.get("eager_dp"):
+        out["eager_dp_value"] = round(args.batch * world * args.steps / m["eager_dp"], 1)
     agg = m["agg"]
     if agg:
         ks = args.kernel_steps
@@ -387,7 +404,7 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         s["metric"] = METRIC.get(w, "QAT images/sec (%s)" % w)
         s["steps"], s["warmup"], s["n_gpus"] = args.steps, args.warmup, world
         detail["sections"][w] = s
-        also_out[w] = {"value": s["value"], "ms_per_step": s["ms_per_step"], "hip_graph": s["hip_graph"],
+        also_out[w] = {"value": s["value"], "ms_per_step": s["ms_per_step"], "hip_graph": s["hip_graph"], **({"eager_dp_value": s["eager_dp_value"]} if "eager_dp_value" in s else {}),
                        **({"roofline": {k: s["roofline"][k] for k in ("bound", "kernel", "frac", "avg_launch_us", "traffic") if k in s["roofline"]}} if "roofline" in s else {})}
     for w, e in also_err.items():
         also_out[w] = {"error": e[:200]}
@@ -447,9 +464,11 @@ def main():
     primary = args.only or args.workload
     also = [] if args.only else [w for w in args.also.split(",") if w and w != primary]
     if args.gpus > 1 and args.also == ap.get_default("also"):
-        # multi-GPU runs measure the scaling of the headline step: by default only the two nin_gc schemes the metric names (same graphed data-parallel step);
-        # the other BASELINE configs are single-GPU lines (`also` of the --gpus 1 run) unless --also asks for them explicitly
-        also = [w for w in also if w == "c1_w2a2"]
+        # multi-GPU runs measure the scaling of the headline step: by default the two nin_gc schemes the metric names (same graphed data-parallel step), plus the
+        # BASELINE config that is DEFINED at this GPU count (configs[3]: resnet DoReFa W2A2 on 4 GPUs; configs[4]: resnet IAO W4A4 + quant_add on 8); the other
+        # configs are single-GPU lines (`also` of the --gpus 1 run) unless --also asks for them explicitly
+        keep = {"c1_w2a2"} | ({"c4"} if args.gpus == 4 else set()) | ({"c5"} if args.gpus == 8 else set())
+        also = [w for w in also if w in keep]
     for w in also:
         if w not in WORKLOADS:
             raise SystemExit("unknown workload in --also: %s" % w)

@@ -524,8 +524,32 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
             ooff[i] = (uint32_t)chan_phys(p.map, g * p.Cg + mc) * HW;
         }
     }
+    // The clip-STE of the activation quantizer as two thresholds on x: both of its conditions -- qmin <= rha(x / s - zp) <= qmax (the clamp of 232) and lo <= x / s - zp
+    // <= hi (Round.backward 163-168) -- are monotone in x (every fp32 step of the chain is), so the pass set is ONE interval [XL, XH] of floats.  Lane 0 finds its
+    // two ends by bisection over the ordered float keys with the exact expressions (2 x 33 evaluations per block); the epilogue then needs two compares per
+    // element instead of two IEEE divisions and a floor.  (NaN x: every compare fails, the gradient is dropped, as in the reference.)
+    float* xlh = reinterpret_cast<float*>(ooff + MB);
+    if (tid == 0) {
+        const float sc = p.qp[0], zp = p.qp[1], slo = p.qp[2], shi = p.qp[3];
+        auto key2f = [](uint32_t k) { return mn_u2f((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };          // ordered key -> float (0 = -NaN side ... 0xffffffff)
+        auto lower_ok = [&](float x) { const float v = x / sc - zp; const float r = mn_rha(v); return r >= p.qmin && !(v < slo); };
+        auto upper_ok = [&](float x) { const float v = x / sc - zp; const float r = mn_rha(v); return r <= p.qmax && !(v > shi); };
+        const uint32_t kmin = 0x007fffffu, kmax = 0xff800000u;          // keys of -inf and +inf
+        // XL = the smallest float in [-inf, +inf] with lower_ok (false ... true); XH = the largest with upper_ok (true ... false)
+        uint32_t lo_k = kmin, hi_k = kmax;
+        if (lower_ok(key2f(kmin))) hi_k = kmin;
+        else if (!lower_ok(key2f(kmax))) lo_k = hi_k = kmax;          // nothing passes
+        else while (hi_k - lo_k > 1u) { const uint32_t mid = lo_k + ((hi_k - lo_k) >> 1); if (lower_ok(key2f(mid))) hi_k = mid; else lo_k = mid; }
+        const float XL = lower_ok(key2f(hi_k)) ? key2f(hi_k) : INFINITY;
+        lo_k = kmin; hi_k = kmax;
+        if (upper_ok(key2f(kmax))) lo_k = kmax;
+        else if (!upper_ok(key2f(kmin))) lo_k = hi_k = kmin;
+        else while (hi_k - lo_k > 1u) { const uint32_t mid = lo_k + ((hi_k - lo_k) >> 1); if (upper_ok(key2f(mid))) lo_k = mid; else hi_k = mid; }
+        const float XH = upper_ok(key2f(lo_k)) ? key2f(lo_k) : -INFINITY;
+        xlh[0] = XL; xlh[1] = XH;
+    }
     __syncthreads();
-    const float sc = p.qp[0], zp = p.qp[1], slo = p.qp[2], shi = p.qp[3];
+    const float XL = xlh[0], XH = xlh[1], ssc = p.qp[0];
 
     const int chunk0 = cb * 4 + wave, cstride = p.CB * 4;
     const int my_chunks = chunk0 < p.nchunks ? (p.nchunks - chunk0 + cstride - 1) / cstride : 0;
@@ -636,10 +660,11 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
                         if (mblk * MB + ml < p.Cg) {
                             const float4 xv = *reinterpret_cast<const float4*>(p.x + (ob + ooff[ml]));
                             if (!last || p.KSB == 0) {
-                                acc[0][t][r] = iao_fq_grad(acc[0][t][r], xv.x, sc, zp, slo, shi, p.qmin, p.qmax);
-                                acc[1][t][r] = iao_fq_grad(acc[1][t][r], xv.y, sc, zp, slo, shi, p.qmin, p.qmax);
-                                acc[2][t][r] = iao_fq_grad(acc[2][t][r], xv.z, sc, zp, slo, shi, p.qmin, p.qmax);
-                                acc[3][t][r] = iao_fq_grad(acc[3][t][r], xv.w, sc, zp, slo, shi, p.qmin, p.qmax);
+                                // ((g s) / s) as the chain rule of 227-239 writes it -- one IEEE division -- masked by the interval test
+                                acc[0][t][r] = (xv.x >= XL && xv.x <= XH) ? (acc[0][t][r] * ssc) / ssc : 0.f;
+                                acc[1][t][r] = (xv.y >= XL && xv.y <= XH) ? (acc[1][t][r] * ssc) / ssc : 0.f;
+                                acc[2][t][r] = (xv.z >= XL && xv.z <= XH) ? (acc[2][t][r] * ssc) / ssc : 0.f;
+                                acc[3][t][r] = (xv.w >= XL && xv.w <= XH) ? (acc[3][t][r] * ssc) / ssc : 0.f;
                             }
                             if (last) {
                                 const float c_ = va[ml];
@@ -764,7 +789,7 @@ static int plan_bf_dgrad(const mn_conv_geom* g, BfDgPlan* pl) {
     pl->NT = NT;
     const int MB = 16 * NT;
     p.num_mblk = (Cg + MB - 1) / MB; p.Mpad = p.num_mblk * MB;
-    pl->lds = (size_t)MB * (p.KpA + 8) * 2 + (size_t)3 * MB * (p.KpB + 8) * 2 + (size_t)(2 * p.KpA + 2 * p.KpB + 2 * MB) * 4;
+    pl->lds = (size_t)MB * (p.KpA + 8) * 2 + (size_t)3 * MB * (p.KpB + 8) * 2 + (size_t)(2 * p.KpA + 2 * p.KpB + 2 * MB + 4) * 4;
     if (pl->lds > 72 * 1024) return 0;
     p.nchunks = (int)((NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;

@@ -23,6 +23,18 @@ __device__ __forceinline__ float act_code(float x, const Pro& p, float sc, float
     return x;
 }
 
+// fl(x / s) without the hardware division sequence: with y = RN(1 / s), q0 = RN(x y), r = x - s q0 (exact: one fma), RN(q0 + r y) IS the correctly rounded quotient
+// (Markstein's division theorem; no overflow / underflow here: |x / s| <= a few hundred for in-range activations, and out-of-range ones are clamped far from any
+// rounding boundary).  3 instructions instead of ~10, bit-identical codes (tests: check_iao_codes_at_boundaries).
+__device__ __forceinline__ float mn_div_m(float x, float s, float inv) {
+    const float q0 = x * inv;
+    const float r = fmaf(-q0, s, x);
+    return fmaf(r, inv, q0);
+}
+__device__ __forceinline__ float iao_code_m(float x, float sc, float inv, float zp, float qmin, float qmax) {
+    return mn_clamp(mn_rha(mn_div_m(x, sc, inv) - zp), qmin, qmax) + zp;
+}
+
 // per-channel fold of the BatchNorm+sign backward for the BNH variants (same algebra as k_bnh_apply, reassociated; `scale` = the weight
 // scale the consumer multiplies the operand with)
 __device__ __forceinline__ void bnh_fold(const float* __restrict__ chan, const float* __restrict__ sums, int C, int co, int training, float n_f, float scale,

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
 
     float sc = 1.f, zp = 0.f;
     if (XMODE == MN_ACTQ_IAO) { sc = p.pro.qp[0]; zp = p.pro.qp[1]; }
+    const float inv_sc = 1.0f / sc;
     float ste_sc = 1.f, ste_zp = 0.f, ste_lo = 0.f, ste_hi = 0.f;
     if (p.epi == QG_EPI_STE && p.ste.mode == MN_ACTQ_IAO) { ste_sc = p.ste.qp[0]; ste_zp = p.ste.qp[1]; ste_lo = p.ste.qp[2]; ste_hi = p.ste.qp[3]; }
 
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void k_pw(const PwParams p) {
             for (int q = 0; q < 4; ++q) {
                 float c8[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) c8[e] = act_code<XMODE>(raw[e][q], p.pro, sc, zp);
+                for (int e = 0; e < 8; ++e)
+                    c8[e] = XMODE == MN_ACTQ_IAO ? iao_code_m(raw[e][q], sc, inv_sc, zp, p.pro.qmin, p.pro.qmax) : act_code<XMODE>(raw[e][q], p.pro, sc, zp);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) b0[q][d] = mn_pack_bf16x2(c8[2 * d], c8[2 * d + 1]);
             }
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
     const int64_t HW = p.HW;
     float sc = 1.f, zp = 0.f;
     if (XMODE == MN_ACTQ_IAO) { sc = p.pro.qp[0]; zp = p.pro.qp[1]; }
+    const float inv_sc = 1.0f / sc;
 
     f32x4 acc[MW][CW];
 #pragma unroll
@@ -598,8 +601,14 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
                     u32x2{mn_pack_bf16x2((float)(u & 0xffu), (float)((u >> 8) & 0xffu)), mn_pack_bf16x2((float)((u >> 16) & 0xffu), (float)(u >> 24))};
                 continue;
             }
-            const float c0 = act_code<XMODE>(rx[i].x, p.pro, sc, zp), c1 = act_code<XMODE>(rx[i].y, p.pro, sc, zp);
-            const float c2 = act_code<XMODE>(rx[i].z, p.pro, sc, zp), c3 = act_code<XMODE>(rx[i].w, p.pro, sc, zp);
+            float c0, c1, c2, c3;
+            if (XMODE == MN_ACTQ_IAO) {
+                c0 = iao_code_m(rx[i].x, sc, inv_sc, zp, p.pro.qmin, p.pro.qmax); c1 = iao_code_m(rx[i].y, sc, inv_sc, zp, p.pro.qmin, p.pro.qmax);
+                c2 = iao_code_m(rx[i].z, sc, inv_sc, zp, p.pro.qmin, p.pro.qmax); c3 = iao_code_m(rx[i].w, sc, inv_sc, zp, p.pro.qmin, p.pro.qmax);
+            } else {
+                c0 = act_code<XMODE>(rx[i].x, p.pro, sc, zp); c1 = act_code<XMODE>(rx[i].y, p.pro, sc, zp);
+                c2 = act_code<XMODE>(rx[i].z, p.pro, sc, zp); c3 = act_code<XMODE>(rx[i].w, p.pro, sc, zp);
+            }
             *reinterpret_cast<u32x2*>(xq + (r0 + 16 * i) * WG_LDP + qd * 4) = u32x2{mn_pack_bf16x2(c0, c1), mn_pack_bf16x2(c2, c3)};
         }
     };

@@ -830,7 +830,13 @@ class IaoBNFuseGeneric(Function):
                 else:
                     out.clamp_(min=0)
                     mm, count = None, 0
-        ctx.save_for_backward(x, weight, bias, gamma, out if relu else None, stats, qw, wqp, aqp, y_raw, xq)
+        # an input that lies on a quantizer grid (the output of QuantMaxPool2d: value = code * scale, |code| <= 128): the raw convolution's backward-weight may
+        # read it as exact codes -- one bf16 term instead of the three-term split of arbitrary fp32 values (a third of the passes of the k x k kernel)
+        grid = getattr(x, "_mn_qgrid", None)
+        if grid is not None and (grid[3] != x._version or not (2 <= grid[1] <= 8) or grid[2] != 0):
+            grid = None
+        ctx.save_for_backward(x, weight, bias, gamma, out if relu else None, stats, qw, wqp, aqp, y_raw, xq, grid[0] if grid is not None else None)
+        ctx.xgrid = (grid[1], grid[2]) if grid is not None else None
         ctx.cfg = (g, aq_.bits, aq_.q_type, wq_.bits, wq_._q_type_static, float(st.eps), n, bool(relu), bool(first_layer))
         ctx.tok_in = getattr(x, "_mn_relu_token", None)
         ctx.x_obj = x
@@ -852,7 +858,7 @@ class IaoBNFuseGeneric(Function):
 
     @staticmethod
     def backward(ctx, gin):
-        x, weight, bias, gamma, a, stats, qw, wqp, aqp, y_raw, xq = ctx.saved_tensors
+        x, weight, bias, gamma, a, stats, qw, wqp, aqp, y_raw, xq, gridqp = ctx.saved_tensors
         g, a_bits, a_qtype, w_bits, w_qtype, eps, n, relu, first_layer = ctx.cfg
         dev = x.device
         if relu and isinstance(gin, LazyReluGrad) and gin._mn_value is None:
@@ -882,7 +888,11 @@ class IaoBNFuseGeneric(Function):
             d_o = torch.empty_like(y_raw)
             _call("mn_bn_stats_bwd", _p(y_raw), _p(stats), _p(coef[2]), _p(coef[3]), _p(d_o), y_raw.shape[0], O, y_raw.shape[2] * y_raw.shape[3], _s())
             dw_raw = torch.empty_like(weight)
-            _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(none), _p(d_o), _p(x), _p(dw_raw), None, _p(ws), nb, CONV_ALGO, _s())
+            if gridqp is not None:
+                aqg = ActQ(ACTQ_IAO, ctx.xgrid[0], ctx.xgrid[1], 0, gridqp.data_ptr())          # x = code * scale exactly: the codes are recovered in the kernel's prologue
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aqg), _p(d_o), _p(x), _p(dw_raw), None, _p(ws), nb, CONV_ALGO, _s())
+            else:
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(none), _p(d_o), _p(x), _p(dw_raw), None, _p(ws), nb, CONV_ALGO, _s())
             dw.add_(dw_raw)
             if ctx.needs_input_grad[0]:
                 dxq, dxr = torch.empty_like(x), torch.empty_like(x)
@@ -928,6 +938,7 @@ class IaoFakeQuantMaxPool2x2(Function):
         ctx.tok_in = getattr(x, "_mn_relu_token", None)
         ctx.x_obj = x
         st.__dict__["_mn_fwd_out"] = (mm, count) if want_mm else None
+        st.__dict__["_mn_fwd_grid"] = (qp, bits, q_type)          # every value of y is code * scale of THIS quantizer (the maximum of quantised values)
         return y
 
     @staticmethod

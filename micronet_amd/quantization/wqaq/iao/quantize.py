@@ -408,7 +408,11 @@ class QuantBNFuseConv2d(QuantConv2d):
         if training_stats and self._fused_pw_ok(input):
             return self._forward_fused_pw(input)
         if self.in_shuffle_groups > 1:
+            grid = getattr(input, "_mn_qgrid", None)
+            grid = grid if (grid is not None and grid[3] == input._version) else None
             input = ops.channel_shuffle(input, self.in_shuffle_groups)
+            if grid is not None:
+                input._mn_qgrid = grid[:3] + (input._version,)          # a permutation of channels keeps every value on the grid
         if training_stats and self._fused_quantizers_ok() and ops.iao_bnfuse_generic_supported(input, self.weight) and ops.CONV_ALGO == 0:
             return self._forward_fused_generic(input)
         if training_stats:
@@ -516,6 +520,9 @@ class QuantMaxPool2d(nn.MaxPool2d):
                 mm = self.__dict__.pop("_mn_fwd_out", None)
                 if mm is not None:
                     out._mn_minmax = mm + (out._version,)
+                grid = self.__dict__.pop("_mn_fwd_grid", None)
+                if grid is not None:
+                    out._mn_qgrid = grid + (out._version,)          # (qp, bits, q_type, version): every value is code * scale of this quantizer
                 return out
             q = input if qp is None else ops.IaoFakeQuant.apply(input, qp, aq.bits, aq.q_type, True)
         else:

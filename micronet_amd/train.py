@@ -176,12 +176,22 @@ class GraphedTrainStep:
         self._host_sync = self.world > 1 and dist.get_backend(group) != "nccl"
         self.data, self.target = data.clone(), target.clone()
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.collectives_in_graph = False
+        if self.world > 1 and any(getattr(m, "_mn_sync", False) for m in model.modules()):
+            # The range collectives of synced IAO observers (dp.sync_observers: one 2-float MAX all-reduce per activation quantizer, each needed before the next
+            # layer can run) sit INSIDE forward.  RCCL collectives issued on the capturing stream are recorded into the graph, so the step CAN be captured with
+            # them -- but that path has never run on this stack (the build boxes have one GPU; two ranks on one device are refused by RCCL, gloo reduces on the
+            # host and cannot be captured), and a capture that fails on some ranks only would dead-lock the job.  It is therefore opt-in (MN_IAO_GRAPH_DP=1, nccl
+            # only); by default such models run the eager data-parallel step (dp.GradSync: bucketed all-reduce overlapped with backward), which callers reach by
+            # catching this error (bench.py does).
+            import os
+            backend = dist.get_backend(group)
+            if os.environ.get("MN_IAO_GRAPH_DP", "") != "1" or backend != "nccl":
+                raise RuntimeError("GraphedTrainStep: the model has cross-rank observer collectives inside forward (backend %s): use the eager DP step "
+                                   "(set MN_IAO_GRAPH_DP=1 to capture them with nccl)" % backend)
+            self.collectives_in_graph = True
         if not hasattr(optimizer, "capturable"):
             raise TypeError("GraphedTrainStep needs micronet_amd.optim.Adam")
-        if self.world > 1 and any(getattr(m, "_mn_sync", False) for m in model.modules()):
-            # the range collectives of synced IAO observers sit INSIDE forward: capturing RCCL calls into the graph is untested on this stack,
-            # so such models run the eager data-parallel step (dp.GradSync: bucketed all-reduce overlapped with backward)
-            raise RuntimeError("GraphedTrainStep: the model has cross-rank observer collectives inside forward; use the eager DP step")
         optimizer.capturable = True
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -195,13 +205,18 @@ class GraphedTrainStep:
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         self.flat = None
-        with torch.cuda.graph(self.graph_a):
-            self._fwd_bwd()
-            if self.world == 1:
-                optimizer.step()
-            else:
-                self.flat = torch.cat([p.grad.reshape(-1) for p in self.params])
-                self.flat.div_(self.world)
+        try:
+            with torch.cuda.graph(self.graph_a):
+                self._fwd_bwd()
+                if self.world == 1:
+                    optimizer.step()
+                else:
+                    self.flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+                    self.flat.div_(self.world)
+        except Exception as e:          # noqa: BLE001 -- a failed capture (e.g. collectives the backend cannot record) must leave a usable process behind
+            torch.cuda.synchronize()
+            optimizer.capturable = False
+            raise RuntimeError("GraphedTrainStep: capture failed (%s: %s); use the eager step" % (type(e).__name__, str(e)[:200])) from e
         if self.world > 1:
             self._captured_grads = [p.grad for p in self.params]   # graph A writes these on every replay: keep them allocated
             off = 0

@@ -148,3 +148,56 @@ def test_sync_observers_marks_only_level_L_minmax_observers():
     assert adds == 8 and n >= acts + 3 * adds            # one per activation quantizer + (res, shortcut, union) per QuantAdd; weight observers are per-channel
     assert not any(getattr(o, "_mn_sync", False) for mod in m.modules() if isinstance(mod, (Q.QuantConv2d,)) for o in [mod.weight_quantizer.observer])
     assert dp.sync_observers(D.prepare(build_model("nin_gc"), inplace=True, a_bits=2, w_bits=2)) == 0
+
+
+# ------------------------------------------------------------------------------------------------ graphed step vs cross-rank observer collectives
+class _Synced(nn.Module):
+    """stands for an IAO activation observer switched on by dp.sync_observers (a collective inside forward)"""
+    _mn_sync = True
+
+    def forward(self, x):
+        return x
+
+
+def _graph_fallback_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from micronet_amd import dp
+    from micronet_amd.train import GraphedTrainStep, make_optimizer, synth_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = nn.Sequential(_net(), _Synced())
+    opt = make_optimizer(model, 0.01, 1e-5)
+    x, y = synth_batch(8)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    msgs = []
+    for env in ("", "1"):           # gloo reduces on the host: never capturable, opt-in or not -> the caller is told to run the eager step
+        os.environ["MN_IAO_GRAPH_DP"] = env
+        try:
+            GraphedTrainStep(model, opt, xs, ys)
+            msgs.append("no error")
+        except RuntimeError as e:
+            msgs.append(str(e))
+    sync = dp.GradSync(model)
+    loss, _ = dp.train_step_dp(model, opt, sync, xs, ys)          # ... which works
+    if rank == 0:
+        q.put((msgs, float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_step_refuses_observer_collectives_it_cannot_capture():
+    """GraphedTrainStep on a model whose forward contains cross-rank observer collectives: with a backend that cannot be captured it raises BEFORE touching the
+    device or the process group (all ranks alike, so nobody dead-locks) and names the eager step; bench.py catches exactly this and measures the eager step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_graph_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    msgs, loss = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(msgs) == 2 and all("eager DP step" in m and "gloo" in m for m in msgs), msgs
+    assert loss == loss
