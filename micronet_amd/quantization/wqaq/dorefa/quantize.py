@@ -219,7 +219,8 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
             return F.relu(super().forward(input))
         momentum = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            if not self.__dict__.pop("_mn_nbt_pre", False):          # (already incremented for this forward by micronet_amd.train.bump_bn_counters: one launch for the net)
+                self.num_batches_tracked.add_(1)
             if self.momentum is None:
                 momentum = 1.0 / float(self.num_batches_tracked)
         if self.emit_minmax and self.training:
@@ -243,7 +244,8 @@ class BatchNorm2dPlain(nn.BatchNorm2d):
         if not (self.affine and ops.bnrelu_supported(input) and self.momentum is not None and (use_batch or self.track_running_stats)):
             return super().forward(input)
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            if not self.__dict__.pop("_mn_nbt_pre", False):
+                self.num_batches_tracked.add_(1)
         return ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                 self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d")
 

@@ -63,6 +63,22 @@ def train_step(model, optimizer, data, target):
     return loss, output
 
 
+def bump_bn_counters(model):
+    """``num_batches_tracked += 1`` of every BatchNorm the streaming kernels run (``BatchNorm2dReLU`` / ``BatchNorm2dPlain`` on their plain paths: 20 tiny launches per
+    resnet18 step) as ONE multi-tensor launch in front of the forward; each module is told that its counter already moved for the coming forward (the flag is
+    consumed there).  Modules with ``momentum=None`` read the counter on the host and keep doing their own increment."""
+    from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dPlain, BatchNorm2dReLU
+    todo = []
+    for m in model.modules():
+        if isinstance(m, (BatchNorm2dReLU, BatchNorm2dPlain)) and m.training and m.track_running_stats and m.num_batches_tracked is not None \
+                and m.momentum is not None and m.num_batches_tracked.is_cuda and not getattr(m, "q_out_bits", 0) and "_mn_nbt_pre" not in m.__dict__:
+            todo.append(m)
+    if len(todo) >= 2:
+        torch._foreach_add_([m.num_batches_tracked for m in todo], 1)
+        for m in todo:
+            m.__dict__["_mn_nbt_pre"] = True
+
+
 def prefetch_weight_path(model, side=None):
     """Quantize the weights of every W-ternary conv of ``model`` NOW, in one launch (ops.MultiTernaryWeight: one autograd node, so the
     backward is one launch too); the owning conv picks its tensor up in its forward.  A step of nin_gc saves 12 launches of ~5 us.
@@ -232,6 +248,7 @@ class GraphedTrainStep:
         side = None
         if os.environ.get("MN_MULTI_WQ", "1") != "0" and os.environ.get("MN_WEIGHT_STREAM", "") != "1":
             prefetch_weight_path(self.model)                     # all ternary weight quantizers of the step in one launch (and one in backward)
+            bump_bn_counters(self.model)
         if os.environ.get("MN_WEIGHT_STREAM", "") == "1":       # the weight path on a second stream: opt-in -- measured on c2: 2.68 -> 2.73 ms,
                                                                 # the fork / join edges of the captured graph cost more than the 14 tiny launches they hide
             if not hasattr(self, "_wstream"):

@@ -242,7 +242,7 @@ def test_wbwtab_bn_fused_graph_vs_reference_golden(W):
             else:
                 assert _rel(got, ref.double().numpy()) <= 1e-5, (i, _rel(got, ref.double().numpy()))
             t = ref
-        assert np.array_equal(OF(x).numpy(), g[f"{key}_fused_logits"])
+        assert _rel(OF(x), g[f"{key}_fused_logits"].astype(np.float64)) <= 1e-6          # (bit-equal on the host that generated the goldens: tests/test_oracle_golden.py)
         lg = F(x.cuda())
         assert bool((lg.argmax(1).cpu() == torch.from_numpy(g[f"{key}_fused_logits"]).argmax(1)).float().mean() >= 0.75)
 
@@ -276,7 +276,7 @@ def test_iao_bn_fused_graph_vs_reference_golden():
     OF = TO.bn_fuse_iao(orc).eval()
     x, _ = synth_batch(4)
     with torch.no_grad():
-        assert np.array_equal(OF(x).numpy(), g[f"{key}_fused_logits"])
+        assert _rel(OF(x), g[f"{key}_fused_logits"].astype(np.float64)) <= 1e-6          # (bit-equal on the host that generated the goldens: tests/test_oracle_golden.py)
         t = x
         for i, (so, sp) in enumerate(zip(OF.model, F.model)):
             ref = so(t)
