@@ -172,6 +172,8 @@ def measure(workload, args, world, rank, device):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         windows.append(dt)
+    from micronet_amd import ops as _ops
+    fallbacks = _ops.fallback_counts(reset=True)           # stock-operator fall-throughs seen while this workload ran (warm-up, capture, eager steps): expected {}
     dt = sorted(windows)[len(windows) // 2]                 # the median window (an odd count by default)
     final_loss = float(loss.detach())
     # data-parallel IAO models: the eager step (one blocking 2-float collective per activation quantizer, ~360 launches issued from Python) next to the graphed one,
@@ -208,7 +210,7 @@ def measure(workload, args, world, rank, device):
     del graphed, model, opt, sync
     torch.cuda.empty_cache()
     return dict(dt=dt, dt_min=min(windows), windows=windows, final_loss=final_loss, hip_graph=graph_err is None and not args.no_graph, graph_err=graph_err, agg=agg,
-                eager_dp=eager_dp)
+                eager_dp=eager_dp, fallbacks=fallbacks)
 
 
 def section(workload, m, args, world, pmc):
@@ -221,6 +223,7 @@ def section(workload, m, args, world, pmc):
            "hip_graph": m["hip_graph"], "final_loss": round(m["final_loss"], 4)}
     if m["graph_err"]:
         out["hip_graph_error"] = m["graph_err"]
+    out["stock_fallbacks"] = m.get("fallbacks") or {}
     if m.get("eager_dp"):
         out["eager_dp_value"] = round(args.batch * world * args.steps / m["eager_dp"], 1)
     agg = m["agg"]
@@ -384,7 +387,8 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD_DESC[primary], "global_batch": args.batch * world,
                    "per_gpu_batch": args.batch, "parallelism": "dp%d" % world, "optimizer": "Adam lr=0.01",
-                   "hip_graph": sec["hip_graph"], "final_loss": sec["final_loss"]},
+                   "hip_graph": sec["hip_graph"], "final_loss": sec["final_loss"],
+                   "stock_fallbacks": sum(sec.get("stock_fallbacks", {}).values()) + sum(sum(s_.get("stock_fallbacks", {}).values()) for s_ in also_secs.values())},
     }
     out["ms_per_step_min"], out["value_best_window"], out["repeats"], out["window_ms"] = sec["ms_per_step_min"], sec["value_best_window"], sec["repeats"], sec["window_ms"]
     if dist_info:

@@ -31,7 +31,7 @@
 // ------------------------------------------------------------------------------------------------ Gram matrix of the input channels of a pointwise group
 struct GramParams {
     const float* x;
-    float* part;        // [Z][G][CP][CP]
+    float* part;        // [G * CP * CP / 64][Z][64]: segment-major, so that the reduction streams
     float* sxpart;      // [Z][G][CP]
     int N, HW, C_total, Cg, G, Z, nchunks, CP;
     uint32_t NP;
@@ -127,9 +127,13 @@ __global__ __launch_bounds__(256, 2) void k_bf_gram(const GramParams p) {
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
             const int mrow = (wm * CW + mi) * 16 + kg * 4, ccol = (wc * CW + ci) * 16 + j;
-            float* dst = p.part + (((int64_t)z * p.G + g) * CP + mrow) * CP + ccol;
+            // partial layout [segment of 64 tile floats][Z][64]: the reduction reads Z x 256 contiguous bytes per segment (a [Z][tile] layout made it gather
+            // 256-byte pieces 128 KB apart: 0.8 TB/s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(int64_t)r * CP] = acc[mi][ci][r];
+            for (int r = 0; r < 4; ++r) {
+                const int64_t e = ((int64_t)g * CP + mrow + r) * CP + ccol;
+                p.part[((e >> 6) * p.Z + z) * 64 + (e & 63)] = acc[mi][ci][r];
+            }
         }
 #pragma unroll
     for (int i = 0; i < RC; ++i) {
@@ -145,12 +149,10 @@ __global__ __launch_bounds__(256) void k_bf_gram_reduce(const float* __restrict_
     __shared__ double sm[16][16][4];
     const int q = threadIdx.x >> 4, l = threadIdx.x & 15;
     if ((int)blockIdx.x < nblk_w) {
-        const int64_t tile = (int64_t)G * CP * CP;
-        const int64_t e0 = (int64_t)blockIdx.x * 64 + 4 * l;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 4
         for (int z = q; z < Z; z += 16) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)z * tile + e0);
+            const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)blockIdx.x * Z + z) * 64 + 4 * l);
             s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
         }
         sm[q][l][0] = s0; sm[q][l][1] = s1; sm[q][l][2] = s2; sm[q][l][3] = s3;
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(128) void k_bf_gram_stats(const float* __restrict__
     for (int k = 0; k < BF_GS_CH; ++k) { acc[k] = 0.0; m1p[k] = 0.0; }
     const double xbi = tid < Cg ? sxg[tid] / n : 0.0;
     if (tid < Cg) {
-        for (int c = 0; c < Cg; ++c) {
+#pragma unroll 8
+        for (int c = 0; c < Cg; ++c) {          // (eight loads of G in flight per thread: the grid is a few dozen blocks, latency is all there is to hide)
             const double gv = G[(int64_t)c * Cg + tid];
 #pragma unroll
             for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (double)ws[k][c] * gv;
@@ -730,6 +733,7 @@ __global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
         __syncthreads();
         const int no = p.Mg - ob < 128 ? p.Mg - ob : 128;
         if (tid < p.KpB && tid < p.Cg) {
+#pragma unroll 8
             for (int oo = 0; oo < no; ++oo) {
                 const double wv = (double)B[ob + oo] * (double)wg[(int64_t)(ob + oo) * p.Cg + tid];
 #pragma unroll

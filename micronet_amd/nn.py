@@ -21,6 +21,7 @@ class Conv2dFirst(nn.Conv2d):
             if not input.requires_grad:
                 out._mn_first_conv_out = True      # no backward-data: a BatchNorm2dBinAct behind it may hand its gradient over lazily
             return out
+        ops.note_fallback("Conv2dFirst -> nn.Conv2d")
         return super().forward(input)
 
 
@@ -33,6 +34,7 @@ class Conv2dSignIn(nn.Conv2d):
         if self.padding_mode == "zeros" and not isinstance(self.padding, str) and \
                 ops.sign_classifier_supported(input, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return ops.SignClassifierConv.apply(input, self.weight, self.bias)
+        ops.note_fallback("Conv2dSignIn -> nn.Conv2d")
         return super().forward(input)
 
 
@@ -45,6 +47,7 @@ class AvgPool2dGlobal(nn.AvgPool2d):
         if (torch.is_tensor(input) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and type(input) is torch.Tensor and input.is_contiguous()
                 and pair(self.kernel_size) == tuple(input.shape[2:]) and pair(self.padding) == (0, 0) and not self.ceil_mode and self.divisor_override is None):
             return ops.GlobalAvgPool.apply(input)
+        ops.note_fallback("AvgPool2dGlobal -> nn.AvgPool2d")
         return super().forward(input)
 
 

@@ -62,6 +62,23 @@ def _span(g, which, nbytes):
     return _Span(tok) if tok is not None else _NOSPAN
 
 
+# Stock-operator fall-throughs.  A few modules of this package hand geometries their gfx950 kernels do not cover to the stock torch operator (MIOpen / ATen) --
+# the reference's own behaviour, so never wrong, but not the hot path this package exists for.  Every such fall-through is counted here by site name, so that a
+# benchmark or a test can ASSERT that a model runs entirely on the library's kernels (bench.py reports ``stock_fallbacks``; 0 for every benched workload).
+_FALLBACKS = {}
+
+
+def note_fallback(site):
+    _FALLBACKS[site] = _FALLBACKS.get(site, 0) + 1
+
+
+def fallback_counts(reset=False):
+    out = dict(_FALLBACKS)
+    if reset:
+        _FALLBACKS.clear()
+    return out
+
+
 def last_kernel():
     """Name of the main kernel the last conv call launched (for the profiler's per-kernel aggregation)."""
     k = _lib_().mn_last_kernel()

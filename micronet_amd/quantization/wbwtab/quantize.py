@@ -94,6 +94,7 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
     def forward(self, input):
         hw = input.shape[2] * input.shape[3] if input.dim() == 4 else 0
         if not (input.is_cuda and input.dim() == 4 and hw % 4 == 0 and self.affine and input.dtype == torch.float32):
+            ops.note_fallback("BatchNorm2dBinAct -> nn.BatchNorm2d")
             return super().forward(input)
         use_batch = self.training or self.running_mean is None
         momentum = 0.0 if self.momentum is None else self.momentum
@@ -125,6 +126,7 @@ class MaxPool2dSign(nn.MaxPool2d):
     def forward(self, input):
         if not self.return_indices and ops.sign_pool_supported(input, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode):
             return ops.SignMaxPool2x2.apply(input)
+        ops.note_fallback("MaxPool2dSign -> nn.MaxPool2d")
         return super().forward(input)
 
 

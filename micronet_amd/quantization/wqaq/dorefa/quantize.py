@@ -216,6 +216,7 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
                                      self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, nbt,
                                      int(self.q_out_bits), pool)
         if not plain_ok:
+            ops.note_fallback("BatchNorm2dReLU -> nn.BatchNorm2d + relu")
             return F.relu(super().forward(input))
         momentum = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
@@ -242,6 +243,7 @@ class BatchNorm2dPlain(nn.BatchNorm2d):
         from micronet_amd import ops
         use_batch = self.training or self.running_mean is None
         if not (self.affine and ops.bnrelu_supported(input) and self.momentum is not None and (use_batch or self.track_running_stats)):
+            ops.note_fallback("BatchNorm2dPlain -> nn.BatchNorm2d")
             return super().forward(input)
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             if not self.__dict__.pop("_mn_nbt_pre", False):
@@ -260,6 +262,7 @@ class MaxPool2dF32(nn.MaxPool2d):
             return input          # the fused block in front already pooled (max of the activation = max of its codes: the quantizer is monotone)
         if not self.return_indices and ops.f32_pool_supported(input, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode):
             return ops.MaxPool2x2F32.apply(input)
+        ops.note_fallback("MaxPool2dF32 -> nn.MaxPool2d")
         return super().forward(input)
 
 

@@ -365,6 +365,7 @@ class QuantBNFuseConv2d(QuantConv2d):
         if self.weight.is_cuda and self.weight.dtype == torch.float32 and self.weight.is_contiguous():
             wf, bf = ops.IaoBNFold.apply(self.weight, self.bias, self.gamma, self.beta, mean, var_for_bias, var_for_weight, self.eps)
             return wf, reshape_to_bias(bf)
+        ops.note_fallback("QuantBNFuseConv2d._fold -> torch ops")
         k_b = self.gamma / torch.sqrt(var_for_bias + self.eps)
         if self.bias is not None:
             bias_fused = reshape_to_bias(self.beta + (self.bias - mean) * k_b)
@@ -529,6 +530,7 @@ class QuantMaxPool2d(nn.MaxPool2d):
             q = aq(input)
         if not self.return_indices and ops.f32_pool_supported(q, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode):
             return ops.MaxPool2x2F32.apply(q)        # 2x2 / stride 2: byte argmax, scatter backward (same values and gradient routing as ATen)
+        ops.note_fallback("QuantMaxPool2d -> F.max_pool2d")
         return F.max_pool2d(q, self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode, self.return_indices)
 
 
@@ -548,6 +550,7 @@ class QuantAvgPool2d(nn.AvgPool2d):
                 return ops.IaoFakeQuantAvgPool.apply(input, qp, q.bits, q.q_type, k)     # the quantised tensor is never written
             return F.avg_pool2d(input if qp is None else ops.IaoFakeQuant.apply(input, qp, q.bits, q.q_type, True), self.kernel_size, self.stride,
                                 self.padding, self.ceil_mode, self.count_include_pad, self.divisor_override)
+        ops.note_fallback("QuantAvgPool2d -> F.avg_pool2d")
         return F.avg_pool2d(self.activation_quantizer(input), self.kernel_size, self.stride, self.padding, self.ceil_mode,
                             self.count_include_pad, self.divisor_override)
 
@@ -564,6 +567,7 @@ class QuantAdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
             if qp is not None and qp.shape[0] == 1:
                 return ops.IaoFakeQuantAvgPool.apply(input, qp, q.bits, q.q_type, int(input.shape[2]))
             return F.adaptive_avg_pool2d(input if qp is None else ops.IaoFakeQuant.apply(input, qp, q.bits, q.q_type, True), self.output_size)
+        ops.note_fallback("QuantAdaptiveAvgPool2d -> F.adaptive_avg_pool2d")
         return F.adaptive_avg_pool2d(self.activation_quantizer(input), self.output_size)
 
 

@@ -17,6 +17,7 @@ CASES = [
     dict(N=2, C=64, O=32, H=8, W=8, groups=2, shuffle=2, bias=True),
     dict(N=2, C=256, O=256, H=4, W=4, groups=2, shuffle=2, bias=False),      # Cg = Mg = 128: the nin_gc tile
     dict(N=5, C=48, O=96, H=2, W=6, groups=1, shuffle=0, bias=True),         # Cg = 48 (padded to 64), Mg = 96 (three K-steps)
+    dict(N=4, C=32, O=32, H=16, W=24, groups=2, shuffle=2, bias=True),       # 24 slabs: three partial Gram tiles per group (Z = 3), several chunks per wave
 ]
 
 
@@ -110,7 +111,9 @@ def check_iaobf_pointwise(be, case, seed=0, nsteps=2, relu_mask=True):
         gram_ref = torch.einsum("gcp,gdp->gcd", xg, xg).numpy()
         gram_got = np.frombuffer(be.to_host(gram).tobytes(), dtype=np.float64).reshape(G, Cg, Cg)
         sx_got = np.frombuffer(be.to_host(sx).tobytes(), dtype=np.float64)
-        assert np.abs(gram_got - gram_ref).max() <= 2e-6 * np.abs(gram_ref).max(), ("gram", np.abs(gram_got - gram_ref).max() / np.abs(gram_ref).max())
+        # a partial tile accumulates <= 2048 pixels x 6 term products in ONE fp32 accumulator per entry (the emulator adds them strictly in order: the worst case);
+        # the Z partials are then summed in fp64.  What the statistics need is checked right below (running mean / var, weight scale within 1e-5 of the reference).
+        assert np.abs(gram_got - gram_ref).max() <= 6e-6 * np.abs(gram_ref).max(), ("gram", np.abs(gram_got - gram_ref).max() / np.abs(gram_ref).max())
         assert np.abs(sx_got - xg.sum(-1).reshape(-1).numpy()).max() <= 2e-6 * np.abs(xg.sum(-1)).max().item()
         # forward preparation
         stats, kfold, bias_f, qw, wqp = be.empty(2 * O), be.empty(O), be.empty(O), be.empty((O, Cg)), be.empty((O, 4))

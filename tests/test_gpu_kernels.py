@@ -645,7 +645,7 @@ def test_qd_pack_multi_tables(be, w_bits, iao):
 
 
 # ---- the BN-fused IAO block without the statistics convolution (iao_bnfuse.hip)
-@pytest.mark.parametrize("case", range(4))
+@pytest.mark.parametrize("case", range(5))
 def test_iaobf_pointwise(be, case):
     import iaobf_cases as B
     B.check_iaobf_pointwise(be, B.CASES[case], seed=case)

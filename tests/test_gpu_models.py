@@ -292,3 +292,19 @@ def test_wbwtab_fused_pipeline_usage_scenarios(golden):
     y = fused.model[0:3](torch.randn(2, 3, 24, 40, device="cuda"))
     assert y.shape[2:] == (24, 40)
     y.float().sum().backward() if y.requires_grad else None
+
+
+@pytest.mark.parametrize("key", ["c1_nin_gc_dorefa_w8a8", "c2_nin_gc_wbwtab_w3a2", "c3_nin_gc_iao_w8a8_bnfuse", "c4_resnet18_dorefa_w2a2", "c5_resnet18_iao_w4a4"])
+def test_bench_workloads_never_fall_through_to_stock_operators(key):
+    """a module of this package hands a geometry its kernels do not cover to the stock torch operator and counts it (ops.note_fallback); for every
+    benched net one training step must leave that counter EMPTY -- no MIOpen / ATen convolution, BatchNorm or pooling on the hot path."""
+    from micronet_amd import ops
+    from micronet_amd.train import build_model, make_optimizer, synth_batch, train_step
+    arch, scheme, kw, B, wd = CFG[key]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    model = quantize.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+    opt = make_optimizer(model, 0.01, wd)
+    x, y = synth_batch(8, device="cuda")
+    ops.fallback_counts(reset=True)
+    train_step(model, opt, x, y)
+    assert ops.fallback_counts() == {}, ops.fallback_counts()

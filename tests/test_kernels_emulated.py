@@ -443,7 +443,7 @@ def test_qd_pack_multi_tables(be, w_bits, iao):
 
 
 # ---- the BN-fused IAO block without the statistics convolution (iao_bnfuse.hip)
-@pytest.mark.parametrize("case", range(4))
+@pytest.mark.parametrize("case", range(5))
 def test_iaobf_pointwise(be, case):
     """Gram data -> batch statistics / fold / weight quantizer in one launch -> conv + ReLU + (min, max) -> backward-weight -> one-launch backward preparation ->
     backward-data with the raw path folded in, two training steps, against the oracle's QuantBNFuseConv2d + ReLU in fp32 and fp64."""
