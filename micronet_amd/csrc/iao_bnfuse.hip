@@ -475,6 +475,28 @@ struct BfDgParams {
     FastDiv fd_hw;
     ChanMap map;
 };
+// The clip-STE of the activation quantizer as an interval [XL, XH] of x (out[0], out[1]): both of its conditions -- qmin <= rha(x / s - zp) <= qmax (the clamp of 232)
+// and lo <= x / s - zp <= hi (Round.backward 163-168) -- are monotone in x (every fp32 step of the chain is), so the pass set is ONE interval of floats.  Its two ends
+// are found by bisection over the ordered float keys with the exact expressions (2 x 33 evaluations, one lane per block); the epilogue then needs two compares per
+// element instead of two IEEE divisions and a floor.  (NaN x: every compare fails, the gradient is dropped, as in the reference.)
+__device__ __forceinline__ void bf_ste_interval(const float* __restrict__ qp, float qmin, float qmax, float* out) {
+    const float sc = qp[0], zp = qp[1], slo = qp[2], shi = qp[3];
+    auto key2f = [](uint32_t k) { return mn_u2f((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };          // ordered key -> float
+    auto lower_ok = [&](float x) { const float v = x / sc - zp; const float r = mn_rha(v); return r >= qmin && !(v < slo); };
+    auto upper_ok = [&](float x) { const float v = x / sc - zp; const float r = mn_rha(v); return r <= qmax && !(v > shi); };
+    const uint32_t kmin = 0x007fffffu, kmax = 0xff800000u;          // keys of -inf and +inf
+    uint32_t lo_k = kmin, hi_k = kmax;
+    if (lower_ok(key2f(kmin))) hi_k = kmin;
+    else if (!lower_ok(key2f(kmax))) lo_k = hi_k = kmax;          // nothing passes
+    else while (hi_k - lo_k > 1u) { const uint32_t mid = lo_k + ((hi_k - lo_k) >> 1); if (lower_ok(key2f(mid))) hi_k = mid; else lo_k = mid; }
+    out[0] = lower_ok(key2f(hi_k)) ? key2f(hi_k) : INFINITY;
+    lo_k = kmin; hi_k = kmax;
+    if (upper_ok(key2f(kmax))) lo_k = kmax;
+    else if (!upper_ok(key2f(kmin))) lo_k = hi_k = kmin;
+    else while (hi_k - lo_k > 1u) { const uint32_t mid = lo_k + ((hi_k - lo_k) >> 1); if (upper_ok(key2f(mid))) lo_k = mid; else hi_k = mid; }
+    out[1] = upper_ok(key2f(lo_k)) ? key2f(lo_k) : -INFINITY;
+}
+
 template <int NT>
 __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -527,30 +549,8 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
             ooff[i] = (uint32_t)chan_phys(p.map, g * p.Cg + mc) * HW;
         }
     }
-    // The clip-STE of the activation quantizer as two thresholds on x: both of its conditions -- qmin <= rha(x / s - zp) <= qmax (the clamp of 232) and lo <= x / s - zp
-    // <= hi (Round.backward 163-168) -- are monotone in x (every fp32 step of the chain is), so the pass set is ONE interval [XL, XH] of floats.  Lane 0 finds its
-    // two ends by bisection over the ordered float keys with the exact expressions (2 x 33 evaluations per block); the epilogue then needs two compares per
-    // element instead of two IEEE divisions and a floor.  (NaN x: every compare fails, the gradient is dropped, as in the reference.)
     float* xlh = reinterpret_cast<float*>(ooff + MB);
-    if (tid == 0) {
-        const float sc = p.qp[0], zp = p.qp[1], slo = p.qp[2], shi = p.qp[3];
-        auto key2f = [](uint32_t k) { return mn_u2f((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };          // ordered key -> float (0 = -NaN side ... 0xffffffff)
-        auto lower_ok = [&](float x) { const float v = x / sc - zp; const float r = mn_rha(v); return r >= p.qmin && !(v < slo); };
-        auto upper_ok = [&](float x) { const float v = x / sc - zp; const float r = mn_rha(v); return r <= p.qmax && !(v > shi); };
-        const uint32_t kmin = 0x007fffffu, kmax = 0xff800000u;          // keys of -inf and +inf
-        // XL = the smallest float in [-inf, +inf] with lower_ok (false ... true); XH = the largest with upper_ok (true ... false)
-        uint32_t lo_k = kmin, hi_k = kmax;
-        if (lower_ok(key2f(kmin))) hi_k = kmin;
-        else if (!lower_ok(key2f(kmax))) lo_k = hi_k = kmax;          // nothing passes
-        else while (hi_k - lo_k > 1u) { const uint32_t mid = lo_k + ((hi_k - lo_k) >> 1); if (lower_ok(key2f(mid))) hi_k = mid; else lo_k = mid; }
-        const float XL = lower_ok(key2f(hi_k)) ? key2f(hi_k) : INFINITY;
-        lo_k = kmin; hi_k = kmax;
-        if (upper_ok(key2f(kmax))) lo_k = kmax;
-        else if (!upper_ok(key2f(kmin))) lo_k = hi_k = kmin;
-        else while (hi_k - lo_k > 1u) { const uint32_t mid = lo_k + ((hi_k - lo_k) >> 1); if (upper_ok(key2f(mid))) lo_k = mid; else hi_k = mid; }
-        const float XH = upper_ok(key2f(lo_k)) ? key2f(lo_k) : -INFINITY;
-        xlh[0] = XL; xlh[1] = XH;
-    }
+    if (tid == 0) bf_ste_interval(p.qp, p.qmin, p.qmax, xlh);
     __syncthreads();
     const float XL = xlh[0], XH = xlh[1], ssc = p.qp[0];
 
@@ -703,6 +703,199 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
     }
 }
 
+// The same kernel for groups of (up to) 128 input channels -- every pointwise layer of nin_gc -- without the second m-block: a block of EIGHT waves (512 threads, one
+// block per CU: the four weight images of all 128 rows take 139 KB of LDS) in which every wave owns a HALF chunk of 32 pixels and all 128 output rows.  Each element
+// of d out and x is then loaded, scaled / centred and split into its three bf16 terms exactly once (k_bf_dgrad<4> does it once per 64-row m-block: twice the VALU
+// work and twice the L2 -> CU traffic), with the same MFMA count per loaded byte doubled.  Lane (j, kg) loads float2 = pixels 2j, 2j + 1 of eight channels per K-step;
+// pixel column q of those loads is the B fragment of MFMA q (q = 0, 1); D leaves as float2 per output row.
+__global__ __launch_bounds__(512, 1) void k_bf_dgrad128(const BfDgParams p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int NT = 8, MB = 128;
+    const int LDA = p.KpA + 8, LDB = p.KpB + 8;
+    uint16_t* wa = reinterpret_cast<uint16_t*>(smem);            // [MB][LDA]
+    uint16_t* wb = wa + MB * LDA;                                 // [3][MB][LDB]
+    float* ks = reinterpret_cast<float*>(wb + 3 * MB * LDB);      // [KpA]
+    float* xb = ks + p.KpA;                                       // [KpB]
+    float* va = xb + p.KpB;                                       // [MB]
+    uint32_t* koffA = reinterpret_cast<uint32_t*>(va + MB);      // [KpA]
+    uint32_t* koffB = koffA + p.KpA;                              // [KpB]
+    uint32_t* ooff = koffB + p.KpB;                               // [MB]
+    float* xlh = reinterpret_cast<float*>(ooff + MB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const uint32_t HW = (uint32_t)p.HW;
+    const int cb = blockIdx.x % p.CB, g = blockIdx.x / p.CB;
+    {
+        const uint16_t* wg = p.wc + (int64_t)g * p.Mpad * p.KpA;
+        const int k8 = p.KpA >> 3;
+        for (int q = tid; q < MB * k8; q += 512) {
+            const int row = q / k8, c8 = q - row * k8;
+            *reinterpret_cast<u32x4*>(wa + row * LDA + c8 * 8) = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.KpA + c8 * 8);
+        }
+        const int k8b = p.KpB >> 3;
+        for (int t = 0; t < 3; ++t) {
+            const uint16_t* mg = p.mt + ((int64_t)t * p.G + g) * p.Mpad * p.KpB;
+            for (int q = tid; q < MB * k8b; q += 512) {
+                const int row = q / k8b, c8 = q - row * k8b;
+                *reinterpret_cast<u32x4*>(wb + (t * MB + row) * LDB + c8 * 8) = *reinterpret_cast<const u32x4*>(mg + (int64_t)row * p.KpB + c8 * 8);
+            }
+        }
+        for (int k = tid; k < p.KpA; k += 512) {
+            ks[k] = k < p.Mg ? p.kscale[g * p.KpA + k] : 0.f;
+            koffA[k] = (uint32_t)(g * p.Mg + (k < p.Mg ? k : p.Mg - 1)) * HW;
+        }
+        for (int k = tid; k < p.KpB; k += 512) {
+            const int kc = k < p.Cg ? k : p.Cg - 1;
+            xb[k] = p.xbar[g * p.Cg + kc];
+            koffB[k] = (uint32_t)chan_phys(p.map, g * p.Cg + kc) * HW;
+        }
+        for (int i = tid; i < MB; i += 512) {
+            const int mc = i < p.Cg ? i : p.Cg - 1;
+            va[i] = p.vadd[g * p.Cg + mc];
+            ooff[i] = (uint32_t)chan_phys(p.map, g * p.Cg + mc) * HW;
+        }
+    }
+    if (tid == 0) bf_ste_interval(p.qp, p.qmin, p.qmax, xlh);
+    __syncthreads();
+    const float XL = xlh[0], XH = xlh[1], ssc = p.qp[0];
+
+    const int nh = (int)((p.NP + 31u) >> 5);                      // half chunks of 32 pixels
+    const int h0 = cb * 8 + wave, hstride = p.CB * 8;
+    const int my = h0 < nh ? (nh - h0 + hstride - 1) / hstride : 0;
+    const int KST = p.KSA + p.KSB;
+    const int total = my * KST;
+    const uint32_t Pmax = p.NP - 2u;
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](float2 (&raw)[8], int ci, int s) {
+        uint32_t P = (uint32_t)(h0 + ci * hstride) * 32u + 2u * j;
+        P = P < Pmax ? P : Pmax;
+        const uint32_t n = fd_div(P, p.fd_hw);
+        const uint32_t pp = P - n * HW;
+        if (s < p.KSA) {
+            const uint32_t go = n * (uint32_t)p.O_total * HW + pp;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = *reinterpret_cast<const float2*>(p.gy + (go + koffA[s * 32 + kg * 8 + e]));
+        } else {
+            const uint32_t go = n * (uint32_t)p.C_total * HW + pp;
+            const int sb = s - p.KSA;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = *reinterpret_cast<const float2*>(p.x + (go + koffB[sb * 32 + kg * 8 + e]));
+        }
+    };
+    int ci_i = 0, s_i = 0;
+    auto issue_next = [&](float2 (&raw)[8]) {
+        issue(raw, ci_i, s_i);
+        if (++s_i == KST) { s_i = 0; ++ci_i; }
+    };
+    auto step = [&](float2 (&raw)[8], int it, int ci, int s) {
+        const bool phaseA = s < p.KSA;
+        const int sb = phaseA ? s : s - p.KSA;
+        u32x4 bq[2][3];
+        {
+            float cf[8];
+            bool kv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = sb * 32 + kg * 8 + e;
+                cf[e] = phaseA ? ks[k] : xb[k];
+                kv[e] = phaseA || k < p.Cg;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float u0 = q == 0 ? raw[2 * d].x : raw[2 * d].y, u1 = q == 0 ? raw[2 * d + 1].x : raw[2 * d + 1].y;
+                    float x0 = phaseA ? u0 * cf[2 * d] : u0 - cf[2 * d], x1 = phaseA ? u1 * cf[2 * d + 1] : u1 - cf[2 * d + 1];
+                    x0 = kv[2 * d] ? x0 : 0.f; x1 = kv[2 * d + 1] ? x1 : 0.f;
+                    const float hh0 = mn_bf16_head(x0), hh1 = mn_bf16_head(x1);
+                    const float r0 = x0 - hh0, r1 = x1 - hh1;
+                    const float m0 = mn_bf16_head(r0), m1 = mn_bf16_head(r1);
+                    bq[q][0][d] = mn_pack_bf16x2(hh0, hh1);
+                    bq[q][1][d] = mn_pack_bf16x2(m0, m1);
+                    bq[q][2][d] = mn_pack_bf16x2(r0 - m0, r1 - m1);
+                }
+        }
+        if (it + 2 < total) issue_next(raw);
+        if (phaseA) {
+            u32x4 av[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const u32x4*>(wa + (t * 16 + j) * LDA + sb * 32 + kg * 8);
+#pragma unroll
+            for (int tb = 2; tb >= 0; --tb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[q][t] = mn_mfma_bf16(av[t], bq[q][tb], acc[q][t]);
+        } else {
+#pragma unroll
+            for (int ta = 2; ta >= 0; --ta) {
+                MN_SCHED_FENCE();
+                u32x4 av[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const u32x4*>(wb + (ta * MB + t * 16 + j) * LDB + sb * 32 + kg * 8);
+#pragma unroll
+                for (int tb = 2 - ta; tb >= 0; --tb)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[q][t] = mn_mfma_bf16(av[t], bq[q][tb], acc[q][t]);
+            }
+        }
+        if (s == p.KSA - 1 || s == KST - 1) {
+            const bool last = s == KST - 1;
+            const uint32_t P = (uint32_t)(h0 + ci * hstride) * 32u + 2u * j;
+            if (P < p.NP) {
+                const uint32_t n = fd_div(P, p.fd_hw);
+                const uint32_t ob = n * (uint32_t)p.C_total * HW + (P - n * HW);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    MN_SCHED_FENCE();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = t * 16 + kg * 4 + r;
+                        if (ml < p.Cg) {
+                            const float2 xv = *reinterpret_cast<const float2*>(p.x + (ob + ooff[ml]));
+                            if (!last || p.KSB == 0) {
+                                acc[0][t][r] = (xv.x >= XL && xv.x <= XH) ? (acc[0][t][r] * ssc) / ssc : 0.f;
+                                acc[1][t][r] = (xv.y >= XL && xv.y <= XH) ? (acc[1][t][r] * ssc) / ssc : 0.f;
+                            }
+                            if (last) {
+                                const float c_ = va[ml];
+                                float o0 = acc[0][t][r] + c_, o1 = acc[1][t][r] + c_;
+                                if (p.relu_mask) { o0 = xv.x > 0.f ? o0 : 0.f; o1 = xv.y > 0.f ? o1 : 0.f; }
+                                *reinterpret_cast<float2*>(p.dx + (ob + ooff[ml])) = make_float2(o0, o1);
+                            }
+                        }
+                    }
+                }
+            }
+            if (last) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    float2 ra[8], rb[8];
+    if (total > 0) issue_next(ra);
+    if (total > 1) issue_next(rb);
+    int ci_c = 0, s_c = 0;
+    for (int it = 0; it < total; it += 2) {
+        step(ra, it, ci_c, s_c);
+        if (++s_c == KST) { s_c = 0; ++ci_c; }
+        if (it + 1 < total) {
+            step(rb, it + 1, ci_c, s_c);
+            if (++s_c == KST) { s_c = 0; ++ci_c; }
+        }
+    }
+}
+
 // M = W^T diag(B) W, v = W^T (dmean / n), x_bar -- one block per (group, input channel) row; M leaves as three bf16 term planes in the [G][Mpad][KpB] layout of
 // k_bf_dgrad's A operand.  Also the transposed quantised-weight codes [G][Mpad][KpA] + their scales (what k_qg_pack(transpose = 1) writes for one tap).
 struct BfMParams {
@@ -775,7 +968,7 @@ __global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
     }
 }
 
-struct BfDgPlan { BfDgParams p; int NT; size_t lds; int grid; int64_t off_wc, off_ks, off_xbar, off_v, ws_bytes; };
+struct BfDgPlan { BfDgParams p; int NT; size_t lds; int grid; int64_t off_wc, off_ks, off_xbar, off_v, ws_bytes; int v128; };
 static int plan_bf_dgrad(const mn_conv_geom* g, BfDgPlan* pl) {
     GramPlan gp;
     if (!plan_gram(g, &gp)) return 0;
@@ -790,20 +983,37 @@ static int plan_bf_dgrad(const mn_conv_geom* g, BfDgPlan* pl) {
     p.KpB = qg_roundup(Cg, 32); p.KSB = p.KpB / 32;
     if (p.KSA > 8) return 0;
     int NT = Cg > 32 ? 4 : (Cg > 16 ? 2 : 1);
-    pl->NT = NT;
     const int MB = 16 * NT;
-    p.num_mblk = (Cg + MB - 1) / MB; p.Mpad = p.num_mblk * MB;
-    pl->lds = (size_t)MB * (p.KpA + 8) * 2 + (size_t)3 * MB * (p.KpB + 8) * 2 + (size_t)(2 * p.KpA + 2 * p.KpB + 2 * MB + 4) * 4;
-    if (pl->lds > 72 * 1024) return 0;
     p.nchunks = (int)((NP + 63) / 64);
-    int CB = (p.nchunks + 3) / 4;
-    const int cap = 512 / (p.G * p.num_mblk) > 0 ? 512 / (p.G * p.num_mblk) : 1;
-    if (CB > cap) CB = cap;
-    p.CB = CB;
     p.fd_hw = make_fastdiv((uint32_t)p.HW);
-    const int64_t nb = (int64_t)qg_roundup(p.G * CB, 8) * p.num_mblk;
-    if (nb > 0x7fffffff) return 0;
-    pl->grid = (int)nb;
+    // more than 64 channels per group (nin_gc: 128): the eight-wave kernel that owns all rows -- one block per CU (the weight images of 128 rows fill the LDS)
+    pl->v128 = (Cg > 64 && Cg <= 128 && NP % 2 == 0 && !MN_ENV("MN_BF_DGRAD_V1")) ? 1 : 0;
+    if (pl->v128) {
+        pl->NT = 8;
+        p.num_mblk = 1; p.Mpad = 128;
+        pl->lds = (size_t)128 * (p.KpA + 8) * 2 + (size_t)3 * 128 * (p.KpB + 8) * 2 + (size_t)(2 * p.KpA + 2 * p.KpB + 2 * 128 + 4) * 4;
+        if (pl->lds > 152 * 1024) pl->v128 = 0;
+    }
+    if (pl->v128) {
+        const int nh = (int)((NP + 31) / 32);
+        int CB = (nh + 7) / 8;
+        const int cap = 256 / p.G > 0 ? 256 / p.G : 1;
+        if (CB > cap) CB = cap;
+        p.CB = CB;
+        pl->grid = p.G * CB;
+    } else {
+        pl->NT = NT;
+        p.num_mblk = (Cg + MB - 1) / MB; p.Mpad = p.num_mblk * MB;
+        pl->lds = (size_t)MB * (p.KpA + 8) * 2 + (size_t)3 * MB * (p.KpB + 8) * 2 + (size_t)(2 * p.KpA + 2 * p.KpB + 2 * MB + 4) * 4;
+        if (pl->lds > 72 * 1024) return 0;
+        int CB = (p.nchunks + 3) / 4;
+        const int cap = 512 / (p.G * p.num_mblk) > 0 ? 512 / (p.G * p.num_mblk) : 1;
+        if (CB > cap) CB = cap;
+        p.CB = CB;
+        const int64_t nb = (int64_t)qg_roundup(p.G * CB, 8) * p.num_mblk;
+        if (nb > 0x7fffffff) return 0;
+        pl->grid = (int)nb;
+    }
     const int64_t mt_bytes = (int64_t)3 * p.G * p.Mpad * p.KpB * 2;
     pl->off_wc = (mt_bytes + 255) / 256 * 256;
     pl->off_ks = (pl->off_wc + (int64_t)p.G * p.Mpad * p.KpA * 2 + 255) / 256 * 256;
@@ -835,6 +1045,14 @@ extern "C" int mn_iaobf_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const
     mn_set_last_kernel("k_bf_dgrad<%d>", pl.NT);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + 8.0 * nx); }
     mn_prof_begin(s);
+    if (pl.v128) {
+        mn_set_last_kernel("k_bf_dgrad128");
+        raise_lds_limit((const void*)k_bf_dgrad128, pl.lds);
+        hipLaunchKernelGGL(k_bf_dgrad128, dim3(pl.grid), dim3(512), pl.lds, s, p);
+        mn_prof_end(s);
+        MN_CHECK_LAUNCH("mn_iaobf_bwd_data");
+        return MN_OK;
+    }
     raise_lds_limit(pl.NT == 4 ? (const void*)k_bf_dgrad<4> : (pl.NT == 2 ? (const void*)k_bf_dgrad<2> : (const void*)k_bf_dgrad<1>), pl.lds);
     if (pl.NT == 4) hipLaunchKernelGGL(k_bf_dgrad<4>, dim3(pl.grid), dim3(256), pl.lds, s, p);
     else if (pl.NT == 2) hipLaunchKernelGGL(k_bf_dgrad<2>, dim3(pl.grid), dim3(256), pl.lds, s, p);

@@ -543,7 +543,8 @@ class QuantAvgPool2d(nn.AvgPool2d):
     def forward(self, input):
         k = self.kernel_size if isinstance(self.kernel_size, int) else (self.kernel_size[0] if self.kernel_size[0] == self.kernel_size[1] else 0)
         st = self.stride if self.stride is not None else self.kernel_size
-        if k and st in (k, (k, k)) and self.padding in (0, (0, 0)) and not self.ceil_mode and self.divisor_override is None and ops.iao_avgpool_supported(input, k):
+        whole = torch.is_tensor(input) and input.dim() == 4 and k and input.shape[2] == k and input.shape[3] == k          # one window = the image: the stride is moot
+        if k and (st in (k, (k, k)) or whole) and self.padding in (0, (0, 0)) and not self.ceil_mode and self.divisor_override is None and ops.iao_avgpool_supported(input, k):
             q = self.activation_quantizer
             qp = q.qparams(input)
             if qp is not None and qp.shape[0] == 1:
