@@ -540,7 +540,8 @@ int mn_iao_bnfold_bwd(const float* dwf, const float* dbf, const float* w, const 
  * 843-851 is linear, and the block needs only the per-channel mean / unbiased variance of its output (853-855) and their gradient; both follow from the
  * per-channel sums sx[c] = sum_p x[c,p] and the Gram matrix gram[g][c][c'] = sum_p x[c,p] x[c',p] of each group's input channels (logical, i.e. post-shuffle,
  * channel order), accumulated on the matrix cores in fp32 over <= 2048 pixels per partial and combined in fp64:
- *   mn_iaobf_gram      x -> gram [G][Cg][Cg], sx [G * Cg] (fp64).
+ *   mn_iaobf_gram      x -> gram [G][Cg][Cg], sx [G * Cg] (fp64).  Also the FIRST layer of a net (k x k, stride 1, "same" padding, groups 1, Cg := Cin * KH * KW <= 128,
+ *                      W % 4 == 0; nin_gc: 5 x 5 on RGB): the Gram matrix of the im2col matrix, gathered from the image without materialising it (G = 1).
  *   mn_iaobf_gram_stats  statistics of the raw convolution's output from the Gram data, no pass over any activation: stats [2][O] = mean[o] = W[o,:] . x_bar + b[o]
  *                      and the unbiased var[o] = W[o,:] S W[o,:]^T / (n - 1) (S = gram - n x_bar x_bar^T), plus vc [O][Cg] = W S for the backward.
  *   mn_iaobf_prep_fwd  ONE launch for: running statistics from stats_in [2][O] (856-879; first_bn: the copy of the first forward of a non-pretrained net; stats_in =

@@ -37,9 +37,13 @@ struct GramParams {
     uint32_t NP;
     FastDiv fd_hw;
     ChanMap in_map;
+    // PATCH mode (the first layer: k x k, stride 1, "same" padding, groups 1, Cin * KH * KW <= 128): the "channels" are the Cin * KH * KW elements of the patch
+    // around each pixel, gathered from the (tiny, cache-resident) image -- the Gram matrix of the im2col matrix without materialising it
+    int H, W, KH, KW, pad_h, pad_w;
+    FastDiv fd_w;
 };
 // CW = CP / 32: a block of 4 waves (2 x 2) owns the CP x CP tile of one group and a strided set of 64-pixel slabs
-template <int CW>
+template <int CW, int PATCH>
 __global__ __launch_bounds__(256, 2) void k_bf_gram(const GramParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     constexpr int CP = 32 * CW, RC = CP / 16;
@@ -60,11 +64,39 @@ __global__ __launch_bounds__(256, 2) void k_bf_gram(const GramParams p) {
     for (int i = 0; i < RC; ++i) sx[i] = 0.f;
 
     float4 rx[RC];
+    int pci[RC], pdy[RC], pdx[RC];          // PATCH: (input channel, row shift, column shift) of this thread's patch elements
+    if (PATCH) {
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const int k = r0 + 16 * i, t = p.KH * p.KW;
+            pci[i] = k / t;
+            pdy[i] = (k - pci[i] * t) / p.KW - p.pad_h;
+            pdx[i] = (k - pci[i] * t) % p.KW - p.pad_w;
+        }
+    }
     auto fetch = [&](int chunk) {
         const uint32_t P = (uint32_t)chunk * 64u + 4u * qd;
         const bool pv = P < p.NP;
         const uint32_t n = fd_div(P, p.fd_hw);
         const int pp = (int)(P - n * (uint32_t)p.HW);
+        if (PATCH) {
+            const int y = (int)fd_div((uint32_t)pp, p.fd_w), x0 = pp - y * p.W;
+#pragma unroll
+            for (int i = 0; i < RC; ++i) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                const int iy = y + pdy[i];
+                if (pv && r0 + 16 * i < p.Cg && iy >= 0 && iy < p.H) {
+                    const float* row = p.x + (((int64_t)n * p.C_total + pci[i]) * p.H + iy) * p.W;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ix = x0 + e + pdx[i];
+                        if (ix >= 0 && ix < p.W) v[e] = row[ix];
+                    }
+                }
+                rx[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < RC; ++i) {
             const int c = r0 + 16 * i;
@@ -179,19 +211,26 @@ __global__ __launch_bounds__(256) void k_bf_gram_reduce(const float* __restrict_
     }
 }
 
-struct GramPlan { GramParams p; int CW; size_t lds; int grid; int64_t off_sx, ws_bytes; };
+struct GramPlan { GramParams p; int CW, patch; size_t lds; int grid; int64_t off_sx, ws_bytes; };
 static int plan_gram(const mn_conv_geom* g, GramPlan* pl) {
-    if (g->KH != 1 || g->KW != 1 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 0 || g->pad_w != 0 || g->groups < 1) return 0;
+    if (g->stride_h != 1 || g->stride_w != 1 || g->dil_h != 1 || g->dil_w != 1 || g->groups < 1) return 0;
+    const int pointwise = g->KH == 1 && g->KW == 1 && g->pad_h == 0 && g->pad_w == 0;
+    // the first layer of a net: k x k with "same" padding on a few input channels (nin_gc: 5 x 5 on RGB = 75 patch elements)
+    const int patch = !pointwise && g->groups == 1 && (g->KH & 1) && (g->KW & 1) && g->pad_h == g->KH / 2 && g->pad_w == g->KW / 2 && g->C * g->KH * g->KW <= 128 &&
+                      g->in_shuffle <= 1 && g->W % 4 == 0;
+    if (!pointwise && !patch) return 0;
     const int64_t HW = (int64_t)g->H * g->W, NP = (int64_t)g->N * HW;
     if (HW % 4 || NP * HW >= ((int64_t)1 << 32) || NP + 256 >= ((int64_t)1 << 31) || NP < 2) return 0;
     if (g->C % g->groups || g->O % g->groups) return 0;
-    const int Cg = g->C / g->groups;
+    const int Cg = patch ? g->C * g->KH * g->KW : g->C / g->groups;
     if (Cg < 1 || Cg > 128) return 0;
     if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
     GramParams& p = pl->p;
-    pl->CW = Cg > 64 ? 4 : 2;
+    pl->patch = patch;
+    pl->CW = Cg > 96 ? 4 : (Cg > 64 ? 3 : 2);
     p.CP = 32 * pl->CW;
-    p.N = g->N; p.HW = (int)HW; p.C_total = g->C; p.Cg = Cg; p.G = g->groups; p.NP = (uint32_t)NP;
+    p.H = g->H; p.W = g->W; p.KH = g->KH; p.KW = g->KW; p.pad_h = g->pad_h; p.pad_w = g->pad_w; p.fd_w = make_fastdiv((uint32_t)g->W);
+    p.N = g->N; p.HW = (int)HW; p.C_total = g->C; p.Cg = Cg; p.G = patch ? 1 : g->groups; p.NP = (uint32_t)NP;
     p.nchunks = (int)((NP + 63) / 64);
     p.in_map = make_chanmap(g->in_shuffle, g->C);
     p.fd_hw = make_fastdiv((uint32_t)HW);
@@ -215,21 +254,22 @@ extern "C" int64_t mn_iaobf_gram_ws_bytes(const mn_conv_geom* g) { GramPlan pl; 
 extern "C" int mn_iaobf_gram(const mn_conv_geom* g, const float* x, double* gram, double* sx, void* ws, int64_t ws_bytes, mn_stream_t stream) {
     GramPlan pl;
     if (!g || !x || !gram || !sx) MN_FAIL(MN_EINVAL, "mn_iaobf_gram: null argument");
-    if (!plan_gram(g, &pl) || !aligned16(x)) MN_FAIL(MN_ENOTSUP, "mn_iaobf_gram: pointwise layers with <= 128 channels per group only");
+    if (!plan_gram(g, &pl) || !aligned16(x)) MN_FAIL(MN_ENOTSUP, "mn_iaobf_gram: pointwise layers with <= 128 channels per group, or a first layer with <= 128 patch elements");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws) || (((uintptr_t)gram) & 7) || (((uintptr_t)sx) & 7)) MN_FAIL(MN_ENOSPC, "mn_iaobf_gram: workspace too small / misaligned");
     hipStream_t s = (hipStream_t)stream;
     GramParams& p = pl.p;
     p.x = x; p.part = (float*)ws; p.sxpart = (float*)((char*)ws + pl.off_sx);
-    mn_set_last_kernel("k_bf_gram<%d>", pl.CW);
+    mn_set_last_kernel("k_bf_gram<%d, %d>", pl.CW, pl.patch);
     mn_prof_bytes(4.0 * (double)g->N * g->C * g->H * g->W + 2.0 * (double)pl.off_sx);
     mn_prof_begin(s);
-    if (pl.CW == 4) {
-        raise_lds_limit((const void*)k_bf_gram<4>, pl.lds);
-        hipLaunchKernelGGL(k_bf_gram<4>, dim3(pl.grid), dim3(256), pl.lds, s, p);
-    } else {
-        raise_lds_limit((const void*)k_bf_gram<2>, pl.lds);
-        hipLaunchKernelGGL(k_bf_gram<2>, dim3(pl.grid), dim3(256), pl.lds, s, p);
-    }
+#define BF_GRAM_LAUNCH(CWV, PV)                                                                   \
+    do {                                                                                          \
+        raise_lds_limit((const void*)k_bf_gram<CWV, PV>, pl.lds);                                 \
+        hipLaunchKernelGGL((k_bf_gram<CWV, PV>), dim3(pl.grid), dim3(256), pl.lds, s, p);         \
+    } while (0)
+    if (pl.patch) { if (pl.CW == 4) BF_GRAM_LAUNCH(4, 1); else if (pl.CW == 3) BF_GRAM_LAUNCH(3, 1); else BF_GRAM_LAUNCH(2, 1); }
+    else { if (pl.CW == 4) BF_GRAM_LAUNCH(4, 0); else if (pl.CW == 3) BF_GRAM_LAUNCH(3, 0); else BF_GRAM_LAUNCH(2, 0); }
+#undef BF_GRAM_LAUNCH
     mn_prof_end(s);
     const int nblk_w = (int)((int64_t)p.G * p.CP * p.CP / 64);
     hipLaunchKernelGGL(k_bf_gram_reduce, dim3(nblk_w + 8), dim3(256), 0, s, (const float*)p.part, (const float*)p.sxpart, gram, sx, p.Z, p.G, p.Cg, p.CP, nblk_w);
@@ -261,11 +301,11 @@ __global__ __launch_bounds__(128) void k_bf_gram_stats(const float* __restrict__
     for (int k = 0; k < BF_GS_CH; ++k) { acc[k] = 0.0; m1p[k] = 0.0; }
     const double xbi = tid < Cg ? sxg[tid] / n : 0.0;
     if (tid < Cg) {
-#pragma unroll 8
-        for (int c = 0; c < Cg; ++c) {          // (eight loads of G in flight per thread: the grid is a few dozen blocks, latency is all there is to hide)
+        const float* __restrict__ wrow = w + (int64_t)o0 * Cg;          // (wave-uniform addresses below: scalar loads, no LDS round trip per FMA)
+        for (int c = 0; c < Cg; ++c) {
             const double gv = G[(int64_t)c * Cg + tid];
 #pragma unroll
-            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (double)ws[k][c] * gv;
+            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (k < nch ? (double)wrow[(int64_t)k * Cg + c] : 0.0) * gv;
         }
 #pragma unroll
         for (int k = 0; k < BF_GS_CH; ++k) m1p[k] = (double)ws[k][tid] * xbi;
@@ -703,199 +743,6 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
     }
 }
 
-// The same kernel for groups of (up to) 128 input channels -- every pointwise layer of nin_gc -- without the second m-block: a block of EIGHT waves (512 threads, one
-// block per CU: the four weight images of all 128 rows take 139 KB of LDS) in which every wave owns a HALF chunk of 32 pixels and all 128 output rows.  Each element
-// of d out and x is then loaded, scaled / centred and split into its three bf16 terms exactly once (k_bf_dgrad<4> does it once per 64-row m-block: twice the VALU
-// work and twice the L2 -> CU traffic), with the same MFMA count per loaded byte doubled.  Lane (j, kg) loads float2 = pixels 2j, 2j + 1 of eight channels per K-step;
-// pixel column q of those loads is the B fragment of MFMA q (q = 0, 1); D leaves as float2 per output row.
-__global__ __launch_bounds__(512, 1) void k_bf_dgrad128(const BfDgParams p) {
-    HIP_DYNAMIC_SHARED(float, smem)
-    constexpr int NT = 8, MB = 128;
-    const int LDA = p.KpA + 8, LDB = p.KpB + 8;
-    uint16_t* wa = reinterpret_cast<uint16_t*>(smem);            // [MB][LDA]
-    uint16_t* wb = wa + MB * LDA;                                 // [3][MB][LDB]
-    float* ks = reinterpret_cast<float*>(wb + 3 * MB * LDB);      // [KpA]
-    float* xb = ks + p.KpA;                                       // [KpB]
-    float* va = xb + p.KpB;                                       // [MB]
-    uint32_t* koffA = reinterpret_cast<uint32_t*>(va + MB);      // [KpA]
-    uint32_t* koffB = koffA + p.KpA;                              // [KpB]
-    uint32_t* ooff = koffB + p.KpB;                               // [MB]
-    float* xlh = reinterpret_cast<float*>(ooff + MB);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
-    const uint32_t HW = (uint32_t)p.HW;
-    const int cb = blockIdx.x % p.CB, g = blockIdx.x / p.CB;
-    {
-        const uint16_t* wg = p.wc + (int64_t)g * p.Mpad * p.KpA;
-        const int k8 = p.KpA >> 3;
-        for (int q = tid; q < MB * k8; q += 512) {
-            const int row = q / k8, c8 = q - row * k8;
-            *reinterpret_cast<u32x4*>(wa + row * LDA + c8 * 8) = *reinterpret_cast<const u32x4*>(wg + (int64_t)row * p.KpA + c8 * 8);
-        }
-        const int k8b = p.KpB >> 3;
-        for (int t = 0; t < 3; ++t) {
-            const uint16_t* mg = p.mt + ((int64_t)t * p.G + g) * p.Mpad * p.KpB;
-            for (int q = tid; q < MB * k8b; q += 512) {
-                const int row = q / k8b, c8 = q - row * k8b;
-                *reinterpret_cast<u32x4*>(wb + (t * MB + row) * LDB + c8 * 8) = *reinterpret_cast<const u32x4*>(mg + (int64_t)row * p.KpB + c8 * 8);
-            }
-        }
-        for (int k = tid; k < p.KpA; k += 512) {
-            ks[k] = k < p.Mg ? p.kscale[g * p.KpA + k] : 0.f;
-            koffA[k] = (uint32_t)(g * p.Mg + (k < p.Mg ? k : p.Mg - 1)) * HW;
-        }
-        for (int k = tid; k < p.KpB; k += 512) {
-            const int kc = k < p.Cg ? k : p.Cg - 1;
-            xb[k] = p.xbar[g * p.Cg + kc];
-            koffB[k] = (uint32_t)chan_phys(p.map, g * p.Cg + kc) * HW;
-        }
-        for (int i = tid; i < MB; i += 512) {
-            const int mc = i < p.Cg ? i : p.Cg - 1;
-            va[i] = p.vadd[g * p.Cg + mc];
-            ooff[i] = (uint32_t)chan_phys(p.map, g * p.Cg + mc) * HW;
-        }
-    }
-    if (tid == 0) bf_ste_interval(p.qp, p.qmin, p.qmax, xlh);
-    __syncthreads();
-    const float XL = xlh[0], XH = xlh[1], ssc = p.qp[0];
-
-    const int nh = (int)((p.NP + 31u) >> 5);                      // half chunks of 32 pixels
-    const int h0 = cb * 8 + wave, hstride = p.CB * 8;
-    const int my = h0 < nh ? (nh - h0 + hstride - 1) / hstride : 0;
-    const int KST = p.KSA + p.KSB;
-    const int total = my * KST;
-    const uint32_t Pmax = p.NP - 2u;
-
-    f32x4 acc[2][NT];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto issue = [&](float2 (&raw)[8], int ci, int s) {
-        uint32_t P = (uint32_t)(h0 + ci * hstride) * 32u + 2u * j;
-        P = P < Pmax ? P : Pmax;
-        const uint32_t n = fd_div(P, p.fd_hw);
-        const uint32_t pp = P - n * HW;
-        if (s < p.KSA) {
-            const uint32_t go = n * (uint32_t)p.O_total * HW + pp;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) raw[e] = *reinterpret_cast<const float2*>(p.gy + (go + koffA[s * 32 + kg * 8 + e]));
-        } else {
-            const uint32_t go = n * (uint32_t)p.C_total * HW + pp;
-            const int sb = s - p.KSA;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) raw[e] = *reinterpret_cast<const float2*>(p.x + (go + koffB[sb * 32 + kg * 8 + e]));
-        }
-    };
-    int ci_i = 0, s_i = 0;
-    auto issue_next = [&](float2 (&raw)[8]) {
-        issue(raw, ci_i, s_i);
-        if (++s_i == KST) { s_i = 0; ++ci_i; }
-    };
-    auto step = [&](float2 (&raw)[8], int it, int ci, int s) {
-        const bool phaseA = s < p.KSA;
-        const int sb = phaseA ? s : s - p.KSA;
-        u32x4 bq[2][3];
-        {
-            float cf[8];
-            bool kv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = sb * 32 + kg * 8 + e;
-                cf[e] = phaseA ? ks[k] : xb[k];
-                kv[e] = phaseA || k < p.Cg;
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const float u0 = q == 0 ? raw[2 * d].x : raw[2 * d].y, u1 = q == 0 ? raw[2 * d + 1].x : raw[2 * d + 1].y;
-                    float x0 = phaseA ? u0 * cf[2 * d] : u0 - cf[2 * d], x1 = phaseA ? u1 * cf[2 * d + 1] : u1 - cf[2 * d + 1];
-                    x0 = kv[2 * d] ? x0 : 0.f; x1 = kv[2 * d + 1] ? x1 : 0.f;
-                    const float hh0 = mn_bf16_head(x0), hh1 = mn_bf16_head(x1);
-                    const float r0 = x0 - hh0, r1 = x1 - hh1;
-                    const float m0 = mn_bf16_head(r0), m1 = mn_bf16_head(r1);
-                    bq[q][0][d] = mn_pack_bf16x2(hh0, hh1);
-                    bq[q][1][d] = mn_pack_bf16x2(m0, m1);
-                    bq[q][2][d] = mn_pack_bf16x2(r0 - m0, r1 - m1);
-                }
-        }
-        if (it + 2 < total) issue_next(raw);
-        if (phaseA) {
-            u32x4 av[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const u32x4*>(wa + (t * 16 + j) * LDA + sb * 32 + kg * 8);
-#pragma unroll
-            for (int tb = 2; tb >= 0; --tb)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[q][t] = mn_mfma_bf16(av[t], bq[q][tb], acc[q][t]);
-        } else {
-#pragma unroll
-            for (int ta = 2; ta >= 0; --ta) {
-                MN_SCHED_FENCE();
-                u32x4 av[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const u32x4*>(wb + (ta * MB + t * 16 + j) * LDB + sb * 32 + kg * 8);
-#pragma unroll
-                for (int tb = 2 - ta; tb >= 0; --tb)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[q][t] = mn_mfma_bf16(av[t], bq[q][tb], acc[q][t]);
-            }
-        }
-        if (s == p.KSA - 1 || s == KST - 1) {
-            const bool last = s == KST - 1;
-            const uint32_t P = (uint32_t)(h0 + ci * hstride) * 32u + 2u * j;
-            if (P < p.NP) {
-                const uint32_t n = fd_div(P, p.fd_hw);
-                const uint32_t ob = n * (uint32_t)p.C_total * HW + (P - n * HW);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    MN_SCHED_FENCE();
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ml = t * 16 + kg * 4 + r;
-                        if (ml < p.Cg) {
-                            const float2 xv = *reinterpret_cast<const float2*>(p.x + (ob + ooff[ml]));
-                            if (!last || p.KSB == 0) {
-                                acc[0][t][r] = (xv.x >= XL && xv.x <= XH) ? (acc[0][t][r] * ssc) / ssc : 0.f;
-                                acc[1][t][r] = (xv.y >= XL && xv.y <= XH) ? (acc[1][t][r] * ssc) / ssc : 0.f;
-                            }
-                            if (last) {
-                                const float c_ = va[ml];
-                                float o0 = acc[0][t][r] + c_, o1 = acc[1][t][r] + c_;
-                                if (p.relu_mask) { o0 = xv.x > 0.f ? o0 : 0.f; o1 = xv.y > 0.f ? o1 : 0.f; }
-                                *reinterpret_cast<float2*>(p.dx + (ob + ooff[ml])) = make_float2(o0, o1);
-                            }
-                        }
-                    }
-                }
-            }
-            if (last) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    };
-    float2 ra[8], rb[8];
-    if (total > 0) issue_next(ra);
-    if (total > 1) issue_next(rb);
-    int ci_c = 0, s_c = 0;
-    for (int it = 0; it < total; it += 2) {
-        step(ra, it, ci_c, s_c);
-        if (++s_c == KST) { s_c = 0; ++ci_c; }
-        if (it + 1 < total) {
-            step(rb, it + 1, ci_c, s_c);
-            if (++s_c == KST) { s_c = 0; ++ci_c; }
-        }
-    }
-}
-
 // M = W^T diag(B) W, v = W^T (dmean / n), x_bar -- one block per (group, input channel) row; M leaves as three bf16 term planes in the [G][Mpad][KpB] layout of
 // k_bf_dgrad's A operand.  Also the transposed quantised-weight codes [G][Mpad][KpA] + their scales (what k_qg_pack(transpose = 1) writes for one tap).
 struct BfMParams {
@@ -926,11 +773,11 @@ __global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
         __syncthreads();
         const int no = p.Mg - ob < 128 ? p.Mg - ob : 128;
         if (tid < p.KpB && tid < p.Cg) {
-#pragma unroll 8
             for (int oo = 0; oo < no; ++oo) {
-                const double wv = (double)B[ob + oo] * (double)wg[(int64_t)(ob + oo) * p.Cg + tid];
+                const float* __restrict__ wo = wg + (int64_t)(ob + oo) * p.Cg;
+                const double wv = (double)B[ob + oo] * (double)wo[tid];
 #pragma unroll
-                for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (double)wcol[r][oo];
+                for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (c0 + r < p.Cg ? (double)wo[c0 + r] : 0.0);          // wave-uniform address: a scalar load
             }
         }
         if (tid < BF_M_ROWS)
@@ -968,10 +815,10 @@ __global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
     }
 }
 
-struct BfDgPlan { BfDgParams p; int NT; size_t lds; int grid; int64_t off_wc, off_ks, off_xbar, off_v, ws_bytes; int v128; };
+struct BfDgPlan { BfDgParams p; int NT; size_t lds; int grid; int64_t off_wc, off_ks, off_xbar, off_v, ws_bytes; };
 static int plan_bf_dgrad(const mn_conv_geom* g, BfDgPlan* pl) {
     GramPlan gp;
-    if (!plan_gram(g, &gp)) return 0;
+    if (!plan_gram(g, &gp) || gp.patch) return 0;          // (the first layer has no backward-data)
     const int Cg = g->C / g->groups, Mg = g->O / g->groups;
     const int64_t NP = (int64_t)g->N * g->H * g->W;
     if (4 * NP * (g->C > g->O ? g->C : g->O) >= ((int64_t)1 << 32) || NP < 4) return 0;        // 32-bit element offsets
@@ -986,34 +833,17 @@ static int plan_bf_dgrad(const mn_conv_geom* g, BfDgPlan* pl) {
     const int MB = 16 * NT;
     p.nchunks = (int)((NP + 63) / 64);
     p.fd_hw = make_fastdiv((uint32_t)p.HW);
-    // more than 64 channels per group (nin_gc: 128): the eight-wave kernel that owns all rows -- one block per CU (the weight images of 128 rows fill the LDS)
-    pl->v128 = (Cg > 64 && Cg <= 128 && NP % 2 == 0 && !MN_ENV("MN_BF_DGRAD_V1")) ? 1 : 0;
-    if (pl->v128) {
-        pl->NT = 8;
-        p.num_mblk = 1; p.Mpad = 128;
-        pl->lds = (size_t)128 * (p.KpA + 8) * 2 + (size_t)3 * 128 * (p.KpB + 8) * 2 + (size_t)(2 * p.KpA + 2 * p.KpB + 2 * 128 + 4) * 4;
-        if (pl->lds > 152 * 1024) pl->v128 = 0;
-    }
-    if (pl->v128) {
-        const int nh = (int)((NP + 31) / 32);
-        int CB = (nh + 7) / 8;
-        const int cap = 256 / p.G > 0 ? 256 / p.G : 1;
-        if (CB > cap) CB = cap;
-        p.CB = CB;
-        pl->grid = p.G * CB;
-    } else {
-        pl->NT = NT;
-        p.num_mblk = (Cg + MB - 1) / MB; p.Mpad = p.num_mblk * MB;
-        pl->lds = (size_t)MB * (p.KpA + 8) * 2 + (size_t)3 * MB * (p.KpB + 8) * 2 + (size_t)(2 * p.KpA + 2 * p.KpB + 2 * MB + 4) * 4;
-        if (pl->lds > 72 * 1024) return 0;
-        int CB = (p.nchunks + 3) / 4;
-        const int cap = 512 / (p.G * p.num_mblk) > 0 ? 512 / (p.G * p.num_mblk) : 1;
-        if (CB > cap) CB = cap;
-        p.CB = CB;
-        const int64_t nb = (int64_t)qg_roundup(p.G * CB, 8) * p.num_mblk;
-        if (nb > 0x7fffffff) return 0;
-        pl->grid = (int)nb;
-    }
+    pl->NT = NT;
+    p.num_mblk = (Cg + MB - 1) / MB; p.Mpad = p.num_mblk * MB;
+    pl->lds = (size_t)MB * (p.KpA + 8) * 2 + (size_t)3 * MB * (p.KpB + 8) * 2 + (size_t)(2 * p.KpA + 2 * p.KpB + 2 * MB + 4) * 4;
+    if (pl->lds > 72 * 1024) return 0;
+    int CB = (p.nchunks + 3) / 4;
+    const int cap = 512 / (p.G * p.num_mblk) > 0 ? 512 / (p.G * p.num_mblk) : 1;
+    if (CB > cap) CB = cap;
+    p.CB = CB;
+    const int64_t nb = (int64_t)qg_roundup(p.G * CB, 8) * p.num_mblk;
+    if (nb > 0x7fffffff) return 0;
+    pl->grid = (int)nb;
     const int64_t mt_bytes = (int64_t)3 * p.G * p.Mpad * p.KpB * 2;
     pl->off_wc = (mt_bytes + 255) / 256 * 256;
     pl->off_ks = (pl->off_wc + (int64_t)p.G * p.Mpad * p.KpA * 2 + 255) / 256 * 256;
@@ -1045,14 +875,6 @@ extern "C" int mn_iaobf_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const
     mn_set_last_kernel("k_bf_dgrad<%d>", pl.NT);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + 8.0 * nx); }
     mn_prof_begin(s);
-    if (pl.v128) {
-        mn_set_last_kernel("k_bf_dgrad128");
-        raise_lds_limit((const void*)k_bf_dgrad128, pl.lds);
-        hipLaunchKernelGGL(k_bf_dgrad128, dim3(pl.grid), dim3(512), pl.lds, s, p);
-        mn_prof_end(s);
-        MN_CHECK_LAUNCH("mn_iaobf_bwd_data");
-        return MN_OK;
-    }
     raise_lds_limit(pl.NT == 4 ? (const void*)k_bf_dgrad<4> : (pl.NT == 2 ? (const void*)k_bf_dgrad<2> : (const void*)k_bf_dgrad<1>), pl.lds);
     if (pl.NT == 4) hipLaunchKernelGGL(k_bf_dgrad<4>, dim3(pl.grid), dim3(256), pl.lds, s, p);
     else if (pl.NT == 2) hipLaunchKernelGGL(k_bf_dgrad<2>, dim3(pl.grid), dim3(256), pl.lds, s, p);

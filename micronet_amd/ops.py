@@ -794,13 +794,27 @@ class IaoBNFuseGeneric(Function):
         dev = x.device
         n = float(g.N * Ho * Wo)
         none = ActQ(ACTQ_NONE, 0, 0, 0, None)
+        # the first layer of a net (an image, <= 128 patch elements per output): the statistics of the raw convolution from the Gram matrix of the im2col matrix
+        # (mn_iaobf_gram in patch mode) -- no raw convolution, no y_raw, and in the backward no raw backward-weight (same algebra as the pointwise layers)
+        gram_first = (not x.requires_grad) and CONV_ALGO == _lib.MN_ALGO_AUTO and g.KH > 1 and bool(lib.mn_iaobf_gram_supported(C.byref(g))) and \
+            bool(lib.mn_conv2d_first_supported(C.byref(g), 0)) and bool(lib.mn_conv2d_first_supported(C.byref(g), 2))
+        y_raw = vc = sx = None
         with torch.cuda.device_of(x):
-            y_raw = torch.empty((g.N, O, Ho, Wo), dtype=torch.float32, device=dev)
             ws, nb = _ws(g, 0, dev)
-            _call("mn_conv2d_fwd", C.byref(g), C.byref(none), None, _p(x), _p(weight), _p(bias), _p(y_raw), _p(ws), nb, CONV_ALGO, _s())
             stats_raw = torch.empty((2, O), dtype=torch.float32, device=dev)
-            wss = torch.empty(int(lib.mn_bn_stats_ws_floats(g.N, O, Ho * Wo)) + 2, dtype=torch.float32, device=dev)
-            _call("mn_bn_stats_fwd", _p(y_raw), g.N, O, Ho * Wo, _p(stats_raw), _p(wss), _s())
+            if gram_first:
+                nbg = int(lib.mn_iaobf_gram_ws_bytes(C.byref(g)))
+                wsg = torch.empty(nbg // 4 + 4, dtype=torch.float32, device=dev)
+                gram = torch.empty((K, K), dtype=torch.float64, device=dev)
+                sx = torch.empty(K, dtype=torch.float64, device=dev)
+                _call("mn_iaobf_gram", C.byref(g), _p(x), _p(gram), _p(sx), _p(wsg), nbg, _s())
+                vc = torch.empty((O, K), dtype=torch.float32, device=dev)
+                _call("mn_iaobf_gram_stats", _p(weight), _p(bias), _p(gram), _p(sx), O, K, 1, n, _p(stats_raw), _p(vc), _s())
+            else:
+                y_raw = torch.empty((g.N, O, Ho, Wo), dtype=torch.float32, device=dev)
+                _call("mn_conv2d_fwd", C.byref(g), C.byref(none), None, _p(x), _p(weight), _p(bias), _p(y_raw), _p(ws), nb, CONV_ALGO, _s())
+                wss = torch.empty(int(lib.mn_bn_stats_ws_floats(g.N, O, Ho * Wo)) + 2, dtype=torch.float32, device=dev)
+                _call("mn_bn_stats_fwd", _p(y_raw), g.N, O, Ho * Wo, _p(stats_raw), _p(wss), _s())
             first_bn = (not st.pretrained_model) and st.num_flag == 0
             if first_bn:
                 st.num_flag += 1
@@ -852,7 +866,7 @@ class IaoBNFuseGeneric(Function):
         grid = getattr(x, "_mn_qgrid", None)
         if grid is not None and (grid[3] != x._version or not (2 <= grid[1] <= 8) or grid[2] != 0):
             grid = None
-        ctx.save_for_backward(x, weight, bias, gamma, out if relu else None, stats, qw, wqp, aqp, y_raw, xq, grid[0] if grid is not None else None)
+        ctx.save_for_backward(x, weight, bias, gamma, out if relu else None, stats, qw, wqp, aqp, y_raw, xq, grid[0] if grid is not None else None, vc, sx)
         ctx.xgrid = (grid[1], grid[2]) if grid is not None else None
         ctx.cfg = (g, aq_.bits, aq_.q_type, wq_.bits, wq_._q_type_static, float(st.eps), n, bool(relu), bool(first_layer))
         ctx.tok_in = getattr(x, "_mn_relu_token", None)
@@ -875,7 +889,7 @@ class IaoBNFuseGeneric(Function):
 
     @staticmethod
     def backward(ctx, gin):
-        x, weight, bias, gamma, a, stats, qw, wqp, aqp, y_raw, xq, gridqp = ctx.saved_tensors
+        x, weight, bias, gamma, a, stats, qw, wqp, aqp, y_raw, xq, gridqp, vc, sx = ctx.saved_tensors
         g, a_bits, a_qtype, w_bits, w_qtype, eps, n, relu, first_layer = ctx.cfg
         dev = x.device
         if relu and isinstance(gin, LazyReluGrad) and gin._mn_value is None:
@@ -899,8 +913,11 @@ class IaoBNFuseGeneric(Function):
             dbias = torch.empty(O, dtype=torch.float32, device=dev) if bias is not None else None
             dgamma, dbeta = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
             coef = torch.empty((4, O), dtype=torch.float32, device=dev)
-            _call("mn_iaobf_prep_bwd", _p(dwq), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(stats), _p(wqp), O, K, g.groups, None, None, n, eps, w_bits, w_qtype,
+            _call("mn_iaobf_prep_bwd", _p(dwq), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(stats), _p(wqp), O, K, g.groups, _p(vc), _p(sx), n, eps, w_bits, w_qtype,
                   _p(dw), _p(dbias), _p(dgamma), _p(dbeta), _p(coef), _s())
+            if vc is not None:          # first layer on the Gram data: dw is complete, there is no input gradient
+                ctx.x_obj = None
+                return None, dw, dbias, dgamma, dbeta, None, None, None, None
             # the statistics path: d y_raw from (dmean, dvar), the raw convolution's backward-weight (and backward-data)
             d_o = torch.empty_like(y_raw)
             _call("mn_bn_stats_bwd", _p(y_raw), _p(stats), _p(coef[2]), _p(coef[3]), _p(d_o), y_raw.shape[0], O, y_raw.shape[2] * y_raw.shape[3], _s())

@@ -268,3 +268,23 @@ def check_iao_codes_at_boundaries(be, seed=0):
     dw_ref = np.einsum("nohw,nchw->oc", g.astype(np.float64), code_ref) * np.float64(sc)
     errw = np.abs(be.to_host(dw).reshape(O, Cc).astype(np.float64) - dw_ref).max() / np.abs(dw_ref).max()
     assert errw <= 2e-6, ("backward-weight codes", errw)
+
+
+def check_gram_patch(be, N=3, Cin=3, H=8, W=12, k=5, seed=0):
+    """mn_iaobf_gram in patch mode (the first layer): Gram matrix and column sums of the im2col matrix of the image, against torch's unfold in fp64."""
+    lib = be.lib
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=gen) * 1.7 + 0.3
+    geom = _lib.ConvGeom(N, Cin, H, W, 16, k, k, 1, 1, k // 2, k // 2, 1, 1, 1, 0)
+    assert lib.mn_iaobf_gram_supported(C.byref(geom)) == 1 and lib.mn_iaobf_bwd_data_supported(C.byref(geom)) == 0
+    K = Cin * k * k
+    nb = int(lib.mn_iaobf_gram_ws_bytes(C.byref(geom)))
+    ws, gram, sx = be.empty(nb // 4 + 4), be.empty(2 * K * K), be.empty(2 * K)
+    be.call("mn_iaobf_gram", C.byref(geom), be.ptr(be.to_dev(x.numpy())), be.ptr(gram), be.ptr(sx), be.ptr(ws), nb, be.stream)
+    cols = torch.nn.functional.unfold(x.double(), k, padding=k // 2)            # [N, K, H * W], rows ordered (c, dy, dx) like weight.reshape(O, K)
+    cols = cols.permute(1, 0, 2).reshape(K, -1)
+    ref = (cols @ cols.t()).numpy()
+    got = np.frombuffer(be.to_host(gram).tobytes(), dtype=np.float64).reshape(K, K)
+    sxg = np.frombuffer(be.to_host(sx).tobytes(), dtype=np.float64)
+    assert np.abs(got - ref).max() <= 6e-6 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    assert np.abs(sxg - cols.sum(1).numpy()).max() <= 2e-6 * np.abs(cols.sum(1).numpy()).max()

@@ -675,3 +675,10 @@ def test_iao_codes_at_rounding_boundaries(be):
     import iaobf_cases as B
     B.check_iao_codes_at_boundaries(be)
     B.check_iao_codes_at_boundaries(be, seed=5)
+
+
+@pytest.mark.parametrize("k,Cin,W", [(5, 3, 12), (3, 7, 8), (5, 5, 4)])
+def test_iaobf_gram_of_first_layer_patches(be, k, Cin, W):
+    import iaobf_cases as B
+    B.check_gram_patch(be, Cin=Cin, W=W, k=k, seed=k + Cin)
+    B.check_gram_patch(be, N=64, Cin=3, H=32, W=32, k=5, seed=1)

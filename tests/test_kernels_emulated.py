@@ -465,3 +465,9 @@ def test_bnfuse_stream_helpers(be):
 def test_iao_codes_at_rounding_boundaries(be):
     import iaobf_cases as B
     B.check_iao_codes_at_boundaries(be)
+
+
+@pytest.mark.parametrize("k,Cin,W", [(5, 3, 12), (3, 7, 8), (5, 5, 4)])
+def test_iaobf_gram_of_first_layer_patches(be, k, Cin, W):
+    import iaobf_cases as B
+    B.check_gram_patch(be, Cin=Cin, W=W, k=k, seed=k + Cin)
