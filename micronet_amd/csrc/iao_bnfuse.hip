@@ -301,11 +301,10 @@ __global__ __launch_bounds__(128) void k_bf_gram_stats(const float* __restrict__
     for (int k = 0; k < BF_GS_CH; ++k) { acc[k] = 0.0; m1p[k] = 0.0; }
     const double xbi = tid < Cg ? sxg[tid] / n : 0.0;
     if (tid < Cg) {
-        const float* __restrict__ wrow = w + (int64_t)o0 * Cg;          // (wave-uniform addresses below: scalar loads, no LDS round trip per FMA)
-        for (int c = 0; c < Cg; ++c) {
+        for (int c = 0; c < Cg; ++c) {          // (tried: unroll 8 -> 46 us, weights by wave-uniform global loads -> 55 us; this form 31 us)
             const double gv = G[(int64_t)c * Cg + tid];
 #pragma unroll
-            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (k < nch ? (double)wrow[(int64_t)k * Cg + c] : 0.0) * gv;
+            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (double)ws[k][c] * gv;
         }
 #pragma unroll
         for (int k = 0; k < BF_GS_CH; ++k) m1p[k] = (double)ws[k][tid] * xbi;
@@ -774,10 +773,9 @@ __global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
         const int no = p.Mg - ob < 128 ? p.Mg - ob : 128;
         if (tid < p.KpB && tid < p.Cg) {
             for (int oo = 0; oo < no; ++oo) {
-                const float* __restrict__ wo = wg + (int64_t)(ob + oo) * p.Cg;
-                const double wv = (double)B[ob + oo] * (double)wo[tid];
+                const double wv = (double)B[ob + oo] * (double)wg[(int64_t)(ob + oo) * p.Cg + tid];
 #pragma unroll
-                for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (c0 + r < p.Cg ? (double)wo[c0 + r] : 0.0);          // wave-uniform address: a scalar load
+                for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (double)wcol[r][oo];
             }
         }
         if (tid < BF_M_ROWS)

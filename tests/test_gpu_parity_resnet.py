@@ -415,6 +415,7 @@ def test_full_batch_teacher_forced_resnet_iao(key):
     # ---- blocks, in four pieces each
     for n in blocks:
         ob, pb = _get(pristine, n), _get(prod, n)
+        pb_whole = copy.deepcopy(pb)          # (the whole-block stage at the end needs the block's quantizers at their FIRST call too: the pieces below consume pb's)
         xin, gout = rec[n]["in"], rec[n]["gout"]
         has_sc = len(ob.shortcut) > 0
         # oracle intermediates of THIS block on the oracle's own input (fresh copy: first observer call, as in the full pass)
@@ -461,6 +462,36 @@ def test_full_batch_teacher_forced_resnet_iao(key):
         errs["ties_masked_frac"] = float((~keep_t).sum()) / keep_t.numel()
         run_piece(n + ":t", errs, tail_o, tail_p, [zb.detach(), zs.detach()], gout * keep_t, True, combine=comb)
         report[n + ":qadd-relu"] = {k: float("%.2e" % v) for k, v in errs.items()}
+        # ---- the WHOLE block with every hand-over live: conv -> fused BN+ReLU (its (min, max) partials feed the next conv's observer) -> conv ->
+        # BN -> [shortcut conv -> BN] -> QuantAdd + ReLU (its partials feed the next block), on the oracle's input and incoming gradient.  The decisions INSIDE the
+        # block cannot be teacher-forced from outside: where the oracle's own mid pre-activation sits within TIE_EPS of the ReLU kink (keep_a: ~1e-5 of the elements)
+        # one flipped mask moves dx by a whole term at the positions that element reaches, so dx is held to 1e-5 at the 99.99th percentile (and its outliers are
+        # counted); the output and every parameter gradient (sums over all positions: one term in 10^6) to the ordinary 1e-5 max-norm.
+        errs = {"mid_ties": float((~keep_a).sum())}
+        ob2, pb2 = copy.deepcopy(ob).train(), pb_whole.train()
+        xo = xin.clone().requires_grad_(True)
+        yo = ob2(xo)
+        yo.backward(gout * keep_t)
+        for p_ in pb2.parameters():
+            p_.grad = None
+        xp = xin.cuda().requires_grad_(True)
+        yp = pb2(xp)
+        e, ff = _flip_aware(yp, yo)
+        check(n + ":whole", errs, "y", e)
+        errs["y_level_flips_frac"] = ff
+        yp.backward((gout * keep_t).cuda())
+        d = (xp.grad.detach().double().cpu() - xo.grad.double()).abs() / xo.grad.double().abs().max().clamp_min(1e-30)
+        errs["dx_max"] = float(d.max())
+        errs["dx_outliers_frac"] = float((d > 1e-5).double().mean())
+        kth = max(1, int(0.9999 * d.numel()))
+        check(n + ":whole", errs, "dx_p9999", float(d.flatten().kthvalue(kth).values))
+        if errs["dx_outliers_frac"] > 1e-3:
+            failures.append((n + ":whole", "dx outliers beyond the reach of the mid-activation ties", errs["dx_outliers_frac"]))
+        pn2 = dict(pb2.named_parameters())
+        for name, p_ in ob2.named_parameters():
+            if p_.grad is not None and name in pn2 and pn2[name].grad is not None:
+                check(n + ":whole", errs, "d" + name, _rel(pn2[name].grad, p_.grad), 2e-5)
+        report[n + ":whole-block"] = {k: float("%.2e" % v) for k, v in errs.items()}
     # ---- classifier tail: average pool -> flatten -> QuantLinear
     errs = {}
     comb = lambda mods, t: mods[1](mods[0](t).view(t.size(0), -1))
