@@ -236,6 +236,7 @@ static int plan_gram(const mn_conv_geom* g, GramPlan* pl) {
     p.fd_hw = make_fastdiv((uint32_t)HW);
     // every fp32 accumulator sums <= 32 slabs (2048 pixels); about two blocks per CU; a partial tile costs CP * CP * 4 bytes written + read back
     int Z = 512 / p.G;
+    if (const char* e = MN_ENV("MN_GRAM_BLOCKS")) { const int v = atoi(e); if (v >= 64 && v <= 4096) Z = v / p.G > 0 ? v / p.G : 1; }          // tuning knob (A/B runs)
     if (Z > (p.nchunks + 7) / 8) Z = (p.nchunks + 7) / 8;
     if (Z < (p.nchunks + 31) / 32) Z = (p.nchunks + 31) / 32;
     if (Z < 1) Z = 1;
@@ -282,61 +283,68 @@ extern "C" int mn_iaobf_gram(const mn_conv_geom* g, const float* x, double* gram
 // var[o] = Vc[o,:] . W[o,:] / (n - 1), everything in fp64; Vc (rounded to fp32: it is the centred quantity, no cancellation left) is kept for the backward, where
 // the raw convolution's weight gradient is dmean x_bar + B Vc.  G is read once per BF_GS_CH channels (a block per channel re-read all of it: 128 KB x O).
 #define BF_GS_CH 8
-__global__ __launch_bounds__(128) void k_bf_gram_stats(const float* __restrict__ w, const float* __restrict__ bias, const double* __restrict__ gram,
+// 256 threads = two halves of 128: half h owns channels o0 + 8 h .. + 7, thread i of a half column i.  The group's whole Gram matrix is staged in LDS first (bulk
+// coalesced loads, all in flight) -- read from global inside the loop it cost one serialised L2 round trip per row (31 us for 128 rows).
+__global__ __launch_bounds__(256) void k_bf_gram_stats(const float* __restrict__ w, const float* __restrict__ bias, const double* __restrict__ gram,
                                                        const double* __restrict__ sx, int O, int Mg, int Cg, double n, float* __restrict__ stats,
                                                        float* __restrict__ vc) {
-    __shared__ float ws[BF_GS_CH][128];
-    __shared__ double red[BF_GS_CH][2][2];
-    const int nb = (Mg + BF_GS_CH - 1) / BF_GS_CH;
-    const int g = blockIdx.x / nb, o0 = g * Mg + (blockIdx.x % nb) * BF_GS_CH;
-    const int tid = threadIdx.x;
+    HIP_DYNAMIC_SHARED(double, gsm)          // [Cg * Cg] G, then ws [2 * BF_GS_CH][128] floats, then red [2 * BF_GS_CH][2][2] doubles
+    double* red = gsm + Cg * Cg;
+    float* ws = reinterpret_cast<float*>(red + 2 * BF_GS_CH * 4);
+    const int nb = (Mg + 2 * BF_GS_CH - 1) / (2 * BF_GS_CH);
+    const int g = blockIdx.x / nb, ob = (blockIdx.x % nb) * 2 * BF_GS_CH;
+    const int tid = threadIdx.x, half = tid >> 7, i = tid & 127;
+    const int o0 = g * Mg + ob + half * BF_GS_CH;
     const double* __restrict__ G = gram + (int64_t)g * Cg * Cg;
     const double* __restrict__ sxg = sx + (int64_t)g * Cg;
-    int nch = Mg - (blockIdx.x % nb) * BF_GS_CH;
-    nch = nch < BF_GS_CH ? nch : BF_GS_CH;
-    for (int k = 0; k < BF_GS_CH; ++k) ws[k][tid] = (k < nch && tid < Cg) ? w[(int64_t)(o0 + k) * Cg + tid] : 0.f;
+    int nch = Mg - ob - half * BF_GS_CH;
+    nch = nch < 0 ? 0 : (nch < BF_GS_CH ? nch : BF_GS_CH);
+    for (int e = tid; e < Cg * Cg; e += 256) gsm[e] = G[e];
+    for (int k = 0; k < BF_GS_CH; ++k) ws[(half * BF_GS_CH + k) * 128 + i] = (k < nch && i < Cg) ? w[(int64_t)(o0 + k) * Cg + i] : 0.f;
     __syncthreads();
+    const float* wsh = ws + half * BF_GS_CH * 128;
     double acc[BF_GS_CH], m1p[BF_GS_CH];
 #pragma unroll
     for (int k = 0; k < BF_GS_CH; ++k) { acc[k] = 0.0; m1p[k] = 0.0; }
-    const double xbi = tid < Cg ? sxg[tid] / n : 0.0;
-    if (tid < Cg) {
-        for (int c = 0; c < Cg; ++c) {          // (tried: unroll 8 -> 46 us, weights by wave-uniform global loads -> 55 us; this form 31 us)
-            const double gv = G[(int64_t)c * Cg + tid];
+    const double xbi = i < Cg ? sxg[i] / n : 0.0;
+    if (i < Cg) {
+        for (int c = 0; c < Cg; ++c) {
+            const double gv = gsm[c * Cg + i];
 #pragma unroll
-            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (double)ws[k][c] * gv;
+            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (double)wsh[k * 128 + c] * gv;
         }
 #pragma unroll
-        for (int k = 0; k < BF_GS_CH; ++k) m1p[k] = (double)ws[k][tid] * xbi;
+        for (int k = 0; k < BF_GS_CH; ++k) m1p[k] = (double)wsh[k * 128 + i] * xbi;
     }
-    // m1[k] = sum_i w[k][i] x_bar[i] (wave shuffles, two waves through LDS)
+    // m1[k] = sum_i w[k][i] x_bar[i]: wave shuffles, the two waves of a half combined through LDS
+    double* redh = red + half * BF_GS_CH * 4;
 #pragma unroll
     for (int k = 0; k < BF_GS_CH; ++k) {
         double v = m1p[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) red[k][tid >> 6][0] = v;
+        if ((tid & 63) == 0) redh[k * 4 + ((tid >> 6) & 1) * 2] = v;
     }
     __syncthreads();
     double qp_[BF_GS_CH];
 #pragma unroll
     for (int k = 0; k < BF_GS_CH; ++k) {
-        const double m1 = red[k][0][0] + red[k][1][0];
+        const double m1 = redh[k * 4] + redh[k * 4 + 2];
         const double vcv = acc[k] - n * m1 * xbi;          // centred: (W S)[o, i]
-        if (k < nch && tid < Cg) vc[(int64_t)(o0 + k) * Cg + tid] = (float)vcv;
-        qp_[k] = tid < Cg ? vcv * (double)ws[k][tid] : 0.0;
+        if (k < nch && i < Cg) vc[(int64_t)(o0 + k) * Cg + i] = (float)vcv;
+        qp_[k] = i < Cg ? vcv * (double)wsh[k * 128 + i] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < BF_GS_CH; ++k) {
         double v = qp_[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) red[k][tid >> 6][1] = v;
+        if ((tid & 63) == 0) redh[k * 4 + ((tid >> 6) & 1) * 2 + 1] = v;
     }
     __syncthreads();
-    if (tid < nch) {
-        const int k = tid;
-        const double m1 = red[k][0][0] + red[k][1][0], q = red[k][0][1] + red[k][1][1];
+    if (i < nch) {
+        const int k = i;
+        const double m1 = redh[k * 4] + redh[k * 4 + 2], q = redh[k * 4 + 1] + redh[k * 4 + 3];
         stats[o0 + k] = (float)(m1 + (bias ? (double)bias[o0 + k] : 0.0));
         stats[O + o0 + k] = (float)(q / (n - 1.0));
     }
@@ -344,9 +352,11 @@ __global__ __launch_bounds__(128) void k_bf_gram_stats(const float* __restrict__
 extern "C" int mn_iaobf_gram_stats(const float* w, const float* bias, const double* gram, const double* sx, int64_t O, int64_t Cg, int64_t groups, double n, float* stats,
                                    float* vc, mn_stream_t stream) {
     if (!w || !gram || !sx || !stats || !vc || O <= 0 || Cg <= 0 || Cg > 128 || groups < 1 || O % groups || !(n > 1.0)) MN_FAIL(MN_EINVAL, "mn_iaobf_gram_stats: bad arguments");
-    const int Mg = (int)(O / groups), nb = (Mg + BF_GS_CH - 1) / BF_GS_CH;
+    const int Mg = (int)(O / groups), nb = (Mg + 2 * BF_GS_CH - 1) / (2 * BF_GS_CH);
+    const size_t lds = (size_t)Cg * Cg * 8 + (size_t)2 * BF_GS_CH * 4 * 8 + (size_t)2 * BF_GS_CH * 128 * 4;
     mn_set_last_kernel("k_bf_gram_stats");
-    hipLaunchKernelGGL(k_bf_gram_stats, dim3((unsigned)(groups * nb)), dim3(128), 0, (hipStream_t)stream, w, bias, gram, sx, (int)O, Mg, (int)Cg, n, stats, vc);
+    raise_lds_limit((const void*)k_bf_gram_stats, lds);
+    hipLaunchKernelGGL(k_bf_gram_stats, dim3((unsigned)(groups * nb)), dim3(256), lds, (hipStream_t)stream, w, bias, gram, sx, (int)O, Mg, (int)Cg, n, stats, vc);
     MN_CHECK_LAUNCH("mn_iaobf_gram_stats");
     return MN_OK;
 }
@@ -751,43 +761,38 @@ struct BfMParams {
     double n;
 };
 #define BF_M_ROWS 8
-__global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
-    __shared__ float wcol[BF_M_ROWS][128];          // B[o] * W[o][c0 + r] for the block's rows
-    const int nrb = p.Mpad / BF_M_ROWS;
-    const int g = blockIdx.x / nrb, c0 = (blockIdx.x % nrb) * BF_M_ROWS, tid = threadIdx.x;
+// 256 threads = two halves of 128: half h owns rows c0 + 8 h .. + 7 of M, thread i of a half column i.  The group's weights (Mg x Cg fp32) are staged in LDS first
+// (the loop over o then reads LDS only: from global it was one serialised L2 round trip per o, 48 us).
+__global__ __launch_bounds__(256) void k_bf_M(const BfMParams p) {
+    HIP_DYNAMIC_SHARED(float, wsm)          // [Mg][Cg] W of the group, then [Mg] B
+    float* bsm = wsm + p.Mg * p.Cg;
+    const int nrb = p.Mpad / (2 * BF_M_ROWS);
+    const int g = blockIdx.x / nrb, tid = threadIdx.x, half = tid >> 7, i = tid & 127;
+    const int c0 = (blockIdx.x % nrb) * 2 * BF_M_ROWS + half * BF_M_ROWS;
     const float* __restrict__ wg = p.w + (int64_t)g * p.Mg * p.Cg;
-    const float* __restrict__ B = p.coef + p.O + g * p.Mg;
     const float* __restrict__ A = p.coef + g * p.Mg;
-    // M[c][c2] = sum_o B[o] W[o][c] W[o][c2] (fp64), BF_M_ROWS rows c per block: W is read once per BF_M_ROWS rows
+    for (int e = tid; e < p.Mg * p.Cg; e += 256) wsm[e] = wg[e];
+    for (int o = tid; o < p.Mg; o += 256) bsm[o] = p.coef[p.O + g * p.Mg + o];
+    __syncthreads();
+    // M[c][c2] = sum_o B[o] W[o][c] W[o][c2] (fp64)
     double m[BF_M_ROWS];
 #pragma unroll
     for (int r = 0; r < BF_M_ROWS; ++r) m[r] = 0.0;
-    double vsum = 0.0;          // thread r < BF_M_ROWS: v[c0 + r] = sum_o (dmean[o] / n) W[o][c0 + r]
-    for (int ob = 0; ob < p.Mg; ob += 128) {
-        __syncthreads();
-        for (int r = 0; r < BF_M_ROWS; ++r) {
-            const int o = ob + tid;
-            wcol[r][tid] = (o < p.Mg && c0 + r < p.Cg) ? wg[(int64_t)o * p.Cg + c0 + r] : 0.f;
-        }
-        __syncthreads();
-        const int no = p.Mg - ob < 128 ? p.Mg - ob : 128;
-        if (tid < p.KpB && tid < p.Cg) {
-            for (int oo = 0; oo < no; ++oo) {
-                const double wv = (double)B[ob + oo] * (double)wg[(int64_t)(ob + oo) * p.Cg + tid];
+    if (i < p.Cg) {
+        for (int o = 0; o < p.Mg; ++o) {
+            const float* wo = wsm + o * p.Cg;
+            const double wv = (double)bsm[o] * (double)wo[i];
 #pragma unroll
-                for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (double)wcol[r][oo];
-            }
+            for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (double)(c0 + r < p.Cg ? wo[c0 + r] : 0.f);
         }
-        if (tid < BF_M_ROWS)
-            for (int oo = 0; oo < no; ++oo) vsum += (double)A[ob + oo] * (double)wcol[tid][oo];
     }
     const int64_t plane = (int64_t)p.G * p.Mpad * p.KpB;
-    for (int c2 = tid; c2 < p.KpB; c2 += 128) {
+    if (i < p.KpB) {
 #pragma unroll
         for (int r = 0; r < BF_M_ROWS; ++r) {
-            const float v = (c2 == tid && c2 < p.Cg && c0 + r < p.Cg) ? (float)m[r] : 0.f;
+            const float v = (i < p.Cg && c0 + r < p.Cg) ? (float)m[r] : 0.f;
             const float t0 = mn_bf16_head(v), r1 = v - t0, t1 = mn_bf16_head(r1), t2 = r1 - t1;
-            const int64_t at = ((int64_t)g * p.Mpad + c0 + r) * p.KpB + c2;
+            const int64_t at = ((int64_t)g * p.Mpad + c0 + r) * p.KpB + i;
             p.mt[at] = (uint16_t)(mn_f2u(t0) >> 16);
             p.mt[plane + at] = (uint16_t)(mn_f2u(t1) >> 16);
             p.mt[2 * plane + at] = (uint16_t)(mn_f2u(t2) >> 16);
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
     // transposed codes of the quantised weights: code = rha(qw / scale[o]) (exact small integers)
     for (int r = 0; r < BF_M_ROWS; ++r) {
         const int c = c0 + r;
-        for (int o = tid; o < p.KpA; o += 128) {
+        for (int o = i; o < p.KpA; o += 128) {
             float code = 0.f;
             if (c < p.Cg && o < p.Mg) {
                 const int oo = g * p.Mg + o;
@@ -805,11 +810,13 @@ __global__ __launch_bounds__(128) void k_bf_M(const BfMParams p) {
             p.wc[((int64_t)g * p.Mpad + c) * p.KpA + o] = (uint16_t)(mn_f2u(code) >> 16);
         }
     }
-    if (c0 == 0)
-        for (int o = tid; o < p.KpA; o += 128) p.kscale[g * p.KpA + o] = o < p.Mg ? p.wscale[(int64_t)(g * p.Mg + o) * p.wscale_stride] : 0.f;
-    if (tid < BF_M_ROWS && c0 + tid < p.Cg) {
-        p.vadd[g * p.Cg + c0 + tid] = (float)vsum;
-        p.xbar[g * p.Cg + c0 + tid] = (float)(p.sx[g * p.Cg + c0 + tid] / p.n);
+    if (blockIdx.x % nrb == 0 && half == 0)
+        for (int o = i; o < p.KpA; o += 128) p.kscale[g * p.KpA + o] = o < p.Mg ? p.wscale[(int64_t)(g * p.Mg + o) * p.wscale_stride] : 0.f;
+    if (i < BF_M_ROWS && c0 + i < p.Cg) {          // v[c] = sum_o (dmean[o] / n) W[o][c]; x_bar
+        double vsum = 0.0;
+        for (int o = 0; o < p.Mg; ++o) vsum += (double)A[o] * (double)wsm[o * p.Cg + c0 + i];
+        p.vadd[g * p.Cg + c0 + i] = (float)vsum;
+        p.xbar[g * p.Cg + c0 + i] = (float)(p.sx[g * p.Cg + c0 + i] / p.n);
     }
 }
 
@@ -866,7 +873,11 @@ extern "C" int mn_iaobf_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const
     m.mt = (uint16_t*)ws; m.wc = (uint16_t*)((char*)ws + pl.off_wc); m.kscale = (float*)((char*)ws + pl.off_ks);
     m.xbar = (float*)((char*)ws + pl.off_xbar); m.vadd = (float*)((char*)ws + pl.off_v);
     m.O = g->O; m.Cg = p.Cg; m.Mg = p.Mg; m.G = p.G; m.Mpad = p.Mpad; m.KpA = p.KpA; m.KpB = p.KpB; m.n = (double)g->N * g->H * g->W;
-    hipLaunchKernelGGL(k_bf_M, dim3((unsigned)(p.G * p.Mpad / BF_M_ROWS)), dim3(128), 0, s, m);
+    {
+        const size_t ldsm = ((size_t)p.Mg * p.Cg + p.Mg) * 4;
+        raise_lds_limit((const void*)k_bf_M, ldsm);
+        hipLaunchKernelGGL(k_bf_M, dim3((unsigned)(p.G * p.Mpad / (2 * BF_M_ROWS))), dim3(256), ldsm, s, m);
+    }
     const IaoRange r = iao_range(aq->bits, aq->q_type, 1);
     p.gy = gy; p.x = x; p.dx = dx; p.wc = m.wc; p.kscale = m.kscale; p.mt = m.mt; p.xbar = m.xbar; p.vadd = m.vadd; p.qp = aq->qp; p.qmin = r.qmin; p.qmax = r.qmax;
     p.relu_mask = relu_mask;
