@@ -201,12 +201,20 @@ __global__ __launch_bounds__(256) void k_bf_gram_reduce(const float* __restrict_
             if (m < Cg && c < Cg) gram[((int64_t)gg * Cg + m) * Cg + c] = t;
         }
     } else {
-        const int64_t total = (int64_t)G * Cg;
-        for (int64_t i = (int64_t)(blockIdx.x - nblk_w) * 256 + threadIdx.x; i < total; i += (int64_t)(gridDim.x - nblk_w) * 256) {
-            const int gg = (int)(i / Cg), c = (int)(i % Cg);
+        // channel sums: 16 lanes per channel, each a strided z subset with four loads in flight, combined by a fixed-order butterfly (one thread per channel walking
+        // all Z partials made this tail -- Z serialised L2 round trips -- the longest part of the launch: 40 us)
+        const int64_t total = (int64_t)G * Cg, nslots = ((total + 15) / 16) * 16;
+        const int per = 256 / 16;
+        for (int64_t i0 = (int64_t)(blockIdx.x - nblk_w) * per; i0 < nslots; i0 += (int64_t)(gridDim.x - nblk_w) * per) {
+            const int64_t i = i0 + q;
             double t = 0.0;
-            for (int z = 0; z < Z; ++z) t += (double)sxpart[((int64_t)z * G + gg) * CP + c];
-            sx[i] = t;
+            if (i < total) {
+                const int gg = (int)(i / Cg), c = (int)(i % Cg);
+#pragma unroll 4
+                for (int z = l; z < Z; z += 16) t += (double)sxpart[((int64_t)z * G + gg) * CP + c];
+            }
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+            if (l == 0 && i < total) sx[i] = t;
         }
     }
 }
@@ -282,6 +290,21 @@ extern "C" int mn_iaobf_gram(const mn_conv_geom* g, const float* x, double* gram
 // A block owns BF_GS_CH output channels of one group: mean[o] = W[o,:] . x_bar + b[o],  Vc[o,:] = W[o,:] S (S = G - n x_bar x_bar^T, the centred second moment),
 // var[o] = Vc[o,:] . W[o,:] / (n - 1), everything in fp64; Vc (rounded to fp32: it is the centred quantity, no cancellation left) is kept for the backward, where
 // the raw convolution's weight gradient is dmean x_bar + B Vc.  G is read once per BF_GS_CH channels (a block per channel re-read all of it: 128 KB x O).
+// global -> LDS copy of n4 16-byte units by `nthr` threads with eight loads in flight per thread (a plain `dst[e] = src[e]` loop waits for every load)
+template <typename V>
+__device__ __forceinline__ void bf_stage16(V* __restrict__ dst, const V* __restrict__ src, int n4, int tid, int nthr) {
+    int e = tid;
+    for (; e + 7 * nthr < n4; e += 8 * nthr) {
+        V v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[e + u * nthr];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[e + u * nthr] = v[u];
+    }
+    for (; e < n4; e += nthr) dst[e] = src[e];
+}
+struct __attribute__((aligned(16))) bf_d2 { double a, b; };
+
 #define BF_GS_CH 8
 // 256 threads = two halves of 128: half h owns channels o0 + 8 h .. + 7, thread i of a half column i.  The group's whole Gram matrix is staged in LDS first (bulk
 // coalesced loads, all in flight) -- read from global inside the loop it cost one serialised L2 round trip per row (31 us for 128 rows).
@@ -299,7 +322,8 @@ __global__ __launch_bounds__(256) void k_bf_gram_stats(const float* __restrict__
     const double* __restrict__ sxg = sx + (int64_t)g * Cg;
     int nch = Mg - ob - half * BF_GS_CH;
     nch = nch < 0 ? 0 : (nch < BF_GS_CH ? nch : BF_GS_CH);
-    for (int e = tid; e < Cg * Cg; e += 256) gsm[e] = G[e];
+    if ((Cg & 1) == 0 && !(((uintptr_t)G) & 15)) bf_stage16(reinterpret_cast<bf_d2*>(gsm), reinterpret_cast<const bf_d2*>(G), Cg * Cg / 2, tid, 256);
+    else for (int e = tid; e < Cg * Cg; e += 256) gsm[e] = G[e];
     for (int k = 0; k < BF_GS_CH; ++k) ws[(half * BF_GS_CH + k) * 128 + i] = (k < nch && i < Cg) ? w[(int64_t)(o0 + k) * Cg + i] : 0.f;
     __syncthreads();
     const float* wsh = ws + half * BF_GS_CH * 128;
@@ -771,7 +795,8 @@ __global__ __launch_bounds__(256) void k_bf_M(const BfMParams p) {
     const int c0 = (blockIdx.x % nrb) * 2 * BF_M_ROWS + half * BF_M_ROWS;
     const float* __restrict__ wg = p.w + (int64_t)g * p.Mg * p.Cg;
     const float* __restrict__ A = p.coef + g * p.Mg;
-    for (int e = tid; e < p.Mg * p.Cg; e += 256) wsm[e] = wg[e];
+    if (((p.Mg * p.Cg) & 3) == 0 && !(((uintptr_t)wg) & 15)) bf_stage16(reinterpret_cast<float4*>(wsm), reinterpret_cast<const float4*>(wg), p.Mg * p.Cg / 4, tid, 256);
+    else for (int e = tid; e < p.Mg * p.Cg; e += 256) wsm[e] = wg[e];
     for (int o = tid; o < p.Mg; o += 256) bsm[o] = p.coef[p.O + g * p.Mg + o];
     __syncthreads();
     // M[c][c2] = sum_o B[o] W[o][c] W[o][c2] (fp64)
