@@ -84,7 +84,11 @@ def prefetch_weight_path(model, side=None):
     backward is one launch too); the owning conv picks its tensor up in its forward.  A step of nin_gc saves 12 launches of ~5 us.
     ``side``: a second stream instead (one launch per layer there, overlapping the first layers; measured slower under graph replay --
     the fork / join edges cost more than the launches they hide); join with ``torch.cuda.current_stream().wait_stream(side)`` after
-    ``backward()``."""
+    ``backward()``.
+
+    CONTRACT for IAO nets: the prefetch performs the weight OBSERVER's step of this iteration (EMA of the per-channel range, ``num_flag``, scale / zero-point) for
+    every module it covers -- the reference performs it inside the module's forward (iao/quantize.py:214-221).  Each call must therefore be followed by exactly
+    one forward of every covered module before the next call; a second prefetch that finds an unconsumed hand-over raises instead of advancing the observers twice."""
     from micronet_amd import ops
     from micronet_amd.quantization.wbwtab import quantize as wb
     from micronet_amd.quantization.wqaq.dorefa import quantize as dr
@@ -116,7 +120,10 @@ def prefetch_weight_path(model, side=None):
                     and m.weight.dtype == torch.float32:
                 q = m.weight_quantizer
                 obs = q.observer
-                q.__dict__.pop("_mn_pre", None)
+                stale = q.__dict__.pop("_mn_pre", None)
+                if stale is not None and stale[0] is m.weight:
+                    raise RuntimeError("prefetch_weight_path: the IAO weight hand-over of the previous call was never consumed (a covered module did not run its "
+                                       "forward since); its observer would advance twice in one iteration -- see the contract in this function's docstring")
                 if 2 <= q.bits <= 24 and not q.qaft and getattr(obs, "q_level", None) in ("C", "FC") and getattr(obs, "_kind", None) in (0, 1) \
                         and not getattr(obs, "_mn_sync", False) and obs.min_val.numel() == m.weight.shape[0]:
                     groups.setdefault((q.bits, q._q_type_static, obs._kind, float(getattr(obs, "momentum", 0.1))), []).append(m)

@@ -15,7 +15,10 @@ prod = Q.prepare(build_model("resnet18"), inplace=True, **kw).cuda().train()
 get = lambda m, n: eval("m." + n.split(".")[0])[int(n.split(".")[1])]
 rec = {}
 blk = get(orc, name)
-blk.register_forward_hook(lambda mod, i, o: (rec.__setitem__("in", i[0].detach().clone()), o.register_hook(lambda g: rec.__setitem__("gout", g.detach().clone()))))
+def _blk_hook(mod, i, o):
+    rec["in"] = i[0].detach().clone()
+    o.register_hook(lambda g: rec.__setitem__("gout", g.detach().clone()))
+blk.register_forward_hook(_blk_hook)
 x, y = synth_batch(256)
 torch.nn.functional.cross_entropy(orc(x), y).backward()
 ob, pb = copy.deepcopy(get(pristine, name)).train(), get(prod, name)
@@ -45,3 +48,14 @@ print("scale oracle", sc_o, "product", sc_p, "obs max oracle", float(ob.residual
 for i in idx:
     i = tuple(int(t) for t in i)
     print(i, "a_o %.9g a_p %.9g  v_o %.7f  g_o %.4e g_p %.4e" % (float(ao[i]), float(ap[i]), float(ao[i]) / sc_o, float(go[i]), float(gp[i])))
+
+print("dx rel", float((xp.grad.cpu() - xo.grad).abs().max() / xo.grad.abs().max()))
+pn = dict(pb.named_parameters())
+for n_, p_ in ob.named_parameters():
+    if p_.grad is not None and n_ in pn and pn[n_].grad is not None:
+        print("  d%-40s rel %.3e" % (n_, float((pn[n_].grad.cpu() - p_.grad).abs().max() / p_.grad.abs().max())))
+# which g_mid elements differ: relation to the clamp of the NEXT quantizer and to the ReLU
+z = ao / sc_o
+big = d > 1e-5 * go.abs().max()
+print("differing g_mid elements: count", int(big.sum()), " of which a_mid == 0:", int((big & (ao == 0)).sum()), " a/s > 7:", int((big & (z > 7)).sum()), " a/s in (7.4, 7.6):", int((big & (z > 7.4) & (z < 7.6)).sum()))
+print("oracle g_mid zero where product nonzero:", int(((go == 0) & (gp != 0)).sum()), " reverse:", int(((go != 0) & (gp == 0)).sum()))

@@ -13,7 +13,7 @@ whole gradient term with it.  The incoming gradient is zeroed at those positions
 back-propagate through identical decisions; the fraction of masked positions is recorded (it is ~1e-5).
 Tolerance: 1e-5 relative (max-norm) on every float result; integer codes: flips only at rounding ties (fraction <= 1e-5).  d weight of a DoReFa conv: the single
 arg-max |w| element carries a cancelling sum over the whole tensor (see tests/test_gpu_parity_full.py) and is judged against an fp64 evaluation.
-Results: ``gpurun_out/parity_r03.json`` (copied to ``profiles/``)."""
+Results: ``gpurun_out/parity_r04.json`` (copied to ``profiles/``)."""
 import copy
 import importlib
 import json
@@ -286,7 +286,7 @@ def test_full_batch_teacher_forced_resnet(key):
             check_pgrads(name, errs, pst, pg_ref, ost, r["in"], r["gout"], keep_out, keep_mid)
         report[name] = {k: float("%.2e" % v) for k, v in errs.items()}
     report["_oracle_loss0"], report["_batch"], report["_failures"] = loss0, BATCH, [list(map(str, f)) for f in failures]
-    _record(os.path.join(ROOT, "gpurun_out", "parity_r03.json"), key, report)
+    _record(os.path.join(ROOT, "gpurun_out", "parity_r04.json"), key, report)
     print(key, "worst rel err over all stages:", worst)
     assert not failures, (key, failures, report)
 
@@ -463,34 +463,103 @@ def test_full_batch_teacher_forced_resnet_iao(key):
         run_piece(n + ":t", errs, tail_o, tail_p, [zb.detach(), zs.detach()], gout * keep_t, True, combine=comb)
         report[n + ":qadd-relu"] = {k: float("%.2e" % v) for k, v in errs.items()}
         # ---- the WHOLE block with every hand-over live: conv -> fused BN+ReLU (its (min, max) partials feed the next conv's observer) -> conv ->
-        # BN -> [shortcut conv -> BN] -> QuantAdd + ReLU (its partials feed the next block), on the oracle's input and incoming gradient.  The decisions INSIDE the
-        # block cannot be teacher-forced from outside: where the oracle's own mid pre-activation sits within TIE_EPS of the ReLU kink (keep_a: ~1e-5 of the elements)
-        # one flipped mask moves dx by a whole term at the positions that element reaches, so dx is held to 1e-5 at the 99.99th percentile (and its outliers are
-        # counted); the output and every parameter gradient (sums over all positions: one term in 10^6) to the ordinary 1e-5 max-norm.
-        errs = {"mid_ties": float((~keep_a).sum())}
-        ob2, pb2 = copy.deepcopy(ob).train(), pb_whole.train()
-        xo = xin.clone().requires_grad_(True)
-        yo = ob2(xo)
-        yo.backward(gout * keep_t)
-        for p_ in pb2.parameters():
-            p_.grad = None
-        xp = xin.cuda().requires_grad_(True)
-        yp = pb2(xp)
-        e, ff = _flip_aware(yp, yo)
-        check(n + ":whole", errs, "y", e)
-        errs["y_level_flips_frac"] = ff
-        yp.backward((gout * keep_t).cuda())
-        d = (xp.grad.detach().double().cpu() - xo.grad.double()).abs() / xo.grad.double().abs().max().clamp_min(1e-30)
-        errs["dx_max"] = float(d.max())
-        errs["dx_outliers_frac"] = float((d > 1e-5).double().mean())
-        kth = max(1, int(0.9999 * d.numel()))
-        check(n + ":whole", errs, "dx_p9999", float(d.flatten().kthvalue(kth).values))
-        if errs["dx_outliers_frac"] > 1e-3:
-            failures.append((n + ":whole", "dx outliers beyond the reach of the mid-activation ties", errs["dx_outliers_frac"]))
-        pn2 = dict(pb2.named_parameters())
-        for name, p_ in ob2.named_parameters():
-            if p_.grad is not None and name in pn2 and pn2[name].grad is not None:
-                check(n + ":whole", errs, "d" + name, _rel(pn2[name].grad, p_.grad), 2e-5)
+        # BN -> [shortcut conv -> BN] -> QuantAdd + ReLU (its partials feed the next block), on the oracle's input and incoming gradient; the product's intermediate
+        # tensors are its own (1 ulp from the oracle's), nothing is re-fed.  Two decisions INSIDE the block sit on a knife edge BY CONSTRUCTION and are neutralised the
+        # same way as everywhere else in this file -- the gradient AT those elements is zeroed on both sides (tensor hooks on the three intermediate activations; the
+        # hooks change no value and no hand-over):
+        #   * the ReLU kink of the mid activation (keep_a, ~1e-5 of the elements);
+        #   * the LARGEST element of every tensor a symmetric IAO quantizer observes: scale = max / 7.5, so that element's code is round(7.5 -+ 1 ulp) = 7 (gradient
+        #     passes) or 8 -> clamped to 7 (torch.clamp's gradient is 0), decided by the last bit of max / (max / 7.5) (measured, scripts/dbg_c5_whole.py: in conv2_x.1
+        #     the two sides' mid maxima differ in the last bit, the oracle clamps and the product does not; ONE element of g_mid then moves BatchNorm-1's d gamma by
+        #     1.6 % because the per-channel sums cancel to ~1e-2 of their terms).  Every element within 4e-6 of the tensor's positive maximum is masked (1-3 elements).
+        # With those two classes out, output, dx and every parameter gradient are held to the ordinary 1e-5 (2e-5 for the cancelling parameter sums).
+        #   * (third class, forward) a ROUNDING tie of one of the block's 4-bit quantizers -- an element whose value / scale sits within 1 ulp of k + 1/2 lands on the
+        #     neighbouring level on one side; at 4 bits that moves 9 x Cout outputs of the next conv by a whole weight step and the two forward passes are no longer
+        #     the same function (measured: conv5_x.1, 38 of 2 M outputs on another level, every gradient then 0.3-3 % apart).  Such a realisation cannot be compared
+        #     and cannot be forced from outside; the stage then re-runs BOTH sides on the same input scaled by (1 + 2^-9) -- another realisation of the rounding
+        #     decisions, every observer again at its first call -- and requires one attempt of three without a forward flip (flipped attempts are recorded).
+        def _top(t):
+            t = t.detach()
+            return (t >= t.abs().max() * (1.0 - TIE_EPS)) & (t > 0)
+
+        def _mask_grad(mod, keep, cuda):
+            keep = keep.cuda() if cuda else keep
+            def fn(m_, i_, o_):
+                if o_.requires_grad:
+                    o_.register_hook(lambda g_: g_ * keep)
+            return mod.register_forward_hook(fn)
+
+        def whole(x_in, attempt):
+            errs_, fails_ = {}, []
+            def chk(name, err, tol=1e-5):
+                errs_[name] = err
+                if not err <= tol:
+                    fails_.append((n + ":whole", name, err, tol))
+            # the oracle's own intermediates on THIS input: where the ties are
+            oc_ = copy.deepcopy(ob).train()
+            with torch.no_grad():
+                z_ = oc_.residual_function[1](oc_.residual_function[0](x_in))
+                kink = z_.abs() <= TIE_EPS          # (before the ReLU: the reference's is in place)
+                a_ = oc_.residual_function[2](z_)
+                zb_ = oc_.residual_function[4](oc_.residual_function[3](a_))
+                zs_ = oc_.shortcut(x_in)
+                u_ = oc_.add(zb_, zs_)
+            k_mid = ~kink & ~_top(a_)
+            k_zb, k_zs = ~_top(zb_), (~_top(zs_) if has_sc else None)
+            k_t = ~((u_.abs() <= TIE_EPS) & (u_ != 0))
+            errs_.update(mid_ties=float((~k_mid).sum()), zb_top_ties=float((~k_zb).sum()))
+            ob2, pb2 = copy.deepcopy(ob).train(), copy.deepcopy(pb_whole).train()
+            handles = []
+            for blk_, cuda in ((ob2, False), (pb2, True)):
+                handles.append(_mask_grad(blk_.residual_function[2], k_mid, cuda))
+                handles.append(_mask_grad(blk_.residual_function[4], k_zb, cuda))
+                if has_sc:
+                    handles.append(_mask_grad(blk_.shortcut[1], k_zs, cuda))
+            xo = x_in.clone().requires_grad_(True)
+            yo = ob2(xo)
+            yo.backward(gout * k_t)
+            for p_ in pb2.parameters():
+                p_.grad = None
+            xp = x_in.cuda().requires_grad_(True)
+            yp = pb2(xp)
+            e, ff = _flip_aware(yp, yo)
+            chk("y", e)
+            errs_["y_level_flips_frac"] = ff
+            yp.backward((gout * k_t).cuda())
+            for h_ in handles:
+                h_.remove()
+            if ff > 0:
+                return errs_, fails_, True
+            # (dx: the input quantizer's own top element and -- identity shortcut -- the QuantAdd's second operand are the block INPUT's knife edges: one element each)
+            d = (xp.grad.detach().double().cpu() - xo.grad.double()).abs() / xo.grad.double().abs().max().clamp_min(1e-30)
+            errs_["dx_max"] = float(d.max())
+            errs_["dx_outliers"] = float((d > 1e-5).sum())
+            kth = max(1, int(0.9999 * d.numel()))
+            chk("dx_p9999", float(d.flatten().kthvalue(kth).values))
+            if errs_["dx_outliers"] > 16:
+                fails_.append((n + ":whole", "dx outliers beyond the reach of the input's top-element tie", errs_["dx_outliers"]))
+            pn2 = dict(pb2.named_parameters())
+            for name, p_ in ob2.named_parameters():
+                if p_.grad is not None and name in pn2 and pn2[name].grad is not None:
+                    chk("d" + name, _rel(pn2[name].grad, p_.grad), 2e-5)
+            return errs_, fails_, False
+
+        errs, flipped_attempts = {}, []
+        for attempt in range(3):
+            errs, fails_, flipped = whole(xin * (1.0 + attempt * 2.0 ** -9), attempt)
+            if not flipped:
+                break
+            flipped_attempts.append(errs["y_level_flips_frac"])
+        errs["attempts_with_forward_level_flips"] = float(len(flipped_attempts))
+        if flipped:
+            failures.append((n + ":whole", "three realisations in a row with forward level flips", flipped_attempts))
+        else:
+            for f_ in fails_:
+                failures.append(f_)
+                worst = max(worst, f_[2]) if isinstance(f_[2], float) else worst
+            for k_, v_ in errs.items():
+                if k_ in ("y", "dx_p9999") or k_.startswith("dresidual") or k_.startswith("dshortcut"):
+                    worst = max(worst, v_)
         report[n + ":whole-block"] = {k: float("%.2e" % v) for k, v in errs.items()}
     # ---- classifier tail: average pool -> flatten -> QuantLinear
     errs = {}
@@ -498,6 +567,6 @@ def test_full_batch_teacher_forced_resnet_iao(key):
     run_piece("tail", errs, [pristine.avg_pool, pristine.fc], [prod.avg_pool, prod.fc], [rec["avg_pool"]["in"]], rec["fc"]["gout"], False, combine=comb)
     report["tail"] = {k: float("%.2e" % v) for k, v in errs.items()}
     report["_oracle_loss0"], report["_batch"], report["_failures"] = loss0, BATCH, [list(map(str, f)) for f in failures]
-    _record(os.path.join(ROOT, "gpurun_out", "parity_r03.json"), key, report)
+    _record(os.path.join(ROOT, "gpurun_out", "parity_r04.json"), key, report)
     print(key, "worst rel err over all stages:", worst)
     assert not failures, (key, failures, report)
