@@ -572,6 +572,32 @@ int64_t mn_iaobf_bwd_data_ws_bytes(const mn_conv_geom* g);
 int mn_iaobf_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, const float* w, const float* qw, const float* wqp,
                       const float* coef, const double* sx, int relu_mask, float* dx, void* ws, int64_t ws_bytes, mn_stream_t stream);
 
+/* The same block for the grouped 3 x 3 layers of nin_gc (models/nin_gc.py:74-79: 3 x 3 / stride 1 / padding 1, 16 input and 32 output channels per group, 8 x 8 or
+ * 16 x 16 maps, N * H * W a multiple of 256) whose input lies on a symmetric <= 8-bit quantizer grid (the output of QuantMaxPool2d, wqaq/iao/quantize.py:1347-1359:
+ * every value = code * xgrid[0]) -- csrc/iao_g3.hip, persistent image-resident kernels.  The reference's dataflow (raw conv 843-851 -> batch statistics 853-855 -> fold
+ * -> quantised conv 947-955, and its autograd) with the raw output never written in the forward:
+ *   mn_iaobf_g3_stats       stats[2][O] = batch mean / unbiased variance of conv2d(x, w, bias)                                  (feeds mn_iaobf_prep_fwd's stats_in)
+ *   mn_iaobf_g3_fwd         out = [relu](conv2d(Q_a(x), qw, bias_f)) + the (min, max) partials of out (mm: 2 * mn_iaobf_g3_mm_count floats, nullable)
+ *   mn_iaobf_g3_bwd_weight  dw (+)= xqp[0] * conv2d_backward_weight(a * [mask > 0], codes_xqp(x)); dbias = sum of the masked a (nullable).  Called twice: (a = d out,
+ *                           mask = the block's rectified output or NULL when the consumer already masked, xqp = the activation quantizer) and (a = d y_raw,
+ *                           xqp = the input's grid, accumulate = 1 into mn_iaobf_prep_bwd's dw)
+ *   mn_iaobf_g3_dyraw       dy = coef[0][o] + coef[1][o] (conv2d(x, w, bias) - stats[0][o])   (coef of mn_iaobf_prep_bwd: the gradient of the batch statistics)
+ *   mn_iaobf_g3_bwd_data    dx = clip-STE_a(conv2d_backward_data(gy * [mask > 0], qw)) + conv2d_backward_data(dy, w)   [* [x > 0] when relu_in]
+ * g->in_shuffle is honoured (x read / dx written through the channel shuffle).  ws: mn_iaobf_g3_ws_bytes(g) bytes. */
+int mn_iaobf_g3_supported(const mn_conv_geom* g);
+int64_t mn_iaobf_g3_ws_bytes(const mn_conv_geom* g);
+int64_t mn_iaobf_g3_mm_count(const mn_conv_geom* g);
+int mn_iaobf_g3_stats(const mn_conv_geom* g, const float* x, const float* xgrid, int grid_bits, const float* w, const float* bias, float* stats, void* ws,
+                      int64_t ws_bytes, mn_stream_t stream);
+int mn_iaobf_g3_fwd(const mn_conv_geom* g, const float* x, const float* aqp, int a_bits, const float* qw, const float* wqp, const float* bias_f, int relu, float* out,
+                    float* mm, mn_stream_t stream);
+int mn_iaobf_g3_dyraw(const mn_conv_geom* g, const float* x, const float* xgrid, int grid_bits, const float* w, const float* bias, const float* stats, const float* coef,
+                      float* dy, mn_stream_t stream);
+int mn_iaobf_g3_bwd_weight(const mn_conv_geom* g, const float* a, const float* mask, const float* x, const float* xqp, int x_bits, int accumulate, float* dw,
+                           float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_iaobf_g3_bwd_data(const mn_conv_geom* g, const float* gy, const float* mask, const float* dy, const float* x, const float* aqp, int a_bits, const float* qw,
+                         const float* wqp, const float* w, int relu_in, float* dx, mn_stream_t stream);
+
 /* ------------------------------------------------------------------ input pipeline of the training loop
  * <scheme>/main.py:203-210: transforms.Compose([RandomCrop(32, padding=4), RandomHorizontalFlip(), ToTensor(), Normalize(mean, std)]) applied to a batch
  * gathered from the uint8 dataset resident in device memory.  images: uint8 [n_images][H][W][C] (HWC, torchvision's CIFAR10.data); index [B]: the

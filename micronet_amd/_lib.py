@@ -189,6 +189,14 @@ PROTOTYPES = {
     "mn_iaobf_bwd_data_supported": (_I, [_G]),
     "mn_iaobf_bwd_data_ws_bytes": (_L, [_G]),
     "mn_iaobf_bwd_data": (_I, [_G, _A, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P]),
+    "mn_iaobf_g3_supported": (_I, [_G]),
+    "mn_iaobf_g3_ws_bytes": (_L, [_G]),
+    "mn_iaobf_g3_mm_count": (_L, [_G]),
+    "mn_iaobf_g3_stats": (_I, [_G, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    "mn_iaobf_g3_fwd": (_I, [_G, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "mn_iaobf_g3_dyraw": (_I, [_G, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "mn_iaobf_g3_bwd_weight": (_I, [_G, _P, _P, _P, _P, _I, _I, _P, _P, _P, _L, _P]),
+    "mn_iaobf_g3_bwd_data": (_I, [_G, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
 }
 
 

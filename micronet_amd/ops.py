@@ -659,6 +659,7 @@ class IaoBNFusePW(Function):
             wq_.q_type = wq_._q_type_static
             wq_._last_qp = wqp
             st.__dict__["_mn_last_qw"] = qw          # (tests: the quantised folded weights of this forward)
+            st.__dict__["_mn_path"] = "pw"
             aq = ActQ(ACTQ_IAO, aq_.bits, aq_.q_type, 0, aqp.data_ptr())
             wd = WQ(WQ_IAO, wq_.bits, 0, 4, wqp.data_ptr())
             a = torch.empty((N, O, H, W), dtype=torch.float32, device=dev)
@@ -830,6 +831,7 @@ class IaoBNFuseGeneric(Function):
             wq_.q_type = wq_._q_type_static
             wq_._last_qp = wqp
             st.__dict__["_mn_last_qw"] = qw
+            st.__dict__["_mn_path"] = "generic"
             aq = ActQ(ACTQ_IAO, aq_.bits, aq_.q_type, 0, aqp.data_ptr())
             wd = WQ(WQ_IAO, wq_.bits, 0, 4, wqp.data_ptr())
             first_layer = (not x.requires_grad) and CONV_ALGO == _lib.MN_ALGO_AUTO and bool(lib.mn_conv2d_first_supported(C.byref(g), 0)) and \
@@ -941,6 +943,123 @@ class IaoBNFuseGeneric(Function):
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
+
+
+def _valid_qgrid(x):
+    """(qp, bits, q_type) of the quantizer grid a tensor is tagged to lie on (the output of the fused QuantMaxPool2d: every value = code * qp[0]), or None."""
+    grid = getattr(x, "_mn_qgrid", None)
+    if grid is None or grid[3] != x._version or not (2 <= grid[1] <= 8) or grid[2] != 0:
+        return None
+    return grid[:3]
+
+
+def iao_bnfuse_g3_supported(x, weight, stride, padding, dilation, groups, in_shuffle):
+    """The grouped 3 x 3 BN-fused IAO block on the persistent kernels of csrc/iao_g3.hip: nin_gc's geometry (16 -> 32 channels per group, 8 x 8 / 16 x 16 maps) and
+    an input tagged as lying on a symmetric <= 8-bit quantizer grid."""
+    if not (iao_bnfuse_generic_supported(x, weight) and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and _valid_qgrid(x) is not None):
+        return False
+    g = _geom(x.shape, weight.shape, stride, padding, dilation, groups, int(in_shuffle) if in_shuffle and in_shuffle > 1 else 0)
+    return bool(_lib_().mn_iaobf_g3_supported(C.byref(g)))
+
+
+class IaoBNFuseG3(Function):
+    """Training-mode ``QuantBNFuseConv2d.forward`` (wqaq/iao/quantize.py:837-994, not qaft, not bn_fuse_calib) [+ the block's ReLU] for the grouped 3 x 3 layers of
+    nin_gc behind a QuantMaxPool2d: the reference's dataflow -- raw convolution (843-851) -> batch statistics (853-855) -> fold + weight quantizer -> quantised
+    convolution (947-955) -- on the persistent image-resident kernels of csrc/iao_g3.hip.  The raw output is never written in the forward (statistics from the
+    accumulators) and recomputed once in the backward (d y_raw); x is read through the channel shuffle in front of the conv (``st.in_shuffle_groups``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, st, aqp, relu, want_mm):
+        lib = _lib_()
+        x, weight, gamma, beta = _chk(x, "input"), _chk(weight, "weight"), _chk(gamma, "gamma"), _chk(beta, "beta")
+        bias = _chk(bias, "bias")
+        wq_, aq_ = st.weight_quantizer, st.activation_quantizer
+        wobs = wq_.observer
+        gridqp, grid_bits, _ = _valid_qgrid(x)
+        sg = int(st.in_shuffle_groups) if st.in_shuffle_groups > 1 else 0
+        g = _geom(x.shape, weight.shape, st.stride, st.padding, st.dilation, st.groups, sg)
+        O = g.O
+        K = weight[0].numel()
+        dev = x.device
+        n = float(g.N * g.H * g.W)
+        with torch.cuda.device_of(x):
+            nb = int(lib.mn_iaobf_g3_ws_bytes(C.byref(g)))
+            ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
+            stats_raw = torch.empty((2, O), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_g3_stats", C.byref(g), _p(x), _p(gridqp), grid_bits, _p(weight), _p(bias), _p(stats_raw), _p(ws), nb, _s())
+            first_bn = (not st.pretrained_model) and st.num_flag == 0
+            if first_bn:
+                st.num_flag += 1
+            first_w = wobs.num_flag == 0
+            stats = torch.empty((2, O), dtype=torch.float32, device=dev)
+            kfold, bias_f = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
+            qw, wqp = torch.empty_like(weight), torch.empty((O, 4), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_prep_fwd", _p(weight), _p(bias), _p(gamma), _p(beta), O, K, _p(stats_raw), float(st.eps), float(st.momentum),
+                  int(first_bn), _p(st.running_mean), _p(st.running_var), wq_.bits, wq_._q_type_static, wobs._kind, int(first_w), float(getattr(wobs, "momentum", 0.1)),
+                  _p(wobs.min_val), _p(wobs.max_val), _p(wq_.scale), _p(wq_.zero_point), _p(stats), _p(kfold), _p(bias_f), _p(qw), _p(wqp), _s())
+            if first_w:
+                wobs.num_flag += 1
+            wq_.q_type = wq_._q_type_static
+            wq_._last_qp = wqp
+            st.__dict__["_mn_last_qw"] = qw
+            st.__dict__["_mn_path"] = "g3"          # (tests: which kernel family ran this forward)
+            out = torch.empty((g.N, O, g.H, g.W), dtype=torch.float32, device=dev)
+            mm, count = None, 0
+            if relu and want_mm:
+                count = int(lib.mn_iaobf_g3_mm_count(C.byref(g)))
+                mm = torch.empty(2 * count, dtype=torch.float32, device=dev)
+            _call("mn_iaobf_g3_fwd", C.byref(g), _p(x), _p(aqp), aq_.bits, _p(qw), _p(wqp), _p(bias_f), int(bool(relu)), _p(out), _p(mm), _s())
+        ctx.save_for_backward(x, weight, bias, gamma, out if relu else None, stats, qw, wqp, aqp, gridqp)
+        ctx.cfg = (g, aq_.bits, wq_.bits, wq_._q_type_static, float(st.eps), n, bool(relu), grid_bits, nb)
+        ctx.tok_in = getattr(x, "_mn_relu_token", None)
+        ctx.x_obj = x
+        if not relu:
+            return out
+        a_bits = aq_.bits
+
+        def compute():          # the un-rectified output for a consumer other than the block's ReLU
+            o2 = torch.empty_like(out)
+            with torch.cuda.device_of(x):
+                _call("mn_iaobf_g3_fwd", C.byref(g), _p(x), _p(aqp), a_bits, _p(qw), _p(wqp), _p(bias_f), 0, _p(o2), None, _s())
+            return o2
+        return LazyReluConvOut(out, dict(compute=compute, mm=(mm, count) if mm is not None else None))
+
+    @staticmethod
+    def backward(ctx, gin):
+        x, weight, bias, gamma, a, stats, qw, wqp, aqp, gridqp = ctx.saved_tensors
+        g, a_bits, w_bits, w_qtype, eps, n, relu, grid_bits, nb = ctx.cfg
+        dev = x.device
+        mask = None
+        if relu and isinstance(gin, LazyReluGrad) and gin._mn_value is None:
+            gy = _chk(gin._mn_g, "grad")
+            mask = None if gin._mn_premasked else a          # the block's own ReLU: applied while the gradient is staged (no pass of its own)
+        else:
+            gy = _chk(gin, "grad")
+        O = weight.shape[0]
+        K = weight[0].numel()
+        dx = None
+        with torch.cuda.device_of(x):
+            ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
+            dwq, dbf = torch.empty_like(weight), torch.empty(O, dtype=torch.float32, device=dev)
+            _call("mn_iaobf_g3_bwd_weight", C.byref(g), _p(gy), _p(mask), _p(x), _p(aqp), a_bits, 0, _p(dwq), _p(dbf), _p(ws), nb, _s())
+            dw = torch.empty_like(weight)
+            dbias = torch.empty(O, dtype=torch.float32, device=dev) if bias is not None else None
+            dgamma, dbeta = torch.empty(O, dtype=torch.float32, device=dev), torch.empty(O, dtype=torch.float32, device=dev)
+            coef = torch.empty((4, O), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_prep_bwd", _p(dwq), _p(dbf), _p(weight), _p(bias), _p(gamma), _p(stats), _p(wqp), O, K, g.groups, None, None, n, eps, w_bits, w_qtype,
+                  _p(dw), _p(dbias), _p(dgamma), _p(dbeta), _p(coef), _s())
+            # the statistics path: d y_raw from (dmean, dvar) on a recomputed raw convolution, its backward-weight accumulated into dw
+            dy = torch.empty((g.N, O, g.H, g.W), dtype=torch.float32, device=dev)
+            _call("mn_iaobf_g3_dyraw", C.byref(g), _p(x), _p(gridqp), grid_bits, _p(weight), _p(bias), _p(stats), _p(coef), _p(dy), _s())
+            _call("mn_iaobf_g3_bwd_weight", C.byref(g), _p(dy), None, _p(x), _p(gridqp), grid_bits, 1, _p(dw), None, _p(ws), nb, _s())
+            if ctx.needs_input_grad[0]:
+                pre = ctx.tok_in is not None and relu_premask_ok(ctx.x_obj)
+                dx = torch.empty_like(x)
+                _call("mn_iaobf_g3_bwd_data", C.byref(g), _p(gy), _p(mask), _p(dy), _p(x), _p(aqp), a_bits, _p(qw), _p(wqp), _p(weight), int(pre), _p(dx), _s())
+                if pre:
+                    ctx.tok_in.dx = dx
+        ctx.x_obj = None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
 def iao_fq_maxpool_supported(x, kernel_size, stride, padding, dilation, ceil_mode):

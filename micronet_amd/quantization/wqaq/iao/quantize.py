@@ -25,6 +25,7 @@ import os
 from micronet_amd import ops
 from micronet_amd.base_module.op import Add
 
+_FUSE_G3 = os.environ.get("MN_NO_G3") is None          # A/B knob: the grouped 3 x 3 layers on the generic kernels
 _PRODUCER_MINMAX = os.environ.get("MN_NO_PRODUCER_MINMAX") is None          # A/B knob: observers read the tensor themselves
 _FUSE_BNFUSE = os.environ.get("MN_NO_BNFUSE_BLOCK") is None                 # A/B knob: QuantBNFuseConv2d on the generic kernels (raw conv + statistics passes)
 
@@ -404,10 +405,20 @@ class QuantBNFuseConv2d(QuantConv2d):
         relu = bool(self.relu_fused)
         return ops.IaoBNFuseGeneric.apply(input, self.weight, self.bias, self.gamma, self.beta, self, qp, relu, relu and _PRODUCER_MINMAX)
 
+    def _forward_fused_g3(self, input):
+        aq = self.activation_quantizer
+        qp = aq.qparams(input)          # (the pool in front left its (min, max) partials on the tensor: no pass over it)
+        aq._last_qp = qp
+        relu = bool(self.relu_fused)
+        return ops.IaoBNFuseG3.apply(input, self.weight, self.bias, self.gamma, self.beta, self, qp, relu, relu and _PRODUCER_MINMAX)
+
     def forward(self, input):
         training_stats = (not self.qaft) and self.training
         if training_stats and self._fused_pw_ok(input):
             return self._forward_fused_pw(input)
+        if training_stats and _FUSE_G3 and self._fused_quantizers_ok() and ops.CONV_ALGO == 0 and \
+                ops.iao_bnfuse_g3_supported(input, self.weight, self.stride, self.padding, self.dilation, self.groups, self.in_shuffle_groups):
+            return self._forward_fused_g3(input)          # (the channel shuffle in front stays folded into the kernels' addressing)
         if self.in_shuffle_groups > 1:
             grid = getattr(input, "_mn_qgrid", None)
             grid = grid if (grid is not None and grid[3] == input._version) else None

@@ -288,3 +288,134 @@ def check_gram_patch(be, N=3, Cin=3, H=8, W=12, k=5, seed=0):
     sxg = np.frombuffer(be.to_host(sx).tobytes(), dtype=np.float64)
     assert np.abs(got - ref).max() <= 6e-6 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
     assert np.abs(sxg - cols.sum(1).numpy()).max() <= 2e-6 * np.abs(cols.sum(1).numpy()).max()
+
+
+# ------------------------------------------------------------------------------------------------ grouped 3 x 3 family (csrc/iao_g3.hip)
+G3_CASES = [
+    # N, groups, HW (8 -> 8 x 8 maps, four images per tile; 16 -> 16 x 16, one image per tile), channel shuffle, bias, blocks (MN_G3_BLOCKS: tiles per block)
+    dict(N=8, G=2, HW=8, shuffle=0, bias=True, blocks=2),          # two tiles per block: the double-buffered pipeline and the running statistics merge
+    dict(N=3, G=1, HW=16, shuffle=0, bias=False, blocks=0),        # one tile per block, three blocks per group
+    dict(N=4, G=2, HW=16, shuffle=2, bias=True, blocks=4),         # channel shuffle in the addressing, two tiles per block
+]
+
+
+def check_g3(be, case, seed=0):
+    """Every entry point of the grouped 3 x 3 BN-fused family against an fp64 evaluation of the same expression (torch conv2d + autograd on the CPU)."""
+    import os
+    import torch.nn.functional as F
+    N, G, HW, sg = case["N"], case["G"], case["HW"], case["shuffle"]
+    Cc, O = 16 * G, 32 * G
+    rng = np.random.RandomState(100 + seed)
+    if case["blocks"]:
+        os.environ["MN_G3_BLOCKS"] = str(case["blocks"])
+    else:
+        os.environ.pop("MN_G3_BLOCKS", None)
+    try:
+        lib = be.lib
+        geom = _lib.ConvGeom(N, Cc, HW, HW, O, 3, 3, 1, 1, 1, 1, 1, 1, G, sg)
+        assert lib.mn_iaobf_g3_supported(C.byref(geom)) == 1
+        s_g = np.float32(0.05)
+        codes = rng.randint(-128, 128, size=(N, Cc, HW, HW)).astype(np.float32)
+        codes[rng.rand(*codes.shape) < 0.3] = 0.0          # (a pooled ReLU output has many zeros)
+        x_h = (codes * s_g).astype(np.float32)
+        w_h = (rng.randn(O, 16, 3, 3) * 0.2).astype(np.float32)
+        b_h = (rng.randn(O) * 0.3).astype(np.float32) if case["bias"] else None
+        xgrid = be.to_dev(np.array([s_g, 0, -128, 127], dtype=np.float32))
+        x, w, bias = be.to_dev(x_h), be.to_dev(w_h), (be.to_dev(b_h) if b_h is not None else None)
+        nb = int(lib.mn_iaobf_g3_ws_bytes(C.byref(geom)))
+        ws = be.empty(nb // 4 + 4)
+        shuf = (lambda t: _shuffle(t, sg)) if sg > 1 else (lambda t: t)
+        xp64 = torch.from_numpy(x_h).double().requires_grad_(True)
+        xl64 = shuf(xp64)
+        w64 = torch.from_numpy(w_h).double()
+        b64 = torch.from_numpy(b_h).double() if b_h is not None else None
+        rel = lambda got, ref: float(np.abs(np.asarray(got, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+        worst = {}
+        # ---- batch statistics of the raw convolution
+        stats = be.empty(2 * O)
+        be.call("mn_iaobf_g3_stats", C.byref(geom), be.ptr(x), be.ptr(xgrid), 8, be.ptr(w), be.ptr(bias), be.ptr(stats), be.ptr(ws), nb, be.stream)
+        y64 = F.conv2d(xl64, w64, b64, padding=1, groups=G).detach()
+        mean64, var64 = y64.mean(dim=(0, 2, 3)).numpy(), y64.var(dim=(0, 2, 3), unbiased=True).numpy()
+        st = be.to_host(stats)
+        worst["mean"], worst["var"] = rel(st[:O], mean64), rel(st[O:], var64)
+        assert worst["mean"] <= 2e-6 and worst["var"] <= 2e-6, worst
+        # ---- quantised convolution + ReLU + (min, max)
+        s_a = np.float32(0.04)          # x / s_a reaches +-160: the clamp of the 8-bit activation quantizer is exercised
+        amax = np.float32(np.abs(x_h).max()) / s_a
+        aqp_h = np.array([s_a, 0, -amax, amax], dtype=np.float32)
+        aqp = be.to_dev(aqp_h)
+        s_w = (0.002 + 0.004 * rng.rand(O)).astype(np.float32)
+        wcodes = rng.randint(-127, 128, size=(O, 16, 3, 3)).astype(np.float32)
+        qw_h = (wcodes * s_w[:, None, None, None]).astype(np.float32)
+        wqp_h = np.stack([s_w, np.zeros(O, np.float32), -np.full(O, 127, np.float32), np.full(O, 127, np.float32)], axis=1).astype(np.float32)
+        bf_h = (rng.randn(O) * 0.5).astype(np.float32)
+        qw, wqp, bias_f = be.to_dev(qw_h), be.to_dev(wqp_h), be.to_dev(bf_h)
+        cnt = int(lib.mn_iaobf_g3_mm_count(C.byref(geom)))
+        assert cnt > 0
+        out, mm = be.empty((N, O, HW, HW)), be.empty(2 * cnt)
+        be.call("mn_iaobf_g3_fwd", C.byref(geom), be.ptr(x), be.ptr(aqp), 8, be.ptr(qw), be.ptr(wqp), be.ptr(bias_f), 1, be.ptr(out), be.ptr(mm), be.stream)
+        v32 = (x_h / s_a).astype(np.float32)
+        r32 = np.sign(v32) * np.floor(np.abs(v32) + np.float32(0.5))
+        xq_h = (np.clip(r32, -128, 127) * s_a).astype(np.float32)
+        xq64 = shuf(torch.from_numpy(xq_h).double())
+        qw64, bf64 = torch.from_numpy(qw_h).double(), torch.from_numpy(bf_h).double()
+        out64 = torch.relu(F.conv2d(xq64, qw64, bf64, padding=1, groups=G)).numpy()
+        out_h = be.to_host(out)
+        worst["out"] = rel(out_h, out64)
+        assert worst["out"] <= 2e-6, worst
+        assert ((out_h > 0) == (out64 > 1e-4 * np.abs(out64).max())).mean() > 0.999
+        mm_h = be.to_host(mm)
+        assert mm_h[:cnt].min() == out_h.min() and mm_h[cnt:].max() == out_h.max()
+        out_nr = be.empty((N, O, HW, HW))
+        be.call("mn_iaobf_g3_fwd", C.byref(geom), be.ptr(x), be.ptr(aqp), 8, be.ptr(qw), be.ptr(wqp), be.ptr(bias_f), 0, be.ptr(out_nr), None, be.stream)
+        assert np.array_equal(np.maximum(be.to_host(out_nr), 0), out_h)
+        # ---- d y_raw
+        coef_h = np.concatenate([rng.randn(O) * 1e-3, rng.randn(O) * 1e-2, np.zeros(2 * O)]).astype(np.float32)
+        coef = be.to_dev(coef_h)
+        dy = be.empty((N, O, HW, HW))
+        be.call("mn_iaobf_g3_dyraw", C.byref(geom), be.ptr(x), be.ptr(xgrid), 8, be.ptr(w), be.ptr(bias), be.ptr(stats), be.ptr(coef), be.ptr(dy), be.stream)
+        dy64 = (coef_h[:O].astype(np.float64)[None, :, None, None] + coef_h[O:2 * O].astype(np.float64)[None, :, None, None] *
+                (y64.numpy() - st[:O].astype(np.float64)[None, :, None, None]))
+        dy_h = be.to_host(dy)
+        worst["dy"] = rel(dy_h, dy64)
+        assert worst["dy"] <= 2e-6, worst
+        # ---- backward-weight: quantised path (masked d out x activation codes, + d bias), then the statistics path accumulated on top (d y_raw x grid codes)
+        g_h = rng.randn(N, O, HW, HW).astype(np.float32)
+        gy = be.to_dev(g_h)
+        gm64 = torch.from_numpy(g_h * (out_h > 0)).double()
+        dw, dbf = be.empty((O, 16, 3, 3)), be.empty(O)
+        be.call("mn_iaobf_g3_bwd_weight", C.byref(geom), be.ptr(gy), be.ptr(out), be.ptr(x), be.ptr(aqp), 8, 0, be.ptr(dw), be.ptr(dbf), be.ptr(ws), nb, be.stream)
+        wv = qw64.clone().requires_grad_(True)
+        (F.conv2d(xq64, wv, None, padding=1, groups=G) * gm64).sum().backward()
+        dw_h = be.to_host(dw)
+        worst["dwq"] = rel(dw_h, wv.grad.numpy())
+        worst["dbf"] = rel(be.to_host(dbf), gm64.sum(dim=(0, 2, 3)).numpy())
+        assert worst["dwq"] <= 2e-6 and worst["dbf"] <= 2e-6, worst
+        # (pre-masked gradient, mask = NULL: the same numbers)
+        gmask = be.to_dev((g_h * (out_h > 0)).astype(np.float32))
+        dw2 = be.empty((O, 16, 3, 3))
+        be.call("mn_iaobf_g3_bwd_weight", C.byref(geom), be.ptr(gmask), None, be.ptr(x), be.ptr(aqp), 8, 0, be.ptr(dw2), None, be.ptr(ws), nb, be.stream)
+        assert np.array_equal(be.to_host(dw2), dw_h)
+        be.call("mn_iaobf_g3_bwd_weight", C.byref(geom), be.ptr(dy), None, be.ptr(x), be.ptr(xgrid), 8, 1, be.ptr(dw), None, be.ptr(ws), nb, be.stream)
+        wr = w64.clone().requires_grad_(True)
+        (F.conv2d(xl64.detach(), wr, None, padding=1, groups=G) * torch.from_numpy(dy_h).double()).sum().backward()
+        worst["dw_sum"] = rel(be.to_host(dw), wv.grad.numpy() + wr.grad.numpy())
+        assert worst["dw_sum"] <= 2e-6, worst
+        # ---- backward-data: clip-STE(W_q^T d out) + W^T d y_raw, with and without the ReLU mask of the block in front
+        for relu_in in (0, 1):
+            dx = be.empty((N, Cc, HW, HW))
+            be.call("mn_iaobf_g3_bwd_data", C.byref(geom), be.ptr(gy), be.ptr(out), be.ptr(dy), be.ptr(x), be.ptr(aqp), 8, be.ptr(qw), be.ptr(wqp), be.ptr(w), relu_in,
+                    be.ptr(dx), be.stream)
+            xa = torch.from_numpy(xq_h).double().requires_grad_(True)
+            (F.conv2d(shuf(xa), qw64, None, padding=1, groups=G) * gm64).sum().backward()
+            passes = (r32 >= -128) & (r32 <= 127) & (v32 <= aqp_h[3]) & (v32 >= aqp_h[2])
+            xb = torch.from_numpy(x_h).double().requires_grad_(True)
+            (F.conv2d(shuf(xb), w64, None, padding=1, groups=G) * torch.from_numpy(dy_h).double()).sum().backward()
+            ref = xa.grad.numpy() * passes + xb.grad.numpy()
+            if relu_in:
+                ref = ref * (x_h > 0)
+            worst["dx%d" % relu_in] = rel(be.to_host(dx), ref)
+            assert worst["dx%d" % relu_in] <= 5e-6, worst          # (288 x 9 term products in one fp32 accumulator, in order on the emulator)
+        return worst
+    finally:
+        os.environ.pop("MN_G3_BLOCKS", None)

@@ -153,12 +153,51 @@ def test_mixed_chain_vs_oracle():
             recs.append(dict(out=out.detach().clone(), **{"d_" + n: p.grad.clone() for n, p in model.named_parameters()}))
         return recs
     r_ours, r_ref, r_64 = run(ours, x.cuda(), g.cuda()), run(orc, x, g), run(o64, x.double(), g.double())
+    # which kernel family ran each block: first-layer Gram path (generic node), pointwise, the grouped 3 x 3 image-resident kernels behind the pool, pointwise
+    assert [b.conv.__dict__.get("_mn_path") for b in ours if hasattr(b, "conv")] == ["generic", "pw", "g3", "pw"]
     for s in range(steps):
         for k in r_ref[s]:
             if k.endswith(".conv.bias"):
                 continue
             e32, e64, own = _rel(r_ours[s][k], r_ref[s][k]), _rel(r_ours[s][k], r_64[s][k]), _rel(r_ref[s][k], r_64[s][k])
             assert e32 <= 1e-5 or e64 <= max(1e-5, 2 * own), (s, k, e32, e64, own)
+
+
+@pytest.mark.parametrize("hw", [16, 32])
+def test_grouped_3x3_family_equals_generic_path(hw):
+    """the grouped 3 x 3 block behind the pool on csrc/iao_g3.hip (statistics from the accumulators, d y_raw recomputed, shuffle in the addressing) against the
+    product's generic path (raw conv written + statistics passes + materialised shuffle) on the same weights: 8 x 8 and 16 x 16 maps, two steps"""
+    Q = _q()
+    base = _mixed_chain(4)
+    x = torch.randn(4, 3, hw, hw).cuda()
+    g = torch.randn(4, 16, hw // 2, hw // 2).cuda()
+
+    def run(model):
+        recs = []
+        for _ in range(2):
+            for p in model.parameters():
+                p.grad = None
+            out = model(x)
+            out.backward(g)
+            recs.append(dict(out=out.detach().clone(), **{"d_" + n: p.grad.clone() for n, p in model.named_parameters()}))
+        return recs
+    a = Q.prepare(copy.deepcopy(base), inplace=True, **KW).cuda().train()
+    ra = run(a)
+    assert a[3].conv.__dict__.get("_mn_path") == "g3"
+    import micronet_amd.quantization.wqaq.iao.quantize as QI          # (the module that owns the knob; `micronet.compression...` may be an alias package)
+    keep = QI._FUSE_G3
+    QI._FUSE_G3 = False
+    try:
+        b = Q.prepare(copy.deepcopy(base), inplace=True, **KW).cuda().train()
+        rb = run(b)
+    finally:
+        QI._FUSE_G3 = keep
+    assert b[3].conv.__dict__.get("_mn_path") == "generic"
+    for s in range(2):
+        for k in ra[s]:
+            if k.endswith(".conv.bias"):
+                continue
+            assert _rel(ra[s][k], rb[s][k]) <= 2e-5, (s, k, _rel(ra[s][k], rb[s][k]))
 
 
 def test_conv_module_called_directly_keeps_the_reference_contract():

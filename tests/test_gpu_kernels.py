@@ -682,3 +682,16 @@ def test_iaobf_gram_of_first_layer_patches(be, k, Cin, W):
     import iaobf_cases as B
     B.check_gram_patch(be, Cin=Cin, W=W, k=k, seed=k + Cin)
     B.check_gram_patch(be, N=64, Cin=3, H=32, W=32, k=5, seed=1)
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_iaobf_grouped_3x3_family(be, ci):
+    import iaobf_cases as B
+    B.check_g3(be, B.G3_CASES[ci], seed=ci)
+
+
+def test_iaobf_grouped_3x3_family_at_nin_gc_shapes(be):
+    """the two layers of nin_gc at a batch that fills the persistent grids (several tiles per block, every group)"""
+    import iaobf_cases as B
+    B.check_g3(be, dict(N=64, G=16, HW=16, shuffle=2, bias=True, blocks=0), seed=7)
+    B.check_g3(be, dict(N=64, G=32, HW=8, shuffle=4, bias=True, blocks=0), seed=8)

@@ -471,3 +471,11 @@ def test_iao_codes_at_rounding_boundaries(be):
 def test_iaobf_gram_of_first_layer_patches(be, k, Cin, W):
     import iaobf_cases as B
     B.check_gram_patch(be, Cin=Cin, W=W, k=k, seed=k + Cin)
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_iaobf_grouped_3x3_family(be, ci):
+    """csrc/iao_g3.hip: statistics of the raw conv, quantised conv + ReLU + (min, max), d y_raw, both backward-weights, the two-path backward-data -- each
+    against an fp64 evaluation (<= 2e-6), through the channel shuffle, one and several tiles per persistent block."""
+    import iaobf_cases as B
+    B.check_g3(be, B.G3_CASES[ci], seed=ci)
