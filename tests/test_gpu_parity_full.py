@@ -241,8 +241,9 @@ def test_full_batch_teacher_forced(key):
         if leaf is not None and inp is leaf and type(prev).__name__ == "QuantMaxPool2d" and getattr(paq_, "_last_qp", None) is not None and paq_.q_type == 0 \
                 and 2 <= paq_.bits <= 8:
             qp_, bits_, qt_ = paq_._last_qp, paq_.bits, paq_.q_type
-            codes_ = xin / qp_.reshape(-1)[0]
-            assert torch.equal(codes_, codes_.round()) and float(codes_.abs().max()) <= 2 ** (bits_ - 1), "the oracle's pool output is not on the product pool's grid"
+            sc_ = qp_.reshape(-1)[0]
+            codes_ = (xin / sc_).round()          # every value is fl(code * scale) with an integer code of the quantizer's range
+            assert torch.equal(codes_ * sc_, xin) and float(codes_.abs().max()) <= 2 ** (bits_ - 1), "the oracle's pool output is not on the product pool's grid"
             inp._mn_qgrid = (qp_, bits_, qt_, inp._version)
         for i in seg:
             for p in pstages[i].parameters():
