@@ -300,7 +300,8 @@ int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, con
 /* y = relu?(conv2d(actq(x), w, bias)) for pointwise (1 x 1, stride 1) code-domain layers, with -- mm != NULL -- the per-wave (min, max) of everything stored left in
  * mm[0 .. count) / mm[count .. 2 count), count = mn_conv2d_fwd_act_mm_count(g, aq, wq) (0: layer not covered): the block `relu(bn(conv(x)))` of the reference's nets
  * after the IAO rewrite folded the BatchNorm into the conv (models/nin_gc.py:53-59 with bn = nn.Identity, wqaq/iao/quantize.py:1567-1624); the NEXT layer's
- * observer (wqaq/iao/quantize.py:23-36) is then updated by mn_iao_observe_partials without a pass of its own over the activation. */
+ * observer (wqaq/iao/quantize.py:23-36) is then updated by mn_iao_observe_partials without a pass of its own over the activation.  Also covered: the first layer
+ * of a net (aq = NULL / MN_ACTQ_NONE, wq = NULL: real operands on the first-layer kernels, mn_conv2d_first_supported). */
 int64_t mn_conv2d_fwd_act_mm_count(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);
 int mn_conv2d_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, int relu, float* mm,
                       void* ws, int64_t ws_bytes, mn_stream_t stream);
@@ -597,6 +598,21 @@ int mn_iaobf_g3_bwd_weight(const mn_conv_geom* g, const float* a, const float* m
                            float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
 int mn_iaobf_g3_bwd_data(const mn_conv_geom* g, const float* gy, const float* mask, const float* dy, const float* x, const float* aqp, int a_bits, const float* qw,
                          const float* wqp, const float* w, int relu_in, float* dx, mn_stream_t stream);
+
+/* The same block for a pointwise layer with a THIN output (1 x 1 / stride 1 / groups 1, O <= 16, C a multiple of 64: the classifier layer of nin_gc,
+ * models/nin_gc.py:83, 1024 -> 10) -- csrc/iao_thin.hip, HBM-bound streaming kernels on the vector units (20 flop per input byte: not matrix-core work).  The
+ * caller runs the reference's dataflow: raw conv (aqp = NULL) -> mn_bn_stats_fwd -> mn_iaobf_prep_fwd -> quantised conv (aqp = the symmetric activation quantizer's
+ * {scale, zp, lo, hi}); backward: both backward-weights (accumulate = 1 for the second), the two-path backward-data.  wt / qwt: mn_iaobf_thin_pack of w / qw
+ * ([C][16], transposed and zero-padded).  g->in_shuffle is honoured. */
+int mn_iaobf_thin_supported(const mn_conv_geom* g);
+int64_t mn_iaobf_thin_mm_count(const mn_conv_geom* g);
+int mn_iaobf_thin_pack(const float* w, int64_t O, int64_t C, float* wt, mn_stream_t stream);
+int mn_iaobf_thin_fwd(const mn_conv_geom* g, const float* x, const float* aqp, int a_bits, const float* wt, const float* bias, int relu, float* out, float* mm,
+                      mn_stream_t stream);
+int mn_iaobf_thin_bwd_weight(const mn_conv_geom* g, const float* a, const float* x, const float* aqp, int a_bits, int accumulate, float* dw, float* dbias,
+                             mn_stream_t stream);
+int mn_iaobf_thin_bwd_data(const mn_conv_geom* g, const float* gy, const float* dy, const float* x, const float* aqp, int a_bits, const float* qwt, const float* wt,
+                           int relu_in, float* dx, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ input pipeline of the training loop
  * <scheme>/main.py:203-210: transforms.Compose([RandomCrop(32, padding=4), RandomHorizontalFlip(), ToTensor(), Normalize(mean, std)]) applied to a batch

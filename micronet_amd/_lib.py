@@ -197,6 +197,12 @@ PROTOTYPES = {
     "mn_iaobf_g3_dyraw": (_I, [_G, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "mn_iaobf_g3_bwd_weight": (_I, [_G, _P, _P, _P, _P, _I, _I, _P, _P, _P, _L, _P]),
     "mn_iaobf_g3_bwd_data": (_I, [_G, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
+    "mn_iaobf_thin_supported": (_I, [_G]),
+    "mn_iaobf_thin_mm_count": (_L, [_G]),
+    "mn_iaobf_thin_pack": (_I, [_P, _L, _L, _P, _P]),
+    "mn_iaobf_thin_fwd": (_I, [_G, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "mn_iaobf_thin_bwd_weight": (_I, [_G, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "mn_iaobf_thin_bwd_data": (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P]),
 }
 
 

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libmicronet_hip.so")
-SOURCES = ["quant_kernels.hip", "conv_kernels.hip", "qgemm_kernels.hip", "qgemm_kxk.hip", "qgemm_sign.hip", "qgemm_k3s.hip", "qgemm_dense.hip", "conv_first.hip", "optim_kernels.hip", "norm_kernels.hip", "iao_ops.hip", "qact_kernels.hip", "data_kernels.hip", "linear_kernels.hip", "iao_bnfuse.hip", "iao_g3.hip"]
+SOURCES = ["quant_kernels.hip", "conv_kernels.hip", "qgemm_kernels.hip", "qgemm_kxk.hip", "qgemm_sign.hip", "qgemm_k3s.hip", "qgemm_dense.hip", "conv_first.hip", "optim_kernels.hip", "norm_kernels.hip", "iao_ops.hip", "qact_kernels.hip", "data_kernels.hip", "linear_kernels.hip", "iao_bnfuse.hip", "iao_g3.hip", "iao_thin.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc"]
 # qgemm_sign.hip: the SLP vectoriser pairs fp32 operations of DIFFERENT staged rows into v_pk_* instructions and pays for it with register shuffles on
 # the loop back edge, each behind a wait for the prefetched loads (the software pipeline of k_pws_wgrad_s drained every iteration)

@@ -29,6 +29,8 @@ struct C1Params {
     const float* wp;      // packed weights [KS*4][Opad]  (fwd)
     const float* bias;
     float* y;             // fwd out [N][O][H][W]
+    int relu;             // fwd: y = relu(conv + bias) (the block's ReLU behind a BN-fused IAO first layer)
+    float* mm;            // fwd, nullable: per-block (min, max) of what is stored: mm[block], mm[grid + block]
     const float* gy;      // wgrad in
     float* part;          // wgrad partials [Z][Opad][80]
     float* dbpart;        // [Z][Opad]
@@ -96,6 +98,8 @@ __global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
     }
     __syncthreads();
 
+    float lo = INFINITY, hi = -INFINITY;
+    int mnan = 0;
     const int npix = p.R * p.W, nchunks = (npix + 63) >> 6;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int pix = chunk * 64 + 4 * j;
@@ -143,10 +147,23 @@ __global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
                     if (m < p.O) {
                         const float bb = p.bias ? p.bias[m] : 0.f;
                         float* dst = p.y + (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol;
-                        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][t][r] + bb, acc[1][t][r] + bb, acc[2][t][r] + bb, acc[3][t][r] + bb);
+                        float4 v = make_float4(acc[0][t][r] + bb, acc[1][t][r] + bb, acc[2][t][r] + bb, acc[3][t][r] + bb);
+                        if (p.relu) { v.x = qa_relu(v.x); v.y = qa_relu(v.y); v.z = qa_relu(v.z); v.w = qa_relu(v.w); }
+                        if (p.mm) {          // plain min / max (NaN-ignoring) + a NaN flag: torch.min / max propagate a NaN
+                            lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+                            hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                            mnan |= (int)((v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w));
+                        }
+                        *reinterpret_cast<float4*>(dst) = v;
                     }
                 }
         }
+    }
+    if (p.mm) {          // (block-uniform) the patch image is dead: its first words serve as reduction scratch
+        if (mnan) lo = hi = NAN;
+        lo = block_reduce(lo, OpMinF(), INFINITY, xs);
+        hi = block_reduce(hi, OpMaxF(), -INFINITY, xs);
+        if (tid == 0) { p.mm[blockIdx.x] = lo; p.mm[gridDim.x + blockIdx.x] = hi; }
     }
 }
 
@@ -390,7 +407,14 @@ int64_t c1_ws_bytes(const mn_conv_geom* g, int which) {
     if (!plan_c1(g, &pl, which)) return 0;
     return which == 0 ? pl.ws_bytes_f : (which == 2 ? pl.ws_bytes_w : 0);
 }
+int c1_fwd_mm_count(const mn_conv_geom* g) {
+    C1Plan pl;
+    return plan_c1(g, &pl) ? pl.grid_f : 0;
+}
 int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes, hipStream_t s) {
+    return c1_fwd_act(g, x, w, bias, y, 0, nullptr, ws, ws_bytes, s);
+}
+int c1_fwd_act(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int relu, float* mm, void* ws, int64_t ws_bytes, hipStream_t s) {
     C1Plan pl;
     if (!plan_c1(g, &pl) || !aligned16(y)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(first-layer): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes_f || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(first-layer): workspace too small");
@@ -398,6 +422,7 @@ int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* b
     float* wp = (float*)ws;
     hipLaunchKernelGGL(k_c1_pack, dim3(mn_grid_for((int64_t)C1_KS * 4 * p.Opad, 256, 256)), dim3(256), 0, s, w, wp, p.O, p.K, p.Opad, C1_KS * 4);
     p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0; p.da = nullptr;
+    p.relu = relu; p.mm = mm;
     mn_set_last_kernel("k_c1_fwd<%d>", pl.MT);
     mn_prof_begin(s);
     if (pl.MT == 4) { raise_lds_limit((const void*)k_c1_fwd<4>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<4>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }

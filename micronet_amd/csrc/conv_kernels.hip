@@ -732,8 +732,13 @@ extern "C" int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_
     return MN_OK;
 }
 
+static int fwd_act_first(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {          // real operands on the first-layer kernels (an image, <= 76 taps)
+    return (!aq || aq->mode == MN_ACTQ_NONE) && (!wq || wq->mode == MN_WQ_REAL) && g->in_shuffle <= 1 && c1_supported(g, 0);
+}
 extern "C" int64_t mn_conv2d_fwd_act_mm_count(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
-    if (!g || check_geom(g, "mn_conv2d_fwd_act_mm_count") || !qg_supported(g, aq, wq, 0)) return 0;
+    if (!g || check_geom(g, "mn_conv2d_fwd_act_mm_count")) return 0;
+    if (fwd_act_first(g, aq, wq)) return c1_fwd_mm_count(g);
+    if (!qg_supported(g, aq, wq, 0)) return 0;
     return qg_fwd_act_mm_count(g);
 }
 extern "C" int mn_conv2d_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, int relu,
@@ -741,8 +746,13 @@ extern "C" int mn_conv2d_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const
     int rc = check_geom(g, "mn_conv2d_fwd_act");
     if (rc) return rc;
     if (!x || !w || !y) MN_FAIL(MN_EINVAL, "mn_conv2d_fwd_act: null tensor");
+    if (fwd_act_first(g, aq, wq) && aligned16(y)) {
+        const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
+        mn_prof_bytes(4.0 * (nx + ny));
+        return c1_fwd_act(g, x, w, bias, y, relu, mm, ws, ws_bytes, (hipStream_t)stream);
+    }
     if (!qg_fwd_act_mm_count(g) || !qg_supported(g, aq, wq, 0) || !aligned16(x) || !aligned16(y))
-        MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd_act: pointwise code-domain layers only");
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd_act: pointwise code-domain layers and first-layer (image) convolutions only");
     {
         const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
         mn_prof_bytes(4.0 * (nx + ny));

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_g3_fwd(const G3FParams p) {
         toff[ks] = ((tap / 3) * m.PW + tap % 3) * G3_PSB + (kg & 1) * 16;
     }
     float mean_[8], m2_[8], lo = INFINITY, hi = -INFINITY;
+    int mnan = 0;          // (plain min / max ignore a NaN: it is flagged and propagated at the end, as torch.min / max would)
 #pragma unroll
     for (int s = 0; s < 8; ++s) { mean_[s] = 0.f; m2_[s] = 0.f; }
 
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_g3_fwd(const G3FParams p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         p.out[((int64_t)(tile * m.IMG + oimg[q]) * m.O_total + g * 32 + ol) * m.HW + orem[q]] = y[q];
-                        if (MODE == G3_QUANT) { lo = OpMinF()(lo, y[q]); hi = OpMaxF()(hi, y[q]); }
+                        if (MODE == G3_QUANT) { lo = fminf(lo, y[q]); hi = fmaxf(hi, y[q]); mnan |= (int)(y[q] != y[q]); }
                     }
                 }
             }
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_g3_fwd(const G3FParams p) {
         }
     }
     if (MODE == G3_QUANT && p.mm) {
+        if (mnan) lo = hi = NAN;
         lo = block_reduce(lo, OpMinF(), INFINITY, cst + 160);
         hi = block_reduce(hi, OpMaxF(), -INFINITY, cst + 160);
         if (tid == 0) { p.mm[blockIdx.x] = lo; p.mm[gridDim.x + blockIdx.x] = hi; }
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void k_g3_dgrad(const G3DParams p) {
     float* sw = reinterpret_cast<float*>(wtr + 3 * 16 * G3_LDT);                    // [32] weight scales
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const int g = blockIdx.x / m.NB, b = blockIdx.x - g * m.NB;
-    const float sc = p.aqp[0], zp = p.aqp[1], slo = p.aqp[2], shi = p.aqp[3];
+    const float sc = p.aqp[0], zp = p.aqp[1], slo = p.aqp[2], shi = p.aqp[3], inv_sc = 1.0f / sc;
 
     for (int i = tid; i < m.npos * G3_GSB / 16; i += 256) reinterpret_cast<u32x4*>(gp)[i] = u32x4{0u, 0u, 0u, 0u};
     for (int i = tid; i < 32 * 144; i += 256) {
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void k_g3_dgrad(const G3DParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[q][r] = iao_fq_grad(acc[q][r], xv[q][r], sc, zp, slo, shi, p.qmin, p.qmax);
+            for (int r = 0; r < 4; ++r) acc[q][r] = iao_fq_grad_m(acc[q][r], xv[q][r], sc, inv_sc, zp, slo, shi, p.qmin, p.qmax);
         __syncthreads();
         commit(false);
         __syncthreads();

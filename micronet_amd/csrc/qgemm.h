@@ -17,6 +17,9 @@ int qg_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
 int c1_supported(const mn_conv_geom* g, int which);
 int64_t c1_ws_bytes(const mn_conv_geom* g, int which);
 int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes, hipStream_t s);
+// ... with the block's ReLU and per-block (min, max) partials of the stored result (mm: 2 * c1_fwd_mm_count(g) floats, nullable)
+int c1_fwd_mm_count(const mn_conv_geom* g);
+int c1_fwd_act(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int relu, float* mm, void* ws, int64_t ws_bytes, hipStream_t s);
 int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, const float* yb, const float* save, const float* gamma, const float* beta,
                      const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);

@@ -874,6 +874,9 @@ struct QddParams {
     float wscale;
     const float* wsc;             // IAO: per-output-channel weight scale (stride wsc_stride floats, 0: per layer), folded into gy before the split; nullptr: none
     int wsc_stride;
+    const float* ste_x;           // IAO: the conv's fp32 input -- the activation quantizer's clip-STE (ref 163-168, 232) is applied while dx is stored; nullptr: none
+    const float* ste_qp;          // {scale, zero point, lo, hi} on the device
+    float ste_qmin, ste_qmax;
     int N, C, Hg, Wg, O, HWg;
     int TAPS, TPS, NSTEP, WSB;    // taps, taps per step, steps per chunk, bytes of weights per step
     int TH, NI, PH, PW, W4, TS;   // TS: bytes per term plane
@@ -1057,6 +1060,14 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
         }
         int n0, oh0, cit;
         tile_origin(item, n0, oh0, cit);
+        float s_sc = 1.f, s_zp = 0.f, s_lo = 0.f, s_hi = 0.f;
+        if (p.ste_x) { s_sc = p.ste_qp[0]; s_zp = p.ste_qp[1]; s_lo = p.ste_qp[2]; s_hi = p.ste_qp[3]; }
+        const float s_inv = 1.0f / s_sc;
+        auto ste4 = [&](float4 v, const float* xp) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp);
+            return make_float4(iao_fq_grad_m(v.x, xv.x, s_sc, s_inv, s_zp, s_lo, s_hi, p.ste_qmin, p.ste_qmax), iao_fq_grad_m(v.y, xv.y, s_sc, s_inv, s_zp, s_lo, s_hi, p.ste_qmin, p.ste_qmax),
+                               iao_fq_grad_m(v.z, xv.z, s_sc, s_inv, s_zp, s_lo, s_hi, p.ste_qmin, p.ste_qmax), iao_fq_grad_m(v.w, xv.w, s_sc, s_inv, s_zp, s_lo, s_hi, p.ste_qmin, p.ste_qmax));
+        };
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
             const int tp = wave * 16 * MF + mf * 16 + 4 * kg;
@@ -1068,9 +1079,11 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
             if (S == 1) {
                 const uint32_t base = (uint32_t)((n * p.C + cit * 64 + j) * p.Hg + oh0 + ohl) * (uint32_t)p.Wg + (uint32_t)ow;
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
-                    *reinterpret_cast<float4*>(p.dx + base + (uint32_t)(nf * 16 * p.HWg)) =
-                        make_float4(acc[0][mf][nf][0] * p.wscale, acc[0][mf][nf][1] * p.wscale, acc[0][mf][nf][2] * p.wscale, acc[0][mf][nf][3] * p.wscale);
+                for (int nf = 0; nf < 4; ++nf) {
+                    float4 v = make_float4(acc[0][mf][nf][0] * p.wscale, acc[0][mf][nf][1] * p.wscale, acc[0][mf][nf][2] * p.wscale, acc[0][mf][nf][3] * p.wscale);
+                    if (p.ste_x) v = ste4(v, p.ste_x + base + (uint32_t)(nf * 16 * p.HWg));
+                    *reinterpret_cast<float4*>(p.dx + base + (uint32_t)(nf * 16 * p.HWg)) = v;
+                }
             } else {
                 const int WX = 2 * p.Wg;
 #pragma unroll
@@ -1079,9 +1092,13 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
 #pragma unroll
                     for (int nf = 0; nf < 4; ++nf) {
                         const f32x4 e = acc[(NACC == 4 ? 2 * ph : 0)][mf][nf], o = acc[(NACC == 4 ? 2 * ph + 1 : 0)][mf][nf];
-                        float* dst = p.dx + base + (uint32_t)(nf * 16 * 4 * p.HWg);
-                        *reinterpret_cast<float4*>(dst) = make_float4(e[0] * p.wscale, o[0] * p.wscale, e[1] * p.wscale, o[1] * p.wscale);
-                        *reinterpret_cast<float4*>(dst + 4) = make_float4(e[2] * p.wscale, o[2] * p.wscale, e[3] * p.wscale, o[3] * p.wscale);
+                        const uint32_t off = base + (uint32_t)(nf * 16 * 4 * p.HWg);
+                        float* dst = p.dx + off;
+                        float4 v0 = make_float4(e[0] * p.wscale, o[0] * p.wscale, e[1] * p.wscale, o[1] * p.wscale);
+                        float4 v1 = make_float4(e[2] * p.wscale, o[2] * p.wscale, e[3] * p.wscale, o[3] * p.wscale);
+                        if (p.ste_x) { v0 = ste4(v0, p.ste_x + off); v1 = ste4(v1, p.ste_x + off + 4); }
+                        *reinterpret_cast<float4*>(dst) = v0;
+                        *reinterpret_cast<float4*>(dst + 4) = v1;
                     }
                 }
             }
@@ -1149,7 +1166,7 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
     QddParams& p = pl.p;
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_bwd);
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s); wpk = reinterpret_cast<const uint16_t*>(ws); }
-    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0;
+    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0; p.ste_x = nullptr; p.ste_qp = nullptr;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
@@ -1574,16 +1591,20 @@ int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, c
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_bwd);
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s, wq->scale, wq->per_channel); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f; p.wsc = wq->scale; p.wsc_stride = wq->per_channel;
+    const IaoRange r = iao_range(aq->bits, 0, 1);
+    static const bool ste_sep = MN_ENV("MN_QD_STE_SEPARATE") != nullptr;          // A/B knob: the clip-STE as a pass of its own (round 3)
+    p.ste_x = ste_sep ? nullptr : x; p.ste_qp = aq->qp; p.ste_qmin = r.qmin; p.ste_qmax = r.qmax;          // the quantizer's clip-STE rides the store of dx
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 8.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     qd_launch_dgrad(pl, s);
     mn_prof_end(s);
-    const int64_t n4 = (int64_t)g->N * g->C * g->H * g->W / 4;
-    const IaoRange r = iao_range(aq->bits, 0, 1);
-    int64_t nb = (n4 + 255) / 256;
-    if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(k_qd_iao_ste, dim3((unsigned)nb), dim3(256), 0, s, dx, x, n4, aq->qp, r.qmin, r.qmax);
+    if (ste_sep) {
+        const int64_t n4 = (int64_t)g->N * g->C * g->H * g->W / 4;
+        int64_t nb = (n4 + 255) / 256;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(k_qd_iao_ste, dim3((unsigned)nb), dim3(256), 0, s, dx, x, n4, aq->qp, r.qmin, r.qmax);
+    }
     MN_CHECK_LAUNCH("mn_conv2d_bwd_data(dense iao)");
     return MN_OK;
 }

@@ -35,6 +35,17 @@ __device__ __forceinline__ float iao_code_m(float x, float sc, float inv, float 
     return mn_clamp(mn_rha(mn_div_m(x, sc, inv) - zp), qmin, qmax) + zp;
 }
 
+// iao_fq_grad (common.h) with both IEEE divisions replaced by the three-instruction correctly rounded quotient: bit-identical results for in-range operands at a
+// third of the instructions (the clip-STE inside an MFMA kernel's epilogue is VALU-bound)
+__device__ __forceinline__ float iao_fq_grad_m(float g, float x, float sc, float inv, float zp, float lo, float hi, float qmin, float qmax) {
+    const float v = mn_div_m(x, sc, inv) - zp;
+    const float r = mn_rha(v);
+    float d = g * sc;
+    d = (r >= qmin && r <= qmax) ? d : 0.f;
+    d = (v > hi || v < lo) ? 0.f : d;
+    return mn_div_m(d, sc, inv);
+}
+
 // per-channel fold of the BatchNorm+sign backward for the BNH variants (same algebra as k_bnh_apply, reassociated; `scale` = the weight
 // scale the consumer multiplies the operand with)
 __device__ __forceinline__ void bnh_fold(const float* __restrict__ chan, const float* __restrict__ sums, int C, int co, int training, float n_f, float scale,

@@ -799,11 +799,21 @@ class IaoBNFuseGeneric(Function):
         # (mn_iaobf_gram in patch mode) -- no raw convolution, no y_raw, and in the backward no raw backward-weight (same algebra as the pointwise layers)
         gram_first = (not x.requires_grad) and CONV_ALGO == _lib.MN_ALGO_AUTO and g.KH > 1 and bool(lib.mn_iaobf_gram_supported(C.byref(g))) and \
             bool(lib.mn_conv2d_first_supported(C.byref(g), 0)) and bool(lib.mn_conv2d_first_supported(C.byref(g), 2))
+        # a pointwise layer with <= 16 outputs (the classifier conv of nin_gc): HBM-bound streaming kernels on the vector units (csrc/iao_thin.hip)
+        thin = CONV_ALGO == _lib.MN_ALGO_AUTO and bool(lib.mn_iaobf_thin_supported(C.byref(g))) and x.requires_grad
+        wt = qwt = None
         y_raw = vc = sx = None
         with torch.cuda.device_of(x):
             ws, nb = _ws(g, 0, dev)
             stats_raw = torch.empty((2, O), dtype=torch.float32, device=dev)
-            if gram_first:
+            if thin:
+                wt = torch.empty((g.C, 16), dtype=torch.float32, device=dev)
+                _call("mn_iaobf_thin_pack", _p(weight), O, g.C, _p(wt), _s())
+                y_raw = torch.empty((g.N, O, Ho, Wo), dtype=torch.float32, device=dev)
+                _call("mn_iaobf_thin_fwd", C.byref(g), _p(x), None, 8, _p(wt), _p(bias), 0, _p(y_raw), None, _s())
+                wss = torch.empty(int(lib.mn_bn_stats_ws_floats(g.N, O, Ho * Wo)) + 2, dtype=torch.float32, device=dev)
+                _call("mn_bn_stats_fwd", _p(y_raw), g.N, O, Ho * Wo, _p(stats_raw), _p(wss), _s())
+            elif gram_first:
                 nbg = int(lib.mn_iaobf_gram_ws_bytes(C.byref(g)))
                 wsg = torch.empty(nbg // 4 + 4, dtype=torch.float32, device=dev)
                 gram = torch.empty((K, K), dtype=torch.float64, device=dev)
@@ -831,17 +841,32 @@ class IaoBNFuseGeneric(Function):
             wq_.q_type = wq_._q_type_static
             wq_._last_qp = wqp
             st.__dict__["_mn_last_qw"] = qw
-            st.__dict__["_mn_path"] = "generic"
+            st.__dict__["_mn_path"] = "thin" if thin else "generic"
             aq = ActQ(ACTQ_IAO, aq_.bits, aq_.q_type, 0, aqp.data_ptr())
             wd = WQ(WQ_IAO, wq_.bits, 0, 4, wqp.data_ptr())
             first_layer = (not x.requires_grad) and CONV_ALGO == _lib.MN_ALGO_AUTO and bool(lib.mn_conv2d_first_supported(C.byref(g), 0)) and \
                 bool(lib.mn_conv2d_first_supported(C.byref(g), 2))
             out = torch.empty((g.N, O, Ho, Wo), dtype=torch.float32, device=dev)
             xq, mm, count, relu_done = None, None, 0, False
-            if first_layer:
+            if thin:
+                qwt = torch.empty((g.C, 16), dtype=torch.float32, device=dev)
+                _call("mn_iaobf_thin_pack", _p(qw), O, g.C, _p(qwt), _s())
+                if relu and want_mm:
+                    count = int(lib.mn_iaobf_thin_mm_count(C.byref(g)))
+                    mm = torch.empty(2 * count, dtype=torch.float32, device=dev)
+                _call("mn_iaobf_thin_fwd", C.byref(g), _p(x), _p(aqp), aq_.bits, _p(qwt), _p(bias_f), int(bool(relu)), _p(out), _p(mm), _s())
+                relu_done = True
+            elif first_layer:
                 xq = torch.empty_like(x)          # the fake-quantised image (tiny): exact fp32 products on the first-layer kernels
                 _call("mn_iao_fq_fwd", _p(x), _p(xq), 1, x.numel(), _p(aqp), aq_.bits, aq_.q_type, 1, _s())
-                _call("mn_conv2d_fwd", C.byref(g), C.byref(none), None, _p(xq), _p(qw), _p(bias_f), _p(out), _p(ws), nb, CONV_ALGO, _s())
+                cnt = int(lib.mn_conv2d_fwd_act_mm_count(C.byref(g), C.byref(none), None)) if relu else 0
+                if cnt > 0:          # the block's ReLU and the (min, max) partials in the first-layer kernel's epilogue
+                    if want_mm:
+                        mm, count = torch.empty(2 * cnt, dtype=torch.float32, device=dev), cnt
+                    _call("mn_conv2d_fwd_act", C.byref(g), C.byref(none), None, _p(xq), _p(qw), _p(bias_f), _p(out), 1, _p(mm), _p(ws), nb, _s())
+                    relu_done = True
+                else:
+                    _call("mn_conv2d_fwd", C.byref(g), C.byref(none), None, _p(xq), _p(qw), _p(bias_f), _p(out), _p(ws), nb, CONV_ALGO, _s())
             else:
                 cnt = int(lib.mn_conv2d_fwd_act_mm_count(C.byref(g), C.byref(aq), C.byref(wd))) if relu else 0
                 if cnt > 0:
@@ -868,7 +893,7 @@ class IaoBNFuseGeneric(Function):
         grid = getattr(x, "_mn_qgrid", None)
         if grid is not None and (grid[3] != x._version or not (2 <= grid[1] <= 8) or grid[2] != 0):
             grid = None
-        ctx.save_for_backward(x, weight, bias, gamma, out if relu else None, stats, qw, wqp, aqp, y_raw, xq, grid[0] if grid is not None else None, vc, sx)
+        ctx.save_for_backward(x, weight, bias, gamma, out if relu else None, stats, qw, wqp, aqp, y_raw, xq, grid[0] if grid is not None else None, vc, sx, wt, qwt)
         ctx.xgrid = (grid[1], grid[2]) if grid is not None else None
         ctx.cfg = (g, aq_.bits, aq_.q_type, wq_.bits, wq_._q_type_static, float(st.eps), n, bool(relu), bool(first_layer))
         ctx.tok_in = getattr(x, "_mn_relu_token", None)
@@ -880,7 +905,9 @@ class IaoBNFuseGeneric(Function):
             o2 = torch.empty_like(out)
             with torch.cuda.device_of(x):
                 ws2, nb2 = _ws(g, 0, dev)
-                if first_layer:
+                if thin:
+                    _call("mn_iaobf_thin_fwd", C.byref(g), _p(x), _p(aqp), aq_.bits, _p(qwt), _p(bias_f), 0, _p(o2), None, _s())
+                elif first_layer:
                     _call("mn_conv2d_fwd", C.byref(g), C.byref(ActQ(ACTQ_NONE, 0, 0, 0, None)), None, _p(xq), _p(qw), _p(bias_f), _p(o2), _p(ws2), nb2, CONV_ALGO, _s())
                 else:
                     aq2 = ActQ(ACTQ_IAO, aq.bits, aq.q_type, 0, aqp.data_ptr())
@@ -891,8 +918,9 @@ class IaoBNFuseGeneric(Function):
 
     @staticmethod
     def backward(ctx, gin):
-        x, weight, bias, gamma, a, stats, qw, wqp, aqp, y_raw, xq, gridqp, vc, sx = ctx.saved_tensors
+        x, weight, bias, gamma, a, stats, qw, wqp, aqp, y_raw, xq, gridqp, vc, sx, wt, qwt = ctx.saved_tensors
         g, a_bits, a_qtype, w_bits, w_qtype, eps, n, relu, first_layer = ctx.cfg
+        thin = wt is not None
         dev = x.device
         if relu and isinstance(gin, LazyReluGrad) and gin._mn_value is None:
             gy = _chk(gin._mn_g, "grad") if gin._mn_premasked else relu_mask(_chk(gin._mn_g, "grad"), a)
@@ -907,7 +935,9 @@ class IaoBNFuseGeneric(Function):
         with torch.cuda.device_of(x):
             dwq, dbf = torch.empty_like(weight), torch.empty(O, dtype=torch.float32, device=dev)
             ws, nb = _ws(g, 2, dev)
-            if first_layer:
+            if thin:
+                _call("mn_iaobf_thin_bwd_weight", C.byref(g), _p(gy), _p(x), _p(aqp), a_bits, 0, _p(dwq), _p(dbf), _s())
+            elif first_layer:
                 _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(none), _p(gy), _p(xq), _p(dwq), _p(dbf), _p(ws), nb, CONV_ALGO, _s())
             else:
                 _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dwq), _p(dbf), _p(ws), nb, CONV_ALGO, _s())
@@ -923,6 +953,16 @@ class IaoBNFuseGeneric(Function):
             # the statistics path: d y_raw from (dmean, dvar), the raw convolution's backward-weight (and backward-data)
             d_o = torch.empty_like(y_raw)
             _call("mn_bn_stats_bwd", _p(y_raw), _p(stats), _p(coef[2]), _p(coef[3]), _p(d_o), y_raw.shape[0], O, y_raw.shape[2] * y_raw.shape[3], _s())
+            if thin:          # the raw backward-weight accumulated into dw, both input gradients (+ the ReLU mask of the block in front) in one pass
+                _call("mn_iaobf_thin_bwd_weight", C.byref(g), _p(d_o), _p(x), None, 8, 1, _p(dw), None, _s())
+                if ctx.needs_input_grad[0]:
+                    pre = ctx.tok_in is not None and relu_premask_ok(ctx.x_obj)
+                    dx = torch.empty_like(x)
+                    _call("mn_iaobf_thin_bwd_data", C.byref(g), _p(gy), _p(d_o), _p(x), _p(aqp), a_bits, _p(qwt), _p(wt), int(pre), _p(dx), _s())
+                    if pre:
+                        ctx.tok_in.dx = dx
+                ctx.x_obj = None
+                return dx, dw, dbias, dgamma, dbeta, None, None, None, None
             dw_raw = torch.empty_like(weight)
             if gridqp is not None:
                 aqg = ActQ(ACTQ_IAO, ctx.xgrid[0], ctx.xgrid[1], 0, gridqp.data_ptr())          # x = code * scale exactly: the codes are recovered in the kernel's prologue

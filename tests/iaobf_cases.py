@@ -419,3 +419,114 @@ def check_g3(be, case, seed=0):
         return worst
     finally:
         os.environ.pop("MN_G3_BLOCKS", None)
+
+
+def check_first_layer_act(be, N=3, Cin=3, H=8, W=12, O=40, k=5, seed=0):
+    """mn_conv2d_fwd_act on the first-layer kernels (real operands): relu(conv) equals the plain forward's values rectified bit for bit, the (min, max) partials
+    reduce to the extremes of what was stored; relu = 0 returns the plain forward."""
+    rng = np.random.RandomState(seed)
+    x = be.to_dev(rng.randn(N, Cin, H, W).astype(np.float32))
+    w = be.to_dev((rng.randn(O, Cin, k, k) * 0.2).astype(np.float32))
+    b = be.to_dev(rng.randn(O).astype(np.float32))
+    geom = _lib.ConvGeom(N, Cin, H, W, O, k, k, 1, 1, k // 2, k // 2, 1, 1, 1, 0)
+    lib = be.lib
+    assert lib.mn_conv2d_first_supported(C.byref(geom), 0) == 1
+    none = be.actq(0)
+    cnt = int(lib.mn_conv2d_fwd_act_mm_count(C.byref(geom), C.byref(none), None))
+    assert cnt > 0
+    nb = int(lib.mn_conv2d_ws_bytes(C.byref(geom), 0, 0))
+    ws = be.empty(nb // 4 + 4)
+    y0, y1, y2, mm = be.empty((N, O, H, W)), be.empty((N, O, H, W)), be.empty((N, O, H, W)), be.empty(2 * cnt)
+    be.call("mn_conv2d_fwd", C.byref(geom), C.byref(none), None, be.ptr(x), be.ptr(w), be.ptr(b), be.ptr(y0), be.ptr(ws), nb, 0, be.stream)
+    be.call("mn_conv2d_fwd_act", C.byref(geom), C.byref(none), None, be.ptr(x), be.ptr(w), be.ptr(b), be.ptr(y1), 1, be.ptr(mm), be.ptr(ws), nb, be.stream)
+    be.call("mn_conv2d_fwd_act", C.byref(geom), C.byref(none), None, be.ptr(x), be.ptr(w), be.ptr(b), be.ptr(y2), 0, None, be.ptr(ws), nb, be.stream)
+    y0h, y1h, mmh = be.to_host(y0), be.to_host(y1), be.to_host(mm)
+    assert np.array_equal(y1h, np.maximum(y0h, 0)) and np.array_equal(be.to_host(y2), y0h)
+    assert mmh[:cnt].min() == y1h.min() and mmh[cnt:].max() == y1h.max()
+
+
+# ------------------------------------------------------------------------------------------------ thin-output pointwise family (csrc/iao_thin.hip)
+def check_thin(be, N=3, Cc=128, O=10, HW=(4, 8), shuffle=0, bias=True, seed=0):
+    """Every entry point of the thin-output family against an fp64 evaluation of the same expression."""
+    import torch.nn.functional as F
+    H, W = HW
+    rng = np.random.RandomState(200 + seed)
+    lib = be.lib
+    geom = _lib.ConvGeom(N, Cc, H, W, O, 1, 1, 1, 1, 0, 0, 1, 1, 1, shuffle)
+    assert lib.mn_iaobf_thin_supported(C.byref(geom)) == 1
+    x_h = np.maximum(rng.randn(N, Cc, H, W) * 1.2 + 0.3, 0).astype(np.float32)
+    w_h = (rng.randn(O, Cc) * 0.1).astype(np.float32)
+    b_h = (rng.randn(O) * 0.3).astype(np.float32) if bias else None
+    x, w, b = be.to_dev(x_h), be.to_dev(w_h), (be.to_dev(b_h) if bias else None)
+    shuf = (lambda t: _shuffle(t, shuffle)) if shuffle > 1 else (lambda t: t)
+    rel = lambda got, ref: float(np.abs(np.asarray(got, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+    worst = {}
+    wt = be.empty((Cc, 16))
+    be.call("mn_iaobf_thin_pack", be.ptr(w), O, Cc, be.ptr(wt), be.stream)
+    wt_h = be.to_host(wt)
+    assert np.array_equal(wt_h[:, :O], w_h.T) and not wt_h[:, O:].any()
+    # raw convolution
+    y = be.empty((N, O, H, W))
+    be.call("mn_iaobf_thin_fwd", C.byref(geom), be.ptr(x), None, 8, be.ptr(wt), be.ptr(b), 0, be.ptr(y), None, be.stream)
+    xl64 = shuf(torch.from_numpy(x_h).double())
+    w64 = torch.from_numpy(w_h).double().reshape(O, Cc, 1, 1)
+    y64 = F.conv2d(xl64, w64, torch.from_numpy(b_h).double() if bias else None).numpy()
+    worst["y_raw"] = rel(be.to_host(y), y64)
+    assert worst["y_raw"] <= 2e-6, worst
+    # quantised convolution + ReLU + (min, max)
+    s_a = np.float32(np.abs(x_h).max() / 100.0)          # x / s_a reaches 100... some values clamp at 127 only if above: make a few clamp
+    s_a = np.float32(s_a * 0.7)
+    amax = np.float32(np.abs(x_h).max()) / s_a
+    aqp_h = np.array([s_a, 0, -amax, amax], dtype=np.float32)
+    aqp = be.to_dev(aqp_h)
+    s_w = (0.001 + 0.002 * rng.rand(O)).astype(np.float32)
+    qw_h = (rng.randint(-127, 128, size=(O, Cc)).astype(np.float32) * s_w[:, None]).astype(np.float32)
+    bf_h = (rng.randn(O) * 0.5).astype(np.float32)
+    qw, bias_f = be.to_dev(qw_h), be.to_dev(bf_h)
+    qwt = be.empty((Cc, 16))
+    be.call("mn_iaobf_thin_pack", be.ptr(qw), O, Cc, be.ptr(qwt), be.stream)
+    cnt = int(lib.mn_iaobf_thin_mm_count(C.byref(geom)))
+    out, mm = be.empty((N, O, H, W)), be.empty(2 * cnt)
+    be.call("mn_iaobf_thin_fwd", C.byref(geom), be.ptr(x), be.ptr(aqp), 8, be.ptr(qwt), be.ptr(bias_f), 1, be.ptr(out), be.ptr(mm), be.stream)
+    v32 = (x_h / s_a).astype(np.float32)
+    r32 = np.sign(v32) * np.floor(np.abs(v32) + np.float32(0.5))
+    xq_h = (np.clip(r32, -128, 127) * s_a).astype(np.float32)
+    assert (r32 > 127).any()
+    xq64 = shuf(torch.from_numpy(xq_h).double())
+    qw64 = torch.from_numpy(qw_h).double().reshape(O, Cc, 1, 1)
+    out64 = torch.relu(F.conv2d(xq64, qw64, torch.from_numpy(bf_h).double())).numpy()
+    out_h = be.to_host(out)
+    worst["out"] = rel(out_h, out64)
+    assert worst["out"] <= 2e-6, worst
+    mm_h = be.to_host(mm)
+    assert mm_h[:cnt].min() == out_h.min() and mm_h[cnt:].max() == out_h.max()
+    # backward-weight: quantised path (+ d bias), then the raw path accumulated on top
+    g_h = (rng.randn(N, O, H, W) * (out_h > 0)).astype(np.float32)
+    dy_h = (rng.randn(N, O, H, W) * 0.1).astype(np.float32)
+    gy, dy = be.to_dev(g_h), be.to_dev(dy_h)
+    dw, dbf = be.empty((O, Cc)), be.empty(O)
+    be.call("mn_iaobf_thin_bwd_weight", C.byref(geom), be.ptr(gy), be.ptr(x), be.ptr(aqp), 8, 0, be.ptr(dw), be.ptr(dbf), be.stream)
+    g64, d64 = torch.from_numpy(g_h).double(), torch.from_numpy(dy_h).double()
+    dwq64 = torch.einsum("nohw,nchw->oc", g64, xq64).numpy()
+    worst["dwq"] = rel(be.to_host(dw), dwq64)
+    worst["dbf"] = rel(be.to_host(dbf), g64.sum(dim=(0, 2, 3)).numpy())
+    assert worst["dwq"] <= 2e-6 and worst["dbf"] <= 2e-6, worst
+    be.call("mn_iaobf_thin_bwd_weight", C.byref(geom), be.ptr(dy), be.ptr(x), None, 8, 1, be.ptr(dw), None, be.stream)
+    dwr64 = torch.einsum("nohw,nchw->oc", d64, xl64).numpy()
+    worst["dw_sum"] = rel(be.to_host(dw), dwq64 + dwr64)
+    assert worst["dw_sum"] <= 2e-6, worst
+    # backward-data
+    for relu_in in (0, 1):
+        dx = be.empty((N, Cc, H, W))
+        be.call("mn_iaobf_thin_bwd_data", C.byref(geom), be.ptr(gy), be.ptr(dy), be.ptr(x), be.ptr(aqp), 8, be.ptr(qwt), be.ptr(wt), relu_in, be.ptr(dx), be.stream)
+        xa = torch.from_numpy(xq_h).double().requires_grad_(True)
+        (F.conv2d(shuf(xa), qw64) * g64).sum().backward()
+        xb = torch.from_numpy(x_h).double().requires_grad_(True)
+        (F.conv2d(shuf(xb), w64) * d64).sum().backward()
+        passes = (r32 >= -128) & (r32 <= 127) & (v32 <= aqp_h[3]) & (v32 >= aqp_h[2])
+        ref = xa.grad.numpy() * passes + xb.grad.numpy()
+        if relu_in:
+            ref = ref * (x_h > 0)
+        worst["dx%d" % relu_in] = rel(be.to_host(dx), ref)
+        assert worst["dx%d" % relu_in] <= 2e-6, worst
+    return worst

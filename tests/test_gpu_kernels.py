@@ -695,3 +695,16 @@ def test_iaobf_grouped_3x3_family_at_nin_gc_shapes(be):
     import iaobf_cases as B
     B.check_g3(be, dict(N=64, G=16, HW=16, shuffle=2, bias=True, blocks=0), seed=7)
     B.check_g3(be, dict(N=64, G=32, HW=8, shuffle=4, bias=True, blocks=0), seed=8)
+
+
+def test_first_layer_forward_with_relu_and_minmax_epilogue(be):
+    import iaobf_cases as B
+    B.check_first_layer_act(be)
+    B.check_first_layer_act(be, N=64, Cin=3, H=32, W=32, O=256, k=5, seed=3)
+
+
+@pytest.mark.parametrize("shuffle,bias", [(0, True), (2, False)])
+def test_iaobf_thin_output_family(be, shuffle, bias):
+    import iaobf_cases as B
+    B.check_thin(be, shuffle=shuffle, bias=bias, seed=shuffle)
+    B.check_thin(be, N=64, Cc=1024, O=10, HW=(8, 8), shuffle=shuffle, bias=bias, seed=5 + shuffle)

@@ -254,7 +254,7 @@ def test_full_batch_teacher_forced(key):
         for i in seg:
             path_ = getattr(getattr(pstages[i], "conv", None), "__dict__", {}).get("_mn_path")
             if path_ is not None:
-                errs["kernel_family"] = {"pw": 1.0, "generic": 2.0, "g3": 3.0}[path_]
+                errs["kernel_family"] = {"pw": 1.0, "generic": 2.0, "g3": 3.0, "thin": 4.0}[path_]
         # ---- weight codes of a BN-fused IAO conv: the folded weight w * gamma / sqrt(var + eps) inherits the round-off of the batch variance (a float accumulate over
         # N*H*W outputs, whose summation order no other implementation reproduces), so an element whose pre-image w_f / scale sits within that round-off of a
         # rounding boundary may land on the neighbouring code -- on either side.  Codes must agree EXCEPT at such ties; where they differ the oracle stage is
@@ -406,6 +406,8 @@ def test_full_batch_teacher_forced(key):
         fams = [v.get("kernel_family") for v in report.values() if isinstance(v, dict) and "kernel_family" in v]
         if fams.count(3.0) != 2:
             failures.append(("c3", "grouped 3 x 3 stages on csrc/iao_g3.hip", fams.count(3.0), 2))
+        if fams.count(4.0) != 1:
+            failures.append(("c3", "classifier conv on csrc/iao_thin.hip", fams.count(4.0), 1))
     report["_oracle_loss0"] = loss0
     report["_batch"] = BATCH
     report["_failures"] = [list(map(str, f)) for f in failures]

@@ -479,3 +479,16 @@ def test_iaobf_grouped_3x3_family(be, ci):
     against an fp64 evaluation (<= 2e-6), through the channel shuffle, one and several tiles per persistent block."""
     import iaobf_cases as B
     B.check_g3(be, B.G3_CASES[ci], seed=ci)
+
+
+def test_first_layer_forward_with_relu_and_minmax_epilogue(be):
+    import iaobf_cases as B
+    B.check_first_layer_act(be)
+    B.check_first_layer_act(be, N=2, Cin=3, H=4, W=8, O=70, k=3, seed=3)
+
+
+@pytest.mark.parametrize("shuffle,bias", [(0, True), (2, False)])
+def test_iaobf_thin_output_family(be, shuffle, bias):
+    """csrc/iao_thin.hip: raw / quantised pointwise conv with <= 16 outputs, both backward-weights, the two-path backward-data against fp64"""
+    import iaobf_cases as B
+    B.check_thin(be, shuffle=shuffle, bias=bias, seed=shuffle)
