@@ -306,69 +306,83 @@ __device__ __forceinline__ void bf_stage16(V* __restrict__ dst, const V* __restr
 struct __attribute__((aligned(16))) bf_d2 { double a, b; };
 
 #define BF_GS_CH 8
-// 256 threads = two halves of 128: half h owns channels o0 + 8 h .. + 7, thread i of a half column i.  The group's whole Gram matrix is staged in LDS first (bulk
-// coalesced loads, all in flight) -- read from global inside the loop it cost one serialised L2 round trip per row (31 us for 128 rows).
+// One block per (group, 8 output channels).  256 threads = two halves of 128: thread i of a half owns column i, the halves split the rows of the Gram matrix (the
+// contraction index) and meet in LDS.  The group's whole Gram matrix is staged in LDS first (bulk coalesced loads, all in flight) -- read from global inside the loop
+// it cost one serialised L2 round trip per row (31 us for 128 rows).
 __global__ __launch_bounds__(256) void k_bf_gram_stats(const float* __restrict__ w, const float* __restrict__ bias, const double* __restrict__ gram,
                                                        const double* __restrict__ sx, int O, int Mg, int Cg, double n, float* __restrict__ stats,
                                                        float* __restrict__ vc) {
-    HIP_DYNAMIC_SHARED(double, gsm)          // [Cg * Cg] G, then ws [2 * BF_GS_CH][128] floats, then red [2 * BF_GS_CH][2][2] doubles
-    double* red = gsm + Cg * Cg;
-    float* ws = reinterpret_cast<float*>(red + 2 * BF_GS_CH * 4);
-    const int nb = (Mg + 2 * BF_GS_CH - 1) / (2 * BF_GS_CH);
-    const int g = blockIdx.x / nb, ob = (blockIdx.x % nb) * 2 * BF_GS_CH;
+    HIP_DYNAMIC_SHARED(double, gsm)          // [Cg * Cg] G, then comb [128][BF_GS_CH] doubles, red [BF_GS_CH][2][2] doubles, ws [BF_GS_CH][128] floats
+    double* comb = gsm + Cg * Cg;
+    double* red = comb + 128 * BF_GS_CH;
+    float* ws = reinterpret_cast<float*>(red + BF_GS_CH * 4);
+    const int nb = (Mg + BF_GS_CH - 1) / BF_GS_CH;
+    const int g = blockIdx.x / nb, ob = (blockIdx.x % nb) * BF_GS_CH;
     const int tid = threadIdx.x, half = tid >> 7, i = tid & 127;
-    const int o0 = g * Mg + ob + half * BF_GS_CH;
+    const int o0 = g * Mg + ob;
     const double* __restrict__ G = gram + (int64_t)g * Cg * Cg;
     const double* __restrict__ sxg = sx + (int64_t)g * Cg;
-    int nch = Mg - ob - half * BF_GS_CH;
-    nch = nch < 0 ? 0 : (nch < BF_GS_CH ? nch : BF_GS_CH);
+    int nch = Mg - ob;
+    nch = nch < BF_GS_CH ? nch : BF_GS_CH;
     if ((Cg & 1) == 0 && !(((uintptr_t)G) & 15)) bf_stage16(reinterpret_cast<bf_d2*>(gsm), reinterpret_cast<const bf_d2*>(G), Cg * Cg / 2, tid, 256);
     else for (int e = tid; e < Cg * Cg; e += 256) gsm[e] = G[e];
-    for (int k = 0; k < BF_GS_CH; ++k) ws[(half * BF_GS_CH + k) * 128 + i] = (k < nch && i < Cg) ? w[(int64_t)(o0 + k) * Cg + i] : 0.f;
+    for (int e = tid; e < BF_GS_CH * 128; e += 256) {
+        const int k = e >> 7, c = e & 127;
+        ws[e] = (k < nch && c < Cg) ? w[(int64_t)(o0 + k) * Cg + c] : 0.f;
+    }
     __syncthreads();
-    const float* wsh = ws + half * BF_GS_CH * 128;
     double acc[BF_GS_CH], m1p[BF_GS_CH];
 #pragma unroll
     for (int k = 0; k < BF_GS_CH; ++k) { acc[k] = 0.0; m1p[k] = 0.0; }
     const double xbi = i < Cg ? sxg[i] / n : 0.0;
     if (i < Cg) {
-        for (int c = 0; c < Cg; ++c) {
+        const int ch = (Cg + 1) >> 1, cb = half * ch, ce = (cb + ch < Cg) ? cb + ch : Cg;
+#pragma unroll 4
+        for (int c = cb; c < ce; ++c) {
             const double gv = gsm[c * Cg + i];
 #pragma unroll
-            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (double)wsh[k * 128 + c] * gv;
+            for (int k = 0; k < BF_GS_CH; ++k) acc[k] += (double)ws[k * 128 + c] * gv;
         }
-#pragma unroll
-        for (int k = 0; k < BF_GS_CH; ++k) m1p[k] = (double)wsh[k * 128 + i] * xbi;
     }
-    // m1[k] = sum_i w[k][i] x_bar[i]: wave shuffles, the two waves of a half combined through LDS
-    double* redh = red + half * BF_GS_CH * 4;
+    if (half == 1) {
 #pragma unroll
-    for (int k = 0; k < BF_GS_CH; ++k) {
-        double v = m1p[k];
+        for (int k = 0; k < BF_GS_CH; ++k) comb[i * BF_GS_CH + k] = acc[k];
+    }
+    __syncthreads();
+    if (half == 0) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) redh[k * 4 + ((tid >> 6) & 1) * 2] = v;
+        for (int k = 0; k < BF_GS_CH; ++k) { acc[k] += comb[i * BF_GS_CH + k]; m1p[k] = i < Cg ? (double)ws[k * 128 + i] * xbi : 0.0; }
+        // m1[k] = sum_i w[k][i] x_bar[i]: wave shuffles, the two waves of the half combined through LDS
+#pragma unroll
+        for (int k = 0; k < BF_GS_CH; ++k) {
+            double v = m1p[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((tid & 63) == 0) red[k * 4 + ((tid >> 6) & 1) * 2] = v;
+        }
     }
     __syncthreads();
     double qp_[BF_GS_CH];
+    if (half == 0) {
 #pragma unroll
-    for (int k = 0; k < BF_GS_CH; ++k) {
-        const double m1 = redh[k * 4] + redh[k * 4 + 2];
-        const double vcv = acc[k] - n * m1 * xbi;          // centred: (W S)[o, i]
-        if (k < nch && i < Cg) vc[(int64_t)(o0 + k) * Cg + i] = (float)vcv;
-        qp_[k] = i < Cg ? vcv * (double)wsh[k * 128 + i] : 0.0;
-    }
+        for (int k = 0; k < BF_GS_CH; ++k) {
+            const double m1 = red[k * 4] + red[k * 4 + 2];
+            const double vcv = acc[k] - n * m1 * xbi;          // centred: (W S)[o, i]
+            if (k < nch && i < Cg) vc[(int64_t)(o0 + k) * Cg + i] = (float)vcv;
+            qp_[k] = i < Cg ? vcv * (double)ws[k * 128 + i] : 0.0;
+        }
 #pragma unroll
-    for (int k = 0; k < BF_GS_CH; ++k) {
-        double v = qp_[k];
+        for (int k = 0; k < BF_GS_CH; ++k) {
+            double v = qp_[k];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) redh[k * 4 + ((tid >> 6) & 1) * 2 + 1] = v;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((tid & 63) == 0) red[k * 4 + ((tid >> 6) & 1) * 2 + 1] = v;
+        }
     }
     __syncthreads();
-    if (i < nch) {
-        const int k = i;
-        const double m1 = redh[k * 4] + redh[k * 4 + 2], q = redh[k * 4 + 1] + redh[k * 4 + 3];
+    if (tid < nch) {
+        const int k = tid;
+        const double m1 = red[k * 4] + red[k * 4 + 2], q = red[k * 4 + 1] + red[k * 4 + 3];
         stats[o0 + k] = (float)(m1 + (bias ? (double)bias[o0 + k] : 0.0));
         stats[O + o0 + k] = (float)(q / (n - 1.0));
     }
@@ -376,8 +390,8 @@ __global__ __launch_bounds__(256) void k_bf_gram_stats(const float* __restrict__
 extern "C" int mn_iaobf_gram_stats(const float* w, const float* bias, const double* gram, const double* sx, int64_t O, int64_t Cg, int64_t groups, double n, float* stats,
                                    float* vc, mn_stream_t stream) {
     if (!w || !gram || !sx || !stats || !vc || O <= 0 || Cg <= 0 || Cg > 128 || groups < 1 || O % groups || !(n > 1.0)) MN_FAIL(MN_EINVAL, "mn_iaobf_gram_stats: bad arguments");
-    const int Mg = (int)(O / groups), nb = (Mg + 2 * BF_GS_CH - 1) / (2 * BF_GS_CH);
-    const size_t lds = (size_t)Cg * Cg * 8 + (size_t)2 * BF_GS_CH * 4 * 8 + (size_t)2 * BF_GS_CH * 128 * 4;
+    const int Mg = (int)(O / groups), nb = (Mg + BF_GS_CH - 1) / BF_GS_CH;
+    const size_t lds = (size_t)Cg * Cg * 8 + (size_t)128 * BF_GS_CH * 8 + (size_t)BF_GS_CH * 4 * 8 + (size_t)BF_GS_CH * 128 * 4;
     mn_set_last_kernel("k_bf_gram_stats");
     raise_lds_limit((const void*)k_bf_gram_stats, lds);
     hipLaunchKernelGGL(k_bf_gram_stats, dim3((unsigned)(groups * nb)), dim3(256), lds, (hipStream_t)stream, w, bias, gram, sx, (int)O, Mg, (int)Cg, n, stats, vc);
@@ -785,37 +799,74 @@ struct BfMParams {
     double n;
 };
 #define BF_M_ROWS 8
-// 256 threads = two halves of 128: half h owns rows c0 + 8 h .. + 7 of M, thread i of a half column i.  The group's weights (Mg x Cg fp32) are staged in LDS first
-// (the loop over o then reads LDS only: from global it was one serialised L2 round trip per o, 48 us).
+// One block per (group, 8 rows of M).  256 threads = two halves of 128: thread i of a half owns column i, the halves split the sum over the output channels and meet
+// in LDS.  The group's weights (Mg x Cg fp32) are staged in LDS first (the loop over o then reads LDS only: from global it was one serialised L2 round trip per o);
+// the transposed weight codes come from ONE 16-byte load per thread (4 input channels of one output channel), v = W^T dmean / n from all 256 threads.  Round 4
+// (first version: 16 rows per block, halves over the rows, strided 4-byte loads for the codes, 8 lanes for v): 54 us -> see DESIGN 4d.
 __global__ __launch_bounds__(256) void k_bf_M(const BfMParams p) {
-    HIP_DYNAMIC_SHARED(float, wsm)          // [Mg][Cg] W of the group, then [Mg] B
+    HIP_DYNAMIC_SHARED(float, wsm)          // [Mg][Cg] W of the group, [Mg (+1)] B, then doubles [128][BF_M_ROWS]
     float* bsm = wsm + p.Mg * p.Cg;
-    const int nrb = p.Mpad / (2 * BF_M_ROWS);
+    double* dsm = reinterpret_cast<double*>(wsm + ((p.Mg * p.Cg + p.Mg + 1) & ~1));
+    const int nrb = p.Mpad / BF_M_ROWS;
     const int g = blockIdx.x / nrb, tid = threadIdx.x, half = tid >> 7, i = tid & 127;
-    const int c0 = (blockIdx.x % nrb) * 2 * BF_M_ROWS + half * BF_M_ROWS;
+    const int c0 = (blockIdx.x % nrb) * BF_M_ROWS;
     const float* __restrict__ wg = p.w + (int64_t)g * p.Mg * p.Cg;
     const float* __restrict__ A = p.coef + g * p.Mg;
     if (((p.Mg * p.Cg) & 3) == 0 && !(((uintptr_t)wg) & 15)) bf_stage16(reinterpret_cast<float4*>(wsm), reinterpret_cast<const float4*>(wg), p.Mg * p.Cg / 4, tid, 256);
     else for (int e = tid; e < p.Mg * p.Cg; e += 256) wsm[e] = wg[e];
     for (int o = tid; o < p.Mg; o += 256) bsm[o] = p.coef[p.O + g * p.Mg + o];
+    // transposed codes of the quantised weights: code = rha(qw / scale[o]) (exact small integers); every entry of the block's rows is written (zero padding)
+    {
+        const bool vec = (p.Cg & 3) == 0 && !(((uintptr_t)p.qw) & 15);
+        for (int e = tid; e < 2 * p.KpA; e += 256) {
+            const int o = e >> 1, q4 = (e & 1) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (o < p.Mg) {
+                const int oo = g * p.Mg + o;
+                const float sc = p.wscale[(int64_t)oo * p.wscale_stride];
+                const float* src = p.qw + (int64_t)oo * p.Cg + c0 + q4;
+                if (vec && c0 + q4 + 3 < p.Cg) {
+                    const float4 f = *reinterpret_cast<const float4*>(src);
+                    v[0] = mn_rha(f.x / sc); v[1] = mn_rha(f.y / sc); v[2] = mn_rha(f.z / sc); v[3] = mn_rha(f.w / sc);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (c0 + q4 + k < p.Cg) v[k] = mn_rha(src[k] / sc);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p.wc[((int64_t)g * p.Mpad + c0 + q4 + k) * p.KpA + o] = (uint16_t)(mn_f2u(v[k]) >> 16);
+        }
+        if (blockIdx.x % nrb == 0)
+            for (int o = tid; o < p.KpA; o += 256) p.kscale[g * p.KpA + o] = o < p.Mg ? p.wscale[(int64_t)(g * p.Mg + o) * p.wscale_stride] : 0.f;
+    }
     __syncthreads();
-    // M[c][c2] = sum_o B[o] W[o][c] W[o][c2] (fp64)
+    // M[c][c2] = sum_o B[o] W[o][c] W[o][c2] (fp64): this half's share of the output channels
+    const int oh = (p.Mg + 1) >> 1, ob = half * oh, oe = (ob + oh < p.Mg) ? ob + oh : p.Mg;
+    int rc[BF_M_ROWS];
+#pragma unroll
+    for (int r = 0; r < BF_M_ROWS; ++r) rc[r] = c0 + r < p.Cg ? c0 + r : p.Cg - 1;          // (rows beyond Cg are padding: computed on a valid column, stored as zero)
     double m[BF_M_ROWS];
 #pragma unroll
     for (int r = 0; r < BF_M_ROWS; ++r) m[r] = 0.0;
     if (i < p.Cg) {
-        for (int o = 0; o < p.Mg; ++o) {
+#pragma unroll 4
+        for (int o = ob; o < oe; ++o) {
             const float* wo = wsm + o * p.Cg;
             const double wv = (double)bsm[o] * (double)wo[i];
 #pragma unroll
-            for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (double)(c0 + r < p.Cg ? wo[c0 + r] : 0.f);
+            for (int r = 0; r < BF_M_ROWS; ++r) m[r] += wv * (double)wo[rc[r]];
         }
     }
+    if (half == 1) {
+#pragma unroll
+        for (int r = 0; r < BF_M_ROWS; ++r) dsm[i * BF_M_ROWS + r] = m[r];
+    }
+    __syncthreads();
     const int64_t plane = (int64_t)p.G * p.Mpad * p.KpB;
-    if (i < p.KpB) {
+    if (half == 0 && i < p.KpB) {
 #pragma unroll
         for (int r = 0; r < BF_M_ROWS; ++r) {
-            const float v = (i < p.Cg && c0 + r < p.Cg) ? (float)m[r] : 0.f;
+            const float v = (i < p.Cg && c0 + r < p.Cg) ? (float)(m[r] + dsm[i * BF_M_ROWS + r]) : 0.f;
             const float t0 = mn_bf16_head(v), r1 = v - t0, t1 = mn_bf16_head(r1), t2 = r1 - t1;
             const int64_t at = ((int64_t)g * p.Mpad + c0 + r) * p.KpB + i;
             p.mt[at] = (uint16_t)(mn_f2u(t0) >> 16);
@@ -823,25 +874,20 @@ __global__ __launch_bounds__(256) void k_bf_M(const BfMParams p) {
             p.mt[2 * plane + at] = (uint16_t)(mn_f2u(t2) >> 16);
         }
     }
-    // transposed codes of the quantised weights: code = rha(qw / scale[o]) (exact small integers)
-    for (int r = 0; r < BF_M_ROWS; ++r) {
-        const int c = c0 + r;
-        for (int o = i; o < p.KpA; o += 128) {
-            float code = 0.f;
-            if (c < p.Cg && o < p.Mg) {
-                const int oo = g * p.Mg + o;
-                code = mn_rha(p.qw[(int64_t)oo * p.Cg + c] / p.wscale[(int64_t)oo * p.wscale_stride]);
-            }
-            p.wc[((int64_t)g * p.Mpad + c) * p.KpA + o] = (uint16_t)(mn_f2u(code) >> 16);
-        }
+    __syncthreads();          // dsm is reused
+    {   // v[c] = sum_o (dmean[o] / n) W[o][c] for the block's rows: 32 partial sums per row (thread = (row, o mod 32)), then one thread per row; x_bar
+        const int r = tid & 7, seg = tid >> 3;
+        double vs = 0.0;
+        if (c0 + r < p.Cg)
+            for (int o = seg; o < p.Mg; o += 32) vs += (double)A[o] * (double)wsm[o * p.Cg + c0 + r];
+        dsm[seg * BF_M_ROWS + r] = vs;
     }
-    if (blockIdx.x % nrb == 0 && half == 0)
-        for (int o = i; o < p.KpA; o += 128) p.kscale[g * p.KpA + o] = o < p.Mg ? p.wscale[(int64_t)(g * p.Mg + o) * p.wscale_stride] : 0.f;
-    if (i < BF_M_ROWS && c0 + i < p.Cg) {          // v[c] = sum_o (dmean[o] / n) W[o][c]; x_bar
+    __syncthreads();
+    if (tid < BF_M_ROWS && c0 + tid < p.Cg) {
         double vsum = 0.0;
-        for (int o = 0; o < p.Mg; ++o) vsum += (double)A[o] * (double)wsm[o * p.Cg + c0 + i];
-        p.vadd[g * p.Cg + c0 + i] = (float)vsum;
-        p.xbar[g * p.Cg + c0 + i] = (float)(p.sx[g * p.Cg + c0 + i] / p.n);
+        for (int seg = 0; seg < 32; ++seg) vsum += dsm[seg * BF_M_ROWS + tid];
+        p.vadd[g * p.Cg + c0 + tid] = (float)vsum;
+        p.xbar[g * p.Cg + c0 + tid] = (float)(p.sx[g * p.Cg + c0 + tid] / p.n);
     }
 }
 
@@ -899,9 +945,9 @@ extern "C" int mn_iaobf_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const
     m.xbar = (float*)((char*)ws + pl.off_xbar); m.vadd = (float*)((char*)ws + pl.off_v);
     m.O = g->O; m.Cg = p.Cg; m.Mg = p.Mg; m.G = p.G; m.Mpad = p.Mpad; m.KpA = p.KpA; m.KpB = p.KpB; m.n = (double)g->N * g->H * g->W;
     {
-        const size_t ldsm = ((size_t)p.Mg * p.Cg + p.Mg) * 4;
+        const size_t ldsm = (size_t)((p.Mg * p.Cg + p.Mg + 1) & ~1) * 4 + (size_t)128 * BF_M_ROWS * 8;
         raise_lds_limit((const void*)k_bf_M, ldsm);
-        hipLaunchKernelGGL(k_bf_M, dim3((unsigned)(p.G * p.Mpad / (2 * BF_M_ROWS))), dim3(256), ldsm, s, m);
+        hipLaunchKernelGGL(k_bf_M, dim3((unsigned)(p.G * p.Mpad / BF_M_ROWS)), dim3(256), ldsm, s, m);
     }
     const IaoRange r = iao_range(aq->bits, aq->q_type, 1);
     p.gy = gy; p.x = x; p.dx = dx; p.wc = m.wc; p.kscale = m.kscale; p.mt = m.mt; p.xbar = m.xbar; p.vadd = m.vadd; p.qp = aq->qp; p.qmin = r.qmin; p.qmax = r.qmax;

@@ -48,10 +48,17 @@ __global__ __launch_bounds__(64 * TH_FW) void k_thin_fwd(const ThinFParams p) {
     float acc[TH_O];
 #pragma unroll
     for (int o = 0; o < TH_O; ++o) acc[o] = 0.f;
-    for (int cb = 0; cb < cs; cb += TH_FU) {          // TH_FU loads of 256 B in flight per wave
+    float xn[TH_FU];          // the next step's TH_FU loads of 256 B are in flight while this step's are consumed
+#pragma unroll
+    for (int u = 0; u < TH_FU; ++u) xn[u] = pv ? xb[(int64_t)chan_phys(m.in_map, c0 + u) * m.HW] : 0.f;
+    for (int cb = 0; cb < cs; cb += TH_FU) {
         float xv[TH_FU];
 #pragma unroll
-        for (int u = 0; u < TH_FU; ++u) xv[u] = pv ? xb[(int64_t)chan_phys(m.in_map, c0 + cb + u) * m.HW] : 0.f;
+        for (int u = 0; u < TH_FU; ++u) xv[u] = xn[u];
+        if (cb + TH_FU < cs) {
+#pragma unroll
+            for (int u = 0; u < TH_FU; ++u) xn[u] = pv ? xb[(int64_t)chan_phys(m.in_map, c0 + cb + TH_FU + u) * m.HW] : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < TH_FU; ++u) {
             float v = xv[u];
@@ -97,6 +104,7 @@ struct ThinWParams {
 };
 #define TH_CL 4          // input channels per backward-weight block
 #define TH_WW 8          // waves per backward-weight block (pixel chunks c, c + 8, ...)
+#define TH_WU 4          // chunks per unrolled step
 __global__ __launch_bounds__(64 * TH_WW) void k_thin_wgrad(const ThinWParams p) {
     __shared__ float red[TH_WW][TH_O * TH_CL + TH_O];
     const ThinGeom& m = p.m;
@@ -117,10 +125,10 @@ __global__ __launch_bounds__(64 * TH_WW) void k_thin_wgrad(const ThinWParams p) 
         for (int k = 0; k < TH_CL; ++k) acc[o][k] = 0.f;
     }
     const uint32_t nchunks = (m.NP + 63u) / 64u;
-    for (uint32_t ch = wave; ch < nchunks; ch += 2 * TH_WW) {          // two chunks per step: their loads are in flight together
-        float xv[2][TH_CL], av[2][TH_O];
+    for (uint32_t ch = wave; ch < nchunks; ch += TH_WU * TH_WW) {          // TH_WU chunks per step: their loads are in flight together
+        float xv[TH_WU][TH_CL], av[TH_WU][TH_O];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < TH_WU; ++h) {
             const uint32_t P = (ch + h * TH_WW) * 64u + lane;
             const bool pv = P < m.NP;
             const uint32_t n = fd_div(pv ? P : 0u, m.fd_hw);
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(64 * TH_WW) void k_thin_wgrad(const ThinWParams p) 
             for (int o = 0; o < TH_O; ++o) av[h][o] = (pv && o < m.O) ? p.a[((int64_t)n * m.O + o) * m.HW + pp] : 0.f;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < TH_WU; ++h) {
             if (quant) {
 #pragma unroll
                 for (int k = 0; k < TH_CL; ++k) xv[h][k] = iao_code_m(xv[h][k], sc, inv_sc, zp, p.qmin, p.qmax) * sc;          // (an invalid pixel has a = 0)
@@ -199,11 +207,18 @@ __global__ __launch_bounds__(64 * TH_DW) void k_thin_dgrad(const ThinDParams p) 
     }
     const int cs = m.C / TH_DW, c0 = wave * cs;
     const int64_t xb = (int64_t)n * m.C * m.HW + pp;
+    float xn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xn[u] = p.x[xb + (int64_t)chan_phys(m.in_map, c0 + u) * m.HW];
     for (int cb = 0; cb < cs; cb += 8) {
         float xv[8];
         int64_t off[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { off[u] = xb + (int64_t)chan_phys(m.in_map, c0 + cb + u) * m.HW; xv[u] = p.x[off[u]]; }
+        for (int u = 0; u < 8; ++u) { off[u] = xb + (int64_t)chan_phys(m.in_map, c0 + cb + u) * m.HW; xv[u] = xn[u]; }
+        if (cb + 8 < cs) {          // the next step's loads fly during this step's arithmetic and stores
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xn[u] = p.x[xb + (int64_t)chan_phys(m.in_map, c0 + cb + 8 + u) * m.HW];
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float* __restrict__ q = p.qwt + (int64_t)(c0 + cb + u) * TH_O;
