@@ -167,6 +167,145 @@ __global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
     }
 }
 
+// Forward on the bf16 matrix cores (round 4).  v_mfma_f32_16x16x4_f32 made the kernel above MFMA-bound (5 GMAC of fp32 MFMA: 64 us at the fp32 peak, 123 us measured,
+// against 55 us for writing y).  Both operands are real, so each is written as three exact bf16 terms and a product uses the six largest term products (2^-24
+// relative: the accuracy of an fp32 multiply) on v_mfma_f32_16x16x32_bf16 -- 6 / 16 of the fp32-MFMA time.  The B operand needs 8 consecutive K per lane, which
+// the channel / tap-strided patch cannot give, so every 64-pixel chunk is expanded ONCE per block into an im2col tile [term][pixel][96 k] in LDS (24 consecutive k
+// of one pixel per thread: patch reads conflict-free along the pixels, three 16-byte writes per term) that the four waves -- each 64 out-channels -- share; the
+// weights are A fragments in registers for the block's lifetime (3 terms x 3 K steps x MT).  Pixel p sits in tile row (p & 3) * 16 + (p >> 2): MFMA column j of
+// n-tile q is pixel 4 j + q, so a lane ends with float4 = 4 consecutive pixels per out-channel (the write side takes the bank conflicts of that permutation: 9
+// writes against 36 fragment reads per chunk).
+#define C1B_KP 96            // padded K (3 K steps of 32)
+#define C1B_LD 104           // u16 per im2col row: 96 + 8 pad (208-byte rows: the 16 rows of a fragment read cover all banks)
+template <int MT>
+__global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* xs = smem;
+    uint16_t* im = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + p.xs_bytes);          // [3][64][C1B_LD]
+    int* ktab = reinterpret_cast<int*>(im + 3 * 64 * C1B_LD);                                      // [96] patch offset of im2col row k (-1: padding)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    uint32_t b = blockIdx.x;
+    const int strip = b % p.strips; b /= p.strips;
+    const int n = b % p.N;
+    const int cblk = b / p.N;
+    const int row0 = strip * p.R;
+    const int m0 = (cblk * 4 + wave) * 16 * MT;
+
+    c1_stage(p, xs, n, row0);
+    for (int k = tid; k < C1B_KP; k += 256) ktab[k] = k < p.K ? c1_koff(p, k) : -1;
+    // A fragments: three exact bf16 terms of w[m0 + t * 16 + j][ks * 32 + kg * 8 .. + 7]
+    u32x4 wa[3][3][MT];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = m0 + t * 16 + j;
+            float t0[8], t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = ks * 32 + kg * 8 + e;
+                const float v = (m < p.O && k < p.K) ? p.wp[(int64_t)m * p.K + k] : 0.f;
+                t0[e] = mn_bf16_head(v);
+                const float r1 = v - t0[e];
+                t1[e] = mn_bf16_head(r1);
+                t2[e] = r1 - t1[e];
+            }
+            wa[0][ks][t] = u32x4{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3]), mn_pack_bf16x2(t0[4], t0[5]), mn_pack_bf16x2(t0[6], t0[7])};
+            wa[1][ks][t] = u32x4{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3]), mn_pack_bf16x2(t1[4], t1[5]), mn_pack_bf16x2(t1[6], t1[7])};
+            wa[2][ks][t] = u32x4{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3]), mn_pack_bf16x2(t2[4], t2[5]), mn_pack_bf16x2(t2[6], t2[7])};
+        }
+    __syncthreads();
+
+    float lo = INFINITY, hi = -INFINITY;
+    int mnan = 0;
+    const int npix = p.R * p.W, nchunks = (npix + 63) >> 6;
+    const int irow = (lane & 3) * 16 + (lane >> 2);          // im2col tile row of the pixel this thread expands (pixel `lane` of the chunk)
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        // ---- expand: thread = (pixel lane, k quarter wave): 24 consecutive k
+        {
+            const int pix = chunk * 64 + lane;
+            const bool pv = pix < npix;
+            const uint32_t prow = fd_div(pv ? pix : 0, p.fd_w);
+            const int pcol = (pv ? pix : 0) - prow * p.W;
+            const float* src = xs + (int)prow * p.PW + pcol;
+            uint16_t* dst = im + irow * C1B_LD + wave * 24;
+#pragma unroll
+            for (int o8 = 0; o8 < 3; ++o8) {
+                float t0[8], t1[8], t2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ko = ktab[wave * 24 + o8 * 8 + e];
+                    const float v = (pv && ko >= 0) ? src[ko] : 0.f;
+                    t0[e] = mn_bf16_head(v);
+                    const float r1 = v - t0[e];
+                    t1[e] = mn_bf16_head(r1);
+                    t2[e] = r1 - t1[e];
+                }
+                *reinterpret_cast<u32x4*>(dst + o8 * 8) = u32x4{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3]), mn_pack_bf16x2(t0[4], t0[5]), mn_pack_bf16x2(t0[6], t0[7])};
+                *reinterpret_cast<u32x4*>(dst + 64 * C1B_LD + o8 * 8) = u32x4{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3]), mn_pack_bf16x2(t1[4], t1[5]), mn_pack_bf16x2(t1[6], t1[7])};
+                *reinterpret_cast<u32x4*>(dst + 128 * C1B_LD + o8 * 8) = u32x4{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3]), mn_pack_bf16x2(t2[4], t2[5]), mn_pack_bf16x2(t2[6], t2[7])};
+            }
+        }
+        __syncthreads();
+        f32x4 acc[4][MT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint16_t* br = im + (q * 16 + j) * C1B_LD + ks * 32 + kg * 8;
+                const u32x4 b0 = *reinterpret_cast<const u32x4*>(br), b1 = *reinterpret_cast<const u32x4*>(br + 64 * C1B_LD), b2 = *reinterpret_cast<const u32x4*>(br + 128 * C1B_LD);
+                // the six term products, smallest first; MT independent accumulators between two MFMAs on the same one
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[q][t] = mn_mfma_bf16(wa[0][ks][t], b2, acc[q][t]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[q][t] = mn_mfma_bf16(wa[2][ks][t], b0, acc[q][t]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[q][t] = mn_mfma_bf16(wa[1][ks][t], b1, acc[q][t]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[q][t] = mn_mfma_bf16(wa[0][ks][t], b1, acc[q][t]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[q][t] = mn_mfma_bf16(wa[1][ks][t], b0, acc[q][t]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[q][t] = mn_mfma_bf16(wa[0][ks][t], b0, acc[q][t]);
+            }
+        __syncthreads();          // the tile is consumed: the next chunk may be expanded
+        // D[row = channel 4 kg + r][col j of n-tile q = pixel 4 j + q]: a float4 of 4 consecutive pixels per channel
+        const int pix = chunk * 64 + 4 * j;
+        if (pix < npix) {
+            const uint32_t prow = fd_div(pix, p.fd_w);
+            const int pcol = pix - prow * p.W;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + t * 16 + kg * 4 + r;
+                    if (m < p.O) {
+                        const float bb = p.bias ? p.bias[m] : 0.f;
+                        float* dst = p.y + (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol;
+                        float4 v = make_float4(acc[0][t][r] + bb, acc[1][t][r] + bb, acc[2][t][r] + bb, acc[3][t][r] + bb);
+                        if (p.relu) { v.x = qa_relu(v.x); v.y = qa_relu(v.y); v.z = qa_relu(v.z); v.w = qa_relu(v.w); }
+                        if (p.mm) {
+                            lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+                            hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                            mnan |= (int)((v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w));
+                        }
+                        *reinterpret_cast<float4*>(dst) = v;
+                    }
+                }
+        }
+    }
+    if (p.mm) {
+        if (mnan) lo = hi = NAN;
+        lo = block_reduce(lo, OpMinF(), INFINITY, xs);
+        hi = block_reduce(hi, OpMaxF(), -INFINITY, xs);
+        if (tid == 0) { p.mm[blockIdx.x] = lo; p.mm[gridDim.x + blockIdx.x] = hi; }
+    }
+}
+
 // backward-weight: block z accumulates dw over its share of (image, strip) tiles for the 64*MT... out-channels of its channel block.
 // wave w owns out-channels [m0, m0 + 16*MT); the five 16-wide tiles of the k axis cover K <= 80.
 // BN = 1: the layer is followed by BatchNorm2d + BinaryActivation and nothing else consumes d loss / d y (the first layer has no
@@ -419,10 +558,25 @@ int c1_fwd_act(const mn_conv_geom* g, const float* x, const float* w, const floa
     if (!plan_c1(g, &pl) || !aligned16(y)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(first-layer): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes_f || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(first-layer): workspace too small");
     C1Params& p = pl.p;
+    p.x = x; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0; p.da = nullptr;
+    p.relu = relu; p.mm = mm;
+    static const bool f32_path = MN_ENV("MN_C1_F32") != nullptr;          // A/B knob: the fp32-MFMA forward
+    const size_t lds_b = (size_t)p.xs_bytes + (size_t)3 * 64 * C1B_LD * 2 + C1B_KP * 4;
+    if (!f32_path && lds_b <= 80 * 1024) {          // three-term bf16 forward (reads the weights as they are: no pack launch)
+        p.wp = w;
+        mn_set_last_kernel("k_c1b_fwd<%d>", pl.MT);
+        mn_prof_begin(s);
+        if (pl.MT == 4) { raise_lds_limit((const void*)k_c1b_fwd<4>, lds_b); hipLaunchKernelGGL(k_c1b_fwd<4>, dim3(pl.grid_f), dim3(256), lds_b, s, p); }
+        else if (pl.MT == 3) { raise_lds_limit((const void*)k_c1b_fwd<3>, lds_b); hipLaunchKernelGGL(k_c1b_fwd<3>, dim3(pl.grid_f), dim3(256), lds_b, s, p); }
+        else if (pl.MT == 2) { raise_lds_limit((const void*)k_c1b_fwd<2>, lds_b); hipLaunchKernelGGL(k_c1b_fwd<2>, dim3(pl.grid_f), dim3(256), lds_b, s, p); }
+        else { raise_lds_limit((const void*)k_c1b_fwd<1>, lds_b); hipLaunchKernelGGL(k_c1b_fwd<1>, dim3(pl.grid_f), dim3(256), lds_b, s, p); }
+        mn_prof_end(s);
+        MN_CHECK_LAUNCH("mn_conv2d_fwd(first-layer)");
+        return MN_OK;
+    }
     float* wp = (float*)ws;
     hipLaunchKernelGGL(k_c1_pack, dim3(mn_grid_for((int64_t)C1_KS * 4 * p.Opad, 256, 256)), dim3(256), 0, s, w, wp, p.O, p.K, p.Opad, C1_KS * 4);
-    p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0; p.da = nullptr;
-    p.relu = relu; p.mm = mm;
+    p.wp = wp;
     mn_set_last_kernel("k_c1_fwd<%d>", pl.MT);
     mn_prof_begin(s);
     if (pl.MT == 4) { raise_lds_limit((const void*)k_c1_fwd<4>, pl.lds); hipLaunchKernelGGL(k_c1_fwd<4>, dim3(pl.grid_f), dim3(256), pl.lds, s, p); }

@@ -28,6 +28,12 @@ def prequantize_weights(model):
             m.weight.data = m.weight_quantizer(m.weight).detach()
             m.weight_quantizer.train(was)
             n += 1
+            # DoReFa layers: record the "stored weights lie on the quantizer grid" verdict now (one host sync per layer, here instead of inside the first forward --
+            # which may be a captured one)
+            if type(m).__module__.endswith("dorefa.quantize") and m.weight.is_cuda and not torch.cuda.is_current_stream_capturing():
+                from micronet_amd.quantization.wqaq.dorefa.quantize import _weight_is_coded
+                m.__dict__.pop("_mn_grid", None)
+                _weight_is_coded(m)
     return n
 
 

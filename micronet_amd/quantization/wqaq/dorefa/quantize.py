@@ -85,15 +85,25 @@ def _weight_is_coded(module):
     key = (w.data_ptr(), w._version, tuple(w.shape))
     c = module.__dict__.get("_mn_grid")
     if c is None or c[0] != key:
+        if w.is_cuda and torch.cuda.is_current_stream_capturing():
+            # the check reads a device value on the host: not possible while a HIP graph is being captured, and the verdict must not be guessed
+            raise RuntimeError("quant_inference forward under stream capture before the stored weights were checked against the quantizer grid: run one eager "
+                               "forward first (or micronet_amd.inference.prequantize_weights(model), which records the verdict)")
         ok = False
         if w.numel() and w.is_cuda and w.dtype == torch.float32:
             n = float(2 ** b - 1)
             with torch.no_grad():
                 k = (w.detach() * n + n) * 0.5
                 ok = bool(((k - k.round()).abs().max() <= 1e-4) & (k.min() >= -1e-4) & (k.max() <= n + 1e-4))
-        c = (key, ok)
+        # (the checked storage is kept alive with the verdict: a later `w.data = other` can then never land on the same address with a stale `ok`)
+        c = (key, ok, w.detach())
         module.__dict__["_mn_grid"] = c
     return c[1]
+
+
+def _forget_weight_grid(module, *args, **kwargs):
+    """load_state_dict pre-hook of the quantised layers: new stored weights, new verdict"""
+    module.__dict__.pop("_mn_grid", None)
 
 
 def _wdesc(module):
@@ -119,6 +129,7 @@ class QuantConv2d(nn.Conv2d):
         self.weight_quantizer = WeightQuantizer(w_bits=w_bits)
         self.in_shuffle_groups = 0     # > 1: this conv reads channel_shuffle(input, groups) (set by prepare(fold_shuffle=True))
         self.lazy_for_bn = False       # True (set by prepare(fuse_blocks=True)): a BatchNorm2dReLU of ours consumes the output -> it may stay un-computed
+        self._register_load_state_dict_pre_hook(_forget_weight_grid, with_module=True)          # (a module-level function: the module must stay picklable)
 
     def forward(self, input):
         from micronet_amd.sign_tensor import QActTensor

@@ -220,3 +220,13 @@ def test_prepared_resnet_pickles(scheme, kw):
     assert [type(a).__mro__[1:] for a in m.modules()] == [type(a).__mro__[1:] for a in m2.modules()]
     sd, sd2 = m.state_dict(), m2.state_dict()
     assert list(sd) == list(sd2) and all(torch.equal(sd[k], sd2[k]) for k in sd)
+
+
+def test_dorefa_weight_grid_verdict_is_forgotten_on_load_state_dict():
+    """the cached "stored weights lie on the quantizer grid" verdict of a quant_inference layer dies with a load_state_dict (new stored weights)."""
+    import importlib
+    Q = importlib.import_module("micronet.compression.quantization.wqaq.dorefa.quantize")
+    m = Q.QuantConv2d(4, 4, 3, a_bits=4, w_bits=4, quant_inference=True)
+    m.__dict__["_mn_grid"] = (("stale",), True, None)
+    m.load_state_dict(m.state_dict())
+    assert "_mn_grid" not in m.__dict__
