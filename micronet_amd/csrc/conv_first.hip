@@ -181,9 +181,9 @@ template <int MT>
 __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
-    uint16_t* im = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + p.xs_bytes);          // [3][64][C1B_LD]
+    uint16_t* im = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + p.xs_bytes);          // [3 terms][64][C1B_LD]
     int* ktab = reinterpret_cast<int*>(im + 3 * 64 * C1B_LD);                                      // [96] patch offset of im2col row k (-1: padding)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
     uint32_t b = blockIdx.x;
     const int strip = b % p.strips; b /= p.strips;
     const int n = b % p.N;
@@ -215,48 +215,56 @@ __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
             wa[2][ks][t] = u32x4{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3]), mn_pack_bf16x2(t2[4], t2[5]), mn_pack_bf16x2(t2[6], t2[7])};
         }
     __syncthreads();
+    // (this wave expands k = 24 wave .. 24 wave + 23 of every pixel; keeping the 24 wave-uniform patch offsets in scalar registers instead of re-reading the LDS table
+    //  spilled 59 SGPRs into an already full vector register file: the table read stays)
 
     float lo = INFINITY, hi = -INFINITY;
     int mnan = 0;
     const int npix = p.R * p.W, nchunks = (npix + 63) >> 6;
     const int irow = (lane & 3) * 16 + (lane >> 2);          // im2col tile row of the pixel this thread expands (pixel `lane` of the chunk)
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        // ---- expand: thread = (pixel lane, k quarter wave): 24 consecutive k
-        {
-            const int pix = chunk * 64 + lane;
-            const bool pv = pix < npix;
-            const uint32_t prow = fd_div(pv ? pix : 0, p.fd_w);
-            const int pcol = (pv ? pix : 0) - prow * p.W;
-            const float* src = xs + (int)prow * p.PW + pcol;
-            uint16_t* dst = im + irow * C1B_LD + wave * 24;
+    constexpr int TB = 3 * 64 * C1B_LD;                      // u16 per tile buffer
+    auto expand = [&](int chunk, int buf) {
+        const int pix = chunk * 64 + lane;
+        const bool pv = pix < npix;
+        const uint32_t prow = fd_div(pv ? pix : 0, p.fd_w);
+        const int pcol = (pv ? pix : 0) - prow * p.W;
+        const float* src = xs + (int)prow * p.PW + pcol;
+        uint16_t* dst = im + buf * TB + irow * C1B_LD + wave * 24;
 #pragma unroll
-            for (int o8 = 0; o8 < 3; ++o8) {
-                float t0[8], t1[8], t2[8];
+        for (int o8 = 0; o8 < 3; ++o8) {
+            float t0[8], t1[8], t2[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ko = ktab[wave * 24 + o8 * 8 + e];
-                    const float v = (pv && ko >= 0) ? src[ko] : 0.f;
-                    t0[e] = mn_bf16_head(v);
-                    const float r1 = v - t0[e];
-                    t1[e] = mn_bf16_head(r1);
-                    t2[e] = r1 - t1[e];
-                }
-                *reinterpret_cast<u32x4*>(dst + o8 * 8) = u32x4{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3]), mn_pack_bf16x2(t0[4], t0[5]), mn_pack_bf16x2(t0[6], t0[7])};
-                *reinterpret_cast<u32x4*>(dst + 64 * C1B_LD + o8 * 8) = u32x4{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3]), mn_pack_bf16x2(t1[4], t1[5]), mn_pack_bf16x2(t1[6], t1[7])};
-                *reinterpret_cast<u32x4*>(dst + 128 * C1B_LD + o8 * 8) = u32x4{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3]), mn_pack_bf16x2(t2[4], t2[5]), mn_pack_bf16x2(t2[6], t2[7])};
+            for (int e = 0; e < 8; ++e) {
+                const int kk = ktab[wave * 24 + o8 * 8 + e];
+                const float v = (pv && kk >= 0) ? src[kk < 0 ? 0 : kk] : 0.f;
+                t0[e] = mn_bf16_head(v);
+                const float r1 = v - t0[e];
+                t1[e] = mn_bf16_head(r1);
+                t2[e] = r1 - t1[e];
             }
+            *reinterpret_cast<u32x4*>(dst + o8 * 8) = u32x4{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3]), mn_pack_bf16x2(t0[4], t0[5]), mn_pack_bf16x2(t0[6], t0[7])};
+            *reinterpret_cast<u32x4*>(dst + 64 * C1B_LD + o8 * 8) = u32x4{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3]), mn_pack_bf16x2(t1[4], t1[5]), mn_pack_bf16x2(t1[6], t1[7])};
+            *reinterpret_cast<u32x4*>(dst + 128 * C1B_LD + o8 * 8) = u32x4{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3]), mn_pack_bf16x2(t2[4], t2[5]), mn_pack_bf16x2(t2[6], t2[7])};
         }
+    };
+    // (one tile buffer, two blocks per CU: the other block's MFMAs fill this block's expand phase.  A double-buffered tile with one block per CU -- the next
+    //  chunk expanded in program order before the current chunk's MFMAs -- measured 156 us against 113 us)
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = 0;
+        if (chunk) __syncthreads();          // the tile is consumed
+        expand(chunk, 0);
         __syncthreads();
         f32x4 acc[4][MT];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint16_t* tile = im + buf * TB;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint16_t* br = im + (q * 16 + j) * C1B_LD + ks * 32 + kg * 8;
+                const uint16_t* br = tile + (q * 16 + j) * C1B_LD + ks * 32 + kg * 8;
                 const u32x4 b0 = *reinterpret_cast<const u32x4*>(br), b1 = *reinterpret_cast<const u32x4*>(br + 64 * C1B_LD), b2 = *reinterpret_cast<const u32x4*>(br + 128 * C1B_LD);
                 // the six term products, smallest first; MT independent accumulators between two MFMAs on the same one
 #pragma unroll
@@ -272,7 +280,6 @@ __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) acc[q][t] = mn_mfma_bf16(wa[0][ks][t], b0, acc[q][t]);
             }
-        __syncthreads();          // the tile is consumed: the next chunk may be expanded
         // D[row = channel 4 kg + r][col j of n-tile q = pixel 4 j + q]: a float4 of 4 consecutive pixels per channel
         const int pix = chunk * 64 + 4 * j;
         if (pix < npix) {
