@@ -51,10 +51,15 @@ __global__ __launch_bounds__(256, 2) void k_bf_gram(const GramParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const int r0 = tid >> 4, qd = tid & 15;
     const int z = blockIdx.x % p.Z, g = blockIdx.x / p.Z;
+    // The Gram matrix is symmetric.  CW == 4 (the 128-channel groups of nin_gc: an 8 x 8 grid of 16 x 16 tiles): wave w owns tile rows w and 7 - w of the UPPER
+    // triangle -- (8 - w) + (w + 1) = 9 tiles instead of 16 --, the reduction mirrors the strictly upper tiles.  Other widths keep the 2 x 2 wave grid (the pairing
+    // does not balance on 4 x 4 / 6 x 6 grids); their lower tiles are computed and ignored.
+    constexpr bool SYM = CW == 4;
     const int wm = wave >> 1, wc = wave & 1;
+    const int nA = 8 - wave;                                  // SYM: tiles 0 .. nA - 1 lie in row `wave` (columns wave ..), the rest in row 7 - wave (columns 7 - wave ..)
     const int64_t HW = p.HW;
 
-    f32x4 acc[CW][CW];
+    f32x4 acc[CW][CW];          // SYM: acc[t / CW][t % CW], t < 9
 #pragma unroll
     for (int mi = 0; mi < CW; ++mi)
 #pragma unroll
@@ -127,6 +132,35 @@ __global__ __launch_bounds__(256, 2) void k_bf_gram(const GramParams p) {
 #pragma unroll
         for (int ksx = 0; ksx < 2; ++ksx) {
             const int ko = ksx * 32 + kg * 8;
+            if (SYM) {
+                // A fragments of the wave's two tile rows; the B fragment of every tile is read where its (run-time) column lives
+                u32x4 a0[3], a1[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    a0[t] = *reinterpret_cast<const u32x4*>(gt + (t * CP + wave * 16 + j) * BF_LDP + ko);
+                    a1[t] = *reinterpret_cast<const u32x4*>(gt + (t * CP + (7 - wave) * 16 + j) * BF_LDP + ko);
+                }
+                // three tiles at a time: three independent accumulators between two MFMAs on the same one (a dependent MFMA stalls the issue), 9 B fragments live
+#pragma unroll
+                for (int tg = 0; tg < 3; ++tg) {
+                    u32x4 bb[3][3], aa[3][3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int tl = tg * 3 + u;
+                        const bool first = tl < nA;                                    // wave-uniform
+                        const int col = first ? wave + tl : 7 - wave + (tl - nA);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            bb[u][t] = *reinterpret_cast<const u32x4*>(gt + (t * CP + col * 16 + j) * BF_LDP + ko);
+                            aa[u][t] = first ? a0[t] : a1[t];
+                        }
+                    }
+#define BF_GRAM_SYM(TA, TB) _Pragma("unroll") for (int u = 0; u < 3; ++u) { f32x4& c = acc[(tg * 3 + u) / CW][(tg * 3 + u) % CW]; c = mn_mfma_bf16(aa[u][TA], bb[u][TB], c); }
+                    BF_GRAM_SYM(0, 2) BF_GRAM_SYM(2, 0) BF_GRAM_SYM(1, 1) BF_GRAM_SYM(0, 1) BF_GRAM_SYM(1, 0) BF_GRAM_SYM(0, 0)
+#undef BF_GRAM_SYM
+                }
+                continue;
+            }
             u32x4 a[3][CW], b[3][CW];
 #pragma unroll
             for (int t = 0; t < 3; ++t)
@@ -158,7 +192,11 @@ __global__ __launch_bounds__(256, 2) void k_bf_gram(const GramParams p) {
     for (int mi = 0; mi < CW; ++mi)
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
-            const int mrow = (wm * CW + mi) * 16 + kg * 4, ccol = (wc * CW + ci) * 16 + j;
+            const int tl = mi * CW + ci;
+            if (SYM && tl >= 9) continue;
+            const int trow = SYM ? (tl < nA ? wave : 7 - wave) : wm * CW + mi;
+            const int tcol = SYM ? (tl < nA ? wave + tl : 7 - wave + (tl - nA)) : wc * CW + ci;
+            const int mrow = trow * 16 + kg * 4, ccol = tcol * 16 + j;
             // partial layout [segment of 64 tile floats][Z][64]: the reduction reads Z x 256 contiguous bytes per segment (a [Z][tile] layout made it gather
             // 256-byte pieces 128 KB apart: 0.8 TB/s)
 #pragma unroll
@@ -181,6 +219,10 @@ __global__ __launch_bounds__(256) void k_bf_gram_reduce(const float* __restrict_
     __shared__ double sm[16][16][4];
     const int q = threadIdx.x >> 4, l = threadIdx.x & 15;
     if ((int)blockIdx.x < nblk_w) {
+        // the block's 64 floats: row m of one group, columns cb .. cb + 63 = tile columns cb / 16 .. + 3; only tiles with tile row <= tile column were computed
+        const int64_t e0 = (int64_t)blockIdx.x * 64;
+        const int cb0 = (int)(e0 % CP), mrow = (int)((e0 / CP) % CP);
+        if ((mrow >> 4) > ((cb0 + 63) >> 4)) return;          // (block-uniform) every tile of this segment lies below the diagonal: its mirror image is written instead
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 4
         for (int z = q; z < Z; z += 16) {
@@ -198,7 +240,10 @@ __global__ __launch_bounds__(256) void k_bf_gram_reduce(const float* __restrict_
             const int c = (int)(ei % CP);
             const int64_t o = ei / CP;
             const int m = (int)(o % CP), gg = (int)(o / CP);
-            if (m < Cg && c < Cg) gram[((int64_t)gg * Cg + m) * Cg + c] = t;
+            if (m < Cg && c < Cg && (m >> 4) <= (c >> 4)) {
+                gram[((int64_t)gg * Cg + m) * Cg + c] = t;
+                if ((m >> 4) < (c >> 4)) gram[((int64_t)gg * Cg + c) * Cg + m] = t;          // the mirror image of a strictly upper tile (diagonal tiles hold both halves)
+            }
         }
     } else {
         // channel sums: 16 lanes per channel, each a strided z subset with four loads in flight, combined by a fixed-order butterfly (one thread per channel walking

@@ -2,17 +2,13 @@
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 O=gpurun_out/ab; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_kernels.py -q -k "first" 2>&1 | tail -3
-for v in new f32; do
-  [ $v = f32 ] && export MN_C1_F32=1
-  for w in c2 c3; do
-    python bench.py --only $w --no-pmc --no-cpu-baseline --repeats 3 --detail $O/${w}_${v}.json > $O/${w}_${v}.out 2> $O/${w}_${v}.err
-    python - $w $v <<'PY'
-import json, os, sys
-w, v = sys.argv[1], sys.argv[2]
-d = json.load(open("gpurun_out/ab/%s_%s.json" % (w, v)))["sections"][w]
-ks = {k: x for k, x in d["kernels"].items() if "c1" in k}
-print(w, v, d["value"], d["ms_per_step"], {k: x["avg_us"] for k, x in ks.items()})
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -k "iaobf" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_bnfuse_block.py -q 2>&1 | tail -2
+python bench.py --only c3 --no-pmc --no-cpu-baseline --repeats 3 --detail $O/c3.json > $O/c3.out 2> $O/c3.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/ab/c3.json"))["sections"]["c3"]
+print("c3", d["value"], d["ms_per_step"])
+for k, v in list(d["kernels"].items())[:8]:
+    print("   %-34s %7.3f ms/step %5.1f x %7.1f us" % (k[:34], v["ms_per_step"], v["launches_per_step"], v["avg_us"]))
 PY
-  done
-done
