@@ -199,6 +199,11 @@ int mn_iao_observe_partials_qparams(const float* mm, int64_t count, int obs_kind
 int mn_iao_qadd_observe(const float* res, const float* shortcut, int64_t n, int obs_kind, int first_res, int first_shortcut, double momentum, float* min_res,
                         float* max_res, float* min_shortcut, float* max_shortcut, float* min_out, float* max_out, int bits, int q_type, int update, float* scale,
                         float* zero_point, float* qp, float* ws, mn_stream_t stream);
+/* the same bookkeeping from the (min, max) partials the producers of res / shortcut left behind (mn_bn2d_fwd_mm, mn_bnrelu_fwd_mm, mn_iao_qadd_fwd_mm): ONE launch, neither
+ * tensor is read; bit-identical to mn_iao_qadd_observe (min / max are exact and order-free) */
+int mn_iao_qadd_observe_partials(const float* mm_res, int64_t count_res, const float* mm_shortcut, int64_t count_shortcut, int obs_kind, int first_res,
+                                 int first_shortcut, double momentum, float* min_res, float* max_res, float* min_shortcut, float* max_shortcut, float* min_out,
+                                 float* max_out, int bits, int q_type, int update, float* scale, float* zero_point, float* qp, mn_stream_t stream);
 int mn_iao_qadd_fwd(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, mn_stream_t stream);
 int mn_iao_qadd_bwd(const float* g, const float* res, const float* shortcut, float* dres, float* dshortcut, int64_t n, const float* qp, int bits, int q_type,
                     int relu, mn_stream_t stream);
@@ -357,6 +362,9 @@ int mn_bnrelu_fwd_mm(const float* y, int64_t N, int64_t C, int64_t HW, const flo
  * arguments as mn_bnrelu_fwd / _bwd. */
 int mn_bn2d_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                 int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream);
+/* ... + per-block (min, max) of the output, mm: 2 * mn_bnrelu_mm_count(N, C, HW) floats */
+int mn_bn2d_fwd_mm(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, int training,
+                   float* running_mean, float* running_var, float* save, float* a, float* ws, float* mm, mn_stream_t stream);
 int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                 int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 /* the two halves of mn_bnsign_bwd for a consumer that forms dy itself: mn_bnsign_bwd_sums = dgamma, dbeta and sums [2][C] =

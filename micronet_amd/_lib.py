@@ -142,6 +142,8 @@ PROTOTYPES = {
     "mn_bnrelu_mm_count": (_L, [_L, _L, _L]),
     "mn_bnrelu_fwd_mm": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mn_iao_qadd_observe": (_I, [_P, _P, _L, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "mn_iao_qadd_observe_partials": (_I, [_P, _L, _P, _L, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mn_bn2d_fwd_mm": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mn_iao_qadd_fwd": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, _P]),
     "mn_iao_qadd_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _P]),
     "mn_qd_packed_bytes": (_L, [_G]),

@@ -479,6 +479,12 @@ extern "C" int mn_bn2d_fwd(const float* y, int64_t N, int64_t C, int64_t HW, con
                            int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
     return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream, 2);
 }
+// ... + per-block min / max of the output (mm: 2 * mn_bnrelu_mm_count(N, C, HW) floats): the BatchNorms in front of an IAO QuantAdd, whose input observers then need no
+// pass of their own (mn_iao_qadd_observe_partials)
+extern "C" int mn_bn2d_fwd_mm(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                              int training, float* running_mean, float* running_var, float* save, float* a, float* ws, float* mm, mn_stream_t stream) {
+    return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream, 2, mm);
+}
 extern "C" int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                            int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
     return bnsign_bwd_impl(da, y, save, gamma, beta, N, C, HW, training, dy, dgamma, dbeta, ws, stream, 2);

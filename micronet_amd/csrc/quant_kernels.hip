@@ -1136,6 +1136,41 @@ extern "C" int mn_iao_qadd_observe(const float* res, const float* shortcut, int6
     MN_CHECK_LAUNCH("mn_iao_qadd_observe");
     return MN_OK;
 }
+// the same bookkeeping from the (min, max) partials the PRODUCERS of res / shortcut left (mm_x[0 .. count_x) minima, mm_x[count_x .. 2 count_x) maxima: mn_bn2d_fwd_mm,
+// mn_bnrelu_fwd_mm, mn_iao_qadd_fwd_mm): one launch, neither tensor is read.  min / max are exact and order-free: bit-identical to mn_iao_qadd_observe.
+__global__ __launch_bounds__(256) void k_qadd_final_p(const float* __restrict__ ma, int ca, const float* __restrict__ mb, int cb, const QaddFinal f) {
+    __shared__ float sc[16];
+    float la = INFINITY, ha = -INFINITY, lb = INFINITY, hb = -INFINITY;
+    for (int i = threadIdx.x; i < ca; i += 256) { la = OpMinF()(la, ma[i]); ha = OpMaxF()(ha, ma[ca + i]); }
+    for (int i = threadIdx.x; i < cb; i += 256) { lb = OpMinF()(lb, mb[i]); hb = OpMaxF()(hb, mb[cb + i]); }
+    la = block_reduce(la, OpMinF(), INFINITY, sc); ha = block_reduce(ha, OpMaxF(), -INFINITY, sc);
+    lb = block_reduce(lb, OpMinF(), INFINITY, sc); hb = block_reduce(hb, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) {
+        observer_update(f.obs_kind, f.first_a, f.momentum, la, ha, f.min_a, f.max_a);
+        observer_update(f.obs_kind, f.first_b, f.momentum, lb, hb, f.min_b, f.max_b);
+        const float mn = OpMinF()(*f.min_a, *f.min_b), mx = OpMaxF()(*f.max_a, *f.max_b);
+        *f.min_o = mn; *f.max_o = mx;
+        iao_qparams_row(mn, mx, f.q_type, f.quant_range, f.update, f.scale, f.zero_point, f.qp);
+    }
+}
+extern "C" int mn_iao_qadd_observe_partials(const float* mm_res, int64_t count_res, const float* mm_shortcut, int64_t count_shortcut, int obs_kind, int first_res,
+                                            int first_shortcut, double momentum, float* min_res, float* max_res, float* min_shortcut, float* max_shortcut,
+                                            float* min_out, float* max_out, int bits, int q_type, int update, float* scale, float* zero_point, float* qp,
+                                            mn_stream_t stream) {
+    if (!mm_res || !mm_shortcut || count_res <= 0 || count_shortcut <= 0 || count_res > (1 << 24) || count_shortcut > (1 << 24) || !min_res || !max_res ||
+        !min_shortcut || !max_shortcut || !min_out || !max_out || !scale || !zero_point || !qp || bits < 2 || bits > 24 || (obs_kind != 0 && obs_kind != 1) ||
+        (q_type != 0 && q_type != 1))
+        MN_FAIL(MN_EINVAL, "mn_iao_qadd_observe_partials: bad arguments");
+    const IaoRange r = iao_range(bits, q_type, 1);
+    QaddFinal f;
+    f.nb = 0; f.obs_kind = obs_kind; f.first_a = first_res; f.first_b = first_shortcut; f.q_type = q_type; f.update = update; f.momentum = momentum;
+    f.quant_range = (q_type == 0) ? (float)((double)(r.qmax - r.qmin) / 2.0) : (float)(r.qmax - r.qmin);
+    f.min_a = min_res; f.max_a = max_res; f.min_b = min_shortcut; f.max_b = max_shortcut; f.min_o = min_out; f.max_o = max_out;
+    f.scale = scale; f.zero_point = zero_point; f.qp = qp;
+    hipLaunchKernelGGL(k_qadd_final_p, dim3(1), dim3(256), 0, (hipStream_t)stream, mm_res, (int)count_res, mm_shortcut, (int)count_shortcut, f);
+    MN_CHECK_LAUNCH("mn_iao_qadd_observe_partials");
+    return MN_OK;
+}
 static int qadd_fwd_grid(int64_t n) { return mn_grid_for(n / 4, 256, 4096); }
 extern "C" int64_t mn_iao_qadd_mm_count(int64_t n) { return (n > 0 && n % 4 == 0) ? qadd_fwd_grid(n) : 0; }
 extern "C" int mn_iao_qadd_fwd_mm(const float* res, const float* shortcut, float* out, int64_t n, const float* qp, int bits, int q_type, int relu, float* mm, mn_stream_t stream);

@@ -432,6 +432,26 @@ def iao_qadd_observe(res, shortcut, obs_res, obs_sc, quantizer, update):
     return qp
 
 
+def _valid_minmax(t):
+    """(mm, count) the producer of ``t`` left on it (per-block minima / maxima of exactly this tensor), or None"""
+    mm = getattr(t, "_mn_minmax", None)
+    if mm is None or mm[2] != t._version or mm[0] is None or mm[1] <= 0:
+        return None
+    return mm[0], mm[1]
+
+
+def iao_qadd_observe_partials(pr, ps, obs_res, obs_sc, quantizer, update):
+    """``iao_qadd_observe`` from the producers' (min, max) partials: one launch, neither tensor is read."""
+    obs = quantizer.observer
+    dev = pr[0].device
+    qp = torch.empty((1, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device_of(pr[0]):
+        _call("mn_iao_qadd_observe_partials", _p(pr[0]), pr[1], _p(ps[0]), ps[1], obs_res._kind, int(obs_res.num_flag == 0), int(obs_sc.num_flag == 0),
+              float(getattr(obs_res, "momentum", 0.1)), _p(obs_res.min_val), _p(obs_res.max_val), _p(obs_sc.min_val), _p(obs_sc.max_val), _p(obs.min_val), _p(obs.max_val),
+              quantizer.bits, quantizer._q_type_static if update else quantizer.q_type, int(update), _p(quantizer.scale), _p(quantizer.zero_point), _p(qp), _s())
+    return qp
+
+
 class IaoQuantAdd(Function):
     """out = Q(res) + Q(shortcut) with one shared per-tensor quantizer (QuantAdd, wqaq/iao/quantize.py:1484-1498): one pass forward, one backward."""
 
@@ -1291,10 +1311,10 @@ class BNReLU(Function):
         save = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
         with torch.cuda.device_of(y):
-            if want_minmax and fn == "mn_bnrelu":
+            if want_minmax and fn in ("mn_bnrelu", "mn_bn2d"):
                 count = int(_lib_().mn_bnrelu_mm_count(N, Cc, HW))
                 mm = torch.empty(2 * count, dtype=torch.float32, device=y.device)
-                _call("mn_bnrelu_fwd_mm", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training), _p(running_mean),
+                _call(fn + "_fwd_mm", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training), _p(running_mean),
                       _p(running_var), _p(save), _p(a), _p(ws), _p(mm), _s())
                 _PENDING_MINMAX[0] = (mm, count)
             else:

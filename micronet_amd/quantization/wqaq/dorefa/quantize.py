@@ -250,6 +250,8 @@ class BatchNorm2dPlain(nn.BatchNorm2d):
     """``nn.BatchNorm2d`` (no activation behind it -- the BatchNorms in front of a residual add, models/resnet.py:21-29) on the streaming kernels of
     ``BatchNorm2dReLU`` instead of MIOpen's: same parameters, buffers and ``state_dict`` keys; anything the kernels do not cover runs the stock forward."""
 
+    emit_minmax = False     # (set by the IAO prepare) leave per-block (min, max) of the output for the observers of the QuantAdd that reads it
+
     def forward(self, input):
         from micronet_amd import ops
         use_batch = self.training or self.running_mean is None
@@ -259,6 +261,13 @@ class BatchNorm2dPlain(nn.BatchNorm2d):
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             if not self.__dict__.pop("_mn_nbt_pre", False):
                 self.num_batches_tracked.add_(1)
+        if self.emit_minmax and self.training:          # (set by the IAO prepare: an IAO QuantAdd observes this output)
+            out = ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                   self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d", True)
+            mm = ops.take_minmax()
+            if mm is not None:
+                out._mn_minmax = mm + (out._version,)
+            return out
         return ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                 self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d")
 

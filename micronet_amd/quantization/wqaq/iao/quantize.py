@@ -613,7 +613,11 @@ class QuantAdd(nn.Module):
             update = (not q.qaft) and q.training
             if update:
                 q.q_type = q._q_type_static
-            qp = ops.iao_qadd_observe(res, shortcut, obs_r, obs_s, q, update)
+            pr, ps = (ops._valid_minmax(res), ops._valid_minmax(shortcut)) if (_PRODUCER_MINMAX and self.training) else (None, None)
+            if pr is not None and ps is not None:          # both producers left (min, max) partials: the two input observers need no pass over the tensors
+                qp = ops.iao_qadd_observe_partials(pr, ps, obs_r, obs_s, q, update)
+            else:
+                qp = ops.iao_qadd_observe(res, shortcut, obs_r, obs_s, q, update)
             for o in (obs_r, obs_s):
                 if o.num_flag == 0:
                     o.num_flag += 1
@@ -745,6 +749,7 @@ def _fuse_residual_tails(model):
             for child in m.children():
                 if type(child) is nn.BatchNorm2d and child.affine and child.track_running_stats:
                     child.__class__ = BatchNorm2dPlain
+                    child.emit_minmax = _PRODUCER_MINMAX          # (an IAO QuantAdd observes this output: its two input observers then read partials only)
     for m in model.modules():
         t = type(m)
         if t.__name__ in ("BasicBlock", "BottleNeck") and t.__module__.split(".")[-1] == "resnet" and isinstance(getattr(m, "add", None), QuantAdd) \

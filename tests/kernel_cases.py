@@ -1341,6 +1341,30 @@ def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, Fa
     be.call("mn_iao_observe", be.ptr(y3), 1, n, 1, 0, 0.1, be.ptr(m1), be.ptr(M1), be.ptr(wso), be.stream)
     be.call("mn_iao_observe_partials", be.ptr(mm), cnt, 1, 0, 0.1, be.ptr(m2), be.ptr(M2), be.stream)
     assert np.array_equal(be.to_host(m1), be.to_host(m2)) and np.array_equal(be.to_host(M1), be.to_host(M2))
+    # ---- the same bookkeeping from producer partials: a as the output of mn_bn2d_fwd_mm (identity BatchNorm: eval statistics 0 / 1, gamma 1, beta 0, eps 0 -- the
+    # kernel stores y itself) and b as (min, max) partials made by hand in another block structure
+    if n % 64 == 0:
+        Cc, HW = 4, 16
+        Nn = n // (Cc * HW)
+        cnt_a = int(be.lib.mn_bnrelu_mm_count(Nn, Cc, HW))
+        assert cnt_a > 0
+        one, zero = be.to_dev(np.ones(Cc, dtype=F)), be.to_dev(np.zeros(Cc, dtype=F))
+        save, a_out, mm_a = be.empty(2 * Cc), be.empty(n), be.empty(2 * cnt_a)
+        wsb = be.empty(int(be.lib.mn_bnsign_ws_floats(Cc)))
+        be.call("mn_bn2d_fwd_mm", be.ptr(dA), Nn, Cc, HW, be.ptr(one), be.ptr(zero), 0.0, 0.1, 0, be.ptr(zero), be.ptr(one), be.ptr(save), be.ptr(a_out), be.ptr(wsb),
+                be.ptr(mm_a), be.stream)
+        assert np.array_equal(be.to_host(a_out), a)
+        nbk = 8
+        bb = b.reshape(nbk, -1)
+        mm_b = be.to_dev(np.concatenate([bb.min(axis=1), bb.max(axis=1)]).astype(F))
+        s3 = fresh()
+        qp3 = be.empty((1, 4))
+        be.call("mn_iao_qadd_observe_partials", be.ptr(mm_a), cnt_a, be.ptr(mm_b), nbk, obs_kind, int(first[0]), int(first[1]), mom, be.ptr(s3["min_a"]),
+                be.ptr(s3["max_a"]), be.ptr(s3["min_b"]), be.ptr(s3["max_b"]), be.ptr(s3["min_o"]), be.ptr(s3["max_o"]), bits, q_type, int(update), be.ptr(s3["scale"]),
+                be.ptr(s3["zp"]), be.ptr(qp3), be.stream)
+        for k in st0:
+            assert np.array_equal(be.to_host(s1[k]), be.to_host(s3[k])), ("partials", k)
+        assert np.array_equal(be.to_host(qp1), be.to_host(qp3)), "qp from partials"
     for k in st0:
         assert np.array_equal(be.to_host(s1[k]), be.to_host(s2[k])), k
     assert np.array_equal(be.to_host(qp1), be.to_host(qp2)), "qp"

@@ -311,3 +311,24 @@ def test_bench_workloads_never_fall_through_to_stock_operators(key):
     ops.fallback_counts(reset=True)
     train_step(model, opt, x, y)
     assert ops.fallback_counts() == {}, ops.fallback_counts()
+
+
+def test_iao_resnet_quantadd_observers_read_producer_partials():
+    """every QuantAdd of the IAO ResNet takes both input ranges from the (min, max) partials its producers left (BatchNorm apply pass, the previous block's
+    QuantAdd + ReLU, the stem's BatchNorm + ReLU): no pass over the two tensors (mn_iao_qadd_observe) in a training step"""
+    from micronet_amd import ops
+    from micronet_amd.train import build_model, make_optimizer, synth_batch, train_step
+    arch, scheme, kw, B, wd = CFG["c5_resnet18_iao_w4a4"]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    model = quantize.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+    opt = make_optimizer(model, 0.01, wd)
+    x, y = synth_batch(8, device="cuda")
+    calls = {"full": 0, "partials": 0}
+    real_full, real_part = ops.iao_qadd_observe, ops.iao_qadd_observe_partials
+    ops.iao_qadd_observe = lambda *a, **k: (calls.__setitem__("full", calls["full"] + 1), real_full(*a, **k))[1]
+    ops.iao_qadd_observe_partials = lambda *a, **k: (calls.__setitem__("partials", calls["partials"] + 1), real_part(*a, **k))[1]
+    try:
+        train_step(model, opt, x, y)
+    finally:
+        ops.iao_qadd_observe, ops.iao_qadd_observe_partials = real_full, real_part
+    assert calls == {"full": 0, "partials": 8}, calls

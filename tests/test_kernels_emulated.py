@@ -419,6 +419,7 @@ def test_iao_quant_add_fused(be, bits, q_type, obs_kind, first, update):
     K.check_iao_qadd(be, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=bits + q_type)
     K.check_iao_qadd(be, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=bits + q_type + 7, relu=True)
     K.check_iao_qadd(be, n=12, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=1)
+    K.check_iao_qadd(be, n=4096, bits=bits, q_type=q_type, obs_kind=obs_kind, first=first, update=update, seed=2)          # (+ the observers from producer partials)
 
 
 @pytest.mark.parametrize("bits,q_type,obs_kind", [(4, 0, 0), (8, 0, 1), (8, 1, 0)])
