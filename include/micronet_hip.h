@@ -445,8 +445,8 @@ int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq, const int
  * The block of the reference's DoReFa nets: `relu(bn(conv(x)))` (models/nin_gc.py:53-59) whose output only feeds the ActivationQuantizer of the next
  * QuantConv2d (wqaq/dorefa/quantize.py:36-46, 107-122), possibly through a 2x2 max-pool (models/nin_gc.py:88,119).  Input: activation codes j (uint8,
  * MN_ACTQ_CODE8); weights: DoReFa codes (wq->mode == MN_WQ_DOREFA, `w` = the fake-quantised fp32 weights).  The conv result y = alpha * acc + bias with
- * acc an EXACT integer is never written as fp32:
- *   mn_qconv_bnq_fwd_stash   conv on codes -> acc as a 16-bit stash [N][O][H][W] + exact batch statistics -> save [2][O] (mean, invstd), running
+ * acc an EXACT integer is never written as fp32 (a_bits_in 2 .. 8, wq->bits 2 .. 8):
+ *   mn_qconv_bnq_fwd_stash   conv on codes -> acc as a 16- / 32-bit stash (mn_qconv_bnq_stash_bits) [N][O][H][W] + exact batch statistics -> save [2][O] (mean, invstd), running
  *                            statistics / num_batches_tracked like nn.BatchNorm2d, chan [MN_QA_NCH][O] (the per-channel constants the streaming
  *                            kernels below read).  ws: mn_qconv_bnq_ws_bytes(g).
  *   mn_qa_fwd                stash (in_f32 == 0) or fp32 y (in_f32 == 1: the block behind the un-quantised first conv) -> a = relu(bn(y)) -> [2x2 max-pool]
@@ -464,9 +464,11 @@ int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in
 int64_t mn_qd_packed_bytes(const mn_conv_geom* g);
 int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, void* const* out_bwd, const int64_t* O, const int64_t* Cin, const int64_t* taps,
                      const float* const* wscale, const int32_t* wscale_stride, int32_t count, int w_bits, mn_stream_t stream);
-/* width of the stash mn_qconv_bnq_fwd_stash writes for this layer: 16, or 32 for a DENSE layer (groups == 1, C and O multiples of 64: the 3 x 3 stride 1 / 2 and
- * 1 x 1 stride 2 convolutions of the reference's ResNets, models/resnet.py:7-65) whose K * (2^a - 1) * (2^w - 1) exceeds 32767; 0 when unsupported.  A 32-bit stash is
- * passed through the same `stash` pointer and read by mn_qa_* / mn_qr_* with in_kind == 2.  Dense layers write [N][O][Ho][Wo] (stride 2: half the input size). */
+/* width of the stash mn_qconv_bnq_fwd_stash writes for this layer: 16, or 32 when K * (2^a - 1) * (2^w - 1) exceeds 32767 -- a DENSE layer (groups == 1, C and O
+ * multiples of 64: the 3 x 3 stride 1 / 2 and 1 x 1 stride 2 convolutions of the reference's ResNets, models/resnet.py:7-65) or a grouped / pointwise layer of
+ * nin_gc at more than 4 bits (W8A8, the reference's CPU configuration: wqaq/dorefa/main.py:135,189-190), and for every layer read through 8-bit activation codes;
+ * 0 when unsupported.  A 32-bit stash is passed through the same `stash` pointer (16-byte aligned) and read by mn_qa_* / mn_qr_* with in_kind == 2.  Dense layers
+ * write [N][O][Ho][Wo] (stride 2: half the input size).  The wide grouped kernels contract bf16 codes with fp32 accumulation: K * (2^a - 1) * (2^w - 1) < 2^24. */
 int mn_qconv_bnq_stash_bits(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in);
 int64_t mn_qconv_bnq_ws_bytes(const mn_conv_geom* g);
 int mn_qconv_bnq_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x_codes, int a_bits_in, const float* w, const float* bias, const float* gamma,
@@ -480,7 +482,7 @@ int mn_qa_supported(int64_t H, int64_t W, int pool);
 int64_t mn_qa_ws_floats(int64_t C);
 /* chan from the (mean, invstd) a BatchNorm over fp32 y saved (mn_bnrelu_fwd's `save`): the first block of a net */
 int mn_qa_chan_from_save(const float* save, const float* gamma, const float* beta, int64_t C, float* chan, mn_stream_t stream);
-/* in_f32: 0 = the int16 stash, 1 = fp32 y, 2 = the int32 stash of a dense layer (mn_qconv_bnq_stash_bits; no pooled variant) */
+/* in_f32: 0 = the int16 stash, 1 = fp32 y, 2 = the int32 stash (mn_qconv_bnq_stash_bits) */
 int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, uint8_t* codes, float* act_f32,
               mn_stream_t stream);
 int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, int quant,

@@ -230,7 +230,7 @@ static int make_pro(const mn_actq* aq, Pro* p, int need_bounds, const char* what
     }
     if (aq->mode == MN_ACTQ_SIGN8) { p->mode = MN_ACTQ_SIGN8; return MN_OK; }
     if (aq->mode == MN_ACTQ_CODE8) {
-        if (aq->bits < 2 || aq->bits > 7) MN_FAIL(MN_EINVAL, "%s: code8 bits=%d", what, aq->bits);
+        if (aq->bits < 2 || aq->bits > 8) MN_FAIL(MN_EINVAL, "%s: code8 bits=%d", what, aq->bits);
         p->mode = MN_ACTQ_CODE8; p->s = dorefa_scale(aq->bits);
         return MN_OK;
     }

@@ -674,7 +674,7 @@ extern "C" int mn_signconv1x1_small_fwd(const int8_t* a, const float* w, const f
 }
 extern "C" int mn_codeconv1x1_small_fwd(const uint8_t* codes, int a_bits, const float* w, const float* bias, float* y, int64_t N, int64_t C, int64_t HW, int64_t O,
                                         mn_stream_t stream) {
-    if (a_bits < 2 || a_bits > 7) MN_FAIL(MN_EINVAL, "mn_codeconv1x1_small_fwd: 2 ... 7 bit codes");
+    if (a_bits < 2 || a_bits > 8) MN_FAIL(MN_EINVAL, "mn_codeconv1x1_small_fwd: 2 ... 8 bit codes");
     return sconv_fwd(codes, 1, dorefa_scale(a_bits), w, bias, y, N, C, HW, O, stream, "mn_codeconv1x1_small_fwd");
 }
 extern "C" int mn_conv1x1_small_bwd_data(const float* gy, const float* w, float* dx, int64_t N, int64_t C, int64_t HW, int64_t O, mn_stream_t stream) {

@@ -61,7 +61,7 @@ __device__ __forceinline__ void qa_load8(const void* __restrict__ in, int64_t of
     if (IN == 1) {
         const float4 a = *reinterpret_cast<const float4*>((const float*)in + off), b = *reinterpret_cast<const float4*>((const float*)in + off + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else if (IN == 2) {          // 32-bit stash of a dense layer (|acc| < 2^24: exact in fp32)
+    } else if (IN == 2) {          // 32-bit stash (dense layers; the wide grouped blocks: 8-bit codes) -- |acc| < 2^24: exact in fp32
         const u32x4 a = *reinterpret_cast<const u32x4*>((const int32_t*)in + off), b = *reinterpret_cast<const u32x4*>((const int32_t*)in + off + 4);
 #pragma unroll
         for (int d = 0; d < 4; ++d) { v[d] = (float)(int)a[d]; v[4 + d] = (float)(int)b[d]; }
@@ -408,7 +408,7 @@ extern "C" int mn_qa_chan_from_save(const float* save, const float* gamma, const
     return MN_OK;
 }
 #define QA_DISPATCH(KERNEL, ...)                                                                                         \
-    if (in_f32 == 2) { hipLaunchKernelGGL((KERNEL<2, 0>), __VA_ARGS__); }                                                \
+    if (in_f32 == 2) { if (pool) hipLaunchKernelGGL((KERNEL<2, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<2, 0>), __VA_ARGS__); } \
     else if (in_f32) { if (pool) hipLaunchKernelGGL((KERNEL<1, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<1, 0>), __VA_ARGS__); } \
     else { if (pool) hipLaunchKernelGGL((KERNEL<0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<0, 0>), __VA_ARGS__); }
 extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, uint8_t* codes, float* act_f32,
@@ -419,7 +419,6 @@ extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t 
     if (!in || !chan || (!codes && !act_f32) || (((uintptr_t)in) & 15) || (codes && (((uintptr_t)codes) & 7)) || (act_f32 && !aligned16(act_f32)))
         MN_FAIL(MN_EINVAL, "mn_qa_fwd: null / misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
-    if (in_f32 == 2 && pool) MN_FAIL(MN_ENOTSUP, "mn_qa_fwd: the 32-bit stash (dense layers) has no pooled variant");
     if (!in_f32 && codes && a_bits <= 3 && !MN_ENV("MN_QA_NO_THRESHOLDS")) g.nthr = (1 << a_bits) - 1;       // integer-threshold forward (A/B knob)
     const dim3 grid((unsigned)C, (unsigned)qa_split(g));
     const double nel = (double)N * C * H * W;
@@ -427,8 +426,8 @@ extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t 
     mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + (codes ? 1.0 : 0.0) * nel / (pool ? 4.0 : 1.0) + (act_f32 ? 4.0 : 0.0) * nel / (pool ? 4.0 : 1.0));
     mn_prof_begin(s);
     if (in_f32 == 2) {
-        if (codes) hipLaunchKernelGGL((k_qa_fwd<2, 0, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr);
-        if (act_f32) hipLaunchKernelGGL((k_qa_fwd<2, 0, 1>), grid, dim3(256), 0, s, g, in, chan, (unsigned char*)nullptr, act_f32);
+        if (codes) { if (pool) hipLaunchKernelGGL((k_qa_fwd<2, 1, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); else hipLaunchKernelGGL((k_qa_fwd<2, 0, 0>), grid, dim3(256), 0, s, g, in, chan, codes, (float*)nullptr); }
+        if (act_f32) { if (pool) hipLaunchKernelGGL((k_qa_fwd<2, 1, 1>), grid, dim3(256), 0, s, g, in, chan, (unsigned char*)nullptr, act_f32); else hipLaunchKernelGGL((k_qa_fwd<2, 0, 1>), grid, dim3(256), 0, s, g, in, chan, (unsigned char*)nullptr, act_f32); }
         mn_prof_end(s);
         MN_CHECK_LAUNCH("mn_qa_fwd");
         return MN_OK;
@@ -450,7 +449,6 @@ extern "C" int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, con
     QaGeom g;
     int rc = qa_geom(&g, N, C, H, W, a_bits, pool, "mn_qa_bwd_sums");
     if (rc) return rc;
-    if (in_f32 == 2 && pool) MN_FAIL(MN_ENOTSUP, "mn_qa_bwd_sums: the 32-bit stash (dense layers) has no pooled variant");
     if (!in || !chan || !dq || !sums || !ws || (((uintptr_t)in) & 15) || !aligned16(dq) || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_qa_bwd_sums: null / misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
     const int S = qa_split(g);
@@ -470,7 +468,6 @@ extern "C" int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, co
     QaGeom g;
     int rc = qa_geom(&g, N, C, H, W, a_bits, pool, "mn_qa_bwd_apply");
     if (rc) return rc;
-    if (in_f32 == 2 && pool) MN_FAIL(MN_ENOTSUP, "mn_qa_bwd_apply: the 32-bit stash (dense layers) has no pooled variant");
     if (!in || !chan || !dq || !sums || !dy || (((uintptr_t)in) & 15) || !aligned16(dq) || !aligned16(dy)) MN_FAIL(MN_EINVAL, "mn_qa_bwd_apply: null / misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)C, (unsigned)qa_split(g));

@@ -110,10 +110,10 @@ int k3s_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const 
 int k3s_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 // the k-bit activation-code (MN_ACTQ_CODE8) variants of the staged-image kernels (qgemm_k3s.hip, qgemm_sign.hip) and the stats / constants launch of qact_kernels.hip
 int k3s_wgrad_code8_supported(const mn_conv_geom* g, int a_bits);
-int k3s_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+int k3s_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, int a_bits, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int k3s_fwd16_supported(const mn_conv_geom* g, const mn_wq* wq);
 int k3s_fwd16_parts(const mn_conv_geom* g, const mn_wq* wq);
-int k3s_fwd_h16(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, const float* w, int16_t* h16, double* part, hipStream_t s);
+int k3s_fwd_h16(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, const float* w, int16_t* h16, int wide, double* part, hipStream_t s);
 int pws_wgrad_code8_supported(const mn_conv_geom* g);
 int pws_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 void qa_launch_stats_prep(const double* part, int CB, int G, int Mpad, int Mr, const float* rowscale, float ascale, const float* bias, double n, float eps,

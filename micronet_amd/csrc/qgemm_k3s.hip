@@ -41,6 +41,8 @@ struct K3wParams {
 // XENC 1: x holds k-bit activation codes j <= 7 (a_bits <= 3): the patch keeps the raw bytes (0 = the zero padding = code 0) and the B fragment is
 // built by byte look-up -- v_perm with the CODES as the selector into an 8-entry table of bf16 bit patterns (high / low byte), then two
 // v_perm to interleave: exact bf16 j, 8 VALU per fragment dword pair instead of 2.  The reduction multiplies by the quantizer's scale.
+// XENC 2: codes j <= 255 (a_bits 4 .. 8): same patch of raw bytes, the fragment is bf16 j = the high half of (float)j (v_cvt_f32_ubyte x 4 + 2 v_perm per
+// shifted dword).
 template <int XENC>
 __global__ __launch_bounds__(256, 2) void k_k3s_wgrad(const K3wParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -171,6 +173,9 @@ __global__ __launch_bounds__(256, 2) void k_k3s_wgrad(const K3wParams p) {
                 const uint32_t ub = s_ == 0 ? mn_alignbyte(bc, bp, 3) : (s_ == 1 ? bc : mn_alignbyte(bn, bc, 1));
                 if (XENC == 0) {
                     bf[s_] = u32x4{mn_perm(0u, ua, 0x010c000cu), mn_perm(0u, ua, 0x030c020cu), mn_perm(0u, ub, 0x010c000cu), mn_perm(0u, ub, 0x030c020cu)};
+                } else if (XENC == 2) {
+                    bf[s_] = u32x4{mn_pack_hi16((float)(ua & 0xffu), (float)((ua >> 8) & 0xffu)), mn_pack_hi16((float)((ua >> 16) & 0xffu), (float)(ua >> 24)),
+                                   mn_pack_hi16((float)(ub & 0xffu), (float)((ub >> 8) & 0xffu)), mn_pack_hi16((float)((ub >> 16) & 0xffu), (float)(ub >> 24))};
                 } else {          // bf16(j), j = 0..7: 0000 3F80 4000 4040 4080 40A0 40C0 40E0
                     const uint32_t ha = mn_perm(0x40404040u, 0x40403F00u, ua), la = mn_perm(0xE0C0A080u, 0x40008000u, ua);
                     const uint32_t hb = mn_perm(0x40404040u, 0x40403F00u, ub), lb = mn_perm(0xE0C0A080u, 0x40008000u, ub);
@@ -292,19 +297,25 @@ int k3s_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, floa
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(sign 3x3)");
     return MN_OK;
 }
-// 3 x 3 backward-weight on k-bit activation codes (bytes, a_bits <= 3): dw = s * sum gy * j
-int k3s_wgrad_code8_supported(const mn_conv_geom* g, int a_bits) { K3wPlan pl; return a_bits >= 2 && a_bits <= 3 && plan_k3s(g, &pl); }
-int k3s_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+// 3 x 3 backward-weight on k-bit activation codes (bytes): dw = s * sum gy * j;  a_bits <= 3: the 8-entry look-up (XENC 1), else the conversion (XENC 2)
+int k3s_wgrad_code8_supported(const mn_conv_geom* g, int a_bits) { K3wPlan pl; return a_bits >= 2 && a_bits <= 8 && plan_k3s(g, &pl); }
+int k3s_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* x, int a_bits, float ascale, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
     K3wPlan pl;
     if (!plan_k3s(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8 3x3): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(code8 3x3): workspace too small");
     K3wParams& p = pl.p;
     p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
-    mn_set_last_kernel("k_k3s_wgrad<1>");
+    const bool lut = a_bits <= 3;
+    mn_set_last_kernel(lut ? "k_k3s_wgrad<1>" : "k_k3s_wgrad<2>");
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + nx); }
     mn_prof_begin(s);
-    raise_lds_limit((const void*)k_k3s_wgrad<1>, pl.lds);
-    hipLaunchKernelGGL(k_k3s_wgrad<1>, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    if (lut) {
+        raise_lds_limit((const void*)k_k3s_wgrad<1>, pl.lds);
+        hipLaunchKernelGGL(k_k3s_wgrad<1>, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    } else {
+        raise_lds_limit((const void*)k_k3s_wgrad<2>, pl.lds);
+        hipLaunchKernelGGL(k_k3s_wgrad<2>, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    }
     mn_prof_end(s);
     qg_launch_wgrad_reduce(p.part, p.dbpart, dw, dbias, p.Z, p.G, p.Mg, p.Cg * 9, p.Mgw, p.Cgw * 9, ascale, nullptr, s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(code8 3x3)");
@@ -584,6 +595,7 @@ struct K3fParams {
     const float* nnz9;        // [9][O]
     unsigned char* h;
     int16_t* h16;             // XENC 1: the 16-bit stash of acc
+    int32_t* h32;             // XENC 2: the 32-bit stash of acc
     float wn;                 // XENC 1: DoReFa weights (2k - n) / n: the integer code is rint(w * wn), wn = 2^w_bits - 1
     double* part;             // [Zb][G*Mg][2]
     int N, C, H, W, O, Cg, Mg, G, Zb;
@@ -594,7 +606,8 @@ struct K3fParams {
 
 // XENC 0: sign codes x ternary weights -> byte stash h (above).  XENC 1: k-bit activation codes j in [0, 127] x DoReFa weight codes: the LDS image
 // holds bf16 128 + j (the frame and the padding slots hold 128 = code 0), acc' - 128 * sum of the row's weight codes is the exact integer acc,
-// stored as int16; statistics in 64-bit integers.
+// stored as int16; statistics in 64-bit integers.  XENC 2: codes j in [0, 255] (or an accumulator beyond int16): the image holds bf16 j itself (the
+// staging threads convert: v_cvt_f32_ubyte, high half), frame and padding are 0, no row constant, |acc| < 2^24 (planner) leaves as a 32-bit stash.
 template <int XENC>
 __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
             zn[mt].v0 = p.nnz9[co]; zn[mt].v1 = p.nnz9[p.O + co]; zn[mt].v2 = p.nnz9[2 * p.O + co]; zn[mt].v3 = p.nnz9[3 * p.O + co];
             zn[mt].v4 = p.nnz9[4 * p.O + co]; zn[mt].v5 = p.nnz9[5 * p.O + co]; zn[mt].v6 = p.nnz9[6 * p.O + co]; zn[mt].v7 = p.nnz9[7 * p.O + co];
             zn[mt].v8 = p.nnz9[8 * p.O + co];
-        } else if (m < p.Mg) {
+        } else if (XENC == 1 && m < p.Mg) {
             float sm = 0.f;
             for (int i = 0; i < wrow; ++i) sm += rintf(wl[m * wrow + i] * p.wn);
             wsum[mt] = 128.f * sm;
@@ -643,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
     }
     __syncthreads();
     {
-        const uint32_t fill = XENC ? 0x43004300u : 0u;          // code 0 (the zero padding) is bf16 128 under XENC 1
+        const uint32_t fill = XENC == 1 ? 0x43004300u : 0u;          // code 0 (the zero padding) is bf16 128 under XENC 1
         for (int i = tid; i < p.TS / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{fill, fill, fill, fill};
     }
     // tap offset (bytes) of this lane's half of every K-step; tap 9 (the padding half of the last step) reads tap 8's slot against zero weights
@@ -696,6 +709,13 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
                 const uint32_t se = 0x000c000cu | ((uint32_t)e << 8) | ((uint32_t)(4 + e) << 24);      // [0, b.byte e, 0, a.byte e]
                 *reinterpret_cast<u32x2*>(lds + s_slot + e * K3F_RS) = u32x2{mn_perm(en[1], en[0], se), mn_perm(en[3], en[2], se)};
             }
+        } else if (XENC == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) en[i] = s_cv[i] ? rg[i] : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)          // slot of pixel e: channels sr, sr + 4 | sr + 8, sr + 12 as bf16 j
+                *reinterpret_cast<u32x2*>(lds + s_slot + e * K3F_RS) = u32x2{mn_pack_hi16((float)((en[0] >> (8 * e)) & 0xffu), (float)((en[1] >> (8 * e)) & 0xffu)),
+                                                                             mn_pack_hi16((float)((en[2] >> (8 * e)) & 0xffu), (float)((en[3] >> (8 * e)) & 0xffu))};
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) en[i] = s_cv[i] ? rg[i] : 0u;
@@ -771,7 +791,8 @@ __global__ __launch_bounds__(256, 2) void k_k3s_fwd(const K3fParams p) {
                                 ai[rr] = (int)(acc[pt][mt][rr] - wsum[mt]);
                                 s1[mt] += ai[rr]; s2[mt] += (long long)ai[rr] * ai[rr];
                             }
-                            *reinterpret_cast<u32x2*>(p.h16 + ((int64_t)n * p.O + g * p.Mg + m) * p.HW + pp) =
+                            if (XENC == 2) *reinterpret_cast<u32x4*>(p.h32 + ((int64_t)n * p.O + g * p.Mg + m) * p.HW + pp) = u32x4{(uint32_t)ai[0], (uint32_t)ai[1], (uint32_t)ai[2], (uint32_t)ai[3]};
+                            else *reinterpret_cast<u32x2*>(p.h16 + ((int64_t)n * p.O + g * p.Mg + m) * p.HW + pp) =
                                 u32x2{((uint32_t)ai[0] & 0xffffu) | ((uint32_t)ai[1] << 16), ((uint32_t)ai[2] & 0xffffu) | ((uint32_t)ai[3] << 16)};
                         }
                     }
@@ -841,7 +862,7 @@ int k3s_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const fl
     K3fPlan pl;
     if (!plan_k3f(g, wq, &pl) || (((uintptr_t)x) & 3) || (((uintptr_t)h) & 3) || !w || !nnz9 || !part) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd_stash(3x3): geometry not covered");
     K3fParams& p = pl.p;
-    p.x = (const char*)x; p.w = w; p.nnz9 = nnz9; p.h = h; p.h16 = nullptr; p.wn = 1.f; p.part = part;
+    p.x = (const char*)x; p.w = w; p.nnz9 = nnz9; p.h = h; p.h16 = nullptr; p.h32 = nullptr; p.wn = 1.f; p.part = part;
     mn_set_last_kernel("k_k3s_fwd");
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(nx + ny); }
     mn_prof_begin(s);
@@ -854,16 +875,22 @@ int k3s_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const fl
 // the same 3 x 3 forward on k-bit activation codes x DoReFa weights, writing the 16-bit stash of acc + the statistics partials
 int k3s_fwd16_supported(const mn_conv_geom* g, const mn_wq* wq) { K3fPlan pl; return plan_k3f(g, wq, &pl, 1) && pl.lds >= 4 * 2 * 16 * 2 * 8; }
 int k3s_fwd16_parts(const mn_conv_geom* g, const mn_wq* wq) { K3fPlan pl; return plan_k3f(g, wq, &pl, 1) ? pl.p.Zb : 0; }
-int k3s_fwd_h16(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, const float* w, int16_t* h16, double* part, hipStream_t s) {
+int k3s_fwd_h16(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, const float* w, int16_t* h16, int wide, double* part, hipStream_t s) {
     K3fPlan pl;
-    if (!plan_k3f(g, wq, &pl, 1) || (((uintptr_t)x) & 3) || (((uintptr_t)h16) & 7) || !w || !part) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnq_fwd_stash(3x3): geometry not covered");
+    if (!plan_k3f(g, wq, &pl, 1) || (((uintptr_t)x) & 3) || (((uintptr_t)h16) & (wide ? 15 : 7)) || !w || !part) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnq_fwd_stash(3x3): geometry not covered");
     K3fParams& p = pl.p;
-    p.x = (const char*)x; p.w = w; p.nnz9 = nullptr; p.h = nullptr; p.h16 = h16; p.part = part; p.wn = (float)((1ll << wq->bits) - 1);
-    mn_set_last_kernel("k_k3s_fwd<1>");
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(nx + 2.0 * ny); }
+    p.x = (const char*)x; p.w = w; p.nnz9 = nullptr; p.h = nullptr; p.h16 = wide ? nullptr : h16; p.h32 = wide ? reinterpret_cast<int32_t*>(h16) : nullptr; p.part = part;
+    p.wn = (float)((1ll << wq->bits) - 1);
+    mn_set_last_kernel(wide ? "k_k3s_fwd<2>" : "k_k3s_fwd<1>");
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(nx + (wide ? 4.0 : 2.0) * ny); }
     mn_prof_begin(s);
-    raise_lds_limit((const void*)k_k3s_fwd<1>, pl.lds);
-    hipLaunchKernelGGL(k_k3s_fwd<1>, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    if (wide) {
+        raise_lds_limit((const void*)k_k3s_fwd<2>, pl.lds);
+        hipLaunchKernelGGL(k_k3s_fwd<2>, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    } else {
+        raise_lds_limit((const void*)k_k3s_fwd<1>, pl.lds);
+        hipLaunchKernelGGL(k_k3s_fwd<1>, dim3(pl.grid), dim3(256), pl.lds, s, p);
+    }
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash(3x3)");
     return MN_OK;

@@ -980,7 +980,7 @@ int qg_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int 
     if (!pw_geom_ok(g)) return kk_supported(g, aq, wq, which);
     if (which == 0) { PwPlan pl; return wq_codeable(wq) && aq_codeable(aq, 0) && plan_pw(g, 0, aq ? aq->mode : MN_ACTQ_NONE, &pl); }
     if (which == 1) { PwPlan pl; return wq_codeable(wq) && plan_pw(g, 1, MN_ACTQ_NONE, &pl); }
-    if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) { WgPlan pl; return aq->bits >= 2 && aq->bits <= 7 && (pws_wgrad_code8_supported(g) || plan_pw_wgrad(g, &pl)); }
+    if (which == 2 && aq && aq->mode == MN_ACTQ_CODE8) { WgPlan pl; return aq->bits >= 2 && aq->bits <= 8 && (pws_wgrad_code8_supported(g) || plan_pw_wgrad(g, &pl)); }
     if (which == 2) { WgPlan pl; return aq_codeable(aq, 1) && plan_pw_wgrad(g, &pl); }
     return 0;
 }
@@ -1124,7 +1124,7 @@ int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
         return pws_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // sign codes: fragments straight from global memory
     const int code8 = aq && aq->mode == MN_ACTQ_CODE8;
     if (code8) {        // k-bit activation codes: the LDS-staged kernel, or (small tiles: the classifier conv) the generic kernel reading bytes
-        if (aq->bits < 2 || aq->bits > 7) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): 2 ... 7 bit codes");
+        if (aq->bits < 2 || aq->bits > 8) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): 2 ... 8 bit codes");
         if (pws_wgrad_code8_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g))
             return pws_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);
     }

@@ -859,7 +859,7 @@ int kk_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
         return qd_iao_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
     if (aq && aq->mode == MN_ACTQ_CODE8) {        // k-bit activation codes: only the wave-private 3x3 kernel reads them
         if (!k3s_wgrad_code8_supported(g, aq->bits) || ws_bytes < k3s_wgrad_ws_bytes(g)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(code8): geometry / bits not covered");
-        return k3s_bwd_weight_code8(g, gy, (const uint8_t*)x, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);
+        return k3s_bwd_weight_code8(g, gy, (const uint8_t*)x, aq->bits, dorefa_scale(aq->bits), dw, dbias, ws, ws_bytes, s);
     }
     KwPlan pl;
     if (!aq_codeable(aq, 1) || !plan_kk_wgrad(g, &pl) || !aligned16(gy) || !aligned16(x))

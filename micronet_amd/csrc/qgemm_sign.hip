@@ -47,6 +47,7 @@ struct PwsParams {
     float* y;                 // PWS_Y: y     PWS_BWD_APPLY: dy        [N][Cout_total][HW]
     char* a8;                 // PWS_SIGN8 output
     int16_t* h16;             // XENC 1 (k-bit activation codes), PWS_STATS: the conv result acc as a 16-bit stash (qact_kernels.hip)
+    int32_t* h32;             // XENC 2 (8-bit-wide codes / accumulators beyond int16), PWS_STATS: acc as a 32-bit stash
     unsigned char* h8;        // PWS_SIGN8, optional: h = (acc + nnz[o]) / 2 in [0, 128] -- the conv result in one byte (acc has the parity
                               // of nnz[o], the number of non-zero weight codes of the channel); the streaming BN backward reads it
     float* part;              // PWS_STATS / PWS_BWD_PART: [CB][G*Mpad][2]
@@ -69,6 +70,10 @@ struct PwsParams {
 // XENC 0: x holds int8 sign codes (+-1).  XENC 1: x holds k-bit activation codes j in [0, 127] as bytes (the DoReFa / IAO activation quantizer's
 // integer, wqaq/dorefa/quantize.py:43-45): the B fragments are built as bf16 128 + j (high byte 0x43, low byte j: one v_perm + one v_or per
 // fragment dword), every product and sum stays an exact integer, and the epilogue subtracts 128 * sum_k code_w[o][k] (c2 = that row constant).
+// XENC 2: codes j in [0, 255] (W8A8, the configuration of the reference's CPU run; also any width whose accumulator leaves int16): the B fragments are
+// bf16 j itself (v_cvt_f32_ubyte + one v_perm per fragment dword: every integer <= 255 is a bf16), no offset and no row constant; |acc| <= K * 255 * 255
+// < 2^24 (planner) stays exact in the fp32 accumulators and leaves as a 32-bit stash.  Statistics: fp32 per lane (a few hundred terms: ~1e-7 relative; an
+// int32 sum of acc made the register allocator spill 93 VGPRs at NT = 4), fp64 from the block partial on.
 template <int NT, int KS, int EPI, int XENC = 0>
 __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -273,6 +278,15 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                     bq[2][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x060c020cu);
                     bq[3][d] = mn_perm(en[2 * d + 1], en[2 * d], 0x070c030cu);
                 }
+            } else if (XENC == 2) {          // bf16 j, j <= 255: the float's high half
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t lo = cur[s * 8 + 2 * d], hi = cur[s * 8 + 2 * d + 1];
+                    bq[0][d] = mn_pack_hi16((float)(lo & 0xffu), (float)(hi & 0xffu));
+                    bq[1][d] = mn_pack_hi16((float)((lo >> 8) & 0xffu), (float)((hi >> 8) & 0xffu));
+                    bq[2][d] = mn_pack_hi16((float)((lo >> 16) & 0xffu), (float)((hi >> 16) & 0xffu));
+                    bq[3][d] = mn_pack_hi16((float)(lo >> 24), (float)(hi >> 24));
+                }
             } else {          // bf16 (128 + j): low byte = the code, high byte 0x43
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -313,6 +327,14 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                     const float xc = XENC == 1 ? rcv[r] : 0.f;
                     const float o[4] = {acc[0][t][r] - xc, acc[1][t][r] - xc, acc[2][t][r] - xc, acc[3][t][r] - xc};
                     const uint32_t off = obase + (uint32_t)(t * 16 + r) * HW;
+                    if (XENC == 2) {
+                        const int oi[4] = {(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+                        s1[t][r] += (o[0] + o[1]) + (o[2] + o[3]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s2[t][r] = fmaf(o[e], o[e], s2[t][r]);
+                        if (p.h32) *reinterpret_cast<u32x4*>(p.h32 + off) = u32x4{(uint32_t)oi[0], (uint32_t)oi[1], (uint32_t)oi[2], (uint32_t)oi[3]};
+                        continue;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s1[t][r] += o[e]; s2[t][r] = fmaf(o[e], o[e], s2[t][r]); }
                     if (XENC == 1) {
@@ -342,7 +364,13 @@ __global__ __launch_bounds__(256, 2) void k_pws(const PwsParams p) {
                     // This epilogue was 60 % of the kernel's cycles (stamps: 2300 per chunk in the K loop, 4100 here): ~40 VALU per (tile, row) in
                     // float -> integer conversions, shifts and unfused multiply-adds.  Integers reach the stash through the float's own mantissa
                     // instead (v + 1.5 * 2^23 holds v in two's complement in its low bits: exact for |v| < 2^22) and one v_perm packs the bytes.
-                    if (ok) {
+                    if (ok && XENC == 2) {
+                        const int oi[4] = {(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+                        s1[t][r] += (o[0] + o[1]) + (o[2] + o[3]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s2[t][r] = fmaf(o[e], o[e], s2[t][r]);
+                        if (p.h32) *reinterpret_cast<u32x4*>(p.h32 + off) = u32x4{(uint32_t)oi[0], (uint32_t)oi[1], (uint32_t)oi[2], (uint32_t)oi[3]};
+                    } else if (ok) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { s1[t][r] += o[e]; s2[t][r] = fmaf(o[e], o[e], s2[t][r]); }      // exact: integers below 2^24 (fused or not)
                         if (XENC == 1) {
@@ -1342,7 +1370,7 @@ static int pws_prepare(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, 
     p.x = (const char*)x; p.wc = pl->pk.codes; p.rowscale = pl->pk.scale_out;
     p.part = (float*)((char*)ws + pl->off_part);
     p.chan = (const float*)((char*)ws + pl->off_chan);
-    p.y = nullptr; p.a8 = nullptr; p.h8 = nullptr; p.h16 = nullptr; p.ascale = 1.f; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr; p.own = nullptr;
+    p.y = nullptr; p.a8 = nullptr; p.h8 = nullptr; p.h16 = nullptr; p.h32 = nullptr; p.ascale = 1.f; p.da = nullptr; p.sums = nullptr; p.training = 1; p.bias = nullptr; p.own = nullptr;
     p.W = g->W; p.fd_w = make_fastdiv((uint32_t)g->W);
     return MN_OK;
 }
@@ -1686,14 +1714,18 @@ extern "C" int mn_qconv_bnsign_bwd_pooled(const mn_conv_geom* g, const mn_wq* wq
 // conv + BatchNorm2d + ReLU + next-layer k-bit quantizer (DoReFa blocks): the forward on activation codes that leaves the 16-bit stash of acc,
 // the exact batch statistics and the per-channel constants of qact_kernels.hip.  Pointwise: k_pws<.., PWS_STATS, XENC 1>; 3 x 3: k_k3s_fwd<1>.
 static int bnq_amax(int a_bits) { return (1 << a_bits) - 1; }
-static int bnq_int16_ok(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
+static int64_t bnq_accmax(const mn_conv_geom* g, const mn_wq* wq, int a_bits) {
     const int64_t K = (int64_t)(g->C / g->groups) * g->KH * g->KW, wmax = (1ll << wq->bits) - 1;
-    return K * bnq_amax(a_bits) * wmax <= 32767;
+    return K * bnq_amax(a_bits) * wmax;
 }
+static int bnq_int16_ok(const mn_conv_geom* g, const mn_wq* wq, int a_bits) { return bnq_accmax(g, wq, a_bits) <= 32767; }
+// the WIDE variant of the grouped kernels (XENC 2: bf16 j for j <= 255, 32-bit stash): 8-bit activation codes, or an accumulator beyond int16
+static int bnq_wide(const mn_conv_geom* g, const mn_wq* wq, int a_bits) { return a_bits == 8 || !bnq_int16_ok(g, wq, a_bits); }
 extern "C" int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in) {
-    if (!g || !wq || wq->mode != MN_WQ_DOREFA || wq->bits < 2 || wq->bits > 8 || a_bits_in < 2 || a_bits_in > 7 || g->groups < 1 || g->C % g->groups || g->O % g->groups) return 0;
+    if (!g || !wq || wq->mode != MN_WQ_DOREFA || wq->bits < 2 || wq->bits > 8 || a_bits_in < 2 || a_bits_in > 8 || g->groups < 1 || g->C % g->groups || g->O % g->groups) return 0;
     if (qd_fwd_supported(g, wq, a_bits_in) && qd_dgrad_supported(g, wq) && qd_wgrad_supported(g, a_bits_in)) return 1;      // dense layers (ResNets): qgemm_dense.hip
-    if (!bnq_int16_ok(g, wq, a_bits_in)) return 0;
+    const int wide = bnq_wide(g, wq, a_bits_in);
+    if (wide && (MN_ENV("MN_NO_BNQ_WIDE") || bnq_accmax(g, wq, a_bits_in) >= (1ll << 24))) return 0;          // fp32 accumulation of bf16 integer products must stay exact
     if (g->stride_h != 1 || g->stride_w != 1) return 0;
     if (((int64_t)g->H * g->W) % 8) return 0;
     if (g->KH == 1 && g->KW == 1) {
@@ -1704,7 +1736,8 @@ extern "C" int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, in
 }
 extern "C" int mn_qconv_bnq_stash_bits(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in) {
     if (!mn_qconv_bnq_supported(g, wq, a_bits_in)) return 0;
-    return (qd_fwd_supported(g, wq, a_bits_in) && qd_stash32(g, wq, a_bits_in)) ? 32 : 16;
+    if (qd_fwd_supported(g, wq, a_bits_in) && qd_dgrad_supported(g, wq) && qd_wgrad_supported(g, a_bits_in)) return qd_stash32(g, wq, a_bits_in) ? 32 : 16;
+    return bnq_wide(g, wq, a_bits_in) ? 32 : 16;
 }
 extern "C" int64_t mn_qconv_bnq_ws_bytes(const mn_conv_geom* g) {
     if (!g) return -1;
@@ -1733,15 +1766,18 @@ extern "C" int mn_qconv_bnq_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
         return MN_OK;
     }
     const double npix = (double)g->N * g->H * g->W;
+    const int wide = bnq_wide(g, wq, a_bits_in);          // XENC 2, 32-bit stash (mn_qconv_bnq_stash_bits)
     if (g->KH == 1 && g->KW == 1) {
         PwsPlan pl;
         int rc = pws_prepare(g, wq, (const int8_t*)x_codes, w, ws, ws_bytes, PWS_NT_FWD, &pl, s, "mn_qconv_bnq_fwd_stash");
         if (rc) return rc;
         PwsParams& p = pl.p;
-        p.h16 = stash;
+        if (wide) p.h32 = reinterpret_cast<int32_t*>(stash); else p.h16 = stash;
         const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
         // the stash is needed in eval mode too (the streaming forward reads it): the statistics pass always runs, its sums are ignored in eval
-        if ((rc = launch_pws<PWS_STATS, 1>(pl, s, nx + 2.0 * ny, "mn_qconv_bnq_fwd_stash(stats)"))) return rc;
+        if (wide) rc = launch_pws<PWS_STATS, 2>(pl, s, nx + 4.0 * ny, "mn_qconv_bnq_fwd_stash(stats, wide)");
+        else rc = launch_pws<PWS_STATS, 1>(pl, s, nx + 2.0 * ny, "mn_qconv_bnq_fwd_stash(stats)");
+        if (rc) return rc;
         qa_launch_stats_prep((const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, ascale, bias, npix, eps, momentum, training, running_mean, running_var, save,
                              (int)g->O, gamma, beta, chan, (long long*)num_batches_tracked, s);
         MN_CHECK_LAUNCH("mn_qconv_bnq_fwd_stash");
@@ -1753,7 +1789,7 @@ extern "C" int mn_qconv_bnq_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
     const int Mg = g->O / g->groups;
     const float wsc = 1.0f / (float)((1ll << wq->bits) - 1);                 // the per-channel weight scale the pack kernel would produce (1 / n)
     hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((g->O + 255) / 256)), dim3(256), 0, s, rowscale, (int)g->O, wsc);
-    int rc = k3s_fwd_h16(g, wq, x_codes, w, stash, part, s);
+    int rc = k3s_fwd_h16(g, wq, x_codes, w, stash, wide, part, s);
     if (rc) return rc;
     qa_launch_stats_prep(part, k3s_fwd16_parts(g, wq), g->groups, Mg, Mg, rowscale, ascale, bias, npix, eps, momentum, training, running_mean, running_var, save,
                          (int)g->O, gamma, beta, chan, (long long*)num_batches_tracked, s);

@@ -2253,7 +2253,7 @@ class SignClassifierConv(Function):
 
 def code_classifier_supported(x, weight, stride, padding, dilation, groups):
     """True when a DoReFa QuantConv2d on a ``QActTensor`` is the small 1x1 classifier the dedicated kernels cover (O <= 16)."""
-    if not isinstance(x, QActTensor) or x.dim() != 4 or weight.dim() != 4 or CONV_ALGO != _lib.MN_ALGO_AUTO or not (2 <= x.bits <= 7):
+    if not isinstance(x, QActTensor) or x.dim() != 4 or weight.dim() != 4 or CONV_ALGO != _lib.MN_ALGO_AUTO or not (2 <= x.bits <= 8):
         return False
     one = lambda v, k: v in (k, (k, k), [k, k])
     if not (weight.shape[2] == 1 and weight.shape[3] == 1 and one(stride, 1) and one(padding, 0) and one(dilation, 1) and groups == 1):

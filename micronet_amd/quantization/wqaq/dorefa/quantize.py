@@ -335,13 +335,10 @@ def _fuse_blocks(model, fold_shuffle=True):
             if isinstance(nxt, MaxPool2dF32) and two(nxt.kernel_size) and two(nxt.stride) and nxt.padding in (0, (0, 0)) and nxt.dilation in (1, (1, 1)) \
                     and not nxt.ceil_mode and not nxt.return_indices:
                 pool, nxt = nxt, (kids[i + 2] if i + 2 < len(kids) else None)
-            # (a dense 3x3 conv -- groups 1, channels in 64s -- may need the 32-bit accumulator stash, which has no pooled epilogue (mn_qa_fwd answers ENOTSUP):
-            #  such a block in front of a pool hands fp32 to the pool kernel instead.  None of the reference's nets has one: their pools follow 1x1 / grouped convs)
-            c = blk.conv
-            wide_pool = pool is not None and c.groups == 1 and tuple(c.kernel_size) == (3, 3) and c.in_channels % 64 == 0 and c.out_channels % 64 == 0
-            if nxt is not None and is_block(nxt) and isinstance(nxt.conv, QuantConv2d) and not wide_pool:
+            # (the streaming kernels read either stash width, pooled or not: mn_qa_* with in_kind 0 / 2)
+            if nxt is not None and is_block(nxt) and isinstance(nxt.conv, QuantConv2d):
                 bits = nxt.conv.activation_quantizer.a_bits
-                if 2 <= bits <= 7 and 2 <= nxt.conv.weight_quantizer.w_bits <= 8:
+                if 2 <= bits <= 8 and 2 <= nxt.conv.weight_quantizer.w_bits <= 8:          # (8-bit codes: the wide kernels, 32-bit stash)
                     blk.bn.q_out_bits = int(bits)
                     blk.bn.q_pool = pool is not None
                     if pool is not None:

@@ -792,7 +792,6 @@ def check_qconv_bnq(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, tra
         x_log = np.ascontiguousarray(x_log.reshape(N, in_shuffle, Cin // in_shuffle, H, W).transpose(0, 2, 1, 3, 4).reshape(x_shape))
     tconv = lambda xx, ww: torch.nn.functional.conv2d(torch.from_numpy(xx), torch.from_numpy(ww), None, 1, padding, 1, groups).numpy()
     acc = tconv(x_log, wcode)                                                # exact integers (float64)
-    assert np.abs(acc).max() <= 32767
     alpha = F(F(1.0 / nw) * s_a)
     y = (acc.astype(F) * alpha + (b.reshape(1, -1, 1, 1) if bias else F(0))).astype(F)      # the fp32 chain of the kernels' epilogue
     y64 = y.astype(np.float64)
@@ -813,18 +812,23 @@ def check_qconv_bnq(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, tra
     g.in_shuffle = in_shuffle
     wq = be.wq(mode=2, bits=w_bits)
     assert be.lib.mn_qconv_bnq_supported(C.byref(g), C.byref(wq), a_bits) == 1, "bnq not supported for this case"
+    sbits = int(be.lib.mn_qconv_bnq_stash_bits(C.byref(g), C.byref(wq), a_bits))
+    Kc = (Cin // groups) * w_shape[2] * w_shape[3]
+    assert sbits == (32 if (a_bits == 8 or Kc * na * nw > 32767) else 16), sbits      # wide stash: 8-bit codes, or an accumulator beyond int16
+    assert np.abs(acc).max() <= (32767 if sbits == 16 else 2 ** 24)
+    kind = 2 if sbits == 32 else 0                                           # mn_qa_*'s in_kind
     nb = max(int(be.lib.mn_qconv_bnq_ws_bytes(C.byref(g))), 4 * int(be.lib.mn_qa_ws_floats(Oc)))
     ws = be.empty(nb // 4 + 8)
     dX = be.to_dev_i8(codes_in.view(np.int8))
     dW, dB = be.to_dev(w), (be.to_dev(b) if bias else None)
     dG, dBe, dRM, dRV = be.to_dev(gamma), be.to_dev(beta), be.to_dev(rm), be.to_dev(rv)
     save, chan = be.empty((2, Oc)), be.empty((9, Oc))
-    stash = be.empty_i8((N, Oc, H, 2 * W))                                   # int16 [N][Oc][H][W]
+    stash = be.empty_i8((N, Oc, H, (sbits // 8) * W))                        # int16 / int32 [N][Oc][H][W]
     nbt = be.to_dev_i64([7])
     be.call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dX), a_bits, be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
             be.ptr(dRM), be.ptr(dRV), be.ptr(nbt), be.ptr(save), be.ptr(stash), be.ptr(chan), be.ptr(ws), nb, be.stream)
     assert int(be.to_host(nbt)[0]) == (8 if training else 7)
-    st = be.to_host(stash).view(np.int16).reshape(N, Oc, H, W)
+    st = be.to_host(stash).view(np.int16 if sbits == 16 else np.int32).reshape(N, Oc, H, W)
     assert np.array_equal(st.astype(np.float64), acc), ("stash != exact integer conv result", float(np.abs(st - acc).max()))
     sv = be.to_host(save)
     assert np.max(np.abs(sv[0] - mean32)) <= 2e-6 * max(np.max(np.abs(mean32)), 1e-3) + 1e-7, "mean"
@@ -835,7 +839,7 @@ def check_qconv_bnq(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, tra
     Ho, Wo = (H // 2, W // 2) if pooled else (H, W)
     codes_out = be.empty_i8((N, Oc, Ho, Wo))
     act = be.empty((N, Oc, Ho, Wo))
-    be.call("mn_qa_fwd", 0, be.ptr(stash), be.ptr(chan), N, Oc, H, W, out_bits, int(pooled), be.ptr(codes_out), be.ptr(act), be.stream)
+    be.call("mn_qa_fwd", kind, be.ptr(stash), be.ptr(chan), N, Oc, H, W, out_bits, int(pooled), be.ptr(codes_out), be.ptr(act), be.stream)
     # the kernels use THEIR (mean, invstd): recompute the reference chain with them so that every downstream comparison is exact up to ties
     m_k, i_k = sv[0].astype(F), sv[1].astype(F)
     zh = ((y - m_k.reshape(1, -1, 1, 1)) * i_k.reshape(1, -1, 1, 1)).astype(F)
@@ -870,9 +874,9 @@ def check_qconv_bnq(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, tra
     dy_ref = gi * (dz - dbeta_ref.reshape(1, -1, 1, 1) / n - zh.astype(np.float64) * dgamma_ref.reshape(1, -1, 1, 1) / n) if training else gi * dz
     dDQ = be.to_dev(dq)
     dy, dgam, dbet, sums = be.empty((N, Oc, H, W)), be.empty(Oc), be.empty(Oc), be.empty((2, Oc))
-    be.call("mn_qa_bwd_sums", 0, be.ptr(stash), be.ptr(chan), be.ptr(dDQ), N, Oc, H, W, out_bits, int(pooled), int(quant), be.ptr(dgam), be.ptr(dbet), be.ptr(sums),
+    be.call("mn_qa_bwd_sums", kind, be.ptr(stash), be.ptr(chan), be.ptr(dDQ), N, Oc, H, W, out_bits, int(pooled), int(quant), be.ptr(dgam), be.ptr(dbet), be.ptr(sums),
             be.ptr(ws), be.stream)
-    be.call("mn_qa_bwd_apply", 0, be.ptr(stash), be.ptr(chan), be.ptr(sums), be.ptr(dDQ), N, Oc, H, W, out_bits, int(pooled), int(quant), int(training), be.ptr(dy),
+    be.call("mn_qa_bwd_apply", kind, be.ptr(stash), be.ptr(chan), be.ptr(sums), be.ptr(dDQ), N, Oc, H, W, out_bits, int(pooled), int(quant), int(training), be.ptr(dy),
             be.stream)
     sc = max(np.max(np.abs(dz)) * np.sqrt(n), 1e-30)
     assert np.max(np.abs(be.to_host(dbet) - dbeta_ref)) <= 2e-6 * sc and np.max(np.abs(be.to_host(dgam) - dgamma_ref)) <= 2e-6 * sc * max(1.0, np.abs(zh).max()), "dgamma / dbeta"
@@ -909,6 +913,14 @@ BNQ_CASES = [
     dict(x_shape=(2, 32, 8, 8), w_shape=(64, 16, 3, 3), groups=2, padding=1),
     dict(x_shape=(2, 32, 16, 16), w_shape=(48, 8, 3, 3), groups=4, padding=1, in_shuffle=2, pooled=True, a_bits=3, w_bits=3, out_bits=2),
     dict(x_shape=(4, 48, 8, 8), w_shape=(48, 48, 1, 1), quant=0, a_bits=4, w_bits=4),
+    # the WIDE variants (8-bit codes / accumulators beyond int16: 32-bit stash, XENC 2 of the grouped kernels) -- W8A8 is the reference's CPU configuration
+    dict(x_shape=(2, 96, 8, 8), w_shape=(96, 48, 1, 1), groups=2, a_bits=8, w_bits=8),
+    dict(x_shape=(3, 80, 8, 16), w_shape=(96, 40, 1, 1), groups=2, in_shuffle=2, pooled=True, a_bits=8, w_bits=8),
+    dict(x_shape=(2, 128, 4, 8), w_shape=(48, 128, 1, 1), bias=False, training=False, a_bits=8, w_bits=8),
+    dict(x_shape=(2, 32, 8, 8), w_shape=(64, 16, 3, 3), groups=2, padding=1, a_bits=8, w_bits=8),
+    dict(x_shape=(2, 32, 16, 16), w_shape=(48, 8, 3, 3), groups=4, padding=1, in_shuffle=2, pooled=True, a_bits=8, w_bits=8, out_bits=8),
+    dict(x_shape=(4, 48, 8, 8), w_shape=(48, 48, 1, 1), quant=0, a_bits=6, w_bits=5),
+    dict(x_shape=(2, 32, 8, 8), w_shape=(64, 16, 3, 3), groups=2, padding=1, a_bits=5, w_bits=6, out_bits=5),
 ]
 
 

@@ -364,6 +364,7 @@ def test_code_classifier(be):
     K.check_code_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bits=3, bias=False, seed=1)
     K.check_code_classifier(be, N=16, Cc=1024, H=8, W=8, Oc=10, bits=2, seed=2)         # nin_gc L9 under DoReFa W2A2
     K.check_code_classifier(be, N=5, Cc=330, H=8, W=8, Oc=10, bits=4, seed=3)
+    K.check_code_classifier(be, N=16, Cc=1024, H=8, W=8, Oc=10, bits=8, seed=4)         # nin_gc L9 under DoReFa W8A8
 
 
 @pytest.mark.parametrize("training", [True, False])
@@ -449,6 +450,13 @@ BNQ_HOT = [
 @pytest.mark.parametrize("training", [True, False])
 def test_qconv_bnq_hot_shapes(be, name, kw, training):
     K.check_qconv_bnq(be, seed=77, training=training, **kw)
+
+
+@pytest.mark.parametrize("name,kw", BNQ_HOT, ids=[n for n, _ in BNQ_HOT])
+def test_qconv_bnq_hot_shapes_w8a8(be, name, kw):
+    """The same layers at W8A8 (the reference's CPU configuration, wqaq/dorefa/main.py:135,189-190): the wide variants of the grouped kernels -- bf16 codes up to
+    255, |acc| < 2^24 exact in the fp32 accumulators, 32-bit stash, pooled and unpooled streaming passes on it."""
+    K.check_qconv_bnq(be, seed=78, training=True, a_bits=8, w_bits=8, **kw)
 
 
 def test_dorefa_weight_quantizer_multi_bit_identical(be):

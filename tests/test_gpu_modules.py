@@ -591,7 +591,7 @@ def test_dorefa_fused_bn_relu_matches_unfused():
         assert rel_err(a(x).cpu(), b(x).cpu()) <= 2e-5
 
 
-@pytest.mark.parametrize("bits,arch", [(2, "nin_gc"), (4, "nin_gc"), (3, "nin_gc"), (2, "nin")])
+@pytest.mark.parametrize("bits,arch", [(2, "nin_gc"), (4, "nin_gc"), (3, "nin_gc"), (2, "nin"), (8, "nin_gc"), (6, "nin_gc")])
 def test_dorefa_fused_blocks_match_unfused(bits, arch):
     """prepare(fuse_blocks=True) (activation codes in one byte, 16-bit integer conv stash, BatchNorm + ReLU + max-pool + next-layer quantizer in streaming
     kernels, shuffle folded) is numerically the SAME function as the unfused module graph: identical logits, gradients to float round-off, identical
@@ -600,6 +600,11 @@ def test_dorefa_fused_blocks_match_unfused(bits, arch):
     from micronet_amd.train import build_model, synth_batch
     Q = _q("wqaq.dorefa")
     x, y = synth_batch(16, device="cuda")
+    # More than 4 bits (the wide kernels: 32-bit stash): a quantizer step is 10 / (2^a - 1) of an activation unit, so the 1e-7 difference between the two paths'
+    # batch statistics (exact integer sums vs fp32 sums of y) lands ~1e-5 of the elements on the other side of a rounding boundary; each such flip moves one input
+    # of the next conv by one step.  The comparison is a consistency check at those widths (the batch-256 parity test judges the fused path against the oracle).
+    wide = bits > 4
+    tl, tg, tk, tb = (1e-3, 5e-3, 5e-2, 5e-5) if wide else (1e-6, 2e-5, 2e-4, 2e-6)
     a = Q.prepare(build_model(arch), inplace=True, a_bits=bits, w_bits=bits).cuda().train()
     b = Q.prepare(build_model(arch), inplace=True, a_bits=bits, w_bits=bits, fuse_blocks=False).cuda().train()
     assert list(a.state_dict().keys()) == list(b.state_dict().keys())
@@ -610,7 +615,7 @@ def test_dorefa_fused_blocks_match_unfused(bits, arch):
         h.remove()
     if arch == "nin_gc":
         assert kinds.count("QActTensor") >= 8, kinds          # the blocks really run fused
-    assert float((oa - ob).abs().max()) <= 1e-6 * float(ob.abs().max()), "logits"
+    assert float((oa - ob).abs().max()) <= tl * float(ob.abs().max()), "logits"
     torch.nn.functional.cross_entropy(oa, y).backward()
     torch.nn.functional.cross_entropy(ob, y).backward()
     gmax = max(float(p.grad.abs().max()) for p in b.parameters())
@@ -623,21 +628,21 @@ def test_dorefa_fused_blocks_match_unfused(bits, arch):
             # the DoReFa weight quantizer routes the gradient of its global max |tanh w| to ONE element: a sum of ~all other terms of both signs
             # (ill-conditioned; the full-batch parity test judges it against fp64).  Everything else to 2e-5, that element to 2e-4.
             k = int(pb.detach().abs().argmax())
-            assert float(d.flatten()[k] / scale) <= 2e-4, (n, "arg-max element", float(d.flatten()[k] / scale))
+            assert float(d.flatten()[k] / scale) <= tk, (n, "arg-max element", float(d.flatten()[k] / scale))
             d = d.flatten().clone()
             d[k] = 0
         e = float(d.max() / scale)
-        assert e <= 2e-5, (n, e)
+        assert e <= tg, (n, e)
     for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         if ba.dtype.is_floating_point:
-            assert float((ba - bb).abs().max()) <= 2e-6 * float(bb.abs().max().clamp_min(1e-6)), n
+            assert float((ba - bb).abs().max()) <= tb * float(bb.abs().max().clamp_min(1e-6)), n
         else:
             assert torch.equal(ba, bb), n
     b.load_state_dict(a.state_dict())
     a.eval(), b.eval()
     with torch.no_grad():
         ea, eb = a(x), b(x)
-    assert float((ea - eb).abs().max()) <= 1e-6 * float(eb.abs().max())
+    assert float((ea - eb).abs().max()) <= 1e-6 * float(eb.abs().max())          # (same running statistics on both sides: no flips at any width)
     # a foreign consumer of a block's output sees the fp32 activation of the reference (hooks, feature taps)
     a.train()
     feats = []

@@ -313,11 +313,25 @@ def test_full_batch_teacher_forced(key):
             if hasattr(out, "codes") and hasattr(out, "bits"):
                 # the codes of the next layer's quantizer vs the oracle's own quantizer on its own activation (wqaq/dorefa/quantize.py:43-45)
                 from oracle import np_oracle as NO
-                _, cref = NO.dorefa_act_fwd(ref_out.numpy(), out.bits)
-                nflip = int((out.codes.cpu().numpy().astype("float32") != cref).sum())
+                import numpy as np
+                a_ref = ref_out.numpy()
+                _, cref = NO.dorefa_act_fwd(a_ref, out.bits)
+                cgot = out.codes.cpu().numpy().astype("float32")
+                flip = cgot != cref
+                nflip = int(flip.sum())
                 errs["codes_flipped_frac"] = nflip / max(1, cref.size)
-                if errs["codes_flipped_frac"] > 1e-5:
-                    failures.append((seg, "activation codes differ from the oracle's quantizer beyond rounding ties", errs["codes_flipped_frac"]))
+                if nflip:
+                    # A code may differ from the oracle's ONLY at a rounding tie of the oracle's own quantizer: v = clamp(0.1 a, 0, 1) / s within the window the
+                    # activation tolerance allows (|a - a_ref| <= 1e-5 max |a_ref|, i.e. 0.1 n 1e-5 max |a_ref| code units) of k + 1/2, and then by one step.
+                    # At 8 bits a step is 1 / 25.5 of an activation unit, so ~1e-5 of the elements sit that close to a boundary; at 2 bits almost none do.
+                    n_ = float(2 ** out.bits - 1)
+                    v = np.clip(a_ref.astype(np.float64) * 0.1, 0.0, 1.0) * n_
+                    dist = np.abs(v - (np.floor(v) + 0.5))
+                    win = 0.1 * n_ * 1e-5 * float(np.abs(a_ref).max())
+                    illegal = flip & ~((dist <= win) & (np.abs(cgot - cref) == 1))
+                    errs["codes_flipped_off_tie"] = int(illegal.sum())
+                    if int(illegal.sum()) or errs["codes_flipped_frac"] > 1e-4:
+                        failures.append((seg, "activation codes differ from the oracle's quantizer away from rounding ties", errs["codes_flipped_frac"], int(illegal.sum())))
         # ---- backward with the oracle's incoming gradient (zeroed at the oracle's activation ties: _untie)
         gout_cpu, gin_ref, pgrad_ref = r_out["gout"], r_in.get("gin"), {str(i): rec[str(i)]["pgrad"] for i in seg}
         if not (binary and len(seg) == 2):        # (+-1 activations have no near-ties in a pooling window: the wbwtab pooled segments stay as they are)
@@ -396,7 +410,7 @@ def test_full_batch_teacher_forced(key):
                     failures.append((seg, "d" + name + " at the arg-max element vs fp64", e_ours, e_ref))
         report["+".join(type(pstages[i]).__name__ + str(i) for i in seg)] = {k: float("%.2e" % v) for k, v in errs.items()}
         for k_, v in errs.items():
-            if k_ in ("sign_mismatch", "ties_masked", "ties_masked_frac", "dead_window_frac", "codes_flipped_frac", "y_elementwise_rel", "dx_elementwise_rel", "weight_codes_flipped", "weight_codes_total", "kernel_family") or "_argmax_element" in k_ or k_.endswith("_vs_fp64") or k_.endswith("_vs_reference_fp32"):
+            if k_ in ("sign_mismatch", "ties_masked", "ties_masked_frac", "dead_window_frac", "codes_flipped_frac", "codes_flipped_off_tie", "y_elementwise_rel", "dx_elementwise_rel", "weight_codes_flipped", "weight_codes_total", "kernel_family") or "_argmax_element" in k_ or k_.endswith("_vs_fp64") or k_.endswith("_vs_reference_fp32"):
                 continue
             lim = max(1e-5, slack.get(k_, 0.0))
             worst = max(worst, v)

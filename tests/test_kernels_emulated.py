@@ -236,6 +236,7 @@ def test_code_classifier(be):
     K.check_code_classifier(be)
     K.check_code_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bits=3, bias=False, seed=1)
     K.check_code_classifier(be, N=5, Cc=330, H=8, W=8, Oc=10, bits=4, seed=3)
+    K.check_code_classifier(be, N=3, Cc=200, H=4, W=8, Oc=10, bits=8, seed=4)          # 8-bit codes (W8A8)
 
 
 @pytest.mark.parametrize("training", [True, False])
