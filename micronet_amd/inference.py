@@ -28,6 +28,8 @@ def prequantize_weights(model):
             m.weight.data = m.weight_quantizer(m.weight).detach()
             m.weight_quantizer.train(was)
             n += 1
+            if type(m).__module__.endswith("wbwtab.quantize") and hasattr(m, "stored_codes") and getattr(m.weight_quantizer, "W", 0) in (2, 3):
+                m.stored_codes = True          # the stored weights ARE the quantizer's output t * alpha[o]: the layer keeps contracting integer codes
             # DoReFa layers: record the "stored weights lie on the quantizer grid" verdict now (one host sync per layer, here instead of inside the first forward --
             # which may be a captured one)
             if type(m).__module__.endswith("dorefa.quantize") and m.weight.is_cuda and not torch.cuda.is_current_stream_capturing():
@@ -71,21 +73,37 @@ def wbwtab_model_bn_fuse(model, W=2, inplace=False):
         if 2 <= k <= bin_bn_fuse_num:
             new = _conv_like(conv, quantize.QuantConv2d, W=W, quant_inference=True)
             new.in_shuffle_groups = getattr(conv, "in_shuffle_groups", 0)
+            # The low-bit deployed path: in front of a binary activation the fold leaves the weights codes x alpha[o] (only signs and the bias change, ref 36-55).
+            # Checked here, once: every non-zero |w| of an output channel equals the channel's maximum -- then the layer contracts the +-1 input codes against
+            # integer weight codes on the matrix cores and (where prepare() had established conv -> bn -> sign in this order: ``lazy_for_bn``) hands its
+            # un-computed result to the sign behind it, exactly like the training graph in eval mode: one byte per activation end to end.
+            mag = w_f.detach().abs().flatten(1)
+            new.stored_codes = bool(((mag == 0) | (mag == mag.amax(1, keepdim=True))).all()) and W in (2, 3)
+            new.lazy_for_bn = bool(new.stored_codes and getattr(conv, "lazy_for_bn", False))
         else:
             new = _conv_like(conv, nn.Conv2d)
+            from micronet_amd.nn import Conv2dFirst, Conv2dSignIn
+            if type(conv) in (Conv2dFirst, Conv2dSignIn):
+                new.__class__ = type(conv)          # the fp32 first / last conv keep their gfx950 kernels (same parameters: only the forward differs)
         new = new.to(w.device)
         new.weight.data, new.bias.data = w_f, b_f
         return new
 
     def walk(module):
-        last = None
+        last, packed_bn = None, False
         for name, child in module.named_children():
             if isinstance(child, nn.Conv2d):
                 last = (name, child)
             elif isinstance(child, nn.BatchNorm2d):
                 module._modules[last[0]] = fuse(last[1], child)
                 module._modules[name] = nn.Identity()
+                packed_bn = isinstance(child, quantize.BatchNorm2dBinAct) and bool(child.packed)      # (prepare() established bn -> sign adjacency for this block)
+            elif isinstance(child, quantize.ActivationQuantizer):
+                if packed_bn and child.A == 2:
+                    child.deploy_packed = True      # conv -> Identity -> sign on the packed kernels (ActivationQuantizer.forward)
+                packed_bn = False
             else:
+                packed_bn = False
                 walk(child)
     walk(model)
     return model

@@ -64,6 +64,9 @@ class Ternary(Function):
 
 
 class ActivationQuantizer(nn.Module):
+    deploy_packed = False      # set by micronet_amd.inference.wbwtab_model_bn_fuse: this sign sits directly behind a BN-folded conv (conv -> Identity -> sign,
+                               # wbwtab/bn_fuse/bn_fuse.py:36-55) of a block that ran packed in training -- the deployed graph keeps one byte per activation
+
     def __init__(self, A=2):
         super().__init__()
         self.A = A
@@ -72,9 +75,29 @@ class ActivationQuantizer(nn.Module):
     def binary(self, input):
         return BinaryActivation.apply(input)
 
+    def _identity_bn(self, C, device):
+        """(gamma = 1, beta = 0, mean = 0, var = 1) of the fused BatchNorm+sign kernels: with eps = 0 they evaluate ((y - 0) * 1) * 1 + 0 = y in fp32, so
+        ``sign(bn(y))`` IS the reference's ``sign(y)`` (0 -> +1).  Cached per (C, device); not part of the ``state_dict``."""
+        cache = self.__dict__.setdefault("_mn_ident", {})
+        key = (int(C), str(device))
+        if key not in cache:
+            one, zero = torch.ones(C, dtype=torch.float32, device=device), torch.zeros(C, dtype=torch.float32, device=device)
+            cache[key] = (one, zero, zero.clone(), one.clone())
+        return cache[key]
+
     def forward(self, input):
         if self.A == 2 and (isinstance(input, SignTensor) or getattr(input, "_mn_binarized", False)):
             return input              # the BatchNorm2dBinAct in front already produced sign(bn(x)) in its fused kernel
+        if self.A == 2 and self.deploy_packed and input.is_cuda and input.dim() == 4:
+            # the deployed (BN-folded) graph on the packed kernels: sign(conv(a) + b) straight from the +-1 codes (the folded conv left its output un-computed), or
+            # -- behind the fp32 first conv -- sign(y) written as one byte per element; same kernels as the training graph's eval mode, identity statistics
+            hw = input.shape[2] * input.shape[3]
+            if isinstance(input, LazyConvOut) and input._mn_value is None:
+                g_, b_, m_, v_ = self._identity_bn(input.shape[1], input.device)
+                return ops.ConvBNSign.apply(input, g_, b_, m_, v_, 0.0, 0.0, False, None)
+            if type(input) is torch.Tensor and input.dtype == torch.float32 and hw % 4 == 0 and input.is_contiguous():
+                g_, b_, m_, v_ = self._identity_bn(input.shape[1], input.device)
+                return ops.BNSign.apply(input, g_, b_, m_, v_, 0.0, 0.0, False, True, False)
         return self.binary(input) if self.A == 2 else self.relu(input)
 
 
@@ -172,11 +195,13 @@ class QuantConv2d(nn.Conv2d):
         self.weight_quantizer = WeightQuantizer(W=W)
         self.in_shuffle_groups = 0     # > 1: this conv reads channel_shuffle(input, groups) (set by prepare(), see add_quant_op)
         self.lazy_for_bn = False       # True (set by prepare()): a packed BatchNorm2dBinAct consumes the output -> it may stay uncomputed
+        self.stored_codes = False      # quant_inference only: the STORED weights are known to be codes x alpha[o] (set by micronet_amd.inference, which checks
+                                       # them): the layer then contracts integer codes on the matrix cores like the training graph does
 
     def forward(self, input):
         tnn_bin_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
         # binary / ternary weights are t * alpha[o]: the conv contracts the integer codes t on the bf16 matrix cores
-        coded = (not self.quant_inference) and self.weight_quantizer.W in (2, 3)
+        coded = self.weight_quantizer.W in (2, 3) and ((not self.quant_inference) or getattr(self, "stored_codes", False))
         return ops.qconv2d(input, tnn_bin_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
                            wdesc=(ops.WQ_TERNARY, 0, 0, 0, None) if coded else None, in_shuffle=self.in_shuffle_groups,
                            lazy_for_bn=self.lazy_for_bn and coded)

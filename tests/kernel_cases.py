@@ -617,6 +617,68 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
     assert close(y, y64, 1e-6)
 
 
+def check_deployed_sign_block(be, x_shape, w_shape, groups=1, in_shuffle=0, padding=0, seed=0, must_support=True):
+    """The DEPLOYED binary block (wbwtab/bn_fuse/bn_fuse.py:36-55: the BatchNorm folded into the conv's bias, the weights still codes x alpha): sign(conv(a) + b)
+    on packed +-1 codes through mn_qconv_bnsign_fwd_stash in eval mode with IDENTITY statistics (gamma 1, beta 0, mean 0, var 1, eps 0) -- the fused kernels then
+    evaluate ((y - 0) * 1) * 1 + 0 = y in fp32, so the result must equal sign(fl(fl(acc * alpha) + b)) (0 -> +1) BIT FOR BIT: acc is an exact integer."""
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    Oc = w_shape[0]
+    a_in = np.where(r.standard_normal(x_shape) > 0, 1, -1).astype(np.int8)
+    w, wkw, _ = make_coded_weights(r, w_shape, 1)
+    b = (r.standard_normal(Oc) * 3.0).astype(F)
+    b[::5] = 0                                                # channels with a zero bias: exact zeros of acc * alpha + b occur (sign(0) = +1)
+    x_log = a_in.astype(F)
+    if in_shuffle > 1:
+        x_log = np.ascontiguousarray(x_log.reshape(N, in_shuffle, Cin // in_shuffle, H, W).transpose(0, 2, 1, 3, 4).reshape(x_shape))
+    g = be.geom(x_shape, w_shape, padding=padding, groups=groups)
+    g.in_shuffle = in_shuffle
+    wq = be.wq(**wkw)
+    sup = int(be.lib.mn_qconv_bnsign_stash_supported(C.byref(g), C.byref(wq)))
+    if not sup:
+        assert not must_support, "deployed block: geometry not covered by the fused sign kernels"
+        return False
+    acc = O.conv2d_fwd(x_log, np.sign(w).astype(F), None, padding=padding, groups=groups)                    # exact integers
+    alpha = np.abs(w).reshape(Oc, -1).max(axis=1).astype(F)
+    y = (acc.astype(F) * alpha.reshape(1, -1, 1, 1)).astype(F) + b.reshape(1, -1, 1, 1)                       # the kernels' fp32 chain
+    a_ref = np.where(y.astype(F) < 0, -1, 1).astype(np.int8)
+    nb = max(int(be.lib.mn_qconv_bnsign_stash_ws_bytes(C.byref(g))), 4 * int(be.lib.mn_bnsign_ws_floats(Oc)))
+    ws = be.empty(nb // 4 + 8)
+    one, zero = np.ones(Oc, dtype=F), np.zeros(Oc, dtype=F)
+    dA, dW, dB = be.to_dev_i8(a_in), be.to_dev(w), be.to_dev(b)
+    dG, dBe, dRM, dRV = be.to_dev(one), be.to_dev(zero), be.to_dev(zero), be.to_dev(one)
+    save, a8 = be.empty((2, Oc)), be.empty_i8((N, Oc, H, W))
+    h8, chan = be.empty_i8((N, Oc, H, W)), be.empty((int(be.lib.mn_qconv_bnsign_stash_chan_rows(C.byref(g))), Oc))
+    be.call("mn_qconv_bnsign_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), 0.0, 0.0, 0,
+            be.ptr(dRM), be.ptr(dRV), None, be.ptr(save), be.ptr(a8), be.ptr(h8), be.ptr(chan), be.ptr(ws), nb, be.stream)
+    sv = be.to_host(save)
+    assert np.array_equal(sv[0], zero) and np.array_equal(sv[1], one), "identity statistics: mean 0, invstd exactly 1"
+    got = be.to_host(a8).view(np.int8)
+    assert np.array_equal(got, a_ref), ("deployed sign block", int((got != a_ref).sum()), got.size)
+    # the same rule for a block fed by the fp32 first conv: sign(y) as bytes from mn_bnsign_fwd_i8 with the identity statistics
+    yf = (r.standard_normal((N, Oc, H, W)) * 2).astype(F)
+    yf[:, :, 0, :2] = 0
+    yf[:, :, 1, :2] = -0.0
+    dY = be.to_dev(yf)
+    a8b = be.empty_i8((N, Oc, H, W))
+    ws2 = be.empty(int(be.lib.mn_bnsign_ws_floats(Oc)) + 8)
+    be.call("mn_bnsign_fwd_i8", be.ptr(dY), N, Oc, H * W, be.ptr(dG), be.ptr(dBe), 0.0, 0.0, 0, be.ptr(dRM), be.ptr(dRV), be.ptr(save), be.ptr(a8b), be.ptr(ws2), be.stream)
+    assert np.array_equal(be.to_host(a8b).view(np.int8), np.where(yf < 0, -1, 1).astype(np.int8)), "sign(y) bytes (0 and -0 -> +1)"
+    return True
+
+
+DEPLOYED_CASES = [
+    dict(x_shape=(2, 96, 8, 8), w_shape=(96, 48, 1, 1), groups=2),
+    dict(x_shape=(3, 80, 8, 16), w_shape=(96, 40, 1, 1), groups=2, in_shuffle=2),
+    dict(x_shape=(2, 32, 8, 8), w_shape=(64, 16, 3, 3), groups=2, padding=1),
+    dict(x_shape=(2, 32, 16, 16), w_shape=(48, 8, 3, 3), groups=4, padding=1, in_shuffle=2),
+    # the layers of the small golden net (tests/golden/inference_meta.json cfg 32-32-32-64-64-64-128-128) the deployment-flow test runs packed
+    dict(x_shape=(4, 32, 32, 32), w_shape=(32, 16, 1, 1), groups=2),
+    dict(x_shape=(4, 64, 16, 16), w_shape=(64, 16, 1, 1), groups=4, in_shuffle=4),
+    dict(x_shape=(4, 128, 8, 8), w_shape=(128, 16, 1, 1), groups=8, in_shuffle=32),
+]
+
+
 def check_sign_classifier(be, N=3, Cc=96, H=4, W=8, Oc=10, bias=True, seed=0):
     """mn_signconv1x1_small_fwd / mn_conv1x1_small_bwd_data (+ backward-weight through mn_conv2d_bwd_weight on the codes) vs fp64."""
     r = np.random.default_rng(seed)

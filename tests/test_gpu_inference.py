@@ -245,6 +245,46 @@ def test_wbwtab_bn_fused_graph_vs_reference_golden(W):
         assert _rel(OF(x), g[f"{key}_fused_logits"].astype(np.float64)) <= 1e-6          # (bit-equal on the host that generated the goldens: tests/test_oracle_golden.py)
         lg = F(x.cuda())
         assert bool((lg.argmax(1).cpu() == torch.from_numpy(g[f"{key}_fused_logits"]).argmax(1)).float().mean() >= 0.75)
+    # ---- the reference's DEPLOYMENT flow: weights stored pre-quantised (wbwtab/quant_model_test/quant_model_para.py: ``m.weight.data = weight_quantizer(m.weight)``),
+    # THEN the fold.  The folded convs in front of a sign then hold codes x alpha (ref 36-55 only flips signs there), and the product's folded graph runs LOW-BIT:
+    # +-1 activations as one byte end to end, integer weight codes on the matrix cores, conv + bias + sign in the fused kernels (no fp32 activation between two
+    # quantised layers).  Checked against the oracle's folded graph stage by stage on the oracle's own stage inputs, handed over PACKED where they are +-1.
+    from micronet_amd.sign_tensor import SignTensor, LazyConvOut
+    orc2 = TO.prepare(_small_net(meta), "wbwtab", inplace=True, A=2, W=W)
+    orc2.load_state_dict({k[len(key) + 9:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(key + "_trained_")})
+    with torch.no_grad():
+        for m in orc2.modules():
+            if isinstance(m, TO.OConv2d) and m.scheme == "wbwtab":
+                m.weight.data = TO.wbwtab_weight(m.weight, W).detach().clone()
+    OF2 = TO.bn_fuse_wbwtab(orc2, W).eval()
+    I2 = Q.prepare(_small_net(meta), inplace=True, A=2, W=W, quant_inference=True)
+    I2.load_state_dict(orc2.state_dict())
+    F2 = inference.wbwtab_model_bn_fuse(I2.cuda(), W=W).eval()
+    qc2 = [m for m in F2.modules() if isinstance(m, Q.QuantConv2d)]
+    assert len(qc2) == 7 and all(m.stored_codes for m in qc2)                       # every folded quantised conv kept codes x alpha
+    assert sum(bool(m.lazy_for_bn) for m in qc2) >= 4                               # ... and most hand their un-computed result to the fused sign
+    seen = []
+    with torch.no_grad():
+        t = x
+        for i, (so, sp) in enumerate(zip(OF2.model, F2.model)):
+            ref = so(t)
+            pm1 = i > 0 and bool(((t == 1) | (t == -1)).all())
+            inp = SignTensor(t.to(torch.int8).cuda().contiguous()) if pm1 else t.cuda()
+            hooks = [m.register_forward_hook(lambda mod, i_, o_: seen.append(type(o_).__name__)) for m in sp.modules() if isinstance(m, Q.QuantConv2d)]
+            got = sp(inp)
+            for h_ in hooks:
+                h_.remove()
+            if bool(((ref == 1) | (ref == -1)).all()):
+                assert isinstance(got, SignTensor), (i, type(got))                  # the deployed stage emits packed signs
+                bad = (got.to_float().cpu() != ref)
+                assert float(bad.float().mean()) <= 2e-4, (i, float(bad.float().mean()))
+            else:
+                got = got.to_float() if hasattr(got, "to_float") else got
+                assert _rel(got, ref.double().numpy()) <= 1e-5, (i, _rel(got, ref.double().numpy()))
+            t = ref
+        assert seen.count("LazyConvOut") >= 4, seen                                 # conv + bias + sign really ran as ONE fused op on the codes
+        lg2 = F2(x.cuda())
+        assert bool((lg2.argmax(1).cpu() == OF2(x).argmax(1)).float().mean() >= 0.75)
 
 
 def test_iao_bn_fused_graph_vs_reference_golden():

@@ -232,6 +232,12 @@ def test_sign_classifier(be):
     K.check_sign_classifier(be, N=5, Cc=330, H=8, W=8, Oc=10, seed=3)                  # two blocks (320 pixels), 21 channels per wave: unrolled loads + tail
 
 
+@pytest.mark.parametrize("case", range(len(K.DEPLOYED_CASES)))
+def test_deployed_sign_block_identity_statistics(be, case):
+    """sign(conv(a) + b) of the BN-folded deployed graph (wbwtab/bn_fuse/bn_fuse.py:36-55) on the fused code kernels, bit for bit."""
+    K.check_deployed_sign_block(be, seed=500 + case, **K.DEPLOYED_CASES[case])
+
+
 def test_code_classifier(be):
     K.check_code_classifier(be)
     K.check_code_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bits=3, bias=False, seed=1)
