@@ -239,7 +239,7 @@ typedef struct mn_conv_geom {
                           one byte per element: a quarter of the HBM traffic of the fp32 +-1 tensor).  fwd and bwd_weight read the
                           codes directly (4-byte aligned rows: H*W % 4 == 0); bwd_data ignores x (the clip-STE of the sign lives
                           in mn_bnsign_bwd).  Code-domain kernels only (else MN_ENOTSUP). */
-#define MN_ACTQ_CODE8 4 /* `x` is NOT fp32: it points to the k-bit activation CODES j of the quantizer (uint8 in [0, 2^bits - 1], bits <= 7, NCHW like x;
+#define MN_ACTQ_CODE8 4 /* `x` is NOT fp32: it points to the k-bit activation CODES j of the quantizer (uint8 in [0, 2^bits - 1], bits <= 8, NCHW like x;
                           value = j * s, s = 1 / (2^bits - 1): DoReFa ActivationQuantizer, wqaq/dorefa/quantize.py:43-45) as written by mn_qa_fwd -- one byte
                           per element instead of four, and the quantizer is not re-evaluated.  Supported by bwd_weight (dw = s * sum gy * j) and bwd_data
                           (x ignored: the clip-STE lives in mn_qa_bwd_*) where mn_qconv_bnq_supported says so; the forward on codes is
@@ -464,6 +464,16 @@ int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in
 int64_t mn_qd_packed_bytes(const mn_conv_geom* g);
 int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, void* const* out_bwd, const int64_t* O, const int64_t* Cin, const int64_t* taps,
                      const float* const* wscale, const int32_t* wscale_stride, int32_t count, int w_bits, mn_stream_t stream);
+/* Backward-weight of a dense layer with the reduction of its split-K partial tiles DEFERRED.  autograd's conv2d backward hands d(quantised weight) to the weight
+ * quantizer's backward (wqaq/dorefa/quantize.py:61-73, wqaq/iao/quantize.py:214-240 through torch.autograd), and in a training step nothing else reads it -- so
+ * every dense conv of the step leaves its partial tiles in ITS OWN workspace (mn_qd_bwd_weight_partials: aq->mode MN_ACTQ_CODE8 with x = activation codes, or
+ * MN_ACTQ_IAO with x = the fp32 activation; no bias gradient; ws of mn_qd_wgrad_partials_ws_bytes bytes, kept untouched until the reduction) and ONE launch sums
+ * all of them (mn_qd_wgrad_reduce_multi: the same fixed-order fp64 sums as mn_conv2d_bwd_weight's own reduction, bit-identical dw).  19 launches less per
+ * resnet18 step. */
+int mn_qd_wgrad_partials_supported(const mn_conv_geom* g, const mn_actq* aq);
+int64_t mn_qd_wgrad_partials_ws_bytes(const mn_conv_geom* g, const mn_actq* aq);
+int mn_qd_bwd_weight_partials(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const void* x, void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_qd_wgrad_reduce_multi(int32_t count, const mn_conv_geom* const* g, const mn_actq* const* aq, void* const* ws, float* const* dw, mn_stream_t stream);
 /* width of the stash mn_qconv_bnq_fwd_stash writes for this layer: 16, or 32 when K * (2^a - 1) * (2^w - 1) exceeds 32767 -- a DENSE layer (groups == 1, C and O
  * multiples of 64: the 3 x 3 stride 1 / 2 and 1 x 1 stride 2 convolutions of the reference's ResNets, models/resnet.py:7-65) or a grouped / pointwise layer of
  * nin_gc at more than 4 bits (W8A8, the reference's CPU configuration: wqaq/dorefa/main.py:135,189-190), and for every layer read through 8-bit activation codes;

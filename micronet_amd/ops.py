@@ -62,6 +62,61 @@ def _span(g, which, nbytes):
     return _Span(tok) if tok is not None else _NOSPAN
 
 
+# Deferred reduction of the dense backward-weight partial tiles (mn_qd_bwd_weight_partials / mn_qd_wgrad_reduce_multi).  A conv whose quantised weight came out of
+# a multi-tensor weight-quantizer node (micronet_amd.train.prefetch_weight_path tags it ``_mn_defer_wgrad``) has exactly one reader of its d(quantised weight): that
+# node's backward, ONE launch at the end of the backward pass.  So the conv's backward leaves its split-K partial tiles in a workspace, returns the (not yet
+# written) dw tensor to autograd, and the node's backward first sums the partial tiles of ALL layers in one launch (bit-identical to the per-layer reductions).
+# Thread-local (one list per replica thread); MN_DEFER_WGRAD=0 switches it off.
+import os as _os0
+DEFER_WGRAD = _os0.environ.get("MN_DEFER_WGRAD", "1") != "0"
+
+
+class _WgradPending(threading.local):
+    def __init__(self):
+        self.items = []
+
+
+_WGRAD_PENDING = _WgradPending()
+
+
+def clear_wgrad_partials():
+    _WGRAD_PENDING.items.clear()
+
+
+def _defer_wgrad(g, aq, gy, x, dw, keep=()):
+    """Launch the backward-weight main kernel only; True when the layer is covered (the reduction is then pending: ``flush_wgrad_partials``)."""
+    if not DEFER_WGRAD or CONV_ALGO != _lib.MN_ALGO_AUTO:
+        return False
+    lib = _lib_()
+    if not lib.mn_qd_wgrad_partials_supported(C.byref(g), C.byref(aq)):
+        return False
+    nb = int(lib.mn_qd_wgrad_partials_ws_bytes(C.byref(g), C.byref(aq)))
+    ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=gy.device)
+    with _span(g, 2, 4 * gy.numel() + x.numel() * x.element_size()):
+        _call("mn_qd_bwd_weight_partials", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(ws), nb, _s())
+    _WGRAD_PENDING.items.append((g, aq, ws, dw, keep))
+    return True
+
+
+def flush_wgrad_partials():
+    """Sum the pending partial tiles of every deferred dense backward-weight into their dw tensors: one launch per device (called by the multi-tensor weight
+    quantizers' backward before they read d(quantised weight); harmless when nothing is pending)."""
+    items = _WGRAD_PENDING.items
+    if not items:
+        return
+    by_dev = {}
+    for it in items:
+        by_dev.setdefault(it[3].device, []).append(it)
+    for dev, its in by_dev.items():
+        n = len(its)
+        GP, AP, PA = C.POINTER(ConvGeom) * n, C.POINTER(ActQ) * n, C.c_void_p * n
+        with torch.cuda.device(dev):
+            with _span(None, 3, sum(4 * it[3].numel() for it in its)):
+                _call("mn_qd_wgrad_reduce_multi", n, GP(*[C.pointer(it[0]) for it in its]), AP(*[C.pointer(it[1]) for it in its]),
+                      PA(*[it[2].data_ptr() for it in its]), PA(*[it[3].data_ptr() for it in its]), _s())
+    items.clear()
+
+
 # Stock-operator fall-throughs.  A few modules of this package hand geometries their gfx950 kernels do not cover to the stock torch operator (MIOpen / ATen) --
 # the reference's own behaviour, so never wrong, but not the hot path this package exists for.  Every such fall-through is counted here by site name, so that a
 # benchmark or a test can ASSERT that a model runs entirely on the library's kernels (bench.py reports ``stock_fallbacks``; 0 for every benched workload).
@@ -211,6 +266,7 @@ class MultiDorefaWeight(Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        flush_wgrad_partials()          # the dense convs of the step left their backward-weight partial tiles: one reduction launch fills every gs[i]
         n, bits = ctx.n, ctx.bits
         ws, scratch, th = ctx.saved_tensors[:n], ctx.saved_tensors[n:2 * n], ctx.saved_tensors[2 * n:]
         idx = [i for i in range(n) if gs[i] is not None]
@@ -400,6 +456,7 @@ class MultiIaoWeight(Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        flush_wgrad_partials()          # (see MultiDorefaWeight.backward)
         ws = ctx.saved_tensors
         bits, q_type, rows, cols = ctx.cfg
         idx = [i for i in range(len(ws)) if gs[i] is not None]
@@ -1512,6 +1569,7 @@ class QConv2d(Function):
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         wd = _wq_desc(wdesc)
         ctx.packed = packed = getattr(wq, "_mn_packed", None) if wd is not None else None
+        ctx.defer_wgrad = bool(getattr(wq, "_mn_defer_wgrad", False))
         if packed is not None and packed[0] is not None:
             wd.packed_fwd = packed[0].data_ptr()
         codes = None
@@ -1589,6 +1647,9 @@ class QConv2d(Function):
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(wq)
                 db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
+                if getattr(ctx, "defer_wgrad", False) and not has_bias and aq_mode == ACTQ_IAO and \
+                        _defer_wgrad(g, aq, gy, x, dw, keep=(qp, getattr(ctx, "iao_codes", None))):
+                    return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
                 ws, nb = _ws(g, 2, x.device)
                 with _span(g, 2, 4 * (gy.numel() + x.numel() + dw.numel())):
                     _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
@@ -1755,7 +1816,7 @@ def pack_dense_weights(mods_wq, w_bits, qps=None):
         wq._mn_packed = o
 
 
-def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw, packed=None):
+def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw, packed=None, defer=False):
     """(dq, dw) of a conv on activation codes: mn_conv2d_bwd_data without clip-STE, mn_conv2d_bwd_weight on the codes."""
     gy = _chk(gy, "grad")
     aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
@@ -1768,9 +1829,10 @@ def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw, pack
             _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wd), _p(gy), _p(wq), None, _p(dq), _p(ws), nb, CONV_ALGO, _s())
     if need_dw:
         dw = torch.empty_like(wq)
-        ws, nb = _ws(g, 2, codes.device)
-        with _span(g, 2, 4 * gy.numel() + codes.numel() + 4 * dw.numel()):
-            _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), None, _p(ws), nb, CONV_ALGO, _s())
+        if not (defer and _defer_wgrad(g, aq, gy, codes, dw)):
+            ws, nb = _ws(g, 2, codes.device)
+            with _span(g, 2, 4 * gy.numel() + codes.numel() + 4 * dw.numel()):
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), None, _p(ws), nb, CONV_ALGO, _s())
     return dq, dw
 
 
@@ -1789,6 +1851,7 @@ class QConvCodeLazy(Function):
         ctx.cfg = (g, a_bits, w_bits, bias is not None)
         ctx.x_ref = x
         ctx.packed = packed = getattr(wq, "_mn_packed", None)
+        ctx.defer_wgrad = bool(getattr(wq, "_mn_defer_wgrad", False))
 
         def compute():          # a foreign consumer: the ordinary conv kernels on the materialised activation, quantizer in their prologue
             xa = x.materialize()
@@ -1821,8 +1884,9 @@ class QConvCodeLazy(Function):
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(wq)
                 db = torch.empty(g.O, dtype=torch.float32, device=codes.device) if has_bias else None
-                ws, nb = _ws(g, 2, codes.device)
-                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
+                if not (getattr(ctx, "defer_wgrad", False) and not has_bias and _defer_wgrad(g, aq, gy, codes, dw)):
+                    ws, nb = _ws(g, 2, codes.device)
+                    _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
         ctx.x_ref = None
         return dx, dw, db, None, None, None, None, None, None
 
@@ -1838,6 +1902,7 @@ class QConvCodeLazy2(Function):
         wq1, wq2 = _chk(wq1, "weight"), _chk(wq2, "weight")
         outs, geoms = [], []
         ctx.packed = (getattr(wq1, "_mn_packed", None), getattr(wq2, "_mn_packed", None))
+        ctx.defer_wgrad = (bool(getattr(wq1, "_mn_defer_wgrad", False)), bool(getattr(wq2, "_mn_defer_wgrad", False)))
         for wq, (stride, padding, dilation, groups) in ((wq1, cfg1), (wq2, cfg2)):
             g = _geom(codes.shape, wq.shape, stride, padding, dilation, groups, 0)
             Ho, Wo = _out_hw(g)
@@ -1859,8 +1924,8 @@ class QConvCodeLazy2(Function):
         geoms, a_bits, w_bits = ctx.cfg
         x = ctx.x_ref
         with torch.cuda.device_of(codes):
-            dq1, dw1 = _code_conv_backward(geoms[0], a_bits, w_bits, codes, wq1, gy1, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.packed[0])
-            dq2, dw2 = _code_conv_backward(geoms[1], a_bits, w_bits, codes, wq2, gy2, ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.packed[1])
+            dq1, dw1 = _code_conv_backward(geoms[0], a_bits, w_bits, codes, wq1, gy1, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.packed[0], ctx.defer_wgrad[0])
+            dq2, dw2 = _code_conv_backward(geoms[1], a_bits, w_bits, codes, wq2, gy2, ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.packed[1], ctx.defer_wgrad[1])
         dx = None
         if ctx.needs_input_grad[0]:
             def expand(dq_, dq2_=dq2):

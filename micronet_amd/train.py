@@ -92,6 +92,7 @@ def prefetch_weight_path(model, side=None):
     from micronet_amd import ops
     from micronet_amd.quantization.wbwtab import quantize as wb
     from micronet_amd.quantization.wqaq.dorefa import quantize as dr
+    ops.clear_wgrad_partials()          # (deferred backward-weight reductions of an aborted previous step)
     if side is None:
         # DoReFa nets: every conv / linear weight quantizer of one bit-width in one MultiDorefaWeight node (2 launches forward, 3 backward per step)
         by_bits = {}
@@ -108,6 +109,7 @@ def prefetch_weight_path(model, side=None):
                 qws = ops.MultiDorefaWeight.apply(bits, *[m.weight for m in grp])
                 for m, wq in zip(grp, qws):
                     m.weight_quantizer._mn_pre = (m.weight, wq, None)
+                    wq._mn_defer_wgrad = True          # d(wq) has ONE reader, this node's backward: the dense convs defer their partial-tile reduction to it (ops.flush_wgrad_partials)
                 if 2 <= bits <= 8:          # the dense layers (ResNets): their weight codes in both fragment orders, one launch for the net
                     ops.pack_dense_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], bits)
     if side is None:
@@ -143,6 +145,7 @@ def prefetch_weight_path(model, side=None):
                     if obs.num_flag == 0:
                         obs.num_flag += 1
                     m.weight_quantizer._mn_pre = (m.weight, wq, st[4])
+                    wq._mn_defer_wgrad = True
                 if cfg[1] == 0 and 2 <= cfg[0] <= 8:
                     convs = [(m, wq, st[4]) for m, wq, st in zip(grp, qws, state) if type(m) is ia.QuantConv2d]
                     ops.pack_dense_weights([(m, wq) for m, wq, _ in convs], cfg[0], qps=[qp for _, _, qp in convs])

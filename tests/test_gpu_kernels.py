@@ -365,6 +365,10 @@ def test_deployed_sign_block_identity_statistics(be, case):
     K.check_deployed_sign_block(be, seed=500 + case, **K.DEPLOYED_CASES[case])
 
 
+def test_qd_wgrad_deferred_reduction_bit_identical(be):
+    K.check_qd_wgrad_deferred(be)
+
+
 def test_code_classifier(be):
     K.check_code_classifier(be)
     K.check_code_classifier(be, N=2, Cc=130, H=2, W=2, Oc=16, bits=3, bias=False, seed=1)
