@@ -322,7 +322,8 @@ int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* 
  * y, a, da, dy: [N][C][HW] fp32 (HW % 4 == 0, 16-byte aligned).  save: [2][C] = mean, invstd (written by fwd, read by bwd).
  * training != 0: batch statistics; running_mean / running_var (nullable) are updated in place with `momentum` and the
  * unbiased variance, as nn.BatchNorm2d does.  training == 0: the running statistics normalise, nothing is updated.
- * ws: >= mn_bnsign_ws_floats(C) floats, 8-byte aligned. */
+ * ws: >= mn_bnsign_ws_floats(C) floats, 8-byte aligned.  The outputs must not alias the inputs (`a` != `y`, `dy` != `da`, `dy` != `y`): the apply pass of a
+ * training call finishes the statistics itself (every block re-reads the channel's partial sums and its first element of y). */
 int64_t mn_bnsign_ws_floats(int64_t C);
 int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                   int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream);

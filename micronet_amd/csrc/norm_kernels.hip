@@ -121,19 +121,73 @@ __global__ void k_bns_eval_stats(int C, float eps, const float* __restrict__ run
 }
 // MODE 0: a = sign(bn(y)).   MODE 1: dy (training: full BN backward; eval: statistics are constants)
 // OUT8 (MODE 0 only): a is written as int8 sign codes (0x01 / 0xFF), 4 per lane and store
+// The "final" step of the partial sums folded into the apply pass (fin.part != null): the S partials of channel c (written by the k_bns_partial launch in front)
+// are summed by EVERY block of that channel in the fixed order of k_bns_final_fwd / _bwd -- so all of them work with bit-identical statistics -- and block
+// sp == 0 writes what the final kernel used to write (save + running statistics; dgamma, dbeta, sums).  One launch less per BatchNorm and direction: 40 of a
+// resnet18 IAO step's ~300.
+struct BnsFin {
+    const double* part;            // [C][S][2] or null (then `save` / `sums` hold the finished values)
+    int S;
+    float eps, momentum;           // MODE 0
+    float* running_mean;           // MODE 0, nullable
+    float* running_var;
+    float* save_out;               // MODE 0: [2][C]
+    float* dgamma;                 // MODE 1, nullable
+    float* dbeta;
+    float* sums_out;               // MODE 1: [2][C]
+};
 template <int MODE, int OUT8 = 0>
 __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ da,
                                                    const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   const float* __restrict__ sums, int training, float* __restrict__ out, float* __restrict__ mm) {
+                                                   const float* __restrict__ sums, int training, float* __restrict__ out, float* __restrict__ mm, const BnsFin fin) {
     // mm (forward, fp32 output only; may be null): per-block min / max of the values written -> mm[block], mm[nblocks + block]: the NEXT layer's IAO observer
     // (wqaq/iao/quantize.py:23-36) reduces these instead of reading the activation again (mn_iao_observe_partials)
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
-    const float mean = save[c], invstd = save[g.C + c], ga = gamma[c], be = beta[c];
+    float mean, invstd;
+    const float ga = gamma[c], be = beta[c];
     float mlo = INFINITY, mhi = -INFINITY;
     float k1 = 0.f, k2 = 0.f;
-    if (MODE == 1 && training) {
-        const float n = (float)g.N * (float)g.HW;
-        k1 = sums[c] / n; k2 = sums[g.C + c] / n;
+    if (fin.part) {
+        __shared__ double fsum[2];
+        if (threadIdx.x == 0) {          // (block-uniform branch; S <= BNS_SPLIT sequential adds: the order of the former final kernels)
+            double s1 = 0.0, s2 = 0.0;
+            for (int i = 0; i < fin.S; ++i) { s1 += fin.part[((int64_t)c * fin.S + i) * 2]; s2 += fin.part[((int64_t)c * fin.S + i) * 2 + 1]; }
+            fsum[0] = s1; fsum[1] = s2;
+        }
+        __syncthreads();
+        const double s1 = fsum[0], s2 = fsum[1];
+        if (MODE == 0) {
+            const double n = (double)g.N * (double)g.HW;
+            const double m = s1 / n;
+            const double mean_d = (double)y[(int64_t)c * g.HW] + m;
+            const double ss = s2 - s1 * m;                 // sum of squared deviations
+            const float var_b = (float)(ss / n);
+            mean = (float)mean_d;
+            invstd = 1.0f / sqrtf(var_b + fin.eps);
+            if (sp == 0 && threadIdx.x == 0) {
+                fin.save_out[c] = mean;
+                fin.save_out[g.C + c] = invstd;
+                if (fin.running_mean) fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)mean_d;
+                if (fin.running_var) fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)(ss / (n - 1.0));
+            }
+        } else {
+            mean = save[c]; invstd = save[g.C + c];
+            if (training) {
+                const float n = (float)g.N * (float)g.HW;
+                k1 = (float)s1 / n; k2 = (float)s2 / n;
+            }
+            if (sp == 0 && threadIdx.x == 0) {
+                if (fin.dbeta) fin.dbeta[c] = (float)s1;
+                if (fin.dgamma) fin.dgamma[c] = (float)s2;
+                fin.sums_out[c] = (float)s1; fin.sums_out[g.C + c] = (float)s2;
+            }
+        }
+    } else {
+        mean = save[c]; invstd = save[g.C + c];
+        if (MODE == 1 && training) {
+            const float n = (float)g.N * (float)g.HW;
+            k1 = sums[c] / n; k2 = sums[g.C + c] / n;
+        }
     }
     const float gi = ga * invstd;
     float4 v_[2], gg_[2];
@@ -381,20 +435,23 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
     g.act = act;
     const int S = bns_split(g);
     const double nel = (double)N * C * HW;
+    BnsFin fin = {};
+    const bool fold = !MN_ENV("MN_BNS_NO_FOLD");          // A/B knob: the separate k_bns_final_* launches
     if (training) {
         mn_set_last_kernel("k_bns_partial<0>"); mn_prof_bytes(4.0 * nel); mn_prof_begin(s);
         hipLaunchKernelGGL(k_bns_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (double*)ws);
         mn_prof_end(s);
-        hipLaunchKernelGGL(k_bns_final_fwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, y, (const double*)ws, S, eps, momentum, running_mean, running_var, save);
+        if (fold) { fin.part = (const double*)ws; fin.S = S; fin.eps = eps; fin.momentum = momentum; fin.running_mean = running_mean; fin.running_var = running_var; fin.save_out = save; }
+        else hipLaunchKernelGGL(k_bns_final_fwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, y, (const double*)ws, S, eps, momentum, running_mean, running_var, save);
     } else {
         hipLaunchKernelGGL(k_bns_eval_stats, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (int)C, eps, (const float*)running_mean, (const float*)running_var, save);
     }
     mn_set_last_kernel(out8 ? "k_bns_apply<0, 1>" : "k_bns_apply<0, 0>"); mn_prof_bytes((out8 ? 5.0 : 8.0) * nel); mn_prof_begin(s);
     if (out8) hipLaunchKernelGGL((k_bns_apply<0, 1>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
-                                 (const float*)nullptr, training, a, (float*)nullptr);
+                                 (const float*)nullptr, training, a, (float*)nullptr, fin);
     else hipLaunchKernelGGL((k_bns_apply<0, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
-                            (const float*)nullptr, training, a, mm);
+                            (const float*)nullptr, training, a, mm, fin);
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bnsign_fwd");
     return MN_OK;
@@ -503,9 +560,11 @@ static int bnsign_bwd_impl(const float* da, const float* y, const float* save, c
     mn_set_last_kernel("k_bns_partial<1>"); mn_prof_bytes(8.0 * nel); mn_prof_begin(s);
     hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws);
     mn_prof_end(s);
-    hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
+    BnsFin fin = {};
+    if (!MN_ENV("MN_BNS_NO_FOLD")) { fin.part = (const double*)ws; fin.S = S; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.sums_out = sums; }
+    else hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
     mn_set_last_kernel("k_bns_apply<1, 0>"); mn_prof_bytes(12.0 * nel); mn_prof_begin(s);
-    hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy, (float*)nullptr);
+    hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy, (float*)nullptr, fin);
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bnsign_bwd");
     return MN_OK;
