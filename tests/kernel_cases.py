@@ -1475,7 +1475,7 @@ def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, Fa
         be.call("mn_bn2d_fwd_mm", be.ptr(dA), Nn, Cc, HW, be.ptr(one), be.ptr(zero), 0.0, 0.1, 0, be.ptr(zero), be.ptr(one), be.ptr(save), be.ptr(a_out), be.ptr(wsb),
                 be.ptr(mm_a), be.stream)
         assert np.array_equal(be.to_host(a_out), a)
-        nbk = 8
+        nbk = 1024 if n % 1024 == 0 and n >= 2048 else 8          # (more than 768 partials: the unrolled pass of k_qadd_final_p runs too)
         bb = b.reshape(nbk, -1)
         mm_b = be.to_dev(np.concatenate([bb.min(axis=1), bb.max(axis=1)]).astype(F))
         s3 = fresh()
