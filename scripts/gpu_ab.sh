@@ -1,0 +1,24 @@
+#!/bin/bash
+# A/B of environment knobs on one workload each: bash scripts/gpu_ab.sh   (prints workload, knob, images/s, ms/step)
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
+O=gpurun_out/ab; mkdir -p $O
+run() { # workload, label, env...
+  w=$1; l=$2; shift 2
+  env "$@" timeout 200 python bench.py --only $w --no-pmc --no-cpu-baseline --no-kernel-timing --repeats 3 > $O/${w}_$l.json 2> $O/${w}_$l.err
+  python - "$w" "$l" <<'PY'
+import json, sys
+w, l = sys.argv[1:3]
+try:
+    d = json.loads(open("gpurun_out/ab/%s_%s.json" % (w, l)).read().strip().splitlines()[-1])
+    print(w, l, d["value"], d["ms_per_step"], d.get("window_ms"))
+except Exception as e:
+    print(w, l, "failed", e)
+PY
+}
+run c4 base MN_X=0
+run c4 nodefer MN_DEFER_WGRAD=0
+run c5 base MN_X=0
+run c5 nodefer MN_DEFER_WGRAD=0
+run c5 nofold MN_BNS_NO_FOLD=1
+run c4 base2 MN_X=0
