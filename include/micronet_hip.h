@@ -470,7 +470,7 @@ int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, void* const* o
  * every dense conv of the step leaves its partial tiles in ITS OWN workspace (mn_qd_bwd_weight_partials: aq->mode MN_ACTQ_CODE8 with x = activation codes, or
  * MN_ACTQ_IAO with x = the fp32 activation; no bias gradient; ws of mn_qd_wgrad_partials_ws_bytes bytes, kept untouched until the reduction) and ONE launch sums
  * all of them (mn_qd_wgrad_reduce_multi: the same fixed-order fp64 sums as mn_conv2d_bwd_weight's own reduction, bit-identical dw).  19 launches less per
- * resnet18 step. */
+ * resnet18 step -- but measured 1 % SLOWER there (the deferred launch reads the partial tiles back from HBM instead of L2): the host side uses it on request only. */
 int mn_qd_wgrad_partials_supported(const mn_conv_geom* g, const mn_actq* aq);
 int64_t mn_qd_wgrad_partials_ws_bytes(const mn_conv_geom* g, const mn_actq* aq);
 int mn_qd_bwd_weight_partials(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const void* x, void* ws, int64_t ws_bytes, mn_stream_t stream);

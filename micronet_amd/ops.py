@@ -66,9 +66,12 @@ def _span(g, which, nbytes):
 # a multi-tensor weight-quantizer node (micronet_amd.train.prefetch_weight_path tags it ``_mn_defer_wgrad``) has exactly one reader of its d(quantised weight): that
 # node's backward, ONE launch at the end of the backward pass.  So the conv's backward leaves its split-K partial tiles in a workspace, returns the (not yet
 # written) dw tensor to autograd, and the node's backward first sums the partial tiles of ALL layers in one launch (bit-identical to the per-layer reductions).
-# Thread-local (one list per replica thread); MN_DEFER_WGRAD=0 switches it off.
+# Thread-local (one list per replica thread).  MEASURED (round 4, same box, c4 / c5 at batch 256): OFF is faster -- 4.183 vs 4.234 ms (c4), 5.312 vs 5.362 ms (c5).
+# The 19 per-layer reductions read partial tiles their own backward-weight kernel has just written (L2 / MALL hits); deferred, the ~300 MB of partial tiles of a
+# step are evicted before the one launch reads them back from HBM, which costs more than the 18 launches it saves.  So the path is OPT-IN (MN_DEFER_WGRAD=1): kept
+# for models whose reductions are many and small.
 import os as _os0
-DEFER_WGRAD = _os0.environ.get("MN_DEFER_WGRAD", "1") != "0"
+DEFER_WGRAD = _os0.environ.get("MN_DEFER_WGRAD", "0") == "1"
 
 
 class _WgradPending(threading.local):
