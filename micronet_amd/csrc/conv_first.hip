@@ -51,6 +51,7 @@ struct C1Params {
     const float* chan;
     int quant;            // dq is the gradient w.r.t. the QUANTISED activation (the clip-STE is applied here)
     float qs;             // quantizer scale 1 / (2^a - 1)
+    float qs_inv;         // RN(1 / qs) (qa_dz_m); 0: IEEE division
 };
 
 // stage the image strip (with zero halo) of image n, rows [row0 - ph, row0 + R + KH - 1 - ph) into xs[c][prow][pcol]
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
                         const float zh = (yv[e] - c0.x) * c0.y;
                         const float zz = zh * c0.z + c0.w;
                         float dz;
-                        if (BN == 2) dz = qa_dz(r[e], qa_relu(zz), zz, p.qs, p.quant);     // expression for expression k_qa_apply<1, 0>
+                        if (BN == 2) dz = qa_dz_m(r[e], qa_relu(zz), zz, p.qs, p.qs_inv, p.quant);     // expression for expression k_qa_apply<1, 0>
                         else dz = (zz > -1.f && zz < 1.f) ? r[e] : 0.f;
                         r[e] = cgi_ * (dz - c1.x - zh * c1.y);
                     }
@@ -637,7 +638,7 @@ static int c1_bwd_weight_any(const mn_conv_geom* g, const float* gy, const float
     p.wp = nullptr; p.bias = nullptr; p.y = nullptr;
     p.da = gy ? nullptr : da; p.yb = yb; p.save = save; p.gamma = gamma; p.beta = beta; p.sums = sums; p.training = training;
     p.n_f = (float)g->N * (float)(g->H * g->W);
-    p.chan = gy ? nullptr : chan; p.quant = quant; p.qs = qs;
+    p.chan = gy ? nullptr : chan; p.quant = quant; p.qs = qs; p.qs_inv = (qs > 0.f && !MN_ENV("MN_QA_IEEE_DIV")) ? 1.0f / qs : 0.f;
     mn_set_last_kernel("k_c1_wgrad<%d, %d>", pl.MT, p.da ? (p.chan ? 2 : 1) : 0);
     { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((p.da ? 8.0 : 4.0) * ny + 4.0 * g->N * g->C * g->H * g->W); }
     mn_prof_begin(s);

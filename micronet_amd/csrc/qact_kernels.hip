@@ -24,6 +24,7 @@ struct QaGeom {
     FastDiv fd_hw8, fd_w8;
     int64_t n8;             // 8-element groups per channel (no pool) / 4-window groups per channel (pool)
     float s;                // quantizer scale 1 / (2^a - 1)
+    float inv_s;            // RN(1 / s) for the division-free clip-STE (qa_dz_m); 0: the IEEE division
     int nthr;               // > 0 (mn_qa_fwd on the integer stash, <= 3 bit codes): levels 2^a - 1 of the integer-threshold forward
 };
 struct QaCh { float alpha, bias, mean, invstd, ga, be, A, B, gi; };
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void k_qa_partial(const QaGeom g, const void* 
             for (int e = 0; e < 8; ++e) {
                 float zh, z;
                 qa_eval<IN>(v[e], k, zh, z);
-                const float dz = qa_dz(gv[e], qa_relu(z), z, g.s, quant);
+                const float dz = qa_dz_m(gv[e], qa_relu(z), z, g.s, g.inv_s, quant);
                 t1 += dz; t2 += dz * zh;
             }
         } else {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void k_qa_partial(const QaGeom g, const void* 
                 float am = a[0], zm = zz[0], zhm = zhh[0];
 #pragma unroll
                 for (int e = 1; e < 4; ++e) if (kx == e) { am = a[e]; zm = zz[e]; zhm = zhh[e]; }
-                const float dz = qa_dz(gv[w], am, zm, g.s, quant);
+                const float dz = qa_dz_m(gv[w], am, zm, g.s, g.inv_s, quant);
                 t1 += dz; t2 += dz * zhm;
             }
         }
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void k_qa_apply(const QaGeom g, const void* __
             for (int e = 0; e < 8; ++e) {
                 float zh, z;
                 qa_eval<IN>(v[e], k, zh, z);
-                const float dz = qa_dz(gv[e], qa_relu(z), z, g.s, quant);
+                const float dz = qa_dz_m(gv[e], qa_relu(z), z, g.s, g.inv_s, quant);
                 r[e] = k.gi * (dz - k1 - zh * k2);
             }
             *reinterpret_cast<float4*>(dy + off) = make_float4(r[0], r[1], r[2], r[3]);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void k_qa_apply(const QaGeom g, const void* __
                 float rr[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float dz = (kx == e) ? qa_dz(gv[w], a[e], zz[e], g.s, quant) : 0.f;
+                    const float dz = (kx == e) ? qa_dz_m(gv[w], a[e], zz[e], g.s, g.inv_s, quant) : 0.f;
                     rr[e] = k.gi * (dz - k1 - zhh[e] * k2);
                 }
                 o0[2 * w] = rr[0]; o0[2 * w + 1] = rr[1]; o1[2 * w] = rr[2]; o1[2 * w + 1] = rr[3];
@@ -388,6 +389,7 @@ static int qa_geom(QaGeom* g, int64_t N, int64_t C, int64_t H, int64_t W, int bi
     g->fd_hw8 = make_fastdiv((uint32_t)g->HW8); g->fd_w8 = make_fastdiv((uint32_t)(g->W8 > 0 ? g->W8 : 1));
     g->n8 = pool ? N * (H / 2) * (W / 8) : N * (HW / 8);
     g->s = dorefa_scale(bits);
+    g->inv_s = MN_ENV("MN_QA_IEEE_DIV") ? 0.f : 1.0f / g->s;
     g->nthr = 0;
     return MN_OK;
 }
@@ -566,8 +568,8 @@ __global__ __launch_bounds__(256) void k_qr_partial(const QaGeom g, const void* 
             const float u = RES ? z + r[e] : z;
             const float a = qa_relu(u);
             float da = 0.f;
-            if (dq) da = dorefa_act_grad(d1[e], a, g.s);
-            if (dq2) da = da + dorefa_act_grad(d2[e], a, g.s);
+            if (dq) da = dorefa_act_grad_m(d1[e], a, g.s, g.inv_s);
+            if (dq2) da = da + dorefa_act_grad_m(d2[e], a, g.s, g.inv_s);
             if (gf) da = (dq || dq2) ? da + d3[e] : d3[e];
             const float dd = (u > 0.f) ? da : 0.f;
             o[e] = dd;

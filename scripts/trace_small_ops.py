@@ -14,6 +14,7 @@ arch, scheme, kw, wd = bench.WORKLOADS[key]
 Q = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
 model = Q.prepare(build_model(arch), inplace=True, **kw).cuda().train()
 opt = make_optimizer(model, 0.01, wd)
+opt.capturable = True          # the graphed step's optimizer path
 x, y = synth_batch(256, device="cuda")
 
 
@@ -31,7 +32,7 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step()
 torch.cuda.synchronize()
 want = ("aten::copy_", "aten::fill_", "aten::add", "aten::add_", "aten::zero_", "aten::clone", "aten::mul", "aten::div", "aten::div_", "aten::cat", "aten::sub", "aten::to",
@@ -39,7 +40,7 @@ want = ("aten::copy_", "aten::fill_", "aten::add", "aten::add_", "aten::zero_", 
 sites = {}
 for ev in prof.events():
     if ev.name in want:
-        st = [s for s in (ev.stack or []) if "micronet" in s or "bench" in s or "torch/autograd" in s][:3]
+        st = [s for s in (ev.stack or []) if "site-packages/torch/nn/modules/module.py" not in s and "torch/autograd/function.py" not in s][:4]
         k = (ev.name, tuple(st))
         sites[k] = sites.get(k, 0) + 1
 for (name, st), n in sorted(sites.items(), key=lambda kv: -kv[1])[:40]:
