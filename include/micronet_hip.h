@@ -256,6 +256,10 @@ typedef struct mn_actq {
     void* codes;     /* optional, MN_ACTQ_IAO on a dense layer (mn_conv2d_iao_codes_bytes(g, aq, wq) > 0): that many bytes owned by the caller.  mn_conv2d_fwd
                         writes the activation's signed codes there instead of into its workspace, and a later mn_conv2d_bwd_weight handed the SAME buffer (same x,
                         same qp) reads them instead of quantising x again.  NULL: every call quantises for itself. */
+    void* stats;     /* optional, MN_ACTQ_IAO forward of a dense layer on the int8 matrix cores (mn_conv2d_iao_stats_rows(g, aq, wq) = R > 0): R * O * 2 doubles owned
+                        by the caller.  mn_conv2d_fwd leaves the exact per-channel sums of the integer accumulator there -- stats[(r * O + o) * 2 + {0, 1}] = sum acc,
+                        sum acc^2 over the pixels of partial r -- from its epilogue: the BatchNorm behind the conv (models/resnet.py:17-29) then needs no statistics
+                        pass of its own (mn_bn_fwd_acc).  NULL: none. */
 } mn_actq;
 
 /* How the (already fake-quantised, fp32 OIHW) weight tensor factors into integer codes x per-channel scale.  The
@@ -298,6 +302,7 @@ int mn_conv2d_first_supported(const mn_conv_geom* g, int which);
 /* 1 if MN_ALGO_QGEMM supports this geometry and quantizer combination for `which` (aq / wq may be NULL = none / real) */
 int mn_conv2d_qgemm_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
 int64_t mn_conv2d_iao_codes_bytes(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);   /* size of mn_actq.codes for this layer; 0: not used */
+int64_t mn_conv2d_iao_stats_rows(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);   /* partial rows R of mn_actq.stats for this layer; 0: not available */
 /* y[N][O][Ho][Wo] = conv2d(actq(x), w, bias); w are the (already fake-quantised) fp32 weights, wq says how they factor
  * (NULL = MN_WQ_REAL) */
 int mn_conv2d_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w,
@@ -366,6 +371,13 @@ int mn_bn2d_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* g
 /* ... + per-block (min, max) of the output, mm: 2 * mn_bnrelu_mm_count(N, C, HW) floats */
 int mn_bn2d_fwd_mm(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, int training,
                    float* running_mean, float* running_var, float* save, float* a, float* ws, float* mm, mn_stream_t stream);
+/* BatchNorm2d [+ ReLU] in TRAINING mode behind a dense IAO conv whose forward left the exact sums of its integer accumulator (mn_actq.stats): y = al[c] * acc + cb[c]
+ * with al[c] = sa[0] * sw[c * sw_stride] (the conv epilogue's fp32 scale) and cb = the conv bias (nullable), so mean and variance of y follow in fp64 from
+ * (sum acc, sum acc^2) -- ONE streaming pass (normalise [+ ReLU] [+ per-block (min, max) -> mm, nullable]) instead of statistics pass + apply pass.  act: 1 ReLU
+ * (mn_bnrelu_fwd), 2 none (mn_bn2d_fwd).  save / running statistics / a as mn_bnsign_fwd; the backward is the ordinary mn_bnrelu_bwd / mn_bn2d_bwd. */
+int mn_bn_fwd_acc(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                  float* running_var, float* save, float* a, float* mm, int act, const double* stats, int64_t rows, const float* sa, const float* sw,
+                  int64_t sw_stride, const float* conv_bias, mn_stream_t stream);
 int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                 int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 /* the two halves of mn_bnsign_bwd for a consumer that forms dy itself: mn_bnsign_bwd_sums = dgamma, dbeta and sums [2][C] =

@@ -135,6 +135,13 @@ struct BnsFin {
     float* dgamma;                 // MODE 1, nullable
     float* dbeta;
     float* sums_out;               // MODE 1: [2][C]
+    // kind 1 (MODE 0): part = [S][C][2] EXACT sums of the integer accumulator of the dense IAO conv that produced y = al[c] * acc + cb[c] (mn_actq.stats): mean and
+    // variance of y in fp64 from them -- the arithmetic of k_qa_stats_prep -- and no statistics pass over y at all (mn_bn_fwd_acc)
+    int kind;
+    const float* sa;               // al[c] = sa[0] * sw[c * sw_stride], the fp32 product of the conv's epilogue
+    const float* sw;
+    int sw_stride;
+    const float* cbias;            // nullable
 };
 template <int MODE, int OUT8 = 0>
 __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ da,
@@ -149,7 +156,14 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
     float k1 = 0.f, k2 = 0.f;
     if (fin.part) {
         __shared__ double fsum[2];
-        if (threadIdx.x == 0) {          // (block-uniform branch; S <= BNS_SPLIT sequential adds: the order of the former final kernels)
+        if (MODE == 0 && fin.kind == 1) {          // partial rows [S][C][2]: up to 512 of them -- one wave sums them (fixed lane order), then a fixed-order tree
+            if (threadIdx.x < 64) {
+                double a1 = 0.0, a2 = 0.0;
+                for (int i = threadIdx.x; i < fin.S; i += 64) { a1 += fin.part[((int64_t)i * g.C + c) * 2]; a2 += fin.part[((int64_t)i * g.C + c) * 2 + 1]; }
+                a1 = wave_reduce(a1, OpAddD()); a2 = wave_reduce(a2, OpAddD());
+                if (threadIdx.x == 0) { fsum[0] = a1; fsum[1] = a2; }
+            }
+        } else if (threadIdx.x == 0) {          // (block-uniform branch; S <= BNS_SPLIT sequential adds: the order of the former final kernels)
             double s1 = 0.0, s2 = 0.0;
             for (int i = 0; i < fin.S; ++i) { s1 += fin.part[((int64_t)c * fin.S + i) * 2]; s2 += fin.part[((int64_t)c * fin.S + i) * 2 + 1]; }
             fsum[0] = s1; fsum[1] = s2;
@@ -158,9 +172,18 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
         const double s1 = fsum[0], s2 = fsum[1];
         if (MODE == 0) {
             const double n = (double)g.N * (double)g.HW;
-            const double m = s1 / n;
-            const double mean_d = (double)y[(int64_t)c * g.HW] + m;
-            const double ss = s2 - s1 * m;                 // sum of squared deviations
+            double m, mean_d, ss;
+            if (fin.kind == 1) {
+                const double al = (double)(fin.sa[0] * fin.sw[(int64_t)c * fin.sw_stride]);
+                m = s1 / n;
+                mean_d = al * m + (double)(fin.cbias ? fin.cbias[c] : 0.f);
+                ss = al * al * (s2 - s1 * m);
+                if (ss < 0.0) ss = 0.0;
+            } else {
+                m = s1 / n;
+                mean_d = (double)y[(int64_t)c * g.HW] + m;
+                ss = s2 - s1 * m;                 // sum of squared deviations
+            }
             const float var_b = (float)(ss / n);
             mean = (float)mean_d;
             invstd = 1.0f / sqrtf(var_b + fin.eps);
@@ -541,6 +564,28 @@ extern "C" int mn_bn2d_fwd(const float* y, int64_t N, int64_t C, int64_t HW, con
 extern "C" int mn_bn2d_fwd_mm(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                               int training, float* running_mean, float* running_var, float* save, float* a, float* ws, float* mm, mn_stream_t stream) {
     return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream, 2, mm);
+}
+// training-mode BatchNorm2d [+ ReLU] from the exact accumulator sums of the dense IAO conv in front (mn_actq.stats): ONE pass over y
+extern "C" int mn_bn_fwd_acc(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                             float* running_var, float* save, float* a, float* mm, int act, const double* stats, int64_t rows, const float* sa, const float* sw,
+                             int64_t sw_stride, const float* conv_bias, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, y, a, "mn_bn_fwd_acc");
+    if (rc) return rc;
+    if (!y || !gamma || !beta || !save || !a || !stats || !sa || !sw || rows <= 0 || rows > 65536 || (act != 1 && act != 2) || (((uintptr_t)stats) & 7))
+        MN_FAIL(MN_EINVAL, "mn_bn_fwd_acc: null / misaligned argument");
+    hipStream_t s = (hipStream_t)stream;
+    BnsGeom g = bns_geom(N, C, HW);
+    g.act = act;
+    const int S = bns_split(g);
+    BnsFin fin = {};
+    fin.part = stats; fin.S = (int)rows; fin.eps = eps; fin.momentum = momentum; fin.running_mean = running_mean; fin.running_var = running_var; fin.save_out = save;
+    fin.kind = 1; fin.sa = sa; fin.sw = sw; fin.sw_stride = (int)sw_stride; fin.cbias = conv_bias;
+    mn_set_last_kernel("k_bns_apply<0, 0>"); mn_prof_bytes(8.0 * (double)N * C * HW); mn_prof_begin(s);
+    hipLaunchKernelGGL((k_bns_apply<0, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
+                       (const float*)nullptr, 1, a, mm, fin);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_bn_fwd_acc");
+    return MN_OK;
 }
 extern "C" int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                            int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {

@@ -1554,6 +1554,11 @@ static int qd_iao_quant_ok(const mn_conv_geom* g, const mn_actq* aq, const mn_wq
 }
 int qd_iao_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
 static int64_t qd_iao_codes_bytes(const mn_conv_geom* g) { return ((int64_t)g->N * g->C * g->H * g->W + 255) / 256 * 256; }
+extern "C" int64_t mn_conv2d_iao_stats_rows(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
+    QdfPlan pl;
+    if (!qd_iao_quant_ok(g, aq, wq, 1) || !qd_fwd_i8(wq) || !plan_qdf(g, 2, &pl, 1) || MN_ENV("MN_QD_NO_EPI_STATS")) return 0;
+    return pl.grid / pl.p.ncot;
+}
 extern "C" int64_t mn_conv2d_iao_codes_bytes(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
     if (!g || !aq || !wq || !qd_iao_supported(g, aq, wq, 0) || !qd_iao_supported(g, aq, nullptr, 2)) return 0;
     return qd_iao_codes_bytes(g);
@@ -1593,7 +1598,7 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
         qd_launch_pack(w, reinterpret_cast<uint16_t*>((char*)ws + cb), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s, wq->scale, wq->per_channel);
         wpk = reinterpret_cast<const uint16_t*>((char*)ws + cb);
     }
-    p.stats = nullptr;
+    p.stats = (i8 && aq->stats && !MN_ENV("MN_QD_NO_EPI_STATS")) ? reinterpret_cast<double*>(aq->stats) : nullptr;          // exact sums of acc for the BatchNorm behind (mn_bn_fwd_acc)
     p.x = (const unsigned char*)cbuf; p.wpk = wpk; p.stash = y; p.xsgn = 1; p.sa = aq->qp; p.sw = wq->scale; p.sw_stride = wq->per_channel; p.bias = bias;
     mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + 4.0 * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }

@@ -1333,6 +1333,30 @@ class _PendingMinMax(threading.local):
 _PENDING_MINMAX = _PendingMinMax()
 
 
+class _PendingAccStats(threading.local):
+    """Hand-over of a dense IAO conv's epilogue statistics (exact per-channel sums of its integer accumulator: mn_actq.stats) from inside ``QConv2d.forward`` to the
+    module that called it, which attaches them to the conv's output for the BatchNorm behind it (``BNReLU`` -> mn_bn_fwd_acc: no statistics pass over y)."""
+
+    def __init__(self):
+        self.slot = [None]
+
+    def __getitem__(self, i):
+        return self.slot[i]
+
+    def __setitem__(self, i, v):
+        self.slot[i] = v
+
+
+_PENDING_ACCSTATS = _PendingAccStats()
+WANT_ACCSTATS = 0x100          # Python-side bit of ``aq_flags`` (never passed to the library): request mn_actq.stats from the forward
+
+
+def take_accstats():
+    st, _PENDING_ACCSTATS[0] = _PENDING_ACCSTATS[0], None
+    return st
+
+
+
 def take_minmax():
     """(mm, count) left by the last forward OF THIS THREAD that was asked for per-block (min, max) partials of its output, or None; cleared by the call."""
     v = _PENDING_MINMAX[0]
@@ -1364,14 +1388,26 @@ class BNReLU(Function):
     the activation (plain nn.BatchNorm2d: ``BatchNorm2dPlain``)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, fn="mn_bnrelu", want_minmax=False):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, fn="mn_bnrelu", want_minmax=False, accstats=None):
         y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
         N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
         a = torch.empty_like(y)
         save = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
         with torch.cuda.device_of(y):
-            if want_minmax and fn in ("mn_bnrelu", "mn_bn2d"):
+            if accstats is not None and training and fn in ("mn_bnrelu", "mn_bn2d") and accstats[0].shape[1] == Cc:
+                # y came out of a dense IAO conv that left the exact sums of its integer accumulator: batch statistics from those, ONE pass over y
+                stats, rows, qp, wscale, sw_stride, cbias = accstats
+                mm = None
+                if want_minmax:
+                    count = int(_lib_().mn_bnrelu_mm_count(N, Cc, HW))
+                    mm = torch.empty(2 * count, dtype=torch.float32, device=y.device)
+                with _span(None, 3, 8 * y.numel()):
+                    _call("mn_bn_fwd_acc", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), _p(save), _p(a), _p(mm),
+                          1 if fn == "mn_bnrelu" else 2, _p(stats), int(rows), _p(qp), _p(wscale), int(sw_stride), _p(cbias), _s())
+                if mm is not None:
+                    _PENDING_MINMAX[0] = (mm, count)
+            elif want_minmax and fn in ("mn_bnrelu", "mn_bn2d"):
                 count = int(_lib_().mn_bnrelu_mm_count(N, Cc, HW))
                 mm = torch.empty(2 * count, dtype=torch.float32, device=y.device)
                 _call(fn + "_fwd_mm", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum), int(training), _p(running_mean),
@@ -1394,7 +1430,7 @@ class BNReLU(Function):
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
         with torch.cuda.device_of(y):
             _call(ctx.fn + "_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, ctx.training, _p(dy), _p(dgamma), _p(dbeta), _p(ws), _s())
-        return dy, dgamma, dbeta, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class GlobalAvgPool(Function):
@@ -1569,10 +1605,17 @@ class QConv2d(Function):
         g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle)
         Ho, Wo = _out_hw(g)
         y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
+        want_stats, aq_flags = bool(aq_flags & WANT_ACCSTATS), aq_flags & ~WANT_ACCSTATS
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         wd = _wq_desc(wdesc)
         ctx.packed = packed = getattr(wq, "_mn_packed", None) if wd is not None else None
         ctx.defer_wgrad = bool(getattr(wq, "_mn_defer_wgrad", False))
+        stats = None
+        if want_stats and aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and wdesc[4] is not None:
+            rows = int(_lib_().mn_conv2d_iao_stats_rows(C.byref(g), C.byref(aq), C.byref(wd)))
+            if rows > 0:          # dense layer on the int8 matrix cores: exact sums of acc / acc^2 per channel from the epilogue, for the BatchNorm behind the conv
+                stats = torch.empty((rows, g.O, 2), dtype=torch.float64, device=x.device)
+                aq.stats = stats.data_ptr()
         if packed is not None and packed[0] is not None:
             wd.packed_fwd = packed[0].data_ptr()
         codes = None
@@ -1586,6 +1629,8 @@ class QConv2d(Function):
             with _span(g, 0, 4 * (x.numel() + y.numel() + wq.numel())):
                 _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _ref(wd), _p(x), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
         wscale = wdesc[4] if wdesc is not None else None
+        if stats is not None:          # (stats, rows, activation qparams, per-channel weight scale, its stride, conv bias): what mn_bn_fwd_acc reads
+            _PENDING_ACCSTATS[0] = (stats, stats.shape[0], qp, wscale, int(wdesc[3]), bias)
         ctx.iao_codes = codes
         ctx.save_for_backward(x, wq, qp, wscale)
         ctx.cfg = (g, aq_mode, aq_bits, aq_qtype, bias is not None, wdesc[:4] if wdesc is not None else None, aq_flags)
@@ -2145,7 +2190,7 @@ def channel_shuffle(x, groups):
 
 
 def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None,
-            wdesc=None, x_is_code=False, in_shuffle=0, lazy_for_bn=False):
+            wdesc=None, x_is_code=False, in_shuffle=0, lazy_for_bn=False, want_accstats=False):
     """``in_shuffle`` > 1: the convolution of ``channel_shuffle(x, in_shuffle)``; the permutation is folded into the kernels'
     channel addressing when the code-domain kernels cover all three passes, else materialised."""
     packed = isinstance(x, SignTensor)
@@ -2163,7 +2208,7 @@ def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ
             if in_shuffle and in_shuffle > 1:
                 x, in_shuffle = channel_shuffle(x, in_shuffle), 0
     return QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc,
-                         _lib.MN_ACTQ_X_IS_CODE if x_is_code else 0, in_shuffle or 0)
+                         (_lib.MN_ACTQ_X_IS_CODE if x_is_code else 0) | (WANT_ACCSTATS if want_accstats else 0), in_shuffle or 0)
 
 
 class QLinearSmall(Function):

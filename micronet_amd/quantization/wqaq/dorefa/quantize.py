@@ -190,6 +190,14 @@ def _swap_conv(child, cls, **kw):
     return new
 
 
+def _accstats_of(t):
+    """the exact accumulator sums a dense IAO conv left on its output ``t`` (``_mn_accstats``), or None -- also None once the tensor was written in place since"""
+    st = getattr(t, "_mn_accstats", None)
+    if st is None or st[-1] != t._version:
+        return None
+    return st[:-1]
+
+
 class BatchNorm2dReLU(nn.BatchNorm2d):
     """``nn.BatchNorm2d`` whose forward also applies the ReLU behind it (same parameters, buffers and ``state_dict`` keys): one fused
     gfx950 op (ops.BNReLU: three streaming passes forward, five backward, z never stored) instead of MIOpen's BatchNorm kernels plus
@@ -235,15 +243,16 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
                 self.num_batches_tracked.add_(1)
             if self.momentum is None:
                 momentum = 1.0 / float(self.num_batches_tracked)
+        acc = _accstats_of(input) if (self.training and self.track_running_stats) else None
         if self.emit_minmax and self.training:
             out = ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                                   self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, "mn_bnrelu", True)
+                                   self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, "mn_bnrelu", True, acc)
             mm = ops.take_minmax()
             if mm is not None:
                 out._mn_minmax = mm + (out._version,)          # (valid only while nothing writes into the tensor in place)
             return out
         return ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                                self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch)
+                                self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, "mn_bnrelu", False, acc)
 
 
 class BatchNorm2dPlain(nn.BatchNorm2d):
@@ -261,15 +270,16 @@ class BatchNorm2dPlain(nn.BatchNorm2d):
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             if not self.__dict__.pop("_mn_nbt_pre", False):
                 self.num_batches_tracked.add_(1)
+        acc = _accstats_of(input) if (self.training and self.track_running_stats) else None
         if self.emit_minmax and self.training:          # (set by the IAO prepare: an IAO QuantAdd observes this output)
             out = ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                                   self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d", True)
+                                   self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d", True, acc)
             mm = ops.take_minmax()
             if mm is not None:
                 out._mn_minmax = mm + (out._version,)
             return out
         return ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                                self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d")
+                                self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d", False, acc)
 
 
 class MaxPool2dF32(nn.MaxPool2d):

@@ -27,6 +27,7 @@ from micronet_amd.base_module.op import Add
 
 _FUSE_G3 = os.environ.get("MN_NO_G3") is None          # A/B knob: the grouped 3 x 3 layers on the generic kernels
 _PRODUCER_MINMAX = os.environ.get("MN_NO_PRODUCER_MINMAX") is None          # A/B knob: observers read the tensor themselves
+_PRODUCER_ACCSTATS = os.environ.get("MN_NO_PRODUCER_ACCSTATS") is None      # A/B knob: the BatchNorm behind a dense conv makes its own statistics pass
 _FUSE_BNFUSE = os.environ.get("MN_NO_BNFUSE_BLOCK") is None                 # A/B knob: QuantBNFuseConv2d on the generic kernels (raw conv + statistics passes)
 
 __all__ = ["ObserverBase", "MinMaxObserver", "MovingAverageMinMaxObserver", "HistogramObserver", "Round", "Quantizer",
@@ -300,10 +301,19 @@ class QuantConv2d(nn.Conv2d):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
         self.weight_quantizer = _weight_quantizer(w_bits, q_type, q_level, weight_observer, out_channels, "C", qaft, ptq)
 
+    emit_accstats = False      # set by prepare(): a BatchNorm2dReLU / BatchNorm2dPlain of ours reads this conv's output next -- in training the forward leaves the exact
+                               # sums of its integer accumulator (dense layers: mn_actq.stats) on the output tensor, and that BatchNorm needs no statistics pass
+
     def _qconv(self, input, weight, bias, quantized=True):
         mode, bits, q_type, qp = _fused_aq(self.activation_quantizer, input)
-        return ops.qconv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups,
-                           aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp, wdesc=_wdesc(self.weight_quantizer, quantized))
+        want = bool(self.emit_accstats and self.training and quantized and _PRODUCER_ACCSTATS)
+        out = ops.qconv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups,
+                          aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp, wdesc=_wdesc(self.weight_quantizer, quantized), want_accstats=want)
+        if want:
+            st = ops.take_accstats()
+            if st is not None and type(out) is torch.Tensor:
+                out._mn_accstats = st + (out._version,)          # (valid only while nothing writes into the tensor in place)
+        return out
 
     def forward(self, input):
         # (the reference quantises the input first; the two quantizers are independent, order is immaterial)
@@ -750,6 +760,14 @@ def _fuse_residual_tails(model):
                 if type(child) is nn.BatchNorm2d and child.affine and child.track_running_stats:
                     child.__class__ = BatchNorm2dPlain
                     child.emit_minmax = _PRODUCER_MINMAX          # (an IAO QuantAdd observes this output: its two input observers then read partials only)
+    # conv -> BatchNorm (ours) adjacency inside a Sequential: the conv's forward hands the exact sums of its integer accumulator to that BatchNorm (dense layers)
+    from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dReLU
+    for m in model.modules():
+        if isinstance(m, nn.Sequential):
+            kids = list(m.children())
+            for a_, b_ in zip(kids, kids[1:]):
+                if type(a_) is QuantConv2d and isinstance(b_, (BatchNorm2dReLU, BatchNorm2dPlain)) and b_.affine and b_.track_running_stats:
+                    a_.emit_accstats = True
     for m in model.modules():
         t = type(m)
         if t.__name__ in ("BasicBlock", "BottleNeck") and t.__module__.split(".")[-1] == "resnet" and isinstance(getattr(m, "add", None), QuantAdd) \

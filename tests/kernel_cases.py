@@ -1410,6 +1410,45 @@ def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=Fa
     y3 = be.to_host(be.conv_fwd(g, aq0, dX, dWn, None, 3, wq=wq))
     dx3 = be.to_host(be.conv_bwd_data(g, aq0, dG, dWn, dX, 3, wq=wq))
     assert np.array_equal(y1, y3) and np.array_equal(dx1, dx3)
+    # ---- the exact sums of the integer accumulator from the forward's epilogue (mn_actq.stats) and the BatchNorm behind the conv from them (mn_bn_fwd_acc: ONE pass)
+    # == the ordinary statistics pass + apply pass over y (mn_bnrelu_fwd / mn_bn2d_fwd), to the round-off of fp32 statistics
+    aqs = be.actq(2, a_bits, 0, dqp)
+    rows = int(be.lib.mn_conv2d_iao_stats_rows(C.byref(g), C.byref(aqs), C.byref(wq)))
+    assert rows > 0, "no epilogue statistics for this dense IAO layer"
+    stats = be.to_dev(np.full((rows, Oc, 4), np.nan, dtype=F))          # rows * Oc * 2 doubles
+    aqs.stats = be.ptr(stats).value
+    cb = (r.standard_normal(Oc) * 0.3).astype(F) if bias else None
+    dCB = be.to_dev(cb) if bias else None
+    dY = be.conv_fwd(g, aqs, dX, dWn, dCB, 3, wq=wq)
+    yv = be.to_host(dY)
+    N_, _, Ho, Wo = yv.shape
+    HW = Ho * Wo
+    st = be.to_host(stats).view(np.float64).reshape(rows, Oc, 2).sum(axis=0)
+    al = (F(sc[0]) * wscale.astype(F)).astype(np.float64)
+    acc = (yv.astype(np.float64) - (cb.astype(np.float64).reshape(1, -1, 1, 1) if bias else 0.0)) / al.reshape(1, -1, 1, 1)
+    acc = np.rint(acc)
+    assert np.array_equal(st[:, 0], acc.sum(axis=(0, 2, 3))) and np.array_equal(st[:, 1], (acc * acc).sum(axis=(0, 2, 3))), "epilogue sums of acc / acc^2 are not exact"
+    if HW % 4 == 0:
+        gamma, beta = (r.standard_normal(Oc) * 0.5 + 1).astype(F), (r.standard_normal(Oc) * 0.3).astype(F)
+        rm, rv = (r.standard_normal(Oc) * 0.1).astype(F), (np.abs(r.standard_normal(Oc)) + 0.5).astype(F)
+        dGa, dBe = be.to_dev(gamma), be.to_dev(beta)
+        ws = be.empty(int(be.lib.mn_bnsign_ws_floats(Oc)) + 8)
+        for act, fn in ((1, "mn_bnrelu_fwd_mm"), (2, "mn_bn2d_fwd_mm")):
+            cnt = int(be.lib.mn_bnrelu_mm_count(N_, Oc, HW))
+            rm1, rv1, rm2, rv2 = be.to_dev(rm), be.to_dev(rv), be.to_dev(rm), be.to_dev(rv)
+            s1, s2, a1, a2, mm1, mm2 = be.empty((2, Oc)), be.empty((2, Oc)), be.empty(yv.shape), be.empty(yv.shape), be.empty(2 * cnt), be.empty(2 * cnt)
+            be.call(fn, be.ptr(dY), N_, Oc, HW, be.ptr(dGa), be.ptr(dBe), 1e-5, 0.1, 1, be.ptr(rm1), be.ptr(rv1), be.ptr(s1), be.ptr(a1), be.ptr(ws), be.ptr(mm1), be.stream)
+            be.call("mn_bn_fwd_acc", be.ptr(dY), N_, Oc, HW, be.ptr(dGa), be.ptr(dBe), 1e-5, 0.1, be.ptr(rm2), be.ptr(rv2), be.ptr(s2), be.ptr(a2), be.ptr(mm2), act,
+                    be.ptr(stats), rows, be.ptr(dqp), be.ptr(dWs), 1, be.ptr(dCB) if bias else None, be.stream)
+            sv1, sv2 = be.to_host(s1), be.to_host(s2)
+            assert np.max(np.abs(sv1[0] - sv2[0])) <= 2e-6 * max(np.max(np.abs(sv1[0])), 1e-3) + 1e-7, ("mean", act)
+            assert np.max(np.abs(sv1[1] - sv2[1]) / sv1[1]) <= 5e-6, ("invstd", act)
+            assert close(be.to_host(rm2), be.to_host(rm1), 2e-6) and close(be.to_host(rv2), be.to_host(rv1), 1e-5), ("running statistics", act)
+            o1, o2 = be.to_host(a1), be.to_host(a2)
+            assert np.max(np.abs(o1 - o2)) <= 1e-5 * max(np.max(np.abs(o1)), 1e-6), ("output", act, float(np.max(np.abs(o1 - o2))))
+            # its (min, max) partials describe ITS output exactly
+            m2 = be.to_host(mm2)
+            assert m2[:cnt].min() == o2.min() and m2[cnt:].max() == o2.max(), ("min / max partials", act)
 
 
 def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, False), update=True, seed=0, relu=False):
