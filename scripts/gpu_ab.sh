@@ -16,13 +16,7 @@ except Exception as e:
     print(w, l, "failed", e)
 PY
 }
-run c1_w2a2 base MN_X=0
-run c1_w2a2 ieee MN_QA_IEEE_DIV=1
-run c1 base MN_X=0
-run c1 ieee MN_QA_IEEE_DIV=1
-run c1 nt2 MN_PWS_NT=2
-run c1 cap1024 MN_PWS_CAP=1024
-run c1 cap256 MN_PWS_CAP=256
+run c5 base MN_X=0
+run c5 noacc MN_NO_PRODUCER_ACCSTATS=1
+run c5 base2 MN_X=0
 run c4 base MN_X=0
-run c4 ieee MN_QA_IEEE_DIV=1
-run c1_w2a2 base2 MN_X=0
