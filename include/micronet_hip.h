@@ -447,6 +447,14 @@ int mn_conv2d_bwd_data_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* 
                            int training, const float* w, float* dx, void* ws, int64_t ws_bytes, mn_stream_t stream);
 int mn_conv2d_bwd_weight_bnh(const mn_conv_geom* g, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
                              const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
+/* ... and behind a block whose output goes through a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119): the pool's backward is folded in as well.  dpool =
+ * d loss / d (pooled output) [N][O][H/2][W/2] (8-byte aligned), own = the block's own sign output [N][O][H][W]: a window's gradient goes to its first +1 in scan
+ * order (ATen's max_pool2d backward), exactly what mn_bnh_bwd_apply(own != NULL) writes -- that full-size dy is then never written or read. */
+int mn_conv2d_bnh_pool_supported(const mn_conv_geom* g, const mn_wq* wq);
+int mn_conv2d_bwd_data_bnh_pool(const mn_conv_geom* g, const mn_wq* wq, const float* dpool, const uint8_t* h, const int8_t* own, const float* chan,
+                                const float* sums, int training, const float* w, float* dx, void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_conv2d_bwd_weight_bnh_pool(const mn_conv_geom* g, const float* dpool, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
+                                  int training, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
 /* same backward when a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119) sits behind the block: `dpool` = d loss / d pool(a),
  * [N][O][H/2][W/2] fp32, `a_own` = the block's own output codes (what mn_qconv_bnsign_fwd wrote); the pool's backward (gradient to
  * the first maximum of each window) is applied while the gradient is read -- a quarter of the bytes, no full-size da tensor. */

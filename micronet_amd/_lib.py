@@ -107,6 +107,9 @@ PROTOTYPES = {
     "mn_conv2d_bnh_supported": (_I, [_G, _W]),
     "mn_conv2d_bwd_data_bnh": (_I, [_G, _W, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
     "mn_conv2d_bwd_weight_bnh": (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    "mn_conv2d_bnh_pool_supported": (_I, [_G, _W]),
+    "mn_conv2d_bwd_data_bnh_pool": (_I, [_G, _W, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
+    "mn_conv2d_bwd_weight_bnh_pool": (_I, [_G, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_qconv_bnsign_bwd": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_qconv_bnsign_bwd_pooled": (_I, [_G, _W, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_signconv1x1_small_supported": (_I, [_L, _L, _L]),

@@ -818,6 +818,25 @@ extern "C" int mn_conv2d_bwd_weight_bnh(const mn_conv_geom* g, const float* da, 
     if (!da || !h || !chan || !sums || !x || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null tensor");
     return pws_bwd_weight_bnh(g, da, h, chan, sums, training, x, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
 }
+// the same two behind a block whose output is MAX-POOLED (2x2 / stride 2): dpool = d loss / d pooled output [N][O][H/2][W/2], own = the block's sign output
+extern "C" int mn_conv2d_bnh_pool_supported(const mn_conv_geom* g, const mn_wq* wq) {
+    if (check_geom(g, "mn_conv2d_bnh_pool_supported") != MN_OK) return 0;
+    return pwd_supported(g, wq) && pws_wgrad_staged(g) && !(g->H & 1) && !(g->W & 3);
+}
+extern "C" int mn_conv2d_bwd_data_bnh_pool(const mn_conv_geom* g, const mn_wq* wq, const float* dpool, const uint8_t* h, const int8_t* own, const float* chan,
+                                           const float* sums, int training, const float* w, float* dx, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_data_bnh_pool");
+    if (rc) return rc;
+    if (!dpool || !h || !own || !chan || !sums || !w || !dx) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data_bnh_pool: null tensor");
+    return pwd_bwd_data_bnh(g, wq, dpool, h, chan, sums, training, w, dx, ws, ws_bytes, (hipStream_t)stream, own);
+}
+extern "C" int mn_conv2d_bwd_weight_bnh_pool(const mn_conv_geom* g, const float* dpool, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
+                                             int training, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_weight_bnh_pool");
+    if (rc) return rc;
+    if (!dpool || !h || !own || !chan || !sums || !x || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh_pool: null tensor");
+    return pws_bwd_weight_bnh(g, dpool, h, chan, sums, training, x, dw, dbias, ws, ws_bytes, (hipStream_t)stream, own);
+}
 extern "C" int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta,
                                              const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                                              mn_stream_t stream) {

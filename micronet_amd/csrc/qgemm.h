@@ -36,8 +36,9 @@ int pws_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, floa
 int pwd_supported(const mn_conv_geom* g, const mn_wq* wq);
 int64_t pwd_ws_bytes(const mn_conv_geom* g);
 int pwd_bwd_data_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
-                     const float* w, float* dx, void* ws, int64_t ws_bytes, hipStream_t s);
+                     const float* w, float* dx, void* ws, int64_t ws_bytes, hipStream_t s, const int8_t* own = nullptr);
 int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* da, const uint8_t* h, const float* chan, const float* sums, int training, const int8_t* x,
-                       float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+                       float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s, const int8_t* own = nullptr);
+int pws_wgrad_staged(const mn_conv_geom* g);          // the LDS-staged backward-weight kernel covers this geometry (the pooled BatchNorm fold lives there only)
 int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s);

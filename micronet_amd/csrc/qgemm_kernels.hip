@@ -339,6 +339,11 @@ struct PwdParams {
     const float* sums;        // [2][G*Kc]
     int training;
     float n_f;
+    // BNH 2: a 2x2 / stride-2 max-pool sits behind the block: gy is the POOLED gradient [N][G*Kc][H/2][W/2] and `own` the block's own sign output [N][G*Kc][H][W];
+    // the gradient of a window goes to its first +1 in scan order (ATen's max_pool2d backward), as in k_bnh_apply<1> -- whose full-size dy is then never written
+    const char* own;
+    int W;
+    FastDiv fd_w;
 };
 template <int NT, int KS, int BNH>
 __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
@@ -400,6 +405,23 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
         const uint32_t n = fd_div(P, p.fd_hw);
         const uint32_t go = n * (uint32_t)p.Cin_total * HW + (P - n * HW);
         const u32x4 o0 = *reinterpret_cast<const u32x4*>(koff + s * 32 + kg * 8), o1 = *reinterpret_cast<const u32x4*>(koff + s * 32 + kg * 8 + 4);
+        if (BNH == 2) {
+            // the lane's pixel quad (row hr, columns w .. w + 3) covers half of two pooling windows: raw = {g[win 0], g[win 1], own codes of row hr & ~1, of row hr | 1}
+            const uint32_t pp = P - n * HW;
+            const uint32_t hr = fd_div(pp, p.fd_w), w = pp - hr * (uint32_t)p.W;
+            const uint32_t gbase = n * (uint32_t)p.Cin_total * (HW >> 2) + (hr >> 1) * ((uint32_t)p.W >> 1) + (w >> 1);      // + channel * HW / 4
+            const uint32_t cbase = n * (uint32_t)p.Cin_total * HW + (hr & ~1u) * (uint32_t)p.W + w;                          // + channel * HW
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t ko = e < 4 ? o0[e & 3] : o1[e & 3];
+                const float2 g2 = *reinterpret_cast<const float2*>(p.gy + (gbase + (ko >> 2)));
+                const uint32_t r0 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + ko));
+                const uint32_t r1 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + ko + (uint32_t)p.W));
+                raw[e] = make_float4(g2.x, g2.y, mn_u2f(r0), mn_u2f(r1));
+                hb[e] = *reinterpret_cast<const uint32_t*>(p.h + (go + ko));
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             raw[e] = *reinterpret_cast<const float4*>(p.gy + (go + o0[e]));
@@ -424,6 +446,13 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
     auto step = [&](float4 (&raw)[8], uint32_t (&hb)[8], int it) {
         const int ci = it / KS, s = it - ci * KS;
         float v[8][4];
+        uint32_t hbit = 0u;          // BNH 2: the parity of this lane's image row (which half of its pooling windows it holds)
+        if (BNH == 2) {
+            uint32_t P = (uint32_t)(chunk0 + ci * cstride) * 64u + 4u * j;
+            P = P < Pmax ? P : Pmax;
+            const uint32_t n = fd_div(P, p.fd_hw);
+            hbit = fd_div(P - n * HW, p.fd_w) & 1u;
+        }
         if (BNH) {
             // operand = BatchNorm+sign backward of (da, h), already times the weight scale: G*dz + E1*h + E0
 #pragma unroll
@@ -434,7 +463,19 @@ __global__ __launch_bounds__(256, 2) void k_pwd(const PwdParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float4 d4 = raw[half * 4 + e];
-                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    if (BNH == 2) {          // route the two windows' gradients to their first +1 (row-major), else to element 0 -- only if that element is in THIS row
+                        const uint32_t r0 = mn_f2u(d4.z), r1 = mn_f2u(d4.w);
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const bool p00 = !((r0 >> (16 * e2)) & 0x80u), p01 = !((r0 >> (16 * e2 + 8)) & 0x80u);
+                            const bool p10 = !((r1 >> (16 * e2)) & 0x80u), p11 = !((r1 >> (16 * e2 + 8)) & 0x80u);
+                            const uint32_t win = p00 ? 0u : (p01 ? 1u : (p10 ? 2u : (p11 ? 3u : 0u)));
+                            const float ge = e2 ? d4.y : d4.x;
+                            dv[2 * e2] = win == hbit * 2u ? ge : 0.f;
+                            dv[2 * e2 + 1] = win == hbit * 2u + 1u ? ge : 0.f;
+                        }
+                    }
                     const uint32_t hw = hb[half * 4 + e];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -953,23 +994,24 @@ static void launch_pwd2(const PwdPlan& pl, hipStream_t s) {
 }
 template <int NT>
 static void launch_pwd(const PwdPlan& pl, hipStream_t s) {
-    if (pl.p.h) launch_pwd2<NT, 1>(pl, s); else launch_pwd2<NT, 0>(pl, s);
+    if (pl.p.h && pl.p.own) launch_pwd2<NT, 2>(pl, s); else if (pl.p.h) launch_pwd2<NT, 1>(pl, s); else launch_pwd2<NT, 0>(pl, s);
 }
 int pwd_supported(const mn_conv_geom* g, const mn_wq* wq) { PwdPlan pd; return wq_codeable(wq) && plan_pwd(g, &pd); }
 int64_t pwd_ws_bytes(const mn_conv_geom* g) { PwdPlan pd; return plan_pwd(g, &pd) ? pd.ws_bytes : 0; }
 // backward-data whose incoming gradient is the BatchNorm+sign backward of (da, h): formed inside the kernel
 int pwd_bwd_data_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
-                     const float* w, float* dx, void* ws, int64_t ws_bytes, hipStream_t s) {
+                     const float* w, float* dx, void* ws, int64_t ws_bytes, hipStream_t s, const int8_t* own) {
     PwdPlan pd;
-    if (!wq_codeable(wq) || !plan_pwd(g, &pd) || !aligned16(da) || !aligned16(dx) || (((uintptr_t)h) & 3))
+    if (!wq_codeable(wq) || !plan_pwd(g, &pd) || !aligned16(dx) || (((uintptr_t)h) & 3) || (own ? ((((uintptr_t)da) & 7) || (((uintptr_t)own) & 3) || (g->H & 1) || (g->W & 3)) : !aligned16(da)))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data_bnh: geometry / quantizer combination not covered");
     if (!ws || ws_bytes < pd.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data_bnh: workspace too small");
     fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
     qg_launch_pack(pd.pk, pd.pack_grid, s);
     pd.p.gy = da; pd.p.dx = dx; pd.p.wc = pd.pk.codes; pd.p.kscale = pd.pk.scale_out;
     pd.p.h = h; pd.p.chan = chan; pd.p.sums = sums; pd.p.training = training; pd.p.n_f = (float)g->N * (float)(g->H * g->W);
-    mn_set_last_kernel("k_pwd<%d, %d, 1>", pd.NT, pd.p.KS);
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(5.0 * ny + 4.0 * nx); }
+    pd.p.own = (const char*)own; pd.p.W = (int)g->W; pd.p.fd_w = make_fastdiv((uint32_t)g->W);
+    mn_set_last_kernel(own ? "k_pwd<%d, %d, 2>" : "k_pwd<%d, %d, 1>", pd.NT, pd.p.KS);
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((own ? 3.0 : 5.0) * ny + 4.0 * nx); }
     mn_prof_begin(s);
     if (pd.NT == 4) launch_pwd<4>(pd, s); else if (pd.NT == 2) launch_pwd<2>(pd, s); else launch_pwd<1>(pd, s);
     mn_prof_end(s);
@@ -1079,7 +1121,7 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
             fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
             qg_launch_pack(pd.pk, pd.pack_grid, s);
             pd.p.gy = gy; pd.p.dx = dx; pd.p.wc = pd.pk.codes; pd.p.kscale = pd.pk.scale_out;
-            pd.p.h = nullptr; pd.p.chan = nullptr; pd.p.sums = nullptr; pd.p.training = 0; pd.p.n_f = 1.f;
+            pd.p.h = nullptr; pd.p.own = nullptr; pd.p.chan = nullptr; pd.p.sums = nullptr; pd.p.training = 0; pd.p.n_f = 1.f;
             mn_set_last_kernel("k_pwd<%d, %d, 0>", pd.NT, pd.p.KS);
             mn_prof_begin(s);
             if (pd.NT == 4) launch_pwd<4>(pd, s); else if (pd.NT == 2) launch_pwd<2>(pd, s); else launch_pwd<1>(pd, s);

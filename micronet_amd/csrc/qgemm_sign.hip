@@ -634,6 +634,11 @@ struct Wg2Params {
     const float* sums;
     int training;
     float n_f;
+    // BNH 2 (k_pws_wgrad_s only): gy is the POOLED gradient [N][Cout][H/2][W/2] of the 2x2 max-pool behind the block, `own` the block's own sign output: the
+    // staging threads route a window's gradient to its first +1 (k_bnh_apply<1>'s rule) before the BatchNorm fold -- the full-size dy is never written
+    const char* own;
+    int W;
+    FastDiv fd_w;
 };
 template <int MW, int CW, int BNH>
 __global__ __launch_bounds__(256, 2) void k_pws_wgrad(const Wg2Params p) {
@@ -880,7 +885,7 @@ __global__ __launch_bounds__(SPEC == 2 ? 768 : (SPEC ? 512 : 256), SPEC ? 1 : 2)
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) acc[mi][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    struct Stage { float4 gv[RPT]; uint32_t hv[RPT]; u32x4 cv; };
+    struct Stage { float4 gv[RPT]; uint32_t hv[RPT]; u32x4 cv; uint32_t hbit; };
     Stage s0, s1;
     // contiguous ranges (st_stride == 1) or interleaved: block z takes steps z, z + Z, ... -- neighbouring blocks then read neighbouring
     // 128-byte pieces of the same rows at about the same time (DRAM page locality)
@@ -897,6 +902,21 @@ __global__ __launch_bounds__(SPEC == 2 ? 768 : (SPEC ? 512 : 256), SPEC ? 1 : 2)
         const uint32_t P = (uint32_t)st * 32u + 4u * sq;
         const uint32_t ni = fd_div(P, p.fd_hw);
         const uint32_t o = ni * (uint32_t)p.Cout_total * HW + (P - ni * HW);
+        if (BNH == 2) {          // pooled gradient: {g[win 0], g[win 1], own codes of the window's upper row, of its lower row} per row and pixel quad
+            const uint32_t pp = P - ni * HW;
+            const uint32_t hr = fd_div(pp, p.fd_w), w = pp - hr * (uint32_t)p.W;
+            const uint32_t gbase = ni * (uint32_t)p.Cout_total * (HW >> 2) + (hr >> 1) * ((uint32_t)p.W >> 1) + (w >> 1);
+            const uint32_t cbase = ni * (uint32_t)p.Cout_total * HW + (hr & ~1u) * (uint32_t)p.W + w;
+            S.hbit = hr & 1u;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const float2 g2 = *reinterpret_cast<const float2*>(p.gy + (gbase + (goff[i] >> 2)));
+                const uint32_t r0 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + goff[i]));
+                const uint32_t r1 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + goff[i] + (uint32_t)p.W));
+                S.gv[i] = make_float4(g2.x, g2.y, mn_u2f(r0), mn_u2f(r1));
+                S.hv[i] = *reinterpret_cast<const uint32_t*>(p.h + (o + goff[i]));
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             S.gv[i] = *reinterpret_cast<const float4*>(p.gy + (o + goff[i]));
@@ -914,6 +934,18 @@ __global__ __launch_bounds__(SPEC == 2 ? 768 : (SPEC ? 512 : 256), SPEC ? 1 : 2)
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             float v[4] = {S.gv[i].x, S.gv[i].y, S.gv[i].z, S.gv[i].w};
+            if (BNH == 2) {          // the two windows' gradients go to their first +1 in scan order (else element 0) -- if that element lies in this row
+                const uint32_t r0 = mn_f2u(S.gv[i].z), r1 = mn_f2u(S.gv[i].w);
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const bool p00 = !((r0 >> (16 * e2)) & 0x80u), p01 = !((r0 >> (16 * e2 + 8)) & 0x80u);
+                    const bool p10 = !((r1 >> (16 * e2)) & 0x80u), p11 = !((r1 >> (16 * e2 + 8)) & 0x80u);
+                    const uint32_t win = p00 ? 0u : (p01 ? 1u : (p10 ? 2u : (p11 ? 3u : 0u)));
+                    const float ge = e2 ? S.gv[i].y : S.gv[i].x;
+                    v[2 * e2] = win == S.hbit * 2u ? ge : 0.f;
+                    v[2 * e2 + 1] = win == S.hbit * 2u + 1u ? ge : 0.f;
+                }
+            }
             if (BNH) {
                 const float4 f0 = *reinterpret_cast<const float4*>(ftab + (sr + 32 * i) * 8);        // hlo, hhi, G, E1
                 const float fE0 = ftab[(sr + 32 * i) * 8 + 4];
@@ -1192,23 +1224,27 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     return 1;
 }
 int pws_wgrad_supported(const mn_conv_geom* g) { Wg2Plan pl; return plan_pws_wgrad(g, &pl); }
+int pws_wgrad_staged(const mn_conv_geom* g) { Wg2Plan pl; return plan_pws_wgrad(g, &pl) && pl.staged; }
 int64_t pws_wgrad_ws_bytes(const mn_conv_geom* g) { Wg2Plan pl; return plan_pws_wgrad(g, &pl) ? pl.ws_bytes : 0; }
 int pws_bwd_weight(const mn_conv_geom* g, const float* gy, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
-    return pws_bwd_weight_bnh(g, gy, nullptr, nullptr, nullptr, 0, x, dw, dbias, ws, ws_bytes, s);
+    return pws_bwd_weight_bnh(g, gy, nullptr, nullptr, nullptr, 0, x, dw, dbias, ws, ws_bytes, s, nullptr);
 }
 int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h, const float* chan, const float* sums, int training, const int8_t* x,
-                       float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+                       float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s, const int8_t* own) {
     Wg2Plan pl;
-    if (!plan_pws_wgrad(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(sign): geometry not covered");
+    if (!plan_pws_wgrad(g, &pl) || (own ? (((uintptr_t)gy) & 7) != 0 : !aligned16(gy)) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(sign): geometry not covered");
+    if (own && (!h || !pl.staged || (((uintptr_t)x) & 15) || (((uintptr_t)own) & 3) || (g->H & 1) || (g->W & 3)))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight_bnh_pool: needs the LDS-staged backward-weight kernel, even H, W %% 4 == 0");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(sign): workspace too small");
     Wg2Params& p = pl.p;
     p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
     p.h = h; p.chan = chan; p.sums = sums; p.training = training; p.n_f = (float)g->N * (float)(g->H * g->W);
+    p.own = (const char*)own; p.W = (int)g->W; p.fd_w = make_fastdiv((uint32_t)g->W);
     if (h && (!chan || !sums || (((uintptr_t)h) & 3))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null / misaligned argument");
     if (pl.staged && ((((uintptr_t)x) & 15) || (h && (((uintptr_t)h) & 3)))) pl.staged = 0;
-    if (pl.staged) mn_set_last_kernel(pl.spec == 2 ? "k_pws_wgrad_s<%d, %d, 0, 2>" : pl.spec ? "k_pws_wgrad_s<%d, %d, 0, 1>" : "k_pws_wgrad_s<%d, %d>", pl.MW, h ? 1 : 0);
+    if (pl.staged) mn_set_last_kernel(pl.spec == 2 ? "k_pws_wgrad_s<%d, %d, 0, 2>" : pl.spec ? "k_pws_wgrad_s<%d, %d, 0, 1>" : "k_pws_wgrad_s<%d, %d>", pl.MW, own ? 2 : (h ? 1 : 0));
     else mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.CW8 ? 2 : pl.MW, pl.CW8 ? 8 : pl.MW, h ? 1 : 0);
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((h ? 5.0 : 4.0) * ny + nx); }
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((own ? 3.0 : (h ? 5.0 : 4.0)) * ny + nx); }
     mn_prof_begin(s);
     if (pl.staged) {
         const int TMs = 32 * pl.MW;
@@ -1216,8 +1252,9 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
         const size_t ldsb = 2 * buf + (p.h ? (size_t)TMs * 32 : 0);
 #define WG3_LAUNCH(MWV, BV) { raise_lds_limit((const void*)k_pws_wgrad_s<MWV, BV>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<MWV, BV>), dim3(pl.grid), dim3(256), ldsb, s, p); }
 #define WG3_LAUNCH_SPEC(BV, SV) { raise_lds_limit((const void*)k_pws_wgrad_s<4, BV, 0, SV>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, BV, 0, SV>), dim3(pl.grid), dim3(256 + 256 * SV), ldsb, s, p); }
-        if (pl.spec == 2) { if (p.h) WG3_LAUNCH_SPEC(1, 2) else WG3_LAUNCH_SPEC(0, 2) }
-        else if (pl.spec) { if (p.h) WG3_LAUNCH_SPEC(1, 1) else WG3_LAUNCH_SPEC(0, 1) }
+        if (pl.spec == 2) { if (own) WG3_LAUNCH_SPEC(2, 2) else if (p.h) WG3_LAUNCH_SPEC(1, 2) else WG3_LAUNCH_SPEC(0, 2) }
+        else if (pl.spec) { if (own) WG3_LAUNCH_SPEC(2, 1) else if (p.h) WG3_LAUNCH_SPEC(1, 1) else WG3_LAUNCH_SPEC(0, 1) }
+        else if (own) { if (pl.MW == 4) WG3_LAUNCH(4, 2) else WG3_LAUNCH(2, 2) }
         else if (p.h) { if (pl.MW == 4) WG3_LAUNCH(4, 1) else WG3_LAUNCH(2, 1) }
         else { if (pl.MW == 4) WG3_LAUNCH(4, 0) else WG3_LAUNCH(2, 0) }
 #undef WG3_LAUNCH

@@ -1640,23 +1640,34 @@ class QConv2d(Function):
     def backward(ctx, gy):
         x, wq, qp, wscale = ctx.saved_tensors
         g, aq_mode, aq_bits, aq_qtype, has_bias, wd4, aq_flags = ctx.cfg
-        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") == "bnh" and aq_mode == ACTQ_SIGN8 and wd4 is not None and \
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") in ("bnh", "bnh_pool") and aq_mode == ACTQ_SIGN8 and wd4 is not None and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO:
-            r = gy._mn_recipe              # the fused BatchNorm+sign behind this conv: dy is formed inside backward-data / backward-weight
+            r = gy._mn_recipe              # the fused BatchNorm+sign (+ max-pool) behind this conv: dy is formed inside backward-data / backward-weight
+            pool = r.get("kind") == "bnh_pool"
             wd = _wq_desc(wd4 + (wscale,))
             dx = dw = db = None
             with torch.cuda.device_of(x):
                 if ctx.needs_input_grad[0]:
                     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
                     ws, nb = _ws(g, 1, x.device)
-                    _call("mn_conv2d_bwd_data_bnh", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(wq),
-                          _p(dx), _p(ws), nb, _s())
+                    with _span(g, 1, (3 if pool else 5) * r["h"].numel() + 4 * dx.numel()):
+                        if pool:
+                            _call("mn_conv2d_bwd_data_bnh_pool", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["own"]), _p(r["chan"]), _p(r["sums"]), r["training"],
+                                  _p(wq), _p(dx), _p(ws), nb, _s())
+                        else:
+                            _call("mn_conv2d_bwd_data_bnh", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(wq),
+                                  _p(dx), _p(ws), nb, _s())
                 if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                     dw = torch.empty_like(wq)
                     db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
                     ws, nb = _ws(g, 2, x.device)
-                    _call("mn_conv2d_bwd_weight_bnh", C.byref(g), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(x), _p(dw),
-                          _p(db), _p(ws), nb, _s())
+                    with _span(g, 2, (3 if pool else 5) * r["h"].numel() + x.numel()):
+                        if pool:
+                            _call("mn_conv2d_bwd_weight_bnh_pool", C.byref(g), _p(r["da"]), _p(r["h"]), _p(r["own"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(x),
+                                  _p(dw), _p(db), _p(ws), nb, _s())
+                        else:
+                            _call("mn_conv2d_bwd_weight_bnh", C.byref(g), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(x), _p(dw),
+                                  _p(db), _p(ws), nb, _s())
             return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
         if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") == "qa" and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
@@ -1668,7 +1679,7 @@ class QConv2d(Function):
                 _call("mn_conv2d_bwd_weight_first_qa", C.byref(g), _p(r["dq"]), _p(r["y"]), _p(r["chan"]), _p(r["sums"]), r["bits"], r["quant"], r["training"],
                       _p(x), _p(dw), _p(db), _p(ws), nb, _s())
             return None, dw, db, None, None, None, None, None, None, None, None, None, None, None
-        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") not in ("bnh", "qa") and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") not in ("bnh", "bnh_pool", "qa") and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
             r = gy._mn_recipe              # the BatchNorm+sign behind the first conv: dy is formed inside the backward-weight kernel
             dw = torch.empty_like(wq)
@@ -1746,6 +1757,8 @@ import os as _os
 # the LDS staging pass, dy is never written).  With the LDS-staged backward-weight kernel (the fold costs one pass per BLOCK there)
 # this is +3.5 % step throughput on c2 (3.25 -> 3.14 ms): ON by default, MN_BNH_FOLD=0 switches it off.
 FOLD_BN_INTO_CONV_BWD = _os.environ.get("MN_BNH_FOLD", "1") != "0"
+# ... and the 2x2 max-pool behind a block as well (k_pwd<.., 2> / k_pws_wgrad_s<.., 2, ..>): MN_BNH_POOL_FOLD=0 restores mn_bnh_bwd_apply's full-size dy (A/B)
+FOLD_POOL_INTO_CONV_BWD = _os.environ.get("MN_BNH_POOL_FOLD", "1") != "0"
 
 
 class ConvBNSign(Function):
@@ -1772,6 +1785,7 @@ class ConvBNSign(Function):
         ctx.save_for_backward(h, chan, gamma, beta)
         ctx.training = int(training)
         ctx.fold_ok = FOLD_BN_INTO_CONV_BWD and bool(_lib_().mn_conv2d_bnh_supported(C.byref(g), _ref(wd)))     # the conv's own backward can form dy from (da, h)
+        ctx.fold_pool_ok = FOLD_POOL_INTO_CONV_BWD and ctx.fold_ok and bool(_lib_().mn_conv2d_bnh_pool_supported(C.byref(g), _ref(wd)))      # ... and from the POOLED gradient
         return SignTensor(a)
 
     @staticmethod
@@ -1789,6 +1803,16 @@ class ConvBNSign(Function):
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=h.device)
         with torch.cuda.device_of(h):
             _call("mn_bnh_bwd_sums", _p(grad), _p(h), _p(own), _p(chan), N, Cc, H, W, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+            if pooled and getattr(ctx, "fold_pool_ok", False) and LAZY_BN_GRAD:
+                # a 2x2 max-pool behind the block: the conv's backward-data / backward-weight route the pooled gradient to each window's first +1 and apply the
+                # BatchNorm+sign backward while (dpool, own codes, h) stream in -- the full-size dy (4 B per element written, then read twice) never exists
+                def expand_p(r):
+                    dy_ = torch.empty(r["h"].shape, dtype=torch.float32, device=r["h"].device)
+                    with torch.cuda.device_of(dy_):
+                        _call("mn_bnh_bwd_apply", _p(r["da"]), _p(r["h"]), _p(r["own"]), _p(r["chan"]), _p(r["sums"]), N, Cc, H, W, r["training"], _p(dy_), _s())
+                    return dy_
+                recipe = dict(kind="bnh_pool", da=grad, own=own, h=h, chan=chan, sums=sums, training=training)
+                return LazyBNGrad(h.shape, h.device, recipe, expand_p), dgamma, dbeta, None, None, None, None, None, None
             if not pooled and ctx.fold_ok and LAZY_BN_GRAD:
                 # d loss / d y is not written: the convolution's backward-data / backward-weight form it from (da, h) while they stream in
                 def expand(r):

@@ -570,6 +570,24 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
             sums = be.empty((2, Oc))
             be.call("mn_bnh_bwd_sums", be.ptr(dGP), be.ptr(h8), be.ptr(a8), be.ptr(chan), N, Oc, H, W, be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(ws), be.stream)
             be.call("mn_bnh_bwd_apply", be.ptr(dGP), be.ptr(h8), be.ptr(a8), be.ptr(chan), be.ptr(sums), N, Oc, H, W, int(training), be.ptr(dy), be.stream)
+            if be.lib.mn_conv2d_bnh_pool_supported(C.byref(g), C.byref(wq)):
+                # the consumers of dy forming it themselves from (pooled gradient, own codes, h): against the two-step path on the dy written above
+                aq8 = be.actq(3)
+                dx_ref2 = be.to_host(be.conv_bwd_data(g, aq8, dy, dW, None, 3, wq=wq))
+                dw_ref2, db_ref2 = be.conv_bwd_weight(g, aq8, dy, dA, 3, bias=True)
+                nb1 = be.lib.mn_conv2d_ws_bytes(C.byref(g), 1, 0)
+                ws1, dx2 = be.empty(max(4, nb1 // 4 + 4)), be.empty((N, x_shape[1], H, W))
+                be.call("mn_conv2d_bwd_data_bnh_pool", C.byref(g), C.byref(wq), be.ptr(dGP), be.ptr(h8), be.ptr(a8), be.ptr(chan), be.ptr(sums), int(training), be.ptr(dW),
+                        be.ptr(dx2), be.ptr(ws1), nb1, be.stream)
+                nb2 = be.lib.mn_conv2d_ws_bytes(C.byref(g), 2, 0)
+                ws2, dw2, db2 = be.empty(max(4, nb2 // 4 + 4)), be.empty(w.shape), be.empty(Oc)
+                be.call("mn_conv2d_bwd_weight_bnh_pool", C.byref(g), be.ptr(dGP), be.ptr(h8), be.ptr(a8), be.ptr(chan), be.ptr(sums), int(training), be.ptr(dA), be.ptr(dw2),
+                        be.ptr(db2), be.ptr(ws2), nb2, be.stream)
+                assert close(be.to_host(dx2), dx_ref2, 5e-6), ("pooled fold dx", np.max(np.abs(be.to_host(dx2) - dx_ref2)) / np.max(np.abs(dx_ref2)))
+                assert close(be.to_host(dw2), be.to_host(dw_ref2), 5e-6), "pooled fold dw"
+                sc_db = max(np.max(np.abs(be.to_host(dy))) * 1e-4, 1e-30)
+                assert np.max(np.abs(be.to_host(db2) - be.to_host(db_ref2))) <= sc_db * N * H * W
+                check_qconv_bnsign.pool_fold_checked = getattr(check_qconv_bnsign, "pool_fold_checked", 0) + 1
         else:
           be.call("mn_qconv_bnsign_bwd_pooled", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save),
                 be.ptr(dGP), be.ptr(a8), int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)

@@ -402,6 +402,18 @@ def test_qconv_bnsign_byte_stash(be, case):
         K.check_qconv_bnsign(be, seed=241, stash=True, pooled=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)
 
 
+def test_conv_backward_with_bn_and_maxpool_folded_in(be):
+    """mn_conv2d_bwd_data_bnh_pool / mn_conv2d_bwd_weight_bnh_pool: the conv's backward forms dy from (pooled gradient, the block's own sign codes, h) -- the pool's
+    first-maximum routing and the BatchNorm+sign backward in the operand load -- against the two-step path through mn_bnh_bwd_apply's full-size dy."""
+    before = getattr(K.check_qconv_bnsign, "pool_fold_checked", 0)
+    for i, case in enumerate(K.WGRAD_SPEC_CASES):
+        K.check_qconv_bnsign(be, seed=320 + i, stash=True, pooled=True, **case)
+        K.check_qconv_bnsign(be, seed=330 + i, stash=True, pooled=True, training=False, **case)
+    K.check_qconv_bnsign(be, seed=340, stash=True, pooled=True, x_shape=(3, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)       # nin_gc L3
+    K.check_qconv_bnsign(be, seed=341, stash=True, pooled=True, x_shape=(4, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=4)      # nin_gc L6
+    assert getattr(K.check_qconv_bnsign, "pool_fold_checked", 0) - before == 8
+
+
 def test_conv_backward_with_bn_folded_in(be):
     K.check_qconv_bnsign(be, seed=250, stash=True, x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2)
     K.check_qconv_bnsign(be, seed=251, stash=True, x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2, bias=False)

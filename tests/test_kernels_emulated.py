@@ -270,6 +270,16 @@ def test_qconv_bnsign_byte_stash(be, case):
         K.check_qconv_bnsign(be, seed=230 + case, stash=True, pooled=True, **K.QGEMM_PW_CASES[case])
 
 
+def test_conv_backward_with_bn_and_maxpool_folded_in(be):
+    """mn_conv2d_bwd_data_bnh_pool / mn_conv2d_bwd_weight_bnh_pool: the conv's backward forms dy from (pooled gradient, the block's own sign codes, h) -- the pool's
+    first-maximum routing and the BatchNorm+sign backward in the operand load -- against the two-step path through mn_bnh_bwd_apply's full-size dy."""
+    before = getattr(K.check_qconv_bnsign, "pool_fold_checked", 0)
+    for i, case in enumerate(K.WGRAD_SPEC_CASES):
+        K.check_qconv_bnsign(be, seed=320 + i, stash=True, pooled=True, **case)
+        K.check_qconv_bnsign(be, seed=330 + i, stash=True, pooled=True, training=False, **case)
+    assert getattr(K.check_qconv_bnsign, "pool_fold_checked", 0) - before == 6
+
+
 def test_conv_backward_with_bn_folded_in(be):
     """mn_conv2d_bwd_data_bnh / mn_conv2d_bwd_weight_bnh (dy formed in registers from (da, h)) on shapes the direct kernels cover."""
     K.check_qconv_bnsign(be, seed=250, stash=True, x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2)
