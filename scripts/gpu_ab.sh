@@ -16,7 +16,7 @@ except Exception as e:
     print(w, l, "failed", e)
 PY
 }
-run c5 base MN_X=0
-run c5 noacc MN_NO_PRODUCER_ACCSTATS=1
-run c5 base2 MN_X=0
-run c4 base MN_X=0
+run c2 base MN_X=0
+run c2 nopoolfold MN_BNH_POOL_FOLD=0
+run c2 base2 MN_X=0
+run c2 nopoolfold2 MN_BNH_POOL_FOLD=0
