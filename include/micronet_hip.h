@@ -281,7 +281,8 @@ typedef struct mn_wq {
                              tensor, 1 = a dense [O] vector, 4 = the rows of an mn_iao_qparams snapshot */
     const float* scale;   /* iao: device pointer */
     const void* packed_fwd; /* optional (NULL: the kernels pack the codes themselves, once per call): the weight codes in the fragment order of the dense */
-    const void* packed_bwd; /* family's forward / backward-data kernels, written by mn_qd_pack_multi for THIS `w` (same step, same quantizer state)   */
+    const void* packed_bwd; /* family's forward / backward-data kernels, written by mn_qd_pack_multi for THIS `w` (same step, same quantizer state) -- or, for a
+                               POINTWISE (1 x 1, stride 1) layer of the code kernels, the images mn_qg_pack_multi wrote (the two families never share a geometry) */
 } mn_wq;
 
 #define MN_ALGO_AUTO 0
@@ -485,6 +486,13 @@ int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, int a_bits_in
 int64_t mn_qd_packed_bytes(const mn_conv_geom* g);
 int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, void* const* out_bwd, const int64_t* O, const int64_t* Cin, const int64_t* taps,
                      const float* const* wscale, const int32_t* wscale_stride, int32_t count, int w_bits, mn_stream_t stream);
+/* The pointwise counterpart of mn_qd_pack_multi: the weight-code images of every pointwise layer of a net -- which[i] = 0: the forward image of the fused
+ * sign / k-bit kernels (mn_qconv_bnsign_fwd*, mn_qconv_bnq_fwd_stash, mn_conv2d_fwd on sign codes), 1: the transposed image of backward-data without a clip-STE
+ * epilogue (mn_conv2d_bwd_data on sign / k-bit codes, mn_conv2d_bwd_data_bnh[_pool]) -- in ONE launch per step.  out[i]: mn_qg_packed_bytes(g, which) bytes,
+ * 16-byte aligned (0: this geometry is not packed ahead), handed to those entry points through mn_wq.packed_fwd / packed_bwd; `w` = the fake-quantised weights. */
+int64_t mn_qg_packed_bytes(const mn_conv_geom* g, int which);
+int mn_qg_pack_multi(int32_t count, const mn_conv_geom* const* g, const mn_wq* const* wq, const float* const* w, const int32_t* which, void* const* out,
+                     mn_stream_t stream);
 /* Backward-weight of a dense layer with the reduction of its split-K partial tiles DEFERRED.  autograd's conv2d backward hands d(quantised weight) to the weight
  * quantizer's backward (wqaq/dorefa/quantize.py:61-73, wqaq/iao/quantize.py:214-240 through torch.autograd), and in a training step nothing else reads it -- so
  * every dense conv of the step leaves its partial tiles in ITS OWN workspace (mn_qd_bwd_weight_partials: aq->mode MN_ACTQ_CODE8 with x = activation codes, or

@@ -35,9 +35,9 @@ __device__ __forceinline__ float wq_code(float w, int mode, float sc, float n) {
     }
     return mn_rha(w / sc);                        // IAO: (clamp(r) + zp)
 }
-__global__ __launch_bounds__(64) void k_qg_pack(const PackParams p) {
+__device__ __forceinline__ void qg_pack_row(const PackParams& p, int blk) {
     const int rows = p.transpose ? p.Mgp : p.Mpad;
-    const int g = blockIdx.x / rows, m = blockIdx.x % rows;
+    const int g = blk / rows, m = blk % rows;
     const int lane = threadIdx.x;
     const bool mv = m < p.Mg;
     const int K = p.Cg * p.T;
@@ -76,6 +76,16 @@ __global__ __launch_bounds__(64) void k_qg_pack(const PackParams p) {
     }
 }
 
+__global__ __launch_bounds__(64) void k_qg_pack(const PackParams p) { qg_pack_row(p, (int)blockIdx.x); }
+// the packs of SEVERAL pointwise layers (forward and backward-data code images) in one launch: mn_qg_pack_multi -- once per training step, right after the weight
+// quantizers, instead of one 5 us launch per conv call and direction (10 per nin_gc step)
+#define QG_PACKM_MAX 20
+struct PackTable { PackParams e[QG_PACKM_MAX]; int blk0[QG_PACKM_MAX + 1]; int count; };
+__global__ __launch_bounds__(64) void k_qg_pack_multi(const PackTable t) {
+    int i = 0;
+    while (i + 1 < t.count && (int)blockIdx.x >= t.blk0[i + 1]) ++i;
+    qg_pack_row(t.e[i], (int)blockIdx.x - t.blk0[i]);
+}
 void qg_launch_pack(const PackParams& p, int grid, hipStream_t s) { hipLaunchKernelGGL(k_qg_pack, dim3(grid), dim3(64), 0, s, p); }
 
 // ------------------------------------------------------------------------------------------------
@@ -983,6 +993,23 @@ static int plan_pwd(const mn_conv_geom* g, PwdPlan* pl) {
     pl->pack_grid = k.G * k.Mgp;
     return 1;
 }
+// the transposed weight codes + contraction-channel scales of this call: the step's pre-packed image (mn_wq.packed_bwd, written by mn_qg_pack_multi in the layout
+// [codes | scales at off_scale] of this very plan) or packed here into the call's workspace
+static void pwd_codes(PwdPlan& pd, const mn_wq* wq, const float* w, void* ws, hipStream_t s) {
+    if (wq->packed_bwd && !MN_ENV("MN_NO_PACKED_PW")) {
+        pd.pk.codes = (uint16_t*)const_cast<void*>(wq->packed_bwd);
+        pd.pk.scale_out = (float*)((char*)const_cast<void*>(wq->packed_bwd) + pd.off_scale);
+        return;
+    }
+    fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
+    qg_launch_pack(pd.pk, pd.pack_grid, s);
+}
+int pwd_pack_plan(const mn_conv_geom* g, PackParams* pk, int* grid, int64_t* off_scale, int64_t* bytes) {
+    PwdPlan pd;
+    if (!plan_pwd(g, &pd)) return 0;
+    *pk = pd.pk; *grid = pd.pack_grid; *off_scale = pd.off_scale; *bytes = pd.ws_bytes;
+    return 1;
+}
 template <int NT, int BNH>
 static void launch_pwd2(const PwdPlan& pl, hipStream_t s) {
     switch (pl.p.KS) {
@@ -1005,8 +1032,7 @@ int pwd_bwd_data_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, co
     if (!wq_codeable(wq) || !plan_pwd(g, &pd) || !aligned16(dx) || (((uintptr_t)h) & 3) || (own ? ((((uintptr_t)da) & 7) || (((uintptr_t)own) & 3) || (g->H & 1) || (g->W & 3)) : !aligned16(da)))
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data_bnh: geometry / quantizer combination not covered");
     if (!ws || ws_bytes < pd.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data_bnh: workspace too small");
-    fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
-    qg_launch_pack(pd.pk, pd.pack_grid, s);
+    pwd_codes(pd, wq, w, ws, s);
     pd.p.gy = da; pd.p.dx = dx; pd.p.wc = pd.pk.codes; pd.p.kscale = pd.pk.scale_out;
     pd.p.h = h; pd.p.chan = chan; pd.p.sums = sums; pd.p.training = training; pd.p.n_f = (float)g->N * (float)(g->H * g->W);
     pd.p.own = (const char*)own; pd.p.W = (int)g->W; pd.p.fd_w = make_fastdiv((uint32_t)g->W);
@@ -1118,8 +1144,7 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     if (ste.mode == MN_ACTQ_NONE && !MN_ENV("MN_NO_PWD")) {      // no clip-STE epilogue: the prefetching kernel
         PwdPlan pd;
         if (plan_pwd(g, &pd) && ws_bytes >= pd.ws_bytes) {
-            fill_pack(pd.pk, wq, w, ws, 0, pd.off_scale);
-            qg_launch_pack(pd.pk, pd.pack_grid, s);
+            pwd_codes(pd, wq, w, ws, s);
             pd.p.gy = gy; pd.p.dx = dx; pd.p.wc = pd.pk.codes; pd.p.kscale = pd.pk.scale_out;
             pd.p.h = nullptr; pd.p.own = nullptr; pd.p.chan = nullptr; pd.p.sums = nullptr; pd.p.training = 0; pd.p.n_f = 1.f;
             mn_set_last_kernel("k_pwd<%d, %d, 0>", pd.NT, pd.p.KS);
@@ -1195,5 +1220,42 @@ int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
                            (pro.mode == MN_ACTQ_DOREFA || pro.mode == MN_ACTQ_CODE8) ? pro.s : 1.f,
                            pro.mode == MN_ACTQ_IAO ? pro.qp : (const float*)nullptr, s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(qgemm)");
+    return MN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the pointwise packs of a whole net in one launch
+int pws_pack_plan(const mn_conv_geom* g, PackParams* pk, int* grid, int64_t* off_scale, int64_t* bytes);          // qgemm_sign.hip
+static int qg_packm_plan(const mn_conv_geom* g, int which, PackParams* pk, int* grid, int64_t* off_scale, int64_t* bytes) {
+    if (!g || (which != 0 && which != 1)) return 0;
+    return which == 0 ? pws_pack_plan(g, pk, grid, off_scale, bytes) : pwd_pack_plan(g, pk, grid, off_scale, bytes);
+}
+extern "C" int64_t mn_qg_packed_bytes(const mn_conv_geom* g, int which) {
+    PackParams pk; int grid; int64_t off, bytes;
+    if (MN_ENV("MN_NO_PACKED_PW") || !qg_packm_plan(g, which, &pk, &grid, &off, &bytes)) return 0;
+    return (off + (int64_t)pk.G * (pk.transpose ? pk.Mgp : pk.Mpad) * 4 + 255) / 256 * 256;
+}
+extern "C" int mn_qg_pack_multi(int32_t count, const mn_conv_geom* const* g, const mn_wq* const* wq, const float* const* w, const int32_t* which, void* const* out,
+                                mn_stream_t stream) {
+    if (count <= 0) return MN_OK;
+    if (!g || !wq || !w || !which || !out) MN_FAIL(MN_EINVAL, "mn_qg_pack_multi: null table");
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < count; base += QG_PACKM_MAX) {
+        PackTable t;
+        const int n = count - base < QG_PACKM_MAX ? count - base : QG_PACKM_MAX;
+        int blk = 0;
+        for (int i = 0; i < n; ++i) {
+            int grid; int64_t off, bytes;
+            if (!wq[base + i] || !wq_codeable(wq[base + i]) || !w[base + i] || !out[base + i] || !aligned16(out[base + i]) ||
+                !qg_packm_plan(g[base + i], which[base + i], &t.e[i], &grid, &off, &bytes))
+                MN_FAIL(MN_EINVAL, "mn_qg_pack_multi: entry %d is not a pointwise layer of the code kernels", base + i);
+            fill_pack(t.e[i], wq[base + i], w[base + i], out[base + i], 0, off);
+            t.blk0[i] = blk;
+            blk += grid;
+        }
+        for (int i = n; i <= QG_PACKM_MAX; ++i) t.blk0[i] = blk;
+        t.count = n;
+        hipLaunchKernelGGL(k_qg_pack_multi, dim3(blk), dim3(64), 0, s, t);
+    }
+    MN_CHECK_LAUNCH("mn_qg_pack_multi");
     return MN_OK;
 }

@@ -1401,8 +1401,13 @@ static int pws_prepare(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, 
     if (!wq_codeable(wq) || !plan_pws(g, nt_max, pl)) MN_FAIL(MN_ENOTSUP, "%s: geometry / weight quantizer not covered by the fused sign kernels", what);
     if (!x || !w || (((uintptr_t)x) & 3)) MN_FAIL(MN_EINVAL, "%s: null / misaligned tensor", what);
     if (!ws || ws_bytes < pl->ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "%s: workspace too small (%lld < %lld)", what, (long long)ws_bytes, (long long)pl->ws_bytes);
-    fill_pack(pl->pk, wq, w, ws, 0, pl->off_scale);
-    qg_launch_pack(pl->pk, pl->pack_grid, s);
+    if (wq->packed_fwd && !MN_ENV("MN_NO_PACKED_PW")) {          // the step's pre-packed image (mn_qg_pack_multi: [codes | row scales at off_scale] of this plan)
+        pl->pk.codes = (uint16_t*)const_cast<void*>(wq->packed_fwd);
+        pl->pk.scale_out = (float*)((char*)const_cast<void*>(wq->packed_fwd) + pl->off_scale);
+    } else {
+        fill_pack(pl->pk, wq, w, ws, 0, pl->off_scale);
+        qg_launch_pack(pl->pk, pl->pack_grid, s);
+    }
     PwsParams& p = pl->p;
     p.x = (const char*)x; p.wc = pl->pk.codes; p.rowscale = pl->pk.scale_out;
     p.part = (float*)((char*)ws + pl->off_part);
@@ -1412,6 +1417,12 @@ static int pws_prepare(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, 
     return MN_OK;
 }
 
+int pws_pack_plan(const mn_conv_geom* g, PackParams* pk, int* grid, int64_t* off_scale, int64_t* bytes) {
+    PwsPlan pl;
+    if (!plan_pws(g, PWS_NT_FWD, &pl)) return 0;
+    *pk = pl.pk; *grid = pl.pack_grid; *off_scale = pl.off_scale; *bytes = pl.ws_bytes;
+    return 1;
+}
 int pws_supported(const mn_conv_geom* g, const mn_wq* wq) {
     PwsPlan pl;
     return wq_codeable(wq) && plan_pws(g, PWS_NT_FWD, &pl);

@@ -1645,6 +1645,8 @@ class QConv2d(Function):
             r = gy._mn_recipe              # the fused BatchNorm+sign (+ max-pool) behind this conv: dy is formed inside backward-data / backward-weight
             pool = r.get("kind") == "bnh_pool"
             wd = _wq_desc(wd4 + (wscale,))
+            if getattr(ctx, "packed", None) is not None and ctx.packed[1] is not None:
+                wd.packed_bwd = ctx.packed[1].data_ptr()
             dx = dw = db = None
             with torch.cuda.device_of(x):
                 if ctx.needs_input_grad[0]:
@@ -1728,6 +1730,7 @@ class QConv2dLazy(Function):
         wscale = wdesc[4] if wdesc is not None else None
         ctx.save_for_backward(codes, wq, None, wscale)
         ctx.cfg = (g, ACTQ_SIGN8, 8, 0, bias is not None, wdesc[:4] if wdesc is not None else None, 0)
+        ctx.packed = packed = getattr(wq, "_mn_packed", None)          # (the step's pre-packed code images: pack_pointwise_weights)
 
         def compute():
             y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=codes.device)
@@ -1737,7 +1740,7 @@ class QConv2dLazy(Function):
                 ws, nb = _ws(g, 0, codes.device)
                 _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _ref(wd), _p(codes), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
             return y
-        recipe = dict(codes=codes, wq=wq, bias=bias, geom=g, wdesc=wdesc, compute=compute)
+        recipe = dict(codes=codes, wq=wq, bias=bias, geom=g, wdesc=wdesc, compute=compute, packed=packed)
         return LazyConvOut((g.N, g.O, Ho, Wo), codes.device, recipe)
 
     @staticmethod
@@ -1777,6 +1780,9 @@ class ConvBNSign(Function):
         save = torch.empty((2, g.O), dtype=torch.float32, device=codes.device)
         chan = torch.empty((int(_lib_().mn_qconv_bnsign_stash_chan_rows(C.byref(g))), g.O), dtype=torch.float32, device=codes.device)
         wd = _wq_desc(wdesc)
+        pk = r.get("packed")
+        if pk is not None and pk[0] is not None:
+            wd.packed_fwd = pk[0].data_ptr()
         with torch.cuda.device_of(codes):
             nb = int(_lib_().mn_qconv_bnsign_stash_ws_bytes(C.byref(g)))
             ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
@@ -1886,6 +1892,49 @@ def pack_dense_weights(mods_wq, w_bits, qps=None):
               PA(*[q.data_ptr() for q in scales]) if qps is not None else None, IA(*[4] * n) if qps is not None else None, n, w_bits, _s())
     for (wq, _), o in zip(items, outs):
         wq._mn_packed = o
+
+
+PACK_PW_MULTI = _os.environ.get("MN_NO_PACKED_PW") is None          # A/B knob: every conv call packs its own weight codes
+
+
+def pack_pointwise_weights(mods_wq, wdesc):
+    """The pointwise (1x1, stride 1) counterpart of ``pack_dense_weights``: the forward and backward-data weight-code images of every such conv of the step in ONE
+    launch (mn_qg_pack_multi) instead of one 5 us launch per conv call and direction.  ``wdesc`` = (mode, bits, q_type, per_channel, None): ternary / binary or
+    DoReFa codes.  The images ride on the quantised weight tensor (``_mn_packed`` = (forward image, backward image)); layers the code kernels do not cover are
+    skipped (their calls keep packing for themselves)."""
+    if not PACK_PW_MULTI:
+        return
+    lib = _lib_()
+    items = []
+    for m, wq in mods_wq:
+        if wq.dim() != 4 or not wq.is_cuda or wq.shape[2] != 1 or wq.shape[3] != 1 or getattr(wq, "_mn_packed", None) is not None:
+            continue
+        one = lambda v: v in (1, (1, 1), [1, 1])
+        if not (one(m.stride) and one(m.dilation) and m.padding in (0, (0, 0), [0, 0])):
+            continue
+        g = _geom((1, wq.shape[1] * m.groups, 8, 8), wq.shape, 1, 0, 1, m.groups, 0)
+        nb = [int(lib.mn_qg_packed_bytes(C.byref(g), k)) for k in (0, 1)]
+        if nb[0] <= 0 and nb[1] <= 0:
+            continue
+        items.append((wq, g, nb))
+    if not items:
+        return
+    dev = items[0][0].device
+    total = sum(nb[0] + nb[1] for _, _, nb in items)
+    buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    gs, wds, wps, whs, outs, off = [], [], [], [], [], 0
+    for wq, g, nb in items:
+        views = [None, None]
+        for k in (0, 1):
+            if nb[k] > 0:
+                views[k] = buf[off:off + nb[k]]
+                off += nb[k]
+                gs.append(g); wds.append(_wq_desc(wdesc)); wps.append(wq.data_ptr()); whs.append(k); outs.append(views[k].data_ptr())
+        wq._mn_packed = (views[0], views[1])
+    n = len(gs)
+    GP, WP, PA, IA = C.POINTER(ConvGeom) * n, C.POINTER(WQ) * n, C.c_void_p * n, C.c_int32 * n
+    with torch.cuda.device(dev):
+        _call("mn_qg_pack_multi", n, GP(*[C.pointer(g) for g in gs]), WP(*[C.pointer(w) for w in wds]), PA(*wps), IA(*whs), PA(*outs), _s())
 
 
 def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw, packed=None, defer=False):

@@ -112,6 +112,8 @@ def prefetch_weight_path(model, side=None):
                     wq._mn_defer_wgrad = True          # d(wq) has ONE reader, this node's backward: the dense convs defer their partial-tile reduction to it (ops.flush_wgrad_partials)
                 if 2 <= bits <= 8:          # the dense layers (ResNets): their weight codes in both fragment orders, one launch for the net
                     ops.pack_dense_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], bits)
+                    # ... and the pointwise layers of the fused k-bit blocks (nin_gc): forward / backward-data images, one launch
+                    ops.pack_pointwise_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], (ops.WQ_DOREFA, bits, 0, 0, None))
     if side is None:
         # IAO nets: every per-channel weight quantizer (observer update + qparams + fake-quant of each output channel) of one flavour in one MultiIaoWeight
         # node, then the dense layers' weight codes in one launch.  QuantBNFuseConv2d is excluded: it quantises weights folded with THIS step's batch statistics.
@@ -161,6 +163,7 @@ def prefetch_weight_path(model, side=None):
             qws = ops.MultiTernaryWeight.apply(*[m.weight for m in grp])
             for m, wq in zip(grp, qws):
                 m.weight_quantizer._mn_pre = (m.weight, wq, None)
+            ops.pack_pointwise_weights(list(zip(grp, qws)), (ops.WQ_TERNARY, 0, 0, 0, None))          # the pointwise blocks' code images: one launch for the net
         return
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)

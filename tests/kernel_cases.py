@@ -1216,6 +1216,91 @@ QDENSE_CASES = [
 ]
 
 
+def check_qg_pack_multi(be, seed=0):
+    """mn_qg_pack_multi: the forward and backward-data weight-code images of several pointwise layers in ONE launch; the entry points handed those images
+    (mn_wq.packed_fwd / packed_bwd) must return BIT-IDENTICAL results to the calls that pack for themselves -- sign-code blocks (ternary weights) and k-bit blocks
+    (DoReFa weights), the backward-data with the BatchNorm fold included.  The poisoned `w` of the pre-packed calls proves the images are what is read."""
+    r = np.random.default_rng(seed)
+    layers = [  # (x_shape, w_shape, groups, in_shuffle, scheme)    scheme 1: sign codes x ternary weights, 2: 2-bit codes x DoReFa W2
+        ((3, 80, 8, 16), (96, 40, 1, 1), 2, 2, 1), ((2, 96, 8, 8), (96, 48, 1, 1), 2, 0, 1), ((4, 160, 8, 8), (192, 80, 1, 1), 2, 0, 1),
+        ((2, 96, 8, 8), (96, 48, 1, 1), 2, 0, 2), ((3, 80, 8, 16), (96, 40, 1, 1), 2, 2, 2),
+    ]
+    G, WQ_, W_, WH, OUT, keep, per = [], [], [], [], [], [], []
+    for (xs, wsh, groups, shuf, scheme) in layers:
+        g = be.geom(xs, wsh, groups=groups)
+        g.in_shuffle = shuf
+        if scheme == 1:
+            w, wkw, _ = make_coded_weights(r, wsh, 1)
+        else:
+            w, wkw, _ = make_coded_weights(r, wsh, 2, 2)
+        dW = be.to_dev(w)
+        imgs = []
+        for which in (0, 1):
+            nb = int(be.lib.mn_qg_packed_bytes(C.byref(g), which))
+            assert nb > 0, (xs, wsh, which)
+            buf = be.empty(nb // 4 + 4)
+            wq = be.wq(**wkw)
+            G.append(g); WQ_.append(wq); W_.append(dW); WH.append(which); OUT.append(buf); imgs.append(buf)
+        keep.append(dW)
+        per.append((xs, wsh, groups, shuf, scheme, g, wkw, dW, w, imgs))
+    n = len(G)
+    GP, WP, PA, IA = C.POINTER(type(G[0])) * n, C.POINTER(type(WQ_[0])) * n, C.c_void_p * n, C.c_int32 * n
+    be.call("mn_qg_pack_multi", n, GP(*[C.pointer(g) for g in G]), WP(*[C.pointer(q) for q in WQ_]), PA(*[be.ptr(w) for w in W_]), IA(*WH), PA(*[be.ptr(o) for o in OUT]),
+            be.stream)
+    for (xs, wsh, groups, shuf, scheme, g, wkw, dW, w, imgs) in per:
+        N, Cin, H, W = xs
+        Oc = wsh[0]
+        dWn = be.to_dev(np.full(wsh, np.nan, dtype=F))
+        gy = be.to_dev(r.standard_normal((N, Oc, H, W)).astype(F))
+        nb1 = int(be.lib.mn_conv2d_ws_bytes(C.byref(g), 1, 0))
+        res = []
+        for packed in (False, True):
+            wq = be.wq(**wkw)
+            if packed:
+                wq.packed_fwd, wq.packed_bwd = be.ptr(imgs[0]).value, be.ptr(imgs[1]).value
+            wsrc = dWn if packed else dW
+            out = {}
+            if scheme == 1:
+                a_in = np.where(np.random.default_rng(7).standard_normal(xs) > 0, 1, -1).astype(np.int8)
+                dA = be.to_dev_i8(a_in)
+                nb = max(int(be.lib.mn_qconv_bnsign_stash_ws_bytes(C.byref(g))), 4 * int(be.lib.mn_bnsign_ws_floats(Oc)))
+                ws = be.empty(nb // 4 + 8)
+                gam, bet = be.to_dev(np.linspace(0.5, 1.5, Oc).astype(F)), be.to_dev(np.linspace(-0.3, 0.3, Oc).astype(F))
+                rm, rv = be.to_dev(np.zeros(Oc, dtype=F)), be.to_dev(np.ones(Oc, dtype=F))
+                save, a8, h8 = be.empty((2, Oc)), be.empty_i8((N, Oc, H, W)), be.empty_i8((N, Oc, H, W))
+                chan = be.empty((int(be.lib.mn_qconv_bnsign_stash_chan_rows(C.byref(g))), Oc))
+                be.call("mn_qconv_bnsign_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(wsrc), None, be.ptr(gam), be.ptr(bet), 1e-5, 0.1, 1, be.ptr(rm), be.ptr(rv),
+                        None, be.ptr(save), be.ptr(a8), be.ptr(h8), be.ptr(chan), be.ptr(ws), nb, be.stream)
+                out["a"], out["h"] = be.to_host(a8).copy(), be.to_host(h8).copy()
+                sums, dgam, dbet = be.empty((2, Oc)), be.empty(Oc), be.empty(Oc)
+                ws3 = be.empty(int(be.lib.mn_bnsign_ws_floats(Oc)) + 8)
+                be.call("mn_bnh_bwd_sums", be.ptr(gy), be.ptr(h8), None, be.ptr(chan), N, Oc, H, W, be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(ws3), be.stream)
+                ws1, dx = be.empty(max(4, nb1 // 4 + 4)), be.empty(xs)
+                be.call("mn_conv2d_bwd_data_bnh", C.byref(g), C.byref(wq), be.ptr(gy), be.ptr(h8), be.ptr(chan), be.ptr(sums), 1, be.ptr(wsrc), be.ptr(dx), be.ptr(ws1), nb1,
+                        be.stream)
+                out["dx_bnh"] = be.to_host(dx).copy()
+                aq = be.actq(3)
+            else:
+                codes = np.random.default_rng(8).integers(0, 4, size=xs).astype(np.uint8)
+                dX = be.to_dev_i8(codes.view(np.int8))
+                nb = max(int(be.lib.mn_qconv_bnq_ws_bytes(C.byref(g))), 4 * int(be.lib.mn_qa_ws_floats(Oc)))
+                ws = be.empty(nb // 4 + 8)
+                gam, bet = be.to_dev(np.linspace(0.5, 1.5, Oc).astype(F)), be.to_dev(np.linspace(-0.3, 0.3, Oc).astype(F))
+                rm, rv = be.to_dev(np.zeros(Oc, dtype=F)), be.to_dev(np.ones(Oc, dtype=F))
+                save, chan, stash = be.empty((2, Oc)), be.empty((9, Oc)), be.empty_i8((N, Oc, H, 2 * W))
+                be.call("mn_qconv_bnq_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dX), 2, be.ptr(wsrc), None, be.ptr(gam), be.ptr(bet), 1e-5, 0.1, 1, be.ptr(rm), be.ptr(rv),
+                        None, be.ptr(save), be.ptr(stash), be.ptr(chan), be.ptr(ws), nb, be.stream)
+                out["stash"], out["chan"] = be.to_host(stash).copy(), be.to_host(chan).copy()
+                aq = be.actq(4, 2)
+            ws1, dx = be.empty(max(4, nb1 // 4 + 4)), be.empty(xs)
+            be.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq), be.ptr(gy), be.ptr(wsrc), None, be.ptr(dx), be.ptr(ws1), nb1, 0, be.stream)
+            out["dx"] = be.to_host(dx).copy()
+            res.append(out)
+        for k in res[0]:
+            assert np.array_equal(res[0][k], res[1][k], equal_nan=True), ("pre-packed != self-packed", k, xs, wsh, scheme)
+            assert np.isfinite(res[1][k].astype(np.float64)).all(), ("NaN from the poisoned weights: the image was not used", k)
+
+
 def check_qd_wgrad_deferred(be, seed=0):
     """mn_qd_bwd_weight_partials (every layer leaves its split-K partial tiles in its own workspace) + ONE mn_qd_wgrad_reduce_multi == mn_conv2d_bwd_weight
     per layer, BIT FOR BIT (same kernels, same fixed-order fp64 reduction) -- DoReFa activation codes and IAO quantizers, 3x3 stride 1 / 2 and 1x1 stride 2."""

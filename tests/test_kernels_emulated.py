@@ -238,6 +238,10 @@ def test_deployed_sign_block_identity_statistics(be, case):
     K.check_deployed_sign_block(be, seed=500 + case, **K.DEPLOYED_CASES[case])
 
 
+def test_qg_pack_multi_images_bit_identical(be):
+    K.check_qg_pack_multi(be)
+
+
 def test_qd_wgrad_deferred_reduction_bit_identical(be):
     K.check_qd_wgrad_deferred(be)
 
