@@ -17,6 +17,7 @@ except Exception as e:
 PY
 }
 run c2 base MN_X=0
-run c2 nopoolfold MN_BNH_POOL_FOLD=0
-run c2 base2 MN_X=0
-run c2 nopoolfold2 MN_BNH_POOL_FOLD=0
+run c2 nopack MN_NO_PACKED_PW=1
+run c1_w2a2 base MN_X=0
+run c1_w2a2 nopack MN_NO_PACKED_PW=1
+run c1 base MN_X=0
