@@ -16,8 +16,10 @@ except Exception as e:
     print(w, l, "failed", e)
 PY
 }
-run c2 base MN_X=0
-run c2 nopack MN_NO_PACKED_PW=1
-run c1_w2a2 base MN_X=0
-run c1_w2a2 nopack MN_NO_PACKED_PW=1
-run c1 base MN_X=0
+# edit below: one line per measurement, e.g.
+#   run c2 base MN_X=0
+#   run c2 nopoolfold MN_BNH_POOL_FOLD=0
+for spec in "$@"; do          # or pass "workload:label:ENV=VALUE" triples on the command line
+  IFS=: read -r w l e <<< "$spec"
+  run "$w" "$l" "${e:-MN_X=0}"
+done

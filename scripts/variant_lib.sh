@@ -10,7 +10,7 @@ extra=""
 if { [ $src = qgemm_sign.hip ] || [ $src = qgemm_kxk.hip ]; } && [ -z "$MN_VARIANT_SLP" ]; then extra="-fno-slp-vectorize"; fi     # as micronet_amd/build.py EXTRA_FLAGS
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc $extra "$@" -c micronet_amd/csrc/$src -o $L/${base}_$tag.o
 objs=""
-for f in quant_kernels conv_kernels qgemm_kernels qgemm_kxk qgemm_sign qgemm_k3s conv_first optim_kernels norm_kernels iao_ops qact_kernels data_kernels; do
+for f in $(python -c "from micronet_amd.build import SOURCES; print(' '.join(s[:-4] for s in SOURCES))"); do          # (every object of the library: micronet_amd/build.py)
   if [ $f = $base ]; then objs="$objs $L/${base}_$tag.o"; else objs="$objs $L/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libmicronet_hip_$tag.so $objs
