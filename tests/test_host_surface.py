@@ -230,3 +230,56 @@ def test_dorefa_weight_grid_verdict_is_forgotten_on_load_state_dict():
     m.__dict__["_mn_grid"] = (("stale",), True, None)
     m.load_state_dict(m.state_dict())
     assert "_mn_grid" not in m.__dict__
+
+
+def test_iao_prepare_marks_convs_that_feed_our_batchnorms():
+    """prepare() of an IAO ResNet: every QuantConv2d that a BatchNorm2dReLU / BatchNorm2dPlain of ours reads next (same nn.Sequential, definition order) is told to
+    leave the exact sums of its integer accumulator on its output (``emit_accstats``: the BatchNorm then normalises in one pass) -- and nothing else changes:
+    module names and ``state_dict`` are the reference's (checked by test_prepare_matches_reference_surface)."""
+    from micronet.compression.quantization.wqaq.iao import quantize
+    from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dPlain, BatchNorm2dReLU
+    q = quantize.prepare(build_model("resnet18"), inplace=True, a_bits=4, w_bits=4, q_type=0, q_level=0)
+    marked = [m for m in q.modules() if getattr(m, "emit_accstats", False)]
+    bns = [m for m in q.modules() if isinstance(m, (BatchNorm2dReLU, BatchNorm2dPlain))]
+    assert len(marked) == len(bns) == 20 and all(type(m) is quantize.QuantConv2d for m in marked)
+    # without the fused BatchNorms there is nobody to hand the sums to
+    q2 = quantize.prepare(build_model("resnet18"), inplace=True, a_bits=4, w_bits=4, q_type=0, q_level=0, fuse_bn_act=False)
+    assert not any(getattr(m, "emit_accstats", False) for m in q2.modules())
+
+
+@pytest.mark.parametrize("W", [3, 2])
+def test_wbwtab_bn_fuse_keeps_code_weights_on_the_packed_path(W):
+    """micronet_amd.inference.wbwtab_model_bn_fuse (ref wbwtab/bn_fuse/bn_fuse.py:20-107) on the host: folded from PRE-QUANTISED weights (codes x alpha per output
+    channel) the quantised convs in front of a sign are marked ``stored_codes`` / ``lazy_for_bn`` and the signs behind them ``deploy_packed`` -- the deployed graph then
+    stays on one byte per activation; folded from raw weights nothing is marked (the reference convolves them as they are, so do we).  Fold arithmetic itself: the
+    golden tests (tests/test_oracle_golden.py pins the oracle, tests/test_gpu_inference.py the product)."""
+    from micronet.compression.quantization.wbwtab import quantize
+    from micronet_amd import inference
+    from micronet_amd.nn import Conv2dFirst, Conv2dSignIn
+    torch.manual_seed(3)
+    I = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=W, quant_inference=True)
+    raw = inference.wbwtab_model_bn_fuse(I, W=W)
+    qc = [m for m in raw.modules() if isinstance(m, quantize.QuantConv2d)]
+    assert len(qc) == 7 and not any(m.stored_codes or m.lazy_for_bn for m in qc)
+    with torch.no_grad():
+        for m in I.modules():
+            if isinstance(m, quantize.QuantConv2d):          # what quant_model_para.py stores: t * alpha[o] (t ternary / binary)
+                t = torch.randint(-1 if W == 3 else 0, 2, m.weight.shape).float()
+                if W == 2:
+                    t = t * 2 - 1
+                t.view(t.shape[0], -1)[:, 0] = 1
+                m.weight.copy_(t * (torch.rand(t.shape[0], 1, 1, 1) * 0.2 + 0.05))
+        for m in I.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(torch.randn_like(m.weight))          # both signs of gamma: the fold flips the weights' sign where gamma < 0
+    F = inference.wbwtab_model_bn_fuse(I, W=W)
+    qc = [m for m in F.modules() if isinstance(m, quantize.QuantConv2d)]
+    assert len(qc) == 7 and all(m.stored_codes and m.lazy_for_bn and m.quant_inference for m in qc)
+    acts = [m for m in F.modules() if isinstance(m, quantize.ActivationQuantizer)]
+    assert len(acts) == 8 and all(a.deploy_packed for a in acts)
+    convs = [m for m in F.modules() if isinstance(m, nn.Conv2d)]
+    assert type(convs[0]) is Conv2dFirst and type(convs[-1]) is Conv2dSignIn          # the fp32 ends keep their kernels
+    assert list(F.state_dict().keys()) == list(raw.state_dict().keys())
+    assert not any(isinstance(m, nn.BatchNorm2d) for m in F.modules())
+    # the training graph is untouched by the conversion (deep copy) and its signs do not take the deployed route
+    assert not any(getattr(m, "deploy_packed", False) for m in I.modules() if isinstance(m, quantize.ActivationQuantizer))
