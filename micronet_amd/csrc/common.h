@@ -153,6 +153,49 @@ __device__ __forceinline__ float dorefa_act_grad_m(float g, float x, float s, fl
     d = (t >= 0.f && t <= 1.f) ? d : 0.f;
     return d * 0.1f;
 }
+// ---- the masks of that backward as an INTERVAL of the block's input value.  dz = STE(gq) * [z > 0] * [0.1 relu(z) <= 1] and z is a monotone function of the
+// value v the pass streams (the fp32 conv output y, or the integer stash: every step of v -> y -> zhat -> z -> relu -> 0.1 a is monotone in fp32 as well), so the
+// two conditions select ONE interval [lo, hi] of v per channel.  Its ends are found by bisection with the EXACT expressions (a lane per channel, ~60 evaluations
+// once per block), after which an element costs two compares instead of the ~10 instructions of z, relu, the clamp test and their selects -- same decisions bit
+// for bit.  Float domain: bisection over the ordered integer image of the floats.
+__device__ __forceinline__ int32_t mn_fkey(float f) { const int32_t b = (int32_t)mn_f2u(f); return b >= 0 ? b : (int32_t)(0x80000000u - (uint32_t)b); }
+__device__ __forceinline__ float mn_keyf(int32_t k) { return mn_u2f(k >= 0 ? (uint32_t)k : (0x80000000u - (uint32_t)k)); }
+struct QaInterval { float lo, hi; };          // pass iff lo <= v && v <= hi (an empty set is lo = 1, hi = 0)
+// zfun(v) -> z; the domain is the integers / float keys w in [-R, R], v = vof(w).  quant: the clamp condition applies.
+template <class ZF, class VF>
+__device__ __forceinline__ QaInterval qa_mask_interval(int32_t R, ZF zfun, VF vof, int quant) {
+    const bool flip = zfun(vof(R)) < zfun(vof(-R));          // z decreases with v: search in w = -v
+    auto zw = [&](int64_t w) { return zfun(vof((int32_t)(flip ? -w : w))); };
+    auto first = [&](bool second) {          // smallest w in [-R, R] with the (monotone) predicate true, R + 1 if none
+        int64_t lo = -(int64_t)R, hi = (int64_t)R + 1;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            const float z = zw(mid);
+            const bool pr = second ? !((z > 0.f ? z : 0.f) * 0.1f <= 1.f) && z > 0.f : z > 0.f;
+            if (pr) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const int64_t w1 = first(false);
+    const int64_t w2 = quant ? first(true) : (int64_t)R + 1;
+    QaInterval r;
+    if (w1 > w2 - 1) { r.lo = 1.f; r.hi = 0.f; return r; }
+    const int64_t a = flip ? -(w2 - 1) : w1, b = flip ? -w1 : w2 - 1;
+    r.lo = vof((int32_t)a); r.hi = vof((int32_t)b);
+    return r;
+}
+__device__ __forceinline__ float dorefa_ste_core_m(float g, float s, float inv) {          // ((g s) / s) * 0.1: the clip-STE without its clamp test (the interval holds it)
+    const float d0 = g * s;
+    float d;
+    if (inv != 0.f) {
+        const float q0 = d0 * inv;
+        const float r = fmaf(-q0, s, d0);
+        d = fmaf(r, inv, q0);
+    } else {
+        d = d0 / s;
+    }
+    return d * 0.1f;
+}
 __device__ __forceinline__ float qa_dz_m(float gq, float a, float z, float s, float inv, int quant) {
     const float d = quant ? dorefa_act_grad_m(gq, a, s, inv) : gq;
     return (z > 0.f) ? d : 0.f;

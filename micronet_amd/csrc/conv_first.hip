@@ -52,6 +52,7 @@ struct C1Params {
     int quant;            // dq is the gradient w.r.t. the QUANTISED activation (the clip-STE is applied here)
     float qs;             // quantizer scale 1 / (2^a - 1)
     float qs_inv;         // RN(1 / qs) (qa_dz_m); 0: IEEE division
+    int interval;         // BN 2: the block's masks as one interval of y per channel (A/B knob MN_QA_NO_INTERVAL)
 };
 
 // stage the image strip (with zero halo) of image n, rows [row0 - ph, row0 + R + KH - 1 - ph) into xs[c][prow][pcol]
@@ -364,6 +365,16 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
             ctab[r * 8 + 4] = p.training ? p.sums[mc] / p.n_f : 0.f;
             ctab[r * 8 + 5] = p.training ? p.sums[p.O + mc] / p.n_f : 0.f;
             ctab[r * 8 + 6] = BN == 2 ? p.chan[8 * p.O + mc] : 0.f; ctab[r * 8 + 7] = 0.f;
+            if (BN == 2 && p.interval) {
+                // the ReLU mask and the quantizer's clamp test as ONE interval of y per channel (qa_mask_interval, common.h): the per-element z, relu, 0.1 a and their
+                // selects (10 of ~21 VALU instructions per element of this VALU-bound fold) become two compares.  A channel whose constants are not finite (or
+                // gamma == 0: z is constant, an overflowing zhat would make it NaN) keeps the element-wise form (slot 7 = 0).
+                const float mean = ctab[r * 8 + 0], invstd = ctab[r * 8 + 1], ga = ctab[r * 8 + 2], be = ctab[r * 8 + 3];
+                if (fabsf(mean) <= 1.0e9f && fabsf(invstd) <= 1.0e9f && fabsf(ga) <= 1.0e9f && fabsf(be) <= 1.0e9f && ga != 0.f && invstd > 0.f) {
+                    const QaInterval iv = qa_mask_interval(0x7f7fffff, [&](float y) { return ((y - mean) * invstd) * ga + be; }, [](int32_t k) { return mn_keyf(k); }, p.quant);
+                    ctab[r * 8 + 2] = iv.lo; ctab[r * 8 + 3] = iv.hi; ctab[r * 8 + 7] = 1.f;
+                }
+            }
         }
         MN_WAVE_SYNC();
     }
@@ -399,13 +410,19 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
                     const float4 c0 = *reinterpret_cast<const float4*>(ctab + (sr + 8 * i) * 8);        // mean, invstd, gamma, beta
                     const float2 c1 = *reinterpret_cast<const float2*>(ctab + (sr + 8 * i) * 8 + 4);    // k1, k2
                     const float cgi_ = BN == 2 ? ctab[(sr + 8 * i) * 8 + 6] : c0.z * c0.y;
+                    const bool ivl = BN == 2 && ctab[(sr + 8 * i) * 8 + 7] != 0.f;          // this row's masks are an interval of y: c0.z = lo, c0.w = hi
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float zh = (yv[e] - c0.x) * c0.y;
-                        const float zz = zh * c0.z + c0.w;
                         float dz;
-                        if (BN == 2) dz = qa_dz_m(r[e], qa_relu(zz), zz, p.qs, p.qs_inv, p.quant);     // expression for expression k_qa_apply<1, 0>
-                        else dz = (zz > -1.f && zz < 1.f) ? r[e] : 0.f;
+                        if (ivl) {
+                            const float d = p.quant ? dorefa_ste_core_m(r[e], p.qs, p.qs_inv) : r[e];
+                            dz = (yv[e] >= c0.z && yv[e] <= c0.w) ? d : 0.f;
+                        } else {
+                            const float zz = zh * c0.z + c0.w;
+                            if (BN == 2) dz = qa_dz_m(r[e], qa_relu(zz), zz, p.qs, p.qs_inv, p.quant);     // expression for expression k_qa_apply<1, 0>
+                            else dz = (zz > -1.f && zz < 1.f) ? r[e] : 0.f;
+                        }
                         r[e] = cgi_ * (dz - c1.x - zh * c1.y);
                     }
                 }
@@ -638,7 +655,7 @@ static int c1_bwd_weight_any(const mn_conv_geom* g, const float* gy, const float
     p.wp = nullptr; p.bias = nullptr; p.y = nullptr;
     p.da = gy ? nullptr : da; p.yb = yb; p.save = save; p.gamma = gamma; p.beta = beta; p.sums = sums; p.training = training;
     p.n_f = (float)g->N * (float)(g->H * g->W);
-    p.chan = gy ? nullptr : chan; p.quant = quant; p.qs = qs; p.qs_inv = (qs > 0.f && !MN_ENV("MN_QA_IEEE_DIV")) ? 1.0f / qs : 0.f;
+    p.chan = gy ? nullptr : chan; p.quant = quant; p.qs = qs; p.qs_inv = (qs > 0.f && !MN_ENV("MN_QA_IEEE_DIV")) ? 1.0f / qs : 0.f; p.interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
     mn_set_last_kernel("k_c1_wgrad<%d, %d>", pl.MT, p.da ? (p.chan ? 2 : 1) : 0);
     { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((p.da ? 8.0 : 4.0) * ny + 4.0 * g->N * g->C * g->H * g->W); }
     mn_prof_begin(s);

@@ -25,6 +25,7 @@ struct QaGeom {
     int64_t n8;             // 8-element groups per channel (no pool) / 4-window groups per channel (pool)
     float s;                // quantizer scale 1 / (2^a - 1)
     float inv_s;            // RN(1 / s) for the division-free clip-STE (qa_dz_m); 0: the IEEE division
+    int interval;           // backward passes: the ReLU / clamp masks as one interval of the streamed value per channel (qa_mask_interval; knob MN_QA_NO_INTERVAL)
     int nthr;               // > 0 (mn_qa_fwd on the integer stash, <= 3 bit codes): levels 2^a - 1 of the integer-threshold forward
 };
 struct QaCh { float alpha, bias, mean, invstd, ga, be, A, B, gi; };
@@ -202,12 +203,36 @@ __global__ __launch_bounds__(256) void k_qa_fwd(const QaGeom g, const void* __re
 // QUANT 1: dq is the gradient w.r.t. the QUANTISED activation (the clip-STE of the quantizer is applied here); 0: w.r.t. the activation itself
 // (the block's consumer is not a quantised conv: e.g. the last block of the net).
 // (qa_relu, qa_dz: common.h -- shared with the first-layer backward-weight kernel that folds this block, conv_first.hip)
+// the block's channel: its backward masks as an interval of the streamed value (stash integer / fp32 y), found by thread 0 and broadcast; use = false: a channel
+// with non-finite (or absurd) constants, or gamma == 0, keeps the element-wise masks
+struct QaIv { float lo, hi; bool use; };
+template <int IN>
+__device__ __forceinline__ QaIv qa_block_interval(const QaGeom& g, const QaCh& k, int quant) {
+    __shared__ float iv_[3];
+    if (threadIdx.x == 0) {
+        float use = 0.f;
+        QaInterval r; r.lo = 1.f; r.hi = 0.f;
+        if (g.interval && qa_finite(k.alpha) && qa_finite(k.bias) && qa_finite(k.mean) && qa_finite(k.invstd) && qa_finite(k.ga) && qa_finite(k.be) && k.ga != 0.f && k.invstd > 0.f &&
+            (IN == 1 || k.alpha != 0.f)) {
+            auto zf = [&](float v) { float zh, z; qa_eval<IN>(v, k, zh, z); return z; };
+            if (IN == 1) r = qa_mask_interval(0x7f7fffff, zf, [](int32_t w) { return mn_keyf(w); }, quant);
+            else r = qa_mask_interval(IN == 2 ? (1 << 24) : 32768, zf, [](int32_t w) { return (float)w; }, quant);
+            use = 1.f;
+        }
+        iv_[0] = r.lo; iv_[1] = r.hi; iv_[2] = use;
+    }
+    __syncthreads();
+    QaIv o; o.lo = iv_[0]; o.hi = iv_[1]; o.use = iv_[2] != 0.f;
+    return o;
+}
 template <int IN, int POOL>
 __global__ __launch_bounds__(256) void k_qa_partial(const QaGeom g, const void* __restrict__ in, const float* __restrict__ chan, const float* __restrict__ dq,
                                                     int quant, double* __restrict__ part) {
     __shared__ double scd[16];
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
     const QaCh k = qa_load_ch(chan, g.C, c);
+    QaIv iv; iv.lo = 1.f; iv.hi = 0.f; iv.use = false;
+    if (!POOL) iv = qa_block_interval<IN>(g, k, quant);          // (the pooled pass needs the activations themselves: the window's first maximum)
     double s1 = 0.0, s2 = 0.0;
     for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
         float t1 = 0.f, t2 = 0.f;
@@ -217,6 +242,16 @@ __global__ __launch_bounds__(256) void k_qa_partial(const QaGeom g, const void* 
             qa_load8<IN>(in, off, v);
             const float4 ga = *reinterpret_cast<const float4*>(dq + off), gb = *reinterpret_cast<const float4*>(dq + off + 4);
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+            if (iv.use) {          // block-uniform
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = IN == 1 ? v[e] : v[e] * k.alpha + k.bias;
+                    const float zh = (y - k.mean) * k.invstd;
+                    const float d = quant ? dorefa_ste_core_m(gv[e], g.s, g.inv_s) : gv[e];
+                    const float dz = (v[e] >= iv.lo && v[e] <= iv.hi) ? d : 0.f;
+                    t1 += dz; t2 += dz * zh;
+                }
+            } else
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float zh, z;
@@ -268,6 +303,8 @@ __global__ __launch_bounds__(256) void k_qa_apply(const QaGeom g, const void* __
     const QaCh k = qa_load_ch(chan, g.C, c);
     float k1 = 0.f, k2 = 0.f;
     if (training) { const float n = (float)g.N * (float)g.HW; k1 = sums[c] / n; k2 = sums[g.C + c] / n; }
+    QaIv iv; iv.lo = 1.f; iv.hi = 0.f; iv.use = false;
+    if (!POOL) iv = qa_block_interval<IN>(g, k, quant);
     for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
         if (!POOL) {
             const int64_t off = qa_off8(g, c, (uint32_t)i);
@@ -275,6 +312,16 @@ __global__ __launch_bounds__(256) void k_qa_apply(const QaGeom g, const void* __
             qa_load8<IN>(in, off, v);
             const float4 ga = *reinterpret_cast<const float4*>(dq + off), gb = *reinterpret_cast<const float4*>(dq + off + 4);
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+            if (iv.use) {          // block-uniform
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = IN == 1 ? v[e] : v[e] * k.alpha + k.bias;
+                    const float zh = (y - k.mean) * k.invstd;
+                    const float d = quant ? dorefa_ste_core_m(gv[e], g.s, g.inv_s) : gv[e];
+                    const float dz = (v[e] >= iv.lo && v[e] <= iv.hi) ? d : 0.f;
+                    r[e] = k.gi * (dz - k1 - zh * k2);
+                }
+            } else
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float zh, z;
@@ -390,6 +437,7 @@ static int qa_geom(QaGeom* g, int64_t N, int64_t C, int64_t H, int64_t W, int bi
     g->n8 = pool ? N * (H / 2) * (W / 8) : N * (HW / 8);
     g->s = dorefa_scale(bits);
     g->inv_s = MN_ENV("MN_QA_IEEE_DIV") ? 0.f : 1.0f / g->s;
+    g->interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
     g->nthr = 0;
     return MN_OK;
 }

@@ -1135,6 +1135,87 @@ def check_qa_thresholds(be, bits=2, pool=False, seed=0):
     assert np.array_equal(got, ref), (bits, pool, np.argwhere(got != ref)[:5])
 
 
+def check_qa_interval_masks(be, in_kind=0, quant=1, bits=2, seed=0):
+    """The backward masks of the k-bit block as ONE interval of the streamed value per channel (qa_mask_interval: mn_qa_bwd_sums / mn_qa_bwd_apply, non-pooled) against
+    the element-wise fp32 chain in numpy, BIT FOR BIT: channels with positive, negative, tiny and huge slopes, a constant channel (gamma = 0: element-wise fall-back),
+    channels that never / always pass, values on both sides of every boundary.  in_kind 0: int16 stash, 2: int32 stash, 1: fp32 y."""
+    r = np.random.default_rng(seed)
+    n = (1 << bits) - 1
+    s32 = F(1.0) / F(n)
+    Cc, N, H, W = 12, 2, 8, 16
+    alpha = (r.random(Cc) * 0.02 + 0.001).astype(F)
+    bias = (r.standard_normal(Cc) * 0.1).astype(F)
+    mean = (r.standard_normal(Cc) * 0.5).astype(F)
+    invstd = (r.random(Cc) * 3 + 0.2).astype(F)
+    ga = (r.standard_normal(Cc) * 1.5).astype(F)
+    beb = (r.standard_normal(Cc) * 2 + 1).astype(F)
+    ga[0], beb[0] = F(0), F(5)                                 # constant channel: element-wise fall-back (always passes the ReLU, clamp decides)
+    ga[1], beb[1] = F(1e-6), F(-1)                             # never positive
+    alpha[2], invstd[2], ga[2] = F(1.0), F(10.0), F(-3.0)      # steep, decreasing
+    ga[3], beb[3] = F(1e-4), F(3.0)                            # always inside (0, 10]
+    ga[4], beb[4] = F(2.0), F(50.0)                            # mostly beyond the clamp
+    if in_kind == 1:
+        alpha[:] = 1; bias[:] = 0
+    chan = np.stack([alpha, bias, mean, invstd, ga, beb, alpha * invstd, (bias - mean) * invstd, ga * invstd]).astype(F)
+    sh = (1, Cc, 1, 1)
+    if in_kind == 1:
+        v = (r.standard_normal((N, Cc, H, W)) * 4).astype(F)
+        # values right at the channel's boundaries: solve z = 0 and 0.1 z = 1 for y in fp64, then step a few ulps around the fp32 neighbours
+        for c in range(Cc):
+            if ga[c] == 0:
+                continue
+            for zt in (0.0, 10.0):
+                y0 = F((zt - float(beb[c])) / float(ga[c]) / float(invstd[c]) + float(mean[c]))
+                u = np.float32(y0).view(np.int32)
+                for d in range(-8, 9):
+                    v[d % N, c, (d + 8) % H, (3 * d + (5 if zt else 0)) % W] = np.int32(int(u) + d).view(np.float32)
+        dev_in = be.to_dev(v)
+    else:
+        lim = 32768 if in_kind == 0 else (1 << 24)
+        st = r.integers(-lim, lim, size=(N, Cc, H, W)).astype(np.int64)
+        st[:, :, :, : W // 2] = r.integers(-600, 600, size=(N, Cc, H, W // 2))          # where the boundaries of typical channels are
+        for c in range(Cc):                                                            # ... and the exact neighbourhood of each channel's boundaries
+            if ga[c] == 0 or alpha[c] == 0:
+                continue
+            for zt in (0.0, 10.0):
+                v0 = int(round((((zt - float(beb[c])) / float(ga[c])) / float(invstd[c]) + float(mean[c]) - float(bias[c])) / float(alpha[c])))
+                for d in range(-6, 7):
+                    st[d % N, c, (d + 6) % H, (2 * d + (7 if zt else 0)) % W] = min(max(v0 + d, -lim), lim - 1)
+        st[0, :, 0, 0], st[0, :, 0, 1] = -lim, lim - 1
+        v = st.astype(F)
+        dev_in = be.to_dev_i16(st.astype(np.int16)) if in_kind == 0 else be.to_dev(st.astype(np.int32).view(F))
+    y = v if in_kind == 1 else ((v * alpha.reshape(sh)).astype(F) + bias.reshape(sh)).astype(F)
+    zh = ((y - mean.reshape(sh)).astype(F) * invstd.reshape(sh)).astype(F)
+    z = ((zh * ga.reshape(sh)).astype(F) + beb.reshape(sh)).astype(F)
+    a = np.where(z > 0, z, F(0)).astype(F)
+    dq = r.standard_normal((N, Cc, H, W)).astype(F)
+    if quant:
+        t = (a * F(0.1)).astype(F)
+        d = ((dq * s32).astype(F) / s32).astype(F)
+        d = (np.where((t >= 0) & (t <= 1), d, F(0)) * F(0.1)).astype(F)
+    else:
+        d = dq
+    dz = np.where(z > 0, d, F(0)).astype(F)
+    assert 0 < (dz != 0).mean() < 1
+    sums = np.stack([r.standard_normal(Cc), r.standard_normal(Cc)]).astype(F) * 10
+    nf = F(N) * F(H * W)
+    k1, k2 = (sums[0] / nf).astype(F), (sums[1] / nf).astype(F)
+    gi = chan[8]
+    dy_ref = (gi.reshape(sh) * ((dz - k1.reshape(sh)).astype(F) - (zh * k2.reshape(sh)).astype(F)).astype(F)).astype(F)
+    dC, dQ, dS = be.to_dev(chan), be.to_dev(dq), be.to_dev(sums)
+    dy = be.empty((N, Cc, H, W))
+    be.call("mn_qa_bwd_apply", in_kind, be.ptr(dev_in), be.ptr(dC), be.ptr(dS), be.ptr(dQ), N, Cc, H, W, bits, 0, int(quant), 1, be.ptr(dy), be.stream)
+    got = be.to_host(dy)
+    assert np.array_equal(got, dy_ref), (in_kind, quant, np.argwhere(got != dy_ref)[:5], float(np.abs(got - dy_ref).max()))
+    # the sums pass sees the same dz: sum dz and sum dz * zhat per channel (fp64 of fp32 terms)
+    ws = be.empty(int(be.lib.mn_qa_ws_floats(Cc)) + 8)
+    dgam, dbet, sm = be.empty(Cc), be.empty(Cc), be.empty((2, Cc))
+    be.call("mn_qa_bwd_sums", in_kind, be.ptr(dev_in), be.ptr(dC), be.ptr(dQ), N, Cc, H, W, bits, 0, int(quant), be.ptr(dgam), be.ptr(dbet), be.ptr(sm), be.ptr(ws), be.stream)
+    s1 = dz.astype(np.float64).sum(axis=(0, 2, 3))
+    sc1 = np.abs(dz).astype(np.float64).sum(axis=(0, 2, 3)).max()
+    assert np.max(np.abs(be.to_host(dbet) - s1)) <= 1e-6 * max(sc1, 1e-30), "sum dz"
+
+
 # ----------------------------------------------------------------------------- dense layers on activation codes (qgemm_dense.hip): the ResNet family
 def check_qdense(be, x_shape, Oc, k=3, stride=1, a_bits=2, w_bits=2, seed=0, prepack=False):
     """mn_qconv_bnq_fwd_stash / mn_conv2d_bwd_data / mn_conv2d_bwd_weight on activation codes for a DENSE layer (groups = 1, C and O multiples of 64; 3x3 stride 1 / 2,

@@ -238,6 +238,11 @@ def test_deployed_sign_block_identity_statistics(be, case):
     K.check_deployed_sign_block(be, seed=500 + case, **K.DEPLOYED_CASES[case])
 
 
+@pytest.mark.parametrize("in_kind,quant,bits", [(0, 1, 2), (0, 0, 4), (2, 1, 8), (2, 0, 8), (1, 1, 2), (1, 1, 8), (1, 0, 3)])
+def test_qa_backward_masks_as_intervals_bit_exact(be, in_kind, quant, bits):
+    K.check_qa_interval_masks(be, in_kind=in_kind, quant=quant, bits=bits, seed=10 * in_kind + quant)
+
+
 def test_qg_pack_multi_images_bit_identical(be):
     K.check_qg_pack_multi(be)
 
