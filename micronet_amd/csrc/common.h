@@ -38,6 +38,8 @@ void mn_prof_end(hipStream_t s);
 typedef unsigned int u32x4 __attribute__((vector_size(16)));
 #ifdef MN_EMULATION
 __device__ __forceinline__ f32x4 mn_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) { return emu_mfma_f32_16x16x32_bf16(a, b, c); }
+typedef float f32x16 __attribute__((vector_size(64)));
+__device__ __forceinline__ f32x16 mn_mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_f32_32x32x16_bf16(a, b, c); }
 typedef int i32x4 __attribute__((vector_size(16)));
 __device__ __forceinline__ i32x4 mn_mfma_i8(u32x4 a, u32x4 b, i32x4 c) { return emu_mfma_i32_16x16x64_i8(a, b, c); }
 __device__ __forceinline__ int mn_wave_any(int pred) { return emu_wave_any(pred); }
@@ -50,6 +52,14 @@ __device__ __forceinline__ f32x4 mn_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     v4f r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mn_bf16x8, a), __builtin_bit_cast(mn_bf16x8, b),
                                                     __builtin_bit_cast(v4f, c), 0, 0, 0);
     return __builtin_bit_cast(f32x4, r);
+}
+// v_mfma_f32_32x32x16_bf16: A[i = lane&31][k = 8*(lane>>5) + e], B[k = 8*(lane>>5) + e][j = lane&31], D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31], reg = 0..15:
+// 8 MACs per operand byte (the 16x16x32 form: 4) at the same matrix-core rate
+typedef float f32x16 __attribute__((vector_size(64)));
+__device__ __forceinline__ f32x16 mn_mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    v16f r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mn_bf16x8, a), __builtin_bit_cast(mn_bf16x8, b), __builtin_bit_cast(v16f, c), 0, 0, 0);
+    return __builtin_bit_cast(f32x16, r);
 }
 // v_mfma_i32_16x16x64_i8: signed bytes, A[i = lane&15][k = 16*(lane>>4) + e], B[k = 16*(lane>>4) + e][j = lane&15], D like the bf16 form; exact i32 accumulation
 typedef int i32x4 __attribute__((vector_size(16)));

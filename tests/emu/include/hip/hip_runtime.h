@@ -252,6 +252,28 @@ static inline __emu_f32x4 emu_mfma_f32_16x16x32_bf16(__emu_u32x4 a, __emu_u32x4 
     emu::yield(emu::WAIT_WAVE);
     return c;
 }
+// v_mfma_f32_32x32x16_bf16: A[i = lane&31][k = 8*(lane>>5) + e], B[k = 8*(lane>>5) + e][j = lane&31]; D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31],
+// reg = 0..15 (cdna_hip_programming.md "Fragment layout").  Same in-order fp32 chain over k as the 16x16x32 form.
+typedef float __emu_f32x16 __attribute__((vector_size(64)));
+static inline __emu_f32x16 emu_mfma_f32_32x32x16_bf16(__emu_u32x4 a, __emu_u32x4 b, __emu_f32x16 c) {
+    emu::Ctx& cx = emu::C();
+    int base = (emu::flat_tid() / 64) * 64, l = emu::lane();
+    for (int e = 0; e < 8; ++e) {
+        cx.wa8[(base + l) * 8 + e] = emu_bf16_to_f32((a[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        cx.wb8[(base + l) * 8 + e] = emu_bf16_to_f32((b[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    }
+    emu::yield(emu::WAIT_WAVE);
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int kb = 0; kb < 2; ++kb)
+            for (int e = 0; e < 8; ++e) acc = fmaf(cx.wa8[(base + kb * 32 + row) * 8 + e], cx.wb8[(base + kb * 32 + col) * 8 + e], acc);
+        c[r] = acc;
+    }
+    emu::yield(emu::WAIT_WAVE);
+    return c;
+}
 // v_mfma_i32_16x16x64_i8: A[i = lane&15][k = 16*(lane>>4) + e], B[k = 16*(lane>>4) + e][j = lane&15] (signed bytes, little endian in the four dwords), D as above
 typedef int __emu_i32x4 __attribute__((vector_size(16)));
 static inline __emu_i32x4 emu_mfma_i32_16x16x64_i8(__emu_u32x4 a, __emu_u32x4 b, __emu_i32x4 c) {
