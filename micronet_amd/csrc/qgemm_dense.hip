@@ -1400,7 +1400,7 @@ __device__ __forceinline__ void qdw_lds_wait(u32x2 (&)[6]) {}
 // the values are defined once qdw_lds_wait has passed them through
 __device__ __forceinline__ u32x2 qdw_lds_ld64(const unsigned char* q) {
     u32x2 r;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"((uint32_t)(uintptr_t)q));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"((uint32_t)(uintptr_t)q) : "memory");          // ("memory": stays behind the barrier / the staging stores before it)
     return r;
 }
 __device__ __forceinline__ void qdw_lds_wait(u32x2 (&w)[6]) {
