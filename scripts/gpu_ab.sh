@@ -19,6 +19,7 @@ PY
 # edit below: one line per measurement, e.g.
 #   run c2 base MN_X=0
 #   run c2 nopoolfold MN_BNH_POOL_FOLD=0
+#   bash scripts/gpu_ab.sh c4:base c4:wgrad32:MN_QD_WGRAD32=1 c5:base c5:wgrad32:MN_QD_WGRAD32=1     (the unmeasured 32x32x16 backward-weight kernel)
 for spec in "$@"; do          # or pass "workload:label:ENV=VALUE" triples on the command line
   IFS=: read -r w l e <<< "$spec"
   run "$w" "$l" "${e:-MN_X=0}"
