@@ -1297,6 +1297,46 @@ QDENSE_CASES = [
 ]
 
 
+def check_qd_wgrad32(be, hot=False):
+    """The opt-in 32 x 32 x 16 backward-weight kernel (MN_QD_WGRAD32=1 in the environment of THIS process: the knob is read once): every tile shape of the planner
+    (W = 4 .. 32, several images per tile with N not a multiple, several (o, c) pairs, split-K over tiles), the 32-bit-stash layer, signed IAO codes with the scale
+    on the device, and the partial tiles left for the multi-layer reduction -- against the same fp64 references and tolerances as k_qd_wgrad."""
+    last = lambda: be.lib.mn_last_kernel().decode()
+    cases = [((2, 64, 8, 8), 64), ((3, 128, 4, 4), 64), ((1, 64, 16, 16), 128), ((1, 64, 8, 32), 64), ((1, 512, 4, 4), 64), ((5, 64, 8, 8), 128)]
+    if hot:          # the four layer shapes of resnet18 on 32 x 32 inputs, a few images each
+        cases += [((8, 64, 32, 32), 64), ((16, 128, 16, 16), 128), ((37, 256, 8, 8), 256), ((70, 512, 4, 4), 512)]
+    for i, (xs, Oc) in enumerate(cases):
+        check_qdense(be, xs, Oc, 3, 1, seed=900 + i)
+        assert last().startswith("k_qd_wgrad32<"), last()
+    check_qdense(be, (2, 64, 8, 8), 64, 3, 1, a_bits=4, w_bits=4, seed=910)
+    assert last().startswith("k_qd_wgrad32<"), last()
+    check_qdense(be, (5, 128, 8, 8), 128, 3, 2, seed=911)          # stride 2 keeps the 16 x 16 x 32 kernel
+    assert last().startswith("k_qd_wgrad<2, 9>"), last()
+    check_qdense_iao(be, (3, 64, 8, 8), 64, a_bits=8, w_bits=8, bias=True, seed=912)
+    check_qd_wgrad_deferred(be, seed=913)
+
+
+WGRAD32_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import abi_driver
+import kernel_cases as K
+K.check_qd_wgrad32(abi_driver.Backend(sys.argv[2]), hot=sys.argv[3] == "1")
+print("wgrad32 ok")
+"""
+
+
+def run_wgrad32_child(backend, hot, timeout):
+    """check_qd_wgrad32 in a child process with MN_QD_WGRAD32=1."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MN_QD_WGRAD32="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", WGRAD32_CHILD, here, backend, "1" if hot else "0"], env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "wgrad32 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def check_qg_pack_multi(be, seed=0):
     """mn_qg_pack_multi: the forward and backward-data weight-code images of several pointwise layers in ONE launch; the entry points handed those images
     (mn_wq.packed_fwd / packed_bwd) must return BIT-IDENTICAL results to the calls that pack for themselves -- sign-code blocks (ternary weights) and k-bit blocks

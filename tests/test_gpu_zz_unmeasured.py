@@ -1,0 +1,13 @@
+"""Kernels that are written and emulator-checked but have NOT yet run on an MI355X (the round's GPU minutes ended first).  They are opt-in (environment knobs), so
+nothing the product does by default depends on them; their first hardware run is recorded here without gating the suite: xfail(strict=False) -- XPASS is the
+expected outcome, and the marker goes away with the first measured A/B."""
+import pytest
+
+import kernel_cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.xfail(reason="k_qd_wgrad32 (MN_QD_WGRAD32=1): first hardware run, opt-in kernel", strict=False)
+def test_qdense_backward_weight_on_32x32x16_mfma_first_hardware_run():
+    K.run_wgrad32_child("gpu", hot=True, timeout=900)

@@ -381,37 +381,10 @@ def test_qdense_layer_prepacked_weights(be, case):
     K.check_qdense(be, xs, Oc, k, s, seed=380 + case, prepack=True)
 
 
-_WGRAD32_SCRIPT = r"""
-import sys
-sys.path.insert(0, sys.argv[1])
-import abi_driver
-import kernel_cases as K
-be = abi_driver.Backend("emu")
-last = lambda: be.lib.mn_last_kernel().decode()
-# every tile shape of the backward-weight planner: W = 4 .. 32, several images per tile with N not a multiple, several pairs, split-K over tiles
-for i, (xs, Oc) in enumerate([((2, 64, 8, 8), 64), ((3, 128, 4, 4), 64), ((1, 64, 16, 16), 128), ((1, 64, 8, 32), 64), ((1, 512, 4, 4), 64), ((5, 64, 8, 8), 128)]):
-    K.check_qdense(be, xs, Oc, 3, 1, seed=900 + i)
-    assert last().startswith("k_qd_wgrad32<"), last()
-K.check_qdense(be, (2, 64, 8, 8), 64, 3, 1, a_bits=4, w_bits=4, seed=910)
-assert last().startswith("k_qd_wgrad32<"), last()
-K.check_qdense(be, (5, 128, 8, 8), 128, 3, 2, seed=911)          # stride 2 keeps the 16 x 16 x 32 kernel
-assert last().startswith("k_qd_wgrad<2, 9>"), last()
-K.check_qdense_iao(be, (3, 64, 8, 8), 64, a_bits=8, w_bits=8, bias=True, seed=912)       # signed codes (IAO), scale from the device
-K.check_qd_wgrad_deferred(be, seed=913)                            # partial tiles left for the multi-layer reduction
-print("wgrad32 ok")
-"""
-
-
 def test_qdense_backward_weight_on_32x32x16_mfma_opt_in():
     """MN_QD_WGRAD32=1 (read once per process: a child process): the 3 x 3 / stride 1 backward-weight on k_qd_wgrad32 -- 32 x 32 x 16 MFMA, 2 K-groups merged through
     the LDS, three conflict-free 8-byte reads per run -- against the same fp64 references and tolerances as k_qd_wgrad."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, MN_QD_WGRAD32="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-c", _WGRAD32_SCRIPT, here], env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "wgrad32 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    K.run_wgrad32_child("emu", hot=False, timeout=1500)
 
 
 def test_qdense_layer_bf16_forward(be):
