@@ -172,34 +172,27 @@ __device__ __forceinline__ int32_t mn_fkey(float f) { const int32_t b = (int32_t
 __device__ __forceinline__ float mn_keyf(int32_t k) { return mn_u2f(k >= 0 ? (uint32_t)k : (0x80000000u - (uint32_t)k)); }
 struct QaInterval { float lo, hi; };          // pass iff lo <= v && v <= hi (an empty set is lo = 1, hi = 0)
 // zfun(v) -> z; the domain is the integers / float keys w in [-R, R], v = vof(w).  quant: the clamp condition applies.
-// one of the two searches: which = 0: the smallest w in [-R, R] with z > 0, which = 1: the smallest w whose activation fails the clamp test; R + 1 if none.
-// w = v for an increasing z, -v for a decreasing one (flip).  The two searches are independent: a block may run them on two threads.
 template <class ZF, class VF>
-__device__ __forceinline__ int64_t qa_mask_search(int32_t R, ZF zfun, VF vof, bool flip, int which) {
-    int64_t lo = -(int64_t)R, hi = (int64_t)R + 1;
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        const float z = zfun(vof((int32_t)(flip ? -mid : mid)));
-        const bool pr = which ? !((z > 0.f ? z : 0.f) * 0.1f <= 1.f) && z > 0.f : z > 0.f;
-        if (pr) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-template <class VF>
-__device__ __forceinline__ QaInterval qa_mask_combine(int32_t R, VF vof, bool flip, int64_t w1, int64_t w2) {
+__device__ __forceinline__ QaInterval qa_mask_interval(int32_t R, ZF zfun, VF vof, int quant) {
+    const bool flip = zfun(vof(R)) < zfun(vof(-R));          // z decreases with v: search in w = -v
+    auto zw = [&](int64_t w) { return zfun(vof((int32_t)(flip ? -w : w))); };
+    auto first = [&](bool second) {          // smallest w in [-R, R] with the (monotone) predicate true, R + 1 if none
+        int64_t lo = -(int64_t)R, hi = (int64_t)R + 1;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            const float z = zw(mid);
+            const bool pr = second ? !((z > 0.f ? z : 0.f) * 0.1f <= 1.f) && z > 0.f : z > 0.f;
+            if (pr) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const int64_t w1 = first(false);
+    const int64_t w2 = quant ? first(true) : (int64_t)R + 1;
     QaInterval r;
     if (w1 > w2 - 1) { r.lo = 1.f; r.hi = 0.f; return r; }
     const int64_t a = flip ? -(w2 - 1) : w1, b = flip ? -w1 : w2 - 1;
     r.lo = vof((int32_t)a); r.hi = vof((int32_t)b);
     return r;
-}
-// zfun(v) -> z; the domain is the integers / float keys w in [-R, R], v = vof(w).  quant: the clamp condition applies.
-template <class ZF, class VF>
-__device__ __forceinline__ QaInterval qa_mask_interval(int32_t R, ZF zfun, VF vof, int quant) {
-    const bool flip = zfun(vof(R)) < zfun(vof(-R));          // z decreases with v: search in w = -v
-    const int64_t w1 = qa_mask_search(R, zfun, vof, flip, 0);
-    const int64_t w2 = quant ? qa_mask_search(R, zfun, vof, flip, 1) : (int64_t)R + 1;
-    return qa_mask_combine(R, vof, flip, w1, w2);
 }
 __device__ __forceinline__ float dorefa_ste_core_m(float g, float s, float inv) {          // ((g s) / s) * 0.1: the clip-STE without its clamp test (the interval holds it)
     const float d0 = g * s;

@@ -209,24 +209,17 @@ struct QaIv { float lo, hi; bool use; };
 template <int IN>
 __device__ __forceinline__ QaIv qa_block_interval(const QaGeom& g, const QaCh& k, int quant) {
     __shared__ float iv_[3];
-    __shared__ long long ws_[2];
-    const bool ok = g.interval && qa_finite(k.alpha) && qa_finite(k.bias) && qa_finite(k.mean) && qa_finite(k.invstd) && qa_finite(k.ga) && qa_finite(k.be) && k.ga != 0.f &&
-                    k.invstd > 0.f && (IN == 1 || k.alpha != 0.f);          // (block-uniform: the channel's constants)
-    if (ok) {
-        const int32_t R = IN == 1 ? 0x7f7fffff : (IN == 2 ? (1 << 24) : 32768);
-        auto zf = [&](float v) { float zh, z; qa_eval<IN>(v, k, zh, z); return z; };
-        auto vf = [](int32_t w) { return IN == 1 ? mn_keyf(w) : (float)w; };
-        const bool flip = zf(vf(R)) < zf(vf(-R));
-        // the two searches on two threads of different waves (~30 dependent evaluations each: the block waits for the slower one, not for their sum)
-        if (threadIdx.x == 0) ws_[0] = qa_mask_search(R, zf, vf, flip, 0);
-        if (threadIdx.x == 64) ws_[1] = quant ? qa_mask_search(R, zf, vf, flip, 1) : (long long)R + 1;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const QaInterval r = qa_mask_combine(R, vf, flip, ws_[0], ws_[1]);
-            iv_[0] = r.lo; iv_[1] = r.hi; iv_[2] = 1.f;
+    if (threadIdx.x == 0) {
+        float use = 0.f;
+        QaInterval r; r.lo = 1.f; r.hi = 0.f;
+        if (g.interval && qa_finite(k.alpha) && qa_finite(k.bias) && qa_finite(k.mean) && qa_finite(k.invstd) && qa_finite(k.ga) && qa_finite(k.be) && k.ga != 0.f && k.invstd > 0.f &&
+            (IN == 1 || k.alpha != 0.f)) {
+            auto zf = [&](float v) { float zh, z; qa_eval<IN>(v, k, zh, z); return z; };
+            if (IN == 1) r = qa_mask_interval(0x7f7fffff, zf, [](int32_t w) { return mn_keyf(w); }, quant);
+            else r = qa_mask_interval(IN == 2 ? (1 << 24) : 32768, zf, [](int32_t w) { return (float)w; }, quant);
+            use = 1.f;
         }
-    } else if (threadIdx.x == 0) {
-        iv_[0] = 1.f; iv_[1] = 0.f; iv_[2] = 0.f;
+        iv_[0] = r.lo; iv_[1] = r.hi; iv_[2] = use;
     }
     __syncthreads();
     QaIv o; o.lo = iv_[0]; o.hi = iv_[1]; o.use = iv_[2] != 0.f;
