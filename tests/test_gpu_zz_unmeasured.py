@@ -10,4 +10,4 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.xfail(reason="k_qd_wgrad32 (MN_QD_WGRAD32=1): first hardware run, opt-in kernel", strict=False)
 def test_qdense_backward_weight_on_32x32x16_mfma_first_hardware_run():
-    K.run_wgrad32_child("gpu", hot=True, timeout=900)
+    K.run_wgrad32_child("gpu", hot=True, timeout=420)
