@@ -609,6 +609,81 @@ __global__ __launch_bounds__(64) void k_pws_stats_prep(const double* __restrict_
     pws_prep_core(K, Kp, wc, g, m, Mpad, co, lane, rowscale[g * Mpad + m], bias ? bias[co] : 0.f, mean_f, inv_f, gamma[co], beta[co], chan, Cout, nnz9);
 }
 
+// k_pws_stats_prep's arguments, for its fold into k_h_sign (MN_HSIGN_FOLD=1): every block of the streaming sign pass evaluates its channel's constants itself (one
+// wave: the same reduction over the partial rows, the same fp32 chains, the same shuffles -- bit-identical values in every block), the block sp == 0 of a channel is
+// the one that writes them (save, running statistics, chan rows, the counter): one latency-bound launch less per block of the net.
+struct HsPrep {
+    const double* part; int CB, G, Mpad, Mr; const float* rowscale; const float* bias; double n; float eps, momentum; int training;
+    float* running_mean; float* running_var; float* save; int Cout, K, Kp; const uint16_t* wc; const float* gamma; const float* beta; float* chan; const float* nnz9;
+    long long* nbt;
+};
+// one wave; returns T, flip and the row's nnz (every lane).  `write`: this wave is the channel's writer.
+__device__ __forceinline__ void pws_stats_prep_dev(const HsPrep& q, int co, int lane, bool write, float& T_out, float& flip_out, float& nnz_out) {
+    const int g = co / q.Mr, m = co - g * q.Mr;
+    float mean_f = 0.f, inv_f = 0.f;
+    if (q.training) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int i = lane; i < q.CB; i += 64) {
+            const double* src = q.part + ((int64_t)i * q.G * q.Mpad + g * q.Mpad + m) * 2;
+            a1 += src[0]; a2 += src[1];
+        }
+        a1 = wave_reduce(a1, OpAddD()); a2 = wave_reduce(a2, OpAddD());
+        if (lane == 0) {
+            const double al = (double)q.rowscale[g * q.Mpad + m];
+            const double ma = a1 / q.n;
+            const double mean = al * ma + (double)(q.bias ? q.bias[co] : 0.f);
+            double ss = al * al * (a2 - a1 * ma);
+            if (ss < 0.0) ss = 0.0;
+            const float var_b = (float)(ss / q.n);
+            mean_f = (float)mean;
+            inv_f = 1.0f / sqrtf(var_b + q.eps);
+            if (write && q.running_mean) q.running_mean[co] = (1.f - q.momentum) * q.running_mean[co] + q.momentum * (float)mean;
+            if (write && q.running_var) q.running_var[co] = (1.f - q.momentum) * q.running_var[co] + q.momentum * (float)(ss / (q.n - 1.0));
+        }
+    } else if (lane == 0) {
+        mean_f = q.running_mean[co];
+        inv_f = 1.0f / sqrtf(q.running_var[co] + q.eps);
+    }
+    if (lane == 0 && write) {
+        q.save[co] = mean_f; q.save[q.Cout + co] = inv_f;
+        if (q.nbt && co == 0 && q.training) *q.nbt += 1;
+    }
+    mean_f = __shfl(mean_f, 0, 64); inv_f = __shfl(inv_f, 0, 64);
+    const float al = q.rowscale[g * q.Mpad + m], b = q.bias ? q.bias[co] : 0.f, ga = q.gamma[co], be = q.beta[co];
+    const int K = q.K;
+    const float zlo = pws_z(-(float)K, al, b, mean_f, inv_f, ga, be), zhi = pws_z((float)K, al, b, mean_f, inv_f, ga, be);
+    const float flip = (zhi < zlo) ? -1.f : 1.f;
+    int T = K + 1, L = K + 1, U = -K - 1;
+    for (int u = -K + lane; u <= K; u += 64) {
+        const float z = pws_z((float)u * flip, al, b, mean_f, inv_f, ga, be);
+        if (!(z < 0.f) && u < T) T = u;
+        if (z > -1.f && u < L) L = u;
+        if (z < 1.f && u > U) U = u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int t2 = __shfl_xor(T, o, 64), l2 = __shfl_xor(L, o, 64), u2 = __shfl_xor(U, o, 64);
+        T = t2 < T ? t2 : T; L = l2 < L ? l2 : L; U = u2 > U ? u2 : U;
+    }
+    int nnz = 0;
+    for (int k = lane; k < q.Kp; k += 64) nnz += (q.wc[((int64_t)g * q.Mpad + m) * q.Kp + k] & 0x7fffu) != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
+    if (write) {
+        float* chan = q.chan;
+        const int Cout = q.Cout;
+        if (lane == 0) {
+            chan[co] = (float)T; chan[Cout + co] = flip; chan[2 * Cout + co] = (float)L; chan[3 * Cout + co] = (float)U;
+            chan[4 * Cout + co] = al * inv_f;
+            chan[5 * Cout + co] = (b - mean_f) * inv_f;
+            chan[6 * Cout + co] = ga * inv_f;
+            chan[7 * Cout + co] = q.nnz9 ? -1.f : (float)nnz;
+        }
+        if (q.nnz9 && lane < 9) chan[(8 + lane) * Cout + co] = q.nnz9[lane * Cout + co];
+    }
+    T_out = (float)T; flip_out = flip; nnz_out = (float)nnz;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pointwise backward-weight on sign codes, without LDS:  dwq[g][m][c] = sum_{n,p} gy[n][g*Mg+m][p] * a[n][g*Cg+c][p].
 // The contraction index is the pixel, and BOTH operands are pixel-contiguous in NCHW: lane (i, kg) loads the 8 pixels of its
@@ -1447,7 +1522,10 @@ static int pws_bn_ok(const mn_conv_geom* g, const mn_wq* wq) { return g && wq &&
 extern "C" int mn_qconv_bnsign_supported(const mn_conv_geom* g, const mn_wq* wq) { return pws_bn_ok(g, wq); }
 extern "C" int64_t mn_qconv_bnsign_ws_bytes(const mn_conv_geom* g) { return g ? pws_ws_bytes(g) : -1; }
 
-static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s);
+struct HsPrep;
+static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s, const HsPrep* fold = nullptr);
+// MN_HSIGN_FOLD=1: k_pws_stats_prep's work inside the streaming sign pass (k_h_sign_prep) -- bit-identical on the emulator, NOT yet timed on a GPU: off by default
+static bool hsign_fold_enabled() { const char* e = MN_ENV("MN_HSIGN_FOLD"); return e && e[0] == '1'; }
 static void pws_chan_prep(PwsPlan& pl, const mn_conv_geom* g, const float* bias, const float* save, const float* gamma, const float* beta, hipStream_t s) {
     hipLaunchKernelGGL(k_pws_chan_prep, dim3((unsigned)g->O), dim3(64), 0, s, pl.p.Kc, pl.p.Kp, pl.p.wc, pl.p.G, pl.p.Mpad, pl.p.Mr, pl.p.rowscale, bias, save, gamma, beta,
                        (float*)pl.p.chan, (int)g->O);
@@ -1470,6 +1548,11 @@ static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const i
     p.h8 = stash_in_stats ? h : nullptr;
     if (training && (rc = launch_pws<PWS_STATS>(pl, s, nx + (stash_in_stats ? ny : 0.0), "mn_qconv_bnsign_fwd(stats)"))) return rc;
     if (chan_out) p.chan = chan_out;                     // caller-owned [8][O]: kept for the streaming backward (mn_bnh_bwd)
+    if (stash_in_stats && hsign_fold_enabled()) {
+        const HsPrep q{(const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, bias, (double)g->N * p.HW, eps, momentum, training, running_mean, running_var, save,
+                       (int)g->O, p.Kc, p.Kp, p.wc, gamma, beta, (float*)p.chan, (const float*)nullptr, (long long*)nbt};
+        return h_sign_launch(g->N, g->O, g->H, g->W, h, (const float*)p.chan, a, s, &q);
+    }
     hipLaunchKernelGGL(k_pws_stats_prep, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, bias,
                        (double)g->N * p.HW, eps, momentum, training, running_mean, running_var, save, (int)g->O, p.Kc, p.Kp, p.wc, gamma, beta,
                        (float*)p.chan, (const float*)nullptr, (long long*)nbt);
@@ -1586,10 +1669,7 @@ __global__ __launch_bounds__(256) void k_h_stats(const HGeom g, const unsigned c
     }
 }
 template <int VEC>
-__global__ __launch_bounds__(256) void k_h_sign(const HGeom g, const unsigned char* __restrict__ h, const float* __restrict__ chan, char* __restrict__ a) {
-    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
-    const float T = chan[c], fl = chan[C + c];
-    const StashNnz z = stash_nnz_load(chan, C, c);
+__device__ __forceinline__ void h_sign_stream(const HGeom& g, const unsigned char* __restrict__ h, char* __restrict__ a, int c, int sp, int S, float T, float fl, const StashNnz& z) {
     const int64_t nv = g.n4 / VEC;
     const uint32_t hwv = (uint32_t)(g.HW4 / VEC);
     for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < nv; i += (int64_t)S * 256) {
@@ -1616,18 +1696,51 @@ __global__ __launch_bounds__(256) void k_h_sign(const HGeom g, const unsigned ch
         else *reinterpret_cast<uint32_t*>(a + off) = out[0];
     }
 }
+template <int VEC>
+__global__ __launch_bounds__(256) void k_h_sign(const HGeom g, const unsigned char* __restrict__ h, const float* __restrict__ chan, char* __restrict__ a) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
+    const float T = chan[c], fl = chan[C + c];
+    const StashNnz z = stash_nnz_load(chan, C, c);
+    h_sign_stream<VEC>(g, h, a, c, sp, S, T, fl, z);
+}
+// MN_HSIGN_FOLD=1: the constants from the block's own evaluation of k_pws_stats_prep's work (HsPrep above) instead of a launch in front
+template <int VEC>
+__global__ __launch_bounds__(256) void k_h_sign_prep(const HGeom g, const unsigned char* __restrict__ h, const HsPrep q, char* __restrict__ a) {
+    __shared__ float hs_[3];
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
+    if (threadIdx.x < 64) {
+        float T_, fl_, nz_;
+        pws_stats_prep_dev(q, c, threadIdx.x, sp == 0, T_, fl_, nz_);
+        if (threadIdx.x == 0) { hs_[0] = T_; hs_[1] = fl_; hs_[2] = nz_; }
+    }
+    __syncthreads();
+    const float T = hs_[0], fl = hs_[1];
+    StashNnz z;
+    if (q.nnz9) {
+        z.v0 = q.nnz9[c]; z.v1 = q.nnz9[C + c]; z.v2 = q.nnz9[2 * C + c]; z.v3 = q.nnz9[3 * C + c]; z.v4 = q.nnz9[4 * C + c];
+        z.v5 = q.nnz9[5 * C + c]; z.v6 = q.nnz9[6 * C + c]; z.v7 = q.nnz9[7 * C + c]; z.v8 = q.nnz9[8 * C + c];
+    } else {
+        const float n7 = hs_[2];
+        z.v0 = n7; z.v1 = n7; z.v2 = n7; z.v3 = n7; z.v4 = n7; z.v5 = n7; z.v6 = n7; z.v7 = n7; z.v8 = n7;
+    }
+    h_sign_stream<VEC>(g, h, a, c, sp, S, T, fl, z);
+}
 static int h_splits(int C) { int S = 2048 / (C > 0 ? C : 1); return S < 1 ? 1 : (S > 64 ? 64 : S); }
-static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s) {
+static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s, const HsPrep* fold) {
     HGeom hg;
     hg.C = (int)O; hg.H = (int)H; hg.W4 = (int)(W / 4); hg.HW = (int)(H * W); hg.HW4 = hg.HW / 4; hg.Mr = 1; hg.Mpad = 1; hg.G = 1;
     hg.fd_hw4 = make_fastdiv((uint32_t)hg.HW4); hg.fd_w4 = make_fastdiv((uint32_t)hg.W4); hg.n4 = N * hg.HW4;
     const bool v4 = hg.HW % 16 == 0 && !(((uintptr_t)h) & 15) && !(((uintptr_t)a) & 15);
     hg.fd_hwv = make_fastdiv((uint32_t)(v4 ? hg.HW4 / 4 : hg.HW4));
     const int S = h_splits((int)O);
-    mn_set_last_kernel("k_h_sign");
+    mn_set_last_kernel(fold ? "k_h_sign_prep" : "k_h_sign");
     mn_prof_bytes(2.0 * (double)N * O * hg.HW);
     mn_prof_begin(s);
-    if (v4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, chan, (char*)a);
+    if (fold) {
+        if (v4) hipLaunchKernelGGL(k_h_sign_prep<4>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, *fold, (char*)a);
+        else hipLaunchKernelGGL(k_h_sign_prep<1>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, *fold, (char*)a);
+    }
+    else if (v4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, chan, (char*)a);
     else hipLaunchKernelGGL(k_h_sign<1>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, chan, (char*)a);
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_qconv_bnsign_fwd_stash(sign from h)");
@@ -1664,6 +1777,10 @@ static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
         int rc3 = 0;
         rc3 = k3s_fwd_h8(g, wq, x, w, nnzf, h, part, s);
         if (rc3) return rc3;
+        const bool fold3 = hsign_fold_enabled();
+        const HsPrep q3{(const double*)part, k3s_fwd_parts(g, wq), (int)g->groups, Mg, Mg, (const float*)alphaf, bias, (double)g->N * Hs * Ws, eps, momentum, training,
+                        running_mean, running_var, save, (int)g->O, Cg * 9, 0, (const uint16_t*)nullptr, gamma, beta, chan, (const float*)nnzf, (long long*)nbt};
+        if (!fold3)
         hipLaunchKernelGGL(k_pws_stats_prep, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)part, k3s_fwd_parts(g, wq), (int)g->groups, Mg, Mg,
                            (const float*)alphaf, bias, (double)g->N * Hs * Ws, eps, momentum, training, running_mean, running_var, save, (int)g->O,
                            Cg * 9, 0, (const uint16_t*)nullptr, gamma, beta, chan, (const float*)nnzf, (long long*)nbt);
@@ -1672,10 +1789,14 @@ static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
         hg3.fd_hw4 = make_fastdiv((uint32_t)hg3.HW4); hg3.fd_w4 = make_fastdiv((uint32_t)hg3.W4); hg3.n4 = (int64_t)g->N * hg3.HW4;
         const bool v4 = hg3.HW % 16 == 0 && !(((uintptr_t)h) & 15) && !(((uintptr_t)a) & 15);
         hg3.fd_hwv = make_fastdiv((uint32_t)(v4 ? hg3.HW4 / 4 : hg3.HW4));
-        mn_set_last_kernel("k_h_sign");
+        mn_set_last_kernel(fold3 ? "k_h_sign_prep" : "k_h_sign");
         mn_prof_bytes(2.0 * (double)g->N * g->O * hg3.HW);
         mn_prof_begin(s);
-        if (v4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, (const float*)chan, (char*)a);
+        if (fold3) {
+            if (v4) hipLaunchKernelGGL(k_h_sign_prep<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, q3, (char*)a);
+            else hipLaunchKernelGGL(k_h_sign_prep<1>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, q3, (char*)a);
+        }
+        else if (v4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, (const float*)chan, (char*)a);
         else hipLaunchKernelGGL(k_h_sign<1>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, (const float*)chan, (char*)a);
         mn_prof_end(s);
         MN_CHECK_LAUNCH("mn_qconv_bnsign_fwd_stash(3x3)");

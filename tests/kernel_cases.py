@@ -544,6 +544,7 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
         nbt = be.to_dev_i64([41])
         be.call("mn_qconv_bnsign_fwd_stash", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, int(training),
                 be.ptr(dRM), be.ptr(dRV), be.ptr(nbt), be.ptr(save), be.ptr(a8), be.ptr(h8), be.ptr(chan), be.ptr(ws), nb, be.stream)
+        check_qconv_bnsign.last_fwd_kernel = be.lib.mn_last_kernel().decode()
         assert int(be.to_host(nbt)[0]) == (42 if training else 41)         # BatchNorm's forward counter: incremented by the statistics launch
         acc_ref = O.conv2d_fwd(x_log, np.sign(w).astype(F), None, padding=padding, groups=groups)
         # nnz per pixel: the non-zero weights that meet a non-zero input (= all of them, except at the zero-padded border of a 3x3 block)
@@ -1316,25 +1317,49 @@ def check_qd_wgrad32(be, hot=False):
     check_qd_wgrad_deferred(be, seed=913)
 
 
-WGRAD32_CHILD = r"""
+def check_hsign_fold(be, kxk_cases):
+    """MN_HSIGN_FOLD=1 in the environment of THIS process: k_pws_stats_prep's work -- batch statistics from the partial rows, running statistics, the integer thresholds,
+    nnz, the counter -- evaluated inside the streaming sign pass (k_h_sign_prep: every block for itself, block 0 of a channel writes): the stashed pointwise and
+    3 x 3 blocks against the same references as the two-launch path (sign codes and stash bit for bit, statistics, counter, and the backward that reads `chan`)."""
+    for case in (1, 2):
+        check_qconv_bnsign(be, seed=220 + case, stash=True, **QGEMM_PW_CASES[case])
+        assert check_qconv_bnsign.last_fwd_kernel == "k_h_sign_prep", check_qconv_bnsign.last_fwd_kernel
+        check_qconv_bnsign(be, seed=225 + case, stash=True, training=False, **QGEMM_PW_CASES[case])        # eval: the sign comes from the MFMA pass, nothing to fold
+        if case in (1, 2):
+            check_qconv_bnsign(be, seed=230 + case, stash=True, pooled=True, **QGEMM_PW_CASES[case])
+    check_qconv_bnsign(be, seed=181, stash=True, x_shape=(2, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)
+    seen = []
+    for i, kw in enumerate(kxk_cases):
+        for training in (True, False):
+            check_qconv_bnsign(be, seed=260 + i, stash=True, training=training, **kw)
+            seen.append(check_qconv_bnsign.last_fwd_kernel)
+    assert seen.count("k_h_sign_prep") >= 4, seen          # the staged-image 3 x 3 path (nin_gc's pattern) in both modes; the generic k x k path keeps two launches
+
+
+CHILD = r"""
 import sys
 sys.path.insert(0, sys.argv[1])
 import abi_driver
 import kernel_cases as K
-K.check_qd_wgrad32(abi_driver.Backend(sys.argv[2]), hot=sys.argv[3] == "1")
-print("wgrad32 ok")
+be = abi_driver.Backend(sys.argv[2])
+%s
+print("child ok")
 """
+
+
+def run_child(body, backend, env, timeout):
+    """Run `body` (python statements using `be` and `K`) in a child process with extra environment: the library reads its MN_* knobs once per process."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", CHILD % body, here, backend], env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "child ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def run_wgrad32_child(backend, hot, timeout):
     """check_qd_wgrad32 in a child process with MN_QD_WGRAD32=1."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, MN_QD_WGRAD32="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-c", WGRAD32_CHILD, here, backend, "1" if hot else "0"], env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0 and "wgrad32 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    run_child("K.check_qd_wgrad32(be, hot=%s)" % bool(hot), backend, {"MN_QD_WGRAD32": "1"}, timeout)
 
 
 def check_qg_pack_multi(be, seed=0):

@@ -310,6 +310,11 @@ def test_qconv_kxk_bnsign_stash(be, case, training):
     K.check_qconv_bnsign(be, seed=260 + case, stash=True, training=training, **KXK_STASH_CASES[case])
 
 
+def test_sign_pass_with_the_statistics_finals_folded_in_opt_in():
+    """MN_HSIGN_FOLD=1 (child process): k_h_sign_prep instead of k_pws_stats_prep + k_h_sign."""
+    K.run_child("K.check_hsign_fold(be, %r)" % (KXK_STASH_CASES,), "emu", {"MN_HSIGN_FOLD": "1"}, 1500)
+
+
 def test_ternary_weight_quantizer_multi(be):
     K.check_ternary_multi(be)
 
