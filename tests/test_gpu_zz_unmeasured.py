@@ -11,3 +11,11 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.xfail(reason="k_qd_wgrad32 (MN_QD_WGRAD32=1): first hardware run, opt-in kernel", strict=False)
 def test_qdense_backward_weight_on_32x32x16_mfma_first_hardware_run():
     K.run_wgrad32_child("gpu", hot=True, timeout=420)
+
+
+@pytest.mark.xfail(reason="k_h_sign_prep (MN_HSIGN_FOLD=1): first hardware run, opt-in kernel", strict=False)
+def test_sign_pass_with_the_statistics_finals_folded_in_first_hardware_run():
+    kxk = [dict(x_shape=(3, 32, 8, 8), w_shape=(64, 16, 3, 3), padding=1, groups=2),
+           dict(x_shape=(2, 32, 16, 16), w_shape=(64, 16, 3, 3), padding=1, groups=2, in_shuffle=2, bias=False),
+           dict(x_shape=(2, 6, 16, 16), w_shape=(40, 6, 3, 3), padding=1)]
+    K.run_child("K.check_hsign_fold(be, %r)" % (kxk,), "gpu", {"MN_HSIGN_FOLD": "1"}, 420)
