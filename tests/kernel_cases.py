@@ -1317,19 +1317,19 @@ def check_qd_wgrad32(be, hot=False):
     check_qd_wgrad_deferred(be, seed=913)
 
 
-def check_hsign_fold(be, kxk_cases):
+def check_hsign_fold(be, kxk_cases, full=False):
     """MN_HSIGN_FOLD=1 in the environment of THIS process: k_pws_stats_prep's work -- batch statistics from the partial rows, running statistics, the integer thresholds,
     nnz, the counter -- evaluated inside the streaming sign pass (k_h_sign_prep: every block for itself, block 0 of a channel writes): the stashed pointwise and
     3 x 3 blocks against the same references as the two-launch path (sign codes and stash bit for bit, statistics, counter, and the backward that reads `chan`)."""
-    for case in (1, 2):
+    for case in ((0, 1, 2, 3) if full else (1,)):
         check_qconv_bnsign(be, seed=220 + case, stash=True, **QGEMM_PW_CASES[case])
         assert check_qconv_bnsign.last_fwd_kernel == "k_h_sign_prep", check_qconv_bnsign.last_fwd_kernel
         check_qconv_bnsign(be, seed=225 + case, stash=True, training=False, **QGEMM_PW_CASES[case])        # eval: the sign comes from the MFMA pass, nothing to fold
         if case in (1, 2):
             check_qconv_bnsign(be, seed=230 + case, stash=True, pooled=True, **QGEMM_PW_CASES[case])
-    check_qconv_bnsign(be, seed=181, stash=True, x_shape=(2, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)
+    check_qconv_bnsign(be, seed=181, stash=True, x_shape=(2, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)          # KS = 4, two m-blocks: the nin_gc pattern
     seen = []
-    for i, kw in enumerate(kxk_cases):
+    for i, kw in enumerate(kxk_cases if full else kxk_cases[:2]):
         for training in (True, False):
             check_qconv_bnsign(be, seed=260 + i, stash=True, training=training, **kw)
             seen.append(check_qconv_bnsign.last_fwd_kernel)

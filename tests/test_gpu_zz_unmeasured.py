@@ -18,4 +18,4 @@ def test_sign_pass_with_the_statistics_finals_folded_in_first_hardware_run():
     kxk = [dict(x_shape=(3, 32, 8, 8), w_shape=(64, 16, 3, 3), padding=1, groups=2),
            dict(x_shape=(2, 32, 16, 16), w_shape=(64, 16, 3, 3), padding=1, groups=2, in_shuffle=2, bias=False),
            dict(x_shape=(2, 6, 16, 16), w_shape=(40, 6, 3, 3), padding=1)]
-    K.run_child("K.check_hsign_fold(be, %r)" % (kxk,), "gpu", {"MN_HSIGN_FOLD": "1"}, 420)
+    K.run_child("K.check_hsign_fold(be, %r, full=True)" % (kxk,), "gpu", {"MN_HSIGN_FOLD": "1"}, 420)
