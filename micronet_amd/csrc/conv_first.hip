@@ -493,8 +493,27 @@ __global__ __launch_bounds__(256) void k_c1_reduce(const float* __restrict__ par
     for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
         const int64_t i = base + og;
         double s = 0.0;
-        if (i < ntile) { for (int z = zg; z < Z; z += 4) s += (double)part[(int64_t)z * ntile + i]; }
-        else if (i < total) { for (int z = zg; z < Z; z += 4) s += (double)dbpart[(int64_t)z * Opad + (i - ntile)]; }
+        // eight loads in flight, added in the order z = zg, zg + 4, ... as before (same sums bit for bit; one load at a time the loop is pure latency: 19.5 us for 15 k outputs)
+        const float* src = i < ntile ? part + i : dbpart + (i - ntile);
+        const int64_t zs = i < ntile ? ntile : (int64_t)Opad;
+        if (i < total) {
+            int z = zg;
+            for (; z + 28 < Z; z += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(z + 4 * u) * zs];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (double)v[u];
+            }
+            for (; z + 12 < Z; z += 16) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = src[(int64_t)(z + 4 * u) * zs];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s += (double)v[u];
+            }
+            for (; z < Z; z += 4) s += (double)src[(int64_t)z * zs];
+        }
         __syncthreads();
         red[zg][og] = s;
         __syncthreads();

@@ -268,6 +268,8 @@ def test_first_conv_qa_wgrad(be, training):
 def test_first_conv_bn_wgrad(be, training):
     K.check_first_conv_bn_wgrad(be, training=training)
     K.check_first_conv_bn_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, seed=1)
+    if training:          # 48 partial tiles: the batched (8 / 4 loads in flight) stages of k_c1_reduce
+        K.check_first_conv_bn_wgrad(be, x_shape=(6, 3, 32, 32), Oc=32, k=5, training=True, seed=5)
 
 
 @pytest.mark.parametrize("case", [0, 1, 2, 3])
