@@ -262,14 +262,16 @@ def test_code_classifier(be):
 def test_first_conv_qa_wgrad(be, training):
     K.check_first_conv_qa_wgrad(be, training=training)
     K.check_first_conv_qa_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, quant=0, bits=4, seed=1)
+    if training:          # 10 partial rows per channel: the batched stage of k_qa_final_bwd
+        K.check_first_conv_qa_wgrad(be, x_shape=(20, 3, 32, 32), Oc=8, k=3, seed=8)
 
 
 @pytest.mark.parametrize("training", [True, False])
 def test_first_conv_bn_wgrad(be, training):
     K.check_first_conv_bn_wgrad(be, training=training)
     K.check_first_conv_bn_wgrad(be, x_shape=(2, 3, 16, 16), Oc=160, k=3, training=training, seed=1)
-    if training:          # 48 partial tiles: the batched (8 / 4 loads in flight) stages of k_c1_reduce
-        K.check_first_conv_bn_wgrad(be, x_shape=(6, 3, 32, 32), Oc=32, k=5, training=True, seed=5)
+    if training:          # many partial tiles / 20 partial rows per channel: the batched (8 / 4 loads in flight) stages of k_c1_reduce and k_bns_final_bwd
+        K.check_first_conv_bn_wgrad(be, x_shape=(20, 3, 32, 32), Oc=8, k=3, training=True, seed=5)
 
 
 @pytest.mark.parametrize("case", [0, 1, 2, 3])
