@@ -300,6 +300,13 @@ __global__ void k_qa_final_bwd(int C, const double* __restrict__ part, int S, fl
 #pragma unroll
         for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
     }
+    for (; i + 4 <= S; i += 4) {
+        double v1[4], v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v1[u] = src[(i + u) * 2]; v2[u] = src[(i + u) * 2 + 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += v1[u]; s2 += v2[u]; }
+    }
     for (; i < S; ++i) { s1 += src[i * 2]; s2 += src[i * 2 + 1]; }
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
