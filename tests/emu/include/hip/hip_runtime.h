@@ -253,7 +253,8 @@ static inline __emu_f32x4 emu_mfma_f32_16x16x32_bf16(__emu_u32x4 a, __emu_u32x4 
     return c;
 }
 // v_mfma_f32_32x32x16_bf16: A[i = lane&31][k = 8*(lane>>5) + e], B[k = 8*(lane>>5) + e][j = lane&31]; D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31],
-// reg = 0..15 (cdna_hip_programming.md "Fragment layout").  Same in-order fp32 chain over k as the 16x16x32 form.
+// reg = 0..15 (cdna_hip_programming.md "Fragment layout"; the same map as ck_tile's WarpGemmAttributeMfmaImplBf16Bf16F32M32N32K16 in /opt/rocm/include: kAMLane 32,
+// kABKLane 2, kABKPerLane 8; kCMLane 2, kCNLane 32, kCM0PerLane 4, kCM1PerLane 4).  Same in-order fp32 chain over k as the 16x16x32 form.
 typedef float __emu_f32x16 __attribute__((vector_size(64)));
 static inline __emu_f32x16 emu_mfma_f32_32x32x16_bf16(__emu_u32x4 a, __emu_u32x4 b, __emu_f32x16 c) {
     emu::Ctx& cx = emu::C();
