@@ -170,6 +170,37 @@ __device__ __forceinline__ float dorefa_act_grad_m(float g, float x, float s, fl
 // for bit.  Float domain: bisection over the ordered integer image of the floats.
 __device__ __forceinline__ int32_t mn_fkey(float f) { const int32_t b = (int32_t)mn_f2u(f); return b >= 0 ? b : (int32_t)(0x80000000u - (uint32_t)b); }
 __device__ __forceinline__ float mn_keyf(int32_t k) { return mn_u2f(k >= 0 ? (uint32_t)k : (0x80000000u - (uint32_t)k)); }
+// s[k] += the rows i = 0 .. S-1 of a [S][NV] fp64 table, eight (then four) rows in flight, added in index order: the one-thread-per-channel "final" kernels
+// issue one dependent row of loads at a time otherwise -- pure latency (same sums bit for bit: the order of the additions is the plain loop's)
+template <int NV>
+__device__ __forceinline__ void mn_row_sums(const double* __restrict__ src, int S, double (&s)[NV]) {
+    int i = 0;
+    for (; i + 8 <= S; i += 8) {
+        double v[8][NV];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[u][k] = src[(i + u) * NV + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) s[k] += v[u][k];
+    }
+    for (; i + 4 <= S; i += 4) {
+        double v[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[u][k] = src[(i + u) * NV + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) s[k] += v[u][k];
+    }
+    for (; i < S; ++i)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s[k] += src[i * NV + k];
+}
 struct QaInterval { float lo, hi; };          // pass iff lo <= v && v <= hi (an empty set is lo = 1, hi = 0)
 // zfun(v) -> z; the domain is the integers / float keys w in [-R, R], v = vof(w).  quant: the clamp condition applies.
 template <class ZF, class VF>

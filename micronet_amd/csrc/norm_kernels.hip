@@ -90,8 +90,9 @@ __global__ void k_bns_final_fwd(const BnsGeom g, const float* __restrict__ y, co
                                 float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < S; ++i) { s1 += part[((int64_t)c * S + i) * 2]; s2 += part[((int64_t)c * S + i) * 2 + 1]; }
+    double sv[2] = {0.0, 0.0};
+    mn_row_sums<2>(part + (int64_t)c * S * 2, S, sv);
+    const double s1 = sv[0], s2 = sv[1];
     const double n = (double)g.N * (double)g.HW;
     const double m = s1 / n;
     const double mean = (double)y[(int64_t)c * g.HW] + m;
@@ -106,24 +107,9 @@ __global__ void k_bns_final_bwd(const BnsGeom g, const double* __restrict__ part
                                 float* __restrict__ sums) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.C) return;
-    double s1 = 0.0, s2 = 0.0;
-    const double* src = part + (int64_t)c * S * 2;
-    int i = 0;
-    for (; i + 8 <= S; i += 8) {          // eight rows in flight, added in the old order (one dependent pair of loads at a time the kernel is pure latency)
-        double v1[8], v2[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { v1[u] = src[(i + u) * 2]; v2[u] = src[(i + u) * 2 + 1]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
-    }
-    for (; i + 4 <= S; i += 4) {
-        double v1[4], v2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { v1[u] = src[(i + u) * 2]; v2[u] = src[(i + u) * 2 + 1]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { s1 += v1[u]; s2 += v2[u]; }
-    }
-    for (; i < S; ++i) { s1 += src[i * 2]; s2 += src[i * 2 + 1]; }
+    double sv[2] = {0.0, 0.0};
+    mn_row_sums<2>(part + (int64_t)c * S * 2, S, sv);
+    const double s1 = sv[0], s2 = sv[1];
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     sums[c] = (float)s1; sums[g.C + c] = (float)s2;

@@ -290,24 +290,9 @@ __global__ __launch_bounds__(256) void k_qa_partial(const QaGeom g, const void* 
 __global__ void k_qa_final_bwd(int C, const double* __restrict__ part, int S, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    const double* src = part + (int64_t)c * S * 2;
-    int i = 0;
-    for (; i + 8 <= S; i += 8) {          // eight rows in flight, added in the old order (one dependent pair of loads at a time the kernel is pure latency)
-        double v1[8], v2[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { v1[u] = src[(i + u) * 2]; v2[u] = src[(i + u) * 2 + 1]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
-    }
-    for (; i + 4 <= S; i += 4) {
-        double v1[4], v2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { v1[u] = src[(i + u) * 2]; v2[u] = src[(i + u) * 2 + 1]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { s1 += v1[u]; s2 += v2[u]; }
-    }
-    for (; i < S; ++i) { s1 += src[i * 2]; s2 += src[i * 2 + 1]; }
+    double sv[2] = {0.0, 0.0};
+    mn_row_sums<2>(part + (int64_t)c * S * 2, S, sv);
+    const double s1 = sv[0], s2 = sv[1];
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     sums[c] = (float)s1; sums[C + c] = (float)s2;
@@ -652,8 +637,9 @@ __global__ void k_qr_final_bwd(int C, const double* __restrict__ part, int S, fl
                                float* __restrict__ dgamma_s, float* __restrict__ dbeta_s, float* __restrict__ sums_s) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int i = 0; i < S; ++i) { const double* d = part + ((int64_t)c * S + i) * 3; s1 += d[0]; s2 += d[1]; s3 += d[2]; }
+    double sv[3] = {0.0, 0.0, 0.0};
+    mn_row_sums<3>(part + (int64_t)c * S * 3, S, sv);
+    const double s1 = sv[0], s2 = sv[1], s3 = sv[2];
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     sums[c] = (float)s1; sums[C + c] = (float)s2;

@@ -1258,8 +1258,9 @@ __global__ void k_bn_stats_final(const float* __restrict__ o, const double* __re
                                  float* __restrict__ stats) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < S; ++i) { s1 += part[((int64_t)c * S + i) * 2]; s2 += part[((int64_t)c * S + i) * 2 + 1]; }
+    double sv[2] = {0.0, 0.0};
+    mn_row_sums<2>(part + (int64_t)c * S * 2, S, sv);
+    const double s1 = sv[0], s2 = sv[1];
     const double n = (double)N * (double)HW;
     const double pivot = (double)o[(int64_t)c * HW];
     const double m = s1 / n;
