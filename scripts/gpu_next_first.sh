@@ -8,3 +8,5 @@ mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_gpu_zz_unmeasured.py -m gpu -q --runxfail -x 2>&1 | tail -15
 # 2. do they pay?  (same box, back to back; identical final_loss in the json = bit-identical step)
 bash scripts/gpu_ab.sh c4:base c4:wgrad32:MN_QD_WGRAD32=1 c5:base c5:wgrad32:MN_QD_WGRAD32=1 c2:base c2:hsfold:MN_HSIGN_FOLD=1 c2:base2 c2:hsfold2:MN_HSIGN_FOLD=1
+# 3. kernel level: the dense backward-weight on the four resnet18 layer shapes, default kernel vs MN_QD_WGRAD32=1
+timeout 300 python scripts/bench_qd_wgrad.py 2>&1 | tail -8
