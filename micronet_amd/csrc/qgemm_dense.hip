@@ -1382,218 +1382,6 @@ __global__ __launch_bounds__(512, 2) void k_qd_wgrad(const QdwParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[t * 4096 + ((2 * coh + c2) * 16 + 4 * kg + r) * 64 + cf * 16 + j] = acc[c2][t][r];
 }
-// ---- the 3 x 3 / stride 1 layers on v_mfma_f32_32x32x16_bf16 (opt-in: MN_QD_WGRAD32=1; same staging, same partial-tile layout, same reduction).
-// What the PMC picture of k_qd_wgrad<1, 9> asks for (3.9 VALU + 0.5 LDS instructions per 16-cycle MFMA, half of the LDS cycles replays):
-//   * a wave owns a 32 o x 32 c tile of all nine taps (9 accumulator tiles of 32 x 32): one A fragment (gy term plane, b128) feeds 9 MFMAs of 32 cycles,
-//     one B fragment 3 -- half the instruction issues and half the A bytes per flop of the 16 x 16 x 32 tiling;
-//   * the 32 lanes of an LDS lane group hold 32 CHANNELS at one pixel offset: with the patch's channel stride an odd multiple of 8 bytes every 8-byte read
-//     (centre, left and right neighbour: three b64 instead of b64 + 2 b32) covers the 64 banks exactly once -- no replays; the gy rows (80 bytes) are
-//     conflict-free for the 32-row b128 reads as they are for the 16-row ones;
-//   * the 8 waves are 2 K-groups x (2 o-blocks x 2 c-blocks): K-group g contracts pixels 16 g .. 16 g + 15 of every 32-pixel K-step, the two groups'
-//     accumulators are added through the (then idle) LDS before the store: the block still writes ONE partial tile, the reduction reads what it read before.
-// fp32 accumulation order differs from k_qd_wgrad's (two K-interleaved chains added once): the same float-accumulate tolerance, not bit-identical to it.
-#ifdef MN_EMULATION
-__device__ __forceinline__ u32x2 qdw_lds_ld64(const unsigned char* q) { return *reinterpret_cast<const u32x2*>(q); }
-__device__ __forceinline__ void qdw_lds_wait(u32x2 (&)[6]) {}
-#else
-// an 8-byte LDS read the compiler can neither narrow nor pair (q: a pointer into the dynamic LDS block: the low 32 bits of its generic address are the LDS offset);
-// the values are defined once qdw_lds_wait has passed them through
-__device__ __forceinline__ u32x2 qdw_lds_ld64(const unsigned char* q) {
-    u32x2 r;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"((uint32_t)(uintptr_t)q) : "memory");          // ("memory": stays behind the barrier / the staging stores before it)
-    return r;
-}
-__device__ __forceinline__ void qdw_lds_wait(u32x2 (&w)[6]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]));
-}
-#endif
-__global__ __launch_bounds__(512, 1) void k_qd_wgrad32(const QdwParams p) {
-    HIP_DYNAMIC_SHARED(float, smem)
-    unsigned char* dyb = reinterpret_cast<unsigned char*>(smem);          // [2][3][64][80]
-    unsigned char* xp = dyb + 2 * 3 * QDW_DYP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), li = lane & 31, lb = lane >> 5;
-    const int kgp = wave >> 2, ob = (wave >> 1) & 1, cb = wave & 1;
-    const uint32_t z = fd_div(blockIdx.x, p.fd_np);
-    const int pair = (int)blockIdx.x - (int)z * p.npairs;
-    const int cot = pair / p.ncit, cit = pair - cot * p.ncit;
-    const int t_begin = (int)z * p.tpz, t_end = (t_begin + p.tpz) < p.ntiles ? (t_begin + p.tpz) : p.ntiles;
-    for (int i = tid; i < (64 * p.CS) / 8; i += 512) *reinterpret_cast<u32x2*>(xp + 8 * i) = u32x2{0u, 0u};
-    // patch staging roles (as k_qd_wgrad<1, .>): unit u = ((c * NI + img) * PH + pr) * W4 + d: input pixels 4d .. 4d + 3 of patch row pr
-    int u_lds[QDW_UPT], u_goff[QDW_UPT], u_pi[QDW_UPT];
-#pragma unroll
-    for (int i = 0; i < QDW_UPT; ++i) {
-        const int u = tid + 512 * i;
-        const uint32_t t0 = fd_div((uint32_t)u, p.fd_w4);
-        const int d = u - (int)t0 * p.W4;
-        const uint32_t t1 = fd_div(t0, p.fd_ph);
-        const int pr = (int)t0 - (int)t1 * p.PH;
-        const uint32_t c = fd_div(t1, p.fd_ni);
-        const int img = (int)t1 - (int)c * p.NI;
-        const bool v = u < p.nunits;
-        u_lds[i] = v ? (int)c * p.CS + (img * p.PH + pr) * p.RB + (4 + 4 * d) * 2 : -1;
-        u_goff[i] = v ? (int)c * p.HX * p.WX + 4 * d : 0;
-        u_pi[i] = pr | (img << 8);
-    }
-    uint32_t preg[QDW_UPT];
-    uint32_t pok = 0u;
-    auto tile_origin = [&](int tile, int& n0, int& oh0) {
-        if (p.NI == 1) { const uint32_t n = fd_div((uint32_t)tile, p.fd_tpi); n0 = (int)n; oh0 = (tile - (int)n * p.tpi) * p.TH; }
-        else { n0 = tile * p.NI; oh0 = 0; }
-    };
-    auto fetch_patch = [&](int tile) {
-        int n0, oh0;
-        tile_origin(tile, n0, oh0);
-        pok = 0u;
-#pragma unroll
-        for (int i = 0; i < QDW_UPT; ++i) {
-            int n = n0 + (u_pi[i] >> 8), ih = oh0 - p.PAD + (u_pi[i] & 255);
-            const bool ok = u_lds[i] >= 0 && n < p.N && ih >= 0 && ih < p.HX;
-            n = n < p.N ? n : p.N - 1;
-            ih = ih < 0 ? 0 : (ih < p.HX ? ih : p.HX - 1);
-            preg[i] = *reinterpret_cast<const uint32_t*>(p.x + (uint32_t)((n * p.C + cit * 64) * p.HX + ih) * (uint32_t)p.WX + (uint32_t)u_goff[i]);
-            pok |= (ok ? 1u : 0u) << i;
-        }
-    };
-    auto commit_patch = [&]() {
-#pragma unroll
-        for (int i = 0; i < QDW_UPT; ++i) {
-            if (u_lds[i] < 0) continue;
-            const bool okv = (pok >> i) & 1u;
-            const uint32_t v = okv ? (p.xsgn ? preg[i] ^ 0x80808080u : preg[i]) : 0u;
-            const float off = (p.xsgn && okv) ? 128.f : 0.f;
-            const float f0 = (float)(v & 0xffu) - off, f1 = (float)((v >> 8) & 0xffu) - off, f2 = (float)((v >> 16) & 0xffu) - off, f3 = (float)(v >> 24) - off;
-            *reinterpret_cast<u32x2*>(xp + u_lds[i]) = u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)};
-        }
-    };
-    const int s_co = tid >> 3, s_f = tid & 7;
-    float4 greg;
-    auto fetch_gy = [&](int tile, int ks) {
-        int n0, oh0;
-        tile_origin(tile, n0, oh0);
-        const int kp = ks * 32 + 4 * s_f;
-        const int col = kp & (p.Wg - 1), t = kp >> p.w_shift;
-        const uint32_t img = fd_div((uint32_t)t, p.fd_th);
-        const int ohl = t - (int)img * p.TH;
-        int n = n0 + (int)img;
-        const bool ok = n < p.N;
-        n = ok ? n : p.N - 1;
-        const float4 v = *reinterpret_cast<const float4*>(p.gy + (uint32_t)((n * p.O + cot * 64 + s_co) * p.Hg + oh0 + ohl) * (uint32_t)p.Wg + (uint32_t)col);
-        greg = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto commit_gy = [&](int buf) {
-        const float v[4] = {greg.x, greg.y, greg.z, greg.w};
-        float t0[4], t1[4], t2[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            t0[e] = mn_bf16_head(v[e]);
-            const float r1 = v[e] - t0[e];
-            t1[e] = mn_bf16_head(r1);
-            t2[e] = r1 - t1[e];
-        }
-        unsigned char* d = dyb + buf * 3 * QDW_DYP + s_co * 80 + s_f * 8;
-        *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
-        *reinterpret_cast<u32x2*>(d + QDW_DYP) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
-        *reinterpret_cast<u32x2*>(d + 2 * QDW_DYP) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
-    };
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    if (t_begin < t_end) {
-        fetch_patch(t_begin);
-        fetch_gy(t_begin, 0);
-    }
-    __syncthreads();                          // zero fill complete
-    int gbuf = 0;
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        commit_patch();
-        commit_gy(gbuf);
-        __syncthreads();
-        if (tile + 1 < t_end) fetch_patch(tile + 1);
-        for (int ks = 0; ks < p.nks; ++ks) {
-            const bool more = ks + 1 < p.nks || tile + 1 < t_end;
-            if (more) fetch_gy(ks + 1 < p.nks ? tile : tile + 1, ks + 1 < p.nks ? ks + 1 : 0);
-            // A: rows o = 32 ob + li, pixels 16 kgp + 8 lb .. + 7 of the K-step, three term planes
-            const unsigned char* gb = dyb + gbuf * 3 * QDW_DYP + (ob * 32 + li) * 80 + kgp * 32 + lb * 16;
-            u32x4 a[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const u32x4*>(gb + t * QDW_DYP);
-            // B: channel c = 32 cb + li, the same 8 pixels as two runs of 4 (a run never crosses a row: W >= 4)
-            int hoff[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int kp = ks * 32 + kgp * 16 + lb * 8 + 4 * h;
-                const int col = kp & (p.Wg - 1), t = kp >> p.w_shift;
-                const uint32_t img = fd_div((uint32_t)t, p.fd_th);
-                const int ohl = t - (int)img * p.TH;
-                hoff[h] = (cb * 32 + li) * p.CS + ((int)img * p.PH + ohl) * p.RB + (4 + col) * 2;
-            }
-            // per kernel row and run: centre, left and right neighbour as three conflict-free ds_read_b64 (qdw_lds_ld64: left to itself the compiler narrows the
-            // neighbours to b32 -- 2-way on this stride -- and pairs centre + right into a half-rate ds_read2_b64); row r + 1 is requested before row r's MFMAs
-            u32x2 raw[2][6];
-            auto request = [&](int r, u32x2 (&w)[6]) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const unsigned char* q = xp + hoff[h] + r * p.RB;
-                    w[3 * h] = qdw_lds_ld64(q - 8); w[3 * h + 1] = qdw_lds_ld64(q); w[3 * h + 2] = qdw_lds_ld64(q + 8);
-                }
-            };
-            request(0, raw[0]);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                u32x2 (&w)[6] = raw[r & 1];
-                qdw_lds_wait(w);
-                if (r < 2) request(r + 1, raw[(r + 1) & 1]);
-                u32x4 b[3];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32x2 pv = w[3 * h], c = w[3 * h + 1], nx = w[3 * h + 2];
-                    b[0][2 * h] = mn_alignbyte(c[0], pv[1], 2); b[0][2 * h + 1] = mn_alignbyte(c[1], c[0], 2);
-                    b[1][2 * h] = c[0]; b[1][2 * h + 1] = c[1];
-                    b[2][2 * h] = mn_alignbyte(c[1], c[0], 2); b[2][2 * h + 1] = mn_alignbyte(nx[0], c[1], 2);
-                }
-                // consecutive MFMAs write different accumulators (a tile comes round every third issue)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int s_ = 0; s_ < 3; ++s_) acc[r * 3 + s_] = mn_mfma32_bf16(a[t], b[s_], acc[r * 3 + s_]);
-            }
-            if (more && ks + 1 < p.nks) commit_gy(gbuf ^ 1);
-            __syncthreads();
-            if (ks + 1 < p.nks) gbuf ^= 1;
-        }
-    }
-    // K-group 1 -> LDS -> K-group 0 adds and stores, three taps a round (48 KB; the launch sizes the LDS for it).  D[row = o: (v & 3) + 8 (v >> 2) + 4 lb][col = c: li]
-    float* dst = p.part + ((int64_t)((int)z * p.npairs + pair) * 9) * 4096;
-    const int tl = tid & 255;
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-        __syncthreads();
-        if (kgp == 1) {
-#pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3)
-#pragma unroll
-                for (int v4 = 0; v4 < 4; ++v4)
-                    *reinterpret_cast<f32x4*>(smem + ((t3 * 4 + v4) * 256 + tl) * 4) =
-                        f32x4{acc[rr * 3 + t3][4 * v4], acc[rr * 3 + t3][4 * v4 + 1], acc[rr * 3 + t3][4 * v4 + 2], acc[rr * 3 + t3][4 * v4 + 3]};
-        }
-        __syncthreads();
-        if (kgp == 0) {
-#pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3)
-#pragma unroll
-                for (int v4 = 0; v4 < 4; ++v4) {
-                    const f32x4 o4 = *reinterpret_cast<const f32x4*>(smem + ((t3 * 4 + v4) * 256 + tl) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int v = 4 * v4 + e;                  // (v & 3) = e, (v >> 2) = v4
-                        dst[(rr * 3 + t3) * 4096 + (ob * 32 + e + 8 * v4 + 4 * lb) * 64 + cb * 32 + li] = acc[rr * 3 + t3][v] + o4[e];
-                    }
-                }
-        }
-    }
-}
 // dw[o][c][tap] = scale * sum over z (fixed order, fp64) of part[z][pair][tap][o % 64][c % 64].  A block owns 64 consecutive (pair, tap, o, c) indices (one
 // 256-byte row of every partial tile): thread (tx = 16 float4 columns, ty = 16 z residues) sums its z subset, the 16 subsets are added in order through LDS.
 __device__ __forceinline__ void qd_wgrad_reduce_block(const float* __restrict__ part, float* __restrict__ dw, int O, int C, int T, int Z, float scale, uint32_t blk,
@@ -1691,9 +1479,6 @@ static int plan_qdw(const mn_conv_geom* g, QdwPlan* pl) {
     pl->ws_bytes = (int64_t)Z * p.npairs * T * 4096 * 4;
     return 1;
 }
-// MN_QD_WGRAD32=1: the 3 x 3 / stride 1 layers on k_qd_wgrad32 (written against the PMC picture of k_qd_wgrad, checked on the emulator, NOT yet timed on a GPU:
-// off by default until it is)
-static bool qd_wgrad32_enabled() { const char* e = MN_ENV("MN_QD_WGRAD32"); return e && e[0] == '1'; }
 int qd_wgrad_supported(const mn_conv_geom* g, int a_bits) {
     if (a_bits < 2 || a_bits > 7) return 0;
     QdwPlan pl;
@@ -1711,16 +1496,10 @@ int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, i
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense): workspace too small");
     QdwParams& p = pl.p;
     p.gy = gy; p.x = x; p.part = reinterpret_cast<float*>(ws); p.xsgn = xsgn;
-    if (pl.S == 1 && pl.T == 9 && qd_wgrad32_enabled()) mn_set_last_kernel("k_qd_wgrad32<%d, %d>", pl.S, pl.T);
-    else mn_set_last_kernel("k_qd_wgrad<%d, %d>", pl.S, pl.T);
+    mn_set_last_kernel("k_qd_wgrad<%d, %d>", pl.S, pl.T);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + nx * (g->O / 64) + (double)pl.ws_bytes); mn_prof_flops(2.0 * ny * g->C * pl.T); }
     mn_prof_begin(s);
-    if (pl.S == 1 && pl.T == 9 && qd_wgrad32_enabled()) {
-        const size_t lds = pl.lds < 49152 ? 49152 : pl.lds;          // the K-group merge of the epilogue
-        raise_lds_limit((const void*)k_qd_wgrad32, lds);
-        hipLaunchKernelGGL(k_qd_wgrad32, dim3(pl.grid), dim3(512), lds, s, p);
-    }
-    else if (pl.S == 1) { raise_lds_limit((const void*)k_qd_wgrad<1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<1, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
+    if (pl.S == 1) { raise_lds_limit((const void*)k_qd_wgrad<1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<1, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
     else if (pl.T == 9) { raise_lds_limit((const void*)k_qd_wgrad<2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
     else { raise_lds_limit((const void*)k_qd_wgrad<2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 1>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
     mn_prof_end(s);

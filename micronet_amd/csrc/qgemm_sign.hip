@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64) void k_pws_stats_prep(const double* __restrict_
     pws_prep_core(K, Kp, wc, g, m, Mpad, co, lane, rowscale[g * Mpad + m], bias ? bias[co] : 0.f, mean_f, inv_f, gamma[co], beta[co], chan, Cout, nnz9);
 }
 
-// k_pws_stats_prep's arguments, for its fold into k_h_sign (MN_HSIGN_FOLD=1): every block of the streaming sign pass evaluates its channel's constants itself (one
+// k_pws_stats_prep's arguments, for its fold into k_h_sign (default; MN_HSIGN_FOLD=0 turns it off): every block of the streaming sign pass evaluates its channel's constants itself (one
 // wave: the same reduction over the partial rows, the same fp32 chains, the same shuffles -- bit-identical values in every block), the block sp == 0 of a channel is
 // the one that writes them (save, running statistics, chan rows, the counter): one latency-bound launch less per block of the net.
 struct HsPrep {
@@ -1524,8 +1524,9 @@ extern "C" int64_t mn_qconv_bnsign_ws_bytes(const mn_conv_geom* g) { return g ? 
 
 struct HsPrep;
 static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s, const HsPrep* fold = nullptr);
-// MN_HSIGN_FOLD=1: k_pws_stats_prep's work inside the streaming sign pass (k_h_sign_prep) -- bit-identical on the emulator, NOT yet timed on a GPU: off by default
-static bool hsign_fold_enabled() { const char* e = MN_ENV("MN_HSIGN_FOLD"); return e && e[0] == '1'; }
+// k_pws_stats_prep's work runs inside the streaming sign pass (k_h_sign_prep; bit-identical; round 5 same-box A/B on c2: 107.2 / 107.7 k -> 108.8 / 108.7 k img/s).
+// MN_HSIGN_FOLD=0 restores the two launches.
+static bool hsign_fold_enabled() { const char* e = MN_ENV("MN_HSIGN_FOLD"); return !(e && e[0] == '0'); }
 static void pws_chan_prep(PwsPlan& pl, const mn_conv_geom* g, const float* bias, const float* save, const float* gamma, const float* beta, hipStream_t s) {
     hipLaunchKernelGGL(k_pws_chan_prep, dim3((unsigned)g->O), dim3(64), 0, s, pl.p.Kc, pl.p.Kp, pl.p.wc, pl.p.G, pl.p.Mpad, pl.p.Mr, pl.p.rowscale, bias, save, gamma, beta,
                        (float*)pl.p.chan, (int)g->O);
@@ -1703,7 +1704,7 @@ __global__ __launch_bounds__(256) void k_h_sign(const HGeom g, const unsigned ch
     const StashNnz z = stash_nnz_load(chan, C, c);
     h_sign_stream<VEC>(g, h, a, c, sp, S, T, fl, z);
 }
-// MN_HSIGN_FOLD=1: the constants from the block's own evaluation of k_pws_stats_prep's work (HsPrep above) instead of a launch in front
+// default (MN_HSIGN_FOLD != 0): the constants from the block's own evaluation of k_pws_stats_prep's work (HsPrep above) instead of a launch in front
 template <int VEC>
 __global__ __launch_bounds__(256) void k_h_sign_prep(const HGeom g, const unsigned char* __restrict__ h, const HsPrep q, char* __restrict__ a) {
     __shared__ float hs_[3];

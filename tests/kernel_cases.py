@@ -1298,27 +1298,8 @@ QDENSE_CASES = [
 ]
 
 
-def check_qd_wgrad32(be, hot=False):
-    """The opt-in 32 x 32 x 16 backward-weight kernel (MN_QD_WGRAD32=1 in the environment of THIS process: the knob is read once): every tile shape of the planner
-    (W = 4 .. 32, several images per tile with N not a multiple, several (o, c) pairs, split-K over tiles), the 32-bit-stash layer, signed IAO codes with the scale
-    on the device, and the partial tiles left for the multi-layer reduction -- against the same fp64 references and tolerances as k_qd_wgrad."""
-    last = lambda: be.lib.mn_last_kernel().decode()
-    cases = [((2, 64, 8, 8), 64), ((3, 128, 4, 4), 64), ((1, 64, 16, 16), 128), ((1, 64, 8, 32), 64), ((1, 512, 4, 4), 64), ((5, 64, 8, 8), 128)]
-    if hot:          # the four layer shapes of resnet18 on 32 x 32 inputs, a few images each
-        cases += [((8, 64, 32, 32), 64), ((16, 128, 16, 16), 128), ((37, 256, 8, 8), 256), ((70, 512, 4, 4), 512)]
-    for i, (xs, Oc) in enumerate(cases):
-        check_qdense(be, xs, Oc, 3, 1, seed=900 + i)
-        assert last().startswith("k_qd_wgrad32<"), last()
-    check_qdense(be, (2, 64, 8, 8), 64, 3, 1, a_bits=4, w_bits=4, seed=910)
-    assert last().startswith("k_qd_wgrad32<"), last()
-    check_qdense(be, (5, 128, 8, 8), 128, 3, 2, seed=911)          # stride 2 keeps the 16 x 16 x 32 kernel
-    assert last().startswith("k_qd_wgrad<2, 9>"), last()
-    check_qdense_iao(be, (3, 64, 8, 8), 64, a_bits=8, w_bits=8, bias=True, seed=912)
-    check_qd_wgrad_deferred(be, seed=913)
-
-
 def check_hsign_fold(be, kxk_cases, full=False):
-    """MN_HSIGN_FOLD=1 in the environment of THIS process: k_pws_stats_prep's work -- batch statistics from the partial rows, running statistics, the integer thresholds,
+    """The default since round 5 (MN_HSIGN_FOLD=0 turns it off): k_pws_stats_prep's work -- batch statistics from the partial rows, running statistics, the integer thresholds,
     nnz, the counter -- evaluated inside the streaming sign pass (k_h_sign_prep: every block for itself, block 0 of a channel writes): the stashed pointwise and
     3 x 3 blocks against the same references as the two-launch path (sign codes and stash bit for bit, statistics, counter, and the backward that reads `chan`)."""
     for case in ((0, 1, 2, 3) if full else (1,)):
@@ -1355,11 +1336,6 @@ def run_child(body, backend, env, timeout):
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-c", CHILD % body, here, backend], env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0 and "child ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
-
-
-def run_wgrad32_child(backend, hot, timeout):
-    """check_qd_wgrad32 in a child process with MN_QD_WGRAD32=1."""
-    run_child("K.check_qd_wgrad32(be, hot=%s)" % bool(hot), backend, {"MN_QD_WGRAD32": "1"}, timeout)
 
 
 def check_qg_pack_multi(be, seed=0):

@@ -444,6 +444,11 @@ def test_qconv_kxk_bnsign_stash(be, case, training):
     K.check_qconv_bnsign(be, seed=260 + case, stash=True, training=training, **KXK_STASH_CASES[case])
 
 
+def test_sign_pass_with_the_statistics_finals_folded_in(be):
+    """k_h_sign_prep (the default since round 5): k_pws_stats_prep's work inside the streaming sign pass."""
+    K.check_hsign_fold(be, KXK_STASH_CASES, full=True)
+
+
 def test_ternary_weight_quantizer_multi(be):
     K.check_ternary_multi(be)
 

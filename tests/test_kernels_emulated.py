@@ -314,9 +314,15 @@ def test_qconv_kxk_bnsign_stash(be, case, training):
     K.check_qconv_bnsign(be, seed=260 + case, stash=True, training=training, **KXK_STASH_CASES[case])
 
 
-def test_sign_pass_with_the_statistics_finals_folded_in_opt_in():
-    """MN_HSIGN_FOLD=1 (child process): k_h_sign_prep instead of k_pws_stats_prep + k_h_sign."""
-    K.run_child("K.check_hsign_fold(be, %r)" % (KXK_STASH_CASES,), "emu", {"MN_HSIGN_FOLD": "1"}, 1500)
+def test_sign_pass_with_the_statistics_finals_folded_in(be):
+    """k_h_sign_prep (the default) instead of k_pws_stats_prep + k_h_sign."""
+    K.check_hsign_fold(be, KXK_STASH_CASES)
+
+
+def test_sign_pass_two_launch_path_opt_out():
+    """MN_HSIGN_FOLD=0 (child process: the knob is read once): k_pws_stats_prep + k_h_sign, the path the generic k x k forward still takes."""
+    K.run_child("K.check_qconv_bnsign(be, seed=221, stash=True, **K.QGEMM_PW_CASES[1]); assert K.check_qconv_bnsign.last_fwd_kernel == 'k_h_sign', K.check_qconv_bnsign.last_fwd_kernel",
+                "emu", {"MN_HSIGN_FOLD": "0"}, 900)
 
 
 def test_ternary_weight_quantizer_multi(be):
@@ -388,12 +394,6 @@ def test_qdense_layer(be, case):
 def test_qdense_layer_prepacked_weights(be, case):
     xs, Oc, k, s = K.QDENSE_CASES[case]
     K.check_qdense(be, xs, Oc, k, s, seed=380 + case, prepack=True)
-
-
-def test_qdense_backward_weight_on_32x32x16_mfma_opt_in():
-    """MN_QD_WGRAD32=1 (read once per process: a child process): the 3 x 3 / stride 1 backward-weight on k_qd_wgrad32 -- 32 x 32 x 16 MFMA, 2 K-groups merged through
-    the LDS, three conflict-free 8-byte reads per run -- against the same fp64 references and tolerances as k_qd_wgrad."""
-    K.run_wgrad32_child("emu", hot=False, timeout=1500)
 
 
 def test_qdense_layer_bf16_forward(be):
