@@ -81,8 +81,10 @@ __device__ __forceinline__ int mn_uniform(int v) { return __builtin_amdgcn_readf
 // scheduling fence: no instruction may be moved across it (keeps software-pipelined loads from being hoisted en bloc)
 #ifdef MN_EMULATION
 #define MN_SCHED_FENCE() do { } while (0)
+#define MN_SETPRIO(n) do { } while (0)
 #else
 #define MN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
 // wave-level hand-over of LDS data between the lanes of ONE wave (no block barrier): the hardware executes a wave's DS operations in
 // order, so only the compiler (and the emulator's lane scheduler) has to be told
@@ -103,6 +105,12 @@ __device__ __forceinline__ uint32_t mn_perm(uint32_t a, uint32_t b, uint32_t sel
 __device__ __forceinline__ uint32_t mn_alignbyte(uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 __device__ __forceinline__ uint32_t mn_perm(uint32_t a, uint32_t b, uint32_t sel) { return __builtin_amdgcn_perm(a, b, sel); }
 #endif
+// a value the optimiser must treat as unknown (stops hoisting / rematerialisation decisions that cost registers)
+#ifdef MN_EMULATION
+__device__ __forceinline__ uint32_t mn_opaque(uint32_t v) { return v; }
+#else
+__device__ __forceinline__ uint32_t mn_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+#endif
 // bf16 "head" of an fp32 (truncation): exact for integers |v| <= 256; v - head is exact in fp32, so
 // v = t0 + t1 + t2 with t_i = head(remainder) reproduces all 24 significant bits (three-term split).
 __device__ __forceinline__ float mn_bf16_head(float v) { return mn_u2f(mn_f2u(v) & 0xffff0000u); }
@@ -111,6 +119,23 @@ __device__ __forceinline__ unsigned mn_pack_bf16x2(float lo_elem, float hi_elem)
     return (mn_f2u(lo_elem) >> 16) | (mn_f2u(hi_elem) & 0xffff0000u);
 }
 
+// Two-term split (round 5): v ~ t0 + t1 with t0 = bf16 round-to-nearest-even of v and t1 = bf16 rne of the exact remainder v - t0: |v - t0 - t1| <= 2^-18 |v|
+// (the three-term truncation split above is exact; see DESIGN "two bf16 terms").  mn_rne_bf16x2 = v_cvt_pk_bf16_f32: low half = lo_elem.
+#ifdef MN_EMULATION
+__device__ __forceinline__ unsigned mn_rne_bf16_bits(float v) { const unsigned u = mn_f2u(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }        // (finite inputs)
+__device__ __forceinline__ unsigned mn_rne_bf16x2(float lo_elem, float hi_elem) { return mn_rne_bf16_bits(lo_elem) | (mn_rne_bf16_bits(hi_elem) << 16); }
+#else
+__device__ __forceinline__ unsigned mn_rne_bf16x2(float lo_elem, float hi_elem) {
+    typedef __bf16 mn_bf2 __attribute__((ext_vector_type(2)));
+    typedef float mn_f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((mn_f2){lo_elem, hi_elem}, mn_bf2));
+}
+#endif
+// the two term words of a pair of floats: hi = rne pair, lo = rne pair of the remainders
+__device__ __forceinline__ void mn_split2_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = mn_rne_bf16x2(a, b);
+    lo = mn_rne_bf16x2(a - mn_u2f(hi << 16), b - mn_u2f(hi & 0xffff0000u));
+}
 // the same from the high halves as they are (no masking of the low halves needed): one v_perm
 __device__ __forceinline__ unsigned mn_pack_hi16(float lo_elem, float hi_elem) { return mn_perm(mn_f2u(hi_elem), mn_f2u(lo_elem), 0x07060302u); }
 

@@ -854,6 +854,10 @@ int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a
     return MN_OK;
 }
 
+// The fp32 gradient operand of the two backward kernels as bf16 TERMS: 3 = exact (three truncation terms carry all 24 significant bits), 2 (default, round 5) =
+// round-to-nearest hi + round-to-nearest remainder: |error| <= 2^-18 |gy| per element (3.8e-6; measured parity in DESIGN / profiles/parity_r05.json), one third fewer
+// matrix passes and LDS plane reads.  MN_QD_TERMS=3 restores the exact split.
+static int qd_terms() { const char* e = MN_ENV("MN_QD_TERMS"); return (e && e[0] == '3') ? 3 : 2; }
 // ================================================================================================ backward-data
 //   dq[n][c][ih][iw] = (1 / n_w) * sum over (o, r, s) of wcode[o][c][r][s] * gy[n][o][oh][ow],   ih = oh S + r - P, iw = ow S + s - P
 // The same organisation with the roles of the channel axes swapped: the staged patch is gy (fp32, three exact bf16 terms: three LDS planes of
@@ -885,7 +889,7 @@ struct QddParams {
     QdUnits units;
 };
 
-template <int MF, int S, int TAPS>
+template <int MF, int S, int TAPS, int NT>
 __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* wbuf = reinterpret_cast<unsigned char*>(smem);
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
     constexpr int TPS = TAPS == 9 ? 3 : 1, NSTEP = TAPS == 9 ? 3 : 1;
     if ((int)blockIdx.x >= p.nitems) return;
-    for (int i = tid; i < (3 * p.TS) / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < (NT * p.TS) / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
     // staging roles: a unit = output channels 4q .. 4q + 3 of the chunk, patch row pr of image img, pixels 4d .. 4d + 3 (order over the threads: QdUnits)
     int u_lds[QDD_UPT], u_goff[QDD_UPT], u_pi[QDD_UPT];
 #pragma unroll
@@ -947,6 +951,24 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
         for (int i = 0; i < QDD_UPT; ++i) {
             if (u_lds[i] < 0) continue;
             const bool ok = (pok >> i) & 1u;
+            if (NT == 2) {                                             // round-to-nearest hi + round-to-nearest remainder (qd_terms)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v[4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const float raw = e == 0 ? preg[i][cc].x : e == 1 ? preg[i][cc].y : e == 2 ? preg[i][cc].z : preg[i][cc].w;
+                        v[cc] = ok ? (p.wsc ? raw * psc[i][cc] : raw) : 0.f;
+                    }
+                    unsigned h0, l0, h1, l1;
+                    mn_split2_bf16x2(v[0], v[1], h0, l0);
+                    mn_split2_bf16x2(v[2], v[3], h1, l1);
+                    unsigned char* d = patch + u_lds[i] + e * QDD_RS;
+                    *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(d + p.TS) = u32x2{l0, l1};
+                }
+                continue;
+            }
             float t0[4][4], t1[4][4], t2[4][4];                    // [channel][pixel]
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
@@ -1037,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
 #pragma unroll
                     for (int nf = 0; nf < 4; ++nf) b[nf] = *reinterpret_cast<const u32x4*>(wb + (tis * 4 + nf) * 1024);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         u32x4 a[MF];
 #pragma unroll
                         for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const u32x4*>(patch + t * p.TS + abase[mf] + toff);
@@ -1148,10 +1170,13 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
 }
 static void qd_launch_dgrad(const QddPlan& pl, hipStream_t s) {
     const QddParams& p = pl.p;
-    if (pl.S == 2 && p.TAPS == 9) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    else if (pl.S == 2) { raise_lds_limit((const void*)k_qd_dgrad<1, 2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 2, 1>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    else if (pl.MF == 2) { raise_lds_limit((const void*)k_qd_dgrad<2, 1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<2, 1, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
-    else { raise_lds_limit((const void*)k_qd_dgrad<1, 1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<1, 1, 9>), dim3(pl.grid), dim3(256), pl.lds, s, p); }
+    const int NT = qd_terms();
+#define QDD_LAUNCH(M_, S_, T_, N_) do { raise_lds_limit((const void*)k_qd_dgrad<M_, S_, T_, N_>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<M_, S_, T_, N_>), dim3(pl.grid), dim3(256), pl.lds, s, p); } while (0)
+    if (pl.S == 2 && p.TAPS == 9) { if (NT == 2) QDD_LAUNCH(1, 2, 9, 2); else QDD_LAUNCH(1, 2, 9, 3); }
+    else if (pl.S == 2) { if (NT == 2) QDD_LAUNCH(1, 2, 1, 2); else QDD_LAUNCH(1, 2, 1, 3); }
+    else if (pl.MF == 2) { if (NT == 2) QDD_LAUNCH(2, 1, 9, 2); else QDD_LAUNCH(2, 1, 9, 3); }
+    else { if (NT == 2) QDD_LAUNCH(1, 1, 9, 2); else QDD_LAUNCH(1, 1, 9, 3); }
+#undef QDD_LAUNCH
 }
 int qd_dgrad_supported(const mn_conv_geom* g, const mn_wq* wq) {
     QddPlan pl;
@@ -1167,7 +1192,7 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_bwd);
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0; p.ste_x = nullptr; p.ste_qp = nullptr;
-    mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
+    mn_set_last_kernel("k_qd_dgrad<%d, %d, %d, %d>", pl.MF, pl.S, p.TAPS, qd_terms());
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     qd_launch_dgrad(pl, s);
@@ -1179,16 +1204,27 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
 // ================================================================================================ backward-weight
 //   dw[o][c][r][s] = s_a * sum over (n, oh, ow) of gy[n][o][oh][ow] * j[n][c][oh S + r - P][ow S + s - P]
 // M = 64 output channels, N = taps x 64 input channels, K = gy-domain pixels (contiguous in NCHW for both operands: no transposition anywhere).
-// A block (8 waves, one per CU) owns one (64 o, 64 c) pair and a range of pixel tiles (split-K); per tile it stages the input patch of its 64
-// channels ONCE as bf16 (rows 8-byte aligned, zero frame), per K-step of 32 pixels the gy rows as three exact bf16 term planes [o][32 px]
-// (80-byte rows, double buffered).  Wave w contracts input-channel fragment (w & 3) against output-channel fragments 2 (w >> 2), + 1 for all
-// taps: 18 accumulator tiles.  The B fragment of a tap = 2 x 4 consecutive gy-domain pixels shifted by the tap:
+// A block (12 waves, one per CU) owns one (64 o, 64 c) pair and a range of pixel tiles (split-K).  Round 5: WAVE-SPECIALISED -- knock-out builds of the
+// round-4 kernel (8 waves that all staged, read fragments and contracted in the same phase between two barriers) showed its time to be the SUM of its parts
+// (fixed 22 us + matrix 16 + gy path 10 + patch 7 + A reads 7 + B reads 7 = 60 us on every resnet18 layer), not their maximum:
+//   * waves 0-3 PRODUCERS: gy rows of 2 - 4 K-steps (32 pixels each) in flight in registers, split into NT bf16 term planes [o][32 px] (80-byte rows, two LDS
+//     buffers); the input patch of the NEXT tile (64 channels, bf16, rows 8-byte aligned, zero frame) into the second patch buffer while the consumers work on
+//     the current one; one barrier per K-step;
+//   * waves 4-11 CONSUMERS (fragment reads + MFMA only): wave w contracts input-channel fragment (w & 3) against output-channel fragments 2 (w >> 2), + 1 for
+//     all taps: 18 accumulator tiles; software-pipelined by kernel ROW: the B words of row r + 1 (or, behind the step's barrier, the A fragments and row 0 of
+//     the next step) are read while row r is contracted.
+// The B fragment of a tap = 2 x 4 consecutive gy-domain pixels shifted by the tap:
 //   S = 1: patch [c][image][row][4 + W + 4]; per kernel row one aligned 8-byte read + its two neighbour dwords per half fragment, the three
 //          column shifts by v_alignbyte (no shifted copies in LDS, no im2col);
 //   S = 2: the patch rows are split by column parity, [c][image][row][even | odd][4 + W/2 + 4]: tap column 1 reads the even plane, column 2 the
 //          odd plane, column 0 the odd plane one pixel to the left; 1 x 1 / stride 2: the even plane of the even rows only.
-// Partial tiles [z][pair][tap][o][c] are summed in fp64 in fixed order by k_qd_wgrad_reduce (deterministic).
-#define QDW_UPT 10             // patch dwords a thread stages per tile
+// Partial tiles [z][pair][tap][c][o] (o innermost: a lane's four accumulator rows are one 16-byte store) are summed in fp64 in fixed order by
+// k_qd_wgrad_reduce (deterministic).
+#define QDW_PUPT 20            // patch dwords a producer thread stages per tile
+#define QDW_PCH 4              // ... in this many chunks
+#ifndef QDW_PRIO
+#define QDW_PRIO 2
+#endif
 #define QDW_DYP 5120           // bytes per gy term plane (64 rows x 80)
 struct QdwParams {
     const float* gy;              // [N][O][Hg][Wg]
@@ -1197,192 +1233,339 @@ struct QdwParams {
     int N, C, Hg, Wg, O, HWg, HX, WX, PAD;
     int TH, NI, PH, PWp, RB, CS, W4, BMt, nks;    // tile rows / images, patch rows, padded plane row (bf16 elements), bytes per patch row, bytes per channel, K-steps per tile
     int tpi, ntiles, tpz, Z, ncit, npairs, nunits, w_shift;
-    FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_tpi, fd_np;
+    FastDiv fd_w4, fd_ph, fd_ni, fd_th, fd_tpi, fd_np, fd_nks;
     int xsgn;                     // x holds signed codes (IAO)
+    int pdb;                      // 1: two patch buffers (the next tile's patch is staged while the current one is contracted); 0: one (shapes whose patch exceeds 64 KB)
 };
 
-template <int S, int TAPS>
-__global__ __launch_bounds__(512, 2) void k_qd_wgrad(const QdwParams p) {
+template <int S, int TAPS, int NT>
+__global__ __launch_bounds__(768) void k_qd_wgrad(const QdwParams p) {
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* dyb = reinterpret_cast<unsigned char*>(smem);          // [2][3][64][80]
-    unsigned char* xp = dyb + 2 * 3 * QDW_DYP;
+    unsigned char* xp0 = dyb + 2 * 3 * QDW_DYP;                           // [2][64 CS]
+    const int XPB = 64 * p.CS;
     const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
-    const int cf = wave & 3, coh = wave >> 2;
     constexpr int KR = TAPS == 9 ? 3 : 1;
     const uint32_t z = fd_div(blockIdx.x, p.fd_np);
     const int pair = (int)blockIdx.x - (int)z * p.npairs;
     const int cot = pair / p.ncit, cit = pair - cot * p.ncit;
     const int t_begin = (int)z * p.tpz, t_end = (t_begin + p.tpz) < p.ntiles ? (t_begin + p.tpz) : p.ntiles;
-    for (int i = tid; i < (64 * p.CS) / 8; i += 512) *reinterpret_cast<u32x2*>(xp + 8 * i) = u32x2{0u, 0u};
-    // patch staging roles: unit u = ((c * NI + img) * PH + pr) * W4 + d: input pixels 4d .. 4d + 3 of patch row pr
-    int u_lds[QDW_UPT], u_goff[QDW_UPT], u_pi[QDW_UPT];
-#pragma unroll
-    for (int i = 0; i < QDW_UPT; ++i) {
-        const int u = tid + 512 * i;
-        const uint32_t t0 = fd_div((uint32_t)u, p.fd_w4);
-        const int d = u - (int)t0 * p.W4;
-        const uint32_t t1 = fd_div(t0, p.fd_ph);
-        const int pr = (int)t0 - (int)t1 * p.PH;
-        const uint32_t c = fd_div(t1, p.fd_ni);
-        const int img = (int)t1 - (int)c * p.NI;
-        const bool v = u < p.nunits;
-        // S = 1: pixels 4d.. at elements 4 + 4d ..;  S = 2: the even pixels (4d, 4d + 2) at even-plane elements 4 + 2d, the odd ones at the odd plane's
-        u_lds[i] = v ? (int)c * p.CS + (img * p.PH + pr) * p.RB + (4 + (S == 2 ? 2 : 4) * d) * 2 : -1;
-        u_goff[i] = v ? (int)c * p.HX * p.WX + 4 * d : 0;
-        u_pi[i] = pr | (img << 8);
-    }
-    uint32_t preg[QDW_UPT];
-    uint32_t pok = 0u;
+    const int n = t_begin < t_end ? (t_end - t_begin) * p.nks : 0;         // K-steps of this block; step k = (tile t_begin + k / nks, ks = k % nks)
     auto tile_origin = [&](int tile, int& n0, int& oh0) {
-        if (p.NI == 1) { const uint32_t n = fd_div((uint32_t)tile, p.fd_tpi); n0 = (int)n; oh0 = (tile - (int)n * p.tpi) * p.TH; }
+        if (p.NI == 1) { const uint32_t nn = fd_div((uint32_t)tile, p.fd_tpi); n0 = (int)nn; oh0 = (tile - (int)nn * p.tpi) * p.TH; }
         else { n0 = tile * p.NI; oh0 = 0; }
     };
-    auto fetch_patch = [&](int tile) {
-        int n0, oh0;
-        tile_origin(tile, n0, oh0);
-        pok = 0u;
+    if (wave < 4) {
+        // ------------------------------------------------------------------------------------------------ producers (256 threads)
+        // patch staging roles: thread (channel pc = tid >> 2, quarter pq = tid & 3) stages positions pos = pq + 4 i of its channel, pos = (img * PH + pr) * W4 + d: input
+        // pixels 4d .. 4d + 3 of patch row pr.  Two words per unit, everything else is per thread or per tile: ug = the unit's global offset inside the tile's window
+        // (img C HX WX + pr WX + 4 d), ul = LDS byte offset inside the channel | pr << 16 | img << 24 (0xffffffff: the thread has no such unit -- it loads its channel's
+        // first word and writes zeros into a dump slot behind the patch buffers: no per-unit branches).
+        MN_SETPRIO(QDW_PRIO);                                              // the staging waves win the VALU arbitration against the two MFMA waves of their SIMD
+        const int pc = tid >> 2, pq = tid & 3;
+        const int npos = p.NI * p.PH * p.W4;
+        uint32_t ul[QDW_PUPT];
+        int ug[QDW_PUPT];
 #pragma unroll
-        for (int i = 0; i < QDW_UPT; ++i) {
-            int n = n0 + (u_pi[i] >> 8), ih = oh0 * S - p.PAD + (u_pi[i] & 255);
-            const bool ok = u_lds[i] >= 0 && n < p.N && ih >= 0 && ih < p.HX;
-            n = n < p.N ? n : p.N - 1;
-            ih = ih < 0 ? 0 : (ih < p.HX ? ih : p.HX - 1);
-            preg[i] = *reinterpret_cast<const uint32_t*>(p.x + (uint32_t)((n * p.C + cit * 64) * p.HX + ih) * (uint32_t)p.WX + (uint32_t)u_goff[i]);
-            pok |= (ok ? 1u : 0u) << i;
+        for (int i = 0; i < QDW_PUPT; ++i) {
+            const int pos = pq + 4 * i;
+            const uint32_t t0 = fd_div((uint32_t)pos, p.fd_w4);
+            const int d = pos - (int)t0 * p.W4;
+            const uint32_t img = fd_div(t0, p.fd_ph);
+            const int pr = (int)t0 - (int)img * p.PH;
+            // S = 1: pixels 4d.. at elements 4 + 4d ..;  S = 2: the even pixels (4d, 4d + 2) at even-plane elements 4 + 2d, the odd ones at the odd plane's
+            const uint32_t lo = (uint32_t)(((int)img * p.PH + pr) * p.RB + (4 + (S == 2 ? 2 : 4) * d) * 2);
+            ul[i] = pos < npos ? (lo | ((uint32_t)pr << 16) | (img << 24)) : 0xffffffffu;
+            ug[i] = pos < npos ? ((int)img * p.C * p.HX + pr) * p.WX + 4 * d : 0;
         }
-    };
-    auto commit_patch = [&]() {
+        const int pc_g = pc * p.HX * p.WX;
+        const uint32_t pc_l = (uint32_t)(pc * p.CS);
+        const uint32_t dump = (uint32_t)((1 + p.pdb) * XPB);          // 16 bytes behind the patch buffers (relative to xp0)
+        // The units are staged in QDW_PCH chunks: chunk c of tile t + 1's patch is committed (into the other patch buffer) and chunk c of tile t + 2's patch fetched
+        // (into the same registers) during one of tile t's step pairs -- the loads have a whole tile to land and no tile boundary carries the whole patch
+        // (measured with s_memtime: 6 500 cycles per boundary when it did, 16 000 when its registers spilled).
+        uint32_t preg[QDW_PUPT];
+        uint32_t pok = 0u;
+        const int nu = (npos + 3) >> 2;                                  // units per thread that exist (uniform)
+        auto fetch_chunk = [&](int c, int tile) {
+            int n0, oh0;
+            tile_origin(tile, n0, oh0);
+            const int ihb = oh0 * S - p.PAD;
+            const int base = ((n0 * p.C + cit * 64) * p.HX + ihb) * p.WX + pc_g;          // (may point above the image for the halo rows: those units load the channel's first word)
 #pragma unroll
-        for (int i = 0; i < QDW_UPT; ++i) {
-            if (u_lds[i] < 0) continue;
-            const bool okv = (pok >> i) & 1u;
-            const uint32_t v = okv ? (p.xsgn ? preg[i] ^ 0x80808080u : preg[i]) : 0u;
-            const float off = (p.xsgn && okv) ? 128.f : 0.f;
-            const float f0 = (float)(v & 0xffu) - off, f1 = (float)((v >> 8) & 0xffu) - off, f2 = (float)((v >> 16) & 0xffu) - off, f3 = (float)(v >> 24) - off;
-            if (S == 1) *reinterpret_cast<u32x2*>(xp + u_lds[i]) = u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)};
-            else {
-                *reinterpret_cast<uint32_t*>(xp + u_lds[i]) = mn_pack_hi16(f0, f2);
-                *reinterpret_cast<uint32_t*>(xp + u_lds[i] + p.PWp * 2) = mn_pack_hi16(f1, f3);
+            for (int i = c * (QDW_PUPT / QDW_PCH); i < (c + 1) * (QDW_PUPT / QDW_PCH); ++i) {
+                if (i >= nu) break;                                   // (uniform)
+                const uint32_t w = mn_opaque(ul[i]);                   // (opaque: nothing derived from a unit's words is hoisted out of the step loop)
+                const int ih = ihb + (int)((w >> 16) & 255u), nn = n0 + (int)(w >> 24);
+                const bool ok = w != 0xffffffffu && (unsigned)ih < (unsigned)p.HX && nn < p.N;
+                const int off = ok ? base + (int)mn_opaque((uint32_t)ug[i]) : pc_g;
+                preg[i] = *reinterpret_cast<const uint32_t*>(p.x + (uint32_t)off);
+                pok = (pok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
             }
-        }
-    };
-    // gy staging role: row co = tid >> 3, float4 f = tid & 7 of the K-step
-    const int s_co = tid >> 3, s_f = tid & 7;
-    float4 greg;
-    auto fetch_gy = [&](int tile, int ks) {
-        int n0, oh0;
-        tile_origin(tile, n0, oh0);
-        const int kp = ks * 32 + 4 * s_f;
-        const int col = kp & (p.Wg - 1), t = kp >> p.w_shift;
-        const uint32_t img = fd_div((uint32_t)t, p.fd_th);
-        const int ohl = t - (int)img * p.TH;
-        int n = n0 + (int)img;
-        const bool ok = n < p.N;
-        n = ok ? n : p.N - 1;
-        const float4 v = *reinterpret_cast<const float4*>(p.gy + (uint32_t)((n * p.O + cot * 64 + s_co) * p.Hg + oh0 + ohl) * (uint32_t)p.Wg + (uint32_t)col);
-        greg = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto commit_gy = [&](int buf) {
-        const float v[4] = {greg.x, greg.y, greg.z, greg.w};
-        float t0[4], t1[4], t2[4];
+        };
+        auto commit_chunk = [&](int c, unsigned char* xp, uint32_t dump_rel) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            t0[e] = mn_bf16_head(v[e]);
-            const float r1 = v[e] - t0[e];
-            t1[e] = mn_bf16_head(r1);
-            t2[e] = r1 - t1[e];
-        }
-        unsigned char* d = dyb + buf * 3 * QDW_DYP + s_co * 80 + s_f * 8;
-        *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
-        *reinterpret_cast<u32x2*>(d + QDW_DYP) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
-        *reinterpret_cast<u32x2*>(d + 2 * QDW_DYP) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
-    };
-    f32x4 acc[2][TAPS];
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) acc[c2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t_begin < t_end) {
-        fetch_patch(t_begin);
-        fetch_gy(t_begin, 0);
-    }
-    __syncthreads();                          // zero fill complete
-    int gbuf = 0;
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        commit_patch();
-        commit_gy(gbuf);                      // buffer gbuf: every wave left it at the previous tile's last barrier
-        __syncthreads();
-        if (tile + 1 < t_end) fetch_patch(tile + 1);               // in flight during the tile's K-steps
-        for (int ks = 0; ks < p.nks; ++ks) {
-            // gy of the next K-step (of this tile, or the first of the next tile): fetched now, committed after this step's MFMAs
-            const bool more = ks + 1 < p.nks || tile + 1 < t_end;
-            if (more) fetch_gy(ks + 1 < p.nks ? tile : tile + 1, ks + 1 < p.nks ? ks + 1 : 0);
-            const unsigned char* gb = dyb + gbuf * 3 * QDW_DYP + ((2 * coh) * 16 + j) * 80 + kg * 16;
-            u32x4 a[2][3];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) a[c2][t] = *reinterpret_cast<const u32x4*>(gb + t * QDW_DYP + c2 * 16 * 80);
-            // this lane's two half fragments: gy-domain pixels kp .. kp + 3 of the tile
-            int hoff[2];
+            for (int i = c * (QDW_PUPT / QDW_PCH); i < (c + 1) * (QDW_PUPT / QDW_PCH); ++i) {
+                if (i >= nu) break;                                   // (uniform)
+                const uint32_t w = mn_opaque(ul[i]);
+                const bool valid = w != 0xffffffffu;
+                const uint32_t lo = valid ? pc_l + (w & 0xfffu) : dump_rel;
+                uint32_t v = ((pok >> i) & 1u) ? preg[i] : 0u;          // (signed codes: 0 ^ 0x80 - 128 = 0 as well)
+                float f0, f1, f2, f3;
+                if (p.xsgn) {                                         // (uniform) signed codes: byte ^ 0x80 - 128
+                    v ^= 0x80808080u;
+                    f0 = (float)(v & 0xffu) - 128.f; f1 = (float)((v >> 8) & 0xffu) - 128.f; f2 = (float)((v >> 16) & 0xffu) - 128.f; f3 = (float)(v >> 24) - 128.f;
+                } else { f0 = (float)(v & 0xffu); f1 = (float)((v >> 8) & 0xffu); f2 = (float)((v >> 16) & 0xffu); f3 = (float)(v >> 24); }
+                if (S == 1) *reinterpret_cast<u32x2*>(xp + lo) = u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)};
+                else {
+                    *reinterpret_cast<uint32_t*>(xp + lo) = mn_pack_hi16(f0, f2);
+                    *reinterpret_cast<uint32_t*>(xp + (valid ? lo + p.PWp * 2 : lo + 4)) = mn_pack_hi16(f1, f3);
+                }
+            }
+        };
+        // gy staging role: rows sr and sr + 32, float4 sq of the K-step.  A register STAGE holds a pair of K-steps (2 x 2 float4); two stages: 2 - 4 K-steps
+        // (16 - 32 KB per CU) in flight.  K-steps per tile are even (planner), so a tile's first step is always the first step of a stage.
+        const int sr = tid >> 3, sq = tid & 7;
+        struct GStage { float4 v[2][2]; int ok; };                   // [step of the pair][row half]; ok: bit h = step h's image exists
+        GStage gs[2];
+        // loads are unconditional (a conditional load makes the register set a phi: copies and a vmcnt(0) right behind the issue); past the block's range the
+        // block's own last pair is read again (an L2 hit)
+        const int nq = n >> 1;
+        auto fetch_gy = [&](GStage& G, int q) {
+            const int qq = q < nq ? q : nq - 1;
+            G.ok = 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int kp = ks * 32 + 8 * kg + 4 * h;
+                const int kk = 2 * qq + h;
+                const uint32_t tl = fd_div((uint32_t)kk, p.fd_nks);
+                const int ks = kk - (int)tl * p.nks;
+                int n0, oh0;
+                tile_origin(t_begin + (int)tl, n0, oh0);
+                const int kp = ks * 32 + 4 * sq;
                 const int col = kp & (p.Wg - 1), t = kp >> p.w_shift;
                 const uint32_t img = fd_div((uint32_t)t, p.fd_th);
                 const int ohl = t - (int)img * p.TH;
-                hoff[h] = (cf * 16 + j) * p.CS + ((int)img * p.PH + ohl * S) * p.RB + (4 + col) * 2;
+                int nn = n0 + (int)img;
+                const bool ok = nn < p.N;
+                G.ok |= (ok ? 1 : 0) << h;
+                nn = ok ? nn : p.N - 1;
+                const float* src = p.gy + (uint32_t)((nn * p.O + cot * 64 + sr) * p.Hg + oh0 + ohl) * (uint32_t)p.Wg + (uint32_t)col;
+                G.v[h][0] = *reinterpret_cast<const float4*>(src);
+                G.v[h][1] = *reinterpret_cast<const float4*>(src + (uint32_t)(32 * p.HWg));
             }
+        };
+        auto commit_gy = [&](const GStage& G, int h) {                 // step h of the pair -> gy buffer h (the step's parity)
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {
-                uint32_t lo[3][2], hi[3][2];                           // [s][half]
+            for (int i = 0; i < 2; ++i) {
+                const float4 g4 = ((G.ok >> h) & 1) ? G.v[h][i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned char* d = dyb + h * 3 * QDW_DYP + (sr + 32 * i) * 80 + sq * 8;
+                if (NT == 2) {
+                    unsigned h0, l0, h1, l1;
+                    mn_split2_bf16x2(g4.x, g4.y, h0, l0);
+                    mn_split2_bf16x2(g4.z, g4.w, h1, l1);
+                    *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(d + QDW_DYP) = u32x2{l0, l1};
+                } else {
+                    const float v[4] = {g4.x, g4.y, g4.z, g4.w};
+                    float t0[4], t1[4], t2[4];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const unsigned char* q = xp + hoff[h] + r * p.RB;
-                    if (S == 1) {
-                        const uint32_t pv = *reinterpret_cast<const uint32_t*>(q - 4), nx = *reinterpret_cast<const uint32_t*>(q + 8);
-                        const u32x2 c = *reinterpret_cast<const u32x2*>(q);
-                        lo[0][h] = mn_alignbyte(c[0], pv, 2); hi[0][h] = mn_alignbyte(c[1], c[0], 2);
-                        lo[1][h] = c[0]; hi[1][h] = c[1];
-                        lo[2][h] = mn_alignbyte(c[1], c[0], 2); hi[2][h] = mn_alignbyte(nx, c[1], 2);
-                    } else {
-                        const u32x2 e = *reinterpret_cast<const u32x2*>(q);
-                        lo[1][h] = e[0]; hi[1][h] = e[1];
-                        if (TAPS == 9) {
-                            const unsigned char* qo = q + p.PWp * 2;
-                            const uint32_t pv = *reinterpret_cast<const uint32_t*>(qo - 4);
-                            const u32x2 o = *reinterpret_cast<const u32x2*>(qo);
-                            lo[0][h] = mn_alignbyte(o[0], pv, 2); hi[0][h] = mn_alignbyte(o[1], o[0], 2);
-                            lo[2][h] = o[0]; hi[2][h] = o[1];
+                    for (int e = 0; e < 4; ++e) {
+                        t0[e] = mn_bf16_head(v[e]);
+                        const float r1 = v[e] - t0[e];
+                        t1[e] = mn_bf16_head(r1);
+                        t2[e] = r1 - t1[e];
+                    }
+                    *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
+                    *reinterpret_cast<u32x2*>(d + QDW_DYP) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
+                    *reinterpret_cast<u32x2*>(d + 2 * QDW_DYP) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
+                }
+            }
+        };
+        if (n > 0) {
+#pragma unroll
+            for (int c = 0; c < QDW_PCH; ++c) fetch_chunk(c, t_begin);
+            fetch_gy(gs[0], 0);
+            MN_SCHED_FENCE();
+            fetch_gy(gs[1], 1);
+        }
+        __syncthreads();                          // barrier Z: the consumers have zero-filled both patch buffers (the frame stays zero)
+        if (n > 0) {
+#pragma unroll
+            for (int c = 0; c < QDW_PCH; ++c) {
+                commit_chunk(c, xp0, dump);
+                if (t_begin + 1 < t_end) fetch_chunk(c, t_begin + 1);
+            }
+            int ks = 0, tile = t_begin;
+            const int ppt = p.nks >> 1;                                  // step pairs per tile (1, 2 or 4)
+            // Barrier k (behind the commit of step k into gy buffer k & 1) releases the consumers' reads of step k; buffer k & 1 is overwritten with step k + 2 behind
+            // barrier k + 1, which the consumers pass with every read of step k complete.  Patch: buffer (t + 1) & 1 is free once the consumers passed the barrier of
+            // tile t's first step (their last reads of tile t - 1 are complete) and must be complete at the barrier of tile t + 1's first step: its chunks are written
+            // in the SECOND half of tile t's step pairs.  One patch buffer (pdb == 0): the whole patch between barrier X and the next tile's first barrier.
+            for (int q0 = 0; q0 < nq; q0 += 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int q = q0 + u;
+                    if (q >= nq) break;                               // (uniform)
+                    if (!p.pdb && ks == 0 && q > 0) {
+                        __syncthreads();                                // barrier X: the consumers' last reads of the single patch buffer are complete
+#pragma unroll
+                        for (int c = 0; c < QDW_PCH; ++c) {
+                            commit_chunk(c, xp0, dump);
+                            if (tile + 1 < t_end) fetch_chunk(c, tile + 1);
                         }
                     }
+                    commit_gy(gs[u], 0);
+                    __syncthreads();
+                    if (p.pdb && tile + 1 < t_end) {
+                        const uint32_t po = (uint32_t)((((tile + 1 - t_begin) & 1)) * XPB);
+                        const int pit = ks >> 1;                         // this pair's index inside the tile
+#pragma unroll
+                        for (int c = 0; c < QDW_PCH; ++c) {
+                            if (((c * ppt) >> 2) != pit) continue;      // (uniform: chunk c belongs to pair c ppt / 4)
+                            commit_chunk(c, xp0 + po, dump - po);
+                            if (tile + 2 < t_end) fetch_chunk(c, tile + 2);
+                        }
+                    }
+                    commit_gy(gs[u], 1);
+                    fetch_gy(gs[u], q + 2);
+                    __syncthreads();
+                    ks += 2;
+                    if (ks == p.nks) { ks = 0; ++tile; }
                 }
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------------ consumers (512 threads)
+        const int cwv = wave - 4, cf = cwv & 3, coh = cwv >> 2;
+        f32x4 acc[2][TAPS];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[c2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        struct AFrag { u32x4 a[2][NT]; };
+        struct BRow { uint32_t w[2][5]; };                                // raw words of one kernel row: [half][..]
+        AFrag aa[2];
+        BRow bb[2];
+        auto load_a = [&](AFrag& A, int buf) {
+            const unsigned char* gb = dyb + buf * 3 * QDW_DYP + ((2 * coh) * 16 + j) * 80 + kg * 16;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) A.a[c2][t] = *reinterpret_cast<const u32x4*>(gb + t * QDW_DYP + c2 * 16 * 80);
+        };
+        // this lane's two half fragments: gy-domain pixels kp .. kp + 3 of the tile (kp = 32 ks + 8 kg + 4 h), kernel row r.  The LDS offset of (step, half) is kept
+        // incrementally: a K-step is 32 / Wg rows further down; past the tile image's last row the next image of the tile follows (PH patch rows per image)
+        const int rk = 32 >> p.w_shift;                                   // gy rows per K-step (0: several K-steps per row cannot happen, Wg <= 32)
+        int boff0[2], bohl0[2], boff[2], bohl[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kp = 8 * kg + 4 * h;
+            const int col = kp & (p.Wg - 1), t = kp >> p.w_shift;
+            const uint32_t img = fd_div((uint32_t)t, p.fd_th);
+            bohl0[h] = t - (int)img * p.TH;
+            boff0[h] = (cf * 16 + j) * p.CS + ((int)img * p.PH + bohl0[h] * S) * p.RB + (4 + col) * 2;
+            boff[h] = boff0[h]; bohl[h] = bohl0[h];
+        }
+        auto next_step_b = [&](bool new_tile) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (new_tile) { boff[h] = boff0[h]; bohl[h] = bohl0[h]; continue; }
+                int o = bohl[h] + rk, a = boff[h] + rk * S * p.RB;
+                while (o >= p.TH) { o -= p.TH; a += (p.PH - p.TH * S) * p.RB; }          // (at most 32 / (Wg TH) images further: a short uniform-trip loop on 4 x 4 images)
+                bohl[h] = o; boff[h] = a;
+            }
+        };
+        auto load_b = [&](BRow& B, int par, int r) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned char* q = xp0 + (par & p.pdb) * XPB + boff[h] + r * p.RB;
+                if (S == 1) {
+                    const u32x2 c = *reinterpret_cast<const u32x2*>(q);
+                    B.w[h][0] = *reinterpret_cast<const uint32_t*>(q - 4); B.w[h][1] = c[0]; B.w[h][2] = c[1]; B.w[h][3] = *reinterpret_cast<const uint32_t*>(q + 8);
+                } else {
+                    const u32x2 e = *reinterpret_cast<const u32x2*>(q);
+                    B.w[h][0] = e[0]; B.w[h][1] = e[1];
+                    if (TAPS == 9) {
+                        const unsigned char* qo = q + p.PWp * 2;
+                        const u32x2 o = *reinterpret_cast<const u32x2*>(qo);
+                        B.w[h][2] = *reinterpret_cast<const uint32_t*>(qo - 4); B.w[h][3] = o[0]; B.w[h][4] = o[1];
+                    }
+                }
+            }
+        };
+        auto mma = [&](const AFrag& A, const BRow& B, int r) {
+            uint32_t lo[3][2], hi[3][2];                                   // [s][half]
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (S == 1) {
+                    const uint32_t pv = B.w[h][0], c0 = B.w[h][1], c1 = B.w[h][2], nx = B.w[h][3];
+                    lo[0][h] = mn_alignbyte(c0, pv, 2); hi[0][h] = mn_alignbyte(c1, c0, 2);
+                    lo[1][h] = c0; hi[1][h] = c1;
+                    lo[2][h] = mn_alignbyte(c1, c0, 2); hi[2][h] = mn_alignbyte(nx, c1, 2);
+                } else {
+                    lo[1][h] = B.w[h][0]; hi[1][h] = B.w[h][1];
+                    if (TAPS == 9) {
+                        const uint32_t pv = B.w[h][2], o0 = B.w[h][3], o1 = B.w[h][4];
+                        lo[0][h] = mn_alignbyte(o0, pv, 2); hi[0][h] = mn_alignbyte(o1, o0, 2);
+                        lo[2][h] = o0; hi[2][h] = o1;
+                    }
+                }
+            }
+            u32x4 b[3];
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) b[s_] = u32x4{lo[s_][0], hi[s_][0], lo[s_][1], hi[s_][1]};
+            // term-outer over the row's taps: MFMAs on the same accumulator are 6 instructions apart (2 with the tap outermost: dependency stalls)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int s_ = 0; s_ < 3; ++s_) {
                     if (TAPS == 1 && s_ != 1) continue;
-                    const u32x4 b = u32x4{lo[s_][0], hi[s_][0], lo[s_][1], hi[s_][1]};
                     const int ti = TAPS == 9 ? r * 3 + s_ : 0;
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
+                    for (int c2 = 0; c2 < 2; ++c2) acc[c2][ti] = mn_mfma_bf16(A.a[c2][t], b[s_], acc[c2][ti]);
+                }
+        };
+        for (int i = tid - 256; i < ((1 + p.pdb) * XPB) / 8; i += 512) *reinterpret_cast<u32x2*>(xp0 + 8 * i) = u32x2{0u, 0u};          // the zero frame of both patch buffers
+        __syncthreads();                          // barrier Z
+        if (n > 0) {
+            int ks = 0, par = 0;
+            __syncthreads();                      // barrier 0
+            load_a(aa[0], 0);
+            load_b(bb[0], 0, 0);
+            for (int k0 = 0; k0 < n; k0 += 2) {
 #pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2) acc[c2][ti] = mn_mfma_bf16(a[c2][t], b, acc[c2][ti]);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int k = k0 + kk;
+                    if (k >= n) break;                                // (uniform)
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) {
+                        const int ph = kk * KR + r;                    // (2 KR phases per unrolled pair of steps: the word sets alternate consistently)
+                        const bool need_x = !p.pdb && ks == p.nks - 1 && k + 1 < n;          // single patch buffer: barrier X behind the tile's last patch reads
+                        if (r + 1 < KR) {
+                            load_b(bb[(ph + 1) & 1], par, r + 1);
+                            if (r + 2 == KR && need_x) __syncthreads();
+                        } else if (k + 1 < n) {
+                            if (KR == 1 && need_x) __syncthreads();
+                            __syncthreads();                          // barrier k + 1
+                            if (++ks == p.nks) { ks = 0; par ^= 1; next_step_b(true); } else next_step_b(false);
+                            load_a(aa[(kk + 1) & 1], (k + 1) & 1);
+                            load_b(bb[(ph + 1) & 1], par, 0);
+                        }
+                        MN_SCHED_FENCE();
+                        mma(aa[kk & 1], bb[ph & 1], r);
+                    }
                 }
             }
-            if (more && ks + 1 < p.nks) commit_gy(gbuf ^ 1);
-            __syncthreads();
-            if (ks + 1 < p.nks) gbuf ^= 1;
         }
+        // D[row = o: 4 kg + r][col = c: j] -> part[tap][c][o]
+        float* dst = p.part + ((int64_t)((int)z * p.npairs + pair) * TAPS) * 4096 + (cf * 16 + j) * 64 + (2 * coh) * 16 + 4 * kg;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) *reinterpret_cast<float4*>(dst + t * 4096 + c2 * 16) = make_float4(acc[c2][t][0], acc[c2][t][1], acc[c2][t][2], acc[c2][t][3]);
     }
-    // D[row = o: 4 kg + r][col = c: j]
-    float* dst = p.part + ((int64_t)((int)z * p.npairs + pair) * TAPS) * 4096;
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[t * 4096 + ((2 * coh + c2) * 16 + 4 * kg + r) * 64 + cf * 16 + j] = acc[c2][t][r];
 }
-// dw[o][c][tap] = scale * sum over z (fixed order, fp64) of part[z][pair][tap][o % 64][c % 64].  A block owns 64 consecutive (pair, tap, o, c) indices (one
+// dw[o][c][tap] = scale * sum over z (fixed order, fp64) of part[z][pair][tap][c % 64][o % 64].  A block owns 64 consecutive (pair, tap, o, c) indices (one
 // 256-byte row of every partial tile): thread (tx = 16 float4 columns, ty = 16 z residues) sums its z subset, the 16 subsets are added in order through LDS.
 __device__ __forceinline__ void qd_wgrad_reduce_block(const float* __restrict__ part, float* __restrict__ dw, int O, int C, int T, int Z, float scale, uint32_t blk,
                                                       double (&red)[16][64]) {
@@ -1404,7 +1587,7 @@ __device__ __forceinline__ void qd_wgrad_reduce_block(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 16; ++k) a += red[k][threadIdx.x];
         const int64_t idx = (int64_t)blk * 64 + threadIdx.x;
-        const int c = (int)(idx & 63), o = (int)((idx >> 6) & 63), t = (int)((idx >> 12) % T), pair = (int)((idx >> 12) / T);
+        const int o = (int)(idx & 63), c = (int)((idx >> 6) & 63), t = (int)((idx >> 12) % T), pair = (int)((idx >> 12) / T);
         const int cot = pair / (C / 64), cit = pair - cot * (C / 64);
         dw[((int64_t)(cot * 64 + o) * C + cit * 64 + c) * T + t] = (float)(a * (double)scale);
     }
@@ -1445,17 +1628,18 @@ static int plan_qdw(const mn_conv_geom* g, QdwPlan* pl) {
     if (p.w_shift < 2 || p.Wg > 32 || p.HWg % 8) return 0;
     if ((int64_t)g->N * g->C * g->H * g->W >= ((int64_t)1 << 31) || (int64_t)g->N * g->O * p.HWg >= ((int64_t)1 << 31)) return 0;
     int ok = 0;
-    for (int BMt = 256; BMt >= 32; BMt >>= 1) {
+    for (int pdb = 1; pdb >= 0 && !ok; --pdb)                 // two patch buffers + 30 KB of gy planes in 160 KB, else one
+    for (int BMt = 256; BMt >= 64; BMt >>= 1) {          // (>= 64: an even number of K-steps per tile, the producers stage K-steps in pairs)
         int TH, NI;
         if (p.HWg >= BMt) { if (BMt % p.Wg) continue; TH = BMt / p.Wg; if (p.Hg % TH) continue; NI = 1; }
         else { if (BMt % p.HWg) continue; NI = BMt / p.HWg; TH = p.Hg; }
         const int PH = (TH - 1) * S + g->KH, PWp = p.Wg + 8, RB = PWp * 2 * S;
-        if (PH > 255 || NI > 255) continue;
+        if (PH > 255 || NI > 63) continue;
         int CS = NI * PH * RB;
         if (((CS / 8) & 1) == 0) CS += 8;                     // odd multiple of 8 bytes: the 16 channels of a fragment fall on distinct 8-byte bank groups
         const int nunits = 64 * NI * PH * (g->W / 4);
-        if ((int64_t)64 * CS > 120 * 1024 || nunits > 512 * QDW_UPT) continue;
-        p.BMt = BMt; p.TH = TH; p.NI = NI; p.PH = PH; p.PWp = PWp; p.RB = RB; p.CS = CS; p.nunits = nunits; p.nks = BMt / 32;
+        if ((int64_t)(1 + pdb) * 64 * CS > 128 * 1024 || nunits > 256 * QDW_PUPT || CS > 4096 || g->W / 4 > 15) continue;          // (the packed unit word of the producers)
+        p.BMt = BMt; p.TH = TH; p.NI = NI; p.PH = PH; p.PWp = PWp; p.RB = RB; p.CS = CS; p.nunits = nunits; p.nks = BMt / 32; p.pdb = pdb;
         ok = 1;
         break;
     }
@@ -1473,9 +1657,9 @@ static int plan_qdw(const mn_conv_geom* g, QdwPlan* pl) {
     Z = (p.ntiles + p.tpz - 1) / p.tpz;
     p.Z = Z;
     p.fd_w4 = make_fastdiv((uint32_t)p.W4); p.fd_ph = make_fastdiv((uint32_t)p.PH); p.fd_ni = make_fastdiv((uint32_t)p.NI);
-    p.fd_th = make_fastdiv((uint32_t)p.TH); p.fd_tpi = make_fastdiv((uint32_t)p.tpi); p.fd_np = make_fastdiv((uint32_t)p.npairs);
+    p.fd_th = make_fastdiv((uint32_t)p.TH); p.fd_tpi = make_fastdiv((uint32_t)p.tpi); p.fd_np = make_fastdiv((uint32_t)p.npairs); p.fd_nks = make_fastdiv((uint32_t)p.nks);
     pl->grid = p.npairs * Z;
-    pl->lds = (size_t)2 * 3 * QDW_DYP + (size_t)64 * p.CS;
+    pl->lds = (size_t)2 * 3 * QDW_DYP + (size_t)(1 + p.pdb) * 64 * p.CS + 16;
     pl->ws_bytes = (int64_t)Z * p.npairs * T * 4096 * 4;
     return 1;
 }
@@ -1496,12 +1680,15 @@ int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, i
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense): workspace too small");
     QdwParams& p = pl.p;
     p.gy = gy; p.x = x; p.part = reinterpret_cast<float*>(ws); p.xsgn = xsgn;
-    mn_set_last_kernel("k_qd_wgrad<%d, %d>", pl.S, pl.T);
+    const int NT = qd_terms();
+    mn_set_last_kernel("k_qd_wgrad<%d, %d, %d>", pl.S, pl.T, NT);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + nx * (g->O / 64) + (double)pl.ws_bytes); mn_prof_flops(2.0 * ny * g->C * pl.T); }
     mn_prof_begin(s);
-    if (pl.S == 1) { raise_lds_limit((const void*)k_qd_wgrad<1, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<1, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
-    else if (pl.T == 9) { raise_lds_limit((const void*)k_qd_wgrad<2, 9>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 9>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
-    else { raise_lds_limit((const void*)k_qd_wgrad<2, 1>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<2, 1>), dim3(pl.grid), dim3(512), pl.lds, s, p); }
+#define QDW_LAUNCH(S_, T_, N_) do { raise_lds_limit((const void*)k_qd_wgrad<S_, T_, N_>, pl.lds); hipLaunchKernelGGL((k_qd_wgrad<S_, T_, N_>), dim3(pl.grid), dim3(768), pl.lds, s, p); } while (0)
+    if (pl.S == 1) { if (NT == 2) QDW_LAUNCH(1, 9, 2); else QDW_LAUNCH(1, 9, 3); }
+    else if (pl.T == 9) { if (NT == 2) QDW_LAUNCH(2, 9, 2); else QDW_LAUNCH(2, 9, 3); }
+    else { if (NT == 2) QDW_LAUNCH(2, 1, 2); else QDW_LAUNCH(2, 1, 3); }
+#undef QDW_LAUNCH
     mn_prof_end(s);
     const int total = p.npairs * pl.T * 4096;
     if (dw) hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(256), 0, s, (const float*)p.part, dw, (int)g->O, (int)g->C, pl.T, p.Z, ascale, ascale_dev);
@@ -1621,7 +1808,7 @@ int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, c
     const IaoRange r = iao_range(aq->bits, 0, 1);
     static const bool ste_sep = MN_ENV("MN_QD_STE_SEPARATE") != nullptr;          // A/B knob: the clip-STE as a pass of its own (round 3)
     p.ste_x = ste_sep ? nullptr : x; p.ste_qp = aq->qp; p.ste_qmin = r.qmin; p.ste_qmax = r.qmax;          // the quantizer's clip-STE rides the store of dx
-    mn_set_last_kernel("k_qd_dgrad<%d, %d, %d>", pl.MF, pl.S, p.TAPS);
+    mn_set_last_kernel("k_qd_dgrad<%d, %d, %d, %d>", pl.MF, pl.S, p.TAPS, qd_terms());
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 8.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     qd_launch_dgrad(pl, s);
