@@ -50,6 +50,7 @@ MB_PER_IMG = {"nin_gc": 22.71, "resnet18": 12.91}        # fused
 WORKLOADS = {
     # name: (arch, scheme module, prepare kwargs, weight decay)   (BASELINE.json configs)
     "c2": ("nin_gc", "wbwtab", dict(A=2, W=3), 0.0),
+    "c2b": ("nin_gc", "wbwtab", dict(A=2, W=2), 0.0),             # the literal `wbwtab/main.py --W 2 --A 2` ("W2A2" of BASELINE.json's metric string)
     "c1": ("nin_gc", "wqaq.dorefa", dict(a_bits=8, w_bits=8), 1e-5),
     "c1_w2a2": ("nin_gc", "wqaq.dorefa", dict(a_bits=2, w_bits=2), 1e-5),
     "c3": ("nin_gc", "wqaq.iao", dict(a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=True), 1e-5),
@@ -58,6 +59,7 @@ WORKLOADS = {
 }
 WORKLOAD_DESC = {
     "c2": "nin_gc CIFAR-10 wbwtab W-ternary/A-binary QAT, batch=256 per GPU (BASELINE configs[1])",
+    "c2b": "nin_gc CIFAR-10 wbwtab W-binary/A-binary QAT (wbwtab/main.py --W 2 --A 2), batch=256 per GPU",
     "c1": "nin_gc CIFAR-10 DoReFa W8A8 QAT (BASELINE configs[0] scheme)",
     "c1_w2a2": "nin_gc CIFAR-10 DoReFa W2A2 QAT, batch=256 per GPU",
     "c3": "nin_gc CIFAR-10 IAO W8A8 per-channel + BN-fuse QAT (BASELINE configs[2])",
@@ -100,8 +102,22 @@ def build(workload, device):
     return model, make_optimizer(model, 0.01, wd)
 
 
-def cpu_baseline(workload, batch, steps, threads=0):
-    """The reference's algorithm on the host cores: the torch-CPU oracle ("port", bit-identical to the reference on CPU)."""
+REFERENCE_DIR = os.environ.get("MICRONET_REFERENCE", "/root/reference")
+
+
+def cpu_baseline(workload, batch, steps, threads=0, kind="auto"):
+    """The reference's algorithm on the host cores.  kind "reference": the reference's OWN modules (imported from MICRONET_REFERENCE, default /root/reference, in a
+    child process -- its package is also called `micronet`; present in the build container only, never on the GPU box); "port": the torch-CPU oracle
+    (oracle/torch_oracle.py, bit-identical to the reference on CPU: tests/test_oracle_golden.py); "auto": the reference where it is importable, else the port."""
+    if kind in ("auto", "reference") and os.path.isdir(os.path.join(REFERENCE_DIR, "micronet")):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-ref-child", "--only", workload, "--cpu-batch", str(batch), "--cpu-steps", str(steps),
+               "--cpu-threads", str(threads)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        if kind == "reference":
+            raise RuntimeError("reference CPU leg failed: %s" % r.stderr[-400:])
     from oracle import torch_oracle as TO
     from micronet_amd.train import build_model, synth_batch
     arch, scheme, kw, wd = WORKLOADS[workload]
@@ -115,9 +131,60 @@ def cpu_baseline(workload, batch, steps, threads=0):
     for _ in range(steps):
         TO.train_step(model, opt, x, y)
     dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 2), unit="images/s", cores=torch.get_num_threads(), host_cores=os.cpu_count(), kind="port", workload=workload,
+    return dict(value=round(batch * steps / dt, 2), unit="images/s", cores=torch.get_num_threads(), host_cores=os.cpu_count(), kind="port", workload=workload, batch=batch,
                 sample="%d timed steps (+1 warm-up) of the same train step at batch %d, oracle/torch_oracle.py (torch-CPU restatement of the reference modules), "
                        "%.1f s of CPU work" % (steps, batch, dt))
+
+
+def cpu_reference_child(workload, batch, steps, threads):
+    """Child process of cpu_baseline(kind="reference"): the reference's own `micronet` package first on sys.path (our shim package of the same name must not win),
+    its own model files, its own `prepare`, the training step of its main.py (wqaq/dorefa/main.py:77-82) with Adam (main.py:142-146), on the synthetic batch."""
+    import importlib
+    sys.path[:] = [REFERENCE_DIR] + [q for q in sys.path if os.path.abspath(q or ".") != ROOT] + [ROOT]
+    assert not any(m == "micronet" or m.startswith("micronet.") for m in sys.modules), "the shim package was imported before the reference"
+    arch, scheme, kw, wd = WORKLOADS[workload]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    assert os.path.abspath(quantize.__file__).startswith(os.path.abspath(REFERENCE_DIR)), quantize.__file__
+    from micronet_amd.train import init_like_main, synth_batch       # (our package: the reference has no synthetic-data helper; init = its main.py:289-297)
+    torch.set_num_threads(threads if threads > 0 else os.cpu_count())
+    torch.manual_seed(1)
+    if arch == "nin_gc":
+        model = importlib.import_module("micronet.models.nin_gc").Net()
+    else:
+        model = importlib.import_module("micronet.models.resnet").resnet18()
+    init_like_main(model)
+    model = quantize.prepare(model, inplace=True, **kw).train()
+    opt = torch.optim.Adam([{"params": [q_], "lr": 0.01, "weight_decay": wd} for q_ in model.parameters()], lr=0.01, weight_decay=wd)
+    x, y = synth_batch(batch)
+
+    def step():
+        out = model(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    print(json.dumps(dict(value=round(batch * steps / dt, 2), unit="images/s", cores=torch.get_num_threads(), host_cores=os.cpu_count(), kind="reference", workload=workload,
+                          batch=batch, sample="%d timed steps (+1 warm-up) at batch %d of the reference's own modules (%s), %.1f s of CPU work"
+                                                % (steps, batch, os.path.relpath(quantize.__file__, REFERENCE_DIR), dt))), flush=True)
+
+
+def cpu_more_legs(args, primary):
+    """The CPU legs besides the primary one: {name: record}.  c1_b128 = BASELINE.json configs[0] (the reference's CPU configuration: DoReFa W8A8, batch 128)."""
+    out = {}
+    for name in [w for w in args.cpu_more.split(",") if w]:
+        w, b, st = ("c1", 128, 4) if name == "c1_b128" else (name, args.cpu_batch, 2)
+        if w == primary and b == args.cpu_batch or w not in WORKLOADS:
+            continue
+        try:
+            out[name] = cpu_baseline(w, b, st, args.cpu_threads, args.cpu_kind)
+        except Exception as e:          # noqa: BLE001 -- a failing extra leg must not cost the line
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
 
 
 def measure(workload, args, world, rank, device):
@@ -323,6 +390,7 @@ def pmc_collect(workloads, batch, timeout_s=240):
     for w in workloads:
         res[w] = {}
         tot_bytes = tot_mfma = tot_gui = 0.0
+        stock_launches = 0
         for k, v in acc[w].items():
             e = {}
             n_f, n_w = cnt[w][k].get("FETCH_SIZE", 0), cnt[w][k].get("WRITE_SIZE", 0)
@@ -338,11 +406,16 @@ def pmc_collect(workloads, batch, timeout_s=240):
                 tot_gui += v["GRBM_GUI_ACTIVE"]
             if e and (k.startswith("k_") or "k_" in k[:8]):
                 res[w][k] = e
+            elif not (k.startswith("k_") or "k_" in k[:8]):
+                c0 = max(cnt[w][k].values()) if cnt[w][k] else 0          # dispatches of a kernel that is not this library's (MIOpen / ATen): the stock operators left in the step
+                stock_launches += c0
         step = {}
         if tot_bytes:
             step["pmc_hbm_bytes_per_step_all_kernels"] = int(tot_bytes / PMC_CHILD_STEPS)
         if tot_gui:
             step["pmc_mfma_busy_all_kernels"] = round(tot_mfma / (tot_gui / N_XCD * N_SIMD), 4)
+        if acc[w]:
+            step["stock_kernel_launches_per_step"] = round(stock_launches / PMC_CHILD_STEPS, 1)
         res[w]["_step"] = step
     return res, err
 
@@ -376,7 +449,7 @@ def compact_roofline(r):
         out["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE(x2 gfx950)+WRITE_SIZE"
     return out
 
-def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info=None):
+def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info=None, cpu_more=None):
     """(final-line dict, detail dict).  The final stdout line is what the driver parses: the contract's keys, the HEADLINE workload's roofline, cpu_baseline, one
     short record per secondary workload, every images/s figure under `values` -- bounded by MAX_LINE_BYTES.  Everything else (per-kernel tables, step_level,
     timed windows of every workload) is `detail`, written to a side file."""
@@ -388,7 +461,10 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         "config": {"workload": WORKLOAD_DESC[primary], "global_batch": args.batch * world,
                    "per_gpu_batch": args.batch, "parallelism": "dp%d" % world, "optimizer": "Adam lr=0.01",
                    "hip_graph": sec["hip_graph"], "final_loss": sec["final_loss"],
-                   "stock_fallbacks": sum(sec.get("stock_fallbacks", {}).values()) + sum(sum(s_.get("stock_fallbacks", {}).values()) for s_ in also_secs.values())},
+                   # quantized layers that fell through to a stock torch operator while any workload of this run executed (expected 0)
+                   "quant_layer_fallbacks": sum(sec.get("stock_fallbacks", {}).values()) + sum(sum(s_.get("stock_fallbacks", {}).values()) for s_ in also_secs.values()),
+                   # launches per step of kernels that are NOT this library's (the un-quantised tail: last BatchNorm, loss, fills), counted in the PMC passes (null without them)
+                   "stock_kernels_per_step": sec.get("step_level", {}).get("stock_kernel_launches_per_step")},
     }
     out["ms_per_step_min"], out["value_best_window"], out["repeats"], out["window_ms"] = sec["ms_per_step_min"], sec["value_best_window"], sec["repeats"], sec["window_ms"]
     if dist_info:
@@ -420,7 +496,12 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
     if cpu is not None:
         out["cpu_baseline"] = cpu
         detail["cpu_baseline"] = cpu
-    for drop in ("also", "step_level", "window_ms"):      # the driver parses the LAST stdout line: never let it outgrow its reader again (round 3: 34 KB -> parsed null)
+    if cpu_more:
+        detail["cpu_baselines"] = cpu_more
+        if "c1_b128" in cpu_more:                            # BASELINE.json configs[0]: nin_gc DoReFa W8A8, batch 128, CPU reference path (wqaq/dorefa/main.py:135,171,189-190)
+            out["cpu_baseline_c1_b128"] = {k: cpu_more["c1_b128"][k] for k in ("value", "unit", "cores", "kind", "batch", "sample") if k in cpu_more["c1_b128"]}
+        out["cpu_values"] = {k: v["value"] for k, v in cpu_more.items() if "value" in v}
+    for drop in ("window_ms", "step_level", "cpu_values", "also"):      # the driver parses the LAST stdout line: never let it outgrow its reader again (round 3: 34 KB -> parsed null)
         if len(json.dumps(out)) + 64 <= MAX_LINE_BYTES:
             break
         out.pop(drop, None)
@@ -446,7 +527,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS), help="primary workload (value / roofline / cpu_baseline)")
-    ap.add_argument("--also", default="c1_w2a2,c1,c3,c4,c5", help="comma-separated secondary workloads reported under `also` ('' = none)")
+    ap.add_argument("--also", default="c1_w2a2,c2b,c1,c3,c4,c5", help="comma-separated secondary workloads reported under `also` ('' = none)")
     ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps each; value = the median window")
     ap.add_argument("--master-port", type=int, default=29531, help="rendezvous port when --gpus N > 1 starts its own ranks")
     ap.add_argument("--only", default=None, choices=list(WORKLOADS), help="measure this single workload (no `also`)")
@@ -459,6 +540,10 @@ def main():
                     help="threads for the CPU baseline; 0 = os.cpu_count(). 16 is the fastest setting measured on the MI355X host "
                          "(2x EPYC 9575F: 97 img/s at 16 threads, 72 at 32, 41 at 64, 24 at 128, 1.1 at 256)")
     ap.add_argument("--cpu-only", action="store_true", help="only time the CPU baseline (no GPU work)")
+    ap.add_argument("--cpu-kind", default="auto", choices=["auto", "reference", "port"], help="CPU leg: the reference's own modules (when MICRONET_REFERENCE is importable) or the port")
+    ap.add_argument("--cpu-more", default="c1_b128,c1_w2a2,c2b,c3,c4,c5",
+                    help="further CPU legs (detail file + cpu_values): c1_b128 = configs[0] (DoReFa W8A8 at batch 128, 4 steps); the others 2 steps at --cpu-batch; '' = none")
+    ap.add_argument("--cpu-ref-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic / mfma_busy stay null)")
     ap.add_argument("--detail", default=None, help="where the per-kernel tables / step_level / windows go (default gpurun_out/bench_detail.json)")
@@ -476,8 +561,13 @@ def main():
     for w in also:
         if w not in WORKLOADS:
             raise SystemExit("unknown workload in --also: %s" % w)
+    if args.cpu_ref_child:
+        cpu_reference_child(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads)
+        return
     if args.cpu_only:
-        print(json.dumps(cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads)), flush=True)
+        out = {primary: cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads, args.cpu_kind)}
+        out.update(cpu_more_legs(args, primary))
+        print(json.dumps(out), flush=True)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         # no launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI) and relay rank 0's JSON line
@@ -531,8 +621,9 @@ def main():
         if world > 1:
             dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None}
-        cpu = cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads) if (world == 1 and not args.no_cpu_baseline) else None
-        out, detail = compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info)
+        cpu = cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads, args.cpu_kind) if (world == 1 and not args.no_cpu_baseline) else None
+        cpu_more = cpu_more_legs(args, primary) if (world == 1 and not args.no_cpu_baseline and not args.only) else None
+        out, detail = compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info, cpu_more)
         out["detail_file"] = write_detail(detail, args)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)

@@ -322,9 +322,11 @@ class QuantConv2d(nn.Conv2d):
 
 
 class QuantConvTranspose2d(nn.ConvTranspose2d):
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, dilation=1,
-                 groups=1, bias=True, padding_mode="zeros", a_bits=8, w_bits=8, q_type=0, weight_observer=0,
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, groups=1,
+                 bias=True, dilation=1, padding_mode="zeros", a_bits=8, w_bits=8, q_type=0, weight_observer=0,
                  quant_inference=False, qaft=False, ptq=False, percentile=0.9999):
+        # positional order as the reference's (iao/quantize.py:511-531: groups, bias, dilation -- nn.ConvTranspose2d's own order; its dorefa / wbwtab
+        # siblings declare dilation, groups, bias)
         super().__init__(in_channels, out_channels, kernel_size, stride, padding, output_padding, groups, bias,
                          dilation, padding_mode)
         self.quant_inference = quant_inference

@@ -322,6 +322,33 @@ class OBNFuseConv2d(OConv2d):
         return out + b_f.reshape(1, -1, 1, 1)
 
 
+class OConvTranspose2d(nn.ConvTranspose2d):
+    """QuantConvTranspose2d of the three schemes (dorefa/quantize.py:126-174, wbwtab/quantize.py:198-244, iao/quantize.py:510-636): the scheme's quantizers in front of
+    F.conv_transpose2d; IAO weights are quantised per LAYER only (555-570).  `src`: an nn.ConvTranspose2d whose parameters are shared."""
+
+    def __init__(self, src, scheme, **cfg):
+        super().__init__(src.in_channels, src.out_channels, src.kernel_size, src.stride, src.padding, src.output_padding, src.groups, src.bias is not None,
+                         src.dilation, src.padding_mode)
+        self.scheme, self.cfg = scheme, cfg
+        self.weight = src.weight
+        if src.bias is not None:
+            self.bias = src.bias
+        if scheme == "iao":
+            self.aq, self.wq = _iao_pair(cfg["a_bits"], cfg["w_bits"], cfg.get("q_type", 0), 1, cfg.get("weight_observer", 0), None, "C", cfg.get("qaft", False),
+                                         cfg.get("ptq", False), cfg.get("percentile", 0.9999))
+
+    quant_inference = False
+
+    def forward(self, x):
+        if self.scheme == "dorefa":
+            qx, qw = dorefa_act(x, self.cfg["a_bits"]), self.weight if self.quant_inference else dorefa_weight(self.weight, self.cfg["w_bits"])
+        elif self.scheme == "wbwtab":
+            qx, qw = x, self.weight if self.quant_inference else wbwtab_weight(self.weight, self.cfg["W"])
+        else:
+            qx, qw = self.aq(x), self.weight if self.quant_inference else self.wq(self.weight)
+        return F.conv_transpose2d(qx, qw, self.bias, self.stride, self.padding, self.output_padding, self.groups, self.dilation)
+
+
 class OLinear(nn.Linear):
     def __init__(self, src, scheme, **cfg):
         super().__init__(src.in_features, src.out_features, src.bias is not None)

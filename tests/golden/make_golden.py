@@ -599,6 +599,49 @@ def gen_inference(out):
     return meta
 
 
+# ---------------------------------------------------------------- QuantConvTranspose2d of the three schemes (dorefa 126-174, wbwtab 198-244, iao 510-636)
+CONVT_CASES = [
+    # name, scheme, ctor kwargs (beyond the shape), steps
+    ("dorefa_w4a4", "dorefa", dict(a_bits=4, w_bits=4), 1),
+    ("wbwtab_w2", "wbwtab", dict(W=2), 1),
+    ("wbwtab_w3", "wbwtab", dict(W=3), 1),
+    ("iao_sym_w8a8", "iao", dict(a_bits=8, w_bits=8, q_type=0), 2),
+    ("iao_asym_w4a4_ma", "iao", dict(a_bits=4, w_bits=4, q_type=1, weight_observer=1), 2),
+]
+
+
+def gen_convt(out):
+    """groups = 1, dilation = 1, bias = True only: the reference's dorefa / wbwtab classes hand (dilation, groups, bias) to nn.ConvTranspose2d in the positions of
+    (groups, bias, dilation) (dorefa/quantize.py:142-153, wbwtab/quantize.py:214-225), so every other combination builds a different layer than the one asked for."""
+    meta = []
+    for ci, (name, scheme, kw, steps) in enumerate(CONVT_CASES):
+        r = rng(900 + ci)
+        cin, cout, k, st, pd, op, H, W, Nb = 8, 6, 3, 2, 1, 1, 8, 8, 2
+        w = (r.standard_normal((cin, cout, k, k)) * 0.3).astype(np.float32)
+        b = (r.standard_normal(cout) * 0.1).astype(np.float32)
+        x = (r.standard_normal((Nb, cin, H, W)) * 4).astype(np.float32)
+        if scheme == "wbwtab":
+            x = np.where(x > 0, 1.0, -1.0).astype(np.float32)            # the layer's input is a BinaryActivation output
+        Ho, Wo = (H - 1) * st - 2 * pd + (k - 1) + op + 1, (W - 1) * st - 2 * pd + (k - 1) + op + 1
+        g = r.standard_normal((Nb, cout, Ho, Wo)).astype(np.float32)
+        ref = {"dorefa": ref_dorefa, "wbwtab": ref_wbwtab, "iao": ref_iao}[scheme]
+        # dorefa / wbwtab: `bias=1` -- the swapped hand-over makes nn's dilation = the `bias` argument, and torch >= 2 rejects dilation (True, True)
+        # ("must be tuple of ints, but found element of type bool"): with the default bias=True these two reference classes cannot run a forward here at all;
+        # the integer 1 is the one value that is both a valid dilation and a true bias flag.  The reference itself is executed unmodified.
+        extra = {} if scheme == "iao" else dict(bias=1)
+        mod = ref.QuantConvTranspose2d(cin, cout, k, stride=st, padding=pd, output_padding=op, **extra, **kw)
+        assert tuple(mod.weight.shape) == w.shape and mod.groups == 1 and tuple(mod.dilation) == (1, 1) and mod.bias is not None
+        mod.weight.data = T(w)
+        mod.bias.data = T(b)
+        mod.train()
+        base = f"convt_{name}"
+        out[base + "_x"], out[base + "_w"], out[base + "_b"], out[base + "_g"] = x, w, b, g
+        for key, val in run_module(mod, x, g, steps=steps).items():
+            out[f"{base}_{key}"] = val
+        meta.append(dict(name=name, scheme=scheme, kw=kw, steps=steps, shape=[cin, cout, k, st, pd, op, H, W, Nb]))
+    return meta
+
+
 def main():
     if "--inference-only" in sys.argv:      # regenerate only inference.npz (the older fixture files stay byte-identical)
         o = {}
@@ -607,6 +650,14 @@ def main():
         with open(os.path.join(HERE, "inference_meta.json"), "w") as f:
             json.dump(dict(cases=inf_meta, cfg=SMALL_CFG, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
         print("inference.npz", os.path.getsize(os.path.join(HERE, "inference.npz")) // 1024, "KiB")
+        return
+    if "--convt-only" in sys.argv:      # regenerate only convt.npz (round 5; the older fixture files stay byte-identical)
+        o = {}
+        meta = gen_convt(o)
+        np.savez_compressed(os.path.join(HERE, "convt.npz"), **o)
+        with open(os.path.join(HERE, "convt_meta.json"), "w") as f:
+            json.dump(dict(cases=meta, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
+        print("convt.npz", os.path.getsize(os.path.join(HERE, "convt.npz")) // 1024, "KiB")
         return
     if "--ops-only" in sys.argv:      # regenerate only iao_ops.npz (the three older fixture files stay byte-identical)
         o = {}
@@ -644,6 +695,12 @@ def main():
     with open(os.path.join(HERE, "inference_meta.json"), "w") as f:
         json.dump(dict(cases=inf_meta, cfg=SMALL_CFG, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
     print("inference.npz", os.path.getsize(os.path.join(HERE, "inference.npz")) // 1024, "KiB")
+    o = {}
+    meta = gen_convt(o)
+    np.savez_compressed(os.path.join(HERE, "convt.npz"), **o)
+    with open(os.path.join(HERE, "convt_meta.json"), "w") as f:
+        json.dump(dict(cases=meta, torch=torch.__version__, reference_version="1.12.0"), f, indent=1)
+    print("convt.npz", os.path.getsize(os.path.join(HERE, "convt.npz")) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -147,23 +147,46 @@ def test_standalone_quantizers_keep_the_reference_call_pattern(golden):
     assert d.ActivationQuantizer(a_bits=32)(x) is x
 
 
-def test_conv_transpose_modules():
-    """QuantConvTranspose2d (dorefa 158-174, wbwtab 229-244, iao 620-636) vs the torch-CPU oracle formulas."""
-    torch.manual_seed(0)
-    d = _q("wqaq.dorefa")
-    mod = d.QuantConvTranspose2d(8, 6, 3, stride=2, padding=1, output_padding=1, a_bits=4, w_bits=4).cuda().train()
-    x = (torch.randn(2, 8, 8, 8) * 4)
-    xt = x.clone().cuda().requires_grad_(True)
-    y = mod(xt)
-    g = torch.randn_like(y)
-    y.backward(g)
-    w_cpu = mod.weight.detach().cpu().clone().requires_grad_(True)
-    x_cpu = x.clone().requires_grad_(True)
-    yr = torch.nn.functional.conv_transpose2d(TO.dorefa_act(x_cpu, 4), TO.dorefa_weight(w_cpu, 4), mod.bias.detach().cpu(), 2, 1, 1, 1, 1)
-    yr.backward(g.cpu())
-    assert rel_err(y.detach().cpu(), yr.detach()) <= 1e-5
-    assert rel_err(xt.grad.cpu(), x_cpu.grad) <= 1e-5
-    assert rel_err(mod.weight.grad.cpu(), w_cpu.grad) <= 1e-5
+def _convt_golden():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return np.load(os.path.join(here, "convt.npz")), json.load(open(os.path.join(here, "convt_meta.json")))
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_conv_transpose_modules_vs_reference_golden(idx):
+    """QuantConvTranspose2d of ALL THREE schemes (dorefa 126-174, wbwtab 198-244, iao 510-636) on the GPU against vectors produced by the reference's own classes
+    (tests/golden/make_golden.py --convt-only): outputs / gradients <= 1e-5 of max|ref|, IAO observer ranges and scales bit-exact, the W = 2 in-place weight update
+    bit-exact."""
+    m, meta = _convt_golden()
+    c = meta["cases"][idx]
+    cin, cout, k, st, pd, op, H, W, Nb = c["shape"]
+    base = "convt_" + c["name"]
+    q = _q({"dorefa": "wqaq.dorefa", "wbwtab": "wbwtab", "iao": "wqaq.iao"}[c["scheme"]])
+    mod = q.QuantConvTranspose2d(cin, cout, k, stride=st, padding=pd, output_padding=op, **c["kw"])
+    mod.weight.data = torch.from_numpy(m[base + "_w"].copy())
+    mod.bias.data = torch.from_numpy(m[base + "_b"].copy())
+    mod = mod.cuda().train()
+    for s in range(c["steps"]):
+        for p_ in mod.parameters():
+            p_.grad = None
+        xt = torch.from_numpy(m[base + "_x"].copy()).cuda().requires_grad_(True)
+        y = mod(xt)
+        y.backward(torch.from_numpy(m[base + "_g"].copy()).cuda())
+        pre = f"{base}_s{s}"
+        assert rel_err(y.detach().cpu().numpy(), m[pre + "_y"]) <= 1e-5, pre
+        assert rel_err(xt.grad.cpu().numpy(), m[pre + "_dx"]) <= 1e-5, pre
+        assert rel_err(mod.weight.grad.cpu().numpy(), m[pre + "_d_weight"]) <= 1e-5, pre
+        assert rel_err(mod.bias.grad.cpu().numpy(), m[pre + "_d_bias"]) <= 1e-5, pre
+    if c["scheme"] == "iao":
+        sd = {k_: v.detach().cpu().numpy() for k_, v in mod.state_dict().items()}
+        for name in ("activation_quantizer.scale", "activation_quantizer.observer.min_val", "activation_quantizer.observer.max_val", "activation_quantizer.zero_point",
+                     "weight_quantizer.scale", "weight_quantizer.observer.min_val", "weight_quantizer.observer.max_val"):
+            assert sd[name].shape == m[f"{base}_buf_{name}"].shape, name
+            assert np.array_equal(sd[name], m[f"{base}_buf_{name}"]), name
+    if c["scheme"] == "wbwtab" and c["kw"]["W"] == 2:
+        assert np.array_equal(mod.weight.detach().cpu().numpy(), m[base + "_par_weight"])
 
 
 @pytest.mark.parametrize("scheme,cfg,okw", [

@@ -6,6 +6,9 @@ Tolerances (stated once, used below):
     so with np.tanh at most a handful of codes may move at rounding boundaries;
   * float conv accumulate (numpy fp64 einsum vs the reference's MKLDNN fp32): |diff| <= 1e-5 * max|ref|.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -303,3 +306,40 @@ def test_bn_fused_inference_graphs_oracle_vs_reference_golden(key):
             outs.append(t)
         assert eq(outs[1].numpy(), g[f"{key}_fused_stage1"]) and eq(outs[8].numpy(), g[f"{key}_fused_stage8"])
         assert eq(fused(x).numpy(), g[f"{key}_fused_logits"])
+
+
+def _convt_golden():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return np.load(os.path.join(here, "convt.npz")), json.load(open(os.path.join(here, "convt_meta.json")))
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_conv_transpose_oracle_vs_reference_golden(idx):
+    """QuantConvTranspose2d of the three schemes (dorefa 126-174, wbwtab 198-244, iao 510-636): TO.OConvTranspose2d reproduces the reference's outputs, gradients and
+    observer buffers on the reference's own inputs (tests/golden/make_golden.py --convt-only)."""
+    m, meta = _convt_golden()
+    c = meta["cases"][idx]
+    cin, cout, k, st, pd, op, H, W, Nb = c["shape"]
+    base = "convt_" + c["name"]
+    torch.set_num_threads(8)
+    src = torch.nn.ConvTranspose2d(cin, cout, k, st, pd, op)
+    src.weight.data = torch.from_numpy(m[base + "_w"].copy())
+    src.bias.data = torch.from_numpy(m[base + "_b"].copy())
+    mod = TO.OConvTranspose2d(src, c["scheme"], **c["kw"]).train()
+    for s in range(c["steps"]):
+        for p_ in mod.parameters():
+            p_.grad = None
+        xt = torch.from_numpy(m[base + "_x"].copy()).requires_grad_(True)
+        y = mod(xt)
+        y.backward(torch.from_numpy(m[base + "_g"].copy()))
+        pre = f"{base}_s{s}"
+        assert eq(y.detach().numpy(), m[pre + "_y"]), pre
+        assert eq(xt.grad.numpy(), m[pre + "_dx"]), pre
+        assert eq(mod.weight.grad.numpy(), m[pre + "_d_weight"]), pre
+        assert eq(mod.bias.grad.numpy(), m[pre + "_d_bias"]), pre
+    if c["scheme"] == "iao":
+        for q_, o_ in (("activation_quantizer", mod.aq), ("weight_quantizer", mod.wq)):
+            assert eq(o_.scale.numpy().reshape(-1), m[f"{base}_buf_{q_}.scale"].reshape(-1)), q_
+            assert eq(o_.observer.min_val.numpy().reshape(-1), m[f"{base}_buf_{q_}.observer.min_val"].reshape(-1)), q_
+    if c["scheme"] == "wbwtab" and c["kw"]["W"] == 2:
+        assert eq(mod.weight.detach().numpy(), m[base + "_par_weight"])          # mean-centred and clamped in place (wbwtab/quantize.py:98-102)
