@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void k_bf_gram_stats(const float* __restrict__
         const int k = tid;
         const double m1 = red[k * 4] + red[k * 4 + 2], q = red[k * 4 + 1] + red[k * 4 + 3];
         stats[o0 + k] = (float)(m1 + (bias ? (double)bias[o0 + k] : 0.0));
-        stats[O + o0 + k] = (float)(q / (n - 1.0));
+        stats[O + o0 + k] = (float)((q > 0.0 ? q : 0.0) / (n - 1.0));          // (a near-constant channel with a large mean can cancel to a slightly negative sum: sqrt(var + eps) must stay real)
     }
 }
 extern "C" int mn_iaobf_gram_stats(const float* w, const float* bias, const double* gram, const double* sx, int64_t O, int64_t Cg, int64_t groups, double n, float* stats,

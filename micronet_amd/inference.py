@@ -17,6 +17,13 @@ import torch
 import torch.nn as nn
 
 
+def mark_stored_codes(m):
+    """Record that the weights m.weight holds RIGHT NOW are codes x alpha[o] (wbwtab QuantConv2d with quant_inference=True): the verdict is tied to the tensor's data
+    pointer and version, so `weight.data = ...`, an in-place update or load_state_dict (pre-hook) drop it; Module._apply (.cuda(), .to()) carries it over."""
+    m.stored_codes = True
+    m._mn_codes_key = (m.weight.data_ptr(), m.weight._version)
+
+
 @torch.no_grad()
 def prequantize_weights(model):
     """For every layer built with ``quant_inference=True``: store the fake-quantised weights (what ``quant_model_test.py:189-191`` does after loading)."""
@@ -29,7 +36,7 @@ def prequantize_weights(model):
             m.weight_quantizer.train(was)
             n += 1
             if type(m).__module__.endswith("wbwtab.quantize") and hasattr(m, "stored_codes") and getattr(m.weight_quantizer, "W", 0) in (2, 3):
-                m.stored_codes = True          # the stored weights ARE the quantizer's output t * alpha[o]: the layer keeps contracting integer codes
+                mark_stored_codes(m)           # the stored weights ARE the quantizer's output t * alpha[o]: the layer keeps contracting integer codes
             # DoReFa layers: record the "stored weights lie on the quantizer grid" verdict now (one host sync per layer, here instead of inside the first forward --
             # which may be a captured one)
             if type(m).__module__.endswith("dorefa.quantize") and m.weight.is_cuda and not torch.cuda.is_current_stream_capturing():
@@ -78,8 +85,8 @@ def wbwtab_model_bn_fuse(model, W=2, inplace=False):
             # integer weight codes on the matrix cores and (where prepare() had established conv -> bn -> sign in this order: ``lazy_for_bn``) hands its
             # un-computed result to the sign behind it, exactly like the training graph in eval mode: one byte per activation end to end.
             mag = w_f.detach().abs().flatten(1)
-            new.stored_codes = bool(((mag == 0) | (mag == mag.amax(1, keepdim=True))).all()) and W in (2, 3)
-            new.lazy_for_bn = bool(new.stored_codes and getattr(conv, "lazy_for_bn", False))
+            coded = bool(((mag == 0) | (mag == mag.amax(1, keepdim=True))).all()) and W in (2, 3)
+            new.lazy_for_bn = bool(coded and getattr(conv, "lazy_for_bn", False))
         else:
             new = _conv_like(conv, nn.Conv2d)
             from micronet_amd.nn import Conv2dFirst, Conv2dSignIn
@@ -87,6 +94,8 @@ def wbwtab_model_bn_fuse(model, W=2, inplace=False):
                 new.__class__ = type(conv)          # the fp32 first / last conv keep their gfx950 kernels (same parameters: only the forward differs)
         new = new.to(w.device)
         new.weight.data, new.bias.data = w_f, b_f
+        if 2 <= k <= bin_bn_fuse_num and coded:
+            mark_stored_codes(new)
         return new
 
     def walk(module):

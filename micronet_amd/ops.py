@@ -680,8 +680,14 @@ class ReluToken:
 
 def relu_premask_ok(x):
     """May the consumer of ``x`` (the output of a fused conv + ReLU) return its input gradient already masked by [x > 0]?  Only when nobody else can observe the
-    un-masked gradient of ``x``: no tensor hooks, no retain_grad."""
+    un-masked gradient of ``x``: no tensor hooks, no retain_grad.  NOT detectable: ``torch.autograd.grad(loss, x)`` on such an intermediate (saliency / Grad-CAM in train
+    mode) -- it would receive the masked gradient; MN_NO_RELU_PREMASK=1 switches the pre-masking off for such uses (tests/test_gpu_bnfuse_block.py)."""
+    if _NO_RELU_PREMASK:
+        return False
     return getattr(x, "_mn_relu_token", None) is not None and not getattr(x, "_backward_hooks", None) and not x.retains_grad
+
+
+_NO_RELU_PREMASK = _os0.environ.get("MN_NO_RELU_PREMASK", "0") == "1"
 
 
 def iao_bnfuse_pw_supported(x, weight, stride, padding, dilation, groups, in_shuffle):
@@ -808,14 +814,13 @@ class ReluOfFusedConv(Function):
     @staticmethod
     def forward(ctx, lazy):
         a = lazy._mn_a
-        ctx.a = a
-        ctx.tok = ReluToken()
+        ctx.save_for_backward(a)          # an OUTPUT saved through autograd (no reference cycle through a.grad_fn: ADVICE r4 -- `ctx.a = a` leaked x, a, qw of every fused block whose
+        ctx.tok = ReluToken()              # grad-enabled forward was never backpropagated)
         return a
 
     @staticmethod
     def backward(ctx, g):
-        a, tok = ctx.a, ctx.tok
-        ctx.a = None
+        (a,), tok = ctx.saved_tensors, ctx.tok
         return LazyReluGrad(g if type(g) is torch.Tensor else _chk(g, "grad"), a, tok.premasked(g))
 
 
@@ -1613,8 +1618,8 @@ class QConv2d(Function):
         stats = None
         if want_stats and aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and wdesc[4] is not None:
             rows = int(_lib_().mn_conv2d_iao_stats_rows(C.byref(g), C.byref(aq), C.byref(wd)))
-            if rows > 0:          # dense layer on the int8 matrix cores: exact sums of acc / acc^2 per channel from the epilogue, for the BatchNorm behind the conv
-                stats = torch.empty((rows, g.O, 2), dtype=torch.float64, device=x.device)
+            if rows > 0 and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:          # dense layer on the int8 matrix cores (16-byte aligned operands, as mn_conv2d_fwd asks):
+                stats = torch.empty((rows, g.O, 2), dtype=torch.float64, device=x.device)          # exact sums of acc / acc^2 per channel from the epilogue, for the BatchNorm behind the conv
                 aq.stats = stats.data_ptr()
         if packed is not None and packed[0] is not None:
             wd.packed_fwd = packed[0].data_ptr()
@@ -1629,6 +1634,8 @@ class QConv2d(Function):
             with _span(g, 0, 4 * (x.numel() + y.numel() + wq.numel())):
                 _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _ref(wd), _p(x), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
         wscale = wdesc[4] if wdesc is not None else None
+        if stats is not None and not _lib_().mn_last_kernel().decode().startswith("k_qd_fwd"):
+            stats = None          # the library took another kernel (workspace / alignment): nothing wrote the sums -- the BatchNorm computes its own statistics
         if stats is not None:          # (stats, rows, activation qparams, per-channel weight scale, its stride, conv bias): what mn_bn_fwd_acc reads
             _PENDING_ACCSTATS[0] = (stats, stats.shape[0], qp, wscale, int(wdesc[3]), bias)
         ctx.iao_codes = codes

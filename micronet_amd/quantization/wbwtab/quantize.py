@@ -187,6 +187,12 @@ class WeightQuantizer(nn.Module):
         return input
 
 
+def _forget_stored_codes(module, *args, **kwargs):
+    """load_state_dict pre-hook: newly loaded weights are not known to be codes x alpha[o] any more (micronet_amd.inference re-establishes the verdict when it checks them)"""
+    module.stored_codes = False
+    module.lazy_for_bn = module.lazy_for_bn and not module.quant_inference
+
+
 class QuantConv2d(nn.Conv2d):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  padding_mode="zeros", W=2, quant_inference=False):
@@ -197,11 +203,25 @@ class QuantConv2d(nn.Conv2d):
         self.lazy_for_bn = False       # True (set by prepare()): a packed BatchNorm2dBinAct consumes the output -> it may stay uncomputed
         self.stored_codes = False      # quant_inference only: the STORED weights are known to be codes x alpha[o] (set by micronet_amd.inference, which checks
                                        # them): the layer then contracts integer codes on the matrix cores like the training graph does
+        self._register_load_state_dict_pre_hook(_forget_stored_codes, with_module=True)          # (a module-level function: the module stays picklable)
+
+    def _codes_valid(self):
+        return bool(getattr(self, "stored_codes", False)) and getattr(self, "_mn_codes_key", None) == (self.weight.data_ptr(), self.weight._version)
+
+    def _apply(self, fn, *args, **kwargs):          # .cuda() / .to(): same values in a new tensor -- the verdict moves with them
+        was = self._codes_valid()
+        out = super()._apply(fn, *args, **kwargs)
+        if was:
+            self._mn_codes_key = (self.weight.data_ptr(), self.weight._version)
+        return out
 
     def forward(self, input):
         tnn_bin_weight = self.weight if self.quant_inference else self.weight_quantizer(self.weight)
         # binary / ternary weights are t * alpha[o]: the conv contracts the integer codes t on the bf16 matrix cores
-        coded = self.weight_quantizer.W in (2, 3) and ((not self.quant_inference) or getattr(self, "stored_codes", False))
+        # (stored_codes is a verdict about ONE weight tensor state: data pointer + version, recorded by micronet_amd.inference.mark_stored_codes; a later
+        #  `weight.data = ...` or in-place update silently invalidates it)
+        stored = self._codes_valid()
+        coded = self.weight_quantizer.W in (2, 3) and ((not self.quant_inference) or stored)
         return ops.qconv2d(input, tnn_bin_weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
                            wdesc=(ops.WQ_TERNARY, 0, 0, 0, None) if coded else None, in_shuffle=self.in_shuffle_groups,
                            lazy_for_bn=self.lazy_for_bn and coded)

@@ -530,3 +530,20 @@ def check_thin(be, N=3, Cc=128, O=10, HW=(4, 8), shuffle=0, bias=True, seed=0):
         worst["dx%d" % relu_in] = rel(be.to_host(dx), ref)
         assert worst["dx%d" % relu_in] <= 2e-6, worst
     return worst
+
+
+def check_gram_stats_variance_clamp(be, O=8, Cg=16, n=4096.0):
+    """the batch variance from Gram data, w^T (G - n xbar xbar^T) w / (n - 1), can cancel to a slightly NEGATIVE number for a near-constant channel with a
+    large mean; sqrt(var + eps) downstream would poison the running statistics and the folded weights with NaN for good.  Gram data of a constant input, rounded DOWN
+    in its last bits: the variance written must be exactly 0, never negative."""
+    c = 37.25
+    gram = np.full((1, Cg, Cg), n * c * c * (1.0 - 3e-16), dtype=np.float64)
+    sx = np.full(Cg, n * c, dtype=np.float64)
+    w = np.random.default_rng(5).standard_normal((O, Cg)).astype(np.float32)
+    d_gram, d_sx = be.to_dev(gram.view(np.float32).reshape(-1)), be.to_dev(sx.view(np.float32).reshape(-1))
+    stats, vc = be.empty(2 * O), be.empty((O, Cg))
+    be.call("mn_iaobf_gram_stats", be.ptr(be.to_dev(w)), None, be.ptr(d_gram), be.ptr(d_sx), O, Cg, 1, float(n), be.ptr(stats), be.ptr(vc), be.stream)
+    got = be.to_host(stats)
+    q_ref = np.einsum("oi,ij,oj->o", w.astype(np.float64), gram[0] - n * np.outer(sx / n, sx / n), w.astype(np.float64))
+    assert (q_ref < 0).any(), "the case no longer provokes a negative sum"
+    assert np.all(got[O:] >= 0.0) and np.all(np.isfinite(got)), got[O:]

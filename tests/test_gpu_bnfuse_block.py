@@ -219,3 +219,21 @@ def test_conv_module_called_directly_keeps_the_reference_contract():
     torch.autograd.backward([yp], [g.cuda()])
     assert _rel(xp.grad, xo.grad) <= 1e-5
     assert _rel(ours[0].conv.weight.grad, orc[0].conv.weight.grad) <= 1e-5
+
+
+def test_forward_without_backward_does_not_leak():
+    """a grad-enabled training-mode forward that is never backpropagated (a skipped step, an exception) must free x, a and qw of every fused block: the ReLU
+    node keeps its output through save_for_backward, not on ctx (that was a reference cycle only backward broke)."""
+    import gc
+    Q = _q()
+    net = Q.prepare(_chain(5), inplace=True, a_bits=8, w_bits=8, q_type=0, q_level=0, weight_observer=0, bn_fuse=True).cuda().train()
+    x = torch.randn(16, 32, 16, 16, device="cuda")
+    for _ in range(3):
+        net(x)
+    gc.collect()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    for _ in range(10):
+        net(x)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() <= base + (1 << 20), (torch.cuda.memory_allocated(), base)          # no gc.collect(): nothing may depend on the cycle collector

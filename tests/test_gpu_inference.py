@@ -324,3 +324,32 @@ def test_iao_bn_fused_graph_vs_reference_golden():
             d = (got - ref).abs() / ref.abs().max().clamp_min(1e-30)
             assert float((d > 1e-5).float().mean()) <= 1e-4 and float(d.max()) <= 2e-2, (i, float(d.max()), float((d > 1e-5).float().mean()))
             t = ref
+
+
+def test_stored_codes_verdict_follows_the_weight_tensor():
+    """`stored_codes` (the deployed wbwtab layer contracts integer codes) is a verdict about ONE state of the weight tensor.  Module moves keep it; new
+    weights (`weight.data = ...`, load_state_dict) drop it, and the layer then convolves what is stored -- like the reference's quant_inference branch
+    (wbwtab/quantize.py:181-185)."""
+    from micronet_amd import inference
+    Q = importlib.import_module("micronet.compression.quantization.wbwtab.quantize")
+    torch.manual_seed(3)
+    m = Q.QuantConv2d(16, 32, 1, W=3, quant_inference=True)
+    inference.prequantize_weights(torch.nn.Sequential(m))
+    assert m._codes_valid()
+    m = m.cuda()
+    assert m._codes_valid()                                     # Module._apply carried the verdict to the new tensor
+    x = torch.sign(torch.randn(2, 16, 8, 8, device="cuda"))
+    x[x == 0] = 1
+    y0 = m(x)
+    ref0 = torch.nn.functional.conv2d(x.cpu(), m.weight.detach().cpu(), m.bias.detach().cpu())
+    assert float((y0.cpu() - ref0).abs().max()) <= 1e-5 * float(ref0.abs().max())
+    w_new = torch.randn_like(m.weight)                          # NOT codes x alpha
+    m.weight.data = w_new
+    assert not m._codes_valid()
+    y1 = m(x)
+    ref1 = torch.nn.functional.conv2d(x.cpu(), w_new.cpu(), m.bias.detach().cpu())
+    assert float((y1.cpu() - ref1).abs().max()) <= 1e-5 * float(ref1.abs().max())
+    inference.mark_stored_codes(m)                              # (a wrong verdict would now decode sign x max|w| ...)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)                                       # ... and load_state_dict drops it again
+    assert not m.stored_codes

@@ -752,3 +752,8 @@ def test_iaobf_thin_output_family(be, shuffle, bias):
     import iaobf_cases as B
     B.check_thin(be, shuffle=shuffle, bias=bias, seed=shuffle)
     B.check_thin(be, N=64, Cc=1024, O=10, HW=(8, 8), shuffle=shuffle, bias=bias, seed=5 + shuffle)
+
+
+def test_iaobf_gram_statistics_never_negative_variance(be):
+    import iaobf_cases as B
+    B.check_gram_stats_variance_clamp(be)

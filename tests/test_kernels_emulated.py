@@ -538,3 +538,8 @@ def test_iaobf_thin_output_family(be, shuffle, bias):
     """csrc/iao_thin.hip: raw / quantised pointwise conv with <= 16 outputs, both backward-weights, the two-path backward-data against fp64"""
     import iaobf_cases as B
     B.check_thin(be, shuffle=shuffle, bias=bias, seed=shuffle)
+
+
+def test_iaobf_gram_statistics_never_negative_variance(be):
+    import iaobf_cases as B
+    B.check_gram_stats_variance_clamp(be)
