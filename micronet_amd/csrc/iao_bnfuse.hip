@@ -698,6 +698,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    uint32_t rbits[(4 * NT + 7) / 8] = {};          // [x > 0] of the chunk's own (channel, pixel) elements, written by the phase-A epilogue
     // step `it` = (chunk it / KST, step s): s < KSA streams d out (phase A), else x (phase B); unconditional loads from clamped offsets
     auto issue = [&](float4 (&raw)[8], int ci, int s) {
         uint32_t P = (uint32_t)(chunk0 + ci * cstride) * 64u + 4u * j;
@@ -793,19 +794,24 @@ __global__ __launch_bounds__(256, 2) void k_bf_dgrad(const BfDgParams p) {
                     for (int r = 0; r < 4; ++r) {
                         const int ml = t * 16 + kg * 4 + r;
                         if (mblk * MB + ml < p.Cg) {
-                            const float4 xv = *reinterpret_cast<const float4*>(p.x + (ob + ooff[ml]));
-                            if (!last || p.KSB == 0) {
+                            const bool ste = !last || p.KSB == 0;          // the clip-STE epilogue (end of phase A) is the ONE place that reads x of the own channels:
+                            const int bsh = ((t * 4 + r) & 7) * 4;         // the ReLU mask of the final epilogue is kept as 4 bits per (channel, pixel quad) meanwhile
+                            uint32_t rb = (rbits[(t * 4 + r) >> 3] >> bsh) & 15u;          // (round 4 read x a second time there: 4 of the 20 bytes per element the kernel moved;
+                            if (ste) {                                                      //  PMC 830 -> 722 MB per launch, 247 -> 200 us)
+                                const float4 xv = *reinterpret_cast<const float4*>(p.x + (ob + ooff[ml]));
                                 // ((g s) / s) as the chain rule of 227-239 writes it -- one IEEE division -- masked by the interval test
                                 acc[0][t][r] = (xv.x >= XL && xv.x <= XH) ? (acc[0][t][r] * ssc) / ssc : 0.f;
                                 acc[1][t][r] = (xv.y >= XL && xv.y <= XH) ? (acc[1][t][r] * ssc) / ssc : 0.f;
                                 acc[2][t][r] = (xv.z >= XL && xv.z <= XH) ? (acc[2][t][r] * ssc) / ssc : 0.f;
                                 acc[3][t][r] = (xv.w >= XL && xv.w <= XH) ? (acc[3][t][r] * ssc) / ssc : 0.f;
+                                rb = (xv.x > 0.f ? 1u : 0u) | (xv.y > 0.f ? 2u : 0u) | (xv.z > 0.f ? 4u : 0u) | (xv.w > 0.f ? 8u : 0u);
+                                rbits[(t * 4 + r) >> 3] = (rbits[(t * 4 + r) >> 3] & ~(15u << bsh)) | (rb << bsh);
                             }
                             if (last) {
                                 const float c_ = va[ml];
                                 float o0 = acc[0][t][r] + c_, o1 = acc[1][t][r] + c_, o2 = acc[2][t][r] + c_, o3 = acc[3][t][r] + c_;
                                 if (p.relu_mask) {
-                                    o0 = xv.x > 0.f ? o0 : 0.f; o1 = xv.y > 0.f ? o1 : 0.f; o2 = xv.z > 0.f ? o2 : 0.f; o3 = xv.w > 0.f ? o3 : 0.f;
+                                    o0 = (rb & 1u) ? o0 : 0.f; o1 = (rb & 2u) ? o1 : 0.f; o2 = (rb & 4u) ? o2 : 0.f; o3 = (rb & 8u) ? o3 : 0.f;
                                 }
                                 *reinterpret_cast<float4*>(p.dx + (ob + ooff[ml])) = make_float4(o0, o1, o2, o3);
                             }
@@ -998,7 +1004,7 @@ extern "C" int mn_iaobf_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const
     p.gy = gy; p.x = x; p.dx = dx; p.wc = m.wc; p.kscale = m.kscale; p.mt = m.mt; p.xbar = m.xbar; p.vadd = m.vadd; p.qp = aq->qp; p.qmin = r.qmin; p.qmax = r.qmax;
     p.relu_mask = relu_mask;
     mn_set_last_kernel("k_bf_dgrad<%d>", pl.NT);
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + 8.0 * nx); }
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + 12.0 * nx); }          // d out once, x twice (operand of the raw path + the clip-STE mask of the own channels), dx once
     mn_prof_begin(s);
     raise_lds_limit(pl.NT == 4 ? (const void*)k_bf_dgrad<4> : (pl.NT == 2 ? (const void*)k_bf_dgrad<2> : (const void*)k_bf_dgrad<1>), pl.lds);
     if (pl.NT == 4) hipLaunchKernelGGL(k_bf_dgrad<4>, dim3(pl.grid), dim3(256), pl.lds, s, p);

@@ -333,11 +333,13 @@ def test_stored_codes_verdict_follows_the_weight_tensor():
     from micronet_amd import inference
     Q = importlib.import_module("micronet.compression.quantization.wbwtab.quantize")
     torch.manual_seed(3)
-    m = Q.QuantConv2d(16, 32, 1, W=3, quant_inference=True)
+    m = Q.QuantConv2d(16, 32, 1, W=3, quant_inference=True).cuda()
     inference.prequantize_weights(torch.nn.Sequential(m))
     assert m._codes_valid()
+    m = m.cpu()
+    assert m._codes_valid()                                     # Module._apply carries the verdict to the new tensor (same values)
     m = m.cuda()
-    assert m._codes_valid()                                     # Module._apply carried the verdict to the new tensor
+    assert m._codes_valid()
     x = torch.sign(torch.randn(2, 16, 8, 8, device="cuda"))
     x[x == 0] = 1
     y0 = m(x)

@@ -158,7 +158,7 @@ def _convt_golden():
 def test_conv_transpose_modules_vs_reference_golden(idx):
     """QuantConvTranspose2d of ALL THREE schemes (dorefa 126-174, wbwtab 198-244, iao 510-636) on the GPU against vectors produced by the reference's own classes
     (tests/golden/make_golden.py --convt-only): outputs / gradients <= 1e-5 of max|ref|, IAO observer ranges and scales bit-exact, the W = 2 in-place weight update
-    bit-exact."""
+    to the last place of the Cin mean."""
     m, meta = _convt_golden()
     c = meta["cases"][idx]
     cin, cout, k, st, pd, op, H, W, Nb = c["shape"]
@@ -186,7 +186,10 @@ def test_conv_transpose_modules_vs_reference_golden(idx):
             assert sd[name].shape == m[f"{base}_buf_{name}"].shape, name
             assert np.array_equal(sd[name], m[f"{base}_buf_{name}"]), name
     if c["scheme"] == "wbwtab" and c["kw"]["W"] == 2:
-        assert np.array_equal(mod.weight.detach().cpu().numpy(), m[base + "_par_weight"])
+        # the in-place mean-centre / clamp of the Parameter (wbwtab/quantize.py:98-102): the kernel sums the Cin axis in fp64 and rounds once, ATen adds fp32 partials --
+        # the mean, and with it every stored weight, may differ in the last place
+        got, ref = mod.weight.detach().cpu().numpy(), m[base + "_par_weight"]
+        assert np.max(np.abs(got - ref)) <= 2.0 ** -22 * max(1.0, float(np.max(np.abs(ref))))
 
 
 @pytest.mark.parametrize("scheme,cfg,okw", [
