@@ -493,16 +493,6 @@ int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, void* const* o
 int64_t mn_qg_packed_bytes(const mn_conv_geom* g, int which);
 int mn_qg_pack_multi(int32_t count, const mn_conv_geom* const* g, const mn_wq* const* wq, const float* const* w, const int32_t* which, void* const* out,
                      mn_stream_t stream);
-/* Backward-weight of a dense layer with the reduction of its split-K partial tiles DEFERRED.  autograd's conv2d backward hands d(quantised weight) to the weight
- * quantizer's backward (wqaq/dorefa/quantize.py:61-73, wqaq/iao/quantize.py:214-240 through torch.autograd), and in a training step nothing else reads it -- so
- * every dense conv of the step leaves its partial tiles in ITS OWN workspace (mn_qd_bwd_weight_partials: aq->mode MN_ACTQ_CODE8 with x = activation codes, or
- * MN_ACTQ_IAO with x = the fp32 activation; no bias gradient; ws of mn_qd_wgrad_partials_ws_bytes bytes, kept untouched until the reduction) and ONE launch sums
- * all of them (mn_qd_wgrad_reduce_multi: the same fixed-order fp64 sums as mn_conv2d_bwd_weight's own reduction, bit-identical dw).  19 launches less per
- * resnet18 step -- but measured 1 % SLOWER there (the deferred launch reads the partial tiles back from HBM instead of L2): the host side uses it on request only. */
-int mn_qd_wgrad_partials_supported(const mn_conv_geom* g, const mn_actq* aq);
-int64_t mn_qd_wgrad_partials_ws_bytes(const mn_conv_geom* g, const mn_actq* aq);
-int mn_qd_bwd_weight_partials(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const void* x, void* ws, int64_t ws_bytes, mn_stream_t stream);
-int mn_qd_wgrad_reduce_multi(int32_t count, const mn_conv_geom* const* g, const mn_actq* const* aq, void* const* ws, float* const* dw, mn_stream_t stream);
 /* width of the stash mn_qconv_bnq_fwd_stash writes for this layer: 16, or 32 when K * (2^a - 1) * (2^w - 1) exceeds 32767 -- a DENSE layer (groups == 1, C and O
  * multiples of 64: the 3 x 3 stride 1 / 2 and 1 x 1 stride 2 convolutions of the reference's ResNets, models/resnet.py:7-65) or a grouped / pointwise layer of
  * nin_gc at more than 4 bits (W8A8, the reference's CPU configuration: wqaq/dorefa/main.py:135,189-190), and for every layer read through 8-bit activation codes;

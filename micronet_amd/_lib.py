@@ -155,10 +155,6 @@ PROTOTYPES = {
     "mn_qd_pack_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "mn_qg_packed_bytes": (_L, [_G, _I]),
     "mn_qg_pack_multi": (_I, [_I, _P, _P, _P, _P, _P, _P]),
-    "mn_qd_wgrad_partials_supported": (_I, [_G, _A]),
-    "mn_qd_wgrad_partials_ws_bytes": (_L, [_G, _A]),
-    "mn_qd_bwd_weight_partials": (_I, [_G, _A, _P, _P, _P, _L, _P]),
-    "mn_qd_wgrad_reduce_multi": (_I, [_I, _P, _P, _P, _P, _P]),
     "mn_qr_ws_floats": (_L, [_L]),
     "mn_qr_fwd": (_I, [_I, _P, _P, _I, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
     "mn_qr_bwd_sums": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -1597,26 +1597,6 @@ __global__ __launch_bounds__(256) void k_qd_wgrad_reduce(const float* __restrict
     __shared__ double red[16][64];
     qd_wgrad_reduce_block(part, dw, O, C, T, Z, scale_p ? scale_p[0] : scale_c, blockIdx.x, red);          // IAO: the activation scale lives on the device
 }
-// The reductions of SEVERAL layers in one launch (mn_qd_wgrad_reduce_multi): every dense backward-weight of a training step leaves its partial tiles in its
-// workspace, and nothing reads d(quantised weight) before the weight quantizers' backward -- one multi-tensor launch at the end of the backward pass -- so the
-// 19 latency-bound 9 us reductions of a ResNet step (a few hundred blocks each) become one launch that fills the chip.  Same arithmetic per layer: bit-identical.
-#define QD_RED_MAX 32
-struct QdRedTable {
-    const float* part[QD_RED_MAX];
-    float* dw[QD_RED_MAX];
-    const float* scale_p[QD_RED_MAX];
-    float scale_c[QD_RED_MAX];
-    int O[QD_RED_MAX], C[QD_RED_MAX], T[QD_RED_MAX], Z[QD_RED_MAX];
-    uint32_t blk0[QD_RED_MAX + 1];          // first block of entry e; blk0[count] = the grid
-    int count;
-};
-__global__ __launch_bounds__(256) void k_qd_wgrad_reduce_multi(const QdRedTable t) {
-    __shared__ double red[16][64];
-    int e = 0;
-    while (e + 1 < t.count && blockIdx.x >= t.blk0[e + 1]) ++e;          // (block-uniform: at most 31 scalar compares)
-    qd_wgrad_reduce_block(t.part[e], t.dw[e], t.O[e], t.C[e], t.T[e], t.Z[e], t.scale_p[e] ? t.scale_p[e][0] : t.scale_c[e], blockIdx.x - t.blk0[e], red);
-}
-
 struct QdwPlan { QdwParams p; int S, T, grid; size_t lds; int64_t ws_bytes; };
 static int plan_qdw(const mn_conv_geom* g, QdwPlan* pl) {
     if (!qd_geom_ok(g)) return 0;
@@ -1676,7 +1656,7 @@ int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, floa
 int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, int xsgn, float ascale, const float* ascale_dev, float* dw, void* ws, int64_t ws_bytes,
                      hipStream_t s) {
     QdwPlan pl;
-    if (!plan_qdw(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(dense): geometry not covered");          // (dw == nullptr: leave the partial tiles in ws, mn_qd_wgrad_reduce_multi sums them)
+    if (!plan_qdw(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(dense): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense): workspace too small");
     QdwParams& p = pl.p;
     p.gy = gy; p.x = x; p.part = reinterpret_cast<float*>(ws); p.xsgn = xsgn;
@@ -1691,7 +1671,7 @@ int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, i
 #undef QDW_LAUNCH
     mn_prof_end(s);
     const int total = p.npairs * pl.T * 4096;
-    if (dw) hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(256), 0, s, (const float*)p.part, dw, (int)g->O, (int)g->C, pl.T, p.Z, ascale, ascale_dev);
+    hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(256), 0, s, (const float*)p.part, dw, (int)g->O, (int)g->C, pl.T, p.Z, ascale, ascale_dev);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(dense)");
     return MN_OK;
 }
@@ -1841,66 +1821,6 @@ int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy,
     if (dbias) hipLaunchKernelGGL(k_qd_bias_grad, dim3((unsigned)g->O), dim3(256), 0, s, gy, dbias, (int)g->N, (int)g->O, pl.p.HWg);
     return qd_bwd_weight_ex(g, gy, (const uint8_t*)cbuf, 1, 1.f, aq->qp, dw, (char*)ws + cb, ws_bytes - cb, s);
 }
-
-// ---- backward-weight of a dense layer with the reduction of its split-K partial tiles DEFERRED (see k_qd_wgrad_reduce_multi)
-static int qd_partials_kind(const mn_conv_geom* g, const mn_actq* aq) {          // 1: DoReFa activation codes (MN_ACTQ_CODE8), 2: IAO (fp32 x + device qparams), 0: not covered
-    if (!g || !aq) return 0;
-    if (aq->mode == MN_ACTQ_CODE8 && qd_wgrad_supported(g, aq->bits)) return 1;
-    if (aq->mode == MN_ACTQ_IAO && qd_iao_supported(g, aq, nullptr, 2)) return 2;
-    return 0;
-}
-extern "C" int mn_qd_wgrad_partials_supported(const mn_conv_geom* g, const mn_actq* aq) { return qd_partials_kind(g, aq) != 0; }
-extern "C" int64_t mn_qd_wgrad_partials_ws_bytes(const mn_conv_geom* g, const mn_actq* aq) {
-    const int kind = qd_partials_kind(g, aq);
-    return kind == 1 ? qd_wgrad_ws_bytes(g) : (kind == 2 ? qd_iao_ws_bytes(g, 2) : 0);
-}
-extern "C" int mn_qd_bwd_weight_partials(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const void* x, void* ws, int64_t ws_bytes, mn_stream_t stream) {
-    const int kind = qd_partials_kind(g, aq);
-    if (!kind || !gy || !x) MN_FAIL(MN_ENOTSUP, "mn_qd_bwd_weight_partials: not a dense layer on activation codes / IAO quantizers");
-    hipStream_t s = (hipStream_t)stream;
-    if (kind == 1) return qd_bwd_weight_ex(g, gy, (const uint8_t*)x, 0, dorefa_scale(aq->bits), nullptr, nullptr, ws, ws_bytes, s);
-    QdwPlan pl;
-    if (!plan_qdw(g, &pl) || !aligned16(x)) MN_FAIL(MN_ENOTSUP, "mn_qd_bwd_weight_partials(iao): geometry not covered");
-    const int64_t cb = qd_iao_codes_bytes(g);
-    if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_qd_bwd_weight_partials(iao): workspace too small");
-    const void* cbuf = aq->codes ? aq->codes : ws;
-    if (!aq->codes) qd_iao_launch_codes(g, aq, (const float*)x, ws, s);
-    return qd_bwd_weight_ex(g, gy, (const uint8_t*)cbuf, 1, 1.f, aq->qp, nullptr, (char*)ws + cb, ws_bytes - cb, s);
-}
-extern "C" int mn_qd_wgrad_reduce_multi(int32_t count, const mn_conv_geom* const* g, const mn_actq* const* aq, void* const* ws, float* const* dw, mn_stream_t stream) {
-    if (count <= 0) return MN_OK;
-    if (!g || !aq || !ws || !dw) MN_FAIL(MN_EINVAL, "mn_qd_wgrad_reduce_multi: null table");
-    hipStream_t s = (hipStream_t)stream;
-    for (int base = 0; base < count; base += QD_RED_MAX) {
-        QdRedTable t;
-        const int n = count - base < QD_RED_MAX ? count - base : QD_RED_MAX;
-        uint32_t blk = 0;
-        for (int i = 0; i < n; ++i) {
-            const mn_conv_geom* gi = g[base + i];
-            const mn_actq* ai = aq[base + i];
-            const int kind = qd_partials_kind(gi, ai);
-            QdwPlan pl;
-            if (!kind || !plan_qdw(gi, &pl) || !ws[base + i] || !dw[base + i]) MN_FAIL(MN_EINVAL, "mn_qd_wgrad_reduce_multi: entry %d is not a deferred dense backward-weight", base + i);
-            t.part[i] = reinterpret_cast<const float*>((const char*)ws[base + i] + (kind == 2 ? qd_iao_codes_bytes(gi) : 0));
-            t.dw[i] = dw[base + i];
-            t.scale_p[i] = kind == 2 ? ai->qp : nullptr;
-            t.scale_c[i] = kind == 1 ? dorefa_scale(ai->bits) : 1.f;
-            t.O[i] = (int)gi->O; t.C[i] = (int)gi->C; t.T[i] = pl.T; t.Z[i] = pl.p.Z;
-            t.blk0[i] = blk;
-            blk += (uint32_t)(pl.p.npairs * pl.T * 4096 / 64);
-        }
-        t.blk0[n] = blk;
-        for (int i = n + 1; i <= QD_RED_MAX; ++i) t.blk0[i] = blk;
-        t.count = n;
-        mn_set_last_kernel("k_qd_wgrad_reduce_multi");
-        mn_prof_begin(s);
-        hipLaunchKernelGGL(k_qd_wgrad_reduce_multi, dim3(blk), dim3(256), 0, s, t);
-        mn_prof_end(s);
-    }
-    MN_CHECK_LAUNCH("mn_qd_wgrad_reduce_multi");
-    return MN_OK;
-}
-
 
 // ================================================================================================ weight codes of a whole net in one launch
 extern "C" int64_t mn_qd_packed_bytes(const mn_conv_geom* g) {

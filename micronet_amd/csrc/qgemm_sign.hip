@@ -1404,7 +1404,6 @@ static int plan_pws(const mn_conv_geom* g, int nt_max, PwsPlan* pl) {
     if (KS < 1 || KS > 4) return 0;                       // up to 128 input channels per group
     pl->KS = KS;
     int NT = nt_max;
-    if (const char* e = MN_ENV("MN_PWS_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) NT = v < nt_max ? v : nt_max; }   // tuning knob
     while (NT > 1 && 16 * (NT / 2) >= Mg) NT /= 2;
     pl->NT = NT;
     const int MB = 16 * NT;
@@ -1414,9 +1413,8 @@ static int plan_pws(const mn_conv_geom* g, int nt_max, PwsPlan* pl) {
     p.Mpad = ((Mg + 127) / 128) * 128;                    // one packed-code layout for every tile height
     p.nchunks = (int)((p.NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
-    int capb = 512;           // one round of 2 blocks per CU: every block stages its weights and ends in a block reduction -- fewer, longer blocks
+    const int capb = 512;           // one round of 2 blocks per CU: every block stages its weights and ends in a block reduction -- fewer, longer blocks
                               // (measured against 1024: STATS 41 -> 33 us on L2, 32 -> 23 on L5, 26 -> 18 on L8; SIGN8 44 -> 38, 32 -> 24, 19 -> 16)
-    if (const char* e = MN_ENV("MN_PWS_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 2048) capb = v; }   // tuning knob
     const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
     p.CB = CB;

@@ -62,62 +62,7 @@ def _span(g, which, nbytes):
     return _Span(tok) if tok is not None else _NOSPAN
 
 
-# Deferred reduction of the dense backward-weight partial tiles (mn_qd_bwd_weight_partials / mn_qd_wgrad_reduce_multi).  A conv whose quantised weight came out of
-# a multi-tensor weight-quantizer node (micronet_amd.train.prefetch_weight_path tags it ``_mn_defer_wgrad``) has exactly one reader of its d(quantised weight): that
-# node's backward, ONE launch at the end of the backward pass.  So the conv's backward leaves its split-K partial tiles in a workspace, returns the (not yet
-# written) dw tensor to autograd, and the node's backward first sums the partial tiles of ALL layers in one launch (bit-identical to the per-layer reductions).
-# Thread-local (one list per replica thread).  MEASURED (round 4, same box, c4 / c5 at batch 256): OFF is faster -- 4.183 vs 4.234 ms (c4), 5.312 vs 5.362 ms (c5).
-# The 19 per-layer reductions read partial tiles their own backward-weight kernel has just written (L2 / MALL hits); deferred, the ~300 MB of partial tiles of a
-# step are evicted before the one launch reads them back from HBM, which costs more than the 18 launches it saves.  So the path is OPT-IN (MN_DEFER_WGRAD=1): kept
-# for models whose reductions are many and small.
 import os as _os0
-DEFER_WGRAD = _os0.environ.get("MN_DEFER_WGRAD", "0") == "1"
-
-
-class _WgradPending(threading.local):
-    def __init__(self):
-        self.items = []
-
-
-_WGRAD_PENDING = _WgradPending()
-
-
-def clear_wgrad_partials():
-    _WGRAD_PENDING.items.clear()
-
-
-def _defer_wgrad(g, aq, gy, x, dw, keep=()):
-    """Launch the backward-weight main kernel only; True when the layer is covered (the reduction is then pending: ``flush_wgrad_partials``)."""
-    if not DEFER_WGRAD or CONV_ALGO != _lib.MN_ALGO_AUTO:
-        return False
-    lib = _lib_()
-    if not lib.mn_qd_wgrad_partials_supported(C.byref(g), C.byref(aq)):
-        return False
-    nb = int(lib.mn_qd_wgrad_partials_ws_bytes(C.byref(g), C.byref(aq)))
-    ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=gy.device)
-    with _span(g, 2, 4 * gy.numel() + x.numel() * x.element_size()):
-        _call("mn_qd_bwd_weight_partials", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(ws), nb, _s())
-    _WGRAD_PENDING.items.append((g, aq, ws, dw, keep))
-    return True
-
-
-def flush_wgrad_partials():
-    """Sum the pending partial tiles of every deferred dense backward-weight into their dw tensors: one launch per device (called by the multi-tensor weight
-    quantizers' backward before they read d(quantised weight); harmless when nothing is pending)."""
-    items = _WGRAD_PENDING.items
-    if not items:
-        return
-    by_dev = {}
-    for it in items:
-        by_dev.setdefault(it[3].device, []).append(it)
-    for dev, its in by_dev.items():
-        n = len(its)
-        GP, AP, PA = C.POINTER(ConvGeom) * n, C.POINTER(ActQ) * n, C.c_void_p * n
-        with torch.cuda.device(dev):
-            with _span(None, 3, sum(4 * it[3].numel() for it in its)):
-                _call("mn_qd_wgrad_reduce_multi", n, GP(*[C.pointer(it[0]) for it in its]), AP(*[C.pointer(it[1]) for it in its]),
-                      PA(*[it[2].data_ptr() for it in its]), PA(*[it[3].data_ptr() for it in its]), _s())
-    items.clear()
 
 
 # Stock-operator fall-throughs.  A few modules of this package hand geometries their gfx950 kernels do not cover to the stock torch operator (MIOpen / ATen) --
@@ -269,7 +214,6 @@ class MultiDorefaWeight(Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        flush_wgrad_partials()          # the dense convs of the step left their backward-weight partial tiles: one reduction launch fills every gs[i]
         n, bits = ctx.n, ctx.bits
         ws, scratch, th = ctx.saved_tensors[:n], ctx.saved_tensors[n:2 * n], ctx.saved_tensors[2 * n:]
         idx = [i for i in range(n) if gs[i] is not None]
@@ -459,7 +403,6 @@ class MultiIaoWeight(Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        flush_wgrad_partials()          # (see MultiDorefaWeight.backward)
         ws = ctx.saved_tensors
         bits, q_type, rows, cols = ctx.cfg
         idx = [i for i in range(len(ws)) if gs[i] is not None]
@@ -1614,7 +1557,6 @@ class QConv2d(Function):
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         wd = _wq_desc(wdesc)
         ctx.packed = packed = getattr(wq, "_mn_packed", None) if wd is not None else None
-        ctx.defer_wgrad = bool(getattr(wq, "_mn_defer_wgrad", False))
         stats = None
         if want_stats and aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and wdesc[4] is not None:
             rows = int(_lib_().mn_conv2d_iao_stats_rows(C.byref(g), C.byref(aq), C.byref(wd)))
@@ -1715,9 +1657,6 @@ class QConv2d(Function):
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(wq)
                 db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
-                if getattr(ctx, "defer_wgrad", False) and not has_bias and aq_mode == ACTQ_IAO and \
-                        _defer_wgrad(g, aq, gy, x, dw, keep=(qp, getattr(ctx, "iao_codes", None))):
-                    return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
                 ws, nb = _ws(g, 2, x.device)
                 with _span(g, 2, 4 * (gy.numel() + x.numel() + dw.numel())):
                     _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
@@ -1944,7 +1883,7 @@ def pack_pointwise_weights(mods_wq, wdesc):
         _call("mn_qg_pack_multi", n, GP(*[C.pointer(g) for g in gs]), WP(*[C.pointer(w) for w in wds]), PA(*wps), IA(*whs), PA(*outs), _s())
 
 
-def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw, packed=None, defer=False):
+def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw, packed=None):
     """(dq, dw) of a conv on activation codes: mn_conv2d_bwd_data without clip-STE, mn_conv2d_bwd_weight on the codes."""
     gy = _chk(gy, "grad")
     aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
@@ -1957,10 +1896,9 @@ def _code_conv_backward(g, a_bits, w_bits, codes, wq, gy, need_dx, need_dw, pack
             _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wd), _p(gy), _p(wq), None, _p(dq), _p(ws), nb, CONV_ALGO, _s())
     if need_dw:
         dw = torch.empty_like(wq)
-        if not (defer and _defer_wgrad(g, aq, gy, codes, dw)):
-            ws, nb = _ws(g, 2, codes.device)
-            with _span(g, 2, 4 * gy.numel() + codes.numel() + 4 * dw.numel()):
-                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), None, _p(ws), nb, CONV_ALGO, _s())
+        ws, nb = _ws(g, 2, codes.device)
+        with _span(g, 2, 4 * gy.numel() + codes.numel() + 4 * dw.numel()):
+            _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), None, _p(ws), nb, CONV_ALGO, _s())
     return dq, dw
 
 
@@ -1979,7 +1917,6 @@ class QConvCodeLazy(Function):
         ctx.cfg = (g, a_bits, w_bits, bias is not None)
         ctx.x_ref = x
         ctx.packed = packed = getattr(wq, "_mn_packed", None)
-        ctx.defer_wgrad = bool(getattr(wq, "_mn_defer_wgrad", False))
 
         def compute():          # a foreign consumer: the ordinary conv kernels on the materialised activation, quantizer in their prologue
             xa = x.materialize()
@@ -2012,9 +1949,8 @@ class QConvCodeLazy(Function):
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(wq)
                 db = torch.empty(g.O, dtype=torch.float32, device=codes.device) if has_bias else None
-                if not (getattr(ctx, "defer_wgrad", False) and not has_bias and _defer_wgrad(g, aq, gy, codes, dw)):
-                    ws, nb = _ws(g, 2, codes.device)
-                    _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
+                ws, nb = _ws(g, 2, codes.device)
+                _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(codes), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
         ctx.x_ref = None
         return dx, dw, db, None, None, None, None, None, None
 
@@ -2030,7 +1966,6 @@ class QConvCodeLazy2(Function):
         wq1, wq2 = _chk(wq1, "weight"), _chk(wq2, "weight")
         outs, geoms = [], []
         ctx.packed = (getattr(wq1, "_mn_packed", None), getattr(wq2, "_mn_packed", None))
-        ctx.defer_wgrad = (bool(getattr(wq1, "_mn_defer_wgrad", False)), bool(getattr(wq2, "_mn_defer_wgrad", False)))
         for wq, (stride, padding, dilation, groups) in ((wq1, cfg1), (wq2, cfg2)):
             g = _geom(codes.shape, wq.shape, stride, padding, dilation, groups, 0)
             Ho, Wo = _out_hw(g)
@@ -2052,8 +1987,8 @@ class QConvCodeLazy2(Function):
         geoms, a_bits, w_bits = ctx.cfg
         x = ctx.x_ref
         with torch.cuda.device_of(codes):
-            dq1, dw1 = _code_conv_backward(geoms[0], a_bits, w_bits, codes, wq1, gy1, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.packed[0], ctx.defer_wgrad[0])
-            dq2, dw2 = _code_conv_backward(geoms[1], a_bits, w_bits, codes, wq2, gy2, ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.packed[1], ctx.defer_wgrad[1])
+            dq1, dw1 = _code_conv_backward(geoms[0], a_bits, w_bits, codes, wq1, gy1, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.packed[0])
+            dq2, dw2 = _code_conv_backward(geoms[1], a_bits, w_bits, codes, wq2, gy2, ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.packed[1])
         dx = None
         if ctx.needs_input_grad[0]:
             def expand(dq_, dq2_=dq2):

@@ -79,12 +79,10 @@ def bump_bn_counters(model):
             m.__dict__["_mn_nbt_pre"] = True
 
 
-def prefetch_weight_path(model, side=None):
+def prefetch_weight_path(model):
     """Quantize the weights of every W-ternary conv of ``model`` NOW, in one launch (ops.MultiTernaryWeight: one autograd node, so the
     backward is one launch too); the owning conv picks its tensor up in its forward.  A step of nin_gc saves 12 launches of ~5 us.
-    ``side``: a second stream instead (one launch per layer there, overlapping the first layers; measured slower under graph replay --
-    the fork / join edges cost more than the launches they hide); join with ``torch.cuda.current_stream().wait_stream(side)`` after
-    ``backward()``.
+    (A second stream for this path was measured slower under graph replay -- the fork / join edges cost more than the launches they hide -- and is gone.)
 
     CONTRACT for IAO nets: the prefetch performs the weight OBSERVER's step of this iteration (EMA of the per-channel range, ``num_flag``, scale / zero-point) for
     every module it covers -- the reference performs it inside the module's forward (iao/quantize.py:214-221).  Each call must therefore be followed by exactly
@@ -92,88 +90,73 @@ def prefetch_weight_path(model, side=None):
     from micronet_amd import ops
     from micronet_amd.quantization.wbwtab import quantize as wb
     from micronet_amd.quantization.wqaq.dorefa import quantize as dr
-    ops.clear_wgrad_partials()          # (deferred backward-weight reductions of an aborted previous step)
-    if side is None:
-        # DoReFa nets: every conv / linear weight quantizer of one bit-width in one MultiDorefaWeight node (2 launches forward, 3 backward per step)
-        by_bits = {}
-        for m in model.modules():
-            if isinstance(m, (dr.QuantConv2d, dr.QuantLinear)) and not m.quant_inference and 2 <= m.weight_quantizer.w_bits <= 31 and m.weight.is_cuda \
-                    and m.weight.is_contiguous():
-                m.weight_quantizer.__dict__.pop("_mn_pre", None)
-                by_bits.setdefault(m.weight_quantizer.w_bits, []).append(m)
-        for bits, ms in by_bits.items():
-            for i in range(0, len(ms), 32):
-                grp = ms[i:i + 32]
-                if len(grp) < 2:
-                    continue
-                qws = ops.MultiDorefaWeight.apply(bits, *[m.weight for m in grp])
-                for m, wq in zip(grp, qws):
-                    m.weight_quantizer._mn_pre = (m.weight, wq, None)
-                    wq._mn_defer_wgrad = True          # d(wq) has ONE reader, this node's backward: the dense convs defer their partial-tile reduction to it (ops.flush_wgrad_partials)
-                if 2 <= bits <= 8:          # the dense layers (ResNets): their weight codes in both fragment orders, one launch for the net
-                    ops.pack_dense_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], bits)
-                    # ... and the pointwise layers of the fused k-bit blocks (nin_gc): forward / backward-data images, one launch
-                    ops.pack_pointwise_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], (ops.WQ_DOREFA, bits, 0, 0, None))
-    if side is None:
-        # IAO nets: every per-channel weight quantizer (observer update + qparams + fake-quant of each output channel) of one flavour in one MultiIaoWeight
-        # node, then the dense layers' weight codes in one launch.  QuantBNFuseConv2d is excluded: it quantises weights folded with THIS step's batch statistics.
-        from micronet_amd.quantization.wqaq.iao import quantize as ia
-        groups = {}
-        for m in model.modules():
-            if type(m) in (ia.QuantConv2d, ia.QuantLinear) and not m.quant_inference and m.training and m.weight.is_cuda and m.weight.is_contiguous() \
-                    and m.weight.dtype == torch.float32:
-                q = m.weight_quantizer
-                obs = q.observer
-                stale = q.__dict__.pop("_mn_pre", None)
-                if stale is not None and stale[0] is m.weight:
-                    raise RuntimeError("prefetch_weight_path: the IAO weight hand-over of the previous call was never consumed (a covered module did not run its "
-                                       "forward since); its observer would advance twice in one iteration -- see the contract in this function's docstring")
-                if 2 <= q.bits <= 24 and not q.qaft and getattr(obs, "q_level", None) in ("C", "FC") and getattr(obs, "_kind", None) in (0, 1) \
-                        and not getattr(obs, "_mn_sync", False) and obs.min_val.numel() == m.weight.shape[0]:
-                    groups.setdefault((q.bits, q._q_type_static, obs._kind, float(getattr(obs, "momentum", 0.1))), []).append(m)
-        for cfg, ms in groups.items():
-            for i in range(0, len(ms), 32):
-                grp = ms[i:i + 32]
-                if len(grp) < 2:
-                    continue
-                state = []
-                for m in grp:
-                    q, obs = m.weight_quantizer, m.weight_quantizer.observer
-                    qp = torch.empty((m.weight.shape[0], 4), dtype=torch.float32, device=m.weight.device)
-                    state.append((obs.min_val, obs.max_val, q.scale, q.zero_point, qp, obs.num_flag == 0))
-                qws = ops.MultiIaoWeight.apply(cfg, state, *[m.weight for m in grp])
-                for m, wq, st in zip(grp, qws, state):
-                    obs = m.weight_quantizer.observer
-                    if obs.num_flag == 0:
-                        obs.num_flag += 1
-                    m.weight_quantizer._mn_pre = (m.weight, wq, st[4])
-                    wq._mn_defer_wgrad = True
-                if cfg[1] == 0 and 2 <= cfg[0] <= 8:
-                    convs = [(m, wq, st[4]) for m, wq, st in zip(grp, qws, state) if type(m) is ia.QuantConv2d]
-                    ops.pack_dense_weights([(m, wq) for m, wq, _ in convs], cfg[0], qps=[qp for _, _, qp in convs])
+    # DoReFa nets: every conv / linear weight quantizer of one bit-width in one MultiDorefaWeight node (2 launches forward, 3 backward per step)
+    by_bits = {}
+    for m in model.modules():
+        if isinstance(m, (dr.QuantConv2d, dr.QuantLinear)) and not m.quant_inference and 2 <= m.weight_quantizer.w_bits <= 31 and m.weight.is_cuda \
+                and m.weight.is_contiguous():
+            m.weight_quantizer.__dict__.pop("_mn_pre", None)
+            by_bits.setdefault(m.weight_quantizer.w_bits, []).append(m)
+    for bits, ms in by_bits.items():
+        for i in range(0, len(ms), 32):
+            grp = ms[i:i + 32]
+            if len(grp) < 2:
+                continue
+            qws = ops.MultiDorefaWeight.apply(bits, *[m.weight for m in grp])
+            for m, wq in zip(grp, qws):
+                m.weight_quantizer._mn_pre = (m.weight, wq, None)
+            if 2 <= bits <= 8:          # the dense layers (ResNets): their weight codes in both fragment orders, one launch for the net
+                ops.pack_dense_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], bits)
+                # ... and the pointwise layers of the fused k-bit blocks (nin_gc): forward / backward-data images, one launch
+                ops.pack_pointwise_weights([(m, wq) for m, wq in zip(grp, qws) if isinstance(m, dr.QuantConv2d)], (ops.WQ_DOREFA, bits, 0, 0, None))
+    # IAO nets: every per-channel weight quantizer (observer update + qparams + fake-quant of each output channel) of one flavour in one MultiIaoWeight
+    # node, then the dense layers' weight codes in one launch.  QuantBNFuseConv2d is excluded: it quantises weights folded with THIS step's batch statistics.
+    from micronet_amd.quantization.wqaq.iao import quantize as ia
+    groups = {}
+    for m in model.modules():
+        if type(m) in (ia.QuantConv2d, ia.QuantLinear) and not m.quant_inference and m.training and m.weight.is_cuda and m.weight.is_contiguous() \
+                and m.weight.dtype == torch.float32:
+            q = m.weight_quantizer
+            obs = q.observer
+            stale = q.__dict__.pop("_mn_pre", None)
+            if stale is not None and stale[0] is m.weight:
+                raise RuntimeError("prefetch_weight_path: the IAO weight hand-over of the previous call was never consumed (a covered module did not run its "
+                                   "forward since); its observer would advance twice in one iteration -- see the contract in this function's docstring")
+            if 2 <= q.bits <= 24 and not q.qaft and getattr(obs, "q_level", None) in ("C", "FC") and getattr(obs, "_kind", None) in (0, 1) \
+                    and not getattr(obs, "_mn_sync", False) and obs.min_val.numel() == m.weight.shape[0]:
+                groups.setdefault((q.bits, q._q_type_static, obs._kind, float(getattr(obs, "momentum", 0.1))), []).append(m)
+    for cfg, ms in groups.items():
+        for i in range(0, len(ms), 32):
+            grp = ms[i:i + 32]
+            if len(grp) < 2:
+                continue
+            state = []
+            for m in grp:
+                q, obs = m.weight_quantizer, m.weight_quantizer.observer
+                qp = torch.empty((m.weight.shape[0], 4), dtype=torch.float32, device=m.weight.device)
+                state.append((obs.min_val, obs.max_val, q.scale, q.zero_point, qp, obs.num_flag == 0))
+            qws = ops.MultiIaoWeight.apply(cfg, state, *[m.weight for m in grp])
+            for m, wq, st in zip(grp, qws, state):
+                obs = m.weight_quantizer.observer
+                if obs.num_flag == 0:
+                    obs.num_flag += 1
+                m.weight_quantizer._mn_pre = (m.weight, wq, st[4])
+            if cfg[1] == 0 and 2 <= cfg[0] <= 8:
+                convs = [(m, wq, st[4]) for m, wq, st in zip(grp, qws, state) if type(m) is ia.QuantConv2d]
+                ops.pack_dense_weights([(m, wq) for m, wq, _ in convs], cfg[0], qps=[qp for _, _, qp in convs])
     mods = [m for m in model.modules() if isinstance(m, wb.QuantConv2d) and not m.quant_inference and m.weight_quantizer.W in (2, 3)]
     for m in mods:
         m.weight_quantizer.__dict__.pop("_mn_pre", None)
-    if side is None:
-        tern = [m for m in mods if m.weight_quantizer.W == 3 and m.weight.is_cuda and m.weight.is_contiguous()]
-        for i in range(0, len(tern), 32):
-            grp = tern[i:i + 32]
-            if len(grp) < 2:
-                continue
-            qws = ops.MultiTernaryWeight.apply(*[m.weight for m in grp])
-            for m, wq in zip(grp, qws):
-                m.weight_quantizer._mn_pre = (m.weight, wq, None)
-            ops.pack_pointwise_weights(list(zip(grp, qws)), (ops.WQ_TERNARY, 0, 0, 0, None))          # the pointwise blocks' code images: one launch for the net
-        return
-    cur = torch.cuda.current_stream()
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        for m in mods:
-            q = m.weight_quantizer
-            wq = q(m.weight)
-            ev = torch.cuda.Event()
-            ev.record(side)
-            q._mn_pre = (m.weight, wq, ev)
+    tern = [m for m in mods if m.weight_quantizer.W == 3 and m.weight.is_cuda and m.weight.is_contiguous()]
+    for i in range(0, len(tern), 32):
+        grp = tern[i:i + 32]
+        if len(grp) < 2:
+            continue
+        qws = ops.MultiTernaryWeight.apply(*[m.weight for m in grp])
+        for m, wq in zip(grp, qws):
+            m.weight_quantizer._mn_pre = (m.weight, wq, None)
+        ops.pack_pointwise_weights(list(zip(grp, qws)), (ops.WQ_TERNARY, 0, 0, 0, None))          # the pointwise blocks' code images: one launch for the net
+    return
 
 
 class GraphedTrainStep:
@@ -258,22 +241,13 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         import os
-        side = None
-        if os.environ.get("MN_MULTI_WQ", "1") != "0" and os.environ.get("MN_WEIGHT_STREAM", "") != "1":
-            prefetch_weight_path(self.model)                     # all ternary weight quantizers of the step in one launch (and one in backward)
+        if os.environ.get("MN_MULTI_WQ", "1") != "0":
+            prefetch_weight_path(self.model)                     # all weight quantizers of the step in one launch (and one in backward)
             bump_bn_counters(self.model)
-        if os.environ.get("MN_WEIGHT_STREAM", "") == "1":       # the weight path on a second stream: opt-in -- measured on c2: 2.68 -> 2.73 ms,
-                                                                # the fork / join edges of the captured graph cost more than the 14 tiny launches they hide
-            if not hasattr(self, "_wstream"):
-                self._wstream = torch.cuda.Stream()
-            side = self._wstream
-            prefetch_weight_path(self.model, side)
         self.output = self.model(self.data)
         self.loss = F.cross_entropy(self.output, self.target)
         self.optimizer.zero_grad(set_to_none=True)
         self.loss.backward()
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
 
     def _reduce_eager(self):
         if self.world > 1:

@@ -1423,49 +1423,6 @@ def check_qg_pack_multi(be, seed=0):
             assert np.isfinite(res[1][k].astype(np.float64)).all(), ("NaN from the poisoned weights: the image was not used", k)
 
 
-def check_qd_wgrad_deferred(be, seed=0):
-    """mn_qd_bwd_weight_partials (every layer leaves its split-K partial tiles in its own workspace) + ONE mn_qd_wgrad_reduce_multi == mn_conv2d_bwd_weight
-    per layer, BIT FOR BIT (same kernels, same fixed-order fp64 reduction) -- DoReFa activation codes and IAO quantizers, 3x3 stride 1 / 2 and 1x1 stride 2."""
-    r = np.random.default_rng(seed)
-    layers = [  # (x_shape, Oc, k, stride, kind)   kind 1: MN_ACTQ_CODE8 (2-bit codes), 2: MN_ACTQ_IAO (4-bit symmetric)
-        ((2, 64, 8, 8), 64, 3, 1, 1), ((2, 64, 8, 8), 128, 3, 2, 1), ((2, 64, 8, 8), 128, 1, 2, 1),
-        ((2, 64, 8, 8), 64, 3, 1, 2), ((2, 128, 4, 4), 128, 3, 1, 2), ((2, 64, 8, 8), 128, 1, 2, 2),
-    ]
-    keep, G, A, WS, DW, ref = [], [], [], [], [], []
-    for (xs, Oc, k, st, kind) in layers:
-        N, Cin, H, W = xs
-        pad = 1 if k == 3 else 0
-        g = be.geom(xs, (Oc, Cin, k, k), stride=st, padding=pad)
-        Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
-        gy = be.to_dev(r.standard_normal((N, Oc, Ho, Wo)).astype(F))
-        if kind == 1:
-            x = be.to_dev_u8(r.integers(0, 4, size=xs).astype(np.uint8))
-            aq = be.actq(4, 2)
-        else:
-            xv = (r.standard_normal(xs) * 1.5).astype(F)
-            x = be.to_dev(xv)
-            sc = F(np.abs(xv).max() / 7.5)
-            qp = be.to_dev(np.array([sc, 0.0, -np.abs(xv).max() / sc, np.abs(xv).max() / sc], dtype=F))
-            keep.append(qp)
-            aq = _lib_actq_iao(be, 4, qp)
-        assert be.lib.mn_qd_wgrad_partials_supported(C.byref(g), C.byref(aq)) == 1, (xs, Oc, k, st, kind)
-        dw_ref, _ = be.conv_bwd_weight(g, aq, gy, x, 0, bias=False)
-        nb = int(be.lib.mn_qd_wgrad_partials_ws_bytes(C.byref(g), C.byref(aq)))
-        assert nb > 0
-        ws = be.empty(nb // 4 + 8)
-        be.call("mn_qd_bwd_weight_partials", C.byref(g), C.byref(aq), be.ptr(gy), be.ptr(x), be.ptr(ws), nb, be.stream)
-        dw = be.empty((Oc, Cin, k, k))
-        keep += [gy, x]
-        G.append(g); A.append(aq); WS.append(ws); DW.append(dw); ref.append(be.to_host(dw_ref).copy())
-    n = len(G)
-    GP, AP, PA = (C.POINTER(type(G[0])) * n), (C.POINTER(type(A[0])) * n), (C.c_void_p * n)
-    be.call("mn_qd_wgrad_reduce_multi", n, GP(*[C.pointer(g) for g in G]), AP(*[C.pointer(a) for a in A]), PA(*[be.ptr(w) for w in WS]), PA(*[be.ptr(d) for d in DW]), be.stream)
-    for i in range(n):
-        got = be.to_host(DW[i])
-        assert np.array_equal(got, ref[i]), ("layer", i, float(np.abs(got - ref[i]).max()))
-        assert np.abs(ref[i]).max() > 0
-
-
 def _lib_actq_iao(be, bits, qp):
     return be.actq(2, bits, 0, qp)
 

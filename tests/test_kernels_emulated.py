@@ -247,9 +247,6 @@ def test_qg_pack_multi_images_bit_identical(be):
     K.check_qg_pack_multi(be)
 
 
-def test_qd_wgrad_deferred_reduction_bit_identical(be):
-    K.check_qd_wgrad_deferred(be)
-
 
 def test_code_classifier(be):
     K.check_code_classifier(be)
