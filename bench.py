@@ -246,7 +246,10 @@ def measure(workload, args, world, rank, device):
     # data-parallel IAO models: the eager step (one blocking 2-float collective per activation quantizer, ~360 launches issued from Python) next to the graphed one,
     # so that the cost of falling back to it is a number
     eager_dp = None
-    if world > 1 and graphed is not None and getattr(graphed, "collectives_in_graph", False):
+    is_iao = WORKLOADS[workload][1].endswith("iao")
+    # IAO models: at world > 1 their default data-parallel step is the EAGER one (range collectives inside forward; micronet_amd/train.py) -- its throughput is
+    # reported next to the graphed step's at every N, N = 1 included, so that the cost of that path is a number (`eager_dp_value`)
+    if graphed is not None and ((world > 1 and getattr(graphed, "collectives_in_graph", False)) or (is_iao and world == 1)):
         sync2 = dp.GradSync(model)
         for _ in range(2):
             dp.train_step_dp(model, opt, sync2, x, y)

@@ -131,6 +131,9 @@ __device__ __forceinline__ unsigned mn_rne_bf16x2(float lo_elem, float hi_elem) 
     return __builtin_bit_cast(unsigned, __builtin_convertvector((mn_f2){lo_elem, hi_elem}, mn_bf2));
 }
 #endif
+// How many bf16 terms carry an fp32 gradient operand through the matrix cores: 3 = exact (truncation split), 2 (default since round 5) = the split below.
+// MN_GRAD_TERMS=3 (or the older MN_QD_TERMS=3) restores the exact split everywhere.
+static inline int mn_grad_terms() { const char* e = MN_ENV("MN_GRAD_TERMS"); if (!e) e = MN_ENV("MN_QD_TERMS"); return (e && e[0] == '3') ? 3 : 2; }
 // the two term words of a pair of floats: hi = rne pair, lo = rne pair of the remainders
 __device__ __forceinline__ void mn_split2_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
     hi = mn_rne_bf16x2(a, b);

@@ -857,7 +857,7 @@ int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a
 // The fp32 gradient operand of the two backward kernels as bf16 TERMS: 3 = exact (three truncation terms carry all 24 significant bits), 2 (default, round 5) =
 // round-to-nearest hi + round-to-nearest remainder: |error| <= 2^-18 |gy| per element (3.8e-6; measured parity in DESIGN / profiles/parity_r05.json), one third fewer
 // matrix passes and LDS plane reads.  MN_QD_TERMS=3 restores the exact split.
-static int qd_terms() { const char* e = MN_ENV("MN_QD_TERMS"); return (e && e[0] == '3') ? 3 : 2; }
+static int qd_terms() { return mn_grad_terms(); }
 // ================================================================================================ backward-data
 //   dq[n][c][ih][iw] = (1 / n_w) * sum over (o, r, s) of wcode[o][c][r][s] * gy[n][o][oh][ow],   ih = oh S + r - P, iw = ow S + s - P
 // The same organisation with the roles of the channel axes swapped: the staged patch is gy (fp32, three exact bf16 terms: three LDS planes of

@@ -1,11 +1,11 @@
 #!/bin/bash
 # The one parameterised GPU-box runner (run through scripts/grun.sh or gpurun directly, from the repo root):
-#   bash scripts/gpu_check.sh [tests|parity|bench|prof|pmc]...      (default: tests bench)
+#   bash scripts/gpu_check.sh [tests|parity|bench|prof]...      (default: tests bench)
 #   tests  : pytest -m gpu (whole suite)            -> gpurun_out/pytest_gpu.log
-#   parity : only tests/test_gpu_parity_full.py      -> gpurun_out/parity_r02.json
+#   parity : only tests/test_gpu_parity_full.py      -> gpurun_out/parity_r05/
 #   bench  : smoke + bench.py (default workloads)    -> gpurun_out/bench.json
 #   prof   : rocprofv3 --kernel-trace --stats of bench.py per workload -> gpurun_out/prof_<w>/
-#   pmc    : scripts/pmc_traffic.sh + scripts/pmc_mfma.sh per workload
+#   (PMC traffic / MFMA-busy: bench.py collects them itself -- roofline.traffic, gpurun_out/bench_detail.json)
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 mkdir -p gpurun_out
@@ -28,7 +28,5 @@ for what in "$@"; do
         f=$(find gpurun_out/prof_$w -name "*kernel_stats.csv" | head -1)
         [ -n "$f" ] && python scripts/prof_summary.py $f gpurun_out/prof_${w}_summary.md "rocprofv3 --kernel-trace --stats: bench.py --only $w --steps 20 --warmup 5" && head -25 gpurun_out/prof_${w}_summary.md
       done ;;
-    pmc)
-      for w in $WL; do bash scripts/pmc_traffic.sh $w | tail -30; bash scripts/pmc_mfma.sh $w | tail -30; done ;;
   esac
 done
