@@ -757,9 +757,12 @@ class ReluOfFusedConv(Function):
     @staticmethod
     def forward(ctx, lazy):
         a = lazy._mn_a
-        ctx.save_for_backward(a)          # an OUTPUT saved through autograd (no reference cycle through a.grad_fn: ADVICE r4 -- `ctx.a = a` leaked x, a, qw of every fused block whose
-        ctx.tok = ReluToken()              # grad-enabled forward was never backpropagated)
-        return a
+        # The conv node saved THIS tensor object for its own backward (the ReLU mask).  Returning it would hang this node on it as grad_fn: conv node -> saved a ->
+        # a.grad_fn (this node) -> next edge -> conv node, a C++ reference cycle only backward() breaks (every fused block of a forward that is never
+        # backpropagated leaked x, a, qw).  The output is therefore a second tensor on the same storage and version counter; `a` itself stays without grad_fn.
+        ctx.save_for_backward(a)
+        ctx.tok = ReluToken()
+        return a.detach()
 
     @staticmethod
     def backward(ctx, g):

@@ -24,9 +24,9 @@ for what in "$@"; do
       timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 1500 gpurun_out/bench.json ;;
     prof)
       for w in $WL; do
-        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_$w -o p -- python $OLDPWD/bench.py --only $w --steps 20 --warmup 5 --no-cpu-baseline > $OLDPWD/gpurun_out/prof_$w.log 2>&1)
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_$w -o p -- python $OLDPWD/bench.py --only $w --steps 20 --warmup 5 --repeats 1 --no-pmc --no-cpu-baseline --no-kernel-timing --detail /tmp/prof_detail_$w.json > $OLDPWD/gpurun_out/prof_$w.log 2>&1)
         f=$(find gpurun_out/prof_$w -name "*kernel_stats.csv" | head -1)
-        [ -n "$f" ] && python scripts/prof_summary.py $f gpurun_out/prof_${w}_summary.md "rocprofv3 --kernel-trace --stats: bench.py --only $w --steps 20 --warmup 5" && head -25 gpurun_out/prof_${w}_summary.md
+        [ -n "$f" ] && python scripts/prof_summary.py $f gpurun_out/prof_${w}_summary.md "rocprofv3 --kernel-trace --stats: bench.py --only $w --steps 20 --warmup 5 --repeats 1 --no-pmc --no-cpu-baseline --no-kernel-timing" && head -25 gpurun_out/prof_${w}_summary.md
       done ;;
   esac
 done
