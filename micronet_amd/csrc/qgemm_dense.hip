@@ -870,7 +870,7 @@ static int qd_terms() { return mn_grad_terms(); }
 //          1 x 1 / stride 2 (the shortcut): only (ph, pw) = (0, 0) receives anything; the other three quarters are written as zeros.
 // No clip-STE epilogue: the consumer of dq (mn_qa_bwd_* / mn_qr_bwd_*) applies the quantizer's STE where it recomputes the activation.
 #define QDD_RS 80
-#define QDD_UPT 2
+#define QDD_UPT_OF(mf) ((mf) == 4 ? 3 : 2)
 struct QddParams {
     const float* gy;              // [N][O][Hg][Wg]
     const uint16_t* wpk;          // k_qd_pack orient 1
@@ -896,23 +896,24 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
     unsigned char* patch = wbuf + 2 * p.WSB;
     const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
     constexpr int TPS = TAPS == 9 ? 3 : 1, NSTEP = TAPS == 9 ? 3 : 1;
+    constexpr int UPT = QDD_UPT_OF(MF);          // staging units per thread (a third one only for the 256-pixel tile)
     if ((int)blockIdx.x >= p.nitems) return;
     for (int i = tid; i < (NT * p.TS) / 16; i += 256) *reinterpret_cast<u32x4*>(patch + 16 * i) = u32x4{0u, 0u, 0u, 0u};
     // staging roles: a unit = output channels 4q .. 4q + 3 of the chunk, patch row pr of image img, pixels 4d .. 4d + 3 (order over the threads: QdUnits)
-    int u_lds[QDD_UPT], u_goff[QDD_UPT], u_pi[QDD_UPT];
+    int u_lds[UPT], u_goff[UPT], u_pi[UPT];
 #pragma unroll
-    for (int i = 0; i < QDD_UPT; ++i) {
+    for (int i = 0; i < UPT; ++i) {
         int q, img, pr, d;
         const bool v = qd_unit(p.units, tid + 256 * i, q, img, pr, d);
         u_lds[i] = v ? ((img * p.PH + pr) * p.PW + 4 * d + 1) * QDD_RS + 8 * q : -1;
         u_goff[i] = v ? 4 * q * p.HWg + 4 * d : 0;
         u_pi[i] = pr | (img << 8);
     }
-    float4 preg[QDD_UPT][4];
-    float psc[QDD_UPT][4];
-    int u_q[QDD_UPT];
+    float4 preg[UPT][4];
+    float psc[UPT][4];
+    int u_q[UPT];
 #pragma unroll
-    for (int i = 0; i < QDD_UPT; ++i) {
+    for (int i = 0; i < UPT; ++i) {
         int q, img, pr, d;
         qd_unit(p.units, tid + 256 * i, q, img, pr, d);
         u_q[i] = q;
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
         tile_origin(item, n0, oh0, cit);
         pok = 0u;
 #pragma unroll
-        for (int i = 0; i < QDD_UPT; ++i) {
+        for (int i = 0; i < UPT; ++i) {
             int n = n0 + (u_pi[i] >> 8), oh = oh0 - 1 + (u_pi[i] & 255);
             const bool ok = u_lds[i] >= 0 && n < p.N && oh >= 0 && oh < p.Hg;
             n = n < p.N ? n : p.N - 1;
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
     };
     auto commit_patch = [&]() {
 #pragma unroll
-        for (int i = 0; i < QDD_UPT; ++i) {
+        for (int i = 0; i < UPT; ++i) {
             if (u_lds[i] < 0) continue;
             const bool ok = (pok >> i) & 1u;
             if (NT == 2) {                                             // round-to-nearest hi + round-to-nearest remainder (qd_terms)
@@ -1140,7 +1141,10 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
     if (p.w_shift < 2 || p.Wg > 32 || p.HWg % 8) return 0;
     if ((int64_t)g->N * g->C * g->H * g->W >= ((int64_t)1 << 31) || (int64_t)g->N * g->O * p.HWg >= ((int64_t)1 << 31)) return 0;
     int MF = 0;
-    for (int mf = (S == 2 ? 1 : 2); mf >= 1; mf >>= 1) {
+    const int NTm = qd_terms();
+    int mf0 = S == 2 ? 1 : 4;          // MF 4 (round 5): 256-pixel tiles -- an item's fixed costs (first patch, epilogue stores: ~45 % of an MF 2 item, s_memtime timeline) over twice the work
+    if (const char* e = MN_ENV("MN_QDD_MF")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) mf0 = S == 2 ? 1 : v; }
+    for (int mf = mf0; mf >= 1; mf >>= 1) {
         const int BM = 64 * mf;
         int TH, NI;
         if (p.HWg >= BM) { if (BM % p.Wg) continue; TH = BM / p.Wg; if (p.Hg % TH) continue; NI = 1; }
@@ -1149,7 +1153,11 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
         if (PH > 255 || NI > 255) continue;
         const int64_t plane = ((int64_t)NI * PH * PW * QDD_RS + 255) / 256 * 256;
         const QdUnits units = qd_make_units(p.Wg / 4, PH, NI, 8);
-        if (3 * plane > 54 * 1024 || units.nunits > 256 * QDD_UPT) continue;
+        if (NTm * plane > 56 * 1024 || units.nunits > 256 * QDD_UPT_OF(mf)) continue;          // two blocks per CU: 2 x (term planes + 24 KB of weights) in 160 KB
+        {   // ... and two blocks per CU there must be: a larger tile that leaves fewer than 512 items loses the overlap of the two blocks' phases (512 x 512 @ 4 x 4: MF 2 75 us, MF 1 61 us)
+            const int64_t nt = NI == 1 ? (int64_t)g->N * (p.Hg / TH) : ((int64_t)g->N + NI - 1) / NI;
+            if (mf > 1 && !MN_ENV("MN_QDD_MF") && nt * (g->C / 64) < 512) continue;
+        }
         MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.TS = (int)plane; p.nunits = units.nunits; p.units = units;
         break;
     }
@@ -1164,7 +1172,7 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
     int tgt = 512;
     if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }
     pl->grid = p.nitems < tgt ? p.nitems : tgt;
-    pl->lds = (size_t)2 * p.WSB + (size_t)3 * p.TS;
+    pl->lds = (size_t)2 * p.WSB + (size_t)NTm * p.TS;
     pl->ws_bytes = ((int64_t)g->O * g->C * p.TAPS * 2 + 255) / 256 * 256;
     return 1;
 }
@@ -1174,6 +1182,7 @@ static void qd_launch_dgrad(const QddPlan& pl, hipStream_t s) {
 #define QDD_LAUNCH(M_, S_, T_, N_) do { raise_lds_limit((const void*)k_qd_dgrad<M_, S_, T_, N_>, pl.lds); hipLaunchKernelGGL((k_qd_dgrad<M_, S_, T_, N_>), dim3(pl.grid), dim3(256), pl.lds, s, p); } while (0)
     if (pl.S == 2 && p.TAPS == 9) { if (NT == 2) QDD_LAUNCH(1, 2, 9, 2); else QDD_LAUNCH(1, 2, 9, 3); }
     else if (pl.S == 2) { if (NT == 2) QDD_LAUNCH(1, 2, 1, 2); else QDD_LAUNCH(1, 2, 1, 3); }
+    else if (pl.MF == 4) { if (NT == 2) QDD_LAUNCH(4, 1, 9, 2); else QDD_LAUNCH(4, 1, 9, 3); }
     else if (pl.MF == 2) { if (NT == 2) QDD_LAUNCH(2, 1, 9, 2); else QDD_LAUNCH(2, 1, 9, 3); }
     else { if (NT == 2) QDD_LAUNCH(1, 1, 9, 2); else QDD_LAUNCH(1, 1, 9, 3); }
 #undef QDD_LAUNCH
