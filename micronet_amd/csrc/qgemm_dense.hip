@@ -1391,19 +1391,17 @@ __global__ __launch_bounds__(768) void k_qd_wgrad(const QdwParams p) {
             }
         };
         if (n > 0) {
-#pragma unroll
-            for (int c = 0; c < QDW_PCH; ++c) fetch_chunk(c, t_begin);
             fetch_gy(gs[0], 0);
             MN_SCHED_FENCE();
             fetch_gy(gs[1], 1);
-        }
-        __syncthreads();                          // barrier Z: the consumers have zero-filled both patch buffers (the frame stays zero)
-        if (n > 0) {
+            if (t_begin + 1 < t_end) {
 #pragma unroll
-            for (int c = 0; c < QDW_PCH; ++c) {
-                commit_chunk(c, xp0, dump);
-                if (t_begin + 1 < t_end) fetch_chunk(c, t_begin + 1);
+                for (int c = 0; c < QDW_PCH; ++c) fetch_chunk(c, t_begin + 1);
             }
+        }
+        __syncthreads();                          // barrier Z0: the consumers have zero-filled the patch buffers (the frame stays zero)
+        __syncthreads();                          // barrier Z:  ... and staged the FIRST tile's patch (512 idle threads instead of these 256: the prologue was 16 k cycles)
+        if (n > 0) {
             int ks = 0, tile = t_begin;
             const int ppt = p.nks >> 1;                                  // step pairs per tile (1, 2 or 4)
             // Barrier k (behind the commit of step k into gy buffer k & 1) releases the consumers' reads of step k; buffer k & 1 is overwritten with step k + 2 behind
@@ -1534,7 +1532,58 @@ __global__ __launch_bounds__(768) void k_qd_wgrad(const QdwParams p) {
                     for (int c2 = 0; c2 < 2; ++c2) acc[c2][ti] = mn_mfma_bf16(A.a[c2][t], b[s_], acc[c2][ti]);
                 }
         };
-        for (int i = tid - 256; i < ((1 + p.pdb) * XPB) / 8; i += 512) *reinterpret_cast<u32x2*>(xp0 + 8 * i) = u32x2{0u, 0u};          // the zero frame of both patch buffers
+        // the first tile's patch: thread (channel ctid >> 3, lane ctid & 7) stages positions pos = lane + 8 i of its channel (the producers' unit, see above)
+        const int ctid = tid - 256, sc_ = ctid >> 3, sl_ = ctid & 7;
+        const int npos_c = p.NI * p.PH * p.W4;
+        uint32_t sreg[10];
+        uint32_t sok = 0u;
+        if (n > 0) {
+            int n0, oh0;
+            tile_origin(t_begin, n0, oh0);
+            const int ihb = oh0 * S - p.PAD;
+            const int cb_g = sc_ * p.HX * p.WX;
+            const int base = ((n0 * p.C + cit * 64) * p.HX + ihb) * p.WX + cb_g;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int pos = sl_ + 8 * i;
+                if (8 * i >= npos_c) break;                          // (uniform)
+                const uint32_t t0 = fd_div((uint32_t)pos, p.fd_w4);
+                const int d = pos - (int)t0 * p.W4;
+                const uint32_t img = fd_div(t0, p.fd_ph);
+                const int pr = (int)t0 - (int)img * p.PH;
+                const int ih = ihb + pr, nn = n0 + (int)img;
+                const bool ok = pos < npos_c && (unsigned)ih < (unsigned)p.HX && nn < p.N;
+                const int off = ok ? base + ((int)img * p.C * p.HX + pr) * p.WX + 4 * d : cb_g;
+                sreg[i] = *reinterpret_cast<const uint32_t*>(p.x + (uint32_t)off);
+                sok |= (ok ? 1u : 0u) << i;
+            }
+        }
+        for (int i = ctid; i < ((1 + p.pdb) * XPB) / 8; i += 512) *reinterpret_cast<u32x2*>(xp0 + 8 * i) = u32x2{0u, 0u};          // the zero frame of both patch buffers
+        __syncthreads();                          // barrier Z0
+        if (n > 0) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int pos = sl_ + 8 * i;
+                if (8 * i >= npos_c) break;                          // (uniform)
+                if (pos >= npos_c) continue;
+                const uint32_t t0 = fd_div((uint32_t)pos, p.fd_w4);
+                const int d = pos - (int)t0 * p.W4;
+                const uint32_t img = fd_div(t0, p.fd_ph);
+                const int pr = (int)t0 - (int)img * p.PH;
+                const uint32_t lo = (uint32_t)(sc_ * p.CS + ((int)img * p.PH + pr) * p.RB + (4 + (S == 2 ? 2 : 4) * d) * 2);
+                uint32_t v = ((sok >> i) & 1u) ? sreg[i] : 0u;
+                float f0, f1, f2, f3;
+                if (p.xsgn) {
+                    v ^= 0x80808080u;
+                    f0 = (float)(v & 0xffu) - 128.f; f1 = (float)((v >> 8) & 0xffu) - 128.f; f2 = (float)((v >> 16) & 0xffu) - 128.f; f3 = (float)(v >> 24) - 128.f;
+                } else { f0 = (float)(v & 0xffu); f1 = (float)((v >> 8) & 0xffu); f2 = (float)((v >> 16) & 0xffu); f3 = (float)(v >> 24); }
+                if (S == 1) *reinterpret_cast<u32x2*>(xp0 + lo) = u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)};
+                else {
+                    *reinterpret_cast<uint32_t*>(xp0 + lo) = mn_pack_hi16(f0, f2);
+                    *reinterpret_cast<uint32_t*>(xp0 + lo + p.PWp * 2) = mn_pack_hi16(f1, f3);
+                }
+            }
+        }
         __syncthreads();                          // barrier Z
         if (n > 0) {
             int ks = 0, par = 0;
