@@ -189,8 +189,7 @@ class WeightQuantizer(nn.Module):
 
 def _forget_stored_codes(module, *args, **kwargs):
     """load_state_dict pre-hook: newly loaded weights are not known to be codes x alpha[o] any more (micronet_amd.inference re-establishes the verdict when it checks them)"""
-    module.stored_codes = False
-    module.lazy_for_bn = module.lazy_for_bn and not module.quant_inference
+    module.stored_codes = False          # (lazy_for_bn is structural -- set by prepare() -- and gated by `coded` in forward: it stays)
 
 
 class QuantConv2d(nn.Conv2d):
