@@ -193,7 +193,7 @@ def measure(workload, args, world, rank, device):
     from micronet_amd.train import GraphedTrainStep, synth_batch
     model, opt = build(workload, device)
     dp.broadcast_parameters(model)
-    if world > 1:
+    if dp.active():
         dp.sync_observers(model)          # IAO activation / QuantAdd ranges over the global batch (SURVEY 8e ii); no-op for DoReFa / wbwtab
     x, y = synth_batch(args.batch, seed=1234 + rank, device=device)
 
@@ -214,7 +214,7 @@ def measure(workload, args, world, rank, device):
             graphed = None
             model, opt = build(workload, device)
             dp.broadcast_parameters(model)
-            if world > 1:
+            if dp.active():
                 dp.sync_observers(model)
     if graphed is None:
         sync = dp.GradSync(model)
@@ -243,13 +243,13 @@ def measure(workload, args, world, rank, device):
     fallbacks = _ops.fallback_counts(reset=True)           # stock-operator fall-throughs seen while this workload ran (warm-up, capture, eager steps): expected {}
     dt = sorted(windows)[len(windows) // 2]                 # the median window (an odd count by default)
     final_loss = float(loss.detach())
-    # data-parallel IAO models: the eager step (one blocking 2-float collective per activation quantizer, ~360 launches issued from Python) next to the graphed one,
-    # so that the cost of falling back to it is a number
+    # IAO models: the EAGER data-parallel step (dp.GradSync; at world > 1 one 2-float range collective per activation quantizer, ~360 launches issued from
+    # Python) next to the graph-replayed one (at world > 1 captured in segments cut at those collectives: micronet_amd/train.py), at every N, so that the cost of
+    # either path is a number (`eager_dp_value`, `graph_segments`)
     eager_dp = None
     is_iao = WORKLOADS[workload][1].endswith("iao")
-    # IAO models: at world > 1 their default data-parallel step is the EAGER one (range collectives inside forward; micronet_amd/train.py) -- its throughput is
-    # reported next to the graphed step's at every N, N = 1 included, so that the cost of that path is a number (`eager_dp_value`)
-    if graphed is not None and ((world > 1 and getattr(graphed, "collectives_in_graph", False)) or (is_iao and world == 1)):
+    segments = len(getattr(graphed, "segments", ())) if graphed is not None else 0
+    if graphed is not None and is_iao and not args.no_kernel_timing:
         sync2 = dp.GradSync(model)
         for _ in range(2):
             dp.train_step_dp(model, opt, sync2, x, y)
@@ -280,7 +280,37 @@ def measure(workload, args, world, rank, device):
     del graphed, model, opt, sync
     torch.cuda.empty_cache()
     return dict(dt=dt, dt_min=min(windows), windows=windows, final_loss=final_loss, hip_graph=graph_err is None and not args.no_graph, graph_err=graph_err, agg=agg,
-                eager_dp=eager_dp, fallbacks=fallbacks)
+                eager_dp=eager_dp, fallbacks=fallbacks, segments=segments)
+
+
+def dp_single_rank(workloads, args, device):
+    """The DATA-PARALLEL step on one rank (MN_DP_SINGLE=1, an RCCL process group of size 1): what one GPU of an N-GPU job executes -- gradients packed into the
+    flat bucket, its all-reduce issued between graph A and graph B, for the IAO models every observer range collective issued between two graph segments -- with
+    nothing on the links.  The difference to the single-GPU step is the data-parallel step's own cost; link time comes on top of it at N > 1."""
+    import copy
+    import datetime
+    out = {}
+    os.environ["MN_DP_SINGLE"] = "1"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(args.master_port + 7))
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device, timeout=datetime.timedelta(seconds=120))
+        a = copy.copy(args)
+        a.no_kernel_timing, a.repeats = True, 1
+        for w in workloads:
+            try:
+                m = measure(w, a, 1, 0, device)
+                out[w] = {"value": round(args.batch * args.steps / m["dt"], 1), "ms_per_step": round(1000.0 * m["dt"] / args.steps, 3), "hip_graph": m["hip_graph"],
+                          **({"graph_segments": m["segments"]} if m.get("segments") else {})}
+            except Exception as e:          # noqa: BLE001
+                out[w] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+    except Exception as e:          # noqa: BLE001 -- a reported extra: the line must survive it
+        out["error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+    finally:
+        os.environ.pop("MN_DP_SINGLE", None)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    return out
 
 
 def section(workload, m, args, world, pmc):
@@ -296,6 +326,8 @@ def section(workload, m, args, world, pmc):
     out["stock_fallbacks"] = m.get("fallbacks") or {}
     if m.get("eager_dp"):
         out["eager_dp_value"] = round(args.batch * world * args.steps / m["eager_dp"], 1)
+    if m.get("segments"):
+        out["graph_segments"] = m["segments"]
     agg = m["agg"]
     if agg:
         ks = args.kernel_steps
@@ -452,7 +484,7 @@ def compact_roofline(r):
         out["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE(x2 gfx950)+WRITE_SIZE"
     return out
 
-def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info=None, cpu_more=None):
+def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info=None, cpu_more=None, dp1=None):
     """(final-line dict, detail dict).  The final stdout line is what the driver parses: the contract's keys, the HEADLINE workload's roofline, cpu_baseline, one
     short record per secondary workload, every images/s figure under `values` -- bounded by MAX_LINE_BYTES.  Everything else (per-kernel tables, step_level,
     timed windows of every workload) is `detail`, written to a side file."""
@@ -475,6 +507,9 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         out["config"]["dist"] = dist_info
     if "hip_graph_error" in sec:
         out["config"]["hip_graph_error"] = sec["hip_graph_error"][:200]
+    for k in ("graph_segments", "eager_dp_value"):          # IAO data parallel: the segmented replay and the eager step it replaces
+        if k in sec:
+            out["config"][k] = sec[k]
     detail = {"headline": dict(out), "sections": {primary: sec}}
     if "roofline" in sec:
         out["roofline"] = compact_roofline(sec["roofline"])
@@ -488,7 +523,7 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         s["metric"] = METRIC.get(w, "QAT images/sec (%s)" % w)
         s["steps"], s["warmup"], s["n_gpus"] = args.steps, args.warmup, world
         detail["sections"][w] = s
-        also_out[w] = {"value": s["value"], "ms_per_step": s["ms_per_step"], "hip_graph": s["hip_graph"], **({"eager_dp_value": s["eager_dp_value"]} if "eager_dp_value" in s else {}),
+        also_out[w] = {"value": s["value"], "ms_per_step": s["ms_per_step"], "hip_graph": s["hip_graph"], **({k: s[k] for k in ("eager_dp_value", "graph_segments") if k in s}),
                        **({"roofline": {k: s["roofline"][k] for k in ("bound", "kernel", "frac", "avg_launch_us", "traffic") if k in s["roofline"]}} if "roofline" in s else {})}
     for w, e in also_err.items():
         also_out[w] = {"error": e[:200]}
@@ -505,7 +540,9 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         if "c1_b128" in cpu_more:                            # BASELINE.json configs[0]: nin_gc DoReFa W8A8, batch 128, CPU reference path (wqaq/dorefa/main.py:135,171,189-190)
             out["cpu_baseline_c1_b128"] = {k: cpu_more["c1_b128"][k] for k in ("value", "unit", "cores", "kind", "batch", "sample") if k in cpu_more["c1_b128"]}
         out["cpu_values"] = {k: v["value"] for k, v in cpu_more.items() if "value" in v}
-    for drop in ("window_ms", "step_level", "cpu_values", "also"):      # the driver parses the LAST stdout line: never let it outgrow its reader again (round 3: 34 KB -> parsed null)
+    if dp1:
+        out["dp_single_rank"] = detail["dp_single_rank"] = dp1
+    for drop in ("window_ms", "step_level", "cpu_values", "dp_single_rank", "also"):      # the driver parses the LAST stdout line: never let it outgrow its reader again (round 3: 34 KB -> parsed null)
         if len(json.dumps(out)) + 64 <= MAX_LINE_BYTES:
             break
         out.pop(drop, None)
@@ -551,6 +588,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic / mfma_busy stay null)")
     ap.add_argument("--detail", default=None, help="where the per-kernel tables / step_level / windows go (default gpurun_out/bench_detail.json)")
+    ap.add_argument("--no-dp-single", action="store_true", help="skip the single-rank data-parallel leg (dp_single_rank: the N-GPU step's own cost measured on one rank)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -613,6 +651,10 @@ def main():
                 raise                   # ranks must stay in lock-step
             also_err[w] = "%s: %s" % (type(e).__name__, str(e)[:300])
 
+    dp1 = None
+    if world == 1 and not args.only and not args.no_kernel_timing and not args.no_dp_single:
+        dp1 = dp_single_rank([w for w in (primary, "c3", "c4", "c5") if w == primary or w in m_also], args, device)
+
     pmc, pmc_err = None, None
     if world == 1 and rank == 0 and not args.no_pmc and not args.no_kernel_timing:
         torch.cuda.synchronize()
@@ -627,7 +669,7 @@ def main():
                          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None}
         cpu = cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads, args.cpu_kind) if (world == 1 and not args.no_cpu_baseline) else None
         cpu_more = cpu_more_legs(args, primary) if (world == 1 and not args.no_cpu_baseline and not args.only) else None
-        out, detail = compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info, cpu_more)
+        out, detail = compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info, cpu_more, dp1)
         out["detail_file"] = write_detail(detail, args)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)

@@ -19,8 +19,17 @@ Cross-rank statistics: the parity target of data-parallel QAT is 
   * BatchNorm / BN-fuse batch mean and variance: per-rank (what ``nn.BatchNorm2d`` does under DP / DDP);
   * weight observers and the DoReFa / wbwtab weight quantizers: rank-invariant (same weights everywhere).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def active(group=None):
+    """Is the data-parallel machinery (gradient all-reduce, observer range collectives) on: a process group with more than one rank -- or with ONE rank under
+    MN_DP_SINGLE=1, i.e. the step one GPU of an N-GPU job executes with every collective issued and nothing on the links.  That is how bench.py puts a number on
+    the data-parallel step's own cost (packing, collective launches, graph segments) on a one-GPU box."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("MN_DP_SINGLE") == "1")
 
 
 class _Bucket:
@@ -42,7 +51,8 @@ class GradSync:
                 cur, size = [], 0
         if cur:
             self._close(cur)
-        if self.world > 1:
+        self.on = active(group)
+        if self.on:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -68,7 +78,7 @@ class GradSync:
 
     def wait(self):
         """Call between ``loss.backward()`` and ``optimizer.step()``."""
-        if self.world == 1:
+        if not self.on:
             return
         for b in self.buckets:
             if b.pending != 0:
@@ -103,15 +113,37 @@ def train_step_dp(model, optimizer, sync, data, target):
     return loss, output
 
 
+# Set by train.GraphedTrainStep while it captures a model whose forward holds range collectives: a callable (buf, group) that ends the HIP graph being
+# captured, notes ``buf`` as the operand of the collective to run after that segment's replay, and begins the next segment.
+_segment_cut = None
+
+
 def allreduce_minmax(min_t, max_t, group=None):
     """In place: min_t <- min over ranks, max_t <- max over ranks (tensors of equal shape, any device the backend supports) with ONE collective:
     MAX over the stacked [-min, max]."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not active(group):
         return
     buf = torch.stack([-min_t.reshape(-1), max_t.reshape(-1)])
-    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+    if _segment_cut is not None:
+        _segment_cut(buf, group)          # a step being captured in HIP-graph segments (train.GraphedTrainStep): the collective runs BETWEEN two replays
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
     min_t.copy_((-buf[0]).view_as(min_t))
     max_t.copy_(buf[1].view_as(max_t))
+
+
+def allreduce_range(buf, group=None):
+    """In place on ``buf`` = [min_0, max_0, min_1, max_1, ...] (floats on the device): every min over the ranks, every max over the ranks, ONE MAX collective on
+    [-min, max, ...].  What a synced IAO observer calls between its local reduction and its running update; inside a segmented graph capture the collective
+    becomes a cut (``_segment_cut``)."""
+    if not active(group):
+        return
+    buf[0::2].neg_()
+    if _segment_cut is not None:
+        _segment_cut(buf, group)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+    buf[0::2].neg_()
 
 
 def sync_observers(model, group=None, enable=True):

@@ -50,6 +50,29 @@ def _range_shape(q_level, out_channels):
     return {"L": (1,), "C": (out_channels, 1, 1, 1), "FC": (out_channels, 1)}[q_level]
 
 
+def _synced(obs):
+    """the observer reduces the current batch's range over the data-parallel ranks first (micronet_amd.dp.sync_observers) and data parallelism is on"""
+    if not getattr(obs, "_mn_sync", False):
+        return False
+    from micronet_amd import dp
+    return dp.active(obs._mn_sync_group)
+
+
+def _global_ranges(items, group):
+    """[(tensor, its producer's partials or None), ...] -> a device buffer [min_0, max_0, min_1, max_1, ...] holding each tensor's range over the GLOBAL batch:
+    the local reductions (from the partials where the producer left them: no pass over the tensor), then ONE MAX collective for all of them.  Slices
+    ``(buf[2 * i:2 * i + 2], 1)`` have the layout of a one-block partials buffer, so the fused observer kernels consume them unchanged."""
+    from micronet_amd import dp
+    cur = torch.empty(2 * len(items), dtype=torch.float32, device=items[0][0].device)
+    for i, (t, mm) in enumerate(items):
+        if mm is not None:
+            ops.iao_observe_partials(mm, 0, True, 0.0, cur[2 * i:2 * i + 1], cur[2 * i + 1:2 * i + 2])
+        else:
+            ops.iao_observe(t, 1, 0, True, 0.0, cur[2 * i:2 * i + 1], cur[2 * i + 1:2 * i + 2])
+    dp.allreduce_range(cur, group)
+    return cur
+
+
 class ObserverBase(nn.Module):
     """min/max at level 'L' (whole tensor), 'C' (conv out-channel) or 'FC' (linear row) (ref 15-36)."""
     _kind = None  # 0 running min/max, 1 EMA
@@ -67,14 +90,10 @@ class ObserverBase(nn.Module):
     @torch.no_grad()
     def forward(self, input):
         rows = 1 if self.q_level == "L" else input.shape[0]
-        if self._mn_sync and rows == 1 and torch.distributed.is_initialized() and torch.distributed.get_world_size(self._mn_sync_group) > 1:
+        if rows == 1 and _synced(self) and self._kind in (0, 1):
             # local (min, max) of this rank's shard -> global over the ranks -> the ordinary update on the two global extremes
-            from micronet_amd import dp
-            cur_min, cur_max = torch.empty_like(self.min_val), torch.empty_like(self.max_val)
-            ops.iao_observe(input, 1, 0, True, 0.0, cur_min, cur_max)
-            dp.allreduce_minmax(cur_min, cur_max, self._mn_sync_group)
-            ops.iao_observe(torch.cat([cur_min.reshape(-1), cur_max.reshape(-1)]), 1, self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1),
-                            self.min_val, self.max_val)
+            cur = _global_ranges([(input, _producer_minmax(input))], self._mn_sync_group)
+            ops.iao_observe_partials((cur, 1), self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1), self.min_val, self.max_val)
         elif rows == 1 and _producer_minmax(input) is not None and self._kind in (0, 1):
             # the kernel that produced this activation left per-block (min, max): the same update without a pass over the tensor
             ops.iao_observe_partials(_producer_minmax(input), self._kind, self.num_flag == 0, getattr(self, "momentum", 0.1), self.min_val, self.max_val)
@@ -190,8 +209,10 @@ class Quantizer(nn.Module):
         if not self.qaft and self.training:
             obs = self.observer
             mm = _producer_minmax(input)
-            if (not self.union and mm is not None and isinstance(obs, ObserverBase) and obs.q_level == "L" and obs._kind in (0, 1) and not obs._mn_sync
-                    and 2 <= self.bits <= 24):
+            if (not self.union and isinstance(obs, ObserverBase) and obs.q_level == "L" and obs._kind in (0, 1) and 2 <= self.bits <= 24 and _synced(obs)
+                    and torch.is_tensor(input) and input.is_cuda):
+                mm = (_global_ranges([(input, mm)], obs._mn_sync_group), 1)          # data parallel: the global batch's range as a one-block partials buffer
+            if (not self.union and mm is not None and isinstance(obs, ObserverBase) and obs.q_level == "L" and obs._kind in (0, 1) and 2 <= self.bits <= 24):
                 # the producing kernel left per-block (min, max): observer update + update_qparams in one launch, no pass over the activation
                 self.q_type = self._q_type_static
                 qp = ops.iao_observe_partials_qparams(mm, obs._kind, obs.num_flag == 0, getattr(obs, "momentum", 0.1), obs.min_val, obs.max_val, self.bits,
@@ -619,13 +640,16 @@ class QuantAdd(nn.Module):
         if (torch.is_tensor(res) and torch.is_tensor(shortcut) and res.is_cuda and shortcut.is_cuda and res.dtype == torch.float32 and shortcut.dtype == torch.float32
                 and res.shape == shortcut.shape and res.is_contiguous() and shortcut.is_contiguous() and res.numel() % 4 == 0 and res.numel() > 0
                 and 2 <= q.bits <= 24 and type(obs_r) is type(obs_s) and getattr(obs_r, "_kind", None) in (0, 1) and obs_r.q_level == "L" and obs_s.q_level == "L"
-                and getattr(q.observer, "q_level", None) == "L" and hasattr(q.observer, "min_val") and not getattr(obs_r, "_mn_sync", False) and not getattr(obs_s, "_mn_sync", False)
+                and getattr(q.observer, "q_level", None) == "L" and hasattr(q.observer, "min_val") and _synced(obs_r) == _synced(obs_s)
                 and getattr(obs_r, "momentum", 0.1) == getattr(obs_s, "momentum", 0.1)):
             # the same bookkeeping and arithmetic in three launches instead of nine (+ one instead of two in backward)
             update = (not q.qaft) and q.training
             if update:
                 q.q_type = q._q_type_static
             pr, ps = (ops._valid_minmax(res), ops._valid_minmax(shortcut)) if (_PRODUCER_MINMAX and self.training) else (None, None)
+            if _synced(obs_r):                             # data parallel: both inputs' ranges over the global batch, one collective for the two
+                cur = _global_ranges([(res, pr), (shortcut, ps)], obs_r._mn_sync_group)
+                pr, ps = (cur[0:2], 1), (cur[2:4], 1)
             if pr is not None and ps is not None:          # both producers left (min, max) partials: the two input observers need no pass over the tensors
                 qp = ops.iao_qadd_observe_partials(pr, ps, obs_r, obs_s, q, update)
             else:

@@ -167,7 +167,9 @@ class GraphedTrainStep:
     world == 1: one graph = forward + loss + zero_grad + backward + Adam.
     world  > 1: graph A = forward + loss + zero_grad + backward + packing of all gradients into one flat bucket (already
     divided by the world size); the RCCL all-reduce of that bucket runs eagerly on the same stream; graph B = Adam reading
-    the reduced bucket.  (nin_gc: one 2.4 MB collective per step.)
+    the reduced bucket.  (nin_gc: one 2.4 MB collective per step.)  IAO models whose activation observers reduce their
+    range over the ranks (dp.sync_observers) are captured in SEGMENTS cut at those collectives -- ``self.segments`` --
+    and replayed as segment, range collective, segment, ..., graph A, gradient all-reduce, graph B.
 
     Data is fed through the static tensors ``self.data`` / ``self.target`` (``copy_`` new batches into them); ``self.loss`` /
     ``self.output`` hold the results of the last replay.  The optimizer must be ``micronet_amd.optim.Adam``: its step count and every
@@ -185,23 +187,20 @@ class GraphedTrainStep:
         self.model, self.optimizer = model, optimizer
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
-        self._host_sync = self.world > 1 and dist.get_backend(group) != "nccl"
+        if not data.is_cuda:
+            raise RuntimeError("GraphedTrainStep: HIP graphs need device tensors (got %s); use the eager DP step (dp.train_step_dp)" % data.device)
+        from micronet_amd import dp
+        self.dp = dp.active(group)            # gradient all-reduce between graph A and graph B (more than one rank, or the MN_DP_SINGLE=1 measurement mode)
+        self._host_sync = self.dp and dist.get_backend(group) != "nccl"
         self.data, self.target = data.clone(), target.clone()
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.collectives_in_graph = False
-        if self.world > 1 and any(getattr(m, "_mn_sync", False) for m in model.modules()):
-            # The range collectives of synced IAO observers (dp.sync_observers: one 2-float MAX all-reduce per activation quantizer, each needed before the next
-            # layer can run) sit INSIDE forward.  RCCL collectives issued on the capturing stream are recorded into the graph, so the step CAN be captured with
-            # them -- but that path has never run on this stack (the build boxes have one GPU; two ranks on one device are refused by RCCL, gloo reduces on the
-            # host and cannot be captured), and a capture that fails on some ranks only would dead-lock the job.  It is therefore opt-in (MN_IAO_GRAPH_DP=1, nccl
-            # only); by default such models run the eager data-parallel step (dp.GradSync: bucketed all-reduce overlapped with backward), which callers reach by
-            # catching this error (bench.py does).
-            import os
-            backend = dist.get_backend(group)
-            if os.environ.get("MN_IAO_GRAPH_DP", "") != "1" or backend != "nccl":
-                raise RuntimeError("GraphedTrainStep: the model has cross-rank observer collectives inside forward (backend %s): use the eager DP step "
-                                   "(set MN_IAO_GRAPH_DP=1 to capture them with nccl)" % backend)
-            self.collectives_in_graph = True
+        # Synced IAO observers (dp.sync_observers) put one 2-float MAX all-reduce per activation quantizer INSIDE forward, each needed before the next layer can
+        # run.  The step is then captured in SEGMENTS: the capture is cut at every such collective (dp.allreduce_minmax -> self._cut), a replayed step is
+        # segment, collective, segment, ... with the last segment holding the rest of forward, the loss and the whole backward.  The collectives stay ordinary
+        # torch.distributed calls between replays (any backend: RCCL enqueues them on the device behind the segment, no host round trip), so nothing depends on
+        # the backend being able to record a collective into a graph.
+        self.segments = []                    # [(graph, operand of the collective that follows it, group)]
+        self._segmented = self.dp and any(getattr(m, "_mn_sync", False) for m in model.modules())
         if not hasattr(optimizer, "capturable"):
             raise TypeError("GraphedTrainStep needs micronet_amd.optim.Adam")
         optimizer.capturable = True
@@ -214,22 +213,39 @@ class GraphedTrainStep:
                 optimizer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         self.flat = None
+        import gc
+        from micronet_amd import dp
+        gc.collect()
+        torch.cuda.empty_cache()
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()             # ONE capture stream for all segments: backward's nodes run on the stream their forward ran on
+        cap.wait_stream(torch.cuda.current_stream())
+        self.graph_a = torch.cuda.CUDAGraph()
+        self._capturing = self.graph_a
         try:
-            with torch.cuda.graph(self.graph_a):
-                self._fwd_bwd()
-                if self.world == 1:
-                    optimizer.step()
-                else:
-                    self.flat = torch.cat([p.grad.reshape(-1) for p in self.params])
-                    self.flat.div_(self.world)
-        except Exception as e:          # noqa: BLE001 -- a failed capture (e.g. collectives the backend cannot record) must leave a usable process behind
+            with torch.cuda.stream(cap):
+                self._capturing.capture_begin(pool=pool)
+                try:
+                    if self._segmented:
+                        dp._segment_cut = lambda buf, group: self._cut(buf, group, pool)
+                    self._fwd_bwd()
+                    if not self.dp:
+                        optimizer.step()
+                    else:
+                        self.flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+                        self.flat.div_(self.world)
+                finally:
+                    dp._segment_cut = None
+                    self._capturing.capture_end()
+            self.graph_a = self._capturing    # the LAST segment (the only one without range collectives)
+        except Exception as e:          # noqa: BLE001 -- a failed capture must leave a usable process behind
             torch.cuda.synchronize()
             optimizer.capturable = False
             raise RuntimeError("GraphedTrainStep: capture failed (%s: %s); use the eager step" % (type(e).__name__, str(e)[:200])) from e
-        if self.world > 1:
+        torch.cuda.current_stream().wait_stream(cap)
+        if self.dp:
             self._captured_grads = [p.grad for p in self.params]   # graph A writes these on every replay: keep them allocated
             off = 0
             for p in self.params:             # Adam reads the reduced bucket in place
@@ -250,7 +266,7 @@ class GraphedTrainStep:
         self.loss.backward()
 
     def _reduce_eager(self):
-        if self.world > 1:
+        if self.dp:
             import torch.distributed as dist
             flat = torch.cat([p.grad.reshape(-1) for p in self.params]).div_(self.world)
             dist.all_reduce(flat, group=self.group)
@@ -259,18 +275,32 @@ class GraphedTrainStep:
                 p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
 
+    def _cut(self, buf, group, pool):
+        """End the segment being captured at a range collective on ``buf`` (allocated by the segment: a fixed address of the graphs' pool) and begin the next."""
+        self._capturing.capture_end()
+        self.segments.append((self._capturing, buf, group))
+        self._capturing = torch.cuda.CUDAGraph()
+        self._capturing.capture_begin(pool=pool)
+
     def step(self):
         self.optimizer.refresh_hyper()        # lr / weight_decay edits of the training loop reach the captured Adam launch
-        self.graph_a.replay()
-        if self.world > 1:
+        if self.dp:
             import torch.distributed as dist
+            # gloo only (the functional check of this path on one GPU): its collective on a device tensor does not order itself behind a freshly launched graph,
+            # hence the host synchronisation.  RCCL enqueues each collective behind the preceding replay on the device (event wait on the current stream) and
+            # the next replay behind the collective: no host round trip in the step.
+            for g, buf, group in self.segments:
+                g.replay()
+                if self._host_sync:
+                    torch.cuda.current_stream().synchronize()
+                dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+            self.graph_a.replay()
             if self._host_sync:
-                # gloo only (the CPU-side functional check of this path): its collective on a device tensor does not order itself behind
-                # a freshly launched graph.  RCCL enqueues the all-reduce behind graph A on the device (event wait on the current
-                # stream) and graph B behind the all-reduce: no host round-trip in the step.
                 torch.cuda.current_stream().synchronize()
             dist.all_reduce(self.flat, group=self.group)
             self.graph_b.replay()
+        else:
+            self.graph_a.replay()
         return self.loss, self.output
 
     def finish(self):

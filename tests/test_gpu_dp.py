@@ -2,7 +2,8 @@
 collective layer is the same torch.distributed API) vs one process on the concatenated batch.
   * IAO net without BatchNorm: with dp.sync_observers every activation-quantizer range / scale equals the single-process full-batch one BIT FOR BIT
     (SURVEY 8e ii), and the all-reduced gradients equal the full-batch gradients to float round-off;
-  * wbwtab nin_gc (packed sign activations, lazy gradients, fused blocks): two steps run, parameters stay bit-identical across the ranks."""
+  * wbwtab nin_gc (packed sign activations, lazy gradients, fused blocks): two steps run, parameters stay bit-identical across the ranks;
+  * the graph-replayed IAO step (forward captured in segments between the range collectives) vs the eager data-parallel step."""
 import os
 import sys
 
@@ -46,6 +47,46 @@ def _worker(rank, world, port, q, what):
         if rank == 0:
             q.put(({k: v.cpu().numpy().copy() for k, v in model.state_dict().items() if "activation_quantizer" in k},
                    [p.grad.cpu().numpy().copy() for p in model.parameters()]))
+    elif what.startswith("segmented"):
+        # the graph-replayed data-parallel step of an IAO model (range collectives inside forward -> captured in segments) next to the eager DP step: learning rate 0
+        # (parameters frozen, observers and BN statistics still move), so the two runs stay comparable step by step
+        from micronet_amd.train import GraphedTrainStep
+        from micronet.compression.quantization.wqaq.iao import quantize as Q
+
+        def fresh():
+            if what == "segmented_resnet18":
+                torch.manual_seed(7)
+                net, kw = build_model("resnet18"), dict(a_bits=4, w_bits=4, q_type=0, q_level=0)
+            else:
+                net, kw = _iao_net(), dict(a_bits=8, w_bits=8, q_type=1, q_level=0)
+            m = Q.prepare(net, inplace=True, **kw).cuda().train()
+            dp.broadcast_parameters(m)
+            assert dp.sync_observers(m) > 0
+            return m, make_optimizer(m, 0.0, 0.0)
+        m1, o1 = fresh()
+        sync = dp.GradSync(m1)
+        for _ in range(5):
+            dp.train_step_dp(m1, o1, sync, xs, ys)
+        m2, o2 = fresh()
+        g = GraphedTrainStep(m2, o2, xs, ys, warmup=3)           # 3 eager steps (collectives included), then replays
+        for _ in range(2):
+            loss, _ = g.step()
+        g.finish()
+        torch.cuda.synchronize()
+        sd1, sd2 = m1.state_dict(), m2.state_dict()
+        ranges = [k for k in sd1 if k.endswith(("min_val", "max_val", "scale", "zero_point"))]
+        bad = [k for k in ranges if not torch.equal(sd1[k], sd2[k])]
+        gerr = max(float((p1.grad - p2.grad).abs().max()) / max(float(p1.grad.abs().max()), 1e-12) for p1, p2 in zip(m1.parameters(), m2.parameters()))
+        for grp in o2.param_groups:                               # and two real steps: the ranks stay bit-identical
+            grp["lr"] = 0.01
+        for _ in range(2):
+            loss, _ = g.step()
+        flat = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
+        other = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        if rank == 0:
+            q.put(dict(segments=len(g.segments), ranges=len(ranges), bad=bad, gerr=gerr, loss=float(loss), in_sync=bool(torch.equal(other[0], other[1])),
+                       moved=float((flat - torch.cat([p.detach().reshape(-1) for p in m1.parameters()])).abs().max())))
     else:
         from micronet.compression.quantization.wbwtab import quantize as Q
         model = Q.prepare(build_model("nin_gc"), inplace=True, A=2, W=3).cuda().train()
@@ -99,3 +140,61 @@ def test_iao_observer_ranges_and_gradients_match_the_global_batch():
 
 def test_wbwtab_fused_net_stays_in_sync_across_ranks():
     assert _run("wbwtab") is True
+
+
+@pytest.mark.parametrize("what", ["segmented", "segmented_resnet18"])
+def test_segmented_graph_step_equals_the_eager_dp_step(what):
+    """IAO data parallel, graph-replayed: forward is captured in segments cut at the observers' range collectives (train.GraphedTrainStep).  With the learning rate
+    at 0 every observer range / scale / zero point after 3 eager + 2 replayed steps is BIT-identical to five eager DP steps, the reduced gradients agree to float
+    round-off (atomic accumulation order), and with a real learning rate the two ranks' parameters stay bit-identical."""
+    r = _run(what)
+    print(what, r)
+    assert r["segments"] >= 4 and r["ranges"] >= 8
+    assert r["bad"] == [], r["bad"][:5]
+    assert r["gerr"] <= 2e-5, r["gerr"]
+    assert r["in_sync"] and r["loss"] == r["loss"] and 0 < r["moved"] <= 0.021
+
+
+def _single_rank_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MN_DP_SINGLE="1")
+    from micronet_amd import dp
+    from micronet_amd.train import GraphedTrainStep, make_optimizer, synth_batch
+    from micronet.compression.quantization.wqaq.iao import quantize as Q
+    torch.cuda.set_device(0)
+    x, y = synth_batch(16, device="cuda")
+
+    def fresh():
+        m = Q.prepare(_iao_net(), inplace=True, a_bits=8, w_bits=8, q_type=1, q_level=0).cuda().train()
+        return m, make_optimizer(m, 0.01, 0.0)
+    m1, o1 = fresh()
+    g1 = GraphedTrainStep(m1, o1, x, y, warmup=2)            # no process group yet: the ordinary single-GPU step, one graph
+    l1 = [float(g1.step()[0]) for _ in range(3)]
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    assert dp.active()
+    m2, o2 = fresh()
+    assert dp.sync_observers(m2) > 0
+    g2 = GraphedTrainStep(m2, o2, x, y, warmup=2)            # the data-parallel step on one rank: segments + range collectives + gradient all-reduce + graph B
+    l2 = [float(g2.step()[0]) for _ in range(3)]
+    torch.cuda.synchronize()
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    keys = [k for k in sd1 if k.endswith(("min_val", "max_val", "scale", "zero_point"))]
+    q.put(dict(segments=(len(g1.segments), len(g2.segments)), dp=(g1.dp, g2.dp), losses=(l1, l2), bad=[k for k in keys if not torch.equal(sd1[k], sd2[k])],
+               perr=max(float((a - b).abs().max()) for a, b in zip(m1.parameters(), m2.parameters()))))
+    dist.destroy_process_group()
+
+
+def test_single_rank_dp_step_equals_the_plain_step():
+    """MN_DP_SINGLE=1 (bench.py's `dp_single_rank` leg): the whole data-parallel step on an RCCL group of ONE rank.  A global range over one rank is the local range
+    and a mean over one rank the gradient itself, so it must reproduce the ordinary single-GPU step: ranges bit for bit, parameters to Adam-amplified round-off."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(35500 + os.getpid() % 2000, q))
+    p.start()
+    r = q.get(timeout=300)
+    p.join(timeout=300)
+    assert p.exitcode == 0
+    print(r)
+    assert r["segments"][0] == 0 and r["segments"][1] >= 4 and r["dp"] == (False, True)
+    assert r["bad"] == [], r["bad"][:5]
+    assert r["perr"] <= 0.05 and all(abs(a - b) <= 2e-2 * max(1.0, abs(a)) for a, b in zip(*r["losses"])), r
