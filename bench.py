@@ -549,6 +549,15 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
     return out, detail
 
 
+def drain_c_stdio():
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:          # noqa: BLE001
+        pass
+
+
 def write_detail(detail, args):
     """Per-kernel tables, step_level and the timed windows of every measured workload: a side file, NOT the final stdout line."""
     path = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
@@ -671,11 +680,16 @@ def main():
         cpu_more = cpu_more_legs(args, primary) if (world == 1 and not args.no_cpu_baseline and not args.only) else None
         out, detail = compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info, cpu_more, dp1)
         out["detail_file"] = write_detail(detail, args)
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
     if world > 1:
+        if rank != 0:
+            drain_c_stdio()          # (whatever a library buffered on the other ranks goes out BEFORE rank 0's line, not at their exit)
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # The driver parses the LAST stdout line.  RCCL prints a version banner through C stdio on communicator creation (fully buffered on a pipe, i.e. flushed at
+        # process exit -- BEHIND a line printed from Python): drain every C stream first, after the process group is gone, then print the line.
+        drain_c_stdio()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -202,6 +202,23 @@ def test_bench_final_line_stays_parsable():
     assert set(detail["sections"]) >= {"c2", "c1", "c3", "c4", "c5"} and "kernels" in detail["sections"]["c4"]
 
 
+def test_bench_line_is_printed_behind_what_libraries_buffered_in_c_stdio():
+    """Round 5: RCCL prints a version banner through C stdio when a communicator is created; on a pipe that buffer is flushed at process exit, i.e. BEHIND a line
+    printed from Python -- and the driver parses the LAST stdout line.  bench.drain_c_stdio() empties the C streams first."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, importlib.util, json\n"
+            "spec = importlib.util.spec_from_file_location('mn_bench', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "ctypes.CDLL(None).printf(b'RCCL version : banner\\n')\n"
+            "b.drain_c_stdio()\n"
+            "print(json.dumps({'metric': 'x'}), flush=True)\n") % os.path.join(root, "bench.py")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines[-1] == '{"metric": "x"}' and lines[0].startswith("RCCL version"), (r.stdout, r.stderr[-300:])
+
+
 @pytest.mark.parametrize("scheme,kw", [("wqaq.dorefa", dict(a_bits=2, w_bits=2)), ("wqaq.iao", dict(a_bits=4, w_bits=4, q_type=0, q_level=0))])
 def test_prepared_resnet_pickles(scheme, kw):
     """The reference saves whole prepared models (wqaq/dorefa/quant_model_test/quant_model_para.py:67,84): torch.save / torch.load of a prepared resnet18 must
