@@ -193,29 +193,46 @@ __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
     const int row0 = strip * p.R;
     const int m0 = (cblk * 4 + wave) * 16 * MT;
 
+    float* bs = reinterpret_cast<float*>(ktab + C1B_KP);                                           // [64 MT] the block's bias
     c1_stage(p, xs, n, row0);
     for (int k = tid; k < C1B_KP; k += 256) ktab[k] = k < p.K ? c1_koff(p, k) : -1;
-    // A fragments: three exact bf16 terms of w[m0 + t * 16 + j][ks * 32 + kg * 8 .. + 7]
+    for (int i = tid; i < 64 * MT; i += 256) { const int m = cblk * 64 * MT + i; bs[i] = (p.bias && m < p.O) ? p.bias[m] : 0.f; }
+    // A fragments: three exact bf16 terms of w[m0 + t * 16 + j][ks * 32 + kg * 8 .. + 7].  The block's weight rows are one contiguous range: they come through LDS
+    // (the tile buffer, not yet in use: 16 MT rows x K <= 64 x 96 floats fit) one wave's rows per round, read from memory coalesced -- a lane fetching its 24 MT
+    // elements itself touches a different 300-byte row per lane and element (measured on nin_gc's first layer: ~20 us of a 113 us kernel, all 512 blocks at once).
     u32x4 wa[3][3][MT];
+    float* wl = reinterpret_cast<float*>(im);
+    for (int r = 0; r < 4; ++r) {
+        if (r) __syncthreads();          // the previous round's rows are consumed
+        const int row_r = (cblk * 4 + r) * 16 * MT;
+        const int nrows = p.O - row_r < 16 * MT ? p.O - row_r : 16 * MT;
+        const int cnt = nrows > 0 ? nrows * p.K : 0;
+        const float* src = p.wp + (int64_t)row_r * p.K;
+        for (int i = tid; i < cnt; i += 256) wl[i] = src[i];
+        __syncthreads();
+        if (wave == r) {
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks)
+            for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const int m = m0 + t * 16 + j;
-            float t0[8], t1[8], t2[8];
+                for (int t = 0; t < MT; ++t) {
+                    const int lrow = t * 16 + j;
+                    const bool mv = row_r + lrow < p.O;
+                    float t0[8], t1[8], t2[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = ks * 32 + kg * 8 + e;
-                const float v = (m < p.O && k < p.K) ? p.wp[(int64_t)m * p.K + k] : 0.f;
-                t0[e] = mn_bf16_head(v);
-                const float r1 = v - t0[e];
-                t1[e] = mn_bf16_head(r1);
-                t2[e] = r1 - t1[e];
-            }
-            wa[0][ks][t] = u32x4{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3]), mn_pack_bf16x2(t0[4], t0[5]), mn_pack_bf16x2(t0[6], t0[7])};
-            wa[1][ks][t] = u32x4{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3]), mn_pack_bf16x2(t1[4], t1[5]), mn_pack_bf16x2(t1[6], t1[7])};
-            wa[2][ks][t] = u32x4{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3]), mn_pack_bf16x2(t2[4], t2[5]), mn_pack_bf16x2(t2[6], t2[7])};
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = ks * 32 + kg * 8 + e;
+                        const float v = (mv && k < p.K) ? wl[lrow * p.K + k] : 0.f;
+                        t0[e] = mn_bf16_head(v);
+                        const float r1 = v - t0[e];
+                        t1[e] = mn_bf16_head(r1);
+                        t2[e] = r1 - t1[e];
+                    }
+                    wa[0][ks][t] = u32x4{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3]), mn_pack_bf16x2(t0[4], t0[5]), mn_pack_bf16x2(t0[6], t0[7])};
+                    wa[1][ks][t] = u32x4{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3]), mn_pack_bf16x2(t1[4], t1[5]), mn_pack_bf16x2(t1[6], t1[7])};
+                    wa[2][ks][t] = u32x4{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3]), mn_pack_bf16x2(t2[4], t2[5]), mn_pack_bf16x2(t2[6], t2[7])};
+                }
         }
+    }
     __syncthreads();
     // (this wave expands k = 24 wave .. 24 wave + 23 of every pixel; keeping the 24 wave-uniform patch offsets in scalar registers instead of re-reading the LDS table
     //  spilled 59 SGPRs into an already full vector register file: the table read stays)
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + t * 16 + kg * 4 + r;
                     if (m < p.O) {
-                        const float bb = p.bias ? p.bias[m] : 0.f;
+                        const float bb = bs[wave * 16 * MT + t * 16 + kg * 4 + r];
                         float* dst = p.y + (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol;
                         float4 v = make_float4(acc[0][t][r] + bb, acc[1][t][r] + bb, acc[2][t][r] + bb, acc[3][t][r] + bb);
                         if (p.relu) { v.x = qa_relu(v.x); v.y = qa_relu(v.y); v.z = qa_relu(v.z); v.w = qa_relu(v.w); }
@@ -605,7 +622,7 @@ int c1_fwd_act(const mn_conv_geom* g, const float* x, const float* w, const floa
     p.x = x; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0; p.da = nullptr;
     p.relu = relu; p.mm = mm;
     static const bool f32_path = MN_ENV("MN_C1_F32") != nullptr;          // A/B knob: the fp32-MFMA forward
-    const size_t lds_b = (size_t)p.xs_bytes + (size_t)3 * 64 * C1B_LD * 2 + C1B_KP * 4;
+    const size_t lds_b = (size_t)p.xs_bytes + (size_t)3 * 64 * C1B_LD * 2 + C1B_KP * 4 + 64 * 4 * 4;          // patch | tile (weight rows before the loop) | k table | bias
     if (!f32_path && lds_b <= 80 * 1024) {          // three-term bf16 forward (reads the weights as they are: no pack launch)
         p.wp = w;
         mn_set_last_kernel("k_c1b_fwd<%d>", pl.MT);
