@@ -396,6 +396,29 @@ int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float* da, const 
 int mn_conv2d_bwd_weight_first_qa(const mn_conv_geom* g, const float* dq, const float* y, const float* chan, const float* sums, int a_bits, int quant,
                                   int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
 
+/* One-pass backward of the first block in training mode (round 5; replaces mn_bnsign_bwd_sums + mn_conv2d_bwd_weight_first_bn, resp. mn_qa_bwd_sums +
+ * mn_conv2d_bwd_weight_first_qa: ONE pass over (da, y) instead of two).  The BatchNorm backward is linear in dz (= da with the clip-STE / ReLU / quantizer masks):
+ * with f_k(pixel) the im2col row of x and f_K = 1,  A[o][k] = sum dz f_k,  S1 = sum dz,  S2 = sum dz zhat = invstd (w[o,:] . A[o,:] + (b - mean) S1),
+ * B[o][k] = sum zhat f_k = invstd ((w G)[o][k] + (b - mean) P[k]),  dw = gamma invstd (A - S1 P / n - (S2 / n) B),  dgamma = S2,  dbeta = S1,
+ * where G = sum f f^T and P = sum f depend on x alone: mn_conv2d_first_xgram writes them as gram [80][80] doubles (row / column K = P, gram[K][K] = n; K =
+ * C KH KW <= 76).  Geometry: mn_conv2d_first_supported(g, 2); ws of the backward: mn_conv2d_ws_bytes(g, 2, 0) bytes; w, bias (nullable): the convolution's
+ * parameters (torch/nn/modules/conv.py via wbwtab/quantize.py:251, dorefa/quantize.py:206: the first layer is not quantised).  dbias (nullable) = sum dy, zero
+ * but for the rounding of the saved mean.  Results agree with the two-pass path to fp32 rounding (not bit for bit: a different summation order). */
+/* ... and the FORWARD statistics of the BatchNorm behind that convolution from the same Gram data, without a pass over y (mn_conv2d_first_gram_bnstats: save =
+ * {mean, invstd} [2][O] and the running update of nn.BatchNorm2d in training mode: mean = w . P / n + b, biased variance = w (G - P P^T / n) w^T / n); mn_bnsign_apply
+ * = the apply pass of mn_bnsign_fwd (out8 = 0) / mn_bnsign_fwd_i8 (out8 = 1) with those statistics given. */
+int mn_conv2d_first_gram_bnstats(const mn_conv_geom* g, const float* w, const float* bias, const double* gram, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* save, mn_stream_t stream);
+int mn_bnsign_apply(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, void* a, int out8, mn_stream_t stream);
+int64_t mn_conv2d_first_xgram_ws_bytes(const mn_conv_geom* g);
+int mn_conv2d_first_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_conv2d_bwd_first_bn_gram(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta, const float* w,
+                                const float* bias, const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                                int64_t ws_bytes, mn_stream_t stream);
+int mn_conv2d_bwd_first_qa_gram(const mn_conv_geom* g, const float* dq, const float* y, const float* chan, int a_bits, int quant, const float* w, const float* bias,
+                                const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
+                                mn_stream_t stream);
+
 /* ------------------------------------------------------------------ conv + BatchNorm2d + BinaryActivation, fused, on packed signs
  * The whole W/A-binary block of the reference -- `relu(bn(conv(x)))` with the ReLU replaced by BinaryActivation
  * (models/nin_gc.py:53-59; wbwtab/quantize.py:79-94, 181-195) -- for pointwise (1x1, stride 1) convolutions whose input is

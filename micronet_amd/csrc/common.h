@@ -231,8 +231,9 @@ __device__ __forceinline__ void mn_row_sums(const double* __restrict__ src, int 
 }
 struct QaInterval { float lo, hi; };          // pass iff lo <= v && v <= hi (an empty set is lo = 1, hi = 0)
 // zfun(v) -> z; the domain is the integers / float keys w in [-R, R], v = vof(w).  quant: the clamp condition applies.
+// sgn: the BinaryActivation's clip-STE instead (wbwtab/quantize.py:26-36): pass iff -1 < z < 1.
 template <class ZF, class VF>
-__device__ __forceinline__ QaInterval qa_mask_interval(int32_t R, ZF zfun, VF vof, int quant) {
+__device__ __forceinline__ QaInterval qa_mask_interval(int32_t R, ZF zfun, VF vof, int quant, bool sgn = false) {
     const bool flip = zfun(vof(R)) < zfun(vof(-R));          // z decreases with v: search in w = -v
     auto zw = [&](int64_t w) { return zfun(vof((int32_t)(flip ? -w : w))); };
     auto first = [&](bool second) {          // smallest w in [-R, R] with the (monotone) predicate true, R + 1 if none
@@ -240,7 +241,7 @@ __device__ __forceinline__ QaInterval qa_mask_interval(int32_t R, ZF zfun, VF vo
         while (lo < hi) {
             const int64_t mid = lo + ((hi - lo) >> 1);
             const float z = zw(mid);
-            const bool pr = second ? !((z > 0.f ? z : 0.f) * 0.1f <= 1.f) && z > 0.f : z > 0.f;
+            const bool pr = sgn ? (second ? !(z < 1.f) && z > -1.f : z > -1.f) : (second ? !((z > 0.f ? z : 0.f) * 0.1f <= 1.f) && z > 0.f : z > 0.f);
             if (pr) hi = mid; else lo = mid + 1;
         }
         return lo;

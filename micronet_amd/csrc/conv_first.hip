@@ -343,7 +343,9 @@ __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
 // those registers, the step is written to the wave's [16 MT rows][32 pixels] image (rows padded to 160 B: conflict-free b128
 // fragment reads) and read back as fragments -- no block barrier inside a tile, the next step's loads fly during the MFMAs.
 #define C1_RSA 160
-template <int MT, int BN>
+// DZ (with BN): the rows are dz alone (the clip-STE / ReLU masks applied, NOT the BatchNorm backward) and im2col column K is a column of ones, so that D[o][K] =
+// sum dz: the one-pass backward of the first block (k_c1_bn_final below finishes it from the Gram data of x).
+template <int MT, int BN, int DZ = 0>
 __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
     int koff[5];
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) koff[nt] = c1_koff(p, nt * 16 + j);     // B[pixel][k = nt*16 + j]
+    const int one_nt = (DZ && (p.K & 15) == j) ? (p.K >> 4) : -1;          // DZ: this lane's column of n-tile one_nt is the column of ones
 
     // staging roles: row sr + 8 i of the wave's 16 MT rows, pixels 4 sq .. 4 sq + 3 of the 32-pixel step
     constexpr int NR = 2 * MT;
@@ -382,6 +385,13 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
             ctab[r * 8 + 4] = p.training ? p.sums[mc] / p.n_f : 0.f;
             ctab[r * 8 + 5] = p.training ? p.sums[p.O + mc] / p.n_f : 0.f;
             ctab[r * 8 + 6] = BN == 2 ? p.chan[8 * p.O + mc] : 0.f; ctab[r * 8 + 7] = 0.f;
+            if (BN == 1 && DZ && p.interval) {          // the sign's clip-STE |z| < 1 as one interval of y per channel (as the DoReFa block below)
+                const float mean = ctab[r * 8 + 0], invstd = ctab[r * 8 + 1], ga = ctab[r * 8 + 2], be = ctab[r * 8 + 3];
+                if (fabsf(mean) <= 1.0e9f && fabsf(invstd) <= 1.0e9f && fabsf(ga) <= 1.0e9f && fabsf(be) <= 1.0e9f && ga != 0.f && invstd > 0.f) {
+                    const QaInterval iv = qa_mask_interval(0x7f7fffff, [&](float y) { return ((y - mean) * invstd) * ga + be; }, [](int32_t k) { return mn_keyf(k); }, 1, true);
+                    ctab[r * 8 + 2] = iv.lo; ctab[r * 8 + 3] = iv.hi; ctab[r * 8 + 7] = 1.f;
+                }
+            }
             if (BN == 2 && p.interval) {
                 // the ReLU mask and the quantizer's clamp test as ONE interval of y per channel (qa_mask_interval, common.h): the per-element z, relu, 0.1 a and their
                 // selects (10 of ~21 VALU instructions per element of this VALU-bound fold) become two compares.  A channel whose constants are not finite (or
@@ -427,7 +437,13 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
                     const float4 c0 = *reinterpret_cast<const float4*>(ctab + (sr + 8 * i) * 8);        // mean, invstd, gamma, beta
                     const float2 c1 = *reinterpret_cast<const float2*>(ctab + (sr + 8 * i) * 8 + 4);    // k1, k2
                     const float cgi_ = BN == 2 ? ctab[(sr + 8 * i) * 8 + 6] : c0.z * c0.y;
-                    const bool ivl = BN == 2 && ctab[(sr + 8 * i) * 8 + 7] != 0.f;          // this row's masks are an interval of y: c0.z = lo, c0.w = hi
+                    const bool ivl = (BN == 2 || DZ) && ctab[(sr + 8 * i) * 8 + 7] != 0.f;          // this row's masks are an interval of y: c0.z = lo, c0.w = hi
+                    if (DZ && ivl) {
+                        // one-pass backward: dz = the masked gradient; the quantizer's STE factor ((g s) / s) * 0.1 is applied as 0.1 by k_c1_bn_final (linear; the
+                        // s / s round trip is dropped: <= 2^-23 relative per element) -- 4 VALU instructions per element instead of ~20 in a kernel that was VALU-bound
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = (yv[e] >= c0.z && yv[e] <= c0.w) ? r[e] : 0.f;
+                    } else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float zh = (yv[e] - c0.x) * c0.y;
@@ -440,10 +456,10 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
                             if (BN == 2) dz = qa_dz_m(r[e], qa_relu(zz), zz, p.qs, p.qs_inv, p.quant);     // expression for expression k_qa_apply<1, 0>
                             else dz = (zz > -1.f && zz < 1.f) ? r[e] : 0.f;
                         }
-                        r[e] = cgi_ * (dz - c1.x - zh * c1.y);
+                        r[e] = DZ ? ((BN == 2 && p.quant) ? dz * 10.f : dz) : cgi_ * (dz - c1.x - zh * c1.y);          // (DZ: a row without interval, k_c1_bn_final scales by 0.1)
                     }
                 }
-                dbs[i] += (r[0] + r[1]) + (r[2] + r[3]);
+                if (!DZ) dbs[i] += (r[0] + r[1]) + (r[2] + r[3]);
                 *reinterpret_cast<float4*>(gsm + (sr + 8 * i) * C1_RSA + 16 * sq) = make_float4(r[0], r[1], r[2], r[3]);
             }
             fetch(st + 1 < nsteps ? st + 1 : st);
@@ -460,7 +476,8 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
 #pragma unroll
                 for (int nt = 0; nt < 5; ++nt) {
                     const float* src = xs + pb + koff[nt];
-                    const float b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+                    float b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+                    if (DZ && nt == one_nt) b0 = b1 = b2 = b3 = 1.f;
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
                         acc[t][nt] = MN_MFMA_F32(ga[t].x, b0, acc[t][nt]);
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
                 const int m = m0 + t * 16 + kq * 4 + r;
                 p.part[((int64_t)z * p.Opad + m) * 80 + nt * 16 + j] = acc[t][nt][r];
             }
-    if (p.want_db) {
+    if (!DZ && p.want_db) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             float v = dbs[i];
@@ -544,6 +561,204 @@ __global__ __launch_bounds__(256) void k_c1_reduce(const float* __restrict__ par
                 if (m < O) db[m] = (float)v;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ one-pass backward of the first block (round 5)
+// The BatchNorm backward is LINEAR in dz = (masked) da: with f_k(pixel) the im2col row of x (f_K = 1), A[o][k] = sum dz[o] f_k, S1 = A[o][K], P[k] = sum f_k,
+// G = sum f f^T and y[o] = w[o,:] . f + b[o]:
+//     S2 = sum dz zhat  = invstd (w[o,:] . A[o,:] + (b - mean) S1)
+//     B[o][k] = sum zhat f_k = invstd ((w G)[o][k] + (b - mean) P[k])
+//     dw[o][k] = gamma invstd (A[o][k] - S1 P[k] / n - (S2 / n) B[o][k]),   dgamma = S2,   dbeta = S1
+// so ONE pass over (da, y) -- k_c1_wgrad<.., DZ 1> -- replaces the sums pass (k_bns_partial<1> / k_qa_partial<1, 0>: 98 us on nin_gc at batch 256) AND the fold in
+// the backward-weight's operand load; G, P (76 x 76 numbers) come from x alone (k_c1_xgram: the c3 block's idea, iao_bnfuse.hip, applied to the image).
+#define C1G_TILE (15 * 256)          // floats per partial: the 15 tile pairs ta <= tb of the 80 x 80 Gram matrix
+__global__ __launch_bounds__(256) void k_c1_xgram(const C1Params p, float* __restrict__ gpart) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* xs = smem;
+    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + p.xs_bytes);          // [4 waves][C1G_TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kq = lane >> 4;
+    int koff[5];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) koff[nt] = c1_koff(p, nt * 16 + j);
+    const int one_nt = ((p.K & 15) == j) ? (p.K >> 4) : -1;
+    f32x4 acc[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = p.N * p.strips, ngroups = (p.R * p.W) >> 4;          // 16 pixels per group (R W % 32 == 0)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / p.strips, strip = tile - n * p.strips, row0 = strip * p.R;
+        __syncthreads();
+        c1_stage(p, xs, n, row0);
+        __syncthreads();
+        for (int gi = wave; gi < ngroups; gi += 4) {
+            // MFMA step e contracts the pixels 4 kq + e: the lane's value of feature tile t is at once A[i = j][kq] and B[kq][j]
+            const int pix = gi * 16 + 4 * kq;
+            const uint32_t prow = fd_div(pix, p.fd_w);
+            const int pb = (int)prow * p.PW + (pix - (int)prow * p.W);
+            float v[5][4];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                const float* src = xs + pb + koff[nt];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[nt][e] = (nt == one_nt) ? 1.f : src[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {          // (15 independent accumulators between two MFMAs on the same one)
+                int pr = 0;
+#pragma unroll
+                for (int ta = 0; ta < 5; ++ta)
+#pragma unroll
+                    for (int tb = ta; tb < 5; ++tb) {
+                        acc[pr] = MN_MFMA_F32(v[ta][e], v[tb][e], acc[pr]);
+                        ++pr;
+                    }
+            }
+        }
+    }
+    // the four waves' tiles summed in wave order: D[row 4 kq + r][col j]
+#pragma unroll
+    for (int pr = 0; pr < 15; ++pr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * C1G_TILE + pr * 256 + (4 * kq + r) * 16 + j] = acc[pr][r];
+    __syncthreads();
+    for (int i = tid; i < C1G_TILE; i += 256)
+        gpart[(int64_t)blockIdx.x * C1G_TILE + i] = ((red[i] + red[C1G_TILE + i]) + red[2 * C1G_TILE + i]) + red[3 * C1G_TILE + i];
+}
+// gram[a][b] (fp64, 80 x 80; row / column K = the feature sums P, gram[K][K] = n): fixed-order sum of the Z partials, both triangles written
+__global__ __launch_bounds__(256) void k_c1_xgram_final(const float* __restrict__ gpart, int Z, double* __restrict__ gram) {
+    __shared__ double red[4][64];
+    const int og = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + og;
+    double s = 0.0;
+    if (i < C1G_TILE) {
+        const float* src = gpart + i;
+        int z = zg;
+        for (; z + 28 < Z; z += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(z + 4 * u) * C1G_TILE];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; z < Z; z += 4) s += (double)src[(int64_t)z * C1G_TILE];
+    }
+    red[zg][og] = s;
+    __syncthreads();
+    if (zg == 0 && i < C1G_TILE) {
+        const double v = ((red[0][og] + red[1][og]) + red[2][og]) + red[3][og];
+        int pr = i >> 8, ta = 0;
+        while (pr >= 5 - ta) { pr -= 5 - ta; ++ta; }
+        const int tb = ta + pr, a = ta * 16 + ((i >> 4) & 15), b = tb * 16 + (i & 15);
+        gram[a * 80 + b] = v;
+        if (ta != tb) gram[b * 80 + a] = v;
+    }
+}
+// the end of the one-pass backward: block o sums its partial row A[o][0 .. 79] in the fixed order of k_c1_reduce and does the per-channel algebra above in fp64
+struct C1BnFin {
+    const float* part; int Z, O, K, Opad;
+    const float* w; const float* bias;
+    const float* save; const float* gamma;      // BatchNorm + sign: mean, invstd [2][O]; gamma
+    const float* chan;                          // or the DoReFa block's [9][O] constants (rows 2 .. 4: mean, invstd, gamma; row 8: gamma * invstd)
+    const double* gram; double n;
+    double scale;                               // of the rows the backward-weight contracted (0.1: the quantizer's STE factor; 1)
+    float* dw; float* dbias; float* dgamma; float* dbeta;
+};
+__global__ __launch_bounds__(320) void k_c1_bn_final(const C1BnFin f) {
+    __shared__ double red[4][80];
+    __shared__ double sA[80], sw[80];
+    const int o = blockIdx.x, t = threadIdx.x, col = t % 80, zg = t / 80;
+    {
+        const float* src = f.part + (int64_t)o * 80 + col;
+        const int64_t zs = (int64_t)f.Opad * 80;
+        double s = 0.0;
+        int z = zg;
+        for (; z + 28 < f.Z; z += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(z + 4 * u) * zs];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; z < f.Z; z += 4) s += (double)src[(int64_t)z * zs];
+        red[zg][col] = s;
+    }
+    if (t < 80) sw[t] = t < f.K ? (double)f.w[(int64_t)o * f.K + t] : 0.0;
+    __syncthreads();
+    if (t < 80) sA[t] = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) * f.scale;
+    __syncthreads();
+    if (t >= f.K) return;
+    float mean_f, invstd_f, cgi_f;
+    if (f.chan) { mean_f = f.chan[2 * f.O + o]; invstd_f = f.chan[3 * f.O + o]; cgi_f = f.chan[8 * f.O + o]; }
+    else { mean_f = f.save[o]; invstd_f = f.save[f.O + o]; cgi_f = f.gamma[o] * invstd_f; }
+    const double invstd = (double)invstd_f, cgi = (double)cgi_f, n = f.n;
+    const double bm = (f.bias ? (double)f.bias[o] : 0.0) - (double)mean_f;
+    const double S1 = sA[f.K];
+    double dot = 0.0, wg = 0.0;
+    {
+        int k = 0;
+        for (; k + 15 <= f.K; k += 15) {          // 15 Gram loads in flight (one at a time the loop is pure latency), added in order
+            double gv[15];
+#pragma unroll
+            for (int u = 0; u < 15; ++u) gv[u] = f.gram[(k + u) * 80 + t];
+#pragma unroll
+            for (int u = 0; u < 15; ++u) { dot += sw[k + u] * sA[k + u]; wg += sw[k + u] * gv[u]; }
+        }
+        for (; k < f.K; ++k) { dot += sw[k] * sA[k]; wg += sw[k] * f.gram[k * 80 + t]; }
+    }
+    const double S2 = invstd * (dot + bm * S1);
+    const double P = f.gram[f.K * 80 + t];
+    const double B = invstd * (wg + bm * P);
+    f.dw[(int64_t)o * f.K + t] = (float)(cgi * (sA[t] - S1 * P / n - (S2 / n) * B));
+    if (t == 0) {
+        if (f.dgamma) f.dgamma[o] = (float)S2;
+        if (f.dbeta) f.dbeta[o] = (float)S1;
+        if (f.dbias) {          // sum dy = -gamma invstd (S2 / n) sum zhat: zero but for the rounding of the saved mean
+            double wp = 0.0;
+            for (int k = 0; k < f.K; ++k) wp += sw[k] * f.gram[f.K * 80 + k];
+            f.dbias[o] = (float)(-cgi * (S2 / n) * (invstd * (wp + n * bm)));
+        }
+    }
+}
+
+// training-mode BatchNorm statistics of y = conv(x, w) + b WITHOUT a pass over y: mean[o] = w[o,:] . P / n + b[o], sum of squared deviations = w (G - P P^T / n) w^T
+// (fp64; the expressions behind it are k_bns_final_fwd's)
+struct C1Stats {
+    const float* w; const float* bias; const double* gram; int O, K; double n;
+    float eps, momentum; float* running_mean; float* running_var; float* save;
+};
+__global__ __launch_bounds__(128) void k_c1_gram_stats(const C1Stats f) {
+    __shared__ double sw[80], st[80];
+    const int o = blockIdx.x, t = threadIdx.x;
+    if (t < 80) sw[t] = t < f.K ? (double)f.w[(int64_t)o * f.K + t] : 0.0;
+    __syncthreads();
+    if (t < 80) {
+        double acc = 0.0;
+        if (t < f.K) {
+            const double pt = f.gram[f.K * 80 + t] / f.n;
+            int k = 0;
+            for (; k + 15 <= f.K; k += 15) {
+                double gv[15], pv[15];
+#pragma unroll
+                for (int u = 0; u < 15; ++u) { gv[u] = f.gram[(k + u) * 80 + t]; pv[u] = f.gram[f.K * 80 + k + u]; }
+#pragma unroll
+                for (int u = 0; u < 15; ++u) acc += sw[k + u] * (gv[u] - pv[u] * pt);
+            }
+            for (; k < f.K; ++k) acc += sw[k] * (f.gram[k * 80 + t] - f.gram[f.K * 80 + k] * pt);
+        }
+        st[t] = sw[t] * acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double ss = 0.0, wp = 0.0;
+        for (int k = 0; k < f.K; ++k) { ss += st[k]; wp += sw[k] * f.gram[f.K * 80 + k]; }
+        if (ss < 0.0) ss = 0.0;
+        const double mean = wp / f.n + (f.bias ? (double)f.bias[o] : 0.0);
+        const float var_b = (float)(ss / f.n);
+        f.save[o] = (float)mean;
+        f.save[f.O + o] = 1.0f / sqrtf(var_b + f.eps);
+        if (f.running_mean) f.running_mean[o] = (1.f - f.momentum) * f.running_mean[o] + f.momentum * (float)mean;
+        if (f.running_var) f.running_var[o] = (1.f - f.momentum) * f.running_var[o] + f.momentum * (float)(ss / (f.n - 1.0));
     }
 }
 
@@ -654,6 +869,17 @@ static void c1_launch_wgrad_mt(const C1Plan& pl, const C1Params& p, hipStream_t 
     else if (p.da) { raise_lds_limit((const void*)k_c1_wgrad<MT, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
     else { raise_lds_limit((const void*)k_c1_wgrad<MT, 0>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 0>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
 }
+template <int MT>
+static void c1_launch_wgrad_dz_mt(const C1Plan& pl, const C1Params& p, hipStream_t s) {
+    if (p.chan) { raise_lds_limit((const void*)k_c1_wgrad<MT, 2, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 2, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    else { raise_lds_limit((const void*)k_c1_wgrad<MT, 1, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 1, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+}
+static void c1_launch_wgrad_dz(const C1Plan& pl, const C1Params& p, hipStream_t s) {
+    if (pl.MT == 4) c1_launch_wgrad_dz_mt<4>(pl, p, s);
+    else if (pl.MT == 3) c1_launch_wgrad_dz_mt<3>(pl, p, s);
+    else if (pl.MT == 2) c1_launch_wgrad_dz_mt<2>(pl, p, s);
+    else c1_launch_wgrad_dz_mt<1>(pl, p, s);
+}
 static void c1_launch_wgrad(const C1Plan& pl, const C1Params& p, hipStream_t s) {
     if (pl.MT == 4) c1_launch_wgrad_mt<4>(pl, p, s);
     else if (pl.MT == 3) c1_launch_wgrad_mt<3>(pl, p, s);
@@ -700,5 +926,73 @@ static int c1_bwd_weight_any(const mn_conv_geom* g, const float* gy, const float
     const int64_t total = (int64_t)p.O * p.K + (dbias ? p.O : 0);
     hipLaunchKernelGGL(k_c1_reduce, dim3(mn_grid_for((int64_t)p.Opad * 81, 64, 2048)), dim3(256), 0, s, (const float*)p.part, (const float*)p.dbpart, dw, dbias, p.Z, p.O, p.K, p.Opad);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(first-layer)");
+    return MN_OK;
+}
+
+// ---- the one-pass backward of the first block (training mode): Gram data of x, then dz-only backward-weight + per-channel finish
+static int c1_xgram_grid(const C1Plan& pl) {
+    const int ntiles = pl.p.N * pl.p.strips;
+    return ntiles < 512 ? ntiles : 512;
+}
+int64_t c1_xgram_ws_bytes(const mn_conv_geom* g) {
+    C1Plan pl;
+    if (!plan_c1(g, &pl, 0)) return 0;          // the forward's strips: two blocks per CU
+    return (int64_t)c1_xgram_grid(pl) * C1G_TILE * 4;
+}
+int c1_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int64_t ws_bytes, hipStream_t s) {
+    C1Plan pl;
+    if (!plan_c1(g, &pl, 0) || !c1_supported(g, 2)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_first_xgram: geometry not covered by the first-layer kernels");
+    const int Zg = c1_xgram_grid(pl);
+    if (!ws || ws_bytes < (int64_t)Zg * C1G_TILE * 4 || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_first_xgram: workspace too small");
+    C1Params& p = pl.p;
+    p.x = x;
+    const size_t lds_b = (size_t)p.xs_bytes + (size_t)4 * C1G_TILE * 4;
+    mn_set_last_kernel("k_c1_xgram");
+    mn_prof_bytes(4.0 * g->N * g->C * g->H * g->W);
+    mn_prof_begin(s);
+    raise_lds_limit((const void*)k_c1_xgram, lds_b);
+    hipLaunchKernelGGL(k_c1_xgram, dim3(Zg), dim3(256), lds_b, s, p, (float*)ws);
+    mn_prof_end(s);
+    hipLaunchKernelGGL(k_c1_xgram_final, dim3(C1G_TILE / 64), dim3(256), 0, s, (const float*)ws, Zg, gram);
+    MN_CHECK_LAUNCH("mn_conv2d_first_xgram");
+    return MN_OK;
+}
+int c1_bwd_first_gram(const mn_conv_geom* g, const float* da, const float* yb, const float* save, const float* gamma, const float* beta, const float* chan, int quant,
+                      int a_bits, const float* w, const float* bias, const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                      int64_t ws_bytes, hipStream_t s) {
+    C1Plan pl;
+    if (!plan_c1(g, &pl, 2) || !aligned16(da) || !aligned16(yb)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_first_gram: geometry not covered by the first-layer kernels");
+    if (!da || !yb || !w || !gram || !x || !dw || (!chan && (!save || !gamma || !beta))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_first_gram: null argument");
+    if (chan && (a_bits < 2 || a_bits > 8)) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_first_gram: activation bits out of range");
+    if (!ws || ws_bytes < pl.ws_bytes_w || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_first_gram: workspace too small");
+    C1Params& p = pl.p;
+    const float qs = chan ? dorefa_scale(a_bits) : 1.f;
+    p.x = x; p.gy = nullptr; p.part = (float*)ws; p.dbpart = nullptr; p.want_db = 0;
+    p.wp = nullptr; p.bias = nullptr; p.y = nullptr;
+    p.da = da; p.yb = yb; p.save = save; p.gamma = gamma; p.beta = beta; p.sums = nullptr; p.training = 0;          // (k1, k2 of the fold are not used: DZ)
+    p.n_f = (float)g->N * (float)(g->H * g->W);
+    p.chan = chan; p.quant = quant; p.qs = qs; p.qs_inv = (qs > 0.f && !MN_ENV("MN_QA_IEEE_DIV")) ? 1.0f / qs : 0.f; p.interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
+    mn_set_last_kernel("k_c1_wgrad<%d, %d, 1>", pl.MT, chan ? 2 : 1);
+    { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(8.0 * ny + 4.0 * g->N * g->C * g->H * g->W); }
+    mn_prof_begin(s);
+    c1_launch_wgrad_dz(pl, p, s);
+    mn_prof_end(s);
+    C1BnFin f;
+    f.part = p.part; f.Z = p.Z; f.O = p.O; f.K = p.K; f.Opad = p.Opad; f.w = w; f.bias = bias; f.save = save; f.gamma = gamma; f.chan = chan; f.gram = gram;
+    f.scale = (chan && quant) ? 0.1 : 1.0;
+    f.n = (double)g->N * (double)(g->H * g->W); f.dw = dw; f.dbias = dbias; f.dgamma = dgamma; f.dbeta = dbeta;
+    hipLaunchKernelGGL(k_c1_bn_final, dim3(p.O), dim3(320), 0, s, f);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_first_gram");
+    return MN_OK;
+}
+int c1_gram_bnstats(const mn_conv_geom* g, const float* w, const float* bias, const double* gram, float eps, float momentum, float* running_mean, float* running_var,
+                    float* save, hipStream_t s) {
+    if (!c1_supported(g, 2)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_first_gram_bnstats: geometry not covered by the first-layer kernels");
+    if (!w || !gram || !save) MN_FAIL(MN_EINVAL, "mn_conv2d_first_gram_bnstats: null argument");
+    C1Stats f;
+    f.w = w; f.bias = bias; f.gram = gram; f.O = g->O; f.K = g->C * g->KH * g->KW; f.n = (double)g->N * (double)(g->H * g->W);
+    f.eps = eps; f.momentum = momentum; f.running_mean = running_mean; f.running_var = running_var; f.save = save;
+    hipLaunchKernelGGL(k_c1_gram_stats, dim3(g->O), dim3(128), 0, s, f);
+    MN_CHECK_LAUNCH("mn_conv2d_first_gram_bnstats");
     return MN_OK;
 }

@@ -854,6 +854,38 @@ extern "C" int mn_conv2d_bwd_weight_first_qa(const mn_conv_geom* g, const float*
     if (!c1_supported(g, 2)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight_first_qa: geometry not covered by the first-layer kernels");
     return c1_bwd_weight_qa(g, dq, y, chan, quant, a_bits, sums, training, x, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
 }
+extern "C" int64_t mn_conv2d_first_xgram_ws_bytes(const mn_conv_geom* g) {
+    if (!g || check_geom(g, "mn_conv2d_first_xgram_ws_bytes")) return 0;
+    return c1_xgram_ws_bytes(g);
+}
+extern "C" int mn_conv2d_first_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_first_xgram");
+    if (rc) return rc;
+    if (!x || !gram || (((uintptr_t)gram) & 7)) MN_FAIL(MN_EINVAL, "mn_conv2d_first_xgram: null / misaligned tensor");
+    return c1_xgram(g, x, gram, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int mn_conv2d_first_gram_bnstats(const mn_conv_geom* g, const float* w, const float* bias, const double* gram, float eps, float momentum,
+                                           float* running_mean, float* running_var, float* save, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_first_gram_bnstats");
+    if (rc) return rc;
+    return c1_gram_bnstats(g, w, bias, gram, eps, momentum, running_mean, running_var, save, (hipStream_t)stream);
+}
+extern "C" int mn_conv2d_bwd_first_bn_gram(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta,
+                                           const float* w, const float* bias, const double* gram, const float* x, float* dw, float* dbias, float* dgamma,
+                                           float* dbeta, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_first_bn_gram");
+    if (rc) return rc;
+    if (!save || !gamma || !beta) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_first_bn_gram: null tensor");
+    return c1_bwd_first_gram(g, da, y, save, gamma, beta, nullptr, 0, 0, w, bias, gram, x, dw, dbias, dgamma, dbeta, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int mn_conv2d_bwd_first_qa_gram(const mn_conv_geom* g, const float* dq, const float* y, const float* chan, int a_bits, int quant, const float* w,
+                                           const float* bias, const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                                           int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_first_qa_gram");
+    if (rc) return rc;
+    if (!chan) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_first_qa_gram: null tensor");
+    return c1_bwd_first_gram(g, dq, y, nullptr, nullptr, nullptr, chan, quant, a_bits, w, bias, gram, x, dw, dbias, dgamma, dbeta, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int mn_conv2d_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw,
                                     float* dbias, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream) {
     int rc = check_geom(g, "mn_conv2d_bwd_weight");

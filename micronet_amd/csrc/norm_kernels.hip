@@ -449,12 +449,12 @@ static int bns_split(const BnsGeom& g) {
 
 static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                            int training, float* running_mean, float* running_var, float* save, float* a, int out8, float* ws, mn_stream_t stream,
-                           int act = 0, float* mm = nullptr) {
+                           int act = 0, float* mm = nullptr, bool stats_given = false) {
     int rc = bns_check(N, C, HW, y, out8 ? (const void*)y : (const void*)a, "mn_bnsign_fwd");
     if (!rc && out8 && (((uintptr_t)a) & 3)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd_i8: output must be 4-byte aligned");
     if (rc) return rc;
-    if (!y || !gamma || !beta || !save || !a || !ws || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: null / misaligned argument");
-    if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: eval mode needs the running statistics");
+    if (!y || !gamma || !beta || !save || !a || (!stats_given && (!ws || (((uintptr_t)ws) & 7)))) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: null / misaligned argument");
+    if (!stats_given && !training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_bnsign_fwd: eval mode needs the running statistics");
     hipStream_t s = (hipStream_t)stream;
     BnsGeom g = bns_geom(N, C, HW);
     g.act = act;
@@ -462,7 +462,9 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
     const double nel = (double)N * C * HW;
     BnsFin fin = {};
     const bool fold = !MN_ENV("MN_BNS_NO_FOLD");          // A/B knob: the separate k_bns_final_* launches
-    if (training) {
+    if (stats_given) {
+        // save = {mean, invstd} is the caller's (mn_conv2d_first_gram_bnstats): the apply pass alone
+    } else if (training) {
         mn_set_last_kernel("k_bns_partial<0>"); mn_prof_bytes(4.0 * nel); mn_prof_begin(s);
         hipLaunchKernelGGL(k_bns_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (double*)ws);
@@ -507,6 +509,11 @@ extern "C" int mn_bn_save_stats(const float* y, int64_t N, int64_t C, int64_t HW
 extern "C" int mn_bnsign_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                              int training, float* running_mean, float* running_var, float* save, float* a, float* ws, mn_stream_t stream) {
     return bnsign_fwd_impl(y, N, C, HW, gamma, beta, eps, momentum, training, running_mean, running_var, save, a, 0, ws, stream);
+}
+/* a = sign(bn(y)) with GIVEN statistics save = {mean, invstd} [2][C] (mn_conv2d_first_gram_bnstats): the apply pass of mn_bnsign_fwd / _i8 alone */
+extern "C" int mn_bnsign_apply(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, void* a, int out8,
+                               mn_stream_t stream) {
+    return bnsign_fwd_impl(y, N, C, HW, gamma, beta, 0.f, 0.f, 1, nullptr, nullptr, const_cast<float*>(save), (float*)a, out8 ? 1 : 0, nullptr, stream, 0, nullptr, true);
 }
 extern "C" int mn_bnsign_fwd_i8(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
                                 int training, float* running_mean, float* running_var, float* save, int8_t* a, float* ws, mn_stream_t stream) {

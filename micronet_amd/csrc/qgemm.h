@@ -25,6 +25,14 @@ int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, co
 int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int c1_bwd_weight_qa(const mn_conv_geom* g, const float* dq, const float* yb, const float* chan, int quant, int a_bits, const float* sums, int training,
                      const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+// one-pass backward of the first block: Gram data of x's im2col rows (gram: 80 x 80 doubles), then dz-only backward-weight + per-channel finish
+int64_t c1_xgram_ws_bytes(const mn_conv_geom* g);
+int c1_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int64_t ws_bytes, hipStream_t s);
+int c1_gram_bnstats(const mn_conv_geom* g, const float* w, const float* bias, const double* gram, float eps, float momentum, float* running_mean, float* running_var,
+                    float* save, hipStream_t s);
+int c1_bwd_first_gram(const mn_conv_geom* g, const float* da, const float* yb, const float* save, const float* gamma, const float* beta, const float* chan, int quant,
+                      int a_bits, const float* w, const float* bias, const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                      int64_t ws_bytes, hipStream_t s);
 // pointwise convolution on int8 sign codes, fused BatchNorm + sign epilogues (qgemm_sign.hip)
 int pws_supported(const mn_conv_geom* g, const mn_wq* wq);
 int64_t pws_ws_bytes(const mn_conv_geom* g);

@@ -20,6 +20,8 @@ class Conv2dFirst(nn.Conv2d):
             out = ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
             if not input.requires_grad:
                 out._mn_first_conv_out = True      # no backward-data: a BatchNorm2dBinAct behind it may hand its gradient over lazily
+                if not isinstance(out, LazyConvOut):
+                    out._mn_first_conv = ops.FirstConvRecord(out, input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
             return out
         ops.note_fallback("Conv2dFirst -> nn.Conv2d")
         return super().forward(input)

@@ -1217,6 +1217,65 @@ class BnBatchStats(Function):
 
 
 LAZY_BN_GRAD = True
+FIRST_GRAM = _os0.environ.get("MN_FIRST_GRAM", "1") != "0"          # one-pass backward of the first block (A/B knob; 0: sums pass + fold in the backward-weight)
+
+
+class FirstConvRecord:
+    """What ``nn.Conv2dFirst`` leaves on its output for the BatchNorm block behind it: the convolution's operands.  With them that block's backward runs the
+    one-pass first-block backward (mn_conv2d_first_xgram + mn_conv2d_bwd_first_*_gram) and hands the finished dw / dbias to the conv node."""
+
+    def __init__(self, y, x, w, bias, stride, padding, dilation, groups):
+        self.x, self.w, self.bias = x, w, bias
+        self.conv = (stride, padding, dilation, groups)
+        self.node, self.version = y.grad_fn, y._version          # the record is valid for exactly this tensor as the conv wrote it
+
+    def valid_for(self, y):
+        return y.grad_fn is self.node and y._version == self.version and self.node is not None
+
+
+def _first_record(y, training):
+    rec = getattr(y, "_mn_first_conv", None)
+    if rec is None or not (FIRST_GRAM and LAZY_BN_GRAD and training and type(y) is torch.Tensor and rec.valid_for(y)):
+        return None
+    return rec
+
+
+def _first_gram(rec, eps, momentum, running_mean, running_var):
+    """Gram data of the first conv's input (mn_conv2d_first_xgram) and, from them, the BatchNorm's batch statistics save = {mean, invstd} + running update -- no pass over
+    the conv output.  -> (gram, save)"""
+    lib = _lib_()
+    x, w, b = _chk(rec.x, "input"), _chk(rec.w, "weight"), _chk(rec.bias, "bias")
+    g = _geom(x.shape, w.shape, *rec.conv)
+    dev = x.device
+    with torch.cuda.device_of(x):
+        nbg = int(lib.mn_conv2d_first_xgram_ws_bytes(C.byref(g)))
+        wsg = torch.empty(nbg // 4 + 4, dtype=torch.float32, device=dev)
+        gram = torch.empty(80 * 80, dtype=torch.float64, device=dev)
+        _call("mn_conv2d_first_xgram", C.byref(g), _p(x), _p(gram), _p(wsg), nbg, _s())
+        save = torch.empty((2, g.O), dtype=torch.float32, device=dev)
+        _call("mn_conv2d_first_gram_bnstats", C.byref(g), _p(w), _p(b), _p(gram), float(eps), float(momentum), _p(running_mean), _p(running_var), _p(save), _s())
+    return gram, save
+
+
+def _first_gram_backward(rec, gram, y, kind, da, save, gamma, beta, chan, bits, quant):
+    """-> (dw, dbias, dgamma, dbeta) of the first block in ONE pass over (da, y); kind "bn": BatchNorm + sign (save, gamma, beta); "qa": the DoReFa block (chan)."""
+    lib = _lib_()
+    x, w, b = _chk(rec.x, "input"), _chk(rec.w, "weight"), _chk(rec.bias, "bias")
+    g = _geom(x.shape, w.shape, *rec.conv)
+    dev = y.device
+    with torch.cuda.device_of(y):
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b) if b is not None else None
+        dgamma, dbeta = torch.empty(g.O, dtype=torch.float32, device=dev), torch.empty(g.O, dtype=torch.float32, device=dev)
+        ws, nb = _ws(g, 2, dev)
+        with _span(g, 2, 8 * y.numel() + 4 * x.numel()):
+            if kind == "bn":
+                _call("mn_conv2d_bwd_first_bn_gram", C.byref(g), _p(da), _p(y), _p(save), _p(gamma), _p(beta), _p(w), _p(b), _p(gram), _p(x), _p(dw), _p(db),
+                      _p(dgamma), _p(dbeta), _p(ws), nb, _s())
+            else:
+                _call("mn_conv2d_bwd_first_qa_gram", C.byref(g), _p(da), _p(y), _p(chan), bits, quant, _p(w), _p(b), _p(gram), _p(x), _p(dw), _p(db),
+                      _p(dgamma), _p(dbeta), _p(ws), nb, _s())
+    return dw, db, dgamma, dbeta
 
 
 class BNSign(Function):
@@ -1228,11 +1287,19 @@ class BNSign(Function):
         y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
         N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
         a = torch.empty(y.shape, dtype=torch.int8 if packed else torch.float32, device=y.device)
-        save = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
-        ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
-        with torch.cuda.device_of(y):
-            _call("mn_bnsign_fwd_i8" if packed else "mn_bnsign_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum),
-                  int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(ws), _s())
+        ctx.first = rec = _first_record(y, training) if lazy_grad else None
+        ctx.gram = None
+        if rec is not None:
+            # y = the first conv's output: batch statistics from the Gram data of its INPUT (kept for the one-pass backward), then the apply pass alone
+            ctx.gram, save = _first_gram(rec, eps, momentum, running_mean, running_var)
+            with torch.cuda.device_of(y):
+                _call("mn_bnsign_apply", _p(y), N, Cc, HW, _p(gamma), _p(beta), _p(save), _p(a), int(bool(packed)), _s())
+        else:
+            save = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+            ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
+            with torch.cuda.device_of(y):
+                _call("mn_bnsign_fwd_i8" if packed else "mn_bnsign_fwd", _p(y), N, Cc, HW, _p(gamma), _p(beta), float(eps), float(momentum),
+                      int(training), _p(running_mean), _p(running_var), _p(save), _p(a), _p(ws), _s())
         ctx.save_for_backward(y, gamma, beta, save)
         ctx.training = int(training)
         ctx.lazy_grad = bool(lazy_grad)
@@ -1248,9 +1315,16 @@ class BNSign(Function):
         training = ctx.training
         if ctx.lazy_grad and LAZY_BN_GRAD:
             # y comes from the first conv (no backward-data): only the sums are computed here; the conv's backward-weight forms dy itself
-            sums = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
-            with torch.cuda.device_of(y):
-                _call("mn_bnsign_bwd_sums", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+            rec = ctx.first
+            sums = None
+            if rec is not None:
+                # ... or everything at once: the BatchNorm backward is linear in dz, so ONE pass over (da, y) gives dw, dgamma, dbeta (csrc/conv_first.hip)
+                dw1, db1, dgamma, dbeta = _first_gram_backward(rec, ctx.gram, y, "bn", da, save, gamma, beta, None, 0, 0)
+                ctx.gram = None
+            else:
+                sums = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+                with torch.cuda.device_of(y):
+                    _call("mn_bnsign_bwd_sums", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
 
             def expand(r):
                 dy_ = torch.empty_like(r["y"])
@@ -1260,6 +1334,8 @@ class BNSign(Function):
                           None, None, _p(ws_), _s())
                 return dy_
             recipe = dict(da=da, y=y, save=save, gamma=gamma, beta=beta, sums=sums, training=training)
+            if rec is not None:
+                recipe.update(kind="first_done", dw=dw1, db=db1, x=rec.x, w=rec.w)
             return LazyBNGrad(y.shape, y.device, recipe, expand), dgamma, dbeta, None, None, None, None, None, None, None
         dy = torch.empty_like(y)
         with torch.cuda.device_of(y):
@@ -1592,6 +1668,11 @@ class QConv2d(Function):
     def backward(ctx, gy):
         x, wq, qp, wscale = ctx.saved_tensors
         g, aq_mode, aq_bits, aq_qtype, has_bias, wd4, aq_flags = ctx.cfg
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") == "first_done":
+            r = gy._mn_recipe              # the block behind this (first) conv already ran the one-pass backward on this conv's operands: dw, dbias are finished
+            if aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and r["x"].data_ptr() == x.data_ptr() and r["w"].data_ptr() == wq.data_ptr() and \
+                    tuple(r["dw"].shape) == tuple(wq.shape) and (not has_bias or r["db"] is not None):
+                return None, r["dw"], (r["db"] if has_bias else None), None, None, None, None, None, None, None, None, None, None, None
         if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") in ("bnh", "bnh_pool") and aq_mode == ACTQ_SIGN8 and wd4 is not None and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO:
             r = gy._mn_recipe              # the fused BatchNorm+sign (+ max-pool) behind this conv: dy is formed inside backward-data / backward-weight
@@ -1633,7 +1714,7 @@ class QConv2d(Function):
                 _call("mn_conv2d_bwd_weight_first_qa", C.byref(g), _p(r["dq"]), _p(r["y"]), _p(r["chan"]), _p(r["sums"]), r["bits"], r["quant"], r["training"],
                       _p(x), _p(dw), _p(db), _p(ws), nb, _s())
             return None, dw, db, None, None, None, None, None, None, None, None, None, None, None
-        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") not in ("bnh", "bnh_pool", "qa") and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
+        if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") not in ("bnh", "bnh_pool", "qa", "first_done") and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
             r = gy._mn_recipe              # the BatchNorm+sign behind the first conv: dy is formed inside the backward-weight kernel
             dw = torch.empty_like(wq)
@@ -2025,7 +2106,7 @@ def qa_supported(shape, pool):
     return len(shape) == 4 and bool(_lib_().mn_qa_supported(shape[2], shape[3], int(bool(pool))))
 
 
-def _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt):
+def _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt, first=None):
     """The statistics half of a fused k-bit block.  ``y`` = a ``LazyQConvOut``: the conv runs HERE on activation codes (mn_qconv_bnq_fwd_stash: 16 / 32-bit stash
     + exact integer statistics; fp32 y never exists); a plain fp32 tensor (the block behind the un-quantised first conv): mn_bn_save_stats.  Returns
     (src, chan [9][C], in_kind 0 int16 / 1 fp32 / 2 int32, (N, C, H, W), device)."""
@@ -2051,11 +2132,14 @@ def _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training
     src = _chk(y, "input")
     N, Cc, H, W = src.shape
     dev = src.device
-    save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
     chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        ws = torch.empty(int(lib.mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=dev)
-        _call("mn_bn_save_stats", _p(src), N, Cc, H * W, float(eps), float(momentum), int(training), _p(running_mean), _p(running_var), _p(save), _p(ws), _s())
+        if first is not None:          # y = the first conv's output: statistics from the Gram data of its input, no pass over y (the Gram data stay on the record holder)
+            first[1], save = _first_gram(first[0], eps, momentum, running_mean, running_var)
+        else:
+            save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+            ws = torch.empty(int(lib.mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=dev)
+            _call("mn_bn_save_stats", _p(src), N, Cc, H * W, float(eps), float(momentum), int(training), _p(running_mean), _p(running_var), _p(save), _p(ws), _s())
         _call("mn_qa_chan_from_save", _p(save), _p(gamma), _p(beta), Cc, _p(chan), _s())
     return src, chan, 1, (N, Cc, H, W), dev
 
@@ -2070,11 +2154,14 @@ class BNReLUQ(Function):
     def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt, out_bits, pool):
         gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
         lazy = isinstance(y, LazyQConvOut) and y._mn_value is None
-        src, chan, in_f32, (N, Cc, H, W), dev = _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt)
+        rec = _first_record(y, training) if (not lazy and not pool and FOLD_BN_INTO_CONV_BWD) else None
+        holder = [rec, None] if rec is not None else None
+        src, chan, in_f32, (N, Cc, H, W), dev = _bn_front(y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt, holder)
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         qbits = out_bits if out_bits else 2          # the kernels want a valid width even when no code is produced
         ctx.save_for_backward(src, chan, gamma, beta)
         ctx.cfg = (in_f32, N, Cc, H, W, qbits, int(bool(pool)), int(training), bool(out_bits))
+        ctx.first, ctx.gram = (rec, holder[1]) if rec is not None else (None, None)
 
         def materialize():
             act = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=dev)
@@ -2097,6 +2184,22 @@ class BNReLUQ(Function):
         else:
             dq, quant = _chk(g, "grad"), 0
         dev = src.device
+        if ctx.first is not None:
+            # the block behind the un-quantised first conv, one pass over (dq, y): dw, dgamma, dbeta at once (csrc/conv_first.hip, the Gram data of x)
+            dq = _chk(dq, "grad")
+            dw1, db1, dgamma, dbeta = _first_gram_backward(ctx.first, ctx.gram, src, "qa", dq, None, None, None, chan, qbits, quant)
+            ctx.gram = None
+
+            def expand1(r):
+                dy_ = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    sums_ = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+                    ws_ = torch.empty(int(_lib_().mn_qa_ws_floats(Cc)), dtype=torch.float32, device=dev)
+                    _call("mn_qa_bwd_sums", 1, _p(r["y"]), _p(r["chan"]), _p(r["dq"]), N, Cc, H, W, r["bits"], 0, r["quant"], None, None, _p(sums_), _p(ws_), _s())
+                    _call("mn_qa_bwd_apply", 1, _p(r["y"]), _p(r["chan"]), _p(sums_), _p(r["dq"]), N, Cc, H, W, r["bits"], 0, r["quant"], r["training"], _p(dy_), _s())
+                return dy_
+            recipe = dict(kind="first_done", dq=dq, y=src, chan=chan, bits=qbits, quant=quant, training=training, dw=dw1, db=db1, x=ctx.first.x, w=ctx.first.w)
+            return LazyBNGrad((N, Cc, H, W), dev, recipe, expand1), dgamma, dbeta, None, None, None, None, None, None, None, None
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):

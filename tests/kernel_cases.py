@@ -801,6 +801,95 @@ def check_first_conv_qa_wgrad(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, training=Tru
     assert eq(be.to_host(dw), be.to_host(dw_ref)) and eq(be.to_host(db), be.to_host(db_ref))
 
 
+def _im2col_gram(x, k):
+    """fp64 Gram data of the im2col rows of x ("same" padding): G [K+1][K+1] with the feature K = 1."""
+    N, Cin, H, W = x.shape
+    pad = k // 2
+    xp = np.zeros((N, Cin, H + 2 * pad, W + 2 * pad), dtype=np.float64)
+    xp[:, :, pad:pad + H, pad:pad + W] = x
+    cols = [xp[:, c, r:r + H, s:s + W].reshape(-1) for c in range(Cin) for r in range(k) for s in range(k)]
+    f = np.stack(cols + [np.ones(N * H * W)], axis=0)
+    return f @ f.T
+
+
+def check_first_conv_gram_bwd(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, kind="bn", quant=1, bits=2, bias=True, seed=0, tol=2e-5):
+    """The one-pass backward of the first block (mn_conv2d_first_xgram + mn_conv2d_bwd_first_bn_gram / _qa_gram: the BatchNorm backward folded into per-channel
+    algebra on Gram data of x) against the two-pass path (sums, then the fold in the backward-weight's operand load) on the SAME tensors -- here y really is
+    conv(x, w) + b, which the identity needs.  Different summation order: agreement to fp32 rounding, not bit for bit."""
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    K = Cin * k * k
+    x = r.standard_normal(x_shape).astype(F)
+    w = (r.standard_normal((Oc, Cin, k, k)) * 0.2).astype(F)
+    b = (r.standard_normal(Oc) * 0.3).astype(F) if bias else None
+    da = r.standard_normal((N, Oc, H, W)).astype(F)
+    if kind == "bn":
+        gamma, beta = (r.standard_normal(Oc) * 0.5 + 1).astype(F), (r.standard_normal(Oc) * 0.3).astype(F)
+    else:
+        gamma, beta = (r.standard_normal(Oc) * 2.0 + 3.0).astype(F), (r.standard_normal(Oc) * 2.0 + 3.0).astype(F)
+    g = be.geom(x_shape, (Oc, Cin, k, k), padding=k // 2)
+    assert be.lib.mn_conv2d_first_supported(C.byref(g), 2) == 1
+    dX, dW, dBi, dDA, dG, dB = be.to_dev(x), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(da), be.to_dev(gamma), be.to_dev(beta)
+    dY = be.conv_fwd(g, be.actq(0), dX, dW, dBi, 0)
+    yh = be.to_host(dY).astype(np.float64)
+    mean, var = yh.mean(axis=(0, 2, 3)), yh.var(axis=(0, 2, 3))
+    dS = be.to_dev(np.stack([mean, 1.0 / np.sqrt(var + 1e-5)]).astype(F))
+    HW = H * W
+    # Gram data
+    nbg = int(be.lib.mn_conv2d_first_xgram_ws_bytes(C.byref(g)))
+    assert nbg > 0
+    wsg, gram = be.empty(nbg // 4 + 4), be.empty(2 * 80 * 80)
+    be.call("mn_conv2d_first_xgram", C.byref(g), be.ptr(dX), be.ptr(gram), be.ptr(wsg), nbg, be.stream)
+    G = be.to_host(gram).view(np.float64).reshape(80, 80)
+    G_ref = _im2col_gram(x, k)
+    assert close(G[:K + 1, :K + 1], G_ref, 2e-6) and G[K, K] == N * HW
+    # forward statistics from the Gram data vs the statistics of y itself; the apply-only pass vs the full BatchNorm + sign forward on the same statistics
+    rm, rv = be.to_dev(np.full(Oc, 0.25, dtype=F)), be.to_dev(np.full(Oc, 2.0, dtype=F))
+    sv = be.empty((2, Oc))
+    be.call("mn_conv2d_first_gram_bnstats", C.byref(g), be.ptr(dW), be.ptr(dBi), be.ptr(gram), 1e-5, 0.1, be.ptr(rm), be.ptr(rv), be.ptr(sv), be.stream)
+    svh = be.to_host(sv)
+    assert np.abs(svh[0] - mean).max() <= 2e-6 * max(np.abs(mean).max(), np.sqrt(var).max()) and np.abs(svh[1] * np.sqrt(var + 1e-5) - 1).max() <= 1e-5
+    n_el = N * HW
+    assert np.abs(be.to_host(rm) - (0.9 * 0.25 + 0.1 * mean)).max() <= 1e-6 and np.abs(be.to_host(rv) / (0.9 * 2.0 + 0.1 * var * n_el / (n_el - 1)) - 1).max() <= 1e-5
+    if kind == "bn" and HW % 4 == 0:
+        wsb = be.empty(int(be.lib.mn_bnsign_ws_floats(Oc)) + 2)
+        sv2, a_full, a_app = be.empty((2, Oc)), be.empty((N, Oc, H, W)), be.empty((N, Oc, H, W))
+        be.call("mn_bnsign_fwd", be.ptr(dY), N, Oc, HW, be.ptr(dG), be.ptr(dB), 1e-5, 0.1, 1, None, None, be.ptr(sv2), be.ptr(a_full), be.ptr(wsb), be.stream)
+        be.call("mn_bnsign_apply", be.ptr(dY), N, Oc, HW, be.ptr(dG), be.ptr(dB), be.ptr(sv2), be.ptr(a_app), 0, be.stream)
+        assert eq(be.to_host(a_app), be.to_host(a_full))
+        a8 = be.empty_i8((N, Oc, H, W))
+        be.call("mn_bnsign_apply", be.ptr(dY), N, Oc, HW, be.ptr(dG), be.ptr(dB), be.ptr(sv2), be.ptr(a8), 1, be.stream)
+        assert eq(be.to_host(a8).astype(F), be.to_host(a_full))
+    # two-pass reference
+    if kind == "bn":
+        ws = be.empty(int(be.lib.mn_bnsign_ws_floats(Oc)) + 2)
+        dy, dgam, dbet = be.empty((N, Oc, H, W)), be.empty(Oc), be.empty(Oc)
+        be.call("mn_bnsign_bwd", be.ptr(dDA), be.ptr(dY), be.ptr(dS), be.ptr(dG), be.ptr(dB), N, Oc, HW, 1, be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), be.stream)
+    else:
+        chan = be.empty((9, Oc))
+        be.call("mn_qa_chan_from_save", be.ptr(dS), be.ptr(dG), be.ptr(dB), Oc, be.ptr(chan), be.stream)
+        ws = be.empty(int(be.lib.mn_qa_ws_floats(Oc)) + 2)
+        sums, dgam, dbet, dy = be.empty((2, Oc)), be.empty(Oc), be.empty(Oc), be.empty((N, Oc, H, W))
+        be.call("mn_qa_bwd_sums", 1, be.ptr(dY), be.ptr(chan), be.ptr(dDA), N, Oc, H, W, bits, 0, quant, be.ptr(dgam), be.ptr(dbet), be.ptr(sums), be.ptr(ws), be.stream)
+        be.call("mn_qa_bwd_apply", 1, be.ptr(dY), be.ptr(chan), be.ptr(sums), be.ptr(dDA), N, Oc, H, W, bits, 0, quant, 1, be.ptr(dy), be.stream)
+    dw_ref, _ = be.conv_bwd_weight(g, be.actq(0), dy, dX, 0, bias=True)
+    # one pass
+    nb = be.lib.mn_conv2d_ws_bytes(C.byref(g), 2, 0)
+    ws2 = be.empty(max(4, nb // 4 + 4))
+    dw, db, dgam2, dbet2 = be.empty((Oc, Cin, k, k)), be.empty(Oc), be.empty(Oc), be.empty(Oc)
+    if kind == "bn":
+        be.call("mn_conv2d_bwd_first_bn_gram", C.byref(g), be.ptr(dDA), be.ptr(dY), be.ptr(dS), be.ptr(dG), be.ptr(dB), be.ptr(dW), be.ptr(dBi), be.ptr(gram),
+                be.ptr(dX), be.ptr(dw), be.ptr(db), be.ptr(dgam2), be.ptr(dbet2), be.ptr(ws2), nb, be.stream)
+    else:
+        be.call("mn_conv2d_bwd_first_qa_gram", C.byref(g), be.ptr(dDA), be.ptr(dY), be.ptr(chan), bits, quant, be.ptr(dW), be.ptr(dBi), be.ptr(gram),
+                be.ptr(dX), be.ptr(dw), be.ptr(db), be.ptr(dgam2), be.ptr(dbet2), be.ptr(ws2), nb, be.stream)
+    dw_ref_h = be.to_host(dw_ref)
+    assert np.abs(dw_ref_h).max() > 0
+    assert close(be.to_host(dw), dw_ref_h, tol), np.abs(be.to_host(dw) - dw_ref_h).max() / np.abs(dw_ref_h).max()
+    assert close(be.to_host(dgam2), be.to_host(dgam), tol) and close(be.to_host(dbet2), be.to_host(dbet), tol)
+    assert np.abs(be.to_host(db)).max() <= 1e-4 * max(np.abs(be.to_host(dbet)).max(), 1e-30)
+
+
 def check_ternary_multi(be, seed=0):
     """mn_ternary_w_fwd_multi / mn_ternary_w_bwd_multi (one launch over several weight tensors) bit-identical to the per-tensor entry points."""
     r = np.random.default_rng(seed)
