@@ -410,6 +410,20 @@ int mn_conv2d_bwd_weight_first_qa(const mn_conv_geom* g, const float* dq, const 
 int mn_conv2d_first_gram_bnstats(const mn_conv_geom* g, const float* w, const float* bias, const double* gram, float eps, float momentum, float* running_mean,
                                  float* running_var, float* save, mn_stream_t stream);
 int mn_bnsign_apply(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, void* a, int out8, mn_stream_t stream);
+/* The FUSED first block (statistics known before the convolution runs, so its epilogue can normalise): y = conv(x, w) + b is never written.
+ *   mn_conv2d_first_bnact_fwd   act 1: codes = int8 sign(bn(y)) (models/nin_gc.py:53-59 with wbwtab/quantize.py:11-36); act 2: codes = the a_bits DoReFa activation
+ *                               code of relu(bn(y)) (wqaq/dorefa/quantize.py:36-46), uint8.  mask4 [N][O][H W / 4]: bit e of the low nibble = the backward's pass
+ *                               test for pixel 4 i + e (act 1: |z| < 1, act 2: z > 0), high nibble (act 2): ... and 0 <= 0.1 relu(z) <= 1 (the quantizer's clamp).
+ *   mn_conv2d_bwd_first_mask_gram  the one-pass backward on (da, mask4) instead of (da, y); quant != 0: da is the gradient w.r.t. the quantised activation (high
+ *                               nibble, rows scaled by 0.1 -- the quantizer's STE).  save / gamma: the BatchNorm's, as given to the forward. */
+/* the unfused forward of the DoReFa first block that leaves the same pass nibbles: mn_qa_fwd(in_f32 = 1, pool = 0, codes) + mask4 (the fused act 2 epilogue is
+ * VALU-bound by the quantizer's rounding -- measured slower than conv + this pass -- so the default DoReFa first block is: conv, this, mn_conv2d_bwd_first_mask_gram) */
+int mn_qa_fwd_f32_mask(const float* y, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, uint8_t* codes, uint8_t* mask4, mn_stream_t stream);
+int mn_conv2d_first_bnact_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* bias, const float* save, const float* gamma, const float* beta,
+                              int act, int a_bits, void* codes, uint8_t* mask4, mn_stream_t stream);
+int mn_conv2d_bwd_first_mask_gram(const mn_conv_geom* g, const float* da, const uint8_t* mask4, int quant, const float* save, const float* gamma, const float* w,
+                                  const float* bias, const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                                  int64_t ws_bytes, mn_stream_t stream);
 int64_t mn_conv2d_first_xgram_ws_bytes(const mn_conv_geom* g);
 int mn_conv2d_first_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int64_t ws_bytes, mn_stream_t stream);
 int mn_conv2d_bwd_first_bn_gram(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta, const float* w,

@@ -87,6 +87,9 @@ PROTOTYPES = {
     "mn_conv2d_bwd_weight_first_qa": (_I, [_G, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
     "mn_conv2d_first_gram_bnstats": (_I, [_G, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),
     "mn_bnsign_apply": (_I, [_P, _L, _L, _L, _P, _P, _P, _P, _I, _P]),
+    "mn_qa_fwd_f32_mask": (_I, [_P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
+    "mn_conv2d_first_bnact_fwd": (_I, [_G, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "mn_conv2d_bwd_first_mask_gram": (_I, [_G, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "mn_conv2d_first_xgram_ws_bytes": (_L, [_G]),
     "mn_conv2d_first_xgram": (_I, [_G, _P, _P, _P, _L, _P]),
     "mn_conv2d_bwd_first_bn_gram": (_I, [_G, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),

@@ -169,6 +169,18 @@ __device__ __forceinline__ float dorefa_act_grad(float g, float x, float s) {
 // the DoReFa block BatchNorm + ReLU + next-layer quantizer (qact_kernels.hip): ReLU with ATen's NaN rule, and dz from the incoming gradient.
 // quant 1: gq is the gradient w.r.t. the QUANTISED activation (the quantizer's clip-STE is applied here); 0: w.r.t. the activation itself
 __device__ __forceinline__ float qa_relu(float z) { return (z > 0.f) ? z : ((z != z) ? z : 0.f); }
+// j = rha(c / s), c = clamp(0.1 a, 0, 1) >= 0, i.e. floor(fl(c / s) + 0.5).  The IEEE division is ~10 instructions per element and made k_qa_fwd
+// VALU-bound (2.9 TB/s of 3 B/elt).  q = c * n differs from fl(c / s) by a few ulp only (s = fl(1/n)), so floor(q + 0.5) is the same integer unless
+// q + 0.5 lies within 2e-4 of one (q <= 255: 3 ulp < 5e-5); only then the division is evaluated -- bit-identical codes, the branch is rarely taken.
+__device__ __forceinline__ uint32_t qa_code(float a, float s) {
+    const float c = mn_clamp(a * 0.1f, 0.f, 1.f);
+    const float nf = (float)(int)(1.0f / s + 0.5f);      // 2^bits - 1
+    const float t = c * nf + 0.5f;
+    float j = floorf(t);
+    const float r = t - j;
+    if (r < 2e-4f || r > 1.f - 2e-4f) j = floorf(c / s + 0.5f);
+    return (j > 0.f) ? (uint32_t)j : 0u;                 // NaN -> 0 (a byte cannot hold it)
+}
 __device__ __forceinline__ float qa_dz(float gq, float a, float z, float s, int quant) {
     const float d = quant ? dorefa_act_grad(gq, a, s) : gq;
     return (z > 0.f) ? d : 0.f;

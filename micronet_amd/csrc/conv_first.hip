@@ -53,6 +53,14 @@ struct C1Params {
     float qs;             // quantizer scale 1 / (2^a - 1)
     float qs_inv;         // RN(1 / qs) (qa_dz_m); 0: IEEE division
     int interval;         // BN 2: the block's masks as one interval of y per channel (A/B knob MN_QA_NO_INTERVAL)
+    // fused first block (k_c1b_fwd<MT, EPI 1 / 2>, k_c1_wgrad<MT, 3, 1>): the forward applies the BatchNorm (statistics known from the Gram data of x) and the
+    // activation in its epilogue and writes CODES (1 byte) + the backward's masks (1 byte per 4 pixels) instead of y (4 bytes)
+    const float* bn_save; // [2][O] mean, invstd
+    const float* bn_gamma;
+    const float* bn_beta;
+    void* codes;          // EPI 1: int8 sign codes; EPI 2: uint8 codes of the next conv's a-bit quantizer
+    uint8_t* mask4;       // [N][O][H W / 4]: low nibble = pass bits of 4 consecutive pixels (EPI 1: |z| < 1; EPI 2: z > 0), high nibble (EPI 2): ... and the clamp test
+    int mask_shift;       // backward: which nibble (4: the gradient is w.r.t. the QUANTISED activation)
 };
 
 // stage the image strip (with zero halo) of image n, rows [row0 - ph, row0 + R + KH - 1 - ph) into xs[c][prow][pcol]
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_c1_fwd(const C1Params p) {
 // writes against 36 fragment reads per chunk).
 #define C1B_KP 96            // padded K (3 K steps of 32)
 #define C1B_LD 104           // u16 per im2col row: 96 + 8 pad (208-byte rows: the 16 rows of a fragment read cover all banks)
-template <int MT>
+template <int MT, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
@@ -197,6 +205,12 @@ __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
     c1_stage(p, xs, n, row0);
     for (int k = tid; k < C1B_KP; k += 256) ktab[k] = k < p.K ? c1_koff(p, k) : -1;
     for (int i = tid; i < 64 * MT; i += 256) { const int m = cblk * 64 * MT + i; bs[i] = (p.bias && m < p.O) ? p.bias[m] : 0.f; }
+    float4* bc = reinterpret_cast<float4*>(bs + 64 * MT);          // EPI: [64 MT] mean, invstd, gamma, beta
+    if (EPI)
+        for (int i = tid; i < 64 * MT; i += 256) {
+            const int m = cblk * 64 * MT + i, mc = m < p.O ? m : p.O - 1;
+            bc[i] = make_float4(p.bn_save[mc], p.bn_save[p.O + mc], p.bn_gamma[mc], p.bn_beta[mc]);
+        }
     // A fragments: three exact bf16 terms of w[m0 + t * 16 + j][ks * 32 + kg * 8 .. + 7].  The block's weight rows are one contiguous range: they come through LDS
     // (the tile buffer, not yet in use: 16 MT rows x K <= 64 x 96 floats fit) one wave's rows per round, read from memory coalesced -- a lane fetching its 24 MT
     // elements itself touches a different 300-byte row per lane and element (measured on nin_gc's first layer: ~20 us of a 113 us kernel, all 512 blocks at once).
@@ -301,6 +315,9 @@ __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
             }
         // D[row = channel 4 kg + r][col j of n-tile q = pixel 4 j + q]: a float4 of 4 consecutive pixels per channel
         const int pix = chunk * 64 + 4 * j;
+        // (opaque per chunk: the 16 MT per-channel constants of the epilogue -- bias, and the BatchNorm's four -- are re-read from LDS; hoisted out of the chunk loop
+        //  they cost 80 registers the kernel does not have: 40 scratch reloads per chunk in the first fused build)
+        const int ch0 = (int)mn_opaque((uint32_t)(wave * 16 * MT));
         if (pix < npix) {
             const uint32_t prow = fd_div(pix, p.fd_w);
             const int pcol = pix - prow * p.W;
@@ -310,9 +327,34 @@ __global__ __launch_bounds__(256, 2) void k_c1b_fwd(const C1Params p) {
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + t * 16 + kg * 4 + r;
                     if (m < p.O) {
-                        const float bb = bs[wave * 16 * MT + t * 16 + kg * 4 + r];
+                        const float bb = bs[ch0 + t * 16 + kg * 4 + r];
                         float* dst = p.y + (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol;
                         float4 v = make_float4(acc[0][t][r] + bb, acc[1][t][r] + bb, acc[2][t][r] + bb, acc[3][t][r] + bb);
+                        if (EPI) {
+                            // BatchNorm + activation on the accumulators, expression for expression k_bns_apply<0, 1> / k_qa_fwd<1, 0, 0>: codes + pass bits leave, y does not
+                            const float4 c = bc[ch0 + t * 16 + kg * 4 + r];
+                            const float yv[4] = {v.x, v.y, v.z, v.w};
+                            uint32_t code = 0u, mk = 0u;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float zh = (yv[q] - c.x) * c.y;
+                                const float z = zh * c.z + c.w;
+                                if (EPI == 1) {
+                                    code |= (z < 0.f ? 0xFFu : 0x01u) << (8 * q);
+                                    mk |= (fabsf(z) < 1.f) ? (1u << q) : 0u;          // (-1 < z && z < 1, NaN included, as ONE compare with a source modifier)
+                                } else {
+                                    const float a = qa_relu(z);
+                                    code |= qa_code(a, p.qs) << (8 * q);
+                                    const float tq = a * 0.1f;
+                                    const bool pos = z > 0.f;
+                                    mk |= (pos ? (1u << q) : 0u) | ((pos && tq >= 0.f && tq <= 1.f) ? (16u << q) : 0u);
+                                }
+                            }
+                            const int64_t e = (((int64_t)n * p.O + m) * p.H + row0 + (int)prow) * p.W + pcol;
+                            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(p.codes) + e) = code;
+                            p.mask4[e >> 2] = (uint8_t)mk;
+                            continue;
+                        }
                         if (p.relu) { v.x = qa_relu(v.x); v.y = qa_relu(v.y); v.z = qa_relu(v.z); v.w = qa_relu(v.w); }
                         if (p.mm) {
                             lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
@@ -373,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
         roff[i] = (uint32_t)mc * (uint32_t)(p.H * p.W) + 4u * sq;
         dbs[i] = 0.f;
     }
-    if (BN) {
+    if (BN == 1 || BN == 2) {
         for (int r = lane; r < 16 * MT; r += 64) {
             const int m = m0 + r;
             const int mc = m < p.O ? m : p.O - 1;
@@ -422,7 +464,8 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const uint32_t off = tbase + roff[i] + (uint32_t)st * 32u;
-                if (BN) { ra[i] = *reinterpret_cast<const float4*>(p.da + off); rb[i] = *reinterpret_cast<const float4*>(p.yb + off); }
+                if (BN == 3) { ra[i] = *reinterpret_cast<const float4*>(p.da + off); rb[i].x = mn_u2f((uint32_t)p.mask4[off >> 2]); }
+                else if (BN) { ra[i] = *reinterpret_cast<const float4*>(p.da + off); rb[i] = *reinterpret_cast<const float4*>(p.yb + off); }
                 else ra[i] = *reinterpret_cast<const float4*>(p.gy + off);
             }
         };
@@ -432,7 +475,11 @@ __global__ __launch_bounds__(256, 2) void k_c1_wgrad(const C1Params p) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 float r[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-                if (BN) {
+                if (BN == 3) {          // the forward's pass bits: dz = the gradient where the bit is set
+                    const uint32_t mk = mn_f2u(rb[i].x) >> p.mask_shift;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = (mk >> e) & 1u ? r[e] : 0.f;
+                } else if (BN) {
                     const float yv[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
                     const float4 c0 = *reinterpret_cast<const float4*>(ctab + (sr + 8 * i) * 8);        // mean, invstd, gamma, beta
                     const float2 c1 = *reinterpret_cast<const float2*>(ctab + (sr + 8 * i) * 8 + 4);    // k1, k2
@@ -829,15 +876,42 @@ int c1_fwd_mm_count(const mn_conv_geom* g) {
 int c1_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes, hipStream_t s) {
     return c1_fwd_act(g, x, w, bias, y, 0, nullptr, ws, ws_bytes, s);
 }
+static size_t c1b_lds_bytes(const C1Params& p) {          // patch | tile (weight rows before the loop) | k table | bias | BatchNorm constants (fused epilogue)
+    return (size_t)p.xs_bytes + (size_t)3 * 64 * C1B_LD * 2 + C1B_KP * 4 + 64 * 4 * 4 + 64 * 4 * 16;
+}
+// the fused first block: act 1 = BatchNorm + sign -> int8 codes, act 2 = BatchNorm + ReLU + the next conv's a-bit DoReFa quantizer -> uint8 codes; mask4 for the backward
+int c1_fwd_bnact(const mn_conv_geom* g, const float* x, const float* w, const float* bias, const float* save, const float* gamma, const float* beta, int act, int a_bits,
+                 void* codes, uint8_t* mask4, hipStream_t s) {
+    C1Plan pl;
+    if (!plan_c1(g, &pl) || (((uintptr_t)codes) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_first_bnact_fwd: geometry not covered by the first-layer kernels");
+    if (!x || !w || !save || !gamma || !beta || !codes || !mask4 || (act != 1 && act != 2) || (act == 2 && (a_bits < 2 || a_bits > 8)))
+        MN_FAIL(MN_EINVAL, "mn_conv2d_first_bnact_fwd: bad arguments");
+    C1Params& p = pl.p;
+    p.x = x; p.bias = bias; p.y = nullptr; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0; p.da = nullptr;
+    p.relu = 0; p.mm = nullptr; p.wp = w;
+    p.bn_save = save; p.bn_gamma = gamma; p.bn_beta = beta; p.codes = codes; p.mask4 = mask4; p.qs = act == 2 ? dorefa_scale(a_bits) : 1.f;
+    const size_t lds_b = c1b_lds_bytes(p);
+    if (lds_b > 80 * 1024) MN_FAIL(MN_ENOTSUP, "mn_conv2d_first_bnact_fwd: image strip too large for the fused kernel");
+    mn_set_last_kernel("k_c1b_fwd<%d, %d>", pl.MT, act);
+    { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(1.25 * ny + 4.0 * g->N * g->C * g->H * g->W); }
+    mn_prof_begin(s);
+#define C1B_LAUNCH(MT_, E_) { raise_lds_limit((const void*)k_c1b_fwd<MT_, E_>, lds_b); hipLaunchKernelGGL((k_c1b_fwd<MT_, E_>), dim3(pl.grid_f), dim3(256), lds_b, s, p); }
+    if (act == 1) { if (pl.MT == 4) C1B_LAUNCH(4, 1) else if (pl.MT == 3) C1B_LAUNCH(3, 1) else if (pl.MT == 2) C1B_LAUNCH(2, 1) else C1B_LAUNCH(1, 1) }
+    else { if (pl.MT == 4) C1B_LAUNCH(4, 2) else if (pl.MT == 3) C1B_LAUNCH(3, 2) else if (pl.MT == 2) C1B_LAUNCH(2, 2) else C1B_LAUNCH(1, 2) }
+#undef C1B_LAUNCH
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_conv2d_first_bnact_fwd");
+    return MN_OK;
+}
 int c1_fwd_act(const mn_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int relu, float* mm, void* ws, int64_t ws_bytes, hipStream_t s) {
     C1Plan pl;
     if (!plan_c1(g, &pl) || !aligned16(y)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(first-layer): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes_f || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(first-layer): workspace too small");
     C1Params& p = pl.p;
     p.x = x; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0; p.da = nullptr;
-    p.relu = relu; p.mm = mm;
+    p.relu = relu; p.mm = mm; p.codes = nullptr; p.mask4 = nullptr;
     static const bool f32_path = MN_ENV("MN_C1_F32") != nullptr;          // A/B knob: the fp32-MFMA forward
-    const size_t lds_b = (size_t)p.xs_bytes + (size_t)3 * 64 * C1B_LD * 2 + C1B_KP * 4 + 64 * 4 * 4;          // patch | tile (weight rows before the loop) | k table | bias
+    const size_t lds_b = c1b_lds_bytes(p);
     if (!f32_path && lds_b <= 80 * 1024) {          // three-term bf16 forward (reads the weights as they are: no pack launch)
         p.wp = w;
         mn_set_last_kernel("k_c1b_fwd<%d>", pl.MT);
@@ -871,7 +945,8 @@ static void c1_launch_wgrad_mt(const C1Plan& pl, const C1Params& p, hipStream_t 
 }
 template <int MT>
 static void c1_launch_wgrad_dz_mt(const C1Plan& pl, const C1Params& p, hipStream_t s) {
-    if (p.chan) { raise_lds_limit((const void*)k_c1_wgrad<MT, 2, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 2, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    if (p.mask4) { raise_lds_limit((const void*)k_c1_wgrad<MT, 3, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 3, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
+    else if (p.chan) { raise_lds_limit((const void*)k_c1_wgrad<MT, 2, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 2, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
     else { raise_lds_limit((const void*)k_c1_wgrad<MT, 1, 1>, pl.lds); hipLaunchKernelGGL((k_c1_wgrad<MT, 1, 1>), dim3(pl.grid_w), dim3(256), pl.lds, s, p); }
 }
 static void c1_launch_wgrad_dz(const C1Plan& pl, const C1Params& p, hipStream_t s) {
@@ -957,12 +1032,26 @@ int c1_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int6
     MN_CHECK_LAUNCH("mn_conv2d_first_xgram");
     return MN_OK;
 }
+static int c1_bwd_first_any(const mn_conv_geom* g, const float* da, const float* yb, const uint8_t* mask4, double mask_scale, const float* save, const float* gamma,
+                            const float* beta, const float* chan, int quant, int a_bits, const float* w, const float* bias, const double* gram, const float* x, float* dw,
+                            float* dbias, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, hipStream_t s);
 int c1_bwd_first_gram(const mn_conv_geom* g, const float* da, const float* yb, const float* save, const float* gamma, const float* beta, const float* chan, int quant,
                       int a_bits, const float* w, const float* bias, const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
                       int64_t ws_bytes, hipStream_t s) {
+    return c1_bwd_first_any(g, da, yb, nullptr, 1.0, save, gamma, beta, chan, quant, a_bits, w, bias, gram, x, dw, dbias, dgamma, dbeta, ws, ws_bytes, s);
+}
+// the fused first block's backward: mask4 = the forward's pass bits (quant: their high nibble, rows scaled by 0.1)
+int c1_bwd_first_mask(const mn_conv_geom* g, const float* da, const uint8_t* mask4, int quant, const float* save, const float* gamma, const float* w, const float* bias,
+                      const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, hipStream_t s) {
+    if (!mask4 || !save || !gamma) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_first_mask_gram: null argument");
+    return c1_bwd_first_any(g, da, nullptr, mask4, quant ? 0.1 : 1.0, save, gamma, gamma, nullptr, quant, 0, w, bias, gram, x, dw, dbias, dgamma, dbeta, ws, ws_bytes, s);
+}
+static int c1_bwd_first_any(const mn_conv_geom* g, const float* da, const float* yb, const uint8_t* mask4, double mask_scale, const float* save, const float* gamma,
+                            const float* beta, const float* chan, int quant, int a_bits, const float* w, const float* bias, const double* gram, const float* x, float* dw,
+                            float* dbias, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, hipStream_t s) {
     C1Plan pl;
-    if (!plan_c1(g, &pl, 2) || !aligned16(da) || !aligned16(yb)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_first_gram: geometry not covered by the first-layer kernels");
-    if (!da || !yb || !w || !gram || !x || !dw || (!chan && (!save || !gamma || !beta))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_first_gram: null argument");
+    if (!plan_c1(g, &pl, 2) || !aligned16(da) || (yb && !aligned16(yb))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_first_gram: geometry not covered by the first-layer kernels");
+    if (!da || (!yb && !mask4) || !w || !gram || !x || !dw || (!chan && (!save || !gamma || !beta))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_first_gram: null argument");
     if (chan && (a_bits < 2 || a_bits > 8)) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_first_gram: activation bits out of range");
     if (!ws || ws_bytes < pl.ws_bytes_w || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_first_gram: workspace too small");
     C1Params& p = pl.p;
@@ -972,14 +1061,15 @@ int c1_bwd_first_gram(const mn_conv_geom* g, const float* da, const float* yb, c
     p.da = da; p.yb = yb; p.save = save; p.gamma = gamma; p.beta = beta; p.sums = nullptr; p.training = 0;          // (k1, k2 of the fold are not used: DZ)
     p.n_f = (float)g->N * (float)(g->H * g->W);
     p.chan = chan; p.quant = quant; p.qs = qs; p.qs_inv = (qs > 0.f && !MN_ENV("MN_QA_IEEE_DIV")) ? 1.0f / qs : 0.f; p.interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
-    mn_set_last_kernel("k_c1_wgrad<%d, %d, 1>", pl.MT, chan ? 2 : 1);
-    { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(8.0 * ny + 4.0 * g->N * g->C * g->H * g->W); }
+    p.mask4 = const_cast<uint8_t*>(mask4); p.mask_shift = (mask4 && quant) ? 4 : 0;
+    mn_set_last_kernel("k_c1_wgrad<%d, %d, 1>", pl.MT, mask4 ? 3 : (chan ? 2 : 1));
+    { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((mask4 ? 4.25 : 8.0) * ny + 4.0 * g->N * g->C * g->H * g->W); }
     mn_prof_begin(s);
     c1_launch_wgrad_dz(pl, p, s);
     mn_prof_end(s);
     C1BnFin f;
     f.part = p.part; f.Z = p.Z; f.O = p.O; f.K = p.K; f.Opad = p.Opad; f.w = w; f.bias = bias; f.save = save; f.gamma = gamma; f.chan = chan; f.gram = gram;
-    f.scale = (chan && quant) ? 0.1 : 1.0;
+    f.scale = mask4 ? mask_scale : ((chan && quant) ? 0.1 : 1.0);
     f.n = (double)g->N * (double)(g->H * g->W); f.dw = dw; f.dbias = dbias; f.dgamma = dgamma; f.dbeta = dbeta;
     hipLaunchKernelGGL(k_c1_bn_final, dim3(p.O), dim3(320), 0, s, f);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_first_gram");

@@ -864,6 +864,20 @@ extern "C" int mn_conv2d_first_xgram(const mn_conv_geom* g, const float* x, doub
     if (!x || !gram || (((uintptr_t)gram) & 7)) MN_FAIL(MN_EINVAL, "mn_conv2d_first_xgram: null / misaligned tensor");
     return c1_xgram(g, x, gram, ws, ws_bytes, (hipStream_t)stream);
 }
+extern "C" int mn_conv2d_first_bnact_fwd(const mn_conv_geom* g, const float* x, const float* w, const float* bias, const float* save, const float* gamma,
+                                        const float* beta, int act, int a_bits, void* codes, uint8_t* mask4, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_first_bnact_fwd");
+    if (rc) return rc;
+    if (!c1_supported(g, 0) || !c1_supported(g, 2)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_first_bnact_fwd: geometry not covered by the first-layer kernels");
+    return c1_fwd_bnact(g, x, w, bias, save, gamma, beta, act, a_bits, codes, mask4, (hipStream_t)stream);
+}
+extern "C" int mn_conv2d_bwd_first_mask_gram(const mn_conv_geom* g, const float* da, const uint8_t* mask4, int quant, const float* save, const float* gamma,
+                                             const float* w, const float* bias, const double* gram, const float* x, float* dw, float* dbias, float* dgamma,
+                                             float* dbeta, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_first_mask_gram");
+    if (rc) return rc;
+    return c1_bwd_first_mask(g, da, mask4, quant, save, gamma, w, bias, gram, x, dw, dbias, dgamma, dbeta, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int mn_conv2d_first_gram_bnstats(const mn_conv_geom* g, const float* w, const float* bias, const double* gram, float eps, float momentum,
                                            float* running_mean, float* running_var, float* save, mn_stream_t stream) {
     int rc = check_geom(g, "mn_conv2d_first_gram_bnstats");

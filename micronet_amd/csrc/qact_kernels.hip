@@ -27,6 +27,7 @@ struct QaGeom {
     float inv_s;            // RN(1 / s) for the division-free clip-STE (qa_dz_m); 0: the IEEE division
     int interval;           // backward passes: the ReLU / clamp masks as one interval of the streamed value per channel (qa_mask_interval; knob MN_QA_NO_INTERVAL)
     int nthr;               // > 0 (mn_qa_fwd on the integer stash, <= 3 bit codes): levels 2^a - 1 of the integer-threshold forward
+    uint8_t* mask4;         // mn_qa_fwd_f32_mask (fp32 input, no pool, codes out): also the backward's pass nibbles, one byte per 4 elements (as mn_conv2d_first_bnact_fwd act 2)
 };
 struct QaCh { float alpha, bias, mean, invstd, ga, be, A, B, gi; };
 __device__ __forceinline__ QaCh qa_load_ch(const float* __restrict__ chan, int C, int c) {
@@ -40,18 +41,6 @@ __device__ __forceinline__ void qa_eval(float v, const QaCh& k, float& zh, float
     const float y = IN == 1 ? v : v * k.alpha + k.bias;
     zh = (y - k.mean) * k.invstd;
     z = zh * k.ga + k.be;
-}
-// j = rha(c / s), c = clamp(0.1 a, 0, 1) >= 0, i.e. floor(fl(c / s) + 0.5).  The IEEE division is ~10 instructions per element and made k_qa_fwd
-// VALU-bound (2.9 TB/s of 3 B/elt).  q = c * n differs from fl(c / s) by a few ulp only (s = fl(1/n)), so floor(q + 0.5) is the same integer unless
-// q + 0.5 lies within 2e-4 of one (q <= 255: 3 ulp < 5e-5); only then the division is evaluated -- bit-identical codes, the branch is rarely taken.
-__device__ __forceinline__ uint32_t qa_code(float a, float s) {
-    const float c = mn_clamp(a * 0.1f, 0.f, 1.f);
-    const float nf = (float)(int)(1.0f / s + 0.5f);      // 2^bits - 1
-    const float t = c * nf + 0.5f;
-    float j = floorf(t);
-    const float r = t - j;
-    if (r < 2e-4f || r > 1.f - 2e-4f) j = floorf(c / s + 0.5f);
-    return (j > 0.f) ? (uint32_t)j : 0u;                 // NaN -> 0 (a byte cannot hold it)
 }
 // 8 consecutive elements (one row segment) of channel c at group index i: element offset
 __device__ __forceinline__ int64_t qa_off8(const QaGeom& g, int c, uint32_t i) {
@@ -166,8 +155,20 @@ __global__ __launch_bounds__(256) void k_qa_fwd(const QaGeom g, const void* __re
             const int64_t off = qa_off8(g, c, (uint32_t)i);
             float v[8], a[8];
             qa_load8<IN>(in, off, v);
+            uint32_t mk = 0u;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { float zh, z; qa_eval<IN>(v[e], k, zh, z); a[e] = qa_relu(z); }
+            for (int e = 0; e < 8; ++e) {
+                float zh, z;
+                qa_eval<IN>(v[e], k, zh, z);
+                a[e] = qa_relu(z);
+                if (IN == 1 && !OUT) {          // low nibble: z > 0; high nibble: ... and the quantizer's clamp test (dorefa_act_grad_m)
+                    const float tq = a[e] * 0.1f;
+                    const bool pos = z > 0.f;
+                    mk |= (pos ? (1u << (e & 3)) : 0u) << (8 * (e >> 2));
+                    mk |= ((pos && tq >= 0.f && tq <= 1.f) ? (16u << (e & 3)) : 0u) << (8 * (e >> 2));
+                }
+            }
+            if (IN == 1 && !OUT && g.mask4) *reinterpret_cast<uint16_t*>(g.mask4 + (off >> 2)) = (uint16_t)mk;
             if (OUT) {
                 *reinterpret_cast<float4*>(af + off) = make_float4(a[0], a[1], a[2], a[3]);
                 *reinterpret_cast<float4*>(af + off + 4) = make_float4(a[4], a[5], a[6], a[7]);
@@ -440,6 +441,7 @@ static int qa_geom(QaGeom* g, int64_t N, int64_t C, int64_t H, int64_t W, int bi
     g->inv_s = MN_ENV("MN_QA_IEEE_DIV") ? 0.f : 1.0f / g->s;
     g->interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
     g->nthr = 0;
+    g->mask4 = nullptr;
     return MN_OK;
 }
 static int qa_split(const QaGeom& g) {
@@ -493,6 +495,25 @@ extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t 
     }
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_qa_fwd");
+    return MN_OK;
+}
+/* mn_qa_fwd(in_f32 = 1, pool = 0, codes) that also writes the pass nibbles mn_conv2d_bwd_first_mask_gram reads (mask4 [N][C][H W / 4]) */
+extern "C" int mn_qa_fwd_f32_mask(const float* y, const float* chan, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, uint8_t* codes, uint8_t* mask4,
+                                  mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, a_bits, 0, "mn_qa_fwd_f32_mask");
+    if (rc) return rc;
+    if (!y || !chan || !codes || !mask4 || !aligned16(y) || (((uintptr_t)codes) & 7) || (((uintptr_t)mask4) & 1)) MN_FAIL(MN_EINVAL, "mn_qa_fwd_f32_mask: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    g.mask4 = mask4;
+    const dim3 grid((unsigned)C, (unsigned)qa_split(g));
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qa_fwd<1, 0>");
+    mn_prof_bytes(nel * 5.25);
+    mn_prof_begin(s);
+    hipLaunchKernelGGL((k_qa_fwd<1, 0, 0>), grid, dim3(256), 0, s, g, (const void*)y, chan, codes, (float*)nullptr);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qa_fwd_f32_mask");
     return MN_OK;
 }
 extern "C" int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, int quant,

@@ -28,6 +28,10 @@ int c1_bwd_weight_qa(const mn_conv_geom* g, const float* dq, const float* yb, co
 // one-pass backward of the first block: Gram data of x's im2col rows (gram: 80 x 80 doubles), then dz-only backward-weight + per-channel finish
 int64_t c1_xgram_ws_bytes(const mn_conv_geom* g);
 int c1_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int64_t ws_bytes, hipStream_t s);
+int c1_fwd_bnact(const mn_conv_geom* g, const float* x, const float* w, const float* bias, const float* save, const float* gamma, const float* beta, int act, int a_bits,
+                 void* codes, uint8_t* mask4, hipStream_t s);
+int c1_bwd_first_mask(const mn_conv_geom* g, const float* da, const uint8_t* mask4, int quant, const float* save, const float* gamma, const float* w, const float* bias,
+                      const double* gram, const float* x, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, hipStream_t s);
 int c1_gram_bnstats(const mn_conv_geom* g, const float* w, const float* bias, const double* gram, float eps, float momentum, float* running_mean, float* running_var,
                     float* save, hipStream_t s);
 int c1_bwd_first_gram(const mn_conv_geom* g, const float* da, const float* yb, const float* save, const float* gamma, const float* beta, const float* chan, int quant,

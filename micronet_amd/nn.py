@@ -13,10 +13,15 @@ from .sign_tensor import LazyConvOut, SignTensor
 
 
 class Conv2dFirst(nn.Conv2d):
+    lazy_for_bn = False        # True (set by prepare()): a fused BatchNorm block of ours consumes the output in training mode -> it may stay un-computed (ops.FirstConvLazy)
+
     def forward(self, input):
         if (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and self.padding_mode == "zeros" and
                 not isinstance(input, (SignTensor, LazyConvOut)) and not isinstance(self.padding, str) and
                 ops.first_conv_supported(input.shape, self.weight.shape, self.stride, self.padding, self.dilation, self.groups)):
+            if (self.lazy_for_bn and self.training and ops.FIRST_FUSED and (self.lazy_for_bn != "qa" or ops.FIRST_FUSED_QA) and ops.FIRST_GRAM and ops.LAZY_BN_GRAD and torch.is_grad_enabled() and
+                    not input.requires_grad and self.weight.requires_grad and type(input) is torch.Tensor):
+                return ops.FirstConvLazy.apply(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
             out = ops.qconv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
             if not input.requires_grad:
                 out._mn_first_conv_out = True      # no backward-data: a BatchNorm2dBinAct behind it may hand its gradient over lazily

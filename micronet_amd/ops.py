@@ -1257,6 +1257,23 @@ def _first_gram(rec, eps, momentum, running_mean, running_var):
     return gram, save
 
 
+def _first_mask_backward(rec, gram, mask4, da, quant, chan, gamma):
+    """The one-pass backward of the first block on (da, pass nibbles): -> (dw, dbias, dgamma, dbeta).  chan rows 2, 3 = the BatchNorm's saved mean, invstd."""
+    x, w, b = _chk(rec.x, "input"), _chk(rec.w, "weight"), _chk(rec.bias, "bias")
+    g = _geom(x.shape, w.shape, *rec.conv)
+    dev = da.device
+    save = chan[2:4]
+    with torch.cuda.device_of(da):
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b) if b is not None else None
+        dgamma, dbeta = torch.empty(g.O, dtype=torch.float32, device=dev), torch.empty(g.O, dtype=torch.float32, device=dev)
+        ws, nb = _ws(g, 2, dev)
+        with _span(g, 2, 4.25 * da.numel() + 4 * x.numel()):
+            _call("mn_conv2d_bwd_first_mask_gram", C.byref(g), _p(da), _p(mask4), int(quant), _p(save), _p(gamma), _p(w), _p(b), _p(gram), _p(x), _p(dw), _p(db),
+                  _p(dgamma), _p(dbeta), _p(ws), nb, _s())
+    return dw, db, dgamma, dbeta
+
+
 def _first_gram_backward(rec, gram, y, kind, da, save, gamma, beta, chan, bits, quant):
     """-> (dw, dbias, dgamma, dbeta) of the first block in ONE pass over (da, y); kind "bn": BatchNorm + sign (save, gamma, beta); "qa": the DoReFa block (chan)."""
     lib = _lib_()
@@ -2168,11 +2185,16 @@ class BNReLUQ(Function):
             with torch.cuda.device(dev):
                 _call("mn_qa_fwd", in_f32, _p(src), _p(chan), N, Cc, H, W, qbits, int(bool(pool)), None, _p(act), _s())
             return act
+        ctx.mask4 = None
         if not out_bits:
             return materialize()
         codes = torch.empty((N, Cc, Ho, Wo), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _call("mn_qa_fwd", in_f32, _p(src), _p(chan), N, Cc, H, W, qbits, int(bool(pool)), _p(codes), None, _s())
+            if rec is not None:          # the first block: the pass also leaves the backward's pass nibbles (1 byte per 4 elements) -- the backward then reads them, not y
+                ctx.mask4 = torch.empty((N, Cc, (H * W) // 4), dtype=torch.uint8, device=dev)
+                _call("mn_qa_fwd_f32_mask", _p(src), _p(chan), N, Cc, H, W, qbits, _p(codes), _p(ctx.mask4), _s())
+            else:
+                _call("mn_qa_fwd", in_f32, _p(src), _p(chan), N, Cc, H, W, qbits, int(bool(pool)), _p(codes), None, _s())
         return QActTensor(codes, out_bits, materialize, pooled=bool(pool))
 
     @staticmethod
@@ -2187,8 +2209,11 @@ class BNReLUQ(Function):
         if ctx.first is not None:
             # the block behind the un-quantised first conv, one pass over (dq, y): dw, dgamma, dbeta at once (csrc/conv_first.hip, the Gram data of x)
             dq = _chk(dq, "grad")
-            dw1, db1, dgamma, dbeta = _first_gram_backward(ctx.first, ctx.gram, src, "qa", dq, None, None, None, chan, qbits, quant)
-            ctx.gram = None
+            if ctx.mask4 is not None:
+                dw1, db1, dgamma, dbeta = _first_mask_backward(ctx.first, ctx.gram, ctx.mask4, dq, quant, chan, gamma)
+            else:
+                dw1, db1, dgamma, dbeta = _first_gram_backward(ctx.first, ctx.gram, src, "qa", dq, None, None, None, chan, qbits, quant)
+            ctx.gram = ctx.mask4 = None
 
             def expand1(r):
                 dy_ = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
@@ -2423,6 +2448,154 @@ class ConvTranspose2d(Function):
             if has_bias and ctx.needs_input_grad[2]:
                 db = gy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None, None
+
+
+FIRST_FUSED = _os0.environ.get("MN_FIRST_FUSED", "1") != "0"          # the fused first block (A/B knob; 0: conv, then the BatchNorm block's own kernels)
+FIRST_FUSED_QA = _os0.environ.get("MN_FIRST_FUSED_QA", "0") == "1"     # ... for the DoReFa block too (off: its epilogue -- the quantizer's rounding -- makes the fused
+#                                                                         forward VALU-bound, 209 us against 110 + 58 us for conv + mn_qa_fwd_f32_mask on nin_gc at batch 256)
+
+
+class FirstConvLazy(Function):
+    """The un-quantised first convolution whose result is NOT computed: a ``LazyConvOut`` (kind "first") carrying the operands.  The BatchNorm block that prepare()
+    found behind it runs conv + BatchNorm + activation in ONE kernel (``FirstConvBNSign`` / ``FirstConvBNReLUQ``: the statistics come from the Gram data of the
+    image, so the conv's epilogue can normalise) and y -- the largest tensor of the step -- is neither written nor read.  Any other consumer materialises y."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, dilation, groups):
+        x, w, bias = _chk(x, "input"), _chk(w, "weight"), _chk(bias, "bias")
+        g = _geom(x.shape, w.shape, stride, padding, dilation, groups)
+        Ho, Wo = _out_hw(g)
+        ctx.save_for_backward(x, w, None, None)
+        ctx.cfg = (g, ACTQ_NONE, 8, 0, bias is not None, None, 0)
+
+        def compute():
+            y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
+            aq = ActQ(ACTQ_NONE, 8, 0, 0, None)
+            with torch.cuda.device_of(x):
+                ws, nb = _ws(g, 0, x.device)
+                _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), None, _p(x), _p(w), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
+            return y
+        recipe = dict(kind="first", x=x, w=w, bias=bias, geom=g, conv=(stride, padding, dilation, groups), compute=compute)
+        return LazyConvOut((g.N, g.O, Ho, Wo), x.device, recipe)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return QConv2d.backward(ctx, gy)[:7]
+
+
+class _FirstRec:
+    def __init__(self, r):
+        self.x, self.w, self.bias, self.conv = r["x"], r["w"], r["bias"], r["conv"]
+
+
+def _first_fused_backward(ctx, da, quant, expand):
+    mask4, gamma, beta, save, x, w, b = ctx.saved_tensors
+    g = ctx.geom
+    dev = x.device
+    with torch.cuda.device_of(x):
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b) if b is not None else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        ws, nb = _ws(g, 2, dev)
+        with _span(g, 2, 4.25 * da.numel() + 4 * x.numel()):
+            _call("mn_conv2d_bwd_first_mask_gram", C.byref(g), _p(da), _p(mask4), int(quant), _p(save), _p(gamma), _p(w), _p(b), _p(ctx.gram), _p(x), _p(dw), _p(db),
+                  _p(dgamma), _p(dbeta), _p(ws), nb, _s())
+    ctx.gram = None
+    recipe = dict(kind="first_done", dw=dw, db=db, x=x, w=w, da=da, save=save, gamma=gamma, beta=beta, compute=ctx.compute, quant=quant)
+    return LazyBNGrad((g.N, g.O, g.H, g.W), dev, recipe, expand), dgamma, dbeta
+
+
+class FirstConvBNSign(Function):
+    """sign(batch_norm(conv(x))) of the first block, training mode, for a ``LazyConvOut`` of kind "first": Gram data of x -> batch statistics -> ONE kernel that
+    convolves, normalises and writes int8 sign codes + the backward's pass bits (mn_conv2d_first_bnact_fwd).  Backward: the one-pass first-block backward on
+    (da, pass bits) -- dw, dbias, dgamma, dbeta at once (mn_conv2d_bwd_first_mask_gram); the conv node receives the finished dw / dbias."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum):
+        r = y.recipe
+        x, w, b, g = r["x"], r["w"], r["bias"], r["geom"]
+        gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
+        ctx.gram, save = _first_gram(_FirstRec(r), eps, momentum, running_mean, running_var)
+        a = torch.empty((g.N, g.O, g.H, g.W), dtype=torch.int8, device=x.device)
+        mask4 = torch.empty((g.N, g.O, (g.H * g.W) // 4), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device_of(x):
+            with _span(g, 0, 4 * x.numel() + 1.25 * a.numel()):
+                _call("mn_conv2d_first_bnact_fwd", C.byref(g), _p(x), _p(w), _p(b), _p(save), _p(gamma), _p(beta), 1, 0, _p(a), _p(mask4), _s())
+        ctx.save_for_backward(mask4, gamma, beta, save, x, w, b)
+        ctx.geom, ctx.compute = g, r["compute"]
+        return SignTensor(a)
+
+    @staticmethod
+    def backward(ctx, da):
+        da = _chk(da, "grad")
+
+        def expand(r):
+            yv = r["compute"]()
+            N, Cc, HW = yv.shape[0], yv.shape[1], yv.shape[2] * yv.shape[3]
+            dy_ = torch.empty_like(yv)
+            with torch.cuda.device_of(dy_):
+                ws_ = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=dy_.device)
+                _call("mn_bnsign_bwd", _p(r["da"]), _p(yv), _p(r["save"]), _p(r["gamma"]), _p(r["beta"]), N, Cc, HW, 1, _p(dy_), None, None, _p(ws_), _s())
+            return dy_
+        gyl, dgamma, dbeta = _first_fused_backward(ctx, da, 0, expand)
+        return gyl, dgamma, dbeta, None, None, None, None
+
+
+class FirstConvBNReLUQ(Function):
+    """relu(batch_norm(conv(x))) -> the a-bit activation quantizer of the next QuantConv2d, for the first block of a DoReFa net (``LazyConvOut`` of kind "first"):
+    as ``FirstConvBNSign`` with uint8 quantizer codes (a ``QActTensor``) and two pass nibbles (ReLU; ReLU and the quantizer's clamp)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, out_bits):
+        r = y.recipe
+        x, w, b, g = r["x"], r["w"], r["bias"], r["geom"]
+        gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
+        ctx.gram, save = _first_gram(_FirstRec(r), eps, momentum, running_mean, running_var)
+        N, Cc, H, W = g.N, g.O, g.H, g.W
+        dev = x.device
+        codes = torch.empty((N, Cc, H, W), dtype=torch.uint8, device=dev)
+        mask4 = torch.empty((N, Cc, (H * W) // 4), dtype=torch.uint8, device=dev)
+        with torch.cuda.device_of(x):
+            with _span(g, 0, 4 * x.numel() + 1.25 * codes.numel()):
+                _call("mn_conv2d_first_bnact_fwd", C.byref(g), _p(x), _p(w), _p(b), _p(save), _p(gamma), _p(beta), 2, int(out_bits), _p(codes), _p(mask4), _s())
+        ctx.save_for_backward(mask4, gamma, beta, save, x, w, b)
+        ctx.geom, ctx.compute, ctx.bits = g, r["compute"], int(out_bits)
+        compute = r["compute"]
+
+        def chan_of():
+            chan = torch.empty((9, Cc), dtype=torch.float32, device=dev)
+            _call("mn_qa_chan_from_save", _p(save), _p(gamma), _p(beta), Cc, _p(chan), _s())
+            return chan
+
+        def materialize():
+            with torch.cuda.device(dev):
+                yv, act = compute(), torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+                _call("mn_qa_fwd", 1, _p(yv), _p(chan_of()), N, Cc, H, W, int(out_bits), 0, None, _p(act), _s())
+            return act
+        ctx.chan_of = chan_of
+        return QActTensor(codes, int(out_bits), materialize, pooled=False)
+
+    @staticmethod
+    def backward(ctx, g_):
+        if isinstance(g_, QGrad) and g_._mn_value is None and g_._mn_dq2 is None:
+            dq, quant = _chk(g_._mn_dq, "grad"), 1          # gradient w.r.t. the quantised activation: the clip-STE = the high pass nibble and the factor 0.1
+        else:
+            dq, quant = _chk(g_, "grad"), 0
+        bits, chan_of = ctx.bits, ctx.chan_of
+
+        def expand(r):
+            yv = r["compute"]()
+            N, Cc, H, W = yv.shape
+            dy_ = torch.empty_like(yv)
+            with torch.cuda.device_of(dy_):
+                chan = chan_of()
+                sums_ = torch.empty((2, Cc), dtype=torch.float32, device=dy_.device)
+                ws_ = torch.empty(int(_lib_().mn_qa_ws_floats(Cc)), dtype=torch.float32, device=dy_.device)
+                _call("mn_qa_bwd_sums", 1, _p(yv), _p(chan), _p(r["da"]), N, Cc, H, W, bits, 0, r["quant"], None, None, _p(sums_), _p(ws_), _s())
+                _call("mn_qa_bwd_apply", 1, _p(yv), _p(chan), _p(sums_), _p(r["da"]), N, Cc, H, W, bits, 0, r["quant"], 1, _p(dy_), _s())
+            return dy_
+        gyl, dgamma, dbeta = _first_fused_backward(ctx, dq, quant, expand)
+        return gyl, dgamma, dbeta, None, None, None, None, None
 
 
 def first_conv_supported(x_shape, w_shape, stride, padding, dilation, groups):

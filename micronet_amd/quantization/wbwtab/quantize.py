@@ -121,7 +121,8 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
             return super().forward(input)
         use_batch = self.training or self.running_mean is None
         momentum = 0.0 if self.momentum is None else self.momentum
-        fused = isinstance(input, LazyConvOut) and (use_batch or self.track_running_stats)
+        first = isinstance(input, LazyConvOut) and input.recipe.get("kind") == "first"          # the un-computed output of the first (un-quantised) conv
+        fused = isinstance(input, LazyConvOut) and not first and (use_batch or self.track_running_stats)
         nbt = None
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             if fused and self.momentum is not None and self.num_batches_tracked.dtype == torch.int64 and self.num_batches_tracked.is_cuda:
@@ -134,6 +135,10 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
             # the conv in front did not compute its output: conv + statistics + normalisation + sign in the fused kernels
             return ops.ConvBNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                         self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, nbt)
+        if first and use_batch and self.packed and input._mn_value is None:
+            # conv + batch statistics (from the Gram data of the image) + normalisation + sign in one kernel: the conv output is never written
+            return ops.FirstConvBNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                             self.running_var if self.track_running_stats else None, self.eps, momentum)
         out = ops.BNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, bool(self.packed),
                                bool(getattr(input, "_mn_first_conv_out", False)))
@@ -298,7 +303,7 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                 if fuse_bn_act and A == 2 and type(prev) is nn.BatchNorm2d and prev.affine and _ordered_parent(module):
                     prev.__class__ = BatchNorm2dBinAct
                     prev.packed = bool(packed_activations)
-                    if packed_activations and fuse_conv_bn and isinstance(prev2, QuantConv2d):
+                    if packed_activations and fuse_conv_bn and isinstance(prev2, (QuantConv2d, Conv2dFirst)):
                         prev2.lazy_for_bn = True        # conv -> bn -> sign in definition order: the conv output need never be stored
         elif type(child) is nn.MaxPool2d and packed_activations and A == 2:
             child.__class__ = MaxPool2dSign       # same object and state; pools SignTensors without unpacking them

@@ -214,6 +214,15 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
         from micronet_amd.sign_tensor import LazyQConvOut
         import torch.nn.functional as F
         lazy = isinstance(input, LazyQConvOut)
+        from micronet_amd.sign_tensor import LazyConvOut
+        if ops.FIRST_FUSED_QA and isinstance(input, LazyConvOut) and input.recipe.get("kind") == "first" and input._mn_value is None and self.affine and self.momentum is not None and \
+                self.training and self.q_out_bits and not self.q_pool and not self.q_also_f32:
+            # the un-computed output of the first (un-quantised) conv: conv + batch statistics (Gram data of the image) + BatchNorm + ReLU + the next conv's
+            # quantizer in one kernel
+            if self.track_running_stats and self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return ops.FirstConvBNReLUQ.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                              self.running_var if self.track_running_stats else None, self.eps, self.momentum, int(self.q_out_bits))
         plain_ok = self.affine and ops.bnrelu_supported(input)
         use_batch = self.training or self.running_mean is None
         stats_ok = self.momentum is not None and (use_batch or self.track_running_stats)
@@ -351,6 +360,9 @@ def _fuse_blocks(model, fold_shuffle=True):
                 if 2 <= bits <= 8 and 2 <= nxt.conv.weight_quantizer.w_bits <= 8:          # (8-bit codes: the wide kernels, 32-bit stash)
                     blk.bn.q_out_bits = int(bits)
                     blk.bn.q_pool = pool is not None
+                    from micronet_amd.nn import Conv2dFirst
+                    if isinstance(blk.conv, Conv2dFirst) and pool is None and not getattr(blk, "channel_shuffle_flag", 0):
+                        blk.conv.lazy_for_bn = "qa"          # the first block: conv + BatchNorm + ReLU + quantizer in one kernel (ops.FirstConvBNReLUQ, knob MN_FIRST_FUSED_QA)
                     if pool is not None:
                         pool._mn_fused_pool = True
 

@@ -890,6 +890,73 @@ def check_first_conv_gram_bwd(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, kind="bn", q
     assert np.abs(be.to_host(db)).max() <= 1e-4 * max(np.abs(be.to_host(dbet)).max(), 1e-30)
 
 
+def check_first_conv_fused(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, act=1, bits=2, bias=True, seed=0):
+    """The fused first block (mn_conv2d_first_bnact_fwd: conv + BatchNorm + sign / ReLU + quantizer in one kernel, codes + pass bits instead of y; backward on
+    (da, mask4)) against the unfused kernels on the same statistics: identical codes, identical masks, bit-identical gradients."""
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    HW = H * W
+    x = r.standard_normal(x_shape).astype(F)
+    w = (r.standard_normal((Oc, Cin, k, k)) * 0.2).astype(F)
+    b = (r.standard_normal(Oc) * 0.3).astype(F) if bias else None
+    da = r.standard_normal((N, Oc, H, W)).astype(F)
+    if act == 1:
+        gamma, beta = (r.standard_normal(Oc) * 0.5 + 1).astype(F), (r.standard_normal(Oc) * 0.3).astype(F)
+    else:
+        gamma, beta = (r.standard_normal(Oc) * 2.0 + 3.0).astype(F), (r.standard_normal(Oc) * 2.0 + 3.0).astype(F)
+    g = be.geom(x_shape, (Oc, Cin, k, k), padding=k // 2)
+    dX, dW, dBi, dDA, dG, dB = be.to_dev(x), be.to_dev(w), (be.to_dev(b) if bias else None), be.to_dev(da), be.to_dev(gamma), be.to_dev(beta)
+    dY = be.conv_fwd(g, be.actq(0), dX, dW, dBi, 0)
+    nbg = int(be.lib.mn_conv2d_first_xgram_ws_bytes(C.byref(g)))
+    wsg, gram, sv = be.empty(nbg // 4 + 4), be.empty(2 * 80 * 80), be.empty((2, Oc))
+    be.call("mn_conv2d_first_xgram", C.byref(g), be.ptr(dX), be.ptr(gram), be.ptr(wsg), nbg, be.stream)
+    be.call("mn_conv2d_first_gram_bnstats", C.byref(g), be.ptr(dW), be.ptr(dBi), be.ptr(gram), 1e-5, 0.1, None, None, be.ptr(sv), be.stream)
+    # host: z exactly as the kernels evaluate it (fp32, no contraction)
+    yh, svh = be.to_host(dY), be.to_host(sv)
+    c4 = lambda v: v.astype(F)[None, :, None, None]
+    z = ((yh - c4(svh[0])) * c4(svh[1])) * c4(gamma) + c4(beta)
+    if act == 1:
+        codes_ref = np.where(z < 0, -1, 1).astype(np.int8)
+        lo_bits, hi_bits = (z > -1) & (z < 1), np.zeros_like(z, dtype=bool)
+    else:
+        chan = be.empty((9, Oc))
+        be.call("mn_qa_chan_from_save", be.ptr(sv), be.ptr(dG), be.ptr(dB), Oc, be.ptr(chan), be.stream)
+        cref = be.to_dev_u8(np.zeros((N, Oc, H, W), dtype=np.uint8))
+        be.call("mn_qa_fwd", 1, be.ptr(dY), be.ptr(chan), N, Oc, H, W, bits, 0, be.ptr(cref), None, be.stream)
+        codes_ref = be.to_host(cref)
+        a = np.where(z > 0, z, 0).astype(F)
+        t = a * F(0.1)
+        lo_bits, hi_bits = z > 0, (z > 0) & (t >= 0) & (t <= 1)
+    pack = lambda bts: (bts.reshape(N, Oc, HW // 4, 4) * np.array([1, 2, 4, 8])).sum(-1).astype(np.uint8)
+    mask_ref = pack(lo_bits) | (pack(hi_bits) << 4)
+    codes = be.to_dev_i8(np.zeros((N, Oc, H, W), dtype=np.int8)) if act == 1 else be.to_dev_u8(np.zeros((N, Oc, H, W), dtype=np.uint8))
+    mask4 = be.to_dev_u8(np.zeros((N, Oc, HW // 4), dtype=np.uint8))
+    be.call("mn_conv2d_first_bnact_fwd", C.byref(g), be.ptr(dX), be.ptr(dW), be.ptr(dBi), be.ptr(sv), be.ptr(dG), be.ptr(dB), act, bits, be.ptr(codes), be.ptr(mask4), be.stream)
+    assert eq(be.to_host(codes), codes_ref)
+    assert eq(be.to_host(mask4), mask_ref)
+    if act == 2:          # the unfused forward pass that leaves the same nibbles
+        c2_, m2_ = be.to_dev_u8(np.zeros((N, Oc, H, W), dtype=np.uint8)), be.to_dev_u8(np.zeros((N, Oc, HW // 4), dtype=np.uint8))
+        be.call("mn_qa_fwd_f32_mask", be.ptr(dY), be.ptr(chan), N, Oc, H, W, bits, be.ptr(c2_), be.ptr(m2_), be.stream)
+        assert eq(be.to_host(c2_), codes_ref) and eq(be.to_host(m2_), mask_ref)
+    # backward: (da, mask4) vs (da, y)
+    nb = be.lib.mn_conv2d_ws_bytes(C.byref(g), 2, 0)
+    ws2 = be.empty(max(4, nb // 4 + 4))
+    for quant in ((0,) if act == 1 else (1, 0)):
+        ref = [be.empty((Oc, Cin, k, k)), be.empty(Oc), be.empty(Oc), be.empty(Oc)]
+        out = [be.empty((Oc, Cin, k, k)), be.empty(Oc), be.empty(Oc), be.empty(Oc)]
+        if act == 1:
+            be.call("mn_conv2d_bwd_first_bn_gram", C.byref(g), be.ptr(dDA), be.ptr(dY), be.ptr(sv), be.ptr(dG), be.ptr(dB), be.ptr(dW), be.ptr(dBi), be.ptr(gram),
+                    be.ptr(dX), be.ptr(ref[0]), be.ptr(ref[1]), be.ptr(ref[2]), be.ptr(ref[3]), be.ptr(ws2), nb, be.stream)
+        else:
+            be.call("mn_conv2d_bwd_first_qa_gram", C.byref(g), be.ptr(dDA), be.ptr(dY), be.ptr(chan), bits, quant, be.ptr(dW), be.ptr(dBi), be.ptr(gram),
+                    be.ptr(dX), be.ptr(ref[0]), be.ptr(ref[1]), be.ptr(ref[2]), be.ptr(ref[3]), be.ptr(ws2), nb, be.stream)
+        be.call("mn_conv2d_bwd_first_mask_gram", C.byref(g), be.ptr(dDA), be.ptr(mask4), quant, be.ptr(sv), be.ptr(dG), be.ptr(dW), be.ptr(dBi), be.ptr(gram),
+                be.ptr(dX), be.ptr(out[0]), be.ptr(out[1]), be.ptr(out[2]), be.ptr(out[3]), be.ptr(ws2), nb, be.stream)
+        assert np.abs(be.to_host(ref[0])).max() > 0
+        for a_, b_ in zip(out, ref):
+            assert eq(be.to_host(a_), be.to_host(b_))
+
+
 def check_ternary_multi(be, seed=0):
     """mn_ternary_w_fwd_multi / mn_ternary_w_bwd_multi (one launch over several weight tensors) bit-identical to the per-tensor entry points."""
     r = np.random.default_rng(seed)

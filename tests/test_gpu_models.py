@@ -332,3 +332,78 @@ def test_iao_resnet_quantadd_observers_read_producer_partials():
     finally:
         ops.iao_qadd_observe, ops.iao_qadd_observe_partials = real_full, real_part
     assert calls == {"full": 0, "partials": 8}, calls
+
+
+def _first_block_run(model, x, monkeypatch, **knobs):
+    """One forward + backward of the net's FIRST block (conv + BatchNorm + activation of models/nin_gc.py:53-59) -> (output as float, parameter gradients)."""
+    import copy
+    from micronet_amd import ops
+    for k, v in knobs.items():
+        monkeypatch.setattr(ops, k, v)
+    blk = copy.deepcopy(model.model[0]).train()
+    out = blk(x)
+    of = out.to_float() if hasattr(out, "to_float") else (out.materialize() if hasattr(out, "materialize") else out)          # SignTensor / QActTensor / plain
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    gout = torch.randn(of.shape, device="cuda", generator=gen)
+    out.backward(gout)
+    return of.detach().clone(), {n: p.grad.detach().clone() for n, p in blk.named_parameters()}, blk
+
+
+def test_first_block_fused_vs_unfused(monkeypatch):
+    """The fused first block (ops.FirstConvLazy -> FirstConvBNSign: conv + Gram-data statistics + BatchNorm + sign in one kernel, backward on pass bits) against
+    the unfused kernels and the two-pass backward: same codes, gradients bit-identical to the one-pass unfused path and within float rounding of the two-pass one;
+    a foreign consumer of the un-computed conv output sees the tensor the reference produces."""
+    from micronet_amd import ops
+    from micronet_amd.sign_tensor import LazyConvOut
+    from micronet_amd.train import build_model
+    from micronet.compression.quantization.wbwtab import quantize
+    torch.manual_seed(3)
+    model = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=3).cuda().train()
+    assert model.model[0].conv.lazy_for_bn is True
+    x = torch.randn(16, 3, 32, 32, device="cuda")
+    o_f, g_f, blk = _first_block_run(model, x, monkeypatch, FIRST_FUSED=True)
+    o_u, g_u, _ = _first_block_run(model, x, monkeypatch, FIRST_FUSED=False)
+    o_2, g_2, _ = _first_block_run(model, x, monkeypatch, FIRST_FUSED=False, FIRST_GRAM=False)
+    assert torch.equal(o_f, o_u)
+    for n in g_f:
+        assert torch.equal(g_f[n], g_u[n]), n
+    flips = float((o_u != o_2).float().mean())          # statistics from the Gram data vs from y: signs differ only at BatchNorm ties
+    assert flips <= 1e-5
+    for n in g_u:
+        if n.endswith("conv.bias"):          # sum of dy: zero but for rounding, in every path
+            assert float(g_u[n].abs().max()) <= 1e-4 * float(g_u["bn.bias"].abs().max()) and float(g_2[n].abs().max()) <= 1e-4 * float(g_2["bn.bias"].abs().max())
+            continue
+        scale = float(g_2[n].abs().max())
+        assert float((g_u[n] - g_2[n]).abs().max()) <= (2e-3 if flips else 2e-5) * scale, n
+    # running statistics follow nn.BatchNorm2d's update in both paths
+    monkeypatch.setattr(ops, "FIRST_FUSED", True)
+    monkeypatch.setattr(ops, "FIRST_GRAM", True)
+    y = blk.conv(x)
+    assert isinstance(y, LazyConvOut) and y.recipe["kind"] == "first"
+    ref = torch.nn.functional.conv2d(x, blk.conv.weight, blk.conv.bias, padding=blk.conv.padding)
+    assert float(((y + 0.0) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())          # any torch operator materialises it
+    (y * 1.0).square().mean().backward()          # ... and the conv's ordinary backward runs behind it
+    assert torch.isfinite(blk.conv.weight.grad).all()
+
+
+def test_first_block_dorefa_mask_backward(monkeypatch):
+    """The DoReFa first block: default (conv, BatchNorm + ReLU + quantizer pass that leaves the pass nibbles, one-pass backward on them) against the fused forward
+    (knob MN_FIRST_FUSED_QA) and against the two-pass backward."""
+    from micronet_amd import ops
+    from micronet_amd.train import build_model
+    from micronet.compression.quantization.wqaq.dorefa import quantize
+    torch.manual_seed(4)
+    model = quantize.prepare(build_model("nin_gc"), inplace=True, a_bits=4, w_bits=4).cuda().train()
+    assert model.model[0].conv.lazy_for_bn == "qa"
+    x = torch.randn(16, 3, 32, 32, device="cuda")
+    o_d, g_d, _ = _first_block_run(model, x, monkeypatch, FIRST_FUSED_QA=False)
+    o_f, g_f, _ = _first_block_run(model, x, monkeypatch, FIRST_FUSED_QA=True)
+    o_2, g_2, _ = _first_block_run(model, x, monkeypatch, FIRST_FUSED_QA=False, FIRST_GRAM=False)
+    assert torch.equal(o_d, o_f)
+    for n in g_d:
+        assert torch.equal(g_d[n], g_f[n]), n
+    assert float((o_d - o_2).abs().max()) <= 1e-4 * float(o_2.abs().max())          # statistics from the Gram data vs from y
+    for n in g_d:
+        if n.endswith("conv.bias"):
+            continue
+        assert float((g_d[n] - g_2[n]).abs().max()) <= 2e-3 * float(g_2[n].abs().max()), n

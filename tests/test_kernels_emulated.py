@@ -263,6 +263,13 @@ def test_first_conv_qa_wgrad(be, training):
         K.check_first_conv_qa_wgrad(be, x_shape=(20, 3, 32, 32), Oc=8, k=3, seed=8)
 
 
+def test_first_conv_fused_block(be):
+    K.check_first_conv_fused(be, act=1)
+    K.check_first_conv_fused(be, act=2, bits=2, seed=1)
+    K.check_first_conv_fused(be, x_shape=(2, 3, 16, 16), Oc=72, k=3, act=1, bias=False, seed=2)
+    K.check_first_conv_fused(be, x_shape=(2, 3, 16, 16), Oc=40, k=3, act=2, bits=4, seed=3)
+
+
 def test_first_conv_gram_backward(be):
     K.check_first_conv_gram_bwd(be, kind="bn")
     K.check_first_conv_gram_bwd(be, kind="qa", quant=1, bits=2, seed=1)
