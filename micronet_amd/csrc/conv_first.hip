@@ -673,27 +673,30 @@ __global__ __launch_bounds__(256) void k_c1_xgram(const C1Params p, float* __res
         gpart[(int64_t)blockIdx.x * C1G_TILE + i] = ((red[i] + red[C1G_TILE + i]) + red[2 * C1G_TILE + i]) + red[3 * C1G_TILE + i];
 }
 // gram[a][b] (fp64, 80 x 80; row / column K = the feature sums P, gram[K][K] = n): fixed-order sum of the Z partials, both triangles written
-__global__ __launch_bounds__(256) void k_c1_xgram_final(const float* __restrict__ gpart, int Z, double* __restrict__ gram) {
-    __shared__ double red[4][64];
+#define C1G_ZG 16          // z-groups of the final sums: 16 waves per block, each partial row read by one of them (4 groups: 8.1 us for 512 partials, pure latency)
+__global__ __launch_bounds__(64 * C1G_ZG) void k_c1_xgram_final(const float* __restrict__ gpart, int Z, double* __restrict__ gram) {
+    __shared__ double red[C1G_ZG][64];
     const int og = threadIdx.x & 63, zg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + og;
     double s = 0.0;
     if (i < C1G_TILE) {
         const float* src = gpart + i;
         int z = zg;
-        for (; z + 28 < Z; z += 32) {
+        for (; z + 7 * C1G_ZG < Z; z += 8 * C1G_ZG) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(z + 4 * u) * C1G_TILE];
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(z + C1G_ZG * u) * C1G_TILE];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += (double)v[u];
         }
-        for (; z < Z; z += 4) s += (double)src[(int64_t)z * C1G_TILE];
+        for (; z < Z; z += C1G_ZG) s += (double)src[(int64_t)z * C1G_TILE];
     }
     red[zg][og] = s;
     __syncthreads();
     if (zg == 0 && i < C1G_TILE) {
-        const double v = ((red[0][og] + red[1][og]) + red[2][og]) + red[3][og];
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < C1G_ZG; ++q) v += red[q][og];
         int pr = i >> 8, ta = 0;
         while (pr >= 5 - ta) { pr -= 5 - ta; ++ta; }
         const int tb = ta + pr, a = ta * 16 + ((i >> 4) & 15), b = tb * 16 + (i & 15);
@@ -711,8 +714,9 @@ struct C1BnFin {
     double scale;                               // of the rows the backward-weight contracted (0.1: the quantizer's STE factor; 1)
     float* dw; float* dbias; float* dgamma; float* dbeta;
 };
-__global__ __launch_bounds__(320) void k_c1_bn_final(const C1BnFin f) {
-    __shared__ double red[4][80];
+#define C1F_ZG 12          // z-groups of the partial-row sums (960 threads: the 256 partial rows of nin_gc's first layer are 3 rounds of 8 loads in flight)
+__global__ __launch_bounds__(80 * C1F_ZG) void k_c1_bn_final(const C1BnFin f) {
+    __shared__ double red[C1F_ZG][80];
     __shared__ double sA[80], sw[80];
     const int o = blockIdx.x, t = threadIdx.x, col = t % 80, zg = t / 80;
     {
@@ -720,19 +724,24 @@ __global__ __launch_bounds__(320) void k_c1_bn_final(const C1BnFin f) {
         const int64_t zs = (int64_t)f.Opad * 80;
         double s = 0.0;
         int z = zg;
-        for (; z + 28 < f.Z; z += 32) {
+        for (; z + 7 * C1F_ZG < f.Z; z += 8 * C1F_ZG) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(z + 4 * u) * zs];
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(z + C1F_ZG * u) * zs];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += (double)v[u];
         }
-        for (; z < f.Z; z += 4) s += (double)src[(int64_t)z * zs];
+        for (; z < f.Z; z += C1F_ZG) s += (double)src[(int64_t)z * zs];
         red[zg][col] = s;
     }
     if (t < 80) sw[t] = t < f.K ? (double)f.w[(int64_t)o * f.K + t] : 0.0;
     __syncthreads();
-    if (t < 80) sA[t] = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) * f.scale;
+    if (t < 80) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < C1F_ZG; ++q) v += red[q][t];
+        sA[t] = v * f.scale;
+    }
     __syncthreads();
     if (t >= f.K) return;
     float mean_f, invstd_f, cgi_f;
@@ -1028,7 +1037,7 @@ int c1_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int6
     raise_lds_limit((const void*)k_c1_xgram, lds_b);
     hipLaunchKernelGGL(k_c1_xgram, dim3(Zg), dim3(256), lds_b, s, p, (float*)ws);
     mn_prof_end(s);
-    hipLaunchKernelGGL(k_c1_xgram_final, dim3(C1G_TILE / 64), dim3(256), 0, s, (const float*)ws, Zg, gram);
+    hipLaunchKernelGGL(k_c1_xgram_final, dim3(C1G_TILE / 64), dim3(64 * C1G_ZG), 0, s, (const float*)ws, Zg, gram);
     MN_CHECK_LAUNCH("mn_conv2d_first_xgram");
     return MN_OK;
 }
@@ -1071,7 +1080,7 @@ static int c1_bwd_first_any(const mn_conv_geom* g, const float* da, const float*
     f.part = p.part; f.Z = p.Z; f.O = p.O; f.K = p.K; f.Opad = p.Opad; f.w = w; f.bias = bias; f.save = save; f.gamma = gamma; f.chan = chan; f.gram = gram;
     f.scale = mask4 ? mask_scale : ((chan && quant) ? 0.1 : 1.0);
     f.n = (double)g->N * (double)(g->H * g->W); f.dw = dw; f.dbias = dbias; f.dgamma = dgamma; f.dbeta = dbeta;
-    hipLaunchKernelGGL(k_c1_bn_final, dim3(p.O), dim3(320), 0, s, f);
+    hipLaunchKernelGGL(k_c1_bn_final, dim3(p.O), dim3(80 * C1F_ZG), 0, s, f);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_first_gram");
     return MN_OK;
 }

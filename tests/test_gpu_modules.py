@@ -366,8 +366,8 @@ def test_wbwtab_fused_conv_bn_matches_unfused():
                              ConvBNReLU(128, 10, 1), nn.AvgPool2d(8)).cuda().train()
     a = w.prepare(net(), inplace=True, A=2, W=3)
     b = w.prepare(net(), inplace=True, A=2, W=3, fuse_conv_bn=False)
-    assert a[1].conv.lazy_for_bn and a[2].conv.lazy_for_bn and a[4].conv.lazy_for_bn and not a[0].conv.__dict__.get("lazy_for_bn", False)
-    assert not b[1].conv.lazy_for_bn
+    assert a[1].conv.lazy_for_bn and a[2].conv.lazy_for_bn and a[4].conv.lazy_for_bn and a[0].conv.lazy_for_bn          # (block 0: the un-quantised first conv, ops.FirstConvLazy)
+    assert not b[1].conv.lazy_for_bn and not b[0].conv.lazy_for_bn
     seen = {}
 
     def conv_hook(m, i, o):     # a foreign consumer: .clone() materialises the lazy output; reference = stock conv on the same input
@@ -377,7 +377,7 @@ def test_wbwtab_fused_conv_bn_matches_unfused():
         seen["lazy"] = (type(o), o.detach().clone(), ref)
     from micronet_amd import ops
     a[2].conv.register_forward_hook(conv_hook)
-    # the first fused block sees bit-identical inputs on both sides (block 0 runs the same kernels)
+    # the first fused block sees bit-identical inputs on both sides (block 0: fused and unfused first block give identical codes, test_first_block_fused_vs_unfused)
     a[1].register_forward_hook(lambda m, i, o: seen.__setitem__("sa", o.detach().float().clone()))
     b[1].register_forward_hook(lambda m, i, o: seen.__setitem__("sb", o.detach().float().clone()))
     b[1].conv.register_forward_hook(lambda m, i, o: seen.__setitem__("yb", o.detach().double().clone()))
@@ -531,26 +531,37 @@ def test_first_block_bn_gradient_stays_lazy_and_matches():
     q = w.prepare(net, inplace=True, A=2, W=3)
     x = torch.randn(8, 3, 16, 16, device="cuda")
     res = {}
-    for lazy in (True, False):
-        ops.LAZY_BN_GRAD = lazy
-        try:
-            q.zero_grad()
-            torch.manual_seed(1)
-            q(x).square().mean().backward()
-            res[lazy] = [p_.grad.clone() for p_ in q.parameters()]
-        finally:
-            ops.LAZY_BN_GRAD = True
-    for (n_, _), a_, b_ in zip(q.named_parameters(), res[True], res[False]):
-        assert torch.equal(a_, b_), n_
-    # a hook on the conv output's gradient is a foreign consumer: it sees the expanded dy
+    ops.FIRST_GRAM = False          # (the two-pass form of the lazy hand-over; the one-pass form on the image's Gram data: test_gpu_models.test_first_block_fused_vs_unfused)
+    try:
+        for lazy in (True, False):
+            ops.LAZY_BN_GRAD = lazy
+            try:
+                q.zero_grad()
+                torch.manual_seed(1)
+                q(x).square().mean().backward()
+                res[lazy] = [p_.grad.clone() for p_ in q.parameters()]
+            finally:
+                ops.LAZY_BN_GRAD = True
+        for (n_, _), a_, b_ in zip(q.named_parameters(), res[True], res[False]):
+            assert torch.equal(a_, b_), n_
+        # a hook on the conv output's gradient is a foreign consumer: it sees the expanded dy
+        seen = {}
+        h = q[0].conv.register_full_backward_hook(lambda m, gi, go: seen.__setitem__("go", (go[0] * 1.0).abs().sum().item()))
+        q.zero_grad()
+        q(x).square().mean().backward()
+        h.remove()
+        assert seen["go"] > 0
+        for a_, p_ in zip(res[True], q.parameters()):
+            assert torch.allclose(a_, p_.grad, rtol=1e-4, atol=1e-7)
+    finally:
+        ops.FIRST_GRAM = True
+    # the default path (fused first block, one-pass backward): the same foreign consumer gets dy from a recomputed conv output
     seen = {}
     h = q[0].conv.register_full_backward_hook(lambda m, gi, go: seen.__setitem__("go", (go[0] * 1.0).abs().sum().item()))
     q.zero_grad()
     q(x).square().mean().backward()
     h.remove()
-    assert seen["go"] > 0
-    for a_, p_ in zip(res[True], q.parameters()):
-        assert torch.allclose(a_, p_.grad, rtol=1e-4, atol=1e-7)
+    assert seen["go"] > 0 and all(torch.isfinite(p_.grad).all() for p_ in q.parameters())
 
 
 def test_bn_backward_folded_into_conv_backward_matches():
@@ -663,9 +674,13 @@ def test_dorefa_fused_blocks_match_unfused(bits, arch):
             d[k] = 0
         e = float(d.max() / scale)
         assert e <= tg, (n, e)
+    bufs_b = dict(b.named_buffers())
     for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         if ba.dtype.is_floating_point:
-            assert float((ba - bb).abs().max()) <= tb * float(bb.abs().max().clamp_min(1e-6)), n
+            scale = float(bb.abs().max().clamp_min(1e-6))
+            if n.endswith("running_mean"):          # a mean is accurate relative to the spread of the data, not to its own (possibly tiny) magnitude: the first block's
+                scale = max(scale, float(bufs_b[n[:-len("running_mean")] + "running_var"].max().sqrt()))          # comes from the image's Gram data on the fused side
+            assert float((ba - bb).abs().max()) <= tb * scale, n
         else:
             assert torch.equal(ba, bb), n
     b.load_state_dict(a.state_dict())

@@ -129,7 +129,7 @@ def test_wbwtab_prepare_packs_activations_by_default():
     bns = [m for m in q.modules() if isinstance(m, quantize.BatchNorm2dBinAct)]
     assert len(bns) == 8 and all(m.packed for m in bns)
     assert sum(isinstance(m, quantize.MaxPool2dSign) for m in q.modules()) == 2
-    assert sum(bool(getattr(m, "lazy_for_bn", False)) for m in q.modules()) == 7       # every quantised conv feeds a packed BN+sign
+    assert sum(bool(getattr(m, "lazy_for_bn", False)) for m in q.modules()) == 8       # every quantised conv -- and the un-quantised first one -- feeds a packed BN+sign
     q2 = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=3, packed_activations=False)
     assert not any(m.packed for m in q2.modules() if isinstance(m, quantize.BatchNorm2dBinAct))
     assert not any(isinstance(m, quantize.MaxPool2dSign) for m in q2.modules())
