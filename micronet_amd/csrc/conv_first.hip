@@ -629,6 +629,10 @@ __global__ __launch_bounds__(256) void k_c1_xgram(const C1Params p, float* __res
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) koff[nt] = c1_koff(p, nt * 16 + j);
     const int one_nt = ((p.K & 15) == j) ? (p.K >> 4) : -1;
+    // the feature K = 1: four floats of 1.0 behind the patch (inside its 64-byte pad, never staged over), addressed instead of the pixel's taps -- a select on the LDS
+    // ADDRESS; selecting the loaded VALUE made every one of the 20 reads of a pixel group a branch of its own (28 us against 13 us of matrix work)
+    const int ones_off = p.C * p.CS;
+    if (tid < 4) xs[ones_off + tid] = 1.f;
     f32x4 acc[15];
 #pragma unroll
     for (int i = 0; i < 15; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -646,9 +650,9 @@ __global__ __launch_bounds__(256) void k_c1_xgram(const C1Params p, float* __res
             float v[5][4];
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) {
-                const float* src = xs + pb + koff[nt];
+                const float* src = xs + ((nt == one_nt) ? ones_off : pb + koff[nt]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[nt][e] = (nt == one_nt) ? 1.f : src[e];
+                for (int e = 0; e < 4; ++e) v[nt][e] = src[e];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {          // (15 independent accumulators between two MFMAs on the same one)

@@ -1337,7 +1337,6 @@ class BNSign(Function):
             if rec is not None:
                 # ... or everything at once: the BatchNorm backward is linear in dz, so ONE pass over (da, y) gives dw, dgamma, dbeta (csrc/conv_first.hip)
                 dw1, db1, dgamma, dbeta = _first_gram_backward(rec, ctx.gram, y, "bn", da, save, gamma, beta, None, 0, 0)
-                ctx.gram = None
             else:
                 sums = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
                 with torch.cuda.device_of(y):
@@ -2213,7 +2212,6 @@ class BNReLUQ(Function):
                 dw1, db1, dgamma, dbeta = _first_mask_backward(ctx.first, ctx.gram, ctx.mask4, dq, quant, chan, gamma)
             else:
                 dw1, db1, dgamma, dbeta = _first_gram_backward(ctx.first, ctx.gram, src, "qa", dq, None, None, None, chan, qbits, quant)
-            ctx.gram = ctx.mask4 = None
 
             def expand1(r):
                 dy_ = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
@@ -2500,7 +2498,6 @@ def _first_fused_backward(ctx, da, quant, expand):
         with _span(g, 2, 4.25 * da.numel() + 4 * x.numel()):
             _call("mn_conv2d_bwd_first_mask_gram", C.byref(g), _p(da), _p(mask4), int(quant), _p(save), _p(gamma), _p(w), _p(b), _p(ctx.gram), _p(x), _p(dw), _p(db),
                   _p(dgamma), _p(dbeta), _p(ws), nb, _s())
-    ctx.gram = None
     recipe = dict(kind="first_done", dw=dw, db=db, x=x, w=w, da=da, save=save, gamma=gamma, beta=beta, compute=ctx.compute, quant=quant)
     return LazyBNGrad((g.N, g.O, g.H, g.W), dev, recipe, expand), dgamma, dbeta
 

@@ -375,9 +375,19 @@ def test_first_block_fused_vs_unfused(monkeypatch):
             continue
         scale = float(g_2[n].abs().max())
         assert float((g_u[n] - g_2[n]).abs().max()) <= (2e-3 if flips else 2e-5) * scale, n
-    # running statistics follow nn.BatchNorm2d's update in both paths
     monkeypatch.setattr(ops, "FIRST_FUSED", True)
     monkeypatch.setattr(ops, "FIRST_GRAM", True)
+    # a second backward through the retained graph gives the same gradients (nothing the backward needs is consumed by the first one)
+    import copy
+    blk2 = copy.deepcopy(model.model[0]).train()
+    out2 = blk2(x)
+    gout = torch.randn(out2.shape, device="cuda")
+    out2.backward(gout, retain_graph=True)
+    g_a = {n: p.grad.detach().clone() for n, p in blk2.named_parameters()}
+    blk2.zero_grad()
+    out2.backward(gout)
+    for n, p in blk2.named_parameters():
+        assert torch.equal(p.grad, g_a[n]), n
     y = blk.conv(x)
     assert isinstance(y, LazyConvOut) and y.recipe["kind"] == "first"
     ref = torch.nn.functional.conv2d(x, blk.conv.weight, blk.conv.bias, padding=blk.conv.padding)
