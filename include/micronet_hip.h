@@ -260,6 +260,10 @@ typedef struct mn_actq {
                         by the caller.  mn_conv2d_fwd leaves the exact per-channel sums of the integer accumulator there -- stats[(r * O + o) * 2 + {0, 1}] = sum acc,
                         sum acc^2 over the pixels of partial r -- from its epilogue: the BatchNorm behind the conv (models/resnet.py:17-29) then needs no statistics
                         pass of its own (mn_bn_fwd_acc).  NULL: none. */
+    const float* dx_add; /* optional, mn_conv2d_bwd_data of a dense MN_ACTQ_IAO layer (mn_conv2d_bwd_data_add_supported): a tensor shaped like dx that is ADDED to dx in the
+                        store -- after the quantizer's clip-STE: dx = STE(W^T gy) + dx_add.  The gradient a residual block's identity shortcut carries to the same input
+                        (models/resnet.py:60-65 with QuantAdd, wqaq/iao/quantize.py:1484-1498) then needs no add kernel of its own.  NULL: none.  A call that cannot honour
+                        it fails with MN_ENOTSUP (never silently drops it). */
 } mn_actq;
 
 /* How the (already fake-quantised, fp32 OIHW) weight tensor factors into integer codes x per-channel scale.  The
@@ -303,6 +307,7 @@ int mn_conv2d_first_supported(const mn_conv_geom* g, int which);
 /* 1 if MN_ALGO_QGEMM supports this geometry and quantizer combination for `which` (aq / wq may be NULL = none / real) */
 int mn_conv2d_qgemm_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, int which);
 int64_t mn_conv2d_iao_codes_bytes(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);   /* size of mn_actq.codes for this layer; 0: not used */
+int mn_conv2d_bwd_data_add_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);   /* 1: mn_conv2d_bwd_data(algo = MN_ALGO_AUTO or MN_ALGO_QGEMM) honours mn_actq.dx_add for this layer */
 int64_t mn_conv2d_iao_stats_rows(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);   /* partial rows R of mn_actq.stats for this layer; 0: not available */
 /* y[N][O][Ho][Wo] = conv2d(actq(x), w, bias); w are the (already fake-quantised) fp32 weights, wq says how they factor
  * (NULL = MN_WQ_REAL) */

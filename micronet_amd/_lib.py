@@ -24,7 +24,7 @@ class ConvGeom(C.Structure):
 
 class ActQ(C.Structure):
     _fields_ = [("mode", C.c_int32), ("bits", C.c_int32), ("q_type", C.c_int32), ("flags", C.c_int32),
-                ("qp", C.c_void_p), ("codes", C.c_void_p), ("stats", C.c_void_p)]
+                ("qp", C.c_void_p), ("codes", C.c_void_p), ("stats", C.c_void_p), ("dx_add", C.c_void_p)]
 
 
 class WQ(C.Structure):
@@ -144,6 +144,7 @@ PROTOTYPES = {
     "mn_qa_bwd_sums": (_I, [_I, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mn_qa_bwd_apply": (_I, [_I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
     "mn_conv2d_iao_codes_bytes": (_L, [_G, _A, _W]),
+    "mn_conv2d_bwd_data_add_supported": (_I, [_G, _A, _W]),
     "mn_conv2d_iao_stats_rows": (_L, [_G, _A, _W]),
     "mn_bn_fwd_acc": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _L, _P, _P]),
     "mn_iao_w_fwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _I, _I, _P]),

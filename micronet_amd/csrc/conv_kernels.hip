@@ -760,6 +760,10 @@ extern "C" int mn_conv2d_fwd_act(const mn_conv_geom* g, const mn_actq* aq, const
     return qg_fwd_act(g, aq, wq, x, w, bias, y, relu, mm, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" int mn_conv2d_bwd_data_add_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
+    if (!g || check_geom(g, "mn_conv2d_bwd_data_add_supported")) return 0;
+    return qd_iao_dx_add_supported(g, aq, wq);
+}
 extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w,
                                   const float* x, float* dx, void* ws, int64_t ws_bytes, int algo, mn_stream_t stream) {
     int rc = check_geom(g, "mn_conv2d_bwd_data");
@@ -770,6 +774,11 @@ extern "C" int mn_conv2d_bwd_data(const mn_conv_geom* g, const mn_actq* aq, cons
     if (ste.mode == MN_ACTQ_SIGN8 || ste.mode == MN_ACTQ_CODE8) ste.mode = MN_ACTQ_NONE;      // codes carry no STE here (it lives in mn_bnsign_bwd / mn_qa_bwd_*); x is not read
     if (ste.mode != MN_ACTQ_NONE && !x) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data: x required for the clip-STE epilogue");
     hipStream_t s = (hipStream_t)stream;
+    if (aq && aq->dx_add) {          // only the dense IAO kernel adds a tensor in its store: anything else must refuse, not drop it
+        if ((algo != MN_ALGO_AUTO && algo != MN_ALGO_QGEMM) || !qd_iao_dx_add_supported(g, aq, wq) || !ws || ws_bytes < qd_iao_ws_bytes(g, 1) || !aligned16(gy) || !aligned16(dx) || !aligned16(x))
+            MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data: mn_actq.dx_add is not available for this layer (mn_conv2d_bwd_data_add_supported)");
+        return qd_iao_bwd_data(g, aq, wq, gy, w, x, dx, ws, ws_bytes, s);
+    }
     {
         const double nx = (double)g->N * g->C * g->H * g->W, nw = (double)g->O * (g->C / g->groups) * g->KH * g->KW;
         const double ny = (double)g->N * g->O * out_dim(g->H, g->KH, g->stride_h, g->pad_h, g->dil_h) * out_dim(g->W, g->KW, g->stride_w, g->pad_w, g->dil_w);

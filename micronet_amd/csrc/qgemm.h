@@ -25,6 +25,11 @@ int c1_bwd_weight_bn(const mn_conv_geom* g, const float* gy, const float* da, co
 int c1_bwd_weight(const mn_conv_geom* g, const float* gy, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int c1_bwd_weight_qa(const mn_conv_geom* g, const float* dq, const float* yb, const float* chan, int quant, int a_bits, const float* sums, int training,
                      const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
+// dense IAO layers (qgemm_dense.hip): the backward-data that adds mn_actq.dx_add in its store, reached directly from mn_conv2d_bwd_data
+int qd_iao_dx_add_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq);
+int64_t qd_iao_ws_bytes(const mn_conv_geom* g, int which);
+int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx, void* ws, int64_t ws_bytes,
+                    hipStream_t s);
 // one-pass backward of the first block: Gram data of x's im2col rows (gram: 80 x 80 doubles), then dz-only backward-weight + per-channel finish
 int64_t c1_xgram_ws_bytes(const mn_conv_geom* g);
 int c1_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int64_t ws_bytes, hipStream_t s);

@@ -880,6 +880,7 @@ struct QddParams {
     int wsc_stride;
     const float* ste_x;           // IAO: the conv's fp32 input -- the activation quantizer's clip-STE (ref 163-168, 232) is applied while dx is stored; nullptr: none
     const float* ste_qp;          // {scale, zero point, lo, hi} on the device
+    const float* dx_add;          // nullable: added to dx in the store, after the clip-STE (mn_actq.dx_add: the identity shortcut's gradient of a residual block)
     float ste_qmin, ste_qmax;
     int N, C, Hg, Wg, O, HWg;
     int TAPS, TPS, NSTEP, WSB;    // taps, taps per step, steps per chunk, bytes of weights per step
@@ -1105,6 +1106,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
                 for (int nf = 0; nf < 4; ++nf) {
                     float4 v = make_float4(acc[0][mf][nf][0] * p.wscale, acc[0][mf][nf][1] * p.wscale, acc[0][mf][nf][2] * p.wscale, acc[0][mf][nf][3] * p.wscale);
                     if (p.ste_x) v = ste4(v, p.ste_x + base + (uint32_t)(nf * 16 * p.HWg));
+                    if (p.dx_add) { const float4 a = *reinterpret_cast<const float4*>(p.dx_add + base + (uint32_t)(nf * 16 * p.HWg)); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
                     *reinterpret_cast<float4*>(p.dx + base + (uint32_t)(nf * 16 * p.HWg)) = v;
                 }
             } else {
@@ -1120,6 +1122,10 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
                         float4 v0 = make_float4(e[0] * p.wscale, o[0] * p.wscale, e[1] * p.wscale, o[1] * p.wscale);
                         float4 v1 = make_float4(e[2] * p.wscale, o[2] * p.wscale, e[3] * p.wscale, o[3] * p.wscale);
                         if (p.ste_x) { v0 = ste4(v0, p.ste_x + off); v1 = ste4(v1, p.ste_x + off + 4); }
+                        if (p.dx_add) {
+                            const float4 a0 = *reinterpret_cast<const float4*>(p.dx_add + off), a1 = *reinterpret_cast<const float4*>(p.dx_add + off + 4);
+                            v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w; v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+                        }
                         *reinterpret_cast<float4*>(dst) = v0;
                         *reinterpret_cast<float4*>(dst + 4) = v1;
                     }
@@ -1200,7 +1206,7 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
     QddParams& p = pl.p;
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_bwd);
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s); wpk = reinterpret_cast<const uint16_t*>(ws); }
-    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0; p.ste_x = nullptr; p.ste_qp = nullptr;
+    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0; p.ste_x = nullptr; p.ste_qp = nullptr; p.dx_add = nullptr;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d, %d>", pl.MF, pl.S, p.TAPS, qd_terms());
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
@@ -1833,6 +1839,9 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
     MN_CHECK_LAUNCH("mn_conv2d_fwd(dense iao)");
     return MN_OK;
 }
+int qd_iao_dx_add_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
+    return g && aq && wq && qd_iao_supported(g, aq, wq, 1) && !MN_ENV("MN_QD_STE_SEPARATE");
+}
 int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx, void* ws, int64_t ws_bytes,
                     hipStream_t s) {
     QddPlan pl;
@@ -1846,6 +1855,8 @@ int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, c
     const IaoRange r = iao_range(aq->bits, 0, 1);
     static const bool ste_sep = MN_ENV("MN_QD_STE_SEPARATE") != nullptr;          // A/B knob: the clip-STE as a pass of its own (round 3)
     p.ste_x = ste_sep ? nullptr : x; p.ste_qp = aq->qp; p.ste_qmin = r.qmin; p.ste_qmax = r.qmax;          // the quantizer's clip-STE rides the store of dx
+    if (aq->dx_add && (ste_sep || !aligned16(aq->dx_add))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense iao): mn_actq.dx_add needs the fused clip-STE and a 16-byte aligned tensor");
+    p.dx_add = aq->dx_add;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d, %d>", pl.MF, pl.S, p.TAPS, qd_terms());
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 8.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);

@@ -659,7 +659,13 @@ class QuantAdd(nn.Module):
                     o.num_flag += 1
             q._last_qp = qp
             want_mm = bool(relu) and self.training and _PRODUCER_MINMAX          # (a ResNet block's output: the next block's convs observe it)
-            out = ops.IaoQuantAdd.apply(res, shortcut, qp, q.bits, q.q_type, bool(relu), want_mm)
+            tok = getattr(shortcut, "_mn_res_token", None)
+            if tok is not None and (tok.claimed or tok.node is None or not torch.is_grad_enabled() or not shortcut.requires_grad or not res.requires_grad
+                                    or not ops._descends_from(res, tok.node)):
+                tok = None          # (only an identity shortcut into the conv that res descends from, and only one QuantAdd per token)
+            if tok is not None:
+                tok.claimed = True
+            out = ops.IaoQuantAdd.apply(res, shortcut, qp, q.bits, q.q_type, bool(relu), want_mm, tok)
             if relu:
                 out._mn_relu_done = True
             if want_mm:

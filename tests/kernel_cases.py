@@ -1748,6 +1748,14 @@ def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=Fa
     y3 = be.to_host(be.conv_fwd(g, aq0, dX, dWn, None, 3, wq=wq))
     dx3 = be.to_host(be.conv_bwd_data(g, aq0, dG, dWn, dX, 3, wq=wq))
     assert np.array_equal(y1, y3) and np.array_equal(dx1, dx3)
+    # a tensor added to dx in the store, after the clip-STE (mn_actq.dx_add: the identity shortcut's gradient of a residual block): == the separate add, to the bit
+    assert be.lib.mn_conv2d_bwd_data_add_supported(C.byref(g), C.byref(aq0), C.byref(wq)) == 1
+    addend = r.standard_normal(x_shape).astype(F)
+    dA = be.to_dev(addend)
+    aqa = be.actq(2, a_bits, 0, dqp)
+    aqa.dx_add = be.ptr(dA).value
+    dx4 = be.to_host(be.conv_bwd_data(g, aqa, dG, dWn, dX, 3, wq=wq))
+    assert np.array_equal(dx4, dx1 + addend)
     # ---- the exact sums of the integer accumulator from the forward's epilogue (mn_actq.stats) and the BatchNorm behind the conv from them (mn_bn_fwd_acc: ONE pass)
     # == the ordinary statistics pass + apply pass over y (mn_bnrelu_fwd / mn_bn2d_fwd), to the round-off of fp32 statistics
     aqs = be.actq(2, a_bits, 0, dqp)

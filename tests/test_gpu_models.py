@@ -417,3 +417,37 @@ def test_first_block_dorefa_mask_backward(monkeypatch):
         if n.endswith("conv.bias"):
             continue
         assert float((g_d[n] - g_2[n]).abs().max()) <= 2e-3 * float(g_2[n].abs().max()), n
+
+
+def test_iao_resnet_shortcut_gradient_folded_into_backward_data(monkeypatch):
+    """ops.RES_ADD_FOLD: the identity shortcut's gradient of an IAO residual block is added inside the first conv's backward-data store (mn_actq.dx_add) instead of by
+    autograd's accumulate kernel.  a + b == b + a: every gradient of a whole-net step is bit-identical with the fold on and off; the five identity blocks of
+    resnet18 fold, the three downsampling ones do not."""
+    import copy
+    from micronet_amd import ops
+    from micronet_amd.train import build_model, synth_batch
+    arch, scheme, kw, B, wd = CFG["c5_resnet18_iao_w4a4"]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    torch.manual_seed(9)
+    base = quantize.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+    x, y = synth_batch(8, device="cuda")
+    grads, folds = {}, {}
+    real = ops.IaoQuantAdd.apply
+    for fold in (True, False):
+        monkeypatch.setattr(ops, "RES_ADD_FOLD", fold)
+        model = copy.deepcopy(base)
+        n = {"tok": 0}
+
+        def counting(*a, _n=n):
+            _n["tok"] += int(len(a) > 7 and a[7] is not None)
+            return real(*a)
+        monkeypatch.setattr(ops.IaoQuantAdd, "apply", staticmethod(counting))
+        try:
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+        finally:
+            monkeypatch.setattr(ops.IaoQuantAdd, "apply", real)
+        grads[fold] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        folds[fold] = n["tok"]
+    assert folds == {True: 5, False: 0}, folds
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k
