@@ -560,6 +560,9 @@ int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, const float* d
                    float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
 int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, const float* sums, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits,
                     int pool, int quant, int training, float* dy, mn_stream_t stream);
+/* the two calls above as TWO launches instead of three: the apply pass sums the partial rows itself (same order: bit-identical statistics) and writes dgamma, dbeta, sums */
+int mn_qa_bwd(int in_f32, const void* in, const float* chan, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, int quant, int training,
+              float* dgamma, float* dbeta, float* sums, float* dy, float* ws, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ the END of a residual block (k-bit DoReFa ResNets)
  * models/resnet.py:60-65 -- relu(add(residual_function(x), shortcut(x))) -- whose residual branch ends in a dense QuantConv2d + BatchNorm2d
@@ -581,6 +584,9 @@ int mn_qr_bwd_sums(int in_kind, const void* in, const float* chan, int res_kind,
                    float* dgamma_s, float* dbeta_s, float* sums_s, float* ws, mn_stream_t stream);
 int mn_qr_bwd_apply(int in_kind, const void* in, const float* chan, const float* sums, int res_kind, const void* res, const float* res_chan, const float* sums_s,
                     const float* du, int64_t N, int64_t C, int64_t H, int64_t W, int training, float* dy, float* dy_s, mn_stream_t stream);
+int mn_qr_bwd(int in_kind, const void* in, const float* chan, int res_kind, const void* res, const float* res_chan, const float* dq, const float* dq2, const float* g_f32,
+              int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int training, float* du, float* dgamma, float* dbeta, float* sums, float* dgamma_s, float* dbeta_s,
+              float* sums_s, float* dy, float* dy_s, float* ws, mn_stream_t stream);          /* mn_qr_bwd_sums + mn_qr_bwd_apply, the final sums inside the apply pass */
 
 /* ------------------------------------------------------------------ QuantLinear with few outputs (O <= 64: the classifier of the ResNets, 512 -> 10)
  * y[n][o] = bias[o] + sum_c Q_a(x[n][c]) * w[o][c]  (wqaq/dorefa/quantize.py:192-199, wqaq/iao/quantize.py:1150-1157; F.linear call sites dorefa 198, iao 1156):

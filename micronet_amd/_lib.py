@@ -143,6 +143,7 @@ PROTOTYPES = {
     "mn_qa_fwd": (_I, [_I, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _P]),
     "mn_qa_bwd_sums": (_I, [_I, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mn_qa_bwd_apply": (_I, [_I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
+    "mn_qa_bwd": (_I, [_I, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mn_conv2d_iao_codes_bytes": (_L, [_G, _A, _W]),
     "mn_conv2d_bwd_data_add_supported": (_I, [_G, _A, _W]),
     "mn_conv2d_iao_stats_rows": (_L, [_G, _A, _W]),
@@ -169,6 +170,7 @@ PROTOTYPES = {
     "mn_qr_fwd": (_I, [_I, _P, _P, _I, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
     "mn_qr_bwd_sums": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mn_qr_bwd_apply": (_I, [_I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P, _P]),
+    "mn_qr_bwd": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mn_qlinear_supported": (_I, [_L, _L, _L]),
     "mn_qlinear_fwd": (_I, [_A, _P, _P, _P, _P, _L, _L, _L, _P]),
     "mn_qlinear_bwd_data": (_I, [_A, _P, _P, _P, _P, _L, _L, _L, _P]),

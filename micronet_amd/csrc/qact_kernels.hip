@@ -27,6 +27,12 @@ struct QaGeom {
     float inv_s;            // RN(1 / s) for the division-free clip-STE (qa_dz_m); 0: the IEEE division
     int interval;           // backward passes: the ReLU / clamp masks as one interval of the streamed value per channel (qa_mask_interval; knob MN_QA_NO_INTERVAL)
     int nthr;               // > 0 (mn_qa_fwd on the integer stash, <= 3 bit codes): levels 2^a - 1 of the integer-threshold forward
+    // the "final" step of the backward sums folded into the apply pass (mn_qa_bwd / mn_qr_bwd: one launch less per BatchNorm backward): every block of channel c sums
+    // the S partial rows itself, in k_qa_final_bwd / k_qr_final_bwd's order (mn_row_sums: bit-identical statistics in all of them), block sp == 0 writes the outputs
+    const double* fin_part; // [C][S][2] (qa) / [C][S][3] (qr); null: `sums` holds the finished values
+    int fin_S;
+    float* fin_dgamma; float* fin_dbeta; float* fin_sums;               // nullable, nullable, [2][C]
+    float* fin_dgamma_s; float* fin_dbeta_s; float* fin_sums_s;         // qr with a shortcut BatchNorm (all nullable)
     uint8_t* mask4;         // mn_qa_fwd_f32_mask (fp32 input, no pool, codes out): also the backward's pass nibbles, one byte per 4 elements (as mn_conv2d_first_bnact_fwd act 2)
 };
 struct QaCh { float alpha, bias, mean, invstd, ga, be, A, B, gi; };
@@ -304,7 +310,23 @@ __global__ __launch_bounds__(256) void k_qa_apply(const QaGeom g, const void* __
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
     const QaCh k = qa_load_ch(chan, g.C, c);
     float k1 = 0.f, k2 = 0.f;
-    if (training) { const float n = (float)g.N * (float)g.HW; k1 = sums[c] / n; k2 = sums[g.C + c] / n; }
+    float s1f, s2f;
+    if (g.fin_part) {          // (block-uniform) the final sums of the partial pass in front, here
+        __shared__ float fs[2];
+        if (threadIdx.x == 0) {
+            double sv[2] = {0.0, 0.0};
+            mn_row_sums<2>(g.fin_part + (int64_t)c * g.fin_S * 2, g.fin_S, sv);
+            fs[0] = (float)sv[0]; fs[1] = (float)sv[1];
+            if (sp == 0) {
+                if (g.fin_dbeta) g.fin_dbeta[c] = fs[0];
+                if (g.fin_dgamma) g.fin_dgamma[c] = fs[1];
+                if (g.fin_sums) { g.fin_sums[c] = fs[0]; g.fin_sums[g.C + c] = fs[1]; }
+            }
+        }
+        __syncthreads();
+        s1f = fs[0]; s2f = fs[1];
+    } else { s1f = sums[c]; s2f = sums[g.C + c]; }
+    if (training) { const float n = (float)g.N * (float)g.HW; k1 = s1f / n; k2 = s2f / n; }
     QaIv iv; iv.lo = 1.f; iv.hi = 0.f; iv.use = false;
     if (!POOL) iv = qa_block_interval<IN>(g, k, quant);
     for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
@@ -442,6 +464,7 @@ static int qa_geom(QaGeom* g, int64_t N, int64_t C, int64_t H, int64_t W, int bi
     g->interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
     g->nthr = 0;
     g->mask4 = nullptr;
+    g->fin_part = nullptr; g->fin_S = 0; g->fin_dgamma = g->fin_dbeta = g->fin_sums = g->fin_dgamma_s = g->fin_dbeta_s = g->fin_sums_s = nullptr;
     return MN_OK;
 }
 static int qa_split(const QaGeom& g) {
@@ -550,6 +573,33 @@ extern "C" int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, co
     QA_DISPATCH(k_qa_apply, grid, dim3(256), 0, s, g, in, chan, dq, sums, training, quant, dy)
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_qa_bwd_apply");
+    return MN_OK;
+}
+
+/* mn_qa_bwd_sums + mn_qa_bwd_apply in TWO launches: the partial pass, then the apply pass whose blocks finish the sums themselves (bit-identical statistics, dgamma /
+ * dbeta / sums written by the apply pass); ws as for mn_qa_bwd_sums */
+extern "C" int mn_qa_bwd(int in_f32, const void* in, const float* chan, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, int quant,
+                         int training, float* dgamma, float* dbeta, float* sums, float* dy, float* ws, mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, a_bits, pool, "mn_qa_bwd");
+    if (rc) return rc;
+    if (!in || !chan || !dq || !sums || !dy || !ws || (((uintptr_t)in) & 15) || !aligned16(dq) || !aligned16(dy) || (((uintptr_t)ws) & 7)) MN_FAIL(MN_EINVAL, "mn_qa_bwd: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = qa_split(g);
+    const dim3 grid((unsigned)C, (unsigned)S);
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qa_partial<%d, %d>", in_f32, pool ? 1 : 0);
+    mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + 4.0 * nel / (pool ? 4.0 : 1.0));
+    mn_prof_begin(s);
+    QA_DISPATCH(k_qa_partial, grid, dim3(256), 0, s, g, in, chan, dq, quant, (double*)ws)
+    mn_prof_end(s);
+    g.fin_part = (const double*)ws; g.fin_S = S; g.fin_dgamma = dgamma; g.fin_dbeta = dbeta; g.fin_sums = sums;
+    mn_set_last_kernel("k_qa_apply<%d, %d>", in_f32, pool ? 1 : 0);
+    mn_prof_bytes(nel * (in_f32 ? 4.0 : 2.0) + 4.0 * nel / (pool ? 4.0 : 1.0) + 4.0 * nel);
+    mn_prof_begin(s);
+    QA_DISPATCH(k_qa_apply, grid, dim3(256), 0, s, g, in, chan, dq, (const float*)sums, training, quant, dy)
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qa_bwd");
     return MN_OK;
 }
 
@@ -677,10 +727,29 @@ __global__ __launch_bounds__(256) void k_qr_apply(const QaGeom g, const void* __
     QaCh ks = k;
     if (RES >= 2) ks = qa_load_ch(res_chan, g.C, c);
     float k1 = 0.f, k2 = 0.f, k1s = 0.f, k2s = 0.f;
+    float s1f, s2f, s3f = 0.f;
+    if (g.fin_part) {          // (block-uniform) k_qr_final_bwd, here
+        __shared__ float fs[3];
+        if (threadIdx.x == 0) {
+            double sv[3] = {0.0, 0.0, 0.0};
+            mn_row_sums<3>(g.fin_part + (int64_t)c * g.fin_S * 3, g.fin_S, sv);
+            fs[0] = (float)sv[0]; fs[1] = (float)sv[1]; fs[2] = (float)sv[2];
+            if (sp == 0) {
+                if (g.fin_dbeta) g.fin_dbeta[c] = fs[0];
+                if (g.fin_dgamma) g.fin_dgamma[c] = fs[1];
+                if (g.fin_sums) { g.fin_sums[c] = fs[0]; g.fin_sums[g.C + c] = fs[1]; }
+                if (g.fin_sums_s) { g.fin_sums_s[c] = fs[0]; g.fin_sums_s[g.C + c] = fs[2]; }
+                if (g.fin_dbeta_s) g.fin_dbeta_s[c] = fs[0];
+                if (g.fin_dgamma_s) g.fin_dgamma_s[c] = fs[2];
+            }
+        }
+        __syncthreads();
+        s1f = fs[0]; s2f = fs[1]; s3f = fs[2];
+    } else { s1f = sums[c]; s2f = sums[g.C + c]; if (RES >= 2) s3f = sums_s[g.C + c]; }
     if (training) {
         const float n = (float)g.N * (float)g.HW;
-        k1 = sums[c] / n; k2 = sums[g.C + c] / n;
-        if (RES >= 2) { k1s = sums_s[c] / n; k2s = sums_s[g.C + c] / n; }
+        k1 = s1f / n; k2 = s2f / n;
+        if (RES >= 2) { k1s = (g.fin_part ? s1f : sums_s[c]) / n; k2s = s3f / n; }
     }
     for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < g.n8; i += (int64_t)S * 256) {
         const int64_t off = qa_off8(g, c, (uint32_t)i);
@@ -788,5 +857,36 @@ extern "C" int mn_qr_bwd_apply(int in_kind, const void* in, const float* chan, c
     QR_DISPATCH(k_qr_apply, grid, dim3(256), 0, s, g, in, chan, sums, res, res_chan, sums_s, du, training, dy, dy_s)
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_qr_bwd_apply");
+    return MN_OK;
+}
+/* mn_qr_bwd_sums + mn_qr_bwd_apply in TWO launches (the apply pass finishes the sums itself, as mn_qa_bwd); arguments as for the two calls */
+extern "C" int mn_qr_bwd(int in_kind, const void* in, const float* chan, int res_kind, const void* res, const float* res_chan, const float* dq, const float* dq2,
+                         const float* g_f32, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int training, float* du, float* dgamma, float* dbeta, float* sums,
+                         float* dgamma_s, float* dbeta_s, float* sums_s, float* dy, float* dy_s, float* ws, mn_stream_t stream) {
+    QaGeom g;
+    int rc = qa_geom(&g, N, C, H, W, a_bits, 0, "mn_qr_bwd");
+    if (rc) return rc;
+    if ((rc = qr_check(in_kind, res_kind, res, res_chan, "mn_qr_bwd"))) return rc;
+    if (!in || !chan || (!dq && !g_f32) || (dq2 && !dq) || !du || !sums || !ws || !dy || (((uintptr_t)in) & 15) || (dq && !aligned16(dq)) || (dq2 && !aligned16(dq2)) ||
+        (g_f32 && !aligned16(g_f32)) || !aligned16(du) || !aligned16(dy) || (((uintptr_t)ws) & 7) || (res_kind >= 2 && (!sums_s || !dy_s || !aligned16(dy_s))))
+        MN_FAIL(MN_EINVAL, "mn_qr_bwd: null / misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = qa_split(g);
+    const dim3 grid((unsigned)C, (unsigned)S);
+    const double nel = (double)N * C * H * W;
+    mn_set_last_kernel("k_qr_partial<%d, %d>", in_kind, res_kind);
+    mn_prof_bytes(nel * ((in_kind == 0 ? 2.0 : 4.0) + (res_kind == 0 ? 0.0 : (res_kind == 2 ? 2.0 : 4.0)) + (dq ? 4.0 : 0.0) + (dq2 ? 4.0 : 0.0) + (g_f32 ? 4.0 : 0.0) + 4.0));
+    mn_prof_begin(s);
+    QR_DISPATCH(k_qr_partial, grid, dim3(256), 0, s, g, in, chan, res, res_chan, dq, dq2, g_f32, du, (double*)ws)
+    mn_prof_end(s);
+    g.fin_part = (const double*)ws; g.fin_S = S; g.fin_dgamma = dgamma; g.fin_dbeta = dbeta; g.fin_sums = sums;
+    if (res_kind >= 2) { g.fin_dgamma_s = dgamma_s; g.fin_dbeta_s = dbeta_s; g.fin_sums_s = sums_s; }
+    if (res_kind == 1) res_kind = 0;          // an identity shortcut's gradient IS du: nothing to form in the apply pass
+    mn_set_last_kernel("k_qr_apply<%d, %d>", in_kind, res_kind);
+    mn_prof_bytes(nel * ((in_kind == 0 ? 2.0 : 4.0) + 8.0 + (res_kind >= 2 ? (res_kind == 2 ? 2.0 : 4.0) + 4.0 : 0.0)));
+    mn_prof_begin(s);
+    QR_DISPATCH(k_qr_apply, grid, dim3(256), 0, s, g, in, chan, (const float*)sums, res, res_chan, (const float*)sums_s, du, training, dy, dy_s)
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_qr_bwd");
     return MN_OK;
 }

@@ -2281,9 +2281,16 @@ class BNReLUQ(Function):
         sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws = torch.empty(int(_lib_().mn_qa_ws_floats(Cc)), dtype=torch.float32, device=dev)
+            lazy_first = in_f32 == 1 and not pool and LAZY_BN_GRAD and FOLD_BN_INTO_CONV_BWD
+            if QA_BWD_TWO_LAUNCHES and not lazy_first:
+                # partial sums, then the apply pass whose blocks finish the sums themselves (mn_qa_bwd: one launch less per block, bit-identical)
+                dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+                with _span(None, 3, 2 * ((2 if in_f32 == 0 else 4) * src.numel() + 4 * dq.numel()) + 4 * dy.numel()):
+                    _call("mn_qa_bwd", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, training, _p(dgamma), _p(dbeta), _p(sums), _p(dy), _p(ws), _s())
+                return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
             with _span(None, 3, (2 if in_f32 == 0 else 4) * src.numel() + 4 * dq.numel()):
                 _call("mn_qa_bwd_sums", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
-            if in_f32 == 1 and not pool and LAZY_BN_GRAD and FOLD_BN_INTO_CONV_BWD:
+            if lazy_first:
                 # the block behind the un-quantised first conv: d loss / d y has ONE consumer, that conv's backward-weight, which forms it from
                 # (dq, y) while they stream in (mn_conv2d_bwd_weight_first_qa) -- dy is neither written nor re-read
                 def expand(r):
@@ -2372,6 +2379,12 @@ class BNAddReLUQ(Function):
         nel = N * Cc * H * W
         with torch.cuda.device(dev):
             ws = torch.empty(int(_lib_().mn_qr_ws_floats(Cc)), dtype=torch.float32, device=dev)
+            if QA_BWD_TWO_LAUNCHES:
+                with _span(None, 3, 2 * src.numel() * src.element_size() + 12 * nel):
+                    _call("mn_qr_bwd", in_kind, _p(src), _p(chan), res_kind, _p(rsrc), _p(rchan), _p(dq), _p(dq2), _p(gf), N, Cc, H, W, qbits, training, _p(du), _p(dgamma),
+                          _p(dbeta), _p(sums), _p(dgamma_s), _p(dbeta_s), _p(sums_s), _p(dy), _p(dy_s), _p(ws), _s())
+                dres = du if res_kind == 1 else dy_s
+                return (dy, dgamma, dbeta, None, None, None, None, None, None, dres, dgamma_s, dbeta_s, None, None, None, None, None, None, None)
             with _span(None, 3, src.numel() * src.element_size() + (rsrc.numel() * rsrc.element_size() if rsrc is not None else 0) + 4 * nel * (1 + sum(t is not None for t in (dq, dq2, gf)))):
                 _call("mn_qr_bwd_sums", in_kind, _p(src), _p(chan), res_kind, _p(rsrc), _p(rchan), _p(dq), _p(dq2), _p(gf), N, Cc, H, W, qbits, _p(du), _p(dgamma), _p(dbeta),
                       _p(sums), _p(dgamma_s), _p(dbeta_s), _p(sums_s), _p(ws), _s())
@@ -2506,6 +2519,7 @@ class ConvTranspose2d(Function):
         return dx, dw, db, None, None, None, None, None
 
 
+QA_BWD_TWO_LAUNCHES = _os0.environ.get("MN_QA_BWD_FOLD", "1") != "0"          # the k-bit blocks' backward: partial sums + apply (which finishes the sums) instead of partial + final + apply
 FIRST_FUSED = _os0.environ.get("MN_FIRST_FUSED", "1") != "0"          # the fused first block (A/B knob; 0: conv, then the BatchNorm block's own kernels)
 FIRST_FUSED_QA = _os0.environ.get("MN_FIRST_FUSED_QA", "0") == "1"     # ... for the DoReFa block too (off: its epilogue -- the quantizer's rounding -- makes the fused
 #                                                                         forward VALU-bound, 209 us against 110 + 58 us for conv + mn_qa_fwd_f32_mask on nin_gc at batch 256)

@@ -1118,6 +1118,11 @@ def check_qconv_bnq(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, tra
     sc = max(np.max(np.abs(dz)) * np.sqrt(n), 1e-30)
     assert np.max(np.abs(be.to_host(dbet) - dbeta_ref)) <= 2e-6 * sc and np.max(np.abs(be.to_host(dgam) - dgamma_ref)) <= 2e-6 * sc * max(1.0, np.abs(zh).max()), "dgamma / dbeta"
     assert close(be.to_host(dy), dy_ref, 1e-5), ("dy", float(np.max(np.abs(be.to_host(dy) - dy_ref)) / np.max(np.abs(dy_ref))))
+    # the two calls as two launches (mn_qa_bwd: the apply pass finishes the sums itself): every output to the bit
+    dy2, dgam2, dbet2, sums2 = be.empty((N, Oc, H, W)), be.empty(Oc), be.empty(Oc), be.empty((2, Oc))
+    be.call("mn_qa_bwd", kind, be.ptr(stash), be.ptr(chan), be.ptr(dDQ), N, Oc, H, W, out_bits, int(pooled), int(quant), int(training), be.ptr(dgam2), be.ptr(dbet2),
+            be.ptr(sums2), be.ptr(dy2), be.ptr(ws), be.stream)
+    assert eq(be.to_host(dy2), be.to_host(dy)) and eq(be.to_host(dgam2), be.to_host(dgam)) and eq(be.to_host(dbet2), be.to_host(dbet)) and eq(be.to_host(sums2), be.to_host(sums))
     # ---- backward of the conv on codes: dx (no STE here) and dw = s_a * sum dy * j
     gy = dy_ref.astype(F)
     dGY = be.to_dev(gy)
@@ -1664,6 +1669,15 @@ def check_qr(be, shape=(3, 6, 4, 8), in_kind=0, res_kind=1, bits=2, training=Tru
         k2s = s3 / n if training else np.zeros(Cc)
         dys_ref = gis.reshape(1, -1, 1, 1) * (d64 - k1.reshape(1, -1, 1, 1) - zhs.astype(np.float64) * k2s.reshape(1, -1, 1, 1))
         assert close(be.to_host(dys), dys_ref, 1e-5), "dy of the shortcut conv"
+    # the two calls as two launches (mn_qr_bwd): every output to the bit
+    du2, dy2, dys2 = be.empty(shape), be.empty(shape), (be.empty(shape) if res_kind >= 2 else None)
+    dgam2, dbet2, sums2 = be.empty(Cc), be.empty(Cc), be.empty((2, Cc))
+    dgam_s2, dbet_s2, sums_s2 = (be.empty(Cc), be.empty(Cc), be.empty((2, Cc))) if res_kind >= 2 else (None, None, None)
+    be.call("mn_qr_bwd", in_kind, be.ptr(src), be.ptr(chan), res_kind, be.ptr(res_dev), be.ptr(res_chan), be.ptr(dDQ), be.ptr(dDQ2), be.ptr(dGF), N, Cc, H, W, bits,
+            int(training), be.ptr(du2), be.ptr(dgam2), be.ptr(dbet2), be.ptr(sums2), be.ptr(dgam_s2), be.ptr(dbet_s2), be.ptr(sums_s2), be.ptr(dy2), be.ptr(dys2), be.ptr(ws),
+            be.stream)
+    for a_, b_ in ((du2, du), (dy2, dy), (dgam2, dgam), (dbet2, dbet), (sums2, sums)) + (((dys2, dys), (dgam_s2, dgam_s), (dbet_s2, dbet_s), (sums_s2, sums_s)) if res_kind >= 2 else ()):
+        assert eq(be.to_host(a_), be.to_host(b_))
 
 
 def _to_dev_i32(be, a):
