@@ -477,9 +477,9 @@ def _descends_from(t, node, limit=96):
         for f in frontier:
             if f is node:
                 return True
-            if f is None or id(f) in seen:
+            if f is None or f in seen:
                 continue
-            seen.add(id(f))
+            seen.add(f)          # (the node objects themselves: ids of short-lived wrappers of C++ nodes are reused)
             n += 1
             nxt.extend(fn for fn, _ in f.next_functions if fn is not None)
         frontier = nxt
