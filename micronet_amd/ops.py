@@ -17,6 +17,7 @@ Reference call sites each op replaces (micronet/compression/quantization/...):
 """
 import ctypes as C
 import threading
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -466,7 +467,8 @@ class ResidualToken:
     __slots__ = ("node", "d_sc", "claimed")
 
     def __init__(self):
-        self.node, self.d_sc, self.claimed = None, None, False
+        self.node, self.d_sc, self.claimed = None, None, False          # node: a WEAK reference to the conv's autograd node (the node saved x, x carries this token:
+        #                                                                  a strong one would close a cycle through C++ that a forward without backward never breaks)
 
 
 def _descends_from(t, node, limit=96):
@@ -1264,10 +1266,11 @@ class FirstConvRecord:
     def __init__(self, y, x, w, bias, stride, padding, dilation, groups):
         self.x, self.w, self.bias = x, w, bias
         self.conv = (stride, padding, dilation, groups)
-        self.node, self.version = y.grad_fn, y._version          # the record is valid for exactly this tensor as the conv wrote it
+        self.node = weakref.ref(y.grad_fn) if y.grad_fn is not None else None          # (weak: the record hangs on y, the node is y's own)
+        self.version = y._version          # the record is valid for exactly this tensor as the conv wrote it
 
     def valid_for(self, y):
-        return y.grad_fn is self.node and y._version == self.version and self.node is not None
+        return self.node is not None and y.grad_fn is not None and self.node() is y.grad_fn and y._version == self.version
 
 
 def _first_record(y, training):
@@ -2421,8 +2424,8 @@ def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ
     y = QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc,
                       (_lib.MN_ACTQ_X_IS_CODE if x_is_code else 0) | (WANT_ACCSTATS if want_accstats else 0), in_shuffle or 0)
     tok = getattr(x, "_mn_res_token", None) if aq_mode == ACTQ_IAO else None
-    if tok is not None and tok.node is None:
-        tok.node = y.grad_fn          # (the autograd node whose backward-data will consume a parked shortcut gradient)
+    if tok is not None and tok.node is None and y.grad_fn is not None:
+        tok.node = weakref.ref(y.grad_fn)          # (the autograd node whose backward-data will consume a parked shortcut gradient)
     return y
 
 

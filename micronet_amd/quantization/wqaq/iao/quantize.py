@@ -660,8 +660,9 @@ class QuantAdd(nn.Module):
             q._last_qp = qp
             want_mm = bool(relu) and self.training and _PRODUCER_MINMAX          # (a ResNet block's output: the next block's convs observe it)
             tok = getattr(shortcut, "_mn_res_token", None)
-            if tok is not None and (tok.claimed or tok.node is None or not torch.is_grad_enabled() or not shortcut.requires_grad or not res.requires_grad
-                                    or not ops._descends_from(res, tok.node)):
+            node = tok.node() if (tok is not None and tok.node is not None) else None
+            if tok is not None and (tok.claimed or node is None or not torch.is_grad_enabled() or not shortcut.requires_grad or not res.requires_grad
+                                    or not ops._descends_from(res, node)):
                 tok = None          # (only an identity shortcut into the conv that res descends from, and only one QuantAdd per token)
             if tok is not None:
                 tok.claimed = True

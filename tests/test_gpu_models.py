@@ -451,3 +451,24 @@ def test_iao_resnet_shortcut_gradient_folded_into_backward_data(monkeypatch):
     assert folds == {True: 5, False: 0}, folds
     for k in grads[True]:
         assert torch.equal(grads[True][k], grads[False][k]), k
+
+
+@pytest.mark.parametrize("key", ["c2_nin_gc_wbwtab_w3a2", "c1_nin_gc_dorefa_w8a8", "c5_resnet18_iao_w4a4"])
+def test_forward_without_backward_does_not_leak(key):
+    """A grad-enabled training-mode forward that is never backpropagated (a skipped step, an exception) must not keep its activations alive: the hand-over objects
+    the fused paths hang on tensors (ops.FirstConvRecord, ops.ResidualToken, LazyConvOut recipes) hold autograd nodes weakly or not at all -- no reference cycle through
+    C++ saved tensors."""
+    import gc
+    from micronet_amd.train import build_model, synth_batch
+    arch, scheme, kw, B, wd = CFG[key]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    model = quantize.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+    x, _ = synth_batch(8, device="cuda")
+    used = []
+    for _ in range(5):
+        out = model(x)
+        del out
+        gc.collect()
+        torch.cuda.synchronize()
+        used.append(torch.cuda.memory_allocated())
+    assert used[4] == used[2] == used[3], used
