@@ -812,6 +812,22 @@ def _im2col_gram(x, k):
     return f @ f.T
 
 
+def check_first_conv_xgram(be, x_shape, k, seed=0):
+    """mn_conv2d_first_xgram alone against the fp64 Gram data of the im2col rows (for geometries whose other kernels are covered elsewhere: here the tile loop)."""
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    K_ = Cin * k * k
+    x = r.standard_normal(x_shape).astype(F)
+    g = be.geom(x_shape, (8, Cin, k, k), padding=k // 2)
+    assert be.lib.mn_conv2d_first_supported(C.byref(g), 2) == 1
+    dX = be.to_dev(x)
+    nbg = int(be.lib.mn_conv2d_first_xgram_ws_bytes(C.byref(g)))
+    wsg, gram = be.empty(nbg // 4 + 4), be.empty(2 * 80 * 80)
+    be.call("mn_conv2d_first_xgram", C.byref(g), be.ptr(dX), be.ptr(gram), be.ptr(wsg), nbg, be.stream)
+    G = be.to_host(gram).view(np.float64).reshape(80, 80)
+    assert close(G[:K_ + 1, :K_ + 1], _im2col_gram(x, k), 2e-6) and G[K_, K_] == N * H * W
+
+
 def check_first_conv_gram_bwd(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, kind="bn", quant=1, bits=2, bias=True, seed=0, tol=2e-5):
     """The one-pass backward of the first block (mn_conv2d_first_xgram + mn_conv2d_bwd_first_bn_gram / _qa_gram: the BatchNorm backward folded into per-channel
     algebra on Gram data of x) against the two-pass path (sums, then the fold in the backward-weight's operand load) on the SAME tensors -- here y really is
