@@ -399,6 +399,16 @@ def test_first_conv_fused_block(be):
     K.check_first_conv_fused(be, x_shape=(32, 3, 32, 32), Oc=256, k=5, act=2, bits=8, seed=5)
 
 
+def test_first_conv_block_edge_geometries(be):
+    """two channel blocks (O > 256), more image tiles than Gram blocks (grid-stride tile loop), a single input channel (K = 9), batch 600"""
+    K.check_first_conv_gram_bwd(be, x_shape=(2, 3, 8, 8), Oc=320, k=5, kind="bn", seed=11)
+    K.check_first_conv_fused(be, x_shape=(2, 3, 8, 8), Oc=320, k=5, act=1, seed=12)
+    K.check_first_conv_xgram(be, (520, 1, 4, 8), 3, seed=14)
+    K.check_first_conv_fused(be, x_shape=(600, 3, 8, 8), Oc=40, k=3, act=2, bits=3, seed=15)
+    K.check_first_conv_gram_bwd(be, x_shape=(600, 3, 8, 8), Oc=40, k=3, kind="bn", seed=17)
+    K.check_first_conv_gram_bwd(be, x_shape=(2, 1, 8, 8), Oc=24, k=3, kind="bn", seed=16)
+
+
 def test_first_conv_gram_backward(be):
     K.check_first_conv_gram_bwd(be, kind="bn")
     K.check_first_conv_gram_bwd(be, kind="qa", quant=1, bits=2, seed=1)
