@@ -498,6 +498,14 @@ int mn_conv2d_bwd_data_bnh_pool(const mn_conv_geom* g, const mn_wq* wq, const fl
                                 const float* sums, int training, const float* w, float* dx, void* ws, int64_t ws_bytes, mn_stream_t stream);
 int mn_conv2d_bwd_weight_bnh_pool(const mn_conv_geom* g, const float* dpool, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
                                   int training, const int8_t* x, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
+/* BOTH gradients of such a block in ONE launch (round 6): backward-data and backward-weight of the pointwise convolution read (da, h) once and rebuild dy once
+ * (wbwtab/quantize.py:11-36, 181-195 + autograd's conv backward; the two calls above read them once each).  own == NULL: da = d loss / d a [N][O][H][W]
+ * (16-byte aligned); own != NULL: da is the pooled gradient as in the *_pool calls.  Covers groups of 128 -> 128 channels with H*W a multiple of 32 (every
+ * pointwise layer of models/nin_gc.py): ask mn_conv2d_bwd_bnh_supported; workspace mn_conv2d_bwd_bnh_ws_bytes (16-byte aligned); dbias nullable. */
+int mn_conv2d_bwd_bnh_supported(const mn_conv_geom* g, const mn_wq* wq, int pooled);
+int64_t mn_conv2d_bwd_bnh_ws_bytes(const mn_conv_geom* g);
+int mn_conv2d_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
+                      int training, const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
 /* same backward when a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119) sits behind the block: `dpool` = d loss / d pool(a),
  * [N][O][H/2][W/2] fp32, `a_own` = the block's own output codes (what mn_qconv_bnsign_fwd wrote); the pool's backward (gradient to
  * the first maximum of each window) is applied while the gradient is read -- a quarter of the bytes, no full-size da tensor. */

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libmicronet_hip.so")
-SOURCES = ["quant_kernels.hip", "conv_kernels.hip", "qgemm_kernels.hip", "qgemm_kxk.hip", "qgemm_sign.hip", "qgemm_k3s.hip", "qgemm_dense.hip", "conv_first.hip", "optim_kernels.hip", "norm_kernels.hip", "iao_ops.hip", "qact_kernels.hip", "data_kernels.hip", "linear_kernels.hip", "iao_bnfuse.hip", "iao_g3.hip", "iao_thin.hip"]
+SOURCES = ["quant_kernels.hip", "conv_kernels.hip", "qgemm_kernels.hip", "qgemm_kxk.hip", "qgemm_sign.hip", "qgemm_pwb.hip", "qgemm_k3s.hip", "qgemm_dense.hip", "conv_first.hip", "optim_kernels.hip", "norm_kernels.hip", "iao_ops.hip", "qact_kernels.hip", "data_kernels.hip", "linear_kernels.hip", "iao_bnfuse.hip", "iao_g3.hip", "iao_thin.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc"]
 # qgemm_sign.hip: the SLP vectoriser pairs fp32 operations of DIFFERENT staged rows into v_pk_* instructions and pays for it with register shuffles on
 # the loop back edge, each behind a wait for the prefetched loads (the software pipeline of k_pws_wgrad_s drained every iteration)
@@ -32,14 +32,21 @@ def build(force=False, verbose=True):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    objs = []
+    # one hipcc process per source file, a few at a time (the container has 8 cores; a file takes 10-60 s)
+    from concurrent.futures import ThreadPoolExecutor
+    objs, cmds = [], []
     for src in SOURCES:
         obj = os.path.join(HERE, "lib", src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmds.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
+    jobs = max(1, min(int(os.environ.get("MN_BUILD_JOBS", "6")), os.cpu_count() or 1))
+    with ThreadPoolExecutor(jobs) as ex:
+        list(ex.map(run, cmds))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -105,6 +105,20 @@ __device__ __forceinline__ uint32_t mn_perm(uint32_t a, uint32_t b, uint32_t sel
 __device__ __forceinline__ uint32_t mn_alignbyte(uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 __device__ __forceinline__ uint32_t mn_perm(uint32_t a, uint32_t b, uint32_t sel) { return __builtin_amdgcn_perm(a, b, sel); }
 #endif
+// ds_read_b64_tr_b16: the LDS transpose read of gfx950.  Every lane gives the LDS address of 4 consecutive bf16 (8-byte aligned); within a 16-lane group the
+// 16 x 4 elements are a [4][16] block -- row e = lanes 4e .. 4e+3 of the group, four columns each -- and lane c receives COLUMN c: result element e = element
+// (c & 3) of lane 4e + (c >> 2).  Feeds an MFMA operand whose K index is the row of a row-major LDS image (measured: scripts/probe/tr16_probe.hip).
+typedef unsigned int mn_u32x2 __attribute__((vector_size(8)));
+#ifdef MN_EMULATION
+__device__ __forceinline__ mn_u32x2 mn_lds_tr16_b64(const unsigned char* p) { return emu_ds_read_tr16_b64(p); }
+#else
+__device__ __forceinline__ mn_u32x2 mn_lds_tr16_b64(const unsigned char* p) {
+    typedef __bf16 mn_bf4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) mn_bf4 mn_lds_bf4;
+    const mn_bf4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((mn_lds_bf4*)(__attribute__((address_space(3))) unsigned char*)p);
+    return __builtin_bit_cast(mn_u32x2, v);
+}
+#endif
 // a value the optimiser must treat as unknown (stops hoisting / rematerialisation decisions that cost registers)
 #ifdef MN_EMULATION
 __device__ __forceinline__ uint32_t mn_opaque(uint32_t v) { return v; }

@@ -846,6 +846,22 @@ extern "C" int mn_conv2d_bwd_weight_bnh_pool(const mn_conv_geom* g, const float*
     if (!dpool || !h || !own || !chan || !sums || !x || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh_pool: null tensor");
     return pws_bwd_weight_bnh(g, dpool, h, chan, sums, training, x, dw, dbias, ws, ws_bytes, (hipStream_t)stream, own);
 }
+// both gradients of the block in one launch (qgemm_pwb.hip)
+extern "C" int mn_conv2d_bwd_bnh_supported(const mn_conv_geom* g, const mn_wq* wq, int pooled) {
+    if (check_geom(g, "mn_conv2d_bwd_bnh_supported") != MN_OK) return 0;
+    return pwb_supported(g, wq, pooled);
+}
+extern "C" int64_t mn_conv2d_bwd_bnh_ws_bytes(const mn_conv_geom* g) {
+    if (check_geom(g, "mn_conv2d_bwd_bnh_ws_bytes") != MN_OK) return -1;
+    return pwb_ws_bytes(g);
+}
+extern "C" int mn_conv2d_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
+                                 int training, const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_bnh");
+    if (rc) return rc;
+    if (!wq || !da || !h || !chan || !sums || !w || !x || !dx || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_bnh: null tensor");
+    return pwb_bwd_bnh(g, wq, da, h, own, chan, sums, training, w, x, dx, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta,
                                              const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                                              mn_stream_t stream) {

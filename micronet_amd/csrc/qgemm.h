@@ -59,3 +59,8 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* da, const uint8_t* h,
 int pws_wgrad_staged(const mn_conv_geom* g);          // the LDS-staged backward-weight kernel covers this geometry (the pooled BatchNorm fold lives there only)
 int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s);
+// backward-data AND backward-weight of a pointwise binary block in one kernel (qgemm_pwb.hip): (da, h) read once
+int pwb_supported(const mn_conv_geom* g, const mn_wq* wq, int pooled);
+int64_t pwb_ws_bytes(const mn_conv_geom* g);
+int pwb_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
+                const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);

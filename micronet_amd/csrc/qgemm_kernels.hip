@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(const PwWgParams p) {
 // order on every run (deterministic), 8x the parallelism of one thread per output.
 __global__ __launch_bounds__(256) void k_pw_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
                                                          float* __restrict__ db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
-                                                         float ascale, const float* __restrict__ qp) {
+                                                         float ascale, const float* __restrict__ qp, const float* __restrict__ rowdiv) {
     const float as = qp ? qp[0] : ascale;
     const int64_t nw = (int64_t)G * Mg * Cg, total = nw + (db ? (int64_t)G * Mg : 0);
     const int sub = threadIdx.x & 7;
@@ -780,6 +780,11 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_reduce(const float* __restrict
         }
         s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
         if (sub == 0) {
+            if (rowdiv) {          // the partials were formed on a row-scaled operand (k_pwb): one fp64 division by the row's scale (0 -> 1: an unscaled row)
+                const int64_t o = i < nw ? i / Cg : i - nw;
+                const float rd = i < total ? rowdiv[(o / Mg) * Mgw + (o % Mg)] : 1.f;
+                s /= (double)(rd == 0.f ? 1.f : rd);
+            }
             if (i < nw) dw[i] = (float)s * as;
             else if (i < total) db[i - nw] = (float)s;
         }
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_reduce(const float* __restrict
 // 17 MB of partials) -- and the 16 sums are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void k_pw_wgrad_reduce_v(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
                                                            float* __restrict__ db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
-                                                           float ascale, const float* __restrict__ qp, int nblk_w) {
+                                                           float ascale, const float* __restrict__ qp, int nblk_w, const float* __restrict__ rowdiv) {
     __shared__ double sm[16][16][4];
     const float as = qp ? qp[0] : ascale;
     const int q = threadIdx.x >> 4, l = threadIdx.x & 15;
@@ -815,6 +820,7 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_reduce_v(const float* __restri
             const int c = (int)(ei % Cgw);
             const int64_t o = ei / Cgw;
             const int m = (int)(o % Mgw), g = (int)(o / Mgw);
+            if (rowdiv && m < Mg) { const float rd = rowdiv[g * Mgw + m]; t /= (double)(rd == 0.f ? 1.f : rd); }
             if (m < Mg && c < Cg) dw[((int64_t)g * Mg + m) * Cg + c] = (float)t * as;
         }
     } else if (db) {
@@ -829,22 +835,34 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_reduce_v(const float* __restri
                 for (int z = sub; z < Z; z += 8) sd += (double)dbpart[((int64_t)z * G + g) * Mgw + m];
             }
             sd += __shfl_xor(sd, 4, 64); sd += __shfl_xor(sd, 2, 64); sd += __shfl_xor(sd, 1, 64);
+            if (rowdiv && sub == 0 && i < total) { const float rd = rowdiv[(i / Mg) * Mgw + (i % Mg)]; sd /= (double)(rd == 0.f ? 1.f : rd); }
             if (sub == 0 && i < total) db[i] = (float)sd;
         }
     }
 }
 
+static void qg_launch_wgrad_reduce_(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
+                                    float ascale, const float* qp, const float* rowdiv, hipStream_t s);
 void qg_launch_wgrad_reduce(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
                             float ascale, const float* qp, hipStream_t s) {
+    qg_launch_wgrad_reduce_(part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp, nullptr, s);
+}
+// ... of partials formed on an operand whose row m of group g was multiplied by rowdiv[g * Mgw + m] (k_pwb, qgemm_pwb.hip): dw, db = sum / rowdiv
+void qg_launch_wgrad_reduce_div(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw, const float* rowdiv,
+                                hipStream_t s) {
+    qg_launch_wgrad_reduce_(part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, 1.f, nullptr, rowdiv, s);
+}
+static void qg_launch_wgrad_reduce_(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
+                                    float ascale, const float* qp, const float* rowdiv, hipStream_t s) {
     const int64_t tile = (int64_t)G * Mgw * Cgw;
     if (Z >= 16 && tile % 64 == 0 && tile / 64 < (1 << 22) && !(((uintptr_t)part) & 15) && !MN_ENV("MN_REDUCE_OLD")) {
         const int nblk_w = (int)(tile / 64);
         const int nblk_b = db ? mn_grid_for((int64_t)G * Mg * 8, 256, 64) : 0;
-        hipLaunchKernelGGL(k_pw_wgrad_reduce_v, dim3(nblk_w + nblk_b), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp, nblk_w);
+        hipLaunchKernelGGL(k_pw_wgrad_reduce_v, dim3(nblk_w + nblk_b), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp, nblk_w, rowdiv);
         return;
     }
     const int64_t total = (int64_t)G * Mg * Cg + (db ? (int64_t)G * Mg : 0);
-    hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(mn_grid_for(total * 8, 256, 4096)), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp);
+    hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(mn_grid_for(total * 8, 256, 4096)), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp, rowdiv);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,358 @@
+// ONE backward kernel per pointwise binary block (round 6): backward-data AND backward-weight of a 1 x 1 grouped convolution on sign codes whose incoming
+// gradient is the BatchNorm+sign backward (optionally behind a 2 x 2 max-pool) of (da, h) -- wbwtab/quantize.py:11-36 (BinaryActivation), :181-195 (QuantConv2d)
+// + autograd's conv backward.  k_pwd<4, 4, BNH> (qgemm_kernels.hip) and k_pws_wgrad_s<4, BNH, 0, 2> (qgemm_sign.hip) each rebuilt the same dy tile from the same
+// (da, h): 15 B per element between them (da 4 + h 1 + dx 4; da 4 + h 1 + x 1).  Here (da, h) cross HBM once: 10 B per element.
+//
+// Geometry: groups of 128 -> 128 channels (every pointwise layer of nin_gc), HW a multiple of 32.  A block owns one group and a contiguous range of 32-pixel steps;
+// 768 threads = 12 waves, three per SIMD, one of each role:
+//   waves 0-3   PRODUCERS   global loads (4 steps in flight in registers), BatchNorm+sign fold (G dz + E1 h + E0, already times the weight scale of the row), exact
+//                           three-term bf16 split, LDS image: three bf16 planes [128 rows o][32 pixels] (64-byte rows, 16-byte slots XOR-swizzled) + the input codes;
+//   waves 4-7   dW          2 x 2 grid of 64 x 64 tiles of dW[o][c] += dy'[o][p] x[c][p]: v_mfma_f32_16x16x32_bf16, A = b128 rows of the planes (K = pixel);
+//   waves 8-11  dx          wave w owns input channels 32 w .. 32 w + 31: dx[c][p] = sum_o W[o][c] dy'[o][p] on v_mfma_f32_32x32x16_bf16 with the weight codes held in
+//                           registers (A) and the SAME planes read through the LDS transpose read ds_read_b64_tr_b16 (B: K = plane row o, N = pixel) -- no second,
+//                           transposed image; every accumulator register is one 128-byte row segment of dx.
+// dy' = alpha[o] dy is what backward-data contracts with the integer codes (k_pwd does the same); backward-weight wants dy, so the fixed-order fp64 reduction of the
+// partial tiles divides row o by alpha[o] (a row with alpha = 0 has all-zero codes: it is staged unscaled and divided by 1).
+// One barrier per step: barrier k publishes step k (buffer k & 1); the producers refill that buffer with step k + 2 only behind barrier k + 1, which both consumer
+// groups reach after their reads of step k.
+#include "qgemm.h"
+
+#include "qgemm_dev.h"
+
+#include <stdlib.h>
+
+#define PWB_NS 4
+#define PWB_PLANE (128 * 64)
+#define PWB_CODES (128 * 48)
+#define PWB_BUF (3 * PWB_PLANE + PWB_CODES)
+#define PWB_ERS 68                                                   // floats per staged row of a wave's 64 x 64 partial tile
+#define PWB_LDS_STAGE (2 * PWB_BUF + 128 * 32)
+#define PWB_LDS_EPI (4 * 64 * PWB_ERS * 4)
+#define PWB_LDS (PWB_LDS_STAGE > PWB_LDS_EPI ? PWB_LDS_STAGE : PWB_LDS_EPI)
+
+struct PwbParams {
+    const float* gy;            // BNH 1: da [N][O][HW]; BNH 2: the pooled gradient [N][O][H/2][W/2]; BNH 0: dy itself
+    const unsigned char* h;     // [N][O][HW] one-byte conv stash
+    const float* chan;          // [8][O]
+    const float* sums;          // [2][O]
+    const char* own;            // BNH 2: the block's own sign output [N][O][H][W]
+    const char* x;              // [N][C][HW] input sign codes (physical channel order: in_map)
+    const uint16_t* wc;         // [G][128 c][128 o] transposed weight codes (bf16)
+    const float* kscale;        // [G][128] weight scale alpha of output channel o
+    float* dx;                  // [N][C][HW]
+    float* part;                // [Z][G][128][128]
+    float* dbpart;              // [Z][G][128]
+    int N, HW, C, O, G, Z, nsteps, st_per_z, want_db, training, W;
+    float n_f;
+    FastDiv fd_hw, fd_w;
+    ChanMap in_map;
+};
+
+// 16-byte slot swizzle of a plane row: conflict-free b128 row reads (16 rows of one fragment) AND transpose reads (4 consecutive rows = 256 contiguous bytes)
+__device__ __forceinline__ uint32_t pwb_sw(uint32_t row) { return (0x1320u >> (4u * ((row >> 2) & 3u))) & 3u; }
+
+template <int BNH>
+__global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
+    constexpr int NS = PWB_NS, PLANE = PWB_PLANE, BUF = PWB_BUF;
+    HIP_DYNAMIC_SHARED(float, smemw)
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table [128][8]
+    float* ftab = reinterpret_cast<float*>(lds + 2 * BUF);
+    const int role = (int)threadIdx.x >> 8;                                // 0 producer, 1 dW, 2 dx
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const uint32_t bz = blockIdx.x;
+    const int z = (int)(bz % (uint32_t)p.Z), g = (int)(bz / (uint32_t)p.Z);
+    const uint32_t HW = (uint32_t)p.HW;
+    const int st0 = z * p.st_per_z;
+    int n = (st0 + p.st_per_z < p.nsteps ? st0 + p.st_per_z : p.nsteps) - st0;
+    n = n > 0 ? n : 0;
+    const int nit = (n + NS - 1) / NS * NS;                                // every role passes the same number of barriers
+
+    if (role == 0) {
+        // ---------------------------------------------------------------------------------------------------------------- producers
+        const int sr = tid >> 3, sq = tid & 7, cr = tid >> 1, chf = tid & 1;          // dy rows sr + 32 i, pixels 4 sq ..; code row cr, pixels 16 chf ..
+        uint32_t goff[4];
+        float dbacc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { goff[i] = (uint32_t)(g * 128 + sr + 32 * i) * HW; dbacc[i] = 0.f; }
+        const uint32_t xoff = (uint32_t)chan_phys(p.in_map, g * 128 + cr) * HW;
+        const bool want_db = p.want_db != 0;
+        if (tid < 128) {
+            const float ks = p.kscale[g * 128 + tid];
+            const float sc = ks == 0.f ? 1.f : ks;
+            float hlo = 0.f, hhi = 0.f, G_ = sc, E1 = 0.f, E0 = 0.f;
+            if (BNH) bnh_fold(p.chan, p.sums, p.O, g * 128 + tid, p.training, p.n_f, sc, hlo, hhi, G_, E1, E0);
+            ftab[tid * 8 + 0] = hlo; ftab[tid * 8 + 1] = hhi; ftab[tid * 8 + 2] = G_; ftab[tid * 8 + 3] = E1; ftab[tid * 8 + 4] = E0;
+        }
+        struct Stage { float4 gv[4]; uint32_t hv[4]; u32x4 cv; uint32_t hbit; };
+        auto fetch = [&](Stage& S, int k) {
+            // past the block's range: re-read the block's own last step (an L2 hit); loads stay unconditional
+            const int kk = k < n ? k : (n > 0 ? n - 1 : 0);
+            int st = st0 + kk;
+            st = st < p.nsteps ? st : p.nsteps - 1;
+            const uint32_t P = (uint32_t)st * 32u + 4u * sq;
+            const uint32_t ni = fd_div(P, p.fd_hw);
+            const uint32_t o = ni * (uint32_t)p.O * HW + (P - ni * HW);
+            if (BNH == 2) {          // pooled gradient: {g[win 0], g[win 1], own codes of the windows' upper row, of their lower row} per row and pixel quad
+                const uint32_t pp = P - ni * HW;
+                const uint32_t hr = fd_div(pp, p.fd_w), w = pp - hr * (uint32_t)p.W;
+                const uint32_t gbase = ni * (uint32_t)p.O * (HW >> 2) + (hr >> 1) * ((uint32_t)p.W >> 1) + (w >> 1);
+                const uint32_t cbase = ni * (uint32_t)p.O * HW + (hr & ~1u) * (uint32_t)p.W + w;
+                S.hbit = hr & 1u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2 g2 = *reinterpret_cast<const float2*>(p.gy + (gbase + (goff[i] >> 2)));
+                    const uint32_t r0 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + goff[i]));
+                    const uint32_t r1 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + goff[i] + (uint32_t)p.W));
+                    S.gv[i] = make_float4(g2.x, g2.y, mn_u2f(r0), mn_u2f(r1));
+                    S.hv[i] = *reinterpret_cast<const uint32_t*>(p.h + (o + goff[i]));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    S.gv[i] = *reinterpret_cast<const float4*>(p.gy + (o + goff[i]));
+                    if (BNH) S.hv[i] = *reinterpret_cast<const uint32_t*>(p.h + (o + goff[i]));
+                }
+            }
+            const uint32_t Pc = (uint32_t)st * 32u + 16u * chf;
+            const uint32_t nc = fd_div(Pc, p.fd_hw);
+            S.cv = *reinterpret_cast<const u32x4*>(p.x + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
+        };
+        const uint32_t doff = (uint32_t)sr * 64u + ((((uint32_t)sq >> 1) ^ pwb_sw((uint32_t)sr)) << 4) + (((uint32_t)sq & 1u) << 3);      // rows sr + 32 i share the swizzle
+        auto commit = [&](Stage& S, int buf, bool valid) {
+            unsigned char* A = lds + buf * BUF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4] = {S.gv[i].x, S.gv[i].y, S.gv[i].z, S.gv[i].w};
+                if (BNH == 2) {          // the two windows' gradients go to their first +1 in scan order (else element 0) -- if that element lies in this row
+                    const uint32_t r0 = mn_f2u(S.gv[i].z), r1 = mn_f2u(S.gv[i].w);
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const bool p00 = !((r0 >> (16 * e2)) & 0x80u), p01 = !((r0 >> (16 * e2 + 8)) & 0x80u);
+                        const bool p10 = !((r1 >> (16 * e2)) & 0x80u), p11 = !((r1 >> (16 * e2 + 8)) & 0x80u);
+                        const uint32_t win = p00 ? 0u : (p01 ? 1u : (p10 ? 2u : (p11 ? 3u : 0u)));
+                        const float ge = e2 ? S.gv[i].y : S.gv[i].x;
+                        v[2 * e2] = win == S.hbit * 2u ? ge : 0.f;
+                        v[2 * e2 + 1] = win == S.hbit * 2u + 1u ? ge : 0.f;
+                    }
+                }
+                const float4 f0 = *reinterpret_cast<const float4*>(ftab + (sr + 32 * i) * 8);        // hlo, hhi, G, E1
+                if (BNH) {
+                    const float fE0 = ftab[(sr + 32 * i) * 8 + 4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float hf = (float)((S.hv[i] >> (8 * e)) & 0xffu);
+                        const float dz = (hf >= f0.x && hf <= f0.y) ? v[e] : 0.f;
+                        v[e] = fmaf(f0.z, dz, fmaf(f0.w, hf, fE0));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= f0.z;
+                }
+                if (want_db) dbacc[i] += valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+                float r1[4], r2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r1[e] = v[e] - mn_bf16_head(v[e]);
+                    r2[e] = r1[e] - mn_bf16_head(r1[e]);
+                }
+                unsigned char* d = A + doff + 32 * 64 * i;
+                *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_hi16(v[0], v[1]), mn_pack_hi16(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{mn_pack_hi16(r1[0], r1[1]), mn_pack_hi16(r1[2], r1[3])};
+                *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{mn_pack_hi16(r2[0], r2[1]), mn_pack_hi16(r2[2], r2[3])};
+            }
+            *reinterpret_cast<u32x4*>(A + 3 * PLANE + cr * 48 + 16 * chf) = S.cv;
+        };
+        Stage st[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { fetch(st[k], k); MN_SCHED_FENCE(); }
+        __syncthreads();                                                   // the fold table
+        for (int t = 0; t < nit; t += NS) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                commit(st[u], u & 1, t + u < n);
+                fetch(st[u], t + u + NS);
+                __syncthreads();
+            }
+        }
+        __syncthreads();                                                   // the staging buffers are free (the dW waves stage their tiles through them)
+        if (want_db) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = dbacc[i];
+                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);     // the 8 pixel quads of the row
+                if (sq == 0) p.dbpart[((int64_t)z * p.G + g) * 128 + sr + 32 * i] = v;
+            }
+        }
+    } else if (role == 1) {
+        // ---------------------------------------------------------------------------------------------------------------- dW: 2 x 2 waves of 64 x 64
+        const int j = lane & 15, kg = lane >> 4, wm = wave >> 1, wcn = wave & 1;
+        const uint32_t aoff = (uint32_t)(wm * 64 + j) * 64u + ((((uint32_t)kg) ^ pwb_sw((uint32_t)j)) << 4);        // + mi * 1024 + plane * PLANE
+        const uint32_t boff = 3u * PLANE + (uint32_t)(wcn * 64 + j) * 48u + 8u * (uint32_t)kg;                        // + ci * 768
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) acc[mi][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int t = 0; t < nit; ++t) {
+            __syncthreads();
+            if (t < n) {
+                const unsigned char* A = lds + (t & 1) * BUF;
+                u32x2 braw[4];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) braw[ci] = *reinterpret_cast<const u32x2*>(A + boff + ci * 768);
+                u32x4 af[3][4];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) af[pl][mi] = *reinterpret_cast<const u32x4*>(A + pl * PLANE + aoff + mi * 1024);
+                u32x4 bf[4];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    // sign byte c -> bf16 +-1.0 = bytes {0x80, (c & 0x80) | 0x3F}
+                    const uint32_t u = (braw[ci][0] & 0x80808080u) | 0x3F3F3F3Fu, v = (braw[ci][1] & 0x80808080u) | 0x3F3F3F3Fu;
+                    bf[ci] = u32x4{mn_perm(u, 0x80u, 0x05000400u), mn_perm(u, 0x80u, 0x07000600u), mn_perm(v, 0x80u, 0x05000400u), mn_perm(v, 0x80u, 0x07000600u)};
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ci = 0; ci < 4; ++ci) acc[mi][ci] = mn_mfma_bf16(af[pl][mi], bf[ci], acc[mi][ci]);
+            }
+        }
+        __syncthreads();                                                   // every wave is done with the staging buffers
+        // partial tile through LDS: a store instruction covers four whole 256-byte rows
+        float* T = reinterpret_cast<float*>(lds) + wave * 64 * PWB_ERS;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[(mi * 16 + kg * 4 + r) * PWB_ERS + ci * 16 + j] = acc[mi][ci][r];
+        MN_WAVE_SYNC();
+        float* dst = p.part + (((int64_t)z * p.G + g) * 128 + wm * 64) * 128 + wcn * 64;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4), col = 4 * (lane & 15);
+            *reinterpret_cast<float4*>(dst + (int64_t)row * 128 + col) = *reinterpret_cast<const float4*>(T + row * PWB_ERS + col);
+        }
+    } else {
+        // ---------------------------------------------------------------------------------------------------------------- dx: wave w = input channels 32 w ..
+        const int m = lane & 31, kgrp = lane >> 5, i16 = lane & 15, nhalf = (lane >> 4) & 1;
+        u32x4 wf[8];                       // A fragments: W[o = 16 ks + 8 kgrp + e][c = 32 wave + m]
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            wf[ks] = *reinterpret_cast<const u32x4*>(p.wc + ((int64_t)(g * 128 + 32 * wave + m) * 128 + 16 * ks + 8 * kgrp));
+        uint32_t ooff[16];                 // accumulator register r = row (r & 3) + 8 (r >> 2) + 4 kgrp of the wave's 32, column m
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ooff[r] = (uint32_t)chan_phys(p.in_map, g * 128 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kgrp) * HW + (uint32_t)m;
+        uint32_t toff[2];                  // transpose reads r2 = 0, 1 of a K-step: plane rows 16 ks + 8 kgrp + 4 r2 + (i16 >> 2), pixels 16 nhalf + 4 (i16 & 3) ..
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const uint32_t row = (uint32_t)(8 * kgrp + 4 * r2 + (i16 >> 2));
+            const uint32_t slot = (uint32_t)(2 * nhalf + ((i16 & 3) >> 1));
+            toff[r2] = row * 64u + ((slot ^ pwb_sw(row)) << 4) + (((uint32_t)i16 & 1u) << 3);
+        }
+        __syncthreads();
+        for (int t = 0; t < nit; ++t) {
+            __syncthreads();
+            if (t < n) {
+                const unsigned char* A = lds + (t & 1) * BUF;
+                f32x16 a0, a1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const mn_u32x2 lo = mn_lds_tr16_b64(A + pl * PLANE + ks * 1024 + toff[0]);
+                        const mn_u32x2 hi = mn_lds_tr16_b64(A + pl * PLANE + ks * 1024 + toff[1]);
+                        const u32x4 bfr = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                        if (ks & 1) a1 = mn_mfma32_bf16(wf[ks], bfr, a1); else a0 = mn_mfma32_bf16(wf[ks], bfr, a0);
+                    }
+                }
+                const uint32_t P = (uint32_t)(st0 + t) * 32u;
+                const uint32_t ni = fd_div(P, p.fd_hw);
+                float* dst = p.dx + (ni * (uint32_t)p.C * HW + (P - ni * HW));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[ooff[r]] = a0[r] + a1[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int pwd_pack_plan(const mn_conv_geom* g, PackParams* pk, int* grid, int64_t* off_scale, int64_t* bytes);          // qgemm_kernels.hip
+void qg_launch_wgrad_reduce_div(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw, const float* rowdiv,
+                                hipStream_t s);
+
+struct PwbPlan { PwbParams p; PackParams pk; int pack_grid, grid; int64_t off_scale, pack_bytes, off_part, off_db, ws_bytes; };
+static int plan_pwb(const mn_conv_geom* g, PwbPlan* pl) {
+    if (g->KH != 1 || g->KW != 1 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 0 || g->pad_w != 0) return 0;
+    if (g->groups < 1 || g->C != 128 * g->groups || g->O != 128 * g->groups) return 0;
+    const int64_t HW = g->H * g->W, NP = (int64_t)g->N * HW;
+    if (HW % 32 || NP <= 0) return 0;
+    if (4 * NP * g->C >= ((int64_t)1 << 32)) return 0;                     // 32-bit element offsets
+    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    if (MN_ENV("MN_NO_PWB")) return 0;                                      // A/B knob: the two-kernel backward (k_pwd + k_pws_wgrad_s)
+    if (!pwd_pack_plan(g, &pl->pk, &pl->pack_grid, &pl->off_scale, &pl->pack_bytes)) return 0;
+    if (pl->pk.Cpad != 128 || pl->pk.Mgp != 128) return 0;
+    PwbParams& p = pl->p;
+    p.N = (int)g->N; p.HW = (int)HW; p.C = (int)g->C; p.O = (int)g->O; p.G = (int)g->groups; p.W = (int)g->W;
+    p.nsteps = (int)(NP / 32);
+    int Z = 256 / p.G;
+    if (const char* e = MN_ENV("MN_PWB_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }   // tuning knob
+    if (Z > p.nsteps) Z = p.nsteps;
+    if (Z < 1) Z = 1;
+    p.Z = Z;
+    p.st_per_z = (p.nsteps + Z - 1) / Z;
+    p.fd_hw = make_fastdiv((uint32_t)HW); p.fd_w = make_fastdiv((uint32_t)g->W);
+    p.in_map = make_chanmap(g->in_shuffle, g->C);
+    p.n_f = (float)g->N * (float)HW;
+    pl->grid = p.G * Z;
+    pl->off_part = (pl->pack_bytes + 255) / 256 * 256;
+    const int64_t part_bytes = (int64_t)Z * p.G * 128 * 128 * 4;
+    pl->off_db = pl->off_part + (part_bytes + 255) / 256 * 256;
+    pl->ws_bytes = pl->off_db + (int64_t)Z * p.G * 128 * 4;
+    return 1;
+}
+int pwb_supported(const mn_conv_geom* g, const mn_wq* wq, int pooled) {
+    PwbPlan pl;
+    if (!wq_codeable(wq) || !plan_pwb(g, &pl)) return 0;
+    if (pooled && ((g->H & 1) || (g->W & 3))) return 0;
+    return 1;
+}
+int64_t pwb_ws_bytes(const mn_conv_geom* g) { PwbPlan pl; return plan_pwb(g, &pl) ? pl.ws_bytes : 0; }
+
+int pwb_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
+                const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    PwbPlan pl;
+    if (!wq_codeable(wq) || !plan_pwb(g, &pl) || (own && ((g->H & 1) || (g->W & 3)))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_bnh: geometry / quantizer combination not covered");
+    if (!aligned16(dx) || !aligned16(dw) || (((uintptr_t)x) & 15) || (((uintptr_t)h) & 3) || (own ? ((((uintptr_t)da) & 7) || (((uintptr_t)own) & 3)) : !aligned16(da)))
+        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_bnh: misaligned tensor");
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_bnh: workspace too small");
+    PwbParams& p = pl.p;
+    if (wq->packed_bwd && !MN_ENV("MN_NO_PACKED_PW")) {
+        p.wc = (const uint16_t*)wq->packed_bwd;
+        p.kscale = (const float*)((const char*)wq->packed_bwd + pl.off_scale);
+    } else {
+        fill_pack(pl.pk, wq, w, ws, 0, pl.off_scale);
+        qg_launch_pack(pl.pk, pl.pack_grid, s);
+        p.wc = pl.pk.codes; p.kscale = pl.pk.scale_out;
+    }
+    p.gy = da; p.h = h; p.chan = chan; p.sums = sums; p.own = (const char*)own; p.x = (const char*)x; p.dx = dx;
+    p.part = (float*)((char*)ws + pl.off_part); p.dbpart = (float*)((char*)ws + pl.off_db);
+    p.want_db = dbias != nullptr; p.training = training;
+    mn_set_last_kernel(own ? "k_pwb<2>" : "k_pwb<1>");
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((own ? 3.0 : 5.0) * ny + 5.0 * nx); }
+    mn_prof_begin(s);
+    if (own) { raise_lds_limit((const void*)k_pwb<2>, PWB_LDS); hipLaunchKernelGGL((k_pwb<2>), dim3(pl.grid), dim3(768), PWB_LDS, s, p); }
+    else { raise_lds_limit((const void*)k_pwb<1>, PWB_LDS); hipLaunchKernelGGL((k_pwb<1>), dim3(pl.grid), dim3(768), PWB_LDS, s, p); }
+    mn_prof_end(s);
+    qg_launch_wgrad_reduce_div(p.part, p.dbpart, dw, dbias, p.Z, p.G, 128, 128, 128, 128, p.kscale, s);
+    MN_CHECK_LAUNCH("mn_conv2d_bwd_bnh");
+    return MN_OK;
+}

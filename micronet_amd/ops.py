@@ -1657,6 +1657,10 @@ def _ws(g, which, device):
     return torch.empty(max(nb // 4, 4), dtype=torch.float32, device=device), nb
 
 
+# backward-data and backward-weight of a pointwise binary block in one kernel that reads (da, h) once (k_pwb); MN_PWB=0 restores the two-kernel backward (A/B)
+FUSE_PW_BWD = _os0.environ.get("MN_PWB", "1") != "0"
+
+
 def _wq_desc(wdesc):
     """wdesc = None | (mode, bits, q_type, per_channel, scale_tensor) -> (ctypes struct or None, keep-alive)"""
     if wdesc is None:
@@ -1741,6 +1745,20 @@ class QConv2d(Function):
             if getattr(ctx, "packed", None) is not None and ctx.packed[1] is not None:
                 wd.packed_bwd = ctx.packed[1].data_ptr()
             dx = dw = db = None
+            want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+            if ctx.needs_input_grad[0] and want_w and FUSE_PW_BWD and _lib_().mn_conv2d_bwd_bnh_supported(C.byref(g), _ref(wd), 1 if pool else 0) and \
+                    r["da"].data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
+                # both gradients from ONE read of (da, h): k_pwb (qgemm_pwb.hip)
+                with torch.cuda.device_of(x):
+                    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                    dw = torch.empty_like(wq)
+                    db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
+                    nb = int(_lib_().mn_conv2d_bwd_bnh_ws_bytes(C.byref(g)))
+                    ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=x.device)
+                    with _span(g, 1, (3 if pool else 5) * r["h"].numel() + 5 * dx.numel()):
+                        _call("mn_conv2d_bwd_bnh", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["own"]) if pool else None, _p(r["chan"]), _p(r["sums"]),
+                              r["training"], _p(wq), _p(x), _p(dx), _p(dw), _p(db), _p(ws), nb, _s())
+                return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
             with torch.cuda.device_of(x):
                 if ctx.needs_input_grad[0]:
                     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)

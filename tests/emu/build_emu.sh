@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../.."
 mkdir -p tests/emu/build
 CXX="g++ -O2 -std=c++17 -fPIC -ffp-contract=off -I tests/emu/include -x c++"
-SRCS="quant_kernels conv_kernels qgemm_kernels qgemm_kxk qgemm_sign qgemm_k3s qgemm_dense conv_first optim_kernels norm_kernels iao_ops qact_kernels data_kernels linear_kernels iao_bnfuse iao_g3 iao_thin"
+SRCS="quant_kernels conv_kernels qgemm_kernels qgemm_kxk qgemm_sign qgemm_pwb qgemm_k3s qgemm_dense conv_first optim_kernels norm_kernels iao_ops qact_kernels data_kernels linear_kernels iao_bnfuse iao_g3 iao_thin"
 pids=""
 for f in $SRCS; do
   extra=""; [ $f = quant_kernels ] && extra="-DMN_EMU_MAIN"

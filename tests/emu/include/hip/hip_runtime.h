@@ -72,6 +72,7 @@ struct Ctx {
     std::vector<float> wa8, wb8;   // bf16 MFMA operands, 8 per lane
     std::vector<int> wi16a, wi16b; // int8 MFMA operands, 16 per lane
     std::vector<int> wflag;
+    std::vector<const void*> wptr;  // ds_read_b64_tr_b16: the lanes' addresses
 };
 inline Ctx& C() { static Ctx c; return c; }
 }  // namespace emu
@@ -295,6 +296,28 @@ static inline __emu_i32x4 emu_mfma_i32_16x16x64_i8(__emu_u32x4 a, __emu_u32x4 b,
     }
     emu::yield(emu::WAIT_WAVE);
     return c;
+}
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read): every lane supplies the address of 4 consecutive 16-bit elements; within each 16-lane group the 16 x 4
+// elements form a [4 rows][16 columns] block (row e = the four lanes 4e .. 4e+3, four columns each) and lane c of the group receives column c: element e
+// of its result = element (c & 3) of lane 4e + (c >> 2).  (Measured on MI355X: scripts/probe/tr16_probe.hip.)
+typedef unsigned __emu_u32x2 __attribute__((vector_size(8)));
+static inline __emu_u32x2 emu_ds_read_tr16_b64(const void* addr) {
+    emu::Ctx& cx = emu::C();
+    int base = (emu::flat_tid() / 64) * 64, l = emu::lane();
+    if (cx.wptr.size() < cx.wflag.size()) cx.wptr.assign(cx.wflag.size(), nullptr);
+    cx.wptr[base + l] = addr;
+    emu::yield(emu::WAIT_WAVE);
+    const int grp = l & ~15, c = l & 15;
+    uint16_t h[4];
+    for (int e = 0; e < 4; ++e) {
+        const uint16_t* src = (const uint16_t*)cx.wptr[base + grp + 4 * e + (c >> 2)];
+        h[e] = src[c & 3];
+    }
+    emu::yield(emu::WAIT_WAVE);
+    __emu_u32x2 r;
+    r[0] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+    r[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    return r;
 }
 // wave-wide "any lane has pred != 0"
 static inline int emu_wave_any(int pred) {

@@ -494,6 +494,24 @@ def check_pool_sign8(be, shape=(3, 5, 8, 16), seed=0):
     assert np.array_equal(be.to_host(din), t.grad.numpy())
 
 
+def _check_pwb(be, g, wq, d_da, h8, a8, chan, sums, training, dW, dA, dx_ref, dw_ref, db_ref, db_tol, x_shape, w_shape, Oc):
+    """mn_conv2d_bwd_bnh (k_pwb: backward-data and backward-weight of the block in one launch, (da, h) read once) against the two-step path's results."""
+    if not be.lib.mn_conv2d_bwd_bnh_supported(C.byref(g), C.byref(wq), 1 if a8 is not None else 0):
+        return
+    nb = int(be.lib.mn_conv2d_bwd_bnh_ws_bytes(C.byref(g)))
+    assert nb > 0
+    for with_bias in (True, False):
+        ws, dx3, dw3, db3 = be.empty(nb // 4 + 4), be.empty(x_shape), be.empty(w_shape), be.empty(Oc)
+        be.call("mn_conv2d_bwd_bnh", C.byref(g), C.byref(wq), be.ptr(d_da), be.ptr(h8), be.ptr(a8) if a8 is not None else None, be.ptr(chan), be.ptr(sums),
+                int(training), be.ptr(dW), be.ptr(dA), be.ptr(dx3), be.ptr(dw3), be.ptr(db3) if with_bias else None, be.ptr(ws), nb, be.stream)
+        assert be.lib.mn_last_kernel().decode() == ("k_pwb<2>" if a8 is not None else "k_pwb<1>")
+        assert close(be.to_host(dx3), dx_ref, 5e-6), ("k_pwb dx", np.max(np.abs(be.to_host(dx3) - dx_ref)) / np.max(np.abs(dx_ref)))
+        assert close(be.to_host(dw3), dw_ref, 5e-6), ("k_pwb dw", np.max(np.abs(be.to_host(dw3) - dw_ref)) / np.max(np.abs(dw_ref)))
+        if with_bias:
+            assert np.max(np.abs(be.to_host(db3) - db_ref)) <= db_tol, "k_pwb dbias"
+    _check_pwb.count = getattr(_check_pwb, "count", 0) + 1
+
+
 def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, pooled=False, stash=False, padding=0, **_):
     """mn_qconv_bnsign_fwd/bwd (conv + BatchNorm + sign on packed codes; y never stored) vs an fp64 numpy evaluation of the
     same block on the same +-1 input and ternary-coded weights."""
@@ -589,6 +607,7 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
                 sc_db = max(np.max(np.abs(be.to_host(dy))) * 1e-4, 1e-30)
                 assert np.max(np.abs(be.to_host(db2) - be.to_host(db_ref2))) <= sc_db * N * H * W
                 check_qconv_bnsign.pool_fold_checked = getattr(check_qconv_bnsign, "pool_fold_checked", 0) + 1
+                _check_pwb(be, g, wq, dGP, h8, a8, chan, sums, training, dW, dA, dx_ref2, be.to_host(dw_ref2), be.to_host(db_ref2), sc_db * N * H * W, x_shape, w.shape, Oc)
         else:
           be.call("mn_qconv_bnsign_bwd_pooled", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save),
                 be.ptr(dGP), be.ptr(a8), int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)
@@ -613,6 +632,7 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
             assert close(be.to_host(dw2), be.to_host(dw_ref2), 5e-6)
             sc_db = max(np.max(np.abs(be.to_host(dy))) * 1e-4, 1e-30)      # d bias in front of a BatchNorm is a sum that cancels to ~0
             assert np.max(np.abs(be.to_host(db2) - be.to_host(db_ref2))) <= sc_db * N * H * W
+            _check_pwb(be, g, wq, dDA, h8, None, chan, sums, training, dW, dA, dx_ref2, be.to_host(dw_ref2), be.to_host(db_ref2), sc_db * N * H * W, x_shape, w.shape, Oc)
     else:
         be.call("mn_qconv_bnsign_bwd", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), be.ptr(save), be.ptr(dDA),
                 int(training), be.ptr(dy), be.ptr(dgam), be.ptr(dbet), be.ptr(ws), nb, be.stream)
@@ -1188,6 +1208,25 @@ WGRAD_SPEC_CASES = [
     dict(x_shape=(3, 96, 4, 8), w_shape=(80, 96, 1, 1)),                              # 3 steps in ONE block: fewer steps than the prefetch depth, odd count
     dict(x_shape=(5, 144, 4, 8), w_shape=(144, 72, 1, 1), groups=2, in_shuffle=2),    # 5 steps, shuffled input channels
 ]
+
+
+# geometries k_pwb covers (groups of 128 -> 128 channels, H*W a multiple of 32): fewer steps than the prefetch depth, an odd count, more blocks than steps,
+# shuffled channels, no bias, four groups
+PWB_CASES = [
+    dict(x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2),          # 3 steps per group
+    dict(x_shape=(1, 128, 8, 8), w_shape=(128, 128, 1, 1), bias=False),                      # one group, 2 steps
+    dict(x_shape=(5, 512, 4, 8), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=4),          # 5 steps, four groups
+]
+
+
+def check_pwb(be, pooled_too=True):
+    before = getattr(_check_pwb, "count", 0)
+    for i, case in enumerate(PWB_CASES):
+        check_qconv_bnsign(be, seed=400 + i, stash=True, **case)
+        check_qconv_bnsign(be, seed=410 + i, stash=True, training=False, **case)
+        if pooled_too:
+            check_qconv_bnsign(be, seed=420 + i, stash=True, pooled=True, **case)
+    assert getattr(_check_pwb, "count", 0) - before == len(PWB_CASES) * (3 if pooled_too else 2), "k_pwb did not take these geometries"
 
 
 def check_wgrad_spec(be):

@@ -456,6 +456,18 @@ def test_conv_backward_with_bn_folded_in(be):
     K.check_qconv_bnsign(be, seed=253, stash=True, x_shape=(8, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=16)
 
 
+def test_pointwise_block_backward_in_one_kernel(be):
+    """mn_conv2d_bwd_bnh (k_pwb): the emulated run's cases + nin_gc's pointwise layers L2 / L5 / L8 (unpooled) and L3 / L6 (pooled) at batch 8."""
+    K.check_pwb(be)
+    before = getattr(K._check_pwb, "count", 0)
+    K.check_qconv_bnsign(be, seed=430, stash=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2)                                   # L2
+    K.check_qconv_bnsign(be, seed=431, stash=True, pooled=True, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2)       # L3
+    K.check_qconv_bnsign(be, seed=432, stash=True, x_shape=(8, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=16)                   # L5
+    K.check_qconv_bnsign(be, seed=433, stash=True, pooled=True, x_shape=(8, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=4)       # L6
+    K.check_qconv_bnsign(be, seed=434, stash=True, x_shape=(8, 1024, 8, 8), w_shape=(1024, 128, 1, 1), groups=8, in_shuffle=32)                   # L8
+    assert getattr(K._check_pwb, "count", 0) - before == 5
+
+
 # stashed block around a 3 x 3 convolution: h written by the k x k kernel, statistics / sign streamed from h (k_h_stats, k_h_sign)
 KXK_STASH_CASES = [
     dict(x_shape=(3, 32, 8, 8), w_shape=(64, 16, 3, 3), padding=1, groups=2),                    # the nin_gc L7 pattern

@@ -312,6 +312,11 @@ def test_conv_backward_with_bn_and_maxpool_folded_in(be):
     assert getattr(K.check_qconv_bnsign, "pool_fold_checked", 0) - before == 6
 
 
+def test_pointwise_block_backward_in_one_kernel(be):
+    """mn_conv2d_bwd_bnh (k_pwb): backward-data + backward-weight of the binary block from ONE read of (da, h), pooled and unpooled, against the two-kernel path."""
+    K.check_pwb(be)
+
+
 def test_conv_backward_with_bn_folded_in(be):
     """mn_conv2d_bwd_data_bnh / mn_conv2d_bwd_weight_bnh (dy formed in registers from (da, h)) on shapes the direct kernels cover."""
     K.check_qconv_bnsign(be, seed=250, stash=True, x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2)
