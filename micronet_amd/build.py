@@ -16,7 +16,7 @@ SOURCES = ["quant_kernels.hip", "conv_kernels.hip", "qgemm_kernels.hip", "qgemm_
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc"]
 # qgemm_sign.hip: the SLP vectoriser pairs fp32 operations of DIFFERENT staged rows into v_pk_* instructions and pays for it with register shuffles on
 # the loop back edge, each behind a wait for the prefetched loads (the software pipeline of k_pws_wgrad_s drained every iteration)
-EXTRA_FLAGS = {"qgemm_sign.hip": ["-fno-slp-vectorize"], "qgemm_kxk.hip": ["-fno-slp-vectorize"]}      # k x k: -3 % on the resnet18 step (A/B)
+EXTRA_FLAGS = {"qgemm_sign.hip": ["-fno-slp-vectorize"], "qgemm_pwb.hip": ["-fno-slp-vectorize"], "qgemm_kxk.hip": ["-fno-slp-vectorize"]}      # k x k: -3 % on the resnet18 step (A/B)
 
 
 def _stale():

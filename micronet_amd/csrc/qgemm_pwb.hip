@@ -21,7 +21,9 @@
 
 #include <stdlib.h>
 
+#ifndef PWB_NS
 #define PWB_NS 4
+#endif
 #define PWB_PLANE (128 * 64)
 #define PWB_CODES (128 * 48)
 #define PWB_BUF (3 * PWB_PLANE + PWB_CODES)
@@ -42,7 +44,7 @@ struct PwbParams {
     float* dx;                  // [N][C][HW]
     float* part;                // [Z][G][128][128]
     float* dbpart;              // [Z][G][128]
-    int N, HW, C, O, G, Z, nsteps, st_per_z, want_db, training, W;
+    int N, HW, C, O, G, Z, nsteps, st_per_z, want_db, training, W, dbg, map;
     float n_f;
     FastDiv fd_hw, fd_w;
     ChanMap in_map;
@@ -51,6 +53,12 @@ struct PwbParams {
 // 16-byte slot swizzle of a plane row: conflict-free b128 row reads (16 rows of one fragment) AND transpose reads (4 consecutive rows = 256 contiguous bytes)
 __device__ __forceinline__ uint32_t pwb_sw(uint32_t row) { return (0x1320u >> (4u * ((row >> 2) & 3u))) & 3u; }
 
+#ifdef PWB_TRACE
+__device__ unsigned long long g_pwb_trace[3 * 64 * 8];
+#define PWB_T(role_, t_, k_) do { if (blockIdx.x == 5 && wave == 1 && lane == 0 && (t_) < 64) g_pwb_trace[((role_) * 64 + (t_)) * 8 + (k_)] = clock64(); } while (0)
+#else
+#define PWB_T(role_, t_, k_) do { } while (0)
+#endif
 template <int BNH>
 __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
     constexpr int NS = PWB_NS, PLANE = PWB_PLANE, BUF = PWB_BUF;
@@ -62,9 +70,19 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
     const uint32_t bz = blockIdx.x;
     const int z = (int)(bz % (uint32_t)p.Z), g = (int)(bz / (uint32_t)p.Z);
     const uint32_t HW = (uint32_t)p.HW;
-    const int st0 = z * p.st_per_z;
-    int n = (st0 + p.st_per_z < p.nsteps ? st0 + p.st_per_z : p.nsteps) - st0;
+    // which steps the block takes, and in which order (pwb_step below): map 0 = the contiguous range [z st_per_z, ...) front to back; 1 = the same range started at a
+    // block-dependent ROTATION (every block of a launch starting at offset 0 of its range walks the HBM channels in lock-step: the rows of a step are 4 KB apart);
+    // 2 = interleaved, steps z, z + Z, z + 2 Z, ...
+    const int st0 = p.map == 2 ? z : z * p.st_per_z;
+    int n = p.map == 2 ? (z < p.nsteps ? (p.nsteps - z + p.Z - 1) / p.Z : 0) : (st0 + p.st_per_z < p.nsteps ? st0 + p.st_per_z : p.nsteps) - st0;
     n = n > 0 ? n : 0;
+    const int rot = (p.map == 1 && n > 0) ? z % n : 0;
+    auto pwb_step = [&](int k) -> int {          // global step index of the block's k-th step, k < n
+        if (p.map == 2) return st0 + k * p.Z;
+        int kk = k + rot;
+        kk = kk >= n ? kk - n : kk;
+        return st0 + kk;
+    };
     const int nit = (n + NS - 1) / NS * NS;                                // every role passes the same number of barriers
 
     if (role == 0) {
@@ -87,7 +105,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         auto fetch = [&](Stage& S, int k) {
             // past the block's range: re-read the block's own last step (an L2 hit); loads stay unconditional
             const int kk = k < n ? k : (n > 0 ? n - 1 : 0);
-            int st = st0 + kk;
+            int st = pwb_step(kk);
             st = st < p.nsteps ? st : p.nsteps - 1;
             const uint32_t P = (uint32_t)st * 32u + 4u * sq;
             const uint32_t ni = fd_div(P, p.fd_hw);
@@ -107,9 +125,12 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                     S.hv[i] = *reinterpret_cast<const uint32_t*>(p.h + (o + goff[i]));
                 }
             } else {
+                uint32_t bo[4];          // byte offsets (plan: 4 N O HW < 2^32): uniform base + 32-bit lane offset, each load from its own offset register
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bo[i] = (o + goff[i]) * 4u;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    S.gv[i] = *reinterpret_cast<const float4*>(p.gy + (o + goff[i]));
+                    S.gv[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.gy) + bo[i]);
                     if (BNH) S.hv[i] = *reinterpret_cast<const uint32_t*>(p.h + (o + goff[i]));
                 }
             }
@@ -169,9 +190,13 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         for (int t = 0; t < nit; t += NS) {
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
+                PWB_T(0, t + u, 0);
                 commit(st[u], u & 1, t + u < n);
+                PWB_T(0, t + u, 1);
                 fetch(st[u], t + u + NS);
+                PWB_T(0, t + u, 2);
                 __syncthreads();
+                PWB_T(0, t + u, 3);
             }
         }
         __syncthreads();                                                   // the staging buffers are free (the dW waves stage their tiles through them)
@@ -196,8 +221,10 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         __syncthreads();
         for (int t = 0; t < nit; ++t) {
             __syncthreads();
-            if (t < n) {
+            PWB_T(1, t, 0);
+            if (t < n && !(p.dbg & 4)) {
                 const unsigned char* A = lds + (t & 1) * BUF;
+                // every LDS read of the step is issued before the first MFMA (read just in time, each group of MFMAs waits for its own LDS round trip)
                 u32x2 braw[4];
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) braw[ci] = *reinterpret_cast<const u32x2*>(A + boff + ci * 768);
@@ -206,6 +233,8 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) af[pl][mi] = *reinterpret_cast<const u32x4*>(A + pl * PLANE + aoff + mi * 1024);
+                PWB_T(1, t, 1);
+                MN_SCHED_FENCE();
                 u32x4 bf[4];
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) {
@@ -219,6 +248,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                         for (int ci = 0; ci < 4; ++ci) acc[mi][ci] = mn_mfma_bf16(af[pl][mi], bf[ci], acc[mi][ci]);
+                PWB_T(1, t, 2);
             }
         }
         __syncthreads();                                                   // every wave is done with the staging buffers
@@ -244,10 +274,10 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             wf[ks] = *reinterpret_cast<const u32x4*>(p.wc + ((int64_t)(g * 128 + 32 * wave + m) * 128 + 16 * ks + 8 * kgrp));
-        uint32_t ooff[16];                 // accumulator register r = row (r & 3) + 8 (r >> 2) + 4 kgrp of the wave's 32, column m
+        uint32_t ooff[16];                 // BYTE offset of accumulator register r = row (r & 3) + 8 (r >> 2) + 4 kgrp of the wave's 32, column m (plan: 4 N C HW < 2^32)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            ooff[r] = (uint32_t)chan_phys(p.in_map, g * 128 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kgrp) * HW + (uint32_t)m;
+            ooff[r] = ((uint32_t)chan_phys(p.in_map, g * 128 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kgrp) * HW + (uint32_t)m) * 4u;
         uint32_t toff[2];                  // transpose reads r2 = 0, 1 of a K-step: plane rows 16 ks + 8 kgrp + 4 r2 + (i16 >> 2), pixels 16 nhalf + 4 (i16 & 3) ..
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
@@ -258,26 +288,49 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         __syncthreads();
         for (int t = 0; t < nit; ++t) {
             __syncthreads();
-            if (t < n) {
+            PWB_T(2, t, 0);
+            if (t < n && !(p.dbg & 2)) {
                 const unsigned char* A = lds + (t & 1) * BUF;
                 f32x16 a0, a1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
+                // B fragments of K-step ks (three planes).  K-steps go in pairs -- the even one into a0, the odd one into a1, alternating, so that two MFMAs on one
+                // accumulator are never adjacent -- and a ring of two pairs sits in registers: an LDS round trip is hidden behind the six MFMAs of a pair
+                u32x4 bq[4][3];
+                auto ldk = [&](u32x4 (&dstq)[3], int ks) {
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
                         const mn_u32x2 lo = mn_lds_tr16_b64(A + pl * PLANE + ks * 1024 + toff[0]);
                         const mn_u32x2 hi = mn_lds_tr16_b64(A + pl * PLANE + ks * 1024 + toff[1]);
-                        const u32x4 bfr = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                        if (ks & 1) a1 = mn_mfma32_bf16(wf[ks], bfr, a1); else a0 = mn_mfma32_bf16(wf[ks], bfr, a0);
+                        dstq[pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                     }
-                }
-                const uint32_t P = (uint32_t)(st0 + t) * 32u;
-                const uint32_t ni = fd_div(P, p.fd_hw);
-                float* dst = p.dx + (ni * (uint32_t)p.C * HW + (P - ni * HW));
+                };
+                ldk(bq[0], 0); ldk(bq[1], 1); ldk(bq[2], 2); ldk(bq[3], 3);
+                MN_SCHED_FENCE();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[ooff[r]] = a0[r] + a1[r];
+                for (int kp = 0; kp < 4; ++kp) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        a0 = mn_mfma32_bf16(wf[2 * kp], bq[(2 * kp) & 3][pl], a0);
+                        a1 = mn_mfma32_bf16(wf[2 * kp + 1], bq[(2 * kp + 1) & 3][pl], a1);
+                    }
+                    if (kp + 2 < 4) { ldk(bq[(2 * kp) & 3], 2 * kp + 4); ldk(bq[(2 * kp + 1) & 3], 2 * kp + 5); }
+                    MN_SCHED_FENCE();
+                }
+                PWB_T(2, t, 1);
+                const uint32_t P = (uint32_t)pwb_step(t) * 32u;
+                const uint32_t ni = fd_div(P, p.fd_hw);
+                // the 16 row segments leave from 16 DIFFERENT registers, addressed as uniform base + 32-bit lane offset: a store whose address / data register is
+                // rewritten for the next one waits until the memory pipeline has read it (measured: ~150 cycles per store, half of the step)
+                char* dst = reinterpret_cast<char*>(p.dx + (ni * (uint32_t)p.C * HW + (P - ni * HW)));
+                float outv[16];
+                uint32_t oo[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { outv[r] = a0[r] + a1[r]; oo[r] = mn_opaque(ooff[r]); }          // (opaque: the zero-extension stays in this block -> saddr form)
+                MN_SCHED_FENCE();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(dst + oo[r]) = outv[r];
+                PWB_T(2, t, 2);
             }
         }
         __syncthreads();
@@ -346,12 +399,34 @@ int pwb_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const u
     p.gy = da; p.h = h; p.chan = chan; p.sums = sums; p.own = (const char*)own; p.x = (const char*)x; p.dx = dx;
     p.part = (float*)((char*)ws + pl.off_part); p.dbpart = (float*)((char*)ws + pl.off_db);
     p.want_db = dbias != nullptr; p.training = training;
+    p.dbg = 0;
+    p.map = 1;
+    if (const char* e = MN_ENV("MN_PWB_MAP")) { const int v = atoi(e); if (v >= 0 && v <= 2) p.map = v; }          // A/B knob: step-to-block map (see the kernel)
+    if (const char* e = MN_ENV("MN_PWB_DBG")) p.dbg = atoi(e);          // ablation bits (timing experiments only: results are wrong)
     mn_set_last_kernel(own ? "k_pwb<2>" : "k_pwb<1>");
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((own ? 3.0 : 5.0) * ny + 5.0 * nx); }
     mn_prof_begin(s);
     if (own) { raise_lds_limit((const void*)k_pwb<2>, PWB_LDS); hipLaunchKernelGGL((k_pwb<2>), dim3(pl.grid), dim3(768), PWB_LDS, s, p); }
     else { raise_lds_limit((const void*)k_pwb<1>, PWB_LDS); hipLaunchKernelGGL((k_pwb<1>), dim3(pl.grid), dim3(768), PWB_LDS, s, p); }
     mn_prof_end(s);
+#ifdef PWB_TRACE
+    if (MN_ENV("MN_PWB_TRACE")) {
+        static int once = 0;
+        if (once++ == 4) {
+            (void)hipStreamSynchronize(s);
+            static unsigned long long hbuf[3 * 64 * 8];
+            (void)hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_pwb_trace), sizeof hbuf);
+            for (int t = 8; t < 20; ++t) {
+                const unsigned long long b0 = hbuf[(0 * 64 + 8) * 8 + 0];
+                fprintf(stderr, "t %2d  prod: top %6lld commit %6lld fetch %6lld barrier %6lld | dW: bar %6lld reads %6lld mfma %6lld | dx: bar %6lld mfma %6lld stores %6lld\n", t,
+                        (long long)(hbuf[(0 * 64 + t) * 8 + 0] - b0), (long long)(hbuf[(0 * 64 + t) * 8 + 1] - b0), (long long)(hbuf[(0 * 64 + t) * 8 + 2] - b0),
+                        (long long)(hbuf[(0 * 64 + t) * 8 + 3] - b0), (long long)(hbuf[(1 * 64 + t) * 8 + 0] - b0), (long long)(hbuf[(1 * 64 + t) * 8 + 1] - b0),
+                        (long long)(hbuf[(1 * 64 + t) * 8 + 2] - b0), (long long)(hbuf[(2 * 64 + t) * 8 + 0] - b0), (long long)(hbuf[(2 * 64 + t) * 8 + 1] - b0),
+                        (long long)(hbuf[(2 * 64 + t) * 8 + 2] - b0));
+            }
+        }
+    }
+#endif
     qg_launch_wgrad_reduce_div(p.part, p.dbpart, dw, dbias, p.Z, p.G, 128, 128, 128, 128, p.kscale, s);
     MN_CHECK_LAUNCH("mn_conv2d_bwd_bnh");
     return MN_OK;
