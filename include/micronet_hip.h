@@ -506,6 +506,18 @@ int mn_conv2d_bwd_bnh_supported(const mn_conv_geom* g, const mn_wq* wq, int pool
 int64_t mn_conv2d_bwd_bnh_ws_bytes(const mn_conv_geom* g);
 int mn_conv2d_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
                       int training, const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
+/* The same one-launch backward for the k-bit (DoReFa) blocks, wqaq/dorefa/quantize.py:36-46, 107-122 + autograd's conv backward (same geometry, same two queries
+ * with pooled = 0, same workspace):
+ *   mn_conv2d_bwd_codes: dx (NO clip-STE: the producing block applies it where it recomputes the activation) and dw = s_x * sum gy * j, dbias from a plain fp32
+ *     gradient gy [N][O][H][W]; x = the input's activation codes j (bytes) of x_bits bits -- x_bits == 0: sign codes (+-1 bytes, wbwtab), dw = sum gy * x.
+ *   mn_conv2d_bwd_qa: the gradient is the BatchNorm + ReLU + next-quantizer backward of (dq, stash), formed while they stream in -- what mn_qa_bwd_apply would
+ *     write as fp32 dy (un-pooled blocks): dq = d loss / d (the block's output; quant != 0: its out_bits-quantised output, the clip-STE is applied here), stash =
+ *     the conv's integer accumulator (int16, stash_bits == 32: int32; mn_qconv_bnq_fwd_stash), chan [9][O], sums [2][O] (mn_qa_bwd_sums). */
+int mn_conv2d_bwd_codes(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x_codes, int x_bits, float* dx, float* dw, float* dbias,
+                        void* ws, int64_t ws_bytes, mn_stream_t stream);
+int mn_conv2d_bwd_qa(const mn_conv_geom* g, const mn_wq* wq, const float* dq, const void* stash, int stash_bits, const float* chan, const float* sums, int out_bits,
+                     int quant, int training, const float* w, const uint8_t* x_codes, int x_bits, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
+                     mn_stream_t stream);
 /* same backward when a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119) sits behind the block: `dpool` = d loss / d pool(a),
  * [N][O][H/2][W/2] fp32, `a_own` = the block's own output codes (what mn_qconv_bnsign_fwd wrote); the pool's backward (gradient to
  * the first maximum of each window) is applied while the gradient is read -- a quarter of the bytes, no full-size da tensor. */

@@ -119,6 +119,8 @@ PROTOTYPES = {
     "mn_conv2d_bwd_bnh_supported": (_I, [_G, _W, _I]),
     "mn_conv2d_bwd_bnh_ws_bytes": (_L, [_G]),
     "mn_conv2d_bwd_bnh": (_I, [_G, _W, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "mn_conv2d_bwd_codes": (_I, [_G, _W, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    "mn_conv2d_bwd_qa": (_I, [_G, _W, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_conv2d_bnh_pool_supported": (_I, [_G, _W]),
     "mn_conv2d_bwd_data_bnh_pool": (_I, [_G, _W, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
     "mn_conv2d_bwd_weight_bnh_pool": (_I, [_G, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),

@@ -862,6 +862,21 @@ extern "C" int mn_conv2d_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const f
     if (!wq || !da || !h || !chan || !sums || !w || !x || !dx || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_bnh: null tensor");
     return pwb_bwd_bnh(g, wq, da, h, own, chan, sums, training, w, x, dx, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
 }
+extern "C" int mn_conv2d_bwd_codes(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x_codes, int x_bits, float* dx, float* dw,
+                                   float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_codes");
+    if (rc) return rc;
+    if (!wq || !gy || !w || !x_codes || !dx || !dw || x_bits < 0 || x_bits > 8) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_codes: null tensor / bad bit width");
+    return pwb_bwd_plain(g, wq, gy, w, x_codes, x_bits, dx, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int mn_conv2d_bwd_qa(const mn_conv_geom* g, const mn_wq* wq, const float* dq, const void* stash, int stash_bits, const float* chan, const float* sums,
+                                int out_bits, int quant, int training, const float* w, const uint8_t* x_codes, int x_bits, float* dx, float* dw, float* dbias, void* ws,
+                                int64_t ws_bytes, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_qa");
+    if (rc) return rc;
+    if (!wq || !dq || !stash || !chan || !sums || !w || !x_codes || !dx || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_qa: null tensor");
+    return pwb_bwd_qa(g, wq, dq, stash, stash_bits, chan, sums, out_bits, quant, training, w, x_codes, x_bits, dx, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta,
                                              const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                                              mn_stream_t stream) {

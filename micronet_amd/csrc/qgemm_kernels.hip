@@ -848,9 +848,9 @@ void qg_launch_wgrad_reduce(const float* part, const float* dbpart, float* dw, f
     qg_launch_wgrad_reduce_(part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp, nullptr, s);
 }
 // ... of partials formed on an operand whose row m of group g was multiplied by rowdiv[g * Mgw + m] (k_pwb, qgemm_pwb.hip): dw, db = sum / rowdiv
-void qg_launch_wgrad_reduce_div(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw, const float* rowdiv,
-                                hipStream_t s) {
-    qg_launch_wgrad_reduce_(part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, 1.f, nullptr, rowdiv, s);
+void qg_launch_wgrad_reduce_div(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw, float ascale,
+                                const float* rowdiv, hipStream_t s) {
+    qg_launch_wgrad_reduce_(part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, nullptr, rowdiv, s);
 }
 static void qg_launch_wgrad_reduce_(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
                                     float ascale, const float* qp, const float* rowdiv, hipStream_t s) {

@@ -1,12 +1,17 @@
-// ONE backward kernel per pointwise binary block (round 6): backward-data AND backward-weight of a 1 x 1 grouped convolution on sign codes whose incoming
-// gradient is the BatchNorm+sign backward (optionally behind a 2 x 2 max-pool) of (da, h) -- wbwtab/quantize.py:11-36 (BinaryActivation), :181-195 (QuantConv2d)
-// + autograd's conv backward.  k_pwd<4, 4, BNH> (qgemm_kernels.hip) and k_pws_wgrad_s<4, BNH, 0, 2> (qgemm_sign.hip) each rebuilt the same dy tile from the same
-// (da, h): 15 B per element between them (da 4 + h 1 + dx 4; da 4 + h 1 + x 1).  Here (da, h) cross HBM once: 10 B per element.
+// ONE backward kernel per pointwise quantised block (round 6): backward-data AND backward-weight of a 1 x 1 grouped convolution on activation codes, with the
+// block's own BatchNorm backward formed while the operands stream in:
+//   BNH 1 / 2   wbwtab: the gradient is the BatchNorm+sign backward (2: behind a 2 x 2 max-pool) of (da, h) -- wbwtab/quantize.py:11-36 (BinaryActivation),
+//               :181-195 (QuantConv2d) + autograd's conv backward.  k_pwd<4, 4, BNH> (qgemm_kernels.hip) and k_pws_wgrad_s<4, BNH, 0, 2> (qgemm_sign.hip) each rebuilt
+//               the same dy tile from the same (da, h): 15 B per element between them.  Here (da, h) cross HBM once: 10 B per element.
+//   BNH 3       DoReFa: the gradient is the BatchNorm + ReLU + next-quantizer backward of (dq, stash) -- wqaq/dorefa/quantize.py:36-46, 107-122 -- what k_qa_apply
+//               (qact_kernels.hip) wrote as fp32 dy for k_pwd<4, 4, 0> and k_pws_wgrad_s<4, 0, 1, 2> to read back: 23 B per element between the three, 11 here.
+//   BNH 0       a plain fp32 gradient dy (the pooled DoReFa blocks, whose dy k_qa_apply<.., 1> still writes): 9 B per element instead of 13.
+//   XENC 0 / 1  the input codes are sign bytes (+-1) / k-bit activation codes j (dW = s sum dy j: the reduction multiplies by the quantizer's scale s).
 //
 // Geometry: groups of 128 -> 128 channels (every pointwise layer of nin_gc), HW a multiple of 32.  A block owns one group and a contiguous range of 32-pixel steps;
 // 768 threads = 12 waves, three per SIMD, one of each role:
-//   waves 0-3   PRODUCERS   global loads (4 steps in flight in registers), BatchNorm+sign fold (G dz + E1 h + E0, already times the weight scale of the row), exact
-//                           three-term bf16 split, LDS image: three bf16 planes [128 rows o][32 pixels] (64-byte rows, 16-byte slots XOR-swizzled) + the input codes;
+//   waves 0-3   PRODUCERS   global loads (NS steps in flight in registers), the BatchNorm fold (already times the weight scale of the row), exact three-term bf16
+//                           split, LDS image: three bf16 planes [128 rows o][32 pixels] (64-byte rows, 16-byte slots XOR-swizzled) + the input codes;
 //   waves 4-7   dW          2 x 2 grid of 64 x 64 tiles of dW[o][c] += dy'[o][p] x[c][p]: v_mfma_f32_16x16x32_bf16, A = b128 rows of the planes (K = pixel);
 //   waves 8-11  dx          wave w owns input channels 32 w .. 32 w + 31: dx[c][p] = sum_o W[o][c] dy'[o][p] on v_mfma_f32_32x32x16_bf16 with the weight codes held in
 //                           registers (A) and the SAME planes read through the LDS transpose read ds_read_b64_tr_b16 (B: K = plane row o, N = pixel) -- no second,
@@ -14,38 +19,38 @@
 // dy' = alpha[o] dy is what backward-data contracts with the integer codes (k_pwd does the same); backward-weight wants dy, so the fixed-order fp64 reduction of the
 // partial tiles divides row o by alpha[o] (a row with alpha = 0 has all-zero codes: it is staged unscaled and divided by 1).
 // One barrier per step: barrier k publishes step k (buffer k & 1); the producers refill that buffer with step k + 2 only behind barrier k + 1, which both consumer
-// groups reach after their reads of step k.
+// groups reach after their reads of step k.  What the timeline (PWB_TRACE) and the ablations of round 6 found on the way is in profiles/README.md: the SLP
+// vectoriser drains the producers' software pipeline (this file is built with -fno-slp-vectorize), a memory instruction whose address / data register is rewritten
+// for the next one serialises on the memory pipeline's operand read, LDS reads issued just in time expose one round trip per MFMA group.
 #include "qgemm.h"
 
 #include "qgemm_dev.h"
 
 #include <stdlib.h>
 
-#ifndef PWB_NS
-#define PWB_NS 4
-#endif
 #define PWB_PLANE (128 * 64)
 #define PWB_CODES (128 * 48)
 #define PWB_BUF (3 * PWB_PLANE + PWB_CODES)
+#define PWB_FROW 12                                                  // floats per row of the fold table
 #define PWB_ERS 68                                                   // floats per staged row of a wave's 64 x 64 partial tile
-#define PWB_LDS_STAGE (2 * PWB_BUF + 128 * 32)
+#define PWB_LDS_STAGE (2 * PWB_BUF + 128 * PWB_FROW * 4)
 #define PWB_LDS_EPI (4 * 64 * PWB_ERS * 4)
 #define PWB_LDS (PWB_LDS_STAGE > PWB_LDS_EPI ? PWB_LDS_STAGE : PWB_LDS_EPI)
 
 struct PwbParams {
-    const float* gy;            // BNH 1: da [N][O][HW]; BNH 2: the pooled gradient [N][O][H/2][W/2]; BNH 0: dy itself
-    const unsigned char* h;     // [N][O][HW] one-byte conv stash
-    const float* chan;          // [8][O]
+    const float* gy;            // BNH 1: da [N][O][HW]; 2: the pooled gradient [N][O][H/2][W/2]; 3: dq [N][O][HW]; 0: dy itself
+    const void* h;              // BNH 1 / 2: the one-byte conv stash [N][O][HW]; 3: the 16-bit (WIDE: 32-bit) stash of acc
+    const float* chan;          // BNH 1 / 2: [8][O] (qgemm_sign.hip); 3: [9][O] (qact_kernels.hip)
     const float* sums;          // [2][O]
     const char* own;            // BNH 2: the block's own sign output [N][O][H][W]
-    const char* x;              // [N][C][HW] input sign codes (physical channel order: in_map)
+    const char* x;              // [N][C][HW] input codes (physical channel order: in_map)
     const uint16_t* wc;         // [G][128 c][128 o] transposed weight codes (bf16)
     const float* kscale;        // [G][128] weight scale alpha of output channel o
     float* dx;                  // [N][C][HW]
     float* part;                // [Z][G][128][128]
     float* dbpart;              // [Z][G][128]
-    int N, HW, C, O, G, Z, nsteps, st_per_z, want_db, training, W, dbg, map;
-    float n_f;
+    int N, HW, C, O, G, Z, nsteps, st_per_z, want_db, training, W, quant;
+    float n_f, qs, qinv;        // BNH 3: scale of the quantizer behind the block, RN(1 / qs) (0: IEEE division)
     FastDiv fd_hw, fd_w;
     ChanMap in_map;
 };
@@ -53,32 +58,31 @@ struct PwbParams {
 // 16-byte slot swizzle of a plane row: conflict-free b128 row reads (16 rows of one fragment) AND transpose reads (4 consecutive rows = 256 contiguous bytes)
 __device__ __forceinline__ uint32_t pwb_sw(uint32_t row) { return (0x1320u >> (4u * ((row >> 2) & 3u))) & 3u; }
 
-#ifdef PWB_TRACE
+#ifdef PWB_TRACE          // s_memtime timeline of one block (scripts/variant_lib.sh trace qgemm_pwb.hip -DPWB_TRACE; MN_PWB_TRACE=1 prints steps 8..19 of the fifth call)
 __device__ unsigned long long g_pwb_trace[3 * 64 * 8];
 #define PWB_T(role_, t_, k_) do { if (blockIdx.x == 5 && wave == 1 && lane == 0 && (t_) < 64) g_pwb_trace[((role_) * 64 + (t_)) * 8 + (k_)] = clock64(); } while (0)
 #else
 #define PWB_T(role_, t_, k_) do { } while (0)
 #endif
-template <int BNH>
+
+template <int BNH, int XENC, int WIDE>
 __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
-    constexpr int NS = PWB_NS, PLANE = PWB_PLANE, BUF = PWB_BUF;
+    constexpr int NS = WIDE ? 3 : 4, PLANE = PWB_PLANE, BUF = PWB_BUF;
     HIP_DYNAMIC_SHARED(float, smemw)
-    unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table [128][8]
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table [128][PWB_FROW]
     float* ftab = reinterpret_cast<float*>(lds + 2 * BUF);
     const int role = (int)threadIdx.x >> 8;                                // 0 producer, 1 dW, 2 dx
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const uint32_t bz = blockIdx.x;
     const int z = (int)(bz % (uint32_t)p.Z), g = (int)(bz / (uint32_t)p.Z);
     const uint32_t HW = (uint32_t)p.HW;
-    // which steps the block takes, and in which order (pwb_step below): map 0 = the contiguous range [z st_per_z, ...) front to back; 1 = the same range started at a
-    // block-dependent ROTATION (every block of a launch starting at offset 0 of its range walks the HBM channels in lock-step: the rows of a step are 4 KB apart);
-    // 2 = interleaved, steps z, z + Z, z + 2 Z, ...
-    const int st0 = p.map == 2 ? z : z * p.st_per_z;
-    int n = p.map == 2 ? (z < p.nsteps ? (p.nsteps - z + p.Z - 1) / p.Z : 0) : (st0 + p.st_per_z < p.nsteps ? st0 + p.st_per_z : p.nsteps) - st0;
+    // The block takes the contiguous range [z st_per_z, ...) of steps, started at a block-dependent ROTATION: the rows of a step are 4 KB apart, and every block of
+    // a launch starting at offset 0 of its range walks the HBM channels in lock-step with all the others (L2: 224 -> 203 us; interleaved steps z, z + Z, ..: 226)
+    const int st0 = z * p.st_per_z;
+    int n = (st0 + p.st_per_z < p.nsteps ? st0 + p.st_per_z : p.nsteps) - st0;
     n = n > 0 ? n : 0;
-    const int rot = (p.map == 1 && n > 0) ? z % n : 0;
+    const int rot = n > 0 ? z % n : 0;
     auto pwb_step = [&](int k) -> int {          // global step index of the block's k-th step, k < n
-        if (p.map == 2) return st0 + k * p.Z;
         int kk = k + rot;
         kk = kk >= n ? kk - n : kk;
         return st0 + kk;
@@ -97,11 +101,32 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         if (tid < 128) {
             const float ks = p.kscale[g * 128 + tid];
             const float sc = ks == 0.f ? 1.f : ks;
-            float hlo = 0.f, hhi = 0.f, G_ = sc, E1 = 0.f, E0 = 0.f;
-            if (BNH) bnh_fold(p.chan, p.sums, p.O, g * 128 + tid, p.training, p.n_f, sc, hlo, hhi, G_, E1, E0);
-            ftab[tid * 8 + 0] = hlo; ftab[tid * 8 + 1] = hhi; ftab[tid * 8 + 2] = G_; ftab[tid * 8 + 3] = E1; ftab[tid * 8 + 4] = E0;
+            float* fr = ftab + tid * PWB_FROW;
+            if (BNH == 3) {
+                // the DoReFa block's channel (k_qa_apply's arithmetic): masks as ONE interval of the stash integer where the constants allow it (qa_mask_interval)
+                const int co = g * 128 + tid, Cc = p.O;
+                const float alpha = p.chan[co], bias = p.chan[Cc + co], mean = p.chan[2 * Cc + co], invstd = p.chan[3 * Cc + co], ga = p.chan[4 * Cc + co],
+                            be = p.chan[5 * Cc + co], gi = p.chan[8 * Cc + co];
+                auto fin = [](float v) { return fabsf(v) <= 1.0e9f; };
+                float use = 0.f;
+                QaInterval r; r.lo = 1.f; r.hi = 0.f;
+                if (fin(alpha) && fin(bias) && fin(mean) && fin(invstd) && fin(ga) && fin(be) && ga != 0.f && invstd > 0.f && alpha != 0.f) {
+                    auto zf = [&](float v) { const float y = v * alpha + bias; const float zh = (y - mean) * invstd; return zh * ga + be; };
+                    r = qa_mask_interval(WIDE ? (1 << 24) : 32768, zf, [](int32_t w) { return (float)w; }, p.quant);
+                    use = 1.f;
+                }
+                const float k1 = p.training ? p.sums[co] / p.n_f : 0.f, k2 = p.training ? p.sums[Cc + co] / p.n_f : 0.f;
+                fr[0] = r.lo; fr[1] = r.hi; fr[2] = gi * sc; fr[3] = use;
+                fr[4] = alpha; fr[5] = bias; fr[6] = mean; fr[7] = invstd;
+                fr[8] = k1; fr[9] = k2; fr[10] = ga; fr[11] = be;
+            } else {
+                float hlo = 0.f, hhi = 0.f, G_ = sc, E1 = 0.f, E0 = 0.f;
+                if (BNH) bnh_fold(p.chan, p.sums, p.O, g * 128 + tid, p.training, p.n_f, sc, hlo, hhi, G_, E1, E0);
+                fr[0] = hlo; fr[1] = hhi; fr[2] = G_; fr[3] = E1; fr[4] = E0;
+            }
         }
-        struct Stage { float4 gv[4]; uint32_t hv[4]; u32x4 cv; uint32_t hbit; };
+        constexpr int HV = WIDE ? 4 : (BNH == 3 ? 2 : 1), H1 = HV > 1 ? 1 : 0, H2 = HV > 2 ? 2 : 0, H3 = HV > 3 ? 3 : 0;          // stash words per row (H1..: in-range indices)
+        struct Stage { float4 gv[4]; uint32_t hv[4][HV]; u32x4 cv; uint32_t hbit; };
         auto fetch = [&](Stage& S, int k) {
             // past the block's range: re-read the block's own last step (an L2 hit); loads stay unconditional
             const int kk = k < n ? k : (n > 0 ? n - 1 : 0);
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                     const uint32_t r0 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + goff[i]));
                     const uint32_t r1 = *reinterpret_cast<const uint32_t*>(p.own + (cbase + goff[i] + (uint32_t)p.W));
                     S.gv[i] = make_float4(g2.x, g2.y, mn_u2f(r0), mn_u2f(r1));
-                    S.hv[i] = *reinterpret_cast<const uint32_t*>(p.h + (o + goff[i]));
+                    S.hv[i][0] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(p.h) + (o + goff[i]));
                 }
             } else {
                 uint32_t bo[4];          // byte offsets (plan: 4 N O HW < 2^32): uniform base + 32-bit lane offset, each load from its own offset register
@@ -131,7 +156,15 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     S.gv[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.gy) + bo[i]);
-                    if (BNH) S.hv[i] = *reinterpret_cast<const uint32_t*>(p.h + (o + goff[i]));
+                    if (BNH == 1) S.hv[i][0] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(p.h) + (o + goff[i]));
+                    if (BNH == 3 && !WIDE) {
+                        const u32x2 u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(p.h) + (bo[i] >> 1));
+                        S.hv[i][0] = u[0]; S.hv[i][H1] = u[1];
+                    }
+                    if (BNH == 3 && WIDE) {
+                        const u32x4 u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.h) + bo[i]);
+                        S.hv[i][0] = u[0]; S.hv[i][H1] = u[1]; S.hv[i][H2] = u[2]; S.hv[i][H3] = u[3];
+                    }
                 }
             }
             const uint32_t Pc = (uint32_t)st * 32u + 16u * chf;
@@ -156,12 +189,42 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                         v[2 * e2 + 1] = win == S.hbit * 2u + 1u ? ge : 0.f;
                     }
                 }
-                const float4 f0 = *reinterpret_cast<const float4*>(ftab + (sr + 32 * i) * 8);        // hlo, hhi, G, E1
-                if (BNH) {
-                    const float fE0 = ftab[(sr + 32 * i) * 8 + 4];
+                const float* fr = ftab + (sr + 32 * i) * PWB_FROW;
+                const float4 f0 = *reinterpret_cast<const float4*>(fr);
+                if (BNH == 3) {
+                    // f0 = lo, hi, gi * scale, use; f1 = alpha, bias, mean, invstd; f2 = k1, k2, gamma, beta
+                    const float4 f1 = *reinterpret_cast<const float4*>(fr + 4), f2 = *reinterpret_cast<const float4*>(fr + 8);
+                    float sv[4];
+                    if (WIDE) {
+                        sv[0] = (float)(int)S.hv[i][0]; sv[1] = (float)(int)S.hv[i][H1]; sv[2] = (float)(int)S.hv[i][H2]; sv[3] = (float)(int)S.hv[i][H3];
+                    } else {
+                        sv[0] = (float)(int16_t)(S.hv[i][0] & 0xffffu); sv[1] = (float)(int16_t)(S.hv[i][0] >> 16);
+                        sv[2] = (float)(int16_t)(S.hv[i][H1] & 0xffffu); sv[3] = (float)(int16_t)(S.hv[i][H1] >> 16);
+                    }
+                    if (f0.w != 0.f) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = sv[e] * f1.x + f1.y;
+                            const float zh = (y - f1.z) * f1.w;
+                            const float d = p.quant ? dorefa_ste_core_m(v[e], p.qs, p.qinv) : v[e];
+                            const float dz = (sv[e] >= f0.x && sv[e] <= f0.y) ? d : 0.f;
+                            v[e] = f0.z * (dz - f2.x - zh * f2.y);
+                        }
+                    } else {          // a channel with non-finite (or absurd) constants, or gamma == 0: the element-wise masks
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = sv[e] * f1.x + f1.y;
+                            const float zh = (y - f1.z) * f1.w;
+                            const float zz = zh * f2.z + f2.w;
+                            const float dz = qa_dz_m(v[e], qa_relu(zz), zz, p.qs, p.qinv, p.quant);
+                            v[e] = f0.z * (dz - f2.x - zh * f2.y);
+                        }
+                    }
+                } else if (BNH) {
+                    const float fE0 = fr[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float hf = (float)((S.hv[i] >> (8 * e)) & 0xffu);
+                        const float hf = (float)((S.hv[i][0] >> (8 * e)) & 0xffu);
                         const float dz = (hf >= f0.x && hf <= f0.y) ? v[e] : 0.f;
                         v[e] = fmaf(f0.z, dz, fmaf(f0.w, hf, fE0));
                     }
@@ -191,7 +254,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 PWB_T(0, t + u, 0);
-                commit(st[u], u & 1, t + u < n);
+                commit(st[u], (t + u) & 1, t + u < n);
                 PWB_T(0, t + u, 1);
                 fetch(st[u], t + u + NS);
                 PWB_T(0, t + u, 2);
@@ -222,7 +285,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         for (int t = 0; t < nit; ++t) {
             __syncthreads();
             PWB_T(1, t, 0);
-            if (t < n && !(p.dbg & 4)) {
+            if (t < n) {
                 const unsigned char* A = lds + (t & 1) * BUF;
                 // every LDS read of the step is issued before the first MFMA (read just in time, each group of MFMAs waits for its own LDS round trip)
                 u32x2 braw[4];
@@ -238,9 +301,16 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                 u32x4 bf[4];
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) {
-                    // sign byte c -> bf16 +-1.0 = bytes {0x80, (c & 0x80) | 0x3F}
-                    const uint32_t u = (braw[ci][0] & 0x80808080u) | 0x3F3F3F3Fu, v = (braw[ci][1] & 0x80808080u) | 0x3F3F3F3Fu;
-                    bf[ci] = u32x4{mn_perm(u, 0x80u, 0x05000400u), mn_perm(u, 0x80u, 0x07000600u), mn_perm(v, 0x80u, 0x05000400u), mn_perm(v, 0x80u, 0x07000600u)};
+                    if (XENC) {          // k-bit activation codes j (bytes) -> bf16 j (exact)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t u = braw[ci][d >> 1] >> (16 * (d & 1));
+                            bf[ci][d] = mn_pack_bf16x2((float)(u & 0xffu), (float)((u >> 8) & 0xffu));
+                        }
+                    } else {             // sign byte c -> bf16 +-1.0 = bytes {0x80, (c & 0x80) | 0x3F}
+                        const uint32_t u = (braw[ci][0] & 0x80808080u) | 0x3F3F3F3Fu, v = (braw[ci][1] & 0x80808080u) | 0x3F3F3F3Fu;
+                        bf[ci] = u32x4{mn_perm(u, 0x80u, 0x05000400u), mn_perm(u, 0x80u, 0x07000600u), mn_perm(v, 0x80u, 0x05000400u), mn_perm(v, 0x80u, 0x07000600u)};
+                    }
                 }
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
@@ -289,7 +359,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         for (int t = 0; t < nit; ++t) {
             __syncthreads();
             PWB_T(2, t, 0);
-            if (t < n && !(p.dbg & 2)) {
+            if (t < n) {
                 const unsigned char* A = lds + (t & 1) * BUF;
                 f32x16 a0, a1;
 #pragma unroll
@@ -339,8 +409,8 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
 
 // ------------------------------------------------------------------------------------------------ host side
 int pwd_pack_plan(const mn_conv_geom* g, PackParams* pk, int* grid, int64_t* off_scale, int64_t* bytes);          // qgemm_kernels.hip
-void qg_launch_wgrad_reduce_div(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw, const float* rowdiv,
-                                hipStream_t s);
+void qg_launch_wgrad_reduce_div(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw, float ascale,
+                                const float* rowdiv, hipStream_t s);
 
 struct PwbPlan { PwbParams p; PackParams pk; int pack_grid, grid; int64_t off_scale, pack_bytes, off_part, off_db, ws_bytes; };
 static int plan_pwb(const mn_conv_geom* g, PwbPlan* pl) {
@@ -348,16 +418,14 @@ static int plan_pwb(const mn_conv_geom* g, PwbPlan* pl) {
     if (g->groups < 1 || g->C != 128 * g->groups || g->O != 128 * g->groups) return 0;
     const int64_t HW = g->H * g->W, NP = (int64_t)g->N * HW;
     if (HW % 32 || NP <= 0) return 0;
-    if (4 * NP * g->C >= ((int64_t)1 << 32)) return 0;                     // 32-bit element offsets
+    if (4 * NP * g->C >= ((int64_t)1 << 32)) return 0;                     // 32-bit byte offsets
     if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
-    if (MN_ENV("MN_NO_PWB")) return 0;                                      // A/B knob: the two-kernel backward (k_pwd + k_pws_wgrad_s)
     if (!pwd_pack_plan(g, &pl->pk, &pl->pack_grid, &pl->off_scale, &pl->pack_bytes)) return 0;
     if (pl->pk.Cpad != 128 || pl->pk.Mgp != 128) return 0;
     PwbParams& p = pl->p;
     p.N = (int)g->N; p.HW = (int)HW; p.C = (int)g->C; p.O = (int)g->O; p.G = (int)g->groups; p.W = (int)g->W;
     p.nsteps = (int)(NP / 32);
-    int Z = 256 / p.G;
-    if (const char* e = MN_ENV("MN_PWB_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }   // tuning knob
+    int Z = 256 / p.G;                                                     // one block per CU (Z = 64 / 256 / 512 per group of L2: 297 / 231 / 236 us against 212)
     if (Z > p.nsteps) Z = p.nsteps;
     if (Z < 1) Z = 1;
     p.Z = Z;
@@ -365,6 +433,7 @@ static int plan_pwb(const mn_conv_geom* g, PwbPlan* pl) {
     p.fd_hw = make_fastdiv((uint32_t)HW); p.fd_w = make_fastdiv((uint32_t)g->W);
     p.in_map = make_chanmap(g->in_shuffle, g->C);
     p.n_f = (float)g->N * (float)HW;
+    p.quant = 0; p.qs = 1.f; p.qinv = 0.f;
     pl->grid = p.G * Z;
     pl->off_part = (pl->pack_bytes + 255) / 256 * 256;
     const int64_t part_bytes = (int64_t)Z * p.G * 128 * 128 * 4;
@@ -380,13 +449,35 @@ int pwb_supported(const mn_conv_geom* g, const mn_wq* wq, int pooled) {
 }
 int64_t pwb_ws_bytes(const mn_conv_geom* g) { PwbPlan pl; return plan_pwb(g, &pl) ? pl.ws_bytes : 0; }
 
-int pwb_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
-                const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+template <int BNH, int XENC, int WIDE>
+static void pwb_launch(const PwbPlan& pl, hipStream_t s) {
+    raise_lds_limit((const void*)k_pwb<BNH, XENC, WIDE>, PWB_LDS);
+    hipLaunchKernelGGL((k_pwb<BNH, XENC, WIDE>), dim3(pl.grid), dim3(768), PWB_LDS, s, pl.p);
+}
+#ifdef PWB_TRACE
+static void pwb_trace_dump(hipStream_t s) {
+    static int once = 0;
+    if (!MN_ENV("MN_PWB_TRACE") || once++ != 4) return;
+    (void)hipStreamSynchronize(s);
+    static unsigned long long hbuf[3 * 64 * 8];
+    (void)hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_pwb_trace), sizeof hbuf);
+    const unsigned long long b0 = hbuf[(0 * 64 + 8) * 8 + 0];
+    for (int t = 8; t < 20; ++t) {
+        auto v = [&](int role, int k) { return (long long)(hbuf[(role * 64 + t) * 8 + k] - b0); };
+        fprintf(stderr, "t %2d  prod: top %6lld commit %6lld fetch %6lld barrier %6lld | dW: bar %6lld reads %6lld mfma %6lld | dx: bar %6lld mfma %6lld stores %6lld\n", t,
+                v(0, 0), v(0, 1), v(0, 2), v(0, 3), v(1, 0), v(1, 1), v(1, 2), v(2, 0), v(2, 1), v(2, 2));
+    }
+}
+#endif
+// mode: 1 wbwtab (h = byte stash; own != NULL: pooled), 3 DoReFa fold (h = 16 / 32-bit stash), 0 plain dy; xenc: 0 sign codes, 1 k-bit codes (dW times ascale)
+static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv_geom* g, const mn_wq* wq, const float* gy, const void* h, const int8_t* own,
+                   const float* chan, const float* sums, int training, int quant, float qs, float ascale, const float* w, const void* x, float* dx, float* dw,
+                   float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
     PwbPlan pl;
-    if (!wq_codeable(wq) || !plan_pwb(g, &pl) || (own && ((g->H & 1) || (g->W & 3)))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_bnh: geometry / quantizer combination not covered");
-    if (!aligned16(dx) || !aligned16(dw) || (((uintptr_t)x) & 15) || (((uintptr_t)h) & 3) || (own ? ((((uintptr_t)da) & 7) || (((uintptr_t)own) & 3)) : !aligned16(da)))
-        MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_bnh: misaligned tensor");
-    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_bnh: workspace too small");
+    if (!wq_codeable(wq) || !plan_pwb(g, &pl) || (own && ((g->H & 1) || (g->W & 3)))) MN_FAIL(MN_ENOTSUP, "%s: geometry / quantizer combination not covered", what);
+    if (!aligned16(dx) || !aligned16(dw) || (((uintptr_t)x) & 15) || (h && (((uintptr_t)h) & 15)) || (own ? ((((uintptr_t)gy) & 7) || (((uintptr_t)own) & 3)) : !aligned16(gy)))
+        MN_FAIL(MN_ENOTSUP, "%s: misaligned tensor", what);
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "%s: workspace too small", what);
     PwbParams& p = pl.p;
     if (wq->packed_bwd && !MN_ENV("MN_NO_PACKED_PW")) {
         p.wc = (const uint16_t*)wq->packed_bwd;
@@ -396,38 +487,46 @@ int pwb_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const u
         qg_launch_pack(pl.pk, pl.pack_grid, s);
         p.wc = pl.pk.codes; p.kscale = pl.pk.scale_out;
     }
-    p.gy = da; p.h = h; p.chan = chan; p.sums = sums; p.own = (const char*)own; p.x = (const char*)x; p.dx = dx;
+    p.gy = gy; p.h = h; p.chan = chan; p.sums = sums; p.own = (const char*)own; p.x = (const char*)x; p.dx = dx;
     p.part = (float*)((char*)ws + pl.off_part); p.dbpart = (float*)((char*)ws + pl.off_db);
     p.want_db = dbias != nullptr; p.training = training;
-    p.dbg = 0;
-    p.map = 1;
-    if (const char* e = MN_ENV("MN_PWB_MAP")) { const int v = atoi(e); if (v >= 0 && v <= 2) p.map = v; }          // A/B knob: step-to-block map (see the kernel)
-    if (const char* e = MN_ENV("MN_PWB_DBG")) p.dbg = atoi(e);          // ablation bits (timing experiments only: results are wrong)
-    mn_set_last_kernel(own ? "k_pwb<2>" : "k_pwb<1>");
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((own ? 3.0 : 5.0) * ny + 5.0 * nx); }
+    p.quant = quant; p.qs = qs; p.qinv = MN_ENV("MN_QA_IEEE_DIV") ? 0.f : 1.0f / qs;
+    const int bnh = mode == 1 ? (own ? 2 : 1) : mode;
+    mn_set_last_kernel("k_pwb<%d, %d, %d>", bnh, xenc, wide);
+    {
+        const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
+        mn_prof_bytes((mode == 1 ? (own ? 3.0 : 5.0) : (mode == 3 ? (wide ? 8.0 : 6.0) : 4.0)) * ny + 5.0 * nx);
+    }
     mn_prof_begin(s);
-    if (own) { raise_lds_limit((const void*)k_pwb<2>, PWB_LDS); hipLaunchKernelGGL((k_pwb<2>), dim3(pl.grid), dim3(768), PWB_LDS, s, p); }
-    else { raise_lds_limit((const void*)k_pwb<1>, PWB_LDS); hipLaunchKernelGGL((k_pwb<1>), dim3(pl.grid), dim3(768), PWB_LDS, s, p); }
+    if (bnh == 1 && !xenc) pwb_launch<1, 0, 0>(pl, s);
+    else if (bnh == 2 && !xenc) pwb_launch<2, 0, 0>(pl, s);
+    else if (bnh == 0 && !xenc) pwb_launch<0, 0, 0>(pl, s);
+    else if (bnh == 0) pwb_launch<0, 1, 0>(pl, s);
+    else if (bnh == 3 && xenc && !wide) pwb_launch<3, 1, 0>(pl, s);
+    else if (bnh == 3 && xenc) pwb_launch<3, 1, 1>(pl, s);
+    else MN_FAIL(MN_ENOTSUP, "%s: variant not built", what);
     mn_prof_end(s);
 #ifdef PWB_TRACE
-    if (MN_ENV("MN_PWB_TRACE")) {
-        static int once = 0;
-        if (once++ == 4) {
-            (void)hipStreamSynchronize(s);
-            static unsigned long long hbuf[3 * 64 * 8];
-            (void)hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_pwb_trace), sizeof hbuf);
-            for (int t = 8; t < 20; ++t) {
-                const unsigned long long b0 = hbuf[(0 * 64 + 8) * 8 + 0];
-                fprintf(stderr, "t %2d  prod: top %6lld commit %6lld fetch %6lld barrier %6lld | dW: bar %6lld reads %6lld mfma %6lld | dx: bar %6lld mfma %6lld stores %6lld\n", t,
-                        (long long)(hbuf[(0 * 64 + t) * 8 + 0] - b0), (long long)(hbuf[(0 * 64 + t) * 8 + 1] - b0), (long long)(hbuf[(0 * 64 + t) * 8 + 2] - b0),
-                        (long long)(hbuf[(0 * 64 + t) * 8 + 3] - b0), (long long)(hbuf[(1 * 64 + t) * 8 + 0] - b0), (long long)(hbuf[(1 * 64 + t) * 8 + 1] - b0),
-                        (long long)(hbuf[(1 * 64 + t) * 8 + 2] - b0), (long long)(hbuf[(2 * 64 + t) * 8 + 0] - b0), (long long)(hbuf[(2 * 64 + t) * 8 + 1] - b0),
-                        (long long)(hbuf[(2 * 64 + t) * 8 + 2] - b0));
-            }
-        }
-    }
+    pwb_trace_dump(s);
 #endif
-    qg_launch_wgrad_reduce_div(p.part, p.dbpart, dw, dbias, p.Z, p.G, 128, 128, 128, 128, p.kscale, s);
-    MN_CHECK_LAUNCH("mn_conv2d_bwd_bnh");
+    qg_launch_wgrad_reduce_div(p.part, p.dbpart, dw, dbias, p.Z, p.G, 128, 128, 128, 128, ascale, p.kscale, s);
+    MN_CHECK_LAUNCH(what);
     return MN_OK;
+}
+int pwb_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
+                const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    return pwb_run("mn_conv2d_bwd_bnh", 1, 0, 0, g, wq, da, h, own, chan, sums, training, 0, 1.f, 1.f, w, x, dx, dw, dbias, ws, ws_bytes, s);
+}
+// plain gradient: x_bits == 0: sign codes, else k-bit activation codes of that width
+int pwb_bwd_plain(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x, int x_bits, float* dx, float* dw, float* dbias, void* ws,
+                  int64_t ws_bytes, hipStream_t s) {
+    const float ascale = x_bits ? dorefa_scale(x_bits) : 1.f;
+    return pwb_run("mn_conv2d_bwd_codes", 0, x_bits ? 1 : 0, 0, g, wq, gy, nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f, ascale, w, x, dx, dw, dbias, ws, ws_bytes, s);
+}
+// DoReFa block: dq = gradient w.r.t. the block's output (quant: w.r.t. its out_bits-quantised output), stash of stash_bits = 16 / 32, chan [9][O], sums [2][O]
+int pwb_bwd_qa(const mn_conv_geom* g, const mn_wq* wq, const float* dq, const void* stash, int stash_bits, const float* chan, const float* sums, int out_bits, int quant,
+               int training, const float* w, const uint8_t* x, int x_bits, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+    if ((stash_bits != 16 && stash_bits != 32) || x_bits < 1 || x_bits > 8 || out_bits < 1 || out_bits > 8) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_qa: bad bit width");
+    const float ascale = dorefa_scale(x_bits), qs = dorefa_scale(out_bits);
+    return pwb_run("mn_conv2d_bwd_qa", 3, 1, stash_bits == 32, g, wq, dq, stash, nullptr, chan, sums, training, quant, qs, ascale, w, x, dx, dw, dbias, ws, ws_bytes, s);
 }

@@ -2108,9 +2108,37 @@ class QConvCodeLazy(Function):
         codes, wq = ctx.saved_tensors
         g, a_bits, w_bits, has_bias = ctx.cfg
         x = ctx.x_ref
-        gy = _chk(gy, "grad")
-        aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
         wd = _wq_dorefa(w_bits, ctx.packed, 1)
+        want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        fused = ctx.needs_input_grad[0] and want_w and FUSE_PW_BWD and codes.data_ptr() % 16 == 0 and \
+            bool(_lib_().mn_conv2d_bwd_bnh_supported(C.byref(g), C.byref(wd), 0))
+        fold = fused and isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") == "qa_pw"
+        if not fold:
+            gy = _chk(gy, "grad")
+            fused = fused and gy.data_ptr() % 16 == 0
+        if fused:
+            # both gradients in one launch (k_pwb, qgemm_pwb.hip); with the block's BatchNorm + ReLU + quantizer backward formed inside from (dq, stash) when the
+            # block left a lazy gradient
+            with torch.cuda.device_of(codes):
+                dq = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+                dw = torch.empty_like(wq)
+                db = torch.empty(g.O, dtype=torch.float32, device=codes.device) if has_bias else None
+                nb = int(_lib_().mn_conv2d_bwd_bnh_ws_bytes(C.byref(g)))
+                ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=codes.device)
+                if fold:
+                    r = gy._mn_recipe
+                    with _span(g, 1, (8 if r["kind_in"] == 2 else 6) * r["dq"].numel() + 5 * dq.numel()):
+                        _call("mn_conv2d_bwd_qa", C.byref(g), C.byref(wd), _p(r["dq"]), _p(r["stash"]), 32 if r["kind_in"] == 2 else 16, _p(r["chan"]), _p(r["sums"]),
+                              r["bits"], r["quant"], r["training"], _p(wq), _p(codes), a_bits, _p(dq), _p(dw), _p(db), _p(ws), nb, _s())
+                else:
+                    with _span(g, 1, 4 * gy.numel() + 5 * dq.numel()):
+                        _call("mn_conv2d_bwd_codes", C.byref(g), C.byref(wd), _p(gy), _p(wq), _p(codes), a_bits, _p(dq), _p(dw), _p(db), _p(ws), nb, _s())
+
+            def expand_f(dq_):
+                return DorefaAct.backward_raw(dq_, x.materialize(), a_bits)
+            ctx.x_ref = None
+            return QGrad(dq, expand_f), dw, db, None, None, None, None, None, None
+        aq = ActQ(ACTQ_CODE8, a_bits, 0, 0, None)
         dx = dw = db = None
         with torch.cuda.device_of(codes):
             if ctx.needs_input_grad[0]:
@@ -2253,6 +2281,9 @@ class BNReLUQ(Function):
         ctx.save_for_backward(src, chan, gamma, beta)
         ctx.cfg = (in_f32, N, Cc, H, W, qbits, int(bool(pool)), int(training), bool(out_bits))
         ctx.first, ctx.gram = (rec, holder[1]) if rec is not None else (None, None)
+        # the conv in front is a pointwise layer k_pwb covers: its backward forms this block's dy itself from (dq, stash) -- the apply pass and its fp32 dy disappear
+        ctx.pwb_fold = bool(lazy and not pool and FUSE_PW_BWD and LAZY_BN_GRAD and _lib_().mn_conv2d_bwd_bnh_supported(
+            C.byref(y.recipe["geom"]), C.byref(WQ(WQ_DOREFA, y.recipe["w_bits"], 0, 0, None)), 0))
 
         def materialize():
             act = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=dev)
@@ -2303,6 +2334,18 @@ class BNReLUQ(Function):
         with torch.cuda.device(dev):
             ws = torch.empty(int(_lib_().mn_qa_ws_floats(Cc)), dtype=torch.float32, device=dev)
             lazy_first = in_f32 == 1 and not pool and LAZY_BN_GRAD and FOLD_BN_INTO_CONV_BWD
+            if getattr(ctx, "pwb_fold", False) and dq.data_ptr() % 16 == 0:
+                with _span(None, 3, (2 if in_f32 == 0 else 4) * src.numel() + 4 * dq.numel()):
+                    _call("mn_qa_bwd_sums", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+
+                def expand_pw(r):
+                    dy_ = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+                    with torch.cuda.device(dev):
+                        _call("mn_qa_bwd_apply", r["kind_in"], _p(r["stash"]), _p(r["chan"]), _p(r["sums"]), _p(r["dq"]), N, Cc, H, W, r["bits"], 0, r["quant"], r["training"],
+                              _p(dy_), _s())
+                    return dy_
+                recipe = dict(kind="qa_pw", dq=dq, stash=src, kind_in=in_f32, chan=chan, sums=sums, bits=qbits, quant=quant, training=training)
+                return LazyBNGrad((N, Cc, H, W), dev, recipe, expand_pw), dgamma, dbeta, None, None, None, None, None, None, None, None
             if QA_BWD_TWO_LAUNCHES and not lazy_first:
                 # partial sums, then the apply pass whose blocks finish the sums themselves (mn_qa_bwd: one launch less per block, bit-identical)
                 dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)

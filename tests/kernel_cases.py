@@ -504,7 +504,7 @@ def _check_pwb(be, g, wq, d_da, h8, a8, chan, sums, training, dW, dA, dx_ref, dw
         ws, dx3, dw3, db3 = be.empty(nb // 4 + 4), be.empty(x_shape), be.empty(w_shape), be.empty(Oc)
         be.call("mn_conv2d_bwd_bnh", C.byref(g), C.byref(wq), be.ptr(d_da), be.ptr(h8), be.ptr(a8) if a8 is not None else None, be.ptr(chan), be.ptr(sums),
                 int(training), be.ptr(dW), be.ptr(dA), be.ptr(dx3), be.ptr(dw3), be.ptr(db3) if with_bias else None, be.ptr(ws), nb, be.stream)
-        assert be.lib.mn_last_kernel().decode() == ("k_pwb<2>" if a8 is not None else "k_pwb<1>")
+        assert be.lib.mn_last_kernel().decode() == ("k_pwb<2, 0, 0>" if a8 is not None else "k_pwb<1, 0, 0>")
         assert close(be.to_host(dx3), dx_ref, 5e-6), ("k_pwb dx", np.max(np.abs(be.to_host(dx3) - dx_ref)) / np.max(np.abs(dx_ref)))
         assert close(be.to_host(dw3), dw_ref, 5e-6), ("k_pwb dw", np.max(np.abs(be.to_host(dw3) - dw_ref)) / np.max(np.abs(dw_ref)))
         if with_bias:
@@ -1182,6 +1182,48 @@ def check_qconv_bnq(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, tra
     if bias:
         db_ref = gy.astype(np.float64).sum(axis=(0, 2, 3))
         assert np.max(np.abs(be.to_host(db) - db_ref)) <= 1e-5 * max(np.abs(gy).sum(axis=(0, 2, 3)).max(), 1e-30), "dbias"
+    # ---- both gradients in one launch (k_pwb): from the plain gradient, and -- un-pooled blocks -- with the block's backward formed from (dq, stash) inside
+    if be.lib.mn_conv2d_bwd_bnh_supported(C.byref(g), C.byref(wq), 0):
+        nb3 = int(be.lib.mn_conv2d_bwd_bnh_ws_bytes(C.byref(g)))
+        ws3, dx3, dw3, db3 = be.empty(nb3 // 4 + 8), be.empty(x_shape), be.empty(w_shape), (be.empty(Oc) if bias else None)
+        be.call("mn_conv2d_bwd_codes", C.byref(g), C.byref(wq), be.ptr(dGY), be.ptr(dW), be.ptr(dX), a_bits, be.ptr(dx3), be.ptr(dw3), be.ptr(db3), be.ptr(ws3), nb3, be.stream)
+        assert be.lib.mn_last_kernel().decode() == "k_pwb<0, 1, 0>"
+        assert close(be.to_host(dx3), dx_ref, 1e-5), ("k_pwb dx", float(np.max(np.abs(be.to_host(dx3) - dx_ref)) / np.max(np.abs(dx_ref))))
+        assert close(be.to_host(dw3), dw_ref, 1e-5), ("k_pwb dw", float(np.max(np.abs(be.to_host(dw3) - dw_ref)) / np.max(np.abs(dw_ref))))
+        if bias:
+            assert np.max(np.abs(be.to_host(db3) - db_ref)) <= 1e-5 * max(np.abs(gy).sum(axis=(0, 2, 3)).max(), 1e-30), "k_pwb dbias"
+        if not pooled:
+            # reference: the two-kernel path on the dy the apply pass wrote above
+            dx_t, dw_t, db_t = be.empty(x_shape), be.empty(w_shape), (be.empty(Oc) if bias else None)
+            be.call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), C.byref(wq), be.ptr(dy), be.ptr(dW), None, be.ptr(dx_t), be.ptr(ws1), nb1, 0, be.stream)
+            be.call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), be.ptr(dy), be.ptr(dX), be.ptr(dw_t), be.ptr(db_t), be.ptr(ws2), nb2, 0, be.stream)
+            dx4, dw4, db4 = be.empty(x_shape), be.empty(w_shape), (be.empty(Oc) if bias else None)
+            be.call("mn_conv2d_bwd_qa", C.byref(g), C.byref(wq), be.ptr(dDQ), be.ptr(stash), sbits, be.ptr(chan), be.ptr(sums), out_bits, int(quant), int(training),
+                    be.ptr(dW), be.ptr(dX), a_bits, be.ptr(dx4), be.ptr(dw4), be.ptr(db4), be.ptr(ws3), nb3, be.stream)
+            assert be.lib.mn_last_kernel().decode() == "k_pwb<3, 1, %d>" % (1 if sbits == 32 else 0)
+            assert close(be.to_host(dx4), be.to_host(dx_t), 5e-6), ("k_pwb<3> dx", float(np.max(np.abs(be.to_host(dx4) - be.to_host(dx_t))) / np.max(np.abs(be.to_host(dx_t)))))
+            assert close(be.to_host(dw4), be.to_host(dw_t), 5e-6), ("k_pwb<3> dw", float(np.max(np.abs(be.to_host(dw4) - be.to_host(dw_t))) / np.max(np.abs(be.to_host(dw_t)))))
+            if bias:
+                sc_db = max(np.max(np.abs(be.to_host(dy))) * 1e-4, 1e-30)      # d bias in front of a BatchNorm is a sum that cancels to ~0
+                assert np.max(np.abs(be.to_host(db4) - be.to_host(db_t))) <= sc_db * N * H * W, "k_pwb<3> dbias"
+        check_qconv_bnq.pwb_checked = getattr(check_qconv_bnq, "pwb_checked", 0) + 1
+
+
+# k-bit blocks on the geometries k_pwb covers (groups of 128 -> 128 channels): 16-bit and 32-bit stash, pooled (plain-gradient form only), eval mode, no quantizer behind
+PWB_BNQ_CASES = [
+    dict(x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2),
+    dict(x_shape=(2, 128, 8, 8), w_shape=(128, 128, 1, 1), bias=False, training=False),
+    dict(x_shape=(2, 256, 8, 8), w_shape=(256, 128, 1, 1), groups=2, pooled=True),
+    dict(x_shape=(3, 256, 4, 8), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2, a_bits=8, w_bits=8),
+    dict(x_shape=(5, 128, 4, 8), w_shape=(128, 128, 1, 1), quant=0, a_bits=4, w_bits=4, out_bits=3),
+]
+
+
+def check_pwb_bnq(be):
+    before = getattr(check_qconv_bnq, "pwb_checked", 0)
+    for i, case in enumerate(PWB_BNQ_CASES):
+        check_qconv_bnq(be, seed=440 + i, **case)
+    assert getattr(check_qconv_bnq, "pwb_checked", 0) - before == len(PWB_BNQ_CASES), "k_pwb did not take these geometries"
 
 
 BNQ_CASES = [

@@ -468,6 +468,16 @@ def test_pointwise_block_backward_in_one_kernel(be):
     assert getattr(K._check_pwb, "count", 0) - before == 5
 
 
+def test_kbit_block_backward_in_one_kernel(be):
+    """mn_conv2d_bwd_codes / mn_conv2d_bwd_qa: the emulated run's cases + nin_gc's DoReFa layers L2 (W2A2, 16-bit stash), L5 (W8A8, 32-bit stash) and L3 (pooled) at batch 8."""
+    K.check_pwb_bnq(be)
+    before = getattr(K.check_qconv_bnq, "pwb_checked", 0)
+    K.check_qconv_bnq(be, seed=450, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2)
+    K.check_qconv_bnq(be, seed=451, x_shape=(8, 512, 16, 16), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=16, a_bits=8, w_bits=8)
+    K.check_qconv_bnq(be, seed=452, x_shape=(8, 256, 32, 32), w_shape=(256, 128, 1, 1), groups=2, in_shuffle=2, pooled=True)
+    assert getattr(K.check_qconv_bnq, "pwb_checked", 0) - before == 3
+
+
 # stashed block around a 3 x 3 convolution: h written by the k x k kernel, statistics / sign streamed from h (k_h_stats, k_h_sign)
 KXK_STASH_CASES = [
     dict(x_shape=(3, 32, 8, 8), w_shape=(64, 16, 3, 3), padding=1, groups=2),                    # the nin_gc L7 pattern

@@ -317,6 +317,12 @@ def test_pointwise_block_backward_in_one_kernel(be):
     K.check_pwb(be)
 
 
+def test_kbit_block_backward_in_one_kernel(be):
+    """mn_conv2d_bwd_codes / mn_conv2d_bwd_qa (k_pwb on k-bit activation codes): both gradients of a DoReFa block in one launch, from the plain gradient and with
+    the BatchNorm + ReLU + quantizer backward formed from (dq, stash) inside, against the two-kernel path."""
+    K.check_pwb_bnq(be)
+
+
 def test_conv_backward_with_bn_folded_in(be):
     """mn_conv2d_bwd_data_bnh / mn_conv2d_bwd_weight_bnh (dy formed in registers from (da, h)) on shapes the direct kernels cover."""
     K.check_qconv_bnsign(be, seed=250, stash=True, x_shape=(2, 128, 4, 8), w_shape=(128, 64, 1, 1), groups=2)
