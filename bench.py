@@ -313,6 +313,28 @@ def dp_single_rank(workloads, args, device):
     return out
 
 
+def _grad_terms():
+    from micronet_amd import _lib
+    return int(_lib.get_lib().mn_dense_grad_terms())
+
+
+def exact_terms_leg(workloads, args):
+    """The ResNet workloads again with the EXACT three-term bf16 split of the fp32 gradient in the dense backward kernels (MN_GRAD_TERMS=3; the library reads the knob
+    once per process: a child per workload): {workload: {"value", "ms_per_step", "grad_terms": 3}} -- reported beside the default two-term figures."""
+    out = {}
+    for w in workloads:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--only", w, "--batch", str(args.batch), "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--repeats", str(max(1, min(3, args.repeats))), "--no-pmc", "--no-cpu-baseline", "--no-kernel-timing", "--no-dp-single", "--detail", "/tmp/mn_terms3_%s.json" % w]
+        try:
+            r = subprocess.run(cmd, env=dict(os.environ, MN_GRAD_TERMS="3"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+            line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            assert line["config"]["grad_terms"]["dense_kernels"] == 3
+            out[w] = {"value": line["value"], "ms_per_step": line["ms_per_step"], "grad_terms": 3}
+        except Exception as e:          # noqa: BLE001 -- a reported extra
+            out[w] = {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
+    return out
+
+
 def section(workload, m, args, world, pmc):
     """value / ms_per_step / roofline / kernels / step_level of one measured workload."""
     arch = WORKLOADS[workload][0]
@@ -324,6 +346,7 @@ def section(workload, m, args, world, pmc):
     if m["graph_err"]:
         out["hip_graph_error"] = m["graph_err"]
     out["stock_fallbacks"] = m.get("fallbacks") or {}
+    out["grad_terms"] = _grad_terms() if arch.startswith("resnet") else 3
     if m.get("eager_dp"):
         out["eager_dp_value"] = round(args.batch * world * args.steps / m["eager_dp"], 1)
     if m.get("segments"):
@@ -337,7 +360,9 @@ def section(workload, m, args, world, pmc):
         p = (pmc or {}).get(workload, {}).get(dom, {})
         # a dense-conv kernel (qgemm_dense.hip) whose matrix-core time bound exceeds its HBM time bound is priced against the bf16 MFMA peak:
         # achieved = ALGORITHMIC flops (2 x MACs; the backward kernels issue 3 bf16 term passes per algorithmic flop) / HIP-event duration
-        terms = 3.0 if ("dgrad" in dom or "wgrad" in dom) else 1.0         # bf16 term passes the matrix cores execute per algorithmic flop (fp32 gy = 3 exact bf16 terms)
+        # bf16 term passes the matrix cores execute per algorithmic flop: the backward kernels split the fp32 gradient -- the dense (ResNet) kernels into
+        # mn_dense_grad_terms() terms (2 by default, 3 under MN_GRAD_TERMS=3), every other kernel into the exact three
+        terms = (float(_grad_terms()) if dom.startswith("k_qd_") else 3.0) if ("dgrad" in dom or "wgrad" in dom or dom.startswith("k_pwb")) else 1.0
         peak_tf = INT8_MFMA_PEAK_TOPS if "fwd8" in dom else BF16_MFMA_PEAK_TFLOPS     # the int8 code-domain forward is priced against the int8 peak
         mfma_bound = d.get("flops", 0.0) > 0 and terms * d["flops"] / (peak_tf * 1e12) > d["bytes"] / (HBM_PEAK_GBS * 1e9)
         if mfma_bound:
@@ -500,7 +525,10 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
                    "quant_layer_fallbacks": sum(sec.get("stock_fallbacks", {}).values()) + sum(sum(s_.get("stock_fallbacks", {}).values()) for s_ in also_secs.values()),
                    # launches per EAGER step of kernels that are NOT this library's (MIOpen BatchNorm of the un-quantised tail, loss, ATen fills / copies / counters),
                    # counted in the PMC passes (null without them); the graph-replayed step's own count is in profiles/r05_<w>_summary.md
-                   "stock_kernels_per_eager_step": sec.get("step_level", {}).get("stock_kernel_launches_per_step")},
+                   "stock_kernels_per_eager_step": sec.get("step_level", {}).get("stock_kernel_launches_per_step"),
+                   # bf16 terms carrying the fp32 gradient operand through the matrix cores: the nin_gc kernels use the exact three; the dense (ResNet: c4, c5) backward
+                   # kernels mn_dense_grad_terms() -- 2 by default (|error| <= 2^-18 |g| per element), 3 under MN_GRAD_TERMS=3; `values_exact_terms` has the 3-term figures
+                   "grad_terms": {"nin_gc_kernels": 3, "dense_kernels": _grad_terms()}},
     }
     out["ms_per_step_min"], out["value_best_window"], out["repeats"], out["window_ms"] = sec["ms_per_step_min"], sec["value_best_window"], sec["repeats"], sec["window_ms"]
     if dist_info:
@@ -664,6 +692,11 @@ def main():
     if world == 1 and not args.only and not args.no_kernel_timing and not args.no_dp_single:
         dp1 = dp_single_rank([w for w in (primary, "c3", "c4", "c5") if w == primary or w in m_also], args, device)
 
+    terms3 = None
+    if world == 1 and not args.only and not args.no_kernel_timing and _grad_terms() != 3:
+        torch.cuda.synchronize()
+        terms3 = exact_terms_leg([w for w in ("c4", "c5") if w in m_also], args)
+
     pmc, pmc_err = None, None
     if world == 1 and rank == 0 and not args.no_pmc and not args.no_kernel_timing:
         torch.cuda.synchronize()
@@ -679,6 +712,10 @@ def main():
         cpu = cpu_baseline(primary, args.cpu_batch, args.cpu_steps, args.cpu_threads, args.cpu_kind) if (world == 1 and not args.no_cpu_baseline) else None
         cpu_more = cpu_more_legs(args, primary) if (world == 1 and not args.no_cpu_baseline and not args.only) else None
         out, detail = compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, dist_info, cpu_more, dp1)
+        if terms3:
+            detail["values_exact_terms"] = terms3
+            if len(json.dumps(out)) + len(json.dumps(terms3)) + 32 <= MAX_LINE_BYTES:
+                out["values_exact_terms"] = {w: v.get("value", v.get("error")) for w, v in terms3.items()}
         out["detail_file"] = write_detail(detail, args)
     if world > 1:
         if rank != 0:

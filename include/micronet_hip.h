@@ -56,6 +56,10 @@ void mn_profile_enable(int on);
 int mn_profile_collect(mn_prof_entry* out, int cap);
 /* 1 if the library was built as the CPU SIMT emulation used by the unit tests, 0 for the gfx950 build */
 int mn_is_emulation(void);
+/* bf16 terms the dense (ResNet-family) backward kernels carry the fp32 gradient operand in: 2 (default: hi = rne(g), lo = rne(g - hi), |error| <= 2^-18 |g|) or 3
+ * (MN_GRAD_TERMS=3 in the environment: the exact truncation split).  The nin_gc kernels (pointwise, grouped 3x3, first block) always use the exact three terms.
+ * bench.py reports it (config.grad_terms) and prices the matrix-core passes with it. */
+int mn_dense_grad_terms(void);
 
 /* ------------------------------------------------------------------ DoReFa
  * wqaq/dorefa/quantize.py */

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "mn_profile_enable": (None, [_I]),
     "mn_profile_collect": (_I, [C.POINTER(ProfEntry), _I]),
     "mn_is_emulation": (_I, []),
+    "mn_dense_grad_terms": (_I, []),
     "mn_round_half_away": (_I, [_P, _P, _L, _P]),
     "mn_dorefa_act_fwd": (_I, [_P, _P, _L, _I, _P]),
     "mn_dorefa_act_bwd": (_I, [_P, _P, _P, _L, _I, _P]),

@@ -13,10 +13,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libmicronet_hip.so")
 SOURCES = ["quant_kernels.hip", "conv_kernels.hip", "qgemm_kernels.hip", "qgemm_kxk.hip", "qgemm_sign.hip", "qgemm_pwb.hip", "qgemm_k3s.hip", "qgemm_dense.hip", "conv_first.hip", "optim_kernels.hip", "norm_kernels.hip", "iao_ops.hip", "qact_kernels.hip", "data_kernels.hip", "linear_kernels.hip", "iao_bnfuse.hip", "iao_g3.hip", "iao_thin.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc"]
-# qgemm_sign.hip: the SLP vectoriser pairs fp32 operations of DIFFERENT staged rows into v_pk_* instructions and pays for it with register shuffles on
-# the loop back edge, each behind a wait for the prefetched loads (the software pipeline of k_pws_wgrad_s drained every iteration)
-EXTRA_FLAGS = {"qgemm_sign.hip": ["-fno-slp-vectorize"], "qgemm_pwb.hip": ["-fno-slp-vectorize"], "qgemm_kxk.hip": ["-fno-slp-vectorize"]}      # k x k: -3 % on the resnet18 step (A/B)
+# -fno-slp-vectorize: the SLP vectoriser pairs fp32 operations of DIFFERENT staged rows into v_pk_* instructions and pays for it with register shuffles on the loop
+# back edge, each behind a wait for the prefetched loads -- the software pipelines of k_pws_wgrad_s (round 3) and k_pwb (round 6: vmcnt(2) instead of vmcnt(27) in
+# every step) drained every iteration.  Round 6 A/B of the whole library with and without it: c3 55.6k -> 58.3k img/s (k_pw_wgrad<4,4,2,2> 531 -> 439 us per step,
+# k_bf_gram<4,0> 402 -> 287), c2 +0.9 %, c1_w2a2 / c4 / c5 unchanged: every file is built without it.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize"]
+EXTRA_FLAGS = {}
 
 
 def _stale():

@@ -122,6 +122,7 @@ void mn_prof_end(hipStream_t s) {
     g_prof_ev[0] = g_prof_ev[1] = nullptr;
 }
 extern "C" int mn_version(void) { return 100; }
+extern "C" int mn_dense_grad_terms(void) { return mn_grad_terms(); }
 extern "C" int mn_is_emulation(void) {
 #ifdef MN_EMULATION
     return 1;

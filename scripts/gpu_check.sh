@@ -2,7 +2,7 @@
 # The one parameterised GPU-box runner (run through scripts/grun.sh or gpurun directly, from the repo root):
 #   bash scripts/gpu_check.sh [tests|parity|bench|prof]...      (default: tests bench)
 #   tests  : pytest -m gpu (whole suite)            -> gpurun_out/pytest_gpu.log
-#   parity : only tests/test_gpu_parity_full.py      -> gpurun_out/parity_r05/
+#   parity : only tests/test_gpu_parity_full.py      -> gpurun_out/parity_r06/
 #   bench  : smoke + bench.py (default workloads)    -> gpurun_out/bench.json
 #   prof   : rocprofv3 --kernel-trace --stats of bench.py per workload -> gpurun_out/prof_<w>/
 #   (PMC traffic / MFMA-busy: bench.py collects them itself -- roofline.traffic, gpurun_out/bench_detail.json)

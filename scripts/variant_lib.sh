@@ -6,8 +6,7 @@ cd "$(dirname "$0")/.."
 L=micronet_amd/lib
 tag=$1; src=$2; shift 2
 base=${src%.hip}
-extra=""
-if { [ $src = qgemm_sign.hip ] || [ $src = qgemm_pwb.hip ] || [ $src = qgemm_kxk.hip ]; } && [ -z "$MN_VARIANT_SLP" ]; then extra="-fno-slp-vectorize"; fi     # as micronet_amd/build.py EXTRA_FLAGS
+extra="-fno-slp-vectorize"; [ -n "$MN_VARIANT_SLP" ] && extra=""          # as micronet_amd/build.py FLAGS
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc $extra "$@" -c micronet_amd/csrc/$src -o $L/${base}_$tag.o
 objs=""
 for f in $(python -c "from micronet_amd.build import SOURCES; print(' '.join(s[:-4] for s in SOURCES))"); do          # (every object of the library: micronet_amd/build.py)

@@ -681,6 +681,16 @@ def test_qdense_resnet18_shapes(be, xs, Oc, k, s):
     K.check_qdense(be, xs, Oc, k, s, seed=hash((xs, Oc, k, s)) % 1000)
 
 
+def test_qdense_hot_shapes_with_exact_three_term_gradient():
+    """MN_GRAD_TERMS=3: the exact three-term bf16 split of the fp32 gradient in the dense backward kernels (the default since round 5 is the two-term split), on the
+    resnet18 shapes that dominate the c4 / c5 steps -- a child process, because the library reads its knobs once."""
+    body = ("assert be.lib.mn_dense_grad_terms() == 3; "
+            "K.check_qdense(be, (37, 64, 32, 32), 64, 3, 1, seed=701); K.check_qdense(be, (37, 128, 16, 16), 128, 3, 1, seed=702); "
+            "K.check_qdense(be, (37, 64, 32, 32), 128, 3, 2, seed=703); K.check_qdense(be, (37, 64, 32, 32), 128, 1, 2, seed=704); "
+            "K.check_qdense(be, (37, 256, 8, 8), 256, 3, 1, seed=705, prepack=True)")
+    K.run_child(body, "gpu", {"MN_GRAD_TERMS": "3"}, 900)
+
+
 @pytest.mark.parametrize("in_kind,res_kind", [(0, 1), (0, 2), (2, 3), (1, 1), (0, 0), (2, 1), (0, 3), (2, 2)])
 @pytest.mark.parametrize("training", [True, False])
 def test_residual_block_end(be, in_kind, res_kind, training):

@@ -14,7 +14,7 @@ here against an fp64 evaluation of the SAME oracle stage and recorded next to th
   * gradients that are heavily cancelling sums (d weight behind a BatchNorm, whose incoming gradient sums to zero per channel):
     ours must be within 1e-5 of the fp64 value OR at least as close to it as the reference's own fp32 result;
   * sign outputs: equal everywhere except where the oracle's own BatchNorm output is within 2e-6 of zero (a tie).
-Every worst error is written to ``gpurun_out/parity_r05.json`` (copied to ``profiles/`` for the round's record)."""
+Every worst error is written to ``gpurun_out/parity_r06.json`` (copied to ``profiles/`` for the round's record)."""
 import copy
 import importlib
 import json
@@ -41,9 +41,9 @@ SEGMENTS_SINGLE = [[i] for i in range(12)]
 
 
 def _record(path, key, value):
-    """One file per config under gpurun_out/parity_r05/ (a later subset run on a fresh GPU box can then never overwrite another config's record: VERDICT r4 weak 1);
-    scripts/merge_parity.py folds them into profiles/parity_r05.json."""
-    d = os.path.join(os.path.dirname(path), "parity_r05")
+    """One file per config under gpurun_out/parity_r06/ (a later subset run on a fresh GPU box can then never overwrite another config's record: VERDICT r4 weak 1);
+    scripts/merge_parity.py folds them into profiles/parity_r06.json."""
+    d = os.path.join(os.path.dirname(path), "parity_r06")
     os.makedirs(d, exist_ok=True)
     json.dump({key: value}, open(os.path.join(d, "%s.json" % key.replace("/", "_").replace(" ", "_")), "w"), indent=1, sort_keys=True)
 
@@ -421,6 +421,6 @@ def test_full_batch_teacher_forced(key):
     report["_oracle_loss0"] = loss0
     report["_batch"] = BATCH
     report["_failures"] = [list(map(str, f)) for f in failures]
-    _record(os.path.join(ROOT, "gpurun_out", "parity_r05.json"), key, report)
+    _record(os.path.join(ROOT, "gpurun_out", "parity_r06.json"), key, report)
     print(key, "worst rel err over all stages:", worst)
     assert not failures, (key, failures, report)

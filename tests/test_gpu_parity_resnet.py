@@ -13,7 +13,7 @@ whole gradient term with it.  The incoming gradient is zeroed at those positions
 back-propagate through identical decisions; the fraction of masked positions is recorded (it is ~1e-5).
 Tolerance: 1e-5 relative (max-norm) on every float result; integer codes: flips only at rounding ties (fraction <= 1e-5).  d weight of a DoReFa conv: the single
 arg-max |w| element carries a cancelling sum over the whole tensor (see tests/test_gpu_parity_full.py) and is judged against an fp64 evaluation.
-Results: ``gpurun_out/parity_r05.json`` (copied to ``profiles/``)."""
+Results: ``gpurun_out/parity_r06/`` (merged into ``profiles/parity_r06.json``), once per gradient-term setting (MN_GRAD_TERMS unset = 2, or 3)."""
 import copy
 import importlib
 import json
@@ -32,11 +32,21 @@ RES = {
 }
 
 
+def _grad_terms():
+    """bf16 terms the dense backward kernels carry the fp32 gradient in: 2 (default) or 3 (MN_GRAD_TERMS=3, the exact split) -- micronet_amd/csrc/common.h:mn_grad_terms"""
+    e = os.environ.get("MN_GRAD_TERMS") or os.environ.get("MN_QD_TERMS") or ""
+    return 3 if e[:1] == "3" else 2
+
+
 def _record(path, key, value):
-    """One file per config under gpurun_out/parity_r05/ (a later subset run on a fresh GPU box can then never overwrite another config's record: VERDICT r4 weak 1);
-    scripts/merge_parity.py folds them into profiles/parity_r05.json."""
-    d = os.path.join(os.path.dirname(path), "parity_r05")
+    """One file per config AND gradient-term setting under gpurun_out/parity_r06/ (a later subset run on a fresh GPU box can then never overwrite another config's
+    record); scripts/merge_parity.py folds them into profiles/parity_r06.json.  The default (two-term) run keeps the plain key, MN_GRAD_TERMS=3 adds "_terms3"."""
+    d = os.path.join(os.path.dirname(path), "parity_r06")
     os.makedirs(d, exist_ok=True)
+    if _grad_terms() == 3:
+        key = key + "_terms3"
+    if isinstance(value, dict):
+        value = dict(value, _grad_terms=_grad_terms())
     json.dump({key: value}, open(os.path.join(d, "%s.json" % key.replace("/", "_").replace(" ", "_")), "w"), indent=1, sort_keys=True)
 
 
@@ -239,8 +249,19 @@ def test_full_batch_teacher_forced_resnet(key):
             xi = r["in"].clone().requires_grad_(True)
             st(xi).backward(r["gout"])
             check(name, errs, "dx", _rel(leaf.grad, xi.grad))
+            st64 = copy.deepcopy(ost).double().train()
+            st64(r["in"].double()).backward(r["gout"].double())
+            g64s = {pn_: p.grad for pn_, p in st64.named_parameters()}
             for pn_, p in st.named_parameters():
-                check(name, errs, "d" + pn_, _rel(dict(pst.named_parameters())[pn_].grad, p.grad), 2e-5 if pn_ == "weight" else 1e-5)
+                g = dict(pst.named_parameters())[pn_].grad
+                if pn_ == "weight":          # against the fp64 evaluation, next to the reference's own fp32 result against it
+                    sc = g64s[pn_].abs().max().clamp_min(1e-300)
+                    e_ours, e_ref = float((g.double().cpu() - g64s[pn_]).abs().max() / sc), float((p.grad.double() - g64s[pn_]).abs().max() / sc)
+                    errs["d" + pn_ + "_vs_reference_fp32"] = _rel(g, p.grad)
+                    errs["d" + pn_ + "_reference_fp32_vs_fp64"] = e_ref
+                    check(name, errs, "d" + pn_ + "_vs_fp64", e_ours, max(1e-5, 2.0 * e_ref))
+                else:
+                    check(name, errs, "d" + pn_, _rel(g, p.grad))
         else:
             # ---- a residual block
             assert type(pst).__name__.startswith("Fused"), "prepare() did not fuse %s" % name
@@ -282,7 +303,7 @@ def test_full_batch_teacher_forced_resnet(key):
             check_pgrads(name, errs, pst, pg_ref, ost, r["in"], r["gout"], keep_out, keep_mid)
         report[name] = {k: float("%.2e" % v) for k, v in errs.items()}
     report["_oracle_loss0"], report["_batch"], report["_failures"] = loss0, BATCH, [list(map(str, f)) for f in failures]
-    _record(os.path.join(ROOT, "gpurun_out", "parity_r05.json"), key, report)
+    _record(os.path.join(ROOT, "gpurun_out", "parity_r06.json"), key, report)
     print(key, "worst rel err over all stages:", worst)
     assert not failures, (key, failures, report)
 
@@ -534,10 +555,29 @@ def test_full_batch_teacher_forced_resnet_iao(key):
             chk("dx_p9999", float(d.flatten().kthvalue(kth).values))
             if errs_["dx_outliers"] > 16:
                 fails_.append((n + ":whole", "dx outliers beyond the reach of the input's top-element tie", errs_["dx_outliers"]))
+            # parameter gradients: against the fp64 evaluation of the same oracle block (same masks), with the reference's own fp32 result against it alongside --
+            # ours must be within 1e-5 of fp64, or as close to it as twice the reference's own fp32 rounding
+            ob64 = copy.deepcopy(ob).double().train()
+            h64 = [_mask_grad(ob64.residual_function[2], k_mid, False), _mask_grad(ob64.residual_function[4], k_zb, False)]
+            if has_sc:
+                h64.append(_mask_grad(ob64.shortcut[1], k_zs, False))
+            x64 = x_in.double().clone().requires_grad_(True)
+            ob64(x64).backward((gout * k_t).double())
+            for h_ in h64:
+                h_.remove()
+            g64s = {name: p_.grad for name, p_ in ob64.named_parameters() if p_.grad is not None}
             pn2 = dict(pb2.named_parameters())
             for name, p_ in ob2.named_parameters():
                 if p_.grad is not None and name in pn2 and pn2[name].grad is not None:
-                    chk("d" + name, _rel(pn2[name].grad, p_.grad), 2e-5)
+                    errs_["d" + name + "_vs_reference_fp32"] = _rel(pn2[name].grad, p_.grad)
+                    if name in g64s:
+                        sc = g64s[name].abs().max().clamp_min(1e-300)
+                        e_ours = float((pn2[name].grad.double().cpu() - g64s[name]).abs().max() / sc)
+                        e_ref = float((p_.grad.double() - g64s[name]).abs().max() / sc)
+                        errs_["d" + name + "_reference_fp32_vs_fp64"] = e_ref
+                        chk("d" + name, e_ours, max(1e-5, 2.0 * e_ref))
+                    else:
+                        chk("d" + name, errs_["d" + name + "_vs_reference_fp32"])
             return errs_, fails_, False
 
         errs, flipped_attempts = {}, []
@@ -563,6 +603,6 @@ def test_full_batch_teacher_forced_resnet_iao(key):
     run_piece("tail", errs, [pristine.avg_pool, pristine.fc], [prod.avg_pool, prod.fc], [rec["avg_pool"]["in"]], rec["fc"]["gout"], False, combine=comb)
     report["tail"] = {k: float("%.2e" % v) for k, v in errs.items()}
     report["_oracle_loss0"], report["_batch"], report["_failures"] = loss0, BATCH, [list(map(str, f)) for f in failures]
-    _record(os.path.join(ROOT, "gpurun_out", "parity_r05.json"), key, report)
+    _record(os.path.join(ROOT, "gpurun_out", "parity_r06.json"), key, report)
     print(key, "worst rel err over all stages:", worst)
     assert not failures, (key, failures, report)
