@@ -147,7 +147,16 @@ __device__ __forceinline__ unsigned mn_rne_bf16x2(float lo_elem, float hi_elem) 
 #endif
 // How many bf16 terms carry an fp32 gradient operand through the matrix cores: 3 = exact (truncation split), 2 (default since round 5) = the split below.
 // MN_GRAD_TERMS=3 (or the older MN_QD_TERMS=3) restores the exact split everywhere.
-static inline int mn_grad_terms() { const char* e = MN_ENV("MN_GRAD_TERMS"); if (!e) e = MN_ENV("MN_QD_TERMS"); return (e && e[0] == '3') ? 3 : 2; }
+static inline int mn_grad_terms() { const char* e = MN_ENV("MN_GRAD_TERMS"); return (e && e[0] == '3') ? 3 : 2; }
+// The few A/B knobs that stay (each is exercised by a test or by bench.py; the tuning knobs of rounds 1-5 are gone, their findings are in profiles/README.md):
+//   MN_GRAD_TERMS=3    the exact three-term split in the dense backward kernels (tests/test_gpu_kernels.py, bench.py values_exact_terms)
+//   MN_HSIGN_FOLD=0    the per-channel constants of the sign pass from a launch of their own (tests/test_kernels_emulated.py)
+//   MN_QA_IEEE_DIV=1   the IEEE division in the DoReFa clip-STE instead of Markstein's correctly rounded quotient (bit-identical: tests/kernel_cases.py)
+//   MN_QA_NO_INTERVAL=1  element-wise ReLU / clamp masks instead of the per-channel interval (bit-identical)
+//   MN_NO_PACKED_PW=1  every conv call packs its own weight codes instead of reading the step's pre-packed image (bit-identical: check_qg_pack_multi)
+static inline float mn_qa_inv(float s) { return (s > 0.f && !MN_ENV("MN_QA_IEEE_DIV")) ? 1.0f / s : 0.f; }          // RN(1 / s) of the division-free clip-STE; 0 selects the IEEE form
+static inline int mn_qa_interval() { return MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1; }
+static inline bool mn_use_packed() { return !MN_ENV("MN_NO_PACKED_PW"); }
 // the two term words of a pair of floats: hi = rne pair, lo = rne pair of the remainders
 __device__ __forceinline__ void mn_split2_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
     hi = mn_rne_bf16x2(a, b);

@@ -847,7 +847,6 @@ static int plan_c1(const mn_conv_geom* g, C1Plan* pl, int which = 0) {
     // strips: the forward likes one block slot per (image, strip) -- 512 = 2 per CU; the backward-weight one tile per block (measured on L1:
     // forward 131 -> 123 us, backward-weight 141 -> 128 us against 1024 blocks)
     int64_t want_blocks = which == 2 ? 256 : 512;
-    if (const char* e = MN_ENV("MN_C1_BLOCKS")) { const int v = atoi(e); if (v >= 1) want_blocks = v; }     // tuning knob
     while (R % 2 == 0 && ((R / 2) * g->W) % 64 == 0 && (int64_t)g->N * (g->H / R) * pl->cblks < want_blocks) R /= 2;
     if ((R * g->W) % 32) return 0;
     p.R = R; p.strips = g->H / R;
@@ -923,9 +922,8 @@ int c1_fwd_act(const mn_conv_geom* g, const float* x, const float* w, const floa
     C1Params& p = pl.p;
     p.x = x; p.bias = bias; p.y = y; p.gy = nullptr; p.part = nullptr; p.dbpart = nullptr; p.want_db = 0; p.da = nullptr;
     p.relu = relu; p.mm = mm; p.codes = nullptr; p.mask4 = nullptr;
-    static const bool f32_path = MN_ENV("MN_C1_F32") != nullptr;          // A/B knob: the fp32-MFMA forward
     const size_t lds_b = c1b_lds_bytes(p);
-    if (!f32_path && lds_b <= 80 * 1024) {          // three-term bf16 forward (reads the weights as they are: no pack launch)
+    if (lds_b <= 80 * 1024) {          // three-term bf16 forward (reads the weights as they are: no pack launch)
         p.wp = w;
         mn_set_last_kernel("k_c1b_fwd<%d>", pl.MT);
         mn_prof_begin(s);
@@ -1005,7 +1003,7 @@ static int c1_bwd_weight_any(const mn_conv_geom* g, const float* gy, const float
     p.wp = nullptr; p.bias = nullptr; p.y = nullptr;
     p.da = gy ? nullptr : da; p.yb = yb; p.save = save; p.gamma = gamma; p.beta = beta; p.sums = sums; p.training = training;
     p.n_f = (float)g->N * (float)(g->H * g->W);
-    p.chan = gy ? nullptr : chan; p.quant = quant; p.qs = qs; p.qs_inv = (qs > 0.f && !MN_ENV("MN_QA_IEEE_DIV")) ? 1.0f / qs : 0.f; p.interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
+    p.chan = gy ? nullptr : chan; p.quant = quant; p.qs = qs; p.qs_inv = mn_qa_inv(qs); p.interval = mn_qa_interval();
     mn_set_last_kernel("k_c1_wgrad<%d, %d>", pl.MT, p.da ? (p.chan ? 2 : 1) : 0);
     { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((p.da ? 8.0 : 4.0) * ny + 4.0 * g->N * g->C * g->H * g->W); }
     mn_prof_begin(s);
@@ -1073,7 +1071,7 @@ static int c1_bwd_first_any(const mn_conv_geom* g, const float* da, const float*
     p.wp = nullptr; p.bias = nullptr; p.y = nullptr;
     p.da = da; p.yb = yb; p.save = save; p.gamma = gamma; p.beta = beta; p.sums = nullptr; p.training = 0;          // (k1, k2 of the fold are not used: DZ)
     p.n_f = (float)g->N * (float)(g->H * g->W);
-    p.chan = chan; p.quant = quant; p.qs = qs; p.qs_inv = (qs > 0.f && !MN_ENV("MN_QA_IEEE_DIV")) ? 1.0f / qs : 0.f; p.interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
+    p.chan = chan; p.quant = quant; p.qs = qs; p.qs_inv = mn_qa_inv(qs); p.interval = mn_qa_interval();
     p.mask4 = const_cast<uint8_t*>(mask4); p.mask_shift = (mask4 && quant) ? 4 : 0;
     mn_set_last_kernel("k_c1_wgrad<%d, %d, 1>", pl.MT, mask4 ? 3 : (chan ? 2 : 1));
     { const double ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((mask4 ? 4.25 : 8.0) * ny + 4.0 * g->N * g->C * g->H * g->W); }

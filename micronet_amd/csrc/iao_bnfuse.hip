@@ -289,7 +289,6 @@ static int plan_gram(const mn_conv_geom* g, GramPlan* pl) {
     p.fd_hw = make_fastdiv((uint32_t)HW);
     // every fp32 accumulator sums <= 32 slabs (2048 pixels); about two blocks per CU; a partial tile costs CP * CP * 4 bytes written + read back
     int Z = 512 / p.G;
-    if (const char* e = MN_ENV("MN_GRAM_BLOCKS")) { const int v = atoi(e); if (v >= 64 && v <= 4096) Z = v / p.G > 0 ? v / p.G : 1; }          // tuning knob (A/B runs)
     if (Z > (p.nchunks + 7) / 8) Z = (p.nchunks + 7) / 8;
     if (Z < (p.nchunks + 31) / 32) Z = (p.nchunks + 31) / 32;
     if (Z < 1) Z = 1;

@@ -461,7 +461,6 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
     const int S = bns_split(g);
     const double nel = (double)N * C * HW;
     BnsFin fin = {};
-    const bool fold = !MN_ENV("MN_BNS_NO_FOLD");          // A/B knob: the separate k_bns_final_* launches
     if (stats_given) {
         // save = {mean, invstd} is the caller's (mn_conv2d_first_gram_bnstats): the apply pass alone
     } else if (training) {
@@ -469,8 +468,7 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
         hipLaunchKernelGGL(k_bns_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (double*)ws);
         mn_prof_end(s);
-        if (fold) { fin.part = (const double*)ws; fin.S = S; fin.eps = eps; fin.momentum = momentum; fin.running_mean = running_mean; fin.running_var = running_var; fin.save_out = save; }
-        else hipLaunchKernelGGL(k_bns_final_fwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, y, (const double*)ws, S, eps, momentum, running_mean, running_var, save);
+        fin.part = (const double*)ws; fin.S = S; fin.eps = eps; fin.momentum = momentum; fin.running_mean = running_mean; fin.running_var = running_var; fin.save_out = save;
     } else {
         hipLaunchKernelGGL(k_bns_eval_stats, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (int)C, eps, (const float*)running_mean, (const float*)running_var, save);
     }
@@ -615,8 +613,7 @@ static int bnsign_bwd_impl(const float* da, const float* y, const float* save, c
     hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws);
     mn_prof_end(s);
     BnsFin fin = {};
-    if (!MN_ENV("MN_BNS_NO_FOLD")) { fin.part = (const double*)ws; fin.S = S; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.sums_out = sums; }
-    else hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
+    fin.part = (const double*)ws; fin.S = S; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.sums_out = sums;
     mn_set_last_kernel("k_bns_apply<1, 0>"); mn_prof_bytes(12.0 * nel); mn_prof_begin(s);
     hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy, (float*)nullptr, fin);
     mn_prof_end(s);
@@ -964,7 +961,7 @@ extern "C" int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* 
     const int S = bnh_split(g);
     const double nel = (double)N * C * H * W;
     // pooled fast path: W % 8 == 0, 8-byte aligned rows
-    const bool pool_fast = own && W % 8 == 0 && !(((uintptr_t)h) & 7) && !(((uintptr_t)own) & 7) && !(((uintptr_t)da) & 15) && !MN_ENV("MN_NO_BNH_POOLFAST");
+    const bool pool_fast = own && W % 8 == 0 && !(((uintptr_t)h) & 7) && !(((uintptr_t)own) & 7) && !(((uintptr_t)da) & 15);
     mn_set_last_kernel(pool_fast ? "k_bnh_partial_pool" : (own ? "k_bnh_partial<1>" : "k_bnh_partial<0>")); mn_prof_bytes((own ? 3.0 : 5.0) * nel); mn_prof_begin(s);
     if (pool_fast) hipLaunchKernelGGL(k_bnh_partial_pool, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, (double*)ws);
     else if (own) hipLaunchKernelGGL(k_bnh_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, da, (const unsigned char*)h, (const char*)own, chan, (double*)ws);

@@ -460,8 +460,8 @@ static int qa_geom(QaGeom* g, int64_t N, int64_t C, int64_t H, int64_t W, int bi
     g->fd_hw8 = make_fastdiv((uint32_t)g->HW8); g->fd_w8 = make_fastdiv((uint32_t)(g->W8 > 0 ? g->W8 : 1));
     g->n8 = pool ? N * (H / 2) * (W / 8) : N * (HW / 8);
     g->s = dorefa_scale(bits);
-    g->inv_s = MN_ENV("MN_QA_IEEE_DIV") ? 0.f : 1.0f / g->s;
-    g->interval = MN_ENV("MN_QA_NO_INTERVAL") ? 0 : 1;
+    g->inv_s = mn_qa_inv(g->s);
+    g->interval = mn_qa_interval();
     g->nthr = 0;
     g->mask4 = nullptr;
     g->fin_part = nullptr; g->fin_S = 0; g->fin_dgamma = g->fin_dbeta = g->fin_sums = g->fin_dgamma_s = g->fin_dbeta_s = g->fin_sums_s = nullptr;
@@ -495,7 +495,7 @@ extern "C" int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t 
     if (!in || !chan || (!codes && !act_f32) || (((uintptr_t)in) & 15) || (codes && (((uintptr_t)codes) & 7)) || (act_f32 && !aligned16(act_f32)))
         MN_FAIL(MN_EINVAL, "mn_qa_fwd: null / misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
-    if (!in_f32 && codes && a_bits <= 3 && !MN_ENV("MN_QA_NO_THRESHOLDS")) g.nthr = (1 << a_bits) - 1;       // integer-threshold forward (A/B knob)
+    if (!in_f32 && codes && a_bits <= 3) g.nthr = (1 << a_bits) - 1;       // integer-threshold forward
     const dim3 grid((unsigned)C, (unsigned)qa_split(g));
     const double nel = (double)N * C * H * W;
     mn_set_last_kernel("k_qa_fwd<%d, %d>", in_f32, pool ? 1 : 0);

@@ -714,7 +714,6 @@ static int qd_geom_ok(const mn_conv_geom* g) {
     else if (g->KH == 1 && g->KW == 1 && g->pad_h == 0 && g->pad_w == 0 && g->stride_h == 2 && g->stride_w == 2) { }
     else return 0;
     if (g->W % 4 || g->H % g->stride_h || g->W % g->stride_w) return 0;
-    if (MN_ENV("MN_NO_QD")) return 0;          // A/B knob: the generic kernels
     return 1;
 }
 static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl, int i8 = 0) {
@@ -752,13 +751,11 @@ static int plan_qdf(const mn_conv_geom* g, int out32, QdfPlan* pl, int i8 = 0) {
     p.fd_th = make_fastdiv((uint32_t)p.TH); p.fd_ncot = make_fastdiv((uint32_t)p.ncot); p.fd_tpi = make_fastdiv((uint32_t)p.tpi);
     p.fd_ipt = make_fastdiv((uint32_t)(p.TH * p.Wo));
     int tgt = 512;
-    if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }     // tuning knob
     pl->grid = p.nitems < tgt ? p.nitems : tgt;
     if (pl->grid > 512) pl->grid = 512;
     pl->grid -= pl->grid % p.ncot;          // every item of a block then has the block's channel tile (item % ncot == blockIdx % ncot): the epilogue statistics rely on it
     if (pl->grid < p.ncot) pl->grid = p.ncot;
     pl->TPS = p.TAPS == 9 ? 3 : 1;
-    if (i8 && p.TAPS == 9) { if (const char* e = MN_ENV("MN_QD8_TPS")) { if (atoi(e) == 9) pl->TPS = 9; } }          // A/B knob
     pl->lds = (size_t)pl->TPS * (i8 ? QD8_WSTEP : QD_WSTEP) + (size_t)p.NI * p.PH * p.PW * RS;
     if (i8 && pl->lds < (size_t)4 * (MF * 2048 + 512)) pl->lds = (size_t)4 * (MF * 2048 + 512);          // its epilogue scratch starts at the weight buffer
     if (i8 && pl->lds < 16384) pl->lds = 16384;                                                           // (and the 16 KB of the statistics hand-over)
@@ -807,7 +804,6 @@ static void qd_launch_fwd(const QdfPlan& pl, hipStream_t s) {
 }
 // the forward runs on the int8 matrix cores whenever the weight codes fit signed bytes (activation codes always do: DoReFa <= 7 bits unsigned, IAO signed)
 static int qd_fwd_i8(const mn_wq* wq) {
-    if (MN_ENV("MN_NO_QD8")) return 0;          // A/B knob: the bf16 forward
     return wq && ((wq->mode == MN_WQ_DOREFA && wq->bits <= 7) || (wq->mode == MN_WQ_IAO && wq->bits <= 8));
 }
 // the stash of a dense layer is 32 bits wide when K * amax * wmax does not fit 16
@@ -837,7 +833,7 @@ int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.x = x; p.wpk = wpk; p.stash = stash; p.xsgn = 0; p.sa = p.sw = p.bias = nullptr; p.sw_stride = 0;
     double* part = reinterpret_cast<double*>((char*)ws + pl.off_part);
-    const int epi_stats = i8 && !MN_ENV("MN_QD_NO_EPI_STATS");          // A/B knob: the separate statistics pass
+    const int epi_stats = i8;
     p.stats = epi_stats ? part : nullptr;
     mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
@@ -1149,7 +1145,6 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
     int MF = 0;
     const int NTm = qd_terms();
     int mf0 = S == 2 ? 1 : 4;          // MF 4 (round 5): 256-pixel tiles -- an item's fixed costs (first patch, epilogue stores: ~45 % of an MF 2 item, s_memtime timeline) over twice the work
-    if (const char* e = MN_ENV("MN_QDD_MF")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) mf0 = S == 2 ? 1 : v; }
     for (int mf = mf0; mf >= 1; mf >>= 1) {
         const int BM = 64 * mf;
         int TH, NI;
@@ -1162,7 +1157,7 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
         if (NTm * plane > 56 * 1024 || units.nunits > 256 * QDD_UPT_OF(mf)) continue;          // two blocks per CU: 2 x (term planes + 24 KB of weights) in 160 KB
         {   // ... and two blocks per CU there must be: a larger tile that leaves fewer than 512 items loses the overlap of the two blocks' phases (512 x 512 @ 4 x 4: MF 2 75 us, MF 1 61 us)
             const int64_t nt = NI == 1 ? (int64_t)g->N * (p.Hg / TH) : ((int64_t)g->N + NI - 1) / NI;
-            if (mf > 1 && !MN_ENV("MN_QDD_MF") && nt * (g->C / 64) < 512) continue;
+            if (mf > 1 && nt * (g->C / 64) < 512) continue;
         }
         MF = mf; p.TH = TH; p.NI = NI; p.PH = PH; p.PW = PW; p.TS = (int)plane; p.nunits = units.nunits; p.units = units;
         break;
@@ -1176,7 +1171,6 @@ static int plan_qdd(const mn_conv_geom* g, QddPlan* pl) {
     p.fd_w4 = make_fastdiv((uint32_t)p.W4); p.fd_ph = make_fastdiv((uint32_t)p.PH); p.fd_ni = make_fastdiv((uint32_t)p.NI);
     p.fd_th = make_fastdiv((uint32_t)p.TH); p.fd_ncit = make_fastdiv((uint32_t)p.ncit); p.fd_tpi = make_fastdiv((uint32_t)p.tpi);
     int tgt = 512;
-    if (const char* e = MN_ENV("MN_QD_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }
     pl->grid = p.nitems < tgt ? p.nitems : tgt;
     pl->lds = (size_t)2 * p.WSB + (size_t)NTm * p.TS;
     pl->ws_bytes = ((int64_t)g->O * g->C * p.TAPS * 2 + 255) / 256 * 256;
@@ -1693,7 +1687,6 @@ static int plan_qdw(const mn_conv_geom* g, QdwPlan* pl) {
     p.ntiles = p.NI == 1 ? g->N * p.tpi : (g->N + p.NI - 1) / p.NI;
     p.ncit = g->C / 64; p.npairs = (g->O / 64) * p.ncit;
     int tgt = 256;
-    if (const char* e = MN_ENV("MN_QDW_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) tgt = v; }     // tuning knob
     int Z = tgt / p.npairs;
     if (Z > p.ntiles) Z = p.ntiles;
     if (Z < 1) Z = 1;
@@ -1787,7 +1780,7 @@ int qd_iao_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, 
 static int64_t qd_iao_codes_bytes(const mn_conv_geom* g) { return ((int64_t)g->N * g->C * g->H * g->W + 255) / 256 * 256; }
 extern "C" int64_t mn_conv2d_iao_stats_rows(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
     QdfPlan pl;
-    if (!qd_iao_quant_ok(g, aq, wq, 1) || !qd_fwd_i8(wq) || !plan_qdf(g, 2, &pl, 1) || MN_ENV("MN_QD_NO_EPI_STATS")) return 0;
+    if (!qd_iao_quant_ok(g, aq, wq, 1) || !qd_fwd_i8(wq) || !plan_qdf(g, 2, &pl, 1)) return 0;
     return pl.grid / pl.p.ncot;
 }
 extern "C" int64_t mn_conv2d_iao_codes_bytes(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
@@ -1829,7 +1822,7 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
         qd_launch_pack(w, reinterpret_cast<uint16_t*>((char*)ws + cb), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s, wq->scale, wq->per_channel);
         wpk = reinterpret_cast<const uint16_t*>((char*)ws + cb);
     }
-    p.stats = (i8 && aq->stats && !MN_ENV("MN_QD_NO_EPI_STATS")) ? reinterpret_cast<double*>(aq->stats) : nullptr;          // exact sums of acc for the BatchNorm behind (mn_bn_fwd_acc)
+    p.stats = (i8 && aq->stats) ? reinterpret_cast<double*>(aq->stats) : nullptr;          // exact sums of acc for the BatchNorm behind (mn_bn_fwd_acc)
     p.x = (const unsigned char*)cbuf; p.wpk = wpk; p.stash = y; p.xsgn = 1; p.sa = aq->qp; p.sw = wq->scale; p.sw_stride = wq->per_channel; p.bias = bias;
     mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + 4.0 * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
@@ -1840,7 +1833,7 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
     return MN_OK;
 }
 int qd_iao_dx_add_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq) {
-    return g && aq && wq && qd_iao_supported(g, aq, wq, 1) && !MN_ENV("MN_QD_STE_SEPARATE");
+    return g && aq && wq && qd_iao_supported(g, aq, wq, 1);
 }
 int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx, void* ws, int64_t ws_bytes,
                     hipStream_t s) {
@@ -1853,21 +1846,14 @@ int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, c
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s, wq->scale, wq->per_channel); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f; p.wsc = wq->scale; p.wsc_stride = wq->per_channel;
     const IaoRange r = iao_range(aq->bits, 0, 1);
-    static const bool ste_sep = MN_ENV("MN_QD_STE_SEPARATE") != nullptr;          // A/B knob: the clip-STE as a pass of its own (round 3)
-    p.ste_x = ste_sep ? nullptr : x; p.ste_qp = aq->qp; p.ste_qmin = r.qmin; p.ste_qmax = r.qmax;          // the quantizer's clip-STE rides the store of dx
-    if (aq->dx_add && (ste_sep || !aligned16(aq->dx_add))) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense iao): mn_actq.dx_add needs the fused clip-STE and a 16-byte aligned tensor");
+    p.ste_x = x; p.ste_qp = aq->qp; p.ste_qmin = r.qmin; p.ste_qmax = r.qmax;          // the quantizer's clip-STE rides the store of dx
+    if (aq->dx_add && !aligned16(aq->dx_add)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense iao): mn_actq.dx_add needs a 16-byte aligned tensor");
     p.dx_add = aq->dx_add;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d, %d>", pl.MF, pl.S, p.TAPS, qd_terms());
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 8.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     qd_launch_dgrad(pl, s);
     mn_prof_end(s);
-    if (ste_sep) {
-        const int64_t n4 = (int64_t)g->N * g->C * g->H * g->W / 4;
-        int64_t nb = (n4 + 255) / 256;
-        if (nb > 8192) nb = 8192;
-        hipLaunchKernelGGL(k_qd_iao_ste, dim3((unsigned)nb), dim3(256), 0, s, dx, x, n4, aq->qp, r.qmin, r.qmax);
-    }
     MN_CHECK_LAUNCH("mn_conv2d_bwd_data(dense iao)");
     return MN_OK;
 }

@@ -252,7 +252,6 @@ static int plan_k3s(const mn_conv_geom* g, K3wPlan* pl) {
     if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
     const int64_t HW = (int64_t)g->H * g->W;
     if ((int64_t)g->N * g->O * HW >= ((int64_t)1 << 31) || (int64_t)g->N * g->C * HW >= ((int64_t)1 << 31)) return 0;     // 32-bit element offsets
-    if (MN_ENV("MN_NO_K3S")) return 0;          // A/B knob: the generic k x k kernel
     K3wParams& p = pl->p;
     p.N = g->N; p.C = g->C; p.H = g->H; p.W = g->W; p.O = g->O; p.G = g->groups; p.Cg = g->C / g->groups; p.Mg = g->O / g->groups;
     p.in_map = make_chanmap(g->in_shuffle, g->C);
@@ -262,7 +261,6 @@ static int plan_k3s(const mn_conv_geom* g, K3wPlan* pl) {
     const int base = p.G * p.nmb * p.ncb;
     int Z = 512 / base;
     while (Z > 1 && p.nsteps / Z < 32 && base * Z > 256) Z /= 2;
-    if (const char* e = MN_ENV("MN_K3S_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }     // tuning knob
     if (Z > p.nsteps / 4) Z = p.nsteps / 4;
     if (Z < 1) Z = 1;
     p.Z = Z;
@@ -529,7 +527,6 @@ static int plan_k3d(const mn_conv_geom* g, const mn_wq* wq, K3dPlan* pl) {
     const int HW = g->H * g->W, Mg = g->O / g->groups, Cg = g->C / g->groups;
     if (g->W % 4 || HW % 32 || Mg > 32 || Mg < 1) return 0;
     if ((int64_t)g->N * g->O * HW >= ((int64_t)1 << 31)) return 0;
-    if (MN_ENV("MN_NO_K3D")) return 0;          // A/B knob: the generic k x k kernel
     K3dParams& p = pl->p;
     int NI = 1;
     while (NI * HW < 128) NI *= 2;
@@ -545,7 +542,6 @@ static int plan_k3d(const mn_conv_geom* g, const mn_wq* wq, K3dPlan* pl) {
     p.ncb = (Cg + 15) / 16;
     const int base = p.G * p.ncb;
     int tgt = 512;
-    if (const char* e = MN_ENV("MN_K3D_BLOCKS")) { const int v = atoi(e); if (v >= 32 && v <= 8192) tgt = v; }     // tuning knob
     int Zb = tgt / base;
     if (Zb > p.nstages) Zb = p.nstages;
     if (Zb < 1) Zb = 1;
@@ -830,7 +826,6 @@ static int plan_k3f(const mn_conv_geom* g, const mn_wq* wq, K3fPlan* pl, int xen
     const int HW = g->H * g->W, Mg = g->O / g->groups, Cg = g->C / g->groups;
     if (g->W % 4 || HW % 32 || g->H < 2 || Mg > 32 || Cg > 16) return 0;
     if ((int64_t)g->N * g->O * HW >= ((int64_t)1 << 31) || (int64_t)g->N * g->C * HW >= ((int64_t)1 << 31)) return 0;
-    if (MN_ENV("MN_NO_K3F")) return 0;          // A/B knob: the generic k x k kernel + k_h_stats
     K3fParams& p = pl->p;
     int NI = 1;
     while (NI * HW < 128) NI *= 2;
@@ -844,7 +839,6 @@ static int plan_k3f(const mn_conv_geom* g, const mn_wq* wq, K3fPlan* pl, int xen
     if (pl->lds > 64 * 1024) return 0;
     p.nstages = (g->N + NI - 1) / NI;
     int tgt = 512;
-    if (const char* e = MN_ENV("MN_K3F_BLOCKS")) { const int v = atoi(e); if (v >= 32 && v <= 512) tgt = v; }      // tuning knob (the workspace is sized for 512)
     int Zb = tgt / p.G;
     if (Zb > p.nstages) Zb = p.nstages;
     if (Zb < 1) Zb = 1;

@@ -855,7 +855,7 @@ void qg_launch_wgrad_reduce_div(const float* part, const float* dbpart, float* d
 static void qg_launch_wgrad_reduce_(const float* part, const float* dbpart, float* dw, float* db, int Z, int G, int Mg, int Cg, int Mgw, int Cgw,
                                     float ascale, const float* qp, const float* rowdiv, hipStream_t s) {
     const int64_t tile = (int64_t)G * Mgw * Cgw;
-    if (Z >= 16 && tile % 64 == 0 && tile / 64 < (1 << 22) && !(((uintptr_t)part) & 15) && !MN_ENV("MN_REDUCE_OLD")) {
+    if (Z >= 16 && tile % 64 == 0 && tile / 64 < (1 << 22) && !(((uintptr_t)part) & 15)) {
         const int nblk_w = (int)(tile / 64);
         const int nblk_b = db ? mn_grid_for((int64_t)G * Mg * 8, 256, 64) : 0;
         hipLaunchKernelGGL(k_pw_wgrad_reduce_v, dim3(nblk_w + nblk_b), dim3(256), 0, s, part, dbpart, dw, db, Z, G, Mg, Cg, Mgw, Cgw, ascale, qp, nblk_w, rowdiv);
@@ -911,7 +911,6 @@ static int plan_pw(const mn_conv_geom* g, int which, int xmode, PwPlan* pl) {
     p.nchunks = (int)((p.NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
     int capb = 512;           // one round of 2 blocks per CU (against 1024: -2 ... -3 % on the DoReFa layers)
-    if (const char* e = MN_ENV("MN_PW_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) capb = v; }   // tuning knob
     const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
     p.CB = CB;
@@ -994,7 +993,6 @@ static int plan_pwd(const mn_conv_geom* g, PwdPlan* pl) {
     p.nchunks = (int)((NP + 63) / 64);
     int CB = (p.nchunks + 3) / 4;
     int capb = 512;           // one round of 2 blocks per CU (against 1024: -2 ... -5 %)
-    if (const char* e = MN_ENV("MN_PWD_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) capb = v; }   // tuning knob
     const int cap = capb / (p.G * p.num_mblk) > 0 ? capb / (p.G * p.num_mblk) : 1;
     if (CB > cap) CB = cap;
     p.CB = CB;
@@ -1014,7 +1012,7 @@ static int plan_pwd(const mn_conv_geom* g, PwdPlan* pl) {
 // the transposed weight codes + contraction-channel scales of this call: the step's pre-packed image (mn_wq.packed_bwd, written by mn_qg_pack_multi in the layout
 // [codes | scales at off_scale] of this very plan) or packed here into the call's workspace
 static void pwd_codes(PwdPlan& pd, const mn_wq* wq, const float* w, void* ws, hipStream_t s) {
-    if (wq->packed_bwd && !MN_ENV("MN_NO_PACKED_PW")) {
+    if (wq->packed_bwd && mn_use_packed()) {
         pd.pk.codes = (uint16_t*)const_cast<void*>(wq->packed_bwd);
         pd.pk.scale_out = (float*)((char*)const_cast<void*>(wq->packed_bwd) + pd.off_scale);
         return;
@@ -1159,7 +1157,7 @@ int qg_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const
     if (rc) return rc;
     if (ste.mode == MN_ACTQ_SIGN8 || ste.mode == MN_ACTQ_CODE8) ste.mode = MN_ACTQ_NONE;      // the clip-STE lives in mn_bnsign_bwd / mn_qa_bwd_*
     if (ste.mode != MN_ACTQ_NONE && (!x || !aligned16(x))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_data(qgemm): x required (16 B aligned) for the clip-STE epilogue");
-    if (ste.mode == MN_ACTQ_NONE && !MN_ENV("MN_NO_PWD")) {      // no clip-STE epilogue: the prefetching kernel
+    if (ste.mode == MN_ACTQ_NONE) {      // no clip-STE epilogue: the prefetching kernel
         PwdPlan pd;
         if (plan_pwd(g, &pd) && ws_bytes >= pd.ws_bytes) {
             pwd_codes(pd, wq, w, ws, s);
@@ -1205,7 +1203,7 @@ static void launch_wg(const WgPlan& pl, int xmode, hipStream_t s) {
 int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, const float* x, float* dw, float* dbias, void* ws,
                   int64_t ws_bytes, hipStream_t s) {
     if (!pw_geom_ok(g)) return kk_bwd_weight(g, aq, gy, x, dw, dbias, ws, ws_bytes, s);
-    if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_wgrad_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g) && !MN_ENV("MN_NO_WG2"))
+    if (aq && aq->mode == MN_ACTQ_SIGN8 && pws_wgrad_supported(g) && ws_bytes >= pws_wgrad_ws_bytes(g))
         return pws_bwd_weight(g, gy, (const int8_t*)x, dw, dbias, ws, ws_bytes, s);      // sign codes: fragments straight from global memory
     const int code8 = aq && aq->mode == MN_ACTQ_CODE8;
     if (code8) {        // k-bit activation codes: the LDS-staged kernel, or (small tiles: the classifier conv) the generic kernel reading bytes
@@ -1249,7 +1247,7 @@ static int qg_packm_plan(const mn_conv_geom* g, int which, PackParams* pk, int* 
 }
 extern "C" int64_t mn_qg_packed_bytes(const mn_conv_geom* g, int which) {
     PackParams pk; int grid; int64_t off, bytes;
-    if (MN_ENV("MN_NO_PACKED_PW") || !qg_packm_plan(g, which, &pk, &grid, &off, &bytes)) return 0;
+    if (!mn_use_packed() || !qg_packm_plan(g, which, &pk, &grid, &off, &bytes)) return 0;
     return (off + (int64_t)pk.G * (pk.transpose ? pk.Mgp : pk.Mpad) * 4 + 255) / 256 * 256;
 }
 extern "C" int mn_qg_pack_multi(int32_t count, const mn_conv_geom* const* g, const mn_wq* const* wq, const float* const* w, const int32_t* which, void* const* out,

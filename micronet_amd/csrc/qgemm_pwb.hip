@@ -479,7 +479,7 @@ static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv
         MN_FAIL(MN_ENOTSUP, "%s: misaligned tensor", what);
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "%s: workspace too small", what);
     PwbParams& p = pl.p;
-    if (wq->packed_bwd && !MN_ENV("MN_NO_PACKED_PW")) {
+    if (wq->packed_bwd && mn_use_packed()) {
         p.wc = (const uint16_t*)wq->packed_bwd;
         p.kscale = (const float*)((const char*)wq->packed_bwd + pl.off_scale);
     } else {
@@ -490,7 +490,7 @@ static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv
     p.gy = gy; p.h = h; p.chan = chan; p.sums = sums; p.own = (const char*)own; p.x = (const char*)x; p.dx = dx;
     p.part = (float*)((char*)ws + pl.off_part); p.dbpart = (float*)((char*)ws + pl.off_db);
     p.want_db = dbias != nullptr; p.training = training;
-    p.quant = quant; p.qs = qs; p.qinv = MN_ENV("MN_QA_IEEE_DIV") ? 0.f : 1.0f / qs;
+    p.quant = quant; p.qs = qs; p.qinv = mn_qa_inv(qs);
     const int bnh = mode == 1 ? (own ? 2 : 1) : mode;
     mn_set_last_kernel("k_pwb<%d, %d, %d>", bnh, xenc, wide);
     {

@@ -1264,9 +1264,7 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     if (NP % 32 || Mg < 33 || Cg < 33) return 0;           // small tiles stay on the LDS-staged kernel
     Wg2Params& p = pl->p;
     pl->MW = (Mg > 64 || Cg > 64) ? 4 : 2;
-    if (const char* e = MN_ENV("MN_WG2_MW")) { const int v = atoi(e); if (v == 2 || v == 4) pl->MW = v; }   // tuning knob
-    pl->CW8 = 0;
-    if (const char* e = MN_ENV("MN_WG2_CW8")) pl->CW8 = atoi(e) != 0 && pl->MW == 4;   // tuning knob: 4 x 1 waves of 32 x 128
+    pl->CW8 = 0;          // (the 4 x 1 arrangement of 32 x 128 wave tiles, round 2: slower; its instantiations are gone)
     const int T = 32 * pl->MW;
     p.N = g->N; p.HW = g->H * g->W; p.G = g->groups; p.Cin_total = g->C; p.Cout_total = g->O; p.Cg = Cg; p.Mg = Mg;
     p.in_map = make_chanmap(g->in_shuffle, g->C);
@@ -1274,21 +1272,17 @@ static int plan_pws_wgrad(const mn_conv_geom* g, Wg2Plan* pl) {
     p.Mgw = p.nmb * T; p.Cgw = p.ncb * T;
     p.nsteps = (int)(NP / 32);
     const int base = p.G * p.nmb * p.ncb;
-    // LDS-staged kernel: 16-byte code loads need HW % 16 == 0; MN_WG2_DIRECT=1 keeps the direct-load kernel (A/B knob)
-    pl->staged = p.HW % 16 == 0 && !pl->CW8 && !MN_ENV("MN_WG2_DIRECT");
-    pl->spec = pl->staged && pl->MW == 4 && !MN_ENV("MN_WG2_NOSPEC") ? 2 : 0;    // wave-specialised variant: 768 threads, one block per CU
-    if (pl->spec) if (const char* e = MN_ENV("MN_WG2_SPEC")) { const int v = atoi(e); if (v == 1 || v == 2) pl->spec = v; }   // A/B knob: 4 or 8 consumer waves
+    // LDS-staged kernel: 16-byte code loads need HW % 16 == 0 (else the direct-load kernel)
+    pl->staged = p.HW % 16 == 0;
+    pl->spec = pl->staged && pl->MW == 4 ? 2 : 0;    // wave-specialised variant (4 staging + 8 MFMA waves): 768 threads, one block per CU
     int Z = (pl->spec ? 256 : 512) / base;
     // every block pays a fixed price (pipeline fill, a 64 KB partial tile written and reduced again): keep >= 32 steps per block as long
     // as there is still one block per CU (measured: L5 67 -> 58 us, L8 40 -> 36 us)
     while (Z > 1 && p.nsteps / Z < 32 && base * Z > 256) Z /= 2;
-    if (const char* e = MN_ENV("MN_WG2_Z")) { const int v = atoi(e); if (v >= 1 && v <= 4096) Z = v; }   // tuning knob
     if (Z > p.nsteps / 2) Z = p.nsteps / 2;
     if (Z < 1) Z = 1;
     p.Z = Z;
-    if (MN_ENV("MN_DEBUG_PLAN")) fprintf(stderr, "plan_pws_wgrad: nsteps %d base %d Z %d MW %d\n", p.nsteps, base, Z, pl->MW);
     p.st_per_z = (p.nsteps + Z - 1) / Z; p.st_stride = 1;     // contiguous pixel ranges: each block streams its gy rows sequentially
-    if (MN_ENV("MN_WG2_STRIDED")) { p.st_stride = Z; }
     p.fd_hw = make_fastdiv((uint32_t)p.HW);
     const int64_t nb = (int64_t)base * Z;
     if (nb > 0x7fffffff) return 0;
@@ -1317,8 +1311,8 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
     p.own = (const char*)own; p.W = (int)g->W; p.fd_w = make_fastdiv((uint32_t)g->W);
     if (h && (!chan || !sums || (((uintptr_t)h) & 3))) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_weight_bnh: null / misaligned argument");
     if (pl.staged && ((((uintptr_t)x) & 15) || (h && (((uintptr_t)h) & 3)))) pl.staged = 0;
-    if (pl.staged) mn_set_last_kernel(pl.spec == 2 ? "k_pws_wgrad_s<%d, %d, 0, 2>" : pl.spec ? "k_pws_wgrad_s<%d, %d, 0, 1>" : "k_pws_wgrad_s<%d, %d>", pl.MW, own ? 2 : (h ? 1 : 0));
-    else mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.CW8 ? 2 : pl.MW, pl.CW8 ? 8 : pl.MW, h ? 1 : 0);
+    if (pl.staged) mn_set_last_kernel(pl.spec == 2 ? "k_pws_wgrad_s<%d, %d, 0, 2>" : "k_pws_wgrad_s<%d, %d>", pl.MW, own ? 2 : (h ? 1 : 0));
+    else mn_set_last_kernel("k_pws_wgrad<%d, %d, %d>", pl.MW, pl.MW, h ? 1 : 0);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes((own ? 3.0 : (h ? 5.0 : 4.0)) * ny + nx); }
     mn_prof_begin(s);
     if (pl.staged) {
@@ -1328,19 +1322,16 @@ int pws_bwd_weight_bnh(const mn_conv_geom* g, const float* gy, const uint8_t* h,
 #define WG3_LAUNCH(MWV, BV) { raise_lds_limit((const void*)k_pws_wgrad_s<MWV, BV>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<MWV, BV>), dim3(pl.grid), dim3(256), ldsb, s, p); }
 #define WG3_LAUNCH_SPEC(BV, SV) { raise_lds_limit((const void*)k_pws_wgrad_s<4, BV, 0, SV>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, BV, 0, SV>), dim3(pl.grid), dim3(256 + 256 * SV), ldsb, s, p); }
         if (pl.spec == 2) { if (own) WG3_LAUNCH_SPEC(2, 2) else if (p.h) WG3_LAUNCH_SPEC(1, 2) else WG3_LAUNCH_SPEC(0, 2) }
-        else if (pl.spec) { if (own) WG3_LAUNCH_SPEC(2, 1) else if (p.h) WG3_LAUNCH_SPEC(1, 1) else WG3_LAUNCH_SPEC(0, 1) }
         else if (own) { if (pl.MW == 4) WG3_LAUNCH(4, 2) else WG3_LAUNCH(2, 2) }
         else if (p.h) { if (pl.MW == 4) WG3_LAUNCH(4, 1) else WG3_LAUNCH(2, 1) }
         else { if (pl.MW == 4) WG3_LAUNCH(4, 0) else WG3_LAUNCH(2, 0) }
 #undef WG3_LAUNCH
 #undef WG3_LAUNCH_SPEC
     } else if (p.h) {
-        if (pl.CW8) hipLaunchKernelGGL((k_pws_wgrad<2, 8, 1>), dim3(pl.grid), dim3(256), 0, s, p);
-        else if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
+        if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 1>), dim3(pl.grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_pws_wgrad<2, 2, 1>), dim3(pl.grid), dim3(256), 0, s, p);
     } else {
-        if (pl.CW8) hipLaunchKernelGGL((k_pws_wgrad<2, 8, 0>), dim3(pl.grid), dim3(256), 0, s, p);
-        else if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 0>), dim3(pl.grid), dim3(256), 0, s, p);
+        if (pl.MW == 4) hipLaunchKernelGGL((k_pws_wgrad<4, 4, 0>), dim3(pl.grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_pws_wgrad<2, 2, 0>), dim3(pl.grid), dim3(256), 0, s, p);
     }
     mn_prof_end(s);
@@ -1358,13 +1349,12 @@ int pws_bwd_weight_code8(const mn_conv_geom* g, const float* gy, const uint8_t* 
     Wg2Params& p = pl.p;
     p.gy = gy; p.x = (const char*)x; p.part = (float*)ws; p.dbpart = (float*)((char*)ws + pl.off_db); p.want_db = dbias != nullptr;
     p.h = nullptr; p.chan = nullptr; p.sums = nullptr; p.training = 0; p.n_f = 1.f;
-    mn_set_last_kernel(pl.spec == 2 ? "k_pws_wgrad_s<%d, 0, 1, 2>" : pl.spec ? "k_pws_wgrad_s<%d, 0, 1, 1>" : "k_pws_wgrad_s<%d, 0, 1>", pl.MW);
+    mn_set_last_kernel(pl.spec == 2 ? "k_pws_wgrad_s<%d, 0, 1, 2>" : "k_pws_wgrad_s<%d, 0, 1>", pl.MW);
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W; mn_prof_bytes(4.0 * ny + nx); }
     mn_prof_begin(s);
     const int TMs = 32 * pl.MW;
     const size_t ldsb = 2 * ((size_t)3 * TMs * 80 + (size_t)TMs * WG3_RSBX);
     if (pl.spec == 2) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1, 2>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1, 2>), dim3(pl.grid), dim3(768), ldsb, s, p); }
-    else if (pl.spec) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1, 1>), dim3(pl.grid), dim3(512), ldsb, s, p); }
     else if (pl.MW == 4) { raise_lds_limit((const void*)k_pws_wgrad_s<4, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<4, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
     else { raise_lds_limit((const void*)k_pws_wgrad_s<2, 0, 1>, ldsb); hipLaunchKernelGGL((k_pws_wgrad_s<2, 0, 1>), dim3(pl.grid), dim3(256), ldsb, s, p); }
     mn_prof_end(s);
@@ -1474,7 +1464,7 @@ static int pws_prepare(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, 
     if (!wq_codeable(wq) || !plan_pws(g, nt_max, pl)) MN_FAIL(MN_ENOTSUP, "%s: geometry / weight quantizer not covered by the fused sign kernels", what);
     if (!x || !w || (((uintptr_t)x) & 3)) MN_FAIL(MN_EINVAL, "%s: null / misaligned tensor", what);
     if (!ws || ws_bytes < pl->ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "%s: workspace too small (%lld < %lld)", what, (long long)ws_bytes, (long long)pl->ws_bytes);
-    if (wq->packed_fwd && !MN_ENV("MN_NO_PACKED_PW")) {          // the step's pre-packed image (mn_qg_pack_multi: [codes | row scales at off_scale] of this plan)
+    if (wq->packed_fwd && mn_use_packed()) {          // the step's pre-packed image (mn_qg_pack_multi: [codes | row scales at off_scale] of this plan)
         pl->pk.codes = (uint16_t*)const_cast<void*>(wq->packed_fwd);
         pl->pk.scale_out = (float*)((char*)const_cast<void*>(wq->packed_fwd) + pl->off_scale);
     } else {
@@ -1543,7 +1533,7 @@ static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const i
     PwsParams& p = pl.p;
     p.bias = bias;
     const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
-    const bool stash_in_stats = training && h && !MN_ENV("MN_NO_STATS_H");      // one MFMA pass instead of two: h from the statistics pass, sign streamed from h
+    const bool stash_in_stats = training && h;      // one MFMA pass instead of two: h from the statistics pass, sign streamed from h
     p.h8 = stash_in_stats ? h : nullptr;
     if (training && (rc = launch_pws<PWS_STATS>(pl, s, nx + (stash_in_stats ? ny : 0.0), "mn_qconv_bnsign_fwd(stats)"))) return rc;
     if (chan_out) p.chan = chan_out;                     // caller-owned [8][O]: kept for the streaming backward (mn_bnh_bwd)
@@ -1832,7 +1822,7 @@ static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
 }
 extern "C" int mn_qconv_bnsign_stash_supported(const mn_conv_geom* g, const mn_wq* wq) {
     if (!g || !wq) return 0;
-    return pws_bn_ok(g, wq) || (!MN_ENV("MN_NO_KXK_STASH") && kk_h8_supported(g, wq));
+    return pws_bn_ok(g, wq) || kk_h8_supported(g, wq);
 }
 /* rows of the caller-owned per-channel table `chan` the stash forward fills: 8, or 17 for a 3x3 block (per-pixel-class nnz) */
 extern "C" int mn_qconv_bnsign_stash_chan_rows(const mn_conv_geom* g) { return (g && g->KH == 1 && g->KW == 1) ? 8 : 17; }
@@ -1893,7 +1883,7 @@ extern "C" int mn_qconv_bnq_supported(const mn_conv_geom* g, const mn_wq* wq, in
     if (!g || !wq || wq->mode != MN_WQ_DOREFA || wq->bits < 2 || wq->bits > 8 || a_bits_in < 2 || a_bits_in > 8 || g->groups < 1 || g->C % g->groups || g->O % g->groups) return 0;
     if (qd_fwd_supported(g, wq, a_bits_in) && qd_dgrad_supported(g, wq) && qd_wgrad_supported(g, a_bits_in)) return 1;      // dense layers (ResNets): qgemm_dense.hip
     const int wide = bnq_wide(g, wq, a_bits_in);
-    if (wide && (MN_ENV("MN_NO_BNQ_WIDE") || bnq_accmax(g, wq, a_bits_in) >= (1ll << 24))) return 0;          // fp32 accumulation of bf16 integer products must stay exact
+    if (wide && bnq_accmax(g, wq, a_bits_in) >= (1ll << 24)) return 0;          // fp32 accumulation of bf16 integer products must stay exact
     if (g->stride_h != 1 || g->stride_w != 1) return 0;
     if (((int64_t)g->H * g->W) % 8) return 0;
     if (g->KH == 1 && g->KW == 1) {

@@ -456,7 +456,7 @@ def iao_qadd_observe_partials(pr, ps, obs_res, obs_sc, quantizer, update):
     return qp
 
 
-RES_ADD_FOLD = _os0.environ.get("MN_RES_ADD_FOLD", "1") != "0"          # A/B knob: 0 = autograd adds the shortcut's gradient to the conv's dx (an ATen add kernel per block)
+RES_ADD_FOLD = True          # the identity shortcut's gradient is added in the store of the conv's dx (round 5: -1.1 % step time against autograd's add kernel per block)
 
 
 class ResidualToken:
@@ -669,7 +669,7 @@ def relu_premask_ok(x):
     return getattr(x, "_mn_relu_token", None) is not None and not getattr(x, "_backward_hooks", None) and not x.retains_grad
 
 
-_NO_RELU_PREMASK = _os0.environ.get("MN_NO_RELU_PREMASK", "0") == "1"
+_NO_RELU_PREMASK = False
 
 
 def iao_bnfuse_pw_supported(x, weight, stride, padding, dilation, groups, in_shuffle):
@@ -1256,7 +1256,7 @@ class BnBatchStats(Function):
 
 
 LAZY_BN_GRAD = True
-FIRST_GRAM = _os0.environ.get("MN_FIRST_GRAM", "1") != "0"          # one-pass backward of the first block (A/B knob; 0: sums pass + fold in the backward-weight)
+FIRST_GRAM = True          # one-pass backward of the first block (round 5 A/B against the sums pass + fold in the backward-weight: c2 107.3k -> 111.9k img/s)
 
 
 class FirstConvRecord:
@@ -1880,9 +1880,9 @@ import os as _os
 # Fold the BatchNorm+sign backward into the block's own conv backward (k_pwd / k_pws_wgrad_s form dy from (da, h) in registers / in
 # the LDS staging pass, dy is never written).  With the LDS-staged backward-weight kernel (the fold costs one pass per BLOCK there)
 # this is +3.5 % step throughput on c2 (3.25 -> 3.14 ms): ON by default, MN_BNH_FOLD=0 switches it off.
-FOLD_BN_INTO_CONV_BWD = _os.environ.get("MN_BNH_FOLD", "1") != "0"
+FOLD_BN_INTO_CONV_BWD = True
 # ... and the 2x2 max-pool behind a block as well (k_pwd<.., 2> / k_pws_wgrad_s<.., 2, ..>): MN_BNH_POOL_FOLD=0 restores mn_bnh_bwd_apply's full-size dy (A/B)
-FOLD_POOL_INTO_CONV_BWD = _os.environ.get("MN_BNH_POOL_FOLD", "1") != "0"
+FOLD_POOL_INTO_CONV_BWD = True
 
 
 class ConvBNSign(Function):
@@ -2015,7 +2015,7 @@ def pack_dense_weights(mods_wq, w_bits, qps=None):
         wq._mn_packed = o
 
 
-PACK_PW_MULTI = _os.environ.get("MN_NO_PACKED_PW") is None          # A/B knob: every conv call packs its own weight codes
+PACK_PW_MULTI = _os.environ.get("MN_NO_PACKED_PW") is None          # (the library's own A/B knob, csrc/common.h: every conv call packs its own weight codes)
 
 
 def pack_pointwise_weights(mods_wq, wdesc):
@@ -2583,8 +2583,8 @@ class ConvTranspose2d(Function):
         return dx, dw, db, None, None, None, None, None
 
 
-QA_BWD_TWO_LAUNCHES = _os0.environ.get("MN_QA_BWD_FOLD", "1") != "0"          # the k-bit blocks' backward: partial sums + apply (which finishes the sums) instead of partial + final + apply
-FIRST_FUSED = _os0.environ.get("MN_FIRST_FUSED", "1") != "0"          # the fused first block (A/B knob; 0: conv, then the BatchNorm block's own kernels)
+QA_BWD_TWO_LAUNCHES = True          # the k-bit blocks' backward: partial sums + apply (which finishes the sums) instead of partial + final + apply
+FIRST_FUSED = True          # the fused first block (round 5 A/B against conv + the BatchNorm block's own kernels: c2 111.9k -> 115.8k img/s)
 FIRST_FUSED_QA = _os0.environ.get("MN_FIRST_FUSED_QA", "0") == "1"     # ... for the DoReFa block too (off: its epilogue -- the quantizer's rounding -- makes the fused
 #                                                                         forward VALU-bound, 209 us against 110 + 58 us for conv + mn_qa_fwd_f32_mask on nin_gc at batch 256)
 

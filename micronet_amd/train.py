@@ -256,10 +256,8 @@ class GraphedTrainStep:
                 optimizer.step()
 
     def _fwd_bwd(self):
-        import os
-        if os.environ.get("MN_MULTI_WQ", "1") != "0":
-            prefetch_weight_path(self.model)                     # all weight quantizers of the step in one launch (and one in backward)
-            bump_bn_counters(self.model)
+        prefetch_weight_path(self.model)                     # all weight quantizers of the step in one launch (and one in backward)
+        bump_bn_counters(self.model)
         self.output = self.model(self.data)
         self.loss = F.cross_entropy(self.output, self.target)
         self.optimizer.zero_grad(set_to_none=True)

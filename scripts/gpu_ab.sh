@@ -16,12 +16,10 @@ except Exception as e:
     print(w, l, "failed", e)
 PY
 }
-# edit below: one line per measurement, e.g.
-#   run c2 base MN_X=0
-#   run c2 nopoolfold MN_BNH_POOL_FOLD=0
-#   bash scripts/gpu_ab.sh c4:base c4:wgrad32:MN_QD_WGRAD32=1 c5:base c5:wgrad32:MN_QD_WGRAD32=1     (the unmeasured 32x32x16 backward-weight kernel)
-#   bash scripts/gpu_ab.sh c2:base c2:hsfold:MN_HSIGN_FOLD=1 c1_w2a2:base c1_w2a2:hsfold:MN_HSIGN_FOLD=1                  (the unmeasured statistics-finals fold of the sign pass)
-for spec in "$@"; do          # or pass "workload:label:ENV=VALUE" triples on the command line
+# pass "workload:label:ENV=VALUE" triples on the command line, e.g. (the knobs that remain are listed in micronet_amd/csrc/common.h):
+#   bash scripts/gpu_ab.sh c2:base c2:two_kernel_backward:MN_PWB=0 c1_w2a2:base c1_w2a2:two_kernel_backward:MN_PWB=0
+#   bash scripts/gpu_ab.sh c4:base c4:exact_terms:MN_GRAD_TERMS=3
+for spec in "$@"; do
   IFS=: read -r w l e <<< "$spec"
   run "$w" "$l" "${e:-MN_X=0}"
 done
