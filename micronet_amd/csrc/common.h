@@ -119,6 +119,12 @@ __device__ __forceinline__ mn_u32x2 mn_lds_tr16_b64(const unsigned char* p) {
     return __builtin_bit_cast(mn_u32x2, v);
 }
 #endif
+// a store with the non-temporal hint (a stream that is not read again by this kernel)
+#ifdef MN_EMULATION
+__device__ __forceinline__ void mn_store_nt(float* p, float v) { *p = v; }
+#else
+__device__ __forceinline__ void mn_store_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+#endif
 // a value the optimiser must treat as unknown (stops hoisting / rematerialisation decisions that cost registers)
 #ifdef MN_EMULATION
 __device__ __forceinline__ uint32_t mn_opaque(uint32_t v) { return v; }
