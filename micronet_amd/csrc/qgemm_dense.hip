@@ -1700,18 +1700,353 @@ static int plan_qdw(const mn_conv_geom* g, QdwPlan* pl) {
     pl->ws_bytes = (int64_t)Z * p.npairs * T * 4096 * 4;
     return 1;
 }
+// ------------------------------------------------------------------------------------------------ backward-weight, stride 1 / 3 x 3: second organisation (round 6)
+// Knock-out builds of k_qd_wgrad<1, 9, 2> on the resnet18 shapes (56 us; profiles/README.md, round 6) put its time at: launch + set-up 8 us, the 32 block-wide
+// hand-overs of a block 10 us with NOTHING between them, the staging waves' own instruction stream 15 us (a branch per staged 4-code unit: ~250 branches per
+// pair of K-steps), consumer LDS reads 7, MFMA 13, the partial tile's store 7 -- added up, not overlapped.  Same data flow, same partial-tile layout, but:
+//   * a hand-over is 64 gy-domain pixels (two MFMA K-steps): 4 per 256-pixel tile instead of 8;
+//   * the staging waves run straight-line code: a patch unit is 16 codes of one channel plane (one dwordx4: 4 or 5 units per thread and tile, committed in
+//     the tile's four steps by static index), addresses from shifts (W, H W powers of two), no per-unit words or branches; gy as 4 float4 per thread and step;
+//   * signed / unsigned codes, the term count and the steps per tile (SPT 4: 256-pixel tiles; 2: 128-pixel tiles where two 256-pixel patches do not fit, W = 4) are
+//     template parameters;
+//   * neighbouring patch rows share their zero pads (row stride W + 4 elements instead of W + 8): two 8 x 8 x 4-image patches fit beside the gy planes.
+#define QW2_ROWB 144                          // bytes per gy term-plane row: 64 pixels bf16 + 16
+#define QW2_PLANE (64 * QW2_ROWB)
+#define QW2_UPT 5
+struct Qdw2Params {
+    const float* gy;              // [N][O][H][W]
+    const unsigned char* x;       // [N][C][H][W] codes
+    float* part;
+    int N, C, O, H, W, HW, wsh, hwsh;
+    int NI, TH, PH, RB, CS;       // images per tile, gy rows per tile image, patch rows per image, bytes per patch row / per channel
+    int tpish, band;              // log2 tiles per image (NI == 1); band: the tile is a band of rows of one image (the halo rows hold data)
+    int ntiles, tpz, Z, ncit, npairs, nu;
+    FastDiv fd_np;
+};
+template <int NT, int XSGN, int SPT>
+__global__ __launch_bounds__(768) void k_qd_wgrad2(const Qdw2Params p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* dyb = reinterpret_cast<unsigned char*>(smem);          // [2][NT][64][144]
+    unsigned char* xp0 = dyb + 2 * NT * QW2_PLANE;                        // [2][64 CS]
+    const int XPB = 64 * p.CS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = mn_uniform(tid >> 6), j = lane & 15, kg = lane >> 4;
+    const uint32_t z = fd_div(blockIdx.x, p.fd_np);
+    const int pair = (int)blockIdx.x - (int)z * p.npairs;
+    const int cot = pair / p.ncit, cit = pair - cot * p.ncit;
+    const int t_begin = (int)z * p.tpz, t_end = (t_begin + p.tpz) < p.ntiles ? (t_begin + p.tpz) : p.ntiles;
+    const int ns = t_begin < t_end ? SPT * (t_end - t_begin) : 0;           // hand-over steps of this block (64 pixels each)
+    auto tile_origin = [&](int T, int& n0, int& oh0) {
+        if (p.NI == 1) { n0 = T >> p.tpish; oh0 = (T & ((1 << p.tpish) - 1)) * p.TH; }
+        else { n0 = T * p.NI; oh0 = 0; }
+    };
+    if (wave < 4) {
+        // ------------------------------------------------------------------------------------------------ producers
+        const int pc = tid >> 2, pq = tid & 3;
+        int u_g[QW2_UPT], u_l[QW2_UPT], u_m[QW2_UPT];                 // global offset inside the tile's window, LDS offset of the unit's first dword, patch row | image << 8
+#pragma unroll
+        for (int i = 0; i < QW2_UPT; ++i) {
+            const int g16 = 16 * (pq + 4 * i);
+            if (p.band) {
+                const int pr = g16 >> p.wsh, col = g16 & (p.W - 1);
+                u_g[i] = g16; u_l[i] = pc * p.CS + pr * p.RB + (4 + col) * 2; u_m[i] = pr;
+            } else {
+                const int m = g16 >> p.hwsh, q = g16 & (p.HW - 1), row = q >> p.wsh, col = q & (p.W - 1);
+                u_g[i] = m * p.C * p.HW + q; u_l[i] = pc * p.CS + (m * p.PH + 1 + row) * p.RB + (4 + col) * 2; u_m[i] = 1 | (m << 8);
+            }
+        }
+        int de[4];                                                    // LDS offset of dword e of a unit relative to its first (a unit spans 16 / W rows when W < 16)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) de[e] = ((4 * e) >> p.wsh) * p.RB + ((4 * e) & (p.W - 1)) * 2;
+        const int safe = (cit * 64 + pc) * p.HW;                      // a valid address for the units that lie outside the image / batch
+        u32x4 preg[QW2_UPT];
+        uint32_t pok = 0u;
+        auto fetch_unit = [&](int i, int T) {
+            int n0, oh0;
+            tile_origin(T, n0, oh0);
+            const int base = (p.band ? ((n0 * p.C + cit * 64) * p.H + oh0 - 1) * p.W : (n0 * p.C + cit * 64) * p.HW) + pc * p.HW;
+            const int ih = oh0 - 1 + (u_m[i] & 255), nn = n0 + (u_m[i] >> 8);
+            const bool ok = (unsigned)ih < (unsigned)p.H && nn < p.N;
+            const int off = ok ? base + u_g[i] : safe;
+            preg[i] = *reinterpret_cast<const u32x4*>(p.x + (uint32_t)off);
+            pok = (pok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+        };
+        auto commit_unit = [&](int i, unsigned char* xp) {
+            const uint32_t okm = 0u - ((pok >> i) & 1u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t v = preg[i][e] & okm;                    // (a mask, not a select: no branch around the staged words)
+                float f0, f1, f2, f3;
+                if (XSGN) { f0 = (float)(int)(signed char)(v & 0xffu); f1 = (float)(int)(signed char)((v >> 8) & 0xffu); f2 = (float)(int)(signed char)((v >> 16) & 0xffu); f3 = (float)(int)(signed char)(v >> 24); }
+                else { f0 = (float)(v & 0xffu); f1 = (float)((v >> 8) & 0xffu); f2 = (float)((v >> 16) & 0xffu); f3 = (float)(v >> 24); }
+                *reinterpret_cast<u32x2*>(xp + u_l[i] + de[e]) = u32x2{mn_pack_hi16(f0, f1), mn_pack_hi16(f2, f3)};
+            }
+        };
+        // gy: rows go + 16 i, float4 column gc of the step's 64 pixels
+        const int go = tid >> 4, gc = tid & 15;
+        float4 G[2][4];
+        int gok[2] = {0, 0};
+        auto fetch_gy = [&](int b, int s) {
+            const int sc = s < ns ? s : ns - 1;                        // (past the block's range its own last step is read again: an L2 hit, never committed)
+            int n0, oh0;
+            tile_origin(t_begin + sc / SPT, n0, oh0);
+            const int pt = 64 * (sc % SPT) + 4 * gc;
+            int nn = n0 + (pt >> p.hwsh);
+            const int q = pt & (p.HW - 1);
+            gok[b] = nn < p.N;
+            nn = nn < p.N ? nn : p.N - 1;
+            const float* src = p.gy + (uint32_t)((nn * p.O + cot * 64 + go) * p.HW + oh0 * p.W + q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) G[b][i] = *reinterpret_cast<const float4*>(src + (uint32_t)(16 * i * p.HW));
+        };
+        auto commit_gy = [&](int b) {                                  // register stage b -> gy buffer b (the step's parity)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t gm = 0u - (uint32_t)gok[b];
+                const float4 g4 = make_float4(mn_u2f(mn_f2u(G[b][i].x) & gm), mn_u2f(mn_f2u(G[b][i].y) & gm), mn_u2f(mn_f2u(G[b][i].z) & gm), mn_u2f(mn_f2u(G[b][i].w) & gm));
+                unsigned char* d = dyb + b * NT * QW2_PLANE + (go + 16 * i) * QW2_ROWB + gc * 8;
+                if (NT == 2) {
+                    unsigned h0, l0, h1, l1;
+                    mn_split2_bf16x2(g4.x, g4.y, h0, l0);
+                    mn_split2_bf16x2(g4.z, g4.w, h1, l1);
+                    *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(d + QW2_PLANE) = u32x2{l0, l1};
+                } else {
+                    const float v[4] = {g4.x, g4.y, g4.z, g4.w};
+                    float t0[4], t1[4], t2[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t0[e] = mn_bf16_head(v[e]);
+                        const float r1 = v[e] - t0[e];
+                        t1[e] = mn_bf16_head(r1);
+                        t2[e] = r1 - t1[e];
+                    }
+                    *reinterpret_cast<u32x2*>(d) = u32x2{mn_pack_bf16x2(t0[0], t0[1]), mn_pack_bf16x2(t0[2], t0[3])};
+                    *reinterpret_cast<u32x2*>(d + QW2_PLANE) = u32x2{mn_pack_bf16x2(t1[0], t1[1]), mn_pack_bf16x2(t1[2], t1[3])};
+                    *reinterpret_cast<u32x2*>(d + 2 * QW2_PLANE) = u32x2{mn_pack_bf16x2(t2[0], t2[1]), mn_pack_bf16x2(t2[2], t2[3])};
+                }
+            }
+        };
+        if (ns > 0) {
+            fetch_gy(0, 0);
+            fetch_gy(1, 1);
+#pragma unroll
+            for (int i = 0; i < QW2_UPT; ++i) if (i < p.nu) fetch_unit(i, t_begin);
+        }
+        for (int i = tid; i < (2 * XPB) / 8; i += 768) *reinterpret_cast<u32x2*>(xp0 + 8 * i) = u32x2{0u, 0u};          // the zero frame of both patch buffers (all 12 waves)
+        __syncthreads();                          // barrier Z
+        if (ns > 0) {
+#pragma unroll
+            for (int i = 0; i < QW2_UPT; ++i) {
+                if (i >= p.nu) break;                                 // (uniform)
+                commit_unit(i, xp0);
+                if (t_begin + 1 < t_end) fetch_unit(i, t_begin + 1);
+            }
+            commit_gy(0);
+            fetch_gy(0, 2);
+        }
+        __syncthreads();                          // barrier 0: step 0 (and the first tile's patch) may be read
+        // Barrier s (behind the commit of step s into gy buffer s & 1) releases the consumers' reads of step s; they arrive at barrier s + 1 with every read of step s
+        // complete, so buffer s & 1 is overwritten with step s + 2 behind barrier s + 1.  Patch: tile t + 1's buffer is free once the consumers passed the barrier of
+        // tile t's first step and must be complete at the barrier of tile t + 1's first step: units 0, 1 | 2 | 3 | 4 go with the four steps in between.
+        for (int s0 = 0; s0 < ns; s0 += SPT) {
+            const int tl = s0 / SPT;                                   // tile of steps s0 .. s0 + SPT - 1 (relative to t_begin)
+#pragma unroll
+            for (int ts = 0; ts < SPT; ++ts) {
+                if (ts == 0 && s0 == 0) continue;                     // (step 0 went with the prologue)
+                commit_gy(ts & 1);
+                fetch_gy(ts & 1, s0 + ts + 2);
+                const int ptl = ts == 0 ? tl : tl + 1;                // the tile whose patch this step completes a part of
+                if (t_begin + ptl < t_end) {
+                    unsigned char* xp = xp0 + (ptl & 1) * XPB;
+                    const bool more = t_begin + ptl + 1 < t_end;
+#pragma unroll
+                    for (int i = 0; i < QW2_UPT; ++i) {
+                        // SPT 4: units 0, 1 | 2 | 3 | 4 with steps 1, 2, 3, 0;  SPT 2: unit 0 | 1 with steps 1, 0
+                        const int when = SPT == 4 ? (i < 2 ? 1 : i == 2 ? 2 : i == 3 ? 3 : 0) : (i == 0 ? 1 : 0);
+                        if (when != ts || i >= (SPT == 4 ? QW2_UPT : 2)) continue;
+                        if (i >= 4 && p.nu <= 4) continue;          // (uniform: only the 32-wide band has a fifth unit)
+                        commit_unit(i, xp);
+                        if (more) fetch_unit(i, t_begin + ptl + 1);
+                    }
+                }
+                __syncthreads();                  // barrier s0 + ts
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------------ consumers (fragment reads + MFMA)
+        const int cwv = wave - 4, cf = cwv & 3, coh = cwv >> 2;
+        f32x4 acc[2][9];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        struct AFrag { u32x4 a[2][NT]; };
+        struct BRow { uint32_t w[2][4]; };                                // raw words of one kernel row: [half][previous, two own, next]
+        AFrag aa[2];
+        BRow bb[2];
+        auto load_a = [&](AFrag& A, int buf, int kk) {
+            const unsigned char* gb = dyb + buf * NT * QW2_PLANE + ((2 * coh) * 16 + j) * QW2_ROWB + kk * 64 + kg * 16;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) A.a[c2][t] = *reinterpret_cast<const u32x4*>(gb + t * QW2_PLANE + c2 * 16 * QW2_ROWB);
+        };
+        int boff[2];
+        auto set_b = [&](int ss) {                                        // K-step ss (32 pixels) of the tile: this lane's pixels 32 ss + 8 kg + 4 h ..
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int P = 32 * ss + 8 * kg + 4 * h;
+                const int img = P >> p.hwsh, q = P & (p.HW - 1), ohl = q >> p.wsh, col = q & (p.W - 1);
+                boff[h] = (cf * 16 + j) * p.CS + (img * p.PH + ohl) * p.RB + (4 + col) * 2;
+            }
+        };
+        auto load_b = [&](BRow& B, int par, int r) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned char* q = xp0 + par * XPB + boff[h] + r * p.RB;
+                const u32x2 c = *reinterpret_cast<const u32x2*>(q);
+                B.w[h][0] = *reinterpret_cast<const uint32_t*>(q - 4); B.w[h][1] = c[0]; B.w[h][2] = c[1]; B.w[h][3] = *reinterpret_cast<const uint32_t*>(q + 8);
+            }
+        };
+        auto mma = [&](const AFrag& A, const BRow& B, int r) {
+            u32x4 b[3];
+            {
+                uint32_t lo[3][2], hi[3][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t pv = B.w[h][0], c0 = B.w[h][1], c1 = B.w[h][2], nx = B.w[h][3];
+                    lo[0][h] = mn_alignbyte(c0, pv, 2); hi[0][h] = mn_alignbyte(c1, c0, 2);
+                    lo[1][h] = c0; hi[1][h] = c1;
+                    lo[2][h] = mn_alignbyte(c1, c0, 2); hi[2][h] = mn_alignbyte(nx, c1, 2);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) b[s_] = u32x4{lo[s_][0], hi[s_][0], lo[s_][1], hi[s_][1]};
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)                                   // term-outer: MFMAs on the same accumulator are 6 instructions apart
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) acc[c2][r * 3 + s_] = mn_mfma_bf16(A.a[c2][t], b[s_], acc[c2][r * 3 + s_]);
+        };
+        for (int i = tid; i < (2 * XPB) / 8; i += 768) *reinterpret_cast<u32x2*>(xp0 + 8 * i) = u32x2{0u, 0u};
+        __syncthreads();                          // barrier Z
+        __syncthreads();                          // barrier 0
+        if (ns > 0) {
+            int ss = 0, par = 0;
+            set_b(0);
+            load_a(aa[0], 0, 0);
+            load_b(bb[0], 0, 0);
+            for (int s0 = 0; s0 < ns; s0 += 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {                              // step s0 + u reads gy buffer u
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const int ph = kk * 3 + r;                    // (six phases per step: the two word sets alternate consistently)
+                            if (r < 2) load_b(bb[(ph + 1) & 1], par, r + 1);
+                            else if (kk == 0) {
+                                ++ss;
+                                set_b(ss);
+                                load_a(aa[1], u, 1);
+                                load_b(bb[(ph + 1) & 1], par, 0);
+                            } else if (s0 + u + 1 < ns) {
+                                __syncthreads();                          // barrier s0 + u + 1
+                                if (++ss == 2 * SPT) { ss = 0; par ^= 1; }
+                                set_b(ss);
+                                load_a(aa[0], u ^ 1, 0);
+                                load_b(bb[0], par, 0);
+                            }
+                            MN_SCHED_FENCE();
+                            mma(aa[kk], bb[ph & 1], r);
+                        }
+                }
+            }
+        }
+        float* dst = p.part + ((int64_t)((int)z * p.npairs + pair) * 9) * 4096 + (cf * 16 + j) * 64 + (2 * coh) * 16 + 4 * kg;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) *reinterpret_cast<float4*>(dst + t * 4096 + c2 * 16) = make_float4(acc[c2][t][0], acc[c2][t][1], acc[c2][t][2], acc[c2][t][3]);
+    }
+}
+struct Qdw2Plan { Qdw2Params p; int SPT, grid; size_t lds; int64_t ws_bytes; };
+static int plan_qdw2(const mn_conv_geom* g, int NT, Qdw2Plan* pl) {
+    if (!qd_geom_ok(g) || g->stride_h != 1 || g->KH != 3 || g->KW != 3 || g->pad_h != 1) return 0;
+    Qdw2Params& p = pl->p;
+    p.N = g->N; p.C = g->C; p.O = g->O; p.H = g->H; p.W = g->W; p.HW = g->H * g->W;
+    p.wsh = qd_log2(p.W); p.hwsh = qd_log2(p.HW);
+    if (p.wsh < 2 || p.W > 32 || p.hwsh < 4) return 0;
+    if ((int64_t)g->N * g->C * p.HW >= ((int64_t)1 << 31) || (int64_t)g->N * g->O * p.HW >= ((int64_t)1 << 31)) return 0;
+    p.ncit = g->C / 64; p.npairs = (g->O / 64) * p.ncit;
+    p.fd_np = make_fastdiv((uint32_t)p.npairs);
+    for (int SPT = 4; SPT >= 2; SPT >>= 1) {
+        const int TP = 64 * SPT, tsh = SPT == 4 ? 8 : 7;          // pixels per tile
+        if (p.HW >= TP) { p.NI = 1; p.TH = TP / p.W; p.tpish = p.hwsh - tsh; }
+        else { p.NI = TP / p.HW; p.TH = p.H; p.tpish = 0; }
+        p.band = p.TH < p.H;
+        if (p.band && p.W < 16) continue;                     // (a 16-code unit must lie inside one row of a band)
+        p.PH = p.TH + 2; p.RB = (p.W + 4) * 2;                  // rows share their pads: [4 zeros][W codes] per row, 4 more zeros behind the channel's last row
+        p.CS = p.NI * p.PH * p.RB + 8;
+        if (((p.CS / 8) & 1) == 0) p.CS += 8;                 // odd multiple of 8 bytes: the 16 channels of a fragment fall on distinct 8-byte bank groups
+        const int upc = p.band ? p.PH * p.W / 16 : TP / 16;   // 16-code units per channel and tile
+        if (upc % 4 || upc / 4 > (SPT == 4 ? QW2_UPT : 2)) continue;
+        p.nu = upc / 4;
+        pl->lds = (size_t)2 * NT * QW2_PLANE + (size_t)2 * 64 * p.CS;
+        if (pl->lds > 160 * 1024) continue;
+        p.ntiles = p.NI == 1 ? g->N << p.tpish : (g->N + p.NI - 1) / p.NI;
+        int Z = 256 / p.npairs;
+        if (Z > p.ntiles) Z = p.ntiles;
+        if (Z < 1) Z = 1;
+        p.tpz = (p.ntiles + Z - 1) / Z;
+        p.Z = (p.ntiles + p.tpz - 1) / p.tpz;
+        pl->SPT = SPT;
+        pl->grid = p.npairs * p.Z;
+        pl->ws_bytes = (int64_t)p.Z * p.npairs * 9 * 4096 * 4;
+        return 1;
+    }
+    return 0;
+}
 int qd_wgrad_supported(const mn_conv_geom* g, int a_bits) {
     if (a_bits < 2 || a_bits > 7) return 0;
     QdwPlan pl;
     return plan_qdw(g, &pl);
 }
-int64_t qd_wgrad_ws_bytes(const mn_conv_geom* g) { QdwPlan pl; return plan_qdw(g, &pl) ? pl.ws_bytes : 0; }
+int64_t qd_wgrad_ws_bytes(const mn_conv_geom* g) {
+    QdwPlan pl;
+    Qdw2Plan p2;
+    const int64_t a = plan_qdw(g, &pl) ? pl.ws_bytes : 0, b = plan_qdw2(g, qd_terms(), &p2) ? p2.ws_bytes : 0;
+    return a > b ? a : b;
+}
 int qd_bwd_weight(const mn_conv_geom* g, const float* gy, const uint8_t* x, float ascale, float* dw, void* ws, int64_t ws_bytes, hipStream_t s) {
     return qd_bwd_weight_ex(g, gy, x, 0, ascale, nullptr, dw, ws, ws_bytes, s);
 }
 // xsgn: x holds signed codes; ascale_dev != nullptr: the activation scale is read from the device (IAO qparams snapshot)
 int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, int xsgn, float ascale, const float* ascale_dev, float* dw, void* ws, int64_t ws_bytes,
                      hipStream_t s) {
+    {
+        Qdw2Plan p2;
+        const int NT = qd_terms();
+        if (plan_qdw2(g, NT, &p2) && aligned16(gy) && aligned16(x) && ws && ws_bytes >= p2.ws_bytes && aligned16(ws)) {
+            Qdw2Params& q = p2.p;
+            q.gy = gy; q.x = x; q.part = reinterpret_cast<float*>(ws);
+            mn_set_last_kernel("k_qd_wgrad2<%d, %d, %d>", NT, xsgn ? 1 : 0, p2.SPT);
+            { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * q.HW; mn_prof_bytes(4.0 * ny * q.ncit + nx * (g->O / 64) + (double)p2.ws_bytes); mn_prof_flops(2.0 * ny * g->C * 9); }
+            mn_prof_begin(s);
+#define QW2_LAUNCH(N_, X_, S_) do { raise_lds_limit((const void*)k_qd_wgrad2<N_, X_, S_>, p2.lds); hipLaunchKernelGGL((k_qd_wgrad2<N_, X_, S_>), dim3(p2.grid), dim3(768), p2.lds, s, q); } while (0)
+#define QW2_LAUNCH_S(N_, X_) do { if (p2.SPT == 4) QW2_LAUNCH(N_, X_, 4); else QW2_LAUNCH(N_, X_, 2); } while (0)
+            if (NT == 2) { if (xsgn) QW2_LAUNCH_S(2, 1); else QW2_LAUNCH_S(2, 0); }
+            else { if (xsgn) QW2_LAUNCH_S(3, 1); else QW2_LAUNCH_S(3, 0); }
+#undef QW2_LAUNCH_S
+#undef QW2_LAUNCH
+            mn_prof_end(s);
+            const int total = q.npairs * 9 * 4096;
+            hipLaunchKernelGGL(k_qd_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(256), 0, s, (const float*)q.part, dw, (int)g->O, (int)g->C, 9, q.Z, ascale, ascale_dev);
+            MN_CHECK_LAUNCH("mn_conv2d_bwd_weight(dense)");
+            return MN_OK;
+        }
+    }
     QdwPlan pl;
     if (!plan_qdw(g, &pl) || !aligned16(gy) || (((uintptr_t)x) & 3)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_weight(dense): geometry not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense): workspace too small");

@@ -478,7 +478,7 @@ def test_dorefa_weight_quantizer_multi_cached(be):
             assert np.array_equal(q, q2) and np.array_equal(d, d2)
 
 
-@pytest.mark.parametrize("case", [0, 1, 4, 6])
+@pytest.mark.parametrize("case", [0, 1, 4, 6, 9])
 def test_qdense_layer_iao(be, case):
     xs, Oc, k, s = K.QDENSE_CASES[case]
     K.check_qdense_iao(be, xs, Oc, k, s, seed=400 + case)
