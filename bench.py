@@ -226,7 +226,7 @@ def measure(workload, args, world, rank, device):
 
     for _ in range(args.warmup):
         one_step()
-    windows = []
+    windows, rank_dts = [], []
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
@@ -236,13 +236,37 @@ def measure(workload, args, world, rank, device):
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            every = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            rank_dts.append([float(e.item()) for e in every])
+            dt = max(rank_dts[-1])
         windows.append(dt)
     from micronet_amd import ops as _ops
     fallbacks = _ops.fallback_counts(reset=True)           # stock-operator fall-throughs seen while this workload ran (warm-up, capture, eager steps): expected {}
     dt = sorted(windows)[len(windows) // 2]                 # the median window (an odd count by default)
     final_loss = float(loss.detach())
+    # data-parallel runs: what the step's collectives cost by themselves -- the gradient bucket(s) all-reduced 10 times back to back, HIP events on the stream
+    dp_info = None
+    if dp.active() and graphed is not None and getattr(graphed, "flat", None) is not None:
+        bufs = [b for b in (graphed.flat, getattr(graphed, "flat2", None)) if b is not None]
+        scratch = [torch.zeros_like(b) for b in bufs]
+        us = []
+        for b in scratch:
+            for _ in range(3):
+                dist.all_reduce(b)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dist.all_reduce(b)
+            e1.record()
+            torch.cuda.synchronize()
+            us.append(round(100.0 * e0.elapsed_time(e1), 1))
+        med = rank_dts[len(rank_dts) // 2] if rank_dts else None
+        dp_info = {"grad_buckets_bytes": [int(b.numel() * b.element_size()) for b in bufs], "allreduce_us": us,
+                   "two_buckets": getattr(graphed, "graph_a2", None) is not None, "one_bucket_reason": getattr(graphed, "one_bucket_reason", None),
+                   "rank_ms_per_step": ([round(1000.0 * d / args.steps, 3) for d in (min(med), max(med))] if med else None)}
+        del scratch
     # IAO models: the EAGER data-parallel step (dp.GradSync; at world > 1 one 2-float range collective per activation quantizer, ~360 launches issued from
     # Python) next to the graph-replayed one (at world > 1 captured in segments cut at those collectives: micronet_amd/train.py), at every N, so that the cost of
     # either path is a number (`eager_dp_value`, `graph_segments`)
@@ -280,7 +304,7 @@ def measure(workload, args, world, rank, device):
     del graphed, model, opt, sync
     torch.cuda.empty_cache()
     return dict(dt=dt, dt_min=min(windows), windows=windows, final_loss=final_loss, hip_graph=graph_err is None and not args.no_graph, graph_err=graph_err, agg=agg,
-                eager_dp=eager_dp, fallbacks=fallbacks, segments=segments)
+                eager_dp=eager_dp, fallbacks=fallbacks, segments=segments, dp_info=dp_info)
 
 
 def dp_single_rank(workloads, args, device):
@@ -301,7 +325,7 @@ def dp_single_rank(workloads, args, device):
             try:
                 m = measure(w, a, 1, 0, device)
                 out[w] = {"value": round(args.batch * args.steps / m["dt"], 1), "ms_per_step": round(1000.0 * m["dt"] / args.steps, 3), "hip_graph": m["hip_graph"],
-                          **({"graph_segments": m["segments"]} if m.get("segments") else {})}
+                          **({"graph_segments": m["segments"]} if m.get("segments") else {}), **({"allreduce_us": m["dp_info"]["allreduce_us"], "two_buckets": m["dp_info"]["two_buckets"]} if m.get("dp_info") else {})}
             except Exception as e:          # noqa: BLE001
                 out[w] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
     except Exception as e:          # noqa: BLE001 -- a reported extra: the line must survive it
@@ -351,6 +375,8 @@ def section(workload, m, args, world, pmc):
         out["eager_dp_value"] = round(args.batch * world * args.steps / m["eager_dp"], 1)
     if m.get("segments"):
         out["graph_segments"] = m["segments"]
+    if m.get("dp_info"):
+        out["dp"] = m["dp_info"]
     agg = m["agg"]
     if agg:
         ks = args.kernel_steps
@@ -535,7 +561,7 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         out["config"]["dist"] = dist_info
     if "hip_graph_error" in sec:
         out["config"]["hip_graph_error"] = sec["hip_graph_error"][:200]
-    for k in ("graph_segments", "eager_dp_value"):          # IAO data parallel: the segmented replay and the eager step it replaces
+    for k in ("graph_segments", "eager_dp_value", "dp"):    # IAO data parallel: the segmented replay and the eager step it replaces; dp: bucket bytes, the all-reduce's own us, per-rank ms
         if k in sec:
             out["config"][k] = sec[k]
     detail = {"headline": dict(out), "sections": {primary: sec}}
@@ -551,7 +577,7 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         s["metric"] = METRIC.get(w, "QAT images/sec (%s)" % w)
         s["steps"], s["warmup"], s["n_gpus"] = args.steps, args.warmup, world
         detail["sections"][w] = s
-        also_out[w] = {"value": s["value"], "ms_per_step": s["ms_per_step"], "hip_graph": s["hip_graph"], **({k: s[k] for k in ("eager_dp_value", "graph_segments") if k in s}),
+        also_out[w] = {"value": s["value"], "ms_per_step": s["ms_per_step"], "hip_graph": s["hip_graph"], **({k: s[k] for k in ("eager_dp_value", "graph_segments", "dp") if k in s}),
                        **({"roofline": {k: s["roofline"][k] for k in ("bound", "kernel", "frac", "avg_launch_us", "traffic") if k in s["roofline"]}} if "roofline" in s else {})}
     for w, e in also_err.items():
         also_out[w] = {"error": e[:200]}

@@ -79,8 +79,11 @@ def bump_bn_counters(model):
             m.__dict__["_mn_nbt_pre"] = True
 
 
-def prefetch_weight_path(model):
-    """Quantize the weights of every W-ternary conv of ``model`` NOW, in one launch (ops.MultiTernaryWeight: one autograd node, so the
+def prefetch_weight_path(model, late=None):
+    """``late`` (two-bucket data-parallel step, GraphedTrainStep): ids of the modules behind the bucket boundary -- every multi-tensor weight node is then built
+    per bucket, so that the late bucket's weight gradients exist when the first half of backward ends (one node over all weights would run last).
+
+    Quantize the weights of every W-ternary conv of ``model`` NOW, in one launch (ops.MultiTernaryWeight: one autograd node, so the
     backward is one launch too); the owning conv picks its tensor up in its forward.  A step of nin_gc saves 12 launches of ~5 us.
     (A second stream for this path was measured slower under graph replay -- the fork / join edges cost more than the launches they hide -- and is gone.)
 
@@ -96,8 +99,8 @@ def prefetch_weight_path(model):
         if isinstance(m, (dr.QuantConv2d, dr.QuantLinear)) and not m.quant_inference and 2 <= m.weight_quantizer.w_bits <= 31 and m.weight.is_cuda \
                 and m.weight.is_contiguous():
             m.weight_quantizer.__dict__.pop("_mn_pre", None)
-            by_bits.setdefault(m.weight_quantizer.w_bits, []).append(m)
-    for bits, ms in by_bits.items():
+            by_bits.setdefault((m.weight_quantizer.w_bits, bool(late) and id(m) in late), []).append(m)
+    for (bits, _), ms in by_bits.items():
         for i in range(0, len(ms), 32):
             grp = ms[i:i + 32]
             if len(grp) < 2:
@@ -124,8 +127,9 @@ def prefetch_weight_path(model):
                                    "forward since); its observer would advance twice in one iteration -- see the contract in this function's docstring")
             if 2 <= q.bits <= 24 and not q.qaft and getattr(obs, "q_level", None) in ("C", "FC") and getattr(obs, "_kind", None) in (0, 1) \
                     and not getattr(obs, "_mn_sync", False) and obs.min_val.numel() == m.weight.shape[0]:
-                groups.setdefault((q.bits, q._q_type_static, obs._kind, float(getattr(obs, "momentum", 0.1))), []).append(m)
+                groups.setdefault((q.bits, q._q_type_static, obs._kind, float(getattr(obs, "momentum", 0.1)), bool(late) and id(m) in late), []).append(m)
     for cfg, ms in groups.items():
+        cfg = cfg[:4]
         for i in range(0, len(ms), 32):
             grp = ms[i:i + 32]
             if len(grp) < 2:
@@ -148,8 +152,12 @@ def prefetch_weight_path(model):
     for m in mods:
         m.weight_quantizer.__dict__.pop("_mn_pre", None)
     tern = [m for m in mods if m.weight_quantizer.W == 3 and m.weight.is_cuda and m.weight.is_contiguous()]
-    for i in range(0, len(tern), 32):
-        grp = tern[i:i + 32]
+    if late:
+        tern = [m for m in tern if id(m) not in late] + [m for m in tern if id(m) in late]
+    bounds = [0, sum(1 for m in tern if id(m) not in late), len(tern)] if late else [0, len(tern)]
+    for lo_, hi_ in zip(bounds[:-1], bounds[1:]):
+      for i in range(lo_, hi_, 32):
+        grp = tern[i:min(i + 32, hi_)]
         if len(grp) < 2:
             continue
         qws = ops.MultiTernaryWeight.apply(*[m.weight for m in grp])
@@ -157,6 +165,40 @@ def prefetch_weight_path(model):
             m.weight_quantizer._mn_pre = (m.weight, wq, None)
         ops.pack_pointwise_weights(list(zip(grp, qws)), (ops.WQ_TERNARY, 0, 0, 0, None))          # the pointwise blocks' code images: one launch for the net
     return
+
+
+def pick_bucket_boundary(model):
+    """Where the data-parallel gradient exchange of the graphed step is split in two: a top-level stage of ``model`` such that the parameters BEHIND it (the late
+    bucket: backward produces their gradients first) can be all-reduced while the stages up to it are still in backward.  Returns (boundary module, [late
+    parameters], [early parameters]) or None (one bucket).  MN_DP_BUCKETS=1 forces one bucket, =2 asks for two whatever the size; the default is two from 16 MB of
+    gradients (resnet18: 44.7 MB -- the boundary falls behind conv3_x: 42 MB overlap the remaining half of backward, 2.7 MB stay exposed; nin_gc's 2.4 MB: one)."""
+    import os
+    env = os.environ.get("MN_DP_BUCKETS", "")
+    params = [p for p in model.parameters() if p.requires_grad]
+    total = sum(p.numel() * p.element_size() for p in params)
+    if env == "1" or (env != "2" and total < (16 << 20)):
+        return None
+    root = model
+    while True:                                   # descend through wrappers that hold everything in one child (nin_gc: Net.tnn_bin)
+        kids = [k for k in root.children()]
+        with_p = [k for k in kids if any(p.requires_grad for p in k.parameters())]
+        if len(with_p) == 1 and len(list(with_p[0].children())) > 1:
+            root = with_p[0]
+        else:
+            break
+    if len(kids) < 3:
+        return None
+    convs = [sum(1 for m in k.modules() if isinstance(m, (nn.Conv2d, nn.Linear))) for k in kids]
+    nconv = max(1, sum(convs))
+    for i in range(len(kids) - 1):                # the earliest boundary that leaves >= 40 % of the weight layers (the work of the second half of backward) in front of it
+        if sum(convs[:i + 1]) >= 0.4 * nconv and sum(convs[i + 1:]) > 0:
+            early_ids = {id(p) for k in kids[:i + 1] for p in k.parameters()}
+            early = [p for p in params if id(p) in early_ids]
+            late = [p for p in params if id(p) not in early_ids]
+            if early and late:
+                return kids[i], late, early
+            return None
+    return None
 
 
 class GraphedTrainStep:
@@ -167,7 +209,9 @@ class GraphedTrainStep:
     world == 1: one graph = forward + loss + zero_grad + backward + Adam.
     world  > 1: graph A = forward + loss + zero_grad + backward + packing of all gradients into one flat bucket (already
     divided by the world size); the RCCL all-reduce of that bucket runs eagerly on the same stream; graph B = Adam reading
-    the reduced bucket.  (nin_gc: one 2.4 MB collective per step.)  IAO models whose activation observers reduce their
+    the reduced bucket.  (nin_gc: one 2.4 MB collective per step.)  From 16 MB of gradients (resnet18) the step has TWO buckets:
+    graph A1 ends where backward reaches the output of a boundary stage (``pick_bucket_boundary``), the late bucket's all-reduce
+    overlaps graph A2 (the rest of backward), the small early bucket follows, then graph B.  IAO models whose activation observers reduce their
     range over the ranks (dp.sync_observers) are captured in SEGMENTS cut at those collectives -- ``self.segments`` --
     and replayed as segment, range collective, segment, ..., graph A, gradient all-reduce, graph B.
 
@@ -201,6 +245,15 @@ class GraphedTrainStep:
         # the backend being able to record a collective into a graph.
         self.segments = []                    # [(graph, operand of the collective that follows it, group)]
         self._segmented = self.dp and any(getattr(m, "_mn_sync", False) for m in model.modules())
+        # Two gradient buckets (pick_bucket_boundary): graph A1 = forward + loss + backward down to the boundary stage's output + packing of the late bucket; its
+        # all-reduce is issued asynchronously and overlaps graph A2 = the rest of backward + packing of the early bucket; that bucket's all-reduce; graph B = Adam.
+        # The boundary is made an autograd LEAF (forward hook: the stage's output is replaced by its detached twin), so each half is an ordinary backward call.
+        self.bound = pick_bucket_boundary(model) if self.dp else None
+        self._late_mods = None
+        if self.bound is not None:
+            late_ids = {id(p) for p in self.bound[1]}
+            self._late_mods = {id(m) for m in model.modules() if any(id(p) in late_ids for p in m.parameters(recurse=False))}
+        self.graph_a2, self.flat2, self.one_bucket_reason = None, None, None
         if not hasattr(optimizer, "capturable"):
             raise TypeError("GraphedTrainStep needs micronet_amd.optim.Adam")
         optimizer.capturable = True
@@ -230,16 +283,22 @@ class GraphedTrainStep:
                 try:
                     if self._segmented:
                         dp._segment_cut = lambda buf, group: self._cut(buf, group, pool)
-                    self._fwd_bwd()
+                    self._fwd_bwd(mid=(lambda: self._cut_backward(pool)) if self.bound is not None else None)
                     if not self.dp:
                         optimizer.step()
+                    elif self.bound is not None:
+                        self.flat2 = torch.cat([p.grad.reshape(-1) for p in self.bound[2]])
+                        self.flat2.div_(self.world)
                     else:
                         self.flat = torch.cat([p.grad.reshape(-1) for p in self.params])
                         self.flat.div_(self.world)
                 finally:
                     dp._segment_cut = None
                     self._capturing.capture_end()
-            self.graph_a = self._capturing    # the LAST segment (the only one without range collectives)
+            if self.bound is not None:
+                self.graph_a2 = self._capturing    # (graph_a was closed by _cut_backward)
+            else:
+                self.graph_a = self._capturing    # the LAST segment (the only one without range collectives)
         except Exception as e:          # noqa: BLE001 -- a failed capture must leave a usable process behind
             torch.cuda.synchronize()
             optimizer.capturable = False
@@ -247,31 +306,70 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(cap)
         if self.dp:
             self._captured_grads = [p.grad for p in self.params]   # graph A writes these on every replay: keep them allocated
-            off = 0
-            for p in self.params:             # Adam reads the reduced bucket in place
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            for flat, ps in ((self.flat, self.params),) if self.bound is None else ((self.flat, self.bound[1]), (self.flat2, self.bound[2])):
+                off = 0
+                for p in ps:                  # Adam reads the reduced buckets in place
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
                 optimizer.step()
 
-    def _fwd_bwd(self):
-        prefetch_weight_path(self.model)                     # all weight quantizers of the step in one launch (and one in backward)
+    def _fwd_bwd(self, mid=None):
+        prefetch_weight_path(self.model, late=self._late_mods)   # all weight quantizers of the step in one launch (and one in backward) per gradient bucket
         bump_bn_counters(self.model)
-        self.output = self.model(self.data)
+        if self.bound is None:
+            self.output = self.model(self.data)
+            self.loss = F.cross_entropy(self.output, self.target)
+            self.optimizer.zero_grad(set_to_none=True)
+            self.loss.backward()
+            return
+        cutpt = {}
+
+        def leaf(mod, inp, out):          # the boundary stage's output becomes a leaf: backward stops there, the second call continues from it
+            if type(out) is not torch.Tensor or not out.requires_grad:
+                cutpt["bad"] = type(out).__name__                # a packed hand-over (QActTensor / SignTensor: codes + lazily expanded gradients cross this edge): one bucket
+                return None
+            cutpt["out"] = out
+            cutpt["leaf"] = out.detach().requires_grad_(True)
+            return cutpt["leaf"]
+        h = self.bound[0].register_forward_hook(leaf)
+        try:
+            self.output = self.model(self.data)
+        finally:
+            h.remove()
         self.loss = F.cross_entropy(self.output, self.target)
         self.optimizer.zero_grad(set_to_none=True)
-        self.loss.backward()
+        if "leaf" not in cutpt:
+            self.bound, self._late_mods, self.one_bucket_reason = None, None, "boundary output is a %s" % cutpt.get("bad", "tensor outside the graph")
+            self.loss.backward()
+            return
+        self.loss.backward()                                  # gradients of the late bucket + of the boundary leaf
+        if mid is not None:
+            mid()
+        g = cutpt["leaf"].grad
+        cutpt["leaf"].grad = None
+        cutpt["out"].backward(g)                              # the early bucket
+
+    def _cut_backward(self, pool):
+        """Capture only: pack the late bucket behind the first half of backward, end graph A1 and begin graph A2."""
+        self.flat = torch.cat([p.grad.reshape(-1) for p in self.bound[1]])
+        self.flat.div_(self.world)
+        self._capturing.capture_end()
+        self.graph_a = self._capturing
+        self._capturing = torch.cuda.CUDAGraph()
+        self._capturing.capture_begin(pool=pool)
 
     def _reduce_eager(self):
         if self.dp:
             import torch.distributed as dist
-            flat = torch.cat([p.grad.reshape(-1) for p in self.params]).div_(self.world)
-            dist.all_reduce(flat, group=self.group)
-            off = 0
-            for p in self.params:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            for ps in ((self.params,) if self.bound is None else (self.bound[1], self.bound[2])):
+                flat = torch.cat([p.grad.reshape(-1) for p in ps]).div_(self.world)
+                dist.all_reduce(flat, group=self.group)
+                off = 0
+                for p in ps:
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
 
     def _cut(self, buf, group, pool):
         """End the segment being captured at a range collective on ``buf`` (allocated by the segment: a fixed address of the graphs' pool) and begin the next."""
@@ -295,7 +393,18 @@ class GraphedTrainStep:
             self.graph_a.replay()
             if self._host_sync:
                 torch.cuda.current_stream().synchronize()
-            dist.all_reduce(self.flat, group=self.group)
+            if self.graph_a2 is None:
+                dist.all_reduce(self.flat, group=self.group)
+            else:
+                # RCCL: the late bucket's all-reduce runs on the communicator's stream behind graph A1 (async_op) while graph A2 -- the rest of backward -- replays
+                # on this one; both collectives are joined in front of graph B
+                w1 = dist.all_reduce(self.flat, group=self.group, async_op=True)
+                self.graph_a2.replay()
+                if self._host_sync:
+                    torch.cuda.current_stream().synchronize()
+                w2 = dist.all_reduce(self.flat2, group=self.group, async_op=True)
+                w1.wait()
+                w2.wait()
             self.graph_b.replay()
         else:
             self.graph_a.replay()

@@ -87,6 +87,36 @@ def _worker(rank, world, port, q, what):
         if rank == 0:
             q.put(dict(segments=len(g.segments), ranges=len(ranges), bad=bad, gerr=gerr, loss=float(loss), in_sync=bool(torch.equal(other[0], other[1])),
                        moved=float((flat - torch.cat([p.detach().reshape(-1) for p in m1.parameters()])).abs().max())))
+    elif what == "buckets":
+        # the graphed data-parallel step of IAO resnet18 (44.7 MB of gradients) with ONE gradient bucket and with TWO (graph A1 | late bucket's all-reduce overlapping
+        # graph A2 | early bucket | graph B): same kernels on the same data, the same element-wise sums over the ranks -> the same parameters
+        from micronet_amd.train import GraphedTrainStep
+        from micronet.compression.quantization.wqaq.iao import quantize as Q
+
+        def run(nb):
+            os.environ["MN_DP_BUCKETS"] = nb
+            torch.manual_seed(7)
+            m = Q.prepare(build_model("resnet18"), inplace=True, a_bits=4, w_bits=4, q_type=0, q_level=0).cuda().train()
+            dp.broadcast_parameters(m)
+            assert dp.sync_observers(m) > 0
+            o = make_optimizer(m, 0.01, 0.0)
+            g = GraphedTrainStep(m, o, xs, ys, warmup=2)
+            for _ in range(3):
+                loss, _ = g.step()
+            g.finish()
+            torch.cuda.synchronize()
+            return m, g, float(loss)
+        m1, g1, l1 = run("1")
+        m2, g2, l2 = run("2")
+        os.environ.pop("MN_DP_BUCKETS", None)
+        flat = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
+        other = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        f1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()])
+        if rank == 0:
+            q.put(dict(two=(g1.graph_a2 is not None, g2.graph_a2 is not None), reason=g2.one_bucket_reason, buckets=(g2.flat.numel(), g2.flat2.numel() if g2.flat2 is not None else 0),
+                       segments=(len(g1.segments), len(g2.segments)), losses=(l1, l2), same=bool(torch.equal(f1, flat)), perr=float((f1 - flat).abs().max()),
+                       in_sync=bool(torch.equal(other[0], other[1]))))
     else:
         from micronet.compression.quantization.wbwtab import quantize as Q
         model = Q.prepare(build_model("nin_gc"), inplace=True, A=2, W=3).cuda().train()
@@ -153,6 +183,18 @@ def test_segmented_graph_step_equals_the_eager_dp_step(what):
     assert r["bad"] == [], r["bad"][:5]
     assert r["gerr"] <= 2e-5, r["gerr"]
     assert r["in_sync"] and r["loss"] == r["loss"] and 0 < r["moved"] <= 0.021
+
+
+def test_two_gradient_buckets_equal_one():
+    """resnet18 (IAO): graph A1 -> all-reduce of the late bucket (conv4_x, conv5_x, fc: 40 MB) overlapping graph A2 -> all-reduce of the early bucket (2.6 MB) -> graph B
+    leaves the parameters of a three-step run where the one-bucket step leaves them (gloo: element-wise sums in rank order), on both ranks."""
+    r = _run("buckets")
+    print(r)
+    assert r["two"] == (False, True), r
+    assert r["buckets"][0] > 8 * r["buckets"][1] > 0, r["buckets"]
+    assert r["segments"][0] == r["segments"][1] >= 4
+    assert r["in_sync"] and r["losses"][0] == r["losses"][0]
+    assert r["same"] or r["perr"] <= 1e-6, r
 
 
 def _single_rank_worker(port, q):
