@@ -268,6 +268,10 @@ typedef struct mn_actq {
                         store -- after the quantizer's clip-STE: dx = STE(W^T gy) + dx_add.  The gradient a residual block's identity shortcut carries to the same input
                         (models/resnet.py:60-65 with QuantAdd, wqaq/iao/quantize.py:1484-1498) then needs no add kernel of its own.  NULL: none.  A call that cannot honour
                         it fails with MN_ENOTSUP (never silently drops it). */
+    void* ste_mask;  /* optional, together with `codes` (same layers): mn_conv2d_iao_codes_bytes(g, aq, wq) / 8 bytes owned by the caller.  mn_conv2d_fwd then also leaves the
+                        quantizer's clip-STE decision of every element there -- bit e of byte i: does the gradient of element 8 i + e pass (Round.backward and the clamp,
+                        wqaq/iao/quantize.py:163-168, 232) -- and a later mn_conv2d_bwd_data handed the SAME buffer (same x, same qp) applies the STE from those bits instead
+                        of reading the fp32 x again (4 bytes per element -> 1 bit; bit-identical dx).  NULL: backward-data reads x. */
 } mn_actq;
 
 /* How the (already fake-quantised, fp32 OIHW) weight tensor factors into integer codes x per-channel scale.  The

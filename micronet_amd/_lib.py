@@ -24,7 +24,7 @@ class ConvGeom(C.Structure):
 
 class ActQ(C.Structure):
     _fields_ = [("mode", C.c_int32), ("bits", C.c_int32), ("q_type", C.c_int32), ("flags", C.c_int32),
-                ("qp", C.c_void_p), ("codes", C.c_void_p), ("stats", C.c_void_p), ("dx_add", C.c_void_p)]
+                ("qp", C.c_void_p), ("codes", C.c_void_p), ("stats", C.c_void_p), ("dx_add", C.c_void_p), ("ste_mask", C.c_void_p)]
 
 
 class WQ(C.Structure):

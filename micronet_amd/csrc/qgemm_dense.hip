@@ -876,6 +876,7 @@ struct QddParams {
     int wsc_stride;
     const float* ste_x;           // IAO: the conv's fp32 input -- the activation quantizer's clip-STE (ref 163-168, 232) is applied while dx is stored; nullptr: none
     const float* ste_qp;          // {scale, zero point, lo, hi} on the device
+    const unsigned char* ste_mask; // IAO: the same decisions as bits (mn_actq.ste_mask, written by the forward's k_qd_iao_codes): bit e of byte i = element 8 i + e passes; replaces ste_x
     const float* dx_add;          // nullable: added to dx in the store, after the clip-STE (mn_actq.dx_add: the identity shortcut's gradient of a residual block)
     float ste_qmin, ste_qmax;
     int N, C, Hg, Wg, O, HWg;
@@ -1081,8 +1082,12 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
         int n0, oh0, cit;
         tile_origin(item, n0, oh0, cit);
         float s_sc = 1.f, s_zp = 0.f, s_lo = 0.f, s_hi = 0.f;
-        if (p.ste_x) { s_sc = p.ste_qp[0]; s_zp = p.ste_qp[1]; s_lo = p.ste_qp[2]; s_hi = p.ste_qp[3]; }
+        if (p.ste_x || p.ste_mask) { s_sc = p.ste_qp[0]; s_zp = p.ste_qp[1]; s_lo = p.ste_qp[2]; s_hi = p.ste_qp[3]; }
         const float s_inv = 1.0f / s_sc;
+        auto ste4m = [&](float4 v, uint32_t m) {                   // iao_fq_grad_m with the two conditions read from the forward's bits
+            return make_float4((m & 1u) ? mn_div_m(v.x * s_sc, s_sc, s_inv) : 0.f, (m & 2u) ? mn_div_m(v.y * s_sc, s_sc, s_inv) : 0.f,
+                               (m & 4u) ? mn_div_m(v.z * s_sc, s_sc, s_inv) : 0.f, (m & 8u) ? mn_div_m(v.w * s_sc, s_sc, s_inv) : 0.f);
+        };
         auto ste4 = [&](float4 v, const float* xp) {
             const float4 xv = *reinterpret_cast<const float4*>(xp);
             return make_float4(iao_fq_grad_m(v.x, xv.x, s_sc, s_inv, s_zp, s_lo, s_hi, p.ste_qmin, p.ste_qmax), iao_fq_grad_m(v.y, xv.y, s_sc, s_inv, s_zp, s_lo, s_hi, p.ste_qmin, p.ste_qmax),
@@ -1101,7 +1106,8 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
 #pragma unroll
                 for (int nf = 0; nf < 4; ++nf) {
                     float4 v = make_float4(acc[0][mf][nf][0] * p.wscale, acc[0][mf][nf][1] * p.wscale, acc[0][mf][nf][2] * p.wscale, acc[0][mf][nf][3] * p.wscale);
-                    if (p.ste_x) v = ste4(v, p.ste_x + base + (uint32_t)(nf * 16 * p.HWg));
+                    if (p.ste_mask) { const uint32_t e0 = base + (uint32_t)(nf * 16 * p.HWg); v = ste4m(v, (uint32_t)p.ste_mask[e0 >> 3] >> (e0 & 4u)); }
+                    else if (p.ste_x) v = ste4(v, p.ste_x + base + (uint32_t)(nf * 16 * p.HWg));
                     if (p.dx_add) { const float4 a = *reinterpret_cast<const float4*>(p.dx_add + base + (uint32_t)(nf * 16 * p.HWg)); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
                     *reinterpret_cast<float4*>(p.dx + base + (uint32_t)(nf * 16 * p.HWg)) = v;
                 }
@@ -1117,7 +1123,8 @@ __global__ __launch_bounds__(256, 2) void k_qd_dgrad(const QddParams p) {
                         float* dst = p.dx + off;
                         float4 v0 = make_float4(e[0] * p.wscale, o[0] * p.wscale, e[1] * p.wscale, o[1] * p.wscale);
                         float4 v1 = make_float4(e[2] * p.wscale, o[2] * p.wscale, e[3] * p.wscale, o[3] * p.wscale);
-                        if (p.ste_x) { v0 = ste4(v0, p.ste_x + off); v1 = ste4(v1, p.ste_x + off + 4); }
+                        if (p.ste_mask) { const uint32_t mb = p.ste_mask[off >> 3]; v0 = ste4m(v0, mb); v1 = ste4m(v1, mb >> 4); }
+                        else if (p.ste_x) { v0 = ste4(v0, p.ste_x + off); v1 = ste4(v1, p.ste_x + off + 4); }
                         if (p.dx_add) {
                             const float4 a0 = *reinterpret_cast<const float4*>(p.dx_add + off), a1 = *reinterpret_cast<const float4*>(p.dx_add + off + 4);
                             v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w; v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
@@ -1200,7 +1207,7 @@ int qd_bwd_data(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const f
     QddParams& p = pl.p;
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_bwd);
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s); wpk = reinterpret_cast<const uint16_t*>(ws); }
-    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0; p.ste_x = nullptr; p.ste_qp = nullptr; p.dx_add = nullptr;
+    p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f / (float)((1ll << wq->bits) - 1); p.wsc = nullptr; p.wsc_stride = 0; p.ste_x = nullptr; p.ste_qp = nullptr; p.ste_mask = nullptr; p.dx_add = nullptr;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d, %d>", pl.MF, pl.S, p.TAPS, qd_terms());
     { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 4.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
@@ -2075,11 +2082,22 @@ int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, i
 // direction first writes the codes once -- k_qd_iao_codes, 4 B in / 1 B out per element -- into its workspace and then runs the dense kernels above on them:
 // forward with the fp32 epilogue, backward-data with the per-channel scale folded into gy followed by the quantizer's clip-STE (k_qd_iao_ste, in place),
 // backward-weight on the signed codes with the activation scale taken from the device snapshot.
-__global__ __launch_bounds__(256) void k_qd_iao_codes(const float* __restrict__ x, signed char* __restrict__ codes, int64_t n8, const float* __restrict__ qp, float qmin, float qmax) {
-    const float sc = qp[0];
+// mask (nullable): one byte per thread = the clip-STE decisions of its 8 elements (iao_fq_grad's two conditions on the same v), read back by k_qd_dgrad's store
+__global__ __launch_bounds__(256) void k_qd_iao_codes(const float* __restrict__ x, signed char* __restrict__ codes, unsigned char* __restrict__ mask, int64_t n8,
+                                                      const float* __restrict__ qp, float qmin, float qmax) {
+    const float sc = qp[0], zp = qp[1], rlo = qp[2], rhi = qp[3];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const float4 a = *reinterpret_cast<const float4*>(x + 8 * i), b = *reinterpret_cast<const float4*>(x + 8 * i + 4);
         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (mask) {
+            uint32_t m = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float vv = v[e] / sc - zp, r = mn_rha(vv);
+                m |= ((r >= qmin && r <= qmax && !(vv > rhi || vv < rlo)) ? 1u : 0u) << e;
+            }
+            mask[i] = (unsigned char)m;
+        }
         uint32_t lo = 0u, hi = 0u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -2134,12 +2152,12 @@ int64_t qd_iao_ws_bytes(const mn_conv_geom* g, int which) {
     if (which == 2) { QdwPlan pl; return plan_qdw(g, &pl) ? qd_iao_codes_bytes(g) + pl.ws_bytes : 0; }
     return 0;
 }
-static void qd_iao_launch_codes(const mn_conv_geom* g, const mn_actq* aq, const float* x, void* codes, hipStream_t s) {
+static void qd_iao_launch_codes(const mn_conv_geom* g, const mn_actq* aq, const float* x, void* codes, void* mask, hipStream_t s) {
     const int64_t n8 = (int64_t)g->N * g->C * g->H * g->W / 8;
     const IaoRange r = iao_range(aq->bits, 0, 1);
     int64_t nb = (n8 + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(k_qd_iao_codes, dim3((unsigned)nb), dim3(256), 0, s, x, (signed char*)codes, n8, aq->qp, r.qmin, r.qmax);
+    hipLaunchKernelGGL(k_qd_iao_codes, dim3((unsigned)nb), dim3(256), 0, s, x, (signed char*)codes, (unsigned char*)mask, n8, aq->qp, r.qmin, r.qmax);
 }
 int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* x, const float* w, const float* bias, float* y, void* ws, int64_t ws_bytes,
                hipStream_t s) {
@@ -2151,7 +2169,7 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
     QdfParams& p = pl.p;
     void* cbuf = aq->codes ? aq->codes : ws;          // a caller-owned buffer keeps the codes for backward-weight
     if (!aligned16(cbuf)) MN_FAIL(MN_EINVAL, "mn_conv2d_fwd(dense iao): mn_actq.codes is not 16-byte aligned");
-    qd_iao_launch_codes(g, aq, x, cbuf, s);
+    qd_iao_launch_codes(g, aq, x, cbuf, aq->codes ? aq->ste_mask : nullptr, s);          // (+ the clip-STE bits for backward-data when the caller keeps the codes)
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_fwd);
     if (!wpk) {
         qd_launch_pack(w, reinterpret_cast<uint16_t*>((char*)ws + cb), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s, wq->scale, wq->per_channel);
@@ -2173,7 +2191,8 @@ int qd_iao_dx_add_supported(const mn_conv_geom* g, const mn_actq* aq, const mn_w
 int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const float* gy, const float* w, const float* x, float* dx, void* ws, int64_t ws_bytes,
                     hipStream_t s) {
     QddPlan pl;
-    if (!qd_iao_quant_ok(g, aq, wq, 2) || !plan_qdd(g, &pl) || !aligned16(gy) || !aligned16(dx) || !aligned16(x) || !w)
+    const unsigned char* smask = aq && aq->codes ? reinterpret_cast<const unsigned char*>(aq->ste_mask) : nullptr;          // the forward's clip-STE bits: x is not read
+    if (!qd_iao_quant_ok(g, aq, wq, 2) || !plan_qdd(g, &pl) || !aligned16(gy) || !aligned16(dx) || (!smask && (!x || !aligned16(x))) || !w)
         MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense iao): geometry / quantizer not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_data(dense iao): workspace too small");
     QddParams& p = pl.p;
@@ -2181,11 +2200,11 @@ int qd_iao_bwd_data(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, c
     if (!wpk) { qd_launch_pack(w, reinterpret_cast<uint16_t*>(ws), g->O, g->C, p.TAPS, wq->bits, 1, s, wq->scale, wq->per_channel); wpk = reinterpret_cast<const uint16_t*>(ws); }
     p.gy = gy; p.wpk = wpk; p.dx = dx; p.wscale = 1.0f; p.wsc = wq->scale; p.wsc_stride = wq->per_channel;
     const IaoRange r = iao_range(aq->bits, 0, 1);
-    p.ste_x = x; p.ste_qp = aq->qp; p.ste_qmin = r.qmin; p.ste_qmax = r.qmax;          // the quantizer's clip-STE rides the store of dx
+    p.ste_x = smask ? nullptr : x; p.ste_mask = smask; p.ste_qp = aq->qp; p.ste_qmin = r.qmin; p.ste_qmax = r.qmax;          // the quantizer's clip-STE rides the store of dx
     if (aq->dx_add && !aligned16(aq->dx_add)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_bwd_data(dense iao): mn_actq.dx_add needs a 16-byte aligned tensor");
     p.dx_add = aq->dx_add;
     mn_set_last_kernel("k_qd_dgrad<%d, %d, %d, %d>", pl.MF, pl.S, p.TAPS, qd_terms());
-    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + 8.0 * nx); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
+    { const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * p.HWg; mn_prof_bytes(4.0 * ny * p.ncit + (smask ? 4.125 : 8.0) * nx + (p.dx_add ? 4.0 * nx : 0.0)); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
     qd_launch_dgrad(pl, s);
     mn_prof_end(s);
@@ -2207,7 +2226,7 @@ int qd_iao_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy,
     const int64_t cb = qd_iao_codes_bytes(g);
     if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_bwd_weight(dense iao): workspace too small");
     const void* cbuf = aq->codes ? aq->codes : ws;
-    if (!aq->codes) qd_iao_launch_codes(g, aq, x, ws, s);          // else: the forward of this step left them there
+    if (!aq->codes) qd_iao_launch_codes(g, aq, x, ws, nullptr, s);          // else: the forward of this step left them there
     if (dbias) hipLaunchKernelGGL(k_qd_bias_grad, dim3((unsigned)g->O), dim3(256), 0, s, gy, dbias, (int)g->N, (int)g->O, pl.p.HWg);
     return qd_bwd_weight_ex(g, gy, (const uint8_t*)cbuf, 1, 1.f, aq->qp, dw, (char*)ws + cb, ws_bytes - cb, s);
 }

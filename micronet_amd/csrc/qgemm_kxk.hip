@@ -453,7 +453,7 @@ int kk_fwd_h8(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const flo
     if (!kk_h8_supported(g, wq) || !plan_kk(g, 0, MN_ACTQ_SIGN8, &pl) || (((uintptr_t)x) & 3) || (((uintptr_t)h) & 3))
         MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd_stash(k x k): geometry / quantizer combination not covered");
     if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_qconv_bnsign_fwd_stash(k x k): workspace too small");
-    mn_actq aq; aq.mode = MN_ACTQ_SIGN8; aq.bits = 8; aq.q_type = 0; aq.flags = 0; aq.qp = nullptr; aq.codes = nullptr; aq.stats = nullptr; aq.dx_add = nullptr;
+    mn_actq aq; aq.mode = MN_ACTQ_SIGN8; aq.bits = 8; aq.q_type = 0; aq.flags = 0; aq.qp = nullptr; aq.codes = nullptr; aq.stats = nullptr; aq.dx_add = nullptr; aq.ste_mask = nullptr;
     Pro pro;
     int rc = make_pro(&aq, &pro, 0, "mn_qconv_bnsign_fwd_stash(k x k)");
     if (rc) return rc;

@@ -1704,12 +1704,15 @@ class QConv2d(Function):
                 aq.stats = stats.data_ptr()
         if packed is not None and packed[0] is not None:
             wd.packed_fwd = packed[0].data_ptr()
-        codes = None
+        codes = ste_mask = None
         if aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[1]:
             nc = int(_lib_().mn_conv2d_iao_codes_bytes(C.byref(g), C.byref(aq), C.byref(wd)))
             if nc > 0:          # dense IAO layer: the forward's signed activation codes are kept for backward-weight (1 byte per element)
                 codes = torch.empty(nc, dtype=torch.int8, device=x.device)
                 aq.codes = codes.data_ptr()
+                if ctx.needs_input_grad[0]:          # ... and the quantizer's clip-STE decisions for backward-data (1 bit per element instead of a second read of x)
+                    ste_mask = torch.empty(nc // 8, dtype=torch.uint8, device=x.device)
+                    aq.ste_mask = ste_mask.data_ptr()
         with torch.cuda.device_of(x):
             ws, nb = _ws(g, 0, x.device)
             with _span(g, 0, 4 * (x.numel() + y.numel() + wq.numel())):
@@ -1719,7 +1722,7 @@ class QConv2d(Function):
             stats = None          # the library took another kernel (workspace / alignment): nothing wrote the sums -- the BatchNorm computes its own statistics
         if stats is not None:          # (stats, rows, activation qparams, per-channel weight scale, its stride, conv bias): what mn_bn_fwd_acc reads
             _PENDING_ACCSTATS[0] = (stats, stats.shape[0], qp, wscale, int(wdesc[3]), bias)
-        ctx.iao_codes = codes
+        ctx.iao_codes, ctx.iao_mask = codes, ste_mask
         ctx.res_tok = None
         if (RES_ADD_FOLD and aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[0]
                 and type(x) is torch.Tensor and _lib_().mn_conv2d_bwd_data_add_supported(C.byref(g), C.byref(aq), C.byref(wd))):
@@ -1806,6 +1809,8 @@ class QConv2d(Function):
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         if getattr(ctx, "iao_codes", None) is not None:
             aq.codes = ctx.iao_codes.data_ptr()
+            if getattr(ctx, "iao_mask", None) is not None:
+                aq.ste_mask = ctx.iao_mask.data_ptr()
         wd = _wq_desc(wd4 + (wscale,)) if wd4 is not None else None
         if wd is not None and getattr(ctx, "packed", None) is not None and ctx.packed[1] is not None:
             wd.packed_bwd = ctx.packed[1].data_ptr()

@@ -1851,6 +1851,24 @@ def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=Fa
     assert np.array_equal(be.to_host(dw_a), be.to_host(dw_b))
     # the IAO weight codes written once by mn_qd_pack_multi (codes = rint(w / scale[o])): same forward and backward-data without reading w again
     dx1 = be.to_host(be.conv_bwd_data(g, aq0, dG, dW, dX, 3, wq=wq))
+    # the clip-STE decisions kept as bits by the forward (mn_actq.ste_mask) and applied by backward-data without reading x: the same dx, to the bit -- with the
+    # range above (nothing clipped) and with half of it (a good part of the elements clipped: both conditions of iao_fq_grad decide)
+    for shrink in (1.0, 0.5):
+        sc2, zp2 = O.iao_qparams((mn * F(shrink)).reshape(1), (mx * F(shrink)).reshape(1), a_bits, 0, True)
+        hi2 = max(abs(mn * F(shrink) / sc2[0]), abs(mx * F(shrink) / sc2[0]))
+        dqp2 = be.to_dev(np.array([sc2[0], zp2[0], -hi2, hi2], dtype=F))
+        aqx = be.actq(2, a_bits, 0, dqp2)
+        dxx = be.to_host(be.conv_bwd_data(g, aqx, dG, dW, dX, 3, wq=wq))
+        smask = be.empty_i8((nc // 8,))
+        aqm = be.actq(2, a_bits, 0, dqp2)
+        aqm.codes, aqm.ste_mask = be.ptr(codes).value, be.ptr(smask).value
+        be.conv_fwd(g, aqm, dX, dW, None, 3, wq=wq)
+        dxm = be.to_host(be.conv_bwd_data(g, aqm, dG, dW, be.to_dev(np.full(x_shape, np.nan, dtype=F)), 3, wq=wq))
+        assert np.array_equal(dxm, dxx), ("ste_mask", shrink)
+        if shrink < 1.0:
+            assert 0.002 * dxx.size < np.count_nonzero(dxx == 0) < 0.9 * dxx.size          # (the clip is exercised)
+    aq.codes = be.ptr(codes).value
+    be.conv_fwd(g, aq, dX, dW, None, 3, wq=wq)          # (the codes of the original range again, for what follows)
     pb = int(be.lib.mn_qd_packed_bytes(C.byref(g)))
     pk_f, pk_b = be.empty_i8((pb,)), be.empty_i8((pb,))
     PA, LA, IA = C.c_void_p * 1, C.c_int64 * 1, C.c_int32 * 1
