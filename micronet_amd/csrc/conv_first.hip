@@ -619,8 +619,13 @@ __global__ __launch_bounds__(256) void k_c1_reduce(const float* __restrict__ par
 //     dw[o][k] = gamma invstd (A[o][k] - S1 P[k] / n - (S2 / n) B[o][k]),   dgamma = S2,   dbeta = S1
 // so ONE pass over (da, y) -- k_c1_wgrad<.., DZ 1> -- replaces the sums pass (k_bns_partial<1> / k_qa_partial<1, 0>: 98 us on nin_gc at batch 256) AND the fold in
 // the backward-weight's operand load; G, P (76 x 76 numbers) come from x alone (k_c1_xgram: the c3 block's idea, iao_bnfuse.hip, applied to the image).
+// Conditioning (round 6): the variance is the cancelling form w (G - P P^T / n) w^T.  With G accumulated in fp32 per block its error is the fp32 error of G times
+// mean(f)^2 / var(f) (un-normalised 0..255 images: large) times |w|^2 lambda_max / var_y (difference filters: large).  So the kernel accumulates the Gram data of
+// SHIFTED features f_k - c[channel(k)], c = the mean of the first <= 256 pixels of each input-channel plane of image 0 (any constant near the mean does; every block
+// computes the same one), which takes the mean out of the cancellation; k_c1_gram_unshift then rebuilds the raw G, P the consumers are written for in fp64:
+// G = G' + c P'^T + P' c^T + n c c^T, P = P' + n c -- consistent with the centred data to fp64 rounding, so G - P P^T / n recovers it.
 #define C1G_TILE (15 * 256)          // floats per partial: the 15 tile pairs ta <= tb of the 80 x 80 Gram matrix
-__global__ __launch_bounds__(256) void k_c1_xgram(const C1Params p, float* __restrict__ gpart) {
+__global__ __launch_bounds__(256) void k_c1_xgram(const C1Params p, float* __restrict__ gpart, float* __restrict__ shift) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
     float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + p.xs_bytes);          // [4 waves][C1G_TILE]
@@ -633,6 +638,16 @@ __global__ __launch_bounds__(256) void k_c1_xgram(const C1Params p, float* __res
     // ADDRESS; selecting the loaded VALUE made every one of the 20 reads of a pixel group a branch of its own (28 us against 13 us of matrix work)
     const int ones_off = p.C * p.CS;
     if (tid < 4) xs[ones_off + tid] = 1.f;
+    __shared__ float csh[80], cred[16];
+    {
+        const int hw = p.H * p.W, ns = hw < 256 ? hw : 256;
+        for (int c = 0; c < p.C; ++c) {          // (C <= 76; CIFAR: 3)
+            const float v = tid < ns ? p.x[(int64_t)c * hw + tid] : 0.f;
+            const float sum = block_reduce(v, OpAddF(), 0.f, cred);
+            if (tid == 0) { csh[c] = sum / (float)ns; if (blockIdx.x == 0) shift[c] = csh[c]; }
+        }
+        __syncthreads();
+    }
     f32x4 acc[15];
 #pragma unroll
     for (int i = 0; i < 15; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -641,6 +656,8 @@ __global__ __launch_bounds__(256) void k_c1_xgram(const C1Params p, float* __res
         const int n = tile / p.strips, strip = tile - n * p.strips, row0 = strip * p.R;
         __syncthreads();
         c1_stage(p, xs, n, row0);
+        __syncthreads();
+        for (int i = tid; i < p.C * p.CS; i += 256) xs[i] -= csh[i / p.CS];          // the shifted features (the zero padding becomes -c: a shift of EVERY feature value)
         __syncthreads();
         for (int gi = wave; gi < ngroups; gi += 4) {
             // MFMA step e contracts the pixels 4 kq + e: the lane's value of feature tile t is at once A[i = j][kq] and B[kq][j]
@@ -706,6 +723,20 @@ __global__ __launch_bounds__(64 * C1G_ZG) void k_c1_xgram_final(const float* __r
         const int tb = ta + pr, a = ta * 16 + ((i >> 4) & 15), b = tb * 16 + (i & 15);
         gram[a * 80 + b] = v;
         if (ta != tb) gram[b * 80 + a] = v;
+    }
+}
+// gram (shifted features, from k_c1_xgram_final) -> the raw Gram data in place (fp64): one block
+__global__ __launch_bounds__(256) void k_c1_gram_unshift(double* __restrict__ gram, const float* __restrict__ shift, int K, int T) {
+    __shared__ double P[80], c[80];
+    const int t = threadIdx.x;
+    if (t < 80) { P[t] = t < K ? gram[K * 80 + t] : 0.0; c[t] = t < K ? (double)shift[t / T] : 0.0; }
+    __syncthreads();
+    const double n = gram[K * 80 + K];
+    for (int i = t; i < 80 * 80; i += 256) {
+        const int a = i / 80, b = i - a * 80;
+        if (a < K && b < K) gram[i] += c[a] * P[b] + P[a] * c[b] + n * c[a] * c[b];
+        else if (a == K && b < K) gram[i] = P[b] + n * c[b];
+        else if (b == K && a < K) gram[i] = P[a] + n * c[a];
     }
 }
 // the end of the one-pass backward: block o sums its partial row A[o][0 .. 79] in the fixed order of k_c1_reduce and does the per-channel algebra above in fp64
@@ -1023,13 +1054,14 @@ static int c1_xgram_grid(const C1Plan& pl) {
 int64_t c1_xgram_ws_bytes(const mn_conv_geom* g) {
     C1Plan pl;
     if (!plan_c1(g, &pl, 0)) return 0;          // the forward's strips: two blocks per CU
-    return (int64_t)c1_xgram_grid(pl) * C1G_TILE * 4;
+    return (int64_t)c1_xgram_grid(pl) * C1G_TILE * 4 + 512;          // + the shift constants (<= 76 floats) behind the partials
 }
 int c1_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int64_t ws_bytes, hipStream_t s) {
     C1Plan pl;
     if (!plan_c1(g, &pl, 0) || !c1_supported(g, 2)) MN_FAIL(MN_ENOTSUP, "mn_conv2d_first_xgram: geometry not covered by the first-layer kernels");
     const int Zg = c1_xgram_grid(pl);
-    if (!ws || ws_bytes < (int64_t)Zg * C1G_TILE * 4 || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_first_xgram: workspace too small");
+    if (!ws || ws_bytes < (int64_t)Zg * C1G_TILE * 4 + 512 || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_first_xgram: workspace too small");
+    float* shift = (float*)ws + (int64_t)Zg * C1G_TILE;
     C1Params& p = pl.p;
     p.x = x;
     const size_t lds_b = (size_t)p.xs_bytes + (size_t)4 * C1G_TILE * 4;
@@ -1037,9 +1069,10 @@ int c1_xgram(const mn_conv_geom* g, const float* x, double* gram, void* ws, int6
     mn_prof_bytes(4.0 * g->N * g->C * g->H * g->W);
     mn_prof_begin(s);
     raise_lds_limit((const void*)k_c1_xgram, lds_b);
-    hipLaunchKernelGGL(k_c1_xgram, dim3(Zg), dim3(256), lds_b, s, p, (float*)ws);
+    hipLaunchKernelGGL(k_c1_xgram, dim3(Zg), dim3(256), lds_b, s, p, (float*)ws, shift);
     mn_prof_end(s);
     hipLaunchKernelGGL(k_c1_xgram_final, dim3(C1G_TILE / 64), dim3(64 * C1G_ZG), 0, s, (const float*)ws, Zg, gram);
+    hipLaunchKernelGGL(k_c1_gram_unshift, dim3(1), dim3(256), 0, s, gram, (const float*)shift, p.K, p.KH * p.KW);
     MN_CHECK_LAUNCH("mn_conv2d_first_xgram");
     return MN_OK;
 }

@@ -926,6 +926,38 @@ def check_first_conv_gram_bwd(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, kind="bn", q
     assert np.abs(be.to_host(db)).max() <= 1e-4 * max(np.abs(be.to_host(dbet)).max(), 1e-30)
 
 
+def check_first_conv_gram_conditioning(be, x_shape=(16, 3, 16, 16), Oc=16, k=3, seed=0):
+    """The Gram-data statistics of the first block on what conditions them worst: un-normalised 0..255 images (mean^2 >> variance) that are smooth (neighbouring taps
+    almost equal) under zero-sum difference filters (var_y << |w|^2 lambda_max(G)).  The kernel accumulates the Gram data of mean-shifted features and rebuilds the
+    raw data in fp64 (k_c1_gram_unshift), so mean / invstd still agree with the statistics of y = conv(x, w) itself."""
+    r = np.random.default_rng(seed)
+    N, Cin, H, W = x_shape
+    base = r.uniform(60, 200, size=(N, Cin, 1, 1))
+    ramp = np.linspace(0, 1, W)[None, None, None, :] * r.uniform(-20, 20, size=(N, Cin, 1, 1)) + np.linspace(0, 1, H)[None, None, :, None] * r.uniform(-20, 20, size=(N, Cin, 1, 1))
+    x = np.clip(base + ramp + r.standard_normal(x_shape) * 2.0, 0, 255).astype(F)
+    w = (r.standard_normal((Oc, Cin, k, k)) * 0.2)
+    w[: Oc // 2] -= w[: Oc // 2].mean(axis=(1, 2, 3), keepdims=True)          # half of the filters zero-sum over all taps (edge / difference filters)
+    w = w.astype(F)
+    b = (r.standard_normal(Oc) * 0.3).astype(F)
+    g = be.geom(x_shape, (Oc, Cin, k, k), padding=k // 2)
+    dX, dW, dBi = be.to_dev(x), be.to_dev(w), be.to_dev(b)
+    import torch
+    yh = torch.nn.functional.conv2d(torch.from_numpy(x.astype(np.float64)), torch.from_numpy(w.astype(np.float64)), torch.from_numpy(b.astype(np.float64)), 1, k // 2).numpy()
+    mean, var = yh.mean(axis=(0, 2, 3)), yh.var(axis=(0, 2, 3))
+    nbg = int(be.lib.mn_conv2d_first_xgram_ws_bytes(C.byref(g)))
+    wsg, gram = be.empty(nbg // 4 + 4), be.empty(2 * 80 * 80)
+    be.call("mn_conv2d_first_xgram", C.byref(g), be.ptr(dX), be.ptr(gram), be.ptr(wsg), nbg, be.stream)
+    sv = be.empty((2, Oc))
+    be.call("mn_conv2d_first_gram_bnstats", C.byref(g), be.ptr(dW), be.ptr(dBi), be.ptr(gram), 1e-5, 0.1, None, None, be.ptr(sv), be.stream)
+    svh = be.to_host(sv)
+    K = Cin * k * k
+    G = be.to_host(gram).view(np.float64).reshape(80, 80)
+    assert close(G[:K + 1, :K + 1], _im2col_gram(x, k), 2e-6)
+    assert np.abs(svh[0] - mean).max() <= 2e-6 * max(np.abs(mean).max(), np.sqrt(var).max())
+    err = np.abs(svh[1] * np.sqrt(var + 1e-5) - 1).max()
+    assert err <= 2e-5, err          # (the un-shifted fp32 accumulation: 1e-3 ... 1e-1 on these inputs)
+
+
 def check_first_conv_fused(be, x_shape=(3, 3, 8, 8), Oc=24, k=5, act=1, bits=2, bias=True, seed=0):
     """The fused first block (mn_conv2d_first_bnact_fwd: conv + BatchNorm + sign / ReLU + quantizer in one kernel, codes + pass bits instead of y; backward on
     (da, mask4)) against the unfused kernels on the same statistics: identical codes, identical masks, bit-identical gradients."""

@@ -815,3 +815,9 @@ def test_iaobf_thin_output_family(be, shuffle, bias):
 def test_iaobf_gram_statistics_never_negative_variance(be):
     import iaobf_cases as B
     B.check_gram_stats_variance_clamp(be)
+
+
+def test_first_conv_gram_statistics_on_unnormalised_images_and_difference_filters(be):
+    K.check_first_conv_gram_conditioning(be)
+    K.check_first_conv_gram_conditioning(be, x_shape=(8, 3, 32, 32), Oc=24, k=5, seed=3)
+    K.check_first_conv_gram_conditioning(be, x_shape=(1024, 3, 32, 32), Oc=32, k=5, seed=4)          # 2048 pixels per block in fp32: 1e-3 ... 1e-1 without the shift
