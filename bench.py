@@ -549,6 +549,7 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
                    "hip_graph": sec["hip_graph"], "final_loss": sec["final_loss"],
                    # quantized layers that fell through to a stock torch operator while any workload of this run executed (expected 0)
                    "quant_layer_fallbacks": sum(sec.get("stock_fallbacks", {}).values()) + sum(sum(s_.get("stock_fallbacks", {}).values()) for s_ in also_secs.values()),
+                   "stock_fallbacks": sum(sec.get("stock_fallbacks", {}).values()) + sum(sum(s_.get("stock_fallbacks", {}).values()) for s_ in also_secs.values()),          # (the key's name until round 5: kept for readers of older lines)
                    # launches per EAGER step of kernels that are NOT this library's (MIOpen BatchNorm of the un-quantised tail, loss, ATen fills / copies / counters),
                    # counted in the PMC passes (null without them); the graph-replayed step's own count is in profiles/r05_<w>_summary.md
                    "stock_kernels_per_eager_step": sec.get("step_level", {}).get("stock_kernel_launches_per_step"),

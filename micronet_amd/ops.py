@@ -1823,7 +1823,9 @@ class QConv2d(Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
                 ws, nb = _ws(g, 1, x.device)
+                # (every operand the dense kernel insists on is checked here: a misaligned view must take the dx.add_ fallback below, not raise inside backward)
                 fold = d_sc is not None and d_sc.shape == dx.shape and d_sc.is_contiguous() and d_sc.data_ptr() % 16 == 0 and wd is not None and \
+                    gy.data_ptr() % 16 == 0 and (x.data_ptr() % 16 == 0 or getattr(ctx, "iao_mask", None) is not None) and \
                     bool(_lib_().mn_conv2d_bwd_data_add_supported(C.byref(g), C.byref(aq), C.byref(wd)))
                 if fold:
                     aq.dx_add = d_sc.data_ptr()

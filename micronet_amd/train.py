@@ -5,6 +5,8 @@ zero biases, N(0, 0.01) linear weights); ``make_optimizer`` is ``main.py:308-315
 tensor); ``train_step`` is the loop body ``main.py:77-82``; ``synth_batch`` is the CIFAR-10-shaped synthetic batch
 of SURVEY.md 8(d) (generated on CPU so the CPU oracle and the GPU see identical bits).
 """
+import sys
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -292,9 +294,16 @@ class GraphedTrainStep:
                     else:
                         self.flat = torch.cat([p.grad.reshape(-1) for p in self.params])
                         self.flat.div_(self.world)
+                except BaseException:
+                    self.segments.clear()                 # (graphs captured so far are dropped with their pool references)
+                    raise
                 finally:
                     dp._segment_cut = None
-                    self._capturing.capture_end()
+                    try:
+                        self._capturing.capture_end()
+                    except Exception:                      # noqa: BLE001 -- a cut that failed half-way leaves no open capture: the ORIGINAL error must surface
+                        if sys.exc_info()[0] is None:
+                            raise
             if self.bound is not None:
                 self.graph_a2 = self._capturing    # (graph_a was closed by _cut_backward)
             else:
