@@ -356,6 +356,9 @@ __device__ __forceinline__ int dw_find(const DwTable& t, int b) {
     while (ti + 1 < t.count && t.b0[ti + 1] <= b) ++ti;
     return ti;
 }
+__device__ __forceinline__ bool dw_vec_ok(const void* a, const void* b, const void* c, const void* d, long long n) {
+    return (n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
 __global__ __launch_bounds__(256) void k_dorefa_w_absmax_multi(const DwTable t) {
     __shared__ float sc[16];
     const int ti = dw_find(t, blockIdx.x), lb = blockIdx.x - t.b0[ti], nb = t.nb[ti];
@@ -363,10 +366,20 @@ __global__ __launch_bounds__(256) void k_dorefa_w_absmax_multi(const DwTable t) 
     const long long n = t.n[ti];
     float m = 0.f;
     float* __restrict__ th = t.th[ti];
-    for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nb * 256) {
-        const float tt = mn_tanh_cr(w[i]);
-        if (th) th[i] = tt;
-        m = OpMaxF()(m, fabsf(tt));
+    if (dw_vec_ok(w, th, nullptr, nullptr, n)) {          // (max is order-independent and the cache element-wise: any assignment of elements to blocks gives the same bits)
+        const long long n4 = n >> 2;
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < n4; i += (long long)nb * 256) {
+            const float4 v = *reinterpret_cast<const float4*>(w + 4 * i);
+            const float4 tt = make_float4(mn_tanh_cr(v.x), mn_tanh_cr(v.y), mn_tanh_cr(v.z), mn_tanh_cr(v.w));
+            if (th) *reinterpret_cast<float4*>(th + 4 * i) = tt;
+            m = OpMaxF()(OpMaxF()(OpMaxF()(OpMaxF()(m, fabsf(tt.x)), fabsf(tt.y)), fabsf(tt.z)), fabsf(tt.w));
+        }
+    } else {
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nb * 256) {
+            const float tt = mn_tanh_cr(w[i]);
+            if (th) th[i] = tt;
+            m = OpMaxF()(m, fabsf(tt));
+        }
     }
     m = block_reduce(m, OpMaxF(), 0.f, sc);
     if (threadIdx.x == 0) t.ws[ti][16 + lb] = m;
@@ -386,16 +399,37 @@ __global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int pha
     if (phase == 0) {
         if (lb == 0 && threadIdx.x == 0) ws[0] = M;
         float* __restrict__ qw = t.out[ti];
-        for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
-            const float tt = th ? th[i] : mn_tanh_cr(w[i]);
-            const float u = (tt / 2.f) / M + 0.5f;
-            const float q = mn_rha(u / s) * s;
-            qw[i] = 2.f * q - 1.f;
+        auto q1 = [&](float tt) { const float u = (tt / 2.f) / M + 0.5f; const float q = mn_rha(u / s) * s; return 2.f * q - 1.f; };
+        if (th && dw_vec_ok(th, qw, nullptr, nullptr, n)) {
+            const long long n4 = n >> 2;
+            for (long long i = (long long)lb * 256 + threadIdx.x; i < n4; i += (long long)nbk * 256) {
+                const float4 tt = *reinterpret_cast<const float4*>(th + 4 * i);
+                *reinterpret_cast<float4*>(qw + 4 * i) = make_float4(q1(tt.x), q1(tt.y), q1(tt.z), q1(tt.w));
+            }
+        } else {
+            for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) qw[i] = q1(th ? th[i] : mn_tanh_cr(w[i]));
         }
     } else if (phase == 1) {
         double acc = 0.0;
         float ties = 0.f;
-        for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
+        // (the element -> block assignment and each thread's order of additions are the single-tensor kernel's: the partials round identically; four strides are
+        //  FETCHED at a time so that eight loads are in flight per thread)
+        const long long st = (long long)nbk * 256;
+        long long i = (long long)lb * 256 + threadIdx.x;
+        if (th) {
+            for (; i + 3 * st < n; i += 4 * st) {
+                float tv[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { tv[u] = th[i + u * st]; gv[u] = g[i + u * st]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float du = ((gv[u] * 2.f) * s) / s;
+                    acc += (double)(-du * (tv[u] / 2.f) / (M * M));
+                    ties += (fabsf(tv[u]) == M) ? 1.f : 0.f;
+                }
+            }
+        }
+        for (; i < n; i += st) {
             const float tt = th ? th[i] : mn_tanh_cr(w[i]);
             const float du = ((g[i] * 2.f) * s) / s;
             acc += (double)(-du * (tt / 2.f) / (M * M));
@@ -413,12 +447,20 @@ __global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int pha
         if (lb == 0 && threadIdx.x == 0) { ws[1] = dM; ws[2] = cnt; }
         const float share = dM / cnt;
         float* __restrict__ dw = t.out[ti];
-        for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) {
-            const float tt = th ? th[i] : mn_tanh_cr(w[i]);
-            const float du = ((g[i] * 2.f) * s) / s;
+        auto d1 = [&](float tt, float gi) {
+            const float du = ((gi * 2.f) * s) / s;
             float dt = (du / M) / 2.f;
             if (fabsf(tt) == M) dt += share * mn_sign(tt);
-            dw[i] = dt * (1.f - tt * tt);
+            return dt * (1.f - tt * tt);
+        };
+        if (th && dw_vec_ok(th, g, dw, nullptr, n)) {
+            const long long n4 = n >> 2;
+            for (long long i = (long long)lb * 256 + threadIdx.x; i < n4; i += (long long)nbk * 256) {
+                const float4 tt = *reinterpret_cast<const float4*>(th + 4 * i), gv = *reinterpret_cast<const float4*>(g + 4 * i);
+                *reinterpret_cast<float4*>(dw + 4 * i) = make_float4(d1(tt.x, gv.x), d1(tt.y, gv.y), d1(tt.z, gv.z), d1(tt.w, gv.w));
+            }
+        } else {
+            for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nbk * 256) dw[i] = d1(th ? th[i] : mn_tanh_cr(w[i]), g[i]);
         }
     }
 }
