@@ -251,6 +251,9 @@ typedef struct mn_conv_geom {
 #define MN_ACTQ_X_IS_CODE 1 /* flags: optional hint that with MN_ACTQ_NONE x holds small integers exact in bf16 (the +-1 of
                               wbwtab's BinaryActivation, wbwtab/quantize.py:13-19).  Never required: real-valued x is split
                               into exact bf16 terms on the fly and all-zero terms are skipped. */
+#define MN_ACTQ_CODES_GIVEN 2 /* flags, MN_ACTQ_IAO forward of a dense layer: mn_actq.codes (and .ste_mask) ALREADY hold this forward's activation codes -- written by
+                                 mn_bn_apply_codes, the BatchNorm [+ ReLU] in front fused with this conv's quantizer (models/resnet.py:17-29 under
+                                 wqaq/iao/quantize.py:492-507) -- so mn_conv2d_fwd quantises nothing and never reads x (pass any aligned non-NULL pointer). */
 typedef struct mn_actq {
     int32_t mode;    /* MN_ACTQ_* */
     int32_t bits;
@@ -272,6 +275,10 @@ typedef struct mn_actq {
                         quantizer's clip-STE decision of every element there -- bit e of byte i: does the gradient of element 8 i + e pass (Round.backward and the clamp,
                         wqaq/iao/quantize.py:163-168, 232) -- and a later mn_conv2d_bwd_data handed the SAME buffer (same x, same qp) applies the STE from those bits instead
                         of reading the fp32 x again (4 bytes per element -> 1 bit; bit-identical dx).  NULL: backward-data reads x. */
+    void* acc_mm;    /* optional, same layers and row count R as `stats`: R * O * 2 int32 owned by the caller.  mn_conv2d_fwd leaves the per-channel extrema of its integer
+                        accumulator there -- acc_mm[(r * O + o) * 2 + {0, 1}] = min acc, max acc over the (valid) pixels of partial r.  y = al[o] * acc + bias[o] and the
+                        BatchNorm [+ ReLU] behind it are monotone in acc per channel, so the (min, max) of THAT activation -- what the next layer's observer wants
+                        (wqaq/iao/quantize.py:23-36) -- follow without a pass over it: mn_bn_acc_prep.  NULL: none. */
 } mn_actq;
 
 /* How the (already fake-quantised, fp32 OIHW) weight tensor factors into integer codes x per-channel scale.  The
@@ -394,6 +401,25 @@ int mn_bn_fwd_acc(const float* y, int64_t N, int64_t C, int64_t HW, const float*
                   int64_t sw_stride, const float* conv_bias, mn_stream_t stream);
 int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                 int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
+/* The BatchNorm [+ ReLU] behind a dense IAO conv and the activation quantizer of the NEXT dense IAO conv as one streaming pass (models/resnet.py:17-29: conv -> bn -> relu
+ * -> conv under wqaq/iao/quantize.py:492-507), in three calls:
+ *   mn_bn_acc_prep     per channel, no pass over y: batch statistics from the conv's exact accumulator sums (the arithmetic of mn_bn_fwd_acc: save, running statistics)
+ *                      and, from the accumulator's extrema (mn_actq.acc_mm), the (min, max) of a = act(bn(y)) over that channel -> mm[c], mm[C + c]: a partials buffer
+ *                      of count C for mn_iao_observe_partials[_qparams] -- the observer sees exactly the extrema a pass over `a` would have found (every step of
+ *                      acc -> y -> bn -> relu is monotone in fp32), before `a` exists;
+ *   (the caller updates the quantizer: mn_iao_observe_partials_qparams -> qp)
+ *   mn_bn_apply_codes  ONE pass over y: a = act(bn(y)) with the finished `save`, then the symmetric `bits`-bit quantizer qp exactly as the dense conv's own code pass
+ *                      evaluates it -> signed codes (1 byte per element, layout of y) + clip-STE bits (1 bit per element): what mn_conv2d_fwd consumes under
+ *                      MN_ACTQ_CODES_GIVEN and mn_conv2d_bwd_data / _bwd_weight through mn_actq.codes / .ste_mask.  fp32 `a` is never written (5.1 B per element
+ *                      instead of 8 + 5.1).  HW % 8 == 0; codes: N * C * HW bytes rounded up to 256, mask: an eighth of that.
+ *   mn_bn_apply        the same normalisation written as fp32 (a consumer outside the fused path; the values the codes were taken from).
+ * act: 1 ReLU, 2 none.  The backward is the ordinary mn_bnrelu_bwd / mn_bn2d_bwd on (da, y). */
+int mn_bn_acc_prep(int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                   float* save, int act, const double* stats, const int32_t* acc_mm, int64_t rows, const float* sa, const float* sw, int64_t sw_stride,
+                   const float* conv_bias, float* mm, mn_stream_t stream);
+int mn_bn_apply_codes(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, int act, const float* qp, int bits,
+                      int8_t* codes, uint8_t* ste_mask, mn_stream_t stream);
+int mn_bn_apply(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, int act, float* a, mn_stream_t stream);
 /* the two halves of mn_bnsign_bwd for a consumer that forms dy itself: mn_bnsign_bwd_sums = dgamma, dbeta and sums [2][C] =
  * {sum dz, sum dz*zhat}; mn_conv2d_bwd_weight_first_bn = backward-weight (+ dbias) of the first-layer convolution
  * (mn_conv2d_first_supported) whose output y went through BatchNorm2d + BinaryActivation: dy is formed from (da, y, save, gamma,

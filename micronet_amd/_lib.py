@@ -14,6 +14,7 @@ MN_ACTQ_NONE, MN_ACTQ_DOREFA, MN_ACTQ_IAO, MN_ACTQ_SIGN8, MN_ACTQ_CODE8 = 0, 1, 
 MN_ALGO_AUTO, MN_ALGO_DIRECT, MN_ALGO_MFMA, MN_ALGO_QGEMM = 0, 1, 2, 3
 MN_WQ_REAL, MN_WQ_TERNARY, MN_WQ_DOREFA, MN_WQ_IAO = 0, 1, 2, 3
 MN_ACTQ_X_IS_CODE = 1
+MN_ACTQ_CODES_GIVEN = 2
 MN_ENOTSUP = -95
 
 
@@ -24,7 +25,7 @@ class ConvGeom(C.Structure):
 
 class ActQ(C.Structure):
     _fields_ = [("mode", C.c_int32), ("bits", C.c_int32), ("q_type", C.c_int32), ("flags", C.c_int32),
-                ("qp", C.c_void_p), ("codes", C.c_void_p), ("stats", C.c_void_p), ("dx_add", C.c_void_p), ("ste_mask", C.c_void_p)]
+                ("qp", C.c_void_p), ("codes", C.c_void_p), ("stats", C.c_void_p), ("dx_add", C.c_void_p), ("ste_mask", C.c_void_p), ("acc_mm", C.c_void_p)]
 
 
 class WQ(C.Structure):
@@ -154,6 +155,9 @@ PROTOTYPES = {
     "mn_conv2d_bwd_data_add_supported": (_I, [_G, _A, _W]),
     "mn_conv2d_iao_stats_rows": (_L, [_G, _A, _W]),
     "mn_bn_fwd_acc": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _L, _P, _P]),
+    "mn_bn_acc_prep": (_I, [_L, _L, _L, _P, _P, C.c_float, C.c_float, _P, _P, _P, _I, _P, _P, _L, _P, _P, _L, _P, _P, _P]),
+    "mn_bn_apply_codes": (_I, [_P, _L, _L, _L, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
+    "mn_bn_apply": (_I, [_P, _L, _L, _L, _P, _P, _P, _I, _P, _P]),
     "mn_iao_w_fwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _I, _I, _P]),
     "mn_iao_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mn_iao_qadd_ws_floats": (_L, []),

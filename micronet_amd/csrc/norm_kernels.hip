@@ -594,6 +594,146 @@ extern "C" int mn_bn_fwd_acc(const float* y, int64_t N, int64_t C, int64_t HW, c
     MN_CHECK_LAUNCH("mn_bn_fwd_acc");
     return MN_OK;
 }
+// ---------------------------------------------------------------- BatchNorm [+ ReLU] behind a dense IAO conv, fused with the NEXT conv's activation quantizer
+// (models/resnet.py:17-29 conv -> bn -> relu -> conv under wqaq/iao/quantize.py:492-507; the observer of that quantizer, :23-36 / :214-240, must see the whole activation
+// before one element is quantised).  y = al[c] * acc + cb[c] with acc the conv's integer accumulator, so per channel every step of
+//     acc -> y -> zh = (y - mean) * invstd -> z = zh * gamma + beta -> a = relu(z)
+// is a monotone fp32 function of acc (rounding is monotone; a negative gamma only swaps the ends): the extrema of `a` over the channel are `a` at the accumulator's
+// extrema, which the conv's epilogue leaves beside its exact sums (mn_actq.acc_mm).  k_bn_acc_prep: one wave per channel, no pass over y.
+struct BnAccPrep {
+    int C, rows, act;
+    double n;                      // N * HW
+    float eps, momentum;
+    const double* stats;           // [rows][C][2]
+    const int32_t* accmm;          // [rows][C][2]
+    const float *sa, *sw, *cbias, *gamma, *beta;
+    int sw_stride;
+    float *running_mean, *running_var, *save, *mm;
+};
+__global__ __launch_bounds__(256) void k_bn_acc_prep(const BnAccPrep p) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (c >= p.C) return;          // (wave-uniform)
+    double s1 = 0.0, s2 = 0.0;     // exact integers < 2^53: any order of summation gives the same double
+    int lo = INT_MAX, hi = INT_MIN;
+    for (int i = lane; i < p.rows; i += 64) {
+        s1 += p.stats[((int64_t)i * p.C + c) * 2]; s2 += p.stats[((int64_t)i * p.C + c) * 2 + 1];
+        const int a = p.accmm[((int64_t)i * p.C + c) * 2], b = p.accmm[((int64_t)i * p.C + c) * 2 + 1];
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+    }
+    s1 = wave_reduce(s1, OpAddD()); s2 = wave_reduce(s2, OpAddD());
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_down(lo, o, 64), b = __shfl_down(hi, o, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if (lane) return;
+    // the statistics: k_bns_apply's fin.kind == 1 arithmetic, expression for expression
+    const float alf = p.sa[0] * p.sw[(int64_t)c * p.sw_stride], cb = p.cbias ? p.cbias[c] : 0.f;
+    const double al = (double)alf;
+    const double m = s1 / p.n;
+    const double mean_d = al * m + (double)cb;
+    double ss = al * al * (s2 - s1 * m);
+    if (ss < 0.0) ss = 0.0;
+    const float var_b = (float)(ss / p.n);
+    const float mean = (float)mean_d, invstd = 1.0f / sqrtf(var_b + p.eps);
+    p.save[c] = mean; p.save[p.C + c] = invstd;
+    if (p.running_mean) p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean_d;
+    if (p.running_var) p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)(ss / (p.n - 1.0));
+    // the activation at the two ends: the conv epilogue's y (k_qd_fwd8), k_bns_apply's z
+    const float ga = p.gamma[c], be = p.beta[c];
+    float e[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float y = (float)(k ? hi : lo) * alf + cb;
+        const float zh = (y - mean) * invstd;
+        const float z = zh * ga + be;
+        e[k] = p.act == 2 ? z : bns_relu(z);
+    }
+    p.mm[c] = OpMinF()(e[0], e[1]); p.mm[p.C + c] = OpMaxF()(e[0], e[1]);
+}
+extern "C" int mn_bn_acc_prep(int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              float* save, int act, const double* stats, const int32_t* acc_mm, int64_t rows, const float* sa, const float* sw, int64_t sw_stride,
+                              const float* conv_bias, float* mm, mn_stream_t stream) {
+    if (N <= 0 || C <= 0 || HW <= 0 || !gamma || !beta || !save || !stats || !acc_mm || !sa || !sw || !mm || rows <= 0 || rows > 65536 || (act != 1 && act != 2) ||
+        (((uintptr_t)stats) & 7) || (((uintptr_t)acc_mm) & 3))
+        MN_FAIL(MN_EINVAL, "mn_bn_acc_prep: null / misaligned argument");
+    BnAccPrep p;
+    p.C = (int)C; p.rows = (int)rows; p.act = act; p.n = (double)N * (double)HW; p.eps = eps; p.momentum = momentum; p.stats = stats; p.accmm = acc_mm;
+    p.sa = sa; p.sw = sw; p.cbias = conv_bias; p.gamma = gamma; p.beta = beta; p.sw_stride = (int)sw_stride;
+    p.running_mean = running_mean; p.running_var = running_var; p.save = save; p.mm = mm;
+    mn_set_last_kernel("k_bn_acc_prep");
+    hipLaunchKernelGGL(k_bn_acc_prep, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    MN_CHECK_LAUNCH("mn_bn_acc_prep");
+    return MN_OK;
+}
+// a = act(bn(y)) (k_bns_apply<0, 0>'s expressions) -> the symmetric quantizer's signed codes + clip-STE bits (k_qd_iao_codes' decisions on a): thread = 8 consecutive
+// elements of one plane (two float4 in, one 8-byte code store, one mask byte).  The pass is VALU-bound before it is HBM-bound (first version: 55 instructions per
+// element, 2.4 TB/s), so: the activation is a template parameter, a / sc is Markstein's three-instruction correctly rounded quotient (mn_div_m: the same float as
+// the IEEE sequence for in-range operands), and with zero_point == 0 (the symmetric quantizer: always) the rounded value serves the code and the clip test.
+template <int ACT, int ZP0>
+__device__ __forceinline__ void bn_apply_codes_body(const BnsGeom& g, const float* __restrict__ y, float mean, float invstd, float ga, float be, float sc, float zp, float rlo,
+                                                    float rhi, float qmin, float qmax, signed char* __restrict__ codes, unsigned char* __restrict__ mask) {
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const float inv = 1.0f / sc;
+    const uint32_t HW8 = (uint32_t)g.HW4 >> 1;
+    const int64_t n8 = g.n4 >> 1;
+    // rha(v) as copysign(floor(|v| + 0.5), v): the float of mn_rha except for the sign of a zero, which neither the code byte nor the comparisons see
+    auto rha = [](float v) { return copysignf(floorf(fabsf(v) + 0.5f), v); };
+    float4 va_[2], vb_[2];
+    int64_t off_[2];
+#define BNC_LOAD(k, idx) { const uint32_t n_ = fd_div(2u * (uint32_t)(idx), g.fd_hw4); off_[k] = ((int64_t)n_ * g.C + c) * g.HW + (int64_t)((uint32_t)(idx) - n_ * HW8) * 8; \
+                           va_[k] = *reinterpret_cast<const float4*>(y + off_[k]); vb_[k] = *reinterpret_cast<const float4*>(y + off_[k] + 4); }
+#define BNC_FIN(k) { const float v[8] = {va_[k].x, va_[k].y, va_[k].z, va_[k].w, vb_[k].x, vb_[k].y, vb_[k].z, vb_[k].w};                                  \
+        uint32_t m = 0u, lo = 0u, hi = 0u;                                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                                                     \
+            const float zh = (v[e] - mean) * invstd;                                                                                                        \
+            const float z = zh * ga + be;                                                                                                                   \
+            /* relu: a NaN stays a NaN in bns_relu -- here it becomes 0 (code 0 either way) and is failed by the z == z term of the clip test */             \
+            const float a = ACT == 2 ? z : fmaxf(z, 0.f);                                                                                                   \
+            const float q = mn_div_m(a, sc, inv);                                                                                                           \
+            const float vv = ZP0 ? q : q - zp, r = rha(vv);                                                                                                 \
+            m |= ((r >= qmin && r <= qmax && !(vv > rhi || vv < rlo) && (ACT == 2 || z == z)) ? 1u : 0u) << e;                                              \
+            const float rq = ZP0 ? r : rha(q);                                                                                                              \
+            const float cl = fminf(fmaxf(rq, qmin), qmax);                             /* clamp(rha(a / sc)); NaN -> 0 (a byte cannot hold it) */            \
+            const float cc = ACT == 2 ? ((rq == rq) ? cl : 0.f) : cl;                                                                                       \
+            const uint32_t byte = (uint32_t)(int)cc & 0xffu;                                                                                                \
+            if (e < 4) lo |= byte << (8 * e); else hi |= byte << (8 * (e - 4));                                                                             \
+        }                                                                                                                                                   \
+        *reinterpret_cast<u32x2*>(codes + off_[k]) = u32x2{lo, hi};                                                                                         \
+        mask[off_[k] >> 3] = (unsigned char)m; }
+    MN_STREAM_2(i, (int64_t)sp * 256 + threadIdx.x, (int64_t)S * 256, n8, BNC_LOAD, BNC_FIN)
+#undef BNC_LOAD
+#undef BNC_FIN
+}
+template <int ACT>
+__global__ __launch_bounds__(256) void k_bn_apply_codes(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ save, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ qp, float qmin, float qmax,
+                                                        signed char* __restrict__ codes, unsigned char* __restrict__ mask) {
+    const int c = blockIdx.x;
+    const float mean = save[c], invstd = save[g.C + c], ga = gamma[c], be = beta[c];
+    const float sc = qp[0], zp = qp[1], rlo = qp[2], rhi = qp[3];
+    if (zp == 0.f) bn_apply_codes_body<ACT, 1>(g, y, mean, invstd, ga, be, sc, zp, rlo, rhi, qmin, qmax, codes, mask);          // (the symmetric quantizer: always)
+    else bn_apply_codes_body<ACT, 0>(g, y, mean, invstd, ga, be, sc, zp, rlo, rhi, qmin, qmax, codes, mask);
+}
+extern "C" int mn_bn_apply_codes(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, int act, const float* qp, int bits,
+                                 int8_t* codes, uint8_t* ste_mask, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, y, y, "mn_bn_apply_codes");
+    if (rc) return rc;
+    if (!y || !gamma || !beta || !save || !qp || !codes || !ste_mask || HW % 8 || bits < 2 || bits > 8 || (act != 1 && act != 2) || (((uintptr_t)codes) & 7))
+        MN_FAIL(MN_EINVAL, "mn_bn_apply_codes: null / misaligned argument, HW not a multiple of 8 or bits outside 2..8");
+    BnsGeom g = bns_geom(N, C, HW);
+    g.act = act;
+    const int S = bns_split(g);
+    const IaoRange r = iao_range(bits, 0, 1);
+    hipStream_t s = (hipStream_t)stream;
+    mn_set_last_kernel("k_bn_apply_codes"); mn_prof_bytes(5.125 * (double)N * C * HW); mn_prof_begin(s);
+    if (act == 1) hipLaunchKernelGGL(k_bn_apply_codes<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, save, gamma, beta, qp, r.qmin, r.qmax, (signed char*)codes, (unsigned char*)ste_mask);
+    else hipLaunchKernelGGL(k_bn_apply_codes<2>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, save, gamma, beta, qp, r.qmin, r.qmax, (signed char*)codes, (unsigned char*)ste_mask);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_bn_apply_codes");
+    return MN_OK;
+}
+extern "C" int mn_bn_apply(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, int act, float* a, mn_stream_t stream) {
+    if (act != 1 && act != 2) MN_FAIL(MN_EINVAL, "mn_bn_apply: act must be 1 (ReLU) or 2 (none)");
+    return bnsign_fwd_impl(y, N, C, HW, gamma, beta, 0.f, 0.f, 1, nullptr, nullptr, const_cast<float*>(save), a, 0, nullptr, stream, act, nullptr, true);
+}
 extern "C" int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                            int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
     return bnsign_bwd_impl(da, y, save, gamma, beta, N, C, HW, training, dy, dgamma, dbeta, ws, stream, 2);

@@ -197,6 +197,10 @@ struct QdfParams {
     // k_qd_fwd8 with a stash output: exact per-channel sums of acc and acc^2 over the block's items (every item of a block has the same channel tile: the grid
     // is a multiple of ncot) -> stats[((blockIdx / ncot) * O + channel) * 2 + {0, 1}]: the partial layout k_qa_stats_prep reads; nullptr: none (k_qd_stats instead)
     double* stats;
+    // k_qd_fwd8, IAO layers: the extrema of acc per channel over the same items -> accmm[((blockIdx / ncot) * O + channel) * 2 + {0, 1}] = min, max (INT_MAX, INT_MIN
+    // for a block without a valid pixel).  y = acc * al + bias is monotone in acc, so is the BatchNorm [+ ReLU] behind it: the range of THAT activation follows from
+    // these without a pass over it (mn_bn_acc_prep); nullptr: none
+    int32_t* accmm;
 };
 
 template <int MF, int TPS>
@@ -529,6 +533,7 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd8(const QdfParams p) {
     fetch_w();
     int gs = 0;
     double st1[4] = {0.0, 0.0, 0.0, 0.0}, st2[4] = {0.0, 0.0, 0.0, 0.0};          // this lane's share of sum acc, sum acc^2 of channels 16 nf + j (exact: < 2^53)
+    int amn[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, amx[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};          // ... and of their extrema (valid pixels only)
     for (int item = (int)blockIdx.x; item < p.nitems; item += stride_items) {
         i32x4 acc[MF][4];
 #pragma unroll
@@ -579,6 +584,18 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd8(const QdfParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const int v = acc[mf][nf][r]; s1 += v; const double dv = (double)v; s2 = fma(dv, dv, s2); }
                 st1[nf] += (double)s1; st2[nf] += s2;
+            }
+        }
+        if (p.accmm) {          // (a lane's four pixels 4 kg .. 4 kg + 3 of fragment mf lie in one image: the pixels per image and tile are a multiple of 4)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int tpm = wave * 16 * MF + mf * 16 + 4 * kg;
+                if (n0 + (int)fd_div((uint32_t)tpm, p.fd_ipt) < p.N) {
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const int v = acc[mf][nf][r]; amn[nf] = v < amn[nf] ? v : amn[nf]; amx[nf] = v > amx[nf] ? v : amx[nf]; }
+                }
             }
         }
         {
@@ -672,6 +689,24 @@ __global__ __launch_bounds__(256, 2) void k_qd_fwd8(const QdfParams p) {
             const int sp = (int)blockIdx.x / p.ncot, cot = (int)blockIdx.x - sp * p.ncot;
             double* dst = p.stats + ((int64_t)sp * p.O + cot * 64 + tid) * 2;
             dst[0] = a1; dst[1] = a2;
+        }
+    }
+    if (p.accmm) {
+        __syncthreads();
+        int* red = reinterpret_cast<int*>(smem);          // [wave][kg][64 channels][2]
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            int* d = red + (((wave * 4 + kg) * 64) + nf * 16 + j) * 2;
+            d[0] = amn[nf]; d[1] = amx[nf];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int lo = INT_MAX, hi = INT_MIN;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const int a = red[(q * 64 + tid) * 2], b = red[(q * 64 + tid) * 2 + 1]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+            const int sp = (int)blockIdx.x / p.ncot, cot = (int)blockIdx.x - sp * p.ncot;
+            int32_t* dst = p.accmm + ((int64_t)sp * p.O + cot * 64 + tid) * 2;
+            dst[0] = lo; dst[1] = hi;
         }
     }
 }
@@ -835,6 +870,7 @@ int qd_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const uint8_t* x, int a
     double* part = reinterpret_cast<double*>((char*)ws + pl.off_part);
     const int epi_stats = i8;
     p.stats = epi_stats ? part : nullptr;
+    p.accmm = nullptr;
     mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + (out32 ? 4.0 : 2.0) * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }
     mn_prof_begin(s);
@@ -2163,19 +2199,22 @@ int qd_iao_fwd(const mn_conv_geom* g, const mn_actq* aq, const mn_wq* wq, const 
                hipStream_t s) {
     QdfPlan pl;
     const int i8 = qd_fwd_i8(wq);
-    if (!qd_iao_quant_ok(g, aq, wq, 1) || !plan_qdf(g, 2, &pl, i8) || !aligned16(x) || !aligned16(y) || !w) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(dense iao): geometry / quantizer not covered");
+    const int given = (aq->flags & MN_ACTQ_CODES_GIVEN) != 0;          // mn_actq.codes already holds this forward's codes (mn_bn_apply_codes wrote them): x is not read
+    if (!qd_iao_quant_ok(g, aq, wq, 1) || !plan_qdf(g, 2, &pl, i8) || (!given && !aligned16(x)) || !aligned16(y) || !w) MN_FAIL(MN_ENOTSUP, "mn_conv2d_fwd(dense iao): geometry / quantizer not covered");
+    if (given && !aq->codes) MN_FAIL(MN_EINVAL, "mn_conv2d_fwd(dense iao): MN_ACTQ_CODES_GIVEN without mn_actq.codes");
     const int64_t cb = qd_iao_codes_bytes(g);
     if (!ws || ws_bytes < cb + pl.ws_bytes || !aligned16(ws)) MN_FAIL(MN_ENOSPC, "mn_conv2d_fwd(dense iao): workspace too small");
     QdfParams& p = pl.p;
     void* cbuf = aq->codes ? aq->codes : ws;          // a caller-owned buffer keeps the codes for backward-weight
     if (!aligned16(cbuf)) MN_FAIL(MN_EINVAL, "mn_conv2d_fwd(dense iao): mn_actq.codes is not 16-byte aligned");
-    qd_iao_launch_codes(g, aq, x, cbuf, aq->codes ? aq->ste_mask : nullptr, s);          // (+ the clip-STE bits for backward-data when the caller keeps the codes)
+    if (!given) qd_iao_launch_codes(g, aq, x, cbuf, aq->codes ? aq->ste_mask : nullptr, s);          // (+ the clip-STE bits for backward-data when the caller keeps the codes)
     const uint16_t* wpk = reinterpret_cast<const uint16_t*>(wq->packed_fwd);
     if (!wpk) {
         qd_launch_pack(w, reinterpret_cast<uint16_t*>((char*)ws + cb), g->O, g->C, p.TAPS, wq->bits, i8 ? 2 : 0, s, wq->scale, wq->per_channel);
         wpk = reinterpret_cast<const uint16_t*>((char*)ws + cb);
     }
     p.stats = (i8 && aq->stats) ? reinterpret_cast<double*>(aq->stats) : nullptr;          // exact sums of acc for the BatchNorm behind (mn_bn_fwd_acc)
+    p.accmm = (i8 && aq->acc_mm) ? reinterpret_cast<int32_t*>(aq->acc_mm) : nullptr;          // ... and its extrema (mn_bn_acc_prep)
     p.x = (const unsigned char*)cbuf; p.wpk = wpk; p.stash = y; p.xsgn = 1; p.sa = aq->qp; p.sw = wq->scale; p.sw_stride = wq->per_channel; p.bias = bias;
     mn_set_last_kernel(i8 ? "k_qd_fwd8<%d, %d>" : "k_qd_fwd<%d, %d>", pl.MF, pl.TPS);
     { const double nx = (double)g->N * g->C * p.HW, ny = (double)g->N * g->O * p.HoWo; mn_prof_bytes(nx * p.ncot + 4.0 * ny); mn_prof_flops(2.0 * ny * g->C * p.TAPS); }

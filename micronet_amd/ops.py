@@ -24,7 +24,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import ActQ, ConvGeom, MicronetHipError, WQ
-from .sign_tensor import LazyBNGrad, LazyConvOut, LazyPoolGrad, LazyQConvOut, LazyReluConvOut, LazyReluGrad, QActTensor, QGrad, SignTensor
+from .sign_tensor import LazyBNAct, LazyBNGrad, LazyConvOut, LazyPoolGrad, LazyQConvOut, LazyReluConvOut, LazyReluGrad, QActTensor, QGrad, SignTensor
 
 ACTQ_NONE, ACTQ_DOREFA, ACTQ_IAO, ACTQ_SIGN8, ACTQ_CODE8 = _lib.MN_ACTQ_NONE, _lib.MN_ACTQ_DOREFA, _lib.MN_ACTQ_IAO, _lib.MN_ACTQ_SIGN8, _lib.MN_ACTQ_CODE8
 WQ_REAL, WQ_TERNARY, WQ_DOREFA, WQ_IAO = _lib.MN_WQ_REAL, _lib.MN_WQ_TERNARY, _lib.MN_WQ_DOREFA, _lib.MN_WQ_IAO
@@ -1480,7 +1480,7 @@ class BNReLU(Function):
         with torch.cuda.device_of(y):
             if accstats is not None and training and fn in ("mn_bnrelu", "mn_bn2d") and accstats[0].shape[1] == Cc:
                 # y came out of a dense IAO conv that left the exact sums of its integer accumulator: batch statistics from those, ONE pass over y
-                stats, rows, qp, wscale, sw_stride, cbias = accstats
+                stats, rows, qp, wscale, sw_stride, cbias = accstats[:6]
                 mm = None
                 if want_minmax:
                     count = int(_lib_().mn_bnrelu_mm_count(N, Cc, HW))
@@ -1514,6 +1514,92 @@ class BNReLU(Function):
         with torch.cuda.device_of(y):
             _call(ctx.fn + "_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, ctx.training, _p(dy), _p(dgamma), _p(dbeta), _p(ws), _s())
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class BNActLazy(Function):
+    """Training-mode BatchNorm2d [+ ReLU] behind a dense IAO conv (models/resnet.py:17-29) whose only consumer is the next dense IAO ``QuantConv2d`` or the block's
+    ``QuantAdd``: returns a ``LazyBNAct`` -- nothing is computed here.  The consumer pulls (``prep`` -> its observer / qparams -> ``iao_bn_apply_codes`` or the fused
+    QuantAdd kernel); the backward is BNReLU's (z recomputed from y)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, act, accstats):
+        y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
+        N, Cc, H, W = y.shape
+        dev = y.device
+        stats, rows, qp_in, wscale, sw_stride, cbias, accmm = accstats
+        save = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        state = {"mm": None}
+
+        def prep():
+            if state["mm"] is None:
+                mm = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _call("mn_bn_acc_prep", N, Cc, H * W, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), _p(save), int(act), _p(stats),
+                          _p(accmm), int(rows), _p(qp_in), _p(wscale), int(sw_stride), _p(cbias), _p(mm), _s())
+                state["mm"] = mm
+            return state["mm"], Cc
+
+        def compute():
+            prep()
+            a = torch.empty_like(y)
+            with torch.cuda.device(dev):
+                _call("mn_bn_apply", _p(y), N, Cc, H * W, _p(gamma), _p(beta), _p(save), int(act), _p(a), _s())
+            return a
+        ctx.save_for_backward(y, gamma, beta, save)
+        ctx.act = int(act)
+        return LazyBNAct(y.shape, dev, dict(kind="bn_act", y=y, gamma=gamma, beta=beta, save=save, act=int(act), prep=prep, compute=compute))
+
+    @staticmethod
+    def backward(ctx, da):
+        y, gamma, beta, save = ctx.saved_tensors
+        da = _chk(da, "grad")
+        N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
+        dgamma, dbeta, dy = torch.empty_like(gamma), torch.empty_like(beta), torch.empty_like(y)
+        ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=y.device)
+        with torch.cuda.device_of(y):
+            _call("mn_bnrelu_bwd" if ctx.act == 1 else "mn_bn2d_bwd", _p(da), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, HW, 1, _p(dy), _p(dgamma), _p(dbeta), _p(ws), _s())
+        return dy, dgamma, dbeta, None, None, None, None, None, None
+
+
+def iao_bn_lazy_supported(y, accstats):
+    return (torch.is_tensor(y) and type(y) is torch.Tensor and y.is_cuda and y.dim() == 4 and y.dtype == torch.float32 and (y.shape[2] * y.shape[3]) % 8 == 0 and
+            accstats is not None and len(accstats) >= 7 and accstats[6] is not None and accstats[0].shape[1] == y.shape[1] and y.is_contiguous() and y.data_ptr() % 16 == 0)
+
+
+def iao_codes_bytes(x_shape, w_shape, stride, padding, dilation, groups, a_bits, w_bits, dummy):
+    """bytes of the signed-code buffer the dense IAO kernels keep for a layer of this geometry (0: they do not cover it); ``dummy``: any device tensor (the descriptors
+    only have to be non-NULL for the query)"""
+    if CONV_ALGO != _lib.MN_ALGO_AUTO:
+        return 0
+    g = _geom(x_shape, w_shape, stride, padding, dilation, groups, 0)
+    aq = ActQ(ACTQ_IAO, a_bits, 0, 0, dummy.data_ptr())
+    wd = WQ(WQ_IAO, w_bits, 0, 4, dummy.data_ptr())
+    return int(_lib_().mn_conv2d_iao_codes_bytes(C.byref(g), C.byref(aq), C.byref(wd)))
+
+
+def iao_bn_apply_codes(lazy, qp, bits, nc):
+    """The pulled half of a ``LazyBNAct`` for a dense IAO conv: act(bn(y)) -> that conv's signed activation codes + clip-STE bits, one pass (``lazy.prep()`` ran)."""
+    r = lazy.recipe
+    y = r["y"]
+    N, Cc, H, W = y.shape
+    codes = torch.empty(nc, dtype=torch.int8, device=y.device)
+    mask = torch.empty(nc // 8, dtype=torch.uint8, device=y.device)
+    with torch.cuda.device_of(y):
+        with _span(None, 3, 5.125 * y.numel()):
+            _call("mn_bn_apply_codes", _p(y), N, Cc, H * W, _p(r["gamma"]), _p(r["beta"]), _p(r["save"]), r["act"], _p(qp), int(bits), _p(codes), _p(mask), _s())
+    return codes, mask
+
+
+class LazyBNActToFloat(Function):
+    """LazyBNAct -> the float32 activation, WITH an autograd link (identity backward)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        return a.materialize()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 class GlobalAvgPool(Function):
@@ -1679,17 +1765,23 @@ class QConv2d(Function):
     ``wdesc`` tells the code-domain kernels how wq factors into integer codes x scale (None: arbitrary fp32 weights)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc, aq_flags, in_shuffle=0):
-        if isinstance(x, SignTensor):       # packed +-1 activations: the kernels read the int8 codes (MN_ACTQ_SIGN8)
+    def forward(ctx, x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc, aq_flags, in_shuffle=0, given=None):
+        ctx.x_shape = tuple(x.shape)
+        if given is not None:               # x is a LazyBNAct whose consumer-side codes + clip-STE bits are already written (iao_bn_apply_codes): fp32 x never exists and
+            if aq_mode != ACTQ_IAO or qp is None or wdesc is None or CONV_ALGO != _lib.MN_ALGO_AUTO:          # no kernel reads it; the codes stand in wherever a pointer is due
+                raise MicronetHipError("activation codes handed over without the dense IAO path")
+            xl, x = x, given[0]
+        elif isinstance(x, SignTensor):     # packed +-1 activations: the kernels read the int8 codes (MN_ACTQ_SIGN8)
             if aq_mode != ACTQ_NONE:
                 raise MicronetHipError("a SignTensor input cannot be combined with a fused activation quantizer")
             x, aq_mode = x.codes, ACTQ_SIGN8
         else:
             x = _chk(x, "input")
         wq, bias = _chk(wq, "weight"), _chk(bias, "bias")
-        if x.dim() != 4 or wq.dim() != 4 or x.shape[1] != wq.shape[1] * groups:
-            raise MicronetHipError("conv2d shape mismatch: input %s weight %s groups %d" % (tuple(x.shape), tuple(wq.shape), groups))
-        g = _geom(x.shape, wq.shape, stride, padding, dilation, groups, in_shuffle)
+        xs = ctx.x_shape
+        if len(xs) != 4 or wq.dim() != 4 or xs[1] != wq.shape[1] * groups:
+            raise MicronetHipError("conv2d shape mismatch: input %s weight %s groups %d" % (xs, tuple(wq.shape), groups))
+        g = _geom(xs, wq.shape, stride, padding, dilation, groups, in_shuffle)
         Ho, Wo = _out_hw(g)
         y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
         want_stats, aq_flags = bool(aq_flags & WANT_ACCSTATS), aq_flags & ~WANT_ACCSTATS
@@ -1701,11 +1793,18 @@ class QConv2d(Function):
             rows = int(_lib_().mn_conv2d_iao_stats_rows(C.byref(g), C.byref(aq), C.byref(wd)))
             if rows > 0 and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:          # dense layer on the int8 matrix cores (16-byte aligned operands, as mn_conv2d_fwd asks):
                 stats = torch.empty((rows, g.O, 2), dtype=torch.float64, device=x.device)          # exact sums of acc / acc^2 per channel from the epilogue, for the BatchNorm behind the conv
-                aq.stats = stats.data_ptr()
+                accmm = torch.empty((rows, g.O, 2), dtype=torch.int32, device=x.device)            # ... and the accumulator's extrema: the range of that BatchNorm's output without a pass (mn_bn_acc_prep)
+                aq.stats, aq.acc_mm = stats.data_ptr(), accmm.data_ptr()
         if packed is not None and packed[0] is not None:
             wd.packed_fwd = packed[0].data_ptr()
         codes = ste_mask = None
-        if aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[1]:
+        if given is not None:
+            codes, ste_mask = given
+            nc = int(_lib_().mn_conv2d_iao_codes_bytes(C.byref(g), C.byref(aq), C.byref(wd)))
+            if nc <= 0 or nc != codes.numel() or ste_mask.numel() * 8 != nc:
+                raise MicronetHipError("activation codes handed over to a layer the dense IAO kernels do not cover")
+            aq.codes, aq.ste_mask, aq.flags = codes.data_ptr(), ste_mask.data_ptr(), aq.flags | _lib.MN_ACTQ_CODES_GIVEN
+        elif aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[1]:
             nc = int(_lib_().mn_conv2d_iao_codes_bytes(C.byref(g), C.byref(aq), C.byref(wd)))
             if nc > 0:          # dense IAO layer: the forward's signed activation codes are kept for backward-weight (1 byte per element)
                 codes = torch.empty(nc, dtype=torch.int8, device=x.device)
@@ -1718,13 +1817,15 @@ class QConv2d(Function):
             with _span(g, 0, 4 * (x.numel() + y.numel() + wq.numel())):
                 _call("mn_conv2d_fwd", C.byref(g), C.byref(aq), _ref(wd), _p(x), _p(wq), _p(bias), _p(y), _p(ws), nb, CONV_ALGO, _s())
         wscale = wdesc[4] if wdesc is not None else None
-        if stats is not None and not _lib_().mn_last_kernel().decode().startswith("k_qd_fwd"):
+        if (stats is not None or given is not None) and not _lib_().mn_last_kernel().decode().startswith("k_qd_fwd"):
+            if given is not None:
+                raise MicronetHipError("activation codes handed over, but the library did not take the dense IAO kernel (%s)" % _lib_().mn_last_kernel().decode())
             stats = None          # the library took another kernel (workspace / alignment): nothing wrote the sums -- the BatchNorm computes its own statistics
-        if stats is not None:          # (stats, rows, activation qparams, per-channel weight scale, its stride, conv bias): what mn_bn_fwd_acc reads
-            _PENDING_ACCSTATS[0] = (stats, stats.shape[0], qp, wscale, int(wdesc[3]), bias)
+        if stats is not None:          # (stats, rows, activation qparams, per-channel weight scale, its stride, conv bias, extrema of acc): what mn_bn_fwd_acc / mn_bn_acc_prep read
+            _PENDING_ACCSTATS[0] = (stats, stats.shape[0], qp, wscale, int(wdesc[3]), bias, accmm)
         ctx.iao_codes, ctx.iao_mask = codes, ste_mask
         ctx.res_tok = None
-        if (RES_ADD_FOLD and aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[0]
+        if (RES_ADD_FOLD and given is None and aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[0]
                 and type(x) is torch.Tensor and _lib_().mn_conv2d_bwd_data_add_supported(C.byref(g), C.byref(aq), C.byref(wd))):
             ctx.res_tok = x._mn_res_token = ResidualToken()          # (x is the caller's tensor object; the node is filled in by qconv2d() below)
         ctx.save_for_backward(x, wq, qp, wscale)
@@ -1739,7 +1840,7 @@ class QConv2d(Function):
             r = gy._mn_recipe              # the block behind this (first) conv already ran the one-pass backward on this conv's operands: dw, dbias are finished
             if aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and r["x"].data_ptr() == x.data_ptr() and r["w"].data_ptr() == wq.data_ptr() and \
                     tuple(r["dw"].shape) == tuple(wq.shape) and (not has_bias or r["db"] is not None):
-                return None, r["dw"], (r["db"] if has_bias else None), None, None, None, None, None, None, None, None, None, None, None
+                return None, r["dw"], (r["db"] if has_bias else None), None, None, None, None, None, None, None, None, None, None, None, None
         if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") in ("bnh", "bnh_pool") and aq_mode == ACTQ_SIGN8 and wd4 is not None and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO:
             r = gy._mn_recipe              # the fused BatchNorm+sign (+ max-pool) behind this conv: dy is formed inside backward-data / backward-weight
@@ -1761,7 +1862,7 @@ class QConv2d(Function):
                     with _span(g, 1, (3 if pool else 5) * r["h"].numel() + 5 * dx.numel()):
                         _call("mn_conv2d_bwd_bnh", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["own"]) if pool else None, _p(r["chan"]), _p(r["sums"]),
                               r["training"], _p(wq), _p(x), _p(dx), _p(dw), _p(db), _p(ws), nb, _s())
-                return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+                return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
             with torch.cuda.device_of(x):
                 if ctx.needs_input_grad[0]:
                     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -1784,7 +1885,7 @@ class QConv2d(Function):
                         else:
                             _call("mn_conv2d_bwd_weight_bnh", C.byref(g), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(x), _p(dw),
                                   _p(db), _p(ws), nb, _s())
-            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") == "qa" and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
             r = gy._mn_recipe              # the DoReFa block (BatchNorm + ReLU + next quantizer) behind the first conv: dy is formed inside the backward-weight kernel
@@ -1794,7 +1895,7 @@ class QConv2d(Function):
                 ws, nb = _ws(g, 2, x.device)
                 _call("mn_conv2d_bwd_weight_first_qa", C.byref(g), _p(r["dq"]), _p(r["y"]), _p(r["chan"]), _p(r["sums"]), r["bits"], r["quant"], r["training"],
                       _p(x), _p(dw), _p(db), _p(ws), nb, _s())
-            return None, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            return None, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         if isinstance(gy, LazyBNGrad) and gy._mn_value is None and gy._mn_recipe.get("kind") not in ("bnh", "bnh_pool", "qa", "first_done") and aq_mode == ACTQ_NONE and not ctx.needs_input_grad[0] and \
                 CONV_ALGO == _lib.MN_ALGO_AUTO and _lib_().mn_conv2d_first_supported(C.byref(g), 2):
             r = gy._mn_recipe              # the BatchNorm+sign behind the first conv: dy is formed inside the backward-weight kernel
@@ -1804,8 +1905,10 @@ class QConv2d(Function):
                 ws, nb = _ws(g, 2, x.device)
                 _call("mn_conv2d_bwd_weight_first_bn", C.byref(g), _p(r["da"]), _p(r["y"]), _p(r["save"]), _p(r["gamma"]), _p(r["beta"]), _p(r["sums"]),
                       r["training"], _p(x), _p(dw), _p(db), _p(ws), nb, _s())
-            return None, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            return None, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         gy = _chk(gy, "grad")
+        x_shape = getattr(ctx, "x_shape", None) or tuple(x.shape)          # (x is the int8 code buffer when the forward was handed the codes: LazyBNAct)
+        x_numel = x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3]
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         if getattr(ctx, "iao_codes", None) is not None:
             aq.codes = ctx.iao_codes.data_ptr()
@@ -1821,7 +1924,7 @@ class QConv2d(Function):
             d_sc, tok.d_sc = tok.d_sc, None
         with torch.cuda.device_of(x):
             if ctx.needs_input_grad[0]:
-                dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                dx = torch.empty(x_shape, dtype=torch.float32, device=x.device)
                 ws, nb = _ws(g, 1, x.device)
                 # (every operand the dense kernel insists on is checked here: a misaligned view must take the dx.add_ fallback below, not raise inside backward)
                 fold = d_sc is not None and d_sc.shape == dx.shape and d_sc.is_contiguous() and d_sc.data_ptr() % 16 == 0 and wd is not None and \
@@ -1829,7 +1932,7 @@ class QConv2d(Function):
                     bool(_lib_().mn_conv2d_bwd_data_add_supported(C.byref(g), C.byref(aq), C.byref(wd)))
                 if fold:
                     aq.dx_add = d_sc.data_ptr()
-                with _span(g, 1, 4 * (gy.numel() + dx.numel() + wq.numel() + (x.numel() if aq_mode not in (ACTQ_NONE, ACTQ_SIGN8) else 0))):
+                with _span(g, 1, 4 * (gy.numel() + dx.numel() + wq.numel() + (x_numel if aq_mode not in (ACTQ_NONE, ACTQ_SIGN8) else 0))):
                     _call("mn_conv2d_bwd_data", C.byref(g), C.byref(aq), _ref(wd), _p(gy), _p(wq), _p(x), _p(dx), _p(ws), nb, CONV_ALGO, _s())
                 aq.dx_add = None
                 if d_sc is not None and not fold:
@@ -1840,9 +1943,9 @@ class QConv2d(Function):
                 dw = torch.empty_like(wq)
                 db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
                 ws, nb = _ws(g, 2, x.device)
-                with _span(g, 2, 4 * (gy.numel() + x.numel() + dw.numel())):
+                with _span(g, 2, 4 * (gy.numel() + x_numel + dw.numel())):
                     _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class QConv2dLazy(Function):
@@ -2472,7 +2575,7 @@ def channel_shuffle(x, groups):
 
 
 def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None,
-            wdesc=None, x_is_code=False, in_shuffle=0, lazy_for_bn=False, want_accstats=False):
+            wdesc=None, x_is_code=False, in_shuffle=0, lazy_for_bn=False, want_accstats=False, given=None):
     """``in_shuffle`` > 1: the convolution of ``channel_shuffle(x, in_shuffle)``; the permutation is folded into the kernels'
     channel addressing when the code-domain kernels cover all three passes, else materialised."""
     packed = isinstance(x, SignTensor)
@@ -2490,7 +2593,7 @@ def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ
             if in_shuffle and in_shuffle > 1:
                 x, in_shuffle = channel_shuffle(x, in_shuffle), 0
     y = QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc,
-                      (_lib.MN_ACTQ_X_IS_CODE if x_is_code else 0) | (WANT_ACCSTATS if want_accstats else 0), in_shuffle or 0)
+                      (_lib.MN_ACTQ_X_IS_CODE if x_is_code else 0) | (WANT_ACCSTATS if want_accstats else 0), in_shuffle or 0, given)
     tok = getattr(x, "_mn_res_token", None) if aq_mode == ACTQ_IAO else None
     if tok is not None and tok.node is None and y.grad_fn is not None:
         tok.node = weakref.ref(y.grad_fn)          # (the autograd node whose backward-data will consume a parked shortcut gradient)

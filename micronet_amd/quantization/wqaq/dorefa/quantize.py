@@ -208,6 +208,8 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
     q_pool = False          # emit its codes (QActTensor), through the 2x2 max-pool behind the block when q_pool
     q_also_f32 = False      # the consumer is a fused residual block with an identity shortcut: emit the codes AND the fp32 activation (one pass, two autograd outputs)
     emit_minmax = False     # (set by the IAO prepare) leave per-block (min, max) of the output for the observer of the IAO layer that reads it
+    iao_lazy_out = False    # (set by the IAO prepare) the only consumer is the next dense IAO QuantConv2d of the same Sequential: behind a conv that left its epilogue
+    #                         statistics the output stays un-computed (ops.BNActLazy -> LazyBNAct) and that conv pulls its activation codes from y in one pass
 
     def forward(self, input):
         from micronet_amd import ops
@@ -253,6 +255,8 @@ class BatchNorm2dReLU(nn.BatchNorm2d):
             if self.momentum is None:
                 momentum = 1.0 / float(self.num_batches_tracked)
         acc = _accstats_of(input) if (self.training and self.track_running_stats) else None
+        if self.iao_lazy_out and acc is not None and ops.iao_bn_lazy_supported(input, acc):
+            return ops.BNActLazy.apply(input, self.weight, self.bias, self.running_mean, self.running_var, self.eps, momentum, 1, acc)
         if self.emit_minmax and self.training:
             out = ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                    self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, "mn_bnrelu", True, acc)

@@ -375,9 +375,54 @@ class LazyReluGrad(torch.Tensor):
         return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
 
 
+class LazyBNAct(torch.Tensor):
+    """The output of a training-mode BatchNorm2d [+ ReLU] behind a dense IAO convolution (models/resnet.py:17-29) that has NOT been computed: logically the float32
+    activation a = act(bn(y)), physically a recipe (y, the BatchNorm's parameters, the conv's epilogue statistics).  Its consumer -- the next dense IAO ``QuantConv2d``
+    (wqaq/iao/quantize.py:492-507) or the block's ``QuantAdd`` (:1484-1498) -- PULLS: ``prep()`` finishes the batch statistics and hands back the per-channel (min,
+    max) of ``a`` for the consumer's observer (mn_bn_acc_prep: no pass over y), then ONE kernel normalises, rectifies and applies the consumer's quantizer
+    (mn_bn_apply_codes / mn_iao_qadd_bn_fwd); fp32 ``a`` is never written.  Any other consumer goes through ``__torch_dispatch__`` and sees the float32 activation."""
+
+    @staticmethod
+    def __new__(cls, shape, device, recipe):
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=torch.float32, device=device, requires_grad=False)
+        r._mn_recipe, r._mn_value = recipe, None
+        return r
+
+    def __init__(self, shape, device, recipe):
+        pass
+
+    @property
+    def recipe(self):
+        return self._mn_recipe
+
+    def prep(self):
+        """(mm, count): per-channel minima / maxima of the activation (a partials buffer); the first call also finishes save = {mean, invstd} and the running statistics"""
+        return self._mn_recipe["prep"]()
+
+    def materialize(self):
+        if self._mn_value is None:
+            self._mn_value = self._mn_recipe["compute"]()
+        return self._mn_value
+
+    def __repr__(self):
+        return "LazyBNAct(shape=%s, device=%s)" % (tuple(self.shape), self.device)
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _alias_ops() and isinstance(args[0], LazyBNAct):
+            a = args[0]
+            r = LazyBNAct(a.shape, a.device, a._mn_recipe)
+            r._mn_value = a._mn_value
+            return r
+        return func(*tree_map(_unwrap_any, args), **tree_map(_unwrap_any, kwargs))
+
+
 def _unwrap_any(t):
     """The plain tensor a foreign operator should see for any wrapper of this module."""
-    if isinstance(t, (QActTensor, QGrad, LazyQConvOut, LazyBNGrad, LazyPoolGrad, LazyConvOut, LazyReluConvOut, LazyReluGrad)):
+    if isinstance(t, (QActTensor, QGrad, LazyQConvOut, LazyBNGrad, LazyPoolGrad, LazyConvOut, LazyReluConvOut, LazyReluGrad, LazyBNAct)):
         return t.materialize()
     if isinstance(t, SignTensor):
         return t._mn_codes.to(torch.float32)

@@ -1958,6 +1958,71 @@ def check_qdense_iao(be, x_shape, Oc, k=3, stride=1, a_bits=4, w_bits=4, bias=Fa
             # its (min, max) partials describe ITS output exactly
             m2 = be.to_host(mm2)
             assert m2[:cnt].min() == o2.min() and m2[cnt:].max() == o2.max(), ("min / max partials", act)
+            check_bn_lazy_pull(be, r, g, aqs, wq, dX, dWn, dCB, dqp, dWs, bias, yv, dGa, dBe, rm, rv, s2, rm2, rv2, o2, act, a_bits, w_bits)
+
+
+def check_bn_lazy_pull(be, r, g, aqs, wq, dX, dWn, dCB, dqp, dWs, bias, yv, dGa, dBe, rm, rv, s2, rm2, rv2, o2, act, a_bits, w_bits):
+    """The BatchNorm [+ ReLU] behind a dense IAO conv as an un-computed activation whose consumer pulls (round 6; models/resnet.py:17-29 under
+    wqaq/iao/quantize.py:492-507): the conv's epilogue leaves the extrema of its accumulator (mn_actq.acc_mm); mn_bn_acc_prep == mn_bn_fwd_acc's statistics bit for
+    bit AND the per-channel (min, max) of the activation exactly, without a pass; mn_bn_apply_codes == the next dense conv's own code pass on the fp32 activation
+    (codes and clip-STE bits, bit for bit); that conv under MN_ACTQ_CODES_GIVEN == the conv on the fp32 activation, never reading x."""
+    N_, Oc, Ho, Wo = yv.shape
+    HW = Ho * Wo
+    rows = int(be.lib.mn_conv2d_iao_stats_rows(C.byref(g), C.byref(aqs), C.byref(wq)))
+    stats = be.to_dev(np.full((rows, Oc, 4), np.nan, dtype=F))
+    accmm = be.to_dev(np.full((rows, Oc, 2), np.nan, dtype=F))          # rows * Oc * 2 int32
+    aqm = be.actq(2, aqs.bits, 0, dqp)
+    aqm.stats, aqm.acc_mm = be.ptr(stats).value, be.ptr(accmm).value
+    dY = be.conv_fwd(g, aqm, dX, dWn, dCB, 3, wq=wq)
+    assert np.array_equal(be.to_host(dY), yv)
+    am = be.to_host(accmm).view(np.int32).reshape(rows, Oc, 2)
+    sc0 = float(be.to_host(dqp)[0])
+    al = (F(sc0) * be.to_host(dWs).astype(F)).astype(np.float64)
+    cbv = be.to_host(dCB).astype(np.float64).reshape(1, -1, 1, 1) if bias else 0.0
+    acc = np.rint((yv.astype(np.float64) - cbv) / al.reshape(1, -1, 1, 1))
+    assert np.array_equal(am[:, :, 0].min(axis=0), acc.min(axis=(0, 2, 3))) and np.array_equal(am[:, :, 1].max(axis=0), acc.max(axis=(0, 2, 3))), "extrema of acc"
+    rm3, rv3, s3, mm3 = be.to_dev(rm), be.to_dev(rv), be.empty((2, Oc)), be.empty(2 * Oc)
+    be.call("mn_bn_acc_prep", N_, Oc, HW, be.ptr(dGa), be.ptr(dBe), 1e-5, 0.1, be.ptr(rm3), be.ptr(rv3), be.ptr(s3), act, be.ptr(stats), be.ptr(accmm), rows,
+            be.ptr(dqp), be.ptr(dWs), 1, be.ptr(dCB) if bias else None, be.ptr(mm3), be.stream)
+    assert np.array_equal(be.to_host(s3), be.to_host(s2)) and np.array_equal(be.to_host(rm3), be.to_host(rm2)) and np.array_equal(be.to_host(rv3), be.to_host(rv2)), \
+        ("prep statistics", act)
+    m3 = be.to_host(mm3)
+    assert np.array_equal(m3[:Oc], o2.min(axis=(0, 2, 3))) and np.array_equal(m3[Oc:], o2.max(axis=(0, 2, 3))), ("per-channel extrema of the activation", act)
+    a3 = be.empty(yv.shape)
+    be.call("mn_bn_apply", be.ptr(dY), N_, Oc, HW, be.ptr(dGa), be.ptr(dBe), be.ptr(s3), act, be.ptr(a3), be.stream)
+    assert np.array_equal(be.to_host(a3), o2), ("mn_bn_apply", act)
+    if HW % 8 or Oc % 64 or Wo % 4:
+        return
+    # the consumer: a dense 3 x 3 IAO conv on that activation, its quantizer's range = the activation's own (and half of it: the clip conditions decide)
+    w2_shape = (64, Oc, 3, 3)
+    w2, wkw2, wscale2 = make_coded_weights(r, w2_shape, 3, w_bits)
+    dW2, dWs2 = be.to_dev(w2), be.to_dev(wscale2)
+    wq2 = be.wq(scale=dWs2, **wkw2)
+    g2 = be.geom(yv.shape, w2_shape, 1, 1)
+    for shrink in (1.0, 0.5):
+        mn, mx = F(o2.min() * shrink), F(o2.max() * shrink)
+        sc, zp = O.iao_qparams(mn.reshape(1), mx.reshape(1), a_bits, 0, True)
+        hi = max(abs(mn / sc[0]), abs(mx / sc[0]))
+        dqp2 = be.to_dev(np.array([sc[0], zp[0], -hi, hi], dtype=F))
+        aq2 = be.actq(2, a_bits, 0, dqp2)
+        nc = int(be.lib.mn_conv2d_iao_codes_bytes(C.byref(g2), C.byref(aq2), C.byref(wq2)))
+        if nc <= 0:
+            return
+        c_ref, m_ref = be.empty_i8((nc,)), be.empty_i8((nc // 8,))
+        aq2.codes, aq2.ste_mask = be.ptr(c_ref).value, be.ptr(m_ref).value
+        y_ref = be.to_host(be.conv_fwd(g2, aq2, be.to_dev(o2), dW2, None, 3, wq=wq2))
+        c_new, m_new = be.empty_i8((nc,)), be.empty_i8((nc // 8,))
+        be.call("mn_bn_apply_codes", be.ptr(dY), N_, Oc, HW, be.ptr(dGa), be.ptr(dBe), be.ptr(s3), act, be.ptr(dqp2), a_bits, be.ptr(c_new), be.ptr(m_new), be.stream)
+        n = o2.size
+        assert np.array_equal(be.to_host(c_new)[:n], be.to_host(c_ref)[:n]), ("codes", act, shrink)
+        assert np.array_equal(be.to_host(m_new)[:n // 8], be.to_host(m_ref)[:n // 8]), ("clip-STE bits", act, shrink)
+        aq3 = be.actq(2, a_bits, 0, dqp2, flags=2)          # MN_ACTQ_CODES_GIVEN
+        aq3.codes, aq3.ste_mask = be.ptr(c_new).value, be.ptr(m_new).value
+        y_new = be.to_host(be.conv_fwd(g2, aq3, be.to_dev(np.full(o2.shape, np.nan, dtype=F)), dW2, None, 3, wq=wq2))
+        assert np.array_equal(y_new, y_ref), ("conv on handed-over codes", act, shrink)
+        if shrink < 1.0 and act == 2:
+            bits = np.unpackbits(be.to_host(m_new)[:n // 8].view(np.uint8))
+            assert 0.002 * n < np.count_nonzero(bits == 0) < 0.9 * n          # (the clip is exercised)
 
 
 def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, False), update=True, seed=0, relu=False):

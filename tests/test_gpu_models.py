@@ -453,6 +453,49 @@ def test_iao_resnet_shortcut_gradient_folded_into_backward_data(monkeypatch):
         assert torch.equal(grads[True][k], grads[False][k]), k
 
 
+def _iao_resnet_two_steps(monkeypatch, iaoq_knobs, batch=8):
+    """two training steps of the IAO resnet18 (observer first call, then the EMA update) -> (losses, parameters, every buffer), + the prepared model of step 2"""
+    from micronet_amd.quantization.wqaq.iao import quantize as iaoq
+    from micronet_amd.train import build_model, make_optimizer, synth_batch, train_step
+    arch, scheme, kw, B, wd = CFG["c5_resnet18_iao_w4a4"]
+    for k, v in iaoq_knobs.items():
+        monkeypatch.setattr(iaoq, k, v)
+    model = iaoq.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+    opt = make_optimizer(model, 0.01, wd)
+    losses = []
+    for step in range(2):
+        x, y = synth_batch(batch, seed=77 + step, device="cuda")
+        losses.append(float(train_step(model, opt, x, y)[0]))
+    return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, model
+
+
+def test_iao_resnet_bn_relu_codes_one_pass(monkeypatch):
+    """Round 6: inside an IAO BasicBlock (models/resnet.py:17-29 under wqaq/iao/quantize.py:492-507) the activation between the two convs stays un-computed
+    (LazyBNAct): its range comes from the first conv's accumulator extrema, the second conv pulls its codes from the first conv's output in one pass.  Same codes,
+    same clip-STE bits, same observer state: two training steps are bit-identical to the unfused modules -- losses, every parameter, every buffer -- and the eight
+    blocks of resnet18 all take the path (no fp32 activation materialised)."""
+    from micronet_amd import ops
+    n = {"pull": 0, "mat": 0}
+    real_pull, real_mat = ops.iao_bn_apply_codes, ops.LazyBNActToFloat.apply
+    monkeypatch.setattr(ops, "iao_bn_apply_codes", lambda *a, **k: (n.__setitem__("pull", n["pull"] + 1), real_pull(*a, **k))[1])
+    monkeypatch.setattr(ops.LazyBNActToFloat, "apply", staticmethod(lambda *a: (n.__setitem__("mat", n["mat"] + 1), real_mat(*a))[1]))
+    l1, s1, m1 = _iao_resnet_two_steps(monkeypatch, dict(_FUSE_BN_CODES=True))
+    assert n == {"pull": 16, "mat": 0}, n
+    l0, s0, _ = _iao_resnet_two_steps(monkeypatch, dict(_FUSE_BN_CODES=False))
+    assert n == {"pull": 16, "mat": 0}, n
+    assert l1 == l0, (l1, l0)
+    for k in s0:
+        assert torch.equal(s1[k], s0[k]) or (torch.isnan(s1[k]).all() and torch.isnan(s0[k]).all()), k
+    # a foreign consumer of the un-computed activation sees the float32 tensor the unfused BatchNorm + ReLU writes
+    from micronet_amd.sign_tensor import LazyBNAct
+    blk = m1.conv2_x[0].residual_function
+    x = torch.randn(4, 64, 32, 32, device="cuda")
+    lazy = blk[2](blk[1](blk[0](x)))
+    assert isinstance(lazy, LazyBNAct)
+    a = lazy + 0.0
+    assert type(a) is torch.Tensor and a.shape == lazy.shape and float(a.min()) == 0.0
+
+
 @pytest.mark.parametrize("key", ["c2_nin_gc_wbwtab_w3a2", "c1_nin_gc_dorefa_w8a8", "c5_resnet18_iao_w4a4"])
 def test_forward_without_backward_does_not_leak(key):
     """A grad-enabled training-mode forward that is never backpropagated (a skipped step, an exception) must not keep its activations alive: the hand-over objects
