@@ -420,6 +420,19 @@ int mn_bn_acc_prep(int64_t N, int64_t C, int64_t HW, const float* gamma, const f
 int mn_bn_apply_codes(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, int act, const float* qp, int bits,
                       int8_t* codes, uint8_t* ste_mask, mn_stream_t stream);
 int mn_bn_apply(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, const float* save, int act, float* a, mn_stream_t stream);
+/* The END of an IAO residual block in one pass: out = [relu] (Q(res) + Q(shortcut)) with res = bn(res_y) and shortcut = sc_x itself (sc_save NULL: identity) or bn(sc_x)
+ * (the down-sampling blocks), one shared per-tensor quantizer qp (models/resnet.py:21-29, 60-65 with QuantAdd, wqaq/iao/quantize.py:1484-1498) -- instead of one
+ * BatchNorm apply pass per side + mn_iao_qadd_fwd.  *_save = {mean, invstd} [2][C] as mn_bn_acc_prep finishes them (which also hands the QuantAdd's two input observers
+ * their ranges: mn_iao_qadd_observe_partials).  mm (nullable): 2 * mn_bnrelu_mm_count(N, C, HW) floats, per-block (min, max) of out.  bits_res / bits_sc: N * C * HW / 8
+ * bytes each; bit e of byte i = element 8 i + e: (the ReLU passes) and (the quantizer's clip-STE passes that input) -- what mn_iao_qadd_bn_bwd reads.  HW % 8 == 0.
+ * mn_iao_qadd_bn_bwd: backward of ONE BatchNorm side from g = d loss / d out: dy (+ dgamma, dbeta) of that BatchNorm, the gradient of its output formed from (g, bits)
+ * on the way; d_other (nullable, with bits_other): the gradient of the other input -- the identity shortcut's -- from the same read of g.  Bit-identical to
+ * mn_iao_qadd_bwd followed by mn_bn2d_bwd.  ws: mn_bnsign_ws_floats(C) floats. */
+int mn_iao_qadd_bn_fwd(const float* res_y, const float* res_save, const float* res_gamma, const float* res_beta, const float* sc_x, const float* sc_save,
+                       const float* sc_gamma, const float* sc_beta, int64_t N, int64_t C, int64_t HW, const float* qp, int bits, int q_type, int relu, float* out, float* mm,
+                       uint8_t* bits_res, uint8_t* bits_sc, mn_stream_t stream);
+int mn_iao_qadd_bn_bwd(const float* g, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C, int64_t HW, const float* qp,
+                       const uint8_t* bits, const uint8_t* bits_other, float* dy, float* d_other, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
 /* the two halves of mn_bnsign_bwd for a consumer that forms dy itself: mn_bnsign_bwd_sums = dgamma, dbeta and sums [2][C] =
  * {sum dz, sum dz*zhat}; mn_conv2d_bwd_weight_first_bn = backward-weight (+ dbias) of the first-layer convolution
  * (mn_conv2d_first_supported) whose output y went through BatchNorm2d + BinaryActivation: dy is formed from (da, y, save, gamma,

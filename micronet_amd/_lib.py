@@ -158,6 +158,8 @@ PROTOTYPES = {
     "mn_bn_acc_prep": (_I, [_L, _L, _L, _P, _P, C.c_float, C.c_float, _P, _P, _P, _I, _P, _P, _L, _P, _P, _L, _P, _P, _P]),
     "mn_bn_apply_codes": (_I, [_P, _L, _L, _L, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
     "mn_bn_apply": (_I, [_P, _L, _L, _L, _P, _P, _P, _I, _P, _P]),
+    "mn_iao_qadd_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "mn_iao_qadd_bn_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mn_iao_w_fwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _I, _I, _P]),
     "mn_iao_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mn_iao_qadd_ws_floats": (_L, []),

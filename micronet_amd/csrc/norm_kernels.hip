@@ -46,19 +46,28 @@ __device__ __forceinline__ float bns_sign(float z) { return (z < 0.f) ? -1.f : (
 __device__ __forceinline__ float bns_relu(float z) { return (z > 0.f) ? z : ((z != z) ? z : 0.f); }       // torch.relu: NaN stays
 
 // MODE 0: s1 = sum(y - pivot), s2 = sum((y - pivot)^2).   MODE 1: s1 = sum dz, s2 = sum dz * zhat.
-template <int MODE>
+// QB (MODE 1, plain BatchNorm): `da` is the gradient of the OUTPUT of the QuantAdd [+ ReLU] this BatchNorm feeds (wqaq/iao/quantize.py:1484-1498); the gradient of the
+// BatchNorm's own output is formed on the way -- qb.bits: one bit per element = (ReLU passes) and (the shared quantizer's clip-STE passes this input), written by the
+// fused forward (k_qadd_bn_fwd); a passing element carries (g * sc) / sc, iao_fq_grad's value.  Same thread -> element map and summation order as without QB.
+struct BnsQB { const unsigned char* bits; const unsigned char* bits_sc; float* dsc; const float* qp; };
+__device__ __forceinline__ uint32_t bns_qb_nibble(const unsigned char* __restrict__ bits, int64_t off) { return ((uint32_t)bits[off >> 3] >> (uint32_t)(off & 4)) & 15u; }
+template <int MODE, int QB = 0>
 __global__ __launch_bounds__(256) void k_bns_partial(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ da,
                                                      const float* __restrict__ save, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, double* __restrict__ part) {
+                                                     const float* __restrict__ beta, double* __restrict__ part, const BnsQB qb) {
     __shared__ double scd[16];
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
     float pivot = 0.f, mean = 0.f, invstd = 0.f, ga = 0.f, be = 0.f;
     if (MODE == 0) pivot = y[(int64_t)c * g.HW];
     else { mean = save[c]; invstd = save[g.C + c]; ga = gamma[c]; be = beta[c]; }
+    float q_sc = 1.f, q_inv = 1.f;
+    if (QB) { q_sc = qb.qp[0]; q_inv = 1.0f / q_sc; }
     double s1 = 0.0, s2 = 0.0;
     float4 v_[2], gg_[2];
+    uint32_t nb_[2];
 #define BNSP_LOAD(k, idx) { const int64_t off = bns_off(g, c, (uint32_t)(idx)); v_[k] = *reinterpret_cast<const float4*>(y + off); \
-                            if (MODE == 1) gg_[k] = *reinterpret_cast<const float4*>(da + off); }
+                            if (MODE == 1) gg_[k] = *reinterpret_cast<const float4*>(da + off);                                    \
+                            if (QB) nb_[k] = bns_qb_nibble(qb.bits, off); }
 #define BNSP_FIN(k) { const float4 v = v_[k];                                                                                         \
         if (MODE == 0) {                                                                                                              \
             const float a = v.x - pivot, b = v.y - pivot, cc = v.z - pivot, d = v.w - pivot;                                          \
@@ -67,7 +76,8 @@ __global__ __launch_bounds__(256) void k_bns_partial(const BnsGeom g, const floa
         } else {                                                                                                                      \
             const float4 gg = gg_[k];                                                                                                 \
             const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};         \
-            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};                                                                             \
+            float gv[4] = {gg.x, gg.y, gg.z, gg.w};                                                                                   \
+            if (QB) { _Pragma("unroll") for (int e = 0; e < 4; ++e) gv[e] = ((nb_[k] >> e) & 1u) ? mn_div_m(gv[e] * q_sc, q_sc, q_inv) : 0.f; } \
             float t1 = 0.f, t2 = 0.f;                                                                                                 \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                           \
                 const float z = zh[e] * ga + be;                                                                                      \
@@ -145,10 +155,13 @@ struct BnsFin {
     int sw_stride;
     const float* cbias;            // nullable
 };
-template <int MODE, int OUT8 = 0>
+template <int MODE, int OUT8 = 0, int QB = 0>
 __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float* __restrict__ y, const float* __restrict__ da,
                                                    const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   const float* __restrict__ sums, int training, float* __restrict__ out, float* __restrict__ mm, const BnsFin fin) {
+                                                   const float* __restrict__ sums, int training, float* __restrict__ out, float* __restrict__ mm, const BnsFin fin,
+                                                   const BnsQB qb) {
+    // QB (MODE 1): as k_bns_partial<1, 1>; qb.dsc (nullable): the gradient of the QuantAdd's OTHER input (an identity shortcut) from the same read of the output
+    // gradient -- (g * sc) / sc where qb.bits_sc passes
     // mm (forward, fp32 output only; may be null): per-block min / max of the values written -> mm[block], mm[nblocks + block]: the NEXT layer's IAO observer
     // (wqaq/iao/quantize.py:23-36) reduces these instead of reading the activation again (mn_iao_observe_partials)
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
@@ -215,10 +228,14 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
         }
     }
     const float gi = ga * invstd;
+    float q_sc = 1.f, q_inv = 1.f;
+    if (QB) { q_sc = qb.qp[0]; q_inv = 1.0f / q_sc; }
     float4 v_[2], gg_[2];
     int64_t off_[2];
+    uint32_t nb_[2], ns_[2];
 #define BNSA_LOAD(k, idx) { off_[k] = bns_off(g, c, (uint32_t)(idx)); v_[k] = *reinterpret_cast<const float4*>(y + off_[k]); \
-                            if (MODE == 1) gg_[k] = *reinterpret_cast<const float4*>(da + off_[k]); }
+                            if (MODE == 1) gg_[k] = *reinterpret_cast<const float4*>(da + off_[k]);                          \
+                            if (QB) { nb_[k] = bns_qb_nibble(qb.bits, off_[k]); if (qb.dsc) ns_[k] = bns_qb_nibble(qb.bits_sc, off_[k]); } }
 #define BNSA_FIN(k) { const float4 v = v_[k]; const int64_t off = off_[k];                                                            \
         const float zh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};             \
         float r[4];                                                                                                                   \
@@ -226,7 +243,13 @@ __global__ __launch_bounds__(256) void k_bns_apply(const BnsGeom g, const float*
             _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float z = zh[e] * ga + be; r[e] = g.act == 2 ? z : (g.act ? bns_relu(z) : bns_sign(z)); } \
         } else {                                                                                                                      \
             const float4 gg = gg_[k];                                                                                                 \
-            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};                                                                             \
+            float gv[4] = {gg.x, gg.y, gg.z, gg.w};                                                                                   \
+            if (QB) {                                                                                                                 \
+                float t[4];                                                                                                           \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) { t[e] = mn_div_m(gv[e] * q_sc, q_sc, q_inv); gv[e] = ((nb_[k] >> e) & 1u) ? t[e] : 0.f; } \
+                if (qb.dsc) *reinterpret_cast<float4*>(qb.dsc + off) = make_float4((ns_[k] & 1u) ? t[0] : 0.f, (ns_[k] & 2u) ? t[1] : 0.f, (ns_[k] & 4u) ? t[2] : 0.f, \
+                                                                                  (ns_[k] & 8u) ? t[3] : 0.f);                      \
+            }                                                                                                                         \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                           \
                 const float z = zh[e] * ga + be;                                                                                      \
                 const float dz = (g.act == 2 || (g.act ? (z > 0.f) : (z > -1.f && z < 1.f))) ? gv[e] : 0.f;                                           \
@@ -466,7 +489,7 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
     } else if (training) {
         mn_set_last_kernel("k_bns_partial<0>"); mn_prof_bytes(4.0 * nel); mn_prof_begin(s);
         hipLaunchKernelGGL(k_bns_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (double*)ws);
+                           (const float*)nullptr, (const float*)nullptr, (double*)ws, BnsQB());
         mn_prof_end(s);
         fin.part = (const double*)ws; fin.S = S; fin.eps = eps; fin.momentum = momentum; fin.running_mean = running_mean; fin.running_var = running_var; fin.save_out = save;
     } else {
@@ -474,9 +497,9 @@ static int bnsign_fwd_impl(const float* y, int64_t N, int64_t C, int64_t HW, con
     }
     mn_set_last_kernel(out8 ? "k_bns_apply<0, 1>" : "k_bns_apply<0, 0>"); mn_prof_bytes((out8 ? 5.0 : 8.0) * nel); mn_prof_begin(s);
     if (out8) hipLaunchKernelGGL((k_bns_apply<0, 1>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
-                                 (const float*)nullptr, training, a, (float*)nullptr, fin);
+                                 (const float*)nullptr, training, a, (float*)nullptr, fin, BnsQB());
     else hipLaunchKernelGGL((k_bns_apply<0, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
-                            (const float*)nullptr, training, a, mm, fin);
+                            (const float*)nullptr, training, a, mm, fin, BnsQB());
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bnsign_fwd");
     return MN_OK;
@@ -495,7 +518,7 @@ extern "C" int mn_bn_save_stats(const float* y, int64_t N, int64_t C, int64_t HW
     if (training) {
         mn_set_last_kernel("k_bns_partial<0>"); mn_prof_bytes(4.0 * (double)N * C * HW); mn_prof_begin(s);
         hipLaunchKernelGGL(k_bns_partial<0>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (double*)ws);
+                           (const float*)nullptr, (const float*)nullptr, (double*)ws, BnsQB());
         mn_prof_end(s);
         hipLaunchKernelGGL(k_bns_final_fwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, y, (const double*)ws, S, eps, momentum, running_mean, running_var, save);
     } else {
@@ -529,7 +552,7 @@ extern "C" int mn_bnsign_bwd_sums(const float* da, const float* y, const float* 
     const BnsGeom g = bns_geom(N, C, HW);
     const int S = bns_split(g);
     mn_set_last_kernel("k_bns_partial<1>"); mn_prof_bytes(8.0 * (double)N * C * HW); mn_prof_begin(s);
-    hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws);
+    hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws, BnsQB());
     mn_prof_end(s);
     hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, g, (const double*)ws, S, dgamma, dbeta, sums);
     MN_CHECK_LAUNCH("mn_bnsign_bwd_sums");
@@ -589,7 +612,7 @@ extern "C" int mn_bn_fwd_acc(const float* y, int64_t N, int64_t C, int64_t HW, c
     fin.kind = 1; fin.sa = sa; fin.sw = sw; fin.sw_stride = (int)sw_stride; fin.cbias = conv_bias;
     mn_set_last_kernel("k_bns_apply<0, 0>"); mn_prof_bytes(8.0 * (double)N * C * HW); mn_prof_begin(s);
     hipLaunchKernelGGL((k_bns_apply<0, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, (const float*)nullptr, (const float*)save, gamma, beta,
-                       (const float*)nullptr, 1, a, mm, fin);
+                       (const float*)nullptr, 1, a, mm, fin, BnsQB());
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bn_fwd_acc");
     return MN_OK;
@@ -734,6 +757,124 @@ extern "C" int mn_bn_apply(const float* y, int64_t N, int64_t C, int64_t HW, con
     if (act != 1 && act != 2) MN_FAIL(MN_EINVAL, "mn_bn_apply: act must be 1 (ReLU) or 2 (none)");
     return bnsign_fwd_impl(y, N, C, HW, gamma, beta, 0.f, 0.f, 1, nullptr, nullptr, const_cast<float*>(save), a, 0, nullptr, stream, act, nullptr, true);
 }
+// ---------------------------------------------------------------- the END of an IAO residual block: BatchNorm(s) + QuantAdd [+ ReLU] in one pass
+// out = [relu] (Q(res) + Q(shortcut)) with res = bn(y_res) and shortcut = a plain tensor (identity) or bn(y_sc) (the down-sampling blocks), one shared per-tensor
+// quantizer (models/resnet.py:21-29, 60-65 under wqaq/iao/quantize.py:1484-1498).  Unfused that is a BatchNorm apply pass per side (8 B per element each) + k_qadd_fwd
+// (12 B); here 12.25 B: the BatchNorm outputs never exist.  Their ranges -- the QuantAdd's two input observers see the whole tensors first -- come from the convs'
+// accumulator extrema (mn_bn_acc_prep).  Expression for expression k_bns_apply<0, 0> (act none) -> iao_fq x 2 -> add -> qa_relu, with a / sc as Markstein's
+// correctly rounded quotient.  Also leaves, for the backward, one bit per element and side: (the ReLU passes) and (the quantizer's clip-STE passes that input) --
+// k_bns_partial<1, 1> / k_bns_apply<1, 0, 1> read them next to the output gradient, so neither d res nor d shortcut is written for a BatchNorm to read back.
+struct QabParams {
+    BnsGeom g;
+    const float *res_y, *res_save, *res_gamma, *res_beta;
+    const float *sc_x, *sc_save, *sc_gamma, *sc_beta;          // sc_save == null: the shortcut is sc_x itself
+    const float* qp;
+    float qmin, qmax;
+    float *out, *mm;
+    unsigned char *bits_res, *bits_sc;
+};
+template <int RELU, int SCBN>
+__global__ __launch_bounds__(256) void k_qadd_bn_fwd(const QabParams p) {
+    const BnsGeom& g = p.g;
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const float mean = p.res_save[c], invstd = p.res_save[g.C + c], ga = p.res_gamma[c], be = p.res_beta[c];
+    float mean2 = 0.f, invstd2 = 1.f, ga2 = 1.f, be2 = 0.f;
+    if (SCBN) { mean2 = p.sc_save[c]; invstd2 = p.sc_save[g.C + c]; ga2 = p.sc_gamma[c]; be2 = p.sc_beta[c]; }
+    const float sc = p.qp[0], zp = p.qp[1], rlo = p.qp[2], rhi = p.qp[3], qmin = p.qmin, qmax = p.qmax;
+    const float inv = 1.0f / sc;
+    const uint32_t HW8 = (uint32_t)g.HW4 >> 1;
+    const int64_t n8 = g.n4 >> 1;
+    float mlo = INFINITY, mhi = -INFINITY;
+    float4 ra_[2], rb_[2], sa_[2], sb_[2];
+    int64_t off_[2];
+#define QAB_LOAD(k, idx) { const uint32_t n_ = fd_div(2u * (uint32_t)(idx), g.fd_hw4); off_[k] = ((int64_t)n_ * g.C + c) * g.HW + (int64_t)((uint32_t)(idx) - n_ * HW8) * 8; \
+                           ra_[k] = *reinterpret_cast<const float4*>(p.res_y + off_[k]); rb_[k] = *reinterpret_cast<const float4*>(p.res_y + off_[k] + 4);                   \
+                           sa_[k] = *reinterpret_cast<const float4*>(p.sc_x + off_[k]); sb_[k] = *reinterpret_cast<const float4*>(p.sc_x + off_[k] + 4); }
+#define QAB_FIN(k) { const float rv[8] = {ra_[k].x, ra_[k].y, ra_[k].z, ra_[k].w, rb_[k].x, rb_[k].y, rb_[k].z, rb_[k].w};                                                   \
+        const float sv[8] = {sa_[k].x, sa_[k].y, sa_[k].z, sa_[k].w, sb_[k].x, sb_[k].y, sb_[k].z, sb_[k].w};                                                                \
+        float o[8];                                                                                                                                                          \
+        uint32_t mr = 0u, ms = 0u;                                                                                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                                                                      \
+            const float zh = (rv[e] - mean) * invstd;                                                                                                                        \
+            const float a = zh * ga + be;                                                                                                                                    \
+            float b = sv[e];                                                                                                                                                 \
+            if (SCBN) { const float zh2 = (b - mean2) * invstd2; b = zh2 * ga2 + be2; }                                                                                     \
+            const float va = mn_div_m(a, sc, inv) - zp, vb = mn_div_m(b, sc, inv) - zp;                                                                                      \
+            const float ra = mn_rha(va), rb = mn_rha(vb);                                                                                                                    \
+            const float sum = (mn_clamp(ra, qmin, qmax) + zp) * sc + (mn_clamp(rb, qmin, qmax) + zp) * sc;                                                                   \
+            o[e] = RELU ? qa_relu(sum) : sum;                                                                                                                                \
+            const bool live = !RELU || sum > 0.f;                                                                                                                            \
+            mr |= ((live && ra >= qmin && ra <= qmax && !(va > rhi || va < rlo)) ? 1u : 0u) << e;                                                                            \
+            ms |= ((live && rb >= qmin && rb <= qmax && !(vb > rhi || vb < rlo)) ? 1u : 0u) << e;                                                                            \
+        }                                                                                                                                                                    \
+        *reinterpret_cast<float4*>(p.out + off_[k]) = make_float4(o[0], o[1], o[2], o[3]);                                                                                   \
+        *reinterpret_cast<float4*>(p.out + off_[k] + 4) = make_float4(o[4], o[5], o[6], o[7]);                                                                               \
+        p.bits_res[off_[k] >> 3] = (unsigned char)mr; p.bits_sc[off_[k] >> 3] = (unsigned char)ms;                                                                           \
+        if (p.mm) { _Pragma("unroll") for (int e = 0; e < 8; ++e) { mlo = OpMinF()(mlo, o[e]); mhi = OpMaxF()(mhi, o[e]); } } }
+    MN_STREAM_2(i, (int64_t)sp * 256 + threadIdx.x, (int64_t)S * 256, n8, QAB_LOAD, QAB_FIN)
+#undef QAB_LOAD
+#undef QAB_FIN
+    if (p.mm) {
+        __shared__ float scm[16];
+        mlo = block_reduce(mlo, OpMinF(), INFINITY, scm);
+        mhi = block_reduce(mhi, OpMaxF(), -INFINITY, scm);
+        if (threadIdx.x == 0) { const int b = sp * (int)gridDim.x + c, nb = (int)(gridDim.x * gridDim.y); p.mm[b] = mlo; p.mm[nb + b] = mhi; }
+    }
+}
+extern "C" int mn_iao_qadd_bn_fwd(const float* res_y, const float* res_save, const float* res_gamma, const float* res_beta, const float* sc_x, const float* sc_save,
+                                  const float* sc_gamma, const float* sc_beta, int64_t N, int64_t C, int64_t HW, const float* qp, int bits, int q_type, int relu, float* out,
+                                  float* mm, uint8_t* bits_res, uint8_t* bits_sc, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, res_y, out, "mn_iao_qadd_bn_fwd");
+    if (rc) return rc;
+    if (!res_y || !res_save || !res_gamma || !res_beta || !sc_x || !aligned16(sc_x) || (sc_save && (!sc_gamma || !sc_beta)) || !qp || !out || !bits_res || !bits_sc || HW % 8 ||
+        bits < 2 || bits > 24 || (q_type != 0 && q_type != 1))
+        MN_FAIL(MN_EINVAL, "mn_iao_qadd_bn_fwd: null / misaligned argument, HW not a multiple of 8 or a bad bit width");
+    QabParams p;
+    p.g = bns_geom(N, C, HW);
+    p.g.act = 2;
+    const int S = bns_split(p.g);
+    const IaoRange r = iao_range(bits, q_type, 1);
+    p.res_y = res_y; p.res_save = res_save; p.res_gamma = res_gamma; p.res_beta = res_beta; p.sc_x = sc_x; p.sc_save = sc_save; p.sc_gamma = sc_gamma; p.sc_beta = sc_beta;
+    p.qp = qp; p.qmin = r.qmin; p.qmax = r.qmax; p.out = out; p.mm = mm; p.bits_res = bits_res; p.bits_sc = bits_sc;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)C, (unsigned)S);
+    mn_set_last_kernel("k_qadd_bn_fwd<%d, %d>", relu ? 1 : 0, sc_save ? 1 : 0); mn_prof_bytes(12.25 * (double)N * C * HW); mn_prof_begin(s);
+    if (relu && sc_save) hipLaunchKernelGGL((k_qadd_bn_fwd<1, 1>), grid, dim3(256), 0, s, p);
+    else if (relu) hipLaunchKernelGGL((k_qadd_bn_fwd<1, 0>), grid, dim3(256), 0, s, p);
+    else if (sc_save) hipLaunchKernelGGL((k_qadd_bn_fwd<0, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_qadd_bn_fwd<0, 0>), grid, dim3(256), 0, s, p);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_iao_qadd_bn_fwd");
+    return MN_OK;
+}
+// backward of ONE BatchNorm side of that block: g = the gradient of the block's output; the gradient of the BatchNorm's own output is formed from (g, bits) on the way
+// (two passes over (g, y) like mn_bn2d_bwd, same order of summation: bit-identical to mn_iao_qadd_bwd -> mn_bn2d_bwd).  d_other (nullable; with bits_other): the
+// gradient of the QuantAdd's other input from the same read of g -- the identity shortcut's.
+extern "C" int mn_iao_qadd_bn_bwd(const float* g, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C, int64_t HW, const float* qp,
+                                  const uint8_t* bits, const uint8_t* bits_other, float* dy, float* d_other, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
+    int rc = bns_check(N, C, HW, y, dy, "mn_iao_qadd_bn_bwd");
+    if (rc) return rc;
+    if (!g || !y || !save || !gamma || !beta || !dy || !ws || !qp || !bits || (d_other && (!bits_other || !aligned16(d_other))) || !aligned16(g) || (((uintptr_t)ws) & 7) || HW % 8)
+        MN_FAIL(MN_EINVAL, "mn_iao_qadd_bn_bwd: null / misaligned argument");
+    hipStream_t s = (hipStream_t)stream;
+    BnsGeom gg = bns_geom(N, C, HW);
+    gg.act = 2;
+    const int S = bns_split(gg);
+    float* sums = ws + C * BNS_SPLIT * 4;
+    const double nel = (double)N * C * HW;
+    BnsQB qb;
+    qb.bits = bits; qb.bits_sc = bits_other; qb.dsc = d_other; qb.qp = qp;
+    mn_set_last_kernel("k_bns_partial<1, 1>"); mn_prof_bytes(8.125 * nel); mn_prof_begin(s);
+    hipLaunchKernelGGL((k_bns_partial<1, 1>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, gg, y, g, save, gamma, beta, (double*)ws, qb);
+    mn_prof_end(s);
+    BnsFin fin = {};
+    fin.part = (const double*)ws; fin.S = S; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.sums_out = sums;
+    mn_set_last_kernel("k_bns_apply<1, 0, 1>"); mn_prof_bytes((d_other ? 16.25 : 12.125) * nel); mn_prof_begin(s);
+    hipLaunchKernelGGL((k_bns_apply<1, 0, 1>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, gg, y, g, save, gamma, beta, (const float*)sums, 1, dy, (float*)nullptr, fin, qb);
+    mn_prof_end(s);
+    MN_CHECK_LAUNCH("mn_iao_qadd_bn_bwd");
+    return MN_OK;
+}
 extern "C" int mn_bn2d_bwd(const float* da, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C,
                            int64_t HW, int training, float* dy, float* dgamma, float* dbeta, float* ws, mn_stream_t stream) {
     return bnsign_bwd_impl(da, y, save, gamma, beta, N, C, HW, training, dy, dgamma, dbeta, ws, stream, 2);
@@ -750,12 +891,12 @@ static int bnsign_bwd_impl(const float* da, const float* y, const float* save, c
     float* sums = ws + C * BNS_SPLIT * 4;
     const double nel = (double)N * C * HW;
     mn_set_last_kernel("k_bns_partial<1>"); mn_prof_bytes(8.0 * nel); mn_prof_begin(s);
-    hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws);
+    hipLaunchKernelGGL(k_bns_partial<1>, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (double*)ws, BnsQB());
     mn_prof_end(s);
     BnsFin fin = {};
     fin.part = (const double*)ws; fin.S = S; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.sums_out = sums;
     mn_set_last_kernel("k_bns_apply<1, 0>"); mn_prof_bytes(12.0 * nel); mn_prof_begin(s);
-    hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy, (float*)nullptr, fin);
+    hipLaunchKernelGGL((k_bns_apply<1, 0>), dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, y, da, save, gamma, beta, (const float*)sums, training, dy, (float*)nullptr, fin, BnsQB());
     mn_prof_end(s);
     MN_CHECK_LAUNCH("mn_bnsign_bwd");
     return MN_OK;

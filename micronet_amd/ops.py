@@ -524,6 +524,83 @@ class IaoQuantAdd(Function):
         return da, db, None, None, None, None, None, None
 
 
+def _ste_from_bits(g, bits, qp):
+    """(g * sc) / sc where the bit passes, else 0 -- the gradient of one QuantAdd input from the fused forward's pass bits (torch ops: only a foreign consumer of the
+    un-computed gradient ever gets here)"""
+    sc = qp.reshape(-1)[0]
+    t = (g * sc) / sc
+    m = ((bits.reshape(-1, 1) >> torch.arange(8, device=bits.device, dtype=torch.uint8)) & 1).reshape(-1)[:g.numel()].reshape(g.shape).bool()
+    return torch.where(m, t, torch.zeros((), dtype=g.dtype, device=g.device))
+
+
+class IaoQuantAddBN(Function):
+    """The END of an IAO residual block (models/resnet.py:21-29, 60-65 with QuantAdd, wqaq/iao/quantize.py:1484-1498) in one pass: ``res`` -- and, in a down-sampling
+    block, ``shortcut`` -- arrive as ``LazyBNAct`` (the un-computed output of the BatchNorm behind a dense conv; ``prep()`` has run: the QuantAdd's observers took
+    their ranges from it) and out = [relu] (Q(bn(y_res)) + Q(shortcut)) is written straight from the convs' outputs (mn_iao_qadd_bn_fwd).  Backward: each BatchNorm
+    side in two passes over (g, y) with the quantizer's clip-STE and the ReLU mask read as bits (mn_iao_qadd_bn_bwd) -- handed to that BatchNorm's autograd node as a
+    finished ``LazyBNGrad(kind="bn_done")``; the identity shortcut's gradient comes out of the res side's apply pass."""
+
+    @staticmethod
+    def forward(ctx, res, shortcut, qp, bits, q_type, relu, want_minmax, res_tok):
+        r = res.recipe
+        y = r["y"]
+        N, Cc, H, W = y.shape
+        dev = y.device
+        sb = isinstance(shortcut, LazyBNAct)
+        q = shortcut.recipe if sb else None
+        sc_x = q["y"] if sb else _chk(shortcut, "shortcut")
+        out = torch.empty_like(y)
+        bits_r = torch.empty(y.numel() // 8, dtype=torch.uint8, device=dev)
+        bits_s = torch.empty(y.numel() // 8, dtype=torch.uint8, device=dev)
+        mm, count = None, 0
+        with torch.cuda.device(dev):
+            if want_minmax:
+                count = int(_lib_().mn_bnrelu_mm_count(N, Cc, H * W))
+                mm = torch.empty(2 * count, dtype=torch.float32, device=dev)
+            with _span(None, 3, 12.25 * y.numel()):
+                _call("mn_iao_qadd_bn_fwd", _p(y), _p(r["save"]), _p(r["gamma"]), _p(r["beta"]), _p(sc_x), _p(q["save"]) if sb else None, _p(q["gamma"]) if sb else None,
+                      _p(q["beta"]) if sb else None, N, Cc, H * W, _p(qp), bits, q_type, int(relu), _p(out), _p(mm), _p(bits_r), _p(bits_s), _s())
+        if mm is not None:
+            _PENDING_MINMAX[0] = (mm, count)
+        saved = [y, r["save"], r["gamma"], r["beta"], qp, bits_r, bits_s]
+        if sb:
+            saved += [sc_x, q["save"], q["gamma"], q["beta"]]
+        ctx.save_for_backward(*saved)
+        ctx.sb = sb
+        ctx.res_tok = res_tok
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        t = ctx.saved_tensors
+        y, save, gamma, beta, qp, bits_r, bits_s = t[:7]
+        g = _chk(g, "grad")
+        N, Cc, H, W = y.shape
+        dev = y.device
+        lib = _lib_()
+
+        def side(yy, sv, ga, be, bits_this, bits_other, want_other):
+            dy, dgamma, dbeta = torch.empty_like(yy), torch.empty_like(ga), torch.empty_like(be)
+            d_other = torch.empty_like(yy) if want_other else None
+            ws = torch.empty(int(lib.mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=dev)
+            with _span(None, 3, (24.25 if want_other else 20.25) * yy.numel()):
+                _call("mn_iao_qadd_bn_bwd", _p(g), _p(yy), _p(sv), _p(ga), _p(be), N, Cc, H * W, _p(qp), _p(bits_this), _p(bits_other) if want_other else None, _p(dy),
+                      _p(d_other), _p(dgamma), _p(dbeta), _p(ws), _s())
+            grad = LazyBNGrad(tuple(yy.shape), dev, dict(kind="bn_done", y=yy, dy=dy, dgamma=dgamma, dbeta=dbeta, g=g, bits=bits_this, qp=qp),
+                              lambda rr: _ste_from_bits(rr["g"], rr["bits"], rr["qp"]))
+            return grad, d_other
+        with torch.cuda.device(dev):
+            want_sc = ctx.needs_input_grad[1]
+            d_res, d_sc = side(y, save, gamma, beta, bits_r, bits_s, want_sc and not ctx.sb)
+            if ctx.sb and want_sc:
+                d_sc, _ = side(t[7], t[8], t[9], t[10], bits_s, None, False)
+        tok = ctx.res_tok
+        if tok is not None and not ctx.sb and d_sc is not None:
+            tok.d_sc = d_sc          # the identity shortcut is the input of a conv that `res` descends from: that conv's backward-data adds it in its store
+            return d_res, None, None, None, None, None, None, None
+        return d_res, d_sc, None, None, None, None, None, None
+
+
 class IaoFakeQuant(Function):
     @staticmethod
     def forward(ctx, x, qp, bits, q_type, is_act):
@@ -1552,6 +1629,9 @@ class BNActLazy(Function):
     @staticmethod
     def backward(ctx, da):
         y, gamma, beta, save = ctx.saved_tensors
+        if isinstance(da, LazyBNGrad) and da._mn_value is None and da._mn_recipe.get("kind") == "bn_done" and da._mn_recipe["y"].data_ptr() == y.data_ptr():
+            r = da._mn_recipe          # the fused QuantAdd behind this BatchNorm ran its backward too (IaoQuantAddBN: mn_iao_qadd_bn_bwd)
+            return r["dy"], r["dgamma"], r["dbeta"], None, None, None, None, None, None
         da = _chk(da, "grad")
         N, Cc, HW = y.shape[0], y.shape[1], y.shape[2] * y.shape[3]
         dgamma, dbeta, dy = torch.empty_like(gamma), torch.empty_like(beta), torch.empty_like(y)

@@ -273,6 +273,8 @@ class BatchNorm2dPlain(nn.BatchNorm2d):
     ``BatchNorm2dReLU`` instead of MIOpen's: same parameters, buffers and ``state_dict`` keys; anything the kernels do not cover runs the stock forward."""
 
     emit_minmax = False     # (set by the IAO prepare) leave per-block (min, max) of the output for the observers of the QuantAdd that reads it
+    iao_lazy_out = False    # (set by the IAO prepare) the only consumer is the residual block's QuantAdd: behind a conv that left its epilogue statistics the output
+    #                         stays un-computed (ops.BNActLazy -> LazyBNAct) and the QuantAdd normalises, quantises and adds in one pass (ops.IaoQuantAddBN)
 
     def forward(self, input):
         from micronet_amd import ops
@@ -284,6 +286,8 @@ class BatchNorm2dPlain(nn.BatchNorm2d):
             if not self.__dict__.pop("_mn_nbt_pre", False):
                 self.num_batches_tracked.add_(1)
         acc = _accstats_of(input) if (self.training and self.track_running_stats) else None
+        if self.iao_lazy_out and acc is not None and ops.iao_bn_lazy_supported(input, acc):
+            return ops.BNActLazy.apply(input, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum, 2, acc)
         if self.emit_minmax and self.training:          # (set by the IAO prepare: an IAO QuantAdd observes this output)
             out = ops.BNReLU.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                    self.running_var if self.track_running_stats else None, self.eps, self.momentum, use_batch, "mn_bn2d", True, acc)

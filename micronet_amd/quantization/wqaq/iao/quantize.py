@@ -30,6 +30,7 @@ _PRODUCER_MINMAX = os.environ.get("MN_NO_PRODUCER_MINMAX") is None          # A/
 _PRODUCER_ACCSTATS = os.environ.get("MN_NO_PRODUCER_ACCSTATS") is None      # A/B knob: the BatchNorm behind a dense conv makes its own statistics pass
 _FUSE_BNFUSE = os.environ.get("MN_NO_BNFUSE_BLOCK") is None                 # A/B knob: QuantBNFuseConv2d on the generic kernels (raw conv + statistics passes)
 _FUSE_BN_CODES = os.environ.get("MN_IAO_BN_CODES", "1") != "0"              # A/B knob (round 6): BatchNorm + ReLU + the next dense conv's activation codes in one pass (LazyBNAct)
+_FUSE_BN_ADD = os.environ.get("MN_IAO_BN_ADD", "1") != "0"                  # A/B knob (round 6): the BatchNorm(s) in front of a residual block's QuantAdd folded into its pass, both directions
 
 __all__ = ["ObserverBase", "MinMaxObserver", "MovingAverageMinMaxObserver", "HistogramObserver", "Round", "Quantizer",
            "SignedQuantizer", "UnsignedQuantizer", "SymmetricQuantizer", "AsymmetricQuantizer", "QuantConv2d",
@@ -670,8 +671,51 @@ class QuantAdd(nn.Module):
         return self._forward(res, shortcut, False)
 
     def _forward(self, res, shortcut, relu):
+        from micronet_amd.sign_tensor import LazyBNAct
         q = self.activation_quantizer
         obs_r, obs_s = self.observer_res, self.observer_shortcut
+        lazy_r = isinstance(res, LazyBNAct) and res._mn_value is None
+        lazy_s = isinstance(shortcut, LazyBNAct) and shortcut._mn_value is None
+        fused = (lazy_r and self.training and not q.qaft and torch.is_tensor(shortcut) and tuple(res.shape) == tuple(shortcut.shape) and 2 <= q.bits <= 24
+                 and type(obs_r) is type(obs_s) and getattr(obs_r, "_kind", None) in (0, 1) and obs_r.q_level == "L" and obs_s.q_level == "L"
+                 and getattr(q.observer, "q_level", None) == "L" and hasattr(q.observer, "min_val") and _synced(obs_r) == _synced(obs_s)
+                 and getattr(obs_r, "momentum", 0.1) == getattr(obs_s, "momentum", 0.1)
+                 and (lazy_s or (type(shortcut) is torch.Tensor and shortcut.is_cuda and shortcut.dtype == torch.float32 and shortcut.is_contiguous()
+                                 and shortcut.data_ptr() % 16 == 0 and ops._valid_minmax(shortcut) is not None)))
+        if fused:
+            # the BatchNorm(s) in front stayed un-computed (LazyBNAct): their per-channel extrema are the two input observers' partials, then ONE pass normalises,
+            # quantises, adds [and rectifies] straight from the convs' outputs
+            q.q_type = q._q_type_static
+            pr = res.prep()
+            ps = shortcut.prep() if lazy_s else ops._valid_minmax(shortcut)
+            if _synced(obs_r):
+                cur = _global_ranges([(res, pr), (shortcut, ps)], obs_r._mn_sync_group)
+                pr, ps = (cur[0:2], 1), (cur[2:4], 1)
+            qp = ops.iao_qadd_observe_partials(pr, ps, obs_r, obs_s, q, True)
+            for o in (obs_r, obs_s):
+                if o.num_flag == 0:
+                    o.num_flag += 1
+            q._last_qp = qp
+            want_mm = bool(relu) and _PRODUCER_MINMAX
+            tok = None if lazy_s else getattr(shortcut, "_mn_res_token", None)
+            node = tok.node() if (tok is not None and tok.node is not None) else None
+            if tok is not None and (tok.claimed or node is None or not torch.is_grad_enabled() or not shortcut.requires_grad or not res.requires_grad
+                                    or not ops._descends_from(res, node)):
+                tok = None
+            if tok is not None:
+                tok.claimed = True
+            out = ops.IaoQuantAddBN.apply(res, shortcut, qp, q.bits, q.q_type, bool(relu), want_mm, tok)
+            if relu:
+                out._mn_relu_done = True
+            if want_mm:
+                mm = ops.take_minmax()
+                if mm is not None:
+                    out._mn_minmax = mm + (out._version,)
+            return out
+        if lazy_r:
+            res = ops.LazyBNActToFloat.apply(res)
+        if lazy_s:
+            shortcut = ops.LazyBNActToFloat.apply(shortcut)
         if (torch.is_tensor(res) and torch.is_tensor(shortcut) and res.is_cuda and shortcut.is_cuda and res.dtype == torch.float32 and shortcut.dtype == torch.float32
                 and res.shape == shortcut.shape and res.is_contiguous() and shortcut.is_contiguous() and res.numel() % 4 == 0 and res.numel() > 0
                 and 2 <= q.bits <= 24 and type(obs_r) is type(obs_s) and getattr(obs_r, "_kind", None) in (0, 1) and obs_r.q_level == "L" and obs_s.q_level == "L"
@@ -849,6 +893,13 @@ def _fuse_residual_tails(model):
                 and isinstance(getattr(m, "residual_function", None), nn.Sequential) and isinstance(getattr(m, "shortcut", None), nn.Sequential):
             from micronet_amd.nn import derive_class
             m.__class__ = derive_class("AddReLU", _ResidualAddReLUMixin, t)
+            # the BatchNorms whose only consumer is this block's QuantAdd (the last module of the residual function, of the shortcut) stay un-computed behind a dense
+            # conv: the QuantAdd normalises, quantises and adds in one pass (LazyBNAct -> ops.IaoQuantAddBN)
+            if _FUSE_BN_ADD:
+                for seq in (m.residual_function, m.shortcut):
+                    kids = list(seq.children())
+                    if len(kids) >= 2 and type(kids[-1]) is BatchNorm2dPlain and type(kids[-2]) is QuantConv2d and kids[-2].emit_accstats and kids[-1].momentum is not None:
+                        kids[-1].iao_lazy_out = True
 
 
 class ReLUAfterFusedConv(nn.ReLU):

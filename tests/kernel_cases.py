@@ -2025,6 +2025,72 @@ def check_bn_lazy_pull(be, r, g, aqs, wq, dX, dWn, dCB, dqp, dWs, bias, yv, dGa,
             assert 0.002 * n < np.count_nonzero(bits == 0) < 0.9 * n          # (the clip is exercised)
 
 
+def check_iao_qadd_bn(be, shape=(3, 6, 4, 8), bits=4, q_type=0, relu=True, scbn=False, shrink=0.6, seed=0):
+    """The END of an IAO residual block in one pass (round 6): mn_iao_qadd_bn_fwd == mn_bn_apply (per side) -> mn_iao_qadd_fwd_mm, and mn_iao_qadd_bn_bwd ==
+    mn_iao_qadd_bwd -> mn_bn2d_bwd (per side), bit for bit -- output, (min, max) of the output, dy / dgamma / dbeta of both BatchNorms, the identity shortcut's
+    gradient -- with a quantizer range that clips a good part of both inputs (both clip-STE conditions and the ReLU mask decide)."""
+    r = np.random.default_rng(seed)
+    N_, Cc, H, W = shape
+    HW, n = H * W, int(np.prod(shape))
+    y_r, x_s = (r.standard_normal(shape) * 2 + 0.3).astype(F), (r.standard_normal(shape) * 1.5 - 0.2).astype(F)
+    g = r.standard_normal(shape).astype(F)
+    mk = lambda: (np.stack([r.standard_normal(Cc) * 0.3, 1.0 / np.sqrt(np.abs(r.standard_normal(Cc)) + 0.5)]).astype(F), (r.standard_normal(Cc) * 0.5 + 1).astype(F),
+                  (r.standard_normal(Cc) * 0.3).astype(F))
+    (sv_r, ga_r, be_r), (sv_s, ga_s, be_s) = mk(), mk()
+    dYr, dXs, dG = be.to_dev(y_r), be.to_dev(x_s), be.to_dev(g)
+    dSr, dGr, dBr, dSs, dGs, dBs = (be.to_dev(v) for v in (sv_r, ga_r, be_r, sv_s, ga_s, be_s))
+    # ---- unfused: the BatchNorm outputs exist
+    a_r = be.empty(shape)
+    be.call("mn_bn_apply", be.ptr(dYr), N_, Cc, HW, be.ptr(dGr), be.ptr(dBr), be.ptr(dSr), 2, be.ptr(a_r), be.stream)
+    if scbn:
+        a_s = be.empty(shape)
+        be.call("mn_bn_apply", be.ptr(dXs), N_, Cc, HW, be.ptr(dGs), be.ptr(dBs), be.ptr(dSs), 2, be.ptr(a_s), be.stream)
+    else:
+        a_s = dXs
+    av, bv = be.to_host(a_r), be.to_host(a_s)
+    mn, mx = F(min(av.min(), bv.min()) * shrink), F(max(av.max(), bv.max()) * shrink)
+    sc, zp = O.iao_qparams(mn.reshape(1), mx.reshape(1), bits, q_type, True)
+    lo, hi = mn / sc[0] - zp[0], mx / sc[0] - zp[0]
+    if q_type == 0:
+        hi = max(abs(lo), abs(hi)); lo = -hi
+    dqp = be.to_dev(np.array([sc[0], zp[0], lo, hi], dtype=F))
+    cnt1 = int(be.lib.mn_iao_qadd_mm_count(n))
+    o1, mm1 = be.empty(shape), be.empty(2 * cnt1)
+    be.call("mn_iao_qadd_fwd_mm", be.ptr(a_r), be.ptr(a_s), be.ptr(o1), n, be.ptr(dqp), bits, q_type, int(relu), be.ptr(mm1), be.stream)
+    da1, db1 = be.empty(shape), be.empty(shape)
+    be.call("mn_iao_qadd_bwd", be.ptr(dG), be.ptr(a_r), be.ptr(a_s), be.ptr(da1), be.ptr(db1), n, be.ptr(dqp), bits, q_type, int(relu), be.stream)
+    ws = be.empty(int(be.lib.mn_bnsign_ws_floats(Cc)) + 8)
+    dy1, dga1, dbe1 = be.empty(shape), be.empty(Cc), be.empty(Cc)
+    be.call("mn_bn2d_bwd", be.ptr(da1), be.ptr(dYr), be.ptr(dSr), be.ptr(dGr), be.ptr(dBr), N_, Cc, HW, 1, be.ptr(dy1), be.ptr(dga1), be.ptr(dbe1), be.ptr(ws), be.stream)
+    if scbn:
+        dys1, dgas1, dbes1 = be.empty(shape), be.empty(Cc), be.empty(Cc)
+        be.call("mn_bn2d_bwd", be.ptr(db1), be.ptr(dXs), be.ptr(dSs), be.ptr(dGs), be.ptr(dBs), N_, Cc, HW, 1, be.ptr(dys1), be.ptr(dgas1), be.ptr(dbes1), be.ptr(ws), be.stream)
+    # ---- fused
+    cnt2 = int(be.lib.mn_bnrelu_mm_count(N_, Cc, HW))
+    o2, mm2 = be.empty(shape), be.empty(2 * cnt2)
+    bits_r, bits_s = be.empty_i8((n // 8,)), be.empty_i8((n // 8,))
+    be.call("mn_iao_qadd_bn_fwd", be.ptr(dYr), be.ptr(dSr), be.ptr(dGr), be.ptr(dBr), be.ptr(dXs), be.ptr(dSs) if scbn else None, be.ptr(dGs) if scbn else None,
+            be.ptr(dBs) if scbn else None, N_, Cc, HW, be.ptr(dqp), bits, q_type, int(relu), be.ptr(o2), be.ptr(mm2), be.ptr(bits_r), be.ptr(bits_s), be.stream)
+    ov1, ov2 = be.to_host(o1), be.to_host(o2)
+    assert np.array_equal(ov1, ov2), "output"
+    m1, m2 = be.to_host(mm1), be.to_host(mm2)
+    assert m1[:cnt1].min() == m2[:cnt2].min() == ov2.min() and m1[cnt1:].max() == m2[cnt2:].max() == ov2.max(), "min / max partials of the output"
+    dy2, dga2, dbe2, dsc2 = be.empty(shape), be.empty(Cc), be.empty(Cc), be.empty(shape)
+    be.call("mn_iao_qadd_bn_bwd", be.ptr(dG), be.ptr(dYr), be.ptr(dSr), be.ptr(dGr), be.ptr(dBr), N_, Cc, HW, be.ptr(dqp), be.ptr(bits_r), None if scbn else be.ptr(bits_s),
+            be.ptr(dy2), None if scbn else be.ptr(dsc2), be.ptr(dga2), be.ptr(dbe2), be.ptr(ws), be.stream)
+    assert np.array_equal(be.to_host(dy2), be.to_host(dy1)) and np.array_equal(be.to_host(dga2), be.to_host(dga1)) and np.array_equal(be.to_host(dbe2), be.to_host(dbe1)), "res side"
+    if scbn:
+        dys2, dgas2, dbes2 = be.empty(shape), be.empty(Cc), be.empty(Cc)
+        be.call("mn_iao_qadd_bn_bwd", be.ptr(dG), be.ptr(dXs), be.ptr(dSs), be.ptr(dGs), be.ptr(dBs), N_, Cc, HW, be.ptr(dqp), be.ptr(bits_s), None, be.ptr(dys2), None,
+                be.ptr(dgas2), be.ptr(dbes2), be.ptr(ws), be.stream)
+        assert np.array_equal(be.to_host(dys2), be.to_host(dys1)) and np.array_equal(be.to_host(dgas2), be.to_host(dgas1)) and np.array_equal(be.to_host(dbes2), be.to_host(dbes1)), \
+            "shortcut side"
+    else:
+        assert np.array_equal(be.to_host(dsc2), be.to_host(db1)), "identity shortcut's gradient"
+    d = be.to_host(da1)
+    assert (0.02 if relu else 0.0005) * n < np.count_nonzero(d == 0) < 0.95 * n          # (masks are exercised)
+
+
 def check_iao_qadd(be, n=4096 + 8, bits=8, q_type=0, obs_kind=1, first=(True, False), update=True, seed=0, relu=False):
     """mn_iao_qadd_observe / _fwd / _bwd (QuantAdd, wqaq/iao/quantize.py:1484-1498, in three launches) == the separate entry points it replaces
     (mn_iao_observe x 2, mn_iao_union_range, mn_iao_qparams, mn_iao_fq_fwd x 2 + add, mn_iao_fq_bwd x 2), bit for bit: outputs, gradients, every buffer."""

@@ -432,20 +432,22 @@ def test_iao_resnet_shortcut_gradient_folded_into_backward_data(monkeypatch):
     base = quantize.prepare(build_model(arch), inplace=True, **kw).cuda().train()
     x, y = synth_batch(8, device="cuda")
     grads, folds = {}, {}
-    real = ops.IaoQuantAdd.apply
+    real, real_bn = ops.IaoQuantAdd.apply, ops.IaoQuantAddBN.apply          # (round 6: the block's QuantAdd is IaoQuantAddBN when the BatchNorm in front stays un-computed)
     for fold in (True, False):
         monkeypatch.setattr(ops, "RES_ADD_FOLD", fold)
         model = copy.deepcopy(base)
         n = {"tok": 0}
 
-        def counting(*a, _n=n):
+        def counting(*a, _n=n, _real=real):
             _n["tok"] += int(len(a) > 7 and a[7] is not None)
-            return real(*a)
+            return _real(*a)
         monkeypatch.setattr(ops.IaoQuantAdd, "apply", staticmethod(counting))
+        monkeypatch.setattr(ops.IaoQuantAddBN, "apply", staticmethod(lambda *a, _n=n: (_n.__setitem__("tok", _n["tok"] + int(len(a) > 7 and a[7] is not None)), real_bn(*a))[1]))
         try:
             torch.nn.functional.cross_entropy(model(x), y).backward()
         finally:
             monkeypatch.setattr(ops.IaoQuantAdd, "apply", real)
+            monkeypatch.setattr(ops.IaoQuantAddBN, "apply", real_bn)
         grads[fold] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
         folds[fold] = n["tok"]
     assert folds == {True: 5, False: 0}, folds
@@ -469,31 +471,36 @@ def _iao_resnet_two_steps(monkeypatch, iaoq_knobs, batch=8):
     return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, model
 
 
-def test_iao_resnet_bn_relu_codes_one_pass(monkeypatch):
-    """Round 6: inside an IAO BasicBlock (models/resnet.py:17-29 under wqaq/iao/quantize.py:492-507) the activation between the two convs stays un-computed
-    (LazyBNAct): its range comes from the first conv's accumulator extrema, the second conv pulls its codes from the first conv's output in one pass.  Same codes,
-    same clip-STE bits, same observer state: two training steps are bit-identical to the unfused modules -- losses, every parameter, every buffer -- and the eight
-    blocks of resnet18 all take the path (no fp32 activation materialised)."""
+@pytest.mark.parametrize("codes,add", [(True, True), (True, False), (False, True)])
+def test_iao_resnet_block_fused_passes(monkeypatch, codes, add):
+    """Round 6, the IAO BasicBlock (models/resnet.py:17-29, 60-65 under wqaq/iao/quantize.py:492-507, 1484-1498) in fewer passes:
+    ``codes``: the activation between the two convs stays un-computed (LazyBNAct) -- its range comes from the first conv's accumulator extrema, the second conv pulls
+    its codes from the first conv's output in one pass;  ``add``: the BatchNorm(s) in front of the block's QuantAdd stay un-computed too -- ONE pass normalises,
+    quantises, adds and rectifies, and each BatchNorm's backward reads the block-output gradient with the clip-STE / ReLU decisions as bits.
+    Same codes, same bits, same observer state, same order of summation: two training steps are bit-identical to the unfused modules -- losses, every parameter, every
+    buffer -- and all eight blocks of resnet18 take the paths (nothing materialised)."""
     from micronet_amd import ops
-    n = {"pull": 0, "mat": 0}
-    real_pull, real_mat = ops.iao_bn_apply_codes, ops.LazyBNActToFloat.apply
+    n = {"pull": 0, "mat": 0, "addbn": 0, "add": 0}
+    real_pull, real_mat, real_addbn, real_add = ops.iao_bn_apply_codes, ops.LazyBNActToFloat.apply, ops.IaoQuantAddBN.apply, ops.IaoQuantAdd.apply
     monkeypatch.setattr(ops, "iao_bn_apply_codes", lambda *a, **k: (n.__setitem__("pull", n["pull"] + 1), real_pull(*a, **k))[1])
     monkeypatch.setattr(ops.LazyBNActToFloat, "apply", staticmethod(lambda *a: (n.__setitem__("mat", n["mat"] + 1), real_mat(*a))[1]))
-    l1, s1, m1 = _iao_resnet_two_steps(monkeypatch, dict(_FUSE_BN_CODES=True))
-    assert n == {"pull": 16, "mat": 0}, n
-    l0, s0, _ = _iao_resnet_two_steps(monkeypatch, dict(_FUSE_BN_CODES=False))
-    assert n == {"pull": 16, "mat": 0}, n
+    monkeypatch.setattr(ops.IaoQuantAddBN, "apply", staticmethod(lambda *a: (n.__setitem__("addbn", n["addbn"] + 1), real_addbn(*a))[1]))
+    monkeypatch.setattr(ops.IaoQuantAdd, "apply", staticmethod(lambda *a: (n.__setitem__("add", n["add"] + 1), real_add(*a))[1]))
+    l1, s1, m1 = _iao_resnet_two_steps(monkeypatch, dict(_FUSE_BN_CODES=codes, _FUSE_BN_ADD=add))
+    assert n == {"pull": 16 if codes else 0, "mat": 0, "addbn": 16 if add else 0, "add": 0 if add else 16}, n
+    l0, s0, _ = _iao_resnet_two_steps(monkeypatch, dict(_FUSE_BN_CODES=False, _FUSE_BN_ADD=False))
     assert l1 == l0, (l1, l0)
     for k in s0:
         assert torch.equal(s1[k], s0[k]) or (torch.isnan(s1[k]).all() and torch.isnan(s0[k]).all()), k
-    # a foreign consumer of the un-computed activation sees the float32 tensor the unfused BatchNorm + ReLU writes
-    from micronet_amd.sign_tensor import LazyBNAct
-    blk = m1.conv2_x[0].residual_function
-    x = torch.randn(4, 64, 32, 32, device="cuda")
-    lazy = blk[2](blk[1](blk[0](x)))
-    assert isinstance(lazy, LazyBNAct)
-    a = lazy + 0.0
-    assert type(a) is torch.Tensor and a.shape == lazy.shape and float(a.min()) == 0.0
+    if codes:
+        # a foreign consumer of the un-computed activation sees the float32 tensor the unfused BatchNorm + ReLU writes
+        from micronet_amd.sign_tensor import LazyBNAct
+        blk = m1.conv2_x[0].residual_function
+        x = torch.randn(4, 64, 32, 32, device="cuda")
+        lazy = blk[2](blk[1](blk[0](x)))
+        assert isinstance(lazy, LazyBNAct)
+        a = lazy + 0.0
+        assert type(a) is torch.Tensor and a.shape == lazy.shape and float(a.min()) == 0.0
 
 
 @pytest.mark.parametrize("key", ["c2_nin_gc_wbwtab_w3a2", "c1_nin_gc_dorefa_w8a8", "c5_resnet18_iao_w4a4"])

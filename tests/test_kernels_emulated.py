@@ -484,6 +484,12 @@ def test_qdense_layer_iao(be, case):
     K.check_qdense_iao(be, xs, Oc, k, s, seed=400 + case)
 
 
+@pytest.mark.parametrize("shape,bits,q_type,relu,scbn", [((3, 6, 4, 8), 4, 0, True, False), ((2, 5, 8, 8), 8, 1, True, True), ((3, 4, 2, 4), 4, 0, False, True),
+                                                         ((9, 3, 4, 4), 6, 0, False, False)])
+def test_iao_qadd_bn_fused(be, shape, bits, q_type, relu, scbn):
+    K.check_iao_qadd_bn(be, shape, bits, q_type, relu, scbn, seed=430 + bits)
+
+
 def test_qdense_layer_iao_w8a8_bias(be):
     K.check_qdense_iao(be, (2, 64, 8, 8), 64, 3, 1, a_bits=8, w_bits=8, bias=True, seed=410)
 
