@@ -469,6 +469,69 @@ struct OpAddF { __device__ __forceinline__ float operator()(float a, float b) co
 struct OpMaxF { __device__ __forceinline__ float operator()(float a, float b) const { return (a != a || b != b) ? (a != a ? a : b) : fmaxf(a, b); } };
 struct OpMinF { __device__ __forceinline__ float operator()(float a, float b) const { return (a != a || b != b) ? (a != a ? a : b) : fminf(a, b); } };
 
+// ---- tails shared by the stand-alone observer kernels (quant_kernels.hip) and by the last block of k_bn_acc_prep (norm_kernels.hip); `sc`: 16 floats of shared memory,
+// called by ALL 256 threads of one block.
+// the observer update from per-block (min, max) partials (mm[0 .. count) minima, mm[count .. 2 count) maxima) [+ the per-tensor quantizer's update_qparams, qp != null]
+__device__ __forceinline__ void mn_obs_partials_tail(const float* __restrict__ mm, int count, int obs_kind, int first, double momentum, float* __restrict__ min_val,
+                                                     float* __restrict__ max_val, int q_type, float quant_range, float* __restrict__ scale, float* __restrict__ zero_point,
+                                                     float* __restrict__ qp, float* sc) {
+    float lo = INFINITY, hi = -INFINITY;
+    {   // eight loads in flight per thread and pass (a plain loop waited one L2 round trip per 256 partials: 8-10 us for the 2-4 k partials of a ResNet layer);
+        // plain min / max ignore a NaN: it is flagged and propagated below, as torch.min / max would
+        int nan = 0, i = threadIdx.x;
+        for (; i + 3 * 256 < count; i += 4 * 256) {
+            const float a0 = mm[i], a1 = mm[i + 256], a2 = mm[i + 512], a3 = mm[i + 768];
+            const float b0 = mm[count + i], b1 = mm[count + i + 256], b2 = mm[count + i + 512], b3 = mm[count + i + 768];
+            lo = fminf(lo, fminf(fminf(a0, a1), fminf(a2, a3)));
+            hi = fmaxf(hi, fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+            nan |= (int)((a0 != a0) | (a1 != a1) | (a2 != a2) | (a3 != a3) | (b0 != b0) | (b1 != b1) | (b2 != b2) | (b3 != b3));
+        }
+        for (; i < count; i += 256) {
+            const float a = mm[i], b = mm[count + i];
+            lo = fminf(lo, a); hi = fmaxf(hi, b);
+            nan |= (int)((a != a) | (b != b));
+        }
+        if (nan) lo = hi = NAN;
+    }
+    lo = block_reduce(lo, OpMinF(), INFINITY, sc);
+    hi = block_reduce(hi, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) {
+        observer_update(obs_kind, first, momentum, lo, hi, min_val, max_val);
+        if (qp) iao_qparams_row(*min_val, *max_val, q_type, quant_range, 1, scale, zero_point, qp);          // + the quantizer's update_qparams in the same launch
+    }
+}
+// QuantAdd's bookkeeping (wqaq/iao/quantize.py:1484-1498) from the two producers' partials: both input observers, their union range, the shared quantizer's qparams
+struct QaddFinal {
+    int nb, obs_kind, first_a, first_b, q_type, update; double momentum; float quant_range;
+    float *min_a, *max_a, *min_b, *max_b, *min_o, *max_o, *scale, *zero_point, *qp;
+};
+__device__ __forceinline__ void mn_qadd_final_tail(const float* __restrict__ ma, int ca, const float* __restrict__ mb, int cb, const QaddFinal& f, float* sc) {
+    float la = INFINITY, ha = -INFINITY, lb = INFINITY, hb = -INFINITY;
+    // eight loads in flight per thread and pass, like mn_obs_partials_tail (the plain loops waited one L2 round trip per 256 partials: 18 us per residual add of
+    // a ResNet step, 2-4 k partials per side); min / max are order-free, so the result is the same
+    auto side = [&](const float* __restrict__ m, int cnt, float& lo, float& hi) {
+        int i = threadIdx.x;
+        for (; i + 3 * 256 < cnt; i += 4 * 256) {
+            const float a0 = m[i], a1 = m[i + 256], a2 = m[i + 512], a3 = m[i + 768];
+            const float b0 = m[cnt + i], b1 = m[cnt + i + 256], b2 = m[cnt + i + 512], b3 = m[cnt + i + 768];
+            lo = OpMinF()(OpMinF()(lo, a0), OpMinF()(OpMinF()(a1, a2), a3));
+            hi = OpMaxF()(OpMaxF()(hi, b0), OpMaxF()(OpMaxF()(b1, b2), b3));
+        }
+        for (; i < cnt; i += 256) { lo = OpMinF()(lo, m[i]); hi = OpMaxF()(hi, m[cnt + i]); }
+    };
+    side(ma, ca, la, ha);
+    side(mb, cb, lb, hb);
+    la = block_reduce(la, OpMinF(), INFINITY, sc); ha = block_reduce(ha, OpMaxF(), -INFINITY, sc);
+    lb = block_reduce(lb, OpMinF(), INFINITY, sc); hb = block_reduce(hb, OpMaxF(), -INFINITY, sc);
+    if (threadIdx.x == 0) {
+        observer_update(f.obs_kind, f.first_a, f.momentum, la, ha, f.min_a, f.max_a);
+        observer_update(f.obs_kind, f.first_b, f.momentum, lb, hb, f.min_b, f.max_b);
+        const float mn = OpMinF()(*f.min_a, *f.min_b), mx = OpMaxF()(*f.max_a, *f.max_b);
+        *f.min_o = mn; *f.max_o = mx;
+        iao_qparams_row(mn, mx, f.q_type, f.quant_range, f.update, f.scale, f.zero_point, f.qp);
+    }
+}
+
 // Byte stash h = (acc + nnz) / 2 of a ternary-weight convolution on +-1 codes: acc has the parity of the number of non-zero weight codes
 // that meet a non-zero input.  For a pointwise block that is nnz[o] everywhere (chan row 7).  For a 3x3 / padding 1 block the taps
 // outside the image meet zeros, so the count depends on the pixel CLASS (top / middle / bottom row x left / middle / right column):

@@ -635,42 +635,47 @@ struct BnAccPrep {
 };
 __global__ __launch_bounds__(256) void k_bn_acc_prep(const BnAccPrep p) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    if (c >= p.C) return;          // (wave-uniform)
-    double s1 = 0.0, s2 = 0.0;     // exact integers < 2^53: any order of summation gives the same double
-    int lo = INT_MAX, hi = INT_MIN;
-    for (int i = lane; i < p.rows; i += 64) {
-        s1 += p.stats[((int64_t)i * p.C + c) * 2]; s2 += p.stats[((int64_t)i * p.C + c) * 2 + 1];
-        const int a = p.accmm[((int64_t)i * p.C + c) * 2], b = p.accmm[((int64_t)i * p.C + c) * 2 + 1];
-        lo = a < lo ? a : lo; hi = b > hi ? b : hi;
-    }
-    s1 = wave_reduce(s1, OpAddD()); s2 = wave_reduce(s2, OpAddD());
+    if (c < p.C) {                 // (wave-uniform)
+        double s1 = 0.0, s2 = 0.0;     // exact integers < 2^53: any order of summation gives the same double
+        int lo = INT_MAX, hi = INT_MIN;
+        for (int i = lane; i < p.rows; i += 64) {
+            s1 += p.stats[((int64_t)i * p.C + c) * 2]; s2 += p.stats[((int64_t)i * p.C + c) * 2 + 1];
+            const int a = p.accmm[((int64_t)i * p.C + c) * 2], b = p.accmm[((int64_t)i * p.C + c) * 2 + 1];
+            lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+        }
+        s1 = wave_reduce(s1, OpAddD()); s2 = wave_reduce(s2, OpAddD());
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_down(lo, o, 64), b = __shfl_down(hi, o, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
-    if (lane) return;
-    // the statistics: k_bns_apply's fin.kind == 1 arithmetic, expression for expression
-    const float alf = p.sa[0] * p.sw[(int64_t)c * p.sw_stride], cb = p.cbias ? p.cbias[c] : 0.f;
-    const double al = (double)alf;
-    const double m = s1 / p.n;
-    const double mean_d = al * m + (double)cb;
-    double ss = al * al * (s2 - s1 * m);
-    if (ss < 0.0) ss = 0.0;
-    const float var_b = (float)(ss / p.n);
-    const float mean = (float)mean_d, invstd = 1.0f / sqrtf(var_b + p.eps);
-    p.save[c] = mean; p.save[p.C + c] = invstd;
-    if (p.running_mean) p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean_d;
-    if (p.running_var) p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)(ss / (p.n - 1.0));
-    // the activation at the two ends: the conv epilogue's y (k_qd_fwd8), k_bns_apply's z
-    const float ga = p.gamma[c], be = p.beta[c];
-    float e[2];
+        for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_down(lo, o, 64), b = __shfl_down(hi, o, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+        if (lane == 0) {
+            // the statistics: k_bns_apply's fin.kind == 1 arithmetic, expression for expression
+            const float alf = p.sa[0] * p.sw[(int64_t)c * p.sw_stride], cb = p.cbias ? p.cbias[c] : 0.f;
+            const double al = (double)alf;
+            const double m = s1 / p.n;
+            const double mean_d = al * m + (double)cb;
+            double ss = al * al * (s2 - s1 * m);
+            if (ss < 0.0) ss = 0.0;
+            const float var_b = (float)(ss / p.n);
+            const float mean = (float)mean_d, invstd = 1.0f / sqrtf(var_b + p.eps);
+            p.save[c] = mean; p.save[p.C + c] = invstd;
+            if (p.running_mean) p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean_d;
+            if (p.running_var) p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)(ss / (p.n - 1.0));
+            // the activation at the two ends: the conv epilogue's y (k_qd_fwd8), k_bns_apply's z
+            const float ga = p.gamma[c], be = p.beta[c];
+            float e[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float y = (float)(k ? hi : lo) * alf + cb;
-        const float zh = (y - mean) * invstd;
-        const float z = zh * ga + be;
-        e[k] = p.act == 2 ? z : bns_relu(z);
+            for (int k = 0; k < 2; ++k) {
+                const float y = (float)(k ? hi : lo) * alf + cb;
+                const float zh = (y - mean) * invstd;
+                const float z = zh * ga + be;
+                e[k] = p.act == 2 ? z : bns_relu(z);
+            }
+            p.mm[c] = OpMinF()(e[0], e[1]); p.mm[p.C + c] = OpMaxF()(e[0], e[1]);
+        }
     }
-    p.mm[c] = OpMinF()(e[0], e[1]); p.mm[p.C + c] = OpMaxF()(e[0], e[1]);
 }
+// (Tried and dropped: the consumer's observer / qparams launch as a tail of this one -- the block that draws the last ticket reduces the C partials.  The partials of
+// the other blocks have to cross XCDs, whose L2s are not coherent with each other: the release fence every block needs writes its XCD's L2 back, and the launch went from
+// 5.7 to 13.8 us -- as much as the two launches it replaced.  profiles/README.md.)
 extern "C" int mn_bn_acc_prep(int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                               float* save, int act, const double* stats, const int32_t* acc_mm, int64_t rows, const float* sa, const float* sw, int64_t sw_stride,
                               const float* conv_bias, float* mm, mn_stream_t stream) {
@@ -709,13 +714,14 @@ __device__ __forceinline__ void bn_apply_codes_body(const BnsGeom& g, const floa
             const float zh = (v[e] - mean) * invstd;                                                                                                        \
             const float z = zh * ga + be;                                                                                                                   \
             /* relu: a NaN stays a NaN in bns_relu -- here it becomes 0 (code 0 either way) and is failed by the z == z term of the clip test */             \
-            const float a = ACT == 2 ? z : fmaxf(z, 0.f);                                                                                                   \
+            /* (+inf and whatever the quotient's fma chain would overflow on: clamped far outside the quantizer's range -- same code, same failed clip test) */ \
+            const float a = ACT == 2 ? fminf(fmaxf(z, -1.0e30f), 1.0e30f) : fminf(fmaxf(z, 0.f), 1.0e30f);                                                  \
             const float q = mn_div_m(a, sc, inv);                                                                                                           \
             const float vv = ZP0 ? q : q - zp, r = rha(vv);                                                                                                 \
             m |= ((r >= qmin && r <= qmax && !(vv > rhi || vv < rlo) && (ACT == 2 || z == z)) ? 1u : 0u) << e;                                              \
             const float rq = ZP0 ? r : rha(q);                                                                                                              \
             const float cl = fminf(fmaxf(rq, qmin), qmax);                             /* clamp(rha(a / sc)); NaN -> 0 (a byte cannot hold it) */            \
-            const float cc = ACT == 2 ? ((rq == rq) ? cl : 0.f) : cl;                                                                                       \
+            const float cc = ACT == 2 ? ((z == z) ? cl : 0.f) : cl;                                                                                         \
             const uint32_t byte = (uint32_t)(int)cc & 0xffu;                                                                                                \
             if (e < 4) lo |= byte << (8 * e); else hi |= byte << (8 * (e - 4));                                                                             \
         }                                                                                                                                                   \

@@ -2119,31 +2119,40 @@ int qd_bwd_weight_ex(const mn_conv_geom* g, const float* gy, const uint8_t* x, i
 // forward with the fp32 epilogue, backward-data with the per-channel scale folded into gy followed by the quantizer's clip-STE (k_qd_iao_ste, in place),
 // backward-weight on the signed codes with the activation scale taken from the device snapshot.
 // mask (nullable): one byte per thread = the clip-STE decisions of its 8 elements (iao_fq_grad's two conditions on the same v), read back by k_qd_dgrad's store
-__global__ __launch_bounds__(256) void k_qd_iao_codes(const float* __restrict__ x, signed char* __restrict__ codes, unsigned char* __restrict__ mask, int64_t n8,
-                                                      const float* __restrict__ qp, float qmin, float qmax) {
-    const float sc = qp[0], zp = qp[1], rlo = qp[2], rhi = qp[3];
+// (the pass is VALU-bound before it is HBM-bound: x / sc is Markstein's correctly rounded quotient -- mn_div_m, the float of the IEEE sequence for in-range operands --
+// rha as copysign(floor(|v| + 0.5), v), and with zero_point == 0 (the symmetric quantizer: always) one rounded value serves the code and the clip test)
+template <int ZP0>
+__device__ __forceinline__ void qd_iao_codes_body(const float* __restrict__ x, signed char* __restrict__ codes, unsigned char* __restrict__ mask, int64_t n8, float sc, float zp,
+                                                  float rlo, float rhi, float qmin, float qmax) {
+    const float inv = 1.0f / sc;
+    auto rha = [](float v) { return copysignf(floorf(fabsf(v) + 0.5f), v); };          // mn_rha's float except for the sign of a zero (seen by neither the byte nor the tests)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const float4 a = *reinterpret_cast<const float4*>(x + 8 * i), b = *reinterpret_cast<const float4*>(x + 8 * i + 4);
         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        if (mask) {
-            uint32_t m = 0u;
+        uint32_t m = 0u, lo = 0u, hi = 0u;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float vv = v[e] / sc - zp, r = mn_rha(vv);
-                m |= ((r >= qmin && r <= qmax && !(vv > rhi || vv < rlo)) ? 1u : 0u) << e;
-            }
-            mask[i] = (unsigned char)m;
-        }
-        uint32_t lo = 0u, hi = 0u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
+            // (+-inf and anything the quotient's fma chain would overflow on: clamped far outside the quantizer's range first -- the same code and a failed clip
+            // test, as the IEEE division gives; a NaN fails the test either way and its byte is forced below)
+            const float xc = fminf(fmaxf(v[e], -1.0e30f), 1.0e30f);
+            const float q = mn_div_m(xc, sc, inv);
+            const float vv = ZP0 ? q : q - zp, r = rha(vv);
+            m |= ((r >= qmin && r <= qmax && !(vv > rhi || vv < rlo)) ? 1u : 0u) << e;
+            const float rq = ZP0 ? r : rha(q);
             // clamp(rha(x / sc), qmin, qmax): the integer of iao_fq (zero_point == 0); NaN -> 0 (a byte cannot hold it)
-            const float c0 = mn_clamp(mn_rha(v[e] / sc), qmin, qmax), c1 = mn_clamp(mn_rha(v[4 + e] / sc), qmin, qmax);
-            lo |= ((uint32_t)(int)(c0 == c0 ? c0 : 0.f) & 0xffu) << (8 * e);
-            hi |= ((uint32_t)(int)(c1 == c1 ? c1 : 0.f) & 0xffu) << (8 * e);
+            const float cc = (v[e] == v[e]) ? fminf(fmaxf(rq, qmin), qmax) : 0.f;
+            const uint32_t byte = (uint32_t)(int)cc & 0xffu;
+            if (e < 4) lo |= byte << (8 * e); else hi |= byte << (8 * (e - 4));
         }
+        if (mask) mask[i] = (unsigned char)m;
         *reinterpret_cast<u32x2*>(codes + 8 * i) = u32x2{lo, hi};
     }
+}
+__global__ __launch_bounds__(256) void k_qd_iao_codes(const float* __restrict__ x, signed char* __restrict__ codes, unsigned char* __restrict__ mask, int64_t n8,
+                                                      const float* __restrict__ qp, float qmin, float qmax) {
+    const float sc = qp[0], zp = qp[1], rlo = qp[2], rhi = qp[3];
+    if (zp == 0.f) qd_iao_codes_body<1>(x, codes, mask, n8, sc, zp, rlo, rhi, qmin, qmax);
+    else qd_iao_codes_body<0>(x, codes, mask, n8, sc, zp, rlo, rhi, qmin, qmax);
 }
 __global__ __launch_bounds__(256) void k_qd_iao_ste(float* __restrict__ dx, const float* __restrict__ x, int64_t n4, const float* __restrict__ qp, float qmin, float qmax) {
     const float sc = qp[0], zp = qp[1], lo = qp[2], hi = qp[3];

@@ -841,30 +841,7 @@ __global__ __launch_bounds__(256) void k_minmax_from_partials(const float* __res
                                                               float* __restrict__ min_val, float* __restrict__ max_val, int q_type, float quant_range,
                                                               float* __restrict__ scale, float* __restrict__ zero_point, float* __restrict__ qp) {
     __shared__ float sc[16];
-    float lo = INFINITY, hi = -INFINITY;
-    {   // eight loads in flight per thread and pass (a plain loop waited one L2 round trip per 256 partials: 8-10 us for the 2-4 k partials of a ResNet layer);
-        // plain min / max ignore a NaN: it is flagged and propagated below, as torch.min / max would
-        int nan = 0, i = threadIdx.x;
-        for (; i + 3 * 256 < count; i += 4 * 256) {
-            const float a0 = mm[i], a1 = mm[i + 256], a2 = mm[i + 512], a3 = mm[i + 768];
-            const float b0 = mm[count + i], b1 = mm[count + i + 256], b2 = mm[count + i + 512], b3 = mm[count + i + 768];
-            lo = fminf(lo, fminf(fminf(a0, a1), fminf(a2, a3)));
-            hi = fmaxf(hi, fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
-            nan |= (int)((a0 != a0) | (a1 != a1) | (a2 != a2) | (a3 != a3) | (b0 != b0) | (b1 != b1) | (b2 != b2) | (b3 != b3));
-        }
-        for (; i < count; i += 256) {
-            const float a = mm[i], b = mm[count + i];
-            lo = fminf(lo, a); hi = fmaxf(hi, b);
-            nan |= (int)((a != a) | (b != b));
-        }
-        if (nan) lo = hi = NAN;
-    }
-    lo = block_reduce(lo, OpMinF(), INFINITY, sc);
-    hi = block_reduce(hi, OpMaxF(), -INFINITY, sc);
-    if (threadIdx.x == 0) {
-        observer_update(obs_kind, first, momentum, lo, hi, min_val, max_val);
-        if (qp) iao_qparams_row(*min_val, *max_val, q_type, quant_range, 1, scale, zero_point, qp);          // + the quantizer's update_qparams in the same launch
-    }
+    mn_obs_partials_tail(mm, count, obs_kind, first, momentum, min_val, max_val, q_type, quant_range, scale, zero_point, qp, sc);
 }
 extern "C" int mn_iao_observe_partials(const float* mm, int64_t count, int obs_kind, int first, double momentum, float* min_val, float* max_val, mn_stream_t stream) {
     if (!mm || count <= 0 || count > (1 << 24) || !min_val || !max_val || (obs_kind != 0 && obs_kind != 1)) MN_FAIL(MN_EINVAL, "mn_iao_observe_partials: bad arguments");
@@ -1097,10 +1074,6 @@ __global__ __launch_bounds__(256) void k_qadd_partial(const float* __restrict__ 
     lb = block_reduce(lb, OpMinF(), INFINITY, sc); hb = block_reduce(hb, OpMaxF(), -INFINITY, sc);
     if (threadIdx.x == 0) { ws[blockIdx.x] = la; ws[OBS_NB + blockIdx.x] = ha; ws[2 * OBS_NB + blockIdx.x] = lb; ws[3 * OBS_NB + blockIdx.x] = hb; }
 }
-struct QaddFinal {
-    int nb, obs_kind, first_a, first_b, q_type, update; double momentum; float quant_range;
-    float *min_a, *max_a, *min_b, *max_b, *min_o, *max_o, *scale, *zero_point, *qp;
-};
 __global__ __launch_bounds__(256) void k_qadd_final(const float* __restrict__ ws, const QaddFinal f) {
     __shared__ float sc[16];
     float la = INFINITY, ha = -INFINITY, lb = INFINITY, hb = -INFINITY;
@@ -1183,30 +1156,7 @@ extern "C" int mn_iao_qadd_observe(const float* res, const float* shortcut, int6
 // mn_bnrelu_fwd_mm, mn_iao_qadd_fwd_mm): one launch, neither tensor is read.  min / max are exact and order-free: bit-identical to mn_iao_qadd_observe.
 __global__ __launch_bounds__(256) void k_qadd_final_p(const float* __restrict__ ma, int ca, const float* __restrict__ mb, int cb, const QaddFinal f) {
     __shared__ float sc[16];
-    float la = INFINITY, ha = -INFINITY, lb = INFINITY, hb = -INFINITY;
-    // eight loads in flight per thread and pass, like k_minmax_from_partials (the plain loops waited one L2 round trip per 256 partials: 18 us per residual add of
-    // a ResNet step, 2-4 k partials per side); min / max are order-free, so the result is the same
-    auto side = [&](const float* __restrict__ m, int cnt, float& lo, float& hi) {
-        int i = threadIdx.x;
-        for (; i + 3 * 256 < cnt; i += 4 * 256) {
-            const float a0 = m[i], a1 = m[i + 256], a2 = m[i + 512], a3 = m[i + 768];
-            const float b0 = m[cnt + i], b1 = m[cnt + i + 256], b2 = m[cnt + i + 512], b3 = m[cnt + i + 768];
-            lo = OpMinF()(OpMinF()(lo, a0), OpMinF()(OpMinF()(a1, a2), a3));
-            hi = OpMaxF()(OpMaxF()(hi, b0), OpMaxF()(OpMaxF()(b1, b2), b3));
-        }
-        for (; i < cnt; i += 256) { lo = OpMinF()(lo, m[i]); hi = OpMaxF()(hi, m[cnt + i]); }
-    };
-    side(ma, ca, la, ha);
-    side(mb, cb, lb, hb);
-    la = block_reduce(la, OpMinF(), INFINITY, sc); ha = block_reduce(ha, OpMaxF(), -INFINITY, sc);
-    lb = block_reduce(lb, OpMinF(), INFINITY, sc); hb = block_reduce(hb, OpMaxF(), -INFINITY, sc);
-    if (threadIdx.x == 0) {
-        observer_update(f.obs_kind, f.first_a, f.momentum, la, ha, f.min_a, f.max_a);
-        observer_update(f.obs_kind, f.first_b, f.momentum, lb, hb, f.min_b, f.max_b);
-        const float mn = OpMinF()(*f.min_a, *f.min_b), mx = OpMaxF()(*f.max_a, *f.max_b);
-        *f.min_o = mn; *f.max_o = mx;
-        iao_qparams_row(mn, mx, f.q_type, f.quant_range, f.update, f.scale, f.zero_point, f.qp);
-    }
+    mn_qadd_final_tail(ma, ca, mb, cb, f, sc);
 }
 extern "C" int mn_iao_qadd_observe_partials(const float* mm_res, int64_t count_res, const float* mm_shortcut, int64_t count_shortcut, int obs_kind, int first_res,
                                             int first_shortcut, double momentum, float* min_res, float* max_res, float* min_shortcut, float* max_shortcut,

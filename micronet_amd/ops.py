@@ -464,9 +464,10 @@ class ResidualToken:
     IDENTITY shortcut is that same x -- and whose other input descends from that conv -- parks the shortcut's gradient here instead of returning it to autograd; the
     conv's backward-data, which autograd runs later, adds it while it stores dx: d loss / d x arrives in ONE tensor and the engine's accumulate kernel (18 us per
     residual block of the IAO resnet18 at batch 256) disappears."""
-    __slots__ = ("node", "d_sc", "claimed")
+    __slots__ = ("node", "d_sc", "claimed", "consumed")
 
     def __init__(self):
+        self.consumed = False          # set when the conv's backward-data has run: a gradient parked after that would be lost, so nobody parks any more
         self.node, self.d_sc, self.claimed = None, None, False          # node: a WEAK reference to the conv's autograd node (the node saved x, x carries this token:
         #                                                                  a strong one would close a cycle through C++ that a forward without backward never breaks)
 
@@ -1509,6 +1510,7 @@ class _PendingAccStats(threading.local):
 
 _PENDING_ACCSTATS = _PendingAccStats()
 WANT_ACCSTATS = 0x100          # Python-side bit of ``aq_flags`` (never passed to the library): request mn_actq.stats from the forward
+DONATE_DX = 0x200              # Python-side bit: this conv is the shortcut conv of a residual block whose first conv reads the same tensor (set by the IAO prepare)
 
 
 def take_accstats():
@@ -1864,7 +1866,7 @@ class QConv2d(Function):
         g = _geom(xs, wq.shape, stride, padding, dilation, groups, in_shuffle)
         Ho, Wo = _out_hw(g)
         y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=x.device)
-        want_stats, aq_flags = bool(aq_flags & WANT_ACCSTATS), aq_flags & ~WANT_ACCSTATS
+        want_stats, donate, aq_flags = bool(aq_flags & WANT_ACCSTATS), bool(aq_flags & DONATE_DX), aq_flags & ~(WANT_ACCSTATS | DONATE_DX)
         aq = ActQ(aq_mode, aq_bits, aq_qtype, aq_flags, qp.data_ptr() if qp is not None else None)
         wd = _wq_desc(wdesc)
         ctx.packed = packed = getattr(wq, "_mn_packed", None) if wd is not None else None
@@ -1904,10 +1906,18 @@ class QConv2d(Function):
         if stats is not None:          # (stats, rows, activation qparams, per-channel weight scale, its stride, conv bias, extrema of acc): what mn_bn_fwd_acc / mn_bn_acc_prep read
             _PENDING_ACCSTATS[0] = (stats, stats.shape[0], qp, wscale, int(wdesc[3]), bias, accmm)
         ctx.iao_codes, ctx.iao_mask = codes, ste_mask
-        ctx.res_tok = None
+        ctx.res_tok = ctx.donate_tok = None
         if (RES_ADD_FOLD and given is None and aq_mode == ACTQ_IAO and wd is not None and qp is not None and CONV_ALGO == _lib.MN_ALGO_AUTO and ctx.needs_input_grad[0]
-                and type(x) is torch.Tensor and _lib_().mn_conv2d_bwd_data_add_supported(C.byref(g), C.byref(aq), C.byref(wd))):
-            ctx.res_tok = x._mn_res_token = ResidualToken()          # (x is the caller's tensor object; the node is filled in by qconv2d() below)
+                and type(x) is torch.Tensor):
+            prev = getattr(x, "_mn_res_token", None)
+            if donate and prev is not None and not prev.claimed and not prev.consumed and prev.node is not None and prev.node() is not None:
+                # a second conv on the same tensor (the 1 x 1 shortcut conv of a down-sampling block, models/resnet.py:21-29: x feeds the residual function's first conv
+                # AND this one): its d x is parked on the first conv's token and added in THAT conv's backward-data store -- autograd's accumulate kernel (12 B per
+                # element) disappears.  This node is younger, so its backward runs first; if it ever does not, `consumed` says so and d x goes back to autograd.
+                prev.claimed = True
+                ctx.donate_tok = prev
+            elif _lib_().mn_conv2d_bwd_data_add_supported(C.byref(g), C.byref(aq), C.byref(wd)):
+                ctx.res_tok = x._mn_res_token = ResidualToken()          # (x is the caller's tensor object; the node is filled in by qconv2d() below)
         ctx.save_for_backward(x, wq, qp, wscale)
         ctx.cfg = (g, aq_mode, aq_bits, aq_qtype, bias is not None, wdesc[:4] if wdesc is not None else None, aq_flags)
         return y
@@ -2000,8 +2010,10 @@ class QConv2d(Function):
         dx = dw = db = None
         tok = getattr(ctx, "res_tok", None)
         d_sc = None
-        if tok is not None and tok.d_sc is not None:          # a QuantAdd parked its identity shortcut's gradient w.r.t. x here: it is added in the store of dx
-            d_sc, tok.d_sc = tok.d_sc, None
+        if tok is not None:
+            tok.consumed = True
+            if tok.d_sc is not None:          # a QuantAdd (or the block's shortcut conv) parked a gradient w.r.t. x here: it is added in the store of dx
+                d_sc, tok.d_sc = tok.d_sc, None
         with torch.cuda.device_of(x):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(x_shape, dtype=torch.float32, device=x.device)
@@ -2025,6 +2037,9 @@ class QConv2d(Function):
                 ws, nb = _ws(g, 2, x.device)
                 with _span(g, 2, 4 * (gy.numel() + x_numel + dw.numel())):
                     _call("mn_conv2d_bwd_weight", C.byref(g), C.byref(aq), _p(gy), _p(x), _p(dw), _p(db), _p(ws), nb, CONV_ALGO, _s())
+        dtok = getattr(ctx, "donate_tok", None)
+        if dtok is not None and dx is not None and not dtok.consumed and dtok.d_sc is None and dtok.node is not None and dtok.node() is not None:
+            dtok.d_sc, dx = dx, None          # (the other conv on x adds it while it stores its own d x)
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -2655,7 +2670,7 @@ def channel_shuffle(x, groups):
 
 
 def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ_NONE, aq_bits=8, aq_qtype=0, qp=None,
-            wdesc=None, x_is_code=False, in_shuffle=0, lazy_for_bn=False, want_accstats=False, given=None):
+            wdesc=None, x_is_code=False, in_shuffle=0, lazy_for_bn=False, want_accstats=False, given=None, donate_dx=False):
     """``in_shuffle`` > 1: the convolution of ``channel_shuffle(x, in_shuffle)``; the permutation is folded into the kernels'
     channel addressing when the code-domain kernels cover all three passes, else materialised."""
     packed = isinstance(x, SignTensor)
@@ -2673,7 +2688,7 @@ def qconv2d(x, wq, bias, stride=1, padding=0, dilation=1, groups=1, aq_mode=ACTQ
             if in_shuffle and in_shuffle > 1:
                 x, in_shuffle = channel_shuffle(x, in_shuffle), 0
     y = QConv2d.apply(x, wq, bias, stride, padding, dilation, groups, aq_mode, aq_bits, aq_qtype, qp, wdesc,
-                      (_lib.MN_ACTQ_X_IS_CODE if x_is_code else 0) | (WANT_ACCSTATS if want_accstats else 0), in_shuffle or 0, given)
+                      (_lib.MN_ACTQ_X_IS_CODE if x_is_code else 0) | (WANT_ACCSTATS if want_accstats else 0) | (DONATE_DX if donate_dx else 0), in_shuffle or 0, given)
     tok = getattr(x, "_mn_res_token", None) if aq_mode == ACTQ_IAO else None
     if tok is not None and tok.node is None and y.grad_fn is not None:
         tok.node = weakref.ref(y.grad_fn)          # (the autograd node whose backward-data will consume a parked shortcut gradient)

@@ -324,6 +324,8 @@ class QuantConv2d(nn.Conv2d):
         self.activation_quantizer = _activation_quantizer(a_bits, q_type, qaft, ptq, percentile)
         self.weight_quantizer = _weight_quantizer(w_bits, q_type, q_level, weight_observer, out_channels, "C", qaft, ptq)
 
+    donate_dx = False          # set by prepare(): the 1 x 1 shortcut conv of a down-sampling residual block -- the block's first conv reads the same tensor, and this conv's
+                               # d x is added in that conv's backward-data store (ops.ResidualToken) instead of by autograd's accumulate kernel
     emit_accstats = False      # set by prepare(): a BatchNorm2dReLU / BatchNorm2dPlain of ours reads this conv's output next -- in training the forward leaves the exact
                                # sums of its integer accumulator (dense layers: mn_actq.stats) on the output tensor, and that BatchNorm needs no statistics pass
 
@@ -336,10 +338,10 @@ class QuantConv2d(nn.Conv2d):
         if not (quantized and self.training and not q.qaft and not q.union and isinstance(obs, ObserverBase) and obs.q_level == "L" and obs._kind in (0, 1)
                 and 2 <= q.bits <= 8 and q._q_type_static == 0 and _wdesc(wq, quantized) is not None and not isinstance(self.padding, str)):
             return None
-        mm, count = lazy.prep()
-        nc = ops.iao_codes_bytes(lazy.shape, self.weight.shape, self.stride, self.padding, self.dilation, self.groups, q.bits, wq.bits, mm)
+        nc = ops.iao_codes_bytes(lazy.shape, self.weight.shape, self.stride, self.padding, self.dilation, self.groups, q.bits, wq.bits, q.scale)
         if nc <= 0:
             return None
+        mm, count = lazy.prep()
         mm._mn_minmax = (mm, count, mm._version)          # the partials stand for the activation as far as the observer is concerned
         qp = q.qparams(mm)
         if qp is None or qp.shape[0] != 1:
@@ -361,7 +363,7 @@ class QuantConv2d(nn.Conv2d):
             input = ops.LazyBNActToFloat.apply(input)
         mode, bits, q_type, qp = _fused_aq(self.activation_quantizer, input)
         out = ops.qconv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups,
-                          aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp, wdesc=_wdesc(self.weight_quantizer, quantized), want_accstats=want)
+                          aq_mode=mode, aq_bits=bits, aq_qtype=q_type, qp=qp, wdesc=_wdesc(self.weight_quantizer, quantized), want_accstats=want, donate_dx=self.donate_dx)
         return self._take_accstats(out, want)
 
     @staticmethod
@@ -895,6 +897,9 @@ def _fuse_residual_tails(model):
             m.__class__ = derive_class("AddReLU", _ResidualAddReLUMixin, t)
             # the BatchNorms whose only consumer is this block's QuantAdd (the last module of the residual function, of the shortcut) stay un-computed behind a dense
             # conv: the QuantAdd normalises, quantises and adds in one pass (LazyBNAct -> ops.IaoQuantAddBN)
+            sc0, rf0 = next(iter(m.shortcut.children()), None), next(iter(m.residual_function.children()), None)
+            if type(sc0) is QuantConv2d and type(rf0) is QuantConv2d:
+                sc0.donate_dx = True
             if _FUSE_BN_ADD:
                 for seq in (m.residual_function, m.shortcut):
                     kids = list(seq.children())

@@ -189,6 +189,7 @@ inline T wave_exchange(T v, int src_lane) {
 }  // namespace emu
 
 static inline void __syncthreads() { emu::yield(emu::WAIT_BLOCK); }
+static inline void __threadfence() {}          // one OS thread: every store is visible at once
 template <typename T>
 static inline T __shfl_down(T v, unsigned d, int width = 64) {
     int l = emu::lane();
