@@ -433,6 +433,18 @@ int mn_iao_qadd_bn_fwd(const float* res_y, const float* res_save, const float* r
                        uint8_t* bits_res, uint8_t* bits_sc, mn_stream_t stream);
 int mn_iao_qadd_bn_bwd(const float* g, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C, int64_t HW, const float* qp,
                        const uint8_t* bits, const uint8_t* bits_other, float* dy, float* d_other, float* dgamma, float* dbeta, float* ws, mn_stream_t stream);
+/* The tail of the reference's nets in one launch per direction: pooled[n][c] = mean over the image of relu(batch_norm(y)) -- BatchNorm2d -> ReLU -> AvgPool2d over the whole
+ * map (models/nin_gc.py:136-147), TRAINING mode (batch statistics, running statistics updated with the unbiased variance, save = {mean, invstd} [2][C]); one block per
+ * channel: meant for the few-channel classifier map (N x 10 x 8 x 8), where the step pays launches, not bytes.  HW % 4 == 0.  _bwd: dy, dgamma, dbeta from d pooled. */
+int mn_bnrelu_gap_supported(int64_t N, int64_t C, int64_t HW);          /* HW / 4 a power of two <= 64 and N * HW <= 16384: a channel lives in one block's registers */
+int mn_bnrelu_gap_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* save, float* pooled, mn_stream_t stream);
+int mn_bnrelu_gap_bwd(const float* dpool, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C, int64_t HW, float* dy, float* dgamma,
+                      float* dbeta, mn_stream_t stream);
+/* nn.CrossEntropyLoss() (mean reduction, ignore_index; the criterion of the reference's main.py, wqaq/dorefa/main.py:87-92) on logits [N][K] and int64 targets: the loss
+ * AND its gradient d loss / d logits (for an incoming gradient of 1) in one launch; mn_scale_by: out = a * scalar[0] (the backward: the incoming scalar gradient). */
+int mn_cross_entropy_fwd(const float* logits, const int64_t* target, int64_t N, int64_t K, int64_t ignore_index, float* loss, float* dlogits, mn_stream_t stream);
+int mn_scale_by(const float* a, const float* scalar, float* out, int64_t n, mn_stream_t stream);
 /* the two halves of mn_bnsign_bwd for a consumer that forms dy itself: mn_bnsign_bwd_sums = dgamma, dbeta and sums [2][C] =
  * {sum dz, sum dz*zhat}; mn_conv2d_bwd_weight_first_bn = backward-weight (+ dbias) of the first-layer convolution
  * (mn_conv2d_first_supported) whose output y went through BatchNorm2d + BinaryActivation: dy is formed from (da, y, save, gamma,

@@ -156,6 +156,11 @@ PROTOTYPES = {
     "mn_conv2d_iao_stats_rows": (_L, [_G, _A, _W]),
     "mn_bn_fwd_acc": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _L, _P, _P]),
     "mn_bn_acc_prep": (_I, [_L, _L, _L, _P, _P, C.c_float, C.c_float, _P, _P, _P, _I, _P, _P, _L, _P, _P, _L, _P, _P, _P]),
+    "mn_bnrelu_gap_supported": (_I, [_L, _L, _L]),
+    "mn_bnrelu_gap_fwd": (_I, [_P, _L, _L, _L, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
+    "mn_bnrelu_gap_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P]),
+    "mn_cross_entropy_fwd": (_I, [_P, _P, _L, _L, _L, _P, _P, _P]),
+    "mn_scale_by": (_I, [_P, _P, _P, _L, _P]),
     "mn_bn_apply_codes": (_I, [_P, _L, _L, _L, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
     "mn_bn_apply": (_I, [_P, _L, _L, _L, _P, _P, _P, _I, _P, _P]),
     "mn_iao_qadd_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P, _I, _I, _I, _P, _P, _P, _P, _P]),

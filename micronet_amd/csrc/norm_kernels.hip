@@ -908,6 +908,197 @@ static int bnsign_bwd_impl(const float* da, const float* y, const float* save, c
     return MN_OK;
 }
 
+// ---------------------------------------------------------------- the TAIL of the reference's nets: BatchNorm2d -> ReLU -> global average pool, and the loss
+// models/nin_gc.py:136-147 ends conv(-> 10) -> bn -> relu -> AvgPool2d(8) -> view; main.py's criterion is nn.CrossEntropyLoss() (wqaq/dorefa/main.py:87-92).  The
+// tensors are tiny (N x 10 x 8 x 8), so the step pays launches, not bytes: MIOpen's BatchNorm, ATen's ReLU / softmax / nll_loss and their backward + fills were 18
+// launches of ~5 us per nin_gc step (4 % of the c2 step).  Here: one kernel per direction for bn + relu + pool (one block per channel; training mode), one for the
+// loss WITH its gradient (the backward only scales it by the incoming scalar).
+// One block per channel; the channel's N * HW / 4 float4 live in REGISTERS (<= TAIL_Q per thread, all loads in flight at once -- the first version walked each
+// image with one thread and paid a memory round trip per float4: 50 us), the three passes (mean, variance, normalise) run on them; float4 i belongs to image
+// i / (HW / 4): with HW / 4 a power of two <= 64 the lanes of one image are neighbours and the per-image pool is a shuffle reduction (deterministic).
+#define TAIL_Q 16
+struct TailGeom { int N, C, HW, HW4, n4, sh; };          // n4 = N * HW4 <= 256 * TAIL_Q, HW4 = 1 << sh
+__device__ __forceinline__ void tail_load(const TailGeom& g, int c, const float* __restrict__ y, float4 (&v)[TAIL_Q], int64_t (&off)[TAIL_Q]) {
+#pragma unroll
+    for (int k = 0; k < TAIL_Q; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        const int ii = i < g.n4 ? i : 0;
+        const int im = ii >> g.sh, q = ii & (g.HW4 - 1);
+        off[k] = ((int64_t)im * g.C + c) * g.HW + 4 * q;
+        v[k] = *reinterpret_cast<const float4*>(y + off[k]);
+    }
+}
+// sum over the HW4 lanes that hold one image (aligned groups of HW4 lanes)
+__device__ __forceinline__ float tail_group_sum(float t, int HW4) {
+    for (int o = HW4 >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+}
+__global__ __launch_bounds__(256) void k_bnrelu_gap_fwd(const TailGeom g, const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        float* __restrict__ save, float* __restrict__ pooled) {
+    __shared__ double scd[16];
+    __shared__ double bc[2];
+    const int c = blockIdx.x;
+    const double n = (double)g.N * (double)g.HW;
+    float4 v[TAIL_Q];
+    int64_t off[TAIL_Q];
+    tail_load(g, c, y, v, off);
+    double s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < TAIL_Q; ++k) if ((int)threadIdx.x + 256 * k < g.n4) s1 += (double)((v[k].x + v[k].y) + (v[k].z + v[k].w));
+    s1 = block_reduce(s1, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) bc[0] = s1 / n;
+    __syncthreads();
+    const float mean = (float)bc[0];
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < TAIL_Q; ++k) {
+        if ((int)threadIdx.x + 256 * k < g.n4) { const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean; s2 += (double)((a * a + b * b) + (cc * cc + d * d)); }
+    }
+    s2 = block_reduce(s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) bc[1] = s2;
+    __syncthreads();
+    const double ss = bc[1];
+    const float invstd = 1.0f / sqrtf((float)(ss / n) + eps);
+    if (threadIdx.x == 0) {
+        save[c] = mean; save[g.C + c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(ss / (n - 1.0));
+    }
+    const float ga = gamma[c], be = beta[c];
+#pragma unroll
+    for (int k = 0; k < TAIL_Q; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float zh = (e[u] - mean) * invstd; t += bns_relu(zh * ga + be); }
+        t = tail_group_sum(i < g.n4 ? t : 0.f, g.HW4);          // (every lane takes part in the shuffles)
+        if (i < g.n4 && (i & (g.HW4 - 1)) == 0) pooled[(int64_t)(i >> g.sh) * g.C + c] = t / (float)g.HW;
+    }
+}
+__global__ __launch_bounds__(256) void k_bnrelu_gap_bwd(const TailGeom g, const float* __restrict__ dpool, const float* __restrict__ y, const float* __restrict__ save,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dy,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double scd[16];
+    __shared__ double bc[2];
+    const int c = blockIdx.x;
+    const float mean = save[c], invstd = save[g.C + c], ga = gamma[c], be = beta[c];
+    float4 v[TAIL_Q];
+    int64_t off[TAIL_Q];
+    float gq[TAIL_Q];
+    tail_load(g, c, y, v, off);
+#pragma unroll
+    for (int k = 0; k < TAIL_Q; ++k) { const int i = (int)threadIdx.x + 256 * k; gq[k] = dpool[(int64_t)((i < g.n4 ? i : 0) >> g.sh) * g.C + c] / (float)g.HW; }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < TAIL_Q; ++k) {
+        if ((int)threadIdx.x + 256 * k >= g.n4) continue;
+        const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float zh = (e[u] - mean) * invstd; const float dz = (zh * ga + be > 0.f) ? gq[k] : 0.f; t1 += dz; t2 += dz * zh; }
+        s1 += (double)t1; s2 += (double)t2;
+    }
+    s1 = block_reduce(s1, OpAddD(), 0.0, scd);
+    s2 = block_reduce(s2, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { bc[0] = s1; bc[1] = s2; dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+    __syncthreads();
+    const float nf = (float)g.N * (float)g.HW;
+    const float k1 = (float)bc[0] / nf, k2 = (float)bc[1] / nf, gi = ga * invstd;
+#pragma unroll
+    for (int k = 0; k < TAIL_Q; ++k) {
+        if ((int)threadIdx.x + 256 * k >= g.n4) continue;
+        const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float zh = (e[u] - mean) * invstd; const float dz = (zh * ga + be > 0.f) ? gq[k] : 0.f; o[u] = gi * (dz - k1 - zh * k2); }
+        *reinterpret_cast<float4*>(dy + off[k]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+static int tail_geom(int64_t N, int64_t C, int64_t HW, TailGeom* g) {
+    if (N <= 0 || C <= 0 || C > 65535 || HW <= 0 || HW % 4) return 0;
+    const int64_t HW4 = HW / 4;
+    int sh = 0;
+    while ((1 << sh) < HW4) ++sh;
+    if ((1 << sh) != HW4 || HW4 > 64 || N * HW4 > 256 * TAIL_Q || N * HW < 2) return 0;
+    g->N = (int)N; g->C = (int)C; g->HW = (int)HW; g->HW4 = (int)HW4; g->n4 = (int)(N * HW4); g->sh = sh;
+    return 1;
+}
+extern "C" int mn_bnrelu_gap_supported(int64_t N, int64_t C, int64_t HW) { TailGeom g; return tail_geom(N, C, HW, &g); }
+extern "C" int mn_bnrelu_gap_fwd(const float* y, int64_t N, int64_t C, int64_t HW, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* save, float* pooled, mn_stream_t stream) {
+    TailGeom g;
+    if (!y || !gamma || !beta || !save || !pooled || !aligned16(y) || !tail_geom(N, C, HW, &g))
+        MN_FAIL(MN_EINVAL, "mn_bnrelu_gap_fwd: bad arguments (mn_bnrelu_gap_supported: HW / 4 a power of two <= 64, N * HW <= 16384; 16-byte aligned input)");
+    mn_set_last_kernel("k_bnrelu_gap_fwd");
+    hipLaunchKernelGGL(k_bnrelu_gap_fwd, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, g, y, gamma, beta, eps, momentum, running_mean, running_var, save, pooled);
+    MN_CHECK_LAUNCH("mn_bnrelu_gap_fwd");
+    return MN_OK;
+}
+extern "C" int mn_bnrelu_gap_bwd(const float* dpool, const float* y, const float* save, const float* gamma, const float* beta, int64_t N, int64_t C, int64_t HW, float* dy,
+                                 float* dgamma, float* dbeta, mn_stream_t stream) {
+    TailGeom g;
+    if (!dpool || !y || !save || !gamma || !beta || !dy || !dgamma || !dbeta || !aligned16(y) || !aligned16(dy) || !tail_geom(N, C, HW, &g))
+        MN_FAIL(MN_EINVAL, "mn_bnrelu_gap_bwd: bad arguments");
+    mn_set_last_kernel("k_bnrelu_gap_bwd");
+    hipLaunchKernelGGL(k_bnrelu_gap_bwd, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, g, dpool, y, save, gamma, beta, dy, dgamma, dbeta);
+    MN_CHECK_LAUNCH("mn_bnrelu_gap_bwd");
+    return MN_OK;
+}
+// loss = mean over the samples with target != ignore_index of (logsumexp(x_i) - x_i[target_i]), and dlogits = d loss / d x for an incoming gradient of 1
+__global__ __launch_bounds__(256) void k_ce_fwd(const float* __restrict__ x, const int64_t* __restrict__ target, int N, int K, int64_t ignore_index, float* __restrict__ loss,
+                                                float* __restrict__ dlogits) {
+    __shared__ double scd[16];
+    __shared__ float s_cnt;
+    double acc = 0.0, cnt = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const int64_t t = target[i];
+        if (t == ignore_index || t < 0 || t >= K) continue;
+        const float* r = x + (int64_t)i * K;
+        float m = r[0];
+        for (int j = 1; j < K; ++j) m = fmaxf(m, r[j]);
+        float se = 0.f;
+        for (int j = 0; j < K; ++j) se += expf(r[j] - m);
+        acc += (double)((m + logf(se)) - r[t]);
+        cnt += 1.0;
+    }
+    acc = block_reduce(acc, OpAddD(), 0.0, scd);
+    cnt = block_reduce(cnt, OpAddD(), 0.0, scd);
+    if (threadIdx.x == 0) { loss[0] = (float)(acc / cnt); s_cnt = (float)cnt; }
+    __syncthreads();
+    const float inv_n = 1.0f / s_cnt;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const int64_t t = target[i];
+        const float* r = x + (int64_t)i * K;
+        float* d = dlogits + (int64_t)i * K;
+        if (t == ignore_index || t < 0 || t >= K) { for (int j = 0; j < K; ++j) d[j] = 0.f; continue; }
+        float m = r[0];
+        for (int j = 1; j < K; ++j) m = fmaxf(m, r[j]);
+        float se = 0.f;
+        for (int j = 0; j < K; ++j) se += expf(r[j] - m);
+        for (int j = 0; j < K; ++j) d[j] = (expf(r[j] - m) / se - (j == (int)t ? 1.f : 0.f)) * inv_n;
+    }
+}
+__global__ __launch_bounds__(256) void k_scale_by(const float* __restrict__ a, const float* __restrict__ s, float* __restrict__ out, int64_t n) {
+    const float f = s[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] * f;
+}
+extern "C" int mn_cross_entropy_fwd(const float* logits, const int64_t* target, int64_t N, int64_t K, int64_t ignore_index, float* loss, float* dlogits, mn_stream_t stream) {
+    if (!logits || !target || !loss || !dlogits || N <= 0 || K <= 0 || K > 4096 || N * K >= ((int64_t)1 << 31)) MN_FAIL(MN_EINVAL, "mn_cross_entropy_fwd: bad arguments");
+    mn_set_last_kernel("k_ce_fwd");
+    hipLaunchKernelGGL(k_ce_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, (int)N, (int)K, ignore_index, loss, dlogits);
+    MN_CHECK_LAUNCH("mn_cross_entropy_fwd");
+    return MN_OK;
+}
+extern "C" int mn_scale_by(const float* a, const float* scalar, float* out, int64_t n, mn_stream_t stream) {
+    if (!a || !scalar || !out || n <= 0) MN_FAIL(MN_EINVAL, "mn_scale_by: bad arguments");
+    mn_set_last_kernel("k_scale_by");
+    hipLaunchKernelGGL(k_scale_by, dim3(mn_grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a, scalar, out, n);
+    MN_CHECK_LAUNCH("mn_scale_by");
+    return MN_OK;
+}
+
 // ---------------------------------------------------------------- last layer of a binary net: 1x1 conv, few outputs, sign-code input
 // The classifier conv of the WbWtAb nets (models/nin_gc.py: 1024 -> 10, 1x1) keeps full-precision weights (the rewrite skips the
 // last conv, wbwtab/quantize.py:251) but its INPUT is the +-1 output of the previous block.  O is tiny, so this is a per-pixel dot

@@ -105,7 +105,8 @@ def train_step_dp(model, optimizer, sync, data, target):
     """``train_step`` with the gradient exchange between backward and the optimizer step."""
     import torch.nn.functional as F
     output = model(data)
-    loss = F.cross_entropy(output, target)
+    from micronet_amd.train import cross_entropy
+    loss = cross_entropy(output, target)
     optimizer.zero_grad()
     loss.backward()
     sync.wait()

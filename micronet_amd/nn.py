@@ -51,11 +51,66 @@ class AvgPool2dGlobal(nn.AvgPool2d):
 
     def forward(self, input):
         pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+        from .sign_tensor import LazyBNAct
+        if isinstance(input, LazyBNAct) and input._mn_value is None and input.recipe.get("kind") == "bn_tail":
+            # the un-computed BatchNorm + ReLU of the last block (TailBNMixin): statistics, normalise, rectify and pool in ONE kernel
+            if pair(self.kernel_size) == tuple(input.shape[2:]) and pair(self.padding) == (0, 0) and not self.ceil_mode and self.divisor_override is None:
+                return ops.BNReLUGapPull.apply(input)
+            input = ops.LazyBNActToFloat.apply(input)
         if (torch.is_tensor(input) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and type(input) is torch.Tensor and input.is_contiguous()
                 and pair(self.kernel_size) == tuple(input.shape[2:]) and pair(self.padding) == (0, 0) and not self.ceil_mode and self.divisor_override is None):
             return ops.GlobalAvgPool.apply(input)
         ops.note_fallback("AvgPool2dGlobal -> nn.AvgPool2d")
         return super().forward(input)
+
+
+class TailBNMixin:
+    """The BatchNorm2d of the net's LAST block -- bn -> relu -> AvgPool2d over the whole map (models/nin_gc.py:136-147) -- in training mode: its output (with the ReLU
+    behind it) stays un-computed (``ops.BNReLUTailLazy``) and the pool computes bn + relu + pool in one kernel per direction.  Installed by ``fuse_tail`` as a subclass
+    of the module's own class (same parameters, buffers, ``state_dict``); eval mode and anything the kernel does not cover run the base class."""
+
+    def forward(self, input):
+        if (TAIL_FUSED and self.training and self.affine and self.track_running_stats and self.momentum is not None and self.running_mean is not None and
+                ops.bn_tail_supported(input)):
+            if self.num_batches_tracked is not None and not self.__dict__.pop("_mn_nbt_pre", False):
+                self.num_batches_tracked.add_(1)
+            return ops.BNReLUTailLazy.apply(input, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum)
+        return super().forward(input)
+
+
+class ReLUTail(nn.ReLU):
+    """The ``nn.ReLU`` behind a ``TailBNMixin`` BatchNorm: an un-computed ``LazyBNAct`` of kind "bn_tail" already stands for relu(bn(y)) (relu is idempotent) and passes
+    through; anything else is the ordinary ReLU."""
+
+    def forward(self, input):
+        from .sign_tensor import LazyBNAct
+        if isinstance(input, LazyBNAct) and input.recipe.get("kind") == "bn_tail":
+            return input
+        return super().forward(input)
+
+
+import os as _os
+TAIL_FUSED = _os.environ.get("MN_TAIL_FUSED", "1") != "0"          # A/B knob (round 6): bn + relu + global pool of the last block in one kernel per direction
+
+
+def fuse_tail(model):
+    """``prepare(fuse_bn_act=True)`` of the DoReFa / WbWtAb rewrites: a reference block (conv -> bn -> relu in definition order) directly in front of an
+    ``AvgPool2dGlobal`` in the same ``nn.Sequential`` gets ``TailBNMixin`` / ``ReLUTail``.  Same objects, parameters, buffers and ``state_dict``."""
+    from micronet_amd.quantization.wqaq.dorefa.quantize import _is_ref_block
+    for seq in model.modules():
+        if not isinstance(seq, nn.Sequential):
+            continue
+        kids = list(seq.children())
+        for blk, pool in zip(kids, kids[1:]):
+            if type(pool) is not AvgPool2dGlobal or not _is_ref_block(blk):
+                continue
+            bn, relu = getattr(blk, "bn", None), getattr(blk, "relu", None)
+            if (type(bn).__name__ in ("BatchNorm2d", "BatchNorm2dReLU") and isinstance(bn, nn.BatchNorm2d) and bn.affine and bn.track_running_stats and
+                    not getattr(bn, "q_out_bits", 0) and not getattr(bn, "emit_minmax", False) and
+                    (type(relu) is nn.ReLU or type(relu).__name__ == "ReLUAfterFusedBN")):
+                bn.__class__ = derive_class("Tail", TailBNMixin, type(bn))
+                if type(relu) is nn.ReLU:
+                    relu.__class__ = ReLUTail
 
 
 # ------------------------------------------------------------------------------------------------ class swaps that survive pickling

@@ -1684,6 +1684,102 @@ class LazyBNActToFloat(Function):
         return g
 
 
+class BNReLUTailLazy(Function):
+    """The BatchNorm2d + ReLU in front of the net's global average pool (models/nin_gc.py:136-147), training mode: returns a ``LazyBNAct`` (kind "bn_tail") -- nothing is
+    computed; ``AvgPool2dGlobal`` pulls it through ONE kernel (``BNReLUGapPull``: statistics, normalise, rectify, pool) and hands this node its finished gradients.
+    Any other consumer gets relu(batch_norm(y)) from ATen (forward and backward)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum):
+        y, gamma, beta = _chk(y, "input"), _chk(gamma, "weight"), _chk(beta, "bias")
+        save = torch.empty((2, y.shape[1]), dtype=torch.float32, device=y.device)
+
+        def compute():
+            return torch.relu(torch.nn.functional.batch_norm(y, running_mean, running_var, gamma, beta, True, momentum, eps))
+        ctx.save_for_backward(y, gamma, beta)
+        ctx.eps = eps
+        return LazyBNAct(y.shape, y.device, dict(kind="bn_tail", y=y, gamma=gamma, beta=beta, save=save, running_mean=running_mean, running_var=running_var, eps=float(eps),
+                                                 momentum=float(momentum), compute=compute))
+
+    @staticmethod
+    def backward(ctx, da):
+        y, gamma, beta = ctx.saved_tensors
+        if isinstance(da, LazyBNGrad) and da._mn_value is None and da._mn_recipe.get("kind") == "bn_done" and da._mn_recipe["y"].data_ptr() == y.data_ptr():
+            r = da._mn_recipe
+            return r["dy"], r["dgamma"], r["dbeta"], None, None, None, None
+        with torch.enable_grad():          # a foreign consumer took the float32 activation: ATen's backward of the same function
+            y_, g_, b_ = y.detach().requires_grad_(True), gamma.detach().requires_grad_(True), beta.detach().requires_grad_(True)
+            a = torch.relu(torch.nn.functional.batch_norm(y_, None, None, g_, b_, True, 0.0, ctx.eps))
+            dy, dg, db = torch.autograd.grad(a, (y_, g_, b_), materialize(da))
+        return dy, dg, db, None, None, None, None
+
+
+class BNReLUGapPull(Function):
+    """pooled = mean over the image of relu(batch_norm(y)) from a ``LazyBNAct`` of kind "bn_tail": mn_bnrelu_gap_fwd / _bwd, one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, lazy):
+        r = lazy.recipe
+        y = r["y"]
+        N, Cc, H, W = y.shape
+        pooled = torch.empty((N, Cc, 1, 1), dtype=torch.float32, device=y.device)
+        with torch.cuda.device_of(y):
+            _call("mn_bnrelu_gap_fwd", _p(y), N, Cc, H * W, _p(r["gamma"]), _p(r["beta"]), r["eps"], r["momentum"], _p(r["running_mean"]), _p(r["running_var"]), _p(r["save"]),
+                  _p(pooled), _s())
+        ctx.save_for_backward(y, r["gamma"], r["beta"], r["save"])
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma, beta, save = ctx.saved_tensors
+        g = _chk(g, "grad")
+        N, Cc, H, W = y.shape
+        dy, dgamma, dbeta = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
+        with torch.cuda.device_of(y):
+            _call("mn_bnrelu_gap_bwd", _p(g), _p(y), _p(save), _p(gamma), _p(beta), N, Cc, H * W, _p(dy), _p(dgamma), _p(dbeta), _s())
+        return LazyBNGrad((N, Cc, H, W), y.device, dict(kind="bn_done", y=y, dy=dy, dgamma=dgamma, dbeta=dbeta, g=g),
+                          lambda rr: (rr["g"].reshape(N, Cc, 1, 1) / float(H * W)).expand(N, Cc, H, W).contiguous())
+
+
+def bn_tail_supported(y):
+    return (type(y) is torch.Tensor and y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and (y.shape[2] * y.shape[3]) % 4 == 0 and y.is_contiguous() and
+            y.data_ptr() % 16 == 0 and y.shape[1] <= 64 and bool(_lib_().mn_bnrelu_gap_supported(y.shape[0], y.shape[1], y.shape[2] * y.shape[3])))
+
+
+class CrossEntropy(Function):
+    """nn.CrossEntropyLoss() (mean reduction; the criterion of the reference's main.py, wqaq/dorefa/main.py:87-92) on [N, K] logits: the loss and its gradient in one
+    launch (mn_cross_entropy_fwd); the backward scales that gradient by the incoming scalar (mn_scale_by)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits = _chk(logits, "logits")
+        N, K = logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        with torch.cuda.device_of(logits):
+            _call("mn_cross_entropy_fwd", _p(logits), _p(target), N, K, int(ignore_index), _p(loss), _p(dl), _s())
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, = ctx.saved_tensors
+        g = _chk(g, "grad")
+        out = torch.empty_like(dl)
+        with torch.cuda.device_of(dl):
+            _call("mn_scale_by", _p(dl), _p(g), _p(out), dl.numel(), _s())
+        return out, None, None
+
+
+def cross_entropy(logits, target, ignore_index=-100):
+    """F.cross_entropy(logits, target) (mean reduction, no weights / smoothing) -- on the gfx950 kernel for float32 CUDA logits [N, K] with int64 targets"""
+    if (type(logits) is torch.Tensor and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.shape[1] <= 4096 and logits.shape[0] > 0 and
+            type(target) is torch.Tensor and target.is_cuda and target.dtype == torch.int64 and target.dim() == 1 and target.shape[0] == logits.shape[0] and
+            target.is_contiguous()):
+        return CrossEntropy.apply(logits, target, ignore_index)
+    return torch.nn.functional.cross_entropy(logits, target, ignore_index=ignore_index)
+
+
 class GlobalAvgPool(Function):
     """nn.AvgPool2d over the whole image (the tail of nin / nin_gc): [N, C, H, W] -> [N, C, 1, 1]."""
 

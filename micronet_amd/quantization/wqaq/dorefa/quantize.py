@@ -570,4 +570,7 @@ def prepare(model, inplace=False, a_bits=8, w_bits=8, quant_inference=False, fus
     if fuse_bn_act and fuse_blocks:          # (quant_inference graphs too: their convs take the code kernels once the stored weights are on the grid)
         _fuse_blocks(model, fold_shuffle=fold_shuffle)
         _fuse_residual_blocks(model)
+    if fuse_bn_act:
+        from micronet_amd.nn import fuse_tail
+        fuse_tail(model)          # bn -> relu -> global average pool of the last block: one kernel per direction (TailBNMixin)
     return model

@@ -58,11 +58,18 @@ def make_optimizer(model, lr=0.01, weight_decay=1e-5, fused=None, **kw):
 
 def train_step(model, optimizer, data, target):
     output = model(data)
-    loss = F.cross_entropy(output, target)
+    loss = cross_entropy(output, target)
     optimizer.zero_grad()
     loss.backward()
     optimizer.step()
     return loss, output
+
+
+def cross_entropy(output, target):
+    """``nn.CrossEntropyLoss()`` of the reference's main.py (wqaq/dorefa/main.py:87-92): the loss and its gradient in one launch on the GPU (ops.CrossEntropy), ATen's
+    otherwise"""
+    from micronet_amd import ops
+    return ops.cross_entropy(output, target)
 
 
 def bump_bn_counters(model):
@@ -70,9 +77,10 @@ def bump_bn_counters(model):
     resnet18 step) as ONE multi-tensor launch in front of the forward; each module is told that its counter already moved for the coming forward (the flag is
     consumed there).  Modules with ``momentum=None`` read the counter on the host and keep doing their own increment."""
     from micronet_amd.quantization.wqaq.dorefa.quantize import BatchNorm2dPlain, BatchNorm2dReLU
+    from micronet_amd.nn import TailBNMixin
     todo = []
     for m in model.modules():
-        if isinstance(m, (BatchNorm2dReLU, BatchNorm2dPlain)) and m.training and m.track_running_stats and m.num_batches_tracked is not None \
+        if isinstance(m, (BatchNorm2dReLU, BatchNorm2dPlain, TailBNMixin)) and m.training and m.track_running_stats and m.num_batches_tracked is not None \
                 and m.momentum is not None and m.num_batches_tracked.is_cuda and not getattr(m, "q_out_bits", 0) and "_mn_nbt_pre" not in m.__dict__:
             todo.append(m)
     if len(todo) >= 2:
@@ -329,7 +337,7 @@ class GraphedTrainStep:
         bump_bn_counters(self.model)
         if self.bound is None:
             self.output = self.model(self.data)
-            self.loss = F.cross_entropy(self.output, self.target)
+            self.loss = cross_entropy(self.output, self.target)
             self.optimizer.zero_grad(set_to_none=True)
             self.loss.backward()
             return
@@ -347,7 +355,7 @@ class GraphedTrainStep:
             self.output = self.model(self.data)
         finally:
             h.remove()
-        self.loss = F.cross_entropy(self.output, self.target)
+        self.loss = cross_entropy(self.output, self.target)
         self.optimizer.zero_grad(set_to_none=True)
         if "leaf" not in cutpt:
             self.bound, self._late_mods, self.one_bucket_reason = None, None, "boundary output is a %s" % cutpt.get("bad", "tensor outside the graph")

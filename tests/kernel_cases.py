@@ -2025,6 +2025,58 @@ def check_bn_lazy_pull(be, r, g, aqs, wq, dX, dWn, dCB, dqp, dWs, bias, yv, dGa,
             assert 0.002 * n < np.count_nonzero(bits == 0) < 0.9 * n          # (the clip is exercised)
 
 
+def check_tail(be, shape=(37, 10, 8, 8), seed=0):
+    """The tail of the reference's nets (models/nin_gc.py:136-147; wqaq/dorefa/main.py:87-92): mn_bnrelu_gap_fwd / _bwd == BatchNorm2d (training) -> ReLU ->
+    AvgPool2d over the map, and mn_cross_entropy_fwd / mn_scale_by == nn.CrossEntropyLoss() with its backward, against fp64 evaluations."""
+    r = np.random.default_rng(seed)
+    N_, Cc, H, W = shape
+    HW = H * W
+    y = (r.standard_normal(shape) * 1.7 + 0.4).astype(F)
+    gamma, beta = (r.standard_normal(Cc) * 0.5 + 1).astype(F), (r.standard_normal(Cc) * 0.3).astype(F)
+    rm, rv = (r.standard_normal(Cc) * 0.1).astype(F), (np.abs(r.standard_normal(Cc)) + 0.5).astype(F)
+    dY, dGa, dBe, dRm, dRv = be.to_dev(y), be.to_dev(gamma), be.to_dev(beta), be.to_dev(rm), be.to_dev(rv)
+    save, pooled = be.empty((2, Cc)), be.empty((N_, Cc))
+    be.call("mn_bnrelu_gap_fwd", be.ptr(dY), N_, Cc, HW, be.ptr(dGa), be.ptr(dBe), 1e-5, 0.1, be.ptr(dRm), be.ptr(dRv), be.ptr(save), be.ptr(pooled), be.stream)
+    y64 = y.astype(np.float64)
+    mean, var = y64.mean(axis=(0, 2, 3)), y64.var(axis=(0, 2, 3))
+    invstd = 1.0 / np.sqrt(var + 1e-5)
+    zh = (y64 - mean.reshape(1, -1, 1, 1)) * invstd.reshape(1, -1, 1, 1)
+    z = zh * gamma.astype(np.float64).reshape(1, -1, 1, 1) + beta.astype(np.float64).reshape(1, -1, 1, 1)
+    a = np.maximum(z, 0.0)
+    assert close(be.to_host(pooled), a.mean(axis=(2, 3)), 2e-6), "pooled"
+    sv = be.to_host(save)
+    assert close(sv[0], mean, 2e-6) and close(sv[1], invstd, 5e-6), "save"
+    n = N_ * HW
+    assert close(be.to_host(dRm), 0.9 * rm + 0.1 * mean, 2e-6) and close(be.to_host(dRv), 0.9 * rv + 0.1 * var * n / (n - 1), 5e-6), "running statistics"
+    gp = r.standard_normal((N_, Cc)).astype(F)
+    dy, dga, dbe = be.empty(shape), be.empty(Cc), be.empty(Cc)
+    be.call("mn_bnrelu_gap_bwd", be.ptr(be.to_dev(gp)), be.ptr(dY), be.ptr(save), be.ptr(dGa), be.ptr(dBe), N_, Cc, HW, be.ptr(dy), be.ptr(dga), be.ptr(dbe), be.stream)
+    dz = np.where(z > 0, gp.astype(np.float64).reshape(N_, Cc, 1, 1) / HW, 0.0)
+    s1, s2 = dz.sum(axis=(0, 2, 3)), (dz * zh).sum(axis=(0, 2, 3))
+    dy_ref = (gamma.astype(np.float64) * invstd).reshape(1, -1, 1, 1) * (dz - s1.reshape(1, -1, 1, 1) / n - zh * s2.reshape(1, -1, 1, 1) / n)
+    assert close(be.to_host(dy), dy_ref, 1e-5) and close(be.to_host(dga), s2, 1e-5) and close(be.to_host(dbe), s1, 1e-5), "backward"
+    # ---- the loss
+    K_ = Cc
+    x = (r.standard_normal((N_, K_)) * 3).astype(F)
+    t = r.integers(0, K_, N_).astype(np.int64)
+    t[3] = -100          # ignore_index
+    loss, dl = be.empty(1), be.empty((N_, K_))
+    dT = be.to_dev(t.view(F).reshape(-1)) if be.kind == "emu" else be.torch.from_numpy(t).cuda()
+    be.call("mn_cross_entropy_fwd", be.ptr(be.to_dev(x)), be.ptr(dT), N_, K_, -100, be.ptr(loss), be.ptr(dl), be.stream)
+    x64 = x.astype(np.float64)
+    lse = np.log(np.exp(x64 - x64.max(axis=1, keepdims=True)).sum(axis=1)) + x64.max(axis=1)
+    valid = t >= 0
+    li = np.where(valid, lse - x64[np.arange(N_), np.where(valid, t, 0)], 0.0)
+    assert abs(float(be.to_host(loss)[0]) - li.sum() / valid.sum()) <= 2e-6 * abs(li.sum() / valid.sum()), "loss"
+    sm = np.exp(x64 - lse.reshape(-1, 1))
+    oh = np.zeros_like(sm); oh[np.arange(N_)[valid], t[valid]] = 1.0
+    dref = np.where(valid.reshape(-1, 1), (sm - oh) / valid.sum(), 0.0)
+    assert close(be.to_host(dl), dref, 2e-6), "d logits"
+    out = be.empty((N_, K_))
+    be.call("mn_scale_by", be.ptr(dl), be.ptr(be.to_dev(np.array([0.5], dtype=F))), be.ptr(out), N_ * K_, be.stream)
+    assert np.array_equal(be.to_host(out), be.to_host(dl) * F(0.5))
+
+
 def check_iao_qadd_bn(be, shape=(3, 6, 4, 8), bits=4, q_type=0, relu=True, scbn=False, shrink=0.6, seed=0):
     """The END of an IAO residual block in one pass (round 6): mn_iao_qadd_bn_fwd == mn_bn_apply (per side) -> mn_iao_qadd_fwd_mm, and mn_iao_qadd_bn_bwd ==
     mn_iao_qadd_bwd -> mn_bn2d_bwd (per side), bit for bit -- output, (min, max) of the output, dy / dgamma / dbeta of both BatchNorms, the identity shortcut's

@@ -471,6 +471,40 @@ def _iao_resnet_two_steps(monkeypatch, iaoq_knobs, batch=8):
     return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, model
 
 
+@pytest.mark.parametrize("key", ["c2_nin_gc_wbwtab_w3a2", "c1_nin_gc_dorefa_w8a8"])
+def test_tail_fused_vs_stock(monkeypatch, key):
+    """Round 6: the net's tail -- BatchNorm2d -> ReLU -> AvgPool2d over the map (models/nin_gc.py:136-147) and nn.CrossEntropyLoss() (wqaq/dorefa/main.py:87-92) -- as
+    three launches (mn_bnrelu_gap_fwd / _bwd, mn_cross_entropy_fwd + mn_scale_by) against MIOpen's BatchNorm / ATen's ReLU, pooling, softmax and nll_loss on the same
+    prepared net: same loss and the same gradients of EVERY parameter to fp32 round-off, no fallback, and the stock modules when the knob is off."""
+    import copy
+    import torch.nn.functional as Fn
+    from micronet_amd import nn as mnn, ops
+    from micronet_amd.train import build_model, synth_batch
+    arch, scheme, kw, B, wd = CFG[key]
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    base = quantize.prepare(build_model(arch), inplace=True, **kw).cuda().train()
+    assert isinstance(base.model[-2].bn, mnn.TailBNMixin)
+    x, y = synth_batch(32, device="cuda")
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(mnn, "TAIL_FUSED", fused)
+        m = copy.deepcopy(base)
+        ops.fallback_counts(reset=True)
+        loss = ops.cross_entropy(m(x), y) if fused else Fn.cross_entropy(m(x), y)
+        loss.backward()
+        assert ops.fallback_counts() == {}, ops.fallback_counts()
+        res[fused] = (float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    assert abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0]), (res[True][0], res[False][0])
+    gscale = max(float(g.abs().max()) for g in res[False][1].values())
+    for k, g0 in res[False][1].items():
+        g1 = res[True][1][k]
+        # (a conv bias in front of a BatchNorm has an exactly zero gradient: what both runs hold there is round-off of the net's gradient scale)
+        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-6 * gscale, (k, float((g1 - g0).abs().max()), float(g0.abs().max()), gscale)
+    for k, v0 in res[False][2].items():          # running statistics, counters
+        v1 = res[True][2][k]
+        assert torch.allclose(v1.float(), v0.float(), rtol=2e-5, atol=1e-7, equal_nan=True), k
+
+
 @pytest.mark.parametrize("codes,add", [(True, True), (True, False), (False, True)])
 def test_iao_resnet_block_fused_passes(monkeypatch, codes, add):
     """Round 6, the IAO BasicBlock (models/resnet.py:17-29, 60-65 under wqaq/iao/quantize.py:492-507, 1484-1498) in fewer passes:

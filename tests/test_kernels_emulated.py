@@ -490,6 +490,11 @@ def test_iao_qadd_bn_fused(be, shape, bits, q_type, relu, scbn):
     K.check_iao_qadd_bn(be, shape, bits, q_type, relu, scbn, seed=430 + bits)
 
 
+def test_tail_bn_relu_pool_and_loss(be):
+    K.check_tail(be, (37, 10, 8, 8), seed=450)
+    K.check_tail(be, (300, 3, 2, 4), seed=452)
+
+
 def test_qdense_layer_iao_w8a8_bias(be):
     K.check_qdense_iao(be, (2, 64, 8, 8), 64, 3, 1, a_bits=8, w_bits=8, bias=True, seed=410)
 
