@@ -123,7 +123,10 @@ struct QdPackTable {
 // [o][c][tap]) and written out in every fragment order wanted as whole 16-byte lanes -- the forward image ([cot][chunk][tap] blocks of 4 KB int8 / 8 KB bf16
 // are contiguous per tile) and the two 32-row chunks of the backward-data image.  (The first version gathered 4-byte elements at strides of T and C T floats
 // per lane: 139 us for resnet18's 11 M weights; this one is bound by the 45 MB it reads.)
-__global__ __launch_bounds__(256) void k_qd_pack_multi(const QdPackTable t) {
+// Round 6: 1024 threads per block and 16-byte loads -- resnet18's 11 M weights are ~300 tiles, i.e. one block per CU: with 4 waves of scalar loads the launch was
+// latency-bound (77-87 us for 45 MB).
+#define QD_PACK_THREADS 1024
+__global__ __launch_bounds__(QD_PACK_THREADS) void k_qd_pack_multi(const QdPackTable t) {
     HIP_DYNAMIC_SHARED(float, smem)
     int16_t* codes = reinterpret_cast<int16_t*>(smem);          // [64 o][64 c][T]
     int e = 0;
@@ -134,18 +137,35 @@ __global__ __launch_bounds__(256) void k_qd_pack_multi(const QdPackTable t) {
     const float* w = t.w[e];
     const float* wsc = t.wsc[e];
     const int row_len = 64 * T, total = 64 * row_len;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int row = i / row_len, col = i - row * row_len;
-        const int o = cot * 64 + row;
-        const float v = w[((int64_t)o * Cn + cit * 64) * T + col];
-        codes[i] = (int16_t)(int)(wsc ? rintf(v / wsc[(int64_t)o * t.wsc_stride[e]]) : rintf(v * t.wn));
+    const int nthr = (int)blockDim.x;
+    if ((((uintptr_t)w) & 15) == 0) {          // a row of the tile starts at a multiple of 64 floats: every quad of it is one aligned 16-byte load
+        for (int i = threadIdx.x; i < total / 4; i += nthr) {
+            const int row = (4 * i) / row_len, col = 4 * i - row * row_len;
+            const int o = cot * 64 + row;
+            const float4 v = *reinterpret_cast<const float4*>(w + ((int64_t)o * Cn + cit * 64) * T + col);
+            int c0, c1, c2, c3;
+            if (wsc) {
+                const float sc = wsc[(int64_t)o * t.wsc_stride[e]];
+                c0 = (int)rintf(v.x / sc); c1 = (int)rintf(v.y / sc); c2 = (int)rintf(v.z / sc); c3 = (int)rintf(v.w / sc);
+            } else {
+                c0 = (int)rintf(v.x * t.wn); c1 = (int)rintf(v.y * t.wn); c2 = (int)rintf(v.z * t.wn); c3 = (int)rintf(v.w * t.wn);
+            }
+            *reinterpret_cast<u32x2*>(codes + 4 * i) = u32x2{((uint32_t)c0 & 0xffffu) | ((uint32_t)c1 << 16), ((uint32_t)c2 & 0xffffu) | ((uint32_t)c3 << 16)};
+        }
+    } else {
+        for (int i = threadIdx.x; i < total; i += nthr) {
+            const int row = i / row_len, col = i - row * row_len;
+            const int o = cot * 64 + row;
+            const float v = w[((int64_t)o * Cn + cit * 64) * T + col];
+            codes[i] = (int16_t)(int)(wsc ? rintf(v / wsc[(int64_t)o * t.wsc_stride[e]]) : rintf(v * t.wn));
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     if (t.outf[e]) {
         if (t.fwd8) {          // orient 2: [cot][chunk = cit][tap][nf][lane][16 signed bytes]: o = 16 nf + (lane & 15), c = 16 (lane >> 4) + b
             unsigned char* dst = reinterpret_cast<unsigned char*>(t.outf[e]) + (int64_t)(cot * ncit + cit) * T * 4096;
-            for (int it = threadIdx.x; it < T * 256; it += 256) {
+            for (int it = threadIdx.x; it < T * 256; it += nthr) {
                 const int tap = it >> 8, nf = (it >> 6) & 3;
                 const int16_t* src = codes + ((nf * 16 + (lane & 15)) * 64 + (lane >> 4) * 16) * T + tap;
                 uint32_t d[4] = {0u, 0u, 0u, 0u};
@@ -155,7 +175,7 @@ __global__ __launch_bounds__(256) void k_qd_pack_multi(const QdPackTable t) {
             }
         } else {               // orient 0: [cot][chunk][tap][ks][nf][lane][8 bf16]: o = 16 nf + (lane & 15), c = 32 ks + 8 (lane >> 4) + b
             unsigned char* dst = reinterpret_cast<unsigned char*>(t.outf[e]) + (int64_t)(cot * ncit + cit) * T * 8192;
-            for (int it = threadIdx.x; it < T * 512; it += 256) {
+            for (int it = threadIdx.x; it < T * 512; it += nthr) {
                 const int tap = it >> 9, ks = (it >> 8) & 1, nf = (it >> 6) & 3;
                 const int16_t* src = codes + ((nf * 16 + (lane & 15)) * 64 + ks * 32 + (lane >> 4) * 8) * T + tap;
                 uint32_t h[8];
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(256) void k_qd_pack_multi(const QdPackTable t) {
     }
     if (t.outd[e]) {           // orient 1: [cit][chunk = o / 32][tap][nf][lane][8 bf16]: c = 16 nf + (lane & 15), o = 32 chunk + 8 (lane >> 4) + b
         const int nch = O / 32;
-        for (int it = threadIdx.x; it < 2 * T * 256; it += 256) {
+        for (int it = threadIdx.x; it < 2 * T * 256; it += nthr) {
             const int half = it / (T * 256), r = it - half * T * 256;
             const int tap = r >> 8, nf = (r >> 6) & 3;
             const int16_t* src = codes + ((half * 32 + (lane >> 4) * 8) * 64 + nf * 16 + (lane & 15)) * T + tap;
@@ -2310,7 +2330,7 @@ extern "C" int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, voi
         const size_t lds = (size_t)64 * 64 * max_t * 2;
         raise_lds_limit((const void*)k_qd_pack_multi, lds);
         mn_set_last_kernel("k_qd_pack_multi");
-        hipLaunchKernelGGL(k_qd_pack_multi, dim3((unsigned)blk), dim3(256), lds, s, t);
+        hipLaunchKernelGGL(k_qd_pack_multi, dim3((unsigned)blk), dim3(QD_PACK_THREADS), lds, s, t);
     }
     MN_CHECK_LAUNCH("mn_qd_pack_multi");
     return MN_OK;

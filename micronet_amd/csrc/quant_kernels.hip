@@ -227,7 +227,27 @@ extern "C" int mn_dorefa_act_bwd(const float* g, const float* x, float* dx, int6
 // algorithm, so it cannot be restated.  What can be done is to take the rounding error out of OUR side: the value is evaluated in fp64 and rounded once, i.e. the
 // correctly rounded fp32 tanh (MKL HA differs from it in the last ulp for 1.5 % of inputs; ocml's tanhf, used until round 2, for 5.4 %).  The tensors are small
 // (<= 11 M weights per net): the fp64 evaluation costs microseconds.  Pinned by tests/golden/tanh_device_vs_cpu.json.
-__device__ __forceinline__ float mn_tanh_cr(float x) { return (float)tanh((double)x); }
+// Round 6: |x| <= 0.25 (every weight of a net in training, in practice) takes the Maclaurin series in fp64 -- x + x z (c3 + z (c5 + ...)), z = x^2, 13 terms: truncation
+// below 2^-66 relative, evaluation error below one fp64 ulp (measured 0.99 ulp against a 60-digit reference), i.e. the same "fp64 value rounded once" at a tenth of the
+// instructions of the library tanh (exp + division), which made the absmax pass ALU-bound (66 us for resnet18's 11 M weights); larger arguments take the library call.
+__device__ __forceinline__ float mn_tanh_cr(float x) {
+    const double xd = (double)x;
+    if (fabsf(x) > 0.25f) return (float)tanh(xd);
+    const double z = xd * xd;
+    double q = 0x1.0b132d39a6050p-16;
+    q = fma(q, z, -0x1.497d8eea25259p-15);
+    q = fma(q, z, 0x1.967e18afcafadp-14);
+    q = fma(q, z, -0x1.f57d7734d1664p-13);
+    q = fma(q, z, 0x1.3558248036744p-11);
+    q = fma(q, z, -0x1.7da36452b75e3p-10);
+    q = fma(q, z, 0x1.d6d3d0e157de0p-9);
+    q = fma(q, z, -0x1.226e355e6c23dp-7);
+    q = fma(q, z, 0x1.664f4882c10fap-6);
+    q = fma(q, z, -0x1.ba1ba1ba1ba1cp-5);
+    q = fma(q, z, 0x1.1111111111111p-3);
+    q = fma(q, z, -0x1.5555555555555p-2);
+    return (float)fma(xd, z * q, xd);
+}
 // DoReFa weight (61-73): global max of |tanh w| -> normalise -> round -> 2q-1.
 // ws layout (floats): [0] M, [1] dM (bwd), [2] tie count (bwd), [16 .. 16+3*NB) per-block partials.
 static const int DW_NB = 1024;  // partial blocks per tensor (a 2.4 M-element resnet layer: 9 elements per thread; 128 blocks left the absmax pass latency-bound at 97 us)
@@ -384,7 +404,28 @@ __global__ __launch_bounds__(256) void k_dorefa_w_absmax_multi(const DwTable t) 
     m = block_reduce(m, OpMaxF(), 0.f, sc);
     if (threadIdx.x == 0) t.ws[ti][16 + lb] = m;
 }
+// One block per tensor finishes what the partial passes left (round 6): which 0: M = max of the absmax partials -> ws[0]; which 1: dM (fp64 sum of the partials, the
+// single-tensor kernel's order) and the tie count -> ws[1], ws[2].  Until round 6 EVERY block of the element-wise phases redid these reductions over up to 1024
+// partials as its prologue (two to four block-wide reductions in front of ~2 float4 of work per thread: 44 us per phase for resnet18's 11 M weights, 2 TB/s).
+__global__ __launch_bounds__(256) void k_dorefa_w_final_multi(const DwTable t, int which) {
+    __shared__ float sc[16];
+    __shared__ double scd[16];
+    const int ti = blockIdx.x, nb = t.nb[ti];
+    float* __restrict__ ws = t.ws[ti];
+    if (which == 0) {
+        const float M = dorefa_w_global_max(ws, nb, sc);
+        if (threadIdx.x == 0) ws[0] = M;
+    } else {
+        double a = 0.0;
+        float c = 0.f;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) { a += (double)ws[16 + nb + i]; c += ws[16 + 2 * nb + i]; }
+        const float dM = (float)block_reduce(a, OpAddD(), 0.0, scd);
+        const float cnt = block_reduce(c, OpAddF(), 0.f, sc);
+        if (threadIdx.x == 0) { ws[1] = dM; ws[2] = cnt; }
+    }
+}
 // phase: 0 forward (qw), 1 backward partial sums, 2 backward (dw).  Blocks of a tensor: the table's partition for phase 1 (one partial per block), b1 for 0 / 2.
+// M (and, phase 2, dM and the tie count) come finished from k_dorefa_w_final_multi.
 __global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int phase) {
     __shared__ float sc[16];
     __shared__ double scd[16];
@@ -395,9 +436,8 @@ __global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int pha
     const float* __restrict__ th = t.th[ti];
     const long long n = t.n[ti];
     const float s = t.s;
-    const float M = dorefa_w_global_max(ws, nb, sc);
+    const float M = ws[0];
     if (phase == 0) {
-        if (lb == 0 && threadIdx.x == 0) ws[0] = M;
         float* __restrict__ qw = t.out[ti];
         auto q1 = [&](float tt) { const float u = (tt / 2.f) / M + 0.5f; const float q = mn_rha(u / s) * s; return 2.f * q - 1.f; };
         if (th && dw_vec_ok(th, qw, nullptr, nullptr, n)) {
@@ -439,12 +479,7 @@ __global__ __launch_bounds__(256) void k_dorefa_w_multi(const DwTable t, int pha
         ties = block_reduce(ties, OpAddF(), 0.f, sc);
         if (threadIdx.x == 0) { ws[16 + nb + lb] = (float)acc; ws[16 + 2 * nb + lb] = ties; }
     } else {
-        double a = 0.0;
-        float c = 0.f;
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) { a += (double)ws[16 + nb + i]; c += ws[16 + 2 * nb + i]; }
-        const float dM = (float)block_reduce(a, OpAddD(), 0.0, scd);
-        const float cnt = block_reduce(c, OpAddF(), 0.f, sc);
-        if (lb == 0 && threadIdx.x == 0) { ws[1] = dM; ws[2] = cnt; }
+        const float dM = ws[1], cnt = ws[2];
         const float share = dM / cnt;
         float* __restrict__ dw = t.out[ti];
         auto d1 = [&](float tt, float gi) {
@@ -487,6 +522,7 @@ extern "C" int mn_dorefa_w_fwd_multi(const float* const* w, float* const* qw, fl
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_dorefa_w_absmax_multi, dim3(grid), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_dorefa_w_final_multi, dim3(count), dim3(256), 0, s, t, 0);
     if ((rc = dw_table(&t, w, nullptr, qw, ws, n, count, w_bits, 1, &grid, "mn_dorefa_w_fwd_multi"))) return rc;
     hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 0);
     MN_CHECK_LAUNCH("mn_dorefa_w_fwd_multi");
@@ -501,7 +537,9 @@ extern "C" int mn_dorefa_w_bwd_multi(const float* const* g, const float* const* 
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_dorefa_w_absmax_multi, dim3(grid), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_dorefa_w_final_multi, dim3(count), dim3(256), 0, s, t, 0);
     hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 1);
+    hipLaunchKernelGGL(k_dorefa_w_final_multi, dim3(count), dim3(256), 0, s, t, 1);
     if ((rc = dw_table(&t, w, g, dw, ws, n, count, w_bits, 1, &grid, "mn_dorefa_w_bwd_multi"))) return rc;
     hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 2);
     MN_CHECK_LAUNCH("mn_dorefa_w_bwd_multi");
@@ -519,6 +557,7 @@ extern "C" int mn_dorefa_w_fwd_multi_cached(const float* const* w, float* const*
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_dorefa_w_absmax_multi, dim3(grid), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_dorefa_w_final_multi, dim3(count), dim3(256), 0, s, t, 0);
     if ((rc = dw_table(&t, w, nullptr, qw, ws, n, count, w_bits, 1, &grid, "mn_dorefa_w_fwd_multi_cached", th))) return rc;
     hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 0);
     MN_CHECK_LAUNCH("mn_dorefa_w_fwd_multi_cached");
@@ -532,7 +571,8 @@ extern "C" int mn_dorefa_w_bwd_multi_cached(const float* const* g, const float* 
     int rc = dw_table(&t, w, g, dw, ws, n, count, w_bits, 0, &grid, "mn_dorefa_w_bwd_multi_cached", th);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 1);          // (ws still holds the forward's absmax partials)
+    hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 1);          // (ws[0] still holds the forward's M)
+    hipLaunchKernelGGL(k_dorefa_w_final_multi, dim3(count), dim3(256), 0, s, t, 1);
     if ((rc = dw_table(&t, w, g, dw, ws, n, count, w_bits, 1, &grid, "mn_dorefa_w_bwd_multi_cached", th))) return rc;
     hipLaunchKernelGGL(k_dorefa_w_multi, dim3(grid), dim3(256), 0, s, t, 2);
     MN_CHECK_LAUNCH("mn_dorefa_w_bwd_multi_cached");
