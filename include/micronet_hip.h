@@ -541,6 +541,10 @@ int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* own, const 
                     float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
 int mn_bnh_bwd_apply(const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int64_t N, int64_t C, int64_t H,
                      int64_t W, int training, float* dy, mn_stream_t stream);
+/* the finish of mn_bnh_bwd_sums alone, on partial sums part [C][splits][2] (doubles) that the producer of d a left (mn_conv2d_bwd_bnh_up): fixed-order sum over the
+ * splits -> sums [2][C], dgamma, dbeta (nullable) */
+int mn_bnh_bwd_sums_final(const double* part, int32_t splits, int64_t N, int64_t C, int64_t H, int64_t W, float* dgamma, float* dbeta, float* sums,
+                          mn_stream_t stream);
 /* ... and the consumers of that dy can form it themselves: backward-data / backward-weight of the block's pointwise convolution whose incoming
  * gradient is the BatchNorm+sign backward of (da, h) -- evaluated in registers while da and h stream in, so dy is never written or re-read
  * (x = the block's input codes; chan, sums as above; needs mn_conv2d_bnh_supported). */
@@ -565,6 +569,15 @@ int mn_conv2d_bwd_bnh_supported(const mn_conv_geom* g, const mn_wq* wq, int pool
 int64_t mn_conv2d_bwd_bnh_ws_bytes(const mn_conv_geom* g);
 int mn_conv2d_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
                       int training, const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream);
+/* ... and, when the block IN FRONT of this one is a BatchNorm+sign block on a pointwise conv too (wbwtab/quantize.py:11-36 behind models/nin_gc.py:18-59's
+ * ConvBNReLU chain), the per-channel sums of THAT block's BatchNorm backward as a by-product: this launch's dx is that block's d a, and its dx waves accumulate
+ * sum dz, sum dz zhat (dz = dx [clip-STE mask from the upstream byte stash up_h], up_chan = the upstream [8][C] constants) into up_part [C][splits][2] doubles --
+ * the upstream block then calls mn_bnh_bwd_sums_final instead of mn_bnh_bwd_sums (no pass over (d a, h)).  splits: mn_conv2d_bwd_bnh_up_splits (0: not
+ * covered; up_k = K of the upstream conv, <= 254).  Same masks as mn_bnh_bwd_sums; the sums agree to fp32 rounding (different summation order). */
+int mn_conv2d_bwd_bnh_up_splits(const mn_conv_geom* g, const mn_wq* wq, int pooled, int64_t up_k);
+int mn_conv2d_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
+                         int training, const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
+                         const uint8_t* up_h, const float* up_chan, double* up_part, mn_stream_t stream);
 /* The same one-launch backward for the k-bit (DoReFa) blocks, wqaq/dorefa/quantize.py:36-46, 107-122 + autograd's conv backward (same geometry, same two queries
  * with pooled = 0, same workspace):
  *   mn_conv2d_bwd_codes: dx (NO clip-STE: the producing block applies it where it recomputes the activation) and dw = s_x * sum gy * j, dbias from a plain fp32

@@ -1450,6 +1450,15 @@ extern "C" int mn_bnh_bwd_sums(const float* da, const uint8_t* h, const int8_t* 
     MN_CHECK_LAUNCH("mn_bnh_bwd_sums");
     return MN_OK;
 }
+// ... when the producer of d a already left the partial sums (mn_conv2d_bwd_bnh_up: part [C][splits][2] doubles): only the fixed-order finish
+extern "C" int mn_bnh_bwd_sums_final(const double* part, int32_t splits, int64_t N, int64_t C, int64_t H, int64_t W, float* dgamma, float* dbeta, float* sums,
+                                     mn_stream_t stream) {
+    if (!part || !sums || splits < 1 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (((uintptr_t)part) & 7)) MN_FAIL(MN_EINVAL, "mn_bnh_bwd_sums_final: bad arguments");
+    const BnsGeom bg = bns_geom(N, C, H * W);
+    hipLaunchKernelGGL(k_bns_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, bg, part, (int)splits, dgamma, dbeta, sums);
+    MN_CHECK_LAUNCH("mn_bnh_bwd_sums_final");
+    return MN_OK;
+}
 // dy = d loss / d y from (da, h) and the sums
 extern "C" int mn_bnh_bwd_apply(const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int64_t N, int64_t C, int64_t H,
                                 int64_t W, int training, float* dy, mn_stream_t stream) {

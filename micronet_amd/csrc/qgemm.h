@@ -62,6 +62,10 @@ int qg_bwd_weight(const mn_conv_geom* g, const mn_actq* aq, const float* gy, con
 // backward-data AND backward-weight of a pointwise binary block in one kernel (qgemm_pwb.hip): (da, h) read once
 int pwb_supported(const mn_conv_geom* g, const mn_wq* wq, int pooled);
 int64_t pwb_ws_bytes(const mn_conv_geom* g);
+int pwb_up_splits(const mn_conv_geom* g);
+int pwb_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
+                   const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const uint8_t* up_h, const float* up_chan,
+                   double* up_part, hipStream_t s);
 int pwb_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
                 const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s);
 int pwb_bwd_plain(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x, int x_bits, float* dx, float* dw, float* dbias, void* ws,

@@ -18,6 +18,10 @@
 //                           transposed image; every accumulator register is one 128-byte row segment of dx.
 // dy' = alpha[o] dy is what backward-data contracts with the integer codes (k_pwd does the same); backward-weight wants dy, so the fixed-order fp64 reduction of the
 // partial tiles divides row o by alpha[o] (a row with alpha = 0 has all-zero codes: it is staged unscaled and divided by 1).
+//   UP 1        (round 6) the block IN FRONT of this one is a BatchNorm+sign block on a pointwise conv as well: this kernel's dx IS that block's d a, so the dx waves
+//               also form the per-channel sums of its BatchNorm backward -- sum dz and sum dz h with dz = dx [hlo <= h <= hhi] from the upstream block's byte stash,
+//               staged through LDS by the producers like the input codes (1 B per element) -- and leave them as the partials k_bns_final_bwd reads: the upstream
+//               block's own pass over (d a, h) (k_bnh_partial: 5 B per element) is not launched (mn_conv2d_bwd_bnh_up / mn_bnh_bwd_sums_final).
 // One barrier per step: barrier k publishes step k (buffer k & 1); the producers refill that buffer with step k + 2 only behind barrier k + 1, which both consumer
 // groups reach after their reads of step k.  What the timeline (PWB_TRACE) and the ablations of round 6 found on the way is in profiles/README.md: the SLP
 // vectoriser drains the producers' software pipeline (this file is built with -fno-slp-vectorize), a memory instruction whose address / data register is rewritten
@@ -31,11 +35,14 @@
 #define PWB_PLANE (128 * 64)
 #define PWB_CODES (128 * 48)
 #define PWB_BUF (3 * PWB_PLANE + PWB_CODES)
+#define PWB_BUF_UP (PWB_BUF + PWB_CODES)                             // + the upstream block's stash bytes, laid out like the input codes
 #define PWB_FROW 12                                                  // floats per row of the fold table
 #define PWB_ERS 68                                                   // floats per staged row of a wave's 64 x 64 partial tile
 #define PWB_LDS_STAGE (2 * PWB_BUF + 128 * PWB_FROW * 4)
 #define PWB_LDS_EPI (4 * 64 * PWB_ERS * 4)
 #define PWB_LDS (PWB_LDS_STAGE > PWB_LDS_EPI ? PWB_LDS_STAGE : PWB_LDS_EPI)
+#define PWB_UTS 36                                                   // floats per row of a dx wave's transposition tile [32 c][32 px] (16-byte aligned rows)
+#define PWB_LDS_UP (2 * PWB_BUF_UP + 128 * PWB_FROW * 4 + 4 * 32 * PWB_UTS * 4)
 
 struct PwbParams {
     const float* gy;            // BNH 1: da [N][O][HW]; 2: the pooled gradient [N][O][H/2][W/2]; 3: dq [N][O][HW]; 0: dy itself
@@ -53,6 +60,9 @@ struct PwbParams {
     float n_f, qs, qinv;        // BNH 3: scale of the quantizer behind the block, RN(1 / qs) (0: IEEE division)
     FastDiv fd_hw, fd_w;
     ChanMap in_map;
+    const unsigned char* up_h;  // UP: the upstream block's byte stash [N][C][HW] (the layout of x)
+    const float* up_chan;       // UP: its [8][C] channel constants (qgemm_sign.hip: T, flip, L, U, A, B, gi, nnz)
+    double* up_part;            // UP: [C][Z][2] partial sums {sum dz, sum dz zhat} of this launch's blocks (k_bns_final_bwd's layout, S = Z)
 };
 
 // 16-byte slot swizzle of a plane row: conflict-free b128 row reads (16 rows of one fragment) AND transpose reads (4 consecutive rows = 256 contiguous bytes)
@@ -65,9 +75,9 @@ __device__ unsigned long long g_pwb_trace[3 * 64 * 8];
 #define PWB_T(role_, t_, k_) do { } while (0)
 #endif
 
-template <int BNH, int XENC, int WIDE>
+template <int BNH, int XENC, int WIDE, int UP = 0>
 __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
-    constexpr int NS = WIDE ? 3 : 4, PLANE = PWB_PLANE, BUF = PWB_BUF;
+    constexpr int NS = WIDE ? 3 : 4, PLANE = PWB_PLANE, BUF = UP ? PWB_BUF_UP : PWB_BUF;
     HIP_DYNAMIC_SHARED(float, smemw)
     unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table [128][PWB_FROW]
     float* ftab = reinterpret_cast<float*>(lds + 2 * BUF);
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
             }
         }
         constexpr int HV = WIDE ? 4 : (BNH == 3 ? 2 : 1), H1 = HV > 1 ? 1 : 0, H2 = HV > 2 ? 2 : 0, H3 = HV > 3 ? 3 : 0;          // stash words per row (H1..: in-range indices)
-        struct Stage { float4 gv[4]; uint32_t hv[4][HV]; u32x4 cv; uint32_t hbit; };
+        struct Stage { float4 gv[4]; uint32_t hv[4][HV]; u32x4 cv; u32x4 uv; uint32_t hbit; };
         auto fetch = [&](Stage& S, int k) {
             // past the block's range: re-read the block's own last step (an L2 hit); loads stay unconditional
             const int kk = k < n ? k : (n > 0 ? n - 1 : 0);
@@ -170,6 +180,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
             const uint32_t Pc = (uint32_t)st * 32u + 16u * chf;
             const uint32_t nc = fd_div(Pc, p.fd_hw);
             S.cv = *reinterpret_cast<const u32x4*>(p.x + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
+            if (UP) S.uv = *reinterpret_cast<const u32x4*>(p.up_h + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
         };
         const uint32_t doff = (uint32_t)sr * 64u + ((((uint32_t)sq >> 1) ^ pwb_sw((uint32_t)sr)) << 4) + (((uint32_t)sq & 1u) << 3);      // rows sr + 32 i share the swizzle
         auto commit = [&](Stage& S, int buf, bool valid) {
@@ -245,6 +256,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                 *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{mn_pack_hi16(r2[0], r2[1]), mn_pack_hi16(r2[2], r2[3])};
             }
             *reinterpret_cast<u32x4*>(A + 3 * PLANE + cr * 48 + 16 * chf) = S.cv;
+            if (UP) *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * 48 + 16 * chf) = S.uv;
         };
         Stage st[NS];
 #pragma unroll
@@ -344,16 +356,38 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             wf[ks] = *reinterpret_cast<const u32x4*>(p.wc + ((int64_t)(g * 128 + 32 * wave + m) * 128 + 16 * ks + 8 * kgrp));
-        uint32_t ooff[16];                 // BYTE offset of accumulator register r = row (r & 3) + 8 (r >> 2) + 4 kgrp of the wave's 32, column m (plan: 4 N C HW < 2^32)
+        // BYTE offset of accumulator register r = row (r & 3) + 8 (r >> 2) + 4 kgrp of the wave's 32, column m (plan: 4 N C HW < 2^32), split into a UNIFORM part per
+        // register (scalar registers: the row of kgrp 0) and ONE lane part (kgrp, m): the channel shuffle is separable over these rows because the shuffle groups
+        // divide 32 (plan_pwb) -- phys(c0 + d + 4 k) = phys(c0 + d) + phys(c0 + 4 k) - phys(c0).  (Round 6: sixteen per-lane offsets cost 16-32 VGPRs.)
+        const int wvu = mn_uniform(wave);
+        uint32_t urow[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            ooff[r] = ((uint32_t)chan_phys(p.in_map, g * 128 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kgrp) * HW + (uint32_t)m) * 4u;
+        for (int r = 0; r < 16; ++r) urow[r] = (uint32_t)chan_phys(p.in_map, g * 128 + 32 * wvu + (r & 3) + 8 * (r >> 2)) * HW * 4u;
+        const uint32_t vlane = (kgrp ? (uint32_t)(chan_phys(p.in_map, g * 128 + 32 * wvu + 4) - chan_phys(p.in_map, g * 128 + 32 * wvu)) * HW * 4u : 0u) + (uint32_t)m * 4u;
         uint32_t toff[2];                  // transpose reads r2 = 0, 1 of a K-step: plane rows 16 ks + 8 kgrp + 4 r2 + (i16 >> 2), pixels 16 nhalf + 4 (i16 & 3) ..
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
             const uint32_t row = (uint32_t)(8 * kgrp + 4 * r2 + (i16 >> 2));
             const uint32_t slot = (uint32_t)(2 * nhalf + ((i16 & 3) >> 1));
             toff[r2] = row * 64u + ((slot ^ pwb_sw(row)) << 4) + (((uint32_t)i16 & 1u) << 3);
+        }
+        // UP: the dx tile of a step goes through a private LDS tile [32 c][36] per wave and comes back TRANSPOSED -- lane = one channel (lane & 31) x one half of the
+        // step's 32 pixels -- so that the sums of the upstream BatchNorm backward are TWO registers per lane (per-register accumulators for the 16 channels of the
+        // MFMA layout: 32 + 16 VGPRs, the weight fragments spilled).  ulo / usp: the channel's mask interval [hlo, hhi] as (lo, hi - lo); an empty interval is (255, 0):
+        // the stash of a conv with K <= 254 never reaches 255 (host check).
+        uint32_t ulo = 255u, usp = 0u;
+        float us1 = 0.f, ush = 0.f, unnz = 0.f;          // ush: sum dz (2 h - nnz) -- the integer the stash stands for, not h itself (2 h and nnz cancel)
+        float* UT = reinterpret_cast<float*>(lds + 2 * BUF + 128 * PWB_FROW * 4) + wave * (32 * PWB_UTS);
+        if (UP) {
+            const int ch = chan_phys(p.in_map, g * 128 + 32 * wave + (lane & 31)), Cu = p.C;
+            const float fl = p.up_chan[Cu + ch], L = p.up_chan[2 * Cu + ch], U = p.up_chan[3 * Cu + ch], nnz = p.up_chan[7 * Cu + ch];
+            float hlo, hhi;
+            if (fl > 0.f) { hlo = ceilf((L + nnz) * 0.5f); hhi = floorf((U + nnz) * 0.5f); }
+            else { hlo = ceilf((nnz - U) * 0.5f); hhi = floorf((nnz - L) * 0.5f); }
+            const bool ok = hlo <= hhi && hhi >= 0.f && hlo <= 254.f;          // (NaN constants: nothing passes, as in the streaming kernels)
+            ulo = ok ? (uint32_t)fmaxf(hlo, 0.f) : 255u;
+            usp = ok ? (uint32_t)fminf(hhi, 254.f) - ulo : 0u;
+            unnz = nnz;
         }
         __syncthreads();
         for (int t = 0; t < nit; ++t) {
@@ -394,16 +428,49 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                 // rewritten for the next one waits until the memory pipeline has read it (measured: ~150 cycles per store, half of the step)
                 char* dst = reinterpret_cast<char*>(p.dx + (ni * (uint32_t)p.C * HW + (P - ni * HW)));
                 float outv[16];
-                uint32_t oo[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { outv[r] = a0[r] + a1[r]; oo[r] = mn_opaque(ooff[r]); }          // (opaque: the zero-extension stays in this block -> saddr form)
+                for (int r = 0; r < 16; ++r) outv[r] = a0[r] + a1[r];
+                const uint32_t vv = mn_opaque(vlane);          // (opaque: the zero-extension stays in this block -> saddr form, base = dst + urow[r] in scalar registers)
                 MN_SCHED_FENCE();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mn_store_nt(reinterpret_cast<float*>(dst + oo[r]), outv[r]);          // streaming: L5 95 -> 81 us, L6 90 -> 84, L2 / L3 / L8 unchanged
+                for (int r = 0; r < 16; ++r) mn_store_nt(reinterpret_cast<float*>((dst + urow[r]) + vv), outv[r]);          // streaming: L5 95 -> 81 us, L6 90 -> 84, L2 / L3 / L8 unchanged
+                if (UP) {          // (behind the stores: the MFMA operands' registers are free; this step's buffer stays valid until the next barrier)
+                    MN_WAVE_SYNC();          // (emulation: the previous step's transposed reads are done)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) UT[((r & 3) + 8 * (r >> 2) + 4 * kgrp) * PWB_UTS + m] = outv[r];
+                    MN_WAVE_SYNC();
+                    const int cl = lane & 31, phx = lane >> 5;
+                    const u32x4 hq = *reinterpret_cast<const u32x4*>(A + 3 * PLANE + PWB_CODES + (32 * wave + cl) * 48 + 16 * phx);
+                    float4 dq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dq[q] = *reinterpret_cast<const float4*>(UT + cl * PWB_UTS + 16 * phx + 4 * q);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dv[4] = {dq[q].x, dq[q].y, dq[q].z, dq[q].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t hb = (hq[q] >> (8 * e)) & 0xffu;
+                            const float dz = (hb - ulo) <= usp ? dv[e] : 0.f;
+                            us1 += dz;
+                            ush += dz * (2.f * (float)hb - unnz);
+                        }
+                    }
+                }
                 PWB_T(2, t, 2);
             }
         }
         __syncthreads();
+        if (UP) {
+            us1 += __shfl_xor(us1, 32, 64); ush += __shfl_xor(ush, 32, 64);          // the two pixel halves of the channel
+            if (lane < 32) {
+                const int ch = chan_phys(p.in_map, g * 128 + 32 * wave + lane), Cu = p.C;
+                const double A_ = (double)p.up_chan[4 * Cu + ch], B_ = (double)p.up_chan[5 * Cu + ch];
+                const double d1 = (double)us1, da_ = (double)ush;
+                double* dstp = p.up_part + ((int64_t)ch * p.Z + z) * 2;
+                dstp[0] = d1;
+                dstp[1] = A_ * da_ + B_ * d1;          // zhat = A (2 h - nnz) + B
+            }
+        }
     }
 }
 
@@ -419,7 +486,7 @@ static int plan_pwb(const mn_conv_geom* g, PwbPlan* pl) {
     const int64_t HW = g->H * g->W, NP = (int64_t)g->N * HW;
     if (HW % 32 || NP <= 0) return 0;
     if (4 * NP * g->C >= ((int64_t)1 << 32)) return 0;                     // 32-bit byte offsets
-    if (g->in_shuffle > 1 && g->C % g->in_shuffle) return 0;
+    if (g->in_shuffle > 1 && (g->C % g->in_shuffle || 32 % g->in_shuffle)) return 0;          // (the dx rows' shuffle must be separable over a wave's 32 channels)
     if (!pwd_pack_plan(g, &pl->pk, &pl->pack_grid, &pl->off_scale, &pl->pack_bytes)) return 0;
     if (pl->pk.Cpad != 128 || pl->pk.Mgp != 128) return 0;
     PwbParams& p = pl->p;
@@ -449,10 +516,11 @@ int pwb_supported(const mn_conv_geom* g, const mn_wq* wq, int pooled) {
 }
 int64_t pwb_ws_bytes(const mn_conv_geom* g) { PwbPlan pl; return plan_pwb(g, &pl) ? pl.ws_bytes : 0; }
 
-template <int BNH, int XENC, int WIDE>
+template <int BNH, int XENC, int WIDE, int UP = 0>
 static void pwb_launch(const PwbPlan& pl, hipStream_t s) {
-    raise_lds_limit((const void*)k_pwb<BNH, XENC, WIDE>, PWB_LDS);
-    hipLaunchKernelGGL((k_pwb<BNH, XENC, WIDE>), dim3(pl.grid), dim3(768), PWB_LDS, s, pl.p);
+    constexpr size_t lds = UP ? (PWB_LDS_UP > PWB_LDS ? PWB_LDS_UP : PWB_LDS) : PWB_LDS;
+    raise_lds_limit((const void*)k_pwb<BNH, XENC, WIDE, UP>, lds);
+    hipLaunchKernelGGL((k_pwb<BNH, XENC, WIDE, UP>), dim3(pl.grid), dim3(768), lds, s, pl.p);
 }
 #ifdef PWB_TRACE
 static void pwb_trace_dump(hipStream_t s) {
@@ -470,9 +538,10 @@ static void pwb_trace_dump(hipStream_t s) {
 }
 #endif
 // mode: 1 wbwtab (h = byte stash; own != NULL: pooled), 3 DoReFa fold (h = 16 / 32-bit stash), 0 plain dy; xenc: 0 sign codes, 1 k-bit codes (dW times ascale)
+struct PwbUp { const uint8_t* h; const float* chan; double* part; };          // the upstream block's stash, [8][C] constants, partials [C][Z][2] (UP variants)
 static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv_geom* g, const mn_wq* wq, const float* gy, const void* h, const int8_t* own,
                    const float* chan, const float* sums, int training, int quant, float qs, float ascale, const float* w, const void* x, float* dx, float* dw,
-                   float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
+                   float* dbias, void* ws, int64_t ws_bytes, hipStream_t s, const PwbUp* up = nullptr) {
     PwbPlan pl;
     if (!wq_codeable(wq) || !plan_pwb(g, &pl) || (own && ((g->H & 1) || (g->W & 3)))) MN_FAIL(MN_ENOTSUP, "%s: geometry / quantizer combination not covered", what);
     if (!aligned16(dx) || !aligned16(dw) || (((uintptr_t)x) & 15) || (h && (((uintptr_t)h) & 15)) || (own ? ((((uintptr_t)gy) & 7) || (((uintptr_t)own) & 3)) : !aligned16(gy)))
@@ -491,14 +560,22 @@ static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv
     p.part = (float*)((char*)ws + pl.off_part); p.dbpart = (float*)((char*)ws + pl.off_db);
     p.want_db = dbias != nullptr; p.training = training;
     p.quant = quant; p.qs = qs; p.qinv = mn_qa_inv(qs);
+    p.up_h = up ? up->h : nullptr; p.up_chan = up ? up->chan : nullptr; p.up_part = up ? up->part : nullptr;
     const int bnh = mode == 1 ? (own ? 2 : 1) : mode;
+    if (up) {
+        if (mode != 1 || xenc || wide) MN_FAIL(MN_ENOTSUP, "%s: the upstream sums ride only on the wbwtab variants", what);
+        if (!up->h || !up->chan || !up->part || (((uintptr_t)up->h) & 15) || (((uintptr_t)up->part) & 7)) MN_FAIL(MN_EINVAL, "%s: null / misaligned upstream operand", what);
+        mn_set_last_kernel("k_pwb<%d, %d, %d, 1>", bnh, xenc, wide);
+    } else
     mn_set_last_kernel("k_pwb<%d, %d, %d>", bnh, xenc, wide);
     {
         const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
-        mn_prof_bytes((mode == 1 ? (own ? 3.0 : 5.0) : (mode == 3 ? (wide ? 8.0 : 6.0) : 4.0)) * ny + 5.0 * nx);
+        mn_prof_bytes((mode == 1 ? (own ? 3.0 : 5.0) : (mode == 3 ? (wide ? 8.0 : 6.0) : 4.0)) * ny + (up ? 6.0 : 5.0) * nx);
     }
     mn_prof_begin(s);
-    if (bnh == 1 && !xenc) pwb_launch<1, 0, 0>(pl, s);
+    if (up && bnh == 1) pwb_launch<1, 0, 0, 1>(pl, s);
+    else if (up && bnh == 2) pwb_launch<2, 0, 0, 1>(pl, s);
+    else if (bnh == 1 && !xenc) pwb_launch<1, 0, 0>(pl, s);
     else if (bnh == 2 && !xenc) pwb_launch<2, 0, 0>(pl, s);
     else if (bnh == 0 && !xenc) pwb_launch<0, 0, 0>(pl, s);
     else if (bnh == 0) pwb_launch<0, 1, 0>(pl, s);
@@ -516,6 +593,14 @@ static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv
 int pwb_bwd_bnh(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
                 const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t s) {
     return pwb_run("mn_conv2d_bwd_bnh", 1, 0, 0, g, wq, da, h, own, chan, sums, training, 0, 1.f, 1.f, w, x, dx, dw, dbias, ws, ws_bytes, s);
+}
+// ... with the BatchNorm-backward sums of the block in front (UP): *splits = the number of partials per channel the launch leaves in up_part ([C][splits][2] doubles)
+int pwb_up_splits(const mn_conv_geom* g) { PwbPlan pl; return plan_pwb(g, &pl) ? pl.p.Z : 0; }
+int pwb_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
+                   const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const uint8_t* up_h, const float* up_chan,
+                   double* up_part, hipStream_t s) {
+    const PwbUp up{up_h, up_chan, up_part};
+    return pwb_run("mn_conv2d_bwd_bnh_up", 1, 0, 0, g, wq, da, h, own, chan, sums, training, 0, 1.f, 1.f, w, x, dx, dw, dbias, ws, ws_bytes, s, &up);
 }
 // plain gradient: x_bits == 0: sign codes, else k-bit activation codes of that width
 int pwb_bwd_plain(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x, int x_bits, float* dx, float* dw, float* dbias, void* ws,

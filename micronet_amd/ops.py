@@ -1937,6 +1937,21 @@ def _ref(d):
     return None if d is None else C.byref(d)
 
 
+class UpSums:
+    """Hand-over between two consecutive BatchNorm+sign blocks on pointwise convs (round 6): block k leaves its byte stash ``h`` and channel constants ``chan`` on its
+    output SignTensor; the ONE-launch backward of block k + 1 (k_pwb) -- whose dx IS block k's d a -- also accumulates the per-channel sums of block k's BatchNorm
+    backward into ``ready = (dx, version, partials, splits)``; block k's backward recognises its incoming gradient as exactly that tensor (same storage, shape,
+    version: autograd hands a single contribution through untouched) and only finishes the partials (mn_bnh_bwd_sums_final) instead of a pass over (d a, h).  Any other
+    path (a second consumer, a hook, a pooled gradient) fails the identity test and takes the ordinary pass: always correct, one streaming pass slower."""
+    __slots__ = ("h", "chan", "k", "ready")
+
+    def __init__(self, h, chan, k):
+        self.h, self.chan, self.k, self.ready = h, chan, int(k), None
+
+
+UP_SUMS_FOLD = _os0.environ.get("MN_UP_SUMS", "1") != "0"          # (A/B and the equality test: MN_UP_SUMS=0 restores k_bnh_partial for every block)
+
+
 class QConv2d(Function):
     """y = conv2d(actq(x), wq, bias): the activation quantizer runs inside the conv kernels' prologue, its clip-STE in the
     backward-data epilogue; ``wq`` is the already fake-quantised weight (its own Function supplies d wq / d w);
@@ -2045,9 +2060,20 @@ class QConv2d(Function):
                     db = torch.empty(g.O, dtype=torch.float32, device=x.device) if has_bias else None
                     nb = int(_lib_().mn_conv2d_bwd_bnh_ws_bytes(C.byref(g)))
                     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=x.device)
-                    with _span(g, 1, (3 if pool else 5) * r["h"].numel() + 5 * dx.numel()):
-                        _call("mn_conv2d_bwd_bnh", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["own"]) if pool else None, _p(r["chan"]), _p(r["sums"]),
-                              r["training"], _p(wq), _p(x), _p(dx), _p(dw), _p(db), _p(ws), nb, _s())
+                    up = getattr(ctx, "up_rec", None)
+                    splits = 0
+                    if up is not None and UP_SUMS_FOLD and tuple(up.h.shape) == tuple(x.shape) and up.h.data_ptr() % 16 == 0 and up.chan.shape[0] == 8:
+                        splits = int(_lib_().mn_conv2d_bwd_bnh_up_splits(C.byref(g), _ref(wd), 1 if pool else 0, up.k))
+                    if splits > 0:          # ... and the sums of the BatchNorm backward of the block in front (this dx is its d a)
+                        part = torch.empty(x.shape[1] * splits * 2, dtype=torch.float64, device=x.device)
+                        with _span(g, 1, (3 if pool else 5) * r["h"].numel() + 6 * dx.numel()):
+                            _call("mn_conv2d_bwd_bnh_up", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["own"]) if pool else None, _p(r["chan"]), _p(r["sums"]),
+                                  r["training"], _p(wq), _p(x), _p(dx), _p(dw), _p(db), _p(ws), nb, _p(up.h), _p(up.chan), _p(part), _s())
+                        up.ready = (dx, dx._version, part, splits)
+                    else:
+                        with _span(g, 1, (3 if pool else 5) * r["h"].numel() + 5 * dx.numel()):
+                            _call("mn_conv2d_bwd_bnh", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["own"]) if pool else None, _p(r["chan"]), _p(r["sums"]),
+                                  r["training"], _p(wq), _p(x), _p(dx), _p(dw), _p(db), _p(ws), nb, _s())
                 return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
             with torch.cuda.device_of(x):
                 if ctx.needs_input_grad[0]:
@@ -2153,6 +2179,7 @@ class QConv2dLazy(Function):
         ctx.save_for_backward(codes, wq, None, wscale)
         ctx.cfg = (g, ACTQ_SIGN8, 8, 0, bias is not None, wdesc[:4] if wdesc is not None else None, 0)
         ctx.packed = packed = getattr(wq, "_mn_packed", None)          # (the step's pre-packed code images: pack_pointwise_weights)
+        ctx.up_rec = getattr(x, "_mn_up", None)          # the BatchNorm+sign block that produced x (UpSums)
 
         def compute():
             y = torch.empty((g.N, g.O, Ho, Wo), dtype=torch.float32, device=codes.device)
@@ -2214,7 +2241,11 @@ class ConvBNSign(Function):
         ctx.training = int(training)
         ctx.fold_ok = FOLD_BN_INTO_CONV_BWD and bool(_lib_().mn_conv2d_bnh_supported(C.byref(g), _ref(wd)))     # the conv's own backward can form dy from (da, h)
         ctx.fold_pool_ok = FOLD_POOL_INTO_CONV_BWD and ctx.fold_ok and bool(_lib_().mn_conv2d_bnh_pool_supported(C.byref(g), _ref(wd)))      # ... and from the POOLED gradient
-        return SignTensor(a)
+        out = SignTensor(a)
+        ctx.up_rec = None
+        if chan.shape[0] == 8 and UP_SUMS_FOLD:          # (pointwise block: one nnz per channel) -- the next block's backward may form this block's sums (UpSums)
+            ctx.up_rec = out._mn_up = UpSums(h, chan, wq.shape[1] * wq.shape[2] * wq.shape[3])
+        return out
 
     @staticmethod
     def backward(ctx, da):
@@ -2229,8 +2260,17 @@ class ConvBNSign(Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         sums = torch.empty((2, Cc), dtype=torch.float32, device=h.device)
         ws = torch.empty(int(_lib_().mn_bnsign_ws_floats(Cc)), dtype=torch.float32, device=h.device)
+        rec = getattr(ctx, "up_rec", None)
+        ready = None
+        if rec is not None:
+            ready, rec.ready = rec.ready, None
         with torch.cuda.device_of(h):
-            _call("mn_bnh_bwd_sums", _p(grad), _p(h), _p(own), _p(chan), N, Cc, H, W, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+            if ready is not None and not pooled and type(da) is torch.Tensor and da.data_ptr() == ready[0].data_ptr() and tuple(da.shape) == tuple(ready[0].shape) and \
+                    da._version == ready[1] and da.is_contiguous():
+                # the producer of d a (the next block's one-launch backward) already summed dz and dz zhat per channel: only the fixed-order finish is left
+                _call("mn_bnh_bwd_sums_final", _p(ready[2]), ready[3], N, Cc, H, W, _p(dgamma), _p(dbeta), _p(sums), _s())
+            else:
+                _call("mn_bnh_bwd_sums", _p(grad), _p(h), _p(own), _p(chan), N, Cc, H, W, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
             if pooled and getattr(ctx, "fold_pool_ok", False) and LAZY_BN_GRAD:
                 # a 2x2 max-pool behind the block: the conv's backward-data / backward-weight route the pooled gradient to each window's first +1 and apply the
                 # BatchNorm+sign backward while (dpool, own codes, h) stream in -- the full-size dy (4 B per element written, then read twice) never exists

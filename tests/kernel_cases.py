@@ -509,6 +509,49 @@ def _check_pwb(be, g, wq, d_da, h8, a8, chan, sums, training, dW, dA, dx_ref, dw
         assert close(be.to_host(dw3), dw_ref, 5e-6), ("k_pwb dw", np.max(np.abs(be.to_host(dw3) - dw_ref)) / np.max(np.abs(dw_ref)))
         if with_bias:
             assert np.max(np.abs(be.to_host(db3) - db_ref)) <= db_tol, "k_pwb dbias"
+    # ... with the BatchNorm-backward sums of an upstream BatchNorm+sign block as a by-product (mn_conv2d_bwd_bnh_up): dx / dw bit-identical to the plain launch, the
+    # finished sums equal to mn_bnh_bwd_sums on (dx, upstream stash) up to the summation order
+    N_, Cin, H_, W_ = x_shape
+    K_up = 128
+    splits = int(be.lib.mn_conv2d_bwd_bnh_up_splits(C.byref(g), C.byref(wq), 1 if a8 is not None else 0, K_up))
+    assert splits > 0 and int(be.lib.mn_conv2d_bwd_bnh_up_splits(C.byref(g), C.byref(wq), 1 if a8 is not None else 0, 255)) == 0
+    r = np.random.default_rng(1234 + Cin + N_)
+    nnz = r.integers(K_up // 2, K_up + 1, Cin).astype(F)
+    up_h = np.floor(r.random(x_shape) * (nnz.reshape(1, -1, 1, 1) + 1)).astype(np.uint8)
+    flip = np.where(r.random(Cin) < 0.5, -1.0, 1.0).astype(F)
+    Lc, Uc = -np.floor(r.random(Cin) * 40).astype(F), np.floor(r.random(Cin) * 40).astype(F)
+    Lc[1], Uc[1] = 5.0, -5.0                      # an empty interval
+    Lc[2], Uc[2] = -1e9, 1e9                      # everything passes
+    Lc[3] = np.nan                                # a poisoned channel: nothing passes
+    Lc[4], Uc[4] = 300.0, 400.0                   # beyond every admissible value
+    up_chan = np.stack([np.zeros(Cin, F), flip, Lc, Uc, (r.standard_normal(Cin) * 0.05).astype(F), (r.standard_normal(Cin) * 0.3).astype(F), np.ones(Cin, F), nnz]).astype(F)
+    d_uh, d_uc = be.to_dev_u8(up_h), be.to_dev(up_chan)
+    ws, dx4, dw4, db4 = be.empty(nb // 4 + 4), be.empty(x_shape), be.empty(w_shape), be.empty(Oc)
+    part = be.empty(Cin * splits * 4 + 2)          # [C][splits][2] doubles
+    be.call("mn_conv2d_bwd_bnh_up", C.byref(g), C.byref(wq), be.ptr(d_da), be.ptr(h8), be.ptr(a8) if a8 is not None else None, be.ptr(chan), be.ptr(sums),
+            int(training), be.ptr(dW), be.ptr(dA), be.ptr(dx4), be.ptr(dw4), be.ptr(db4), be.ptr(ws), nb, be.ptr(d_uh), be.ptr(d_uc), be.ptr(part), be.stream)
+    assert be.lib.mn_last_kernel().decode() == ("k_pwb<2, 0, 0, 1>" if a8 is not None else "k_pwb<1, 0, 0, 1>")
+    assert np.array_equal(be.to_host(dx4), be.to_host(dx3)) and np.array_equal(be.to_host(dw4), be.to_host(dw3))
+    s_up, dg_up, db_up = be.empty((2, Cin)), be.empty(Cin), be.empty(Cin)
+    be.call("mn_bnh_bwd_sums_final", be.ptr(part), splits, N_, Cin, H_, W_, be.ptr(dg_up), be.ptr(db_up), be.ptr(s_up), be.stream)
+    s_ref, dg_ref, db_ref2 = be.empty((2, Cin)), be.empty(Cin), be.empty(Cin)
+    ws2 = be.empty(int(be.lib.mn_bnsign_ws_floats(Cin)) + 2)
+    be.call("mn_bnh_bwd_sums", be.ptr(dx4), be.ptr(d_uh), None, be.ptr(d_uc), N_, Cin, H_, W_, be.ptr(dg_ref), be.ptr(db_ref2), be.ptr(s_ref), be.ptr(ws2), be.stream)
+    got, ref = be.to_host(s_up).astype(np.float64), be.to_host(s_ref).astype(np.float64)
+    # the sums cancel: judge against the sum of magnitudes (an fp64 evaluation from the same dx)
+    dxh = be.to_host(dx4).astype(np.float64)
+    acc = 2.0 * up_h.astype(np.float64) - nnz.reshape(1, -1, 1, 1)
+    u = acc * flip.reshape(1, -1, 1, 1)
+    with np.errstate(invalid="ignore"):
+        mask = (u >= Lc.reshape(1, -1, 1, 1)) & (u <= Uc.reshape(1, -1, 1, 1))
+    dz = np.where(mask, dxh, 0.0)
+    zh = acc * up_chan[4].astype(np.float64).reshape(1, -1, 1, 1) + up_chan[5].astype(np.float64).reshape(1, -1, 1, 1)
+    e1, e2 = dz.sum(axis=(0, 2, 3)), (dz * zh).sum(axis=(0, 2, 3))
+    m1, m2 = np.abs(dz).sum(axis=(0, 2, 3)) + 1e-30, np.abs(dz * zh).sum(axis=(0, 2, 3)) + 1e-30
+    assert np.max(np.abs(got[0] - e1) / m1) <= 2e-6 and np.max(np.abs(got[1] - e2) / m2) <= 2e-6, ("k_pwb upstream sums", np.max(np.abs(got[0] - e1) / m1), np.max(np.abs(got[1] - e2) / m2))
+    assert np.max(np.abs(ref[0] - e1) / m1) <= 2e-6 and np.max(np.abs(ref[1] - e2) / m2) <= 2e-6
+    assert np.all(got[:, 1] == 0) and np.all(got[:, 3] == 0) and np.all(got[:, 4] == 0)
+    assert np.array_equal(be.to_host(dg_up), be.to_host(s_up)[1]) and np.array_equal(be.to_host(db_up), be.to_host(s_up)[0])
     _check_pwb.count = getattr(_check_pwb, "count", 0) + 1
 
 
