@@ -578,6 +578,7 @@ int mn_conv2d_bwd_bnh_up_splits(const mn_conv_geom* g, const mn_wq* wq, int pool
 int mn_conv2d_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
                          int training, const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                          const uint8_t* up_h, const float* up_chan, double* up_part, mn_stream_t stream);
+/* (the k-bit counterparts of the *_up call: mn_conv2d_bwd_codes_up / mn_conv2d_bwd_qa_up below) */
 /* The same one-launch backward for the k-bit (DoReFa) blocks, wqaq/dorefa/quantize.py:36-46, 107-122 + autograd's conv backward (same geometry, same two queries
  * with pooled = 0, same workspace):
  *   mn_conv2d_bwd_codes: dx (NO clip-STE: the producing block applies it where it recomputes the activation) and dw = s_x * sum gy * j, dbias from a plain fp32
@@ -590,6 +591,16 @@ int mn_conv2d_bwd_codes(const mn_conv_geom* g, const mn_wq* wq, const float* gy,
 int mn_conv2d_bwd_qa(const mn_conv_geom* g, const mn_wq* wq, const float* dq, const void* stash, int stash_bits, const float* chan, const float* sums, int out_bits,
                      int quant, int training, const float* w, const uint8_t* x_codes, int x_bits, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                      mn_stream_t stream);
+/* ... with the sums of the BatchNorm backward of the k-bit block IN FRONT as a by-product (round 6; the k-bit counterpart of mn_conv2d_bwd_bnh_up): this dx is that
+ * block's d q, so the launch also accumulates sum dz and sum dz zhat per input channel -- dz = clip-STE(dx) under the ReLU / clamp masks of the upstream block's 16-bit
+ * stash up_stash [N][C][H][W] (up_chan = its [9][C] constants, up_quant: dx is w.r.t. its x_bits-quantised output), mn_qa_bwd_sums' arithmetic element by element --
+ * into up_part [C][splits][2] doubles (splits: mn_conv2d_bwd_bnh_up_splits(g, wq, 0, 1)); the upstream block then calls mn_qa_bwd_sums_final instead of
+ * mn_qa_bwd_sums (no pass over (dq, stash)).  16-bit stashes on both sides (stash_bits == 16). */
+int mn_conv2d_bwd_codes_up(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x_codes, int x_bits, float* dx, float* dw, float* dbias,
+                           void* ws, int64_t ws_bytes, const void* up_stash, const float* up_chan, int up_quant, double* up_part, mn_stream_t stream);
+int mn_conv2d_bwd_qa_up(const mn_conv_geom* g, const mn_wq* wq, const float* dq, const void* stash, const float* chan, const float* sums, int out_bits, int quant,
+                        int training, const float* w, const uint8_t* x_codes, int x_bits, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
+                        const void* up_stash, const float* up_chan, int up_quant, double* up_part, mn_stream_t stream);
 /* same backward when a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119) sits behind the block: `dpool` = d loss / d pool(a),
  * [N][O][H/2][W/2] fp32, `a_own` = the block's own output codes (what mn_qconv_bnsign_fwd wrote); the pool's backward (gradient to
  * the first maximum of each window) is applied while the gradient is read -- a quarter of the bytes, no full-size da tensor. */
@@ -650,6 +661,8 @@ int mn_qa_fwd(int in_f32, const void* in, const float* chan, int64_t N, int64_t 
               mn_stream_t stream);
 int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits, int pool, int quant,
                    float* dgamma, float* dbeta, float* sums, float* ws, mn_stream_t stream);
+/* its finish alone, on partial sums part [C][splits][2] (doubles) the producer of dq left (mn_conv2d_bwd_qa_up / mn_conv2d_bwd_codes_up) */
+int mn_qa_bwd_sums_final(const double* part, int32_t splits, int64_t C, float* dgamma, float* dbeta, float* sums, mn_stream_t stream);
 int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, const float* sums, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits,
                     int pool, int quant, int training, float* dy, mn_stream_t stream);
 /* the two calls above as TWO launches instead of three: the apply pass sums the partial rows itself (same order: bit-identical statistics) and writes dgamma, dbeta, sums */

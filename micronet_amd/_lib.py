@@ -126,6 +126,9 @@ PROTOTYPES = {
     "mn_bnh_bwd_sums_final": (_I, [_P, _I, _L, _L, _L, _L, _P, _P, _P, _P]),
     "mn_conv2d_bwd_codes": (_I, [_G, _W, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_conv2d_bwd_qa": (_I, [_G, _W, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    "mn_conv2d_bwd_codes_up": (_I, [_G, _W, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P, _I, _P, _P]),
+    "mn_conv2d_bwd_qa_up": (_I, [_G, _W, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P, _I, _P, _P]),
+    "mn_qa_bwd_sums_final": (_I, [_P, _I, _L, _P, _P, _P, _P]),
     "mn_conv2d_bnh_pool_supported": (_I, [_G, _W]),
     "mn_conv2d_bwd_data_bnh_pool": (_I, [_G, _W, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
     "mn_conv2d_bwd_weight_bnh_pool": (_I, [_G, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),

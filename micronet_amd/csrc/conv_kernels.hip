@@ -890,6 +890,23 @@ extern "C" int mn_conv2d_bwd_qa(const mn_conv_geom* g, const mn_wq* wq, const fl
     if (!wq || !dq || !stash || !chan || !sums || !w || !x_codes || !dx || !dw) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_qa: null tensor");
     return pwb_bwd_qa(g, wq, dq, stash, stash_bits, chan, sums, out_bits, quant, training, w, x_codes, x_bits, dx, dw, dbias, ws, ws_bytes, (hipStream_t)stream);
 }
+extern "C" int mn_conv2d_bwd_codes_up(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x_codes, int x_bits, float* dx, float* dw,
+                                      float* dbias, void* ws, int64_t ws_bytes, const void* up_stash, const float* up_chan, int up_quant, double* up_part,
+                                      mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_codes_up");
+    if (rc) return rc;
+    if (!wq || !gy || !w || !x_codes || !dx || !dw || !up_stash || !up_chan || !up_part) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_codes_up: null tensor");
+    return pwb_bwd_plain_up(g, wq, gy, w, x_codes, x_bits, dx, dw, dbias, ws, ws_bytes, up_stash, up_chan, up_quant, up_part, (hipStream_t)stream);
+}
+extern "C" int mn_conv2d_bwd_qa_up(const mn_conv_geom* g, const mn_wq* wq, const float* dq, const void* stash, const float* chan, const float* sums, int out_bits,
+                                   int quant, int training, const float* w, const uint8_t* x_codes, int x_bits, float* dx, float* dw, float* dbias, void* ws,
+                                   int64_t ws_bytes, const void* up_stash, const float* up_chan, int up_quant, double* up_part, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_qa_up");
+    if (rc) return rc;
+    if (!wq || !dq || !stash || !chan || !sums || !w || !x_codes || !dx || !dw || !up_stash || !up_chan || !up_part) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_qa_up: null tensor");
+    return pwb_bwd_qa_up(g, wq, dq, stash, chan, sums, out_bits, quant, training, w, x_codes, x_bits, dx, dw, dbias, ws, ws_bytes, up_stash, up_chan, up_quant, up_part,
+                         (hipStream_t)stream);
+}
 extern "C" int mn_conv2d_bwd_weight_first_bn(const mn_conv_geom* g, const float* da, const float* y, const float* save, const float* gamma, const float* beta,
                                              const float* sums, int training, const float* x, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                                              mn_stream_t stream) {

@@ -558,6 +558,13 @@ extern "C" int mn_qa_bwd_sums(int in_f32, const void* in, const float* chan, con
     MN_CHECK_LAUNCH("mn_qa_bwd_sums");
     return MN_OK;
 }
+/* the finish of mn_qa_bwd_sums alone, on partial sums [C][splits][2] (doubles) the producer of dq left (mn_conv2d_bwd_qa_up / mn_conv2d_bwd_codes_up) */
+extern "C" int mn_qa_bwd_sums_final(const double* part, int32_t splits, int64_t C, float* dgamma, float* dbeta, float* sums, mn_stream_t stream) {
+    if (!part || !sums || splits < 1 || C <= 0 || (((uintptr_t)part) & 7)) MN_FAIL(MN_EINVAL, "mn_qa_bwd_sums_final: bad arguments");
+    hipLaunchKernelGGL(k_qa_final_bwd, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (int)C, part, (int)splits, dgamma, dbeta, sums);
+    MN_CHECK_LAUNCH("mn_qa_bwd_sums_final");
+    return MN_OK;
+}
 extern "C" int mn_qa_bwd_apply(int in_f32, const void* in, const float* chan, const float* sums, const float* dq, int64_t N, int64_t C, int64_t H, int64_t W, int a_bits,
                                int pool, int quant, int training, float* dy, mn_stream_t stream) {
     QaGeom g;

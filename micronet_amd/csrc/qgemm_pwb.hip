@@ -22,6 +22,8 @@
 //               also form the per-channel sums of its BatchNorm backward -- sum dz and sum dz h with dz = dx [hlo <= h <= hhi] from the upstream block's byte stash,
 //               staged through LDS by the producers like the input codes (1 B per element) -- and leave them as the partials k_bns_final_bwd reads: the upstream
 //               block's own pass over (d a, h) (k_bnh_partial: 5 B per element) is not launched (mn_conv2d_bwd_bnh_up / mn_bnh_bwd_sums_final).
+//   UP 2        the same for a k-bit (DoReFa) block in front: this dx is its d q; dz = clip-STE(dx) [ReLU / clamp masks of the upstream 16-bit stash, k_qa_partial's
+//               arithmetic] -- sum dz, sum dz zhat; k_qa_partial (6 B per element) is not launched (mn_conv2d_bwd_qa_up / mn_conv2d_bwd_codes_up / mn_qa_bwd_sums_final).
 // One barrier per step: barrier k publishes step k (buffer k & 1); the producers refill that buffer with step k + 2 only behind barrier k + 1, which both consumer
 // groups reach after their reads of step k.  What the timeline (PWB_TRACE) and the ablations of round 6 found on the way is in profiles/README.md: the SLP
 // vectoriser drains the producers' software pipeline (this file is built with -fno-slp-vectorize), a memory instruction whose address / data register is rewritten
@@ -36,6 +38,8 @@
 #define PWB_CODES (128 * 48)
 #define PWB_BUF (3 * PWB_PLANE + PWB_CODES)
 #define PWB_BUF_UP (PWB_BUF + PWB_CODES)                             // + the upstream block's stash bytes, laid out like the input codes
+#define PWB_UP2_ROW 80                                               // UP 2: bytes per row of the staged 16-bit upstream stash [128 c][32 px]
+#define PWB_BUF_UP2 (PWB_BUF + 128 * PWB_UP2_ROW)
 #define PWB_FROW 12                                                  // floats per row of the fold table
 #define PWB_ERS 68                                                   // floats per staged row of a wave's 64 x 64 partial tile
 #define PWB_LDS_STAGE (2 * PWB_BUF + 128 * PWB_FROW * 4)
@@ -43,6 +47,7 @@
 #define PWB_LDS (PWB_LDS_STAGE > PWB_LDS_EPI ? PWB_LDS_STAGE : PWB_LDS_EPI)
 #define PWB_UTS 36                                                   // floats per row of a dx wave's transposition tile [32 c][32 px] (16-byte aligned rows)
 #define PWB_LDS_UP (2 * PWB_BUF_UP + 128 * PWB_FROW * 4 + 4 * 32 * PWB_UTS * 4)
+#define PWB_LDS_UP2 (2 * PWB_BUF_UP2 + 128 * PWB_FROW * 4 + 4 * 32 * PWB_UTS * 4)
 
 struct PwbParams {
     const float* gy;            // BNH 1: da [N][O][HW]; 2: the pooled gradient [N][O][H/2][W/2]; 3: dq [N][O][HW]; 0: dy itself
@@ -60,9 +65,11 @@ struct PwbParams {
     float n_f, qs, qinv;        // BNH 3: scale of the quantizer behind the block, RN(1 / qs) (0: IEEE division)
     FastDiv fd_hw, fd_w;
     ChanMap in_map;
-    const unsigned char* up_h;  // UP: the upstream block's byte stash [N][C][HW] (the layout of x)
-    const float* up_chan;       // UP: its [8][C] channel constants (qgemm_sign.hip: T, flip, L, U, A, B, gi, nnz)
+    const unsigned char* up_h;  // UP 1: the upstream block's byte stash [N][C][HW] (the layout of x); UP 2: its 16-bit stash
+    const float* up_chan;       // UP 1: its [8][C] channel constants (qgemm_sign.hip: T, flip, L, U, A, B, gi, nnz); UP 2: [9][C] (qact_kernels.hip)
     double* up_part;            // UP: [C][Z][2] partial sums {sum dz, sum dz zhat} of this launch's blocks (k_bns_final_bwd's layout, S = Z)
+    float up_qs, up_qinv;       // UP 2: scale of the quantizer behind the upstream block, RN(1 / qs) (0: IEEE division)
+    int up_quant;               // UP 2: this dx is w.r.t. the upstream block's QUANTISED output (the clip-STE applies)
 };
 
 // 16-byte slot swizzle of a plane row: conflict-free b128 row reads (16 rows of one fragment) AND transpose reads (4 consecutive rows = 256 contiguous bytes)
@@ -77,7 +84,7 @@ __device__ unsigned long long g_pwb_trace[3 * 64 * 8];
 
 template <int BNH, int XENC, int WIDE, int UP = 0>
 __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
-    constexpr int NS = WIDE ? 3 : 4, PLANE = PWB_PLANE, BUF = UP ? PWB_BUF_UP : PWB_BUF;
+    constexpr int NS = (WIDE || UP == 2) ? 3 : 4, PLANE = PWB_PLANE, BUF = UP == 2 ? PWB_BUF_UP2 : (UP ? PWB_BUF_UP : PWB_BUF);
     HIP_DYNAMIC_SHARED(float, smemw)
     unsigned char* lds = reinterpret_cast<unsigned char*>(smemw);          // [2][BUF], then the fold table [128][PWB_FROW]
     float* ftab = reinterpret_cast<float*>(lds + 2 * BUF);
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
             }
         }
         constexpr int HV = WIDE ? 4 : (BNH == 3 ? 2 : 1), H1 = HV > 1 ? 1 : 0, H2 = HV > 2 ? 2 : 0, H3 = HV > 3 ? 3 : 0;          // stash words per row (H1..: in-range indices)
-        struct Stage { float4 gv[4]; uint32_t hv[4][HV]; u32x4 cv; u32x4 uv; uint32_t hbit; };
+        struct Stage { float4 gv[4]; uint32_t hv[4][HV]; u32x4 cv; u32x4 uv; u32x4 uw; uint32_t hbit; };
         auto fetch = [&](Stage& S, int k) {
             // past the block's range: re-read the block's own last step (an L2 hit); loads stay unconditional
             const int kk = k < n ? k : (n > 0 ? n - 1 : 0);
@@ -180,7 +187,11 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
             const uint32_t Pc = (uint32_t)st * 32u + 16u * chf;
             const uint32_t nc = fd_div(Pc, p.fd_hw);
             S.cv = *reinterpret_cast<const u32x4*>(p.x + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
-            if (UP) S.uv = *reinterpret_cast<const u32x4*>(p.up_h + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
+            if (UP == 1) S.uv = *reinterpret_cast<const u32x4*>(p.up_h + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
+            if (UP == 2) {
+                const unsigned char* us = p.up_h + 2u * (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff);          // (plan: 4 N C HW < 2^32)
+                S.uv = *reinterpret_cast<const u32x4*>(us); S.uw = *reinterpret_cast<const u32x4*>(us + 16);
+            }
         };
         const uint32_t doff = (uint32_t)sr * 64u + ((((uint32_t)sq >> 1) ^ pwb_sw((uint32_t)sr)) << 4) + (((uint32_t)sq & 1u) << 3);      // rows sr + 32 i share the swizzle
         auto commit = [&](Stage& S, int buf, bool valid) {
@@ -256,7 +267,11 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                 *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{mn_pack_hi16(r2[0], r2[1]), mn_pack_hi16(r2[2], r2[3])};
             }
             *reinterpret_cast<u32x4*>(A + 3 * PLANE + cr * 48 + 16 * chf) = S.cv;
-            if (UP) *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * 48 + 16 * chf) = S.uv;
+            if (UP == 1) *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * 48 + 16 * chf) = S.uv;
+            if (UP == 2) {
+                *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * PWB_UP2_ROW + 32 * chf) = S.uv;
+                *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * PWB_UP2_ROW + 32 * chf + 16) = S.uw;
+            }
         };
         Stage st[NS];
 #pragma unroll
@@ -378,7 +393,20 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         uint32_t ulo = 255u, usp = 0u;
         float us1 = 0.f, ush = 0.f, unnz = 0.f;          // ush: sum dz (2 h - nnz) -- the integer the stash stands for, not h itself (2 h and nnz cancel)
         float* UT = reinterpret_cast<float*>(lds + 2 * BUF + 128 * PWB_FROW * 4) + wave * (32 * PWB_UTS);
-        if (UP) {
+        float qa_alpha = 0.f, qa_bias = 0.f, qa_mean = 0.f, qa_invstd = 0.f, qa_ga = 0.f, qa_be = 0.f, qa_lo = 1.f, qa_hi = 0.f;          // UP 2: the lane's upstream channel
+        bool qa_use = false;
+        if (UP == 2) {
+            const int ch = chan_phys(p.in_map, g * 128 + 32 * wave + (lane & 31)), Cu = p.C;
+            qa_alpha = p.up_chan[ch]; qa_bias = p.up_chan[Cu + ch]; qa_mean = p.up_chan[2 * Cu + ch]; qa_invstd = p.up_chan[3 * Cu + ch];
+            qa_ga = p.up_chan[4 * Cu + ch]; qa_be = p.up_chan[5 * Cu + ch];
+            auto fin = [](float v) { return fabsf(v) <= 1.0e9f; };
+            if (fin(qa_alpha) && fin(qa_bias) && fin(qa_mean) && fin(qa_invstd) && fin(qa_ga) && fin(qa_be) && qa_ga != 0.f && qa_invstd > 0.f && qa_alpha != 0.f) {
+                auto zf = [&](float v) { const float y = v * qa_alpha + qa_bias; const float zh = (y - qa_mean) * qa_invstd; return zh * qa_ga + qa_be; };
+                const QaInterval r = qa_mask_interval(32768, zf, [](int32_t w) { return (float)w; }, p.up_quant);
+                qa_lo = r.lo; qa_hi = r.hi; qa_use = true;
+            }
+        }
+        if (UP == 1) {
             const int ch = chan_phys(p.in_map, g * 128 + 32 * wave + (lane & 31)), Cu = p.C;
             const float fl = p.up_chan[Cu + ch], L = p.up_chan[2 * Cu + ch], U = p.up_chan[3 * Cu + ch], nnz = p.up_chan[7 * Cu + ch];
             float hlo, hhi;
@@ -440,19 +468,45 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                     for (int r = 0; r < 16; ++r) UT[((r & 3) + 8 * (r >> 2) + 4 * kgrp) * PWB_UTS + m] = outv[r];
                     MN_WAVE_SYNC();
                     const int cl = lane & 31, phx = lane >> 5;
-                    const u32x4 hq = *reinterpret_cast<const u32x4*>(A + 3 * PLANE + PWB_CODES + (32 * wave + cl) * 48 + 16 * phx);
                     float4 dq[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) dq[q] = *reinterpret_cast<const float4*>(UT + cl * PWB_UTS + 16 * phx + 4 * q);
+                    if (UP == 1) {
+                        const u32x4 hq = *reinterpret_cast<const u32x4*>(A + 3 * PLANE + PWB_CODES + (32 * wave + cl) * 48 + 16 * phx);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float dv[4] = {dq[q].x, dq[q].y, dq[q].z, dq[q].w};
+                        for (int q = 0; q < 4; ++q) {
+                            const float dv[4] = {dq[q].x, dq[q].y, dq[q].z, dq[q].w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const uint32_t hb = (hq[q] >> (8 * e)) & 0xffu;
-                            const float dz = (hb - ulo) <= usp ? dv[e] : 0.f;
-                            us1 += dz;
-                            ush += dz * (2.f * (float)hb - unnz);
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t hb = (hq[q] >> (8 * e)) & 0xffu;
+                                const float dz = (hb - ulo) <= usp ? dv[e] : 0.f;
+                                us1 += dz;
+                                ush += dz * (2.f * (float)hb - unnz);
+                            }
+                        }
+                    } else {          // UP 2: k_qa_partial's arithmetic on (this dx, the upstream 16-bit stash)
+                        const unsigned char* hs = A + 3 * PLANE + PWB_CODES + (32 * wave + cl) * PWB_UP2_ROW + 32 * phx;
+                        const u32x4 s0 = *reinterpret_cast<const u32x4*>(hs), s1 = *reinterpret_cast<const u32x4*>(hs + 16);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float dv[4] = {dq[q].x, dq[q].y, dq[q].z, dq[q].w};
+                            const uint32_t w0 = q < 2 ? s0[2 * q] : s1[2 * q - 4], w1 = q < 2 ? s0[2 * q + 1] : s1[2 * q - 3];
+                            const float sv[4] = {(float)(int16_t)(w0 & 0xffffu), (float)(int16_t)(w0 >> 16), (float)(int16_t)(w1 & 0xffffu), (float)(int16_t)(w1 >> 16)};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float y = sv[e] * qa_alpha + qa_bias;
+                                const float zh = (y - qa_mean) * qa_invstd;
+                                float dz;
+                                if (qa_use) {
+                                    const float d = p.up_quant ? dorefa_ste_core_m(dv[e], p.up_qs, p.up_qinv) : dv[e];
+                                    dz = (sv[e] >= qa_lo && sv[e] <= qa_hi) ? d : 0.f;
+                                } else {
+                                    const float zz = zh * qa_ga + qa_be;
+                                    dz = qa_dz_m(dv[e], qa_relu(zz), zz, p.up_qs, p.up_qinv, p.up_quant);
+                                }
+                                us1 += dz;
+                                ush += dz * zh;
+                            }
                         }
                     }
                 }
@@ -464,11 +518,16 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
             us1 += __shfl_xor(us1, 32, 64); ush += __shfl_xor(ush, 32, 64);          // the two pixel halves of the channel
             if (lane < 32) {
                 const int ch = chan_phys(p.in_map, g * 128 + 32 * wave + lane), Cu = p.C;
-                const double A_ = (double)p.up_chan[4 * Cu + ch], B_ = (double)p.up_chan[5 * Cu + ch];
+                (void)Cu;
                 const double d1 = (double)us1, da_ = (double)ush;
                 double* dstp = p.up_part + ((int64_t)ch * p.Z + z) * 2;
                 dstp[0] = d1;
-                dstp[1] = A_ * da_ + B_ * d1;          // zhat = A (2 h - nnz) + B
+                if (UP == 1) {
+                    const double A_ = (double)p.up_chan[4 * Cu + ch], B_ = (double)p.up_chan[5 * Cu + ch];
+                    dstp[1] = A_ * da_ + B_ * d1;          // zhat = A (2 h - nnz) + B
+                } else {
+                    dstp[1] = da_;
+                }
             }
         }
     }
@@ -518,7 +577,8 @@ int64_t pwb_ws_bytes(const mn_conv_geom* g) { PwbPlan pl; return plan_pwb(g, &pl
 
 template <int BNH, int XENC, int WIDE, int UP = 0>
 static void pwb_launch(const PwbPlan& pl, hipStream_t s) {
-    constexpr size_t lds = UP ? (PWB_LDS_UP > PWB_LDS ? PWB_LDS_UP : PWB_LDS) : PWB_LDS;
+    constexpr size_t lds_up = UP == 2 ? PWB_LDS_UP2 : PWB_LDS_UP;
+    constexpr size_t lds = UP ? (lds_up > PWB_LDS ? lds_up : PWB_LDS) : PWB_LDS;
     raise_lds_limit((const void*)k_pwb<BNH, XENC, WIDE, UP>, lds);
     hipLaunchKernelGGL((k_pwb<BNH, XENC, WIDE, UP>), dim3(pl.grid), dim3(768), lds, s, pl.p);
 }
@@ -538,7 +598,9 @@ static void pwb_trace_dump(hipStream_t s) {
 }
 #endif
 // mode: 1 wbwtab (h = byte stash; own != NULL: pooled), 3 DoReFa fold (h = 16 / 32-bit stash), 0 plain dy; xenc: 0 sign codes, 1 k-bit codes (dW times ascale)
-struct PwbUp { const uint8_t* h; const float* chan; double* part; };          // the upstream block's stash, [8][C] constants, partials [C][Z][2] (UP variants)
+// the upstream block (UP variants): kind 1: byte stash + [8][C] constants (wbwtab); kind 2: 16-bit stash + [9][C] constants, the width of the quantizer behind it and
+// whether this dx is w.r.t. its quantised output (DoReFa); partials [C][Z][2]
+struct PwbUp { int kind; const void* h; const float* chan; double* part; int bits, quant; };
 static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv_geom* g, const mn_wq* wq, const float* gy, const void* h, const int8_t* own,
                    const float* chan, const float* sums, int training, int quant, float qs, float ascale, const float* w, const void* x, float* dx, float* dw,
                    float* dbias, void* ws, int64_t ws_bytes, hipStream_t s, const PwbUp* up = nullptr) {
@@ -560,21 +622,25 @@ static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv
     p.part = (float*)((char*)ws + pl.off_part); p.dbpart = (float*)((char*)ws + pl.off_db);
     p.want_db = dbias != nullptr; p.training = training;
     p.quant = quant; p.qs = qs; p.qinv = mn_qa_inv(qs);
-    p.up_h = up ? up->h : nullptr; p.up_chan = up ? up->chan : nullptr; p.up_part = up ? up->part : nullptr;
+    p.up_h = up ? (const unsigned char*)up->h : nullptr; p.up_chan = up ? up->chan : nullptr; p.up_part = up ? up->part : nullptr;
+    p.up_quant = up ? up->quant : 0; p.up_qs = (up && up->kind == 2) ? dorefa_scale(up->bits) : 1.f; p.up_qinv = mn_qa_inv(p.up_qs);
     const int bnh = mode == 1 ? (own ? 2 : 1) : mode;
     if (up) {
-        if (mode != 1 || xenc || wide) MN_FAIL(MN_ENOTSUP, "%s: the upstream sums ride only on the wbwtab variants", what);
+        if (up->kind == 1 ? (mode != 1 || xenc || wide) : (up->kind != 2 || (mode != 3 && mode != 0) || !xenc || wide || up->bits < 1 || up->bits > 8))
+            MN_FAIL(MN_ENOTSUP, "%s: the upstream sums do not ride on this variant", what);
         if (!up->h || !up->chan || !up->part || (((uintptr_t)up->h) & 15) || (((uintptr_t)up->part) & 7)) MN_FAIL(MN_EINVAL, "%s: null / misaligned upstream operand", what);
-        mn_set_last_kernel("k_pwb<%d, %d, %d, 1>", bnh, xenc, wide);
+        mn_set_last_kernel("k_pwb<%d, %d, %d, %d>", bnh, xenc, wide, up->kind);
     } else
     mn_set_last_kernel("k_pwb<%d, %d, %d>", bnh, xenc, wide);
     {
         const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
-        mn_prof_bytes((mode == 1 ? (own ? 3.0 : 5.0) : (mode == 3 ? (wide ? 8.0 : 6.0) : 4.0)) * ny + (up ? 6.0 : 5.0) * nx);
+        mn_prof_bytes((mode == 1 ? (own ? 3.0 : 5.0) : (mode == 3 ? (wide ? 8.0 : 6.0) : 4.0)) * ny + (up ? 5.0 + up->kind : 5.0) * nx);
     }
     mn_prof_begin(s);
     if (up && bnh == 1) pwb_launch<1, 0, 0, 1>(pl, s);
     else if (up && bnh == 2) pwb_launch<2, 0, 0, 1>(pl, s);
+    else if (up && bnh == 3) pwb_launch<3, 1, 0, 2>(pl, s);
+    else if (up && bnh == 0) pwb_launch<0, 1, 0, 2>(pl, s);
     else if (bnh == 1 && !xenc) pwb_launch<1, 0, 0>(pl, s);
     else if (bnh == 2 && !xenc) pwb_launch<2, 0, 0>(pl, s);
     else if (bnh == 0 && !xenc) pwb_launch<0, 0, 0>(pl, s);
@@ -599,8 +665,23 @@ int pwb_up_splits(const mn_conv_geom* g) { PwbPlan pl; return plan_pwb(g, &pl) ?
 int pwb_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
                    const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const uint8_t* up_h, const float* up_chan,
                    double* up_part, hipStream_t s) {
-    const PwbUp up{up_h, up_chan, up_part};
+    const PwbUp up{1, up_h, up_chan, up_part, 0, 0};
     return pwb_run("mn_conv2d_bwd_bnh_up", 1, 0, 0, g, wq, da, h, own, chan, sums, training, 0, 1.f, 1.f, w, x, dx, dw, dbias, ws, ws_bytes, s, &up);
+}
+// the k-bit (DoReFa) counterparts: the block in front left a 16-bit stash; up_bits = the width of ITS output quantizer (= x_bits), up_quant: this dx is w.r.t. its codes
+int pwb_bwd_plain_up(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x, int x_bits, float* dx, float* dw, float* dbias, void* ws,
+                     int64_t ws_bytes, const void* up_stash, const float* up_chan, int up_quant, double* up_part, hipStream_t s) {
+    if (x_bits < 1 || x_bits > 8) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_codes_up: bad bit width");
+    const PwbUp up{2, up_stash, up_chan, up_part, x_bits, up_quant};
+    return pwb_run("mn_conv2d_bwd_codes_up", 0, 1, 0, g, wq, gy, nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f, dorefa_scale(x_bits), w, x, dx, dw, dbias, ws, ws_bytes, s, &up);
+}
+int pwb_bwd_qa_up(const mn_conv_geom* g, const mn_wq* wq, const float* dq, const void* stash, const float* chan, const float* sums, int out_bits, int quant, int training,
+                  const float* w, const uint8_t* x, int x_bits, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const void* up_stash, const float* up_chan,
+                  int up_quant, double* up_part, hipStream_t s) {
+    if (x_bits < 1 || x_bits > 8 || out_bits < 1 || out_bits > 8) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_qa_up: bad bit width");
+    const PwbUp up{2, up_stash, up_chan, up_part, x_bits, up_quant};
+    return pwb_run("mn_conv2d_bwd_qa_up", 3, 1, 0, g, wq, dq, stash, nullptr, chan, sums, training, quant, dorefa_scale(out_bits), dorefa_scale(x_bits), w, x, dx, dw, dbias, ws,
+                   ws_bytes, s, &up);
 }
 // plain gradient: x_bits == 0: sign codes, else k-bit activation codes of that width
 int pwb_bwd_plain(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x, int x_bits, float* dx, float* dw, float* dbias, void* ws,

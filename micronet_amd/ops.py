@@ -1943,12 +1943,13 @@ class UpSums:
     backward into ``ready = (dx, version, partials, splits)``; block k's backward recognises its incoming gradient as exactly that tensor (same storage, shape,
     version: autograd hands a single contribution through untouched) and only finishes the partials (mn_bnh_bwd_sums_final) instead of a pass over (d a, h).  Any other
     path (a second consumer, a hook, a pooled gradient) fails the identity test and takes the ordinary pass: always correct, one streaming pass slower."""
-    __slots__ = ("h", "chan", "k", "ready")
+    __slots__ = ("h", "chan", "k", "ready", "kind")
 
-    def __init__(self, h, chan, k):
-        self.h, self.chan, self.k, self.ready = h, chan, int(k), None
+    def __init__(self, h, chan, k, kind=1):          # kind 1: byte stash of a wbwtab block; 2: 16-bit stash of a k-bit (DoReFa) block (its `ready[0]` is the raw dq of a QGrad)
+        self.h, self.chan, self.k, self.ready, self.kind = h, chan, int(k), None, kind
 
 
+UP_SUMS_PLAIN = False          # (the k-bit hand-over also behind a plain gradient: tests only)
 UP_SUMS_FOLD = _os0.environ.get("MN_UP_SUMS", "1") != "0"          # (A/B and the equality test: MN_UP_SUMS=0 restores k_bnh_partial for every block)
 
 
@@ -2062,7 +2063,7 @@ class QConv2d(Function):
                     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=x.device)
                     up = getattr(ctx, "up_rec", None)
                     splits = 0
-                    if up is not None and UP_SUMS_FOLD and tuple(up.h.shape) == tuple(x.shape) and up.h.data_ptr() % 16 == 0 and up.chan.shape[0] == 8:
+                    if up is not None and up.kind == 1 and UP_SUMS_FOLD and tuple(up.h.shape) == tuple(x.shape) and up.h.data_ptr() % 16 == 0 and up.chan.shape[0] == 8:
                         splits = int(_lib_().mn_conv2d_bwd_bnh_up_splits(C.byref(g), _ref(wd), 1 if pool else 0, up.k))
                     if splits > 0:          # ... and the sums of the BatchNorm backward of the block in front (this dx is its d a)
                         part = torch.empty(x.shape[1] * splits * 2, dtype=torch.float64, device=x.device)
@@ -2432,6 +2433,7 @@ class QConvCodeLazy(Function):
         ctx.save_for_backward(codes, wq)
         ctx.cfg = (g, a_bits, w_bits, bias is not None)
         ctx.x_ref = x
+        ctx.up_rec = getattr(x, "_mn_up", None)          # the k-bit block that produced x (UpSums, kind 2)
         ctx.packed = packed = getattr(wq, "_mn_packed", None)
 
         def compute():          # a foreign consumer: the ordinary conv kernels on the materialised activation, quantizer in their prologue
@@ -2466,14 +2468,33 @@ class QConvCodeLazy(Function):
                 db = torch.empty(g.O, dtype=torch.float32, device=codes.device) if has_bias else None
                 nb = int(_lib_().mn_conv2d_bwd_bnh_ws_bytes(C.byref(g)))
                 ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=codes.device)
+                up = getattr(ctx, "up_rec", None)
+                splits, part = 0, None
+                # (only on the variant that forms its own dy from (dq, stash): there the producer waves set the pace and the sums ride for +18 us where k_qa_partial
+                #  takes 25-50; behind a plain dy -- the pooled blocks -- the dx waves set it and the same arithmetic costs +84 us per launch: measured, UP_SUMS_PLAIN)
+                if up is not None and up.kind == 2 and UP_SUMS_FOLD and tuple(up.h.shape) == tuple(codes.shape) and up.h.dtype == torch.int16 and up.h.data_ptr() % 16 == 0 \
+                        and ((fold and gy._mn_recipe["kind_in"] == 0) or (not fold and UP_SUMS_PLAIN)):
+                    splits = int(_lib_().mn_conv2d_bwd_bnh_up_splits(C.byref(g), C.byref(wd), 0, 1))
+                    if splits > 0:          # ... and the sums of the BatchNorm backward of the k-bit block in front (this dq is its gradient): UpSums
+                        part = torch.empty(codes.shape[1] * splits * 2, dtype=torch.float64, device=codes.device)
                 if fold:
                     r = gy._mn_recipe
-                    with _span(g, 1, (8 if r["kind_in"] == 2 else 6) * r["dq"].numel() + 5 * dq.numel()):
-                        _call("mn_conv2d_bwd_qa", C.byref(g), C.byref(wd), _p(r["dq"]), _p(r["stash"]), 32 if r["kind_in"] == 2 else 16, _p(r["chan"]), _p(r["sums"]),
-                              r["bits"], r["quant"], r["training"], _p(wq), _p(codes), a_bits, _p(dq), _p(dw), _p(db), _p(ws), nb, _s())
+                    with _span(g, 1, (8 if r["kind_in"] == 2 else 6) * r["dq"].numel() + (7 if part is not None else 5) * dq.numel()):
+                        if part is not None:
+                            _call("mn_conv2d_bwd_qa_up", C.byref(g), C.byref(wd), _p(r["dq"]), _p(r["stash"]), _p(r["chan"]), _p(r["sums"]), r["bits"], r["quant"], r["training"],
+                                  _p(wq), _p(codes), a_bits, _p(dq), _p(dw), _p(db), _p(ws), nb, _p(up.h), _p(up.chan), 1, _p(part), _s())
+                        else:
+                            _call("mn_conv2d_bwd_qa", C.byref(g), C.byref(wd), _p(r["dq"]), _p(r["stash"]), 32 if r["kind_in"] == 2 else 16, _p(r["chan"]), _p(r["sums"]),
+                                  r["bits"], r["quant"], r["training"], _p(wq), _p(codes), a_bits, _p(dq), _p(dw), _p(db), _p(ws), nb, _s())
                 else:
-                    with _span(g, 1, 4 * gy.numel() + 5 * dq.numel()):
-                        _call("mn_conv2d_bwd_codes", C.byref(g), C.byref(wd), _p(gy), _p(wq), _p(codes), a_bits, _p(dq), _p(dw), _p(db), _p(ws), nb, _s())
+                    with _span(g, 1, 4 * gy.numel() + (7 if part is not None else 5) * dq.numel()):
+                        if part is not None:
+                            _call("mn_conv2d_bwd_codes_up", C.byref(g), C.byref(wd), _p(gy), _p(wq), _p(codes), a_bits, _p(dq), _p(dw), _p(db), _p(ws), nb, _p(up.h), _p(up.chan),
+                                  1, _p(part), _s())
+                        else:
+                            _call("mn_conv2d_bwd_codes", C.byref(g), C.byref(wd), _p(gy), _p(wq), _p(codes), a_bits, _p(dq), _p(dw), _p(db), _p(ws), nb, _s())
+                if part is not None:
+                    up.ready = (dq, dq._version, part, splits)
 
             def expand_f(dq_):
                 return DorefaAct.backward_raw(dq_, x.materialize(), a_bits)
@@ -2641,7 +2662,11 @@ class BNReLUQ(Function):
                 _call("mn_qa_fwd_f32_mask", _p(src), _p(chan), N, Cc, H, W, qbits, _p(codes), _p(ctx.mask4), _s())
             else:
                 _call("mn_qa_fwd", in_f32, _p(src), _p(chan), N, Cc, H, W, qbits, int(bool(pool)), _p(codes), None, _s())
-        return QActTensor(codes, out_bits, materialize, pooled=bool(pool))
+        out = QActTensor(codes, out_bits, materialize, pooled=bool(pool))
+        ctx.up_rec = None
+        if lazy and not pool and in_f32 == 0 and UP_SUMS_FOLD:          # (16-bit stash, no pool: the next block's one-launch backward may form this block's sums)
+            ctx.up_rec = out._mn_up = UpSums(src, chan, 1, kind=2)
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -2672,12 +2697,22 @@ class BNReLUQ(Function):
             return LazyBNGrad((N, Cc, H, W), dev, recipe, expand1), dgamma, dbeta, None, None, None, None, None, None, None, None
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        rec = getattr(ctx, "up_rec", None)
+        ready = None
+        if rec is not None:
+            ready, rec.ready = rec.ready, None
+        # the producer of dq (the next block's one-launch backward) already summed dz and dz zhat per channel (UpSums): only the fixed-order finish is left
+        presummed = ready is not None and quant == 1 and not pool and type(dq) is torch.Tensor and dq.data_ptr() == ready[0].data_ptr() and \
+            tuple(dq.shape) == tuple(ready[0].shape) and dq._version == ready[1] and dq.is_contiguous()
         with torch.cuda.device(dev):
             ws = torch.empty(int(_lib_().mn_qa_ws_floats(Cc)), dtype=torch.float32, device=dev)
             lazy_first = in_f32 == 1 and not pool and LAZY_BN_GRAD and FOLD_BN_INTO_CONV_BWD
+            if presummed:
+                _call("mn_qa_bwd_sums_final", _p(ready[2]), ready[3], Cc, _p(dgamma), _p(dbeta), _p(sums), _s())
             if getattr(ctx, "pwb_fold", False) and dq.data_ptr() % 16 == 0:
-                with _span(None, 3, (2 if in_f32 == 0 else 4) * src.numel() + 4 * dq.numel()):
-                    _call("mn_qa_bwd_sums", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
+                if not presummed:
+                    with _span(None, 3, (2 if in_f32 == 0 else 4) * src.numel() + 4 * dq.numel()):
+                        _call("mn_qa_bwd_sums", in_f32, _p(src), _p(chan), _p(dq), N, Cc, H, W, qbits, pool, quant, _p(dgamma), _p(dbeta), _p(sums), _p(ws), _s())
 
                 def expand_pw(r):
                     dy_ = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
@@ -2687,6 +2722,11 @@ class BNReLUQ(Function):
                     return dy_
                 recipe = dict(kind="qa_pw", dq=dq, stash=src, kind_in=in_f32, chan=chan, sums=sums, bits=qbits, quant=quant, training=training)
                 return LazyBNGrad((N, Cc, H, W), dev, recipe, expand_pw), dgamma, dbeta, None, None, None, None, None, None, None, None
+            if presummed:
+                dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+                with _span(None, 3, (2 if in_f32 == 0 else 4) * src.numel() + 4 * dq.numel() + 4 * dy.numel()):
+                    _call("mn_qa_bwd_apply", in_f32, _p(src), _p(chan), _p(sums), _p(dq), N, Cc, H, W, qbits, pool, quant, training, _p(dy), _s())
+                return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
             if QA_BWD_TWO_LAUNCHES and not lazy_first:
                 # partial sums, then the apply pass whose blocks finish the sums themselves (mn_qa_bwd: one launch less per block, bit-identical)
                 dy = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)

@@ -210,7 +210,31 @@ class QuantConv2d(nn.Conv2d):
         self._register_load_state_dict_pre_hook(_forget_stored_codes, with_module=True)          # (a module-level function: the module stays picklable)
 
     def _codes_valid(self):
-        return bool(getattr(self, "stored_codes", False)) and getattr(self, "_mn_codes_key", None) == (self.weight.data_ptr(), self.weight._version)
+        if not getattr(self, "stored_codes", False):
+            return False
+        if self.__dict__.pop("_mn_codes_carry", False):          # a copy (deepcopy / pickle / DataParallel replica) of a module whose verdict held: same values in a
+            self._mn_codes_key = (self.weight.data_ptr(), self.weight._version)          # new tensor -- re-keyed at first use
+            return True
+        ok = getattr(self, "_mn_codes_key", None) == (self.weight.data_ptr(), self.weight._version)
+        if not ok and not getattr(self, "_mn_codes_noted", False):
+            self._mn_codes_noted = True
+            ops.note_fallback("wbwtab.QuantConv2d: stored_codes verdict no longer matches the weight tensor (float path)")
+        return ok
+
+    def __getstate__(self):          # copy.deepcopy / pickle / torch.save(model): the raw-pointer key does not travel, the verdict about the VALUES does
+        st = dict(self.__dict__)
+        key = st.pop("_mn_codes_key", None)
+        st.pop("_mn_codes_noted", None)
+        st["_mn_codes_carry"] = bool(st.get("stored_codes", False)) and (st.get("_mn_codes_carry", False) or key == (self.weight.data_ptr(), self.weight._version))
+        return st
+
+    def _replicate_for_data_parallel(self):          # nn.DataParallel: the replica's weight is a broadcast copy of the same values
+        r = super()._replicate_for_data_parallel()
+        valid = bool(getattr(self, "stored_codes", False)) and (self.__dict__.get("_mn_codes_carry", False) or
+                                                                  getattr(self, "_mn_codes_key", None) == (self.weight.data_ptr(), self.weight._version))
+        r.__dict__.pop("_mn_codes_key", None)
+        r.__dict__["_mn_codes_carry"] = valid
+        return r
 
     def _apply(self, fn, *args, **kwargs):          # .cuda() / .to(): same values in a new tensor -- the verdict moves with them
         was = self._codes_valid()

@@ -1281,7 +1281,78 @@ def check_qconv_bnq(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, tra
             if bias:
                 sc_db = max(np.max(np.abs(be.to_host(dy))) * 1e-4, 1e-30)      # d bias in front of a BatchNorm is a sum that cancels to ~0
                 assert np.max(np.abs(be.to_host(db4) - be.to_host(db_t))) <= sc_db * N * H * W, "k_pwb<3> dbias"
+        if not pooled and sbits == 16:
+            _check_pwb_up2(be, g, wq, r, dGY, dDQ, stash, chan, sums, out_bits, quant, training, dW, dX, a_bits, dx3, dw3, dx4, dw4, nb3, x_shape, w_shape, seed)
         check_qconv_bnq.pwb_checked = getattr(check_qconv_bnq, "pwb_checked", 0) + 1
+
+
+def _check_pwb_up2(be, g, wq, r, dGY, dDQ, stash, chan, sums, out_bits, quant, training, dW, dX, a_bits, dx3, dw3, dx4, dw4, nb3, x_shape, w_shape, seed):
+    """mn_conv2d_bwd_codes_up / mn_conv2d_bwd_qa_up (k_pwb<.., UP 2>): dx / dw bit-identical to the plain launches; the by-product -- sum dz, sum dz zhat of a k-bit
+    block in front, finished by mn_qa_bwd_sums_final -- against mn_qa_bwd_sums on (that dx, the upstream 16-bit stash) and an fp64 evaluation of the same masks."""
+    N, Cin, H, W = x_shape
+    splits = int(be.lib.mn_conv2d_bwd_bnh_up_splits(C.byref(g), C.byref(wq), 0, 1))
+    assert splits > 0
+    # an upstream block: integers in the 16-bit stash, constants that put the ReLU kink and the clamp edge inside the range for most channels
+    up_st = r.integers(-300, 301, size=x_shape).astype(np.int16)
+    alpha_u = np.full(Cin, 0.01, F)
+    bias_u = (r.standard_normal(Cin) * 0.1).astype(F)
+    mean_u = (r.standard_normal(Cin) * 0.2).astype(F)
+    inv_u = (np.abs(r.standard_normal(Cin)) * 0.5 + 0.5).astype(F)
+    ga_u = (r.standard_normal(Cin) * 2.0 + 4.0).astype(F)
+    be_u = (r.standard_normal(Cin) * 2.0 + 3.0).astype(F)
+    ga_u[1] = -ga_u[1] - 0.5            # a decreasing channel
+    ga_u[2] = 0.0                       # gamma == 0: element-wise masks
+    be_u[3] = np.nan                    # a poisoned channel: element-wise masks, NaN comparisons
+    ga_u[4], be_u[4] = 1e-3, -5.0       # nothing passes the ReLU
+    up_chan = np.zeros((9, Cin), F)
+    up_chan[0], up_chan[1], up_chan[2], up_chan[3], up_chan[4], up_chan[5] = alpha_u, bias_u, mean_u, inv_u, ga_u, be_u
+    up_chan[8] = ga_u * inv_u
+    d_us, d_uc = be.to_dev_i8(up_st.view(np.int8).reshape(N, Cin, H, 2 * W)), be.to_dev(up_chan)
+    for up_quant in (1, 0):
+        for form in ("codes", "qa"):
+            ws, dx5, dw5 = be.empty(nb3 // 4 + 8), be.empty(x_shape), be.empty(w_shape)
+            part = be.empty(Cin * splits * 4 + 2)
+            if form == "codes":
+                be.call("mn_conv2d_bwd_codes_up", C.byref(g), C.byref(wq), be.ptr(dGY), be.ptr(dW), be.ptr(dX), a_bits, be.ptr(dx5), be.ptr(dw5), None, be.ptr(ws), nb3,
+                        be.ptr(d_us), be.ptr(d_uc), up_quant, be.ptr(part), be.stream)
+                assert be.lib.mn_last_kernel().decode() == "k_pwb<0, 1, 0, 2>"
+                assert np.array_equal(be.to_host(dx5), be.to_host(dx3)) and np.array_equal(be.to_host(dw5), be.to_host(dw3))
+            else:
+                be.call("mn_conv2d_bwd_qa_up", C.byref(g), C.byref(wq), be.ptr(dDQ), be.ptr(stash), be.ptr(chan), be.ptr(sums), out_bits, int(quant), int(training),
+                        be.ptr(dW), be.ptr(dX), a_bits, be.ptr(dx5), be.ptr(dw5), None, be.ptr(ws), nb3, be.ptr(d_us), be.ptr(d_uc), up_quant, be.ptr(part), be.stream)
+                assert be.lib.mn_last_kernel().decode() == "k_pwb<3, 1, 0, 2>"
+                assert np.array_equal(be.to_host(dx5), be.to_host(dx4)) and np.array_equal(be.to_host(dw5), be.to_host(dw4))
+            s_up, dg_up, db_up = be.empty((2, Cin)), be.empty(Cin), be.empty(Cin)
+            be.call("mn_qa_bwd_sums_final", be.ptr(part), splits, Cin, be.ptr(dg_up), be.ptr(db_up), be.ptr(s_up), be.stream)
+            s_ref, dg_ref, db_ref = be.empty((2, Cin)), be.empty(Cin), be.empty(Cin)
+            ws2 = be.empty(int(be.lib.mn_qa_ws_floats(Cin)) + 2)
+            be.call("mn_qa_bwd_sums", 0, be.ptr(d_us), be.ptr(d_uc), be.ptr(dx5), N, Cin, H, W, a_bits, 0, up_quant, be.ptr(dg_ref), be.ptr(db_ref), be.ptr(s_ref), be.ptr(ws2),
+                    be.stream)
+            got, ref = be.to_host(s_up).astype(np.float64), be.to_host(s_ref).astype(np.float64)
+            # fp64 evaluation from the same dx with the kernels' fp32 chain for the masks
+            dxh = be.to_host(dx5)
+            sa = F(1.0 / (2 ** a_bits - 1))
+            with np.errstate(invalid="ignore"):
+                yv = (up_st.astype(F) * alpha_u.reshape(1, -1, 1, 1) + bias_u.reshape(1, -1, 1, 1)).astype(F)
+                zh = ((yv - mean_u.reshape(1, -1, 1, 1)) * inv_u.reshape(1, -1, 1, 1)).astype(F)
+                z = (zh * ga_u.reshape(1, -1, 1, 1) + be_u.reshape(1, -1, 1, 1)).astype(F)
+                a_ = np.where(z > 0, z, F(0)).astype(F)          # (NaN > 0 is false)
+                if up_quant:
+                    t_ = (a_ * F(0.1)).astype(F)
+                    d_ = ((dxh * sa) / sa).astype(F)
+                    d_ = (np.where((t_ >= 0) & (t_ <= 1), d_, F(0)) * F(0.1)).astype(F)
+                else:
+                    d_ = dxh
+                dz = np.where(z > 0, d_, F(0)).astype(np.float64)
+            zh64 = np.nan_to_num(zh.astype(np.float64))
+            e1, e2 = dz.sum(axis=(0, 2, 3)), (dz * zh64).sum(axis=(0, 2, 3))
+            m1, m2 = np.abs(dz).sum(axis=(0, 2, 3)) + 1e-30, np.abs(dz * zh64).sum(axis=(0, 2, 3)) + 1e-30
+            e_got = (np.max(np.abs(got[0] - e1) / m1), np.max(np.abs(got[1] - e2) / m2))
+            assert e_got[0] <= 2e-6 and e_got[1] <= 2e-6, ("k_pwb<UP 2> upstream sums", form, up_quant, e_got)
+            assert np.max(np.abs(ref[0] - e1) / m1) <= 2e-6 and np.max(np.abs(ref[1] - e2) / m2) <= 2e-6
+            assert got[0, 4] == 0 and got[1, 4] == 0 and got[0, 3] == 0
+            assert np.array_equal(be.to_host(dg_up), be.to_host(s_up)[1]) and np.array_equal(be.to_host(db_up), be.to_host(s_up)[0])
+    _check_pwb_up2.count = getattr(_check_pwb_up2, "count", 0) + 1
 
 
 # k-bit blocks on the geometries k_pwb covers (groups of 128 -> 128 channels): 16-bit and 32-bit stash, pooled (plain-gradient form only), eval mode, no quantizer behind
@@ -1295,10 +1366,11 @@ PWB_BNQ_CASES = [
 
 
 def check_pwb_bnq(be):
-    before = getattr(check_qconv_bnq, "pwb_checked", 0)
+    before, before_up = getattr(check_qconv_bnq, "pwb_checked", 0), getattr(_check_pwb_up2, "count", 0)
     for i, case in enumerate(PWB_BNQ_CASES):
         check_qconv_bnq(be, seed=440 + i, **case)
     assert getattr(check_qconv_bnq, "pwb_checked", 0) - before == len(PWB_BNQ_CASES), "k_pwb did not take these geometries"
+    assert getattr(_check_pwb_up2, "count", 0) - before_up == 3, "the upstream-sums variants (k_pwb<.., UP 2>) ran on the three un-pooled 16-bit cases"
 
 
 BNQ_CASES = [

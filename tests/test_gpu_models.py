@@ -505,6 +505,45 @@ def test_tail_fused_vs_stock(monkeypatch, key):
         assert torch.allclose(v1.float(), v0.float(), rtol=2e-5, atol=1e-7, equal_nan=True), k
 
 
+@pytest.mark.parametrize("scheme,kw,up_call,final_call", [
+    ("wbwtab", dict(A=2, W=3), ("mn_conv2d_bwd_bnh_up",), "mn_bnh_bwd_sums_final"),
+    ("wqaq.dorefa", dict(a_bits=2, w_bits=2), ("mn_conv2d_bwd_qa_up", "mn_conv2d_bwd_codes_up"), "mn_qa_bwd_sums_final"),
+])
+def test_upstream_sums_ride_on_the_next_blocks_backward(monkeypatch, scheme, kw, up_call, final_call):
+    """Round 6, ops.UpSums: the one-launch backward of a pointwise block (k_pwb<.., UP>) also forms the BatchNorm-backward sums of the block in front -- its dx IS that
+    block's incoming gradient -- so that block only finishes partials instead of streaming (gradient, stash) again (wbwtab: k_bnh_partial, DoReFa: k_qa_partial).
+    Whole nin_gc step with the hand-over on and off: the hand-over happens for the un-pooled pointwise pairs and every gradient agrees to the summation order."""
+    import copy
+    from micronet_amd import ops
+    from micronet_amd.train import build_model, synth_batch
+    quantize = importlib.import_module("micronet.compression.quantization.%s.quantize" % scheme)
+    torch.manual_seed(11)
+    base = quantize.prepare(build_model("nin_gc"), inplace=True, **kw).cuda().train()
+    x, y = synth_batch(32, device="cuda")
+    real = ops._call
+    res, calls = {}, {}
+    monkeypatch.setattr(ops, "UP_SUMS_PLAIN", True)          # (k-bit blocks: also behind a plain gradient, which the default leaves alone -- slower there)
+    for on in (True, False):
+        monkeypatch.setattr(ops, "UP_SUMS_FOLD", on)
+        n = {}
+        monkeypatch.setattr(ops, "_call", lambda name, *a, _n=n: (_n.__setitem__(name, _n.get(name, 0) + 1), real(name, *a))[1])
+        m = copy.deepcopy(base)
+        ops.fallback_counts(reset=True)
+        ops.cross_entropy(m(x), y).backward()
+        assert ops.fallback_counts() == {}, ops.fallback_counts()
+        res[on] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        calls[on] = n
+    monkeypatch.setattr(ops, "_call", real)
+    ups = {on: sum(calls[on].get(c, 0) for c in up_call) for on in (True, False)}
+    # nin_gc (models/nin_gc.py:18-59): the consumer is a pointwise block k_pwb covers, the block in front left a byte / 16-bit stash and is not pooled
+    assert ups[True] >= 2 and calls[True].get(final_call, 0) == ups[True], calls[True]
+    assert ups[False] == 0 and calls[False].get(final_call, 0) == 0, calls[False]
+    gscale = max(float(g.abs().max()) for g in res[False].values())
+    for k, g0 in res[False].items():
+        g1 = res[True][k]
+        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-6 * gscale, (k, float((g1 - g0).abs().max()), float(g0.abs().max()))
+
+
 @pytest.mark.parametrize("codes,add", [(True, True), (True, False), (False, True)])
 def test_iao_resnet_block_fused_passes(monkeypatch, codes, add):
     """Round 6, the IAO BasicBlock (models/resnet.py:17-29, 60-65 under wqaq/iao/quantize.py:492-507, 1484-1498) in fewer passes:

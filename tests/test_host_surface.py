@@ -330,3 +330,39 @@ def test_residual_token_only_for_descendants():
     for _ in range(200):
         deep = deep + 1.0
     assert not ops._descends_from(deep, a.grad_fn, limit=96)          # (beyond the search budget: the fold is simply not taken)
+
+
+def test_stored_codes_verdict_survives_copies_of_the_module():
+    """the deployed wbwtab layer's ``stored_codes`` verdict is keyed on (data pointer, version) of ONE weight tensor.  copy.deepcopy, a pickle round trip and
+    nn.DataParallel's replicas hold the same VALUES in a new tensor: the verdict travels with them (re-keyed at first use, no raw pointer in the pickle); a copy of a
+    module whose verdict no longer held does not get one, and new values in the copy drop it again."""
+    import copy
+    import io
+    import pickle
+    from micronet.compression.quantization.wbwtab import quantize
+    from micronet_amd import inference, ops
+    torch.manual_seed(5)
+    m = quantize.QuantConv2d(8, 16, 1, W=3, quant_inference=True)
+    inference.mark_stored_codes(m)
+    assert m._codes_valid()
+    d = copy.deepcopy(m)
+    assert d.weight.data_ptr() != m.weight.data_ptr() and "_mn_codes_key" not in d.__dict__ and d._codes_valid() and d._codes_valid()
+    p = pickle.loads(pickle.dumps(m))
+    assert p._codes_valid()
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    t = torch.load(buf, weights_only=False)
+    assert t._codes_valid()
+    r = m._replicate_for_data_parallel()
+    r.weight = m.weight.detach().clone()          # what replicate() hands a replica: a broadcast copy, not a Parameter
+    assert r._codes_valid()
+    assert m._codes_valid()                       # the original is untouched by all of this
+    # new values: the verdict goes, visibly
+    ops.fallback_counts(reset=True)
+    d.weight.data = torch.randn_like(d.weight)
+    assert not d._codes_valid() and any("stored_codes" in k for k in ops.fallback_counts(reset=True))
+    assert not copy.deepcopy(d)._codes_valid()    # ... and a copy of THAT module has none either
+    with torch.no_grad():
+        m.weight.mul_(1.0)                        # an in-place update of the original (what an optimizer step does): the version moves on
+    assert not m._codes_valid() and not copy.deepcopy(m)._codes_valid()
