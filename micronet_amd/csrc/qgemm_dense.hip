@@ -119,83 +119,100 @@ struct QdPackTable {
     int O[QD_PACK_MAX], C[QD_PACK_MAX], T[QD_PACK_MAX], wsc_stride[QD_PACK_MAX], blk0[QD_PACK_MAX + 1];
     int n; float wn; int fwd8;          // fwd8: the forward image in the int8 order (orient 2)
 };
-// A block owns one (64 o, 64 c) tile of one tensor: the tile's 64 rows of 64 T contiguous floats are read coalesced, turned into codes ONCE (int16 in LDS,
-// [o][c][tap]) and written out in every fragment order wanted as whole 16-byte lanes -- the forward image ([cot][chunk][tap] blocks of 4 KB int8 / 8 KB bf16
-// are contiguous per tile) and the two 32-row chunks of the backward-data image.  (The first version gathered 4-byte elements at strides of T and C T floats
-// per lane: 139 us for resnet18's 11 M weights; this one is bound by the 45 MB it reads.)
-// Round 6: 1024 threads per block and 16-byte loads -- resnet18's 11 M weights are ~300 tiles, i.e. one block per CU: with 4 waves of scalar loads the launch was
-// latency-bound (77-87 us for 45 MB).
-#define QD_PACK_THREADS 1024
+// A block owns a 16-row slice of one (64 o, 64 c) tile of one tensor: the slice's 16 rows of 64 T contiguous floats are read coalesced (all of a thread's 16-byte
+// loads in flight at once), turned into codes ONCE (int16 in LDS, [o][c][tap]) and written out in every fragment order wanted as whole 16-byte lanes -- one nf of the
+// forward image ([cot][chunk][tap][nf] blocks of 1 KB int8 / 2 x 1 KB bf16) and two of the four lane groups of one 32-row chunk of the backward-data image.
+// (History: the first version gathered 4-byte elements at strides of T and C T floats per lane: 139 us for resnet18's 11 M weights; whole tiles by 256 and then 1024
+// threads: 77-105 us -- ~300 blocks, one per CU, each serialising 147 KB of loads behind one another; slices give 1200 blocks of 256 threads and ~5 blocks per CU.)
+#define QD_PACK_THREADS 256
+#define QD_PACK_ROWS 16
+#define QD_PACK_MAXQ 9          // float4 loads per thread: 16 rows x 64 c x 9 taps / 4 / 256
 __global__ __launch_bounds__(QD_PACK_THREADS) void k_qd_pack_multi(const QdPackTable t) {
     HIP_DYNAMIC_SHARED(float, smem)
-    int16_t* codes = reinterpret_cast<int16_t*>(smem);          // [64 o][64 c][T]
+    int16_t* codes = reinterpret_cast<int16_t*>(smem);          // [16 o][64 c][T]
     int e = 0;
     while (e + 1 < t.n && (int)blockIdx.x >= t.blk0[e + 1]) ++e;
     const int O = t.O[e], Cn = t.C[e], T = t.T[e];
-    const int tile = (int)blockIdx.x - t.blk0[e];
+    const int sl = (int)blockIdx.x - t.blk0[e];
+    const int tile = sl >> 2, sub = sl & 3;                      // sub: rows 16 sub .. 16 sub + 15 of the tile (the forward image's nf)
     const int ncit = Cn / 64, cot = tile / ncit, cit = tile - cot * ncit;
     const float* w = t.w[e];
     const float* wsc = t.wsc[e];
-    const int row_len = 64 * T, total = 64 * row_len;
-    const int nthr = (int)blockDim.x;
-    if ((((uintptr_t)w) & 15) == 0) {          // a row of the tile starts at a multiple of 64 floats: every quad of it is one aligned 16-byte load
-        for (int i = threadIdx.x; i < total / 4; i += nthr) {
-            const int row = (4 * i) / row_len, col = 4 * i - row * row_len;
-            const int o = cot * 64 + row;
-            const float4 v = *reinterpret_cast<const float4*>(w + ((int64_t)o * Cn + cit * 64) * T + col);
-            int c0, c1, c2, c3;
-            if (wsc) {
-                const float sc = wsc[(int64_t)o * t.wsc_stride[e]];
-                c0 = (int)rintf(v.x / sc); c1 = (int)rintf(v.y / sc); c2 = (int)rintf(v.z / sc); c3 = (int)rintf(v.w / sc);
-            } else {
-                c0 = (int)rintf(v.x * t.wn); c1 = (int)rintf(v.y * t.wn); c2 = (int)rintf(v.z * t.wn); c3 = (int)rintf(v.w * t.wn);
+    const int row_len = 64 * T, total = QD_PACK_ROWS * row_len;
+    const int o_base = cot * 64 + sub * 16;
+    const int tid = threadIdx.x;
+    if ((((uintptr_t)w) & 15) == 0) {          // a row of the slice starts at a multiple of 64 floats: every quad of it is one aligned 16-byte load
+        const int nq = total / 4;
+        float4 v[QD_PACK_MAXQ];
+#pragma unroll
+        for (int u = 0; u < QD_PACK_MAXQ; ++u) {
+            const int i = tid + QD_PACK_THREADS * u;
+            if (i < nq) {
+                const int row = (4 * i) / row_len, col = 4 * i - row * row_len;
+                v[u] = *reinterpret_cast<const float4*>(w + ((int64_t)(o_base + row) * Cn + cit * 64) * T + col);
             }
-            *reinterpret_cast<u32x2*>(codes + 4 * i) = u32x2{((uint32_t)c0 & 0xffffu) | ((uint32_t)c1 << 16), ((uint32_t)c2 & 0xffffu) | ((uint32_t)c3 << 16)};
+        }
+#pragma unroll
+        for (int u = 0; u < QD_PACK_MAXQ; ++u) {
+            const int i = tid + QD_PACK_THREADS * u;
+            if (i < nq) {
+                int c0, c1, c2, c3;
+                if (wsc) {
+                    const int row = (4 * i) / row_len;
+                    const float sc = wsc[(int64_t)(o_base + row) * t.wsc_stride[e]];
+                    c0 = (int)rintf(v[u].x / sc); c1 = (int)rintf(v[u].y / sc); c2 = (int)rintf(v[u].z / sc); c3 = (int)rintf(v[u].w / sc);
+                } else {
+                    c0 = (int)rintf(v[u].x * t.wn); c1 = (int)rintf(v[u].y * t.wn); c2 = (int)rintf(v[u].z * t.wn); c3 = (int)rintf(v[u].w * t.wn);
+                }
+                *reinterpret_cast<u32x2*>(codes + 4 * i) = u32x2{((uint32_t)c0 & 0xffffu) | ((uint32_t)c1 << 16), ((uint32_t)c2 & 0xffffu) | ((uint32_t)c3 << 16)};
+            }
         }
     } else {
-        for (int i = threadIdx.x; i < total; i += nthr) {
+        for (int i = tid; i < total; i += QD_PACK_THREADS) {
             const int row = i / row_len, col = i - row * row_len;
-            const int o = cot * 64 + row;
+            const int o = o_base + row;
             const float v = w[((int64_t)o * Cn + cit * 64) * T + col];
             codes[i] = (int16_t)(int)(wsc ? rintf(v / wsc[(int64_t)o * t.wsc_stride[e]]) : rintf(v * t.wn));
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = tid & 63;
     if (t.outf[e]) {
-        if (t.fwd8) {          // orient 2: [cot][chunk = cit][tap][nf][lane][16 signed bytes]: o = 16 nf + (lane & 15), c = 16 (lane >> 4) + b
+        if (t.fwd8) {          // orient 2: [cot][chunk = cit][tap][nf][lane][16 signed bytes]: o = 16 nf + (lane & 15), c = 16 (lane >> 4) + b; this slice: nf = sub
             unsigned char* dst = reinterpret_cast<unsigned char*>(t.outf[e]) + (int64_t)(cot * ncit + cit) * T * 4096;
-            for (int it = threadIdx.x; it < T * 256; it += nthr) {
-                const int tap = it >> 8, nf = (it >> 6) & 3;
-                const int16_t* src = codes + ((nf * 16 + (lane & 15)) * 64 + (lane >> 4) * 16) * T + tap;
+            for (int it = tid; it < T * 64; it += QD_PACK_THREADS) {
+                const int tap = it >> 6;
+                const int16_t* src = codes + ((lane & 15) * 64 + (lane >> 4) * 16) * T + tap;
                 uint32_t d[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int b_ = 0; b_ < 16; ++b_) d[b_ >> 2] |= ((uint32_t)src[b_ * T] & 0xffu) << (8 * (b_ & 3));
-                *reinterpret_cast<u32x4*>(dst + (int64_t)it * 16) = u32x4{d[0], d[1], d[2], d[3]};
+                *reinterpret_cast<u32x4*>(dst + (int64_t)((tap * 4 + sub) * 64 + lane) * 16) = u32x4{d[0], d[1], d[2], d[3]};
             }
-        } else {               // orient 0: [cot][chunk][tap][ks][nf][lane][8 bf16]: o = 16 nf + (lane & 15), c = 32 ks + 8 (lane >> 4) + b
+        } else {               // orient 0: [cot][chunk][tap][ks][nf][lane][8 bf16]: o = 16 nf + (lane & 15), c = 32 ks + 8 (lane >> 4) + b; this slice: nf = sub
             unsigned char* dst = reinterpret_cast<unsigned char*>(t.outf[e]) + (int64_t)(cot * ncit + cit) * T * 8192;
-            for (int it = threadIdx.x; it < T * 512; it += nthr) {
-                const int tap = it >> 9, ks = (it >> 8) & 1, nf = (it >> 6) & 3;
-                const int16_t* src = codes + ((nf * 16 + (lane & 15)) * 64 + ks * 32 + (lane >> 4) * 8) * T + tap;
+            for (int it = tid; it < T * 128; it += QD_PACK_THREADS) {
+                const int tap = it >> 7, ks = (it >> 6) & 1;
+                const int16_t* src = codes + ((lane & 15) * 64 + ks * 32 + (lane >> 4) * 8) * T + tap;
                 uint32_t h[8];
 #pragma unroll
                 for (int b_ = 0; b_ < 8; ++b_) h[b_] = mn_f2u((float)src[b_ * T]) >> 16;
-                *reinterpret_cast<u32x4*>(dst + (int64_t)it * 16) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+                *reinterpret_cast<u32x4*>(dst + (int64_t)(((tap * 2 + ks) * 4 + sub) * 64 + lane) * 16) =
+                    u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
             }
         }
     }
-    if (t.outd[e]) {           // orient 1: [cit][chunk = o / 32][tap][nf][lane][8 bf16]: c = 16 nf + (lane & 15), o = 32 chunk + 8 (lane >> 4) + b
-        const int nch = O / 32;
-        for (int it = threadIdx.x; it < 2 * T * 256; it += nthr) {
-            const int half = it / (T * 256), r = it - half * T * 256;
-            const int tap = r >> 8, nf = (r >> 6) & 3;
-            const int16_t* src = codes + ((half * 32 + (lane >> 4) * 8) * 64 + nf * 16 + (lane & 15)) * T + tap;
+    if (t.outd[e]) {           // orient 1: [cit][chunk = o / 32][tap][nf][lane][8 bf16]: c = 16 nf + (lane & 15), o = 32 chunk + 8 (lane >> 4) + b;
+        const int nch = O / 32;          // this slice: chunk = 2 cot + (sub >> 1), the lane groups (lane >> 4) = 2 (sub & 1), 2 (sub & 1) + 1
+        unsigned char* dst0 = reinterpret_cast<unsigned char*>(t.outd[e]) + ((int64_t)(cit * nch + cot * 2 + (sub >> 1)) * T) * 4096;
+        for (int it = tid; it < T * 128; it += QD_PACK_THREADS) {
+            const int tap = it >> 7, nf = (it >> 5) & 3, l5 = it & 31;
+            const int lg = l5 >> 4, c = nf * 16 + (l5 & 15);          // local rows 8 lg .. 8 lg + 7 of the slice
+            const int16_t* src = codes + ((lg * 8) * 64 + c) * T + tap;
             uint32_t h[8];
 #pragma unroll
             for (int b_ = 0; b_ < 8; ++b_) h[b_] = mn_f2u((float)src[b_ * 64 * T]) >> 16;
-            unsigned char* dst = reinterpret_cast<unsigned char*>(t.outd[e]) + ((int64_t)(cit * nch + cot * 2 + half) * T) * 4096 + (int64_t)r * 16;
-            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            const int olane = ((2 * (sub & 1) + lg) << 4) | (l5 & 15);
+            *reinterpret_cast<u32x4*>(dst0 + (int64_t)((tap * 4 + nf) * 64 + olane) * 16) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
         }
     }
 }
@@ -2323,11 +2340,11 @@ extern "C" int mn_qd_pack_multi(const float* const* w, void* const* out_fwd, voi
             t.wsc_stride[i] = (wscale && wscale_stride) ? wscale_stride[k] : 0;
             t.O[i] = (int)O[k]; t.C[i] = (int)Cin[k]; t.T[i] = (int)taps[k];
             t.blk0[i] = blk;
-            blk += (int)((O[k] / 64) * (Cin[k] / 64));          // one block per (64 o, 64 c) tile
+            blk += (int)((O[k] / 64) * (Cin[k] / 64)) * 4;          // four 16-row slices per (64 o, 64 c) tile
             if (taps[k] > max_t) max_t = (int)taps[k];
         }
         t.blk0[t.n] = blk;
-        const size_t lds = (size_t)64 * 64 * max_t * 2;
+        const size_t lds = (size_t)QD_PACK_ROWS * 64 * max_t * 2;
         raise_lds_limit((const void*)k_qd_pack_multi, lds);
         mn_set_last_kernel("k_qd_pack_multi");
         hipLaunchKernelGGL(k_qd_pack_multi, dim3((unsigned)blk), dim3(QD_PACK_THREADS), lds, s, t);
