@@ -21,6 +21,7 @@ spawns on itself at N = 1 (separate passes: FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA
 domain combined with --pmc; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) -- `--no-pmc` skips them (traffic null).
 """
 import argparse
+import re
 import collections
 import csv
 import glob
@@ -430,6 +431,8 @@ PMC_PASSES = [("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GR
 
 def _kname(full):
     k = full.replace("void ", "").split("(")[0]
+    # k_pwb's fourth template argument (UP: upstream sums ride along) defaults to 0 and is left out of the name the library reports (mn_last_kernel) when it is 0
+    k = re.sub(r"^(k_pwb<\d+, \d+, \d+), 0>$", r"\1>", k)
     return k
 
 

@@ -578,6 +578,13 @@ int mn_conv2d_bwd_bnh_up_splits(const mn_conv_geom* g, const mn_wq* wq, int pool
 int mn_conv2d_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums,
                          int training, const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
                          const uint8_t* up_h, const float* up_chan, double* up_part, mn_stream_t stream);
+/* ... and when the block in front is a 3x3 / padding-1 BatchNorm+sign block (models/nin_gc.py:62-147: layers 4 | 5 and 7 | 8): its stash offset depends on the pixel's
+ * border class, so up_chan = its [17][C] constants (rows 8..16: nnz of the nine classes, mn_qconv_bnsign_stash_chan_rows == 17) and the dx waves run mn_bnh_bwd_sums'
+ * test on acc = 2 h - nnz(pixel) itself.  Un-pooled consumers, W a power of two >= 8; splits: mn_conv2d_bwd_bnh_up9_splits (0: not covered). */
+int mn_conv2d_bwd_bnh_up9_splits(const mn_conv_geom* g, const mn_wq* wq, int64_t up_k);
+int mn_conv2d_bwd_bnh_up9(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
+                          const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const uint8_t* up_h, const float* up_chan,
+                          double* up_part, mn_stream_t stream);
 /* (the k-bit counterparts of the *_up call: mn_conv2d_bwd_codes_up / mn_conv2d_bwd_qa_up below) */
 /* The same one-launch backward for the k-bit (DoReFa) blocks, wqaq/dorefa/quantize.py:36-46, 107-122 + autograd's conv backward (same geometry, same two queries
  * with pooled = 0, same workspace):

@@ -124,6 +124,8 @@ PROTOTYPES = {
     "mn_conv2d_bwd_bnh_up_splits": (_I, [_G, _W, _I, _L]),
     "mn_conv2d_bwd_bnh_up": (_I, [_G, _W, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P]),
     "mn_bnh_bwd_sums_final": (_I, [_P, _I, _L, _L, _L, _L, _P, _P, _P, _P]),
+    "mn_conv2d_bwd_bnh_up9_splits": (_I, [_G, _W, _L]),
+    "mn_conv2d_bwd_bnh_up9": (_I, [_G, _W, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P]),
     "mn_conv2d_bwd_codes": (_I, [_G, _W, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_conv2d_bwd_qa": (_I, [_G, _W, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "mn_conv2d_bwd_codes_up": (_I, [_G, _W, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P, _I, _P, _P]),

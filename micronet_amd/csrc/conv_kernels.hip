@@ -875,6 +875,19 @@ extern "C" int mn_conv2d_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, cons
     if (!wq || !da || !h || !chan || !sums || !w || !x || !dx || !dw || !up_h || !up_chan || !up_part) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_bnh_up: null tensor");
     return pwb_bwd_bnh_up(g, wq, da, h, own, chan, sums, training, w, x, dx, dw, dbias, ws, ws_bytes, up_h, up_chan, up_part, (hipStream_t)stream);
 }
+extern "C" int mn_conv2d_bwd_bnh_up9_splits(const mn_conv_geom* g, const mn_wq* wq, int64_t up_k) {
+    if (check_geom(g, "mn_conv2d_bwd_bnh_up9_splits") != MN_OK) return 0;
+    if (up_k < 1 || up_k > 254 || !pwb_supported(g, wq, 0)) return 0;
+    return pwb_up9_splits(g);
+}
+extern "C" int mn_conv2d_bwd_bnh_up9(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums, int training,
+                                     const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const uint8_t* up_h,
+                                     const float* up_chan, double* up_part, mn_stream_t stream) {
+    int rc = check_geom(g, "mn_conv2d_bwd_bnh_up9");
+    if (rc) return rc;
+    if (!wq || !da || !h || !chan || !sums || !w || !x || !dx || !dw || !up_h || !up_chan || !up_part) MN_FAIL(MN_EINVAL, "mn_conv2d_bwd_bnh_up9: null tensor");
+    return pwb_bwd_bnh_up9(g, wq, da, h, chan, sums, training, w, x, dx, dw, dbias, ws, ws_bytes, up_h, up_chan, up_part, (hipStream_t)stream);
+}
 extern "C" int mn_conv2d_bwd_codes(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x_codes, int x_bits, float* dx, float* dw,
                                    float* dbias, void* ws, int64_t ws_bytes, mn_stream_t stream) {
     int rc = check_geom(g, "mn_conv2d_bwd_codes");

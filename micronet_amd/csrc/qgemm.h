@@ -66,6 +66,10 @@ int pwb_up_splits(const mn_conv_geom* g);
 int pwb_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const int8_t* own, const float* chan, const float* sums, int training,
                    const float* w, const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const uint8_t* up_h, const float* up_chan,
                    double* up_part, hipStream_t s);
+int pwb_up9_splits(const mn_conv_geom* g);
+int pwb_bwd_bnh_up9(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums, int training, const float* w,
+                    const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const uint8_t* up_h, const float* up_chan, double* up_part,
+                    hipStream_t s);
 int pwb_bwd_plain_up(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x, int x_bits, float* dx, float* dw, float* dbias, void* ws,
                      int64_t ws_bytes, const void* up_stash, const float* up_chan, int up_quant, double* up_part, hipStream_t s);
 int pwb_bwd_qa_up(const mn_conv_geom* g, const mn_wq* wq, const float* dq, const void* stash, const float* chan, const float* sums, int out_bits, int quant, int training,

@@ -22,6 +22,8 @@
 //               also form the per-channel sums of its BatchNorm backward -- sum dz and sum dz h with dz = dx [hlo <= h <= hhi] from the upstream block's byte stash,
 //               staged through LDS by the producers like the input codes (1 B per element) -- and leave them as the partials k_bns_final_bwd reads: the upstream
 //               block's own pass over (d a, h) (k_bnh_partial: 5 B per element) is not launched (mn_conv2d_bwd_bnh_up / mn_bnh_bwd_sums_final).
+//   UP 3        UP 1 behind a 3x3 / padding-1 block (models/nin_gc.py: layers 4 | 5 and 7 | 8): the stash's offset nnz depends on the pixel's border class (chan rows
+//               8..16, common.h: StashNnz), so the pass test runs on acc = 2 h - nnz(pixel) itself -- k_bnh_partial<0>'s arithmetic (mn_conv2d_bwd_bnh_up9).
 //   UP 2        the same for a k-bit (DoReFa) block in front: this dx is its d q; dz = clip-STE(dx) [ReLU / clamp masks of the upstream 16-bit stash, k_qa_partial's
 //               arithmetic] -- sum dz, sum dz zhat; k_qa_partial (6 B per element) is not launched (mn_conv2d_bwd_qa_up / mn_conv2d_bwd_codes_up / mn_qa_bwd_sums_final).
 // One barrier per step: barrier k publishes step k (buffer k & 1); the producers refill that buffer with step k + 2 only behind barrier k + 1, which both consumer
@@ -70,6 +72,7 @@ struct PwbParams {
     double* up_part;            // UP: [C][Z][2] partial sums {sum dz, sum dz zhat} of this launch's blocks (k_bns_final_bwd's layout, S = Z)
     float up_qs, up_qinv;       // UP 2: scale of the quantizer behind the upstream block, RN(1 / qs) (0: IEEE division)
     int up_quant;               // UP 2: this dx is w.r.t. the upstream block's QUANTISED output (the clip-STE applies)
+    int up_wsh, up_H, up_W;     // UP 3: log2 of the plane's width (a power of two >= 8), its height and width
 };
 
 // 16-byte slot swizzle of a plane row: conflict-free b128 row reads (16 rows of one fragment) AND transpose reads (4 consecutive rows = 256 contiguous bytes)
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
             const uint32_t Pc = (uint32_t)st * 32u + 16u * chf;
             const uint32_t nc = fd_div(Pc, p.fd_hw);
             S.cv = *reinterpret_cast<const u32x4*>(p.x + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
-            if (UP == 1) S.uv = *reinterpret_cast<const u32x4*>(p.up_h + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
+            if (UP == 1 || UP == 3) S.uv = *reinterpret_cast<const u32x4*>(p.up_h + (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff));
             if (UP == 2) {
                 const unsigned char* us = p.up_h + 2u * (nc * (uint32_t)p.C * HW + (Pc - nc * HW) + xoff);          // (plan: 4 N C HW < 2^32)
                 S.uv = *reinterpret_cast<const u32x4*>(us); S.uw = *reinterpret_cast<const u32x4*>(us + 16);
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                 *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{mn_pack_hi16(r2[0], r2[1]), mn_pack_hi16(r2[2], r2[3])};
             }
             *reinterpret_cast<u32x4*>(A + 3 * PLANE + cr * 48 + 16 * chf) = S.cv;
-            if (UP == 1) *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * 48 + 16 * chf) = S.uv;
+            if (UP == 1 || UP == 3) *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * 48 + 16 * chf) = S.uv;
             if (UP == 2) {
                 *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * PWB_UP2_ROW + 32 * chf) = S.uv;
                 *reinterpret_cast<u32x4*>(A + 3 * PLANE + PWB_CODES + cr * PWB_UP2_ROW + 32 * chf + 16) = S.uw;
@@ -406,6 +409,24 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                 qa_lo = r.lo; qa_hi = r.hi; qa_use = true;
             }
         }
+        // UP 3: the lane's upstream channel -- flip, the pass interval [L, U] of acc * flip as (mid, half): L <= u <= U <=> |u - mid| <= half, exact for the small
+        // integers u takes once the bounds are clamped to +-512 (|acc| <= 254); NaN bounds / an empty interval: half < 0, nothing passes -- and the nnz of the nine
+        // pixel classes.  Two elements per instruction (packed fp32): the dx waves set the pace of the un-pooled variants, a VALU instruction costs them 4 cycles.
+        typedef float pf2 __attribute__((vector_size(8)));
+        pf2 u9_fl2 = {0.f, 0.f}, u9_mid2 = {0.f, 0.f}, us1v = {0.f, 0.f}, ushv = {0.f, 0.f};
+        float u9_half = -1.f;
+        StashNnz u9;
+        u9.v0 = u9.v1 = u9.v2 = u9.v3 = u9.v4 = u9.v5 = u9.v6 = u9.v7 = u9.v8 = 0.f;
+        if (UP == 3) {
+            const int ch = chan_phys(p.in_map, g * 128 + 32 * wave + (lane & 31)), Cu = p.C;
+            const float fl = p.up_chan[Cu + ch], L = p.up_chan[2 * Cu + ch], U = p.up_chan[3 * Cu + ch];
+            const bool ok = L == L && U == U && fl == fl;
+            const float Lc = fmaxf(L, -512.f), Uc = fminf(U, 512.f);
+            const float mid = 0.5f * (Lc + Uc);
+            u9_half = ok ? 0.5f * (Uc - Lc) : -1.f;
+            u9_fl2 = pf2{fl, fl}; u9_mid2 = pf2{ok ? mid : 0.f, ok ? mid : 0.f};
+            u9 = stash_nnz_load(p.up_chan, Cu, ch);
+        }
         if (UP == 1) {
             const int ch = chan_phys(p.in_map, g * 128 + 32 * wave + (lane & 31)), Cu = p.C;
             const float fl = p.up_chan[Cu + ch], L = p.up_chan[2 * Cu + ch], U = p.up_chan[3 * Cu + ch], nnz = p.up_chan[7 * Cu + ch];
@@ -484,6 +505,34 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                                 ush += dz * (2.f * (float)hb - unnz);
                             }
                         }
+                    } else if (UP == 3) {          // k_bnh_partial<0>'s arithmetic with the nnz of each pixel's border class
+                        const u32x4 hq = *reinterpret_cast<const u32x4*>(A + 3 * PLANE + PWB_CODES + (32 * wave + cl) * 48 + 16 * phx);
+                        const uint32_t pix0 = (P - ni * HW) + 16u * (uint32_t)phx;          // first of the lane's 16 pixels inside its plane
+#pragma unroll
+                        for (int hc = 0; hc < 2; ++hc) {          // two runs of 8 pixels: each inside one row (W >= 8, a power of two)
+                            const uint32_t px = pix0 + 8u * hc;
+                            const int row = (int)(px >> p.up_wsh), col = (int)(px & (uint32_t)(p.up_W - 1));
+                            const float top = row == 0 ? 1.f : 0.f, bot = row == p.up_H - 1 ? 1.f : 0.f;
+                            const float m0 = u9.v3 + top * (u9.v0 - u9.v3) + bot * (u9.v6 - u9.v3);
+                            const float m1 = u9.v4 + top * (u9.v1 - u9.v4) + bot * (u9.v7 - u9.v4);
+                            const float m2 = u9.v5 + top * (u9.v2 - u9.v5) + bot * (u9.v8 - u9.v5);
+                            const float nfirst = col == 0 ? m0 : m1, nlast = col + 7 == p.up_W - 1 ? m2 : m1;
+#pragma unroll
+                            for (int q2 = 0; q2 < 2; ++q2) {
+                                const int q = 2 * hc + q2;
+                                const float dv[4] = {dq[q].x, dq[q].y, dq[q].z, dq[q].w};
+#pragma unroll
+                                for (int pr = 0; pr < 2; ++pr) {
+                                    const pf2 h2 = {(float)((hq[q] >> (16 * pr)) & 0xffu), (float)((hq[q] >> (16 * pr + 8)) & 0xffu)};
+                                    const pf2 nz2 = {(q2 == 0 && pr == 0) ? nfirst : m1, (q2 == 1 && pr == 1) ? nlast : m1};
+                                    const pf2 acc2 = (h2 + h2) - nz2;
+                                    const pf2 w2 = acc2 * u9_fl2 - u9_mid2;
+                                    const pf2 dz2 = {fabsf(w2[0]) <= u9_half ? dv[2 * pr] : 0.f, fabsf(w2[1]) <= u9_half ? dv[2 * pr + 1] : 0.f};
+                                    us1v += dz2;
+                                    ushv += dz2 * acc2;
+                                }
+                            }
+                        }
                     } else {          // UP 2: k_qa_partial's arithmetic on (this dx, the upstream 16-bit stash)
                         const unsigned char* hs = A + 3 * PLANE + PWB_CODES + (32 * wave + cl) * PWB_UP2_ROW + 32 * phx;
                         const u32x4 s0 = *reinterpret_cast<const u32x4*>(hs), s1 = *reinterpret_cast<const u32x4*>(hs + 16);
@@ -515,6 +564,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
         }
         __syncthreads();
         if (UP) {
+            if (UP == 3) { us1 = us1v[0] + us1v[1]; ush = ushv[0] + ushv[1]; }
             us1 += __shfl_xor(us1, 32, 64); ush += __shfl_xor(ush, 32, 64);          // the two pixel halves of the channel
             if (lane < 32) {
                 const int ch = chan_phys(p.in_map, g * 128 + 32 * wave + lane), Cu = p.C;
@@ -522,7 +572,7 @@ __global__ __launch_bounds__(768, 1) void k_pwb(const PwbParams p) {
                 const double d1 = (double)us1, da_ = (double)ush;
                 double* dstp = p.up_part + ((int64_t)ch * p.Z + z) * 2;
                 dstp[0] = d1;
-                if (UP == 1) {
+                if (UP == 1 || UP == 3) {
                     const double A_ = (double)p.up_chan[4 * Cu + ch], B_ = (double)p.up_chan[5 * Cu + ch];
                     dstp[1] = A_ * da_ + B_ * d1;          // zhat = A (2 h - nnz) + B
                 } else {
@@ -624,9 +674,13 @@ static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv
     p.quant = quant; p.qs = qs; p.qinv = mn_qa_inv(qs);
     p.up_h = up ? (const unsigned char*)up->h : nullptr; p.up_chan = up ? up->chan : nullptr; p.up_part = up ? up->part : nullptr;
     p.up_quant = up ? up->quant : 0; p.up_qs = (up && up->kind == 2) ? dorefa_scale(up->bits) : 1.f; p.up_qinv = mn_qa_inv(p.up_qs);
+    p.up_H = (int)g->H; p.up_W = (int)g->W; p.up_wsh = 0;
+    while ((1 << p.up_wsh) < p.up_W) ++p.up_wsh;
     const int bnh = mode == 1 ? (own ? 2 : 1) : mode;
     if (up) {
-        if (up->kind == 1 ? (mode != 1 || xenc || wide) : (up->kind != 2 || (mode != 3 && mode != 0) || !xenc || wide || up->bits < 1 || up->bits > 8))
+        if (up->kind == 1 ? (mode != 1 || xenc || wide) :
+            up->kind == 3 ? (mode != 1 || own || xenc || wide || g->W < 8 || (g->W & (g->W - 1))) :
+            (up->kind != 2 || (mode != 3 && mode != 0) || !xenc || wide || up->bits < 1 || up->bits > 8))
             MN_FAIL(MN_ENOTSUP, "%s: the upstream sums do not ride on this variant", what);
         if (!up->h || !up->chan || !up->part || (((uintptr_t)up->h) & 15) || (((uintptr_t)up->part) & 7)) MN_FAIL(MN_EINVAL, "%s: null / misaligned upstream operand", what);
         mn_set_last_kernel("k_pwb<%d, %d, %d, %d>", bnh, xenc, wide, up->kind);
@@ -634,10 +688,11 @@ static int pwb_run(const char* what, int mode, int xenc, int wide, const mn_conv
     mn_set_last_kernel("k_pwb<%d, %d, %d>", bnh, xenc, wide);
     {
         const double nx = (double)g->N * g->C * g->H * g->W, ny = (double)g->N * g->O * g->H * g->W;
-        mn_prof_bytes((mode == 1 ? (own ? 3.0 : 5.0) : (mode == 3 ? (wide ? 8.0 : 6.0) : 4.0)) * ny + (up ? 5.0 + up->kind : 5.0) * nx);
+        mn_prof_bytes((mode == 1 ? (own ? 3.0 : 5.0) : (mode == 3 ? (wide ? 8.0 : 6.0) : 4.0)) * ny + (up ? (up->kind == 2 ? 7.0 : 6.0) : 5.0) * nx);
     }
     mn_prof_begin(s);
-    if (up && bnh == 1) pwb_launch<1, 0, 0, 1>(pl, s);
+    if (up && up->kind == 3) pwb_launch<1, 0, 0, 3>(pl, s);
+    else if (up && bnh == 1) pwb_launch<1, 0, 0, 1>(pl, s);
     else if (up && bnh == 2) pwb_launch<2, 0, 0, 1>(pl, s);
     else if (up && bnh == 3) pwb_launch<3, 1, 0, 2>(pl, s);
     else if (up && bnh == 0) pwb_launch<0, 1, 0, 2>(pl, s);
@@ -667,6 +722,14 @@ int pwb_bwd_bnh_up(const mn_conv_geom* g, const mn_wq* wq, const float* da, cons
                    double* up_part, hipStream_t s) {
     const PwbUp up{1, up_h, up_chan, up_part, 0, 0};
     return pwb_run("mn_conv2d_bwd_bnh_up", 1, 0, 0, g, wq, da, h, own, chan, sums, training, 0, 1.f, 1.f, w, x, dx, dw, dbias, ws, ws_bytes, s, &up);
+}
+// the block in front is a 3x3 / padding-1 BatchNorm+sign block: up_chan = its [17][C] constants (rows 8..16: nnz of the nine pixel classes); un-pooled consumers only
+int pwb_up9_splits(const mn_conv_geom* g) { PwbPlan pl; return (plan_pwb(g, &pl) && g->W >= 8 && !(g->W & (g->W - 1))) ? pl.p.Z : 0; }
+int pwb_bwd_bnh_up9(const mn_conv_geom* g, const mn_wq* wq, const float* da, const uint8_t* h, const float* chan, const float* sums, int training, const float* w,
+                    const int8_t* x, float* dx, float* dw, float* dbias, void* ws, int64_t ws_bytes, const uint8_t* up_h, const float* up_chan, double* up_part,
+                    hipStream_t s) {
+    const PwbUp up{3, up_h, up_chan, up_part, 0, 0};
+    return pwb_run("mn_conv2d_bwd_bnh_up9", 1, 0, 0, g, wq, da, h, nullptr, chan, sums, training, 0, 1.f, 1.f, w, x, dx, dw, dbias, ws, ws_bytes, s, &up);
 }
 // the k-bit (DoReFa) counterparts: the block in front left a 16-bit stash; up_bits = the width of ITS output quantizer (= x_bits), up_quant: this dx is w.r.t. its codes
 int pwb_bwd_plain_up(const mn_conv_geom* g, const mn_wq* wq, const float* gy, const float* w, const void* x, int x_bits, float* dx, float* dw, float* dbias, void* ws,

@@ -1945,11 +1945,12 @@ class UpSums:
     path (a second consumer, a hook, a pooled gradient) fails the identity test and takes the ordinary pass: always correct, one streaming pass slower."""
     __slots__ = ("h", "chan", "k", "ready", "kind")
 
-    def __init__(self, h, chan, k, kind=1):          # kind 1: byte stash of a wbwtab block; 2: 16-bit stash of a k-bit (DoReFa) block (its `ready[0]` is the raw dq of a QGrad)
+    def __init__(self, h, chan, k, kind=1):          # kind 1: byte stash of a wbwtab block (3: behind a 3x3 conv -- nnz per border class); 2: 16-bit stash of a k-bit (DoReFa) block (its `ready[0]` is the raw dq of a QGrad)
         self.h, self.chan, self.k, self.ready, self.kind = h, chan, int(k), None, kind
 
 
 UP_SUMS_PLAIN = False          # (the k-bit hand-over also behind a plain gradient: tests only)
+UP_SUMS_3X3 = _os0.environ.get("MN_UP_SUMS_3X3", "1") != "0"          # (A/B: the hand-over behind a 3x3 block, k_pwb<1, 0, 0, 3>)
 UP_SUMS_FOLD = _os0.environ.get("MN_UP_SUMS", "1") != "0"          # (A/B and the equality test: MN_UP_SUMS=0 restores k_bnh_partial for every block)
 
 
@@ -2062,14 +2063,22 @@ class QConv2d(Function):
                     nb = int(_lib_().mn_conv2d_bwd_bnh_ws_bytes(C.byref(g)))
                     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=x.device)
                     up = getattr(ctx, "up_rec", None)
-                    splits = 0
+                    splits, up9 = 0, False
                     if up is not None and up.kind == 1 and UP_SUMS_FOLD and tuple(up.h.shape) == tuple(x.shape) and up.h.data_ptr() % 16 == 0 and up.chan.shape[0] == 8:
                         splits = int(_lib_().mn_conv2d_bwd_bnh_up_splits(C.byref(g), _ref(wd), 1 if pool else 0, up.k))
+                    elif up is not None and up.kind == 3 and UP_SUMS_FOLD and UP_SUMS_3X3 and not pool and tuple(up.h.shape) == tuple(x.shape) and up.h.data_ptr() % 16 == 0 and \
+                            up.chan.shape[0] == 17:          # a 3x3 block in front: the stash offset per pixel class (k_pwb<1, 0, 0, 3>)
+                        splits = int(_lib_().mn_conv2d_bwd_bnh_up9_splits(C.byref(g), _ref(wd), up.k))
+                        up9 = splits > 0
                     if splits > 0:          # ... and the sums of the BatchNorm backward of the block in front (this dx is its d a)
                         part = torch.empty(x.shape[1] * splits * 2, dtype=torch.float64, device=x.device)
                         with _span(g, 1, (3 if pool else 5) * r["h"].numel() + 6 * dx.numel()):
-                            _call("mn_conv2d_bwd_bnh_up", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["own"]) if pool else None, _p(r["chan"]), _p(r["sums"]),
-                                  r["training"], _p(wq), _p(x), _p(dx), _p(dw), _p(db), _p(ws), nb, _p(up.h), _p(up.chan), _p(part), _s())
+                            if up9:
+                                _call("mn_conv2d_bwd_bnh_up9", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["chan"]), _p(r["sums"]), r["training"], _p(wq), _p(x),
+                                      _p(dx), _p(dw), _p(db), _p(ws), nb, _p(up.h), _p(up.chan), _p(part), _s())
+                            else:
+                                _call("mn_conv2d_bwd_bnh_up", C.byref(g), _ref(wd), _p(r["da"]), _p(r["h"]), _p(r["own"]) if pool else None, _p(r["chan"]), _p(r["sums"]),
+                                      r["training"], _p(wq), _p(x), _p(dx), _p(dw), _p(db), _p(ws), nb, _p(up.h), _p(up.chan), _p(part), _s())
                         up.ready = (dx, dx._version, part, splits)
                     else:
                         with _span(g, 1, (3 if pool else 5) * r["h"].numel() + 5 * dx.numel()):
@@ -2244,8 +2253,8 @@ class ConvBNSign(Function):
         ctx.fold_pool_ok = FOLD_POOL_INTO_CONV_BWD and ctx.fold_ok and bool(_lib_().mn_conv2d_bnh_pool_supported(C.byref(g), _ref(wd)))      # ... and from the POOLED gradient
         out = SignTensor(a)
         ctx.up_rec = None
-        if chan.shape[0] == 8 and UP_SUMS_FOLD:          # (pointwise block: one nnz per channel) -- the next block's backward may form this block's sums (UpSums)
-            ctx.up_rec = out._mn_up = UpSums(h, chan, wq.shape[1] * wq.shape[2] * wq.shape[3])
+        if chan.shape[0] in (8, 17) and UP_SUMS_FOLD:          # (8: pointwise block, one nnz per channel; 17: 3x3 block, nnz per border class) -- the next block's
+            ctx.up_rec = out._mn_up = UpSums(h, chan, wq.shape[1] * wq.shape[2] * wq.shape[3], kind=1 if chan.shape[0] == 8 else 3)          # backward may form this block's sums
         return out
 
     @staticmethod

@@ -552,7 +552,64 @@ def _check_pwb(be, g, wq, d_da, h8, a8, chan, sums, training, dW, dA, dx_ref, dw
     assert np.max(np.abs(ref[0] - e1) / m1) <= 2e-6 and np.max(np.abs(ref[1] - e2) / m2) <= 2e-6
     assert np.all(got[:, 1] == 0) and np.all(got[:, 3] == 0) and np.all(got[:, 4] == 0)
     assert np.array_equal(be.to_host(dg_up), be.to_host(s_up)[1]) and np.array_equal(be.to_host(db_up), be.to_host(s_up)[0])
+    if a8 is None and W_ >= 8 and (W_ & (W_ - 1)) == 0:
+        _check_pwb_up9(be, g, wq, d_da, h8, chan, sums, training, dW, dA, dx3, dw3, nb, x_shape, w_shape, Oc)
     _check_pwb.count = getattr(_check_pwb, "count", 0) + 1
+
+
+def _check_pwb_up9(be, g, wq, d_da, h8, chan, sums, training, dW, dA, dx3, dw3, nb, x_shape, w_shape, Oc):
+    """mn_conv2d_bwd_bnh_up9 (k_pwb<1, 0, 0, 3>): the block in front is a 3x3 / padding-1 BatchNorm+sign block -- [17][C] constants, the stash offset nnz per border
+    class of the pixel.  dx / dw bit-identical to the plain launch; the finished sums against mn_bnh_bwd_sums on (dx, upstream stash) and an fp64 evaluation."""
+    N_, Cin, H_, W_ = x_shape
+    K_up = 144
+    splits = int(be.lib.mn_conv2d_bwd_bnh_up9_splits(C.byref(g), C.byref(wq), K_up))
+    assert splits > 0 and int(be.lib.mn_conv2d_bwd_bnh_up9_splits(C.byref(g), C.byref(wq), 255)) == 0
+    r = np.random.default_rng(4321 + Cin + N_ + W_)
+    # nnz of the nine classes: the full count in the middle, fewer taps at the borders (what k_row_nnz9 leaves: any non-negative integers serve the arithmetic)
+    full = r.integers(K_up // 2, K_up + 1, Cin)
+    nnz9 = np.stack([np.floor(full * f).astype(np.int64) for f in (4 / 9, 6 / 9, 4 / 9, 6 / 9, 1.0, 6 / 9, 4 / 9, 6 / 9, 4 / 9)]).astype(F)       # [9][C]
+    rc = np.where(np.arange(H_) == 0, 0, np.where(np.arange(H_) == H_ - 1, 2, 1))
+    cc = np.where(np.arange(W_) == 0, 0, np.where(np.arange(W_) == W_ - 1, 2, 1))
+    cls = 3 * rc[:, None] + cc[None, :]                                       # [H][W]
+    nnz_px = nnz9[cls.reshape(-1)].reshape(H_, W_, Cin).transpose(2, 0, 1)[None]      # [1][C][H][W]
+    up_h = np.floor(r.random(x_shape) * (nnz_px + 1)).astype(np.uint8)
+    flip = np.where(r.random(Cin) < 0.5, -1.0, 1.0).astype(F)
+    Lc, Uc = -np.floor(r.random(Cin) * 40).astype(F), np.floor(r.random(Cin) * 40).astype(F)
+    Lc[1], Uc[1] = 5.0, -5.0                      # an empty interval
+    Lc[2], Uc[2] = -1e9, 1e9                      # everything passes
+    Lc[3] = np.nan                                # a poisoned channel: nothing passes
+    up_chan = np.zeros((17, Cin), F)
+    up_chan[1], up_chan[2], up_chan[3] = flip, Lc, Uc
+    up_chan[4], up_chan[5], up_chan[6], up_chan[7] = (r.standard_normal(Cin) * 0.05).astype(F), (r.standard_normal(Cin) * 0.3).astype(F), 1.0, -1.0
+    up_chan[8:17] = nnz9
+    d_uh, d_uc = be.to_dev_u8(up_h), be.to_dev(up_chan)
+    ws, dx4, dw4, db4 = be.empty(nb // 4 + 4), be.empty(x_shape), be.empty(w_shape), be.empty(Oc)
+    part = be.empty(Cin * splits * 4 + 2)
+    be.call("mn_conv2d_bwd_bnh_up9", C.byref(g), C.byref(wq), be.ptr(d_da), be.ptr(h8), be.ptr(chan), be.ptr(sums), int(training), be.ptr(dW), be.ptr(dA), be.ptr(dx4),
+            be.ptr(dw4), be.ptr(db4), be.ptr(ws), nb, be.ptr(d_uh), be.ptr(d_uc), be.ptr(part), be.stream)
+    assert be.lib.mn_last_kernel().decode() == "k_pwb<1, 0, 0, 3>"
+    assert np.array_equal(be.to_host(dx4), be.to_host(dx3)) and np.array_equal(be.to_host(dw4), be.to_host(dw3))
+    s_up, dg_up, db_up = be.empty((2, Cin)), be.empty(Cin), be.empty(Cin)
+    be.call("mn_bnh_bwd_sums_final", be.ptr(part), splits, N_, Cin, H_, W_, be.ptr(dg_up), be.ptr(db_up), be.ptr(s_up), be.stream)
+    s_ref, dg_ref, db_ref2 = be.empty((2, Cin)), be.empty(Cin), be.empty(Cin)
+    ws2 = be.empty(int(be.lib.mn_bnsign_ws_floats(Cin)) + 2)
+    be.call("mn_bnh_bwd_sums", be.ptr(dx4), be.ptr(d_uh), None, be.ptr(d_uc), N_, Cin, H_, W_, be.ptr(dg_ref), be.ptr(db_ref2), be.ptr(s_ref), be.ptr(ws2), be.stream)
+    got, ref = be.to_host(s_up).astype(np.float64), be.to_host(s_ref).astype(np.float64)
+    dxh = be.to_host(dx4).astype(np.float64)
+    acc = 2.0 * up_h.astype(np.float64) - nnz_px
+    u = acc * flip.reshape(1, -1, 1, 1)
+    with np.errstate(invalid="ignore"):
+        mask = (u >= Lc.reshape(1, -1, 1, 1)) & (u <= Uc.reshape(1, -1, 1, 1))
+    dz = np.where(mask, dxh, 0.0)
+    zh = acc * up_chan[4].astype(np.float64).reshape(1, -1, 1, 1) + up_chan[5].astype(np.float64).reshape(1, -1, 1, 1)
+    e1, e2 = dz.sum(axis=(0, 2, 3)), (dz * zh).sum(axis=(0, 2, 3))
+    m1, m2 = np.abs(dz).sum(axis=(0, 2, 3)) + 1e-30, np.abs(dz * zh).sum(axis=(0, 2, 3)) + 1e-30
+    e_got = (np.max(np.abs(got[0] - e1) / m1), np.max(np.abs(got[1] - e2) / m2))
+    assert e_got[0] <= 2e-6 and e_got[1] <= 2e-6, ("k_pwb<UP 3> upstream sums", e_got)
+    assert np.max(np.abs(ref[0] - e1) / m1) <= 2e-6 and np.max(np.abs(ref[1] - e2) / m2) <= 2e-6
+    assert np.all(got[:, 1] == 0) and np.all(got[:, 3] == 0)
+    assert np.array_equal(be.to_host(dg_up), be.to_host(s_up)[1]) and np.array_equal(be.to_host(db_up), be.to_host(s_up)[0])
+    _check_pwb_up9.count = getattr(_check_pwb_up9, "count", 0) + 1
 
 
 def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, training=True, seed=0, pooled=False, stash=False, padding=0, **_):
@@ -1406,6 +1463,11 @@ PWB_CASES = [
     dict(x_shape=(1, 128, 8, 8), w_shape=(128, 128, 1, 1), bias=False),                      # one group, 2 steps
     dict(x_shape=(5, 512, 4, 8), w_shape=(512, 128, 1, 1), groups=4, in_shuffle=4),          # 5 steps, four groups
 ]
+# planes 16 and 32 pixels wide (un-pooled only): the border classes of mn_conv2d_bwd_bnh_up9 inside a lane's run of 16 pixels
+PWB_CASES_WIDE = [
+    dict(x_shape=(1, 128, 4, 16), w_shape=(128, 128, 1, 1)),
+    dict(x_shape=(1, 128, 2, 32), w_shape=(128, 128, 1, 1), bias=False),
+]
 
 
 def check_pwb(be, pooled_too=True):
@@ -1415,7 +1477,11 @@ def check_pwb(be, pooled_too=True):
         check_qconv_bnsign(be, seed=410 + i, stash=True, training=False, **case)
         if pooled_too:
             check_qconv_bnsign(be, seed=420 + i, stash=True, pooled=True, **case)
-    assert getattr(_check_pwb, "count", 0) - before == len(PWB_CASES) * (3 if pooled_too else 2), "k_pwb did not take these geometries"
+    before9 = getattr(_check_pwb_up9, "count", 0)
+    for i, case in enumerate(PWB_CASES_WIDE):
+        check_qconv_bnsign(be, seed=430 + i, stash=True, **case)
+    assert getattr(_check_pwb, "count", 0) - before == len(PWB_CASES) * (3 if pooled_too else 2) + len(PWB_CASES_WIDE), "k_pwb did not take these geometries"
+    assert getattr(_check_pwb_up9, "count", 0) - before9 == len(PWB_CASES_WIDE) and getattr(_check_pwb_up9, "count", 0) >= len(PWB_CASES_WIDE) + 2 * len(PWB_CASES)
 
 
 def check_wgrad_spec(be):

@@ -536,6 +536,9 @@ def test_upstream_sums_ride_on_the_next_blocks_backward(monkeypatch, scheme, kw,
     monkeypatch.setattr(ops, "_call", real)
     ups = {on: sum(calls[on].get(c, 0) for c in up_call) for on in (True, False)}
     # nin_gc (models/nin_gc.py:18-59): the consumer is a pointwise block k_pwb covers, the block in front left a byte / 16-bit stash and is not pooled
+    if scheme == "wbwtab":          # + the two pointwise blocks behind a 3x3 block (layers 4 | 5, 7 | 8: mn_conv2d_bwd_bnh_up9)
+        assert calls[True].get("mn_conv2d_bwd_bnh_up9", 0) == 2 and calls[False].get("mn_conv2d_bwd_bnh_up9", 0) == 0, calls[True]
+        ups[True] += 2
     assert ups[True] >= 2 and calls[True].get(final_call, 0) == ups[True], calls[True]
     assert ups[False] == 0 and calls[False].get(final_call, 0) == 0, calls[False]
     gscale = max(float(g.abs().max()) for g in res[False].values())
