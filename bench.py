@@ -407,6 +407,14 @@ def section(workload, m, args, world, pmc):
                            "bytes_per_launch": int(d["bytes"] / d["launches"]),
                            "avg_launch_us": round(1000.0 * d["ms"] / d["launches"], 2), "launches": d["launches"],
                            "timing": "HIP events on the launch stream around every launch, %d eager steps after the timed region" % ks}
+        # every instantiation of the dominant kernel's template together (k_pwb<BNH, XENC, WIDE, UP> is one source kernel: the pooled / un-pooled / upstream-sums
+        # variants of a net's pointwise layers appear as separate rows): designed bytes of all their launches over the sum of their HIP-event durations
+        stem = dom.split("<")[0]
+        fam = {k: v for k, v in agg.items() if k.split("<")[0] == stem}
+        if len(fam) > 1 and not mfma_bound:
+            fb, fm, fl = sum(v["bytes"] for v in fam.values()), sum(v["ms"] for v in fam.values()), sum(v["launches"] for v in fam.values())
+            out["roofline"]["template_family"] = {"kernel": stem + "<*>", "instantiations": sorted(fam), "launches": fl, "avg_launch_us": round(1000.0 * fm / fl, 2),
+                                                  "achieved": round(fb / (fm * 1e-3) / 1e9, 1), "frac": round(fb / (fm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out["kernels"] = {k: {"ms_per_step": round(v["ms"] / ks, 4), "launches_per_step": v["launches"] / ks,
                               "avg_us": round(1000.0 * v["ms"] / v["launches"], 1),
                               "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
@@ -534,6 +542,8 @@ def compact_roofline(r):
             "mfma_issued_frac", "hbm_GBps")
     out = {k: r[k] for k in keep if k in r}
     out["timing"] = "HIP events on the launch stream"
+    if "template_family" in r:          # all instantiations of the dominant kernel's template together (short form)
+        out["template_family"] = {k: r["template_family"][k] for k in ("kernel", "launches", "avg_launch_us", "achieved", "frac")}
     if r.get("traffic") is not None:
         out["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE(x2 gfx950)+WRITE_SIZE"
     return out
@@ -597,6 +607,8 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
         detail["cpu_baselines"] = cpu_more
         if "c1_b128" in cpu_more:                            # BASELINE.json configs[0]: nin_gc DoReFa W8A8, batch 128, CPU reference path (wqaq/dorefa/main.py:135,171,189-190)
             out["cpu_baseline_c1_b128"] = {k: cpu_more["c1_b128"][k] for k in ("value", "unit", "cores", "kind", "batch", "sample") if k in cpu_more["c1_b128"]}
+            if "sample" in out["cpu_baseline_c1_b128"]:          # (the long form stays in the detail file: the line is bounded)
+                out["cpu_baseline_c1_b128"]["sample"] = out["cpu_baseline_c1_b128"]["sample"].split(",")[0].replace(" of the same train step", "") + ", as cpu_baseline"
         out["cpu_values"] = {k: v["value"] for k, v in cpu_more.items() if "value" in v}
     if dp1:
         out["dp_single_rank"] = detail["dp_single_rank"] = dp1
