@@ -1470,18 +1470,27 @@ PWB_CASES_WIDE = [
 ]
 
 
-def check_pwb(be, pooled_too=True):
-    before = getattr(_check_pwb, "count", 0)
+def check_pwb(be, pooled_too=True, light=False):
+    """light (the CPU emulator, where a case takes ~20 s): every geometry once and every mode once -- case 0 training, case 1 eval, case 2 pooled -- instead of the full
+    cross product the GPU runs."""
+    before, before9 = getattr(_check_pwb, "count", 0), getattr(_check_pwb_up9, "count", 0)
+    runs = 0
     for i, case in enumerate(PWB_CASES):
-        check_qconv_bnsign(be, seed=400 + i, stash=True, **case)
-        check_qconv_bnsign(be, seed=410 + i, stash=True, training=False, **case)
-        if pooled_too:
-            check_qconv_bnsign(be, seed=420 + i, stash=True, pooled=True, **case)
-    before9 = getattr(_check_pwb_up9, "count", 0)
+        modes = [("train", i == 0), ("eval", i == 1), ("pooled", i == 2)] if light else [("train", True), ("eval", True), ("pooled", pooled_too)]
+        for mode, on in modes:
+            if not on:
+                continue
+            runs += 1
+            if mode == "train":
+                check_qconv_bnsign(be, seed=400 + i, stash=True, **case)
+            elif mode == "eval":
+                check_qconv_bnsign(be, seed=410 + i, stash=True, training=False, **case)
+            else:
+                check_qconv_bnsign(be, seed=420 + i, stash=True, pooled=True, **case)
     for i, case in enumerate(PWB_CASES_WIDE):
         check_qconv_bnsign(be, seed=430 + i, stash=True, **case)
-    assert getattr(_check_pwb, "count", 0) - before == len(PWB_CASES) * (3 if pooled_too else 2) + len(PWB_CASES_WIDE), "k_pwb did not take these geometries"
-    assert getattr(_check_pwb_up9, "count", 0) - before9 == len(PWB_CASES_WIDE) and getattr(_check_pwb_up9, "count", 0) >= len(PWB_CASES_WIDE) + 2 * len(PWB_CASES)
+    assert getattr(_check_pwb, "count", 0) - before == runs + len(PWB_CASES_WIDE), "k_pwb did not take these geometries"
+    assert getattr(_check_pwb_up9, "count", 0) - before9 >= len(PWB_CASES_WIDE) + (2 if light else 2 * len(PWB_CASES)), "mn_conv2d_bwd_bnh_up9 did not run on the un-pooled cases"
 
 
 def check_wgrad_spec(be):

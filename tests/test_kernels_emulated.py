@@ -314,7 +314,7 @@ def test_conv_backward_with_bn_and_maxpool_folded_in(be):
 
 def test_pointwise_block_backward_in_one_kernel(be):
     """mn_conv2d_bwd_bnh (k_pwb): backward-data + backward-weight of the binary block from ONE read of (da, h), pooled and unpooled, against the two-kernel path."""
-    K.check_pwb(be)
+    K.check_pwb(be, light=True)
 
 
 def test_kbit_block_backward_in_one_kernel(be):
