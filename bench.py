@@ -194,8 +194,16 @@ def measure(workload, args, world, rank, device):
     from micronet_amd.train import GraphedTrainStep, synth_batch
     model, opt = build(workload, device)
     dp.broadcast_parameters(model)
-    if dp.active():
-        dp.sync_observers(model)          # IAO activation / QuantAdd ranges over the global batch (SURVEY 8e ii); no-op for DoReFa / wbwtab
+
+    def dp_buffers(mdl):
+        # IAO activation / QuantAdd ranges: reduced over the global batch before use (default, SURVEY 8e ii: one blocking collective per quantizer; no-op for DoReFa /
+        # wbwtab) or -- MN_DP_OBSERVERS=replica -- the reference's nn.DataParallel semantics: per-rank ranges, rank 0's buffers broadcast once per step (dp.ReplicaBuffers)
+        if dp.active():
+            if os.environ.get("MN_DP_OBSERVERS", "global") == "replica":
+                dp.replica_buffers(mdl)
+            else:
+                dp.sync_observers(mdl)
+    dp_buffers(model)
     x, y = synth_batch(args.batch, seed=1234 + rank, device=device)
 
     def barrier():
@@ -215,8 +223,7 @@ def measure(workload, args, world, rank, device):
             graphed = None
             model, opt = build(workload, device)
             dp.broadcast_parameters(model)
-            if dp.active():
-                dp.sync_observers(model)
+            dp_buffers(model)
     if graphed is None:
         sync = dp.GradSync(model)
 
@@ -329,10 +336,19 @@ def dp_single_rank(workloads, args, device):
                           **({"graph_segments": m["segments"]} if m.get("segments") else {}), **({"allreduce_us": m["dp_info"]["allreduce_us"], "two_buckets": m["dp_info"]["two_buckets"]} if m.get("dp_info") else {})}
             except Exception as e:          # noqa: BLE001
                 out[w] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+        # the IAO workloads once more with the reference's DataParallel buffer semantics (MN_DP_OBSERVERS=replica): no collective inside forward, one flat broadcast per step
+        os.environ["MN_DP_OBSERVERS"] = "replica"
+        for w in [w_ for w_ in workloads if WORKLOADS[w_][1].endswith("iao")]:
+            try:
+                m = measure(w, a, 1, 0, device)
+                out[w + "_replica"] = {"value": round(args.batch * args.steps / m["dt"], 1), "ms_per_step": round(1000.0 * m["dt"] / args.steps, 3), "graph_segments": m.get("segments", 0)}
+            except Exception as e:          # noqa: BLE001
+                out[w + "_replica"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
     except Exception as e:          # noqa: BLE001 -- a reported extra: the line must survive it
         out["error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
     finally:
         os.environ.pop("MN_DP_SINGLE", None)
+        os.environ.pop("MN_DP_OBSERVERS", None)
         if dist.is_initialized():
             dist.destroy_process_group()
     return out

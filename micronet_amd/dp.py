@@ -101,6 +101,46 @@ def broadcast_parameters(model, src=0, group=None):
         dist.broadcast(t.data, src=src, group=group)
 
 
+class ReplicaBuffers:
+    """The reference's own data-parallel semantics for module BUFFERS -- IAO observer ranges, scales and zero points, BatchNorm running statistics
+    (wqaq/iao/main.py:496-500: ``nn.DataParallel`` re-creates the replicas from the module on device 0 in every forward, so each replica updates and uses its buffers from
+    ITS shard of the batch and only device 0's survive the step): no collective inside forward; once per step, next to the gradient all-reduce, rank 0's floating-point
+    buffers are broadcast as ONE flat tensor.  The alternative to ``sync_observers`` (every activation range reduced over the global batch before it is used: bit-identical
+    to one process on the concatenated batch, one blocking collective per quantizer -- 30 per resnet18 step)."""
+
+    def __init__(self, model, group=None, src=0):
+        self.group, self.src = group, src
+        self.bufs = [b for b in model.buffers() if b.is_floating_point() and b.numel() > 0]
+        self.flat = None
+        if self.bufs:
+            dev = self.bufs[0].device
+            self.flat = torch.empty(sum(b.numel() for b in self.bufs), dtype=torch.float32, device=dev)
+            self.views, o = [], 0
+            for b in self.bufs:
+                self.views.append(self.flat[o:o + b.numel()].view(b.shape))
+                o += b.numel()
+            self._all_f32 = all(b.dtype == torch.float32 for b in self.bufs)
+        model._mn_replica_buffers = self
+
+    def exchange(self):
+        """pack -> broadcast from rank 0 -> unpack (three launches and one small collective; a no-op without a process group)."""
+        if self.flat is None or not active(self.group):
+            return
+        if self._all_f32:
+            torch.cat([b.detach().reshape(-1) for b in self.bufs], out=self.flat)
+        else:
+            torch.cat([b.detach().to(torch.float32).reshape(-1) for b in self.bufs], out=self.flat)
+        dist.broadcast(self.flat, src=self.src, group=self.group)
+        with torch.no_grad():
+            torch._foreach_copy_([b.detach() for b in self.bufs], self.views)
+
+
+def replica_buffers(model, group=None):
+    """Switch ``model`` to the reference's DataParallel buffer semantics (``ReplicaBuffers``) and make sure no observer reduces its range over the ranks."""
+    sync_observers(model, group, enable=False)
+    return ReplicaBuffers(model, group)
+
+
 def train_step_dp(model, optimizer, sync, data, target):
     """``train_step`` with the gradient exchange between backward and the optimizer step."""
     import torch.nn.functional as F
@@ -110,6 +150,9 @@ def train_step_dp(model, optimizer, sync, data, target):
     optimizer.zero_grad()
     loss.backward()
     sync.wait()
+    rb = getattr(model, "_mn_replica_buffers", None)
+    if rb is not None:
+        rb.exchange()
     optimizer.step()
     return loss, output
 

@@ -422,6 +422,9 @@ class GraphedTrainStep:
                 w2 = dist.all_reduce(self.flat2, group=self.group, async_op=True)
                 w1.wait()
                 w2.wait()
+            rb = getattr(self.model, "_mn_replica_buffers", None)
+            if rb is not None:          # the reference's DataParallel buffer semantics (dp.ReplicaBuffers): rank 0's observer / BatchNorm state, one flat broadcast per step
+                rb.exchange()
             self.graph_b.replay()
         else:
             self.graph_a.replay()

@@ -199,3 +199,56 @@ def test_graphed_step_refuses_host_tensors_on_every_rank_alike():
         assert p.exitcode == 0
     assert len(msgs) == 1 and "eager DP step" in msgs[0] and "cpu" in msgs[0], msgs
     assert loss == loss
+
+
+def _bn_net():
+    torch.manual_seed(5)
+    return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 10))
+
+
+def _replica_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from micronet_amd import dp
+    from micronet_amd.train import make_optimizer, synth_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = _bn_net()
+    dp.broadcast_parameters(model)
+    rb = dp.replica_buffers(model)
+    sync = dp.GradSync(model)
+    opt = make_optimizer(model, 0.01, 0.0)
+    x, y = synth_batch(8)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    # what rank 0's BatchNorm sees in step 1 (its own shard, the common start weights): the running mean every rank must hold after the step
+    with torch.no_grad():
+        ref = _bn_net()
+        y0 = ref[0](x[0:4])
+        want = 0.9 * torch.zeros(8) + 0.1 * y0.mean(dim=(0, 2, 3))
+    dp.train_step_dp(model, opt, sync, xs, ys)
+    got = model[1].running_mean.clone()
+    for _ in range(2):
+        dp.train_step_dp(model, opt, sync, xs, ys)
+    state = [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())]
+    gathered = [None, None]
+    dist.all_gather_object(gathered, state)
+    if rank == 1:
+        q.put(dict(step1_err=float((got - want).abs().max()), same=all(torch.equal(a.float(), b.float()) for a, b in zip(*gathered)), nbuf=len(rb.bufs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_buffers_follow_rank_zero():
+    """dp.ReplicaBuffers (the reference's nn.DataParallel semantics for buffers): after a step every rank holds rank 0's BatchNorm running statistics -- computed from
+    rank 0's shard -- and, with the gradient all-reduce, the same parameters."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got["same"] and got["nbuf"] == 2 and got["step1_err"] <= 1e-6, got

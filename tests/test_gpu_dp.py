@@ -11,6 +11,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import numpy as np
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
@@ -47,6 +48,28 @@ def _worker(rank, world, port, q, what):
         if rank == 0:
             q.put(({k: v.cpu().numpy().copy() for k, v in model.state_dict().items() if "activation_quantizer" in k},
                    [p.grad.cpu().numpy().copy() for p in model.parameters()]))
+    elif what == "replica":
+        # the reference's DataParallel buffer semantics (dp.ReplicaBuffers): no range collective in forward -- the graph-replayed step is ONE graph A, the ranks use
+        # their own shard's ranges within a step, rank 0's observer / BatchNorm state is what every rank holds after it
+        from micronet_amd.train import GraphedTrainStep
+        from micronet.compression.quantization.wqaq.iao import quantize as Q
+        torch.manual_seed(7)
+        m = Q.prepare(build_model("resnet18"), inplace=True, a_bits=4, w_bits=4, q_type=0, q_level=0).cuda().train()
+        dp.broadcast_parameters(m)
+        rb = dp.replica_buffers(m)
+        o = make_optimizer(m, 0.01, 1e-5)
+        g = GraphedTrainStep(m, o, xs, ys, warmup=2)
+        for _ in range(3):
+            loss = g.step()[0]
+        torch.cuda.synchronize()
+        g.finish()
+        sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+        gathered = [None, None]
+        dist.all_gather_object(gathered, sd)
+        if rank == 0:
+            bad = [k for k in gathered[0] if not torch.equal(gathered[0][k], gathered[1][k]) and not (torch.isnan(gathered[0][k]).all() and torch.isnan(gathered[1][k]).all())]
+            q.put(dict(segments=len(g.segments), synced=sum(int(getattr(mm, "_mn_sync", False)) for mm in m.modules()), bad=bad, loss=float(loss),
+                       nbuf=len(rb.bufs), flat=int(rb.flat.numel())))
     elif what.startswith("segmented"):
         # the graph-replayed data-parallel step of an IAO model (range collectives inside forward -> captured in segments) next to the eager DP step: learning rate 0
         # (parameters frozen, observers and BN statistics still move), so the two runs stay comparable step by step
@@ -240,3 +263,13 @@ def test_single_rank_dp_step_equals_the_plain_step():
     assert r["segments"][0] == 0 and r["segments"][1] >= 4 and r["dp"] == (False, True)
     assert r["bad"] == [], r["bad"][:5]
     assert r["perr"] <= 0.05 and all(abs(a - b) <= 2e-2 * max(1.0, abs(a)) for a, b in zip(*r["losses"])), r
+
+
+def test_replica_buffer_semantics_need_no_collective_in_forward():
+    """dp.replica_buffers (what nn.DataParallel does in wqaq/iao/main.py:496-500: every replica updates its buffers from its own shard, device 0's survive): the
+    graph-replayed resnet18 IAO step is one graph A (no segments, no synced observer), and after every step both ranks hold the same parameters AND the same buffers --
+    rank 0's observer ranges / scales / zero points and BatchNorm running statistics, handed over by one flat broadcast next to the gradient all-reduce."""
+    r = _run("replica")
+    assert r["segments"] == 0 and r["synced"] == 0, r
+    assert r["bad"] == [], r["bad"][:8]
+    assert r["nbuf"] > 50 and np.isfinite(r["loss"])
