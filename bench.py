@@ -627,7 +627,9 @@ def compose_line(primary, sec, also_secs, also_err, pmc_err, cpu, args, world, d
                 out["cpu_baseline_c1_b128"]["sample"] = out["cpu_baseline_c1_b128"]["sample"].split(",")[0].replace(" of the same train step", "") + ", as cpu_baseline"
         out["cpu_values"] = {k: v["value"] for k, v in cpu_more.items() if "value" in v}
     if dp1:
-        out["dp_single_rank"] = detail["dp_single_rank"] = dp1
+        detail["dp_single_rank"] = dp1
+        # the line carries the short form (images/s, ms per step, graph segments); bucket bytes / all-reduce times per workload are in the detail file
+        out["dp_single_rank"] = {w: ({k: v[k] for k in ("value", "ms_per_step", "graph_segments", "error") if k in v} if isinstance(v, dict) else v) for w, v in dp1.items()}
     for drop in ("window_ms", "step_level", "cpu_values", "dp_single_rank", "also"):      # the driver parses the LAST stdout line: never let it outgrow its reader again (round 3: 34 KB -> parsed null)
         if len(json.dumps(out)) + 64 <= MAX_LINE_BYTES:
             break

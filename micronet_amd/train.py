@@ -211,6 +211,12 @@ def pick_bucket_boundary(model):
     return None
 
 
+# Capture mode of every HIP-graph capture in this module: "thread_local" -- only THIS thread's unsafe calls invalidate a capture.  With a process group alive,
+# ProcessGroupNCCL's watchdog thread polls the events of finished collectives (hipEventQuery) on its own schedule; under the default "global" mode one such poll
+# while a capture is open is "operation not permitted when stream is capturing" and takes the process down (seen in bench.py's dp_single_rank leg, round 6).
+_CAPTURE_MODE = "thread_local"
+
+
 class GraphedTrainStep:
     """The training step of ``train_step`` captured ONCE in HIP graphs and replayed: ~150 kernel launches per nin_gc step
     become one ``hipGraphLaunch``, so the host never gates the GPU (the eager step spends as long in Python / ctypes /
@@ -289,7 +295,7 @@ class GraphedTrainStep:
         self._capturing = self.graph_a
         try:
             with torch.cuda.stream(cap):
-                self._capturing.capture_begin(pool=pool)
+                self._capturing.capture_begin(pool=pool, capture_error_mode=_CAPTURE_MODE)
                 try:
                     if self._segmented:
                         dp._segment_cut = lambda buf, group: self._cut(buf, group, pool)
@@ -329,7 +335,7 @@ class GraphedTrainStep:
                     p.grad = flat[off:off + p.numel()].view_as(p)
                     off += p.numel()
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode=_CAPTURE_MODE):
                 optimizer.step()
 
     def _fwd_bwd(self, mid=None):
@@ -375,7 +381,7 @@ class GraphedTrainStep:
         self._capturing.capture_end()
         self.graph_a = self._capturing
         self._capturing = torch.cuda.CUDAGraph()
-        self._capturing.capture_begin(pool=pool)
+        self._capturing.capture_begin(pool=pool, capture_error_mode=_CAPTURE_MODE)
 
     def _reduce_eager(self):
         if self.dp:
@@ -393,7 +399,7 @@ class GraphedTrainStep:
         self._capturing.capture_end()
         self.segments.append((self._capturing, buf, group))
         self._capturing = torch.cuda.CUDAGraph()
-        self._capturing.capture_begin(pool=pool)
+        self._capturing.capture_begin(pool=pool, capture_error_mode=_CAPTURE_MODE)
 
     def step(self):
         self.optimizer.refresh_hyper()        # lr / weight_decay edits of the training loop reach the captured Adam launch
