@@ -359,6 +359,18 @@ def _grad_terms():
     return int(_lib.get_lib().mn_dense_grad_terms())
 
 
+def dp_single_child(workloads, args):
+    """dp_single_rank in a process of its own: it brings up a process group (an RCCL communicator, its watchdog thread) next to HIP-graph captures -- whatever goes wrong
+    there must not cost the line of the run that asked for it."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dp-single-child", ",".join(workloads), "--batch", str(args.batch), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--master-port", str(args.master_port), "--no-pmc", "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:          # noqa: BLE001 -- a reported extra
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+
+
 def exact_terms_leg(workloads, args):
     """The ResNet workloads again with the EXACT three-term bf16 split of the fp32 gradient in the dense backward kernels (MN_GRAD_TERMS=3; the library reads the knob
     once per process: a child per workload): {workload: {"value", "ms_per_step", "grad_terms": 3}} -- reported beside the default two-term figures."""
@@ -687,6 +699,7 @@ def main():
     ap.add_argument("--detail", default=None, help="where the per-kernel tables / step_level / windows go (default gpurun_out/bench_detail.json)")
     ap.add_argument("--no-dp-single", action="store_true", help="skip the single-rank data-parallel leg (dp_single_rank: the N-GPU step's own cost measured on one rank)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dp-single-child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     primary = args.only or args.workload
@@ -730,6 +743,11 @@ def main():
     if args.pmc_child:
         pmc_child(args, device)
         return
+    if args.dp_single_child:          # (a child of the default run: the single-rank data-parallel leg in a process of its own)
+        res = dp_single_rank([w for w in args.dp_single_child.split(",") if w in WORKLOADS], args, device)
+        drain_c_stdio()          # (RCCL's version banner sits in C stdio: out before the line the parent parses)
+        print(json.dumps(res), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MN_DIST_BACKEND", "nccl")      # "gloo": functional check of the multi-rank path on one GPU
@@ -750,7 +768,7 @@ def main():
 
     dp1 = None
     if world == 1 and not args.only and not args.no_kernel_timing and not args.no_dp_single:
-        dp1 = dp_single_rank([w for w in (primary, "c3", "c4", "c5") if w == primary or w in m_also], args, device)
+        dp1 = dp_single_child([w for w in (primary, "c3", "c4", "c5") if w == primary or w in m_also], args)
 
     terms3 = None
     if world == 1 and not args.only and not args.no_kernel_timing and _grad_terms() != 3:
