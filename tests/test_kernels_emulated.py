@@ -306,10 +306,11 @@ def test_conv_backward_with_bn_and_maxpool_folded_in(be):
     """mn_conv2d_bwd_data_bnh_pool / mn_conv2d_bwd_weight_bnh_pool: the conv's backward forms dy from (pooled gradient, the block's own sign codes, h) -- the pool's
     first-maximum routing and the BatchNorm+sign backward in the operand load -- against the two-step path through mn_bnh_bwd_apply's full-size dy."""
     before = getattr(K.check_qconv_bnsign, "pool_fold_checked", 0)
-    for i, case in enumerate(K.WGRAD_SPEC_CASES):
+    for i, case in enumerate(K.WGRAD_SPEC_CASES):          # (the emulator runs every geometry once, eval mode on one of them; the GPU twin runs the cross product)
         K.check_qconv_bnsign(be, seed=320 + i, stash=True, pooled=True, **case)
-        K.check_qconv_bnsign(be, seed=330 + i, stash=True, pooled=True, training=False, **case)
-    assert getattr(K.check_qconv_bnsign, "pool_fold_checked", 0) - before == 6
+        if i == 1:
+            K.check_qconv_bnsign(be, seed=330 + i, stash=True, pooled=True, training=False, **case)
+    assert getattr(K.check_qconv_bnsign, "pool_fold_checked", 0) - before == 4
 
 
 def test_pointwise_block_backward_in_one_kernel(be):
