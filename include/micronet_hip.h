@@ -117,6 +117,11 @@ int mn_ternary_w_bwd_multi(const float* const* g, const float* const* w, float* 
 int mn_binary_w_fwd(float* w_inplace, float* qw, float* alpha, int64_t O, int64_t C, int64_t R, mn_stream_t stream);
 int mn_binary_w_bwd(const float* g, const float* w, const float* alpha, float* dw, int64_t O, int64_t K,
                     mn_stream_t stream);
+/* ... over n <= 32 weight tensors in ONE launch each way (wbwtab/quantize.py:98-102, 121-130 once per conv of the net: a W = 2 nin_gc step quantizes 7 of them):
+ * w[i] is [O[i]][C[i]][R[i]] (R = KH * KW <= 256) and is mutated in place like the single-tensor call; same arithmetic per tensor. */
+int mn_binary_w_fwd_multi(float* const* w, float* const* qw, float* const* alpha, const int64_t* O, const int64_t* C, const int64_t* R, int32_t n, mn_stream_t stream);
+int mn_binary_w_bwd_multi(const float* const* g, const float* const* w, float* const* alpha, float* const* dw, const int64_t* O, const int64_t* C, const int64_t* R,
+                          int32_t n, mn_stream_t stream);
 
 /* ------------------------------------------------------------------ IAO
  * wqaq/iao/quantize.py */

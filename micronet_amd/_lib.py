@@ -70,6 +70,8 @@ PROTOTYPES = {
     "mn_ternary_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "mn_binary_w_fwd": (_I, [_P, _P, _P, _L, _L, _L, _P]),
     "mn_binary_w_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P]),
+    "mn_binary_w_fwd_multi": (_I, [_P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "mn_binary_w_bwd_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "mn_iao_observe_ws_floats": (_L, [_L, _L]),
     "mn_iao_observe": (_I, [_P, _L, _L, _I, _I, _D, _P, _P, _P, _P]),
     "mn_iao_qparams": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P]),

@@ -743,13 +743,11 @@ extern "C" int mn_ternary_w_bwd(const float* g, const float* w, const float* sta
 // ------------------------------------------------------------------------------------------------
 // Binary weights (98-102, 121-130): in-place mean-centre over Cin + clamp, then sign * mean|w|.
 // One workgroup per output channel; w row = [C][R].
-__global__ __launch_bounds__(256) void k_binary_w_fwd(float* __restrict__ w, float* __restrict__ qw, float* __restrict__ alpha_out,
-                                                      int C, int R) {
-    HIP_DYNAMIC_SHARED(double, colsum)   // [R] column sums, then [R] means as float reinterpretation is avoided: keep doubles
+__device__ __forceinline__ void binary_w_fwd_row(float* __restrict__ w, float* __restrict__ qw, float* __restrict__ alpha_out, int C, int R, int row, double* colsum) {
     __shared__ double scd[16];
     const int64_t K = (int64_t)C * R;
-    float* wr = w + (int64_t)blockIdx.x * K;
-    float* qr = qw + (int64_t)blockIdx.x * K;
+    float* wr = w + (int64_t)row * K;
+    float* qr = qw + (int64_t)row * K;
     // column (kh,kw) sums over the Cin axis: thread t owns column t % R, rows t / R, t / R + stride ...
     for (int r = threadIdx.x; r < R; r += blockDim.x) colsum[r] = 0.0;
     __syncthreads();
@@ -785,18 +783,74 @@ __global__ __launch_bounds__(256) void k_binary_w_fwd(float* __restrict__ w, flo
     sabs = block_reduce(sabs, OpAddD(), 0.0, scd);
     const float alpha = (float)sabs / (float)K;
     for (int64_t i = threadIdx.x; i < K; i += blockDim.x) qr[i] = ((wr[i] < 0.f) ? -1.f : 1.f) * alpha;
-    if (threadIdx.x == 0) alpha_out[blockIdx.x] = alpha;
+    if (threadIdx.x == 0) alpha_out[row] = alpha;
 }
-__global__ __launch_bounds__(256) void k_binary_w_bwd(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ alpha_in,
-                                                      float* __restrict__ dw, int64_t K) {
+__global__ __launch_bounds__(256) void k_binary_w_fwd(float* __restrict__ w, float* __restrict__ qw, float* __restrict__ alpha_out,
+                                                      int C, int R) {
+    HIP_DYNAMIC_SHARED(double, colsum)   // [R] column sums, then [blockDim] partials
+    binary_w_fwd_row(w, qw, alpha_out, C, R, (int)blockIdx.x, colsum);
+}
+__device__ __forceinline__ void binary_w_bwd_row(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ alpha_in,
+                                                 float* __restrict__ dw, int64_t K, int row) {
     __shared__ double scd[16];
-    const int64_t off = (int64_t)blockIdx.x * K;
-    const float alpha = alpha_in[blockIdx.x];
+    const int64_t off = (int64_t)row * K;
+    const float alpha = alpha_in[row];
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < K; i += blockDim.x) s += (double)(g[off + i] * ((w[off + i] < 0.f) ? -1.f : 1.f));
     s = block_reduce(s, OpAddD(), 0.0, scd);
     const float share = (float)s / (float)K;      // d mean|w| / dw_i = sign(w_i)/K
     for (int64_t i = threadIdx.x; i < K; i += blockDim.x) dw[off + i] = g[off + i] * alpha + mn_sign(w[off + i]) * share;
+}
+__global__ __launch_bounds__(256) void k_binary_w_bwd(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ alpha_in,
+                                                      float* __restrict__ dw, int64_t K) {
+    binary_w_bwd_row(g, w, alpha_in, dw, K, (int)blockIdx.x);
+}
+// The same two kernels over SEVERAL weight tensors in one launch (round 6: the W = 2 nin_gc step spent 7 + 7 launches here, and -- its code images being packed per
+// conv call because the quantizer had not run yet at the start of the step -- 10 more in k_qg_pack: 186 us of a 1.9 ms step).  Same arithmetic per tensor.
+struct BinTable {
+    float* w[MN_TERN_MAXT];            // forward: mutated in place (the reference's weight.data), backward: read
+    const float* g[MN_TERN_MAXT];
+    float* out[MN_TERN_MAXT];          // forward: qw; backward: dw
+    float* alpha[MN_TERN_MAXT];
+    int C[MN_TERN_MAXT], R[MN_TERN_MAXT];
+    int row_end[MN_TERN_MAXT];
+    int n;
+};
+template <int BWD>
+__global__ __launch_bounds__(256) void k_binary_w_multi(const BinTable t) {
+    HIP_DYNAMIC_SHARED(double, colsum)
+    int ti = 0;
+    while (ti + 1 < t.n && (int)blockIdx.x >= t.row_end[ti]) ++ti;
+    const int row = (int)blockIdx.x - (ti ? t.row_end[ti - 1] : 0);
+    if (!BWD) binary_w_fwd_row(t.w[ti], t.out[ti], t.alpha[ti], t.C[ti], t.R[ti], row, colsum);
+    else binary_w_bwd_row(t.g[ti], t.w[ti], t.alpha[ti], t.out[ti], (int64_t)t.C[ti] * t.R[ti], row);
+}
+static int binary_multi(int bwd, float* const* w, const float* const* g, float* const* out, float* const* alpha, const int64_t* O, const int64_t* Cn, const int64_t* R,
+                        int n, mn_stream_t stream, const char* what) {
+    if (n <= 0 || n > MN_TERN_MAXT || !w || !out || !alpha || !O || !Cn || !R || (bwd && !g)) MN_FAIL(MN_EINVAL, "%s: bad arguments (1 .. %d tensors)", what, MN_TERN_MAXT);
+    BinTable t;
+    int64_t rows = 0, rmax = 1;
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || !out[i] || !alpha[i] || (bwd && !g[i]) || O[i] <= 0 || Cn[i] <= 0 || R[i] <= 0 || R[i] > 256 || Cn[i] * R[i] > 0x7fffffff) MN_FAIL(MN_EINVAL, "%s: bad tensor %d", what, i);
+        rows += O[i];
+        if (rows > 0x7fffffff) MN_FAIL(MN_EINVAL, "%s: too many rows", what);
+        t.w[i] = w[i]; t.g[i] = bwd ? g[i] : nullptr; t.out[i] = out[i]; t.alpha[i] = alpha[i]; t.C[i] = (int)Cn[i]; t.R[i] = (int)R[i]; t.row_end[i] = (int)rows;
+        if (R[i] > rmax) rmax = R[i];
+    }
+    t.n = n;
+    const size_t sh = (size_t)(rmax + 256) * sizeof(double);
+    if (bwd) hipLaunchKernelGGL(k_binary_w_multi<1>, dim3((unsigned)rows), dim3(256), sh, (hipStream_t)stream, t);
+    else hipLaunchKernelGGL(k_binary_w_multi<0>, dim3((unsigned)rows), dim3(256), sh, (hipStream_t)stream, t);
+    MN_CHECK_LAUNCH(what);
+    return MN_OK;
+}
+extern "C" int mn_binary_w_fwd_multi(float* const* w, float* const* qw, float* const* alpha, const int64_t* O, const int64_t* C, const int64_t* R, int32_t n,
+                                     mn_stream_t stream) {
+    return binary_multi(0, w, nullptr, qw, alpha, O, C, R, n, stream, "mn_binary_w_fwd_multi");
+}
+extern "C" int mn_binary_w_bwd_multi(const float* const* g, const float* const* w, float* const* alpha, float* const* dw, const int64_t* O, const int64_t* C,
+                                     const int64_t* R, int32_t n, mn_stream_t stream) {
+    return binary_multi(1, const_cast<float* const*>(reinterpret_cast<const float* const*>(w)), g, dw, alpha, O, C, R, n, stream, "mn_binary_w_bwd_multi");
 }
 extern "C" int mn_binary_w_fwd(float* w, float* qw, float* alpha, int64_t O, int64_t C, int64_t R, mn_stream_t stream) {
     if (O <= 0 || C <= 0 || R <= 0 || R > 256 || !w || !qw || !alpha) MN_FAIL(MN_EINVAL, "mn_binary_w_fwd: bad arguments (R=%lld must be <= 256)", (long long)R);

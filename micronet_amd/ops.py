@@ -353,6 +353,47 @@ class BinaryWeight(Function):
         return dw
 
 
+class MultiBinaryWeight(Function):
+    """BinaryWeight over several conv weights in ONE launch each way (mn_binary_w_fwd_multi / _bwd_multi): every tensor is mean-centred and clamped IN PLACE like the
+    single-tensor op (the reference mutates weight.data, wbwtab/quantize.py:98-102, 123), then sign(w) * mean|w|.  Same arithmetic per tensor."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        for w in ws:
+            if not w.is_contiguous() or w.dim() != 4:
+                raise MicronetHipError("binary weight quantizer mutates 4-D conv weights in place and needs them contiguous")
+            _chk(w, "weight")
+        n = len(ws)
+        qws = [torch.empty_like(w) for w in ws]
+        alphas = [torch.empty(w.shape[0], dtype=torch.float32, device=w.device) for w in ws]
+        PA, LA = C.c_void_p * n, C.c_int64 * n
+        with torch.cuda.device_of(ws[0]):
+            _call("mn_binary_w_fwd_multi", PA(*[w.data_ptr() for w in ws]), PA(*[q.data_ptr() for q in qws]), PA(*[a.data_ptr() for a in alphas]),
+                  LA(*[w.shape[0] for w in ws]), LA(*[w.shape[1] for w in ws]), LA(*[w.shape[2] * w.shape[3] for w in ws]), n, _s())
+        ctx.save_for_backward(*ws, *alphas)
+        ctx.n = n
+        return tuple(qws)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        ws, alphas = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        idx = [i for i in range(n) if gs[i] is not None]
+        dws = [None] * n
+        if idx:
+            g = [_chk(gs[i], "grad") for i in idx]
+            out = [torch.empty_like(ws[i]) for i in idx]
+            m = len(idx)
+            PA, LA = C.c_void_p * m, C.c_int64 * m
+            with torch.cuda.device_of(ws[0]):
+                _call("mn_binary_w_bwd_multi", PA(*[t.data_ptr() for t in g]), PA(*[ws[i].data_ptr() for i in idx]), PA(*[alphas[i].data_ptr() for i in idx]),
+                      PA(*[t.data_ptr() for t in out]), LA(*[ws[i].shape[0] for i in idx]), LA(*[ws[i].shape[1] for i in idx]),
+                      LA(*[ws[i].shape[2] * ws[i].shape[3] for i in idx]), m, _s())
+            for k, i in enumerate(idx):
+                dws[i] = out[k]
+        return tuple(dws)
+
+
 # ------------------------------------------------------------------------------------------------ IAO
 def iao_observe(x, rows, obs_kind, first, momentum, min_val, max_val):
     x = _chk(x.detach(), "input")

@@ -174,6 +174,22 @@ def prefetch_weight_path(model, late=None):
         for m, wq in zip(grp, qws):
             m.weight_quantizer._mn_pre = (m.weight, wq, None)
         ops.pack_pointwise_weights(list(zip(grp, qws)), (ops.WQ_TERNARY, 0, 0, 0, None))          # the pointwise blocks' code images: one launch for the net
+    # W = 2 (binary weights, the literal `--W 2 --A 2` of wbwtab/main.py): the same two launches (round 6: until then 7 + 7 quantizer launches and, the codes not
+    # existing yet at the start of the step, 10 per-call packs -- 186 us of a 1.9 ms step).  The in-place mean-centring of every weight happens here, before the
+    # first forward of the step instead of inside each conv's forward: the same values either way (no layer reads another layer's weight).
+    bins = [m for m in mods if m.weight_quantizer.W == 2 and m.weight.is_cuda and m.weight.is_contiguous() and m.weight.dim() == 4 and m.weight.shape[2] * m.weight.shape[3] <= 256]
+    if late:
+        bins = [m for m in bins if id(m) not in late] + [m for m in bins if id(m) in late]
+    bounds = [0, sum(1 for m in bins if id(m) not in late), len(bins)] if late else [0, len(bins)]
+    for lo_, hi_ in zip(bounds[:-1], bounds[1:]):
+      for i in range(lo_, hi_, 32):
+        grp = bins[i:min(i + 32, hi_)]
+        if len(grp) < 2:
+            continue
+        qws = ops.MultiBinaryWeight.apply(*[m.weight for m in grp])
+        for m, wq in zip(grp, qws):
+            m.weight_quantizer._mn_pre = (m.weight, wq, None)
+        ops.pack_pointwise_weights(list(zip(grp, qws)), (ops.WQ_TERNARY, 0, 0, 0, None))
     return
 
 

@@ -1147,6 +1147,31 @@ def check_ternary_multi(be, seed=0):
         assert eq(be.to_host(q1[i]), be.to_host(q2[i])) and eq(be.to_host(s1[i]), be.to_host(s2[i])) and eq(be.to_host(d1[i]), be.to_host(d2[i])), i
 
 
+def check_binary_multi(be, seed=0):
+    """mn_binary_w_fwd_multi / mn_binary_w_bwd_multi (one launch over several conv weights, each mean-centred and clamped IN PLACE) bit-identical to the per-tensor
+    entry points: the mutated weights, the quantised weights, alpha and the gradients."""
+    r = np.random.default_rng(seed)
+    shapes = [(24, 16, 1), (40, 3, 25), (7, 128, 1), (64, 16, 9)]          # [O][C][R]
+    ws = [(r.standard_normal(sh) * 0.8).astype(F) for sh in shapes]
+    gs = [r.standard_normal(sh).astype(F) for sh in shapes]
+    n = len(ws)
+    w1, w2, dG = [be.to_dev(w) for w in ws], [be.to_dev(w) for w in ws], [be.to_dev(g) for g in gs]
+    q1, a1, d1 = [be.empty(sh) for sh in shapes], [be.empty(sh[0]) for sh in shapes], [be.empty(sh) for sh in shapes]
+    for i, sh in enumerate(shapes):
+        be.call("mn_binary_w_fwd", be.ptr(w1[i]), be.ptr(q1[i]), be.ptr(a1[i]), sh[0], sh[1], sh[2], be.stream)
+        be.call("mn_binary_w_bwd", be.ptr(dG[i]), be.ptr(w1[i]), be.ptr(a1[i]), be.ptr(d1[i]), sh[0], sh[1] * sh[2], be.stream)
+    q2, a2, d2 = [be.empty(sh) for sh in shapes], [be.empty(sh[0]) for sh in shapes], [be.empty(sh) for sh in shapes]
+    PA, LA = C.c_void_p * n, C.c_int64 * n
+    arr = lambda ts: PA(*[be.ptr(t).value for t in ts])
+    Os, Cs, Rs = LA(*[sh[0] for sh in shapes]), LA(*[sh[1] for sh in shapes]), LA(*[sh[2] for sh in shapes])
+    be.call("mn_binary_w_fwd_multi", arr(w2), arr(q2), arr(a2), Os, Cs, Rs, n, be.stream)
+    be.call("mn_binary_w_bwd_multi", arr(dG), arr(w2), arr(a2), arr(d2), Os, Cs, Rs, n, be.stream)
+    for i in range(n):
+        assert not eq(be.to_host(w2[i]), ws[i])          # mutated in place
+        assert eq(be.to_host(w1[i]), be.to_host(w2[i])) and eq(be.to_host(q1[i]), be.to_host(q2[i])) and eq(be.to_host(a1[i]), be.to_host(a2[i])) and \
+            eq(be.to_host(d1[i]), be.to_host(d2[i])), i
+
+
 def check_pool_f32(be, shape=(3, 5, 8, 16), seed=0):
     """mn_maxpool2x2_f32_fwd/bwd vs torch CPU max_pool2d: values, the gradient routing (ties -> first maximum, NaN wins) bit-exact."""
     import torch

@@ -499,6 +499,7 @@ def test_sign_pass_with_the_statistics_finals_folded_in(be):
 
 def test_ternary_weight_quantizer_multi(be):
     K.check_ternary_multi(be)
+    K.check_binary_multi(be)
 
 
 @pytest.mark.parametrize("training", [True, False])

@@ -358,6 +358,7 @@ def test_sign_pass_two_launch_path_opt_out():
 
 def test_ternary_weight_quantizer_multi(be):
     K.check_ternary_multi(be)
+    K.check_binary_multi(be)
 
 
 @pytest.mark.parametrize("training", [True, False])
