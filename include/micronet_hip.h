@@ -533,6 +533,13 @@ int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, const int8
                               const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
                               int64_t* num_batches_tracked, float* save, int8_t* a, uint8_t* h, float* chan, void* ws, int64_t ws_bytes,
                               mn_stream_t stream);
+/* ... of a pointwise block whose output goes through nn.MaxPool2d(2, 2) (models/nin_gc.py:88,119), training mode: the sign pass also writes the POOLED codes a_pool
+ * [N][O][H/2][W/2] -- the window's maximum is +1 iff one of its four elements is -- so mn_maxpool2x2_sign8_fwd's pass over `a` is not launched (round 6).  H even, W a
+ * multiple of 16; every other output as mn_qconv_bnsign_fwd_stash. */
+int mn_qconv_bnsign_fwd_stash_pool_supported(const mn_conv_geom* g, const mn_wq* wq);
+int mn_qconv_bnsign_fwd_stash_pool(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                                   float eps, float momentum, int training, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save,
+                                   int8_t* a, int8_t* a_pool, uint8_t* h, float* chan, void* ws, int64_t ws_bytes, mn_stream_t stream);
 /* The stash forward also covers k x k convolutions with ternary / binary weights on sign codes (nin_gc's grouped 3x3 layers,
  * models/nin_gc.py:88-119): the code-domain k x k kernel writes h instead of y, the batch statistics and the sign are streamed from h
  * (one byte per element each).  These two queries answer for both kinds of block; the stash forward needs the workspace they name. */

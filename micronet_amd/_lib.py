@@ -115,6 +115,8 @@ PROTOTYPES = {
     "mn_qconv_bnsign_stash_chan_rows": (_I, [_G]),
     "mn_qconv_bnsign_fwd": (_I, [_G, _W, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _L, _P]),
     "mn_qconv_bnsign_fwd_stash": (_I, [_G, _W, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "mn_qconv_bnsign_fwd_stash_pool_supported": (_I, [_G, _W]),
+    "mn_qconv_bnsign_fwd_stash_pool": (_I, [_G, _W, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "mn_bnh_bwd_sums": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P]),
     "mn_bnh_bwd_apply": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P, _P]),
     "mn_conv2d_bnh_supported": (_I, [_G, _W]),

@@ -1511,7 +1511,8 @@ extern "C" int mn_qconv_bnsign_supported(const mn_conv_geom* g, const mn_wq* wq)
 extern "C" int64_t mn_qconv_bnsign_ws_bytes(const mn_conv_geom* g) { return g ? pws_ws_bytes(g) : -1; }
 
 struct HsPrep;
-static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s, const HsPrep* fold = nullptr);
+static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s, const HsPrep* fold = nullptr,
+                         int8_t* a_pool = nullptr);
 // k_pws_stats_prep's work runs inside the streaming sign pass (k_h_sign_prep; bit-identical; round 5 same-box A/B on c2: 107.2 / 107.7 k -> 108.8 / 108.7 k img/s).
 // MN_HSIGN_FOLD=0 restores the two launches.
 static bool hsign_fold_enabled() { const char* e = MN_ENV("MN_HSIGN_FOLD"); return !(e && e[0] == '0'); }
@@ -1522,7 +1523,7 @@ static void pws_chan_prep(PwsPlan& pl, const mn_conv_geom* g, const float* bias,
 
 static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
                                  const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var, int64_t* nbt,
-                                 float* save, int8_t* a, uint8_t* h, float* chan_out, void* ws, int64_t ws_bytes, mn_stream_t stream) {
+                                 float* save, int8_t* a, uint8_t* h, float* chan_out, void* ws, int64_t ws_bytes, mn_stream_t stream, int8_t* a_pool = nullptr) {
     if (!g || !gamma || !beta || !save || !a || (((uintptr_t)a) & 3)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd: null / misaligned argument");
     if (!pws_bn_ok(g, wq)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd: needs a pointwise convolution with ternary / binary weights");
     if (!training && (!running_mean || !running_var)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd: eval mode needs the running statistics");
@@ -1540,8 +1541,9 @@ static int qconv_bnsign_fwd_impl(const mn_conv_geom* g, const mn_wq* wq, const i
     if (stash_in_stats && hsign_fold_enabled()) {
         const HsPrep q{(const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, bias, (double)g->N * p.HW, eps, momentum, training, running_mean, running_var, save,
                        (int)g->O, p.Kc, p.Kp, p.wc, gamma, beta, (float*)p.chan, (const float*)nullptr, (long long*)nbt};
-        return h_sign_launch(g->N, g->O, g->H, g->W, h, (const float*)p.chan, a, s, &q);
+        return h_sign_launch(g->N, g->O, g->H, g->W, h, (const float*)p.chan, a, s, &q, a_pool);
     }
+    if (a_pool) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd_stash_pool: only the training-mode stash forward with the folded sign pass writes pooled codes");
     hipLaunchKernelGGL(k_pws_stats_prep, dim3((unsigned)g->O), dim3(64), 0, s, (const double*)p.part, p.CB, p.G, p.Mpad, p.Mr, p.rowscale, bias,
                        (double)g->N * p.HW, eps, momentum, training, running_mean, running_var, save, (int)g->O, p.Kc, p.Kp, p.wc, gamma, beta,
                        (float*)p.chan, (const float*)nullptr, (long long*)nbt);
@@ -1567,6 +1569,21 @@ extern "C" int mn_qconv_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq,
                                           chan, ws, ws_bytes, (hipStream_t)stream);
     return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, num_batches_tracked, save, a, h, chan, ws,
                                  ws_bytes, stream);
+}
+
+/* the same forward for a pointwise block whose output goes through a 2x2 / stride-2 max-pool: a_pool [N][O][H/2][W/2] receives the pooled sign codes from the sign pass
+ * itself (what mn_maxpool2x2_sign8_fwd would compute from `a`) */
+extern "C" int mn_qconv_bnsign_fwd_stash_pool_supported(const mn_conv_geom* g, const mn_wq* wq) {
+    return g && wq && pws_bn_ok(g, wq) && hsign_fold_enabled() && !(g->H & 1) && !(g->W & 15) && (g->H * g->W) % 16 == 0;
+}
+extern "C" int mn_qconv_bnsign_fwd_stash_pool(const mn_conv_geom* g, const mn_wq* wq, const int8_t* x, const float* w, const float* bias, const float* gamma,
+                                              const float* beta, float eps, float momentum, int training, float* running_mean, float* running_var,
+                                              int64_t* num_batches_tracked, float* save, int8_t* a, int8_t* a_pool, uint8_t* h, float* chan, void* ws, int64_t ws_bytes,
+                                              mn_stream_t stream) {
+    if (!h || !chan || !a_pool || (((uintptr_t)h) & 15) || (((uintptr_t)a) & 15)) MN_FAIL(MN_EINVAL, "mn_qconv_bnsign_fwd_stash_pool: null / misaligned tensor");
+    if (!training || !mn_qconv_bnsign_fwd_stash_pool_supported(g, wq)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd_stash_pool: geometry / mode not covered");
+    return qconv_bnsign_fwd_impl(g, wq, x, w, bias, gamma, beta, eps, momentum, training, running_mean, running_var, num_batches_tracked, save, a, h, chan, ws,
+                                 ws_bytes, stream, a_pool);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1716,6 +1733,42 @@ __device__ __forceinline__ void h_sign_stream_pw(const HGeom& g, const unsigned 
         else *reinterpret_cast<uint32_t*>(a + off) = out[0];
     }
 }
+// ... and, for a block whose output goes through a 2x2 / stride-2 max-pool (models/nin_gc.py:88,119), the POOLED codes in the same pass: a thread takes 16 pixels of a
+// row pair, the window's maximum is +1 iff any of its four pass bits is set (OR of the two rows' masks, then of the even / odd byte lanes); mn_maxpool2x2_sign8_fwd's
+// pass over the full-size codes (1.25 B per element, one launch) is not needed.  H even, W a multiple of 16.
+__device__ __forceinline__ void h_sign_stream_pw_pool(const HGeom& g, const unsigned char* __restrict__ h, char* __restrict__ a, char* __restrict__ ap, int c, int sp, int S,
+                                                      float T, float fl, float nnz) {
+    float tf;
+    uint32_t inv;
+    if (fl > 0.f) { tf = ceilf((T + nnz) * 0.5f); inv = 0u; }
+    else { tf = floorf((nnz - T) * 0.5f) + 1.f; inv = 0x00010001u; }
+    tf = fminf(fmaxf(tf, 0.f), 256.f);
+    const uint32_t tt = (uint32_t)tf * 0x00010001u;
+    const int W = 4 * g.W4, W16 = W >> 4, Hh = g.H >> 1;
+    const uint32_t upp = (uint32_t)(Hh * W16);          // units per plane
+    const int64_t nu = (int64_t)(g.n4 / g.HW4) * upp;   // N planes of this channel
+    for (int64_t i = (int64_t)sp * 256 + threadIdx.x; i < nu; i += (int64_t)S * 256) {
+        const uint32_t n = (uint32_t)(i / upp), u = (uint32_t)(i - (int64_t)n * upp);
+        const uint32_t rp = u / (uint32_t)W16, cx = u - rp * (uint32_t)W16;
+        const int64_t plane = (int64_t)n * g.C + c;
+        const int64_t off0 = plane * g.HW + (int64_t)(2 * rp) * W + 16 * cx;
+        const u32x4 ha = *reinterpret_cast<const u32x4*>(h + off0), hb = *reinterpret_cast<const u32x4*>(h + off0 + W);
+        uint32_t oa[4], ob[4], pp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ea = ha[k] & 0x00ff00ffu, da = (ha[k] >> 8) & 0x00ff00ffu, eb = hb[k] & 0x00ff00ffu, db = (hb[k] >> 8) & 0x00ff00ffu;
+            const uint32_t mea = ((((ea | 0x01000100u) - tt) >> 8) & 0x00010001u) ^ inv, moa = ((((da | 0x01000100u) - tt) >> 8) & 0x00010001u) ^ inv;
+            const uint32_t meb = ((((eb | 0x01000100u) - tt) >> 8) & 0x00010001u) ^ inv, mob = ((((db | 0x01000100u) - tt) >> 8) & 0x00010001u) ^ inv;
+            oa[k] = (0x00ff00ffu - mea * 0xfeu) | ((0x00ff00ffu - moa * 0xfeu) << 8);
+            ob[k] = (0x00ff00ffu - meb * 0xfeu) | ((0x00ff00ffu - mob * 0xfeu) << 8);
+            const uint32_t P = mea | moa | meb | mob;          // 16-bit lane j: the window of pixels 4 k + 2 j, 4 k + 2 j + 1
+            pp[k] = (0xffu - (P & 1u) * 0xfeu) | ((0xffu - ((P >> 16) & 1u) * 0xfeu) << 8);
+        }
+        *reinterpret_cast<u32x4*>(a + off0) = u32x4{oa[0], oa[1], oa[2], oa[3]};
+        *reinterpret_cast<u32x4*>(a + off0 + W) = u32x4{ob[0], ob[1], ob[2], ob[3]};
+        *reinterpret_cast<u32x2*>(ap + (plane * Hh + rp) * (W >> 1) + 8 * cx) = u32x2{pp[0] | (pp[1] << 16), pp[2] | (pp[3] << 16)};
+    }
+}
 template <int VEC>
 __global__ __launch_bounds__(256) void k_h_sign(const HGeom g, const unsigned char* __restrict__ h, const float* __restrict__ chan, char* __restrict__ a) {
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
@@ -1725,8 +1778,8 @@ __global__ __launch_bounds__(256) void k_h_sign(const HGeom g, const unsigned ch
     h_sign_stream<VEC>(g, h, a, c, sp, S, T, fl, z);
 }
 // default (MN_HSIGN_FOLD != 0): the constants from the block's own evaluation of k_pws_stats_prep's work (HsPrep above) instead of a launch in front
-template <int VEC>
-__global__ __launch_bounds__(256) void k_h_sign_prep(const HGeom g, const unsigned char* __restrict__ h, const HsPrep q, char* __restrict__ a) {
+template <int VEC, int POOLED = 0>
+__global__ __launch_bounds__(256) void k_h_sign_prep(const HGeom g, const unsigned char* __restrict__ h, const HsPrep q, char* __restrict__ a, char* __restrict__ ap) {
     __shared__ float hs_[3];
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y, C = g.C;
     if (threadIdx.x < 64) {
@@ -1736,6 +1789,7 @@ __global__ __launch_bounds__(256) void k_h_sign_prep(const HGeom g, const unsign
     }
     __syncthreads();
     const float T = hs_[0], fl = hs_[1];
+    if (POOLED) { h_sign_stream_pw_pool(g, h, a, ap, c, sp, S, T, fl, hs_[2]); return; }          // (pointwise blocks only: host check)
     if (!q.nnz9) { h_sign_stream_pw<VEC>(g, h, a, c, sp, S, T, fl, hs_[2]); return; }          // a pointwise block: one nnz per channel
     StashNnz z;
     z.v0 = q.nnz9[c]; z.v1 = q.nnz9[C + c]; z.v2 = q.nnz9[2 * C + c]; z.v3 = q.nnz9[3 * C + c]; z.v4 = q.nnz9[4 * C + c];
@@ -1743,7 +1797,7 @@ __global__ __launch_bounds__(256) void k_h_sign_prep(const HGeom g, const unsign
     h_sign_stream<VEC>(g, h, a, c, sp, S, T, fl, z);
 }
 static int h_splits(int C) { int S = 2048 / (C > 0 ? C : 1); return S < 1 ? 1 : (S > 64 ? 64 : S); }
-static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s, const HsPrep* fold) {
+static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8_t* h, const float* chan, int8_t* a, hipStream_t s, const HsPrep* fold, int8_t* a_pool) {
     HGeom hg;
     hg.C = (int)O; hg.H = (int)H; hg.W4 = (int)(W / 4); hg.HW = (int)(H * W); hg.HW4 = hg.HW / 4; hg.Mr = 1; hg.Mpad = 1; hg.G = 1;
     hg.fd_hw4 = make_fastdiv((uint32_t)hg.HW4); hg.fd_w4 = make_fastdiv((uint32_t)hg.W4); hg.n4 = N * hg.HW4;
@@ -1751,11 +1805,14 @@ static int h_sign_launch(int64_t N, int64_t O, int64_t H, int64_t W, const uint8
     hg.fd_hwv = make_fastdiv((uint32_t)(v4 ? hg.HW4 / 4 : hg.HW4));
     const int S = h_splits((int)O);
     mn_set_last_kernel(fold ? "k_h_sign_prep" : "k_h_sign");
-    mn_prof_bytes(2.0 * (double)N * O * hg.HW);
+    mn_prof_bytes((a_pool ? 2.25 : 2.0) * (double)N * O * hg.HW);
     mn_prof_begin(s);
-    if (fold) {
-        if (v4) hipLaunchKernelGGL(k_h_sign_prep<4>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, *fold, (char*)a);
-        else hipLaunchKernelGGL(k_h_sign_prep<1>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, *fold, (char*)a);
+    if (a_pool) {
+        if (!fold || fold->nnz9 || !v4 || (H & 1) || (W & 15) || (((uintptr_t)a_pool) & 7)) MN_FAIL(MN_ENOTSUP, "mn_qconv_bnsign_fwd_stash_pool: needs a pointwise block in training mode, H even, W a multiple of 16");
+        hipLaunchKernelGGL((k_h_sign_prep<4, 1>), dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, *fold, (char*)a, (char*)a_pool);
+    } else if (fold) {
+        if (v4) hipLaunchKernelGGL((k_h_sign_prep<4, 0>), dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, *fold, (char*)a, (char*)nullptr);
+        else hipLaunchKernelGGL((k_h_sign_prep<1, 0>), dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, *fold, (char*)a, (char*)nullptr);
     }
     else if (v4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, chan, (char*)a);
     else hipLaunchKernelGGL(k_h_sign<1>, dim3((unsigned)O, (unsigned)S), dim3(256), 0, s, hg, (const unsigned char*)h, chan, (char*)a);
@@ -1810,8 +1867,8 @@ static int qconv_kxk_bnsign_fwd_stash(const mn_conv_geom* g, const mn_wq* wq, co
         mn_prof_bytes(2.0 * (double)g->N * g->O * hg3.HW);
         mn_prof_begin(s);
         if (fold3) {
-            if (v4) hipLaunchKernelGGL(k_h_sign_prep<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, q3, (char*)a);
-            else hipLaunchKernelGGL(k_h_sign_prep<1>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, q3, (char*)a);
+            if (v4) hipLaunchKernelGGL((k_h_sign_prep<4, 0>), dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, q3, (char*)a, (char*)nullptr);
+            else hipLaunchKernelGGL((k_h_sign_prep<1, 0>), dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, q3, (char*)a, (char*)nullptr);
         }
         else if (v4) hipLaunchKernelGGL(k_h_sign<4>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, (const float*)chan, (char*)a);
         else hipLaunchKernelGGL(k_h_sign<1>, dim3((unsigned)g->O, (unsigned)S), dim3(256), 0, s, hg3, (const unsigned char*)h, (const float*)chan, (char*)a);

@@ -1904,6 +1904,7 @@ def sign_pool_supported(a, kernel_size, stride, padding, dilation, ceil_mode):
 
 
 LAZY_POOL_GRAD = True
+POOL_IN_SIGN_PASS = _os0.environ.get("MN_POOL_IN_SIGN", "1") != "0"          # (A/B: pooled sign codes from the producing block's sign pass instead of a pool launch)
 
 
 def _expand_pool_grad(g, codes):
@@ -1922,9 +1923,11 @@ class SignMaxPool2x2(Function):
     def forward(ctx, a):
         codes = a.codes
         N, Cc, H, W = codes.shape
-        out = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.int8, device=codes.device)
-        with torch.cuda.device_of(codes):
-            _call("mn_maxpool2x2_sign8_fwd", _p(codes), N * Cc, H, W, _p(out), _s())
+        out = getattr(a, "_mn_pooled", None)          # the producing block's sign pass already wrote them (ConvBNSign, pool_next)
+        if out is None or tuple(out.shape) != (N, Cc, H // 2, W // 2):
+            out = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.int8, device=codes.device)
+            with torch.cuda.device_of(codes):
+                _call("mn_maxpool2x2_sign8_fwd", _p(codes), N * Cc, H, W, _p(out), _s())
         ctx.save_for_backward(codes)
         return SignTensor(out)
 
@@ -2271,7 +2274,7 @@ class ConvBNSign(Function):
     streaming passes over (da, h) with no convolution recompute (mn_bnh_bwd_sums / mn_bnh_bwd_apply)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt=None):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, training, nbt=None, pool_next=False):
         r = y.recipe
         codes, wq, bias, g, wdesc = r["codes"], r["wq"], r["bias"], r["geom"], r["wdesc"]
         gamma, beta = _chk(gamma, "weight"), _chk(beta, "bias")
@@ -2286,13 +2289,23 @@ class ConvBNSign(Function):
         with torch.cuda.device_of(codes):
             nb = int(_lib_().mn_qconv_bnsign_stash_ws_bytes(C.byref(g)))
             ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=codes.device)
-            _call("mn_qconv_bnsign_fwd_stash", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), float(eps), float(momentum),
-                  int(training), _p(running_mean), _p(running_var), _p(nbt), _p(save), _p(a), _p(h), _p(chan), _p(ws), nb, _s())
+            # a 2x2 / stride-2 max-pool behind the block (prepare() marked it): the sign pass writes the pooled codes too, the pool module hands them on (SignMaxPool2x2)
+            ap = None
+            if pool_next and training and POOL_IN_SIGN_PASS and a.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0 and \
+                    _lib_().mn_qconv_bnsign_fwd_stash_pool_supported(C.byref(g), _ref(wd)):
+                ap = torch.empty((y.shape[0], y.shape[1], y.shape[2] // 2, y.shape[3] // 2), dtype=torch.int8, device=codes.device)
+                _call("mn_qconv_bnsign_fwd_stash_pool", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), float(eps), float(momentum),
+                      int(training), _p(running_mean), _p(running_var), _p(nbt), _p(save), _p(a), _p(ap), _p(h), _p(chan), _p(ws), nb, _s())
+            else:
+                _call("mn_qconv_bnsign_fwd_stash", C.byref(g), _ref(wd), _p(codes), _p(wq), _p(bias), _p(gamma), _p(beta), float(eps), float(momentum),
+                      int(training), _p(running_mean), _p(running_var), _p(nbt), _p(save), _p(a), _p(h), _p(chan), _p(ws), nb, _s())
         ctx.save_for_backward(h, chan, gamma, beta)
         ctx.training = int(training)
         ctx.fold_ok = FOLD_BN_INTO_CONV_BWD and bool(_lib_().mn_conv2d_bnh_supported(C.byref(g), _ref(wd)))     # the conv's own backward can form dy from (da, h)
         ctx.fold_pool_ok = FOLD_POOL_INTO_CONV_BWD and ctx.fold_ok and bool(_lib_().mn_conv2d_bnh_pool_supported(C.byref(g), _ref(wd)))      # ... and from the POOLED gradient
         out = SignTensor(a)
+        if ap is not None:
+            out._mn_pooled = ap
         ctx.up_rec = None
         if chan.shape[0] in (8, 17) and UP_SUMS_FOLD:          # (8: pointwise block, one nnz per channel; 17: 3x3 block, nnz per border class) -- the next block's
             ctx.up_rec = out._mn_up = UpSums(h, chan, wq.shape[1] * wq.shape[2] * wq.shape[3], kind=1 if chan.shape[0] == 8 else 3)          # backward may form this block's sums
@@ -2331,7 +2344,7 @@ class ConvBNSign(Function):
                         _call("mn_bnh_bwd_apply", _p(r["da"]), _p(r["h"]), _p(r["own"]), _p(r["chan"]), _p(r["sums"]), N, Cc, H, W, r["training"], _p(dy_), _s())
                     return dy_
                 recipe = dict(kind="bnh_pool", da=grad, own=own, h=h, chan=chan, sums=sums, training=training)
-                return LazyBNGrad(h.shape, h.device, recipe, expand_p), dgamma, dbeta, None, None, None, None, None, None
+                return LazyBNGrad(h.shape, h.device, recipe, expand_p), dgamma, dbeta, None, None, None, None, None, None, None
             if not pooled and ctx.fold_ok and LAZY_BN_GRAD:
                 # d loss / d y is not written: the convolution's backward-data / backward-weight form it from (da, h) while they stream in
                 def expand(r):
@@ -2340,10 +2353,10 @@ class ConvBNSign(Function):
                         _call("mn_bnh_bwd_apply", _p(r["da"]), _p(r["h"]), None, _p(r["chan"]), _p(r["sums"]), N, Cc, H, W, r["training"], _p(dy_), _s())
                     return dy_
                 recipe = dict(kind="bnh", da=grad, h=h, chan=chan, sums=sums, training=training)
-                return LazyBNGrad(h.shape, h.device, recipe, expand), dgamma, dbeta, None, None, None, None, None, None
+                return LazyBNGrad(h.shape, h.device, recipe, expand), dgamma, dbeta, None, None, None, None, None, None, None
             dy = torch.empty(h.shape, dtype=torch.float32, device=h.device)
             _call("mn_bnh_bwd_apply", _p(grad), _p(h), _p(own), _p(chan), _p(sums), N, Cc, H, W, training, _p(dy), _s())
-        return dy, dgamma, dbeta, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ k-bit (DoReFa) fused block

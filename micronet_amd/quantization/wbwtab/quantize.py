@@ -134,7 +134,8 @@ class BatchNorm2dBinAct(nn.BatchNorm2d):
         if fused:
             # the conv in front did not compute its output: conv + statistics + normalisation + sign in the fused kernels
             return ops.ConvBNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                                        self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, nbt)
+                                        self.running_var if self.track_running_stats else None, self.eps, momentum, use_batch, nbt,
+                                        bool(getattr(self, "pool_next", False)))
         if first and use_batch and self.packed and input._mn_value is None:
             # conv + batch statistics (from the Gram data of the image) + normalisation + sign in one kernel: the conv output is never written
             return ops.FirstConvBNSign.apply(input, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
@@ -331,6 +332,10 @@ def add_quant_op(module, layer_counter, layer_num, A=2, W=2, quant_inference=Fal
                         prev2.lazy_for_bn = True        # conv -> bn -> sign in definition order: the conv output need never be stored
         elif type(child) is nn.MaxPool2d and packed_activations and A == 2:
             child.__class__ = MaxPool2dSign       # same object and state; pools SignTensors without unpacking them
+            two = lambda v: v in (2, (2, 2), [2, 2])
+            if prev is not None and _is_ref_block(prev) and type(getattr(prev, "bn", None)) is BatchNorm2dBinAct and _ordered_parent(module) and two(child.kernel_size) and \
+                    two(child.stride) and child.padding in (0, (0, 0)) and child.dilation in (1, (1, 1)) and not child.ceil_mode:
+                prev.bn.pool_next = True          # the block's sign pass writes the pooled codes as well (ops.ConvBNSign): this pool only hands them on
         elif type(child) is nn.AvgPool2d and fuse_bn_act:
             from micronet_amd.nn import AvgPool2dGlobal
             child.__class__ = AvgPool2dGlobal     # same object and state; its own kernel only when the window is the whole image

@@ -664,6 +664,21 @@ def check_qconv_bnsign(be, x_shape, w_shape, groups=1, bias=True, in_shuffle=0, 
                 be.ptr(dRM), be.ptr(dRV), be.ptr(nbt), be.ptr(save), be.ptr(a8), be.ptr(h8), be.ptr(chan), be.ptr(ws), nb, be.stream)
         check_qconv_bnsign.last_fwd_kernel = be.lib.mn_last_kernel().decode()
         assert int(be.to_host(nbt)[0]) == (42 if training else 41)         # BatchNorm's forward counter: incremented by the statistics launch
+        if training and w_shape[2] == 1 and H % 2 == 0 and W % 16 == 0 and be.lib.mn_qconv_bnsign_fwd_stash_pool_supported(C.byref(g), C.byref(wq)):
+            # the same forward with the POOLED sign codes written by the sign pass (a 2x2 / stride-2 max-pool behind the block): every output bit for bit, and
+            # a_pool == mn_maxpool2x2_sign8_fwd(a)
+            dRM2, dRV2, nbt2 = be.to_dev(rm), be.to_dev(rv), be.to_dev_i64([41])
+            save2, a82, h82, chan2 = be.empty((2, Oc)), be.empty_i8((N, Oc, H, W)), be.empty_i8((N, Oc, H, W)), be.empty((8, Oc))
+            ap = be.empty_i8((N, Oc, H // 2, W // 2))
+            ws_p = be.empty(nb // 4 + 8)
+            be.call("mn_qconv_bnsign_fwd_stash_pool", C.byref(g), C.byref(wq), be.ptr(dA), be.ptr(dW), be.ptr(dB), be.ptr(dG), be.ptr(dBe), eps, mom, 1,
+                    be.ptr(dRM2), be.ptr(dRV2), be.ptr(nbt2), be.ptr(save2), be.ptr(a82), be.ptr(ap), be.ptr(h82), be.ptr(chan2), be.ptr(ws_p), nb, be.stream)
+            assert np.array_equal(be.to_host(a82), be.to_host(a8)) and np.array_equal(be.to_host(h82), be.to_host(h8)) and np.array_equal(be.to_host(chan2), be.to_host(chan))
+            assert np.array_equal(be.to_host(save2), be.to_host(save)) and np.array_equal(be.to_host(dRM2), be.to_host(dRM)) and int(be.to_host(nbt2)[0]) == 42
+            o8 = be.empty_i8((N, Oc, H // 2, W // 2))
+            be.call("mn_maxpool2x2_sign8_fwd", be.ptr(a8), N * Oc, H, W, be.ptr(o8), be.stream)
+            assert np.array_equal(be.to_host(ap), be.to_host(o8)), "pooled codes from the sign pass"
+            check_qconv_bnsign.pool_sign_checked = getattr(check_qconv_bnsign, "pool_sign_checked", 0) + 1
         acc_ref = O.conv2d_fwd(x_log, np.sign(w).astype(F), None, padding=padding, groups=groups)
         # nnz per pixel: the non-zero weights that meet a non-zero input (= all of them, except at the zero-padded border of a 3x3 block)
         nnz = O.conv2d_fwd(np.ones_like(x_log), (w != 0).astype(F), None, padding=padding, groups=groups)
@@ -1512,8 +1527,10 @@ def check_pwb(be, pooled_too=True, light=False):
                 check_qconv_bnsign(be, seed=410 + i, stash=True, training=False, **case)
             else:
                 check_qconv_bnsign(be, seed=420 + i, stash=True, pooled=True, **case)
+    before_ps = getattr(check_qconv_bnsign, "pool_sign_checked", 0)
     for i, case in enumerate(PWB_CASES_WIDE):
         check_qconv_bnsign(be, seed=430 + i, stash=True, **case)
+    assert getattr(check_qconv_bnsign, "pool_sign_checked", 0) - before_ps == len(PWB_CASES_WIDE), "mn_qconv_bnsign_fwd_stash_pool did not run on the wide planes"
     assert getattr(_check_pwb, "count", 0) - before == runs + len(PWB_CASES_WIDE), "k_pwb did not take these geometries"
     assert getattr(_check_pwb_up9, "count", 0) - before9 >= len(PWB_CASES_WIDE) + (2 if light else 2 * len(PWB_CASES)), "mn_conv2d_bwd_bnh_up9 did not run on the un-pooled cases"
 

@@ -598,3 +598,33 @@ def test_forward_without_backward_does_not_leak(key):
         torch.cuda.synchronize()
         used.append(torch.cuda.memory_allocated())
     assert used[4] == used[2] == used[3], used
+
+
+def test_pooled_codes_come_from_the_sign_pass(monkeypatch):
+    """Round 6: a BatchNorm+sign block in front of nn.MaxPool2d(2, 2) (models/nin_gc.py:88,119; prepare() marks it ``pool_next``) writes the pooled sign codes in its own
+    sign pass (mn_qconv_bnsign_fwd_stash_pool); the pool module hands them on instead of launching mn_maxpool2x2_sign8_fwd.  Same logits and the same gradients to the
+    bit with the hand-over on and off; both pools of nin_gc take it."""
+    import copy
+    from micronet_amd import ops
+    from micronet_amd.train import build_model, synth_batch
+    from micronet.compression.quantization.wbwtab import quantize
+    torch.manual_seed(13)
+    base = quantize.prepare(build_model("nin_gc"), inplace=True, A=2, W=3).cuda().train()
+    assert sum(int(getattr(m, "pool_next", False)) for m in base.modules()) == 2
+    x, y = synth_batch(32, device="cuda")
+    real = ops._call
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "POOL_IN_SIGN_PASS", on)
+        n = {}
+        monkeypatch.setattr(ops, "_call", lambda name, *a, _n=n: (_n.__setitem__(name, _n.get(name, 0) + 1), real(name, *a))[1])
+        m = copy.deepcopy(base)
+        out = m(x)
+        ops.cross_entropy(out, y).backward()
+        res[on] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, n)
+    monkeypatch.setattr(ops, "_call", real)
+    assert res[True][2].get("mn_qconv_bnsign_fwd_stash_pool", 0) == 2 and res[True][2].get("mn_maxpool2x2_sign8_fwd", 0) == 0, res[True][2]
+    assert res[False][2].get("mn_qconv_bnsign_fwd_stash_pool", 0) == 0 and res[False][2].get("mn_maxpool2x2_sign8_fwd", 0) == 2, res[False][2]
+    assert torch.equal(res[True][0], res[False][0])
+    for k, g0 in res[False][1].items():
+        assert torch.equal(res[True][1][k], g0), k
